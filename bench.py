@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Franka Panda 7-DOF fused fkine+jacob0, configurations / second.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 launched by torch.distributed.run,
+one rank per GPU).  A "step" is one pass of the hot path (ONE fused kernel launch) over one batch
+of synthetic input that is already resident in HBM: BASELINE.json configs[1] -- ETS Panda, 22 ETs,
+q ~ U(-pi,pi)^7, N = 1e6 per GPU, fp64.  W untimed warm-up steps, then exactly K timed steps between
+barrier+synchronize pairs; the MAX over ranks is the step time; rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline     achieved = 520 B/config x N / (average duration of the dominant kernel, from HIP events
+               recorded on the launch stream around each of the K launches of a second, un-timed loop)
+               against the 8 TB/s HBM3E peak; traffic = HBM bytes per launch from the PMC passes
+               (profiles/r01_pmc.json when present, else null).
+  cpu_baseline the reference's OWN native code (oracle/_ref, built unmodified from the reference
+               sources) timed on this box's host cores on the same q array: one ETS_fkine call over
+               the whole array + the Python per-row ETS_jacob0 loop a reference user needs today
+               (kind "reference"); falls back to the plain-C restatement (kind "port").
+Multi-GPU: the batch dimension is embarrassingly parallel -> each rank owns N rows (weak scaling),
+no collective on the data path; the single output gather (RCCL all_gather over xGMI) is timed
+separately and reported as gather_ms, never inside `value`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "robotics-toolbox-python_amd")]
+
+BYTES_PER_CONFIG = 56 + 128 + 336  # q read + T written + J0 written
+HBM_PEAK_GBS = 8000.0              # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(q_host, T_gpu, J_gpu, max_seconds=25.0):
+    """Reference CPU path on this box (1 core: the extension holds the GIL and has no threads).
+    The same pass doubles as the parity guard of the timed configuration: the GPU's T/J rows of the
+    sample are compared with what the CPU leg just produced."""
+    import numpy as np
+    from oracle import chains
+    ch = chains.panda_ets()
+    try:
+        from oracle import ref_harness
+        if not ref_harness.available():
+            raise ImportError("oracle/_ref not built")
+        ref = ref_harness.RefETS(ch)
+        kind = "reference"
+        fk = lambda a: ref.fkine(a)
+        jc = lambda a: ref.jacob0_batch(a)
+    except Exception:
+        from oracle import oracle
+        kind = "port"
+        fk = lambda a: oracle.fkine(ch, a)
+        jc = lambda a: oracle.jacob0(ch, a)
+    n = min(len(q_host), 200000)
+    sample = np.ascontiguousarray(q_host[:n])
+    fk(sample[:1000]); jc(sample[:1000])  # warm-up
+    reps, t_used, best = 0, 0.0, None
+    while reps < 5 and t_used < max_seconds:
+        t0 = time.perf_counter()
+        Tc = fk(sample)
+        Jc = jc(sample)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        t_used += dt
+        reps += 1
+    err = max(float(np.abs(T_gpu[:n].cpu().numpy() - Tc).max()), float(np.abs(J_gpu[:n].cpu().numpy() - Jc).max()))
+    if not err <= 1e-10:
+        raise SystemExit("bench: parity check vs the CPU %s failed, max |err| = %g" % (kind, err))
+    return {"value": n / best, "unit": "configurations/s", "cores": 1, "kind": kind, "max_abs_err_gpu_vs_cpu": err,
+            "sample": "first %d of the %d bench configurations, best of %d passes; ETS_fkine over the array "
+                      "+ per-row ETS_jacob0 loop (the reference has no batched Jacobian)" % (n, len(q_host), reps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=int, default=1000000, help="configurations per GPU per step")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--tune", action="append", default=[], help="key=value for rtbhip_tune (A/B runs)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import rtbhip
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    for kv in args.tune:
+        k, v = kv.split("=")
+        rtbhip.tune(k, int(v))
+
+    N = args.n
+    robot = rtbhip.models.Panda()
+    ets = robot.ets()
+    rng = np.random.default_rng(rank)  # seed 0 on rank 0 = BASELINE config 2
+    q_host = rng.uniform(-np.pi, np.pi, (N, 7))
+    q = torch.from_numpy(q_host).to(dev)
+    T = torch.empty((N, 4, 4), dtype=torch.float64, device=dev)
+    J = torch.empty((N, 6, 7), dtype=torch.float64, device=dev)
+    lib = rtbhip.lib()
+    import ctypes as C
+    h = ets._handle()
+    qp, Tp, Jp = C.c_void_p(q.data_ptr()), C.c_void_p(T.data_ptr()), C.c_void_p(J.data_ptr())
+
+    def step():
+        rc = lib.rtbhip_fkine_jacob(h, qp, N, None, None, 0, Tp, Jp, 1, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError(lib.rtbhip_last_error().decode())
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant-kernel duration from HIP events on the launch stream (outside the timed region)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for a, b in ev:
+        a.record()
+        step()
+        b.record()
+    torch.cuda.synchronize()
+    kern_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    kern_avg_ms = sum(kern_ms) / len(kern_ms)
+
+    gather_ms = None
+    if dist is not None:
+        out = torch.cat([T.reshape(N, 16), J.reshape(N, 42)], dim=1).contiguous()
+        buf = torch.empty((world * N, 58), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(buf, out)  # warm-up (communicator setup)
+        barrier()
+        g0 = time.perf_counter()
+        dist.all_gather_into_tensor(buf, out)
+        barrier()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+
+    if rank == 0:
+        achieved = BYTES_PER_CONFIG * N / (kern_avg_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "configurations/sec (Panda 7-DOF fkine+jacob0)",
+            "value": world * N * args.steps / elapsed,
+            "unit": "configurations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: ETS Panda (22 ETs, 7 joints) fused fkine+jacob0, "
+                                   "q~U(-pi,pi)^7 seed 0, N=%d per GPU, fp64, device-resident" % N,
+                       "configs_per_gpu": N, "sharding": "rows/%d, no data-path collective" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_kin<T,J>", "kernel_avg_ms": kern_avg_ms, "kernel_min_ms": kern_ms[0],
+                         "algorithmic_bytes_per_launch": BYTES_PER_CONFIG * N},
+        }
+        if gather_ms is not None:
+            line["gather_ms"] = gather_ms
+        if not args.no_cpu and world == 1:  # reported on rank 0 at N=1 only
+            line["cpu_baseline"] = cpu_baseline(q_host, T, J)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,147 @@
+/* rtbhip.h -- C ABI of librtbhip.so: the MI355X (gfx950) batched kinematics/dynamics backend.
+ *
+ * This is the drop-in boundary for the ONE hot path of petercorke/robotics-toolbox-python that
+ * this project replaces: what sits under the reference's two CPython extension modules
+ *     fknm  (src/roboticstoolbox/core/fknm.cpp:23-93, method table of 15 functions) and
+ *     frne  (src/roboticstoolbox/core/frne.c:42-62,   method table of 3 functions).
+ * Those are CPython-ABI modules (PyCapsule handles + NumPy arrays); the entry points below are the
+ * plain-C equivalents a maintainer binds with ctypes (INTEGRATION.md shows the stub): opaque
+ * 64-bit handles instead of capsules, caller-owned buffers instead of returned ndarrays, and -- new
+ * -- a batch dimension N on every call, because the reference only loops over rows in C for
+ * ETS_fkine (fknm.cpp:1038-1052) and in Python everywhere else.
+ *
+ * General rules
+ *   - every function returns 0 on success, a negative RTBHIP_E* code otherwise; the text of the
+ *     last error of the calling thread is rtbhip_last_error().  Nothing throws across the ABI.
+ *   - all matrices are float64.  A 4x4 homogeneous transform is 16 doubles ROW-major (the
+ *     layout of one [i,:,:] slice of the (N,4,4) C-order array ETS_fkine returns, fknm.cpp:1002-1005).
+ *   - q is (N, q_width) C-contiguous; q_width = max jindex + 1 (== n for a serial arm).
+ *   - mem: RTBHIP_MEM_HOST   pointers are host memory; the call stages through device buffers
+ *                            and returns when the results are in the output arrays;
+ *          RTBHIP_MEM_DEVICE pointers are device memory of the CURRENT hip device; the call only
+ *                            enqueues work on `stream` (a hipStream_t, NULL = default stream).
+ *   - small per-call parameters (base, tool, gravity, fext, we, qlim) are always HOST pointers.
+ *   - handles are bound to no device: the chain/dynamics tables (a few KB) are uploaded lazily
+ *     to whichever device a call runs on and cached there.
+ */
+#ifndef RTBHIP_H
+#define RTBHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTBHIP_OK 0
+#define RTBHIP_EINVAL (-1)   /* bad argument (NULL, negative size, unknown handle, bad kind ...) */
+#define RTBHIP_EHIP (-2)     /* a HIP runtime call failed (no device, OOM, launch failure)       */
+#define RTBHIP_ELIMIT (-3)   /* chain too long / too many joints for this build                  */
+
+#define RTBHIP_MEM_HOST 0
+#define RTBHIP_MEM_DEVICE 1
+
+/* elementary transform kinds: 0..5 are the reference's axis numbers (robot/ET.py:244-266) */
+#define RTBHIP_ET_RX 0
+#define RTBHIP_ET_RY 1
+#define RTBHIP_ET_RZ 2
+#define RTBHIP_ET_TX 3
+#define RTBHIP_ET_TY 4
+#define RTBHIP_ET_TZ 5
+#define RTBHIP_ET_CONST 6
+
+#define RTBHIP_MAX_JOINTS 32
+#define RTBHIP_MAX_ETS 512
+
+/* One elementary transform.  Replaces `struct ET` (core/structs.h:42-56) as built by ET_init
+ * (core/fknm.cpp:1182-1239): isjoint <=> kind != RTBHIP_ET_CONST, axis == kind, isflip == flip,
+ * jindex == jindex, T == T (but row-major and COPIED -- the reference borrows the NumPy buffer). */
+typedef struct rtbhip_et {
+    int32_t kind;
+    int32_t flip;
+    int32_t jindex;
+    int32_t reserved;
+    double T[16];
+} rtbhip_et;
+
+typedef uint64_t rtbhip_chain_t; /* replaces the "ETS" PyCapsule (fknm.cpp:1066-1114) */
+typedef uint64_t rtbhip_dyn_t;   /* replaces the "Robot" PyCapsule of frne (frne.c:233-299) */
+
+const char *rtbhip_last_error(void);
+int rtbhip_version(void);
+int rtbhip_device_count(int *count);
+
+/* ETS_init (fknm.cpp:1066-1114).  qlim: 2*n doubles, n lows then n highs, in chain joint order, or
+ * NULL for the reference defaults [-pi,pi] / [0,1] (robot/ET.py:109-115). */
+int rtbhip_chain_create(const rtbhip_et *ets, int32_t m, const double *qlim, rtbhip_chain_t *chain);
+int rtbhip_chain_destroy(rtbhip_chain_t chain);
+int rtbhip_chain_info(rtbhip_chain_t chain, int32_t *n, int32_t *m, int32_t *q_width);
+
+/* ETS_fkine (fknm.cpp:923-1064 -> _ETS_fkine methods.cpp:318-352): T[i] = base * chain(q[i]) * tool.
+ * base16/tool16 may be NULL (identity). */
+int rtbhip_fkine(rtbhip_chain_t chain, const double *q, int64_t N, const double *base16,
+                 const double *tool16, double *T, int32_t mem, void *stream);
+
+/* ETS_jacob0 / ETS_jacobe (fknm.cpp:785-921 -> methods.cpp:112-316), batched: J is (N,6,n)
+ * C-order; frame 0 = jacob0 (expressed in the chain's start frame), 1 = jacobe. */
+int rtbhip_jacob(rtbhip_chain_t chain, const double *q, int64_t N, const double *tool16,
+                 int32_t frame, double *J, int32_t mem, void *stream);
+
+/* The headline fused op (one chain walk per configuration): T as rtbhip_fkine (base applies to T
+ * only -- Robot.jacob0 never sees the base, RobotKinematics.py:158), J as rtbhip_jacob. */
+int rtbhip_fkine_jacob(rtbhip_chain_t chain, const double *q, int64_t N, const double *base16,
+                       const double *tool16, int32_t frame, double *T, double *J, int32_t mem,
+                       void *stream);
+
+/* ETS_hessian0 / ETS_hessiane (fknm.cpp:583-783 -> methods.cpp:16-32), batched: H is (N,n,6,n). */
+int rtbhip_hessian(rtbhip_chain_t chain, const double *q, int64_t N, const double *tool16,
+                   int32_t frame, double *H, int32_t mem, void *stream);
+
+/* IK_LM_c (fknm.cpp:394-525 -> ik.cpp:19-75,157-209), batched over N targets, LM loop resident
+ * on the device.  Tep (N,4,4) row-major; q0 (N,n) or NULL; we6 host or NULL; method 0 chan /
+ * 1 wampler / 2 sugihara; seed keys the counter-based restart generator (the reference uses an
+ * unseeded std::rand, ik.cpp:293).  flavour 0 reproduces the C loop (ETS.ik_LM), 1 the Python
+ * solver's loop (ETS.ikine_LM, robot/IK.py:297-367: E tested after the step, %-wrap).
+ * Outputs: q_out (N,n), success/iters/searches int32 (N), residual (N). */
+int rtbhip_ik_lm(rtbhip_chain_t chain, const double *Tep, int64_t N, const double *q0,
+                 int32_t ilimit, int32_t slimit, double tol, int32_t reject_jl, const double *we6,
+                 double lambda, int32_t method, int32_t flavour, uint64_t seed, double *q_out,
+                 int32_t *success, int32_t *iters, int32_t *searches, double *residual,
+                 int32_t mem, void *stream);
+
+/* The restart vector the device generator yields for (seed, target index, search index, joint):
+ * uniform in [qlim_lo, qlim_hi).  Exposed so tests can hand the CPU oracle the same sequence. */
+int rtbhip_ik_restart(rtbhip_chain_t chain, uint64_t seed, int64_t target, int32_t search,
+                      double *q_n);
+
+/* frne.init (frne.c:233-299): L24 is the (n,24) block of DHRobot._init_rne (DHRobot.py:1342-1358). */
+int rtbhip_dyn_create(const double *L24, int32_t n, int32_t mdh, rtbhip_dyn_t *dyn);
+int rtbhip_dyn_destroy(rtbhip_dyn_t dyn); /* frne.delete (frne.c:80-103) */
+
+/* frne.frne (frne.c:106-230 -> newton_euler ne.c:62-493), batched: q,qd,qdd,tau are (N,n).
+ * grav3 is what frne.frne is handed (already negated by DHRobot.rne, DHRobot.py:1449); fext6 may
+ * be NULL (zero wrench). */
+int rtbhip_rne(rtbhip_dyn_t dyn, const double *q, const double *qd, const double *qdd, int64_t N,
+               const double *grav3, const double *fext6, double *tau, int32_t mem, void *stream);
+
+/* Mixed fleet (BASELINE config 5): n_chains independent chains, each with its own batch; one
+ * launch walks all of them (block -> chain map).  q[c] is (N[c], q_width_c), T[c] (N[c],4,4),
+ * J[c] (N[c],6,n_c).  The pointer tables themselves are HOST arrays. */
+int rtbhip_fleet_fkine_jacob(const rtbhip_chain_t *chains, int32_t n_chains,
+                             const double *const *q, const int64_t *N, int32_t frame,
+                             double *const *T, double *const *J, int32_t mem, void *stream);
+
+/* Multi-GPU partition helper: contiguous row block [begin, begin+count) of rank `rank` out of
+ * `world` (the first N % world ranks get one extra row).  Pure host arithmetic. */
+int rtbhip_shard_range(int64_t N, int32_t rank, int32_t world, int64_t *begin, int64_t *count);
+
+/* Launch-geometry report for the last kernel a call on this thread enqueued (diagnostics). */
+int rtbhip_last_launch(int32_t *grid, int32_t *block, int32_t *lds_bytes);
+
+/* Tuning knobs for benchmarking (A/B of launch geometry / store paths); unknown keys are ignored. */
+int rtbhip_tune(const char *key, int32_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTBHIP_H */

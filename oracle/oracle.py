@@ -1,0 +1,174 @@
+"""oracle/oracle.py -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+
+ctypes front-end of oracle/liboracle.so (the plain-C restatement, rtb_oracle.c).  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+Parity status: pinned (see rtb_oracle.h header).
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+class _CChain(C.Structure):
+    _fields_ = [("m", C.c_int), ("n", C.c_int), ("kind", _ip), ("flip", _ip), ("jindex", _ip),
+                ("consts", _dp)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-f", os.path.join(_HERE, "Makefile"), "lib"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        for name in ("oracle_fkine", "oracle_jacob", "oracle_hessian", "oracle_angle_axis",
+                     "oracle_ik_lm", "oracle_ikine_lm", "oracle_rne_dh", "oracle_dh_A",
+                     "oracle_dh_fkine"):
+            getattr(_LIB, name).restype = None
+    return _LIB
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _f64(a, shape=None):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    return a if shape is None else np.ascontiguousarray(a.reshape(shape))
+
+
+def _cchain(ch):
+    keep = (np.ascontiguousarray(ch.kind, dtype=np.int32), np.ascontiguousarray(ch.flip, dtype=np.int32),
+            np.ascontiguousarray(ch.jindex, dtype=np.int32), _f64(ch.consts, (-1, 16)))
+    cc = _CChain(int(ch.m), int(ch.n), keep[0].ctypes.data_as(_ip), keep[1].ctypes.data_as(_ip),
+                 keep[2].ctypes.data_as(_ip), keep[3].ctypes.data_as(_dp))
+    return cc, keep
+
+
+def fkine(ch, q, base=None, tool=None):
+    q = _f64(q)
+    q2 = q.reshape(-1, q.shape[-1]) if q.ndim > 1 else q.reshape(1, -1)
+    N, w = q2.shape
+    T = np.empty((N, 4, 4))
+    cc, keep = _cchain(ch)
+    b, t = _f64(base, (4, 4)), _f64(tool, (4, 4))
+    lib().oracle_fkine(C.byref(cc), _d(q2), C.c_long(N), C.c_int(w), _d(b), _d(t), _d(T))
+    return T
+
+
+def jacob(ch, q, tool=None, frame=0):
+    q = _f64(q)
+    q2 = q.reshape(-1, q.shape[-1]) if q.ndim > 1 else q.reshape(1, -1)
+    N, w = q2.shape
+    J = np.empty((N, 6, ch.n))
+    cc, keep = _cchain(ch)
+    t = _f64(tool, (4, 4))
+    lib().oracle_jacob(C.byref(cc), _d(q2), C.c_long(N), C.c_int(w), _d(t), C.c_int(frame), _d(J))
+    return J
+
+
+def jacob0(ch, q, tool=None):
+    return jacob(ch, q, tool, 0)
+
+
+def jacobe(ch, q, tool=None):
+    return jacob(ch, q, tool, 1)
+
+
+def hessian0(ch, q, tool=None):
+    J = jacob(ch, q, tool, 0)
+    H = np.empty((J.shape[0], ch.n, 6, ch.n))
+    for i in range(J.shape[0]):
+        Ji = np.ascontiguousarray(J[i])
+        lib().oracle_hessian(C.c_int(ch.n), _d(Ji), _d(H[i]))
+    return H
+
+
+def angle_axis(Te, Tep):
+    Te, Tep = _f64(Te, (4, 4)), _f64(Tep, (4, 4))
+    e = np.empty(6)
+    lib().oracle_angle_axis(_d(Te), _d(Tep), _d(e))
+    return e
+
+
+METHODS = {"chan": 0, "wampler": 1, "sugihara": 2}
+
+
+def ik_lm(ch, Tep, q0=None, ilimit=30, slimit=100, tol=1e-6, reject_jl=True, we=None, k=1.0,
+          method="chan", restarts=None):
+    """C-flavoured LM (reference ETS.ik_LM -> IK_LM_c).  restarts: (slimit+1, n) start vectors."""
+    n = ch.n
+    if restarts is None:
+        raise ValueError("oracle ik_lm needs the restart vectors (the RNG is external)")
+    restarts = _f64(restarts, (-1, n))
+    assert restarts.shape[0] >= slimit + 1
+    cc, keep = _cchain(ch)
+    q = np.zeros(n)
+    sol, it, search = C.c_int(0), C.c_int(0), C.c_int(0)
+    E = C.c_double(0)
+    Tep = _f64(Tep, (4, 4))
+    q0 = _f64(q0, (n,)) if q0 is not None else None
+    we = _f64(we, (6,)) if we is not None else None
+    qlim = _f64(ch.qlim, (2, n))
+    lib().oracle_ik_lm(C.byref(cc), _d(qlim), _d(Tep), _d(q0), C.c_int(ilimit), C.c_int(slimit),
+                       C.c_double(tol), C.c_int(int(bool(reject_jl))), _d(we), C.c_double(k),
+                       C.c_int(METHODS[method] if isinstance(method, str) else int(method)),
+                       _d(restarts), _d(q), C.byref(sol), C.byref(it), C.byref(search), C.byref(E))
+    return q, sol.value, it.value, search.value, E.value
+
+
+def ikine_lm(ch, Tep, q0s, ilimit=30, slimit=100, tol=1e-6, joint_limits=True, we=None, k=1.0,
+             method="chan"):
+    """Python-flavoured LM (reference ETS.ikine_LM -> IK.py).  q0s: (slimit, n) start vectors."""
+    n = ch.n
+    q0s = _f64(q0s, (-1, n))
+    assert q0s.shape[0] >= slimit
+    cc, keep = _cchain(ch)
+    q = np.zeros(n)
+    ok, it, se = C.c_int(0), C.c_int(0), C.c_int(0)
+    E = C.c_double(0)
+    Tep = _f64(Tep, (4, 4))
+    we = _f64(we, (6,)) if we is not None else None
+    qlim = _f64(ch.qlim, (2, n))
+    lib().oracle_ikine_lm(C.byref(cc), _d(qlim), _d(Tep), _d(q0s), C.c_int(ilimit), C.c_int(slimit),
+                          C.c_double(tol), C.c_int(int(bool(joint_limits))), _d(we), C.c_double(k),
+                          C.c_int(METHODS[method] if isinstance(method, str) else int(method)),
+                          _d(q), C.byref(ok), C.byref(it), C.byref(se), C.byref(E))
+    return q, ok.value, it.value, se.value, E.value
+
+
+def rne_dh(L24, mdh, q, qd, qdd, grav_c, fext=None):
+    """grav_c is what frne.frne is handed (already negated by DHRobot.rne, DHRobot.py:1449)."""
+    L = _f64(L24, (-1, 24))
+    n = L.shape[0]
+    q, qd, qdd = _f64(q, (-1, n)), _f64(qd, (-1, n)), _f64(qdd, (-1, n))
+    N = q.shape[0]
+    tau = np.empty((N, n))
+    g = _f64(grav_c, (3,))
+    f = _f64(fext, (6,)) if fext is not None else None
+    lib().oracle_rne_dh(_d(L), C.c_int(n), C.c_int(int(mdh)), _d(q), _d(qd), _d(qdd), C.c_long(N),
+                        _d(g), _d(f), _d(tau))
+    return tau
+
+
+def dh_fkine(dh7, mdh, q, base=None, tool=None):
+    dh = _f64(dh7, (-1, 7))
+    n = dh.shape[0]
+    q = _f64(q, (-1, n))
+    N = q.shape[0]
+    T = np.empty((N, 4, 4))
+    b, t = _f64(base, (4, 4)), _f64(tool, (4, 4))
+    lib().oracle_dh_fkine(_d(dh), C.c_int(n), C.c_int(int(mdh)), _d(q), C.c_long(N), _d(b), _d(t), _d(T))
+    return T

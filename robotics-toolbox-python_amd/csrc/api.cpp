@@ -1,0 +1,460 @@
+// api.cpp -- the extern "C" entry points of librtbhip.so (declared in include/rtbhip.h).
+// Argument checking, handle registry, lazy per-device upload of the chain / link tables, and the
+// host-memory convenience path (stage -> launch -> copy back).  No arithmetic lives here.
+#include "rtbhip_internal.h"
+#include <atomic>
+#include <cstring>
+#include <memory>
+#include <unordered_map>
+
+namespace rtbhip {
+
+// ---------------------------------------------------------------- errors
+static thread_local std::string g_err;
+static thread_local int g_last_launch[3] = {0, 0, 0};
+
+void set_error(const std::string &msg) { g_err = msg; }
+int hip_fail(hipError_t e, const char *what)
+{
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();  // clear sticky state where possible
+    return RTBHIP_EHIP;
+}
+void note_launch(int grid, int block, int lds)
+{
+    g_last_launch[0] = grid; g_last_launch[1] = block; g_last_launch[2] = lds;
+}
+
+// ---------------------------------------------------------------- handle registry
+static std::mutex g_reg_mu;
+static std::unordered_map<uint64_t, std::unique_ptr<Chain>> g_chains;
+static std::unordered_map<uint64_t, std::unique_ptr<Dyn>> g_dyns;
+static std::atomic<uint64_t> g_next{1};
+
+Chain *chain_from_handle(rtbhip_chain_t h)
+{
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    auto it = g_chains.find(h);
+    return it == g_chains.end() ? nullptr : it->second.get();
+}
+Dyn *dyn_from_handle(rtbhip_dyn_t h)
+{
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    auto it = g_dyns.find(h);
+    return it == g_dyns.end() ? nullptr : it->second.get();
+}
+
+int chain_device_ops(Chain *c, const DevOp **out, const double **qlim_out)
+{
+    int dev = 0;
+    RTB_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(c->mu);
+    auto it = c->dev_ops.find(dev);
+    if (it == c->dev_ops.end()) {
+        DevOp *d = nullptr;
+        double *ql = nullptr;
+        size_t bytes = (c->ops.size() ? c->ops.size() : 1) * sizeof(DevOp);
+        RTB_HIP(hipMalloc((void **)&d, bytes));
+        if (!c->ops.empty()) RTB_HIP(hipMemcpy(d, c->ops.data(), c->ops.size() * sizeof(DevOp), hipMemcpyHostToDevice));
+        RTB_HIP(hipMalloc((void **)&ql, (c->qlim.size() ? c->qlim.size() : 1) * sizeof(double)));
+        if (!c->qlim.empty()) RTB_HIP(hipMemcpy(ql, c->qlim.data(), c->qlim.size() * sizeof(double), hipMemcpyHostToDevice));
+        c->dev_ops[dev] = d;
+        c->dev_qlim[dev] = ql;
+        it = c->dev_ops.find(dev);
+    }
+    *out = it->second;
+    if (qlim_out) *qlim_out = c->dev_qlim[dev];
+    return RTBHIP_OK;
+}
+
+int dyn_device_links(Dyn *d, const DevLink **out)
+{
+    int dev = 0;
+    RTB_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(d->mu);
+    auto it = d->dev_links.find(dev);
+    if (it == d->dev_links.end()) {
+        DevLink *p = nullptr;
+        RTB_HIP(hipMalloc((void **)&p, d->links.size() * sizeof(DevLink)));
+        RTB_HIP(hipMemcpy(p, d->links.data(), d->links.size() * sizeof(DevLink), hipMemcpyHostToDevice));
+        d->dev_links[dev] = p;
+        it = d->dev_links.find(dev);
+    }
+    *out = it->second;
+    return RTBHIP_OK;
+}
+
+int device_cu_count(int *cus)
+{
+    int dev = 0;
+    RTB_HIP(hipGetDevice(&dev));
+    RTB_HIP(hipDeviceGetAttribute(cus, hipDeviceAttributeMultiprocessorCount, dev));
+    return RTBHIP_OK;
+}
+
+// ---------------------------------------------------------------- host staging helper
+// RAII device buffers for the RTBHIP_MEM_HOST convenience path.
+struct Staging {
+    std::vector<void *> bufs;
+    ~Staging() { for (void *p : bufs) (void)hipFree(p); }
+    int in(const void *host, size_t bytes, void **dev)
+    {
+        *dev = nullptr;
+        if (host == nullptr || bytes == 0) return RTBHIP_OK;
+        RTB_HIP(hipMalloc(dev, bytes));
+        bufs.push_back(*dev);
+        RTB_HIP(hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice));
+        return RTBHIP_OK;
+    }
+    int out(size_t bytes, void **dev)
+    {
+        *dev = nullptr;
+        if (bytes == 0) return RTBHIP_OK;
+        RTB_HIP(hipMalloc(dev, bytes));
+        bufs.push_back(*dev);
+        return RTBHIP_OK;
+    }
+};
+#define RTB_TRY(expr)                   \
+    do {                                \
+        int _rc = (expr);               \
+        if (_rc != RTBHIP_OK) return _rc; \
+    } while (0)
+
+static int fetch(void *host, const void *dev, size_t bytes)
+{
+    if (host == nullptr || bytes == 0) return RTBHIP_OK;
+    RTB_HIP(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+    return RTBHIP_OK;
+}
+
+static Affine affine_from16(const double *m16)
+{
+    Affine a;
+    a.used = m16 != nullptr;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 4; c++) a.v[4 * r + c] = m16 ? m16[4 * r + c] : (r == c ? 1.0 : 0.0);
+    return a;
+}
+
+static int check_batch(const char *fn, const void *q, int64_t N, int mem)
+{
+    if (N < 0) { set_error(std::string(fn) + ": negative N"); return RTBHIP_EINVAL; }
+    if (N > 0 && q == nullptr) { set_error(std::string(fn) + ": NULL input with N > 0"); return RTBHIP_EINVAL; }
+    if (mem != RTBHIP_MEM_HOST && mem != RTBHIP_MEM_DEVICE) { set_error(std::string(fn) + ": bad mem kind"); return RTBHIP_EINVAL; }
+    return RTBHIP_OK;
+}
+
+static int kin_entry(const char *fn, rtbhip_chain_t h, const double *q, int64_t N, const double *base16,
+                     const double *tool16, int frame, double *T, double *J, double *H, int mem, void *stream)
+{
+    Chain *c = chain_from_handle(h);
+    if (!c) { set_error(std::string(fn) + ": unknown chain handle"); return RTBHIP_EINVAL; }
+    RTB_TRY(check_batch(fn, q, N, mem));
+    if (frame != 0 && frame != 1) { set_error(std::string(fn) + ": frame must be 0 (jacob0) or 1 (jacobe)"); return RTBHIP_EINVAL; }
+    if (N > 0 && !T && !J && !H) { set_error(std::string(fn) + ": no output buffer"); return RTBHIP_EINVAL; }
+    if (N == 0) return RTBHIP_OK;
+    const DevOp *ops = nullptr;
+    RTB_TRY(chain_device_ops(c, &ops, nullptr));
+    Affine base = affine_from16(base16), tool = affine_from16(tool16);
+    const size_t n = (size_t)c->n, qw = (size_t)c->q_width;
+    if (mem == RTBHIP_MEM_DEVICE)
+        return launch_kin(c, ops, q, N, base, tool, frame, T, J, H, (hipStream_t)stream);
+    Staging st;
+    void *dq, *dT = nullptr, *dJ = nullptr, *dH = nullptr;
+    RTB_TRY(st.in(q, (size_t)N * qw * 8, &dq));
+    if (T) RTB_TRY(st.out((size_t)N * 128, &dT));
+    if (J) RTB_TRY(st.out((size_t)N * 48 * n, &dJ));
+    if (H) RTB_TRY(st.out((size_t)N * 48 * n * n, &dH));
+    RTB_TRY(launch_kin(c, ops, (const double *)dq, N, base, tool, frame, (double *)dT, (double *)dJ, (double *)dH, nullptr));
+    RTB_HIP(hipDeviceSynchronize());
+    RTB_TRY(fetch(T, dT, (size_t)N * 128));
+    RTB_TRY(fetch(J, dJ, (size_t)N * 48 * n));
+    RTB_TRY(fetch(H, dH, (size_t)N * 48 * n * n));
+    return RTBHIP_OK;
+}
+
+void kin_tune(const char *key, int value);
+void rne_tune(const char *key, int value);
+void ik_tune(const char *key, int value);
+
+}  // namespace rtbhip
+
+using namespace rtbhip;
+
+extern "C" {
+
+const char *rtbhip_last_error(void) { return g_err.c_str(); }
+int rtbhip_version(void) { return 100; }
+
+int rtbhip_device_count(int *count)
+{
+    if (!count) { set_error("device_count: NULL"); return RTBHIP_EINVAL; }
+    *count = 0;
+    RTB_HIP(hipGetDeviceCount(count));
+    return RTBHIP_OK;
+}
+
+int rtbhip_chain_create(const rtbhip_et *ets, int32_t m, const double *qlim, rtbhip_chain_t *chain)
+{
+    if (!chain) { set_error("chain_create: NULL out"); return RTBHIP_EINVAL; }
+    std::unique_ptr<Chain> c(new Chain());
+    RTB_TRY(compile_chain(ets, m, qlim, c.get()));
+    uint64_t h = g_next.fetch_add(1);
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    g_chains[h] = std::move(c);
+    *chain = h;
+    return RTBHIP_OK;
+}
+
+int rtbhip_chain_destroy(rtbhip_chain_t chain)
+{
+    std::unique_ptr<Chain> c;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        auto it = g_chains.find(chain);
+        if (it == g_chains.end()) { set_error("chain_destroy: unknown handle"); return RTBHIP_EINVAL; }
+        c = std::move(it->second);
+        g_chains.erase(it);
+    }
+    for (auto &kv : c->dev_ops) (void)hipFree(kv.second);
+    for (auto &kv : c->dev_qlim) (void)hipFree(kv.second);
+    return RTBHIP_OK;
+}
+
+int rtbhip_chain_info(rtbhip_chain_t chain, int32_t *n, int32_t *m, int32_t *q_width)
+{
+    Chain *c = chain_from_handle(chain);
+    if (!c) { set_error("chain_info: unknown handle"); return RTBHIP_EINVAL; }
+    if (n) *n = c->n;
+    if (m) *m = (int32_t)c->ops.size();
+    if (q_width) *q_width = c->q_width;
+    return RTBHIP_OK;
+}
+
+int rtbhip_fkine(rtbhip_chain_t chain, const double *q, int64_t N, const double *base16,
+                 const double *tool16, double *T, int32_t mem, void *stream)
+{
+    if (N > 0 && !T) { set_error("fkine: NULL T"); return RTBHIP_EINVAL; }
+    return kin_entry("fkine", chain, q, N, base16, tool16, 0, T, nullptr, nullptr, mem, stream);
+}
+
+int rtbhip_jacob(rtbhip_chain_t chain, const double *q, int64_t N, const double *tool16,
+                 int32_t frame, double *J, int32_t mem, void *stream)
+{
+    if (N > 0 && !J) { set_error("jacob: NULL J"); return RTBHIP_EINVAL; }
+    return kin_entry("jacob", chain, q, N, nullptr, tool16, frame, nullptr, J, nullptr, mem, stream);
+}
+
+int rtbhip_fkine_jacob(rtbhip_chain_t chain, const double *q, int64_t N, const double *base16,
+                       const double *tool16, int32_t frame, double *T, double *J, int32_t mem,
+                       void *stream)
+{
+    if (N > 0 && (!T || !J)) { set_error("fkine_jacob: NULL T or J"); return RTBHIP_EINVAL; }
+    return kin_entry("fkine_jacob", chain, q, N, base16, tool16, frame, T, J, nullptr, mem, stream);
+}
+
+int rtbhip_hessian(rtbhip_chain_t chain, const double *q, int64_t N, const double *tool16,
+                   int32_t frame, double *H, int32_t mem, void *stream)
+{
+    if (N > 0 && !H) { set_error("hessian: NULL H"); return RTBHIP_EINVAL; }
+    return kin_entry("hessian", chain, q, N, nullptr, tool16, frame, nullptr, nullptr, H, mem, stream);
+}
+
+int rtbhip_ik_lm(rtbhip_chain_t chain, const double *Tep, int64_t N, const double *q0,
+                 int32_t ilimit, int32_t slimit, double tol, int32_t reject_jl, const double *we6,
+                 double lambda, int32_t method, int32_t flavour, uint64_t seed, double *q_out,
+                 int32_t *success, int32_t *iters, int32_t *searches, double *residual,
+                 int32_t mem, void *stream)
+{
+    Chain *c = chain_from_handle(chain);
+    if (!c) { set_error("ik_lm: unknown chain handle"); return RTBHIP_EINVAL; }
+    RTB_TRY(check_batch("ik_lm", Tep, N, mem));
+    if (method < 0 || method > 2) { set_error("ik_lm: method must be 0 chan, 1 wampler, 2 sugihara"); return RTBHIP_EINVAL; }
+    if (flavour < 0 || flavour > 1) { set_error("ik_lm: flavour must be 0 (ik_LM) or 1 (ikine_LM)"); return RTBHIP_EINVAL; }
+    if (ilimit < 1 || slimit < 1) { set_error("ik_lm: ilimit and slimit must be >= 1"); return RTBHIP_EINVAL; }
+    if (c->n < 1) { set_error("ik_lm: chain has no joints"); return RTBHIP_EINVAL; }
+    if (c->q_width != c->n) { set_error("ik_lm: chain must use jindex 0..n-1 (reference ik.cpp:34-37 assumes the same)"); return RTBHIP_EINVAL; }
+    if (N > 0 && (!q_out || !success || !iters || !searches || !residual)) { set_error("ik_lm: NULL output"); return RTBHIP_EINVAL; }
+    if (N == 0) return RTBHIP_OK;
+    IkParams p;
+    p.ilimit = ilimit; p.slimit = slimit; p.reject_jl = reject_jl ? 1 : 0; p.method = method;
+    p.flavour = flavour; p.tol = tol; p.lambda = lambda; p.seed = seed;
+    for (int i = 0; i < 6; i++) p.we[i] = we6 ? we6[i] : 1.0;
+    const DevOp *ops = nullptr;
+    const double *qlim = nullptr;
+    RTB_TRY(chain_device_ops(c, &ops, &qlim));
+    const size_t n = (size_t)c->n;
+    if (mem == RTBHIP_MEM_DEVICE)
+        return launch_ik(c, ops, qlim, Tep, N, q0, p, q_out, success, iters, searches, residual, (hipStream_t)stream);
+    Staging st;
+    void *dTep, *dq0, *dq, *ds, *di, *dse, *dr;
+    RTB_TRY(st.in(Tep, (size_t)N * 128, &dTep));
+    RTB_TRY(st.in(q0, (size_t)N * n * 8, &dq0));
+    RTB_TRY(st.out((size_t)N * n * 8, &dq));
+    RTB_TRY(st.out((size_t)N * 4, &ds));
+    RTB_TRY(st.out((size_t)N * 4, &di));
+    RTB_TRY(st.out((size_t)N * 4, &dse));
+    RTB_TRY(st.out((size_t)N * 8, &dr));
+    RTB_TRY(launch_ik(c, ops, qlim, (const double *)dTep, N, (const double *)dq0, p, (double *)dq, (int32_t *)ds,
+                      (int32_t *)di, (int32_t *)dse, (double *)dr, nullptr));
+    RTB_HIP(hipDeviceSynchronize());
+    RTB_TRY(fetch(q_out, dq, (size_t)N * n * 8));
+    RTB_TRY(fetch(success, ds, (size_t)N * 4));
+    RTB_TRY(fetch(iters, di, (size_t)N * 4));
+    RTB_TRY(fetch(searches, dse, (size_t)N * 4));
+    RTB_TRY(fetch(residual, dr, (size_t)N * 8));
+    return RTBHIP_OK;
+}
+
+int rtbhip_ik_restart(rtbhip_chain_t chain, uint64_t seed, int64_t target, int32_t search, double *q_n)
+{
+    Chain *c = chain_from_handle(chain);
+    if (!c || !q_n) { set_error("ik_restart: bad argument"); return RTBHIP_EINVAL; }
+    ik_restart_host(c, seed, target, search, q_n);
+    return RTBHIP_OK;
+}
+
+int rtbhip_dyn_create(const double *L24, int32_t n, int32_t mdh, rtbhip_dyn_t *dyn)
+{
+    if (!L24 || !dyn || n < 1) { set_error("dyn_create: bad argument"); return RTBHIP_EINVAL; }
+    if (n > RTBHIP_MAX_JOINTS) { set_error("dyn_create: more than RTBHIP_MAX_JOINTS links"); return RTBHIP_ELIMIT; }
+    if (mdh != 0 && mdh != 1) { set_error("dyn_create: mdh must be 0 or 1"); return RTBHIP_EINVAL; }
+    std::unique_ptr<Dyn> d(new Dyn());
+    d->n = n;
+    d->mdh = mdh;
+    d->links.resize(n);
+    for (int i = 0; i < n; i++) {
+        const double *l = L24 + 24 * i;  // layout: DHRobot.py:1342-1358
+        DevLink &k = d->links[i];
+        std::memset(&k, 0, sizeof k);
+        int sigma = (int)l[4];  // frne.c:279 casts the double to the enum the same way
+        if (sigma != 0 && sigma != 1) { set_error("dyn_create: sigma must be 0 (R) or 1 (P)"); return RTBHIP_EINVAL; }
+        k.sa = sin(l[0]); k.ca = cos(l[0]);  // frne.c:325-326 evaluates these per call; constant per link
+        k.a = l[1]; k.theta = l[2]; k.d = l[3]; k.sigma = sigma; k.offset = l[5];
+        k.m = l[6]; k.rx = l[7]; k.ry = l[8]; k.rz = l[9];
+        for (int j = 0; j < 9; j++) k.I[j] = l[10 + j];
+        k.Jm = l[19]; k.G = l[20]; k.B = l[21]; k.Tc0 = l[22]; k.Tc1 = l[23];
+    }
+    uint64_t h = g_next.fetch_add(1);
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    g_dyns[h] = std::move(d);
+    *dyn = h;
+    return RTBHIP_OK;
+}
+
+int rtbhip_dyn_destroy(rtbhip_dyn_t dyn)
+{
+    std::unique_ptr<Dyn> d;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        auto it = g_dyns.find(dyn);
+        if (it == g_dyns.end()) { set_error("dyn_destroy: unknown handle"); return RTBHIP_EINVAL; }
+        d = std::move(it->second);
+        g_dyns.erase(it);
+    }
+    for (auto &kv : d->dev_links) (void)hipFree(kv.second);
+    return RTBHIP_OK;
+}
+
+int rtbhip_rne(rtbhip_dyn_t dyn, const double *q, const double *qd, const double *qdd, int64_t N,
+               const double *grav3, const double *fext6, double *tau, int32_t mem, void *stream)
+{
+    Dyn *d = dyn_from_handle(dyn);
+    if (!d) { set_error("rne: unknown dyn handle"); return RTBHIP_EINVAL; }
+    RTB_TRY(check_batch("rne", q, N, mem));
+    if (!grav3) { set_error("rne: NULL gravity"); return RTBHIP_EINVAL; }
+    if (N > 0 && (!qd || !qdd || !tau)) { set_error("rne: NULL qd/qdd/tau"); return RTBHIP_EINVAL; }
+    if (N == 0) return RTBHIP_OK;
+    const DevLink *links = nullptr;
+    RTB_TRY(dyn_device_links(d, &links));
+    if (mem == RTBHIP_MEM_DEVICE)
+        return launch_rne(d, links, q, qd, qdd, N, grav3, fext6, tau, (hipStream_t)stream);
+    Staging st;
+    const size_t bytes = (size_t)N * d->n * 8;
+    void *dq, *dqd, *dqdd, *dtau;
+    RTB_TRY(st.in(q, bytes, &dq));
+    RTB_TRY(st.in(qd, bytes, &dqd));
+    RTB_TRY(st.in(qdd, bytes, &dqdd));
+    RTB_TRY(st.out(bytes, &dtau));
+    RTB_TRY(launch_rne(d, links, (const double *)dq, (const double *)dqd, (const double *)dqdd, N, grav3, fext6,
+                       (double *)dtau, nullptr));
+    RTB_HIP(hipDeviceSynchronize());
+    RTB_TRY(fetch(tau, dtau, bytes));
+    return RTBHIP_OK;
+}
+
+int rtbhip_fleet_fkine_jacob(const rtbhip_chain_t *chains, int32_t n_chains, const double *const *q,
+                             const int64_t *N, int32_t frame, double *const *T, double *const *J,
+                             int32_t mem, void *stream)
+{
+    if (n_chains < 0 || (n_chains > 0 && (!chains || !q || !N || !T || !J))) { set_error("fleet: bad argument"); return RTBHIP_EINVAL; }
+    if (frame != 0 && frame != 1) { set_error("fleet: frame must be 0 or 1"); return RTBHIP_EINVAL; }
+    if (mem != RTBHIP_MEM_HOST && mem != RTBHIP_MEM_DEVICE) { set_error("fleet: bad mem kind"); return RTBHIP_EINVAL; }
+    std::vector<FleetEntry> entries;
+    Staging st;
+    std::vector<void *> dT(n_chains, nullptr), dJ(n_chains, nullptr);
+    int64_t tile0 = 0;
+    for (int i = 0; i < n_chains; i++) {
+        Chain *c = chain_from_handle(chains[i]);
+        if (!c) { set_error("fleet: unknown chain handle"); return RTBHIP_EINVAL; }
+        if (N[i] < 0) { set_error("fleet: negative N"); return RTBHIP_EINVAL; }
+        if (N[i] == 0) continue;
+        if (!q[i] || !T[i] || !J[i]) { set_error("fleet: NULL buffer"); return RTBHIP_EINVAL; }
+        FleetEntry e;
+        RTB_TRY(chain_device_ops(c, &e.ops, nullptr));
+        e.m = (int32_t)c->ops.size(); e.n = c->n; e.q_width = c->q_width; e.N = N[i]; e.tile0 = tile0;
+        e.stride = 0;
+        if (mem == RTBHIP_MEM_DEVICE) {
+            e.q = q[i]; e.T = T[i]; e.J = J[i];
+        } else {
+            void *dq;
+            RTB_TRY(st.in(q[i], (size_t)N[i] * c->q_width * 8, &dq));
+            RTB_TRY(st.out((size_t)N[i] * 128, &dT[i]));
+            RTB_TRY(st.out((size_t)N[i] * 48 * c->n, &dJ[i]));
+            e.q = (const double *)dq; e.T = (double *)dT[i]; e.J = (double *)dJ[i];
+        }
+        tile0 += (N[i] + 63) / 64;
+        entries.push_back(e);
+    }
+    if (entries.empty()) return RTBHIP_OK;
+    RTB_TRY(launch_fleet(entries, frame, mem == RTBHIP_MEM_DEVICE ? (hipStream_t)stream : nullptr));
+    if (mem == RTBHIP_MEM_HOST) {
+        RTB_HIP(hipDeviceSynchronize());
+        for (int i = 0; i < n_chains; i++) {
+            if (N[i] == 0) continue;
+            Chain *c = chain_from_handle(chains[i]);
+            RTB_TRY(fetch(T[i], dT[i], (size_t)N[i] * 128));
+            RTB_TRY(fetch(J[i], dJ[i], (size_t)N[i] * 48 * c->n));
+        }
+    }
+    return RTBHIP_OK;
+}
+
+int rtbhip_shard_range(int64_t N, int32_t rank, int32_t world, int64_t *begin, int64_t *count)
+{
+    if (N < 0 || world < 1 || rank < 0 || rank >= world || !begin || !count) { set_error("shard_range: bad argument"); return RTBHIP_EINVAL; }
+    int64_t base = N / world, extra = N % world;
+    *count = base + (rank < extra ? 1 : 0);
+    *begin = base * rank + (rank < extra ? rank : extra);
+    return RTBHIP_OK;
+}
+
+int rtbhip_last_launch(int32_t *grid, int32_t *block, int32_t *lds_bytes)
+{
+    if (grid) *grid = g_last_launch[0];
+    if (block) *block = g_last_launch[1];
+    if (lds_bytes) *lds_bytes = g_last_launch[2];
+    return RTBHIP_OK;
+}
+
+int rtbhip_tune(const char *key, int32_t value)
+{
+    if (!key) { set_error("tune: NULL key"); return RTBHIP_EINVAL; }
+    kin_tune(key, value);
+    rne_tune(key, value);
+    ik_tune(key, value);
+    return RTBHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,233 @@
+// kin_device.h -- per-lane kinematics primitives shared by the fkine/jacobian/hessian, fleet and IK
+// kernels.  One lane owns one configuration; the SE(3) pose is a 3x4 affine held in 12 fp64
+// registers and every routine below indexes it statically so nothing spills to scratch.
+//
+// What it replaces in the reference: _ET_T + rx..tz (core/methods.cpp:354-370,
+// core/fknm.cpp:1320-1555), the chain walks of _ETS_fkine (methods.cpp:318-352) and
+// _ETS_jacob0/_ETS_jacobe (methods.cpp:112-316), and _ETS_hessian (methods.cpp:16-32).
+//
+// The Jacobian is NOT computed the way the reference does (reverse walk, end-effector-frame
+// columns from rows of U, then a 6x6 block rotation); one forward walk records each joint's axis z_j
+// and origin p_j in the start frame, and the columns are closed as  Jv = z_j x (p_e - p_j), Jw = z_j
+// once the end-effector position is known.  Same quantity, ~1/3 of the flops, differs from the
+// reference only by rounding (tests pin |dJ| <= 1e-10; observed ~1e-15).
+//
+// All functions are __host__ __device__ so tests/emu can execute the exact kernel body, lane by
+// lane, on the CPU build box (which has no GPU).  The product never takes that path.
+#pragma once
+#include "rtbhip_internal.h"
+#include <cmath>
+
+#define RTB_HD __host__ __device__ __forceinline__
+
+namespace rtbhip {
+
+constexpr int kWave = 64;
+
+struct Pose {
+    double r00, r01, r02, r10, r11, r12, r20, r21, r22;
+    double tx, ty, tz;
+};
+
+RTB_HD void pose_identity(Pose &P)
+{
+    P.r00 = 1; P.r01 = 0; P.r02 = 0;
+    P.r10 = 0; P.r11 = 1; P.r12 = 0;
+    P.r20 = 0; P.r21 = 0; P.r22 = 1;
+    P.tx = 0; P.ty = 0; P.tz = 0;
+}
+
+// P <- P * Rot_axis(c, s): a rotation about a coordinate axis only mixes two columns.
+RTB_HD void pose_rotx(Pose &P, double c, double s)
+{
+    double a, b;
+    a = P.r01; b = P.r02; P.r01 = a * c + b * s; P.r02 = b * c - a * s;
+    a = P.r11; b = P.r12; P.r11 = a * c + b * s; P.r12 = b * c - a * s;
+    a = P.r21; b = P.r22; P.r21 = a * c + b * s; P.r22 = b * c - a * s;
+}
+RTB_HD void pose_roty(Pose &P, double c, double s)
+{
+    double a, b;
+    a = P.r00; b = P.r02; P.r00 = a * c - b * s; P.r02 = a * s + b * c;
+    a = P.r10; b = P.r12; P.r10 = a * c - b * s; P.r12 = a * s + b * c;
+    a = P.r20; b = P.r22; P.r20 = a * c - b * s; P.r22 = a * s + b * c;
+}
+RTB_HD void pose_rotz(Pose &P, double c, double s)
+{
+    double a, b;
+    a = P.r00; b = P.r01; P.r00 = a * c + b * s; P.r01 = b * c - a * s;
+    a = P.r10; b = P.r11; P.r10 = a * c + b * s; P.r11 = b * c - a * s;
+    a = P.r20; b = P.r21; P.r20 = a * c + b * s; P.r21 = b * c - a * s;
+}
+// P <- P * Trans(axis, d): t += d * column
+RTB_HD void pose_tx(Pose &P, double d) { P.tx += d * P.r00; P.ty += d * P.r10; P.tz += d * P.r20; }
+RTB_HD void pose_ty(Pose &P, double d) { P.tx += d * P.r01; P.ty += d * P.r11; P.tz += d * P.r21; }
+RTB_HD void pose_tz(Pose &P, double d) { P.tx += d * P.r02; P.ty += d * P.r12; P.tz += d * P.r22; }
+RTB_HD void pose_t3(Pose &P, double x, double y, double z)
+{
+    P.tx += x * P.r00 + y * P.r01 + z * P.r02;
+    P.ty += x * P.r10 + y * P.r11 + z * P.r12;
+    P.tz += x * P.r20 + y * P.r21 + z * P.r22;
+}
+// P <- P * A for a general constant affine a = {R row-major (9), t (3)}
+template <class F>
+RTB_HD void pose_mul_general(Pose &P, F a)
+{
+    pose_t3(P, a(9), a(10), a(11));
+    double x, y, z;
+    x = P.r00; y = P.r01; z = P.r02;
+    P.r00 = x * a(0) + y * a(3) + z * a(6); P.r01 = x * a(1) + y * a(4) + z * a(7); P.r02 = x * a(2) + y * a(5) + z * a(8);
+    x = P.r10; y = P.r11; z = P.r12;
+    P.r10 = x * a(0) + y * a(3) + z * a(6); P.r11 = x * a(1) + y * a(4) + z * a(7); P.r12 = x * a(2) + y * a(5) + z * a(8);
+    x = P.r20; y = P.r21; z = P.r22;
+    P.r20 = x * a(0) + y * a(3) + z * a(6); P.r21 = x * a(1) + y * a(4) + z * a(7); P.r22 = x * a(2) + y * a(5) + z * a(8);
+}
+// P <- A * P  (used once per configuration for the base transform)
+RTB_HD void pose_premul(Pose &P, const double *a /* row-major 3x4 */)
+{
+    Pose O;
+    O.r00 = a[0] * P.r00 + a[1] * P.r10 + a[2] * P.r20;
+    O.r01 = a[0] * P.r01 + a[1] * P.r11 + a[2] * P.r21;
+    O.r02 = a[0] * P.r02 + a[1] * P.r12 + a[2] * P.r22;
+    O.tx = a[0] * P.tx + a[1] * P.ty + a[2] * P.tz + a[3];
+    O.r10 = a[4] * P.r00 + a[5] * P.r10 + a[6] * P.r20;
+    O.r11 = a[4] * P.r01 + a[5] * P.r11 + a[6] * P.r21;
+    O.r12 = a[4] * P.r02 + a[5] * P.r12 + a[6] * P.r22;
+    O.ty = a[4] * P.tx + a[5] * P.ty + a[6] * P.tz + a[7];
+    O.r20 = a[8] * P.r00 + a[9] * P.r10 + a[10] * P.r20;
+    O.r21 = a[8] * P.r01 + a[9] * P.r11 + a[10] * P.r21;
+    O.r22 = a[8] * P.r02 + a[9] * P.r12 + a[10] * P.r22;
+    O.tz = a[8] * P.tx + a[9] * P.ty + a[10] * P.tz + a[11];
+    P = O;
+}
+
+// ---------------------------------------------------------------- the chain walk
+// Interprets the device program for ONE lane.  `ops` is wave-uniform (scalar loads on the GPU).
+//   qcol(c)       -> joint coordinate column c of this lane's configuration
+//   rec(slot, v)  -> per-lane Jacobian scratch write; slot = r*n + jcol holds p_j (r=0..2) and
+//                    z_j (r=3..5), i.e. exactly where row r of column jcol of the finished J lives.
+// WANT_J = false skips the recording (pure fkine).
+template <bool WANT_J, class OpsP, class QCol, class Rec>
+RTB_HD void chain_walk(OpsP ops, int m, int n, Pose &P, QCol qcol, Rec rec)
+{
+    for (int i = 0; i < m; ++i) {
+        const int kind = ops[i].kind;
+        if (kind <= K_JTZ) {
+            double eta = qcol(ops[i].jq);
+            if (ops[i].flip) eta = -eta;  // methods.cpp:363-366
+            const int j = ops[i].jcol;
+            if (kind <= K_JRZ) {
+                double s, c;
+                sincos(eta, &s, &c);  // accurate fp64 path (no fast-math): fknm.cpp:1324-1325
+                if (kind == K_JRX) {
+                    if (WANT_J) { rec(3 * n + j, P.r00); rec(4 * n + j, P.r10); rec(5 * n + j, P.r20); }
+                    pose_rotx(P, c, s);
+                } else if (kind == K_JRY) {
+                    if (WANT_J) { rec(3 * n + j, P.r01); rec(4 * n + j, P.r11); rec(5 * n + j, P.r21); }
+                    pose_roty(P, c, s);
+                } else {
+                    if (WANT_J) { rec(3 * n + j, P.r02); rec(4 * n + j, P.r12); rec(5 * n + j, P.r22); }
+                    pose_rotz(P, c, s);
+                }
+                if (WANT_J) { rec(j, P.tx); rec(n + j, P.ty); rec(2 * n + j, P.tz); }
+            } else {
+                if (kind == K_JTX) {
+                    if (WANT_J) { rec(3 * n + j, P.r00); rec(4 * n + j, P.r10); rec(5 * n + j, P.r20); }
+                    pose_tx(P, eta);
+                } else if (kind == K_JTY) {
+                    if (WANT_J) { rec(3 * n + j, P.r01); rec(4 * n + j, P.r11); rec(5 * n + j, P.r21); }
+                    pose_ty(P, eta);
+                } else {
+                    if (WANT_J) { rec(3 * n + j, P.r02); rec(4 * n + j, P.r12); rec(5 * n + j, P.r22); }
+                    pose_tz(P, eta);
+                }
+            }
+        } else {
+            switch (kind) {
+            case K_CRX: pose_rotx(P, ops[i].p[0], ops[i].p[1]); break;
+            case K_CRY: pose_roty(P, ops[i].p[0], ops[i].p[1]); break;
+            case K_CRZ: pose_rotz(P, ops[i].p[0], ops[i].p[1]); break;
+            case K_CTX: pose_tx(P, ops[i].p[0]); break;
+            case K_CTY: pose_ty(P, ops[i].p[0]); break;
+            case K_CTZ: pose_tz(P, ops[i].p[0]); break;
+            case K_CT3: pose_t3(P, ops[i].p[0], ops[i].p[1], ops[i].p[2]); break;
+            default: pose_mul_general(P, [&](int k) { return ops[i].p[k]; }); break;
+            }
+        }
+    }
+}
+
+// Closes the Jacobian columns in place in the per-lane scratch once the end-effector pose P is
+// known: frame 0 -> jacob0, frame 1 -> jacobe (= blkdiag(Re^T, Re^T) jacob0).
+//   get(slot) / put(slot, v) : per-lane scratch access.
+template <class OpsP, class Get, class Put>
+RTB_HD void jacobian_close(OpsP ops, int m, int n, const Pose &P, int frame, Get get, Put put)
+{
+    for (int i = 0; i < m; ++i) {
+        const int kind = ops[i].kind;
+        if (kind > K_JTZ) continue;
+        const int j = ops[i].jcol;
+        double zx = get(3 * n + j), zy = get(4 * n + j), zz = get(5 * n + j);
+        double vx, vy, vz, wx, wy, wz;
+        if (kind <= K_JRZ) {
+            double dx = P.tx - get(j), dy = P.ty - get(n + j), dz = P.tz - get(2 * n + j);
+            vx = zy * dz - zz * dy;
+            vy = zz * dx - zx * dz;
+            vz = zx * dy - zy * dx;
+            wx = zx; wy = zy; wz = zz;
+        } else {
+            vx = zx; vy = zy; vz = zz;
+            wx = 0.0; wy = 0.0; wz = 0.0;
+        }
+        if (ops[i].flip) {  // methods.cpp:142-145,172-175
+            vx = -vx; vy = -vy; vz = -vz;
+            wx = -wx; wy = -wy; wz = -wz;
+        }
+        if (frame == 1) {
+            double a = vx, b = vy, c = vz;
+            vx = P.r00 * a + P.r10 * b + P.r20 * c;
+            vy = P.r01 * a + P.r11 * b + P.r21 * c;
+            vz = P.r02 * a + P.r12 * b + P.r22 * c;
+            a = wx; b = wy; c = wz;
+            wx = P.r00 * a + P.r10 * b + P.r20 * c;
+            wy = P.r01 * a + P.r11 * b + P.r21 * c;
+            wz = P.r02 * a + P.r12 * b + P.r22 * c;
+        }
+        put(j, vx); put(n + j, vy); put(2 * n + j, vz);
+        put(3 * n + j, wx); put(4 * n + j, wy); put(5 * n + j, wz);
+    }
+}
+
+// Writes the 4x4 (row-major, 16 doubles) of pose P through put(k, v), k = 0..15.
+template <class Put>
+RTB_HD void pose_store16(const Pose &P, Put put)
+{
+    put(0, P.r00); put(1, P.r01); put(2, P.r02); put(3, P.tx);
+    put(4, P.r10); put(5, P.r11); put(6, P.r12); put(7, P.ty);
+    put(8, P.r20); put(9, P.r21); put(10, P.r22); put(11, P.tz);
+    put(12, 0.0); put(13, 0.0); put(14, 0.0); put(15, 1.0);
+}
+
+// One (j, i>=j) block of the Hessian from a finished Jacobian in per-lane scratch
+// (methods.cpp:16-32):  H[j,0:3,i] = Jw_j x Jv_i ; H[j,3:6,i] = Jw_j x Jw_i ; mirrored for i != j.
+template <class Get, class Put>
+RTB_HD void hessian_from_jacobian(int n, Get get, Put put /* put(index into n*6*n, v) */)
+{
+    for (int j = 0; j < n; ++j) {
+        const double wjx = get(3 * n + j), wjy = get(4 * n + j), wjz = get(5 * n + j);
+        for (int i = j; i < n; ++i) {
+            const double vx = get(i), vy = get(n + i), vz = get(2 * n + i);
+            const double wx = get(3 * n + i), wy = get(4 * n + i), wz = get(5 * n + i);
+            const double ax = wjy * vz - wjz * vy, ay = wjz * vx - wjx * vz, az = wjx * vy - wjy * vx;
+            const double bx = wjy * wz - wjz * wy, by = wjz * wx - wjx * wz, bz = wjx * wy - wjy * wx;
+            put((j * 6 + 0) * n + i, ax); put((j * 6 + 1) * n + i, ay); put((j * 6 + 2) * n + i, az);
+            put((j * 6 + 3) * n + i, bx); put((j * 6 + 4) * n + i, by); put((j * 6 + 5) * n + i, bz);
+            if (i != j) {
+                put((i * 6 + 0) * n + j, ax); put((i * 6 + 1) * n + j, ay); put((i * 6 + 2) * n + j, az);
+                put((i * 6 + 3) * n + j, 0.0); put((i * 6 + 4) * n + j, 0.0); put((i * 6 + 5) * n + j, 0.0);
+            }
+        }
+    }
+}
+
+}  // namespace rtbhip

@@ -1,0 +1,211 @@
+// kin_kernels.hip -- gfx950 kernels for batched fkine / jacob0 / jacobe / hessian (headline path).
+//
+// Replaces the hot loops of core/fknm.cpp:1038-1052 (ETS_fkine trajectory loop) and the Python
+// per-row loops around ETS_jacob0/ETS_jacobe/ETS_hessian0 (fknm.cpp:583-921).
+//
+// Launch shape: one wavefront (64 lanes) per workgroup, one configuration per lane, grid-stride
+// over 64-configuration tiles.  Single-wave workgroups make every LDS hand-off wave-private (the
+// s_barrier of a one-wave group is free) and let the dispatcher balance tiles across the 256 CUs.
+// The chain program is read through the constant address space => s_load into SGPRs.
+// Roofline: HBM-bound by construction -- 8*qw bytes in, 128 + 48n bytes out per configuration
+// (520 B for the Panda), ~0.6 kflop of fp64 VALU + n sincos per configuration.
+#include "kin_tile.h"
+#include <algorithm>
+#include <cstring>
+
+namespace rtbhip {
+
+typedef const __attribute__((address_space(4))) DevOp *ConstOps;
+
+template <bool WANT_T, bool WANT_J, bool WANT_H, bool COALESCED>
+__global__ __launch_bounds__(kWave) void k_kin(KinParams kp, const DevOp *ops_g,
+                                              const double *__restrict__ q, double *__restrict__ T,
+                                              double *__restrict__ J, double *__restrict__ H)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *rows = lds;
+    double *qs = lds + kWave * kp.stride;
+    ConstOps ops = (ConstOps)ops_g;
+    const int lane = threadIdx.x;
+    const int64_t tiles = (kp.N + kWave - 1) / kWave;
+    const int W = 6 * kp.n;
+
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t cfg0 = tile * kWave;
+        const int64_t cfg = cfg0 + lane;
+        const int64_t left = kp.N - cfg0;
+        const int ncfg = left < kWave ? (int)left : kWave;
+        const bool live = lane < ncfg;
+
+        kin_load_q(kp, q, cfg, lane, qs);
+        Pose P;
+        kin_walk<(WANT_J || WANT_H)>(kp, ops, lane, qs, rows, P);
+        if (WANT_H) kin_hessian(kp, lane, rows, live, H + cfg * (int64_t)(kp.n * W));
+        if (WANT_J) {
+            if (COALESCED) {
+                __syncthreads();
+                kin_flush(rows, kp.stride, W, ncfg, J + cfg0 * W, lane);
+            } else {
+                kin_store_own(rows, kp.stride, W, live, J + cfg * W, lane);
+            }
+        }
+        if (WANT_T) {
+            if (COALESCED) __syncthreads();
+            kin_stage_T(kp, lane, rows, P);
+            if (COALESCED) {
+                __syncthreads();
+                kin_flush(rows, kp.stride, 16, ncfg, T + cfg0 * 16, lane);
+            } else {
+                kin_store_own(rows, kp.stride, 16, live, T + cfg * 16, lane);
+            }
+        }
+        __syncthreads();  // rows/qs are rewritten by the next tile
+    }
+}
+
+namespace {
+int g_coalesced = 1;   // tuning knobs (rtbhip_tune)
+int g_tiles_per_wave = 1;
+}  // namespace
+
+void kin_tune(const char *key, int value)
+{
+    std::string k(key);
+    if (k == "coalesced") g_coalesced = value;
+    if (k == "tiles_per_wave") g_tiles_per_wave = value < 1 ? 1 : value;
+}
+
+template <bool WT, bool WJ, bool WH>
+static hipError_t launch_variant(bool coalesced, dim3 grid, size_t lds, hipStream_t s, const KinParams &kp,
+                                 const DevOp *ops, const double *q, double *T, double *J, double *H)
+{
+    if (coalesced) {
+        auto k = k_kin<WT, WJ, WH, true>;
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(k, grid, dim3(kWave), lds, s, kp, ops, q, T, J, H);
+    } else {
+        auto k = k_kin<WT, WJ, WH, false>;
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(k, grid, dim3(kWave), lds, s, kp, ops, q, T, J, H);
+    }
+    return hipGetLastError();
+}
+
+int launch_kin(const Chain *c, const DevOp *ops, const double *q, int64_t N, const Affine &base,
+               const Affine &tool, int frame, double *T, double *J, double *H, hipStream_t s)
+{
+    if (N == 0) return RTBHIP_OK;
+    KinParams kp;
+    kp.m = (int)c->ops.size();
+    kp.n = c->n;
+    kp.qw = c->q_width;
+    kp.stride = kin_stride(c->n);
+    kp.frame = frame;
+    kp.has_base = base.used;
+    kp.has_tool = tool.used;
+    kp.pad = 0;
+    kp.N = N;
+    for (int i = 0; i < 12; i++) { kp.base[i] = base.v[i]; kp.tool[i] = tool.v[i]; }
+    const size_t lds = kin_lds_bytes(c->n, c->q_width);
+    if (lds > 160 * 1024) { set_error("chain too large for the per-wave LDS staging"); return RTBHIP_ELIMIT; }
+    const int64_t tiles = (N + kWave - 1) / kWave;
+    int64_t g = (tiles + g_tiles_per_wave - 1) / g_tiles_per_wave;
+    if (g > 0x7fffffff) g = 0x7fffffff;
+    dim3 grid((unsigned)g);
+    const bool co = g_coalesced != 0;
+    hipError_t e;
+    const bool wt = T != nullptr, wj = J != nullptr, wh = H != nullptr;
+    if (wt && wj && !wh) e = launch_variant<true, true, false>(co, grid, lds, s, kp, ops, q, T, J, H);
+    else if (wt && !wj && !wh) e = launch_variant<true, false, false>(co, grid, lds, s, kp, ops, q, T, J, H);
+    else if (!wt && wj && !wh) e = launch_variant<false, true, false>(co, grid, lds, s, kp, ops, q, T, J, H);
+    else if (!wt && !wj && wh) e = launch_variant<false, false, true>(co, grid, lds, s, kp, ops, q, T, J, H);
+    else if (wt && wj && wh) e = launch_variant<true, true, true>(co, grid, lds, s, kp, ops, q, T, J, H);
+    else { set_error("launch_kin: unsupported output combination"); return RTBHIP_EINVAL; }
+    note_launch((int)grid.x, kWave, (int)lds);
+    if (e != hipSuccess) return hip_fail(e, "k_kin launch");
+    return RTBHIP_OK;
+}
+
+// ---------------------------------------------------------------- mixed fleet (BASELINE config 5)
+// One launch walks up to kFleetMax different chains, each with its own batch: the global tile index
+// is mapped to (chain, local tile) by a scan over the per-chain first-tile table (wave-uniform, in
+// kernarg => SGPRs); chain length, joint count and LDS row stride are then run-time values of that
+// block.  Same phases as k_kin.
+constexpr int kFleetMax = 32;
+struct FleetArgs {
+    FleetEntry e[kFleetMax];
+    int32_t count, frame;
+    int64_t tiles;
+};
+
+__global__ __launch_bounds__(kWave) void k_fleet(FleetArgs fa)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x;
+    for (int64_t gt = blockIdx.x; gt < fa.tiles; gt += gridDim.x) {
+        int ci = 0;
+        for (int i = 1; i < fa.count; ++i)
+            if (gt >= fa.e[i].tile0) ci = i;
+        const FleetEntry &fe = fa.e[ci];
+        KinParams kp;
+        kp.m = fe.m; kp.n = fe.n; kp.qw = fe.q_width; kp.stride = fe.stride;
+        kp.frame = fa.frame; kp.has_base = 0; kp.has_tool = 0; kp.pad = 0; kp.N = fe.N;
+        double *rows = lds;
+        double *qs = lds + kWave * kp.stride;
+        ConstOps ops = (ConstOps)fe.ops;
+        const int64_t tile = gt - fe.tile0;
+        const int64_t cfg0 = tile * kWave, cfg = cfg0 + lane;
+        const int64_t left = kp.N - cfg0;
+        const int ncfg = left < kWave ? (int)left : kWave;
+        const int W = 6 * kp.n;
+        kin_load_q(kp, fe.q, cfg, lane, qs);
+        Pose P;
+        kin_walk<true>(kp, ops, lane, qs, rows, P);
+        __syncthreads();
+        kin_flush(rows, kp.stride, W, ncfg, fe.J + cfg0 * W, lane);
+        __syncthreads();
+        kin_stage_T(kp, lane, rows, P);
+        __syncthreads();
+        kin_flush(rows, kp.stride, 16, ncfg, fe.T + cfg0 * 16, lane);
+        __syncthreads();
+    }
+}
+
+int launch_fleet(const std::vector<FleetEntry> &entries, int frame, hipStream_t s)
+{
+    for (size_t first = 0; first < entries.size(); first += kFleetMax) {
+        FleetArgs fa;
+        std::memset(&fa, 0, sizeof fa);
+        fa.count = (int)std::min<size_t>(kFleetMax, entries.size() - first);
+        fa.frame = frame;
+        size_t lds = 0;
+        int64_t tiles = 0;
+        for (int i = 0; i < fa.count; i++) {
+            fa.e[i] = entries[first + i];
+            fa.e[i].stride = kin_stride(fa.e[i].n);
+            fa.e[i].tile0 = tiles;
+            tiles += (fa.e[i].N + kWave - 1) / kWave;
+            lds = std::max(lds, kin_lds_bytes(fa.e[i].n, fa.e[i].q_width));
+        }
+        fa.tiles = tiles;
+        if (lds > 160 * 1024) { set_error("fleet: chain too large for LDS staging"); return RTBHIP_ELIMIT; }
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)k_fleet, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return hip_fail(e, "k_fleet attr");
+        }
+        int64_t g = tiles > 0x7fffffff ? 0x7fffffff : tiles;
+        hipLaunchKernelGGL(k_fleet, dim3((unsigned)g), dim3(kWave), lds, s, fa);
+        note_launch((int)g, kWave, (int)lds);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "k_fleet launch");
+    }
+    return RTBHIP_OK;
+}
+
+}  // namespace rtbhip

@@ -1,0 +1,124 @@
+// kin_tile.h -- the per-tile phases of the fused fkine + Jacobian (+ Hessian) kernel.
+//
+// A tile is 64 consecutive configurations = one wavefront; lane l owns configuration cfg0 + l.
+// LDS (per wave, private -- no inter-wave traffic):
+//     rows : 64 x stride doubles, lane-major ("AoS"): rows[l*stride + slot].  stride is odd, so the
+//            lane stride in dwords is 2 (mod 4): ds_write_b64 (16-lane groups, 32 banks) and
+//            ds_read_b64 (32-lane groups, 64 banks) are conflict-free for per-lane access.
+//            Holds the Jacobian scratch (p_j, z_j), then the finished J, then (re-used) the 4x4.
+//     qs   : qw x 64 doubles, column-major ("SoA"): qs[c*64 + l].
+// Why LDS at all: the outputs are (N,4,4) and (N,6,n) row-major, i.e. 128 B and 48n B contiguous
+// PER CONFIGURATION.  A lane-per-configuration store would scatter 16 B pieces at a 336 B stride;
+// staging the wave's outputs in LDS lets the wave write its 64 x 336 B = 21 KB of J (and 8 KB of T)
+// as one contiguous run, 16 B per lane per instruction -- the fully coalesced pattern.
+//
+// Every phase is a __host__ __device__ function of (lane, LDS pointers): the GPU kernel calls them
+// with lane = threadIdx.x between s_barriers; tests/emu calls them in a loop over lanes on the CPU.
+#pragma once
+#include "kin_device.h"
+
+namespace rtbhip {
+
+struct KinParams {
+    int32_t m, n, qw, stride;
+    int32_t frame, has_base, has_tool, pad;
+    int64_t N;
+    double base[12];
+    double tool[12];
+};
+
+RTB_HD int kin_stride(int n)
+{
+    int s = 6 * n;
+    if (s < 16) s = 16;
+    return s + 1;  // odd
+}
+RTB_HD size_t kin_lds_bytes(int n, int qw) { return (size_t)kWave * (kin_stride(n) + qw) * sizeof(double); }
+
+// phase A: this lane's joint coordinates -> qs (zero for lanes past the end of the batch)
+RTB_HD void kin_load_q(const KinParams &kp, const double *__restrict__ q, int64_t cfg, int lane,
+                       double *qs)
+{
+    const bool live = cfg < kp.N;
+    const double *src = q + cfg * kp.qw;
+    int c = 0;
+    for (; c + 4 <= kp.qw; c += 4) {  // 4 independent loads in flight before the first LDS write
+        double a0 = live ? src[c] : 0.0, a1 = live ? src[c + 1] : 0.0;
+        double a2 = live ? src[c + 2] : 0.0, a3 = live ? src[c + 3] : 0.0;
+        qs[(c + 0) * kWave + lane] = a0;
+        qs[(c + 1) * kWave + lane] = a1;
+        qs[(c + 2) * kWave + lane] = a2;
+        qs[(c + 3) * kWave + lane] = a3;
+    }
+    for (; c < kp.qw; ++c) qs[c * kWave + lane] = live ? src[c] : 0.0;
+}
+
+// phase B: walk the chain, leave the pose in P (tool applied) and the finished J in rows.
+template <bool WANT_J, class OpsP>
+RTB_HD void kin_walk(const KinParams &kp, OpsP ops, int lane, const double *qs, double *rows, Pose &P)
+{
+    double *mine = rows + lane * kp.stride;
+    pose_identity(P);
+    chain_walk<WANT_J>(ops, kp.m, kp.n, P,
+                       [&](int c) { return qs[c * kWave + lane]; },
+                       [&](int slot, double v) { mine[slot] = v; });
+    if (kp.has_tool) pose_mul_general(P, [&](int k) { return kp.tool[(k < 9) ? (k / 3) * 4 + k % 3 : (k - 9) * 4 + 3]; });
+    if (WANT_J)
+        jacobian_close(ops, kp.m, kp.n, P, kp.frame, [&](int s) { return mine[s]; },
+                       [&](int s, double v) { mine[s] = v; });
+}
+
+// phase D: this lane's 4x4 into rows (after the J flush; the region is re-used)
+RTB_HD void kin_stage_T(const KinParams &kp, int lane, double *rows, Pose P)
+{
+    if (kp.has_base) pose_premul(P, kp.base);
+    double *mine = rows + lane * kp.stride;
+    pose_store16(P, [&](int k, double v) { mine[k] = v; });
+}
+
+// phases C / E: the wave writes `ncfg` staged rows of W doubles (W even) as one contiguous run.
+// Lane l writes the 16-byte pieces l, l+64, l+128, ... of the run; (cfg, e) tracks which staged
+// row / element piece f falls in without a division per piece.
+RTB_HD void kin_flush(const double *rows, int stride, int W, int ncfg, double *__restrict__ dst,
+                      int lane)
+{
+    const int total = ncfg * W;
+    int f = 2 * lane;
+    int cfg = f / W, e = f - cfg * W;
+    const int da = 128 / W, db = 128 - da * W;
+    for (; f < total; f += 128) {
+        const double *src = rows + cfg * stride + e;
+        double2 v;
+        v.x = src[0];
+        v.y = src[1];
+        *reinterpret_cast<double2 *>(dst + f) = v;
+        e += db;
+        cfg += da;
+        if (e >= W) { e -= W; cfg += 1; }
+    }
+}
+
+// un-coalesced alternative (A/B baseline): every lane stores its own row straight from LDS
+RTB_HD void kin_store_own(const double *rows, int stride, int W, bool live, double *__restrict__ dst_row,
+                          int lane)
+{
+    if (!live) return;
+    const double *mine = rows + lane * stride;
+    for (int e = 0; e < W; e += 2) {
+        double2 v;
+        v.x = mine[e];
+        v.y = mine[e + 1];
+        *reinterpret_cast<double2 *>(dst_row + e) = v;
+    }
+}
+
+// Hessian epilogue: straight from the finished J in rows to this lane's (n,6,n) block.
+RTB_HD void kin_hessian(const KinParams &kp, int lane, const double *rows, bool live,
+                        double *__restrict__ Hrow)
+{
+    if (!live) return;
+    const double *mine = rows + lane * kp.stride;
+    hessian_from_jacobian(kp.n, [&](int s) { return mine[s]; }, [&](int idx, double v) { Hrow[idx] = v; });
+}
+
+}  // namespace rtbhip

@@ -1,0 +1,141 @@
+// rne_kernels.hip -- gfx950 kernel for batched inverse dynamics of DH / MDH chains.
+// Replaces the Python per-row loop of DHRobot.rne (robot/DHRobot.py:1442-1451) around frne.frne
+// (core/frne.c:106-230) -> newton_euler (core/ne.c:62-493).
+//
+// One lane = one (q, qd, qdd) sample; both Newton-Euler recursions fused in registers (rne_device.h).
+// I/O per sample: 3*8n bytes in, 8n bytes out (224 B for the 7-DOF Panda) against ~2.2 kflop + n
+// sincos of fp64 VALU: the HBM and fp64-issue roofs are within 2x of each other for this kernel.
+// The wave's (64 x n) input tiles are contiguous in memory; they are fetched with fully coalesced
+// 8-byte-per-lane loads into a lane-major LDS tile (odd row stride => conflict-free) and the torques
+// leave the same way.
+#include "rne_device.h"
+
+namespace rtbhip {
+
+typedef const __attribute__((address_space(4))) DevLink *ConstLinks;
+constexpr int kW = 64;
+
+struct RneParams {
+    int32_t n, has_fext;
+    int64_t N;
+    double grav[3];
+    double fext[6];
+};
+
+__device__ __forceinline__ int rne_stride(int n) { int s = 3 * n; return (s & 1) ? s : s + 1; }
+
+// coalesced copy of `count` doubles between a contiguous global run and lane-major LDS rows
+// (row = element index / n, col = element % n, placed at rows[row*stride + col_off + col]).
+template <bool TO_LDS>
+__device__ __forceinline__ void tile_copy(double *rows, int stride, int col_off, int n, int count,
+                                          const double *__restrict__ gsrc, double *__restrict__ gdst, int lane)
+{
+    int f = lane;
+    int r = f / n, c = f - r * n;
+    const int da = kW / n, db = kW - da * n;
+    for (; f < count; f += kW) {
+        if (TO_LDS) rows[r * stride + col_off + c] = gsrc[f];
+        else gdst[f] = rows[r * stride + col_off + c];
+        c += db; r += da;
+        if (c >= n) { c -= n; r += 1; }
+    }
+}
+
+template <int NJ, bool MDH>
+__global__ __launch_bounds__(kW) void k_rne(RneParams rp, const DevLink *links_g, const double *__restrict__ q,
+                                           const double *__restrict__ qd, const double *__restrict__ qdd,
+                                           double *__restrict__ tau)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    ConstLinks links = (ConstLinks)links_g;
+    const int lane = threadIdx.x;
+    const int n = NJ > 0 ? NJ : rp.n;
+    const int stride = rne_stride(n);
+    const int64_t tiles = (rp.N + kW - 1) / kW;
+    const V3 grav = v3(rp.grav[0], rp.grav[1], rp.grav[2]);
+    const V3 ftip = rp.has_fext ? v3(rp.fext[0], rp.fext[1], rp.fext[2]) : v3(0, 0, 0);
+    const V3 ntip = rp.has_fext ? v3(rp.fext[3], rp.fext[4], rp.fext[5]) : v3(0, 0, 0);
+    double *mine = lds + lane * stride;
+
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t cfg0 = tile * kW;
+        const int64_t left = rp.N - cfg0;
+        const int ncfg = left < kW ? (int)left : kW;
+        const int count = ncfg * n;
+        tile_copy<true>(lds, stride, 0, n, count, q + cfg0 * n, nullptr, lane);
+        tile_copy<true>(lds, stride, n, n, count, qd + cfg0 * n, nullptr, lane);
+        tile_copy<true>(lds, stride, 2 * n, n, count, qdd + cfg0 * n, nullptr, lane);
+        __syncthreads();
+        if (lane < ncfg) {
+            if (NJ > 0) {
+                constexpr int C = NJ > 0 ? NJ : 1;
+                double rq[C], rqd[C], rqdd[C], rt[C];
+#pragma unroll
+                for (int j = 0; j < C; ++j) { rq[j] = mine[j]; rqd[j] = mine[n + j]; rqdd[j] = mine[2 * n + j]; }
+                rne_lane<NJ, MDH>(links, n, grav, ftip, ntip, [&](int j) { return rq[j]; }, [&](int j) { return rqd[j]; },
+                                  [&](int j) { return rqdd[j]; }, [&](int j, double v) { rt[j] = v; });
+#pragma unroll
+                for (int j = 0; j < C; ++j) mine[j] = rt[j];
+            } else {
+                // run-time n: torques overwrite the q slots only after q is dead (q is read in the
+                // forward pass only), qd/qdd stay readable for the projection.
+                rne_lane<0, MDH>(links, n, grav, ftip, ntip, [&](int j) { return mine[j]; }, [&](int j) { return mine[n + j]; },
+                                 [&](int j) { return mine[2 * n + j]; }, [&](int j, double v) { mine[j] = v; });
+            }
+        }
+        __syncthreads();
+        tile_copy<false>(lds, stride, 0, n, count, nullptr, tau + cfg0 * n, lane);
+        __syncthreads();
+    }
+}
+
+namespace { int g_rne_tiles_per_wave = 1; }
+void rne_tune(const char *key, int value)
+{
+    if (std::string(key) == "rne_tiles_per_wave") g_rne_tiles_per_wave = value < 1 ? 1 : value;
+}
+
+template <int NJ>
+static void launch_nj(bool mdh, dim3 grid, size_t lds, hipStream_t s, const RneParams &rp, const DevLink *links,
+                      const double *q, const double *qd, const double *qdd, double *tau)
+{
+    if (mdh) hipLaunchKernelGGL((k_rne<NJ, true>), grid, dim3(kW), lds, s, rp, links, q, qd, qdd, tau);
+    else hipLaunchKernelGGL((k_rne<NJ, false>), grid, dim3(kW), lds, s, rp, links, q, qd, qdd, tau);
+}
+
+int launch_rne(const Dyn *d, const DevLink *links, const double *q, const double *qd, const double *qdd,
+               int64_t N, const double *grav3, const double *fext6, double *tau, hipStream_t s)
+{
+    if (N == 0) return RTBHIP_OK;
+    RneParams rp;
+    rp.n = d->n;
+    rp.has_fext = fext6 != nullptr;
+    rp.N = N;
+    for (int i = 0; i < 3; i++) rp.grav[i] = grav3[i];
+    for (int i = 0; i < 6; i++) rp.fext[i] = fext6 ? fext6[i] : 0.0;
+    int stride = 3 * d->n;
+    if (!(stride & 1)) stride += 1;
+    const size_t lds = (size_t)kW * stride * sizeof(double);
+    const int64_t tiles = (N + kW - 1) / kW;
+    int64_t g = (tiles + g_rne_tiles_per_wave - 1) / g_rne_tiles_per_wave;
+    if (g > 0x7fffffff) g = 0x7fffffff;
+    dim3 grid((unsigned)g);
+    const bool mdh = d->mdh != 0;
+    switch (d->n) {
+    case 1: launch_nj<1>(mdh, grid, lds, s, rp, links, q, qd, qdd, tau); break;
+    case 2: launch_nj<2>(mdh, grid, lds, s, rp, links, q, qd, qdd, tau); break;
+    case 3: launch_nj<3>(mdh, grid, lds, s, rp, links, q, qd, qdd, tau); break;
+    case 4: launch_nj<4>(mdh, grid, lds, s, rp, links, q, qd, qdd, tau); break;
+    case 5: launch_nj<5>(mdh, grid, lds, s, rp, links, q, qd, qdd, tau); break;
+    case 6: launch_nj<6>(mdh, grid, lds, s, rp, links, q, qd, qdd, tau); break;
+    case 7: launch_nj<7>(mdh, grid, lds, s, rp, links, q, qd, qdd, tau); break;
+    case 8: launch_nj<8>(mdh, grid, lds, s, rp, links, q, qd, qdd, tau); break;
+    default: launch_nj<0>(mdh, grid, lds, s, rp, links, q, qd, qdd, tau); break;
+    }
+    note_launch((int)grid.x, kW, (int)lds);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "k_rne launch");
+    return RTBHIP_OK;
+}
+
+}  // namespace rtbhip

@@ -1,0 +1,146 @@
+"""ctypes binding of librtbhip.so (the C ABI declared in include/rtbhip.h).
+
+This is the stub a reference maintainer would add next to ``from roboticstoolbox.fknm import ...``
+(reference robot/ETS.py:28-38): same roles, but a C ABI instead of a CPython extension module.
+The library is mandatory: there is NO CPU fallback in this package -- every compute entry point
+raises if the HIP library is missing or no GPU is visible.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "librtbhip.so")
+
+MEM_HOST, MEM_DEVICE = 0, 1
+ET_CONST = 6
+
+
+class RtbHipError(RuntimeError):
+    pass
+
+
+class rtbhip_et(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("flip", C.c_int32), ("jindex", C.c_int32),
+                ("reserved", C.c_int32), ("T", C.c_double * 16)]
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_vp = C.c_void_p
+_i64 = C.c_int64
+_u64 = C.c_uint64
+_i32 = C.c_int32
+
+# name -> (restype, argtypes); must list every symbol include/rtbhip.h declares
+SIGNATURES = {
+    "rtbhip_last_error": (C.c_char_p, []),
+    "rtbhip_version": (C.c_int, []),
+    "rtbhip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "rtbhip_chain_create": (C.c_int, [C.POINTER(rtbhip_et), _i32, _vp, C.POINTER(_u64)]),
+    "rtbhip_chain_destroy": (C.c_int, [_u64]),
+    "rtbhip_chain_info": (C.c_int, [_u64, _ip, _ip, _ip]),
+    "rtbhip_fkine": (C.c_int, [_u64, _vp, _i64, _vp, _vp, _vp, _i32, _vp]),
+    "rtbhip_jacob": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _vp, _i32, _vp]),
+    "rtbhip_fkine_jacob": (C.c_int, [_u64, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
+    "rtbhip_hessian": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _vp, _i32, _vp]),
+    "rtbhip_ik_lm": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _i32, C.c_double, _i32, _vp, C.c_double,
+                               _i32, _i32, _u64, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "rtbhip_ik_restart": (C.c_int, [_u64, _u64, _i64, _i32, _vp]),
+    "rtbhip_dyn_create": (C.c_int, [_vp, _i32, _i32, C.POINTER(_u64)]),
+    "rtbhip_dyn_destroy": (C.c_int, [_u64]),
+    "rtbhip_rne": (C.c_int, [_u64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp]),
+    "rtbhip_fleet_fkine_jacob": (C.c_int, [C.POINTER(_u64), _i32, C.POINTER(_vp), C.POINTER(_i64), _i32,
+                                           C.POINTER(_vp), C.POINTER(_vp), _i32, _vp]),
+    "rtbhip_shard_range": (C.c_int, [_i64, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
+    "rtbhip_last_launch": (C.c_int, [_ip, _ip, _ip]),
+    "rtbhip_tune": (C.c_int, [C.c_char_p, _i32]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises RtbHipError (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RtbHipError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950); this package has no CPU fallback" % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().rtbhip_last_error()
+        raise RtbHipError("librtbhip error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().rtbhip_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def tune(key, value):
+    check(lib().rtbhip_tune(key.encode(), int(value)))
+
+
+def last_launch():
+    g, b, l = _i32(0), _i32(0), _i32(0)
+    lib().rtbhip_last_launch(C.byref(g), C.byref(b), C.byref(l))
+    return g.value, b.value, l.value
+
+
+def shard_range(N, rank, world):
+    b, c = _i64(0), _i64(0)
+    check(lib().rtbhip_shard_range(int(N), int(rank), int(world), C.byref(b), C.byref(c)))
+    return b.value, c.value
+
+
+# ---------------------------------------------------------------- buffer plumbing
+def is_torch(x):
+    return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
+
+
+def host_ptr(a):
+    """void* of a C-contiguous float64 / int32 ndarray (or None)."""
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def small(a, n):
+    """Host-side small parameter (base/tool/gravity/...) -> contiguous float64 array of n elements."""
+    if a is None:
+        return None
+    if is_torch(a):
+        a = a.detach().cpu().numpy()
+    if hasattr(a, "A") and not isinstance(a, np.ndarray):  # spatialmath SE3-like
+        a = a.A
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64)).reshape(-1)
+    if a.size != n:
+        raise ValueError("expected %d values, got %d" % (n, a.size))
+    return a
+
+
+def as_numeric(x, what="q"):
+    """ndarray(float64) from array-like; TypeError for symbolic/object input -- the reference's
+    control-flow signal (core/fknm.cpp:1304-1318 `_check_array_type`, "Symbolic value")."""
+    try:
+        a = np.asarray(x)
+    except Exception:
+        raise TypeError("Symbolic value")
+    if a.dtype == object or a.dtype.kind not in "fiub":
+        raise TypeError("Symbolic value")
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def current_stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

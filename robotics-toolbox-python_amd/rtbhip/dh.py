@@ -1,0 +1,241 @@
+"""DH robots: the drop-in surface for ``DHRobot.fkine / jacob0 / jacobe / rne``.
+
+Mirrors reference robot/DHLink.py (RevoluteDH, PrismaticDH, RevoluteMDH, PrismaticMDH; `_to_ets`
+:173-225) and robot/DHRobot.py (`ets` :878-918, `fkine` :920-979, `_init_rne` :1340-1361,
+`rne` :1373-1456, `delete_rne` :1363-1371).  Kinematics run through the ETS lowering on the GPU;
+inverse dynamics through rtbhip_rne.  No CPU arithmetic path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib, as_numeric, host_ptr, is_torch, MEM_HOST, MEM_DEVICE
+from .et import ET, ETS
+
+
+class DHLink:
+    def __init__(self, d=0.0, alpha=0.0, theta=0.0, a=0.0, sigma=0, mdh=False, offset=0.0, flip=False,
+                 qlim=None, m=0.0, r=None, I=None, Jm=0.0, G=0.0, B=0.0, Tc=None, **kw):
+        self.d, self.alpha, self.theta, self.a = float(d), float(alpha), float(theta), float(a)
+        self.sigma, self.mdh, self.offset, self.flip = int(sigma), bool(mdh), float(offset), bool(flip)
+        self.qlim = None if qlim is None else np.asarray(qlim, dtype=np.float64).reshape(2)
+        self.m = float(m)
+        self.r = np.zeros(3) if r is None else np.asarray(r, dtype=np.float64).reshape(3)
+        self.I = self._inertia(I)
+        self.Jm, self.G, self.B = float(Jm), float(G), float(B)
+        self.Tc = np.zeros(2) if Tc is None else np.asarray(Tc, dtype=np.float64).reshape(2)
+
+    @staticmethod
+    def _inertia(I):
+        """3x3 from (3,3) / 9 / 6 = [Ixx Iyy Izz Ixy Iyz Ixz] / 3 (reference robot/Link.py:719-751)."""
+        if I is None:
+            return np.zeros((3, 3))
+        I = np.asarray(I, dtype=np.float64)
+        if I.shape == (3, 3):
+            M = I
+        elif I.size == 9:
+            M = I.reshape(3, 3)
+        elif I.size == 6:
+            M = np.array([[I[0], I[3], I[5]], [I[3], I[1], I[4]], [I[5], I[4], I[2]]])
+        elif I.size == 3:
+            M = np.diag(I)
+        else:
+            raise ValueError("invalid shape passed: must be (3,3), (6,), (3,)")
+        if np.any(np.abs(M - M.T) > 1e-8):
+            raise ValueError("3x3 matrix is not symmetric")
+        return M.copy()
+
+    @property
+    def isrevolute(self): return self.sigma == 0
+    @property
+    def isprismatic(self): return self.sigma == 1
+
+    def ets(self):
+        """DH -> elementary transforms, same sequence as reference robot/DHLink.py:173-225."""
+        out = []
+        a, al, th, d, off, fl = self.a, self.alpha, self.theta, self.d, self.offset, self.flip
+        if self.mdh:
+            if a != 0: out.append(ET.tx(a))
+            if al != 0: out.append(ET.Rx(al))
+            if self.isrevolute:
+                if off != 0: out.append(ET.Rz(off))
+                if d != 0: out.append(ET.tz(d))
+                out.append(ET.Rz(flip=fl, qlim=self.qlim))
+            else:
+                if th != 0: out.append(ET.Rz(th))
+                if off != 0: out.append(ET.tz(off))
+                out.append(ET.tz(flip=fl, qlim=self.qlim))
+        else:
+            if self.isrevolute:
+                if off != 0: out.append(ET.Rz(off))
+                out.append(ET.Rz(flip=fl, qlim=self.qlim))
+                if d != 0: out.append(ET.tz(d))
+            else:
+                if th != 0: out.append(ET.Rz(th))
+                if off != 0: out.append(ET.tz(off))
+                out.append(ET.tz(flip=fl, qlim=self.qlim))
+            if a != 0: out.append(ET.tx(a))
+            if al != 0: out.append(ET.Rx(al))
+        return ETS(out)
+
+
+class RevoluteDH(DHLink):
+    def __init__(self, d=0.0, a=0.0, alpha=0.0, offset=0.0, qlim=None, flip=False, **kw):
+        super().__init__(d=d, a=a, alpha=alpha, theta=0.0, sigma=0, mdh=False, offset=offset, qlim=qlim, flip=flip, **kw)
+
+
+class PrismaticDH(DHLink):
+    def __init__(self, theta=0.0, a=0.0, alpha=0.0, offset=0.0, qlim=None, flip=False, **kw):
+        super().__init__(theta=theta, a=a, alpha=alpha, d=0.0, sigma=1, mdh=False, offset=offset, qlim=qlim, flip=flip, **kw)
+
+
+class RevoluteMDH(DHLink):
+    def __init__(self, d=0.0, a=0.0, alpha=0.0, offset=0.0, qlim=None, flip=False, **kw):
+        super().__init__(d=d, a=a, alpha=alpha, theta=0.0, sigma=0, mdh=True, offset=offset, qlim=qlim, flip=flip, **kw)
+
+
+class PrismaticMDH(DHLink):
+    def __init__(self, theta=0.0, a=0.0, alpha=0.0, offset=0.0, qlim=None, flip=False, **kw):
+        super().__init__(theta=theta, a=a, alpha=alpha, d=0.0, sigma=1, mdh=True, offset=offset, qlim=qlim, flip=flip, **kw)
+
+
+def _mat4(T):
+    if T is None:
+        return None
+    if hasattr(T, "A") and not isinstance(T, np.ndarray):
+        T = T.A
+    T = np.asarray(T, dtype=np.float64)
+    if T.shape != (4, 4):
+        raise ValueError("expected a 4x4 transform")
+    return T.copy()
+
+
+class DHRobot:
+    def __init__(self, links, name="", manufacturer="", base=None, tool=None, gravity=None, **kw):
+        self.links = list(links)
+        if not self.links:
+            raise ValueError("no links")
+        if len({l.mdh for l in self.links}) != 1:
+            raise ValueError("Robot has mixed D&H links conventions")  # reference robot/DHRobot.py:90-112
+        self.name, self.manufacturer = name, manufacturer
+        self.base = _mat4(base)
+        self.tool = _mat4(tool)
+        self.gravity = np.array([0.0, 0.0, -9.81]) if gravity is None else np.asarray(gravity, dtype=np.float64).reshape(3)
+        self._ets = None
+        self._dyn = None
+
+    def __len__(self): return len(self.links)
+    def __iter__(self): return iter(self.links)
+    def __getitem__(self, i): return self.links[i]
+
+    @property
+    def n(self): return len(self.links)
+    @property
+    def mdh(self): return int(self.links[0].mdh)
+
+    @property
+    def qlim(self):
+        lo, hi = [], []
+        for l in self.links:
+            if l.qlim is not None:
+                lo.append(l.qlim[0]); hi.append(l.qlim[1])
+            elif l.isrevolute:
+                lo.append(-np.pi); hi.append(np.pi)
+            else:
+                lo.append(0.0); hi.append(1.0)
+        return np.array([lo, hi])
+
+    def ets(self):
+        """reference robot/DHRobot.py:878-918 (base / tool become constant SE3 transforms)."""
+        if self._ets is None:
+            e = ETS()
+            if self.base is not None and not np.array_equal(self.base, np.eye(4)):
+                e = e * ET.SE3(self.base)
+            for l in self.links:
+                e = e * l.ets()
+            if self.tool is not None and not np.array_equal(self.tool, np.eye(4)):
+                e = e * ET.SE3(self.tool)
+            self._ets = e
+        return self._ets
+
+    def fkine(self, q, **kw):
+        """(4,4) or (N,4,4).  The reference multiplies closed-form DH matrices in Python
+        (robot/DHRobot.py:953-979, DHLink.A robot/DHLink.py:633-673); the ETS lowering evaluated on
+        the GPU is the same product (tests pin the two against each other)."""
+        return self.ets().eval(q)
+
+    def jacob0(self, q, **kw): return self.ets().jacob0(q)
+    def jacobe(self, q, **kw): return self.ets().jacobe(q)
+
+    # ------------------------------------------------------------ dynamics
+    def L24(self):
+        """The 24-double/link block of reference robot/DHRobot.py:1342-1358."""
+        L = np.zeros((self.n, 24))
+        for i, l in enumerate(self.links):
+            L[i, 0:6] = [l.alpha, l.a, l.theta, l.d, l.sigma, l.offset]
+            L[i, 6] = l.m
+            L[i, 7:10] = l.r
+            L[i, 10:19] = l.I.flatten()
+            L[i, 19:24] = [l.Jm, l.G, l.B, l.Tc[0], l.Tc[1]]
+        return np.ascontiguousarray(L)
+
+    def dynchanged(self):
+        self.delete_rne()
+
+    def delete_rne(self):
+        if self._dyn is not None and _lib._lib is not None:
+            _lib._lib.rtbhip_dyn_destroy(self._dyn)
+        self._dyn = None
+
+    def __del__(self):
+        try:
+            self.delete_rne()
+        except Exception:
+            pass
+
+    def _dyn_handle(self):
+        if self._dyn is None:
+            L = self.L24()
+            h = C.c_uint64(0)
+            check(lib().rtbhip_dyn_create(host_ptr(L), self.n, self.mdh, C.byref(h)))
+            self._dyn = h.value
+        return self._dyn
+
+    def rne(self, q, qd=None, qdd=None, gravity=None, fext=None, base_wrench=False):
+        """Inverse dynamics tau(q, qd, qdd): (n,) or (N,n)
+        (reference robot/DHRobot.py:1373-1456 -> frne.frne core/frne.c:106-230)."""
+        if base_wrench:
+            raise NotImplementedError("base_wrench is served by the reference's rne_python only")
+        n = self.n
+        tm = is_torch(q) and q.is_cuda
+        if tm:
+            single = q.dim() == 1
+            arrs = [x.reshape(-1, n).contiguous() for x in (q, qd, qdd)]
+        else:
+            arrs = [as_numeric(x) for x in (q, qd, qdd)]
+            single = arrs[0].ndim == 1
+            arrs = [np.ascontiguousarray(x.reshape(-1, n)) for x in arrs]
+        N = arrs[0].shape[0]
+        single = single or N == 1                # reference returns tau[0, :] whenever trajn == 1
+        if any(x.shape != (N, n) for x in arrs):
+            raise ValueError("q, qd, qdd must all be (%d,) or (N,%d)" % (n, n))
+        g = self.gravity if gravity is None else np.asarray(gravity, dtype=np.float64).reshape(3)
+        if self.base is not None:
+            g = self.base[:3, :3].T @ g          # reference robot/DHRobot.py:1431-1433
+        gc = np.ascontiguousarray(-g)            # "we negate gravity here" robot/DHRobot.py:1449
+        f = None if fext is None else np.ascontiguousarray(np.asarray(fext, dtype=np.float64).reshape(6))
+        if tm:
+            import torch
+            tau = torch.empty((N, n), dtype=torch.float64, device=arrs[0].device)
+            ptr = lambda x: C.c_void_p(x.data_ptr())
+            stream = _lib.current_stream_ptr()
+            mem = MEM_DEVICE
+        else:
+            tau = np.empty((N, n))
+            ptr = host_ptr
+            stream = None
+            mem = MEM_HOST
+        check(lib().rtbhip_rne(self._dyn_handle(), ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2]), N, host_ptr(gc),
+                               host_ptr(f), ptr(tau), mem, stream))
+        return tau[0] if single else tau

@@ -1,0 +1,441 @@
+"""ET / ETS -- the drop-in surface of the batched kinematics path.
+
+Mirrors the call signatures and result shapes of the reference's ``roboticstoolbox.robot.ET.ET``
+and ``roboticstoolbox.robot.ETS.ETS`` for the hot path only (constructors, ``eval``, ``fkine``,
+``jacob0``, ``jacobe``, ``hessian0``, ``hessiane``, ``ik_LM``, ``ikine_LM``): reference
+robot/ET.py:595-935 (constructors), robot/ETS.py:1006-1199 (eval/fkine/jacob0),
+:1327-1420 (hessians), :2014-2170 (ik_LM), :2618-2637 (ikine_LM).  Everything is executed by
+librtbhip.so on the GPU; there is no Python/NumPy arithmetic path in this module (elementary
+constant matrices are the only thing evaluated on the host, once, at construction).
+
+Batch extension: where the reference takes one configuration (jacob0/jacobe/hessian0/ik_LM), a
+2-D ``q`` of shape (N, n) [or ``Tep`` of shape (N,4,4)] returns a leading batch axis.
+Inputs may be NumPy arrays (host path: staged through the device) or float64 CUDA torch tensors
+(zero-copy device path on the current stream; outputs are torch tensors on the same device).
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib, as_numeric, small, host_ptr, is_torch, MEM_HOST, MEM_DEVICE
+
+_AXES = {"Rx": 0, "Ry": 1, "Rz": 2, "tx": 3, "ty": 4, "tz": 5}
+_METHODS = {"chan": 0, "wampler": 1, "sugihara": 2}
+
+
+def _elementary(axis, eta):
+    """Constant 4x4 of a static elementary transform (what trotx/troty/trotz/transl give a float)."""
+    T = np.eye(4)
+    k = _AXES[axis]
+    if k <= 2:
+        c, s = math.cos(eta), math.sin(eta)
+        b, d = (k + 1) % 3, (k + 2) % 3
+        T[b, b], T[b, d], T[d, b], T[d, d] = c, -s, s, c
+    else:
+        T[k - 3, 3] = eta
+    return T
+
+
+class ET:
+    """One elementary transform (reference robot/ET.py BaseET/ET)."""
+
+    def __init__(self, axis, eta=None, flip=False, jindex=None, qlim=None, T=None, unit="rad"):
+        self.axis = axis
+        if eta is not None:
+            if isinstance(eta, str) or not np.isscalar(eta) or isinstance(eta, complex):
+                raise TypeError("Symbolic value")  # symbolic chains stay on the reference's Python path
+            eta = float(eta)
+            if unit == "deg" and axis[0] == "R":
+                eta = eta * math.pi / 180.0
+        self.eta = eta
+        self.isflip = bool(flip)
+        self.jindex = jindex
+        self.qlim = None if qlim is None else np.asarray(qlim, dtype=np.float64).reshape(2)
+        if axis == "SE3":
+            T = np.asarray(T.A if hasattr(T, "A") and not isinstance(T, np.ndarray) else T, dtype=np.float64)
+            if T.shape != (4, 4):
+                raise ValueError("ET.SE3 needs a 4x4 matrix")
+            self.T = T.copy()
+            self.isjoint = False
+        elif eta is None:
+            self.T = np.eye(4)
+            self.isjoint = True
+        else:
+            self.T = _elementary(axis, eta)
+            self.isjoint = False
+
+    # constructors, same names/arguments as reference robot/ET.py:611-935
+    @classmethod
+    def Rx(cls, eta=None, unit="rad", **kw): return cls("Rx", eta, unit=unit, **kw)
+    @classmethod
+    def Ry(cls, eta=None, unit="rad", **kw): return cls("Ry", eta, unit=unit, **kw)
+    @classmethod
+    def Rz(cls, eta=None, unit="rad", **kw): return cls("Rz", eta, unit=unit, **kw)
+    @classmethod
+    def tx(cls, eta=None, **kw): return cls("tx", eta, **kw)
+    @classmethod
+    def ty(cls, eta=None, **kw): return cls("ty", eta, **kw)
+    @classmethod
+    def tz(cls, eta=None, **kw): return cls("tz", eta, **kw)
+    @classmethod
+    def SE3(cls, T, **kw): return cls("SE3", T=T, **kw)
+
+    @property
+    def isrotation(self): return self.axis[0] == "R"
+    @property
+    def istranslation(self): return self.axis[0] == "t"
+
+    def __mul__(self, other): return ETS(self) * other
+    def __add__(self, other): return ETS(self) * other
+
+    def __repr__(self):
+        if self.axis == "SE3":
+            return "SE3(...)"
+        arg = "q%s" % ("" if self.jindex is None else self.jindex) if self.isjoint else "%.4g" % self.eta
+        return "%s(%s%s)" % (self.axis, "-" if self.isflip else "", arg)
+
+
+@dataclass
+class IKSolution:
+    """Result of ikine_LM (reference robot/IK.py:27-101)."""
+    q: np.ndarray
+    success: bool = False
+    iterations: int = 0
+    searches: int = 0
+    residual: float = 0.0
+    reason: str = ""
+    each: dict = field(default_factory=dict, repr=False)  # per-target arrays for a batch of Tep
+
+    def __iter__(self):
+        return iter((self.q, self.success, self.iterations, self.searches, self.residual, self.reason))
+
+
+class ETS:
+    """A sequence of elementary transforms bound to a device chain handle (reference robot/ETS.py)."""
+
+    def __init__(self, arg=None):
+        if arg is None:
+            ets = []
+        elif isinstance(arg, ET):
+            ets = [arg]
+        elif isinstance(arg, ETS):
+            ets = list(arg._ets)
+        else:
+            ets = []
+            for a in arg:
+                ets.extend(a._ets if isinstance(a, ETS) else [a])
+        self._ets = ets
+        self._handle_ = None
+        self._qlim = None
+
+    # ------------------------------------------------------------ structure
+    def __mul__(self, other):
+        if isinstance(other, ET):
+            return ETS(self._ets + [other])
+        if isinstance(other, ETS):
+            return ETS(self._ets + other._ets)
+        return NotImplemented
+
+    __add__ = __mul__
+
+    def __len__(self): return len(self._ets)
+    def __iter__(self): return iter(self._ets)
+    def __getitem__(self, i): return self._ets[i]
+    def __repr__(self): return " * ".join(repr(e) for e in self._ets) or "ETS()"
+
+    def __del__(self):
+        h = getattr(self, "_handle_", None)
+        if h is not None and _lib._lib is not None:
+            try:
+                _lib._lib.rtbhip_chain_destroy(h)
+            except Exception:
+                pass
+
+    @property
+    def m(self): return len(self._ets)
+
+    def joints(self): return [e for e in self._ets if e.isjoint]
+
+    @property
+    def n(self): return len(self.joints())
+
+    def _assigned_jindices(self):
+        """Joints without an explicit jindex are numbered in order of appearance
+        (reference robot/ETS.py:62-100 `_auto_jindex`)."""
+        js = self.joints()
+        if all(e.jindex is None for e in js):
+            return list(range(len(js)))
+        if any(e.jindex is None for e in js):
+            raise ValueError("either all or none of the joints must have a jindex")
+        return [int(e.jindex) for e in js]
+
+    @property
+    def jindices(self): return np.array(self._assigned_jindices(), dtype=int)
+
+    @property
+    def qlim(self):
+        """(2, n) joint limits, defaults as reference robot/ET.py:109-115."""
+        if self._qlim is not None:
+            return self._qlim
+        lo, hi = [], []
+        for e in self.joints():
+            if e.qlim is not None:
+                lo.append(e.qlim[0]); hi.append(e.qlim[1])
+            elif e.isrotation:
+                lo.append(-math.pi); hi.append(math.pi)
+            else:
+                lo.append(0.0); hi.append(1.0)
+        return np.array([lo, hi], dtype=np.float64)
+
+    @qlim.setter
+    def qlim(self, v):
+        v = np.asarray(v, dtype=np.float64)
+        if v.shape == (self.n, 2):
+            v = v.T
+        if v.shape != (2, self.n):
+            raise ValueError("qlim must be (2, n)")
+        self._qlim = np.ascontiguousarray(v)
+        self._drop_handle()
+
+    def _drop_handle(self):
+        if self._handle_ is not None and _lib._lib is not None:
+            _lib._lib.rtbhip_chain_destroy(self._handle_)
+        self._handle_ = None
+
+    def optable(self):
+        """The flat description handed to rtbhip_chain_create: (kind, flip, jindex, T16) per ET."""
+        jidx = iter(self._assigned_jindices())
+        rows = []
+        for e in self._ets:
+            if e.isjoint:
+                rows.append((_AXES[e.axis], int(e.isflip), next(jidx), np.eye(4)))
+            else:
+                rows.append((_lib.ET_CONST, 0, 0, e.T))
+        return rows
+
+    def _handle(self):
+        if self._handle_ is None:
+            rows = self.optable()
+            arr = (_lib.rtbhip_et * max(1, len(rows)))()
+            for i, (kind, flip, jindex, T) in enumerate(rows):
+                arr[i].kind, arr[i].flip, arr[i].jindex, arr[i].reserved = kind, flip, jindex, 0
+                flat = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
+                for k in range(16):
+                    arr[i].T[k] = flat[k]
+            ql = np.ascontiguousarray(self.qlim.reshape(-1)) if self.n else None
+            h = C.c_uint64(0)
+            check(lib().rtbhip_chain_create(arr, len(rows), host_ptr(ql), C.byref(h)))
+            self._handle_ = h.value
+        return self._handle_
+
+    @property
+    def q_width(self):
+        j = self._assigned_jindices()
+        return (max(j) + 1) if j else 0
+
+    # ------------------------------------------------------------ argument shaping
+    def _shape_q(self, q):
+        """-> (q2d, single, torch_mode).  1-D, (1,n) and (n,1) are ONE configuration
+        (reference core/fknm.cpp:964-988); anything else is a trajectory of rows."""
+        qw = self.q_width
+        if is_torch(q):
+            import torch
+            if not q.is_cuda:
+                return self._shape_q(q.detach().numpy())
+            if q.dtype != torch.float64:
+                raise TypeError("device q must be float64")
+            single = q.dim() == 1 or (q.dim() == 2 and (q.shape[0] == 1 or q.shape[1] == 1))
+            q2 = q.reshape(1, -1) if single else q
+            q2 = q2.contiguous()
+            if q2.shape[1] != qw:
+                raise ValueError("q has %d columns, chain needs %d" % (q2.shape[1], qw))
+            return q2, single, True
+        a = as_numeric(q)
+        if a.ndim == 0:
+            a = a.reshape(1)
+        if a.ndim > 2:
+            raise ValueError("q must be 1-D or 2-D")
+        single = a.ndim == 1 or a.shape[0] == 1 or a.shape[1] == 1
+        a = a.reshape(1, -1) if single else a
+        if a.shape[1] != qw:
+            raise ValueError("q has %d columns, chain needs %d" % (a.shape[1], qw))
+        return np.ascontiguousarray(a), single, False
+
+    @staticmethod
+    def _out(shape, like, torch_mode, dtype=None):
+        if torch_mode:
+            import torch
+            return torch.empty(shape, dtype=dtype or torch.float64, device=like.device)
+        return np.empty(shape, dtype=dtype or np.float64)
+
+    @staticmethod
+    def _ptr(x, torch_mode):
+        if x is None:
+            return None
+        return C.c_void_p(x.data_ptr()) if torch_mode else host_ptr(x)
+
+    @staticmethod
+    def _stream(torch_mode):
+        return _lib.current_stream_ptr() if torch_mode else None
+
+    # ------------------------------------------------------------ kinematics
+    def eval(self, q, base=None, tool=None, include_base=True):
+        """Forward kinematics as ndarray: (4,4) for one q, (N,4,4) for a trajectory
+        (reference ETS.eval robot/ETS.py:1021-1141 -> ETS_fkine core/fknm.cpp:923-1064)."""
+        q2, single, tm = self._shape_q(q)
+        N = q2.shape[0]
+        T = self._out((N, 4, 4), q2, tm)
+        b = small(base, 16) if (base is not None and include_base) else None
+        t = small(tool, 16)
+        check(lib().rtbhip_fkine(self._handle(), self._ptr(q2, tm), N, host_ptr(b), host_ptr(t),
+                                 self._ptr(T, tm), MEM_DEVICE if tm else MEM_HOST, self._stream(tm)))
+        return T[0] if single else T
+
+    def fkine(self, q, base=None, tool=None, include_base=True):
+        """reference ETS.fkine (robot/ETS.py:1006-1019) wraps eval() in spatialmath.SE3; spatialmath
+        is not a dependency here, so the SE(3) matrices are returned as an ndarray -- wrap with
+        ``SE3(list(T), check=False)`` where spatialmath is available."""
+        return self.eval(q, base=base, tool=tool, include_base=include_base)
+
+    def _jac(self, q, tool, frame):
+        q2, single, tm = self._shape_q(q)
+        N = q2.shape[0]
+        J = self._out((N, 6, self.n), q2, tm)
+        t = small(tool, 16)
+        check(lib().rtbhip_jacob(self._handle(), self._ptr(q2, tm), N, host_ptr(t), frame,
+                                 self._ptr(J, tm), MEM_DEVICE if tm else MEM_HOST, self._stream(tm)))
+        return J[0] if single else J
+
+    def jacob0(self, q, tool=None):
+        """Geometric Jacobian in the chain's start frame: (6,n), or (N,6,n) for a trajectory
+        (reference ETS.jacob0 robot/ETS.py:1143-1199 -> ETS_jacob0 core/fknm.cpp:785-850)."""
+        return self._jac(q, tool, 0)
+
+    def jacobe(self, q, tool=None):
+        """End-effector-frame Jacobian (reference robot/ETS.py:1274-1330, core/fknm.cpp:852-921)."""
+        return self._jac(q, tool, 1)
+
+    def fkine_jacob0(self, q, base=None, tool=None, frame=0):
+        """Fused fkine + Jacobian in one chain walk (the headline op; no reference equivalent --
+        a reference user calls eval() then jacob0() per row)."""
+        q2, single, tm = self._shape_q(q)
+        N = q2.shape[0]
+        T = self._out((N, 4, 4), q2, tm)
+        J = self._out((N, 6, self.n), q2, tm)
+        b, t = small(base, 16), small(tool, 16)
+        check(lib().rtbhip_fkine_jacob(self._handle(), self._ptr(q2, tm), N, host_ptr(b), host_ptr(t), frame,
+                                       self._ptr(T, tm), self._ptr(J, tm), MEM_DEVICE if tm else MEM_HOST,
+                                       self._stream(tm)))
+        return (T[0], J[0]) if single else (T, J)
+
+    def _hess(self, q, tool, frame):
+        if q is None:
+            raise NotImplementedError("hessian from a supplied J0/Je is not offered by the GPU backend: pass q")
+        q2, single, tm = self._shape_q(q)
+        N = q2.shape[0]
+        n = self.n
+        H = self._out((N, n, 6, n), q2, tm)
+        t = small(tool, 16)
+        check(lib().rtbhip_hessian(self._handle(), self._ptr(q2, tm), N, host_ptr(t), frame,
+                                   self._ptr(H, tm), MEM_DEVICE if tm else MEM_HOST, self._stream(tm)))
+        return H[0] if single else H
+
+    def hessian0(self, q=None, J0=None, tool=None):
+        """(n,6,n) Hessian in the start frame (reference robot/ETS.py:1332-1420, fknm.cpp:583-682)."""
+        return self._hess(q, tool, 0)
+
+    def hessiane(self, q=None, Je=None, tool=None):
+        return self._hess(q, tool, 1)
+
+    # ------------------------------------------------------------ inverse kinematics
+    def _ik(self, Tep, q0, ilimit, slimit, tol, mask, joint_limits, k, method, flavour, seed):
+        n = self.n
+        tm = is_torch(Tep) and Tep.is_cuda
+        if tm:
+            Tq = Tep.reshape(-1, 4, 4).contiguous()
+            single = Tep.dim() == 2
+        else:
+            if hasattr(Tep, "A") and not isinstance(Tep, np.ndarray):
+                Tep = np.array([x.A for x in Tep]) if len(Tep) > 1 else Tep.A
+            a = as_numeric(Tep, "Tep")
+            single = a.ndim == 2
+            if a.shape[-2:] != (4, 4):
+                raise ValueError("Tep must be a 4x4 SE3 matrix")
+            Tq = np.ascontiguousarray(a.reshape(-1, 4, 4))
+        N = Tq.shape[0]
+        q0p = None
+        if q0 is not None:
+            if tm:
+                q0p = q0.reshape(-1, n).contiguous()
+                if q0p.shape[0] == 1 and N > 1:
+                    q0p = q0p.expand(N, n).contiguous()
+            else:
+                q0p = as_numeric(q0, "q0").reshape(-1, n)
+                if q0p.shape[0] == 1 and N > 1:
+                    q0p = np.repeat(q0p, N, axis=0)
+                q0p = np.ascontiguousarray(q0p)
+            if q0p.shape[0] != N:
+                raise ValueError("q0 must be (n,) or (N,n)")
+        if isinstance(method, str):
+            if method not in _METHODS:
+                # the reference dispatches on the first letter (core/fknm.cpp:481-495)
+                method = {"s": "sugihara", "w": "wampler"}.get(method[:1], "chan")
+            method = _METHODS[method]
+        if tm:
+            import torch
+            qo = torch.empty((N, n), dtype=torch.float64, device=Tq.device)
+            ok = torch.empty((N,), dtype=torch.int32, device=Tq.device)
+            it = torch.empty((N,), dtype=torch.int32, device=Tq.device)
+            se = torch.empty((N,), dtype=torch.int32, device=Tq.device)
+            E = torch.empty((N,), dtype=torch.float64, device=Tq.device)
+        else:
+            qo = np.empty((N, n)); ok = np.empty(N, np.int32); it = np.empty(N, np.int32)
+            se = np.empty(N, np.int32); E = np.empty(N)
+        we = small(mask, 6)
+        check(lib().rtbhip_ik_lm(self._handle(), self._ptr(Tq, tm), N, self._ptr(q0p, tm), int(ilimit), int(slimit),
+                                 float(tol), int(bool(joint_limits)), host_ptr(we), float(k), int(method), int(flavour),
+                                 int(seed) & 0xFFFFFFFFFFFFFFFF, self._ptr(qo, tm), self._ptr(ok, tm), self._ptr(it, tm),
+                                 self._ptr(se, tm), self._ptr(E, tm), MEM_DEVICE if tm else MEM_HOST, self._stream(tm)))
+        return single, qo, ok, it, se, E
+
+    def ik_LM(self, Tep, q0=None, ilimit=30, slimit=100, tol=1e-6, mask=None, joint_limits=True, k=1.0,
+              method="chan", seed=0):
+        """Levenberg-Marquardt IK, loop resident on the GPU (reference ETS.ik_LM robot/ETS.py:2014-2170
+        -> IK_LM_c core/fknm.cpp:394-525).  One Tep -> the reference's 5-tuple
+        (q, success, iterations, searches, residual); Tep (N,4,4) -> the same tuple of arrays."""
+        single, q, ok, it, se, E = self._ik(Tep, q0, ilimit, slimit, tol, mask, joint_limits, k, method, 0, seed)
+        if single:
+            return q[0], int(ok[0]), int(it[0]), int(se[0]), float(E[0])
+        return q, ok, it, se, E
+
+    def ikine_LM(self, Tep, q0=None, ilimit=30, slimit=100, tol=1e-6, mask=None, joint_limits=True, seed=None,
+                 k=1.0, method="chan", kq=0.0, km=0.0, ps=0.0, pi=0.3, **kwargs):
+        """The Python solver's flavour of LM (reference ETS.ikine_LM robot/ETS.py:2618-2637 ->
+        IK_LM.solve/_solve/step robot/IK.py:174-367,994-1017): E is tested after the step and q is
+        wrapped with Python's %.  Null-space terms (kq, km) default to 0 in the reference and are not
+        offered on the GPU."""
+        if kq or km:
+            raise NotImplementedError("null-space terms kq/km are not implemented in the GPU solver")
+        single, q, ok, it, se, E = self._ik(Tep, q0, ilimit, slimit, tol, mask, joint_limits, k, method, 1,
+                                            0 if seed is None else seed)
+        if is_torch(q):
+            q, ok, it, se, E = (x.cpu().numpy() for x in (q, ok, it, se, E))
+        if single:
+            good = bool(ok[0])
+            return IKSolution(q=q[0], success=good, iterations=int(it[0]), searches=int(se[0]),
+                              residual=float(E[0]), reason="Success" if good else "iteration and search limit reached")
+        allok = bool(ok.all())  # aggregate exactly like reference robot/IK.py:263-290
+        return IKSolution(q=q, success=allok, iterations=int(it.sum()), searches=int(se.sum()),
+                          residual=float(E.min()) if len(E) else float("inf"),
+                          reason="" if allok else "iteration and search limit reached",
+                          each={"success": ok.astype(bool), "iterations": it, "searches": se, "residual": E})
+
+    def ik_restart(self, seed, target, search):
+        """The restart vector the device generator yields (test hook, rtbhip_ik_restart)."""
+        out = np.empty(self.n)
+        check(lib().rtbhip_ik_restart(self._handle(), int(seed) & 0xFFFFFFFFFFFFFFFF, int(target), int(search),
+                                      host_ptr(out)))
+        return out

@@ -1,0 +1,43 @@
+"""Mixed-fleet evaluation (BASELINE config 5): several different chains, each with its own batch,
+walked by ONE kernel launch (variable-length chains, block -> chain map)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib, as_numeric, is_torch, MEM_HOST, MEM_DEVICE
+
+
+def fleet_fkine_jacob(chains, qs, frame=0):
+    """chains: list of ETS; qs: list of (N_c, n_c) arrays (all NumPy or all CUDA float64 tensors).
+    Returns (list of T (N_c,4,4), list of J (N_c,6,n_c))."""
+    if len(chains) != len(qs):
+        raise ValueError("one q batch per chain")
+    k = len(chains)
+    tm = k > 0 and is_torch(qs[0]) and qs[0].is_cuda
+    handles = (C.c_uint64 * max(1, k))()
+    qp = (C.c_void_p * max(1, k))()
+    Tp = (C.c_void_p * max(1, k))()
+    Jp = (C.c_void_p * max(1, k))()
+    Ns = (C.c_int64 * max(1, k))()
+    keep, Ts, Js = [], [], []
+    for i, (ch, q) in enumerate(zip(chains, qs)):
+        handles[i] = ch._handle()
+        if tm:
+            import torch
+            q2 = q.reshape(-1, ch.q_width).contiguous()
+            T = torch.empty((q2.shape[0], 4, 4), dtype=torch.float64, device=q2.device)
+            J = torch.empty((q2.shape[0], 6, ch.n), dtype=torch.float64, device=q2.device)
+            qp[i], Tp[i], Jp[i] = q2.data_ptr(), T.data_ptr(), J.data_ptr()
+        else:
+            q2 = np.ascontiguousarray(as_numeric(q).reshape(-1, ch.q_width))
+            T = np.empty((q2.shape[0], 4, 4))
+            J = np.empty((q2.shape[0], 6, ch.n))
+            qp[i], Tp[i], Jp[i] = q2.ctypes.data, T.ctypes.data, J.ctypes.data
+        Ns[i] = q2.shape[0]
+        keep.append(q2)
+        Ts.append(T)
+        Js.append(J)
+    check(lib().rtbhip_fleet_fkine_jacob(handles, k, qp, Ns, int(frame), Tp, Jp, MEM_DEVICE if tm else MEM_HOST,
+                                         _lib.current_stream_ptr() if tm else None))
+    return Ts, Js

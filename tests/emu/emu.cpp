@@ -1,0 +1,102 @@
+// tests/emu/emu.cpp -- TEST INFRASTRUCTURE: executes the kernels' own per-lane phase functions
+// (robotics-toolbox-python_amd/csrc/kin_tile.h, rne_device.h, ik_device.h -- all __host__ __device__)
+// lane by lane on the CPU, in the same phase order and with the same LDS layout as the gfx950
+// kernels.  The build container has no GPU; this lets `pytest -m "not gpu"` catch logic errors in the
+// kernel bodies (indexing, staging, flush arithmetic, recursion order) before GPU minutes are spent.
+// It is NOT a product path: librtbhip.so contains none of this and fails loudly without a GPU.
+#include "../../robotics-toolbox-python_amd/csrc/kin_tile.h"
+#include "../../robotics-toolbox-python_amd/csrc/rne_device.h"
+#include <vector>
+
+using namespace rtbhip;
+
+static Affine aff16(const double *m)
+{
+    Affine a;
+    a.used = m != nullptr;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 4; c++) a.v[4 * r + c] = m ? m[4 * r + c] : (r == c ? 1.0 : 0.0);
+    return a;
+}
+
+extern "C" int emu_kin(rtbhip_chain_t h, const double *q, int64_t N, const double *base16, const double *tool16,
+                       int frame, double *T, double *J, double *H, int coalesced)
+{
+    Chain *c = chain_from_handle(h);
+    if (!c) return -1;
+    KinParams kp;
+    kp.m = (int)c->ops.size(); kp.n = c->n; kp.qw = c->q_width; kp.stride = kin_stride(c->n);
+    kp.frame = frame; kp.N = N; kp.pad = 0;
+    Affine b = aff16(base16), t = aff16(tool16);
+    kp.has_base = b.used; kp.has_tool = t.used;
+    for (int i = 0; i < 12; i++) { kp.base[i] = b.v[i]; kp.tool[i] = t.v[i]; }
+    std::vector<double> lds(kin_lds_bytes(kp.n, kp.qw) / sizeof(double), -777.0);
+    double *rows = lds.data(), *qs = lds.data() + kWave * kp.stride;
+    const DevOp *ops = c->ops.data();
+    const int W = 6 * kp.n;
+    const int64_t tiles = (N + kWave - 1) / kWave;
+    for (int64_t tile = 0; tile < tiles; ++tile) {
+        const int64_t cfg0 = tile * kWave;
+        const int ncfg = (int)std::min<int64_t>(kWave, N - cfg0);
+        Pose P[kWave];
+        for (int l = 0; l < kWave; ++l) kin_load_q(kp, q, cfg0 + l, l, qs);
+        for (int l = 0; l < kWave; ++l) {
+            if (J || H) kin_walk<true>(kp, ops, l, qs, rows, P[l]);
+            else kin_walk<false>(kp, ops, l, qs, rows, P[l]);
+        }
+        if (H) for (int l = 0; l < kWave; ++l) kin_hessian(kp, l, rows, l < ncfg, H + (cfg0 + l) * (int64_t)(kp.n * W));
+        if (J) for (int l = 0; l < kWave; ++l) {
+            if (coalesced) kin_flush(rows, kp.stride, W, ncfg, J + cfg0 * W, l);
+            else kin_store_own(rows, kp.stride, W, l < ncfg, J + (cfg0 + l) * W, l);
+        }
+        if (T) {
+            for (int l = 0; l < kWave; ++l) kin_stage_T(kp, l, rows, P[l]);
+            for (int l = 0; l < kWave; ++l) {
+                if (coalesced) kin_flush(rows, kp.stride, 16, ncfg, T + cfg0 * 16, l);
+                else kin_store_own(rows, kp.stride, 16, l < ncfg, T + (cfg0 + l) * 16, l);
+            }
+        }
+    }
+    return 0;
+}
+
+template <int NJ>
+static void rne_run(const Dyn *d, const double *q, const double *qd, const double *qdd, int64_t N, V3 g, V3 f, V3 nt,
+                    double *tau)
+{
+    const DevLink *links = d->links.data();
+    const int n = d->n;
+    for (int64_t s = 0; s < N; ++s) {
+        const double *a = q + s * n, *b = qd + s * n, *c = qdd + s * n;
+        double *o = tau + s * n;
+        auto qi = [&](int j) { return a[j]; };
+        auto qdi = [&](int j) { return b[j]; };
+        auto qddi = [&](int j) { return c[j]; };
+        auto out = [&](int j, double v) { o[j] = v; };
+        if (d->mdh) rne_lane<NJ, true>(links, n, g, f, nt, qi, qdi, qddi, out);
+        else rne_lane<NJ, false>(links, n, g, f, nt, qi, qdi, qddi, out);
+    }
+}
+
+extern "C" int emu_rne(rtbhip_dyn_t h, const double *q, const double *qd, const double *qdd, int64_t N,
+                       const double *grav3, const double *fext6, double *tau, int force_generic)
+{
+    Dyn *d = dyn_from_handle(h);
+    if (!d) return -1;
+    V3 g = v3(grav3[0], grav3[1], grav3[2]);
+    V3 f = fext6 ? v3(fext6[0], fext6[1], fext6[2]) : v3(0, 0, 0);
+    V3 nt = fext6 ? v3(fext6[3], fext6[4], fext6[5]) : v3(0, 0, 0);
+    if (force_generic) { rne_run<0>(d, q, qd, qdd, N, g, f, nt, tau); return 0; }
+    switch (d->n) {
+    case 1: rne_run<1>(d, q, qd, qdd, N, g, f, nt, tau); break;
+    case 2: rne_run<2>(d, q, qd, qdd, N, g, f, nt, tau); break;
+    case 3: rne_run<3>(d, q, qd, qdd, N, g, f, nt, tau); break;
+    case 4: rne_run<4>(d, q, qd, qdd, N, g, f, nt, tau); break;
+    case 5: rne_run<5>(d, q, qd, qdd, N, g, f, nt, tau); break;
+    case 6: rne_run<6>(d, q, qd, qdd, N, g, f, nt, tau); break;
+    case 7: rne_run<7>(d, q, qd, qdd, N, g, f, nt, tau); break;
+    case 8: rne_run<8>(d, q, qd, qdd, N, g, f, nt, tau); break;
+    default: rne_run<0>(d, q, qd, qdd, N, g, f, nt, tau); break;
+    }
+    return 0;
+}

@@ -1,0 +1,99 @@
+"""tests/emu_harness.py -- TEST INFRASTRUCTURE.  Python front-end of tests/emu/libemu.so, which runs
+the kernels' own __host__ __device__ phase functions lane by lane on the CPU (see tests/emu/emu.cpp).
+Used by the `-m "not gpu"` suite to check kernel-body logic against the oracle where no GPU exists."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "robotics-toolbox-python_amd")
+EMU_SO = os.path.join(ROOT, "tests", "emu", "libemu.so")
+SRCS = ["tests/emu/emu.cpp"] + ["robotics-toolbox-python_amd/csrc/" + f for f in
+                                ("api.cpp", "chain.cpp", "kin_kernels.hip", "rne_kernels.hip", "ik_kernels.hip")]
+_vp, _u64, _i64, _i32 = C.c_void_p, C.c_uint64, C.c_int64, C.c_int32
+_lib = None
+
+
+def _stale():
+    if not os.path.exists(EMU_SO):
+        return True
+    t = os.path.getmtime(EMU_SO)
+    deps = [os.path.join(ROOT, s) for s in SRCS] + [os.path.join(PKG, "csrc", f) for f in os.listdir(os.path.join(PKG, "csrc"))]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build():
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-x", "hip", "-w",
+           "-I" + os.path.join(ROOT, "include")] + [os.path.join(ROOT, s) for s in SRCS] + ["-o", EMU_SO]
+    subprocess.check_call(cmd)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if _stale():
+            build()
+        _lib = C.CDLL(EMU_SO)
+        import sys
+        sys.path.insert(0, PKG)
+        from rtbhip._lib import rtbhip_et
+        _lib.rtbhip_chain_create.argtypes = [C.POINTER(rtbhip_et), _i32, _vp, C.POINTER(_u64)]
+        _lib.rtbhip_dyn_create.argtypes = [_vp, _i32, _i32, C.POINTER(_u64)]
+        _lib.emu_kin.argtypes = [_u64, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _i32]
+        _lib.emu_rne.argtypes = [_u64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32]
+        _lib.rtbhip_last_error.restype = C.c_char_p
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def chain_handle(ets):
+    """ets: an rtbhip.ETS (its optable() is handed to the emu library's own chain compiler)."""
+    from rtbhip._lib import rtbhip_et
+    rows = ets.optable()
+    arr = (rtbhip_et * max(1, len(rows)))()
+    for i, (kind, flip, jindex, T) in enumerate(rows):
+        arr[i].kind, arr[i].flip, arr[i].jindex = kind, flip, jindex
+        flat = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
+        for k in range(16):
+            arr[i].T[k] = flat[k]
+    ql = np.ascontiguousarray(ets.qlim.reshape(-1)) if ets.n else None
+    h = _u64(0)
+    rc = lib().rtbhip_chain_create(arr, len(rows), _p(ql), C.byref(h))
+    assert rc == 0, lib().rtbhip_last_error()
+    return h.value
+
+
+def kin(ets, q, base=None, tool=None, frame=0, want=("T", "J"), coalesced=True):
+    h = chain_handle(ets)
+    q = np.ascontiguousarray(np.asarray(q, dtype=np.float64).reshape(-1, ets.q_width))
+    N, n = q.shape[0], ets.n
+    T = np.full((N, 4, 4), np.nan) if "T" in want else None
+    J = np.full((N, 6, n), np.nan) if "J" in want else None
+    H = np.full((N, n, 6, n), np.nan) if "H" in want else None
+    b = None if base is None else np.ascontiguousarray(base, dtype=np.float64)
+    t = None if tool is None else np.ascontiguousarray(tool, dtype=np.float64)
+    rc = lib().emu_kin(h, _p(q), N, _p(b), _p(t), frame, _p(T), _p(J), _p(H), int(coalesced))
+    assert rc == 0
+    return T, J, H
+
+
+def rne(L24, mdh, q, qd, qdd, grav_c, fext=None, force_generic=False):
+    L = np.ascontiguousarray(L24, dtype=np.float64).reshape(-1, 24)
+    n = L.shape[0]
+    h = _u64(0)
+    rc = lib().rtbhip_dyn_create(_p(L), n, int(mdh), C.byref(h))
+    assert rc == 0, lib().rtbhip_last_error()
+    q, qd, qdd = (np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1, n)) for x in (q, qd, qdd))
+    tau = np.full(q.shape, np.nan)
+    g = np.ascontiguousarray(grav_c, dtype=np.float64)
+    f = None if fext is None else np.ascontiguousarray(fext, dtype=np.float64)
+    rc = lib().emu_rne(h.value, _p(q), _p(qd), _p(qdd), q.shape[0], _p(g), _p(f), _p(tau), int(force_generic))
+    assert rc == 0
+    return tau

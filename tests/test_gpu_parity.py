@@ -1,0 +1,315 @@
+"""-m gpu: the parity tests proper.  Everything goes through the C ABI (ctypes -> librtbhip.so ->
+gfx950 kernels) and is compared with the CPU oracle on the same seeded inputs, with the committed
+golden fixtures, and -- at BASELINE.json's full sizes -- through size-independent properties.
+
+Tolerances (fp64; north_star: <= 1e-10 max pose error vs the reference CPU path):
+    T, J, H : max abs error <= 1e-10  (observed ~1e-15)
+    tau     : <= 1e-9 relative to max |tau|
+"""
+import numpy as np
+import numpy.testing as nt
+import pytest
+import torch
+
+import rtbhip
+from oracle import oracle, chains
+from helpers import literals, ref_outputs, mixed_spec, product_ets, tool_base
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+LIT = literals()
+REF = ref_outputs()
+
+
+def test_native_library_is_the_path():
+    assert rtbhip.device_count() >= 1
+    import ctypes
+    # the loaded shared object is the in-tree HIP library, not a fallback
+    assert rtbhip.lib()._name.endswith("robotics-toolbox-python_amd/lib/librtbhip.so")
+    g, b, l = rtbhip.last_launch()
+    p = rtbhip.models.Panda()
+    p.fkine(np.zeros(7))
+    g, b, l = rtbhip.last_launch()
+    assert (g, b) == (1, 64) and l > 0
+
+
+def test_golden_literals_G1_G2_G3_G8():
+    p = rtbhip.models.Panda()
+    q1 = LIT["panda_q"]
+    for q in (q1, list(q1), q1[None, :], q1[:, None]):                     # test_ETS.py:359-362
+        nt.assert_array_almost_equal(p.fkine(q), LIT["G1_panda_fkine"], decimal=6)
+        nt.assert_array_almost_equal(p.jacob0(q), LIT["G2_panda_jacob0"], decimal=6)
+        assert p.jacob0(q).shape == (6, 7) and p.fkine(q).shape == (4, 4)
+    with pytest.raises(TypeError):
+        p.jacob0("Wfgsrth")                                                   # test_ETS.py:363
+    T = p.fkine(q1)
+    tr2jac = np.zeros((6, 6)); tr2jac[:3, :3] = T[:3, :3].T; tr2jac[3:, 3:] = T[:3, :3].T
+    nt.assert_array_almost_equal(p.jacobe(q1), tr2jac @ p.jacob0(q1), decimal=12)   # test_ETS.py:365-398
+    raw = LIT["G8_panda_hessian0_raw"]
+    nt.assert_array_almost_equal(p.hessian0(q1), np.stack([raw[:, :, i] for i in range(7)]), decimal=6)
+    # hessian with the ee segment as `tool` (test_ETS.py:1130-1579)
+    arm = rtbhip.ETS(p.ets()[:-2])
+    ee = chains.elementary("tz", 103 * 1e-3) @ chains.elementary("Rz", -np.pi / 4)
+    raw = LIT["G8_panda_hessian0_tool_raw"]
+    nt.assert_array_almost_equal(arm.hessian0(q1, tool=ee), np.stack([raw[:, :, i] for i in range(7)]), decimal=6)
+
+
+def test_reference_run_fixtures_panda():
+    tool, base = tool_base()
+    ets = rtbhip.models.Panda().ets()
+    q = REF["panda_q"]
+    nt.assert_allclose(ets.eval(q), REF["panda_fkine"], atol=TOL)
+    nt.assert_allclose(ets.eval(q, base=base, tool=tool), REF["panda_fkine_bt"], atol=TOL)
+    nt.assert_allclose(ets.jacob0(q), REF["panda_jacob0"], atol=TOL)
+    nt.assert_allclose(ets.jacobe(q), REF["panda_jacobe"], atol=TOL)
+    nt.assert_allclose(ets.jacob0(q, tool=tool), REF["panda_jacob0_tool"], atol=TOL)
+    nt.assert_allclose(ets.jacobe(q, tool=tool), REF["panda_jacobe_tool"], atol=TOL)
+    nt.assert_allclose(ets.hessian0(q[:8]), REF["panda_hessian0"], atol=TOL)
+    T, J = ets.fkine_jacob0(q, base=base, tool=tool)
+    nt.assert_allclose(T, REF["panda_fkine_bt"], atol=TOL)       # base reaches T ...
+    nt.assert_allclose(J, REF["panda_jacob0_tool"], atol=TOL)    # ... but never the Jacobian
+
+
+def test_mixed_chain_all_axes_flips_se3():
+    ets = product_ets(mixed_spec())
+    q = REF["mixed_q"]
+    nt.assert_allclose(ets.eval(q), REF["mixed_fkine"], atol=TOL)
+    nt.assert_allclose(ets.jacob0(q), REF["mixed_jacob0"], atol=TOL)
+    nt.assert_allclose(ets.jacobe(q), REF["mixed_jacobe"], atol=TOL)
+
+
+def test_batch_equals_row_by_row():
+    """test_ETS.py:236-260: 6-joint Rx,Ry,Rz,tx,ty,tz robot, qt = arange(60).reshape(10,6)."""
+    ET = rtbhip.ET
+    r = ET.Rx() * ET.Ry() * ET.Rz() * ET.tx() * ET.ty() * ET.tz()
+    qt = np.arange(60.0).reshape(10, 6)
+    TT = r.eval(qt)
+    JJ = r.jacob0(qt)
+    for i in range(10):
+        nt.assert_allclose(TT[i], r.eval(qt[i]), atol=1e-14)
+        nt.assert_allclose(JJ[i], r.jacob0(qt[i]), atol=1e-14)
+
+
+@pytest.mark.parametrize("N", [1, 63, 64, 65, 1000, 4097])
+def test_ragged_sizes_vs_oracle(N):
+    ets = rtbhip.models.Panda().ets()
+    ch = chains.panda_ets()
+    rng = np.random.default_rng(N)
+    q = rng.uniform(-np.pi, np.pi, (N, 7))
+    T, J = ets.fkine_jacob0(q)
+    nt.assert_allclose(T.reshape(-1, 4, 4), oracle.fkine(ch, q), atol=TOL)
+    nt.assert_allclose(J.reshape(-1, 6, 7), oracle.jacob0(ch, q), atol=TOL)
+
+
+@pytest.mark.parametrize("coalesced", [1, 0])
+def test_store_path_variants_agree(coalesced):
+    rtbhip.tune("coalesced", coalesced)
+    try:
+        ets = rtbhip.models.Panda().ets()
+        ch = chains.panda_ets()
+        rng = np.random.default_rng(3)
+        q = rng.uniform(-np.pi, np.pi, (777, 7))
+        T, J = ets.fkine_jacob0(q)
+        nt.assert_allclose(T, oracle.fkine(ch, q), atol=TOL)
+        nt.assert_allclose(J, oracle.jacob0(ch, q), atol=TOL)
+    finally:
+        rtbhip.tune("coalesced", 1)
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 11, 16, 23])
+def test_joint_counts(n):
+    rng = np.random.default_rng(n)
+    axes = ["Rx", "Ry", "Rz", "tx", "ty", "tz"]
+    spec = []
+    for j in range(n):
+        spec.append((axes[rng.integers(6)], float(rng.normal())))
+        spec.append((axes[rng.integers(6)], None, bool(rng.integers(2))))
+    ets = product_ets(spec)
+    ch = chains.Chain(spec)
+    q = rng.normal(size=(200, n))
+    for frame, fn in ((0, ets.jacob0), (1, ets.jacobe)):
+        nt.assert_allclose(fn(q), oracle.jacob(ch, q, frame=frame), atol=1e-9)
+    nt.assert_allclose(ets.eval(q), oracle.fkine(ch, q), atol=1e-9)
+    if n <= 11:
+        nt.assert_allclose(ets.hessian0(q[:20]), oracle.hessian0(ch, q[:20]), atol=1e-9)
+
+
+def test_config1_puma_dh_fkine_1e3():
+    """BASELINE configs[0]: Puma560 6-DOF DH, fkine over 1e3 random q."""
+    puma = rtbhip.models.DH.Puma560()
+    tab = chains.puma560()
+    rng = np.random.default_rng(0)
+    q = rng.uniform(tab.qlim[:, 0], tab.qlim[:, 1], (1000, 6))
+    T = puma.fkine(q)
+    nt.assert_allclose(T, oracle.dh_fkine(tab.dh, 0, q), atol=TOL)       # closed-form DHLink.A product
+    nt.assert_allclose(T, oracle.fkine(tab.ets(), q), atol=TOL)          # ETS lowering through fknm's algorithm
+    nt.assert_allclose(puma.fkine(REF["puma_q"]), REF["puma_fkine"], atol=TOL)
+    nt.assert_allclose(puma.jacob0(REF["puma_q"]), REF["puma_jacob0"], atol=TOL)
+
+
+def test_G11_dh_literals():
+    r0 = rtbhip.DHRobot([rtbhip.PrismaticDH(), rtbhip.RevoluteDH(), rtbhip.PrismaticDH(theta=2.0), rtbhip.RevoluteDH()])
+    q = np.array([1, 2, 3, 4.0])
+    nt.assert_array_almost_equal(r0.fkine(q), LIT["G11_dh_rprp_fkine"], decimal=6)        # test_DHRobot.py:170-189
+    TT = r0.fkine(np.tile(q, (4, 1)))                                                      # :191-208
+    for i in range(4):
+        nt.assert_array_almost_equal(TT[i], LIT["G11_dh_rprp_fkine"], decimal=6)
+    panda = rtbhip.models.DH.Panda()
+    nt.assert_array_almost_equal(panda.fkine(np.arange(1, 8.0)), LIT["G11_dh_panda_fkine"], decimal=4)   # :438-451
+    r1 = rtbhip.DHRobot([rtbhip.PrismaticDH(theta=4), rtbhip.RevoluteDH(a=2), rtbhip.PrismaticDH(theta=2), rtbhip.RevoluteDH()])
+    nt.assert_array_almost_equal(r1.jacobe(q), LIT["G11_dh_rprp_jacobe"], decimal=4)       # :453-479
+
+
+def test_G9_puma_rne_literals_and_traj_and_reinit():
+    puma = rtbhip.models.DH.Puma560()
+    z, o = np.zeros(6), np.ones(6)
+    qn = puma.qn
+    nt.assert_array_almost_equal(puma.rne(qn, z, z), LIT["G9_puma_rne_tr0"], decimal=4)    # test_DHRobot.py:1036-1062
+    nt.assert_array_almost_equal(puma.rne(qn, z, o), LIT["G9_puma_rne_tr1"], decimal=4)
+    nt.assert_array_almost_equal(puma.rne(qn, o, o), LIT["G9_puma_rne_tr2"], decimal=4)
+    nt.assert_array_almost_equal(puma.rne(qn, o, z), LIT["G9_puma_rne_tr3"], decimal=4)
+    nt.assert_array_almost_equal(puma.rne(qn, o, o, gravity=[0, 0, 0]), LIT["G9_puma_rne_tr4"], decimal=4)
+    nt.assert_array_almost_equal(puma.rne(qn, z, z, fext=LIT["G9_fext"]), LIT["G9_puma_rne_tr5"], decimal=4)
+    t = puma.rne(np.c_[qn, qn].T, np.c_[z, o].T, np.c_[z, o].T)                             # :1064-1076
+    nt.assert_array_almost_equal(t[0], LIT["G9_puma_rne_tr0"], decimal=4)
+    nt.assert_array_almost_equal(t[1], LIT["G9_puma_rne_tr2"], decimal=4)
+    puma.delete_rne()                                                                       # :1078-1090
+    nt.assert_array_almost_equal(puma.rne(qn, z, z), LIT["G9_puma_rne_tr0"], decimal=4)
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+
+
+def test_rne_reference_run_fixtures():
+    puma, pd = rtbhip.models.DH.Puma560(), rtbhip.models.DH.Panda()
+    a = (REF["puma_q"], REF["puma_qd"], REF["puma_qdd"])
+    assert _rel(puma.rne(*a), REF["puma_rne"]) <= 1e-9
+    assert _rel(puma.rne(*a, fext=[1, 2, 3, 1, 2, 3]), REF["puma_rne_fext"]) <= 1e-9
+    assert _rel(puma.rne(*a, gravity=[0, 0, 0]), REF["puma_rne_g0"]) <= 1e-9
+    assert _rel(puma.rne(*a, gravity=[1.5, -2.0, -9.0]), REF["puma_rne_gx"]) <= 1e-9
+    b = (REF["pandadh_q"], REF["pandadh_qd"], REF["pandadh_qdd"])
+    assert _rel(pd.rne(*b), REF["pandadh_rne"]) <= 1e-9
+    assert _rel(pd.rne(*b, fext=[-1, 0.5, 2, 0.3, -0.2, 0.1]), REF["pandadh_rne_fext"]) <= 1e-9
+    # prismatic branches incl. prismatic-first chains, DH and MDH, through the raw C ABI objects
+    import ctypes as C
+    from rtbhip import _lib
+    for name in ("rprp0", "rprp1", "prp0", "prp1"):
+        L = np.ascontiguousarray(REF[name + "_L24"])
+        n = L.shape[0]
+        h = C.c_uint64(0)
+        _lib.check(_lib.lib().rtbhip_dyn_create(_lib.host_ptr(L), n, int(name[-1]), C.byref(h)))
+        q, qd, qdd = (np.ascontiguousarray(REF[name + s]) for s in ("_q", "_qd", "_qdd"))
+        tau = np.empty_like(q)
+        g = np.ascontiguousarray(-np.array([0.5, -1.0, -9.81]))
+        f = np.array([1, 2, 3, 4, 5, 6.0]) if name.startswith("rprp") else None
+        _lib.check(_lib.lib().rtbhip_rne(h.value, _lib.host_ptr(q), _lib.host_ptr(qd), _lib.host_ptr(qdd), q.shape[0],
+                                         _lib.host_ptr(g), _lib.host_ptr(f), _lib.host_ptr(tau), 0, None))
+        assert _rel(tau, REF[name + "_rne"]) <= 1e-9, name
+        _lib.check(_lib.lib().rtbhip_dyn_destroy(h.value))
+
+
+@pytest.mark.parametrize("n", [1, 3, 8, 9, 14])
+def test_rne_link_counts_vs_oracle(n):
+    """n <= 8 takes the register-resident template, n > 8 the run-time-n fallback."""
+    rng = np.random.default_rng(100 + n)
+    for mdh in (0, 1):
+        links = []
+        for j in range(n):
+            kw = dict(a=rng.normal() * 0.2, alpha=rng.normal(), m=abs(rng.normal()) + 0.1, r=rng.normal(size=3) * 0.1,
+                      I=np.abs(rng.normal(size=3)) * 0.1, Jm=1e-4, G=5.0 + j, B=1e-3, Tc=[0.1, -0.1])
+            pris = rng.integers(3) == 0
+            cls = {(0, False): rtbhip.RevoluteDH, (0, True): rtbhip.PrismaticDH,
+                   (1, False): rtbhip.RevoluteMDH, (1, True): rtbhip.PrismaticMDH}[(mdh, bool(pris))]
+            links.append(cls(theta=rng.normal(), **kw) if pris else cls(d=rng.normal() * 0.2, **kw))
+        rob = rtbhip.DHRobot(links, gravity=[0.3, -0.2, -9.81])
+        q, qd, qdd = rng.normal(size=(130, n)), rng.normal(size=(130, n)), rng.normal(size=(130, n))
+        tau = rob.rne(q, qd, qdd, fext=[1, -2, 3, 0.1, 0.2, -0.3])
+        ref = oracle.rne_dh(rob.L24(), mdh, q, qd, qdd, -rob.gravity, [1, -2, 3, 0.1, 0.2, -0.3])
+        assert _rel(tau, ref) <= 1e-9
+
+
+def test_device_tensor_path_matches_host_path():
+    ets = rtbhip.models.Panda().ets()
+    rng = np.random.default_rng(11)
+    q = rng.uniform(-np.pi, np.pi, (5000, 7))
+    Th, Jh = ets.fkine_jacob0(q)
+    qd = torch.from_numpy(q).cuda()
+    Td, Jd = ets.fkine_jacob0(qd)
+    assert Td.is_cuda and Td.shape == (5000, 4, 4) and Jd.shape == (5000, 6, 7)
+    torch.cuda.synchronize()
+    nt.assert_array_equal(Td.cpu().numpy(), Th)
+    nt.assert_array_equal(Jd.cpu().numpy(), Jh)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):                      # launches follow torch's current stream
+        T2 = ets.eval(qd)
+    s.synchronize()
+    nt.assert_array_equal(T2.cpu().numpy(), Th)
+
+
+def test_fleet_one_launch_many_chains():
+    rng = np.random.default_rng(21)
+    panda = rtbhip.models.Panda().ets()
+    puma = rtbhip.models.DH.Puma560().ets()
+    mixed = product_ets(mixed_spec())
+    chs = [panda, puma, mixed, panda]
+    och = [chains.panda_ets(), chains.puma560().ets(), chains.Chain(mixed_spec()), chains.panda_ets()]
+    qs = [rng.normal(size=(N, c.n)) for N, c in zip((1000, 65, 1, 129), chs)]
+    Ts, Js = rtbhip.fleet_fkine_jacob(chs, qs)
+    for T, J, oc, q in zip(Ts, Js, och, qs):
+        nt.assert_allclose(T, oracle.fkine(oc, q), atol=TOL)
+        nt.assert_allclose(J, oracle.jacob0(oc, q), atol=TOL)
+
+
+def test_full_size_1e6_properties_and_sampled_parity():
+    """BASELINE configs[1] at full size: N = 1e6, device resident.  Size-independent properties +
+    oracle parity on a strided sample."""
+    N = 1000000
+    ets = rtbhip.models.Panda().ets()
+    ch = chains.panda_ets()
+    rng = np.random.default_rng(0)
+    qh = rng.uniform(-np.pi, np.pi, (N, 7))
+    q = torch.from_numpy(qh).cuda()
+    T, J0 = ets.fkine_jacob0(q)
+    _, Je = ets.fkine_jacob0(q, frame=1)
+    R = T[:, :3, :3]
+    eye = torch.eye(3, dtype=torch.float64, device="cuda")
+    assert float((R @ R.transpose(1, 2) - eye).abs().max()) < 1e-13                      # rotations stay orthonormal
+    assert float((torch.linalg.det(R) - 1).abs().max()) < 1e-13
+    assert bool((T[:, 3, :] == torch.tensor([0, 0, 0, 1.0], dtype=torch.float64, device="cuda")).all())
+    # jacobe == blkdiag(R^T, R^T) jacob0 for every configuration
+    Jv = R.transpose(1, 2) @ J0[:, :3, :]
+    Jw = R.transpose(1, 2) @ J0[:, 3:, :]
+    assert float((torch.cat([Jv, Jw], dim=1) - Je).abs().max()) < 1e-12
+    # Jacobian is the derivative of fkine: central difference on joint 3 for a strided sample
+    idx = torch.arange(0, N, 9973, device="cuda")
+    h = 1e-6
+    dq = torch.zeros(7, dtype=torch.float64, device="cuda"); dq[3] = h
+    Tp, Tm = ets.eval(q[idx] + dq), ets.eval(q[idx] - dq)
+    assert float(((Tp[:, :3, 3] - Tm[:, :3, 3]) / (2 * h) - J0[idx, :3, 3]).abs().max()) < 1e-7
+    # idempotence: a second launch writes bit-identical output
+    T2, J2 = ets.fkine_jacob0(q)
+    assert bool((T2 == T).all()) and bool((J2 == J0).all())
+    sel = np.arange(0, N, 997)
+    nt.assert_allclose(T[sel].cpu().numpy(), oracle.fkine(ch, qh[sel]), atol=TOL)
+    nt.assert_allclose(J0[sel].cpu().numpy(), oracle.jacob0(ch, qh[sel]), atol=TOL)
+
+
+def test_full_size_rne_1e6_sampled_parity_and_linearity():
+    """BASELINE configs[3] per-GPU share (1.25e6 of the 1e7 triples), DH Panda."""
+    N = 1250000
+    pd = rtbhip.models.DH.Panda()
+    tab = chains.panda_dh()
+    rng = np.random.default_rng(3)
+    qh = rng.uniform(tab.qlim[:, 0], tab.qlim[:, 1], (N, 7))
+    qdh, qddh = rng.normal(size=(N, 7)), rng.normal(size=(N, 7))
+    q, qd, qdd = (torch.from_numpy(x).cuda() for x in (qh, qdh, qddh))
+    tau = pd.rne(q, qd, qdd)
+    sel = np.arange(0, N, 1249)
+    ref = oracle.rne_dh(tab.L24(), 1, qh[sel], qdh[sel], qddh[sel], -tab.gravity)
+    assert _rel(tau[sel].cpu().numpy(), ref) <= 1e-9
+    # inverse dynamics is affine in qdd at fixed (q, qd): tau(qdd1+qdd2) - tau(qdd1) == tau(qdd2) - tau(0)
+    z = torch.zeros_like(qdd)
+    lhs = pd.rne(q, qd, qdd + 1.0) - tau
+    rhs = pd.rne(q, qd, z + 1.0) - pd.rne(q, qd, z)
+    assert float((lhs - rhs).abs().max()) < 1e-9
