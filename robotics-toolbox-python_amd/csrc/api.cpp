@@ -44,25 +44,47 @@ Dyn *dyn_from_handle(rtbhip_dyn_t h)
     return it == g_dyns.end() ? nullptr : it->second.get();
 }
 
-int chain_device_ops(Chain *c, const DevOp **out, const double **qlim_out)
+static DevChain view_of(const Chain *c, const void *base)
+{
+    DevChain v;
+    const char *p = (const char *)base;
+    v.seg = (const DevSeg *)p;
+    p += c->seg.size() * sizeof(DevSeg);
+    v.jmeta = (const int32_t *)p;
+    return v;
+}
+
+DevChain chain_host_view(const Chain *c)
+{
+    DevChain v;
+    v.seg = c->seg.data();
+    v.jmeta = c->jmeta.data();
+    return v;
+}
+
+int chain_device_ops(Chain *c, DevChain *out, const double **qlim_out)
 {
     int dev = 0;
     RTB_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(c->mu);
     auto it = c->dev_ops.find(dev);
     if (it == c->dev_ops.end()) {
-        DevOp *d = nullptr;
+        std::vector<char> blob(c->seg.size() * sizeof(DevSeg) + c->jmeta.size() * sizeof(int32_t) + 16, 0);
+        char *w = blob.data();
+        std::memcpy(w, c->seg.data(), c->seg.size() * sizeof(DevSeg));
+        w += c->seg.size() * sizeof(DevSeg);
+        if (!c->jmeta.empty()) std::memcpy(w, c->jmeta.data(), c->jmeta.size() * sizeof(int32_t));
+        void *d = nullptr;
         double *ql = nullptr;
-        size_t bytes = (c->ops.size() ? c->ops.size() : 1) * sizeof(DevOp);
-        RTB_HIP(hipMalloc((void **)&d, bytes));
-        if (!c->ops.empty()) RTB_HIP(hipMemcpy(d, c->ops.data(), c->ops.size() * sizeof(DevOp), hipMemcpyHostToDevice));
+        RTB_HIP(hipMalloc(&d, blob.size()));
+        RTB_HIP(hipMemcpy(d, blob.data(), blob.size(), hipMemcpyHostToDevice));
         RTB_HIP(hipMalloc((void **)&ql, (c->qlim.size() ? c->qlim.size() : 1) * sizeof(double)));
         if (!c->qlim.empty()) RTB_HIP(hipMemcpy(ql, c->qlim.data(), c->qlim.size() * sizeof(double), hipMemcpyHostToDevice));
         c->dev_ops[dev] = d;
         c->dev_qlim[dev] = ql;
         it = c->dev_ops.find(dev);
     }
-    *out = it->second;
+    *out = view_of(c, it->second);
     if (qlim_out) *qlim_out = c->dev_qlim[dev];
     return RTBHIP_OK;
 }
@@ -154,7 +176,7 @@ static int kin_entry(const char *fn, rtbhip_chain_t h, const double *q, int64_t 
     if (frame != 0 && frame != 1) { set_error(std::string(fn) + ": frame must be 0 (jacob0) or 1 (jacobe)"); return RTBHIP_EINVAL; }
     if (N > 0 && !T && !J && !H) { set_error(std::string(fn) + ": no output buffer"); return RTBHIP_EINVAL; }
     if (N == 0) return RTBHIP_OK;
-    const DevOp *ops = nullptr;
+    DevChain ops;
     RTB_TRY(chain_device_ops(c, &ops, nullptr));
     Affine base = affine_from16(base16), tool = affine_from16(tool16);
     const size_t n = (size_t)c->n, qw = (size_t)c->q_width;
@@ -227,7 +249,7 @@ int rtbhip_chain_info(rtbhip_chain_t chain, int32_t *n, int32_t *m, int32_t *q_w
     Chain *c = chain_from_handle(chain);
     if (!c) { set_error("chain_info: unknown handle"); return RTBHIP_EINVAL; }
     if (n) *n = c->n;
-    if (m) *m = (int32_t)c->ops.size();
+    if (m) *m = (int32_t)c->ets.size();
     if (q_width) *q_width = c->q_width;
     return RTBHIP_OK;
 }
@@ -281,7 +303,7 @@ int rtbhip_ik_lm(rtbhip_chain_t chain, const double *Tep, int64_t N, const doubl
     p.ilimit = ilimit; p.slimit = slimit; p.reject_jl = reject_jl ? 1 : 0; p.method = method;
     p.flavour = flavour; p.tol = tol; p.lambda = lambda; p.seed = seed;
     for (int i = 0; i < 6; i++) p.we[i] = we6 ? we6[i] : 1.0;
-    const DevOp *ops = nullptr;
+    DevChain ops;
     const double *qlim = nullptr;
     RTB_TRY(chain_device_ops(c, &ops, &qlim));
     const size_t n = (size_t)c->n;
@@ -402,9 +424,9 @@ int rtbhip_fleet_fkine_jacob(const rtbhip_chain_t *chains, int32_t n_chains, con
         if (N[i] == 0) continue;
         if (!q[i] || !T[i] || !J[i]) { set_error("fleet: NULL buffer"); return RTBHIP_EINVAL; }
         FleetEntry e;
-        RTB_TRY(chain_device_ops(c, &e.ops, nullptr));
-        e.m = (int32_t)c->ops.size(); e.n = c->n; e.q_width = c->q_width; e.N = N[i]; e.tile0 = tile0;
-        e.stride = 0;
+        RTB_TRY(chain_device_ops(c, &e.dc, nullptr));
+        e.n = c->n; e.q_width = c->q_width; e.N = N[i]; e.tile0 = tile0;
+        e.stride = 0; e.pad = 0;
         if (mem == RTBHIP_MEM_DEVICE) {
             e.q = q[i]; e.T = T[i]; e.J = J[i];
         } else {

@@ -1,13 +1,18 @@
 // chain.cpp -- host-side "chain compiler": lowers the elementary-transform list that the
 // reference keeps as ET/ETS structs (core/structs.h:25-56, built by ET_init fknm.cpp:1182-1239
-// and ETS_init fknm.cpp:1066-1114) to the flat device program the kernels interpret.
+// and ETS_init fknm.cpp:1066-1114) to the canonical segment form the kernels execute
+// (see rtbhip_internal.h).
 //
-// Design (MI355X-first, not a translation): the reference multiplies a full 4x4 for every ET
-// (methods.cpp:334-341).  Here each ET is classified once, on the host, into the cheapest update of
-// a 3x4 affine pose held in registers: a constant rotation about one axis touches two columns
-// (12 flops), a single-axis translation one column (3 FMAs), a general constant the full 36.  Runs of
-// adjacent constants are folded into one op when -- and only when -- the folded op is cheaper than
-// the specialised sequence (the reference's ETS.compile(), robot/ETS.py:857-906, always folds).
+// Design (MI355X-first, not a translation): the reference walks m ETs, building and multiplying a
+// full 4x4 for each (methods.cpp:334-341) behind a function pointer per ET.  A GPU wants the
+// opposite: no per-ET dispatch at all.  So (1) every run of constant ETs is folded into ONE affine
+// (what the reference's optional ETS.compile() does, robot/ETS.py:857-906), and (2) every joint is
+// rewritten to act on the local z axis: Rx(q) = M Rz(q) M^T and tx(q) = M tz(q) M^T for the cyclic
+// axis permutation M that maps z to x (similarly y); M and M^T are absorbed into the constants on
+// either side -- a column / row permutation, exact in floating point.  The device code is then the
+// same straight-line sequence for every chain: n x { P <- P*C_j ; note axis and origin ;
+// rotate two columns by q_j or slide along one }, then P <- P*C_n.
+// Folding re-associates the constant products (rounding ~1e-16, against a 1e-10 parity budget).
 #include "rtbhip_internal.h"
 #include <cmath>
 #include <cstring>
@@ -16,22 +21,17 @@ namespace rtbhip {
 
 namespace {
 
-struct Aff {  // row-major 3x4
-    double r[9];
-    double t[3];
-};
-
-Aff aff_identity()
+DevSeg seg_identity()
 {
-    Aff a;
+    DevSeg a;
     for (int i = 0; i < 9; i++) a.r[i] = (i % 4 == 0) ? 1.0 : 0.0;
     a.t[0] = a.t[1] = a.t[2] = 0.0;
     return a;
 }
 
-Aff aff_mul(const Aff &A, const Aff &B)
+DevSeg seg_mul(const DevSeg &A, const DevSeg &B)
 {
-    Aff C;
+    DevSeg C;
     for (int i = 0; i < 3; i++) {
         for (int j = 0; j < 3; j++) {
             double s = 0.0;
@@ -45,78 +45,32 @@ Aff aff_mul(const Aff &A, const Aff &B)
     return C;
 }
 
-bool rot_is_identity(const Aff &a)
+// cyclic axis permutation M_a with M_a e_z = e_a (a = 0 x, 1 y, 2 z); perm[c] = row holding the 1 of column c
+void axis_perm(int a, int perm[3])
 {
-    for (int i = 0; i < 9; i++)
-        if (a.r[i] != ((i % 4 == 0) ? 1.0 : 0.0)) return false;
-    return true;
+    // z -> a, x -> a+1, y -> a+2 (cyclic, det +1)
+    perm[2] = a;
+    perm[0] = (a + 1) % 3;
+    perm[1] = (a + 2) % 3;
 }
 
-// exact structural test for a rotation about coordinate axis k (what trotx/y/z produce)
-bool rot_about_axis(const Aff &a, int k, double *c, double *s)
+// A <- A * M  (columns of R permuted: new column c = old column perm[c]) -- exact
+DevSeg right_perm(const DevSeg &A, const int perm[3])
 {
-    int b = (k + 1) % 3, d = (k + 2) % 3;
-    const double *r = a.r;
-    if (r[3 * k + k] != 1.0) return false;
-    if (r[3 * k + b] != 0.0 || r[3 * k + d] != 0.0 || r[3 * b + k] != 0.0 || r[3 * d + k] != 0.0)
-        return false;
-    if (r[3 * b + b] != r[3 * d + d]) return false;
-    if (r[3 * b + d] != -r[3 * d + b]) return false;
-    *c = r[3 * b + b];
-    *s = r[3 * d + b];
-    return true;
+    DevSeg O = A;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) O.r[3 * r + c] = A.r[3 * r + perm[c]];
+    return O;
 }
 
-// Lower one constant affine to 0..2 device ops; returns the flop cost it adds.
-int emit_const(const Aff &a, std::vector<DevOp> *out)
+// returns M^T as a segment (to be left-multiplied into the next constant run) -- entries 0/1
+DevSeg perm_transpose_seg(const int perm[3])
 {
-    DevOp op;
-    std::memset(&op, 0, sizeof op);
-    bool t0 = (a.t[0] == 0.0 && a.t[1] == 0.0 && a.t[2] == 0.0);
-    if (rot_is_identity(a)) {
-        int nz = (a.t[0] != 0.0) + (a.t[1] != 0.0) + (a.t[2] != 0.0);
-        if (nz == 0) return 0;  // identity: nothing to do
-        if (nz == 1) {
-            int k = (a.t[0] != 0.0) ? 0 : (a.t[1] != 0.0) ? 1 : 2;
-            op.kind = K_CTX + k;
-            op.p[0] = a.t[k];
-            if (out) out->push_back(op);
-            return 3;
-        }
-        op.kind = K_CT3;
-        op.p[0] = a.t[0]; op.p[1] = a.t[1]; op.p[2] = a.t[2];
-        if (out) out->push_back(op);
-        return 9;
-    }
-    if (t0) {
-        for (int k = 0; k < 3; k++) {
-            double c, s;
-            if (rot_about_axis(a, k, &c, &s)) {
-                op.kind = K_CRX + k;
-                op.p[0] = c; op.p[1] = s;
-                if (out) out->push_back(op);
-                return 12;
-            }
-        }
-    }
-    op.kind = K_CGEN;
-    for (int i = 0; i < 9; i++) op.p[i] = a.r[i];
-    for (int i = 0; i < 3; i++) op.p[9 + i] = a.t[i];
-    if (out) out->push_back(op);
-    return 36;
-}
-
-void flush_run(std::vector<Aff> *run, std::vector<DevOp> *ops)
-{
-    if (run->empty()) return;
-    int separate = 0;
-    for (const Aff &a : *run) separate += emit_const(a, nullptr) + 2;  // +2: interpreter dispatch
-    Aff folded = (*run)[0];
-    for (size_t i = 1; i < run->size(); i++) folded = aff_mul(folded, (*run)[i]);
-    int together = emit_const(folded, nullptr) + 2;
-    if (together < separate) emit_const(folded, ops);
-    else for (const Aff &a : *run) emit_const(a, ops);
-    run->clear();
+    DevSeg O;
+    std::memset(&O, 0, sizeof O);
+    // M[perm[c]][c] = 1  =>  M^T[c][perm[c]] = 1
+    for (int c = 0; c < 3; c++) O.r[3 * c + perm[c]] = 1.0;
+    return O;
 }
 
 }  // namespace
@@ -126,8 +80,10 @@ int compile_chain(const rtbhip_et *ets, int m, const double *qlim, Chain *out)
     if (m < 0 || (m > 0 && ets == nullptr)) { set_error("chain_create: bad ets/m"); return RTBHIP_EINVAL; }
     if (m > RTBHIP_MAX_ETS) { set_error("chain_create: more than RTBHIP_MAX_ETS transforms"); return RTBHIP_ELIMIT; }
     out->ets.assign(ets, ets + m);
-    out->ops.clear();
-    std::vector<Aff> run;
+    out->seg.clear();
+    out->jmeta.clear();
+    DevSeg cur = seg_identity();  // constant run being accumulated
+    bool cur_is_identity = true;
     int n = 0, qw = 0;
     std::vector<double> lo, hi;
     for (int i = 0; i < m; i++) {
@@ -138,37 +94,38 @@ int compile_chain(const rtbhip_et *ets, int m, const double *qlim, Chain *out)
                           " is not affine (bottom row must be 0 0 0 1)");
                 return RTBHIP_EINVAL;
             }
-            Aff a;
+            DevSeg a;
             for (int r = 0; r < 3; r++) {
                 for (int c = 0; c < 3; c++) a.r[3 * r + c] = e.T[4 * r + c];
                 a.t[r] = e.T[4 * r + 3];
             }
-            run.push_back(a);
+            cur = cur_is_identity ? a : seg_mul(cur, a);
+            cur_is_identity = false;
             continue;
         }
         if (e.kind < 0 || e.kind > 5) {
             set_error("chain_create: unknown transform kind " + std::to_string(e.kind));
             return RTBHIP_EINVAL;
         }
-        if (e.jindex < 0 || e.jindex >= 4 * RTBHIP_MAX_JOINTS) {
-            set_error("chain_create: jindex out of range");
+        if (e.jindex < 0 || e.jindex > 255) {
+            set_error("chain_create: jindex out of range (0..255)");
             return RTBHIP_EINVAL;
         }
-        flush_run(&run, &out->ops);
-        DevOp op;
-        std::memset(&op, 0, sizeof op);
-        op.kind = e.kind;  // K_JRX.. == RTBHIP_ET_RX..
-        op.jq = e.jindex;
-        op.jcol = n++;
-        op.flip = e.flip ? 1 : 0;
-        out->ops.push_back(op);
+        if (n == RTBHIP_MAX_JOINTS) { set_error("chain_create: more than RTBHIP_MAX_JOINTS joints"); return RTBHIP_ELIMIT; }
+        const int axis = e.kind % 3;
+        const bool prismatic = e.kind >= 3;
+        int perm[3];
+        axis_perm(axis, perm);
+        out->seg.push_back(axis == 2 ? cur : right_perm(cur, perm));   // C_j * M_a
+        out->jmeta.push_back((prismatic ? 1 : 0) | (e.jindex << 8) | ((e.flip ? 1 : 0) << 16));
+        if (axis == 2) { cur = seg_identity(); cur_is_identity = true; }
+        else { cur = perm_transpose_seg(perm); cur_is_identity = false; }  // M_a^T starts the next run
+        n++;
         if (e.jindex + 1 > qw) qw = e.jindex + 1;
-        bool rot = e.kind <= 2;  // default limits: robot/ET.py:109-115
-        lo.push_back(rot ? -M_PI : 0.0);
-        hi.push_back(rot ? M_PI : 1.0);
+        lo.push_back(prismatic ? 0.0 : -M_PI);  // default limits: robot/ET.py:109-115
+        hi.push_back(prismatic ? 1.0 : M_PI);
     }
-    flush_run(&run, &out->ops);
-    if (n > RTBHIP_MAX_JOINTS) { set_error("chain_create: more than RTBHIP_MAX_JOINTS joints"); return RTBHIP_ELIMIT; }
+    out->seg.push_back(cur);  // C_n (identity when the chain ends with a z joint)
     out->n = n;
     out->q_width = qw;
     out->qlim.resize(2 * (size_t)n);
@@ -177,6 +134,19 @@ int compile_chain(const rtbhip_et *ets, int m, const double *qlim, Chain *out)
         out->qlim[n + j] = qlim ? qlim[n + j] : hi[j];
     }
     return RTBHIP_OK;
+}
+
+// tail = C_n * tool (per-call tool folded on the host; tool may be unused => C_n)
+void chain_tail(const Chain *c, const Affine &tool, double out12[12])
+{
+    DevSeg t;
+    for (int r = 0; r < 3; r++) {
+        for (int k = 0; k < 3; k++) t.r[3 * r + k] = tool.v[4 * r + k];
+        t.t[r] = tool.v[4 * r + 3];
+    }
+    DevSeg res = tool.used ? seg_mul(c->seg.back(), t) : c->seg.back();
+    for (int i = 0; i < 9; i++) out12[i] = res.r[i];
+    for (int i = 0; i < 3; i++) out12[9 + i] = res.t[i];
 }
 
 }  // namespace rtbhip

@@ -2,7 +2,7 @@
 #include "rtbhip_internal.h"
 namespace rtbhip {
 void ik_tune(const char *, int) {}
-int launch_ik(const Chain *, const DevOp *, const double *, const double *, int64_t, const double *, const IkParams &,
+int launch_ik(const Chain *, const DevChain &, const double *, const double *, int64_t, const double *, const IkParams &,
               double *, int32_t *, int32_t *, int32_t *, double *, hipStream_t)
 {
     set_error("ik_lm: not built yet");

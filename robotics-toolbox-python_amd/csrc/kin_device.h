@@ -19,6 +19,7 @@
 #include <cmath>
 
 #define RTB_HD __host__ __device__ __forceinline__
+#include "trig.h"
 
 namespace rtbhip {
 
@@ -101,75 +102,63 @@ RTB_HD void pose_premul(Pose &P, const double *a /* row-major 3x4 */)
     P = O;
 }
 
-// ---------------------------------------------------------------- the chain walk
-// Interprets the device program for ONE lane.  `ops` is wave-uniform (scalar loads on the GPU).
-//   qcol(c)       -> joint coordinate column c of this lane's configuration
-//   rec(slot, v)  -> per-lane Jacobian scratch write; slot = r*n + jcol holds p_j (r=0..2) and
-//                    z_j (r=3..5), i.e. exactly where row r of column jcol of the finished J lives.
-// WANT_J = false skips the recording (pure fkine).
-template <bool WANT_J, class OpsP, class QCol, class Rec>
-RTB_HD void chain_walk(OpsP ops, int m, int n, Pose &P, QCol qcol, Rec rec)
+// P <- P * C for a constant segment read through a wave-uniform table
+template <class CV>
+RTB_HD void pose_mul_seg(Pose &P, const CV &cv, int j)
 {
-    for (int i = 0; i < m; ++i) {
-        const int kind = ops[i].kind;
-        if (kind <= K_JTZ) {
-            double eta = qcol(ops[i].jq);
-            if (ops[i].flip) eta = -eta;  // methods.cpp:363-366
-            const int j = ops[i].jcol;
-            if (kind <= K_JRZ) {
-                double s, c;
-                sincos(eta, &s, &c);  // accurate fp64 path (no fast-math): fknm.cpp:1324-1325
-                if (kind == K_JRX) {
-                    if (WANT_J) { rec(3 * n + j, P.r00); rec(4 * n + j, P.r10); rec(5 * n + j, P.r20); }
-                    pose_rotx(P, c, s);
-                } else if (kind == K_JRY) {
-                    if (WANT_J) { rec(3 * n + j, P.r01); rec(4 * n + j, P.r11); rec(5 * n + j, P.r21); }
-                    pose_roty(P, c, s);
-                } else {
-                    if (WANT_J) { rec(3 * n + j, P.r02); rec(4 * n + j, P.r12); rec(5 * n + j, P.r22); }
-                    pose_rotz(P, c, s);
-                }
-                if (WANT_J) { rec(j, P.tx); rec(n + j, P.ty); rec(2 * n + j, P.tz); }
-            } else {
-                if (kind == K_JTX) {
-                    if (WANT_J) { rec(3 * n + j, P.r00); rec(4 * n + j, P.r10); rec(5 * n + j, P.r20); }
-                    pose_tx(P, eta);
-                } else if (kind == K_JTY) {
-                    if (WANT_J) { rec(3 * n + j, P.r01); rec(4 * n + j, P.r11); rec(5 * n + j, P.r21); }
-                    pose_ty(P, eta);
-                } else {
-                    if (WANT_J) { rec(3 * n + j, P.r02); rec(4 * n + j, P.r12); rec(5 * n + j, P.r22); }
-                    pose_tz(P, eta);
-                }
-            }
+    pose_mul_general(P, [&](int k) { return k < 9 ? cv.seg[j].r[k] : cv.seg[j].t[k - 9]; });
+}
+template <class CV>
+RTB_HD void pose_from_seg(Pose &P, const CV &cv, int j)
+{
+    P.r00 = cv.seg[j].r[0]; P.r01 = cv.seg[j].r[1]; P.r02 = cv.seg[j].r[2];
+    P.r10 = cv.seg[j].r[3]; P.r11 = cv.seg[j].r[4]; P.r12 = cv.seg[j].r[5];
+    P.r20 = cv.seg[j].r[6]; P.r21 = cv.seg[j].r[7]; P.r22 = cv.seg[j].r[8];
+    P.tx = cv.seg[j].t[0]; P.ty = cv.seg[j].t[1]; P.tz = cv.seg[j].t[2];
+}
+
+// ---------------------------------------------------------------- the chain walk (run-time n)
+// Executes the canonical segment form  C_0 Z_0(q) C_1 ... Z_{n-1}(q) * tail  for ONE lane
+// (tail = C_n * tool, folded on the host).
+//   qcol(c)       -> joint coordinate column c of this lane's configuration
+//   rec(slot, v)  -> per-lane Jacobian scratch write; slot = r*n + j holds p_j (r=0..2) and
+//                    z_j (r=3..5), i.e. exactly where row r of column j of the finished J lives.
+// WANT_J = false skips the recording (pure fkine).
+template <bool WANT_J, class CV, class QCol, class Rec>
+RTB_HD void chain_walk(const CV &cv, int n, const double *tail, Pose &P, QCol qcol, Rec rec)
+{
+    pose_identity(P);
+    for (int j = 0; j < n; ++j) {
+        if (j == 0) pose_from_seg(P, cv, 0); else pose_mul_seg(P, cv, j);
+        const int jm = cv.jmeta[j];
+        double eta = qcol(jm_jq(jm));
+        if (jm_flip(jm)) eta = -eta;  // methods.cpp:363-366
+        if (WANT_J) {
+            rec(j, P.tx); rec(n + j, P.ty); rec(2 * n + j, P.tz);
+            rec(3 * n + j, P.r02); rec(4 * n + j, P.r12); rec(5 * n + j, P.r22);
+        }
+        if (jm_prismatic(jm)) {
+            pose_tz(P, eta);
         } else {
-            switch (kind) {
-            case K_CRX: pose_rotx(P, ops[i].p[0], ops[i].p[1]); break;
-            case K_CRY: pose_roty(P, ops[i].p[0], ops[i].p[1]); break;
-            case K_CRZ: pose_rotz(P, ops[i].p[0], ops[i].p[1]); break;
-            case K_CTX: pose_tx(P, ops[i].p[0]); break;
-            case K_CTY: pose_ty(P, ops[i].p[0]); break;
-            case K_CTZ: pose_tz(P, ops[i].p[0]); break;
-            case K_CT3: pose_t3(P, ops[i].p[0], ops[i].p[1], ops[i].p[2]); break;
-            default: pose_mul_general(P, [&](int k) { return ops[i].p[k]; }); break;
-            }
+            double s, c;
+            rtb_sincos(eta, &s, &c);  // full fp64 accuracy (trig.h), no fast-math: fknm.cpp:1324-1325
+            pose_rotz(P, c, s);
         }
     }
+    pose_mul_general(P, [&](int k) { return tail[k]; });
 }
 
 // Closes the Jacobian columns in place in the per-lane scratch once the end-effector pose P is
 // known: frame 0 -> jacob0, frame 1 -> jacobe (= blkdiag(Re^T, Re^T) jacob0).
 //   get(slot) / put(slot, v) : per-lane scratch access.
-template <class OpsP, class Get, class Put>
-RTB_HD void jacobian_close(OpsP ops, int m, int n, const Pose &P, int frame, Get get, Put put)
+template <class CV, class Get, class Put>
+RTB_HD void jacobian_close(const CV &cv, int n, const Pose &P, int frame, Get get, Put put)
 {
-    for (int i = 0; i < m; ++i) {
-        const int kind = ops[i].kind;
-        if (kind > K_JTZ) continue;
-        const int j = ops[i].jcol;
+    for (int j = 0; j < n; ++j) {
+        const int jm = cv.jmeta[j];
         double zx = get(3 * n + j), zy = get(4 * n + j), zz = get(5 * n + j);
         double vx, vy, vz, wx, wy, wz;
-        if (kind <= K_JRZ) {
+        if (!jm_prismatic(jm)) {
             double dx = P.tx - get(j), dy = P.ty - get(n + j), dz = P.tz - get(2 * n + j);
             vx = zy * dz - zz * dy;
             vy = zz * dx - zx * dz;
@@ -179,7 +168,7 @@ RTB_HD void jacobian_close(OpsP ops, int m, int n, const Pose &P, int frame, Get
             vx = zx; vy = zy; vz = zz;
             wx = 0.0; wy = 0.0; wz = 0.0;
         }
-        if (ops[i].flip) {  // methods.cpp:142-145,172-175
+        if (jm_flip(jm)) {  // methods.cpp:142-145,172-175
             vx = -vx; vy = -vy; vz = -vz;
             wx = -wx; wy = -wy; wz = -wz;
         }

@@ -9,23 +9,35 @@
 // The chain program is read through the constant address space => s_load into SGPRs.
 // Roofline: HBM-bound by construction -- 8*qw bytes in, 128 + 48n bytes out per configuration
 // (520 B for the Panda), ~0.6 kflop of fp64 VALU + n sincos per configuration.
-#include "kin_tile.h"
+#include "kin_reg.h"
 #include <algorithm>
 #include <cstring>
 
 namespace rtbhip {
 
-typedef const __attribute__((address_space(4))) DevOp *ConstOps;
+// The chain tables through the constant address space: uniform loads become s_load (SGPR operands).
+#define RTB_CONST __attribute__((address_space(4)))
+struct ConstChain {
+    const RTB_CONST DevSeg *seg;
+    const RTB_CONST int32_t *jmeta;
+};
+__device__ __forceinline__ ConstChain const_view(const DevChain &dc)
+{
+    ConstChain cv;
+    cv.seg = (const RTB_CONST DevSeg *)dc.seg;
+    cv.jmeta = (const RTB_CONST int32_t *)dc.jmeta;
+    return cv;
+}
 
 template <bool WANT_T, bool WANT_J, bool WANT_H, bool COALESCED>
-__global__ __launch_bounds__(kWave) void k_kin(KinParams kp, const DevOp *ops_g,
+__global__ __launch_bounds__(kWave) void k_kin(KinParams kp, DevChain dc,
                                               const double *__restrict__ q, double *__restrict__ T,
                                               double *__restrict__ J, double *__restrict__ H)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *rows = lds;
     double *qs = lds + kWave * kp.stride;
-    ConstOps ops = (ConstOps)ops_g;
+    const ConstChain ops = const_view(dc);
     const int lane = threadIdx.x;
     const int64_t tiles = (kp.N + kWave - 1) / kWave;
     const int W = 6 * kp.n;
@@ -63,9 +75,48 @@ __global__ __launch_bounds__(kWave) void k_kin(KinParams kp, const DevOp *ops_g,
     }
 }
 
+// ---------------------------------------------------------------- register-resident variant (n <= 8)
+template <int NJ, bool WANT_T, bool WANT_J>
+__global__ __launch_bounds__(kWave) void k_kin_reg(KinParams kp, DevChain dc, const double *__restrict__ q,
+                                                  double *__restrict__ T, double *__restrict__ J)
+{
+    extern __shared__ __attribute__((aligned(16))) double buf[];
+    const ConstChain cv = const_view(dc);
+    const int lane = threadIdx.x;
+    constexpr int W = 6 * NJ;
+    // ONE tile per single-wave workgroup, no grid-stride loop: with a loop LICM hoists every
+    // segment's (loop-invariant) scalar loads into the preheader, where they overflow the SGPR file
+    // and come back as v_readlane pairs on each use.  The dispatcher balances the tiles instead.
+    {
+        const int64_t cfg0 = (int64_t)blockIdx.x * kWave;
+        const int64_t left = kp.N - cfg0;
+        const int ncfg = left < kWave ? (int)left : kWave;
+        Pose P;
+        double jac[6 * NJ];
+        reg_compute<NJ, WANT_J>(kp, cv, q, cfg0 + lane, P, jac);
+        if (WANT_J) {
+#pragma unroll
+            for (int r = 0; r < kWave / kJRound; ++r) {
+                if (lane / kJRound == r) reg_stage_J<NJ>(jac, buf, lane % kJRound);
+                __syncthreads();
+                int rows = ncfg - r * kJRound;
+                rows = rows < 0 ? 0 : (rows > kJRound ? kJRound : rows);
+                kin_flush(buf, W + 1, W, rows, J + (cfg0 + r * kJRound) * W, lane);
+                __syncthreads();
+            }
+        }
+        if (WANT_T) {
+            reg_stage_T(kp, P, buf, lane);
+            __syncthreads();
+            kin_flush(buf, 17, 16, ncfg, T + cfg0 * 16, lane);
+        }
+    }
+}
+
 namespace {
 int g_coalesced = 1;   // tuning knobs (rtbhip_tune)
 int g_tiles_per_wave = 1;
+int g_use_reg = 1;
 }  // namespace
 
 void kin_tune(const char *key, int value)
@@ -73,11 +124,12 @@ void kin_tune(const char *key, int value)
     std::string k(key);
     if (k == "coalesced") g_coalesced = value;
     if (k == "tiles_per_wave") g_tiles_per_wave = value < 1 ? 1 : value;
+    if (k == "reg") g_use_reg = value;
 }
 
 template <bool WT, bool WJ, bool WH>
 static hipError_t launch_variant(bool coalesced, dim3 grid, size_t lds, hipStream_t s, const KinParams &kp,
-                                 const DevOp *ops, const double *q, double *T, double *J, double *H)
+                                 const DevChain &ops, const double *q, double *T, double *J, double *H)
 {
     if (coalesced) {
         auto k = k_kin<WT, WJ, WH, true>;
@@ -97,27 +149,54 @@ static hipError_t launch_variant(bool coalesced, dim3 grid, size_t lds, hipStrea
     return hipGetLastError();
 }
 
-int launch_kin(const Chain *c, const DevOp *ops, const double *q, int64_t N, const Affine &base,
+template <int NJ>
+static hipError_t launch_reg(dim3 grid, size_t lds, hipStream_t s, const KinParams &kp, const DevChain &dc,
+                             const double *q, double *T, double *J)
+{
+    if (T && J) hipLaunchKernelGGL((k_kin_reg<NJ, true, true>), grid, dim3(kWave), lds, s, kp, dc, q, T, J);
+    else if (T) hipLaunchKernelGGL((k_kin_reg<NJ, true, false>), grid, dim3(kWave), lds, s, kp, dc, q, T, J);
+    else hipLaunchKernelGGL((k_kin_reg<NJ, false, true>), grid, dim3(kWave), lds, s, kp, dc, q, T, J);
+    return hipGetLastError();
+}
+
+int launch_kin(const Chain *c, const DevChain &ops, const double *q, int64_t N, const Affine &base,
                const Affine &tool, int frame, double *T, double *J, double *H, hipStream_t s)
 {
     if (N == 0) return RTBHIP_OK;
     KinParams kp;
-    kp.m = (int)c->ops.size();
     kp.n = c->n;
     kp.qw = c->q_width;
     kp.stride = kin_stride(c->n);
     kp.frame = frame;
     kp.has_base = base.used;
-    kp.has_tool = tool.used;
     kp.pad = 0;
     kp.N = N;
-    for (int i = 0; i < 12; i++) { kp.base[i] = base.v[i]; kp.tool[i] = tool.v[i]; }
-    const size_t lds = kin_lds_bytes(c->n, c->q_width);
-    if (lds > 160 * 1024) { set_error("chain too large for the per-wave LDS staging"); return RTBHIP_ELIMIT; }
+    for (int i = 0; i < 12; i++) kp.base[i] = base.v[i];
+    chain_tail(c, tool, kp.tail);
     const int64_t tiles = (N + kWave - 1) / kWave;
     int64_t g = (tiles + g_tiles_per_wave - 1) / g_tiles_per_wave;
     if (g > 0x7fffffff) g = 0x7fffffff;
     dim3 grid((unsigned)g);
+    if (g_use_reg && !H && c->n >= 1 && c->n <= kRegMaxJoints && tiles <= 0x7fffffff) {
+        grid = dim3((unsigned)tiles);
+        const size_t rl = (size_t)reg_lds_doubles(c->n) * sizeof(double);
+        hipError_t e = hipSuccess;
+        switch (c->n) {
+        case 1: e = launch_reg<1>(grid, rl, s, kp, ops, q, T, J); break;
+        case 2: e = launch_reg<2>(grid, rl, s, kp, ops, q, T, J); break;
+        case 3: e = launch_reg<3>(grid, rl, s, kp, ops, q, T, J); break;
+        case 4: e = launch_reg<4>(grid, rl, s, kp, ops, q, T, J); break;
+        case 5: e = launch_reg<5>(grid, rl, s, kp, ops, q, T, J); break;
+        case 6: e = launch_reg<6>(grid, rl, s, kp, ops, q, T, J); break;
+        case 7: e = launch_reg<7>(grid, rl, s, kp, ops, q, T, J); break;
+        default: e = launch_reg<8>(grid, rl, s, kp, ops, q, T, J); break;
+        }
+        note_launch((int)grid.x, kWave, (int)rl);
+        if (e != hipSuccess) return hip_fail(e, "k_kin_reg launch");
+        return RTBHIP_OK;
+    }
+    const size_t lds = kin_lds_bytes(c->n, c->q_width);
+    if (lds > 160 * 1024) { set_error("chain too large for the per-wave LDS staging"); return RTBHIP_ELIMIT; }
     const bool co = g_coalesced != 0;
     hipError_t e;
     const bool wt = T != nullptr, wj = J != nullptr, wh = H != nullptr;
@@ -154,11 +233,13 @@ __global__ __launch_bounds__(kWave) void k_fleet(FleetArgs fa)
             if (gt >= fa.e[i].tile0) ci = i;
         const FleetEntry &fe = fa.e[ci];
         KinParams kp;
-        kp.m = fe.m; kp.n = fe.n; kp.qw = fe.q_width; kp.stride = fe.stride;
-        kp.frame = fa.frame; kp.has_base = 0; kp.has_tool = 0; kp.pad = 0; kp.N = fe.N;
+        kp.n = fe.n; kp.qw = fe.q_width; kp.stride = fe.stride;
+        kp.frame = fa.frame; kp.has_base = 0; kp.pad = 0; kp.N = fe.N;
+        const ConstChain ops = const_view(fe.dc);
+        for (int k = 0; k < 9; ++k) kp.tail[k] = ops.seg[fe.n].r[k];
+        for (int k = 0; k < 3; ++k) kp.tail[9 + k] = ops.seg[fe.n].t[k];
         double *rows = lds;
         double *qs = lds + kWave * kp.stride;
-        ConstOps ops = (ConstOps)fe.ops;
         const int64_t tile = gt - fe.tile0;
         const int64_t cfg0 = tile * kWave, cfg = cfg0 + lane;
         const int64_t left = kp.N - cfg0;

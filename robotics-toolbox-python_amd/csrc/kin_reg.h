@@ -1,0 +1,127 @@
+// kin_reg.h -- register-resident variant of the fused fkine + Jacobian tile for chains with a
+// compile-time joint count NJ (1..8: every arm of BASELINE.json's configs except the 14-DOF YuMi).
+//
+// Why a second variant: the run-time-n tile (kin_tile.h) keeps the per-joint (p_j, z_j) scratch in
+// LDS because a register array cannot be indexed by a run-time joint number.  That costs 8(6n+qw)
+// bytes of LDS per lane -- 25 KB per wave for the Panda -- which caps a CU at 6 waves and leaves the
+// kernel latency-bound (first MI355X measurement: 0.178 ms / 1e6 configs = 36 % of the HBM roof,
+// ~28k cycles of mostly-stalled wave lifetime).  With NJ a template parameter the canonical
+// segment walk is one straight-line block -- no branches, no interpreter -- in which
+//   * all NJ sin/cos pairs are evaluated up front (NJ independent dependency chains for the
+//     scheduler to interleave) before the pose-dependent products start;
+//   * p_j, z_j, sin_j, cos_j are named registers; q is read straight into registers;
+//   * LDS is only the output transposer, time-shared in rounds of 32 lanes for J and one round of
+//     64 for T: 32*(6n+1)*8 B = 11 KB per wave for n = 7  =>  occupancy is set by VGPRs, not LDS.
+#pragma once
+#include "kin_tile.h"
+#include "trig.h"
+
+namespace rtbhip {
+
+// Keeps the machine scheduler from hoisting every segment's scalar loads to the top of the
+// straight-line walk (which overflows the 102 SGPRs and turns each constant operand into a pair of
+// v_readlane from a spill VGPR): loads of segment j+1 may overlap segment j, not run further ahead.
+RTB_HD void sched_fence()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+constexpr int kRegMaxJoints = 8;
+constexpr int kJRound = 32;  // lanes staged per J round
+
+RTB_HD int reg_lds_doubles(int n)
+{
+    const int a = kJRound * (6 * n + 1), b = kWave * 17;
+    return a > b ? a : b;
+}
+
+// whole per-lane compute of one tile: q -> (P = C_0 Z_0 ... C_n tool, finished J in registers).
+// jac slot r*NJ + j : rows 0..2 = p_j, rows 3..5 = z_j until the closing loop finishes them.
+template <int NJ, bool WANT_J, class CV>
+RTB_HD void reg_compute(const KinParams &kp, const CV &cv, const double *__restrict__ q, int64_t cfg,
+                        Pose &P, double (&jac)[6 * NJ])
+{
+    const bool live = cfg < kp.N;
+    const double *qrow = q + cfg * kp.qw;
+    double c[NJ], s[NJ], d[NJ];
+    // wave-uniform per-joint blend weights (SGPR doubles) instead of per-lane selects:
+    // rv = 1 for a revolute joint, pv = 1 for a prismatic one, sg = -1 where the joint is flipped.
+    double rv[NJ], pv[NJ], sg[NJ];
+    bool big = false;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {   // joint coordinates in chain order (methods.cpp:363-366 for flip)
+        const int jm = cv.jmeta[j];
+        pv[j] = jm_prismatic(jm) ? 1.0 : 0.0;
+        rv[j] = 1.0 - pv[j];
+        sg[j] = jm_flip(jm) ? -1.0 : 1.0;
+        d[j] = (live ? qrow[jm_jq(jm)] : 0.0) * sg[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {   // NJ independent evaluations, one basic block
+        sincos_reduced(d[j], s[j], c[j]);
+        big = big || !(fabs(d[j]) < kTrigFastLimit);
+    }
+    if (wave_any(big)) {             // |q| >= 2^20, NaN, inf: library path for the whole wave
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) sincos(d[j], &s[j], &c[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        if (j == 0) pose_from_seg(P, cv, 0); else pose_mul_seg(P, cv, j);
+        if (WANT_J) {
+            jac[j] = P.tx; jac[NJ + j] = P.ty; jac[2 * NJ + j] = P.tz;
+            jac[3 * NJ + j] = P.r02; jac[4 * NJ + j] = P.r12; jac[5 * NJ + j] = P.r22;
+        }
+        // revolute: rotate by (c, s), no slide; prismatic: identity rotation, slide d
+        pose_rotz(P, fma(rv[j], c[j], pv[j]), rv[j] * s[j]);
+        pose_tz(P, pv[j] * d[j]);
+        sched_fence();
+    }
+    pose_mul_general(P, [&](int k) { return kp.tail[k]; });
+    sched_fence();
+    if (WANT_J) {
+        // Jv = z x (p_e - p), Jw = z (revolute) ; Jv = z, Jw = 0 (prismatic); flip negates
+        // (methods.cpp:142-195); frame 1 rotates both halves by Re^T.
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const double zx = sg[j] * jac[3 * NJ + j], zy = sg[j] * jac[4 * NJ + j], zz = sg[j] * jac[5 * NJ + j];
+            const double dx = P.tx - jac[j], dy = P.ty - jac[NJ + j], dz = P.tz - jac[2 * NJ + j];
+            double vx = fma(rv[j], zy * dz - zz * dy, pv[j] * zx);
+            double vy = fma(rv[j], zz * dx - zx * dz, pv[j] * zy);
+            double vz = fma(rv[j], zx * dy - zy * dx, pv[j] * zz);
+            double wx = rv[j] * zx, wy = rv[j] * zy, wz = rv[j] * zz;
+            if (kp.frame == 1) {
+                double a = vx, b = vy, e = vz;
+                vx = P.r00 * a + P.r10 * b + P.r20 * e;
+                vy = P.r01 * a + P.r11 * b + P.r21 * e;
+                vz = P.r02 * a + P.r12 * b + P.r22 * e;
+                a = wx; b = wy; e = wz;
+                wx = P.r00 * a + P.r10 * b + P.r20 * e;
+                wy = P.r01 * a + P.r11 * b + P.r21 * e;
+                wz = P.r02 * a + P.r12 * b + P.r22 * e;
+            }
+            jac[j] = vx; jac[NJ + j] = vy; jac[2 * NJ + j] = vz;
+            jac[3 * NJ + j] = wx; jac[4 * NJ + j] = wy; jac[5 * NJ + j] = wz;
+        }
+    }
+}
+
+// staging: lane writes its finished J row / its 4x4 into the wave's LDS transposer
+template <int NJ>
+RTB_HD void reg_stage_J(const double (&jac)[6 * NJ], double *buf, int slot_lane)
+{
+    double *mine = buf + slot_lane * (6 * NJ + 1);
+#pragma unroll
+    for (int k = 0; k < 6 * NJ; ++k) mine[k] = jac[k];
+}
+
+RTB_HD void reg_stage_T(const KinParams &kp, Pose P, double *buf, int lane)
+{
+    if (kp.has_base) pose_premul(P, kp.base);
+    double *mine = buf + lane * 17;
+    pose_store16(P, [&](int k, double v) { mine[k] = v; });
+}
+
+}  // namespace rtbhip

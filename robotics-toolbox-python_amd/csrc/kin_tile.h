@@ -20,11 +20,11 @@
 namespace rtbhip {
 
 struct KinParams {
-    int32_t m, n, qw, stride;
-    int32_t frame, has_base, has_tool, pad;
+    int32_t n, qw, stride, frame;
+    int32_t has_base, pad;
     int64_t N;
-    double base[12];
-    double tool[12];
+    double base[12];  // row-major 3x4, applied to T only
+    double tail[12];  // C_n * tool as {R row-major (9), t (3)}
 };
 
 RTB_HD int kin_stride(int n)
@@ -54,17 +54,15 @@ RTB_HD void kin_load_q(const KinParams &kp, const double *__restrict__ q, int64_
 }
 
 // phase B: walk the chain, leave the pose in P (tool applied) and the finished J in rows.
-template <bool WANT_J, class OpsP>
-RTB_HD void kin_walk(const KinParams &kp, OpsP ops, int lane, const double *qs, double *rows, Pose &P)
+template <bool WANT_J, class CV>
+RTB_HD void kin_walk(const KinParams &kp, const CV &cv, int lane, const double *qs, double *rows, Pose &P)
 {
     double *mine = rows + lane * kp.stride;
-    pose_identity(P);
-    chain_walk<WANT_J>(ops, kp.m, kp.n, P,
+    chain_walk<WANT_J>(cv, kp.n, kp.tail, P,
                        [&](int c) { return qs[c * kWave + lane]; },
                        [&](int slot, double v) { mine[slot] = v; });
-    if (kp.has_tool) pose_mul_general(P, [&](int k) { return kp.tool[(k < 9) ? (k / 3) * 4 + k % 3 : (k - 9) * 4 + 3]; });
     if (WANT_J)
-        jacobian_close(ops, kp.m, kp.n, P, kp.frame, [&](int s) { return mine[s]; },
+        jacobian_close(cv, kp.n, P, kp.frame, [&](int s) { return mine[s]; },
                        [&](int s, double v) { mine[s] = v; });
 }
 

@@ -12,6 +12,7 @@
 #pragma once
 #include "rtbhip_internal.h"
 #include <cmath>
+#include "trig.h"
 
 #ifndef RTB_HD
 #define RTB_HD __host__ __device__ __forceinline__
@@ -84,7 +85,7 @@ RTB_HD void rne_lane(LinksP links, int n_rt, V3 grav, V3 ftip, V3 ntip, InQ qin,
         const double th = pris ? l.theta : qj + l.offset;   // frne.c:196-202
         const double d = pris ? qj + l.offset : l.d;
         double s, c;
-        sincos(th, &s, &c);
+        rtb_sincos(th, &s, &c);
         st[j] = s; ct[j] = c; dj[j] = d;
         R3 R; V3 ps;
         link_frame<MDH>(l, s, c, d, R, ps);

@@ -11,41 +11,41 @@
 namespace rtbhip {
 
 // ---------------------------------------------------------------- device chain program
-// The host "chain compiler" (chain.cpp) lowers the user's elementary-transform list to this
-// program.  It is wave-uniform data: kernels read it through the scalar cache (s_load), so the
-// constants arrive in SGPRs and cost no VGPRs and no LDS bandwidth.
-enum DevKind : int32_t {
-    K_JRX = 0, K_JRY = 1, K_JRZ = 2,   // variable rotation about x/y/z
-    K_JTX = 3, K_JTY = 4, K_JTZ = 5,   // variable translation along x/y/z
-    K_CRX = 6, K_CRY = 7, K_CRZ = 8,   // constant rotation about x/y/z  p = {c, s}
-    K_CTX = 9, K_CTY = 10, K_CTZ = 11, // constant translation along one axis p = {d}
-    K_CT3 = 12,                        // constant translation p = {x,y,z}
-    K_CGEN = 13,                       // general constant p = {R row-major (9), t (3)}
+// The host "chain compiler" (chain.cpp) lowers the user's elementary-transform list to the
+// CANONICAL SEGMENT FORM
+//        T(q) = C_0 * Z_0(q) * C_1 * Z_1(q) * ... * C_{n-1} * Z_{n-1}(q) * C_n
+// where every C_j is one constant affine (all constant ETs between two joints folded together, the
+// reference's ETS.compile() robot/ETS.py:857-906) and every joint acts about/along the local z axis
+// (an Rx/Ry/tx/ty joint is conjugated by an exact axis permutation that is absorbed into the
+// neighbouring constants).  The device code for a chain is then branch-free and identical for every
+// robot: "multiply by a constant 3x4, rotate two columns / slide along one" n times.
+// It is wave-uniform data: kernels read it through the scalar cache (s_load), so the constants
+// arrive in SGPRs and cost no VGPRs and no LDS bandwidth.
+struct DevSeg {
+    double r[9];  // rotation, row-major
+    double t[3];
 };
+static_assert(sizeof(DevSeg) == 96, "DevSeg layout");
 
-struct alignas(16) DevOp {
-    int32_t kind;
-    int32_t jq;    // q column read by a joint op
-    int32_t jcol;  // Jacobian column (order of joints in the chain)
-    int32_t flip;
-    double p[12];
-};
-static_assert(sizeof(DevOp) == 112, "DevOp layout");
+// per joint, in chain order: bit 0 = prismatic, bits 8..15 = q column (jindex), bit 16 = flip
+__host__ __device__ inline int jm_prismatic(int jm) { return jm & 1; }
+__host__ __device__ inline int jm_jq(int jm) { return (jm >> 8) & 0xff; }
+__host__ __device__ inline int jm_flip(int jm) { return (jm >> 16) & 1; }
 
-struct DevChainHeader {
-    int32_t m;        // number of device ops
-    int32_t n;        // joints
-    int32_t q_width;  // columns of q
-    int32_t pad;
+// What a kernel receives: two wave-uniform tables in one device allocation.
+struct DevChain {
+    const DevSeg *seg;     // n + 1 constants C_0 .. C_n
+    const int32_t *jmeta;  // n joint descriptors
 };
 
 // Host-side chain object behind an rtbhip_chain_t handle.
 struct Chain {
     std::vector<rtbhip_et> ets;   // as given (for chain_info / debugging)
-    std::vector<DevOp> ops;       // compiled program
+    std::vector<DevSeg> seg;      // n + 1
+    std::vector<int32_t> jmeta;   // n
     std::vector<double> qlim;     // 2*n (lows, highs)
     int n = 0, q_width = 0;
-    std::map<int, DevOp *> dev_ops;    // per-device upload of ops
+    std::map<int, void *> dev_ops;     // per-device upload: [seg | jmeta]
     std::map<int, double *> dev_qlim;  // per-device upload of qlim
     std::mutex mu;
 };
@@ -78,26 +78,29 @@ int hip_fail(hipError_t e, const char *what);
 
 Chain *chain_from_handle(rtbhip_chain_t h);
 Dyn *dyn_from_handle(rtbhip_dyn_t h);
-int chain_device_ops(Chain *c, const DevOp **out, const double **qlim_out);
+int chain_device_ops(Chain *c, DevChain *out, const double **qlim_out);
+DevChain chain_host_view(const Chain *c);
 int dyn_device_links(Dyn *d, const DevLink **out);
 int compile_chain(const rtbhip_et *ets, int m, const double *qlim, Chain *out);
+struct Affine;
+void chain_tail(const Chain *c, const Affine &tool, double out12[12]);
 void note_launch(int grid, int block, int lds);
 int device_cu_count(int *cus);
 
 // ---------------------------------------------------------------- kernel launchers (device pointers)
 struct Affine { double v[12]; int used; };  // row-major 3x4, host-side small parameter
 
-int launch_kin(const Chain *c, const DevOp *ops, const double *q, int64_t N, const Affine &base,
+int launch_kin(const Chain *c, const DevChain &dc, const double *q, int64_t N, const Affine &base,
                const Affine &tool, int frame, double *T, double *J, double *H, hipStream_t s);
 
 struct FleetEntry {   // device-visible descriptor of one chain of a fleet launch
-    const DevOp *ops;
+    DevChain dc;
     const double *q;
     double *T;
     double *J;
     int64_t N;
     int64_t tile0;    // first global tile index of this chain
-    int32_t m, n, q_width, stride;
+    int32_t n, q_width, stride, pad;
 };
 int launch_fleet(const std::vector<FleetEntry> &entries, int frame, hipStream_t s);
 
@@ -111,7 +114,7 @@ struct IkParams {
     double we[6];
     uint64_t seed;
 };
-int launch_ik(const Chain *c, const DevOp *ops, const double *qlim, const double *Tep, int64_t N,
+int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const double *Tep, int64_t N,
               const double *q0, const IkParams &p, double *q_out, int32_t *success, int32_t *iters,
               int32_t *searches, double *residual, hipStream_t s);
 void ik_restart_host(const Chain *c, uint64_t seed, int64_t target, int search, double *q_n);

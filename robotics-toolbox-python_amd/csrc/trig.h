@@ -1,0 +1,72 @@
+// trig.h -- fp64 sin/cos pair for joint angles.
+//
+// The reference calls libm cos()/sin() per revolute joint (core/fknm.cpp:1324-1325,
+// core/frne.c:323-326).  On the GPU the library sincos() is ~100 instructions with a data-dependent
+// branch into a Payne-Hanek reduction, which (a) dominates the per-configuration instruction count
+// and (b) puts every call in its own basic block, so the n independent evaluations of a
+// configuration cannot be interleaved.  Joint angles are small numbers, so the common case is
+// served by a branch-free straight-line evaluation:
+//     k = rint(x * 2/pi);  r = x - k*pi/2 by three FMAs against a 3 x 53-bit split of pi/2
+//     (absolute reduction error < 1e-16 for |x| < 2^20), then the classic minimax kernels for
+//     sin r, cos r on |r| <= pi/4 (Sun fdlibm __kernel_sin/__kernel_cos coefficients) and a
+//     quadrant swap.  Max abs error vs libm: < 3e-16 (tests/test_kernel_emu.py pins 5e-16).
+// |x| >= 2^20 (never a joint angle, but the ABI accepts any double) falls back to the library
+// routine, whole wave at once, so parity holds for every input.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cmath>
+
+#ifndef RTB_HD
+#define RTB_HD __host__ __device__ __forceinline__
+#endif
+
+namespace rtbhip {
+
+constexpr double kTrigFastLimit = 1048576.0;  // 2^20
+
+RTB_HD void sincos_reduced(double x, double &s, double &c)
+{
+    const double k = rint(x * 0x1.45f306dc9c883p-1);        // x * 2/pi
+    double r = fma(-k, 0x1.921fb54442d18p+0, x);           // pi/2, high 53 bits
+    r = fma(-k, 0x1.1a62633145c07p-54, r);                 // next 53 bits
+    r = fma(-k, -0x1.f1976b7ed8fbcp-110, r);               // and the next
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double sr = fma(r * z, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double cr = fma(z * z, pc, fma(z, -0.5, 1.0));
+    const int q = (int)k & 3;                               // |k| < 2^20 fits
+    const double a = (q & 1) ? cr : sr;
+    const double b = (q & 1) ? sr : cr;
+    s = (q & 2) ? -a : a;
+    c = ((q + 1) & 2) ? -b : b;
+}
+
+// true when any lane of the wavefront holds `pred` (the CPU emulation runs one lane at a time)
+RTB_HD bool wave_any(bool pred)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __any(pred) != 0;
+#else
+    return pred;
+#endif
+}
+
+RTB_HD void rtb_sincos(double x, double *s, double *c)
+{
+    if (wave_any(!(fabs(x) < kTrigFastLimit))) {   // also catches NaN / inf
+        sincos(x, s, c);
+        return;
+    }
+    sincos_reduced(x, *s, *c);
+}
+
+}  // namespace rtbhip

@@ -247,7 +247,7 @@ class ETS:
                 return self._shape_q(q.detach().numpy())
             if q.dtype != torch.float64:
                 raise TypeError("device q must be float64")
-            single = q.dim() == 1 or (q.dim() == 2 and (q.shape[0] == 1 or q.shape[1] == 1))
+            single = q.dim() == 1 or (q.dim() == 2 and self._one_config(tuple(q.shape), qw))
             q2 = q.reshape(1, -1) if single else q
             q2 = q2.contiguous()
             if q2.shape[1] != qw:
@@ -258,11 +258,19 @@ class ETS:
             a = a.reshape(1)
         if a.ndim > 2:
             raise ValueError("q must be 1-D or 2-D")
-        single = a.ndim == 1 or a.shape[0] == 1 or a.shape[1] == 1
+        single = a.ndim == 1 or self._one_config(a.shape, qw)
         a = a.reshape(1, -1) if single else a
         if a.shape[1] != qw:
             raise ValueError("q has %d columns, chain needs %d" % (a.shape[1], qw))
         return np.ascontiguousarray(a), single, False
+
+    @staticmethod
+    def _one_config(shape, qw):
+        """(1,n) and (n,1) are one configuration (core/fknm.cpp:968-981).  For a one-joint chain the
+        reference's rule would swallow every (N,1) trajectory; there (N,1) with N > 1 is a batch."""
+        if shape[0] == 1:
+            return True
+        return shape[1] == 1 and qw != 1
 
     @staticmethod
     def _out(shape, like, torch_mode, dtype=None):

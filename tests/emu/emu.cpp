@@ -4,7 +4,7 @@
 // kernels.  The build container has no GPU; this lets `pytest -m "not gpu"` catch logic errors in the
 // kernel bodies (indexing, staging, flush arithmetic, recursion order) before GPU minutes are spent.
 // It is NOT a product path: librtbhip.so contains none of this and fails loudly without a GPU.
-#include "../../robotics-toolbox-python_amd/csrc/kin_tile.h"
+#include "../../robotics-toolbox-python_amd/csrc/kin_reg.h"
 #include "../../robotics-toolbox-python_amd/csrc/rne_device.h"
 #include <vector>
 
@@ -25,14 +25,15 @@ extern "C" int emu_kin(rtbhip_chain_t h, const double *q, int64_t N, const doubl
     Chain *c = chain_from_handle(h);
     if (!c) return -1;
     KinParams kp;
-    kp.m = (int)c->ops.size(); kp.n = c->n; kp.qw = c->q_width; kp.stride = kin_stride(c->n);
+    kp.n = c->n; kp.qw = c->q_width; kp.stride = kin_stride(c->n);
     kp.frame = frame; kp.N = N; kp.pad = 0;
     Affine b = aff16(base16), t = aff16(tool16);
-    kp.has_base = b.used; kp.has_tool = t.used;
-    for (int i = 0; i < 12; i++) { kp.base[i] = b.v[i]; kp.tool[i] = t.v[i]; }
+    kp.has_base = b.used;
+    for (int i = 0; i < 12; i++) kp.base[i] = b.v[i];
+    chain_tail(c, t, kp.tail);
     std::vector<double> lds(kin_lds_bytes(kp.n, kp.qw) / sizeof(double), -777.0);
     double *rows = lds.data(), *qs = lds.data() + kWave * kp.stride;
-    const DevOp *ops = c->ops.data();
+    const DevChain ops = chain_host_view(c);
     const int W = 6 * kp.n;
     const int64_t tiles = (N + kWave - 1) / kWave;
     for (int64_t tile = 0; tile < tiles; ++tile) {
@@ -58,6 +59,69 @@ extern "C" int emu_kin(rtbhip_chain_t h, const double *q, int64_t N, const doubl
         }
     }
     return 0;
+}
+
+template <int NJ>
+static void emu_reg_run(const KinParams &kp, const DevChain &cv, const double *q, int64_t N, double *T, double *J)
+{
+    std::vector<double> buf(reg_lds_doubles(NJ), -777.0);
+    constexpr int W = 6 * NJ;
+    const int64_t tiles = (N + kWave - 1) / kWave;
+    for (int64_t tile = 0; tile < tiles; ++tile) {
+        const int64_t cfg0 = tile * kWave;
+        const int ncfg = (int)std::min<int64_t>(kWave, N - cfg0);
+        Pose P[kWave];
+        double jac[kWave][6 * NJ];
+        for (int l = 0; l < kWave; ++l) {
+            if (J) reg_compute<NJ, true>(kp, cv, q, cfg0 + l, P[l], jac[l]);
+            else reg_compute<NJ, false>(kp, cv, q, cfg0 + l, P[l], jac[l]);
+        }
+        if (J)
+            for (int r = 0; r < kWave / kJRound; ++r) {
+                for (int l = 0; l < kWave; ++l)
+                    if (l / kJRound == r) reg_stage_J<NJ>(jac[l], buf.data(), l % kJRound);
+                int rows = std::max(0, std::min(kJRound, ncfg - r * kJRound));
+                for (int l = 0; l < kWave; ++l) kin_flush(buf.data(), W + 1, W, rows, J + (cfg0 + r * kJRound) * W, l);
+            }
+        if (T) {
+            for (int l = 0; l < kWave; ++l) reg_stage_T(kp, P[l], buf.data(), l);
+            for (int l = 0; l < kWave; ++l) kin_flush(buf.data(), 17, 16, ncfg, T + cfg0 * 16, l);
+        }
+    }
+}
+
+extern "C" int emu_kin_reg(rtbhip_chain_t h, const double *q, int64_t N, const double *base16, const double *tool16,
+                           int frame, double *T, double *J)
+{
+    Chain *c = chain_from_handle(h);
+    if (!c || c->n < 1 || c->n > kRegMaxJoints) return -1;
+    KinParams kp;
+    kp.n = c->n; kp.qw = c->q_width; kp.stride = kin_stride(c->n);
+    kp.frame = frame; kp.N = N; kp.pad = 0;
+    Affine b = aff16(base16), t = aff16(tool16);
+    kp.has_base = b.used;
+    for (int i = 0; i < 12; i++) kp.base[i] = b.v[i];
+    chain_tail(c, t, kp.tail);
+    const DevChain cv = chain_host_view(c);
+    switch (c->n) {
+    case 1: emu_reg_run<1>(kp, cv, q, N, T, J); break;
+    case 2: emu_reg_run<2>(kp, cv, q, N, T, J); break;
+    case 3: emu_reg_run<3>(kp, cv, q, N, T, J); break;
+    case 4: emu_reg_run<4>(kp, cv, q, N, T, J); break;
+    case 5: emu_reg_run<5>(kp, cv, q, N, T, J); break;
+    case 6: emu_reg_run<6>(kp, cv, q, N, T, J); break;
+    case 7: emu_reg_run<7>(kp, cv, q, N, T, J); break;
+    default: emu_reg_run<8>(kp, cv, q, N, T, J); break;
+    }
+    return 0;
+}
+
+extern "C" void emu_sincos(const double *x, int64_t n, double *s, double *c, int reduced_only)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        if (reduced_only) sincos_reduced(x[i], s[i], c[i]);
+        else rtb_sincos(x[i], &s[i], &c[i]);
+    }
 }
 
 template <int NJ>

@@ -45,6 +45,8 @@ def lib():
         _lib.rtbhip_dyn_create.argtypes = [_vp, _i32, _i32, C.POINTER(_u64)]
         _lib.emu_kin.argtypes = [_u64, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _i32]
         _lib.emu_rne.argtypes = [_u64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32]
+        _lib.emu_kin_reg.argtypes = [_u64, _vp, _i64, _vp, _vp, _i32, _vp, _vp]
+        _lib.emu_sincos.argtypes = [_vp, _i64, _vp, _vp, _i32]
         _lib.rtbhip_last_error.restype = C.c_char_p
     return _lib
 
@@ -70,7 +72,15 @@ def chain_handle(ets):
     return h.value
 
 
-def kin(ets, q, base=None, tool=None, frame=0, want=("T", "J"), coalesced=True):
+def sincos(x, reduced_only=False):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    s, c = np.empty_like(x), np.empty_like(x)
+    lib().emu_sincos(_p(x), x.size, _p(s), _p(c), int(reduced_only))
+    return s, c
+
+
+def kin(ets, q, base=None, tool=None, frame=0, want=("T", "J"), coalesced=True, reg=False):
+    """reg=True runs the register-resident variant (kin_reg.h), else the run-time-n tile (kin_tile.h)."""
     h = chain_handle(ets)
     q = np.ascontiguousarray(np.asarray(q, dtype=np.float64).reshape(-1, ets.q_width))
     N, n = q.shape[0], ets.n
@@ -79,7 +89,11 @@ def kin(ets, q, base=None, tool=None, frame=0, want=("T", "J"), coalesced=True):
     H = np.full((N, n, 6, n), np.nan) if "H" in want else None
     b = None if base is None else np.ascontiguousarray(base, dtype=np.float64)
     t = None if tool is None else np.ascontiguousarray(tool, dtype=np.float64)
-    rc = lib().emu_kin(h, _p(q), N, _p(b), _p(t), frame, _p(T), _p(J), _p(H), int(coalesced))
+    if reg:
+        assert H is None
+        rc = lib().emu_kin_reg(h, _p(q), N, _p(b), _p(t), frame, _p(T), _p(J))
+    else:
+        rc = lib().emu_kin(h, _p(q), N, _p(b), _p(t), frame, _p(T), _p(J), _p(H), int(coalesced))
     assert rc == 0
     return T, J, H
 

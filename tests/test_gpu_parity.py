@@ -31,6 +31,7 @@ def test_native_library_is_the_path():
     p.fkine(np.zeros(7))
     g, b, l = rtbhip.last_launch()
     assert (g, b) == (1, 64) and l > 0
+    assert rtbhip.lib().rtbhip_version() >= 100
 
 
 def test_golden_literals_G1_G2_G3_G8():
@@ -103,7 +104,9 @@ def test_ragged_sizes_vs_oracle(N):
 
 @pytest.mark.parametrize("coalesced", [1, 0])
 def test_store_path_variants_agree(coalesced):
+    """run-time-n tile kernel (forced with reg=0), both store paths."""
     rtbhip.tune("coalesced", coalesced)
+    rtbhip.tune("reg", 0)
     try:
         ets = rtbhip.models.Panda().ets()
         ch = chains.panda_ets()
@@ -114,6 +117,23 @@ def test_store_path_variants_agree(coalesced):
         nt.assert_allclose(J, oracle.jacob0(ch, q), atol=TOL)
     finally:
         rtbhip.tune("coalesced", 1)
+        rtbhip.tune("reg", 1)
+
+
+def test_huge_and_nonfinite_joint_values():
+    """|q| >= 2^20 takes the library sincos path; NaN stays NaN (no hang, no garbage elsewhere)."""
+    ets = rtbhip.models.Panda().ets()
+    ch = chains.panda_ets()
+    rng = np.random.default_rng(8)
+    q = rng.uniform(-np.pi, np.pi, (200, 7))
+    q[5, 2] = 1.5e7
+    q[77, 0] = -3.0e9
+    T, J = ets.fkine_jacob0(q)
+    nt.assert_allclose(T, oracle.fkine(ch, q), atol=1e-9)
+    nt.assert_allclose(J, oracle.jacob0(ch, q), atol=1e-9)
+    q[9, 4] = np.nan
+    T, J = ets.fkine_jacob0(q)
+    assert np.isnan(T[9]).any() and not np.isnan(np.delete(T, 9, axis=0)).any()
 
 
 @pytest.mark.parametrize("n", [1, 2, 5, 11, 16, 23])

@@ -38,7 +38,7 @@ def test_chain_compiler_counts_and_folding():
     # identity constants vanish; two general constants fold into one
     A = np.eye(4); A[:3, :3] = [[0, -1, 0], [0, 0, -1], [1, 0, 0]]; A[:3, 3] = [1, 2, 3]
     e = rtbhip.ET.SE3(A) * rtbhip.ET.SE3(A) * rtbhip.ET.tx(0.0) * rtbhip.ET.Rz() * rtbhip.ET.Rx(0.0)
-    assert _info(e) == (1, 2, 1)
+    assert _info(e) == (1, 5, 1)
     # jindex: all-or-none, explicit indices define the q width
     e = rtbhip.ET.Rz(jindex=2) * rtbhip.ET.tx(1.0) * rtbhip.ET.Ry(jindex=0)
     assert _info(e) == (2, 3, 3)

@@ -14,6 +14,74 @@ LIT = literals()
 REF = ref_outputs()
 
 
+def test_sincos_accuracy_and_fallback():
+    """trig.h: branch-free reduced-range path within 5e-16 of libm for |x| < 2^20, library beyond."""
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-np.pi, np.pi, 200000), rng.uniform(-1e3, 1e3, 200000),
+                        rng.uniform(-1048575, 1048575, 200000), np.linspace(-7, 7, 100001),
+                        np.array([0.0, -0.0, np.pi / 2, np.pi, -np.pi, 1e-300, 1048575.9])])
+    s, c = emu.sincos(x, reduced_only=True)
+    assert np.abs(s - np.sin(x)).max() < 5e-16 and np.abs(c - np.cos(x)).max() < 5e-16
+    xb = np.array([1048576.0, 1e7, -3e9, 2.0 ** 40 + 0.5, 1e300])
+    s, c = emu.sincos(xb)
+    nt.assert_array_equal(s, np.sin(xb))
+    nt.assert_array_equal(c, np.cos(xb))
+    s, c = emu.sincos(np.array([np.nan, np.inf, -np.inf]))
+    assert np.isnan(s).all() and np.isnan(c).all()
+
+
+@pytest.mark.parametrize("reg", [True, False])
+def test_register_variant_fixture_parity(reg):
+    """kin_reg.h (compile-time joint count, n <= 8) against the reference-run fixtures."""
+    tool, base = tool_base()
+    ets = rtbhip.models.Panda().ets()
+    q = REF["panda_q"]
+    T, J, _ = emu.kin(ets, q, reg=reg)
+    nt.assert_allclose(T, REF["panda_fkine"], atol=1e-12)
+    nt.assert_allclose(J, REF["panda_jacob0"], atol=1e-12)
+    T, J, _ = emu.kin(ets, q, base=base, tool=tool, reg=reg)
+    nt.assert_allclose(T, REF["panda_fkine_bt"], atol=1e-12)
+    nt.assert_allclose(J, REF["panda_jacob0_tool"], atol=1e-12)
+    _, J, _ = emu.kin(ets, q, tool=tool, frame=1, want=("J",), reg=reg)
+    nt.assert_allclose(J, REF["panda_jacobe_tool"], atol=1e-12)
+    T, _, _ = emu.kin(ets, q, base=base, want=("T",), reg=reg)
+    nt.assert_allclose(T, oracle.fkine(chains.panda_ets(), q, base=base), atol=1e-12)
+    mx = product_ets(mixed_spec())
+    for frame, key in ((0, "mixed_jacob0"), (1, "mixed_jacobe")):
+        T, J, _ = emu.kin(mx, REF["mixed_q"], frame=frame, reg=reg)
+        nt.assert_allclose(T, REF["mixed_fkine"], atol=1e-12)
+        nt.assert_allclose(J, REF[key], atol=1e-12)
+
+
+@pytest.mark.parametrize("N", [1, 31, 32, 33, 63, 64, 65, 97, 1000])
+def test_register_variant_ragged_tiles(N):
+    ets = rtbhip.models.Panda().ets()
+    ch = chains.panda_ets()
+    rng = np.random.default_rng(N)
+    q = rng.uniform(-np.pi, np.pi, (N, 7))
+    T, J, _ = emu.kin(ets, q, reg=True)
+    nt.assert_allclose(T, oracle.fkine(ch, q), atol=1e-12)
+    nt.assert_allclose(J, oracle.jacob0(ch, q), atol=1e-12)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 8])
+def test_register_variant_joint_counts(n):
+    rng = np.random.default_rng(40 + n)
+    axes = ["Rx", "Ry", "Rz", "tx", "ty", "tz"]
+    spec = []
+    for j in range(n):
+        if rng.integers(3):
+            spec.append((axes[rng.integers(6)], float(rng.normal())))
+        spec.append((axes[rng.integers(6)], None, bool(rng.integers(2))))
+    ets = product_ets(spec)
+    ch = chains.Chain(spec)
+    q = rng.normal(size=(70, n))
+    for frame in (0, 1):
+        T, J, _ = emu.kin(ets, q, frame=frame, reg=True)
+        nt.assert_allclose(T, oracle.fkine(ch, q), atol=1e-11)
+        nt.assert_allclose(J, oracle.jacob(ch, q, frame=frame), atol=1e-11)
+
+
 @pytest.mark.parametrize("coalesced", [True, False])
 def test_panda_fixture_parity(coalesced):
     tool, base = tool_base()
