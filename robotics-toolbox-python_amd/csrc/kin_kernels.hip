@@ -76,8 +76,11 @@ __global__ __launch_bounds__(kWave) void k_kin(KinParams kp, DevChain dc,
 }
 
 // ---------------------------------------------------------------- register-resident variant (n <= 8)
+#ifndef RTB_REG_WAVES
+#define RTB_REG_WAVES 3   // waves per SIMD the register allocator must leave room for (<= 168 VGPRs)
+#endif
 template <int NJ, bool WANT_T, bool WANT_J>
-__global__ __launch_bounds__(kWave) void k_kin_reg(KinParams kp, DevChain dc, const double *__restrict__ q,
+__global__ __launch_bounds__(kWave, RTB_REG_WAVES) void k_kin_reg(KinParams kp, DevChain dc, const double *__restrict__ q,
                                                   double *__restrict__ T, double *__restrict__ J)
 {
     extern __shared__ __attribute__((aligned(16))) double buf[];

@@ -29,7 +29,10 @@ RTB_HD void sched_fence()
 }
 
 constexpr int kRegMaxJoints = 8;
-constexpr int kJRound = 32;  // lanes staged per J round
+#ifndef RTB_JROUND
+#define RTB_JROUND 32
+#endif
+constexpr int kJRound = RTB_JROUND;  // lanes staged per J round
 
 RTB_HD int reg_lds_doubles(int n)
 {
@@ -37,26 +40,25 @@ RTB_HD int reg_lds_doubles(int n)
     return a > b ? a : b;
 }
 
-// whole per-lane compute of one tile: q -> (P = C_0 Z_0 ... C_n tool, finished J in registers).
-// jac slot r*NJ + j : rows 0..2 = p_j, rows 3..5 = z_j until the closing loop finishes them.
+// Per-lane core: joint values qv[] (chain order, as the caller holds them) -> P = C_0 Z_0 ... tail and
+// the finished Jacobian in registers.  jac slot r*NJ + j : rows 0..2 = p_j, rows 3..5 = z_j until
+// the closing loop finishes them.  Used by the tile kernel (reg_compute) and by the IK loop.
 template <int NJ, bool WANT_J, class CV>
-RTB_HD void reg_compute(const KinParams &kp, const CV &cv, const double *__restrict__ q, int64_t cfg,
-                        Pose &P, double (&jac)[6 * NJ])
+RTB_HD void reg_core(const CV &cv, const double *tail, int frame, const double (&qv)[NJ], Pose &P,
+                     double (&jac)[6 * NJ])
 {
-    const bool live = cfg < kp.N;
-    const double *qrow = q + cfg * kp.qw;
     double c[NJ], s[NJ], d[NJ];
     // wave-uniform per-joint blend weights (SGPR doubles) instead of per-lane selects:
     // rv = 1 for a revolute joint, pv = 1 for a prismatic one, sg = -1 where the joint is flipped.
     double rv[NJ], pv[NJ], sg[NJ];
     bool big = false;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {   // joint coordinates in chain order (methods.cpp:363-366 for flip)
+    for (int j = 0; j < NJ; ++j) {   // methods.cpp:363-366 for flip
         const int jm = cv.jmeta[j];
         pv[j] = jm_prismatic(jm) ? 1.0 : 0.0;
         rv[j] = 1.0 - pv[j];
         sg[j] = jm_flip(jm) ? -1.0 : 1.0;
-        d[j] = (live ? qrow[jm_jq(jm)] : 0.0) * sg[j];
+        d[j] = qv[j] * sg[j];
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {   // NJ independent evaluations, one basic block
@@ -79,7 +81,7 @@ RTB_HD void reg_compute(const KinParams &kp, const CV &cv, const double *__restr
         pose_tz(P, pv[j] * d[j]);
         sched_fence();
     }
-    pose_mul_general(P, [&](int k) { return kp.tail[k]; });
+    pose_mul_general(P, [&](int k) { return tail[k]; });
     sched_fence();
     if (WANT_J) {
         // Jv = z x (p_e - p), Jw = z (revolute) ; Jv = z, Jw = 0 (prismatic); flip negates
@@ -92,7 +94,7 @@ RTB_HD void reg_compute(const KinParams &kp, const CV &cv, const double *__restr
             double vy = fma(rv[j], zz * dx - zx * dz, pv[j] * zy);
             double vz = fma(rv[j], zx * dy - zy * dx, pv[j] * zz);
             double wx = rv[j] * zx, wy = rv[j] * zy, wz = rv[j] * zz;
-            if (kp.frame == 1) {
+            if (frame == 1) {
                 double a = vx, b = vy, e = vz;
                 vx = P.r00 * a + P.r10 * b + P.r20 * e;
                 vy = P.r01 * a + P.r11 * b + P.r21 * e;
@@ -106,6 +108,19 @@ RTB_HD void reg_compute(const KinParams &kp, const CV &cv, const double *__restr
             jac[3 * NJ + j] = wx; jac[4 * NJ + j] = wy; jac[5 * NJ + j] = wz;
         }
     }
+}
+
+// whole per-lane compute of one tile: q row in memory -> (P, J)
+template <int NJ, bool WANT_J, class CV>
+RTB_HD void reg_compute(const KinParams &kp, const CV &cv, const double *__restrict__ q, int64_t cfg,
+                        Pose &P, double (&jac)[6 * NJ])
+{
+    const bool live = cfg < kp.N;
+    const double *qrow = q + cfg * kp.qw;
+    double qv[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) qv[j] = live ? qrow[jm_jq(cv.jmeta[j])] : 0.0;
+    reg_core<NJ, WANT_J>(cv, kp.tail, kp.frame, qv, P, jac);
 }
 
 // staging: lane writes its finished J row / its 4x4 into the wave's LDS transposer

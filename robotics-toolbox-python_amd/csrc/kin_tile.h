@@ -74,6 +74,13 @@ RTB_HD void kin_stage_T(const KinParams &kp, int lane, double *rows, Pose P)
     pose_store16(P, [&](int k, double v) { mine[k] = v; });
 }
 
+// Output rows are written once and never re-read by this kernel: non-temporal 16-byte stores
+// (global_store_dwordx4 ... nt) measured 0.0935 vs 0.105 ms per 1e6 Panda configurations on MI355X
+// (the bare access-pattern probe, scripts/roofline_probe.hip: 0.0868 vs 0.1013 ms).
+#ifndef RTB_NT_STORE
+#define RTB_NT_STORE 1
+#endif
+
 // phases C / E: the wave writes `ncfg` staged rows of W doubles (W even) as one contiguous run.
 // Lane l writes the 16-byte pieces l, l+64, l+128, ... of the run; (cfg, e) tracks which staged
 // row / element piece f falls in without a division per piece.
@@ -89,7 +96,13 @@ RTB_HD void kin_flush(const double *rows, int stride, int W, int ncfg, double *_
         double2 v;
         v.x = src[0];
         v.y = src[1];
+#if RTB_NT_STORE && defined(__HIP_DEVICE_COMPILE__)
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        v2d w = {v.x, v.y};
+        __builtin_nontemporal_store(w, reinterpret_cast<v2d *>(dst + f));   // global_store_dwordx4 ... nt
+#else
         *reinterpret_cast<double2 *>(dst + f) = v;
+#endif
         e += db;
         cfg += da;
         if (e >= W) { e -= W; cfg += 1; }

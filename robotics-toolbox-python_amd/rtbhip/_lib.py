@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "librtbhip.so")
+LIB_PATH = os.environ.get("RTBHIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "librtbhip.so")
 
 MEM_HOST, MEM_DEVICE = 0, 1
 ET_CONST = 6

@@ -4,7 +4,7 @@
 // kernels.  The build container has no GPU; this lets `pytest -m "not gpu"` catch logic errors in the
 // kernel bodies (indexing, staging, flush arithmetic, recursion order) before GPU minutes are spent.
 // It is NOT a product path: librtbhip.so contains none of this and fails loudly without a GPU.
-#include "../../robotics-toolbox-python_amd/csrc/kin_reg.h"
+#include "../../robotics-toolbox-python_amd/csrc/ik_device.h"
 #include "../../robotics-toolbox-python_amd/csrc/rne_device.h"
 #include <vector>
 
@@ -122,6 +122,47 @@ extern "C" void emu_sincos(const double *x, int64_t n, double *s, double *c, int
         if (reduced_only) sincos_reduced(x[i], s[i], c[i]);
         else rtb_sincos(x[i], &s[i], &c[i]);
     }
+}
+
+template <int NJ>
+static void emu_ik_run(const Chain *c, const IkDev &p, const double *Tep, const double *q0, double *q_out, int32_t *success,
+                       int32_t *iters, int32_t *searches, double *residual)
+{
+    const DevChain cv = chain_host_view(c);
+    const double *qlim = c->qlim.data();
+    for (int64_t t = 0; t < p.N; ++t) {   // one lane at a time: same state machine as the kernel
+        IkState<NJ> st;
+        ik_begin<NJ>(st, p, qlim, t, Tep + 16 * t, p.has_q0 ? q0 + (int64_t)NJ * t : nullptr);
+        int ok = 0;
+        while (!ik_advance<NJ>(st, p, cv, qlim, ok)) {}
+        for (int j = 0; j < NJ; ++j) q_out[t * NJ + j] = st.q[j];
+        success[t] = ok; iters[t] = st.it; searches[t] = st.search; residual[t] = st.E;
+    }
+}
+
+extern "C" int emu_ik(rtbhip_chain_t h, const double *Tep, int64_t N, const double *q0, int ilimit, int slimit, double tol,
+                      int reject_jl, const double *we6, double lambda, int method, int flavour, uint64_t seed,
+                      double *q_out, int32_t *success, int32_t *iters, int32_t *searches, double *residual)
+{
+    Chain *c = chain_from_handle(h);
+    if (!c || c->n < 1 || c->n > kRegMaxJoints) return -1;
+    IkDev p;
+    p.ilimit = ilimit; p.slimit = slimit; p.reject_jl = reject_jl; p.method = method; p.flavour = flavour;
+    p.has_q0 = q0 != nullptr; p.tol = tol; p.lambda = lambda; p.seed = seed; p.N = N;
+    for (int k = 0; k < 6; ++k) p.we[k] = we6 ? we6[k] : 1.0;
+    Affine none; none.used = 0;
+    chain_tail(c, none, p.tail);
+    switch (c->n) {
+    case 1: emu_ik_run<1>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
+    case 2: emu_ik_run<2>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
+    case 3: emu_ik_run<3>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
+    case 4: emu_ik_run<4>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
+    case 5: emu_ik_run<5>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
+    case 6: emu_ik_run<6>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
+    case 7: emu_ik_run<7>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
+    default: emu_ik_run<8>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
+    }
+    return 0;
 }
 
 template <int NJ>

