@@ -18,16 +18,6 @@
 
 namespace rtbhip {
 
-// Keeps the machine scheduler from hoisting every segment's scalar loads to the top of the
-// straight-line walk (which overflows the 102 SGPRs and turns each constant operand into a pair of
-// v_readlane from a spill VGPR): loads of segment j+1 may overlap segment j, not run further ahead.
-RTB_HD void sched_fence()
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-}
-
 constexpr int kRegMaxJoints = 8;
 #ifndef RTB_JROUND
 #define RTB_JROUND 32

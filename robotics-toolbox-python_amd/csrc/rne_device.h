@@ -27,34 +27,37 @@ RTB_HD V3 operator*(double s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
 RTB_HD V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 RTB_HD double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 
-struct R3 { double m[9]; };  // row-major
-RTB_HD V3 rmul(const R3 &r, V3 v)   // R v
+// Link frame (frne.c:329-347).  The rotation is never formed as a matrix: standard DH is
+// R = Rz(theta) Rx(alpha), modified DH is R = Rx(alpha) Rz(theta), so R v and R^T v are two planar
+// rotations applied in turn straight from (sin theta, cos theta) [per lane] and (sin alpha, cos
+// alpha) [wave-uniform] -- 12 flops instead of 15 and no 9-register matrix to keep live.
+struct Rot { double s, c, sa, ca; };
+template <bool MDH>
+RTB_HD V3 rot_fwd(const Rot &r, V3 v)   // R v
 {
-    return v3(r.m[0] * v.x + r.m[1] * v.y + r.m[2] * v.z, r.m[3] * v.x + r.m[4] * v.y + r.m[5] * v.z,
-              r.m[6] * v.x + r.m[7] * v.y + r.m[8] * v.z);
-}
-RTB_HD V3 rtmul(const R3 &r, V3 v)  // R^T v
-{
-    return v3(r.m[0] * v.x + r.m[3] * v.y + r.m[6] * v.z, r.m[1] * v.x + r.m[4] * v.y + r.m[7] * v.z,
-              r.m[2] * v.x + r.m[5] * v.y + r.m[8] * v.z);
-}
-
-// link rotation and offset vector from the joint state: frne.c:329-347
-template <bool MDH, class LinkT>
-RTB_HD void link_frame(const LinkT &l, double st, double ct, double d, R3 &R, V3 &ps)
-{
-    const double sa = l.sa, ca = l.ca;
     if (!MDH) {
-        R.m[0] = ct; R.m[1] = -ca * st; R.m[2] = sa * st;
-        R.m[3] = st; R.m[4] = ca * ct;  R.m[5] = -sa * ct;
-        R.m[6] = 0;  R.m[7] = sa;       R.m[8] = ca;
-        ps = v3(l.a, d * sa, d * ca);
+        const double uy = r.ca * v.y - r.sa * v.z, uz = r.sa * v.y + r.ca * v.z;
+        return v3(r.c * v.x - r.s * uy, r.s * v.x + r.c * uy, uz);
     } else {
-        R.m[0] = ct;      R.m[1] = -st;     R.m[2] = 0;
-        R.m[3] = st * ca; R.m[4] = ca * ct; R.m[5] = -sa;
-        R.m[6] = st * sa; R.m[7] = ct * sa; R.m[8] = ca;
-        ps = v3(l.a, -d * sa, d * ca);
+        const double ux = r.c * v.x - r.s * v.y, uy = r.s * v.x + r.c * v.y;
+        return v3(ux, r.ca * uy - r.sa * v.z, r.sa * uy + r.ca * v.z);
     }
+}
+template <bool MDH>
+RTB_HD V3 rot_inv(const Rot &r, V3 v)   // R^T v
+{
+    if (!MDH) {
+        const double ux = r.c * v.x + r.s * v.y, uy = r.c * v.y - r.s * v.x;
+        return v3(ux, r.ca * uy + r.sa * v.z, r.ca * v.z - r.sa * uy);
+    } else {
+        const double uy = r.ca * v.y + r.sa * v.z, uz = r.ca * v.z - r.sa * v.y;
+        return v3(r.c * v.x + r.s * uy, r.c * uy - r.s * v.x, uz);
+    }
+}
+template <bool MDH, class LinkT>
+RTB_HD V3 link_offset(const LinkT &l, double d)   // p* (frne.c:337,347)
+{
+    return MDH ? v3(l.a, -d * l.sa, d * l.ca) : v3(l.a, d * l.sa, d * l.ca);
 }
 
 template <class LinkT>
@@ -65,14 +68,36 @@ RTB_HD V3 inertia_times(const LinkT &l, V3 v)  // vmath.c mat_vect_mult: m[r + 3
 }
 
 // One sample.  links: wave-uniform link table (scalar loads on the GPU).
-// qv/qdv/qddv/tau: per-lane accessors  in(j) -> double, out(j, v).
+// qin/qdin/qddin/tau: per-lane accessors  in(j) -> double, out(j, v).  q(j) must stay readable until
+// tau(j) has been written (the kernel lets tau overwrite the q slots).
 template <int NJ, bool MDH, class LinksP, class InQ, class InQd, class InQdd, class Out>
 RTB_HD void rne_lane(LinksP links, int n_rt, V3 grav, V3 ftip, V3 ntip, InQ qin, InQd qdin, InQdd qddin, Out tau)
 {
     constexpr int CAP = NJ > 0 ? NJ : RTBHIP_MAX_JOINTS;
     const int n = NJ > 0 ? NJ : n_rt;
-    double st[CAP], ct[CAP], dj[CAP];
+    double st[CAP], ct[CAP];
     V3 F[CAP], Nn[CAP];
+
+    // ---- joint angles -> sin/cos.  Compile-time NJ: all NJ evaluations in one basic block (branch-free
+    // reduction, trig.h) so the scheduler interleaves the independent chains; one wave-wide fallback.
+    if (NJ > 0) {
+        bool big = false;
+#pragma unroll
+        for (int j = 0; j < n; ++j) {
+            const auto &l = links[j];
+            const double th = (l.sigma != 0) ? l.theta : qin(j) + l.offset;   // frne.c:196-202
+            st[j] = th;
+            big = big || !(fabs(th) < kTrigFastLimit);
+        }
+        if (wave_any(big)) {
+#pragma unroll
+            for (int j = 0; j < n; ++j) { double s, c; sincos(st[j], &s, &c); st[j] = s; ct[j] = c; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < n; ++j) { double s, c; sincos_reduced(st[j], s, c); st[j] = s; ct[j] = c; }
+        }
+        sched_fence();
+    }
 
     // ---- forward recursion (ne.c:133-348)
     V3 w = v3(0, 0, 0), wd = v3(0, 0, 0), a = v3(0, 0, 0);
@@ -81,56 +106,56 @@ RTB_HD void rne_lane(LinksP links, int n_rt, V3 grav, V3 ftip, V3 ntip, InQ qin,
     for (int j = 0; j < n; ++j) {
         const auto &l = links[j];
         const bool pris = l.sigma != 0;
-        const double qj = qin(j), qdj = qdin(j), qddj = qddin(j);
-        const double th = pris ? l.theta : qj + l.offset;   // frne.c:196-202
-        const double d = pris ? qj + l.offset : l.d;
-        double s, c;
-        rtb_sincos(th, &s, &c);
-        st[j] = s; ct[j] = c; dj[j] = d;
-        R3 R; V3 ps;
-        link_frame<MDH>(l, s, c, d, R, ps);
+        const double qdj = qdin(j), qddj = qddin(j);
+        if (NJ == 0) {
+            const double th = pris ? l.theta : qin(j) + l.offset;
+            rtb_sincos(th, &st[j], &ct[j]);
+        }
+        const double d = pris ? qin(j) + l.offset : l.d;
+        const Rot R = {st[j], ct[j], l.sa, l.ca};
+        const V3 ps = link_offset<MDH>(l, d);
         const V3 qdv = v3(0, 0, qdj);
         V3 qddv = v3(qddx, qddy, qddj);
         V3 wn, wdn, an;
         if (MDH) {
             if (!pris) {
                 if (j == 0) {
-                    wn = qdv; wdn = qddv; an = rtmul(R, grav);
+                    wn = qdv; wdn = qddv; an = rot_inv<MDH>(R, grav);
                 } else {
-                    const V3 t1 = rtmul(R, w);
+                    const V3 t1 = rot_inv<MDH>(R, w);
                     wn = t1 + qdv;
-                    wdn = (cross(t1, qdv) + rtmul(R, wd)) + qddv;
-                    an = rtmul(R, (cross(wd, ps) + cross(w, cross(w, ps))) + a);
+                    wdn = (cross(t1, qdv) + rot_inv<MDH>(R, wd)) + qddv;
+                    an = rot_inv<MDH>(R, (cross(wd, ps) + cross(w, cross(w, ps))) + a);
                 }
             } else {
                 if (j == 0) {
                     wn = qdv; wdn = qddv; an = grav;
                 } else {
-                    wn = rtmul(R, w);
-                    wdn = rtmul(R, wd);
-                    an = rtmul(R, (cross(wd, ps) + cross(w, cross(w, ps))) + a);
+                    wn = rot_inv<MDH>(R, w);
+                    wdn = rot_inv<MDH>(R, wd);
+                    an = rot_inv<MDH>(R, (cross(wd, ps) + cross(w, cross(w, ps))) + a);
                     an = (an + 2.0 * cross(wn, qdv)) + qddv;
                 }
             }
         } else {
             if (!pris) {
                 const V3 t1 = (j == 0) ? qdv : w + qdv;
-                wn = rtmul(R, t1);
+                wn = rot_inv<MDH>(R, t1);
                 const V3 t3 = (j == 0) ? qddv : (wd + qddv) + cross(w, qdv);
-                wdn = rtmul(R, t3);
-                an = (cross(wdn, ps) + cross(wn, cross(wn, ps))) + rtmul(R, (j == 0) ? grav : a);
+                wdn = rot_inv<MDH>(R, t3);
+                an = (cross(wdn, ps) + cross(wn, cross(wn, ps))) + rot_inv<MDH>(R, (j == 0) ? grav : a);
             } else {
-                wn = (j == 0) ? v3(0, 0, 0) : rtmul(R, w);
-                wdn = (j == 0) ? v3(0, 0, 0) : rtmul(R, wd);
+                wn = (j == 0) ? v3(0, 0, 0) : rot_inv<MDH>(R, w);
+                wdn = (j == 0) ? v3(0, 0, 0) : rot_inv<MDH>(R, wd);
                 if (j == 0) {
                     qddv = qddv + grav;
                     qddx = qddv.x; qddy = qddv.y;
-                    an = rtmul(R, qddv);
+                    an = rot_inv<MDH>(R, qddv);
                 } else {
-                    an = rtmul(R, qddv + a);
+                    an = rot_inv<MDH>(R, qddv + a);
                 }
                 an = an + cross(wdn, ps);
-                an = an + 2.0 * cross(wn, rtmul(R, qdv));
+                an = an + 2.0 * cross(wn, rot_inv<MDH>(R, qdv));
                 an = an + cross(wn, cross(wn, ps));
             }
         }
@@ -139,40 +164,46 @@ RTB_HD void rne_lane(LinksP links, int n_rt, V3 grav, V3 ftip, V3 ntip, InQ qin,
         const V3 ac = (cross(wd, rc) + cross(w, cross(w, rc))) + a;   // ne.c:228-232
         F[j] = l.m * ac;
         Nn[j] = inertia_times(l, wd) + cross(w, inertia_times(l, w));
+        if (NJ > 0) sched_fence();   // keep link j+1's scalar table loads from being hoisted over link j
     }
 
     // ---- backward recursion + joint projection (ne.c:354-492), fused
-    V3 f = ftip, nn = ntip;   // f_{j+1}, n_{j+1} expressed as the reference's "tip" values for the last link
-    R3 Rn; V3 psn = v3(0, 0, 0);  // frame of link j+1
+    V3 f = ftip, nn = ntip;   // f_{j+1}, n_{j+1}; the reference's "tip" values for the last link
+    Rot Rn = {0, 1, 0, 1};    // frame of link j+1
+    V3 psn = v3(0, 0, 0);
 #pragma unroll
     for (int jj = 0; jj < n; ++jj) {
         const int j = n - 1 - jj;
         const auto &l = links[j];
         const bool last = (jj == 0);
+        const bool pris = l.sigma != 0;
         const V3 rc = v3(l.rx, l.ry, l.rz);
-        R3 R; V3 ps;
-        link_frame<MDH>(l, st[j], ct[j], dj[j], R, ps);
+        const double d = pris ? qin(j) + l.offset : l.d;
+        const Rot R = {st[j], ct[j], l.sa, l.ca};
+        const V3 ps = link_offset<MDH>(l, d);
         V3 fj, nj;
         if (MDH) {
-            const V3 fn = last ? f : rmul(Rn, f);
+            const V3 fn = last ? f : rot_fwd<MDH>(Rn, f);
             fj = fn + F[j];
-            const V3 t1 = last ? nn : rmul(Rn, nn) + cross(psn, fn);
+            const V3 t1 = last ? nn : rot_fwd<MDH>(Rn, nn) + cross(psn, fn);
             nj = (t1 + cross(rc, F[j])) + Nn[j];
         } else {
-            fj = F[j] + (last ? f : rmul(Rn, f));
+            fj = F[j] + (last ? f : rot_fwd<MDH>(Rn, f));
             V3 t1 = cross(ps + rc, F[j]);
-            if (!last) t1 = t1 + rmul(Rn, cross(rtmul(Rn, ps), f) + nn);
+            if (!last) t1 = t1 + rot_fwd<MDH>(Rn, cross(rot_inv<MDH>(Rn, ps), f) + nn);
             else t1 = (t1 + cross(ps, f)) + nn;
             nj = t1 + Nn[j];
         }
-        const V3 ax = MDH ? v3(0, 0, 1) : rtmul(R, v3(0, 0, 1));
+        // joint axis in the link frame: z for MDH, R^T z = (0, sin alpha, cos alpha) for DH
+        const V3 prj = pris ? fj : nj;
         const double qdj = qdin(j), qddj = qddin(j);
-        double t = (l.sigma != 0) ? dot(fj, ax) : dot(nj, ax);
+        double t = MDH ? prj.z : l.sa * prj.y + l.ca * prj.z;
         t += l.G * l.G * l.Jm * qddj;
         t += l.G * l.G * l.B * qdj;
         t += fabs(l.G) * ((qdj > 0 ? l.Tc0 : 0.0) + (qdj < 0 ? l.Tc1 : 0.0));
         tau(j, t);
         f = fj; nn = nj; Rn = R; psn = ps;
+        if (NJ > 0) sched_fence();
     }
 }
 

@@ -41,50 +41,64 @@ __device__ __forceinline__ void tile_copy(double *rows, int stride, int col_off,
     }
 }
 
+#ifndef RTB_RNE_WAVES
+#define RTB_RNE_WAVES 2   // waves per SIMD the register allocator must leave room for (<= 256 VGPRs)
+#endif
+
+// One tile: stage the wave's (64 x n) q / qd / qdd blocks in LDS (coalesced), run the per-lane
+// recursion with the LDS row as the accessor target (q is read once, up front; qd/qdd are re-read
+// from LDS where they are used, so they occupy no registers across the recursions; tau overwrites the
+// q slots, which are dead by then), write the torques back coalesced.
 template <int NJ, bool MDH>
-__global__ __launch_bounds__(kW) void k_rne(RneParams rp, const DevLink *links_g, const double *__restrict__ q,
-                                           const double *__restrict__ qd, const double *__restrict__ qdd,
-                                           double *__restrict__ tau)
+__device__ __forceinline__ void rne_tile(const RneParams &rp, ConstLinks links, int n, int stride, int64_t tile,
+                                         const double *__restrict__ q, const double *__restrict__ qd,
+                                         const double *__restrict__ qdd, double *__restrict__ tau, double *lds, int lane)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    ConstLinks links = (ConstLinks)links_g;
-    const int lane = threadIdx.x;
-    const int n = NJ > 0 ? NJ : rp.n;
-    const int stride = rne_stride(n);
-    const int64_t tiles = (rp.N + kW - 1) / kW;
     const V3 grav = v3(rp.grav[0], rp.grav[1], rp.grav[2]);
     const V3 ftip = rp.has_fext ? v3(rp.fext[0], rp.fext[1], rp.fext[2]) : v3(0, 0, 0);
     const V3 ntip = rp.has_fext ? v3(rp.fext[3], rp.fext[4], rp.fext[5]) : v3(0, 0, 0);
     double *mine = lds + lane * stride;
+    const int64_t cfg0 = tile * kW;
+    const int64_t left = rp.N - cfg0;
+    const int ncfg = left < kW ? (int)left : kW;
+    const int count = ncfg * n;
+    tile_copy<true>(lds, stride, 0, n, count, q + cfg0 * n, nullptr, lane);
+    tile_copy<true>(lds, stride, n, n, count, qd + cfg0 * n, nullptr, lane);
+    tile_copy<true>(lds, stride, 2 * n, n, count, qdd + cfg0 * n, nullptr, lane);
+    __syncthreads();
+    if (lane < ncfg) {
+        rne_lane<NJ, MDH>(links, n, grav, ftip, ntip, [&](int j) { return mine[j]; }, [&](int j) { return mine[n + j]; },
+                          [&](int j) { return mine[2 * n + j]; }, [&](int j, double v) { mine[j] = v; });
+    }
+    __syncthreads();
+    tile_copy<false>(lds, stride, 0, n, count, nullptr, tau + cfg0 * n, lane);
+}
 
+// compile-time joint count: ONE tile per single-wave workgroup (no grid-stride loop -- with a loop
+// LICM hoists every link's scalar table loads into the preheader, where they overflow the SGPR file;
+// first MI355X measurement of the looped version: 256 VGPRs + 90 AGPRs + 112 spilled SGPRs, one
+// wave per SIMD, 0.31 ms per 1.25e6 Panda triples).
+template <int NJ, bool MDH>
+__global__ __launch_bounds__(kW, RTB_RNE_WAVES) void k_rne(RneParams rp, const DevLink *links_g, const double *__restrict__ q,
+                                           const double *__restrict__ qd, const double *__restrict__ qdd,
+                                           double *__restrict__ tau)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    rne_tile<NJ, MDH>(rp, (ConstLinks)links_g, NJ, rne_stride(NJ), blockIdx.x, q, qd, qdd, tau, lds, threadIdx.x);
+}
+
+// run-time joint count (n > 8): grid-stride over tiles, per-link state in private memory
+template <bool MDH>
+__global__ __launch_bounds__(kW) void k_rne_rt(RneParams rp, const DevLink *links_g, const double *__restrict__ q,
+                                              const double *__restrict__ qd, const double *__restrict__ qdd,
+                                              double *__restrict__ tau)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int n = rp.n;
+    const int stride = rne_stride(n);
+    const int64_t tiles = (rp.N + kW - 1) / kW;
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const int64_t cfg0 = tile * kW;
-        const int64_t left = rp.N - cfg0;
-        const int ncfg = left < kW ? (int)left : kW;
-        const int count = ncfg * n;
-        tile_copy<true>(lds, stride, 0, n, count, q + cfg0 * n, nullptr, lane);
-        tile_copy<true>(lds, stride, n, n, count, qd + cfg0 * n, nullptr, lane);
-        tile_copy<true>(lds, stride, 2 * n, n, count, qdd + cfg0 * n, nullptr, lane);
-        __syncthreads();
-        if (lane < ncfg) {
-            if (NJ > 0) {
-                constexpr int C = NJ > 0 ? NJ : 1;
-                double rq[C], rqd[C], rqdd[C], rt[C];
-#pragma unroll
-                for (int j = 0; j < C; ++j) { rq[j] = mine[j]; rqd[j] = mine[n + j]; rqdd[j] = mine[2 * n + j]; }
-                rne_lane<NJ, MDH>(links, n, grav, ftip, ntip, [&](int j) { return rq[j]; }, [&](int j) { return rqd[j]; },
-                                  [&](int j) { return rqdd[j]; }, [&](int j, double v) { rt[j] = v; });
-#pragma unroll
-                for (int j = 0; j < C; ++j) mine[j] = rt[j];
-            } else {
-                // run-time n: torques overwrite the q slots only after q is dead (q is read in the
-                // forward pass only), qd/qdd stay readable for the projection.
-                rne_lane<0, MDH>(links, n, grav, ftip, ntip, [&](int j) { return mine[j]; }, [&](int j) { return mine[n + j]; },
-                                 [&](int j) { return mine[2 * n + j]; }, [&](int j, double v) { mine[j] = v; });
-            }
-        }
-        __syncthreads();
-        tile_copy<false>(lds, stride, 0, n, count, nullptr, tau + cfg0 * n, lane);
+        rne_tile<0, MDH>(rp, (ConstLinks)links_g, n, stride, tile, q, qd, qdd, tau, lds, threadIdx.x);
         __syncthreads();
     }
 }
@@ -102,6 +116,12 @@ static void launch_nj(bool mdh, dim3 grid, size_t lds, hipStream_t s, const RneP
     if (mdh) hipLaunchKernelGGL((k_rne<NJ, true>), grid, dim3(kW), lds, s, rp, links, q, qd, qdd, tau);
     else hipLaunchKernelGGL((k_rne<NJ, false>), grid, dim3(kW), lds, s, rp, links, q, qd, qdd, tau);
 }
+static void launch_rt(bool mdh, dim3 grid, size_t lds, hipStream_t s, const RneParams &rp, const DevLink *links,
+                      const double *q, const double *qd, const double *qdd, double *tau)
+{
+    if (mdh) hipLaunchKernelGGL((k_rne_rt<true>), grid, dim3(kW), lds, s, rp, links, q, qd, qdd, tau);
+    else hipLaunchKernelGGL((k_rne_rt<false>), grid, dim3(kW), lds, s, rp, links, q, qd, qdd, tau);
+}
 
 int launch_rne(const Dyn *d, const DevLink *links, const double *q, const double *qd, const double *qdd,
                int64_t N, const double *grav3, const double *fext6, double *tau, hipStream_t s)
@@ -117,11 +137,12 @@ int launch_rne(const Dyn *d, const DevLink *links, const double *q, const double
     if (!(stride & 1)) stride += 1;
     const size_t lds = (size_t)kW * stride * sizeof(double);
     const int64_t tiles = (N + kW - 1) / kW;
-    int64_t g = (tiles + g_rne_tiles_per_wave - 1) / g_rne_tiles_per_wave;
+    const bool mdh = d->mdh != 0;
+    const bool rt = d->n > 8 || tiles > 0x7fffffff;
+    int64_t g = rt ? (tiles + g_rne_tiles_per_wave - 1) / g_rne_tiles_per_wave : tiles;
     if (g > 0x7fffffff) g = 0x7fffffff;
     dim3 grid((unsigned)g);
-    const bool mdh = d->mdh != 0;
-    switch (d->n) {
+    switch (rt ? 0 : d->n) {
     case 1: launch_nj<1>(mdh, grid, lds, s, rp, links, q, qd, qdd, tau); break;
     case 2: launch_nj<2>(mdh, grid, lds, s, rp, links, q, qd, qdd, tau); break;
     case 3: launch_nj<3>(mdh, grid, lds, s, rp, links, q, qd, qdd, tau); break;
@@ -130,7 +151,7 @@ int launch_rne(const Dyn *d, const DevLink *links, const double *q, const double
     case 6: launch_nj<6>(mdh, grid, lds, s, rp, links, q, qd, qdd, tau); break;
     case 7: launch_nj<7>(mdh, grid, lds, s, rp, links, q, qd, qdd, tau); break;
     case 8: launch_nj<8>(mdh, grid, lds, s, rp, links, q, qd, qdd, tau); break;
-    default: launch_nj<0>(mdh, grid, lds, s, rp, links, q, qd, qdd, tau); break;
+    default: launch_rt(mdh, grid, lds, s, rp, links, q, qd, qdd, tau); break;
     }
     note_launch((int)grid.x, kW, (int)lds);
     hipError_t e = hipGetLastError();

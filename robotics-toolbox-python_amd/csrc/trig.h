@@ -50,6 +50,16 @@ RTB_HD void sincos_reduced(double x, double &s, double &c)
     c = ((q + 1) & 2) ? -b : b;
 }
 
+// Keeps the machine scheduler from hoisting every segment's scalar loads to the top of the
+// straight-line walk (which overflows the 102 SGPRs and turns each constant operand into a pair of
+// v_readlane from a spill VGPR): loads of segment j+1 may overlap segment j, not run further ahead.
+RTB_HD void sched_fence()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // true when any lane of the wavefront holds `pred` (the CPU emulation runs one lane at a time)
 RTB_HD bool wave_any(bool pred)
 {
