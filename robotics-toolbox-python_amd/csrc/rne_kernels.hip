@@ -62,16 +62,59 @@ __device__ __forceinline__ void rne_tile(const RneParams &rp, ConstLinks links, 
     const int64_t left = rp.N - cfg0;
     const int ncfg = left < kW ? (int)left : kW;
     const int count = ncfg * n;
-    tile_copy<true>(lds, stride, 0, n, count, q + cfg0 * n, nullptr, lane);
-    tile_copy<true>(lds, stride, n, n, count, qd + cfg0 * n, nullptr, lane);
-    tile_copy<true>(lds, stride, 2 * n, n, count, qdd + cfg0 * n, nullptr, lane);
+    if (NJ > 0) {
+        // all 3*NJ coalesced 8-byte loads of the tile in flight at once (a run-time-trip-count copy
+        // loop serialises load -> wait -> LDS write: 21 dependent HBM round trips per tile measured as
+        // 65 % of the wave lifetime in s_waitcnt), then the LDS transposition.
+        constexpr int C = NJ > 0 ? NJ : 1;
+        double r0[C], r1[C], r2[C];
+        const double *g0 = q + cfg0 * NJ, *g1 = qd + cfg0 * NJ, *g2 = qdd + cfg0 * NJ;
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            const int f = lane + kW * k;
+            const bool in = f < count;
+            r0[k] = in ? g0[f] : 0.0;
+            r1[k] = in ? g1[f] : 0.0;
+            r2[k] = in ? g2[f] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            const int f = lane + kW * k;
+            const int r = f / C, c = f - r * C;
+            double *dst = lds + r * stride + c;
+            dst[0] = r0[k];
+            dst[C] = r1[k];
+            dst[2 * C] = r2[k];
+        }
+    } else {
+        tile_copy<true>(lds, stride, 0, n, count, q + cfg0 * n, nullptr, lane);
+        tile_copy<true>(lds, stride, n, n, count, qd + cfg0 * n, nullptr, lane);
+        tile_copy<true>(lds, stride, 2 * n, n, count, qdd + cfg0 * n, nullptr, lane);
+    }
     __syncthreads();
     if (lane < ncfg) {
         rne_lane<NJ, MDH>(links, n, grav, ftip, ntip, [&](int j) { return mine[j]; }, [&](int j) { return mine[n + j]; },
                           [&](int j) { return mine[2 * n + j]; }, [&](int j, double v) { mine[j] = v; });
     }
     __syncthreads();
-    tile_copy<false>(lds, stride, 0, n, count, nullptr, tau + cfg0 * n, lane);
+    if (NJ > 0) {
+        constexpr int C = NJ > 0 ? NJ : 1;
+        double *g = tau + cfg0 * NJ;
+        double r0[C];
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            const int f = lane + kW * k;
+            const int r = f / C, c = f - r * C;
+            r0[k] = lds[r * stride + c];
+        }
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            const int f = lane + kW * k;
+            if (f < count) __builtin_nontemporal_store(r0[k], g + f);
+        }
+    } else {
+        tile_copy<false>(lds, stride, 0, n, count, nullptr, tau + cfg0 * n, lane);
+    }
 }
 
 // compile-time joint count: ONE tile per single-wave workgroup (no grid-stride loop -- with a loop
