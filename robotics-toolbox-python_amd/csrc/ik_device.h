@@ -5,11 +5,12 @@
 // (ik.cpp:241-286), _rand_q (ik.cpp:288-299), _check_lim (ik.cpp:227-239) and, as "flavour 1", the
 // Python solver behind ikine_LM (robot/IK.py:297-367 `_solve`, :994-1017 `IK_LM.step`).
 //
-// One lane owns one target pose.  The reference's nested while-loops are restated as a per-lane
-// state machine whose transition (`ik_advance`) performs exactly ONE LM iteration: every lane of a
-// wave executes the same instruction stream (FK + Jacobian + 6-vector error + normal equations +
-// solve) regardless of which search/iteration it is in, so lanes that converge early can be handed
-// a new target (persistent lanes, ik_kernels.hip) without divergence.
+// One lane runs one SEARCH of one target at a time.  The reference's nested while-loops are restated
+// as a per-lane transition (`ik_iter`) that performs exactly ONE LM iteration: every lane of a wave
+// executes the same instruction stream (FK + Jacobian + 6-vector error + normal equations + solve)
+// regardless of which target / search / iteration it is in, and a per-wave scheduler (below) keeps
+// the lanes fed: fresh targets while there are any, then speculative later searches of the wave's
+// unresolved targets.
 //
 // Differences from the reference that cannot be bit-matched and are covered by statistical parity
 // (SURVEY.md 8c): restarts come from a counter-based generator keyed by (seed, target, draw, joint)
@@ -27,6 +28,7 @@ constexpr double kIkPiHalf = 1.57079632679489661923132169163975144;
 
 struct IkDev {   // wave-uniform solver parameters (kernarg)
     int32_t ilimit, slimit, reject_jl, method, flavour, has_q0;
+    int32_t fresh_cap, pad;   // scheduler: fresh targets a wave may take per pass
     double tol, lambda;
     double we[6];
     double tail[12];
@@ -58,19 +60,20 @@ RTB_HD void ik_restart(uint64_t seed, int64_t target, int draw, QL qlim, double 
 
 // ---------------------------------------------------------------- pose error (ik.cpp:241-286)
 // Te = current pose P, Tep = {R row-major (9), t (3)}.
-RTB_HD void ik_angle_axis(const Pose &P, const double (&Td)[12], double (&e)[6])
+template <class TD>
+RTB_HD void ik_angle_axis(const Pose &P, TD Td, double (&e)[6])
 {
-    e[0] = Td[9] - P.tx; e[1] = Td[10] - P.ty; e[2] = Td[11] - P.tz;
+    e[0] = Td(9) - P.tx; e[1] = Td(10) - P.ty; e[2] = Td(11) - P.tz;
     // R = Rd * Re^T ; only the entries the formula reads
-    const double r00 = Td[0] * P.r00 + Td[1] * P.r01 + Td[2] * P.r02;
-    const double r01 = Td[0] * P.r10 + Td[1] * P.r11 + Td[2] * P.r12;
-    const double r02 = Td[0] * P.r20 + Td[1] * P.r21 + Td[2] * P.r22;
-    const double r10 = Td[3] * P.r00 + Td[4] * P.r01 + Td[5] * P.r02;
-    const double r11 = Td[3] * P.r10 + Td[4] * P.r11 + Td[5] * P.r12;
-    const double r12 = Td[3] * P.r20 + Td[4] * P.r21 + Td[5] * P.r22;
-    const double r20 = Td[6] * P.r00 + Td[7] * P.r01 + Td[8] * P.r02;
-    const double r21 = Td[6] * P.r10 + Td[7] * P.r11 + Td[8] * P.r12;
-    const double r22 = Td[6] * P.r20 + Td[7] * P.r21 + Td[8] * P.r22;
+    const double r00 = Td(0) * P.r00 + Td(1) * P.r01 + Td(2) * P.r02;
+    const double r01 = Td(0) * P.r10 + Td(1) * P.r11 + Td(2) * P.r12;
+    const double r02 = Td(0) * P.r20 + Td(1) * P.r21 + Td(2) * P.r22;
+    const double r10 = Td(3) * P.r00 + Td(4) * P.r01 + Td(5) * P.r02;
+    const double r11 = Td(3) * P.r10 + Td(4) * P.r11 + Td(5) * P.r12;
+    const double r12 = Td(3) * P.r20 + Td(4) * P.r21 + Td(5) * P.r22;
+    const double r20 = Td(6) * P.r00 + Td(7) * P.r01 + Td(8) * P.r02;
+    const double r21 = Td(6) * P.r10 + Td(7) * P.r11 + Td(8) * P.r12;
+    const double r22 = Td(6) * P.r20 + Td(7) * P.r21 + Td(8) * P.r22;
     const double lx = r21 - r12, ly = r02 - r20, lz = r10 - r01;
     const double nrm = sqrt(lx * lx + ly * ly + lz * lz);
     const double tr = r00 + r11 + r22;
@@ -146,41 +149,73 @@ RTB_HD void ik_lm_step(const double (&jac)[6 * NJ], const double (&e)[6], const 
     }
 }
 
-// ---------------------------------------------------------------- per-lane solver state
+// ---------------------------------------------------------------- searches as pure functions
+// The reference runs, per target, up to `slimit` SEARCHES one after another; each search starts from
+// a given or random q and takes at most `ilimit` LM steps (ik.cpp:39-72, IK.py:297-367).  With the
+// counter-based restart generator a search is a pure function of (target, search index):
+//        (ok, iterations it contributes, final q, last E).
+// The answer for a target is the LOWEST-indexed successful search; the reported iteration count is
+// the sum of the contributions of all searches up to and including it.  Nothing forces the searches
+// to run one after another, and the device scheduler below does not (speculative parallel searches).
+//
+// Search index conventions (what the reference reports as `searches`):
+//   flavour 0 (C, ik.cpp)   s = 1 .. s_last, s_last = max(slimit,1); iter starts at 1 for s = 1 and 0
+//                           after a restart (ik.cpp:39,67); start of search s: q0 if given and s == 1,
+//                           else restart draw s-1-has_q0; failure reports search = s_last+1 and the
+//                           NEXT restart vector as q (ik.cpp:66-69).
+//   flavour 1 (IK.py)       s = 0 .. s_last, s_last = max(slimit,1)-1; start: q0 / draw 0 for s == 0,
+//                           draw s otherwise (IK.py:222-240,351-357); success reports s+1, failure
+//                           reports slimit and the last search's final q.
+// The target pose (R row-major (9), t (3)) is NOT part of the lane state: it is read once per
+// iteration, so the kernel keeps it in the wave's LDS (IkWaveShared::Td, 24 VGPRs saved) and every
+// function below reaches it through an accessor  td(k) -> double / tdput(k, v).
 template <int NJ>
-struct IkState {
+struct IkLane {
     double q[NJ];
-    double Td[12];     // target: R row-major (9), t (3)
-    double E;
-    int64_t tgt;       // target index, -1 = lane idle
-    int32_t iter, search, it, draws;
+    double E;          // E of the last iteration evaluated
+    int32_t iter;      // the reference's in-search iteration counter
+    int32_t s;         // search index
+    int32_t slot;      // target slot of this wave (scheduler), unused by the sequential driver
+    int32_t status;    // kIkIdle / kIkRun / kIkParkedOk / kIkParkedLast
+    int32_t fin, ok, contrib;   // set by ik_iter when the search ended in this iteration
 };
+constexpr int kIkIdle = 0, kIkRun = 1, kIkParkedOk = 2, kIkParkedLast = 3;
 
-// Start a target.  Tep16: row-major 4x4 as the caller holds it (IK_LM_c input, fknm.cpp:465-472).
-template <int NJ, class QL>
-RTB_HD void ik_begin(IkState<NJ> &st, const IkDev &p, QL qlim, int64_t tgt, const double *Tep16,
-                     const double *q0row)
+RTB_HD int ik_s_first(const IkDev &p) { return p.flavour == 0 ? 1 : 0; }
+RTB_HD int ik_s_last(const IkDev &p)
 {
-    st.tgt = tgt;
+    const int sl = p.slimit < 1 ? 1 : p.slimit;
+    return p.flavour == 0 ? sl : sl - 1;
+}
+
+template <class TDPut>
+RTB_HD void ik_load_target(TDPut tdput, const double *Tep16)
+{
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) st.Td[3 * r + c] = Tep16[4 * r + c];
-        st.Td[9 + r] = Tep16[4 * r + 3];
+        for (int c = 0; c < 3; ++c) tdput(3 * r + c, Tep16[4 * r + c]);
+        tdput(9 + r, Tep16[4 * r + 3]);
     }
+}
+
+// Start search s of target tgt in this lane (the target pose must already be loaded).
+template <int NJ, class QL>
+RTB_HD void ik_search_begin(IkLane<NJ> &st, const IkDev &p, QL qlim, int64_t tgt, int s, const double *q0row)
+{
+    st.s = s;
     st.E = 0.0;
-    st.it = 0;
-    st.draws = 0;
-    if (p.flavour == 0) { st.iter = 1; st.search = 1; }    // ik.cpp:39, fknm.cpp:406
-    else { st.iter = 0; st.search = 0; }                    // IK.py:299-313
-    if (q0row) {
+    st.fin = 0; st.ok = 0; st.contrib = 0;
+    const int s0 = ik_s_first(p);
+    st.iter = (p.flavour == 0 && s == s0) ? 1 : 0;          // ik.cpp:39 vs :67
+    if (s == s0 && q0row) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) st.q[j] = q0row[j];
-        if (p.flavour == 1) st.draws = 1;                   // row 0 of the pre-drawn starts is replaced by q0 (IK.py:229-232)
     } else {
-        ik_restart<NJ>(p.seed, tgt, st.draws, qlim, st.q);
-        st.draws++;
+        const int draw = p.flavour == 0 ? s - 1 - (q0row ? 1 : 0) : s;
+        ik_restart<NJ>(p.seed, tgt, draw, qlim, st.q);
     }
+    st.status = kIkRun;
 }
 
 RTB_HD double ik_wrap_c(double q) { return fmod(q + kIkPi, kIkPi2) - kIkPi; }        // ik.cpp:51
@@ -191,27 +226,26 @@ RTB_HD double ik_wrap_py(double q)                                              
     return r - kIkPi;
 }
 
-// One LM iteration + the reference's loop bookkeeping.  Returns true when the target is finished;
-// then (st.q, success, st.it, st.search, st.E) are the 5 outputs.
-template <int NJ, class CV, class QL>
-RTB_HD bool ik_advance(IkState<NJ> &st, const IkDev &p, const CV &cv, QL qlim, int &success)
+// ONE LM iteration of the lane's current search.  Every lane of a wave executes this whatever its
+// status (idle / parked lanes compute on their stale state and discard the result) so the wave has a
+// single instruction stream.  Sets st.fin / st.ok / st.contrib when the search ended.
+template <int NJ, class CV, class QL, class TD>
+RTB_HD void ik_iter(IkLane<NJ> &st, const IkDev &p, const CV &cv, QL qlim, TD td)
 {
     Pose P;
     double jac[6 * NJ], e[6], dq[NJ];
     reg_core<NJ, true>(cv, p.tail, 0, st.q, P, jac);           // ik.cpp:44,56 / IK.py:994,1009
-    ik_angle_axis(P, st.Td, e);
+    ik_angle_axis(P, td, e);
     double E = 0.0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) E += e[k] * p.we[k] * e[k];
     E *= 0.5;                                                   // ik.cpp:46
-    st.E = E;
     const double wn = (p.method == 1) ? p.lambda : (p.method == 2) ? E + p.lambda : p.lambda * E;   // ik.cpp:169,183,205
     ik_lm_step<NJ>(jac, e, p.we, wn, dq);
+    if (st.status != kIkRun) return;
+    st.E = E;
     const bool arrived = E < p.tol;
-    bool finished = false;
-    success = 0;
     if (p.flavour == 0) {
-        bool end_search = false;
         if (arrived) {                                          // ik.cpp:48-54
             bool ok = true;
 #pragma unroll
@@ -219,25 +253,14 @@ RTB_HD bool ik_advance(IkState<NJ> &st, const IkDev &p, const CV &cv, QL qlim, i
                 st.q[j] = ik_wrap_c(st.q[j]);
                 if (st.q[j] < qlim[j] || st.q[j] > qlim[NJ + j]) ok = false;   // ik.cpp:227-239
             }
-            if (!p.reject_jl) ok = true;
-            st.it += st.iter;
-            if (ok) { success = 1; finished = true; }
-            else end_search = true;
+            st.fin = 1; st.ok = (ok || !p.reject_jl) ? 1 : 0; st.contrib = st.iter;
         } else {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) st.q[j] += dq[j];      // ik.cpp:57
             st.iter++;
-            if (st.iter > p.ilimit) { st.it += st.iter; end_search = true; }
-        }
-        if (end_search) {                                       // ik.cpp:66-69
-            st.iter = 0;
-            st.search++;
-            ik_restart<NJ>(p.seed, st.tgt, st.draws, qlim, st.q);
-            st.draws++;
-            if (st.search > p.slimit) finished = true;
+            if (st.iter > p.ilimit) { st.fin = 1; st.ok = 0; st.contrib = st.iter; }
         }
     } else {
-        bool end_search = false;
         st.iter++;                                              // IK.py:315
 #pragma unroll
         for (int j = 0; j < NJ; ++j) st.q[j] += dq[j];          // the step is taken before E is tested (IK.py:319-327)
@@ -248,30 +271,197 @@ RTB_HD bool ik_advance(IkState<NJ> &st, const IkDev &p, const CV &cv, QL qlim, i
                 st.q[j] = ik_wrap_py(st.q[j]);
                 if (st.q[j] < qlim[j] || st.q[j] > qlim[NJ + j]) ok = false;
             }
-            if (ok || !p.reject_jl) {                           // IK.py:336-349
-                st.it += st.iter;
-                st.search += 1;
-                success = 1;
-                finished = true;
-            } else {
-                end_search = true;
-            }
+            st.fin = 1; st.ok = (ok || !p.reject_jl) ? 1 : 0; st.contrib = st.iter;   // IK.py:336-351
         } else if (st.iter >= p.ilimit) {
-            end_search = true;
-        }
-        if (end_search) {                                       // IK.py:351
-            st.it += st.iter;
-            st.iter = 0;
-            st.search++;
-            if (st.search >= p.slimit) {
-                st.search = p.slimit;                           // IK.py:359-366
-                finished = true;
-            } else {
-                ik_restart<NJ>(p.seed, st.tgt, st.search, qlim, st.q);
-            }
+            st.fin = 1; st.ok = 0; st.contrib = st.iter;
         }
     }
-    return finished;
+}
+
+// What the reference reports for a target whose winning / last search is held by this lane.
+template <int NJ, class QL>
+RTB_HD void ik_emit(const IkLane<NJ> &st, const IkDev &p, QL qlim, int64_t tgt, bool has_q0, bool success, int it_total,
+                    double E_last, double *__restrict__ q_out, int32_t *__restrict__ success_out,
+                    int32_t *__restrict__ iters, int32_t *__restrict__ searches, double *__restrict__ residual)
+{
+    double qf[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) qf[j] = st.q[j];
+    int se;
+    if (success) {
+        se = p.flavour == 0 ? st.s : st.s + 1;
+    } else if (p.flavour == 0) {
+        se = ik_s_last(p) + 1;
+        ik_restart<NJ>(p.seed, tgt, ik_s_last(p) - (has_q0 ? 1 : 0), qlim, qf);   // ik.cpp:66-69: q is the next restart
+    } else {
+        se = p.slimit;                                                             // IK.py:359-366
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) q_out[tgt * NJ + j] = qf[j];
+    success_out[tgt] = success ? 1 : 0;
+    iters[tgt] = it_total;
+    searches[tgt] = se;
+    residual[tgt] = success ? st.E : E_last;
+}
+
+// ---------------------------------------------------------------- per-wave scheduler (speculative searches)
+// A wave (single-wave workgroup) owns up to 64 targets at a time, one per SLOT, and its 64 lanes are
+// workers that each run one (slot, search) at a time.  While fresh targets remain every idle lane
+// takes a new target (search s_first).  When the global supply is exhausted, idle lanes are handed
+// the NEXT search indices of the wave's unresolved targets, so the long tail of hard targets
+// (dozens of restarts, thousands of sequential iterations in the reference) is walked up to 64
+// searches at a time.  Results are accounted strictly in search order, so the outputs are identical
+// to running the searches one after another.
+// All tables live in the wave's LDS; the phases below are per-lane functions called between
+// wave-level barriers by the kernel (lane = threadIdx.x) and, lane by lane, by tests/emu.
+constexpr int kIkRing = 32;                 // outstanding (unaccounted) searches per slot
+struct IkWaveShared {
+    int64_t tgt[64];
+    double Elast[64];                       // E of the slot's last-index search (failure output)
+    int32_t b[64];                          // lowest search index not yet accounted
+    int32_t next[64];                       // next search index to hand out
+    int32_t best[64];                       // lowest successful search index seen so far
+    int32_t it[64];                         // iterations accounted so far
+    int32_t res[64];                        // 0 unresolved, 1 won (winner = b), 2 failed
+    int32_t list[64];                       // scratch: compacted slot list
+    int32_t rec[64][kIkRing];               // per outstanding search: 1 finished | 2 ok | contrib << 2
+    double Td[12][64];                      // per LANE: the target pose of the search the lane is running
+};
+constexpr int kIkNoBest = 0x7fffffff;
+
+RTB_HD void ik_lds_min(int32_t *p, int32_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicMin(p, v);
+#else
+    if (v < *p) *p = v;
+#endif
+}
+RTB_HD void ik_lds_max(int32_t *p, int32_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicMax(p, v);
+#else
+    if (v > *p) *p = v;
+#endif
+}
+RTB_HD int ik_rank(unsigned long long mask, int lane)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popcll(mask & ((1ull << lane) - 1ull));
+#else
+    return __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+#endif
+}
+
+// phase A: a lane whose search just ended posts the result and parks or goes idle
+template <int NJ>
+RTB_HD void ik_report(IkLane<NJ> &st, IkWaveShared &sh, int s_last)
+{
+    if (st.status != kIkRun || !st.fin) return;
+    sh.rec[st.slot][st.s & (kIkRing - 1)] = 1 | (st.ok ? 2 : 0) | (st.contrib << 2);
+    if (st.ok) ik_lds_min(&sh.best[st.slot], st.s);
+    if (st.s == s_last) sh.Elast[st.slot] = st.E;
+    st.status = st.ok ? kIkParkedOk : (st.s == s_last ? kIkParkedLast : kIkIdle);
+    st.fin = 0;
+}
+
+// phase B: lane i accounts slot i in search order
+RTB_HD void ik_account(int i, IkWaveShared &sh, int s_last)
+{
+    int b = sh.b[i], it = sh.it[i], res = 0;
+    for (;;) {
+        const int r = sh.rec[i][b & (kIkRing - 1)];
+        if (!(r & 1)) break;
+        sh.rec[i][b & (kIkRing - 1)] = 0;
+        it += r >> 2;
+        if (r & 2) { res = 1; break; }
+        if (b == s_last) { res = 2; break; }
+        ++b;
+    }
+    sh.b[i] = b; sh.it[i] = it; sh.res[i] = res;
+}
+
+// phase C: parked lanes of a resolved slot emit / release; searches beyond a known success are cancelled
+template <int NJ, class QL>
+RTB_HD void ik_finalize(IkLane<NJ> &st, IkWaveShared &sh, const IkDev &p, QL qlim, double *__restrict__ q_out,
+                        int32_t *__restrict__ success, int32_t *__restrict__ iters, int32_t *__restrict__ searches,
+                        double *__restrict__ residual)
+{
+    if (st.status == kIkIdle) return;
+    const int res = sh.res[st.slot];
+    if (res == 1) {
+        if (st.status == kIkParkedOk && st.s == sh.b[st.slot])
+            ik_emit<NJ>(st, p, qlim, sh.tgt[st.slot], p.has_q0 != 0, true, sh.it[st.slot], 0.0, q_out, success, iters, searches, residual);
+        st.status = kIkIdle;
+    } else if (res == 2) {
+        if (st.status == kIkParkedLast)
+            ik_emit<NJ>(st, p, qlim, sh.tgt[st.slot], p.has_q0 != 0, false, sh.it[st.slot], sh.Elast[st.slot], q_out, success, iters, searches, residual);
+        st.status = kIkIdle;
+    } else if (st.s > sh.best[st.slot]) {
+        st.status = kIkIdle;      // a lower-indexed search already succeeded: this one can never be reported
+    }
+}
+
+// phase D1 helper: initialise slot `slot` for target tgt and start its first search in this lane
+template <int NJ, class QL>
+RTB_HD void ik_start_target(IkLane<NJ> &st, IkWaveShared &sh, int lane, const IkDev &p, QL qlim, int slot, int64_t tgt,
+                            const double *__restrict__ Tep, const double *__restrict__ q0)
+{
+    const int s0 = ik_s_first(p);
+    sh.tgt[slot] = tgt; sh.b[slot] = s0; sh.next[slot] = s0 + 1; sh.best[slot] = kIkNoBest; sh.it[slot] = 0;
+    sh.res[slot] = 0; sh.Elast[slot] = 0.0;
+    for (int k = 0; k < kIkRing; ++k) sh.rec[slot][k] = 0;
+    st.slot = slot;
+    ik_load_target([&](int k, double v) { sh.Td[k][lane] = v; }, Tep + 16 * tgt);
+    ik_search_begin<NJ>(st, p, qlim, tgt, s0, p.has_q0 ? q0 + (int64_t)NJ * tgt : nullptr);
+}
+
+// phase D0: a slot none of whose searches is outstanding (its last running search just failed) must be
+// continued before anything else is started -- this is the reference's "next restart".
+RTB_HD bool ik_starved(int i, const IkWaveShared &sh) { return sh.res[i] == 0 && sh.next[i] == sh.b[i]; }
+
+// phase D2, step 1: idle lane number `r` (of the idle lanes) picks a slot round-robin over the nb busy
+// slots (sh.list) and the q-th next search index of it; returns whether that index may start now.
+RTB_HD bool ik_pick(const IkWaveShared &sh, int r, int nb, int s_last, int &slot, int &s)
+{
+    slot = sh.list[r % nb];
+    s = sh.next[slot] + r / nb;
+    return s <= s_last && s - sh.b[slot] < kIkRing && s < sh.best[slot];
+}
+// step 2 (after every lane has picked): claim the index and start the search
+template <int NJ, class QL>
+RTB_HD void ik_start_spec(IkLane<NJ> &st, IkWaveShared &sh, int lane, const IkDev &p, QL qlim, int slot, int s,
+                          const double *__restrict__ Tep, const double *__restrict__ q0)
+{
+    ik_lds_max(&sh.next[slot], s + 1);
+    const int64_t tgt = sh.tgt[slot];
+    st.slot = slot;
+    ik_load_target([&](int k, double v) { sh.Td[k][lane] = v; }, Tep + 16 * tgt);
+    ik_search_begin<NJ>(st, p, qlim, tgt, s, p.has_q0 ? q0 + (int64_t)NJ * tgt : nullptr);
+}
+
+// Sequential driver (one target, searches in order): the specification the scheduler must reproduce.
+// Used by tests/emu; the kernel never calls it.
+template <int NJ, class CV, class QL>
+RTB_HD void ik_solve_sequential(const IkDev &p, const CV &cv, QL qlim, int64_t tgt, const double *Tep,
+                                const double *q0, double *q_out, int32_t *success, int32_t *iters,
+                                int32_t *searches, double *residual)
+{
+    IkLane<NJ> st;
+    double Td[12];
+    ik_load_target([&](int k, double v) { Td[k] = v; }, Tep + 16 * tgt);
+    const int s_last = ik_s_last(p);
+    int it = 0;
+    for (int s = ik_s_first(p);; ++s) {
+        ik_search_begin<NJ>(st, p, qlim, tgt, s, p.has_q0 ? q0 + (int64_t)NJ * tgt : nullptr);
+        while (!st.fin) ik_iter<NJ>(st, p, cv, qlim, [&](int k) { return Td[k]; });
+        it += st.contrib;
+        if (st.ok || s == s_last) {
+            ik_emit<NJ>(st, p, qlim, tgt, p.has_q0 != 0, st.ok != 0, it, st.E, q_out, success, iters, searches, residual);
+            return;
+        }
+    }
 }
 
 }  // namespace rtbhip

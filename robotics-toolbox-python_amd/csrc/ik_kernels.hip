@@ -2,11 +2,13 @@
 // resident on the device.  Replaces the one-target-per-call IK_LM_c (core/fknm.cpp:394-525 ->
 // core/ik.cpp:19-75,157-209) and the Python loop over targets of IKSolver.solve (robot/IK.py:263-290).
 //
-// Persistent lanes: the grid is sized to the chip, not to N.  Every lane runs the per-target state
-// machine of ik_device.h; a lane whose target finishes (after 5 or after 3000 iterations -- the
-// spread is that wide) takes the next unsolved target from a device-wide counter.  The fetch is
-// aggregated per wave (one atomicAdd for all idle lanes of the wave) so the counter sees at most
-// one atomic per wave per iteration.  This is compute/latency-bound work (~1.5 kflop of dependent
+// Persistent waves: the grid is sized to the chip, not to N.  Every lane runs one SEARCH of one target
+// at a time (ik_device.h); idle lanes take fresh targets from a device-wide counter (one atomicAdd
+// per wave per scheduling pass) and, once the supply is exhausted, later search indices of their own
+// wave's unresolved targets -- the 1 % of targets that need dozens of restarts (up to ~3000
+// sequential iterations in the reference, against a mean of 75) no longer set the kernel's duration.
+// First MI355X measurement of the previous one-lane-per-target version: 13.4 ms per 1e5 targets
+// with 97 % of the lane-iterations idle.  This is compute/latency-bound work (~1.5 kflop of dependent
 // fp64 per iteration, 204 B of I/O per target): MFMA does not apply (7x7 normal equations per lane).
 #include "ik_device.h"
 #include <atomic>
@@ -19,59 +21,98 @@ struct ConstChainIk {
     const RTB_CONST int32_t *jmeta;
 };
 
+// Wave-level driver of the scheduler phases of ik_device.h (the same sequence tests/emu replays on the CPU).
 template <int NJ>
-__global__ __launch_bounds__(kWave) void k_ik(IkDev p, DevChain dc, const double *qlim_g, const double *__restrict__ Tep,
-                                             const double *__restrict__ q0, unsigned long long *counter,
-                                             double *__restrict__ q_out, int32_t *__restrict__ success,
-                                             int32_t *__restrict__ iters, int32_t *__restrict__ searches,
-                                             double *__restrict__ residual)
+__global__ __launch_bounds__(kWave, 2) void k_ik(IkDev p, DevChain dc, const double *qlim_g, const double *__restrict__ Tep,
+                                                const double *__restrict__ q0, unsigned long long *counter,
+                                                double *__restrict__ q_out, int32_t *__restrict__ success,
+                                                int32_t *__restrict__ iters, int32_t *__restrict__ searches,
+                                                double *__restrict__ residual)
 {
+    __shared__ IkWaveShared sh;
     ConstChainIk cv;
     cv.seg = (const RTB_CONST DevSeg *)dc.seg;
     cv.jmeta = (const RTB_CONST int32_t *)dc.jmeta;
     const RTB_CONST double *qlim = (const RTB_CONST double *)qlim_g;
     const int lane = threadIdx.x;
-    IkState<NJ> st;
-    st.tgt = -1; st.E = 0.0; st.iter = 0; st.search = 0; st.it = 0; st.draws = 0;
+    const int s_last = ik_s_last(p);
+    IkLane<NJ> st;
+    st.status = kIkIdle; st.E = 0.0; st.iter = 0; st.s = 0; st.slot = 0; st.fin = 0; st.ok = 0; st.contrib = 0;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) st.q[j] = 0.0;
 #pragma unroll
-    for (int k = 0; k < 12; ++k) st.Td[k] = (k == 0 || k == 4 || k == 8) ? 1.0 : 0.0;
-    bool exhausted = false;
+    for (int k = 0; k < 12; ++k) sh.Td[k][lane] = (k == 0 || k == 4 || k == 8) ? 1.0 : 0.0;
+    unsigned long long busy = 0;     // wave-uniform: slots holding an unresolved target
+    bool exhausted = false;          // wave-uniform: the global supply of fresh targets has run out
+    bool first = true;
+    // watchdog: a correct run resolves some slot at least every (ilimit+2)*(searches+2) iterations
+    const long long patience = (long long)(p.ilimit + 2) * (s_last + 3) + 64;
+    long long quiet = 0;
     for (;;) {
-        const bool need = st.tgt < 0 && !exhausted;
-        const unsigned long long m = __ballot(need);
-        if (m) {   // wave-uniform
-            const int leader = __ffsll((long long)m) - 1;
-            unsigned long long base = 0;
-            if (lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(m));
-            const unsigned lo = __shfl((unsigned)(base & 0xffffffffu), leader);
-            const unsigned hi = __shfl((unsigned)(base >> 32), leader);
-            base = ((unsigned long long)hi << 32) | lo;
-            if (need) {
-                const int64_t t = (int64_t)base + __popcll(m & ((1ull << lane) - 1ull));
-                if (t < p.N) ik_begin<NJ>(st, p, qlim, t, Tep + 16 * t, p.has_q0 ? q0 + (int64_t)NJ * t : nullptr);
-                else exhausted = true;
+        if (first || __any(st.fin != 0)) {
+            first = false;
+            ik_report<NJ>(st, sh, s_last);                                             // phase A
+            __syncthreads();
+            if ((busy >> lane) & 1ull) ik_account(lane, sh, s_last);                    // phase B
+            __syncthreads();
+            ik_finalize<NJ>(st, sh, p, qlim, q_out, success, iters, searches, residual);   // phase C
+            const unsigned long long freed = __ballot(((busy >> lane) & 1ull) && sh.res[lane] != 0);
+            if (freed) quiet = 0;
+            busy &= ~freed;
+            __syncthreads();
+            unsigned long long idle = __ballot(st.status == kIkIdle);
+            const unsigned long long starved = __ballot(((busy >> lane) & 1ull) && ik_starved(lane, sh));
+            if (starved) {                                                              // phase D0: continuations
+                if ((starved >> lane) & 1ull) sh.list[ik_rank(starved, lane)] = lane;
+                __syncthreads();
+                const int r = ik_rank(idle, lane);
+                if (((idle >> lane) & 1ull) && r < __popcll(starved)) {
+                    const int slot = sh.list[r];
+                    ik_start_spec<NJ>(st, sh, lane, p, qlim, slot, sh.next[slot], Tep, q0);
+                }
+                __syncthreads();
+                idle = __ballot(st.status == kIkIdle);
+            }
+            if (!exhausted && idle) {                                                   // phase D1: fresh targets
+                const unsigned long long freeslots = ~busy;
+                // free slots >= idle lanes (every busy slot keeps a lane); the per-pass cap spreads a batch
+                // smaller than the grid's lane count evenly over the waves
+                int nf = __popcll(idle);
+                nf = nf > p.fresh_cap ? p.fresh_cap : nf;
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(counter, (unsigned long long)nf);
+                const unsigned lo = __shfl((unsigned)(base & 0xffffffffu), 0);
+                const unsigned hi = __shfl((unsigned)(base >> 32), 0);
+                base = ((unsigned long long)hi << 32) | lo;
+                long long nvalid = (long long)p.N - (long long)base;
+                nvalid = nvalid < 0 ? 0 : (nvalid > nf ? nf : nvalid);
+                if (nvalid < nf) exhausted = true;
+                if ((freeslots >> lane) & 1ull) sh.list[ik_rank(freeslots, lane)] = lane;
+                __syncthreads();
+                const int r = ik_rank(idle, lane);
+                int myslot = -1;
+                if (((idle >> lane) & 1ull) && r < nvalid) {
+                    myslot = sh.list[r];
+                    ik_start_target<NJ>(st, sh, lane, p, qlim, myslot, (int64_t)base + r, Tep, q0);
+                }
+                busy |= __ballot(((freeslots >> lane) & 1ull) && ik_rank(freeslots, lane) < nvalid);
+                __syncthreads();
+                idle = __ballot(st.status == kIkIdle);
+            }
+            if (idle && busy) {                                                         // phase D2: speculative searches
+                if ((busy >> lane) & 1ull) sh.list[ik_rank(busy, lane)] = lane;
+                __syncthreads();
+                const int nb = __popcll(busy);
+                int slot = 0, s = 0;
+                const bool mine = ((idle >> lane) & 1ull) && ik_pick(sh, ik_rank(idle, lane), nb, s_last, slot, s);
+                __syncthreads();
+                if (mine) ik_start_spec<NJ>(st, sh, lane, p, qlim, slot, s, Tep, q0);
+                __syncthreads();
             }
         }
-        const bool active = st.tgt >= 0;
-        if (!__any(active)) break;
-        int ok = 0;
-        const bool fin = ik_advance<NJ>(st, p, cv, qlim, ok);
-        if (active && fin) {
-            const int64_t t = st.tgt;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) q_out[t * NJ + j] = st.q[j];
-            success[t] = ok;
-            iters[t] = st.it;
-            searches[t] = st.search;
-            residual[t] = st.E;
-            st.tgt = -1;
-        }
-        if (st.tgt < 0) {   // parked lanes keep executing the iteration: keep their state finite
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) st.q[j] = 0.0;
-        }
+        if (busy == 0 && exhausted) break;
+        if (++quiet > patience) break;      // never expected; unresolved targets keep their memset outputs
+        ik_iter<NJ>(st, p, cv, qlim, [&](int k) { return sh.Td[k][lane]; });
     }
 }
 
@@ -141,6 +182,8 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
     const int64_t tiles = (N + kWave - 1) / kWave;
     int64_t g = (int64_t)cus * g_ik_waves_per_cu;
     if (g > tiles) g = tiles;
+    const int64_t cap = (N + g - 1) / g;
+    p.fresh_cap = cap > 64 ? 64 : (int32_t)cap;
     dim3 grid((unsigned)g);
     switch (c->n) {
     case 1: launch_nj<1>(grid, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual); break;

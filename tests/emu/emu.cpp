@@ -7,6 +7,8 @@
 #include "../../robotics-toolbox-python_amd/csrc/ik_device.h"
 #include "../../robotics-toolbox-python_amd/csrc/rne_device.h"
 #include <vector>
+#include <cstdio>
+#include <cstdlib>
 
 using namespace rtbhip;
 
@@ -130,14 +132,124 @@ static void emu_ik_run(const Chain *c, const IkDev &p, const double *Tep, const 
 {
     const DevChain cv = chain_host_view(c);
     const double *qlim = c->qlim.data();
-    for (int64_t t = 0; t < p.N; ++t) {   // one lane at a time: same state machine as the kernel
-        IkState<NJ> st;
-        ik_begin<NJ>(st, p, qlim, t, Tep + 16 * t, p.has_q0 ? q0 + (int64_t)NJ * t : nullptr);
-        int ok = 0;
-        while (!ik_advance<NJ>(st, p, cv, qlim, ok)) {}
-        for (int j = 0; j < NJ; ++j) q_out[t * NJ + j] = st.q[j];
-        success[t] = ok; iters[t] = st.it; searches[t] = st.search; residual[t] = st.E;
+    for (int64_t t = 0; t < p.N; ++t)   // the specification: searches one after another
+        ik_solve_sequential<NJ>(p, cv, qlim, t, Tep, q0, q_out, success, iters, searches, residual);
+}
+
+// Replays k_ik's wave-level driver (ik_kernels.hip) on the CPU: `waves` single-wave workgroups advanced
+// round-robin, one scheduling pass + one LM iteration each per turn, sharing the fresh-target counter.
+template <int NJ>
+struct EmuWave {
+    IkWaveShared sh;
+    IkLane<NJ> st[kWave];
+    unsigned long long busy = 0;
+    bool exhausted = false, first = true, done = false;
+    long long passes = 0, iters = 0, lane_iters_useful = 0;
+};
+
+template <int NJ>
+static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const double *Tep, const double *q0, double *q_out,
+                           int32_t *success, int32_t *iters, int32_t *searches, double *residual, double *stats)
+{
+    const DevChain cv = chain_host_view(c);
+    const double *qlim = c->qlim.data();
+    const int s_last = ik_s_last(p);
+    unsigned long long counter = 0;
+    std::vector<EmuWave<NJ>> W(waves);
+    for (auto &w : W)
+        for (int l = 0; l < kWave; ++l) {
+            IkLane<NJ> &st = w.st[l];
+            st.status = kIkIdle; st.E = 0; st.iter = 0; st.s = 0; st.slot = 0; st.fin = 0; st.ok = 0; st.contrib = 0;
+            for (int j = 0; j < NJ; ++j) st.q[j] = 0.0;
+            for (int k = 0; k < 12; ++k) w.sh.Td[k][l] = (k == 0 || k == 4 || k == 8) ? 1.0 : 0.0;
+        }
+    auto ballot = [&](EmuWave<NJ> &w, auto pred) { unsigned long long m = 0; for (int l = 0; l < kWave; ++l) if (pred(l)) m |= 1ull << l; return m; };
+    int live = waves;
+    long long guard = 0;
+    while (live > 0) {
+        if (++guard > 400000) {
+            if (getenv("EMU_IK_DEBUG"))
+                for (size_t wi = 0; wi < W.size(); ++wi) {
+                    auto &w = W[wi];
+                    if (w.done) continue;
+                    fprintf(stderr, "wave %zu busy=%llx exhausted=%d counter=%llu\n", wi, w.busy, (int)w.exhausted, counter);
+                    for (int l = 0; l < kWave; ++l)
+                        if ((w.busy >> l) & 1ull)
+                            fprintf(stderr, "  slot %d tgt=%lld b=%d next=%d best=%d it=%d res=%d\n", l, (long long)w.sh.tgt[l], w.sh.b[l], w.sh.next[l], w.sh.best[l], w.sh.it[l], w.sh.res[l]);
+                    for (int l = 0; l < kWave; ++l)
+                        fprintf(stderr, "  lane %d status=%d slot=%d s=%d iter=%d fin=%d\n", l, w.st[l].status, w.st[l].slot, w.st[l].s, w.st[l].iter, w.st[l].fin);
+                }
+            return -2;
+        }
+        for (auto &w : W) {
+            if (w.done) continue;
+            bool anyfin = false;
+            for (int l = 0; l < kWave; ++l) anyfin = anyfin || w.st[l].fin != 0;
+            if (w.first || anyfin) {
+                w.first = false;
+                w.passes++;
+                for (int l = 0; l < kWave; ++l) ik_report<NJ>(w.st[l], w.sh, s_last);
+                for (int l = 0; l < kWave; ++l) if ((w.busy >> l) & 1ull) ik_account(l, w.sh, s_last);
+                for (int l = 0; l < kWave; ++l) ik_finalize<NJ>(w.st[l], w.sh, p, qlim, q_out, success, iters, searches, residual);
+                const unsigned long long freed = ballot(w, [&](int l) { return ((w.busy >> l) & 1ull) && w.sh.res[l] != 0; });
+                w.busy &= ~freed;
+                unsigned long long idle = ballot(w, [&](int l) { return w.st[l].status == kIkIdle; });
+                const unsigned long long starved = ballot(w, [&](int l) { return ((w.busy >> l) & 1ull) && ik_starved(l, w.sh); });
+                if (starved) {
+                    for (int l = 0; l < kWave; ++l) if ((starved >> l) & 1ull) w.sh.list[ik_rank(starved, l)] = l;
+                    const int ns = __builtin_popcountll(starved);
+                    if (__builtin_popcountll(idle) < ns) return -3;      // cannot happen: every newly starved slot just released a lane
+                    for (int l = 0; l < kWave; ++l) {
+                        const int r = ik_rank(idle, l);
+                        if (((idle >> l) & 1ull) && r < ns) {
+                            const int slot = w.sh.list[r];
+                            ik_start_spec<NJ>(w.st[l], w.sh, l, p, qlim, slot, w.sh.next[slot], Tep, q0);
+                        }
+                    }
+                    idle = ballot(w, [&](int l) { return w.st[l].status == kIkIdle; });
+                }
+                if (!w.exhausted && idle) {
+                    const unsigned long long freeslots = ~w.busy;
+                    int nf = __builtin_popcountll(idle);
+                    nf = nf > p.fresh_cap ? p.fresh_cap : nf;
+                    const unsigned long long base = counter;
+                    counter += nf;
+                    long long nvalid = (long long)p.N - (long long)base;
+                    nvalid = nvalid < 0 ? 0 : (nvalid > nf ? nf : nvalid);
+                    if (nvalid < nf) w.exhausted = true;
+                    for (int l = 0; l < kWave; ++l) if ((freeslots >> l) & 1ull) w.sh.list[ik_rank(freeslots, l)] = l;
+                    for (int l = 0; l < kWave; ++l) {
+                        const int r = ik_rank(idle, l);
+                        if (((idle >> l) & 1ull) && r < nvalid)
+                            ik_start_target<NJ>(w.st[l], w.sh, l, p, qlim, w.sh.list[r], (int64_t)base + r, Tep, q0);
+                    }
+                    w.busy |= ballot(w, [&](int l) { return ((freeslots >> l) & 1ull) && ik_rank(freeslots, l) < nvalid; });
+                    idle = ballot(w, [&](int l) { return w.st[l].status == kIkIdle; });
+                }
+                if (idle && w.busy) {
+                    for (int l = 0; l < kWave; ++l) if ((w.busy >> l) & 1ull) w.sh.list[ik_rank(w.busy, l)] = l;
+                    const int nb = __builtin_popcountll(w.busy);
+                    int slot[kWave], ss[kWave];
+                    bool mine[kWave];
+                    for (int l = 0; l < kWave; ++l)
+                        mine[l] = ((idle >> l) & 1ull) && ik_pick(w.sh, ik_rank(idle, l), nb, s_last, slot[l], ss[l]);
+                    for (int l = 0; l < kWave; ++l) if (mine[l]) ik_start_spec<NJ>(w.st[l], w.sh, l, p, qlim, slot[l], ss[l], Tep, q0);
+                }
+            }
+            if (w.busy == 0 && w.exhausted) { w.done = true; --live; continue; }
+            w.iters++;
+            for (int l = 0; l < kWave; ++l) {
+                if (w.st[l].status == kIkRun) w.lane_iters_useful++;
+                ik_iter<NJ>(w.st[l], p, cv, qlim, [&](int k) { return w.sh.Td[k][l]; });
+            }
+        }
     }
+    if (stats) {
+        long long mx = 0, tot = 0, useful = 0, passes = 0;
+        for (auto &w : W) { mx = std::max(mx, w.iters); tot += w.iters; useful += w.lane_iters_useful; passes += w.passes; }
+        stats[0] = (double)mx; stats[1] = (double)tot; stats[2] = (double)useful; stats[3] = (double)passes;
+    }
+    return 0;
 }
 
 extern "C" int emu_ik(rtbhip_chain_t h, const double *Tep, int64_t N, const double *q0, int ilimit, int slimit, double tol,
@@ -148,7 +260,7 @@ extern "C" int emu_ik(rtbhip_chain_t h, const double *Tep, int64_t N, const doub
     if (!c || c->n < 1 || c->n > kRegMaxJoints) return -1;
     IkDev p;
     p.ilimit = ilimit; p.slimit = slimit; p.reject_jl = reject_jl; p.method = method; p.flavour = flavour;
-    p.has_q0 = q0 != nullptr; p.tol = tol; p.lambda = lambda; p.seed = seed; p.N = N;
+    p.has_q0 = q0 != nullptr; p.tol = tol; p.lambda = lambda; p.seed = seed; p.N = N; p.fresh_cap = 64; p.pad = 0;
     for (int k = 0; k < 6; ++k) p.we[k] = we6 ? we6[k] : 1.0;
     Affine none; none.used = 0;
     chain_tail(c, none, p.tail);
@@ -163,6 +275,33 @@ extern "C" int emu_ik(rtbhip_chain_t h, const double *Tep, int64_t N, const doub
     default: emu_ik_run<8>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
     }
     return 0;
+}
+
+extern "C" int emu_ik_wave(rtbhip_chain_t h, int waves, double *stats, const double *Tep, int64_t N, const double *q0, int ilimit, int slimit, double tol,
+                      int reject_jl, const double *we6, double lambda, int method, int flavour, uint64_t seed,
+                      double *q_out, int32_t *success, int32_t *iters, int32_t *searches, double *residual)
+{
+    Chain *c = chain_from_handle(h);
+    if (!c || c->n < 1 || c->n > kRegMaxJoints) return -1;
+    IkDev p;
+    p.ilimit = ilimit; p.slimit = slimit; p.reject_jl = reject_jl; p.method = method; p.flavour = flavour;
+    p.has_q0 = q0 != nullptr; p.tol = tol; p.lambda = lambda; p.seed = seed; p.N = N; p.fresh_cap = 64; p.pad = 0;
+    for (int k = 0; k < 6; ++k) p.we[k] = we6 ? we6[k] : 1.0;
+    Affine none; none.used = 0;
+    chain_tail(c, none, p.tail);
+    { const int64_t g = waves; const int64_t cap = (N + g - 1) / g; p.fresh_cap = cap > 64 ? 64 : (int)cap; }
+    int rc = 0;
+    switch (c->n) {
+    case 1: rc = emu_ik_wave_run<1>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
+    case 2: rc = emu_ik_wave_run<2>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
+    case 3: rc = emu_ik_wave_run<3>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
+    case 4: rc = emu_ik_wave_run<4>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
+    case 5: rc = emu_ik_wave_run<5>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
+    case 6: rc = emu_ik_wave_run<6>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
+    case 7: rc = emu_ik_wave_run<7>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
+    default: rc = emu_ik_wave_run<8>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
+    }
+    return rc;
 }
 
 template <int NJ>

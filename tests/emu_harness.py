@@ -49,6 +49,8 @@ def lib():
         _lib.emu_sincos.argtypes = [_vp, _i64, _vp, _vp, _i32]
         _lib.emu_ik.argtypes = [_u64, _vp, _i64, _vp, _i32, _i32, C.c_double, _i32, _vp, C.c_double, _i32, _i32, _u64,
                                 _vp, _vp, _vp, _vp, _vp]
+        _lib.emu_ik_wave.argtypes = [_u64, _i32, _vp, _vp, _i64, _vp, _i32, _i32, C.c_double, _i32, _vp, C.c_double, _i32,
+                                     _i32, _u64, _vp, _vp, _vp, _vp, _vp]
         _lib.rtbhip_ik_restart.argtypes = [_u64, _u64, _i64, _i32, _vp]
         _lib.rtbhip_last_error.restype = C.c_char_p
     return _lib
@@ -120,8 +122,11 @@ METHODS = {"chan": 0, "wampler": 1, "sugihara": 2}
 
 
 def ik(ets, Tep, q0=None, ilimit=30, slimit=100, tol=1e-6, joint_limits=True, mask=None, k=1.0, method="chan",
-       flavour=0, seed=0):
-    """Runs the IK kernel's per-lane state machine (ik_device.h) on the CPU, target by target."""
+       flavour=0, seed=0, waves=0, stats=None):
+    """Runs the IK kernel's per-lane search functions (ik_device.h) on the CPU.  waves == 0: the
+    sequential specification (searches of a target one after another); waves > 0: a replay of the
+    kernel's per-wave speculative scheduler with that many single-wave workgroups (stats, if a list,
+    receives [max wave iterations, total wave iterations, useful lane iterations, scheduling passes])."""
     h = chain_handle(ets)
     n = ets.n
     Tep = np.ascontiguousarray(np.asarray(Tep, dtype=np.float64).reshape(-1, 4, 4))
@@ -130,9 +135,16 @@ def ik(ets, Tep, q0=None, ilimit=30, slimit=100, tol=1e-6, joint_limits=True, ma
     we = None if mask is None else np.ascontiguousarray(mask, dtype=np.float64)
     q = np.full((N, n), np.nan); ok = np.zeros(N, np.int32); it = np.zeros(N, np.int32); se = np.zeros(N, np.int32)
     E = np.zeros(N)
-    rc = lib().emu_ik(h, _p(Tep), N, _p(q0a), ilimit, slimit, tol, int(joint_limits), _p(we), k, METHODS[method], flavour,
-                      seed, _p(q), _p(ok), _p(it), _p(se), _p(E))
-    assert rc == 0
+    if waves > 0:
+        st = np.zeros(4)
+        rc = lib().emu_ik_wave(h, waves, _p(st), _p(Tep), N, _p(q0a), ilimit, slimit, tol, int(joint_limits), _p(we), k,
+                               METHODS[method], flavour, seed, _p(q), _p(ok), _p(it), _p(se), _p(E))
+        if stats is not None:
+            stats[:] = list(st)
+    else:
+        rc = lib().emu_ik(h, _p(Tep), N, _p(q0a), ilimit, slimit, tol, int(joint_limits), _p(we), k, METHODS[method], flavour,
+                          seed, _p(q), _p(ok), _p(it), _p(se), _p(E))
+    assert rc == 0, rc
     return q, ok, it, se, E
 
 

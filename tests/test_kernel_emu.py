@@ -246,3 +246,24 @@ def test_ik_restart_generator_is_uniform_in_limits():
     u = (r - ch.qlim[0]) / (ch.qlim[1] - ch.qlim[0])
     assert abs(u.mean() - 0.5) < 0.02 and abs(u.std() - 12 ** -0.5) < 0.02
     assert len(np.unique(r)) == r.size
+
+
+@pytest.mark.parametrize("flavour", [0, 1])
+@pytest.mark.parametrize("N,waves,slimit,with_q0", [(300, 3, 100, False), (64, 1, 100, False), (130, 4, 7, True),
+                                                     (1, 2, 100, False), (500, 2, 40, False)])
+def test_ik_wave_scheduler_equals_sequential_searches(flavour, N, waves, slimit, with_q0):
+    """The per-wave speculative scheduler (fresh targets, then parallel later searches, accounted in
+    search order) must report exactly what running each target's searches one after another reports,
+    including for unreachable targets that exhaust every search and joint-limit rejections."""
+    ets, ch = _panda_limited()
+    rng = np.random.default_rng(23 + N)
+    Tep = oracle.fkine(ch, rng.uniform(ch.qlim[0], ch.qlim[1], (N, 7)))
+    Tep[::17, :3, 3] += 2.5                     # some unreachable targets: every search fails
+    q0 = rng.uniform(ch.qlim[0], ch.qlim[1], (N, 7)) if with_q0 else None
+    a = emu.ik(ets, Tep, q0=q0, slimit=slimit, flavour=flavour, seed=11)
+    st = [0, 0, 0, 0]
+    b = emu.ik(ets, Tep, q0=q0, slimit=slimit, flavour=flavour, seed=11, waves=waves, stats=st)
+    for x, y in zip(a, b):
+        nt.assert_array_equal(x, y)
+    assert a[1].sum() < N                        # the failures really are in the mix
+    assert st[2] >= a[2].sum() - N * 2           # speculation only ever ADDS lane-iterations
