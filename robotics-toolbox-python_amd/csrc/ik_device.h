@@ -114,6 +114,7 @@ RTB_HD void ik_lm_step(const double (&jac)[6 * NJ], const double (&e)[6], const 
             A[r][c] = (r == c) ? a + wn : a;
         }
     }
+    sched_fence();   // J is dead from here on: do not let the factorisation overlap the products above
     // LDL^T: A = L D L^T
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -166,18 +167,19 @@ RTB_HD void ik_lm_step(const double (&jac)[6 * NJ], const double (&e)[6], const 
 //   flavour 1 (IK.py)       s = 0 .. s_last, s_last = max(slimit,1)-1; start: q0 / draw 0 for s == 0,
 //                           draw s otherwise (IK.py:222-240,351-357); success reports s+1, failure
 //                           reports slimit and the last search's final q.
-// The target pose (R row-major (9), t (3)) is NOT part of the lane state: it is read once per
-// iteration, so the kernel keeps it in the wave's LDS (IkWaveShared::Td, 24 VGPRs saved) and every
-// function below reaches it through an accessor  td(k) -> double / tdput(k, v).
+// The target pose (R row-major (9), t (3)) and the joint vector q are NOT part of the register state:
+// each is read once at the top of an iteration (and q written once at the bottom), so the kernel
+// keeps them in the wave's LDS (IkWaveShared::Td / ::q, 38 VGPRs that would otherwise be live across
+// the whole iteration and push the kernel into scratch) and every function below reaches them through
+// accessors:  td(k) -> double, tdput(k, v);  qa.get(j) -> double, qa.put(j, v).
 template <int NJ>
 struct IkLane {
-    double q[NJ];
     double E;          // E of the last iteration evaluated
     int32_t iter;      // the reference's in-search iteration counter
     int32_t s;         // search index
     int32_t slot;      // target slot of this wave (scheduler), unused by the sequential driver
     int32_t status;    // kIkIdle / kIkRun / kIkParkedOk / kIkParkedLast
-    int32_t fin, ok, contrib;   // set by ik_iter when the search ended in this iteration
+    int32_t fin, ok;   // set by ik_iter when the search ended in this iteration (it contributes `iter` iterations)
 };
 constexpr int kIkIdle = 0, kIkRun = 1, kIkParkedOk = 2, kIkParkedLast = 3;
 
@@ -200,20 +202,23 @@ RTB_HD void ik_load_target(TDPut tdput, const double *Tep16)
 }
 
 // Start search s of target tgt in this lane (the target pose must already be loaded).
-template <int NJ, class QL>
-RTB_HD void ik_search_begin(IkLane<NJ> &st, const IkDev &p, QL qlim, int64_t tgt, int s, const double *q0row)
+template <int NJ, class QL, class QA>
+RTB_HD void ik_search_begin(IkLane<NJ> &st, QA qa, const IkDev &p, QL qlim, int64_t tgt, int s, const double *q0row)
 {
     st.s = s;
     st.E = 0.0;
-    st.fin = 0; st.ok = 0; st.contrib = 0;
+    st.fin = 0; st.ok = 0;
     const int s0 = ik_s_first(p);
     st.iter = (p.flavour == 0 && s == s0) ? 1 : 0;          // ik.cpp:39 vs :67
     if (s == s0 && q0row) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) st.q[j] = q0row[j];
+        for (int j = 0; j < NJ; ++j) qa.put(j, q0row[j]);
     } else {
         const int draw = p.flavour == 0 ? s - 1 - (q0row ? 1 : 0) : s;
-        ik_restart<NJ>(p.seed, tgt, draw, qlim, st.q);
+        double qn[NJ];
+        ik_restart<NJ>(p.seed, tgt, draw, qlim, qn);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) qa.put(j, qn[j]);
     }
     st.status = kIkRun;
 }
@@ -228,13 +233,19 @@ RTB_HD double ik_wrap_py(double q)                                              
 
 // ONE LM iteration of the lane's current search.  Every lane of a wave executes this whatever its
 // status (idle / parked lanes compute on their stale state and discard the result) so the wave has a
-// single instruction stream.  Sets st.fin / st.ok / st.contrib when the search ended.
-template <int NJ, class CV, class QL, class TD>
-RTB_HD void ik_iter(IkLane<NJ> &st, const IkDev &p, const CV &cv, QL qlim, TD td)
+// single instruction stream.  Sets st.fin / st.ok when the search ended.
+template <int NJ, class CV, class QL, class TD, class QA>
+RTB_HD void ik_iter(IkLane<NJ> &st, const IkDev &p, const CV &cv, QL qlim, TD td, QA qa)
 {
     Pose P;
     double jac[6 * NJ], e[6], dq[NJ];
-    reg_core<NJ, true>(cv, p.tail, 0, st.q, P, jac);           // ik.cpp:44,56 / IK.py:994,1009
+    {
+        double qv[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) qv[j] = qa.get(j);
+        reg_core<NJ, true>(cv, p.tail, 0, qv, P, jac);         // ik.cpp:44,56 / IK.py:994,1009
+    }
+    sched_fence();
     ik_angle_axis(P, td, e);
     double E = 0.0;
 #pragma unroll
@@ -250,43 +261,46 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const IkDev &p, const CV &cv, QL qlim, TD td
             bool ok = true;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                st.q[j] = ik_wrap_c(st.q[j]);
-                if (st.q[j] < qlim[j] || st.q[j] > qlim[NJ + j]) ok = false;   // ik.cpp:227-239
+                const double w = ik_wrap_c(qa.get(j));
+                qa.put(j, w);
+                if (w < qlim[j] || w > qlim[NJ + j]) ok = false;   // ik.cpp:227-239
             }
-            st.fin = 1; st.ok = (ok || !p.reject_jl) ? 1 : 0; st.contrib = st.iter;
+            st.fin = 1; st.ok = (ok || !p.reject_jl) ? 1 : 0;
         } else {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) st.q[j] += dq[j];      // ik.cpp:57
+            for (int j = 0; j < NJ; ++j) qa.put(j, qa.get(j) + dq[j]);      // ik.cpp:57
             st.iter++;
-            if (st.iter > p.ilimit) { st.fin = 1; st.ok = 0; st.contrib = st.iter; }
+            if (st.iter > p.ilimit) { st.fin = 1; st.ok = 0; }
         }
     } else {
         st.iter++;                                              // IK.py:315
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) st.q[j] += dq[j];          // the step is taken before E is tested (IK.py:319-327)
+        for (int j = 0; j < NJ; ++j) dq[j] += qa.get(j);        // the step is taken before E is tested (IK.py:319-327)
         if (arrived) {
             bool ok = true;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                st.q[j] = ik_wrap_py(st.q[j]);
-                if (st.q[j] < qlim[j] || st.q[j] > qlim[NJ + j]) ok = false;
+                dq[j] = ik_wrap_py(dq[j]);
+                if (dq[j] < qlim[j] || dq[j] > qlim[NJ + j]) ok = false;
             }
-            st.fin = 1; st.ok = (ok || !p.reject_jl) ? 1 : 0; st.contrib = st.iter;   // IK.py:336-351
+            st.fin = 1; st.ok = (ok || !p.reject_jl) ? 1 : 0;   // IK.py:336-351
         } else if (st.iter >= p.ilimit) {
-            st.fin = 1; st.ok = 0; st.contrib = st.iter;
+            st.fin = 1; st.ok = 0;
         }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) qa.put(j, dq[j]);
     }
 }
 
 // What the reference reports for a target whose winning / last search is held by this lane.
-template <int NJ, class QL>
-RTB_HD void ik_emit(const IkLane<NJ> &st, const IkDev &p, QL qlim, int64_t tgt, bool has_q0, bool success, int it_total,
+template <int NJ, class QL, class QA>
+RTB_HD void ik_emit(const IkLane<NJ> &st, QA qa, const IkDev &p, QL qlim, int64_t tgt, bool has_q0, bool success, int it_total,
                     double E_last, double *__restrict__ q_out, int32_t *__restrict__ success_out,
                     int32_t *__restrict__ iters, int32_t *__restrict__ searches, double *__restrict__ residual)
 {
     double qf[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) qf[j] = st.q[j];
+    for (int j = 0; j < NJ; ++j) qf[j] = qa.get(j);
     int se;
     if (success) {
         se = p.flavour == 0 ? st.s : st.s + 1;
@@ -324,8 +338,17 @@ struct IkWaveShared {
     int32_t it[64];                         // iterations accounted so far
     int32_t res[64];                        // 0 unresolved, 1 won (winner = b), 2 failed
     int32_t list[64];                       // scratch: compacted slot list
-    int32_t rec[64][kIkRing];               // per outstanding search: 1 finished | 2 ok | contrib << 2
+    uint16_t rec[64][kIkRing];              // per outstanding search: 1 finished | 2 ok | iterations << 2
     double Td[12][64];                      // per LANE: the target pose of the search the lane is running
+    double q[kRegMaxJoints][64];            // per LANE: the joint vector of that search
+};
+constexpr int kIkMaxIlimit = 16000;         // (ilimit + 1) << 2 must fit the 16-bit record
+
+struct IkLdsQ {   // accessor of one lane's q column in the wave's LDS
+    IkWaveShared *sh;
+    int lane;
+    RTB_HD double get(int j) const { return sh->q[j][lane]; }
+    RTB_HD void put(int j, double v) const { sh->q[j][lane] = v; }
 };
 constexpr int kIkNoBest = 0x7fffffff;
 
@@ -359,7 +382,7 @@ template <int NJ>
 RTB_HD void ik_report(IkLane<NJ> &st, IkWaveShared &sh, int s_last)
 {
     if (st.status != kIkRun || !st.fin) return;
-    sh.rec[st.slot][st.s & (kIkRing - 1)] = 1 | (st.ok ? 2 : 0) | (st.contrib << 2);
+    sh.rec[st.slot][st.s & (kIkRing - 1)] = (uint16_t)(1 | (st.ok ? 2 : 0) | (st.iter << 2));
     if (st.ok) ik_lds_min(&sh.best[st.slot], st.s);
     if (st.s == s_last) sh.Elast[st.slot] = st.E;
     st.status = st.ok ? kIkParkedOk : (st.s == s_last ? kIkParkedLast : kIkIdle);
@@ -384,7 +407,7 @@ RTB_HD void ik_account(int i, IkWaveShared &sh, int s_last)
 
 // phase C: parked lanes of a resolved slot emit / release; searches beyond a known success are cancelled
 template <int NJ, class QL>
-RTB_HD void ik_finalize(IkLane<NJ> &st, IkWaveShared &sh, const IkDev &p, QL qlim, double *__restrict__ q_out,
+RTB_HD void ik_finalize(IkLane<NJ> &st, IkWaveShared &sh, int lane, const IkDev &p, QL qlim, double *__restrict__ q_out,
                         int32_t *__restrict__ success, int32_t *__restrict__ iters, int32_t *__restrict__ searches,
                         double *__restrict__ residual)
 {
@@ -392,11 +415,11 @@ RTB_HD void ik_finalize(IkLane<NJ> &st, IkWaveShared &sh, const IkDev &p, QL qli
     const int res = sh.res[st.slot];
     if (res == 1) {
         if (st.status == kIkParkedOk && st.s == sh.b[st.slot])
-            ik_emit<NJ>(st, p, qlim, sh.tgt[st.slot], p.has_q0 != 0, true, sh.it[st.slot], 0.0, q_out, success, iters, searches, residual);
+            ik_emit<NJ>(st, IkLdsQ{&sh, lane}, p, qlim, sh.tgt[st.slot], p.has_q0 != 0, true, sh.it[st.slot], 0.0, q_out, success, iters, searches, residual);
         st.status = kIkIdle;
     } else if (res == 2) {
         if (st.status == kIkParkedLast)
-            ik_emit<NJ>(st, p, qlim, sh.tgt[st.slot], p.has_q0 != 0, false, sh.it[st.slot], sh.Elast[st.slot], q_out, success, iters, searches, residual);
+            ik_emit<NJ>(st, IkLdsQ{&sh, lane}, p, qlim, sh.tgt[st.slot], p.has_q0 != 0, false, sh.it[st.slot], sh.Elast[st.slot], q_out, success, iters, searches, residual);
         st.status = kIkIdle;
     } else if (st.s > sh.best[st.slot]) {
         st.status = kIkIdle;      // a lower-indexed search already succeeded: this one can never be reported
@@ -414,7 +437,7 @@ RTB_HD void ik_start_target(IkLane<NJ> &st, IkWaveShared &sh, int lane, const Ik
     for (int k = 0; k < kIkRing; ++k) sh.rec[slot][k] = 0;
     st.slot = slot;
     ik_load_target([&](int k, double v) { sh.Td[k][lane] = v; }, Tep + 16 * tgt);
-    ik_search_begin<NJ>(st, p, qlim, tgt, s0, p.has_q0 ? q0 + (int64_t)NJ * tgt : nullptr);
+    ik_search_begin<NJ>(st, IkLdsQ{&sh, lane}, p, qlim, tgt, s0, p.has_q0 ? q0 + (int64_t)NJ * tgt : nullptr);
 }
 
 // phase D0: a slot none of whose searches is outstanding (its last running search just failed) must be
@@ -438,7 +461,7 @@ RTB_HD void ik_start_spec(IkLane<NJ> &st, IkWaveShared &sh, int lane, const IkDe
     const int64_t tgt = sh.tgt[slot];
     st.slot = slot;
     ik_load_target([&](int k, double v) { sh.Td[k][lane] = v; }, Tep + 16 * tgt);
-    ik_search_begin<NJ>(st, p, qlim, tgt, s, p.has_q0 ? q0 + (int64_t)NJ * tgt : nullptr);
+    ik_search_begin<NJ>(st, IkLdsQ{&sh, lane}, p, qlim, tgt, s, p.has_q0 ? q0 + (int64_t)NJ * tgt : nullptr);
 }
 
 // Sequential driver (one target, searches in order): the specification the scheduler must reproduce.
@@ -449,16 +472,21 @@ RTB_HD void ik_solve_sequential(const IkDev &p, const CV &cv, QL qlim, int64_t t
                                 int32_t *searches, double *residual)
 {
     IkLane<NJ> st;
-    double Td[12];
+    double Td[12], qs[NJ];
+    struct QLocal {
+        double *q;
+        RTB_HD double get(int j) const { return q[j]; }
+        RTB_HD void put(int j, double v) const { q[j] = v; }
+    } qa{qs};
     ik_load_target([&](int k, double v) { Td[k] = v; }, Tep + 16 * tgt);
     const int s_last = ik_s_last(p);
     int it = 0;
     for (int s = ik_s_first(p);; ++s) {
-        ik_search_begin<NJ>(st, p, qlim, tgt, s, p.has_q0 ? q0 + (int64_t)NJ * tgt : nullptr);
-        while (!st.fin) ik_iter<NJ>(st, p, cv, qlim, [&](int k) { return Td[k]; });
-        it += st.contrib;
+        ik_search_begin<NJ>(st, qa, p, qlim, tgt, s, p.has_q0 ? q0 + (int64_t)NJ * tgt : nullptr);
+        while (!st.fin) ik_iter<NJ>(st, p, cv, qlim, [&](int k) { return Td[k]; }, qa);
+        it += st.iter;
         if (st.ok || s == s_last) {
-            ik_emit<NJ>(st, p, qlim, tgt, p.has_q0 != 0, st.ok != 0, it, st.E, q_out, success, iters, searches, residual);
+            ik_emit<NJ>(st, qa, p, qlim, tgt, p.has_q0 != 0, st.ok != 0, it, st.E, q_out, success, iters, searches, residual);
             return;
         }
     }

@@ -22,8 +22,11 @@ struct ConstChainIk {
 };
 
 // Wave-level driver of the scheduler phases of ik_device.h (the same sequence tests/emu replays on the CPU).
+#ifndef RTB_IK_WAVES
+#define RTB_IK_WAVES 2
+#endif
 template <int NJ>
-__global__ __launch_bounds__(kWave, 2) void k_ik(IkDev p, DevChain dc, const double *qlim_g, const double *__restrict__ Tep,
+__global__ __launch_bounds__(kWave, RTB_IK_WAVES) void k_ik(IkDev p, DevChain dc, const double *qlim_g, const double *__restrict__ Tep,
                                                 const double *__restrict__ q0, unsigned long long *counter,
                                                 double *__restrict__ q_out, int32_t *__restrict__ success,
                                                 int32_t *__restrict__ iters, int32_t *__restrict__ searches,
@@ -37,9 +40,9 @@ __global__ __launch_bounds__(kWave, 2) void k_ik(IkDev p, DevChain dc, const dou
     const int lane = threadIdx.x;
     const int s_last = ik_s_last(p);
     IkLane<NJ> st;
-    st.status = kIkIdle; st.E = 0.0; st.iter = 0; st.s = 0; st.slot = 0; st.fin = 0; st.ok = 0; st.contrib = 0;
+    st.status = kIkIdle; st.E = 0.0; st.iter = 0; st.s = 0; st.slot = 0; st.fin = 0; st.ok = 0;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) st.q[j] = 0.0;
+    for (int j = 0; j < NJ; ++j) sh.q[j][lane] = 0.0;
 #pragma unroll
     for (int k = 0; k < 12; ++k) sh.Td[k][lane] = (k == 0 || k == 4 || k == 8) ? 1.0 : 0.0;
     unsigned long long busy = 0;     // wave-uniform: slots holding an unresolved target
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(kWave, 2) void k_ik(IkDev p, DevChain dc, const dou
             __syncthreads();
             if ((busy >> lane) & 1ull) ik_account(lane, sh, s_last);                    // phase B
             __syncthreads();
-            ik_finalize<NJ>(st, sh, p, qlim, q_out, success, iters, searches, residual);   // phase C
+            ik_finalize<NJ>(st, sh, lane, p, qlim, q_out, success, iters, searches, residual);   // phase C
             const unsigned long long freed = __ballot(((busy >> lane) & 1ull) && sh.res[lane] != 0);
             if (freed) quiet = 0;
             busy &= ~freed;
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(kWave, 2) void k_ik(IkDev p, DevChain dc, const dou
         }
         if (busy == 0 && exhausted) break;
         if (++quiet > patience) break;      // never expected; unresolved targets keep their memset outputs
-        ik_iter<NJ>(st, p, cv, qlim, [&](int k) { return sh.Td[k][lane]; });
+        ik_iter<NJ>(st, p, cv, qlim, [&](int k) { return sh.Td[k][lane]; }, IkLdsQ{&sh, lane});
     }
 }
 
@@ -151,6 +154,7 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
               hipStream_t s)
 {
     if (N == 0) return RTBHIP_OK;
+    if (ip.ilimit > kIkMaxIlimit) { set_error("ik_lm: ilimit above 16000 is not supported by the device scheduler"); return RTBHIP_ELIMIT; }
     if (c->n > kRegMaxJoints) { set_error("ik_lm: this build solves chains of up to 8 joints on the device"); return RTBHIP_ELIMIT; }
     for (int j = 0; j < c->n; ++j)
         if (jm_jq(c->jmeta[j]) != j) { set_error("ik_lm: jindex must equal the joint order (the reference's ik.cpp:57 adds dq in that order)"); return RTBHIP_EINVAL; }
@@ -179,9 +183,10 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
     }
     unsigned long long *ctr = ring + (g_ctr_next.fetch_add(1) % kCtrRing);
     RTB_HIP(hipMemsetAsync(ctr, 0, sizeof(unsigned long long), s));
-    const int64_t tiles = (N + kWave - 1) / kWave;
+    // a batch smaller than the grid's lane count is spread over ALL the waves (fresh_cap targets per
+    // wave and pass) instead of filling ceil(N/64) of them: every SIMD then holds its share of the tail
     int64_t g = (int64_t)cus * g_ik_waves_per_cu;
-    if (g > tiles) g = tiles;
+    if (g > N) g = N;
     const int64_t cap = (N + g - 1) / g;
     p.fresh_cap = cap > 64 ? 64 : (int32_t)cap;
     dim3 grid((unsigned)g);

@@ -159,8 +159,8 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
     for (auto &w : W)
         for (int l = 0; l < kWave; ++l) {
             IkLane<NJ> &st = w.st[l];
-            st.status = kIkIdle; st.E = 0; st.iter = 0; st.s = 0; st.slot = 0; st.fin = 0; st.ok = 0; st.contrib = 0;
-            for (int j = 0; j < NJ; ++j) st.q[j] = 0.0;
+            st.status = kIkIdle; st.E = 0; st.iter = 0; st.s = 0; st.slot = 0; st.fin = 0; st.ok = 0;
+            for (int j = 0; j < NJ; ++j) w.sh.q[j][l] = 0.0;
             for (int k = 0; k < 12; ++k) w.sh.Td[k][l] = (k == 0 || k == 4 || k == 8) ? 1.0 : 0.0;
         }
     auto ballot = [&](EmuWave<NJ> &w, auto pred) { unsigned long long m = 0; for (int l = 0; l < kWave; ++l) if (pred(l)) m |= 1ull << l; return m; };
@@ -190,7 +190,7 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
                 w.passes++;
                 for (int l = 0; l < kWave; ++l) ik_report<NJ>(w.st[l], w.sh, s_last);
                 for (int l = 0; l < kWave; ++l) if ((w.busy >> l) & 1ull) ik_account(l, w.sh, s_last);
-                for (int l = 0; l < kWave; ++l) ik_finalize<NJ>(w.st[l], w.sh, p, qlim, q_out, success, iters, searches, residual);
+                for (int l = 0; l < kWave; ++l) ik_finalize<NJ>(w.st[l], w.sh, l, p, qlim, q_out, success, iters, searches, residual);
                 const unsigned long long freed = ballot(w, [&](int l) { return ((w.busy >> l) & 1ull) && w.sh.res[l] != 0; });
                 w.busy &= ~freed;
                 unsigned long long idle = ballot(w, [&](int l) { return w.st[l].status == kIkIdle; });
@@ -240,7 +240,7 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
             w.iters++;
             for (int l = 0; l < kWave; ++l) {
                 if (w.st[l].status == kIkRun) w.lane_iters_useful++;
-                ik_iter<NJ>(w.st[l], p, cv, qlim, [&](int k) { return w.sh.Td[k][l]; });
+                ik_iter<NJ>(w.st[l], p, cv, qlim, [&](int k) { return w.sh.Td[k][l]; }, IkLdsQ{&w.sh, l});
             }
         }
     }
