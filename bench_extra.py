@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--n-rne", type=int, default=1250000)
     ap.add_argument("--n-ik", type=int, default=100000)
+    ap.add_argument("--n-fleet", type=int, default=1000000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--tune", action="append", default=[])
     args = ap.parse_args()
@@ -106,21 +107,47 @@ def main():
         print(json.dumps(line), flush=True)
 
     if "fleet" in what:
-        rng = np.random.default_rng(4)
-        panda = rtbhip.models.Panda().ets()
-        puma = rtbhip.models.DH.Puma560().ets()
-        pdh = rtbhip.models.DH.Panda().ets()
-        chs = [panda, puma, pdh, panda, puma, pdh, panda, puma]
-        N = 250000
-        qs = [torch.from_numpy(rng.uniform(-3, 3, (N, c.n))).cuda() for c in chs]
-        avg, best = ev_time(lambda: rtbhip.fleet_fkine_jacob(chs, qs), args.steps, 2)
+        # BASELINE configs[4]: 16 URDF arms (rtbhip/data/urdf, 4..10 joints on the path to the deepest
+        # leaf), N configurations each, q ~ U(qlim) seed 4+i, ONE variable-length-chain launch
+        from rtbhip import urdf
+        N = args.n_fleet
+        robots = [urdf.load(nm) for nm in urdf.FLEET16]
+        chs = [r.ets() for r in robots]
+        qs = []
+        for i, c in enumerate(chs):
+            ql = np.clip(c.qlim, -2 * np.pi, 2 * np.pi)
+            qs.append(torch.from_numpy(np.random.default_rng(4 + i).uniform(ql[0], ql[1], (N, c.n))).cuda())
+        avg, best = ev_time(lambda: rtbhip.fleet_fkine_jacob(chs, qs), max(3, args.steps // 2), 2)
         byts = sum(N * (8 * c.n + 128 + 48 * c.n) for c in chs)
-        line = {"metric": "configurations/sec (mixed fleet of %d chains, one launch)" % len(chs),
-                "value": N * len(chs) / (avg * 1e-3), "unit": "configurations/s", "kernel_avg_ms": avg,
+        line = {"metric": "configurations/sec (mixed fleet: %d URDF arms x %d, one launch)" % (len(chs), N),
+                "value": N * len(chs) / (avg * 1e-3), "unit": "configurations/s", "kernel_avg_ms": avg, "kernel_min_ms": best,
+                "arms": {nm: c.n for nm, c in zip(urdf.FLEET16, chs)},
                 "roofline": {"bound": "hbm", "achieved": byts / (avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                             "frac": byts / (avg * 1e-3) / 1e9 / 8000.0}}
+                             "frac": byts / (avg * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": byts}}
+        # the same 16 batches through the per-chain register-resident kernel, 16 launches
+        def per_chain():
+            for c, q in zip(chs, qs):
+                c.fkine_jacob0(q)
+        avg2, best2 = ev_time(per_chain, max(3, args.steps // 2), 1)
+        line["per_chain_launches"] = {"value": N * len(chs) / (avg2 * 1e-3), "kernel_avg_ms": avg2,
+                                      "achieved_GBs": byts / (avg2 * 1e-3) / 1e9}
+        if not args.no_cpu:
+            from oracle import ref_harness
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from helpers import chain_from_ets
+            if ref_harness.available():
+                n = 20000
+                t_cpu, err = 0.0, 0.0
+                for c, q in zip(chs, qs):
+                    ref = ref_harness.RefETS(chain_from_ets(c))
+                    qh = q[:n].cpu().numpy()
+                    t0 = time.perf_counter(); Tc = ref.fkine(qh); Jc = ref.jacob0_batch(qh); t_cpu += time.perf_counter() - t0
+                    Tg, Jg = c.fkine_jacob0(q[:n])
+                    err = max(err, float(np.abs(Tg.cpu().numpy() - Tc).max()), float(np.abs(Jg.cpu().numpy() - Jc).max()))
+                line["cpu_baseline"] = {"value": n * len(chs) / t_cpu, "unit": "configurations/s", "cores": 1, "kind": "reference",
+                                        "sample": "first %d configurations of each of the 16 arms; ETS_fkine + per-row ETS_jacob0" % n,
+                                        "max_abs_err_gpu_vs_cpu": err}
         print(json.dumps(line), flush=True)
-
 
 if __name__ == "__main__":
     main()

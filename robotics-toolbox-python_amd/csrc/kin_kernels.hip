@@ -79,41 +79,46 @@ __global__ __launch_bounds__(kWave) void k_kin(KinParams kp, DevChain dc,
 #ifndef RTB_REG_WAVES
 #define RTB_REG_WAVES 3   // waves per SIMD the register allocator must leave room for (<= 168 VGPRs)
 #endif
+// One register-resident tile (64 configurations) of a chain with NJ joints; shared by k_kin_reg and k_fleet.
+template <int NJ, bool WANT_T, bool WANT_J>
+__device__ __forceinline__ void reg_tile(const KinParams &kp, const ConstChain &cv, const double *__restrict__ q,
+                                         double *__restrict__ T, double *__restrict__ J, double *buf, int lane,
+                                         int64_t tile)
+{
+    constexpr int W = 6 * NJ;
+    const int64_t cfg0 = tile * kWave;
+    const int64_t left = kp.N - cfg0;
+    const int ncfg = left < kWave ? (int)left : kWave;
+    Pose P;
+    double jac[6 * NJ];
+    reg_compute<NJ, WANT_J>(kp, cv, q, cfg0 + lane, P, jac);
+    if (WANT_J) {
+#pragma unroll
+        for (int r = 0; r < kWave / kJRound; ++r) {
+            if (lane / kJRound == r) reg_stage_J<NJ>(jac, buf, lane % kJRound);
+            __syncthreads();
+            int rows = ncfg - r * kJRound;
+            rows = rows < 0 ? 0 : (rows > kJRound ? kJRound : rows);
+            kin_flush(buf, W + 1, W, rows, J + (cfg0 + r * kJRound) * W, lane);
+            __syncthreads();
+        }
+    }
+    if (WANT_T) {
+        reg_stage_T(kp, P, buf, lane);
+        __syncthreads();
+        kin_flush(buf, 17, 16, ncfg, T + cfg0 * 16, lane);
+    }
+}
+
+// ONE tile per single-wave workgroup, no grid-stride loop: with a loop LICM hoists every segment's
+// (loop-invariant) scalar loads into the preheader, where they overflow the SGPR file and come back
+// as v_readlane pairs on each use.  The dispatcher balances the tiles instead.
 template <int NJ, bool WANT_T, bool WANT_J>
 __global__ __launch_bounds__(kWave, RTB_REG_WAVES) void k_kin_reg(KinParams kp, DevChain dc, const double *__restrict__ q,
                                                   double *__restrict__ T, double *__restrict__ J)
 {
     extern __shared__ __attribute__((aligned(16))) double buf[];
-    const ConstChain cv = const_view(dc);
-    const int lane = threadIdx.x;
-    constexpr int W = 6 * NJ;
-    // ONE tile per single-wave workgroup, no grid-stride loop: with a loop LICM hoists every
-    // segment's (loop-invariant) scalar loads into the preheader, where they overflow the SGPR file
-    // and come back as v_readlane pairs on each use.  The dispatcher balances the tiles instead.
-    {
-        const int64_t cfg0 = (int64_t)blockIdx.x * kWave;
-        const int64_t left = kp.N - cfg0;
-        const int ncfg = left < kWave ? (int)left : kWave;
-        Pose P;
-        double jac[6 * NJ];
-        reg_compute<NJ, WANT_J>(kp, cv, q, cfg0 + lane, P, jac);
-        if (WANT_J) {
-#pragma unroll
-            for (int r = 0; r < kWave / kJRound; ++r) {
-                if (lane / kJRound == r) reg_stage_J<NJ>(jac, buf, lane % kJRound);
-                __syncthreads();
-                int rows = ncfg - r * kJRound;
-                rows = rows < 0 ? 0 : (rows > kJRound ? kJRound : rows);
-                kin_flush(buf, W + 1, W, rows, J + (cfg0 + r * kJRound) * W, lane);
-                __syncthreads();
-            }
-        }
-        if (WANT_T) {
-            reg_stage_T(kp, P, buf, lane);
-            __syncthreads();
-            kin_flush(buf, 17, 16, ncfg, T + cfg0 * 16, lane);
-        }
-    }
+    reg_tile<NJ, WANT_T, WANT_J>(kp, const_view(dc), q, T, J, buf, threadIdx.x, blockIdx.x);
 }
 
 namespace {
@@ -224,44 +229,69 @@ struct FleetArgs {
     FleetEntry e[kFleetMax];
     int32_t count, frame;
     int64_t tiles;
+    int64_t tile_base;   // first global tile of this launch (launches are chunked at 2^31-1 workgroups)
 };
 
-__global__ __launch_bounds__(kWave) void k_fleet(FleetArgs fa)
+// One tile per workgroup (no grid-stride loop, as k_kin_reg).  Chains of up to kRegMaxJoints joints run
+// the register-resident tile (switch on the wave-uniform joint count); longer ones the LDS tile.
+__global__ __launch_bounds__(kWave, RTB_REG_WAVES) void k_fleet(FleetArgs fa)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
-    for (int64_t gt = blockIdx.x; gt < fa.tiles; gt += gridDim.x) {
-        int ci = 0;
-        for (int i = 1; i < fa.count; ++i)
-            if (gt >= fa.e[i].tile0) ci = i;
-        const FleetEntry &fe = fa.e[ci];
-        KinParams kp;
-        kp.n = fe.n; kp.qw = fe.q_width; kp.stride = fe.stride;
-        kp.frame = fa.frame; kp.has_base = 0; kp.pad = 0; kp.N = fe.N;
-        const ConstChain ops = const_view(fe.dc);
-        for (int k = 0; k < 9; ++k) kp.tail[k] = ops.seg[fe.n].r[k];
-        for (int k = 0; k < 3; ++k) kp.tail[9 + k] = ops.seg[fe.n].t[k];
-        double *rows = lds;
-        double *qs = lds + kWave * kp.stride;
-        const int64_t tile = gt - fe.tile0;
-        const int64_t cfg0 = tile * kWave, cfg = cfg0 + lane;
-        const int64_t left = kp.N - cfg0;
-        const int ncfg = left < kWave ? (int)left : kWave;
-        const int W = 6 * kp.n;
-        kin_load_q(kp, fe.q, cfg, lane, qs);
-        Pose P;
-        kin_walk<true>(kp, ops, lane, qs, rows, P);
-        __syncthreads();
-        kin_flush(rows, kp.stride, W, ncfg, fe.J + cfg0 * W, lane);
-        __syncthreads();
-        kin_stage_T(kp, lane, rows, P);
-        __syncthreads();
-        kin_flush(rows, kp.stride, 16, ncfg, fe.T + cfg0 * 16, lane);
-        __syncthreads();
+    const int64_t gt = (int64_t)blockIdx.x + fa.tile_base;
+    int ci = 0;
+    for (int i = 1; i < fa.count; ++i)
+        if (gt >= fa.e[i].tile0) ci = i;
+    const FleetEntry &fe = fa.e[ci];
+    KinParams kp;
+    kp.n = fe.n; kp.qw = fe.q_width; kp.stride = fe.stride;
+    kp.frame = fa.frame; kp.has_base = 0; kp.pad = 0; kp.N = fe.N;
+    const ConstChain ops = const_view(fe.dc);
+    for (int k = 0; k < 9; ++k) kp.tail[k] = ops.seg[fe.n].r[k];
+    for (int k = 0; k < 3; ++k) kp.tail[9 + k] = ops.seg[fe.n].t[k];
+    const int64_t tile = gt - fe.tile0;
+    switch (fe.n) {
+    case 1: reg_tile<1, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
+    case 2: reg_tile<2, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
+    case 3: reg_tile<3, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
+    case 4: reg_tile<4, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
+    case 5: reg_tile<5, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
+    case 6: reg_tile<6, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
+    case 7: reg_tile<7, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
+    case 8: reg_tile<8, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
+    default: break;
     }
+    double *rows = lds;
+    double *qs = lds + kWave * kp.stride;
+    const int64_t cfg0 = tile * kWave, cfg = cfg0 + lane;
+    const int64_t left = kp.N - cfg0;
+    const int ncfg = left < kWave ? (int)left : kWave;
+    const int W = 6 * kp.n;
+    kin_load_q(kp, fe.q, cfg, lane, qs);
+    Pose P;
+    kin_walk<true>(kp, ops, lane, qs, rows, P);
+    __syncthreads();
+    kin_flush(rows, kp.stride, W, ncfg, fe.J + cfg0 * W, lane);
+    __syncthreads();
+    kin_stage_T(kp, lane, rows, P);
+    __syncthreads();
+    kin_flush(rows, kp.stride, 16, ncfg, fe.T + cfg0 * 16, lane);
 }
 
-int launch_fleet(const std::vector<FleetEntry> &entries, int frame, hipStream_t s)
+// Dynamic LDS is a per-launch quantity and the LDS-tile chains (n > 8) need 3-5x what the
+// register-resident ones do, so a mixed fleet is walked as (at most) two launches, one per class --
+// otherwise the few long chains would cap every workgroup of the launch at 4 per CU.
+static int launch_fleet_class(const std::vector<FleetEntry> &entries, int frame, hipStream_t s);
+int launch_fleet(const std::vector<FleetEntry> &all, int frame, hipStream_t s)
+{
+    std::vector<FleetEntry> reg, tile;
+    for (const FleetEntry &e : all) (e.n <= kRegMaxJoints ? reg : tile).push_back(e);
+    if (!reg.empty()) { int rc = launch_fleet_class(reg, frame, s); if (rc != RTBHIP_OK) return rc; }
+    if (!tile.empty()) { int rc = launch_fleet_class(tile, frame, s); if (rc != RTBHIP_OK) return rc; }
+    return RTBHIP_OK;
+}
+
+static int launch_fleet_class(const std::vector<FleetEntry> &entries, int frame, hipStream_t s)
 {
     for (size_t first = 0; first < entries.size(); first += kFleetMax) {
         FleetArgs fa;
@@ -275,7 +305,8 @@ int launch_fleet(const std::vector<FleetEntry> &entries, int frame, hipStream_t 
             fa.e[i].stride = kin_stride(fa.e[i].n);
             fa.e[i].tile0 = tiles;
             tiles += (fa.e[i].N + kWave - 1) / kWave;
-            lds = std::max(lds, kin_lds_bytes(fa.e[i].n, fa.e[i].q_width));
+            lds = std::max(lds, fa.e[i].n <= kRegMaxJoints ? (size_t)reg_lds_doubles(fa.e[i].n) * sizeof(double)
+                                                            : kin_lds_bytes(fa.e[i].n, fa.e[i].q_width));
         }
         fa.tiles = tiles;
         if (lds > 160 * 1024) { set_error("fleet: chain too large for LDS staging"); return RTBHIP_ELIMIT; }
@@ -283,11 +314,14 @@ int launch_fleet(const std::vector<FleetEntry> &entries, int frame, hipStream_t 
             hipError_t e = hipFuncSetAttribute((const void *)k_fleet, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return hip_fail(e, "k_fleet attr");
         }
-        int64_t g = tiles > 0x7fffffff ? 0x7fffffff : tiles;
-        hipLaunchKernelGGL(k_fleet, dim3((unsigned)g), dim3(kWave), lds, s, fa);
-        note_launch((int)g, kWave, (int)lds);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return hip_fail(e, "k_fleet launch");
+        for (int64_t t0 = 0; t0 < tiles; t0 += 0x7fffffff) {
+            const int64_t g = std::min<int64_t>(0x7fffffff, tiles - t0);
+            fa.tile_base = t0;
+            hipLaunchKernelGGL(k_fleet, dim3((unsigned)g), dim3(kWave), lds, s, fa);
+            note_launch((int)g, kWave, (int)lds);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return hip_fail(e, "k_fleet launch");
+        }
     }
     return RTBHIP_OK;
 }

@@ -8,9 +8,10 @@ from ._lib import RtbHipError, lib, device_count, tune, shard_range, last_launch
 from .et import ET, ETS, IKSolution  # noqa: F401
 from .dh import DHLink, DHRobot, RevoluteDH, PrismaticDH, RevoluteMDH, PrismaticMDH  # noqa: F401
 from . import models  # noqa: F401
+from . import urdf  # noqa: F401
 from .fleet import fleet_fkine_jacob  # noqa: F401
 from .shard import ShardedBatch  # noqa: F401
 
 __all__ = ["ET", "ETS", "IKSolution", "DHLink", "DHRobot", "RevoluteDH", "PrismaticDH", "RevoluteMDH",
-           "PrismaticMDH", "models", "fleet_fkine_jacob", "ShardedBatch", "RtbHipError", "lib",
+           "PrismaticMDH", "models", "urdf", "fleet_fkine_jacob", "ShardedBatch", "RtbHipError", "lib",
            "device_count", "tune", "shard_range", "last_launch"]

@@ -1,0 +1,268 @@
+"""URDF -> elementary-transform-sequence lowering for the GPU kinematics path.
+
+What it replaces in the reference: ``tools/urdf/urdf.py:1662-1760`` (``URDF.__init__``: one
+``ET.SE3(trans * RPY) [* joint ET]`` per joint), ``Robot.URDF_read`` (``robot/Robot.py:218-284``) and
+the serial-path part of ``BaseRobot.ets(start, end)`` (``robot/BaseRobot.py:1426-1467``) -- without
+spatialmath, and only for what the batched kernels need: joint origins, axes, limits, the link tree,
+and each link's ``<inertial>`` block (kept for the dynamics rows of SURVEY 8f).
+
+Only plain URDF is parsed.  The robot descriptions the reference ships as xacro
+(rtb-data/rtbdata/xacro) are pre-expanded to kinematic URDFs in ``rtbhip/data/urdf`` by
+``scripts/make_urdf_data.py``; ``load("Panda")`` etc. read those.
+
+Lowering rules (same as the reference):
+  * constant part of a joint = Trans(origin xyz) * RPY(origin rpy), RPY in the URDF/'zyx' order
+    R = Rz(yaw) Ry(pitch) Rx(roll)                                   (urdf.py:1704-1709)
+  * axis aligned with +-x/+-y/+-z -> Rx/Ry/Rz (revolute, continuous) or tx/ty/tz (prismatic), with
+    ``flip`` for the negative direction                               (urdf.py:1726-1754)
+  * any other axis: the constant part is post-multiplied by the reference's normalising rotation
+    ``angvec2r(|v|, v/|v|)`` and the joint then acts about/along z   (urdf.py:1710-1722)
+  * fixed (and unsupported floating/planar) joints contribute the constant part only.
+"""
+import math
+import os
+import xml.etree.ElementTree as XT
+
+import numpy as np
+
+from .et import ET, ETS
+
+DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "urdf")
+
+
+def _floats(text, n, default):
+    if text is None:
+        return np.array(default, dtype=np.float64)
+    v = np.array([float(x) for x in text.split()], dtype=np.float64)
+    if v.size != n:
+        raise ValueError("expected %d numbers, got %r" % (n, text))
+    return v
+
+
+def rpy_matrix(rpy):
+    """R = Rz(yaw) Ry(pitch) Rx(roll) -- spatialmath SE3.RPY(order='zyx'), the URDF convention."""
+    r, p, y = (float(v) for v in rpy)
+    cr, sr, cp, sp, cy, sy = math.cos(r), math.sin(r), math.cos(p), math.sin(p), math.cos(y), math.sin(y)
+    Rx = np.array([[1, 0, 0], [0, cr, -sr], [0, sr, cr]], dtype=np.float64)
+    Ry = np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]], dtype=np.float64)
+    Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]], dtype=np.float64)
+    return Rz @ Ry @ Rx
+
+
+def angvec_matrix(theta, v):
+    """Rodrigues rotation by theta about unit vector v (spatialmath angvec2r)."""
+    x, y, z = v
+    K = np.array([[0, -z, y], [z, 0, -x], [-y, x, 0]], dtype=np.float64)
+    return np.eye(3) + math.sin(theta) * K + (1 - math.cos(theta)) * (K @ K)
+
+
+class URDFJoint:
+    def __init__(self, el):
+        self.name = el.get("name")
+        self.type = el.get("type")
+        self.parent = el.find("parent").get("link")
+        self.child = el.find("child").get("link")
+        o = el.find("origin")
+        self.xyz = _floats(None if o is None else o.get("xyz"), 3, [0, 0, 0])
+        self.rpy = _floats(None if o is None else o.get("rpy"), 3, [0, 0, 0])
+        a = el.find("axis")
+        self.axis = _floats(None if a is None else a.get("xyz"), 3, [1, 0, 0])   # URDF default axis
+        lim = el.find("limit")
+        self.lower = self.upper = None
+        if lim is not None and self.type in ("revolute", "prismatic"):
+            self.lower = float(lim.get("lower", 0.0))
+            self.upper = float(lim.get("upper", 0.0))
+        d = el.find("dynamics")
+        self.friction = None if d is None or d.get("friction") is None else float(d.get("friction"))
+        self.damping = None if d is None or d.get("damping") is None else float(d.get("damping"))
+
+    @property
+    def actuated(self):
+        return self.type in ("revolute", "continuous", "prismatic")
+
+    def constant(self):
+        """4x4 constant part, incl. the reference's normalising rotation for a skew axis."""
+        T = np.eye(4)
+        R = rpy_matrix(self.rpy)
+        if self.actuated and np.count_nonzero(self.axis) >= 2:
+            n = float(np.linalg.norm(self.axis))
+            R = R @ angvec_matrix(n, self.axis / n)                  # urdf.py:1713-1718
+        T[:3, :3] = R
+        T[:3, 3] = self.xyz
+        return T
+
+    def variable(self, jindex=None):
+        """The joint's variable ET (None for a fixed joint)."""
+        if not self.actuated:
+            return None
+        ax = self.axis
+        if np.count_nonzero(ax) >= 2:
+            k, flip = 2, False                                        # urdf.py:1722
+        else:
+            k = int(np.argmax(np.abs(ax)))
+            if ax[k] == 0:
+                return None
+            flip = bool(ax[k] < 0)
+        rot = self.type in ("revolute", "continuous")
+        name = ("Rx", "Ry", "Rz")[k] if rot else ("tx", "ty", "tz")[k]
+        qlim = None if self.lower is None else [self.lower, self.upper]
+        return ET(name, flip=flip, jindex=jindex, qlim=qlim)
+
+
+class URDFLink:
+    def __init__(self, el):
+        self.name = el.get("name")
+        self.m = 0.0
+        self.r = np.zeros(3)
+        self.I = np.zeros((3, 3))
+        self.parent = None      # URDFLink
+        self.joint = None       # URDFJoint that attaches this link to its parent
+        self.children = []
+        ine = el.find("inertial")
+        if ine is not None:
+            mass = ine.find("mass")
+            if mass is not None:
+                self.m = float(mass.get("value", 0.0))
+            o = ine.find("origin")
+            if o is not None:
+                self.r = _floats(o.get("xyz"), 3, [0, 0, 0])
+            I = ine.find("inertia")
+            if I is not None:
+                g = lambda k: float(I.get(k, 0.0))
+                self.I = np.array([[g("ixx"), g("ixy"), g("ixz")], [g("ixy"), g("iyy"), g("iyz")],
+                                   [g("ixz"), g("iyz"), g("izz")]])
+
+
+class URDFRobot:
+    """Link tree of one URDF with batched kinematics over any root->link path."""
+
+    def __init__(self, urdf_string, name=None, ee=None, tool=None):
+        root = XT.fromstring(urdf_string)
+        if root.tag != "robot":
+            raise ValueError("not a URDF: root element is <%s>" % root.tag)
+        self.name = name or root.get("name", "")
+        self.links = [URDFLink(e) for e in root.findall("link")]
+        self.joints = [URDFJoint(e) for e in root.findall("joint")]
+        self.linkdict = {l.name: l for l in self.links}
+        if len(self.linkdict) != len(self.links):
+            raise ValueError("Duplicate link names")                  # urdf.py:1649-1652
+        if len({j.name for j in self.joints}) != len(self.joints):
+            raise ValueError("Duplicate joint names")
+        for j in self.joints:
+            child, parent = self.linkdict[j.child], self.linkdict[j.parent]
+            child.parent, child.joint = parent, j
+            parent.children.append(child)
+        roots = [l for l in self.links if l.parent is None]
+        if len(roots) != 1:
+            raise ValueError("URDF must have exactly one root link, found %d" % len(roots))
+        self.base_link = roots[0]
+        # robot-wide joint numbering: actuated joints in URDF joint order
+        self.jindex = {}
+        for j in self.joints:
+            if j.actuated and j.variable() is not None:
+                self.jindex[j.name] = len(self.jindex)
+        self.n = len(self.jindex)
+        self.tool = None if tool is None else np.asarray(tool, dtype=np.float64)
+        self._ee = ee
+        self._cache = {}
+
+    # ------------------------------------------------------------ structure
+    def path(self, end):
+        """Links from the root (exclusive) to `end` (inclusive)."""
+        link = self.linkdict[end] if isinstance(end, str) else end
+        out = []
+        while link.parent is not None:
+            out.append(link)
+            link = link.parent
+        return out[::-1]
+
+    def njoints(self, end):
+        return sum(1 for l in self.path(end) if l.joint.actuated and l.joint.variable() is not None)
+
+    @property
+    def leaves(self):
+        return [l for l in self.links if not l.children]
+
+    @property
+    def ee(self):
+        """Default end link: the one given at construction, else the leaf whose path carries the most
+        joints (first in URDF order on ties)."""
+        if self._ee is not None:
+            return self._ee
+        best = max(self.leaves, key=lambda l: self.njoints(l))
+        return best.name
+
+    def ets(self, end=None, start=None, compact=True):
+        """ETS from the root (or `start`) to `end`.  compact=True numbers the joints 0..n-1 along the
+        path (q is (N, n)); compact=False keeps the robot-wide jindex (q is (N, robot.n))."""
+        end = self.ee if end is None else (end if isinstance(end, str) else end.name)
+        key = (end, start, compact)
+        if key in self._cache:
+            return self._cache[key]
+        links = self.path(end)
+        if start is not None:
+            names = [l.name for l in links]
+            if start != self.base_link.name:
+                if start not in names:
+                    raise ValueError("start link %r is not an ancestor of %r" % (start, end))
+                links = links[names.index(start) + 1:]
+        ets, k = [], 0
+        for l in links:
+            ets.append(ET.SE3(l.joint.constant()))
+            j = l.joint
+            if j.actuated:
+                var = j.variable(jindex=k if compact else self.jindex[j.name])
+                if var is not None:
+                    ets.append(var)
+                    k += 1
+        e = ETS(ets)
+        self._cache[key] = e
+        return e
+
+    def qlim(self, end=None):
+        return self.ets(end).qlim
+
+    # ------------------------------------------------------------ kinematics pass-throughs
+    def fkine(self, q, end=None, tool=None):
+        return self.ets(end).eval(q, tool=self.tool if tool is None else tool)
+
+    def jacob0(self, q, end=None, tool=None):
+        return self.ets(end).jacob0(q, tool=self.tool if tool is None else tool)
+
+    def jacobe(self, q, end=None, tool=None):
+        return self.ets(end).jacobe(q, tool=self.tool if tool is None else tool)
+
+    def fkine_jacob0(self, q, end=None, tool=None):
+        return self.ets(end).fkine_jacob0(q, tool=self.tool if tool is None else tool)
+
+    def ik_LM(self, Tep, end=None, **kw):
+        return self.ets(end).ik_LM(Tep, **kw)
+
+
+def loadstr(urdf_string, **kw):
+    return URDFRobot(urdf_string, **kw)
+
+
+def available():
+    return sorted(f[:-5] for f in os.listdir(DATA_DIR) if f.endswith(".urdf"))
+
+
+# end links / gripper tools of the reference's model classes (models/URDF/*.py `gripper_links`)
+_MODEL_EE = {
+    "Panda": ("panda_hand", [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0.1034], [0, 0, 0, 1]]),   # models/URDF/Panda.py:43-48
+}
+
+
+def load(name, **kw):
+    """One of the pre-expanded robot descriptions in rtbhip/data/urdf (see available())."""
+    path = os.path.join(DATA_DIR, name + ".urdf")
+    if not os.path.exists(path):
+        raise ValueError("unknown robot %r; available: %s" % (name, ", ".join(available())))
+    if name in _MODEL_EE and "ee" not in kw:
+        kw["ee"], kw["tool"] = _MODEL_EE[name][0], np.array(_MODEL_EE[name][1], dtype=np.float64)
+    return URDFRobot(open(path).read(), name=name, **kw)
+
+
+# the 16 arms of BASELINE config 5 ("mixed fleet", 4..10 joints on the path to the deepest leaf)
+FLEET16 = ["AL5D", "px100", "px150", "rx200", "vx300s", "wx250s", "UR3", "UR5", "UR10", "Puma560", "LBR", "Panda",
+           "KinovaGen3", "Mico", "Fetch", "YuMi"]

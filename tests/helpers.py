@@ -53,3 +53,59 @@ def tool_base():
     tool = chains.elementary("tx", 0.1) @ chains.elementary("Ry", 0.3) @ chains.elementary("tz", -0.05)
     base = chains.elementary("Rz", 0.7) @ chains.elementary("tx", 0.2) @ chains.elementary("Rx", -0.4)
     return tool, base
+
+
+def chain_from_ets(ets):
+    """Oracle Chain (oracle/chains.py) with the same op-table as a product ETS whose joints are
+    numbered 0..n-1 in order of appearance."""
+    from oracle import chains
+    spec = []
+    for kind, flip, jindex, T in ets.optable():
+        if kind == 6:
+            spec.append(np.array(T, dtype=np.float64))
+        else:
+            spec.append((("Rx", "Ry", "Rz", "tx", "ty", "tz")[kind], None, bool(flip)))
+    return chains.Chain(spec, qlim=ets.qlim)
+
+
+def urdf_fk_numpy(urdf_path, end, q):
+    """Independent restatement of URDF forward kinematics straight from the XML (no product code):
+    T = prod over the joints on the path of  Trans(xyz) * RPY(rpy) * Motion(axis, q_j), the joint
+    motion being a Rodrigues rotation about / a slide along the axis AS WRITTEN in the file."""
+    import math
+    import xml.etree.ElementTree as XT
+    root = XT.parse(urdf_path).getroot()
+    parent_of = {}
+    for j in root.findall("joint"):
+        parent_of[j.find("child").get("link")] = j
+    chain, link = [], end
+    while link in parent_of:
+        chain.append(parent_of[link])
+        link = parent_of[link].find("parent").get("link")
+    chain.reverse()
+    T, k = np.eye(4), 0
+    for j in chain:
+        o = j.find("origin")
+        xyz = [float(v) for v in (o.get("xyz", "0 0 0") if o is not None else "0 0 0").split()]
+        r, p, y = [float(v) for v in (o.get("rpy", "0 0 0") if o is not None else "0 0 0").split()]
+        Rx = np.array([[1, 0, 0], [0, math.cos(r), -math.sin(r)], [0, math.sin(r), math.cos(r)]])
+        Ry = np.array([[math.cos(p), 0, math.sin(p)], [0, 1, 0], [-math.sin(p), 0, math.cos(p)]])
+        Rz = np.array([[math.cos(y), -math.sin(y), 0], [math.sin(y), math.cos(y), 0], [0, 0, 1]])
+        A = np.eye(4)
+        A[:3, :3] = Rz @ Ry @ Rx
+        A[:3, 3] = xyz
+        T = T @ A
+        typ = j.get("type")
+        if typ in ("revolute", "continuous", "prismatic"):
+            a = j.find("axis")
+            ax = np.array([float(v) for v in (a.get("xyz") if a is not None else "1 0 0").split()])
+            ax = ax / np.linalg.norm(ax)
+            M = np.eye(4)
+            if typ == "prismatic":
+                M[:3, 3] = ax * q[k]
+            else:
+                K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+                M[:3, :3] = np.eye(3) + math.sin(q[k]) * K + (1 - math.cos(q[k])) * (K @ K)
+            T = T @ M
+            k += 1
+    return T

@@ -1,0 +1,114 @@
+"""URDF -> ETS lowering (rtbhip/urdf.py, SURVEY 8f-3 / BASELINE config 5).  CPU tests run the lowered
+chains through tests/emu (the kernels' own device functions executed on the host) and the C oracle;
+the GPU test walks the 16-arm fleet in one launch."""
+import os
+
+import numpy as np
+import numpy.testing as nt
+import pytest
+
+import rtbhip
+from rtbhip import urdf
+from oracle import oracle
+from helpers import chain_from_ets, urdf_fk_numpy
+
+TOL = 1e-10
+
+
+def _rand_q(rng, ets, N):
+    ql = np.clip(ets.qlim, -6.3, 6.3)      # some descriptions carry +-1e10-style "no limit" limits
+    return rng.uniform(ql[0], ql[1], (N, ets.n))
+
+
+def test_all_twenty_descriptions_load_and_lower():
+    names = urdf.available()
+    assert len(names) == 20 and set(urdf.FLEET16) <= set(names) and len(set(urdf.FLEET16)) == 16
+    dof = {}
+    for name in names:
+        r = urdf.load(name)
+        e = r.ets()
+        assert e.n == r.njoints(r.ee) >= 4
+        assert e.qlim.shape == (2, e.n) and np.all(e.qlim[0] <= e.qlim[1])
+        dof[name] = e.n
+    assert dof["AL5D"] == 4 and dof["Panda"] == 7 and dof["UR5"] == 6 and dof["Fetch"] == 10
+    assert urdf.load("YuMi").n == 18 and urdf.load("Panda").n == 9       # arm joints + gripper fingers
+
+
+def test_G12_readme_panda_fkine_qr():
+    """reference README.md:218-226: URDF Panda fkine(qr), gripper tool included, 4 significant figures."""
+    import emu_harness as emu
+    p = urdf.load("Panda")
+    qr = np.array([0, -0.3, 0, -2.2, 0, 2.0, np.pi / 4])
+    T, _, _ = emu.kin(p.ets(), qr, tool=p.tool, want=("T",))
+    want = np.array([[0.995, 0, 0.09983, 0.484], [0, -1, 0, 0], [0.09983, 0, -0.995, 0.4126], [0, 0, 0, 1]])
+    nt.assert_allclose(T[0], want, atol=6e-4)
+
+
+@pytest.mark.parametrize("name", urdf.FLEET16)
+def test_lowering_equals_independent_urdf_fk_and_oracle(name):
+    """The lowered chain (kernel device code via tests/emu) == FK computed straight from the XML
+    (tests/helpers.urdf_fk_numpy) == the C oracle on the same op-table; J0 == numerical Jacobian."""
+    import emu_harness as emu
+    r = urdf.load(name)
+    e = r.ets()
+    rng = np.random.default_rng(abs(hash(name)) % 1000)
+    q = _rand_q(rng, e, 6)
+    T, J, _ = emu.kin(e, q, want=("T", "J"), reg=e.n <= 8)
+    path = os.path.join(urdf.DATA_DIR, name + ".urdf")
+    for i in range(len(q)):
+        nt.assert_allclose(T[i], urdf_fk_numpy(path, r.ee, q[i]), atol=1e-12)
+    oc = chain_from_ets(e)
+    nt.assert_allclose(T, oracle.fkine(oc, q), atol=TOL)
+    nt.assert_allclose(J, oracle.jacob0(oc, q), atol=TOL)
+    h = 1e-6
+    for k in range(e.n):
+        dq = np.zeros(e.n); dq[k] = h
+        Tp, _, _ = emu.kin(e, q[0] + dq, want=("T",), reg=e.n <= 8)
+        Tm, _, _ = emu.kin(e, q[0] - dq, want=("T",), reg=e.n <= 8)
+        nt.assert_allclose(J[0][:3, k], (Tp[0][:3, 3] - Tm[0][:3, 3]) / (2 * h), atol=1e-6)
+
+
+def test_skew_axis_quirk_and_robotwide_jindex_and_errors():
+    xml = """<robot name="t"><link name="a"/><link name="b"/><link name="c"/><link name="d"/>
+      <joint name="j1" type="revolute"><parent link="a"/><child link="b"/><origin xyz="0 0 0.1" rpy="0.1 0.2 0.3"/>
+        <axis xyz="0 -1 0"/><limit lower="-1" upper="2"/></joint>
+      <joint name="j2" type="prismatic"><parent link="b"/><child link="c"/><origin xyz="0.2 0 0"/>
+        <axis xyz="1 0 0"/><limit lower="0" upper="0.5"/></joint>
+      <joint name="j3" type="continuous"><parent link="a"/><child link="d"/><axis xyz="0 0.6 0.8"/></joint></robot>"""
+    r = urdf.loadstr(xml)
+    e = r.ets("c")
+    assert [x.axis for x in e.joints()] == ["Ry", "tx"] and e.joints()[0].isflip and not e.joints()[1].isflip
+    nt.assert_allclose(e.qlim, [[-1, 0], [2, 0.5]])
+    # skew axis: the reference folds angvec2r(|v|, v/|v|) into the constant and turns about z (urdf.py:1710-1722)
+    e3 = r.ets("d")
+    assert e3.joints()[0].axis == "Rz"
+    nt.assert_allclose(e3[0].T[:3, :3], urdf.angvec_matrix(1.0, np.array([0, 0.6, 0.8])), atol=1e-15)
+    nt.assert_allclose(e3.qlim, [[-np.pi], [np.pi]])
+    # robot-wide numbering keeps URDF joint order; compact numbering is per path
+    assert list(r.ets("d", compact=False).jindices) == [2] and list(r.ets("d").jindices) == [0]
+    with pytest.raises(ValueError):
+        urdf.loadstr(xml.replace('name="d"/>', 'name="c"/>', 1))
+    with pytest.raises(ValueError):
+        urdf.loadstr("<notrobot/>")
+    with pytest.raises(ValueError):
+        urdf.load("NoSuchRobot")
+
+
+@pytest.mark.gpu
+def test_gpu_fleet16_urdf_arms_one_launch_vs_oracle():
+    """BASELINE config 5 shape: the 16 URDF arms (4..10 joints on the path), each with its own batch,
+    through ONE rtbhip_fleet_fkine_jacob launch; every arm against the C oracle."""
+    rng = np.random.default_rng(5)
+    robots = [urdf.load(n) for n in urdf.FLEET16]
+    chs = [r.ets() for r in robots]
+    assert sorted({c.n for c in chs}) == [4, 5, 6, 7, 8, 9, 10]
+    sizes = [1000, 65, 1, 129, 64, 63, 500, 7, 2048, 100, 300, 77, 1025, 640, 33, 999]
+    qs = [_rand_q(rng, c, N) for c, N in zip(chs, sizes)]
+    Ts, Js = rtbhip.fleet_fkine_jacob(chs, qs)
+    for c, q, T, J in zip(chs, qs, Ts, Js):
+        oc = chain_from_ets(c)
+        nt.assert_allclose(T, oracle.fkine(oc, q), atol=TOL)
+        nt.assert_allclose(J, oracle.jacob0(oc, q), atol=TOL)
+        Tb, Jb = c.fkine_jacob0(q)                       # the per-chain kernels agree with the fleet kernel
+        nt.assert_allclose(T, np.reshape(Tb, T.shape), atol=1e-13)
+        nt.assert_allclose(J, np.reshape(Jb, J.shape), atol=1e-13)
