@@ -31,11 +31,12 @@ def ev_time(fn, steps, warmup):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--what", default="rne,ik,fleet")
+    ap.add_argument("--what", default="rne,ik,fleet,dyn")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--n-rne", type=int, default=1250000)
     ap.add_argument("--n-ik", type=int, default=100000)
     ap.add_argument("--n-fleet", type=int, default=1000000)
+    ap.add_argument("--n-dyn", type=int, default=1000000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--tune", action="append", default=[])
     args = ap.parse_args()
@@ -73,6 +74,39 @@ def main():
                                         "sample": "frne.frne per-row loop (DHRobot.rne) over the first %d triples" % n,
                                         "max_rel_err_gpu_vs_cpu": float(np.abs(g - tau).max() / np.abs(tau).max())}
         print(json.dumps(line), flush=True)
+
+    if "dyn" in what:
+        # M(q), C(q,qd), forward dynamics for the DH Panda, one fused kernel each
+        N = args.n_dyn
+        rob = rtbhip.models.DH.Panda()
+        tab = chains.panda_dh()
+        rng = np.random.default_rng(6)
+        q = torch.from_numpy(rng.uniform(tab.qlim[:, 0], tab.qlim[:, 1], (N, 7))).cuda()
+        qd = torch.from_numpy(rng.normal(size=(N, 7))).cuda()
+        tq = torch.from_numpy(rng.normal(size=(N, 7)) * 5).cuda()
+        for name, fn, passes, byts in (("inertia", lambda: rob.inertia(q), 7, 56 + 392),
+                                       ("coriolis", lambda: rob.coriolis(q, qd), 28, 112 + 392),
+                                       ("accel", lambda: rob.accel(q, qd, tq), 8, 168 + 56)):
+            avg, best = ev_time(fn, max(3, args.steps // 2), 2)
+            line = {"metric": "configurations/sec (DH Panda %s)" % name, "value": N / (avg * 1e-3), "unit": "configurations/s",
+                    "n": N, "kernel_avg_ms": avg, "kernel_min_ms": best, "rne_passes_per_config": passes,
+                    "rne_passes_per_s": passes * N / (avg * 1e-3),
+                    "roofline": {"bound": "fp64-valu", "achieved": byts * N / (avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                 "frac": byts * N / (avg * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": byts * N}}
+            if not args.no_cpu and name == "inertia":
+                from oracle import ref_harness
+                if ref_harness.available():
+                    ref = ref_harness.RefRNE(tab.L24(), 1)
+                    n = 3000
+                    qh = q[:n].cpu().numpy()
+                    t0 = time.perf_counter()
+                    Mc = np.array([ref.rne(np.tile(qk, (7, 1)), np.zeros((7, 7)), np.eye(7), gravity=[0, 0, 0]) for qk in qh])
+                    dt = time.perf_counter() - t0
+                    g = rob.inertia(q[:n]).cpu().numpy()
+                    line["cpu_baseline"] = {"value": n / dt, "unit": "configurations/s", "cores": 1, "kind": "reference",
+                                            "sample": "Dynamics.inertia's loop (7 frne.frne calls per configuration) over the first %d" % n,
+                                            "max_abs_err_gpu_vs_cpu": float(np.abs(g - Mc).max())}
+            print(json.dumps(line), flush=True)
 
     if "ik" in what:
         N = args.n_ik

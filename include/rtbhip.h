@@ -120,9 +120,23 @@ int rtbhip_dyn_destroy(rtbhip_dyn_t dyn); /* frne.delete (frne.c:80-103) */
 
 /* frne.frne (frne.c:106-230 -> newton_euler ne.c:62-493), batched: q,qd,qdd,tau are (N,n).
  * grav3 is what frne.frne is handed (already negated by DHRobot.rne, DHRobot.py:1449); fext6 may
- * be NULL (zero wrench). */
+ * be NULL (zero wrench).  qd and/or qdd may be NULL (all zeros: what Dynamics.gravload,
+ * robot/Dynamics.py:863-922, and Dynamics.itorque, :1407-1465, feed the reference's rne). */
 int rtbhip_rne(rtbhip_dyn_t dyn, const double *q, const double *qd, const double *qdd, int64_t N,
                const double *grav3, const double *fext6, double *tau, int32_t mem, void *stream);
+
+/* The Dynamics-mixin terms the reference derives from repeated rne calls, one fused
+ * kernel each, all passes of a configuration in one lane:
+ *   rtbhip_inertia   Dynamics.inertia  (robot/Dynamics.py:704-763): M (N,n,n); row i = tau for qdd = e_i, qd = 0, g = 0
+ *   rtbhip_coriolis  Dynamics.coriolis (:765-861): C (N,n,n), friction removed as nofriction(True, True) does
+ *   rtbhip_accel     Dynamics.accel    (:424-509): qdd (N,n) = M^-1 (torque - rne(q, qd, 0)); grav3 in the
+ *                    convention of rtbhip_rne (what frne.frne is handed)
+ * Chains of up to 8 joints; longer ones return RTBHIP_ELIMIT. */
+int rtbhip_inertia(rtbhip_dyn_t dyn, const double *q, int64_t N, double *M, int32_t mem, void *stream);
+int rtbhip_coriolis(rtbhip_dyn_t dyn, const double *q, const double *qd, int64_t N, double *C, int32_t mem,
+                    void *stream);
+int rtbhip_accel(rtbhip_dyn_t dyn, const double *q, const double *qd, const double *torque, int64_t N,
+                 const double *grav3, double *qdd, int32_t mem, void *stream);
 
 /* Mixed fleet (BASELINE config 5): n_chains independent chains, each with its own batch; one
  * launch walks all of them (block -> chain map).  q[c] is (N[c], q_width_c), T[c] (N[c],4,4),

@@ -163,6 +163,57 @@ def rne_dh(L24, mdh, q, qd, qdd, grav_c, fext=None):
     return tau
 
 
+def nofriction_L24(L24):
+    """Dynamics.nofriction(True, True) on the 24-double link block: B = 0, Tc = 0 (robot/Dynamics.py:146-183)."""
+    L = _f64(L24, (-1, 24)).copy()
+    L[:, 21:24] = 0.0
+    return L
+
+
+def inertia_dh(L24, mdh, q):
+    """Dynamics.inertia (robot/Dynamics.py:748-763): per configuration, rne over n rows with qdd = I."""
+    L = _f64(L24, (-1, 24)); n = L.shape[0]
+    q = _f64(q, (-1, n))
+    out = np.zeros((q.shape[0], n, n))
+    for k, qk in enumerate(q):
+        out[k] = rne_dh(L, mdh, np.tile(qk, (n, 1)), np.zeros((n, n)), np.eye(n), [0, 0, 0])
+    return out
+
+
+def coriolis_dh(L24, mdh, q, qd):
+    """Dynamics.coriolis (robot/Dynamics.py:811-861), statement for statement."""
+    L = nofriction_L24(L24); n = L.shape[0]
+    q, qd = _f64(q, (-1, n)), _f64(qd, (-1, n))
+    Cm = np.zeros((q.shape[0], n, n))
+    Csq = np.zeros((q.shape[0], n, n))
+    z = np.zeros(n)
+    for k, qk in enumerate(q):
+        for i in range(n):
+            QD = np.zeros(n); QD[i] = 1
+            Csq[k, :, i] = Csq[k, :, i] + rne_dh(L, mdh, qk, QD, z, [0, 0, 0])[0]
+    for k, (qk, qdk) in enumerate(zip(q, qd)):
+        for i in range(n):
+            for j in range(i + 1, n):
+                QD = np.zeros(n); QD[i] = 1; QD[j] = 1
+                tau = rne_dh(L, mdh, qk, QD, z, [0, 0, 0])[0]
+                Cm[k, :, j] = Cm[k, :, j] + (tau - Csq[k, :, j] - Csq[k, :, i]) * qdk[i] / 2
+                Cm[k, :, i] = Cm[k, :, i] + (tau - Csq[k, :, j] - Csq[k, :, i]) * qdk[j] / 2
+        Cm[k] = Cm[k] + Csq[k] @ np.diag(qdk)
+    return Cm
+
+
+def accel_dh(L24, mdh, q, qd, torque, grav_c):
+    """Dynamics.accel (robot/Dynamics.py:484-505): M from n unit accelerations, tau_0, numpy.linalg.solve."""
+    L = _f64(L24, (-1, 24)); n = L.shape[0]
+    q, qd, torque = _f64(q, (-1, n)), _f64(qd, (-1, n)), _f64(torque, (-1, n))
+    out = np.zeros_like(q)
+    for k in range(q.shape[0]):
+        M = rne_dh(L, mdh, np.tile(q[k], (n, 1)), np.zeros((n, n)), np.eye(n), [0, 0, 0])
+        tau = rne_dh(L, mdh, q[k], qd[k], np.zeros(n), grav_c)[0]
+        out[k] = np.linalg.solve(M, torque[k] - tau)
+    return out
+
+
 def dh_fkine(dh7, mdh, q, base=None, tool=None):
     dh = _f64(dh7, (-1, 7))
     n = dh.shape[0]

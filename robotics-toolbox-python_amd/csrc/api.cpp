@@ -386,7 +386,7 @@ int rtbhip_rne(rtbhip_dyn_t dyn, const double *q, const double *qd, const double
     if (!d) { set_error("rne: unknown dyn handle"); return RTBHIP_EINVAL; }
     RTB_TRY(check_batch("rne", q, N, mem));
     if (!grav3) { set_error("rne: NULL gravity"); return RTBHIP_EINVAL; }
-    if (N > 0 && (!qd || !qdd || !tau)) { set_error("rne: NULL qd/qdd/tau"); return RTBHIP_EINVAL; }
+    if (N > 0 && !tau) { set_error("rne: NULL tau"); return RTBHIP_EINVAL; }   // qd / qdd may be NULL (= zeros)
     if (N == 0) return RTBHIP_OK;
     const DevLink *links = nullptr;
     RTB_TRY(dyn_device_links(d, &links));
@@ -404,6 +404,51 @@ int rtbhip_rne(rtbhip_dyn_t dyn, const double *q, const double *qd, const double
     RTB_HIP(hipDeviceSynchronize());
     RTB_TRY(fetch(tau, dtau, bytes));
     return RTBHIP_OK;
+}
+
+/* Dynamics.inertia / coriolis / accel (robot/Dynamics.py:704-861, 424-509) */
+static int dyn_entry(const char *fn, rtbhip_dyn_t dyn, int mode, const double *q, const double *qd, const double *tq,
+                     int64_t N, const double *grav3, double *out, int32_t mem, void *stream)
+{
+    Dyn *d = dyn_from_handle(dyn);
+    if (!d) { set_error(std::string(fn) + ": unknown dyn handle"); return RTBHIP_EINVAL; }
+    RTB_TRY(check_batch(fn, q, N, mem));
+    if (N > 0 && !out) { set_error(std::string(fn) + ": NULL output"); return RTBHIP_EINVAL; }
+    if (N > 0 && mode >= 1 && !qd) { set_error(std::string(fn) + ": NULL qd"); return RTBHIP_EINVAL; }
+    if (N > 0 && mode == 2 && (!tq || !grav3)) { set_error(std::string(fn) + ": NULL torque/gravity"); return RTBHIP_EINVAL; }
+    if (N == 0) return RTBHIP_OK;
+    const DevLink *links = nullptr;
+    RTB_TRY(dyn_device_links(d, &links));
+    if (mem == RTBHIP_MEM_DEVICE)
+        return launch_dyn(d, links, mode, q, qd, tq, N, grav3, out, (hipStream_t)stream);
+    Staging st;
+    const size_t n = (size_t)d->n, bytes = (size_t)N * n * 8, obytes = mode == 2 ? bytes : bytes * n;
+    void *dq, *dqd = nullptr, *dtq = nullptr, *dout;
+    RTB_TRY(st.in(q, bytes, &dq));
+    if (mode >= 1) RTB_TRY(st.in(qd, bytes, &dqd));
+    if (mode == 2) RTB_TRY(st.in(tq, bytes, &dtq));
+    RTB_TRY(st.out(obytes, &dout));
+    RTB_TRY(launch_dyn(d, links, mode, (const double *)dq, (const double *)dqd, (const double *)dtq, N, grav3,
+                       (double *)dout, nullptr));
+    RTB_HIP(hipDeviceSynchronize());
+    RTB_TRY(fetch(out, dout, obytes));
+    return RTBHIP_OK;
+}
+
+int rtbhip_inertia(rtbhip_dyn_t dyn, const double *q, int64_t N, double *M, int32_t mem, void *stream)
+{
+    return dyn_entry("inertia", dyn, 0, q, nullptr, nullptr, N, nullptr, M, mem, stream);
+}
+
+int rtbhip_coriolis(rtbhip_dyn_t dyn, const double *q, const double *qd, int64_t N, double *Cm, int32_t mem, void *stream)
+{
+    return dyn_entry("coriolis", dyn, 1, q, qd, nullptr, N, nullptr, Cm, mem, stream);
+}
+
+int rtbhip_accel(rtbhip_dyn_t dyn, const double *q, const double *qd, const double *torque, int64_t N,
+                 const double *grav3, double *qdd, int32_t mem, void *stream)
+{
+    return dyn_entry("accel", dyn, 2, q, qd, torque, N, grav3, qdd, mem, stream);
 }
 
 int rtbhip_fleet_fkine_jacob(const rtbhip_chain_t *chains, int32_t n_chains, const double *const *q,

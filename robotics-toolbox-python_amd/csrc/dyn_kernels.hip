@@ -1,0 +1,162 @@
+// dyn_kernels.hip -- gfx950 kernels for the dynamics terms the reference derives from repeated
+// Newton-Euler calls (robot/Dynamics.py): the joint-space inertia matrix M(q) (`inertia`, :704-763:
+// n RNE calls per configuration), the Coriolis/centripetal matrix C(q, qd) (`coriolis`, :765-861:
+// n + n(n-1)/2 RNE calls) and the forward dynamics qdd = M^-1 (tau - tau_0) (`accel`, :424-509: n + 1
+// RNE calls and a dense solve).  In the reference every one of those RNE calls is a Python -> C
+// round trip (DHRobot.rne -> frne.frne); here one lane owns one configuration and runs all the
+// passes back to back on the rne_lane recursion of rne_device.h, with the pass index a wave-uniform
+// loop counter, the unit vectors generated on the fly (no (n,n) input blocks), the partial results in
+// the wave's LDS tile, and the (N,n,n) / (N,n) outputs written as contiguous runs.
+// Bound: fp64 VALU issue (~1.5 kflop x (n .. n(n+1)/2 + 1) passes against 8n..16n bytes in and
+// 8n^2 bytes out per configuration).
+#include "dyn_device.h"
+
+namespace rtbhip {
+
+typedef const __attribute__((address_space(4))) DevLink *ConstLinksD;
+constexpr int kDW = 64;
+
+struct DynParams {
+    int32_t n, mode;
+    int64_t N;
+    double grav[3];
+};
+
+
+// contiguous run of ncfg rows of W doubles (row stride `stride` in LDS) -> global, 16 bytes per lane per
+// piece; W may be odd (a piece may then straddle two rows, and the run may end on a single double)
+__device__ __forceinline__ void dyn_flush(const double *rows, int stride, int W, int ncfg, double *__restrict__ dst, int lane)
+{
+    const int total = ncfg * W;
+    for (int f = 2 * lane; f < total; f += 2 * kDW) {
+        const int r = f / W, e = f - r * W;
+        const double a = rows[r * stride + e];
+        if (f + 1 < total) {
+            const double b = (e + 1 < W) ? rows[r * stride + e + 1] : rows[(r + 1) * stride];
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            v2d w = {a, b};
+            __builtin_nontemporal_store(w, reinterpret_cast<v2d *>(dst + f));
+        } else {
+            __builtin_nontemporal_store(a, dst + f);
+        }
+    }
+}
+
+// K input arrays of (N, NJ) each -> lane-major LDS rows [k*NJ + j], all loads in flight at once
+template <int NJ, int K>
+__device__ __forceinline__ void dyn_load(double *lds, int stride, const double *const (&src)[K], int64_t cfg0, int count, int lane)
+{
+    double r[K][NJ];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) {
+            const int f = lane + kDW * i;
+            r[k][i] = (f < count) ? src[k][cfg0 * NJ + f] : 0.0;
+        }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) {
+            const int f = lane + kDW * i;
+            const int row = f / NJ, c = f - row * NJ;
+            lds[row * stride + k * NJ + c] = r[k][i];
+        }
+}
+
+// LDS per wave (doubles): inputs 64 x (K*NJ | 1), then the n x n work / output tiles
+template <int NJ, int MODE>
+struct DynLayout {
+    static constexpr int K = MODE == kDynInertia ? 1 : (MODE == kDynCoriolis ? 2 : 3);
+    static constexpr int in_stride = (K * NJ) | 1;
+    static constexpr int W = NJ * NJ;
+    static constexpr int w_stride = W | 1;
+    static constexpr int tiles = MODE == kDynCoriolis ? 2 : 1;     // coriolis: C and Csq
+    static constexpr int doubles = kDW * (in_stride + tiles * w_stride);
+};
+
+template <int NJ, bool MDH, int MODE>
+__global__ __launch_bounds__(kDW, 2) void k_dyn(DynParams dp, const DevLink *links_g, const double *__restrict__ q,
+                                                const double *__restrict__ qd, const double *__restrict__ tq,
+                                                double *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    typedef DynLayout<NJ, MODE> L;
+    ConstLinksD links = (ConstLinksD)links_g;
+    const int lane = threadIdx.x;
+    const int64_t cfg0 = (int64_t)blockIdx.x * kDW;
+    const int64_t left = dp.N - cfg0;
+    const int ncfg = left < kDW ? (int)left : kDW;
+    const int count = ncfg * NJ;
+    double *in = lds;
+    double *A = lds + kDW * L::in_stride;            // n x n tile: M (inertia, accel) or C (coriolis)
+    double *B = A + kDW * L::w_stride;               // coriolis only: Csq
+    if (MODE == kDynInertia) { const double *const src[1] = {q}; dyn_load<NJ, 1>(in, L::in_stride, src, cfg0, count, lane); }
+    if (MODE == kDynCoriolis) { const double *const src[2] = {q, qd}; dyn_load<NJ, 2>(in, L::in_stride, src, cfg0, count, lane); }
+    if (MODE == kDynAccel) { const double *const src[3] = {q, qd, tq}; dyn_load<NJ, 3>(in, L::in_stride, src, cfg0, count, lane); }
+    __syncthreads();
+    if (lane < ncfg)
+        dyn_lane<NJ, MDH, MODE>(links, in + lane * L::in_stride, A + lane * L::w_stride, B + lane * L::w_stride,
+                                v3(dp.grav[0], dp.grav[1], dp.grav[2]));
+    __syncthreads();
+    if (MODE == kDynAccel) dyn_flush(A, L::w_stride, NJ, ncfg, out + cfg0 * NJ, lane);
+    else dyn_flush(A, L::w_stride, L::W, ncfg, out + cfg0 * L::W, lane);
+}
+
+template <int NJ, int MODE>
+static hipError_t launch_mode(bool mdh, dim3 grid, hipStream_t s, const DynParams &dp, const DevLink *links, const double *q,
+                              const double *qd, const double *tq, double *out, size_t *lds_out)
+{
+    const size_t lds = (size_t)DynLayout<NJ, MODE>::doubles * sizeof(double);
+    *lds_out = lds;
+    if (mdh) {
+        auto k = k_dyn<NJ, true, MODE>;
+        if (lds > 48 * 1024) { hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
+        hipLaunchKernelGGL(k, grid, dim3(kDW), lds, s, dp, links, q, qd, tq, out);
+    } else {
+        auto k = k_dyn<NJ, false, MODE>;
+        if (lds > 48 * 1024) { hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
+        hipLaunchKernelGGL(k, grid, dim3(kDW), lds, s, dp, links, q, qd, tq, out);
+    }
+    return hipGetLastError();
+}
+
+template <int NJ>
+static hipError_t launch_nj(int mode, bool mdh, dim3 grid, hipStream_t s, const DynParams &dp, const DevLink *links,
+                            const double *q, const double *qd, const double *tq, double *out, size_t *lds)
+{
+    if (mode == kDynInertia) return launch_mode<NJ, kDynInertia>(mdh, grid, s, dp, links, q, qd, tq, out, lds);
+    if (mode == kDynCoriolis) return launch_mode<NJ, kDynCoriolis>(mdh, grid, s, dp, links, q, qd, tq, out, lds);
+    return launch_mode<NJ, kDynAccel>(mdh, grid, s, dp, links, q, qd, tq, out, lds);
+}
+
+int launch_dyn(const Dyn *d, const DevLink *links, int mode, const double *q, const double *qd, const double *tq,
+               int64_t N, const double *grav3, double *out, hipStream_t s)
+{
+    if (N == 0) return RTBHIP_OK;
+    if (d->n > 8) { set_error("inertia/coriolis/accel: this build handles chains of up to 8 joints on the device"); return RTBHIP_ELIMIT; }
+    const int64_t tiles = (N + kDW - 1) / kDW;
+    if (tiles > 0x7fffffff) { set_error("inertia/coriolis/accel: batch too large for one launch"); return RTBHIP_ELIMIT; }
+    DynParams dp;
+    dp.n = d->n; dp.mode = mode; dp.N = N;
+    for (int i = 0; i < 3; i++) dp.grav[i] = grav3 ? grav3[i] : 0.0;
+    dim3 grid((unsigned)tiles);
+    const bool mdh = d->mdh != 0;
+    hipError_t e = hipSuccess;
+    size_t lds = 0;
+    switch (d->n) {
+    case 1: e = launch_nj<1>(mode, mdh, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    case 2: e = launch_nj<2>(mode, mdh, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    case 3: e = launch_nj<3>(mode, mdh, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    case 4: e = launch_nj<4>(mode, mdh, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    case 5: e = launch_nj<5>(mode, mdh, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    case 6: e = launch_nj<6>(mode, mdh, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    case 7: e = launch_nj<7>(mode, mdh, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    default: e = launch_nj<8>(mode, mdh, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    }
+    note_launch((int)grid.x, kDW, (int)lds);
+    if (e != hipSuccess) return hip_fail(e, "k_dyn launch");
+    return RTBHIP_OK;
+}
+
+}  // namespace rtbhip

@@ -19,6 +19,7 @@
 // of forming the explicit inverse with a pivoted LU.
 #pragma once
 #include "kin_reg.h"
+#include "ldl.h"
 
 namespace rtbhip {
 
@@ -96,7 +97,7 @@ RTB_HD void ik_lm_step(const double (&jac)[6 * NJ], const double (&e)[6], const 
                        double (&dq)[NJ])
 {
     double A[NJ][NJ];   // lower triangle used; after factorisation holds L (unit diagonal implied)
-    double g[NJ], dval[NJ], dinv[NJ];
+    double g[NJ];
     double we_e[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) we_e[k] = we[k] * e[k];
@@ -115,39 +116,7 @@ RTB_HD void ik_lm_step(const double (&jac)[6 * NJ], const double (&e)[6], const 
         }
     }
     sched_fence();   // J is dead from here on: do not let the factorisation overlap the products above
-    // LDL^T: A = L D L^T
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        double d = A[j][j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k] * dval[k];
-        dval[j] = d;
-        dinv[j] = 1.0 / d;
-#pragma unroll
-        for (int i = j + 1; i < NJ; ++i) {
-            double v = A[i][j];
-#pragma unroll
-            for (int k = 0; k < j; ++k) v -= A[i][k] * A[j][k] * dval[k];
-            A[i][j] = v * dinv[j];
-        }
-    }
-    // forward: L y = g ; diagonal ; backward: L^T x = z
-#pragma unroll
-    for (int i = 0; i < NJ; ++i) {
-        double v = g[i];
-#pragma unroll
-        for (int k = 0; k < i; ++k) v -= A[i][k] * g[k];
-        g[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < NJ; ++i) g[i] *= dinv[i];
-#pragma unroll
-    for (int i = NJ - 1; i >= 0; --i) {
-        double v = g[i];
-#pragma unroll
-        for (int k = i + 1; k < NJ; ++k) v -= A[k][i] * dq[k];
-        dq[i] = v;
-    }
+    ldl_solve<NJ>(A, g, dq);
 }
 
 // ---------------------------------------------------------------- searches as pure functions

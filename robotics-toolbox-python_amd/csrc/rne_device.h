@@ -70,7 +70,8 @@ RTB_HD V3 inertia_times(const LinkT &l, V3 v)  // vmath.c mat_vect_mult: m[r + 3
 // One sample.  links: wave-uniform link table (scalar loads on the GPU).
 // qin/qdin/qddin/tau: per-lane accessors  in(j) -> double, out(j, v).  q(j) must stay readable until
 // tau(j) has been written (the kernel lets tau overwrite the q slots).
-template <int NJ, bool MDH, class LinksP, class InQ, class InQd, class InQdd, class Out>
+// FRICTION = false drops the viscous and Coulomb terms (Dynamics.nofriction(True, True), used by coriolis()).
+template <int NJ, bool MDH, bool FRICTION = true, class LinksP, class InQ, class InQd, class InQdd, class Out>
 RTB_HD void rne_lane(LinksP links, int n_rt, V3 grav, V3 ftip, V3 ntip, InQ qin, InQd qdin, InQdd qddin, Out tau)
 {
     constexpr int CAP = NJ > 0 ? NJ : RTBHIP_MAX_JOINTS;
@@ -199,8 +200,10 @@ RTB_HD void rne_lane(LinksP links, int n_rt, V3 grav, V3 ftip, V3 ntip, InQ qin,
         const double qdj = qdin(j), qddj = qddin(j);
         double t = MDH ? prj.z : l.sa * prj.y + l.ca * prj.z;
         t += l.G * l.G * l.Jm * qddj;
-        t += l.G * l.G * l.B * qdj;
-        t += fabs(l.G) * ((qdj > 0 ? l.Tc0 : 0.0) + (qdj < 0 ? l.Tc1 : 0.0));
+        if (FRICTION) {
+            t += l.G * l.G * l.B * qdj;
+            t += fabs(l.G) * ((qdj > 0 ? l.Tc0 : 0.0) + (qdj < 0 ? l.Tc1 : 0.0));
+        }
         tau(j, t);
         f = fj; nn = nj; Rn = R; psn = ps;
         if (NJ > 0) sched_fence();

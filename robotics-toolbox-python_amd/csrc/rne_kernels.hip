@@ -34,7 +34,7 @@ __device__ __forceinline__ void tile_copy(double *rows, int stride, int col_off,
     int r = f / n, c = f - r * n;
     const int da = kW / n, db = kW - da * n;
     for (; f < count; f += kW) {
-        if (TO_LDS) rows[r * stride + col_off + c] = gsrc[f];
+        if (TO_LDS) rows[r * stride + col_off + c] = gsrc ? gsrc[f] : 0.0;
         else gdst[f] = rows[r * stride + col_off + c];
         c += db; r += da;
         if (c >= n) { c -= n; r += 1; }
@@ -74,8 +74,8 @@ __device__ __forceinline__ void rne_tile(const RneParams &rp, ConstLinks links, 
             const int f = lane + kW * k;
             const bool in = f < count;
             r0[k] = in ? g0[f] : 0.0;
-            r1[k] = in ? g1[f] : 0.0;
-            r2[k] = in ? g2[f] : 0.0;
+            r1[k] = (in && qd) ? g1[f] : 0.0;      // NULL qd / qdd = zeros (gravload, itorque)
+            r2[k] = (in && qdd) ? g2[f] : 0.0;
         }
 #pragma unroll
         for (int k = 0; k < C; ++k) {
@@ -88,8 +88,8 @@ __device__ __forceinline__ void rne_tile(const RneParams &rp, ConstLinks links, 
         }
     } else {
         tile_copy<true>(lds, stride, 0, n, count, q + cfg0 * n, nullptr, lane);
-        tile_copy<true>(lds, stride, n, n, count, qd + cfg0 * n, nullptr, lane);
-        tile_copy<true>(lds, stride, 2 * n, n, count, qdd + cfg0 * n, nullptr, lane);
+        tile_copy<true>(lds, stride, n, n, count, qd ? qd + cfg0 * n : nullptr, nullptr, lane);
+        tile_copy<true>(lds, stride, 2 * n, n, count, qdd ? qdd + cfg0 * n : nullptr, nullptr, lane);
     }
     __syncthreads();
     if (lane < ncfg) {

@@ -108,6 +108,9 @@ int launch_rne(const Dyn *d, const DevLink *links, const double *q, const double
                const double *qdd, int64_t N, const double *grav3, const double *fext6, double *tau,
                hipStream_t s);
 
+int launch_dyn(const Dyn *d, const DevLink *links, int mode, const double *q, const double *qd, const double *tq,
+               int64_t N, const double *grav3, double *out, hipStream_t s);
+
 struct IkParams {
     int ilimit, slimit, reject_jl, method, flavour;
     double tol, lambda;

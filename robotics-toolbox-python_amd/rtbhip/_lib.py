@@ -51,6 +51,9 @@ SIGNATURES = {
     "rtbhip_dyn_create": (C.c_int, [_vp, _i32, _i32, C.POINTER(_u64)]),
     "rtbhip_dyn_destroy": (C.c_int, [_u64]),
     "rtbhip_rne": (C.c_int, [_u64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp]),
+    "rtbhip_inertia": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _vp]),
+    "rtbhip_coriolis": (C.c_int, [_u64, _vp, _vp, _i64, _vp, _i32, _vp]),
+    "rtbhip_accel": (C.c_int, [_u64, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp]),
     "rtbhip_fleet_fkine_jacob": (C.c_int, [C.POINTER(_u64), _i32, C.POINTER(_vp), C.POINTER(_i64), _i32,
                                            C.POINTER(_vp), C.POINTER(_vp), _i32, _vp]),
     "rtbhip_shard_range": (C.c_int, [_i64, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64)]),

@@ -202,40 +202,87 @@ class DHRobot:
             self._dyn = h.value
         return self._dyn
 
-    def rne(self, q, qd=None, qdd=None, gravity=None, fext=None, base_wrench=False):
-        """Inverse dynamics tau(q, qd, qdd): (n,) or (N,n)
-        (reference robot/DHRobot.py:1373-1456 -> frne.frne core/frne.c:106-230)."""
-        if base_wrench:
-            raise NotImplementedError("base_wrench is served by the reference's rne_python only")
+    def _dyn_args(self, arrays):
+        """-> (list of (N,n) contiguous arrays or None, N, single, torch_mode, ptr(), stream, mem, device)"""
         n = self.n
-        tm = is_torch(q) and q.is_cuda
+        first = next(x for x in arrays if x is not None)
+        tm = is_torch(first) and first.is_cuda
+        out = []
         if tm:
-            single = q.dim() == 1
-            arrs = [x.reshape(-1, n).contiguous() for x in (q, qd, qdd)]
+            single = first.dim() == 1
+            for x in arrays:
+                out.append(None if x is None else x.reshape(-1, n).contiguous())
         else:
-            arrs = [as_numeric(x) for x in (q, qd, qdd)]
-            single = arrs[0].ndim == 1
-            arrs = [np.ascontiguousarray(x.reshape(-1, n)) for x in arrs]
-        N = arrs[0].shape[0]
-        single = single or N == 1                # reference returns tau[0, :] whenever trajn == 1
-        if any(x.shape != (N, n) for x in arrs):
-            raise ValueError("q, qd, qdd must all be (%d,) or (N,%d)" % (n, n))
+            single = as_numeric(first).ndim == 1
+            for x in arrays:
+                out.append(None if x is None else np.ascontiguousarray(as_numeric(x).reshape(-1, n)))
+        N = next(x for x in out if x is not None).shape[0]
+        single = single or N == 1                # reference returns row 0 whenever trajn == 1
+        if any(x is not None and tuple(x.shape) != (N, n) for x in out):
+            raise ValueError("all inputs must be (%d,) or (N,%d)" % (n, n))
+        if tm:
+            return out, N, single, True, (lambda x: None if x is None else C.c_void_p(x.data_ptr())), \
+                _lib.current_stream_ptr(), MEM_DEVICE, first.device
+        return out, N, single, False, host_ptr, None, MEM_HOST, None
+
+    @staticmethod
+    def _empty(shape, tm, device):
+        if tm:
+            import torch
+            return torch.empty(shape, dtype=torch.float64, device=device)
+        return np.empty(shape)
+
+    def _gravity_c(self, gravity):
         g = self.gravity if gravity is None else np.asarray(gravity, dtype=np.float64).reshape(3)
         if self.base is not None:
             g = self.base[:3, :3].T @ g          # reference robot/DHRobot.py:1431-1433
-        gc = np.ascontiguousarray(-g)            # "we negate gravity here" robot/DHRobot.py:1449
+        return np.ascontiguousarray(-g)          # "we negate gravity here" robot/DHRobot.py:1449
+
+    def rne(self, q, qd=None, qdd=None, gravity=None, fext=None, base_wrench=False):
+        """Inverse dynamics tau(q, qd, qdd): (n,) or (N,n)
+        (reference robot/DHRobot.py:1373-1456 -> frne.frne core/frne.c:106-230).
+        qd / qdd = None means zeros (no zero arrays are read by the kernel)."""
+        if base_wrench:
+            raise NotImplementedError("base_wrench is served by the reference's rne_python only")
+        arrs, N, single, tm, ptr, stream, mem, dev = self._dyn_args([q, qd, qdd])
+        gc = self._gravity_c(gravity)
         f = None if fext is None else np.ascontiguousarray(np.asarray(fext, dtype=np.float64).reshape(6))
-        if tm:
-            import torch
-            tau = torch.empty((N, n), dtype=torch.float64, device=arrs[0].device)
-            ptr = lambda x: C.c_void_p(x.data_ptr())
-            stream = _lib.current_stream_ptr()
-            mem = MEM_DEVICE
-        else:
-            tau = np.empty((N, n))
-            ptr = host_ptr
-            stream = None
-            mem = MEM_HOST
+        tau = self._empty((N, self.n), tm, dev)
         check(lib().rtbhip_rne(self._dyn_handle(), ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2]), N, host_ptr(gc),
                                host_ptr(f), ptr(tau), mem, stream))
         return tau[0] if single else tau
+
+    # ---- the Dynamics-mixin terms (reference robot/Dynamics.py), one fused kernel each
+    def gravload(self, q=None, gravity=None):
+        """tau_g(q) (reference Dynamics.gravload robot/Dynamics.py:863-922): rne(q, 0, 0)."""
+        return self.rne(q, None, None, gravity=gravity)
+
+    def itorque(self, q, qdd):
+        """M(q) qdd (reference Dynamics.itorque robot/Dynamics.py:1407-1465): rne(q, 0, qdd) without gravity."""
+        return self.rne(q, None, qdd, gravity=[0, 0, 0])
+
+    def inertia(self, q):
+        """Joint-space inertia matrix: (n,n) or (N,n,n) (reference Dynamics.inertia robot/Dynamics.py:704-763:
+        n rne calls per configuration; here one kernel pass per unit acceleration inside one lane)."""
+        arrs, N, single, tm, ptr, stream, mem, dev = self._dyn_args([q])
+        M = self._empty((N, self.n, self.n), tm, dev)
+        check(lib().rtbhip_inertia(self._dyn_handle(), ptr(arrs[0]), N, ptr(M), mem, stream))
+        return M[0] if single else M
+
+    def coriolis(self, q, qd):
+        """Coriolis/centripetal matrix C(q, qd): (n,n) or (N,n,n)
+        (reference Dynamics.coriolis robot/Dynamics.py:765-861: n + n(n-1)/2 frictionless rne calls)."""
+        arrs, N, single, tm, ptr, stream, mem, dev = self._dyn_args([q, qd])
+        Cm = self._empty((N, self.n, self.n), tm, dev)
+        check(lib().rtbhip_coriolis(self._dyn_handle(), ptr(arrs[0]), ptr(arrs[1]), N, ptr(Cm), mem, stream))
+        return Cm[0] if single else Cm
+
+    def accel(self, q, qd, torque, gravity=None):
+        """Forward dynamics qdd = M^-1 (torque - rne(q, qd, 0)): (n,) or (N,n)
+        (reference Dynamics.accel robot/Dynamics.py:424-509)."""
+        arrs, N, single, tm, ptr, stream, mem, dev = self._dyn_args([q, qd, torque])
+        gc = self._gravity_c(gravity)
+        qdd = self._empty((N, self.n), tm, dev)
+        check(lib().rtbhip_accel(self._dyn_handle(), ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2]), N, host_ptr(gc),
+                                 ptr(qdd), mem, stream))
+        return qdd[0] if single else qdd

@@ -6,6 +6,7 @@
 // It is NOT a product path: librtbhip.so contains none of this and fails loudly without a GPU.
 #include "../../robotics-toolbox-python_amd/csrc/ik_device.h"
 #include "../../robotics-toolbox-python_amd/csrc/rne_device.h"
+#include "../../robotics-toolbox-python_amd/csrc/dyn_device.h"
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
@@ -341,6 +342,55 @@ extern "C" int emu_rne(rtbhip_dyn_t h, const double *q, const double *qd, const 
     case 7: rne_run<7>(d, q, qd, qdd, N, g, f, nt, tau); break;
     case 8: rne_run<8>(d, q, qd, qdd, N, g, f, nt, tau); break;
     default: rne_run<0>(d, q, qd, qdd, N, g, f, nt, tau); break;
+    }
+    return 0;
+}
+
+// dynamics terms: the kernel's per-lane body (dyn_device.h) on host arrays laid out like the LDS tile rows
+template <int NJ, bool MDH, int MODE>
+static void dyn_run(const Dyn *d, const double *q, const double *qd, const double *tq, int64_t N, V3 g, double *out)
+{
+    const DevLink *links = d->links.data();
+    std::vector<double> in(3 * NJ), A(NJ * NJ), B(NJ * NJ);
+    for (int64_t s = 0; s < N; ++s) {
+        for (int j = 0; j < NJ; ++j) {
+            in[j] = q[s * NJ + j];
+            in[NJ + j] = qd ? qd[s * NJ + j] : 0.0;
+            in[2 * NJ + j] = tq ? tq[s * NJ + j] : 0.0;
+        }
+        dyn_lane<NJ, MDH, MODE>(links, in.data(), A.data(), B.data(), g);
+        const int W = MODE == kDynAccel ? NJ : NJ * NJ;
+        for (int k = 0; k < W; ++k) out[s * W + k] = A[k];
+    }
+}
+template <int NJ>
+static void dyn_nj(const Dyn *d, int mode, const double *q, const double *qd, const double *tq, int64_t N, V3 g, double *out)
+{
+    if (d->mdh) {
+        if (mode == 0) dyn_run<NJ, true, kDynInertia>(d, q, qd, tq, N, g, out);
+        else if (mode == 1) dyn_run<NJ, true, kDynCoriolis>(d, q, qd, tq, N, g, out);
+        else dyn_run<NJ, true, kDynAccel>(d, q, qd, tq, N, g, out);
+    } else {
+        if (mode == 0) dyn_run<NJ, false, kDynInertia>(d, q, qd, tq, N, g, out);
+        else if (mode == 1) dyn_run<NJ, false, kDynCoriolis>(d, q, qd, tq, N, g, out);
+        else dyn_run<NJ, false, kDynAccel>(d, q, qd, tq, N, g, out);
+    }
+}
+extern "C" int emu_dyn(rtbhip_dyn_t h, int mode, const double *q, const double *qd, const double *tq, int64_t N,
+                       const double *grav3, double *out)
+{
+    Dyn *d = dyn_from_handle(h);
+    if (!d || d->n > 8) return -1;
+    V3 g = grav3 ? v3(grav3[0], grav3[1], grav3[2]) : v3(0, 0, 0);
+    switch (d->n) {
+    case 1: dyn_nj<1>(d, mode, q, qd, tq, N, g, out); break;
+    case 2: dyn_nj<2>(d, mode, q, qd, tq, N, g, out); break;
+    case 3: dyn_nj<3>(d, mode, q, qd, tq, N, g, out); break;
+    case 4: dyn_nj<4>(d, mode, q, qd, tq, N, g, out); break;
+    case 5: dyn_nj<5>(d, mode, q, qd, tq, N, g, out); break;
+    case 6: dyn_nj<6>(d, mode, q, qd, tq, N, g, out); break;
+    case 7: dyn_nj<7>(d, mode, q, qd, tq, N, g, out); break;
+    default: dyn_nj<8>(d, mode, q, qd, tq, N, g, out); break;
     }
     return 0;
 }

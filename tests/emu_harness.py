@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "robotics-toolbox-python_amd")
 EMU_SO = os.path.join(ROOT, "tests", "emu", "libemu.so")
 SRCS = ["tests/emu/emu.cpp"] + ["robotics-toolbox-python_amd/csrc/" + f for f in
-                                ("api.cpp", "chain.cpp", "kin_kernels.hip", "rne_kernels.hip", "ik_kernels.hip")]
+                                ("api.cpp", "chain.cpp", "kin_kernels.hip", "rne_kernels.hip", "ik_kernels.hip", "dyn_kernels.hip")]
 _vp, _u64, _i64, _i32 = C.c_void_p, C.c_uint64, C.c_int64, C.c_int32
 _lib = None
 
@@ -45,6 +45,7 @@ def lib():
         _lib.rtbhip_dyn_create.argtypes = [_vp, _i32, _i32, C.POINTER(_u64)]
         _lib.emu_kin.argtypes = [_u64, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _i32]
         _lib.emu_rne.argtypes = [_u64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32]
+        _lib.emu_dyn.argtypes = [_u64, _i32, _vp, _vp, _vp, _i64, _vp, _vp]
         _lib.emu_kin_reg.argtypes = [_u64, _vp, _i64, _vp, _vp, _i32, _vp, _vp]
         _lib.emu_sincos.argtypes = [_vp, _i64, _vp, _vp, _i32]
         _lib.emu_ik.argtypes = [_u64, _vp, _i64, _vp, _i32, _i32, C.c_double, _i32, _vp, C.c_double, _i32, _i32, _u64,
@@ -116,6 +117,21 @@ def rne(L24, mdh, q, qd, qdd, grav_c, fext=None, force_generic=False):
     rc = lib().emu_rne(h.value, _p(q), _p(qd), _p(qdd), q.shape[0], _p(g), _p(f), _p(tau), int(force_generic))
     assert rc == 0
     return tau
+
+
+def dyn(L24, mdh, mode, q, qd=None, torque=None, grav_c=None):
+    """mode 0 inertia (N,n,n), 1 coriolis (N,n,n), 2 accel (N,n): dyn_device.h's per-lane body on the CPU."""
+    L = np.ascontiguousarray(L24, dtype=np.float64).reshape(-1, 24)
+    n = L.shape[0]
+    h = _u64(0)
+    assert lib().rtbhip_dyn_create(_p(L), n, int(mdh), C.byref(h)) == 0, lib().rtbhip_last_error()
+    conv = lambda x: None if x is None else np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1, n))
+    q, qd, torque = conv(q), conv(qd), conv(torque)
+    N = q.shape[0]
+    out = np.full((N, n) if mode == 2 else (N, n, n), np.nan)
+    g = None if grav_c is None else np.ascontiguousarray(grav_c, dtype=np.float64)
+    assert lib().emu_dyn(h.value, mode, _p(q), _p(qd), _p(torque), N, _p(g), _p(out)) == 0
+    return out
 
 
 METHODS = {"chan": 0, "wampler": 1, "sugihara": 2}

@@ -59,6 +59,16 @@ def main():
     for k in range(6):
         add("G9_puma_rne_tr%d" % k, "test_DHRobot.py", "test_rne", "tr%d" % k)
     add("G9_fext", "test_DHRobot.py", "test_rne", "fext")
+    # Dynamics-mixin goldens: Puma560 at qn
+    add("D_puma_accel_qd", "test_DHRobot.py", "test_accel", "qd")
+    add("D_puma_accel_torque", "test_DHRobot.py", "test_accel", "torque")
+    add("D_puma_accel", "test_DHRobot.py", "test_accel", "res")
+    add("D_puma_inertia", "test_DHRobot.py", "test_inertia", "Ir")
+    add("D_puma_coriolis_qd", "test_DHRobot.py", "test_coriolis", "qd")
+    add("D_puma_coriolis", "test_DHRobot.py", "test_coriolis", "Cr")
+    add("D_puma_gravload", "test_DHRobot.py", "test_gravload", "taur")
+    add("D_puma_itorque_qdd", "test_DHRobot.py", "test_itorque", "qdd")
+    add("D_puma_itorque", "test_DHRobot.py", "test_itorque", "tauir")
     # G11 -- DH robots
     add("G11_dh_rprp_fkine", "test_DHRobot.py", "test_fkine", "T1")
     add("G11_dh_panda_fkine", "test_DHRobot.py", "test_fkine_panda", "T")

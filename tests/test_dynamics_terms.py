@@ -1,0 +1,123 @@
+"""Dynamics-mixin terms: inertia / coriolis / gravload / itorque / accel as fused kernels.
+   * the oracle's restatement of robot/Dynamics.py (oracle/oracle.py *_dh) is pinned on the reference's
+     own goldens (tests/test_DHRobot.py:1092-1202, lifted into tests/golden/reference_literals.json);
+   * the kernels' per-lane body (dyn_device.h) runs on the CPU through tests/emu against that oracle;
+   * the GPU kernels run through the C ABI against the oracle and the goldens."""
+import numpy as np
+import numpy.testing as nt
+import pytest
+
+import rtbhip
+from oracle import oracle, chains
+from helpers import literals
+
+LIT = literals()
+QN = np.array([0, np.pi / 4, np.pi, 0, np.pi / 4, 0])
+
+
+def _puma():
+    t = chains.puma560()
+    return t, t.L24(), -t.gravity
+
+
+def test_oracle_restatement_matches_reference_goldens():
+    t, L, gc = _puma()
+    nt.assert_array_almost_equal(oracle.inertia_dh(L, 0, QN)[0], LIT["D_puma_inertia"], decimal=4)
+    nt.assert_array_almost_equal(oracle.coriolis_dh(L, 0, QN, LIT["D_puma_coriolis_qd"])[0], LIT["D_puma_coriolis"], decimal=4)
+    nt.assert_array_almost_equal(oracle.accel_dh(L, 0, QN, LIT["D_puma_accel_qd"], LIT["D_puma_accel_torque"], gc)[0],
+                                 LIT["D_puma_accel"], decimal=4)
+    z = np.zeros(6)
+    nt.assert_array_almost_equal(oracle.rne_dh(L, 0, QN, z, z, gc)[0], LIT["D_puma_gravload"], decimal=4)
+    nt.assert_array_almost_equal(oracle.rne_dh(L, 0, QN, z, LIT["D_puma_itorque_qdd"], [0, 0, 0])[0],
+                                 LIT["D_puma_itorque"], decimal=4)
+
+
+@pytest.mark.parametrize("robot", ["puma", "panda"])
+def test_emu_kernel_body_vs_oracle(robot):
+    import emu_harness as emu
+    t = chains.puma560() if robot == "puma" else chains.panda_dh()
+    mdh = 0 if robot == "puma" else 1
+    L, gc, n = t.L24(), -t.gravity, t.L24().shape[0]
+    rng = np.random.default_rng(8)
+    q = rng.uniform(t.qlim[:, 0], t.qlim[:, 1], (9, n))
+    qd, tq = rng.normal(size=(9, n)), rng.normal(size=(9, n)) * 5
+    M = emu.dyn(L, mdh, 0, q)
+    nt.assert_allclose(M, oracle.inertia_dh(L, mdh, q), rtol=1e-11, atol=1e-12)
+    nt.assert_allclose(M, np.swapaxes(M, 1, 2), atol=1e-12)
+    Cm = emu.dyn(L, mdh, 1, q, qd)
+    nt.assert_allclose(Cm, oracle.coriolis_dh(L, mdh, q, qd), rtol=1e-10, atol=1e-11)
+    a = emu.dyn(L, mdh, 2, q, qd, tq, gc)
+    ref = oracle.accel_dh(L, mdh, q, qd, tq, gc)
+    nt.assert_allclose(a, ref, rtol=1e-9, atol=1e-9 * np.abs(ref).max())
+
+
+def test_emu_goldens_puma_qn():
+    import emu_harness as emu
+    t, L, gc = _puma()
+    nt.assert_array_almost_equal(emu.dyn(L, 0, 0, QN)[0], LIT["D_puma_inertia"], decimal=4)
+    nt.assert_array_almost_equal(emu.dyn(L, 0, 1, QN, LIT["D_puma_coriolis_qd"])[0], LIT["D_puma_coriolis"], decimal=4)
+    nt.assert_array_almost_equal(emu.dyn(L, 0, 2, QN, LIT["D_puma_accel_qd"], LIT["D_puma_accel_torque"], gc)[0],
+                                 LIT["D_puma_accel"], decimal=4)
+
+
+@pytest.mark.gpu
+def test_gpu_goldens_and_shapes_puma():
+    """reference tests/test_DHRobot.py:1092-1202: single q -> (n,) / (n,n); stacked q -> leading batch axis."""
+    puma = rtbhip.models.DH.Puma560()
+    q2 = np.c_[QN, QN].T
+    nt.assert_array_almost_equal(puma.inertia(QN), LIT["D_puma_inertia"], decimal=4)
+    qd = LIT["D_puma_coriolis_qd"]
+    nt.assert_array_almost_equal(puma.coriolis(QN, qd), LIT["D_puma_coriolis"], decimal=4)
+    C1 = puma.coriolis(q2, np.c_[qd, qd].T)
+    assert C1.shape == (2, 6, 6)
+    nt.assert_array_almost_equal(C1[1], LIT["D_puma_coriolis"], decimal=4)
+    nt.assert_array_almost_equal(puma.gravload(QN), LIT["D_puma_gravload"], decimal=4)
+    nt.assert_array_almost_equal(puma.gravload(q2)[1], LIT["D_puma_gravload"], decimal=4)
+    qdd = LIT["D_puma_itorque_qdd"]
+    nt.assert_array_almost_equal(puma.itorque(QN, qdd), LIT["D_puma_itorque"], decimal=4)
+    nt.assert_array_almost_equal(puma.itorque(q2, np.c_[qdd, qdd].T)[0], LIT["D_puma_itorque"], decimal=4)
+    aq, at = LIT["D_puma_accel_qd"], LIT["D_puma_accel_torque"]
+    nt.assert_array_almost_equal(puma.accel(QN, aq, at), LIT["D_puma_accel"], decimal=4)
+    nt.assert_array_almost_equal(puma.accel(q2, np.c_[aq, aq].T, np.c_[at, at].T)[1], LIT["D_puma_accel"], decimal=4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("robot,N", [("puma", 1000), ("panda", 4097), ("panda", 63)])
+def test_gpu_vs_oracle_and_identities(robot, N):
+    import torch
+    rob = rtbhip.models.DH.Puma560() if robot == "puma" else rtbhip.models.DH.Panda()
+    t = chains.puma560() if robot == "puma" else chains.panda_dh()
+    mdh, L, gc, n = rob.mdh, t.L24(), -t.gravity, rob.n
+    rng = np.random.default_rng(N)
+    q = rng.uniform(t.qlim[:, 0], t.qlim[:, 1], (N, n))
+    qd, tq, qdd = rng.normal(size=(N, n)), rng.normal(size=(N, n)) * 5, rng.normal(size=(N, n))
+    k = min(N, 200)                                    # the oracle composition is a Python loop: bounded sample
+    M = rob.inertia(q)
+    nt.assert_allclose(M[:k], oracle.inertia_dh(L, mdh, q[:k]), rtol=1e-11, atol=1e-12)
+    Cm = rob.coriolis(q, qd)
+    nt.assert_allclose(Cm[:k], oracle.coriolis_dh(L, mdh, q[:k], qd[:k]), rtol=1e-10, atol=1e-11)
+    a = rob.accel(q, qd, tq)
+    ref = oracle.accel_dh(L, mdh, q[:k], qd[:k], tq[:k], gc)
+    nt.assert_allclose(a[:k], ref, rtol=1e-9, atol=1e-9 * np.abs(ref).max())
+    # size-independent identities over the whole batch
+    nt.assert_allclose(M, np.swapaxes(M, 1, 2), atol=1e-11)                       # symmetric
+    assert np.linalg.eigvalsh(M).min() > 0                                        # positive definite
+    nt.assert_allclose(rob.itorque(q, qdd), np.einsum("nij,nj->ni", M, qdd), rtol=1e-10, atol=1e-10)
+    nt.assert_allclose(rob.gravload(q), rob.rne(q, np.zeros_like(q), np.zeros_like(q)), atol=0)   # NULL == zeros
+    # forward dynamics inverts inverse dynamics: rne(q, qd, accel(q, qd, tau)) == tau
+    back = rob.rne(q, qd, a)
+    nt.assert_allclose(back, tq, rtol=1e-8, atol=1e-8 * np.abs(tq).max())
+    # device-pointer path == host-pointer path
+    qt, qdt, tqt = (torch.from_numpy(x).cuda() for x in (q, qd, tq))
+    nt.assert_array_equal(rob.inertia(qt).cpu().numpy(), M)
+    nt.assert_array_equal(rob.coriolis(qt, qdt).cpu().numpy(), Cm)
+    nt.assert_array_equal(rob.accel(qt, qdt, tqt).cpu().numpy(), a)
+
+
+@pytest.mark.gpu
+def test_gpu_dynamics_limits_and_errors():
+    L = np.zeros((9, 24)); L[:, 6] = 1.0
+    rob9 = rtbhip.DHRobot([rtbhip.RevoluteDH(a=0.1, m=1.0) for _ in range(9)])
+    with pytest.raises(rtbhip.RtbHipError):
+        rob9.inertia(np.zeros(9))                       # > 8 joints: loud ELIMIT, no silent fallback
+    assert rob9.gravload(np.zeros((3, 9))).shape == (3, 9)      # rne itself handles any n
