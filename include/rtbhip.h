@@ -97,6 +97,20 @@ int rtbhip_fkine_jacob(rtbhip_chain_t chain, const double *q, int64_t N, const d
 int rtbhip_hessian(rtbhip_chain_t chain, const double *q, int64_t N, const double *tool16,
                    int32_t frame, double *H, int32_t mem, void *stream);
 
+/* Differential-kinematics consumers computed from the Jacobian while it is still in registers (SURVEY 8f-4;
+ * chains of up to 8 joints):
+ *   rtbhip_jacob_dot       Robot.jacob0_dot (robot/Robot.py:964-1098, representation=None): Jd (N,6,n) = H(q) . qd,
+ *                          frame 0 -> hessian0, 1 -> hessiane; qd is (N, q_width) like q
+ *   rtbhip_manipulability  ETS.manipulability method "yoshikawa" (robot/ETS.py:1687-1819): m (N);
+ *                          axes_mask bit r = Cartesian row r used (63 all, 7 trans, 56 rot)
+ *   rtbhip_jacobm          ETS.jacobm / Robot.jacobm (robot/ETS.py:1628-1685, robot/Robot.py:1120-1235): Jm (N,n) */
+int rtbhip_jacob_dot(rtbhip_chain_t chain, const double *q, const double *qd, int64_t N, const double *tool16,
+                     int32_t frame, double *Jd, int32_t mem, void *stream);
+int rtbhip_manipulability(rtbhip_chain_t chain, const double *q, int64_t N, const double *tool16, int32_t axes_mask,
+                          double *m, int32_t mem, void *stream);
+int rtbhip_jacobm(rtbhip_chain_t chain, const double *q, int64_t N, const double *tool16, int32_t axes_mask, double *Jm,
+                  int32_t mem, void *stream);
+
 /* IK_LM_c (fknm.cpp:394-525 -> ik.cpp:19-75,157-209), batched over N targets, LM loop resident
  * on the device.  Tep (N,4,4) row-major; q0 (N,n) or NULL; we6 host or NULL; method 0 chan /
  * 1 wampler / 2 sugihara; seed keys the counter-based restart generator (the reference uses an

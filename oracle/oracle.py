@@ -96,6 +96,65 @@ def hessian0(ch, q, tool=None):
     return H
 
 
+def hessian(ch, q, tool=None, frame=0):
+    J = jacob(ch, q, tool, frame)
+    H = np.empty((J.shape[0], ch.n, 6, ch.n))
+    for i in range(J.shape[0]):
+        Ji = np.ascontiguousarray(J[i])
+        lib().oracle_hessian(C.c_int(ch.n), _d(Ji), _d(H[i]))
+    return H
+
+
+def jacob_dot(ch, q, qd, tool=None, frame=0):
+    """Robot.jacob0_dot (robot/Robot.py:1063-1098, representation=None): tensordot(H, qd, (0, 0))."""
+    H = hessian(ch, q, tool, frame)
+    qd = _f64(qd).reshape(H.shape[0], ch.n)
+    return np.array([np.tensordot(H[i], qd[i], (0, 0)) for i in range(H.shape[0])])
+
+
+def _axes_list(axes):
+    if isinstance(axes, str):
+        if axes.startswith("all"):
+            return [True] * 6
+        if axes.startswith("trans"):
+            return [True] * 3 + [False] * 3
+        if axes.startswith("rot"):
+            return [False] * 3 + [True] * 3
+        raise ValueError("axes must be all, trans or rot")
+    return [bool(a) for a in axes]
+
+
+def manipulability(ch, q, axes="all", tool=None):
+    """ETS.manipulability, method 'yoshikawa' (robot/ETS.py:1766-1819)."""
+    ax = _axes_list(axes)
+    J = jacob(ch, q, tool, 0)
+    out = np.zeros(J.shape[0])
+    for k in range(J.shape[0]):
+        Jk = J[k][ax, :]
+        if Jk.shape[0] == Jk.shape[1]:
+            out[k] = abs(np.linalg.det(Jk))
+        else:
+            out[k] = np.sqrt(abs(np.linalg.det(Jk @ Jk.T)))
+    return out
+
+
+def jacobm(ch, q, axes="all", tool=None):
+    """Robot.jacobm (robot/Robot.py:1185-1235) / ETS.jacobm (robot/ETS.py:1669-1685): (N, n)."""
+    ax = _axes_list(axes)
+    J = jacob(ch, q, tool, 0)
+    H = hessian(ch, q, tool, 0)
+    m = manipulability(ch, q, axes, tool)
+    out = np.zeros((J.shape[0], ch.n))
+    for k in range(J.shape[0]):
+        Jk = J[k][ax, :]
+        Hk = H[k][:, ax, :]
+        b = np.linalg.inv(Jk @ Jk.T)
+        for i in range(ch.n):
+            c = Jk @ Hk[i].T
+            out[k, i] = m[k] * (c.flatten("F")).T @ b.flatten("F")
+    return out
+
+
 def angle_axis(Te, Tep):
     Te, Tep = _f64(Te, (4, 4)), _f64(Tep, (4, 4))
     e = np.empty(6)

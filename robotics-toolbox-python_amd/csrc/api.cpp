@@ -283,6 +283,53 @@ int rtbhip_hessian(rtbhip_chain_t chain, const double *q, int64_t N, const doubl
     return kin_entry("hessian", chain, q, N, nullptr, tool16, frame, nullptr, nullptr, H, mem, stream);
 }
 
+/* Robot.jacob0_dot / ETS.manipulability (yoshikawa) / ETS.jacobm */
+static int diff_entry(const char *fn, rtbhip_chain_t h, int mode, int axes, const double *q, const double *qd, int64_t N,
+                      const double *tool16, int frame, double *out, int mem, void *stream)
+{
+    Chain *c = chain_from_handle(h);
+    if (!c) { set_error(std::string(fn) + ": unknown chain handle"); return RTBHIP_EINVAL; }
+    RTB_TRY(check_batch(fn, q, N, mem));
+    if (frame != 0 && frame != 1) { set_error(std::string(fn) + ": frame must be 0 or 1"); return RTBHIP_EINVAL; }
+    if (mode != 0 && (axes & 63) == 0) { set_error(std::string(fn) + ": empty axes mask"); return RTBHIP_EINVAL; }
+    if (N > 0 && (!out || (mode == 0 && !qd))) { set_error(std::string(fn) + ": NULL qd/output"); return RTBHIP_EINVAL; }
+    if (N == 0) return RTBHIP_OK;
+    DevChain ops;
+    RTB_TRY(chain_device_ops(c, &ops, nullptr));
+    Affine tool = affine_from16(tool16);
+    const size_t n = (size_t)c->n, qw = (size_t)c->q_width;
+    if (mem == RTBHIP_MEM_DEVICE)
+        return launch_kin_diff(c, ops, mode, axes, q, qd, N, tool, frame, out, (hipStream_t)stream);
+    Staging st;
+    void *dq, *dqd = nullptr, *dout;
+    const size_t obytes = (size_t)N * 8 * (mode == 0 ? 6 * n : (mode == 1 ? 1 : n));
+    RTB_TRY(st.in(q, (size_t)N * qw * 8, &dq));
+    if (mode == 0) RTB_TRY(st.in(qd, (size_t)N * qw * 8, &dqd));
+    RTB_TRY(st.out(obytes, &dout));
+    RTB_TRY(launch_kin_diff(c, ops, mode, axes, (const double *)dq, (const double *)dqd, N, tool, frame, (double *)dout, nullptr));
+    RTB_HIP(hipDeviceSynchronize());
+    RTB_TRY(fetch(out, dout, obytes));
+    return RTBHIP_OK;
+}
+
+int rtbhip_jacob_dot(rtbhip_chain_t chain, const double *q, const double *qd, int64_t N, const double *tool16,
+                     int32_t frame, double *Jd, int32_t mem, void *stream)
+{
+    return diff_entry("jacob_dot", chain, 0, 63, q, qd, N, tool16, frame, Jd, mem, stream);
+}
+
+int rtbhip_manipulability(rtbhip_chain_t chain, const double *q, int64_t N, const double *tool16, int32_t axes_mask,
+                          double *m, int32_t mem, void *stream)
+{
+    return diff_entry("manipulability", chain, 1, axes_mask, q, nullptr, N, tool16, 0, m, mem, stream);
+}
+
+int rtbhip_jacobm(rtbhip_chain_t chain, const double *q, int64_t N, const double *tool16, int32_t axes_mask, double *Jm,
+                  int32_t mem, void *stream)
+{
+    return diff_entry("jacobm", chain, 2, axes_mask, q, nullptr, N, tool16, 0, Jm, mem, stream);
+}
+
 int rtbhip_ik_lm(rtbhip_chain_t chain, const double *Tep, int64_t N, const double *q0,
                  int32_t ilimit, int32_t slimit, double tol, int32_t reject_jl, const double *we6,
                  double lambda, int32_t method, int32_t flavour, uint64_t seed, double *q_out,

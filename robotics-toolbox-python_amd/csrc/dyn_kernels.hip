@@ -10,6 +10,7 @@
 // Bound: fp64 VALU issue (~1.5 kflop x (n .. n(n+1)/2 + 1) passes against 8n..16n bytes in and
 // 8n^2 bytes out per configuration).
 #include "dyn_device.h"
+#include "kin_tile.h"
 
 namespace rtbhip {
 
@@ -22,25 +23,6 @@ struct DynParams {
     double grav[3];
 };
 
-
-// contiguous run of ncfg rows of W doubles (row stride `stride` in LDS) -> global, 16 bytes per lane per
-// piece; W may be odd (a piece may then straddle two rows, and the run may end on a single double)
-__device__ __forceinline__ void dyn_flush(const double *rows, int stride, int W, int ncfg, double *__restrict__ dst, int lane)
-{
-    const int total = ncfg * W;
-    for (int f = 2 * lane; f < total; f += 2 * kDW) {
-        const int r = f / W, e = f - r * W;
-        const double a = rows[r * stride + e];
-        if (f + 1 < total) {
-            const double b = (e + 1 < W) ? rows[r * stride + e + 1] : rows[(r + 1) * stride];
-            typedef double v2d __attribute__((ext_vector_type(2)));
-            v2d w = {a, b};
-            __builtin_nontemporal_store(w, reinterpret_cast<v2d *>(dst + f));
-        } else {
-            __builtin_nontemporal_store(a, dst + f);
-        }
-    }
-}
 
 // K input arrays of (N, NJ) each -> lane-major LDS rows [k*NJ + j], all loads in flight at once
 template <int NJ, int K>
@@ -99,8 +81,8 @@ __global__ __launch_bounds__(kDW, 2) void k_dyn(DynParams dp, const DevLink *lin
         dyn_lane<NJ, MDH, MODE>(links, in + lane * L::in_stride, A + lane * L::w_stride, B + lane * L::w_stride,
                                 v3(dp.grav[0], dp.grav[1], dp.grav[2]));
     __syncthreads();
-    if (MODE == kDynAccel) dyn_flush(A, L::w_stride, NJ, ncfg, out + cfg0 * NJ, lane);
-    else dyn_flush(A, L::w_stride, L::W, ncfg, out + cfg0 * L::W, lane);
+    if (MODE == kDynAccel) flush_run(A, L::w_stride, NJ, ncfg, out + cfg0 * NJ, lane);
+    else flush_run(A, L::w_stride, L::W, ncfg, out + cfg0 * L::W, lane);
 }
 
 template <int NJ, int MODE>

@@ -10,6 +10,7 @@
 // Roofline: HBM-bound by construction -- 8*qw bytes in, 128 + 48n bytes out per configuration
 // (520 B for the Panda), ~0.6 kflop of fp64 VALU + n sincos per configuration.
 #include "kin_reg.h"
+#include "diff_device.h"
 #include <algorithm>
 #include <cstring>
 
@@ -119,6 +120,91 @@ __global__ __launch_bounds__(kWave, RTB_REG_WAVES) void k_kin_reg(KinParams kp, 
 {
     extern __shared__ __attribute__((aligned(16))) double buf[];
     reg_tile<NJ, WANT_T, WANT_J>(kp, const_view(dc), q, T, J, buf, threadIdx.x, blockIdx.x);
+}
+
+// ---------------------------------------------------------------- differential-kinematics consumers (n <= 8)
+// jacob0_dot / manipulability / jacobm straight from the register-resident Jacobian: the (n,6,n) Hessian
+// the reference materialises for each of them (robot/Robot.py:1069, robot/ETS.py:1671) never exists.
+enum { kDiffJdot = 0, kDiffManip = 1, kDiffJacobm = 2 };
+template <int NJ, int MODE>
+__global__ __launch_bounds__(kWave, 2) void k_kin_diff(KinParams kp, DevChain dc, int axes, const double *__restrict__ q,
+                                                       const double *__restrict__ qd, double *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) double buf[];
+    const ConstChain cv = const_view(dc);
+    const int lane = threadIdx.x;
+    const int64_t cfg0 = (int64_t)blockIdx.x * kWave, cfg = cfg0 + lane;
+    const int64_t left = kp.N - cfg0;
+    const int ncfg = left < kWave ? (int)left : kWave;
+    Pose P;
+    double jac[6 * NJ];
+    reg_compute<NJ, true>(kp, cv, q, cfg, P, jac);
+    if (MODE == kDiffJdot) {
+        double v[NJ], jd[6 * NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) v[j] = cfg < kp.N ? qd[cfg * kp.qw + jm_jq(cv.jmeta[j])] : 0.0;
+        jacob_dot<NJ>(jac, v, jd);
+        constexpr int W = 6 * NJ;
+#pragma unroll
+        for (int r = 0; r < kWave / kJRound; ++r) {
+            if (lane / kJRound == r) reg_stage_J<NJ>(jd, buf, lane % kJRound);
+            __syncthreads();
+            int rows = ncfg - r * kJRound;
+            rows = rows < 0 ? 0 : (rows > kJRound ? kJRound : rows);
+            kin_flush(buf, W + 1, W, rows, out + (cfg0 + r * kJRound) * W, lane);
+            __syncthreads();
+        }
+    } else if (MODE == kDiffManip) {
+        const double m = manipulability_yoshikawa<NJ>(jac, axes);
+        if (cfg < kp.N) out[cfg] = m;                      // 8 bytes per lane, contiguous across the wave
+    } else {
+        double jm[NJ];
+        jacobm<NJ>(jac, axes, jm);
+        constexpr int S = NJ | 1;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) buf[lane * S + j] = jm[j];
+        __syncthreads();
+        flush_run(buf, S, NJ, ncfg, out + cfg0 * NJ, lane);
+    }
+}
+
+template <int NJ>
+static hipError_t launch_diff_nj(int mode, dim3 grid, size_t lds, hipStream_t s, const KinParams &kp, const DevChain &dc,
+                                 int axes, const double *q, const double *qd, double *out)
+{
+    if (mode == kDiffJdot) hipLaunchKernelGGL((k_kin_diff<NJ, kDiffJdot>), grid, dim3(kWave), lds, s, kp, dc, axes, q, qd, out);
+    else if (mode == kDiffManip) hipLaunchKernelGGL((k_kin_diff<NJ, kDiffManip>), grid, dim3(kWave), lds, s, kp, dc, axes, q, qd, out);
+    else hipLaunchKernelGGL((k_kin_diff<NJ, kDiffJacobm>), grid, dim3(kWave), lds, s, kp, dc, axes, q, qd, out);
+    return hipGetLastError();
+}
+
+int launch_kin_diff(const Chain *c, const DevChain &dc, int mode, int axes, const double *q, const double *qd, int64_t N,
+                    const Affine &tool, int frame, double *out, hipStream_t s)
+{
+    if (N == 0) return RTBHIP_OK;
+    if (c->n < 1 || c->n > kRegMaxJoints) { set_error("jacob_dot/manipulability/jacobm: chains of 1..8 joints on the device"); return RTBHIP_ELIMIT; }
+    const int64_t tiles = (N + kWave - 1) / kWave;
+    if (tiles > 0x7fffffff) { set_error("jacob_dot/manipulability/jacobm: batch too large for one launch"); return RTBHIP_ELIMIT; }
+    KinParams kp;
+    kp.n = c->n; kp.qw = c->q_width; kp.stride = kin_stride(c->n); kp.frame = frame; kp.has_base = 0; kp.pad = 0; kp.N = N;
+    for (int i = 0; i < 12; i++) kp.base[i] = 0.0;
+    chain_tail(c, tool, kp.tail);
+    const size_t lds = (size_t)reg_lds_doubles(c->n) * sizeof(double);
+    dim3 grid((unsigned)tiles);
+    hipError_t e = hipSuccess;
+    switch (c->n) {
+    case 1: e = launch_diff_nj<1>(mode, grid, lds, s, kp, dc, axes, q, qd, out); break;
+    case 2: e = launch_diff_nj<2>(mode, grid, lds, s, kp, dc, axes, q, qd, out); break;
+    case 3: e = launch_diff_nj<3>(mode, grid, lds, s, kp, dc, axes, q, qd, out); break;
+    case 4: e = launch_diff_nj<4>(mode, grid, lds, s, kp, dc, axes, q, qd, out); break;
+    case 5: e = launch_diff_nj<5>(mode, grid, lds, s, kp, dc, axes, q, qd, out); break;
+    case 6: e = launch_diff_nj<6>(mode, grid, lds, s, kp, dc, axes, q, qd, out); break;
+    case 7: e = launch_diff_nj<7>(mode, grid, lds, s, kp, dc, axes, q, qd, out); break;
+    default: e = launch_diff_nj<8>(mode, grid, lds, s, kp, dc, axes, q, qd, out); break;
+    }
+    note_launch((int)grid.x, kWave, (int)lds);
+    if (e != hipSuccess) return hip_fail(e, "k_kin_diff launch");
+    return RTBHIP_OK;
 }
 
 namespace {

@@ -109,6 +109,27 @@ RTB_HD void kin_flush(const double *rows, int stride, int W, int ncfg, double *_
     }
 }
 
+#if defined(__HIPCC__)
+// contiguous run of ncfg rows of W doubles (row stride `stride` in LDS) -> global, 16 bytes per lane per
+// piece; W may be odd (a piece may then straddle two rows, and the run may end on a single double)
+__device__ __forceinline__ void flush_run(const double *rows, int stride, int W, int ncfg, double *__restrict__ dst, int lane)
+{
+    const int total = ncfg * W;
+    for (int f = 2 * lane; f < total; f += 2 * kWave) {
+        const int r = f / W, e = f - r * W;
+        const double a = rows[r * stride + e];
+        if (f + 1 < total) {
+            const double b = (e + 1 < W) ? rows[r * stride + e + 1] : rows[(r + 1) * stride];
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            v2d w = {a, b};
+            __builtin_nontemporal_store(w, reinterpret_cast<v2d *>(dst + f));
+        } else {
+            __builtin_nontemporal_store(a, dst + f);
+        }
+    }
+}
+#endif
+
 // un-coalesced alternative (A/B baseline): every lane stores its own row straight from LDS
 RTB_HD void kin_store_own(const double *rows, int stride, int W, bool live, double *__restrict__ dst_row,
                           int lane)

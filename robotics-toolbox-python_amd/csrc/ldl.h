@@ -8,11 +8,10 @@
 
 namespace rtbhip {
 
-// A: lower triangle read (destroyed: holds L afterwards); g: right-hand side (destroyed); x: solution.
+// A: lower triangle read; on return holds L (unit diagonal implied) with 1/d_j in dinv and d_j in dval.
 template <int N>
-RTB_HD void ldl_solve(double (&A)[N][N], double (&g)[N], double (&x)[N])
+RTB_HD void ldl_factor(double (&A)[N][N], double (&dval)[N], double (&dinv)[N])
 {
-    double dval[N], dinv[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         double d = A[j][j];
@@ -28,7 +27,12 @@ RTB_HD void ldl_solve(double (&A)[N][N], double (&g)[N], double (&x)[N])
             A[i][j] = v * dinv[j];
         }
     }
-    // forward: L y = g ; diagonal ; backward: L^T x = z
+}
+
+// forward: L y = g ; diagonal ; backward: L^T x = z   (g destroyed)
+template <int N>
+RTB_HD void ldl_backsolve(const double (&A)[N][N], const double (&dinv)[N], double (&g)[N], double (&x)[N])
+{
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         double v = g[i];
@@ -45,6 +49,48 @@ RTB_HD void ldl_solve(double (&A)[N][N], double (&g)[N], double (&x)[N])
         for (int k = i + 1; k < N; ++k) v -= A[k][i] * x[k];
         x[i] = v;
     }
+}
+
+// A: lower triangle read (destroyed: holds L afterwards); g: right-hand side (destroyed); x: solution.
+template <int N>
+RTB_HD void ldl_solve(double (&A)[N][N], double (&g)[N], double (&x)[N])
+{
+    double dval[N], dinv[N];
+    ldl_factor<N>(A, dval, dinv);
+    ldl_backsolve<N>(A, dinv, g, x);
+}
+
+// Determinant of a general N x N matrix by LU with partial pivoting (what numpy.linalg.det does through
+// LAPACK getrf).  The per-lane row exchange is a compare-and-swap chain on statically indexed
+// registers: after processing rows k+1..N-1 the largest |a[i][k]| sits in row k.  a is destroyed.
+template <int N>
+RTB_HD double det_lu(double (&a)[N][N])
+{
+    double det = 1.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) {
+            const bool sw = fabs(a[i][k]) > fabs(a[k][k]);
+#pragma unroll
+            for (int c = k; c < N; ++c) {
+                const double u = a[k][c], v = a[i][c];
+                a[k][c] = sw ? v : u;
+                a[i][c] = sw ? u : v;
+            }
+            det = sw ? -det : det;
+        }
+        const double piv = a[k][k];
+        det *= piv;
+        const double inv = piv != 0.0 ? 1.0 / piv : 0.0;
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) {
+            const double f = a[i][k] * inv;
+#pragma unroll
+            for (int c = k + 1; c < N; ++c) a[i][c] -= f * a[k][c];
+        }
+    }
+    return det;
 }
 
 }  // namespace rtbhip

@@ -93,6 +93,9 @@ struct Affine { double v[12]; int used; };  // row-major 3x4, host-side small pa
 int launch_kin(const Chain *c, const DevChain &dc, const double *q, int64_t N, const Affine &base,
                const Affine &tool, int frame, double *T, double *J, double *H, hipStream_t s);
 
+int launch_kin_diff(const Chain *c, const DevChain &dc, int mode, int axes, const double *q, const double *qd, int64_t N,
+                    const Affine &tool, int frame, double *out, hipStream_t s);
+
 struct FleetEntry {   // device-visible descriptor of one chain of a fleet launch
     DevChain dc;
     const double *q;

@@ -358,6 +358,68 @@ class ETS:
     def hessiane(self, q=None, Je=None, tool=None):
         return self._hess(q, tool, 1)
 
+    # ------------------------------------------------------------ differential-kinematics consumers
+    def jacob0_dot(self, q, qd, J0=None, representation=None, tool=None):
+        """d/dt J0 = hessian0(q) . qd: (6,n) or (N,6,n) (reference Robot.jacob0_dot robot/Robot.py:964-1098)."""
+        return self._jdot(q, qd, representation, tool, 0)
+
+    def jacobe_dot(self, q, qd, tool=None):
+        return self._jdot(q, qd, None, tool, 1)
+
+    def _jdot(self, q, qd, representation, tool, frame):
+        if representation is not None:
+            raise NotImplementedError("analytical-Jacobian rates use a numerical Hessian in the reference and stay there")
+        q2, single, tm = self._shape_q(q)
+        qd2, _, tm2 = self._shape_q(qd)
+        if tm != tm2 or tuple(q2.shape) != tuple(qd2.shape):
+            raise ValueError("q and qd must have the same shape and live in the same memory")
+        N = q2.shape[0]
+        Jd = self._out((N, 6, self.n), q2, tm)
+        check(lib().rtbhip_jacob_dot(self._handle(), self._ptr(q2, tm), self._ptr(qd2, tm), N, host_ptr(small(tool, 16)), frame,
+                                     self._ptr(Jd, tm), MEM_DEVICE if tm else MEM_HOST, self._stream(tm)))
+        return Jd[0] if single else Jd
+
+    @staticmethod
+    def _axes_mask(axes):
+        if isinstance(axes, str):
+            if axes.startswith("all"):
+                return 63
+            if axes.startswith("trans"):
+                return 7
+            if axes.startswith("rot"):
+                return 56
+            raise ValueError("axes must be all, trans or rot")          # robot/ETS.py:1764
+        ax = [bool(a) for a in axes]
+        if len(ax) != 6:
+            raise ValueError("axes must be all, trans, rot or a list of 6 booleans")
+        return sum(1 << i for i, a in enumerate(ax) if a)
+
+    def manipulability(self, q, method="yoshikawa", axes="all", tool=None):
+        """Yoshikawa manipulability: scalar or (N,) (reference ETS.manipulability robot/ETS.py:1687-1819).
+        'invcondition' / 'minsingular' need an SVD per configuration and are not offered on the GPU."""
+        if method != "yoshikawa":
+            if method in ("invcondition", "minsingular"):
+                raise NotImplementedError("method %r is not implemented in the GPU backend" % method)
+            raise ValueError("Invalid method chosen")
+        mask = self._axes_mask(axes)
+        q2, single, tm = self._shape_q(q)
+        N = q2.shape[0]
+        m = self._out((N,), q2, tm)
+        check(lib().rtbhip_manipulability(self._handle(), self._ptr(q2, tm), N, host_ptr(small(tool, 16)), mask,
+                                          self._ptr(m, tm), MEM_DEVICE if tm else MEM_HOST, self._stream(tm)))
+        return float(m[0]) if single else m
+
+    def jacobm(self, q, axes="all", tool=None):
+        """Manipulability Jacobian: (n,1) for one q as the reference returns it (robot/ETS.py:1628-1685),
+        (N,n) for a trajectory."""
+        mask = self._axes_mask(axes)
+        q2, single, tm = self._shape_q(q)
+        N = q2.shape[0]
+        Jm = self._out((N, self.n), q2, tm)
+        check(lib().rtbhip_jacobm(self._handle(), self._ptr(q2, tm), N, host_ptr(small(tool, 16)), mask,
+                                  self._ptr(Jm, tm), MEM_DEVICE if tm else MEM_HOST, self._stream(tm)))
+        return Jm[0].reshape(self.n, 1) if single else Jm
+
     # ------------------------------------------------------------ inverse kinematics
     def _ik(self, Tep, q0, ilimit, slimit, tol, mask, joint_limits, k, method, flavour, seed):
         n = self.n

@@ -46,6 +46,11 @@ class ERobot:
     def hessiane(self, q=None, end=None, start=None, Je=None, tool=None):
         return self._ets.hessiane(q, Je=Je, tool=self.tool if tool is None else tool)
 
+    def jacob0_dot(self, q, qd, **kw): return self._ets.jacob0_dot(q, qd, tool=self.tool, **kw)
+    def manipulability(self, q, method="yoshikawa", axes="all", **kw):
+        return self._ets.manipulability(q, method=method, axes=axes, tool=self.tool)
+    def jacobm(self, q, axes="all", **kw): return self._ets.jacobm(q, axes=axes, tool=self.tool)
+
     def ik_LM(self, Tep, **kw): return self._ets.ik_LM(Tep, **kw)
     def ikine_LM(self, Tep, **kw): return self._ets.ikine_LM(Tep, **kw)
 

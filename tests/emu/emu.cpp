@@ -7,6 +7,7 @@
 #include "../../robotics-toolbox-python_amd/csrc/ik_device.h"
 #include "../../robotics-toolbox-python_amd/csrc/rne_device.h"
 #include "../../robotics-toolbox-python_amd/csrc/dyn_device.h"
+#include "../../robotics-toolbox-python_amd/csrc/diff_device.h"
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
@@ -391,6 +392,51 @@ extern "C" int emu_dyn(rtbhip_dyn_t h, int mode, const double *q, const double *
     case 6: dyn_nj<6>(d, mode, q, qd, tq, N, g, out); break;
     case 7: dyn_nj<7>(d, mode, q, qd, tq, N, g, out); break;
     default: dyn_nj<8>(d, mode, q, qd, tq, N, g, out); break;
+    }
+    return 0;
+}
+
+// differential-kinematics consumers: diff_device.h on the register-resident Jacobian of kin_reg.h
+template <int NJ>
+static void diff_run(const KinParams &kp, const DevChain &cv, int mode, int axes, const double *q, const double *qd, int64_t N, double *out)
+{
+    for (int64_t s = 0; s < N; ++s) {
+        Pose P;
+        double jac[6 * NJ];
+        reg_compute<NJ, true>(kp, cv, q, s, P, jac);
+        if (mode == 0) {
+            double v[NJ], jd[6 * NJ];
+            for (int j = 0; j < NJ; ++j) v[j] = qd[s * kp.qw + jm_jq(cv.jmeta[j])];
+            jacob_dot<NJ>(jac, v, jd);
+            for (int k = 0; k < 6 * NJ; ++k) out[s * 6 * NJ + k] = jd[k];
+        } else if (mode == 1) {
+            out[s] = manipulability_yoshikawa<NJ>(jac, axes);
+        } else {
+            double jm[NJ];
+            jacobm<NJ>(jac, axes, jm);
+            for (int k = 0; k < NJ; ++k) out[s * NJ + k] = jm[k];
+        }
+    }
+}
+extern "C" int emu_diff(rtbhip_chain_t h, int mode, int axes, const double *q, const double *qd, int64_t N,
+                        const double *tool16, int frame, double *out)
+{
+    Chain *c = chain_from_handle(h);
+    if (!c || c->n < 1 || c->n > kRegMaxJoints) return -1;
+    KinParams kp;
+    kp.n = c->n; kp.qw = c->q_width; kp.stride = kin_stride(c->n); kp.frame = frame; kp.N = N; kp.pad = 0; kp.has_base = 0;
+    Affine t = aff16(tool16);
+    chain_tail(c, t, kp.tail);
+    const DevChain cv = chain_host_view(c);
+    switch (c->n) {
+    case 1: diff_run<1>(kp, cv, mode, axes, q, qd, N, out); break;
+    case 2: diff_run<2>(kp, cv, mode, axes, q, qd, N, out); break;
+    case 3: diff_run<3>(kp, cv, mode, axes, q, qd, N, out); break;
+    case 4: diff_run<4>(kp, cv, mode, axes, q, qd, N, out); break;
+    case 5: diff_run<5>(kp, cv, mode, axes, q, qd, N, out); break;
+    case 6: diff_run<6>(kp, cv, mode, axes, q, qd, N, out); break;
+    case 7: diff_run<7>(kp, cv, mode, axes, q, qd, N, out); break;
+    default: diff_run<8>(kp, cv, mode, axes, q, qd, N, out); break;
     }
     return 0;
 }

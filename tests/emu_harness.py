@@ -45,6 +45,7 @@ def lib():
         _lib.rtbhip_dyn_create.argtypes = [_vp, _i32, _i32, C.POINTER(_u64)]
         _lib.emu_kin.argtypes = [_u64, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _i32]
         _lib.emu_rne.argtypes = [_u64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32]
+        _lib.emu_diff.argtypes = [_u64, _i32, _i32, _vp, _vp, _i64, _vp, _i32, _vp]
         _lib.emu_dyn.argtypes = [_u64, _i32, _vp, _vp, _vp, _i64, _vp, _vp]
         _lib.emu_kin_reg.argtypes = [_u64, _vp, _i64, _vp, _vp, _i32, _vp, _vp]
         _lib.emu_sincos.argtypes = [_vp, _i64, _vp, _vp, _i32]
@@ -117,6 +118,19 @@ def rne(L24, mdh, q, qd, qdd, grav_c, fext=None, force_generic=False):
     rc = lib().emu_rne(h.value, _p(q), _p(qd), _p(qdd), q.shape[0], _p(g), _p(f), _p(tau), int(force_generic))
     assert rc == 0
     return tau
+
+
+def diff(ets, mode, q, qd=None, axes=63, tool=None, frame=0):
+    """mode 0 jacob_dot (N,6,n), 1 manipulability (N,), 2 jacobm (N,n): diff_device.h on the CPU."""
+    h = chain_handle(ets)
+    n = ets.n
+    q = np.ascontiguousarray(np.asarray(q, dtype=np.float64).reshape(-1, ets.q_width))
+    qd = None if qd is None else np.ascontiguousarray(np.asarray(qd, dtype=np.float64).reshape(-1, ets.q_width))
+    N = q.shape[0]
+    out = np.full({0: (N, 6, n), 1: (N,), 2: (N, n)}[mode], np.nan)
+    t = None if tool is None else np.ascontiguousarray(tool, dtype=np.float64)
+    assert lib().emu_diff(h, mode, axes, _p(q), _p(qd), N, _p(t), frame, _p(out)) == 0
+    return out
 
 
 def dyn(L24, mdh, mode, q, qd=None, torque=None, grav_c=None):

@@ -69,6 +69,9 @@ def main():
     add("D_puma_gravload", "test_DHRobot.py", "test_gravload", "taur")
     add("D_puma_itorque_qdd", "test_DHRobot.py", "test_itorque", "qdd")
     add("D_puma_itorque", "test_DHRobot.py", "test_itorque", "tauir")
+    # manipulability / jacobm goldens
+    add("K_panda_jacobm_q", "test_ERobot.py", "test_jacobm", "q1")
+    add("K_panda_jacobm", "test_ERobot.py", "test_jacobm", "ans")
     # G11 -- DH robots
     add("G11_dh_rprp_fkine", "test_DHRobot.py", "test_fkine", "T1")
     add("G11_dh_panda_fkine", "test_DHRobot.py", "test_fkine_panda", "T")

@@ -1,0 +1,130 @@
+"""jacob0_dot / manipulability / jacobm computed from the register-resident Jacobian.
+Pins: reference tests/test_ERobot.py:28-51 (jacobm literal, ETS Panda), tests/test_ETS.py:4303-4334
+(manipulability of the URDF Panda / Puma to 4 decimals), tests/test_DHRobot.py:1246-1262 (jacob0_dot ==
+numerical Hessian . qd)."""
+import numpy as np
+import numpy.testing as nt
+import pytest
+
+import rtbhip
+from rtbhip import urdf
+from oracle import oracle, chains
+from helpers import literals, chain_from_ets, product_ets, mixed_spec
+
+LIT = literals()
+
+
+def _cases():
+    panda = rtbhip.models.Panda().ets()
+    puma = rtbhip.models.DH.Puma560().ets()
+    ur5 = urdf.load("UR5").ets()
+    return [("panda", panda, chains.panda_ets()), ("puma", puma, chain_from_ets(puma)), ("ur5", ur5, chain_from_ets(ur5))]
+
+
+def test_oracle_pins():
+    ch = chains.panda_ets()
+    q1 = LIT["K_panda_jacobm_q"]
+    nt.assert_array_almost_equal(oracle.jacobm(ch, q1)[0].reshape(7, 1), LIT["K_panda_jacobm"])
+    # jacob0_dot == (numerical Hessian of jacob0) . qd  (reference tests/test_jacob.py:73-81)
+    qd = np.array([0.1, -0.2, 0.3, -0.4, 0.5, -0.6, 0.7])
+    h = 1e-6
+    Jd = np.zeros((6, 7))
+    for i in range(7):
+        d = np.zeros(7); d[i] = h
+        Jd += (oracle.jacob0(ch, q1 + d)[0] - oracle.jacob0(ch, q1 - d)[0]) / (2 * h) * qd[i]
+    nt.assert_array_almost_equal(oracle.jacob_dot(ch, q1, qd)[0], Jd, decimal=6)
+
+
+def test_manipulability_goldens_reference_models():
+    """reference tests/test_ETS.py:4303-4334: URDF Panda at qr, URDF Puma560 at qn."""
+    import emu_harness as emu
+    p = urdf.load("Panda")
+    qr = np.array([0, -0.3, 0, -2.2, 0, 2.0, np.pi / 4])
+    for axes, mask, want in (("all", 63, 0.0837), ("trans", 7, 0.1438), ("rot", 56, 2.7455)):
+        nt.assert_almost_equal(emu.diff(p.ets(), 1, qr, axes=mask, tool=p.tool)[0], want, decimal=4)
+        nt.assert_almost_equal(oracle.manipulability(chain_from_ets(p.ets()), qr, axes, tool=p.tool)[0], want, decimal=4)
+    pu = urdf.load("Puma560")
+    qn = np.array([0, np.pi / 4, np.pi, 0, np.pi / 4, 0])
+    for mask, want in ((63, 0.0805), (7, 0.1354), (56, 2.44949)):
+        nt.assert_almost_equal(emu.diff(pu.ets(), 1, qn, axes=mask)[0], want, decimal=4)
+
+
+@pytest.mark.parametrize("name", ["panda", "puma", "ur5", "mixed"])
+def test_emu_vs_oracle(name):
+    import emu_harness as emu
+    if name == "mixed":
+        spec = mixed_spec()
+        e, ch = product_ets(spec), chains.Chain(spec)
+    else:
+        _, e, ch = [c for c in _cases() if c[0] == name][0]
+    rng = np.random.default_rng(3)
+    q, qd = rng.uniform(-2, 2, (20, e.n)), rng.normal(size=(20, e.n))
+    for frame in (0, 1):
+        nt.assert_allclose(emu.diff(e, 0, q, qd, frame=frame), oracle.jacob_dot(ch, q, qd, frame=frame), atol=1e-11)
+    for axes, mask in (("all", 63), ("trans", 7), ("rot", 56), ([True, False, True, True, False, True], 45)):
+        m, ref = emu.diff(e, 1, q, axes=mask), oracle.manipulability(ch, q, axes)
+        nt.assert_allclose(m, ref, rtol=1e-9, atol=1e-12)
+    if e.n >= 6:
+        for axes, mask in (("all", 63), ("trans", 7), ("rot", 56)):
+            jm, ref = emu.diff(e, 2, q, axes=mask), oracle.jacobm(ch, q, axes)
+            nt.assert_allclose(jm, ref, rtol=1e-7, atol=1e-9 * max(1.0, np.abs(ref).max()))
+    nt.assert_array_almost_equal(emu.diff(rtbhip.models.Panda().ets(), 2, LIT["K_panda_jacobm_q"])[0].reshape(7, 1),
+                                 LIT["K_panda_jacobm"])
+
+
+@pytest.mark.gpu
+def test_gpu_goldens_shapes_errors():
+    panda = rtbhip.models.Panda()
+    q1 = LIT["K_panda_jacobm_q"]
+    for q in (q1, list(q1), q1.reshape(1, 7), q1.reshape(7, 1)):            # reference tests/test_ERobot.py:48-51
+        jm = panda.jacobm(q)
+        assert jm.shape == (7, 1)
+        nt.assert_array_almost_equal(jm, LIT["K_panda_jacobm"])
+    p = urdf.load("Panda")
+    qr = np.array([0, -0.3, 0, -2.2, 0, 2.0, np.pi / 4])
+    nt.assert_almost_equal(p.ets().manipulability(qr, tool=p.tool), 0.0837, decimal=4)
+    nt.assert_almost_equal(p.ets().manipulability(qr, axes="trans", tool=p.tool), 0.1438, decimal=4)
+    nt.assert_almost_equal(p.ets().manipulability(qr, axes="rot", tool=p.tool), 2.7455, decimal=4)
+    m2 = p.ets().manipulability(np.c_[qr, qr].T, tool=p.tool)
+    assert m2.shape == (2,)
+    with pytest.raises(ValueError):
+        panda.manipulability(qr, axes="abcdef")
+    with pytest.raises(ValueError):
+        panda.manipulability(qr, method="nonsense")
+    with pytest.raises(NotImplementedError):
+        panda.manipulability(qr, method="minsingular")
+    nine = rtbhip.DHRobot([rtbhip.RevoluteDH(a=0.1) for _ in range(9)]).ets()
+    with pytest.raises(rtbhip.RtbHipError):
+        nine.manipulability(np.zeros(9))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [1, 65, 4097])
+def test_gpu_vs_oracle(N):
+    import torch
+    for name, e, ch in _cases():
+        rng = np.random.default_rng(N)
+        q, qd = rng.uniform(-2, 2, (N, e.n)), rng.normal(size=(N, e.n))
+        k = min(N, 300)
+        Jd = e.jacob0_dot(q, qd).reshape(N, 6, e.n)
+        nt.assert_allclose(Jd[:k], oracle.jacob_dot(ch, q[:k], qd[:k]), atol=1e-10)
+        nt.assert_allclose(e.jacobe_dot(q, qd).reshape(N, 6, e.n)[:k], oracle.jacob_dot(ch, q[:k], qd[:k], frame=1), atol=1e-10)
+        # J is linear in qd and equals H . qd of the batched Hessian kernel
+        H = e.hessian0(q).reshape(N, e.n, 6, e.n)
+        nt.assert_allclose(Jd, np.einsum("njrc,nj->nrc", H, qd), atol=1e-11)
+        for axes in ("all", "trans", "rot"):
+            m = np.atleast_1d(e.manipulability(q, axes=axes))
+            nt.assert_allclose(m[:k], oracle.manipulability(ch, q[:k], axes), rtol=1e-9, atol=1e-12)
+            jm = e.jacobm(q, axes=axes).reshape(N, e.n)
+            ref = oracle.jacobm(ch, q[:k], axes)
+            nt.assert_allclose(jm[:k], ref, rtol=1e-7, atol=1e-9 * max(1.0, np.abs(ref).max()))
+        # jacobm is the gradient of the manipulability (central differences on a few rows)
+        h = 1e-6
+        for i in range(min(N, 3)):
+            g = np.array([(e.manipulability(q[i] + h * np.eye(e.n)[c]) - e.manipulability(q[i] - h * np.eye(e.n)[c])) / (2 * h)
+                          for c in range(e.n)])
+            nt.assert_allclose(e.jacobm(q[i]).reshape(-1), g, atol=2e-6 * max(1.0, np.abs(g).max()))
+        qt, qdt = torch.from_numpy(q).cuda(), torch.from_numpy(qd).cuda()
+        nt.assert_array_equal(e.jacob0_dot(qt, qdt).cpu().numpy().reshape(N, 6, e.n), Jd)
+        nt.assert_array_equal(np.atleast_1d(e.manipulability(qt).cpu().numpy() if N > 1 else e.manipulability(qt)),
+                              np.atleast_1d(e.manipulability(q)))
