@@ -31,7 +31,7 @@ def ev_time(fn, steps, warmup):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--what", default="rne,ik,fleet,dyn")
+    ap.add_argument("--what", default="rne,ik,fleet,dyn,tree")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--n-rne", type=int, default=1250000)
     ap.add_argument("--n-ik", type=int, default=100000)
@@ -107,6 +107,20 @@ def main():
                                             "sample": "Dynamics.inertia's loop (7 frne.frne calls per configuration) over the first %d" % n,
                                             "max_abs_err_gpu_vs_cpu": float(np.abs(g - Mc).max())}
             print(json.dumps(line), flush=True)
+
+    if "tree" in what:
+        # Robot.rne of a URDF arm (UR5, 6 link groups, <inertial> masses) through k_tree_rne
+        from rtbhip import urdf
+        N = args.n_dyn
+        er = urdf.load("UR5").erobot()
+        rng = np.random.default_rng(7)
+        q, qd, qdd = (torch.from_numpy(x).cuda() for x in (rng.uniform(-3, 3, (N, er.n)), rng.normal(size=(N, er.n)), rng.normal(size=(N, er.n))))
+        avg, best = ev_time(lambda: er.rne(q, qd, qdd), args.steps, 3)
+        byts = 32 * er.n
+        print(json.dumps({"metric": "triples/sec (URDF UR5 Robot.rne, %d link groups)" % er.n, "value": N / (avg * 1e-3), "unit": "triples/s",
+                          "n": N, "kernel_avg_ms": avg, "kernel_min_ms": best,
+                          "roofline": {"bound": "fp64-valu", "achieved": byts * N / (avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                       "frac": byts * N / (avg * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": byts * N}}), flush=True)
 
     if "ik" in what:
         N = args.n_ik

@@ -152,6 +152,29 @@ int rtbhip_coriolis(rtbhip_dyn_t dyn, const double *q, const double *qd, int64_t
 int rtbhip_accel(rtbhip_dyn_t dyn, const double *q, const double *qd, const double *torque, int64_t N,
                  const double *grav3, double *qdd, int32_t mem, void *stream);
 
+/* Robot.rne for ETS robots (robot/Robot.py:1704-1903): inverse dynamics over a tree of LINK
+ * GROUPS -- every joint link together with the static links that precede it in link order (:1777-1789).
+ * One rtbhip_tree_group per group, in the reference's order (parents before children):
+ *   parent  index of the group holding the first member link's parent link, -1 for the base
+ *   T       the group's constant transform, row-major 4x4: product of the member links' constant parts
+ *           (static links' A(), then the joint link's Ts, Link.A robot/Link.py:1642-1651)
+ *   kind    joint axis 0..5 (Rx,Ry,Rz,tx,ty,tz); flip as ET.flip; jindex = column of q / qd / qdd
+ *   m,h,I   the group's spatial inertia about the group-frame origin: mass, first moment sum(m r), rotational
+ *           inertia (xx,yy,zz,xy,xz,yz).  The reference's own value is the plain sum of the member links'
+ *           SpatialInertia(m, r) (:1793-1800), i.e. I = sum m (|r|^2 1 - r r^T) and no inertia tensor.
+ * rtbhip_tree_rne: q,qd,qdd (N,ng); gravity3 = the robot's gravity vector (e.g. 0,0,-9.81; the base is
+ * accelerated by its negative, :1804-1807); tau (N,ng), column j = group j as the reference's Q[:, j]. */
+typedef struct rtbhip_tree_group {
+    int32_t parent, kind, flip, jindex;
+    double T[16];
+    double m, h[3], I[6];
+} rtbhip_tree_group;
+typedef uint64_t rtbhip_tree_t;
+int rtbhip_tree_create(const rtbhip_tree_group *groups, int32_t ng, rtbhip_tree_t *tree);
+int rtbhip_tree_destroy(rtbhip_tree_t tree);
+int rtbhip_tree_rne(rtbhip_tree_t tree, const double *q, const double *qd, const double *qdd, int64_t N,
+                    const double *gravity3, double *tau, int32_t mem, void *stream);
+
 /* Mixed fleet (BASELINE config 5): n_chains independent chains, each with its own batch; one
  * launch walks all of them (block -> chain map).  q[c] is (N[c], q_width_c), T[c] (N[c],4,4),
  * J[c] (N[c],6,n_c).  The pointer tables themselves are HOST arrays. */

@@ -2,6 +2,7 @@
 // Argument checking, handle registry, lazy per-device upload of the chain / link tables, and the
 // host-memory convenience path (stage -> launch -> copy back).  No arithmetic lives here.
 #include "rtbhip_internal.h"
+#include "tree_device.h"
 #include <atomic>
 #include <cstring>
 #include <memory>
@@ -29,6 +30,7 @@ void note_launch(int grid, int block, int lds)
 static std::mutex g_reg_mu;
 static std::unordered_map<uint64_t, std::unique_ptr<Chain>> g_chains;
 static std::unordered_map<uint64_t, std::unique_ptr<Dyn>> g_dyns;
+static std::unordered_map<uint64_t, std::unique_ptr<Tree>> g_trees;
 static std::atomic<uint64_t> g_next{1};
 
 Chain *chain_from_handle(rtbhip_chain_t h)
@@ -42,6 +44,13 @@ Dyn *dyn_from_handle(rtbhip_dyn_t h)
     std::lock_guard<std::mutex> lk(g_reg_mu);
     auto it = g_dyns.find(h);
     return it == g_dyns.end() ? nullptr : it->second.get();
+}
+
+Tree *tree_from_handle(rtbhip_tree_t h)
+{
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    auto it = g_trees.find(h);
+    return it == g_trees.end() ? nullptr : it->second.get();
 }
 
 static DevChain view_of(const Chain *c, const void *base)
@@ -101,6 +110,23 @@ int dyn_device_links(Dyn *d, const DevLink **out)
         RTB_HIP(hipMemcpy(p, d->links.data(), d->links.size() * sizeof(DevLink), hipMemcpyHostToDevice));
         d->dev_links[dev] = p;
         it = d->dev_links.find(dev);
+    }
+    *out = it->second;
+    return RTBHIP_OK;
+}
+
+int tree_device_groups(Tree *t, const DevGroup **out)
+{
+    int dev = 0;
+    RTB_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(t->mu);
+    auto it = t->dev_groups.find(dev);
+    if (it == t->dev_groups.end()) {
+        DevGroup *p = nullptr;
+        RTB_HIP(hipMalloc((void **)&p, t->groups.size() * sizeof(DevGroup)));
+        RTB_HIP(hipMemcpy(p, t->groups.data(), t->groups.size() * sizeof(DevGroup), hipMemcpyHostToDevice));
+        t->dev_groups[dev] = p;
+        it = t->dev_groups.find(dev);
     }
     *out = it->second;
     return RTBHIP_OK;
@@ -448,6 +474,59 @@ int rtbhip_rne(rtbhip_dyn_t dyn, const double *q, const double *qd, const double
     RTB_TRY(st.out(bytes, &dtau));
     RTB_TRY(launch_rne(d, links, (const double *)dq, (const double *)dqd, (const double *)dqdd, N, grav3, fext6,
                        (double *)dtau, nullptr));
+    RTB_HIP(hipDeviceSynchronize());
+    RTB_TRY(fetch(tau, dtau, bytes));
+    return RTBHIP_OK;
+}
+
+int rtbhip_tree_create(const rtbhip_tree_group *groups, int32_t ng, rtbhip_tree_t *tree)
+{
+    if (!tree) { set_error("tree_create: NULL handle pointer"); return RTBHIP_EINVAL; }
+    std::unique_ptr<Tree> t(new Tree());
+    RTB_TRY(compile_tree(groups, ng, t.get()));
+    const uint64_t h = g_next.fetch_add(1);
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    g_trees[h] = std::move(t);
+    *tree = h;
+    return RTBHIP_OK;
+}
+
+int rtbhip_tree_destroy(rtbhip_tree_t tree)
+{
+    std::unique_ptr<Tree> t;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        auto it = g_trees.find(tree);
+        if (it == g_trees.end()) { set_error("tree_destroy: unknown handle"); return RTBHIP_EINVAL; }
+        t = std::move(it->second);
+        g_trees.erase(it);
+    }
+    for (auto &kv : t->dev_groups) (void)hipFree(kv.second);
+    return RTBHIP_OK;
+}
+
+int rtbhip_tree_rne(rtbhip_tree_t tree, const double *q, const double *qd, const double *qdd, int64_t N,
+                    const double *gravity3, double *tau, int32_t mem, void *stream)
+{
+    Tree *t = tree_from_handle(tree);
+    if (!t) { set_error("tree_rne: unknown tree handle"); return RTBHIP_EINVAL; }
+    RTB_TRY(check_batch("tree_rne", q, N, mem));
+    if (!gravity3) { set_error("tree_rne: NULL gravity"); return RTBHIP_EINVAL; }
+    if (N > 0 && !tau) { set_error("tree_rne: NULL tau"); return RTBHIP_EINVAL; }
+    if (N == 0) return RTBHIP_OK;
+    const DevGroup *groups = nullptr;
+    RTB_TRY(tree_device_groups(t, &groups));
+    if (mem == RTBHIP_MEM_DEVICE)
+        return launch_tree_rne(t, groups, q, qd, qdd, N, gravity3, tau, (hipStream_t)stream);
+    Staging st;
+    const size_t bytes = (size_t)N * t->n * 8;
+    void *dq, *dqd, *dqdd, *dtau;
+    RTB_TRY(st.in(q, bytes, &dq));
+    RTB_TRY(st.in(qd, bytes, &dqd));
+    RTB_TRY(st.in(qdd, bytes, &dqdd));
+    RTB_TRY(st.out(bytes, &dtau));
+    RTB_TRY(launch_tree_rne(t, groups, (const double *)dq, (const double *)dqd, (const double *)dqdd, N, gravity3,
+                            (double *)dtau, nullptr));
     RTB_HIP(hipDeviceSynchronize());
     RTB_TRY(fetch(tau, dtau, bytes));
     return RTBHIP_OK;

@@ -67,6 +67,20 @@ struct Dyn {
     std::mutex mu;
 };
 
+// Host-side dynamics tree behind an rtbhip_tree_t handle (tree.cpp, tree_device.h).
+struct DevGroup;
+struct Tree {
+    std::vector<DevGroup> groups;
+    int n = 0, nslots = 0;
+    std::map<int, DevGroup *> dev_groups;
+    std::mutex mu;
+};
+int compile_tree(const rtbhip_tree_group *groups, int ng, Tree *out);
+Tree *tree_from_handle(rtbhip_tree_t h);
+int tree_device_groups(Tree *t, const DevGroup **out);
+int launch_tree_rne(const Tree *t, const DevGroup *groups, const double *q, const double *qd, const double *qdd, int64_t N,
+                    const double *grav3, double *tau, hipStream_t s);
+
 // ---------------------------------------------------------------- error plumbing
 void set_error(const std::string &msg);
 int hip_fail(hipError_t e, const char *what);

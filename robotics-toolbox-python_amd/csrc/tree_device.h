@@ -1,0 +1,179 @@
+// tree_device.h -- per-lane recursive Newton-Euler for ETS robots (link trees with point... spatial
+// inertias), the device restatement of Robot.rne (reference robot/Robot.py:1704-1903).
+//
+// The reference walks "link groups" (every joint link together with the static links that precede it
+// in link order, :1777-1789) with spatialmath's 6-D spatial vectors: v, a per group from the parent
+// group's (:1853-1870), f = I a + v x* I v (:1872), then tau_j = s_j . f_j and f_parent += X^T f_j
+// backwards (:1875-1893).  Here one lane owns one (q, qd, qdd) sample and the 6-vectors are pairs of
+// 3-vectors in registers ([linear; angular], spatialmath's order); the group transform is the
+// canonical segment  C_j Z_j(q)  of chain.cpp (constant affine, then a rotation about / slide along
+// the local z axis), so  X_up  is "constant 3x3 transpose times vector, then a planar rotation".
+//
+// Tree support without per-group state arrays in LDS: groups are processed in the reference's
+// (topological) order; a group whose parent is not the immediately preceding group reads the parent's
+// (v, a) from a small LDS slot that the parent wrote, and in the backward pass adds its transformed
+// force into that slot instead of handing it on in registers.  A serial chain uses no slot at all.
+//
+// Reference quirks reproduced on purpose (the oracle restates them too): the group inertia is the plain
+// sum of the member links' SpatialInertia(m, r) -- no inertia tensor, no re-expression of a static
+// link's centre of mass in the joint frame (:1793-1800); a flipped joint negates the angle in the
+// transform but not the motion subspace (robot/ET.py:592-608 ignores `flip`); no friction, no motor
+// inertia; gravity enters as the base acceleration -g (:1804-1807).
+#pragma once
+#include "rne_device.h"
+
+namespace rtbhip {
+
+struct alignas(16) DevGroup {   // wave-uniform, read through the scalar cache
+    DevSeg C;                   // parent-group frame -> this group's joint frame before the joint motion
+    double M, h[3];             // mass and first moment (sum m r) in the group frame
+    double I[6];                // rotational inertia about the group-frame origin: xx, yy, zz, xy, xz, yz
+    int32_t parent;             // parent group (-1: attached to the base)
+    int32_t jmeta;              // bit 0 prismatic, bits 8..15 q column, bit 16 flip
+    int32_t save_slot;          // >= 0: this group's (v, a) and force accumulator live in that LDS slot
+    int32_t parent_slot;        // >= 0: parent != previous group -> parent state is read from that slot
+    int32_t out_col;            // column of tau (the reference's group order)
+    int32_t pad[3];
+};
+static_assert(sizeof(DevGroup) == 208, "DevGroup layout");
+
+constexpr int kTreeSlotDoubles = 18;   // v (6), a (6), force accumulator (6)
+
+RTB_HD V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+
+template <class G> RTB_HD V3 seg_rt(const G &g, V3 v)   // R_C^T v
+{
+    return v3(g.C.r[0] * v.x + g.C.r[3] * v.y + g.C.r[6] * v.z, g.C.r[1] * v.x + g.C.r[4] * v.y + g.C.r[7] * v.z,
+              g.C.r[2] * v.x + g.C.r[5] * v.y + g.C.r[8] * v.z);
+}
+template <class G> RTB_HD V3 seg_r(const G &g, V3 v)    // R_C v
+{
+    return v3(g.C.r[0] * v.x + g.C.r[1] * v.y + g.C.r[2] * v.z, g.C.r[3] * v.x + g.C.r[4] * v.y + g.C.r[5] * v.z,
+              g.C.r[6] * v.x + g.C.r[7] * v.y + g.C.r[8] * v.z);
+}
+RTB_HD V3 rz_t(double s, double c, V3 v) { return v3(c * v.x + s * v.y, c * v.y - s * v.x, v.z); }   // Rz(theta)^T v
+RTB_HD V3 rz(double s, double c, V3 v) { return v3(c * v.x - s * v.y, s * v.x + c * v.y, v.z); }     // Rz(theta) v
+template <class G> RTB_HD V3 inertia_rot(const G &g, V3 w)   // I_bar w
+{
+    return v3(g.I[0] * w.x + g.I[3] * w.y + g.I[4] * w.z, g.I[3] * w.x + g.I[1] * w.y + g.I[5] * w.z,
+              g.I[4] * w.x + g.I[5] * w.y + g.I[2] * w.z);
+}
+
+// One sample.  groups: wave-uniform table; qin/qdin/qddin(column) -> double; tau(column, value);
+// slot(index) -> double& into this lane's kTreeSlotDoubles * nslots scratch (LDS on the GPU).
+template <int NG, class GroupsP, class InQ, class InQd, class InQdd, class Out, class Slot>
+RTB_HD void tree_rne_lane(GroupsP groups, int nslots, V3 gravity, InQ qin, InQd qdin, InQdd qddin, Out tau, Slot slot)
+{
+    double sn[NG], cs[NG];
+    V3 Fl[NG], Fa[NG];
+    for (int k = 0; k < nslots; ++k)
+        for (int e = 12; e < 18; ++e) slot(k * kTreeSlotDoubles + e) = 0.0;
+
+    // ---- joint angles -> sin/cos up front (branch-free reduction; one wave-wide library fallback)
+    {
+        bool big = false;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const auto &g = groups[j];
+            const double th = jm_prismatic(g.jmeta) ? 0.0 : qin(jm_jq(g.jmeta)) * (jm_flip(g.jmeta) ? -1.0 : 1.0);
+            sn[j] = th;
+            big = big || !(fabs(th) < kTrigFastLimit);
+        }
+        if (wave_any(big)) {
+#pragma unroll
+            for (int j = 0; j < NG; ++j) { double s, c; sincos(sn[j], &s, &c); sn[j] = s; cs[j] = c; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NG; ++j) { double s, c; sincos_reduced(sn[j], s, c); sn[j] = s; cs[j] = c; }
+        }
+        sched_fence();
+    }
+
+    // ---- forward recursion (Robot.py:1822-1872)
+    V3 vl = v3(0, 0, 0), va = v3(0, 0, 0), al = v3(0, 0, 0), aa = v3(0, 0, 0);   // state of the previous group
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const auto &g = groups[j];
+        const bool pris = jm_prismatic(g.jmeta) != 0;
+        const int col = jm_jq(g.jmeta);
+        const double qdj = qdin(col), qddj = qddin(col);
+        const double d = pris ? qin(col) * (jm_flip(g.jmeta) ? -1.0 : 1.0) : 0.0;
+        V3 pvl, pva, pal, paa;     // parent state
+        if (g.parent < 0) {
+            pvl = v3(0, 0, 0); pva = v3(0, 0, 0);
+            pal = v3(-gravity.x, -gravity.y, -gravity.z); paa = v3(0, 0, 0);     // a_grav = -SpatialAcceleration(gravity)
+        } else if (g.parent_slot >= 0) {
+            const int b = g.parent_slot * kTreeSlotDoubles;
+            pvl = v3(slot(b + 0), slot(b + 1), slot(b + 2)); pva = v3(slot(b + 3), slot(b + 4), slot(b + 5));
+            pal = v3(slot(b + 6), slot(b + 7), slot(b + 8)); paa = v3(slot(b + 9), slot(b + 10), slot(b + 11));
+        } else {
+            pvl = vl; pva = va; pal = al; paa = aa;
+        }
+        // frame j in the parent frame: R = R_C Rz(theta), p = t_C (+ R_C z d for a prismatic joint)
+        const V3 p = v3(g.C.t[0] + g.C.r[2] * d, g.C.t[1] + g.C.r[5] * d, g.C.t[2] + g.C.r[8] * d);
+        const double s = sn[j], c = cs[j];
+        // X_up on motion vectors: w' = R^T w ; v' = R^T (v + w x p)
+        va = rz_t(s, c, seg_rt(g, pva));
+        vl = rz_t(s, c, seg_rt(g, pvl + cross(pva, p)));
+        aa = rz_t(s, c, seg_rt(g, paa));
+        al = rz_t(s, c, seg_rt(g, pal + cross(paa, p)));
+        // joint velocity vJ = s_j qd (the motion subspace ignores `flip`, ET.py:592-608), then
+        // a += s_j qdd + v x vJ with the spatial motion cross product (Robot.py:1866-1870)
+        if (pris) {
+            vl.z += qdj;
+            al = al + cross(va, v3(0, 0, qdj));
+            al.z += qddj;
+        } else {
+            va.z += qdj;
+            al = al + cross(vl, v3(0, 0, qdj));
+            aa = aa + cross(va, v3(0, 0, qdj));
+            aa.z += qddj;
+        }
+        if (g.save_slot >= 0) {
+            const int b = g.save_slot * kTreeSlotDoubles;
+            slot(b + 0) = vl.x; slot(b + 1) = vl.y; slot(b + 2) = vl.z; slot(b + 3) = va.x; slot(b + 4) = va.y; slot(b + 5) = va.z;
+            slot(b + 6) = al.x; slot(b + 7) = al.y; slot(b + 8) = al.z; slot(b + 9) = aa.x; slot(b + 10) = aa.y; slot(b + 11) = aa.z;
+        }
+        // f = I a + v x* (I v) with I = [[M 1, -h x], [h x, I_bar]]  (Robot.py:1872)
+        const V3 h = v3(g.h[0], g.h[1], g.h[2]);
+        const V3 Ivl = g.M * vl + cross(va, h), Iva = cross(h, vl) + inertia_rot(g, va);
+        const V3 Ial = g.M * al + cross(aa, h), Iaa = cross(h, al) + inertia_rot(g, aa);
+        Fl[j] = Ial + cross(va, Ivl);
+        Fa[j] = (Iaa + cross(va, Iva)) + cross(vl, Ivl);
+        sched_fence();
+    }
+
+    // ---- backward recursion (Robot.py:1875-1893)
+    V3 cl = v3(0, 0, 0), ca = v3(0, 0, 0);   // force handed down by group j+1 when its parent is group j
+#pragma unroll
+    for (int jj = 0; jj < NG; ++jj) {
+        const int j = NG - 1 - jj;
+        const auto &g = groups[j];
+        const bool pris = jm_prismatic(g.jmeta) != 0;
+        V3 fl = Fl[j] + cl, fa = Fa[j] + ca;
+        if (g.save_slot >= 0) {
+            const int b = g.save_slot * kTreeSlotDoubles + 12;
+            fl = fl + v3(slot(b + 0), slot(b + 1), slot(b + 2));
+            fa = fa + v3(slot(b + 3), slot(b + 4), slot(b + 5));
+        }
+        tau(g.out_col, pris ? fl.z : fa.z);                    // Q[k, j] = sum(f[j] * s[j])
+        cl = v3(0, 0, 0); ca = v3(0, 0, 0);
+        if (g.parent >= 0) {
+            // f_parent += X_up^T f: lin' = R lin ; ang' = R ang + p x (R lin)
+            const double d = pris ? qin(jm_jq(g.jmeta)) * (jm_flip(g.jmeta) ? -1.0 : 1.0) : 0.0;
+            const V3 p = v3(g.C.t[0] + g.C.r[2] * d, g.C.t[1] + g.C.r[5] * d, g.C.t[2] + g.C.r[8] * d);
+            const V3 tl = seg_r(g, rz(sn[j], cs[j], fl));
+            const V3 ta = seg_r(g, rz(sn[j], cs[j], fa)) + cross(p, tl);
+            if (g.parent_slot >= 0) {
+                const int b = g.parent_slot * kTreeSlotDoubles + 12;
+                slot(b + 0) += tl.x; slot(b + 1) += tl.y; slot(b + 2) += tl.z;
+                slot(b + 3) += ta.x; slot(b + 4) += ta.y; slot(b + 5) += ta.z;
+            } else {
+                cl = tl; ca = ta;
+            }
+        }
+        sched_fence();
+    }
+}
+
+}  // namespace rtbhip

@@ -1,0 +1,109 @@
+// tree_kernels.hip -- gfx950 kernel for batched inverse dynamics of ETS robots (link trees): replaces the
+// Python triple loop of Robot.rne (reference robot/Robot.py:1809-1893: samples x groups, spatialmath
+// objects per step).  One lane = one (q, qd, qdd) sample, the per-lane recursion of tree_device.h with
+// the group count a template parameter (per-group force / sin / cos in named registers), one tile of 64
+// samples per single-wave workgroup, inputs and torques through the wave's LDS transposer so global
+// accesses are contiguous, branch-point state in per-lane LDS slots.
+// Bytes: 3*8n in + 8n out per sample; ~0.25 kflop per group: fp64-issue bound like k_rne.
+#include "tree_device.h"
+#include "kin_tile.h"
+
+namespace rtbhip {
+
+typedef const __attribute__((address_space(4))) DevGroup *ConstGroups;
+
+struct TreeParams {
+    int32_t n, nslots;
+    int64_t N;
+    double grav[3];
+};
+
+constexpr int kTreeMaxGroups = 12;
+
+template <int NG>
+__global__ __launch_bounds__(kWave, (NG <= 8 ? 2 : 1)) void k_tree_rne(TreeParams tp, const DevGroup *groups_g, const double *__restrict__ q,
+                                                      const double *__restrict__ qd, const double *__restrict__ qdd,
+                                                      double *__restrict__ tau)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    ConstGroups groups = (ConstGroups)groups_g;
+    const int lane = threadIdx.x;
+    constexpr int stride = (4 * NG) | 1;            // per lane: q | qd | qdd | tau
+    double *slots = lds + kWave * stride;                       // [slot * 18 + k][lane]
+    const int64_t cfg0 = (int64_t)blockIdx.x * kWave;
+    const int64_t left = tp.N - cfg0;
+    const int ncfg = left < kWave ? (int)left : kWave;
+    const int count = ncfg * NG;
+    {
+        double r0[NG], r1[NG], r2[NG];
+        const double *g0 = q + cfg0 * NG, *g1 = qd + cfg0 * NG, *g2 = qdd + cfg0 * NG;
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int f = lane + kWave * k;
+            const bool in = f < count;
+            r0[k] = in ? g0[f] : 0.0;
+            r1[k] = (in && qd) ? g1[f] : 0.0;
+            r2[k] = (in && qdd) ? g2[f] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int f = lane + kWave * k;
+            const int r = f / NG, c = f - r * NG;
+            double *dst = lds + r * stride + c;
+            dst[0] = r0[k]; dst[NG] = r1[k]; dst[2 * NG] = r2[k];
+        }
+    }
+    __syncthreads();
+    double *mine = lds + lane * stride;
+    if (lane < ncfg)
+        tree_rne_lane<NG>(groups, tp.nslots, v3(tp.grav[0], tp.grav[1], tp.grav[2]), [&](int c) { return mine[c]; },
+                          [&](int c) { return mine[NG + c]; }, [&](int c) { return mine[2 * NG + c]; },
+                          [&](int c, double v) { mine[3 * NG + c] = v; },
+                          [&](int i) -> double & { return slots[i * kWave + lane]; });
+    __syncthreads();
+    flush_run(lds + 3 * NG, stride, NG, ncfg, tau + cfg0 * NG, lane);
+}
+
+template <int NG>
+static void launch_ng(dim3 grid, size_t lds, hipStream_t s, const TreeParams &tp, const DevGroup *g, const double *q,
+                      const double *qd, const double *qdd, double *tau)
+{
+    auto k = k_tree_rne<NG>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, dim3(kWave), lds, s, tp, g, q, qd, qdd, tau);
+}
+
+int launch_tree_rne(const Tree *t, const DevGroup *groups, const double *q, const double *qd, const double *qdd, int64_t N,
+                    const double *grav3, double *tau, hipStream_t s)
+{
+    if (N == 0) return RTBHIP_OK;
+    if (t->n > kTreeMaxGroups) { set_error("tree_rne: this build handles up to 12 joints (link groups) on the device"); return RTBHIP_ELIMIT; }
+    const int64_t tiles = (N + kWave - 1) / kWave;
+    if (tiles > 0x7fffffff) { set_error("tree_rne: batch too large for one launch"); return RTBHIP_ELIMIT; }
+    TreeParams tp;
+    tp.n = t->n; tp.nslots = t->nslots; tp.N = N;
+    for (int i = 0; i < 3; i++) tp.grav[i] = grav3[i];
+    const size_t lds = (size_t)kWave * (((4 * t->n) | 1) + kTreeSlotDoubles * t->nslots) * sizeof(double);
+    if (lds > 160 * 1024) { set_error("tree_rne: tree needs more LDS than a CU has"); return RTBHIP_ELIMIT; }
+    dim3 grid((unsigned)tiles);
+    switch (t->n) {
+    case 1: launch_ng<1>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
+    case 2: launch_ng<2>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
+    case 3: launch_ng<3>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
+    case 4: launch_ng<4>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
+    case 5: launch_ng<5>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
+    case 6: launch_ng<6>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
+    case 7: launch_ng<7>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
+    case 8: launch_ng<8>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
+    case 9: launch_ng<9>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
+    case 10: launch_ng<10>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
+    case 11: launch_ng<11>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
+    default: launch_ng<12>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
+    }
+    note_launch((int)grid.x, kWave, (int)lds);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "k_tree_rne launch");
+    return RTBHIP_OK;
+}
+
+}  // namespace rtbhip

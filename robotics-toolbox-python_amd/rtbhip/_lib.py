@@ -26,6 +26,11 @@ class rtbhip_et(C.Structure):
                 ("reserved", C.c_int32), ("T", C.c_double * 16)]
 
 
+class rtbhip_tree_group(C.Structure):
+    _fields_ = [("parent", C.c_int32), ("kind", C.c_int32), ("flip", C.c_int32), ("jindex", C.c_int32),
+                ("T", C.c_double * 16), ("m", C.c_double), ("h", C.c_double * 3), ("I", C.c_double * 6)]
+
+
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
 _vp = C.c_void_p
@@ -54,6 +59,9 @@ SIGNATURES = {
     "rtbhip_jacob_dot": (C.c_int, [_u64, _vp, _vp, _i64, _vp, _i32, _vp, _i32, _vp]),
     "rtbhip_manipulability": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _vp, _i32, _vp]),
     "rtbhip_jacobm": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _vp, _i32, _vp]),
+    "rtbhip_tree_create": (C.c_int, [C.POINTER(rtbhip_tree_group), _i32, C.POINTER(_u64)]),
+    "rtbhip_tree_destroy": (C.c_int, [_u64]),
+    "rtbhip_tree_rne": (C.c_int, [_u64, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp]),
     "rtbhip_inertia": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _vp]),
     "rtbhip_coriolis": (C.c_int, [_u64, _vp, _vp, _i64, _vp, _i32, _vp]),
     "rtbhip_accel": (C.c_int, [_u64, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp]),

@@ -1,0 +1,222 @@
+"""Link / ERobot -- ETS robots (link trees) with batched inverse dynamics on the GPU.
+
+Mirrors the part of the reference's ``Link`` (robot/Link.py) and ``ERobot`` / ``Robot`` (robot/ERobot.py,
+robot/Robot.py, robot/BaseRobot.py) that ``Robot.rne`` (robot/Robot.py:1704-1903) touches: links with an
+ETS whose last element may be a joint, mass ``m``, centre of mass ``r``, a parent link; link ordering and
+automatic joint numbering by depth-first traversal (BaseRobot._sort_links, robot/BaseRobot.py:198-340);
+the grouping of static links with the next joint (Robot.py:1777-1789).  The dynamics run in
+``k_tree_rne`` (csrc/tree_kernels.hip) behind ``rtbhip_tree_rne``; nothing is computed in Python.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib, as_numeric, host_ptr, is_torch, MEM_HOST, MEM_DEVICE
+from .et import ET, ETS, _AXES
+
+
+class Link:
+    """reference robot/Link.py: Link(ets=ETS(...), m=, r=, I=, parent=, name=, jindex=)"""
+
+    def __init__(self, ets=None, m=0.0, r=None, I=None, parent=None, name=None, jindex=None, qlim=None, **kw):
+        if ets is None:
+            ets = ETS()
+        elif isinstance(ets, ET):
+            ets = ETS(ets)
+        self.ets = ets
+        joints = [k for k, e in enumerate(ets) if e.isjoint]
+        if len(joints) > 1:
+            raise ValueError("An elementary link can only have one joint variable")       # robot/Link.py:230-240
+        if joints and joints[0] != len(ets) - 1:
+            raise ValueError("Variable link must be at the end of the ETS")
+        self.isjoint = bool(joints)
+        self.m = float(m)
+        self.r = np.zeros(3) if r is None else np.asarray(r, dtype=np.float64).reshape(3)
+        self.I = np.zeros((3, 3)) if I is None else np.asarray(I, dtype=np.float64)
+        self.parent = parent
+        self.name = name
+        self.jindex = jindex if jindex is not None else (ets[-1].jindex if self.isjoint else None)
+        self.qlim = qlim
+        self.children = []
+
+    @property
+    def v(self):
+        return self.ets[-1] if self.isjoint else None
+
+    def Ts(self):
+        """Constant part of the link transform (robot/Link.py:1642-1651), 4x4."""
+        T = np.eye(4)
+        for e in self.ets:
+            if not e.isjoint:
+                T = T @ e.T
+        return T
+
+
+class ERobot:
+    def __init__(self, links, name="", gravity=(0, 0, -9.81), **kw):
+        links = list(links)
+        names = {}
+        for k, l in enumerate(links):
+            if not isinstance(l, Link):
+                raise TypeError("links should all be Link subclass")
+            if not l.name:
+                l.name = "link-%d" % k
+            if l.name in names:
+                raise ValueError("link name %s is not unique" % l.name)
+            names[l.name] = l
+            l.children = []
+        for l in links:
+            if isinstance(l.parent, str):
+                l.parent = names[l.parent]
+        if all(l.parent is None for l in links):                    # BaseRobot.py:243-245: a serial chain in list order
+            for a, b in zip(links[:-1], links[1:]):
+                b.parent = a
+        bases = [l for l in links if l.parent is None]
+        if len(bases) != 1:
+            raise ValueError("Multiple base links" if bases else "Invalid link configuration provided, must have a base link")
+        for l in links:
+            if l.parent is not None:
+                l.parent.children.append(l)
+        # depth-first order and automatic joint numbering (BaseRobot.py:316-330, dfs_links :1842)
+        order = []
+        stack = [bases[0]]
+        while stack:
+            l = stack.pop()
+            order.append(l)
+            stack.extend(reversed(l.children))
+        auto = all(l.jindex is None for l in order if l.isjoint)
+        if auto:
+            k = 0
+            for l in order:
+                if l.isjoint:
+                    l.jindex = k
+                    k += 1
+        elif any(l.jindex is None for l in order if l.isjoint):
+            raise ValueError("all links must have a jindex, or none have a jindex")
+        else:
+            order = links                                            # explicit numbering keeps the given order (:355)
+        self.links = order
+        self.name = name
+        self.base_link = bases[0]
+        self.n = sum(1 for l in order if l.isjoint)
+        if sorted(l.jindex for l in order if l.isjoint) != list(range(self.n)):
+            raise ValueError("joint index was repeated or out of range")
+        self.gravity = np.asarray(gravity, dtype=np.float64).reshape(3)
+        self._tree = None
+
+    def __len__(self): return len(self.links)
+    def __getitem__(self, i): return self.links[i]
+
+    # ------------------------------------------------------------ kinematics over a path
+    def ets(self, end=None, start=None):
+        """ETS from the base to link `end` (default: the last link), robot-wide jindex kept."""
+        end = self.links[-1] if end is None else (end if isinstance(end, Link) else next(l for l in self.links if l.name == end))
+        path = []
+        l = end
+        while l is not None:
+            path.append(l)
+            l = l.parent
+        out = []
+        for l in reversed(path):
+            for e in l.ets:
+                if e.isjoint:
+                    out.append(ET(e.axis, flip=e.isflip, jindex=l.jindex, qlim=e.qlim))
+                else:
+                    out.append(e)
+        return ETS(out)
+
+    # ------------------------------------------------------------ dynamics
+    def link_groups(self):
+        """Robot.py:1777-1789: static links are grouped with the first joint that follows them in link order."""
+        groups, cur = [], []
+        for i, l in enumerate(self.links):
+            cur.append(i)
+            if l.isjoint:
+                groups.append(cur)
+                cur = []
+        return groups
+
+    def group_table(self):
+        """One record per link group for rtbhip_tree_create (see include/rtbhip.h)."""
+        groups = self.link_groups()
+        where = {}
+        for g, idx in enumerate(groups):
+            for i in idx:
+                where[i] = g
+        index_of = {id(l): i for i, l in enumerate(self.links)}
+        recs = []
+        for g, idx in enumerate(groups):
+            T = np.eye(4)
+            m, h, I = 0.0, np.zeros(3), np.zeros((3, 3))
+            for i in idx:
+                l = self.links[i]
+                T = T @ l.Ts()
+                m += l.m                                             # SpatialInertia(m, r) summed as is (Robot.py:1793-1800)
+                h += l.m * l.r
+                I += l.m * (np.dot(l.r, l.r) * np.eye(3) - np.outer(l.r, l.r))
+            first, joint = self.links[idx[0]], self.links[idx[-1]]
+            parent = -1
+            if first.parent is not None:
+                pi = index_of[id(first.parent)]
+                if pi not in where:
+                    raise ValueError("parent link %s carries no joint up to the end of the link list" % first.parent.name)
+                parent = where[pi]
+            recs.append(dict(parent=parent, kind=_AXES[joint.v.axis], flip=int(joint.v.isflip), jindex=int(joint.jindex), T=T,
+                             m=m, h=h, I=np.array([I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]])))
+        return recs
+
+    def _handle(self):
+        if self._tree is None:
+            recs = self.group_table()
+            arr = (_lib.rtbhip_tree_group * len(recs))()
+            for k, r in enumerate(recs):
+                arr[k].parent, arr[k].kind, arr[k].flip, arr[k].jindex = r["parent"], r["kind"], r["flip"], r["jindex"]
+                arr[k].T[:] = list(np.ascontiguousarray(r["T"]).reshape(16))
+                arr[k].m = r["m"]
+                arr[k].h[:] = list(r["h"])
+                arr[k].I[:] = list(r["I"])
+            h = C.c_uint64(0)
+            check(lib().rtbhip_tree_create(arr, len(recs), C.byref(h)))
+            self._tree = h.value
+        return self._tree
+
+    def dynchanged(self):
+        if self._tree is not None and _lib._lib is not None:
+            _lib._lib.rtbhip_tree_destroy(self._tree)
+        self._tree = None
+
+    def __del__(self):
+        try:
+            self.dynchanged()
+        except Exception:
+            pass
+
+    def rne(self, q, qd=None, qdd=None, symbolic=False, gravity=None):
+        """Inverse dynamics: (n,) or (N,n) (reference Robot.rne robot/Robot.py:1704-1903)."""
+        if symbolic:
+            raise TypeError("Symbolic value")          # symbolic dynamics stay on the reference's Python path
+        n = self.n
+        first = q
+        tm = is_torch(first) and first.is_cuda
+        if tm:
+            single = q.dim() == 1
+            arrs = [None if x is None else x.reshape(-1, n).contiguous() for x in (q, qd, qdd)]
+        else:
+            single = as_numeric(q).ndim == 1
+            arrs = [None if x is None else np.ascontiguousarray(as_numeric(x).reshape(-1, n)) for x in (q, qd, qdd)]
+        N = arrs[0].shape[0]
+        single = single or N == 1                      # Robot.py:1900-1903
+        if any(x is not None and tuple(x.shape) != (N, n) for x in arrs):
+            raise ValueError("q, qd, qdd must all be (%d,) or (N,%d)" % (n, n))
+        g = np.ascontiguousarray(self.gravity if gravity is None else np.asarray(gravity, dtype=np.float64).reshape(3))
+        if tm:
+            import torch
+            tau = torch.empty((N, n), dtype=torch.float64, device=arrs[0].device)
+            ptr = lambda x: None if x is None else C.c_void_p(x.data_ptr())
+            stream, mem = _lib.current_stream_ptr(), MEM_DEVICE
+        else:
+            tau = np.empty((N, n))
+            ptr, stream, mem = host_ptr, None, MEM_HOST
+        check(lib().rtbhip_tree_rne(self._handle(), ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2]), N, host_ptr(g), ptr(tau), mem, stream))
+        return tau[0] if single else tau

@@ -238,6 +238,46 @@ class URDFRobot:
     def ik_LM(self, Tep, end=None, **kw):
         return self.ets(end).ik_LM(Tep, **kw)
 
+    # ------------------------------------------------------------ dynamics
+    def erobot(self, exclude=()):
+        """The link tree as an rtbhip.ERobot (what URDF.__init__ + Robot.__init__ build in the reference:
+        one Link per URDF link with ets = [SE3(constant) * joint ET], m, r from <inertial>).  `exclude`
+        names links whose whole subtree is left out -- the reference removes gripper links from
+        robot.links (BaseRobot.py:277-289), so Robot.rne never sees them."""
+        from .erobot import Link, ERobot
+        drop = set()
+
+        def mark(l):
+            drop.add(l.name)
+            for c in l.children:
+                mark(c)
+        for nm in exclude:
+            mark(self.linkdict[nm])
+        made = {}
+        links = []
+        for l in self.links:                                  # URDF file order (parents may come later in the file)
+            if l.name in drop:
+                continue
+            ets = []
+            if l.joint is not None:
+                ets.append(ET.SE3(l.joint.constant()))
+                var = l.joint.variable()
+                if var is not None:
+                    ets.append(var)
+            k = Link(ets=ETS(ets), m=l.m, r=l.r, I=l.I, name=l.name)
+            made[l.name] = k
+            links.append(k)
+        for l in self.links:
+            if l.name in made and l.parent is not None:
+                made[l.name].parent = made[l.parent.name]
+        return ERobot(links, name=self.name)
+
+    def rne(self, q, qd=None, qdd=None, gravity=None, exclude=()):
+        key = ("erobot", tuple(exclude))
+        if key not in self._cache:
+            self._cache[key] = self.erobot(exclude)
+        return self._cache[key].rne(q, qd, qdd, gravity=gravity)
+
 
 def loadstr(urdf_string, **kw):
     return URDFRobot(urdf_string, **kw)

@@ -8,6 +8,7 @@
 #include "../../robotics-toolbox-python_amd/csrc/rne_device.h"
 #include "../../robotics-toolbox-python_amd/csrc/dyn_device.h"
 #include "../../robotics-toolbox-python_amd/csrc/diff_device.h"
+#include "../../robotics-toolbox-python_amd/csrc/tree_device.h"
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
@@ -437,6 +438,43 @@ extern "C" int emu_diff(rtbhip_chain_t h, int mode, int axes, const double *q, c
     case 6: diff_run<6>(kp, cv, mode, axes, q, qd, N, out); break;
     case 7: diff_run<7>(kp, cv, mode, axes, q, qd, N, out); break;
     default: diff_run<8>(kp, cv, mode, axes, q, qd, N, out); break;
+    }
+    return 0;
+}
+
+// ETS-robot inverse dynamics: tree.cpp's compiled table + tree_device.h's per-lane recursion on the CPU
+template <int NG>
+static void tree_run(const Tree *t, const double *q, const double *qd, const double *qdd, int64_t N, V3 g, double *tau)
+{
+    std::vector<double> slots((size_t)kTreeSlotDoubles * std::max(1, t->nslots));
+    for (int64_t s = 0; s < N; ++s) {
+        const double *a = q + s * NG, *b = qd + s * NG, *c = qdd + s * NG;
+        double *o = tau + s * NG;
+        tree_rne_lane<NG>(t->groups.data(), t->nslots, g, [&](int k) { return a[k]; }, [&](int k) { return b[k]; },
+                          [&](int k) { return c[k]; }, [&](int k, double v) { o[k] = v; },
+                          [&](int i) -> double & { return slots[i]; });
+    }
+}
+extern "C" int emu_tree_rne(const rtbhip_tree_group *groups, int ng, const double *q, const double *qd, const double *qdd,
+                            int64_t N, const double *grav3, double *tau)
+{
+    Tree t;
+    if (compile_tree(groups, ng, &t) != RTBHIP_OK) return -1;
+    V3 g = v3(grav3[0], grav3[1], grav3[2]);
+    switch (ng) {
+    case 1: tree_run<1>(&t, q, qd, qdd, N, g, tau); break;
+    case 2: tree_run<2>(&t, q, qd, qdd, N, g, tau); break;
+    case 3: tree_run<3>(&t, q, qd, qdd, N, g, tau); break;
+    case 4: tree_run<4>(&t, q, qd, qdd, N, g, tau); break;
+    case 5: tree_run<5>(&t, q, qd, qdd, N, g, tau); break;
+    case 6: tree_run<6>(&t, q, qd, qdd, N, g, tau); break;
+    case 7: tree_run<7>(&t, q, qd, qdd, N, g, tau); break;
+    case 8: tree_run<8>(&t, q, qd, qdd, N, g, tau); break;
+    case 9: tree_run<9>(&t, q, qd, qdd, N, g, tau); break;
+    case 10: tree_run<10>(&t, q, qd, qdd, N, g, tau); break;
+    case 11: tree_run<11>(&t, q, qd, qdd, N, g, tau); break;
+    case 12: tree_run<12>(&t, q, qd, qdd, N, g, tau); break;
+    default: return -2;
     }
     return 0;
 }

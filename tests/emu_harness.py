@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "robotics-toolbox-python_amd")
 EMU_SO = os.path.join(ROOT, "tests", "emu", "libemu.so")
 SRCS = ["tests/emu/emu.cpp"] + ["robotics-toolbox-python_amd/csrc/" + f for f in
-                                ("api.cpp", "chain.cpp", "kin_kernels.hip", "rne_kernels.hip", "ik_kernels.hip", "dyn_kernels.hip")]
+                                ("api.cpp", "chain.cpp", "tree.cpp", "kin_kernels.hip", "rne_kernels.hip", "ik_kernels.hip", "dyn_kernels.hip",
+                                 "tree_kernels.hip")]
 _vp, _u64, _i64, _i32 = C.c_void_p, C.c_uint64, C.c_int64, C.c_int32
 _lib = None
 
@@ -131,6 +132,27 @@ def diff(ets, mode, q, qd=None, axes=63, tool=None, frame=0):
     t = None if tool is None else np.ascontiguousarray(tool, dtype=np.float64)
     assert lib().emu_diff(h, mode, axes, _p(q), _p(qd), N, _p(t), frame, _p(out)) == 0
     return out
+
+
+def tree_rne(recs, q, qd, qdd, gravity):
+    """recs: ERobot.group_table(); runs tree.cpp + tree_device.h on the CPU."""
+    from rtbhip._lib import rtbhip_tree_group
+    ng = len(recs)
+    arr = (rtbhip_tree_group * ng)()
+    for k, r in enumerate(recs):
+        arr[k].parent, arr[k].kind, arr[k].flip, arr[k].jindex = r["parent"], r["kind"], r["flip"], r["jindex"]
+        arr[k].T[:] = list(np.ascontiguousarray(r["T"]).reshape(16))
+        arr[k].m = r["m"]
+        arr[k].h[:] = list(r["h"])
+        arr[k].I[:] = list(r["I"])
+    q, qd, qdd = (np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1, ng)) for x in (q, qd, qdd))
+    tau = np.full(q.shape, np.nan)
+    g = np.ascontiguousarray(gravity, dtype=np.float64)
+    f = lib().emu_tree_rne
+    f.argtypes = [C.POINTER(rtbhip_tree_group), _i32, _vp, _vp, _vp, _i64, _vp, _vp]
+    rc = f(arr, ng, _p(q), _p(qd), _p(qdd), q.shape[0], _p(g), _p(tau))
+    assert rc == 0, rc
+    return tau
 
 
 def dyn(L24, mdh, mode, q, qd=None, torque=None, grav_c=None):
