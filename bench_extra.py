@@ -108,6 +108,22 @@ def main():
                                             "max_abs_err_gpu_vs_cpu": float(np.abs(g - Mc).max())}
             print(json.dumps(line), flush=True)
 
+    if "kin" in what:
+        # the other kinematics outputs of the Panda chain at N = 1e6: fkine only, jacob0 only, hessian0, jacob0_dot, manipulability
+        N = args.n_dyn
+        ets = rtbhip.models.Panda().ets()
+        rng = np.random.default_rng(0)
+        q = torch.from_numpy(rng.uniform(-np.pi, np.pi, (N, 7))).cuda()
+        qd = torch.from_numpy(rng.normal(size=(N, 7))).cuda()
+        for name, fn, byts in (("fkine", lambda: ets.eval(q), 56 + 128), ("jacob0", lambda: ets.jacob0(q), 56 + 336),
+                               ("hessian0", lambda: ets.hessian0(q), 56 + 2352), ("jacob0_dot", lambda: ets.jacob0_dot(q, qd), 112 + 336),
+                               ("manipulability", lambda: ets.manipulability(q), 56 + 8), ("jacobm", lambda: ets.jacobm(q), 56 + 56)):
+            avg, best = ev_time(fn, args.steps, 2)
+            print(json.dumps({"metric": "configurations/sec (Panda %s)" % name, "value": N / (avg * 1e-3), "unit": "configurations/s", "n": N,
+                              "kernel_avg_ms": avg, "kernel_min_ms": best,
+                              "roofline": {"bound": "hbm", "achieved": byts * N / (avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                           "frac": byts * N / (avg * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": byts * N}}), flush=True)
+
     if "tree" in what:
         # Robot.rne of a URDF arm (UR5, 6 link groups, <inertial> masses) through k_tree_rne
         from rtbhip import urdf

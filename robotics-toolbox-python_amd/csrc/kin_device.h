@@ -219,4 +219,42 @@ RTB_HD void hessian_from_jacobian(int n, Get get, Put put /* put(index into n*6*
     }
 }
 
+// One entry H[j, row, i] of the Hessian from a finished Jacobian stored as Jrow[r * n + c]
+// (methods.cpp:16-32: for j <= i  (w_j x v_i ; w_j x w_i), mirrored translational block, zero
+// rotational block below the diagonal).
+RTB_HD double hessian_entry(const double *Jrow, int n, int j, int row, int i)
+{
+    const bool up = j <= i;
+    if (row >= 3 && !up) return 0.0;
+    const int ac = up ? j : i, bc = up ? i : j;
+    const int k = row >= 3 ? row - 3 : row;
+    const int k1 = k == 2 ? 0 : k + 1, k2 = k == 0 ? 2 : k - 1;
+    const int bo = row >= 3 ? 3 : 0;
+    const double a1 = Jrow[(3 + k1) * n + ac], a2 = Jrow[(3 + k2) * n + ac];
+    const double b1 = Jrow[(bo + k1) * n + bc], b2 = Jrow[(bo + k2) * n + bc];
+    return a1 * b2 - a2 * b1;
+}
+
+// The tile's Hessians are one contiguous run of ncfg * n*6*n doubles; lane l produces the 16-byte
+// pieces l, l+64, ... of that run straight from the wave's staged Jacobians (jl: row stride jstride),
+// so the (N,n,6,n) output is written fully coalesced with no second staging buffer.
+template <int NJ, class Store>
+RTB_HD void hessian_run(const double *jl, int jstride, int ncfg, int lane, Store store /* store(f, a, b, both) */)
+{
+    constexpr int HW = NJ * 6 * NJ;
+    const int total = ncfg * HW;
+    for (int f = 2 * lane; f < total; f += 2 * kWave) {
+        double v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = f + u;
+            const int r = e / HW, w = e - r * HW;
+            const int j = w / (6 * NJ), w2 = w - j * 6 * NJ;
+            const int row = w2 / NJ, i = w2 - row * NJ;
+            v[u] = e < total ? hessian_entry(jl + r * jstride, NJ, j, row, i) : 0.0;
+        }
+        store(f, v[0], v[1], f + 1 < total);
+    }
+}
+
 }  // namespace rtbhip

@@ -122,6 +122,52 @@ __global__ __launch_bounds__(kWave, RTB_REG_WAVES) void k_kin_reg(KinParams kp, 
     reg_tile<NJ, WANT_T, WANT_J>(kp, const_view(dc), q, T, J, buf, threadIdx.x, blockIdx.x);
 }
 
+// ---------------------------------------------------------------- Hessian, register-resident (n <= 8)
+// H is 48 n^2 bytes per configuration (2352 B for the Panda): the kernel is a pure HBM writer.  The
+// first version wrote each lane's block with 8-byte stores at a 2352-byte stride (3.27 ms per 1e6
+// Panda configurations, 9 % of the HBM peak); here the wave stages its 64 Jacobians in LDS once and
+// every lane generates the 16-byte pieces of the tile's contiguous output run on the fly.
+template <int NJ>
+__global__ __launch_bounds__(kWave, 2) void k_kin_hess(KinParams kp, DevChain dc, const double *__restrict__ q,
+                                                       double *__restrict__ H)
+{
+    extern __shared__ __attribute__((aligned(16))) double buf[];
+    const ConstChain cv = const_view(dc);
+    const int lane = threadIdx.x;
+    const int64_t cfg0 = (int64_t)blockIdx.x * kWave;
+    const int64_t left = kp.N - cfg0;
+    const int ncfg = left < kWave ? (int)left : kWave;
+    constexpr int W = 6 * NJ;
+    {
+        Pose P;
+        double jac[6 * NJ];
+        reg_compute<NJ, true>(kp, cv, q, cfg0 + lane, P, jac);
+        double *mine = buf + lane * (W + 1);
+#pragma unroll
+        for (int k = 0; k < W; ++k) mine[k] = jac[k];
+    }
+    __syncthreads();
+    double *dst = H + cfg0 * (int64_t)(NJ * W);
+    hessian_run<NJ>(buf, W + 1, ncfg, lane, [&](int f, double a, double b, bool both) {
+        if (both) {
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            v2d w = {a, b};
+            __builtin_nontemporal_store(w, reinterpret_cast<v2d *>(dst + f));
+        } else {
+            __builtin_nontemporal_store(a, dst + f);
+        }
+    });
+}
+
+template <int NJ>
+static hipError_t launch_hess_nj(dim3 grid, hipStream_t s, const KinParams &kp, const DevChain &dc, const double *q, double *H)
+{
+    const size_t lds = (size_t)kWave * (6 * NJ + 1) * sizeof(double);
+    hipLaunchKernelGGL((k_kin_hess<NJ>), grid, dim3(kWave), lds, s, kp, dc, q, H);
+    note_launch((int)grid.x, kWave, (int)lds);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- differential-kinematics consumers (n <= 8)
 // jacob0_dot / manipulability / jacobm straight from the register-resident Jacobian: the (n,6,n) Hessian
 // the reference materialises for each of them (robot/Robot.py:1069, robot/ETS.py:1671) never exists.
@@ -271,6 +317,22 @@ int launch_kin(const Chain *c, const DevChain &ops, const double *q, int64_t N, 
     int64_t g = (tiles + g_tiles_per_wave - 1) / g_tiles_per_wave;
     if (g > 0x7fffffff) g = 0x7fffffff;
     dim3 grid((unsigned)g);
+    if (g_use_reg && H && !T && !J && c->n >= 1 && c->n <= kRegMaxJoints && tiles <= 0x7fffffff) {
+        grid = dim3((unsigned)tiles);
+        hipError_t e = hipSuccess;
+        switch (c->n) {
+        case 1: e = launch_hess_nj<1>(grid, s, kp, ops, q, H); break;
+        case 2: e = launch_hess_nj<2>(grid, s, kp, ops, q, H); break;
+        case 3: e = launch_hess_nj<3>(grid, s, kp, ops, q, H); break;
+        case 4: e = launch_hess_nj<4>(grid, s, kp, ops, q, H); break;
+        case 5: e = launch_hess_nj<5>(grid, s, kp, ops, q, H); break;
+        case 6: e = launch_hess_nj<6>(grid, s, kp, ops, q, H); break;
+        case 7: e = launch_hess_nj<7>(grid, s, kp, ops, q, H); break;
+        default: e = launch_hess_nj<8>(grid, s, kp, ops, q, H); break;
+        }
+        if (e != hipSuccess) return hip_fail(e, "k_kin_hess launch");
+        return RTBHIP_OK;
+    }
     if (g_use_reg && !H && c->n >= 1 && c->n <= kRegMaxJoints && tiles <= 0x7fffffff) {
         grid = dim3((unsigned)tiles);
         const size_t rl = (size_t)reg_lds_doubles(c->n) * sizeof(double);

@@ -121,6 +121,49 @@ extern "C" int emu_kin_reg(rtbhip_chain_t h, const double *q, int64_t N, const d
     return 0;
 }
 
+template <int NJ>
+static void emu_hess_run(const KinParams &kp, const DevChain &cv, const double *q, int64_t N, double *H)
+{
+    constexpr int W = 6 * NJ;
+    std::vector<double> buf(kWave * (W + 1), -777.0);
+    const int64_t tiles = (N + kWave - 1) / kWave;
+    for (int64_t tile = 0; tile < tiles; ++tile) {
+        const int64_t cfg0 = tile * kWave;
+        const int ncfg = (int)std::min<int64_t>(kWave, N - cfg0);
+        for (int l = 0; l < kWave; ++l) {
+            Pose P;
+            double jac[6 * NJ];
+            reg_compute<NJ, true>(kp, cv, q, cfg0 + l, P, jac);
+            for (int k = 0; k < W; ++k) buf[l * (W + 1) + k] = jac[k];
+        }
+        double *dst = H + cfg0 * (int64_t)(NJ * W);
+        for (int l = 0; l < kWave; ++l)
+            hessian_run<NJ>(buf.data(), W + 1, ncfg, l, [&](int f, double a, double b, bool both) { dst[f] = a; if (both) dst[f + 1] = b; });
+    }
+}
+
+extern "C" int emu_kin_hess(rtbhip_chain_t h, const double *q, int64_t N, const double *tool16, int frame, double *H)
+{
+    Chain *c = chain_from_handle(h);
+    if (!c || c->n < 1 || c->n > kRegMaxJoints) return -1;
+    KinParams kp;
+    kp.n = c->n; kp.qw = c->q_width; kp.stride = kin_stride(c->n); kp.frame = frame; kp.N = N; kp.pad = 0; kp.has_base = 0;
+    Affine t = aff16(tool16);
+    chain_tail(c, t, kp.tail);
+    const DevChain cv = chain_host_view(c);
+    switch (c->n) {
+    case 1: emu_hess_run<1>(kp, cv, q, N, H); break;
+    case 2: emu_hess_run<2>(kp, cv, q, N, H); break;
+    case 3: emu_hess_run<3>(kp, cv, q, N, H); break;
+    case 4: emu_hess_run<4>(kp, cv, q, N, H); break;
+    case 5: emu_hess_run<5>(kp, cv, q, N, H); break;
+    case 6: emu_hess_run<6>(kp, cv, q, N, H); break;
+    case 7: emu_hess_run<7>(kp, cv, q, N, H); break;
+    default: emu_hess_run<8>(kp, cv, q, N, H); break;
+    }
+    return 0;
+}
+
 extern "C" void emu_sincos(const double *x, int64_t n, double *s, double *c, int reduced_only)
 {
     for (int64_t i = 0; i < n; ++i) {

@@ -46,6 +46,7 @@ def lib():
         _lib.rtbhip_dyn_create.argtypes = [_vp, _i32, _i32, C.POINTER(_u64)]
         _lib.emu_kin.argtypes = [_u64, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _i32]
         _lib.emu_rne.argtypes = [_u64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32]
+        _lib.emu_kin_hess.argtypes = [_u64, _vp, _i64, _vp, _i32, _vp]
         _lib.emu_diff.argtypes = [_u64, _i32, _i32, _vp, _vp, _i64, _vp, _i32, _vp]
         _lib.emu_dyn.argtypes = [_u64, _i32, _vp, _vp, _vp, _i64, _vp, _vp]
         _lib.emu_kin_reg.argtypes = [_u64, _vp, _i64, _vp, _vp, _i32, _vp, _vp]
@@ -119,6 +120,17 @@ def rne(L24, mdh, q, qd, qdd, grav_c, fext=None, force_generic=False):
     rc = lib().emu_rne(h.value, _p(q), _p(qd), _p(qdd), q.shape[0], _p(g), _p(f), _p(tau), int(force_generic))
     assert rc == 0
     return tau
+
+
+def hess_reg(ets, q, tool=None, frame=0):
+    """The register-resident Hessian path (k_kin_hess: staged Jacobians + hessian_run) on the CPU."""
+    h = chain_handle(ets)
+    q = np.ascontiguousarray(np.asarray(q, dtype=np.float64).reshape(-1, ets.q_width))
+    N, n = q.shape[0], ets.n
+    H = np.full((N, n, 6, n), np.nan)
+    t = None if tool is None else np.ascontiguousarray(tool, dtype=np.float64)
+    assert lib().emu_kin_hess(h, _p(q), N, _p(t), frame, _p(H)) == 0
+    return H
 
 
 def diff(ets, mode, q, qd=None, axes=63, tool=None, frame=0):

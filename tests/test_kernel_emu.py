@@ -267,3 +267,23 @@ def test_ik_wave_scheduler_equals_sequential_searches(flavour, N, waves, slimit,
         nt.assert_array_equal(x, y)
     assert a[1].sum() < N                        # the failures really are in the mix
     assert st[2] >= a[2].sum() - N * 2           # speculation only ever ADDS lane-iterations
+
+
+@pytest.mark.parametrize("N", [1, 63, 64, 65, 200])
+def test_hessian_register_path_equals_oracle_and_lds_tile_path(N):
+    """k_kin_hess: 64 staged Jacobians -> every lane generates 16-byte pieces of the tile's contiguous
+    (N,n,6,n) run.  Must equal the oracle (methods.cpp:16-32) and the run-time-n LDS-tile path, for both
+    frames, odd and even joint counts (odd n*6*n run lengths end on a single double)."""
+    rng = np.random.default_rng(N)
+    for ets, ch in ((rtbhip.models.Panda().ets(), chains.panda_ets()),
+                    (rtbhip.models.DH.Puma560().ets(), chains.puma560().ets())):
+        q = rng.uniform(-2, 2, (N, ets.n))
+        for frame in (0, 1):
+            Hr = emu.hess_reg(ets, q, frame=frame)
+            nt.assert_allclose(Hr, oracle.hessian(ch, q, frame=frame), atol=1e-12)
+            _, _, Ht = emu.kin(ets, q, frame=frame, want=("H",))
+            nt.assert_allclose(Hr, Ht, atol=1e-13)
+    three = rtbhip.ET.Rz() * rtbhip.ET.tx(0.3) * rtbhip.ET.Ry() * rtbhip.ET.tz(0.2) * rtbhip.ET.tx()
+    q3 = rng.uniform(-1, 1, (N, 3))
+    _, _, Ht = emu.kin(three, q3, want=("H",))
+    nt.assert_allclose(emu.hess_reg(three, q3), Ht, atol=1e-13)
