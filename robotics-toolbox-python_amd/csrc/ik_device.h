@@ -29,10 +29,9 @@ constexpr double kIkPiHalf = 1.57079632679489661923132169163975144;
 
 struct IkDev {   // wave-uniform solver parameters (kernarg)
     int32_t ilimit, slimit, reject_jl, method, flavour, has_q0;
-    int32_t fresh_cap, pad;   // scheduler: fresh targets a wave may take per pass
+    int32_t fresh_cap, pool_chunk;   // scheduler: fresh targets a wave may start per pass / reserves per refill
     double tol, lambda;
     double we[6];
-    double tail[12];
     uint64_t seed;
     int64_t N;
 };
@@ -138,8 +137,9 @@ RTB_HD void ik_lm_step(const double (&jac)[6 * NJ], const double (&e)[6], const 
 //                           reports slimit and the last search's final q.
 // The target pose (R row-major (9), t (3)) and the joint vector q are NOT part of the register state:
 // each is read once at the top of an iteration (and q written once at the bottom), so the kernel
-// keeps them in the wave's LDS (IkWaveShared::Td / ::q, 38 VGPRs that would otherwise be live across
-// the whole iteration and push the kernel into scratch) and every function below reaches them through
+// keeps them in the wave's LDS (IkWaveShared::Td per target slot, ::q per lane; 38 VGPRs that would
+// otherwise be live across the whole iteration and push the kernel into scratch; and a search that
+// starts on an already loaded target touches no global memory) and every function below reaches them through
 // accessors:  td(k) -> double, tdput(k, v);  qa.get(j) -> double, qa.put(j, v).
 template <int NJ>
 struct IkLane {
@@ -203,8 +203,8 @@ RTB_HD double ik_wrap_py(double q)                                              
 // ONE LM iteration of the lane's current search.  Every lane of a wave executes this whatever its
 // status (idle / parked lanes compute on their stale state and discard the result) so the wave has a
 // single instruction stream.  Sets st.fin / st.ok when the search ended.
-template <int NJ, class CV, class QL, class TD, class QA>
-RTB_HD void ik_iter(IkLane<NJ> &st, const IkDev &p, const CV &cv, QL qlim, TD td, QA qa)
+template <int NJ, class PD, class CV, class QL, class TD, class QA>
+RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, QA qa)
 {
     Pose P;
     double jac[6 * NJ], e[6], dq[NJ];
@@ -212,7 +212,8 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const IkDev &p, const CV &cv, QL qlim, TD td
         double qv[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) qv[j] = qa.get(j);
-        reg_core<NJ, true>(cv, p.tail, 0, qv, P, jac);         // ik.cpp:44,56 / IK.py:994,1009
+        // the chain's last constant C_n (no tool in IK) is segment NJ of the table: {r[9], t[3]} contiguous
+        reg_core<NJ, true>(cv, &cv.seg[NJ].r[0], 0, qv, P, jac);   // ik.cpp:44,56 / IK.py:994,1009
     }
     sched_fence();
     ik_angle_axis(P, td, e);
@@ -308,7 +309,7 @@ struct IkWaveShared {
     int32_t res[64];                        // 0 unresolved, 1 won (winner = b), 2 failed
     int32_t list[64];                       // scratch: compacted slot list
     uint16_t rec[64][kIkRing];              // per outstanding search: 1 finished | 2 ok | iterations << 2
-    double Td[12][64];                      // per LANE: the target pose of the search the lane is running
+    double Td[12][64];                      // per SLOT: the target pose (read by every lane working on the slot)
     double q[kRegMaxJoints][64];            // per LANE: the joint vector of that search
 };
 constexpr int kIkMaxIlimit = 16000;         // (ilimit + 1) << 2 must fit the 16-bit record
@@ -405,7 +406,7 @@ RTB_HD void ik_start_target(IkLane<NJ> &st, IkWaveShared &sh, int lane, const Ik
     sh.res[slot] = 0; sh.Elast[slot] = 0.0;
     for (int k = 0; k < kIkRing; ++k) sh.rec[slot][k] = 0;
     st.slot = slot;
-    ik_load_target([&](int k, double v) { sh.Td[k][lane] = v; }, Tep + 16 * tgt);
+    ik_load_target([&](int k, double v) { sh.Td[k][slot] = v; }, Tep + 16 * tgt);   // once per target, not per search
     ik_search_begin<NJ>(st, IkLdsQ{&sh, lane}, p, qlim, tgt, s0, p.has_q0 ? q0 + (int64_t)NJ * tgt : nullptr);
 }
 
@@ -429,7 +430,6 @@ RTB_HD void ik_start_spec(IkLane<NJ> &st, IkWaveShared &sh, int lane, const IkDe
     ik_lds_max(&sh.next[slot], s + 1);
     const int64_t tgt = sh.tgt[slot];
     st.slot = slot;
-    ik_load_target([&](int k, double v) { sh.Td[k][lane] = v; }, Tep + 16 * tgt);
     ik_search_begin<NJ>(st, IkLdsQ{&sh, lane}, p, qlim, tgt, s, p.has_q0 ? q0 + (int64_t)NJ * tgt : nullptr);
 }
 

@@ -44,9 +44,11 @@ __global__ __launch_bounds__(kWave, RTB_IK_WAVES) void k_ik(IkDev p, DevChain dc
 #pragma unroll
     for (int j = 0; j < NJ; ++j) sh.q[j][lane] = 0.0;
 #pragma unroll
-    for (int k = 0; k < 12; ++k) sh.Td[k][lane] = (k == 0 || k == 4 || k == 8) ? 1.0 : 0.0;
+    for (int k = 0; k < 12; ++k) sh.Td[k][lane] = (k == 0 || k == 4 || k == 8) ? 1.0 : 0.0;   // slot `lane`
     unsigned long long busy = 0;     // wave-uniform: slots holding an unresolved target
     bool exhausted = false;          // wave-uniform: the global supply of fresh targets has run out
+    bool drained = false;            // wave-uniform: the device-wide counter has passed N
+    unsigned long long pool_next = 0, pool_end = 0;   // wave-uniform: targets reserved by this wave and not started yet
     bool first = true;
     // watchdog: a correct run resolves some slot at least every (ilimit+2)*(searches+2) iterations
     const long long patience = (long long)(p.ilimit + 2) * (s_last + 3) + 64;
@@ -82,14 +84,25 @@ __global__ __launch_bounds__(kWave, RTB_IK_WAVES) void k_ik(IkDev p, DevChain dc
                 // smaller than the grid's lane count evenly over the waves
                 int nf = __popcll(idle);
                 nf = nf > p.fresh_cap ? p.fresh_cap : nf;
-                unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(counter, (unsigned long long)nf);
-                const unsigned lo = __shfl((unsigned)(base & 0xffffffffu), 0);
-                const unsigned hi = __shfl((unsigned)(base >> 32), 0);
-                base = ((unsigned long long)hi << 32) | lo;
-                long long nvalid = (long long)p.N - (long long)base;
-                nvalid = nvalid < 0 ? 0 : (nvalid > nf ? nf : nvalid);
-                if (nvalid < nf) exhausted = true;
+                // targets are reserved from the device-wide counter in chunks and handed out from the wave's
+                // own pool: the atomic's round trip (and its s_waitcnt) is paid once per chunk, not per pass
+                if (pool_next == pool_end) {
+                    unsigned long long got = 0;
+                    const unsigned long long chunk = p.pool_chunk > 0 ? (unsigned long long)p.pool_chunk : (unsigned long long)nf;
+                    if (lane == 0) got = atomicAdd(counter, chunk);
+                    const unsigned lo = __shfl((unsigned)(got & 0xffffffffu), 0);
+                    const unsigned hi = __shfl((unsigned)(got >> 32), 0);
+                    got = ((unsigned long long)hi << 32) | lo;
+                    const unsigned long long NN = (unsigned long long)p.N;
+                    pool_next = got < NN ? got : NN;
+                    pool_end = got + chunk < NN ? got + chunk : NN;
+                    if (pool_end == NN) drained = true;      // the counter has passed N: this is the wave's last refill
+                }
+                const unsigned long long base = pool_next;
+                long long nvalid = (long long)(pool_end - pool_next);
+                nvalid = nvalid > nf ? nf : nvalid;
+                pool_next += (unsigned long long)nvalid;
+                if (drained && pool_next == pool_end) exhausted = true;
                 if ((freeslots >> lane) & 1ull) sh.list[ik_rank(freeslots, lane)] = lane;
                 __syncthreads();
                 const int r = ik_rank(idle, lane);
@@ -115,7 +128,17 @@ __global__ __launch_bounds__(kWave, RTB_IK_WAVES) void k_ik(IkDev p, DevChain dc
         }
         if (busy == 0 && exhausted) break;
         if (++quiet > patience) break;      // never expected; unresolved targets keep their memset outputs
-        ik_iter<NJ>(st, p, cv, qlim, [&](int k) { return sh.Td[k][lane]; }, IkLdsQ{&sh, lane});
+        {
+            // The chain / limit tables are loop-invariant, and LICM would hoist all ~100 scalar loads out of
+            // this persistent loop into SGPRs that do not exist (184 spilled SGPRs, 670 v_readlane in the
+            // first build).  Laundering the table pointers once per iteration keeps the loads inside it,
+            // where the scalar cache serves them and the VALU never sees them.
+            ConstChainIk cvi = cv;
+            const RTB_CONST double *ql = qlim;
+            asm volatile("" : "+s"(cvi.seg), "+s"(cvi.jmeta), "+s"(ql));
+            const int myslot = st.slot;
+            ik_iter<NJ>(st, p, cvi, ql, [&](int k) { return sh.Td[k][myslot]; }, IkLdsQ{&sh, lane});
+        }
     }
 }
 
@@ -162,9 +185,6 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
     p.ilimit = ip.ilimit; p.slimit = ip.slimit; p.reject_jl = ip.reject_jl; p.method = ip.method;
     p.flavour = ip.flavour; p.has_q0 = q0 != nullptr; p.tol = ip.tol; p.lambda = ip.lambda;
     for (int k = 0; k < 6; ++k) p.we[k] = ip.we[k];
-    Affine none; none.used = 0;
-    for (int k = 0; k < 12; ++k) none.v[k] = 0.0;
-    chain_tail(c, none, p.tail);
     p.seed = ip.seed;
     p.N = N;
     int dev = 0, cus = 0;
@@ -189,6 +209,10 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
     if (g > N) g = N;
     const int64_t cap = (N + g - 1) / g;
     p.fresh_cap = cap > 64 ? 64 : (int32_t)cap;
+    // big batches reserve in chunks (one atomic round trip per 64 / 16 targets); batches of the order of the
+    // grid's lane count reserve exactly what a pass starts, so no wave sits on targets another could run
+    const int64_t lanes = g * kWave;
+    p.pool_chunk = N >= 8 * lanes ? 64 : (N >= 3 * lanes ? 16 : 0);
     dim3 grid((unsigned)g);
     switch (c->n) {
     case 1: launch_nj<1>(grid, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual); break;

@@ -33,22 +33,22 @@ RTB_HD int reg_lds_doubles(int n)
 // Per-lane core: joint values qv[] (chain order, as the caller holds them) -> P = C_0 Z_0 ... tail and
 // the finished Jacobian in registers.  jac slot r*NJ + j : rows 0..2 = p_j, rows 3..5 = z_j until
 // the closing loop finishes them.  Used by the tile kernel (reg_compute) and by the IK loop.
-template <int NJ, bool WANT_J, class CV>
-RTB_HD void reg_core(const CV &cv, const double *tail, int frame, const double (&qv)[NJ], Pose &P,
+template <int NJ, bool WANT_J, class CV, class TL>
+RTB_HD void reg_core(const CV &cv, TL tail /* tail[k], k = 0..11 */, int frame, const double (&qv)[NJ], Pose &P,
                      double (&jac)[6 * NJ])
 {
     double c[NJ], s[NJ], d[NJ];
-    // wave-uniform per-joint blend weights (SGPR doubles) instead of per-lane selects:
-    // rv = 1 for a revolute joint, pv = 1 for a prismatic one, sg = -1 where the joint is flipped.
-    double rv[NJ], pv[NJ], sg[NJ];
+    // Wave-uniform per-joint blend weights instead of per-lane selects: rv = 1 for a revolute joint,
+    // pv = 1 for a prismatic one, sg = -1 where the joint is flipped.  They are re-derived from the
+    // one-dword joint descriptor at every use (a few SALU ops) rather than kept as 3*NJ SGPR doubles
+    // across the whole walk: inside the persistent IK loop those 42 SGPRs were what overflowed the
+    // scalar register file.
+    int jmv[NJ];
     bool big = false;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {   // methods.cpp:363-366 for flip
-        const int jm = cv.jmeta[j];
-        pv[j] = jm_prismatic(jm) ? 1.0 : 0.0;
-        rv[j] = 1.0 - pv[j];
-        sg[j] = jm_flip(jm) ? -1.0 : 1.0;
-        d[j] = qv[j] * sg[j];
+        jmv[j] = cv.jmeta[j];
+        d[j] = qv[j] * (jm_flip(jmv[j]) ? -1.0 : 1.0);
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {   // NJ independent evaluations, one basic block
@@ -61,14 +61,15 @@ RTB_HD void reg_core(const CV &cv, const double *tail, int frame, const double (
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
+        const double pvj = jm_prismatic(jmv[j]) ? 1.0 : 0.0, rvj = 1.0 - pvj;
         if (j == 0) pose_from_seg(P, cv, 0); else pose_mul_seg(P, cv, j);
         if (WANT_J) {
             jac[j] = P.tx; jac[NJ + j] = P.ty; jac[2 * NJ + j] = P.tz;
             jac[3 * NJ + j] = P.r02; jac[4 * NJ + j] = P.r12; jac[5 * NJ + j] = P.r22;
         }
         // revolute: rotate by (c, s), no slide; prismatic: identity rotation, slide d
-        pose_rotz(P, fma(rv[j], c[j], pv[j]), rv[j] * s[j]);
-        pose_tz(P, pv[j] * d[j]);
+        pose_rotz(P, fma(rvj, c[j], pvj), rvj * s[j]);
+        pose_tz(P, pvj * d[j]);
         sched_fence();
     }
     pose_mul_general(P, [&](int k) { return tail[k]; });
@@ -78,12 +79,13 @@ RTB_HD void reg_core(const CV &cv, const double *tail, int frame, const double (
         // (methods.cpp:142-195); frame 1 rotates both halves by Re^T.
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const double zx = sg[j] * jac[3 * NJ + j], zy = sg[j] * jac[4 * NJ + j], zz = sg[j] * jac[5 * NJ + j];
+            const double pvj = jm_prismatic(jmv[j]) ? 1.0 : 0.0, rvj = 1.0 - pvj, sgj = jm_flip(jmv[j]) ? -1.0 : 1.0;
+            const double zx = sgj * jac[3 * NJ + j], zy = sgj * jac[4 * NJ + j], zz = sgj * jac[5 * NJ + j];
             const double dx = P.tx - jac[j], dy = P.ty - jac[NJ + j], dz = P.tz - jac[2 * NJ + j];
-            double vx = fma(rv[j], zy * dz - zz * dy, pv[j] * zx);
-            double vy = fma(rv[j], zz * dx - zx * dz, pv[j] * zy);
-            double vz = fma(rv[j], zx * dy - zy * dx, pv[j] * zz);
-            double wx = rv[j] * zx, wy = rv[j] * zy, wz = rv[j] * zz;
+            double vx = fma(rvj, zy * dz - zz * dy, pvj * zx);
+            double vy = fma(rvj, zz * dx - zx * dz, pvj * zy);
+            double vz = fma(rvj, zx * dy - zy * dx, pvj * zz);
+            double wx = rvj * zx, wy = rvj * zy, wz = rvj * zz;
             if (frame == 1) {
                 double a = vx, b = vy, e = vz;
                 vx = P.r00 * a + P.r10 * b + P.r20 * e;

@@ -189,7 +189,8 @@ struct EmuWave {
     IkWaveShared sh;
     IkLane<NJ> st[kWave];
     unsigned long long busy = 0;
-    bool exhausted = false, first = true, done = false;
+    bool exhausted = false, first = true, done = false, drained = false;
+    unsigned long long pool_next = 0, pool_end = 0;
     long long passes = 0, iters = 0, lane_iters_useful = 0;
 };
 
@@ -258,11 +259,20 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
                     const unsigned long long freeslots = ~w.busy;
                     int nf = __builtin_popcountll(idle);
                     nf = nf > p.fresh_cap ? p.fresh_cap : nf;
-                    const unsigned long long base = counter;
-                    counter += nf;
-                    long long nvalid = (long long)p.N - (long long)base;
-                    nvalid = nvalid < 0 ? 0 : (nvalid > nf ? nf : nvalid);
-                    if (nvalid < nf) w.exhausted = true;
+                    if (w.pool_next == w.pool_end) {
+                        const unsigned long long chunk = p.pool_chunk > 0 ? (unsigned long long)p.pool_chunk : (unsigned long long)nf;
+                        const unsigned long long got = counter;
+                        counter += chunk;
+                        const unsigned long long NN = (unsigned long long)p.N;
+                        w.pool_next = got < NN ? got : NN;
+                        w.pool_end = got + chunk < NN ? got + chunk : NN;
+                        if (w.pool_end == NN) w.drained = true;
+                    }
+                    const unsigned long long base = w.pool_next;
+                    long long nvalid = (long long)(w.pool_end - w.pool_next);
+                    nvalid = nvalid > nf ? nf : nvalid;
+                    w.pool_next += (unsigned long long)nvalid;
+                    if (w.drained && w.pool_next == w.pool_end) w.exhausted = true;
                     for (int l = 0; l < kWave; ++l) if ((freeslots >> l) & 1ull) w.sh.list[ik_rank(freeslots, l)] = l;
                     for (int l = 0; l < kWave; ++l) {
                         const int r = ik_rank(idle, l);
@@ -286,7 +296,7 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
             w.iters++;
             for (int l = 0; l < kWave; ++l) {
                 if (w.st[l].status == kIkRun) w.lane_iters_useful++;
-                ik_iter<NJ>(w.st[l], p, cv, qlim, [&](int k) { return w.sh.Td[k][l]; }, IkLdsQ{&w.sh, l});
+                ik_iter<NJ>(w.st[l], p, cv, qlim, [&](int k) { return w.sh.Td[k][w.st[l].slot]; }, IkLdsQ{&w.sh, l});
             }
         }
     }
@@ -306,10 +316,8 @@ extern "C" int emu_ik(rtbhip_chain_t h, const double *Tep, int64_t N, const doub
     if (!c || c->n < 1 || c->n > kRegMaxJoints) return -1;
     IkDev p;
     p.ilimit = ilimit; p.slimit = slimit; p.reject_jl = reject_jl; p.method = method; p.flavour = flavour;
-    p.has_q0 = q0 != nullptr; p.tol = tol; p.lambda = lambda; p.seed = seed; p.N = N; p.fresh_cap = 64; p.pad = 0;
+    p.has_q0 = q0 != nullptr; p.tol = tol; p.lambda = lambda; p.seed = seed; p.N = N; p.fresh_cap = 64; p.pool_chunk = 64;
     for (int k = 0; k < 6; ++k) p.we[k] = we6 ? we6[k] : 1.0;
-    Affine none; none.used = 0;
-    chain_tail(c, none, p.tail);
     switch (c->n) {
     case 1: emu_ik_run<1>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
     case 2: emu_ik_run<2>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
@@ -331,11 +339,10 @@ extern "C" int emu_ik_wave(rtbhip_chain_t h, int waves, double *stats, const dou
     if (!c || c->n < 1 || c->n > kRegMaxJoints) return -1;
     IkDev p;
     p.ilimit = ilimit; p.slimit = slimit; p.reject_jl = reject_jl; p.method = method; p.flavour = flavour;
-    p.has_q0 = q0 != nullptr; p.tol = tol; p.lambda = lambda; p.seed = seed; p.N = N; p.fresh_cap = 64; p.pad = 0;
+    p.has_q0 = q0 != nullptr; p.tol = tol; p.lambda = lambda; p.seed = seed; p.N = N; p.fresh_cap = 64; p.pool_chunk = 64;
     for (int k = 0; k < 6; ++k) p.we[k] = we6 ? we6[k] : 1.0;
-    Affine none; none.used = 0;
-    chain_tail(c, none, p.tail);
-    { const int64_t g = waves; const int64_t cap = (N + g - 1) / g; p.fresh_cap = cap > 64 ? 64 : (int)cap; }
+    { const int64_t g = waves; const int64_t cap = (N + g - 1) / g; p.fresh_cap = cap > 64 ? 64 : (int)cap;
+      const int64_t lanes = g * kWave; p.pool_chunk = N >= 8 * lanes ? 64 : (N >= 3 * lanes ? 16 : 0); }
     int rc = 0;
     switch (c->n) {
     case 1: rc = emu_ik_wave_run<1>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
