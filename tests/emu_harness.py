@@ -27,10 +27,25 @@ def _stale():
 
 
 def build():
+    """One object per source, compiled in parallel (build/emu is git-ignored), then linked."""
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-x", "hip", "-w",
-           "-I" + os.path.join(ROOT, "include")] + [os.path.join(ROOT, s) for s in SRCS] + ["-o", EMU_SO]
-    subprocess.check_call(cmd)
+    objdir = os.path.join(ROOT, "build", "emu")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-x", "hip", "-w", "-I" + os.path.join(ROOT, "include")]
+    hdrs = [os.path.join(PKG, "csrc", f) for f in os.listdir(os.path.join(PKG, "csrc")) if f.endswith(".h")]
+    newest_hdr = max(os.path.getmtime(h) for h in hdrs + [os.path.join(ROOT, "include", "rtbhip.h")])
+
+    def one(src):
+        src = os.path.join(ROOT, src)
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        if not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_hdr):
+            subprocess.check_call([hipcc] + flags + ["-c", src, "-o", obj])
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(one, SRCS))
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", EMU_SO])
 
 
 def lib():
