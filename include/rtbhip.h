@@ -113,7 +113,9 @@ int rtbhip_jacobm(rtbhip_chain_t chain, const double *q, int64_t N, const double
 
 /* IK_LM_c (fknm.cpp:394-525 -> ik.cpp:19-75,157-209), batched over N targets, LM loop resident
  * on the device.  Tep (N,4,4) row-major; q0 (N,n) or NULL; we6 host or NULL; method 0 chan /
- * 1 wampler / 2 sugihara; seed keys the counter-based restart generator (the reference uses an
+ * 1 wampler / 2 sugihara, or -- the same search loop with the steps of IK_GN_c / IK_NR_c
+ * (fknm.cpp:164-392 -> ik.cpp:79-156) -- 3 Gauss-Newton, 4 Newton-Raphson (`lambda` is then
+ * pinv_damping; both take the minimum-norm step J^T (J J^T + d^2 I)^-1 e, see ik_device.h); seed keys the counter-based restart generator (the reference uses an
  * unseeded std::rand, ik.cpp:293).  flavour 0 reproduces the C loop (ETS.ik_LM), 1 the Python
  * solver's loop (ETS.ikine_LM, robot/IK.py:297-367: E tested after the step, %-wrap).
  * Outputs: q_out (N,n), success/iters/searches int32 (N), residual (N). */

@@ -104,6 +104,17 @@ class RefETS:
                                  float(k), method)
 
 
+    def ik_GN(self, Tep, q0=None, ilimit=30, slimit=100, tol=1e-6, joint_limits=True, mask=None, pinv=True, pinv_damping=0.0):
+        """IK_GN_c (fknm.cpp:279-392) with the argument order of ETS.ik_GN (ETS.py:2430-2442)."""
+        Tep = np.ascontiguousarray(Tep, dtype=np.float64)
+        return self.fknm.IK_GN_c(self.cap, Tep, q0, ilimit, slimit, tol, int(joint_limits), mask, int(pinv), float(pinv_damping))
+
+    def ik_NR(self, Tep, q0=None, ilimit=30, slimit=100, tol=1e-6, joint_limits=True, mask=None, pinv=True, pinv_damping=0.0):
+        """IK_NR_c (fknm.cpp:164-277) with the argument order of ETS.ik_NR (ETS.py:2287-2298)."""
+        Tep = np.ascontiguousarray(Tep, dtype=np.float64)
+        return self.fknm.IK_NR_c(self.cap, Tep, q0, ilimit, slimit, tol, int(joint_limits), mask, int(pinv), float(pinv_damping))
+
+
 class RefRNE:
     """frne capsule from the 24-double/link block (DHRobot._init_rne, DHRobot.py:1340-1361)."""
 

@@ -365,7 +365,7 @@ int rtbhip_ik_lm(rtbhip_chain_t chain, const double *Tep, int64_t N, const doubl
     Chain *c = chain_from_handle(chain);
     if (!c) { set_error("ik_lm: unknown chain handle"); return RTBHIP_EINVAL; }
     RTB_TRY(check_batch("ik_lm", Tep, N, mem));
-    if (method < 0 || method > 2) { set_error("ik_lm: method must be 0 chan, 1 wampler, 2 sugihara"); return RTBHIP_EINVAL; }
+    if (method < 0 || method > 4) { set_error("ik_lm: method must be 0 chan, 1 wampler, 2 sugihara, 3 gauss-newton, 4 newton-raphson"); return RTBHIP_EINVAL; }
     if (flavour < 0 || flavour > 1) { set_error("ik_lm: flavour must be 0 (ik_LM) or 1 (ikine_LM)"); return RTBHIP_EINVAL; }
     if (ilimit < 1 || slimit < 1) { set_error("ik_lm: ilimit and slimit must be >= 1"); return RTBHIP_EINVAL; }
     if (c->n < 1) { set_error("ik_lm: chain has no joints"); return RTBHIP_EINVAL; }

@@ -118,6 +118,43 @@ RTB_HD void ik_lm_step(const double (&jac)[6 * NJ], const double (&e)[6], const 
     ldl_solve<NJ>(A, g, dq);
 }
 
+// ---------------------------------------------------------------- Gauss-Newton / Newton-Raphson steps
+// _IK_GN (ik.cpp:79-120):  dq solves (J^T W J) dq = J^T W e  through an SVD (use_pinv) or a column-pivoted QR.
+// _IK_NR (ik.cpp:122-156): dq = J^+ e with the damped pseudo-inverse V diag(s/(s^2+d^2)) U^T (ik.cpp:211-226),
+//                          or J^-1 e for a 6-joint arm without pinv.
+// Both are minimum-norm solutions of J dq = e; with J of full row rank they are  dq = J_a^T (J_a J_a^T + d^2 I)^-1 e_a
+// exactly (the damped pseudo-inverse identity; for GN the positive weights drop out of the minimum-norm
+// solution, rows with a zero weight are simply absent).  That 6x6 symmetric system is solved in registers.
+// Deviation, covered by the statistical IK acceptance of SURVEY 8c: at a rank-deficient J the reference's
+// SVD truncates a singular value (GN) or divides by s^2 = 0 (NR), and GN's QR branch on a redundant arm
+// returns a basic rather than the minimum-norm solution; the search simply fails or restarts here.
+template <int NJ>
+RTB_HD void ik_pinv_step(const double (&jac)[6 * NJ], const double (&e)[6], int rows, double damping, double (&dq)[NJ])
+{
+    double B[6][6], y[6], g[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const bool ur = (rows >> r) & 1;
+        g[r] = ur ? e[r] : 0.0;
+#pragma unroll
+        for (int c = 0; c <= r; ++c) {
+            const bool uc = (rows >> c) & 1;
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < NJ; ++k) s += jac[r * NJ + k] * jac[c * NJ + k];
+            B[r][c] = (ur && uc) ? (r == c ? s + damping * damping : s) : (r == c ? 1.0 : 0.0);
+        }
+    }
+    ldl_solve<6>(B, g, y);
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) {
+        double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) s += jac[r * NJ + k] * y[r];
+        dq[k] = s;
+    }
+}
+
 // ---------------------------------------------------------------- searches as pure functions
 // The reference runs, per target, up to `slimit` SEARCHES one after another; each search starts from
 // a given or random q and takes at most `ilimit` LM steps (ik.cpp:39-72, IK.py:297-367).  With the
@@ -221,8 +258,18 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, Q
 #pragma unroll
     for (int k = 0; k < 6; ++k) E += e[k] * p.we[k] * e[k];
     E *= 0.5;                                                   // ik.cpp:46
-    const double wn = (p.method == 1) ? p.lambda : (p.method == 2) ? E + p.lambda : p.lambda * E;   // ik.cpp:169,183,205
-    ik_lm_step<NJ>(jac, e, p.we, wn, dq);
+    if (p.method >= 3) {            // 3 Gauss-Newton, 4 Newton-Raphson: `lambda` carries pinv_damping (NR only)
+        int rows = 63;
+        if (p.method == 3) {
+            rows = 0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) rows |= (p.we[k] != 0.0) ? (1 << k) : 0;
+        }
+        ik_pinv_step<NJ>(jac, e, rows, p.method == 4 ? p.lambda : 0.0, dq);
+    } else {
+        const double wn = (p.method == 1) ? p.lambda : (p.method == 2) ? E + p.lambda : p.lambda * E;   // ik.cpp:169,183,205
+        ik_lm_step<NJ>(jac, e, p.we, wn, dq);
+    }
     if (st.status != kIkRun) return;
     st.E = E;
     const bool arrived = E < p.tol;

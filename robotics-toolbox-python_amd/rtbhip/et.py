@@ -23,7 +23,7 @@ from . import _lib
 from ._lib import check, lib, as_numeric, small, host_ptr, is_torch, MEM_HOST, MEM_DEVICE
 
 _AXES = {"Rx": 0, "Ry": 1, "Rz": 2, "tx": 3, "ty": 4, "tz": 5}
-_METHODS = {"chan": 0, "wampler": 1, "sugihara": 2}
+_METHODS = {"chan": 0, "wampler": 1, "sugihara": 2, "gn": 3, "nr": 4}
 
 
 def _elementary(axis, eta):
@@ -477,6 +477,28 @@ class ETS:
         -> IK_LM_c core/fknm.cpp:394-525).  One Tep -> the reference's 5-tuple
         (q, success, iterations, searches, residual); Tep (N,4,4) -> the same tuple of arrays."""
         single, q, ok, it, se, E = self._ik(Tep, q0, ilimit, slimit, tol, mask, joint_limits, k, method, 0, seed)
+        if single:
+            return q[0], int(ok[0]), int(it[0]), int(se[0]), float(E[0])
+        return q, ok, it, se, E
+
+    def ik_GN(self, Tep, q0=None, ilimit=30, slimit=100, tol=1e-6, mask=None, joint_limits=True, pinv=True,
+              pinv_damping=0.0, seed=0):
+        """Gauss-Newton IK on the GPU (reference ETS.ik_GN robot/ETS.py:2316-2442 -> IK_GN_c): same search loop,
+        minimum-norm step of (J^T W J) dq = J^T W e.  `pinv=False` on a 6-joint arm is the same unique step;
+        on a redundant arm the reference's QR branch returns a different (basic) solution of the singular system."""
+        single, q, ok, it, se, E = self._ik(Tep, q0, ilimit, slimit, tol, mask, joint_limits, 0.0, "gn", 0, seed)
+        if single:
+            return q[0], int(ok[0]), int(it[0]), int(se[0]), float(E[0])
+        return q, ok, it, se, E
+
+    def ik_NR(self, Tep, q0=None, ilimit=30, slimit=100, tol=1e-6, mask=None, joint_limits=True, pinv=True,
+              pinv_damping=0.0, seed=0):
+        """Newton-Raphson IK on the GPU (reference ETS.ik_NR robot/ETS.py:2172-2298 -> IK_NR_c): dq = J^+ e with
+        the damped pseudo-inverse (core/ik.cpp:211-226).  Redundant arms need pinv (the reference forces it)."""
+        if not pinv and self.n != 6:
+            pinv = True                                       # ik.cpp:128-129
+        single, q, ok, it, se, E = self._ik(Tep, q0, ilimit, slimit, tol, mask, joint_limits,
+                                            float(pinv_damping) if pinv else 0.0, "nr", 0, seed)
         if single:
             return q[0], int(ok[0]), int(it[0]), int(se[0]), float(E[0])
         return q, ok, it, se, E

@@ -52,6 +52,8 @@ class ERobot:
     def jacobm(self, q, axes="all", **kw): return self._ets.jacobm(q, axes=axes, tool=self.tool)
 
     def ik_LM(self, Tep, **kw): return self._ets.ik_LM(Tep, **kw)
+    def ik_GN(self, Tep, **kw): return self._ets.ik_GN(Tep, **kw)
+    def ik_NR(self, Tep, **kw): return self._ets.ik_NR(Tep, **kw)
     def ikine_LM(self, Tep, **kw): return self._ets.ikine_LM(Tep, **kw)
 
 

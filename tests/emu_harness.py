@@ -197,7 +197,7 @@ def dyn(L24, mdh, mode, q, qd=None, torque=None, grav_c=None):
     return out
 
 
-METHODS = {"chan": 0, "wampler": 1, "sugihara": 2}
+METHODS = {"chan": 0, "wampler": 1, "sugihara": 2, "gn": 3, "nr": 4}
 
 
 def ik(ets, Tep, q0=None, ilimit=30, slimit=100, tol=1e-6, joint_limits=True, mask=None, k=1.0, method="chan",

@@ -175,6 +175,26 @@ def main():
         out["ik_%s_q" % meth] = np.array([r[0] for r in res])
         out["ik_%s_meta" % meth] = np.array([[r[1], r[2], r[3]] for r in res], dtype=np.int64)
         out["ik_%s_E" % meth] = np.array([r[4] for r in res])
+    # Gauss-Newton / Newton-Raphson (IK_GN_c / IK_NR_c), same targets and starts; + a 6-joint arm without pinv
+    for meth, fn in (("gn", ref.ik_GN), ("nr", ref.ik_NR)):
+        res = [fn(Tep[i], q0=q0[i]) for i in range(len(qs))]
+        out["ik_%s_q" % meth] = np.array([r[0] for r in res])
+        out["ik_%s_meta" % meth] = np.array([[r[1], r[2], r[3]] for r in res], dtype=np.int64)
+        out["ik_%s_E" % meth] = np.array([r[4] for r in res])
+    res = [ref.ik_NR(Tep[i], q0=q0[i], pinv_damping=0.05) for i in range(len(qs))]
+    out["ik_nrd_q"] = np.array([r[0] for r in res])
+    out["ik_nrd_meta"] = np.array([[r[1], r[2], r[3]] for r in res], dtype=np.int64)
+    pets = puma.ets()
+    pets.qlim = np.array([puma.qlim[:, 0], puma.qlim[:, 1]])
+    refp6 = rh.RefETS(pets)
+    qs6 = rng.uniform(puma.qlim[:, 0], puma.qlim[:, 1], (16, 6))
+    T6 = refp6.fkine(qs6)
+    q06 = qs6 + 0.05 * rng.normal(size=qs6.shape)
+    out["ik6_Tep"], out["ik6_q0"] = T6, q06
+    for meth, fn in (("gn", refp6.ik_GN), ("nr", refp6.ik_NR)):
+        res = [fn(T6[i], q0=q06[i], pinv=False) for i in range(len(qs6))]
+        out["ik6_%s_q" % meth] = np.array([r[0] for r in res])
+        out["ik6_%s_meta" % meth] = np.array([[r[1], r[2], r[3]] for r in res], dtype=np.int64)
     np.savez_compressed(os.path.join(HERE, "ref_outputs.npz"), **out)
     print("wrote ref_outputs.npz with", len(out), "arrays,",
           os.path.getsize(os.path.join(HERE, "ref_outputs.npz")), "bytes")

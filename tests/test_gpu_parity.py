@@ -383,6 +383,36 @@ def test_ik_reference_run_fixtures_first_search():
         nt.assert_allclose(q[first], REF["ik_%s_q" % method][first], atol=1e-6)
 
 
+def test_ik_gn_nr_reference_fixtures_and_statistics():
+    """IK_GN_c / IK_NR_c through the same device scheduler (method 3 / 4): first-search cases equal the
+    reference's own outputs; over random reachable targets every reported success satisfies E < tol and
+    the limits, and the success rate is not below the reference's own on its fixture sample."""
+    ets, ch = _panda_limited()
+    puma = rtbhip.models.DH.Puma560().ets()
+    puma.qlim = chains.puma560().qlim.T
+    for key, e, Tep, q0, fn, kw in (("ik_gn", ets, REF["ik_Tep"], REF["ik_q0"], "ik_GN", {}),
+                                    ("ik_nr", ets, REF["ik_Tep"], REF["ik_q0"], "ik_NR", {}),
+                                    ("ik_nrd", ets, REF["ik_Tep"], REF["ik_q0"], "ik_NR", dict(pinv_damping=0.05)),
+                                    ("ik6_gn", puma, REF["ik6_Tep"], REF["ik6_q0"], "ik_GN", dict(pinv=False)),
+                                    ("ik6_nr", puma, REF["ik6_Tep"], REF["ik6_q0"], "ik_NR", dict(pinv=False))):
+        q, ok, it, se, E = getattr(e, fn)(Tep, q0=q0, **kw)
+        meta = REF[key + "_meta"]
+        first = (meta[:, 2] == 1) & (meta[:, 0] == 1)
+        nt.assert_array_equal(np.c_[ok, it, se][first], meta[first])
+        nt.assert_allclose(q[first], REF[key + "_q"][first], atol=1e-6)
+    rng = np.random.default_rng(12)
+    N = 5000
+    Tep = oracle.fkine(ch, rng.uniform(ch.qlim[0], ch.qlim[1], (N, 7)))
+    for fn, ref_rate in (("ik_GN", REF["ik_gn_meta"][:, 0].mean()), ("ik_NR", REF["ik_nr_meta"][:, 0].mean())):
+        q, ok, it, se, E = getattr(ets, fn)(Tep, seed=5)
+        good = ok == 1
+        assert good.mean() >= min(0.9, ref_rate) - 0.03
+        assert np.all(E[good] < 1e-6)
+        assert np.all(q[good] >= ch.qlim[0] - 1e-12) and np.all(q[good] <= ch.qlim[1] + 1e-12)
+        err = np.abs(oracle.fkine(ch, q[good]) - Tep[good]).reshape(good.sum(), -1).max(axis=1)
+        assert err.max() < 2e-3                       # E = e.e/2 < 1e-6  =>  |e| < 1.5e-3
+
+
 def test_ik_config3_1e5_targets_statistics():
     """BASELINE configs[2]: 1e5 random reachable targets, Franka limits, defaults
     (ilimit 30, slimit 100, tol 1e-6, chan, k=1).  Every reported success must satisfy E < tol,

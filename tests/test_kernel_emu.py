@@ -287,3 +287,25 @@ def test_hessian_register_path_equals_oracle_and_lds_tile_path(N):
     q3 = rng.uniform(-1, 1, (N, 3))
     _, _, Ht = emu.kin(three, q3, want=("H",))
     nt.assert_allclose(emu.hess_reg(three, q3), Ht, atol=1e-13)
+
+
+def test_ik_gn_nr_reference_run_fixtures_first_search():
+    """IK_GN_c / IK_NR_c (the reference's own extension, tests/golden/ref_outputs.npz): where the first
+    search converges no RNG is involved and the minimum-norm step equals the reference's SVD / QR / damped
+    pseudo-inverse step to rounding: same (success, iterations, searches), q to 1e-6."""
+    ets, _ = _panda_limited()
+    puma = rtbhip.models.DH.Puma560().ets()
+    puma.qlim = chains.puma560().qlim.T
+    n_checked = 0
+    for key, e, Tep, q0, kw in (("ik_gn", ets, REF["ik_Tep"], REF["ik_q0"], dict(method="gn")),
+                                ("ik_nr", ets, REF["ik_Tep"], REF["ik_q0"], dict(method="nr", k=0.0)),
+                                ("ik_nrd", ets, REF["ik_Tep"], REF["ik_q0"], dict(method="nr", k=0.05)),
+                                ("ik6_gn", puma, REF["ik6_Tep"], REF["ik6_q0"], dict(method="gn")),
+                                ("ik6_nr", puma, REF["ik6_Tep"], REF["ik6_q0"], dict(method="nr", k=0.0))):
+        q, ok, it, se, E = emu.ik(e, Tep, q0=q0, **kw)
+        meta = REF[key + "_meta"]
+        first = (meta[:, 2] == 1) & (meta[:, 0] == 1)
+        n_checked += int(first.sum())
+        nt.assert_array_equal(np.c_[ok, it, se][first], meta[first])
+        nt.assert_allclose(q[first], REF[key + "_q"][first], atol=1e-6)
+    assert n_checked >= 40
