@@ -43,7 +43,6 @@ def main():
     import numpy as np
     import torch
     import rtbhip
-    from oracle import chains
     torch.cuda.set_device(0)
     for kv in args.tune:
         k, v = kv.split("=")
@@ -53,9 +52,9 @@ def main():
     if "rne" in what:
         N = args.n_rne
         rob = rtbhip.models.DH.Panda()
-        tab = chains.panda_dh()
+        ql = rob.qlim
         rng = np.random.default_rng(3)
-        qh = rng.uniform(tab.qlim[:, 0], tab.qlim[:, 1], (N, 7))
+        qh = rng.uniform(ql[0], ql[1], (N, 7))
         qdh, qddh = rng.normal(size=(N, 7)), rng.normal(size=(N, 7))
         q, qd, qdd = (torch.from_numpy(x).cuda() for x in (qh, qdh, qddh))
         avg, best = ev_time(lambda: rob.rne(q, qd, qdd), args.steps, 3)
@@ -66,7 +65,7 @@ def main():
         if not args.no_cpu:
             from oracle import ref_harness
             if ref_harness.available():
-                ref = ref_harness.RefRNE(tab.L24(), 1)
+                ref = ref_harness.RefRNE(rob.L24(), 1)
                 n = 100000
                 t0 = time.perf_counter(); tau = ref.rne(qh[:n], qdh[:n], qddh[:n]); dt = time.perf_counter() - t0
                 g = rob.rne(q[:n], qd[:n], qdd[:n]).cpu().numpy()
@@ -79,9 +78,9 @@ def main():
         # M(q), C(q,qd), forward dynamics for the DH Panda, one fused kernel each
         N = args.n_dyn
         rob = rtbhip.models.DH.Panda()
-        tab = chains.panda_dh()
+        ql = rob.qlim
         rng = np.random.default_rng(6)
-        q = torch.from_numpy(rng.uniform(tab.qlim[:, 0], tab.qlim[:, 1], (N, 7))).cuda()
+        q = torch.from_numpy(rng.uniform(ql[0], ql[1], (N, 7))).cuda()
         qd = torch.from_numpy(rng.normal(size=(N, 7))).cuda()
         tq = torch.from_numpy(rng.normal(size=(N, 7)) * 5).cuda()
         for name, fn, passes, byts in (("inertia", lambda: rob.inertia(q), 7, 56 + 392),
@@ -96,7 +95,7 @@ def main():
             if not args.no_cpu and name == "inertia":
                 from oracle import ref_harness
                 if ref_harness.available():
-                    ref = ref_harness.RefRNE(tab.L24(), 1)
+                    ref = ref_harness.RefRNE(rob.L24(), 1)
                     n = 3000
                     qh = q[:n].cpu().numpy()
                     t0 = time.perf_counter()
@@ -141,10 +140,9 @@ def main():
     if "ik" in what:
         N = args.n_ik
         ets = rtbhip.models.Panda().ets()
-        ets.qlim = chains.PANDA_QLIM
-        ch = chains.panda_ets(with_limits=True)
+        ets.qlim = rtbhip.models.PANDA_QLIM
         rng = np.random.default_rng(1)
-        qs = torch.from_numpy(rng.uniform(ch.qlim[0], ch.qlim[1], (N, 7))).cuda()
+        qs = torch.from_numpy(rng.uniform(ets.qlim[0], ets.qlim[1], (N, 7))).cuda()
         Tep = ets.eval(qs)
         res = {}
         def run():
@@ -156,9 +154,9 @@ def main():
                 "success_rate": float(ok.float().mean()), "mean_iterations": float(it.float().mean()),
                 "max_iterations": int(it.max()), "lm_iterations_per_s": float(it.sum()) / (avg * 1e-3)}
         if not args.no_cpu:
-            from oracle import ref_harness
+            from oracle import ref_harness, chains
             if ref_harness.available():
-                ref = ref_harness.RefETS(ch)
+                ref = ref_harness.RefETS(chains.panda_ets(with_limits=True))
                 n = 2000
                 Th = Tep[:n].cpu().numpy()
                 t0 = time.perf_counter()

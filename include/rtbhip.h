@@ -101,13 +101,14 @@ int rtbhip_hessian(rtbhip_chain_t chain, const double *q, int64_t N, const doubl
  * chains of up to 8 joints):
  *   rtbhip_jacob_dot       Robot.jacob0_dot (robot/Robot.py:964-1098, representation=None): Jd (N,6,n) = H(q) . qd,
  *                          frame 0 -> hessian0, 1 -> hessiane; qd is (N, q_width) like q
- *   rtbhip_manipulability  ETS.manipulability method "yoshikawa" (robot/ETS.py:1687-1819): m (N);
- *                          axes_mask bit r = Cartesian row r used (63 all, 7 trans, 56 rot)
+ *   rtbhip_manipulability  ETS.manipulability (robot/ETS.py:1687-1819): m (N); method 0 "yoshikawa",
+ *                          1 "minsingular", 2 "invcondition"; axes_mask bit r = Cartesian row r used
+ *                          (63 all, 7 trans, 56 rot)
  *   rtbhip_jacobm          ETS.jacobm / Robot.jacobm (robot/ETS.py:1628-1685, robot/Robot.py:1120-1235): Jm (N,n) */
 int rtbhip_jacob_dot(rtbhip_chain_t chain, const double *q, const double *qd, int64_t N, const double *tool16,
                      int32_t frame, double *Jd, int32_t mem, void *stream);
 int rtbhip_manipulability(rtbhip_chain_t chain, const double *q, int64_t N, const double *tool16, int32_t axes_mask,
-                          double *m, int32_t mem, void *stream);
+                          int32_t method, double *m, int32_t mem, void *stream);
 int rtbhip_jacobm(rtbhip_chain_t chain, const double *q, int64_t N, const double *tool16, int32_t axes_mask, double *Jm,
                   int32_t mem, void *stream);
 

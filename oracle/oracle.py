@@ -124,14 +124,18 @@ def _axes_list(axes):
     return [bool(a) for a in axes]
 
 
-def manipulability(ch, q, axes="all", tool=None):
-    """ETS.manipulability, method 'yoshikawa' (robot/ETS.py:1766-1819)."""
+def manipulability(ch, q, axes="all", tool=None, method="yoshikawa"):
+    """ETS.manipulability (robot/ETS.py:1766-1819): yoshikawa / invcondition / minsingular."""
     ax = _axes_list(axes)
     J = jacob(ch, q, tool, 0)
     out = np.zeros(J.shape[0])
     for k in range(J.shape[0]):
         Jk = J[k][ax, :]
-        if Jk.shape[0] == Jk.shape[1]:
+        if method == "invcondition":
+            out[k] = 1 / np.linalg.cond(Jk)
+        elif method == "minsingular":
+            out[k] = np.linalg.svd(Jk, compute_uv=False)[-1]
+        elif Jk.shape[0] == Jk.shape[1]:
             out[k] = abs(np.linalg.det(Jk))
         else:
             out[k] = np.sqrt(abs(np.linalg.det(Jk @ Jk.T)))

@@ -345,9 +345,10 @@ int rtbhip_jacob_dot(rtbhip_chain_t chain, const double *q, const double *qd, in
 }
 
 int rtbhip_manipulability(rtbhip_chain_t chain, const double *q, int64_t N, const double *tool16, int32_t axes_mask,
-                          double *m, int32_t mem, void *stream)
+                          int32_t method, double *m, int32_t mem, void *stream)
 {
-    return diff_entry("manipulability", chain, 1, axes_mask, q, nullptr, N, tool16, 0, m, mem, stream);
+    if (method < 0 || method > 2) { set_error("manipulability: method must be 0 yoshikawa, 1 minsingular, 2 invcondition"); return RTBHIP_EINVAL; }
+    return diff_entry("manipulability", chain, 1, (axes_mask & 63) | (method << 8), q, nullptr, N, tool16, 0, m, mem, stream);
 }
 
 int rtbhip_jacobm(rtbhip_chain_t chain, const double *q, int64_t N, const double *tool16, int32_t axes_mask, double *Jm,

@@ -78,6 +78,42 @@ RTB_HD double manipulability_yoshikawa(const double (&jac)[6 * NJ], int axes)
     return sqrt(fabs(det_lu<6>(B)));              // ETS.py:1786-1787
 }
 
+// Smallest singular value of J_a (mode 1, ETS.py:1793-1796 `minsingular`) or 1/cond_2(J_a) = s_min / s_max
+// (mode 2, :1789-1791 `condition`), from the eigenvalues of the smaller Gram matrix: J_a J_a^T when the row
+// count does not exceed the joint count, else J_a^T J_a.
+template <int NJ>
+RTB_HD double manipulability_singular(const double (&jac)[6 * NJ], int axes, int mode)
+{
+    int rows = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) rows += (axes >> r) & 1;
+    double lo = 1e300, hi = 0.0;
+    if (rows <= NJ) {
+        double B[6][6];
+        jjt_masked<NJ>(jac, axes, B);
+        jacobi_eigenvalues<6>(B);
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+            if ((axes >> r) & 1) { lo = B[r][r] < lo ? B[r][r] : lo; hi = B[r][r] > hi ? B[r][r] : hi; }
+    } else {
+        double G[NJ][NJ];
+#pragma unroll
+        for (int i = 0; i < NJ; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                double s = 0.0;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) s += ((axes >> r) & 1) ? jac[r * NJ + i] * jac[r * NJ + j] : 0.0;
+                G[i][j] = s; G[j][i] = s;
+            }
+        jacobi_eigenvalues<NJ>(G);
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) { lo = G[i][i] < lo ? G[i][i] : lo; hi = G[i][i] > hi ? G[i][i] : hi; }
+    }
+    lo = lo < 0.0 ? 0.0 : lo;
+    return mode == 1 ? sqrt(lo) : sqrt(lo / hi);
+}
+
 template <int NJ>
 RTB_HD void jacobm(const double (&jac)[6 * NJ], int axes, double (&jm)[NJ])
 {

@@ -201,7 +201,9 @@ __global__ __launch_bounds__(kWave, 2) void k_kin_diff(KinParams kp, DevChain dc
             __syncthreads();
         }
     } else if (MODE == kDiffManip) {
-        const double m = manipulability_yoshikawa<NJ>(jac, axes);
+        // axes: bits 0..5 = Cartesian rows, bits 8..9 = method (0 yoshikawa, 1 minsingular, 2 invcondition)
+        const int method = (axes >> 8) & 3;
+        const double m = method == 0 ? manipulability_yoshikawa<NJ>(jac, axes & 63) : manipulability_singular<NJ>(jac, axes & 63, method);
         if (cfg < kp.N) out[cfg] = m;                      // 8 bytes per lane, contiguous across the wave
     } else {
         double jm[NJ];

@@ -93,4 +93,42 @@ RTB_HD double det_lu(double (&a)[N][N])
     return det;
 }
 
+// Eigenvalues of a symmetric N x N matrix by cyclic Jacobi rotations with a fixed number of sweeps
+// (uniform control flow, every index static).  a is destroyed; its diagonal holds the eigenvalues on
+// return.  A zero off-diagonal element leaves its pair untouched (t = 0), so identity-embedded rows keep
+// their diagonal value exactly.  7 sweeps reach fp64 round-off for N <= 8 (quadratic convergence).
+template <int N>
+RTB_HD void jacobi_eigenvalues(double (&a)[N][N])
+{
+#pragma unroll 1
+    for (int sweep = 0; sweep < 7; ++sweep) {
+#pragma unroll
+        for (int p = 0; p < N - 1; ++p) {
+#pragma unroll
+            for (int q = p + 1; q < N; ++q) {
+                const double apq = a[p][q];
+                const bool skip = apq == 0.0;
+                const double tau = (a[q][q] - a[p][p]) / (2.0 * (skip ? 1.0 : apq));
+                double t = 1.0 / (fabs(tau) + sqrt(1.0 + tau * tau));
+                t = tau < 0.0 ? -t : t;
+                t = skip ? 0.0 : t;
+                const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+                a[p][p] -= t * apq;
+                a[q][q] += t * apq;
+                a[p][q] = 0.0;
+                a[q][p] = 0.0;
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    if (k != p && k != q) {
+                        const double akp = a[k][p], akq = a[k][q];
+                        const double np_ = c * akp - s * akq, nq_ = s * akp + c * akq;
+                        a[k][p] = np_; a[p][k] = np_;
+                        a[k][q] = nq_; a[q][k] = nq_;
+                    }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace rtbhip

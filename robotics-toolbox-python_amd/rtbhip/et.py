@@ -395,17 +395,17 @@ class ETS:
         return sum(1 << i for i, a in enumerate(ax) if a)
 
     def manipulability(self, q, method="yoshikawa", axes="all", tool=None):
-        """Yoshikawa manipulability: scalar or (N,) (reference ETS.manipulability robot/ETS.py:1687-1819).
-        'invcondition' / 'minsingular' need an SVD per configuration and are not offered on the GPU."""
-        if method != "yoshikawa":
-            if method in ("invcondition", "minsingular"):
-                raise NotImplementedError("method %r is not implemented in the GPU backend" % method)
+        """Manipulability measure: scalar or (N,) (reference ETS.manipulability robot/ETS.py:1687-1819):
+        "yoshikawa" sqrt|det(J J^T)|, "minsingular" the smallest singular value of J, "invcondition"
+        s_min / s_max (singular values from an in-register Jacobi eigen-solve of the Gram matrix)."""
+        methods = {"yoshikawa": 0, "minsingular": 1, "invcondition": 2}
+        if method not in methods:
             raise ValueError("Invalid method chosen")
         mask = self._axes_mask(axes)
         q2, single, tm = self._shape_q(q)
         N = q2.shape[0]
         m = self._out((N,), q2, tm)
-        check(lib().rtbhip_manipulability(self._handle(), self._ptr(q2, tm), N, host_ptr(small(tool, 16)), mask,
+        check(lib().rtbhip_manipulability(self._handle(), self._ptr(q2, tm), N, host_ptr(small(tool, 16)), mask, methods[method],
                                           self._ptr(m, tm), MEM_DEVICE if tm else MEM_HOST, self._stream(tm)))
         return float(m[0]) if single else m
 

@@ -461,7 +461,8 @@ static void diff_run(const KinParams &kp, const DevChain &cv, int mode, int axes
             jacob_dot<NJ>(jac, v, jd);
             for (int k = 0; k < 6 * NJ; ++k) out[s * 6 * NJ + k] = jd[k];
         } else if (mode == 1) {
-            out[s] = manipulability_yoshikawa<NJ>(jac, axes);
+            const int method = (axes >> 8) & 3;
+            out[s] = method == 0 ? manipulability_yoshikawa<NJ>(jac, axes & 63) : manipulability_singular<NJ>(jac, axes & 63, method);
         } else {
             double jm[NJ];
             jacobm<NJ>(jac, axes, jm);

@@ -36,10 +36,12 @@ def test_oracle_pins():
 
 
 def test_manipulability_goldens_reference_models():
-    """reference tests/test_ETS.py:4303-4334: URDF Panda at qr, URDF Puma560 at qn."""
+    """reference tests/test_ETS.py:4303-4353: URDF Panda at qr, URDF Puma560 at qn."""
     import emu_harness as emu
     p = urdf.load("Panda")
     qr = np.array([0, -0.3, 0, -2.2, 0, 2.0, np.pi / 4])
+    nt.assert_almost_equal(emu.diff(p.ets(), 1, qr, axes=63 | (2 << 8), tool=p.tool)[0], 0.11222, decimal=4)      # test_cond
+    nt.assert_almost_equal(emu.diff(p.ets(), 1, qr, axes=63 | (1 << 8), tool=p.tool)[0], 0.209013, decimal=4)     # test_minsingular
     for axes, mask, want in (("all", 63, 0.0837), ("trans", 7, 0.1438), ("rot", 56, 2.7455)):
         nt.assert_almost_equal(emu.diff(p.ets(), 1, qr, axes=mask, tool=p.tool)[0], want, decimal=4)
         nt.assert_almost_equal(oracle.manipulability(chain_from_ets(p.ets()), qr, axes, tool=p.tool)[0], want, decimal=4)
@@ -64,6 +66,10 @@ def test_emu_vs_oracle(name):
     for axes, mask in (("all", 63), ("trans", 7), ("rot", 56), ([True, False, True, True, False, True], 45)):
         m, ref = emu.diff(e, 1, q, axes=mask), oracle.manipulability(ch, q, axes)
         nt.assert_allclose(m, ref, rtol=1e-9, atol=1e-12)
+    for axes, mask in (("all", 63), ("trans", 7), ("rot", 56), ([True, False, True, True, False, True], 45)):
+        for method, code in (("minsingular", 1), ("invcondition", 2)):
+            m, ref = emu.diff(e, 1, q, axes=mask | (code << 8)), oracle.manipulability(ch, q, axes, method=method)
+            nt.assert_allclose(m, ref, rtol=1e-7, atol=1e-9)
     if e.n >= 6:
         for axes, mask in (("all", 63), ("trans", 7), ("rot", 56)):
             jm, ref = emu.diff(e, 2, q, axes=mask), oracle.jacobm(ch, q, axes)
@@ -91,8 +97,9 @@ def test_gpu_goldens_shapes_errors():
         panda.manipulability(qr, axes="abcdef")
     with pytest.raises(ValueError):
         panda.manipulability(qr, method="nonsense")
-    with pytest.raises(NotImplementedError):
-        panda.manipulability(qr, method="minsingular")
+    # reference tests/test_ETS.py:4339-4353 (URDF Panda at qr)
+    nt.assert_almost_equal(p.ets().manipulability(qr, method="invcondition", tool=p.tool), 0.11222, decimal=4)
+    nt.assert_almost_equal(p.ets().manipulability(qr, method="minsingular", tool=p.tool), 0.209013, decimal=4)
     nine = rtbhip.DHRobot([rtbhip.RevoluteDH(a=0.1) for _ in range(9)]).ets()
     with pytest.raises(rtbhip.RtbHipError):
         nine.manipulability(np.zeros(9))
@@ -115,6 +122,9 @@ def test_gpu_vs_oracle(N):
         for axes in ("all", "trans", "rot"):
             m = np.atleast_1d(e.manipulability(q, axes=axes))
             nt.assert_allclose(m[:k], oracle.manipulability(ch, q[:k], axes), rtol=1e-9, atol=1e-12)
+            for method in ("minsingular", "invcondition"):
+                m = np.atleast_1d(e.manipulability(q, axes=axes, method=method))
+                nt.assert_allclose(m[:k], oracle.manipulability(ch, q[:k], axes, method=method), rtol=1e-7, atol=1e-9)
             jm = e.jacobm(q, axes=axes).reshape(N, e.n)
             ref = oracle.jacobm(ch, q[:k], axes)
             nt.assert_allclose(jm[:k], ref, rtol=1e-7, atol=1e-9 * max(1.0, np.abs(ref).max()))
