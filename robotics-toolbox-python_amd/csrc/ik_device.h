@@ -30,6 +30,7 @@ constexpr double kIkPiHalf = 1.57079632679489661923132169163975144;
 struct IkDev {   // wave-uniform solver parameters (kernarg)
     int32_t ilimit, slimit, reject_jl, method, flavour, has_q0;
     int32_t fresh_cap, pool_chunk;   // scheduler: fresh targets a wave may start per pass / reserves per refill
+    int32_t pass_mask, pad;          // scheduler: the pass runs on iterations with (tick & pass_mask) == 0
     double tol, lambda;
     double we[6];
     uint64_t seed;
@@ -270,7 +271,7 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, Q
         const double wn = (p.method == 1) ? p.lambda : (p.method == 2) ? E + p.lambda : p.lambda * E;   // ik.cpp:169,183,205
         ik_lm_step<NJ>(jac, e, p.we, wn, dq);
     }
-    if (st.status != kIkRun) return;
+    if (st.status != kIkRun || st.fin) return;    // a search that has ended waits, untouched, for the next pass
     st.E = E;
     const bool arrived = E < p.tol;
     if (p.flavour == 0) {

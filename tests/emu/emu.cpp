@@ -191,6 +191,7 @@ struct EmuWave {
     unsigned long long busy = 0;
     bool exhausted = false, first = true, done = false, drained = false;
     unsigned long long pool_next = 0, pool_end = 0;
+    unsigned tick = 0;
     long long passes = 0, iters = 0, lane_iters_useful = 0;
 };
 
@@ -232,7 +233,7 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
             if (w.done) continue;
             bool anyfin = false;
             for (int l = 0; l < kWave; ++l) anyfin = anyfin || w.st[l].fin != 0;
-            if (w.first || anyfin) {
+            if (w.first || ((w.tick++ & p.pass_mask) == 0 && anyfin)) {
                 w.first = false;
                 w.passes++;
                 for (int l = 0; l < kWave; ++l) ik_report<NJ>(w.st[l], w.sh, s_last);
@@ -316,7 +317,7 @@ extern "C" int emu_ik(rtbhip_chain_t h, const double *Tep, int64_t N, const doub
     if (!c || c->n < 1 || c->n > kRegMaxJoints) return -1;
     IkDev p;
     p.ilimit = ilimit; p.slimit = slimit; p.reject_jl = reject_jl; p.method = method; p.flavour = flavour;
-    p.has_q0 = q0 != nullptr; p.tol = tol; p.lambda = lambda; p.seed = seed; p.N = N; p.fresh_cap = 64; p.pool_chunk = 64;
+    p.has_q0 = q0 != nullptr; p.tol = tol; p.lambda = lambda; p.seed = seed; p.N = N; p.fresh_cap = 64; p.pool_chunk = 64; p.pass_mask = 0; p.pad = 0;
     for (int k = 0; k < 6; ++k) p.we[k] = we6 ? we6[k] : 1.0;
     switch (c->n) {
     case 1: emu_ik_run<1>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
@@ -339,8 +340,9 @@ extern "C" int emu_ik_wave(rtbhip_chain_t h, int waves, double *stats, const dou
     if (!c || c->n < 1 || c->n > kRegMaxJoints) return -1;
     IkDev p;
     p.ilimit = ilimit; p.slimit = slimit; p.reject_jl = reject_jl; p.method = method; p.flavour = flavour;
-    p.has_q0 = q0 != nullptr; p.tol = tol; p.lambda = lambda; p.seed = seed; p.N = N; p.fresh_cap = 64; p.pool_chunk = 64;
+    p.has_q0 = q0 != nullptr; p.tol = tol; p.lambda = lambda; p.seed = seed; p.N = N; p.fresh_cap = 64; p.pool_chunk = 64; p.pass_mask = 0; p.pad = 0;
     for (int k = 0; k < 6; ++k) p.we[k] = we6 ? we6[k] : 1.0;
+    if (const char *pm = getenv("EMU_IK_PASS_MASK")) p.pass_mask = atoi(pm);
     { const int64_t g = waves; const int64_t cap = (N + g - 1) / g; p.fresh_cap = cap > 64 ? 64 : (int)cap;
       const int64_t lanes = g * kWave; p.pool_chunk = N >= 8 * lanes ? 64 : (N >= 3 * lanes ? 16 : 0); }
     int rc = 0;

@@ -265,6 +265,15 @@ def test_ik_wave_scheduler_equals_sequential_searches(flavour, N, waves, slimit,
     b = emu.ik(ets, Tep, q0=q0, slimit=slimit, flavour=flavour, seed=11, waves=waves, stats=st)
     for x, y in zip(a, b):
         nt.assert_array_equal(x, y)
+    import os
+    for mask in ("1", "3"):                      # the pass may run only every 2nd / 4th iteration: same outputs
+        os.environ["EMU_IK_PASS_MASK"] = mask
+        try:
+            c = emu.ik(ets, Tep, q0=q0, slimit=slimit, flavour=flavour, seed=11, waves=waves)
+        finally:
+            del os.environ["EMU_IK_PASS_MASK"]
+        for x, y in zip(a, c):
+            nt.assert_array_equal(x, y)
     assert a[1].sum() < N                        # the failures really are in the mix
     assert st[2] >= a[2].sum() - N * 2           # speculation only ever ADDS lane-iterations
 
