@@ -115,7 +115,7 @@ __device__ __forceinline__ void reg_tile(const KinParams &kp, const ConstChain &
 // (loop-invariant) scalar loads into the preheader, where they overflow the SGPR file and come back
 // as v_readlane pairs on each use.  The dispatcher balances the tiles instead.
 template <int NJ, bool WANT_T, bool WANT_J>
-__global__ __launch_bounds__(kWave, RTB_REG_WAVES) void k_kin_reg(KinParams kp, DevChain dc, const double *__restrict__ q,
+__global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints ? RTB_REG_WAVES : 2)) void k_kin_reg(KinParams kp, DevChain dc, const double *__restrict__ q,
                                                   double *__restrict__ T, double *__restrict__ J)
 {
     extern __shared__ __attribute__((aligned(16))) double buf[];
@@ -335,7 +335,7 @@ int launch_kin(const Chain *c, const DevChain &ops, const double *q, int64_t N, 
         if (e != hipSuccess) return hip_fail(e, "k_kin_hess launch");
         return RTBHIP_OK;
     }
-    if (g_use_reg && !H && c->n >= 1 && c->n <= kRegMaxJoints && tiles <= 0x7fffffff) {
+    if (g_use_reg && !H && c->n >= 1 && c->n <= kKinRegMax && tiles <= 0x7fffffff) {
         grid = dim3((unsigned)tiles);
         const size_t rl = (size_t)reg_lds_doubles(c->n) * sizeof(double);
         hipError_t e = hipSuccess;
@@ -347,7 +347,9 @@ int launch_kin(const Chain *c, const DevChain &ops, const double *q, int64_t N, 
         case 5: e = launch_reg<5>(grid, rl, s, kp, ops, q, T, J); break;
         case 6: e = launch_reg<6>(grid, rl, s, kp, ops, q, T, J); break;
         case 7: e = launch_reg<7>(grid, rl, s, kp, ops, q, T, J); break;
-        default: e = launch_reg<8>(grid, rl, s, kp, ops, q, T, J); break;
+        case 8: e = launch_reg<8>(grid, rl, s, kp, ops, q, T, J); break;
+        case 9: e = launch_reg<9>(grid, rl, s, kp, ops, q, T, J); break;
+        default: e = launch_reg<10>(grid, rl, s, kp, ops, q, T, J); break;
         }
         note_launch((int)grid.x, kWave, (int)rl);
         if (e != hipSuccess) return hip_fail(e, "k_kin_reg launch");
@@ -382,9 +384,12 @@ struct FleetArgs {
     int64_t tile_base;   // first global tile of this launch (launches are chunked at 2^31-1 workgroups)
 };
 
-// One tile per workgroup (no grid-stride loop, as k_kin_reg).  Chains of up to kRegMaxJoints joints run
-// the register-resident tile (switch on the wave-uniform joint count); longer ones the LDS tile.
-__global__ __launch_bounds__(kWave, RTB_REG_WAVES) void k_fleet(FleetArgs fa)
+// One tile per workgroup (no grid-stride loop, as k_kin_reg).  Three launch classes, because registers and
+// dynamic LDS are per-kernel / per-launch quantities: CLS 0 chains of 1..8 joints (register-resident tile, 3
+// waves per SIMD), CLS 1 chains of 9..10 joints (register-resident, 2 waves per SIMD), CLS 2 longer chains
+// (LDS tile).  Inside a class the joint count of a tile is wave-uniform: a switch picks the tile body.
+template <int CLS>
+__global__ __launch_bounds__(kWave, (CLS == 0 ? RTB_REG_WAVES : 2)) void k_fleet(FleetArgs fa)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
@@ -400,16 +405,21 @@ __global__ __launch_bounds__(kWave, RTB_REG_WAVES) void k_fleet(FleetArgs fa)
     for (int k = 0; k < 9; ++k) kp.tail[k] = ops.seg[fe.n].r[k];
     for (int k = 0; k < 3; ++k) kp.tail[9 + k] = ops.seg[fe.n].t[k];
     const int64_t tile = gt - fe.tile0;
-    switch (fe.n) {
-    case 1: reg_tile<1, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
-    case 2: reg_tile<2, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
-    case 3: reg_tile<3, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
-    case 4: reg_tile<4, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
-    case 5: reg_tile<5, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
-    case 6: reg_tile<6, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
-    case 7: reg_tile<7, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
-    case 8: reg_tile<8, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
-    default: break;
+    if (CLS == 0) {
+        switch (fe.n) {
+        case 1: reg_tile<1, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
+        case 2: reg_tile<2, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
+        case 3: reg_tile<3, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
+        case 4: reg_tile<4, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
+        case 5: reg_tile<5, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
+        case 6: reg_tile<6, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
+        case 7: reg_tile<7, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
+        default: reg_tile<8, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
+        }
+    } else if (CLS == 1) {
+        if (fe.n == 9) reg_tile<9, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile);
+        else reg_tile<10, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile);
+        return;
     }
     double *rows = lds;
     double *qs = lds + kWave * kp.stride;
@@ -428,20 +438,21 @@ __global__ __launch_bounds__(kWave, RTB_REG_WAVES) void k_fleet(FleetArgs fa)
     kin_flush(rows, kp.stride, 16, ncfg, fe.T + cfg0 * 16, lane);
 }
 
-// Dynamic LDS is a per-launch quantity and the LDS-tile chains (n > 8) need 3-5x what the
-// register-resident ones do, so a mixed fleet is walked as (at most) two launches, one per class --
-// otherwise the few long chains would cap every workgroup of the launch at 4 per CU.
-static int launch_fleet_class(const std::vector<FleetEntry> &entries, int frame, hipStream_t s);
+// Dynamic LDS and the register budget are per-launch quantities, so a mixed fleet is walked as (at most)
+// three launches, one per class -- a single launch capped every workgroup at 4 per CU (2.32 vs 1.57 ms for the
+// 16-arm fleet of BASELINE config 5).
+static int fleet_class_of(int n) { return n <= kRegMaxJoints ? 0 : (n <= kKinRegMax ? 1 : 2); }
+static int launch_fleet_class(int cls, const std::vector<FleetEntry> &entries, int frame, hipStream_t s);
 int launch_fleet(const std::vector<FleetEntry> &all, int frame, hipStream_t s)
 {
-    std::vector<FleetEntry> reg, tile;
-    for (const FleetEntry &e : all) (e.n <= kRegMaxJoints ? reg : tile).push_back(e);
-    if (!reg.empty()) { int rc = launch_fleet_class(reg, frame, s); if (rc != RTBHIP_OK) return rc; }
-    if (!tile.empty()) { int rc = launch_fleet_class(tile, frame, s); if (rc != RTBHIP_OK) return rc; }
+    std::vector<FleetEntry> by[3];
+    for (const FleetEntry &e : all) by[fleet_class_of(e.n)].push_back(e);
+    for (int c = 0; c < 3; ++c)
+        if (!by[c].empty()) { int rc = launch_fleet_class(c, by[c], frame, s); if (rc != RTBHIP_OK) return rc; }
     return RTBHIP_OK;
 }
 
-static int launch_fleet_class(const std::vector<FleetEntry> &entries, int frame, hipStream_t s)
+static int launch_fleet_class(int cls, const std::vector<FleetEntry> &entries, int frame, hipStream_t s)
 {
     for (size_t first = 0; first < entries.size(); first += kFleetMax) {
         FleetArgs fa;
@@ -455,19 +466,22 @@ static int launch_fleet_class(const std::vector<FleetEntry> &entries, int frame,
             fa.e[i].stride = kin_stride(fa.e[i].n);
             fa.e[i].tile0 = tiles;
             tiles += (fa.e[i].N + kWave - 1) / kWave;
-            lds = std::max(lds, fa.e[i].n <= kRegMaxJoints ? (size_t)reg_lds_doubles(fa.e[i].n) * sizeof(double)
-                                                            : kin_lds_bytes(fa.e[i].n, fa.e[i].q_width));
+            lds = std::max(lds, cls < 2 ? (size_t)reg_lds_doubles(fa.e[i].n) * sizeof(double)
+                                        : kin_lds_bytes(fa.e[i].n, fa.e[i].q_width));
         }
         fa.tiles = tiles;
         if (lds > 160 * 1024) { set_error("fleet: chain too large for LDS staging"); return RTBHIP_ELIMIT; }
+        const void *kfn = cls == 0 ? (const void *)k_fleet<0> : (cls == 1 ? (const void *)k_fleet<1> : (const void *)k_fleet<2>);
         if (lds > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void *)k_fleet, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return hip_fail(e, "k_fleet attr");
         }
         for (int64_t t0 = 0; t0 < tiles; t0 += 0x7fffffff) {
             const int64_t g = std::min<int64_t>(0x7fffffff, tiles - t0);
             fa.tile_base = t0;
-            hipLaunchKernelGGL(k_fleet, dim3((unsigned)g), dim3(kWave), lds, s, fa);
+            if (cls == 0) hipLaunchKernelGGL(k_fleet<0>, dim3((unsigned)g), dim3(kWave), lds, s, fa);
+            else if (cls == 1) hipLaunchKernelGGL(k_fleet<1>, dim3((unsigned)g), dim3(kWave), lds, s, fa);
+            else hipLaunchKernelGGL(k_fleet<2>, dim3((unsigned)g), dim3(kWave), lds, s, fa);
             note_launch((int)g, kWave, (int)lds);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return hip_fail(e, "k_fleet launch");

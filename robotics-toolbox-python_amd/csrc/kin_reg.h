@@ -18,7 +18,8 @@
 
 namespace rtbhip {
 
-constexpr int kRegMaxJoints = 8;
+constexpr int kRegMaxJoints = 8;    // register-resident consumers (IK, Hessian, jacob_dot, manipulability ...)
+constexpr int kKinRegMax = 10;      // fkine / Jacobian tiles: 9 and 10 joints still fit the register file at 2 waves per SIMD
 #ifndef RTB_JROUND
 #define RTB_JROUND 32
 #endif

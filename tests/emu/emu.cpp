@@ -99,7 +99,7 @@ extern "C" int emu_kin_reg(rtbhip_chain_t h, const double *q, int64_t N, const d
                            int frame, double *T, double *J)
 {
     Chain *c = chain_from_handle(h);
-    if (!c || c->n < 1 || c->n > kRegMaxJoints) return -1;
+    if (!c || c->n < 1 || c->n > kKinRegMax) return -1;
     KinParams kp;
     kp.n = c->n; kp.qw = c->q_width; kp.stride = kin_stride(c->n);
     kp.frame = frame; kp.N = N; kp.pad = 0;
@@ -116,7 +116,9 @@ extern "C" int emu_kin_reg(rtbhip_chain_t h, const double *q, int64_t N, const d
     case 5: emu_reg_run<5>(kp, cv, q, N, T, J); break;
     case 6: emu_reg_run<6>(kp, cv, q, N, T, J); break;
     case 7: emu_reg_run<7>(kp, cv, q, N, T, J); break;
-    default: emu_reg_run<8>(kp, cv, q, N, T, J); break;
+    case 8: emu_reg_run<8>(kp, cv, q, N, T, J); break;
+    case 9: emu_reg_run<9>(kp, cv, q, N, T, J); break;
+    default: emu_reg_run<10>(kp, cv, q, N, T, J); break;
     }
     return 0;
 }

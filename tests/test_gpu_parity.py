@@ -136,7 +136,7 @@ def test_huge_and_nonfinite_joint_values():
     assert np.isnan(T[9]).any() and not np.isnan(np.delete(T, 9, axis=0)).any()
 
 
-@pytest.mark.parametrize("n", [1, 2, 5, 11, 16, 23])
+@pytest.mark.parametrize("n", [1, 2, 5, 8, 9, 10, 11, 16, 23])
 def test_joint_counts(n):
     rng = np.random.default_rng(n)
     axes = ["Rx", "Ry", "Rz", "tx", "ty", "tz"]

@@ -64,7 +64,7 @@ def test_register_variant_ragged_tiles(N):
     nt.assert_allclose(J, oracle.jacob0(ch, q), atol=1e-12)
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 8])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 8, 9, 10])
 def test_register_variant_joint_counts(n):
     rng = np.random.default_rng(40 + n)
     axes = ["Rx", "Ry", "Rz", "tx", "ty", "tz"]
