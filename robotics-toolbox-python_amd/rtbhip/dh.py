@@ -168,6 +168,19 @@ class DHRobot:
     def jacob0(self, q, **kw): return self.ets().jacob0(q)
     def jacobe(self, q, **kw): return self.ets().jacobe(q)
 
+    # the Robot-level pass-throughs a DHRobot inherits in the reference (robot/RobotKinematics.py, robot/Robot.py):
+    # everything goes through the lowered ETS (base and tool are part of it, the link qlim travel with the joints)
+    def hessian0(self, q=None, **kw): return self.ets().hessian0(q)
+    def hessiane(self, q=None, **kw): return self.ets().hessiane(q)
+    def jacob0_dot(self, q, qd, **kw): return self.ets().jacob0_dot(q, qd)
+    def manipulability(self, q, method="yoshikawa", axes="all", **kw):
+        return self.ets().manipulability(q, method=method, axes=axes)
+    def jacobm(self, q, axes="all", **kw): return self.ets().jacobm(q, axes=axes)
+    def ik_LM(self, Tep, **kw): return self.ets().ik_LM(Tep, **kw)
+    def ik_GN(self, Tep, **kw): return self.ets().ik_GN(Tep, **kw)
+    def ik_NR(self, Tep, **kw): return self.ets().ik_NR(Tep, **kw)
+    def ikine_LM(self, Tep, **kw): return self.ets().ikine_LM(Tep, **kw)
+
     # ------------------------------------------------------------ dynamics
     def L24(self):
         """The 24-double/link block of reference robot/DHRobot.py:1342-1358."""

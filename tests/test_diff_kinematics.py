@@ -138,3 +138,25 @@ def test_gpu_vs_oracle(N):
         nt.assert_array_equal(e.jacob0_dot(qt, qdt).cpu().numpy().reshape(N, 6, e.n), Jd)
         nt.assert_array_equal(np.atleast_1d(e.manipulability(qt).cpu().numpy() if N > 1 else e.manipulability(qt)),
                               np.atleast_1d(e.manipulability(q)))
+
+
+@pytest.mark.gpu
+def test_gpu_dhrobot_passthroughs_puma_goldens():
+    """reference tests/test_DHRobot.py:1264-1290 (test_yoshi on the DH Puma560 at qn) and an IK round trip."""
+    puma = rtbhip.models.DH.Puma560()
+    qn = puma.qn
+    nt.assert_almost_equal(puma.manipulability(qn), 0.0786, decimal=4)
+    m2 = puma.manipulability(np.c_[qn, qn].T)
+    nt.assert_almost_equal(m2[0], 0.0786, decimal=4)
+    nt.assert_almost_equal(puma.manipulability(qn, axes="trans"), 0.111181, decimal=4)
+    nt.assert_almost_equal(puma.manipulability(qn, axes="rot"), 2.44949, decimal=4)
+    Tep = puma.fkine(qn)
+    for fn in (puma.ik_LM, puma.ik_GN, puma.ik_NR):
+        q, ok, it, se, E = fn(Tep, seed=1)
+        assert ok == 1 and E < 1e-6
+        nt.assert_allclose(puma.fkine(q), Tep, atol=2e-3)
+    sol = puma.ikine_LM(Tep, seed=1)
+    assert sol.success and sol.residual < 1e-6
+    qd = [0.1, -0.2, 0.3, -0.4, 0.5, -0.6]
+    H = puma.hessian0(qn)
+    nt.assert_allclose(puma.jacob0_dot(qn, qd), np.tensordot(H, qd, (0, 0)), atol=1e-12)
