@@ -112,3 +112,39 @@ def test_gpu_fleet16_urdf_arms_one_launch_vs_oracle():
         Tb, Jb = c.fkine_jacob0(q)                       # the per-chain kernels agree with the fleet kernel
         nt.assert_allclose(T, np.reshape(Tb, T.shape), atol=1e-13)
         nt.assert_allclose(J, np.reshape(Jb, J.shape), atol=1e-13)
+
+
+@pytest.mark.gpu
+def test_gpu_full_size_fleet16_1e6_each_properties_and_sampled_parity():
+    """BASELINE configs[4] at full size: 16 URDF arms x 1e6 configurations, device resident, one fleet call.
+    Size-independent properties over every row (rotation blocks orthonormal with det +1, bottom row 0 0 0 1,
+    angular Jacobian columns of revolute joints unit length, prismatic ones zero) + oracle parity on a sample."""
+    import torch
+    N = 1000000
+    robots = [urdf.load(n) for n in urdf.FLEET16]
+    chs = [r.ets() for r in robots]
+    qs = []
+    for i, c in enumerate(chs):
+        ql = np.clip(c.qlim, -2 * np.pi, 2 * np.pi)
+        g = torch.Generator(device="cuda").manual_seed(4 + i)
+        lo, hi = (torch.from_numpy(x).cuda() for x in (ql[0], ql[1]))
+        qs.append(lo + (hi - lo) * torch.rand((N, c.n), dtype=torch.float64, device="cuda", generator=g))
+    Ts, Js = rtbhip.fleet_fkine_jacob(chs, qs)
+    torch.cuda.synchronize()
+    eye = torch.eye(3, dtype=torch.float64, device="cuda")
+    for c, q, T, J in zip(chs, qs, Ts, Js):
+        R = T[:, :3, :3]
+        assert float((R @ R.transpose(1, 2) - eye).abs().max()) < 1e-12
+        assert float((torch.linalg.det(R) - 1).abs().max()) < 1e-12
+        assert bool((T[:, 3, :] == torch.tensor([0.0, 0, 0, 1], dtype=torch.float64, device="cuda")).all())
+        wn = torch.linalg.norm(J[:, 3:, :], dim=1)                       # (N, n)
+        rev = torch.tensor([e.isrotation for e in c.joints()], device="cuda")
+        assert float((wn[:, rev] - 1).abs().max()) < 1e-12
+        if (~rev).any():
+            assert float(wn[:, ~rev].abs().max()) == 0.0
+        idx = torch.randint(0, N, (64,), device="cuda")
+        oc = chain_from_ets(c)
+        qh = q[idx].cpu().numpy()
+        nt.assert_allclose(T[idx].cpu().numpy(), oracle.fkine(oc, qh), atol=TOL)
+        nt.assert_allclose(J[idx].cpu().numpy(), oracle.jacob0(oc, qh), atol=TOL)
+        del T, J
