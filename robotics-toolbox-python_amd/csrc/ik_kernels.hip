@@ -131,7 +131,22 @@ __global__ __launch_bounds__(kWave, RTB_IK_WAVES) void k_ik(IkDev p, DevChain dc
             }
         }
         if (busy == 0 && exhausted) break;
-        if (++quiet > patience) break;      // never expected; unresolved targets keep their memset outputs
+        if (++quiet > patience) {
+            // Watchdog (never expected to fire): no target of this wave was resolved for longer than any single
+            // target can take.  Leave loudly recognisable outputs instead of whatever the buffers held:
+            // success 0, searches / iterations -1, residual and q NaN for the wave's unresolved and unstarted targets.
+            const double nan = __longlong_as_double(0x7ff8000000000000ll);
+            if ((busy >> lane) & 1ull) {
+                const int64_t t = sh.tgt[lane];
+                for (int j = 0; j < NJ; ++j) q_out[t * NJ + j] = nan;
+                success[t] = 0; iters[t] = -1; searches[t] = -1; residual[t] = nan;
+            }
+            for (unsigned long long t = pool_next + lane; t < pool_end; t += kWave) {
+                for (int j = 0; j < NJ; ++j) q_out[t * NJ + j] = nan;
+                success[t] = 0; iters[t] = -1; searches[t] = -1; residual[t] = nan;
+            }
+            break;
+        }
         {
             // The chain / limit tables are loop-invariant, and LICM would hoist all ~100 scalar loads out of
             // this persistent loop into SGPRs that do not exist (184 spilled SGPRs, 670 v_readlane in the
