@@ -70,8 +70,16 @@ RTB_HD V3 inertia_times(const LinkT &l, V3 v)  // vmath.c mat_vect_mult: m[r + 3
 // One sample.  links: wave-uniform link table (scalar loads on the GPU).
 // qin/qdin/qddin/tau: per-lane accessors  in(j) -> double, out(j, v).  q(j) must stay readable until
 // tau(j) has been written (the kernel lets tau overwrite the q slots).
+// a + (0,0,z)  and  a x (0,0,s): the joint rate / acceleration vectors of a revolute joint have only a z component;
+// the compiler may not drop the zero terms of the general formulas itself (IEEE: 0*x is not 0 for inf / NaN).
+// Finite inputs give bit-identical results (up to the sign of a zero).
+RTB_HD V3 addz(V3 a, double z) { return v3(a.x, a.y, a.z + z); }
+RTB_HD V3 crossz(V3 a, double s) { return v3(a.y * s, -(a.x * s), 0.0); }
+
 // FRICTION = false drops the viscous and Coulomb terms (Dynamics.nofriction(True, True), used by coriolis()).
-template <int NJ, bool MDH, bool FRICTION = true, class LinksP, class InQ, class InQd, class InQdd, class Out>
+// ALLREV = true promises that every link is revolute (sigma == 0): the prismatic branches, the per-lane
+// selects between joint kinds and the gravity leak of ne.c:311 disappear at compile time.
+template <int NJ, bool MDH, bool FRICTION = true, bool ALLREV = false, class LinksP, class InQ, class InQd, class InQdd, class Out>
 RTB_HD void rne_lane(LinksP links, int n_rt, V3 grav, V3 ftip, V3 ntip, InQ qin, InQd qdin, InQdd qddin, Out tau)
 {
     constexpr int CAP = NJ > 0 ? NJ : RTBHIP_MAX_JOINTS;
@@ -86,7 +94,7 @@ RTB_HD void rne_lane(LinksP links, int n_rt, V3 grav, V3 ftip, V3 ntip, InQ qin,
 #pragma unroll
         for (int j = 0; j < n; ++j) {
             const auto &l = links[j];
-            const double th = (l.sigma != 0) ? l.theta : qin(j) + l.offset;   // frne.c:196-202
+            const double th = (!ALLREV && l.sigma != 0) ? l.theta : qin(j) + l.offset;   // frne.c:196-202
             st[j] = th;
             big = big || !(fabs(th) < kTrigFastLimit);
         }
@@ -106,7 +114,7 @@ RTB_HD void rne_lane(LinksP links, int n_rt, V3 grav, V3 ftip, V3 ntip, InQ qin,
 #pragma unroll
     for (int j = 0; j < n; ++j) {
         const auto &l = links[j];
-        const bool pris = l.sigma != 0;
+        const bool pris = ALLREV ? false : (l.sigma != 0);
         const double qdj = qdin(j), qddj = qddin(j);
         if (NJ == 0) {
             const double th = pris ? l.theta : qin(j) + l.offset;
@@ -124,8 +132,9 @@ RTB_HD void rne_lane(LinksP links, int n_rt, V3 grav, V3 ftip, V3 ntip, InQ qin,
                     wn = qdv; wdn = qddv; an = rot_inv<MDH>(R, grav);
                 } else {
                     const V3 t1 = rot_inv<MDH>(R, w);
-                    wn = t1 + qdv;
-                    wdn = (cross(t1, qdv) + rot_inv<MDH>(R, wd)) + qddv;
+                    wn = addz(t1, qdj);
+                    const V3 u = crossz(t1, qdj) + rot_inv<MDH>(R, wd);
+                    wdn = ALLREV ? addz(u, qddj) : u + qddv;
                     an = rot_inv<MDH>(R, (cross(wd, ps) + cross(w, cross(w, ps))) + a);
                 }
             } else {
@@ -140,9 +149,9 @@ RTB_HD void rne_lane(LinksP links, int n_rt, V3 grav, V3 ftip, V3 ntip, InQ qin,
             }
         } else {
             if (!pris) {
-                const V3 t1 = (j == 0) ? qdv : w + qdv;
+                const V3 t1 = (j == 0) ? qdv : addz(w, qdj);
                 wn = rot_inv<MDH>(R, t1);
-                const V3 t3 = (j == 0) ? qddv : (wd + qddv) + cross(w, qdv);
+                const V3 t3 = (j == 0) ? qddv : (ALLREV ? addz(wd, qddj) : wd + qddv) + crossz(w, qdj);
                 wdn = rot_inv<MDH>(R, t3);
                 an = (cross(wdn, ps) + cross(wn, cross(wn, ps))) + rot_inv<MDH>(R, (j == 0) ? grav : a);
             } else {
@@ -177,7 +186,7 @@ RTB_HD void rne_lane(LinksP links, int n_rt, V3 grav, V3 ftip, V3 ntip, InQ qin,
         const int j = n - 1 - jj;
         const auto &l = links[j];
         const bool last = (jj == 0);
-        const bool pris = l.sigma != 0;
+        const bool pris = ALLREV ? false : (l.sigma != 0);
         const V3 rc = v3(l.rx, l.ry, l.rz);
         const double d = pris ? qin(j) + l.offset : l.d;
         const Rot R = {st[j], ct[j], l.sa, l.ca};

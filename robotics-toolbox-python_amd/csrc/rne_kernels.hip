@@ -49,7 +49,7 @@ __device__ __forceinline__ void tile_copy(double *rows, int stride, int col_off,
 // recursion with the LDS row as the accessor target (q is read once, up front; qd/qdd are re-read
 // from LDS where they are used, so they occupy no registers across the recursions; tau overwrites the
 // q slots, which are dead by then), write the torques back coalesced.
-template <int NJ, bool MDH>
+template <int NJ, bool MDH, bool ALLREV>
 __device__ __forceinline__ void rne_tile(const RneParams &rp, ConstLinks links, int n, int stride, int64_t tile,
                                          const double *__restrict__ q, const double *__restrict__ qd,
                                          const double *__restrict__ qdd, double *__restrict__ tau, double *lds, int lane)
@@ -93,7 +93,7 @@ __device__ __forceinline__ void rne_tile(const RneParams &rp, ConstLinks links, 
     }
     __syncthreads();
     if (lane < ncfg) {
-        rne_lane<NJ, MDH>(links, n, grav, ftip, ntip, [&](int j) { return mine[j]; }, [&](int j) { return mine[n + j]; },
+        rne_lane<NJ, MDH, true, ALLREV>(links, n, grav, ftip, ntip, [&](int j) { return mine[j]; }, [&](int j) { return mine[n + j]; },
                           [&](int j) { return mine[2 * n + j]; }, [&](int j, double v) { mine[j] = v; });
     }
     __syncthreads();
@@ -121,13 +121,13 @@ __device__ __forceinline__ void rne_tile(const RneParams &rp, ConstLinks links, 
 // LICM hoists every link's scalar table loads into the preheader, where they overflow the SGPR file;
 // first MI355X measurement of the looped version: 256 VGPRs + 90 AGPRs + 112 spilled SGPRs, one
 // wave per SIMD, 0.31 ms per 1.25e6 Panda triples).
-template <int NJ, bool MDH>
+template <int NJ, bool MDH, bool ALLREV>
 __global__ __launch_bounds__(kW, RTB_RNE_WAVES) void k_rne(RneParams rp, const DevLink *links_g, const double *__restrict__ q,
                                            const double *__restrict__ qd, const double *__restrict__ qdd,
                                            double *__restrict__ tau)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    rne_tile<NJ, MDH>(rp, (ConstLinks)links_g, NJ, rne_stride(NJ), blockIdx.x, q, qd, qdd, tau, lds, threadIdx.x);
+    rne_tile<NJ, MDH, ALLREV>(rp, (ConstLinks)links_g, NJ, rne_stride(NJ), blockIdx.x, q, qd, qdd, tau, lds, threadIdx.x);
 }
 
 // run-time joint count (n > 8): grid-stride over tiles, per-link state in private memory
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(kW) void k_rne_rt(RneParams rp, const DevLink *link
     const int stride = rne_stride(n);
     const int64_t tiles = (rp.N + kW - 1) / kW;
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        rne_tile<0, MDH>(rp, (ConstLinks)links_g, n, stride, tile, q, qd, qdd, tau, lds, threadIdx.x);
+        rne_tile<0, MDH, false>(rp, (ConstLinks)links_g, n, stride, tile, q, qd, qdd, tau, lds, threadIdx.x);
         __syncthreads();
     }
 }
@@ -153,11 +153,13 @@ void rne_tune(const char *key, int value)
 }
 
 template <int NJ>
-static void launch_nj(bool mdh, dim3 grid, size_t lds, hipStream_t s, const RneParams &rp, const DevLink *links,
+static void launch_nj(bool mdh, bool allrev, dim3 grid, size_t lds, hipStream_t s, const RneParams &rp, const DevLink *links,
                       const double *q, const double *qd, const double *qdd, double *tau)
 {
-    if (mdh) hipLaunchKernelGGL((k_rne<NJ, true>), grid, dim3(kW), lds, s, rp, links, q, qd, qdd, tau);
-    else hipLaunchKernelGGL((k_rne<NJ, false>), grid, dim3(kW), lds, s, rp, links, q, qd, qdd, tau);
+    if (mdh && allrev) hipLaunchKernelGGL((k_rne<NJ, true, true>), grid, dim3(kW), lds, s, rp, links, q, qd, qdd, tau);
+    else if (mdh) hipLaunchKernelGGL((k_rne<NJ, true, false>), grid, dim3(kW), lds, s, rp, links, q, qd, qdd, tau);
+    else if (allrev) hipLaunchKernelGGL((k_rne<NJ, false, true>), grid, dim3(kW), lds, s, rp, links, q, qd, qdd, tau);
+    else hipLaunchKernelGGL((k_rne<NJ, false, false>), grid, dim3(kW), lds, s, rp, links, q, qd, qdd, tau);
 }
 static void launch_rt(bool mdh, dim3 grid, size_t lds, hipStream_t s, const RneParams &rp, const DevLink *links,
                       const double *q, const double *qd, const double *qdd, double *tau)
@@ -181,19 +183,21 @@ int launch_rne(const Dyn *d, const DevLink *links, const double *q, const double
     const size_t lds = (size_t)kW * stride * sizeof(double);
     const int64_t tiles = (N + kW - 1) / kW;
     const bool mdh = d->mdh != 0;
+    bool allrev = true;
+    for (const DevLink &l : d->links) allrev = allrev && l.sigma == 0;
     const bool rt = d->n > 8 || tiles > 0x7fffffff;
     int64_t g = rt ? (tiles + g_rne_tiles_per_wave - 1) / g_rne_tiles_per_wave : tiles;
     if (g > 0x7fffffff) g = 0x7fffffff;
     dim3 grid((unsigned)g);
     switch (rt ? 0 : d->n) {
-    case 1: launch_nj<1>(mdh, grid, lds, s, rp, links, q, qd, qdd, tau); break;
-    case 2: launch_nj<2>(mdh, grid, lds, s, rp, links, q, qd, qdd, tau); break;
-    case 3: launch_nj<3>(mdh, grid, lds, s, rp, links, q, qd, qdd, tau); break;
-    case 4: launch_nj<4>(mdh, grid, lds, s, rp, links, q, qd, qdd, tau); break;
-    case 5: launch_nj<5>(mdh, grid, lds, s, rp, links, q, qd, qdd, tau); break;
-    case 6: launch_nj<6>(mdh, grid, lds, s, rp, links, q, qd, qdd, tau); break;
-    case 7: launch_nj<7>(mdh, grid, lds, s, rp, links, q, qd, qdd, tau); break;
-    case 8: launch_nj<8>(mdh, grid, lds, s, rp, links, q, qd, qdd, tau); break;
+    case 1: launch_nj<1>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau); break;
+    case 2: launch_nj<2>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau); break;
+    case 3: launch_nj<3>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau); break;
+    case 4: launch_nj<4>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau); break;
+    case 5: launch_nj<5>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau); break;
+    case 6: launch_nj<6>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau); break;
+    case 7: launch_nj<7>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau); break;
+    case 8: launch_nj<8>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau); break;
     default: launch_rt(mdh, grid, lds, s, rp, links, q, qd, qdd, tau); break;
     }
     note_launch((int)grid.x, kW, (int)lds);
