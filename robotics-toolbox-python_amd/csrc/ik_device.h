@@ -101,17 +101,23 @@ RTB_HD void ik_lm_step(const double (&jac)[6 * NJ], const double (&e)[6], const 
     double we_e[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) we_e[k] = we[k] * e[k];
+    // row r of W J once (6 products), then each of its normal-equation entries is 6 fused multiply-adds on it:
+    // the same products in the same order as (J[k][r] * we[k]) * J[k][c], formed 7 times instead of 28
 #pragma unroll
     for (int r = 0; r < NJ; ++r) {
+        double wjr[6];
         double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) s += jac[k * NJ + r] * we_e[k];
+        for (int k = 0; k < 6; ++k) {
+            wjr[k] = jac[k * NJ + r] * we[k];
+            s += jac[k * NJ + r] * we_e[k];
+        }
         g[r] = s;
 #pragma unroll
         for (int c = 0; c <= r; ++c) {
             double a = 0.0;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) a += (jac[k * NJ + r] * we[k]) * jac[k * NJ + c];
+            for (int k = 0; k < 6; ++k) a += wjr[k] * jac[k * NJ + c];
             A[r][c] = (r == c) ? a + wn : a;
         }
     }
@@ -241,7 +247,9 @@ RTB_HD double ik_wrap_py(double q)                                              
 // ONE LM iteration of the lane's current search.  Every lane of a wave executes this whatever its
 // status (idle / parked lanes compute on their stale state and discard the result) so the wave has a
 // single instruction stream.  Sets st.fin / st.ok when the search ended.
-template <int NJ, class PD, class CV, class QL, class TD, class QA>
+// PINV = false: the three Levenberg-Marquardt steps (method 0..2); PINV = true: Gauss-Newton / Newton-Raphson
+// (method 3 / 4).  A compile-time choice so that neither kernel carries the other's step in its register budget.
+template <int NJ, bool PINV, class PD, class CV, class QL, class TD, class QA>
 RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, QA qa)
 {
     Pose P;
@@ -259,7 +267,7 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, Q
 #pragma unroll
     for (int k = 0; k < 6; ++k) E += e[k] * p.we[k] * e[k];
     E *= 0.5;                                                   // ik.cpp:46
-    if (p.method >= 3) {            // 3 Gauss-Newton, 4 Newton-Raphson: `lambda` carries pinv_damping (NR only)
+    if (PINV) {                     // 3 Gauss-Newton, 4 Newton-Raphson: `lambda` carries pinv_damping (NR only)
         int rows = 63;
         if (p.method == 3) {
             rows = 0;
@@ -500,7 +508,10 @@ RTB_HD void ik_solve_sequential(const IkDev &p, const CV &cv, QL qlim, int64_t t
     int it = 0;
     for (int s = ik_s_first(p);; ++s) {
         ik_search_begin<NJ>(st, qa, p, qlim, tgt, s, p.has_q0 ? q0 + (int64_t)NJ * tgt : nullptr);
-        while (!st.fin) ik_iter<NJ>(st, p, cv, qlim, [&](int k) { return Td[k]; }, qa);
+        while (!st.fin) {
+            if (p.method >= 3) ik_iter<NJ, true>(st, p, cv, qlim, [&](int k) { return Td[k]; }, qa);
+            else ik_iter<NJ, false>(st, p, cv, qlim, [&](int k) { return Td[k]; }, qa);
+        }
         it += st.iter;
         if (st.ok || s == s_last) {
             ik_emit<NJ>(st, qa, p, qlim, tgt, p.has_q0 != 0, st.ok != 0, it, st.E, q_out, success, iters, searches, residual);

@@ -25,7 +25,7 @@ struct ConstChainIk {
 #ifndef RTB_IK_WAVES
 #define RTB_IK_WAVES 2
 #endif
-template <int NJ>
+template <int NJ, bool PINV>
 __global__ __launch_bounds__(kWave, RTB_IK_WAVES) void k_ik(IkDev p, DevChain dc, const double *qlim_g, const double *__restrict__ Tep,
                                                 const double *__restrict__ q0, unsigned long long *counter,
                                                 double *__restrict__ q_out, int32_t *__restrict__ success,
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(kWave, RTB_IK_WAVES) void k_ik(IkDev p, DevChain dc
             const RTB_CONST double *ql = qlim;
             asm volatile("" : "+s"(cvi.seg), "+s"(cvi.jmeta), "+s"(ql));
             const int myslot = st.slot;
-            ik_iter<NJ>(st, p, cvi, ql, [&](int k) { return sh.Td[k][myslot]; }, IkLdsQ{&sh, lane});
+            ik_iter<NJ, PINV>(st, p, cvi, ql, [&](int k) { return sh.Td[k][myslot]; }, IkLdsQ{&sh, lane});
         }
     }
 }
@@ -190,7 +190,8 @@ static void launch_nj(dim3 grid, hipStream_t s, const IkDev &p, const DevChain &
                       const double *q0, unsigned long long *ctr, double *q_out, int32_t *success, int32_t *iters,
                       int32_t *searches, double *residual)
 {
-    hipLaunchKernelGGL((k_ik<NJ>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual);
+    if (p.method >= 3) hipLaunchKernelGGL((k_ik<NJ, true>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual);
+    else hipLaunchKernelGGL((k_ik<NJ, false>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual);
 }
 
 int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const double *Tep, int64_t N, const double *q0,

@@ -299,7 +299,8 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
             w.iters++;
             for (int l = 0; l < kWave; ++l) {
                 if (w.st[l].status == kIkRun) w.lane_iters_useful++;
-                ik_iter<NJ>(w.st[l], p, cv, qlim, [&](int k) { return w.sh.Td[k][w.st[l].slot]; }, IkLdsQ{&w.sh, l});
+                if (p.method >= 3) ik_iter<NJ, true>(w.st[l], p, cv, qlim, [&](int k) { return w.sh.Td[k][w.st[l].slot]; }, IkLdsQ{&w.sh, l});
+                else ik_iter<NJ, false>(w.st[l], p, cv, qlim, [&](int k) { return w.sh.Td[k][w.st[l].slot]; }, IkLdsQ{&w.sh, l});
             }
         }
     }
