@@ -226,6 +226,38 @@ def rne_dh(L24, mdh, q, qd, qdd, grav_c, fext=None):
     return tau
 
 
+def ikine_py(ch, Tep, q0s, step="nr", ilimit=30, slimit=100, tol=1e-6, joint_limits=True, we=None, k=1.0):
+    """NumPy restatement of the Python solvers' loop, IKSolver._solve (robot/IK.py:297-367), with the steps of
+    IK_NR / IK_GN (q += pinv(J) e, :736-763, :1176-1220) or IK_LM chan (:994-1017).  q0s: (slimit, n) starts."""
+    n = ch.n
+    q0s = _f64(q0s, (-1, n))
+    Tep = _f64(Tep, (4, 4))
+    We = np.diag(np.ones(6) if we is None else _f64(we, (6,)))
+    total_i, E, q = 0, 0.0, q0s[0].copy()
+    for search in range(slimit):
+        q = q0s[search].copy()
+        i = 0
+        while i < ilimit:
+            i += 1
+            Te = fkine(ch, q)[0]
+            e = angle_axis(Te, Tep)
+            E = 0.5 * e @ We @ e
+            J = jacob0(ch, q)[0]
+            if step in ("nr", "gn"):
+                q = q + np.linalg.pinv(J) @ e
+            else:
+                g = J.T @ We @ e
+                q = q + np.linalg.inv(J.T @ We @ J + k * E * np.eye(n)) @ g
+            if E < tol:
+                q = (q + np.pi) % (2 * np.pi) - np.pi
+                ok = bool(np.all(q >= ch.qlim[0]) and np.all(q <= ch.qlim[1]))
+                if not ok and joint_limits:
+                    break
+                return q, 1, total_i + i, search + 1, E
+        total_i += i
+    return q, 0, total_i, slimit, E
+
+
 def nofriction_L24(L24):
     """Dynamics.nofriction(True, True) on the 24-double link block: B = 0, Tc = 0 (robot/Dynamics.py:146-183)."""
     L = _f64(L24, (-1, 24)).copy()

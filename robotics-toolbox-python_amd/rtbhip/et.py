@@ -525,6 +525,38 @@ class ETS:
                           reason="" if allok else "iteration and search limit reached",
                           each={"success": ok.astype(bool), "iterations": it, "searches": se, "residual": E})
 
+    def _ikine_pinv(self, name, Tep, q0, ilimit, slimit, tol, mask, joint_limits, seed, pinv, kq, km):
+        if kq or km:
+            raise NotImplementedError("null-space terms kq/km are not implemented in the GPU solver")
+        if not pinv and self.n != 6:
+            raise ValueError("%s: a %d-joint chain needs pinv=True (numpy.linalg.inv of a 6x%d Jacobian is undefined)"
+                             % (name, self.n, self.n))
+        single, q, ok, it, se, E = self._ik(Tep, q0, ilimit, slimit, tol, mask, joint_limits, 0.0, name, 1,
+                                            0 if seed is None else seed)
+        if is_torch(q):
+            q, ok, it, se, E = (x.cpu().numpy() for x in (q, ok, it, se, E))
+        if single:
+            good = bool(ok[0])
+            return IKSolution(q=q[0], success=good, iterations=int(it[0]), searches=int(se[0]),
+                              residual=float(E[0]), reason="Success" if good else "iteration and search limit reached")
+        allok = bool(ok.all())
+        return IKSolution(q=q, success=allok, iterations=int(it.sum()), searches=int(se.sum()),
+                          residual=float(E.min()) if len(E) else float("inf"),
+                          reason="" if allok else "iteration and search limit reached",
+                          each={"success": ok.astype(bool), "iterations": it, "searches": se, "residual": E})
+
+    def ikine_NR(self, Tep, q0=None, ilimit=30, slimit=100, tol=1e-6, mask=None, joint_limits=True, seed=None,
+                 pinv=False, kq=0.0, km=0.0, **kwargs):
+        """The Python Newton-Raphson solver (reference ETS.ikine_NR robot/ETS.py:2639-2776 -> IK_NR robot/IK.py:579-763):
+        q += pinv(J) e inside the Python solver's loop semantics (flavour 1)."""
+        return self._ikine_pinv("nr", Tep, q0, ilimit, slimit, tol, mask, joint_limits, seed, pinv, kq, km)
+
+    def ikine_GN(self, Tep, q0=None, ilimit=30, slimit=100, tol=1e-6, mask=None, joint_limits=True, seed=None,
+                 pinv=False, kq=0.0, km=0.0, **kwargs):
+        """The Python Gauss-Newton solver (reference ETS.ikine_GN robot/ETS.py:2778-2915 -> IK_GN robot/IK.py:1020-1220;
+        its step is the same pinv(J) e)."""
+        return self._ikine_pinv("nr", Tep, q0, ilimit, slimit, tol, mask, joint_limits, seed, pinv, kq, km)
+
     def ik_restart(self, seed, target, search):
         """The restart vector the device generator yields (test hook, rtbhip_ik_restart)."""
         out = np.empty(self.n)

@@ -413,6 +413,21 @@ def test_ik_gn_nr_reference_fixtures_and_statistics():
         assert err.max() < 2e-3                       # E = e.e/2 < 1e-6  =>  |e| < 1.5e-3
 
 
+def test_ikine_nr_gn_python_flavour():
+    """ETS.ikine_NR / ikine_GN: IKSolution results, success on the reference's G10 target, pinv rule for redundant arms."""
+    ets, ch = _panda_limited()
+    Tep = oracle.fkine(ch, np.array([0, -0.3, 0, -2.2, 0, 2.0, np.pi / 4]))[0]
+    for fn in (ets.ikine_NR, ets.ikine_GN):
+        sol = fn(Tep, pinv=True, seed=0)
+        assert sol.success and sol.residual < 1e-6                      # reference tests/test_IK.py:19-37, 253-273
+        e = oracle.angle_axis(oracle.fkine(ch, sol.q)[0], Tep)
+        assert 0.5 * e @ e < 1e-5
+        with pytest.raises(ValueError):
+            fn(Tep)                                                     # pinv=False on a 7-joint arm
+    sol = ets.ikine_NR(np.stack([Tep, Tep]), pinv=True, seed=1)
+    assert sol.q.shape == (2, 7) and sol.each["success"].all()
+
+
 def test_ik_config3_1e5_targets_statistics():
     """BASELINE configs[2]: 1e5 random reachable targets, Franka limits, defaults
     (ilimit 30, slimit 100, tol 1e-6, chan, k=1).  Every reported success must satisfy E < tol,

@@ -318,3 +318,27 @@ def test_ik_gn_nr_reference_run_fixtures_first_search():
         nt.assert_array_equal(np.c_[ok, it, se][first], meta[first])
         nt.assert_allclose(q[first], REF[key + "_q"][first], atol=1e-6)
     assert n_checked >= 40
+
+
+@pytest.mark.parametrize("step", ["nr", "gn"])
+def test_ikine_nr_gn_python_loop_semantics(step):
+    """ikine_NR / ikine_GN (flavour 1 + pseudo-inverse step) against a NumPy restatement of IKSolver._solve with
+    numpy.linalg.pinv.  Undamped Newton steps from random restarts pass near singular configurations where an
+    SVD-truncated pseudo-inverse and an exact minimum-norm solve part ways, so the comparison is made where no
+    restart is involved: start vectors near the solution, first search converges -> same iteration count, q to 1e-6."""
+    ets, ch = _panda_limited()
+    rng = np.random.default_rng(31)
+    N = 24
+    qs = rng.uniform(ch.qlim[0] + 0.15, ch.qlim[1] - 0.15, (N, 7))
+    Tep = oracle.fkine(ch, qs)
+    q0 = qs + 0.05 * rng.normal(size=qs.shape)
+    q, ok, it, se, E = emu.ik(ets, Tep, q0=q0, method=step, flavour=1, seed=77, slimit=5, k=0.0)   # k carries pinv_damping
+    checked = 0
+    for i in range(N):
+        rs = np.array([q0[i]] + [emu.ik_restart(ets, 77, i, d) for d in range(1, 5)])
+        o = oracle.ikine_py(ch, Tep[i], rs, step=step, slimit=5)
+        if o[1] and o[3] == 1:
+            checked += 1
+            assert (o[1], o[2], o[3]) == (ok[i], it[i], se[i])
+            nt.assert_allclose(q[i], o[0], atol=1e-6)
+    assert checked >= 12
