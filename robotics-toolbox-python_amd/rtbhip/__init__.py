@@ -1,8 +1,14 @@
 """rtbhip -- MI355X-native batched kinematics/dynamics backend behind the Robotics Toolbox API.
 
-Only the hot path named in BASELINE.json is here: ET/ETS (eval, fkine, jacob0, jacobe, hessian0,
-ik_LM, ikine_LM), DHRobot (fkine, jacob0, jacobe, rne) and the Panda / Puma560 models.  All
-arithmetic runs in hand-written HIP kernels (../csrc) behind the C ABI of include/rtbhip.h.
+Only the hot path named in BASELINE.json / SURVEY.md section 8 is here:
+  ET / ETS            eval, fkine, jacob0, jacobe, hessian0/e, jacob0_dot, manipulability, jacobm,
+                      ik_LM / ik_GN / ik_NR (C-solver semantics), ikine_LM / ikine_GN / ikine_NR (Python-solver semantics)
+  DHLink / DHRobot    fkine, jacob0/e, rne, gravload, itorque, inertia, coriolis, accel (+ the ETS pass-throughs)
+  Link / ERobot       ETS robots (link trees): rne
+  urdf                plain-URDF loader + the reference's URDF -> ETS lowering, 20 pre-expanded robot descriptions
+  fleet_fkine_jacob   many different chains in one call;  ShardedBatch / shard_range  one row block per GPU rank
+All arithmetic runs in hand-written HIP kernels (../csrc) behind the C ABI of include/rtbhip.h; there is no
+CPU fallback: every call raises RtbHipError when librtbhip.so or a GPU is missing.
 """
 from ._lib import RtbHipError, lib, device_count, tune, shard_range, last_launch  # noqa: F401
 from .et import ET, ETS, IKSolution  # noqa: F401
