@@ -57,7 +57,7 @@ struct DynLayout {
     static constexpr int doubles = kDW * (in_stride + tiles * w_stride);
 };
 
-template <int NJ, bool MDH, int MODE>
+template <int NJ, bool MDH, int MODE, bool ALLREV>
 __global__ __launch_bounds__(kDW, 2) void k_dyn(DynParams dp, const DevLink *links_g, const double *__restrict__ q,
                                                 const double *__restrict__ qd, const double *__restrict__ tq,
                                                 double *__restrict__ out)
@@ -78,38 +78,42 @@ __global__ __launch_bounds__(kDW, 2) void k_dyn(DynParams dp, const DevLink *lin
     if (MODE == kDynAccel) { const double *const src[3] = {q, qd, tq}; dyn_load<NJ, 3>(in, L::in_stride, src, cfg0, count, lane); }
     __syncthreads();
     if (lane < ncfg)
-        dyn_lane<NJ, MDH, MODE>(links, in + lane * L::in_stride, A + lane * L::w_stride, B + lane * L::w_stride,
+        dyn_lane<NJ, MDH, MODE, ALLREV>(links, in + lane * L::in_stride, A + lane * L::w_stride, B + lane * L::w_stride,
                                 v3(dp.grav[0], dp.grav[1], dp.grav[2]));
     __syncthreads();
     if (MODE == kDynAccel) flush_run(A, L::w_stride, NJ, ncfg, out + cfg0 * NJ, lane);
     else flush_run(A, L::w_stride, L::W, ncfg, out + cfg0 * L::W, lane);
 }
 
+template <int NJ, int MODE, bool MDH, bool ALLREV>
+static hipError_t launch_one(dim3 grid, hipStream_t s, size_t lds, const DynParams &dp, const DevLink *links, const double *q,
+                             const double *qd, const double *tq, double *out)
+{
+    auto k = k_dyn<NJ, MDH, MODE, ALLREV>;
+    if (lds > 48 * 1024) { hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL(k, grid, dim3(kDW), lds, s, dp, links, q, qd, tq, out);
+    return hipGetLastError();
+}
+
 template <int NJ, int MODE>
-static hipError_t launch_mode(bool mdh, dim3 grid, hipStream_t s, const DynParams &dp, const DevLink *links, const double *q,
+static hipError_t launch_mode(bool mdh, bool allrev, dim3 grid, hipStream_t s, const DynParams &dp, const DevLink *links, const double *q,
                               const double *qd, const double *tq, double *out, size_t *lds_out)
 {
     const size_t lds = (size_t)DynLayout<NJ, MODE>::doubles * sizeof(double);
     *lds_out = lds;
-    if (mdh) {
-        auto k = k_dyn<NJ, true, MODE>;
-        if (lds > 48 * 1024) { hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
-        hipLaunchKernelGGL(k, grid, dim3(kDW), lds, s, dp, links, q, qd, tq, out);
-    } else {
-        auto k = k_dyn<NJ, false, MODE>;
-        if (lds > 48 * 1024) { hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
-        hipLaunchKernelGGL(k, grid, dim3(kDW), lds, s, dp, links, q, qd, tq, out);
-    }
-    return hipGetLastError();
+    if (mdh) return allrev ? launch_one<NJ, MODE, true, true>(grid, s, lds, dp, links, q, qd, tq, out)
+                           : launch_one<NJ, MODE, true, false>(grid, s, lds, dp, links, q, qd, tq, out);
+    return allrev ? launch_one<NJ, MODE, false, true>(grid, s, lds, dp, links, q, qd, tq, out)
+                  : launch_one<NJ, MODE, false, false>(grid, s, lds, dp, links, q, qd, tq, out);
 }
 
 template <int NJ>
-static hipError_t launch_nj(int mode, bool mdh, dim3 grid, hipStream_t s, const DynParams &dp, const DevLink *links,
+static hipError_t launch_nj(int mode, bool mdh, bool allrev, dim3 grid, hipStream_t s, const DynParams &dp, const DevLink *links,
                             const double *q, const double *qd, const double *tq, double *out, size_t *lds)
 {
-    if (mode == kDynInertia) return launch_mode<NJ, kDynInertia>(mdh, grid, s, dp, links, q, qd, tq, out, lds);
-    if (mode == kDynCoriolis) return launch_mode<NJ, kDynCoriolis>(mdh, grid, s, dp, links, q, qd, tq, out, lds);
-    return launch_mode<NJ, kDynAccel>(mdh, grid, s, dp, links, q, qd, tq, out, lds);
+    if (mode == kDynInertia) return launch_mode<NJ, kDynInertia>(mdh, allrev, grid, s, dp, links, q, qd, tq, out, lds);
+    if (mode == kDynCoriolis) return launch_mode<NJ, kDynCoriolis>(mdh, allrev, grid, s, dp, links, q, qd, tq, out, lds);
+    return launch_mode<NJ, kDynAccel>(mdh, allrev, grid, s, dp, links, q, qd, tq, out, lds);
 }
 
 int launch_dyn(const Dyn *d, const DevLink *links, int mode, const double *q, const double *qd, const double *tq,
@@ -124,17 +128,19 @@ int launch_dyn(const Dyn *d, const DevLink *links, int mode, const double *q, co
     for (int i = 0; i < 3; i++) dp.grav[i] = grav3 ? grav3[i] : 0.0;
     dim3 grid((unsigned)tiles);
     const bool mdh = d->mdh != 0;
+    bool allrev = true;
+    for (const DevLink &l : d->links) allrev = allrev && l.sigma == 0;
     hipError_t e = hipSuccess;
     size_t lds = 0;
     switch (d->n) {
-    case 1: e = launch_nj<1>(mode, mdh, grid, s, dp, links, q, qd, tq, out, &lds); break;
-    case 2: e = launch_nj<2>(mode, mdh, grid, s, dp, links, q, qd, tq, out, &lds); break;
-    case 3: e = launch_nj<3>(mode, mdh, grid, s, dp, links, q, qd, tq, out, &lds); break;
-    case 4: e = launch_nj<4>(mode, mdh, grid, s, dp, links, q, qd, tq, out, &lds); break;
-    case 5: e = launch_nj<5>(mode, mdh, grid, s, dp, links, q, qd, tq, out, &lds); break;
-    case 6: e = launch_nj<6>(mode, mdh, grid, s, dp, links, q, qd, tq, out, &lds); break;
-    case 7: e = launch_nj<7>(mode, mdh, grid, s, dp, links, q, qd, tq, out, &lds); break;
-    default: e = launch_nj<8>(mode, mdh, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    case 1: e = launch_nj<1>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    case 2: e = launch_nj<2>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    case 3: e = launch_nj<3>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    case 4: e = launch_nj<4>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    case 5: e = launch_nj<5>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    case 6: e = launch_nj<6>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    case 7: e = launch_nj<7>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    default: e = launch_nj<8>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
     }
     note_launch((int)grid.x, kDW, (int)lds);
     if (e != hipSuccess) return hip_fail(e, "k_dyn launch");

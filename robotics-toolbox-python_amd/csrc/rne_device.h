@@ -79,34 +79,38 @@ RTB_HD V3 crossz(V3 a, double s) { return v3(a.y * s, -(a.x * s), 0.0); }
 // FRICTION = false drops the viscous and Coulomb terms (Dynamics.nofriction(True, True), used by coriolis()).
 // ALLREV = true promises that every link is revolute (sigma == 0): the prismatic branches, the per-lane
 // selects between joint kinds and the gravity leak of ne.c:311 disappear at compile time.
-template <int NJ, bool MDH, bool FRICTION = true, bool ALLREV = false, class LinksP, class InQ, class InQd, class InQdd, class Out>
-RTB_HD void rne_lane(LinksP links, int n_rt, V3 grav, V3 ftip, V3 ntip, InQ qin, InQd qdin, InQdd qddin, Out tau)
+// sin/cos of the joint angles of one sample.  Compile-time NJ: all NJ evaluations in one basic block
+// (branch-free reduction, trig.h) so the scheduler interleaves the independent chains; one wave-wide
+// fallback.  Split from the recursions so that the multi-pass kernels (inertia, coriolis, accel: 7..28
+// Newton-Euler passes over the SAME q) evaluate it once.
+template <int NJ, bool ALLREV, class LinksP, class InQ>
+RTB_HD void rne_trig(LinksP links, InQ qin, double (&st)[NJ], double (&ct)[NJ])
+{
+    bool big = false;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const auto &l = links[j];
+        const double th = (!ALLREV && l.sigma != 0) ? l.theta : qin(j) + l.offset;   // frne.c:196-202
+        st[j] = th;
+        big = big || !(fabs(th) < kTrigFastLimit);
+    }
+    if (wave_any(big)) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { double s, c; sincos(st[j], &s, &c); st[j] = s; ct[j] = c; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { double s, c; sincos_reduced(st[j], s, c); st[j] = s; ct[j] = c; }
+    }
+    sched_fence();
+}
+
+template <int NJ, bool MDH, bool FRICTION, bool ALLREV, bool HAVE_TRIG, class LinksP, class InQ, class InQd, class InQdd, class Out>
+RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_MAX_JOINTS], double (&ct)[NJ > 0 ? NJ : RTBHIP_MAX_JOINTS],
+                     V3 grav, V3 ftip, V3 ntip, InQ qin, InQd qdin, InQdd qddin, Out tau)
 {
     constexpr int CAP = NJ > 0 ? NJ : RTBHIP_MAX_JOINTS;
     const int n = NJ > 0 ? NJ : n_rt;
-    double st[CAP], ct[CAP];
     V3 F[CAP], Nn[CAP];
-
-    // ---- joint angles -> sin/cos.  Compile-time NJ: all NJ evaluations in one basic block (branch-free
-    // reduction, trig.h) so the scheduler interleaves the independent chains; one wave-wide fallback.
-    if (NJ > 0) {
-        bool big = false;
-#pragma unroll
-        for (int j = 0; j < n; ++j) {
-            const auto &l = links[j];
-            const double th = (!ALLREV && l.sigma != 0) ? l.theta : qin(j) + l.offset;   // frne.c:196-202
-            st[j] = th;
-            big = big || !(fabs(th) < kTrigFastLimit);
-        }
-        if (wave_any(big)) {
-#pragma unroll
-            for (int j = 0; j < n; ++j) { double s, c; sincos(st[j], &s, &c); st[j] = s; ct[j] = c; }
-        } else {
-#pragma unroll
-            for (int j = 0; j < n; ++j) { double s, c; sincos_reduced(st[j], s, c); st[j] = s; ct[j] = c; }
-        }
-        sched_fence();
-    }
 
     // ---- forward recursion (ne.c:133-348)
     V3 w = v3(0, 0, 0), wd = v3(0, 0, 0), a = v3(0, 0, 0);
@@ -217,6 +221,16 @@ RTB_HD void rne_lane(LinksP links, int n_rt, V3 grav, V3 ftip, V3 ntip, InQ qin,
         f = fj; nn = nj; Rn = R; psn = ps;
         if (NJ > 0) sched_fence();
     }
+}
+
+// One sample, trig included (the single-pass kernels and the run-time-n path).
+template <int NJ, bool MDH, bool FRICTION = true, bool ALLREV = false, class LinksP, class InQ, class InQd, class InQdd, class Out>
+RTB_HD void rne_lane(LinksP links, int n_rt, V3 grav, V3 ftip, V3 ntip, InQ qin, InQd qdin, InQdd qddin, Out tau)
+{
+    constexpr int CAP = NJ > 0 ? NJ : RTBHIP_MAX_JOINTS;
+    double st[CAP], ct[CAP];
+    if constexpr (NJ > 0) rne_trig<NJ, ALLREV>(links, qin, st, ct);
+    rne_core<NJ, MDH, FRICTION, ALLREV, (NJ > 0)>(links, n_rt, st, ct, grav, ftip, ntip, qin, qdin, qddin, tau);
 }
 
 }  // namespace rtbhip

@@ -415,7 +415,10 @@ static void dyn_run(const Dyn *d, const double *q, const double *qd, const doubl
             in[NJ + j] = qd ? qd[s * NJ + j] : 0.0;
             in[2 * NJ + j] = tq ? tq[s * NJ + j] : 0.0;
         }
-        dyn_lane<NJ, MDH, MODE>(links, in.data(), A.data(), B.data(), g);
+        bool allrev = true;
+        for (const DevLink &l : d->links) allrev = allrev && l.sigma == 0;
+        if (allrev) dyn_lane<NJ, MDH, MODE, true>(links, in.data(), A.data(), B.data(), g);
+        else dyn_lane<NJ, MDH, MODE, false>(links, in.data(), A.data(), B.data(), g);
         const int W = MODE == kDynAccel ? NJ : NJ * NJ;
         for (int k = 0; k < W; ++k) out[s * W + k] = A[k];
     }
