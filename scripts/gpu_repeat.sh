@@ -1,0 +1,5 @@
+#!/bin/bash
+# flakiness check: the GPU parity suite three times over
+export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+for i in 1 2 3; do timeout 900 python -m pytest tests -m gpu -x -q -p no:cacheprovider 2>&1 | tail -1; done
