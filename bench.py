@@ -33,6 +33,23 @@ BYTES_PER_CONFIG = 56 + 128 + 336  # q read + T written + J0 written
 HBM_PEAK_GBS = 8000.0              # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def cpu_baseline_all_cores(sample, timeout_s=90.0):
+    """the same reference path on every host core.  Runs in a separate, time-limited process
+    (oracle/cpu_pool_bench.py: a fork pool with one reference chain per worker) so that nothing it does -- or
+    fails to do -- can stall this one; any failure is reported instead of a number."""
+    import subprocess
+    import tempfile
+    import numpy as np
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "q.npy")
+        np.save(path, sample)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_pool_bench.py"), path],
+                           capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+    if r.returncode != 0:
+        raise RuntimeError("cpu_pool_bench.py rc=%d: %s" % (r.returncode, r.stderr.strip()[-300:]))
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
 def cpu_baseline(q_host, T_gpu, J_gpu, max_seconds=25.0):
     """Reference CPU path on this box (1 core: the extension holds the GIL and has no threads).
     The same pass doubles as the parity guard of the timed configuration: the GPU's T/J rows of the
@@ -68,9 +85,15 @@ def cpu_baseline(q_host, T_gpu, J_gpu, max_seconds=25.0):
     err = max(float(np.abs(T_gpu[:n].cpu().numpy() - Tc).max()), float(np.abs(J_gpu[:n].cpu().numpy() - Jc).max()))
     if not err <= 1e-10:
         raise SystemExit("bench: parity check vs the CPU %s failed, max |err| = %g" % (kind, err))
-    return {"value": n / best, "unit": "configurations/s", "cores": 1, "kind": kind, "max_abs_err_gpu_vs_cpu": err,
-            "sample": "first %d of the %d bench configurations, best of %d passes; ETS_fkine over the array "
-                      "+ per-row ETS_jacob0 loop (the reference has no batched Jacobian)" % (n, len(q_host), reps)}
+    out = {"value": n / best, "unit": "configurations/s", "cores": 1, "kind": kind, "max_abs_err_gpu_vs_cpu": err,
+           "sample": "first %d of the %d bench configurations, best of %d passes; ETS_fkine over the array "
+                     "+ per-row ETS_jacob0 loop (the reference has no batched Jacobian)" % (n, len(q_host), reps)}
+    if kind == "reference" and (os.cpu_count() or 1) > 1:
+        try:
+            out["all_cores"] = cpu_baseline_all_cores(q_host)      # every configuration of the step: enough rows per core
+        except Exception as e:                    # the single-core figure above is the contract; this one is a bonus
+            out["all_cores"] = {"error": repr(e)}
+    return out
 
 
 def main():
