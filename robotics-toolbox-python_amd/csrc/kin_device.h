@@ -241,19 +241,29 @@ RTB_HD double hessian_entry(const double *Jrow, int n, int j, int row, int i)
 template <int NJ, class Store>
 RTB_HD void hessian_run(const double *jl, int jstride, int ncfg, int lane, Store store /* store(f, a, b, both) */)
 {
-    constexpr int HW = NJ * 6 * NJ;
+    constexpr int HW = NJ * 6 * NJ, BW = 6 * NJ;
     const int total = ncfg * HW;
-    for (int f = 2 * lane; f < total; f += 2 * kWave) {
-        double v[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int e = f + u;
-            const int r = e / HW, w = e - r * HW;
-            const int j = w / (6 * NJ), w2 = w - j * 6 * NJ;
-            const int row = w2 / NJ, i = w2 - row * NJ;
-            v[u] = e < total ? hessian_entry(jl + r * jstride, NJ, j, row, i) : 0.0;
-        }
-        store(f, v[0], v[1], f + 1 < total);
+    // (r, j, row, i) of entry f = 2*lane, then advanced by the wave's stride of 128 entries with carries --
+    // compile-time increments instead of six divisions per piece
+    constexpr int STEP = 2 * kWave;
+    constexpr int dR = STEP / HW, remR = STEP % HW, dJ = remR / BW, remJ = remR % BW, dRow = remJ / NJ, dI = remJ % NJ;
+    int f = 2 * lane;
+    int r = f / HW, w = f - r * HW;
+    int j = w / BW, w2 = w - j * BW;
+    int row = w2 / NJ, i = w2 - row * NJ;
+    for (; f < total; f += STEP) {
+        const double *Jr = jl + r * jstride;
+        const double a = hessian_entry(Jr, NJ, j, row, i);
+        // the neighbour entry f + 1: next column, wrapping into the next row / block / configuration
+        int i2 = i + 1, row2 = row, j2 = j, r2 = r;
+        if (i2 == NJ) { i2 = 0; if (++row2 == 6) { row2 = 0; if (++j2 == NJ) { j2 = 0; ++r2; } } }
+        const bool both = f + 1 < total;
+        const double b = both ? hessian_entry(jl + r2 * jstride, NJ, j2, row2, i2) : 0.0;
+        store(f, a, b, both);
+        i += dI; if (i >= NJ) { i -= NJ; ++row; }
+        row += dRow; if (row >= 6) { row -= 6; ++j; }
+        j += dJ; if (j >= NJ) { j -= NJ; ++r; }
+        r += dR;
     }
 }
 

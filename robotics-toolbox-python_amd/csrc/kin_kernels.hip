@@ -122,6 +122,8 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints ? RTB_REG_WAVES : 2)) v
     reg_tile<NJ, WANT_T, WANT_J>(kp, const_view(dc), q, T, J, buf, threadIdx.x, blockIdx.x);
 }
 
+static int g_hess_mode = 0;   // A/B knob (rtbhip_tune "hess_mode")
+
 // ---------------------------------------------------------------- Hessian, register-resident (n <= 8)
 // H is 48 n^2 bytes per configuration (2352 B for the Panda): the kernel is a pure HBM writer.  The
 // first version wrote each lane's block with 8-byte stores at a 2352-byte stride (3.27 ms per 1e6
@@ -159,9 +161,66 @@ __global__ __launch_bounds__(kWave, 2) void k_kin_hess(KinParams kp, DevChain dc
     });
 }
 
+// Variant B (A/B knob hess_mode = 1): every lane forms the (6,n) block H[j] of its OWN configuration in
+// registers (static indexing, no per-entry LDS gathers), the wave transposes the 64 blocks through LDS and
+// writes them as 64 segments of 48n bytes (2352-byte stride between configurations), one round per j.
+template <int NJ>
+__global__ __launch_bounds__(kWave, 2) void k_kin_hess_rounds(KinParams kp, DevChain dc, const double *__restrict__ q,
+                                                              double *__restrict__ H)
+{
+    extern __shared__ __attribute__((aligned(16))) double buf[];
+    const ConstChain cv = const_view(dc);
+    const int lane = threadIdx.x;
+    const int64_t cfg0 = (int64_t)blockIdx.x * kWave;
+    const int64_t left = kp.N - cfg0;
+    const int ncfg = left < kWave ? (int)left : kWave;
+    constexpr int W = 6 * NJ;
+    Pose P;
+    double jac[6 * NJ];
+    reg_compute<NJ, true>(kp, cv, q, cfg0 + lane, P, jac);
+    double *mine = buf + lane * (W + 1);
+    double *dst0 = H + cfg0 * (int64_t)(NJ * W);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const double wjx = jac[3 * NJ + j], wjy = jac[4 * NJ + j], wjz = jac[5 * NJ + j];
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) {
+            // j <= i: (w_j x v_i ; w_j x w_i);  j > i: (w_i x v_j ; 0)   (methods.cpp:16-32)
+            const int a = j <= i ? j : i, b = j <= i ? i : j;
+            const double ax = jac[3 * NJ + a], ay = jac[4 * NJ + a], az = jac[5 * NJ + a];
+            const double vx = jac[b], vy = jac[NJ + b], vz = jac[2 * NJ + b];
+            mine[0 * NJ + i] = ay * vz - az * vy;
+            mine[1 * NJ + i] = az * vx - ax * vz;
+            mine[2 * NJ + i] = ax * vy - ay * vx;
+            if (j <= i) {
+                const double ux = jac[3 * NJ + i], uy = jac[4 * NJ + i], uz = jac[5 * NJ + i];
+                mine[3 * NJ + i] = wjy * uz - wjz * uy;
+                mine[4 * NJ + i] = wjz * ux - wjx * uz;
+                mine[5 * NJ + i] = wjx * uy - wjy * ux;
+            } else {
+                mine[3 * NJ + i] = 0.0; mine[4 * NJ + i] = 0.0; mine[5 * NJ + i] = 0.0;
+            }
+        }
+        __syncthreads();
+        for (int f = 2 * lane; f < ncfg * W; f += 2 * kWave) {
+            const int c = f / W, e = f - c * W;
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            v2d w = {buf[c * (W + 1) + e], buf[c * (W + 1) + e + 1]};
+            __builtin_nontemporal_store(w, reinterpret_cast<v2d *>(dst0 + (int64_t)c * (NJ * W) + j * W + e));
+        }
+        __syncthreads();
+    }
+}
+
 template <int NJ>
 static hipError_t launch_hess_nj(dim3 grid, hipStream_t s, const KinParams &kp, const DevChain &dc, const double *q, double *H)
 {
+    if (g_hess_mode == 1) {
+        const size_t lds1 = (size_t)kWave * (6 * NJ + 1) * sizeof(double);
+        hipLaunchKernelGGL((k_kin_hess_rounds<NJ>), grid, dim3(kWave), lds1, s, kp, dc, q, H);
+        note_launch((int)grid.x, kWave, (int)lds1);
+        return hipGetLastError();
+    }
     const size_t lds = (size_t)kWave * (6 * NJ + 1) * sizeof(double);
     hipLaunchKernelGGL((k_kin_hess<NJ>), grid, dim3(kWave), lds, s, kp, dc, q, H);
     note_launch((int)grid.x, kWave, (int)lds);
@@ -267,6 +326,7 @@ void kin_tune(const char *key, int value)
     if (k == "coalesced") g_coalesced = value;
     if (k == "tiles_per_wave") g_tiles_per_wave = value < 1 ? 1 : value;
     if (k == "reg") g_use_reg = value;
+    if (k == "hess_mode") g_hess_mode = value;
 }
 
 template <bool WT, bool WJ, bool WH>
