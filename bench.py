@@ -99,8 +99,8 @@ def cpu_baseline(q_host, T_gpu, J_gpu, max_seconds=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--n", type=int, default=1000000, help="configurations per GPU per step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--tune", action="append", default=[], help="key=value for rtbhip_tune (A/B runs)")
