@@ -148,3 +148,18 @@ def test_gpu_full_size_fleet16_1e6_each_properties_and_sampled_parity():
         nt.assert_allclose(T[idx].cpu().numpy(), oracle.fkine(oc, qh), atol=TOL)
         nt.assert_allclose(J[idx].cpu().numpy(), oracle.jacob0(oc, qh), atol=TOL)
         del T, J
+
+
+@pytest.mark.gpu
+def test_gpu_fleet_more_chains_than_one_launch_table_holds():
+    """40 chains (> the 32-entry kernel-argument table): the call is split into several launches per class."""
+    rng = np.random.default_rng(8)
+    robots = [urdf.load(urdf.FLEET16[i % 16]) for i in range(40)]
+    chs = [r.ets() for r in robots]
+    qs = [_rand_q(rng, c, 50 + 3 * i) for i, c in enumerate(chs)]
+    Ts, Js = rtbhip.fleet_fkine_jacob(chs, qs)
+    for c, q, T, J in zip(chs, qs, Ts, Js):
+        oc = chain_from_ets(c)
+        nt.assert_allclose(T, oracle.fkine(oc, q), atol=TOL)
+        nt.assert_allclose(J, oracle.jacob0(oc, q), atol=TOL)
+    assert rtbhip.fleet_fkine_jacob([], []) == ([], [])
