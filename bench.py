@@ -108,6 +108,16 @@ def main():
 
     import numpy as np
     import torch
+    if not os.path.exists(os.path.join(ROOT, "robotics-toolbox-python_amd", "lib", "librtbhip.so")):
+        import __graft_entry__                   # a checkout without the (git-ignored) built library: compile it
+        libpath = os.path.join(ROOT, "robotics-toolbox-python_amd", "lib", "librtbhip.so")
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            __graft_entry__.build_lib()
+        else:
+            t_wait = time.time()
+            while not os.path.exists(libpath) and time.time() - t_wait < 600:
+                time.sleep(1.0)
+            time.sleep(2.0)                      # let the linker finish writing
     import rtbhip
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
