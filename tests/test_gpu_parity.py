@@ -475,3 +475,28 @@ def test_ik_small_chains_and_errors():
     perm = ET.Rz(jindex=1) * ET.tx(1.0) * ET.Rz(jindex=0)
     with pytest.raises(rtbhip.RtbHipError):
         perm.ik_LM(np.eye(4))
+
+
+def test_large_batch_64bit_indexing():
+    """N = 20,000,003 Panda configurations (q 1.1 GB, T 2.6 GB, J 6.7 GB on the device): element offsets pass
+    2^31, the last tile is ragged; the first and last rows must equal the oracle."""
+    import torch
+    N = 20000003
+    ets = rtbhip.models.Panda().ets()
+    ch = chains.panda_ets()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    q = (torch.rand((N, 7), dtype=torch.float64, device="cuda", generator=g) - 0.5) * 6.0
+    T, J = ets.fkine_jacob0(q)
+    torch.cuda.synchronize()
+    idx = torch.cat([torch.arange(0, 70), torch.arange(N - 70, N), torch.tensor([N // 2, 2 ** 24 + 1, 16777216 + 64 * 1000 + 5])]).cuda()
+    qh = q[idx].cpu().numpy()
+    nt.assert_allclose(T[idx].cpu().numpy(), oracle.fkine(ch, qh), atol=TOL)
+    nt.assert_allclose(J[idx].cpu().numpy(), oracle.jacob0(ch, qh), atol=TOL)
+    assert bool(torch.isfinite(T[-1]).all()) and float((T[:, 3, 3] - 1).abs().max()) == 0.0
+    del T, J
+    tau_arm = rtbhip.models.DH.Panda()
+    tau = tau_arm.rne(q, q, q)                         # 4 x 1.1 GB more: the RNE tile indexing at the same size
+    tab = chains.panda_dh()
+    ref = oracle.rne_dh(tab.L24(), 1, qh, qh, qh, -tab.gravity)
+    got = tau[idx].cpu().numpy()
+    nt.assert_allclose(got, ref, rtol=1e-9, atol=1e-9 * np.abs(ref).max())
