@@ -366,7 +366,7 @@ struct IkWaveShared {
     int32_t list[64];                       // scratch: compacted slot list
     uint16_t rec[64][kIkRing];              // per outstanding search: 1 finished | 2 ok | iterations << 2
     double Td[12][64];                      // per SLOT: the target pose (read by every lane working on the slot)
-    double q[kRegMaxJoints][64];            // per LANE: the joint vector of that search
+    double q[kIkMaxJoints][64];             // per LANE: the joint vector of that search
 };
 constexpr int kIkMaxIlimit = 16000;         // (ilimit + 1) << 2 must fit the 16-bit record
 

@@ -26,7 +26,7 @@ struct ConstChainIk {
 #define RTB_IK_WAVES 2
 #endif
 template <int NJ, bool PINV>
-__global__ __launch_bounds__(kWave, RTB_IK_WAVES) void k_ik(IkDev p, DevChain dc, const double *qlim_g, const double *__restrict__ Tep,
+__global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints ? RTB_IK_WAVES : 1)) void k_ik(IkDev p, DevChain dc, const double *qlim_g, const double *__restrict__ Tep,
                                                 const double *__restrict__ q0, unsigned long long *counter,
                                                 double *__restrict__ q_out, int32_t *__restrict__ success,
                                                 int32_t *__restrict__ iters, int32_t *__restrict__ searches,
@@ -200,7 +200,7 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
 {
     if (N == 0) return RTBHIP_OK;
     if (ip.ilimit > kIkMaxIlimit) { set_error("ik_lm: ilimit above 16000 is not supported by the device scheduler"); return RTBHIP_ELIMIT; }
-    if (c->n > kRegMaxJoints) { set_error("ik_lm: this build solves chains of up to 8 joints on the device"); return RTBHIP_ELIMIT; }
+    if (c->n > kIkMaxJoints) { set_error("ik_lm: this build solves chains of up to 12 joints on the device"); return RTBHIP_ELIMIT; }
     for (int j = 0; j < c->n; ++j)
         if (jm_jq(c->jmeta[j]) != j) { set_error("ik_lm: jindex must equal the joint order (the reference's ik.cpp:57 adds dq in that order)"); return RTBHIP_EINVAL; }
     IkDev p;
@@ -227,7 +227,7 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
     RTB_HIP(hipMemsetAsync(ctr, 0, sizeof(unsigned long long), s));
     // a batch smaller than the grid's lane count is spread over ALL the waves (fresh_cap targets per
     // wave and pass) instead of filling ceil(N/64) of them: every SIMD then holds its share of the tail
-    int64_t g = (int64_t)cus * g_ik_waves_per_cu;
+    int64_t g = (int64_t)cus * (c->n <= kRegMaxJoints ? g_ik_waves_per_cu : 4);   // 9..12 joints: one wave per SIMD
     if (g > N) g = N;
     const int64_t cap = (N + g - 1) / g;
     p.fresh_cap = cap > 64 ? 64 : (int32_t)cap;
@@ -245,7 +245,11 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
     case 5: launch_nj<5>(grid, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual); break;
     case 6: launch_nj<6>(grid, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual); break;
     case 7: launch_nj<7>(grid, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual); break;
-    default: launch_nj<8>(grid, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual); break;
+    case 8: launch_nj<8>(grid, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual); break;
+    case 9: launch_nj<9>(grid, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual); break;
+    case 10: launch_nj<10>(grid, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual); break;
+    case 11: launch_nj<11>(grid, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual); break;
+    default: launch_nj<12>(grid, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual); break;
     }
     note_launch((int)grid.x, kWave, 0);
     hipError_t e = hipGetLastError();

@@ -19,6 +19,7 @@
 namespace rtbhip {
 
 constexpr int kRegMaxJoints = 8;    // register-resident consumers (IK, Hessian, jacob_dot, manipulability ...)
+constexpr int kIkMaxJoints = 12;    // IK: chains of 9..12 joints run at one wave per SIMD (the whole 512-register budget)
 constexpr int kKinRegMax = 10;      // fkine / Jacobian tiles: 9 and 10 joints still fit the register file at 2 waves per SIMD
 #ifndef RTB_JROUND
 #define RTB_JROUND 32

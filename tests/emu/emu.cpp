@@ -317,7 +317,7 @@ extern "C" int emu_ik(rtbhip_chain_t h, const double *Tep, int64_t N, const doub
                       double *q_out, int32_t *success, int32_t *iters, int32_t *searches, double *residual)
 {
     Chain *c = chain_from_handle(h);
-    if (!c || c->n < 1 || c->n > kRegMaxJoints) return -1;
+    if (!c || c->n < 1 || c->n > kIkMaxJoints) return -1;
     IkDev p;
     p.ilimit = ilimit; p.slimit = slimit; p.reject_jl = reject_jl; p.method = method; p.flavour = flavour;
     p.has_q0 = q0 != nullptr; p.tol = tol; p.lambda = lambda; p.seed = seed; p.N = N; p.fresh_cap = 64; p.pool_chunk = 64; p.pass_mask = 0; p.pad = 0;
@@ -330,7 +330,11 @@ extern "C" int emu_ik(rtbhip_chain_t h, const double *Tep, int64_t N, const doub
     case 5: emu_ik_run<5>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
     case 6: emu_ik_run<6>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
     case 7: emu_ik_run<7>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
-    default: emu_ik_run<8>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
+    case 8: emu_ik_run<8>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
+    case 9: emu_ik_run<9>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
+    case 10: emu_ik_run<10>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
+    case 11: emu_ik_run<11>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
+    default: emu_ik_run<12>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
     }
     return 0;
 }
@@ -340,7 +344,7 @@ extern "C" int emu_ik_wave(rtbhip_chain_t h, int waves, double *stats, const dou
                       double *q_out, int32_t *success, int32_t *iters, int32_t *searches, double *residual)
 {
     Chain *c = chain_from_handle(h);
-    if (!c || c->n < 1 || c->n > kRegMaxJoints) return -1;
+    if (!c || c->n < 1 || c->n > kIkMaxJoints) return -1;
     IkDev p;
     p.ilimit = ilimit; p.slimit = slimit; p.reject_jl = reject_jl; p.method = method; p.flavour = flavour;
     p.has_q0 = q0 != nullptr; p.tol = tol; p.lambda = lambda; p.seed = seed; p.N = N; p.fresh_cap = 64; p.pool_chunk = 64; p.pass_mask = 0; p.pad = 0;
@@ -357,7 +361,11 @@ extern "C" int emu_ik_wave(rtbhip_chain_t h, int waves, double *stats, const dou
     case 5: rc = emu_ik_wave_run<5>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
     case 6: rc = emu_ik_wave_run<6>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
     case 7: rc = emu_ik_wave_run<7>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
-    default: rc = emu_ik_wave_run<8>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
+    case 8: rc = emu_ik_wave_run<8>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
+    case 9: rc = emu_ik_wave_run<9>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
+    case 10: rc = emu_ik_wave_run<10>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
+    case 11: rc = emu_ik_wave_run<11>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
+    default: rc = emu_ik_wave_run<12>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
     }
     return rc;
 }

@@ -461,6 +461,29 @@ def test_ik_config3_1e5_targets_statistics():
         assert (se.cpu().numpy()[~okh] == 101).all()
 
 
+def test_ik_ten_joint_chain_equals_oracle():
+    """URDF Fetch (10 joints on the path): IK at one wave per SIMD; same restart vectors -> the oracle's results."""
+    from rtbhip import urdf
+    from helpers import chain_from_ets
+    ets = urdf.load("Fetch").ets()
+    ets.qlim = np.clip(ets.qlim, -np.pi, np.pi)
+    ch = chain_from_ets(ets)
+    rng = np.random.default_rng(10)
+    N = 300
+    Tep = oracle.fkine(ch, rng.uniform(ch.qlim[0], ch.qlim[1], (N, 10)))
+    q, ok, it, se, E = ets.ik_LM(Tep, seed=5, slimit=30)
+    for i in range(0, N, 15):
+        rs = np.array([ets.ik_restart(5, i, d) for d in range(31)])
+        o = oracle.ik_lm(ch, Tep[i], restarts=rs, slimit=30)
+        assert (o[1], o[2], o[3]) == (ok[i], it[i], se[i])
+        nt.assert_allclose(q[i], o[0], atol=1e-6)
+    good = ok == 1
+    assert good.mean() > 0.8 and np.all(E[good] < 1e-6)
+    thirteen = rtbhip.DHRobot([rtbhip.RevoluteDH(a=0.1) for _ in range(13)]).ets()
+    with pytest.raises(rtbhip.RtbHipError):
+        thirteen.ik_LM(np.eye(4))
+
+
 def test_ik_small_chains_and_errors():
     ET = rtbhip.ET
     arm = ET.Rz() * ET.tx(1.0) * ET.Rz() * ET.tx(1.0)            # planar 2R
@@ -469,7 +492,7 @@ def test_ik_small_chains_and_errors():
     q, ok, it, se, E = arm.ik_LM(Tep, mask=[1, 1, 0, 0, 0, 1], joint_limits=False)
     assert ok.all()
     nt.assert_allclose(oracle.fkine(ch, q)[:, :2, 3], Tep[:, :2, 3], atol=2e-3)
-    big = rtbhip.ETS([ET.Rz() for _ in range(9)])
+    big = rtbhip.ETS([ET.Rz() for _ in range(13)])             # 13 joints: beyond the 12 the device build solves
     with pytest.raises(rtbhip.RtbHipError):
         big.ik_LM(np.eye(4))
     perm = ET.Rz(jindex=1) * ET.tx(1.0) * ET.Rz(jindex=0)

@@ -342,3 +342,28 @@ def test_ikine_nr_gn_python_loop_semantics(step):
             assert (o[1], o[2], o[3]) == (ok[i], it[i], se[i])
             nt.assert_allclose(q[i], o[0], atol=1e-6)
     assert checked >= 12
+
+
+@pytest.mark.parametrize("robot,n", [("Fetch", 10), ("KinovaGen3", 9)])
+def test_ik_nine_to_twelve_joint_chains(robot, n):
+    """IK on chains of 9..12 joints (URDF Fetch: torso + 7-joint arm + gripper path, Kinova Gen3 + finger): the
+    same search functions at a larger compile-time joint count; must equal the oracle's sequential loops."""
+    from rtbhip import urdf
+    from helpers import chain_from_ets
+    ets = urdf.load(robot).ets()
+    assert ets.n == n
+    ets.qlim = np.clip(ets.qlim, -np.pi, np.pi)
+    ch = chain_from_ets(ets)
+    rng = np.random.default_rng(n)
+    N = 12
+    Tep = oracle.fkine(ch, rng.uniform(ch.qlim[0], ch.qlim[1], (N, n)))
+    q, ok, it, se, E = emu.ik(ets, Tep, seed=5, slimit=30)
+    for i in range(N):
+        rs = np.array([emu.ik_restart(ets, 5, i, d) for d in range(31)])
+        o = oracle.ik_lm(ch, Tep[i], restarts=rs, slimit=30)
+        assert (o[1], o[2], o[3]) == (ok[i], it[i], se[i])
+        nt.assert_allclose(q[i], o[0], atol=1e-6)
+    b = emu.ik(ets, Tep, seed=5, slimit=30, waves=2)
+    for x, y in zip((q, ok, it, se, E), b):
+        nt.assert_array_equal(x, y)
+    assert ok.mean() >= 0.5
