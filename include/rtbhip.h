@@ -98,7 +98,7 @@ int rtbhip_hessian(rtbhip_chain_t chain, const double *q, int64_t N, const doubl
                    int32_t frame, double *H, int32_t mem, void *stream);
 
 /* Differential-kinematics consumers computed from the Jacobian while it is still in registers (SURVEY 8f-4;
- * chains of up to 8 joints):
+ * chains of up to 10 joints):
  *   rtbhip_jacob_dot       Robot.jacob0_dot (robot/Robot.py:964-1098, representation=None): Jd (N,6,n) = H(q) . qd,
  *                          frame 0 -> hessian0, 1 -> hessiane; qd is (N, q_width) like q
  *   rtbhip_manipulability  ETS.manipulability (robot/ETS.py:1687-1819): m (N); method 0 "yoshikawa",

@@ -130,7 +130,7 @@ static int g_hess_mode = 0;   // A/B knob (rtbhip_tune "hess_mode")
 // Panda configurations, 9 % of the HBM peak); here the wave stages its 64 Jacobians in LDS once and
 // every lane generates the 16-byte pieces of the tile's contiguous output run on the fly.
 template <int NJ>
-__global__ __launch_bounds__(kWave, 2) void k_kin_hess(KinParams kp, DevChain dc, const double *__restrict__ q,
+__global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints ? 2 : 1)) void k_kin_hess(KinParams kp, DevChain dc, const double *__restrict__ q,
                                                        double *__restrict__ H)
 {
     extern __shared__ __attribute__((aligned(16))) double buf[];
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kWave, 2) void k_kin_hess(KinParams kp, DevChain dc
 // registers (static indexing, no per-entry LDS gathers), the wave transposes the 64 blocks through LDS and
 // writes them as 64 segments of 48n bytes (2352-byte stride between configurations), one round per j.
 template <int NJ>
-__global__ __launch_bounds__(kWave, 2) void k_kin_hess_rounds(KinParams kp, DevChain dc, const double *__restrict__ q,
+__global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints ? 2 : 1)) void k_kin_hess_rounds(KinParams kp, DevChain dc, const double *__restrict__ q,
                                                               double *__restrict__ H)
 {
     extern __shared__ __attribute__((aligned(16))) double buf[];
@@ -232,7 +232,7 @@ static hipError_t launch_hess_nj(dim3 grid, hipStream_t s, const KinParams &kp, 
 // the reference materialises for each of them (robot/Robot.py:1069, robot/ETS.py:1671) never exists.
 enum { kDiffJdot = 0, kDiffManip = 1, kDiffJacobm = 2 };
 template <int NJ, int MODE>
-__global__ __launch_bounds__(kWave, 2) void k_kin_diff(KinParams kp, DevChain dc, int axes, const double *__restrict__ q,
+__global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints ? 2 : 1)) void k_kin_diff(KinParams kp, DevChain dc, int axes, const double *__restrict__ q,
                                                        const double *__restrict__ qd, double *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) double buf[];
@@ -289,7 +289,7 @@ int launch_kin_diff(const Chain *c, const DevChain &dc, int mode, int axes, cons
                     const Affine &tool, int frame, double *out, hipStream_t s)
 {
     if (N == 0) return RTBHIP_OK;
-    if (c->n < 1 || c->n > kRegMaxJoints) { set_error("jacob_dot/manipulability/jacobm: chains of 1..8 joints on the device"); return RTBHIP_ELIMIT; }
+    if (c->n < 1 || c->n > kKinRegMax) { set_error("jacob_dot/manipulability/jacobm: chains of 1..10 joints on the device"); return RTBHIP_ELIMIT; }
     const int64_t tiles = (N + kWave - 1) / kWave;
     if (tiles > 0x7fffffff) { set_error("jacob_dot/manipulability/jacobm: batch too large for one launch"); return RTBHIP_ELIMIT; }
     KinParams kp;
@@ -307,7 +307,9 @@ int launch_kin_diff(const Chain *c, const DevChain &dc, int mode, int axes, cons
     case 5: e = launch_diff_nj<5>(mode, grid, lds, s, kp, dc, axes, q, qd, out); break;
     case 6: e = launch_diff_nj<6>(mode, grid, lds, s, kp, dc, axes, q, qd, out); break;
     case 7: e = launch_diff_nj<7>(mode, grid, lds, s, kp, dc, axes, q, qd, out); break;
-    default: e = launch_diff_nj<8>(mode, grid, lds, s, kp, dc, axes, q, qd, out); break;
+    case 8: e = launch_diff_nj<8>(mode, grid, lds, s, kp, dc, axes, q, qd, out); break;
+    case 9: e = launch_diff_nj<9>(mode, grid, lds, s, kp, dc, axes, q, qd, out); break;
+    default: e = launch_diff_nj<10>(mode, grid, lds, s, kp, dc, axes, q, qd, out); break;
     }
     note_launch((int)grid.x, kWave, (int)lds);
     if (e != hipSuccess) return hip_fail(e, "k_kin_diff launch");
@@ -379,7 +381,7 @@ int launch_kin(const Chain *c, const DevChain &ops, const double *q, int64_t N, 
     int64_t g = (tiles + g_tiles_per_wave - 1) / g_tiles_per_wave;
     if (g > 0x7fffffff) g = 0x7fffffff;
     dim3 grid((unsigned)g);
-    if (g_use_reg && H && !T && !J && c->n >= 1 && c->n <= kRegMaxJoints && tiles <= 0x7fffffff) {
+    if (g_use_reg && H && !T && !J && c->n >= 1 && c->n <= kKinRegMax && tiles <= 0x7fffffff) {
         grid = dim3((unsigned)tiles);
         hipError_t e = hipSuccess;
         switch (c->n) {
@@ -390,7 +392,9 @@ int launch_kin(const Chain *c, const DevChain &ops, const double *q, int64_t N, 
         case 5: e = launch_hess_nj<5>(grid, s, kp, ops, q, H); break;
         case 6: e = launch_hess_nj<6>(grid, s, kp, ops, q, H); break;
         case 7: e = launch_hess_nj<7>(grid, s, kp, ops, q, H); break;
-        default: e = launch_hess_nj<8>(grid, s, kp, ops, q, H); break;
+        case 8: e = launch_hess_nj<8>(grid, s, kp, ops, q, H); break;
+        case 9: e = launch_hess_nj<9>(grid, s, kp, ops, q, H); break;
+        default: e = launch_hess_nj<10>(grid, s, kp, ops, q, H); break;
         }
         if (e != hipSuccess) return hip_fail(e, "k_kin_hess launch");
         return RTBHIP_OK;

@@ -147,7 +147,7 @@ static void emu_hess_run(const KinParams &kp, const DevChain &cv, const double *
 extern "C" int emu_kin_hess(rtbhip_chain_t h, const double *q, int64_t N, const double *tool16, int frame, double *H)
 {
     Chain *c = chain_from_handle(h);
-    if (!c || c->n < 1 || c->n > kRegMaxJoints) return -1;
+    if (!c || c->n < 1 || c->n > kKinRegMax) return -1;
     KinParams kp;
     kp.n = c->n; kp.qw = c->q_width; kp.stride = kin_stride(c->n); kp.frame = frame; kp.N = N; kp.pad = 0; kp.has_base = 0;
     Affine t = aff16(tool16);
@@ -161,7 +161,9 @@ extern "C" int emu_kin_hess(rtbhip_chain_t h, const double *q, int64_t N, const 
     case 5: emu_hess_run<5>(kp, cv, q, N, H); break;
     case 6: emu_hess_run<6>(kp, cv, q, N, H); break;
     case 7: emu_hess_run<7>(kp, cv, q, N, H); break;
-    default: emu_hess_run<8>(kp, cv, q, N, H); break;
+    case 8: emu_hess_run<8>(kp, cv, q, N, H); break;
+    case 9: emu_hess_run<9>(kp, cv, q, N, H); break;
+    default: emu_hess_run<10>(kp, cv, q, N, H); break;
     }
     return 0;
 }
@@ -490,7 +492,7 @@ extern "C" int emu_diff(rtbhip_chain_t h, int mode, int axes, const double *q, c
                         const double *tool16, int frame, double *out)
 {
     Chain *c = chain_from_handle(h);
-    if (!c || c->n < 1 || c->n > kRegMaxJoints) return -1;
+    if (!c || c->n < 1 || c->n > kKinRegMax) return -1;
     KinParams kp;
     kp.n = c->n; kp.qw = c->q_width; kp.stride = kin_stride(c->n); kp.frame = frame; kp.N = N; kp.pad = 0; kp.has_base = 0;
     Affine t = aff16(tool16);
@@ -504,7 +506,9 @@ extern "C" int emu_diff(rtbhip_chain_t h, int mode, int axes, const double *q, c
     case 5: diff_run<5>(kp, cv, mode, axes, q, qd, N, out); break;
     case 6: diff_run<6>(kp, cv, mode, axes, q, qd, N, out); break;
     case 7: diff_run<7>(kp, cv, mode, axes, q, qd, N, out); break;
-    default: diff_run<8>(kp, cv, mode, axes, q, qd, N, out); break;
+    case 8: diff_run<8>(kp, cv, mode, axes, q, qd, N, out); break;
+    case 9: diff_run<9>(kp, cv, mode, axes, q, qd, N, out); break;
+    default: diff_run<10>(kp, cv, mode, axes, q, qd, N, out); break;
     }
     return 0;
 }

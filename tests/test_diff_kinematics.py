@@ -18,7 +18,9 @@ def _cases():
     panda = rtbhip.models.Panda().ets()
     puma = rtbhip.models.DH.Puma560().ets()
     ur5 = urdf.load("UR5").ets()
-    return [("panda", panda, chains.panda_ets()), ("puma", puma, chain_from_ets(puma)), ("ur5", ur5, chain_from_ets(ur5))]
+    fetch = urdf.load("Fetch").ets()                       # 10 joints: the one-wave-per-SIMD instantiations
+    return [("panda", panda, chains.panda_ets()), ("puma", puma, chain_from_ets(puma)), ("ur5", ur5, chain_from_ets(ur5)),
+            ("fetch", fetch, chain_from_ets(fetch))]
 
 
 def test_oracle_pins():
@@ -51,12 +53,15 @@ def test_manipulability_goldens_reference_models():
         nt.assert_almost_equal(emu.diff(pu.ets(), 1, qn, axes=mask)[0], want, decimal=4)
 
 
-@pytest.mark.parametrize("name", ["panda", "puma", "ur5", "mixed"])
+@pytest.mark.parametrize("name", ["panda", "puma", "ur5", "mixed", "fetch10", "gen3_9"])
 def test_emu_vs_oracle(name):
     import emu_harness as emu
     if name == "mixed":
         spec = mixed_spec()
         e, ch = product_ets(spec), chains.Chain(spec)
+    elif name in ("fetch10", "gen3_9"):
+        e = urdf.load("Fetch" if name == "fetch10" else "KinovaGen3").ets()
+        ch = chain_from_ets(e)
     else:
         _, e, ch = [c for c in _cases() if c[0] == name][0]
     rng = np.random.default_rng(3)
@@ -100,9 +105,9 @@ def test_gpu_goldens_shapes_errors():
     # reference tests/test_ETS.py:4339-4353 (URDF Panda at qr)
     nt.assert_almost_equal(p.ets().manipulability(qr, method="invcondition", tool=p.tool), 0.11222, decimal=4)
     nt.assert_almost_equal(p.ets().manipulability(qr, method="minsingular", tool=p.tool), 0.209013, decimal=4)
-    nine = rtbhip.DHRobot([rtbhip.RevoluteDH(a=0.1) for _ in range(9)]).ets()
+    eleven = rtbhip.DHRobot([rtbhip.RevoluteDH(a=0.1) for _ in range(11)]).ets()
     with pytest.raises(rtbhip.RtbHipError):
-        nine.manipulability(np.zeros(9))
+        eleven.manipulability(np.zeros(11))
 
 
 @pytest.mark.gpu
