@@ -18,7 +18,7 @@ struct TreeParams {
     double grav[3];
 };
 
-constexpr int kTreeMaxGroups = 12;
+constexpr int kTreeMaxGroups = 16;
 
 template <int NG>
 __global__ __launch_bounds__(kWave, (NG <= 8 ? 2 : 1)) void k_tree_rne(TreeParams tp, const DevGroup *groups_g, const double *__restrict__ q,
@@ -77,7 +77,7 @@ int launch_tree_rne(const Tree *t, const DevGroup *groups, const double *q, cons
                     const double *grav3, double *tau, hipStream_t s)
 {
     if (N == 0) return RTBHIP_OK;
-    if (t->n > kTreeMaxGroups) { set_error("tree_rne: this build handles up to 12 joints (link groups) on the device"); return RTBHIP_ELIMIT; }
+    if (t->n > kTreeMaxGroups) { set_error("tree_rne: this build handles up to 16 joints (link groups) on the device"); return RTBHIP_ELIMIT; }
     const int64_t tiles = (N + kWave - 1) / kWave;
     if (tiles > 0x7fffffff) { set_error("tree_rne: batch too large for one launch"); return RTBHIP_ELIMIT; }
     TreeParams tp;
@@ -98,7 +98,11 @@ int launch_tree_rne(const Tree *t, const DevGroup *groups, const double *q, cons
     case 9: launch_ng<9>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
     case 10: launch_ng<10>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
     case 11: launch_ng<11>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
-    default: launch_ng<12>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
+    case 12: launch_ng<12>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
+    case 13: launch_ng<13>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
+    case 14: launch_ng<14>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
+    case 15: launch_ng<15>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
+    default: launch_ng<16>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
     }
     note_launch((int)grid.x, kWave, (int)lds);
     hipError_t e = hipGetLastError();

@@ -545,6 +545,10 @@ extern "C" int emu_tree_rne(const rtbhip_tree_group *groups, int ng, const doubl
     case 10: tree_run<10>(&t, q, qd, qdd, N, g, tau); break;
     case 11: tree_run<11>(&t, q, qd, qdd, N, g, tau); break;
     case 12: tree_run<12>(&t, q, qd, qdd, N, g, tau); break;
+    case 13: tree_run<13>(&t, q, qd, qdd, N, g, tau); break;
+    case 14: tree_run<14>(&t, q, qd, qdd, N, g, tau); break;
+    case 15: tree_run<15>(&t, q, qd, qdd, N, g, tau); break;
+    case 16: tree_run<16>(&t, q, qd, qdd, N, g, tau); break;
     default: return -2;
     }
     return 0;

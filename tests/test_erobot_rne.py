@@ -178,7 +178,8 @@ def test_gpu_random_trees_vs_oracle(seed, N):
     nt.assert_array_equal(rob.rne(qt, qdt, qddt, gravity=g).cpu().numpy().reshape(N, rob.n), tau)
 
 
-URDF_CASES = [("UR5", ()), ("KinovaGen3", ()), ("UR10", ()), ("AL5D", ()), ("Fetch", ()), ("px100", ()), ("Mico", ()), ("YuMi", ())]
+URDF_CASES = [("UR5", ()), ("KinovaGen3", ()), ("UR10", ()), ("AL5D", ()), ("Fetch", ()), ("px100", ()), ("Mico", ()), ("YuMi", ()),
+              ("YuMi", ("gripper_r_base", "gripper_l_base"))]
 
 
 def _urdf_case(name, exclude):
@@ -200,8 +201,8 @@ def test_emu_urdf_robots_vs_oracle(name, exclude):
     """URDF robots with <inertial> data: erobot() link tree -> group table -> kernel body (tests/emu) vs oracle."""
     import emu_harness as emu
     r, er, orc, exclude, q, qd, qdd = _urdf_case(name, exclude)
-    if er.n > 12:
-        pytest.skip("more than 12 link groups")
+    if er.n > 16:
+        pytest.skip("more than 16 link groups")
     assert sum(l.m for l in er.links) > 0
     got = emu.tree_rne(er.group_table(), q[:10], qd[:10], qdd[:10], [0, 0, -9.81])
     want = oer.erobot_rne(orc, q[:10], qd[:10], qdd[:10])
@@ -212,7 +213,7 @@ def test_emu_urdf_robots_vs_oracle(name, exclude):
 @pytest.mark.parametrize("name,exclude", URDF_CASES)
 def test_gpu_urdf_robots_vs_oracle(name, exclude):
     r, er, orc, exclude, q, qd, qdd = _urdf_case(name, exclude)
-    if er.n > 12:
+    if er.n > 16:
         with pytest.raises(rtbhip.RtbHipError):
             r.rne(q, qd, qdd, exclude=exclude)                 # loud ELIMIT, no fallback
         return
