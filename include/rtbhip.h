@@ -70,6 +70,11 @@ typedef uint64_t rtbhip_dyn_t;   /* replaces the "Robot" PyCapsule of frne (frne
 const char *rtbhip_last_error(void);
 int rtbhip_version(void);
 int rtbhip_device_count(int *count);
+/* Optional: rtbhip_init(n) fails loudly unless at least max(n,1) HIP devices are visible (n = -1: any number);
+ * rtbhip_shutdown() frees every cached device table (handles stay valid; tables are re-uploaded on next use).
+ * Neither is required: tables are uploaded lazily to the device that is current when a call runs. */
+int rtbhip_init(int32_t n_devices);
+void rtbhip_shutdown(void);
 
 /* ETS_init (fknm.cpp:1066-1114).  qlim: 2*n doubles, n lows then n highs, in chain joint order, or
  * NULL for the reference defaults [-pi,pi] / [0,1] (robot/ET.py:109-115). */

@@ -225,6 +225,7 @@ static int kin_entry(const char *fn, rtbhip_chain_t h, const double *q, int64_t 
 void kin_tune(const char *key, int value);
 void rne_tune(const char *key, int value);
 void ik_tune(const char *key, int value);
+void ik_release_device_state();
 
 }  // namespace rtbhip
 
@@ -234,6 +235,38 @@ extern "C" {
 
 const char *rtbhip_last_error(void) { return g_err.c_str(); }
 int rtbhip_version(void) { return 100; }
+
+int rtbhip_init(int32_t n_devices)
+{
+    int have = 0;
+    RTB_HIP(hipGetDeviceCount(&have));
+    if (have < 1) { set_error("init: no HIP device is visible"); return RTBHIP_EHIP; }
+    if (n_devices > have) { set_error("init: fewer HIP devices are visible than requested"); return RTBHIP_EHIP; }
+    return RTBHIP_OK;
+}
+
+void rtbhip_shutdown(void)
+{
+    // device copies of every table are dropped (handles stay valid: tables are re-uploaded lazily on next use)
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    for (auto &kv : g_chains) {
+        std::lock_guard<std::mutex> l2(kv.second->mu);
+        for (auto &d : kv.second->dev_ops) (void)hipFree(d.second);
+        for (auto &d : kv.second->dev_qlim) (void)hipFree(d.second);
+        kv.second->dev_ops.clear(); kv.second->dev_qlim.clear();
+    }
+    for (auto &kv : g_dyns) {
+        std::lock_guard<std::mutex> l2(kv.second->mu);
+        for (auto &d : kv.second->dev_links) (void)hipFree(d.second);
+        kv.second->dev_links.clear();
+    }
+    for (auto &kv : g_trees) {
+        std::lock_guard<std::mutex> l2(kv.second->mu);
+        for (auto &d : kv.second->dev_groups) (void)hipFree(d.second);
+        kv.second->dev_groups.clear();
+    }
+    ik_release_device_state();
+}
 
 int rtbhip_device_count(int *count)
 {

@@ -176,6 +176,13 @@ void ik_tune(const char *key, int value)
     if (std::string(key) == "ik_pass_mask") g_ik_pass_mask = value < 0 ? 0 : value;
 }
 
+void ik_release_device_state()
+{
+    std::lock_guard<std::mutex> lk(g_ctr_mu);
+    for (auto &kv : g_ctr) (void)hipFree(kv.second);
+    g_ctr.clear();
+}
+
 void ik_restart_host(const Chain *c, uint64_t seed, int64_t target, int draw, double *q_n)
 {
     const int n = c->n;

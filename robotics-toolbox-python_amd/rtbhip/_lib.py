@@ -43,6 +43,8 @@ SIGNATURES = {
     "rtbhip_last_error": (C.c_char_p, []),
     "rtbhip_version": (C.c_int, []),
     "rtbhip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "rtbhip_init": (C.c_int, [_i32]),
+    "rtbhip_shutdown": (None, []),
     "rtbhip_chain_create": (C.c_int, [C.POINTER(rtbhip_et), _i32, _vp, C.POINTER(_u64)]),
     "rtbhip_chain_destroy": (C.c_int, [_u64]),
     "rtbhip_chain_info": (C.c_int, [_u64, _ip, _ip, _ip]),

@@ -484,6 +484,21 @@ def test_ik_ten_joint_chain_equals_oracle():
         thirteen.ik_LM(np.eye(4))
 
 
+def test_init_and_shutdown_keep_handles_usable():
+    lib = rtbhip.lib()
+    assert lib.rtbhip_init(-1) == 0 and lib.rtbhip_init(1) == 0
+    assert lib.rtbhip_init(10 ** 6) != 0
+    ets = rtbhip.models.Panda().ets()
+    q = np.random.default_rng(0).uniform(-3, 3, (100, 7))
+    T0 = ets.eval(q)
+    arm = rtbhip.models.DH.Puma560()
+    t0 = arm.rne(q[:, :6], q[:, :6], q[:, :6])
+    lib.rtbhip_shutdown()                                   # drops every cached device table
+    nt.assert_array_equal(ets.eval(q), T0)                  # ... which are re-uploaded on next use
+    nt.assert_array_equal(arm.rne(q[:, :6], q[:, :6], q[:, :6]), t0)
+    assert ets.ik_LM(T0[0], seed=1)[1] in (0, 1)
+
+
 def test_ik_small_chains_and_errors():
     ET = rtbhip.ET
     arm = ET.Rz() * ET.tx(1.0) * ET.Rz() * ET.tx(1.0)            # planar 2R
