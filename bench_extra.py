@@ -123,6 +123,22 @@ def main():
                               "roofline": {"bound": "hbm", "achieved": byts * N / (avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                            "frac": byts * N / (avg * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": byts * N}}), flush=True)
 
+        # partial_fkine0 order 3: (N,7,7,6,7) output = 16.5 KB per configuration, so a tenth of the batch; the time includes the
+        # fkine/jacob0/hessian0 launch that feeds it and the temporaries' allocation (whole-call time, host clock around a sync)
+        import time
+        Np = N // 10
+        qp = q[:Np].contiguous()
+        ets.partial_fkine0(qp, 3); torch.cuda.synchronize()
+        ts = []
+        for _ in range(max(3, args.steps // 4)):
+            t0 = time.perf_counter(); ets.partial_fkine0(qp, 3); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        avg = 1e3 * sum(ts) / len(ts)
+        byts = 56 + 8 * 7 * 7 * 6 * 7
+        print(json.dumps({"metric": "configurations/sec (Panda partial_fkine0 n=3)", "value": Np / (avg * 1e-3), "unit": "configurations/s", "n": Np,
+                          "call_avg_ms": avg, "call_min_ms": 1e3 * min(ts),
+                          "roofline": {"bound": "hbm", "achieved": byts * Np / (avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                       "frac": byts * Np / (avg * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": byts * Np}}), flush=True)
+
     if "tree" in what:
         # Robot.rne of a URDF arm (UR5, 6 link groups, <inertial> masses) through k_tree_rne
         from rtbhip import urdf

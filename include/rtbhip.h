@@ -117,6 +117,13 @@ int rtbhip_manipulability(rtbhip_chain_t chain, const double *q, int64_t N, cons
 int rtbhip_jacobm(rtbhip_chain_t chain, const double *q, int64_t N, const double *tool16, int32_t axes_mask, double *Jm,
                   int32_t mem, void *stream);
 
+/* ETS.partial_fkine0 (robot/ETS.py:1821-2013; Robot.partial_fkine0, robot/RobotKinematics.py:456-500): the
+ * order-th partial derivative of the forward kinematics, order 3..6 (order 1 is jacob0, order 2 hessian0).
+ * out is (N, n^(order-1), 6, n), C order, i.e. (N,n,n,6,n) at order 3 -- the reference's tensor with a leading
+ * batch axis.  The lower-order tensors are stream-ordered temporaries (hipMallocAsync on `stream`). */
+int rtbhip_partial_fkine0(rtbhip_chain_t chain, const double *q, int64_t N, const double *tool16, int32_t order,
+                          double *out, int32_t mem, void *stream);
+
 /* IK_LM_c (fknm.cpp:394-525 -> ik.cpp:19-75,157-209), batched over N targets, LM loop resident
  * on the device.  Tep (N,4,4) row-major; q0 (N,n) or NULL; we6 host or NULL; method 0 chan /
  * 1 wampler / 2 sugihara, or -- the same search loop with the steps of IK_GN_c / IK_NR_c

@@ -112,6 +112,39 @@ def jacob_dot(ch, q, qd, tool=None, frame=0):
     return np.array([np.tensordot(H[i], qd[i], (0, 0)) for i in range(H.shape[0])])
 
 
+def partial_fkine0(ch, q, n, tool=None):
+    """ETS.partial_fkine0 (robot/ETS.py:1862-2013) for one configuration: dT[c][..., l, k, :, j] from the
+    product rule on H[k, :, j] = J_w[:, k] x J[:, j].  Same term bookkeeping as the reference
+    (`add_indices` / `add_pdi`, :1888-1927), plain loops."""
+    q = _f64(q).reshape(-1)
+    nj = ch.n
+    dT = [jacob(ch, q, tool, 0)[0], hessian(ch, q, tool, 0)[0]]
+    terms = [([1], [0])]                       # positions in the digit vector (j, k, l, ...)
+    while len(dT) < n:
+        c = len(dT) + 1                        # order of the tensor being built
+        nxt = []
+        for a, b in terms:
+            nxt.append((a + [c - 1], b))
+            nxt.append((a, b + [c - 1]))
+        terms = nxt
+        pd = np.zeros([nj] * (c - 1) + [6, nj])
+        for digits in np.ndindex(*([nj] * c)):                 # digits[0] = j, digits[1] = k, ...
+            trn = np.zeros(3)
+            rot = np.zeros(3)
+            for a, b in terms:
+                ta, tb = dT[len(a) - 1], dT[len(b) - 1]
+                ia = tuple(digits[i] for i in reversed(a[1:]))
+                ib = tuple(digits[i] for i in reversed(b[1:]))
+                wa = ta[ia + (slice(3, 6), digits[a[0]])]
+                rot += np.cross(wa, tb[ib + (slice(3, 6), digits[b[0]])])
+                trn += np.cross(wa, tb[ib + (slice(0, 3), digits[b[0]])])
+            lead = tuple(reversed(digits[1:]))
+            pd[lead + (slice(0, 3), digits[0])] = trn
+            pd[lead + (slice(3, 6), digits[0])] = rot
+        dT.append(pd)
+    return dT[n - 1]
+
+
 def _axes_list(axes):
     if isinstance(axes, str):
         if axes.startswith("all"):

@@ -2,6 +2,7 @@
 // Argument checking, handle registry, lazy per-device upload of the chain / link tables, and the
 // host-memory convenience path (stage -> launch -> copy back).  No arithmetic lives here.
 #include "rtbhip_internal.h"
+#include "partial_device.h"
 #include "tree_device.h"
 #include <atomic>
 #include <cstring>
@@ -388,6 +389,72 @@ int rtbhip_jacobm(rtbhip_chain_t chain, const double *q, int64_t N, const double
                   int32_t mem, void *stream)
 {
     return diff_entry("jacobm", chain, 2, axes_mask, q, nullptr, N, tool16, 0, Jm, mem, stream);
+}
+
+// stream-ordered temporaries: keep freed blocks in the current device's default pool instead of returning them at every sync
+static int pool_keep_cached()
+{
+    static std::mutex mu;
+    static std::vector<int> done;
+    int dev = 0;
+    RTB_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    for (int d : done) if (d == dev) return RTBHIP_OK;
+    hipMemPool_t pool;
+    RTB_HIP(hipDeviceGetDefaultMemPool(&pool, dev));
+    uint64_t keep = ~0ull;
+    RTB_HIP(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
+    done.push_back(dev);
+    return RTBHIP_OK;
+}
+
+/* ETS.partial_fkine0 (robot/ETS.py:1821-2013): order >= 3; orders 1 and 2 are jacob0 / hessian0 */
+int rtbhip_partial_fkine0(rtbhip_chain_t chain, const double *q, int64_t N, const double *tool16, int32_t order,
+                          double *out, int32_t mem, void *stream)
+{
+    Chain *c = chain_from_handle(chain);
+    if (!c) { set_error("partial_fkine0: unknown chain handle"); return RTBHIP_EINVAL; }
+    RTB_TRY(check_batch("partial_fkine0", q, N, mem));
+    if (order < 3 || order > kPartialMaxOrder) { set_error("partial_fkine0: order must be 3.." + std::to_string(kPartialMaxOrder)); return RTBHIP_EINVAL; }
+    if (c->n < 1) { set_error("partial_fkine0: chain has no joints"); return RTBHIP_EINVAL; }
+    if (N > 0 && !out) { set_error("partial_fkine0: NULL output"); return RTBHIP_EINVAL; }
+    if (N == 0) return RTBHIP_OK;
+    DevChain ops;
+    RTB_TRY(chain_device_ops(c, &ops, nullptr));
+    Affine base = affine_from16(nullptr), tool = affine_from16(tool16);
+    const int n = c->n;
+    hipStream_t s = mem == RTBHIP_MEM_DEVICE ? (hipStream_t)stream : nullptr;
+    Staging st;
+    void *dq = nullptr, *dout = nullptr;
+    const size_t obytes = (size_t)N * (size_t)partial_size(n, order) * 8;
+    if (mem == RTBHIP_MEM_HOST) {
+        RTB_TRY(st.in(q, (size_t)N * c->q_width * 8, &dq));
+        RTB_TRY(st.out(obytes, &dout));
+    } else { dq = (void *)q; dout = out; }
+    // the lower-order tensors are stream-ordered temporaries from the device's memory pool (kept cached between
+    // calls): the call only enqueues work, as every other device-pointer entry point does
+    RTB_TRY(pool_keep_cached());
+    double *lower[kPartialMaxOrder] = {nullptr};
+    int rc = RTBHIP_OK;
+    for (int a = 1; a < order && rc == RTBHIP_OK; ++a) {
+        void *p = nullptr;
+        hipError_t e = hipMallocAsync(&p, (size_t)N * (size_t)partial_size(n, a) * 8, s);
+        if (e != hipSuccess) rc = hip_fail(e, "hipMallocAsync (partial_fkine0 temporaries)");
+        lower[a - 1] = (double *)p;
+    }
+    // the two specialised launches (register-resident Jacobian, staged Hessian) beat the combined generic tile
+    if (rc == RTBHIP_OK) rc = launch_kin(c, ops, (const double *)dq, N, base, tool, 0, nullptr, lower[0], nullptr, s);
+    if (rc == RTBHIP_OK) rc = launch_kin(c, ops, (const double *)dq, N, base, tool, 0, nullptr, nullptr, lower[1], s);
+    for (int a = 3; a <= order && rc == RTBHIP_OK; ++a)
+        rc = launch_partial(n, a, lower, N, a == order ? (double *)dout : lower[a - 1], s);
+    for (int a = 1; a < order; ++a)
+        if (lower[a - 1]) (void)hipFreeAsync(lower[a - 1], s);
+    RTB_TRY(rc);
+    if (mem == RTBHIP_MEM_HOST) {
+        RTB_HIP(hipStreamSynchronize(s));
+        RTB_TRY(fetch(out, dout, obytes));
+    }
+    return RTBHIP_OK;
 }
 
 int rtbhip_ik_lm(rtbhip_chain_t chain, const double *Tep, int64_t N, const double *q0,

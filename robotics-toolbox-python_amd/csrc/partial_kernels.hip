@@ -1,0 +1,134 @@
+// partial_kernels.hip -- gfx950 kernel for ETS.partial_fkine0 (robot/ETS.py:1821-2013): the order-c
+// tensor of the forward kinematics' partial derivatives from the lower-order ones.  The output
+// (N, n^(c-1), 6, n) is a flat array of (6, n) blocks, block index = global column / n.  One lane owns one
+// 6-vector column; a workgroup of 256 lanes owns floor(256 / n) consecutive blocks, assembles them in LDS and
+// writes them as one contiguous run of 16-byte stores (lane-per-column stores would touch each 128-byte line
+// six times with 8n useful bytes).  The Jacobians and Hessians of the one or two configurations a workgroup
+// touches are copied to LDS first: every column reads 9 x 2^(c-2) of their elements at lane-scattered addresses,
+// and as global loads those share the texture-address path with the stores (measured: 0.34 ms of loads +
+// 0.30 ms of stores = 0.64 ms per 1e5 Panda configurations at order 3, not overlapped).  Bound: HBM writes, 48 n^c bytes per configuration (16.5 KB at order 3,
+// 115 KB at order 4 for the Panda) against 2^(c-2) x 18 flops per column.
+#include "partial_device.h"
+#include "rtbhip_internal.h"
+
+namespace rtbhip {
+
+struct PartialSrc {
+    const double *p[kPartialMaxOrder];
+};
+
+constexpr int kPartialStage = 2560;                                  // most doubles of LDS spent on staged Jacobians + Hessians
+
+constexpr int kPartialBlock = 256;
+
+// (6, n) blocks per workgroup: as many as 256 lanes hold, rounded down so that a workgroup's run of 48 n bytes per
+// block is a whole number of 128-byte lines (neighbouring workgroups -- possibly on different XCDs, i.e. different
+// L2s -- then never share a line)
+__host__ __device__ inline int partial_blocks_per_group(int n)
+{
+    int per = kPartialBlock / n, m = 8;
+    for (int g = 3 * n; m > 1 && g % m != 0;) m >>= 1;              // m = gcd(3 n, 8)
+    m = 8 / m;
+    return per >= m ? per - per % m : per;
+}
+
+// LDS: [tile: per x 6n doubles][stage: stage_cfgs x (6n + 6n^2) doubles], sized by the launcher -- the kernel is bound by
+// the bytes its resident workgroups keep in flight, so every KB of LDS not asked for is occupancy
+template <int C>
+__global__ __launch_bounds__(kPartialBlock) void k_partial(PartialPlan plan, PartialSrc src, int stage_cfgs, double *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int n = plan.n, tid = threadIdx.x;
+    const int per = partial_blocks_per_group(n);
+    double *tile = lds, *stage = lds + ((per * 6 * n + 1) & ~1);
+    const uint32_t bpc = (uint32_t)plan.cols / (uint32_t)n;           // blocks per configuration
+    const int64_t b0 = (int64_t)blockIdx.x * per;
+    const int64_t left = plan.N * bpc - b0;
+    const int nb = left < per ? (int)left : per;
+    const int64_t cfg0 = b0 / bpc;                                   // wave-uniform: scalar unit
+    const uint32_t lb0 = (uint32_t)(b0 - cfg0 * bpc);
+    // orders 1 and 2 of the K configurations this workgroup touches -> LDS: [K Jacobians][K Hessians]
+    const int K = (int)((lb0 + nb - 1) / bpc) + 1;
+    const int szj = 6 * n, szh = 6 * n * n;
+    const bool staged = K <= stage_cfgs;
+    if (staged) {
+        const double *J = src.p[0] + cfg0 * szj, *H = src.p[1] + cfg0 * szh;
+        // [K Jacobians][K Hessians] are two contiguous source runs; all loads in flight before the first LDS write
+        constexpr int kIt = (kPartialStage + kPartialBlock - 1) / kPartialBlock;
+        double r[kIt];
+        const int tj = K * szj, tot = K * (szj + szh);
+#pragma unroll
+        for (int u = 0; u < kIt; ++u) {
+            const int i = tid + u * kPartialBlock;
+            r[u] = i < tj ? J[i] : (i < tot ? H[i - tj] : 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < kIt; ++u) {
+            const int i = tid + u * kPartialBlock;
+            if (i < tot) stage[i] = r[u];
+        }
+        __syncthreads();
+    }
+    typedef const __attribute__((address_space(3))) double *LdsPtr;     // explicit LDS loads (ds_read), never flat
+    const LdsPtr sj = (LdsPtr)stage, sh = (LdsPtr)stage + K * szj;
+    uint32_t j, lbr;
+    const int bl = (int)divmod24((uint32_t)tid, (uint32_t)n, 1.0f / (float)n, &j);
+    if (bl < nb) {
+        const uint32_t dc = divmod24(lb0 + bl, bpc, 1.0f / (float)bpc, &lbr);     // this workgroup may straddle configurations
+        double *t = tile + mad24((uint32_t)bl, 6u * n, j);
+        const int64_t cfg = cfg0 + dc;
+        const uint32_t col = mad24(lbr, (uint32_t)n, j);
+        auto put = [&](int r, double v) { t[r * n] = v; };
+        if (staged) {
+            const LdsPtr cj = sj + mad24(dc, (uint32_t)szj, 0), ch = sh + mad24(dc, (uint32_t)szh, 0);
+            partial_column<C>(plan, [&](int order, int64_t c, int off) -> double {
+                if (order == 1) return cj[off];
+                if (order == 2) return ch[off];
+                return src.p[order - 1][c * plan.size[order] + off];
+            }, cfg, col, put);
+        } else {
+            partial_column<C>(plan, [&](int order, int64_t c, int off) -> double { return src.p[order - 1][c * plan.size[order] + off]; },
+                              cfg, col, put);
+        }
+    }
+    __syncthreads();
+    const int pairs = nb * 3 * n;                                    // 6n doubles per block, two per store
+    double *dst = out + b0 * 6 * n;                                  // 48 n bytes per block: 16-byte aligned
+    for (int i = tid; i < pairs; i += kPartialBlock) {
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const v2d w = *reinterpret_cast<const v2d *>(tile + 2 * i);
+        __builtin_nontemporal_store(w, reinterpret_cast<v2d *>(dst + 2 * i));          // global_store_dwordx4 ... nt
+    }
+}
+
+// lower[a-1] = order-a tensor (device), a = 1 .. order-1; out = order-`order` tensor
+int launch_partial(int n, int order, const double *const *lower, int64_t N, double *out, hipStream_t s)
+{
+    if (N == 0) return RTBHIP_OK;
+    PartialPlan plan;
+    partial_plan(n, order, &plan);
+    plan.N = N;
+    PartialSrc src;
+    for (int a = 0; a < kPartialMaxOrder; ++a) src.p[a] = a < order - 1 ? lower[a] : nullptr;
+    const int per = partial_blocks_per_group(n);
+    const int64_t blocks = (N * (int64_t)(plan.cols / n) + per - 1) / per;
+    if (plan.size[order - 1] >= (1 << 24) || plan.cols >= (1 << 24)) { set_error("partial_fkine0: tensor too large (n^order must stay below 2^24)"); return RTBHIP_ELIMIT; }
+    if (blocks > 0x7fffffff) { set_error("partial_fkine0: batch too large for one launch"); return RTBHIP_ELIMIT; }
+    const dim3 grid((unsigned)blocks), block(kPartialBlock);
+    const int64_t bpc = plan.cols / n;
+    int stage_cfgs = (int)((per + bpc - 2) / bpc) + 1;                 // most configurations one workgroup can touch
+    if ((int64_t)stage_cfgs * (6 * n + 6 * n * n) > kPartialStage) stage_cfgs = 0;
+    const size_t lds = (size_t)(((per * 6 * n + 1) & ~1) + stage_cfgs * (6 * n + 6 * n * n)) * sizeof(double);
+    switch (order) {
+    case 3: hipLaunchKernelGGL(k_partial<3>, grid, block, lds, s, plan, src, stage_cfgs, out); break;
+    case 4: hipLaunchKernelGGL(k_partial<4>, grid, block, lds, s, plan, src, stage_cfgs, out); break;
+    case 5: hipLaunchKernelGGL(k_partial<5>, grid, block, lds, s, plan, src, stage_cfgs, out); break;
+    default: hipLaunchKernelGGL(k_partial<6>, grid, block, lds, s, plan, src, stage_cfgs, out); break;
+    }
+    note_launch((int)blocks, kPartialBlock, (int)lds);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "k_partial launch");
+    return RTBHIP_OK;
+}
+
+}  // namespace rtbhip

@@ -61,6 +61,7 @@ SIGNATURES = {
     "rtbhip_jacob_dot": (C.c_int, [_u64, _vp, _vp, _i64, _vp, _i32, _vp, _i32, _vp]),
     "rtbhip_manipulability": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _i32, _vp, _i32, _vp]),
     "rtbhip_jacobm": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _vp, _i32, _vp]),
+    "rtbhip_partial_fkine0": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _vp, _i32, _vp]),
     "rtbhip_tree_create": (C.c_int, [C.POINTER(rtbhip_tree_group), _i32, C.POINTER(_u64)]),
     "rtbhip_tree_destroy": (C.c_int, [_u64]),
     "rtbhip_tree_rne": (C.c_int, [_u64, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp]),
@@ -84,6 +85,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RtbHipError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950); this package has no CPU fallback" % LIB_PATH)
+        # One HIP runtime per process: PyTorch ships its own libamdhip64 / libhsa-runtime64, and whichever copy is
+        # loaded first serves both (same SONAME).  torch's must be that copy -- it cannot see the GPU through the
+        # system runtime -- so bring it in before librtbhip.so pulls in /opt/rocm's.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)

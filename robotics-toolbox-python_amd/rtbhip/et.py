@@ -420,6 +420,23 @@ class ETS:
                                   self._ptr(Jm, tm), MEM_DEVICE if tm else MEM_HOST, self._stream(tm)))
         return Jm[0].reshape(self.n, 1) if single else Jm
 
+    def partial_fkine0(self, q, n=3, tool=None):
+        """n-th partial derivative of the forward kinematics (robot/ETS.py:1821-2013): n = 1 is jacob0,
+        n = 2 hessian0, n >= 3 the (n_joints, ..., 6, n_joints) tensor; a 2-D q adds a leading batch axis."""
+        n = int(n)
+        if n < 1:
+            raise ValueError("n must be >= 1")
+        if n == 1:
+            return self.jacob0(q, tool=tool)
+        if n == 2:
+            return self.hessian0(q, tool=tool)
+        q2, single, tm = self._shape_q(q)
+        N = q2.shape[0]
+        out = self._out((N,) + (self.n,) * (n - 1) + (6, self.n), q2, tm)
+        check(lib().rtbhip_partial_fkine0(self._handle(), self._ptr(q2, tm), N, host_ptr(small(tool, 16)), n,
+                                          self._ptr(out, tm), MEM_DEVICE if tm else MEM_HOST, self._stream(tm)))
+        return out[0] if single else out
+
     # ------------------------------------------------------------ inverse kinematics
     def _ik(self, Tep, q0, ilimit, slimit, tol, mask, joint_limits, k, method, flavour, seed):
         n = self.n

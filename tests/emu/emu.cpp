@@ -9,6 +9,7 @@
 #include "../../robotics-toolbox-python_amd/csrc/dyn_device.h"
 #include "../../robotics-toolbox-python_amd/csrc/diff_device.h"
 #include "../../robotics-toolbox-python_amd/csrc/tree_device.h"
+#include "../../robotics-toolbox-python_amd/csrc/partial_device.h"
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
@@ -509,6 +510,37 @@ extern "C" int emu_diff(rtbhip_chain_t h, int mode, int axes, const double *q, c
     case 8: diff_run<8>(kp, cv, mode, axes, q, qd, N, out); break;
     case 9: diff_run<9>(kp, cv, mode, axes, q, qd, N, out); break;
     default: diff_run<10>(kp, cv, mode, axes, q, qd, N, out); break;
+    }
+    return 0;
+}
+
+// ETS.partial_fkine0: the host plan + the per-column device function of partial_device.h, every column of
+// every order replayed on the CPU from the emulated Jacobian and Hessian
+extern "C" int emu_partial(rtbhip_chain_t h, const double *q, int64_t N, const double *tool16, int order, double *out)
+{
+    Chain *c = chain_from_handle(h);
+    if (!c || order < 3 || order > kPartialMaxOrder) return -1;
+    const int n = c->n;
+    std::vector<std::vector<double>> lower(order - 1);
+    for (int a = 1; a < order; ++a) lower[a - 1].assign((size_t)N * partial_size(n, a), 0.0);
+    if (emu_kin(h, q, N, nullptr, tool16, 0, nullptr, lower[0].data(), lower[1].data(), 1) != 0) return -1;
+    auto src = [&](int o, int64_t cfg, int off) -> double { return lower[o - 1][(size_t)cfg * partial_size(n, o) + off]; };
+    for (int a = 3; a <= order; ++a) {
+        PartialPlan plan;
+        partial_plan(n, a, &plan);
+        plan.N = N;
+        double *dst = a == order ? out : lower[a - 1].data();
+        for (int64_t cfg = 0; cfg < N; ++cfg)
+            for (uint32_t col = 0; col < (uint32_t)plan.cols; ++col) {
+                double *o = dst + cfg * partial_size(n, a) + (col / n) * 6 * n + col % n;      // (.., 6, n) block col / n, column col % n
+                auto put = [&](int r, double v) { o[r * n] = v; };
+                switch (a) {
+                case 3: partial_column<3>(plan, src, cfg, col, put); break;
+                case 4: partial_column<4>(plan, src, cfg, col, put); break;
+                case 5: partial_column<5>(plan, src, cfg, col, put); break;
+                default: partial_column<6>(plan, src, cfg, col, put); break;
+                }
+            }
     }
     return 0;
 }

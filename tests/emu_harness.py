@@ -13,7 +13,7 @@ PKG = os.path.join(ROOT, "robotics-toolbox-python_amd")
 EMU_SO = os.path.join(ROOT, "tests", "emu", "libemu.so")
 SRCS = ["tests/emu/emu.cpp"] + ["robotics-toolbox-python_amd/csrc/" + f for f in
                                 ("api.cpp", "chain.cpp", "tree.cpp", "kin_kernels.hip", "rne_kernels.hip", "ik_kernels.hip", "dyn_kernels.hip",
-                                 "tree_kernels.hip")]
+                                 "tree_kernels.hip", "partial_kernels.hip")]
 _vp, _u64, _i64, _i32 = C.c_void_p, C.c_uint64, C.c_int64, C.c_int32
 _lib = None
 
@@ -63,6 +63,7 @@ def lib():
         _lib.emu_rne.argtypes = [_u64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32]
         _lib.emu_kin_hess.argtypes = [_u64, _vp, _i64, _vp, _i32, _vp]
         _lib.emu_diff.argtypes = [_u64, _i32, _i32, _vp, _vp, _i64, _vp, _i32, _vp]
+        _lib.emu_partial.argtypes = [_u64, _vp, _i64, _vp, _i32, _vp]
         _lib.emu_dyn.argtypes = [_u64, _i32, _vp, _vp, _vp, _i64, _vp, _vp]
         _lib.emu_kin_reg.argtypes = [_u64, _vp, _i64, _vp, _vp, _i32, _vp, _vp]
         _lib.emu_sincos.argtypes = [_vp, _i64, _vp, _vp, _i32]
@@ -158,6 +159,17 @@ def diff(ets, mode, q, qd=None, axes=63, tool=None, frame=0):
     out = np.full({0: (N, 6, n), 1: (N,), 2: (N, n)}[mode], np.nan)
     t = None if tool is None else np.ascontiguousarray(tool, dtype=np.float64)
     assert lib().emu_diff(h, mode, axes, _p(q), _p(qd), N, _p(t), frame, _p(out)) == 0
+    return out
+
+
+def partial(ets, q, order, tool=None):
+    """ETS.partial_fkine0 through partial_device.h on the CPU: (N, n, ..., 6, n)."""
+    h = chain_handle(ets)
+    q = np.ascontiguousarray(np.asarray(q, dtype=np.float64).reshape(-1, ets.q_width))
+    N, n = q.shape[0], ets.n
+    out = np.full((N,) + (n,) * (order - 1) + (6, n), np.nan)
+    t = None if tool is None else np.ascontiguousarray(tool, dtype=np.float64)
+    assert lib().emu_partial(h, _p(q), N, _p(t), order, _p(out)) == 0
     return out
 
 

@@ -72,6 +72,7 @@ def main():
     # manipulability / jacobm goldens
     add("K_panda_jacobm_q", "test_ERobot.py", "test_jacobm", "q1")
     add("K_panda_jacobm", "test_ERobot.py", "test_jacobm", "ans")
+    add("K_panda_partial_fkine3", "test_ETS.py", "test_partial_fkine", "ans")     # (7,7,6,7) at panda_q
     # G11 -- DH robots
     add("G11_dh_rprp_fkine", "test_DHRobot.py", "test_fkine", "T1")
     add("G11_dh_panda_fkine", "test_DHRobot.py", "test_fkine_panda", "T")

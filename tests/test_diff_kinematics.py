@@ -165,3 +165,74 @@ def test_gpu_dhrobot_passthroughs_puma_goldens():
     qd = [0.1, -0.2, 0.3, -0.4, 0.5, -0.6]
     H = puma.hessian0(qn)
     nt.assert_allclose(puma.jacob0_dot(qn, qd), np.tensordot(H, qd, (0, 0)), atol=1e-12)
+
+
+# ---------------------------------------------------------------- partial_fkine0 (ETS.py:1821-2013)
+def test_oracle_partial_fkine3_golden():
+    """tests/test_ETS.py:1796-4263: the (7,7,6,7) literal for the Panda at q1 (assert_almost_equal, 7 dp)."""
+    q = np.array(LIT["panda_q"])
+    ans = np.array(LIT["K_panda_partial_fkine3"])
+    assert ans.shape == (7, 7, 6, 7)
+    got = oracle.partial_fkine0(chains.panda_ets(), q, 3)
+    nt.assert_almost_equal(got, ans)
+    # orders 1 and 2 are the Jacobian and the Hessian
+    nt.assert_allclose(oracle.partial_fkine0(chains.panda_ets(), q, 2), oracle.hessian0(chains.panda_ets(), q)[0])
+
+
+def test_emu_partial_fkine_matches_oracle_and_golden():
+    import emu_harness as emu
+    ch = chains.panda_ets()
+    ets = rtbhip.models.Panda().ets()
+    q = np.array(LIT["panda_q"])
+    nt.assert_almost_equal(emu.partial(ets, q, 3)[0], np.array(LIT["K_panda_partial_fkine3"]))
+    rng = np.random.default_rng(5)
+    qs = rng.uniform(-np.pi, np.pi, (3, 7))
+    tool = chains.elementary("tx", 0.1) @ chains.elementary("Ry", 0.3)
+    got = emu.partial(ets, qs, 3, tool=tool)
+    for i in range(3):
+        nt.assert_allclose(got[i], oracle.partial_fkine0(ch, qs[i], 3, tool=tool), atol=1e-12)
+    # order 4 on a short chain with every joint kind, against the oracle and a finite difference of order 3
+    spec = [("Rz", None), ("tx", 0.3), ("Ry", None, True), ("tz", None), ("Rx", None), ("ty", 0.2)]
+    short = chains.Chain(spec, name="short4")
+    es = product_ets(spec)
+    q4 = rng.uniform(-1, 1, (2, 4))
+    g4 = emu.partial(es, q4, 4)
+    assert g4.shape == (2, 4, 4, 4, 6, 4)
+    for i in range(2):
+        nt.assert_allclose(g4[i], oracle.partial_fkine0(short, q4[i], 4), atol=1e-12)
+    g5 = emu.partial(es, q4, 5)
+    nt.assert_allclose(g5[1], oracle.partial_fkine0(short, q4[1], 5), atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_gpu_partial_fkine0():
+    import torch
+    panda = rtbhip.models.Panda()
+    q1 = np.array(LIT["panda_q"])
+    ans = np.array(LIT["K_panda_partial_fkine3"])
+    nt.assert_almost_equal(panda.ets().partial_fkine0(q1, 3), ans)            # reference tests/test_ETS.py:4259-4263
+    nt.assert_almost_equal(panda.partial_fkine0(q1, 3), ans)                  # Robot level (r2 in the same test)
+    nt.assert_array_equal(panda.ets().partial_fkine0(q1, 1), panda.ets().jacob0(q1))
+    nt.assert_array_equal(panda.ets().partial_fkine0(q1, 2), panda.ets().hessian0(q1))
+    rng = np.random.default_rng(11)
+    for name, e, ch in _cases()[:3]:
+        N = 130
+        q = rng.uniform(-2, 2, (N, e.n))
+        P3 = e.partial_fkine0(q, 3)
+        assert P3.shape == (N, e.n, e.n, 6, e.n)
+        for i in (0, 63, 64, 129):
+            nt.assert_allclose(P3[i], oracle.partial_fkine0(ch, q[i], 3), atol=1e-11)
+        # (the reference's tensor is the product rule applied to H[k,:,j] = J_w[:,k] x J[:,j] for every index order; it is
+        # the true derivative of its Hessian only where that expression is, so there is no finite-difference property to test)
+        qt = torch.from_numpy(q).cuda()
+        nt.assert_array_equal(e.partial_fkine0(qt, 3).cpu().numpy(), P3)
+    e, ch = _cases()[2][1:]                                                   # UR5: orders 4 and 5
+    q = rng.uniform(-2, 2, (3, e.n))
+    P4 = e.partial_fkine0(q, 4)
+    nt.assert_allclose(P4[2], oracle.partial_fkine0(ch, q[2], 4), atol=1e-11)
+    P5 = e.partial_fkine0(q[:2], 5)
+    assert P5.shape == (2,) + (6,) * 4 + (6, 6)
+    nt.assert_allclose(P5[0], oracle.partial_fkine0(ch, q[0], 5), atol=1e-11)
+    with pytest.raises(rtbhip.RtbHipError):
+        e.partial_fkine0(q, 7)
+    assert e.partial_fkine0(np.zeros((0, 6)), 3).shape == (0, 6, 6, 6, 6)
