@@ -202,8 +202,10 @@ RTB_HD void pose_store16(const Pose &P, Put put)
 template <class Get, class Put>
 RTB_HD void hessian_from_jacobian(int n, Get get, Put put /* put(index into n*6*n, v) */)
 {
+#pragma unroll
     for (int j = 0; j < n; ++j) {
         const double wjx = get(3 * n + j), wjy = get(4 * n + j), wjz = get(5 * n + j);
+#pragma unroll
         for (int i = j; i < n; ++i) {
             const double vx = get(i), vy = get(n + i), vz = get(2 * n + i);
             const double wx = get(3 * n + i), wy = get(4 * n + i), wz = get(5 * n + i);
@@ -264,6 +266,24 @@ RTB_HD void hessian_run(const double *jl, int jstride, int ncfg, int lane, Store
         row += dRow; if (row >= 6) { row -= 6; ++j; }
         j += dJ; if (j >= NJ) { j -= NJ; ++r; }
         r += dR;
+    }
+}
+
+// Contiguous run of ncfg rows of W doubles (W even, row stride `stride` in the staging buffer) handed out as
+// 16-byte pieces: lane l gets pieces l, l+64, ...; (row, column) advance by compile-time steps with a carry.
+template <int W, class Store>
+RTB_HD void flush_rows(const double *rows, int stride, int ncfg, int lane, Store store /* store(f, a, b) */)
+{
+    static_assert(W % 2 == 0, "pieces must not straddle rows");
+    constexpr int STEP = 2 * kWave, dR = STEP / W, dE = STEP % W;
+    const int total = ncfg * W;
+    int f = 2 * lane;
+    int r = f / W, e = f - r * W;
+    for (; f < total; f += STEP) {
+        const double *p = rows + r * stride + e;
+        store(f, p[0], p[1]);
+        e += dE; r += dR;
+        if (e >= W) { e -= W; ++r; }
     }
 }
 

@@ -164,9 +164,13 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints ? 2 : 1)) void k_kin_he
 // Variant B (A/B knob hess_mode = 1): every lane forms the (6,n) block H[j] of its OWN configuration in
 // registers (static indexing, no per-entry LDS gathers), the wave transposes the 64 blocks through LDS and
 // writes them as 64 segments of 48n bytes (2352-byte stride between configurations), one round per j.
-template <int NJ>
-__global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints ? 2 : 1)) void k_kin_hess_rounds(KinParams kp, DevChain dc, const double *__restrict__ q,
-                                                              double *__restrict__ H)
+// Hessian, tiled form (default): every lane keeps its finished Jacobian in registers; in R rounds a group of 64/R lanes
+// expands its Hessians (compile-time indices: ~9 fp64 ops per (j, i) block instead of ~50 integer + select
+// instructions per entry in hessian_run) into an LDS tile of whole (n,6,n) rows, which the full wave then writes as one
+// contiguous run.  LDS per wave (64/R) x (6 n^2 + 1) doubles: n = 7, R = 8 -> 18.9 KB.
+template <int NJ, int R>
+__global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && R >= 8 ? 2 : 1)) void k_kin_hess_tile(KinParams kp, DevChain dc, const double *__restrict__ q,
+                                                                                               double *__restrict__ H)
 {
     extern __shared__ __attribute__((aligned(16))) double buf[];
     const ConstChain cv = const_view(dc);
@@ -174,53 +178,47 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints ? 2 : 1)) void k_kin_he
     const int64_t cfg0 = (int64_t)blockIdx.x * kWave;
     const int64_t left = kp.N - cfg0;
     const int ncfg = left < kWave ? (int)left : kWave;
-    constexpr int W = 6 * NJ;
+    constexpr int HW = NJ * 6 * NJ, S = HW | 1, G = kWave / R;
     Pose P;
     double jac[6 * NJ];
     reg_compute<NJ, true>(kp, cv, q, cfg0 + lane, P, jac);
-    double *mine = buf + lane * (W + 1);
-    double *dst0 = H + cfg0 * (int64_t)(NJ * W);
+    const int grp = lane / G;
+    double *mine = buf + (lane - grp * G) * S;
+    for (int r = 0; r < R; ++r) {
+        const int cnt = ncfg - r * G < G ? ncfg - r * G : G;
+        if (cnt <= 0) break;                                         // wave-uniform
+        if (grp == r) {
+            // the expansion must stay inside its round: hoisted out of the loop it would hold all 6 n^2 entries in registers
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const double wjx = jac[3 * NJ + j], wjy = jac[4 * NJ + j], wjz = jac[5 * NJ + j];
-#pragma unroll
-        for (int i = 0; i < NJ; ++i) {
-            // j <= i: (w_j x v_i ; w_j x w_i);  j > i: (w_i x v_j ; 0)   (methods.cpp:16-32)
-            const int a = j <= i ? j : i, b = j <= i ? i : j;
-            const double ax = jac[3 * NJ + a], ay = jac[4 * NJ + a], az = jac[5 * NJ + a];
-            const double vx = jac[b], vy = jac[NJ + b], vz = jac[2 * NJ + b];
-            mine[0 * NJ + i] = ay * vz - az * vy;
-            mine[1 * NJ + i] = az * vx - ax * vz;
-            mine[2 * NJ + i] = ax * vy - ay * vx;
-            if (j <= i) {
-                const double ux = jac[3 * NJ + i], uy = jac[4 * NJ + i], uz = jac[5 * NJ + i];
-                mine[3 * NJ + i] = wjy * uz - wjz * uy;
-                mine[4 * NJ + i] = wjz * ux - wjx * uz;
-                mine[5 * NJ + i] = wjx * uy - wjy * ux;
-            } else {
-                mine[3 * NJ + i] = 0.0; mine[4 * NJ + i] = 0.0; mine[5 * NJ + i] = 0.0;
-            }
+            for (int k = 0; k < 6 * NJ; ++k) asm volatile("" : "+v"(jac[k]));
+            hessian_from_jacobian(NJ, [&](int k) { return jac[k]; }, [&](int idx, double v) { mine[idx] = v; });
         }
         __syncthreads();
-        for (int f = 2 * lane; f < ncfg * W; f += 2 * kWave) {
-            const int c = f / W, e = f - c * W;
+        double *dst = H + (cfg0 + r * G) * (int64_t)HW;
+        flush_rows<HW>(buf, S, cnt, lane, [&](int f, double a, double b) {
             typedef double v2d __attribute__((ext_vector_type(2)));
-            v2d w = {buf[c * (W + 1) + e], buf[c * (W + 1) + e + 1]};
-            __builtin_nontemporal_store(w, reinterpret_cast<v2d *>(dst0 + (int64_t)c * (NJ * W) + j * W + e));
-        }
+            v2d w = {a, b};
+            __builtin_nontemporal_store(w, reinterpret_cast<v2d *>(dst + f));
+        });
         __syncthreads();
     }
 }
-
+template <int NJ, int R>
+static hipError_t launch_hess_tile(dim3 grid, hipStream_t s, const KinParams &kp, const DevChain &dc, const double *q, double *H)
+{
+    const size_t lds = (size_t)(kWave / R) * ((NJ * 6 * NJ) | 1) * sizeof(double);
+    auto k = k_kin_hess_tile<NJ, R>;
+    if (lds > 48 * 1024) { hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL(k, grid, dim3(kWave), lds, s, kp, dc, q, H);
+    note_launch((int)grid.x, kWave, (int)lds);
+    return hipGetLastError();
+}
 template <int NJ>
 static hipError_t launch_hess_nj(dim3 grid, hipStream_t s, const KinParams &kp, const DevChain &dc, const double *q, double *H)
 {
-    if (g_hess_mode == 1) {
-        const size_t lds1 = (size_t)kWave * (6 * NJ + 1) * sizeof(double);
-        hipLaunchKernelGGL((k_kin_hess_rounds<NJ>), grid, dim3(kWave), lds1, s, kp, dc, q, H);
-        note_launch((int)grid.x, kWave, (int)lds1);
-        return hipGetLastError();
-    }
+    // measured (Panda, 1e6, min of 10): R = 2 0.59 ms, R = 4 0.44 ms, R = 8 0.51 ms, R = 16 0.88 ms, hessian_run (mode 1) 0.61-0.64 ms
+    if (g_hess_mode == 0) return launch_hess_tile<NJ, 4>(grid, s, kp, dc, q, H);
+    if (g_hess_mode == 2) return launch_hess_tile<NJ, 8>(grid, s, kp, dc, q, H);
     const size_t lds = (size_t)kWave * (6 * NJ + 1) * sizeof(double);
     hipLaunchKernelGGL((k_kin_hess<NJ>), grid, dim3(kWave), lds, s, kp, dc, q, H);
     note_launch((int)grid.x, kWave, (int)lds);

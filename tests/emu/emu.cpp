@@ -145,6 +145,56 @@ static void emu_hess_run(const KinParams &kp, const DevChain &cv, const double *
     }
 }
 
+// k_kin_hess_tile<NJ, R>: rounds of 64/R lanes expanding their Hessians into the tile, whole-wave flush_rows
+template <int NJ, int R>
+static void emu_hess_tile_run(const KinParams &kp, const DevChain &cv, const double *q, int64_t N, double *H)
+{
+    constexpr int HW = NJ * 6 * NJ, S = HW | 1, G = kWave / R;
+    std::vector<double> buf((size_t)G * S, -777.0);
+    std::vector<double> jacs((size_t)kWave * 6 * NJ);
+    const int64_t tiles = (N + kWave - 1) / kWave;
+    for (int64_t tile = 0; tile < tiles; ++tile) {
+        const int64_t cfg0 = tile * kWave;
+        const int ncfg = (int)std::min<int64_t>(kWave, N - cfg0);
+        for (int l = 0; l < kWave; ++l) {
+            Pose P;
+            double jac[6 * NJ];
+            reg_compute<NJ, true>(kp, cv, q, cfg0 + l, P, jac);
+            for (int k = 0; k < 6 * NJ; ++k) jacs[(size_t)l * 6 * NJ + k] = jac[k];
+        }
+        for (int r = 0; r < R; ++r) {
+            const int cnt = std::min(G, ncfg - r * G);
+            if (cnt <= 0) break;
+            for (int l = r * G; l < (r + 1) * G; ++l) {
+                const double *jac = &jacs[(size_t)l * 6 * NJ];
+                double *mine = buf.data() + (size_t)(l - r * G) * S;
+                hessian_from_jacobian(NJ, [&](int k) { return jac[k]; }, [&](int idx, double v) { mine[idx] = v; });
+            }
+            double *dst = H + (cfg0 + r * G) * (int64_t)HW;
+            for (int l = 0; l < kWave; ++l)
+                flush_rows<HW>(buf.data(), S, cnt, l, [&](int f, double a, double b) { dst[f] = a; dst[f + 1] = b; });
+        }
+    }
+}
+
+extern "C" int emu_kin_hess_tile(rtbhip_chain_t h, const double *q, int64_t N, const double *tool16, int frame, int rounds, double *H)
+{
+    Chain *c = chain_from_handle(h);
+    if (!c || c->n < 1 || c->n > kKinRegMax) return -1;
+    KinParams kp;
+    kp.n = c->n; kp.qw = c->q_width; kp.stride = kin_stride(c->n); kp.frame = frame; kp.N = N; kp.pad = 0; kp.has_base = 0;
+    Affine t = aff16(tool16);
+    chain_tail(c, t, kp.tail);
+    const DevChain cv = chain_host_view(c);
+#define RTB_HT(NJ) case NJ: if (rounds == 4) emu_hess_tile_run<NJ, 4>(kp, cv, q, N, H); else if (rounds == 16) emu_hess_tile_run<NJ, 16>(kp, cv, q, N, H); else emu_hess_tile_run<NJ, 8>(kp, cv, q, N, H); break;
+    switch (c->n) {
+    RTB_HT(1) RTB_HT(2) RTB_HT(3) RTB_HT(4) RTB_HT(5) RTB_HT(6) RTB_HT(7) RTB_HT(8) RTB_HT(9)
+    default: if (rounds == 4) emu_hess_tile_run<10, 4>(kp, cv, q, N, H); else if (rounds == 16) emu_hess_tile_run<10, 16>(kp, cv, q, N, H); else emu_hess_tile_run<10, 8>(kp, cv, q, N, H); break;
+    }
+#undef RTB_HT
+    return 0;
+}
+
 extern "C" int emu_kin_hess(rtbhip_chain_t h, const double *q, int64_t N, const double *tool16, int frame, double *H)
 {
     Chain *c = chain_from_handle(h);

@@ -62,6 +62,7 @@ def lib():
         _lib.emu_kin.argtypes = [_u64, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _i32]
         _lib.emu_rne.argtypes = [_u64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32]
         _lib.emu_kin_hess.argtypes = [_u64, _vp, _i64, _vp, _i32, _vp]
+        _lib.emu_kin_hess_tile.argtypes = [_u64, _vp, _i64, _vp, _i32, _i32, _vp]
         _lib.emu_diff.argtypes = [_u64, _i32, _i32, _vp, _vp, _i64, _vp, _i32, _vp]
         _lib.emu_partial.argtypes = [_u64, _vp, _i64, _vp, _i32, _vp]
         _lib.emu_dyn.argtypes = [_u64, _i32, _vp, _vp, _vp, _i64, _vp, _vp]
@@ -138,14 +139,18 @@ def rne(L24, mdh, q, qd, qdd, grav_c, fext=None, force_generic=False):
     return tau
 
 
-def hess_reg(ets, q, tool=None, frame=0):
-    """The register-resident Hessian path (k_kin_hess: staged Jacobians + hessian_run) on the CPU."""
+def hess_reg(ets, q, tool=None, frame=0, rounds=0):
+    """The register-resident Hessian paths on the CPU: rounds=0 k_kin_hess (staged Jacobians + hessian_run),
+    rounds=4/8/16 k_kin_hess_tile (per-lane expansion into an LDS tile, whole-wave flush)."""
     h = chain_handle(ets)
     q = np.ascontiguousarray(np.asarray(q, dtype=np.float64).reshape(-1, ets.q_width))
     N, n = q.shape[0], ets.n
     H = np.full((N, n, 6, n), np.nan)
     t = None if tool is None else np.ascontiguousarray(tool, dtype=np.float64)
-    assert lib().emu_kin_hess(h, _p(q), N, _p(t), frame, _p(H)) == 0
+    if rounds:
+        assert lib().emu_kin_hess_tile(h, _p(q), N, _p(t), frame, rounds, _p(H)) == 0
+    else:
+        assert lib().emu_kin_hess(h, _p(q), N, _p(t), frame, _p(H)) == 0
     return H
 
 

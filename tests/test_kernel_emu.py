@@ -292,10 +292,13 @@ def test_hessian_register_path_equals_oracle_and_lds_tile_path(N):
             nt.assert_allclose(Hr, oracle.hessian(ch, q, frame=frame), atol=1e-12)
             _, _, Ht = emu.kin(ets, q, frame=frame, want=("H",))
             nt.assert_allclose(Hr, Ht, atol=1e-13)
+            for rounds in (4, 8, 16):                               # k_kin_hess_tile<NJ, R>
+                nt.assert_array_equal(emu.hess_reg(ets, q, frame=frame, rounds=rounds), Hr)
     three = rtbhip.ET.Rz() * rtbhip.ET.tx(0.3) * rtbhip.ET.Ry() * rtbhip.ET.tz(0.2) * rtbhip.ET.tx()
     q3 = rng.uniform(-1, 1, (N, 3))
     _, _, Ht = emu.kin(three, q3, want=("H",))
     nt.assert_allclose(emu.hess_reg(three, q3), Ht, atol=1e-13)
+    nt.assert_allclose(emu.hess_reg(three, q3, rounds=8), Ht, atol=1e-13)
 
 
 def test_ik_gn_nr_reference_run_fixtures_first_search():
