@@ -138,6 +138,18 @@ int rtbhip_ik_lm(rtbhip_chain_t chain, const double *Tep, int64_t N, const doubl
                  int32_t *success, int32_t *iters, int32_t *searches, double *residual,
                  int32_t mem, void *stream);
 
+/* The same with the null-space motion of the Python solvers (IK_LM / IK_GN / IK_NR keyword arguments kq, km, ps, pi;
+ * robot/IK.py:507-576 `_null_Sigma`, `_calc_qnull`, added to the step at :758, :1015, :1215): joint-limit avoidance with
+ * gain 1/kq inside the influence distance pi (minimum distance ps) and manipulability maximisation with gain 1/km,
+ * projected into the null space of J.  flavour must be 1.  As in the reference the term is applied only when kq > 0;
+ * chains of 6..8 joints (below 6 the projector vanishes and the call equals rtbhip_ik_lm). */
+int rtbhip_ik_lm_nullspace(rtbhip_chain_t chain, const double *Tep, int64_t N, const double *q0,
+                           int32_t ilimit, int32_t slimit, double tol, int32_t reject_jl, const double *we6,
+                           double lambda, int32_t method, int32_t flavour, uint64_t seed,
+                           double kq, double km, double ps, double pi, double *q_out,
+                           int32_t *success, int32_t *iters, int32_t *searches, double *residual,
+                           int32_t mem, void *stream);
+
 /* The restart vector the device generator yields for (seed, target index, search index, joint):
  * uniform in [qlim_lo, qlim_hi).  Exposed so tests can hand the CPU oracle the same sequence. */
 int rtbhip_ik_restart(rtbhip_chain_t chain, uint64_t seed, int64_t target, int32_t search,

@@ -259,9 +259,36 @@ def rne_dh(L24, mdh, q, qd, qdd, grav_c, fext=None):
     return tau
 
 
-def ikine_py(ch, Tep, q0s, step="nr", ilimit=30, slimit=100, tol=1e-6, joint_limits=True, we=None, k=1.0):
+def null_sigma(ch, q, ps, pi):
+    """_null_Sigma (robot/IK.py:507-539): joint-limit avoidance gradient, (n,1)."""
+    pi = pi * np.ones(ch.n) if np.ndim(pi) == 0 else np.asarray(pi, dtype=float)
+    S = np.zeros((ch.n, 1))
+    for i in range(ch.n):
+        qi, ql0, ql1 = q[i], ch.qlim[0, i], ch.qlim[1, i]
+        if qi - ql0 <= pi[i]:
+            S[i, 0] = -np.power(((qi - ql0) - pi[i]), 2) / np.power((ps - pi[i]), 2)
+        if ql1 - qi <= pi[i]:
+            S[i, 0] = np.power(((ql1 - qi) - pi[i]), 2) / np.power((ps - pi[i]), 2)
+    return -S
+
+
+def calc_qnull(ch, q, J, kq, km, ps, pi):
+    """_calc_qnull (robot/IK.py:542-576), including its guard `kq > 0 or kq > 0` on the projection."""
+    grad = np.zeros(ch.n)
+    qnull = np.zeros(ch.n)
+    if kq > 0:
+        grad += (1.0 / kq * null_sigma(ch, q, ps, pi)).flatten()
+    if km > 0:
+        grad += (1.0 / km * jacobm(ch, q)[0].reshape(ch.n, 1)).flatten()
+    if kq > 0 or kq > 0:
+        qnull = (np.eye(ch.n) - np.linalg.pinv(J) @ J) @ grad
+    return qnull.flatten()
+
+
+def ikine_py(ch, Tep, q0s, step="nr", ilimit=30, slimit=100, tol=1e-6, joint_limits=True, we=None, k=1.0,
+             kq=0.0, km=0.0, ps=0.0, pi=0.3, method="chan"):
     """NumPy restatement of the Python solvers' loop, IKSolver._solve (robot/IK.py:297-367), with the steps of
-    IK_NR / IK_GN (q += pinv(J) e, :736-763, :1176-1220) or IK_LM chan (:994-1017).  q0s: (slimit, n) starts."""
+    IK_NR / IK_GN (q += pinv(J) e + qnull, :736-763, :1176-1220) or IK_LM (:994-1017).  q0s: (slimit, n) starts."""
     n = ch.n
     q0s = _f64(q0s, (-1, n))
     Tep = _f64(Tep, (4, 4))
@@ -276,11 +303,16 @@ def ikine_py(ch, Tep, q0s, step="nr", ilimit=30, slimit=100, tol=1e-6, joint_lim
             e = angle_axis(Te, Tep)
             E = 0.5 * e @ We @ e
             J = jacob0(ch, q)[0]
-            if step in ("nr", "gn"):
-                q = q + np.linalg.pinv(J) @ e
-            else:
-                g = J.T @ We @ e
-                q = q + np.linalg.inv(J.T @ We @ J + k * E * np.eye(n)) @ g
+            try:
+                qnull = calc_qnull(ch, q, J, kq, km, ps, pi)
+                if step in ("nr", "gn"):
+                    q = q + np.linalg.pinv(J) @ e + qnull
+                else:
+                    g = J.T @ We @ e
+                    Wn = {"chan": k * E, "wampler": k, "sugihara": E + k}[method] * np.eye(n)
+                    q = q + np.linalg.inv(J.T @ We @ J + Wn) @ g + qnull
+            except np.linalg.LinAlgError:                  # IK.py:320-323: abandon the search
+                break
             if E < tol:
                 q = (q + np.pi) % (2 * np.pi) - np.pi
                 ok = bool(np.all(q >= ch.qlim[0]) and np.all(q <= ch.qlim[1]))

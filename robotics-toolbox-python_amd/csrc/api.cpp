@@ -463,6 +463,17 @@ int rtbhip_ik_lm(rtbhip_chain_t chain, const double *Tep, int64_t N, const doubl
                  int32_t *success, int32_t *iters, int32_t *searches, double *residual,
                  int32_t mem, void *stream)
 {
+    return rtbhip_ik_lm_nullspace(chain, Tep, N, q0, ilimit, slimit, tol, reject_jl, we6, lambda, method, flavour, seed,
+                                  0.0, 0.0, 0.1, 0.3, q_out, success, iters, searches, residual, mem, stream);
+}
+
+int rtbhip_ik_lm_nullspace(rtbhip_chain_t chain, const double *Tep, int64_t N, const double *q0,
+                           int32_t ilimit, int32_t slimit, double tol, int32_t reject_jl, const double *we6,
+                           double lambda, int32_t method, int32_t flavour, uint64_t seed,
+                           double kq, double km, double ps, double pi, double *q_out,
+                           int32_t *success, int32_t *iters, int32_t *searches, double *residual,
+                           int32_t mem, void *stream)
+{
     Chain *c = chain_from_handle(chain);
     if (!c) { set_error("ik_lm: unknown chain handle"); return RTBHIP_EINVAL; }
     RTB_TRY(check_batch("ik_lm", Tep, N, mem));
@@ -476,6 +487,9 @@ int rtbhip_ik_lm(rtbhip_chain_t chain, const double *Tep, int64_t N, const doubl
     IkParams p;
     p.ilimit = ilimit; p.slimit = slimit; p.reject_jl = reject_jl ? 1 : 0; p.method = method;
     p.flavour = flavour; p.tol = tol; p.lambda = lambda; p.seed = seed;
+    p.kq = kq; p.km = km; p.ps = ps; p.pi = pi;
+    if (kq > 0.0 && flavour != 1) { set_error("ik_lm: null-space terms belong to the Python solvers (flavour 1)"); return RTBHIP_EINVAL; }
+    if (kq > 0.0 && ps == pi) { set_error("ik_lm: ps must differ from pi"); return RTBHIP_EINVAL; }
     for (int i = 0; i < 6; i++) p.we[i] = we6 ? we6[i] : 1.0;
     DevChain ops;
     const double *qlim = nullptr;

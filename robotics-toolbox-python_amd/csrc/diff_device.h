@@ -114,13 +114,11 @@ RTB_HD double manipulability_singular(const double (&jac)[6 * NJ], int axes, int
     return mode == 1 ? sqrt(lo) : sqrt(lo / hi);
 }
 
+// jacobm given the LDL^T factorisation (B, dinv) of the masked J J^T
 template <int NJ>
-RTB_HD void jacobm(const double (&jac)[6 * NJ], int axes, double (&jm)[NJ])
+RTB_HD void jacobm_factored(const double (&jac)[6 * NJ], int axes, const double (&B)[6][6], const double (&dinv)[6], double (&jm)[NJ])
 {
-    double B[6][6], dval[6], dinv[6];
-    jjt_masked<NJ>(jac, axes, B);
     const double m = manipulability_yoshikawa<NJ>(jac, axes);     // Robot.py:1216-1222
-    ldl_factor<6>(B, dval, dinv);
     // G = (J_a J_a^T)^-1 J_a, column by column (rows outside `axes` come out zero)
     double G[6 * NJ];
 #pragma unroll
@@ -151,6 +149,15 @@ RTB_HD void jacobm(const double (&jac)[6 * NJ], int axes, double (&jm)[NJ])
         }
         jm[i] = m * acc;
     }
+}
+
+template <int NJ>
+RTB_HD void jacobm(const double (&jac)[6 * NJ], int axes, double (&jm)[NJ])
+{
+    double B[6][6], dval[6], dinv[6];
+    jjt_masked<NJ>(jac, axes, B);
+    ldl_factor<6>(B, dval, dinv);
+    jacobm_factored<NJ>(jac, axes, B, dinv, jm);
 }
 
 }  // namespace rtbhip

@@ -20,6 +20,7 @@
 #pragma once
 #include "kin_reg.h"
 #include "ldl.h"
+#include "diff_device.h"
 
 namespace rtbhip {
 
@@ -35,6 +36,7 @@ struct IkDev {   // wave-uniform solver parameters (kernarg)
     double we[6];
     uint64_t seed;
     int64_t N;
+    double kq, km, ps, pi;           // null-space terms of the Python solvers (IK.py:507-576); kq <= 0: none
 };
 
 // ---------------------------------------------------------------- restart generator
@@ -162,6 +164,54 @@ RTB_HD void ik_pinv_step(const double (&jac)[6 * NJ], const double (&e)[6], int 
     }
 }
 
+// ---------------------------------------------------------------- null-space motion of the Python solvers
+// _calc_qnull (robot/IK.py:542-576) with _null_Sigma (:507-539): the gradient  -Sigma / kq  (joint-limit avoidance inside
+// the influence distance pi, minimum distance ps)  +  jacobm(q) / km  (manipulability), projected with I - pinv(J) J.
+// As in the reference the projection -- and with it the whole term -- is applied only when kq > 0 (its guard reads
+// `lambda_Sigma > 0 or lambda_Sigma > 0`).  For a J of full row rank  I - pinv(J) J = I - J^T (J J^T)^-1 J: the 6x6
+// factorisation is shared with jacobm.  Chains of fewer than 6 joints have full column rank away from singularities,
+// where the projector is zero: those never come here.
+template <int NJ, class PD, class QL, class QA>
+RTB_HD void ik_qnull(const double (&jac)[6 * NJ], const PD &p, QL qlim, QA qa, double (&qn)[NJ])
+{
+    static_assert(NJ >= 6, "null-space motion needs a redundant or square arm");
+    double grad[NJ];
+    const double den = (p.ps - p.pi) * (p.ps - p.pi);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const double qi = qa.get(j), lo = qlim[j], hi = qlim[NJ + j];
+        double sg = 0.0;
+        if (qi - lo <= p.pi) sg = -(((qi - lo) - p.pi) * ((qi - lo) - p.pi)) / den;
+        if (hi - qi <= p.pi) sg = (((hi - qi) - p.pi) * ((hi - qi) - p.pi)) / den;
+        grad[j] = (1.0 / p.kq) * -sg;
+    }
+    double B[6][6], dval[6], dinv[6];
+    jjt_masked<NJ>(jac, 63, B);
+    ldl_factor<6>(B, dval, dinv);
+    if (p.km > 0.0) {
+        double jm[NJ];
+        jacobm_factored<NJ>(jac, 63, B, dinv, jm);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) grad[j] += (1.0 / p.km) * jm[j];
+    }
+    double y[6], x[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k < NJ; ++k) a += jac[r * NJ + k] * grad[k];
+        y[r] = a;
+    }
+    ldl_backsolve<6>(B, dinv, y, x);
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) {
+        double a = grad[k];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) a -= jac[r * NJ + k] * x[r];
+        qn[k] = a;
+    }
+}
+
 // ---------------------------------------------------------------- searches as pure functions
 // The reference runs, per target, up to `slimit` SEARCHES one after another; each search starts from
 // a given or random q and takes at most `ilimit` LM steps (ik.cpp:39-72, IK.py:297-367).  With the
@@ -247,11 +297,14 @@ RTB_HD double ik_wrap_py(double q)                                              
 // ONE LM iteration of the lane's current search.  Every lane of a wave executes this whatever its
 // status (idle / parked lanes compute on their stale state and discard the result) so the wave has a
 // single instruction stream.  Sets st.fin / st.ok when the search ended.
-// PINV = false: the three Levenberg-Marquardt steps (method 0..2); PINV = true: Gauss-Newton / Newton-Raphson
-// (method 3 / 4).  A compile-time choice so that neither kernel carries the other's step in its register budget.
-template <int NJ, bool PINV, class PD, class CV, class QL, class TD, class QA>
+// STEP bit 0 clear: the three Levenberg-Marquardt steps (method 0..2); set: Gauss-Newton / Newton-Raphson (method 3 / 4).
+// STEP bit 1: the Python solvers' null-space motion is added to the step.  Compile-time choices so that no kernel
+// carries another's step in its register budget.
+constexpr int kIkStepPinv = 1, kIkStepNull = 2;
+template <int NJ, int STEP, class PD, class CV, class QL, class TD, class QA>
 RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, QA qa)
 {
+    constexpr bool PINV = (STEP & kIkStepPinv) != 0, NULLSP = (STEP & kIkStepNull) != 0 && NJ >= 6;
     Pose P;
     double jac[6 * NJ], e[6], dq[NJ];
     {
@@ -267,6 +320,8 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, Q
 #pragma unroll
     for (int k = 0; k < 6; ++k) E += e[k] * p.we[k] * e[k];
     E *= 0.5;                                                   // ik.cpp:46
+    double qn[NULLSP ? NJ : 1];
+    if constexpr (NULLSP) ik_qnull<NJ>(jac, p, qlim, qa, qn);   // IK.py:753,1011,1210 (before the step: J dies in it)
     if (PINV) {                     // 3 Gauss-Newton, 4 Newton-Raphson: `lambda` carries pinv_damping (NR only)
         int rows = 63;
         if (p.method == 3) {
@@ -278,6 +333,10 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, Q
     } else {
         const double wn = (p.method == 1) ? p.lambda : (p.method == 2) ? E + p.lambda : p.lambda * E;   // ik.cpp:169,183,205
         ik_lm_step<NJ>(jac, e, p.we, wn, dq);
+    }
+    if constexpr (NULLSP) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) dq[j] += qn[j];
     }
     if (st.status != kIkRun || st.fin) return;    // a search that has ended waits, untouched, for the next pass
     st.E = E;
@@ -315,6 +374,23 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, Q
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) qa.put(j, dq[j]);
+    }
+}
+
+// which compiled step variant serves these parameters (host launcher, emu and the sequential driver agree on it)
+template <class PD>
+RTB_HD int ik_step_variant(const PD &p, int n)
+{
+    return (p.method >= 3 ? kIkStepPinv : 0) | ((p.kq > 0.0 && n >= 6) ? kIkStepNull : 0);
+}
+template <int NJ, class PD, class CV, class QL, class TD, class QA>
+RTB_HD void ik_iter_any(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, QA qa)
+{
+    switch (ik_step_variant(p, NJ)) {
+    case 0: ik_iter<NJ, 0>(st, p, cv, qlim, td, qa); break;
+    case 1: ik_iter<NJ, 1>(st, p, cv, qlim, td, qa); break;
+    case 2: ik_iter<NJ, 2>(st, p, cv, qlim, td, qa); break;
+    default: ik_iter<NJ, 3>(st, p, cv, qlim, td, qa); break;
     }
 }
 
@@ -509,8 +585,7 @@ RTB_HD void ik_solve_sequential(const IkDev &p, const CV &cv, QL qlim, int64_t t
     for (int s = ik_s_first(p);; ++s) {
         ik_search_begin<NJ>(st, qa, p, qlim, tgt, s, p.has_q0 ? q0 + (int64_t)NJ * tgt : nullptr);
         while (!st.fin) {
-            if (p.method >= 3) ik_iter<NJ, true>(st, p, cv, qlim, [&](int k) { return Td[k]; }, qa);
-            else ik_iter<NJ, false>(st, p, cv, qlim, [&](int k) { return Td[k]; }, qa);
+            ik_iter_any<NJ>(st, p, cv, qlim, [&](int k) { return Td[k]; }, qa);
         }
         it += st.iter;
         if (st.ok || s == s_last) {

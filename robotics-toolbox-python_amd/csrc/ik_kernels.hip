@@ -25,8 +25,8 @@ struct ConstChainIk {
 #ifndef RTB_IK_WAVES
 #define RTB_IK_WAVES 2
 #endif
-template <int NJ, bool PINV>
-__global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints ? RTB_IK_WAVES : 1)) void k_ik(IkDev p, DevChain dc, const double *qlim_g, const double *__restrict__ Tep,
+template <int NJ, int STEP>
+__global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull) ? RTB_IK_WAVES : 1)) void k_ik(IkDev p, DevChain dc, const double *qlim_g, const double *__restrict__ Tep,
                                                 const double *__restrict__ q0, unsigned long long *counter,
                                                 double *__restrict__ q_out, int32_t *__restrict__ success,
                                                 int32_t *__restrict__ iters, int32_t *__restrict__ searches,
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints ? RTB_IK_WAVES : 1)) vo
             const RTB_CONST double *ql = qlim;
             asm volatile("" : "+s"(cvi.seg), "+s"(cvi.jmeta), "+s"(ql));
             const int myslot = st.slot;
-            ik_iter<NJ, PINV>(st, p, cvi, ql, [&](int k) { return sh.Td[k][myslot]; }, IkLdsQ{&sh, lane});
+            ik_iter<NJ, STEP>(st, p, cvi, ql, [&](int k) { return sh.Td[k][myslot]; }, IkLdsQ{&sh, lane});
         }
     }
 }
@@ -197,8 +197,13 @@ static void launch_nj(dim3 grid, hipStream_t s, const IkDev &p, const DevChain &
                       const double *q0, unsigned long long *ctr, double *q_out, int32_t *success, int32_t *iters,
                       int32_t *searches, double *residual)
 {
-    if (p.method >= 3) hipLaunchKernelGGL((k_ik<NJ, true>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual);
-    else hipLaunchKernelGGL((k_ik<NJ, false>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual);
+    const int v = ik_step_variant(p, NJ);
+    if constexpr (NJ >= 6 && NJ <= kRegMaxJoints) {        // the null-space variants exist for 6..8 joints (launch_ik checks)
+        if (v == 2) { hipLaunchKernelGGL((k_ik<NJ, 2>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual); return; }
+        if (v == 3) { hipLaunchKernelGGL((k_ik<NJ, 3>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual); return; }
+    }
+    if (v & kIkStepPinv) hipLaunchKernelGGL((k_ik<NJ, 1>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual);
+    else hipLaunchKernelGGL((k_ik<NJ, 0>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual);
 }
 
 int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const double *Tep, int64_t N, const double *q0,
@@ -216,6 +221,8 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
     for (int k = 0; k < 6; ++k) p.we[k] = ip.we[k];
     p.seed = ip.seed;
     p.N = N;
+    p.kq = ip.kq; p.km = ip.km; p.ps = ip.ps; p.pi = ip.pi;
+    if (p.kq > 0.0 && c->n > kRegMaxJoints) { set_error("ik_lm: null-space terms are built for chains of up to 8 joints"); return RTBHIP_ELIMIT; }
     int dev = 0, cus = 0;
     RTB_HIP(hipGetDevice(&dev));
     if (device_cu_count(&cus) != RTBHIP_OK) return RTBHIP_EHIP;
@@ -234,7 +241,8 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
     RTB_HIP(hipMemsetAsync(ctr, 0, sizeof(unsigned long long), s));
     // a batch smaller than the grid's lane count is spread over ALL the waves (fresh_cap targets per
     // wave and pass) instead of filling ceil(N/64) of them: every SIMD then holds its share of the tail
-    int64_t g = (int64_t)cus * (c->n <= kRegMaxJoints ? g_ik_waves_per_cu : 4);   // 9..12 joints: one wave per SIMD
+    const bool one_wave = c->n > kRegMaxJoints || (ik_step_variant(p, c->n) & kIkStepNull);   // 9..12 joints, null-space: one wave per SIMD
+    int64_t g = (int64_t)cus * (one_wave ? 4 : g_ik_waves_per_cu);
     if (g > N) g = N;
     const int64_t cap = (N + g - 1) / g;
     p.fresh_cap = cap > 64 ? 64 : (int32_t)cap;

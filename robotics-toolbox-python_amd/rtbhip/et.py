@@ -438,7 +438,7 @@ class ETS:
         return out[0] if single else out
 
     # ------------------------------------------------------------ inverse kinematics
-    def _ik(self, Tep, q0, ilimit, slimit, tol, mask, joint_limits, k, method, flavour, seed):
+    def _ik(self, Tep, q0, ilimit, slimit, tol, mask, joint_limits, k, method, flavour, seed, nullspace=None):
         n = self.n
         tm = is_torch(Tep) and Tep.is_cuda
         if tm:
@@ -482,10 +482,12 @@ class ETS:
             qo = np.empty((N, n)); ok = np.empty(N, np.int32); it = np.empty(N, np.int32)
             se = np.empty(N, np.int32); E = np.empty(N)
         we = small(mask, 6)
-        check(lib().rtbhip_ik_lm(self._handle(), self._ptr(Tq, tm), N, self._ptr(q0p, tm), int(ilimit), int(slimit),
-                                 float(tol), int(bool(joint_limits)), host_ptr(we), float(k), int(method), int(flavour),
-                                 int(seed) & 0xFFFFFFFFFFFFFFFF, self._ptr(qo, tm), self._ptr(ok, tm), self._ptr(it, tm),
-                                 self._ptr(se, tm), self._ptr(E, tm), MEM_DEVICE if tm else MEM_HOST, self._stream(tm)))
+        kq, km, ps, pi = nullspace if nullspace is not None else (0.0, 0.0, 0.1, 0.3)
+        check(lib().rtbhip_ik_lm_nullspace(self._handle(), self._ptr(Tq, tm), N, self._ptr(q0p, tm), int(ilimit), int(slimit),
+                                           float(tol), int(bool(joint_limits)), host_ptr(we), float(k), int(method), int(flavour),
+                                           int(seed) & 0xFFFFFFFFFFFFFFFF, float(kq), float(km), float(ps), float(pi),
+                                           self._ptr(qo, tm), self._ptr(ok, tm), self._ptr(it, tm),
+                                           self._ptr(se, tm), self._ptr(E, tm), MEM_DEVICE if tm else MEM_HOST, self._stream(tm)))
         return single, qo, ok, it, se, E
 
     def ik_LM(self, Tep, q0=None, ilimit=30, slimit=100, tol=1e-6, mask=None, joint_limits=True, k=1.0,
@@ -524,12 +526,10 @@ class ETS:
                  k=1.0, method="chan", kq=0.0, km=0.0, ps=0.0, pi=0.3, **kwargs):
         """The Python solver's flavour of LM (reference ETS.ikine_LM robot/ETS.py:2618-2637 ->
         IK_LM.solve/_solve/step robot/IK.py:174-367,994-1017): E is tested after the step and q is
-        wrapped with Python's %.  Null-space terms (kq, km) default to 0 in the reference and are not
-        offered on the GPU."""
-        if kq or km:
-            raise NotImplementedError("null-space terms kq/km are not implemented in the GPU solver")
+        wrapped with Python's %.  kq / km / ps / pi: the null-space motion of robot/IK.py:507-576 (joint-limit
+        avoidance and manipulability maximisation; as in the reference it acts only when kq > 0)."""
         single, q, ok, it, se, E = self._ik(Tep, q0, ilimit, slimit, tol, mask, joint_limits, k, method, 1,
-                                            0 if seed is None else seed)
+                                            0 if seed is None else seed, self._nullspace(kq, km, ps, pi))
         if is_torch(q):
             q, ok, it, se, E = (x.cpu().numpy() for x in (q, ok, it, se, E))
         if single:
@@ -542,14 +542,18 @@ class ETS:
                           reason="" if allok else "iteration and search limit reached",
                           each={"success": ok.astype(bool), "iterations": it, "searches": se, "residual": E})
 
-    def _ikine_pinv(self, name, Tep, q0, ilimit, slimit, tol, mask, joint_limits, seed, pinv, kq, km):
-        if kq or km:
-            raise NotImplementedError("null-space terms kq/km are not implemented in the GPU solver")
+    @staticmethod
+    def _nullspace(kq, km, ps, pi):
+        if np.ndim(pi) != 0:
+            raise NotImplementedError("a per-joint influence distance pi is not offered; pass a scalar")
+        return (float(kq), float(km), float(ps), float(pi))
+
+    def _ikine_pinv(self, name, Tep, q0, ilimit, slimit, tol, mask, joint_limits, seed, pinv, kq, km, ps=0.0, pi=0.3):
         if not pinv and self.n != 6:
             raise ValueError("%s: a %d-joint chain needs pinv=True (numpy.linalg.inv of a 6x%d Jacobian is undefined)"
                              % (name, self.n, self.n))
         single, q, ok, it, se, E = self._ik(Tep, q0, ilimit, slimit, tol, mask, joint_limits, 0.0, name, 1,
-                                            0 if seed is None else seed)
+                                            0 if seed is None else seed, self._nullspace(kq, km, ps, pi))
         if is_torch(q):
             q, ok, it, se, E = (x.cpu().numpy() for x in (q, ok, it, se, E))
         if single:
@@ -563,16 +567,16 @@ class ETS:
                           each={"success": ok.astype(bool), "iterations": it, "searches": se, "residual": E})
 
     def ikine_NR(self, Tep, q0=None, ilimit=30, slimit=100, tol=1e-6, mask=None, joint_limits=True, seed=None,
-                 pinv=False, kq=0.0, km=0.0, **kwargs):
+                 pinv=False, kq=0.0, km=0.0, ps=0.0, pi=0.3, **kwargs):
         """The Python Newton-Raphson solver (reference ETS.ikine_NR robot/ETS.py:2639-2776 -> IK_NR robot/IK.py:579-763):
         q += pinv(J) e inside the Python solver's loop semantics (flavour 1)."""
-        return self._ikine_pinv("nr", Tep, q0, ilimit, slimit, tol, mask, joint_limits, seed, pinv, kq, km)
+        return self._ikine_pinv("nr", Tep, q0, ilimit, slimit, tol, mask, joint_limits, seed, pinv, kq, km, ps, pi)
 
     def ikine_GN(self, Tep, q0=None, ilimit=30, slimit=100, tol=1e-6, mask=None, joint_limits=True, seed=None,
-                 pinv=False, kq=0.0, km=0.0, **kwargs):
+                 pinv=False, kq=0.0, km=0.0, ps=0.0, pi=0.3, **kwargs):
         """The Python Gauss-Newton solver (reference ETS.ikine_GN robot/ETS.py:2778-2915 -> IK_GN robot/IK.py:1020-1220;
         its step is the same pinv(J) e)."""
-        return self._ikine_pinv("nr", Tep, q0, ilimit, slimit, tol, mask, joint_limits, seed, pinv, kq, km)
+        return self._ikine_pinv("nr", Tep, q0, ilimit, slimit, tol, mask, joint_limits, seed, pinv, kq, km, ps, pi)
 
     def ik_restart(self, seed, target, search):
         """The restart vector the device generator yields (test hook, rtbhip_ik_restart)."""

@@ -352,8 +352,7 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
             w.iters++;
             for (int l = 0; l < kWave; ++l) {
                 if (w.st[l].status == kIkRun) w.lane_iters_useful++;
-                if (p.method >= 3) ik_iter<NJ, true>(w.st[l], p, cv, qlim, [&](int k) { return w.sh.Td[k][w.st[l].slot]; }, IkLdsQ{&w.sh, l});
-                else ik_iter<NJ, false>(w.st[l], p, cv, qlim, [&](int k) { return w.sh.Td[k][w.st[l].slot]; }, IkLdsQ{&w.sh, l});
+                ik_iter_any<NJ>(w.st[l], p, cv, qlim, [&](int k) { return w.sh.Td[k][w.st[l].slot]; }, IkLdsQ{&w.sh, l});
             }
         }
     }
@@ -365,6 +364,10 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
     return 0;
 }
 
+// null-space terms for the next emu_ik / emu_ik_wave calls (kq <= 0: none)
+static double g_emu_ns[4] = {0.0, 0.0, 0.1, 0.3};
+extern "C" void emu_ik_nullspace(double kq, double km, double ps, double pi) { g_emu_ns[0] = kq; g_emu_ns[1] = km; g_emu_ns[2] = ps; g_emu_ns[3] = pi; }
+
 extern "C" int emu_ik(rtbhip_chain_t h, const double *Tep, int64_t N, const double *q0, int ilimit, int slimit, double tol,
                       int reject_jl, const double *we6, double lambda, int method, int flavour, uint64_t seed,
                       double *q_out, int32_t *success, int32_t *iters, int32_t *searches, double *residual)
@@ -374,6 +377,7 @@ extern "C" int emu_ik(rtbhip_chain_t h, const double *Tep, int64_t N, const doub
     IkDev p;
     p.ilimit = ilimit; p.slimit = slimit; p.reject_jl = reject_jl; p.method = method; p.flavour = flavour;
     p.has_q0 = q0 != nullptr; p.tol = tol; p.lambda = lambda; p.seed = seed; p.N = N; p.fresh_cap = 64; p.pool_chunk = 64; p.pass_mask = 0; p.pad = 0;
+    p.kq = g_emu_ns[0]; p.km = g_emu_ns[1]; p.ps = g_emu_ns[2]; p.pi = g_emu_ns[3];
     for (int k = 0; k < 6; ++k) p.we[k] = we6 ? we6[k] : 1.0;
     switch (c->n) {
     case 1: emu_ik_run<1>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
@@ -401,6 +405,7 @@ extern "C" int emu_ik_wave(rtbhip_chain_t h, int waves, double *stats, const dou
     IkDev p;
     p.ilimit = ilimit; p.slimit = slimit; p.reject_jl = reject_jl; p.method = method; p.flavour = flavour;
     p.has_q0 = q0 != nullptr; p.tol = tol; p.lambda = lambda; p.seed = seed; p.N = N; p.fresh_cap = 64; p.pool_chunk = 64; p.pass_mask = 0; p.pad = 0;
+    p.kq = g_emu_ns[0]; p.km = g_emu_ns[1]; p.ps = g_emu_ns[2]; p.pi = g_emu_ns[3];
     for (int k = 0; k < 6; ++k) p.we[k] = we6 ? we6[k] : 1.0;
     if (const char *pm = getenv("EMU_IK_PASS_MASK")) p.pass_mask = atoi(pm);
     { const int64_t g = waves; const int64_t cap = (N + g - 1) / g; p.fresh_cap = cap > 64 ? 64 : (int)cap;

@@ -64,6 +64,8 @@ def lib():
         _lib.emu_kin_hess.argtypes = [_u64, _vp, _i64, _vp, _i32, _vp]
         _lib.emu_kin_hess_tile.argtypes = [_u64, _vp, _i64, _vp, _i32, _i32, _vp]
         _lib.emu_diff.argtypes = [_u64, _i32, _i32, _vp, _vp, _i64, _vp, _i32, _vp]
+        _lib.emu_ik_nullspace.argtypes = [C.c_double] * 4
+        _lib.emu_ik_nullspace.restype = None
         _lib.emu_partial.argtypes = [_u64, _vp, _i64, _vp, _i32, _vp]
         _lib.emu_dyn.argtypes = [_u64, _i32, _vp, _vp, _vp, _i64, _vp, _vp]
         _lib.emu_kin_reg.argtypes = [_u64, _vp, _i64, _vp, _vp, _i32, _vp, _vp]
@@ -242,6 +244,11 @@ def ik(ets, Tep, q0=None, ilimit=30, slimit=100, tol=1e-6, joint_limits=True, ma
                           seed, _p(q), _p(ok), _p(it), _p(se), _p(E))
     assert rc == 0, rc
     return q, ok, it, se, E
+
+
+def ik_nullspace(kq=0.0, km=0.0, ps=0.0, pi=0.3):
+    """Null-space terms for the following emu.ik calls (kq <= 0 switches them off again)."""
+    lib().emu_ik_nullspace(float(kq), float(km), float(ps), float(pi))
 
 
 def ik_restart(ets, seed, target, draw):

@@ -12,6 +12,7 @@ import pytest
 import torch
 
 import rtbhip
+from rtbhip import urdf
 from oracle import oracle, chains
 from helpers import literals, ref_outputs, mixed_spec, product_ets, tool_base
 
@@ -426,6 +427,64 @@ def test_ikine_nr_gn_python_flavour():
             fn(Tep)                                                     # pinv=False on a 7-joint arm
     sol = ets.ikine_NR(np.stack([Tep, Tep]), pinv=True, seed=1)
     assert sol.q.shape == (2, 7) and sol.each["success"].all()
+
+
+def test_ikine_nullspace_terms():
+    """kq / km / ps / pi of the Python solvers (robot/IK.py:507-576).  The reference's own cases: tests/test_IK.py:166-183
+    (IK_NR pinv kq=0.01 km=1), :194-205 (IK_LM chan kq=km=0.1), :261-272 (IK_GN pinv kq=km=1) -- success and E < 1e-5 on
+    the Panda target; then first-search agreement with the NumPy restatement on a batch with active limit avoidance."""
+    ets, ch = _panda_limited()
+    plain = rtbhip.models.Panda().ets()                    # the reference's tests use the model without Franka limits
+    Tep = oracle.fkine(ch, np.array([0, -0.3, 0, -2.2, 0, 2.0, np.pi / 4]))[0]
+    for e in (plain, ets):
+        for sol in (e.ikine_NR(Tep, pinv=True, seed=0, kq=0.01, km=1.0), e.ikine_LM(Tep, method="chan", seed=0, kq=0.1, km=0.1),
+                    e.ikine_GN(Tep, pinv=True, seed=0, kq=1.0, km=1.0)):
+            assert sol.success and sol.residual < 1e-6
+            err = oracle.angle_axis(oracle.fkine(ch, sol.q)[0], Tep)
+            assert 0.5 * err @ err < 1e-5
+    rng = np.random.default_rng(41)
+    N = 200
+    qs = rng.uniform(ch.qlim[0] + 0.25, ch.qlim[1] - 0.25, (N, 7))
+    qs[::2, 3] = ch.qlim[1, 3] - 0.12
+    qs[1::4, 1] = ch.qlim[0, 1] + 0.1
+    T = oracle.fkine(ch, qs)
+    q0 = np.clip(qs + 0.03 * rng.normal(size=qs.shape), ch.qlim[0] + 0.02, ch.qlim[1] - 0.02)
+    for step, kw, ns in (("lm", dict(method="chan", k=1.0), (0.1, 0.1, 0.0, 0.3)), ("nr", dict(pinv=True), (0.01, 1.0, 0.0, 0.3)),
+                         ("lm", dict(method="wampler", k=0.01), (0.5, 0.0, 0.05, 0.4))):
+        kq, km, ps, pi = ns
+        fn = ets.ikine_LM if step == "lm" else ets.ikine_NR
+        sol = fn(T, q0=q0, seed=5, slimit=3, kq=kq, km=km, ps=ps, pi=pi, **kw)
+        base = fn(T, q0=q0, seed=5, slimit=3, **kw)
+        assert np.nanmax(np.abs(sol.q - base.q)) > 1e-6                 # the term acts
+        checked = 0
+        for i in range(0, N, 4):
+            rs = np.array([q0[i]] + [ets.ik_restart(5, i, d) for d in range(1, 3)])
+            o = oracle.ikine_py(ch, T[i], rs, step=step, slimit=3, k=kw.get("k", 0.0), kq=kq, km=km, ps=ps, pi=pi, method=kw.get("method", "chan"))
+            if o[1] and o[3] == 1:
+                checked += 1
+                assert (o[1], o[2], o[3]) == (sol.each["success"][i], sol.each["iterations"][i], sol.each["searches"][i])
+                nt.assert_allclose(sol.q[i], o[0], atol=1e-6)
+        assert checked >= 25
+    # a device batch gives what the host path gives; 9+ joints are refused loudly; 5 joints run (projector vanishes)
+    import torch
+    st = ets.ikine_LM(torch.from_numpy(T).cuda(), q0=torch.from_numpy(q0).cuda(), seed=5, slimit=3, kq=0.1, km=0.1)
+    sh = ets.ikine_LM(T, q0=q0, seed=5, slimit=3, kq=0.1, km=0.1)
+    nt.assert_array_equal(st.q, sh.q)
+    gen3 = urdf.load("KinovaGen3").ets()
+    if gen3.n > 8:
+        with pytest.raises(rtbhip.RtbHipError):
+            gen3.ikine_LM(gen3.eval(np.zeros(gen3.n)), kq=0.1)
+    with pytest.raises(rtbhip.RtbHipError):
+        lib_ik_flavour0_nullspace(ets, Tep)
+
+
+def lib_ik_flavour0_nullspace(ets, Tep):
+    """kq with the C-solver flavour is an argument error at the ABI."""
+    from rtbhip._lib import lib, check, host_ptr, MEM_HOST
+    q = np.empty((1, 7)); ok = np.empty(1, np.int32); it = np.empty(1, np.int32); se = np.empty(1, np.int32); E = np.empty(1)
+    T = np.ascontiguousarray(Tep.reshape(1, 4, 4))
+    check(lib().rtbhip_ik_lm_nullspace(ets._handle(), host_ptr(T), 1, None, 30, 100, 1e-6, 1, None, 1.0, 0, 0, 0, 0.1, 0.0, 0.0, 0.3,
+                                       host_ptr(q), host_ptr(ok), host_ptr(it), host_ptr(se), host_ptr(E), MEM_HOST, None))
 
 
 def test_ik_config3_1e5_targets_statistics():

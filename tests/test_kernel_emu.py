@@ -347,6 +347,45 @@ def test_ikine_nr_gn_python_loop_semantics(step):
     assert checked >= 12
 
 
+@pytest.mark.parametrize("step,method,k,ns", [("lm", "chan", 1.0, (0.1, 0.1, 0.0, 0.3)), ("lm", "sugihara", 0.01, (0.5, 0.0, 0.05, 0.4)),
+                                              ("nr", "nr", 0.0, (0.01, 1.0, 0.0, 0.3)), ("gn", "gn", 0.0, (1.0, 1.0, 0.0, 0.3))])
+def test_ikine_nullspace_terms_equal_python_solver(step, method, k, ns):
+    """kq / km / ps / pi of IK_LM / IK_NR / IK_GN (robot/IK.py:507-576, added at :758, :1015, :1215): the device
+    step against the NumPy restatement (numpy.linalg.pinv projector, oracle jacobm), first-search cases started near
+    the solution and near a joint limit so the avoidance term is active.  Parameter sets of tests/test_IK.py:166-173
+    (NR kq=0.01 km=1), :194-196 (LM kq=km=0.1), :261-263 (GN kq=km=1)."""
+    ets, ch = _panda_limited()
+    rng = np.random.default_rng(41)
+    N = 20
+    qs = rng.uniform(ch.qlim[0] + 0.25, ch.qlim[1] - 0.25, (N, 7))
+    qs[::2, 3] = ch.qlim[1, 3] - 0.12                      # inside the influence distance of joint 4's upper limit
+    qs[1::4, 1] = ch.qlim[0, 1] + 0.1
+    Tep = oracle.fkine(ch, qs)
+    q0 = qs + 0.03 * rng.normal(size=qs.shape)
+    q0 = np.clip(q0, ch.qlim[0] + 0.02, ch.qlim[1] - 0.02)
+    kq, km, ps, pi = ns
+    emu.ik_nullspace(kq, km, ps, pi)
+    try:
+        q, ok, it, se, E = emu.ik(ets, Tep, q0=q0, method=method, flavour=1, seed=5, slimit=3, k=k)
+        qw, okw, itw, sew, Ew = emu.ik(ets, Tep, q0=q0, method=method, flavour=1, seed=5, slimit=3, k=k, waves=2)
+    finally:
+        emu.ik_nullspace()
+    nt.assert_array_equal(q, qw)                            # the wave scheduler replays the same searches
+    nt.assert_array_equal(np.c_[ok, it, se], np.c_[okw, itw, sew])
+    # the term must have changed something: without it the same problem takes a different path
+    q_plain = emu.ik(ets, Tep, q0=q0, method=method, flavour=1, seed=5, slimit=3, k=k)[0]
+    assert np.nanmax(np.abs(q_plain - q)) > 1e-6
+    checked = 0
+    for i in range(N):
+        rs = np.array([q0[i]] + [emu.ik_restart(ets, 5, i, d) for d in range(1, 3)])
+        o = oracle.ikine_py(ch, Tep[i], rs, step=step, slimit=3, k=k, kq=kq, km=km, ps=ps, pi=pi, method=method if step == "lm" else "chan")
+        if o[1] and o[3] == 1:
+            checked += 1
+            assert (o[1], o[2], o[3]) == (ok[i], it[i], se[i])
+            nt.assert_allclose(q[i], o[0], atol=1e-7)
+    assert checked >= 10
+
+
 @pytest.mark.parametrize("robot,n", [("Fetch", 10), ("KinovaGen3", 9)])
 def test_ik_nine_to_twelve_joint_chains(robot, n):
     """IK on chains of 9..12 joints (URDF Fetch: torso + 7-joint arm + gripper path, Kinova Gen3 + finger): the
