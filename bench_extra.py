@@ -139,6 +139,33 @@ def main():
                           "roofline": {"bound": "hbm", "achieved": byts * Np / (avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                        "frac": byts * Np / (avg * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": byts * Np}}), flush=True)
 
+    if "graph" in what:
+        # launch-bound regime (a control loop's batch): fkine+jacob0, hessian0 and rne on 4096 configurations, eager vs one captured hipGraph
+        import time
+        N = 4096
+        ets = rtbhip.models.Panda().ets()
+        arm = rtbhip.models.DH.Panda()
+        rng = np.random.default_rng(0)
+        q = torch.from_numpy(rng.uniform(-2, 2, (N, 7))).cuda()
+        qd = torch.from_numpy(rng.normal(size=(N, 7))).cuda()
+        def step():
+            return ets.fkine_jacob0(q), ets.hessian0(q), arm.rne(q, qd, qd)
+        step(); torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            keep = step()
+        reps = 300
+        def clock(fn):
+            fn(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps * 1e6
+        te, tg = clock(step), clock(g.replay)
+        print(json.dumps({"metric": "us per control step (Panda fkine+jacob0, hessian0, rne; N=4096)", "eager_us": te, "hipgraph_us": tg,
+                          "value": N / (tg * 1e-6), "unit": "configurations/s", "n": N}), flush=True)
+
     if "tree" in what:
         # Robot.rne of a URDF arm (UR5, 6 link groups, <inertial> masses) through k_tree_rne
         from rtbhip import urdf
