@@ -31,7 +31,7 @@ def ev_time(fn, steps, warmup):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--what", default="rne,ik,fleet,dyn,tree")
+    ap.add_argument("--what", default="rne,ik,fleet,dyn,tree,kin,graph")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--n-rne", type=int, default=1250000)
     ap.add_argument("--n-ik", type=int, default=100000)
@@ -125,7 +125,6 @@ def main():
 
         # partial_fkine0 order 3: (N,7,7,6,7) output = 16.5 KB per configuration, so a tenth of the batch; the time includes the
         # fkine/jacob0/hessian0 launch that feeds it and the temporaries' allocation (whole-call time, host clock around a sync)
-        import time
         Np = N // 10
         qp = q[:Np].contiguous()
         ets.partial_fkine0(qp, 3); torch.cuda.synchronize()
@@ -141,7 +140,6 @@ def main():
 
     if "graph" in what:
         # launch-bound regime (a control loop's batch): fkine+jacob0, hessian0 and rne on 4096 configurations, eager vs one captured hipGraph
-        import time
         N = 4096
         ets = rtbhip.models.Panda().ets()
         arm = rtbhip.models.DH.Panda()
