@@ -123,6 +123,14 @@ def main():
                               "roofline": {"bound": "hbm", "achieved": byts * N / (avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                            "frac": byts * N / (avg * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": byts * N}}), flush=True)
 
+        # fkine_all: the 8 link frames of the DH Panda (1 KB per configuration out)
+        arm = rtbhip.models.DH.Panda()
+        avg, best = ev_time(lambda: arm.fkine_all(q), args.steps, 2)
+        byts = 56 + 8 * 128
+        print(json.dumps({"metric": "configurations/sec (DH Panda fkine_all, 8 frames)", "value": N / (avg * 1e-3), "unit": "configurations/s", "n": N,
+                          "kernel_avg_ms": avg, "kernel_min_ms": best,
+                          "roofline": {"bound": "hbm", "achieved": byts * N / (avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                       "frac": byts * N / (avg * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": byts * N}}), flush=True)
         # partial_fkine0 order 3: (N,7,7,6,7) output = 16.5 KB per configuration, so a tenth of the batch; the time includes the
         # fkine/jacob0/hessian0 launch that feeds it and the temporaries' allocation (whole-call time, host clock around a sync)
         Np = N // 10
@@ -208,6 +216,21 @@ def main():
                                         "success_rate": float(np.mean([o[1] for o in out])),
                                         "mean_iterations": float(np.mean([o[2] for o in out]))}
         print(json.dumps(line), flush=True)
+        # SURVEY 8d config 3, second setting: the reference's ik_benchmark notebook (k = 0.1, no joint-limit rejection); and the
+        # throughput regime of the default setting (10x the targets: the chip is full, the tail amortised)
+        def extra(metric, T, **kw):
+            r = {}
+            def go():
+                r["o"] = ets.ik_LM(T, seed=2, **kw)
+            a, b = ev_time(go, max(3, args.steps // 4), 1)
+            _, ok2, it2, _, _ = r["o"]
+            n2 = T.shape[0]
+            print(json.dumps({"metric": metric, "value": n2 / (a * 1e-3), "unit": "solves/s", "n": n2, "kernel_avg_ms": a, "kernel_min_ms": b,
+                              "success_rate": float(ok2.float().mean()), "mean_iterations": float(it2.float().mean()),
+                              "lm_iterations_per_s": float(it2.sum()) / (a * 1e-3)}), flush=True)
+        extra("solves/sec (Panda ik_LM chan k=0.1, joint_limits=False: the ik_benchmark notebook setting)", Tep, k=0.1, joint_limits=False)
+        qs10 = torch.from_numpy(rng.uniform(ets.qlim[0], ets.qlim[1], (10 * N, 7))).cuda()
+        extra("solves/sec (Panda ik_LM defaults, %d targets)" % (10 * N), ets.eval(qs10))
 
     if "fleet" in what:
         # BASELINE configs[4]: 16 URDF arms (rtbhip/data/urdf, 4..10 joints on the path to the deepest

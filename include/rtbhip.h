@@ -117,6 +117,12 @@ int rtbhip_manipulability(rtbhip_chain_t chain, const double *q, int64_t N, cons
 int rtbhip_jacobm(rtbhip_chain_t chain, const double *q, int64_t N, const double *tool16, int32_t axes_mask, double *Jm,
                   int32_t mem, void *stream);
 
+/* DHRobot.fkine_all (robot/DHRobot.py:1012-1064) / Robot.fkine_all (robot/Robot.py:638-698), batched: the poses of
+ * intermediate frames of the chain.  marks[m] = k (nondecreasing, 0 <= k <= number of transforms, at most 33 marks)
+ * makes frame m the product  base * E_1(q) ... E_k(q)  of the first k elementary transforms; out is (N, nmarks, 4, 4). */
+int rtbhip_link_frames(rtbhip_chain_t chain, const double *q, int64_t N, const double *base16, const int32_t *marks,
+                       int32_t nmarks, double *out, int32_t mem, void *stream);
+
 /* ETS.partial_fkine0 (robot/ETS.py:1821-2013; Robot.partial_fkine0, robot/RobotKinematics.py:456-500): the
  * order-th partial derivative of the forward kinematics, order 3..6 (order 1 is jacob0, order 2 hessian0).
  * out is (N, n^(order-1), 6, n), C order, i.e. (N,n,n,6,n) at order 3 -- the reference's tensor with a leading

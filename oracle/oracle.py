@@ -112,6 +112,30 @@ def jacob_dot(ch, q, qd, tool=None, frame=0):
     return np.array([np.tensordot(H[i], qd[i], (0, 0)) for i in range(H.shape[0])])
 
 
+def link_frames(ch, q, marks, base=None):
+    """DHRobot.fkine_all / Robot.fkine_all (robot/DHRobot.py:1058-1064, robot/Robot.py:667-698): Tj = base; Tj *= A_k(q) and
+    every partial product kept.  Frame m = base * (first marks[m] elementary transforms), each built as the reference's
+    rx/ry/rz/tx/ty/tz do (core/fknm.cpp:1320-1555; flip negates the coordinate).  (N, nmarks, 4, 4)."""
+    from . import chains as _ch
+    q = _f64(q).reshape(-1, max(1, int(ch.jindex.max()) + 1 if ch.n else 1)) if ch.n else np.zeros((np.atleast_2d(q).shape[0], 0))
+    names = ["Rx", "Ry", "Rz", "tx", "ty", "tz"]
+    out = np.empty((q.shape[0], len(marks), 4, 4))
+    for i in range(q.shape[0]):
+        T = np.eye(4) if base is None else np.array(base, dtype=float)
+        prefix = [T.copy()]
+        for k in range(ch.m):
+            if ch.kind[k] == 6:
+                A = ch.consts[k].reshape(4, 4)
+            else:
+                eta = q[i, ch.jindex[k]]
+                A = _ch.elementary(names[ch.kind[k]], -eta if ch.flip[k] else eta)
+            T = T @ A
+            prefix.append(T.copy())
+        for m, k in enumerate(marks):
+            out[i, m] = prefix[k]
+    return out
+
+
 def partial_fkine0(ch, q, n, tool=None):
     """ETS.partial_fkine0 (robot/ETS.py:1862-2013) for one configuration: dT[c][..., l, k, :, j] from the
     product rule on H[k, :, j] = J_w[:, k] x J[:, j].  Same term bookkeeping as the reference

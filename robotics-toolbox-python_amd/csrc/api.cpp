@@ -3,6 +3,7 @@
 // host-memory convenience path (stage -> launch -> copy back).  No arithmetic lives here.
 #include "rtbhip_internal.h"
 #include "partial_device.h"
+#include "frames_device.h"
 #include "tree_device.h"
 #include <atomic>
 #include <cstring>
@@ -389,6 +390,36 @@ int rtbhip_jacobm(rtbhip_chain_t chain, const double *q, int64_t N, const double
                   int32_t mem, void *stream)
 {
     return diff_entry("jacobm", chain, 2, axes_mask, q, nullptr, N, tool16, 0, Jm, mem, stream);
+}
+
+/* DHRobot.fkine_all / Robot.fkine_all (robot/DHRobot.py:1012-1064, robot/Robot.py:638-698), batched */
+int rtbhip_link_frames(rtbhip_chain_t chain, const double *q, int64_t N, const double *base16, const int32_t *marks,
+                       int32_t nmarks, double *out, int32_t mem, void *stream)
+{
+    Chain *c = chain_from_handle(chain);
+    if (!c) { set_error("link_frames: unknown chain handle"); return RTBHIP_EINVAL; }
+    if (mem != RTBHIP_MEM_HOST && mem != RTBHIP_MEM_DEVICE) { set_error("link_frames: bad mem kind"); return RTBHIP_EINVAL; }
+    if (N < 0) { set_error("link_frames: negative N"); return RTBHIP_EINVAL; }
+    if (nmarks > 0 && !marks) { set_error("link_frames: NULL marks"); return RTBHIP_EINVAL; }
+    FrameTable ft;
+    RTB_TRY(compile_frames(c, marks, nmarks, &ft));
+    if (N == 0 || nmarks == 0) return RTBHIP_OK;
+    if ((c->q_width > 0 && !q) || !out) { set_error("link_frames: NULL q / output"); return RTBHIP_EINVAL; }
+    Affine b = affine_from16(base16);
+    ft.has_base = b.used;
+    for (int i = 0; i < 12; i++) ft.base[i] = b.v[i];
+    DevChain ops;
+    RTB_TRY(chain_device_ops(c, &ops, nullptr));
+    if (mem == RTBHIP_MEM_DEVICE) return launch_frames(c, ops, ft, q, N, out, (hipStream_t)stream);
+    Staging st;
+    void *dq, *dout;
+    const size_t obytes = (size_t)N * nmarks * 128;
+    RTB_TRY(st.in(q, (size_t)N * c->q_width * 8, &dq));
+    RTB_TRY(st.out(obytes, &dout));
+    RTB_TRY(launch_frames(c, ops, ft, (const double *)dq, N, (double *)dout, nullptr));
+    RTB_HIP(hipDeviceSynchronize());
+    RTB_TRY(fetch(out, dout, obytes));
+    return RTBHIP_OK;
 }
 
 // stream-ordered temporaries: keep freed blocks in the current device's default pool instead of returning them at every sync

@@ -14,6 +14,7 @@
 // rotate two columns by q_j or slide along one }, then P <- P*C_n.
 // Folding re-associates the constant products (rounding ~1e-16, against a 1e-10 parity budget).
 #include "rtbhip_internal.h"
+#include "frames_device.h"
 #include <cmath>
 #include <cstring>
 
@@ -132,6 +133,56 @@ int compile_chain(const rtbhip_et *ets, int m, const double *qlim, Chain *out)
     for (int j = 0; j < n; j++) {
         out->qlim[j] = qlim ? qlim[j] : lo[j];
         out->qlim[n + j] = qlim ? qlim[n + j] : hi[j];
+    }
+    return RTBHIP_OK;
+}
+
+// marks[m] = k: frame m is the product of the first k transforms of the chain.  Re-runs the folding of compile_chain and
+// records, at each mark, how many joints precede it and the constant run accumulated since the last joint.
+int compile_frames(const Chain *c, const int32_t *marks, int nmarks, FrameTable *ft)
+{
+    if (nmarks < 0 || nmarks > kMaxFrames) { set_error("link_frames: at most " + std::to_string(kMaxFrames) + " frames per call"); return RTBHIP_ELIMIT; }
+    const int m = (int)c->ets.size();
+    ft->nmarks = nmarks;
+    int next = 0;
+    for (int k = 0; k < nmarks; ++k) {
+        if (marks[k] < 0 || marks[k] > m || (k > 0 && marks[k] < marks[k - 1])) {
+            set_error("link_frames: marks must be nondecreasing transform counts in 0..m");
+            return RTBHIP_EINVAL;
+        }
+    }
+    DevSeg cur = seg_identity();
+    bool cur_is_identity = true;
+    int n = 0;
+    auto record = [&](int done) {
+        while (next < nmarks && marks[next] == done) {
+            ft->jcount[next] = n;
+            ft->ident[next] = cur_is_identity ? 1 : 0;
+            for (int i = 0; i < 9; i++) ft->F[next][i] = cur.r[i];
+            for (int i = 0; i < 3; i++) ft->F[next][9 + i] = cur.t[i];
+            ++next;
+        }
+    };
+    record(0);
+    for (int i = 0; i < m; i++) {
+        const rtbhip_et &e = c->ets[i];
+        if (e.kind == RTBHIP_ET_CONST) {
+            DevSeg a;
+            for (int r = 0; r < 3; r++) {
+                for (int k = 0; k < 3; k++) a.r[3 * r + k] = e.T[4 * r + k];
+                a.t[r] = e.T[4 * r + 3];
+            }
+            cur = cur_is_identity ? a : seg_mul(cur, a);
+            cur_is_identity = false;
+        } else {
+            const int axis = e.kind % 3;
+            int perm[3];
+            axis_perm(axis, perm);
+            if (axis == 2) { cur = seg_identity(); cur_is_identity = true; }
+            else { cur = perm_transpose_seg(perm); cur_is_identity = false; }
+            n++;
+        }
+        record(i + 1);
     }
     return RTBHIP_OK;
 }

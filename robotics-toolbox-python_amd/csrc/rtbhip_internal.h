@@ -110,6 +110,9 @@ int launch_kin(const Chain *c, const DevChain &dc, const double *q, int64_t N, c
 int launch_kin_diff(const Chain *c, const DevChain &dc, int mode, int axes, const double *q, const double *qd, int64_t N,
                     const Affine &tool, int frame, double *out, hipStream_t s);
 
+struct FrameTable;
+int compile_frames(const Chain *c, const int32_t *marks, int nmarks, FrameTable *ft);
+int launch_frames(const Chain *c, const DevChain &dc, const FrameTable &ft, const double *q, int64_t N, double *out, hipStream_t s);
 int launch_partial(int n, int order, const double *const *lower, int64_t N, double *out, hipStream_t s);
 
 struct FleetEntry {   // device-visible descriptor of one chain of a fleet launch

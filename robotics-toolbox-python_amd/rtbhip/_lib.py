@@ -63,6 +63,7 @@ SIGNATURES = {
     "rtbhip_jacob_dot": (C.c_int, [_u64, _vp, _vp, _i64, _vp, _i32, _vp, _i32, _vp]),
     "rtbhip_manipulability": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _i32, _vp, _i32, _vp]),
     "rtbhip_jacobm": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _vp, _i32, _vp]),
+    "rtbhip_link_frames": (C.c_int, [_u64, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _vp]),
     "rtbhip_partial_fkine0": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _vp, _i32, _vp]),
     "rtbhip_tree_create": (C.c_int, [C.POINTER(rtbhip_tree_group), _i32, C.POINTER(_u64)]),
     "rtbhip_tree_destroy": (C.c_int, [_u64]),

@@ -165,6 +165,17 @@ class DHRobot:
         the GPU is the same product (tests pin the two against each other)."""
         return self.ets().eval(q)
 
+    def fkine_all(self, q, **kw):
+        """Poses of frames {0} (the base) to {n}: (n+1,4,4) or (N,n+1,4,4).  reference robot/DHRobot.py:1012-1064:
+        Tj = base; Tj *= L.A(q_j) for every link -- the tool is not applied."""
+        e = self.ets()
+        k = 1 if (self.base is not None and not np.array_equal(self.base, np.eye(4))) else 0
+        marks = [k]
+        for l in self.links:
+            k += len(l.ets())
+            marks.append(k)
+        return e.link_frames(q, marks)
+
     def jacob0(self, q, **kw): return self.ets().jacob0(q)
     def jacobe(self, q, **kw): return self.ets().jacobe(q)
 

@@ -126,6 +126,41 @@ class ERobot:
                     out.append(e)
         return ETS(out)
 
+    def fkine_all(self, q, base=None):
+        """Pose of every link frame: T[0] = base, T[k+1] = link k of self.links; (nlinks+1,4,4) or (N,nlinks+1,4,4)
+        (reference Robot.fkine_all robot/Robot.py:638-698, a Python recursion over the link tree).  One chain walk per
+        leaf of the tree: the frames of all the links on its path come out of the same launch."""
+        index = {id(l): k for k, l in enumerate(self.links)}
+        done = {}
+        is_torch = type(q).__module__.startswith("torch")
+        for leaf in (l for l in self.links if not l.children):
+            path = []
+            l = leaf
+            while l is not None:
+                path.append(l)
+                l = l.parent
+            path.reverse()
+            marks, want, k = [], [], 0
+            for l in path:
+                k += len(l.ets)
+                if id(l) not in done:
+                    marks.append(k); want.append(l)
+            if not marks:
+                continue
+            e = self.ets(end=leaf)
+            qa = q if is_torch else np.asarray(q, dtype=np.float64)
+            F = e.link_frames(qa[..., :e.q_width], marks, base=base)       # the path reads the robot-wide joint columns it uses
+            for m, l in enumerate(want):
+                done[id(l)] = F[..., m, :, :]
+        first = next(iter(done.values()))
+        if is_torch:
+            import torch
+            T0 = torch.eye(4, dtype=first.dtype, device=first.device) if base is None else torch.as_tensor(np.asarray(base, dtype=np.float64)).to(first.device)
+            T0 = T0.expand(first.shape)
+            return torch.stack([T0] + [done[id(l)] for l in self.links], dim=-3)
+        T0 = np.broadcast_to(np.eye(4) if base is None else np.asarray(base, dtype=np.float64), first.shape)
+        return np.stack([T0] + [done[id(l)] for l in self.links], axis=-3)
+
     # ------------------------------------------------------------ dynamics
     def link_groups(self):
         """Robot.py:1777-1789: static links are grouped with the first joint that follows them in link order."""

@@ -302,6 +302,18 @@ class ETS:
                                  self._ptr(T, tm), MEM_DEVICE if tm else MEM_HOST, self._stream(tm)))
         return T[0] if single else T
 
+    def link_frames(self, q, marks, base=None):
+        """Poses of intermediate frames: frame m = base * (product of the first marks[m] transforms).  (nmarks,4,4) for
+        one q, (N,nmarks,4,4) for a trajectory -- what DHRobot.fkine_all / Robot.fkine_all build link by link in Python
+        (robot/DHRobot.py:1012-1064, robot/Robot.py:638-698), in one chain walk per configuration."""
+        marks = np.ascontiguousarray(marks, dtype=np.int32).reshape(-1)
+        q2, single, tm = self._shape_q(q)
+        N = q2.shape[0]
+        out = self._out((N, len(marks), 4, 4), q2, tm)
+        check(lib().rtbhip_link_frames(self._handle(), self._ptr(q2, tm), N, host_ptr(small(base, 16)), host_ptr(marks),
+                                       len(marks), self._ptr(out, tm), MEM_DEVICE if tm else MEM_HOST, self._stream(tm)))
+        return out[0] if single else out
+
     def fkine(self, q, base=None, tool=None, include_base=True):
         """reference ETS.fkine (robot/ETS.py:1006-1019) wraps eval() in spatialmath.SE3; spatialmath
         is not a dependency here, so the SE(3) matrices are returned as an ndarray -- wrap with

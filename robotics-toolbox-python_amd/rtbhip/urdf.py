@@ -272,6 +272,13 @@ class URDFRobot:
                 made[l.name].parent = made[l.parent.name]
         return ERobot(links, name=self.name)
 
+    def fkine_all(self, q, exclude=()):
+        """Pose of every link frame (reference Robot.fkine_all robot/Robot.py:638-698): see ERobot.fkine_all."""
+        key = ("erobot", tuple(exclude))
+        if key not in self._cache:
+            self._cache[key] = self.erobot(exclude)
+        return self._cache[key].fkine_all(q)
+
     def rne(self, q, qd=None, qdd=None, gravity=None, exclude=()):
         key = ("erobot", tuple(exclude))
         if key not in self._cache:

@@ -13,7 +13,7 @@ PKG = os.path.join(ROOT, "robotics-toolbox-python_amd")
 EMU_SO = os.path.join(ROOT, "tests", "emu", "libemu.so")
 SRCS = ["tests/emu/emu.cpp"] + ["robotics-toolbox-python_amd/csrc/" + f for f in
                                 ("api.cpp", "chain.cpp", "tree.cpp", "kin_kernels.hip", "rne_kernels.hip", "ik_kernels.hip", "dyn_kernels.hip",
-                                 "tree_kernels.hip", "partial_kernels.hip")]
+                                 "tree_kernels.hip", "partial_kernels.hip", "frames_kernels.hip")]
 _vp, _u64, _i64, _i32 = C.c_void_p, C.c_uint64, C.c_int64, C.c_int32
 _lib = None
 
@@ -66,6 +66,7 @@ def lib():
         _lib.emu_diff.argtypes = [_u64, _i32, _i32, _vp, _vp, _i64, _vp, _i32, _vp]
         _lib.emu_ik_nullspace.argtypes = [C.c_double] * 4
         _lib.emu_ik_nullspace.restype = None
+        _lib.emu_link_frames.argtypes = [_u64, _vp, _i64, _vp, _vp, _i32, _vp]
         _lib.emu_partial.argtypes = [_u64, _vp, _i64, _vp, _i32, _vp]
         _lib.emu_dyn.argtypes = [_u64, _i32, _vp, _vp, _vp, _i64, _vp, _vp]
         _lib.emu_kin_reg.argtypes = [_u64, _vp, _i64, _vp, _vp, _i32, _vp, _vp]
@@ -166,6 +167,18 @@ def diff(ets, mode, q, qd=None, axes=63, tool=None, frame=0):
     out = np.full({0: (N, 6, n), 1: (N,), 2: (N, n)}[mode], np.nan)
     t = None if tool is None else np.ascontiguousarray(tool, dtype=np.float64)
     assert lib().emu_diff(h, mode, axes, _p(q), _p(qd), N, _p(t), frame, _p(out)) == 0
+    return out
+
+
+def link_frames(ets, q, marks, base=None):
+    """fkine_all through chain.cpp's compile_frames + frames_device.h on the CPU: (N, nmarks, 4, 4)."""
+    h = chain_handle(ets)
+    q = np.ascontiguousarray(np.asarray(q, dtype=np.float64).reshape(-1, max(ets.q_width, 1)))[:, :ets.q_width]
+    q = np.ascontiguousarray(q)
+    marks = np.ascontiguousarray(marks, dtype=np.int32)
+    out = np.full((q.shape[0], len(marks), 4, 4), np.nan)
+    b = None if base is None else np.ascontiguousarray(base, dtype=np.float64)
+    assert lib().emu_link_frames(h, _p(q), q.shape[0], _p(b), _p(marks), len(marks), _p(out)) == 0
     return out
 
 
