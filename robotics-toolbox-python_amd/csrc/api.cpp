@@ -576,6 +576,10 @@ int rtbhip_dyn_create(const double *L24, int32_t n, int32_t mdh, rtbhip_dyn_t *d
         k.m = l[6]; k.rx = l[7]; k.ry = l[8]; k.rz = l[9];
         for (int j = 0; j < 9; j++) k.I[j] = l[10 + j];
         k.Jm = l[19]; k.G = l[20]; k.B = l[21]; k.Tc0 = l[22]; k.Tc1 = l[23];
+        k.gjm = k.G * k.G * k.Jm; k.gb = k.G * k.G * k.B; k.ag = fabs(k.G);
+        k.flags = 0;
+        if (k.rx == 0.0 && k.ry == 0.0 && k.rz == 0.0) k.flags |= kLinkRZero;
+        if (k.I[1] == 0.0 && k.I[2] == 0.0 && k.I[3] == 0.0 && k.I[5] == 0.0 && k.I[6] == 0.0 && k.I[7] == 0.0) k.flags |= kLinkIDiag;
     }
     uint64_t h = g_next.fetch_add(1);
     std::lock_guard<std::mutex> lk(g_reg_mu);

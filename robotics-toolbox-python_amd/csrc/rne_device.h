@@ -111,6 +111,9 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
     constexpr int CAP = NJ > 0 ? NJ : RTBHIP_MAX_JOINTS;
     const int n = NJ > 0 ? NJ : n_rt;
     V3 F[CAP], Nn[CAP];
+    int flg[CAP];                  // all the links' shortcut flags in one batch of scalar loads, ahead of the branches on them
+#pragma unroll
+    for (int j = 0; j < n; ++j) flg[j] = links[j].flags;
 
     // ---- forward recursion (ne.c:133-348)
     V3 w = v3(0, 0, 0), wd = v3(0, 0, 0), a = v3(0, 0, 0);
@@ -174,10 +177,21 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
             }
         }
         w = wn; wd = wdn; a = an;
-        const V3 rc = v3(l.rx, l.ry, l.rz);
-        const V3 ac = (cross(wd, rc) + cross(w, cross(w, rc))) + a;   // ne.c:228-232
+        // Exact zeros in the link table are skipped through wave-uniform branches (scalar loads + s_cbranch): a centre of
+        // mass at the link origin (the DH Panda) removes 33 fp64 operations per link, a diagonal inertia tensor (Puma560)
+        // 12; the values are those of the general formulas (up to the sign of a zero)
+        V3 ac = a;
+        if (!(flg[j] & kLinkRZero)) {
+            const V3 rc = v3(l.rx, l.ry, l.rz);
+            ac = (cross(wd, rc) + cross(w, cross(w, rc))) + a;         // ne.c:228-232
+        }
         F[j] = l.m * ac;
-        Nn[j] = inertia_times(l, wd) + cross(w, inertia_times(l, w));
+        if (flg[j] & kLinkIDiag) {
+            const V3 iw = v3(l.I[0] * w.x, l.I[4] * w.y, l.I[8] * w.z);
+            Nn[j] = v3(l.I[0] * wd.x, l.I[4] * wd.y, l.I[8] * wd.z) + cross(w, iw);
+        } else {
+            Nn[j] = inertia_times(l, wd) + cross(w, inertia_times(l, w));
+        }
         if (NJ > 0) sched_fence();   // keep link j+1's scalar table loads from being hoisted over link j
     }
 
@@ -191,7 +205,8 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
         const auto &l = links[j];
         const bool last = (jj == 0);
         const bool pris = ALLREV ? false : (l.sigma != 0);
-        const V3 rc = v3(l.rx, l.ry, l.rz);
+        const bool rzero = (flg[j] & kLinkRZero) != 0;
+        const V3 rc = rzero ? v3(0, 0, 0) : v3(l.rx, l.ry, l.rz);
         const double d = pris ? qin(j) + l.offset : l.d;
         const Rot R = {st[j], ct[j], l.sa, l.ca};
         const V3 ps = link_offset<MDH>(l, d);
@@ -200,7 +215,7 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
             const V3 fn = last ? f : rot_fwd<MDH>(Rn, f);
             fj = fn + F[j];
             const V3 t1 = last ? nn : rot_fwd<MDH>(Rn, nn) + cross(psn, fn);
-            nj = (t1 + cross(rc, F[j])) + Nn[j];
+            nj = rzero ? t1 + Nn[j] : (t1 + cross(rc, F[j])) + Nn[j];
         } else {
             fj = F[j] + (last ? f : rot_fwd<MDH>(Rn, f));
             V3 t1 = cross(ps + rc, F[j]);
@@ -212,10 +227,10 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
         const V3 prj = pris ? fj : nj;
         const double qdj = qdin(j), qddj = qddin(j);
         double t = MDH ? prj.z : l.sa * prj.y + l.ca * prj.z;
-        t += l.G * l.G * l.Jm * qddj;
+        t += l.gjm * qddj;
         if (FRICTION) {
-            t += l.G * l.G * l.B * qdj;
-            t += fabs(l.G) * ((qdj > 0 ? l.Tc0 : 0.0) + (qdj < 0 ? l.Tc1 : 0.0));
+            t += l.gb * qdj;
+            t += l.ag * ((qdj > 0 ? l.Tc0 : 0.0) + (qdj < 0 ? l.Tc1 : 0.0));
         }
         tau(j, t);
         f = fj; nn = nj; Rn = R; psn = ps;

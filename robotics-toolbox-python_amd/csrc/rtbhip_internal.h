@@ -57,9 +57,11 @@ struct alignas(16) DevLink {   // per-link constants for the Newton-Euler kernel
     double m, rx, ry, rz;
     double I[9];               // as given (DHRobot.py:1353), read column-major like vmath.c
     double Jm, G, B, Tc0, Tc1;
+    double gjm, gb, ag;        // (G*G)*Jm, (G*G)*B, |G|: the products ne.c:464-492 forms per call, rounded in the same order
     int32_t sigma;             // 0 revolute, 1 prismatic
-    int32_t pad;
+    int32_t flags;             // wave-uniform shortcuts: kLinkRZero (centre of mass at the link origin), kLinkIDiag (diagonal inertia)
 };
+constexpr int kLinkRZero = 1, kLinkIDiag = 2;
 struct Dyn {
     std::vector<DevLink> links;
     int n = 0, mdh = 0;

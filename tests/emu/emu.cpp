@@ -411,6 +411,7 @@ extern "C" int emu_ik_wave(rtbhip_chain_t h, int waves, double *stats, const dou
     if (const char *pm = getenv("EMU_IK_PASS_MASK")) p.pass_mask = atoi(pm);
     { const int64_t g = waves; const int64_t cap = (N + g - 1) / g; p.fresh_cap = cap > 64 ? 64 : (int)cap;
       const int64_t lanes = g * kWave; p.pool_chunk = N >= 8 * lanes ? 64 : (N >= 3 * lanes ? 16 : 0); }
+    if (const char *fc = getenv("EMU_IK_FRESH_CAP")) p.fresh_cap = atoi(fc);
     int rc = 0;
     switch (c->n) {
     case 1: rc = emu_ik_wave_run<1>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
