@@ -430,28 +430,38 @@ RTB_HD void ik_emit(const IkLane<NJ> &st, QA qa, const IkDev &p, QL qlim, int64_
 // to running the searches one after another.
 // All tables live in the wave's LDS; the phases below are per-lane functions called between
 // wave-level barriers by the kernel (lane = threadIdx.x) and, lane by lane, by tests/emu.
-constexpr int kIkRing = 32;                 // outstanding (unaccounted) searches per slot
-struct IkWaveShared {
-    int64_t tgt[64];
+// kIkRing = 64: a wave left with ONE unresolved target can put all its 64 lanes on it (CPU replay of config 3, 2048
+// waves: longest wave 219 -> 194 iterations, lane utilisation 0.72 -> 0.78 against a ring of 32).  The struct is sized so
+// that 8 waves per CU still fit the 160 KB of LDS for chains of up to 8 joints (20288 B with QR = 8): 32-bit target
+// indices, 16-bit b / res, 8-bit list, and only as many q rows as the kernel's joint count class needs.
+constexpr int kIkRing = 64;                 // outstanding (unaccounted) searches per slot
+template <int QR>
+struct IkWaveSharedT {
+    uint32_t tgt[64];                       // target index (launch_ik refuses batches of 2^32 targets or more)
     double Elast[64];                       // E of the slot's last-index search (failure output)
-    int32_t b[64];                          // lowest search index not yet accounted
-    int32_t next[64];                       // next search index to hand out
-    int32_t best[64];                       // lowest successful search index seen so far
+    int16_t b[64];                          // lowest search index not yet accounted (slimit <= 32000)
+    int32_t next[64];                       // next search index to hand out (LDS atomic max)
+    int32_t best[64];                       // lowest successful search index seen so far (LDS atomic min)
     int32_t it[64];                         // iterations accounted so far
-    int32_t res[64];                        // 0 unresolved, 1 won (winner = b), 2 failed
-    int32_t list[64];                       // scratch: compacted slot list
+    int16_t res[64];                        // 0 unresolved, 1 won (winner = b), 2 failed
+    uint8_t list[64];                       // scratch: compacted slot list
     uint16_t rec[64][kIkRing];              // per outstanding search: 1 finished | 2 ok | iterations << 2
     double Td[12][64];                      // per SLOT: the target pose (read by every lane working on the slot)
-    double q[kIkMaxJoints][64];             // per LANE: the joint vector of that search
+    double q[QR][64];                       // per LANE: the joint vector of that search
 };
+template <int NJ> using IkWaveSharedFor = IkWaveSharedT<(NJ <= kRegMaxJoints ? kRegMaxJoints : kIkMaxJoints)>;
+static_assert(sizeof(IkWaveSharedT<kRegMaxJoints>) * 8 <= 160 * 1024, "8 IK waves per CU must fit the LDS");
+constexpr int kIkMaxSlimit = 32000;
 constexpr int kIkMaxIlimit = 16000;         // (ilimit + 1) << 2 must fit the 16-bit record
 
-struct IkLdsQ {   // accessor of one lane's q column in the wave's LDS
-    IkWaveShared *sh;
+template <class SH>
+struct IkLdsQT {   // accessor of one lane's q column in the wave's LDS
+    SH *sh;
     int lane;
     RTB_HD double get(int j) const { return sh->q[j][lane]; }
     RTB_HD void put(int j, double v) const { sh->q[j][lane] = v; }
 };
+template <class SH> RTB_HD IkLdsQT<SH> ik_lds_q(SH &sh, int lane) { return IkLdsQT<SH>{&sh, lane}; }
 constexpr int kIkNoBest = 0x7fffffff;
 
 RTB_HD void ik_lds_min(int32_t *p, int32_t v)
@@ -480,8 +490,8 @@ RTB_HD int ik_rank(unsigned long long mask, int lane)
 }
 
 // phase A: a lane whose search just ended posts the result and parks or goes idle
-template <int NJ>
-RTB_HD void ik_report(IkLane<NJ> &st, IkWaveShared &sh, int s_last)
+template <int NJ, class SH>
+RTB_HD void ik_report(IkLane<NJ> &st, SH &sh, int s_last)
 {
     if (st.status != kIkRun || !st.fin) return;
     sh.rec[st.slot][st.s & (kIkRing - 1)] = (uint16_t)(1 | (st.ok ? 2 : 0) | (st.iter << 2));
@@ -492,7 +502,8 @@ RTB_HD void ik_report(IkLane<NJ> &st, IkWaveShared &sh, int s_last)
 }
 
 // phase B: lane i accounts slot i in search order
-RTB_HD void ik_account(int i, IkWaveShared &sh, int s_last)
+template <class SH>
+RTB_HD void ik_account(int i, SH &sh, int s_last)
 {
     int b = sh.b[i], it = sh.it[i], res = 0;
     for (;;) {
@@ -504,12 +515,12 @@ RTB_HD void ik_account(int i, IkWaveShared &sh, int s_last)
         if (b == s_last) { res = 2; break; }
         ++b;
     }
-    sh.b[i] = b; sh.it[i] = it; sh.res[i] = res;
+    sh.b[i] = (int16_t)b; sh.it[i] = it; sh.res[i] = (int16_t)res;
 }
 
 // phase C: parked lanes of a resolved slot emit / release; searches beyond a known success are cancelled
-template <int NJ, class QL>
-RTB_HD void ik_finalize(IkLane<NJ> &st, IkWaveShared &sh, int lane, const IkDev &p, QL qlim, double *__restrict__ q_out,
+template <int NJ, class SH, class QL>
+RTB_HD void ik_finalize(IkLane<NJ> &st, SH &sh, int lane, const IkDev &p, QL qlim, double *__restrict__ q_out,
                         int32_t *__restrict__ success, int32_t *__restrict__ iters, int32_t *__restrict__ searches,
                         double *__restrict__ residual)
 {
@@ -517,11 +528,11 @@ RTB_HD void ik_finalize(IkLane<NJ> &st, IkWaveShared &sh, int lane, const IkDev 
     const int res = sh.res[st.slot];
     if (res == 1) {
         if (st.status == kIkParkedOk && st.s == sh.b[st.slot])
-            ik_emit<NJ>(st, IkLdsQ{&sh, lane}, p, qlim, sh.tgt[st.slot], p.has_q0 != 0, true, sh.it[st.slot], 0.0, q_out, success, iters, searches, residual);
+            ik_emit<NJ>(st, ik_lds_q(sh, lane), p, qlim, sh.tgt[st.slot], p.has_q0 != 0, true, sh.it[st.slot], 0.0, q_out, success, iters, searches, residual);
         st.status = kIkIdle;
     } else if (res == 2) {
         if (st.status == kIkParkedLast)
-            ik_emit<NJ>(st, IkLdsQ{&sh, lane}, p, qlim, sh.tgt[st.slot], p.has_q0 != 0, false, sh.it[st.slot], sh.Elast[st.slot], q_out, success, iters, searches, residual);
+            ik_emit<NJ>(st, ik_lds_q(sh, lane), p, qlim, sh.tgt[st.slot], p.has_q0 != 0, false, sh.it[st.slot], sh.Elast[st.slot], q_out, success, iters, searches, residual);
         st.status = kIkIdle;
     } else if (st.s > sh.best[st.slot]) {
         st.status = kIkIdle;      // a lower-indexed search already succeeded: this one can never be reported
@@ -529,40 +540,42 @@ RTB_HD void ik_finalize(IkLane<NJ> &st, IkWaveShared &sh, int lane, const IkDev 
 }
 
 // phase D1 helper: initialise slot `slot` for target tgt and start its first search in this lane
-template <int NJ, class QL>
-RTB_HD void ik_start_target(IkLane<NJ> &st, IkWaveShared &sh, int lane, const IkDev &p, QL qlim, int slot, int64_t tgt,
+template <int NJ, class SH, class QL>
+RTB_HD void ik_start_target(IkLane<NJ> &st, SH &sh, int lane, const IkDev &p, QL qlim, int slot, int64_t tgt,
                             const double *__restrict__ Tep, const double *__restrict__ q0)
 {
     const int s0 = ik_s_first(p);
-    sh.tgt[slot] = tgt; sh.b[slot] = s0; sh.next[slot] = s0 + 1; sh.best[slot] = kIkNoBest; sh.it[slot] = 0;
+    sh.tgt[slot] = (uint32_t)tgt; sh.b[slot] = (int16_t)s0; sh.next[slot] = s0 + 1; sh.best[slot] = kIkNoBest; sh.it[slot] = 0;
     sh.res[slot] = 0; sh.Elast[slot] = 0.0;
     for (int k = 0; k < kIkRing; ++k) sh.rec[slot][k] = 0;
     st.slot = slot;
     ik_load_target([&](int k, double v) { sh.Td[k][slot] = v; }, Tep + 16 * tgt);   // once per target, not per search
-    ik_search_begin<NJ>(st, IkLdsQ{&sh, lane}, p, qlim, tgt, s0, p.has_q0 ? q0 + (int64_t)NJ * tgt : nullptr);
+    ik_search_begin<NJ>(st, ik_lds_q(sh, lane), p, qlim, tgt, s0, p.has_q0 ? q0 + (int64_t)NJ * tgt : nullptr);
 }
 
 // phase D0: a slot none of whose searches is outstanding (its last running search just failed) must be
 // continued before anything else is started -- this is the reference's "next restart".
-RTB_HD bool ik_starved(int i, const IkWaveShared &sh) { return sh.res[i] == 0 && sh.next[i] == sh.b[i]; }
+template <class SH>
+RTB_HD bool ik_starved(int i, const SH &sh) { return sh.res[i] == 0 && sh.next[i] == sh.b[i]; }
 
 // phase D2, step 1: idle lane number `r` (of the idle lanes) picks a slot round-robin over the nb busy
 // slots (sh.list) and the q-th next search index of it; returns whether that index may start now.
-RTB_HD bool ik_pick(const IkWaveShared &sh, int r, int nb, int s_last, int &slot, int &s)
+template <class SH>
+RTB_HD bool ik_pick(const SH &sh, int r, int nb, int s_last, int &slot, int &s)
 {
     slot = sh.list[r % nb];
     s = sh.next[slot] + r / nb;
     return s <= s_last && s - sh.b[slot] < kIkRing && s < sh.best[slot];
 }
 // step 2 (after every lane has picked): claim the index and start the search
-template <int NJ, class QL>
-RTB_HD void ik_start_spec(IkLane<NJ> &st, IkWaveShared &sh, int lane, const IkDev &p, QL qlim, int slot, int s,
+template <int NJ, class SH, class QL>
+RTB_HD void ik_start_spec(IkLane<NJ> &st, SH &sh, int lane, const IkDev &p, QL qlim, int slot, int s,
                           const double *__restrict__ Tep, const double *__restrict__ q0)
 {
     ik_lds_max(&sh.next[slot], s + 1);
     const int64_t tgt = sh.tgt[slot];
     st.slot = slot;
-    ik_search_begin<NJ>(st, IkLdsQ{&sh, lane}, p, qlim, tgt, s, p.has_q0 ? q0 + (int64_t)NJ * tgt : nullptr);
+    ik_search_begin<NJ>(st, ik_lds_q(sh, lane), p, qlim, tgt, s, p.has_q0 ? q0 + (int64_t)NJ * tgt : nullptr);
 }
 
 // Sequential driver (one target, searches in order): the specification the scheduler must reproduce.

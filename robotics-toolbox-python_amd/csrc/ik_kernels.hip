@@ -32,7 +32,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                                                 int32_t *__restrict__ iters, int32_t *__restrict__ searches,
                                                 double *__restrict__ residual)
 {
-    __shared__ IkWaveShared sh;
+    __shared__ IkWaveSharedFor<NJ> sh;
     ConstChainIk cv;
     cv.seg = (const RTB_CONST DevSeg *)dc.seg;
     cv.jmeta = (const RTB_CONST int32_t *)dc.jmeta;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
             const RTB_CONST double *ql = qlim;
             asm volatile("" : "+s"(cvi.seg), "+s"(cvi.jmeta), "+s"(ql));
             const int myslot = st.slot;
-            ik_iter<NJ, STEP>(st, p, cvi, ql, [&](int k) { return sh.Td[k][myslot]; }, IkLdsQ{&sh, lane});
+            ik_iter<NJ, STEP>(st, p, cvi, ql, [&](int k) { return sh.Td[k][myslot]; }, ik_lds_q(sh, lane));
         }
     }
 }
@@ -211,6 +211,8 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
               hipStream_t s)
 {
     if (N == 0) return RTBHIP_OK;
+    if (ip.slimit > kIkMaxSlimit) { set_error("ik_lm: slimit above 32000 is not supported by the device scheduler"); return RTBHIP_ELIMIT; }
+    if (N >= (1ll << 32)) { set_error("ik_lm: at most 2^32 - 1 targets per call"); return RTBHIP_ELIMIT; }
     if (ip.ilimit > kIkMaxIlimit) { set_error("ik_lm: ilimit above 16000 is not supported by the device scheduler"); return RTBHIP_ELIMIT; }
     if (c->n > kIkMaxJoints) { set_error("ik_lm: this build solves chains of up to 12 joints on the device"); return RTBHIP_ELIMIT; }
     for (int j = 0; j < c->n; ++j)

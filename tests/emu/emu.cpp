@@ -242,7 +242,7 @@ static void emu_ik_run(const Chain *c, const IkDev &p, const double *Tep, const 
 // round-robin, one scheduling pass + one LM iteration each per turn, sharing the fresh-target counter.
 template <int NJ>
 struct EmuWave {
-    IkWaveShared sh;
+    IkWaveSharedT<kIkMaxJoints> sh;
     IkLane<NJ> st[kWave];
     unsigned long long busy = 0;
     bool exhausted = false, first = true, done = false, drained = false;
@@ -353,7 +353,9 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
             w.iters++;
             for (int l = 0; l < kWave; ++l) {
                 if (w.st[l].status == kIkRun) w.lane_iters_useful++;
-                ik_iter_any<NJ>(w.st[l], p, cv, qlim, [&](int k) { return w.sh.Td[k][w.st[l].slot]; }, IkLdsQ{&w.sh, l});
+                static const bool emu_ik_status = getenv("EMU_IK_STATUS") != nullptr; if (emu_ik_status) { static long long cnt[4] = {0, 0, 0, 0}; static long long total = 0; cnt[w.st[l].status]++;
+                    if ((++total % 4000000) == 0) fprintf(stderr, "status idle %lld run %lld parkedok %lld parkedlast %lld\n", cnt[0], cnt[1], cnt[2], cnt[3]); }
+                ik_iter_any<NJ>(w.st[l], p, cv, qlim, [&](int k) { return w.sh.Td[k][w.st[l].slot]; }, ik_lds_q(w.sh, l));
             }
         }
     }
