@@ -316,6 +316,8 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
                     const unsigned long long freeslots = ~w.busy;
                     int nf = __builtin_popcountll(idle);
                     nf = nf > p.fresh_cap ? p.fresh_cap : nf;
+                    { static const int mb = getenv("EMU_IK_MAX_BUSY") ? atoi(getenv("EMU_IK_MAX_BUSY")) : 64;
+                      const int room = mb - __builtin_popcountll(w.busy); nf = nf > room ? (room > 0 ? room : 0) : nf; }
                     if (w.pool_next == w.pool_end) {
                         const unsigned long long chunk = p.pool_chunk > 0 ? (unsigned long long)p.pool_chunk : (unsigned long long)nf;
                         const unsigned long long got = counter;
