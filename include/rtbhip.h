@@ -110,6 +110,10 @@ int rtbhip_hessian(rtbhip_chain_t chain, const double *q, int64_t N, const doubl
  *                          1 "minsingular", 2 "invcondition"; axes_mask bit r = Cartesian row r used
  *                          (63 all, 7 trans, 56 rot)
  *   rtbhip_jacobm          ETS.jacobm / Robot.jacobm (robot/ETS.py:1628-1685, robot/Robot.py:1120-1235): Jm (N,n) */
+/* ETS.jacob0_analytical (robot/ETS.py:1562-1626): Ja (N,6,n) = blkdiag(I, A^-1) jacob0, A = rotvelxform of the end-effector
+ * rotation; representation 0 "rpy/xyz", 1 "rpy/zyx", 2 "eul", 3 "exp" (conventions of spatialmath-python, see diff_device.h). */
+int rtbhip_jacob0_analytical(rtbhip_chain_t chain, const double *q, int64_t N, const double *tool16, int32_t representation,
+                             double *Ja, int32_t mem, void *stream);
 int rtbhip_jacob_dot(rtbhip_chain_t chain, const double *q, const double *qd, int64_t N, const double *tool16,
                      int32_t frame, double *Jd, int32_t mem, void *stream);
 int rtbhip_manipulability(rtbhip_chain_t chain, const double *q, int64_t N, const double *tool16, int32_t axes_mask,

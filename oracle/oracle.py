@@ -7,6 +7,7 @@ Parity status: pinned (see rtb_oracle.h header).
 import ctypes as C
 import os
 import subprocess
+import math
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -110,6 +111,62 @@ def jacob_dot(ch, q, qd, tool=None, frame=0):
     H = hessian(ch, q, tool, frame)
     qd = _f64(qd).reshape(H.shape[0], ch.n)
     return np.array([np.tensordot(H[i], qd[i], (0, 0)) for i in range(H.shape[0])])
+
+
+def tr2x(T, representation="rpy/xyz"):
+    """spatialmath-python 1.1.x `tr2x` (third-party, absent from the reference tree): [t, Gamma] with Gamma = tr2rpy(order
+    "xyz" / "zyx") = (roll, pitch, yaw), tr2eul = (phi, theta, psi) or the rotation vector of trlog.  Conventions:
+    R = Rx(yaw) Ry(pitch) Rz(roll) for "xyz", Rz(yaw) Ry(pitch) Rx(roll) for "zyx", Rz(phi) Ry(theta) Rz(psi) for "eul"."""
+    R, t = np.asarray(T)[:3, :3], np.asarray(T)[:3, 3]
+    if representation == "rpy/xyz":
+        g = [-math.atan2(R[0, 1], R[0, 0]), math.atan2(R[0, 2], math.hypot(R[1, 2], R[2, 2])), -math.atan2(R[1, 2], R[2, 2])]
+    elif representation == "rpy/zyx":
+        g = [math.atan2(R[2, 1], R[2, 2]), -math.atan2(R[2, 0], math.hypot(R[0, 0], R[1, 0])), math.atan2(R[1, 0], R[0, 0])]
+    elif representation == "eul":
+        phi = math.atan2(R[1, 2], R[0, 2])
+        sp, cp = math.sin(phi), math.cos(phi)
+        g = [phi, math.atan2(cp * R[0, 2] + sp * R[1, 2], R[2, 2]), math.atan2(-sp * R[0, 0] + cp * R[1, 0], -sp * R[0, 1] + cp * R[1, 1])]
+    elif representation == "exp":
+        l = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+        nrm = np.linalg.norm(l)
+        th = math.atan2(nrm, np.trace(R) - 1)
+        g = list(l * (th / nrm)) if nrm > 1e-12 else [0.0, 0.0, 0.0]
+    else:
+        raise ValueError(representation)
+    return np.r_[t, g]
+
+
+def _rot(axis, a):
+    c, s = math.cos(a), math.sin(a)
+    return {"x": np.array([[1, 0, 0], [0, c, -s], [0, s, c]]), "y": np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]]),
+            "z": np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])}[axis]
+
+
+def rotvelxform_inverse(R, representation):
+    """What `rotvelxform(R, inverse=True, full=True, representation=...)` returns (ETS.py:1624-1625): blkdiag(I, A^-1), A
+    mapping the rates of Gamma to the angular velocity.  Built from the ANGLES of tr2x (the device builds it from the entries
+    of R): omega = a x1' + R_a b x2' + R_a R_b c x3' for R = R_a(x1) R_b(x2) R_c(x3); left Jacobian of SO(3) for "exp"."""
+    g = tr2x(np.r_[np.c_[R, np.zeros(3)], [[0, 0, 0, 1]]], representation)[3:]
+    ex, ey, ez = np.eye(3)
+    if representation == "rpy/xyz":
+        A = np.c_[_rot("x", g[2]) @ _rot("y", g[1]) @ ez, _rot("x", g[2]) @ ey, ex]
+    elif representation == "rpy/zyx":
+        A = np.c_[_rot("z", g[2]) @ _rot("y", g[1]) @ ex, _rot("z", g[2]) @ ey, ez]
+    elif representation == "eul":
+        A = np.c_[ez, _rot("z", g[0]) @ ey, _rot("z", g[0]) @ _rot("y", g[1]) @ ez]
+    else:
+        th = np.linalg.norm(g)
+        S = np.array([[0, -g[2], g[1]], [g[2], 0, -g[0]], [-g[1], g[0], 0]])
+        A = np.eye(3) if th < 1e-9 else np.eye(3) + (1 - math.cos(th)) / th ** 2 * S + (th - math.sin(th)) / th ** 3 * S @ S
+    X = np.eye(6)
+    X[3:, 3:] = np.linalg.inv(A)
+    return X
+
+
+def jacob0_analytical(ch, q, representation="rpy/xyz", tool=None):
+    """ETS.jacob0_analytical (robot/ETS.py:1622-1626): A @ jacob0(q)."""
+    T, J = fkine(ch, q, tool=tool), jacob(ch, q, tool, 0)
+    return np.array([rotvelxform_inverse(T[i][:3, :3], representation) @ J[i] for i in range(J.shape[0])])
 
 
 def link_frames(ch, q, marks, base=None):

@@ -352,7 +352,7 @@ static int diff_entry(const char *fn, rtbhip_chain_t h, int mode, int axes, cons
     if (!c) { set_error(std::string(fn) + ": unknown chain handle"); return RTBHIP_EINVAL; }
     RTB_TRY(check_batch(fn, q, N, mem));
     if (frame != 0 && frame != 1) { set_error(std::string(fn) + ": frame must be 0 or 1"); return RTBHIP_EINVAL; }
-    if (mode != 0 && (axes & 63) == 0) { set_error(std::string(fn) + ": empty axes mask"); return RTBHIP_EINVAL; }
+    if (mode != 0 && mode != 3 && (axes & 63) == 0) { set_error(std::string(fn) + ": empty axes mask"); return RTBHIP_EINVAL; }
     if (N > 0 && (!out || (mode == 0 && !qd))) { set_error(std::string(fn) + ": NULL qd/output"); return RTBHIP_EINVAL; }
     if (N == 0) return RTBHIP_OK;
     DevChain ops;
@@ -363,7 +363,7 @@ static int diff_entry(const char *fn, rtbhip_chain_t h, int mode, int axes, cons
         return launch_kin_diff(c, ops, mode, axes, q, qd, N, tool, frame, out, (hipStream_t)stream);
     Staging st;
     void *dq, *dqd = nullptr, *dout;
-    const size_t obytes = (size_t)N * 8 * (mode == 0 ? 6 * n : (mode == 1 ? 1 : n));
+    const size_t obytes = (size_t)N * 8 * ((mode == 0 || mode == 3) ? 6 * n : (mode == 1 ? 1 : n));
     RTB_TRY(st.in(q, (size_t)N * qw * 8, &dq));
     if (mode == 0) RTB_TRY(st.in(qd, (size_t)N * qw * 8, &dqd));
     RTB_TRY(st.out(obytes, &dout));
@@ -377,6 +377,13 @@ int rtbhip_jacob_dot(rtbhip_chain_t chain, const double *q, const double *qd, in
                      int32_t frame, double *Jd, int32_t mem, void *stream)
 {
     return diff_entry("jacob_dot", chain, 0, 63, q, qd, N, tool16, frame, Jd, mem, stream);
+}
+
+int rtbhip_jacob0_analytical(rtbhip_chain_t chain, const double *q, int64_t N, const double *tool16, int32_t representation,
+                             double *Ja, int32_t mem, void *stream)
+{
+    if (representation < 0 || representation > 3) { set_error("jacob0_analytical: representation must be 0 rpy/xyz, 1 rpy/zyx, 2 eul, 3 exp"); return RTBHIP_EINVAL; }
+    return diff_entry("jacob0_analytical", chain, 3, representation, q, nullptr, N, tool16, 0, Ja, mem, stream);
 }
 
 int rtbhip_manipulability(rtbhip_chain_t chain, const double *q, int64_t N, const double *tool16, int32_t axes_mask,

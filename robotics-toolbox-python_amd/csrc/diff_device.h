@@ -114,6 +114,78 @@ RTB_HD double manipulability_singular(const double (&jac)[6 * NJ], int axes, int
     return mode == 1 ? sqrt(lo) : sqrt(lo / hi);
 }
 
+// Analytical Jacobian (ETS.jacob0_analytical robot/ETS.py:1562-1626): Ja = blkdiag(I, A^-1) J0 with A the map from the
+// rates of the orientation parameters Gamma to the angular velocity (spatialmath-python 1.1.x `rotvelxform(R, inverse=True,
+// full=True)`, a third-party dependency absent from the reference tree; its conventions, restated):
+//   rep 0 "rpy/xyz"  Gamma = (roll, pitch, yaw), R = Rx(yaw) Ry(pitch) Rz(roll)      (tr2rpy order "xyz")
+//   rep 1 "rpy/zyx"  Gamma = (roll, pitch, yaw), R = Rz(yaw) Ry(pitch) Rx(roll)      (tr2rpy order "zyx")
+//   rep 2 "eul"      Gamma = (phi, theta, psi),  R = Rz(phi) Ry(theta) Rz(psi)       (tr2eul)
+//   rep 3 "exp"      Gamma = theta * axis,       R = exp([Gamma]x)                    (trlog)
+// For a product of axis rotations R = R_a(x1) R_b(x2) R_c(x3):  omega = a x1' + R_a b x2' + R_a R_b c x3', so the
+// columns of A are read off the pose itself (R_a R_b c is a column of R; R_a b needs one sine / cosine pair, a ratio
+// of entries of R) and A^-1 is a 3x3 adjugate.  For the rotation vector A is the left Jacobian of SO(3) and
+// A^-1 = I - [Gamma]x / 2 + (1/theta^2 - (1 + cos theta) / (2 theta sin theta)) [Gamma]x^2.
+RTB_HD void rotvel_inverse(const Pose &P, int rep, double (&Ai)[3][3])
+{
+    if (rep == 3) {
+        const double lx = P.r21 - P.r12, ly = P.r02 - P.r20, lz = P.r10 - P.r01;      // 2 sin(theta) axis
+        const double nrm = sqrt(lx * lx + ly * ly + lz * lz), tr = P.r00 + P.r11 + P.r22;
+        const double th = atan2(nrm, tr - 1.0);
+        const double k = nrm > 1e-12 ? th / nrm : 0.5;
+        const double gx = k * lx, gy = k * ly, gz = k * lz;
+        double c;
+        if (th < 1e-4) c = 1.0 / 12.0 + th * th / 720.0;
+        else c = 1.0 / (th * th) - (1.0 + cos(th)) / (2.0 * th * sin(th));
+        // [g]x^2 = g g^T - |g|^2 I
+        const double g2 = gx * gx + gy * gy + gz * gz;
+        Ai[0][0] = 1.0 + c * (gx * gx - g2); Ai[0][1] = 0.5 * gz + c * gx * gy;   Ai[0][2] = -0.5 * gy + c * gx * gz;
+        Ai[1][0] = -0.5 * gz + c * gx * gy;  Ai[1][1] = 1.0 + c * (gy * gy - g2); Ai[1][2] = 0.5 * gx + c * gy * gz;
+        Ai[2][0] = 0.5 * gy + c * gx * gz;   Ai[2][1] = -0.5 * gx + c * gy * gz;  Ai[2][2] = 1.0 + c * (gz * gz - g2);
+        return;
+    }
+    double A[3][3];   // A[row][column], columns in Gamma order
+    if (rep == 0) {
+        const double cp = sqrt(P.r12 * P.r12 + P.r22 * P.r22);          // cos(pitch) >= 0
+        const double cy = P.r22 / cp, sy = -P.r12 / cp;                  // yaw = -atan2(R12, R22)
+        A[0][0] = P.r02; A[1][0] = P.r12; A[2][0] = P.r22;               // roll: Rx Ry z = third column of R
+        A[0][1] = 0.0;   A[1][1] = cy;    A[2][1] = sy;                  // pitch: Rx(yaw) y
+        A[0][2] = 1.0;   A[1][2] = 0.0;   A[2][2] = 0.0;                 // yaw: x
+    } else if (rep == 1) {
+        const double cp = sqrt(P.r00 * P.r00 + P.r10 * P.r10);
+        const double cy = P.r00 / cp, sy = P.r10 / cp;                   // yaw = atan2(R10, R00)
+        A[0][0] = P.r00; A[1][0] = P.r10; A[2][0] = P.r20;               // roll: Rz Ry x = first column of R
+        A[0][1] = -sy;   A[1][1] = cy;    A[2][1] = 0.0;                 // pitch: Rz(yaw) y
+        A[0][2] = 0.0;   A[1][2] = 0.0;   A[2][2] = 1.0;                 // yaw: z
+    } else {
+        const double st = sqrt(P.r02 * P.r02 + P.r12 * P.r12);          // sin(theta) >= 0
+        const double cf = st > 0.0 ? P.r02 / st : 1.0, sf = st > 0.0 ? P.r12 / st : 0.0;   // phi = atan2(R12, R02), 0 when singular
+        A[0][0] = 0.0;   A[1][0] = 0.0;   A[2][0] = 1.0;                 // phi: z
+        A[0][1] = -sf;   A[1][1] = cf;    A[2][1] = 0.0;                 // theta: Rz(phi) y
+        A[0][2] = P.r02; A[1][2] = P.r12; A[2][2] = P.r22;               // psi: Rz Ry z = third column of R
+    }
+    const double c00 = A[1][1] * A[2][2] - A[1][2] * A[2][1], c01 = A[1][2] * A[2][0] - A[1][0] * A[2][2], c02 = A[1][0] * A[2][1] - A[1][1] * A[2][0];
+    const double det = A[0][0] * c00 + A[0][1] * c01 + A[0][2] * c02;
+    const double id = 1.0 / det;
+    Ai[0][0] = c00 * id; Ai[1][0] = c01 * id; Ai[2][0] = c02 * id;
+    Ai[0][1] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) * id; Ai[1][1] = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) * id; Ai[2][1] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) * id;
+    Ai[0][2] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) * id; Ai[1][2] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) * id; Ai[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) * id;
+}
+
+template <int NJ>
+RTB_HD void jacob_analytical(const Pose &P, const double (&jac)[6 * NJ], int rep, double (&ja)[6 * NJ])
+{
+    double Ai[3][3];
+    rotvel_inverse(P, rep, Ai);
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+        ja[i] = jac[i]; ja[NJ + i] = jac[NJ + i]; ja[2 * NJ + i] = jac[2 * NJ + i];
+        const double wx = jac[3 * NJ + i], wy = jac[4 * NJ + i], wz = jac[5 * NJ + i];
+        ja[3 * NJ + i] = Ai[0][0] * wx + Ai[0][1] * wy + Ai[0][2] * wz;
+        ja[4 * NJ + i] = Ai[1][0] * wx + Ai[1][1] * wy + Ai[1][2] * wz;
+        ja[5 * NJ + i] = Ai[2][0] * wx + Ai[2][1] * wy + Ai[2][2] * wz;
+    }
+}
+
 // jacobm given the LDL^T factorisation (B, dinv) of the masked J J^T
 template <int NJ>
 RTB_HD void jacobm_factored(const double (&jac)[6 * NJ], int axes, const double (&B)[6][6], const double (&dinv)[6], double (&jm)[NJ])

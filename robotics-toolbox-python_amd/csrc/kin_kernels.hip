@@ -228,7 +228,7 @@ static hipError_t launch_hess_nj(dim3 grid, hipStream_t s, const KinParams &kp, 
 // ---------------------------------------------------------------- differential-kinematics consumers (n <= 8)
 // jacob0_dot / manipulability / jacobm straight from the register-resident Jacobian: the (n,6,n) Hessian
 // the reference materialises for each of them (robot/Robot.py:1069, robot/ETS.py:1671) never exists.
-enum { kDiffJdot = 0, kDiffManip = 1, kDiffJacobm = 2 };
+enum { kDiffJdot = 0, kDiffManip = 1, kDiffJacobm = 2, kDiffAnalytical = 3 };
 template <int NJ, int MODE>
 __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints ? 2 : 1)) void k_kin_diff(KinParams kp, DevChain dc, int axes, const double *__restrict__ q,
                                                        const double *__restrict__ qd, double *__restrict__ out)
@@ -242,11 +242,16 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints ? 2 : 1)) void k_kin_di
     Pose P;
     double jac[6 * NJ];
     reg_compute<NJ, true>(kp, cv, q, cfg, P, jac);
-    if (MODE == kDiffJdot) {
-        double v[NJ], jd[6 * NJ];
+    if (MODE == kDiffJdot || MODE == kDiffAnalytical) {
+        double jd[6 * NJ];
+        if (MODE == kDiffJdot) {
+            double v[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) v[j] = cfg < kp.N ? qd[cfg * kp.qw + jm_jq(cv.jmeta[j])] : 0.0;
-        jacob_dot<NJ>(jac, v, jd);
+            for (int j = 0; j < NJ; ++j) v[j] = cfg < kp.N ? qd[cfg * kp.qw + jm_jq(cv.jmeta[j])] : 0.0;
+            jacob_dot<NJ>(jac, v, jd);
+        } else {
+            jacob_analytical<NJ>(P, jac, axes, jd);          // axes carries the representation code
+        }
         constexpr int W = 6 * NJ;
 #pragma unroll
         for (int r = 0; r < kWave / kJRound; ++r) {
@@ -279,6 +284,7 @@ static hipError_t launch_diff_nj(int mode, dim3 grid, size_t lds, hipStream_t s,
 {
     if (mode == kDiffJdot) hipLaunchKernelGGL((k_kin_diff<NJ, kDiffJdot>), grid, dim3(kWave), lds, s, kp, dc, axes, q, qd, out);
     else if (mode == kDiffManip) hipLaunchKernelGGL((k_kin_diff<NJ, kDiffManip>), grid, dim3(kWave), lds, s, kp, dc, axes, q, qd, out);
+    else if (mode == kDiffAnalytical) hipLaunchKernelGGL((k_kin_diff<NJ, kDiffAnalytical>), grid, dim3(kWave), lds, s, kp, dc, axes, q, qd, out);
     else hipLaunchKernelGGL((k_kin_diff<NJ, kDiffJacobm>), grid, dim3(kWave), lds, s, kp, dc, axes, q, qd, out);
     return hipGetLastError();
 }

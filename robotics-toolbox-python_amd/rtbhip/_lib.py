@@ -61,6 +61,7 @@ SIGNATURES = {
     "rtbhip_dyn_destroy": (C.c_int, [_u64]),
     "rtbhip_rne": (C.c_int, [_u64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp]),
     "rtbhip_jacob_dot": (C.c_int, [_u64, _vp, _vp, _i64, _vp, _i32, _vp, _i32, _vp]),
+    "rtbhip_jacob0_analytical": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _vp, _i32, _vp]),
     "rtbhip_manipulability": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _i32, _vp, _i32, _vp]),
     "rtbhip_jacobm": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _vp, _i32, _vp]),
     "rtbhip_link_frames": (C.c_int, [_u64, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _vp]),

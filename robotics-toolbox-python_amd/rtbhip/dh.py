@@ -187,6 +187,7 @@ class DHRobot:
     def manipulability(self, q, method="yoshikawa", axes="all", **kw):
         return self.ets().manipulability(q, method=method, axes=axes)
     def jacobm(self, q, axes="all", **kw): return self.ets().jacobm(q, axes=axes)
+    def jacob0_analytical(self, q, representation="rpy/xyz", **kw): return self.ets().jacob0_analytical(q, representation=representation)
     def partial_fkine0(self, q, n=3, **kw): return self.ets().partial_fkine0(q, n=n)
     def ik_LM(self, Tep, **kw): return self.ets().ik_LM(Tep, **kw)
     def ik_GN(self, Tep, **kw): return self.ets().ik_GN(Tep, **kw)

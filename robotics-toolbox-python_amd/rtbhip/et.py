@@ -432,6 +432,21 @@ class ETS:
                                   self._ptr(Jm, tm), MEM_DEVICE if tm else MEM_HOST, self._stream(tm)))
         return Jm[0].reshape(self.n, 1) if single else Jm
 
+    _REPRESENTATIONS = {"rpy/xyz": 0, "rpy/zyx": 1, "eul": 2, "exp": 3}
+
+    def jacob0_analytical(self, q, representation="rpy/xyz", tool=None):
+        """Analytical Jacobian in the base frame: (6,n), or (N,6,n) for a trajectory (reference ETS.jacob0_analytical
+        robot/ETS.py:1562-1626: rotvelxform(R, inverse=True, full=True) @ jacob0)."""
+        if representation not in self._REPRESENTATIONS:
+            raise ValueError("representation must be one of %s" % ", ".join(self._REPRESENTATIONS))
+        q2, single, tm = self._shape_q(q)
+        N = q2.shape[0]
+        Ja = self._out((N, 6, self.n), q2, tm)
+        check(lib().rtbhip_jacob0_analytical(self._handle(), self._ptr(q2, tm), N, host_ptr(small(tool, 16)),
+                                             self._REPRESENTATIONS[representation], self._ptr(Ja, tm),
+                                             MEM_DEVICE if tm else MEM_HOST, self._stream(tm)))
+        return Ja[0] if single else Ja
+
     def partial_fkine0(self, q, n=3, tool=None):
         """n-th partial derivative of the forward kinematics (robot/ETS.py:1821-2013): n = 1 is jacob0,
         n = 2 hessian0, n >= 3 the (n_joints, ..., 6, n_joints) tensor; a 2-D q adds a leading batch axis."""

@@ -50,6 +50,7 @@ class ERobot:
     def manipulability(self, q, method="yoshikawa", axes="all", **kw):
         return self._ets.manipulability(q, method=method, axes=axes, tool=self.tool)
     def jacobm(self, q, axes="all", **kw): return self._ets.jacobm(q, axes=axes, tool=self.tool)
+    def jacob0_analytical(self, q, representation="rpy/xyz", **kw): return self._ets.jacob0_analytical(q, representation=representation, tool=self.tool)
     def partial_fkine0(self, q, n=3, **kw): return self._ets.partial_fkine0(q, n=n, tool=self.tool)
 
     def ik_LM(self, Tep, **kw): return self._ets.ik_LM(Tep, **kw)

@@ -540,6 +540,10 @@ static void diff_run(const KinParams &kp, const DevChain &cv, int mode, int axes
             for (int j = 0; j < NJ; ++j) v[j] = qd[s * kp.qw + jm_jq(cv.jmeta[j])];
             jacob_dot<NJ>(jac, v, jd);
             for (int k = 0; k < 6 * NJ; ++k) out[s * 6 * NJ + k] = jd[k];
+        } else if (mode == 3) {
+            double ja[6 * NJ];
+            jacob_analytical<NJ>(P, jac, axes, ja);
+            for (int k = 0; k < 6 * NJ; ++k) out[s * 6 * NJ + k] = ja[k];
         } else if (mode == 1) {
             const int method = (axes >> 8) & 3;
             out[s] = method == 0 ? manipulability_yoshikawa<NJ>(jac, axes & 63) : manipulability_singular<NJ>(jac, axes & 63, method);

@@ -158,13 +158,14 @@ def hess_reg(ets, q, tool=None, frame=0, rounds=0):
 
 
 def diff(ets, mode, q, qd=None, axes=63, tool=None, frame=0):
-    """mode 0 jacob_dot (N,6,n), 1 manipulability (N,), 2 jacobm (N,n): diff_device.h on the CPU."""
+    """mode 0 jacob_dot (N,6,n), 1 manipulability (N,), 2 jacobm (N,n), 3 jacob0_analytical (N,6,n; axes = representation
+    code): diff_device.h on the CPU."""
     h = chain_handle(ets)
     n = ets.n
     q = np.ascontiguousarray(np.asarray(q, dtype=np.float64).reshape(-1, ets.q_width))
     qd = None if qd is None else np.ascontiguousarray(np.asarray(qd, dtype=np.float64).reshape(-1, ets.q_width))
     N = q.shape[0]
-    out = np.full({0: (N, 6, n), 1: (N,), 2: (N, n)}[mode], np.nan)
+    out = np.full({0: (N, 6, n), 1: (N,), 2: (N, n), 3: (N, 6, n)}[mode], np.nan)
     t = None if tool is None else np.ascontiguousarray(tool, dtype=np.float64)
     assert lib().emu_diff(h, mode, axes, _p(q), _p(qd), N, _p(t), frame, _p(out)) == 0
     return out

@@ -87,3 +87,62 @@ def test_gpu_jacobians_equal_numerical_jacobian(name, make, q):
         d = np.zeros(ets.n); d[i] = h
         Jd += (ets.jacob0(np.asarray(q) + d) - ets.jacob0(np.asarray(q) - d)) / (2 * h) * qd[i]
     nt.assert_array_almost_equal(ets.jacob0_dot(q, qd), Jd, decimal=4)
+
+
+# ---------------------------------------------------------------- analytical Jacobians (test_jacob.py:40-70)
+REPS = ["rpy/xyz", "rpy/zyx", "eul", "exp"]
+REP_CODE = {r: k for k, r in enumerate(REPS)}
+
+
+def _numjac_x(ch, q, rep, tool=None):
+    """numjac(lambda q: tr2x(robot.fkine(q).A, representation=rep), q) of the reference's tests."""
+    from oracle import oracle
+    h = 1e-6
+    cols = []
+    for i in range(len(q)):
+        d = np.zeros(len(q)); d[i] = h
+        xp = oracle.tr2x(oracle.fkine(ch, q + d, tool=tool)[0], rep)
+        xm = oracle.tr2x(oracle.fkine(ch, q - d, tool=tool)[0], rep)
+        dx = xp - xm
+        dx[3:] = (dx[3:] + np.pi) % (2 * np.pi) - np.pi if rep != "exp" else dx[3:]
+        cols.append(dx / (2 * h))
+    return np.array(cols).T
+
+
+@pytest.mark.parametrize("rep", REPS)
+def test_oracle_and_emu_analytical_jacobian_equals_numerical(rep):
+    import emu_harness as emu
+    from oracle import oracle
+    from helpers import chain_from_ets
+    ets = puma_ets()
+    ch = chain_from_ets(ets)
+    q = np.array([0.1, 0.2, 0.3, 0.1, 0.2, 0.3])
+    Ja = _numjac_x(ch, q, rep)
+    nt.assert_array_almost_equal(oracle.jacob0_analytical(ch, q, rep)[0], Ja)                  # 6 decimals, as the reference
+    nt.assert_array_almost_equal(emu.diff(ets, 3, q, axes=REP_CODE[rep])[0], Ja)
+    rng = np.random.default_rng(3)
+    qs = rng.uniform(-1.2, 1.2, (20, 6))
+    nt.assert_allclose(emu.diff(ets, 3, qs, axes=REP_CODE[rep]), oracle.jacob0_analytical(ch, qs, rep), atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_gpu_analytical_jacobians():
+    import torch
+    from oracle import oracle
+    from helpers import chain_from_ets
+    ets = puma_ets()
+    ch = chain_from_ets(ets)
+    q = np.array([0.1, 0.2, 0.3, 0.1, 0.2, 0.3])
+    rng = np.random.default_rng(3)
+    qs = rng.uniform(-1.2, 1.2, (300, 6))
+    for rep in REPS:
+        nt.assert_array_almost_equal(ets.jacob0_analytical(q, representation=rep), _numjac_x(ch, q, rep))
+        Ja = ets.jacob0_analytical(qs, representation=rep)
+        nt.assert_allclose(Ja, oracle.jacob0_analytical(ch, qs, rep), atol=1e-9)
+        nt.assert_array_equal(ets.jacob0_analytical(torch.from_numpy(qs).cuda(), representation=rep).cpu().numpy(), Ja)
+    panda = rtbhip.models.Panda()
+    qp = rng.uniform(-1, 1, (10, 7))
+    chp = chain_from_ets(panda.ets())
+    nt.assert_allclose(panda.jacob0_analytical(qp, "eul"), oracle.jacob0_analytical(chp, qp, "eul", tool=panda.tool), atol=1e-9)
+    with pytest.raises(ValueError):
+        ets.jacob0_analytical(q, representation="quaternion")
