@@ -63,15 +63,14 @@ RTB_HD void reg_core(const CV &cv, TL tail /* tail[k], k = 0..11 */, int frame, 
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const double pvj = jm_prismatic(jmv[j]) ? 1.0 : 0.0, rvj = 1.0 - pvj;
         if (j == 0) pose_from_seg(P, cv, 0); else pose_mul_seg(P, cv, j);
         if (WANT_J) {
             jac[j] = P.tx; jac[NJ + j] = P.ty; jac[2 * NJ + j] = P.tz;
             jac[3 * NJ + j] = P.r02; jac[4 * NJ + j] = P.r12; jac[5 * NJ + j] = P.r22;
         }
-        // revolute: rotate by (c, s), no slide; prismatic: identity rotation, slide d
-        pose_rotz(P, fma(rvj, c[j], pvj), rvj * s[j]);
-        pose_tz(P, pvj * d[j]);
+        // revolute: rotate by (c, s); prismatic: slide d -- a wave-uniform branch on the joint descriptor (s_cbranch)
+        if (jm_prismatic(jmv[j])) pose_tz(P, d[j]);
+        else pose_rotz(P, c[j], s[j]);
         sched_fence();
     }
     pose_mul_general(P, [&](int k) { return tail[k]; });
@@ -81,13 +80,17 @@ RTB_HD void reg_core(const CV &cv, TL tail /* tail[k], k = 0..11 */, int frame, 
         // (methods.cpp:142-195); frame 1 rotates both halves by Re^T.
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const double pvj = jm_prismatic(jmv[j]) ? 1.0 : 0.0, rvj = 1.0 - pvj, sgj = jm_flip(jmv[j]) ? -1.0 : 1.0;
-            const double zx = sgj * jac[3 * NJ + j], zy = sgj * jac[4 * NJ + j], zz = sgj * jac[5 * NJ + j];
-            const double dx = P.tx - jac[j], dy = P.ty - jac[NJ + j], dz = P.tz - jac[2 * NJ + j];
-            double vx = fma(rvj, zy * dz - zz * dy, pvj * zx);
-            double vy = fma(rvj, zz * dx - zx * dz, pvj * zy);
-            double vz = fma(rvj, zx * dy - zy * dx, pvj * zz);
-            double wx = rvj * zx, wy = rvj * zy, wz = rvj * zz;
+            double zx = jac[3 * NJ + j], zy = jac[4 * NJ + j], zz = jac[5 * NJ + j];
+            if (jm_flip(jmv[j])) { zx = -zx; zy = -zy; zz = -zz; }          // wave-uniform
+            double vx, vy, vz, wx, wy, wz;
+            if (jm_prismatic(jmv[j])) {                                      // wave-uniform
+                vx = zx; vy = zy; vz = zz;
+                wx = 0.0; wy = 0.0; wz = 0.0;
+            } else {
+                const double dx = P.tx - jac[j], dy = P.ty - jac[NJ + j], dz = P.tz - jac[2 * NJ + j];
+                vx = zy * dz - zz * dy; vy = zz * dx - zx * dz; vz = zx * dy - zy * dx;
+                wx = zx; wy = zy; wz = zz;
+            }
             if (frame == 1) {
                 double a = vx, b = vy, e = vz;
                 vx = P.r00 * a + P.r10 * b + P.r20 * e;
