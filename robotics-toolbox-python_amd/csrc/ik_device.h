@@ -94,8 +94,8 @@ RTB_HD void ik_angle_axis(const Pose &P, TD Td, double (&e)[6])
 
 // ---------------------------------------------------------------- one LM step
 // dq = (J^T W J + wn I)^-1 J^T W e, J in registers (slot r*NJ + j), W = diag(we).
-template <int NJ>
-RTB_HD void ik_lm_step(const double (&jac)[6 * NJ], const double (&e)[6], const double *we, double wn,
+template <int NJ, class W>
+RTB_HD void ik_lm_step(const double (&jac)[6 * NJ], const double (&e)[6], W we /* we[k], k < 6 */, double wn,
                        double (&dq)[NJ])
 {
     double A[NJ][NJ];   // lower triangle used; after factorisation holds L (unit diagonal implied)
@@ -246,8 +246,10 @@ struct IkLane {
 };
 constexpr int kIkIdle = 0, kIkRun = 1, kIkParkedOk = 2, kIkParkedLast = 3;
 
-RTB_HD int ik_s_first(const IkDev &p) { return p.flavour == 0 ? 1 : 0; }
-RTB_HD int ik_s_last(const IkDev &p)
+template <class PD>
+RTB_HD int ik_s_first(const PD &p) { return p.flavour == 0 ? 1 : 0; }
+template <class PD>
+RTB_HD int ik_s_last(const PD &p)
 {
     const int sl = p.slimit < 1 ? 1 : p.slimit;
     return p.flavour == 0 ? sl : sl - 1;
@@ -265,8 +267,8 @@ RTB_HD void ik_load_target(TDPut tdput, const double *Tep16)
 }
 
 // Start search s of target tgt in this lane (the target pose must already be loaded).
-template <int NJ, class QL, class QA>
-RTB_HD void ik_search_begin(IkLane<NJ> &st, QA qa, const IkDev &p, QL qlim, int64_t tgt, int s, const double *q0row)
+template <int NJ, class PD, class QL, class QA>
+RTB_HD void ik_search_begin(IkLane<NJ> &st, QA qa, const PD &p, QL qlim, int64_t tgt, int s, const double *q0row)
 {
     st.s = s;
     st.E = 0.0;
@@ -332,7 +334,7 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, Q
         ik_pinv_step<NJ>(jac, e, rows, p.method == 4 ? p.lambda : 0.0, dq);
     } else {
         const double wn = (p.method == 1) ? p.lambda : (p.method == 2) ? E + p.lambda : p.lambda * E;   // ik.cpp:169,183,205
-        ik_lm_step<NJ>(jac, e, p.we, wn, dq);
+        ik_lm_step<NJ>(jac, e, &p.we[0], wn, dq);
     }
     if constexpr (NULLSP) {
 #pragma unroll
@@ -395,8 +397,8 @@ RTB_HD void ik_iter_any(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD t
 }
 
 // What the reference reports for a target whose winning / last search is held by this lane.
-template <int NJ, class QL, class QA>
-RTB_HD void ik_emit(const IkLane<NJ> &st, QA qa, const IkDev &p, QL qlim, int64_t tgt, bool has_q0, bool success, int it_total,
+template <int NJ, class PD, class QL, class QA>
+RTB_HD void ik_emit(const IkLane<NJ> &st, QA qa, const PD &p, QL qlim, int64_t tgt, bool has_q0, bool success, int it_total,
                     double E_last, double *__restrict__ q_out, int32_t *__restrict__ success_out,
                     int32_t *__restrict__ iters, int32_t *__restrict__ searches, double *__restrict__ residual)
 {
@@ -519,8 +521,8 @@ RTB_HD void ik_account(int i, SH &sh, int s_last)
 }
 
 // phase C: parked lanes of a resolved slot emit / release; searches beyond a known success are cancelled
-template <int NJ, class SH, class QL>
-RTB_HD void ik_finalize(IkLane<NJ> &st, SH &sh, int lane, const IkDev &p, QL qlim, double *__restrict__ q_out,
+template <int NJ, class SH, class PD, class QL>
+RTB_HD void ik_finalize(IkLane<NJ> &st, SH &sh, int lane, const PD &p, QL qlim, double *__restrict__ q_out,
                         int32_t *__restrict__ success, int32_t *__restrict__ iters, int32_t *__restrict__ searches,
                         double *__restrict__ residual)
 {
@@ -540,8 +542,8 @@ RTB_HD void ik_finalize(IkLane<NJ> &st, SH &sh, int lane, const IkDev &p, QL qli
 }
 
 // phase D1 helper: initialise slot `slot` for target tgt and start its first search in this lane
-template <int NJ, class SH, class QL>
-RTB_HD void ik_start_target(IkLane<NJ> &st, SH &sh, int lane, const IkDev &p, QL qlim, int slot, int64_t tgt,
+template <int NJ, class SH, class PD, class QL>
+RTB_HD void ik_start_target(IkLane<NJ> &st, SH &sh, int lane, const PD &p, QL qlim, int slot, int64_t tgt,
                             const double *__restrict__ Tep, const double *__restrict__ q0)
 {
     const int s0 = ik_s_first(p);
@@ -568,8 +570,8 @@ RTB_HD bool ik_pick(const SH &sh, int r, int nb, int s_last, int &slot, int &s)
     return s <= s_last && s - sh.b[slot] < kIkRing && s < sh.best[slot];
 }
 // step 2 (after every lane has picked): claim the index and start the search
-template <int NJ, class SH, class QL>
-RTB_HD void ik_start_spec(IkLane<NJ> &st, SH &sh, int lane, const IkDev &p, QL qlim, int slot, int s,
+template <int NJ, class SH, class PD, class QL>
+RTB_HD void ik_start_spec(IkLane<NJ> &st, SH &sh, int lane, const PD &p, QL qlim, int slot, int s,
                           const double *__restrict__ Tep, const double *__restrict__ q0)
 {
     ik_lds_max(&sh.next[slot], s + 1);

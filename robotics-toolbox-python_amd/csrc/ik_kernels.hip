@@ -21,6 +21,20 @@ struct ConstChainIk {
     const RTB_CONST int32_t *jmeta;
 };
 
+// The kernel's argument block, member for member.  Inside the persistent loop everything is read through a pointer to
+// the kernarg segment that is laundered once per iteration: as plain by-value arguments the eleven pointers and the
+// solver parameters stayed in SGPRs across the whole loop (the scheduling pass needs them, the LM iteration does not)
+// and the register allocator paid for that with v_readlane / v_writelane traffic inside the iteration.
+struct IkKernArgs {
+    IkDev p;
+    DevChain dc;
+    const double *qlim, *Tep, *q0;
+    unsigned long long *counter;
+    double *q_out;
+    int32_t *success, *iters, *searches;
+    double *residual;
+};
+
 // Wave-level driver of the scheduler phases of ik_device.h (the same sequence tests/emu replays on the CPU).
 #ifndef RTB_IK_WAVES
 #define RTB_IK_WAVES 2
@@ -33,10 +47,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                                                 double *__restrict__ residual)
 {
     __shared__ IkWaveSharedFor<NJ> sh;
-    ConstChainIk cv;
-    cv.seg = (const RTB_CONST DevSeg *)dc.seg;
-    cv.jmeta = (const RTB_CONST int32_t *)dc.jmeta;
-    const RTB_CONST double *qlim = (const RTB_CONST double *)qlim_g;
+    const RTB_CONST IkKernArgs *ka = (const RTB_CONST IkKernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = threadIdx.x;
     const int s_last = ik_s_last(p);
     IkLane<NJ> st;
@@ -55,11 +66,18 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
     const long long patience = (long long)(p.ilimit + 2) * (s_last + 3) + 64;
     long long quiet = 0;
     for (;;) {
+        asm volatile("" : "+s"(ka));
         // the scheduling pass runs when some search has ended -- at most every (pass_mask + 1)-th iteration: a
         // finished lane then idles for up to pass_mask iterations (of ~31 per search) and the pass, several
         // hundred mostly scalar / LDS instructions, is amortised over more useful iterations
-        if (first || ((tick++ & p.pass_mask) == 0 && __any(st.fin != 0))) {
+        if (first || ((tick++ & ka->p.pass_mask) == 0 && __any(st.fin != 0))) {
             first = false;
+            const RTB_CONST IkDev &p = ka->p;      // shadows the by-value arguments for the whole pass
+            const RTB_CONST double *qlim = (const RTB_CONST double *)ka->qlim;
+            const double *Tep = ka->Tep, *q0 = ka->q0;
+            unsigned long long *counter = ka->counter;
+            double *q_out = ka->q_out, *residual = ka->residual;
+            int32_t *success = ka->success, *iters = ka->iters, *searches = ka->searches;
             ik_report<NJ>(st, sh, s_last);                                             // phase A
             __syncthreads();
             if ((busy >> lane) & 1ull) ik_account(lane, sh, s_last);                    // phase B
@@ -136,6 +154,8 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
             // target can take.  Leave loudly recognisable outputs instead of whatever the buffers held:
             // success 0, searches / iterations -1, residual and q NaN for the wave's unresolved and unstarted targets.
             const double nan = __longlong_as_double(0x7ff8000000000000ll);
+            double *q_out = ka->q_out, *residual = ka->residual;
+            int32_t *success = ka->success, *iters = ka->iters, *searches = ka->searches;
             if ((busy >> lane) & 1ull) {
                 const int64_t t = sh.tgt[lane];
                 for (int j = 0; j < NJ; ++j) q_out[t * NJ + j] = nan;
@@ -152,11 +172,13 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
             // this persistent loop into SGPRs that do not exist (184 spilled SGPRs, 670 v_readlane in the
             // first build).  Laundering the table pointers once per iteration keeps the loads inside it,
             // where the scalar cache serves them and the VALU never sees them.
-            ConstChainIk cvi = cv;
-            const RTB_CONST double *ql = qlim;
+            ConstChainIk cvi;
+            cvi.seg = (const RTB_CONST DevSeg *)ka->dc.seg;
+            cvi.jmeta = (const RTB_CONST int32_t *)ka->dc.jmeta;
+            const RTB_CONST double *ql = (const RTB_CONST double *)ka->qlim;
             asm volatile("" : "+s"(cvi.seg), "+s"(cvi.jmeta), "+s"(ql));
             const int myslot = st.slot;
-            ik_iter<NJ, STEP>(st, p, cvi, ql, [&](int k) { return sh.Td[k][myslot]; }, ik_lds_q(sh, lane));
+            ik_iter<NJ, STEP>(st, ka->p, cvi, ql, [&](int k) { return sh.Td[k][myslot]; }, ik_lds_q(sh, lane));
         }
     }
 }
