@@ -12,7 +12,7 @@ enum { kDynInertia = 0, kDynCoriolis = 1, kDynAccel = 2 };
 
 // mine : this lane's inputs  [q (n) | qd (n) | torque (n)]   (what the mode needs)
 // mA   : n x n work/output tile (row-major): M for inertia / accel (accel leaves qdd in mA[0..n-1]), C for coriolis
-// mB   : n x n scratch (coriolis only): Csq
+// mB   : unused (was the Csq tile of the first coriolis version)
 // With sin/cos fixed across the passes, most of the forward recursion becomes loop-invariant in the
 // compiler's eyes and LICM hoists it out of the pass loop -- into ~100 VGPRs the kernel does not have
 // (first build: 428 B/lane of scratch, inertia 0.54 -> 0.90 ms).  Making the trig values opaque once per
@@ -38,9 +38,14 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, double *mB, V
 #pragma unroll 1
         for (int i = 0; i < NJ; ++i) {
             dyn_opaque<NJ>(st, ct);
+            // inertia: the full row as computed (the reference returns the unsymmetrised matrix); accel: only the lower
+            // triangle the LDL^T solve reads, packed -- 28 instead of 49 doubles of LDS per lane for n = 7
             rne_core<NJ, MDH, true, ALLREV, true>(links, NJ, st, ct, zero, zero, zero, qin, [&](int) { return 0.0; },
                                     [&](int j) { return j == i ? 1.0 : 0.0; },
-                                    [&](int j, double v) { mA[i * NJ + j] = v; });
+                                    [&](int j, double v) {
+                                        if (MODE == kDynAccel) { if (j <= i) mA[i * (i + 1) / 2 + j] = v; }
+                                        else mA[i * NJ + j] = v;
+                                    });
         }
     }
     if (MODE == kDynAccel) {
@@ -52,41 +57,46 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, double *mB, V
 #pragma unroll
         for (int r = 0; r < NJ; ++r)
 #pragma unroll
-            for (int c = 0; c <= r; ++c) M[r][c] = mA[r * NJ + c];
+            for (int c = 0; c <= r; ++c) M[r][c] = mA[r * (r + 1) / 2 + c];
         ldl_solve<NJ>(M, b, x);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) mA[j] = x[j];        // the tile's first n slots become the output row
     }
     if (MODE == kDynCoriolis) {
-        // centripetal: QD = e_i -> Csq[:, i] (Dynamics.py:828-833), friction removed (:820)
+        // Dynamics.py:828-856 regrouped so that ONE n x n tile per lane suffices (the reference keeps Csq and C; two tiles
+        // are 58 KB of LDS per wave for n = 7, i.e. two waves per CU on a kernel that is fp64-issue bound):
+        //   C[:,k] = sum_{j != k} (T_jk - Csq_k - Csq_j) qd_j / 2 + Csq_k qd_k
+        //          = 1/2 sum_{j != k} T_jk qd_j + Csq_k (2 qd_k - S / 2) - U / 2,   S = sum_j qd_j,  U = sum_j Csq_j qd_j
+        // with T_jk the pass at QD = e_j + e_k and Csq_j the pass at QD = e_j (friction removed, :820).  Same terms,
+        // different association: agreement with the reference order is ~1e-15 relative.
+        double S = 0.0, U[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { S += mine[NJ + j]; U[j] = 0.0; }
 #pragma unroll 1
         for (int i = 0; i < NJ; ++i) {
+            const double qdi = mine[NJ + i], wi = 2.0 * qdi - 0.5 * S;
             dyn_opaque<NJ>(st, ct);
             rne_core<NJ, MDH, false, ALLREV, true>(links, NJ, st, ct, zero, zero, zero, qin, [&](int j) { return j == i ? 1.0 : 0.0; },
-                                     [&](int) { return 0.0; }, [&](int r, double v) { mB[r * NJ + i] = v; });
+                                     [&](int) { return 0.0; }, [&](int r, double v) { mA[r * NJ + i] = v * wi; U[r] += v * qdi; });
         }
 #pragma unroll
-        for (int k = 0; k < NJ * NJ; ++k) mA[k] = 0.0;
-        // Coriolis: QD = e_i + e_j, i < j (Dynamics.py:839-854), same accumulation order
+        for (int r = 0; r < NJ; ++r)
+#pragma unroll
+            for (int c = 0; c < NJ; ++c) mA[r * NJ + c] -= 0.5 * U[r];
 #pragma unroll 1
         for (int i = 0; i < NJ; ++i) {
 #pragma unroll 1
             for (int j = i + 1; j < NJ; ++j) {
-                const double qdi = mine[NJ + i], qdj = mine[NJ + j];
+                const double hi = 0.5 * mine[NJ + i], hj = 0.5 * mine[NJ + j];
                 dyn_opaque<NJ>(st, ct);
                 rne_core<NJ, MDH, false, ALLREV, true>(links, NJ, st, ct, zero, zero, zero, qin,
                                          [&](int k) { return (k == i || k == j) ? 1.0 : 0.0; }, [&](int) { return 0.0; },
                                          [&](int r, double tau) {
-                                             const double t = tau - mB[r * NJ + j] - mB[r * NJ + i];
-                                             mA[r * NJ + j] = mA[r * NJ + j] + t * qdi / 2;
-                                             mA[r * NJ + i] = mA[r * NJ + i] + t * qdj / 2;
+                                             mA[r * NJ + j] += tau * hi;
+                                             mA[r * NJ + i] += tau * hj;
                                          });
             }
         }
-#pragma unroll
-        for (int r = 0; r < NJ; ++r)                              // + Csq diag(qd) (Dynamics.py:856)
-#pragma unroll
-            for (int c = 0; c < NJ; ++c) mA[r * NJ + c] = mA[r * NJ + c] + mB[r * NJ + c] * mine[NJ + c];
     }
 }
 

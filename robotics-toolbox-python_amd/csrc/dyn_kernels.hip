@@ -51,9 +51,9 @@ template <int NJ, int MODE>
 struct DynLayout {
     static constexpr int K = MODE == kDynInertia ? 1 : (MODE == kDynCoriolis ? 2 : 3);
     static constexpr int in_stride = (K * NJ) | 1;
-    static constexpr int W = NJ * NJ;
+    static constexpr int W = MODE == kDynAccel ? (NJ * (NJ + 1) / 2 > NJ ? NJ * (NJ + 1) / 2 : NJ) : NJ * NJ;   // accel: packed lower triangle of M
     static constexpr int w_stride = W | 1;
-    static constexpr int tiles = MODE == kDynCoriolis ? 2 : 1;     // coriolis: C and Csq
+    static constexpr int tiles = 1;                                // coriolis too: Csq is folded into C as it is produced (dyn_device.h)
     static constexpr int doubles = kDW * (in_stride + tiles * w_stride);
 };
 
@@ -72,13 +72,13 @@ __global__ __launch_bounds__(kDW, 2) void k_dyn(DynParams dp, const DevLink *lin
     const int count = ncfg * NJ;
     double *in = lds;
     double *A = lds + kDW * L::in_stride;            // n x n tile: M (inertia, accel) or C (coriolis)
-    double *B = A + kDW * L::w_stride;               // coriolis only: Csq
+    double *B = nullptr;                             // (second tile of the first coriolis version; no mode uses it now)
     if (MODE == kDynInertia) { const double *const src[1] = {q}; dyn_load<NJ, 1>(in, L::in_stride, src, cfg0, count, lane); }
     if (MODE == kDynCoriolis) { const double *const src[2] = {q, qd}; dyn_load<NJ, 2>(in, L::in_stride, src, cfg0, count, lane); }
     if (MODE == kDynAccel) { const double *const src[3] = {q, qd, tq}; dyn_load<NJ, 3>(in, L::in_stride, src, cfg0, count, lane); }
     __syncthreads();
     if (lane < ncfg)
-        dyn_lane<NJ, MDH, MODE, ALLREV>(links, in + lane * L::in_stride, A + lane * L::w_stride, B + lane * L::w_stride,
+        dyn_lane<NJ, MDH, MODE, ALLREV>(links, in + lane * L::in_stride, A + lane * L::w_stride, B,
                                 v3(dp.grav[0], dp.grav[1], dp.grav[2]));
     __syncthreads();
     if (MODE == kDynAccel) flush_run(A, L::w_stride, NJ, ncfg, out + cfg0 * NJ, lane);
