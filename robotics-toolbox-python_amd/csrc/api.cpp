@@ -268,6 +268,10 @@ void rtbhip_shutdown(void)
         kv.second->dev_groups.clear();
     }
     ik_release_device_state();
+    // the stream-ordered temporaries of partial_fkine0 stay cached in the device's default pool: hand them back
+    int dev = 0;
+    hipMemPool_t pool;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) (void)hipMemPoolTrimTo(pool, 0);
 }
 
 int rtbhip_device_count(int *count)
