@@ -182,7 +182,7 @@ int rtbhip_rne(rtbhip_dyn_t dyn, const double *q, const double *qd, const double
  *   rtbhip_coriolis  Dynamics.coriolis (:765-861): C (N,n,n), friction removed as nofriction(True, True) does
  *   rtbhip_accel     Dynamics.accel    (:424-509): qdd (N,n) = M^-1 (torque - rne(q, qd, 0)); grav3 in the
  *                    convention of rtbhip_rne (what frne.frne is handed)
- * Chains of up to 8 joints; longer ones return RTBHIP_ELIMIT. */
+ * Chains of up to 10 joints; longer ones return RTBHIP_ELIMIT. */
 int rtbhip_inertia(rtbhip_dyn_t dyn, const double *q, int64_t N, double *M, int32_t mem, void *stream);
 int rtbhip_coriolis(rtbhip_dyn_t dyn, const double *q, const double *qd, int64_t N, double *C, int32_t mem,
                     void *stream);

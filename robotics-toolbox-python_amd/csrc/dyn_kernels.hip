@@ -58,7 +58,7 @@ struct DynLayout {
 };
 
 template <int NJ, bool MDH, int MODE, bool ALLREV>
-__global__ __launch_bounds__(kDW, 2) void k_dyn(DynParams dp, const DevLink *links_g, const double *__restrict__ q,
+__global__ __launch_bounds__(kDW, (NJ <= 8 ? 2 : 1)) void k_dyn(DynParams dp, const DevLink *links_g, const double *__restrict__ q,
                                                 const double *__restrict__ qd, const double *__restrict__ tq,
                                                 double *__restrict__ out)
 {
@@ -120,7 +120,7 @@ int launch_dyn(const Dyn *d, const DevLink *links, int mode, const double *q, co
                int64_t N, const double *grav3, double *out, hipStream_t s)
 {
     if (N == 0) return RTBHIP_OK;
-    if (d->n > 8) { set_error("inertia/coriolis/accel: this build handles chains of up to 8 joints on the device"); return RTBHIP_ELIMIT; }
+    if (d->n > 10) { set_error("inertia/coriolis/accel: this build handles chains of up to 10 joints on the device"); return RTBHIP_ELIMIT; }
     const int64_t tiles = (N + kDW - 1) / kDW;
     if (tiles > 0x7fffffff) { set_error("inertia/coriolis/accel: batch too large for one launch"); return RTBHIP_ELIMIT; }
     DynParams dp;
@@ -140,7 +140,9 @@ int launch_dyn(const Dyn *d, const DevLink *links, int mode, const double *q, co
     case 5: e = launch_nj<5>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
     case 6: e = launch_nj<6>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
     case 7: e = launch_nj<7>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
-    default: e = launch_nj<8>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    case 8: e = launch_nj<8>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    case 9: e = launch_nj<9>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;   // 9, 10: one wave per SIMD
+    default: e = launch_nj<10>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
     }
     note_launch((int)grid.x, kDW, (int)lds);
     if (e != hipSuccess) return hip_fail(e, "k_dyn launch");

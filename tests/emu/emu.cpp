@@ -512,7 +512,7 @@ extern "C" int emu_dyn(rtbhip_dyn_t h, int mode, const double *q, const double *
                        const double *grav3, double *out)
 {
     Dyn *d = dyn_from_handle(h);
-    if (!d || d->n > 8) return -1;
+    if (!d || d->n > 10) return -1;
     V3 g = grav3 ? v3(grav3[0], grav3[1], grav3[2]) : v3(0, 0, 0);
     switch (d->n) {
     case 1: dyn_nj<1>(d, mode, q, qd, tq, N, g, out); break;
@@ -522,7 +522,9 @@ extern "C" int emu_dyn(rtbhip_dyn_t h, int mode, const double *q, const double *
     case 5: dyn_nj<5>(d, mode, q, qd, tq, N, g, out); break;
     case 6: dyn_nj<6>(d, mode, q, qd, tq, N, g, out); break;
     case 7: dyn_nj<7>(d, mode, q, qd, tq, N, g, out); break;
-    default: dyn_nj<8>(d, mode, q, qd, tq, N, g, out); break;
+    case 8: dyn_nj<8>(d, mode, q, qd, tq, N, g, out); break;
+    case 9: dyn_nj<9>(d, mode, q, qd, tq, N, g, out); break;
+    default: dyn_nj<10>(d, mode, q, qd, tq, N, g, out); break;
     }
     return 0;
 }

@@ -114,10 +114,51 @@ def test_gpu_vs_oracle_and_identities(robot, N):
     nt.assert_array_equal(rob.accel(qt, qdt, tqt).cpu().numpy(), a)
 
 
+def _ten_joint_arm():
+    """A 10-joint DH arm with a prismatic joint, centre-of-mass offsets, full and diagonal inertia tensors, motor inertia
+    and friction: the 9- and 10-joint instantiations (one wave per SIMD)."""
+    rng = np.random.default_rng(10)
+    links = []
+    for k in range(10):
+        I = rng.uniform(0.01, 0.1, 3)
+        Ifull = np.diag(I) if k % 2 else np.diag(I) + 0.002 * (np.ones((3, 3)) - np.eye(3))
+        kw = dict(a=0.05 + 0.02 * k, alpha=[0.0, np.pi / 2, -np.pi / 2][k % 3], m=1.0 + 0.1 * k,
+                  r=[0.0, 0.0, 0.0] if k % 3 == 0 else list(rng.uniform(-0.05, 0.05, 3)), I=Ifull, Jm=1e-4 * k, G=1.0 + k, B=1e-3, Tc=[0.01, -0.02])
+        links.append(rtbhip.PrismaticDH(theta=0.3, qlim=[0.0, 0.4], **kw) if k == 4 else rtbhip.RevoluteDH(d=0.1, **kw))
+    return rtbhip.DHRobot(links, name="ten")
+
+
+@pytest.mark.parametrize("n", [9, 10])
+def test_emu_nine_and_ten_joints(n):
+    import emu_harness as emu
+    rob = _ten_joint_arm()
+    rob = rtbhip.DHRobot(rob.links[:n])
+    L = rob.L24()
+    rng = np.random.default_rng(n)
+    q, qd, tq = rng.uniform(-1, 1, (3, n)), rng.normal(size=(3, n)), rng.normal(size=(3, n))
+    q[:, 4] = rng.uniform(0, 0.4, 3)
+    gc = -np.array([0.0, 0.0, -9.81])
+    nt.assert_allclose(emu.dyn(L, 0, 0, q), oracle.inertia_dh(L, 0, q), rtol=1e-11, atol=1e-12)
+    nt.assert_allclose(emu.dyn(L, 0, 1, q, qd), oracle.coriolis_dh(L, 0, q, qd), rtol=1e-10, atol=1e-11)
+    ref = oracle.accel_dh(L, 0, q, qd, tq, gc)
+    nt.assert_allclose(emu.dyn(L, 0, 2, q, qd, tq, grav_c=gc), ref, rtol=1e-9, atol=1e-9 * np.abs(ref).max())
+
+
 @pytest.mark.gpu
 def test_gpu_dynamics_limits_and_errors():
-    L = np.zeros((9, 24)); L[:, 6] = 1.0
-    rob9 = rtbhip.DHRobot([rtbhip.RevoluteDH(a=0.1, m=1.0) for _ in range(9)])
+    rob11 = rtbhip.DHRobot([rtbhip.RevoluteDH(a=0.1, m=1.0) for _ in range(11)])
     with pytest.raises(rtbhip.RtbHipError):
-        rob9.inertia(np.zeros(9))                       # > 8 joints: loud ELIMIT, no silent fallback
-    assert rob9.gravload(np.zeros((3, 9))).shape == (3, 9)      # rne itself handles any n
+        rob11.inertia(np.zeros(11))                     # > 10 joints: loud ELIMIT, no silent fallback
+    assert rob11.gravload(np.zeros((3, 11))).shape == (3, 11)   # rne itself handles any n
+    for n in (9, 10):
+        rob = rtbhip.DHRobot(_ten_joint_arm().links[:n])
+        L = rob.L24()
+        rng = np.random.default_rng(n)
+        N = 130
+        q, qd, tq = rng.uniform(-1, 1, (N, n)), rng.normal(size=(N, n)), rng.normal(size=(N, n))
+        q[:, 4] = rng.uniform(0, 0.4, N)
+        k = 20
+        nt.assert_allclose(rob.inertia(q)[:k], oracle.inertia_dh(L, 0, q[:k]), rtol=1e-11, atol=1e-12)
+        nt.assert_allclose(rob.coriolis(q, qd)[:k], oracle.coriolis_dh(L, 0, q[:k], qd[:k]), rtol=1e-10, atol=1e-11)
+        a = rob.accel(q, qd, tq)
+        nt.assert_allclose(rob.rne(q, qd, a), tq, rtol=1e-8, atol=1e-8 * np.abs(tq).max())
