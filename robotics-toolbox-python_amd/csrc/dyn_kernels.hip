@@ -47,14 +47,17 @@ __device__ __forceinline__ void dyn_load(double *lds, int stride, const double *
 }
 
 // LDS per wave (doubles): inputs 64 x (K*NJ | 1), then the n x n work / output tiles
-template <int NJ, int MODE>
+template <int NJ, int MODE, bool ALLREV = false>
 struct DynLayout {
+    // inertia of an all-revolute chain reads q only for the sines / cosines, before the first pass writes its row: the
+    // input row then lives in the output tile itself (28.7 -> 25.1 KB per wave for n = 7: 5 -> 6 waves per CU)
+    static constexpr bool alias_in = MODE == kDynInertia && ALLREV;
     static constexpr int K = MODE == kDynInertia ? 1 : (MODE == kDynCoriolis ? 2 : 3);
     static constexpr int in_stride = (K * NJ) | 1;
     static constexpr int W = MODE == kDynAccel ? (NJ * (NJ + 1) / 2 > NJ ? NJ * (NJ + 1) / 2 : NJ) : NJ * NJ;   // accel: packed lower triangle of M
     static constexpr int w_stride = W | 1;
     static constexpr int tiles = 1;                                // coriolis too: Csq is folded into C as it is produced (dyn_device.h)
-    static constexpr int doubles = kDW * (in_stride + tiles * w_stride);
+    static constexpr int doubles = kDW * ((alias_in ? 0 : in_stride) + tiles * w_stride);
 };
 
 template <int NJ, bool MDH, int MODE, bool ALLREV>
@@ -63,22 +66,23 @@ __global__ __launch_bounds__(kDW, (NJ <= 8 ? 2 : 1)) void k_dyn(DynParams dp, co
                                                 double *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    typedef DynLayout<NJ, MODE> L;
+    typedef DynLayout<NJ, MODE, ALLREV> L;
     ConstLinksD links = (ConstLinksD)links_g;
     const int lane = threadIdx.x;
     const int64_t cfg0 = (int64_t)blockIdx.x * kDW;
     const int64_t left = dp.N - cfg0;
     const int ncfg = left < kDW ? (int)left : kDW;
     const int count = ncfg * NJ;
-    double *in = lds;
-    double *A = lds + kDW * L::in_stride;            // n x n tile: M (inertia, accel) or C (coriolis)
+    double *A = lds + (L::alias_in ? 0 : kDW * L::in_stride);   // n x n tile: M (inertia, accel) or C (coriolis)
+    double *in = L::alias_in ? A : lds;
+    constexpr int in_stride = L::alias_in ? L::w_stride : L::in_stride;
     double *B = nullptr;                             // (second tile of the first coriolis version; no mode uses it now)
-    if (MODE == kDynInertia) { const double *const src[1] = {q}; dyn_load<NJ, 1>(in, L::in_stride, src, cfg0, count, lane); }
-    if (MODE == kDynCoriolis) { const double *const src[2] = {q, qd}; dyn_load<NJ, 2>(in, L::in_stride, src, cfg0, count, lane); }
-    if (MODE == kDynAccel) { const double *const src[3] = {q, qd, tq}; dyn_load<NJ, 3>(in, L::in_stride, src, cfg0, count, lane); }
+    if (MODE == kDynInertia) { const double *const src[1] = {q}; dyn_load<NJ, 1>(in, in_stride, src, cfg0, count, lane); }
+    if (MODE == kDynCoriolis) { const double *const src[2] = {q, qd}; dyn_load<NJ, 2>(in, in_stride, src, cfg0, count, lane); }
+    if (MODE == kDynAccel) { const double *const src[3] = {q, qd, tq}; dyn_load<NJ, 3>(in, in_stride, src, cfg0, count, lane); }
     __syncthreads();
     if (lane < ncfg)
-        dyn_lane<NJ, MDH, MODE, ALLREV>(links, in + lane * L::in_stride, A + lane * L::w_stride, B,
+        dyn_lane<NJ, MDH, MODE, ALLREV>(links, in + lane * in_stride, A + lane * L::w_stride, B,
                                 v3(dp.grav[0], dp.grav[1], dp.grav[2]));
     __syncthreads();
     if (MODE == kDynAccel) flush_run(A, L::w_stride, NJ, ncfg, out + cfg0 * NJ, lane);
@@ -99,7 +103,7 @@ template <int NJ, int MODE>
 static hipError_t launch_mode(bool mdh, bool allrev, dim3 grid, hipStream_t s, const DynParams &dp, const DevLink *links, const double *q,
                               const double *qd, const double *tq, double *out, size_t *lds_out)
 {
-    const size_t lds = (size_t)DynLayout<NJ, MODE>::doubles * sizeof(double);
+    const size_t lds = (size_t)(allrev ? DynLayout<NJ, MODE, true>::doubles : DynLayout<NJ, MODE, false>::doubles) * sizeof(double);
     *lds_out = lds;
     if (mdh) return allrev ? launch_one<NJ, MODE, true, true>(grid, s, lds, dp, links, q, qd, tq, out)
                            : launch_one<NJ, MODE, true, false>(grid, s, lds, dp, links, q, qd, tq, out);
