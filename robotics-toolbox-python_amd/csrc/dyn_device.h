@@ -27,10 +27,13 @@ RTB_HD void dyn_opaque(double (&st)[NJ], double (&ct)[NJ])
 }
 
 template <int NJ, bool MDH, int MODE, bool ALLREV, class LinksP>
-RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, double *mB, V3 grav)
+RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, double *mB, V3 grav, const double *qrow = nullptr)
 {
     const V3 zero = v3(0, 0, 0);
-    auto qin = [&](int j) { return mine[j]; };
+    // qrow: where this lane's q lives when it is not mine[0..n) -- all-revolute chains read q only for the trig below,
+    // so the kernel may keep it in the output tile (overwritten by the first pass) instead of a row of its own
+    const double *qsrc = qrow ? qrow : mine;
+    auto qin = [&](int j) { return qsrc[j]; };
     double st[NJ], ct[NJ];
     rne_trig<NJ, ALLREV>(links, qin, st, ct);      // every pass below is at the same q: sin/cos once
     if (MODE == kDynInertia || MODE == kDynAccel) {

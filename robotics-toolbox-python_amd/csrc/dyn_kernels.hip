@@ -52,8 +52,10 @@ struct DynLayout {
     // inertia of an all-revolute chain reads q only for the sines / cosines, before the first pass writes its row: the
     // input row then lives in the output tile itself (28.7 -> 25.1 KB per wave for n = 7: 5 -> 6 waves per CU)
     static constexpr bool alias_in = MODE == kDynInertia && ALLREV;
+    // coriolis of an all-revolute chain: the same for q; only the qd row keeps a place of its own (4 -> 5 waves per CU)
+    static constexpr bool alias_q = (MODE == kDynCoriolis || MODE == kDynAccel) && ALLREV;
     static constexpr int K = MODE == kDynInertia ? 1 : (MODE == kDynCoriolis ? 2 : 3);
-    static constexpr int in_stride = (K * NJ) | 1;
+    static constexpr int in_stride = (((MODE == kDynCoriolis || MODE == kDynAccel) && ALLREV ? K - 1 : K) * NJ) | 1;
     static constexpr int W = MODE == kDynAccel ? (NJ * (NJ + 1) / 2 > NJ ? NJ * (NJ + 1) / 2 : NJ) : NJ * NJ;   // accel: packed lower triangle of M
     static constexpr int w_stride = W | 1;
     static constexpr int tiles = 1;                                // coriolis too: Csq is folded into C as it is produced (dyn_device.h)
@@ -78,12 +80,33 @@ __global__ __launch_bounds__(kDW, (NJ <= 8 ? 2 : 1)) void k_dyn(DynParams dp, co
     constexpr int in_stride = L::alias_in ? L::w_stride : L::in_stride;
     double *B = nullptr;                             // (second tile of the first coriolis version; no mode uses it now)
     if (MODE == kDynInertia) { const double *const src[1] = {q}; dyn_load<NJ, 1>(in, in_stride, src, cfg0, count, lane); }
-    if (MODE == kDynCoriolis) { const double *const src[2] = {q, qd}; dyn_load<NJ, 2>(in, in_stride, src, cfg0, count, lane); }
-    if (MODE == kDynAccel) { const double *const src[3] = {q, qd, tq}; dyn_load<NJ, 3>(in, in_stride, src, cfg0, count, lane); }
+    if (MODE == kDynCoriolis) {
+        if (L::alias_q) {
+            const double *const s0[1] = {q}, *const s1[1] = {qd};
+            dyn_load<NJ, 1>(A, L::w_stride, s0, cfg0, count, lane);
+            dyn_load<NJ, 1>(in, in_stride, s1, cfg0, count, lane);
+        } else {
+            const double *const src[2] = {q, qd};
+            dyn_load<NJ, 2>(in, in_stride, src, cfg0, count, lane);
+        }
+    }
+    if (MODE == kDynAccel) {
+        if (L::alias_q) {
+            const double *const s0[1] = {q}, *const s1[2] = {qd, tq};
+            dyn_load<NJ, 1>(A, L::w_stride, s0, cfg0, count, lane);
+            dyn_load<NJ, 2>(in, in_stride, s1, cfg0, count, lane);
+        } else {
+            const double *const src[3] = {q, qd, tq};
+            dyn_load<NJ, 3>(in, in_stride, src, cfg0, count, lane);
+        }
+    }
     __syncthreads();
-    if (lane < ncfg)
-        dyn_lane<NJ, MDH, MODE, ALLREV>(links, in + lane * in_stride, A + lane * L::w_stride, B,
-                                v3(dp.grav[0], dp.grav[1], dp.grav[2]));
+    if (lane < ncfg) {
+        // alias_q: the row holds qd only, at the offset dyn_lane expects it (mine[n + j])
+        const double *mine = in + lane * in_stride - (L::alias_q ? NJ : 0);
+        dyn_lane<NJ, MDH, MODE, ALLREV>(links, mine, A + lane * L::w_stride, B, v3(dp.grav[0], dp.grav[1], dp.grav[2]),
+                                        L::alias_q ? A + lane * L::w_stride : nullptr);
+    }
     __syncthreads();
     if (MODE == kDynAccel) flush_run(A, L::w_stride, NJ, ncfg, out + cfg0 * NJ, lane);
     else flush_run(A, L::w_stride, L::W, ncfg, out + cfg0 * L::W, lane);
