@@ -20,6 +20,10 @@ struct PartialSrc {
 constexpr int kPartialStage = 2560;                                  // most doubles of LDS spent on staged Jacobians + Hessians
 
 constexpr int kPartialBlock = 256;
+#ifndef RTB_PARTIAL_U
+#define RTB_PARTIAL_U 2
+#endif
+constexpr int kPartialU = RTB_PARTIAL_U;      // columns per lane: the kernel is bound by the bytes its resident workgroups keep in flight
 
 // (6, n) blocks per workgroup: as many as 256 lanes hold, rounded down so that a workgroup's run of 48 n bytes per
 // block is a whole number of 128-byte lines (neighbouring workgroups -- possibly on different XCDs, i.e. different
@@ -40,11 +44,12 @@ __global__ __launch_bounds__(kPartialBlock) void k_partial(PartialPlan plan, Par
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int n = plan.n, tid = threadIdx.x;
     const int per = partial_blocks_per_group(n);
-    double *tile = lds, *stage = lds + ((per * 6 * n + 1) & ~1);
+    double *tile = lds, *stage = lds + ((per * kPartialU * 6 * n + 1) & ~1);
     const uint32_t bpc = (uint32_t)plan.cols / (uint32_t)n;           // blocks per configuration
-    const int64_t b0 = (int64_t)blockIdx.x * per;
+    const int perU = per * kPartialU;
+    const int64_t b0 = (int64_t)blockIdx.x * perU;
     const int64_t left = plan.N * bpc - b0;
-    const int nb = left < per ? (int)left : per;
+    const int nb = left < perU ? (int)left : perU;
     const int64_t cfg0 = b0 / bpc;                                   // wave-uniform: scalar unit
     const uint32_t lb0 = (uint32_t)(b0 - cfg0 * bpc);
     // orders 1 and 2 of the K configurations this workgroup touches -> LDS: [K Jacobians][K Hessians]
@@ -72,8 +77,11 @@ __global__ __launch_bounds__(kPartialBlock) void k_partial(PartialPlan plan, Par
     typedef const __attribute__((address_space(3))) double *LdsPtr;     // explicit LDS loads (ds_read), never flat
     const LdsPtr sj = (LdsPtr)stage, sh = (LdsPtr)stage + K * szj;
     uint32_t j, lbr;
-    const int bl = (int)divmod24((uint32_t)tid, (uint32_t)n, 1.0f / (float)n, &j);
-    if (bl < nb) {
+    const int bl0 = (int)divmod24((uint32_t)tid, (uint32_t)n, 1.0f / (float)n, &j);
+#pragma unroll
+    for (int u = 0; u < kPartialU; ++u) {
+        const int bl = bl0 + u * per;
+        if (bl0 >= per || bl >= nb) continue;
         const uint32_t dc = divmod24(lb0 + bl, bpc, 1.0f / (float)bpc, &lbr);     // this workgroup may straddle configurations
         double *t = tile + mad24((uint32_t)bl, 6u * n, j);
         const int64_t cfg = cfg0 + dc;
@@ -110,15 +118,15 @@ int launch_partial(int n, int order, const double *const *lower, int64_t N, doub
     plan.N = N;
     PartialSrc src;
     for (int a = 0; a < kPartialMaxOrder; ++a) src.p[a] = a < order - 1 ? lower[a] : nullptr;
-    const int per = partial_blocks_per_group(n);
-    const int64_t blocks = (N * (int64_t)(plan.cols / n) + per - 1) / per;
+    const int per = partial_blocks_per_group(n), perU = per * kPartialU;
+    const int64_t blocks = (N * (int64_t)(plan.cols / n) + perU - 1) / perU;
     if (plan.size[order - 1] >= (1 << 24) || plan.cols >= (1 << 24)) { set_error("partial_fkine0: tensor too large (n^order must stay below 2^24)"); return RTBHIP_ELIMIT; }
     if (blocks > 0x7fffffff) { set_error("partial_fkine0: batch too large for one launch"); return RTBHIP_ELIMIT; }
     const dim3 grid((unsigned)blocks), block(kPartialBlock);
     const int64_t bpc = plan.cols / n;
-    int stage_cfgs = (int)((per + bpc - 2) / bpc) + 1;                 // most configurations one workgroup can touch
+    int stage_cfgs = (int)((perU + bpc - 2) / bpc) + 1;                // most configurations one workgroup can touch
     if ((int64_t)stage_cfgs * (6 * n + 6 * n * n) > kPartialStage) stage_cfgs = 0;
-    const size_t lds = (size_t)(((per * 6 * n + 1) & ~1) + stage_cfgs * (6 * n + 6 * n * n)) * sizeof(double);
+    const size_t lds = (size_t)(((per * kPartialU * 6 * n + 1) & ~1) + stage_cfgs * (6 * n + 6 * n * n)) * sizeof(double);
     switch (order) {
     case 3: hipLaunchKernelGGL(k_partial<3>, grid, block, lds, s, plan, src, stage_cfgs, out); break;
     case 4: hipLaunchKernelGGL(k_partial<4>, grid, block, lds, s, plan, src, stage_cfgs, out); break;
