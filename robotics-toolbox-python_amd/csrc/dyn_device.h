@@ -12,7 +12,6 @@ enum { kDynInertia = 0, kDynCoriolis = 1, kDynAccel = 2 };
 
 // mine : this lane's inputs  [q (n) | qd (n) | torque (n)]   (what the mode needs)
 // mA   : n x n work/output tile (row-major): M for inertia / accel (accel leaves qdd in mA[0..n-1]), C for coriolis
-// mB   : unused (was the Csq tile of the first coriolis version)
 // With sin/cos fixed across the passes, most of the forward recursion becomes loop-invariant in the
 // compiler's eyes and LICM hoists it out of the pass loop -- into ~100 VGPRs the kernel does not have
 // (first build: 428 B/lane of scratch, inertia 0.54 -> 0.90 ms).  Making the trig values opaque once per
@@ -27,7 +26,7 @@ RTB_HD void dyn_opaque(double (&st)[NJ], double (&ct)[NJ])
 }
 
 template <int NJ, bool MDH, int MODE, bool ALLREV, class LinksP>
-RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, double *mB, V3 grav, const double *qrow = nullptr)
+RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, const double *qrow = nullptr)
 {
     const V3 zero = v3(0, 0, 0);
     // qrow: where this lane's q lives when it is not mine[0..n) -- all-revolute chains read q only for the trig below,

@@ -78,7 +78,6 @@ __global__ __launch_bounds__(kDW, (NJ <= 8 ? 2 : 1)) void k_dyn(DynParams dp, co
     double *A = lds + (L::alias_in ? 0 : kDW * L::in_stride);   // n x n tile: M (inertia, accel) or C (coriolis)
     double *in = L::alias_in ? A : lds;
     constexpr int in_stride = L::alias_in ? L::w_stride : L::in_stride;
-    double *B = nullptr;                             // (second tile of the first coriolis version; no mode uses it now)
     if (MODE == kDynInertia) { const double *const src[1] = {q}; dyn_load<NJ, 1>(in, in_stride, src, cfg0, count, lane); }
     if (MODE == kDynCoriolis) {
         if (L::alias_q) {
@@ -104,7 +103,7 @@ __global__ __launch_bounds__(kDW, (NJ <= 8 ? 2 : 1)) void k_dyn(DynParams dp, co
     if (lane < ncfg) {
         // alias_q: the row holds qd only, at the offset dyn_lane expects it (mine[n + j])
         const double *mine = in + lane * in_stride - (L::alias_q ? NJ : 0);
-        dyn_lane<NJ, MDH, MODE, ALLREV>(links, mine, A + lane * L::w_stride, B, v3(dp.grav[0], dp.grav[1], dp.grav[2]),
+        dyn_lane<NJ, MDH, MODE, ALLREV>(links, mine, A + lane * L::w_stride, v3(dp.grav[0], dp.grav[1], dp.grav[2]),
                                         L::alias_q ? A + lane * L::w_stride : nullptr);
     }
     __syncthreads();

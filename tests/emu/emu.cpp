@@ -480,7 +480,7 @@ template <int NJ, bool MDH, int MODE>
 static void dyn_run(const Dyn *d, const double *q, const double *qd, const double *tq, int64_t N, V3 g, double *out)
 {
     const DevLink *links = d->links.data();
-    std::vector<double> in(3 * NJ), A(NJ * NJ), B(NJ * NJ);
+    std::vector<double> in(3 * NJ), A(NJ * NJ);
     for (int64_t s = 0; s < N; ++s) {
         for (int j = 0; j < NJ; ++j) {
             in[j] = q[s * NJ + j];
@@ -489,8 +489,8 @@ static void dyn_run(const Dyn *d, const double *q, const double *qd, const doubl
         }
         bool allrev = true;
         for (const DevLink &l : d->links) allrev = allrev && l.sigma == 0;
-        if (allrev) dyn_lane<NJ, MDH, MODE, true>(links, in.data(), A.data(), B.data(), g);
-        else dyn_lane<NJ, MDH, MODE, false>(links, in.data(), A.data(), B.data(), g);
+        if (allrev) dyn_lane<NJ, MDH, MODE, true>(links, in.data(), A.data(), g);
+        else dyn_lane<NJ, MDH, MODE, false>(links, in.data(), A.data(), g);
         const int W = MODE == kDynAccel ? NJ : NJ * NJ;
         for (int k = 0; k < W; ++k) out[s * W + k] = A[k];
     }
