@@ -128,7 +128,7 @@ def _ten_joint_arm():
     return rtbhip.DHRobot(links, name="ten")
 
 
-@pytest.mark.parametrize("n", [9, 10])
+@pytest.mark.parametrize("n", [5, 9, 10])
 def test_emu_nine_and_ten_joints(n):
     import emu_harness as emu
     rob = _ten_joint_arm()
@@ -150,7 +150,7 @@ def test_gpu_dynamics_limits_and_errors():
     with pytest.raises(rtbhip.RtbHipError):
         rob11.inertia(np.zeros(11))                     # > 10 joints: loud ELIMIT, no silent fallback
     assert rob11.gravload(np.zeros((3, 11))).shape == (3, 11)   # rne itself handles any n
-    for n in (9, 10):
+    for n in (5, 8, 9, 10):                               # 5, 8: the non-all-revolute instantiations of the 2-wave kernels
         rob = rtbhip.DHRobot(_ten_joint_arm().links[:n])
         L = rob.L24()
         rng = np.random.default_rng(n)
