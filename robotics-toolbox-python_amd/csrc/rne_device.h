@@ -104,6 +104,30 @@ RTB_HD void rne_trig(LinksP links, InQ qin, double (&st)[NJ], double (&ct)[NJ])
     sched_fence();
 }
 
+// The fields one link's forward / backward step reads, copied out of the (scalar-memory) link table in ONE batch at the
+// top of the step.  Left to itself the compiler loads each field in the basic block that uses it and waits for it there:
+// with the zero-skipping branches that is 6-7 load -> s_waitcnt -> use sequences per link (SQ counters: 77 scalar loads
+// per wave, a third of the wave's lifetime in s_waitcnt).  A batch is one wait.
+struct LinkFwd { double sa, ca, a, d, theta, offset, m; int sigma; };
+struct LinkBwd { double sa, ca, a, d, offset, gjm, gb, ag, Tc0, Tc1; int sigma; };
+template <bool ALLREV, class LinkT>
+RTB_HD LinkFwd link_fwd(const LinkT &l)
+{
+    LinkFwd o;
+    o.sa = l.sa; o.ca = l.ca; o.a = l.a; o.d = l.d; o.m = l.m;
+    o.theta = ALLREV ? 0.0 : l.theta; o.offset = ALLREV ? 0.0 : l.offset; o.sigma = ALLREV ? 0 : l.sigma;
+    return o;
+}
+template <bool ALLREV, bool FRICTION, class LinkT>
+RTB_HD LinkBwd link_bwd(const LinkT &l)
+{
+    LinkBwd o;
+    o.sa = l.sa; o.ca = l.ca; o.a = l.a; o.d = l.d; o.offset = ALLREV ? 0.0 : l.offset; o.sigma = ALLREV ? 0 : l.sigma;
+    o.gjm = l.gjm;
+    o.gb = FRICTION ? l.gb : 0.0; o.ag = FRICTION ? l.ag : 0.0; o.Tc0 = FRICTION ? l.Tc0 : 0.0; o.Tc1 = FRICTION ? l.Tc1 : 0.0;
+    return o;
+}
+
 template <int NJ, bool MDH, bool FRICTION, bool ALLREV, bool HAVE_TRIG, class LinksP, class InQ, class InQd, class InQdd, class Out>
 RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_MAX_JOINTS], double (&ct)[NJ > 0 ? NJ : RTBHIP_MAX_JOINTS],
                      V3 grav, V3 ftip, V3 ntip, InQ qin, InQd qdin, InQdd qddin, Out tau)
@@ -120,7 +144,8 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
     double qddx = 0.0, qddy = 0.0;  // ne.c:311 lets gravity leak into qddv.x/.y for later links
 #pragma unroll
     for (int j = 0; j < n; ++j) {
-        const auto &l = links[j];
+        const auto &lt = links[j];                    // r and I: loaded inside the branches that need them
+        const LinkFwd l = link_fwd<ALLREV>(lt);
         const bool pris = ALLREV ? false : (l.sigma != 0);
         const double qdj = qdin(j), qddj = qddin(j);
         if (NJ == 0) {
@@ -182,15 +207,15 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
         // 12; the values are those of the general formulas (up to the sign of a zero)
         V3 ac = a;
         if (!(flg[j] & kLinkRZero)) {
-            const V3 rc = v3(l.rx, l.ry, l.rz);
+            const V3 rc = v3(lt.rx, lt.ry, lt.rz);
             ac = (cross(wd, rc) + cross(w, cross(w, rc))) + a;         // ne.c:228-232
         }
         F[j] = l.m * ac;
         if (flg[j] & kLinkIDiag) {
-            const V3 iw = v3(l.I[0] * w.x, l.I[4] * w.y, l.I[8] * w.z);
-            Nn[j] = v3(l.I[0] * wd.x, l.I[4] * wd.y, l.I[8] * wd.z) + cross(w, iw);
+            const V3 iw = v3(lt.I[0] * w.x, lt.I[4] * w.y, lt.I[8] * w.z);
+            Nn[j] = v3(lt.I[0] * wd.x, lt.I[4] * wd.y, lt.I[8] * wd.z) + cross(w, iw);
         } else {
-            Nn[j] = inertia_times(l, wd) + cross(w, inertia_times(l, w));
+            Nn[j] = inertia_times(lt, wd) + cross(w, inertia_times(lt, w));
         }
         if (NJ > 0) sched_fence();   // keep link j+1's scalar table loads from being hoisted over link j
     }
@@ -202,11 +227,12 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
 #pragma unroll
     for (int jj = 0; jj < n; ++jj) {
         const int j = n - 1 - jj;
-        const auto &l = links[j];
+        const auto &lt = links[j];
+        const LinkBwd l = link_bwd<ALLREV, FRICTION>(lt);
         const bool last = (jj == 0);
         const bool pris = ALLREV ? false : (l.sigma != 0);
         const bool rzero = (flg[j] & kLinkRZero) != 0;
-        const V3 rc = rzero ? v3(0, 0, 0) : v3(l.rx, l.ry, l.rz);
+        const V3 rc = rzero ? v3(0, 0, 0) : v3(lt.rx, lt.ry, lt.rz);
         const double d = pris ? qin(j) + l.offset : l.d;
         const Rot R = {st[j], ct[j], l.sa, l.ca};
         const V3 ps = link_offset<MDH>(l, d);
