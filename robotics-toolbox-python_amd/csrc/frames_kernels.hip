@@ -22,7 +22,7 @@ __global__ __launch_bounds__(kFW) void k_frames(FrameTable ft, DevChain dc, int 
 {
     __shared__ __attribute__((aligned(16))) double tile[kFW * kFStride];
     const int lane = threadIdx.x;
-    const int64_t cfg0 = (int64_t)blockIdx.x * kFW;
+    const int64_t cfg0 = (int64_t)xcd_tile() * kFW;
     const int64_t left = N - cfg0;
     const int ncfg = left < kFW ? (int)left : kFW;
     ConstChainF cv;

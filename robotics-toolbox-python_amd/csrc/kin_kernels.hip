@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints ? RTB_REG_WAVES : 2)) v
                                                   double *__restrict__ T, double *__restrict__ J)
 {
     extern __shared__ __attribute__((aligned(16))) double buf[];
-    reg_tile<NJ, WANT_T, WANT_J>(kp, const_view(dc), q, T, J, buf, threadIdx.x, blockIdx.x);
+    reg_tile<NJ, WANT_T, WANT_J>(kp, const_view(dc), q, T, J, buf, threadIdx.x, xcd_tile());
 }
 
 static int g_hess_mode = 0;   // A/B knob (rtbhip_tune "hess_mode")
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && R >= 8 ? 2 : 1)) voi
     extern __shared__ __attribute__((aligned(16))) double buf[];
     const ConstChain cv = const_view(dc);
     const int lane = threadIdx.x;
-    const int64_t cfg0 = (int64_t)blockIdx.x * kWave;
+    const int64_t cfg0 = (int64_t)blockIdx.x * kWave;     // (the XCD-contiguous mapping of k_kin_reg costs this kernel 3 %)
     const int64_t left = kp.N - cfg0;
     const int ncfg = left < kWave ? (int)left : kWave;
     constexpr int HW = NJ * 6 * NJ, S = HW | 1, G = kWave / R;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints ? 2 : 1)) void k_kin_di
     extern __shared__ __attribute__((aligned(16))) double buf[];
     const ConstChain cv = const_view(dc);
     const int lane = threadIdx.x;
-    const int64_t cfg0 = (int64_t)blockIdx.x * kWave, cfg = cfg0 + lane;
+    const int64_t cfg0 = (int64_t)xcd_tile() * kWave, cfg = cfg0 + lane;
     const int64_t left = kp.N - cfg0;
     const int ncfg = left < kWave ? (int)left : kWave;
     Pose P;
