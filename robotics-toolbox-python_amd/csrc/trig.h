@@ -67,7 +67,8 @@ RTB_HD void sched_fence()
 // time.  Measured on the headline kernel, 8 interleaved A/B pairs on one box: 0.082-0.090 -> 0.080-0.083 ms, and much
 // steadier; jacob0-only 0.068 -> 0.065, jacob0_dot and fkine_all 1-2 %.  Kernels whose runs are already tens of KB per
 // wave or that are compute-bound lose 1-3 % with it (Hessian tile, k_partial, the fleet, RNE, the dynamics terms) and keep
-// the identity mapping.  A bijection of [0, grid) for any grid size.
+// the identity mapping.  Leap-frogging chunks of 16 or 128 consecutive tiles per XCD instead of eighths: slower and as
+// unsteady as the identity (0.082-0.090 ms against a steady 0.080).  A bijection of [0, grid) for any grid size.
 #ifndef RTB_XCD_REMAP
 #define RTB_XCD_REMAP 1
 #endif
