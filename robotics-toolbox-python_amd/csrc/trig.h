@@ -72,12 +72,16 @@ RTB_HD void sched_fence()
 #ifndef RTB_XCD_REMAP
 #define RTB_XCD_REMAP 1
 #endif
+RTB_HD unsigned xcd_tile_of(unsigned g, unsigned b)     // grid size, workgroup id -> tile
+{
+    const unsigned x = b & 7u, q8 = g >> 3, r8 = g & 7u;
+    return x * q8 + (x < r8 ? x : r8) + (b >> 3);
+}
 #if defined(__HIPCC__)
 __device__ __forceinline__ unsigned xcd_tile()
 {
 #if RTB_XCD_REMAP
-    const unsigned g = gridDim.x, b = blockIdx.x, x = b & 7u, q8 = g >> 3, r8 = g & 7u;
-    return x * q8 + (x < r8 ? x : r8) + (b >> 3);
+    return xcd_tile_of(gridDim.x, blockIdx.x);
 #else
     return blockIdx.x;
 #endif

@@ -220,6 +220,8 @@ extern "C" int emu_kin_hess(rtbhip_chain_t h, const double *q, int64_t N, const 
     return 0;
 }
 
+extern "C" unsigned emu_xcd_tile(unsigned g, unsigned b) { return xcd_tile_of(g, b); }
+
 extern "C" void emu_sincos(const double *x, int64_t n, double *s, double *c, int reduced_only)
 {
     for (int64_t i = 0; i < n; ++i) {

@@ -409,3 +409,18 @@ def test_ik_nine_to_twelve_joint_chains(robot, n):
     for x, y in zip((q, ok, it, se, E), b):
         nt.assert_array_equal(x, y)
     assert ok.mean() >= 0.5
+
+
+def test_xcd_tile_mapping_is_a_bijection_with_contiguous_eighths():
+    """xcd_tile_of (trig.h): workgroup ids b = 8 i + x (XCD x) -> tiles; a permutation of [0, g) for every grid size, each
+    XCD's tiles one contiguous block, visited in increasing order."""
+    import ctypes as C
+    lib = emu.lib()
+    lib.emu_xcd_tile.restype = C.c_uint
+    lib.emu_xcd_tile.argtypes = [C.c_uint, C.c_uint]
+    for g in list(range(1, 70)) + [255, 256, 257, 15625, 15632]:
+        tiles = np.array([lib.emu_xcd_tile(g, b) for b in range(g)])
+        assert sorted(tiles.tolist()) == list(range(g)), g
+        for x in range(min(8, g)):
+            mine = tiles[x::8]
+            assert np.all(np.diff(mine) == 1), (g, x)
