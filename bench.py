@@ -8,17 +8,23 @@ q ~ U(-pi,pi)^7, N = 1e6 per GPU, fp64.  W untimed warm-up steps, then exactly K
 barrier+synchronize pairs; the MAX over ranks is the step time; rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline     achieved = 520 B/config x N / (average duration of the dominant kernel, from HIP events
-               recorded on the launch stream around each of the K launches of a second, un-timed loop)
-               against the 8 TB/s HBM3E peak; traffic = HBM bytes per launch from the PMC passes
-               (profiles/r01_pmc.json when present, else null).
+  roofline     achieved = 520 B/config x N / (average duration of the dominant kernel = the device-side duration
+               of the K timed launches, ONE HIP-event pair on the launch stream around the timed loop, / K)
+               against the 8 TB/s HBM3E peak; traffic = HBM bytes per launch from the committed rocprofv3 --pmc
+               passes of this command (profiles/r02_pmc.json; `traffic_source` says so -- it is not measured
+               by this run), else null.
+  host_path    (N=1 only, never `value`) the same 1e6 configurations handed over as NumPy arrays through the
+               RTBHIP_MEM_HOST boundary: PCIe-inclusive configurations/s of the pinned, chunked, double-buffered
+               H2D -> kernel -> D2H pipeline inside the library.
   cpu_baseline the reference's OWN native code (oracle/_ref, built unmodified from the reference
                sources) timed on this box's host cores on the same q array: one ETS_fkine call over
                the whole array + the Python per-row ETS_jacob0 loop a reference user needs today
                (kind "reference"); falls back to the plain-C restatement (kind "port").
 Multi-GPU: the batch dimension is embarrassingly parallel -> each rank owns N rows (weak scaling),
 no collective on the data path; the single output gather (RCCL all_gather over xGMI) is timed
-separately and reported as gather_ms, never inside `value`.
+separately and reported as gather_ms, never inside `value`.  `--gpus N` with no launcher (WORLD_SIZE unset)
+re-executes this script under `python -m torch.distributed.run --nproc-per-node N`; under a launcher the world
+must equal --gpus.
 """
 import argparse
 import json
@@ -29,8 +35,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "robotics-toolbox-python_amd")]
 
+from benchlib import HBM_PEAK_GBS, Ranks, spawn_ranks_if_needed, per_launch_min_ms, ensure_library, pmc_traffic  # noqa: E402
+
 BYTES_PER_CONFIG = 56 + 128 + 336  # q read + T written + J0 written
-HBM_PEAK_GBS = 8000.0              # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
 def cpu_baseline_all_cores(sample, timeout_s=90.0):
@@ -96,49 +103,43 @@ def cpu_baseline(q_host, T_gpu, J_gpu, max_seconds=25.0):
     return out
 
 
+def host_path(ets, q_host, T_dev, J_dev, reps=3):
+    """PCIe-inclusive rate of the host-pointer boundary (what `panda.fkine(numpy_q)` uses): NumPy in, NumPy out."""
+    import numpy as np
+    N = len(q_host)
+    ets.fkine_jacob0(q_host[:4096])                   # staging buffers / streams come up once
+    best, out = None, None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = ets.fkine_jacob0(q_host)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    err = max(float(np.abs(out[0] - T_dev.cpu().numpy()).max()), float(np.abs(out[1] - J_dev.cpu().numpy()).max()))
+    if err != 0.0:
+        raise SystemExit("bench: host-pointer path differs from the device-pointer path, max |err| = %g" % err)
+    return {"value": N / best, "unit": "configurations/s", "ms_per_call": best * 1e3, "pcie_GBs": BYTES_PER_CONFIG * N / best / 1e9,
+            "what": "rtbhip_fkine_jacob(RTBHIP_MEM_HOST) on %d pageable NumPy configurations in, T and J0 NumPy arrays out; "
+                    "best of %d calls; bit-equal to the device-pointer results" % (N, reps)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--n", type=int, default=1000000, help="configurations per GPU per step")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline and host_path legs")
     ap.add_argument("--tune", action="append", default=[], help="key=value for rtbhip_tune (A/B runs)")
     args = ap.parse_args()
+    spawn_ranks_if_needed(args.gpus, os.path.abspath(__file__), sys.argv[1:])
 
     import numpy as np
     import torch
-    if not os.path.exists(os.path.join(ROOT, "robotics-toolbox-python_amd", "lib", "librtbhip.so")):
-        import __graft_entry__                   # a checkout without the (git-ignored) built library: compile it
-        libpath = os.path.join(ROOT, "robotics-toolbox-python_amd", "lib", "librtbhip.so")
-        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
-            __graft_entry__.build_lib()
-        else:
-            t_wait = time.time()
-            while not os.path.exists(libpath) and time.time() - t_wait < 600:
-                time.sleep(1.0)
-            time.sleep(2.0)                      # let the linker finish writing
+    ensure_library(ROOT)
     import rtbhip
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    # test hook (never set by the driver): RTBHIP_BENCH_BACKEND=gloo lets the multi-rank code path be
-    # exercised on a 1-GPU box, every rank sharing device 0 and the collectives going through host memory
-    backend = os.environ.get("RTBHIP_BENCH_BACKEND", "nccl")
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            torch.cuda.set_device(local)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        else:
-            torch.cuda.set_device(local % torch.cuda.device_count())
-            dist.init_process_group(backend, rank=rank, world_size=world)
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", torch.cuda.current_device())
+    rk = Ranks()
+    rank, world, dev = rk.rank, rk.world, rk.dev
     for kv in args.tune:
         k, v = kv.split("=")
         rtbhip.tune(k, int(v))
@@ -155,60 +156,23 @@ def main():
     import ctypes as C
     h = ets._handle()
     qp, Tp, Jp = C.c_void_p(q.data_ptr()), C.c_void_p(T.data_ptr()), C.c_void_p(J.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def step():
-        rc = lib.rtbhip_fkine_jacob(h, qp, N, None, None, 0, Tp, Jp, 1, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        rc = lib.rtbhip_fkine_jacob(h, qp, N, None, None, 0, Tp, Jp, 1, stream)
         if rc != 0:
             raise RuntimeError(lib.rtbhip_last_error().decode())
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # dominant-kernel duration from HIP events on the launch stream (outside the timed region)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    for a, b in ev:
-        a.record()
-        step()
-        b.record()
-    torch.cuda.synchronize()
-    kern_ms = sorted(a.elapsed_time(b) for a, b in ev)
-    kern_avg_ms = sum(kern_ms) / len(kern_ms)
-
-    gather_ms = None
-    if dist is not None and backend == "nccl":
-        out = torch.cat([T.reshape(N, 16), J.reshape(N, 42)], dim=1).contiguous()
-        buf = torch.empty((world * N, 58), dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(buf, out)  # warm-up (communicator setup)
-        barrier()
-        g0 = time.perf_counter()
-        dist.all_gather_into_tensor(buf, out)
-        barrier()
-        gather_ms = (time.perf_counter() - g0) * 1e3
+    elapsed, kern_avg_ms = rk.timed_steps(step, args.steps, args.warmup)
+    kern_min_ms = per_launch_min_ms(step, min(args.steps, 50))
+    # the one exchange of the path, outside the timed region: T|J rows of every rank to every rank
+    gather_ms = rk.gather_ms(torch.cat([T.reshape(N, 16), J.reshape(N, 42)], dim=1)) if world > 1 else None
 
     if rank == 0:
         achieved = BYTES_PER_CONFIG * N / (kern_avg_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_source = pmc_traffic(ROOT, "r02_pmc.json")
+        if traffic is None:
+            traffic, traffic_source = pmc_traffic(ROOT, "r01_pmc.json")
         line = {
             "metric": "configurations/sec (Panda 7-DOF fkine+jacob0)",
             "value": world * N * args.steps / elapsed,
@@ -224,20 +188,25 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: ETS Panda (22 ETs, 7 joints) fused fkine+jacob0, "
                                    "q~U(-pi,pi)^7 seed 0, N=%d per GPU, fp64, device-resident" % N,
-                       "configs_per_gpu": N, "sharding": "rows/%d, no data-path collective" % world},
+                       "configs_per_gpu": N, "sharding": "rows/%d, no data-path collective" % world,
+                       "backend": rk.backend if world > 1 else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_kin_reg<7,true,true>", "kernel_avg_ms": kern_avg_ms, "kernel_min_ms": kern_ms[0],
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": "k_kin_reg<7,true,true>", "kernel_avg_ms": kern_avg_ms, "kernel_min_ms": kern_min_ms,
+                         "kernel_avg_source": "one HIP-event pair on the launch stream around the K timed launches / K",
                          "algorithmic_bytes_per_launch": BYTES_PER_CONFIG * N},
         }
+        if rk.shared:
+            line["config"]["devices_shared"] = True   # gloo test hook: more ranks than GPUs, NOT a scaling measurement
         if gather_ms is not None:
             line["gather_ms"] = gather_ms
+            line["gather"] = "all_gather_into_tensor of (N,58) f64 rows per rank, %s" % (
+                "RCCL over xGMI" if rk.backend == "nccl" else "gloo through host memory (test hook)")
         if not args.no_cpu and world == 1:  # reported on rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(q_host, T, J)
-        print(json.dumps(line))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+            line["host_path"] = host_path(ets, q_host, T, J)
+        print(json.dumps(line), flush=True)
+    rk.finish()
 
 
 if __name__ == "__main__":

@@ -5,7 +5,13 @@ driver only runs bench.py).  One JSON object per line:
    ik     BASELINE configs[2]: ik_LM over 1e5 reachable targets, defaults (chan, k=1)
    fleet  config-5-shaped mixed fleet through one launch
 Each leg times K launches with HIP events on the launch stream and, for rne/ik, the reference's own
-CPU path (oracle/_ref) on a bounded sample."""
+CPU path (oracle/_ref) on a bounded sample.
+
+Multi-GPU (`--gpus N`, self-spawning like bench.py; legs rne and fleet only):
+   rne    BASELINE configs[3] as stated: N = 1e7 triples in total, split into contiguous row blocks by
+          rtbhip_shard_range, one block per rank ("scaling": "strong"); the gather of tau (all_gather over
+          RCCL/xGMI) is timed separately as gather_ms
+   fleet  BASELINE configs[4]: 16 URDF arms x 1e6 configurations, every arm's batch split by rows over the ranks"""
 import argparse
 import json
 import os
@@ -14,6 +20,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "robotics-toolbox-python_amd")]
+
+from benchlib import HBM_PEAK_GBS, FP64_VALU_PEAK_TFLOPS, Ranks, spawn_ranks_if_needed, ensure_library  # noqa: E402
 
 
 def ev_time(fn, steps, warmup):
@@ -32,37 +40,63 @@ def ev_time(fn, steps, warmup):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="rne,ik,fleet,dyn,tree,kin,graph")
+    ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--n-rne", type=int, default=1250000)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n-rne", type=int, default=0, help="TOTAL triples over all ranks (default: 1.25e6 on one GPU = the "
+                    "per-GPU share of config 4; 1e7 = config 4 itself with --gpus > 1)")
     ap.add_argument("--n-ik", type=int, default=100000)
     ap.add_argument("--n-fleet", type=int, default=1000000)
     ap.add_argument("--n-dyn", type=int, default=1000000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--tune", action="append", default=[])
     args = ap.parse_args()
+    spawn_ranks_if_needed(args.gpus, os.path.abspath(__file__), sys.argv[1:])
     import numpy as np
     import torch
+    ensure_library(ROOT)
     import rtbhip
-    torch.cuda.set_device(0)
+    rk = Ranks()
+    rank, world = rk.rank, rk.world
     for kv in args.tune:
         k, v = kv.split("=")
         rtbhip.tune(k, int(v))
     what = args.what.split(",")
+    if world > 1:
+        what = [w for w in what if w in ("rne", "fleet")]    # the legs BASELINE shards; the rest are single-GPU figures
 
     if "rne" in what:
-        N = args.n_rne
+        Ntot = args.n_rne or (10000000 if world > 1 else 1250000)
+        sb = rtbhip.ShardedBatch(Ntot, rank, world)
+        N = sb.count
         rob = rtbhip.models.DH.Panda()
         ql = rob.qlim
-        rng = np.random.default_rng(3)
+        rng = np.random.default_rng(3 + 1000 * rank)          # rank 0 of a single-GPU run = SURVEY 8d config 4's seed
         qh = rng.uniform(ql[0], ql[1], (N, 7))
         qdh, qddh = rng.normal(size=(N, 7)), rng.normal(size=(N, 7))
         q, qd, qdd = (torch.from_numpy(x).cuda() for x in (qh, qdh, qddh))
-        avg, best = ev_time(lambda: rob.rne(q, qd, qdd), args.steps, 3)
-        line = {"metric": "triples/sec (DH Panda rne)", "value": N / (avg * 1e-3), "unit": "triples/s", "n": N,
+        hold = {}
+        def rne_step():
+            hold["tau"] = rob.rne(q, qd, qdd)
+        elapsed, avg = rk.timed_steps(rne_step, args.steps, args.warmup)
+        _, best = ev_time(rne_step, min(args.steps, 10), 0)
+        step_ms = elapsed / args.steps * 1e3
+        line = {"metric": "triples/sec (DH Panda rne)", "value": Ntot / (step_ms * 1e-3), "unit": "triples/s", "n": Ntot,
+                "n_gpus": world, "scaling": "strong", "ms_per_step": step_ms, "rows_rank0": N,
                 "kernel_avg_ms": avg, "kernel_min_ms": best,
-                "roofline": {"bound": "hbm", "achieved": 224.0 * N / (avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                             "frac": 224.0 * N / (avg * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": 224 * N}}
-        if not args.no_cpu:
+                "roofline": {"bound": "hbm", "achieved": 224.0 * N / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": 224.0 * N / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": 224 * N,
+                             "kernel": "k_rne<7,MDH,all-revolute> on rank 0's rows"}}
+        if world > 1:
+            pad = torch.zeros((sb.max_count, 7), dtype=torch.float64, device=q.device)
+            pad[:N] = hold["tau"]
+            line["gather_ms"] = rk.gather_ms(pad)
+            line["gather"] = "all_gather_into_tensor of the (rows,7) tau shards, %d bytes in total" % (56 * Ntot)
+            if rk.shared:
+                line["devices_shared"] = True
+        if rank != 0:
+            line = None
+        if line is not None and not args.no_cpu and world == 1:
             from oracle import ref_harness
             if ref_harness.available():
                 ref = ref_harness.RefRNE(rob.L24(), 1)
@@ -72,7 +106,8 @@ def main():
                 line["cpu_baseline"] = {"value": n / dt, "unit": "triples/s", "cores": 1, "kind": "reference",
                                         "sample": "frne.frne per-row loop (DHRobot.rne) over the first %d triples" % n,
                                         "max_rel_err_gpu_vs_cpu": float(np.abs(g - tau).max() / np.abs(tau).max())}
-        print(json.dumps(line), flush=True)
+        if line is not None:
+            print(json.dumps(line), flush=True)
 
     if "dyn" in what:
         # M(q), C(q,qd), forward dynamics for the DH Panda, one fused kernel each
@@ -236,20 +271,36 @@ def main():
         # BASELINE configs[4]: 16 URDF arms (rtbhip/data/urdf, 4..10 joints on the path to the deepest
         # leaf), N configurations each, q ~ U(qlim) seed 4+i, ONE variable-length-chain launch
         from rtbhip import urdf
-        N = args.n_fleet
+        Ntot = args.n_fleet                                    # per arm, over all ranks
+        sb = rtbhip.ShardedBatch(Ntot, rank, world)
+        N = sb.count
         robots = [urdf.load(nm) for nm in urdf.FLEET16]
         chs = [r.ets() for r in robots]
         qs = []
         for i, c in enumerate(chs):
             ql = np.clip(c.qlim, -2 * np.pi, 2 * np.pi)
-            qs.append(torch.from_numpy(np.random.default_rng(4 + i).uniform(ql[0], ql[1], (N, c.n))).cuda())
-        avg, best = ev_time(lambda: rtbhip.fleet_fkine_jacob(chs, qs), max(3, args.steps // 2), 2)
+            qs.append(torch.from_numpy(np.random.default_rng(4 + i + 1000 * rank).uniform(ql[0], ql[1], (N, c.n))).cuda())
+        hold = {}
+        def fleet_step():
+            hold["out"] = rtbhip.fleet_fkine_jacob(chs, qs)
+        elapsed, avg = rk.timed_steps(fleet_step, max(3, args.steps // 2), 2)
+        _, best = ev_time(fleet_step, 3, 0)
+        step_ms = elapsed / max(3, args.steps // 2) * 1e3
         byts = sum(N * (8 * c.n + 128 + 48 * c.n) for c in chs)
-        line = {"metric": "configurations/sec (mixed fleet: %d URDF arms x %d, one launch)" % (len(chs), N),
-                "value": N * len(chs) / (avg * 1e-3), "unit": "configurations/s", "kernel_avg_ms": avg, "kernel_min_ms": best,
+        line = {"metric": "configurations/sec (mixed fleet: %d URDF arms x %d, one launch per rank)" % (len(chs), Ntot),
+                "value": Ntot * len(chs) / (step_ms * 1e-3), "unit": "configurations/s", "n_gpus": world, "scaling": "strong",
+                "ms_per_step": step_ms, "kernel_avg_ms": avg, "kernel_min_ms": best,
                 "arms": {nm: c.n for nm, c in zip(urdf.FLEET16, chs)},
-                "roofline": {"bound": "hbm", "achieved": byts / (avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                             "frac": byts / (avg * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": byts}}
+                "roofline": {"bound": "hbm", "achieved": byts / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": byts / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": byts,
+                             "kernel": "k_fleet<0> + k_fleet<1> on rank 0's rows"}}
+        if rk.shared:
+            line["devices_shared"] = True
+        if world > 1:
+            if rank == 0:
+                print(json.dumps(line), flush=True)
+            rk.finish()
+            return
         # the same 16 batches through the per-chain register-resident kernel, 16 launches
         def per_chain():
             for c, q in zip(chs, qs):
@@ -274,6 +325,8 @@ def main():
                                         "sample": "first %d configurations of each of the 16 arms; ETS_fkine + per-row ETS_jacob0" % n,
                                         "max_abs_err_gpu_vs_cpu": err}
         print(json.dumps(line), flush=True)
+    rk.finish()
+
 
 if __name__ == "__main__":
     main()

@@ -33,6 +33,9 @@ class ShardedBatch:
         if self.world == 1 or not (dist.is_available() and dist.is_initialized()):
             return local_out
         tail = tuple(local_out.shape[1:])
+        home = local_out.device
+        if local_out.is_cuda and dist.get_backend() == "gloo":
+            local_out = local_out.cpu()        # gloo moves host memory; RCCL ("nccl") takes the device buffer as it is
         send = local_out
         if self.count != self.max_count:
             send = torch.zeros((self.max_count,) + tail, dtype=local_out.dtype, device=local_out.device)
@@ -49,6 +52,6 @@ class ShardedBatch:
                 return None
             parts = torch.stack(lst)
         if self.N == self.world * self.max_count:
-            return parts.reshape((self.N,) + tail)
+            return parts.reshape((self.N,) + tail).to(home)
         rows = [parts[r, :shard_range(self.N, r, self.world)[1]] for r in range(self.world)]
-        return torch.cat(rows, dim=0)
+        return torch.cat(rows, dim=0).to(home)

@@ -1,0 +1,120 @@
+"""-m gpu: the N>1 path with REAL kernels -- two ranks (one process each, gloo rendezvous on 127.0.0.1) share the
+box's one GPU; each launches rtbhip_fkine_jacob and rtbhip_rne on its own row block (rtbhip_shard_range through
+ShardedBatch), the shards are gathered with the path's one collective, and the full result is compared with the
+CPU oracle -- including N not divisible by the world size and a world larger than N.  On an 8-GPU node the same
+code runs with backend "nccl" (RCCL over xGMI), one GPU per rank; only the backend string differs.
+Also: `bench.py --gpus 2` spawns two ranks by itself and says so on its JSON line."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, N, to_all, outq):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "robotics-toolbox-python_amd")]
+    import torch
+    import torch.distributed as dist
+    import rtbhip
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank % torch.cuda.device_count())
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # every rank derives the SAME global inputs from the seed, then keeps only its rows
+        rng = np.random.default_rng(99)
+        qg = rng.uniform(-np.pi, np.pi, (N, 7))
+        arm = rtbhip.models.DH.Panda()
+        qa = rng.uniform(arm.qlim[0], arm.qlim[1], (N, 7))
+        qd, qdd = rng.normal(size=(N, 7)), rng.normal(size=(N, 7))
+        sb = rtbhip.ShardedBatch(N)
+        ets = rtbhip.models.Panda().ets()
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(sb.local(a))).cuda()
+        T, J = ets.fkine_jacob0(dev(qg))
+        tau = arm.rne(dev(qa), dev(qd), dev(qdd))
+        assert T.is_cuda and T.shape == (sb.count, 4, 4) and J.shape == (sb.count, 6, 7) and tau.shape == (sb.count, 7)
+        TJ = torch.cat([T.reshape(sb.count, 16), J.reshape(sb.count, 42)], dim=1)
+        full = sb.gather(TJ, to_all=to_all)
+        ftau = sb.gather(tau, to_all=to_all)
+        if to_all or rank == 0:
+            outq.put((rank, sb.begin, sb.count, full.cpu().numpy(), ftau.cpu().numpy()))
+        else:
+            assert full is None and ftau is None
+            outq.put((rank, sb.begin, sb.count, None, None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N,world,to_all", [(4097, 2, True), (1000, 2, False), (130, 3, True), (2, 3, True)])
+def test_two_ranks_real_kernels_gathered_equal_oracle(N, world, to_all):
+    from oracle import oracle, chains
+    ctx = mp.get_context("spawn")
+    outq = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, to_all, outq)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([outq.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # the row blocks tile [0, N) in rank order
+    assert res[0][1] == 0 and all(res[i][1] + res[i][2] == res[i + 1][1] for i in range(world - 1))
+    assert res[-1][1] + res[-1][2] == N
+    rng = np.random.default_rng(99)
+    qg = rng.uniform(-np.pi, np.pi, (N, 7))
+    tab = chains.panda_dh()
+    qa = rng.uniform(tab.qlim[:, 0], tab.qlim[:, 1], (N, 7))
+    qd, qdd = rng.normal(size=(N, 7)), rng.normal(size=(N, 7))
+    ch = chains.panda_ets()
+    Tref, Jref = oracle.fkine(ch, qg), oracle.jacob0(ch, qg)
+    tref = oracle.rne_dh(tab.L24(), 1, qa, qd, qdd, -tab.gravity)
+    holders = [r for r in res if r[3] is not None]
+    assert len(holders) == (world if to_all else 1)
+    for _, _, _, full, ftau in holders:
+        assert full.shape == (N, 58) and ftau.shape == (N, 7)
+        assert np.abs(full[:, :16].reshape(N, 4, 4) - Tref).max() <= 1e-10
+        assert np.abs(full[:, 16:].reshape(N, 6, 7) - Jref).max() <= 1e-10
+        assert np.abs(ftau - tref).max() / max(1.0, np.abs(tref).max()) <= 1e-9
+
+
+def _run_bench(script, extra):
+    env = dict(os.environ, RTBHIP_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, script), "--gpus", "2"] + extra, capture_output=True, text=True,
+                       timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_gpus_2_spawns_two_ranks():
+    lines = _run_bench("bench.py", ["--steps", "5", "--warmup", "2", "--n", "200000", "--no-cpu"])
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["gather_ms"] > 0
+    assert line["config"]["configs_per_gpu"] == 200000
+    assert line["roofline"]["kernel_avg_ms"] <= line["ms_per_step"] * 1.001     # device time of the loop <= host time of the loop
+    assert line["value"] == pytest.approx(2 * 200000 * 5 / (line["ms_per_step"] * 5e-3), rel=1e-9)
+
+
+def test_bench_extra_gpus_2_shards_config4_and_config5():
+    lines = _run_bench("bench_extra.py", ["--what", "rne,fleet", "--steps", "4", "--n-rne", "200001", "--n-fleet", "20001", "--no-cpu"])
+    assert len(lines) == 2
+    rne, fleet = lines
+    assert rne["n_gpus"] == 2 and rne["n"] == 200001 and rne["rows_rank0"] == 100001 and rne["scaling"] == "strong" and rne["gather_ms"] > 0
+    assert fleet["n_gpus"] == 2 and fleet["scaling"] == "strong" and len(fleet["arms"]) == 16
