@@ -309,10 +309,14 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, Q
     constexpr bool PINV = (STEP & kIkStepPinv) != 0, NULLSP = (STEP & kIkStepNull) != 0 && NJ >= 6;
     Pose P;
     double jac[6 * NJ], e[6], dq[NJ];
+    bool q_finite = true;
     {
         double qv[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) qv[j] = qa.get(j);
+        for (int j = 0; j < NJ; ++j) {
+            qv[j] = qa.get(j);
+            q_finite = q_finite && __builtin_isfinite(qv[j]);
+        }
         // the chain's last constant C_n (no tool in IK) is segment NJ of the table: {r[9], t[3]} contiguous
         reg_core<NJ, true>(cv, &cv.seg[NJ].r[0], 0, qv, P, jac);   // ik.cpp:44,56 / IK.py:994,1009
     }
@@ -341,9 +345,9 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, Q
         for (int j = 0; j < NJ; ++j) dq[j] += qn[j];
     }
     if (st.status != kIkRun || st.fin) return;    // a search that has ended waits, untouched, for the next pass
-    st.E = E;
     const bool arrived = E < p.tol;
     if (p.flavour == 0) {
+        st.E = E;
         if (arrived) {                                          // ik.cpp:48-54
             bool ok = true;
 #pragma unroll
@@ -361,6 +365,14 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, Q
         }
     } else {
         st.iter++;                                              // IK.py:315
+        if ((PINV || NULLSP) && !q_finite) {
+            // numpy.linalg.pinv raises LinAlgError on a non-finite J (LAPACK gesdd refuses NaN: info != 0), and J -- a polynomial in
+            // the sines and cosines -- is non-finite exactly when q is.  IK.py:320-323: the search is abandoned, the iteration
+            // counted, E and q left as the last completed step had them.  (numpy.linalg.inv of the plain LM step does not raise.)
+            st.fin = 1; st.ok = 0;
+            return;
+        }
+        st.E = E;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) dq[j] += qa.get(j);        // the step is taken before E is tested (IK.py:319-327)
         if (arrived) {

@@ -9,6 +9,12 @@ Run in the BUILD container (needs /root/reference and oracle/_ref built by
   ref_outputs.npz         : outputs of the reference's own fknm/frne extension (oracle/_ref, built
                             unmodified from /root/reference) on seeded inputs -- the differential
                             pins for fkine / jacob0 / jacobe / hessian0 / ik_LM / rne.
+  ref_python_ik.npz       : outputs of the reference's own PYTHON solvers (robot/IK.py: IK_LM / IK_NR / IK_GN
+                            `.solve`, loaded unmodified under the stand-in modules of oracle/ref_python.py) with and
+                            without the null-space terms kq, km, ps, pi, for explicit start-vector tables (so no RNG
+                            is involved even across many searches), and of `fknm.Angle_Axis` on random, identical,
+                            half-turn and near-threshold rotation pairs.  `python make_golden.py python_ik` writes
+                            only this file.
 """
 import ast
 import json
@@ -41,7 +47,107 @@ def literal(fname, func, var, nth=0):
     raise KeyError((fname, func, var))
 
 
+def rodrigues(axis, th):
+    a = np.asarray(axis, dtype=float)
+    a = a / np.linalg.norm(a)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return np.eye(3) + math.sin(th) * K + (1 - math.cos(th)) * (K @ K)
+
+
+def python_ik():
+    """Fixtures from the reference's Python solvers and its compiled Angle_Axis (pins SURVEY rows a7 and a9)."""
+    sys.path.insert(0, os.path.join(ROOT, "robotics-toolbox-python_amd"))
+    import ctypes as C
+    import rtbhip
+    from oracle import chains, ref_python as rp
+    out = {}
+    rng = np.random.default_rng(20260922)
+
+    # ---- Angle_Axis (core/fknm.cpp:112-162 -> _angle_axis core/ik.cpp:241-286)
+    def se3(R, t):
+        T = np.eye(4); T[:3, :3] = R; T[:3, 3] = t
+        return T
+    Te, Tep, tag = [], [], []
+    def add(a, b, what):
+        Te.append(a); Tep.append(b); tag.append(what)
+    for _ in range(64):
+        add(se3(rodrigues(rng.normal(size=3), rng.uniform(-3.1, 3.1)), rng.normal(size=3)),
+            se3(rodrigues(rng.normal(size=3), rng.uniform(-3.1, 3.1)), rng.normal(size=3)), 0)          # generic: atan2 branch
+    for _ in range(6):
+        R = rodrigues(rng.normal(size=3), rng.uniform(-3, 3))
+        add(se3(R, rng.normal(size=3)), se3(R, rng.normal(size=3)), 1)                                   # identical: |li| = 0, tr = 3
+    for ax in ([1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 0], [1, -2, 3]):
+        R0 = rodrigues(rng.normal(size=3), rng.uniform(-3, 3))
+        add(se3(R0, rng.normal(size=3)), se3(rodrigues(ax, math.pi) @ R0, rng.normal(size=3)), 2)        # half turn: |li| ~ 0, tr = -1
+        add(se3(np.eye(3), np.zeros(3)), se3(rodrigues(ax, math.pi), np.zeros(3)), 2)
+    for th in (4e-7, 4.9e-7, 5.1e-7, 6e-7, 1e-5, math.pi - 4e-7, math.pi - 4.9e-7, math.pi - 5.1e-7, math.pi - 6e-7, math.pi - 1e-5):
+        for ax in ([0, 0, 1], [1, 2, -1]):                                                               # |li| = 2 sin(th) around the 1e-6 test
+            R0 = rodrigues(rng.normal(size=3), rng.uniform(-3, 3))
+            add(se3(R0, rng.normal(size=3)), se3(rodrigues(ax, th) @ R0, rng.normal(size=3)), 3)
+    out["aa_Te"], out["aa_Tep"], out["aa_tag"] = np.array(Te), np.array(Tep), np.array(tag)
+    out["aa_e"] = np.array([rp.angle_axis(a, b) for a, b in zip(Te, Tep)])
+
+    # ---- IK_LM / IK_NR / IK_GN .solve (robot/IK.py:174-367, 507-576, 736-763, 994-1017, 1176-1220)
+    ch = chains.panda_ets(with_limits=True)
+    duck = rp.DuckETS(ch)
+    ets = rtbhip.models.Panda().ets()
+    ets.qlim = chains.PANDA_QLIM
+    SEED, N, SMAX = 1234, 16, 100
+    lib, h = rtbhip.lib(), ets._handle()
+    starts = np.empty((N, SMAX, 7))             # the device generator's start vectors (host function of librtbhip, no GPU needed)
+    buf = np.empty(7)
+    for i in range(N):
+        for d in range(SMAX):
+            assert lib.rtbhip_ik_restart(h, SEED, i, d, buf.ctypes.data_as(C.c_void_p)) == 0
+            starts[i, d] = buf
+    out["ik_seed"], out["ik_starts"] = np.array(SEED), starts
+    qs = rng.uniform(ch.qlim[0], ch.qlim[1], (N, 7))
+    Tep = np.array([duck.eval(x) for x in qs])
+    Tep[5, :3, 3] += 2.5                         # one unreachable target: every search runs to ilimit
+    out["ik_Tep"] = Tep
+    q0 = qs + 0.2 * rng.normal(size=qs.shape)
+    out["ik_q0"] = q0
+    # near-solution, near-limit problems for the null-space terms (as tests/test_kernel_emu.py's emu check)
+    qn = rng.uniform(ch.qlim[0] + 0.25, ch.qlim[1] - 0.25, (N, 7))
+    qn[::2, 3] = ch.qlim[1, 3] - 0.12
+    qn[1::4, 1] = ch.qlim[0, 1] + 0.1
+    Tn = np.array([duck.eval(x) for x in qn])
+    q0n = np.clip(qn + 0.03 * rng.normal(size=qn.shape), ch.qlim[0] + 0.02, ch.qlim[1] - 0.02)
+    out["ikn_Tep"], out["ikn_q0"] = Tn, q0n
+
+    def run(key, solver, T, first, slimit, **kw):
+        res = []
+        for i in range(N):
+            tab = starts[i, :slimit].copy()
+            if first is not None:
+                tab[0] = first[i]
+            res.append(rp.solve(solver, duck, T[i], tab, slimit=slimit, **kw))
+        out[key + "_q"] = np.array([r[0] for r in res])
+        out[key + "_meta"] = np.array([[r[1], r[2], r[3]] for r in res], dtype=np.int64)
+        out[key + "_E"] = np.array([r[4] for r in res])
+        print("  %-16s success %2d/%d  iterations %5d  searches %4d" % (key, sum(r[1] for r in res), N, sum(r[2] for r in res), sum(r[3] for r in res)))
+
+    run("lm_chan", "IK_LM", Tep, None, 100, method="chan", k=1.0)
+    run("lm_wampler", "IK_LM", Tep, None, 100, method="wampler", k=0.01)
+    run("lm_sugihara", "IK_LM", Tep, None, 100, method="sugihara", k=0.01)
+    run("lm_chan_q0", "IK_LM", Tep, q0, 100, method="chan", k=1.0)
+    run("lm_chan_nojl_mask", "IK_LM", Tep, None, 40, method="chan", k=0.1, joint_limits=False, mask=[1, 1, 1, 0.5, 0.5, 0.25])
+    run("lm_chan_short", "IK_LM", Tep, None, 4, method="chan", k=1.0, ilimit=5)
+    run("nr_q0", "IK_NR", Tn, q0n, 5, pinv=True)
+    run("gn_q0", "IK_GN", Tn, q0n, 5, pinv=True)
+    run("lm_chan_ns", "IK_LM", Tn, q0n, 3, method="chan", k=1.0, kq=0.1, km=0.1, ps=0.0, pi=0.3)         # tests/test_IK.py:194-196
+    run("lm_sugihara_ns", "IK_LM", Tn, q0n, 3, method="sugihara", k=0.01, kq=0.5, km=0.0, ps=0.05, pi=0.4)
+    run("lm_wampler_ns_km", "IK_LM", Tn, q0n, 3, method="wampler", k=0.01, kq=0.0, km=0.5)               # km alone: the guard at IK.py:572 drops it
+    run("nr_ns", "IK_NR", Tn, q0n, 3, pinv=True, kq=0.01, km=1.0)                                        # tests/test_IK.py:166-173
+    run("gn_ns", "IK_GN", Tn, q0n, 3, pinv=True, kq=1.0, km=1.0)                                         # tests/test_IK.py:261-263
+    path = os.path.join(HERE, "ref_python_ik.npz")
+    np.savez_compressed(path, **out)
+    print("wrote ref_python_ik.npz with", len(out), "arrays,", os.path.getsize(path), "bytes")
+
+
 def main():
+    if sys.argv[1:] == ["python_ik"]:
+        return python_ik()
     lit = {}
 
     def add(key, fname, func, var, nth=0):
@@ -199,6 +305,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ref_outputs.npz"), **out)
     print("wrote ref_outputs.npz with", len(out), "arrays,",
           os.path.getsize(os.path.join(HERE, "ref_outputs.npz")), "bytes")
+    python_ik()
 
 
 if __name__ == "__main__":

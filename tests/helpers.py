@@ -17,6 +17,52 @@ def ref_outputs():
     return dict(np.load(os.path.join(GOLD, "ref_outputs.npz")))
 
 
+def ref_python_ik():
+    """Outputs of the reference's own Python solvers (robot/IK.py) and of fknm.Angle_Axis -- make_golden.py python_ik."""
+    return dict(np.load(os.path.join(GOLD, "ref_python_ik.npz")))
+
+
+# the cases of ref_python_ik.npz: key -> (problem set, first start from q0?, slimit, step, solver keywords)
+#   problem set "ik": random reachable targets (one unreachable), "ikn": near-solution / near-limit starts
+PY_IK_CASES = {
+    "lm_chan": ("ik", False, 100, "lm", dict(method="chan", k=1.0)),
+    "lm_wampler": ("ik", False, 100, "lm", dict(method="wampler", k=0.01)),
+    "lm_sugihara": ("ik", False, 100, "lm", dict(method="sugihara", k=0.01)),
+    "lm_chan_q0": ("ik", True, 100, "lm", dict(method="chan", k=1.0)),
+    "lm_chan_nojl_mask": ("ik", False, 40, "lm", dict(method="chan", k=0.1, joint_limits=False, mask=[1, 1, 1, 0.5, 0.5, 0.25])),
+    "lm_chan_short": ("ik", False, 4, "lm", dict(method="chan", k=1.0, ilimit=5)),
+    "nr_q0": ("ikn", True, 5, "nr", dict()),
+    "gn_q0": ("ikn", True, 5, "gn", dict()),
+    "lm_chan_ns": ("ikn", True, 3, "lm", dict(method="chan", k=1.0, kq=0.1, km=0.1, ps=0.0, pi=0.3)),
+    "lm_sugihara_ns": ("ikn", True, 3, "lm", dict(method="sugihara", k=0.01, kq=0.5, km=0.0, ps=0.05, pi=0.4)),
+    "lm_wampler_ns_km": ("ikn", True, 3, "lm", dict(method="wampler", k=0.01, kq=0.0, km=0.5)),
+    "nr_ns": ("ikn", True, 3, "nr", dict(kq=0.01, km=1.0)),
+    "gn_ns": ("ikn", True, 3, "gn", dict(kq=1.0, km=1.0)),
+}
+
+
+def angle_axis_tolerance(Te, Tep):
+    """Per-pair absolute tolerance for angle-axis errors: a = atan2(|li|, tr - 1) li / |li| with li a difference of nearly
+    equal entries of R, so near a half turn (|li| -> 0) a rounding difference of a few ulp in R moves the DIRECTION li / |li|
+    by ~ulp / |li| (times an angle up to pi).  5e-15 away from that corner."""
+    out = np.empty(len(Te))
+    for i, (a, b) in enumerate(zip(Te, Tep)):
+        R = b[:3, :3] @ a[:3, :3].T
+        nrm = np.linalg.norm([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+        out[i] = 5e-15 + 2e-15 / max(nrm, 1e-6)
+    return out
+
+
+def py_ik_problem(PY, key):
+    """(Tep (N,4,4), start table (N,slimit,n)) of one fixture case."""
+    prob, first, slimit, step, kw = PY_IK_CASES[key]
+    Tep = PY[prob + "_Tep"]
+    tab = PY["ik_starts"][:, :slimit].copy()
+    if first:
+        tab[:, 0] = PY[prob + "_q0"]
+    return Tep, tab
+
+
 def mixed_spec():
     """The mixed chain of make_golden.py, as (oracle spec, builder for the product ETS)."""
     from oracle import chains

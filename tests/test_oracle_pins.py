@@ -7,10 +7,11 @@ import numpy.testing as nt
 import pytest
 
 from oracle import oracle, chains, ref_harness
-from helpers import literals, ref_outputs, mixed_spec, tool_base
+from helpers import literals, ref_outputs, mixed_spec, tool_base, ref_python_ik, PY_IK_CASES, py_ik_problem, angle_axis_tolerance
 
 LIT = literals()
 REF = ref_outputs()
+PY = ref_python_ik()
 
 
 def test_G1_G2_panda_fkine_jacob0_literals():
@@ -142,6 +143,51 @@ def test_oracle_ik_matches_reference_run_fixtures():
             nt.assert_allclose(q, REF["ik_%s_q" % meth][i], atol=1e-8)
             hit += 1
         assert hit >= 15
+
+
+def test_oracle_angle_axis_matches_reference_Angle_Axis():
+    """fknm.Angle_Axis (fknm.cpp:112-162 -> ik.cpp:241-286) on random pairs, identical rotations (|li| = 0, tr > 0 -> zero),
+    half turns about five axes (|li| ~ 0, tr <= 0 -> pi/2 (diag R + 1)) and rotations either side of the |li| < 1e-6 test."""
+    e = np.array([oracle.angle_axis(a, b) for a, b in zip(PY["aa_Te"], PY["aa_Tep"])])
+    assert np.all(np.abs(e - PY["aa_e"]).max(axis=1) <= angle_axis_tolerance(PY["aa_Te"], PY["aa_Tep"]))
+    assert np.abs(e - PY["aa_e"])[PY["aa_tag"] <= 2].max() <= 5e-15
+    tag = PY["aa_tag"]
+    assert np.all(PY["aa_e"][tag == 1][:, 3:] == 0.0)                       # the (1,1,1) branch really was taken
+    half = PY["aa_e"][tag == 2][:, 3:]
+    assert np.all(np.abs(np.abs(half).max(axis=1) - np.pi) < 2.0) and np.all(half >= -1e-12)   # pi/2 (diag + 1) in [0, pi]
+    assert np.any(np.all(PY["aa_e"][tag == 3][:, 3:] == 0.0, axis=1)) and np.any(np.abs(PY["aa_e"][tag == 3][:, 3:]).max(axis=1) > 3.0)
+
+
+@pytest.mark.parametrize("key", sorted(PY_IK_CASES))
+def test_oracle_python_ik_matches_reference_IK_py(key):
+    """The NumPy restatement of the Python solvers (oracle.ikine_py; oracle.ikine_lm for the plain LM cases) against the
+    reference's OWN robot/IK.py run under stand-in modules (oracle/ref_python.py) on explicit start tables: identical
+    (success, iterations, searches) and q to 1e-7 -- across many searches, failures, joint-limit rejections, masks and the
+    null-space terms kq / km / ps / pi.  Undamped NR / GN searches that start far from the solution are chaotic (1e-16
+    differences decide whether a wandering search happens to land); there only what the first search decides is compared."""
+    ch = chains.panda_ets(with_limits=True)
+    prob, first, slimit, step, kw = PY_IK_CASES[key]
+    Tep, tab = py_ik_problem(PY, key)
+    meta, qref, Eref = PY[key + "_meta"], PY[key + "_q"], PY[key + "_E"]
+    kw = dict(kw)
+    we = kw.pop("mask", None)
+    checked = 0
+    for i in range(len(Tep)):
+        o = oracle.ikine_py(ch, Tep[i], tab[i], step=step, slimit=slimit, we=we, **kw)
+        if step != "lm" and not (meta[i, 0] == 1 and meta[i, 2] == 1):
+            continue
+        assert (o[1], o[2], o[3]) == tuple(meta[i]), (key, i)
+        if meta[i, 0]:
+            nt.assert_allclose(o[0], qref[i], atol=1e-7)
+            assert abs(o[4] - Eref[i]) <= 1e-9 * max(1.0, abs(Eref[i]))
+        checked += 1
+        if step == "lm" and "kq" not in kw:                       # the C restatement of the same loop
+            c = oracle.ikine_lm(ch, Tep[i], tab[i], slimit=slimit, we=we, ilimit=kw.get("ilimit", 30),
+                                joint_limits=kw.get("joint_limits", True), k=kw["k"], method=kw["method"])
+            assert (c[1], c[2], c[3]) == tuple(meta[i]), (key, i)
+            if meta[i, 0]:
+                nt.assert_allclose(c[0], qref[i], atol=1e-7)
+    assert checked >= (len(Tep) if step == "lm" else 6)
 
 
 @pytest.mark.skipif(not ref_harness.available(), reason="oracle/_ref not built here")
