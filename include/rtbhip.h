@@ -102,6 +102,18 @@ int rtbhip_fkine_jacob(rtbhip_chain_t chain, const double *q, int64_t N, const d
 int rtbhip_hessian(rtbhip_chain_t chain, const double *q, int64_t N, const double *tool16,
                    int32_t frame, double *H, int32_t mem, void *stream);
 
+/* ETS_hessian0 / ETS_hessiane in the form the reference binds them, (ets, q, J, tool) WITH the Jacobian supplied
+ * (fknm.cpp:583-783: when J is given only _ETS_hessian runs on it, methods.cpp:16-32 -- a pure function of J, so no
+ * chain handle is needed): J (N,6,n) -> H (N,n,6,n); J0 gives hessian0, Je gives hessiane.  Device buffers must be
+ * 16-byte aligned. */
+int rtbhip_hessian_from_jacobian(const double *J, int64_t N, int32_t n, double *H, int32_t mem, void *stream);
+
+/* fknm.Angle_Axis (fknm.cpp:112-162 -> _angle_axis ik.cpp:241-286; used by tools/p_servo.py:7-43 and IK.py:398),
+ * batched: e (N,6) = [Tep.t - Te.t ; angle-axis vector of Tep.R Te.R^T], N = max(nTe, nTep); Te is (nTe,4,4) and Tep
+ * (nTep,4,4) row-major, each count either N or 1 (that pose is then used for every pair).  Device buffers must be
+ * 16-byte aligned. */
+int rtbhip_angle_axis(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, double *e, int32_t mem, void *stream);
+
 /* Differential-kinematics consumers computed from the Jacobian while it is still in registers (SURVEY 8f-4;
  * chains of up to 10 joints):
  *   rtbhip_jacob_dot       Robot.jacob0_dot (robot/Robot.py:964-1098, representation=None): Jd (N,6,n) = H(q) . qd,
@@ -114,6 +126,11 @@ int rtbhip_hessian(rtbhip_chain_t chain, const double *q, int64_t N, const doubl
  * rotation; representation 0 "rpy/xyz", 1 "rpy/zyx", 2 "eul", 3 "exp" (conventions of spatialmath-python, see diff_device.h). */
 int rtbhip_jacob0_analytical(rtbhip_chain_t chain, const double *q, int64_t N, const double *tool16, int32_t representation,
                              double *Ja, int32_t mem, void *stream);
+/* Robot.jacob0_dot with an orientation representation (robot/Robot.py:1065-1098): Jd (N,6,n) = tensordot(H, qd) with H the
+ * reference's own numerical Hessian of jacob0_analytical -- spatialmath `numhess`, forward differences with dx = 1e-8
+ * (the reference has no closed form for this quantity); representation codes as rtbhip_jacob0_analytical. */
+int rtbhip_jacob0_dot_analytical(rtbhip_chain_t chain, const double *q, const double *qd, int64_t N, const double *tool16,
+                                 int32_t representation, double *Jd, int32_t mem, void *stream);
 int rtbhip_jacob_dot(rtbhip_chain_t chain, const double *q, const double *qd, int64_t N, const double *tool16,
                      int32_t frame, double *Jd, int32_t mem, void *stream);
 int rtbhip_manipulability(rtbhip_chain_t chain, const double *q, int64_t N, const double *tool16, int32_t axes_mask,
@@ -152,7 +169,7 @@ int rtbhip_ik_lm(rtbhip_chain_t chain, const double *Tep, int64_t N, const doubl
  * robot/IK.py:507-576 `_null_Sigma`, `_calc_qnull`, added to the step at :758, :1015, :1215): joint-limit avoidance with
  * gain 1/kq inside the influence distance pi (minimum distance ps) and manipulability maximisation with gain 1/km,
  * projected into the null space of J.  flavour must be 1.  As in the reference the term is applied only when kq > 0;
- * chains of 6..8 joints (below 6 the projector vanishes and the call equals rtbhip_ik_lm). */
+ * chains of 6..8 joints; kq > 0 on any other chain returns RTBHIP_ELIMIT (nothing is dropped silently). */
 int rtbhip_ik_lm_nullspace(rtbhip_chain_t chain, const double *Tep, int64_t N, const double *q0,
                            int32_t ilimit, int32_t slimit, double tol, int32_t reject_jl, const double *we6,
                            double lambda, int32_t method, int32_t flavour, uint64_t seed,

@@ -169,6 +169,20 @@ def jacob0_analytical(ch, q, representation="rpy/xyz", tool=None):
     return np.array([rotvelxform_inverse(T[i][:3, :3], representation) @ J[i] for i in range(J.shape[0])])
 
 
+def jacob0_dot_analytical(ch, q, qd, representation="rpy/xyz", tool=None, dx=1e-8):
+    """Robot.jacob0_dot with a `representation` (robot/Robot.py:1090-1098): H = numhess(jacob0_analytical, q) -- spatialmath's
+    forward difference H[i] = (J(q + dx e_i) - J(q)) / dx with dx = 1e-8 (third-party, restated) -- then tensordot(H, qd, (0, 0))."""
+    q = _f64(q).reshape(-1, ch.n)
+    qd = _f64(qd).reshape(-1, ch.n)
+    out = np.zeros((q.shape[0], 6, ch.n))
+    I = np.eye(ch.n)
+    for s in range(q.shape[0]):
+        J0 = jacob0_analytical(ch, q[s], representation, tool)[0]
+        H = np.stack([(jacob0_analytical(ch, q[s] + I[:, i] * dx, representation, tool)[0] - J0) / dx for i in range(ch.n)], axis=0)
+        out[s] = np.tensordot(H, qd[s], (0, 0))
+    return out
+
+
 def link_frames(ch, q, marks, base=None):
     """DHRobot.fkine_all / Robot.fkine_all (robot/DHRobot.py:1058-1064, robot/Robot.py:667-698): Tj = base; Tj *= A_k(q) and
     every partial product kept.  Frame m = base * (first marks[m] elementary transforms), each built as the reference's

@@ -6,7 +6,9 @@
 #include "frames_device.h"
 #include "tree_device.h"
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <memory>
 #include <unordered_map>
 
@@ -28,32 +30,71 @@ void note_launch(int grid, int block, int lds)
     g_last_launch[0] = grid; g_last_launch[1] = block; g_last_launch[2] = lds;
 }
 
+// ---------------------------------------------------------------- tracing ranges (opt-in)
+// RTBHIP_ROCTX=1: every compute entry point is bracketed by a roctx range named after it, so `rocprofv3 --marker-trace`
+// shows which ABI call a kernel belongs to (the reference has no tracing hooks).  The marker library is looked
+// up at run time -- nothing links against it and nothing happens when the variable is unset.
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        const char *on = std::getenv("RTBHIP_ROCTX");
+        if (!on || !*on || *on == '0') return;
+        for (const char *name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            if (void *h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+                push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+                pop = (int (*)())dlsym(h, "roctxRangePop");
+                if (push && pop) return;
+                push = nullptr; pop = nullptr;
+            }
+        }
+    }
+};
+const Roctx &roctx() { static const Roctx r; return r; }
+struct TraceRange {
+    bool on;
+    explicit TraceRange(const char *name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+    ~TraceRange() { if (on) roctx().pop(); }
+    TraceRange(const TraceRange &) = delete;
+};
+}  // namespace
+#define RTB_TRACE(name) ::rtbhip::TraceRange _trace_range(name)
+
 // ---------------------------------------------------------------- handle registry
 static std::mutex g_reg_mu;
-static std::unordered_map<uint64_t, std::unique_ptr<Chain>> g_chains;
-static std::unordered_map<uint64_t, std::unique_ptr<Dyn>> g_dyns;
-static std::unordered_map<uint64_t, std::unique_ptr<Tree>> g_trees;
+static std::unordered_map<uint64_t, std::shared_ptr<Chain>> g_chains;
+static std::unordered_map<uint64_t, std::shared_ptr<Dyn>> g_dyns;
+static std::unordered_map<uint64_t, std::shared_ptr<Tree>> g_trees;
 static std::atomic<uint64_t> g_next{1};
 
-Chain *chain_from_handle(rtbhip_chain_t h)
+std::shared_ptr<Chain> chain_from_handle(rtbhip_chain_t h)
 {
     std::lock_guard<std::mutex> lk(g_reg_mu);
     auto it = g_chains.find(h);
-    return it == g_chains.end() ? nullptr : it->second.get();
+    return it == g_chains.end() ? nullptr : it->second;
 }
-Dyn *dyn_from_handle(rtbhip_dyn_t h)
+std::shared_ptr<Dyn> dyn_from_handle(rtbhip_dyn_t h)
 {
     std::lock_guard<std::mutex> lk(g_reg_mu);
     auto it = g_dyns.find(h);
-    return it == g_dyns.end() ? nullptr : it->second.get();
+    return it == g_dyns.end() ? nullptr : it->second;
 }
 
-Tree *tree_from_handle(rtbhip_tree_t h)
+std::shared_ptr<Tree> tree_from_handle(rtbhip_tree_t h)
 {
     std::lock_guard<std::mutex> lk(g_reg_mu);
     auto it = g_trees.find(h);
-    return it == g_trees.end() ? nullptr : it->second.get();
+    return it == g_trees.end() ? nullptr : it->second;
 }
+
+Chain::~Chain()
+{
+    for (auto &kv : dev_ops) (void)hipFree(kv.second);
+    for (auto &kv : dev_qlim) (void)hipFree(kv.second);
+}
+Dyn::~Dyn() { for (auto &kv : dev_links) (void)hipFree(kv.second); }
 
 static DevChain view_of(const Chain *c, const void *base)
 {
@@ -87,10 +128,15 @@ int chain_device_ops(Chain *c, DevChain *out, const double **qlim_out)
         if (!c->jmeta.empty()) std::memcpy(w, c->jmeta.data(), c->jmeta.size() * sizeof(int32_t));
         void *d = nullptr;
         double *ql = nullptr;
-        RTB_HIP(hipMalloc(&d, blob.size()));
-        RTB_HIP(hipMemcpy(d, blob.data(), blob.size(), hipMemcpyHostToDevice));
-        RTB_HIP(hipMalloc((void **)&ql, (c->qlim.size() ? c->qlim.size() : 1) * sizeof(double)));
-        if (!c->qlim.empty()) RTB_HIP(hipMemcpy(ql, c->qlim.data(), c->qlim.size() * sizeof(double), hipMemcpyHostToDevice));
+        hipError_t e = hipMalloc(&d, blob.size());
+        if (e == hipSuccess) e = hipMemcpy(d, blob.data(), blob.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void **)&ql, (c->qlim.size() ? c->qlim.size() : 1) * sizeof(double));
+        if (e == hipSuccess && !c->qlim.empty()) e = hipMemcpy(ql, c->qlim.data(), c->qlim.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {             // nothing half-uploaded stays behind
+            if (d) (void)hipFree(d);
+            if (ql) (void)hipFree(ql);
+            return hip_fail(e, "chain table upload");
+        }
         c->dev_ops[dev] = d;
         c->dev_qlim[dev] = ql;
         it = c->dev_ops.find(dev);
@@ -108,8 +154,9 @@ int dyn_device_links(Dyn *d, const DevLink **out)
     auto it = d->dev_links.find(dev);
     if (it == d->dev_links.end()) {
         DevLink *p = nullptr;
-        RTB_HIP(hipMalloc((void **)&p, d->links.size() * sizeof(DevLink)));
-        RTB_HIP(hipMemcpy(p, d->links.data(), d->links.size() * sizeof(DevLink), hipMemcpyHostToDevice));
+        hipError_t e = hipMalloc((void **)&p, d->links.size() * sizeof(DevLink));
+        if (e == hipSuccess) e = hipMemcpy(p, d->links.data(), d->links.size() * sizeof(DevLink), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { if (p) (void)hipFree(p); return hip_fail(e, "link table upload"); }
         d->dev_links[dev] = p;
         it = d->dev_links.find(dev);
     }
@@ -125,8 +172,9 @@ int tree_device_groups(Tree *t, const DevGroup **out)
     auto it = t->dev_groups.find(dev);
     if (it == t->dev_groups.end()) {
         DevGroup *p = nullptr;
-        RTB_HIP(hipMalloc((void **)&p, t->groups.size() * sizeof(DevGroup)));
-        RTB_HIP(hipMemcpy(p, t->groups.data(), t->groups.size() * sizeof(DevGroup), hipMemcpyHostToDevice));
+        hipError_t e = hipMalloc((void **)&p, t->groups.size() * sizeof(DevGroup));
+        if (e == hipSuccess) e = hipMemcpy(p, t->groups.data(), t->groups.size() * sizeof(DevGroup), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { if (p) (void)hipFree(p); return hip_fail(e, "tree table upload"); }
         t->dev_groups[dev] = p;
         it = t->dev_groups.find(dev);
     }
@@ -192,13 +240,30 @@ static int check_batch(const char *fn, const void *q, int64_t N, int mem)
     if (N < 0) { set_error(std::string(fn) + ": negative N"); return RTBHIP_EINVAL; }
     if (N > 0 && q == nullptr) { set_error(std::string(fn) + ": NULL input with N > 0"); return RTBHIP_EINVAL; }
     if (mem != RTBHIP_MEM_HOST && mem != RTBHIP_MEM_DEVICE) { set_error(std::string(fn) + ": bad mem kind"); return RTBHIP_EINVAL; }
+    if (mem == RTBHIP_MEM_DEVICE && N > 0) {
+        // tables are uploaded to, and kernels launched on, the CURRENT device: a buffer of another GPU here would be a fault or a
+        // silent peer access (e.g. a tensor on cuda:1 while device 0 is current) -- refuse it
+        hipPointerAttribute_t at;
+        int cur = 0;
+        if (hipPointerGetAttributes(&at, q) == hipSuccess && hipGetDevice(&cur) == hipSuccess) {
+            if (at.type == hipMemoryTypeDevice && at.device != cur) {
+                set_error(std::string(fn) + ": the device buffer belongs to GPU " + std::to_string(at.device) + " but GPU " + std::to_string(cur) +
+                          " is current (hipSetDevice / torch.cuda.device(...) around the call)");
+                return RTBHIP_EINVAL;
+            }
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     return RTBHIP_OK;
 }
 
 static int kin_entry(const char *fn, rtbhip_chain_t h, const double *q, int64_t N, const double *base16,
                      const double *tool16, int frame, double *T, double *J, double *H, int mem, void *stream)
 {
-    Chain *c = chain_from_handle(h);
+    const std::shared_ptr<Chain> c_owner = chain_from_handle(h);
+    Chain *c = c_owner.get();
+    RTB_TRACE((std::string("rtbhip_") + fn).c_str());
     if (!c) { set_error(std::string(fn) + ": unknown chain handle"); return RTBHIP_EINVAL; }
     RTB_TRY(check_batch(fn, q, N, mem));
     if (frame != 0 && frame != 1) { set_error(std::string(fn) + ": frame must be 0 (jacob0) or 1 (jacobe)"); return RTBHIP_EINVAL; }
@@ -285,7 +350,7 @@ int rtbhip_device_count(int *count)
 int rtbhip_chain_create(const rtbhip_et *ets, int32_t m, const double *qlim, rtbhip_chain_t *chain)
 {
     if (!chain) { set_error("chain_create: NULL out"); return RTBHIP_EINVAL; }
-    std::unique_ptr<Chain> c(new Chain());
+    std::shared_ptr<Chain> c(new Chain());
     RTB_TRY(compile_chain(ets, m, qlim, c.get()));
     uint64_t h = g_next.fetch_add(1);
     std::lock_guard<std::mutex> lk(g_reg_mu);
@@ -296,7 +361,7 @@ int rtbhip_chain_create(const rtbhip_et *ets, int32_t m, const double *qlim, rtb
 
 int rtbhip_chain_destroy(rtbhip_chain_t chain)
 {
-    std::unique_ptr<Chain> c;
+    std::shared_ptr<Chain> c;             // the device tables go with the last reference (a launch in flight keeps one)
     {
         std::lock_guard<std::mutex> lk(g_reg_mu);
         auto it = g_chains.find(chain);
@@ -304,14 +369,13 @@ int rtbhip_chain_destroy(rtbhip_chain_t chain)
         c = std::move(it->second);
         g_chains.erase(it);
     }
-    for (auto &kv : c->dev_ops) (void)hipFree(kv.second);
-    for (auto &kv : c->dev_qlim) (void)hipFree(kv.second);
     return RTBHIP_OK;
 }
 
 int rtbhip_chain_info(rtbhip_chain_t chain, int32_t *n, int32_t *m, int32_t *q_width)
 {
-    Chain *c = chain_from_handle(chain);
+    const std::shared_ptr<Chain> c_owner = chain_from_handle(chain);
+    Chain *c = c_owner.get();
     if (!c) { set_error("chain_info: unknown handle"); return RTBHIP_EINVAL; }
     if (n) *n = c->n;
     if (m) *m = (int32_t)c->ets.size();
@@ -348,16 +412,66 @@ int rtbhip_hessian(rtbhip_chain_t chain, const double *q, int64_t N, const doubl
     return kin_entry("hessian", chain, q, N, nullptr, tool16, frame, nullptr, nullptr, H, mem, stream);
 }
 
+/* ETS_hessian0 / ETS_hessiane with a supplied Jacobian (core/fknm.cpp:583-783 -> _ETS_hessian core/methods.cpp:16-32) */
+int rtbhip_hessian_from_jacobian(const double *J, int64_t N, int32_t n, double *H, int32_t mem, void *stream)
+{
+    RTB_TRACE("rtbhip_hessian_from_jacobian");
+    RTB_TRY(check_batch("hessian_from_jacobian", J, N, mem));
+    if (n < 1 || n > RTBHIP_MAX_JOINTS) { set_error("hessian_from_jacobian: n must be 1..RTBHIP_MAX_JOINTS"); return RTBHIP_ELIMIT; }
+    if (N > 0 && !H) { set_error("hessian_from_jacobian: NULL H"); return RTBHIP_EINVAL; }
+    if (N == 0) return RTBHIP_OK;
+    if (mem == RTBHIP_MEM_DEVICE) {
+        if (((uintptr_t)J | (uintptr_t)H) & 15) { set_error("hessian_from_jacobian: device buffers must be 16-byte aligned"); return RTBHIP_EINVAL; }
+        return launch_hess_from_jac(n, J, N, H, (hipStream_t)stream);
+    }
+    Staging st;
+    void *dJ, *dH;
+    const size_t jb = (size_t)N * 48 * n, hb = jb * n;
+    RTB_TRY(st.in(J, jb, &dJ));
+    RTB_TRY(st.out(hb, &dH));
+    RTB_TRY(launch_hess_from_jac(n, (const double *)dJ, N, (double *)dH, nullptr));
+    RTB_HIP(hipDeviceSynchronize());
+    RTB_TRY(fetch(H, dH, hb));
+    return RTBHIP_OK;
+}
+
+/* fknm.Angle_Axis (core/fknm.cpp:112-162 -> _angle_axis core/ik.cpp:241-286), batched with broadcasting */
+int rtbhip_angle_axis(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, double *e, int32_t mem, void *stream)
+{
+    RTB_TRACE("rtbhip_angle_axis");
+    if (mem != RTBHIP_MEM_HOST && mem != RTBHIP_MEM_DEVICE) { set_error("angle_axis: bad mem kind"); return RTBHIP_EINVAL; }
+    if (nTe < 0 || nTep < 0) { set_error("angle_axis: negative count"); return RTBHIP_EINVAL; }
+    if (nTe == 0 || nTep == 0) return RTBHIP_OK;
+    const int64_t N = nTe > nTep ? nTe : nTep;
+    if ((nTe != N && nTe != 1) || (nTep != N && nTep != 1)) { set_error("angle_axis: the pose counts must be equal, or one of them 1"); return RTBHIP_EINVAL; }
+    if (!Te || !Tep || !e) { set_error("angle_axis: NULL buffer"); return RTBHIP_EINVAL; }
+    if (mem == RTBHIP_MEM_DEVICE) {
+        if (((uintptr_t)Te | (uintptr_t)Tep | (uintptr_t)e) & 15) { set_error("angle_axis: device buffers must be 16-byte aligned"); return RTBHIP_EINVAL; }
+        return launch_angle_axis(Te, nTe, Tep, nTep, N, e, (hipStream_t)stream);
+    }
+    Staging st;
+    void *dA, *dB, *dE;
+    RTB_TRY(st.in(Te, (size_t)nTe * 128, &dA));
+    RTB_TRY(st.in(Tep, (size_t)nTep * 128, &dB));
+    RTB_TRY(st.out((size_t)N * 48, &dE));
+    RTB_TRY(launch_angle_axis((const double *)dA, nTe, (const double *)dB, nTep, N, (double *)dE, nullptr));
+    RTB_HIP(hipDeviceSynchronize());
+    RTB_TRY(fetch(e, dE, (size_t)N * 48));
+    return RTBHIP_OK;
+}
+
 /* Robot.jacob0_dot / ETS.manipulability (yoshikawa) / ETS.jacobm */
 static int diff_entry(const char *fn, rtbhip_chain_t h, int mode, int axes, const double *q, const double *qd, int64_t N,
                       const double *tool16, int frame, double *out, int mem, void *stream)
 {
-    Chain *c = chain_from_handle(h);
+    const std::shared_ptr<Chain> c_owner = chain_from_handle(h);
+    Chain *c = c_owner.get();
+    RTB_TRACE((std::string("rtbhip_") + fn).c_str());
     if (!c) { set_error(std::string(fn) + ": unknown chain handle"); return RTBHIP_EINVAL; }
     RTB_TRY(check_batch(fn, q, N, mem));
     if (frame != 0 && frame != 1) { set_error(std::string(fn) + ": frame must be 0 or 1"); return RTBHIP_EINVAL; }
-    if (mode != 0 && mode != 3 && (axes & 63) == 0) { set_error(std::string(fn) + ": empty axes mask"); return RTBHIP_EINVAL; }
-    if (N > 0 && (!out || (mode == 0 && !qd))) { set_error(std::string(fn) + ": NULL qd/output"); return RTBHIP_EINVAL; }
+    if (mode != 0 && mode != 3 && mode != 4 && (axes & 63) == 0) { set_error(std::string(fn) + ": empty axes mask"); return RTBHIP_EINVAL; }
+    if (N > 0 && (!out || ((mode == 0 || mode == 4) && !qd))) { set_error(std::string(fn) + ": NULL qd/output"); return RTBHIP_EINVAL; }
     if (N == 0) return RTBHIP_OK;
     DevChain ops;
     RTB_TRY(chain_device_ops(c, &ops, nullptr));
@@ -367,9 +481,9 @@ static int diff_entry(const char *fn, rtbhip_chain_t h, int mode, int axes, cons
         return launch_kin_diff(c, ops, mode, axes, q, qd, N, tool, frame, out, (hipStream_t)stream);
     Staging st;
     void *dq, *dqd = nullptr, *dout;
-    const size_t obytes = (size_t)N * 8 * ((mode == 0 || mode == 3) ? 6 * n : (mode == 1 ? 1 : n));
+    const size_t obytes = (size_t)N * 8 * ((mode == 0 || mode == 3 || mode == 4) ? 6 * n : (mode == 1 ? 1 : n));
     RTB_TRY(st.in(q, (size_t)N * qw * 8, &dq));
-    if (mode == 0) RTB_TRY(st.in(qd, (size_t)N * qw * 8, &dqd));
+    if (mode == 0 || mode == 4) RTB_TRY(st.in(qd, (size_t)N * qw * 8, &dqd));
     RTB_TRY(st.out(obytes, &dout));
     RTB_TRY(launch_kin_diff(c, ops, mode, axes, (const double *)dq, (const double *)dqd, N, tool, frame, (double *)dout, nullptr));
     RTB_HIP(hipDeviceSynchronize());
@@ -390,6 +504,13 @@ int rtbhip_jacob0_analytical(rtbhip_chain_t chain, const double *q, int64_t N, c
     return diff_entry("jacob0_analytical", chain, 3, representation, q, nullptr, N, tool16, 0, Ja, mem, stream);
 }
 
+int rtbhip_jacob0_dot_analytical(rtbhip_chain_t chain, const double *q, const double *qd, int64_t N, const double *tool16,
+                                 int32_t representation, double *Jd, int32_t mem, void *stream)
+{
+    if (representation < 0 || representation > 3) { set_error("jacob0_dot_analytical: representation must be 0 rpy/xyz, 1 rpy/zyx, 2 eul, 3 exp"); return RTBHIP_EINVAL; }
+    return diff_entry("jacob0_dot_analytical", chain, 4, representation, q, qd, N, tool16, 0, Jd, mem, stream);
+}
+
 int rtbhip_manipulability(rtbhip_chain_t chain, const double *q, int64_t N, const double *tool16, int32_t axes_mask,
                           int32_t method, double *m, int32_t mem, void *stream)
 {
@@ -407,7 +528,9 @@ int rtbhip_jacobm(rtbhip_chain_t chain, const double *q, int64_t N, const double
 int rtbhip_link_frames(rtbhip_chain_t chain, const double *q, int64_t N, const double *base16, const int32_t *marks,
                        int32_t nmarks, double *out, int32_t mem, void *stream)
 {
-    Chain *c = chain_from_handle(chain);
+    const std::shared_ptr<Chain> c_owner = chain_from_handle(chain);
+    Chain *c = c_owner.get();
+    RTB_TRACE("rtbhip_link_frames");
     if (!c) { set_error("link_frames: unknown chain handle"); return RTBHIP_EINVAL; }
     if (mem != RTBHIP_MEM_HOST && mem != RTBHIP_MEM_DEVICE) { set_error("link_frames: bad mem kind"); return RTBHIP_EINVAL; }
     if (N < 0) { set_error("link_frames: negative N"); return RTBHIP_EINVAL; }
@@ -454,7 +577,9 @@ static int pool_keep_cached()
 int rtbhip_partial_fkine0(rtbhip_chain_t chain, const double *q, int64_t N, const double *tool16, int32_t order,
                           double *out, int32_t mem, void *stream)
 {
-    Chain *c = chain_from_handle(chain);
+    const std::shared_ptr<Chain> c_owner = chain_from_handle(chain);
+    Chain *c = c_owner.get();
+    RTB_TRACE("rtbhip_partial_fkine0");
     if (!c) { set_error("partial_fkine0: unknown chain handle"); return RTBHIP_EINVAL; }
     RTB_TRY(check_batch("partial_fkine0", q, N, mem));
     if (order < 3 || order > kPartialMaxOrder) { set_error("partial_fkine0: order must be 3.." + std::to_string(kPartialMaxOrder)); return RTBHIP_EINVAL; }
@@ -516,7 +641,9 @@ int rtbhip_ik_lm_nullspace(rtbhip_chain_t chain, const double *Tep, int64_t N, c
                            int32_t *success, int32_t *iters, int32_t *searches, double *residual,
                            int32_t mem, void *stream)
 {
-    Chain *c = chain_from_handle(chain);
+    const std::shared_ptr<Chain> c_owner = chain_from_handle(chain);
+    Chain *c = c_owner.get();
+    RTB_TRACE("rtbhip_ik_lm");
     if (!c) { set_error("ik_lm: unknown chain handle"); return RTBHIP_EINVAL; }
     RTB_TRY(check_batch("ik_lm", Tep, N, mem));
     if (method < 0 || method > 4) { set_error("ik_lm: method must be 0 chan, 1 wampler, 2 sugihara, 3 gauss-newton, 4 newton-raphson"); return RTBHIP_EINVAL; }
@@ -561,7 +688,8 @@ int rtbhip_ik_lm_nullspace(rtbhip_chain_t chain, const double *Tep, int64_t N, c
 
 int rtbhip_ik_restart(rtbhip_chain_t chain, uint64_t seed, int64_t target, int32_t search, double *q_n)
 {
-    Chain *c = chain_from_handle(chain);
+    const std::shared_ptr<Chain> c_owner = chain_from_handle(chain);
+    Chain *c = c_owner.get();
     if (!c || !q_n) { set_error("ik_restart: bad argument"); return RTBHIP_EINVAL; }
     ik_restart_host(c, seed, target, search, q_n);
     return RTBHIP_OK;
@@ -572,7 +700,7 @@ int rtbhip_dyn_create(const double *L24, int32_t n, int32_t mdh, rtbhip_dyn_t *d
     if (!L24 || !dyn || n < 1) { set_error("dyn_create: bad argument"); return RTBHIP_EINVAL; }
     if (n > RTBHIP_MAX_JOINTS) { set_error("dyn_create: more than RTBHIP_MAX_JOINTS links"); return RTBHIP_ELIMIT; }
     if (mdh != 0 && mdh != 1) { set_error("dyn_create: mdh must be 0 or 1"); return RTBHIP_EINVAL; }
-    std::unique_ptr<Dyn> d(new Dyn());
+    std::shared_ptr<Dyn> d(new Dyn());
     d->n = n;
     d->mdh = mdh;
     d->links.resize(n);
@@ -601,7 +729,7 @@ int rtbhip_dyn_create(const double *L24, int32_t n, int32_t mdh, rtbhip_dyn_t *d
 
 int rtbhip_dyn_destroy(rtbhip_dyn_t dyn)
 {
-    std::unique_ptr<Dyn> d;
+    std::shared_ptr<Dyn> d;
     {
         std::lock_guard<std::mutex> lk(g_reg_mu);
         auto it = g_dyns.find(dyn);
@@ -609,14 +737,15 @@ int rtbhip_dyn_destroy(rtbhip_dyn_t dyn)
         d = std::move(it->second);
         g_dyns.erase(it);
     }
-    for (auto &kv : d->dev_links) (void)hipFree(kv.second);
     return RTBHIP_OK;
 }
 
 int rtbhip_rne(rtbhip_dyn_t dyn, const double *q, const double *qd, const double *qdd, int64_t N,
                const double *grav3, const double *fext6, double *tau, int32_t mem, void *stream)
 {
-    Dyn *d = dyn_from_handle(dyn);
+    const std::shared_ptr<Dyn> d_owner = dyn_from_handle(dyn);
+    Dyn *d = d_owner.get();
+    RTB_TRACE("rtbhip_rne");
     if (!d) { set_error("rne: unknown dyn handle"); return RTBHIP_EINVAL; }
     RTB_TRY(check_batch("rne", q, N, mem));
     if (!grav3) { set_error("rne: NULL gravity"); return RTBHIP_EINVAL; }
@@ -643,7 +772,7 @@ int rtbhip_rne(rtbhip_dyn_t dyn, const double *q, const double *qd, const double
 int rtbhip_tree_create(const rtbhip_tree_group *groups, int32_t ng, rtbhip_tree_t *tree)
 {
     if (!tree) { set_error("tree_create: NULL handle pointer"); return RTBHIP_EINVAL; }
-    std::unique_ptr<Tree> t(new Tree());
+    std::shared_ptr<Tree> t(new Tree());
     RTB_TRY(compile_tree(groups, ng, t.get()));
     const uint64_t h = g_next.fetch_add(1);
     std::lock_guard<std::mutex> lk(g_reg_mu);
@@ -654,7 +783,7 @@ int rtbhip_tree_create(const rtbhip_tree_group *groups, int32_t ng, rtbhip_tree_
 
 int rtbhip_tree_destroy(rtbhip_tree_t tree)
 {
-    std::unique_ptr<Tree> t;
+    std::shared_ptr<Tree> t;
     {
         std::lock_guard<std::mutex> lk(g_reg_mu);
         auto it = g_trees.find(tree);
@@ -662,14 +791,15 @@ int rtbhip_tree_destroy(rtbhip_tree_t tree)
         t = std::move(it->second);
         g_trees.erase(it);
     }
-    for (auto &kv : t->dev_groups) (void)hipFree(kv.second);
     return RTBHIP_OK;
 }
 
 int rtbhip_tree_rne(rtbhip_tree_t tree, const double *q, const double *qd, const double *qdd, int64_t N,
                     const double *gravity3, double *tau, int32_t mem, void *stream)
 {
-    Tree *t = tree_from_handle(tree);
+    const std::shared_ptr<Tree> t_owner = tree_from_handle(tree);
+    Tree *t = t_owner.get();
+    RTB_TRACE("rtbhip_tree_rne");
     if (!t) { set_error("tree_rne: unknown tree handle"); return RTBHIP_EINVAL; }
     RTB_TRY(check_batch("tree_rne", q, N, mem));
     if (!gravity3) { set_error("tree_rne: NULL gravity"); return RTBHIP_EINVAL; }
@@ -697,7 +827,9 @@ int rtbhip_tree_rne(rtbhip_tree_t tree, const double *q, const double *qd, const
 static int dyn_entry(const char *fn, rtbhip_dyn_t dyn, int mode, const double *q, const double *qd, const double *tq,
                      int64_t N, const double *grav3, double *out, int32_t mem, void *stream)
 {
-    Dyn *d = dyn_from_handle(dyn);
+    const std::shared_ptr<Dyn> d_owner = dyn_from_handle(dyn);
+    Dyn *d = d_owner.get();
+    RTB_TRACE((std::string("rtbhip_") + fn).c_str());
     if (!d) { set_error(std::string(fn) + ": unknown dyn handle"); return RTBHIP_EINVAL; }
     RTB_TRY(check_batch(fn, q, N, mem));
     if (N > 0 && !out) { set_error(std::string(fn) + ": NULL output"); return RTBHIP_EINVAL; }
@@ -743,6 +875,7 @@ int rtbhip_fleet_fkine_jacob(const rtbhip_chain_t *chains, int32_t n_chains, con
                              int32_t mem, void *stream)
 {
     if (n_chains < 0 || (n_chains > 0 && (!chains || !q || !N || !T || !J))) { set_error("fleet: bad argument"); return RTBHIP_EINVAL; }
+    RTB_TRACE("rtbhip_fleet_fkine_jacob");
     if (frame != 0 && frame != 1) { set_error("fleet: frame must be 0 or 1"); return RTBHIP_EINVAL; }
     if (mem != RTBHIP_MEM_HOST && mem != RTBHIP_MEM_DEVICE) { set_error("fleet: bad mem kind"); return RTBHIP_EINVAL; }
     std::vector<FleetEntry> entries;
@@ -750,7 +883,8 @@ int rtbhip_fleet_fkine_jacob(const rtbhip_chain_t *chains, int32_t n_chains, con
     std::vector<void *> dT(n_chains, nullptr), dJ(n_chains, nullptr);
     int64_t tile0 = 0;
     for (int i = 0; i < n_chains; i++) {
-        Chain *c = chain_from_handle(chains[i]);
+        const std::shared_ptr<Chain> c_owner = chain_from_handle(chains[i]);
+        Chain *c = c_owner.get();
         if (!c) { set_error("fleet: unknown chain handle"); return RTBHIP_EINVAL; }
         if (N[i] < 0) { set_error("fleet: negative N"); return RTBHIP_EINVAL; }
         if (N[i] == 0) continue;
@@ -777,7 +911,8 @@ int rtbhip_fleet_fkine_jacob(const rtbhip_chain_t *chains, int32_t n_chains, con
         RTB_HIP(hipDeviceSynchronize());
         for (int i = 0; i < n_chains; i++) {
             if (N[i] == 0) continue;
-            Chain *c = chain_from_handle(chains[i]);
+            const std::shared_ptr<Chain> c_owner = chain_from_handle(chains[i]);
+            Chain *c = c_owner.get();
             RTB_TRY(fetch(T[i], dT[i], (size_t)N[i] * 128));
             RTB_TRY(fetch(J[i], dJ[i], (size_t)N[i] * 48 * c->n));
         }

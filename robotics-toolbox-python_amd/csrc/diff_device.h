@@ -186,6 +186,39 @@ RTB_HD void jacob_analytical(const Pose &P, const double (&jac)[6 * NJ], int rep
     }
 }
 
+// Rate of the analytical Jacobian as the reference computes it (kin_kernels.hip, mode kDiffAnalyticalDot): forward differences
+// of jacob0_analytical, dx = 1e-8, contracted with qd.  n + 1 chain walks; the loop over joints is a real loop (one copy of
+// the walk), so the chain pointers are re-derived per pass on the device -- hoisted, its scalar loads overflow the SGPR file.
+template <int NJ, class CV, class TL>
+RTB_HD void jacob_analytical_dot(const CV &cv, TL tail, const double (&qv)[NJ], const double (&v)[NJ], int rep, double (&jd)[6 * NJ])
+{
+    constexpr double dx = 1e-8;                               // spatialmath.base.numhess default
+    Pose P;
+    double jac[6 * NJ], ja0[6 * NJ];
+    reg_core<NJ, true>(cv, tail, 0, qv, P, jac);
+    jacob_analytical<NJ>(P, jac, rep, ja0);
+#pragma unroll
+    for (int k = 0; k < 6 * NJ; ++k) jd[k] = 0.0;
+#pragma nounroll
+    for (int i = 0; i < NJ; ++i) {
+        double q2[NJ], vi = 0.0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            q2[j] = qv[j] + (j == i ? dx : 0.0);              // x + I[:, i] * dx
+            vi = j == i ? v[j] : vi;
+        }
+        double ja[6 * NJ];
+        CV cvi = cv;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+s"(cvi.seg), "+s"(cvi.jmeta));
+#endif
+        reg_core<NJ, true>(cvi, tail, 0, q2, P, jac);
+        jacob_analytical<NJ>(P, jac, rep, ja);
+#pragma unroll
+        for (int k = 0; k < 6 * NJ; ++k) jd[k] += ((ja[k] - ja0[k]) / dx) * vi;   // Hi = (Ji - J0) / dx ; Jd += Hi * qd[i]
+    }
+}
+
 // jacobm given the LDL^T factorisation (B, dinv) of the masked J J^T
 template <int NJ>
 RTB_HD void jacobm_factored(const double (&jac)[6 * NJ], int axes, const double (&B)[6][6], const double (&dinv)[6], double (&jm)[NJ])

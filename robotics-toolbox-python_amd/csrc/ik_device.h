@@ -137,9 +137,25 @@ RTB_HD void ik_lm_step(const double (&jac)[6 * NJ], const double (&e)[6], W we /
 // Deviation, covered by the statistical IK acceptance of SURVEY 8c: at a rank-deficient J the reference's
 // SVD truncates a singular value (GN) or divides by s^2 = 0 (NR), and GN's QR branch on a redundant arm
 // returns a basic rather than the minimum-norm solution; the search simply fails or restarts here.
-template <int NJ>
-RTB_HD void ik_pinv_step(const double (&jac)[6 * NJ], const double (&e)[6], int rows, double damping, double (&dq)[NJ])
+// When the used rows outnumber the joints (a 4- or 5-joint arm with a full mask) J_a has full COLUMN rank instead and
+// J_a J_a^T is singular; the pseudo-inverse step is then the least-squares one,  (J_a^T W J_a + d^2 I) dq = J_a^T W e_a
+// (W = the mask weights for GN -- they matter here --, 1 for NR; what the reference's SVD / damped pseudo-inverse return),
+// an n x n system: ik_lm_step with the damping in place of the LM term.
+template <int NJ, class W>
+RTB_HD void ik_pinv_step(const double (&jac)[6 * NJ], const double (&e)[6], int rows, double damping, W we, bool weighted, double (&dq)[NJ])
 {
+    if constexpr (NJ < 6) {
+        int used = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) used += (rows >> r) & 1;
+        if (used > NJ) {                                       // wave-uniform
+            double w[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) w[r] = ((rows >> r) & 1) ? (weighted ? we[r] : 1.0) : 0.0;
+            ik_lm_step<NJ>(jac, e, &w[0], damping * damping, dq);
+            return;
+        }
+    }
     double B[6][6], y[6], g[6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
@@ -169,8 +185,8 @@ RTB_HD void ik_pinv_step(const double (&jac)[6 * NJ], const double (&e)[6], int 
 // the influence distance pi, minimum distance ps)  +  jacobm(q) / km  (manipulability), projected with I - pinv(J) J.
 // As in the reference the projection -- and with it the whole term -- is applied only when kq > 0 (its guard reads
 // `lambda_Sigma > 0 or lambda_Sigma > 0`).  For a J of full row rank  I - pinv(J) J = I - J^T (J J^T)^-1 J: the 6x6
-// factorisation is shared with jacobm.  Chains of fewer than 6 joints have full column rank away from singularities,
-// where the projector is zero: those never come here.
+// factorisation is shared with jacobm.  Chains of fewer than 6 joints (projector zero away from singularities, not at
+// them) are refused by launch_ik when kq > 0 and never come here.
 template <int NJ, class PD, class QL, class QA>
 RTB_HD void ik_qnull(const double (&jac)[6 * NJ], const PD &p, QL qlim, QA qa, double (&qn)[NJ])
 {
@@ -255,6 +271,15 @@ RTB_HD int ik_s_last(const PD &p)
     return p.flavour == 0 ? sl : sl - 1;
 }
 
+// Watchdog budget of a wave, in loop iterations: the longest a correct run can go without resolving any of its targets.
+// The slowest first resolution is a slot whose searches all fail and run one after another on one lane: s_last + 1 searches
+// of up to ilimit + 1 iterations, each followed by a wait of up to pass_mask iterations for the next scheduling pass.
+template <class PD>
+RTB_HD long long ik_patience(const PD &p, int s_last)
+{
+    return (long long)(p.ilimit + 2 + p.pass_mask) * (s_last + 3) + 64;
+}
+
 template <class TDPut>
 RTB_HD void ik_load_target(TDPut tdput, const double *Tep16)
 {
@@ -335,7 +360,7 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, Q
 #pragma unroll
             for (int k = 0; k < 6; ++k) rows |= (p.we[k] != 0.0) ? (1 << k) : 0;
         }
-        ik_pinv_step<NJ>(jac, e, rows, p.method == 4 ? p.lambda : 0.0, dq);
+        ik_pinv_step<NJ>(jac, e, rows, p.method == 4 ? p.lambda : 0.0, &p.we[0], p.method == 3, dq);
     } else {
         const double wn = (p.method == 1) ? p.lambda : (p.method == 2) ? E + p.lambda : p.lambda * E;   // ik.cpp:169,183,205
         ik_lm_step<NJ>(jac, e, &p.we[0], wn, dq);

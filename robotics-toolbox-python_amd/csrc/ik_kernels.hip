@@ -62,8 +62,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
     unsigned long long pool_next = 0, pool_end = 0;   // wave-uniform: targets reserved by this wave and not started yet
     bool first = true;
     unsigned tick = 0;
-    // watchdog: a correct run resolves some slot at least every (ilimit+2)*(searches+2) iterations
-    const long long patience = (long long)(p.ilimit + 2) * (s_last + 3) + 64;
+    const long long patience = ik_patience(p, s_last);    // watchdog budget (ik_device.h), the pass latency included
     long long quiet = 0;
     for (;;) {
         asm volatile("" : "+s"(ka));
@@ -246,7 +245,12 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
     p.seed = ip.seed;
     p.N = N;
     p.kq = ip.kq; p.km = ip.km; p.ps = ip.ps; p.pi = ip.pi;
-    if (p.kq > 0.0 && c->n > kRegMaxJoints) { set_error("ik_lm: null-space terms are built for chains of up to 8 joints"); return RTBHIP_ELIMIT; }
+    if (p.kq > 0.0 && (c->n > kRegMaxJoints || c->n < 6)) {
+        // below 6 joints I - pinv(J) J vanishes only away from singularities; the reference still applies it there, so the
+        // parameters are refused rather than silently dropped
+        set_error("ik_lm: null-space terms (kq > 0) are built for chains of 6..8 joints");
+        return RTBHIP_ELIMIT;
+    }
     int dev = 0, cus = 0;
     RTB_HIP(hipGetDevice(&dev));
     if (device_cu_count(&cus) != RTBHIP_OK) return RTBHIP_EHIP;

@@ -11,6 +11,7 @@
 // (520 B for the Panda), ~0.6 kflop of fp64 VALU + n sincos per configuration.
 #include "kin_reg.h"
 #include "diff_device.h"
+#include "servo_device.h"
 #include <algorithm>
 #include <cstring>
 
@@ -161,6 +162,35 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints ? 2 : 1)) void k_kin_he
     });
 }
 
+// The tile's Hessians from the lanes' finished Jacobians (registers): R rounds, in round r the 64/R lanes of group r
+// expand theirs (compile-time indices) into whole (n,6,n) rows of the LDS tile, which the full wave writes as one
+// contiguous run.  Shared by k_kin_hess_tile (J from the chain walk) and k_hess_from_jac (J supplied by the caller).
+template <int NJ, int R>
+__device__ __forceinline__ void hess_tile_emit(double (&jac)[6 * NJ], double *buf, int lane, int ncfg, double *__restrict__ Hrun)
+{
+    constexpr int HW = NJ * 6 * NJ, S = HW | 1, G = kWave / R;
+    const int grp = lane / G;
+    double *mine = buf + (lane - grp * G) * S;
+    for (int r = 0; r < R; ++r) {
+        const int cnt = ncfg - r * G < G ? ncfg - r * G : G;
+        if (cnt <= 0) break;                                         // wave-uniform
+        if (grp == r) {
+            // the expansion must stay inside its round: hoisted out of the loop it would hold all 6 n^2 entries in registers
+#pragma unroll
+            for (int k = 0; k < 6 * NJ; ++k) asm volatile("" : "+v"(jac[k]));
+            hessian_from_jacobian(NJ, [&](int k) { return jac[k]; }, [&](int idx, double v) { mine[idx] = v; });
+        }
+        __syncthreads();
+        double *dst = Hrun + (int64_t)(r * G) * HW;
+        flush_rows<HW>(buf, S, cnt, lane, [&](int f, double a, double b) {
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            v2d w = {a, b};
+            __builtin_nontemporal_store(w, reinterpret_cast<v2d *>(dst + f));
+        });
+        __syncthreads();
+    }
+}
+
 // Variant B (A/B knob hess_mode = 1): every lane forms the (6,n) block H[j] of its OWN configuration in
 // registers (static indexing, no per-entry LDS gathers), the wave transposes the 64 blocks through LDS and
 // writes them as 64 segments of 48n bytes (2352-byte stride between configurations), one round per j.
@@ -178,30 +208,10 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && R >= 8 ? 2 : 1)) voi
     const int64_t cfg0 = (int64_t)blockIdx.x * kWave;     // (the XCD-contiguous mapping of k_kin_reg costs this kernel 3 %)
     const int64_t left = kp.N - cfg0;
     const int ncfg = left < kWave ? (int)left : kWave;
-    constexpr int HW = NJ * 6 * NJ, S = HW | 1, G = kWave / R;
     Pose P;
     double jac[6 * NJ];
     reg_compute<NJ, true>(kp, cv, q, cfg0 + lane, P, jac);
-    const int grp = lane / G;
-    double *mine = buf + (lane - grp * G) * S;
-    for (int r = 0; r < R; ++r) {
-        const int cnt = ncfg - r * G < G ? ncfg - r * G : G;
-        if (cnt <= 0) break;                                         // wave-uniform
-        if (grp == r) {
-            // the expansion must stay inside its round: hoisted out of the loop it would hold all 6 n^2 entries in registers
-#pragma unroll
-            for (int k = 0; k < 6 * NJ; ++k) asm volatile("" : "+v"(jac[k]));
-            hessian_from_jacobian(NJ, [&](int k) { return jac[k]; }, [&](int idx, double v) { mine[idx] = v; });
-        }
-        __syncthreads();
-        double *dst = H + (cfg0 + r * G) * (int64_t)HW;
-        flush_rows<HW>(buf, S, cnt, lane, [&](int f, double a, double b) {
-            typedef double v2d __attribute__((ext_vector_type(2)));
-            v2d w = {a, b};
-            __builtin_nontemporal_store(w, reinterpret_cast<v2d *>(dst + f));
-        });
-        __syncthreads();
-    }
+    hess_tile_emit<NJ, R>(jac, buf, lane, ncfg, H + cfg0 * (int64_t)(NJ * 6 * NJ));
 }
 template <int NJ, int R>
 static hipError_t launch_hess_tile(dim3 grid, hipStream_t s, const KinParams &kp, const DevChain &dc, const double *q, double *H)
@@ -225,12 +235,126 @@ static hipError_t launch_hess_nj(dim3 grid, hipStream_t s, const KinParams &kp, 
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- Hessian from a SUPPLIED Jacobian
+// ETS_hessian0 / ETS_hessiane as the reference binds them take (ets, q, J, tool) and, when J is given, only run
+// _ETS_hessian on it (core/fknm.cpp:583-783 -> core/methods.cpp:16-32): a pure function of J.  The tile's 64 Jacobians
+// arrive as one contiguous run through LDS, every lane picks its own up into registers, then the same tile emission as
+// k_kin_hess_tile.  Bytes: 48 n read + 48 n^2 written per Jacobian; HBM-bound.
+template <int NJ, int R>
+__global__ __launch_bounds__(kWave, 1) void k_hess_from_jac(const double *__restrict__ J, int64_t N, double *__restrict__ H)
+{
+    extern __shared__ __attribute__((aligned(16))) double buf[];
+    constexpr int W = 6 * NJ;
+    const int lane = threadIdx.x;
+    const int64_t cfg0 = (int64_t)blockIdx.x * kWave;
+    const int64_t left = N - cfg0;
+    const int ncfg = left < kWave ? (int)left : kWave;
+    hj_load_tile(J + cfg0 * W, W, ncfg, buf, lane);
+    __syncthreads();
+    double jac[W];
+    const double *mine = buf + lane * (W + 1);
+#pragma unroll
+    for (int k = 0; k < W; ++k) jac[k] = lane < ncfg ? mine[k] : 0.0;
+    __syncthreads();
+    hess_tile_emit<NJ, R>(jac, buf, lane, ncfg, H + cfg0 * (int64_t)(NJ * W));
+}
+
+// run-time n (chains of more than 10 joints): one lane per Jacobian, straight from and to global memory
+__global__ __launch_bounds__(kWave) void k_hess_from_jac_any(int n, const double *__restrict__ J, int64_t N, double *__restrict__ H)
+{
+    const int64_t cfg = (int64_t)blockIdx.x * kWave + threadIdx.x;
+    if (cfg >= N) return;
+    const double *Jr = J + cfg * (int64_t)(6 * n);
+    double *Hr = H + cfg * (int64_t)(6 * n * n);
+    hessian_from_jacobian(n, [&](int k) { return Jr[k]; }, [&](int idx, double v) { Hr[idx] = v; });
+}
+
+template <int NJ>
+static hipError_t launch_hess_from_jac_nj(dim3 grid, hipStream_t s, const double *J, int64_t N, double *H)
+{
+    constexpr int R = 4;
+    const size_t a = (size_t)(kWave / R) * ((NJ * 6 * NJ) | 1), b = (size_t)kWave * (6 * NJ + 1);
+    const size_t lds = (a > b ? a : b) * sizeof(double);
+    auto k = k_hess_from_jac<NJ, R>;
+    if (lds > 48 * 1024) { hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL(k, grid, dim3(kWave), lds, s, J, N, H);
+    note_launch((int)grid.x, kWave, (int)lds);
+    return hipGetLastError();
+}
+
+int launch_hess_from_jac(int n, const double *J, int64_t N, double *H, hipStream_t s)
+{
+    if (N == 0) return RTBHIP_OK;
+    if (n < 1 || n > RTBHIP_MAX_JOINTS) { set_error("hessian_from_jacobian: n must be 1..32"); return RTBHIP_ELIMIT; }
+    const int64_t tiles = (N + kWave - 1) / kWave;
+    if (tiles > 0x7fffffff) { set_error("hessian_from_jacobian: batch too large for one launch"); return RTBHIP_ELIMIT; }
+    dim3 grid((unsigned)tiles);
+    hipError_t e = hipSuccess;
+    switch (n) {
+    case 1: e = launch_hess_from_jac_nj<1>(grid, s, J, N, H); break;
+    case 2: e = launch_hess_from_jac_nj<2>(grid, s, J, N, H); break;
+    case 3: e = launch_hess_from_jac_nj<3>(grid, s, J, N, H); break;
+    case 4: e = launch_hess_from_jac_nj<4>(grid, s, J, N, H); break;
+    case 5: e = launch_hess_from_jac_nj<5>(grid, s, J, N, H); break;
+    case 6: e = launch_hess_from_jac_nj<6>(grid, s, J, N, H); break;
+    case 7: e = launch_hess_from_jac_nj<7>(grid, s, J, N, H); break;
+    case 8: e = launch_hess_from_jac_nj<8>(grid, s, J, N, H); break;
+    case 9: e = launch_hess_from_jac_nj<9>(grid, s, J, N, H); break;
+    case 10: e = launch_hess_from_jac_nj<10>(grid, s, J, N, H); break;
+    default:
+        hipLaunchKernelGGL(k_hess_from_jac_any, grid, dim3(kWave), 0, s, n, J, N, H);
+        note_launch((int)grid.x, kWave, 0);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) return hip_fail(e, "k_hess_from_jac launch");
+    return RTBHIP_OK;
+}
+
+// ---------------------------------------------------------------- fknm.Angle_Axis, batched
+// e[i] = angle_axis(Te[i or 0], Tep[i or 0]) (core/fknm.cpp:112-162 -> core/ik.cpp:241-286).  256 B in, 48 B out per
+// pair; both tiles through LDS as contiguous runs; a broadcast operand (count 1) is read by every lane from the same
+// 128 bytes.  LDS: 64 x 17 doubles per operand, the first re-used for the 64 x 7 staging of e.
+__global__ __launch_bounds__(kWave) void k_angle_axis(const double *__restrict__ Te, int te_each, const double *__restrict__ Tep, int tep_each,
+                                                     int64_t N, double *__restrict__ e)
+{
+    __shared__ __attribute__((aligned(16))) double a[kWave * kAaStride];
+    __shared__ __attribute__((aligned(16))) double b[kWave * kAaStride];
+    const int lane = threadIdx.x;
+    const int64_t cfg0 = (int64_t)xcd_tile() * kWave;
+    const int64_t left = N - cfg0;
+    const int ncfg = left < kWave ? (int)left : kWave;
+    if (te_each) aa_load_tile(Te + cfg0 * 16, ncfg, a, lane); else aa_load_tile(Te, 1, a, lane);
+    if (tep_each) aa_load_tile(Tep + cfg0 * 16, ncfg, b, lane); else aa_load_tile(Tep, 1, b, lane);
+    __syncthreads();
+    double te16[12], tep16[12];
+    const int la = te_each ? (lane < ncfg ? lane : 0) : 0, lb = tep_each ? (lane < ncfg ? lane : 0) : 0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { te16[k] = a[la * kAaStride + k]; tep16[k] = b[lb * kAaStride + k]; }
+    __syncthreads();
+    aa_lane(te16, tep16, a + lane * 7);
+    __syncthreads();
+    kin_flush(a, 7, 6, ncfg, e + cfg0 * 6, lane);
+}
+
+int launch_angle_axis(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, int64_t N, double *e, hipStream_t s)
+{
+    if (N == 0) return RTBHIP_OK;
+    const int64_t tiles = (N + kWave - 1) / kWave;
+    if (tiles > 0x7fffffff) { set_error("angle_axis: batch too large for one launch"); return RTBHIP_ELIMIT; }
+    hipLaunchKernelGGL(k_angle_axis, dim3((unsigned)tiles), dim3(kWave), 0, s, Te, nTe == N ? 1 : 0, Tep,
+                       nTep == N ? 1 : 0, N, e);
+    note_launch((int)tiles, kWave, (int)(2 * kWave * kAaStride * sizeof(double)));
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return hip_fail(err, "k_angle_axis launch");
+    return RTBHIP_OK;
+}
+
 // ---------------------------------------------------------------- differential-kinematics consumers (n <= 8)
 // jacob0_dot / manipulability / jacobm straight from the register-resident Jacobian: the (n,6,n) Hessian
 // the reference materialises for each of them (robot/Robot.py:1069, robot/ETS.py:1671) never exists.
-enum { kDiffJdot = 0, kDiffManip = 1, kDiffJacobm = 2, kDiffAnalytical = 3 };
+enum { kDiffJdot = 0, kDiffManip = 1, kDiffJacobm = 2, kDiffAnalytical = 3, kDiffAnalyticalDot = 4 };
 template <int NJ, int MODE>
-__global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints ? 2 : 1)) void k_kin_diff(KinParams kp, DevChain dc, int axes, const double *__restrict__ q,
+__global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && MODE != 4 ? 2 : 1)) void k_kin_diff(KinParams kp, DevChain dc, int axes, const double *__restrict__ q,
                                                        const double *__restrict__ qd, double *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) double buf[];
@@ -241,6 +365,33 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints ? 2 : 1)) void k_kin_di
     const int ncfg = left < kWave ? (int)left : kWave;
     Pose P;
     double jac[6 * NJ];
+    if constexpr (MODE == kDiffAnalyticalDot) {
+        // Robot.jacob0_dot with an orientation `representation` (robot/Robot.py:1065-1098): the reference has no closed form
+        // ("not actually sure this can be written in closed form") and takes  H = numhess(jacob0_analytical, q)  -- spatialmath's
+        // FORWARD difference  H[i] = (Ja(q + dx e_i) - Ja(q)) / dx,  dx = 1e-8 -- then  Jd = tensordot(H, qd, (0, 0)).  Restated
+        // as it stands (a drop-in returns the reference's numbers, truncation error included): n + 1 chain walks per lane,
+        // everything in registers.
+        const bool live = cfg < kp.N;
+        double qv[NJ], v[NJ], jd[6 * NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int col = jm_jq(cv.jmeta[j]);
+            qv[j] = live ? q[cfg * kp.qw + col] : 0.0;
+            v[j] = live ? qd[cfg * kp.qw + col] : 0.0;
+        }
+        jacob_analytical_dot<NJ>(cv, kp.tail, qv, v, axes, jd);
+        constexpr int W = 6 * NJ;
+#pragma unroll
+        for (int r = 0; r < kWave / kJRound; ++r) {
+            if (lane / kJRound == r) reg_stage_J<NJ>(jd, buf, lane % kJRound);
+            __syncthreads();
+            int rows = ncfg - r * kJRound;
+            rows = rows < 0 ? 0 : (rows > kJRound ? kJRound : rows);
+            kin_flush(buf, W + 1, W, rows, out + (cfg0 + r * kJRound) * W, lane);
+            __syncthreads();
+        }
+        return;
+    }
     reg_compute<NJ, true>(kp, cv, q, cfg, P, jac);
     if (MODE == kDiffJdot || MODE == kDiffAnalytical) {
         double jd[6 * NJ];
@@ -285,6 +436,7 @@ static hipError_t launch_diff_nj(int mode, dim3 grid, size_t lds, hipStream_t s,
     if (mode == kDiffJdot) hipLaunchKernelGGL((k_kin_diff<NJ, kDiffJdot>), grid, dim3(kWave), lds, s, kp, dc, axes, q, qd, out);
     else if (mode == kDiffManip) hipLaunchKernelGGL((k_kin_diff<NJ, kDiffManip>), grid, dim3(kWave), lds, s, kp, dc, axes, q, qd, out);
     else if (mode == kDiffAnalytical) hipLaunchKernelGGL((k_kin_diff<NJ, kDiffAnalytical>), grid, dim3(kWave), lds, s, kp, dc, axes, q, qd, out);
+    else if (mode == kDiffAnalyticalDot) hipLaunchKernelGGL((k_kin_diff<NJ, kDiffAnalyticalDot>), grid, dim3(kWave), lds, s, kp, dc, axes, q, qd, out);
     else hipLaunchKernelGGL((k_kin_diff<NJ, kDiffJacobm>), grid, dim3(kWave), lds, s, kp, dc, axes, q, qd, out);
     return hipGetLastError();
 }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -48,6 +49,7 @@ struct Chain {
     std::map<int, void *> dev_ops;     // per-device upload: [seg | jmeta]
     std::map<int, double *> dev_qlim;  // per-device upload of qlim
     std::mutex mu;
+    ~Chain();                          // frees the per-device uploads (runs when the last user lets go, see *_from_handle)
 };
 
 // Host-side dynamics object behind an rtbhip_dyn_t handle.
@@ -67,6 +69,7 @@ struct Dyn {
     int n = 0, mdh = 0;
     std::map<int, DevLink *> dev_links;
     std::mutex mu;
+    ~Dyn();
 };
 
 // Host-side dynamics tree behind an rtbhip_tree_t handle (tree.cpp, tree_device.h).
@@ -76,9 +79,10 @@ struct Tree {
     int n = 0, nslots = 0;
     std::map<int, DevGroup *> dev_groups;
     std::mutex mu;
+    ~Tree();
 };
 int compile_tree(const rtbhip_tree_group *groups, int ng, Tree *out);
-Tree *tree_from_handle(rtbhip_tree_t h);
+std::shared_ptr<Tree> tree_from_handle(rtbhip_tree_t h);
 int tree_device_groups(Tree *t, const DevGroup **out);
 int launch_tree_rne(const Tree *t, const DevGroup *groups, const double *q, const double *qd, const double *qdd, int64_t N,
                     const double *grav3, double *tau, hipStream_t s);
@@ -92,8 +96,10 @@ int hip_fail(hipError_t e, const char *what);
         if (_e != hipSuccess) return ::rtbhip::hip_fail(_e, #call); \
     } while (0)
 
-Chain *chain_from_handle(rtbhip_chain_t h);
-Dyn *dyn_from_handle(rtbhip_dyn_t h);
+// Handle lookups hand out SHARED ownership: a destroy racing with a launch on another thread only drops the registry's
+// reference, the object (and its device tables) lives until the last call using it returns.
+std::shared_ptr<Chain> chain_from_handle(rtbhip_chain_t h);
+std::shared_ptr<Dyn> dyn_from_handle(rtbhip_dyn_t h);
 int chain_device_ops(Chain *c, DevChain *out, const double **qlim_out);
 DevChain chain_host_view(const Chain *c);
 int dyn_device_links(Dyn *d, const DevLink **out);
@@ -111,6 +117,9 @@ int launch_kin(const Chain *c, const DevChain &dc, const double *q, int64_t N, c
 
 int launch_kin_diff(const Chain *c, const DevChain &dc, int mode, int axes, const double *q, const double *qd, int64_t N,
                     const Affine &tool, int frame, double *out, hipStream_t s);
+
+int launch_hess_from_jac(int n, const double *J, int64_t N, double *H, hipStream_t s);
+int launch_angle_axis(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, int64_t N, double *e, hipStream_t s);
 
 struct FrameTable;
 int compile_frames(const Chain *c, const int32_t *marks, int nmarks, FrameTable *ft);

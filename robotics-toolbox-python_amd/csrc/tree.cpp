@@ -73,4 +73,6 @@ int compile_tree(const rtbhip_tree_group *in, int ng, Tree *out)
     return RTBHIP_OK;
 }
 
+Tree::~Tree() { for (auto &kv : dev_groups) (void)hipFree(kv.second); }
+
 }  // namespace rtbhip

@@ -6,12 +6,14 @@ Only the hot path named in BASELINE.json / SURVEY.md section 8 is here:
   DHLink / DHRobot    fkine, jacob0/e, rne, gravload, itorque, inertia, coriolis, accel (+ the ETS pass-throughs)
   Link / ERobot       ETS robots (link trees): rne
   urdf                plain-URDF loader + the reference's URDF -> ETS lowering, 20 pre-expanded robot descriptions
+  angle_axis / p_servo / hessian_from_jacobian    the exports of the extension module that take finished matrices
+  compat.fknm / compat.frne   plug-in modules with the reference extension modules' own function tables
   fleet_fkine_jacob   many different chains in one call;  ShardedBatch / shard_range  one row block per GPU rank
 All arithmetic runs in hand-written HIP kernels (../csrc) behind the C ABI of include/rtbhip.h; there is no
 CPU fallback: every call raises RtbHipError when librtbhip.so or a GPU is missing.
 """
 from ._lib import RtbHipError, lib, device_count, tune, shard_range, last_launch  # noqa: F401
-from .et import ET, ETS, IKSolution  # noqa: F401
+from .et import ET, ETS, IKSolution, angle_axis, p_servo, hessian_from_jacobian  # noqa: F401
 from .dh import DHLink, DHRobot, RevoluteDH, PrismaticDH, RevoluteMDH, PrismaticMDH  # noqa: F401
 from .erobot import Link, ERobot  # noqa: F401
 from . import models  # noqa: F401
@@ -19,6 +21,6 @@ from . import urdf  # noqa: F401
 from .fleet import fleet_fkine_jacob  # noqa: F401
 from .shard import ShardedBatch  # noqa: F401
 
-__all__ = ["ET", "ETS", "IKSolution", "DHLink", "DHRobot", "RevoluteDH", "PrismaticDH", "RevoluteMDH",
+__all__ = ["ET", "ETS", "IKSolution", "angle_axis", "p_servo", "hessian_from_jacobian", "DHLink", "DHRobot", "RevoluteDH", "PrismaticDH", "RevoluteMDH",
            "PrismaticMDH", "Link", "ERobot", "models", "urdf", "fleet_fkine_jacob", "ShardedBatch", "RtbHipError", "lib",
            "device_count", "tune", "shard_range", "last_launch"]

@@ -52,6 +52,8 @@ SIGNATURES = {
     "rtbhip_jacob": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _vp, _i32, _vp]),
     "rtbhip_fkine_jacob": (C.c_int, [_u64, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
     "rtbhip_hessian": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _vp, _i32, _vp]),
+    "rtbhip_hessian_from_jacobian": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp]),
+    "rtbhip_angle_axis": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp]),
     "rtbhip_ik_lm": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _i32, C.c_double, _i32, _vp, C.c_double,
                                _i32, _i32, _u64, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "rtbhip_ik_lm_nullspace": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _i32, C.c_double, _i32, _vp, C.c_double, _i32, _i32, _u64,
@@ -61,6 +63,7 @@ SIGNATURES = {
     "rtbhip_dyn_destroy": (C.c_int, [_u64]),
     "rtbhip_rne": (C.c_int, [_u64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp]),
     "rtbhip_jacob_dot": (C.c_int, [_u64, _vp, _vp, _i64, _vp, _i32, _vp, _i32, _vp]),
+    "rtbhip_jacob0_dot_analytical": (C.c_int, [_u64, _vp, _vp, _i64, _vp, _i32, _vp, _i32, _vp]),
     "rtbhip_jacob0_analytical": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _vp, _i32, _vp]),
     "rtbhip_manipulability": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _i32, _vp, _i32, _vp]),
     "rtbhip_jacobm": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _vp, _i32, _vp]),

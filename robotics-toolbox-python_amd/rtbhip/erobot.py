@@ -109,21 +109,53 @@ class ERobot:
     def __getitem__(self, i): return self.links[i]
 
     # ------------------------------------------------------------ kinematics over a path
-    def ets(self, end=None, start=None):
-        """ETS from the base to link `end` (default: the last link), robot-wide jindex kept."""
-        end = self.links[-1] if end is None else (end if isinstance(end, Link) else next(l for l in self.links if l.name == end))
-        path = []
-        l = end
+    def _getlink(self, link, default):
+        if link is None:
+            return default
+        if isinstance(link, Link):
+            if link not in self.links:
+                raise ValueError("link not in robot links")              # BaseRobot.py:1407-1410
+            return link
+        if isinstance(link, str):
+            for l in self.links:
+                if l.name == link:
+                    return l
+            raise ValueError("no link named %s" % link)
+        raise TypeError("unknown argument")
+
+    def _link_ets(self, l):
+        """A link's ETS with the robot-wide joint number on its joint."""
+        return [ET(e.axis, flip=e.isflip, jindex=l.jindex, qlim=e.qlim) if e.isjoint else e for e in l.ets]
+
+    def ets(self, start=None, end=None):
+        """ETS of the path from link `start` (default: the base link) to link `end` (default: the last link), links given as
+        Link objects or names; robot-wide jindex kept.  The reference's rule (BaseRobot.ets robot/BaseRobot.py:1555-1652 ->
+        _find_ets :1426-1467): the path INCLUDES the start link's own transform when it descends from it, and climbing
+        towards the root multiplies by the inverse of each link left behind."""
+        a = self._getlink(start, self.base_link)
+        b = self._getlink(end, self.links[-1])
+        up, l = [], a
+        anc_a = []
         while l is not None:
-            path.append(l)
+            anc_a.append(l)
             l = l.parent
+        down, l = [], b
+        while l is not None and l not in anc_a:
+            down.append(l)
+            l = l.parent
+        if l is None:
+            raise ValueError("Could not find the requested ETS in this robot")
+        meet = l                                                   # lowest common ancestor (a itself when b is below a)
         out = []
-        for l in reversed(path):
-            for e in l.ets:
-                if e.isjoint:
-                    out.append(ET(e.axis, flip=e.isflip, jindex=l.jindex, qlim=e.qlim))
-                else:
-                    out.append(e)
+        if meet is a:
+            out += self._link_ets(a)                               # toplevel: path = link.ets (:1445-1446)
+        else:
+            l = a
+            while l is not meet:                                   # climbing: link.ets.inv() of every link left (:1459-1465)
+                out += [e.inv() for e in reversed(self._link_ets(l))]
+                l = l.parent
+        for l in reversed(down):
+            out += self._link_ets(l)
         return ETS(out)
 
     def fkine_all(self, q, base=None):

@@ -39,6 +39,70 @@ def _elementary(axis, eta):
     return T
 
 
+def hessian_from_jacobian(J, n=None):
+    """H (n,6,n) [or (N,n,6,n)] from a finished Jacobian J (6,n) [or (N,6,n)]: _ETS_hessian (core/methods.cpp:16-32), the
+    part of ETS_hessian0 / ETS_hessiane (core/fknm.cpp:583-783) that runs when the caller supplies J.  NumPy in -> NumPy
+    out (staged through the device); float64 CUDA tensor in -> tensor out on the current stream."""
+    tm = is_torch(J) and J.is_cuda
+    if tm:
+        single = J.dim() == 2
+        J3 = (J.reshape((1,) + tuple(J.shape)) if single else J).contiguous()
+    else:
+        a = as_numeric(J.detach().numpy() if is_torch(J) else J, "J")
+        single = a.ndim == 2
+        J3 = np.ascontiguousarray(a.reshape((1,) + a.shape) if single else a)
+    if len(J3.shape) != 3 or J3.shape[1] != 6 or (n is not None and J3.shape[2] != n):
+        raise ValueError("J must be (6,n) or (N,6,n)")
+    N, _, nj = J3.shape
+    H = ETS._out((N, nj, 6, nj), J3, tm)
+    check(lib().rtbhip_hessian_from_jacobian(ETS._ptr(J3, tm), N, nj, ETS._ptr(H, tm), MEM_DEVICE if tm else MEM_HOST, ETS._stream(tm)))
+    return H[0] if single else H
+
+
+def angle_axis(Te, Tep):
+    """Pose error e = [Tep.t - Te.t ; angle-axis vector of Tep.R Te.R^T] (reference `rtb.angle_axis`, tools/p_servo.py:13-20
+    -> fknm.Angle_Axis core/fknm.cpp:112-162 -> _angle_axis core/ik.cpp:241-286): (6,) for one pair, (N,6) when either
+    argument is a stack of N poses (a single pose on the other side is used for every pair)."""
+    tm = is_torch(Te) and Te.is_cuda and is_torch(Tep) and Tep.is_cuda
+    def shape(T):
+        if tm:
+            return T.reshape(-1, 4, 4).contiguous(), T.dim() == 2
+        if hasattr(T, "A") and not isinstance(T, np.ndarray) and not is_torch(T):
+            T = T.A
+        a = as_numeric(T.detach().cpu().numpy() if is_torch(T) else T, "T")
+        if a.shape[-2:] != (4, 4):
+            raise ValueError("poses must be 4x4")
+        return np.ascontiguousarray(a.reshape(-1, 4, 4)), a.ndim == 2
+    A, sa = shape(Te)
+    B, sb = shape(Tep)
+    N = max(A.shape[0], B.shape[0])
+    if (A.shape[0] not in (1, N)) or (B.shape[0] not in (1, N)):
+        raise ValueError("Te and Tep must hold the same number of poses, or one of them a single pose")
+    e = ETS._out((N, 6), A, tm)
+    check(lib().rtbhip_angle_axis(ETS._ptr(A, tm), A.shape[0], ETS._ptr(B, tm), B.shape[0], ETS._ptr(e, tm),
+                                  MEM_DEVICE if tm else MEM_HOST, ETS._stream(tm)))
+    return e[0] if (sa and sb) else e
+
+
+def p_servo(wTe, wTep, gain=1.0, threshold=0.1, method="angle-axis"):
+    """Position-based servoing, batched (reference tools/p_servo.py:46-117, method "angle-axis"): v = diag(gain) e with
+    e = angle_axis(wTe, wTep), arrived = sum|e| < threshold.  The reference's default method "rpy" goes through
+    spatialmath's tr2rpy and is not offered here."""
+    if method != "angle-axis":
+        raise NotImplementedError("p_servo: only method='angle-axis' runs on the GPU backend")
+    e = angle_axis(wTe, wTep)
+    k = np.asarray(gain, dtype=np.float64)
+    if k.ndim not in (0, 1) or (k.ndim == 1 and k.shape[0] != 6):
+        raise ValueError("gain must be a scalar or a 6-vector")
+    if is_torch(e):
+        import torch
+        kt = torch.as_tensor(k, dtype=e.dtype, device=e.device)
+        return e * kt, e.abs().sum(dim=-1) < threshold
+    v = e * k
+    arrived = np.abs(e).sum(axis=-1) < threshold
+    return v, (bool(arrived) if e.ndim == 1 else arrived)
+
+
 class ET:
     """One elementary transform (reference robot/ET.py BaseET/ET)."""
 
@@ -91,6 +155,15 @@ class ET:
     def __mul__(self, other): return ETS(self) * other
     def __add__(self, other): return ETS(self) * other
 
+    def inv(self):
+        """Inverse of this ET (reference robot/ET.py:413-445): a joint keeps its axis and toggles `flip`, a constant is
+        the inverse matrix."""
+        if self.isjoint:
+            return ET(self.axis, flip=not self.isflip, jindex=self.jindex, qlim=self.qlim)
+        if self.axis == "SE3":
+            return ET("SE3", T=np.linalg.inv(self.T))
+        return ET(self.axis, -self.eta)
+
     def __repr__(self):
         if self.axis == "SE3":
             return "SE3(...)"
@@ -140,6 +213,22 @@ class ETS:
         return NotImplemented
 
     __add__ = __mul__
+
+    def inv(self):
+        """Inverse ETS: the inverses of the elements in reverse order (reference robot/ETS.py:545-580)."""
+        return ETS([e.inv() for e in reversed(self._ets)])
+
+    def split(self):
+        """Link segments: every piece but possibly the last ends with a joint (reference robot/ETS.py:511-543)."""
+        out, cur = [], []
+        for e in self._ets:
+            cur.append(e)
+            if e.isjoint:
+                out.append(ETS(cur))
+                cur = []
+        if cur:
+            out.append(ETS(cur))
+        return out
 
     def __len__(self): return len(self._ets)
     def __iter__(self): return iter(self._ets)
@@ -351,9 +440,13 @@ class ETS:
                                        self._stream(tm)))
         return (T[0], J[0]) if single else (T, J)
 
-    def _hess(self, q, tool, frame):
+    def _hess(self, q, tool, frame, J=None):
+        if J is not None:
+            # the reference's own calling form: ETS_hessian0(ets, q, J0, tool) with J0 given only runs _ETS_hessian on it
+            # (core/fknm.cpp:583-783 -> methods.cpp:16-32); q and tool are then not looked at
+            return hessian_from_jacobian(J, self.n)
         if q is None:
-            raise NotImplementedError("hessian from a supplied J0/Je is not offered by the GPU backend: pass q")
+            raise ValueError("one of q or the Jacobian must be supplied")
         q2, single, tm = self._shape_q(q)
         N = q2.shape[0]
         n = self.n
@@ -364,31 +457,40 @@ class ETS:
         return H[0] if single else H
 
     def hessian0(self, q=None, J0=None, tool=None):
-        """(n,6,n) Hessian in the start frame (reference robot/ETS.py:1332-1420, fknm.cpp:583-682)."""
-        return self._hess(q, tool, 0)
+        """(n,6,n) Hessian in the start frame (reference robot/ETS.py:1332-1420, fknm.cpp:583-682); from q, or -- as the
+        reference allows -- from an already computed J0 ((6,n), or (N,6,n) for a batch)."""
+        return self._hess(q, tool, 0, J0)
 
     def hessiane(self, q=None, Je=None, tool=None):
-        return self._hess(q, tool, 1)
+        """(n,6,n) Hessian in the end-effector frame (reference robot/ETS.py:1422-1510, fknm.cpp:684-783), from q or Je."""
+        return self._hess(q, tool, 1, Je)
 
     # ------------------------------------------------------------ differential-kinematics consumers
     def jacob0_dot(self, q, qd, J0=None, representation=None, tool=None):
-        """d/dt J0 = hessian0(q) . qd: (6,n) or (N,6,n) (reference Robot.jacob0_dot robot/Robot.py:964-1098)."""
+        """d/dt J0 = hessian0(q) . qd: (6,n) or (N,6,n) (reference Robot.jacob0_dot robot/Robot.py:964-1098).  With an
+        orientation `representation` ("rpy/xyz", "rpy/zyx", "eul", "exp") the rate of the ANALYTICAL Jacobian, which the
+        reference obtains from a forward-difference numerical Hessian of jacob0_analytical (:1090-1093); reproduced as such."""
         return self._jdot(q, qd, representation, tool, 0)
 
     def jacobe_dot(self, q, qd, tool=None):
         return self._jdot(q, qd, None, tool, 1)
 
     def _jdot(self, q, qd, representation, tool, frame):
-        if representation is not None:
-            raise NotImplementedError("analytical-Jacobian rates use a numerical Hessian in the reference and stay there")
+        if representation is not None and representation not in self._REPRESENTATIONS:
+            raise ValueError("representation must be one of %s" % ", ".join(self._REPRESENTATIONS))
         q2, single, tm = self._shape_q(q)
         qd2, _, tm2 = self._shape_q(qd)
         if tm != tm2 or tuple(q2.shape) != tuple(qd2.shape):
             raise ValueError("q and qd must have the same shape and live in the same memory")
         N = q2.shape[0]
         Jd = self._out((N, 6, self.n), q2, tm)
-        check(lib().rtbhip_jacob_dot(self._handle(), self._ptr(q2, tm), self._ptr(qd2, tm), N, host_ptr(small(tool, 16)), frame,
-                                     self._ptr(Jd, tm), MEM_DEVICE if tm else MEM_HOST, self._stream(tm)))
+        if representation is not None:
+            check(lib().rtbhip_jacob0_dot_analytical(self._handle(), self._ptr(q2, tm), self._ptr(qd2, tm), N, host_ptr(small(tool, 16)),
+                                                     self._REPRESENTATIONS[representation], self._ptr(Jd, tm),
+                                                     MEM_DEVICE if tm else MEM_HOST, self._stream(tm)))
+        else:
+            check(lib().rtbhip_jacob_dot(self._handle(), self._ptr(q2, tm), self._ptr(qd2, tm), N, host_ptr(small(tool, 16)), frame,
+                                         self._ptr(Jd, tm), MEM_DEVICE if tm else MEM_HOST, self._stream(tm)))
         return Jd[0] if single else Jd
 
     @staticmethod

@@ -28,7 +28,35 @@ class ERobot:
     @qlim.setter
     def qlim(self, v): self._ets.qlim = v
 
-    def ets(self, *a, **k): return self._ets
+    def _links(self):
+        """The link segments the reference's Robot(ETS) makes (robot/Robot.py:117-131): a link frame after every joint, named
+        link0, link1, ...; trailing constants form a last, static link."""
+        return self._ets.split()
+
+    def ets(self, start=None, end=None):
+        """The whole chain, or -- BaseRobot.ets(start, end), robot/BaseRobot.py:1555-1652 -- the part from link `start` to
+        link `end` (names "link0".."linkK" or indices); as in the reference the start link's own transform is included."""
+        if start is None and end is None:
+            return self._ets
+        segs = self._links()
+
+        def index(x, default):
+            if x is None:
+                return default
+            if isinstance(x, str):
+                names = ["link%d" % k for k in range(len(segs))]
+                if x not in names:
+                    raise ValueError("no link named %s" % x)
+                return names.index(x)
+            k = int(x)
+            if not 0 <= k < len(segs):
+                raise ValueError("link not in robot links")
+            return k
+        a, b = index(start, 0), index(end, len(segs) - 1)
+        if a > b:
+            raise ValueError("Could not find the requested ETS in this robot")
+        out = ETS([e for seg in segs[a:b + 1] for e in seg])
+        return out
 
     def fkine(self, q, end=None, start=None, tool=None, include_base=True):
         t = self.tool if tool is None else tool

@@ -11,6 +11,7 @@
 #include "../../robotics-toolbox-python_amd/csrc/tree_device.h"
 #include "../../robotics-toolbox-python_amd/csrc/partial_device.h"
 #include "../../robotics-toolbox-python_amd/csrc/frames_device.h"
+#include "../../robotics-toolbox-python_amd/csrc/servo_device.h"
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
@@ -29,7 +30,8 @@ static Affine aff16(const double *m)
 extern "C" int emu_kin(rtbhip_chain_t h, const double *q, int64_t N, const double *base16, const double *tool16,
                        int frame, double *T, double *J, double *H, int coalesced)
 {
-    Chain *c = chain_from_handle(h);
+    const std::shared_ptr<Chain> c_owner = chain_from_handle(h);
+    Chain *c = c_owner.get();
     if (!c) return -1;
     KinParams kp;
     kp.n = c->n; kp.qw = c->q_width; kp.stride = kin_stride(c->n);
@@ -100,7 +102,8 @@ static void emu_reg_run(const KinParams &kp, const DevChain &cv, const double *q
 extern "C" int emu_kin_reg(rtbhip_chain_t h, const double *q, int64_t N, const double *base16, const double *tool16,
                            int frame, double *T, double *J)
 {
-    Chain *c = chain_from_handle(h);
+    const std::shared_ptr<Chain> c_owner = chain_from_handle(h);
+    Chain *c = c_owner.get();
     if (!c || c->n < 1 || c->n > kKinRegMax) return -1;
     KinParams kp;
     kp.n = c->n; kp.qw = c->q_width; kp.stride = kin_stride(c->n);
@@ -180,7 +183,8 @@ static void emu_hess_tile_run(const KinParams &kp, const DevChain &cv, const dou
 
 extern "C" int emu_kin_hess_tile(rtbhip_chain_t h, const double *q, int64_t N, const double *tool16, int frame, int rounds, double *H)
 {
-    Chain *c = chain_from_handle(h);
+    const std::shared_ptr<Chain> c_owner = chain_from_handle(h);
+    Chain *c = c_owner.get();
     if (!c || c->n < 1 || c->n > kKinRegMax) return -1;
     KinParams kp;
     kp.n = c->n; kp.qw = c->q_width; kp.stride = kin_stride(c->n); kp.frame = frame; kp.N = N; kp.pad = 0; kp.has_base = 0;
@@ -198,7 +202,8 @@ extern "C" int emu_kin_hess_tile(rtbhip_chain_t h, const double *q, int64_t N, c
 
 extern "C" int emu_kin_hess(rtbhip_chain_t h, const double *q, int64_t N, const double *tool16, int frame, double *H)
 {
-    Chain *c = chain_from_handle(h);
+    const std::shared_ptr<Chain> c_owner = chain_from_handle(h);
+    Chain *c = c_owner.get();
     if (!c || c->n < 1 || c->n > kKinRegMax) return -1;
     KinParams kp;
     kp.n = c->n; kp.qw = c->q_width; kp.stride = kin_stride(c->n); kp.frame = frame; kp.N = N; kp.pad = 0; kp.has_base = 0;
@@ -216,6 +221,84 @@ extern "C" int emu_kin_hess(rtbhip_chain_t h, const double *q, int64_t N, const 
     case 8: emu_hess_run<8>(kp, cv, q, N, H); break;
     case 9: emu_hess_run<9>(kp, cv, q, N, H); break;
     default: emu_hess_run<10>(kp, cv, q, N, H); break;
+    }
+    return 0;
+}
+
+// k_hess_from_jac<NJ, 4>: the tile's Jacobians through the LDS staging (hj_load_tile), each lane's into "registers", then the
+// tile emission of k_kin_hess_tile
+template <int NJ>
+static void emu_hess_from_jac_run(const double *J, int64_t N, double *H)
+{
+    constexpr int R = 4, W = 6 * NJ, HW = NJ * W, S = HW | 1, G = kWave / R;
+    std::vector<double> buf(std::max<size_t>((size_t)G * S, (size_t)kWave * (W + 1)), -777.0);
+    std::vector<double> jacs((size_t)kWave * W);
+    const int64_t tiles = (N + kWave - 1) / kWave;
+    for (int64_t tile = 0; tile < tiles; ++tile) {
+        const int64_t cfg0 = tile * kWave;
+        const int ncfg = (int)std::min<int64_t>(kWave, N - cfg0);
+        for (int l = 0; l < kWave; ++l) hj_load_tile(J + cfg0 * W, W, ncfg, buf.data(), l);
+        for (int l = 0; l < kWave; ++l)
+            for (int k = 0; k < W; ++k) jacs[(size_t)l * W + k] = l < ncfg ? buf[(size_t)l * (W + 1) + k] : 0.0;
+        for (int r = 0; r < R; ++r) {
+            const int cnt = std::min(G, ncfg - r * G);
+            if (cnt <= 0) break;
+            for (int l = r * G; l < (r + 1) * G; ++l) {
+                const double *jac = &jacs[(size_t)l * W];
+                double *mine = buf.data() + (size_t)(l - r * G) * S;
+                hessian_from_jacobian(NJ, [&](int k) { return jac[k]; }, [&](int idx, double v) { mine[idx] = v; });
+            }
+            double *dst = H + (cfg0 + r * G) * (int64_t)HW;
+            for (int l = 0; l < kWave; ++l)
+                flush_rows<HW>(buf.data(), S, cnt, l, [&](int f, double a, double b) { dst[f] = a; dst[f + 1] = b; });
+        }
+    }
+}
+
+extern "C" int emu_hess_from_jac(const double *J, int64_t N, int n, double *H)
+{
+    switch (n) {
+    case 1: emu_hess_from_jac_run<1>(J, N, H); break;
+    case 2: emu_hess_from_jac_run<2>(J, N, H); break;
+    case 3: emu_hess_from_jac_run<3>(J, N, H); break;
+    case 4: emu_hess_from_jac_run<4>(J, N, H); break;
+    case 5: emu_hess_from_jac_run<5>(J, N, H); break;
+    case 6: emu_hess_from_jac_run<6>(J, N, H); break;
+    case 7: emu_hess_from_jac_run<7>(J, N, H); break;
+    case 8: emu_hess_from_jac_run<8>(J, N, H); break;
+    case 9: emu_hess_from_jac_run<9>(J, N, H); break;
+    case 10: emu_hess_from_jac_run<10>(J, N, H); break;
+    default:                                              // k_hess_from_jac_any: one lane per Jacobian
+        for (int64_t i = 0; i < N; ++i) {
+            const double *Jr = J + i * (int64_t)(6 * n);
+            double *Hr = H + i * (int64_t)(6 * n * n);
+            hessian_from_jacobian(n, [&](int k) { return Jr[k]; }, [&](int idx, double v) { Hr[idx] = v; });
+        }
+    }
+    return 0;
+}
+
+// k_angle_axis: both operand tiles through LDS (aa_load_tile), per-lane aa_lane, staged e rows flushed as one run
+extern "C" int emu_angle_axis(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, double *e)
+{
+    const int64_t N = std::max(nTe, nTep);
+    std::vector<double> a(kWave * kAaStride, -777.0), b(kWave * kAaStride, -777.0);
+    const int64_t tiles = (N + kWave - 1) / kWave;
+    for (int64_t tile = 0; tile < tiles; ++tile) {
+        const int64_t cfg0 = tile * kWave;
+        const int ncfg = (int)std::min<int64_t>(kWave, N - cfg0);
+        const bool ea = nTe == N, eb = nTep == N;
+        for (int l = 0; l < kWave; ++l) {
+            if (ea) aa_load_tile(Te + cfg0 * 16, ncfg, a.data(), l); else aa_load_tile(Te, 1, a.data(), l);
+            if (eb) aa_load_tile(Tep + cfg0 * 16, ncfg, b.data(), l); else aa_load_tile(Tep, 1, b.data(), l);
+        }
+        double t1[kWave][12], t2[kWave][12];
+        for (int l = 0; l < kWave; ++l) {
+            const int la = ea ? (l < ncfg ? l : 0) : 0, lb = eb ? (l < ncfg ? l : 0) : 0;
+            for (int k = 0; k < 12; ++k) { t1[l][k] = a[la * kAaStride + k]; t2[l][k] = b[lb * kAaStride + k]; }
+        }
+        for (int l = 0; l < kWave; ++l) aa_lane(t1[l], t2[l], a.data() + l * 7);
+        for (int l = 0; l < kWave; ++l) kin_flush(a.data(), 7, 6, ncfg, e + cfg0 * 6, l);
     }
     return 0;
 }
@@ -251,6 +334,7 @@ struct EmuWave {
     unsigned long long pool_next = 0, pool_end = 0;
     unsigned tick = 0;
     long long passes = 0, iters = 0, lane_iters_useful = 0;
+    long long quiet = 0;       // the kernel's watchdog counter, replayed: a false fire fails the run (-4)
 };
 
 template <int NJ>
@@ -298,6 +382,7 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
                 for (int l = 0; l < kWave; ++l) if ((w.busy >> l) & 1ull) ik_account(l, w.sh, s_last);
                 for (int l = 0; l < kWave; ++l) ik_finalize<NJ>(w.st[l], w.sh, l, p, qlim, q_out, success, iters, searches, residual);
                 const unsigned long long freed = ballot(w, [&](int l) { return ((w.busy >> l) & 1ull) && w.sh.res[l] != 0; });
+                if (freed) w.quiet = 0;
                 w.busy &= ~freed;
                 unsigned long long idle = ballot(w, [&](int l) { return w.st[l].status == kIkIdle; });
                 const unsigned long long starved = ballot(w, [&](int l) { return ((w.busy >> l) & 1ull) && ik_starved(l, w.sh); });
@@ -354,6 +439,7 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
                 }
             }
             if (w.busy == 0 && w.exhausted) { w.done = true; --live; continue; }
+            if (++w.quiet > ik_patience(p, s_last)) return -4;   // the kernel would overwrite valid results with its NaN markers here
             w.iters++;
             for (int l = 0; l < kWave; ++l) {
                 if (w.st[l].status == kIkRun) w.lane_iters_useful++;
@@ -379,7 +465,8 @@ extern "C" int emu_ik(rtbhip_chain_t h, const double *Tep, int64_t N, const doub
                       int reject_jl, const double *we6, double lambda, int method, int flavour, uint64_t seed,
                       double *q_out, int32_t *success, int32_t *iters, int32_t *searches, double *residual)
 {
-    Chain *c = chain_from_handle(h);
+    const std::shared_ptr<Chain> c_owner = chain_from_handle(h);
+    Chain *c = c_owner.get();
     if (!c || c->n < 1 || c->n > kIkMaxJoints) return -1;
     IkDev p;
     p.ilimit = ilimit; p.slimit = slimit; p.reject_jl = reject_jl; p.method = method; p.flavour = flavour;
@@ -407,7 +494,8 @@ extern "C" int emu_ik_wave(rtbhip_chain_t h, int waves, double *stats, const dou
                       int reject_jl, const double *we6, double lambda, int method, int flavour, uint64_t seed,
                       double *q_out, int32_t *success, int32_t *iters, int32_t *searches, double *residual)
 {
-    Chain *c = chain_from_handle(h);
+    const std::shared_ptr<Chain> c_owner = chain_from_handle(h);
+    Chain *c = c_owner.get();
     if (!c || c->n < 1 || c->n > kIkMaxJoints) return -1;
     IkDev p;
     p.ilimit = ilimit; p.slimit = slimit; p.reject_jl = reject_jl; p.method = method; p.flavour = flavour;
@@ -457,7 +545,8 @@ static void rne_run(const Dyn *d, const double *q, const double *qd, const doubl
 extern "C" int emu_rne(rtbhip_dyn_t h, const double *q, const double *qd, const double *qdd, int64_t N,
                        const double *grav3, const double *fext6, double *tau, int force_generic)
 {
-    Dyn *d = dyn_from_handle(h);
+    const std::shared_ptr<Dyn> d_owner = dyn_from_handle(h);
+    Dyn *d = d_owner.get();
     if (!d) return -1;
     V3 g = v3(grav3[0], grav3[1], grav3[2]);
     V3 f = fext6 ? v3(fext6[0], fext6[1], fext6[2]) : v3(0, 0, 0);
@@ -513,7 +602,8 @@ static void dyn_nj(const Dyn *d, int mode, const double *q, const double *qd, co
 extern "C" int emu_dyn(rtbhip_dyn_t h, int mode, const double *q, const double *qd, const double *tq, int64_t N,
                        const double *grav3, double *out)
 {
-    Dyn *d = dyn_from_handle(h);
+    const std::shared_ptr<Dyn> d_owner = dyn_from_handle(h);
+    Dyn *d = d_owner.get();
     if (!d || d->n > 10) return -1;
     V3 g = grav3 ? v3(grav3[0], grav3[1], grav3[2]) : v3(0, 0, 0);
     switch (d->n) {
@@ -548,6 +638,11 @@ static void diff_run(const KinParams &kp, const DevChain &cv, int mode, int axes
             double ja[6 * NJ];
             jacob_analytical<NJ>(P, jac, axes, ja);
             for (int k = 0; k < 6 * NJ; ++k) out[s * 6 * NJ + k] = ja[k];
+        } else if (mode == 4) {
+            double qv[NJ], v[NJ], jd[6 * NJ];
+            for (int j = 0; j < NJ; ++j) { qv[j] = q[s * kp.qw + jm_jq(cv.jmeta[j])]; v[j] = qd[s * kp.qw + jm_jq(cv.jmeta[j])]; }
+            jacob_analytical_dot<NJ>(cv, kp.tail, qv, v, axes, jd);
+            for (int k = 0; k < 6 * NJ; ++k) out[s * 6 * NJ + k] = jd[k];
         } else if (mode == 1) {
             const int method = (axes >> 8) & 3;
             out[s] = method == 0 ? manipulability_yoshikawa<NJ>(jac, axes & 63) : manipulability_singular<NJ>(jac, axes & 63, method);
@@ -561,7 +656,8 @@ static void diff_run(const KinParams &kp, const DevChain &cv, int mode, int axes
 extern "C" int emu_diff(rtbhip_chain_t h, int mode, int axes, const double *q, const double *qd, int64_t N,
                         const double *tool16, int frame, double *out)
 {
-    Chain *c = chain_from_handle(h);
+    const std::shared_ptr<Chain> c_owner = chain_from_handle(h);
+    Chain *c = c_owner.get();
     if (!c || c->n < 1 || c->n > kKinRegMax) return -1;
     KinParams kp;
     kp.n = c->n; kp.qw = c->q_width; kp.stride = kin_stride(c->n); kp.frame = frame; kp.N = N; kp.pad = 0; kp.has_base = 0;
@@ -586,7 +682,8 @@ extern "C" int emu_diff(rtbhip_chain_t h, int mode, int axes, const double *q, c
 // fkine_all: compile_frames (chain.cpp) + frames_walk (frames_device.h) on the CPU
 extern "C" int emu_link_frames(rtbhip_chain_t h, const double *q, int64_t N, const double *base16, const int32_t *marks, int nmarks, double *out)
 {
-    Chain *c = chain_from_handle(h);
+    const std::shared_ptr<Chain> c_owner = chain_from_handle(h);
+    Chain *c = c_owner.get();
     if (!c) return -1;
     FrameTable ft;
     if (compile_frames(c, marks, nmarks, &ft) != RTBHIP_OK) return -2;
@@ -608,7 +705,8 @@ extern "C" int emu_link_frames(rtbhip_chain_t h, const double *q, int64_t N, con
 // every order replayed on the CPU from the emulated Jacobian and Hessian
 extern "C" int emu_partial(rtbhip_chain_t h, const double *q, int64_t N, const double *tool16, int order, double *out)
 {
-    Chain *c = chain_from_handle(h);
+    const std::shared_ptr<Chain> c_owner = chain_from_handle(h);
+    Chain *c = c_owner.get();
     if (!c || order < 3 || order > kPartialMaxOrder) return -1;
     const int n = c->n;
     std::vector<std::vector<double>> lower(order - 1);

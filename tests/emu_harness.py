@@ -77,6 +77,8 @@ def lib():
                                      _i32, _u64, _vp, _vp, _vp, _vp, _vp]
         _lib.rtbhip_ik_restart.argtypes = [_u64, _u64, _i64, _i32, _vp]
         _lib.rtbhip_last_error.restype = C.c_char_p
+        _lib.emu_hess_from_jac.argtypes = [_vp, _i64, _i32, _vp]
+        _lib.emu_angle_axis.argtypes = [_vp, _i64, _vp, _i64, _vp]
     return _lib
 
 
@@ -157,6 +159,25 @@ def hess_reg(ets, q, tool=None, frame=0, rounds=0):
     return H
 
 
+def hess_from_jac(J):
+    """k_hess_from_jac: (N,6,n) Jacobians -> (N,n,6,n) Hessians."""
+    J = np.ascontiguousarray(J, dtype=np.float64)
+    N, _, n = J.shape
+    H = np.full((N, n, 6, n), np.nan)
+    assert lib().emu_hess_from_jac(_p(J), N, n, _p(H)) == 0
+    return H
+
+
+def angle_axis(Te, Tep):
+    """k_angle_axis: (N|1,4,4) x (N|1,4,4) -> (N,6)."""
+    Te = np.ascontiguousarray(np.asarray(Te, dtype=np.float64).reshape(-1, 4, 4))
+    Tep = np.ascontiguousarray(np.asarray(Tep, dtype=np.float64).reshape(-1, 4, 4))
+    N = max(len(Te), len(Tep))
+    e = np.full((N, 6), np.nan)
+    assert lib().emu_angle_axis(_p(Te), len(Te), _p(Tep), len(Tep), _p(e)) == 0
+    return e
+
+
 def diff(ets, mode, q, qd=None, axes=63, tool=None, frame=0):
     """mode 0 jacob_dot (N,6,n), 1 manipulability (N,), 2 jacobm (N,n), 3 jacob0_analytical (N,6,n; axes = representation
     code): diff_device.h on the CPU."""
@@ -165,7 +186,7 @@ def diff(ets, mode, q, qd=None, axes=63, tool=None, frame=0):
     q = np.ascontiguousarray(np.asarray(q, dtype=np.float64).reshape(-1, ets.q_width))
     qd = None if qd is None else np.ascontiguousarray(np.asarray(qd, dtype=np.float64).reshape(-1, ets.q_width))
     N = q.shape[0]
-    out = np.full({0: (N, 6, n), 1: (N,), 2: (N, n), 3: (N, 6, n)}[mode], np.nan)
+    out = np.full({0: (N, 6, n), 1: (N,), 2: (N, n), 3: (N, 6, n), 4: (N, 6, n)}[mode], np.nan)
     t = None if tool is None else np.ascontiguousarray(tool, dtype=np.float64)
     assert lib().emu_diff(h, mode, axes, _p(q), _p(qd), N, _p(t), frame, _p(out)) == 0
     return out

@@ -83,6 +83,81 @@ def test_emu_vs_oracle(name):
                                  LIT["K_panda_jacobm"])
 
 
+def _central_rate(ch, q, qd, rep, h=1e-5):
+    """An accurate derivative of the analytical Jacobian along qd (central differences of the oracle), to show that the
+    forward-difference quantity the reference defines is what it claims to be (reference test: 4 decimals, tests/test_jacob.py:83-97)."""
+    Jd = np.zeros((6, ch.n))
+    for i in range(ch.n):
+        d = np.zeros(ch.n); d[i] = h
+        Jd += (oracle.jacob0_analytical(ch, q + d, rep)[0] - oracle.jacob0_analytical(ch, q - d, rep)[0]) / (2 * h) * qd[i]
+    return Jd
+
+
+@pytest.mark.parametrize("rep", ["rpy/xyz", "rpy/zyx", "eul", "exp"])
+def test_emu_jacob0_dot_with_representation(rep):
+    """Robot.jacob0_dot(q, qd, representation=...) (robot/Robot.py:1065-1098): forward-difference numerical Hessian of
+    jacob0_analytical contracted with qd.  The device function against the NumPy restatement of exactly that (both carry the
+    1e-8 step's round-off, so they agree to ~1e-6), and against an accurate derivative at the reference test's 4 decimals;
+    ETS Puma560 at the reference's own q / qd (tests/test_jacob.py:19-22), plus the Panda."""
+    import emu_harness as emu
+    code = {"rpy/xyz": 0, "rpy/zyx": 1, "eul": 2, "exp": 3}[rep]
+    puma = rtbhip.models.DH.Puma560().ets()
+    for e, ch, q, qd in ((puma, chain_from_ets(puma), np.array([0.1, 0.2, 0.3, 0.1, 0.2, 0.3]), np.array([0.1, -0.2, 0.3, -0.1, 0.2, -0.3])),
+                         (rtbhip.models.Panda().ets(), chains.panda_ets(), LIT["K_panda_jacobm_q"], np.array([0.1, -0.2, 0.3, -0.4, 0.5, -0.6, 0.7]))):
+        Jd = emu.diff(e, 4, q, qd=qd, axes=code)[0]
+        nt.assert_allclose(Jd, oracle.jacob0_dot_analytical(ch, q, qd, rep)[0], atol=5e-6)
+        nt.assert_array_almost_equal(Jd, _central_rate(ch, q, qd, rep), decimal=4)
+        # translational rows of the analytical Jacobian are those of jacob0: their rate is the geometric one
+        nt.assert_allclose(Jd[:3], oracle.jacob_dot(ch, q, qd)[0][:3], atol=5e-6)
+
+
+@pytest.mark.gpu
+def test_gpu_jacob0_dot_representation_and_hessian_from_jacobian():
+    import torch
+    rng = np.random.default_rng(12)
+    for name, e, ch in _cases():
+        N = 130
+        q, qd = rng.uniform(-1.2, 1.2, (N, e.n)), rng.normal(size=(N, e.n))
+        for rep in ("rpy/xyz", "rpy/zyx", "eul", "exp"):
+            Jd = e.jacob0_dot(q, qd, representation=rep)
+            assert Jd.shape == (N, 6, e.n)
+            ref = oracle.jacob0_dot_analytical(ch, q[:40], qd[:40], rep)
+            scale = max(1.0, np.abs(ref).max())
+            nt.assert_allclose(Jd[:40], ref, atol=2e-5 * scale)
+            nt.assert_array_equal(e.jacob0_dot(torch.from_numpy(q).cuda(), torch.from_numpy(qd).cuda(), representation=rep).cpu().numpy(), Jd)
+        one = e.jacob0_dot(q[0], qd[0], representation="eul")
+        assert one.shape == (6, e.n)
+        with pytest.raises(ValueError):
+            e.jacob0_dot(q[0], qd[0], representation="quaternion")
+        # the reference's calling form hessian0(q, J0=J0) / hessiane(Je=...) (robot/Robot.py:1069, robot/ETS.py:1419,1537)
+        J0, Je = e.jacob0(q), e.jacobe(q)
+        nt.assert_array_equal(e.hessian0(J0=J0), e.hessian0(q))
+        nt.assert_array_equal(e.hessiane(Je=Je), e.hessiane(q))
+        nt.assert_allclose(e.hessian0(J0=J0)[:30], oracle.hessian(ch, q[:30]), atol=1e-10)
+        H1 = e.hessian0(J0=J0[0])
+        assert H1.shape == (e.n, 6, e.n)
+        Ht = rtbhip.hessian_from_jacobian(torch.from_numpy(J0).cuda())
+        nt.assert_array_equal(Ht.cpu().numpy(), e.hessian0(q))
+        with pytest.raises(ValueError):
+            e.hessian0()
+        with pytest.raises(ValueError):
+            e.hessian0(J0=np.zeros((6, e.n + 1)))
+    # 14 joints: the run-time-n lane loop
+    J14 = rng.normal(size=(70, 6, 14))
+    H14 = rtbhip.hessian_from_jacobian(J14)
+    import emu_harness as emu
+    nt.assert_allclose(H14, emu.hess_from_jac(J14), atol=1e-13)
+    # p_servo, method "angle-axis" (tools/p_servo.py:46-117)
+    Te, Tep = e.eval(q[:50]), e.eval(q[:50] + 0.01)
+    v, arrived = rtbhip.p_servo(Te, Tep, gain=2.0, threshold=0.5)
+    nt.assert_allclose(v, 2.0 * rtbhip.angle_axis(Te, Tep), atol=0)
+    assert arrived.shape == (50,) and arrived.dtype == bool
+    v1, a1 = rtbhip.p_servo(Te[0], Tep[0], gain=[1, 1, 1, 2, 2, 2], threshold=0.5)
+    assert v1.shape == (6,) and isinstance(a1, bool)
+    with pytest.raises(NotImplementedError):
+        rtbhip.p_servo(Te[0], Tep[0], method="rpy")
+
+
 @pytest.mark.gpu
 def test_gpu_goldens_shapes_errors():
     panda = rtbhip.models.Panda()

@@ -465,7 +465,7 @@ def test_ikine_nullspace_terms():
                 assert (o[1], o[2], o[3]) == (sol.each["success"][i], sol.each["iterations"][i], sol.each["searches"][i])
                 nt.assert_allclose(sol.q[i], o[0], atol=1e-6)
         assert checked >= 25
-    # a device batch gives what the host path gives; 9+ joints are refused loudly; 5 joints run (projector vanishes)
+    # a device batch gives what the host path gives; chains outside 6..8 joints are refused loudly (nothing dropped silently)
     import torch
     st = ets.ikine_LM(torch.from_numpy(T).cuda(), q0=torch.from_numpy(q0).cuda(), seed=5, slimit=3, kq=0.1, km=0.1)
     sh = ets.ikine_LM(T, q0=q0, seed=5, slimit=3, kq=0.1, km=0.1)
@@ -474,6 +474,11 @@ def test_ikine_nullspace_terms():
     if gen3.n > 8:
         with pytest.raises(rtbhip.RtbHipError):
             gen3.ikine_LM(gen3.eval(np.zeros(gen3.n)), kq=0.1)
+    five = urdf.load("px100").ets()
+    assert five.n < 6
+    with pytest.raises(rtbhip.RtbHipError):
+        five.ikine_LM(five.eval(np.zeros(five.n)), kq=0.1)
+    assert five.ikine_LM(five.eval(np.full(five.n, 0.1)), q0=np.full(five.n, 0.12), km=0.1).success     # km alone: the reference's guard drops it
     with pytest.raises(rtbhip.RtbHipError):
         lib_ik_flavour0_nullspace(ets, Tep)
 

@@ -6,6 +6,7 @@ import os
 import re
 
 import numpy as np
+import numpy.testing as nt
 import pytest
 
 import rtbhip
@@ -138,3 +139,54 @@ def test_dh_lowering_and_L24_match_independent_tables():
         assert kind == ch.kind[i]
         if kind == 6:
             np.testing.assert_array_equal(np.asarray(T).reshape(16), ch.consts[i])
+
+
+def test_robot_ets_start_end_follow_the_reference_path_rule():
+    """BaseRobot.ets(start, end) (robot/BaseRobot.py:1555-1652 -> _find_ets :1426-1467): descending from `start` the path
+    includes the start link's own transform; climbing multiplies by the inverse of every link left behind.  Checked
+    numerically with the CPU oracle on a branched tree, and on the ETS-model facade's link0..linkK segments."""
+    from oracle import oracle, chains
+    from helpers import chain_from_ets
+    ET, Link = rtbhip.ET, rtbhip.Link
+    l0 = Link(ET.tz(0.3) * ET.Rz(), name="l0")
+    l1 = Link(ET.tx(0.2) * ET.Ry(flip=True), name="l1", parent=l0)
+    l2 = Link(ET.Rx(0.4) * ET.tz(), name="l2", parent=l1)
+    r1 = Link(ET.ty(-0.1) * ET.Rx(), name="r1", parent=l0)
+    r2 = Link(ET.SE3(chains.elementary("Rz", 0.5) @ chains.elementary("tx", 0.3)) * ET.Rz(), name="r2", parent=r1)
+    rob = rtbhip.ERobot([l0, l1, l2, r1, r2])
+    q = np.random.default_rng(0).uniform(-1, 1, rob.n)
+
+    def fk(e):
+        if e.n:                                 # chain_from_ets numbers the joints in order of appearance
+            return oracle.fkine(chain_from_ets(e), q[e.jindices])[0]
+        T = np.eye(4)
+        for x in e:
+            T = T @ x.T
+        return T
+    full = fk(rob.ets(end="l2"))
+    nt.assert_allclose(fk(rob.ets()), fk(rob.ets(end=rob.links[-1])), atol=1e-15)
+    # descending: start's own transform is part of the path
+    nt.assert_allclose(fk(rob.ets(end="l0")) @ fk(rob.ets(start="l1", end="l2")), full, atol=1e-14)
+    nt.assert_allclose(fk(rob.ets(start=l2, end=l2)), fk(rtbhip.ETS([e for e in rob._link_ets(l2)])), atol=1e-15)
+    # across branches: up l2, l1 (inverted), down r1, r2
+    cross = fk(rob.ets(start="l2", end="r2"))
+    nt.assert_allclose(full @ cross, fk(rob.ets(end="r2")), atol=1e-13)
+    assert [e.isflip for e in rob.ets(start="l2", end="l0") if e.isjoint][:2] == [True, False]     # tz -> flipped, Ry(flip) -> unflipped
+    with pytest.raises(ValueError):
+        rob.ets(end="nope")
+    with pytest.raises(ValueError):
+        rob.ets(start=Link(ET.Rz(), name="stranger"))
+    # ETS-model facade: the reference's Robot(ETS) link segments
+    panda = rtbhip.models.Panda()
+    segs = panda.ets().split()
+    assert len(segs) == 8 and all(s[-1].isjoint for s in segs[:7]) and not any(e.isjoint for e in segs[7])
+    assert panda.ets() is panda.ets(None, None)
+    part = panda.ets(start="link2", end="link4")
+    assert part.n == 3 and len(part) == sum(len(s) for s in segs[2:5])
+    assert panda.ets(end=3).n == 4
+    with pytest.raises(ValueError):
+        panda.ets(start="link5", end="link2")
+    e = ET.Rz(jindex=0) * ET.tx(0.3) * ET.SE3(chains.elementary("Ry", 0.2))
+    inv = e.inv()
+    assert [x.axis for x in inv] == ["SE3", "tx", "Rz"] and inv[2].isflip and inv[1].eta == -0.3
+    nt.assert_allclose(inv[0].T @ e[2].T, np.eye(4), atol=1e-15)

@@ -301,6 +301,25 @@ def test_hessian_register_path_equals_oracle_and_lds_tile_path(N):
     nt.assert_allclose(emu.hess_reg(three, q3, rounds=8), Ht, atol=1e-13)
 
 
+@pytest.mark.parametrize("n", [1, 2, 5, 7, 10, 11, 14])
+def test_hessian_from_supplied_jacobian(n):
+    """k_hess_from_jac (ETS_hessian0 / ETS_hessiane with J given, fknm.cpp:583-783 -> methods.cpp:16-32): Jacobian tiles
+    through LDS, register expansion, tile flush; the run-time-n lane loop beyond 10 joints.  Against the oracle's Hessian
+    of the same chain, both frames, ragged batch sizes."""
+    spec = []
+    rng = np.random.default_rng(n)
+    for j in range(n):
+        spec.append((["Rz", "Ry", "Rx", "tz", "tx"][j % 5], None, bool(j % 3 == 2)))
+        spec.append((["tx", "tz", "Ry"][j % 3], float(rng.uniform(-0.4, 0.4))))
+    ch = chains.Chain(spec, name="c%d" % n)
+    for N in (1, 63, 64, 65, 130):
+        q = rng.uniform(-2, 2, (N, n))
+        for frame in (0, 1):
+            J = oracle.jacob(ch, q, None, frame)
+            H = emu.hess_from_jac(J)
+            nt.assert_allclose(H, oracle.hessian(ch, q, frame=frame), atol=1e-13)
+
+
 def test_ik_gn_nr_reference_run_fixtures_first_search():
     """IK_GN_c / IK_NR_c (the reference's own extension, tests/golden/ref_outputs.npz): where the first
     search converges no RNG is involved and the minimum-norm step equals the reference's SVD / QR / damped
@@ -384,6 +403,77 @@ def test_ikine_nullspace_terms_equal_python_solver(step, method, k, ns):
             assert (o[1], o[2], o[3]) == (ok[i], it[i], se[i])
             nt.assert_allclose(q[i], o[0], atol=1e-7)
     assert checked >= 10
+
+
+@pytest.mark.parametrize("robot", ["AL5D", "px100"])
+def test_ik_gn_nr_on_arms_with_fewer_than_six_joints(robot):
+    """Gauss-Newton / Newton-Raphson on 4- and 5-joint arms: the 6 x n Jacobian has full COLUMN rank, J J^T is singular, and
+    the pseudo-inverse step is the least-squares one (n x n normal equations).  Against the NumPy restatement with
+    numpy.linalg.pinv (first-search cases: same counts, q to 1e-6) and, where the reference's own build is present, against
+    IK_GN_c / IK_NR_c themselves; the success rate must be that of the pseudo-inverse, not of a noise-pivot solve."""
+    from rtbhip import urdf
+    from helpers import chain_from_ets
+    from oracle import ref_harness
+    ets = urdf.load(robot).ets()
+    assert ets.n < 6
+    ets.qlim = np.clip(ets.qlim, -np.pi, np.pi)
+    ch = chain_from_ets(ets)
+    rng = np.random.default_rng(ets.n)
+    N = 40
+    qs = rng.uniform(ch.qlim[0] + 0.1, ch.qlim[1] - 0.1, (N, ets.n))
+    Tep = oracle.fkine(ch, qs)
+    q0 = qs + 0.1 * rng.normal(size=qs.shape)
+    for method in ("gn", "nr"):
+        q, ok, it, se, E = emu.ik(ets, Tep, q0=q0, method=method, flavour=1, seed=3, slimit=10, k=0.0)
+        checked = 0
+        for i in range(N):
+            rs = np.array([q0[i]] + [emu.ik_restart(ets, 3, i, d) for d in range(1, 10)])
+            o = oracle.ikine_py(ch, Tep[i], rs, step=method, slimit=10)
+            if o[1] and o[3] == 1:
+                checked += 1
+                assert (o[1], o[2], o[3]) == (ok[i], it[i], se[i])
+                nt.assert_allclose(q[i], o[0], atol=1e-6)
+        assert checked >= 25 and ok.mean() >= 0.9
+        # random starts, C-solver flavour: the advisor's scenario (57 % with the rank-deficient 6 x 6 solve, 100 % with pinv)
+        qc, okc, itc, sec, Ec = emu.ik(ets, Tep, method=method, flavour=0, seed=4, k=0.0)
+        assert okc.mean() >= 0.95
+        good = okc == 1
+        err = np.abs(oracle.fkine(ch, qc[good]) - Tep[good]).reshape(good.sum(), -1).max(axis=1)
+        assert err.max() < 2e-3
+        if ref_harness.available():
+            ref = ref_harness.RefETS(ch)
+            fn = ref.ik_GN if method == "gn" else ref.ik_NR
+            q1, ok1, it1, se1, E1 = emu.ik(ets, Tep, q0=q0, method=method, flavour=0, seed=3, k=0.0)
+            hit = 0
+            for i in range(N):
+                r = fn(Tep[i], q0=q0[i])
+                if r[1] == 1 and r[3] == 1:
+                    hit += 1
+                    assert (r[1], r[2], r[3]) == (ok1[i], it1[i], se1[i])
+                    nt.assert_allclose(q1[i], r[0], atol=1e-6)
+            assert hit >= 25
+    # a position-only mask leaves 3 rows <= n: the row form again (weights drop out of the minimum-norm solution)
+    qm, okm, itm, sem, Em = emu.ik(ets, Tep, q0=q0, method="gn", flavour=0, seed=3, k=0.0, mask=[1, 1, 1, 0, 0, 0])
+    assert okm.mean() >= 0.9
+
+
+@pytest.mark.parametrize("ilimit,slimit", [(20, 100), (20, 200), (30, 100)])
+def test_ik_watchdog_budget_covers_the_pass_latency(ilimit, slimit):
+    """64 unreachable targets in one wave, the scheduling pass only every 4th iteration (the production default): every
+    search of every slot fails and each finished search waits for its pass.  The replay carries the kernel's watchdog
+    counter and returns an error if it would have fired (it did, for ilimit % 4 == 0, before the pass latency entered
+    the budget: valid failure results would have been overwritten with NaN markers)."""
+    import os
+    ets, ch = _panda_limited()
+    Tep = oracle.fkine(ch, np.zeros((64, 7)))
+    Tep[:, :3, 3] += 5.0
+    os.environ["EMU_IK_PASS_MASK"] = "3"
+    try:
+        q, ok, it, se, E = emu.ik(ets, Tep, ilimit=ilimit, slimit=slimit, seed=1, waves=1)
+    finally:
+        del os.environ["EMU_IK_PASS_MASK"]
+    assert not ok.any() and np.all(se == slimit + 1) and np.all(it == slimit * (ilimit + 1))     # ik.cpp:39,66-68
+    assert np.all(np.isfinite(q))
 
 
 @pytest.mark.parametrize("robot,n", [("Fetch", 10), ("KinovaGen3", 9)])

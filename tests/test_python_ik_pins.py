@@ -73,6 +73,20 @@ def test_emu_search_functions_equal_reference_python_solvers(key):
         nt.assert_array_equal(a, b)
 
 
+def test_emu_angle_axis_kernel_body_equals_reference_Angle_Axis():
+    """k_angle_axis replayed on the CPU (tile loads through LDS, per-lane error vector, staged flush): every branch of
+    ik.cpp:241-286 against the reference's compiled Angle_Axis, ragged tiles, broadcasting of a single pose."""
+    import emu_harness as emu
+    Te, Tep, ref = PY["aa_Te"], PY["aa_Tep"], PY["aa_e"]
+    e = emu.angle_axis(Te, Tep)
+    assert np.all(np.abs(e - ref).max(axis=1) <= angle_axis_tolerance(Te, Tep))
+    assert np.abs(e - ref)[PY["aa_tag"] <= 2].max() <= 5e-15
+    for n in (1, 63, 64, 65):
+        nt.assert_array_equal(emu.angle_axis(Te[:n], Tep[:n]), e[:n])
+    nt.assert_array_equal(emu.angle_axis(Te[7], Tep[:70]), np.array([emu.angle_axis(Te[7], Tep[i])[0] for i in range(70)]))
+    nt.assert_array_equal(emu.angle_axis(Te[:70], Tep[9]), np.array([emu.angle_axis(Te[i], Tep[9])[0] for i in range(70)]))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("key", sorted(PY_IK_CASES))
 def test_gpu_ikine_equals_reference_python_solvers(key):
