@@ -35,7 +35,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "robotics-toolbox-python_amd")]
 
-from benchlib import HBM_PEAK_GBS, Ranks, spawn_ranks_if_needed, per_launch_min_ms, ensure_library, pmc_traffic  # noqa: E402
+from benchlib import HBM_PEAK_GBS, Ranks, spawn_ranks_if_needed, bench_argv, per_launch_min_ms, ensure_library, pmc_traffic  # noqa: E402
 
 BYTES_PER_CONFIG = 56 + 128 + 336  # q read + T written + J0 written
 
@@ -130,8 +130,9 @@ def main():
     ap.add_argument("--n", type=int, default=1000000, help="configurations per GPU per step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline and host_path legs")
     ap.add_argument("--tune", action="append", default=[], help="key=value for rtbhip_tune (A/B runs)")
-    args = ap.parse_args()
-    spawn_ranks_if_needed(args.gpus, os.path.abspath(__file__), sys.argv[1:])
+    argv = bench_argv()
+    args = ap.parse_args(argv)
+    spawn_ranks_if_needed(args.gpus, os.path.abspath(__file__), argv)
 
     import numpy as np
     import torch

@@ -21,7 +21,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "robotics-toolbox-python_amd")]
 
-from benchlib import HBM_PEAK_GBS, FP64_VALU_PEAK_TFLOPS, Ranks, spawn_ranks_if_needed, ensure_library  # noqa: E402
+from benchlib import HBM_PEAK_GBS, FP64_VALU_PEAK_TFLOPS, Ranks, spawn_ranks_if_needed, bench_argv, ensure_library  # noqa: E402
 
 
 def ev_time(fn, steps, warmup):
@@ -50,8 +50,9 @@ def main():
     ap.add_argument("--n-dyn", type=int, default=1000000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--tune", action="append", default=[])
-    args = ap.parse_args()
-    spawn_ranks_if_needed(args.gpus, os.path.abspath(__file__), sys.argv[1:])
+    argv = bench_argv()
+    args = ap.parse_args(argv)
+    spawn_ranks_if_needed(args.gpus, os.path.abspath(__file__), argv)
     import numpy as np
     import torch
     ensure_library(ROOT)

@@ -30,9 +30,21 @@ def spawn_ranks_if_needed(n_gpus, script, argv):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    # the script's own flags travel in the environment: torch.distributed.run's parser claims abbreviations of ITS options
+    # even after the script name ("--n" is "ambiguous: --nnodes, --nproc-per-node, ...")
+    import json
+    env = dict(os.environ, RTBHIP_BENCH_ARGV=json.dumps(list(argv)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
-    raise SystemExit(subprocess.call(cmd))
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def bench_argv():
+    """The flags of this run: sys.argv, or -- in a rank spawned by spawn_ranks_if_needed -- what the parent was given."""
+    import json
+    if "RTBHIP_BENCH_ARGV" in os.environ and len(sys.argv) == 1:
+        return json.loads(os.environ["RTBHIP_BENCH_ARGV"])
+    return sys.argv[1:]
 
 
 class Ranks:

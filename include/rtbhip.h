@@ -16,8 +16,9 @@
  *   - all matrices are float64.  A 4x4 homogeneous transform is 16 doubles ROW-major (the
  *     layout of one [i,:,:] slice of the (N,4,4) C-order array ETS_fkine returns, fknm.cpp:1002-1005).
  *   - q is (N, q_width) C-contiguous; q_width = max jindex + 1 (== n for a serial arm).
- *   - mem: RTBHIP_MEM_HOST   pointers are host memory; the call stages through device buffers
- *                            and returns when the results are in the output arrays;
+ *   - mem: RTBHIP_MEM_HOST   pointers are host memory; the call streams the rows through the device
+ *                            (chunked, double-buffered, see rtbhip_host_alloc) and returns when the
+ *                            results are in the output arrays;
  *          RTBHIP_MEM_DEVICE pointers are device memory of the CURRENT hip device; the call only
  *                            enqueues work on `stream` (a hipStream_t, NULL = default stream).
  *   - small per-call parameters (base, tool, gravity, fext, we, qlim) are always HOST pointers.
@@ -235,6 +236,15 @@ int rtbhip_tree_rne(rtbhip_tree_t tree, const double *q, const double *qd, const
 int rtbhip_fleet_fkine_jacob(const rtbhip_chain_t *chains, int32_t n_chains,
                              const double *const *q, const int64_t *N, int32_t frame,
                              double *const *T, double *const *J, int32_t mem, void *stream);
+
+/* Pinned host memory for the RTBHIP_MEM_HOST boundary.  Host arrays are streamed through the device in row chunks that
+ * alternate between two persistent slots (stream + device buffer + pinned staging each), so H2D / kernel of one chunk overlap
+ * the D2H of the previous one and nothing is allocated per call.  Pageable arrays are copied through the pinned staging by a few
+ * copy threads; arrays that are ALREADY pinned (these blocks, hipHostMalloc, hipHostRegister) are the DMA endpoints themselves --
+ * results land directly in the caller's array.  Blocks are cached between uses (pinning is the expensive part; cap
+ * RTBHIP_PINNED_CACHE_MB, default 4096); rtbhip_shutdown() returns them. */
+int rtbhip_host_alloc(uint64_t bytes, void **ptr);
+int rtbhip_host_free(void *ptr);
 
 /* Multi-GPU partition helper: contiguous row block [begin, begin+count) of rank `rank` out of
  * `world` (the first N % world ranks get one extra row).  Pure host arithmetic. */

@@ -190,16 +190,24 @@ int device_cu_count(int *cus)
     return RTBHIP_OK;
 }
 
+#define RTB_TRY_(expr)                  \
+    do {                                \
+        int _rc = (expr);               \
+        if (_rc != RTBHIP_OK) return _rc; \
+    } while (0)
+
 // ---------------------------------------------------------------- host staging helper
-// RAII device buffers for the RTBHIP_MEM_HOST convenience path.
+// RAII device buffers of the RTBHIP_MEM_HOST path of the calls that are not row-pipelined (IK, the dynamics terms, the
+// differential-kinematics consumers ...): drawn from a cache of device blocks (hostpipe.cpp), not allocated per call.
+// The high-volume calls -- fkine / jacob / fkine_jacob / hessian and rne -- go through host_pipeline instead.
 struct Staging {
     std::vector<void *> bufs;
-    ~Staging() { for (void *p : bufs) (void)hipFree(p); }
+    ~Staging() { for (void *p : bufs) dev_cache_free(p); }
     int in(const void *host, size_t bytes, void **dev)
     {
         *dev = nullptr;
         if (host == nullptr || bytes == 0) return RTBHIP_OK;
-        RTB_HIP(hipMalloc(dev, bytes));
+        RTB_TRY_(dev_cache_alloc(bytes, dev));
         bufs.push_back(*dev);
         RTB_HIP(hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice));
         return RTBHIP_OK;
@@ -208,7 +216,7 @@ struct Staging {
     {
         *dev = nullptr;
         if (bytes == 0) return RTBHIP_OK;
-        RTB_HIP(hipMalloc(dev, bytes));
+        RTB_TRY_(dev_cache_alloc(bytes, dev));
         bufs.push_back(*dev);
         return RTBHIP_OK;
     }
@@ -275,24 +283,22 @@ static int kin_entry(const char *fn, rtbhip_chain_t h, const double *q, int64_t 
     const size_t n = (size_t)c->n, qw = (size_t)c->q_width;
     if (mem == RTBHIP_MEM_DEVICE)
         return launch_kin(c, ops, q, N, base, tool, frame, T, J, H, (hipStream_t)stream);
-    Staging st;
-    void *dq, *dT = nullptr, *dJ = nullptr, *dH = nullptr;
-    RTB_TRY(st.in(q, (size_t)N * qw * 8, &dq));
-    if (T) RTB_TRY(st.out((size_t)N * 128, &dT));
-    if (J) RTB_TRY(st.out((size_t)N * 48 * n, &dJ));
-    if (H) RTB_TRY(st.out((size_t)N * 48 * n * n, &dH));
-    RTB_TRY(launch_kin(c, ops, (const double *)dq, N, base, tool, frame, (double *)dT, (double *)dJ, (double *)dH, nullptr));
-    RTB_HIP(hipDeviceSynchronize());
-    RTB_TRY(fetch(T, dT, (size_t)N * 128));
-    RTB_TRY(fetch(J, dJ, (size_t)N * 48 * n));
-    RTB_TRY(fetch(H, dH, (size_t)N * 48 * n * n));
-    return RTBHIP_OK;
+    // host arrays: rows stream through the two-slot pipeline (hostpipe.cpp); the functor sees device copies of one chunk
+    HostIO io;
+    io.add_in(q, qw * 8);
+    io.add_out(T, 128);
+    io.add_out(J, 48 * n);
+    io.add_out(H, 48 * n * n);
+    return host_pipeline(io, N, [&](const void *const *din, void *const *dout, int64_t, int64_t rows, hipStream_t s) {
+        return launch_kin(c, ops, (const double *)din[0], rows, base, tool, frame, (double *)dout[0], (double *)dout[1], (double *)dout[2], s);
+    });
 }
 
 void kin_tune(const char *key, int value);
 void rne_tune(const char *key, int value);
 void ik_tune(const char *key, int value);
 void ik_release_device_state();
+void hostpipe_tune(const char *key, int value);
 
 }  // namespace rtbhip
 
@@ -333,6 +339,9 @@ void rtbhip_shutdown(void)
         kv.second->dev_groups.clear();
     }
     ik_release_device_state();
+    hostpipe_release();
+    dev_cache_release();
+    host_cache_trim(0);
     // the stream-ordered temporaries of partial_fkine0 stay cached in the device's default pool: hand them back
     int dev = 0;
     hipMemPool_t pool;
@@ -755,18 +764,13 @@ int rtbhip_rne(rtbhip_dyn_t dyn, const double *q, const double *qd, const double
     RTB_TRY(dyn_device_links(d, &links));
     if (mem == RTBHIP_MEM_DEVICE)
         return launch_rne(d, links, q, qd, qdd, N, grav3, fext6, tau, (hipStream_t)stream);
-    Staging st;
-    const size_t bytes = (size_t)N * d->n * 8;
-    void *dq, *dqd, *dqdd, *dtau;
-    RTB_TRY(st.in(q, bytes, &dq));
-    RTB_TRY(st.in(qd, bytes, &dqd));
-    RTB_TRY(st.in(qdd, bytes, &dqdd));
-    RTB_TRY(st.out(bytes, &dtau));
-    RTB_TRY(launch_rne(d, links, (const double *)dq, (const double *)dqd, (const double *)dqdd, N, grav3, fext6,
-                       (double *)dtau, nullptr));
-    RTB_HIP(hipDeviceSynchronize());
-    RTB_TRY(fetch(tau, dtau, bytes));
-    return RTBHIP_OK;
+    HostIO io;
+    const size_t row = (size_t)d->n * 8;
+    io.add_in(q, row); io.add_in(qd, row); io.add_in(qdd, row);
+    io.add_out(tau, row);
+    return host_pipeline(io, N, [&](const void *const *din, void *const *dout, int64_t, int64_t rows, hipStream_t s) {
+        return launch_rne(d, links, (const double *)din[0], (const double *)din[1], (const double *)din[2], rows, grav3, fext6, (double *)dout[0], s);
+    });
 }
 
 int rtbhip_tree_create(const rtbhip_tree_group *groups, int32_t ng, rtbhip_tree_t *tree)
@@ -920,6 +924,14 @@ int rtbhip_fleet_fkine_jacob(const rtbhip_chain_t *chains, int32_t n_chains, con
     return RTBHIP_OK;
 }
 
+int rtbhip_host_alloc(uint64_t bytes, void **ptr)
+{
+    if (!ptr) { set_error("host_alloc: NULL out"); return RTBHIP_EINVAL; }
+    return host_alloc((size_t)bytes, ptr);
+}
+
+int rtbhip_host_free(void *ptr) { return host_free(ptr); }
+
 int rtbhip_shard_range(int64_t N, int32_t rank, int32_t world, int64_t *begin, int64_t *count)
 {
     if (N < 0 || world < 1 || rank < 0 || rank >= world || !begin || !count) { set_error("shard_range: bad argument"); return RTBHIP_EINVAL; }
@@ -943,6 +955,7 @@ int rtbhip_tune(const char *key, int32_t value)
     kin_tune(key, value);
     rne_tune(key, value);
     ik_tune(key, value);
+    hostpipe_tune(key, value);
     return RTBHIP_OK;
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -108,6 +109,31 @@ struct Affine;
 void chain_tail(const Chain *c, const Affine &tool, double out12[12]);
 void note_launch(int grid, int block, int lds);
 int device_cu_count(int *cus);
+
+// ---------------------------------------------------------------- the host-pointer boundary (hostpipe.cpp)
+// Row-chunked, double-buffered H2D -> kernel -> D2H over two persistent slots (streams, device buffers, pinned staging).
+// in[i] / out[i] are HOST arrays of N rows of in_row[i] / out_row[i] bytes (NULL entries are skipped and handed to the
+// functor as NULL); the functor enqueues the kernel(s) for rows [row0, row0 + rows) on device copies of the chunk.
+struct HostIO {
+    static constexpr int kMax = 6;
+    const void *in[kMax] = {nullptr};
+    size_t in_row[kMax] = {0};
+    int n_in = 0;
+    void *out[kMax] = {nullptr};
+    size_t out_row[kMax] = {0};
+    int n_out = 0;
+    void add_in(const void *p, size_t row) { in[n_in] = p; in_row[n_in] = row; ++n_in; }
+    void add_out(void *p, size_t row) { out[n_out] = p; out_row[n_out] = row; ++n_out; }
+};
+using ChunkLaunch = std::function<int(const void *const *din, void *const *dout, int64_t row0, int64_t rows, hipStream_t s)>;
+int host_pipeline(const HostIO &io, int64_t N, const ChunkLaunch &launch);
+void hostpipe_release();
+int host_alloc(size_t bytes, void **out);        // pinned host memory, cached between uses (rtbhip_host_alloc)
+int host_free(void *p);
+void host_cache_trim(size_t keep_bytes);
+int dev_cache_alloc(size_t bytes, void **out);   // device staging buffers of the remaining host-path calls: cached, not per call
+void dev_cache_free(void *p);
+void dev_cache_release();
 
 // ---------------------------------------------------------------- kernel launchers (device pointers)
 struct Affine { double v[12]; int used; };  // row-major 3x4, host-side small parameter

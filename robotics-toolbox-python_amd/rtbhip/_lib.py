@@ -77,6 +77,8 @@ SIGNATURES = {
     "rtbhip_accel": (C.c_int, [_u64, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp]),
     "rtbhip_fleet_fkine_jacob": (C.c_int, [C.POINTER(_u64), _i32, C.POINTER(_vp), C.POINTER(_i64), _i32,
                                            C.POINTER(_vp), C.POINTER(_vp), _i32, _vp]),
+    "rtbhip_host_alloc": (C.c_int, [_u64, C.POINTER(_vp)]),
+    "rtbhip_host_free": (C.c_int, [_vp]),
     "rtbhip_shard_range": (C.c_int, [_i64, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
     "rtbhip_last_launch": (C.c_int, [_ip, _ip, _ip]),
     "rtbhip_tune": (C.c_int, [C.c_char_p, _i32]),
@@ -158,6 +160,42 @@ def small(a, n):
     if a.size != n:
         raise ValueError("expected %d values, got %d" % (n, a.size))
     return a
+
+
+class _PinnedBlock:
+    """One block of rtbhip_host_alloc, exposed through the array interface; goes back to the library's cache when the last
+    array viewing it is collected."""
+
+    def __init__(self, nbytes):
+        p = _vp()
+        check(lib().rtbhip_host_alloc(int(nbytes), C.byref(p)))
+        self.ptr, self.nbytes = p.value, int(nbytes)
+        self.__array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 3}
+
+    def __del__(self):
+        try:
+            if self.ptr and _lib is not None:
+                _lib.rtbhip_host_free(_vp(self.ptr))
+        except Exception:
+            pass
+        self.ptr = None
+
+
+PINNED_MIN_BYTES = 1 << 20
+
+
+def host_empty(shape, dtype=np.float64):
+    """Result array of the host path.  From 1 MB up it is PINNED host memory (a cached block of rtbhip_host_alloc): the
+    device-to-host DMA then writes straight into it instead of into a staging buffer that a CPU copy has to empty."""
+    dtype = np.dtype(dtype)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    if nbytes < PINNED_MIN_BYTES:
+        return np.empty(shape, dtype=dtype)
+    try:
+        blk = _PinnedBlock(nbytes)
+    except RtbHipError:
+        return np.empty(shape, dtype=dtype)        # pinning refused (ulimit / fragmentation): a pageable array still works
+    return np.asarray(blk).view(dtype).reshape(shape)
 
 
 def as_numeric(x, what="q"):

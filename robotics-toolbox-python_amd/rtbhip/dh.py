@@ -256,7 +256,7 @@ class DHRobot:
         if tm:
             import torch
             return torch.empty(shape, dtype=torch.float64, device=device)
-        return np.empty(shape)
+        return _lib.host_empty(shape)
 
     def _gravity_c(self, gravity):
         g = self.gravity if gravity is None else np.asarray(gravity, dtype=np.float64).reshape(3)

@@ -283,7 +283,7 @@ class ERobot:
             ptr = lambda x: None if x is None else C.c_void_p(x.data_ptr())
             stream, mem = _lib.current_stream_ptr(), MEM_DEVICE
         else:
-            tau = np.empty((N, n))
+            tau = _lib.host_empty((N, n))
             ptr, stream, mem = host_ptr, None, MEM_HOST
         check(lib().rtbhip_tree_rne(self._handle(), ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2]), N, host_ptr(g), ptr(tau), mem, stream))
         return tau[0] if single else tau

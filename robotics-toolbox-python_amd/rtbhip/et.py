@@ -366,7 +366,7 @@ class ETS:
         if torch_mode:
             import torch
             return torch.empty(shape, dtype=dtype or torch.float64, device=like.device)
-        return np.empty(shape, dtype=dtype or np.float64)
+        return _lib.host_empty(shape, dtype or np.float64)      # pinned from 1 MB up: the D2H DMA writes into it directly
 
     @staticmethod
     def _ptr(x, torch_mode):

@@ -31,8 +31,8 @@ def fleet_fkine_jacob(chains, qs, frame=0):
             qp[i], Tp[i], Jp[i] = q2.data_ptr(), T.data_ptr(), J.data_ptr()
         else:
             q2 = np.ascontiguousarray(as_numeric(q).reshape(-1, ch.q_width))
-            T = np.empty((q2.shape[0], 4, 4))
-            J = np.empty((q2.shape[0], 6, ch.n))
+            T = _lib.host_empty((q2.shape[0], 4, 4))
+            J = _lib.host_empty((q2.shape[0], 6, ch.n))
             qp[i], Tp[i], Jp[i] = q2.ctypes.data, T.ctypes.data, J.ctypes.data
         Ns[i] = q2.shape[0]
         keep.append(q2)

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "robotics-toolbox-python_amd")
 EMU_SO = os.path.join(ROOT, "tests", "emu", "libemu.so")
 SRCS = ["tests/emu/emu.cpp"] + ["robotics-toolbox-python_amd/csrc/" + f for f in
-                                ("api.cpp", "chain.cpp", "tree.cpp", "kin_kernels.hip", "rne_kernels.hip", "ik_kernels.hip", "dyn_kernels.hip",
+                                ("api.cpp", "chain.cpp", "tree.cpp", "hostpipe.cpp", "kin_kernels.hip", "rne_kernels.hip", "ik_kernels.hip", "dyn_kernels.hip",
                                  "tree_kernels.hip", "partial_kernels.hip", "frames_kernels.hip")]
 _vp, _u64, _i64, _i32 = C.c_void_p, C.c_uint64, C.c_int64, C.c_int32
 _lib = None

@@ -47,7 +47,9 @@ def _worker(rank, world, port, N, to_all, outq):
         dev = lambda a: torch.from_numpy(np.ascontiguousarray(sb.local(a))).cuda()
         T, J = ets.fkine_jacob0(dev(qg))
         tau = arm.rne(dev(qa), dev(qd), dev(qdd))
-        assert T.is_cuda and T.shape == (sb.count, 4, 4) and J.shape == (sb.count, 6, 7) and tau.shape == (sb.count, 7)
+        # a one-row block comes back as ONE configuration ((4,4), (6,7), (7,)): the reference's shape rule for (1,n) input
+        T, J, tau = T.reshape(sb.count, 4, 4), J.reshape(sb.count, 6, 7), tau.reshape(sb.count, 7)
+        assert T.is_cuda
         TJ = torch.cat([T.reshape(sb.count, 16), J.reshape(sb.count, 42)], dim=1)
         full = sb.gather(TJ, to_all=to_all)
         ftau = sb.gather(tau, to_all=to_all)
