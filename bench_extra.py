@@ -37,6 +37,21 @@ def ev_time(fn, steps, warmup):
     return sum(ms) / len(ms), ms[0]
 
 
+# fp64 operations of ONE Levenberg-Marquardt iteration of the 7-joint Panda as k_ik executes it (fused multiply-add = 2):
+# FK + Jacobian walk incl. 7 sincos ~0.60 k, angle-axis error + E ~0.12 k, J^T W J + g (lower triangle) ~0.46 k,
+# 7x7 LDL^T factor + solves ~0.25 k, update / wrap / limit test ~0.05 k  (the reference's formulation needs ~5.5 k)
+IK_FLOPS_PER_ITERATION = 1480.0
+
+
+def ik_roofline(lm_iterations_per_s):
+    """IK is not HBM-bound (204 B of I/O per target against ~75 iterations): the roof is the fp64 vector rate.  `achieved`
+    counts only the iterations the REFERENCE's sequential loops would have run (reported iteration counts), i.e. discarded
+    speculative searches and idle lanes count against the kernel."""
+    tf = lm_iterations_per_s * IK_FLOPS_PER_ITERATION / 1e12
+    return {"bound": "fp64-valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
+            "flops_per_iteration": IK_FLOPS_PER_ITERATION, "kernel": "k_ik<7,0>"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="rne,ik,fleet,dyn,tree,kin,graph")
@@ -237,7 +252,8 @@ def main():
         line = {"metric": "solves/sec (Panda ik_LM chan k=1, joint limits, ilimit 30 slimit 100 tol 1e-6)",
                 "value": N / (avg * 1e-3), "unit": "solves/s", "n": N, "kernel_avg_ms": avg, "kernel_min_ms": best,
                 "success_rate": float(ok.float().mean()), "mean_iterations": float(it.float().mean()),
-                "max_iterations": int(it.max()), "lm_iterations_per_s": float(it.sum()) / (avg * 1e-3)}
+                "max_iterations": int(it.max()), "lm_iterations_per_s": float(it.sum()) / (avg * 1e-3),
+                "roofline": ik_roofline(float(it.sum()) / (avg * 1e-3))}
         if not args.no_cpu:
             from oracle import ref_harness, chains
             if ref_harness.available():
@@ -263,7 +279,8 @@ def main():
             n2 = T.shape[0]
             print(json.dumps({"metric": metric, "value": n2 / (a * 1e-3), "unit": "solves/s", "n": n2, "kernel_avg_ms": a, "kernel_min_ms": b,
                               "success_rate": float(ok2.float().mean()), "mean_iterations": float(it2.float().mean()),
-                              "lm_iterations_per_s": float(it2.sum()) / (a * 1e-3)}), flush=True)
+                              "lm_iterations_per_s": float(it2.sum()) / (a * 1e-3),
+                              "roofline": ik_roofline(float(it2.sum()) / (a * 1e-3))}), flush=True)
         extra("solves/sec (Panda ik_LM chan k=0.1, joint_limits=False: the ik_benchmark notebook setting)", Tep, k=0.1, joint_limits=False)
         qs10 = torch.from_numpy(rng.uniform(ets.qlim[0], ets.qlim[1], (10 * N, 7))).cuda()
         extra("solves/sec (Panda ik_LM defaults, %d targets)" % (10 * N), ets.eval(qs10))

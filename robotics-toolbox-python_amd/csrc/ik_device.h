@@ -31,7 +31,7 @@ constexpr double kIkPiHalf = 1.57079632679489661923132169163975144;
 struct IkDev {   // wave-uniform solver parameters (kernarg)
     int32_t ilimit, slimit, reject_jl, method, flavour, has_q0;
     int32_t fresh_cap, pool_chunk;   // scheduler: fresh targets a wave may start per pass / reserves per refill
-    int32_t pass_mask, pad;          // scheduler: the pass runs on iterations with (tick & pass_mask) == 0
+    int32_t pass_mask, spec_policy;  // scheduler: the pass runs on iterations with (tick & pass_mask) == 0; 0 round-robin / 1 failure-weighted speculation
     double tol, lambda;
     double we[6];
     uint64_t seed;
@@ -435,7 +435,7 @@ RTB_HD void ik_iter_any(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD t
 
 // What the reference reports for a target whose winning / last search is held by this lane.
 template <int NJ, class PD, class QL, class QA>
-RTB_HD void ik_emit(const IkLane<NJ> &st, QA qa, const PD &p, QL qlim, int64_t tgt, bool has_q0, bool success, int it_total,
+RTB_HD void ik_emit(const IkLane<NJ> &st, QA qa, const PD &p, QL qlim, int64_t tgt, int64_t row, bool has_q0, bool success, int it_total,
                     double E_last, double *__restrict__ q_out, int32_t *__restrict__ success_out,
                     int32_t *__restrict__ iters, int32_t *__restrict__ searches, double *__restrict__ residual)
 {
@@ -452,11 +452,11 @@ RTB_HD void ik_emit(const IkLane<NJ> &st, QA qa, const PD &p, QL qlim, int64_t t
         se = p.slimit;                                                             // IK.py:359-366
     }
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) q_out[tgt * NJ + j] = qf[j];
-    success_out[tgt] = success ? 1 : 0;
-    iters[tgt] = it_total;
-    searches[tgt] = se;
-    residual[tgt] = success ? st.E : E_last;
+    for (int j = 0; j < NJ; ++j) q_out[row * NJ + j] = qf[j];
+    success_out[row] = success ? 1 : 0;
+    iters[row] = it_total;
+    searches[row] = se;
+    residual[row] = success ? st.E : E_last;
 }
 
 // ---------------------------------------------------------------- per-wave scheduler (speculative searches)
@@ -476,9 +476,10 @@ RTB_HD void ik_emit(const IkLane<NJ> &st, QA qa, const PD &p, QL qlim, int64_t t
 constexpr int kIkRing = 64;                 // outstanding (unaccounted) searches per slot
 template <int QR>
 struct IkWaveSharedT {
-    uint32_t tgt[64];                       // target index (launch_ik refuses batches of 2^32 targets or more)
+    uint32_t vix[64];                       // work-item index = output row (the target itself without a work list; < 2^32)
     double Elast[64];                       // E of the slot's last-index search (failure output)
     int16_t b[64];                          // lowest search index not yet accounted (slimit <= 32000)
+    int16_t slast[64];                      // last search index of the slot's work item
     int32_t next[64];                       // next search index to hand out (LDS atomic max)
     int32_t best[64];                       // lowest successful search index seen so far (LDS atomic min)
     int32_t it[64];                         // iterations accounted so far
@@ -490,6 +491,14 @@ struct IkWaveSharedT {
 };
 template <int NJ> using IkWaveSharedFor = IkWaveSharedT<(NJ <= kRegMaxJoints ? kRegMaxJoints : kIkMaxJoints)>;
 static_assert(sizeof(IkWaveSharedT<kRegMaxJoints>) * 8 <= 160 * 1024, "8 IK waves per CU must fit the LDS");
+
+// A work item: searches s0 .. s1 (inclusive, in the flavour's own numbering) of target `tgt`.  Without a work list item v is
+// target v with the whole range.  A search is a pure function of (target, search index), so any partition of a target's
+// searches into items can be run anywhere, in any order, and merged afterwards IN SEARCH ORDER (ik_merge_*): launch_ik uses
+// that to spread the hard targets of a batch that is small against the chip over all the waves (phased schedule, below).
+struct IkWork { int32_t tgt; int16_t s0, s1; };
+template <class SH>
+RTB_HD int64_t ik_slot_tgt(const SH &sh, int slot, const IkWork *work) { return work ? (int64_t)work[sh.vix[slot]].tgt : (int64_t)sh.vix[slot]; }
 constexpr int kIkMaxSlimit = 32000;
 constexpr int kIkMaxIlimit = 16000;         // (ilimit + 1) << 2 must fit the 16-bit record
 
@@ -530,9 +539,10 @@ RTB_HD int ik_rank(unsigned long long mask, int lane)
 
 // phase A: a lane whose search just ended posts the result and parks or goes idle
 template <int NJ, class SH>
-RTB_HD void ik_report(IkLane<NJ> &st, SH &sh, int s_last)
+RTB_HD void ik_report(IkLane<NJ> &st, SH &sh)
 {
     if (st.status != kIkRun || !st.fin) return;
+    const int s_last = sh.slast[st.slot];
     sh.rec[st.slot][st.s & (kIkRing - 1)] = (uint16_t)(1 | (st.ok ? 2 : 0) | (st.iter << 2));
     if (st.ok) ik_lds_min(&sh.best[st.slot], st.s);
     if (st.s == s_last) sh.Elast[st.slot] = st.E;
@@ -542,8 +552,9 @@ RTB_HD void ik_report(IkLane<NJ> &st, SH &sh, int s_last)
 
 // phase B: lane i accounts slot i in search order
 template <class SH>
-RTB_HD void ik_account(int i, SH &sh, int s_last)
+RTB_HD void ik_account(int i, SH &sh)
 {
+    const int s_last = sh.slast[i];
     int b = sh.b[i], it = sh.it[i], res = 0;
     for (;;) {
         const int r = sh.rec[i][b & (kIkRing - 1)];
@@ -559,7 +570,7 @@ RTB_HD void ik_account(int i, SH &sh, int s_last)
 
 // phase C: parked lanes of a resolved slot emit / release; searches beyond a known success are cancelled
 template <int NJ, class SH, class PD, class QL>
-RTB_HD void ik_finalize(IkLane<NJ> &st, SH &sh, int lane, const PD &p, QL qlim, double *__restrict__ q_out,
+RTB_HD void ik_finalize(IkLane<NJ> &st, SH &sh, int lane, const PD &p, QL qlim, const IkWork *work, double *__restrict__ q_out,
                         int32_t *__restrict__ success, int32_t *__restrict__ iters, int32_t *__restrict__ searches,
                         double *__restrict__ residual)
 {
@@ -567,11 +578,11 @@ RTB_HD void ik_finalize(IkLane<NJ> &st, SH &sh, int lane, const PD &p, QL qlim, 
     const int res = sh.res[st.slot];
     if (res == 1) {
         if (st.status == kIkParkedOk && st.s == sh.b[st.slot])
-            ik_emit<NJ>(st, ik_lds_q(sh, lane), p, qlim, sh.tgt[st.slot], p.has_q0 != 0, true, sh.it[st.slot], 0.0, q_out, success, iters, searches, residual);
+            ik_emit<NJ>(st, ik_lds_q(sh, lane), p, qlim, ik_slot_tgt(sh, st.slot, work), sh.vix[st.slot], p.has_q0 != 0, true, sh.it[st.slot], 0.0, q_out, success, iters, searches, residual);
         st.status = kIkIdle;
     } else if (res == 2) {
         if (st.status == kIkParkedLast)
-            ik_emit<NJ>(st, ik_lds_q(sh, lane), p, qlim, sh.tgt[st.slot], p.has_q0 != 0, false, sh.it[st.slot], sh.Elast[st.slot], q_out, success, iters, searches, residual);
+            ik_emit<NJ>(st, ik_lds_q(sh, lane), p, qlim, ik_slot_tgt(sh, st.slot, work), sh.vix[st.slot], p.has_q0 != 0, false, sh.it[st.slot], sh.Elast[st.slot], q_out, success, iters, searches, residual);
         st.status = kIkIdle;
     } else if (st.s > sh.best[st.slot]) {
         st.status = kIkIdle;      // a lower-indexed search already succeeded: this one can never be reported
@@ -580,11 +591,13 @@ RTB_HD void ik_finalize(IkLane<NJ> &st, SH &sh, int lane, const PD &p, QL qlim, 
 
 // phase D1 helper: initialise slot `slot` for target tgt and start its first search in this lane
 template <int NJ, class SH, class PD, class QL>
-RTB_HD void ik_start_target(IkLane<NJ> &st, SH &sh, int lane, const PD &p, QL qlim, int slot, int64_t tgt,
+RTB_HD void ik_start_target(IkLane<NJ> &st, SH &sh, int lane, const PD &p, QL qlim, int slot, int64_t v, const IkWork *work,
                             const double *__restrict__ Tep, const double *__restrict__ q0)
 {
-    const int s0 = ik_s_first(p);
-    sh.tgt[slot] = (uint32_t)tgt; sh.b[slot] = (int16_t)s0; sh.next[slot] = s0 + 1; sh.best[slot] = kIkNoBest; sh.it[slot] = 0;
+    const int64_t tgt = work ? (int64_t)work[v].tgt : v;
+    const int s0 = work ? (int)work[v].s0 : ik_s_first(p);
+    sh.vix[slot] = (uint32_t)v; sh.b[slot] = (int16_t)s0; sh.next[slot] = s0 + 1; sh.best[slot] = kIkNoBest; sh.it[slot] = 0;
+    sh.slast[slot] = (int16_t)(work ? (int)work[v].s1 : ik_s_last(p));
     sh.res[slot] = 0; sh.Elast[slot] = 0.0;
     for (int k = 0; k < kIkRing; ++k) sh.rec[slot][k] = 0;
     st.slot = slot;
@@ -600,21 +613,94 @@ RTB_HD bool ik_starved(int i, const SH &sh) { return sh.res[i] == 0 && sh.next[i
 // phase D2, step 1: idle lane number `r` (of the idle lanes) picks a slot round-robin over the nb busy
 // slots (sh.list) and the q-th next search index of it; returns whether that index may start now.
 template <class SH>
-RTB_HD bool ik_pick(const SH &sh, int r, int nb, int s_last, int &slot, int &s)
+RTB_HD bool ik_pick(const SH &sh, int r, int nb, int ni, int policy, int s_first, int &slot, int &s)
 {
-    slot = sh.list[r % nb];
-    s = sh.next[slot] + r / nb;
-    return s <= s_last && s - sh.b[slot] < kIkRing && s < sh.best[slot];
+    if (policy == 0) {
+        slot = sh.list[r % nb];
+        s = sh.next[slot] + r / nb;
+    } else {
+        // failure-weighted: a slot that has already failed f searches gets f + 1 shares of the idle lanes (its explored range
+        // doubles per round): the targets that will exhaust every search -- 1 % of a batch, 40 x the mean cost -- are walked wide
+        // early instead of keeping their wave busy after all the others have gone
+        int W = 0;
+        for (int k = 0; k < nb; ++k) { const int f = sh.b[sh.list[k]] - s_first; W += 1 + (f < 0 ? 0 : (f > 63 ? 63 : f)); }
+        const int pos = (int)(((long long)r * W) / ni);
+        int cum = 0, k = 0, w = 1;
+        for (; k < nb; ++k) {
+            const int f = sh.b[sh.list[k]] - s_first;
+            w = 1 + (f < 0 ? 0 : (f > 63 ? 63 : f));
+            if (pos < cum + w) break;
+            cum += w;
+        }
+        if (k >= nb) { k = nb - 1; cum -= w; }
+        slot = sh.list[k];
+        const int r0 = (int)(((long long)cum * ni + W - 1) / W);      // first idle-lane rank that maps to this slot
+        s = sh.next[slot] + (r - r0);
+    }
+    return s <= sh.slast[slot] && s - sh.b[slot] < kIkRing && s < sh.best[slot];
 }
 // step 2 (after every lane has picked): claim the index and start the search
 template <int NJ, class SH, class PD, class QL>
-RTB_HD void ik_start_spec(IkLane<NJ> &st, SH &sh, int lane, const PD &p, QL qlim, int slot, int s,
+RTB_HD void ik_start_spec(IkLane<NJ> &st, SH &sh, int lane, const PD &p, QL qlim, int slot, int s, const IkWork *work,
                           const double *__restrict__ Tep, const double *__restrict__ q0)
 {
     ik_lds_max(&sh.next[slot], s + 1);
-    const int64_t tgt = sh.tgt[slot];
+    const int64_t tgt = ik_slot_tgt(sh, slot, work);
     st.slot = slot;
     ik_search_begin<NJ>(st, ik_lds_q(sh, lane), p, qlim, tgt, s, p.has_q0 ? q0 + (int64_t)NJ * tgt : nullptr);
+}
+
+// ---------------------------------------------------------------- phased schedule for batches small against the chip
+// With the whole batch resident at once (BASELINE config 3: 1e5 targets on 131072 lanes) a wave is stuck with the targets it
+// drew: the ~1 % that exhaust all `slimit` searches cost 40x the mean and decide when their wave -- and the kernel -- ends
+// (CPU replay: longest wave 194 iterations, mean 97, ideal 57).  So the search range is cut into phases, each its own launch
+// over ALL the waves:   phase A  searches [first, first+6) of every target (plain mode);
+//                       phase B  the next 16 searches of the targets still unresolved (one work item each);
+//                       phase C  the rest of the range of the few still unresolved, split into <= 8 work items per target.
+// Items of a target are merged in search order, so the reported (q, success, iterations, searches, residual) are exactly
+// those of the sequential loops.  Unresolved targets are compacted with an atomic counter: the ORDER of the work list is
+// not deterministic, the results are.
+struct IkPhases { int a_last, b_last, c_chunks, c_len, s_last; };   // last search of phase A / B; chunking of phase C
+template <class PD>
+RTB_HD IkPhases ik_phases(const PD &p)
+{
+    IkPhases ph;
+    const int s0 = ik_s_first(p);
+    ph.s_last = ik_s_last(p);
+    const int total = ph.s_last - s0 + 1;
+    const int na = total < 6 ? total : 6;
+    const int nb = total - na < 16 ? total - na : 16;
+    ph.a_last = s0 + na - 1;
+    ph.b_last = ph.a_last + nb;
+    const int rest = ph.s_last - ph.b_last;
+    ph.c_chunks = rest <= 0 ? 0 : (rest + 12) / 13 > 8 ? 8 : (rest + 12) / 13;
+    ph.c_len = ph.c_chunks ? (rest + ph.c_chunks - 1) / ph.c_chunks : 0;
+    return ph;
+}
+// after phase A (plain mode, results already in the final arrays): an unresolved target becomes item `slot` of phase B
+RTB_HD IkWork ik_item_b(const IkPhases &ph, int64_t tgt) { IkWork w; w.tgt = (int32_t)tgt; w.s0 = (int16_t)(ph.a_last + 1); w.s1 = (int16_t)ph.b_last; return w; }
+// chunk c of phase C
+RTB_HD IkWork ik_item_c(const IkPhases &ph, int64_t tgt, int c)
+{
+    IkWork w;
+    w.tgt = (int32_t)tgt;
+    const int a = ph.b_last + 1 + c * ph.c_len, b = a + ph.c_len - 1;
+    w.s0 = (int16_t)a; w.s1 = (int16_t)(b > ph.s_last ? ph.s_last : b);
+    return w;
+}
+// Fold the result row `v` of a later item into the target's running result: iterations add up; a success, or the item that
+// ends with the range's last search, also supplies (q, success, searches, residual).  Returns whether the target is resolved.
+template <int NJ_RT>
+RTB_HD bool ik_merge_item(int n, bool range_ends_here, int64_t tgt, int64_t v, const double *vq, const int32_t *vok, const int32_t *vit,
+                          const int32_t *vse, const double *vE, double *q_out, int32_t *success, int32_t *iters, int32_t *searches, double *residual)
+{
+    iters[tgt] += vit[v];
+    if (vok[v] || range_ends_here) {
+        for (int j = 0; j < n; ++j) q_out[tgt * n + j] = vq[v * n + j];
+        success[tgt] = vok[v]; searches[tgt] = vse[v]; residual[tgt] = vE[v];
+        return true;
+    }
+    return false;
 }
 
 // Sequential driver (one target, searches in order): the specification the scheduler must reproduce.
@@ -641,7 +727,7 @@ RTB_HD void ik_solve_sequential(const IkDev &p, const CV &cv, QL qlim, int64_t t
         }
         it += st.iter;
         if (st.ok || s == s_last) {
-            ik_emit<NJ>(st, qa, p, qlim, tgt, p.has_q0 != 0, st.ok != 0, it, st.E, q_out, success, iters, searches, residual);
+            ik_emit<NJ>(st, qa, p, qlim, tgt, tgt, p.has_q0 != 0, st.ok != 0, it, st.E, q_out, success, iters, searches, residual);
             return;
         }
     }

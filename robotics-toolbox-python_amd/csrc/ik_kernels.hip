@@ -33,6 +33,8 @@ struct IkKernArgs {
     double *q_out;
     int32_t *success, *iters, *searches;
     double *residual;
+    const IkWork *work;              // NULL: item v is target v with the whole search range
+    const unsigned *count;           // NULL: p.N items; else the item count is read from the device (a compacted list)
 };
 
 // Wave-level driver of the scheduler phases of ik_device.h (the same sequence tests/emu replays on the CPU).
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                                                 const double *__restrict__ q0, unsigned long long *counter,
                                                 double *__restrict__ q_out, int32_t *__restrict__ success,
                                                 int32_t *__restrict__ iters, int32_t *__restrict__ searches,
-                                                double *__restrict__ residual)
+                                                double *__restrict__ residual, const IkWork *work_g, const unsigned *count_g)
 {
     __shared__ IkWaveSharedFor<NJ> sh;
     const RTB_CONST IkKernArgs *ka = (const RTB_CONST IkKernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -64,6 +66,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
     unsigned tick = 0;
     const long long patience = ik_patience(p, s_last);    // watchdog budget (ik_device.h), the pass latency included
     long long quiet = 0;
+    const unsigned long long NN = count_g ? (unsigned long long)*count_g : (unsigned long long)p.N;   // wave-uniform
     for (;;) {
         asm volatile("" : "+s"(ka));
         // the scheduling pass runs when some search has ended -- at most every (pass_mask + 1)-th iteration: a
@@ -77,11 +80,12 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
             unsigned long long *counter = ka->counter;
             double *q_out = ka->q_out, *residual = ka->residual;
             int32_t *success = ka->success, *iters = ka->iters, *searches = ka->searches;
-            ik_report<NJ>(st, sh, s_last);                                             // phase A
+            const IkWork *work = ka->work;
+            ik_report<NJ>(st, sh);                                                     // phase A
             __syncthreads();
-            if ((busy >> lane) & 1ull) ik_account(lane, sh, s_last);                    // phase B
+            if ((busy >> lane) & 1ull) ik_account(lane, sh);                            // phase B
             __syncthreads();
-            ik_finalize<NJ>(st, sh, lane, p, qlim, q_out, success, iters, searches, residual);   // phase C
+            ik_finalize<NJ>(st, sh, lane, p, qlim, work, q_out, success, iters, searches, residual);   // phase C
             const unsigned long long freed = __ballot(((busy >> lane) & 1ull) && sh.res[lane] != 0);
             if (freed) quiet = 0;
             busy &= ~freed;
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                 const int r = ik_rank(idle, lane);
                 if (((idle >> lane) & 1ull) && r < __popcll(starved)) {
                     const int slot = sh.list[r];
-                    ik_start_spec<NJ>(st, sh, lane, p, qlim, slot, sh.next[slot], Tep, q0);
+                    ik_start_spec<NJ>(st, sh, lane, p, qlim, slot, sh.next[slot], work, Tep, q0);
                 }
                 __syncthreads();
                 idle = __ballot(st.status == kIkIdle);
@@ -104,7 +108,12 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                 // free slots >= idle lanes (every busy slot keeps a lane); the per-pass cap spreads a batch
                 // smaller than the grid's lane count evenly over the waves
                 int nf = __popcll(idle);
-                nf = nf > p.fresh_cap ? p.fresh_cap : nf;
+                int cap = p.fresh_cap;
+                if (ka->count) {                    // compacted list: its size is only known here
+                    const unsigned per_wave = ((unsigned)NN + gridDim.x - 1u) / gridDim.x;
+                    cap = per_wave < 1u ? 1 : (per_wave > 64u ? 64 : (int)per_wave);
+                }
+                nf = nf > cap ? cap : nf;
                 // targets are reserved from the device-wide counter in chunks and handed out from the wave's
                 // own pool: the atomic's round trip (and its s_waitcnt) is paid once per chunk, not per pass
                 if (pool_next == pool_end) {
@@ -114,7 +123,6 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                     const unsigned lo = __shfl((unsigned)(got & 0xffffffffu), 0);
                     const unsigned hi = __shfl((unsigned)(got >> 32), 0);
                     got = ((unsigned long long)hi << 32) | lo;
-                    const unsigned long long NN = (unsigned long long)p.N;
                     pool_next = got < NN ? got : NN;
                     pool_end = got + chunk < NN ? got + chunk : NN;
                     if (pool_end == NN) drained = true;      // the counter has passed N: this is the wave's last refill
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                 int myslot = -1;
                 if (((idle >> lane) & 1ull) && r < nvalid) {
                     myslot = sh.list[r];
-                    ik_start_target<NJ>(st, sh, lane, p, qlim, myslot, (int64_t)base + r, Tep, q0);
+                    ik_start_target<NJ>(st, sh, lane, p, qlim, myslot, (int64_t)base + r, work, Tep, q0);
                 }
                 busy |= __ballot(((freeslots >> lane) & 1ull) && ik_rank(freeslots, lane) < nvalid);
                 __syncthreads();
@@ -141,9 +149,9 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                 __syncthreads();
                 const int nb = __popcll(busy);
                 int slot = 0, s = 0;
-                const bool mine = ((idle >> lane) & 1ull) && ik_pick(sh, ik_rank(idle, lane), nb, s_last, slot, s);
+                const bool mine = ((idle >> lane) & 1ull) && ik_pick(sh, ik_rank(idle, lane), nb, __popcll(idle), p.spec_policy, ik_s_first(p), slot, s);
                 __syncthreads();
-                if (mine) ik_start_spec<NJ>(st, sh, lane, p, qlim, slot, s, Tep, q0);
+                if (mine) ik_start_spec<NJ>(st, sh, lane, p, qlim, slot, s, work, Tep, q0);
                 __syncthreads();
             }
         }
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
             double *q_out = ka->q_out, *residual = ka->residual;
             int32_t *success = ka->success, *iters = ka->iters, *searches = ka->searches;
             if ((busy >> lane) & 1ull) {
-                const int64_t t = sh.tgt[lane];
+                const int64_t t = sh.vix[lane];
                 for (int j = 0; j < NJ; ++j) q_out[t * NJ + j] = nan;
                 success[t] = 0; iters[t] = -1; searches[t] = -1; residual[t] = nan;
             }
@@ -182,7 +190,48 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
     }
 }
 
+// ---- phased schedule: compaction and in-order merge of the work items (ik_device.h: ik_phases / ik_item_* / ik_merge_item)
+__global__ __launch_bounds__(256) void k_ik_list_b(IkPhases ph, int64_t N, const int32_t *__restrict__ success, IkWork *__restrict__ wB,
+                                                   unsigned *cntB)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= N || success[t]) return;
+    wB[atomicAdd(cntB, 1u)] = ik_item_b(ph, t);
+}
+
+__global__ __launch_bounds__(256) void k_ik_merge_b(IkPhases ph, int n, const IkWork *__restrict__ wB, const unsigned *cntB, const double *vq,
+                                                    const int32_t *vok, const int32_t *vit, const int32_t *vse, const double *vE, double *q_out,
+                                                    int32_t *success, int32_t *iters, int32_t *searches, double *residual, IkWork *__restrict__ wC,
+                                                    int32_t *__restrict__ ownC, unsigned *cntOwn, unsigned *cntC)
+{
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= (int64_t)*cntB) return;
+    const int64_t tgt = wB[v].tgt;
+    if (ik_merge_item<0>(n, ph.c_chunks == 0, tgt, v, vq, vok, vit, vse, vE, q_out, success, iters, searches, residual)) return;
+    const unsigned r = atomicAdd(cntOwn, 1u);
+    ownC[r] = (int32_t)tgt;
+    for (int c = 0; c < ph.c_chunks; ++c) wC[(size_t)r * ph.c_chunks + c] = ik_item_c(ph, tgt, c);
+    atomicAdd(cntC, (unsigned)ph.c_chunks);
+}
+
+__global__ __launch_bounds__(256) void k_ik_merge_c(IkPhases ph, int n, const IkWork *__restrict__ wC, const int32_t *__restrict__ ownC,
+                                                    const unsigned *cntOwn, const double *vq, const int32_t *vok, const int32_t *vit, const int32_t *vse,
+                                                    const double *vE, double *q_out, int32_t *success, int32_t *iters, int32_t *searches,
+                                                    double *residual)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= (int64_t)*cntOwn) return;
+    const int64_t tgt = ownC[r];
+    for (int c = 0; c < ph.c_chunks; ++c) {          // in search order: the first success wins, later items are discarded speculation
+        const int64_t v = r * ph.c_chunks + c;
+        if (ik_merge_item<0>(n, wC[v].s1 == ph.s_last, tgt, v, vq, vok, vit, vse, vE, q_out, success, iters, searches, residual)) break;
+    }
+}
+
 namespace {
+int g_ik_phased = 0;      // 0 never (default: the CPU replay and the GPU both say it loses), 1 automatic, 2 always (tests)
+int g_ik_spec_policy = 0;
+int g_ik_fresh_pct = 100; // share of a wave's even part of the batch it may start per scheduling pass, in percent
 int g_ik_waves_per_cu = 8;
 int g_ik_pass_mask = 3;   // measured on MI355X, 1e6 Panda targets: 8.20 (0) / 7.75 (1) / 7.66 (3) / 8.08 ms (7)
 std::mutex g_ctr_mu;
@@ -195,6 +244,9 @@ void ik_tune(const char *key, int value)
 {
     if (std::string(key) == "ik_waves_per_cu") g_ik_waves_per_cu = value < 1 ? 1 : value;
     if (std::string(key) == "ik_pass_mask") g_ik_pass_mask = value < 0 ? 0 : value;
+    if (std::string(key) == "ik_phased") g_ik_phased = value < 0 ? 0 : (value > 2 ? 2 : value);
+    if (std::string(key) == "ik_fresh_pct") g_ik_fresh_pct = value < 1 ? 1 : value;
+    if (std::string(key) == "ik_spec_policy") g_ik_spec_policy = value != 0;
 }
 
 void ik_release_device_state()
@@ -216,15 +268,15 @@ void ik_restart_host(const Chain *c, uint64_t seed, int64_t target, int draw, do
 template <int NJ>
 static void launch_nj(dim3 grid, hipStream_t s, const IkDev &p, const DevChain &dc, const double *qlim, const double *Tep,
                       const double *q0, unsigned long long *ctr, double *q_out, int32_t *success, int32_t *iters,
-                      int32_t *searches, double *residual)
+                      int32_t *searches, double *residual, const IkWork *work, const unsigned *count)
 {
     const int v = ik_step_variant(p, NJ);
     if constexpr (NJ >= 6 && NJ <= kRegMaxJoints) {        // the null-space variants exist for 6..8 joints (launch_ik checks)
-        if (v == 2) { hipLaunchKernelGGL((k_ik<NJ, 2>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual); return; }
-        if (v == 3) { hipLaunchKernelGGL((k_ik<NJ, 3>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual); return; }
+        if (v == 2) { hipLaunchKernelGGL((k_ik<NJ, 2>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count); return; }
+        if (v == 3) { hipLaunchKernelGGL((k_ik<NJ, 3>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count); return; }
     }
-    if (v & kIkStepPinv) hipLaunchKernelGGL((k_ik<NJ, 1>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual);
-    else hipLaunchKernelGGL((k_ik<NJ, 0>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual);
+    if (v & kIkStepPinv) hipLaunchKernelGGL((k_ik<NJ, 1>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count);
+    else hipLaunchKernelGGL((k_ik<NJ, 0>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count);
 }
 
 int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const double *Tep, int64_t N, const double *q0,
@@ -265,39 +317,111 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
             ring = it->second;
         }
     }
-    unsigned long long *ctr = ring + (g_ctr_next.fetch_add(1) % kCtrRing);
-    RTB_HIP(hipMemsetAsync(ctr, 0, sizeof(unsigned long long), s));
     // a batch smaller than the grid's lane count is spread over ALL the waves (fresh_cap targets per
     // wave and pass) instead of filling ceil(N/64) of them: every SIMD then holds its share of the tail
     const bool one_wave = c->n > kRegMaxJoints || (ik_step_variant(p, c->n) & kIkStepNull);   // 9..12 joints, null-space: one wave per SIMD
-    int64_t g = (int64_t)cus * (one_wave ? 4 : g_ik_waves_per_cu);
-    if (g > N) g = N;
-    const int64_t cap = (N + g - 1) / g;
-    p.fresh_cap = cap > 64 ? 64 : (int32_t)cap;
-    p.pass_mask = g_ik_pass_mask;
-    // big batches reserve in chunks (one atomic round trip per 64 / 16 targets); batches of the order of the
-    // grid's lane count reserve exactly what a pass starts, so no wave sits on targets another could run
-    const int64_t lanes = g * kWave;
-    p.pool_chunk = N >= 8 * lanes ? 64 : (N >= 3 * lanes ? 16 : 0);
-    dim3 grid((unsigned)g);
-    switch (c->n) {
-    case 1: launch_nj<1>(grid, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual); break;
-    case 2: launch_nj<2>(grid, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual); break;
-    case 3: launch_nj<3>(grid, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual); break;
-    case 4: launch_nj<4>(grid, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual); break;
-    case 5: launch_nj<5>(grid, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual); break;
-    case 6: launch_nj<6>(grid, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual); break;
-    case 7: launch_nj<7>(grid, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual); break;
-    case 8: launch_nj<8>(grid, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual); break;
-    case 9: launch_nj<9>(grid, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual); break;
-    case 10: launch_nj<10>(grid, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual); break;
-    case 11: launch_nj<11>(grid, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual); break;
-    default: launch_nj<12>(grid, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual); break;
+    const int64_t gmax = (int64_t)cus * (one_wave ? 4 : g_ik_waves_per_cu);
+    const int n = c->n;
+    // one launch of the scheduler kernel over `items` work items (the targets themselves when work == NULL)
+    auto run = [&](const IkDev &pp, int64_t items, const IkWork *work, const unsigned *count, double *qo, int32_t *ok, int32_t *it,
+                   int32_t *se, double *E) -> int {
+        IkDev p2 = pp;
+        int64_t g = gmax;
+        if (!count && g > items) g = items;
+        if (g < 1) g = 1;
+        const int64_t cap = ((items + g - 1) / g * g_ik_fresh_pct + 99) / 100;
+        p2.fresh_cap = cap > 64 ? 64 : (cap < 1 ? 1 : (int32_t)cap);
+        p2.pass_mask = g_ik_pass_mask;
+        p2.spec_policy = g_ik_spec_policy;
+        // big batches reserve in chunks (one atomic round trip per 64 / 16 targets); batches of the order of the
+        // grid's lane count reserve exactly what a pass starts, so no wave sits on targets another could run
+        const int64_t lanes = g * kWave;
+        p2.pool_chunk = count ? 0 : (items >= 8 * lanes ? 64 : (items >= 3 * lanes ? 16 : 0));
+        p2.N = items;
+        unsigned long long *ctr = ring + (g_ctr_next.fetch_add(1) % kCtrRing);
+        RTB_HIP(hipMemsetAsync(ctr, 0, sizeof(unsigned long long), s));
+        dim3 grid((unsigned)g);
+        switch (n) {
+        case 1: launch_nj<1>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
+        case 2: launch_nj<2>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
+        case 3: launch_nj<3>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
+        case 4: launch_nj<4>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
+        case 5: launch_nj<5>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
+        case 6: launch_nj<6>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
+        case 7: launch_nj<7>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
+        case 8: launch_nj<8>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
+        case 9: launch_nj<9>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
+        case 10: launch_nj<10>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
+        case 11: launch_nj<11>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
+        default: launch_nj<12>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
+        }
+        note_launch((int)grid.x, kWave, 0);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "k_ik launch");
+        return RTBHIP_OK;
+    };
+
+    // Phased schedule (ik_device.h) when the whole batch is resident at once and the search range is long enough to split;
+    // rtbhip_tune("ik_phased", 0 / 1 / 2) = never / automatic / always (tests).
+    const IkPhases ph = ik_phases(p);
+    const bool phased = g_ik_phased == 2 ? ph.b_last > ph.a_last
+                                         : (g_ik_phased == 1 && ph.b_last > ph.a_last && N <= 4 * gmax * kWave && N <= (1 << 24));
+    if (!phased) return run(p, N, nullptr, nullptr, q_out, success, iters, searches, residual);
+
+    // ---- phase A: the first searches of every target, results straight into the caller's arrays
+    IkDev pa = p;
+    pa.slimit = p.flavour == 0 ? ph.a_last : ph.a_last + 1;
+    {
+        const int rca = run(pa, N, nullptr, nullptr, q_out, success, iters, searches, residual);
+        if (rca != RTBHIP_OK) return rca;
     }
-    note_launch((int)grid.x, kWave, 0);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "k_ik launch");
-    return RTBHIP_OK;
+    // stream-ordered temporaries (kept cached by the device pool): work lists, their counters, item result rows
+    const int kc = ph.c_chunks > 0 ? ph.c_chunks : 1;
+    const size_t nB = (size_t)N, nC = (size_t)N * kc;       // worst case: nothing resolves
+    // (lists and rows are sized for that worst case -- nothing can overflow; the automatic mode only phases batches of at most
+    // 4 x the grid's lanes, so this is a few hundred MB at the very most and normally a few MB are touched)
+    unsigned *cnt = nullptr; IkWork *wB = nullptr, *wC = nullptr; int32_t *ownC = nullptr;
+    double *vq = nullptr, *vE = nullptr; int32_t *vok = nullptr, *vit = nullptr, *vse = nullptr;
+    const size_t rows = nB > nC ? nB : nC;
+    auto alloc = [&](void **ptr, size_t bytes) -> int {
+        hipError_t e = hipMallocAsync(ptr, bytes, s);
+        return e == hipSuccess ? RTBHIP_OK : hip_fail(e, "hipMallocAsync (ik phases)");
+    };
+    int rc = alloc((void **)&cnt, 4 * sizeof(unsigned));
+    if (rc == RTBHIP_OK) rc = alloc((void **)&wB, nB * sizeof(IkWork));
+    if (rc == RTBHIP_OK) rc = alloc((void **)&wC, nC * sizeof(IkWork));
+    if (rc == RTBHIP_OK) rc = alloc((void **)&ownC, nB * sizeof(int32_t));
+    if (rc == RTBHIP_OK) rc = alloc((void **)&vq, rows * n * sizeof(double));
+    if (rc == RTBHIP_OK) rc = alloc((void **)&vE, rows * sizeof(double));
+    if (rc == RTBHIP_OK) rc = alloc((void **)&vok, rows * sizeof(int32_t));
+    if (rc == RTBHIP_OK) rc = alloc((void **)&vit, rows * sizeof(int32_t));
+    if (rc == RTBHIP_OK) rc = alloc((void **)&vse, rows * sizeof(int32_t));
+    const unsigned blocks = (unsigned)((N + 255) / 256);
+    if (rc == RTBHIP_OK) {
+        hipError_t e = hipMemsetAsync(cnt, 0, 4 * sizeof(unsigned), s);
+        if (e != hipSuccess) rc = hip_fail(e, "hipMemsetAsync (ik phases)");
+    }
+    if (rc == RTBHIP_OK) {
+        // ---- phase B: unresolved targets -> one item each for the next searches
+        hipLaunchKernelGGL(k_ik_list_b, dim3(blocks), dim3(256), 0, s, ph, N, success, wB, cnt + 0);
+        rc = run(p, N, wB, cnt + 0, vq, vok, vit, vse, vE);
+    }
+    if (rc == RTBHIP_OK) {
+        // merge B; the targets still unresolved get their phase-C items (c_chunks consecutive rows each)
+        hipLaunchKernelGGL(k_ik_merge_b, dim3(blocks), dim3(256), 0, s, ph, n, wB, cnt + 0, vq, vok, vit, vse, vE, q_out, success, iters, searches,
+                           residual, wC, ownC, cnt + 1, cnt + 2);
+        if (ph.c_chunks > 0) {
+            rc = run(p, (int64_t)nC, wC, cnt + 2, vq, vok, vit, vse, vE);
+            if (rc == RTBHIP_OK)
+                hipLaunchKernelGGL(k_ik_merge_c, dim3(blocks), dim3(256), 0, s, ph, n, wC, ownC, cnt + 1, vq, vok, vit, vse, vE, q_out, success, iters,
+                                   searches, residual);
+        }
+        hipError_t e = hipGetLastError();
+        if (rc == RTBHIP_OK && e != hipSuccess) rc = hip_fail(e, "ik phase kernels");
+    }
+    for (void *ptr : {(void *)cnt, (void *)wB, (void *)wC, (void *)ownC, (void *)vq, (void *)vE, (void *)vok, (void *)vit, (void *)vse})
+        if (ptr) (void)hipFreeAsync(ptr, s);
+    return rc;
 }
 
 }  // namespace rtbhip

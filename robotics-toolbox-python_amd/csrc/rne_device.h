@@ -128,6 +128,91 @@ RTB_HD LinkBwd link_bwd(const LinkT &l)
     return o;
 }
 
+#ifndef RTB_RNE_PREFETCH
+#define RTB_RNE_PREFETCH 0
+#endif
+#ifndef RTB_RNE_LI
+#define RTB_RNE_LI 0
+#endif
+// ---- fused forms of the vector algebra of the recursions.  A sum of cross products and rotated vectors is accumulated as a
+// chain of fused multiply-adds (two per component and product) instead of "cross, cross, add, add": the same terms, one rounding
+// per product less, ~10 % fewer fp64 instructions per link.
+RTB_HD double fmad(double a, double b, double c) { return __builtin_fma(a, b, c); }
+RTB_HD V3 cross_add(V3 a, V3 b, V3 acc)          // acc + a x b
+{
+    return v3(fmad(a.y, b.z, fmad(-a.z, b.y, acc.x)), fmad(a.z, b.x, fmad(-a.x, b.z, acc.y)), fmad(a.x, b.y, fmad(-a.y, b.x, acc.z)));
+}
+template <bool MDH>
+RTB_HD V3 rot_inv_add(const Rot &r, V3 v, V3 acc)   // acc + R^T v
+{
+    if (!MDH) {
+        const double uy = fmad(r.c, v.y, -(r.s * v.x));
+        return v3(fmad(r.c, v.x, fmad(r.s, v.y, acc.x)), fmad(r.ca, uy, fmad(r.sa, v.z, acc.y)), fmad(r.ca, v.z, fmad(-r.sa, uy, acc.z)));
+    } else {
+        const double uy = fmad(r.ca, v.y, r.sa * v.z);
+        return v3(fmad(r.c, v.x, fmad(r.s, uy, acc.x)), fmad(r.c, uy, fmad(-r.s, v.x, acc.y)), fmad(r.ca, v.z, fmad(-r.sa, v.y, acc.z)));
+    }
+}
+template <bool MDH>
+RTB_HD V3 rot_fwd_add(const Rot &r, V3 v, V3 acc)   // acc + R v
+{
+    if (!MDH) {
+        const double uy = fmad(r.ca, v.y, -(r.sa * v.z));
+        return v3(fmad(r.c, v.x, fmad(-r.s, uy, acc.x)), fmad(r.s, v.x, fmad(r.c, uy, acc.y)), fmad(r.sa, v.y, fmad(r.ca, v.z, acc.z)));
+    } else {
+        const double uy = fmad(r.s, v.x, r.c * v.y);
+        return v3(fmad(r.c, v.x, fmad(-r.s, v.y, acc.x)), fmad(r.ca, uy, fmad(-r.sa, v.z, acc.y)), fmad(r.sa, uy, fmad(r.ca, v.z, acc.z)));
+    }
+}
+
+// Everything one forward step reads from the link table and from the q / qd / qdd tile, fetched as ONE batch.  In the
+// compile-time-n kernels the batch of step j+1 is issued at the top of step j (and waited for at the top of step j+1, a whole
+// step of arithmetic later): the scalar-memory and LDS round trips -- about 300 cycles each, 3 per link and pass when they were
+// taken where the data was needed (SQ counters: a third of the wave's lifetime in s_waitcnt) -- overlap the arithmetic.
+// s_waitcnt lgkmcnt counts scalar loads and LDS reads together and scalar loads return out of order, so any wait is a wait
+// for everything outstanding: the batch has to contain ALL of a step's operands, conditional ones (r, I) included.
+// The inertia tensor and the centre of mass of link j (used at the END of step j) are fetched at the top of step j, in the same
+// breath: by the time they are needed -- the one wait of the step -- the next step's batch has arrived with them, and only one
+// link's tensor is held in SGPRs at a time.
+struct FwdOps { LinkFwd f; double qj, qdj, qddj; };
+struct LinkInertia { double I[9]; double rx, ry, rz; };
+template <bool ALLREV, class LinkT, class InQ, class InQd, class InQdd>
+RTB_HD FwdOps fwd_ops(const LinkT &lt, int j, InQ qin, InQd qdin, InQdd qddin)
+{
+    FwdOps o;
+    o.f = link_fwd<ALLREV>(lt);
+    o.qj = (!ALLREV && o.f.sigma != 0) ? qin(j) : 0.0;       // only a prismatic link needs q again (its d)
+    o.qdj = qdin(j); o.qddj = qddin(j);
+    return o;
+}
+template <class LinkT>
+RTB_HD LinkInertia link_inertia(const LinkT &lt, int flags)
+{
+    LinkInertia o;
+    if (flags & kLinkIDiag) {
+        o.I[0] = lt.I[0]; o.I[4] = lt.I[4]; o.I[8] = lt.I[8];
+        o.I[1] = o.I[2] = o.I[3] = o.I[5] = o.I[6] = o.I[7] = 0.0;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o.I[k] = lt.I[k];
+    }
+    if (flags & kLinkRZero) { o.rx = 0.0; o.ry = 0.0; o.rz = 0.0; }
+    else { o.rx = lt.rx; o.ry = lt.ry; o.rz = lt.rz; }
+    return o;
+}
+struct BwdOps { LinkBwd b; double rx, ry, rz; double qj, qdj, qddj; };
+template <bool ALLREV, bool FRICTION, class LinkT, class InQ, class InQd, class InQdd>
+RTB_HD BwdOps bwd_ops(const LinkT &lt, int flags, int j, InQ qin, InQd qdin, InQdd qddin)
+{
+    BwdOps o;
+    o.b = link_bwd<ALLREV, FRICTION>(lt);
+    if (flags & kLinkRZero) { o.rx = 0.0; o.ry = 0.0; o.rz = 0.0; }
+    else { o.rx = lt.rx; o.ry = lt.ry; o.rz = lt.rz; }
+    o.qj = (!ALLREV && o.b.sigma != 0) ? qin(j) : 0.0;
+    o.qdj = qdin(j); o.qddj = qddin(j);
+    return o;
+}
+
 template <int NJ, bool MDH, bool FRICTION, bool ALLREV, bool HAVE_TRIG, class LinksP, class InQ, class InQd, class InQdd, class Out>
 RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_MAX_JOINTS], double (&ct)[NJ > 0 ? NJ : RTBHIP_MAX_JOINTS],
                      V3 grav, V3 ftip, V3 ntip, InQ qin, InQd qdin, InQdd qddin, Out tau)
@@ -142,17 +227,27 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
     // ---- forward recursion (ne.c:133-348)
     V3 w = v3(0, 0, 0), wd = v3(0, 0, 0), a = v3(0, 0, 0);
     double qddx = 0.0, qddy = 0.0;  // ne.c:311 lets gravity leak into qddv.x/.y for later links
+    constexpr bool PF = RTB_RNE_PREFETCH != 0 && NJ > 0;
+    FwdOps cur = fwd_ops<ALLREV>(links[0], 0, qin, qdin, qddin);
 #pragma unroll
     for (int j = 0; j < n; ++j) {
-        const auto &lt = links[j];                    // r and I: loaded inside the branches that need them
-        const LinkFwd l = link_fwd<ALLREV>(lt);
+        if (!PF && j > 0) cur = fwd_ops<ALLREV>(links[j], j, qin, qdin, qddin);
+        FwdOps nxt = cur;
+        if (PF) sched_fence();     // cur's wait sits above this line, the next batch below it
+        if (PF && j + 1 < n) nxt = fwd_ops<ALLREV>(links[j + 1], j + 1, qin, qdin, qddin);
+#if RTB_RNE_LI
+        const LinkInertia li = link_inertia(links[j], flg[j]);
+#else
+        const auto &li = links[j];
+#endif
+        const LinkFwd &l = cur.f;
         const bool pris = ALLREV ? false : (l.sigma != 0);
-        const double qdj = qdin(j), qddj = qddin(j);
+        const double qdj = cur.qdj, qddj = cur.qddj;
         if (NJ == 0) {
             const double th = pris ? l.theta : qin(j) + l.offset;
             rtb_sincos(th, &st[j], &ct[j]);
         }
-        const double d = pris ? qin(j) + l.offset : l.d;
+        const double d = pris ? (NJ == 0 ? qin(j) : cur.qj) + l.offset : l.d;
         const Rot R = {st[j], ct[j], l.sa, l.ca};
         const V3 ps = link_offset<MDH>(l, d);
         const V3 qdv = v3(0, 0, qdj);
@@ -165,9 +260,10 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
                 } else {
                     const V3 t1 = rot_inv<MDH>(R, w);
                     wn = addz(t1, qdj);
-                    const V3 u = crossz(t1, qdj) + rot_inv<MDH>(R, wd);
+                    // crossz(t1, qdj) + R^T wd [+ qddv]
+                    const V3 u = rot_inv_add<MDH>(R, wd, v3(t1.y * qdj, -(t1.x * qdj), 0.0));
                     wdn = ALLREV ? addz(u, qddj) : u + qddv;
-                    an = rot_inv<MDH>(R, (cross(wd, ps) + cross(w, cross(w, ps))) + a);
+                    an = rot_inv<MDH>(R, cross_add(wd, ps, cross_add(w, cross(w, ps), a)));
                 }
             } else {
                 if (j == 0) {
@@ -175,7 +271,7 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
                 } else {
                     wn = rot_inv<MDH>(R, w);
                     wdn = rot_inv<MDH>(R, wd);
-                    an = rot_inv<MDH>(R, (cross(wd, ps) + cross(w, cross(w, ps))) + a);
+                    an = rot_inv<MDH>(R, cross_add(wd, ps, cross_add(w, cross(w, ps), a)));
                     an = (an + 2.0 * cross(wn, qdv)) + qddv;
                 }
             }
@@ -183,9 +279,11 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
             if (!pris) {
                 const V3 t1 = (j == 0) ? qdv : addz(w, qdj);
                 wn = rot_inv<MDH>(R, t1);
-                const V3 t3 = (j == 0) ? qddv : (ALLREV ? addz(wd, qddj) : wd + qddv) + crossz(w, qdj);
+                // (wd + qddv) + crossz(w, qdj)
+                const V3 t3 = (j == 0) ? qddv : (ALLREV ? v3(fmad(w.y, qdj, wd.x), fmad(-w.x, qdj, wd.y), wd.z + qddj)
+                                                         : (wd + qddv) + crossz(w, qdj));
                 wdn = rot_inv<MDH>(R, t3);
-                an = (cross(wdn, ps) + cross(wn, cross(wn, ps))) + rot_inv<MDH>(R, (j == 0) ? grav : a);
+                an = cross_add(wdn, ps, cross_add(wn, cross(wn, ps), rot_inv<MDH>(R, (j == 0) ? grav : a)));
             } else {
                 wn = (j == 0) ? v3(0, 0, 0) : rot_inv<MDH>(R, w);
                 wdn = (j == 0) ? v3(0, 0, 0) : rot_inv<MDH>(R, wd);
@@ -207,60 +305,65 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
         // 12; the values are those of the general formulas (up to the sign of a zero)
         V3 ac = a;
         if (!(flg[j] & kLinkRZero)) {
-            const V3 rc = v3(lt.rx, lt.ry, lt.rz);
-            ac = (cross(wd, rc) + cross(w, cross(w, rc))) + a;         // ne.c:228-232
+            const V3 rc = v3(li.rx, li.ry, li.rz);
+            ac = cross_add(wd, rc, cross_add(w, cross(w, rc), a));     // ne.c:228-232
         }
         F[j] = l.m * ac;
         if (flg[j] & kLinkIDiag) {
-            const V3 iw = v3(lt.I[0] * w.x, lt.I[4] * w.y, lt.I[8] * w.z);
-            Nn[j] = v3(lt.I[0] * wd.x, lt.I[4] * wd.y, lt.I[8] * wd.z) + cross(w, iw);
+            const V3 iw = v3(li.I[0] * w.x, li.I[4] * w.y, li.I[8] * w.z);
+            Nn[j] = cross_add(w, iw, v3(li.I[0] * wd.x, li.I[4] * wd.y, li.I[8] * wd.z));
         } else {
-            Nn[j] = inertia_times(lt, wd) + cross(w, inertia_times(lt, w));
+            Nn[j] = cross_add(w, inertia_times(li, w), inertia_times(li, wd));
         }
-        if (NJ > 0) sched_fence();   // keep link j+1's scalar table loads from being hoisted over link j
+        cur = nxt;
+        if (!PF && NJ > 0) sched_fence();
     }
 
     // ---- backward recursion + joint projection (ne.c:354-492), fused
     V3 f = ftip, nn = ntip;   // f_{j+1}, n_{j+1}; the reference's "tip" values for the last link
     Rot Rn = {0, 1, 0, 1};    // frame of link j+1
     V3 psn = v3(0, 0, 0);
+    BwdOps bc = bwd_ops<ALLREV, FRICTION>(links[n - 1], flg[n - 1], n - 1, qin, qdin, qddin);
 #pragma unroll
     for (int jj = 0; jj < n; ++jj) {
         const int j = n - 1 - jj;
-        const auto &lt = links[j];
-        const LinkBwd l = link_bwd<ALLREV, FRICTION>(lt);
+        if (!PF && jj > 0) bc = bwd_ops<ALLREV, FRICTION>(links[j], flg[j], j, qin, qdin, qddin);
+        BwdOps bn = bc;
+        if (PF) sched_fence();
+        if (PF && j > 0) bn = bwd_ops<ALLREV, FRICTION>(links[j - 1], flg[j - 1], j - 1, qin, qdin, qddin);
+        const LinkBwd &l = bc.b;
         const bool last = (jj == 0);
         const bool pris = ALLREV ? false : (l.sigma != 0);
         const bool rzero = (flg[j] & kLinkRZero) != 0;
-        const V3 rc = rzero ? v3(0, 0, 0) : v3(lt.rx, lt.ry, lt.rz);
-        const double d = pris ? qin(j) + l.offset : l.d;
+        const V3 rc = v3(bc.rx, bc.ry, bc.rz);
+        const double d = pris ? (NJ == 0 ? qin(j) : bc.qj) + l.offset : l.d;
         const Rot R = {st[j], ct[j], l.sa, l.ca};
         const V3 ps = link_offset<MDH>(l, d);
         V3 fj, nj;
         if (MDH) {
             const V3 fn = last ? f : rot_fwd<MDH>(Rn, f);
             fj = fn + F[j];
-            const V3 t1 = last ? nn : rot_fwd<MDH>(Rn, nn) + cross(psn, fn);
-            nj = rzero ? t1 + Nn[j] : (t1 + cross(rc, F[j])) + Nn[j];
+            const V3 base = rzero ? Nn[j] : cross_add(rc, F[j], Nn[j]);
+            nj = last ? nn + base : cross_add(psn, fn, rot_fwd_add<MDH>(Rn, nn, base));
         } else {
-            fj = F[j] + (last ? f : rot_fwd<MDH>(Rn, f));
-            V3 t1 = cross(ps + rc, F[j]);
-            if (!last) t1 = t1 + rot_fwd<MDH>(Rn, cross(rot_inv<MDH>(Rn, ps), f) + nn);
-            else t1 = (t1 + cross(ps, f)) + nn;
-            nj = t1 + Nn[j];
+            fj = last ? F[j] + f : rot_fwd_add<MDH>(Rn, f, F[j]);
+            const V3 base = cross_add(ps + rc, F[j], Nn[j]);
+            if (!last) nj = rot_fwd_add<MDH>(Rn, cross_add(rot_inv<MDH>(Rn, ps), f, nn), base);
+            else nj = cross_add(ps, f, nn + base);
         }
         // joint axis in the link frame: z for MDH, R^T z = (0, sin alpha, cos alpha) for DH
         const V3 prj = pris ? fj : nj;
-        const double qdj = qdin(j), qddj = qddin(j);
-        double t = MDH ? prj.z : l.sa * prj.y + l.ca * prj.z;
-        t += l.gjm * qddj;
+        const double qdj = bc.qdj, qddj = bc.qddj;
+        double t = MDH ? prj.z : fmad(l.sa, prj.y, l.ca * prj.z);
+        t = fmad(l.gjm, qddj, t);
         if (FRICTION) {
-            t += l.gb * qdj;
-            t += l.ag * ((qdj > 0 ? l.Tc0 : 0.0) + (qdj < 0 ? l.Tc1 : 0.0));
+            t = fmad(l.gb, qdj, t);
+            t = fmad(l.ag, (qdj > 0 ? l.Tc0 : 0.0) + (qdj < 0 ? l.Tc1 : 0.0), t);
         }
         tau(j, t);
         f = fj; nn = nj; Rn = R; psn = ps;
-        if (NJ > 0) sched_fence();
+        bc = bn;
+        if (!PF && NJ > 0) sched_fence();
     }
 }
 

@@ -339,7 +339,8 @@ struct EmuWave {
 
 template <int NJ>
 static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const double *Tep, const double *q0, double *q_out,
-                           int32_t *success, int32_t *iters, int32_t *searches, double *residual, double *stats)
+                           int32_t *success, int32_t *iters, int32_t *searches, double *residual, double *stats,
+                           const IkWork *work = nullptr)
 {
     const DevChain cv = chain_host_view(c);
     const double *qlim = c->qlim.data();
@@ -365,7 +366,7 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
                     fprintf(stderr, "wave %zu busy=%llx exhausted=%d counter=%llu\n", wi, w.busy, (int)w.exhausted, counter);
                     for (int l = 0; l < kWave; ++l)
                         if ((w.busy >> l) & 1ull)
-                            fprintf(stderr, "  slot %d tgt=%lld b=%d next=%d best=%d it=%d res=%d\n", l, (long long)w.sh.tgt[l], w.sh.b[l], w.sh.next[l], w.sh.best[l], w.sh.it[l], w.sh.res[l]);
+                            fprintf(stderr, "  slot %d item=%lld b=%d next=%d best=%d it=%d res=%d\n", l, (long long)w.sh.vix[l], w.sh.b[l], w.sh.next[l], w.sh.best[l], w.sh.it[l], w.sh.res[l]);
                     for (int l = 0; l < kWave; ++l)
                         fprintf(stderr, "  lane %d status=%d slot=%d s=%d iter=%d fin=%d\n", l, w.st[l].status, w.st[l].slot, w.st[l].s, w.st[l].iter, w.st[l].fin);
                 }
@@ -378,9 +379,9 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
             if (w.first || ((w.tick++ & p.pass_mask) == 0 && anyfin)) {
                 w.first = false;
                 w.passes++;
-                for (int l = 0; l < kWave; ++l) ik_report<NJ>(w.st[l], w.sh, s_last);
-                for (int l = 0; l < kWave; ++l) if ((w.busy >> l) & 1ull) ik_account(l, w.sh, s_last);
-                for (int l = 0; l < kWave; ++l) ik_finalize<NJ>(w.st[l], w.sh, l, p, qlim, q_out, success, iters, searches, residual);
+                for (int l = 0; l < kWave; ++l) ik_report<NJ>(w.st[l], w.sh);
+                for (int l = 0; l < kWave; ++l) if ((w.busy >> l) & 1ull) ik_account(l, w.sh);
+                for (int l = 0; l < kWave; ++l) ik_finalize<NJ>(w.st[l], w.sh, l, p, qlim, work, q_out, success, iters, searches, residual);
                 const unsigned long long freed = ballot(w, [&](int l) { return ((w.busy >> l) & 1ull) && w.sh.res[l] != 0; });
                 if (freed) w.quiet = 0;
                 w.busy &= ~freed;
@@ -394,7 +395,7 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
                         const int r = ik_rank(idle, l);
                         if (((idle >> l) & 1ull) && r < ns) {
                             const int slot = w.sh.list[r];
-                            ik_start_spec<NJ>(w.st[l], w.sh, l, p, qlim, slot, w.sh.next[slot], Tep, q0);
+                            ik_start_spec<NJ>(w.st[l], w.sh, l, p, qlim, slot, w.sh.next[slot], work, Tep, q0);
                         }
                     }
                     idle = ballot(w, [&](int l) { return w.st[l].status == kIkIdle; });
@@ -423,7 +424,7 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
                     for (int l = 0; l < kWave; ++l) {
                         const int r = ik_rank(idle, l);
                         if (((idle >> l) & 1ull) && r < nvalid)
-                            ik_start_target<NJ>(w.st[l], w.sh, l, p, qlim, w.sh.list[r], (int64_t)base + r, Tep, q0);
+                            ik_start_target<NJ>(w.st[l], w.sh, l, p, qlim, w.sh.list[r], (int64_t)base + r, work, Tep, q0);
                     }
                     w.busy |= ballot(w, [&](int l) { return ((freeslots >> l) & 1ull) && ik_rank(freeslots, l) < nvalid; });
                     idle = ballot(w, [&](int l) { return w.st[l].status == kIkIdle; });
@@ -434,8 +435,8 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
                     int slot[kWave], ss[kWave];
                     bool mine[kWave];
                     for (int l = 0; l < kWave; ++l)
-                        mine[l] = ((idle >> l) & 1ull) && ik_pick(w.sh, ik_rank(idle, l), nb, s_last, slot[l], ss[l]);
-                    for (int l = 0; l < kWave; ++l) if (mine[l]) ik_start_spec<NJ>(w.st[l], w.sh, l, p, qlim, slot[l], ss[l], Tep, q0);
+                        mine[l] = ((idle >> l) & 1ull) && ik_pick(w.sh, ik_rank(idle, l), nb, __builtin_popcountll(idle), p.spec_policy, ik_s_first(p), slot[l], ss[l]);
+                    for (int l = 0; l < kWave; ++l) if (mine[l]) ik_start_spec<NJ>(w.st[l], w.sh, l, p, qlim, slot[l], ss[l], work, Tep, q0);
                 }
             }
             if (w.busy == 0 && w.exhausted) { w.done = true; --live; continue; }
@@ -457,6 +458,61 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
     return 0;
 }
 
+// launch_ik's phased schedule (ik_kernels.hip) replayed with the same planning / item / merge functions of ik_device.h: phase A in
+// plain mode into the final arrays, then the work lists of phases B and C through the wave scheduler, merged in search order.
+template <int NJ>
+static int emu_ik_phased_run(const Chain *c, const IkDev &p, int waves, const double *Tep, const double *q0, double *q_out,
+                             int32_t *success, int32_t *iters, int32_t *searches, double *residual, double *stats)
+{
+    const int n = NJ;
+    const IkPhases ph = ik_phases(p);
+    if (ph.b_last <= ph.a_last) return emu_ik_wave_run<NJ>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats);
+    double st3[3][4] = {{0}};
+    IkDev pa = p;
+    pa.slimit = p.flavour == 0 ? ph.a_last : ph.a_last + 1;
+    int rc = emu_ik_wave_run<NJ>(c, pa, waves, Tep, q0, q_out, success, iters, searches, residual, st3[0]);
+    if (rc) return rc;
+    std::vector<IkWork> wB;
+    for (int64_t t = p.N - 1; t >= 0; --t)                 // any order will do (the device's is whatever the atomics give): reversed here
+        if (!success[t]) wB.push_back(ik_item_b(ph, t));
+    auto run_items = [&](const std::vector<IkWork> &w, std::vector<double> &vq, std::vector<int32_t> &vok, std::vector<int32_t> &vit,
+                         std::vector<int32_t> &vse, std::vector<double> &vE, double *stats_out) {
+        const size_t m = w.size();
+        vq.assign(m * n + 1, 0.0); vok.assign(m + 1, 0); vit.assign(m + 1, 0); vse.assign(m + 1, 0); vE.assign(m + 1, 0.0);
+        if (!m) return 0;
+        IkDev pi = p;
+        pi.N = (int64_t)m;
+        const int64_t cap = ((int64_t)m + waves - 1) / waves;
+        pi.fresh_cap = cap > 64 ? 64 : (cap < 1 ? 1 : (int)cap);
+        pi.pool_chunk = 0;
+        return emu_ik_wave_run<NJ>(c, pi, waves, Tep, q0, vq.data(), vok.data(), vit.data(), vse.data(), vE.data(), stats_out, w.data());
+    };
+    std::vector<double> vq, vE; std::vector<int32_t> vok, vit, vse;
+    rc = run_items(wB, vq, vok, vit, vse, vE, st3[1]);
+    if (rc) return rc;
+    std::vector<IkWork> wC; std::vector<int32_t> own;
+    for (size_t v = 0; v < wB.size(); ++v) {
+        const int64_t tgt = wB[v].tgt;
+        if (ik_merge_item<0>(n, ph.c_chunks == 0, tgt, (int64_t)v, vq.data(), vok.data(), vit.data(), vse.data(), vE.data(), q_out, success, iters, searches, residual)) continue;
+        own.push_back((int32_t)tgt);
+        for (int k = 0; k < ph.c_chunks; ++k) wC.push_back(ik_item_c(ph, tgt, k));
+    }
+    if (ph.c_chunks > 0) {
+        rc = run_items(wC, vq, vok, vit, vse, vE, st3[2]);
+        if (rc) return rc;
+        for (size_t r = 0; r < own.size(); ++r)
+            for (int k = 0; k < ph.c_chunks; ++k) {
+                const int64_t v = (int64_t)r * ph.c_chunks + k;
+                if (ik_merge_item<0>(n, wC[v].s1 == ph.s_last, own[r], v, vq.data(), vok.data(), vit.data(), vse.data(), vE.data(), q_out, success, iters, searches, residual)) break;
+            }
+    }
+    if (stats) for (int k = 0; k < 4; ++k) stats[k] = st3[0][k] + st3[1][k] + st3[2][k];   // [0]: the launches follow one another
+    if (getenv("EMU_IK_DEBUG"))
+        fprintf(stderr, "phases: A max %g tot %g useful %g | B items %zu max %g tot %g useful %g | C items %zu max %g tot %g useful %g\n", st3[0][0], st3[0][1], st3[0][2],
+                wB.size(), st3[1][0], st3[1][1], st3[1][2], wC.size(), st3[2][0], st3[2][1], st3[2][2]);
+    return 0;
+}
+
 // null-space terms for the next emu_ik / emu_ik_wave calls (kq <= 0: none)
 static double g_emu_ns[4] = {0.0, 0.0, 0.1, 0.3};
 extern "C" void emu_ik_nullspace(double kq, double km, double ps, double pi) { g_emu_ns[0] = kq; g_emu_ns[1] = km; g_emu_ns[2] = ps; g_emu_ns[3] = pi; }
@@ -470,7 +526,7 @@ extern "C" int emu_ik(rtbhip_chain_t h, const double *Tep, int64_t N, const doub
     if (!c || c->n < 1 || c->n > kIkMaxJoints) return -1;
     IkDev p;
     p.ilimit = ilimit; p.slimit = slimit; p.reject_jl = reject_jl; p.method = method; p.flavour = flavour;
-    p.has_q0 = q0 != nullptr; p.tol = tol; p.lambda = lambda; p.seed = seed; p.N = N; p.fresh_cap = 64; p.pool_chunk = 64; p.pass_mask = 0; p.pad = 0;
+    p.has_q0 = q0 != nullptr; p.tol = tol; p.lambda = lambda; p.seed = seed; p.N = N; p.fresh_cap = 64; p.pool_chunk = 64; p.pass_mask = 0; p.spec_policy = getenv("EMU_IK_SPEC_POLICY") ? atoi(getenv("EMU_IK_SPEC_POLICY")) : 0;
     p.kq = g_emu_ns[0]; p.km = g_emu_ns[1]; p.ps = g_emu_ns[2]; p.pi = g_emu_ns[3];
     for (int k = 0; k < 6; ++k) p.we[k] = we6 ? we6[k] : 1.0;
     switch (c->n) {
@@ -499,7 +555,7 @@ extern "C" int emu_ik_wave(rtbhip_chain_t h, int waves, double *stats, const dou
     if (!c || c->n < 1 || c->n > kIkMaxJoints) return -1;
     IkDev p;
     p.ilimit = ilimit; p.slimit = slimit; p.reject_jl = reject_jl; p.method = method; p.flavour = flavour;
-    p.has_q0 = q0 != nullptr; p.tol = tol; p.lambda = lambda; p.seed = seed; p.N = N; p.fresh_cap = 64; p.pool_chunk = 64; p.pass_mask = 0; p.pad = 0;
+    p.has_q0 = q0 != nullptr; p.tol = tol; p.lambda = lambda; p.seed = seed; p.N = N; p.fresh_cap = 64; p.pool_chunk = 64; p.pass_mask = 0; p.spec_policy = getenv("EMU_IK_SPEC_POLICY") ? atoi(getenv("EMU_IK_SPEC_POLICY")) : 0;
     p.kq = g_emu_ns[0]; p.km = g_emu_ns[1]; p.ps = g_emu_ns[2]; p.pi = g_emu_ns[3];
     for (int k = 0; k < 6; ++k) p.we[k] = we6 ? we6[k] : 1.0;
     if (const char *pm = getenv("EMU_IK_PASS_MASK")) p.pass_mask = atoi(pm);
@@ -507,20 +563,15 @@ extern "C" int emu_ik_wave(rtbhip_chain_t h, int waves, double *stats, const dou
       const int64_t lanes = g * kWave; p.pool_chunk = N >= 8 * lanes ? 64 : (N >= 3 * lanes ? 16 : 0); }
     if (const char *fc = getenv("EMU_IK_FRESH_CAP")) p.fresh_cap = atoi(fc);
     int rc = 0;
+    const bool phased = getenv("EMU_IK_PHASED") != nullptr && atoi(getenv("EMU_IK_PHASED")) != 0;
+#define RTB_EMU_IK(NJ) case NJ: rc = phased ? emu_ik_phased_run<NJ>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats) \
+                                             : emu_ik_wave_run<NJ>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
     switch (c->n) {
-    case 1: rc = emu_ik_wave_run<1>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
-    case 2: rc = emu_ik_wave_run<2>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
-    case 3: rc = emu_ik_wave_run<3>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
-    case 4: rc = emu_ik_wave_run<4>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
-    case 5: rc = emu_ik_wave_run<5>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
-    case 6: rc = emu_ik_wave_run<6>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
-    case 7: rc = emu_ik_wave_run<7>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
-    case 8: rc = emu_ik_wave_run<8>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
-    case 9: rc = emu_ik_wave_run<9>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
-    case 10: rc = emu_ik_wave_run<10>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
-    case 11: rc = emu_ik_wave_run<11>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
-    default: rc = emu_ik_wave_run<12>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
+    RTB_EMU_IK(1) RTB_EMU_IK(2) RTB_EMU_IK(3) RTB_EMU_IK(4) RTB_EMU_IK(5) RTB_EMU_IK(6) RTB_EMU_IK(7) RTB_EMU_IK(8) RTB_EMU_IK(9) RTB_EMU_IK(10) RTB_EMU_IK(11)
+    default: rc = phased ? emu_ik_phased_run<12>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats)
+                         : emu_ik_wave_run<12>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
     }
+#undef RTB_EMU_IK
     return rc;
 }
 
