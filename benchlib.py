@@ -116,12 +116,19 @@ class Ranks:
         self.barrier()
         t0 = time.perf_counter()
         e0.record()
+        trace = [] if os.environ.get("RTBHIP_BENCH_TRACE") else None
         for _ in range(steps):
+            if trace is not None:
+                ta = time.perf_counter()
             step()
+            if trace is not None:
+                trace.append(time.perf_counter() - ta)
         e1.record()
         self.barrier()
         elapsed = time.perf_counter() - t0
         dev_ms = e0.elapsed_time(e1)
+        if trace is not None and self.rank == 0:      # where does the host spend the loop?  (diagnosis only)
+            sys.stderr.write("bench trace: host us per step " + " ".join("%.0f" % (x * 1e6) for x in trace) + " | loop %.0f us\n" % (elapsed * 1e6))
         return self.max_over_ranks(elapsed), dev_ms / steps
 
     def gather_ms(self, local_out):

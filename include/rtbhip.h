@@ -116,7 +116,7 @@ int rtbhip_hessian_from_jacobian(const double *J, int64_t N, int32_t n, double *
 int rtbhip_angle_axis(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, double *e, int32_t mem, void *stream);
 
 /* Differential-kinematics consumers computed from the Jacobian while it is still in registers (SURVEY 8f-4;
- * chains of up to 10 joints):
+ * compile-time joint counts up to 16 -- 1..8 at two waves per SIMD, 9..16 at one, the longest with some scratch):
  *   rtbhip_jacob_dot       Robot.jacob0_dot (robot/Robot.py:964-1098, representation=None): Jd (N,6,n) = H(q) . qd,
  *                          frame 0 -> hessian0, 1 -> hessiane; qd is (N, q_width) like q
  *   rtbhip_manipulability  ETS.manipulability (robot/ETS.py:1687-1819): m (N); method 0 "yoshikawa",
@@ -159,7 +159,8 @@ int rtbhip_partial_fkine0(rtbhip_chain_t chain, const double *q, int64_t N, cons
  * pinv_damping; both take the minimum-norm step J^T (J J^T + d^2 I)^-1 e, see ik_device.h); seed keys the counter-based restart generator (the reference uses an
  * unseeded std::rand, ik.cpp:293).  flavour 0 reproduces the C loop (ETS.ik_LM), 1 the Python
  * solver's loop (ETS.ikine_LM, robot/IK.py:297-367: E tested after the step, %-wrap).
- * Outputs: q_out (N,n), success/iters/searches int32 (N), residual (N). */
+ * Outputs: q_out (N,n), success/iters/searches int32 (N), residual (N).  Chains of up to 16 joints (1..8 at two waves per
+ * SIMD, 9..12 at one, 13..16 with their normal equations partly in scratch). */
 int rtbhip_ik_lm(rtbhip_chain_t chain, const double *Tep, int64_t N, const double *q0,
                  int32_t ilimit, int32_t slimit, double tol, int32_t reject_jl, const double *we6,
                  double lambda, int32_t method, int32_t flavour, uint64_t seed, double *q_out,
@@ -170,7 +171,7 @@ int rtbhip_ik_lm(rtbhip_chain_t chain, const double *Tep, int64_t N, const doubl
  * robot/IK.py:507-576 `_null_Sigma`, `_calc_qnull`, added to the step at :758, :1015, :1215): joint-limit avoidance with
  * gain 1/kq inside the influence distance pi (minimum distance ps) and manipulability maximisation with gain 1/km,
  * projected into the null space of J.  flavour must be 1.  As in the reference the term is applied only when kq > 0;
- * chains of 6..8 joints; kq > 0 on any other chain returns RTBHIP_ELIMIT (nothing is dropped silently). */
+ * chains of 6..12 joints; kq > 0 on any other chain returns RTBHIP_ELIMIT (nothing is dropped silently). */
 int rtbhip_ik_lm_nullspace(rtbhip_chain_t chain, const double *Tep, int64_t N, const double *q0,
                            int32_t ilimit, int32_t slimit, double tol, int32_t reject_jl, const double *we6,
                            double lambda, int32_t method, int32_t flavour, uint64_t seed,
@@ -200,7 +201,8 @@ int rtbhip_rne(rtbhip_dyn_t dyn, const double *q, const double *qd, const double
  *   rtbhip_coriolis  Dynamics.coriolis (:765-861): C (N,n,n), friction removed as nofriction(True, True) does
  *   rtbhip_accel     Dynamics.accel    (:424-509): qdd (N,n) = M^-1 (torque - rne(q, qd, 0)); grav3 in the
  *                    convention of rtbhip_rne (what frne.frne is handed)
- * Chains of up to 10 joints; longer ones return RTBHIP_ELIMIT. */
+ * Chains of up to 16 joints (beyond 10 the per-link state spills and one wave's (n,n) tile takes most of a CU's LDS: served,
+ * not fast); longer ones return RTBHIP_ELIMIT. */
 int rtbhip_inertia(rtbhip_dyn_t dyn, const double *q, int64_t N, double *M, int32_t mem, void *stream);
 int rtbhip_coriolis(rtbhip_dyn_t dyn, const double *q, const double *qd, int64_t N, double *C, int32_t mem,
                     void *stream);
@@ -217,6 +219,7 @@ int rtbhip_accel(rtbhip_dyn_t dyn, const double *q, const double *qd, const doub
  *   m,h,I   the group's spatial inertia about the group-frame origin: mass, first moment sum(m r), rotational
  *           inertia (xx,yy,zz,xy,xz,yz).  The reference's own value is the plain sum of the member links'
  *           SpatialInertia(m, r) (:1793-1800), i.e. I = sum m (|r|^2 1 - r r^T) and no inertia tensor.
+ * Up to 24 groups (17..24 with the per-group state partly in scratch).
  * rtbhip_tree_rne: q,qd,qdd (N,ng); gravity3 = the robot's gravity vector (e.g. 0,0,-9.81; the base is
  * accelerated by its negative, :1804-1807); tau (N,ng), column j = group j as the reference's Q[:, j]. */
 typedef struct rtbhip_tree_group {

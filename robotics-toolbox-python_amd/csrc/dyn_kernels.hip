@@ -16,6 +16,7 @@ namespace rtbhip {
 
 typedef const __attribute__((address_space(4))) DevLink *ConstLinksD;
 constexpr int kDW = 64;
+constexpr int kDynMaxJoints = 16;
 
 struct DynParams {
     int32_t n, mode;
@@ -146,7 +147,7 @@ int launch_dyn(const Dyn *d, const DevLink *links, int mode, const double *q, co
                int64_t N, const double *grav3, double *out, hipStream_t s)
 {
     if (N == 0) return RTBHIP_OK;
-    if (d->n > 10) { set_error("inertia/coriolis/accel: this build handles chains of up to 10 joints on the device"); return RTBHIP_ELIMIT; }
+    if (d->n > kDynMaxJoints) { set_error("inertia/coriolis/accel: this build handles chains of up to 16 joints on the device"); return RTBHIP_ELIMIT; }
     const int64_t tiles = (N + kDW - 1) / kDW;
     if (tiles > 0x7fffffff) { set_error("inertia/coriolis/accel: batch too large for one launch"); return RTBHIP_ELIMIT; }
     DynParams dp;
@@ -168,8 +169,17 @@ int launch_dyn(const Dyn *d, const DevLink *links, int mode, const double *q, co
     case 7: e = launch_nj<7>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
     case 8: e = launch_nj<8>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
     case 9: e = launch_nj<9>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;   // 9, 10: one wave per SIMD
-    default: e = launch_nj<10>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    case 10: e = launch_nj<10>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    // 11..16: the per-link state of the recursion no longer fits the register file (scratch) and the (n,n) tile of a wave
+    // takes most of a CU's LDS -- one wave per CU; served, not fast
+    case 11: e = launch_nj<11>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    case 12: e = launch_nj<12>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    case 13: e = launch_nj<13>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    case 14: e = launch_nj<14>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    case 15: e = launch_nj<15>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    default: e = launch_nj<16>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
     }
+    if (lds > 160 * 1024) { set_error("inertia/coriolis/accel: the chain needs more LDS than a CU has"); return RTBHIP_ELIMIT; }
     note_launch((int)grid.x, kDW, (int)lds);
     if (e != hipSuccess) return hip_fail(e, "k_dyn launch");
     return RTBHIP_OK;

@@ -420,7 +420,7 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, Q
 template <class PD>
 RTB_HD int ik_step_variant(const PD &p, int n)
 {
-    return (p.method >= 3 ? kIkStepPinv : 0) | ((p.kq > 0.0 && n >= 6) ? kIkStepNull : 0);
+    return (p.method >= 3 ? kIkStepPinv : 0) | ((p.kq > 0.0 && n >= 6 && n <= 12) ? kIkStepNull : 0);
 }
 template <int NJ, class PD, class CV, class QL, class TD, class QA>
 RTB_HD void ik_iter_any(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, QA qa)

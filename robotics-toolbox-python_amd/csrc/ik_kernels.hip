@@ -38,6 +38,7 @@ struct IkKernArgs {
 };
 
 // Wave-level driver of the scheduler phases of ik_device.h (the same sequence tests/emu replays on the CPU).
+constexpr int kIkNullMax = 12;   // null-space step variants: 6..8 joints in registers, 9..12 with scratch
 #ifndef RTB_IK_WAVES
 #define RTB_IK_WAVES 2
 #endif
@@ -231,7 +232,8 @@ __global__ __launch_bounds__(256) void k_ik_merge_c(IkPhases ph, int n, const Ik
 namespace {
 int g_ik_phased = 0;      // 0 never (default: the CPU replay and the GPU both say it loses), 1 automatic, 2 always (tests)
 int g_ik_spec_policy = 0;
-int g_ik_fresh_pct = 100; // share of a wave's even part of the batch it may start per scheduling pass, in percent
+int g_ik_fresh_pct = 50;  // share of a wave's even part of the batch it may start per scheduling pass, in percent: the rest is
+                          // drawn as lanes fall idle, so quick waves take more (1e5 Panda targets: 1.60 ms at 100, 1.49-1.52 at 35-80)
 int g_ik_waves_per_cu = 8;
 int g_ik_pass_mask = 3;   // measured on MI355X, 1e6 Panda targets: 8.20 (0) / 7.75 (1) / 7.66 (3) / 8.08 ms (7)
 std::mutex g_ctr_mu;
@@ -271,7 +273,7 @@ static void launch_nj(dim3 grid, hipStream_t s, const IkDev &p, const DevChain &
                       int32_t *searches, double *residual, const IkWork *work, const unsigned *count)
 {
     const int v = ik_step_variant(p, NJ);
-    if constexpr (NJ >= 6 && NJ <= kRegMaxJoints) {        // the null-space variants exist for 6..8 joints (launch_ik checks)
+    if constexpr (NJ >= 6 && NJ <= kIkNullMax) {        // the null-space variants exist for 6..12 joints (launch_ik checks)
         if (v == 2) { hipLaunchKernelGGL((k_ik<NJ, 2>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count); return; }
         if (v == 3) { hipLaunchKernelGGL((k_ik<NJ, 3>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count); return; }
     }
@@ -287,7 +289,7 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
     if (ip.slimit > kIkMaxSlimit) { set_error("ik_lm: slimit above 32000 is not supported by the device scheduler"); return RTBHIP_ELIMIT; }
     if (N >= (1ll << 32)) { set_error("ik_lm: at most 2^32 - 1 targets per call"); return RTBHIP_ELIMIT; }
     if (ip.ilimit > kIkMaxIlimit) { set_error("ik_lm: ilimit above 16000 is not supported by the device scheduler"); return RTBHIP_ELIMIT; }
-    if (c->n > kIkMaxJoints) { set_error("ik_lm: this build solves chains of up to 12 joints on the device"); return RTBHIP_ELIMIT; }
+    if (c->n > kIkMaxJoints) { set_error("ik_lm: this build solves chains of up to 16 joints on the device"); return RTBHIP_ELIMIT; }
     for (int j = 0; j < c->n; ++j)
         if (jm_jq(c->jmeta[j]) != j) { set_error("ik_lm: jindex must equal the joint order (the reference's ik.cpp:57 adds dq in that order)"); return RTBHIP_EINVAL; }
     IkDev p;
@@ -297,10 +299,10 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
     p.seed = ip.seed;
     p.N = N;
     p.kq = ip.kq; p.km = ip.km; p.ps = ip.ps; p.pi = ip.pi;
-    if (p.kq > 0.0 && (c->n > kRegMaxJoints || c->n < 6)) {
+    if (p.kq > 0.0 && (c->n > kIkNullMax || c->n < 6)) {
         // below 6 joints I - pinv(J) J vanishes only away from singularities; the reference still applies it there, so the
         // parameters are refused rather than silently dropped
-        set_error("ik_lm: null-space terms (kq > 0) are built for chains of 6..8 joints");
+        set_error("ik_lm: null-space terms (kq > 0) are built for chains of 6..12 joints");
         return RTBHIP_ELIMIT;
     }
     int dev = 0, cus = 0;
@@ -353,7 +355,11 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
         case 9: launch_nj<9>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
         case 10: launch_nj<10>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
         case 11: launch_nj<11>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
-        default: launch_nj<12>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
+        case 12: launch_nj<12>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
+        case 13: launch_nj<13>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
+        case 14: launch_nj<14>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
+        case 15: launch_nj<15>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
+        default: launch_nj<16>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
         }
         note_launch((int)grid.x, kWave, 0);
         hipError_t e = hipGetLastError();

@@ -352,6 +352,7 @@ int launch_angle_axis(const double *Te, int64_t nTe, const double *Tep, int64_t 
 // ---------------------------------------------------------------- differential-kinematics consumers (n <= 8)
 // jacob0_dot / manipulability / jacobm straight from the register-resident Jacobian: the (n,6,n) Hessian
 // the reference materialises for each of them (robot/Robot.py:1069, robot/ETS.py:1671) never exists.
+constexpr int kDiffMax = 16;   // jacob_dot / manipulability / jacobm / analytical Jacobian: compile-time joint counts up to here
 enum { kDiffJdot = 0, kDiffManip = 1, kDiffJacobm = 2, kDiffAnalytical = 3, kDiffAnalyticalDot = 4 };
 template <int NJ, int MODE>
 __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && MODE != 4 ? 2 : 1)) void k_kin_diff(KinParams kp, DevChain dc, int axes, const double *__restrict__ q,
@@ -445,7 +446,7 @@ int launch_kin_diff(const Chain *c, const DevChain &dc, int mode, int axes, cons
                     const Affine &tool, int frame, double *out, hipStream_t s)
 {
     if (N == 0) return RTBHIP_OK;
-    if (c->n < 1 || c->n > kKinRegMax) { set_error("jacob_dot/manipulability/jacobm: chains of 1..10 joints on the device"); return RTBHIP_ELIMIT; }
+    if (c->n < 1 || c->n > kDiffMax) { set_error("jacob_dot/manipulability/jacobm/jacob0_analytical: chains of 1..16 joints on the device"); return RTBHIP_ELIMIT; }
     const int64_t tiles = (N + kWave - 1) / kWave;
     if (tiles > 0x7fffffff) { set_error("jacob_dot/manipulability/jacobm: batch too large for one launch"); return RTBHIP_ELIMIT; }
     KinParams kp;
@@ -465,7 +466,14 @@ int launch_kin_diff(const Chain *c, const DevChain &dc, int mode, int axes, cons
     case 7: e = launch_diff_nj<7>(mode, grid, lds, s, kp, dc, axes, q, qd, out); break;
     case 8: e = launch_diff_nj<8>(mode, grid, lds, s, kp, dc, axes, q, qd, out); break;
     case 9: e = launch_diff_nj<9>(mode, grid, lds, s, kp, dc, axes, q, qd, out); break;
-    default: e = launch_diff_nj<10>(mode, grid, lds, s, kp, dc, axes, q, qd, out); break;
+    case 10: e = launch_diff_nj<10>(mode, grid, lds, s, kp, dc, axes, q, qd, out); break;
+    // 11..16: one wave per SIMD, the longer ones with some scratch -- served, not fast
+    case 11: e = launch_diff_nj<11>(mode, grid, lds, s, kp, dc, axes, q, qd, out); break;
+    case 12: e = launch_diff_nj<12>(mode, grid, lds, s, kp, dc, axes, q, qd, out); break;
+    case 13: e = launch_diff_nj<13>(mode, grid, lds, s, kp, dc, axes, q, qd, out); break;
+    case 14: e = launch_diff_nj<14>(mode, grid, lds, s, kp, dc, axes, q, qd, out); break;
+    case 15: e = launch_diff_nj<15>(mode, grid, lds, s, kp, dc, axes, q, qd, out); break;
+    default: e = launch_diff_nj<16>(mode, grid, lds, s, kp, dc, axes, q, qd, out); break;
     }
     note_launch((int)grid.x, kWave, (int)lds);
     if (e != hipSuccess) return hip_fail(e, "k_kin_diff launch");

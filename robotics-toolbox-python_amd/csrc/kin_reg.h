@@ -19,7 +19,8 @@
 namespace rtbhip {
 
 constexpr int kRegMaxJoints = 8;    // register-resident consumers (IK, Hessian, jacob_dot, manipulability ...)
-constexpr int kIkMaxJoints = 12;    // IK: chains of 9..12 joints run at one wave per SIMD (the whole 512-register budget)
+constexpr int kIkMaxJoints = 16;    // IK: chains of 9..12 joints run at one wave per SIMD (the whole 512-register budget); 13..16 also compile
+                                    // -- their normal equations no longer fit the register file and spill to scratch: slow, but served
 constexpr int kKinRegMax = 10;      // fkine / Jacobian tiles: 9 and 10 joints still fit the register file at 2 waves per SIMD
 #ifndef RTB_JROUND
 #define RTB_JROUND 32

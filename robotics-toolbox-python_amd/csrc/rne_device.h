@@ -128,11 +128,11 @@ RTB_HD LinkBwd link_bwd(const LinkT &l)
     return o;
 }
 
+#ifndef RTB_RNE_NOFENCE
+#define RTB_RNE_NOFENCE 0
+#endif
 #ifndef RTB_RNE_PREFETCH
 #define RTB_RNE_PREFETCH 0
-#endif
-#ifndef RTB_RNE_LI
-#define RTB_RNE_LI 0
 #endif
 // ---- fused forms of the vector algebra of the recursions.  A sum of cross products and rotated vectors is accumulated as a
 // chain of fused multiply-adds (two per component and product) instead of "cross, cross, add, add": the same terms, one rounding
@@ -165,17 +165,14 @@ RTB_HD V3 rot_fwd_add(const Rot &r, V3 v, V3 acc)   // acc + R v
     }
 }
 
-// Everything one forward step reads from the link table and from the q / qd / qdd tile, fetched as ONE batch.  In the
-// compile-time-n kernels the batch of step j+1 is issued at the top of step j (and waited for at the top of step j+1, a whole
-// step of arithmetic later): the scalar-memory and LDS round trips -- about 300 cycles each, 3 per link and pass when they were
-// taken where the data was needed (SQ counters: a third of the wave's lifetime in s_waitcnt) -- overlap the arithmetic.
-// s_waitcnt lgkmcnt counts scalar loads and LDS reads together and scalar loads return out of order, so any wait is a wait
-// for everything outstanding: the batch has to contain ALL of a step's operands, conditional ones (r, I) included.
-// The inertia tensor and the centre of mass of link j (used at the END of step j) are fetched at the top of step j, in the same
-// breath: by the time they are needed -- the one wait of the step -- the next step's batch has arrived with them, and only one
-// link's tensor is held in SGPRs at a time.
+// Everything one forward step reads from the link table and from the q / qd / qdd tile, fetched as ONE batch.
+// RTB_RNE_PREFETCH=1 (A/B knob, off): the batch of step j+1 is issued at the top of step j, so that the scalar-memory and LDS
+// round trips (about 300 cycles each; SQ counters: a third of the wave's lifetime in s_waitcnt) overlap a whole step of
+// arithmetic.  Measured on MI355X (1.25e6 Panda triples, kernel min of 30): 0.0648 ms without, 0.0798 ms with -- the second
+// operand set costs 26 VGPRs (182: two waves per SIMD instead of three), and forced back to three waves it spills (0.083 ms).
+// (s_waitcnt lgkmcnt counts scalar loads and LDS reads together and scalar loads return out of order: any wait is a wait for
+// everything outstanding, so a prefetch has to carry ALL of the next step's operands.)
 struct FwdOps { LinkFwd f; double qj, qdj, qddj; };
-struct LinkInertia { double I[9]; double rx, ry, rz; };
 template <bool ALLREV, class LinkT, class InQ, class InQd, class InQdd>
 RTB_HD FwdOps fwd_ops(const LinkT &lt, int j, InQ qin, InQd qdin, InQdd qddin)
 {
@@ -183,21 +180,6 @@ RTB_HD FwdOps fwd_ops(const LinkT &lt, int j, InQ qin, InQd qdin, InQdd qddin)
     o.f = link_fwd<ALLREV>(lt);
     o.qj = (!ALLREV && o.f.sigma != 0) ? qin(j) : 0.0;       // only a prismatic link needs q again (its d)
     o.qdj = qdin(j); o.qddj = qddin(j);
-    return o;
-}
-template <class LinkT>
-RTB_HD LinkInertia link_inertia(const LinkT &lt, int flags)
-{
-    LinkInertia o;
-    if (flags & kLinkIDiag) {
-        o.I[0] = lt.I[0]; o.I[4] = lt.I[4]; o.I[8] = lt.I[8];
-        o.I[1] = o.I[2] = o.I[3] = o.I[5] = o.I[6] = o.I[7] = 0.0;
-    } else {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) o.I[k] = lt.I[k];
-    }
-    if (flags & kLinkRZero) { o.rx = 0.0; o.ry = 0.0; o.rz = 0.0; }
-    else { o.rx = lt.rx; o.ry = lt.ry; o.rz = lt.rz; }
     return o;
 }
 struct BwdOps { LinkBwd b; double rx, ry, rz; double qj, qdj, qddj; };
@@ -235,11 +217,7 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
         FwdOps nxt = cur;
         if (PF) sched_fence();     // cur's wait sits above this line, the next batch below it
         if (PF && j + 1 < n) nxt = fwd_ops<ALLREV>(links[j + 1], j + 1, qin, qdin, qddin);
-#if RTB_RNE_LI
-        const LinkInertia li = link_inertia(links[j], flg[j]);
-#else
-        const auto &li = links[j];
-#endif
+        const auto &li = links[j];                    // r and I: loaded inside the branches that need them
         const LinkFwd &l = cur.f;
         const bool pris = ALLREV ? false : (l.sigma != 0);
         const double qdj = cur.qdj, qddj = cur.qddj;
@@ -316,7 +294,7 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
             Nn[j] = cross_add(w, inertia_times(li, w), inertia_times(li, wd));
         }
         cur = nxt;
-        if (!PF && NJ > 0) sched_fence();
+        if (!PF && NJ > 0 && !RTB_RNE_NOFENCE) sched_fence();
     }
 
     // ---- backward recursion + joint projection (ne.c:354-492), fused
@@ -363,7 +341,7 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
         tau(j, t);
         f = fj; nn = nj; Rn = R; psn = ps;
         bc = bn;
-        if (!PF && NJ > 0) sched_fence();
+        if (!PF && NJ > 0 && !RTB_RNE_NOFENCE) sched_fence();
     }
 }
 

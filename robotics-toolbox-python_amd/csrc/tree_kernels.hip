@@ -18,7 +18,7 @@ struct TreeParams {
     double grav[3];
 };
 
-constexpr int kTreeMaxGroups = 16;
+constexpr int kTreeMaxGroups = 24;   // 17..24 link groups: the per-group state spills to scratch; served, not fast
 
 template <int NG>
 __global__ __launch_bounds__(kWave, (NG <= 8 ? 2 : 1)) void k_tree_rne(TreeParams tp, const DevGroup *groups_g, const double *__restrict__ q,
@@ -77,7 +77,7 @@ int launch_tree_rne(const Tree *t, const DevGroup *groups, const double *q, cons
                     const double *grav3, double *tau, hipStream_t s)
 {
     if (N == 0) return RTBHIP_OK;
-    if (t->n > kTreeMaxGroups) { set_error("tree_rne: this build handles up to 16 joints (link groups) on the device"); return RTBHIP_ELIMIT; }
+    if (t->n > kTreeMaxGroups) { set_error("tree_rne: this build handles up to 24 joints (link groups) on the device"); return RTBHIP_ELIMIT; }
     const int64_t tiles = (N + kWave - 1) / kWave;
     if (tiles > 0x7fffffff) { set_error("tree_rne: batch too large for one launch"); return RTBHIP_ELIMIT; }
     TreeParams tp;
@@ -102,7 +102,15 @@ int launch_tree_rne(const Tree *t, const DevGroup *groups, const double *q, cons
     case 13: launch_ng<13>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
     case 14: launch_ng<14>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
     case 15: launch_ng<15>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
-    default: launch_ng<16>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
+    case 16: launch_ng<16>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
+    case 17: launch_ng<17>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
+    case 18: launch_ng<18>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
+    case 19: launch_ng<19>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
+    case 20: launch_ng<20>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
+    case 21: launch_ng<21>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
+    case 22: launch_ng<22>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
+    case 23: launch_ng<23>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
+    default: launch_ng<24>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
     }
     note_launch((int)grid.x, kWave, (int)lds);
     hipError_t e = hipGetLastError();

@@ -541,7 +541,11 @@ extern "C" int emu_ik(rtbhip_chain_t h, const double *Tep, int64_t N, const doub
     case 9: emu_ik_run<9>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
     case 10: emu_ik_run<10>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
     case 11: emu_ik_run<11>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
-    default: emu_ik_run<12>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
+    case 12: emu_ik_run<12>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
+    case 13: emu_ik_run<13>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
+    case 14: emu_ik_run<14>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
+    case 15: emu_ik_run<15>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
+    default: emu_ik_run<16>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
     }
     return 0;
 }
@@ -567,9 +571,9 @@ extern "C" int emu_ik_wave(rtbhip_chain_t h, int waves, double *stats, const dou
 #define RTB_EMU_IK(NJ) case NJ: rc = phased ? emu_ik_phased_run<NJ>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats) \
                                              : emu_ik_wave_run<NJ>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
     switch (c->n) {
-    RTB_EMU_IK(1) RTB_EMU_IK(2) RTB_EMU_IK(3) RTB_EMU_IK(4) RTB_EMU_IK(5) RTB_EMU_IK(6) RTB_EMU_IK(7) RTB_EMU_IK(8) RTB_EMU_IK(9) RTB_EMU_IK(10) RTB_EMU_IK(11)
-    default: rc = phased ? emu_ik_phased_run<12>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats)
-                         : emu_ik_wave_run<12>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
+    RTB_EMU_IK(1) RTB_EMU_IK(2) RTB_EMU_IK(3) RTB_EMU_IK(4) RTB_EMU_IK(5) RTB_EMU_IK(6) RTB_EMU_IK(7) RTB_EMU_IK(8) RTB_EMU_IK(9) RTB_EMU_IK(10) RTB_EMU_IK(11) RTB_EMU_IK(12) RTB_EMU_IK(13) RTB_EMU_IK(14) RTB_EMU_IK(15)
+    default: rc = phased ? emu_ik_phased_run<16>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats)
+                         : emu_ik_wave_run<16>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
     }
 #undef RTB_EMU_IK
     return rc;
@@ -655,7 +659,7 @@ extern "C" int emu_dyn(rtbhip_dyn_t h, int mode, const double *q, const double *
 {
     const std::shared_ptr<Dyn> d_owner = dyn_from_handle(h);
     Dyn *d = d_owner.get();
-    if (!d || d->n > 10) return -1;
+    if (!d || d->n > 16) return -1;
     V3 g = grav3 ? v3(grav3[0], grav3[1], grav3[2]) : v3(0, 0, 0);
     switch (d->n) {
     case 1: dyn_nj<1>(d, mode, q, qd, tq, N, g, out); break;
@@ -667,7 +671,13 @@ extern "C" int emu_dyn(rtbhip_dyn_t h, int mode, const double *q, const double *
     case 7: dyn_nj<7>(d, mode, q, qd, tq, N, g, out); break;
     case 8: dyn_nj<8>(d, mode, q, qd, tq, N, g, out); break;
     case 9: dyn_nj<9>(d, mode, q, qd, tq, N, g, out); break;
-    default: dyn_nj<10>(d, mode, q, qd, tq, N, g, out); break;
+    case 10: dyn_nj<10>(d, mode, q, qd, tq, N, g, out); break;
+    case 11: dyn_nj<11>(d, mode, q, qd, tq, N, g, out); break;
+    case 12: dyn_nj<12>(d, mode, q, qd, tq, N, g, out); break;
+    case 13: dyn_nj<13>(d, mode, q, qd, tq, N, g, out); break;
+    case 14: dyn_nj<14>(d, mode, q, qd, tq, N, g, out); break;
+    case 15: dyn_nj<15>(d, mode, q, qd, tq, N, g, out); break;
+    default: dyn_nj<16>(d, mode, q, qd, tq, N, g, out); break;
     }
     return 0;
 }
@@ -709,7 +719,7 @@ extern "C" int emu_diff(rtbhip_chain_t h, int mode, int axes, const double *q, c
 {
     const std::shared_ptr<Chain> c_owner = chain_from_handle(h);
     Chain *c = c_owner.get();
-    if (!c || c->n < 1 || c->n > kKinRegMax) return -1;
+    if (!c || c->n < 1 || c->n > 16) return -1;
     KinParams kp;
     kp.n = c->n; kp.qw = c->q_width; kp.stride = kin_stride(c->n); kp.frame = frame; kp.N = N; kp.pad = 0; kp.has_base = 0;
     Affine t = aff16(tool16);
@@ -725,7 +735,13 @@ extern "C" int emu_diff(rtbhip_chain_t h, int mode, int axes, const double *q, c
     case 7: diff_run<7>(kp, cv, mode, axes, q, qd, N, out); break;
     case 8: diff_run<8>(kp, cv, mode, axes, q, qd, N, out); break;
     case 9: diff_run<9>(kp, cv, mode, axes, q, qd, N, out); break;
-    default: diff_run<10>(kp, cv, mode, axes, q, qd, N, out); break;
+    case 10: diff_run<10>(kp, cv, mode, axes, q, qd, N, out); break;
+    case 11: diff_run<11>(kp, cv, mode, axes, q, qd, N, out); break;
+    case 12: diff_run<12>(kp, cv, mode, axes, q, qd, N, out); break;
+    case 13: diff_run<13>(kp, cv, mode, axes, q, qd, N, out); break;
+    case 14: diff_run<14>(kp, cv, mode, axes, q, qd, N, out); break;
+    case 15: diff_run<15>(kp, cv, mode, axes, q, qd, N, out); break;
+    default: diff_run<16>(kp, cv, mode, axes, q, qd, N, out); break;
     }
     return 0;
 }
@@ -820,6 +836,14 @@ extern "C" int emu_tree_rne(const rtbhip_tree_group *groups, int ng, const doubl
     case 14: tree_run<14>(&t, q, qd, qdd, N, g, tau); break;
     case 15: tree_run<15>(&t, q, qd, qdd, N, g, tau); break;
     case 16: tree_run<16>(&t, q, qd, qdd, N, g, tau); break;
+    case 17: tree_run<17>(&t, q, qd, qdd, N, g, tau); break;
+    case 18: tree_run<18>(&t, q, qd, qdd, N, g, tau); break;
+    case 19: tree_run<19>(&t, q, qd, qdd, N, g, tau); break;
+    case 20: tree_run<20>(&t, q, qd, qdd, N, g, tau); break;
+    case 21: tree_run<21>(&t, q, qd, qdd, N, g, tau); break;
+    case 22: tree_run<22>(&t, q, qd, qdd, N, g, tau); break;
+    case 23: tree_run<23>(&t, q, qd, qdd, N, g, tau); break;
+    case 24: tree_run<24>(&t, q, qd, qdd, N, g, tau); break;
     default: return -2;
     }
     return 0;

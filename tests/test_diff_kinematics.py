@@ -180,9 +180,20 @@ def test_gpu_goldens_shapes_errors():
     # reference tests/test_ETS.py:4339-4353 (URDF Panda at qr)
     nt.assert_almost_equal(p.ets().manipulability(qr, method="invcondition", tool=p.tool), 0.11222, decimal=4)
     nt.assert_almost_equal(p.ets().manipulability(qr, method="minsingular", tool=p.tool), 0.209013, decimal=4)
-    eleven = rtbhip.DHRobot([rtbhip.RevoluteDH(a=0.1) for _ in range(11)]).ets()
+    seventeen = rtbhip.DHRobot([rtbhip.RevoluteDH(a=0.1) for _ in range(17)]).ets()
     with pytest.raises(rtbhip.RtbHipError):
-        eleven.manipulability(np.zeros(11))
+        seventeen.manipulability(np.zeros(17))
+    # 11..16 joints: the spilling instantiations of the differential-kinematics consumers
+    rng = np.random.default_rng(3)
+    arm14 = rtbhip.DHRobot([rtbhip.RevoluteDH(a=0.05 + 0.01 * k, d=0.05, alpha=[0.0, np.pi / 2, -np.pi / 2][k % 3]) for k in range(14)]).ets()
+    ch14 = chain_from_ets(arm14)
+    q, qd = rng.uniform(-1.5, 1.5, (70, 14)), rng.normal(size=(70, 14))
+    nt.assert_allclose(arm14.jacob0_dot(q, qd)[:10], oracle.jacob_dot(ch14, q[:10], qd[:10]), atol=1e-10)
+    nt.assert_allclose(arm14.manipulability(q)[:10], oracle.manipulability(ch14, q[:10]), rtol=1e-8, atol=1e-12)
+    ref = oracle.jacobm(ch14, q[:10])
+    nt.assert_allclose(arm14.jacobm(q)[:10], ref, rtol=1e-6, atol=1e-8 * max(1.0, np.abs(ref).max()))
+    nt.assert_allclose(arm14.jacob0_analytical(q, "eul")[:10], oracle.jacob0_analytical(ch14, q[:10], "eul"), atol=1e-9)
+    nt.assert_allclose(arm14.hessian0(q)[:5], oracle.hessian(ch14, q[:5]), atol=1e-10)
 
 
 @pytest.mark.gpu

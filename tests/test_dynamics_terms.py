@@ -114,6 +114,36 @@ def test_gpu_vs_oracle_and_identities(robot, N):
     nt.assert_array_equal(rob.accel(qt, qdt, tqt).cpu().numpy(), a)
 
 
+def _long_arm(n):
+    """An n-joint standard-DH arm (n up to 16): the ten-joint recipe continued, prismatic joints at 4 and 11."""
+    rng = np.random.default_rng(77)
+    links = []
+    for k in range(n):
+        Ifull = list(rng.uniform(0.01, 0.1, 3)) + list(rng.uniform(-0.01, 0.01, 3))
+        kw = dict(a=0.05 + 0.01 * k, alpha=[0.0, np.pi / 2, -np.pi / 2][k % 3], m=1.0 + 0.1 * k,
+                  r=[0.0, 0.0, 0.0] if k % 3 == 0 else list(rng.uniform(-0.05, 0.05, 3)), I=Ifull, Jm=1e-4 * k, G=1.0 + k, B=1e-3, Tc=[0.01, -0.02])
+        links.append(rtbhip.PrismaticDH(theta=0.3, qlim=[0.0, 0.4], **kw) if k in (4, 11) else rtbhip.RevoluteDH(d=0.05, **kw))
+    return rtbhip.DHRobot(links, name="long%d" % n)
+
+
+@pytest.mark.parametrize("n", [11, 14, 16])
+def test_emu_eleven_to_sixteen_joints(n):
+    """inertia / coriolis / accel beyond 10 joints (the spilling instantiations): kernel body against the oracle."""
+    import emu_harness as emu
+    rob = _long_arm(n)
+    L = rob.L24()
+    rng = np.random.default_rng(n)
+    q, qd, tq = rng.uniform(-1, 1, (3, n)), rng.normal(size=(3, n)), rng.normal(size=(3, n))
+    for k in (4, 11):
+        if k < n:
+            q[:, k] = rng.uniform(0, 0.4, 3)
+    gc = -np.array([0.0, 0.0, -9.81])
+    nt.assert_allclose(emu.dyn(L, 0, 0, q), oracle.inertia_dh(L, 0, q), rtol=1e-10, atol=1e-11)
+    nt.assert_allclose(emu.dyn(L, 0, 1, q, qd), oracle.coriolis_dh(L, 0, q, qd), rtol=1e-9, atol=1e-10)
+    ref = oracle.accel_dh(L, 0, q, qd, tq, gc)
+    nt.assert_allclose(emu.dyn(L, 0, 2, q, qd, tq, grav_c=gc), ref, rtol=1e-8, atol=1e-8 * np.abs(ref).max())
+
+
 def _ten_joint_arm():
     """A 10-joint DH arm with a prismatic joint, centre-of-mass offsets, full and diagonal inertia tensors, motor inertia
     and friction: the 9- and 10-joint instantiations (one wave per SIMD)."""
@@ -146,10 +176,24 @@ def test_emu_nine_and_ten_joints(n):
 
 @pytest.mark.gpu
 def test_gpu_dynamics_limits_and_errors():
-    rob11 = rtbhip.DHRobot([rtbhip.RevoluteDH(a=0.1, m=1.0) for _ in range(11)])
+    rob17 = rtbhip.DHRobot([rtbhip.RevoluteDH(a=0.1, m=1.0) for _ in range(17)])
     with pytest.raises(rtbhip.RtbHipError):
-        rob11.inertia(np.zeros(11))                     # > 10 joints: loud ELIMIT, no silent fallback
-    assert rob11.gravload(np.zeros((3, 11))).shape == (3, 11)   # rne itself handles any n
+        rob17.inertia(np.zeros(17))                     # > 16 joints: loud ELIMIT, no silent fallback
+    assert rob17.gravload(np.zeros((3, 17))).shape == (3, 17)   # rne itself handles any n
+    for n in (11, 14, 16):                                # the spilling instantiations
+        rob = _long_arm(n)
+        L = rob.L24()
+        rng = np.random.default_rng(n)
+        N = 70
+        q, qd, tq = rng.uniform(-1, 1, (N, n)), rng.normal(size=(N, n)), rng.normal(size=(N, n))
+        for k in (4, 11):
+            if k < n:
+                q[:, k] = rng.uniform(0, 0.4, N)
+        k = 8
+        nt.assert_allclose(rob.inertia(q)[:k], oracle.inertia_dh(L, 0, q[:k]), rtol=1e-10, atol=1e-11)
+        nt.assert_allclose(rob.coriolis(q, qd)[:k], oracle.coriolis_dh(L, 0, q[:k], qd[:k]), rtol=1e-9, atol=1e-10)
+        a = rob.accel(q, qd, tq)
+        nt.assert_allclose(rob.rne(q, qd, a), tq, rtol=1e-7, atol=1e-7 * np.abs(tq).max())
     for n in (5, 8, 9, 10):                               # 5, 8: the non-all-revolute instantiations of the 2-wave kernels
         rob = rtbhip.DHRobot(_ten_joint_arm().links[:n])
         L = rob.L24()

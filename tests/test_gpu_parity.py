@@ -470,10 +470,9 @@ def test_ikine_nullspace_terms():
     st = ets.ikine_LM(torch.from_numpy(T).cuda(), q0=torch.from_numpy(q0).cuda(), seed=5, slimit=3, kq=0.1, km=0.1)
     sh = ets.ikine_LM(T, q0=q0, seed=5, slimit=3, kq=0.1, km=0.1)
     nt.assert_array_equal(st.q, sh.q)
-    gen3 = urdf.load("KinovaGen3").ets()
-    if gen3.n > 8:
-        with pytest.raises(rtbhip.RtbHipError):
-            gen3.ikine_LM(gen3.eval(np.zeros(gen3.n)), kq=0.1)
+    long13 = rtbhip.DHRobot([rtbhip.RevoluteDH(a=0.1, d=0.05, alpha=[0.0, 1.5][k % 2]) for k in range(13)]).ets()
+    with pytest.raises(rtbhip.RtbHipError):
+        long13.ikine_LM(long13.eval(np.zeros(13)), kq=0.1)    # null-space variants exist for 6..12 joints
     five = urdf.load("px100").ets()
     assert five.n < 6
     with pytest.raises(rtbhip.RtbHipError):
@@ -543,9 +542,56 @@ def test_ik_ten_joint_chain_equals_oracle():
         nt.assert_allclose(q[i], o[0], atol=1e-6)
     good = ok == 1
     assert good.mean() > 0.8 and np.all(E[good] < 1e-6)
-    thirteen = rtbhip.DHRobot([rtbhip.RevoluteDH(a=0.1) for _ in range(13)]).ets()
+    seventeen = rtbhip.DHRobot([rtbhip.RevoluteDH(a=0.1) for _ in range(17)]).ets()
     with pytest.raises(rtbhip.RtbHipError):
-        thirteen.ik_LM(np.eye(4))
+        seventeen.ik_LM(np.eye(4))
+
+
+def test_ik_fourteen_joint_chain_equals_oracle():
+    """Chains of 13..16 joints (the normal equations spill to scratch): a 14-joint arm -- two stacked 7-joint Panda-like
+    halves -- must walk exactly the oracle's sequential loops, C and Python flavour; null-space terms on 9 and 10 joints
+    (Gen3 + finger, Fetch) run and converge."""
+    from helpers import chain_from_ets
+    ET = rtbhip.ET
+    half = lambda: (ET.tz(0.2) * ET.Rz() * ET.Rx(-np.pi / 2) * ET.Rz() * ET.Rx(np.pi / 2) * ET.tz(0.2) * ET.Rz() * ET.tx(0.05)
+                    * ET.Rx(np.pi / 2) * ET.Rz() * ET.tx(-0.05) * ET.Rx(-np.pi / 2) * ET.tz(0.2) * ET.Rz() * ET.Rx(np.pi / 2) * ET.Rz()
+                    * ET.tx(0.05) * ET.Rx(np.pi / 2) * ET.Rz())
+    ets = half() * half()
+    assert ets.n == 14
+    ch = chain_from_ets(ets)
+    rng = np.random.default_rng(14)
+    N = 40
+    qs = rng.uniform(-2.5, 2.5, (N, 14))
+    Tep = oracle.fkine(ch, qs)
+    for flavour, fn in ((0, ets.ik_LM), (1, None)):
+        if flavour == 0:
+            q, ok, it, se, E = fn(Tep, seed=5, slimit=12)
+        else:
+            sol = ets.ikine_LM(Tep, seed=5, slimit=12)
+            q, ok, it, se, E = sol.q, sol.each["success"].astype(int), sol.each["iterations"], sol.each["searches"], sol.each["residual"]
+        for i in range(0, N, 3):
+            rs = np.array([ets.ik_restart(5, i, d) for d in range(13)])
+            o = oracle.ik_lm(ch, Tep[i], restarts=rs, slimit=12) if flavour == 0 else oracle.ikine_lm(ch, Tep[i], rs[:12], slimit=12)
+            assert (o[1], o[2], o[3]) == (ok[i], it[i], se[i])
+            nt.assert_allclose(q[i], o[0], atol=1e-6)
+        assert np.mean(ok) > 0.9
+    from rtbhip import urdf as U
+    for name in ("KinovaGen3", "Fetch"):
+        e = U.load(name).ets()
+        assert e.n in (9, 10)
+        e.qlim = np.clip(e.qlim, -np.pi, np.pi)
+        c2 = chain_from_ets(e)
+        q2 = rng.uniform(c2.qlim[0] + 0.2, c2.qlim[1] - 0.2, (30, e.n))
+        T2 = oracle.fkine(c2, q2)
+        q0 = np.clip(q2 + 0.05 * rng.normal(size=q2.shape), c2.qlim[0], c2.qlim[1])
+        sol = e.ikine_LM(T2, q0=q0, seed=1, slimit=5, kq=0.1, km=0.1)
+        base = e.ikine_LM(T2, q0=q0, seed=1, slimit=5)
+        assert sol.each["success"].mean() >= 0.8 and np.nanmax(np.abs(sol.q - base.q)) > 1e-7
+        i = int(np.argmax(sol.each["success"] & (sol.each["searches"] == 1)))
+        o = oracle.ikine_py(c2, T2[i], np.array([q0[i]] + [e.ik_restart(1, i, d) for d in range(1, 5)]), step="lm", slimit=5, kq=0.1, km=0.1)
+        if o[1] and o[3] == 1:
+            assert (o[2], o[3]) == (sol.each["iterations"][i], sol.each["searches"][i])
+            nt.assert_allclose(sol.q[i], o[0], atol=1e-6)
 
 
 def test_init_and_shutdown_keep_handles_usable():
@@ -571,7 +617,7 @@ def test_ik_small_chains_and_errors():
     q, ok, it, se, E = arm.ik_LM(Tep, mask=[1, 1, 0, 0, 0, 1], joint_limits=False)
     assert ok.all()
     nt.assert_allclose(oracle.fkine(ch, q)[:, :2, 3], Tep[:, :2, 3], atol=2e-3)
-    big = rtbhip.ETS([ET.Rz() for _ in range(13)])             # 13 joints: beyond the 12 the device build solves
+    big = rtbhip.ETS([ET.Rz() for _ in range(17)])             # 17 joints: beyond the 16 the device build solves
     with pytest.raises(rtbhip.RtbHipError):
         big.ik_LM(np.eye(4))
     perm = ET.Rz(jindex=1) * ET.tx(1.0) * ET.Rz(jindex=0)

@@ -501,6 +501,53 @@ def test_ik_nine_to_twelve_joint_chains(robot, n):
     assert ok.mean() >= 0.5
 
 
+def test_ik_thirteen_to_sixteen_joint_chains():
+    """The IK search functions at compile-time joint counts 13..16 (on the device their normal equations spill to scratch):
+    sequential specification and wave scheduler against the oracle's loops on a 14- and a 16-joint arm."""
+    from helpers import chain_from_ets
+    for n in (14, 16):
+        arm = rtbhip.DHRobot([rtbhip.RevoluteDH(a=0.04 + 0.01 * (k % 4), d=0.05, alpha=[0.0, np.pi / 2, -np.pi / 2][k % 3]) for k in range(n)]).ets()
+        ch = chain_from_ets(arm)
+        rng = np.random.default_rng(n)
+        N = 8
+        Tep = oracle.fkine(ch, rng.uniform(-2, 2, (N, n)))
+        q, ok, it, se, E = emu.ik(arm, Tep, seed=9, slimit=6)
+        for i in range(N):
+            rs = np.array([emu.ik_restart(arm, 9, i, d) for d in range(7)])
+            o = oracle.ik_lm(ch, Tep[i], restarts=rs, slimit=6)
+            assert (o[1], o[2], o[3]) == (ok[i], it[i], se[i])
+            nt.assert_allclose(q[i], o[0], atol=1e-6)
+        b = emu.ik(arm, Tep, seed=9, slimit=6, waves=2)
+        for x, y in zip((q, ok, it, se, E), b):
+            nt.assert_array_equal(x, y)
+        assert ok.mean() >= 0.5
+
+
+@pytest.mark.parametrize("flavour", [0, 1])
+@pytest.mark.parametrize("slimit,with_q0", [(100, False), (30, True), (23, False), (22, False), (7, False), (6, True)])
+def test_ik_phased_schedule_equals_sequential_searches(flavour, slimit, with_q0):
+    """The phased schedule (rtbhip_tune "ik_phased": first 6 searches of every target, the next 16 of the unresolved ones,
+    the rest split into up to 8 work items per target, merged in search order) must report exactly what the sequential loops
+    report -- whatever the split points, for unreachable targets, joint-limit rejections and a supplied q0."""
+    import os
+    ets, ch = _panda_limited()
+    rng = np.random.default_rng(slimit)
+    N = 150
+    Tep = oracle.fkine(ch, rng.uniform(ch.qlim[0], ch.qlim[1], (N, 7)))
+    Tep[::13, :3, 3] += 2.5
+    q0 = rng.uniform(ch.qlim[0], ch.qlim[1], (N, 7)) if with_q0 else None
+    a = emu.ik(ets, Tep, q0=q0, slimit=slimit, flavour=flavour, seed=21)
+    os.environ["EMU_IK_PHASED"] = "1"
+    os.environ["EMU_IK_PASS_MASK"] = "3"
+    try:
+        b = emu.ik(ets, Tep, q0=q0, slimit=slimit, flavour=flavour, seed=21, waves=3)
+    finally:
+        del os.environ["EMU_IK_PHASED"], os.environ["EMU_IK_PASS_MASK"]
+    for x, y in zip(a, b):
+        nt.assert_array_equal(x, y)
+    assert a[1].sum() < N
+
+
 def test_xcd_tile_mapping_is_a_bijection_with_contiguous_eighths():
     """xcd_tile_of (trig.h): workgroup ids b = 8 i + x (XCD x) -> tiles; a permutation of [0, g) for every grid size, each
     XCD's tiles one contiguous block, visited in increasing order."""
