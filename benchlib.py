@@ -109,10 +109,16 @@ class Ranks:
         ranks.  The same K launches are also bracketed by ONE HIP-event pair on the launch stream, so the device-side
         duration of the loop (-> average kernel duration) comes from the timed region itself and can never exceed
         the host-clock step time (round-1 judge note: per-launch event pairs added >= 5 us each)."""
+        import gc
         import torch
         for _ in range(warmup):
             step()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # no collector pause inside the timed region: a full collection of this process's heap (torch + numpy imported) is a
+        # 40-60 ms host stall, which visit r2a/r2d traces showed landing in the middle of 20-30 launches of 65 us each
+        gc.collect()
+        gc_was = gc.isenabled()
+        gc.disable()
         self.barrier()
         t0 = time.perf_counter()
         e0.record()
@@ -126,6 +132,8 @@ class Ranks:
         e1.record()
         self.barrier()
         elapsed = time.perf_counter() - t0
+        if gc_was:
+            gc.enable()
         dev_ms = e0.elapsed_time(e1)
         if trace is not None and self.rank == 0:      # where does the host spend the loop?  (diagnosis only)
             sys.stderr.write("bench trace: host us per step " + " ".join("%.0f" % (x * 1e6) for x in trace) + " | loop %.0f us\n" % (elapsed * 1e6))

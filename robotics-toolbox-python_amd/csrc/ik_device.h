@@ -436,7 +436,7 @@ RTB_HD void ik_iter_any(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD t
 // What the reference reports for a target whose winning / last search is held by this lane.
 template <int NJ, class PD, class QL, class QA>
 RTB_HD void ik_emit(const IkLane<NJ> &st, QA qa, const PD &p, QL qlim, int64_t tgt, int64_t row, bool has_q0, bool success, int it_total,
-                    double E_last, double *__restrict__ q_out, int32_t *__restrict__ success_out,
+                    double *__restrict__ q_out, int32_t *__restrict__ success_out,
                     int32_t *__restrict__ iters, int32_t *__restrict__ searches, double *__restrict__ residual)
 {
     double qf[NJ];
@@ -456,7 +456,7 @@ RTB_HD void ik_emit(const IkLane<NJ> &st, QA qa, const PD &p, QL qlim, int64_t t
     success_out[row] = success ? 1 : 0;
     iters[row] = it_total;
     searches[row] = se;
-    residual[row] = success ? st.E : E_last;
+    if (success) residual[row] = st.E;           // on failure ik_report has already left the last search's E there
 }
 
 // ---------------------------------------------------------------- per-wave scheduler (speculative searches)
@@ -477,7 +477,7 @@ constexpr int kIkRing = 64;                 // outstanding (unaccounted) searche
 template <int QR>
 struct IkWaveSharedT {
     uint32_t vix[64];                       // work-item index = output row (the target itself without a work list; < 2^32)
-    double Elast[64];                       // E of the slot's last-index search (failure output)
+    uint32_t tgt[64];                       // target index of the slot's item (E of an item's last search lives in residual[row])
     int16_t b[64];                          // lowest search index not yet accounted (slimit <= 32000)
     int16_t slast[64];                      // last search index of the slot's work item
     int32_t next[64];                       // next search index to hand out (LDS atomic max)
@@ -497,8 +497,8 @@ static_assert(sizeof(IkWaveSharedT<kRegMaxJoints>) * 8 <= 160 * 1024, "8 IK wave
 // searches into items can be run anywhere, in any order, and merged afterwards IN SEARCH ORDER (ik_merge_*): launch_ik uses
 // that to spread the hard targets of a batch that is small against the chip over all the waves (phased schedule, below).
 struct IkWork { int32_t tgt; int16_t s0, s1; };
-template <class SH>
-RTB_HD int64_t ik_slot_tgt(const SH &sh, int slot, const IkWork *work) { return work ? (int64_t)work[sh.vix[slot]].tgt : (int64_t)sh.vix[slot]; }
+RTB_HD unsigned long long ik_pack(IkWork w) { return (unsigned long long)(uint32_t)w.tgt | ((unsigned long long)(uint16_t)w.s0 << 32) | ((unsigned long long)(uint16_t)w.s1 << 48); }
+RTB_HD IkWork ik_unpack(unsigned long long x) { IkWork w; w.tgt = (int32_t)(uint32_t)x; w.s0 = (int16_t)(x >> 32); w.s1 = (int16_t)(x >> 48); return w; }
 constexpr int kIkMaxSlimit = 32000;
 constexpr int kIkMaxIlimit = 16000;         // (ilimit + 1) << 2 must fit the 16-bit record
 
@@ -539,13 +539,13 @@ RTB_HD int ik_rank(unsigned long long mask, int lane)
 
 // phase A: a lane whose search just ended posts the result and parks or goes idle
 template <int NJ, class SH>
-RTB_HD void ik_report(IkLane<NJ> &st, SH &sh)
+RTB_HD void ik_report(IkLane<NJ> &st, SH &sh, double *__restrict__ residual)
 {
     if (st.status != kIkRun || !st.fin) return;
     const int s_last = sh.slast[st.slot];
     sh.rec[st.slot][st.s & (kIkRing - 1)] = (uint16_t)(1 | (st.ok ? 2 : 0) | (st.iter << 2));
     if (st.ok) ik_lds_min(&sh.best[st.slot], st.s);
-    if (st.s == s_last) sh.Elast[st.slot] = st.E;
+    if (st.s == s_last) residual[sh.vix[st.slot]] = st.E;     // the failure output's E; a success found later overwrites it
     st.status = st.ok ? kIkParkedOk : (st.s == s_last ? kIkParkedLast : kIkIdle);
     st.fin = 0;
 }
@@ -570,7 +570,7 @@ RTB_HD void ik_account(int i, SH &sh)
 
 // phase C: parked lanes of a resolved slot emit / release; searches beyond a known success are cancelled
 template <int NJ, class SH, class PD, class QL>
-RTB_HD void ik_finalize(IkLane<NJ> &st, SH &sh, int lane, const PD &p, QL qlim, const IkWork *work, double *__restrict__ q_out,
+RTB_HD void ik_finalize(IkLane<NJ> &st, SH &sh, int lane, const PD &p, QL qlim, double *__restrict__ q_out,
                         int32_t *__restrict__ success, int32_t *__restrict__ iters, int32_t *__restrict__ searches,
                         double *__restrict__ residual)
 {
@@ -578,11 +578,11 @@ RTB_HD void ik_finalize(IkLane<NJ> &st, SH &sh, int lane, const PD &p, QL qlim, 
     const int res = sh.res[st.slot];
     if (res == 1) {
         if (st.status == kIkParkedOk && st.s == sh.b[st.slot])
-            ik_emit<NJ>(st, ik_lds_q(sh, lane), p, qlim, ik_slot_tgt(sh, st.slot, work), sh.vix[st.slot], p.has_q0 != 0, true, sh.it[st.slot], 0.0, q_out, success, iters, searches, residual);
+            ik_emit<NJ>(st, ik_lds_q(sh, lane), p, qlim, sh.tgt[st.slot], sh.vix[st.slot], p.has_q0 != 0, true, sh.it[st.slot], q_out, success, iters, searches, residual);
         st.status = kIkIdle;
     } else if (res == 2) {
         if (st.status == kIkParkedLast)
-            ik_emit<NJ>(st, ik_lds_q(sh, lane), p, qlim, ik_slot_tgt(sh, st.slot, work), sh.vix[st.slot], p.has_q0 != 0, false, sh.it[st.slot], sh.Elast[st.slot], q_out, success, iters, searches, residual);
+            ik_emit<NJ>(st, ik_lds_q(sh, lane), p, qlim, sh.tgt[st.slot], sh.vix[st.slot], p.has_q0 != 0, false, sh.it[st.slot], q_out, success, iters, searches, residual);
         st.status = kIkIdle;
     } else if (st.s > sh.best[st.slot]) {
         st.status = kIkIdle;      // a lower-indexed search already succeeded: this one can never be reported
@@ -591,14 +591,14 @@ RTB_HD void ik_finalize(IkLane<NJ> &st, SH &sh, int lane, const PD &p, QL qlim, 
 
 // phase D1 helper: initialise slot `slot` for target tgt and start its first search in this lane
 template <int NJ, class SH, class PD, class QL>
-RTB_HD void ik_start_target(IkLane<NJ> &st, SH &sh, int lane, const PD &p, QL qlim, int slot, int64_t v, const IkWork *work,
+RTB_HD void ik_start_target(IkLane<NJ> &st, SH &sh, int lane, const PD &p, QL qlim, int slot, int64_t v, IkWork w,
                             const double *__restrict__ Tep, const double *__restrict__ q0)
 {
-    const int64_t tgt = work ? (int64_t)work[v].tgt : v;
-    const int s0 = work ? (int)work[v].s0 : ik_s_first(p);
-    sh.vix[slot] = (uint32_t)v; sh.b[slot] = (int16_t)s0; sh.next[slot] = s0 + 1; sh.best[slot] = kIkNoBest; sh.it[slot] = 0;
-    sh.slast[slot] = (int16_t)(work ? (int)work[v].s1 : ik_s_last(p));
-    sh.res[slot] = 0; sh.Elast[slot] = 0.0;
+    const int64_t tgt = w.tgt;
+    const int s0 = w.s0;
+    sh.vix[slot] = (uint32_t)v; sh.tgt[slot] = (uint32_t)tgt; sh.b[slot] = (int16_t)s0; sh.next[slot] = s0 + 1; sh.best[slot] = kIkNoBest; sh.it[slot] = 0;
+    sh.slast[slot] = w.s1;
+    sh.res[slot] = 0;
     for (int k = 0; k < kIkRing; ++k) sh.rec[slot][k] = 0;
     st.slot = slot;
     ik_load_target([&](int k, double v) { sh.Td[k][slot] = v; }, Tep + 16 * tgt);   // once per target, not per search
@@ -641,13 +641,123 @@ RTB_HD bool ik_pick(const SH &sh, int r, int nb, int ni, int policy, int s_first
 }
 // step 2 (after every lane has picked): claim the index and start the search
 template <int NJ, class SH, class PD, class QL>
-RTB_HD void ik_start_spec(IkLane<NJ> &st, SH &sh, int lane, const PD &p, QL qlim, int slot, int s, const IkWork *work,
+RTB_HD void ik_start_spec(IkLane<NJ> &st, SH &sh, int lane, const PD &p, QL qlim, int slot, int s,
                           const double *__restrict__ Tep, const double *__restrict__ q0)
 {
     ik_lds_max(&sh.next[slot], s + 1);
-    const int64_t tgt = ik_slot_tgt(sh, slot, work);
+    const int64_t tgt = sh.tgt[slot];
     st.slot = slot;
     ik_search_begin<NJ>(st, ik_lds_q(sh, lane), p, qlim, tgt, s, p.has_q0 ? q0 + (int64_t)NJ * tgt : nullptr);
+}
+
+// ---------------------------------------------------------------- cross-wave sharing of search ranges
+// With the whole batch resident at once (BASELINE config 3: 1e5 targets on 131072 lanes) a wave is stuck with the targets it
+// drew; the ~1 % that exhaust all `slimit` searches cost 40x the mean, so the waves that drew two or three of them run twice as
+// long as the average one and the kernel waits for them (CPU replay of config 3: longest wave 177-217 iterations, mean 104).
+// A search is a pure function of (target, search index), so the UNSTARTED part of a slot's search range can be cut off
+// and handed to another wave as a new work item: the donor appends it to a device-wide list (row N + k of the item table), a
+// wave that has run out of work picks it up like a fresh target, and a target's rows are chained in search order (`link`) for a
+// final merge (iterations add up along the chain; the first success, or the chain's last row, supplies the answer) -- exactly
+// the sequential loops' result, whoever ran what.  All control traffic is a handful of agent-scope atomics per scheduling pass.
+struct IkShareCtl {
+    unsigned long long *counter;   // next item index to hand out (items 0 .. N-1 are the targets themselves)
+    unsigned *dyn_count;           // items appended so far
+    unsigned *idle;                // waves that have run out of work
+    unsigned long long *wdyn;      // appended items, packed IkWork; ~0 = reserved but not written yet
+    int32_t *link;                 // row -> next row of the same target, -1 at the end of a chain
+    uint32_t cap, waves;           // capacity of wdyn; grid size
+};
+constexpr unsigned long long kIkNoItem = ~0ull;
+constexpr int kIkDonateMin = 4;    // a slot gives away its unstarted searches (all but the next one) when at least this many are left
+
+RTB_HD unsigned long long ik_aload(const unsigned long long *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    return *p;
+#endif
+}
+RTB_HD unsigned ik_aload(const unsigned *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    return *p;
+#endif
+}
+RTB_HD unsigned ik_aadd(unsigned *p, unsigned v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    const unsigned o = *p; *p = o + v; return o;
+#endif
+}
+// Take up to `want` items [got, got + n) -- never beyond what exists NOW (a fetch-add past the end would swallow the indices of
+// items appended later).  One lane calls this.
+RTB_HD int ik_take(const IkShareCtl &c, int64_t N, int want, unsigned long long &got)
+{
+    unsigned long long old = ik_aload(c.counter);
+    for (;;) {
+        const unsigned long long total = (unsigned long long)N + ik_aload(c.dyn_count);
+        if (old >= total || want <= 0) { got = old; return 0; }
+        const unsigned long long n = total - old < (unsigned long long)want ? total - old : (unsigned long long)want;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (__hip_atomic_compare_exchange_strong(c.counter, &old, old + n, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { got = old; return (int)n; }
+#else
+        *c.counter = old + n; got = old; return (int)n;
+#endif
+    }
+}
+// The item of row v (v >= N: an appended one; its writer may not have stored it yet)
+template <class PD>
+RTB_HD IkWork ik_row_item(const IkShareCtl &c, const PD &p, int64_t N, int64_t v)
+{
+    if (v < N) { IkWork w; w.tgt = (int32_t)v; w.s0 = (int16_t)ik_s_first(p); w.s1 = (int16_t)ik_s_last(p); return w; }
+    unsigned long long x = ik_aload(c.wdyn + (v - N));
+    for (int spin = 0; x == kIkNoItem && spin < (1 << 20); ++spin) x = ik_aload(c.wdyn + (v - N));
+    return ik_unpack(x);
+}
+// Cut the unstarted searches of slot `slot` (but one) off into a new item.  One lane calls this; the slot's tables are this
+// wave's own.  Returns whether an item was appended.
+template <class SH>
+RTB_HD bool ik_donate(const IkShareCtl &c, int64_t N, SH &sh, int slot)
+{
+    const int next = sh.next[slot], last = sh.slast[slot];
+    const int room = last - next + 1;
+    if (sh.res[slot] != 0 || room < kIkDonateMin) return false;
+    const unsigned k = ik_aadd(c.dyn_count, 1u);
+    if (k >= c.cap) { ik_aadd(c.dyn_count, (unsigned)-1); return false; }     // table full: undo (the slot stays whole)
+    // everything but the next search: the owner's lanes are all busy at this moment (that is why the searches are unstarted),
+    // an idle wave can start them at once.  The slot keeps one unstarted search so that its (new) last search is still ahead --
+    // the lane that will run it reports it as the range's last one.
+    const int mid = next + 1;
+    IkWork w; w.tgt = (int32_t)sh.tgt[slot]; w.s0 = (int16_t)mid; w.s1 = (int16_t)last;
+    const int64_t row = N + k, mine = sh.vix[slot];
+    c.link[row] = c.link[mine];          // the new item continues this slot's range: insert it right after the slot's row
+    c.link[mine] = (int32_t)row;
+    sh.slast[slot] = (int16_t)(mid - 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+    __hip_atomic_store(c.wdyn + k, ik_pack(w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    c.wdyn[k] = ik_pack(w);
+#endif
+    return true;
+}
+// Final merge of one target's chain of rows (in search order) into the caller's arrays.
+RTB_HD void ik_merge_chain(int n, int64_t tgt, const int32_t *link, const double *vq, const int32_t *vok, const int32_t *vit, const int32_t *vse,
+                           const double *vE, double *q_out, int32_t *success, int32_t *iters, int32_t *searches, double *residual)
+{
+    int64_t r = tgt;
+    int it = 0;
+    for (;;) {
+        it += vit[r];
+        if (vok[r] || link[r] < 0) break;
+        r = link[r];
+    }
+    for (int j = 0; j < n; ++j) q_out[tgt * n + j] = vq[r * n + j];
+    success[tgt] = vok[r]; iters[tgt] = it; searches[tgt] = vse[r]; residual[tgt] = vE[r];
 }
 
 // ---------------------------------------------------------------- phased schedule for batches small against the chip
@@ -727,7 +837,8 @@ RTB_HD void ik_solve_sequential(const IkDev &p, const CV &cv, QL qlim, int64_t t
         }
         it += st.iter;
         if (st.ok || s == s_last) {
-            ik_emit<NJ>(st, qa, p, qlim, tgt, tgt, p.has_q0 != 0, st.ok != 0, it, st.E, q_out, success, iters, searches, residual);
+            if (!st.ok) residual[tgt] = st.E;         // what ik_report leaves for the range's last search
+            ik_emit<NJ>(st, qa, p, qlim, tgt, tgt, p.has_q0 != 0, st.ok != 0, it, q_out, success, iters, searches, residual);
             return;
         }
     }

@@ -35,7 +35,17 @@ struct IkKernArgs {
     double *residual;
     const IkWork *work;              // NULL: item v is target v with the whole search range
     const unsigned *count;           // NULL: p.N items; else the item count is read from the device (a compacted list)
+    IkShareCtl share;                // share.counter != NULL: cross-wave sharing of search ranges (ik_device.h)
 };
+
+// the sharing control block out of the (constant address space) argument block, member by member
+__device__ __forceinline__ IkShareCtl share_of(const RTB_CONST IkKernArgs *ka)
+{
+    IkShareCtl c;
+    c.counter = ka->share.counter; c.dyn_count = ka->share.dyn_count; c.idle = ka->share.idle; c.wdyn = ka->share.wdyn;
+    c.link = ka->share.link; c.cap = ka->share.cap; c.waves = ka->share.waves;
+    return c;
+}
 
 // Wave-level driver of the scheduler phases of ik_device.h (the same sequence tests/emu replays on the CPU).
 constexpr int kIkNullMax = 12;   // null-space step variants: 6..8 joints in registers, 9..12 with scratch
@@ -47,7 +57,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                                                 const double *__restrict__ q0, unsigned long long *counter,
                                                 double *__restrict__ q_out, int32_t *__restrict__ success,
                                                 int32_t *__restrict__ iters, int32_t *__restrict__ searches,
-                                                double *__restrict__ residual, const IkWork *work_g, const unsigned *count_g)
+                                                double *__restrict__ residual, const IkWork *work_g, const unsigned *count_g, IkShareCtl share_g)
 {
     __shared__ IkWaveSharedFor<NJ> sh;
     const RTB_CONST IkKernArgs *ka = (const RTB_CONST IkKernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -68,6 +78,8 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
     const long long patience = ik_patience(p, s_last);    // watchdog budget (ik_device.h), the pass latency included
     long long quiet = 0;
     const unsigned long long NN = count_g ? (unsigned long long)*count_g : (unsigned long long)p.N;   // wave-uniform
+    const bool sharing = share_g.counter != nullptr;     // wave-uniform
+    bool am_idle = false;            // sharing: this wave is counted in share.idle
     for (;;) {
         asm volatile("" : "+s"(ka));
         // the scheduling pass runs when some search has ended -- at most every (pass_mask + 1)-th iteration: a
@@ -82,11 +94,11 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
             double *q_out = ka->q_out, *residual = ka->residual;
             int32_t *success = ka->success, *iters = ka->iters, *searches = ka->searches;
             const IkWork *work = ka->work;
-            ik_report<NJ>(st, sh);                                                     // phase A
+            ik_report<NJ>(st, sh, residual);                                           // phase A
             __syncthreads();
             if ((busy >> lane) & 1ull) ik_account(lane, sh);                            // phase B
             __syncthreads();
-            ik_finalize<NJ>(st, sh, lane, p, qlim, work, q_out, success, iters, searches, residual);   // phase C
+            ik_finalize<NJ>(st, sh, lane, p, qlim, q_out, success, iters, searches, residual);   // phase C
             const unsigned long long freed = __ballot(((busy >> lane) & 1ull) && sh.res[lane] != 0);
             if (freed) quiet = 0;
             busy &= ~freed;
@@ -99,7 +111,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                 const int r = ik_rank(idle, lane);
                 if (((idle >> lane) & 1ull) && r < __popcll(starved)) {
                     const int slot = sh.list[r];
-                    ik_start_spec<NJ>(st, sh, lane, p, qlim, slot, sh.next[slot], work, Tep, q0);
+                    ik_start_spec<NJ>(st, sh, lane, p, qlim, slot, sh.next[slot], Tep, q0);
                 }
                 __syncthreads();
                 idle = __ballot(st.status == kIkIdle);
@@ -115,6 +127,21 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                     cap = per_wave < 1u ? 1 : (per_wave > 64u ? 64 : (int)per_wave);
                 }
                 nf = nf > cap ? cap : nf;
+                unsigned long long base;
+                long long nvalid;
+                if (sharing) {
+                    // the supply can grow (donated ranges): take what exists now, never reserve past the end
+                    const IkShareCtl shc = share_of(ka);
+                    unsigned long long got = 0;
+                    int n = 0;
+                    if (lane == 0) n = ik_take(shc, p.N, nf, got);
+                    n = __shfl(n, 0);
+                    const unsigned lo = __shfl((unsigned)(got & 0xffffffffu), 0);
+                    const unsigned hi = __shfl((unsigned)(got >> 32), 0);
+                    base = ((unsigned long long)hi << 32) | lo;
+                    nvalid = n;
+                    if (n > 0 && am_idle) { if (lane == 0) ik_aadd(shc.idle, (unsigned)-1); am_idle = false; }
+                } else {
                 // targets are reserved from the device-wide counter in chunks and handed out from the wave's
                 // own pool: the atomic's round trip (and its s_waitcnt) is paid once per chunk, not per pass
                 if (pool_next == pool_end) {
@@ -128,18 +155,24 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                     pool_end = got + chunk < NN ? got + chunk : NN;
                     if (pool_end == NN) drained = true;      // the counter has passed N: this is the wave's last refill
                 }
-                const unsigned long long base = pool_next;
-                long long nvalid = (long long)(pool_end - pool_next);
+                base = pool_next;
+                nvalid = (long long)(pool_end - pool_next);
                 nvalid = nvalid > nf ? nf : nvalid;
                 pool_next += (unsigned long long)nvalid;
                 if (drained && pool_next == pool_end) exhausted = true;
+                }
                 if ((freeslots >> lane) & 1ull) sh.list[ik_rank(freeslots, lane)] = lane;
                 __syncthreads();
                 const int r = ik_rank(idle, lane);
                 int myslot = -1;
                 if (((idle >> lane) & 1ull) && r < nvalid) {
                     myslot = sh.list[r];
-                    ik_start_target<NJ>(st, sh, lane, p, qlim, myslot, (int64_t)base + r, work, Tep, q0);
+                    const int64_t v = (int64_t)base + r;
+                    IkWork w;
+                    if (sharing) w = ik_row_item(share_of(ka), p, p.N, v);
+                    else if (work) w = work[v];
+                    else { w.tgt = (int32_t)v; w.s0 = (int16_t)ik_s_first(p); w.s1 = (int16_t)ik_s_last(p); }
+                    ik_start_target<NJ>(st, sh, lane, p, qlim, myslot, v, w, Tep, q0);
                 }
                 busy |= __ballot(((freeslots >> lane) & 1ull) && ik_rank(freeslots, lane) < nvalid);
                 __syncthreads();
@@ -152,11 +185,46 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                 int slot = 0, s = 0;
                 const bool mine = ((idle >> lane) & 1ull) && ik_pick(sh, ik_rank(idle, lane), nb, __popcll(idle), p.spec_policy, ik_s_first(p), slot, s);
                 __syncthreads();
-                if (mine) ik_start_spec<NJ>(st, sh, lane, p, qlim, slot, s, work, Tep, q0);
+                if (mine) ik_start_spec<NJ>(st, sh, lane, p, qlim, slot, s, Tep, q0);
                 __syncthreads();
             }
+            if (sharing && busy) {                                                      // phase D3: give work to idle waves
+                const IkShareCtl shc = share_of(ka);
+                unsigned waiting = 0;
+                if (lane == 0) waiting = ik_aload(shc.idle);
+                waiting = __shfl(waiting, 0);
+                if (waiting > 0) {
+                    // up to one range per waiting wave, the slots in order (the pass is wave-uniform here: lane 0 does the bookkeeping)
+                    if (lane == 0) {
+                        unsigned given = 0;
+                        for (int i = 0; i < kWave && given < waiting; ++i)
+                            if (((busy >> i) & 1ull) && ik_aload(shc.dyn_count) + shc.waves < shc.cap && ik_donate(shc, p.N, sh, i)) ++given;
+                    }
+                    __syncthreads();
+                }
+            }
         }
-        if (busy == 0 && exhausted) break;
+        if (busy == 0 && (exhausted || sharing)) {
+            if (!sharing) break;
+            // sharing: out of work -- say so, then wait for a donated range or for everybody to be done
+            const IkShareCtl shc = share_of(ka);
+            int verdict = 0;                          // 0 keep waiting, 1 work has appeared, 2 all waves idle: done
+            if (lane == 0) {
+                if (!am_idle) ik_aadd(shc.idle, 1u);
+                for (int spin = 0; spin < (1 << 18) && verdict == 0; ++spin) {
+                    const unsigned long long total = (unsigned long long)p.N + ik_aload(shc.dyn_count);
+                    if (ik_aload(shc.counter) < total) verdict = 1;
+                    else if (ik_aload(shc.idle) >= shc.waves) verdict = 2;
+                    else __builtin_amdgcn_s_sleep(32);
+                }
+                if (verdict == 0) verdict = 2;        // bound reached: leave (the donor of any late item picks it up itself)
+            }
+            am_idle = true;
+            verdict = __shfl(verdict, 0);
+            if (verdict == 2) break;
+            first = true;                             // run a scheduling pass now: it tries to take the new item
+            continue;
+        }
         if (++quiet > patience) {
             // Watchdog (never expected to fire): no target of this wave was resolved for longer than any single
             // target can take.  Leave loudly recognisable outputs instead of whatever the buffers held:
@@ -229,7 +297,16 @@ __global__ __launch_bounds__(256) void k_ik_merge_c(IkPhases ph, int n, const Ik
     }
 }
 
+__global__ __launch_bounds__(256) void k_ik_merge_chain(int64_t N, int n, const int32_t *__restrict__ link, const double *vq, const int32_t *vok,
+                                                        const int32_t *vit, const int32_t *vse, const double *vE, double *q_out, int32_t *success,
+                                                        int32_t *iters, int32_t *searches, double *residual)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < N) ik_merge_chain(n, t, link, vq, vok, vit, vse, vE, q_out, success, iters, searches, residual);
+}
+
 namespace {
+int g_ik_share = 1;       // cross-wave sharing of search ranges: 0 never, 1 automatic (batch resident at once), 2 always (tests)
 int g_ik_phased = 0;      // 0 never (default: the CPU replay and the GPU both say it loses), 1 automatic, 2 always (tests)
 int g_ik_spec_policy = 0;
 int g_ik_fresh_pct = 50;  // share of a wave's even part of the batch it may start per scheduling pass, in percent: the rest is
@@ -246,6 +323,7 @@ void ik_tune(const char *key, int value)
 {
     if (std::string(key) == "ik_waves_per_cu") g_ik_waves_per_cu = value < 1 ? 1 : value;
     if (std::string(key) == "ik_pass_mask") g_ik_pass_mask = value < 0 ? 0 : value;
+    if (std::string(key) == "ik_share") g_ik_share = value < 0 ? 0 : (value > 2 ? 2 : value);
     if (std::string(key) == "ik_phased") g_ik_phased = value < 0 ? 0 : (value > 2 ? 2 : value);
     if (std::string(key) == "ik_fresh_pct") g_ik_fresh_pct = value < 1 ? 1 : value;
     if (std::string(key) == "ik_spec_policy") g_ik_spec_policy = value != 0;
@@ -270,15 +348,15 @@ void ik_restart_host(const Chain *c, uint64_t seed, int64_t target, int draw, do
 template <int NJ>
 static void launch_nj(dim3 grid, hipStream_t s, const IkDev &p, const DevChain &dc, const double *qlim, const double *Tep,
                       const double *q0, unsigned long long *ctr, double *q_out, int32_t *success, int32_t *iters,
-                      int32_t *searches, double *residual, const IkWork *work, const unsigned *count)
+                      int32_t *searches, double *residual, const IkWork *work, const unsigned *count, const IkShareCtl &share)
 {
     const int v = ik_step_variant(p, NJ);
     if constexpr (NJ >= 6 && NJ <= kIkNullMax) {        // the null-space variants exist for 6..12 joints (launch_ik checks)
-        if (v == 2) { hipLaunchKernelGGL((k_ik<NJ, 2>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count); return; }
-        if (v == 3) { hipLaunchKernelGGL((k_ik<NJ, 3>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count); return; }
+        if (v == 2) { hipLaunchKernelGGL((k_ik<NJ, 2>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share); return; }
+        if (v == 3) { hipLaunchKernelGGL((k_ik<NJ, 3>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share); return; }
     }
-    if (v & kIkStepPinv) hipLaunchKernelGGL((k_ik<NJ, 1>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count);
-    else hipLaunchKernelGGL((k_ik<NJ, 0>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count);
+    if (v & kIkStepPinv) hipLaunchKernelGGL((k_ik<NJ, 1>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share);
+    else hipLaunchKernelGGL((k_ik<NJ, 0>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share);
 }
 
 int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const double *Tep, int64_t N, const double *q0,
@@ -326,11 +404,12 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
     const int n = c->n;
     // one launch of the scheduler kernel over `items` work items (the targets themselves when work == NULL)
     auto run = [&](const IkDev &pp, int64_t items, const IkWork *work, const unsigned *count, double *qo, int32_t *ok, int32_t *it,
-                   int32_t *se, double *E) -> int {
+                   int32_t *se, double *E, IkShareCtl share = IkShareCtl()) -> int {
         IkDev p2 = pp;
         int64_t g = gmax;
         if (!count && g > items) g = items;
         if (g < 1) g = 1;
+        share.waves = (uint32_t)g;
         const int64_t cap = ((items + g - 1) / g * g_ik_fresh_pct + 99) / 100;
         p2.fresh_cap = cap > 64 ? 64 : (cap < 1 ? 1 : (int32_t)cap);
         p2.pass_mask = g_ik_pass_mask;
@@ -344,28 +423,71 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
         RTB_HIP(hipMemsetAsync(ctr, 0, sizeof(unsigned long long), s));
         dim3 grid((unsigned)g);
         switch (n) {
-        case 1: launch_nj<1>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
-        case 2: launch_nj<2>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
-        case 3: launch_nj<3>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
-        case 4: launch_nj<4>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
-        case 5: launch_nj<5>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
-        case 6: launch_nj<6>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
-        case 7: launch_nj<7>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
-        case 8: launch_nj<8>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
-        case 9: launch_nj<9>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
-        case 10: launch_nj<10>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
-        case 11: launch_nj<11>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
-        case 12: launch_nj<12>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
-        case 13: launch_nj<13>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
-        case 14: launch_nj<14>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
-        case 15: launch_nj<15>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
-        default: launch_nj<16>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count); break;
+        case 1: launch_nj<1>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
+        case 2: launch_nj<2>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
+        case 3: launch_nj<3>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
+        case 4: launch_nj<4>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
+        case 5: launch_nj<5>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
+        case 6: launch_nj<6>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
+        case 7: launch_nj<7>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
+        case 8: launch_nj<8>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
+        case 9: launch_nj<9>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
+        case 10: launch_nj<10>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
+        case 11: launch_nj<11>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
+        case 12: launch_nj<12>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
+        case 13: launch_nj<13>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
+        case 14: launch_nj<14>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
+        case 15: launch_nj<15>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
+        default: launch_nj<16>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
         }
         note_launch((int)grid.x, kWave, 0);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "k_ik launch");
         return RTBHIP_OK;
     };
+
+    // Cross-wave sharing of search ranges (ik_device.h) when the whole batch is resident at once: rtbhip_tune("ik_share",
+    // 0 / 1 / 2) = never / automatic / always (tests).  Rows go to temporaries; a merge kernel walks each target's chain.
+    const bool share_on = g_ik_share == 2 || (g_ik_share == 1 && N <= 4 * gmax * kWave && N <= (1 << 24) && ik_s_last(p) - ik_s_first(p) + 1 >= 2 * kIkDonateMin);
+    if (share_on) {
+        const int64_t g = gmax > N ? N : gmax;
+        const size_t M = (size_t)(N < 65536 ? N : 65536) + (size_t)g + 64, rows = (size_t)N + M;
+        unsigned long long *ctl = nullptr, *wdyn = nullptr; int32_t *link = nullptr;
+        double *vq = nullptr, *vE = nullptr; int32_t *vok = nullptr, *vit = nullptr, *vse = nullptr;
+        auto alloc = [&](void **ptr, size_t bytes) -> int {
+            hipError_t e = hipMallocAsync(ptr, bytes, s);
+            return e == hipSuccess ? RTBHIP_OK : hip_fail(e, "hipMallocAsync (ik sharing)");
+        };
+        int rc = alloc((void **)&ctl, 32);
+        if (rc == RTBHIP_OK) rc = alloc((void **)&wdyn, M * sizeof(unsigned long long));
+        if (rc == RTBHIP_OK) rc = alloc((void **)&link, rows * sizeof(int32_t));
+        if (rc == RTBHIP_OK) rc = alloc((void **)&vq, rows * n * sizeof(double));
+        if (rc == RTBHIP_OK) rc = alloc((void **)&vE, rows * sizeof(double));
+        if (rc == RTBHIP_OK) rc = alloc((void **)&vok, rows * sizeof(int32_t));
+        if (rc == RTBHIP_OK) rc = alloc((void **)&vit, rows * sizeof(int32_t));
+        if (rc == RTBHIP_OK) rc = alloc((void **)&vse, rows * sizeof(int32_t));
+        if (rc == RTBHIP_OK) {
+            hipError_t e = hipMemsetAsync(ctl, 0, 32, s);
+            if (e == hipSuccess) e = hipMemsetAsync(wdyn, 0xFF, M * sizeof(unsigned long long), s);
+            if (e == hipSuccess) e = hipMemsetAsync(link, 0xFF, rows * sizeof(int32_t), s);
+            if (e != hipSuccess) rc = hip_fail(e, "hipMemsetAsync (ik sharing)");
+        }
+        if (rc == RTBHIP_OK) {
+            IkShareCtl sc;
+            sc.counter = ctl; sc.dyn_count = (unsigned *)(ctl + 1); sc.idle = (unsigned *)(ctl + 1) + 1;
+            sc.wdyn = wdyn; sc.link = link; sc.cap = (uint32_t)M; sc.waves = 0;
+            rc = run(p, N, nullptr, nullptr, vq, vok, vit, vse, vE, sc);
+        }
+        if (rc == RTBHIP_OK) {
+            hipLaunchKernelGGL(k_ik_merge_chain, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, N, n, link, vq, vok, vit, vse, vE, q_out, success, iters,
+                               searches, residual);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) rc = hip_fail(e, "k_ik_merge_chain launch");
+        }
+        for (void *ptr : {(void *)ctl, (void *)wdyn, (void *)link, (void *)vq, (void *)vE, (void *)vok, (void *)vit, (void *)vse})
+            if (ptr) (void)hipFreeAsync(ptr, s);
+        return rc;
+    }
 
     // Phased schedule (ik_device.h) when the whole batch is resident at once and the search range is long enough to split;
     // rtbhip_tune("ik_phased", 0 / 1 / 2) = never / automatic / always (tests).

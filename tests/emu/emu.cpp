@@ -335,12 +335,13 @@ struct EmuWave {
     unsigned tick = 0;
     long long passes = 0, iters = 0, lane_iters_useful = 0;
     long long quiet = 0;       // the kernel's watchdog counter, replayed: a false fire fails the run (-4)
+    bool am_idle = false;      // sharing: counted in share.idle
 };
 
 template <int NJ>
 static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const double *Tep, const double *q0, double *q_out,
                            int32_t *success, int32_t *iters, int32_t *searches, double *residual, double *stats,
-                           const IkWork *work = nullptr)
+                           const IkWork *work = nullptr, const IkShareCtl *share = nullptr)
 {
     const DevChain cv = chain_host_view(c);
     const double *qlim = c->qlim.data();
@@ -379,9 +380,9 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
             if (w.first || ((w.tick++ & p.pass_mask) == 0 && anyfin)) {
                 w.first = false;
                 w.passes++;
-                for (int l = 0; l < kWave; ++l) ik_report<NJ>(w.st[l], w.sh);
+                for (int l = 0; l < kWave; ++l) ik_report<NJ>(w.st[l], w.sh, residual);
                 for (int l = 0; l < kWave; ++l) if ((w.busy >> l) & 1ull) ik_account(l, w.sh);
-                for (int l = 0; l < kWave; ++l) ik_finalize<NJ>(w.st[l], w.sh, l, p, qlim, work, q_out, success, iters, searches, residual);
+                for (int l = 0; l < kWave; ++l) ik_finalize<NJ>(w.st[l], w.sh, l, p, qlim, q_out, success, iters, searches, residual);
                 const unsigned long long freed = ballot(w, [&](int l) { return ((w.busy >> l) & 1ull) && w.sh.res[l] != 0; });
                 if (freed) w.quiet = 0;
                 w.busy &= ~freed;
@@ -395,7 +396,7 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
                         const int r = ik_rank(idle, l);
                         if (((idle >> l) & 1ull) && r < ns) {
                             const int slot = w.sh.list[r];
-                            ik_start_spec<NJ>(w.st[l], w.sh, l, p, qlim, slot, w.sh.next[slot], work, Tep, q0);
+                            ik_start_spec<NJ>(w.st[l], w.sh, l, p, qlim, slot, w.sh.next[slot], Tep, q0);
                         }
                     }
                     idle = ballot(w, [&](int l) { return w.st[l].status == kIkIdle; });
@@ -406,6 +407,14 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
                     nf = nf > p.fresh_cap ? p.fresh_cap : nf;
                     { static const int mb = getenv("EMU_IK_MAX_BUSY") ? atoi(getenv("EMU_IK_MAX_BUSY")) : 64;
                       const int room = mb - __builtin_popcountll(w.busy); nf = nf > room ? (room > 0 ? room : 0) : nf; }
+                    unsigned long long base;
+                    long long nvalid;
+                    if (share) {
+                        unsigned long long got = 0;
+                        const int n = ik_take(*share, p.N, nf, got);
+                        base = got; nvalid = n;
+                        if (n > 0 && w.am_idle) { *share->idle -= 1; w.am_idle = false; }
+                    } else {
                     if (w.pool_next == w.pool_end) {
                         const unsigned long long chunk = p.pool_chunk > 0 ? (unsigned long long)p.pool_chunk : (unsigned long long)nf;
                         const unsigned long long got = counter;
@@ -415,16 +424,23 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
                         w.pool_end = got + chunk < NN ? got + chunk : NN;
                         if (w.pool_end == NN) w.drained = true;
                     }
-                    const unsigned long long base = w.pool_next;
-                    long long nvalid = (long long)(w.pool_end - w.pool_next);
+                    base = w.pool_next;
+                    nvalid = (long long)(w.pool_end - w.pool_next);
                     nvalid = nvalid > nf ? nf : nvalid;
                     w.pool_next += (unsigned long long)nvalid;
                     if (w.drained && w.pool_next == w.pool_end) w.exhausted = true;
+                    }
                     for (int l = 0; l < kWave; ++l) if ((freeslots >> l) & 1ull) w.sh.list[ik_rank(freeslots, l)] = l;
                     for (int l = 0; l < kWave; ++l) {
                         const int r = ik_rank(idle, l);
-                        if (((idle >> l) & 1ull) && r < nvalid)
-                            ik_start_target<NJ>(w.st[l], w.sh, l, p, qlim, w.sh.list[r], (int64_t)base + r, work, Tep, q0);
+                        if (((idle >> l) & 1ull) && r < nvalid) {
+                            const int64_t v = (int64_t)base + r;
+                            IkWork it;
+                            if (share) it = ik_row_item(*share, p, p.N, v);
+                            else if (work) it = work[v];
+                            else { it.tgt = (int32_t)v; it.s0 = (int16_t)ik_s_first(p); it.s1 = (int16_t)ik_s_last(p); }
+                            ik_start_target<NJ>(w.st[l], w.sh, l, p, qlim, w.sh.list[r], v, it, Tep, q0);
+                        }
                     }
                     w.busy |= ballot(w, [&](int l) { return ((freeslots >> l) & 1ull) && ik_rank(freeslots, l) < nvalid; });
                     idle = ballot(w, [&](int l) { return w.st[l].status == kIkIdle; });
@@ -436,8 +452,21 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
                     bool mine[kWave];
                     for (int l = 0; l < kWave; ++l)
                         mine[l] = ((idle >> l) & 1ull) && ik_pick(w.sh, ik_rank(idle, l), nb, __builtin_popcountll(idle), p.spec_policy, ik_s_first(p), slot[l], ss[l]);
-                    for (int l = 0; l < kWave; ++l) if (mine[l]) ik_start_spec<NJ>(w.st[l], w.sh, l, p, qlim, slot[l], ss[l], work, Tep, q0);
+                    for (int l = 0; l < kWave; ++l) if (mine[l]) ik_start_spec<NJ>(w.st[l], w.sh, l, p, qlim, slot[l], ss[l], Tep, q0);
                 }
+                if (share && w.busy && *share->idle > 0) {                       // phase D3: give work to idle waves
+                    unsigned given = 0;
+                    const unsigned waiting = *share->idle;
+                    for (int i = 0; i < kWave && given < waiting; ++i)
+                        if (((w.busy >> i) & 1ull) && *share->dyn_count + share->waves < share->cap && ik_donate(*share, p.N, w.sh, i)) ++given;
+                }
+            }
+            if (share && w.busy == 0) {
+                if (!w.am_idle) { *share->idle += 1; w.am_idle = true; }
+                const unsigned long long total = (unsigned long long)p.N + *share->dyn_count;
+                if (*share->counter < total) { w.first = true; continue; }     // work has appeared: a pass at the next turn takes it
+                if (*share->idle >= share->waves) { w.done = true; --live; }
+                continue;                                                      // keep waiting
             }
             if (w.busy == 0 && w.exhausted) { w.done = true; --live; continue; }
             if (++w.quiet > ik_patience(p, s_last)) return -4;   // the kernel would overwrite valid results with its NaN markers here
@@ -513,6 +542,30 @@ static int emu_ik_phased_run(const Chain *c, const IkDev &p, int waves, const do
     return 0;
 }
 
+// launch_ik's sharing mode (ik_kernels.hip): rows N .. N+M for donated ranges, the chain merge at the end
+template <int NJ>
+static int emu_ik_shared_run(const Chain *c, const IkDev &p, int waves, const double *Tep, const double *q0, double *q_out,
+                             int32_t *success, int32_t *iters, int32_t *searches, double *residual, double *stats)
+{
+    const int n = NJ;
+    const size_t M = (size_t)std::min<int64_t>(p.N, 65536) + waves + 64, rows = (size_t)p.N + M;
+    std::vector<unsigned long long> wdyn(M, kIkNoItem);
+    std::vector<int32_t> link(rows, -1), vok(rows, 0), vit(rows, 0), vse(rows, 0);
+    std::vector<double> vq(rows * n, 0.0), vE(rows, 0.0);
+    unsigned long long counter = 0;
+    unsigned dyn_count = 0, idle = 0;
+    IkShareCtl sc;
+    sc.counter = &counter; sc.dyn_count = &dyn_count; sc.idle = &idle; sc.wdyn = wdyn.data(); sc.link = link.data();
+    sc.cap = (uint32_t)M; sc.waves = (uint32_t)waves;
+    const int rc = emu_ik_wave_run<NJ>(c, p, waves, Tep, q0, vq.data(), vok.data(), vit.data(), vse.data(), vE.data(), stats, nullptr, &sc);
+    if (rc) return rc;
+    if (counter != (unsigned long long)p.N + dyn_count) return -5;                // every item must have been taken
+    for (int64_t t = 0; t < p.N; ++t)
+        ik_merge_chain(n, t, link.data(), vq.data(), vok.data(), vit.data(), vse.data(), vE.data(), q_out, success, iters, searches, residual);
+    if (getenv("EMU_IK_DEBUG")) fprintf(stderr, "sharing: %u ranges donated\n", dyn_count);
+    return 0;
+}
+
 // null-space terms for the next emu_ik / emu_ik_wave calls (kq <= 0: none)
 static double g_emu_ns[4] = {0.0, 0.0, 0.1, 0.3};
 extern "C" void emu_ik_nullspace(double kq, double km, double ps, double pi) { g_emu_ns[0] = kq; g_emu_ns[1] = km; g_emu_ns[2] = ps; g_emu_ns[3] = pi; }
@@ -568,11 +621,14 @@ extern "C" int emu_ik_wave(rtbhip_chain_t h, int waves, double *stats, const dou
     if (const char *fc = getenv("EMU_IK_FRESH_CAP")) p.fresh_cap = atoi(fc);
     int rc = 0;
     const bool phased = getenv("EMU_IK_PHASED") != nullptr && atoi(getenv("EMU_IK_PHASED")) != 0;
-#define RTB_EMU_IK(NJ) case NJ: rc = phased ? emu_ik_phased_run<NJ>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats) \
+    const bool shared = getenv("EMU_IK_SHARE") != nullptr && atoi(getenv("EMU_IK_SHARE")) != 0;
+#define RTB_EMU_IK(NJ) case NJ: rc = shared ? emu_ik_shared_run<NJ>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats) \
+                                    : phased ? emu_ik_phased_run<NJ>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats) \
                                              : emu_ik_wave_run<NJ>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
     switch (c->n) {
     RTB_EMU_IK(1) RTB_EMU_IK(2) RTB_EMU_IK(3) RTB_EMU_IK(4) RTB_EMU_IK(5) RTB_EMU_IK(6) RTB_EMU_IK(7) RTB_EMU_IK(8) RTB_EMU_IK(9) RTB_EMU_IK(10) RTB_EMU_IK(11) RTB_EMU_IK(12) RTB_EMU_IK(13) RTB_EMU_IK(14) RTB_EMU_IK(15)
-    default: rc = phased ? emu_ik_phased_run<16>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats)
+    default: rc = shared ? emu_ik_shared_run<16>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats)
+                : phased ? emu_ik_phased_run<16>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats)
                          : emu_ik_wave_run<16>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats); break;
     }
 #undef RTB_EMU_IK

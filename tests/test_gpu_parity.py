@@ -581,17 +581,56 @@ def test_ik_fourteen_joint_chain_equals_oracle():
         assert e.n in (9, 10)
         e.qlim = np.clip(e.qlim, -np.pi, np.pi)
         c2 = chain_from_ets(e)
-        q2 = rng.uniform(c2.qlim[0] + 0.2, c2.qlim[1] - 0.2, (30, e.n))
+        span = c2.qlim[1] - c2.qlim[0]
+        q2 = rng.uniform(c2.qlim[0] + 0.1 * span, c2.qlim[1] - 0.1 * span, (30, e.n))
         T2 = oracle.fkine(c2, q2)
-        q0 = np.clip(q2 + 0.05 * rng.normal(size=q2.shape), c2.qlim[0], c2.qlim[1])
+        q0 = np.clip(q2 + 0.02 * span * rng.normal(size=q2.shape), c2.qlim[0], c2.qlim[1])
         sol = e.ikine_LM(T2, q0=q0, seed=1, slimit=5, kq=0.1, km=0.1)
         base = e.ikine_LM(T2, q0=q0, seed=1, slimit=5)
-        assert sol.each["success"].mean() >= 0.8 and np.nanmax(np.abs(sol.q - base.q)) > 1e-7
-        i = int(np.argmax(sol.each["success"] & (sol.each["searches"] == 1)))
-        o = oracle.ikine_py(c2, T2[i], np.array([q0[i]] + [e.ik_restart(1, i, d) for d in range(1, 5)]), step="lm", slimit=5, kq=0.1, km=0.1)
-        if o[1] and o[3] == 1:
-            assert (o[2], o[3]) == (sol.each["iterations"][i], sol.each["searches"][i])
-            nt.assert_allclose(sol.q[i], o[0], atol=1e-6)
+        assert np.nanmax(np.abs(np.nan_to_num(sol.q) - np.nan_to_num(base.q))) > 1e-7      # the terms act
+        # gains of 10 on a 9- / 10-joint arm push many searches out of the limits and into overflow: the success rate is what the
+        # reference's formulas give, not a quality of the kernel -- so the yardstick is the NumPy restatement, target by target
+        agree = hits = 0
+        for i in range(30):
+            o = oracle.ikine_py(c2, T2[i], np.array([q0[i]] + [e.ik_restart(1, i, d) for d in range(1, 5)]), step="lm", slimit=5, kq=0.1, km=0.1)
+            same = (o[1], o[2], o[3]) == (sol.each["success"][i], sol.each["iterations"][i], sol.each["searches"][i])
+            agree += same
+            if o[1] and o[3] == 1:
+                hits += 1
+                assert same
+                nt.assert_allclose(sol.q[i], o[0], atol=1e-6)
+        assert agree >= 27 and hits >= 3
+
+
+@pytest.mark.parametrize("flavour", [0, 1])
+def test_ik_cross_wave_sharing_and_phased_schedule_equal_plain(flavour):
+    """Cross-wave sharing of search ranges (rtbhip_tune "ik_share") and the phased schedule ("ik_phased") only change WHO runs a
+    search: every output must be bit-equal to the plain scheduler's, for reachable and unreachable targets, with and without q0,
+    at a size where the grid is under-filled (donations happen) and at one where it is over-filled."""
+    import torch
+    ets, ch = _panda_limited()
+    rng = np.random.default_rng(77 + flavour)
+    for N, with_q0, slimit in ((3000, False, 100), (150000, False, 100), (4000, True, 37), (500, False, 9)):
+        Tep = oracle.fkine(ch, rng.uniform(ch.qlim[0], ch.qlim[1], (N, 7)))
+        Tep[::41, :3, 3] += 2.5
+        q0 = rng.uniform(ch.qlim[0], ch.qlim[1], (N, 7)) if with_q0 else None
+        Tt = torch.from_numpy(Tep).cuda()
+        q0t = None if q0 is None else torch.from_numpy(q0).cuda()
+        run = (lambda: ets.ik_LM(Tt, q0=q0t, seed=3, slimit=slimit)) if flavour == 0 else \
+              (lambda: tuple(torch.as_tensor(x) for x in (lambda s: (s.q, s.each["success"], s.each["iterations"], s.each["searches"], s.each["residual"]))(ets.ikine_LM(Tt, q0=q0t, seed=3, slimit=slimit))))
+        try:
+            rtbhip.tune("ik_share", 0); rtbhip.tune("ik_phased", 0)
+            base = [x.cpu().numpy() for x in run()]
+            rtbhip.tune("ik_share", 2)
+            shared = [x.cpu().numpy() for x in run()]
+            rtbhip.tune("ik_share", 0); rtbhip.tune("ik_phased", 2)
+            phased = [x.cpu().numpy() for x in run()]
+        finally:
+            rtbhip.tune("ik_share", 1); rtbhip.tune("ik_phased", 0)
+        for a, b, c in zip(base, shared, phased):
+            nt.assert_array_equal(a, b)
+            nt.assert_array_equal(a, c)
+        assert 0 < base[1].sum() < N
 
 
 def test_init_and_shutdown_keep_handles_usable():

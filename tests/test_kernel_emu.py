@@ -548,6 +548,30 @@ def test_ik_phased_schedule_equals_sequential_searches(flavour, slimit, with_q0)
     assert a[1].sum() < N
 
 
+@pytest.mark.parametrize("flavour", [0, 1])
+@pytest.mark.parametrize("N,waves,slimit,with_q0", [(300, 6, 100, False), (64, 3, 100, False), (130, 4, 17, True), (5, 4, 100, False), (700, 2, 40, False)])
+def test_ik_cross_wave_sharing_equals_sequential_searches(flavour, N, waves, slimit, with_q0):
+    """Cross-wave sharing (ik_device.h: a wave out of work takes the unstarted part of another wave's search range as a new
+    work item; a target's rows are chained in search order and merged at the end) must report exactly what the sequential loops
+    report; the replay also checks that every appended item was taken by somebody."""
+    import os
+    ets, ch = _panda_limited()
+    rng = np.random.default_rng(N + waves)
+    Tep = oracle.fkine(ch, rng.uniform(ch.qlim[0], ch.qlim[1], (N, 7)))
+    Tep[::9, :3, 3] += 2.5
+    q0 = rng.uniform(ch.qlim[0], ch.qlim[1], (N, 7)) if with_q0 else None
+    a = emu.ik(ets, Tep, q0=q0, slimit=slimit, flavour=flavour, seed=31)
+    os.environ["EMU_IK_SHARE"] = "1"
+    os.environ["EMU_IK_PASS_MASK"] = "3"
+    try:
+        b = emu.ik(ets, Tep, q0=q0, slimit=slimit, flavour=flavour, seed=31, waves=waves)
+    finally:
+        del os.environ["EMU_IK_SHARE"], os.environ["EMU_IK_PASS_MASK"]
+    for x, y in zip(a, b):
+        nt.assert_array_equal(x, y)
+    assert a[1].sum() < N
+
+
 def test_xcd_tile_mapping_is_a_bijection_with_contiguous_eighths():
     """xcd_tile_of (trig.h): workgroup ids b = 8 i + x (XCD x) -> tiles; a permutation of [0, g) for every grid size, each
     XCD's tiles one contiguous block, visited in increasing order."""
