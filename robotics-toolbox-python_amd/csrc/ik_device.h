@@ -686,6 +686,22 @@ RTB_HD unsigned ik_aload(const unsigned *p)
     return *p;
 #endif
 }
+RTB_HD int32_t ik_aload(const int32_t *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    return *p;
+#endif
+}
+RTB_HD void ik_astore(int32_t *p, int32_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    *p = v;
+#endif
+}
 RTB_HD unsigned ik_aadd(unsigned *p, unsigned v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -735,8 +751,11 @@ RTB_HD bool ik_donate(const IkShareCtl &c, int64_t N, SH &sh, int slot)
     const int mid = next + 1;
     IkWork w; w.tgt = (int32_t)sh.tgt[slot]; w.s0 = (int16_t)mid; w.s1 = (int16_t)last;
     const int64_t row = N + k, mine = sh.vix[slot];
-    c.link[row] = c.link[mine];          // the new item continues this slot's range: insert it right after the slot's row
-    c.link[mine] = (int32_t)row;
+    // the new item continues this slot's range: insert it right after the slot's row.  link[mine] may have been written by the
+    // wave (possibly on another XCD, whose L2 this one does not snoop) that donated `mine` itself: agent-scope accesses, not
+    // plain ones that could be served from a stale line
+    ik_astore(c.link + row, ik_aload(c.link + mine));
+    ik_astore(c.link + mine, (int32_t)row);
     sh.slast[slot] = (int16_t)(mid - 1);
 #if defined(__HIP_DEVICE_COMPILE__)
     __hip_atomic_store(c.wdyn + k, ik_pack(w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -211,11 +211,17 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
             int verdict = 0;                          // 0 keep waiting, 1 work has appeared, 2 all waves idle: done
             if (lane == 0) {
                 if (!am_idle) ik_aadd(shc.idle, 1u);
-                for (int spin = 0; spin < (1 << 18) && verdict == 0; ++spin) {
+                // poll with exponential back-off (up to ~27 us between looks): two thousand waves hammering three words of
+                // memory starve the atomics of the waves that still work (first GPU run: 350 ms instead of 1.5)
+                int nap = 1;
+                for (int spin = 0; spin < (1 << 15) && verdict == 0; ++spin) {
                     const unsigned long long total = (unsigned long long)p.N + ik_aload(shc.dyn_count);
                     if (ik_aload(shc.counter) < total) verdict = 1;
-                    else if (ik_aload(shc.idle) >= shc.waves) verdict = 2;
-                    else __builtin_amdgcn_s_sleep(32);
+                    else if ((spin & 3) == 3 && ik_aload(shc.idle) >= shc.waves) verdict = 2;
+                    else {
+                        for (int k = 0; k < nap; ++k) __builtin_amdgcn_s_sleep(127);
+                        nap = nap < 8 ? nap * 2 : 8;
+                    }
                 }
                 if (verdict == 0) verdict = 2;        // bound reached: leave (the donor of any late item picks it up itself)
             }
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(256) void k_ik_merge_chain(int64_t N, int n, const 
 }
 
 namespace {
-int g_ik_share = 1;       // cross-wave sharing of search ranges: 0 never, 1 automatic (batch resident at once), 2 always (tests)
+int g_ik_share = 0;       // cross-wave sharing of search ranges: 0 never, 1 automatic (batch resident at once), 2 always (tests)
 int g_ik_phased = 0;      // 0 never (default: the CPU replay and the GPU both say it loses), 1 automatic, 2 always (tests)
 int g_ik_spec_policy = 0;
 int g_ik_fresh_pct = 50;  // share of a wave's even part of the batch it may start per scheduling pass, in percent: the rest is

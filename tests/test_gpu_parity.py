@@ -626,7 +626,7 @@ def test_ik_cross_wave_sharing_and_phased_schedule_equal_plain(flavour):
             rtbhip.tune("ik_share", 0); rtbhip.tune("ik_phased", 2)
             phased = [x.cpu().numpy() for x in run()]
         finally:
-            rtbhip.tune("ik_share", 1); rtbhip.tune("ik_phased", 0)
+            rtbhip.tune("ik_share", 0); rtbhip.tune("ik_phased", 0)
         for a, b, c in zip(base, shared, phased):
             nt.assert_array_equal(a, b)
             nt.assert_array_equal(a, c)
