@@ -660,7 +660,8 @@ RTB_HD void ik_start_spec(IkLane<NJ> &st, SH &sh, int lane, const PD &p, QL qlim
 // final merge (iterations add up along the chain; the first success, or the chain's last row, supplies the answer) -- exactly
 // the sequential loops' result, whoever ran what.  All control traffic is a handful of agent-scope atomics per scheduling pass.
 struct IkShareCtl {
-    unsigned long long *counter;   // next item index to hand out (items 0 .. N-1 are the targets themselves)
+    unsigned *dyn_taken;           // appended items handed out so far (the targets themselves, items 0 .. N-1, are handed out by the
+                                   // ordinary fetch-add counter: a compare-and-swap there had 2048 waves retrying against each other)
     unsigned *dyn_count;           // items appended so far
     unsigned *idle;                // waves that have run out of work
     unsigned long long *wdyn;      // appended items, packed IkWork; ~0 = reserved but not written yet
@@ -710,22 +711,23 @@ RTB_HD unsigned ik_aadd(unsigned *p, unsigned v)
     const unsigned o = *p; *p = o + v; return o;
 #endif
 }
-// Take up to `want` items [got, got + n) -- never beyond what exists NOW (a fetch-add past the end would swallow the indices of
-// items appended later).  One lane calls this.
-RTB_HD int ik_take(const IkShareCtl &c, int64_t N, int want, unsigned long long &got)
+// Take up to `want` APPENDED items [got, got + n) -- never beyond what exists now (a fetch-add past the end would swallow the
+// indices of items appended later).  One lane calls this; only waves that have run out of targets do.
+RTB_HD int ik_take_dyn(const IkShareCtl &c, int want, unsigned &got)
 {
-    unsigned long long old = ik_aload(c.counter);
+    unsigned old = ik_aload(c.dyn_taken);
     for (;;) {
-        const unsigned long long total = (unsigned long long)N + ik_aload(c.dyn_count);
+        const unsigned total = ik_aload(c.dyn_count);
         if (old >= total || want <= 0) { got = old; return 0; }
-        const unsigned long long n = total - old < (unsigned long long)want ? total - old : (unsigned long long)want;
+        const unsigned n = total - old < (unsigned)want ? total - old : (unsigned)want;
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (__hip_atomic_compare_exchange_strong(c.counter, &old, old + n, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { got = old; return (int)n; }
+        if (__hip_atomic_compare_exchange_strong(c.dyn_taken, &old, old + n, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { got = old; return (int)n; }
 #else
-        *c.counter = old + n; got = old; return (int)n;
+        *c.dyn_taken = old + n; got = old; return (int)n;
 #endif
     }
 }
+RTB_HD bool ik_dyn_waiting(const IkShareCtl &c) { return ik_aload(c.dyn_taken) < ik_aload(c.dyn_count); }
 // The item of row v (v >= N: an appended one; its writer may not have stored it yet)
 template <class PD>
 RTB_HD IkWork ik_row_item(const IkShareCtl &c, const PD &p, int64_t N, int64_t v)

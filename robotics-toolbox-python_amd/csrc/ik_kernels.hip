@@ -42,12 +42,13 @@ struct IkKernArgs {
 __device__ __forceinline__ IkShareCtl share_of(const RTB_CONST IkKernArgs *ka)
 {
     IkShareCtl c;
-    c.counter = ka->share.counter; c.dyn_count = ka->share.dyn_count; c.idle = ka->share.idle; c.wdyn = ka->share.wdyn;
+    c.dyn_taken = ka->share.dyn_taken; c.dyn_count = ka->share.dyn_count; c.idle = ka->share.idle; c.wdyn = ka->share.wdyn;
     c.link = ka->share.link; c.cap = ka->share.cap; c.waves = ka->share.waves;
     return c;
 }
 
 // Wave-level driver of the scheduler phases of ik_device.h (the same sequence tests/emu replays on the CPU).
+constexpr int kIkTakeLanes = 16;   // sharing: a wave looks for donated ranges when at least this many of its lanes are free
 constexpr int kIkNullMax = 12;   // null-space step variants: 6..8 joints in registers, 9..12 with scratch
 #ifndef RTB_IK_WAVES
 #define RTB_IK_WAVES 2
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
     const long long patience = ik_patience(p, s_last);    // watchdog budget (ik_device.h), the pass latency included
     long long quiet = 0;
     const unsigned long long NN = count_g ? (unsigned long long)*count_g : (unsigned long long)p.N;   // wave-uniform
-    const bool sharing = share_g.counter != nullptr;     // wave-uniform
+    const bool sharing = share_g.dyn_count != nullptr;   // wave-uniform
     bool am_idle = false;            // sharing: this wave is counted in share.idle
     for (;;) {
         asm volatile("" : "+s"(ka));
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                 __syncthreads();
                 idle = __ballot(st.status == kIkIdle);
             }
-            if (!exhausted && idle) {                                                   // phase D1: fresh targets
+            if ((!exhausted || sharing) && idle) {                                      // phase D1: fresh targets
                 const unsigned long long freeslots = ~busy;
                 // free slots >= idle lanes (every busy slot keeps a lane); the per-pass cap spreads a batch
                 // smaller than the grid's lane count evenly over the waves
@@ -127,21 +128,9 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                     cap = per_wave < 1u ? 1 : (per_wave > 64u ? 64 : (int)per_wave);
                 }
                 nf = nf > cap ? cap : nf;
-                unsigned long long base;
-                long long nvalid;
-                if (sharing) {
-                    // the supply can grow (donated ranges): take what exists now, never reserve past the end
-                    const IkShareCtl shc = share_of(ka);
-                    unsigned long long got = 0;
-                    int n = 0;
-                    if (lane == 0) n = ik_take(shc, p.N, nf, got);
-                    n = __shfl(n, 0);
-                    const unsigned lo = __shfl((unsigned)(got & 0xffffffffu), 0);
-                    const unsigned hi = __shfl((unsigned)(got >> 32), 0);
-                    base = ((unsigned long long)hi << 32) | lo;
-                    nvalid = n;
-                    if (n > 0 && am_idle) { if (lane == 0) ik_aadd(shc.idle, (unsigned)-1); am_idle = false; }
-                } else {
+                unsigned long long base = 0;
+                long long nvalid = 0;
+                if (!exhausted) {
                 // targets are reserved from the device-wide counter in chunks and handed out from the wave's
                 // own pool: the atomic's round trip (and its s_waitcnt) is paid once per chunk, not per pass
                 if (pool_next == pool_end) {
@@ -160,6 +149,18 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                 nvalid = nvalid > nf ? nf : nvalid;
                 pool_next += (unsigned long long)nvalid;
                 if (drained && pool_next == pool_end) exhausted = true;
+                }
+                if (sharing && exhausted && nvalid == 0 && nf >= kIkTakeLanes) {
+                    // the targets are all handed out: ranges other waves have cut off (rows N, N+1, ...)
+                    const IkShareCtl shc = share_of(ka);
+                    unsigned got = 0;
+                    int n = 0;
+                    if (lane == 0) n = ik_take_dyn(shc, nf, got);
+                    n = __shfl(n, 0);
+                    got = __shfl(got, 0);
+                    base = (unsigned long long)p.N + got;
+                    nvalid = n;
+                    if (n > 0 && am_idle) { if (lane == 0) ik_aadd(shc.idle, (unsigned)-1); am_idle = false; }
                 }
                 if ((freeslots >> lane) & 1ull) sh.list[ik_rank(freeslots, lane)] = lane;
                 __syncthreads();
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                 if (mine) ik_start_spec<NJ>(st, sh, lane, p, qlim, slot, s, Tep, q0);
                 __syncthreads();
             }
-            if (sharing && busy) {                                                      // phase D3: give work to idle waves
+            if (sharing && exhausted && busy) {                                         // phase D3: give work to idle waves
                 const IkShareCtl shc = share_of(ka);
                 unsigned waiting = 0;
                 if (lane == 0) waiting = ik_aload(shc.idle);
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                 }
             }
         }
-        if (busy == 0 && (exhausted || sharing)) {
+        if (busy == 0 && exhausted) {
             if (!sharing) break;
             // sharing: out of work -- say so, then wait for a donated range or for everybody to be done
             const IkShareCtl shc = share_of(ka);
@@ -215,8 +216,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                 // memory starve the atomics of the waves that still work (first GPU run: 350 ms instead of 1.5)
                 int nap = 1;
                 for (int spin = 0; spin < (1 << 15) && verdict == 0; ++spin) {
-                    const unsigned long long total = (unsigned long long)p.N + ik_aload(shc.dyn_count);
-                    if (ik_aload(shc.counter) < total) verdict = 1;
+                    if (ik_dyn_waiting(shc)) verdict = 1;
                     else if ((spin & 3) == 3 && ik_aload(shc.idle) >= shc.waves) verdict = 2;
                     else {
                         for (int k = 0; k < nap; ++k) __builtin_amdgcn_s_sleep(127);
@@ -480,7 +480,7 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
         }
         if (rc == RTBHIP_OK) {
             IkShareCtl sc;
-            sc.counter = ctl; sc.dyn_count = (unsigned *)(ctl + 1); sc.idle = (unsigned *)(ctl + 1) + 1;
+            sc.dyn_taken = (unsigned *)ctl; sc.dyn_count = (unsigned *)ctl + 1; sc.idle = (unsigned *)ctl + 2;
             sc.wdyn = wdyn; sc.link = link; sc.cap = (uint32_t)M; sc.waves = 0;
             rc = run(p, N, nullptr, nullptr, vq, vok, vit, vse, vE, sc);
         }

@@ -401,20 +401,15 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
                     }
                     idle = ballot(w, [&](int l) { return w.st[l].status == kIkIdle; });
                 }
-                if (!w.exhausted && idle) {
+                if ((!w.exhausted || share) && idle) {
                     const unsigned long long freeslots = ~w.busy;
                     int nf = __builtin_popcountll(idle);
                     nf = nf > p.fresh_cap ? p.fresh_cap : nf;
                     { static const int mb = getenv("EMU_IK_MAX_BUSY") ? atoi(getenv("EMU_IK_MAX_BUSY")) : 64;
                       const int room = mb - __builtin_popcountll(w.busy); nf = nf > room ? (room > 0 ? room : 0) : nf; }
-                    unsigned long long base;
-                    long long nvalid;
-                    if (share) {
-                        unsigned long long got = 0;
-                        const int n = ik_take(*share, p.N, nf, got);
-                        base = got; nvalid = n;
-                        if (n > 0 && w.am_idle) { *share->idle -= 1; w.am_idle = false; }
-                    } else {
+                    unsigned long long base = 0;
+                    long long nvalid = 0;
+                    if (!w.exhausted) {
                     if (w.pool_next == w.pool_end) {
                         const unsigned long long chunk = p.pool_chunk > 0 ? (unsigned long long)p.pool_chunk : (unsigned long long)nf;
                         const unsigned long long got = counter;
@@ -429,6 +424,12 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
                     nvalid = nvalid > nf ? nf : nvalid;
                     w.pool_next += (unsigned long long)nvalid;
                     if (w.drained && w.pool_next == w.pool_end) w.exhausted = true;
+                    }
+                    if (share && w.exhausted && nvalid == 0 && nf >= 16) {
+                        unsigned got = 0;
+                        const int n = ik_take_dyn(*share, nf, got);
+                        base = (unsigned long long)p.N + got; nvalid = n;
+                        if (n > 0 && w.am_idle) { *share->idle -= 1; w.am_idle = false; }
                     }
                     for (int l = 0; l < kWave; ++l) if ((freeslots >> l) & 1ull) w.sh.list[ik_rank(freeslots, l)] = l;
                     for (int l = 0; l < kWave; ++l) {
@@ -454,17 +455,16 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
                         mine[l] = ((idle >> l) & 1ull) && ik_pick(w.sh, ik_rank(idle, l), nb, __builtin_popcountll(idle), p.spec_policy, ik_s_first(p), slot[l], ss[l]);
                     for (int l = 0; l < kWave; ++l) if (mine[l]) ik_start_spec<NJ>(w.st[l], w.sh, l, p, qlim, slot[l], ss[l], Tep, q0);
                 }
-                if (share && w.busy && *share->idle > 0) {                       // phase D3: give work to idle waves
+                if (share && w.exhausted && w.busy && *share->idle > 0) {        // phase D3: give work to idle waves
                     unsigned given = 0;
                     const unsigned waiting = *share->idle;
                     for (int i = 0; i < kWave && given < waiting; ++i)
                         if (((w.busy >> i) & 1ull) && *share->dyn_count + share->waves < share->cap && ik_donate(*share, p.N, w.sh, i)) ++given;
                 }
             }
-            if (share && w.busy == 0) {
+            if (share && w.busy == 0 && w.exhausted) {
                 if (!w.am_idle) { *share->idle += 1; w.am_idle = true; }
-                const unsigned long long total = (unsigned long long)p.N + *share->dyn_count;
-                if (*share->counter < total) { w.first = true; continue; }     // work has appeared: a pass at the next turn takes it
+                if (ik_dyn_waiting(*share)) { w.first = true; continue; }      // work has appeared: a pass at the next turn takes it
                 if (*share->idle >= share->waves) { w.done = true; --live; }
                 continue;                                                      // keep waiting
             }
@@ -552,14 +552,13 @@ static int emu_ik_shared_run(const Chain *c, const IkDev &p, int waves, const do
     std::vector<unsigned long long> wdyn(M, kIkNoItem);
     std::vector<int32_t> link(rows, -1), vok(rows, 0), vit(rows, 0), vse(rows, 0);
     std::vector<double> vq(rows * n, 0.0), vE(rows, 0.0);
-    unsigned long long counter = 0;
-    unsigned dyn_count = 0, idle = 0;
+    unsigned dyn_taken = 0, dyn_count = 0, idle = 0;
     IkShareCtl sc;
-    sc.counter = &counter; sc.dyn_count = &dyn_count; sc.idle = &idle; sc.wdyn = wdyn.data(); sc.link = link.data();
+    sc.dyn_taken = &dyn_taken; sc.dyn_count = &dyn_count; sc.idle = &idle; sc.wdyn = wdyn.data(); sc.link = link.data();
     sc.cap = (uint32_t)M; sc.waves = (uint32_t)waves;
     const int rc = emu_ik_wave_run<NJ>(c, p, waves, Tep, q0, vq.data(), vok.data(), vit.data(), vse.data(), vE.data(), stats, nullptr, &sc);
     if (rc) return rc;
-    if (counter != (unsigned long long)p.N + dyn_count) return -5;                // every item must have been taken
+    if (dyn_taken != dyn_count) return -5;                                        // every appended item must have been taken
     for (int64_t t = 0; t < p.N; ++t)
         ik_merge_chain(n, t, link.data(), vq.data(), vok.data(), vit.data(), vse.data(), vE.data(), q_out, success, iters, searches, residual);
     if (getenv("EMU_IK_DEBUG")) fprintf(stderr, "sharing: %u ranges donated\n", dyn_count);
