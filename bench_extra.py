@@ -30,9 +30,15 @@ def ev_time(fn, steps, warmup):
         fn()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    import gc
+    gc.collect()                      # no collector pause (40-60 ms here) between a launch and its closing event
+    was = gc.isenabled()
+    gc.disable()
     for a, b in ev:
         a.record(); fn(); b.record()
     torch.cuda.synchronize()
+    if was:
+        gc.enable()
     ms = sorted(a.elapsed_time(b) for a, b in ev)
     return sum(ms) / len(ms), ms[0]
 
@@ -343,6 +349,36 @@ def main():
                                         "sample": "first %d configurations of each of the 16 arms; ETS_fkine + per-row ETS_jacob0" % n,
                                         "max_abs_err_gpu_vs_cpu": err}
         print(json.dumps(line), flush=True)
+        # The 14-DOF entry of BASELINE config 5: YuMi is ONE robot with two 7-joint arms (+ finger joints).  The reference
+        # evaluates a branch on the robot-wide q (Robot.jacob0(q, end=...), robot/Robot.py:1974-1981), so both arms read the
+        # SAME (N, 18) array here: 17 chains of 16 robots in one launch, T + J0 for each hand.
+        yumi = robots[-1]
+        ends = [nm for nm in ("gripper_r_finger_r", "gripper_l_finger_l") if nm in yumi.linkdict]
+        if len(ends) == 2:
+            arms = [yumi.ets(end=e, compact=False) for e in ends]
+            lo, hi = np.full(yumi.n, -1.0), np.full(yumi.n, 1.0)
+            for a in arms:
+                ql = np.clip(a.qlim, -2 * np.pi, 2 * np.pi)
+                lo[a.jindices], hi[a.jindices] = ql[0], ql[1]
+            qy = torch.from_numpy(np.random.default_rng(99).uniform(lo, hi, (N, yumi.n))).cuda()
+            chs17, qs17 = chs[:-1] + arms, qs[:-1] + [qy, qy]
+            def fleet17():
+                hold["out17"] = rtbhip.fleet_fkine_jacob(chs17, qs17)
+            avg17, best17 = ev_time(fleet17, max(3, args.steps // 2), 2)
+            byts17 = sum(N * (8 * c.n + 128 + 48 * c.n) for c in chs[:-1]) + N * (8 * yumi.n + 2 * (128 + 48 * 8))
+            T17, J17 = hold["out17"]
+            chk = [yumi.ets(end=e) for e in ends]                   # the same branches with path-local joint numbers
+            err17 = 0.0
+            for a, c, Tg, Jg in zip(arms, chk, T17[-2:], J17[-2:]):
+                Tc, Jc = c.fkine_jacob0(qy[:4096][:, torch.from_numpy(a.jindices).cuda()].contiguous())
+                err17 = max(err17, float((Tg[:4096] - Tc).abs().max()), float((Jg[:4096] - Jc).abs().max()))
+            print(json.dumps({"metric": "configurations/sec (mixed fleet, YuMi as the 14-DOF dual-arm robot: both hands from its %d-column q; "
+                                        "17 chains of 16 robots x %d, one launch)" % (yumi.n, N),
+                              "value": N * 17 / (avg17 * 1e-3), "unit": "chain evaluations/s", "robots_per_s": N * 16 / (avg17 * 1e-3), "n_gpus": 1,
+                              "kernel_avg_ms": avg17, "kernel_min_ms": best17, "yumi_q_columns": int(yumi.n), "yumi_arm_joints": [int(a.n) for a in arms],
+                              "wide_q_vs_path_q_max_abs_diff": err17,
+                              "roofline": {"bound": "hbm", "achieved": byts17 / (avg17 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": byts17 / (avg17 * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": byts17}}), flush=True)
     rk.finish()
 
 

@@ -82,6 +82,11 @@ void rtbhip_shutdown(void);
 int rtbhip_chain_create(const rtbhip_et *ets, int32_t m, const double *qlim, rtbhip_chain_t *chain);
 int rtbhip_chain_destroy(rtbhip_chain_t chain);
 int rtbhip_chain_info(rtbhip_chain_t chain, int32_t *n, int32_t *m, int32_t *q_width);
+/* Row pitch of q (columns per configuration).  A chain created from a branch of a tree robot keeps the robot-wide joint numbers
+ * (Robot.ets(start, end), robot/Robot.py:1974-1981: jacob0 / jacobe / fkine of a branch are evaluated on the ROBOT's q); by
+ * default the pitch is max(jindex)+1, which is short of robot.n when the branch does not hold the robot's last joint.  Setting it
+ * (max(jindex)+1 <= q_width <= 256) lets every branch of one robot read the same (N, robot.n) array. */
+int rtbhip_chain_set_q_width(rtbhip_chain_t chain, int32_t q_width);
 
 /* ETS_fkine (fknm.cpp:923-1064 -> _ETS_fkine methods.cpp:318-352): T[i] = base * chain(q[i]) * tool.
  * base16/tool16 may be NULL (identity). */

@@ -392,6 +392,21 @@ int rtbhip_chain_info(rtbhip_chain_t chain, int32_t *n, int32_t *m, int32_t *q_w
     return RTBHIP_OK;
 }
 
+int rtbhip_chain_set_q_width(rtbhip_chain_t chain, int32_t q_width)
+{
+    const std::shared_ptr<Chain> c_owner = chain_from_handle(chain);
+    Chain *c = c_owner.get();
+    if (!c) { set_error("chain_set_q_width: unknown handle"); return RTBHIP_EINVAL; }
+    int need = 0;
+    for (int32_t jm : c->jmeta) need = std::max(need, jm_jq(jm) + 1);
+    if (q_width < need || q_width > 256) {
+        set_error("chain_set_q_width: width " + std::to_string(q_width) + " outside [" + std::to_string(need) + ", 256] for this chain");
+        return RTBHIP_EINVAL;
+    }
+    c->q_width = q_width;     // the kernels take the row pitch of q from here; the chain tables do not depend on it
+    return RTBHIP_OK;
+}
+
 int rtbhip_fkine(rtbhip_chain_t chain, const double *q, int64_t N, const double *base16,
                  const double *tool16, double *T, int32_t mem, void *stream)
 {

@@ -655,31 +655,41 @@ RTB_HD void ik_start_spec(IkLane<NJ> &st, SH &sh, int lane, const PD &p, QL qlim
 // drew; the ~1 % that exhaust all `slimit` searches cost 40x the mean, so the waves that drew two or three of them run twice as
 // long as the average one and the kernel waits for them (CPU replay of config 3: longest wave 177-217 iterations, mean 104).
 // A search is a pure function of (target, search index), so the UNSTARTED part of a slot's search range can be cut off
-// and handed to another wave as a new work item: the donor appends it to a device-wide list (row N + k of the item table), a
-// wave that has run out of work picks it up like a fresh target, and a target's rows are chained in search order (`link`) for a
-// final merge (iterations add up along the chain; the first success, or the chain's last row, supplies the answer) -- exactly
-// the sequential loops' result, whoever ran what.  All control traffic is a handful of agent-scope atomics per scheduling pass.
+// and handed to another wave as a new work item, and a target's rows are chained in search order (`link`) for a final merge
+// (iterations add up along the chain; the first success, or the chain's last row, supplies the answer) -- exactly the
+// sequential loops' result, whoever ran what.
+//
+// Hand-over protocol.  (The first design -- one shared list every idle wave polled and raced for with compare-and-swap -- was
+// correct but 150x SLOWER on the MI355X: each appended item woke ~1500 waiting waves into a retry storm on one address.  The
+// second -- tickets, below, but on ONE control word -- worked at last, yet gained nothing: same-address read-modify-writes
+// cross the fabric one at a time, ~0.2 us each, and the ~5600 of a config-3 launch (a ticket per wave, two per hand-over)
+// add up to more than the kernel's own 1.4 ms.  Hence kIkQueues independent queues, each control word in its own 256-byte line.)
+//   * queue g has one 64-bit word  tickets << 32 | appended.  A wave that has run out of work takes a TICKET t in its queue
+//     (wave number mod kIkQueues; one fetch-add of 1 << 32) and then polls only ITS OWN word of the item table; a donor
+//     reserves indices k .. k+g-1 in a queue with one fetch-add of g and stores the items there: item k goes to the holder of
+//     ticket k, nobody races for it, no two waves poll the same address.
+//   * tickets - appended of a queue = its waves waiting right now (an exact snapshot: both halves come from one atomic).
+//     A donor looks at all queue words with ONE vector load per scheduling pass (lane g reads word g), and only while it holds
+//     a range worth cutting; it serves the first queue with waiters, starting from a rotating offset.
+//   * termination: after taking its ticket a wave reads all queue words twice.  If the sum of tickets - appended equals the
+//     grid size and nothing moved between the two reads, every wave of the grid holds an unserved ticket, nothing can be
+//     appended any more, and this wave stores the EXIT mark into every outstanding ticket's word.  (While any wave is busy it
+//     holds no ticket, so the sum is short; the wave that takes the LAST ticket reads a quiescent state and sees it.  A queue
+//     never fills up: donors stop at `qlimit`, the table has room for one more item per concurrent donor beyond it.)
+constexpr int kIkQueues = 16;
+constexpr int kIkQueueStride = 32;      // 64-bit words between two queues' control words: one 256-byte line each
 struct IkShareCtl {
-    unsigned *dyn_taken;           // appended items handed out so far (the targets themselves, items 0 .. N-1, are handed out by the
-                                   // ordinary fetch-add counter: a compare-and-swap there had 2048 waves retrying against each other)
-    unsigned *dyn_count;           // items appended so far
-    unsigned *idle;                // waves that have run out of work
-    unsigned long long *wdyn;      // appended items, packed IkWork; ~0 = reserved but not written yet
+    unsigned long long *tc;        // word g * kIkQueueStride: tickets handed to waiting waves (high half) | items appended (low half) of queue g
+    unsigned long long *wdyn;      // word g * qcap + k: item k of queue g, packed IkWork; ~0 = not written yet
     int32_t *link;                 // row -> next row of the same target, -1 at the end of a chain
-    uint32_t cap, waves;           // capacity of wdyn; grid size
+    uint32_t qlimit, qcap, waves;  // items a queue may take; words per queue (qlimit + a ticket / a racing donor per wave); grid size
+    uint32_t after;                // a slot's range is cut only once this many of the target's searches have FAILED (see ik_donatable)
 };
-constexpr unsigned long long kIkNoItem = ~0ull;
+constexpr unsigned long long kIkNoItem = ~0ull, kIkExitItem = ~0ull - 1ull;
 constexpr int kIkDonateMin = 4;    // a slot gives away its unstarted searches (all but the next one) when at least this many are left
+constexpr int kIkGiveMax = 4;      // ranges a wave hands over per scheduling pass (bounds both the pass and what donors racing past qlimit can add)
 
 RTB_HD unsigned long long ik_aload(const unsigned long long *p)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    return *p;
-#endif
-}
-RTB_HD unsigned ik_aload(const unsigned *p)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -703,68 +713,64 @@ RTB_HD void ik_astore(int32_t *p, int32_t v)
     *p = v;
 #endif
 }
-RTB_HD unsigned ik_aadd(unsigned *p, unsigned v)
+RTB_HD void ik_astore(unsigned long long *p, unsigned long long v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    *p = v;
+#endif
+}
+RTB_HD unsigned long long ik_aadd(unsigned long long *p, unsigned long long v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
-    const unsigned o = *p; *p = o + v; return o;
+    const unsigned long long o = *p; *p = o + v; return o;
 #endif
 }
-// Take up to `want` APPENDED items [got, got + n) -- never beyond what exists now (a fetch-add past the end would swallow the
-// indices of items appended later).  One lane calls this; only waves that have run out of targets do.
-RTB_HD int ik_take_dyn(const IkShareCtl &c, int want, unsigned &got)
+RTB_HD unsigned long long *ik_queue_word(const IkShareCtl &c, int g) { return c.tc + (size_t)g * kIkQueueStride; }
+RTB_HD unsigned ik_word_tickets(unsigned long long x) { return (unsigned)(x >> 32); }
+RTB_HD unsigned ik_word_count(unsigned long long x) { return (unsigned)(x & 0xffffffffull); }
+// waves of a queue waiting for an item (tickets beyond the appended items)
+RTB_HD unsigned ik_word_waiting(unsigned long long x) { return ik_word_tickets(x) > ik_word_count(x) ? ik_word_tickets(x) - ik_word_count(x) : 0u; }
+// row of item k of queue g in the result temporaries / the link table
+RTB_HD int64_t ik_item_row(const IkShareCtl &c, int64_t N, int g, unsigned k) { return N + (int64_t)g * c.qcap + k; }
+// A wave that has run dry takes a ticket in queue g (one lane calls this).
+RTB_HD unsigned ik_ticket(const IkShareCtl &c, int g) { return ik_word_tickets(ik_aadd(ik_queue_word(c, g), 1ull << 32)); }
+// EXIT into the words of the outstanding tickets of queue g, whose control word read x (lane-strided)
+RTB_HD void ik_release_queue(const IkShareCtl &c, int g, unsigned long long x, int lane)
 {
-    unsigned old = ik_aload(c.dyn_taken);
-    for (;;) {
-        const unsigned total = ik_aload(c.dyn_count);
-        if (old >= total || want <= 0) { got = old; return 0; }
-        const unsigned n = total - old < (unsigned)want ? total - old : (unsigned)want;
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (__hip_atomic_compare_exchange_strong(c.dyn_taken, &old, old + n, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { got = old; return (int)n; }
-#else
-        *c.dyn_taken = old + n; got = old; return (int)n;
-#endif
-    }
+    for (unsigned k = ik_word_count(x) + (unsigned)lane; k < ik_word_tickets(x); k += (unsigned)kWave)
+        ik_astore(c.wdyn + (size_t)g * c.qcap + k, kIkExitItem);
 }
-RTB_HD bool ik_dyn_waiting(const IkShareCtl &c) { return ik_aload(c.dyn_taken) < ik_aload(c.dyn_count); }
-// The item of row v (v >= N: an appended one; its writer may not have stored it yet)
-template <class PD>
-RTB_HD IkWork ik_row_item(const IkShareCtl &c, const PD &p, int64_t N, int64_t v)
-{
-    if (v < N) { IkWork w; w.tgt = (int32_t)v; w.s0 = (int16_t)ik_s_first(p); w.s1 = (int16_t)ik_s_last(p); return w; }
-    unsigned long long x = ik_aload(c.wdyn + (v - N));
-    for (int spin = 0; x == kIkNoItem && spin < (1 << 20); ++spin) x = ik_aload(c.wdyn + (v - N));
-    return ik_unpack(x);
-}
-// Cut the unstarted searches of slot `slot` (but one) off into a new item.  One lane calls this; the slot's tables are this
-// wave's own.  Returns whether an item was appended.
+// Cut the unstarted searches of slot `slot` (but one) off into item k of queue g (indices reserved by the caller).  One lane
+// calls this; the slot's tables are this wave's own.
 template <class SH>
-RTB_HD bool ik_donate(const IkShareCtl &c, int64_t N, SH &sh, int slot)
+RTB_HD void ik_donate(const IkShareCtl &c, int64_t N, SH &sh, int slot, int g, unsigned k)
 {
-    const int next = sh.next[slot], last = sh.slast[slot];
-    const int room = last - next + 1;
-    if (sh.res[slot] != 0 || room < kIkDonateMin) return false;
-    const unsigned k = ik_aadd(c.dyn_count, 1u);
-    if (k >= c.cap) { ik_aadd(c.dyn_count, (unsigned)-1); return false; }     // table full: undo (the slot stays whole)
     // everything but the next search: the owner's lanes are all busy at this moment (that is why the searches are unstarted),
     // an idle wave can start them at once.  The slot keeps one unstarted search so that its (new) last search is still ahead --
     // the lane that will run it reports it as the range's last one.
-    const int mid = next + 1;
+    const int mid = sh.next[slot] + 1, last = sh.slast[slot];
     IkWork w; w.tgt = (int32_t)sh.tgt[slot]; w.s0 = (int16_t)mid; w.s1 = (int16_t)last;
-    const int64_t row = N + k, mine = sh.vix[slot];
+    const int64_t row = ik_item_row(c, N, g, k), mine = sh.vix[slot];
     // the new item continues this slot's range: insert it right after the slot's row.  link[mine] may have been written by the
     // wave (possibly on another XCD, whose L2 this one does not snoop) that donated `mine` itself: agent-scope accesses, not
     // plain ones that could be served from a stale line
     ik_astore(c.link + row, ik_aload(c.link + mine));
     ik_astore(c.link + mine, (int32_t)row);
     sh.slast[slot] = (int16_t)(mid - 1);
-#if defined(__HIP_DEVICE_COMPILE__)
-    __hip_atomic_store(c.wdyn + k, ik_pack(w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    c.wdyn[k] = ik_pack(w);
-#endif
-    return true;
+    ik_astore(c.wdyn + (size_t)g * c.qcap + k, ik_pack(w));      // hands the item to the holder of ticket k (now or later)
+}
+// A slot whose range is worth cutting: enough unstarted searches, and a target that has already failed `after` searches (all
+// searches below the ring base b have been accounted as failures).  Without the second condition a donor hands out pure
+// speculation -- in the ik_benchmark-notebook setting, where nearly every first search succeeds, every range given away at the
+// end of the kernel cost its receiver a whole search for nothing (measured: 0.49 -> 0.74 ms per 1e5 targets).
+template <class SH>
+RTB_HD bool ik_donatable(const SH &sh, int slot, int s_first, int after)
+{
+    return sh.res[slot] == 0 && (int)sh.slast[slot] - (int)sh.next[slot] + 1 >= kIkDonateMin && (int)sh.b[slot] - s_first >= after;
 }
 // Final merge of one target's chain of rows (in search order) into the caller's arrays.
 RTB_HD void ik_merge_chain(int n, int64_t tgt, const int32_t *link, const double *vq, const int32_t *vok, const int32_t *vit, const int32_t *vse,

@@ -42,13 +42,12 @@ struct IkKernArgs {
 __device__ __forceinline__ IkShareCtl share_of(const RTB_CONST IkKernArgs *ka)
 {
     IkShareCtl c;
-    c.dyn_taken = ka->share.dyn_taken; c.dyn_count = ka->share.dyn_count; c.idle = ka->share.idle; c.wdyn = ka->share.wdyn;
-    c.link = ka->share.link; c.cap = ka->share.cap; c.waves = ka->share.waves;
+    c.tc = ka->share.tc; c.wdyn = ka->share.wdyn; c.qlimit = ka->share.qlimit; c.qcap = ka->share.qcap;
+    c.link = ka->share.link; c.waves = ka->share.waves; c.after = ka->share.after;
     return c;
 }
 
 // Wave-level driver of the scheduler phases of ik_device.h (the same sequence tests/emu replays on the CPU).
-constexpr int kIkTakeLanes = 16;   // sharing: a wave looks for donated ranges when at least this many of its lanes are free
 constexpr int kIkNullMax = 12;   // null-space step variants: 6..8 joints in registers, 9..12 with scratch
 #ifndef RTB_IK_WAVES
 #define RTB_IK_WAVES 2
@@ -79,8 +78,9 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
     const long long patience = ik_patience(p, s_last);    // watchdog budget (ik_device.h), the pass latency included
     long long quiet = 0;
     const unsigned long long NN = count_g ? (unsigned long long)*count_g : (unsigned long long)p.N;   // wave-uniform
-    const bool sharing = share_g.dyn_count != nullptr;   // wave-uniform
-    bool am_idle = false;            // sharing: this wave is counted in share.idle
+    const bool sharing = share_g.tc != nullptr;   // wave-uniform
+    unsigned long long pend_item = kIkNoItem;   // sharing, wave-uniform: a range handed to this wave (ticket pend_tick of its queue), started at the next pass
+    unsigned pend_tick = 0;
     for (;;) {
         asm volatile("" : "+s"(ka));
         // the scheduling pass runs when some search has ended -- at most every (pass_mask + 1)-th iteration: a
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                 __syncthreads();
                 idle = __ballot(st.status == kIkIdle);
             }
-            if ((!exhausted || sharing) && idle) {                                      // phase D1: fresh targets
+            if ((!exhausted || pend_item != kIkNoItem) && idle) {                       // phase D1: fresh targets
                 const unsigned long long freeslots = ~busy;
                 // free slots >= idle lanes (every busy slot keeps a lane); the per-pass cap spreads a batch
                 // smaller than the grid's lane count evenly over the waves
@@ -150,17 +150,12 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                 pool_next += (unsigned long long)nvalid;
                 if (drained && pool_next == pool_end) exhausted = true;
                 }
-                if (sharing && exhausted && nvalid == 0 && nf >= kIkTakeLanes) {
-                    // the targets are all handed out: ranges other waves have cut off (rows N, N+1, ...)
-                    const IkShareCtl shc = share_of(ka);
-                    unsigned got = 0;
-                    int n = 0;
-                    if (lane == 0) n = ik_take_dyn(shc, nf, got);
-                    n = __shfl(n, 0);
-                    got = __shfl(got, 0);
-                    base = (unsigned long long)p.N + got;
-                    nvalid = n;
-                    if (n > 0 && am_idle) { if (lane == 0) ik_aadd(shc.idle, (unsigned)-1); am_idle = false; }
+                IkWork pend = ik_unpack(pend_item);
+                if (exhausted && pend_item != kIkNoItem) {
+                    // the range another wave cut off for this one (the row of its ticket): started like a fresh target
+                    base = (unsigned long long)ik_item_row(share_of(ka), p.N, (int)(blockIdx.x % kIkQueues), pend_tick);
+                    nvalid = 1;
+                    pend_item = kIkNoItem;
                 }
                 if ((freeslots >> lane) & 1ull) sh.list[ik_rank(freeslots, lane)] = lane;
                 __syncthreads();
@@ -170,7 +165,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                     myslot = sh.list[r];
                     const int64_t v = (int64_t)base + r;
                     IkWork w;
-                    if (sharing) w = ik_row_item(share_of(ka), p, p.N, v);
+                    if (sharing && v >= p.N) w = pend;
                     else if (work) w = work[v];
                     else { w.tgt = (int32_t)v; w.s0 = (int16_t)ik_s_first(p); w.s1 = (int16_t)ik_s_last(p); }
                     ik_start_target<NJ>(st, sh, lane, p, qlim, myslot, v, w, Tep, q0);
@@ -189,46 +184,78 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                 if (mine) ik_start_spec<NJ>(st, sh, lane, p, qlim, slot, s, Tep, q0);
                 __syncthreads();
             }
-            if (sharing && exhausted && busy) {                                         // phase D3: give work to idle waves
-                const IkShareCtl shc = share_of(ka);
-                unsigned waiting = 0;
-                if (lane == 0) waiting = ik_aload(shc.idle);
-                waiting = __shfl(waiting, 0);
-                if (waiting > 0) {
-                    // up to one range per waiting wave, the slots in order (the pass is wave-uniform here: lane 0 does the bookkeeping)
-                    if (lane == 0) {
-                        unsigned given = 0;
-                        for (int i = 0; i < kWave && given < waiting; ++i)
-                            if (((busy >> i) & 1ull) && ik_aload(shc.dyn_count) + shc.waves < shc.cap && ik_donate(shc, p.N, sh, i)) ++given;
+            if (sharing && exhausted && busy) {                                         // phase D3: give work to waiting waves
+                // only a wave that holds a range worth cutting looks at the control words at all
+                const unsigned long long cand = __ballot(((busy >> lane) & 1ull) && ik_donatable(sh, lane, ik_s_first(p), (int)ka->share.after));
+                if (cand) {
+                    const IkShareCtl shc = share_of(ka);
+                    unsigned long long x = 0;         // one vector load: lane g reads queue g's word
+                    if (lane < kIkQueues) x = ik_aload(ik_queue_word(shc, lane));
+                    const unsigned long long open = __ballot(lane < kIkQueues && ik_word_waiting(x) > 0 && ik_word_count(x) < shc.qlimit);
+                    if (open) {
+                        // the first queue with waiters at or after a start that differs from wave to wave and from pass to pass
+                        const int start = (int)((blockIdx.x + tick) % kIkQueues);
+                        const unsigned long long rot = ((open >> start) | (open << (kIkQueues - start))) & ((1ull << kIkQueues) - 1ull);
+                        const int g = (start + __builtin_ctzll(rot)) % kIkQueues;
+                        const unsigned long long xg = ((unsigned long long)__shfl((unsigned)(x >> 32), g) << 32) | __shfl((unsigned)(x & 0xffffffffull), g);
+                        unsigned give = ik_word_waiting(xg);
+                        const unsigned nc = (unsigned)__popcll(cand);
+                        give = give > nc ? nc : give;
+                        give = give > (unsigned)kIkGiveMax ? (unsigned)kIkGiveMax : give;
+                        if (lane == 0) {              // the pass is wave-uniform here: lane 0 does the bookkeeping
+                            const unsigned k0 = ik_word_count(ik_aadd(ik_queue_word(shc, g), (unsigned long long)give));
+                            unsigned i = 0;
+                            for (unsigned long long m = cand; m && i < give; m &= m - 1ull, ++i) ik_donate(shc, p.N, sh, __builtin_ctzll(m), g, k0 + i);
+                        }
+                        __syncthreads();
                     }
-                    __syncthreads();
                 }
             }
         }
-        if (busy == 0 && exhausted) {
+        if (busy == 0 && exhausted && pend_item == kIkNoItem) {
             if (!sharing) break;
-            // sharing: out of work -- say so, then wait for a donated range or for everybody to be done
+            // sharing: out of work -- take a ticket, then wait on this ticket's own word for a range or for the EXIT mark
             const IkShareCtl shc = share_of(ka);
-            int verdict = 0;                          // 0 keep waiting, 1 work has appeared, 2 all waves idle: done
-            if (lane == 0) {
-                if (!am_idle) ik_aadd(shc.idle, 1u);
-                // poll with exponential back-off (up to ~27 us between looks): two thousand waves hammering three words of
-                // memory starve the atomics of the waves that still work (first GPU run: 350 ms instead of 1.5)
-                int nap = 1;
-                for (int spin = 0; spin < (1 << 15) && verdict == 0; ++spin) {
-                    if (ik_dyn_waiting(shc)) verdict = 1;
-                    else if ((spin & 3) == 3 && ik_aload(shc.idle) >= shc.waves) verdict = 2;
-                    else {
-                        for (int k = 0; k < nap; ++k) __builtin_amdgcn_s_sleep(127);
-                        nap = nap < 8 ? nap * 2 : 8;
-                    }
-                }
-                if (verdict == 0) verdict = 2;        // bound reached: leave (the donor of any late item picks it up itself)
+            const int g = (int)(blockIdx.x % kIkQueues);
+            unsigned t = 0, lo = 0, hi = 0;
+            if (lane == 0) t = ik_ticket(shc, g);
+            t = __shfl(t, 0);
+            // the last ticket of the grid?  all queue words, twice (ik_device.h)
+            unsigned long long x1 = 0, x2 = 0;
+            if (lane < kIkQueues) x1 = ik_aload(ik_queue_word(shc, lane));
+            unsigned w = lane < kIkQueues ? ik_word_waiting(x1) : 0u;
+            for (int o = 32; o; o >>= 1) w += __shfl_xor(w, o);
+            bool fin = false;
+            if (w == shc.waves) {
+                if (lane < kIkQueues) x2 = ik_aload(ik_queue_word(shc, lane));
+                fin = !__any(x1 != x2);
             }
-            am_idle = true;
-            verdict = __shfl(verdict, 0);
-            if (verdict == 2) break;
-            first = true;                             // run a scheduling pass now: it tries to take the new item
+            if (fin) {                                // every wave is dry: let the others go
+                for (int q = 0; q < kIkQueues; ++q) {
+                    const unsigned long long xq = ((unsigned long long)__shfl((unsigned)(x1 >> 32), q) << 32) | __shfl((unsigned)(x1 & 0xffffffffull), q);
+                    ik_release_queue(shc, q, xq, lane);
+                }
+                break;
+            }
+            if (lane == 0) {
+                // ~1 us between looks at first, ~8 us later; bounded (about a second) so that a protocol error ends as missing
+                // results, which the merge reports, and not as a hung GPU
+                const unsigned long long *word = shc.wdyn + (size_t)g * shc.qcap + t;
+                unsigned long long x = kIkNoItem;
+                int nap = 1;
+                for (int spin = 0; spin < (1 << 17); ++spin) {
+                    x = ik_aload(word);
+                    if (x != kIkNoItem) break;
+                    for (int k = 0; k < nap; ++k) __builtin_amdgcn_s_sleep(32);
+                    nap = nap < 8 ? nap + 1 : 8;
+                }
+                lo = (unsigned)(x & 0xffffffffull); hi = (unsigned)(x >> 32);
+            }
+            lo = __shfl(lo, 0); hi = __shfl(hi, 0);
+            const unsigned long long x = ((unsigned long long)hi << 32) | lo;
+            if (x == kIkNoItem || x == kIkExitItem) break;
+            pend_item = x; pend_tick = t;
+            first = true;                             // run a scheduling pass now: it starts the range
             continue;
         }
         if (++quiet > patience) {
@@ -312,6 +339,7 @@ __global__ __launch_bounds__(256) void k_ik_merge_chain(int64_t N, int n, const 
 }
 
 namespace {
+int g_ik_donate_after = 3;   // sharing: failed searches of a target before its range may be cut (rtbhip_tune "ik_donate_after")
 int g_ik_share = 0;       // cross-wave sharing of search ranges: 0 never, 1 automatic (batch resident at once), 2 always (tests)
 int g_ik_phased = 0;      // 0 never (default: the CPU replay and the GPU both say it loses), 1 automatic, 2 always (tests)
 int g_ik_spec_policy = 0;
@@ -333,6 +361,7 @@ void ik_tune(const char *key, int value)
     if (std::string(key) == "ik_phased") g_ik_phased = value < 0 ? 0 : (value > 2 ? 2 : value);
     if (std::string(key) == "ik_fresh_pct") g_ik_fresh_pct = value < 1 ? 1 : value;
     if (std::string(key) == "ik_spec_policy") g_ik_spec_policy = value != 0;
+    if (std::string(key) == "ik_donate_after") g_ik_donate_after = value < 0 ? 0 : value;
 }
 
 void ik_release_device_state()
@@ -454,34 +483,39 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
 
     // Cross-wave sharing of search ranges (ik_device.h) when the whole batch is resident at once: rtbhip_tune("ik_share",
     // 0 / 1 / 2) = never / automatic / always (tests).  Rows go to temporaries; a merge kernel walks each target's chain.
-    const bool share_on = g_ik_share == 2 || (g_ik_share == 1 && N <= 4 * gmax * kWave && N <= (1 << 24) && ik_s_last(p) - ik_s_first(p) + 1 >= 2 * kIkDonateMin);
+    // (the protocol's termination needs every wave of the grid resident at once: the grid is at most 8 single-wave workgroups per CU)
+    const bool share_fits = g_ik_waves_per_cu <= 8 && N <= (1 << 24);
+    const bool share_on = share_fits && (g_ik_share == 2 || (g_ik_share == 1 && N <= 4 * gmax * kWave &&
+                                                              ik_s_last(p) - ik_s_first(p) + 1 >= 2 * kIkDonateMin));
     if (share_on) {
         const int64_t g = gmax > N ? N : gmax;
-        const size_t M = (size_t)(N < 65536 ? N : 65536) + (size_t)g + 64, rows = (size_t)N + M;
-        unsigned long long *ctl = nullptr, *wdyn = nullptr; int32_t *link = nullptr;
-        double *vq = nullptr, *vE = nullptr; int32_t *vok = nullptr, *vit = nullptr, *vse = nullptr;
-        auto alloc = [&](void **ptr, size_t bytes) -> int {
-            hipError_t e = hipMallocAsync(ptr, bytes, s);
-            return e == hipSuccess ? RTBHIP_OK : hip_fail(e, "hipMallocAsync (ik sharing)");
-        };
-        int rc = alloc((void **)&ctl, 32);
-        if (rc == RTBHIP_OK) rc = alloc((void **)&wdyn, M * sizeof(unsigned long long));
-        if (rc == RTBHIP_OK) rc = alloc((void **)&link, rows * sizeof(int32_t));
-        if (rc == RTBHIP_OK) rc = alloc((void **)&vq, rows * n * sizeof(double));
-        if (rc == RTBHIP_OK) rc = alloc((void **)&vE, rows * sizeof(double));
-        if (rc == RTBHIP_OK) rc = alloc((void **)&vok, rows * sizeof(int32_t));
-        if (rc == RTBHIP_OK) rc = alloc((void **)&vit, rows * sizeof(int32_t));
-        if (rc == RTBHIP_OK) rc = alloc((void **)&vse, rows * sizeof(int32_t));
-        if (rc == RTBHIP_OK) {
-            hipError_t e = hipMemsetAsync(ctl, 0, 32, s);
-            if (e == hipSuccess) e = hipMemsetAsync(wdyn, 0xFF, M * sizeof(unsigned long long), s);
-            if (e == hipSuccess) e = hipMemsetAsync(link, 0xFF, rows * sizeof(int32_t), s);
+        // every queue takes up to qlimit items; its table also has a word for every ticket beyond them (one per wave of the queue)
+        // and for what donors racing past the limit may add (kIkGiveMax each)
+        const size_t qlimit = (size_t)(N < 65536 ? N : 65536) / 8 + 256, qcap = qlimit + (size_t)(kIkGiveMax + 1) * (size_t)g + 64;
+        const size_t M = (size_t)kIkQueues * qcap, rows = (size_t)N + M, ctl_bytes = (size_t)kIkQueues * kIkQueueStride * sizeof(unsigned long long);
+        // one stream-ordered allocation (the device pool keeps it cached between calls), carved up; two fills: the control words
+        // to zero, item table + links (adjacent) to all-ones (= "no item yet" / "end of chain")
+        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t o_ctl = 0, o_wdyn = o_ctl + up(ctl_bytes), o_link = o_wdyn + M * sizeof(unsigned long long);
+        const size_t o_vq = up(o_link + rows * sizeof(int32_t)), o_vE = o_vq + up(rows * n * sizeof(double)), o_vok = o_vE + up(rows * sizeof(double));
+        const size_t o_vit = o_vok + up(rows * sizeof(int32_t)), o_vse = o_vit + up(rows * sizeof(int32_t)), total = o_vse + up(rows * sizeof(int32_t));
+        char *blk = nullptr;
+        {
+            hipError_t e = hipMallocAsync((void **)&blk, total, s);
+            if (e != hipSuccess) return hip_fail(e, "hipMallocAsync (ik sharing)");
+        }
+        int rc = RTBHIP_OK;
+        {
+            hipError_t e = hipMemsetAsync(blk + o_ctl, 0, ctl_bytes, s);
+            if (e == hipSuccess) e = hipMemsetAsync(blk + o_wdyn, 0xFF, o_link + rows * sizeof(int32_t) - o_wdyn, s);
             if (e != hipSuccess) rc = hip_fail(e, "hipMemsetAsync (ik sharing)");
         }
+        int32_t *link = (int32_t *)(blk + o_link), *vok = (int32_t *)(blk + o_vok), *vit = (int32_t *)(blk + o_vit), *vse = (int32_t *)(blk + o_vse);
+        double *vq = (double *)(blk + o_vq), *vE = (double *)(blk + o_vE);
         if (rc == RTBHIP_OK) {
             IkShareCtl sc;
-            sc.dyn_taken = (unsigned *)ctl; sc.dyn_count = (unsigned *)ctl + 1; sc.idle = (unsigned *)ctl + 2;
-            sc.wdyn = wdyn; sc.link = link; sc.cap = (uint32_t)M; sc.waves = 0;
+            sc.tc = (unsigned long long *)(blk + o_ctl); sc.wdyn = (unsigned long long *)(blk + o_wdyn); sc.link = link;
+            sc.qlimit = (uint32_t)qlimit; sc.qcap = (uint32_t)qcap; sc.after = (uint32_t)g_ik_donate_after; sc.waves = 0;      // waves: set by run()
             rc = run(p, N, nullptr, nullptr, vq, vok, vit, vse, vE, sc);
         }
         if (rc == RTBHIP_OK) {
@@ -490,8 +524,7 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) rc = hip_fail(e, "k_ik_merge_chain launch");
         }
-        for (void *ptr : {(void *)ctl, (void *)wdyn, (void *)link, (void *)vq, (void *)vE, (void *)vok, (void *)vit, (void *)vse})
-            if (ptr) (void)hipFreeAsync(ptr, s);
+        (void)hipFreeAsync(blk, s);
         return rc;
     }
 

@@ -48,6 +48,7 @@ SIGNATURES = {
     "rtbhip_chain_create": (C.c_int, [C.POINTER(rtbhip_et), _i32, _vp, C.POINTER(_u64)]),
     "rtbhip_chain_destroy": (C.c_int, [_u64]),
     "rtbhip_chain_info": (C.c_int, [_u64, _ip, _ip, _ip]),
+    "rtbhip_chain_set_q_width": (C.c_int, [_u64, C.c_int32]),
     "rtbhip_fkine": (C.c_int, [_u64, _vp, _i64, _vp, _vp, _vp, _i32, _vp]),
     "rtbhip_jacob": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _vp, _i32, _vp]),
     "rtbhip_fkine_jacob": (C.c_int, [_u64, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),

@@ -203,6 +203,7 @@ class ETS:
         self._ets = ets
         self._handle_ = None
         self._qlim = None
+        self._q_width = None
 
     # ------------------------------------------------------------ structure
     def __mul__(self, other):
@@ -318,12 +319,26 @@ class ETS:
             h = C.c_uint64(0)
             check(lib().rtbhip_chain_create(arr, len(rows), host_ptr(ql), C.byref(h)))
             self._handle_ = h.value
+            if self._q_width is not None:
+                check(lib().rtbhip_chain_set_q_width(self._handle_, int(self._q_width)))
         return self._handle_
 
     @property
     def q_width(self):
+        """Columns of a q row: max(jindex)+1, or what was assigned -- a branch of a tree robot reads the robot-wide q
+        (reference Robot.jacob0(q, start, end) = self.ets(start, end).jacob0(q) on the ROBOT's q, robot/Robot.py:1974-1981)."""
         j = self._assigned_jindices()
-        return (max(j) + 1) if j else 0
+        need = (max(j) + 1) if j else 0
+        return need if self._q_width is None else max(need, self._q_width)
+
+    @q_width.setter
+    def q_width(self, w):
+        j = self._assigned_jindices()
+        need = (max(j) + 1) if j else 0
+        if w is not None and not need <= int(w) <= 256:
+            raise ValueError("q_width must be in [%d, 256] for this chain" % need)
+        self._q_width = None if w is None else int(w)
+        self._drop_handle()
 
     # ------------------------------------------------------------ argument shaping
     def _shape_q(self, q):

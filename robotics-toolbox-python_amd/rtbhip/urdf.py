@@ -216,6 +216,8 @@ class URDFRobot:
                     ets.append(var)
                     k += 1
         e = ETS(ets)
+        if not compact:
+            e.q_width = self.n          # every branch reads the same (N, robot.n) array
         self._cache[key] = e
         return e
 

@@ -335,7 +335,9 @@ struct EmuWave {
     unsigned tick = 0;
     long long passes = 0, iters = 0, lane_iters_useful = 0;
     long long quiet = 0;       // the kernel's watchdog counter, replayed: a false fire fails the run (-4)
-    bool am_idle = false;      // sharing: counted in share.idle
+    unsigned long long pend_item = kIkNoItem;   // sharing: a range handed to this wave (row N + pend_tick), started at its next pass
+    unsigned pend_tick = 0;
+    bool waiting = false;      // sharing: holds ticket pend_tick and polls its word
 };
 
 template <int NJ>
@@ -373,7 +375,8 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
                 }
             return -2;
         }
-        for (auto &w : W) {
+        for (size_t wi = 0; wi < W.size(); ++wi) {
+            auto &w = W[wi];
             if (w.done) continue;
             bool anyfin = false;
             for (int l = 0; l < kWave; ++l) anyfin = anyfin || w.st[l].fin != 0;
@@ -401,7 +404,7 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
                     }
                     idle = ballot(w, [&](int l) { return w.st[l].status == kIkIdle; });
                 }
-                if ((!w.exhausted || share) && idle) {
+                if ((!w.exhausted || w.pend_item != kIkNoItem) && idle) {
                     const unsigned long long freeslots = ~w.busy;
                     int nf = __builtin_popcountll(idle);
                     nf = nf > p.fresh_cap ? p.fresh_cap : nf;
@@ -425,11 +428,10 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
                     w.pool_next += (unsigned long long)nvalid;
                     if (w.drained && w.pool_next == w.pool_end) w.exhausted = true;
                     }
-                    if (share && w.exhausted && nvalid == 0 && nf >= 16) {
-                        unsigned got = 0;
-                        const int n = ik_take_dyn(*share, nf, got);
-                        base = (unsigned long long)p.N + got; nvalid = n;
-                        if (n > 0 && w.am_idle) { *share->idle -= 1; w.am_idle = false; }
+                    const IkWork pend = ik_unpack(w.pend_item);
+                    if (w.exhausted && w.pend_item != kIkNoItem) {
+                        base = (unsigned long long)ik_item_row(*share, p.N, (int)(wi % kIkQueues), w.pend_tick); nvalid = 1;
+                        w.pend_item = kIkNoItem;
                     }
                     for (int l = 0; l < kWave; ++l) if ((freeslots >> l) & 1ull) w.sh.list[ik_rank(freeslots, l)] = l;
                     for (int l = 0; l < kWave; ++l) {
@@ -437,7 +439,7 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
                         if (((idle >> l) & 1ull) && r < nvalid) {
                             const int64_t v = (int64_t)base + r;
                             IkWork it;
-                            if (share) it = ik_row_item(*share, p, p.N, v);
+                            if (share && v >= p.N) it = pend;
                             else if (work) it = work[v];
                             else { it.tgt = (int32_t)v; it.s0 = (int16_t)ik_s_first(p); it.s1 = (int16_t)ik_s_last(p); }
                             ik_start_target<NJ>(w.st[l], w.sh, l, p, qlim, w.sh.list[r], v, it, Tep, q0);
@@ -455,18 +457,50 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
                         mine[l] = ((idle >> l) & 1ull) && ik_pick(w.sh, ik_rank(idle, l), nb, __builtin_popcountll(idle), p.spec_policy, ik_s_first(p), slot[l], ss[l]);
                     for (int l = 0; l < kWave; ++l) if (mine[l]) ik_start_spec<NJ>(w.st[l], w.sh, l, p, qlim, slot[l], ss[l], Tep, q0);
                 }
-                if (share && w.exhausted && w.busy && *share->idle > 0) {        // phase D3: give work to idle waves
-                    unsigned given = 0;
-                    const unsigned waiting = *share->idle;
-                    for (int i = 0; i < kWave && given < waiting; ++i)
-                        if (((w.busy >> i) & 1ull) && *share->dyn_count + share->waves < share->cap && ik_donate(*share, p.N, w.sh, i)) ++given;
+                if (share && w.exhausted && w.busy) {                            // phase D3: give work to waiting waves
+                    const unsigned long long cand = ballot(w, [&](int l) { return ((w.busy >> l) & 1ull) && ik_donatable(w.sh, l, ik_s_first(p), (int)share->after); });
+                    if (cand) {
+                        unsigned long long x[kIkQueues], open = 0;
+                        for (int g = 0; g < kIkQueues; ++g) {
+                            x[g] = ik_aload(ik_queue_word(*share, g));
+                            if (ik_word_waiting(x[g]) > 0 && ik_word_count(x[g]) < share->qlimit) open |= 1ull << g;
+                        }
+                        if (open) {
+                            const int start = (int)((wi + w.tick) % kIkQueues);
+                            const unsigned long long rot = ((open >> start) | (open << (kIkQueues - start))) & ((1ull << kIkQueues) - 1ull);
+                            const int g = (start + __builtin_ctzll(rot)) % kIkQueues;
+                            unsigned give = ik_word_waiting(x[g]);
+                            const unsigned nc = (unsigned)__builtin_popcountll(cand);
+                            give = give > nc ? nc : give;
+                            give = give > (unsigned)kIkGiveMax ? (unsigned)kIkGiveMax : give;
+                            const unsigned k0 = ik_word_count(ik_aadd(ik_queue_word(*share, g), (unsigned long long)give));
+                            unsigned i = 0;
+                            for (unsigned long long m = cand; m && i < give; m &= m - 1ull, ++i) ik_donate(*share, p.N, w.sh, __builtin_ctzll(m), g, k0 + i);
+                        }
+                    }
                 }
             }
-            if (share && w.busy == 0 && w.exhausted) {
-                if (!w.am_idle) { *share->idle += 1; w.am_idle = true; }
-                if (ik_dyn_waiting(*share)) { w.first = true; continue; }      // work has appeared: a pass at the next turn takes it
-                if (*share->idle >= share->waves) { w.done = true; --live; }
-                continue;                                                      // keep waiting
+            if (share && w.busy == 0 && w.exhausted && w.pend_item == kIkNoItem) {
+                // the kernel's wait loop, one look per turn: ticket first, then this ticket's own word
+                const int g = (int)(wi % kIkQueues);
+                if (!w.waiting) {
+                    w.pend_tick = ik_ticket(*share, g);
+                    unsigned long long x1[kIkQueues];
+                    unsigned sum = 0;
+                    for (int q = 0; q < kIkQueues; ++q) { x1[q] = ik_aload(ik_queue_word(*share, q)); sum += ik_word_waiting(x1[q]); }
+                    if (sum == share->waves) {        // (single-threaded replay: the second read cannot differ)
+                        for (int q = 0; q < kIkQueues; ++q)
+                            for (int l = 0; l < kWave; ++l) ik_release_queue(*share, q, x1[q], l);
+                        w.done = true; --live; continue;
+                    }
+                    w.waiting = true;
+                }
+                const unsigned long long x = share->wdyn[(size_t)g * share->qcap + w.pend_tick];
+                if (x == kIkNoItem) continue;                                  // keep waiting
+                w.waiting = false;
+                if (x == kIkExitItem) { w.done = true; --live; continue; }
+                w.pend_item = x; w.first = true;                               // a pass at the next turn starts it
+                continue;
             }
             if (w.busy == 0 && w.exhausted) { w.done = true; --live; continue; }
             if (++w.quiet > ik_patience(p, s_last)) return -4;   // the kernel would overwrite valid results with its NaN markers here
@@ -548,20 +582,28 @@ static int emu_ik_shared_run(const Chain *c, const IkDev &p, int waves, const do
                              int32_t *success, int32_t *iters, int32_t *searches, double *residual, double *stats)
 {
     const int n = NJ;
-    const size_t M = (size_t)std::min<int64_t>(p.N, 65536) + waves + 64, rows = (size_t)p.N + M;
-    std::vector<unsigned long long> wdyn(M, kIkNoItem);
+    const size_t qlimit = (size_t)std::min<int64_t>(p.N, 65536) / 8 + 256, qcap = qlimit + (size_t)(kIkGiveMax + 1) * waves + 64;
+    const size_t M = (size_t)kIkQueues * qcap, rows = (size_t)p.N + M;
+    std::vector<unsigned long long> wdyn(M, kIkNoItem), tc((size_t)kIkQueues * kIkQueueStride, 0ull);
     std::vector<int32_t> link(rows, -1), vok(rows, 0), vit(rows, 0), vse(rows, 0);
     std::vector<double> vq(rows * n, 0.0), vE(rows, 0.0);
-    unsigned dyn_taken = 0, dyn_count = 0, idle = 0;
     IkShareCtl sc;
-    sc.dyn_taken = &dyn_taken; sc.dyn_count = &dyn_count; sc.idle = &idle; sc.wdyn = wdyn.data(); sc.link = link.data();
-    sc.cap = (uint32_t)M; sc.waves = (uint32_t)waves;
+    sc.tc = tc.data(); sc.wdyn = wdyn.data(); sc.link = link.data();
+    sc.qlimit = (uint32_t)qlimit; sc.qcap = (uint32_t)qcap; sc.waves = (uint32_t)waves;
+    sc.after = getenv("EMU_IK_DONATE_AFTER") ? (uint32_t)atoi(getenv("EMU_IK_DONATE_AFTER")) : 3u;
     const int rc = emu_ik_wave_run<NJ>(c, p, waves, Tep, q0, vq.data(), vok.data(), vit.data(), vse.data(), vE.data(), stats, nullptr, &sc);
     if (rc) return rc;
-    if (dyn_taken != dyn_count) return -5;                                        // every appended item must have been taken
+    // every wave ends holding one unserved ticket, so every appended item has been handed to a ticket before it
+    unsigned long long unserved = 0, donated = 0;
+    for (int g = 0; g < kIkQueues; ++g) {
+        const unsigned long long x = tc[(size_t)g * kIkQueueStride];
+        if (ik_word_tickets(x) < ik_word_count(x) || ik_word_count(x) > qcap) return -5;
+        unserved += ik_word_waiting(x); donated += ik_word_count(x);
+    }
+    if (unserved != (unsigned long long)waves) return -5;
     for (int64_t t = 0; t < p.N; ++t)
         ik_merge_chain(n, t, link.data(), vq.data(), vok.data(), vit.data(), vse.data(), vE.data(), q_out, success, iters, searches, residual);
-    if (getenv("EMU_IK_DEBUG")) fprintf(stderr, "sharing: %u ranges donated\n", dyn_count);
+    if (getenv("EMU_IK_DEBUG")) fprintf(stderr, "sharing: %llu ranges donated\n", donated);
     return 0;
 }
 

@@ -59,6 +59,7 @@ def lib():
         from rtbhip._lib import rtbhip_et
         _lib.rtbhip_chain_create.argtypes = [C.POINTER(rtbhip_et), _i32, _vp, C.POINTER(_u64)]
         _lib.rtbhip_dyn_create.argtypes = [_vp, _i32, _i32, C.POINTER(_u64)]
+        _lib.rtbhip_chain_set_q_width.argtypes = [_u64, _i32]
         _lib.emu_kin.argtypes = [_u64, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _i32]
         _lib.emu_rne.argtypes = [_u64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32]
         _lib.emu_kin_hess.argtypes = [_u64, _vp, _i64, _vp, _i32, _vp]
@@ -100,6 +101,8 @@ def chain_handle(ets):
     h = _u64(0)
     rc = lib().rtbhip_chain_create(arr, len(rows), _p(ql), C.byref(h))
     assert rc == 0, lib().rtbhip_last_error()
+    if getattr(ets, "_q_width", None) is not None:
+        assert lib().rtbhip_chain_set_q_width(h, C.c_int32(ets._q_width)) == 0, lib().rtbhip_last_error()
     return h.value
 
 

@@ -47,6 +47,28 @@ def test_chain_compiler_counts_and_folding():
         (rtbhip.ET.Rz(jindex=1) * rtbhip.ET.Rz()).jindices
 
 
+def test_q_width_of_a_branch_can_be_the_robots():
+    """A branch of a tree robot is evaluated on the ROBOT's q (reference Robot.jacob0(q, start, end), robot/Robot.py:1974-1981):
+    rtbhip_chain_set_q_width widens the row pitch beyond max(jindex)+1; narrower than the chain needs, or beyond 256, is refused."""
+    e = rtbhip.ET.Rz(jindex=2) * rtbhip.ET.tx(1.0) * rtbhip.ET.Ry(jindex=0)
+    assert e.q_width == 3
+    e.q_width = 9
+    assert _info(e) == (2, 3, 9) and e.q_width == 9
+    lib = _lib.lib()
+    assert lib.rtbhip_chain_set_q_width(e._handle(), 2) == -1 and b"outside [3, 256]" in lib.rtbhip_last_error()
+    assert lib.rtbhip_chain_set_q_width(e._handle(), 257) == -1
+    assert lib.rtbhip_chain_set_q_width(12345, 4) == -1
+    with pytest.raises(ValueError):
+        e.q_width = 2
+    e.q_width = None
+    assert _info(e) == (2, 3, 3)
+    from rtbhip import urdf
+    y = urdf.load("YuMi")
+    r, l = y.ets(end="gripper_r_finger_r", compact=False), y.ets(end="gripper_l_finger_l", compact=False)
+    assert r.q_width == l.q_width == y.n == 18 and _info(r)[2] == 18
+    assert sorted(set(r.jindices) | set(l.jindices)) == list(range(14)) + [14, 17]       # 7 + 7 arm joints and a finger each
+
+
 def test_chain_create_rejects_bad_input():
     lib = _lib.lib()
     h = C.c_uint64(0)

@@ -155,6 +155,24 @@ def test_explicit_jindex_permutation():
     nt.assert_allclose(J, oracle.jacob0(ch, q), atol=1e-12)   # columns in chain order (methods.cpp:120,201)
 
 
+def test_branch_chain_on_robot_wide_q():
+    """q_width beyond max(jindex)+1 (rtbhip_chain_set_q_width): YuMi's two arms read the same 18-column rows and give what the
+    path-numbered chains give on the picked columns -- LDS-tile walk and register walk."""
+    from rtbhip import urdf
+    y = urdf.load("YuMi")
+    rng = np.random.default_rng(18)
+    q = rng.uniform(-1.0, 1.0, (130, y.n))
+    for end in ("gripper_r_finger_r", "gripper_l_finger_l"):
+        wide, local = y.ets(end=end, compact=False), y.ets(end=end)
+        assert wide.q_width == 18 and local.q_width == local.n == 8
+        qs = np.ascontiguousarray(q[:, wide.jindices])
+        for reg in (False, True):
+            Tw, Jw, _ = emu.kin(wide, q, reg=reg)
+            Tl, Jl, _ = emu.kin(local, qs, reg=reg)
+            nt.assert_array_equal(Tw, Tl)
+            nt.assert_array_equal(Jw, Jl)
+
+
 def test_rne_fixture_parity():
     pu, pd = chains.puma560(), chains.panda_dh()
     for generic in (False, True):
@@ -551,9 +569,10 @@ def test_ik_phased_schedule_equals_sequential_searches(flavour, slimit, with_q0)
 @pytest.mark.parametrize("flavour", [0, 1])
 @pytest.mark.parametrize("N,waves,slimit,with_q0", [(300, 6, 100, False), (64, 3, 100, False), (130, 4, 17, True), (5, 4, 100, False), (700, 2, 40, False)])
 def test_ik_cross_wave_sharing_equals_sequential_searches(flavour, N, waves, slimit, with_q0):
-    """Cross-wave sharing (ik_device.h: a wave out of work takes the unstarted part of another wave's search range as a new
-    work item; a target's rows are chained in search order and merged at the end) must report exactly what the sequential loops
-    report; the replay also checks that every appended item was taken by somebody."""
+    """Cross-wave sharing (ik_device.h: a wave out of work takes a ticket and is handed the unstarted part of another wave's
+    search range as a new work item; a target's rows are chained in search order and merged at the end) must report exactly what
+    the sequential loops report; the replay also checks that every wave ends on an unserved ticket, i.e. every appended item
+    was handed to somebody."""
     import os
     ets, ch = _panda_limited()
     rng = np.random.default_rng(N + waves)
@@ -564,11 +583,13 @@ def test_ik_cross_wave_sharing_equals_sequential_searches(flavour, N, waves, sli
     os.environ["EMU_IK_SHARE"] = "1"
     os.environ["EMU_IK_PASS_MASK"] = "3"
     try:
-        b = emu.ik(ets, Tep, q0=q0, slimit=slimit, flavour=flavour, seed=31, waves=waves)
+        for after in ("0", "3"):                 # ranges cut at once / only from targets with three failed searches (the default)
+            os.environ["EMU_IK_DONATE_AFTER"] = after
+            b = emu.ik(ets, Tep, q0=q0, slimit=slimit, flavour=flavour, seed=31, waves=waves)
+            for x, y in zip(a, b):
+                nt.assert_array_equal(x, y)
     finally:
-        del os.environ["EMU_IK_SHARE"], os.environ["EMU_IK_PASS_MASK"]
-    for x, y in zip(a, b):
-        nt.assert_array_equal(x, y)
+        del os.environ["EMU_IK_SHARE"], os.environ["EMU_IK_PASS_MASK"], os.environ["EMU_IK_DONATE_AFTER"]
     assert a[1].sum() < N
 
 
