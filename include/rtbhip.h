@@ -184,6 +184,15 @@ int rtbhip_ik_lm_nullspace(rtbhip_chain_t chain, const double *Tep, int64_t N, c
                            int32_t *success, int32_t *iters, int32_t *searches, double *residual,
                            int32_t mem, void *stream);
 
+/* IK_QP (robot/IK.py:1222-1520, behind ETS.ikine_QP robot/ETS.py:2932-3110): the Python solver loop (flavour 1) whose step is the
+ * quadratic programme  min 1/2 x^T Q x + c^T x  s.t. [J 1] x = e  over x = (dq, slack), Q = diag(kj 1_n, ks / sum|e| 1_6),
+ * c = (-jacobm / km, 0) (IK.py:1437-1497).  Without inequality rows (kq = 0, the reference's default) the QP has the closed
+ * form of ik_device.h (a minimum-norm step damped by kj sum|e| / ks), solved per lane like the other steps.  kq > 0 (joint-limit
+ * velocity dampers as inequality rows) returns RTBHIP_ELIMIT; km > 0 needs a chain of 6..12 joints. */
+int rtbhip_ik_qp(rtbhip_chain_t chain, const double *Tep, int64_t N, const double *q0, int32_t ilimit, int32_t slimit, double tol,
+                 int32_t reject_jl, const double *we6, uint64_t seed, double kj, double ks, double kq, double km, double ps, double pi,
+                 double *q_out, int32_t *success, int32_t *iters, int32_t *searches, double *residual, int32_t mem, void *stream);
+
 /* The restart vector the device generator yields for (seed, target index, search index, joint):
  * uniform in [qlim_lo, qlim_hi).  Exposed so tests can hand the CPU oracle the same sequence. */
 int rtbhip_ik_restart(rtbhip_chain_t chain, uint64_t seed, int64_t target, int32_t search,

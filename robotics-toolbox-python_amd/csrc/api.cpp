@@ -658,10 +658,38 @@ int rtbhip_ik_lm(rtbhip_chain_t chain, const double *Tep, int64_t N, const doubl
                                   0.0, 0.0, 0.1, 0.3, q_out, success, iters, searches, residual, mem, stream);
 }
 
+static int ik_entry(rtbhip_chain_t chain, const double *Tep, int64_t N, const double *q0,
+                           int32_t ilimit, int32_t slimit, double tol, int32_t reject_jl, const double *we6,
+                           double lambda, int32_t method, int32_t flavour, uint64_t seed,
+                           double kq, double km, double ps, double pi, double ks, double *q_out,
+                           int32_t *success, int32_t *iters, int32_t *searches, double *residual,
+                           int32_t mem, void *stream);
+
 int rtbhip_ik_lm_nullspace(rtbhip_chain_t chain, const double *Tep, int64_t N, const double *q0,
                            int32_t ilimit, int32_t slimit, double tol, int32_t reject_jl, const double *we6,
                            double lambda, int32_t method, int32_t flavour, uint64_t seed,
                            double kq, double km, double ps, double pi, double *q_out,
+                           int32_t *success, int32_t *iters, int32_t *searches, double *residual,
+                           int32_t mem, void *stream)
+{
+    if (method < 0 || method > 4) { set_error("ik_lm: method must be 0 chan, 1 wampler, 2 sugihara, 3 gauss-newton, 4 newton-raphson"); return RTBHIP_EINVAL; }
+    return ik_entry(chain, Tep, N, q0, ilimit, slimit, tol, reject_jl, we6, lambda, method, flavour, seed, kq, km, ps, pi, 1.0, q_out, success, iters,
+                    searches, residual, mem, stream);
+}
+
+int rtbhip_ik_qp(rtbhip_chain_t chain, const double *Tep, int64_t N, const double *q0, int32_t ilimit, int32_t slimit, double tol,
+                 int32_t reject_jl, const double *we6, uint64_t seed, double kj, double ks, double kq, double km, double ps, double pi,
+                 double *q_out, int32_t *success, int32_t *iters, int32_t *searches, double *residual, int32_t mem, void *stream)
+{
+    if (!(kj > 0.0) || !(ks > 0.0)) { set_error("ik_qp: kj and ks must be positive (Q must be positive definite)"); return RTBHIP_EINVAL; }
+    return ik_entry(chain, Tep, N, q0, ilimit, slimit, tol, reject_jl, we6, kj, 5, 1, seed, kq, km, ps, pi, ks, q_out, success, iters, searches,
+                    residual, mem, stream);
+}
+
+static int ik_entry(rtbhip_chain_t chain, const double *Tep, int64_t N, const double *q0,
+                           int32_t ilimit, int32_t slimit, double tol, int32_t reject_jl, const double *we6,
+                           double lambda, int32_t method, int32_t flavour, uint64_t seed,
+                           double kq, double km, double ps, double pi, double ks, double *q_out,
                            int32_t *success, int32_t *iters, int32_t *searches, double *residual,
                            int32_t mem, void *stream)
 {
@@ -670,7 +698,6 @@ int rtbhip_ik_lm_nullspace(rtbhip_chain_t chain, const double *Tep, int64_t N, c
     RTB_TRACE("rtbhip_ik_lm");
     if (!c) { set_error("ik_lm: unknown chain handle"); return RTBHIP_EINVAL; }
     RTB_TRY(check_batch("ik_lm", Tep, N, mem));
-    if (method < 0 || method > 4) { set_error("ik_lm: method must be 0 chan, 1 wampler, 2 sugihara, 3 gauss-newton, 4 newton-raphson"); return RTBHIP_EINVAL; }
     if (flavour < 0 || flavour > 1) { set_error("ik_lm: flavour must be 0 (ik_LM) or 1 (ikine_LM)"); return RTBHIP_EINVAL; }
     if (ilimit < 1 || slimit < 1) { set_error("ik_lm: ilimit and slimit must be >= 1"); return RTBHIP_EINVAL; }
     if (c->n < 1) { set_error("ik_lm: chain has no joints"); return RTBHIP_EINVAL; }
@@ -680,7 +707,7 @@ int rtbhip_ik_lm_nullspace(rtbhip_chain_t chain, const double *Tep, int64_t N, c
     IkParams p;
     p.ilimit = ilimit; p.slimit = slimit; p.reject_jl = reject_jl ? 1 : 0; p.method = method;
     p.flavour = flavour; p.tol = tol; p.lambda = lambda; p.seed = seed;
-    p.kq = kq; p.km = km; p.ps = ps; p.pi = pi;
+    p.kq = kq; p.km = km; p.ps = ps; p.pi = pi; p.ks = ks;
     if (kq > 0.0 && flavour != 1) { set_error("ik_lm: null-space terms belong to the Python solvers (flavour 1)"); return RTBHIP_EINVAL; }
     if (kq > 0.0 && ps == pi) { set_error("ik_lm: ps must differ from pi"); return RTBHIP_EINVAL; }
     for (int i = 0; i < 6; i++) p.we[i] = we6 ? we6[i] : 1.0;

@@ -37,6 +37,7 @@ struct IkDev {   // wave-uniform solver parameters (kernarg)
     uint64_t seed;
     int64_t N;
     double kq, km, ps, pi;           // null-space terms of the Python solvers (IK.py:507-576); kq <= 0: none
+    double ks;                       // IK_QP (method 5): slack gain; its joint-velocity gain kj travels in `lambda`
 };
 
 // ---------------------------------------------------------------- restart generator
@@ -142,7 +143,7 @@ RTB_HD void ik_lm_step(const double (&jac)[6 * NJ], const double (&e)[6], W we /
 // (W = the mask weights for GN -- they matter here --, 1 for NR; what the reference's SVD / damped pseudo-inverse return),
 // an n x n system: ik_lm_step with the damping in place of the LM term.
 template <int NJ, class W>
-RTB_HD void ik_pinv_step(const double (&jac)[6 * NJ], const double (&e)[6], int rows, double damping, W we, bool weighted, double (&dq)[NJ])
+RTB_HD void ik_pinv_step(const double (&jac)[6 * NJ], const double (&e)[6], int rows, double d2 /* damping squared */, W we, bool weighted, double (&dq)[NJ])
 {
     if constexpr (NJ < 6) {
         int used = 0;
@@ -152,7 +153,7 @@ RTB_HD void ik_pinv_step(const double (&jac)[6 * NJ], const double (&e)[6], int 
             double w[6];
 #pragma unroll
             for (int r = 0; r < 6; ++r) w[r] = ((rows >> r) & 1) ? (weighted ? we[r] : 1.0) : 0.0;
-            ik_lm_step<NJ>(jac, e, &w[0], damping * damping, dq);
+            ik_lm_step<NJ>(jac, e, &w[0], d2, dq);
             return;
         }
     }
@@ -167,7 +168,7 @@ RTB_HD void ik_pinv_step(const double (&jac)[6 * NJ], const double (&e)[6], int 
             double s = 0.0;
 #pragma unroll
             for (int k = 0; k < NJ; ++k) s += jac[r * NJ + k] * jac[c * NJ + k];
-            B[r][c] = (ur && uc) ? (r == c ? s + damping * damping : s) : (r == c ? 1.0 : 0.0);
+            B[r][c] = (ur && uc) ? (r == c ? s + d2 : s) : (r == c ? 1.0 : 0.0);
         }
     }
     ldl_solve<6>(B, g, y);
@@ -226,6 +227,25 @@ RTB_HD void ik_qnull(const double (&jac)[6 * NJ], const PD &p, QL qlim, QA qa, d
         for (int r = 0; r < 6; ++r) a -= jac[r * NJ + k] * x[r];
         qn[k] = a;
     }
+}
+
+// ---------------------------------------------------------------- IK_QP (robot/IK.py:1222-1520), the case without inequality rows
+// The step of IK_QP is the quadratic programme   min 1/2 x^T Q x + c^T x   s.t.  [J 1_6] x = e,   x = (dq, delta),
+// Q = diag(kj 1_n, (ks / sum|e|) 1_6),  c = (-jacobm(q) / km, 0)  (IK.py:1437-1497); the joint-limit velocity dampers add
+// inequality rows only when kq > 0.  Without them it is an equality-constrained strictly convex QP and has the closed form
+//      dq = g + J^T (J J^T + d^2 1)^-1 (e - J g),      d^2 = kj sum|e| / ks,     g = jacobm(q) / (kj km)   (0 when km = 0)
+// (eliminate the multipliers of the 6 equality rows): a damped minimum-norm step whose damping follows the error -- the
+// same 6x6 solve as the Gauss-Newton / Newton-Raphson steps above.  The reference hands the QP to quadprog (an absent
+// third-party dependency); the minimiser of a strictly convex QP is unique, so any exact solver returns this x.
+template <int NJ, class PD>
+RTB_HD void ik_qp_gain(const double (&jac)[6 * NJ], const PD &p, double (&g)[NJ])
+{
+    static_assert(NJ >= 6, "jacobm needs J J^T invertible: a redundant or square arm");
+    double jm[NJ];
+    jacobm<NJ>(jac, 63, jm);
+    const double s = 1.0 / (p.lambda * p.km);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) g[j] = s * jm[j];
 }
 
 // ---------------------------------------------------------------- searches as pure functions
@@ -352,15 +372,35 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, Q
     for (int k = 0; k < 6; ++k) E += e[k] * p.we[k] * e[k];
     E *= 0.5;                                                   // ik.cpp:46
     double qn[NULLSP ? NJ : 1];
-    if constexpr (NULLSP) ik_qnull<NJ>(jac, p, qlim, qa, qn);   // IK.py:753,1011,1210 (before the step: J dies in it)
-    if (PINV) {                     // 3 Gauss-Newton, 4 Newton-Raphson: `lambda` carries pinv_damping (NR only)
+    if constexpr (NULLSP) {
+        if (PINV && p.method == 5) ik_qp_gain<NJ>(jac, p, qn);  // IK_QP's manipulability term (wave-uniform branch)
+        else ik_qnull<NJ>(jac, p, qlim, qa, qn);                // IK.py:753,1011,1210 (before the step: J dies in it)
+    }
+    if (PINV) {                     // 3 Gauss-Newton, 4 Newton-Raphson (`lambda` carries pinv_damping), 5 IK_QP (`lambda` carries kj)
         int rows = 63;
+        double d2 = 0.0;
         if (p.method == 3) {
             rows = 0;
 #pragma unroll
             for (int k = 0; k < 6; ++k) rows |= (p.we[k] != 0.0) ? (1 << k) : 0;
+        } else if (p.method == 4) {
+            d2 = p.lambda * p.lambda;
+        } else if (p.method == 5) {
+            double se = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) se += fabs(e[k]);
+            d2 = p.lambda * se / p.ks;                          // IK.py:1442-1446
+            if constexpr (NULLSP) {                             // e - J g
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    double a = e[r];
+#pragma unroll
+                    for (int k = 0; k < NJ; ++k) a -= jac[r * NJ + k] * qn[k];
+                    e[r] = a;
+                }
+            }
         }
-        ik_pinv_step<NJ>(jac, e, rows, p.method == 4 ? p.lambda : 0.0, &p.we[0], p.method == 3, dq);
+        ik_pinv_step<NJ>(jac, e, rows, d2, &p.we[0], p.method == 3, dq);
     } else {
         const double wn = (p.method == 1) ? p.lambda : (p.method == 2) ? E + p.lambda : p.lambda * E;   // ik.cpp:169,183,205
         ik_lm_step<NJ>(jac, e, &p.we[0], wn, dq);
@@ -420,7 +460,8 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, Q
 template <class PD>
 RTB_HD int ik_step_variant(const PD &p, int n)
 {
-    return (p.method >= 3 ? kIkStepPinv : 0) | ((p.kq > 0.0 && n >= 6 && n <= 12) ? kIkStepNull : 0);
+    const bool extra = p.method == 5 ? p.km > 0.0 : p.kq > 0.0;     // IK_QP: the manipulability term; the others: null-space motion
+    return (p.method >= 3 ? kIkStepPinv : 0) | ((extra && n >= 6 && n <= 12) ? kIkStepNull : 0);
 }
 template <int NJ, class PD, class CV, class QL, class TD, class QA>
 RTB_HD void ik_iter_any(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, QA qa)

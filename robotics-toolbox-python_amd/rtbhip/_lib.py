@@ -59,6 +59,8 @@ SIGNATURES = {
                                _i32, _i32, _u64, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "rtbhip_ik_lm_nullspace": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _i32, C.c_double, _i32, _vp, C.c_double, _i32, _i32, _u64,
                                          C.c_double, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "rtbhip_ik_qp": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _i32, C.c_double, _i32, _vp, _u64, C.c_double, C.c_double, C.c_double, C.c_double,
+                               C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "rtbhip_ik_restart": (C.c_int, [_u64, _u64, _i64, _i32, _vp]),
     "rtbhip_dyn_create": (C.c_int, [_vp, _i32, _i32, C.POINTER(_u64)]),
     "rtbhip_dyn_destroy": (C.c_int, [_u64]),

@@ -23,7 +23,7 @@ from . import _lib
 from ._lib import check, lib, as_numeric, small, host_ptr, is_torch, MEM_HOST, MEM_DEVICE
 
 _AXES = {"Rx": 0, "Ry": 1, "Rz": 2, "tx": 3, "ty": 4, "tz": 5}
-_METHODS = {"chan": 0, "wampler": 1, "sugihara": 2, "gn": 3, "nr": 4}
+_METHODS = {"chan": 0, "wampler": 1, "sugihara": 2, "gn": 3, "nr": 4, "qp": 5}
 
 
 def _elementary(axis, eta):
@@ -582,7 +582,7 @@ class ETS:
         return out[0] if single else out
 
     # ------------------------------------------------------------ inverse kinematics
-    def _ik(self, Tep, q0, ilimit, slimit, tol, mask, joint_limits, k, method, flavour, seed, nullspace=None):
+    def _ik(self, Tep, q0, ilimit, slimit, tol, mask, joint_limits, k, method, flavour, seed, nullspace=None, qp=None):
         n = self.n
         tm = is_torch(Tep) and Tep.is_cuda
         if tm:
@@ -627,6 +627,13 @@ class ETS:
             se = np.empty(N, np.int32); E = np.empty(N)
         we = small(mask, 6)
         kq, km, ps, pi = nullspace if nullspace is not None else (0.0, 0.0, 0.1, 0.3)
+        if qp is not None:
+            kj, ks = qp
+            check(lib().rtbhip_ik_qp(self._handle(), self._ptr(Tq, tm), N, self._ptr(q0p, tm), int(ilimit), int(slimit), float(tol),
+                                     int(bool(joint_limits)), host_ptr(we), int(seed) & 0xFFFFFFFFFFFFFFFF, float(kj), float(ks), float(kq),
+                                     float(km), float(ps), float(pi), self._ptr(qo, tm), self._ptr(ok, tm), self._ptr(it, tm),
+                                     self._ptr(se, tm), self._ptr(E, tm), MEM_DEVICE if tm else MEM_HOST, self._stream(tm)))
+            return single, qo, ok, it, se, E
         check(lib().rtbhip_ik_lm_nullspace(self._handle(), self._ptr(Tq, tm), N, self._ptr(q0p, tm), int(ilimit), int(slimit),
                                            float(tol), int(bool(joint_limits)), host_ptr(we), float(k), int(method), int(flavour),
                                            int(seed) & 0xFFFFFFFFFFFFFFFF, float(kq), float(km), float(ps), float(pi),
@@ -692,12 +699,12 @@ class ETS:
             raise NotImplementedError("a per-joint influence distance pi is not offered; pass a scalar")
         return (float(kq), float(km), float(ps), float(pi))
 
-    def _ikine_pinv(self, name, Tep, q0, ilimit, slimit, tol, mask, joint_limits, seed, pinv, kq, km, ps=0.0, pi=0.3):
-        if not pinv and self.n != 6:
+    def _ikine_pinv(self, name, Tep, q0, ilimit, slimit, tol, mask, joint_limits, seed, pinv, kq, km, ps=0.0, pi=0.3, qp=None):
+        if qp is None and not pinv and self.n != 6:
             raise ValueError("%s: a %d-joint chain needs pinv=True (numpy.linalg.inv of a 6x%d Jacobian is undefined)"
                              % (name, self.n, self.n))
         single, q, ok, it, se, E = self._ik(Tep, q0, ilimit, slimit, tol, mask, joint_limits, 0.0, name, 1,
-                                            0 if seed is None else seed, self._nullspace(kq, km, ps, pi))
+                                            0 if seed is None else seed, self._nullspace(kq, km, ps, pi), qp=qp)
         if is_torch(q):
             q, ok, it, se, E = (x.cpu().numpy() for x in (q, ok, it, se, E))
         if single:
@@ -721,6 +728,15 @@ class ETS:
         """The Python Gauss-Newton solver (reference ETS.ikine_GN robot/ETS.py:2778-2915 -> IK_GN robot/IK.py:1020-1220;
         its step is the same pinv(J) e)."""
         return self._ikine_pinv("nr", Tep, q0, ilimit, slimit, tol, mask, joint_limits, seed, pinv, kq, km, ps, pi)
+
+    def ikine_QP(self, Tep, q0=None, ilimit=30, slimit=100, tol=1e-6, mask=None, joint_limits=True, seed=None,
+                 kj=1.0, ks=1.0, kq=0.0, km=0.0, ps=0.0, pi=0.3, **kwargs):
+        """The quadratic-programming solver (reference ETS.ikine_QP robot/ETS.py:2932-3110 -> IK_QP robot/IK.py:1222-1520;
+        note the two defaults of the reference: kj = 1.0 here, 0.01 in the IK_QP class).  Each step minimises
+        kj/2 |dq|^2 + ks/(2 sum|e|) |slack|^2 - jacobm.dq/km subject to J dq + slack = e; without inequality rows the programme
+        has a closed form (csrc/ik_device.h) and runs per lane like the other solvers.  kq > 0 (joint-limit velocity dampers as
+        inequality rows) is refused loudly (RtbHipError), as is km > 0 on chains outside 6..12 joints."""
+        return self._ikine_pinv("qp", Tep, q0, ilimit, slimit, tol, mask, joint_limits, seed, True, kq, km, ps, pi, qp=(kj, ks))
 
     def ik_restart(self, seed, target, search):
         """The restart vector the device generator yields (test hook, rtbhip_ik_restart)."""

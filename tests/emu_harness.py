@@ -67,6 +67,8 @@ def lib():
         _lib.emu_diff.argtypes = [_u64, _i32, _i32, _vp, _vp, _i64, _vp, _i32, _vp]
         _lib.emu_ik_nullspace.argtypes = [C.c_double] * 4
         _lib.emu_ik_nullspace.restype = None
+        _lib.emu_ik_qp_ks.argtypes = [C.c_double]
+        _lib.emu_ik_qp_ks.restype = None
         _lib.emu_link_frames.argtypes = [_u64, _vp, _i64, _vp, _vp, _i32, _vp]
         _lib.emu_partial.argtypes = [_u64, _vp, _i64, _vp, _i32, _vp]
         _lib.emu_dyn.argtypes = [_u64, _i32, _vp, _vp, _vp, _i64, _vp, _vp]
@@ -254,7 +256,7 @@ def dyn(L24, mdh, mode, q, qd=None, torque=None, grav_c=None):
     return out
 
 
-METHODS = {"chan": 0, "wampler": 1, "sugihara": 2, "gn": 3, "nr": 4}
+METHODS = {"chan": 0, "wampler": 1, "sugihara": 2, "gn": 3, "nr": 4, "qp": 5}
 
 
 def ik(ets, Tep, q0=None, ilimit=30, slimit=100, tol=1e-6, joint_limits=True, mask=None, k=1.0, method="chan",
@@ -287,6 +289,11 @@ def ik(ets, Tep, q0=None, ilimit=30, slimit=100, tol=1e-6, joint_limits=True, ma
 def ik_nullspace(kq=0.0, km=0.0, ps=0.0, pi=0.3):
     """Null-space terms for the following emu.ik calls (kq <= 0 switches them off again)."""
     lib().emu_ik_nullspace(float(kq), float(km), float(ps), float(pi))
+
+
+def ik_qp_ks(ks=1.0):
+    """IK_QP's slack gain for the following emu.ik(method="qp", k=kj) calls."""
+    lib().emu_ik_qp_ks(float(ks))
 
 
 def ik_restart(ets, seed, target, draw):

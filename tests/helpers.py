@@ -38,6 +38,10 @@ PY_IK_CASES = {
     "lm_wampler_ns_km": ("ikn", True, 3, "lm", dict(method="wampler", k=0.01, kq=0.0, km=0.5)),
     "nr_ns": ("ikn", True, 3, "nr", dict(kq=0.01, km=1.0)),
     "gn_ns": ("ikn", True, 3, "gn", dict(kq=1.0, km=1.0)),
+    "qp_class_default": ("ik", False, 100, "qp", dict(kj=0.01, ks=1.0)),
+    "qp_ets_default_q0": ("ikn", True, 5, "qp", dict(kj=1.0, ks=1.0)),
+    "qp_km": ("ikn", True, 3, "qp", dict(kj=0.1, ks=1.0, km=10.0)),
+    "qp_mask_nojl": ("ik", True, 20, "qp", dict(kj=0.1, ks=2.0, joint_limits=False, mask=[1, 1, 1, 0.5, 0.5, 0.25])),
 }
 
 

@@ -639,6 +639,60 @@ def test_ik_cross_wave_sharing_and_phased_schedule_equal_plain(flavour):
         assert 0 < base[1].sum() < N
 
 
+def test_ik_qp_error_paths_and_batch_vs_oracle():
+    """ETS.ikine_QP (IK_QP, robot/IK.py:1222-1520): inequality rows (kq > 0) and the manipulability term on a 5-joint arm are
+    refused loudly; a UR5 batch on device tensors equals the KKT restatement target by target."""
+    import torch
+    from rtbhip import urdf as U
+    from helpers import chain_from_ets
+    panda, _ = _panda_limited()
+    with pytest.raises(rtbhip.RtbHipError):
+        panda.ikine_QP(np.eye(4), kq=0.1)
+    with pytest.raises(rtbhip.RtbHipError):
+        panda.ikine_QP(np.eye(4), kj=0.0)
+    with pytest.raises(rtbhip.RtbHipError):
+        U.load("px100").ets().ikine_QP(np.eye(4), km=1.0)
+    e = U.load("UR5").ets()
+    e.qlim = np.clip(e.qlim, -np.pi, np.pi)
+    ch = chain_from_ets(e)
+    rng = np.random.default_rng(66)
+    N = 200
+    qs = rng.uniform(ch.qlim[0] * 0.8, ch.qlim[1] * 0.8, (N, 6))
+    Tep = oracle.fkine(ch, qs)
+    q0 = qs + 0.15 * rng.normal(size=qs.shape)
+    sol = e.ikine_QP(torch.from_numpy(Tep).cuda(), q0=torch.from_numpy(q0).cuda(), seed=8, slimit=3, kj=0.01)
+    for i in range(0, N, 7):
+        rs = np.array([q0[i]] + [e.ik_restart(8, i, d) for d in range(1, 3)])
+        o = oracle.ikine_py(ch, Tep[i], rs, step="qp", slimit=3, kj=0.01, ks=1.0)
+        assert (o[1], o[2], o[3]) == (sol.each["success"][i], sol.each["iterations"][i], sol.each["searches"][i])
+        if o[1]:
+            nt.assert_allclose(sol.q[i], o[0], atol=1e-7)
+    assert sol.each["success"].mean() > 0.8
+
+
+def test_branches_of_a_tree_robot_read_the_robot_wide_q():
+    """rtbhip_chain_set_q_width: YuMi's two arms evaluated from ONE (N, 18) array -- per-chain kernels, the fleet launch, host
+    and device pointers -- equal the path-numbered chains on the picked columns."""
+    import torch
+    from rtbhip import urdf as U
+    y = U.load("YuMi")
+    rng = np.random.default_rng(18)
+    q = rng.uniform(-1.0, 1.0, (1000, y.n))
+    ends = ("gripper_r_finger_r", "gripper_l_finger_l")
+    wide = [y.ets(end=e, compact=False) for e in ends]
+    local = [y.ets(end=e) for e in ends]
+    qd = torch.from_numpy(q).cuda()
+    Tf, Jf = rtbhip.fleet_fkine_jacob(wide, [qd, qd])
+    for w, l, Tw, Jw in zip(wide, local, Tf, Jf):
+        qs = np.ascontiguousarray(q[:, w.jindices])
+        Tl, Jl = l.fkine_jacob0(qs)
+        nt.assert_array_equal(w.eval(q), Tl)
+        nt.assert_array_equal(w.jacob0(q), Jl)
+        nt.assert_array_equal(Tw.cpu().numpy(), Tl)
+        nt.assert_array_equal(Jw.cpu().numpy(), Jl)
+        nt.assert_array_equal(w.hessian0(q[:50]), l.hessian0(qs[:50]))
+
+
 def test_init_and_shutdown_keep_handles_usable():
     lib = rtbhip.lib()
     assert lib.rtbhip_init(-1) == 0 and lib.rtbhip_init(1) == 0

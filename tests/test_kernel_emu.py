@@ -475,6 +475,44 @@ def test_ik_gn_nr_on_arms_with_fewer_than_six_joints(robot):
     assert okm.mean() >= 0.9
 
 
+@pytest.mark.parametrize("robot,kw", [("AL5D", dict(kj=0.05, ks=1.0)), ("px100", dict(kj=0.01, ks=2.0)), ("UR5", dict(kj=0.01, ks=1.0)),
+                                      ("Fetch", dict(kj=0.02, ks=1.0, km=500.0)), ("KinovaGen3", dict(kj=1.0, ks=1.0))])
+def test_ik_qp_joint_counts_against_the_kkt_restatement(robot, kw):
+    """IK_QP (robot/IK.py:1222-1520, kq = 0) on chains of 4, 5, 6, 9 and 10 joints: the device's closed-form step (a minimum-norm
+    step damped by kj sum|e| / ks, plus the manipulability term where km > 0) inside the Python solver's loop against the NumPy
+    restatement that builds the reference's Q, c, Aeq, beq and solves the KKT system.  Every target, every search: the QP step is
+    damped, so nothing is chaotic here.  (Panda: pinned on the reference's own IK_QP code in test_python_ik_pins.py.)"""
+    from rtbhip import urdf
+    from helpers import chain_from_ets
+    ets = urdf.load(robot).ets()
+    ets.qlim = np.clip(ets.qlim, -np.pi, np.pi)
+    ch = chain_from_ets(ets)
+    n = ets.n
+    rng = np.random.default_rng(100 + n)
+    N = 16
+    span = ch.qlim[1] - ch.qlim[0]
+    qs = rng.uniform(ch.qlim[0] + 0.1 * span, ch.qlim[1] - 0.1 * span, (N, n))
+    Tep = oracle.fkine(ch, qs)
+    q0 = np.clip(qs + 0.05 * span * rng.normal(size=qs.shape), ch.qlim[0], ch.qlim[1])
+    emu.ik_qp_ks(kw["ks"])
+    emu.ik_nullspace(0.0, kw.get("km", 0.0), 0.0, 0.3)
+    try:
+        q, ok, it, se, E = emu.ik(ets, Tep, q0=q0, method="qp", flavour=1, seed=6, slimit=4, k=kw["kj"])
+        wav = emu.ik(ets, Tep, q0=q0, method="qp", flavour=1, seed=6, slimit=4, k=kw["kj"], waves=2)
+    finally:
+        emu.ik_qp_ks()
+        emu.ik_nullspace()
+    for a, b in zip((q, ok, it, se, E), wav):
+        nt.assert_array_equal(a, b)
+    for i in range(N):
+        rs = np.array([q0[i]] + [emu.ik_restart(ets, 6, i, d) for d in range(1, 4)])
+        o = oracle.ikine_py(ch, Tep[i], rs, step="qp", slimit=4, **kw)
+        assert (o[1], o[2], o[3]) == (ok[i], it[i], se[i]), (robot, i)
+        if o[1]:
+            nt.assert_allclose(q[i], o[0], atol=1e-7)
+    assert ok.mean() >= (0.5 if "km" not in kw else 0.2)
+
+
 @pytest.mark.parametrize("ilimit,slimit", [(20, 100), (20, 200), (30, 100)])
 def test_ik_watchdog_budget_covers_the_pass_latency(ilimit, slimit):
     """64 unreachable targets in one wave, the scheduling pass only every 4th iteration (the production default): every

@@ -174,7 +174,7 @@ def test_oracle_python_ik_matches_reference_IK_py(key):
     checked = 0
     for i in range(len(Tep)):
         o = oracle.ikine_py(ch, Tep[i], tab[i], step=step, slimit=slimit, we=we, **kw)
-        if step != "lm" and not (meta[i, 0] == 1 and meta[i, 2] == 1):
+        if step not in ("lm", "qp") and not (meta[i, 0] == 1 and meta[i, 2] == 1):
             continue
         assert (o[1], o[2], o[3]) == tuple(meta[i]), (key, i)
         if meta[i, 0]:
@@ -187,7 +187,7 @@ def test_oracle_python_ik_matches_reference_IK_py(key):
             assert (c[1], c[2], c[3]) == tuple(meta[i]), (key, i)
             if meta[i, 0]:
                 nt.assert_allclose(c[0], qref[i], atol=1e-7)
-    assert checked >= (len(Tep) if step == "lm" else 6)
+    assert checked >= (len(Tep) if step in ("lm", "qp") else 6)
 
 
 @pytest.mark.skipif(not ref_harness.available(), reason="oracle/_ref not built here")

@@ -1,6 +1,7 @@
 """SURVEY rows a7 / a9 pinned on the reference itself: tests/golden/ref_python_ik.npz holds what the reference's OWN
-Python solvers (robot/IK.py IK_LM / IK_NR / IK_GN `.solve`, run unmodified under the stand-in modules of
-oracle/ref_python.py) and its compiled `fknm.Angle_Axis` return.  The start-vector tables of those runs are the device
+Python solvers (robot/IK.py IK_LM / IK_NR / IK_GN / IK_QP `.solve`, run unmodified under the stand-in modules of
+oracle/ref_python.py; IK_QP with an exact KKT solve standing in for the absent qpsolvers/quadprog, kq = 0) and its compiled
+`fknm.Angle_Axis` return.  The start-vector tables of those runs are the device
 generator's (rtbhip_ik_restart, a host function), so the device's ikine_* -- whose restarts nobody can hand it --
 must reproduce the reference's (q, success, iterations, searches, residual) across MANY searches, not only
 first-search cases.
@@ -41,14 +42,14 @@ def _check(key, q, ok, it, se, E):
     checked = 0
     for i in range(len(meta)):
         # undamped NR / GN searches from far-away random starts are chaotic: compare what the first search decides
-        if step != "lm" and not (meta[i, 0] == 1 and meta[i, 2] == 1):
+        if step not in ("lm", "qp") and not (meta[i, 0] == 1 and meta[i, 2] == 1):
             continue
         assert (int(ok[i]), int(it[i]), int(se[i])) == tuple(meta[i]), (key, i)
         if meta[i, 0]:
             nt.assert_allclose(q[i], qref[i], atol=1e-6)
             assert abs(E[i] - Eref[i]) <= 1e-9 + 1e-6 * abs(Eref[i])
         checked += 1
-    assert checked >= (len(meta) if step == "lm" else 6), (key, checked)
+    assert checked >= (len(meta) if step in ("lm", "qp") else 6), (key, checked)
 
 
 @pytest.mark.parametrize("key", sorted(PY_IK_CASES))
@@ -60,7 +61,9 @@ def test_emu_search_functions_equal_reference_python_solvers(key):
     kw = dict(kw)
     ns = (kw.pop("kq", 0.0), kw.pop("km", 0.0), kw.pop("ps", 0.0), kw.pop("pi", 0.3))
     args = dict(q0=tab[:, 0] if first else None, slimit=slimit, flavour=1, seed=SEED, method=kw.pop("method", step),
-                k=kw.pop("k", 0.0), ilimit=kw.pop("ilimit", 30), joint_limits=kw.pop("joint_limits", True), mask=kw.pop("mask", None))
+                k=kw.pop("kj") if step == "qp" else kw.pop("k", 0.0), ilimit=kw.pop("ilimit", 30),
+                joint_limits=kw.pop("joint_limits", True), mask=kw.pop("mask", None))
+    emu.ik_qp_ks(kw.pop("ks", 1.0))
     assert not kw
     emu.ik_nullspace(*ns)
     try:
@@ -68,6 +71,7 @@ def test_emu_search_functions_equal_reference_python_solvers(key):
         wav = emu.ik(ets, Tep, waves=2, **args)
     finally:
         emu.ik_nullspace()
+        emu.ik_qp_ks()
     _check(key, *seq)
     for a, b in zip(seq, wav):
         nt.assert_array_equal(a, b)
@@ -94,8 +98,8 @@ def test_gpu_ikine_equals_reference_python_solvers(key):
     prob, first, slimit, step, kw = PY_IK_CASES[key]
     Tep, tab = py_ik_problem(PY, key)
     kw = dict(kw)
-    fn = {"lm": ets.ikine_LM, "nr": ets.ikine_NR, "gn": ets.ikine_GN}[step]
-    if step != "lm":
+    fn = {"lm": ets.ikine_LM, "nr": ets.ikine_NR, "gn": ets.ikine_GN, "qp": ets.ikine_QP}[step]
+    if step in ("nr", "gn"):
         kw["pinv"] = True
     sol = fn(Tep, q0=tab[:, 0] if first else None, slimit=slimit, seed=SEED, **kw)
     e = sol.each
