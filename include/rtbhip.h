@@ -187,8 +187,10 @@ int rtbhip_ik_lm_nullspace(rtbhip_chain_t chain, const double *Tep, int64_t N, c
 /* IK_QP (robot/IK.py:1222-1520, behind ETS.ikine_QP robot/ETS.py:2932-3110): the Python solver loop (flavour 1) whose step is the
  * quadratic programme  min 1/2 x^T Q x + c^T x  s.t. [J 1] x = e  over x = (dq, slack), Q = diag(kj 1_n, ks / sum|e| 1_6),
  * c = (-jacobm / km, 0) (IK.py:1437-1497).  Without inequality rows (kq = 0, the reference's default) the QP has the closed
- * form of ik_device.h (a minimum-norm step damped by kj sum|e| / ks), solved per lane like the other steps.  kq > 0 (joint-limit
- * velocity dampers as inequality rows) returns RTBHIP_ELIMIT; km > 0 needs a chain of 6..12 joints. */
+ * form of ik_device.h (a minimum-norm step damped by kj sum|e| / ks); with kq > 0 every joint inside the influence distance pi
+ * of a limit adds one row on its own velocity (IK.py:1453-1481) and a primal-dual active-set loop around the same 6x6 solve
+ * finds the minimiser.  Both per lane, inside the search scheduler of rtbhip_ik_lm.  km > 0 or kq > 0 need a chain of 6..12
+ * joints (RTBHIP_ELIMIT otherwise); a per-joint influence distance (array pi) is not offered. */
 int rtbhip_ik_qp(rtbhip_chain_t chain, const double *Tep, int64_t N, const double *q0, int32_t ilimit, int32_t slimit, double tol,
                  int32_t reject_jl, const double *we6, uint64_t seed, double kj, double ks, double kq, double km, double ps, double pi,
                  double *q_out, int32_t *success, int32_t *iters, int32_t *searches, double *residual, int32_t mem, void *stream);

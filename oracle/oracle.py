@@ -380,31 +380,41 @@ def calc_qnull(ch, q, J, kq, km, ps, pi):
     return qnull.flatten()
 
 
-def solve_eq_qp(Q, c, Aeq, beq):
-    """min 1/2 x^T Q x + c^T x  s.t.  Aeq x = beq, through its KKT system -- what qpsolvers.solve_qp(..., solver="quadprog")
-    returns when there are no inequality rows (the minimiser of a strictly convex QP is unique).  qpsolvers / quadprog are absent
-    third-party dependencies of the reference (pyproject optional `qpsolvers`, IK.py:26-31)."""
-    n, m = Q.shape[0], Aeq.shape[0]
-    K = np.block([[Q, Aeq.T], [Aeq, np.zeros((m, m))]])
-    sol = np.linalg.solve(K, np.concatenate((-c, beq)))
-    return sol[:n]
-
-
-def qp_step(ch, q, e, J, kj, ks, km):
-    """IK_QP.step (robot/IK.py:1437-1497) for kq = 0, matrix for matrix: Q, Aeq, beq, c as the reference builds them."""
+def qp_step(ch, q, e, J, kj, ks, km, kq=0.0, ps=0.0, pi=0.3):
+    """IK_QP.step (robot/IK.py:1437-1500), matrix for matrix: Q, c, Aeq, beq, Ain, bin as the reference builds them; the QP itself
+    goes to oracle/qp.py (the reference: qpsolvers / quadprog, an absent optional dependency)."""
+    from . import qp
     n = ch.n
+    pi = pi * np.ones(n) if np.ndim(pi) == 0 else np.asarray(pi, dtype=float)
     Q = np.eye(n + 6)
     Q[:n, :n] *= kj
     Q[n:, n:] = ks * (1 / np.sum(np.abs(e))) * np.eye(6)
     Aeq = np.concatenate((J, np.eye(6)), axis=1)
     beq = e.reshape((6,))
+    if kq > 0.0:
+        Ain = np.zeros((n + 6, n + 6))
+        bin_ = np.zeros(n + 6)
+        Ain_l = np.zeros((n, n))
+        Bin_l = np.zeros(n)
+        for i in range(n):
+            ql0, ql1 = ch.qlim[0, i], ch.qlim[1, i]
+            if ql1 - q[i] <= pi[i]:
+                Bin_l[i] = ((ql1 - q[i]) - ps) / (pi[i] - ps)
+                Ain_l[i, i] = 1
+            if q[i] - ql0 <= pi[i]:
+                Bin_l[i] = -(((ql0 - q[i]) + ps) / (pi[i] - ps))
+                Ain_l[i, i] = -1
+        Ain[:n, :n] = Ain_l
+        bin_[:n] = (1.0 / kq) * Bin_l
+    else:
+        Ain, bin_ = None, None
     if km > 0.0:
         Jm = jacobm(ch, q)[0].reshape((n,))
         c = np.concatenate(((1.0 / km) * -Jm, np.zeros(6)))
     else:
         c = np.zeros(n + 6)
-    xd = solve_eq_qp(Q, c, Aeq, beq)
-    if not np.all(np.isfinite(xd)):
+    xd = qp.solve_qp(Q, c, Ain, bin_, Aeq, beq)
+    if xd is None:
         raise np.linalg.LinAlgError("QP Unsolvable")
     return xd[:n]
 
@@ -412,7 +422,7 @@ def qp_step(ch, q, e, J, kj, ks, km):
 def ikine_py(ch, Tep, q0s, step="nr", ilimit=30, slimit=100, tol=1e-6, joint_limits=True, we=None, k=1.0,
              kq=0.0, km=0.0, ps=0.0, pi=0.3, method="chan", kj=1.0, ks=1.0):
     """NumPy restatement of the Python solvers' loop, IKSolver._solve (robot/IK.py:297-367), with the steps of
-    IK_NR / IK_GN (q += pinv(J) e + qnull, :736-763, :1176-1220), IK_LM (:994-1017) or IK_QP (step "qp", :1437-1497, kq = 0).
+    IK_NR / IK_GN (q += pinv(J) e + qnull, :736-763, :1176-1220), IK_LM (:994-1017) or IK_QP (step "qp", :1437-1500).
     q0s: (slimit, n) starts."""
     n = ch.n
     q0s = _f64(q0s, (-1, n))
@@ -430,11 +440,9 @@ def ikine_py(ch, Tep, q0s, step="nr", ilimit=30, slimit=100, tol=1e-6, joint_lim
             J = jacob0(ch, q)[0]
             try:
                 if step == "qp":
-                    if kq > 0:
-                        raise NotImplementedError("oracle: IK_QP with inequality rows (kq > 0)")
                     if not np.all(np.isfinite(J)):
                         raise np.linalg.LinAlgError("QP Unsolvable")
-                    q = q + qp_step(ch, q, e, J, kj, ks, km)
+                    q = q + qp_step(ch, q, e, J, kj, ks, km, kq, ps, pi)
                     qnull = None
                 else:
                     qnull = calc_qnull(ch, q, J, kq, km, ps, pi)

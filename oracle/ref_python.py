@@ -14,9 +14,9 @@ a pyproject dependency, is absent and there is no network).  IK.py needs exactly
                                           number coming out of the reference's compiled fknm; only `jacobm` (ETS.py:1669-1685,
                                           ten lines of NumPy over the reference's own J and H) is restated.
   * `qpsolvers.solve_qp` (IK_QP only, IK.py:16-21, 1497)   an absent optional third-party dependency (quadprog behind it).  The
-                                          stand-in below solves the KKT system of the equality-constrained programme exactly --
-                                          the minimiser of a strictly convex QP is unique, so it returns what quadprog returns --
-                                          and refuses inequality rows (kq > 0), which this oracle does not cover.
+                                          stand-in is oracle/qp.py: an exact solver that enumerates the active sets of the (few)
+                                          inequality rows and solves each KKT system -- the minimiser of a strictly convex QP is
+                                          unique, so it returns what quadprog returns to rounding.
 
 Only tests/golden/make_golden.py (fixture generation, build container) and tests that are skipped where
 /root/reference is absent import this module.  Nothing here can run on the GPU box.
@@ -64,19 +64,10 @@ class SE3:
         return self._data[0] if len(self._data) == 1 else np.array(self._data)
 
 
-def solve_qp(P, q, G=None, h=None, A=None, b=None, lb=None, ub=None, solver=None, **kw):
-    """Stand-in for qpsolvers.solve_qp as IK_QP.step calls it (IK.py:1497): min 1/2 x^T P x + q^T x  s.t.  A x = b, through the
-    KKT system.  Inequality rows (G, h: the joint-limit velocity dampers of kq > 0) and bounds are refused."""
-    if G is not None or h is not None or lb is not None or ub is not None:
-        raise NotImplementedError("oracle stand-in for qpsolvers: equality-constrained programmes only")
-    P, q, A, b = (np.asarray(x, dtype=float) for x in (P, q, A, b))
-    n, m = P.shape[0], A.shape[0]
-    K = np.block([[P, A.T], [A, np.zeros((m, m))]])
-    try:
-        sol = np.linalg.solve(K, np.concatenate((-q, b)))
-    except np.linalg.LinAlgError:
-        return None                           # IK.py:1499-1500 turns None into LinAlgError("QP Unsolvable")
-    return sol[:n] if np.all(np.isfinite(sol)) else None
+def solve_qp(*args, **kw):
+    """Stand-in for qpsolvers.solve_qp as IK_QP.step calls it (IK.py:1497): the exact enumerating solver of oracle/qp.py."""
+    from . import qp
+    return qp.solve_qp(*args, **kw)
 
 
 def ik_module():

@@ -229,7 +229,7 @@ RTB_HD void ik_qnull(const double (&jac)[6 * NJ], const PD &p, QL qlim, QA qa, d
     }
 }
 
-// ---------------------------------------------------------------- IK_QP (robot/IK.py:1222-1520), the case without inequality rows
+// ---------------------------------------------------------------- IK_QP (robot/IK.py:1222-1520)
 // The step of IK_QP is the quadratic programme   min 1/2 x^T Q x + c^T x   s.t.  [J 1_6] x = e,   x = (dq, delta),
 // Q = diag(kj 1_n, (ks / sum|e|) 1_6),  c = (-jacobm(q) / km, 0)  (IK.py:1437-1497); the joint-limit velocity dampers add
 // inequality rows only when kq > 0.  Without them it is an equality-constrained strictly convex QP and has the closed form
@@ -241,11 +241,78 @@ template <int NJ, class PD>
 RTB_HD void ik_qp_gain(const double (&jac)[6 * NJ], const PD &p, double (&g)[NJ])
 {
     static_assert(NJ >= 6, "jacobm needs J J^T invertible: a redundant or square arm");
-    double jm[NJ];
-    jacobm<NJ>(jac, 63, jm);
-    const double s = 1.0 / (p.lambda * p.km);
+    if (p.km > 0.0) {                  // wave-uniform
+        double jm[NJ];
+        jacobm<NJ>(jac, 63, jm);
+        const double s = 1.0 / (p.lambda * p.km);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) g[j] = s * jm[j];
+        for (int j = 0; j < NJ; ++j) g[j] = s * jm[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) g[j] = 0.0;
+    }
+}
+
+// kq > 0: the joint-limit velocity dampers (IK.py:1453-1481) add, for every joint inside the influence distance pi of a limit,
+// ONE inequality row on its own velocity:   s_i dq_i <= beta_i,
+//      near the upper limit  s = +1, beta = ((hi - q) - ps) / (pi - ps) / kq;   near the lower  s = -1, beta = ((q - lo) - ps) / (pi - ps) / kq
+// (the lower-limit test comes second in the reference and overrides).  With the slack eliminated the programme is a strictly
+// convex QP in dq with one-sided bounds, H = kj 1 + (ks / sum|e|) J^T J.  Primal-dual active set: with a set A of joints held
+// on their bounds (dq_i = s_i beta_i) the rest has the closed form above on the remaining columns,
+//      y = (J_F J_F^T + d^2 1)^-1 (e - J_A v_A - J_F g_F),     u_i = g_i + J_i^T y   for every joint
+// (u_i is the free joint's step, and for a held joint kj s_i (u_i - v_i) is its multiplier), and the next set is simply
+//      A' = { i constrained :  s_i u_i > beta_i }
+// -- a free joint that violates its bound is held, a held joint whose multiplier turns negative is released.  A' = A is the
+// KKT point, the unique minimiser (what quadprog returns to rounding).  Every lane of the wave runs the same number of rounds
+// (a converged lane recomputes the same numbers); no fixed point after kIkQpRounds rounds reports failure, which the solver
+// loop treats like the reference's "QP Unsolvable" (numpy.linalg.LinAlgError: the search is abandoned, IK.py:320-323).
+constexpr int kIkQpRounds = 12;
+template <int NJ, class PD, class QL, class QA>
+RTB_HD bool ik_qp_bounded(const double (&jac)[6 * NJ], const double (&e)[6], double d2, const double (&g)[NJ], const PD &p, QL qlim, QA qa,
+                          double (&dq)[NJ])
+{
+    double sgn[NJ], beta[NJ];          // sgn 0: the joint has no row
+    const double scale = 1.0 / ((p.pi - p.ps) * p.kq);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const double qi = qa.get(j), lo = qlim[j], hi = qlim[NJ + j];
+        sgn[j] = 0.0; beta[j] = 0.0;
+        if (hi - qi <= p.pi) { beta[j] = ((hi - qi) - p.ps) * scale; sgn[j] = 1.0; }
+        if (qi - lo <= p.pi) { beta[j] = ((qi - lo) - p.ps) * scale; sgn[j] = -1.0; }
+    }
+    unsigned act = 0;
+    bool fixed_point = false;
+    for (int round = 0; round < kIkQpRounds; ++round) {
+        double B[6][6], ep[6], y[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            double a = e[r];
+#pragma unroll
+            for (int k = 0; k < NJ; ++k) a -= jac[r * NJ + k] * (((act >> k) & 1u) ? sgn[k] * beta[k] : g[k]);
+            ep[r] = a;
+#pragma unroll
+            for (int c = 0; c <= r; ++c) {
+                double b = 0.0;
+#pragma unroll
+                for (int k = 0; k < NJ; ++k) b += ((act >> k) & 1u) ? 0.0 : jac[r * NJ + k] * jac[c * NJ + k];
+                B[r][c] = (r == c) ? b + d2 : b;
+            }
+        }
+        ldl_solve<6>(B, ep, y);
+        unsigned next = 0;
+#pragma unroll
+        for (int k = 0; k < NJ; ++k) {
+            double u = g[k];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) u += jac[r * NJ + k] * y[r];
+            if (sgn[k] != 0.0 && sgn[k] * u > beta[k]) next |= 1u << k;
+            dq[k] = ((act >> k) & 1u) ? sgn[k] * beta[k] : u;
+        }
+        fixed_point = next == act;
+        if (!wave_any(!fixed_point)) break;
+        act = next;                    // (a lane at its fixed point keeps its set: next == act)
+    }
+    return fixed_point;
 }
 
 // ---------------------------------------------------------------- searches as pure functions
@@ -376,6 +443,7 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, Q
         if (PINV && p.method == 5) ik_qp_gain<NJ>(jac, p, qn);  // IK_QP's manipulability term (wave-uniform branch)
         else ik_qnull<NJ>(jac, p, qlim, qa, qn);                // IK.py:753,1011,1210 (before the step: J dies in it)
     }
+    bool qp_ok = true, qp_done = false;
     if (PINV) {                     // 3 Gauss-Newton, 4 Newton-Raphson (`lambda` carries pinv_damping), 5 IK_QP (`lambda` carries kj)
         int rows = 63;
         double d2 = 0.0;
@@ -390,24 +458,31 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, Q
 #pragma unroll
             for (int k = 0; k < 6; ++k) se += fabs(e[k]);
             d2 = p.lambda * se / p.ks;                          // IK.py:1442-1446
-            if constexpr (NULLSP) {                             // e - J g
+            if constexpr (NULLSP) {
+                if (p.kq > 0.0) {                               // inequality rows: active-set rounds (wave-uniform branch)
+                    qp_ok = ik_qp_bounded<NJ>(jac, e, d2, qn, p, qlim, qa, dq);
+                    qp_done = true;
+                } else {                                        // e - J g
 #pragma unroll
-                for (int r = 0; r < 6; ++r) {
-                    double a = e[r];
+                    for (int r = 0; r < 6; ++r) {
+                        double a = e[r];
 #pragma unroll
-                    for (int k = 0; k < NJ; ++k) a -= jac[r * NJ + k] * qn[k];
-                    e[r] = a;
+                        for (int k = 0; k < NJ; ++k) a -= jac[r * NJ + k] * qn[k];
+                        e[r] = a;
+                    }
                 }
             }
         }
-        ik_pinv_step<NJ>(jac, e, rows, d2, &p.we[0], p.method == 3, dq);
+        if (!qp_done) ik_pinv_step<NJ>(jac, e, rows, d2, &p.we[0], p.method == 3, dq);
     } else {
         const double wn = (p.method == 1) ? p.lambda : (p.method == 2) ? E + p.lambda : p.lambda * E;   // ik.cpp:169,183,205
         ik_lm_step<NJ>(jac, e, &p.we[0], wn, dq);
     }
     if constexpr (NULLSP) {
+        if (!qp_done) {                // (the bounded QP returns the whole step)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) dq[j] += qn[j];
+            for (int j = 0; j < NJ; ++j) dq[j] += qn[j];
+        }
     }
     if (st.status != kIkRun || st.fin) return;    // a search that has ended waits, untouched, for the next pass
     const bool arrived = E < p.tol;
@@ -430,7 +505,7 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, Q
         }
     } else {
         st.iter++;                                              // IK.py:315
-        if ((PINV || NULLSP) && !q_finite) {
+        if ((PINV || NULLSP) && (!q_finite || !qp_ok)) {
             // numpy.linalg.pinv raises LinAlgError on a non-finite J (LAPACK gesdd refuses NaN: info != 0), and J -- a polynomial in
             // the sines and cosines -- is non-finite exactly when q is.  IK.py:320-323: the search is abandoned, the iteration
             // counted, E and q left as the last completed step had them.  (numpy.linalg.inv of the plain LM step does not raise.)
@@ -460,7 +535,7 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, Q
 template <class PD>
 RTB_HD int ik_step_variant(const PD &p, int n)
 {
-    const bool extra = p.method == 5 ? p.km > 0.0 : p.kq > 0.0;     // IK_QP: the manipulability term; the others: null-space motion
+    const bool extra = p.method == 5 ? (p.km > 0.0 || p.kq > 0.0) : p.kq > 0.0;     // IK_QP: manipulability term / inequality rows; the others: null-space motion
     return (p.method >= 3 ? kIkStepPinv : 0) | ((extra && n >= 6 && n <= 12) ? kIkStepNull : 0);
 }
 template <int NJ, class PD, class CV, class QL, class TD, class QA>

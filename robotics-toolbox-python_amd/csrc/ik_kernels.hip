@@ -412,15 +412,10 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
     p.seed = ip.seed;
     p.N = N;
     p.kq = ip.kq; p.km = ip.km; p.ps = ip.ps; p.pi = ip.pi; p.ks = ip.ks;
-    if (p.method == 5) {                     // IK_QP (ik_device.h): the equality-constrained case has a closed-form step
-        if (p.kq > 0.0) {
-            set_error("ik_qp: kq > 0 adds inequality rows (joint-limit velocity dampers) to the QP; only the equality-constrained problem (kq = 0, the reference's default) is solved on the device");
-            return RTBHIP_ELIMIT;
-        }
-        if (p.km > 0.0 && (c->n > kIkNullMax || c->n < 6)) {
-            set_error("ik_qp: the manipulability term (km > 0) is built for chains of 6..12 joints");
-            return RTBHIP_ELIMIT;
-        }
+    if (p.method == 5 && (p.km > 0.0 || p.kq > 0.0) && (c->n > kIkNullMax || c->n < 6)) {
+        // IK_QP (ik_device.h): the manipulability term needs J J^T invertible, and both live in the one-wave-per-SIMD step variants
+        set_error("ik_qp: the manipulability term (km > 0) and the joint-limit rows (kq > 0) are built for chains of 6..12 joints");
+        return RTBHIP_ELIMIT;
     }
     if (p.method != 5 && p.kq > 0.0 && (c->n > kIkNullMax || c->n < 6)) {
         // below 6 joints I - pinv(J) J vanishes only away from singularities; the reference still applies it there, so the

@@ -733,9 +733,9 @@ class ETS:
                  kj=1.0, ks=1.0, kq=0.0, km=0.0, ps=0.0, pi=0.3, **kwargs):
         """The quadratic-programming solver (reference ETS.ikine_QP robot/ETS.py:2932-3110 -> IK_QP robot/IK.py:1222-1520;
         note the two defaults of the reference: kj = 1.0 here, 0.01 in the IK_QP class).  Each step minimises
-        kj/2 |dq|^2 + ks/(2 sum|e|) |slack|^2 - jacobm.dq/km subject to J dq + slack = e; without inequality rows the programme
-        has a closed form (csrc/ik_device.h) and runs per lane like the other solvers.  kq > 0 (joint-limit velocity dampers as
-        inequality rows) is refused loudly (RtbHipError), as is km > 0 on chains outside 6..12 joints."""
+        kj/2 |dq|^2 + ks/(2 sum|e|) |slack|^2 - jacobm.dq/km subject to J dq + slack = e and, when kq > 0, to one velocity-damper
+        row per joint inside the influence distance pi of a limit; solved per lane on the device (closed form without rows, a
+        primal-dual active set with them: csrc/ik_device.h) -- no qpsolvers dependency.  km > 0 / kq > 0 need 6..12 joints."""
         return self._ikine_pinv("qp", Tep, q0, ilimit, slimit, tol, mask, joint_limits, seed, True, kq, km, ps, pi, qp=(kj, ks))
 
     def ik_restart(self, seed, target, search):

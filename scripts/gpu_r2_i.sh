@@ -16,9 +16,9 @@ N = 100000
 rng = np.random.default_rng(1)
 Tep = ets.eval(torch.from_numpy(rng.uniform(ets.qlim[0], ets.qlim[1], (N, 7))).cuda())
 for name, fn in (("ikine_LM", lambda: ets.ikine_LM(Tep, seed=2)), ("ikine_QP kj=0.01 (IK_QP class default)", lambda: ets.ikine_QP(Tep, seed=2, kj=0.01)),
-                 ("ikine_QP kj=1 (ETS.ikine_QP default)", lambda: ets.ikine_QP(Tep, seed=2)), ("ikine_NR pinv", lambda: ets.ikine_NR(Tep, seed=2, pinv=True))):
+                 ("ikine_QP kj=1 (ETS.ikine_QP default)", lambda: ets.ikine_QP(Tep, seed=2)), ("ikine_QP kj=0.01 kq=1 (velocity-damper rows)", lambda: ets.ikine_QP(Tep, seed=2, kj=0.01, kq=1.0)), ("ikine_NR pinv", lambda: ets.ikine_NR(Tep, seed=2, pinv=True))):
     fn(); torch.cuda.synchronize()
     t = time.perf_counter(); s = fn(); torch.cuda.synchronize(); dt = time.perf_counter() - t
-    print("%-40s %7.2f ms  success %.4f  mean it %.1f" % (name, dt * 1e3, s.each["success"].mean(), s.each["iterations"].mean()))
+    print("%-46s %7.2f ms  success %.4f  mean it %.1f" % (name, dt * 1e3, s.each["success"].mean(), s.each["iterations"].mean()))
 PY
 timeout 200 python /tmp/qp_time.py 2>&1 | grep -v amdgpu.ids | tee $O/qp_time.txt

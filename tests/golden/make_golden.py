@@ -140,12 +140,16 @@ def python_ik():
     run("lm_wampler_ns_km", "IK_LM", Tn, q0n, 3, method="wampler", k=0.01, kq=0.0, km=0.5)               # km alone: the guard at IK.py:572 drops it
     run("nr_ns", "IK_NR", Tn, q0n, 3, pinv=True, kq=0.01, km=1.0)                                        # tests/test_IK.py:166-173
     run("gn_ns", "IK_GN", Tn, q0n, 3, pinv=True, kq=1.0, km=1.0)                                         # tests/test_IK.py:261-263
-    # ---- IK_QP .solve (robot/IK.py:1222-1520), kq = 0: the reference's own step code; the absent qpsolvers/quadprog is
-    # stood in for by an exact KKT solve of the equality-constrained programme (oracle/ref_python.solve_qp)
+    # ---- IK_QP .solve (robot/IK.py:1222-1520): the reference's own step code; the absent qpsolvers/quadprog is stood in for by
+    # the exact enumerating solver of oracle/qp.py (the minimiser of a strictly convex QP is unique)
     run("qp_class_default", "IK_QP", Tep, None, 100)                                                      # IK_QP(): kj = 0.01, ks = 1
     run("qp_ets_default_q0", "IK_QP", Tn, q0n, 5, kj=1.0, ks=1.0)                                          # ETS.ikine_QP defaults (ETS.py:2942)
     run("qp_km", "IK_QP", Tn, q0n, 3, kj=0.1, ks=1.0, km=10.0)
     run("qp_mask_nojl", "IK_QP", Tep, q0, 20, kj=0.1, ks=2.0, joint_limits=False, mask=[1, 1, 1, 0.5, 0.5, 0.25])
+    # kq > 0: the velocity dampers become inequality rows (IK.py:1453-1481); near-limit problems so rows are active
+    run("qp_kq", "IK_QP", Tn, q0n, 3, kj=0.01, ks=1.0, kq=1.0, ps=0.0, pi=0.3)
+    run("qp_kq_km", "IK_QP", Tn, q0n, 3, kj=0.1, ks=1.0, kq=0.5, km=10.0, ps=0.05, pi=0.4)
+    run("qp_kq_far", "IK_QP", Tep, None, 30, kj=0.01, ks=1.0, kq=2.0, ps=0.0, pi=0.3)
     path = os.path.join(HERE, "ref_python_ik.npz")
     np.savez_compressed(path, **out)
     print("wrote ref_python_ik.npz with", len(out), "arrays,", os.path.getsize(path), "bytes")

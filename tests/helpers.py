@@ -42,6 +42,9 @@ PY_IK_CASES = {
     "qp_ets_default_q0": ("ikn", True, 5, "qp", dict(kj=1.0, ks=1.0)),
     "qp_km": ("ikn", True, 3, "qp", dict(kj=0.1, ks=1.0, km=10.0)),
     "qp_mask_nojl": ("ik", True, 20, "qp", dict(kj=0.1, ks=2.0, joint_limits=False, mask=[1, 1, 1, 0.5, 0.5, 0.25])),
+    "qp_kq": ("ikn", True, 3, "qp", dict(kj=0.01, ks=1.0, kq=1.0, ps=0.0, pi=0.3)),
+    "qp_kq_km": ("ikn", True, 3, "qp", dict(kj=0.1, ks=1.0, kq=0.5, km=10.0, ps=0.05, pi=0.4)),
+    "qp_kq_far": ("ik", False, 30, "qp", dict(kj=0.01, ks=1.0, kq=2.0, ps=0.0, pi=0.3)),
 }
 
 

@@ -640,18 +640,21 @@ def test_ik_cross_wave_sharing_and_phased_schedule_equal_plain(flavour):
 
 
 def test_ik_qp_error_paths_and_batch_vs_oracle():
-    """ETS.ikine_QP (IK_QP, robot/IK.py:1222-1520): inequality rows (kq > 0) and the manipulability term on a 5-joint arm are
-    refused loudly; a UR5 batch on device tensors equals the KKT restatement target by target."""
+    """ETS.ikine_QP (IK_QP, robot/IK.py:1222-1520): the manipulability term / the joint-limit rows on a 5-joint arm and ps == pi
+    are refused loudly; a UR5 batch on device tensors equals the restatement (the reference's matrices + an exact enumerating QP
+    solver) target by target, without and with inequality rows."""
     import torch
     from rtbhip import urdf as U
     from helpers import chain_from_ets
     panda, _ = _panda_limited()
     with pytest.raises(rtbhip.RtbHipError):
-        panda.ikine_QP(np.eye(4), kq=0.1)
+        panda.ikine_QP(np.eye(4), kq=0.1, ps=0.3, pi=0.3)
     with pytest.raises(rtbhip.RtbHipError):
         panda.ikine_QP(np.eye(4), kj=0.0)
     with pytest.raises(rtbhip.RtbHipError):
         U.load("px100").ets().ikine_QP(np.eye(4), km=1.0)
+    with pytest.raises(rtbhip.RtbHipError):
+        U.load("px100").ets().ikine_QP(np.eye(4), kq=1.0)
     e = U.load("UR5").ets()
     e.qlim = np.clip(e.qlim, -np.pi, np.pi)
     ch = chain_from_ets(e)
@@ -660,14 +663,15 @@ def test_ik_qp_error_paths_and_batch_vs_oracle():
     qs = rng.uniform(ch.qlim[0] * 0.8, ch.qlim[1] * 0.8, (N, 6))
     Tep = oracle.fkine(ch, qs)
     q0 = qs + 0.15 * rng.normal(size=qs.shape)
-    sol = e.ikine_QP(torch.from_numpy(Tep).cuda(), q0=torch.from_numpy(q0).cuda(), seed=8, slimit=3, kj=0.01)
-    for i in range(0, N, 7):
-        rs = np.array([q0[i]] + [e.ik_restart(8, i, d) for d in range(1, 3)])
-        o = oracle.ikine_py(ch, Tep[i], rs, step="qp", slimit=3, kj=0.01, ks=1.0)
-        assert (o[1], o[2], o[3]) == (sol.each["success"][i], sol.each["iterations"][i], sol.each["searches"][i])
-        if o[1]:
-            nt.assert_allclose(sol.q[i], o[0], atol=1e-7)
-    assert sol.each["success"].mean() > 0.8
+    for kw in (dict(kj=0.01), dict(kj=0.01, kq=1.0, ps=0.0, pi=0.5)):
+        sol = e.ikine_QP(torch.from_numpy(Tep).cuda(), q0=torch.from_numpy(q0).cuda(), seed=8, slimit=3, **kw)
+        for i in range(0, N, 7):
+            rs = np.array([q0[i]] + [e.ik_restart(8, i, d) for d in range(1, 3)])
+            o = oracle.ikine_py(ch, Tep[i], rs, step="qp", slimit=3, ks=1.0, **kw)
+            assert (o[1], o[2], o[3]) == (sol.each["success"][i], sol.each["iterations"][i], sol.each["searches"][i])
+            if o[1]:
+                nt.assert_allclose(sol.q[i], o[0], atol=1e-7)
+        assert sol.each["success"].mean() > 0.8
 
 
 def test_branches_of_a_tree_robot_read_the_robot_wide_q():

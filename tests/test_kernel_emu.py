@@ -476,11 +476,13 @@ def test_ik_gn_nr_on_arms_with_fewer_than_six_joints(robot):
 
 
 @pytest.mark.parametrize("robot,kw", [("AL5D", dict(kj=0.05, ks=1.0)), ("px100", dict(kj=0.01, ks=2.0)), ("UR5", dict(kj=0.01, ks=1.0)),
-                                      ("Fetch", dict(kj=0.02, ks=1.0, km=500.0)), ("KinovaGen3", dict(kj=1.0, ks=1.0))])
+                                      ("Fetch", dict(kj=0.02, ks=1.0, km=500.0)), ("KinovaGen3", dict(kj=1.0, ks=1.0)),
+                                      ("UR5", dict(kj=0.01, ks=1.0, kq=1.0, ps=0.0, pi=0.6)), ("KinovaGen3", dict(kj=0.05, ks=1.0, kq=0.5, km=200.0, ps=0.05, pi=0.5))])
 def test_ik_qp_joint_counts_against_the_kkt_restatement(robot, kw):
-    """IK_QP (robot/IK.py:1222-1520, kq = 0) on chains of 4, 5, 6, 9 and 10 joints: the device's closed-form step (a minimum-norm
-    step damped by kj sum|e| / ks, plus the manipulability term where km > 0) inside the Python solver's loop against the NumPy
-    restatement that builds the reference's Q, c, Aeq, beq and solves the KKT system.  Every target, every search: the QP step is
+    """IK_QP (robot/IK.py:1222-1520) on chains of 4, 5, 6, 9 and 10 joints: the device's step (closed form: a minimum-norm step
+    damped by kj sum|e| / ks, plus the manipulability term where km > 0; a primal-dual active set where kq > 0 adds velocity-damper
+    rows) inside the Python solver's loop against the NumPy restatement that builds the reference's Q, c, Aeq, beq, Ain, bin and
+    solves the programme by enumerating active sets (oracle/qp.py: a different method on purpose).  Every target, every search: the QP step is
     damped, so nothing is chaotic here.  (Panda: pinned on the reference's own IK_QP code in test_python_ik_pins.py.)"""
     from rtbhip import urdf
     from helpers import chain_from_ets
@@ -495,7 +497,7 @@ def test_ik_qp_joint_counts_against_the_kkt_restatement(robot, kw):
     Tep = oracle.fkine(ch, qs)
     q0 = np.clip(qs + 0.05 * span * rng.normal(size=qs.shape), ch.qlim[0], ch.qlim[1])
     emu.ik_qp_ks(kw["ks"])
-    emu.ik_nullspace(0.0, kw.get("km", 0.0), 0.0, 0.3)
+    emu.ik_nullspace(kw.get("kq", 0.0), kw.get("km", 0.0), kw.get("ps", 0.0), kw.get("pi", 0.3))
     try:
         q, ok, it, se, E = emu.ik(ets, Tep, q0=q0, method="qp", flavour=1, seed=6, slimit=4, k=kw["kj"])
         wav = emu.ik(ets, Tep, q0=q0, method="qp", flavour=1, seed=6, slimit=4, k=kw["kj"], waves=2)

@@ -190,6 +190,36 @@ def test_oracle_python_ik_matches_reference_IK_py(key):
     assert checked >= (len(Tep) if step in ("lm", "qp") else 6)
 
 
+def test_oracle_qp_solver_against_scipy():
+    """oracle/qp.py (the stand-in for qpsolvers/quadprog behind the reference's IK_QP.step: enumeration of active sets + KKT
+    solves) against scipy.optimize SLSQP on random programmes of IK_QP's shape: same minimiser (to SLSQP's accuracy), same
+    objective to 1e-10, constraints satisfied, and at least half of the programmes with an active row."""
+    from scipy.optimize import minimize
+    from oracle import qp
+    rng = np.random.default_rng(5)
+    active = 0
+    for trial in range(30):
+        n = 7
+        J = rng.normal(size=(6, n)); e = rng.normal(size=6) * 0.3
+        P = np.eye(n + 6); P[:n, :n] *= 0.01; P[n:, n:] = 1.0 / np.abs(e).sum() * np.eye(6)
+        c = np.concatenate((rng.normal(size=n) * 0.01, np.zeros(6)))
+        A = np.concatenate((J, np.eye(6)), axis=1)
+        G = np.zeros((n + 6, n + 6)); h = np.zeros(n + 6)
+        for i in range(n):
+            if rng.random() < 0.5:
+                G[i, i] = rng.choice([-1.0, 1.0]); h[i] = rng.uniform(-0.02, 0.05)
+        x = qp.solve_qp(P, c, G, h, A, e)
+        assert x is not None
+        f = lambda z: 0.5 * z @ P @ z + c @ z
+        res = minimize(f, np.zeros(n + 6), jac=lambda z: P @ z + c, method="SLSQP",
+                       constraints=[{"type": "eq", "fun": lambda z: A @ z - e, "jac": lambda z: A},
+                                    {"type": "ineq", "fun": lambda z: h - G @ z, "jac": lambda z: -G}], options={"ftol": 1e-15, "maxiter": 1000})
+        assert np.abs(A @ x - e).max() < 1e-12 and np.all(G @ x - h <= 1e-12)
+        assert f(x) <= f(res.x) + 1e-10 and np.abs(x - res.x).max() < 1e-5
+        active += int(np.any(np.abs((G @ x - h)[np.any(G != 0, axis=1)]) < 1e-10))
+    assert active >= 15
+
+
 @pytest.mark.skipif(not ref_harness.available(), reason="oracle/_ref not built here")
 def test_oracle_matches_live_reference_build():
     rng = np.random.default_rng(99)
