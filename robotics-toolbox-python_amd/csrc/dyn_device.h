@@ -40,14 +40,22 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, cons
 #pragma unroll 1
         for (int i = 0; i < NJ; ++i) {
             dyn_opaque<NJ>(st, ct);
-            // inertia: the full row as computed (the reference returns the unsymmetrised matrix); accel: only the lower
-            // triangle the LDL^T solve reads, packed -- 28 instead of 49 doubles of LDS per lane for n = 7
-            rne_core<NJ, MDH, true, ALLREV, true>(links, NJ, st, ct, zero, zero, zero, qin, [&](int) { return 0.0; },
-                                    [&](int j) { return j == i ? 1.0 : 0.0; },
-                                    [&](int j, double v) {
-                                        if (MODE == kDynAccel) { if (j <= i) mA[i * (i + 1) / 2 + j] = v; }
-                                        else mA[i * NJ + j] = v;
-                                    });
+            if constexpr (ALLREV) {
+                // column i of M from the acceleration-only pass (rne_device.h): torques of joints j >= i = entries (j, i) of the
+                // packed lower triangle -- what accel's LDL^T solve reads, and what the inertia kernel's flush mirrors into (n, n)
+                rne_core<NJ, MDH, false, true, true, true>(links, NJ, st, ct, zero, zero, zero, qin, [&](int) { return 0.0; },
+                                        [&](int j) { return j == i ? 1.0 : 0.0; },
+                                        [&](int j, double v) { mA[j * (j + 1) / 2 + i] = v; }, i);
+            } else {
+                // inertia: the full row as computed (the reference returns the unsymmetrised matrix); accel: only the lower
+                // triangle the LDL^T solve reads, packed -- 28 instead of 49 doubles of LDS per lane for n = 7
+                rne_core<NJ, MDH, true, ALLREV, true>(links, NJ, st, ct, zero, zero, zero, qin, [&](int) { return 0.0; },
+                                        [&](int j) { return j == i ? 1.0 : 0.0; },
+                                        [&](int j, double v) {
+                                            if (MODE == kDynAccel) { if (j <= i) mA[i * (i + 1) / 2 + j] = v; }
+                                            else mA[i * NJ + j] = v;
+                                        });
+            }
         }
     }
     if (MODE == kDynAccel) {

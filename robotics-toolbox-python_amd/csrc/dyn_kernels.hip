@@ -57,11 +57,39 @@ struct DynLayout {
     static constexpr bool alias_q = (MODE == kDynCoriolis || MODE == kDynAccel) && ALLREV;
     static constexpr int K = MODE == kDynInertia ? 1 : (MODE == kDynCoriolis ? 2 : 3);
     static constexpr int in_stride = (((MODE == kDynCoriolis || MODE == kDynAccel) && ALLREV ? K - 1 : K) * NJ) | 1;
-    static constexpr int W = MODE == kDynAccel ? (NJ * (NJ + 1) / 2 > NJ ? NJ * (NJ + 1) / 2 : NJ) : NJ * NJ;   // accel: packed lower triangle of M
+    // accel: packed lower triangle of M; inertia of an all-revolute chain too (its columns come from the mirrored
+    // acceleration-only passes of rne_device.h, so the tile holds 28 instead of 49 doubles per lane for n = 7 -- 6 -> 10 waves per
+    // CU -- and the flush expands it to the full matrix)
+    static constexpr bool packed = MODE == kDynAccel || (MODE == kDynInertia && ALLREV);
+    static constexpr int W = packed ? (NJ * (NJ + 1) / 2 > NJ ? NJ * (NJ + 1) / 2 : NJ) : NJ * NJ;
     static constexpr int w_stride = W | 1;
     static constexpr int tiles = 1;                                // coriolis too: Csq is folded into C as it is produced (dyn_device.h)
     static constexpr int doubles = kDW * ((alias_in ? 0 : in_stride) + tiles * w_stride);
 };
+
+// packed lower triangles (row r, column c <= r at r (r + 1) / 2 + c) of ncfg lanes -> the full symmetric (n, n) matrices as one
+// contiguous run of 16-byte non-temporal stores
+template <int NJ>
+__device__ __forceinline__ void flush_symmetric(const double *rows, int stride, int ncfg, double *__restrict__ dst, int lane)
+{
+    constexpr int W = NJ * NJ;
+    const int total = ncfg * W;
+    auto at = [&](int f) {
+        const int cfg = f / W, rem = f - cfg * W, r = rem / NJ, c = rem - r * NJ;
+        const int hi = r > c ? r : c, lo = r > c ? c : r;
+        return rows[cfg * stride + hi * (hi + 1) / 2 + lo];
+    };
+    for (int f = 2 * lane; f < total; f += 2 * kDW) {
+        const double a = at(f);
+        if (f + 1 < total) {
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            v2d w = {a, at(f + 1)};
+            __builtin_nontemporal_store(w, reinterpret_cast<v2d *>(dst + f));
+        } else {
+            __builtin_nontemporal_store(a, dst + f);
+        }
+    }
+}
 
 template <int NJ, bool MDH, int MODE, bool ALLREV>
 __global__ __launch_bounds__(kDW, (NJ <= 8 ? 2 : 1)) void k_dyn(DynParams dp, const DevLink *links_g, const double *__restrict__ q,
@@ -109,6 +137,7 @@ __global__ __launch_bounds__(kDW, (NJ <= 8 ? 2 : 1)) void k_dyn(DynParams dp, co
     }
     __syncthreads();
     if (MODE == kDynAccel) flush_run(A, L::w_stride, NJ, ncfg, out + cfg0 * NJ, lane);
+    else if (MODE == kDynInertia && L::packed) flush_symmetric<NJ>(A, L::w_stride, ncfg, out + cfg0 * (NJ * NJ), lane);
     else flush_run(A, L::w_stride, L::W, ncfg, out + cfg0 * L::W, lane);
 }
 

@@ -52,6 +52,9 @@ constexpr int kIkNullMax = 12;   // null-space step variants: 6..8 joints in reg
 #ifndef RTB_IK_WAVES
 #define RTB_IK_WAVES 2
 #endif
+#ifndef RTB_IK_SHARE
+#define RTB_IK_SHARE 1          // 0: build without the cross-wave sharing code (A/B of what its presence costs the plain schedule)
+#endif
 template <int NJ, int STEP>
 __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull) ? RTB_IK_WAVES : 1)) void k_ik(IkDev p, DevChain dc, const double *qlim_g, const double *__restrict__ Tep,
                                                 const double *__restrict__ q0, unsigned long long *counter,
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
     const long long patience = ik_patience(p, s_last);    // watchdog budget (ik_device.h), the pass latency included
     long long quiet = 0;
     const unsigned long long NN = count_g ? (unsigned long long)*count_g : (unsigned long long)p.N;   // wave-uniform
-    const bool sharing = share_g.tc != nullptr;   // wave-uniform
+    const bool sharing = RTB_IK_SHARE && share_g.tc != nullptr;   // wave-uniform
     unsigned long long pend_item = kIkNoItem;   // sharing, wave-uniform: a range handed to this wave (ticket pend_tick of its queue), started at the next pass
     unsigned pend_tick = 0;
     for (;;) {

@@ -195,10 +195,27 @@ RTB_HD BwdOps bwd_ops(const LinkT &lt, int flags, int j, InQ qin, InQd qdin, InQ
     return o;
 }
 
-template <int NJ, bool MDH, bool FRICTION, bool ALLREV, bool HAVE_TRIG, class LinksP, class InQ, class InQd, class InQdd, class Out>
+// ACC (all-revolute chains, compile-time n): the pass is known to run at qd = 0 and zero gravity with the links before `first`
+// at rest -- what Dynamics.inertia / accel ask for column `first` of M(q): qdd = e_first (robot/Dynamics.py:752-758, 492-496).
+// Then w = 0 throughout, every link before `first` has F = N = 0, and -- M being symmetric -- only the torques of joints
+// >= first are needed: the forward recursion starts at `first` without its velocity terms, the backward one stops there, and
+// the caller mirrors the column.  The terms left out are exact zeros of the general formulas (0 x + y = y), so the values are
+// those of the full pass (up to the sign of a zero); the mirrored half differs from the reference's separately rounded entries
+// by a few ulp.  ~2.3x fewer fp64 operations per column of a 7-joint arm.
+template <int NJ, bool MDH, bool FRICTION, bool ALLREV, bool HAVE_TRIG, bool ACC = false, class LinksP, class InQ, class InQd, class InQdd, class Out>
 RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_MAX_JOINTS], double (&ct)[NJ > 0 ? NJ : RTBHIP_MAX_JOINTS],
-                     V3 grav, V3 ftip, V3 ntip, InQ qin, InQd qdin, InQdd qddin, Out tau)
+                     V3 grav, V3 ftip, V3 ntip, InQ qin, InQd qdin, InQdd qddin, Out tau, int first = 0)
 {
+    static_assert(!ACC || (ALLREV && NJ > 0 && HAVE_TRIG), "the acceleration-only pass is built for all-revolute chains with compile-time n");
+    if constexpr (ACC) {
+        // `first` is the caller's pass counter: keep the optimiser from splitting the caller's loop into one specialised copy of this
+        // whole recursion per value of it (the host build of tests/emu did not finish in 45 minutes); on the device it stays scalar
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+s"(first));
+#else
+        asm volatile("" : "+r"(first));
+#endif
+    }
     constexpr int CAP = NJ > 0 ? NJ : RTBHIP_MAX_JOINTS;
     const int n = NJ > 0 ? NJ : n_rt;
     V3 F[CAP], Nn[CAP];
@@ -228,6 +245,26 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
         const double d = pris ? (NJ == 0 ? qin(j) : cur.qj) + l.offset : l.d;
         const Rot R = {st[j], ct[j], l.sa, l.ca};
         const V3 ps = link_offset<MDH>(l, d);
+        if constexpr (ACC) {
+            if (j >= first) {          // wave-uniform
+                V3 wdn, an;
+                if (MDH) {             // w = 0:  wd' = R^T wd + z qdd,  a' = R^T (a + wd x p*)
+                    wdn = addz(rot_inv<MDH>(R, wd), qddj);
+                    an = rot_inv<MDH>(R, cross_add(wd, ps, a));
+                } else {               //         wd' = R^T (wd + z qdd),  a' = wd' x p* + R^T a
+                    wdn = rot_inv<MDH>(R, v3(wd.x, wd.y, wd.z + qddj));
+                    an = cross_add(wdn, ps, rot_inv<MDH>(R, a));
+                }
+                wd = wdn; a = an;
+                V3 ac = a;
+                if (!(flg[j] & kLinkRZero)) ac = cross_add(wd, v3(li.rx, li.ry, li.rz), a);
+                F[j] = l.m * ac;
+                Nn[j] = (flg[j] & kLinkIDiag) ? v3(li.I[0] * wd.x, li.I[4] * wd.y, li.I[8] * wd.z) : inertia_times(li, wd);
+            }
+            cur = nxt;
+            if (!PF && !RTB_RNE_NOFENCE) sched_fence();
+            continue;
+        }
         const V3 qdv = v3(0, 0, qdj);
         V3 qddv = v3(qddx, qddy, qddj);
         V3 wn, wdn, an;
@@ -305,6 +342,7 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
 #pragma unroll
     for (int jj = 0; jj < n; ++jj) {
         const int j = n - 1 - jj;
+        if (ACC && j < first) break;   // wave-uniform: the torques of the joints before `first` come from the mirror
         if (!PF && jj > 0) bc = bwd_ops<ALLREV, FRICTION>(links[j], flg[j], j, qin, qdin, qddin);
         BwdOps bn = bc;
         if (PF) sched_fence();

@@ -738,7 +738,15 @@ static void dyn_run(const Dyn *d, const double *q, const double *qd, const doubl
         if (allrev) dyn_lane<NJ, MDH, MODE, true>(links, in.data(), A.data(), g);
         else dyn_lane<NJ, MDH, MODE, false>(links, in.data(), A.data(), g);
         const int W = MODE == kDynAccel ? NJ : NJ * NJ;
-        for (int k = 0; k < W; ++k) out[s * W + k] = A[k];
+        if (MODE == kDynInertia && allrev) {           // packed lower triangle -> (n, n), as the kernel's flush_symmetric
+            for (int r = 0; r < NJ; ++r)
+                for (int c = 0; c < NJ; ++c) {
+                    const int hi = r > c ? r : c, lo = r > c ? c : r;
+                    out[s * W + r * NJ + c] = A[hi * (hi + 1) / 2 + lo];
+                }
+        } else {
+            for (int k = 0; k < W; ++k) out[s * W + k] = A[k];
+        }
     }
 }
 template <int NJ>
