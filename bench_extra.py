@@ -147,8 +147,14 @@ def main():
             line = {"metric": "configurations/sec (DH Panda %s)" % name, "value": N / (avg * 1e-3), "unit": "configurations/s",
                     "n": N, "kernel_avg_ms": avg, "kernel_min_ms": best, "rne_passes_per_config": passes,
                     "rne_passes_per_s": passes * N / (avg * 1e-3),
-                    "roofline": {"bound": "fp64-valu", "achieved": byts * N / (avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                 "frac": byts * N / (avg * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": byts * N}}
+                    "pass_kind": {"inertia": "acceleration-only passes from link i on, mirrored (csrc/rne_device.h ACC)",
+                                  "coriolis": "full passes (the reference's C is not symmetric)",
+                                  "accel": "1 full pass + 7 acceleration-only passes + LDL^T solve"}[name],
+                    # the HBM roof is the one these lines are priced against (algorithmic bytes / time); what actually limits the
+                    # kernels is fp64 issue at the occupancy their LDS tiles allow
+                    "roofline": {"bound": "hbm", "limited_by": "fp64 issue / LDS-set occupancy", "achieved": byts * N / (avg * 1e-3) / 1e9,
+                                 "peak": 8000.0, "unit": "GB/s", "frac": byts * N / (avg * 1e-3) / 1e9 / 8000.0,
+                                 "algorithmic_bytes_per_launch": byts * N}}
             if not args.no_cpu and name == "inertia":
                 from oracle import ref_harness
                 if ref_harness.available():

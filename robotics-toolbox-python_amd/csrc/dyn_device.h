@@ -25,6 +25,16 @@ RTB_HD void dyn_opaque(double (&st)[NJ], double (&ct)[NJ])
 #endif
 }
 
+// a[i] for a wave-uniform run-time i without indexing the register array (that would send it to scratch)
+template <int NJ>
+RTB_HD double dyn_pick(const double (&a)[NJ], int i)
+{
+    double r = 0.0;
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) r += (i == k) ? a[k] : 0.0;      // (a select chain gets turned back into an indexed load)
+    return r;
+}
+
 template <int NJ, bool MDH, int MODE, bool ALLREV, class LinksP>
 RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, const double *qrow = nullptr)
 {
@@ -35,6 +45,21 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, cons
     auto qin = [&](int j) { return qsrc[j]; };
     double st[NJ], ct[NJ];
     rne_trig<NJ, ALLREV>(links, qin, st, ct);      // every pass below is at the same q: sin/cos once
+    double b[NJ];
+    if (MODE == kDynAccel) {
+        // tau_0 = rne(q, qd, 0) with gravity and friction (Dynamics.py:500); b = torque - tau_0 stays in registers across the
+        // passes for M.  This pass comes FIRST so that the kernel may keep q, qd and torque in the M tile itself until here (the
+        // passes below overwrite them): 22.5 -> 14.8 KB of LDS per wave for n = 7, 7 -> 10 waves per CU
+        dyn_opaque<NJ>(st, ct);
+        rne_core<NJ, MDH, true, ALLREV, true>(links, NJ, st, ct, grav, zero, zero, qin, [&](int j) { return mine[NJ + j]; },
+                                [&](int) { return 0.0; }, [&](int j, double v) { b[j] = mine[2 * NJ + j] - v; });
+#if defined(__HIP_DEVICE_COMPILE__)
+        // the pass must be over -- its link state dead -- before the passes below start (scheduled together they spill)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(b[j]));
+        sched_fence();
+#endif
+    }
     if (MODE == kDynInertia || MODE == kDynAccel) {
         // row i of the result = tau for qdd = e_i, qd = 0, no gravity (Dynamics.py:752-758, :492-496)
 #pragma unroll 1
@@ -59,11 +84,8 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, cons
         }
     }
     if (MODE == kDynAccel) {
-        // tau_0 = rne(q, qd, 0) with gravity and friction (Dynamics.py:500), then M qdd = torque - tau_0
-        double b[NJ], x[NJ], M[NJ][NJ];
-        dyn_opaque<NJ>(st, ct);
-        rne_core<NJ, MDH, true, ALLREV, true>(links, NJ, st, ct, grav, zero, zero, qin, [&](int j) { return mine[NJ + j]; },
-                                [&](int) { return 0.0; }, [&](int j, double v) { b[j] = mine[2 * NJ + j] - v; });
+        // M qdd = torque - tau_0
+        double x[NJ], M[NJ][NJ];
 #pragma unroll
         for (int r = 0; r < NJ; ++r)
 #pragma unroll
@@ -79,12 +101,13 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, cons
         //          = 1/2 sum_{j != k} T_jk qd_j + Csq_k (2 qd_k - S / 2) - U / 2,   S = sum_j qd_j,  U = sum_j Csq_j qd_j
         // with T_jk the pass at QD = e_j + e_k and Csq_j the pass at QD = e_j (friction removed, :820).  Same terms,
         // different association: agreement with the reference order is ~1e-15 relative.
-        double S = 0.0, U[NJ];
+        // qd in registers: the kernel may keep the input row in the C tile itself, which the first pass starts to overwrite
+        double S = 0.0, U[NJ], qdv[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) { S += mine[NJ + j]; U[j] = 0.0; }
+        for (int j = 0; j < NJ; ++j) { qdv[j] = mine[NJ + j]; S += qdv[j]; U[j] = 0.0; }
 #pragma unroll 1
         for (int i = 0; i < NJ; ++i) {
-            const double qdi = mine[NJ + i], wi = 2.0 * qdi - 0.5 * S;
+            const double qdi = dyn_pick<NJ>(qdv, i), wi = 2.0 * qdi - 0.5 * S;
             dyn_opaque<NJ>(st, ct);
             rne_core<NJ, MDH, false, ALLREV, true>(links, NJ, st, ct, zero, zero, zero, qin, [&](int j) { return j == i ? 1.0 : 0.0; },
                                      [&](int) { return 0.0; }, [&](int r, double v) { mA[r * NJ + i] = v * wi; U[r] += v * qdi; });
@@ -97,7 +120,7 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, cons
         for (int i = 0; i < NJ; ++i) {
 #pragma unroll 1
             for (int j = i + 1; j < NJ; ++j) {
-                const double hi = 0.5 * mine[NJ + i], hj = 0.5 * mine[NJ + j];
+                const double hi = 0.5 * dyn_pick<NJ>(qdv, i), hj = 0.5 * dyn_pick<NJ>(qdv, j);
                 dyn_opaque<NJ>(st, ct);
                 rne_core<NJ, MDH, false, ALLREV, true>(links, NJ, st, ct, zero, zero, zero, qin,
                                          [&](int k) { return (k == i || k == j) ? 1.0 : 0.0; }, [&](int) { return 0.0; },

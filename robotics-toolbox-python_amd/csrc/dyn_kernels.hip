@@ -56,6 +56,10 @@ struct DynLayout {
     // coriolis of an all-revolute chain: the same for q; only the qd row keeps a place of its own (4 -> 5 waves per CU)
     static constexpr bool alias_q = (MODE == kDynCoriolis || MODE == kDynAccel) && ALLREV;
     static constexpr int K = MODE == kDynInertia ? 1 : (MODE == kDynCoriolis ? 2 : 3);
+    // accel of an all-revolute chain: q, qd and the torque row all live in the (packed) M tile until the first pass -- the full one,
+    // which leaves torque - tau_0 in registers -- has read them (dyn_device.h); needs 3 n <= n (n + 1) / 2, i.e. n >= 5
+    static constexpr bool alias_all = (MODE == kDynAccel && ALLREV && 3 * NJ <= NJ * (NJ + 1) / 2) ||
+                                      (MODE == kDynCoriolis && ALLREV && NJ >= 2);       // coriolis: q | qd in the n x n tile, qd copied to registers first
     static constexpr int in_stride = (((MODE == kDynCoriolis || MODE == kDynAccel) && ALLREV ? K - 1 : K) * NJ) | 1;
     // accel: packed lower triangle of M; inertia of an all-revolute chain too (its columns come from the mirrored
     // acceleration-only passes of rne_device.h, so the tile holds 28 instead of 49 doubles per lane for n = 7 -- 6 -> 10 waves per
@@ -64,7 +68,7 @@ struct DynLayout {
     static constexpr int W = packed ? (NJ * (NJ + 1) / 2 > NJ ? NJ * (NJ + 1) / 2 : NJ) : NJ * NJ;
     static constexpr int w_stride = W | 1;
     static constexpr int tiles = 1;                                // coriolis too: Csq is folded into C as it is produced (dyn_device.h)
-    static constexpr int doubles = kDW * ((alias_in ? 0 : in_stride) + tiles * w_stride);
+    static constexpr int doubles = kDW * ((alias_in || alias_all ? 0 : in_stride) + tiles * w_stride);
 };
 
 // packed lower triangles (row r, column c <= r at r (r + 1) / 2 + c) of ncfg lanes -> the full symmetric (n, n) matrices as one
@@ -104,12 +108,15 @@ __global__ __launch_bounds__(kDW, (NJ <= 8 ? 2 : 1)) void k_dyn(DynParams dp, co
     const int64_t left = dp.N - cfg0;
     const int ncfg = left < kDW ? (int)left : kDW;
     const int count = ncfg * NJ;
-    double *A = lds + (L::alias_in ? 0 : kDW * L::in_stride);   // n x n tile: M (inertia, accel) or C (coriolis)
-    double *in = L::alias_in ? A : lds;
-    constexpr int in_stride = L::alias_in ? L::w_stride : L::in_stride;
+    double *A = lds + (L::alias_in || L::alias_all ? 0 : kDW * L::in_stride);   // n x n tile: M (inertia, accel) or C (coriolis)
+    double *in = (L::alias_in || L::alias_all) ? A : lds;
+    constexpr int in_stride = (L::alias_in || L::alias_all) ? L::w_stride : L::in_stride;
     if (MODE == kDynInertia) { const double *const src[1] = {q}; dyn_load<NJ, 1>(in, in_stride, src, cfg0, count, lane); }
     if (MODE == kDynCoriolis) {
-        if (L::alias_q) {
+        if (L::alias_all) {
+            const double *const src[2] = {q, qd};
+            dyn_load<NJ, 2>(A, L::w_stride, src, cfg0, count, lane);
+        } else if (L::alias_q) {
             const double *const s0[1] = {q}, *const s1[1] = {qd};
             dyn_load<NJ, 1>(A, L::w_stride, s0, cfg0, count, lane);
             dyn_load<NJ, 1>(in, in_stride, s1, cfg0, count, lane);
@@ -119,7 +126,10 @@ __global__ __launch_bounds__(kDW, (NJ <= 8 ? 2 : 1)) void k_dyn(DynParams dp, co
         }
     }
     if (MODE == kDynAccel) {
-        if (L::alias_q) {
+        if (L::alias_all) {
+            const double *const src[3] = {q, qd, tq};
+            dyn_load<NJ, 3>(A, L::w_stride, src, cfg0, count, lane);
+        } else if (L::alias_q) {
             const double *const s0[1] = {q}, *const s1[2] = {qd, tq};
             dyn_load<NJ, 1>(A, L::w_stride, s0, cfg0, count, lane);
             dyn_load<NJ, 2>(in, in_stride, s1, cfg0, count, lane);
@@ -131,9 +141,9 @@ __global__ __launch_bounds__(kDW, (NJ <= 8 ? 2 : 1)) void k_dyn(DynParams dp, co
     __syncthreads();
     if (lane < ncfg) {
         // alias_q: the row holds qd only, at the offset dyn_lane expects it (mine[n + j])
-        const double *mine = in + lane * in_stride - (L::alias_q ? NJ : 0);
+        const double *mine = in + lane * in_stride - ((L::alias_q && !L::alias_all) ? NJ : 0);
         dyn_lane<NJ, MDH, MODE, ALLREV>(links, mine, A + lane * L::w_stride, v3(dp.grav[0], dp.grav[1], dp.grav[2]),
-                                        L::alias_q ? A + lane * L::w_stride : nullptr);
+                                        (L::alias_q && !L::alias_all) ? A + lane * L::w_stride : nullptr);
     }
     __syncthreads();
     if (MODE == kDynAccel) flush_run(A, L::w_stride, NJ, ncfg, out + cfg0 * NJ, lane);

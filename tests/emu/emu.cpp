@@ -735,8 +735,12 @@ static void dyn_run(const Dyn *d, const double *q, const double *qd, const doubl
         }
         bool allrev = true;
         for (const DevLink &l : d->links) allrev = allrev && l.sigma == 0;
-        if (allrev) dyn_lane<NJ, MDH, MODE, true>(links, in.data(), A.data(), g);
-        else dyn_lane<NJ, MDH, MODE, false>(links, in.data(), A.data(), g);
+        // accel of an all-revolute chain with n >= 5: the kernel keeps q | qd | torque in the M tile itself (dyn_kernels.hip: alias_all)
+        const bool alias_all = (MODE == kDynAccel && allrev && 3 * NJ <= NJ * (NJ + 1) / 2) || (MODE == kDynCoriolis && allrev && NJ >= 2);
+        if (alias_all) for (int k = 0; k < (MODE == kDynAccel ? 3 : 2) * NJ; ++k) A[k] = in[k];
+        const double *mine = alias_all ? A.data() : in.data();
+        if (allrev) dyn_lane<NJ, MDH, MODE, true>(links, mine, A.data(), g);
+        else dyn_lane<NJ, MDH, MODE, false>(links, mine, A.data(), g);
         const int W = MODE == kDynAccel ? NJ : NJ * NJ;
         if (MODE == kDynInertia && allrev) {           // packed lower triangle -> (n, n), as the kernel's flush_symmetric
             for (int r = 0; r < NJ; ++r)
