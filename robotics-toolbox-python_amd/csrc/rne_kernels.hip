@@ -73,9 +73,14 @@ __device__ __forceinline__ void rne_tile(const RneParams &rp, ConstLinks links, 
         for (int k = 0; k < C; ++k) {
             const int f = lane + kW * k;
             const bool in = f < count;
+#if defined(RTB_RNE_PROBE_NOLOAD)   // timing probe only (wrong results): what the tile loads cost the wave's lifetime
+            r0[k] = in ? 1e-3 * f : 0.0; r1[k] = in ? 2e-3 * f : 0.0; r2[k] = in ? 3e-3 * f : 0.0;
+            (void)g0; (void)g1; (void)g2;
+#else
             r0[k] = in ? g0[f] : 0.0;
             r1[k] = (in && qd) ? g1[f] : 0.0;      // NULL qd / qdd = zeros (gravload, itorque)
             r2[k] = (in && qdd) ? g2[f] : 0.0;
+#endif
         }
 #pragma unroll
         for (int k = 0; k < C; ++k) {
