@@ -7,10 +7,11 @@ driver only runs bench.py).  One JSON object per line:
 Each leg times K launches with HIP events on the launch stream and, for rne/ik, the reference's own
 CPU path (oracle/_ref) on a bounded sample.
 
-Multi-GPU (`--gpus N`, self-spawning like bench.py; legs rne and fleet only):
+Multi-GPU (`--gpus N`, self-spawning like bench.py; legs rne, ik and fleet only):
    rne    BASELINE configs[3] as stated: N = 1e7 triples in total, split into contiguous row blocks by
           rtbhip_shard_range, one block per rank ("scaling": "strong"); the gather of tau (all_gather over
           RCCL/xGMI) is timed separately as gather_ms
+   ik     BASELINE configs[2]: the 1e5 targets in row blocks over the ranks
    fleet  BASELINE configs[4]: 16 URDF arms x 1e6 configurations, every arm's batch split by rows over the ranks"""
 import argparse
 import json
@@ -85,7 +86,7 @@ def main():
         rtbhip.tune(k, int(v))
     what = args.what.split(",")
     if world > 1:
-        what = [w for w in what if w in ("rne", "fleet")]    # the legs BASELINE shards; the rest are single-GPU figures
+        what = [w for w in what if w in ("rne", "ik", "fleet")]    # the legs BASELINE shards; the rest are single-GPU figures
 
     if "rne" in what:
         Ntot = args.n_rne or (10000000 if world > 1 else 1250000)
@@ -257,6 +258,31 @@ def main():
         qs = torch.from_numpy(rng.uniform(ets.qlim[0], ets.qlim[1], (N, 7))).cuda()
         Tep = ets.eval(qs)
         res = {}
+        if world > 1:
+            # BASELINE configs[2] over the ranks: the same 1e5 targets, each rank solves its row block (targets are independent;
+            # imbalance between targets is handled inside each GPU).  The restart generator is keyed by the target's index within
+            # a call, so a target's later searches start elsewhere than in the single-GPU run: same statistics, not the same q.
+            sb = rtbhip.ShardedBatch(N, rank, world)
+            Tl = Tep[sb.begin:sb.begin + sb.count].contiguous()
+            def run_local():
+                res["out"] = ets.ik_LM(Tl, seed=2)
+            K = max(3, args.steps // 4)
+            elapsed, dev_ms = rk.timed_steps(run_local, K, 1)
+            _, ok, it, _, _ = res["out"]
+            solved, iters = rk.sum_over_ranks(float(ok.sum())), rk.sum_over_ranks(float(it.sum()))
+            step_s = elapsed / K
+            line = {"metric": "solves/sec (Panda ik_LM chan k=1, joint limits, ilimit 30 slimit 100 tol 1e-6; %d targets in row blocks over the ranks)" % N,
+                    "value": N / step_s, "unit": "solves/s", "n": N, "n_gpus": world, "scaling": "strong", "ms_per_step": step_s * 1e3,
+                    "rows_rank0": sb.count, "kernel_avg_ms": dev_ms, "success_rate": solved / N, "mean_iterations": iters / N,
+                    "lm_iterations_per_s": iters / step_s, "roofline": ik_roofline(iters / step_s / world)}
+            line["roofline"]["note"] = "per GPU: whole-job LM iterations / s divided by the world size"
+            if rk.shared:
+                line["devices_shared"] = True
+            if rank == 0:
+                print(json.dumps(line), flush=True)
+            what = [w for w in what if w != "ik"]
+    if "ik" in what:
+        N = args.n_ik
         def run():
             res["out"] = ets.ik_LM(Tep, seed=2)
         avg, best = ev_time(run, max(3, args.steps // 4), 1)

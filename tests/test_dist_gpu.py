@@ -114,9 +114,10 @@ def test_bench_gpus_2_spawns_two_ranks():
     assert line["value"] == pytest.approx(2 * 200000 * 5 / (line["ms_per_step"] * 5e-3), rel=1e-9)
 
 
-def test_bench_extra_gpus_2_shards_config4_and_config5():
-    lines = _run_bench("bench_extra.py", ["--what", "rne,fleet", "--steps", "4", "--n-rne", "200001", "--n-fleet", "20001", "--no-cpu"])
-    assert len(lines) == 2
-    rne, fleet = lines
+def test_bench_extra_gpus_2_shards_config4_config3_and_config5():
+    lines = _run_bench("bench_extra.py", ["--what", "rne,ik,fleet", "--steps", "4", "--n-rne", "200001", "--n-ik", "20001", "--n-fleet", "20001", "--no-cpu"])
+    assert len(lines) == 3
+    rne, ik, fleet = lines
     assert rne["n_gpus"] == 2 and rne["n"] == 200001 and rne["rows_rank0"] == 100001 and rne["scaling"] == "strong" and rne["gather_ms"] > 0
+    assert ik["n_gpus"] == 2 and ik["n"] == 20001 and ik["rows_rank0"] == 10001 and 0.97 < ik["success_rate"] <= 1.0 and ik["roofline"]["bound"] == "fp64-valu"
     assert fleet["n_gpus"] == 2 and fleet["scaling"] == "strong" and len(fleet["arms"]) == 16
