@@ -1,6 +1,4 @@
 #!/bin/bash
-# gpu_one.sh <pytest args...> : run a subset of the GPU tests
 export TMPDIR=/tmp
-mkdir -p gpurun_out
-timeout 900 python -m pytest "$@" -m gpu -x -q > gpurun_out/pytest_one.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_one.log
-grep -v Warning gpurun_out/pytest_one.log | tail -25
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_dist_gpu.py -m gpu -q --timeout 600 --tb=short -k "single_gpu_line" 2>&1 | grep -v "Warning\|^  \|^$" | tail -15 | cut -c1-300

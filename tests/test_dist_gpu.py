@@ -121,3 +121,32 @@ def test_bench_extra_gpus_2_shards_config4_config3_and_config5():
     assert rne["n_gpus"] == 2 and rne["n"] == 200001 and rne["rows_rank0"] == 100001 and rne["scaling"] == "strong" and rne["gather_ms"] > 0
     assert ik["n_gpus"] == 2 and ik["n"] == 20001 and ik["rows_rank0"] == 10001 and 0.97 < ik["success_rate"] <= 1.0 and ik["roofline"]["bound"] == "fp64-valu"
     assert fleet["n_gpus"] == 2 and fleet["scaling"] == "strong" and len(fleet["arms"]) == 16
+
+
+def test_bench_single_gpu_line_carries_the_contract_objects():
+    """`python bench.py` as the driver runs it (N = 1, default workload): ONE JSON line with the contract's keys, the roofline
+    object priced on 520 B per configuration, the reference-built CPU baseline, and the host-pointer rate as its own object."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RTBHIP_BENCH_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3"], capture_output=True, text=True,
+                       timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines                                     # exactly one line on stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 3 and d["dtype"] == "f64" and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] == pytest.approx(1e6 / (d["ms_per_step"] * 1e-3), rel=1e-9)
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s" and 0.3 < rf["frac"] < 1.0
+    assert rf["achieved"] == pytest.approx(520e6 / (rf["kernel_avg_ms"] * 1e-3) / 1e9, rel=1e-6)
+    assert rf["kernel_avg_ms"] <= d["ms_per_step"] * 1.001
+    assert rf["traffic"] is None or (0.95 * 520e6 < rf["traffic"] < 1.1 * 520e6 and "profiles/" in rf["traffic_source"])
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "reference" and cb["cores"] == 1 and cb["value"] > 1e5 and cb["max_abs_err_gpu_vs_cpu"] < 1e-10 and "sample" in cb
+    hp = d["host_path"]
+    assert hp["value"] > 1e7 and hp["value"] < d["value"] and hp["unit"] == "configurations/s"
