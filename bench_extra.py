@@ -260,12 +260,13 @@ def main():
         res = {}
         if world > 1:
             # BASELINE configs[2] over the ranks: the same 1e5 targets, each rank solves its row block (targets are independent;
-            # imbalance between targets is handled inside each GPU).  The restart generator is keyed by the target's index within
-            # a call, so a target's later searches start elsewhere than in the single-GPU run: same statistics, not the same q.
+            # imbalance between targets is handled inside each GPU).  Inside sb.ik_rows() the restart generator is keyed by the
+            # GLOBAL row number (rtbhip_ik_target_base), so the gathered solutions are the single-GPU run's, whatever the split.
             sb = rtbhip.ShardedBatch(N, rank, world)
             Tl = Tep[sb.begin:sb.begin + sb.count].contiguous()
             def run_local():
-                res["out"] = ets.ik_LM(Tl, seed=2)
+                with sb.ik_rows():
+                    res["out"] = ets.ik_LM(Tl, seed=2)
             K = max(3, args.steps // 4)
             elapsed, dev_ms = rk.timed_steps(run_local, K, 1)
             _, ok, it, _, _ = res["out"]

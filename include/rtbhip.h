@@ -195,6 +195,13 @@ int rtbhip_ik_qp(rtbhip_chain_t chain, const double *Tep, int64_t N, const doubl
                  int32_t reject_jl, const double *we6, uint64_t seed, double kj, double ks, double kq, double km, double ps, double pi,
                  double *q_out, int32_t *success, int32_t *iters, int32_t *searches, double *residual, int32_t mem, void *stream);
 
+/* Sharded IK: the restart generator is keyed by (seed, target row, search, joint).  A rank that solves rows [begin, begin + count)
+ * of a larger batch (rtbhip_shard_range) calls rtbhip_ik_target_base(begin) first: its targets then draw exactly the start vectors
+ * they would draw in one call over the whole batch, so the gathered result does not depend on how the rows were split.  The base
+ * is per calling thread and stays in force until set again (0 = the default).  (The reference draws from an unseeded std::rand,
+ * ik.cpp:293: nothing to reproduce there.) */
+int rtbhip_ik_target_base(int64_t base);
+
 /* The restart vector the device generator yields for (seed, target index, search index, joint):
  * uniform in [qlim_lo, qlim_hi).  Exposed so tests can hand the CPU oracle the same sequence. */
 int rtbhip_ik_restart(rtbhip_chain_t chain, uint64_t seed, int64_t target, int32_t search,

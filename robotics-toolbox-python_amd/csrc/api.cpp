@@ -665,6 +665,15 @@ static int ik_entry(rtbhip_chain_t chain, const double *Tep, int64_t N, const do
                            int32_t *success, int32_t *iters, int32_t *searches, double *residual,
                            int32_t mem, void *stream);
 
+// restart-generator key of row 0 for the IK calls this thread makes from now on (rtbhip.h)
+static thread_local int64_t t_ik_target_base = 0;
+int rtbhip_ik_target_base(int64_t base)
+{
+    if (base < 0) { set_error("ik_target_base: negative base"); return RTBHIP_EINVAL; }
+    t_ik_target_base = base;
+    return RTBHIP_OK;
+}
+
 int rtbhip_ik_lm_nullspace(rtbhip_chain_t chain, const double *Tep, int64_t N, const double *q0,
                            int32_t ilimit, int32_t slimit, double tol, int32_t reject_jl, const double *we6,
                            double lambda, int32_t method, int32_t flavour, uint64_t seed,
@@ -707,7 +716,7 @@ static int ik_entry(rtbhip_chain_t chain, const double *Tep, int64_t N, const do
     IkParams p;
     p.ilimit = ilimit; p.slimit = slimit; p.reject_jl = reject_jl ? 1 : 0; p.method = method;
     p.flavour = flavour; p.tol = tol; p.lambda = lambda; p.seed = seed;
-    p.kq = kq; p.km = km; p.ps = ps; p.pi = pi; p.ks = ks;
+    p.kq = kq; p.km = km; p.ps = ps; p.pi = pi; p.ks = ks; p.target0 = t_ik_target_base;
     if (kq > 0.0 && flavour != 1) { set_error("ik_lm: null-space terms belong to the Python solvers (flavour 1)"); return RTBHIP_EINVAL; }
     if (kq > 0.0 && ps == pi) { set_error("ik_lm: ps must differ from pi"); return RTBHIP_EINVAL; }
     for (int i = 0; i < 6; i++) p.we[i] = we6 ? we6[i] : 1.0;

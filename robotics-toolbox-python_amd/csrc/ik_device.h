@@ -38,6 +38,8 @@ struct IkDev {   // wave-uniform solver parameters (kernarg)
     int64_t N;
     double kq, km, ps, pi;           // null-space terms of the Python solvers (IK.py:507-576); kq <= 0: none
     double ks;                       // IK_QP (method 5): slack gain; its joint-velocity gain kj travels in `lambda`
+    int64_t target0;                 // added to a target's row number where it keys the restart generator (rtbhip_ik_target_base):
+                                     // a row block of a larger batch then draws what the whole batch would have drawn for those targets
 };
 
 // ---------------------------------------------------------------- restart generator
@@ -393,7 +395,7 @@ RTB_HD void ik_search_begin(IkLane<NJ> &st, QA qa, const PD &p, QL qlim, int64_t
     } else {
         const int draw = p.flavour == 0 ? s - 1 - (q0row ? 1 : 0) : s;
         double qn[NJ];
-        ik_restart<NJ>(p.seed, tgt, draw, qlim, qn);
+        ik_restart<NJ>(p.seed, tgt + p.target0, draw, qlim, qn);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) qa.put(j, qn[j]);
     }
@@ -563,7 +565,7 @@ RTB_HD void ik_emit(const IkLane<NJ> &st, QA qa, const PD &p, QL qlim, int64_t t
         se = p.flavour == 0 ? st.s : st.s + 1;
     } else if (p.flavour == 0) {
         se = ik_s_last(p) + 1;
-        ik_restart<NJ>(p.seed, tgt, ik_s_last(p) - (has_q0 ? 1 : 0), qlim, qf);   // ik.cpp:66-69: q is the next restart
+        ik_restart<NJ>(p.seed, tgt + p.target0, ik_s_last(p) - (has_q0 ? 1 : 0), qlim, qf);   // ik.cpp:66-69: q is the next restart
     } else {
         se = p.slimit;                                                             // IK.py:359-366
     }

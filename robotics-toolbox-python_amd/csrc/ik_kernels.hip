@@ -412,7 +412,7 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
     p.ilimit = ip.ilimit; p.slimit = ip.slimit; p.reject_jl = ip.reject_jl; p.method = ip.method;
     p.flavour = ip.flavour; p.has_q0 = q0 != nullptr; p.tol = ip.tol; p.lambda = ip.lambda;
     for (int k = 0; k < 6; ++k) p.we[k] = ip.we[k];
-    p.seed = ip.seed;
+    p.seed = ip.seed; p.target0 = ip.target0;
     p.N = N;
     p.kq = ip.kq; p.km = ip.km; p.ps = ip.ps; p.pi = ip.pi; p.ks = ip.ks;
     if (p.method == 5 && (p.km > 0.0 || p.kq > 0.0) && (c->n > kIkNullMax || c->n < 6)) {

@@ -177,6 +177,7 @@ struct IkParams {
     uint64_t seed;
     double kq = 0.0, km = 0.0, ps = 0.1, pi = 0.3;   // null-space terms of the Python solvers; kq <= 0: none
     double ks = 1.0;                                 // IK_QP (method 5): slack gain (kj travels in lambda)
+    int64_t target0 = 0;                             // restart-generator key offset of row 0 (rtbhip_ik_target_base)
 };
 int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const double *Tep, int64_t N,
               const double *q0, const IkParams &p, double *q_out, int32_t *success, int32_t *iters,

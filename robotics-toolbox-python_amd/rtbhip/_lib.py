@@ -61,6 +61,7 @@ SIGNATURES = {
                                          C.c_double, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "rtbhip_ik_qp": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _i32, C.c_double, _i32, _vp, _u64, C.c_double, C.c_double, C.c_double, C.c_double,
                                C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "rtbhip_ik_target_base": (C.c_int, [_i64]),
     "rtbhip_ik_restart": (C.c_int, [_u64, _u64, _i64, _i32, _vp]),
     "rtbhip_dyn_create": (C.c_int, [_vp, _i32, _i32, C.POINTER(_u64)]),
     "rtbhip_dyn_destroy": (C.c_int, [_u64]),
@@ -123,6 +124,21 @@ def device_count():
     n = C.c_int(0)
     rc = lib().rtbhip_device_count(C.byref(n))
     return n.value if rc == 0 else 0
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def ik_target_base(base):
+    """`with rtbhip.ik_target_base(begin): ets.ik_LM(Tep[begin:begin + count], ...)` -- the IK calls inside solve a row block of a
+    larger batch and draw the restart vectors the whole batch would draw for those rows (rtbhip_ik_target_base): sharded IK then
+    returns, row for row, what one call over all the targets returns."""
+    check(lib().rtbhip_ik_target_base(int(base)))
+    try:
+        yield
+    finally:
+        lib().rtbhip_ik_target_base(0)
 
 
 def tune(key, value):

@@ -25,6 +25,13 @@ class ShardedBatch:
         """This rank's rows of a global (N, ...) array."""
         return x[self.begin:self.begin + self.count]
 
+    def ik_rows(self):
+        """Context manager for this rank's IK calls: `with sb.ik_rows(): ets.ik_LM(sb.local(Tep))` draws, for every local row,
+        the restart vectors one call over all N targets would draw (rtbhip_ik_target_base(begin)) -- the gathered solutions are
+        the single-GPU ones, however the rows were split."""
+        from ._lib import ik_target_base
+        return ik_target_base(self.begin)
+
     def gather(self, local_out, to_all=False, dst=0):
         """ONE collective: all_gather_into_tensor (to_all) or gather-to-dst of equal-size padded
         shards.  Returns the (N, ...) result on the receiving rank(s), None elsewhere."""

@@ -613,6 +613,9 @@ extern "C" void emu_ik_nullspace(double kq, double km, double ps, double pi) { g
 // IK_QP (method 5): slack gain for the next emu_ik / emu_ik_wave calls (kj is passed as lambda)
 static double g_emu_ks = 1.0;
 extern "C" void emu_ik_qp_ks(double ks) { g_emu_ks = ks; }
+// restart-generator key of row 0 for the next emu_ik / emu_ik_wave calls (rtbhip_ik_target_base)
+static int64_t g_emu_target0 = 0;
+extern "C" void emu_ik_target_base(int64_t b) { g_emu_target0 = b; }
 
 extern "C" int emu_ik(rtbhip_chain_t h, const double *Tep, int64_t N, const double *q0, int ilimit, int slimit, double tol,
                       int reject_jl, const double *we6, double lambda, int method, int flavour, uint64_t seed,
@@ -624,7 +627,7 @@ extern "C" int emu_ik(rtbhip_chain_t h, const double *Tep, int64_t N, const doub
     IkDev p;
     p.ilimit = ilimit; p.slimit = slimit; p.reject_jl = reject_jl; p.method = method; p.flavour = flavour;
     p.has_q0 = q0 != nullptr; p.tol = tol; p.lambda = lambda; p.seed = seed; p.N = N; p.fresh_cap = 64; p.pool_chunk = 64; p.pass_mask = 0; p.spec_policy = getenv("EMU_IK_SPEC_POLICY") ? atoi(getenv("EMU_IK_SPEC_POLICY")) : 0;
-    p.kq = g_emu_ns[0]; p.km = g_emu_ns[1]; p.ps = g_emu_ns[2]; p.pi = g_emu_ns[3]; p.ks = g_emu_ks;
+    p.kq = g_emu_ns[0]; p.km = g_emu_ns[1]; p.ps = g_emu_ns[2]; p.pi = g_emu_ns[3]; p.ks = g_emu_ks; p.target0 = g_emu_target0;
     for (int k = 0; k < 6; ++k) p.we[k] = we6 ? we6[k] : 1.0;
     switch (c->n) {
     case 1: emu_ik_run<1>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
@@ -657,7 +660,7 @@ extern "C" int emu_ik_wave(rtbhip_chain_t h, int waves, double *stats, const dou
     IkDev p;
     p.ilimit = ilimit; p.slimit = slimit; p.reject_jl = reject_jl; p.method = method; p.flavour = flavour;
     p.has_q0 = q0 != nullptr; p.tol = tol; p.lambda = lambda; p.seed = seed; p.N = N; p.fresh_cap = 64; p.pool_chunk = 64; p.pass_mask = 0; p.spec_policy = getenv("EMU_IK_SPEC_POLICY") ? atoi(getenv("EMU_IK_SPEC_POLICY")) : 0;
-    p.kq = g_emu_ns[0]; p.km = g_emu_ns[1]; p.ps = g_emu_ns[2]; p.pi = g_emu_ns[3]; p.ks = g_emu_ks;
+    p.kq = g_emu_ns[0]; p.km = g_emu_ns[1]; p.ps = g_emu_ns[2]; p.pi = g_emu_ns[3]; p.ks = g_emu_ks; p.target0 = g_emu_target0;
     for (int k = 0; k < 6; ++k) p.we[k] = we6 ? we6[k] : 1.0;
     if (const char *pm = getenv("EMU_IK_PASS_MASK")) p.pass_mask = atoi(pm);
     { const int64_t g = waves; const int64_t cap = (N + g - 1) / g; p.fresh_cap = cap > 64 ? 64 : (int)cap;

@@ -69,6 +69,8 @@ def lib():
         _lib.emu_ik_nullspace.restype = None
         _lib.emu_ik_qp_ks.argtypes = [C.c_double]
         _lib.emu_ik_qp_ks.restype = None
+        _lib.emu_ik_target_base.argtypes = [_i64]
+        _lib.emu_ik_target_base.restype = None
         _lib.emu_link_frames.argtypes = [_u64, _vp, _i64, _vp, _vp, _i32, _vp]
         _lib.emu_partial.argtypes = [_u64, _vp, _i64, _vp, _i32, _vp]
         _lib.emu_dyn.argtypes = [_u64, _i32, _vp, _vp, _vp, _i64, _vp, _vp]
@@ -294,6 +296,11 @@ def ik_nullspace(kq=0.0, km=0.0, ps=0.0, pi=0.3):
 def ik_qp_ks(ks=1.0):
     """IK_QP's slack gain for the following emu.ik(method="qp", k=kj) calls."""
     lib().emu_ik_qp_ks(float(ks))
+
+
+def ik_target_base(base=0):
+    """Restart-generator key of row 0 for the following emu.ik calls (rtbhip_ik_target_base)."""
+    lib().emu_ik_target_base(int(base))
 
 
 def ik_restart(ets, seed, target, draw):

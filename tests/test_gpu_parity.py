@@ -697,6 +697,34 @@ def test_branches_of_a_tree_robot_read_the_robot_wide_q():
         nt.assert_array_equal(w.hessian0(q[:50]), l.hessian0(qs[:50]))
 
 
+def test_ik_row_blocks_with_target_base_equal_the_whole_batch():
+    """Sharded IK: each row block solved by its own call inside `ShardedBatch.ik_rows()` / `rtbhip.ik_target_base(begin)`
+    returns, bit for bit, the rows of the single call over all targets -- C flavour, Python flavour and IK_QP."""
+    import torch
+    ets, ch = _panda_limited()
+    rng = np.random.default_rng(31)
+    N = 5000
+    Tep = oracle.fkine(ch, rng.uniform(ch.qlim[0], ch.qlim[1], (N, 7)))
+    Tep[::37, :3, 3] += 2.5
+    Tt = torch.from_numpy(Tep).cuda()
+    runs = (lambda T: [x.cpu().numpy() for x in ets.ik_LM(T, seed=4, slimit=20)],
+            lambda T: (lambda s: [s.q, s.each["success"], s.each["iterations"], s.each["searches"], s.each["residual"]])(ets.ikine_LM(T, seed=4, slimit=20)),
+            lambda T: (lambda s: [s.q, s.each["success"], s.each["iterations"], s.each["searches"], s.each["residual"]])(ets.ikine_QP(T, seed=4, slimit=20, kj=0.01)))
+    for run in runs:
+        whole = run(Tt)
+        assert whole[3].max() > 3
+        for world in (2, 3):
+            parts = []
+            for r in range(world):
+                sb = rtbhip.ShardedBatch(N, r, world)
+                with sb.ik_rows():
+                    parts.append(run(sb.local(Tt).contiguous()))
+            for k in range(5):
+                nt.assert_array_equal(np.concatenate([p[k] for p in parts]), whole[k])
+    plain = runs[0](Tt[N // 2:].contiguous())
+    assert not np.array_equal(plain[0], runs[0](Tt)[0][N // 2:])
+
+
 def test_init_and_shutdown_keep_handles_usable():
     lib = rtbhip.lib()
     assert lib.rtbhip_init(-1) == 0 and lib.rtbhip_init(1) == 0

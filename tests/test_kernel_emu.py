@@ -633,6 +633,29 @@ def test_ik_cross_wave_sharing_equals_sequential_searches(flavour, N, waves, sli
     assert a[1].sum() < N
 
 
+def test_ik_row_block_with_target_base_equals_the_whole_batch():
+    """rtbhip_ik_target_base: rows [b, b + c) of a batch solved on their own, with the restart generator keyed from b, give exactly
+    what the whole batch gives for those rows (multi-search targets included) -- sharded IK does not depend on the split."""
+    ets, ch = _panda_limited()
+    rng = np.random.default_rng(21)
+    N = 60
+    Tep = oracle.fkine(ch, rng.uniform(ch.qlim[0], ch.qlim[1], (N, 7)))
+    Tep[::11, :3, 3] += 2.5
+    for flavour in (0, 1):
+        whole = emu.ik(ets, Tep, seed=12, slimit=25, flavour=flavour)
+        assert whole[3].max() > 3                                     # restarts matter in this batch
+        for b, c in ((0, 17), (17, 30), (47, 13)):
+            emu.ik_target_base(b)
+            try:
+                part = emu.ik(ets, Tep[b:b + c], seed=12, slimit=25, flavour=flavour, waves=2)
+            finally:
+                emu.ik_target_base(0)
+            for x, y in zip(whole, part):
+                nt.assert_array_equal(x[b:b + c], y)
+        wrong = emu.ik(ets, Tep[17:47], seed=12, slimit=25, flavour=flavour)
+        assert not np.array_equal(wrong[0], whole[0][17:47])          # without the base the block is a different problem
+
+
 def test_xcd_tile_mapping_is_a_bijection_with_contiguous_eighths():
     """xcd_tile_of (trig.h): workgroup ids b = 8 i + x (XCD x) -> tiles; a permutation of [0, g) for every grid size, each
     XCD's tiles one contiguous block, visited in increasing order."""
