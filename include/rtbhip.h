@@ -279,7 +279,14 @@ int rtbhip_shard_range(int64_t N, int32_t rank, int32_t world, int64_t *begin, i
 /* Launch-geometry report for the last kernel a call on this thread enqueued (diagnostics). */
 int rtbhip_last_launch(int32_t *grid, int32_t *block, int32_t *lds_bytes);
 
-/* Tuning knobs for benchmarking (A/B of launch geometry / store paths); unknown keys are ignored. */
+/* Tuning knobs for benchmarking (A/B of launch geometry / store paths); process-wide; unknown keys are ignored.  Results never
+ * depend on them (every setting is covered by bit-equality tests); the defaults are the measured best.  IK scheduler:
+ *   "ik_share" 0 | 1 | 2      cross-wave sharing of search ranges: never (default) / when the batch is resident at once / always
+ *   "ik_donate_after" k       ... ranges are cut only from targets with k failed searches (default 3)
+ *   "ik_phased" 0 | 1 | 2     phased schedule (first searches, then compacted work lists): never (default) / automatic / always
+ *   "ik_fresh_pct" p, "ik_pass_mask" m, "ik_waves_per_cu" w, "ik_spec_policy" 0 | 1     pacing of the per-wave scheduler
+ * Others: "coalesced", "reg", "tiles_per_wave", "hess_mode" (fkine / Jacobian / Hessian store paths), "rne_tiles_per_wave",
+ *         "host_chunk_kb" (host-pointer pipeline). */
 int rtbhip_tune(const char *key, int32_t value);
 
 #ifdef __cplusplus
