@@ -25,16 +25,6 @@ RTB_HD void dyn_opaque(double (&st)[NJ], double (&ct)[NJ])
 #endif
 }
 
-// a[i] for a wave-uniform run-time i without indexing the register array (that would send it to scratch)
-template <int NJ>
-RTB_HD double dyn_pick(const double (&a)[NJ], int i)
-{
-    double r = 0.0;
-#pragma unroll
-    for (int k = 0; k < NJ; ++k) r += (i == k) ? a[k] : 0.0;      // (a select chain gets turned back into an indexed load)
-    return r;
-}
-
 template <int NJ, bool MDH, int MODE, bool ALLREV, class LinksP>
 RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, const double *qrow = nullptr)
 {
@@ -95,40 +85,37 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, cons
         for (int j = 0; j < NJ; ++j) mA[j] = x[j];        // the tile's first n slots become the output row
     }
     if (MODE == kDynCoriolis) {
-        // Dynamics.py:828-856 regrouped so that ONE n x n tile per lane suffices (the reference keeps Csq and C; two tiles
-        // are 58 KB of LDS per wave for n = 7, i.e. two waves per CU on a kernel that is fp64-issue bound):
-        //   C[:,k] = sum_{j != k} (T_jk - Csq_k - Csq_j) qd_j / 2 + Csq_k qd_k
-        //          = 1/2 sum_{j != k} T_jk qd_j + Csq_k (2 qd_k - S / 2) - U / 2,   S = sum_j qd_j,  U = sum_j Csq_j qd_j
-        // with T_jk the pass at QD = e_j + e_k and Csq_j the pass at QD = e_j (friction removed, :820).  Same terms,
-        // different association: agreement with the reference order is ~1e-15 relative.
+        // Dynamics.coriolis (robot/Dynamics.py:811-861) builds C from n passes at QD = e_i (Csq) and n (n - 1) / 2 passes at
+        // QD = e_i + e_j (gravity, friction and acceleration removed).  Such a pass is a homogeneous quadratic form of qd,
+        //      tau_r(v) = sum_ab h_rab v_a v_b   (h symmetric in a, b),
+        // the reference's combination (T_jk - Csq_j - Csq_k) / 2 is h_rjk, and its result is  C[r, k] = sum_j h_rjk qd_j  -- the
+        // polar form of tau against e_k.  The same numbers come from TWO passes per column instead of the reference's 28 in all:
+        //      C[:, k] = ( tau(qd + s e_k) - tau(qd - s e_k) ) / (4 s)          (exact for a quadratic form)
+        // with s the power of two next above max|qd_j| (1 for qd = 0), so that the probe is neither lost in qd nor qd in the probe,
+        // whatever the scale of the velocities, and the scaling is exact: 14 passes for a 7-joint arm; agreement with the
+        // reference's order of operations ~1e-15 of max|C| (tests: oracle.coriolis_dh statement for statement, emu and GPU,
+        // velocities from 1e-9 to 1e9).
         // qd in registers: the kernel may keep the input row in the C tile itself, which the first pass starts to overwrite
-        double S = 0.0, U[NJ], qdv[NJ];
+        double qdv[NJ], vmax = 0.0;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) { qdv[j] = mine[NJ + j]; S += qdv[j]; U[j] = 0.0; }
+        for (int j = 0; j < NJ; ++j) { qdv[j] = mine[NJ + j]; vmax = fmax(vmax, fabs(qdv[j])); }
+        // s = 2^ceil(log2(vmax)) through the exponent field (exact); 1 for qd = 0 and for non-finite rows (which come out NaN as
+        // they should); the exponent is kept where s^2 neither overflows nor underflows
+        int ex = 0;
+        const double mant = frexp(vmax, &ex);                      // vmax = mant 2^ex, mant in [0.5, 1)
+        if (mant == 0.5) ex -= 1;
+        if (!(vmax > 0.0) || !(vmax < 1.7e308)) ex = 0;
+        ex = ex > 400 ? 400 : (ex < -400 ? -400 : ex);
+        const double sc = ldexp(1.0, ex);
+        const double inv4s = 0.25 / sc;
 #pragma unroll 1
-        for (int i = 0; i < NJ; ++i) {
-            const double qdi = dyn_pick<NJ>(qdv, i), wi = 2.0 * qdi - 0.5 * S;
+        for (int k = 0; k < NJ; ++k) {
             dyn_opaque<NJ>(st, ct);
-            rne_core<NJ, MDH, false, ALLREV, true>(links, NJ, st, ct, zero, zero, zero, qin, [&](int j) { return j == i ? 1.0 : 0.0; },
-                                     [&](int) { return 0.0; }, [&](int r, double v) { mA[r * NJ + i] = v * wi; U[r] += v * qdi; });
-        }
-#pragma unroll
-        for (int r = 0; r < NJ; ++r)
-#pragma unroll
-            for (int c = 0; c < NJ; ++c) mA[r * NJ + c] -= 0.5 * U[r];
-#pragma unroll 1
-        for (int i = 0; i < NJ; ++i) {
-#pragma unroll 1
-            for (int j = i + 1; j < NJ; ++j) {
-                const double hi = 0.5 * dyn_pick<NJ>(qdv, i), hj = 0.5 * dyn_pick<NJ>(qdv, j);
-                dyn_opaque<NJ>(st, ct);
-                rne_core<NJ, MDH, false, ALLREV, true>(links, NJ, st, ct, zero, zero, zero, qin,
-                                         [&](int k) { return (k == i || k == j) ? 1.0 : 0.0; }, [&](int) { return 0.0; },
-                                         [&](int r, double tau) {
-                                             mA[r * NJ + j] += tau * hi;
-                                             mA[r * NJ + i] += tau * hj;
-                                         });
-            }
+            rne_core<NJ, MDH, false, ALLREV, true>(links, NJ, st, ct, zero, zero, zero, qin, [&](int j) { return j == k ? qdv[j] + sc : qdv[j]; },
+                                     [&](int) { return 0.0; }, [&](int r, double v) { mA[r * NJ + k] = v; });
+            dyn_opaque<NJ>(st, ct);
+            rne_core<NJ, MDH, false, ALLREV, true>(links, NJ, st, ct, zero, zero, zero, qin, [&](int j) { return j == k ? qdv[j] - sc : qdv[j]; },
+                                     [&](int) { return 0.0; }, [&](int r, double v) { mA[r * NJ + k] = (mA[r * NJ + k] - v) * inv4s; });
         }
     }
 }

@@ -81,6 +81,45 @@ def test_gpu_goldens_and_shapes_puma():
     nt.assert_array_almost_equal(puma.accel(q2, np.c_[aq, aq].T, np.c_[at, at].T)[1], LIT["D_puma_accel"], decimal=4)
 
 
+def _coriolis_scale_cases(n, rng):
+    """qd rows of very different scales (and mixed within a row, zero, one nonzero entry): the two-passes-per-column coriolis of
+    dyn_device.h probes with a power of two next above max|qd|, so its accuracy must not depend on the scale."""
+    base = rng.normal(size=(8, n))
+    rows = [base[0] * 1e-9, base[1] * 1e-3, base[2], base[3] * 1e3, base[4] * 1e9, np.zeros(n), base[6] * np.logspace(-6, 3, n)]
+    one = np.zeros(n); one[n // 2] = -3.7
+    rows.append(one)
+    return np.array(rows)
+
+
+@pytest.mark.parametrize("robot", ["puma", "panda"])
+def test_emu_coriolis_accuracy_is_scale_free(robot):
+    import emu_harness as emu
+    t = chains.puma560() if robot == "puma" else chains.panda_dh()
+    mdh, L, n = (0 if robot == "puma" else 1), t.L24(), t.L24().shape[0]
+    rng = np.random.default_rng(77)
+    qd = _coriolis_scale_cases(n, rng)
+    q = rng.uniform(t.qlim[:, 0], t.qlim[:, 1], (len(qd), n))
+    C = emu.dyn(L, mdh, 1, q, qd)
+    ref = oracle.coriolis_dh(L, mdh, q, qd)
+    for i in range(len(qd)):
+        scale = np.abs(ref[i]).max()
+        assert np.abs(C[i] - ref[i]).max() <= 1e-13 * scale + (0.0 if scale > 0 else 0.0), (i, np.abs(C[i] - ref[i]).max(), scale)
+    assert np.all(C[5] == 0.0)
+
+
+@pytest.mark.gpu
+def test_gpu_coriolis_accuracy_is_scale_free():
+    rob, t = rtbhip.models.DH.Panda(), chains.panda_dh()
+    rng = np.random.default_rng(78)
+    qd = _coriolis_scale_cases(7, rng)
+    q = rng.uniform(t.qlim[:, 0], t.qlim[:, 1], (len(qd), 7))
+    C = rob.coriolis(q, qd)
+    ref = oracle.coriolis_dh(t.L24(), 1, q, qd)
+    for i in range(len(qd)):
+        assert np.abs(C[i] - ref[i]).max() <= 1e-13 * np.abs(ref[i]).max()
+    assert np.all(C[5] == 0.0)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("robot,N", [("puma", 1000), ("panda", 4097), ("panda", 63)])
 def test_gpu_vs_oracle_and_identities(robot, N):
