@@ -149,7 +149,7 @@ def main():
                     "n": N, "kernel_avg_ms": avg, "kernel_min_ms": best, "rne_passes_per_config": passes,
                     "rne_passes_per_s": passes * N / (avg * 1e-3),
                     "pass_kind": {"inertia": "acceleration-only passes from link i on, mirrored (csrc/rne_device.h ACC)",
-                                  "coriolis": "2 velocity passes per column, qd +- s e_k (polar form of the quadratic velocity torque; the reference runs 28 passes)",
+                                  "coriolis": "2 velocity passes per column, qd +- s e_k (polar form of the quadratic velocity torque; the reference runs 28 passes, and so do the waves that hold a row whose velocities span more than 2^16)",
                                   "accel": "1 full pass + 7 acceleration-only passes + LDL^T solve"}[name],
                     # the HBM roof is the one these lines are priced against (algorithmic bytes / time); what actually limits the
                     # kernels is fp64 issue at the occupancy their LDS tiles allow

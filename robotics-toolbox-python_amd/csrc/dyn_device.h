@@ -25,6 +25,16 @@ RTB_HD void dyn_opaque(double (&st)[NJ], double (&ct)[NJ])
 #endif
 }
 
+// a[i] for a wave-uniform run-time i without indexing the register array (that would send it to scratch)
+template <int NJ>
+RTB_HD double dyn_pick(const double (&a)[NJ], int i)
+{
+    double r = 0.0;
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) r += (i == k) ? a[k] : 0.0;      // (a select chain gets turned back into an indexed load)
+    return r;
+}
+
 template <int NJ, bool MDH, int MODE, bool ALLREV, class LinksP>
 RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, const double *qrow = nullptr)
 {
@@ -92,9 +102,12 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, cons
         // polar form of tau against e_k.  The same numbers come from TWO passes per column instead of the reference's 28 in all:
         //      C[:, k] = ( tau(qd + s e_k) - tau(qd - s e_k) ) / (4 s)          (exact for a quadratic form)
         // with s the power of two next above max|qd_j| (1 for qd = 0), so that the probe is neither lost in qd nor qd in the probe,
-        // whatever the scale of the velocities, and the scaling is exact: 14 passes for a 7-joint arm; agreement with the
-        // reference's order of operations ~1e-15 of max|C| (tests: oracle.coriolis_dh statement for statement, emu and GPU,
-        // velocities from 1e-9 to 1e9).
+        // whatever the overall scale of the velocities, and the scaling is exact: 14 passes for a 7-joint arm; agreement with
+        // the reference's order of operations ~1e-15 of max|C| (tests: oracle.coriolis_dh statement for statement, emu and
+        // GPU, velocities from 1e-9 to 1e9).  Its rounding error scales with (max|qd|)^2 max|h| / s, the reference's with the
+        // largest single term |h_rjk qd_j|: for a row whose nonzero velocities span more than 2^16 the two can differ by that
+        // ratio, so such rows -- any one of them sends its whole wave there; with normally distributed velocities that is ~1 % of
+        // the waves (a threshold of 2^12 sent 17 % of them) -- take the reference's own scheme below instead.
         // qd in registers: the kernel may keep the input row in the C tile itself, which the first pass starts to overwrite
         double qdv[NJ], vmax = 0.0;
 #pragma unroll
@@ -108,6 +121,10 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, cons
         ex = ex > 400 ? 400 : (ex < -400 ? -400 : ex);
         const double sc = ldexp(1.0, ex);
         const double inv4s = 0.25 / sc;
+        bool wide = false;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) wide = wide || (qdv[j] != 0.0 && fabs(qdv[j]) * 65536.0 < vmax);
+        if (!wave_any(wide)) {
 #pragma unroll 1
         for (int k = 0; k < NJ; ++k) {
             dyn_opaque<NJ>(st, ct);
@@ -116,6 +133,41 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, cons
             dyn_opaque<NJ>(st, ct);
             rne_core<NJ, MDH, false, ALLREV, true>(links, NJ, st, ct, zero, zero, zero, qin, [&](int j) { return j == k ? qdv[j] - sc : qdv[j]; },
                                      [&](int) { return 0.0; }, [&](int r, double v) { mA[r * NJ + k] = (mA[r * NJ + k] - v) * inv4s; });
+        }
+        } else {
+        // Dynamics.py:828-856 regrouped so that ONE n x n tile per lane suffices (the reference keeps Csq and C):
+        //   C[:,k] = sum_{j != k} (T_jk - Csq_k - Csq_j) qd_j / 2 + Csq_k qd_k
+        //          = 1/2 sum_{j != k} T_jk qd_j + Csq_k (2 qd_k - S / 2) - U / 2,   S = sum_j qd_j,  U = sum_j Csq_j qd_j
+        // with T_jk the pass at QD = e_j + e_k and Csq_j the pass at QD = e_j (friction removed, :820).  Same terms,
+        // different association: agreement with the reference order is ~1e-15 relative.
+        double S = 0.0, U[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { S += qdv[j]; U[j] = 0.0; }
+#pragma unroll 1
+        for (int i = 0; i < NJ; ++i) {
+            const double qdi = dyn_pick<NJ>(qdv, i), wi = 2.0 * qdi - 0.5 * S;
+            dyn_opaque<NJ>(st, ct);
+            rne_core<NJ, MDH, false, ALLREV, true>(links, NJ, st, ct, zero, zero, zero, qin, [&](int j) { return j == i ? 1.0 : 0.0; },
+                                     [&](int) { return 0.0; }, [&](int r, double v) { mA[r * NJ + i] = v * wi; U[r] += v * qdi; });
+        }
+#pragma unroll
+        for (int r = 0; r < NJ; ++r)
+#pragma unroll
+            for (int c = 0; c < NJ; ++c) mA[r * NJ + c] -= 0.5 * U[r];
+#pragma unroll 1
+        for (int i = 0; i < NJ; ++i) {
+#pragma unroll 1
+            for (int j = i + 1; j < NJ; ++j) {
+                const double hi = 0.5 * dyn_pick<NJ>(qdv, i), hj = 0.5 * dyn_pick<NJ>(qdv, j);
+                dyn_opaque<NJ>(st, ct);
+                rne_core<NJ, MDH, false, ALLREV, true>(links, NJ, st, ct, zero, zero, zero, qin,
+                                         [&](int k) { return (k == i || k == j) ? 1.0 : 0.0; }, [&](int) { return 0.0; },
+                                         [&](int r, double tau) {
+                                             mA[r * NJ + j] += tau * hi;
+                                             mA[r * NJ + i] += tau * hj;
+                                         });
+            }
+        }
         }
     }
 }

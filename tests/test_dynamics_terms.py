@@ -83,11 +83,13 @@ def test_gpu_goldens_and_shapes_puma():
 
 def _coriolis_scale_cases(n, rng):
     """qd rows of very different scales (and mixed within a row, zero, one nonzero entry): the two-passes-per-column coriolis of
-    dyn_device.h probes with a power of two next above max|qd|, so its accuracy must not depend on the scale."""
+    dyn_device.h probes with a power of two next above max|qd|, so its accuracy must not depend on the scale; a row whose nonzero
+    velocities span more than 2^16 (row 6: nine orders of magnitude) takes the reference's own 28-pass scheme instead."""
     base = rng.normal(size=(8, n))
     rows = [base[0] * 1e-9, base[1] * 1e-3, base[2], base[3] * 1e3, base[4] * 1e9, np.zeros(n), base[6] * np.logspace(-6, 3, n)]
     one = np.zeros(n); one[n // 2] = -3.7
     rows.append(one)
+    rows.append(base[7] * np.logspace(-1.5, 1.5, n))           # spread below 2^16: still the two-pass scheme
     return np.array(rows)
 
 
@@ -103,7 +105,7 @@ def test_emu_coriolis_accuracy_is_scale_free(robot):
     ref = oracle.coriolis_dh(L, mdh, q, qd)
     for i in range(len(qd)):
         scale = np.abs(ref[i]).max()
-        assert np.abs(C[i] - ref[i]).max() <= 1e-13 * scale + (0.0 if scale > 0 else 0.0), (i, np.abs(C[i] - ref[i]).max(), scale)
+        assert np.abs(C[i] - ref[i]).max() <= (1e-12 if i == 8 else 1e-13) * scale, (i, np.abs(C[i] - ref[i]).max(), scale)
     assert np.all(C[5] == 0.0)
 
 
@@ -116,7 +118,7 @@ def test_gpu_coriolis_accuracy_is_scale_free():
     C = rob.coriolis(q, qd)
     ref = oracle.coriolis_dh(t.L24(), 1, q, qd)
     for i in range(len(qd)):
-        assert np.abs(C[i] - ref[i]).max() <= 1e-13 * np.abs(ref[i]).max()
+        assert np.abs(C[i] - ref[i]).max() <= (1e-12 if i == 8 else 1e-13) * np.abs(ref[i]).max()
     assert np.all(C[5] == 0.0)
 
 
