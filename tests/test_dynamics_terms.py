@@ -84,7 +84,8 @@ def test_gpu_goldens_and_shapes_puma():
 def _coriolis_scale_cases(n, rng):
     """qd rows of very different scales (and mixed within a row, zero, one nonzero entry): the two-passes-per-column coriolis of
     dyn_device.h probes with a power of two next above max|qd|, so its accuracy must not depend on the scale; a row whose nonzero
-    velocities span more than 2^16 (row 6: nine orders of magnitude) takes the reference's own 28-pass scheme instead."""
+    velocities span more than 2^16 (row 6: nine orders of magnitude) takes the reference's own 28-pass scheme instead (in the
+    one-tile regrouping of round 1, whose sums S and U carry the large entries: 1e-12 of max|C| there, 1e-13 elsewhere)."""
     base = rng.normal(size=(8, n))
     rows = [base[0] * 1e-9, base[1] * 1e-3, base[2], base[3] * 1e3, base[4] * 1e9, np.zeros(n), base[6] * np.logspace(-6, 3, n)]
     one = np.zeros(n); one[n // 2] = -3.7
@@ -105,7 +106,7 @@ def test_emu_coriolis_accuracy_is_scale_free(robot):
     ref = oracle.coriolis_dh(L, mdh, q, qd)
     for i in range(len(qd)):
         scale = np.abs(ref[i]).max()
-        assert np.abs(C[i] - ref[i]).max() <= (1e-12 if i == 8 else 1e-13) * scale, (i, np.abs(C[i] - ref[i]).max(), scale)
+        assert np.abs(C[i] - ref[i]).max() <= (1e-12 if i in (6, 8) else 1e-13) * scale, (i, np.abs(C[i] - ref[i]).max(), scale)
     assert np.all(C[5] == 0.0)
 
 
@@ -118,7 +119,7 @@ def test_gpu_coriolis_accuracy_is_scale_free():
     C = rob.coriolis(q, qd)
     ref = oracle.coriolis_dh(t.L24(), 1, q, qd)
     for i in range(len(qd)):
-        assert np.abs(C[i] - ref[i]).max() <= (1e-12 if i == 8 else 1e-13) * np.abs(ref[i]).max()
+        assert np.abs(C[i] - ref[i]).max() <= (1e-12 if i in (6, 8) else 1e-13) * np.abs(ref[i]).max()
     assert np.all(C[5] == 0.0)
 
 
