@@ -141,14 +141,16 @@ def main():
         q = torch.from_numpy(rng.uniform(ql[0], ql[1], (N, 7))).cuda()
         qd = torch.from_numpy(rng.normal(size=(N, 7))).cuda()
         tq = torch.from_numpy(rng.normal(size=(N, 7)) * 5).cuda()
-        for name, fn, passes, byts in (("inertia", lambda: rob.inertia(q), 7, 56 + 392),
+        for name, fn, passes, byts in (("gravload", lambda: rob.gravload(q), 1, 56 + 56),
+                                       ("inertia", lambda: rob.inertia(q), 7, 56 + 392),
                                        ("coriolis", lambda: rob.coriolis(q, qd), 14, 112 + 392),
                                        ("accel", lambda: rob.accel(q, qd, tq), 8, 168 + 56)):
             avg, best = ev_time(fn, max(3, args.steps // 2), 2)
             line = {"metric": "configurations/sec (DH Panda %s)" % name, "value": N / (avg * 1e-3), "unit": "configurations/s",
                     "n": N, "kernel_avg_ms": avg, "kernel_min_ms": best, "rne_passes_per_config": passes,
                     "rne_passes_per_s": passes * N / (avg * 1e-3),
-                    "pass_kind": {"inertia": "acceleration-only passes from link i on, mirrored (csrc/rne_device.h ACC)",
+                    "pass_kind": {"gravload": "one pass at qd = 0: acceleration-only forward recursion, gravity as the base's acceleration (k_rne_atrest)",
+                                  "inertia": "acceleration-only passes from link i on, mirrored (csrc/rne_device.h ACC)",
                                   "coriolis": "2 velocity passes per column, qd +- s e_k (polar form of the quadratic velocity torque; the reference runs 28 passes, and so do the waves that hold a row whose velocities span more than 2^16)",
                                   "accel": "1 full pass + 7 acceleration-only passes + LDL^T solve"}[name],
                     # the HBM roof is the one these lines are priced against (algorithmic bytes / time); what actually limits the

@@ -224,7 +224,9 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
     for (int j = 0; j < n; ++j) flg[j] = links[j].flags;
 
     // ---- forward recursion (ne.c:133-348)
-    V3 w = v3(0, 0, 0), wd = v3(0, 0, 0), a = v3(0, 0, 0);
+    // (ACC: the gravity field enters as the base's linear acceleration -- the general formulas inject it at link 0 in exactly that
+    // role -- so a pass at qd = 0 WITH gravity, `first` = 0, is Dynamics.gravload / the qd = NULL calls of rtbhip_rne)
+    V3 w = v3(0, 0, 0), wd = v3(0, 0, 0), a = ACC ? grav : v3(0, 0, 0);
     double qddx = 0.0, qddy = 0.0;  // ne.c:311 lets gravity leak into qddv.x/.y for later links
     constexpr bool PF = RTB_RNE_PREFETCH != 0 && NJ > 0;
     FwdOps cur = fwd_ops<ALLREV>(links[0], 0, qin, qdin, qddin);
@@ -384,13 +386,16 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
 }
 
 // One sample, trig included (the single-pass kernels and the run-time-n path).
-template <int NJ, bool MDH, bool FRICTION = true, bool ALLREV = false, class LinksP, class InQ, class InQd, class InQdd, class Out>
+// ATREST: the caller knows qd = 0 for every joint (rtbhip_rne with qd = NULL: Dynamics.gravload, Dynamics.itorque): the
+// acceleration-only recursion from link 0, whole backward pass (all-revolute chains with compile-time n)
+template <int NJ, bool MDH, bool FRICTION = true, bool ALLREV = false, bool ATREST = false, class LinksP, class InQ, class InQd, class InQdd, class Out>
 RTB_HD void rne_lane(LinksP links, int n_rt, V3 grav, V3 ftip, V3 ntip, InQ qin, InQd qdin, InQdd qddin, Out tau)
 {
     constexpr int CAP = NJ > 0 ? NJ : RTBHIP_MAX_JOINTS;
     double st[CAP], ct[CAP];
     if constexpr (NJ > 0) rne_trig<NJ, ALLREV>(links, qin, st, ct);
-    rne_core<NJ, MDH, FRICTION, ALLREV, (NJ > 0)>(links, n_rt, st, ct, grav, ftip, ntip, qin, qdin, qddin, tau);
+    if constexpr (ATREST) rne_core<NJ, MDH, false, true, true, true>(links, n_rt, st, ct, grav, ftip, ntip, qin, qdin, qddin, tau, 0);
+    else rne_core<NJ, MDH, FRICTION, ALLREV, (NJ > 0)>(links, n_rt, st, ct, grav, ftip, ntip, qin, qdin, qddin, tau);
 }
 
 }  // namespace rtbhip

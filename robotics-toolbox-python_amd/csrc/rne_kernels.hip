@@ -49,7 +49,7 @@ __device__ __forceinline__ void tile_copy(double *rows, int stride, int col_off,
 // recursion with the LDS row as the accessor target (q is read once, up front; qd/qdd are re-read
 // from LDS where they are used, so they occupy no registers across the recursions; tau overwrites the
 // q slots, which are dead by then), write the torques back coalesced.
-template <int NJ, bool MDH, bool ALLREV>
+template <int NJ, bool MDH, bool ALLREV, bool ATREST = false>
 __device__ __forceinline__ void rne_tile(const RneParams &rp, ConstLinks links, int n, int stride, int64_t tile,
                                          const double *__restrict__ q, const double *__restrict__ qd,
                                          const double *__restrict__ qdd, double *__restrict__ tau, double *lds, int lane)
@@ -98,8 +98,12 @@ __device__ __forceinline__ void rne_tile(const RneParams &rp, ConstLinks links, 
     }
     __syncthreads();
     if (lane < ncfg) {
-        rne_lane<NJ, MDH, true, ALLREV>(links, n, grav, ftip, ntip, [&](int j) { return mine[j]; }, [&](int j) { return mine[n + j]; },
-                          [&](int j) { return mine[2 * n + j]; }, [&](int j, double v) { mine[j] = v; });
+        if constexpr (ATREST)
+            rne_lane<NJ, MDH, false, true, true>(links, n, grav, ftip, ntip, [&](int j) { return mine[j]; }, [&](int) { return 0.0; },
+                              [&](int j) { return mine[2 * n + j]; }, [&](int j, double v) { mine[j] = v; });
+        else
+            rne_lane<NJ, MDH, true, ALLREV>(links, n, grav, ftip, ntip, [&](int j) { return mine[j]; }, [&](int j) { return mine[n + j]; },
+                              [&](int j) { return mine[2 * n + j]; }, [&](int j, double v) { mine[j] = v; });
     }
     __syncthreads();
     if (NJ > 0) {
@@ -135,6 +139,17 @@ __global__ __launch_bounds__(kW, RTB_RNE_WAVES) void k_rne(RneParams rp, const D
     rne_tile<NJ, MDH, ALLREV>(rp, (ConstLinks)links_g, NJ, rne_stride(NJ), blockIdx.x, q, qd, qdd, tau, lds, threadIdx.x);
 }
 
+// qd = NULL on an all-revolute chain (Dynamics.gravload: qd = qdd = 0; Dynamics.itorque: qd = 0, no gravity): every link's
+// angular velocity is zero, so the forward recursion is the acceleration-only one of rne_device.h (ACC) from link 0 -- about
+// half its fp64 operations -- with gravity entering as the base's linear acceleration; the backward recursion is the usual one.
+template <int NJ, bool MDH>
+__global__ __launch_bounds__(kW, RTB_RNE_WAVES) void k_rne_atrest(RneParams rp, const DevLink *links_g, const double *__restrict__ q,
+                                                  const double *__restrict__ qdd, double *__restrict__ tau)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    rne_tile<NJ, MDH, true, true>(rp, (ConstLinks)links_g, NJ, rne_stride(NJ), blockIdx.x, q, nullptr, qdd, tau, lds, threadIdx.x);
+}
+
 // run-time joint count (n > 8): grid-stride over tiles, per-link state in private memory
 template <bool MDH>
 __global__ __launch_bounds__(kW) void k_rne_rt(RneParams rp, const DevLink *links_g, const double *__restrict__ q,
@@ -161,6 +176,11 @@ template <int NJ>
 static void launch_nj(bool mdh, bool allrev, dim3 grid, size_t lds, hipStream_t s, const RneParams &rp, const DevLink *links,
                       const double *q, const double *qd, const double *qdd, double *tau)
 {
+    if (allrev && !qd) {
+        if (mdh) hipLaunchKernelGGL((k_rne_atrest<NJ, true>), grid, dim3(kW), lds, s, rp, links, q, qdd, tau);
+        else hipLaunchKernelGGL((k_rne_atrest<NJ, false>), grid, dim3(kW), lds, s, rp, links, q, qdd, tau);
+        return;
+    }
     if (mdh && allrev) hipLaunchKernelGGL((k_rne<NJ, true, true>), grid, dim3(kW), lds, s, rp, links, q, qd, qdd, tau);
     else if (mdh) hipLaunchKernelGGL((k_rne<NJ, true, false>), grid, dim3(kW), lds, s, rp, links, q, qd, qdd, tau);
     else if (allrev) hipLaunchKernelGGL((k_rne<NJ, false, true>), grid, dim3(kW), lds, s, rp, links, q, qd, qdd, tau);

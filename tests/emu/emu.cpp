@@ -689,12 +689,21 @@ static void rne_run(const Dyn *d, const double *q, const double *qd, const doubl
     const DevLink *links = d->links.data();
     const int n = d->n;
     for (int64_t s = 0; s < N; ++s) {
-        const double *a = q + s * n, *b = qd + s * n, *c = qdd + s * n;
+        const double *a = q + s * n, *b = qd ? qd + s * n : nullptr, *c = qdd ? qdd + s * n : nullptr;
         double *o = tau + s * n;
         auto qi = [&](int j) { return a[j]; };
-        auto qdi = [&](int j) { return b[j]; };
-        auto qddi = [&](int j) { return c[j]; };
+        auto qdi = [&](int j) { return b ? b[j] : 0.0; };
+        auto qddi = [&](int j) { return c ? c[j] : 0.0; };
         auto out = [&](int j, double v) { o[j] = v; };
+        bool allrev = true;
+        for (const DevLink &l : d->links) allrev = allrev && l.sigma == 0;
+        if constexpr (NJ > 0) {
+            if (!qd && allrev) {             // the kernel launcher's choice for qd = NULL on an all-revolute chain: k_rne_atrest
+                if (d->mdh) rne_lane<NJ, true, false, true, true>(links, n, g, f, nt, qi, qdi, qddi, out);
+                else rne_lane<NJ, false, false, true, true>(links, n, g, f, nt, qi, qdi, qddi, out);
+                continue;
+            }
+        }
         if (d->mdh) rne_lane<NJ, true>(links, n, g, f, nt, qi, qdi, qddi, out);
         else rne_lane<NJ, false>(links, n, g, f, nt, qi, qdi, qddi, out);
     }

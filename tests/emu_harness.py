@@ -142,8 +142,8 @@ def rne(L24, mdh, q, qd, qdd, grav_c, fext=None, force_generic=False):
     h = _u64(0)
     rc = lib().rtbhip_dyn_create(_p(L), n, int(mdh), C.byref(h))
     assert rc == 0, lib().rtbhip_last_error()
-    q, qd, qdd = (np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1, n)) for x in (q, qd, qdd))
-    tau = np.full(q.shape, np.nan)
+    q, qd, qdd = (None if x is None else np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1, n)) for x in (q, qd, qdd))
+    tau = np.full(q.shape, np.nan)                     # qd / qdd None = NULL pointers: what gravload / itorque hand rtbhip_rne
     g = np.ascontiguousarray(grav_c, dtype=np.float64)
     f = None if fext is None else np.ascontiguousarray(fext, dtype=np.float64)
     rc = lib().emu_rne(h.value, _p(q), _p(qd), _p(qdd), q.shape[0], _p(g), _p(f), _p(tau), int(force_generic))

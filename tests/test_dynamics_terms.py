@@ -81,6 +81,28 @@ def test_gpu_goldens_and_shapes_puma():
     nt.assert_array_almost_equal(puma.accel(q2, np.c_[aq, aq].T, np.c_[at, at].T)[1], LIT["D_puma_accel"], decimal=4)
 
 
+@pytest.mark.parametrize("robot", ["puma", "panda"])
+def test_emu_rne_at_rest_variant(robot):
+    """qd = NULL on an all-revolute chain takes the acceleration-only forward recursion with gravity as the base's acceleration
+    (k_rne_atrest): gravload (qdd NULL too), itorque (no gravity), and the general qd = NULL call with gravity, qdd and an
+    external wrench must equal the full recursion fed zeros."""
+    import emu_harness as emu
+    t = chains.puma560() if robot == "puma" else chains.panda_dh()
+    mdh, L, gc, n = (0 if robot == "puma" else 1), t.L24(), -t.gravity, t.L24().shape[0]
+    rng = np.random.default_rng(12)
+    q = rng.uniform(t.qlim[:, 0], t.qlim[:, 1], (70, n))
+    qdd = rng.normal(size=(70, n))
+    z = np.zeros_like(q)
+    fext = np.array([1.0, -2.0, 0.5, 0.1, 0.2, -0.3])
+    for args in ((None, gc, None), (qdd, [0, 0, 0], None), (qdd, gc, fext)):
+        acc, g, f = args
+        fast = emu.rne(L, mdh, q, None, acc, g, fext=f)
+        full = emu.rne(L, mdh, q, z, z if acc is None else acc, g, fext=f)
+        ref = oracle.rne_dh(L, mdh, q, z, z if acc is None else acc, g, fext=f)
+        nt.assert_allclose(fast, ref, rtol=1e-12, atol=1e-12)
+        nt.assert_allclose(fast, full, rtol=1e-14, atol=1e-13)
+
+
 def _coriolis_scale_cases(n, rng):
     """qd rows of very different scales (and mixed within a row, zero, one nonzero entry): the two-passes-per-column coriolis of
     dyn_device.h probes with a power of two next above max|qd|, so its accuracy must not depend on the scale; a row whose nonzero
@@ -145,7 +167,8 @@ def test_gpu_vs_oracle_and_identities(robot, N):
     nt.assert_allclose(M, np.swapaxes(M, 1, 2), atol=1e-11)                       # symmetric
     assert np.linalg.eigvalsh(M).min() > 0                                        # positive definite
     nt.assert_allclose(rob.itorque(q, qdd), np.einsum("nij,nj->ni", M, qdd), rtol=1e-10, atol=1e-10)
-    nt.assert_allclose(rob.gravload(q), rob.rne(q, np.zeros_like(q), np.zeros_like(q)), atol=0)   # NULL == zeros
+    full = rob.rne(q, np.zeros_like(q), np.zeros_like(q))                         # NULL qd = the at-rest recursion, zeros = the full one
+    nt.assert_allclose(rob.gravload(q), full, rtol=0, atol=1e-14 * np.abs(full).max())
     # forward dynamics inverts inverse dynamics: rne(q, qd, accel(q, qd, tau)) == tau
     back = rob.rne(q, qd, a)
     nt.assert_allclose(back, tq, rtol=1e-8, atol=1e-8 * np.abs(tq).max())
