@@ -103,6 +103,30 @@ def test_emu_rne_at_rest_variant(robot):
         nt.assert_allclose(fast, full, rtol=1e-14, atol=1e-13)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("robot", ["puma", "panda"])
+def test_gpu_rne_at_rest_variant(robot):
+    """rtbhip_rne with qd = NULL (k_rne_atrest) on the device: gravload, itorque and a call with gravity, qdd and an external wrench
+    against the oracle's full recursion fed zeros; host and device pointers; ragged tile."""
+    import torch
+    rob = rtbhip.models.DH.Puma560() if robot == "puma" else rtbhip.models.DH.Panda()
+    t = chains.puma560() if robot == "puma" else chains.panda_dh()
+    mdh, L, gc, n = rob.mdh, t.L24(), -t.gravity, rob.n
+    rng = np.random.default_rng(13)
+    N = 1000 + 37
+    q = rng.uniform(t.qlim[:, 0], t.qlim[:, 1], (N, n))
+    qdd = rng.normal(size=(N, n))
+    z = np.zeros_like(q)
+    fext = np.array([1.0, -2.0, 0.5, 0.1, 0.2, -0.3])
+    nt.assert_allclose(rob.gravload(q), oracle.rne_dh(L, mdh, q, z, z, gc), rtol=1e-12, atol=1e-12)
+    nt.assert_allclose(rob.itorque(q, qdd), oracle.rne_dh(L, mdh, q, z, qdd, [0, 0, 0]), rtol=1e-12, atol=1e-12)
+    ref = oracle.rne_dh(L, mdh, q, z, qdd, gc, fext=fext)
+    host = rob.rne(q, None, qdd, fext=fext)
+    nt.assert_allclose(host, ref, rtol=1e-12, atol=1e-12)
+    dev = rob.rne(torch.from_numpy(q).cuda(), None, torch.from_numpy(qdd).cuda(), fext=fext)
+    nt.assert_array_equal(dev.cpu().numpy(), host)
+
+
 def _coriolis_scale_cases(n, rng):
     """qd rows of very different scales (and mixed within a row, zero, one nonzero entry): the two-passes-per-column coriolis of
     dyn_device.h probes with a power of two next above max|qd|, so its accuracy must not depend on the scale; a row whose nonzero
