@@ -350,6 +350,7 @@ struct IkLane {
     int32_t fin, ok;   // set by ik_iter when the search ended in this iteration (it contributes `iter` iterations)
 };
 constexpr int kIkIdle = 0, kIkRun = 1, kIkParkedOk = 2, kIkParkedLast = 3;
+constexpr int kIkOkPending = 2;    // IkLane::ok of a search that reached the tolerance and awaits its wrap + limit test (ik_settle)
 
 template <class PD>
 RTB_HD int ik_s_first(const PD &p) { return p.flavour == 0 ? 1 : 0; }
@@ -490,15 +491,8 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, Q
     const bool arrived = E < p.tol;
     if (p.flavour == 0) {
         st.E = E;
-        if (arrived) {                                          // ik.cpp:48-54
-            bool ok = true;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const double w = ik_wrap_c(qa.get(j));
-                qa.put(j, w);
-                if (w < qlim[j] || w > qlim[NJ + j]) ok = false;   // ik.cpp:227-239
-            }
-            st.fin = 1; st.ok = (ok || !p.reject_jl) ? 1 : 0;
+        if (arrived) {                                          // ik.cpp:48-54: the wrap and the limit test happen in ik_settle
+            st.fin = 1; st.ok = kIkOkPending;
         } else {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) qa.put(j, qa.get(j) + dq[j]);      // ik.cpp:57
@@ -518,19 +512,32 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, Q
 #pragma unroll
         for (int j = 0; j < NJ; ++j) dq[j] += qa.get(j);        // the step is taken before E is tested (IK.py:319-327)
         if (arrived) {
-            bool ok = true;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                dq[j] = ik_wrap_py(dq[j]);
-                if (dq[j] < qlim[j] || dq[j] > qlim[NJ + j]) ok = false;
-            }
-            st.fin = 1; st.ok = (ok || !p.reject_jl) ? 1 : 0;   // IK.py:336-351
+            st.fin = 1; st.ok = kIkOkPending;                    // IK.py:336-351: wrap and limit test in ik_settle
         } else if (st.iter >= p.ilimit) {
             st.fin = 1; st.ok = 0;
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) qa.put(j, dq[j]);
     }
+}
+
+// The end of a search that reached the tolerance: wrap q into [-pi, pi) the way the solver does (C: fmod, ik.cpp:51; Python: %,
+// IK.py:331) and test the joint limits (ik.cpp:227-239, IK.py:336-351).  Kept OUT of ik_iter: with 64 lanes some lane arrives in
+// nearly every iteration, and the wave would execute these ~260 instructions (seven fmod expansions) every time; here they run
+// once per scheduling pass (ik_report) -- at most every (pass_mask + 1)-th iteration.  The search is over either way (fin is set
+// by ik_iter); only `ok` and the wrapped q are pending.
+template <int NJ, class PD, class QL, class QA>
+RTB_HD void ik_settle(IkLane<NJ> &st, const PD &p, QL qlim, QA qa)
+{
+    if (!st.fin || st.ok != kIkOkPending) return;
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const double w = p.flavour == 0 ? ik_wrap_c(qa.get(j)) : ik_wrap_py(qa.get(j));
+        qa.put(j, w);
+        if (w < qlim[j] || w > qlim[NJ + j]) ok = false;
+    }
+    st.ok = (ok || !p.reject_jl) ? 1 : 0;
 }
 
 // which compiled step variant serves these parameters (host launcher, emu and the sequential driver agree on it)
@@ -656,10 +663,11 @@ RTB_HD int ik_rank(unsigned long long mask, int lane)
 }
 
 // phase A: a lane whose search just ended posts the result and parks or goes idle
-template <int NJ, class SH>
-RTB_HD void ik_report(IkLane<NJ> &st, SH &sh, double *__restrict__ residual)
+template <int NJ, class SH, class PD, class QL, class QA>
+RTB_HD void ik_report(IkLane<NJ> &st, SH &sh, double *__restrict__ residual, const PD &p, QL qlim, QA qa)
 {
     if (st.status != kIkRun || !st.fin) return;
+    ik_settle<NJ>(st, p, qlim, qa);
     const int s_last = sh.slast[st.slot];
     sh.rec[st.slot][st.s & (kIkRing - 1)] = (uint16_t)(1 | (st.ok ? 2 : 0) | (st.iter << 2));
     if (st.ok) ik_lds_min(&sh.best[st.slot], st.s);
@@ -979,6 +987,7 @@ RTB_HD void ik_solve_sequential(const IkDev &p, const CV &cv, QL qlim, int64_t t
         ik_search_begin<NJ>(st, qa, p, qlim, tgt, s, p.has_q0 ? q0 + (int64_t)NJ * tgt : nullptr);
         while (!st.fin) {
             ik_iter_any<NJ>(st, p, cv, qlim, [&](int k) { return Td[k]; }, qa);
+            ik_settle<NJ>(st, p, qlim, qa);
         }
         it += st.iter;
         if (st.ok || s == s_last) {

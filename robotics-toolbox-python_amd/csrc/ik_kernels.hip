@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
             double *q_out = ka->q_out, *residual = ka->residual;
             int32_t *success = ka->success, *iters = ka->iters, *searches = ka->searches;
             const IkWork *work = ka->work;
-            ik_report<NJ>(st, sh, residual);                                           // phase A
+            ik_report<NJ>(st, sh, residual, p, qlim, ik_lds_q(sh, lane));              // phase A
             __syncthreads();
             if ((busy >> lane) & 1ull) ik_account(lane, sh);                            // phase B
             __syncthreads();

@@ -383,7 +383,7 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
             if (w.first || ((w.tick++ & p.pass_mask) == 0 && anyfin)) {
                 w.first = false;
                 w.passes++;
-                for (int l = 0; l < kWave; ++l) ik_report<NJ>(w.st[l], w.sh, residual);
+                for (int l = 0; l < kWave; ++l) ik_report<NJ>(w.st[l], w.sh, residual, p, qlim, ik_lds_q(w.sh, l));
                 for (int l = 0; l < kWave; ++l) if ((w.busy >> l) & 1ull) ik_account(l, w.sh);
                 for (int l = 0; l < kWave; ++l) ik_finalize<NJ>(w.st[l], w.sh, l, p, qlim, q_out, success, iters, searches, residual);
                 const unsigned long long freed = ballot(w, [&](int l) { return ((w.busy >> l) & 1ull) && w.sh.res[l] != 0; });
