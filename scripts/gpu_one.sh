@@ -1,4 +1,5 @@
 #!/bin/bash
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_dynamics_terms.py -m gpu -q --timeout 600 --tb=short 2>&1 | grep -v "Warning\|^  \|^$" | tail -12 | cut -c1-300
+mkdir -p gpurun_out/r2n
+timeout 200 python bench_extra.py --what ik --steps 16 2>/dev/null | grep '^{' > gpurun_out/r2n/bench_ik.jsonl; cut -c1-330 gpurun_out/r2n/bench_ik.jsonl
