@@ -80,6 +80,15 @@ void rtbhip_shutdown(void);
 /* ETS_init (fknm.cpp:1066-1114).  qlim: 2*n doubles, n lows then n highs, in chain joint order, or
  * NULL for the reference defaults [-pi,pi] / [0,1] (robot/ET.py:109-115). */
 int rtbhip_chain_create(const rtbhip_et *ets, int32_t m, const double *qlim, rtbhip_chain_t *chain);
+/* Product-of-exponentials robots (robot/PoERobot.py: PoERevolute / PoEPrismatic :124-154, PoERobot :157-324):
+ * T(q) = exp([S_1] q_1) ... exp([S_n] q_n) T0.  twists is (n,6), row i = (v, w) of the unit joint twist S_i in the base frame
+ * (spatialmath Twist3 order; PoERevolute(axis, point): w = axis/|axis|, v = -w x point; PoEPrismatic(axis): w = 0,
+ * v = axis/|axis|); T0_16 the end-effector pose at q = 0 (row-major, NULL = identity).  The twists are lowered directly to the
+ * chain form every other call of this library runs (csrc/chain.cpp compile_poe) -- the handle then serves
+ * rtbhip_fkine / rtbhip_jacob (frame 0: PoERobot.jacob0 :230-250, frame 1: jacobe :252-270) and everything else that takes a
+ * chain (hessian, ik_lm, ...), which the reference reaches only through its ETS re-expression (_update_ets :272-324).
+ * Joint i reads column i of q.  Non-unit twists and twists with a pitch are refused (RTBHIP_EINVAL). */
+int rtbhip_chain_create_poe(const double *twists, int32_t n, const double *T0_16, const double *qlim, rtbhip_chain_t *chain);
 int rtbhip_chain_destroy(rtbhip_chain_t chain);
 int rtbhip_chain_info(rtbhip_chain_t chain, int32_t *n, int32_t *m, int32_t *q_width);
 /* Row pitch of q (columns per configuration).  A chain created from a branch of a tree robot keeps the robot-wide joint numbers

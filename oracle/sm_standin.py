@@ -1,0 +1,210 @@
+"""oracle/sm_standin.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A stand-in for the slice of spatialmath-python (pyproject.toml:22 `spatialmath-python>=1.1.16`: a third-party dependency of the
+reference that is neither vendored nor installable here) that the reference's robot/ET.py, robot/ETS.py and robot/IK.py touch
+when their NUMERIC paths -- and the symbolic fall-back of ETS.eval / ETS.jacob0 -- run.  It exists so that those files can be
+executed unmodified (oracle/ref_classes.py); it computes nothing of the kinematics, which stay in whichever `fknm` module the
+classes are bound to.  Everything below restates the published behaviour of the spatialmath function of the same name for the
+argument kinds the reference passes; anything else raises so that a silent divergence is impossible.
+"""
+import math
+import types
+
+import numpy as np
+
+try:
+    import sympy
+except ImportError:                                  # pragma: no cover
+    sympy = None
+
+
+def issymbol(x):
+    """spatialmath.base.symbolic.issymbol: a sympy expression (robot/ET.py:59,84,163,315)."""
+    return sympy is not None and isinstance(x, sympy.Expr)
+
+
+def _sc(theta):
+    if issymbol(theta):
+        return sympy.sin(theta), sympy.cos(theta), object
+    return math.sin(theta), math.cos(theta), np.float64
+
+
+def _unit(theta, unit):
+    if unit.lower().startswith("deg") and not issymbol(theta):
+        return math.radians(theta)
+    return theta
+
+
+def trotx(theta, unit="rad"):
+    s, c, dt = _sc(_unit(theta, unit))
+    return np.array([[1, 0, 0, 0], [0, c, -s, 0], [0, s, c, 0], [0, 0, 0, 1]], dtype=dt)
+
+
+def troty(theta, unit="rad"):
+    s, c, dt = _sc(_unit(theta, unit))
+    return np.array([[c, 0, s, 0], [0, 1, 0, 0], [-s, 0, c, 0], [0, 0, 0, 1]], dtype=dt)
+
+
+def trotz(theta, unit="rad"):
+    s, c, dt = _sc(_unit(theta, unit))
+    return np.array([[c, -s, 0, 0], [s, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=dt)
+
+
+def getvector(v, dim=None, out="array", dtype=np.float64):
+    """spatialmath.base.argcheck.getvector for the uses at robot/ET.py:69,446 and robot/ETS.py (q vectors)."""
+    if np.isscalar(v) or issymbol(v):
+        v = [v]
+    a = np.asarray(v)
+    if a.dtype != object:
+        a = a.astype(dtype)
+    if a.ndim == 2 and 1 in a.shape:
+        a = a.reshape(-1)
+    if a.ndim != 1:
+        raise ValueError("expecting a vector")
+    if dim is not None and a.shape[0] != dim:
+        raise ValueError("incorrect vector length: expected %d, got %d" % (dim, a.shape[0]))
+    if out == "array":
+        return a
+    if out == "list":
+        return list(a)
+    if out in ("sequence", "tuple"):
+        return tuple(a)
+    if out == "row":
+        return a.reshape(1, -1)
+    if out == "col":
+        return a.reshape(-1, 1)
+    raise ValueError("invalid output specifier")
+
+
+def getmatrix(m, shape, dtype=np.float64):
+    """spatialmath.base.argcheck.getmatrix as robot/ETS.py:1080 calls it: (None, None) -> a 2-D array, a vector becoming one row."""
+    a = np.asarray(m)
+    if a.dtype != object:
+        a = a.astype(dtype)
+    if a.ndim == 0:
+        a = a.reshape(1, 1)
+    elif a.ndim == 1:
+        if shape[0] is not None and shape[1] is None:
+            a = a.reshape(shape[0], -1)
+        elif shape[1] is not None and shape[0] is None:
+            a = a.reshape(-1, shape[1])
+        else:
+            a = a.reshape(1, -1)
+    if a.ndim != 2:
+        raise ValueError("expecting a matrix")
+    for have, want in zip(a.shape, shape):
+        if want is not None and have != want:
+            raise ValueError("matrix has the wrong shape")
+    return a
+
+
+def verifymatrix(m, shape):
+    if not isinstance(m, np.ndarray) or m.shape != tuple(shape):
+        raise TypeError("input must be a numPy ndarray of shape %s" % (shape,))
+
+
+def t2r(T):
+    return np.asarray(T)[:3, :3]
+
+
+def tr2jac(T):
+    """spatialmath.base.tr2jac: blkdiag(R, R) (robot/ETS.py, the Python fall-back of jacobe)."""
+    R = t2r(T)
+    J = np.zeros((6, 6), dtype=np.asarray(T).dtype)
+    J[:3, :3] = R
+    J[3:, 3:] = R
+    return J
+
+
+def simplify(x):
+    return sympy.simplify(x) if issymbol(x) else x
+
+
+def _not_offered(name):
+    def f(*a, **k):
+        raise NotImplementedError("spatialmath stand-in: %s is not restated (oracle/sm_standin.py)" % name)
+    f.__name__ = name
+    return f
+
+
+class SE3:
+    """spatialmath.SE3 as far as robot/ET.py, robot/ETS.py and robot/IK.py use it: construction from a 4x4 / a stack (with
+    check=False), Empty() / append() (ETS.fkine, robot/ETS.py:1006-1017), isinstance, len, iteration, `.A`, `.inv()`, `.t`, `.R`, `*`."""
+
+    def __init__(self, arg=None, check=True):
+        if arg is None:
+            self._data = [np.eye(4)]
+        elif isinstance(arg, SE3):
+            self._data = [a.copy() for a in arg._data]
+        else:
+            A = np.asarray(arg)
+            if A.dtype != object:
+                A = A.astype(np.float64)
+            if A.ndim == 2:
+                self._data = [A]
+            elif A.ndim == 3:
+                self._data = list(A)
+            else:
+                raise ValueError("bad argument to SE3 constructor")
+        for a in self._data:
+            if a.shape != (4, 4):
+                raise ValueError("SE3 needs 4x4 matrices")
+
+    @classmethod
+    def Empty(cls):
+        x = cls()
+        x._data = []
+        return x
+
+    def append(self, other):
+        self._data.extend(other._data)
+
+    def __len__(self): return len(self._data)
+    def __iter__(self): return (SE3(a, check=False) for a in self._data)
+    def __getitem__(self, i): return SE3(self._data[i], check=False)
+
+    @property
+    def A(self): return self._data[0] if len(self._data) == 1 else np.array(self._data)
+
+    @property
+    def t(self): return self.A[..., :3, 3]
+
+    @property
+    def R(self): return self.A[..., :3, :3]
+
+    def inv(self):
+        out = []
+        for a in self._data:
+            X = np.eye(4, dtype=a.dtype)
+            X[:3, :3] = a[:3, :3].T
+            X[:3, 3] = -a[:3, :3].T @ a[:3, 3]
+            out.append(X)
+        return SE3(np.array(out) if len(out) > 1 else out[0], check=False)
+
+    def __mul__(self, other):
+        if isinstance(other, SE3):
+            return SE3(self.A @ other.A, check=False)
+        return NotImplemented
+
+
+class SE2:
+    """Only ever an isinstance target on the paths exercised (the 2-D classes ET2 / ETS2 are not run)."""
+
+    def __init__(self, *a, **k):
+        raise NotImplementedError("spatialmath stand-in: SE2 is not restated")
+
+
+def modules():
+    """(spatialmath, spatialmath.base) module objects to be placed in sys.modules while the reference files are loaded."""
+    sm = types.ModuleType("spatialmath")
+    smb = types.ModuleType("spatialmath.base")
+    for f in (trotx, troty, trotz, issymbol, getvector, getmatrix, verifymatrix, t2r, tr2jac, simplify):
+        setattr(smb, f.__name__, f)
+    for name in ("tr2rpy", "trot2", "transl2", "tr2xyt", "tr2jac2", "rotvelxform"):
+        setattr(smb, name, _not_offered(name))
+    # used only by tools/p_servo.py's pure-Python fall-back, which never runs (Angle_Axis does not raise)
+    smb.iszerovec = lambda v, tol=20: bool(np.linalg.norm(v) < tol * np.finfo(np.float64).eps)
+    smb.norm = lambda v: float(np.linalg.norm(v))
+    smb.isscalar = np.isscalar
+    sm.SE3, sm.SE2, sm.base = SE3, SE2, smb
+    return sm, smb

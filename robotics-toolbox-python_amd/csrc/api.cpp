@@ -368,6 +368,18 @@ int rtbhip_chain_create(const rtbhip_et *ets, int32_t m, const double *qlim, rtb
     return RTBHIP_OK;
 }
 
+int rtbhip_chain_create_poe(const double *twists, int32_t n, const double *T0_16, const double *qlim, rtbhip_chain_t *chain)
+{
+    if (!chain) { set_error("chain_create_poe: NULL out"); return RTBHIP_EINVAL; }
+    std::shared_ptr<Chain> c(new Chain());
+    RTB_TRY(compile_poe(twists, n, T0_16, qlim, c.get()));
+    uint64_t h = g_next.fetch_add(1);
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    g_chains[h] = std::move(c);
+    *chain = h;
+    return RTBHIP_OK;
+}
+
 int rtbhip_chain_destroy(rtbhip_chain_t chain)
 {
     std::shared_ptr<Chain> c;             // the device tables go with the last reference (a launch in flight keeps one)

@@ -137,6 +137,101 @@ int compile_chain(const rtbhip_et *ets, int m, const double *qlim, Chain *out)
     return RTBHIP_OK;
 }
 
+// Product-of-exponentials chains (reference robot/PoERobot.py): T(q) = exp([S_1] q_1) ... exp([S_n] q_n) T0 with unit joint
+// twists S_i = (v_i, w_i) given in the BASE frame (PoERevolute: w = unit axis, v = -w x point, Twist3.UnitRevolute;
+// PoEPrismatic: w = 0, v = unit direction).  The reference evaluates that product with one matrix exponential per joint in
+// Python (PoERobot.fkine :209-228, jacob0 :230-250, jacobe :252-270) and, for everything else, re-expresses the robot as an
+// ETS through roll-pitch-yaw angles (_update_ets :272-324).  Here the twists are lowered DIRECTLY to the canonical segment
+// form: with W_i any frame whose z axis is the screw axis and whose origin lies on it, exp([S_i] q) = W_i Z(q) W_i^-1
+// (Z = rotation about / translation along z), so the product telescopes to
+//        T(q) = (W_1) Z(q_1) (W_1^-1 W_2) Z(q_2) ... Z(q_n) (W_n^-1 T0)
+// -- n joints about z and n + 1 constants, no exponential, no angle extraction, nothing the device code does not already run.
+int compile_poe(const double *twists, int n, const double *T0, const double *qlim, Chain *out)
+{
+    if (n < 0 || (n > 0 && twists == nullptr)) { set_error("chain_create_poe: bad twists/n"); return RTBHIP_EINVAL; }
+    if (n > RTBHIP_MAX_JOINTS) { set_error("chain_create_poe: more than RTBHIP_MAX_JOINTS joints"); return RTBHIP_ELIMIT; }
+    if (T0 && (T0[12] != 0.0 || T0[13] != 0.0 || T0[14] != 0.0 || T0[15] != 1.0)) {
+        set_error("chain_create_poe: T0 is not affine (bottom row must be 0 0 0 1)");
+        return RTBHIP_EINVAL;
+    }
+    std::vector<rtbhip_et> ets;
+    ets.reserve(2 * (size_t)n + 1);
+    double Rp[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, cp[3] = {0, 0, 0};   // W_{i-1}: rotation (row-major), origin
+    auto push_const = [&](const double R[9], const double c[3]) {      // W_{i-1}^-1 * [R | c]
+        rtbhip_et e;
+        std::memset(&e, 0, sizeof e);
+        e.kind = RTBHIP_ET_CONST;
+        for (int r = 0; r < 3; r++) {
+            for (int k = 0; k < 3; k++) {
+                double s = 0.0;
+                for (int j = 0; j < 3; j++) s += Rp[3 * j + r] * R[3 * j + k];
+                e.T[4 * r + k] = s;
+            }
+            double s = 0.0;
+            for (int j = 0; j < 3; j++) s += Rp[3 * j + r] * (c[j] - cp[j]);
+            e.T[4 * r + 3] = s;
+        }
+        e.T[15] = 1.0;
+        ets.push_back(e);
+    };
+    for (int i = 0; i < n; i++) {
+        const double *v = twists + 6 * (size_t)i, *w = v + 3;
+        const double wn = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+        const double vn = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        double a[3], c[3] = {0, 0, 0};
+        bool prismatic;
+        if (!(wn == wn) || !(vn == vn)) { set_error("chain_create_poe: twist " + std::to_string(i) + " is not finite"); return RTBHIP_EINVAL; }
+        if (wn == 0.0) {
+            if (std::fabs(vn - 1.0) > 1e-9) { set_error("chain_create_poe: twist " + std::to_string(i) + " is not a unit prismatic twist (w = 0 needs |v| = 1)"); return RTBHIP_EINVAL; }
+            prismatic = true;
+            for (int k = 0; k < 3; k++) a[k] = v[k] / vn;
+        } else {
+            if (std::fabs(wn - 1.0) > 1e-9) { set_error("chain_create_poe: twist " + std::to_string(i) + " is not a unit revolute twist (|w| must be 1)"); return RTBHIP_EINVAL; }
+            const double pitch = (w[0] * v[0] + w[1] * v[1] + w[2] * v[2]) / (wn * wn);
+            if (std::fabs(pitch) > 1e-9 * (1.0 + vn)) { set_error("chain_create_poe: twist " + std::to_string(i) + " has a pitch (w . v != 0): only pure revolute / prismatic joints"); return RTBHIP_EINVAL; }
+            prismatic = false;
+            for (int k = 0; k < 3; k++) a[k] = w[k] / wn;
+            // the point of the axis nearest the origin: w x v / |w|^2  (PoERobot.py:75 `principal_point`)
+            c[0] = (w[1] * v[2] - w[2] * v[1]) / (wn * wn);
+            c[1] = (w[2] * v[0] - w[0] * v[2]) / (wn * wn);
+            c[2] = (w[0] * v[1] - w[1] * v[0]) / (wn * wn);
+        }
+        // x: the coordinate axis least aligned with a, made orthogonal to it; y = a x x
+        int k0 = 0;
+        if (std::fabs(a[1]) < std::fabs(a[k0])) k0 = 1;
+        if (std::fabs(a[2]) < std::fabs(a[k0])) k0 = 2;
+        double x[3] = {0, 0, 0};
+        x[k0] = 1.0;
+        const double d = a[k0];
+        double xn = 0.0;
+        for (int k = 0; k < 3; k++) { x[k] -= d * a[k]; xn += x[k] * x[k]; }
+        xn = std::sqrt(xn);
+        for (int k = 0; k < 3; k++) x[k] /= xn;
+        const double y[3] = {a[1] * x[2] - a[2] * x[1], a[2] * x[0] - a[0] * x[2], a[0] * x[1] - a[1] * x[0]};
+        double R[9];
+        for (int r = 0; r < 3; r++) { R[3 * r] = x[r]; R[3 * r + 1] = y[r]; R[3 * r + 2] = a[r]; }
+        push_const(R, c);
+        rtbhip_et j;
+        std::memset(&j, 0, sizeof j);
+        j.kind = prismatic ? RTBHIP_ET_TZ : RTBHIP_ET_RZ;
+        j.jindex = i;
+        for (int k = 0; k < 4; k++) j.T[5 * k] = 1.0;
+        ets.push_back(j);
+        std::memcpy(Rp, R, sizeof Rp);
+        std::memcpy(cp, c, sizeof cp);
+    }
+    {
+        double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, c[3] = {0, 0, 0};
+        if (T0)
+            for (int r = 0; r < 3; r++) {
+                for (int k = 0; k < 3; k++) R[3 * r + k] = T0[4 * r + k];
+                c[r] = T0[4 * r + 3];
+            }
+        push_const(R, c);
+    }
+    return compile_chain(ets.data(), (int)ets.size(), qlim, out);
+}
+
 // marks[m] = k: frame m is the product of the first k transforms of the chain.  Re-runs the folding of compile_chain and
 // records, at each mark, how many joints precede it and the constant run accumulated since the last joint.
 int compile_frames(const Chain *c, const int32_t *marks, int nmarks, FrameTable *ft)

@@ -105,6 +105,7 @@ int chain_device_ops(Chain *c, DevChain *out, const double **qlim_out);
 DevChain chain_host_view(const Chain *c);
 int dyn_device_links(Dyn *d, const DevLink **out);
 int compile_chain(const rtbhip_et *ets, int m, const double *qlim, Chain *out);
+int compile_poe(const double *twists, int n, const double *T0, const double *qlim, Chain *out);
 struct Affine;
 void chain_tail(const Chain *c, const Affine &tool, double out12[12]);
 void note_launch(int grid, int block, int lds);

@@ -4,7 +4,8 @@ Only the hot path named in BASELINE.json / SURVEY.md section 8 is here:
   ET / ETS            eval, fkine, jacob0, jacobe, hessian0/e, jacob0_dot, manipulability, jacobm,
                       ik_LM / ik_GN / ik_NR (C-solver semantics), ikine_LM / ikine_GN / ikine_NR (Python-solver semantics)
   DHLink / DHRobot    fkine, jacob0/e, rne, gravload, itorque, inertia, coriolis, accel (+ the ETS pass-throughs)
-  Link / ERobot       ETS robots (link trees): rne
+  Link / ERobot       ETS robots (link trees): rne, and the RobotKinematics surface over ets(start, end)
+  PoERevolute / PoEPrismatic / PoERobot   product-of-exponentials robots: twists lowered to the same chain form
   urdf                plain-URDF loader + the reference's URDF -> ETS lowering, 20 pre-expanded robot descriptions
   angle_axis / p_servo / hessian_from_jacobian    the exports of the extension module that take finished matrices
   compat.fknm / compat.frne   plug-in modules with the reference extension modules' own function tables
@@ -16,11 +17,13 @@ from ._lib import RtbHipError, lib, device_count, tune, shard_range, last_launch
 from .et import ET, ETS, IKSolution, angle_axis, p_servo, hessian_from_jacobian  # noqa: F401
 from .dh import DHLink, DHRobot, RevoluteDH, PrismaticDH, RevoluteMDH, PrismaticMDH  # noqa: F401
 from .erobot import Link, ERobot  # noqa: F401
+from .poe import PoELink, PoERevolute, PoEPrismatic, PoERobot  # noqa: F401
+from .kinematics import RobotKinematics  # noqa: F401
 from . import models  # noqa: F401
 from . import urdf  # noqa: F401
 from .fleet import fleet_fkine_jacob  # noqa: F401
 from .shard import ShardedBatch  # noqa: F401
 
 __all__ = ["ET", "ETS", "IKSolution", "angle_axis", "p_servo", "hessian_from_jacobian", "DHLink", "DHRobot", "RevoluteDH", "PrismaticDH", "RevoluteMDH",
-           "PrismaticMDH", "Link", "ERobot", "models", "urdf", "fleet_fkine_jacob", "ShardedBatch", "RtbHipError", "lib",
+           "PrismaticMDH", "Link", "ERobot", "PoELink", "PoERevolute", "PoEPrismatic", "PoERobot", "RobotKinematics", "models", "urdf", "fleet_fkine_jacob", "ShardedBatch", "RtbHipError", "lib",
            "device_count", "tune", "shard_range", "last_launch", "ik_target_base"]

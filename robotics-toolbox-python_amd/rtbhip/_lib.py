@@ -46,6 +46,7 @@ SIGNATURES = {
     "rtbhip_init": (C.c_int, [_i32]),
     "rtbhip_shutdown": (None, []),
     "rtbhip_chain_create": (C.c_int, [C.POINTER(rtbhip_et), _i32, _vp, C.POINTER(_u64)]),
+    "rtbhip_chain_create_poe": (C.c_int, [_vp, _i32, _vp, _vp, C.POINTER(_u64)]),
     "rtbhip_chain_destroy": (C.c_int, [_u64]),
     "rtbhip_chain_info": (C.c_int, [_u64, _ip, _ip, _ip]),
     "rtbhip_chain_set_q_width": (C.c_int, [_u64, C.c_int32]),
@@ -127,18 +128,25 @@ def device_count():
 
 
 import contextlib
+import threading
+
+_ik_base = threading.local()          # the base this thread has declared (the library keeps its copy per thread too)
 
 
 @contextlib.contextmanager
 def ik_target_base(base):
     """`with rtbhip.ik_target_base(begin): ets.ik_LM(Tep[begin:begin + count], ...)` -- the IK calls inside solve a row block of a
     larger batch and draw the restart vectors the whole batch would draw for those rows (rtbhip_ik_target_base): sharded IK then
-    returns, row for row, what one call over all the targets returns."""
+    returns, row for row, what one call over all the targets returns.  Nests: leaving the block restores the base that was in
+    force when it was entered."""
+    prev = getattr(_ik_base, "value", 0)
     check(lib().rtbhip_ik_target_base(int(base)))
+    _ik_base.value = int(base)
     try:
         yield
     finally:
-        lib().rtbhip_ik_target_base(0)
+        _ik_base.value = prev
+        check(lib().rtbhip_ik_target_base(prev))
 
 
 def tune(key, value):

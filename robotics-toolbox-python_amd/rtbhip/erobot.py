@@ -14,6 +14,7 @@ import numpy as np
 from . import _lib
 from ._lib import check, lib, as_numeric, host_ptr, is_torch, MEM_HOST, MEM_DEVICE
 from .et import ET, ETS, _AXES
+from .kinematics import RobotKinematics, as_se3
 
 
 class Link:
@@ -53,8 +54,22 @@ class Link:
         return T
 
 
-class ERobot:
-    def __init__(self, links, name="", gravity=(0, 0, -9.81), **kw):
+class ERobot(RobotKinematics):
+    """ERobot(links) or ERobot(ets) (reference Robot.__init__ robot/Robot.py:60-160): a list of Link objects, or an ETS that is cut
+    into one link per joint ("a link frame after every joint", named link0, link1, ...; :116-131).  Kinematics: the
+    RobotKinematics surface over ets(start, end); dynamics: rne."""
+
+    def __init__(self, links, name="", gravity=(0, 0, -9.81), base=None, tool=None, manufacturer="", **kw):
+        if kw:
+            raise TypeError("unexpected keyword argument(s): %s" % ", ".join(sorted(kw)))
+        if isinstance(links, ET):
+            links = ETS(links)
+        if isinstance(links, ETS):
+            parent, cut = None, []
+            for j, seg in enumerate(links.split()):
+                parent = Link(seg, parent=parent, name="link%d" % j)
+                cut.append(parent)
+            links = cut
         links = list(links)
         names = {}
         for k, l in enumerate(links):
@@ -98,6 +113,9 @@ class ERobot:
             order = links                                            # explicit numbering keeps the given order (:355)
         self.links = order
         self.name = name
+        self.manufacturer = manufacturer
+        self.base = as_se3(base, "base")
+        self.tool = as_se3(tool, "tool")
         self.base_link = bases[0]
         self.n = sum(1 for l in order if l.isjoint)
         if sorted(l.jindex for l in order if l.isjoint) != list(range(self.n)):
@@ -134,6 +152,9 @@ class ERobot:
         towards the root multiplies by the inverse of each link left behind."""
         a = self._getlink(start, self.base_link)
         b = self._getlink(end, self.links[-1])
+        made = self.__dict__.setdefault("_ets_made", {})
+        if (id(a), id(b)) in made:
+            return made[(id(a), id(b))]            # one ETS object (and one device chain table) per path
         up, l = [], a
         anc_a = []
         while l is not None:
@@ -156,7 +177,20 @@ class ERobot:
                 l = l.parent
         for l in reversed(down):
             out += self._link_ets(l)
-        return ETS(out)
+        made[(id(a), id(b))] = ETS(out)
+        return made[(id(a), id(b))]
+
+    @property
+    def qlim(self):
+        """(2, n) joint limits in joint-number order (reference BaseRobot.qlim robot/BaseRobot.py:783-850)."""
+        lim = np.zeros((2, self.n))
+        for l in self.links:
+            if l.isjoint:
+                ql = l.qlim if l.qlim is not None else l.v.qlim
+                if ql is None:
+                    ql = (-np.pi, np.pi) if l.v.isrotation else (0.0, 1.0)
+                lim[:, l.jindex] = np.asarray(ql, dtype=np.float64).reshape(2)
+        return lim
 
     def fkine_all(self, q, base=None):
         """Pose of every link frame: T[0] = base, T[k+1] = link k of self.links; (nlinks+1,4,4) or (N,nlinks+1,4,4)

@@ -5,10 +5,11 @@ import math
 import numpy as np
 
 from .et import ET, ETS
+from .kinematics import RobotKinematics
 from .dh import DHRobot, RevoluteDH, RevoluteMDH
 
 
-class ERobot:
+class ERobot(RobotKinematics):
     """Minimal ETS-robot facade: the kinematic pass-throughs of reference
     robot/RobotKinematics.py:92-97 (fkine applies the robot base), :158 (jacob0), :219 (jacobe),
     :736 (ik_LM), :1209-1225 (ikine_LM)."""
@@ -55,36 +56,13 @@ class ERobot:
         a, b = index(start, 0), index(end, len(segs) - 1)
         if a > b:
             raise ValueError("Could not find the requested ETS in this robot")
-        out = ETS([e for seg in segs[a:b + 1] for e in seg])
-        return out
+        made = self.__dict__.setdefault("_ets_made", {})
+        if (a, b) not in made:
+            made[(a, b)] = ETS([e for seg in segs[a:b + 1] for e in seg])
+        return made[(a, b)]
 
-    def fkine(self, q, end=None, start=None, tool=None, include_base=True):
-        t = self.tool if tool is None else tool
-        return self._ets.eval(q, base=self.base, tool=t, include_base=include_base)
-
-    def jacob0(self, q, end=None, start=None, tool=None):
-        return self._ets.jacob0(q, tool=self.tool if tool is None else tool)
-
-    def jacobe(self, q, end=None, start=None, tool=None):
-        return self._ets.jacobe(q, tool=self.tool if tool is None else tool)
-
-    def hessian0(self, q=None, end=None, start=None, J0=None, tool=None):
-        return self._ets.hessian0(q, J0=J0, tool=self.tool if tool is None else tool)
-
-    def hessiane(self, q=None, end=None, start=None, Je=None, tool=None):
-        return self._ets.hessiane(q, Je=Je, tool=self.tool if tool is None else tool)
-
-    def jacob0_dot(self, q, qd, **kw): return self._ets.jacob0_dot(q, qd, tool=self.tool, **kw)
-    def manipulability(self, q, method="yoshikawa", axes="all", **kw):
-        return self._ets.manipulability(q, method=method, axes=axes, tool=self.tool)
-    def jacobm(self, q, axes="all", **kw): return self._ets.jacobm(q, axes=axes, tool=self.tool)
-    def jacob0_analytical(self, q, representation="rpy/xyz", **kw): return self._ets.jacob0_analytical(q, representation=representation, tool=self.tool)
-    def partial_fkine0(self, q, n=3, **kw): return self._ets.partial_fkine0(q, n=n, tool=self.tool)
-
-    def ik_LM(self, Tep, **kw): return self._ets.ik_LM(Tep, **kw)
-    def ik_GN(self, Tep, **kw): return self._ets.ik_GN(Tep, **kw)
-    def ik_NR(self, Tep, **kw): return self._ets.ik_NR(Tep, **kw)
-    def ikine_LM(self, Tep, **kw): return self._ets.ikine_LM(Tep, **kw)
+    # fkine, jacob0, jacobe, hessian0/e, jacob0_dot, manipulability, jacobm, jacob0_analytical, partial_fkine0, ik_* and ikine_*
+    # come from RobotKinematics: each is self.ets(start, end).<method>(...) with the robot's base / tool, as in the reference.
 
 
 class Panda(ERobot):

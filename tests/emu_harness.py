@@ -94,6 +94,15 @@ def _p(a):
 def chain_handle(ets):
     """ets: an rtbhip.ETS (its optable() is handed to the emu library's own chain compiler)."""
     from rtbhip._lib import rtbhip_et
+    if hasattr(ets, "_twists"):                       # a PoE chain: the emu library's own copy of compile_poe (csrc/chain.cpp)
+        ql = np.ascontiguousarray(ets.qlim.reshape(-1)) if ets.n else None
+        tw, T0 = np.ascontiguousarray(ets._twists), np.ascontiguousarray(ets._T0)
+        h = _u64(0)
+        fn = lib().rtbhip_chain_create_poe
+        fn.argtypes = [_vp, _i32, _vp, _vp, C.POINTER(_u64)]
+        rc = fn(_p(tw), tw.shape[0], _p(T0), _p(ql), C.byref(h))
+        assert rc == 0, lib().rtbhip_last_error()
+        return h.value
     rows = ets.optable()
     arr = (rtbhip_et * max(1, len(rows)))()
     for i, (kind, flip, jindex, T) in enumerate(rows):
