@@ -130,8 +130,12 @@ def main():
     ap.add_argument("--n", type=int, default=1000000, help="configurations per GPU per step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline and host_path legs")
     ap.add_argument("--tune", action="append", default=[], help="key=value for rtbhip_tune (A/B runs)")
+    ap.add_argument("--gather", action="store_true", help="build the process group and time the output gather even with one rank "
+                                                          "(a world-size-1 RCCL group: rehearses the collective on a single-GPU box)")
     argv = bench_argv()
     args = ap.parse_args(argv)
+    if args.gather:
+        os.environ["RTBHIP_BENCH_FORCE_GROUP"] = "1"
     spawn_ranks_if_needed(args.gpus, os.path.abspath(__file__), argv)
 
     import numpy as np
@@ -167,7 +171,7 @@ def main():
     elapsed, kern_avg_ms = rk.timed_steps(step, args.steps, args.warmup)
     kern_min_ms = per_launch_min_ms(step, min(args.steps, 50))
     # the one exchange of the path, outside the timed region: T|J rows of every rank to every rank
-    gather_ms = rk.gather_ms(torch.cat([T.reshape(N, 16), J.reshape(N, 42)], dim=1)) if world > 1 else None
+    gather_ms = rk.gather_ms(torch.cat([T.reshape(N, 16), J.reshape(N, 42)], dim=1)) if rk.dist is not None else None
 
     if rank == 0:
         achieved = BYTES_PER_CONFIG * N / (kern_avg_ms * 1e-3) / 1e9
@@ -190,7 +194,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: ETS Panda (22 ETs, 7 joints) fused fkine+jacob0, "
                                    "q~U(-pi,pi)^7 seed 0, N=%d per GPU, fp64, device-resident" % N,
                        "configs_per_gpu": N, "sharding": "rows/%d, no data-path collective" % world,
-                       "backend": rk.backend if world > 1 else None},
+                       "backend": rk.backend if rk.dist is not None else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "k_kin_reg<7,true,true>", "kernel_avg_ms": kern_avg_ms, "kernel_min_ms": kern_min_ms,
@@ -202,7 +206,8 @@ def main():
         if gather_ms is not None:
             line["gather_ms"] = gather_ms
             line["gather"] = "all_gather_into_tensor of (N,58) f64 rows per rank, %s" % (
-                "RCCL over xGMI" if rk.backend == "nccl" else "gloo through host memory (test hook)")
+                ("RCCL, a world-size-1 group on one GPU (--gather: rehearsal of the collective, no xGMI traffic)" if world == 1 else "RCCL over xGMI")
+                if rk.backend == "nccl" else "gloo through host memory (test hook)")
         if not args.no_cpu and world == 1:  # reported on rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(q_host, T, J)
             line["host_path"] = host_path(ets, q_host, T, J)

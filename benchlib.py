@@ -63,9 +63,19 @@ class Ranks:
             raise SystemExit("bench: no GPU visible (this package has no CPU path)")
         self.dist = None
         self.shared = False
-        if self.world > 1:
+        # `--gather` (RTBHIP_BENCH_FORCE_GROUP=1): build the process group and run the output gather even with ONE rank -- the
+        # RCCL communicator, its kernels and the device-buffer all_gather then execute on a single-GPU box, so the first multi-GPU
+        # run is not the first RCCL run
+        self.forced = self.world == 1 and os.environ.get("RTBHIP_BENCH_FORCE_GROUP") == "1"
+        if self.world > 1 or self.forced:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                import socket
+                s = socket.socket()
+                s.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+                s.close()
             if self.backend == "nccl":
                 if ndev < self.world:
                     raise SystemExit("bench: %d ranks but %d GPUs (RTBHIP_BENCH_BACKEND=gloo shares devices in a test)"

@@ -275,8 +275,8 @@ def Angle_Axis(Te, Tep):
 
 
 def ET_T(et, eta):
-    """core/fknm.cpp:1241-1281: the 4x4 (Fortran order) of one elementary transform at joint value eta -- the one-element
-    chain through rtbhip_fkine.  A non-float eta is `TypeError("Symbolic value")` exactly as in the reference."""
+    """core/fknm.cpp:1241-1281: the 4x4 (Fortran order) of one elementary transform at joint value eta -- for a joint the
+    one-element chain through rtbhip_fkine, for a constant a copy of its matrix.  A non-float eta is `TypeError("Symbolic value")` exactly as in the reference."""
     if not isinstance(et, _ET):
         raise ValueError("PyCapsule_GetPointer called with incorrect name")
     if et.isstaticsym:
@@ -286,6 +286,9 @@ def ET_T(et, eta):
         if not isinstance(eta, float):
             raise TypeError("Symbolic value")
         val = eta
+    if not et.isjoint:
+        # a constant element: the reference copies the stored matrix (_ET_T, core/methods.cpp:354-370) -- nothing to compute
+        return np.asfortranarray(np.array(et.T, dtype=np.float64).reshape(4, 4))
     one = _ET(0, et.isjoint, et.isflip, 0, et.axis, et.T, et.qlim)
     chain = _ETS([one], 1 if et.isjoint else 0, 1)
     T = np.empty((1, 4, 4))

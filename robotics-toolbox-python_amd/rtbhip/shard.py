@@ -32,12 +32,20 @@ class ShardedBatch:
         from ._lib import ik_target_base
         return ik_target_base(self.begin)
 
-    def gather(self, local_out, to_all=False, dst=0):
+    def gather(self, local_out, to_all=False, dst=0, collective="auto"):
         """ONE collective: all_gather_into_tensor (to_all) or gather-to-dst of equal-size padded
-        shards.  Returns the (N, ...) result on the receiving rank(s), None elsewhere."""
+        shards.  Returns the (N, ...) result on the receiving rank(s), None elsewhere.  A world of one rank needs no exchange
+        and gets its own array back -- unless collective="always", which runs the collective regardless (a world-size-1 RCCL
+        group exercises the communicator and its kernels on a single-GPU box)."""
         import torch
         import torch.distributed as dist
-        if self.world == 1 or not (dist.is_available() and dist.is_initialized()):
+        if collective not in ("auto", "always"):
+            raise ValueError("collective must be 'auto' or 'always'")
+        if not (dist.is_available() and dist.is_initialized()):
+            if collective == "always":
+                raise RuntimeError("gather(collective='always') needs an initialised process group")
+            return local_out
+        if self.world == 1 and collective == "auto":
             return local_out
         tail = tuple(local_out.shape[1:])
         home = local_out.device

@@ -95,6 +95,74 @@ def test_two_ranks_real_kernels_gathered_equal_oracle(N, world, to_all):
         assert np.abs(ftau - tref).max() / max(1.0, np.abs(tref).max()) <= 1e-9
 
 
+def _nccl_world1_worker(port, outq):
+    """ONE rank, backend "nccl" (= RCCL): communicator set-up, all_reduce, all_gather_into_tensor and gather on DEVICE buffers
+    that rtbhip_fkine_jacob / rtbhip_rne just filled -- the code path an 8-GPU node runs, on the one GPU of this box."""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "robotics-toolbox-python_amd")]
+    import torch
+    import torch.distributed as dist
+    import rtbhip
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        N = 4097
+        rng = np.random.default_rng(99)
+        qg = rng.uniform(-np.pi, np.pi, (N, 7))
+        sb = rtbhip.ShardedBatch(N)
+        assert (sb.rank, sb.world, sb.begin, sb.count) == (0, 1, 0, N)
+        ets = rtbhip.models.Panda().ets()
+        T, J = ets.fkine_jacob0(torch.from_numpy(qg).cuda())
+        TJ = torch.cat([T.reshape(N, 16), J.reshape(N, 42)], dim=1)
+        a = sb.gather(TJ, to_all=True, collective="always")            # all_gather_into_tensor on the device buffer
+        b = sb.gather(TJ, to_all=False, dst=0, collective="always")    # dist.gather to rank 0
+        assert a.is_cuda and b.is_cuda and a.data_ptr() != TJ.data_ptr() and b.data_ptr() != TJ.data_ptr()
+        t = torch.tensor([3.5], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        torch.cuda.synchronize()
+        loaded = [l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l]
+        outq.put((a.cpu().numpy(), b.cpu().numpy(), TJ.cpu().numpy(), float(t.item()), sorted(set(loaded))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_nccl_world1_gathers_device_buffers_through_rccl():
+    from oracle import oracle, chains
+    ctx = mp.get_context("spawn")
+    outq = ctx.Queue()
+    p = ctx.Process(target=_nccl_world1_worker, args=(_free_port(), outq))
+    p.start()
+    a, b, tj, red, loaded = outq.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert loaded, "librccl was not mapped: the collective did not go through RCCL"
+    assert np.array_equal(a, tj) and np.array_equal(b, tj) and red == 3.5
+    qg = np.random.default_rng(99).uniform(-np.pi, np.pi, (4097, 7))
+    ch = chains.panda_ets()
+    assert np.abs(a[:, :16].reshape(-1, 4, 4) - oracle.fkine(ch, qg)).max() <= 1e-10
+    assert np.abs(a[:, 16:].reshape(-1, 6, 7) - oracle.jacob0(ch, qg)).max() <= 1e-10
+
+
+def test_bench_gather_flag_runs_the_rccl_gather_with_one_rank():
+    """`torchrun --nproc-per-node 1 bench.py --gpus 1 --gather`: backend nccl, world 1, gather_ms on the line."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RTBHIP_BENCH_BACKEND", "RTBHIP_BENCH_FORCE_GROUP"):
+        env.pop(k, None)
+    # the script's flags travel in RTBHIP_BENCH_ARGV, as in benchlib.spawn_ranks_if_needed (torch.distributed.run's parser claims
+    # abbreviations of its own options even after the script name)
+    env["RTBHIP_BENCH_ARGV"] = json.dumps(["--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu", "--gather"])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 1 and d["config"]["backend"] == "nccl" and d["gather_ms"] > 0 and "RCCL" in d["gather"]
+
+
 def _run_bench(script, extra):
     env = dict(os.environ, RTBHIP_BENCH_BACKEND="gloo")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
