@@ -220,3 +220,92 @@ def test_gpu_urdf_robots_vs_oracle(name, exclude):
     tau = r.rne(q, qd, qdd, exclude=exclude)
     want = oer.erobot_rne(orc, q[:40], qd[:40], qdd[:40])
     nt.assert_allclose(tau[:40], want, rtol=1e-10, atol=1e-10 * max(1.0, np.abs(want).max()))
+
+
+# ------------------------------------------------------------------------------------------------ cross-pin on the compiled frne
+# The reference has TWO inverse dynamics: the compiled recursive Newton-Euler of DH robots (core/ne.c:62-493 behind frne.frne)
+# and the spatial-vector Robot.rne of ETS robots (robot/Robot.py:1704-1903), which keeps only SpatialInertia(m, r) of every
+# link -- no inertia tensor (:1797), no motor inertia, no friction.  For a DH arm whose links are POINT MASSES (I = 0,
+# Jm = B = Tc = 0) the two must therefore give the same torques.  frne is runnable here (oracle/_ref), so this pins
+# oracle/erobot.py -- and through it k_tree_rne -- on the reference's own binary for real 6- and 7-joint arms, beyond the two-link
+# closed forms of tests/test_ERobot.py.
+def dh_point_mass_arm(tab, rng):
+    """(L24 with point masses, oracle link list, product links) of a DH table lowered the way Robot(DHRobot.ets()) cuts it:
+    one link per joint, constants in front.  The mass of DH link j sits at r_j in DH frame {j}; the ETS link frame j is the frame
+    right after joint j's motion, so r' = C_j r_j with C_j the constants that follow the joint inside the DH link (standard
+    DH: tz(d) tx(a) Rx(alpha); modified DH: none, the joint closes the link)."""
+    L = tab.L24().copy()
+    L[:, 10:19] = 0.0                    # inertia tensor
+    L[:, 19] = 0.0                       # Jm
+    L[:, 21:24] = 0.0                    # B, Tc+, Tc-
+    L[:, 7:10] = rng.uniform(-0.3, 0.3, (tab.n, 3))
+    L[:, 6] = rng.uniform(0.2, 5.0, tab.n)
+    ch = tab.ets()
+    items, j = [], -1
+    segs, after = [], []                 # per joint: items of its link; constants following it before the next joint
+    for i in range(ch.m):
+        if int(ch.kind[i]) == 6:
+            T = ch.consts[i].reshape(4, 4)
+            items.append(T)
+            if j >= 0:
+                after[j] = after[j] @ T
+        else:
+            items.append((("Rx", "Ry", "Rz", "tx", "ty", "tz")[int(ch.kind[i])], None, bool(ch.flip[i])))
+            segs.append(items)
+            items = []
+            after.append(np.eye(4))
+            j += 1
+    orc, prod = [], []
+    for j, seg in enumerate(segs):
+        C = np.eye(4) if tab.mdh else after[j]
+        r = C[:3, :3] @ L[j, 7:10] + C[:3, 3]
+        orc.append(dict(name="l%d" % j, parent=None if j == 0 else "l%d" % (j - 1), ets=seg, m=L[j, 6], r=r))
+        ets = ETS()
+        for it in seg:
+            ets = ets * (ET.SE3(it) if isinstance(it, np.ndarray) else getattr(ET, it[0])(flip=it[2]))
+        prod.append(Link(ets=ets, m=L[j, 6], r=r, parent=prod[-1] if prod else None, name="l%d" % j))
+    return L, orc, prod
+
+
+@pytest.mark.parametrize("robot", ["puma560", "panda_dh"])
+def test_oracle_erobot_rne_equals_compiled_frne_for_point_mass_dh_arms(robot):
+    from oracle import ref_harness
+    import emu_harness as emu
+    if not ref_harness.available():
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(5)
+    tab = getattr(chains, robot)()
+    tab.tool = None
+    L, orc, prod = dh_point_mass_arm(tab, rng)
+    N = 40
+    q, qd, qdd = rng.uniform(-2.5, 2.5, (N, tab.n)), rng.normal(size=(N, tab.n)), rng.normal(size=(N, tab.n))
+    for g in ([0, 0, -9.81], [1.0, -2.0, 3.0], [0, 0, 0]):
+        ref = ref_harness.RefRNE(L, tab.mdh, gravity=g)
+        want = ref.rne(q, qd, qdd)                                        # core/ne.c through frne.frne
+        ref.delete()
+        scale = max(1.0, np.abs(want).max())
+        got = oer.erobot_rne(orc, q, qd, qdd, g)                          # robot/Robot.py:1704-1903 restated
+        assert np.abs(got - want).max() <= 1e-12 * scale, np.abs(got - want).max()
+        ker = emu.tree_rne(ERobot(prod).group_table(), q, qd, qdd, g)     # the kernel body, replayed on the CPU
+        assert np.abs(ker - want).max() <= 1e-9 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("robot", ["puma560", "panda_dh"])
+def test_gpu_tree_rne_equals_compiled_frne_for_point_mass_dh_arms(robot):
+    from oracle import ref_harness
+    rng = np.random.default_rng(5)
+    tab = getattr(chains, robot)()
+    tab.tool = None
+    L, orc, prod = dh_point_mass_arm(tab, rng)
+    rob = ERobot(prod)
+    N = 300
+    q, qd, qdd = rng.uniform(-2.5, 2.5, (N, tab.n)), rng.normal(size=(N, tab.n)), rng.normal(size=(N, tab.n))
+    tau = rob.rne(q, qd, qdd)
+    if ref_harness.available():
+        ref = ref_harness.RefRNE(L, tab.mdh, gravity=[0, 0, -9.81])
+        want = ref.rne(q, qd, qdd)
+        ref.delete()
+    else:
+        want = oer.erobot_rne(orc, q, qd, qdd)
+    assert np.abs(tau - want).max() <= 1e-9 * max(1.0, np.abs(want).max())
