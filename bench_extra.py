@@ -61,7 +61,7 @@ def ik_roofline(lm_iterations_per_s):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--what", default="rne,ik,fleet,dyn,tree,kin,graph")
+    ap.add_argument("--what", default="rne,ik,fleet,dyn,tree,kin,poe,graph")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
@@ -211,6 +211,40 @@ def main():
                           "call_avg_ms": avg, "call_min_ms": 1e3 * min(ts),
                           "roofline": {"bound": "hbm", "achieved": byts * Np / (avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                        "frac": byts * Np / (avg * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": byts * Np}}), flush=True)
+
+    if "poe" in what:
+        # north_star's "SE(3) DH / product-of-exponentials chain": a 6-joint PoE robot (UR5-like screw axes), twists lowered by
+        # rtbhip_chain_create_poe to the same canonical chain -- the headline kernel class (k_kin_reg<6>), priced on the same roof
+        N = args.n_dyn
+        axes = [([0, 0, 1], [0, 0, 0]), ([0, 1, 0], [0, 0, 0.089]), ([0, 1, 0], [0.425, 0, 0.089]), ([0, 1, 0], [0.817, 0, 0.089]),
+                ([0, 0, -1], [0.817, 0.109, 0]), ([0, 1, 0], [0.817, 0, -0.006])]
+        T0 = np.array([[-1.0, 0, 0, 0.817], [0, 0, 1, 0.191], [0, 1, 0, -0.006], [0, 0, 0, 1]])
+        robot = rtbhip.PoERobot([rtbhip.PoERevolute(a, p) for a, p in axes], T0, name="UR5-PoE")
+        chain = robot._path(None, None)
+        rng = np.random.default_rng(8)
+        qh = rng.uniform(-np.pi, np.pi, (N, 6))
+        q = torch.from_numpy(qh).cuda()
+        hold = {}
+        def poe_step():
+            hold["o"] = chain.fkine_jacob0(q)
+        avg, best = ev_time(poe_step, args.steps, 3)
+        byts = 48 + 128 + 288
+        line = {"metric": "configurations/sec (6-joint PoE robot fkine+jacob0, twists lowered by rtbhip_chain_create_poe)", "value": N / (avg * 1e-3),
+                "unit": "configurations/s", "n": N, "kernel_avg_ms": avg, "kernel_min_ms": best,
+                "roofline": {"bound": "hbm", "achieved": byts * N / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": byts * N / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": byts * N,
+                             "kernel": "k_kin_reg<6,true,true>"}}
+        if not args.no_cpu:
+            from oracle import poe as opoe
+            ref = opoe.PoE([opoe.unit_revolute(a, p) for a, p in axes], T0)
+            n = 3000
+            t0 = time.perf_counter(); Tc = ref.fkine(qh[:n]); Jc = ref.jacob0(qh[:n]); dt = time.perf_counter() - t0
+            Tg, Jg = hold["o"]
+            line["cpu_baseline"] = {"value": n / dt, "unit": "configurations/s", "cores": 1, "kind": "port",
+                                    "sample": "closed-form PoERobot.fkine + jacob0 restated in NumPy (oracle/poe.py; the reference's own is Python over "
+                                              "spatialmath, absent here) on the first %d configurations" % n,
+                                    "max_abs_err_gpu_vs_cpu": max(float(np.abs(Tg[:n].cpu().numpy() - Tc).max()), float(np.abs(Jg[:n].cpu().numpy() - Jc).max()))}
+        print(json.dumps(line), flush=True)
 
     if "graph" in what:
         # launch-bound regime (a control loop's batch): fkine+jacob0, hessian0 and rne on 4096 configurations, eager vs one captured hipGraph
