@@ -19,8 +19,10 @@
  *   - mem: RTBHIP_MEM_HOST   pointers are host memory; the call streams the rows through the device
  *                            (chunked, double-buffered, see rtbhip_host_alloc) and returns when the
  *                            results are in the output arrays;
- *          RTBHIP_MEM_DEVICE pointers are device memory of the CURRENT hip device; the call only
- *                            enqueues work on `stream` (a hipStream_t, NULL = default stream).
+ *          RTBHIP_MEM_DEVICE pointers are device memory; the call only enqueues work on `stream` (a hipStream_t,
+ *                            NULL = default stream).  The call runs on the GPU that OWNS the buffers: when that is
+ *                            not the current device the library switches to it for the duration of the call and
+ *                            switches back (`stream` must then be a stream of that GPU).
  *   - small per-call parameters (base, tool, gravity, fext, we, qlim) are always HOST pointers.
  *   - handles are bound to no device: the chain/dynamics tables (a few KB) are uploaded lazily
  *     to whichever device a call runs on and cached there.
@@ -89,6 +91,11 @@ int rtbhip_chain_create(const rtbhip_et *ets, int32_t m, const double *qlim, rtb
  * chain (hessian, ik_lm, ...), which the reference reaches only through its ETS re-expression (_update_ets :272-324).
  * Joint i reads column i of q.  Non-unit twists and twists with a pitch are refused (RTBHIP_EINVAL). */
 int rtbhip_chain_create_poe(const double *twists, int32_t n, const double *T0_16, const double *qlim, rtbhip_chain_t *chain);
+/* Make a handle's table resident on `device` (-1: the current device) now.  Tables are otherwise uploaded on a handle's first use on
+ * a device (one allocation + one synchronous copy); after the explicit upload every device-pointer call with the handle on that
+ * device only enqueues kernels on `stream`, so a sequence of calls can be captured into a hipGraph without a warm-up call.
+ * rtbhip_chain_upload also sizes the per-device scheduler state of rtbhip_ik_lm. */
+int rtbhip_chain_upload(rtbhip_chain_t chain, int32_t device);
 int rtbhip_chain_destroy(rtbhip_chain_t chain);
 int rtbhip_chain_info(rtbhip_chain_t chain, int32_t *n, int32_t *m, int32_t *q_width);
 /* Row pitch of q (columns per configuration).  A chain created from a branch of a tree robot keeps the robot-wide joint numbers
@@ -184,12 +191,13 @@ int rtbhip_ik_lm(rtbhip_chain_t chain, const double *Tep, int64_t N, const doubl
 /* The same with the null-space motion of the Python solvers (IK_LM / IK_GN / IK_NR keyword arguments kq, km, ps, pi;
  * robot/IK.py:507-576 `_null_Sigma`, `_calc_qnull`, added to the step at :758, :1015, :1215): joint-limit avoidance with
  * gain 1/kq inside the influence distance pi (minimum distance ps) and manipulability maximisation with gain 1/km,
- * projected into the null space of J.  flavour must be 1.  As in the reference the term is applied only when kq > 0;
+ * projected into the null space of J.  pi: n influence distances, one per joint (a HOST array: the reference takes a scalar or an
+ * array, IK.py:519-520; NULL = 0.3 for every joint).  flavour must be 1.  As in the reference the term is applied only when kq > 0;
  * chains of 6..12 joints; kq > 0 on any other chain returns RTBHIP_ELIMIT (nothing is dropped silently). */
 int rtbhip_ik_lm_nullspace(rtbhip_chain_t chain, const double *Tep, int64_t N, const double *q0,
                            int32_t ilimit, int32_t slimit, double tol, int32_t reject_jl, const double *we6,
                            double lambda, int32_t method, int32_t flavour, uint64_t seed,
-                           double kq, double km, double ps, double pi, double *q_out,
+                           double kq, double km, double ps, const double *pi, double *q_out,
                            int32_t *success, int32_t *iters, int32_t *searches, double *residual,
                            int32_t mem, void *stream);
 
@@ -199,9 +207,9 @@ int rtbhip_ik_lm_nullspace(rtbhip_chain_t chain, const double *Tep, int64_t N, c
  * form of ik_device.h (a minimum-norm step damped by kj sum|e| / ks); with kq > 0 every joint inside the influence distance pi
  * of a limit adds one row on its own velocity (IK.py:1453-1481) and a primal-dual active-set loop around the same 6x6 solve
  * finds the minimiser.  Both per lane, inside the search scheduler of rtbhip_ik_lm.  km > 0 or kq > 0 need a chain of 6..12
- * joints (RTBHIP_ELIMIT otherwise); a per-joint influence distance (array pi) is not offered. */
+ * joints (RTBHIP_ELIMIT otherwise); pi as in rtbhip_ik_lm_nullspace (n values or NULL; IK.py:1441-1442). */
 int rtbhip_ik_qp(rtbhip_chain_t chain, const double *Tep, int64_t N, const double *q0, int32_t ilimit, int32_t slimit, double tol,
-                 int32_t reject_jl, const double *we6, uint64_t seed, double kj, double ks, double kq, double km, double ps, double pi,
+                 int32_t reject_jl, const double *we6, uint64_t seed, double kj, double ks, double kq, double km, double ps, const double *pi,
                  double *q_out, int32_t *success, int32_t *iters, int32_t *searches, double *residual, int32_t mem, void *stream);
 
 /* Sharded IK: the restart generator is keyed by (seed, target row, search, joint).  A rank that solves rows [begin, begin + count)
@@ -219,6 +227,7 @@ int rtbhip_ik_restart(rtbhip_chain_t chain, uint64_t seed, int64_t target, int32
 /* frne.init (frne.c:233-299): L24 is the (n,24) block of DHRobot._init_rne (DHRobot.py:1342-1358). */
 int rtbhip_dyn_create(const double *L24, int32_t n, int32_t mdh, rtbhip_dyn_t *dyn);
 int rtbhip_dyn_destroy(rtbhip_dyn_t dyn); /* frne.delete (frne.c:80-103) */
+int rtbhip_dyn_upload(rtbhip_dyn_t dyn, int32_t device); /* as rtbhip_chain_upload */
 
 /* frne.frne (frne.c:106-230 -> newton_euler ne.c:62-493), batched: q,qd,qdd,tau are (N,n).
  * grav3 is what frne.frne is handed (already negated by DHRobot.rne, DHRobot.py:1449); fext6 may
@@ -262,6 +271,7 @@ typedef struct rtbhip_tree_group {
 typedef uint64_t rtbhip_tree_t;
 int rtbhip_tree_create(const rtbhip_tree_group *groups, int32_t ng, rtbhip_tree_t *tree);
 int rtbhip_tree_destroy(rtbhip_tree_t tree);
+int rtbhip_tree_upload(rtbhip_tree_t tree, int32_t device); /* as rtbhip_chain_upload */
 int rtbhip_tree_rne(rtbhip_tree_t tree, const double *q, const double *qd, const double *qdd, int64_t N,
                     const double *gravity3, double *tau, int32_t mem, void *stream);
 
@@ -277,9 +287,14 @@ int rtbhip_fleet_fkine_jacob(const rtbhip_chain_t *chains, int32_t n_chains,
  * the D2H of the previous one and nothing is allocated per call.  Pageable arrays are copied through the pinned staging by a few
  * copy threads; arrays that are ALREADY pinned (these blocks, hipHostMalloc, hipHostRegister) are the DMA endpoints themselves --
  * results land directly in the caller's array.  Blocks are cached between uses (pinning is the expensive part; cap
- * RTBHIP_PINNED_CACHE_MB, default 4096); rtbhip_shutdown() returns them. */
+ * RTBHIP_PINNED_CACHE_MB, default 1024); rtbhip_shutdown() returns them. */
 int rtbhip_host_alloc(uint64_t bytes, void **ptr);
 int rtbhip_host_free(void *ptr);
+/* Idle cached memory back to the driver / the OS: device staging blocks of the host-pointer calls that are not row-pipelined (IK, the
+ * dynamics terms, hessian_from_jacobian, the fleet; cached per device up to RTBHIP_DEVICE_CACHE_MB, default 512 -- a block released
+ * above that goes back at once) down to keep_device_bytes per device, pinned host blocks (RTBHIP_PINNED_CACHE_MB, default 1024) down
+ * to keep_pinned_bytes.  rtbhip_trim(0, 0) keeps nothing that is not in use. */
+int rtbhip_trim(uint64_t keep_device_bytes, uint64_t keep_pinned_bytes);
 
 /* Multi-GPU partition helper: contiguous row block [begin, begin+count) of rank `rank` out of
  * `world` (the first N % world ranks get one extra row).  Pure host arithmetic. */
@@ -295,6 +310,7 @@ int rtbhip_last_launch(int32_t *grid, int32_t *block, int32_t *lds_bytes);
  *   "ik_phased" 0 | 1 | 2     phased schedule (first searches, then compacted work lists): never (default) / automatic / always
  *   "ik_fresh_pct" p, "ik_pass_mask" m, "ik_waves_per_cu" w, "ik_spec_policy" 0 | 1     pacing of the per-wave scheduler
  * Others: "coalesced", "reg", "tiles_per_wave", "hess_mode" (fkine / Jacobian / Hessian store paths), "rne_tiles_per_wave",
+ *         "partial3" 1 | 0 (order-3 partial_fkine0 on workgroups that own whole configurations / on the general kernel),
  *         "host_chunk_kb" (host-pointer pipeline). */
 int rtbhip_tune(const char *key, int32_t value);
 

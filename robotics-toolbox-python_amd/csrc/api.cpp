@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 #include <memory>
 #include <unordered_map>
+#include <functional>
 
 namespace rtbhip {
 
@@ -63,10 +64,13 @@ struct TraceRange {
 #define RTB_TRACE(name) ::rtbhip::TraceRange _trace_range(name)
 
 // ---------------------------------------------------------------- handle registry
-static std::mutex g_reg_mu;
-static std::unordered_map<uint64_t, std::shared_ptr<Chain>> g_chains;
-static std::unordered_map<uint64_t, std::shared_ptr<Dyn>> g_dyns;
-static std::unordered_map<uint64_t, std::shared_ptr<Tree>> g_trees;
+// The registries are heap objects that are never destroyed: handles that are still registered when the process exits (module-level
+// robot objects whose Python __del__ never ran) must not have their destructors -- which call hipFree -- run during static
+// destruction, possibly after the HIP runtime has been torn down.  The OS reclaims device memory with the process.
+static std::mutex &g_reg_mu = *new std::mutex();
+static std::unordered_map<uint64_t, std::shared_ptr<Chain>> &g_chains = *new std::unordered_map<uint64_t, std::shared_ptr<Chain>>();
+static std::unordered_map<uint64_t, std::shared_ptr<Dyn>> &g_dyns = *new std::unordered_map<uint64_t, std::shared_ptr<Dyn>>();
+static std::unordered_map<uint64_t, std::shared_ptr<Tree>> &g_trees = *new std::unordered_map<uint64_t, std::shared_ptr<Tree>>();
 static std::atomic<uint64_t> g_next{1};
 
 std::shared_ptr<Chain> chain_from_handle(rtbhip_chain_t h)
@@ -243,26 +247,36 @@ static Affine affine_from16(const double *m16)
     return a;
 }
 
-static int check_batch(const char *fn, const void *q, int64_t N, int mem)
-{
-    if (N < 0) { set_error(std::string(fn) + ": negative N"); return RTBHIP_EINVAL; }
-    if (N > 0 && q == nullptr) { set_error(std::string(fn) + ": NULL input with N > 0"); return RTBHIP_EINVAL; }
-    if (mem != RTBHIP_MEM_HOST && mem != RTBHIP_MEM_DEVICE) { set_error(std::string(fn) + ": bad mem kind"); return RTBHIP_EINVAL; }
-    if (mem == RTBHIP_MEM_DEVICE && N > 0) {
-        // tables are uploaded to, and kernels launched on, the CURRENT device: a buffer of another GPU here would be a fault or a
-        // silent peer access (e.g. a tensor on cuda:1 while device 0 is current) -- refuse it
+// The device a device-pointer call runs on.  The caller's buffers decide: when they live on a GPU other than the current one
+// (a tensor on cuda:1 while device 0 is current -- a single process driving several GPUs) the call switches to that GPU for its
+// duration -- table look-up / upload, launch geometry and the launch itself all happen there -- and the destructor restores the
+// caller's current device.  `stream` must be a stream of the buffers' device (NULL = that device's default stream).
+struct DeviceScope {
+    int prev = -1;
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+    int enter_for(const char *fn, const void *buf)
+    {
         hipPointerAttribute_t at;
         int cur = 0;
-        if (hipPointerGetAttributes(&at, q) == hipSuccess && hipGetDevice(&cur) == hipSuccess) {
-            if (at.type == hipMemoryTypeDevice && at.device != cur) {
-                set_error(std::string(fn) + ": the device buffer belongs to GPU " + std::to_string(at.device) + " but GPU " + std::to_string(cur) +
-                          " is current (hipSetDevice / torch.cuda.device(...) around the call)");
-                return RTBHIP_EINVAL;
+        if (buf && hipPointerGetAttributes(&at, buf) == hipSuccess && hipGetDevice(&cur) == hipSuccess) {
+            if (at.type == hipMemoryTypeDevice && at.device != cur && prev < 0) {
+                hipError_t e = hipSetDevice(at.device);
+                if (e != hipSuccess) return hip_fail(e, (std::string(fn) + ": hipSetDevice to the buffer's GPU").c_str());
+                prev = cur;
             }
         } else {
             (void)hipGetLastError();
         }
+        return RTBHIP_OK;
     }
+};
+
+static int check_batch(const char *fn, const void *q, int64_t N, int mem, DeviceScope *scope)
+{
+    if (N < 0) { set_error(std::string(fn) + ": negative N"); return RTBHIP_EINVAL; }
+    if (N > 0 && q == nullptr) { set_error(std::string(fn) + ": NULL input with N > 0"); return RTBHIP_EINVAL; }
+    if (mem != RTBHIP_MEM_HOST && mem != RTBHIP_MEM_DEVICE) { set_error(std::string(fn) + ": bad mem kind"); return RTBHIP_EINVAL; }
+    if (mem == RTBHIP_MEM_DEVICE && N > 0 && scope) return scope->enter_for(fn, q);
     return RTBHIP_OK;
 }
 
@@ -273,7 +287,8 @@ static int kin_entry(const char *fn, rtbhip_chain_t h, const double *q, int64_t 
     Chain *c = c_owner.get();
     RTB_TRACE((std::string("rtbhip_") + fn).c_str());
     if (!c) { set_error(std::string(fn) + ": unknown chain handle"); return RTBHIP_EINVAL; }
-    RTB_TRY(check_batch(fn, q, N, mem));
+    DeviceScope dscope;
+    RTB_TRY(check_batch(fn, q, N, mem, &dscope));
     if (frame != 0 && frame != 1) { set_error(std::string(fn) + ": frame must be 0 (jacob0) or 1 (jacobe)"); return RTBHIP_EINVAL; }
     if (N > 0 && !T && !J && !H) { set_error(std::string(fn) + ": no output buffer"); return RTBHIP_EINVAL; }
     if (N == 0) return RTBHIP_OK;
@@ -297,7 +312,9 @@ static int kin_entry(const char *fn, rtbhip_chain_t h, const double *q, int64_t 
 void kin_tune(const char *key, int value);
 void rne_tune(const char *key, int value);
 void ik_tune(const char *key, int value);
+void partial_tune(const char *key, int value);
 void ik_release_device_state();
+int ik_prepare_device();
 void hostpipe_tune(const char *key, int value);
 
 }  // namespace rtbhip
@@ -380,6 +397,57 @@ int rtbhip_chain_create_poe(const double *twists, int32_t n, const double *T0_16
     return RTBHIP_OK;
 }
 
+// Make the handle's device table resident on `device` (-1: the current one) NOW: after this returns, device-pointer calls with the
+// handle on that device only enqueue kernels -- no allocation, no synchronous copy -- so they can be captured into a hipGraph
+// without a warm-up call.  Also sizes the per-device scheduler state rtbhip_ik_lm needs.
+static int upload_on(int32_t device, const std::function<int()> &fn)
+{
+    int cur = 0;
+    RTB_HIP(hipGetDevice(&cur));
+    int have = 0;
+    RTB_HIP(hipGetDeviceCount(&have));
+    if (device < -1 || device >= have) { set_error("upload: no such device"); return RTBHIP_EINVAL; }
+    const bool sw = device >= 0 && device != cur;
+    if (sw) RTB_HIP(hipSetDevice(device));
+    const int rc = fn();
+    if (sw) (void)hipSetDevice(cur);
+    return rc;
+}
+
+int rtbhip_chain_upload(rtbhip_chain_t chain, int32_t device)
+{
+    const std::shared_ptr<Chain> c = chain_from_handle(chain);
+    if (!c) { set_error("chain_upload: unknown handle"); return RTBHIP_EINVAL; }
+    return upload_on(device, [&]() -> int {
+        DevChain ops;
+        RTB_TRY(chain_device_ops(c.get(), &ops, nullptr));
+        return ik_prepare_device();
+    });
+}
+
+int rtbhip_dyn_upload(rtbhip_dyn_t dyn, int32_t device)
+{
+    const std::shared_ptr<Dyn> d = dyn_from_handle(dyn);
+    if (!d) { set_error("dyn_upload: unknown handle"); return RTBHIP_EINVAL; }
+    return upload_on(device, [&]() -> int { const DevLink *l; return dyn_device_links(d.get(), &l); });
+}
+
+int rtbhip_tree_upload(rtbhip_tree_t tree, int32_t device)
+{
+    const std::shared_ptr<Tree> t = tree_from_handle(tree);
+    if (!t) { set_error("tree_upload: unknown handle"); return RTBHIP_EINVAL; }
+    return upload_on(device, [&]() -> int { const DevGroup *g; return tree_device_groups(t.get(), &g); });
+}
+
+// Hand idle cached memory back: device staging blocks of the host-pointer calls above `keep_device_bytes`, pinned host blocks above
+// `keep_pinned_bytes` (0, 0 = everything that is not in use).
+int rtbhip_trim(uint64_t keep_device_bytes, uint64_t keep_pinned_bytes)
+{
+    dev_cache_trim((size_t)keep_device_bytes);
+    host_cache_trim((size_t)keep_pinned_bytes);
+    return RTBHIP_OK;
+}
+
 int rtbhip_chain_destroy(rtbhip_chain_t chain)
 {
     std::shared_ptr<Chain> c;             // the device tables go with the last reference (a launch in flight keeps one)
@@ -452,7 +520,8 @@ int rtbhip_hessian(rtbhip_chain_t chain, const double *q, int64_t N, const doubl
 int rtbhip_hessian_from_jacobian(const double *J, int64_t N, int32_t n, double *H, int32_t mem, void *stream)
 {
     RTB_TRACE("rtbhip_hessian_from_jacobian");
-    RTB_TRY(check_batch("hessian_from_jacobian", J, N, mem));
+    DeviceScope dscope;
+    RTB_TRY(check_batch("hessian_from_jacobian", J, N, mem, &dscope));
     if (n < 1 || n > RTBHIP_MAX_JOINTS) { set_error("hessian_from_jacobian: n must be 1..RTBHIP_MAX_JOINTS"); return RTBHIP_ELIMIT; }
     if (N > 0 && !H) { set_error("hessian_from_jacobian: NULL H"); return RTBHIP_EINVAL; }
     if (N == 0) return RTBHIP_OK;
@@ -483,6 +552,8 @@ int rtbhip_angle_axis(const double *Te, int64_t nTe, const double *Tep, int64_t 
     if (!Te || !Tep || !e) { set_error("angle_axis: NULL buffer"); return RTBHIP_EINVAL; }
     if (mem == RTBHIP_MEM_DEVICE) {
         if (((uintptr_t)Te | (uintptr_t)Tep | (uintptr_t)e) & 15) { set_error("angle_axis: device buffers must be 16-byte aligned"); return RTBHIP_EINVAL; }
+        DeviceScope dscope;
+        RTB_TRY(dscope.enter_for("angle_axis", e));
         return launch_angle_axis(Te, nTe, Tep, nTep, N, e, (hipStream_t)stream);
     }
     Staging st;
@@ -504,7 +575,8 @@ static int diff_entry(const char *fn, rtbhip_chain_t h, int mode, int axes, cons
     Chain *c = c_owner.get();
     RTB_TRACE((std::string("rtbhip_") + fn).c_str());
     if (!c) { set_error(std::string(fn) + ": unknown chain handle"); return RTBHIP_EINVAL; }
-    RTB_TRY(check_batch(fn, q, N, mem));
+    DeviceScope dscope;
+    RTB_TRY(check_batch(fn, q, N, mem, &dscope));
     if (frame != 0 && frame != 1) { set_error(std::string(fn) + ": frame must be 0 or 1"); return RTBHIP_EINVAL; }
     if (mode != 0 && mode != 3 && mode != 4 && (axes & 63) == 0) { set_error(std::string(fn) + ": empty axes mask"); return RTBHIP_EINVAL; }
     if (N > 0 && (!out || ((mode == 0 || mode == 4) && !qd))) { set_error(std::string(fn) + ": NULL qd/output"); return RTBHIP_EINVAL; }
@@ -617,7 +689,8 @@ int rtbhip_partial_fkine0(rtbhip_chain_t chain, const double *q, int64_t N, cons
     Chain *c = c_owner.get();
     RTB_TRACE("rtbhip_partial_fkine0");
     if (!c) { set_error("partial_fkine0: unknown chain handle"); return RTBHIP_EINVAL; }
-    RTB_TRY(check_batch("partial_fkine0", q, N, mem));
+    DeviceScope dscope;
+    RTB_TRY(check_batch("partial_fkine0", q, N, mem, &dscope));
     if (order < 3 || order > kPartialMaxOrder) { set_error("partial_fkine0: order must be 3.." + std::to_string(kPartialMaxOrder)); return RTBHIP_EINVAL; }
     if (c->n < 1) { set_error("partial_fkine0: chain has no joints"); return RTBHIP_EINVAL; }
     if (N > 0 && !out) { set_error("partial_fkine0: NULL output"); return RTBHIP_EINVAL; }
@@ -667,13 +740,13 @@ int rtbhip_ik_lm(rtbhip_chain_t chain, const double *Tep, int64_t N, const doubl
                  int32_t mem, void *stream)
 {
     return rtbhip_ik_lm_nullspace(chain, Tep, N, q0, ilimit, slimit, tol, reject_jl, we6, lambda, method, flavour, seed,
-                                  0.0, 0.0, 0.1, 0.3, q_out, success, iters, searches, residual, mem, stream);
+                                  0.0, 0.0, 0.1, nullptr, q_out, success, iters, searches, residual, mem, stream);
 }
 
 static int ik_entry(rtbhip_chain_t chain, const double *Tep, int64_t N, const double *q0,
                            int32_t ilimit, int32_t slimit, double tol, int32_t reject_jl, const double *we6,
                            double lambda, int32_t method, int32_t flavour, uint64_t seed,
-                           double kq, double km, double ps, double pi, double ks, double *q_out,
+                           double kq, double km, double ps, const double *pi, double ks, double *q_out,
                            int32_t *success, int32_t *iters, int32_t *searches, double *residual,
                            int32_t mem, void *stream);
 
@@ -689,7 +762,7 @@ int rtbhip_ik_target_base(int64_t base)
 int rtbhip_ik_lm_nullspace(rtbhip_chain_t chain, const double *Tep, int64_t N, const double *q0,
                            int32_t ilimit, int32_t slimit, double tol, int32_t reject_jl, const double *we6,
                            double lambda, int32_t method, int32_t flavour, uint64_t seed,
-                           double kq, double km, double ps, double pi, double *q_out,
+                           double kq, double km, double ps, const double *pi, double *q_out,
                            int32_t *success, int32_t *iters, int32_t *searches, double *residual,
                            int32_t mem, void *stream)
 {
@@ -699,7 +772,7 @@ int rtbhip_ik_lm_nullspace(rtbhip_chain_t chain, const double *Tep, int64_t N, c
 }
 
 int rtbhip_ik_qp(rtbhip_chain_t chain, const double *Tep, int64_t N, const double *q0, int32_t ilimit, int32_t slimit, double tol,
-                 int32_t reject_jl, const double *we6, uint64_t seed, double kj, double ks, double kq, double km, double ps, double pi,
+                 int32_t reject_jl, const double *we6, uint64_t seed, double kj, double ks, double kq, double km, double ps, const double *pi,
                  double *q_out, int32_t *success, int32_t *iters, int32_t *searches, double *residual, int32_t mem, void *stream)
 {
     if (!(kj > 0.0) || !(ks > 0.0)) { set_error("ik_qp: kj and ks must be positive (Q must be positive definite)"); return RTBHIP_EINVAL; }
@@ -710,7 +783,7 @@ int rtbhip_ik_qp(rtbhip_chain_t chain, const double *Tep, int64_t N, const doubl
 static int ik_entry(rtbhip_chain_t chain, const double *Tep, int64_t N, const double *q0,
                            int32_t ilimit, int32_t slimit, double tol, int32_t reject_jl, const double *we6,
                            double lambda, int32_t method, int32_t flavour, uint64_t seed,
-                           double kq, double km, double ps, double pi, double ks, double *q_out,
+                           double kq, double km, double ps, const double *pi, double ks, double *q_out,
                            int32_t *success, int32_t *iters, int32_t *searches, double *residual,
                            int32_t mem, void *stream)
 {
@@ -718,7 +791,8 @@ static int ik_entry(rtbhip_chain_t chain, const double *Tep, int64_t N, const do
     Chain *c = c_owner.get();
     RTB_TRACE("rtbhip_ik_lm");
     if (!c) { set_error("ik_lm: unknown chain handle"); return RTBHIP_EINVAL; }
-    RTB_TRY(check_batch("ik_lm", Tep, N, mem));
+    DeviceScope dscope;
+    RTB_TRY(check_batch("ik_lm", Tep, N, mem, &dscope));
     if (flavour < 0 || flavour > 1) { set_error("ik_lm: flavour must be 0 (ik_LM) or 1 (ikine_LM)"); return RTBHIP_EINVAL; }
     if (ilimit < 1 || slimit < 1) { set_error("ik_lm: ilimit and slimit must be >= 1"); return RTBHIP_EINVAL; }
     if (c->n < 1) { set_error("ik_lm: chain has no joints"); return RTBHIP_EINVAL; }
@@ -728,9 +802,12 @@ static int ik_entry(rtbhip_chain_t chain, const double *Tep, int64_t N, const do
     IkParams p;
     p.ilimit = ilimit; p.slimit = slimit; p.reject_jl = reject_jl ? 1 : 0; p.method = method;
     p.flavour = flavour; p.tol = tol; p.lambda = lambda; p.seed = seed;
-    p.kq = kq; p.km = km; p.ps = ps; p.pi = pi; p.ks = ks; p.target0 = t_ik_target_base;
+    p.kq = kq; p.km = km; p.ps = ps; p.ks = ks; p.target0 = t_ik_target_base;
+    for (int j = 0; j < 16; ++j) p.pi[j] = pi ? pi[j < c->n ? j : (c->n > 0 ? c->n - 1 : 0)] : 0.3;      // NULL: the reference's default
     if (kq > 0.0 && flavour != 1) { set_error("ik_lm: null-space terms belong to the Python solvers (flavour 1)"); return RTBHIP_EINVAL; }
-    if (kq > 0.0 && ps == pi) { set_error("ik_lm: ps must differ from pi"); return RTBHIP_EINVAL; }
+    if (kq > 0.0)
+        for (int j = 0; j < c->n && j < 16; ++j)
+            if (ps == p.pi[j]) { set_error("ik_lm: ps must differ from pi"); return RTBHIP_EINVAL; }
     for (int i = 0; i < 6; i++) p.we[i] = we6 ? we6[i] : 1.0;
     DevChain ops;
     const double *qlim = nullptr;
@@ -819,7 +896,8 @@ int rtbhip_rne(rtbhip_dyn_t dyn, const double *q, const double *qd, const double
     Dyn *d = d_owner.get();
     RTB_TRACE("rtbhip_rne");
     if (!d) { set_error("rne: unknown dyn handle"); return RTBHIP_EINVAL; }
-    RTB_TRY(check_batch("rne", q, N, mem));
+    DeviceScope dscope;
+    RTB_TRY(check_batch("rne", q, N, mem, &dscope));
     if (!grav3) { set_error("rne: NULL gravity"); return RTBHIP_EINVAL; }
     if (N > 0 && !tau) { set_error("rne: NULL tau"); return RTBHIP_EINVAL; }   // qd / qdd may be NULL (= zeros)
     if (N == 0) return RTBHIP_OK;
@@ -868,7 +946,8 @@ int rtbhip_tree_rne(rtbhip_tree_t tree, const double *q, const double *qd, const
     Tree *t = t_owner.get();
     RTB_TRACE("rtbhip_tree_rne");
     if (!t) { set_error("tree_rne: unknown tree handle"); return RTBHIP_EINVAL; }
-    RTB_TRY(check_batch("tree_rne", q, N, mem));
+    DeviceScope dscope;
+    RTB_TRY(check_batch("tree_rne", q, N, mem, &dscope));
     if (!gravity3) { set_error("tree_rne: NULL gravity"); return RTBHIP_EINVAL; }
     if (N > 0 && !tau) { set_error("tree_rne: NULL tau"); return RTBHIP_EINVAL; }
     if (N == 0) return RTBHIP_OK;
@@ -898,7 +977,8 @@ static int dyn_entry(const char *fn, rtbhip_dyn_t dyn, int mode, const double *q
     Dyn *d = d_owner.get();
     RTB_TRACE((std::string("rtbhip_") + fn).c_str());
     if (!d) { set_error(std::string(fn) + ": unknown dyn handle"); return RTBHIP_EINVAL; }
-    RTB_TRY(check_batch(fn, q, N, mem));
+    DeviceScope dscope;
+    RTB_TRY(check_batch(fn, q, N, mem, &dscope));
     if (N > 0 && !out) { set_error(std::string(fn) + ": NULL output"); return RTBHIP_EINVAL; }
     if (N > 0 && mode >= 1 && !qd) { set_error(std::string(fn) + ": NULL qd"); return RTBHIP_EINVAL; }
     if (N > 0 && mode == 2 && (!tq || !grav3)) { set_error(std::string(fn) + ": NULL torque/gravity"); return RTBHIP_EINVAL; }
@@ -947,6 +1027,10 @@ int rtbhip_fleet_fkine_jacob(const rtbhip_chain_t *chains, int32_t n_chains, con
     if (mem != RTBHIP_MEM_HOST && mem != RTBHIP_MEM_DEVICE) { set_error("fleet: bad mem kind"); return RTBHIP_EINVAL; }
     std::vector<FleetEntry> entries;
     Staging st;
+    DeviceScope dscope;
+    if (mem == RTBHIP_MEM_DEVICE)
+        for (int i = 0; i < n_chains; i++)
+            if (N[i] > 0 && q[i]) { RTB_TRY(dscope.enter_for("fleet", q[i])); break; }
     std::vector<void *> dT(n_chains, nullptr), dJ(n_chains, nullptr);
     int64_t tile0 = 0;
     for (int i = 0; i < n_chains; i++) {
@@ -1018,6 +1102,7 @@ int rtbhip_tune(const char *key, int32_t value)
     kin_tune(key, value);
     rne_tune(key, value);
     ik_tune(key, value);
+    partial_tune(key, value);
     hostpipe_tune(key, value);
     return RTBHIP_OK;
 }

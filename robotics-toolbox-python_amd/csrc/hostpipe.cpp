@@ -21,6 +21,7 @@
 #include <cstring>
 #include <functional>
 #include <thread>
+#include <unistd.h>
 
 namespace rtbhip {
 
@@ -32,7 +33,8 @@ public:
     // dst/src host memory; splits the range over the workers and waits
     void copy(void *dst, const void *src, size_t bytes)
     {
-        if (bytes < (1u << 20) || workers_.empty()) { std::memcpy(dst, src, bytes); return; }
+        // worker threads do not survive fork(): in a child the vector is non-empty but nobody would ever take a job
+        if (bytes < (1u << 20) || workers_.empty() || getpid() != owner_) { std::memcpy(dst, src, bytes); return; }
         const size_t parts = workers_.size() + 1;
         const size_t step = ((bytes / parts) + 4095) & ~(size_t)4095;
         std::unique_lock<std::mutex> lk(mu_);
@@ -53,6 +55,7 @@ private:
     struct Job { char *dst; const char *src; size_t n; };
     CopyPool()
     {
+        owner_ = getpid();
         unsigned hw = std::thread::hardware_concurrency();
         int n = hw >= 16 ? 7 : (hw >= 4 ? (int)hw / 2 - 1 : 0);
         if (const char *e = std::getenv("RTBHIP_COPY_THREADS")) n = std::max(0, std::atoi(e) - 1);
@@ -60,6 +63,7 @@ private:
     }
     ~CopyPool()
     {
+        if (getpid() != owner_) { for (auto &t : workers_) t.detach(); return; }      // a forked child: no threads to join
         { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
         cv_.notify_all();
         for (auto &t : workers_) t.join();
@@ -84,6 +88,7 @@ private:
     std::vector<std::thread> workers_;
     int pending_ = 0;
     bool stop_ = false;
+    pid_t owner_ = 0;
 };
 
 bool is_pinned_host(const void *p)
@@ -108,11 +113,15 @@ struct Slot {
     void *dev = nullptr, *pin = nullptr;     // device buffer [inputs | outputs]; pinned staging of the same layout
     size_t dev_cap = 0, pin_cap = 0;
 };
-struct Pipe {
-    std::mutex mu;                           // one host-path call at a time
-    std::map<int, std::array<Slot, 2>> per_device;
+struct DeviceSlots {
+    std::mutex mu;                           // one host-path call at a time PER DEVICE: calls on different GPUs overlap
+    std::array<Slot, 2> slots;
 };
-Pipe &pipe() { static Pipe p; return p; }
+struct Pipe {
+    std::mutex mu;                           // guards the map only
+    std::map<int, std::unique_ptr<DeviceSlots>> per_device;
+};
+Pipe &pipe() { static Pipe &p = *new Pipe(); return p; }                  // never destroyed
 
 int slot_reserve(Slot &s, size_t dev_bytes, size_t pin_bytes)
 {
@@ -145,15 +154,16 @@ void hostpipe_release()
 {
     Pipe &p = pipe();
     std::lock_guard<std::mutex> lk(p.mu);
-    for (auto &kv : p.per_device)
-        for (Slot &s : kv.second) {
+    for (auto &kv : p.per_device) {
+        std::lock_guard<std::mutex> l2(kv.second->mu);
+        for (Slot &s : kv.second->slots) {
             if (s.dev) (void)hipFree(s.dev);
             if (s.pin) (void)hipHostFree(s.pin);
             if (s.done) (void)hipEventDestroy(s.done);
             if (s.stream) (void)hipStreamDestroy(s.stream);
             s = Slot();
         }
-    p.per_device.clear();
+    }
 }
 
 int host_pipeline(const HostIO &io, int64_t N, const ChunkLaunch &launch)
@@ -188,8 +198,15 @@ int host_pipeline(const HostIO &io, int64_t N, const ChunkLaunch &launch)
     int dev = 0;
     RTB_HIP(hipGetDevice(&dev));
     Pipe &P = pipe();
-    std::lock_guard<std::mutex> lk(P.mu);
-    std::array<Slot, 2> &slots = P.per_device[dev];
+    DeviceSlots *ds = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        auto &up_ = P.per_device[dev];
+        if (!up_) up_.reset(new DeviceSlots());
+        ds = up_.get();                      // entries are never erased: the pointer stays valid
+    }
+    std::lock_guard<std::mutex> lk(ds->mu);
+    std::array<Slot, 2> &slots = ds->slots;
     for (Slot &s : slots) { int rc = slot_reserve(s, total, pin_total); if (rc != RTBHIP_OK) return rc; }
 
     const int64_t nchunks = (N + rows_chunk - 1) / rows_chunk;
@@ -258,10 +275,10 @@ struct HostCache {
     size_t cached = 0;
     size_t cap = [] {
         const char *e = std::getenv("RTBHIP_PINNED_CACHE_MB");
-        return (size_t)(e && std::atoll(e) >= 0 ? std::atoll(e) : 4096) << 20;
+        return (size_t)(e && std::atoll(e) >= 0 ? std::atoll(e) : 1024) << 20;
     }();
 };
-HostCache &hcache() { static HostCache c; return c; }
+HostCache &hcache() { static HostCache &c = *new HostCache(); return c; }   // never destroyed (no hipHostFree at exit)
 }  // namespace
 
 int host_alloc(size_t bytes, void **out)
@@ -332,13 +349,22 @@ void host_cache_trim(size_t keep_bytes)
 }
 
 // ---------------------------------------------------------------- cached device buffers for the other host-path calls
+// IK, the dynamics terms, hessian_from_jacobian, the fleet ... stage their host arrays in blocks drawn from here instead of a
+// hipMalloc per call.  The cache is BOUNDED: idle blocks above RTBHIP_DEVICE_CACHE_MB (default 512) per device go straight back to
+// the driver when they are released, so one large call (hessian_from_jacobian at N = 1e6 needs 2.3 GB) does not leave its buffers
+// parked where torch's or anybody else's allocator cannot reach them; rtbhip_trim() empties it on request.
 namespace {
 struct DevCache {
     std::mutex mu;
     std::map<int, std::multimap<size_t, void *>> free_blocks;   // per device
+    std::map<int, size_t> cached;                               // idle bytes per device
     std::map<void *, std::pair<int, size_t>> live;
+    size_t cap = [] {
+        const char *e = std::getenv("RTBHIP_DEVICE_CACHE_MB");
+        return (size_t)(e && std::atoll(e) >= 0 ? std::atoll(e) : 512) << 20;
+    }();
 };
-DevCache &dcache() { static DevCache c; return c; }
+DevCache &dcache() { static DevCache &c = *new DevCache(); return c; }   // never destroyed: no hipFree during static destruction
 size_t size_class(size_t b)
 {
     size_t c = 4096;
@@ -358,10 +384,11 @@ int dev_cache_alloc(size_t bytes, void **out)
     {
         std::lock_guard<std::mutex> lk(c.mu);
         auto &fb = c.free_blocks[dev];
-        auto it = fb.find(want);
-        if (it != fb.end()) {
+        auto it = fb.lower_bound(want);
+        if (it != fb.end() && it->first <= 2 * want) {          // the smallest idle block that fits, up to twice the request
             *out = it->second;
-            c.live[*out] = {dev, want};
+            c.live[*out] = {dev, it->first};
+            c.cached[dev] -= it->first;
             fb.erase(it);
             return RTBHIP_OK;
         }
@@ -369,6 +396,7 @@ int dev_cache_alloc(size_t bytes, void **out)
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) {
+        (void)hipGetLastError();
         dev_cache_release();
         e = hipMalloc(&p, want);
         if (e != hipSuccess) return hip_fail(e, "hipMalloc (host-path staging)");
@@ -383,23 +411,41 @@ void dev_cache_free(void *p)
 {
     if (!p) return;
     DevCache &c = dcache();
-    std::lock_guard<std::mutex> lk(c.mu);
-    auto it = c.live.find(p);
-    if (it == c.live.end()) return;
-    c.free_blocks[it->second.first].emplace(it->second.second, p);
-    c.live.erase(it);
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        auto it = c.live.find(p);
+        if (it == c.live.end()) return;
+        const int dev = it->second.first;
+        const size_t sz = it->second.second;
+        c.live.erase(it);
+        if (c.cached[dev] + sz <= c.cap) {
+            c.free_blocks[dev].emplace(sz, p);
+            c.cached[dev] += sz;
+            return;
+        }
+    }
+    (void)hipFree(p);                                           // above the cap: back to the driver now
 }
 
-void dev_cache_release()
+void dev_cache_trim(size_t keep_bytes)
 {
     DevCache &c = dcache();
     std::vector<void *> drop;
     {
         std::lock_guard<std::mutex> lk(c.mu);
-        for (auto &kv : c.free_blocks) for (auto &b : kv.second) drop.push_back(b.second);
-        c.free_blocks.clear();
+        for (auto &kv : c.free_blocks) {
+            size_t &have = c.cached[kv.first];
+            while (have > keep_bytes && !kv.second.empty()) {
+                auto it = std::prev(kv.second.end());           // largest first
+                have -= it->first;
+                drop.push_back(it->second);
+                kv.second.erase(it);
+            }
+        }
     }
     for (void *p : drop) (void)hipFree(p);
 }
+
+void dev_cache_release() { dev_cache_trim(0); }
 
 }  // namespace rtbhip

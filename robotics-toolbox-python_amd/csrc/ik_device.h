@@ -36,7 +36,8 @@ struct IkDev {   // wave-uniform solver parameters (kernarg)
     double we[6];
     uint64_t seed;
     int64_t N;
-    double kq, km, ps, pi;           // null-space terms of the Python solvers (IK.py:507-576); kq <= 0: none
+    double kq, km, ps;               // null-space terms of the Python solvers (IK.py:507-576); kq <= 0: none
+    double pi[16];                   // ... the influence distance, one per joint (IK.py:507-540 and :1441-1442 accept a scalar or an array)
     double ks;                       // IK_QP (method 5): slack gain; its joint-velocity gain kj travels in `lambda`
     int64_t target0;                 // added to a target's row number where it keys the restart generator (rtbhip_ik_target_base):
                                      // a row block of a larger batch then draws what the whole batch would have drawn for those targets
@@ -195,13 +196,13 @@ RTB_HD void ik_qnull(const double (&jac)[6 * NJ], const PD &p, QL qlim, QA qa, d
 {
     static_assert(NJ >= 6, "null-space motion needs a redundant or square arm");
     double grad[NJ];
-    const double den = (p.ps - p.pi) * (p.ps - p.pi);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const double qi = qa.get(j), lo = qlim[j], hi = qlim[NJ + j];
+        const double pij = p.pi[j], den = (p.ps - pij) * (p.ps - pij);
         double sg = 0.0;
-        if (qi - lo <= p.pi) sg = -(((qi - lo) - p.pi) * ((qi - lo) - p.pi)) / den;
-        if (hi - qi <= p.pi) sg = (((hi - qi) - p.pi) * ((hi - qi) - p.pi)) / den;
+        if (qi - lo <= pij) sg = -(((qi - lo) - pij) * ((qi - lo) - pij)) / den;
+        if (hi - qi <= pij) sg = (((hi - qi) - pij) * ((hi - qi) - pij)) / den;
         grad[j] = (1.0 / p.kq) * -sg;
     }
     double B[6][6], dval[6], dinv[6];
@@ -274,13 +275,13 @@ RTB_HD bool ik_qp_bounded(const double (&jac)[6 * NJ], const double (&e)[6], dou
                           double (&dq)[NJ])
 {
     double sgn[NJ], beta[NJ];          // sgn 0: the joint has no row
-    const double scale = 1.0 / ((p.pi - p.ps) * p.kq);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const double qi = qa.get(j), lo = qlim[j], hi = qlim[NJ + j];
+        const double pij = p.pi[j], scale = 1.0 / ((pij - p.ps) * p.kq);
         sgn[j] = 0.0; beta[j] = 0.0;
-        if (hi - qi <= p.pi) { beta[j] = ((hi - qi) - p.ps) * scale; sgn[j] = 1.0; }
-        if (qi - lo <= p.pi) { beta[j] = ((qi - lo) - p.ps) * scale; sgn[j] = -1.0; }
+        if (hi - qi <= pij) { beta[j] = ((hi - qi) - p.ps) * scale; sgn[j] = 1.0; }
+        if (qi - lo <= pij) { beta[j] = ((qi - lo) - p.ps) * scale; sgn[j] = -1.0; }
     }
     unsigned act = 0;
     bool fixed_point = false;

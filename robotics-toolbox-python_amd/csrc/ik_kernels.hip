@@ -374,6 +374,30 @@ void ik_release_device_state()
     g_ctr.clear();
 }
 
+// the per-device ring of fresh-target counters a launch draws from: allocated here or on the first rtbhip_ik_lm of a device
+static int ik_counter_ring(unsigned long long **ring_out)
+{
+    int dev = 0;
+    RTB_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_ctr_mu);
+    auto it = g_ctr.find(dev);
+    if (it == g_ctr.end()) {
+        unsigned long long *ring = nullptr;
+        RTB_HIP(hipMalloc((void **)&ring, kCtrRing * sizeof(unsigned long long)));
+        g_ctr[dev] = ring;
+        *ring_out = ring;
+    } else {
+        *ring_out = it->second;
+    }
+    return RTBHIP_OK;
+}
+
+int ik_prepare_device()
+{
+    unsigned long long *ring = nullptr;
+    return ik_counter_ring(&ring);
+}
+
 void ik_restart_host(const Chain *c, uint64_t seed, int64_t target, int draw, double *q_n)
 {
     const int n = c->n;
@@ -397,6 +421,7 @@ static void launch_nj(dim3 grid, hipStream_t s, const IkDev &p, const DevChain &
     else hipLaunchKernelGGL((k_ik<NJ, 0>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share);
 }
 
+#define RTB_TRY_IK(expr) do { int _rc = (expr); if (_rc != RTBHIP_OK) return _rc; } while (0)
 int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const double *Tep, int64_t N, const double *q0,
               const IkParams &ip, double *q_out, int32_t *success, int32_t *iters, int32_t *searches, double *residual,
               hipStream_t s)
@@ -414,7 +439,8 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
     for (int k = 0; k < 6; ++k) p.we[k] = ip.we[k];
     p.seed = ip.seed; p.target0 = ip.target0;
     p.N = N;
-    p.kq = ip.kq; p.km = ip.km; p.ps = ip.ps; p.pi = ip.pi; p.ks = ip.ks;
+    p.kq = ip.kq; p.km = ip.km; p.ps = ip.ps; p.ks = ip.ks;
+    for (int j = 0; j < 16; ++j) p.pi[j] = ip.pi[j];
     if (p.method == 5 && (p.km > 0.0 || p.kq > 0.0) && (c->n > kIkNullMax || c->n < 6)) {
         // IK_QP (ik_device.h): the manipulability term needs J J^T invertible, and both live in the one-wave-per-SIMD step variants
         set_error("ik_qp: the manipulability term (km > 0) and the joint-limit rows (kq > 0) are built for chains of 6..12 joints");
@@ -430,16 +456,7 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
     RTB_HIP(hipGetDevice(&dev));
     if (device_cu_count(&cus) != RTBHIP_OK) return RTBHIP_EHIP;
     unsigned long long *ring = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(g_ctr_mu);
-        auto it = g_ctr.find(dev);
-        if (it == g_ctr.end()) {
-            RTB_HIP(hipMalloc((void **)&ring, kCtrRing * sizeof(unsigned long long)));
-            g_ctr[dev] = ring;
-        } else {
-            ring = it->second;
-        }
-    }
+    RTB_TRY_IK(ik_counter_ring(&ring));
     // a batch smaller than the grid's lane count is spread over ALL the waves (fresh_cap targets per
     // wave and pass) instead of filling ceil(N/64) of them: every SIMD then holds its share of the tail
     const bool one_wave = c->n > kRegMaxJoints || (ik_step_variant(p, c->n) & kIkStepNull);   // 9..12 joints, null-space: one wave per SIMD

@@ -126,4 +126,47 @@ RTB_HD void partial_column(const PartialPlan &p, const Src &src, int64_t cfg, ui
     put(3, rot[0]); put(4, rot[1]); put(5, rot[2]);
 }
 
+// Order 3, written out (the plan of partial_plan(n, 3): two terms, in this order, so the sums round as partial_column<3>'s):
+//     dT3[d2, d1, :, d0] = rot(H[d2][:, d1]) x J[:, d0]  +  rot(J[:, d1]) x H[d2][:, d0]
+// jac(off) / hes(off): element `off` of this configuration's (6, n) Jacobian / (n, 6, n) Hessian.  No plan look-ups, no offset
+// arithmetic beyond three multiply-adds: the digit -> offset linear forms of the general routine are constants here.
+template <class Jac, class Hes, class Put>
+RTB_HD void partial3_column(int n, const Jac &jac, const Hes &hes, uint32_t d0, uint32_t d1, uint32_t d2, Put put)
+{
+    const uint32_t hs = mad24(d2, 6u * (uint32_t)n, 0);             // slice d2 of the Hessian
+    const uint32_t a1 = hs + d1, b2 = hs + d0;
+    double trn[3], rot[3];
+    {
+        const double w0 = hes(a1 + 3 * n), w1 = hes(a1 + 4 * n), w2 = hes(a1 + 5 * n);
+        const double v0 = jac(d0), v1 = jac(d0 + n), v2 = jac(d0 + 2 * n);
+        const double u0 = jac(d0 + 3 * n), u1 = jac(d0 + 4 * n), u2 = jac(d0 + 5 * n);
+        trn[0] = 0.0 + (w1 * v2 - w2 * v1); trn[1] = 0.0 + (w2 * v0 - w0 * v2); trn[2] = 0.0 + (w0 * v1 - w1 * v0);
+        rot[0] = 0.0 + (w1 * u2 - w2 * u1); rot[1] = 0.0 + (w2 * u0 - w0 * u2); rot[2] = 0.0 + (w0 * u1 - w1 * u0);
+    }
+    {
+        const double w0 = jac(d1 + 3 * n), w1 = jac(d1 + 4 * n), w2 = jac(d1 + 5 * n);
+        const double v0 = hes(b2), v1 = hes(b2 + n), v2 = hes(b2 + 2 * n);
+        const double u0 = hes(b2 + 3 * n), u1 = hes(b2 + 4 * n), u2 = hes(b2 + 5 * n);
+        trn[0] += w1 * v2 - w2 * v1; trn[1] += w2 * v0 - w0 * v2; trn[2] += w0 * v1 - w1 * v0;
+        rot[0] += w1 * u2 - w2 * u1; rot[1] += w2 * u0 - w0 * u2; rot[2] += w0 * u1 - w1 * u0;
+    }
+    put(0, trn[0]); put(1, trn[1]); put(2, trn[2]);
+    put(3, rot[0]); put(4, rot[1]); put(5, rot[2]);
+}
+
+// How the order-3 kernel cuts the batch: G whole configurations per workgroup (so every Jacobian and Hessian is staged exactly
+// once), U columns per lane.  G is the most whose output run (48 n^3 bytes each) fits the tile budget; 0 = not served (the general
+// kernel takes over).
+constexpr int kPartial3TileBytes = 36 * 1024;
+constexpr int kPartial3MaxU = 4;
+RTB_HD void partial3_geometry(int n, int block, int *G, int *U)
+{
+    const int cols = n * n * n;
+    int g = kPartial3TileBytes / (48 * cols);
+    const int cap = block * kPartial3MaxU / cols;                   // columns the lanes can hold
+    if (g > cap) g = cap;
+    *G = g < 1 ? 0 : g;
+    *U = g < 1 ? 0 : (g * cols + block - 1) / block;
+}
+
 }  // namespace rtbhip

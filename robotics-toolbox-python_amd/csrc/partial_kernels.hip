@@ -10,6 +10,7 @@
 // 115 KB at order 4 for the Panda) against 2^(c-2) x 18 flops per column.
 #include "partial_device.h"
 #include "rtbhip_internal.h"
+#include <string>
 
 namespace rtbhip {
 
@@ -109,10 +110,93 @@ __global__ __launch_bounds__(kPartialBlock) void k_partial(PartialPlan plan, Par
     }
 }
 
+// Order 3 -- the (N, n, n, 6, n) tensor, what ETS.partial_fkine0(q, n=3) returns -- on workgroups that own WHOLE configurations:
+// G of them each (partial3_geometry), their Jacobians and Hessians staged once (the general kernel's runs of floor(256/n) blocks
+// straddle configurations and re-stage them: 1.8x the input bytes, profiles/r01_t_pmc_secondary.txt), the G x n^3 columns dealt to
+// the lanes U at a time, the output assembled in LDS and written as ONE contiguous run of 16-byte non-temporal stores.
+template <int U>
+__global__ __launch_bounds__(kPartialBlock) void k_partial3(int n, int G, int64_t N, const double *__restrict__ J, const double *__restrict__ H,
+                                                            double *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x;
+    const uint32_t nn = (uint32_t)(n * n), cols = nn * (uint32_t)n;
+    const int szj = 6 * n, szh = 6 * n * n;
+    const int64_t cfg0 = (int64_t)blockIdx.x * G;
+    const int g = (int)(N - cfg0 < G ? N - cfg0 : G);
+    double *tile = lds, *stage = lds + ((G * 6 * (int)cols + 1) & ~1);          // [g output runs][g Jacobians][g Hessians]
+    {
+        const double *Js = J + cfg0 * szj, *Hs = H + cfg0 * szh;
+        const int tj = g * szj, tot = g * (szj + szh);
+        for (int i0 = 0; i0 < tot; i0 += 4 * kPartialBlock) {                   // four loads in flight per lane and round
+            double r[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + tid + u * kPartialBlock;
+                r[u] = i < tj ? Js[i] : (i < tot ? Hs[i - tj] : 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + tid + u * kPartialBlock;
+                if (i < tot) stage[i] = r[u];
+            }
+        }
+        __syncthreads();
+    }
+    typedef const __attribute__((address_space(3))) double *LdsPtr;
+    const LdsPtr sj = (LdsPtr)stage, sh = (LdsPtr)stage + g * szj;
+    const float inv_n = 1.0f / (float)n, inv_cols = 1.0f / (float)cols;
+    const uint32_t total = (uint32_t)g * cols;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint32_t idx = (uint32_t)tid + (uint32_t)u * kPartialBlock;
+        if (idx >= total) continue;
+        uint32_t col, d0, d1, d2;
+        const uint32_t dc = divmod24(idx, cols, inv_cols, &col);
+        uint32_t r = divmod24(col, (uint32_t)n, inv_n, &d0);
+        d2 = divmod24(r, (uint32_t)n, inv_n, &d1);
+        const LdsPtr cj = sj + mad24(dc, (uint32_t)szj, 0), ch = sh + mad24(dc, (uint32_t)szh, 0);
+        double *t = tile + mad24(dc, 6u * cols, mad24(r, 6u * (uint32_t)n, d0));       // block r = col / n of configuration dc, column d0
+        partial3_column(n, [&](uint32_t off) -> double { return cj[off]; }, [&](uint32_t off) -> double { return ch[off]; }, d0, d1, d2,
+                        [&](int row, double v) { t[row * n] = v; });
+    }
+    __syncthreads();
+    const int pairs = g * 3 * (int)cols;
+    double *dst = out + cfg0 * 6 * (int64_t)cols;
+    for (int i = tid; i < pairs; i += kPartialBlock) {
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const v2d w = *reinterpret_cast<const v2d *>(tile + 2 * i);
+        __builtin_nontemporal_store(w, reinterpret_cast<v2d *>(dst + 2 * i));
+    }
+}
+
+static int g_partial3 = 1;        // rtbhip_tune("partial3", 0): the general kernel at order 3 too (A/B)
+void partial_tune(const char *key, int value) { if (std::string(key) == "partial3") g_partial3 = value != 0; }
+
 // lower[a-1] = order-a tensor (device), a = 1 .. order-1; out = order-`order` tensor
 int launch_partial(int n, int order, const double *const *lower, int64_t N, double *out, hipStream_t s)
 {
     if (N == 0) return RTBHIP_OK;
+    if (order == 3 && g_partial3) {
+        int G = 0, U = 0;
+        partial3_geometry(n, kPartialBlock, &G, &U);
+        if (G > 0 && (int64_t)6 * n * n * n * G < (1 << 24)) {
+            const int64_t blocks = (N + G - 1) / G;
+            if (blocks > 0x7fffffff) { set_error("partial_fkine0: batch too large for one launch"); return RTBHIP_ELIMIT; }
+            const size_t lds = (size_t)(((G * 6 * n * n * n + 1) & ~1) + G * (6 * n + 6 * n * n)) * sizeof(double);
+            const dim3 grid((unsigned)blocks), block(kPartialBlock);
+            switch (U) {
+            case 1: hipLaunchKernelGGL(k_partial3<1>, grid, block, lds, s, n, G, N, lower[0], lower[1], out); break;
+            case 2: hipLaunchKernelGGL(k_partial3<2>, grid, block, lds, s, n, G, N, lower[0], lower[1], out); break;
+            case 3: hipLaunchKernelGGL(k_partial3<3>, grid, block, lds, s, n, G, N, lower[0], lower[1], out); break;
+            default: hipLaunchKernelGGL(k_partial3<4>, grid, block, lds, s, n, G, N, lower[0], lower[1], out); break;
+            }
+            note_launch((int)blocks, kPartialBlock, (int)lds);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return hip_fail(e, "k_partial3 launch");
+            return RTBHIP_OK;
+        }
+    }
     PartialPlan plan;
     partial_plan(n, order, &plan);
     plan.N = N;

@@ -135,6 +135,7 @@ void host_cache_trim(size_t keep_bytes);
 int dev_cache_alloc(size_t bytes, void **out);   // device staging buffers of the remaining host-path calls: cached, not per call
 void dev_cache_free(void *p);
 void dev_cache_release();
+void dev_cache_trim(size_t keep_bytes);
 
 // ---------------------------------------------------------------- kernel launchers (device pointers)
 struct Affine { double v[12]; int used; };  // row-major 3x4, host-side small parameter
@@ -176,7 +177,8 @@ struct IkParams {
     double tol, lambda;
     double we[6];
     uint64_t seed;
-    double kq = 0.0, km = 0.0, ps = 0.1, pi = 0.3;   // null-space terms of the Python solvers; kq <= 0: none
+    double kq = 0.0, km = 0.0, ps = 0.1;             // null-space terms of the Python solvers; kq <= 0: none
+    double pi[16];                                   // ... influence distance per joint (filled by ik_entry)
     double ks = 1.0;                                 // IK_QP (method 5): slack gain (kj travels in lambda)
     int64_t target0 = 0;                             // restart-generator key offset of row 0 (rtbhip_ik_target_base)
 };

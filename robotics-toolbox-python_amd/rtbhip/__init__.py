@@ -13,7 +13,7 @@ Only the hot path named in BASELINE.json / SURVEY.md section 8 is here:
 All arithmetic runs in hand-written HIP kernels (../csrc) behind the C ABI of include/rtbhip.h; there is no
 CPU fallback: every call raises RtbHipError when librtbhip.so or a GPU is missing.
 """
-from ._lib import RtbHipError, lib, device_count, tune, shard_range, last_launch, ik_target_base  # noqa: F401
+from ._lib import RtbHipError, lib, device_count, tune, shard_range, last_launch, ik_target_base, trim  # noqa: F401
 from .et import ET, ETS, IKSolution, angle_axis, p_servo, hessian_from_jacobian  # noqa: F401
 from .dh import DHLink, DHRobot, RevoluteDH, PrismaticDH, RevoluteMDH, PrismaticMDH  # noqa: F401
 from .erobot import Link, ERobot  # noqa: F401
@@ -26,4 +26,4 @@ from .shard import ShardedBatch  # noqa: F401
 
 __all__ = ["ET", "ETS", "IKSolution", "angle_axis", "p_servo", "hessian_from_jacobian", "DHLink", "DHRobot", "RevoluteDH", "PrismaticDH", "RevoluteMDH",
            "PrismaticMDH", "Link", "ERobot", "PoELink", "PoERevolute", "PoEPrismatic", "PoERobot", "RobotKinematics", "models", "urdf", "fleet_fkine_jacob", "ShardedBatch", "RtbHipError", "lib",
-           "device_count", "tune", "shard_range", "last_launch", "ik_target_base"]
+           "device_count", "tune", "shard_range", "last_launch", "ik_target_base", "trim"]

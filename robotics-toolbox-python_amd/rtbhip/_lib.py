@@ -47,6 +47,10 @@ SIGNATURES = {
     "rtbhip_shutdown": (None, []),
     "rtbhip_chain_create": (C.c_int, [C.POINTER(rtbhip_et), _i32, _vp, C.POINTER(_u64)]),
     "rtbhip_chain_create_poe": (C.c_int, [_vp, _i32, _vp, _vp, C.POINTER(_u64)]),
+    "rtbhip_chain_upload": (C.c_int, [_u64, _i32]),
+    "rtbhip_dyn_upload": (C.c_int, [_u64, _i32]),
+    "rtbhip_tree_upload": (C.c_int, [_u64, _i32]),
+    "rtbhip_trim": (C.c_int, [_u64, _u64]),
     "rtbhip_chain_destroy": (C.c_int, [_u64]),
     "rtbhip_chain_info": (C.c_int, [_u64, _ip, _ip, _ip]),
     "rtbhip_chain_set_q_width": (C.c_int, [_u64, C.c_int32]),
@@ -59,9 +63,9 @@ SIGNATURES = {
     "rtbhip_ik_lm": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _i32, C.c_double, _i32, _vp, C.c_double,
                                _i32, _i32, _u64, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "rtbhip_ik_lm_nullspace": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _i32, C.c_double, _i32, _vp, C.c_double, _i32, _i32, _u64,
-                                         C.c_double, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+                                         C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "rtbhip_ik_qp": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _i32, C.c_double, _i32, _vp, _u64, C.c_double, C.c_double, C.c_double, C.c_double,
-                               C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+                               C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "rtbhip_ik_target_base": (C.c_int, [_i64]),
     "rtbhip_ik_restart": (C.c_int, [_u64, _u64, _i64, _i32, _vp]),
     "rtbhip_dyn_create": (C.c_int, [_vp, _i32, _i32, C.POINTER(_u64)]),
@@ -237,6 +241,21 @@ def as_numeric(x, what="q"):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+_stream_dev = threading.local()       # the GPU whose current stream the next launch uses (set by note_device)
+
+
+def note_device(x):
+    """Remember which GPU a device-path call's buffers live on: the launch goes to THAT device's current stream (the library switches
+    to the buffers' GPU when it is not the current one, rtbhip.h `mem`)."""
+    _stream_dev.value = x.device if (is_torch(x) and x.is_cuda) else None
+
+
 def current_stream_ptr():
     import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dev = getattr(_stream_dev, "value", None)
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def trim(keep_device_bytes=0, keep_pinned_bytes=0):
+    """Hand idle cached staging memory back (rtbhip_trim): device blocks of the host-path calls, pinned host blocks."""
+    check(lib().rtbhip_trim(int(keep_device_bytes), int(keep_pinned_bytes)))

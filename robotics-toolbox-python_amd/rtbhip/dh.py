@@ -12,6 +12,7 @@ import numpy as np
 from . import _lib
 from ._lib import check, lib, as_numeric, host_ptr, is_torch, MEM_HOST, MEM_DEVICE
 from .et import ET, ETS
+from .kinematics import RobotKinematics
 
 
 class DHLink:
@@ -111,7 +112,7 @@ def _mat4(T):
     return T.copy()
 
 
-class DHRobot:
+class DHRobot(RobotKinematics):
     def __init__(self, links, name="", manufacturer="", base=None, tool=None, gravity=None, **kw):
         self.links = list(links)
         if not self.links:
@@ -146,8 +147,10 @@ class DHRobot:
                 lo.append(0.0); hi.append(1.0)
         return np.array([lo, hi])
 
-    def ets(self):
-        """reference robot/DHRobot.py:878-918 (base / tool become constant SE3 transforms)."""
+    def ets(self, start=None, end=None):
+        """reference robot/DHRobot.py:878-918 (base / tool become constant SE3 transforms).  The reference's ets(*args, **kwargs)
+        ignores its arguments; here a start / end other than None is refused."""
+        self._refuse("ets", start=start, end=end)
         if self._ets is None:
             e = ETS()
             if self.base is not None and not np.array_equal(self.base, np.eye(4)):
@@ -159,14 +162,28 @@ class DHRobot:
             self._ets = e
         return self._ets
 
-    def fkine(self, q, **kw):
-        """(4,4) or (N,4,4).  The reference multiplies closed-form DH matrices in Python
-        (robot/DHRobot.py:953-979, DHLink.A robot/DHLink.py:633-673); the ETS lowering evaluated on
-        the GPU is the same product (tests pin the two against each other)."""
+    # ------------------------------------------------------------ kinematics
+    # DHRobot is a Robot in the reference (robot/DHRobot.py:38): apart from the five methods it defines itself (below) it inherits
+    # the RobotKinematics surface, every call of which goes through self.ets(start, end) -- and DHRobot.ets takes and ignores any
+    # arguments (:878).  A drop-in must not ignore silently: None is accepted, anything else is refused.
+    def _kin_base(self): return None        # base and tool are inside ets()
+    def _kin_tool(self): return None
+
+    @staticmethod
+    def _refuse(method, **kw):
+        bad = sorted(k for k, v in kw.items() if v is not None)
+        if bad:
+            raise TypeError("DHRobot.%s: %s has no effect on a DH robot in the reference and is refused here" % (method, ", ".join(bad)))
+
+    def fkine(self, q, **kwargs):
+        """(4,4) or (N,4,4).  The reference multiplies closed-form DH matrices in Python (robot/DHRobot.py:920-979, DHLink.A
+        robot/DHLink.py:633-673), base and tool included; the ETS lowering evaluated on the GPU is the same product (tests pin
+        the two against each other).  The reference's signature is fkine(q, **kwargs) with the keywords unused."""
+        self._refuse("fkine", **kwargs)
         return self.ets().eval(q)
 
-    def fkine_all(self, q, **kw):
-        """Poses of frames {0} (the base) to {n}: (n+1,4,4) or (N,n+1,4,4).  reference robot/DHRobot.py:1012-1064:
+    def fkine_all(self, q, old=None):
+        """Poses of frames {0} (the base) to {n}: (n+1,4,4) or (N,n+1,4,4).  reference robot/DHRobot.py:1018-1064:
         Tj = base; Tj *= L.A(q_j) for every link -- the tool is not applied."""
         e = self.ets()
         k = 1 if (self.base is not None and not np.array_equal(self.base, np.eye(4))) else 0
@@ -176,23 +193,57 @@ class DHRobot:
             marks.append(k)
         return e.link_frames(q, marks)
 
-    def jacob0(self, q, **kw): return self.ets().jacob0(q)
-    def jacobe(self, q, **kw): return self.ets().jacobe(q)
+    @staticmethod
+    def _half(J, half):
+        """robot/DHRobot.py:1131-1139, :1188-1196: the translational or the rotational rows."""
+        if half is None:
+            return J
+        if half == "trans":
+            return J[..., :3, :]
+        if half == "rot":
+            return J[..., 3:, :]
+        raise ValueError("bad half specified")
 
-    # the Robot-level pass-throughs a DHRobot inherits in the reference (robot/RobotKinematics.py, robot/Robot.py):
-    # everything goes through the lowered ETS (base and tool are part of it, the link qlim travel with the joints)
-    def hessian0(self, q=None, **kw): return self.ets().hessian0(q)
-    def hessiane(self, q=None, **kw): return self.ets().hessiane(q)
-    def jacob0_dot(self, q, qd, **kw): return self.ets().jacob0_dot(q, qd)
-    def manipulability(self, q, method="yoshikawa", axes="all", **kw):
-        return self.ets().manipulability(q, method=method, axes=axes)
-    def jacobm(self, q, axes="all", **kw): return self.ets().jacobm(q, axes=axes)
-    def jacob0_analytical(self, q, representation="rpy/xyz", **kw): return self.ets().jacob0_analytical(q, representation=representation)
-    def partial_fkine0(self, q, n=3, **kw): return self.ets().partial_fkine0(q, n=n)
-    def ik_LM(self, Tep, **kw): return self.ets().ik_LM(Tep, **kw)
-    def ik_GN(self, Tep, **kw): return self.ets().ik_GN(Tep, **kw)
-    def ik_NR(self, Tep, **kw): return self.ets().ik_NR(Tep, **kw)
-    def ikine_LM(self, Tep, **kw): return self.ets().ikine_LM(Tep, **kw)
+    def jacobe(self, q, half=None, **kwargs):
+        """Jacobian in the end-effector frame (robot/DHRobot.py:1066-1140); half = "trans" / "rot" returns those three rows."""
+        self._refuse("jacobe", **kwargs)
+        return self._half(self.ets().jacobe(q), half)
+
+    def _rotate_rows(self, Je, T):
+        """tr2jac(T) @ Je (robot/DHRobot.py:1182): both halves of every column rotated by T's rotation -- the one place a supplied
+        pose enters; a pre-multiplication of what the kernel returned."""
+        T = T.A if hasattr(T, "A") and not isinstance(T, np.ndarray) and not is_torch(T) else T
+        if is_torch(Je):
+            import torch
+            R = torch.as_tensor(T, dtype=Je.dtype, device=Je.device)[..., :3, :3]
+            return torch.cat([R @ Je[..., :3, :], R @ Je[..., 3:, :]], dim=-2)
+        R = np.asarray(T, dtype=np.float64)[..., :3, :3]
+        return np.concatenate([R @ Je[..., :3, :], R @ Je[..., 3:, :]], axis=-2)
+
+    def jacob0(self, q=None, T=None, half=None, start=None, end=None):
+        """World-frame Jacobian (robot/DHRobot.py:1142-1198): tr2jac(T) @ jacobe(q) with T = fkine(q) unless the caller supplies
+        it.  Without T this is the kernel's jacob0 directly (the same matrix); with T the end-effector-frame Jacobian is rotated by
+        the SUPPLIED pose, as the reference does."""
+        self._refuse("jacob0", start=start, end=end)
+        if T is None:
+            return self._half(self.ets().jacob0(q), half)
+        return self._half(self._rotate_rows(self.ets().jacobe(q), T), half)
+
+    def jacob0_analytical(self, q, representation=None, T=None):
+        """robot/DHRobot.py:1200-1275: representation None returns jacob0."""
+        if representation is None:
+            return self.jacob0(q, T=T)
+        if T is not None:
+            raise TypeError("DHRobot.jacob0_analytical: a supplied pose T is not offered with a representation (the kernel forms the "
+                            "rate transform from the pose it computes)")
+        return self.ets().jacob0_analytical(q, representation=representation)
+
+    def hessian0(self, q=None, J0=None, start=None, end=None):
+        """robot/DHRobot.py:1277-1331: self.ets().hessian0(q, J0)."""
+        self._refuse("hessian0", start=start, end=end)
+        return self.ets().hessian0(q, J0=J0)
+
+    # hessiane, partial_fkine0, manipulability, jacobm, jacob0_dot, ik_LM / ik_GN / ik_NR, ikine_LM / NR / GN / QP: RobotKinematics
 
     # ------------------------------------------------------------ dynamics
     def L24(self):
@@ -228,6 +279,13 @@ class DHRobot:
             self._dyn = h.value
         return self._dyn
 
+    def upload(self, device=None):
+        """Chain and link tables resident on `device` now (rtbhip_chain_upload / rtbhip_dyn_upload): hipGraph capture needs no warm-up."""
+        dev = -1 if device is None else int(getattr(device, "index", device) or 0)
+        self.ets().upload(device)
+        check(lib().rtbhip_dyn_upload(self._dyn_handle(), dev))
+        return self
+
     def _dyn_args(self, arrays):
         """-> (list of (N,n) contiguous arrays or None, N, single, torch_mode, ptr(), stream, mem, device)"""
         n = self.n
@@ -247,6 +305,7 @@ class DHRobot:
         if any(x is not None and tuple(x.shape) != (N, n) for x in out):
             raise ValueError("all inputs must be (%d,) or (N,%d)" % (n, n))
         if tm:
+            _lib.note_device(first)
             return out, N, single, True, (lambda x: None if x is None else C.c_void_p(x.data_ptr())), \
                 _lib.current_stream_ptr(), MEM_DEVICE, first.device
         return out, N, single, False, host_ptr, None, MEM_HOST, None
@@ -269,7 +328,9 @@ class DHRobot:
         (reference robot/DHRobot.py:1373-1456 -> frne.frne core/frne.c:106-230).
         qd / qdd = None means zeros (no zero arrays are read by the kernel)."""
         if base_wrench:
-            raise NotImplementedError("base_wrench is served by the reference's rne_python only")
+            # robot/DHRobot.py:1409-1412 sends base_wrench=True to rne_python (:1458-1796), a second, pure-Python formulation that no
+            # test, example or other module of the reference calls with this flag; not offered on the device path
+            raise NotImplementedError("rne(base_wrench=True) is the reference's pure-Python rne_python; not offered by the GPU backend")
         arrs, N, single, tm, ptr, stream, mem, dev = self._dyn_args([q, qd, qdd])
         gc = self._gravity_c(gravity)
         f = None if fext is None else np.ascontiguousarray(np.asarray(fext, dtype=np.float64).reshape(6))

@@ -282,6 +282,11 @@ class ERobot(RobotKinematics):
             self._tree = h.value
         return self._tree
 
+    def upload(self, device=None):
+        """The link-group table resident on `device` now (rtbhip_tree_upload)."""
+        check(lib().rtbhip_tree_upload(self._handle(), -1 if device is None else int(getattr(device, "index", device) or 0)))
+        return self
+
     def dynchanged(self):
         if self._tree is not None and _lib._lib is not None:
             _lib._lib.rtbhip_tree_destroy(self._tree)
@@ -315,6 +320,7 @@ class ERobot(RobotKinematics):
             import torch
             tau = torch.empty((N, n), dtype=torch.float64, device=arrs[0].device)
             ptr = lambda x: None if x is None else C.c_void_p(x.data_ptr())
+            _lib.note_device(arrs[0])
             stream, mem = _lib.current_stream_ptr(), MEM_DEVICE
         else:
             tau = _lib.host_empty((N, n))

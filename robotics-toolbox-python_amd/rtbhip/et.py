@@ -47,6 +47,7 @@ def hessian_from_jacobian(J, n=None):
     if tm:
         single = J.dim() == 2
         J3 = (J.reshape((1,) + tuple(J.shape)) if single else J).contiguous()
+        _lib.note_device(J3)
     else:
         a = as_numeric(J.detach().numpy() if is_torch(J) else J, "J")
         single = a.ndim == 2
@@ -66,6 +67,7 @@ def angle_axis(Te, Tep):
     tm = is_torch(Te) and Te.is_cuda and is_torch(Tep) and Tep.is_cuda
     def shape(T):
         if tm:
+            _lib.note_device(T)
             return T.reshape(-1, 4, 4).contiguous(), T.dim() == 2
         if hasattr(T, "A") and not isinstance(T, np.ndarray) and not is_torch(T):
             T = T.A
@@ -323,6 +325,12 @@ class ETS:
                 check(lib().rtbhip_chain_set_q_width(self._handle_, int(self._q_width)))
         return self._handle_
 
+    def upload(self, device=None):
+        """Make the chain table resident on `device` (None: the current GPU) now (rtbhip_chain_upload): afterwards every call with
+        device tensors only enqueues kernels, so a sequence of calls can be captured into a hipGraph without a warm-up call."""
+        check(lib().rtbhip_chain_upload(self._handle(), -1 if device is None else int(getattr(device, "index", device) or 0)))
+        return self
+
     @property
     def q_width(self):
         """Columns of a q row: max(jindex)+1, or what was assigned -- a branch of a tree robot reads the robot-wide q
@@ -356,6 +364,7 @@ class ETS:
             q2 = q2.contiguous()
             if q2.shape[1] != qw:
                 raise ValueError("q has %d columns, chain needs %d" % (q2.shape[1], qw))
+            _lib.note_device(q2)
             return q2, single, True
         a = as_numeric(q)
         if a.ndim == 0:
@@ -587,6 +596,7 @@ class ETS:
         tm = is_torch(Tep) and Tep.is_cuda
         if tm:
             Tq = Tep.reshape(-1, 4, 4).contiguous()
+            _lib.note_device(Tq)
             single = Tep.dim() == 2
         else:
             if hasattr(Tep, "A") and not isinstance(Tep, np.ndarray):
@@ -626,17 +636,17 @@ class ETS:
             qo = np.empty((N, n)); ok = np.empty(N, np.int32); it = np.empty(N, np.int32)
             se = np.empty(N, np.int32); E = np.empty(N)
         we = small(mask, 6)
-        kq, km, ps, pi = nullspace if nullspace is not None else (0.0, 0.0, 0.1, 0.3)
+        kq, km, ps, pi = nullspace if nullspace is not None else (0.0, 0.0, 0.1, None)
         if qp is not None:
             kj, ks = qp
             check(lib().rtbhip_ik_qp(self._handle(), self._ptr(Tq, tm), N, self._ptr(q0p, tm), int(ilimit), int(slimit), float(tol),
                                      int(bool(joint_limits)), host_ptr(we), int(seed) & 0xFFFFFFFFFFFFFFFF, float(kj), float(ks), float(kq),
-                                     float(km), float(ps), float(pi), self._ptr(qo, tm), self._ptr(ok, tm), self._ptr(it, tm),
+                                     float(km), float(ps), host_ptr(pi), self._ptr(qo, tm), self._ptr(ok, tm), self._ptr(it, tm),
                                      self._ptr(se, tm), self._ptr(E, tm), MEM_DEVICE if tm else MEM_HOST, self._stream(tm)))
             return single, qo, ok, it, se, E
         check(lib().rtbhip_ik_lm_nullspace(self._handle(), self._ptr(Tq, tm), N, self._ptr(q0p, tm), int(ilimit), int(slimit),
                                            float(tol), int(bool(joint_limits)), host_ptr(we), float(k), int(method), int(flavour),
-                                           int(seed) & 0xFFFFFFFFFFFFFFFF, float(kq), float(km), float(ps), float(pi),
+                                           int(seed) & 0xFFFFFFFFFFFFFFFF, float(kq), float(km), float(ps), host_ptr(pi),
                                            self._ptr(qo, tm), self._ptr(ok, tm), self._ptr(it, tm),
                                            self._ptr(se, tm), self._ptr(E, tm), MEM_DEVICE if tm else MEM_HOST, self._stream(tm)))
         return single, qo, ok, it, se, E
@@ -679,6 +689,7 @@ class ETS:
         IK_LM.solve/_solve/step robot/IK.py:174-367,994-1017): E is tested after the step and q is
         wrapped with Python's %.  kq / km / ps / pi: the null-space motion of robot/IK.py:507-576 (joint-limit
         avoidance and manipulability maximisation; as in the reference it acts only when kq > 0)."""
+        self._no_extra("ikine_LM", kwargs)
         single, q, ok, it, se, E = self._ik(Tep, q0, ilimit, slimit, tol, mask, joint_limits, k, method, 1,
                                             0 if seed is None else seed, self._nullspace(kq, km, ps, pi))
         if is_torch(q):
@@ -693,16 +704,18 @@ class ETS:
                           reason="" if allok else "iteration and search limit reached",
                           each={"success": ok.astype(bool), "iterations": it, "searches": se, "residual": E})
 
-    @staticmethod
-    def _nullspace(kq, km, ps, pi):
-        if np.ndim(pi) != 0:
-            raise NotImplementedError("a per-joint influence distance pi is not offered; pass a scalar")
-        return (float(kq), float(km), float(ps), float(pi))
+    def _nullspace(self, kq, km, ps, pi):
+        """(kq, km, ps, pi[n]): the influence distance is a scalar or one value per joint (robot/IK.py:519-520, :1441-1442)."""
+        pv = np.asarray(pi.detach().cpu().numpy() if is_torch(pi) else pi, dtype=np.float64).reshape(-1)
+        if pv.size == 1:
+            pv = np.full(max(1, self.n), float(pv[0]))
+        if pv.size != self.n:
+            raise ValueError("pi must be a scalar or one influence distance per joint (%d)" % self.n)
+        return (float(kq), float(km), float(ps), np.ascontiguousarray(pv))
 
     def _ikine_pinv(self, name, Tep, q0, ilimit, slimit, tol, mask, joint_limits, seed, pinv, kq, km, ps=0.0, pi=0.3, qp=None):
         if qp is None and not pinv and self.n != 6:
-            raise ValueError("%s: a %d-joint chain needs pinv=True (numpy.linalg.inv of a 6x%d Jacobian is undefined)"
-                             % (name, self.n, self.n))
+            return self._ikine_no_inverse(Tep, q0, slimit, seed)
         single, q, ok, it, se, E = self._ik(Tep, q0, ilimit, slimit, tol, mask, joint_limits, 0.0, name, 1,
                                             0 if seed is None else seed, self._nullspace(kq, km, ps, pi), qp=qp)
         if is_torch(q):
@@ -717,16 +730,54 @@ class ETS:
                           reason="" if allok else "iteration and search limit reached",
                           each={"success": ok.astype(bool), "iterations": it, "searches": se, "residual": E})
 
+    def _ikine_no_inverse(self, Tep, q0, slimit, seed):
+        """ikine_NR / ikine_GN with pinv=False on a chain whose Jacobian is not square: in the reference numpy.linalg.inv raises
+        LinAlgError in the FIRST step of every search, which the solver loop catches (robot/IK.py:317-323: "abandon search and try
+        again"), so after slimit searches of one counted iteration each it returns a failed IKSolution holding the last start
+        vector, residual 0.0 and the LinAlgError count in `reason` (:349-367).  Nothing is computed in the reference and nothing is
+        launched here; the start vectors are this backend's restart draws (rtbhip_ik_restart)."""
+        tm = is_torch(Tep)
+        a = Tep.detach().cpu().numpy() if tm else (Tep.A if hasattr(Tep, "A") and not isinstance(Tep, np.ndarray) else np.asarray(Tep))
+        if a.shape[-2:] != (4, 4):
+            raise ValueError("Tep must be a 4x4 SE3 matrix")
+        single = a.ndim == 2
+        N = 1 if single else a.shape[0]
+        slimit = int(slimit)
+        n = self.n
+        q0a = None if q0 is None else as_numeric(q0.detach().cpu().numpy() if is_torch(q0) else q0, "q0").reshape(-1, n)
+        q = np.empty((N, n))
+        for t in range(N):
+            if q0a is not None and slimit == 1:
+                q[t] = q0a[min(t, q0a.shape[0] - 1)]
+            else:
+                q[t] = self.ik_restart(0 if seed is None else seed, t, slimit - 1)
+        reason = "iteration and search limit reached, %d numpy.LinAlgError encountered" % slimit
+        if single:
+            return IKSolution(q=q[0], success=False, iterations=slimit, searches=slimit, residual=0.0, reason=reason)
+        z = np.zeros(N)
+        return IKSolution(q=q, success=False, iterations=slimit * N, searches=slimit * N, residual=0.0, reason=reason,
+                          each={"success": np.zeros(N, bool), "iterations": np.full(N, slimit, np.int32), "searches": np.full(N, slimit, np.int32), "residual": z})
+
+    @staticmethod
+    def _no_extra(name, kwargs):
+        """The reference forwards **kwargs to the solver class (robot/IK.py: IK_LM.__init__ :860-885, IK_NR :673-697, IK_GN :1113-1137,
+        IK_QP :1313-...), which hands them to IKSolver.__init__ (:149) -- and that takes named arguments only: an unknown keyword is
+        a TypeError there; it is one here."""
+        if kwargs:
+            raise TypeError("%s() got an unexpected keyword argument '%s'" % (name, sorted(kwargs)[0]))
+
     def ikine_NR(self, Tep, q0=None, ilimit=30, slimit=100, tol=1e-6, mask=None, joint_limits=True, seed=None,
                  pinv=False, kq=0.0, km=0.0, ps=0.0, pi=0.3, **kwargs):
         """The Python Newton-Raphson solver (reference ETS.ikine_NR robot/ETS.py:2639-2776 -> IK_NR robot/IK.py:579-763):
         q += pinv(J) e inside the Python solver's loop semantics (flavour 1)."""
+        self._no_extra("ikine_NR", kwargs)
         return self._ikine_pinv("nr", Tep, q0, ilimit, slimit, tol, mask, joint_limits, seed, pinv, kq, km, ps, pi)
 
     def ikine_GN(self, Tep, q0=None, ilimit=30, slimit=100, tol=1e-6, mask=None, joint_limits=True, seed=None,
                  pinv=False, kq=0.0, km=0.0, ps=0.0, pi=0.3, **kwargs):
         """The Python Gauss-Newton solver (reference ETS.ikine_GN robot/ETS.py:2778-2915 -> IK_GN robot/IK.py:1020-1220;
         its step is the same pinv(J) e)."""
+        self._no_extra("ikine_GN", kwargs)
         return self._ikine_pinv("nr", Tep, q0, ilimit, slimit, tol, mask, joint_limits, seed, pinv, kq, km, ps, pi)
 
     def ikine_QP(self, Tep, q0=None, ilimit=30, slimit=100, tol=1e-6, mask=None, joint_limits=True, seed=None,
@@ -736,6 +787,7 @@ class ETS:
         kj/2 |dq|^2 + ks/(2 sum|e|) |slack|^2 - jacobm.dq/km subject to J dq + slack = e and, when kq > 0, to one velocity-damper
         row per joint inside the influence distance pi of a limit; solved per lane on the device (closed form without rows, a
         primal-dual active set with them: csrc/ik_device.h) -- no qpsolvers dependency.  km > 0 / kq > 0 need 6..12 joints."""
+        self._no_extra("ikine_QP", kwargs)
         return self._ikine_pinv("qp", Tep, q0, ilimit, slimit, tol, mask, joint_limits, seed, True, kq, km, ps, pi, qp=(kj, ks))
 
     def ik_restart(self, seed, target, search):

@@ -26,6 +26,7 @@ def fleet_fkine_jacob(chains, qs, frame=0):
         if tm:
             import torch
             q2 = q.reshape(-1, ch.q_width).contiguous()
+            _lib.note_device(q2)
             T = torch.empty((q2.shape[0], 4, 4), dtype=torch.float64, device=q2.device)
             J = torch.empty((q2.shape[0], 6, ch.n), dtype=torch.float64, device=q2.device)
             qp[i], Tp[i], Jp[i] = q2.data_ptr(), T.data_ptr(), J.data_ptr()

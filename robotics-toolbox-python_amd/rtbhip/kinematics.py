@@ -40,12 +40,19 @@ class RobotKinematics:
         self.__dict__.pop("_path_cache", None)
 
     def _tool(self, tool):
-        return self.tool if tool is None else tool
+        return self._kin_tool() if tool is None else tool
+
+    def _kin_base(self):
+        """The base transform fkine applies (None: identity).  DHRobot overrides both hooks: its ets() already holds base and tool."""
+        return self.base
+
+    def _kin_tool(self):
+        return self.tool
 
     # ------------------------------------------------------------ forward / differential kinematics
     def fkine(self, q, end=None, start=None, tool=None, include_base=True):
         """(4,4) or (N,4,4): RobotKinematics.py:28-97 (the reference wraps the same array in spatialmath.SE3)."""
-        return self._path(start, end).fkine(q, base=self.base, tool=self._tool(tool), include_base=include_base)
+        return self._path(start, end).fkine(q, base=self._kin_base(), tool=self._tool(tool), include_base=include_base)
 
     def jacob0(self, q, end=None, start=None, tool=None):
         return self._path(start, end).jacob0(q, tool=self._tool(tool))
@@ -60,7 +67,7 @@ class RobotKinematics:
         return self._path(start, end).hessiane(q, Je=Je, tool=self._tool(tool))
 
     def partial_fkine0(self, q, n=3, end=None, start=None):
-        return self._path(start, end).partial_fkine0(q, n=n, tool=self.tool)
+        return self._path(start, end).partial_fkine0(q, n=n, tool=self._kin_tool())
 
     def jacob0_analytical(self, q, representation="rpy/xyz", end=None, start=None, tool=None):
         return self._path(start, end).jacob0_analytical(q, representation=representation, tool=self._tool(tool))
@@ -70,17 +77,17 @@ class RobotKinematics:
         and is not offered on the device path."""
         if J is not None:
             raise NotImplementedError("manipulability(J=...) is not offered: pass q (the Jacobian never leaves the registers)")
-        return self._path(start, end).manipulability(q, method=method, axes=axes, tool=self.tool)
+        return self._path(start, end).manipulability(q, method=method, axes=axes, tool=self._kin_tool())
 
     def jacobm(self, q=None, J=None, H=None, end=None, start=None, axes="all"):
         """robot/Robot.py:1101-1235."""
         if J is not None or H is not None:
             raise NotImplementedError("jacobm(J=..., H=...) is not offered: pass q")
-        return self._path(start, end).jacobm(q, axes=axes, tool=self.tool)
+        return self._path(start, end).jacobm(q, axes=axes, tool=self._kin_tool())
 
     def jacob0_dot(self, q, qd, J0=None, representation=None):
         """robot/Robot.py:964-1098 (no start / end there either)."""
-        return self._path(None, None).jacob0_dot(q, qd, J0=J0, representation=representation, tool=self.tool)
+        return self._path(None, None).jacob0_dot(q, qd, J0=J0, representation=representation, tool=self._kin_tool())
 
     # ------------------------------------------------------------ inverse kinematics
     def ik_LM(self, Tep, end=None, start=None, q0=None, ilimit=30, slimit=100, tol=1e-6, mask=None, joint_limits=True, k=1.0,

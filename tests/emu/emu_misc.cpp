@@ -1,0 +1,175 @@
+// tests/emu/emu_misc.cpp -- TEST INFRASTRUCTURE: differential-kinematics consumers, link frames, partial_fkine0, tree RNE replayed on the CPU.
+#include "emu_common.h"
+
+template <int NJ>
+static void diff_run(const KinParams &kp, const DevChain &cv, int mode, int axes, const double *q, const double *qd, int64_t N, double *out)
+{
+    for (int64_t s = 0; s < N; ++s) {
+        Pose P;
+        double jac[6 * NJ];
+        reg_compute<NJ, true>(kp, cv, q, s, P, jac);
+        if (mode == 0) {
+            double v[NJ], jd[6 * NJ];
+            for (int j = 0; j < NJ; ++j) v[j] = qd[s * kp.qw + jm_jq(cv.jmeta[j])];
+            jacob_dot<NJ>(jac, v, jd);
+            for (int k = 0; k < 6 * NJ; ++k) out[s * 6 * NJ + k] = jd[k];
+        } else if (mode == 3) {
+            double ja[6 * NJ];
+            jacob_analytical<NJ>(P, jac, axes, ja);
+            for (int k = 0; k < 6 * NJ; ++k) out[s * 6 * NJ + k] = ja[k];
+        } else if (mode == 4) {
+            double qv[NJ], v[NJ], jd[6 * NJ];
+            for (int j = 0; j < NJ; ++j) { qv[j] = q[s * kp.qw + jm_jq(cv.jmeta[j])]; v[j] = qd[s * kp.qw + jm_jq(cv.jmeta[j])]; }
+            jacob_analytical_dot<NJ>(cv, kp.tail, qv, v, axes, jd);
+            for (int k = 0; k < 6 * NJ; ++k) out[s * 6 * NJ + k] = jd[k];
+        } else if (mode == 1) {
+            const int method = (axes >> 8) & 3;
+            out[s] = method == 0 ? manipulability_yoshikawa<NJ>(jac, axes & 63) : manipulability_singular<NJ>(jac, axes & 63, method);
+        } else {
+            double jm[NJ];
+            jacobm<NJ>(jac, axes, jm);
+            for (int k = 0; k < NJ; ++k) out[s * NJ + k] = jm[k];
+        }
+    }
+}
+extern "C" int emu_diff(rtbhip_chain_t h, int mode, int axes, const double *q, const double *qd, int64_t N,
+                        const double *tool16, int frame, double *out)
+{
+    const std::shared_ptr<Chain> c_owner = chain_from_handle(h);
+    Chain *c = c_owner.get();
+    if (!c || c->n < 1 || c->n > 16) return -1;
+    KinParams kp;
+    kp.n = c->n; kp.qw = c->q_width; kp.stride = kin_stride(c->n); kp.frame = frame; kp.N = N; kp.pad = 0; kp.has_base = 0;
+    Affine t = aff16(tool16);
+    chain_tail(c, t, kp.tail);
+    const DevChain cv = chain_host_view(c);
+    switch (c->n) {
+    case 1: diff_run<1>(kp, cv, mode, axes, q, qd, N, out); break;
+    case 2: diff_run<2>(kp, cv, mode, axes, q, qd, N, out); break;
+    case 3: diff_run<3>(kp, cv, mode, axes, q, qd, N, out); break;
+    case 4: diff_run<4>(kp, cv, mode, axes, q, qd, N, out); break;
+    case 5: diff_run<5>(kp, cv, mode, axes, q, qd, N, out); break;
+    case 6: diff_run<6>(kp, cv, mode, axes, q, qd, N, out); break;
+    case 7: diff_run<7>(kp, cv, mode, axes, q, qd, N, out); break;
+    case 8: diff_run<8>(kp, cv, mode, axes, q, qd, N, out); break;
+    case 9: diff_run<9>(kp, cv, mode, axes, q, qd, N, out); break;
+    case 10: diff_run<10>(kp, cv, mode, axes, q, qd, N, out); break;
+    case 11: diff_run<11>(kp, cv, mode, axes, q, qd, N, out); break;
+    case 12: diff_run<12>(kp, cv, mode, axes, q, qd, N, out); break;
+    case 13: diff_run<13>(kp, cv, mode, axes, q, qd, N, out); break;
+    case 14: diff_run<14>(kp, cv, mode, axes, q, qd, N, out); break;
+    case 15: diff_run<15>(kp, cv, mode, axes, q, qd, N, out); break;
+    default: diff_run<16>(kp, cv, mode, axes, q, qd, N, out); break;
+    }
+    return 0;
+}
+
+// fkine_all: compile_frames (chain.cpp) + frames_walk (frames_device.h) on the CPU
+extern "C" int emu_link_frames(rtbhip_chain_t h, const double *q, int64_t N, const double *base16, const int32_t *marks, int nmarks, double *out)
+{
+    const std::shared_ptr<Chain> c_owner = chain_from_handle(h);
+    Chain *c = c_owner.get();
+    if (!c) return -1;
+    FrameTable ft;
+    if (compile_frames(c, marks, nmarks, &ft) != RTBHIP_OK) return -2;
+    Affine b = aff16(base16);
+    ft.has_base = b.used;
+    for (int i = 0; i < 12; i++) ft.base[i] = b.v[i];
+    const DevChain cv = chain_host_view(c);
+    for (int64_t s = 0; s < N; ++s) {
+        const double *row = q + s * c->q_width;
+        double *dst = out + s * (int64_t)nmarks * 16;
+        frames_walk(cv, c->n, ft, [&](int k) { return row[k]; }, [&](int m, const Pose &P) {
+            pose_store16(P, [&](int k, double v) { dst[m * 16 + k] = v; });
+        });
+    }
+    return 0;
+}
+
+// ETS.partial_fkine0: the host plan + the per-column device function of partial_device.h, every column of
+// every order replayed on the CPU from the emulated Jacobian and Hessian
+extern "C" int emu_partial(rtbhip_chain_t h, const double *q, int64_t N, const double *tool16, int order, double *out)
+{
+    const std::shared_ptr<Chain> c_owner = chain_from_handle(h);
+    Chain *c = c_owner.get();
+    if (!c || order < 3 || order > kPartialMaxOrder) return -1;
+    const int n = c->n;
+    std::vector<std::vector<double>> lower(order - 1);
+    for (int a = 1; a < order; ++a) lower[a - 1].assign((size_t)N * partial_size(n, a), 0.0);
+    if (emu_kin(h, q, N, nullptr, tool16, 0, nullptr, lower[0].data(), lower[1].data(), 1) != 0) return -1;
+    auto src = [&](int o, int64_t cfg, int off) -> double { return lower[o - 1][(size_t)cfg * partial_size(n, o) + off]; };
+    for (int a = 3; a <= order; ++a) {
+        PartialPlan plan;
+        partial_plan(n, a, &plan);
+        plan.N = N;
+        double *dst = a == order ? out : lower[a - 1].data();
+        for (int64_t cfg = 0; cfg < N; ++cfg)
+            for (uint32_t col = 0; col < (uint32_t)plan.cols; ++col) {
+                double *o = dst + cfg * partial_size(n, a) + (col / n) * 6 * n + col % n;      // (.., 6, n) block col / n, column col % n
+                auto put = [&](int r, double v) { o[r * n] = v; };
+                if (a == 3 && !(getenv("EMU_PARTIAL3") && atoi(getenv("EMU_PARTIAL3")) == 0)) {
+                    // order 3 as k_partial3 runs it: the written-out column on this configuration's Jacobian and Hessian
+                    const double *Jc = lower[0].data() + (size_t)cfg * 6 * n, *Hc = lower[1].data() + (size_t)cfg * 6 * n * n;
+                    const uint32_t d0 = col % n, d1 = (col / n) % n, d2 = col / (n * n);
+                    partial3_column(n, [&](uint32_t off) -> double { return Jc[off]; }, [&](uint32_t off) -> double { return Hc[off]; }, d0, d1, d2, put);
+                    continue;
+                }
+                switch (a) {
+                case 3: partial_column<3>(plan, src, cfg, col, put); break;
+                case 4: partial_column<4>(plan, src, cfg, col, put); break;
+                case 5: partial_column<5>(plan, src, cfg, col, put); break;
+                default: partial_column<6>(plan, src, cfg, col, put); break;
+                }
+            }
+    }
+    return 0;
+}
+
+// ETS-robot inverse dynamics: tree.cpp's compiled table + tree_device.h's per-lane recursion on the CPU
+template <int NG>
+static void tree_run(const Tree *t, const double *q, const double *qd, const double *qdd, int64_t N, V3 g, double *tau)
+{
+    std::vector<double> slots((size_t)kTreeSlotDoubles * std::max(1, t->nslots));
+    for (int64_t s = 0; s < N; ++s) {
+        const double *a = q + s * NG, *b = qd + s * NG, *c = qdd + s * NG;
+        double *o = tau + s * NG;
+        tree_rne_lane<NG>(t->groups.data(), t->nslots, g, [&](int k) { return a[k]; }, [&](int k) { return b[k]; },
+                          [&](int k) { return c[k]; }, [&](int k, double v) { o[k] = v; },
+                          [&](int i) -> double & { return slots[i]; });
+    }
+}
+extern "C" int emu_tree_rne(const rtbhip_tree_group *groups, int ng, const double *q, const double *qd, const double *qdd,
+                            int64_t N, const double *grav3, double *tau)
+{
+    Tree t;
+    if (compile_tree(groups, ng, &t) != RTBHIP_OK) return -1;
+    V3 g = v3(grav3[0], grav3[1], grav3[2]);
+    switch (ng) {
+    case 1: tree_run<1>(&t, q, qd, qdd, N, g, tau); break;
+    case 2: tree_run<2>(&t, q, qd, qdd, N, g, tau); break;
+    case 3: tree_run<3>(&t, q, qd, qdd, N, g, tau); break;
+    case 4: tree_run<4>(&t, q, qd, qdd, N, g, tau); break;
+    case 5: tree_run<5>(&t, q, qd, qdd, N, g, tau); break;
+    case 6: tree_run<6>(&t, q, qd, qdd, N, g, tau); break;
+    case 7: tree_run<7>(&t, q, qd, qdd, N, g, tau); break;
+    case 8: tree_run<8>(&t, q, qd, qdd, N, g, tau); break;
+    case 9: tree_run<9>(&t, q, qd, qdd, N, g, tau); break;
+    case 10: tree_run<10>(&t, q, qd, qdd, N, g, tau); break;
+    case 11: tree_run<11>(&t, q, qd, qdd, N, g, tau); break;
+    case 12: tree_run<12>(&t, q, qd, qdd, N, g, tau); break;
+    case 13: tree_run<13>(&t, q, qd, qdd, N, g, tau); break;
+    case 14: tree_run<14>(&t, q, qd, qdd, N, g, tau); break;
+    case 15: tree_run<15>(&t, q, qd, qdd, N, g, tau); break;
+    case 16: tree_run<16>(&t, q, qd, qdd, N, g, tau); break;
+    case 17: tree_run<17>(&t, q, qd, qdd, N, g, tau); break;
+    case 18: tree_run<18>(&t, q, qd, qdd, N, g, tau); break;
+    case 19: tree_run<19>(&t, q, qd, qdd, N, g, tau); break;
+    case 20: tree_run<20>(&t, q, qd, qdd, N, g, tau); break;
+    case 21: tree_run<21>(&t, q, qd, qdd, N, g, tau); break;
+    case 22: tree_run<22>(&t, q, qd, qdd, N, g, tau); break;
+    case 23: tree_run<23>(&t, q, qd, qdd, N, g, tau); break;
+    case 24: tree_run<24>(&t, q, qd, qdd, N, g, tau); break;
+    default: return -2;
+    }
+    return 0;
+}

@@ -1,5 +1,5 @@
 """tests/emu_harness.py -- TEST INFRASTRUCTURE.  Python front-end of tests/emu/libemu.so, which runs
-the kernels' own __host__ __device__ phase functions lane by lane on the CPU (see tests/emu/emu.cpp).
+the kernels' own __host__ __device__ phase functions lane by lane on the CPU (see tests/emu/emu_common.h).
 Used by the `-m "not gpu"` suite to check kernel-body logic against the oracle where no GPU exists."""
 import ctypes as C
 import os
@@ -11,7 +11,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "robotics-toolbox-python_amd")
 EMU_SO = os.path.join(ROOT, "tests", "emu", "libemu.so")
-SRCS = ["tests/emu/emu.cpp"] + ["robotics-toolbox-python_amd/csrc/" + f for f in
+SRCS = ["tests/emu/" + f for f in ("emu_kin.cpp", "emu_ik_seq.cpp", "emu_ik_wave_a.cpp", "emu_ik_wave_b.cpp", "emu_ik_wave_c.cpp", "emu_rne.cpp", "emu_dyn_a.cpp", "emu_dyn_b.cpp", "emu_dyn_c.cpp", "emu_dyn_d.cpp", "emu_dyn_e.cpp", "emu_dyn_f.cpp",
+                                   "emu_misc.cpp")] + ["robotics-toolbox-python_amd/csrc/" + f for f in
                                 ("api.cpp", "chain.cpp", "tree.cpp", "hostpipe.cpp", "kin_kernels.hip", "rne_kernels.hip", "ik_kernels.hip", "dyn_kernels.hip",
                                  "tree_kernels.hip", "partial_kernels.hip", "frames_kernels.hip")]
 _vp, _u64, _i64, _i32 = C.c_void_p, C.c_uint64, C.c_int64, C.c_int32
@@ -26,26 +27,49 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _deps_newer(obj, dep_file):
+    if not os.path.exists(obj) or not os.path.exists(dep_file):
+        return True
+    t = os.path.getmtime(obj)
+    txt = open(dep_file).read().replace("\\\n", " ")
+    deps = txt.split(":", 1)[1].split() if ":" in txt else []
+    return any((not os.path.exists(d)) or os.path.getmtime(d) > t for d in deps if not d.startswith("/opt/") and not d.startswith("/usr/"))
+
+
 def build():
-    """One object per source, compiled in parallel (build/emu is git-ignored), then linked."""
+    """tests/emu/*.cpp -- the replay drivers, which only instantiate the kernels' __host__ __device__ bodies -- are compiled HOST side only
+    (--cuda-host-only), one object per source in parallel (build/emu is git-ignored; an object is rebuilt when a file it includes
+    changed); the library's own sources (api.cpp, chain.cpp, the kernel files with their launchers ...) are not compiled a second
+    time: the objects of the product build (build/obj, __graft_entry__.build_lib) are linked in as they are."""
     from concurrent.futures import ThreadPoolExecutor
+    import sys
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.build_lib()
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     objdir = os.path.join(ROOT, "build", "emu")
     os.makedirs(objdir, exist_ok=True)
-    flags = ["--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-x", "hip", "-w", "-I" + os.path.join(ROOT, "include")]
-    hdrs = [os.path.join(PKG, "csrc", f) for f in os.listdir(os.path.join(PKG, "csrc")) if f.endswith(".h")]
-    newest_hdr = max(os.path.getmtime(h) for h in hdrs + [os.path.join(ROOT, "include", "rtbhip.h")])
+    flags = ["--offload-arch=gfx950", "--cuda-host-only", "-O2", "-std=c++17", "-fPIC", "-x", "hip", "-w", "-I" + os.path.join(ROOT, "include")]
 
     def one(src):
         src = os.path.join(ROOT, src)
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        if not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_hdr):
-            subprocess.check_call([hipcc] + flags + ["-c", src, "-o", obj])
+        dep = obj + ".d"
+        if _deps_newer(obj, dep):
+            # the 13..16-joint dynamics bodies are the long poles of this build: -O1 for them (the replay's arithmetic is the same:
+            # no fast-math either way, contraction is decided per statement by the front end)
+            fl = [f if f != "-O2" else "-O1" for f in flags] if os.path.basename(src) in ("emu_dyn_d.cpp", "emu_dyn_e.cpp", "emu_dyn_f.cpp") else flags
+            subprocess.check_call([hipcc] + fl + ["-MD", "-MF", dep, "-c", src, "-o", obj])
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
-        objs = list(ex.map(one, SRCS))
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", EMU_SO])
+        objs = list(ex.map(one, [x for x in SRCS if x.startswith("tests/emu/")]))
+    prod = [os.path.join(ROOT, "build", "obj", os.path.basename(x) + ".o") for x in SRCS if not x.startswith("tests/emu/")]
+    missing = [o for o in prod if not os.path.exists(o)]
+    if missing:                                  # a prebuilt library travelled without its objects: compile them
+        g.build_lib(force=True)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + prod + ["-o", EMU_SO])
 
 
 def lib():
@@ -299,7 +323,13 @@ def ik(ets, Tep, q0=None, ilimit=30, slimit=100, tol=1e-6, joint_limits=True, ma
 
 def ik_nullspace(kq=0.0, km=0.0, ps=0.0, pi=0.3):
     """Null-space terms for the following emu.ik calls (kq <= 0 switches them off again)."""
-    lib().emu_ik_nullspace(float(kq), float(km), float(ps), float(pi))
+    pv = np.asarray(pi, dtype=np.float64).reshape(-1)
+    lib().emu_ik_nullspace(float(kq), float(km), float(ps), float(pv[0]))
+    if pv.size > 1:                                  # one influence distance per joint (robot/IK.py:519-520)
+        pv = np.ascontiguousarray(pv)
+        fn = lib().emu_ik_nullspace_pi
+        fn.argtypes, fn.restype = [_vp, _i32], None
+        fn(_p(pv), pv.size)
 
 
 def ik_qp_ks(ks=1.0):

@@ -54,6 +54,9 @@ def rodrigues(axis, th):
     return np.eye(3) + math.sin(th) * K + (1 - math.cos(th)) * (K @ K)
 
 
+PI_ARRAY = np.array([0.3, 0.2, 0.4, 0.25, 0.3, 0.5, 0.35])
+
+
 def python_ik():
     """Fixtures from the reference's Python solvers and its compiled Angle_Axis (pins SURVEY rows a7 and a9)."""
     sys.path.insert(0, os.path.join(ROOT, "robotics-toolbox-python_amd"))
@@ -150,6 +153,9 @@ def python_ik():
     run("qp_kq", "IK_QP", Tn, q0n, 3, kj=0.01, ks=1.0, kq=1.0, ps=0.0, pi=0.3)
     run("qp_kq_km", "IK_QP", Tn, q0n, 3, kj=0.1, ks=1.0, kq=0.5, km=10.0, ps=0.05, pi=0.4)
     run("qp_kq_far", "IK_QP", Tep, None, 30, kj=0.01, ks=1.0, kq=2.0, ps=0.0, pi=0.3)
+    # an influence distance PER JOINT (IK.py:519-520 and :1441-1442 accept an ndarray)
+    run("lm_chan_ns_pi_array", "IK_LM", Tn, q0n, 3, method="chan", k=1.0, kq=0.1, km=0.1, ps=0.0, pi=PI_ARRAY)
+    run("qp_kq_pi_array", "IK_QP", Tn, q0n, 3, kj=0.01, ks=1.0, kq=1.0, ps=0.02, pi=PI_ARRAY)
     path = os.path.join(HERE, "ref_python_ik.npz")
     np.savez_compressed(path, **out)
     print("wrote ref_python_ik.npz with", len(out), "arrays,", os.path.getsize(path), "bytes")

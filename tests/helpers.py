@@ -22,6 +22,8 @@ def ref_python_ik():
     return dict(np.load(os.path.join(GOLD, "ref_python_ik.npz")))
 
 
+PI_ARRAY = np.array([0.3, 0.2, 0.4, 0.25, 0.3, 0.5, 0.35])     # one influence distance per joint (make_golden.py)
+
 # the cases of ref_python_ik.npz: key -> (problem set, first start from q0?, slimit, step, solver keywords)
 #   problem set "ik": random reachable targets (one unreachable), "ikn": near-solution / near-limit starts
 PY_IK_CASES = {
@@ -45,6 +47,8 @@ PY_IK_CASES = {
     "qp_kq": ("ikn", True, 3, "qp", dict(kj=0.01, ks=1.0, kq=1.0, ps=0.0, pi=0.3)),
     "qp_kq_km": ("ikn", True, 3, "qp", dict(kj=0.1, ks=1.0, kq=0.5, km=10.0, ps=0.05, pi=0.4)),
     "qp_kq_far": ("ik", False, 30, "qp", dict(kj=0.01, ks=1.0, kq=2.0, ps=0.0, pi=0.3)),
+    "lm_chan_ns_pi_array": ("ikn", True, 3, "lm", dict(method="chan", k=1.0, kq=0.1, km=0.1, ps=0.0, pi=PI_ARRAY)),
+    "qp_kq_pi_array": ("ikn", True, 3, "qp", dict(kj=0.01, ks=1.0, kq=1.0, ps=0.02, pi=PI_ARRAY)),
 }
 
 

@@ -44,6 +44,14 @@ def _check(key, q, ok, it, se, E):
         # undamped NR / GN searches from far-away random starts are chaotic: compare what the first search decides
         if step not in ("lm", "qp") and not (meta[i, 0] == 1 and meta[i, 2] == 1):
             continue
+        if meta[i, 0] == 0 and not np.all(np.isfinite(qref[i])):
+            # a search of the reference blew up numerically (q became NaN: numpy.linalg.inv of J^T W J + k E 1 with E -> 0 on a
+            # redundant arm, then "SVD did not converge" one step later, robot/IK.py:320-323).  WHICH iteration overflows is a
+            # property of the linear-algebra routine, not of the algorithm: the decision, the search count and the iteration
+            # count to within one per search are compared
+            assert (int(ok[i]), int(se[i])) == (0, int(meta[i, 2])) and abs(int(it[i]) - int(meta[i, 1])) <= int(meta[i, 2]), (key, i)
+            checked += 1
+            continue
         assert (int(ok[i]), int(it[i]), int(se[i])) == tuple(meta[i]), (key, i)
         if meta[i, 0]:
             nt.assert_allclose(q[i], qref[i], atol=1e-6)

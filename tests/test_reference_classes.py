@@ -94,8 +94,8 @@ def test_gpu_reference_classes_on_the_shim():
     nt.assert_allclose(one, pr.eval(Q1), atol=1e-10)
     base = pr.eval(Q[0]); tool = pr.eval(Q[1])
     nt.assert_allclose(pg.eval(Q[:33], base=base, tool=tool), pr.eval(Q[:33], base=base, tool=tool), atol=1e-10)
-    nt.assert_allclose(pg.eval(Q[:33], base=gpu.SE3(base), tool=gpu.SE3(tool), include_base=False),
-                       pr.eval(Q[:33], base=ref.SE3(base), tool=ref.SE3(tool), include_base=False), atol=1e-10)
+    nt.assert_allclose(pg.eval(Q[:33], base=base, tool=tool, include_base=False), pr.eval(Q[:33], base=base, tool=tool, include_base=False), atol=1e-10)
+    nt.assert_allclose(pg.eval(Q[:33], base=gpu.SE3(base), tool=gpu.SE3(tool)), pr.eval(Q[:33], base=base, tool=tool), atol=1e-10)   # the shim takes `.A`
     fk = pg.fkine(Q[:5])
     assert len(fk) == 5 and isinstance(fk, gpu.SE3)
     nt.assert_allclose(fk.A, Tr[:5], atol=1e-10)
