@@ -59,6 +59,23 @@ def ik_roofline(lm_iterations_per_s):
             "flops_per_iteration": IK_FLOPS_PER_ITERATION, "kernel": "k_ik<7,0>"}
 
 
+# VALU instructions per lane (= per configuration / triple) of the fp64-issue-bound secondary kernels, measured with SQ_INSTS_VALU / SQ_WAVES
+# (profiles/r03_a_sq_summary.txt).  Their roof is the fp64 vector rate, not HBM: each instruction is priced as one fp64 FMA (2 flop) -- an
+# upper bound of the arithmetic actually done (address, select and LDS-move instructions are in the count), i.e. the fraction is the share of
+# the chip's VALU issue slots the kernel fills.
+VALU_PER_UNIT = {"gravload": 833, "inertia": 3433, "coriolis": 10708, "accel": 3377, "tree_ur5": 1930, "jacob0_dot": 1692,
+                 "manipulability": 1512, "jacobm": 2732}
+
+
+def valu_roofline(key, units_per_s, kernel, hbm_bytes_per_unit):
+    instr = VALU_PER_UNIT[key]
+    tf = 2.0 * instr * units_per_s / 1e12
+    return {"bound": "fp64-valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
+            "valu_instructions_per_unit": instr, "counted_as": "one fp64 FMA (2 flop) per VALU instruction: issue-slot utilisation, an upper bound of the flops",
+            "source": "profiles/r03_a_sq_summary.txt (SQ_INSTS_VALU / SQ_WAVES)", "kernel": kernel,
+            "hbm_GBs": hbm_bytes_per_unit * units_per_s / 1e9}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="rne,ik,fleet,dyn,tree,kin,poe,graph")
@@ -153,11 +170,8 @@ def main():
                                   "inertia": "acceleration-only passes from link i on, mirrored (csrc/rne_device.h ACC)",
                                   "coriolis": "2 velocity passes per column, qd +- s e_k (polar form of the quadratic velocity torque; the reference runs 28 passes, and so do the waves that hold a row whose velocities span more than 2^16)",
                                   "accel": "1 full pass + 7 acceleration-only passes + LDL^T solve"}[name],
-                    # the HBM roof is the one these lines are priced against (algorithmic bytes / time); what actually limits the
-                    # kernels is fp64 issue at the occupancy their LDS tiles allow
-                    "roofline": {"bound": "hbm", "limited_by": "fp64 issue / LDS-set occupancy", "achieved": byts * N / (avg * 1e-3) / 1e9,
-                                 "peak": 8000.0, "unit": "GB/s", "frac": byts * N / (avg * 1e-3) / 1e9 / 8000.0,
-                                 "algorithmic_bytes_per_launch": byts * N}}
+                    "roofline": valu_roofline(name, N / (avg * 1e-3), {"gravload": "k_rne_atrest<7,MDH>", "inertia": "k_dyn<7,MDH,inertia>",
+                                                                        "coriolis": "k_dyn<7,MDH,coriolis>", "accel": "k_dyn<7,MDH,accel>"}[name], byts)}
             if not args.no_cpu and name == "inertia":
                 from oracle import ref_harness
                 if ref_harness.available():
@@ -184,10 +198,13 @@ def main():
                                ("hessian0", lambda: ets.hessian0(q), 56 + 2352), ("jacob0_dot", lambda: ets.jacob0_dot(q, qd), 112 + 336),
                                ("manipulability", lambda: ets.manipulability(q), 56 + 8), ("jacobm", lambda: ets.jacobm(q), 56 + 56)):
             avg, best = ev_time(fn, args.steps, 2)
+            if name in VALU_PER_UNIT:      # jacob0_dot / manipulability / jacobm: a few hundred bytes of I/O against 1.5-2.7 k instructions per configuration
+                rf = valu_roofline(name, N / (avg * 1e-3), "k_kin_diff<7,%s>" % name, byts)
+            else:
+                rf = {"bound": "hbm", "achieved": byts * N / (avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                      "frac": byts * N / (avg * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": byts * N}
             print(json.dumps({"metric": "configurations/sec (Panda %s)" % name, "value": N / (avg * 1e-3), "unit": "configurations/s", "n": N,
-                              "kernel_avg_ms": avg, "kernel_min_ms": best,
-                              "roofline": {"bound": "hbm", "achieved": byts * N / (avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                           "frac": byts * N / (avg * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": byts * N}}), flush=True)
+                              "kernel_avg_ms": avg, "kernel_min_ms": best, "roofline": rf}), flush=True)
 
         # fkine_all: the 8 link frames of the DH Panda (1 KB per configuration out)
         arm = rtbhip.models.DH.Panda()
@@ -206,11 +223,15 @@ def main():
         for _ in range(max(3, args.steps // 4)):
             t0 = time.perf_counter(); ets.partial_fkine0(qp, 3); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
         avg = 1e3 * sum(ts) / len(ts)
+        # device-side duration of the call's launches (the Jacobian + Hessian kernel that feeds it, then k_partial3): HIP events on the stream
+        dev_avg, dev_min = ev_time(lambda: ets.partial_fkine0(qp, 3), max(3, args.steps // 2), 1)
         byts = 56 + 8 * 7 * 7 * 6 * 7
         print(json.dumps({"metric": "configurations/sec (Panda partial_fkine0 n=3)", "value": Np / (avg * 1e-3), "unit": "configurations/s", "n": Np,
-                          "call_avg_ms": avg, "call_min_ms": 1e3 * min(ts),
-                          "roofline": {"bound": "hbm", "achieved": byts * Np / (avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                       "frac": byts * Np / (avg * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": byts * Np}}), flush=True)
+                          "call_avg_ms": avg, "call_min_ms": 1e3 * min(ts), "kernel_avg_ms": dev_avg, "kernel_min_ms": dev_min,
+                          "roofline": {"bound": "hbm", "achieved": byts * Np / (dev_avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                       "frac": byts * Np / (dev_avg * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": byts * Np,
+                                       "kernel": "k_kin_hess_tile<7,4> + k_partial3<3>: both launches of the call, device-side (the host-clock "
+                                                 "time of the whole call, temporaries included, is call_avg_ms)"}}), flush=True)
 
     if "poe" in what:
         # north_star's "SE(3) DH / product-of-exponentials chain": a 6-joint PoE robot (UR5-like screw axes), twists lowered by
@@ -283,8 +304,7 @@ def main():
         byts = 32 * er.n
         print(json.dumps({"metric": "triples/sec (URDF UR5 Robot.rne, %d link groups)" % er.n, "value": N / (avg * 1e-3), "unit": "triples/s",
                           "n": N, "kernel_avg_ms": avg, "kernel_min_ms": best,
-                          "roofline": {"bound": "fp64-valu", "achieved": byts * N / (avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                       "frac": byts * N / (avg * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": byts * N}}), flush=True)
+                          "roofline": valu_roofline("tree_ur5", N / (avg * 1e-3), "k_tree_rne<6>", byts)}), flush=True)
 
     if "ik" in what:
         N = args.n_ik
