@@ -305,6 +305,9 @@ int rtbhip_last_launch(int32_t *grid, int32_t *block, int32_t *lds_bytes);
 
 /* Tuning knobs for benchmarking (A/B of launch geometry / store paths); process-wide; unknown keys are ignored.  Results never
  * depend on them (every setting is covered by bit-equality tests); the defaults are the measured best.  IK scheduler:
+ *   "ik_flat" 0 | 1 | 2       flat schedule (search ranges cut into chunks, (target, chunk) items drawn from one counter by whichever wave has
+ *                             idle lanes): never / when the batch is resident at once (default) / always; "ik_flat_l0", "ik_flat_len": searches
+ *                             in a target's first / in every later chunk (4, 8)
  *   "ik_share" 0 | 1 | 2      cross-wave sharing of search ranges: never (default) / when the batch is resident at once / always
  *   "ik_donate_after" k       ... ranges are cut only from targets with k failed searches (default 3)
  *   "ik_phased" 0 | 1 | 2     phased schedule (first searches, then compacted work lists): never (default) / automatic / always

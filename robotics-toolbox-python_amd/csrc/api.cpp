@@ -844,6 +844,7 @@ int rtbhip_ik_restart(rtbhip_chain_t chain, uint64_t seed, int64_t target, int32
     return RTBHIP_OK;
 }
 
+static int g_rne_pszero = 1;      // rtbhip_tune("rne_pszero", 0): handles created afterwards do not take the p* = 0 shortcut (A/B; same values)
 int rtbhip_dyn_create(const double *L24, int32_t n, int32_t mdh, rtbhip_dyn_t *dyn)
 {
     if (!L24 || !dyn || n < 1) { set_error("dyn_create: bad argument"); return RTBHIP_EINVAL; }
@@ -868,6 +869,7 @@ int rtbhip_dyn_create(const double *L24, int32_t n, int32_t mdh, rtbhip_dyn_t *d
         k.flags = 0;
         if (k.rx == 0.0 && k.ry == 0.0 && k.rz == 0.0) k.flags |= kLinkRZero;
         if (k.I[1] == 0.0 && k.I[2] == 0.0 && k.I[3] == 0.0 && k.I[5] == 0.0 && k.I[6] == 0.0 && k.I[7] == 0.0) k.flags |= kLinkIDiag;
+        if (g_rne_pszero && k.sigma == 0 && k.a == 0.0 && k.d == 0.0) k.flags |= kLinkPsZero;      // p* = 0 (DH Panda links 2 and 6, Puma560 link 5 and 6)
     }
     uint64_t h = g_next.fetch_add(1);
     std::lock_guard<std::mutex> lk(g_reg_mu);
@@ -1103,6 +1105,7 @@ int rtbhip_tune(const char *key, int32_t value)
     rne_tune(key, value);
     ik_tune(key, value);
     partial_tune(key, value);
+    if (std::string(key) == "rne_pszero") g_rne_pszero = value != 0;
     hostpipe_tune(key, value);
     return RTBHIP_OK;
 }

@@ -41,6 +41,13 @@ struct IkDev {   // wave-uniform solver parameters (kernarg)
     double ks;                       // IK_QP (method 5): slack gain; its joint-velocity gain kj travels in `lambda`
     int64_t target0;                 // added to a target's row number where it keys the restart generator (rtbhip_ik_target_base):
                                      // a row block of a larger batch then draws what the whole batch would have drawn for those targets
+    // flat schedule (below, "one launch, every search range cut into chunks"): flat_chunks > 0 switches it on; then N above counts
+    // work items (flat_n targets x flat_chunks), item v = chunk v / flat_n of target v % flat_n
+    int32_t flat_chunks, flat_l0, flat_len;
+    uint32_t flat_n;
+    int32_t *flat_done;              // per target: index of the lowest chunk that has SUCCEEDED so far (kIkFlatNone: none yet); device memory
+    unsigned long long *stats;       // diagnostics (RTBHIP_IK_STATS): 4 words per wave -- loop iterations, scheduling passes, lane-iterations
+                                     // spent on a running search, work items started; NULL in normal runs
 };
 
 // ---------------------------------------------------------------- restart generator
@@ -611,6 +618,7 @@ struct IkWaveSharedT {
     int32_t it[64];                         // iterations accounted so far
     int16_t res[64];                        // 0 unresolved, 1 won (winner = b), 2 failed
     uint8_t list[64];                       // scratch: compacted slot list
+    uint8_t chunk[64];                      // flat schedule: chunk index of the slot's item (0 otherwise)
     uint16_t rec[64][kIkRing];              // per outstanding search: 1 finished | 2 ok | iterations << 2
     double Td[12][64];                      // per SLOT: the target pose (read by every lane working on the slot)
     double q[QR][64];                       // per LANE: the joint vector of that search
@@ -711,6 +719,8 @@ RTB_HD void ik_finalize(IkLane<NJ> &st, SH &sh, int lane, const PD &p, QL qlim, 
         if (st.status == kIkParkedLast)
             ik_emit<NJ>(st, ik_lds_q(sh, lane), p, qlim, sh.tgt[st.slot], sh.vix[st.slot], p.has_q0 != 0, false, sh.it[st.slot], q_out, success, iters, searches, residual);
         st.status = kIkIdle;
+    } else if (res == 3) {
+        st.status = kIkIdle;      // flat schedule: an EARLIER chunk of this target has succeeded on some other wave -- nothing of this item is needed
     } else if (st.s > sh.best[st.slot]) {
         st.status = kIkIdle;      // a lower-indexed search already succeeded: this one can never be reported
     }
@@ -912,6 +922,80 @@ RTB_HD void ik_merge_chain(int n, int64_t tgt, const int32_t *link, const double
     }
     for (int j = 0; j < n; ++j) q_out[tgt * n + j] = vq[r * n + j];
     success[tgt] = vok[r]; iters[tgt] = it; searches[tgt] = vse[r]; residual[tgt] = vE[r];
+}
+
+// ---------------------------------------------------------------- flat schedule: every search range cut into chunks, ONE launch
+// BASELINE config 3 (1e5 targets on 131072 lanes) has the whole batch resident at once, so a wave is stuck with the ~49 targets it
+// drew; the ~1 % that exhaust all `slimit` searches cost 40x the mean, and the two or three waves that drew four of them decide when
+// the kernel ends (lane-occupancy histogram, profiles/r03_*_ik_occupancy.txt: longest wave ~4x the mean).  Earlier attempts moved work
+// between waves AFTER the fact (cross-wave sharing: a hand-over protocol whose atomics cost what it saved) or in separate launches
+// (phased: three tails instead of one).  Here nothing is handed over: the search range of EVERY target is cut up front into chunks --
+// chunk 0 = its first flat_l0 searches, then flat_len each -- and the work items (target, chunk) are numbered CHUNK-MAJOR, all chunk-0
+// items first.  Waves draw item numbers from the one device-wide counter they already use for fresh targets, so the later chunks of
+// the hard targets are picked up by whichever waves have idle lanes -- all over the chip, as soon as those lanes exist.
+//   * `done[t]` holds the lowest chunk of target t that has succeeded.  An item (t, c) with done[t] < c is skipped when its number is
+//     drawn (one load per drawn number, 64 numbers per draw) and, if it is already running, dropped at its wave's next scheduling pass.
+//   * later-chunk items are speculation on top of the wave's own: a wave serves its own slots' next searches first and draws
+//     later-chunk numbers only for the lanes that are still idle after that.
+//   * every item writes its result row (item number); a merge kernel walks each target's rows in chunk order -- iterations add up, the
+//     first success or the last chunk supplies the answer -- so the reported (q, success, iterations, searches, residual) are exactly
+//     the sequential loops'.  (A row that is needed is always complete: an item is skipped or dropped only when an EARLIER chunk has
+//     succeeded, and then the merge stops before it.)
+constexpr int32_t kIkFlatNone = 0x7f7f7f7f;      // what hipMemsetAsync(0x7f) leaves
+struct IkFlatPlan { int chunks, l0, len; };
+template <class PD>
+RTB_HD IkFlatPlan ik_flat_plan(const PD &p, int l0, int len)
+{
+    IkFlatPlan f;
+    const int total = ik_s_last(p) - ik_s_first(p) + 1;
+    f.l0 = l0 < 1 ? 1 : (l0 > total ? total : l0);
+    f.len = len < 1 ? 1 : len;
+    f.chunks = 1 + (total - f.l0 + f.len - 1) / f.len;
+    return f;
+}
+// item v of the flat numbering -> (work item, chunk)
+template <class PD>
+RTB_HD IkWork ik_flat_item(const PD &p, uint32_t v, int *chunk)
+{
+    const uint32_t c = v / p.flat_n, t = v - c * p.flat_n;
+    const int s_first = ik_s_first(p), s_last = ik_s_last(p);
+    const int a = c == 0 ? s_first : s_first + p.flat_l0 + (int)(c - 1) * p.flat_len;
+    const int b = c == 0 ? s_first + p.flat_l0 - 1 : a + p.flat_len - 1;
+    IkWork w;
+    w.tgt = (int32_t)t; w.s0 = (int16_t)a; w.s1 = (int16_t)(b > s_last ? s_last : b);
+    *chunk = (int)c;
+    return w;
+}
+// is item v still worth starting?  (chunk 0 always is)
+template <class PD>
+RTB_HD bool ik_flat_live(const PD &p, uint32_t v)
+{
+    if (v < p.flat_n) return true;
+    const uint32_t c = v / p.flat_n, t = v - c * p.flat_n;
+    return ik_aload(p.flat_done + t) > (int32_t)c;
+}
+RTB_HD void ik_flat_publish(int32_t *done, uint32_t t, int c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __hip_atomic_fetch_min(done + t, (int32_t)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    if (c < done[t]) done[t] = c;
+#endif
+}
+// Merge of one target's rows, chunk by chunk (rows are item numbers: chunk c of target t is row c * N + t).
+RTB_HD void ik_merge_flat(int n, int chunks, int64_t N, int64_t t, const double *vq, const int32_t *vok, const int32_t *vit, const int32_t *vse,
+                          const double *vE, double *q_out, int32_t *success, int32_t *iters, int32_t *searches, double *residual)
+{
+    int it = 0;
+    for (int c = 0; c < chunks; ++c) {
+        const int64_t r = (int64_t)c * N + t;
+        it += vit[r];
+        if (vok[r] || c == chunks - 1) {
+            for (int j = 0; j < n; ++j) q_out[t * n + j] = vq[r * n + j];
+            success[t] = vok[r]; iters[t] = it; searches[t] = vse[r]; residual[t] = vE[r];
+            return;
+        }
+    }
 }
 
 // ---------------------------------------------------------------- phased schedule for batches small against the chip

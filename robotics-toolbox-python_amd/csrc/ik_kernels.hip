@@ -12,6 +12,9 @@
 // fp64 per iteration, 204 B of I/O per target): MFMA does not apply (7x7 normal equations per lane).
 #include "ik_device.h"
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 
 namespace rtbhip {
 
@@ -76,6 +79,9 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
     bool exhausted = false;          // wave-uniform: the global supply of fresh targets has run out
     bool drained = false;            // wave-uniform: the device-wide counter has passed N
     unsigned long long pool_next = 0, pool_end = 0;   // wave-uniform: targets reserved by this wave and not started yet
+    unsigned long long pool_live = 0;                 // flat schedule, wave-uniform: bit k = item pool_next + k was drawn, is still worth starting and has not been started
+    const bool flat = p.flat_chunks > 0;              // wave-uniform
+    unsigned long long st_iters = 0, st_passes = 0, st_lane = 0, st_items = 0;   // diagnostics (p.stats), wave-uniform
     bool first = true;
     unsigned tick = 0;
     const long long patience = ik_patience(p, s_last);    // watchdog budget (ik_device.h), the pass latency included
@@ -91,6 +97,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
         // hundred mostly scalar / LDS instructions, is amortised over more useful iterations
         if (first || ((tick++ & ka->p.pass_mask) == 0 && __any(st.fin != 0))) {
             first = false;
+            ++st_passes;
             const RTB_CONST IkDev &p = ka->p;      // shadows the by-value arguments for the whole pass
             const RTB_CONST double *qlim = (const RTB_CONST double *)ka->qlim;
             const double *Tep = ka->Tep, *q0 = ka->q0;
@@ -101,8 +108,17 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
             ik_report<NJ>(st, sh, residual, p, qlim, ik_lds_q(sh, lane));              // phase A
             __syncthreads();
             if ((busy >> lane) & 1ull) ik_account(lane, sh);                            // phase B
+            if (flat) {
+                // a later-chunk item whose target has meanwhile succeeded in an EARLIER chunk (on whichever wave) is dropped
+                const bool chk = ((busy >> lane) & 1ull) && sh.chunk[lane] > 0;
+                if (__any(chk)) {
+                    const int32_t d = chk ? ik_aload(p.flat_done + sh.tgt[lane]) : kIkFlatNone;
+                    if (chk && sh.res[lane] == 0 && d < (int32_t)sh.chunk[lane]) sh.res[lane] = 3;
+                }
+            }
             __syncthreads();
             ik_finalize<NJ>(st, sh, lane, p, qlim, q_out, success, iters, searches, residual);   // phase C
+            if (flat && ((busy >> lane) & 1ull) && sh.res[lane] == 1) ik_flat_publish(p.flat_done, sh.tgt[lane], sh.chunk[lane]);
             const unsigned long long freed = __ballot(((busy >> lane) & 1ull) && sh.res[lane] != 0);
             if (freed) quiet = 0;
             busy &= ~freed;
@@ -120,72 +136,113 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                 __syncthreads();
                 idle = __ballot(st.status == kIkIdle);
             }
-            if ((!exhausted || pend_item != kIkNoItem) && idle) {                       // phase D1: fresh targets
-                const unsigned long long freeslots = ~busy;
-                // free slots >= idle lanes (every busy slot keeps a lane); the per-pass cap spreads a batch
-                // smaller than the grid's lane count evenly over the waves
-                int nf = __popcll(idle);
-                int cap = p.fresh_cap;
-                if (ka->count) {                    // compacted list: its size is only known here
-                    const unsigned per_wave = ((unsigned)NN + gridDim.x - 1u) / gridDim.x;
-                    cap = per_wave < 1u ? 1 : (per_wave > 64u ? 64 : (int)per_wave);
+            // flat schedule, once the chunk-0 items are all out: the item numbers left are later chunks -- speculation for other waves' targets --
+            // so the wave's own next searches (D2) come first and numbers are drawn (D1) only for the lanes still idle after that
+            const bool late = flat && pool_next >= (unsigned long long)p.flat_n;
+            for (int step = 0; step < 2; ++step) {
+            if ((step == 0) != late) {
+                if ((!exhausted || pend_item != kIkNoItem) && idle) {                       // phase D1: fresh targets
+                    const unsigned long long freeslots = ~busy;
+                    // free slots >= idle lanes (every busy slot keeps a lane); the per-pass cap spreads a batch
+                    // smaller than the grid's lane count evenly over the waves
+                    int nf = __popcll(idle);
+                    int cap = p.fresh_cap;
+                    if (ka->count) {                    // compacted list: its size is only known here
+                        const unsigned per_wave = ((unsigned)NN + gridDim.x - 1u) / gridDim.x;
+                        cap = per_wave < 1u ? 1 : (per_wave > 64u ? 64 : (int)per_wave);
+                    }
+                    nf = nf > cap ? cap : nf;
+                    unsigned long long base = 0;
+                    long long nvalid = 0;
+                    int flat_off = 0;
+                    if (flat && !exhausted) {
+                        // flat schedule: while chunk-0 numbers are being drawn, exactly as many as this pass starts (nothing is hoarded: every
+                        // one of them is alive); afterwards 64 per draw, each lane looking at one (a later-chunk item whose target has already
+                        // succeeded is dead on arrival), and up to four draws per pass while draws come back with nothing alive
+                        if (late) nf = __popcll(idle);
+                        for (int round = 0; (round < 4 || busy == 0) && pool_live == 0 && !drained; ++round) {   // (a wave with nothing else to do keeps drawing)
+                            const unsigned long long want = pool_next < (unsigned long long)p.flat_n ? (unsigned long long)nf : 64ull;
+                            unsigned long long got = 0;
+                            if (lane == 0) got = atomicAdd(counter, want);
+                            const unsigned lo = __shfl((unsigned)(got & 0xffffffffu), 0);
+                            const unsigned hi = __shfl((unsigned)(got >> 32), 0);
+                            got = ((unsigned long long)hi << 32) | lo;
+                            pool_next = got < NN ? got : NN;
+                            if (got + want >= NN) drained = true;
+                            const unsigned long long id = got + (unsigned long long)lane;
+                            pool_live = __ballot((unsigned long long)lane < want && id < NN && ik_flat_live(p, (uint32_t)id));
+                        }
+                        nvalid = __popcll(pool_live);
+                        nvalid = nvalid > nf ? nf : nvalid;
+                        base = pool_next;
+                        // the r-th idle lane takes the r-th live number: offsets through the scratch list
+                        if ((pool_live >> lane) & 1ull) { const int k = ik_rank(pool_live, lane); if (k < nvalid) sh.list[k] = (uint8_t)lane; }
+                        __syncthreads();
+                        { const int r0 = ik_rank(idle, lane); flat_off = (((idle >> lane) & 1ull) && r0 < nvalid) ? (int)sh.list[r0] : 0; }
+                        __syncthreads();
+                        for (long long k = 0; k < nvalid; ++k) pool_live &= pool_live - 1ull;      // the nvalid lowest live numbers are taken
+                        if (drained && pool_live == 0) exhausted = true;
+                    } else if (!exhausted) {
+                    // targets are reserved from the device-wide counter in chunks and handed out from the wave's
+                    // own pool: the atomic's round trip (and its s_waitcnt) is paid once per chunk, not per pass
+                    if (pool_next == pool_end) {
+                        unsigned long long got = 0;
+                        const unsigned long long chunk = p.pool_chunk > 0 ? (unsigned long long)p.pool_chunk : (unsigned long long)nf;
+                        if (lane == 0) got = atomicAdd(counter, chunk);
+                        const unsigned lo = __shfl((unsigned)(got & 0xffffffffu), 0);
+                        const unsigned hi = __shfl((unsigned)(got >> 32), 0);
+                        got = ((unsigned long long)hi << 32) | lo;
+                        pool_next = got < NN ? got : NN;
+                        pool_end = got + chunk < NN ? got + chunk : NN;
+                        if (pool_end == NN) drained = true;      // the counter has passed N: this is the wave's last refill
+                    }
+                    base = pool_next;
+                    nvalid = (long long)(pool_end - pool_next);
+                    nvalid = nvalid > nf ? nf : nvalid;
+                    pool_next += (unsigned long long)nvalid;
+                    if (drained && pool_next == pool_end) exhausted = true;
+                    }
+                    IkWork pend = ik_unpack(pend_item);
+                    if (exhausted && pend_item != kIkNoItem) {
+                        // the range another wave cut off for this one (the row of its ticket): started like a fresh target
+                        base = (unsigned long long)ik_item_row(share_of(ka), p.N, (int)(blockIdx.x % kIkQueues), pend_tick);
+                        nvalid = 1;
+                        pend_item = kIkNoItem;
+                    }
+                    if ((freeslots >> lane) & 1ull) sh.list[ik_rank(freeslots, lane)] = lane;
+                    __syncthreads();
+                    const int r = ik_rank(idle, lane);
+                    int myslot = -1;
+                    if (((idle >> lane) & 1ull) && r < nvalid) {
+                        myslot = sh.list[r];
+                        const int64_t v = flat ? (int64_t)base + flat_off : (int64_t)base + r;
+                        IkWork w;
+                        int chunk = 0;
+                        if (flat) w = ik_flat_item(p, (uint32_t)v, &chunk);
+                        else if (sharing && v >= p.N) w = pend;
+                        else if (work) w = work[v];
+                        else { w.tgt = (int32_t)v; w.s0 = (int16_t)ik_s_first(p); w.s1 = (int16_t)ik_s_last(p); }
+                        ik_start_target<NJ>(st, sh, lane, p, qlim, myslot, v, w, Tep, q0);
+                        sh.chunk[myslot] = (uint8_t)chunk;
+                    }
+                    st_items += (unsigned long long)nvalid;
+                    busy |= __ballot(((freeslots >> lane) & 1ull) && ik_rank(freeslots, lane) < nvalid);
+                    __syncthreads();
+                    idle = __ballot(st.status == kIkIdle);
                 }
-                nf = nf > cap ? cap : nf;
-                unsigned long long base = 0;
-                long long nvalid = 0;
-                if (!exhausted) {
-                // targets are reserved from the device-wide counter in chunks and handed out from the wave's
-                // own pool: the atomic's round trip (and its s_waitcnt) is paid once per chunk, not per pass
-                if (pool_next == pool_end) {
-                    unsigned long long got = 0;
-                    const unsigned long long chunk = p.pool_chunk > 0 ? (unsigned long long)p.pool_chunk : (unsigned long long)nf;
-                    if (lane == 0) got = atomicAdd(counter, chunk);
-                    const unsigned lo = __shfl((unsigned)(got & 0xffffffffu), 0);
-                    const unsigned hi = __shfl((unsigned)(got >> 32), 0);
-                    got = ((unsigned long long)hi << 32) | lo;
-                    pool_next = got < NN ? got : NN;
-                    pool_end = got + chunk < NN ? got + chunk : NN;
-                    if (pool_end == NN) drained = true;      // the counter has passed N: this is the wave's last refill
+            } else {
+                if (idle && busy) {                                                         // phase D2: speculative searches
+                    if ((busy >> lane) & 1ull) sh.list[ik_rank(busy, lane)] = lane;
+                    __syncthreads();
+                    const int nb = __popcll(busy);
+                    int slot = 0, s = 0;
+                    const bool mine = ((idle >> lane) & 1ull) && ik_pick(sh, ik_rank(idle, lane), nb, __popcll(idle), p.spec_policy, ik_s_first(p), slot, s);
+                    __syncthreads();
+                    if (mine) ik_start_spec<NJ>(st, sh, lane, p, qlim, slot, s, Tep, q0);
+                    __syncthreads();
+                    idle = __ballot(st.status == kIkIdle);
                 }
-                base = pool_next;
-                nvalid = (long long)(pool_end - pool_next);
-                nvalid = nvalid > nf ? nf : nvalid;
-                pool_next += (unsigned long long)nvalid;
-                if (drained && pool_next == pool_end) exhausted = true;
-                }
-                IkWork pend = ik_unpack(pend_item);
-                if (exhausted && pend_item != kIkNoItem) {
-                    // the range another wave cut off for this one (the row of its ticket): started like a fresh target
-                    base = (unsigned long long)ik_item_row(share_of(ka), p.N, (int)(blockIdx.x % kIkQueues), pend_tick);
-                    nvalid = 1;
-                    pend_item = kIkNoItem;
-                }
-                if ((freeslots >> lane) & 1ull) sh.list[ik_rank(freeslots, lane)] = lane;
-                __syncthreads();
-                const int r = ik_rank(idle, lane);
-                int myslot = -1;
-                if (((idle >> lane) & 1ull) && r < nvalid) {
-                    myslot = sh.list[r];
-                    const int64_t v = (int64_t)base + r;
-                    IkWork w;
-                    if (sharing && v >= p.N) w = pend;
-                    else if (work) w = work[v];
-                    else { w.tgt = (int32_t)v; w.s0 = (int16_t)ik_s_first(p); w.s1 = (int16_t)ik_s_last(p); }
-                    ik_start_target<NJ>(st, sh, lane, p, qlim, myslot, v, w, Tep, q0);
-                }
-                busy |= __ballot(((freeslots >> lane) & 1ull) && ik_rank(freeslots, lane) < nvalid);
-                __syncthreads();
-                idle = __ballot(st.status == kIkIdle);
             }
-            if (idle && busy) {                                                         // phase D2: speculative searches
-                if ((busy >> lane) & 1ull) sh.list[ik_rank(busy, lane)] = lane;
-                __syncthreads();
-                const int nb = __popcll(busy);
-                int slot = 0, s = 0;
-                const bool mine = ((idle >> lane) & 1ull) && ik_pick(sh, ik_rank(idle, lane), nb, __popcll(idle), p.spec_policy, ik_s_first(p), slot, s);
-                __syncthreads();
-                if (mine) ik_start_spec<NJ>(st, sh, lane, p, qlim, slot, s, Tep, q0);
-                __syncthreads();
             }
             if (sharing && exhausted && busy) {                                         // phase D3: give work to waiting waves
                 // only a wave that holds a range worth cutting looks at the control words at all
@@ -290,8 +347,13 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
             const RTB_CONST double *ql = (const RTB_CONST double *)ka->qlim;
             asm volatile("" : "+s"(cvi.seg), "+s"(cvi.jmeta), "+s"(ql));
             const int myslot = st.slot;
+            if (ka->p.stats) { ++st_iters; st_lane += (unsigned long long)__popcll(__ballot(st.status == kIkRun && !st.fin)); }
             ik_iter<NJ, STEP>(st, ka->p, cvi, ql, [&](int k) { return sh.Td[k][myslot]; }, ik_lds_q(sh, lane));
         }
+    }
+    if (ka->p.stats && lane == 0) {
+        unsigned long long *o = ka->p.stats + 4ull * blockIdx.x;
+        o[0] = st_iters; o[1] = st_passes; o[2] = st_lane; o[3] = st_items;
     }
 }
 
@@ -341,7 +403,17 @@ __global__ __launch_bounds__(256) void k_ik_merge_chain(int64_t N, int n, const 
     if (t < N) ik_merge_chain(n, t, link, vq, vok, vit, vse, vE, q_out, success, iters, searches, residual);
 }
 
+__global__ __launch_bounds__(256) void k_ik_merge_flat(int64_t N, int n, int chunks, const double *vq, const int32_t *vok, const int32_t *vit, const int32_t *vse,
+                                                       const double *vE, double *q_out, int32_t *success, int32_t *iters, int32_t *searches, double *residual)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < N) ik_merge_flat(n, chunks, N, t, vq, vok, vit, vse, vE, q_out, success, iters, searches, residual);
+}
+
 namespace {
+int g_ik_flat = 1;        // flat schedule (ik_device.h): 0 never, 1 automatic (the batch is resident at once), 2 always (tests)
+int g_ik_flat_l0 = 4;     // searches in a target's first chunk ...
+int g_ik_flat_len = 8;    // ... and in every later one (measured on the MI355X, 1e5 Panda targets: 4 / 8 1.39 ms, 4 / 16 1.45, 8 / 16 1.42, 12 / 24 1.51; plain 1.55)
 int g_ik_donate_after = 3;   // sharing: failed searches of a target before its range may be cut (rtbhip_tune "ik_donate_after")
 int g_ik_share = 0;       // cross-wave sharing of search ranges: 0 never, 1 automatic (batch resident at once), 2 always (tests)
 int g_ik_phased = 0;      // 0 never (default: the CPU replay and the GPU both say it loses), 1 automatic, 2 always (tests)
@@ -359,6 +431,9 @@ constexpr int kCtrRing = 256;
 void ik_tune(const char *key, int value)
 {
     if (std::string(key) == "ik_waves_per_cu") g_ik_waves_per_cu = value < 1 ? 1 : value;
+    if (std::string(key) == "ik_flat") g_ik_flat = value < 0 ? 0 : (value > 2 ? 2 : value);
+    if (std::string(key) == "ik_flat_l0") g_ik_flat_l0 = value < 1 ? 1 : value;
+    if (std::string(key) == "ik_flat_len") g_ik_flat_len = value < 1 ? 1 : value;
     if (std::string(key) == "ik_pass_mask") g_ik_pass_mask = value < 0 ? 0 : value;
     if (std::string(key) == "ik_share") g_ik_share = value < 0 ? 0 : (value > 2 ? 2 : value);
     if (std::string(key) == "ik_phased") g_ik_phased = value < 0 ? 0 : (value > 2 ? 2 : value);
@@ -441,6 +516,7 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
     p.N = N;
     p.kq = ip.kq; p.km = ip.km; p.ps = ip.ps; p.ks = ip.ks;
     for (int j = 0; j < 16; ++j) p.pi[j] = ip.pi[j];
+    p.flat_chunks = 0; p.flat_l0 = 0; p.flat_len = 0; p.flat_n = 0; p.flat_done = nullptr; p.stats = nullptr;
     if (p.method == 5 && (p.km > 0.0 || p.kq > 0.0) && (c->n > kIkNullMax || c->n < 6)) {
         // IK_QP (ik_device.h): the manipulability term needs J J^T invertible, and both live in the one-wave-per-SIMD step variants
         set_error("ik_qp: the manipulability term (km > 0) and the joint-limit rows (kq > 0) are built for chains of 6..12 joints");
@@ -464,13 +540,15 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
     const int n = c->n;
     // one launch of the scheduler kernel over `items` work items (the targets themselves when work == NULL)
     auto run = [&](const IkDev &pp, int64_t items, const IkWork *work, const unsigned *count, double *qo, int32_t *ok, int32_t *it,
-                   int32_t *se, double *E, IkShareCtl share = IkShareCtl()) -> int {
+                   int32_t *se, double *E, IkShareCtl share = IkShareCtl(), int64_t first_items = -1) -> int {
         IkDev p2 = pp;
         int64_t g = gmax;
         if (!count && g > items) g = items;
         if (g < 1) g = 1;
         share.waves = (uint32_t)g;
-        const int64_t cap = ((items + g - 1) / g * g_ik_fresh_pct + 99) / 100;
+        // (flat schedule: the per-pass cap spreads the chunk-0 items -- one per target -- not the whole item count)
+        const int64_t cap_items = first_items > 0 ? first_items : items;
+        const int64_t cap = ((cap_items + g - 1) / g * g_ik_fresh_pct + 99) / 100;
         p2.fresh_cap = cap > 64 ? 64 : (cap < 1 ? 1 : (int32_t)cap);
         p2.pass_mask = g_ik_pass_mask;
         p2.spec_policy = g_ik_spec_policy;
@@ -481,6 +559,15 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
         p2.N = items;
         unsigned long long *ctr = ring + (g_ctr_next.fetch_add(1) % kCtrRing);
         RTB_HIP(hipMemsetAsync(ctr, 0, sizeof(unsigned long long), s));
+        // diagnostics: RTBHIP_IK_STATS=<file> appends one JSON line per scheduler launch with the per-wave counters (loop iterations,
+        // scheduling passes, lane-iterations spent on a running search, items started).  Synchronises the stream: not for timed runs.
+        static const char *stats_path = std::getenv("RTBHIP_IK_STATS");
+        unsigned long long *dstats = nullptr;
+        if (stats_path && *stats_path) {
+            RTB_HIP(hipMallocAsync((void **)&dstats, (size_t)g * 4 * sizeof(unsigned long long), s));
+            RTB_HIP(hipMemsetAsync(dstats, 0, (size_t)g * 4 * sizeof(unsigned long long), s));
+            p2.stats = dstats;
+        }
         dim3 grid((unsigned)g);
         switch (n) {
         case 1: launch_nj<1>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
@@ -503,8 +590,62 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
         note_launch((int)grid.x, kWave, 0);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "k_ik launch");
+        if (dstats) {
+            std::vector<unsigned long long> hs((size_t)g * 4);
+            RTB_HIP(hipMemcpyAsync(hs.data(), dstats, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            RTB_HIP(hipStreamSynchronize(s));
+            (void)hipFreeAsync(dstats, s);
+            if (FILE *f = std::fopen(stats_path, "a")) {
+                std::fprintf(f, "{\"grid\": %lld, \"items\": %lld, \"flat_chunks\": %d, \"waves_per_cu\": %d, \"pass_mask\": %d, \"n\": %d, \"per_wave\": [",
+                             (long long)g, (long long)items, (int)p2.flat_chunks, g_ik_waves_per_cu, g_ik_pass_mask, n);
+                for (int64_t w = 0; w < g; ++w)
+                    std::fprintf(f, "%s[%llu,%llu,%llu,%llu]", w ? "," : "", hs[4 * w], hs[4 * w + 1], hs[4 * w + 2], hs[4 * w + 3]);
+                std::fprintf(f, "]}\n");
+                std::fclose(f);
+            }
+        }
         return RTBHIP_OK;
     };
+
+    // Flat schedule (ik_device.h): one launch over (target, chunk) items drawn chunk-major from the device-wide counter; rows go to
+    // temporaries, a merge kernel folds each target's rows in chunk order.  rtbhip_tune("ik_flat", 0 / 1 / 2) = never / automatic (the
+    // batch is resident at once: the regime in which a wave is stuck with the targets it drew) / always (tests).
+    {
+        const IkFlatPlan fp = ik_flat_plan(p, g_ik_flat_l0, g_ik_flat_len);
+        const bool flat_fits = fp.chunks > 1 && fp.chunks < 250 && (long long)N * fp.chunks < (1ll << 32) - 4096;
+        const bool flat_on = flat_fits && (g_ik_flat == 2 || (g_ik_flat == 1 && N <= 3 * gmax * kWave));
+        if (flat_on) {
+            const size_t rows = (size_t)N * fp.chunks;
+            auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+            const size_t o_done = 0, o_vq = up((size_t)N * sizeof(int32_t)), o_vE = o_vq + up(rows * n * sizeof(double)), o_vok = o_vE + up(rows * sizeof(double));
+            const size_t o_vit = o_vok + up(rows * sizeof(int32_t)), o_vse = o_vit + up(rows * sizeof(int32_t)), total = o_vse + up(rows * sizeof(int32_t));
+            char *blk = nullptr;
+            {
+                hipError_t e = hipMallocAsync((void **)&blk, total, s);
+                if (e != hipSuccess) return hip_fail(e, "hipMallocAsync (ik flat schedule)");
+            }
+            int rc = RTBHIP_OK;
+            {
+                hipError_t e = hipMemsetAsync(blk + o_done, 0x7f, (size_t)N * sizeof(int32_t), s);      // kIkFlatNone
+                if (e != hipSuccess) rc = hip_fail(e, "hipMemsetAsync (ik flat schedule)");
+            }
+            int32_t *vok = (int32_t *)(blk + o_vok), *vit = (int32_t *)(blk + o_vit), *vse = (int32_t *)(blk + o_vse);
+            double *vq = (double *)(blk + o_vq), *vE = (double *)(blk + o_vE);
+            if (rc == RTBHIP_OK) {
+                IkDev pf = p;
+                pf.flat_chunks = fp.chunks; pf.flat_l0 = fp.l0; pf.flat_len = fp.len; pf.flat_n = (uint32_t)N; pf.flat_done = (int32_t *)(blk + o_done);
+                rc = run(pf, (int64_t)rows, nullptr, nullptr, vq, vok, vit, vse, vE, IkShareCtl(), N);
+            }
+            if (rc == RTBHIP_OK) {
+                hipLaunchKernelGGL(k_ik_merge_flat, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, N, n, fp.chunks, vq, vok, vit, vse, vE, q_out, success,
+                                   iters, searches, residual);
+                hipError_t e = hipGetLastError();
+                if (e != hipSuccess) rc = hip_fail(e, "k_ik_merge_flat launch");
+            }
+            (void)hipFreeAsync(blk, s);
+            return rc;
+        }
+    }
 
     // Cross-wave sharing of search ranges (ik_device.h) when the whole batch is resident at once: rtbhip_tune("ik_share",
     // 0 / 1 / 2) = never / automatic / always (tests).  Rows go to temporaries; a merge kernel walks each target's chain.

@@ -250,12 +250,13 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
         if constexpr (ACC) {
             if (j >= first) {          // wave-uniform
                 V3 wdn, an;
+                const bool ps0 = (flg[j] & kLinkPsZero) != 0;      // wave-uniform: p* = 0, the cross products with it are exact zeros
                 if (MDH) {             // w = 0:  wd' = R^T wd + z qdd,  a' = R^T (a + wd x p*)
                     wdn = addz(rot_inv<MDH>(R, wd), qddj);
-                    an = rot_inv<MDH>(R, cross_add(wd, ps, a));
+                    an = rot_inv<MDH>(R, ps0 ? a : cross_add(wd, ps, a));
                 } else {               //         wd' = R^T (wd + z qdd),  a' = wd' x p* + R^T a
                     wdn = rot_inv<MDH>(R, v3(wd.x, wd.y, wd.z + qddj));
-                    an = cross_add(wdn, ps, rot_inv<MDH>(R, a));
+                    an = ps0 ? rot_inv<MDH>(R, a) : cross_add(wdn, ps, rot_inv<MDH>(R, a));
                 }
                 wd = wdn; a = an;
                 V3 ac = a;
@@ -280,7 +281,8 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
                     // crossz(t1, qdj) + R^T wd [+ qddv]
                     const V3 u = rot_inv_add<MDH>(R, wd, v3(t1.y * qdj, -(t1.x * qdj), 0.0));
                     wdn = ALLREV ? addz(u, qddj) : u + qddv;
-                    an = rot_inv<MDH>(R, cross_add(wd, ps, cross_add(w, cross(w, ps), a)));
+                    // (p* = 0 -- a link whose origin coincides with its predecessor's: wave-uniform -- leaves a' = R^T a)
+                    an = rot_inv<MDH>(R, (flg[j] & kLinkPsZero) ? a : cross_add(wd, ps, cross_add(w, cross(w, ps), a)));
                 }
             } else {
                 if (j == 0) {
@@ -300,7 +302,10 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
                 const V3 t3 = (j == 0) ? qddv : (ALLREV ? v3(fmad(w.y, qdj, wd.x), fmad(-w.x, qdj, wd.y), wd.z + qddj)
                                                          : (wd + qddv) + crossz(w, qdj));
                 wdn = rot_inv<MDH>(R, t3);
-                an = cross_add(wdn, ps, cross_add(wn, cross(wn, ps), rot_inv<MDH>(R, (j == 0) ? grav : a)));
+                {
+                    const V3 ra = rot_inv<MDH>(R, (j == 0) ? grav : a);
+                    an = (flg[j] & kLinkPsZero) ? ra : cross_add(wdn, ps, cross_add(wn, cross(wn, ps), ra));
+                }
             } else {
                 wn = (j == 0) ? v3(0, 0, 0) : rot_inv<MDH>(R, w);
                 wdn = (j == 0) ? v3(0, 0, 0) : rot_inv<MDH>(R, wd);
@@ -362,7 +367,10 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
             const V3 fn = last ? f : rot_fwd<MDH>(Rn, f);
             fj = fn + F[j];
             const V3 base = rzero ? Nn[j] : cross_add(rc, F[j], Nn[j]);
-            nj = last ? nn + base : cross_add(psn, fn, rot_fwd_add<MDH>(Rn, nn, base));
+            // (psn = p* of link j + 1: zero for a kLinkPsZero link, wave-uniform)
+            if (last) nj = nn + base;
+            else if (flg[j + 1 < n ? j + 1 : j] & kLinkPsZero) nj = rot_fwd_add<MDH>(Rn, nn, base);
+            else nj = cross_add(psn, fn, rot_fwd_add<MDH>(Rn, nn, base));
         } else {
             fj = last ? F[j] + f : rot_fwd_add<MDH>(Rn, f, F[j]);
             const V3 base = cross_add(ps + rc, F[j], Nn[j]);

@@ -62,9 +62,9 @@ struct alignas(16) DevLink {   // per-link constants for the Newton-Euler kernel
     double Jm, G, B, Tc0, Tc1;
     double gjm, gb, ag;        // (G*G)*Jm, (G*G)*B, |G|: the products ne.c:464-492 forms per call, rounded in the same order
     int32_t sigma;             // 0 revolute, 1 prismatic
-    int32_t flags;             // wave-uniform shortcuts: kLinkRZero (centre of mass at the link origin), kLinkIDiag (diagonal inertia)
+    int32_t flags;             // wave-uniform shortcuts: kLinkRZero (centre of mass at the link origin), kLinkIDiag (diagonal inertia), kLinkPsZero (a = d = 0)
 };
-constexpr int kLinkRZero = 1, kLinkIDiag = 2;
+constexpr int kLinkRZero = 1, kLinkIDiag = 2, kLinkPsZero = 4;   // kLinkPsZero: revolute link with a = d = 0 (its frame origin coincides with its predecessor's)
 struct Dyn {
     std::vector<DevLink> links;
     int n = 0, mdh = 0;

@@ -11,6 +11,7 @@ struct EmuWave {
     unsigned long long busy = 0;
     bool exhausted = false, first = true, done = false, drained = false;
     unsigned long long pool_next = 0, pool_end = 0;
+    unsigned long long pool_live = 0;      // flat schedule: live, unstarted numbers of the last draw (bit k = number pool_next + k)
     unsigned tick = 0;
     long long passes = 0, iters = 0, lane_iters_useful = 0;
     long long quiet = 0;       // the kernel's watchdog counter, replayed: a false fire fails the run (-4)
@@ -39,7 +40,20 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
     auto ballot = [&](EmuWave<NJ> &w, auto pred) { unsigned long long m = 0; for (int l = 0; l < kWave; ++l) if (pred(l)) m |= 1ull << l; return m; };
     int live = waves;
     long long guard = 0;
+    static const bool trace = getenv("EMU_IK_TRACE") != nullptr;
+    long long turn = 0;
     while (live > 0) {
+        if (trace && (turn++ % 10) == 0) {          // every tenth turn: live waves, running lanes, busy slots by chunk class
+            long long run = 0, slots0 = 0, slots1 = 0;
+            for (auto &w : W) {
+                if (w.done) continue;
+                for (int l = 0; l < kWave; ++l) {
+                    run += w.st[l].status == kIkRun && !w.st[l].fin;
+                    if ((w.busy >> l) & 1ull) { if (w.sh.chunk[l] == 0) ++slots0; else ++slots1; }
+                }
+            }
+            fprintf(stderr, "turn %lld live %d running_lanes %lld (%.2f) slots chunk0 %lld later %lld counter %llu\n", turn - 1, live, run, (double)run / (64.0 * waves), slots0, slots1, counter);
+        }
         if (++guard > 400000) {
             if (getenv("EMU_IK_DEBUG"))
                 for (size_t wi = 0; wi < W.size(); ++wi) {
@@ -64,7 +78,14 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
                 w.passes++;
                 for (int l = 0; l < kWave; ++l) ik_report<NJ>(w.st[l], w.sh, residual, p, qlim, ik_lds_q(w.sh, l));
                 for (int l = 0; l < kWave; ++l) if ((w.busy >> l) & 1ull) ik_account(l, w.sh);
+                const bool flat = p.flat_chunks > 0;
+                if (flat)                  // drop later-chunk items whose target has meanwhile succeeded in an earlier chunk
+                    for (int l = 0; l < kWave; ++l)
+                        if (((w.busy >> l) & 1ull) && w.sh.chunk[l] > 0 && w.sh.res[l] == 0 && ik_aload(p.flat_done + w.sh.tgt[l]) < (int32_t)w.sh.chunk[l]) w.sh.res[l] = 3;
                 for (int l = 0; l < kWave; ++l) ik_finalize<NJ>(w.st[l], w.sh, l, p, qlim, q_out, success, iters, searches, residual);
+                if (flat)
+                    for (int l = 0; l < kWave; ++l)
+                        if (((w.busy >> l) & 1ull) && w.sh.res[l] == 1) ik_flat_publish(p.flat_done, w.sh.tgt[l], w.sh.chunk[l]);
                 const unsigned long long freed = ballot(w, [&](int l) { return ((w.busy >> l) & 1ull) && w.sh.res[l] != 0; });
                 if (freed) w.quiet = 0;
                 w.busy &= ~freed;
@@ -83,58 +104,92 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
                     }
                     idle = ballot(w, [&](int l) { return w.st[l].status == kIkIdle; });
                 }
-                if ((!w.exhausted || w.pend_item != kIkNoItem) && idle) {
-                    const unsigned long long freeslots = ~w.busy;
-                    int nf = __builtin_popcountll(idle);
-                    nf = nf > p.fresh_cap ? p.fresh_cap : nf;
-                    { static const int mb = getenv("EMU_IK_MAX_BUSY") ? atoi(getenv("EMU_IK_MAX_BUSY")) : 64;
-                      const int room = mb - __builtin_popcountll(w.busy); nf = nf > room ? (room > 0 ? room : 0) : nf; }
-                    unsigned long long base = 0;
-                    long long nvalid = 0;
-                    if (!w.exhausted) {
-                    if (w.pool_next == w.pool_end) {
-                        const unsigned long long chunk = p.pool_chunk > 0 ? (unsigned long long)p.pool_chunk : (unsigned long long)nf;
-                        const unsigned long long got = counter;
-                        counter += chunk;
-                        const unsigned long long NN = (unsigned long long)p.N;
-                        w.pool_next = got < NN ? got : NN;
-                        w.pool_end = got + chunk < NN ? got + chunk : NN;
-                        if (w.pool_end == NN) w.drained = true;
-                    }
-                    base = w.pool_next;
-                    nvalid = (long long)(w.pool_end - w.pool_next);
-                    nvalid = nvalid > nf ? nf : nvalid;
-                    w.pool_next += (unsigned long long)nvalid;
-                    if (w.drained && w.pool_next == w.pool_end) w.exhausted = true;
-                    }
-                    const IkWork pend = ik_unpack(w.pend_item);
-                    if (w.exhausted && w.pend_item != kIkNoItem) {
-                        base = (unsigned long long)ik_item_row(*share, p.N, (int)(wi % kIkQueues), w.pend_tick); nvalid = 1;
-                        w.pend_item = kIkNoItem;
-                    }
-                    for (int l = 0; l < kWave; ++l) if ((freeslots >> l) & 1ull) w.sh.list[ik_rank(freeslots, l)] = l;
-                    for (int l = 0; l < kWave; ++l) {
-                        const int r = ik_rank(idle, l);
-                        if (((idle >> l) & 1ull) && r < nvalid) {
-                            const int64_t v = (int64_t)base + r;
-                            IkWork it;
-                            if (share && v >= p.N) it = pend;
-                            else if (work) it = work[v];
-                            else { it.tgt = (int32_t)v; it.s0 = (int16_t)ik_s_first(p); it.s1 = (int16_t)ik_s_last(p); }
-                            ik_start_target<NJ>(w.st[l], w.sh, l, p, qlim, w.sh.list[r], v, it, Tep, q0);
+                const bool late = flat && w.pool_next >= (unsigned long long)p.flat_n;      // the kernel's order of D1 / D2 (ik_kernels.hip)
+                for (int step = 0; step < 2; ++step) {
+                if ((step == 0) != late) {
+                    if ((!w.exhausted || w.pend_item != kIkNoItem) && idle) {
+                        const unsigned long long freeslots = ~w.busy;
+                        int nf = __builtin_popcountll(idle);
+                        nf = nf > p.fresh_cap ? p.fresh_cap : nf;
+                        { static const int mb = getenv("EMU_IK_MAX_BUSY") ? atoi(getenv("EMU_IK_MAX_BUSY")) : 64;
+                          const int room = mb - __builtin_popcountll(w.busy); nf = nf > room ? (room > 0 ? room : 0) : nf; }
+                        unsigned long long base = 0;
+                        long long nvalid = 0;
+                        int flat_off[kWave] = {0};
+                        if (flat && !w.exhausted) {
+                            const unsigned long long NN = (unsigned long long)p.N;
+                            if (late) nf = __builtin_popcountll(idle);
+                            for (int round = 0; (round < 4 || w.busy == 0) && w.pool_live == 0 && !w.drained; ++round) {
+                                const unsigned long long want = w.pool_next < (unsigned long long)p.flat_n ? (unsigned long long)nf : 64ull;
+                                const unsigned long long got = counter;
+                                counter += want;
+                                w.pool_next = got < NN ? got : NN;
+                                if (got + want >= NN) w.drained = true;
+                                w.pool_live = 0;
+                                for (int l = 0; l < kWave; ++l) {
+                                    const unsigned long long id = got + (unsigned long long)l;
+                                    if ((unsigned long long)l < want && id < NN && ik_flat_live(p, (uint32_t)id)) w.pool_live |= 1ull << l;
+                                }
+                            }
+                            nvalid = __builtin_popcountll(w.pool_live);
+                            nvalid = nvalid > nf ? nf : nvalid;
+                            base = w.pool_next;
+                            uint8_t offs[kWave];
+                            for (int l = 0; l < kWave; ++l) if ((w.pool_live >> l) & 1ull) { const int k = ik_rank(w.pool_live, l); if (k < nvalid) offs[k] = (uint8_t)l; }
+                            for (int l = 0; l < kWave; ++l) { const int r0 = ik_rank(idle, l); flat_off[l] = (((idle >> l) & 1ull) && r0 < nvalid) ? (int)offs[r0] : 0; }
+                            for (long long k = 0; k < nvalid; ++k) w.pool_live &= w.pool_live - 1ull;
+                            if (w.drained && w.pool_live == 0) w.exhausted = true;
+                        } else if (!w.exhausted) {
+                        if (w.pool_next == w.pool_end) {
+                            const unsigned long long chunk = p.pool_chunk > 0 ? (unsigned long long)p.pool_chunk : (unsigned long long)nf;
+                            const unsigned long long got = counter;
+                            counter += chunk;
+                            const unsigned long long NN = (unsigned long long)p.N;
+                            w.pool_next = got < NN ? got : NN;
+                            w.pool_end = got + chunk < NN ? got + chunk : NN;
+                            if (w.pool_end == NN) w.drained = true;
                         }
+                        base = w.pool_next;
+                        nvalid = (long long)(w.pool_end - w.pool_next);
+                        nvalid = nvalid > nf ? nf : nvalid;
+                        w.pool_next += (unsigned long long)nvalid;
+                        if (w.drained && w.pool_next == w.pool_end) w.exhausted = true;
+                        }
+                        const IkWork pend = ik_unpack(w.pend_item);
+                        if (w.exhausted && w.pend_item != kIkNoItem) {
+                            base = (unsigned long long)ik_item_row(*share, p.N, (int)(wi % kIkQueues), w.pend_tick); nvalid = 1;
+                            w.pend_item = kIkNoItem;
+                        }
+                        for (int l = 0; l < kWave; ++l) if ((freeslots >> l) & 1ull) w.sh.list[ik_rank(freeslots, l)] = l;
+                        for (int l = 0; l < kWave; ++l) {
+                            const int r = ik_rank(idle, l);
+                            if (((idle >> l) & 1ull) && r < nvalid) {
+                                const int64_t v = flat ? (int64_t)base + flat_off[l] : (int64_t)base + r;
+                                IkWork it;
+                                int chunk = 0;
+                                if (flat) it = ik_flat_item(p, (uint32_t)v, &chunk);
+                                else if (share && v >= p.N) it = pend;
+                                else if (work) it = work[v];
+                                else { it.tgt = (int32_t)v; it.s0 = (int16_t)ik_s_first(p); it.s1 = (int16_t)ik_s_last(p); }
+                                ik_start_target<NJ>(w.st[l], w.sh, l, p, qlim, w.sh.list[r], v, it, Tep, q0);
+                                w.sh.chunk[w.sh.list[r]] = (uint8_t)chunk;
+                            }
+                        }
+                        w.busy |= ballot(w, [&](int l) { return ((freeslots >> l) & 1ull) && ik_rank(freeslots, l) < nvalid; });
+                        idle = ballot(w, [&](int l) { return w.st[l].status == kIkIdle; });
                     }
-                    w.busy |= ballot(w, [&](int l) { return ((freeslots >> l) & 1ull) && ik_rank(freeslots, l) < nvalid; });
-                    idle = ballot(w, [&](int l) { return w.st[l].status == kIkIdle; });
+                } else {
+                    if (idle && w.busy) {
+                        for (int l = 0; l < kWave; ++l) if ((w.busy >> l) & 1ull) w.sh.list[ik_rank(w.busy, l)] = l;
+                        const int nb = __builtin_popcountll(w.busy);
+                        int slot[kWave], ss[kWave];
+                        bool mine[kWave];
+                        for (int l = 0; l < kWave; ++l)
+                            mine[l] = ((idle >> l) & 1ull) && ik_pick(w.sh, ik_rank(idle, l), nb, __builtin_popcountll(idle), p.spec_policy, ik_s_first(p), slot[l], ss[l]);
+                        for (int l = 0; l < kWave; ++l) if (mine[l]) ik_start_spec<NJ>(w.st[l], w.sh, l, p, qlim, slot[l], ss[l], Tep, q0);
+                        idle = ballot(w, [&](int l) { return w.st[l].status == kIkIdle; });
+                    }
                 }
-                if (idle && w.busy) {
-                    for (int l = 0; l < kWave; ++l) if ((w.busy >> l) & 1ull) w.sh.list[ik_rank(w.busy, l)] = l;
-                    const int nb = __builtin_popcountll(w.busy);
-                    int slot[kWave], ss[kWave];
-                    bool mine[kWave];
-                    for (int l = 0; l < kWave; ++l)
-                        mine[l] = ((idle >> l) & 1ull) && ik_pick(w.sh, ik_rank(idle, l), nb, __builtin_popcountll(idle), p.spec_policy, ik_s_first(p), slot[l], ss[l]);
-                    for (int l = 0; l < kWave; ++l) if (mine[l]) ik_start_spec<NJ>(w.st[l], w.sh, l, p, qlim, slot[l], ss[l], Tep, q0);
                 }
                 if (share && w.exhausted && w.busy) {                            // phase D3: give work to waiting waves
                     const unsigned long long cand = ballot(w, [&](int l) { return ((w.busy >> l) & 1ull) && ik_donatable(w.sh, l, ik_s_first(p), (int)share->after); });
@@ -197,6 +252,27 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
         for (auto &w : W) { mx = std::max(mx, w.iters); tot += w.iters; useful += w.lane_iters_useful; passes += w.passes; }
         stats[0] = (double)mx; stats[1] = (double)tot; stats[2] = (double)useful; stats[3] = (double)passes;
     }
+    return 0;
+}
+
+// launch_ik's flat schedule (ik_kernels.hip) replayed: one run of the wave scheduler over the (target, chunk) items with the planning /
+// item / liveness / merge functions of ik_device.h; rows in temporaries, merged chunk by chunk.
+template <int NJ>
+static int emu_ik_flat_run(const Chain *c, const IkDev &p, int waves, int l0, int len, const double *Tep, const double *q0, double *q_out,
+                           int32_t *success, int32_t *iters, int32_t *searches, double *residual, double *stats)
+{
+    const IkFlatPlan fp = ik_flat_plan(p, l0, len);
+    if (fp.chunks <= 1) return emu_ik_wave_run<NJ>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats);
+    const int64_t N = p.N;
+    const size_t rows = (size_t)N * fp.chunks;
+    std::vector<double> vq(rows * NJ, 0.0), vE(rows, 0.0);
+    std::vector<int32_t> vok(rows, -7), vit(rows, -7), vse(rows, -7), done((size_t)N, kIkFlatNone);
+    IkDev pf = p;
+    pf.flat_chunks = fp.chunks; pf.flat_l0 = fp.l0; pf.flat_len = fp.len; pf.flat_n = (uint32_t)N; pf.flat_done = done.data();
+    pf.N = (int64_t)rows;
+    const int rc = emu_ik_wave_run<NJ>(c, pf, waves, Tep, q0, vq.data(), vok.data(), vit.data(), vse.data(), vE.data(), stats);
+    if (rc != 0) return rc;
+    for (int64_t t = 0; t < N; ++t) ik_merge_flat(NJ, fp.chunks, N, t, vq.data(), vok.data(), vit.data(), vse.data(), vE.data(), q_out, success, iters, searches, residual);
     return 0;
 }
 
@@ -293,7 +369,10 @@ int emu_ik_wave_mid(int n, bool shared, bool phased, const Chain *c, const IkDev
                     int32_t *success, int32_t *iters, int32_t *searches, double *residual, double *stats);
 int emu_ik_wave_hi(int n, bool shared, bool phased, const Chain *c, const IkDev &p, int waves, const double *Tep, const double *q0, double *q_out,
                    int32_t *success, int32_t *iters, int32_t *searches, double *residual, double *stats);
-#define RTB_EMU_IK(NJ) case NJ: return shared ? emu_ik_shared_run<NJ>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats) \
+#define RTB_EMU_IK(NJ) case NJ: if (getenv("EMU_IK_FLAT") && atoi(getenv("EMU_IK_FLAT")) != 0) \
+            return emu_ik_flat_run<NJ>(c, p, waves, getenv("EMU_IK_FLAT_L0") ? atoi(getenv("EMU_IK_FLAT_L0")) : 4, getenv("EMU_IK_FLAT_LEN") ? atoi(getenv("EMU_IK_FLAT_LEN")) : 8, \
+                                       Tep, q0, q_out, success, iters, searches, residual, stats); \
+        return shared ? emu_ik_shared_run<NJ>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats) \
                                      : phased ? emu_ik_phased_run<NJ>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats) \
                                               : emu_ik_wave_run<NJ>(c, p, waves, Tep, q0, q_out, success, iters, searches, residual, stats);
 #define RTB_EMU_IK_DISPATCH(NAME, CASES) \

@@ -509,7 +509,13 @@ def test_ik_config3_1e5_targets_statistics():
     assert (qh[okh] >= ch.qlim[0]).all() and (qh[okh] <= ch.qlim[1]).all()
     Tsol = ets.eval(q).cpu().numpy()
     Th = Tep.cpu().numpy()
-    assert np.abs(Tsol[okh] - Th[okh]).max() < 1e-2 * 0 + 5e-3      # E < 1e-6  =>  |dT| <~ sqrt(2E)
+    # the reference's own criterion (tests/test_IK.py:15): the error of the REACHED pose, recomputed from FK(q), below 1e-5 --
+    # here at the solver's own level: E(FK(q), Tep) within rounding of the reported residual, hence < 1e-6
+    e = rtbhip.angle_axis(torch.from_numpy(Tsol).cuda(), Tep).cpu().numpy()
+    Ecalc = 0.5 * (e * e).sum(axis=1)
+    assert (Ecalc[okh] < 1e-6).all()
+    assert np.abs(Ecalc[okh] - Eh[okh]).max() < 1e-12
+    assert np.abs(Tsol[okh] - Th[okh]).max() < 2.0 * np.sqrt(2e-6)      # |dT| <= |e| (1 + reach) with |e| < sqrt(2 tol)
     sub = np.arange(0, N, 250)
     o_ok = []
     for i in sub:
@@ -518,7 +524,7 @@ def test_ik_config3_1e5_targets_statistics():
         o_ok.append(o[1])
         assert (o[1], o[2], o[3]) == (ok[i].item(), it[i].item(), se[i].item())
     assert okh[sub].mean() >= np.mean(o_ok) - 1e-3
-    assert not okh.all() or True
+    assert 0.985 < okh.mean() < 0.997                                   # 0.9 % of this batch exhausts all 100 searches (in the oracle too)
     # failures (if any) carry the reference's bookkeeping: searches == slimit + 1
     if (~okh).any():
         assert (se.cpu().numpy()[~okh] == 101).all()
@@ -606,7 +612,7 @@ def test_ik_fourteen_joint_chain_equals_oracle():
 
 @pytest.mark.parametrize("flavour", [0, 1])
 def test_ik_cross_wave_sharing_and_phased_schedule_equal_plain(flavour):
-    """Cross-wave sharing of search ranges (rtbhip_tune "ik_share") and the phased schedule ("ik_phased") only change WHO runs a
+    """The flat schedule ("ik_flat", the default for batches resident at once), cross-wave sharing of search ranges (rtbhip_tune "ik_share") and the phased schedule ("ik_phased") only change WHO runs a
     search: every output must be bit-equal to the plain scheduler's, for reachable and unreachable targets, with and without q0,
     at a size where the grid is under-filled (donations happen) and at one where it is over-filled."""
     import torch
@@ -621,8 +627,14 @@ def test_ik_cross_wave_sharing_and_phased_schedule_equal_plain(flavour):
         run = (lambda: ets.ik_LM(Tt, q0=q0t, seed=3, slimit=slimit)) if flavour == 0 else \
               (lambda: tuple(torch.as_tensor(x) for x in (lambda s: (s.q, s.each["success"], s.each["iterations"], s.each["searches"], s.each["residual"]))(ets.ikine_LM(Tt, q0=q0t, seed=3, slimit=slimit))))
         try:
-            rtbhip.tune("ik_share", 0); rtbhip.tune("ik_phased", 0)
+            rtbhip.tune("ik_share", 0); rtbhip.tune("ik_phased", 0); rtbhip.tune("ik_flat", 0)
             base = [x.cpu().numpy() for x in run()]
+            for l0, length in ((4, 8), (1, 3), (7, 40)):              # the flat schedule, three cuts of the search range
+                rtbhip.tune("ik_flat", 2); rtbhip.tune("ik_flat_l0", l0); rtbhip.tune("ik_flat_len", length)
+                flat = [x.cpu().numpy() for x in run()]
+                for a, b in zip(base, flat):
+                    nt.assert_array_equal(a, b)
+            rtbhip.tune("ik_flat", 0); rtbhip.tune("ik_flat_l0", 4); rtbhip.tune("ik_flat_len", 8)
             rtbhip.tune("ik_share", 2)
             shared = [x.cpu().numpy() for x in run()]
             rtbhip.tune("ik_donate_after", 0)                     # ranges cut as soon as a wave waits, not after three failures
@@ -632,6 +644,7 @@ def test_ik_cross_wave_sharing_and_phased_schedule_equal_plain(flavour):
             phased = [x.cpu().numpy() for x in run()]
         finally:
             rtbhip.tune("ik_share", 0); rtbhip.tune("ik_phased", 0); rtbhip.tune("ik_donate_after", 3)
+            rtbhip.tune("ik_flat", 1); rtbhip.tune("ik_flat_l0", 4); rtbhip.tune("ik_flat_len", 8)
         for a, b, b0, c in zip(base, shared, shared0, phased):
             nt.assert_array_equal(a, b)
             nt.assert_array_equal(a, b0)

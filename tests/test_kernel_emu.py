@@ -607,6 +607,33 @@ def test_ik_phased_schedule_equals_sequential_searches(flavour, slimit, with_q0)
 
 
 @pytest.mark.parametrize("flavour", [0, 1])
+@pytest.mark.parametrize("N,waves,slimit,with_q0,l0,length", [(300, 6, 100, False, 4, 8), (64, 3, 100, False, 4, 16), (130, 4, 17, True, 4, 8), (5, 4, 100, False, 1, 1),
+                                                              (700, 2, 40, False, 8, 5), (200, 5, 4, False, 4, 8), (200, 5, 5, True, 4, 8), (90, 7, 100, False, 3, 97)])
+def test_ik_flat_schedule_equals_sequential_searches(flavour, N, waves, slimit, with_q0, l0, length):
+    """The flat schedule (ik_device.h: every target's search range cut into chunks, the (target, chunk) items numbered chunk-major and
+    drawn from the one device-wide counter by whichever wave has idle lanes; later chunks of a target that has succeeded are skipped or
+    dropped; rows merged chunk by chunk) must report exactly what the sequential loops report -- for every cut of the range (a range
+    no longer than the first chunk falls back to the plain schedule), unreachable targets, joint-limit rejections and a supplied q0."""
+    import os
+    ets, ch = _panda_limited()
+    rng = np.random.default_rng(N + waves + slimit)
+    Tep = oracle.fkine(ch, rng.uniform(ch.qlim[0], ch.qlim[1], (N, 7)))
+    Tep[::9, :3, 3] += 2.5
+    q0 = rng.uniform(ch.qlim[0], ch.qlim[1], (N, 7)) if with_q0 else None
+    a = emu.ik(ets, Tep, q0=q0, slimit=slimit, flavour=flavour, seed=41)
+    os.environ.update(EMU_IK_FLAT="1", EMU_IK_PASS_MASK="3", EMU_IK_FLAT_L0=str(l0), EMU_IK_FLAT_LEN=str(length))
+    try:
+        st = [0, 0, 0, 0]
+        b = emu.ik(ets, Tep, q0=q0, slimit=slimit, flavour=flavour, seed=41, waves=waves, stats=st)
+    finally:
+        for k in ("EMU_IK_FLAT", "EMU_IK_PASS_MASK", "EMU_IK_FLAT_L0", "EMU_IK_FLAT_LEN"):
+            del os.environ[k]
+    for x, y in zip(a, b):
+        nt.assert_array_equal(x, y)
+    assert a[1].sum() < N and st[0] > 0
+
+
+@pytest.mark.parametrize("flavour", [0, 1])
 @pytest.mark.parametrize("N,waves,slimit,with_q0", [(300, 6, 100, False), (64, 3, 100, False), (130, 4, 17, True), (5, 4, 100, False), (700, 2, 40, False)])
 def test_ik_cross_wave_sharing_equals_sequential_searches(flavour, N, waves, slimit, with_q0):
     """Cross-wave sharing (ik_device.h: a wave out of work takes a ticket and is handed the unstarted part of another wave's
