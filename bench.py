@@ -35,7 +35,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "robotics-toolbox-python_amd")]
 
-from benchlib import HBM_PEAK_GBS, Ranks, spawn_ranks_if_needed, bench_argv, per_launch_min_ms, ensure_library, pmc_traffic  # noqa: E402
+from benchlib import protect_stdout, HBM_PEAK_GBS, Ranks, spawn_ranks_if_needed, bench_argv, per_launch_min_ms, ensure_library, pmc_traffic  # noqa: E402
 
 BYTES_PER_CONFIG = 56 + 128 + 336  # q read + T written + J0 written
 
@@ -137,6 +137,7 @@ def main():
     if args.gather:
         os.environ["RTBHIP_BENCH_FORCE_GROUP"] = "1"
     spawn_ranks_if_needed(args.gpus, os.path.abspath(__file__), argv)
+    protect_stdout()
 
     import numpy as np
     import torch

@@ -22,7 +22,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "robotics-toolbox-python_amd")]
 
-from benchlib import HBM_PEAK_GBS, FP64_VALU_PEAK_TFLOPS, Ranks, spawn_ranks_if_needed, bench_argv, ensure_library  # noqa: E402
+from benchlib import protect_stdout, HBM_PEAK_GBS, FP64_VALU_PEAK_TFLOPS, Ranks, spawn_ranks_if_needed, bench_argv, ensure_library  # noqa: E402
 
 
 def ev_time(fn, steps, warmup):
@@ -92,6 +92,7 @@ def main():
     argv = bench_argv()
     args = ap.parse_args(argv)
     spawn_ranks_if_needed(args.gpus, os.path.abspath(__file__), argv)
+    protect_stdout()
     import numpy as np
     import torch
     ensure_library(ROOT)

@@ -39,6 +39,20 @@ def spawn_ranks_if_needed(n_gpus, script, argv):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def protect_stdout():
+    """The contract is ONE JSON line on stdout.  Native libraries write there too -- RCCL prints a five-line version banner on fd 1 when the
+    first communicator comes up (seen on the GPU box: visit r3a) -- so fd 1 is pointed at stderr for everything below Python, and
+    sys.stdout keeps a private duplicate of the real stdout: only print() reaches it."""
+    import io
+    try:
+        sys.stdout.flush()
+        real = os.dup(1)
+        os.dup2(2, 1)
+        sys.stdout = io.TextIOWrapper(os.fdopen(real, "wb"), line_buffering=True)
+    except OSError:
+        pass                                # no usable fd 2: leave things as they are
+
+
 def bench_argv():
     """The flags of this run: sys.argv, or -- in a rank spawned by spawn_ranks_if_needed -- what the parent was given."""
     import json

@@ -613,7 +613,9 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
     {
         const IkFlatPlan fp = ik_flat_plan(p, g_ik_flat_l0, g_ik_flat_len);
         const bool flat_fits = fp.chunks > 1 && fp.chunks < 250 && (long long)N * fp.chunks < (1ll << 32) - 4096;
-        const bool flat_on = flat_fits && (g_ik_flat == 2 || (g_ik_flat == 1 && N <= 3 * gmax * kWave));
+        // automatic: the batch is resident at once (a wave cannot trade targets) AND large enough that waves hold several targets each -- below
+        // that a wave's 64 lanes already serve its one or two targets' searches in parallel and the temporaries would only add latency
+        const bool flat_on = flat_fits && (g_ik_flat == 2 || (g_ik_flat == 1 && N <= 3 * gmax * kWave && N >= 4 * gmax));
         if (flat_on) {
             const size_t rows = (size_t)N * fp.chunks;
             auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };

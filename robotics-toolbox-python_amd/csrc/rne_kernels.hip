@@ -139,6 +139,25 @@ __global__ __launch_bounds__(kW, RTB_RNE_WAVES) void k_rne(RneParams rp, const D
     rne_tile<NJ, MDH, ALLREV>(rp, (ConstLinks)links_g, NJ, rne_stride(NJ), blockIdx.x, q, qd, qdd, tau, lds, threadIdx.x);
 }
 
+// Persistent form of k_rne (rtbhip_tune("rne_persist", 1)): the grid is sized to the chip (three waves per SIMD) and every wave walks
+// tiles blockIdx.x, + gridDim.x, ... .  The loop the comment above warns about, made safe the way k_ik does it: the link-table pointer is
+// laundered once per trip, so the scalar loads stay inside the trip (the scalar cache serves them) instead of being hoisted into SGPRs that
+// do not exist.  What it buys: no workgroup dispatch between tiles (a slot that finishes a tile starts the next one at once).
+template <int NJ, bool MDH, bool ALLREV>
+__global__ __launch_bounds__(kW, RTB_RNE_WAVES) void k_rne_persist(RneParams rp, const DevLink *links_g, const double *__restrict__ q,
+                                                   const double *__restrict__ qd, const double *__restrict__ qdd,
+                                                   double *__restrict__ tau)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int64_t tiles = (rp.N + kW - 1) / kW;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        ConstLinks l = (ConstLinks)links_g;
+        asm volatile("" : "+s"(l));
+        rne_tile<NJ, MDH, ALLREV>(rp, l, NJ, rne_stride(NJ), tile, q, qd, qdd, tau, lds, threadIdx.x);
+        __syncthreads();
+    }
+}
+
 // qd = NULL on an all-revolute chain (Dynamics.gravload: qd = qdd = 0; Dynamics.itorque: qd = 0, no gravity): every link's
 // angular velocity is zero, so the forward recursion is the acceleration-only one of rne_device.h (ACC) from link 0 -- about
 // half its fp64 operations -- with gravity entering as the base's linear acceleration; the backward recursion is the usual one.
@@ -166,9 +185,10 @@ __global__ __launch_bounds__(kW) void k_rne_rt(RneParams rp, const DevLink *link
     }
 }
 
-namespace { int g_rne_tiles_per_wave = 1; }
+namespace { int g_rne_tiles_per_wave = 1; int g_rne_persist = 0; }
 void rne_tune(const char *key, int value)
 {
+    if (std::string(key) == "rne_persist") g_rne_persist = value < 0 ? 0 : (value > 4 ? 4 : value);      // waves per SIMD of the persistent grid, 0 = one tile per workgroup
     if (std::string(key) == "rne_tiles_per_wave") g_rne_tiles_per_wave = value < 1 ? 1 : value;
 }
 
@@ -180,6 +200,15 @@ static void launch_nj(bool mdh, bool allrev, dim3 grid, size_t lds, hipStream_t 
         if (mdh) hipLaunchKernelGGL((k_rne_atrest<NJ, true>), grid, dim3(kW), lds, s, rp, links, q, qdd, tau);
         else hipLaunchKernelGGL((k_rne_atrest<NJ, false>), grid, dim3(kW), lds, s, rp, links, q, qdd, tau);
         return;
+    }
+    if (g_rne_persist && allrev) {
+        int cus = 0;
+        if (device_cu_count(&cus) == RTBHIP_OK && (int64_t)grid.x > (int64_t)cus * 4 * g_rne_persist) {
+            const dim3 pg((unsigned)(cus * 4 * g_rne_persist));          // g_rne_persist waves per SIMD
+            if (mdh) hipLaunchKernelGGL((k_rne_persist<NJ, true, true>), pg, dim3(kW), lds, s, rp, links, q, qd, qdd, tau);
+            else hipLaunchKernelGGL((k_rne_persist<NJ, false, true>), pg, dim3(kW), lds, s, rp, links, q, qd, qdd, tau);
+            return;
+        }
     }
     if (mdh && allrev) hipLaunchKernelGGL((k_rne<NJ, true, true>), grid, dim3(kW), lds, s, rp, links, q, qd, qdd, tau);
     else if (mdh) hipLaunchKernelGGL((k_rne<NJ, true, false>), grid, dim3(kW), lds, s, rp, links, q, qd, qdd, tau);
