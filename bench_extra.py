@@ -22,7 +22,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "robotics-toolbox-python_amd")]
 
-from benchlib import protect_stdout, HBM_PEAK_GBS, FP64_VALU_PEAK_TFLOPS, Ranks, spawn_ranks_if_needed, bench_argv, ensure_library  # noqa: E402
+from benchlib import protect_stdout, HBM_PEAK_GBS, FP64_VALU_PEAK_TFLOPS, Ranks, spawn_ranks_if_needed, bench_argv, ensure_library, pmc_traffic  # noqa: E402
 
 
 def ev_time(fn, steps, warmup):
@@ -128,6 +128,9 @@ def main():
                 "roofline": {"bound": "hbm", "achieved": 224.0 * N / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": 224.0 * N / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": 224 * N,
                              "kernel": "k_rne<7,MDH,all-revolute> on rank 0's rows"}}
+        if N == 1250000:        # the committed PMC passes are of this shard size
+            tr, src = pmc_traffic(ROOT, "r03_pmc_rne.json")
+            line["roofline"]["traffic"], line["roofline"]["traffic_source"] = tr, src
         if world > 1:
             pad = torch.zeros((sb.max_count, 7), dtype=torch.float64, device=q.device)
             pad[:N] = hold["tau"]
@@ -395,9 +398,13 @@ def main():
             ql = np.clip(c.qlim, -2 * np.pi, 2 * np.pi)
             qs.append(torch.from_numpy(np.random.default_rng(4 + i + 1000 * rank).uniform(ql[0], ql[1], (N, c.n))).cuda())
         hold = {}
+        # the legs before this one leave torch's caching allocator full of blocks of other sizes; it then serves this leg's 32 result
+        # tensors per call (7.1 GB) by splitting them and falls back to hipMalloc inside the timed loop (visit r3g: 2.6 ms per step
+        # against 1.45 ms of kernels; the leg alone: 1.49 ms).  Start from an empty cache; the warm-up calls size it for this leg.
+        torch.cuda.empty_cache()
         def fleet_step():
             hold["out"] = rtbhip.fleet_fkine_jacob(chs, qs)
-        elapsed, avg = rk.timed_steps(fleet_step, max(3, args.steps // 2), 2)
+        elapsed, avg = rk.timed_steps(fleet_step, max(3, args.steps // 2), 3)
         _, best = ev_time(fleet_step, 3, 0)
         step_ms = elapsed / max(3, args.steps // 2) * 1e3
         byts = sum(N * (8 * c.n + 128 + 48 * c.n) for c in chs)

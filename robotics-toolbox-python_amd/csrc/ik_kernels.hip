@@ -81,6 +81,8 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
     unsigned long long pool_next = 0, pool_end = 0;   // wave-uniform: targets reserved by this wave and not started yet
     unsigned long long pool_live = 0;                 // flat schedule, wave-uniform: bit k = item pool_next + k was drawn, is still worth starting and has not been started
     const bool flat = p.flat_chunks > 0;              // wave-uniform
+    bool evidence = false;                            // flat schedule, wave-uniform: one of this wave's own chunk-0 items has FAILED -- first chunks do fail in this batch
+    bool c0_out = false;                              // flat schedule, wave-uniform: the device-wide counter has passed the chunk-0 numbers
     unsigned long long st_iters = 0, st_passes = 0, st_lane = 0, st_items = 0;   // diagnostics (p.stats), wave-uniform
     bool first = true;
     unsigned tick = 0;
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
             __syncthreads();
             ik_finalize<NJ>(st, sh, lane, p, qlim, q_out, success, iters, searches, residual);   // phase C
             if (flat && ((busy >> lane) & 1ull) && sh.res[lane] == 1) ik_flat_publish(p.flat_done, sh.tgt[lane], sh.chunk[lane]);
+            if (flat && !evidence) evidence = __any(((busy >> lane) & 1ull) && sh.res[lane] == 2 && sh.chunk[lane] == 0);
             const unsigned long long freed = __ballot(((busy >> lane) & 1ull) && sh.res[lane] != 0);
             if (freed) quiet = 0;
             busy &= ~freed;
@@ -138,9 +141,12 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
             }
             // flat schedule, once the chunk-0 items are all out: the item numbers left are later chunks -- speculation for other waves' targets --
             // so the wave's own next searches (D2) come first and numbers are drawn (D1) only for the lanes still idle after that
-            const bool late = flat && pool_next >= (unsigned long long)p.flat_n;
+            const bool late = flat && c0_out;
             for (int step = 0; step < 2; ++step) {
             if ((step == 0) != late) {
+                // (flat schedule: later-chunk numbers are drawn only by waves that have seen a first chunk fail.  Where first chunks do not fail --
+                // the ik_benchmark-notebook setting: every first search succeeds -- nobody draws them, nothing is started on speculation
+                // that the whole batch contradicts, and the launch behaves like the plain schedule: 0.53 -> 0.71 ms per 1e5 targets without this)
                 if ((!exhausted || pend_item != kIkNoItem) && idle) {                       // phase D1: fresh targets
                     const unsigned long long freeslots = ~busy;
                     // free slots >= idle lanes (every busy slot keeps a lane); the per-pass cap spreads a batch
@@ -159,9 +165,17 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                         // flat schedule: while chunk-0 numbers are being drawn, exactly as many as this pass starts (nothing is hoarded: every
                         // one of them is alive); afterwards 64 per draw, each lane looking at one (a later-chunk item whose target has already
                         // succeeded is dead on arrival), and up to four draws per pass while draws come back with nothing alive
-                        if (late) nf = __popcll(idle);
+                        if (c0_out) nf = __popcll(idle);
+                        // (the gate is on DRAWING later-chunk numbers; numbers already drawn and alive are started whenever lanes are idle)
                         for (int round = 0; (round < 4 || busy == 0) && pool_live == 0 && !drained; ++round) {   // (a wave with nothing else to do keeps drawing)
-                            const unsigned long long want = pool_next < (unsigned long long)p.flat_n ? (unsigned long long)nf : 64ull;
+                            if (!c0_out) {           // a look at the counter before drawing: a wave without evidence must not draw later-chunk numbers
+                                unsigned long long peek = 0;
+                                if (lane == 0) peek = ik_aload(counter);
+                                const unsigned plo = __shfl((unsigned)(peek & 0xffffffffu), 0), phi = __shfl((unsigned)(peek >> 32), 0);
+                                c0_out = (((unsigned long long)phi << 32) | plo) >= (unsigned long long)p.flat_n;
+                            }
+                            if (c0_out && !evidence) break;
+                            const unsigned long long want = !c0_out ? (unsigned long long)nf : 64ull;
                             unsigned long long got = 0;
                             if (lane == 0) got = atomicAdd(counter, want);
                             const unsigned lo = __shfl((unsigned)(got & 0xffffffffu), 0);
@@ -169,6 +183,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                             got = ((unsigned long long)hi << 32) | lo;
                             pool_next = got < NN ? got : NN;
                             if (got + want >= NN) drained = true;
+                            if (got + want >= (unsigned long long)p.flat_n) c0_out = true;
                             const unsigned long long id = got + (unsigned long long)lane;
                             pool_live = __ballot((unsigned long long)lane < want && id < NN && ik_flat_live(p, (uint32_t)id));
                         }
@@ -272,6 +287,9 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                 }
             }
         }
+        // flat schedule: a wave without evidence leaves once the chunk-0 numbers are out.  Every later chunk that is NEEDED belongs to a target whose
+        // first chunk failed, and the wave that saw that failure has evidence and stays until the counter is drained -- it draws what is left
+        if (flat && busy == 0 && !evidence && pool_live == 0 && c0_out) break;
         if (busy == 0 && exhausted && pend_item == kIkNoItem) {
             if (!sharing) break;
             // sharing: out of work -- take a ticket, then wait on this ticket's own word for a range or for the EXIT mark
@@ -615,7 +633,11 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
         const bool flat_fits = fp.chunks > 1 && fp.chunks < 250 && (long long)N * fp.chunks < (1ll << 32) - 4096;
         // automatic: the batch is resident at once (a wave cannot trade targets) AND large enough that waves hold several targets each -- below
         // that a wave's 64 lanes already serve its one or two targets' searches in parallel and the temporaries would only add latency
-        const bool flat_on = flat_fits && (g_ik_flat == 2 || (g_ik_flat == 1 && N <= 3 * gmax * kWave && N >= 4 * gmax));
+        // ... AND converged searches can still be rejected (joint limits): that is what makes first chunks fail (Panda defaults: a search succeeds
+        // with p = 0.27, 28 % of the targets fail their first four).  Without the rejection practically every first search succeeds, no later
+        // chunk is ever needed, and the few waves that do see a failed first chunk would have to drain the whole dead item range by themselves
+        // (ik_benchmark-notebook setting, 1e5 targets: 0.60 ms plain, 0.98 flat) -- the plain schedule is the right one there
+        const bool flat_on = flat_fits && (g_ik_flat == 2 || (g_ik_flat == 1 && N <= 3 * gmax * kWave && N >= 4 * gmax && p.reject_jl != 0));
         if (flat_on) {
             const size_t rows = (size_t)N * fp.chunks;
             auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -623,6 +645,7 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
             const size_t o_vit = o_vok + up(rows * sizeof(int32_t)), o_vse = o_vit + up(rows * sizeof(int32_t)), total = o_vse + up(rows * sizeof(int32_t));
             char *blk = nullptr;
             {
+                if (pool_keep_cached() != RTBHIP_OK) (void)hipGetLastError();       // the rows' block stays in the pool between calls
                 hipError_t e = hipMallocAsync((void **)&blk, total, s);
                 if (e != hipSuccess) return hip_fail(e, "hipMallocAsync (ik flat schedule)");
             }

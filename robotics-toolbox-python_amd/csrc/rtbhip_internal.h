@@ -110,6 +110,7 @@ struct Affine;
 void chain_tail(const Chain *c, const Affine &tool, double out12[12]);
 void note_launch(int grid, int block, int lds);
 int device_cu_count(int *cus);
+int pool_keep_cached();    // the current device's default stream-ordered pool keeps freed blocks (release threshold raised once per device)
 
 // ---------------------------------------------------------------- the host-pointer boundary (hostpipe.cpp)
 // Row-chunked, double-buffered H2D -> kernel -> D2H over two persistent slots (streams, device buffers, pinned staging).

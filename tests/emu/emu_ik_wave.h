@@ -12,6 +12,8 @@ struct EmuWave {
     bool exhausted = false, first = true, done = false, drained = false;
     unsigned long long pool_next = 0, pool_end = 0;
     unsigned long long pool_live = 0;      // flat schedule: live, unstarted numbers of the last draw (bit k = number pool_next + k)
+    bool evidence = false;                 // flat schedule: one of this wave's own chunk-0 items has failed
+    bool c0_out = false;                   // flat schedule: the counter has passed the chunk-0 numbers
     unsigned tick = 0;
     long long passes = 0, iters = 0, lane_iters_useful = 0;
     long long quiet = 0;       // the kernel's watchdog counter, replayed: a false fire fails the run (-4)
@@ -85,7 +87,10 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
                 for (int l = 0; l < kWave; ++l) ik_finalize<NJ>(w.st[l], w.sh, l, p, qlim, q_out, success, iters, searches, residual);
                 if (flat)
                     for (int l = 0; l < kWave; ++l)
-                        if (((w.busy >> l) & 1ull) && w.sh.res[l] == 1) ik_flat_publish(p.flat_done, w.sh.tgt[l], w.sh.chunk[l]);
+                        if ((w.busy >> l) & 1ull) {
+                            if (w.sh.res[l] == 1) ik_flat_publish(p.flat_done, w.sh.tgt[l], w.sh.chunk[l]);
+                            if (w.sh.res[l] == 2 && w.sh.chunk[l] == 0) w.evidence = true;
+                        }
                 const unsigned long long freed = ballot(w, [&](int l) { return ((w.busy >> l) & 1ull) && w.sh.res[l] != 0; });
                 if (freed) w.quiet = 0;
                 w.busy &= ~freed;
@@ -104,7 +109,7 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
                     }
                     idle = ballot(w, [&](int l) { return w.st[l].status == kIkIdle; });
                 }
-                const bool late = flat && w.pool_next >= (unsigned long long)p.flat_n;      // the kernel's order of D1 / D2 (ik_kernels.hip)
+                const bool late = flat && w.c0_out;      // the kernel's order of D1 / D2 (ik_kernels.hip)
                 for (int step = 0; step < 2; ++step) {
                 if ((step == 0) != late) {
                     if ((!w.exhausted || w.pend_item != kIkNoItem) && idle) {
@@ -118,13 +123,16 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
                         int flat_off[kWave] = {0};
                         if (flat && !w.exhausted) {
                             const unsigned long long NN = (unsigned long long)p.N;
-                            if (late) nf = __builtin_popcountll(idle);
+                            if (w.c0_out) nf = __builtin_popcountll(idle);
                             for (int round = 0; (round < 4 || w.busy == 0) && w.pool_live == 0 && !w.drained; ++round) {
-                                const unsigned long long want = w.pool_next < (unsigned long long)p.flat_n ? (unsigned long long)nf : 64ull;
+                                if (!w.c0_out) w.c0_out = counter >= (unsigned long long)p.flat_n;
+                                if (w.c0_out && !w.evidence) break;
+                                const unsigned long long want = !w.c0_out ? (unsigned long long)nf : 64ull;
                                 const unsigned long long got = counter;
                                 counter += want;
                                 w.pool_next = got < NN ? got : NN;
                                 if (got + want >= NN) w.drained = true;
+                                if (got + want >= (unsigned long long)p.flat_n) w.c0_out = true;
                                 w.pool_live = 0;
                                 for (int l = 0; l < kWave; ++l) {
                                     const unsigned long long id = got + (unsigned long long)l;
@@ -236,6 +244,7 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
                 w.pend_item = x; w.first = true;                               // a pass at the next turn starts it
                 continue;
             }
+            if (p.flat_chunks > 0 && w.busy == 0 && !w.evidence && w.pool_live == 0 && w.c0_out) { w.done = true; --live; continue; }
             if (w.busy == 0 && w.exhausted) { w.done = true; --live; continue; }
             if (++w.quiet > ik_patience(p, s_last)) return -4;   // the kernel would overwrite valid results with its NaN markers here
             w.iters++;

@@ -631,6 +631,18 @@ def test_ik_flat_schedule_equals_sequential_searches(flavour, N, waves, slimit, 
     for x, y in zip(a, b):
         nt.assert_array_equal(x, y)
     assert a[1].sum() < N and st[0] > 0
+    # the regime in which first chunks (almost) never fail -- the ik_benchmark-notebook setting, k = 0.1 without joint-limit rejection:
+    # waves without a failed first chunk of their own do not draw later chunks and leave; drawn-but-unstarted numbers must still start
+    ok_T = np.delete(Tep, np.s_[::9], axis=0)
+    a2 = emu.ik(ets, ok_T, slimit=slimit, flavour=flavour, seed=41, joint_limits=False, k=0.1)
+    os.environ.update(EMU_IK_FLAT="1", EMU_IK_PASS_MASK="3", EMU_IK_FLAT_L0=str(l0), EMU_IK_FLAT_LEN=str(length))
+    try:
+        b2 = emu.ik(ets, ok_T, slimit=slimit, flavour=flavour, seed=41, joint_limits=False, k=0.1, waves=waves)
+    finally:
+        for k in ("EMU_IK_FLAT", "EMU_IK_PASS_MASK", "EMU_IK_FLAT_L0", "EMU_IK_FLAT_LEN"):
+            del os.environ[k]
+    for x, y in zip(a2, b2):
+        nt.assert_array_equal(x, y)
 
 
 @pytest.mark.parametrize("flavour", [0, 1])
