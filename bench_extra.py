@@ -461,7 +461,9 @@ def main():
             chs17, qs17 = chs[:-1] + arms, qs[:-1] + [qy, qy]
             def fleet17():
                 hold["out17"] = rtbhip.fleet_fkine_jacob(chs17, qs17)
-            avg17, best17 = ev_time(fleet17, max(3, args.steps // 2), 2)
+            hold.pop("out", None)
+            torch.cuda.empty_cache()                                # as above: the 34 result tensors of this leg have other sizes
+            avg17, best17 = ev_time(fleet17, max(3, args.steps // 2), 3)
             byts17 = sum(N * (8 * c.n + 128 + 48 * c.n) for c in chs[:-1]) + N * (8 * yumi.n + 2 * (128 + 48 * 8))
             T17, J17 = hold["out17"]
             chk = [yumi.ets(end=e) for e in ends]                   # the same branches with path-local joint numbers

@@ -4,7 +4,7 @@
 # SQ counters of k_rne.  Every step has its own timeout.
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r3g
+O=$R/gpurun_out/${VISIT:-r3g}
 mkdir -p $O
 cd $R
 timeout 1200 python -m pytest tests -m gpu -q -rf --timeout 600 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
