@@ -236,6 +236,13 @@ int rtbhip_dyn_upload(rtbhip_dyn_t dyn, int32_t device); /* as rtbhip_chain_uplo
 int rtbhip_rne(rtbhip_dyn_t dyn, const double *q, const double *qd, const double *qdd, int64_t N,
                const double *grav3, const double *fext6, double *tau, int32_t mem, void *stream);
 
+/* DHRobot.rne(..., base_wrench=True) -> rne_python (robot/DHRobot.py:1409-1412, 1765-1770), batched: the torques as rtbhip_rne and
+ * wbase (N,6) = [R_1 f_1, R_1 n_1], the force and moment link 1 exerts on the base, rotated into frame 0 -- what the backward
+ * recursion of rtbhip_rne holds when it ends.  (The reference allocates wbase as (N,n), so its own call only works for six-joint
+ * robots; here wbase is (N,6) for any n.)  Served by the run-time-n kernel: correct for every chain, not the fast path. */
+int rtbhip_rne_base_wrench(rtbhip_dyn_t dyn, const double *q, const double *qd, const double *qdd, int64_t N,
+                           const double *grav3, const double *fext6, double *tau, double *wbase, int32_t mem, void *stream);
+
 /* The Dynamics-mixin terms the reference derives from repeated rne calls, one fused
  * kernel each, all passes of a configuration in one lane:
  *   rtbhip_inertia   Dynamics.inertia  (robot/Dynamics.py:704-763): M (N,n,n); row i = tau for qdd = e_i, qd = 0, g = 0

@@ -30,7 +30,22 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REF_PKG = "/root/reference/src/roboticstoolbox"
 PYC_DIR = os.path.join(HERE, "_ref", "pyref")
 FILES = ["tools/types.py", "tools/p_servo.py", "robot/IK.py", "robot/ET.py", "robot/ETS.py"]
+# the DH side (load_dh): the classes a `DHRobot` is made of and the two DH models the benchmark configurations name
+DH_FILES = ["robot/Link.py", "robot/Gripper.py", "robot/RobotProto.py", "robot/DHLink.py", "robot/Dynamics.py", "robot/RobotKinematics.py",
+            "robot/BaseRobot.py", "robot/Robot.py", "robot/DHRobot.py", "models/DH/Puma560.py", "models/DH/Panda.py"]
 _LOADED = {}
+
+
+class _Placeholders(types.ModuleType):
+    """A module whose every attribute is an empty class: stands for the reference's dependencies that the numeric paths import but
+    never call (spatialgeometry shapes, ansitable, the plotting back-ends, the URDF / xacro readers)."""
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        cls = type(name, (), {"__init__": lambda self, *a, **k: None})
+        setattr(self, name, cls)
+        return cls
 
 
 def _pyc(rel):
@@ -41,11 +56,15 @@ def available():
     return all(os.path.exists(os.path.join(REF_PKG, f)) or os.path.exists(_pyc(f)) for f in FILES)
 
 
+def dh_available():
+    return available() and all(os.path.exists(os.path.join(REF_PKG, f)) or os.path.exists(_pyc(f)) for f in DH_FILES)
+
+
 def compile_pyc():
     """The `refpy` recipe of oracle/Makefile: byte-compile the reference files from where they lie into oracle/_ref/pyref."""
     import py_compile
     os.makedirs(PYC_DIR, exist_ok=True)
-    for f in FILES:
+    for f in FILES + DH_FILES:
         py_compile.compile(os.path.join(REF_PKG, f), cfile=_pyc(f), dfile="roboticstoolbox/" + f, doraise=True)
 
 
@@ -64,19 +83,51 @@ def _exec(modname, rel):
     return mod
 
 
-_NAMES = ("spatialmath", "spatialmath.base", "qpsolvers", "roboticstoolbox", "roboticstoolbox.fknm", "roboticstoolbox.tools",
+class _SceneNode:
+    """spatialgeometry.SceneNode as far as robot/Link.py:62,155-160 and robot/BaseRobot.py:73-110 rely on it: a node with a local
+    transform `_T`, a parent and a list of children.  (The scene graph itself -- world transforms for a visualiser -- is not restated.)"""
+
+    def __init__(self, T=None, scene_parent=None, scene_children=None):
+        import numpy as np
+        self._T = np.eye(4) if T is None else np.asarray(T)
+        self._wT = np.eye(4)
+        self._scene_parent = scene_parent
+        self._scene_children = list(scene_children) if scene_children is not None else []
+
+    def _propogate_scene_tree(self):
+        pass
+
+    def _update_scene_tree(self, *a, **k):
+        pass
+
+
+class _SceneGroup(_SceneNode):
+    def __len__(self): return len(self._scene_children)
+    def __iter__(self): return iter(self._scene_children)
+    def __getitem__(self, i): return self._scene_children[i]
+    def append(self, x): self._scene_children.append(x)
+
+
+_PLACEHOLDERS = ("spatialgeometry", "ansitable", "roboticstoolbox.backends", "roboticstoolbox.backends.Connector",
+                 "roboticstoolbox.backends.PyPlot", "roboticstoolbox.backends.PyPlot.EllipsePlot", "roboticstoolbox.tools.xacro",
+                 "roboticstoolbox.tools.URDF", "roboticstoolbox.tools.data", "roboticstoolbox.tools.params")
+_NAMES = ("spatialmath", "spatialmath.base", "spatialmath.base.argcheck", "spatialmath.base.symbolic", "qpsolvers", "roboticstoolbox",
+          "roboticstoolbox.fknm", "roboticstoolbox.frne", "roboticstoolbox.tools",
           "roboticstoolbox.tools.types", "roboticstoolbox.tools.p_servo", "roboticstoolbox.robot", "roboticstoolbox.robot.IK",
-          "roboticstoolbox.robot.ET", "roboticstoolbox.robot.ETS")
+          "roboticstoolbox.robot.ET", "roboticstoolbox.robot.ETS", "roboticstoolbox.models", "roboticstoolbox.models.DH") + _PLACEHOLDERS + tuple(
+              "roboticstoolbox." + f[:-3].replace("/", ".") for f in DH_FILES)
 
 
-def load(fknm, tag):
-    """A namespace with the reference's `ET`, `ETS`, `IK` module, `SE3` stand-in ... whose `roboticstoolbox.fknm` is `fknm`."""
+def load(fknm, tag, frne=None):
+    """A namespace with the reference's `ET`, `ETS`, `IK` module, `SE3` stand-in ... whose `roboticstoolbox.fknm` is `fknm`.
+    With an `frne` module as well, the DH side is loaded too (`DHRobot`, `RevoluteDH` ..., `Puma560`, `PandaDH`): see load_dh."""
     if tag in _LOADED:
         return _LOADED[tag]
     saved = {k: sys.modules.get(k) for k in _NAMES}
     try:
         sm, smb = sm_standin.modules()
         sys.modules["spatialmath"], sys.modules["spatialmath.base"] = sm, smb
+        sys.modules["spatialmath.base.argcheck"], sys.modules["spatialmath.base.symbolic"] = smb.argcheck, smb.symbolic
         qps = types.ModuleType("qpsolvers")
 
         def solve_qp(*a, **k):
@@ -107,6 +158,8 @@ def load(fknm, tag):
         for name in ("IK_LM", "IK_NR", "IK_GN", "IK_QP", "IKSolution", "IKSolver"):
             setattr(rtb, name, getattr(ik, name))
         ns = types.SimpleNamespace(ET=et.ET, ETS=ets.ETS, IK=ik, SE3=sm.SE3, rtb=rtb, fknm=fknm, p_servo=ps, tag=tag)
+        if frne is not None:
+            _load_dh(ns, rtb, tools, robot, frne)
     finally:
         for k, v in saved.items():          # the classes keep their own references; the stand-ins must not leak to other importers
             if v is None:
@@ -115,6 +168,59 @@ def load(fknm, tag):
                 sys.modules[k] = v
     _LOADED[tag] = ns
     return ns
+
+
+def _load_dh(ns, rtb, tools, robot, frne):
+    """robot/Link.py ... robot/DHRobot.py and models/DH/{Puma560,Panda}.py executed unmodified; `roboticstoolbox.frne` is `frne`."""
+    sys.modules["roboticstoolbox.frne"] = frne
+    rtb.frne = frne
+    rtb.rtb_set_param = lambda *a, **k: None
+    for name in _PLACEHOLDERS:
+        m = _Placeholders(name)
+        m.__path__ = []
+        sys.modules[name] = m
+    sys.modules["roboticstoolbox.tools.params"].rtb_get_param = rtb.rtb_get_param
+    sys.modules["spatialgeometry"].SceneNode, sys.modules["spatialgeometry"].SceneGroup = _SceneNode, _SceneGroup
+    sys.modules["roboticstoolbox.backends"].load_backend = lambda *a, **k: None
+    import pathlib
+    sys.modules["roboticstoolbox.tools.data"].rtb_path_to_datafile = lambda *a, **k: pathlib.PurePosixPath("/rtb-data-not-installed", *[str(x) for x in a])
+    tools.xacro, tools.URDF = sys.modules["roboticstoolbox.tools.xacro"], sys.modules["roboticstoolbox.tools.URDF"]
+    rtb.backends = sys.modules["roboticstoolbox.backends"]
+    mods = {}
+    for rel in [f for f in DH_FILES if f.startswith("robot/")]:
+        short = rel[:-3].split("/")[-1]
+        mods[short] = _exec("roboticstoolbox.robot." + short, rel)
+        setattr(robot, short, mods[short])
+        if short == "Link":
+            rtb.Link, rtb.Link2, rtb.BaseLink = mods[short].Link, mods[short].Link2, mods[short].BaseLink
+        if short == "DHLink":
+            for nm in ("DHLink", "RevoluteDH", "PrismaticDH", "RevoluteMDH", "PrismaticMDH"):
+                setattr(rtb, nm, getattr(mods[short], nm))
+        if short == "Gripper":
+            rtb.Gripper = mods[short].Gripper
+        if short == "Robot":
+            rtb.Robot, rtb.Robot2 = mods[short].Robot, mods[short].Robot2
+    rtb.DHRobot = mods["DHRobot"].DHRobot
+    models = types.ModuleType("roboticstoolbox.models")
+    models.__path__ = []
+    sys.modules["roboticstoolbox.models"] = models
+    dh = types.ModuleType("roboticstoolbox.models.DH")
+    dh.__path__ = []
+    sys.modules["roboticstoolbox.models.DH"] = dh
+    models.DH = dh
+    rtb.models = models
+    dh.Puma560 = _exec("roboticstoolbox.models.DH.Puma560", "models/DH/Puma560.py").Puma560
+    dh.Panda = _exec("roboticstoolbox.models.DH.Panda", "models/DH/Panda.py").Panda
+    ns.frne, ns.DHRobot, ns.Puma560, ns.PandaDH, ns.mods = frne, rtb.DHRobot, dh.Puma560, dh.Panda, mods
+    for nm in ("DHLink", "RevoluteDH", "PrismaticDH", "RevoluteMDH", "PrismaticMDH"):
+        setattr(ns, nm, getattr(rtb, nm))
+
+
+def load_dh(fknm, frne, tag):
+    """The DH side as well: `ns.DHRobot`, `ns.RevoluteDH` ..., `ns.Puma560()`, `ns.PandaDH()` are the reference's own classes
+    (robot/DHRobot.py:35, robot/DHLink.py, robot/Dynamics.py, models/DH/*.py) with `roboticstoolbox.fknm` / `.frne` bound to the given
+    modules: `rtbhip.compat.fknm` / `.frne` for the thing under test, the reference's compiled extensions for the checker."""
+    return load(fknm, tag, frne=frne)
 
 
 def load_reference():

@@ -120,6 +120,65 @@ def simplify(x):
     return sympy.simplify(x) if issymbol(x) else x
 
 
+# ---- the further names robot/Link.py, DHLink.py, Dynamics.py, BaseRobot.py, Robot.py and DHRobot.py import (oracle/ref_classes.load_dh)
+def isvector(v, dim=None):
+    """spatialmath.base.argcheck.isvector: a 1-D (or 1 x n / n x 1) array-like of the given length."""
+    try:
+        a = np.asarray(v)
+    except Exception:
+        return False
+    if a.ndim == 2 and 1 in a.shape:
+        a = a.reshape(-1)
+    return a.ndim == 1 and a.dtype != object and (dim is None or a.shape[0] == dim)
+
+
+def ismatrix(m, shape):
+    """spatialmath.base.argcheck.ismatrix: an ndarray of that shape, None standing for any extent."""
+    if not isinstance(m, np.ndarray) or m.ndim != 2:
+        return False
+    return all(want is None or have == want for have, want in zip(m.shape, shape))
+
+
+def isscalar(x):
+    """spatialmath.base.argcheck.isscalar: a real number (int, float, numpy scalar) or a sympy expression."""
+    return isinstance(x, (int, float, np.integer, np.floating)) or issymbol(x)
+
+
+def getunit(v, unit="rad", dim=None):
+    """spatialmath.base.argcheck.getunit: the value(s) in radians."""
+    a = np.asarray(v, dtype=np.float64) if not np.isscalar(v) else v
+    if unit.lower().startswith("deg"):
+        return np.radians(a)
+    return a
+
+
+def transl(x, y=None, z=None):
+    """spatialmath.base.transl(x, y, z) / transl(v): the 4x4 of a pure translation (models/DH/Panda.py:159)."""
+    v = np.asarray(x, dtype=np.float64).reshape(-1) if y is None else np.array([x, y, z], dtype=np.float64)
+    T = np.eye(4)
+    T[:3, 3] = v
+    return T
+
+
+def islistof(value, what, n=None):
+    """spatialmath.base.argcheck.islistof: a list / tuple whose members all are `what` (a type or a predicate), of length n if given."""
+    if not isinstance(value, (list, tuple)):
+        return False
+    if n is not None and len(value) != n:
+        return False
+    if isinstance(what, type):
+        return all(isinstance(x, what) for x in value)
+    return all(what(x) for x in value)
+
+
+def rot2jac(R, representation=None):
+    """spatialmath.base.rot2jac: blkdiag(R, R) (robot/Dynamics.py, the operational-space terms)."""
+    J = np.zeros((6, 6))
+    J[:3, :3] = R
+    J[3:, 3:] = R
+    return J
+
+
 def _not_offered(name):
     def f(*a, **k):
         raise NotImplementedError("spatialmath stand-in: %s is not restated (oracle/sm_standin.py)" % name)
@@ -186,6 +245,40 @@ class SE3:
             return SE3(self.A @ other.A, check=False)
         return NotImplemented
 
+    def __imul__(self, other):
+        return self.__mul__(other)
+
+    # the constructors robot/DHRobot.py, DHLink.py and the models/DH files use
+    @classmethod
+    def Rx(cls, theta, unit="rad"): return cls(trotx(theta, unit), check=False)
+
+    @classmethod
+    def Ry(cls, theta, unit="rad"): return cls(troty(theta, unit), check=False)
+
+    @classmethod
+    def Rz(cls, theta, unit="rad"): return cls(trotz(theta, unit), check=False)
+
+    @classmethod
+    def Trans(cls, x, y=None, z=None):
+        v = np.asarray(x, dtype=np.float64).reshape(-1) if y is None else np.array([x, y, z], dtype=np.float64)
+        T = np.eye(4)
+        T[:3, 3] = v
+        return cls(T, check=False)
+
+    @classmethod
+    def Tx(cls, x): return cls.Trans(x, 0.0, 0.0)
+
+    @classmethod
+    def Ty(cls, y): return cls.Trans(0.0, y, 0.0)
+
+    @classmethod
+    def Tz(cls, z): return cls.Trans(0.0, 0.0, z)
+
+    def __eq__(self, other):
+        return isinstance(other, SE3) and len(self) == len(other) and all(np.array_equal(a, b) for a, b in zip(self._data, other._data))
+
+    __hash__ = None
+
 
 class SE2:
     """Only ever an isinstance target on the paths exercised (the 2-D classes ET2 / ETS2 are not run)."""
@@ -198,13 +291,29 @@ def modules():
     """(spatialmath, spatialmath.base) module objects to be placed in sys.modules while the reference files are loaded."""
     sm = types.ModuleType("spatialmath")
     smb = types.ModuleType("spatialmath.base")
-    for f in (trotx, troty, trotz, issymbol, getvector, getmatrix, verifymatrix, t2r, tr2jac, simplify):
+    for f in (trotx, troty, trotz, issymbol, getvector, getmatrix, verifymatrix, t2r, tr2jac, simplify, isvector, ismatrix, getunit, rot2jac, transl, islistof):
         setattr(smb, f.__name__, f)
-    for name in ("tr2rpy", "trot2", "transl2", "tr2xyt", "tr2jac2", "rotvelxform"):
+    for name in ("tr2rpy", "tr2eul", "trlog", "trot2", "transl2", "tr2xyt", "tr2jac2", "rotvelxform", "r2x", "rotvelxform_inv_dot", "numhess"):
         setattr(smb, name, _not_offered(name))
+    argcheck = types.ModuleType("spatialmath.base.argcheck")
+    for f in (getvector, getmatrix, verifymatrix, isscalar, isvector, ismatrix, getunit):
+        setattr(argcheck, f.__name__, f)
+    symbolic = types.ModuleType("spatialmath.base.symbolic")
+    symbolic.issymbol, symbolic.simplify = issymbol, simplify
+    # spatialmath.base.symbolic.sin / cos / sqrt: the sympy function for a symbol, math's otherwise (robot/DHRobot.py:1620, DHLink.py)
+    symbolic.sin = lambda x: sympy.sin(x) if issymbol(x) else math.sin(x)
+    symbolic.cos = lambda x: sympy.cos(x) if issymbol(x) else math.cos(x)
+    symbolic.sqrt = lambda x: sympy.sqrt(x) if issymbol(x) else math.sqrt(x)
+    symbolic.pi = (lambda: sympy.S.Pi) if sympy is not None else _not_offered("pi")
+    symbolic.zero = (lambda: sympy.S.Zero) if sympy is not None else _not_offered("zero")
+    symbolic.symbol = (lambda *a, **k: sympy.symbols(*a, **k)) if sympy is not None else _not_offered("symbol")
+    smb.argcheck, smb.symbolic = argcheck, symbolic
+    for name in ("Twist3", "SpatialAcceleration", "SpatialVelocity", "SpatialInertia", "SpatialForce"):   # import targets only
+        setattr(sm, name, type(name, (), {"__init__": lambda self, *a, **k: (_ for _ in ()).throw(
+            NotImplementedError("spatialmath stand-in: this class is not restated"))}))
     # used only by tools/p_servo.py's pure-Python fall-back, which never runs (Angle_Axis does not raise)
     smb.iszerovec = lambda v, tol=20: bool(np.linalg.norm(v) < tol * np.finfo(np.float64).eps)
     smb.norm = lambda v: float(np.linalg.norm(v))
-    smb.isscalar = np.isscalar
+    smb.isscalar = isscalar
     sm.SE3, sm.SE2, sm.base = SE3, SE2, smb
     return sm, smb

@@ -899,29 +899,45 @@ int rtbhip_dyn_destroy(rtbhip_dyn_t dyn)
     return RTBHIP_OK;
 }
 
-int rtbhip_rne(rtbhip_dyn_t dyn, const double *q, const double *qd, const double *qdd, int64_t N,
-               const double *grav3, const double *fext6, double *tau, int32_t mem, void *stream)
+static int rne_entry(const char *fn, rtbhip_dyn_t dyn, const double *q, const double *qd, const double *qdd, int64_t N,
+                     const double *grav3, const double *fext6, double *tau, double *wbase, bool want_wbase, int32_t mem, void *stream)
 {
     const std::shared_ptr<Dyn> d_owner = dyn_from_handle(dyn);
     Dyn *d = d_owner.get();
-    RTB_TRACE("rtbhip_rne");
-    if (!d) { set_error("rne: unknown dyn handle"); return RTBHIP_EINVAL; }
+    if (!d) { set_error(std::string(fn) + ": unknown dyn handle"); return RTBHIP_EINVAL; }
     DeviceScope dscope;
-    RTB_TRY(check_batch("rne", q, N, mem, &dscope));
-    if (!grav3) { set_error("rne: NULL gravity"); return RTBHIP_EINVAL; }
-    if (N > 0 && !tau) { set_error("rne: NULL tau"); return RTBHIP_EINVAL; }   // qd / qdd may be NULL (= zeros)
+    RTB_TRY(check_batch(fn, q, N, mem, &dscope));
+    if (!grav3) { set_error(std::string(fn) + ": NULL gravity"); return RTBHIP_EINVAL; }
+    if (N > 0 && !tau) { set_error(std::string(fn) + ": NULL tau"); return RTBHIP_EINVAL; }   // qd / qdd may be NULL (= zeros)
+    if (want_wbase && N > 0 && !wbase) { set_error(std::string(fn) + ": NULL wbase"); return RTBHIP_EINVAL; }
     if (N == 0) return RTBHIP_OK;
     const DevLink *links = nullptr;
     RTB_TRY(dyn_device_links(d, &links));
     if (mem == RTBHIP_MEM_DEVICE)
-        return launch_rne(d, links, q, qd, qdd, N, grav3, fext6, tau, (hipStream_t)stream);
+        return launch_rne(d, links, q, qd, qdd, N, grav3, fext6, tau, (hipStream_t)stream, wbase);
     HostIO io;
     const size_t row = (size_t)d->n * 8;
     io.add_in(q, row); io.add_in(qd, row); io.add_in(qdd, row);
     io.add_out(tau, row);
+    if (want_wbase) io.add_out(wbase, 6 * 8);
     return host_pipeline(io, N, [&](const void *const *din, void *const *dout, int64_t, int64_t rows, hipStream_t s) {
-        return launch_rne(d, links, (const double *)din[0], (const double *)din[1], (const double *)din[2], rows, grav3, fext6, (double *)dout[0], s);
+        return launch_rne(d, links, (const double *)din[0], (const double *)din[1], (const double *)din[2], rows, grav3, fext6, (double *)dout[0], s,
+                          want_wbase ? (double *)dout[1] : nullptr);
     });
+}
+
+int rtbhip_rne(rtbhip_dyn_t dyn, const double *q, const double *qd, const double *qdd, int64_t N,
+               const double *grav3, const double *fext6, double *tau, int32_t mem, void *stream)
+{
+    RTB_TRACE("rtbhip_rne");
+    return rne_entry("rne", dyn, q, qd, qdd, N, grav3, fext6, tau, nullptr, false, mem, stream);
+}
+
+int rtbhip_rne_base_wrench(rtbhip_dyn_t dyn, const double *q, const double *qd, const double *qdd, int64_t N,
+                           const double *grav3, const double *fext6, double *tau, double *wbase, int32_t mem, void *stream)
+{
+    RTB_TRACE("rtbhip_rne_base_wrench");
+    return rne_entry("rne_base_wrench", dyn, q, qd, qdd, N, grav3, fext6, tau, wbase, true, mem, stream);
 }
 
 int rtbhip_tree_create(const rtbhip_tree_group *groups, int32_t ng, rtbhip_tree_t *tree)

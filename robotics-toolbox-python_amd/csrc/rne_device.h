@@ -202,9 +202,19 @@ RTB_HD BwdOps bwd_ops(const LinkT &lt, int flags, int j, InQ qin, InQd qdin, InQ
 // the caller mirrors the column.  The terms left out are exact zeros of the general formulas (0 x + y = y), so the values are
 // those of the full pass (up to the sign of a zero); the mirrored half differs from the reference's separately rounded entries
 // by a few ulp.  ~2.3x fewer fp64 operations per column of a 7-joint arm.
-template <int NJ, bool MDH, bool FRICTION, bool ALLREV, bool HAVE_TRIG, bool ACC = false, class LinksP, class InQ, class InQd, class InQdd, class Out>
+// Base wrench (DHRobot.rne(base_wrench=True) -> rne_python, robot/DHRobot.py:1765-1770): the force and moment the first link
+// exerts on the base, `R_1 f_1` and `R_1 n_1` -- what the backward recursion holds when it ends, rotated into frame 0.  The
+// receiver is a functor `wout(k, v)`, k = 0..5 = (f, n); NoWrench compiles the epilogue away.
+struct NoWrench {
+    static constexpr bool on = false;
+    RTB_HD bool wanted() const { return false; }
+    RTB_HD void operator()(int, double) const {}
+};
+
+template <int NJ, bool MDH, bool FRICTION, bool ALLREV, bool HAVE_TRIG, bool ACC = false, class LinksP, class InQ, class InQd, class InQdd, class Out,
+          class WOut = NoWrench>
 RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_MAX_JOINTS], double (&ct)[NJ > 0 ? NJ : RTBHIP_MAX_JOINTS],
-                     V3 grav, V3 ftip, V3 ntip, InQ qin, InQd qdin, InQdd qddin, Out tau, int first = 0)
+                     V3 grav, V3 ftip, V3 ntip, InQ qin, InQd qdin, InQdd qddin, Out tau, int first = 0, WOut wout = WOut())
 {
     static_assert(!ACC || (ALLREV && NJ > 0 && HAVE_TRIG), "the acceleration-only pass is built for all-revolute chains with compile-time n");
     if constexpr (ACC) {
@@ -391,19 +401,27 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
         bc = bn;
         if (!PF && NJ > 0 && !RTB_RNE_NOFENCE) sched_fence();
     }
+    if constexpr (WOut::on && !ACC) {
+        if (wout.wanted()) {           // wave-uniform
+            const V3 fb = rot_fwd<MDH>(Rn, f), nb = rot_fwd<MDH>(Rn, nn);
+            wout(0, fb.x); wout(1, fb.y); wout(2, fb.z);
+            wout(3, nb.x); wout(4, nb.y); wout(5, nb.z);
+        }
+    }
 }
 
 // One sample, trig included (the single-pass kernels and the run-time-n path).
 // ATREST: the caller knows qd = 0 for every joint (rtbhip_rne with qd = NULL: Dynamics.gravload, Dynamics.itorque): the
 // acceleration-only recursion from link 0, whole backward pass (all-revolute chains with compile-time n)
-template <int NJ, bool MDH, bool FRICTION = true, bool ALLREV = false, bool ATREST = false, class LinksP, class InQ, class InQd, class InQdd, class Out>
-RTB_HD void rne_lane(LinksP links, int n_rt, V3 grav, V3 ftip, V3 ntip, InQ qin, InQd qdin, InQdd qddin, Out tau)
+template <int NJ, bool MDH, bool FRICTION = true, bool ALLREV = false, bool ATREST = false, class LinksP, class InQ, class InQd, class InQdd, class Out,
+          class WOut = NoWrench>
+RTB_HD void rne_lane(LinksP links, int n_rt, V3 grav, V3 ftip, V3 ntip, InQ qin, InQd qdin, InQdd qddin, Out tau, WOut wout = WOut())
 {
     constexpr int CAP = NJ > 0 ? NJ : RTBHIP_MAX_JOINTS;
     double st[CAP], ct[CAP];
     if constexpr (NJ > 0) rne_trig<NJ, ALLREV>(links, qin, st, ct);
     if constexpr (ATREST) rne_core<NJ, MDH, false, true, true, true>(links, n_rt, st, ct, grav, ftip, ntip, qin, qdin, qddin, tau, 0);
-    else rne_core<NJ, MDH, FRICTION, ALLREV, (NJ > 0)>(links, n_rt, st, ct, grav, ftip, ntip, qin, qdin, qddin, tau);
+    else rne_core<NJ, MDH, FRICTION, ALLREV, (NJ > 0)>(links, n_rt, st, ct, grav, ftip, ntip, qin, qdin, qddin, tau, 0, wout);
 }
 
 }  // namespace rtbhip

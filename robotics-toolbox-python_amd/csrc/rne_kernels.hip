@@ -20,6 +20,15 @@ struct RneParams {
     int64_t N;
     double grav[3];
     double fext[6];
+    double *wbase;       // (N, 6) base wrench, or NULL (served by the run-time-n kernel only)
+};
+
+// receiver of the base wrench in the run-time-n kernel: row `cfg` of rp.wbase
+struct WrenchRow {
+    static constexpr bool on = true;
+    double *row;
+    RTB_HD bool wanted() const { return row != nullptr; }
+    RTB_HD void operator()(int k, double v) const { row[k] = v; }
 };
 
 __device__ __forceinline__ int rne_stride(int n) { int s = 3 * n; return (s & 1) ? s : s + 1; }
@@ -101,6 +110,10 @@ __device__ __forceinline__ void rne_tile(const RneParams &rp, ConstLinks links, 
         if constexpr (ATREST)
             rne_lane<NJ, MDH, false, true, true>(links, n, grav, ftip, ntip, [&](int j) { return mine[j]; }, [&](int) { return 0.0; },
                               [&](int j) { return mine[2 * n + j]; }, [&](int j, double v) { mine[j] = v; });
+        else if constexpr (NJ == 0)
+            rne_lane<NJ, MDH, true, ALLREV>(links, n, grav, ftip, ntip, [&](int j) { return mine[j]; }, [&](int j) { return mine[n + j]; },
+                              [&](int j) { return mine[2 * n + j]; }, [&](int j, double v) { mine[j] = v; },
+                              WrenchRow{rp.wbase ? rp.wbase + (cfg0 + lane) * 6 : nullptr});
         else
             rne_lane<NJ, MDH, true, ALLREV>(links, n, grav, ftip, ntip, [&](int j) { return mine[j]; }, [&](int j) { return mine[n + j]; },
                               [&](int j) { return mine[2 * n + j]; }, [&](int j, double v) { mine[j] = v; });
@@ -223,13 +236,14 @@ static void launch_rt(bool mdh, dim3 grid, size_t lds, hipStream_t s, const RneP
 }
 
 int launch_rne(const Dyn *d, const DevLink *links, const double *q, const double *qd, const double *qdd,
-               int64_t N, const double *grav3, const double *fext6, double *tau, hipStream_t s)
+               int64_t N, const double *grav3, const double *fext6, double *tau, hipStream_t s, double *wbase)
 {
     if (N == 0) return RTBHIP_OK;
     RneParams rp;
     rp.n = d->n;
     rp.has_fext = fext6 != nullptr;
     rp.N = N;
+    rp.wbase = wbase;
     for (int i = 0; i < 3; i++) rp.grav[i] = grav3[i];
     for (int i = 0; i < 6; i++) rp.fext[i] = fext6 ? fext6[i] : 0.0;
     int stride = 3 * d->n;
@@ -239,7 +253,7 @@ int launch_rne(const Dyn *d, const DevLink *links, const double *q, const double
     const bool mdh = d->mdh != 0;
     bool allrev = true;
     for (const DevLink &l : d->links) allrev = allrev && l.sigma == 0;
-    const bool rt = d->n > 8 || tiles > 0x7fffffff;
+    const bool rt = d->n > 8 || tiles > 0x7fffffff || wbase != nullptr;
     int64_t g = rt ? (tiles + g_rne_tiles_per_wave - 1) / g_rne_tiles_per_wave : tiles;
     if (g > 0x7fffffff) g = 0x7fffffff;
     dim3 grid((unsigned)g);

@@ -168,7 +168,7 @@ int launch_fleet(const std::vector<FleetEntry> &entries, int frame, hipStream_t 
 
 int launch_rne(const Dyn *d, const DevLink *links, const double *q, const double *qd,
                const double *qdd, int64_t N, const double *grav3, const double *fext6, double *tau,
-               hipStream_t s);
+               hipStream_t s, double *wbase = nullptr);   // wbase (N,6): base wrench as well (run-time-n kernel)
 
 int launch_dyn(const Dyn *d, const DevLink *links, int mode, const double *q, const double *qd, const double *tq,
                int64_t N, const double *grav3, double *out, hipStream_t s);

@@ -71,6 +71,7 @@ SIGNATURES = {
     "rtbhip_dyn_create": (C.c_int, [_vp, _i32, _i32, C.POINTER(_u64)]),
     "rtbhip_dyn_destroy": (C.c_int, [_u64]),
     "rtbhip_rne": (C.c_int, [_u64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp]),
+    "rtbhip_rne_base_wrench": (C.c_int, [_u64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp]),
     "rtbhip_jacob_dot": (C.c_int, [_u64, _vp, _vp, _i64, _vp, _i32, _vp, _i32, _vp]),
     "rtbhip_jacob0_dot_analytical": (C.c_int, [_u64, _vp, _vp, _i64, _vp, _i32, _vp, _i32, _vp]),
     "rtbhip_jacob0_analytical": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _vp, _i32, _vp]),

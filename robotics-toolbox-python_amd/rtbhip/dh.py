@@ -328,9 +328,28 @@ class DHRobot(RobotKinematics):
         (reference robot/DHRobot.py:1373-1456 -> frne.frne core/frne.c:106-230).
         qd / qdd = None means zeros (no zero arrays are read by the kernel)."""
         if base_wrench:
-            # robot/DHRobot.py:1409-1412 sends base_wrench=True to rne_python (:1458-1796), a second, pure-Python formulation that no
-            # test, example or other module of the reference calls with this flag; not offered on the device path
-            raise NotImplementedError("rne(base_wrench=True) is the reference's pure-Python rne_python; not offered by the GPU backend")
+            # robot/DHRobot.py:1409-1412 sends base_wrench=True to rne_python (:1458-1796), which returns (tau, wbase) with
+            # wbase = [R_1 f_1, R_1 n_1] (:1765-1770).  That second, pure-Python formulation agrees with the compiled frne for standard
+            # DH chains without a base transform -- the case served here, from the backward recursion the kernel already runs.  Its
+            # modified-DH branch does not (operator precedence at :1649 rotates only the first term of the linear acceleration; the
+            # torques it returns differ from DHRobot.rne's) and with a base it enters gravity with the opposite sign (:1597 against
+            # :1591); neither is reproduced.  The reference allocates wbase as (N, n) (:1557), so its call only succeeds for six-joint
+            # robots; here wbase is (N, 6) for any n.  A prismatic joint's extension is q + offset as in frne (rne_python drops the
+            # offset, :1612).
+            if self.mdh:
+                raise NotImplementedError("rne(base_wrench=True): the reference's rne_python disagrees with its own frne for modified-DH "
+                                          "chains (robot/DHRobot.py:1649); not offered")
+            if self.base is not None and not np.array_equal(self.base, np.eye(4)):
+                raise NotImplementedError("rne(base_wrench=True) with a base transform: the reference's rne_python enters gravity with the "
+                                          "opposite sign there (robot/DHRobot.py:1597); not offered")
+            arrs, N, single, tm, ptr, stream, mem, dev = self._dyn_args([q, qd, qdd])
+            gc = self._gravity_c(gravity)
+            f = None if fext is None else np.ascontiguousarray(np.asarray(fext, dtype=np.float64).reshape(6))
+            tau = self._empty((N, self.n), tm, dev)
+            wb = self._empty((N, 6), tm, dev)
+            check(lib().rtbhip_rne_base_wrench(self._dyn_handle(), ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2]), N, host_ptr(gc),
+                                               host_ptr(f), ptr(tau), ptr(wb), mem, stream))
+            return (tau[0], wb[0]) if single else (tau, wb)
         arrs, N, single, tm, ptr, stream, mem, dev = self._dyn_args([q, qd, qdd])
         gc = self._gravity_c(gravity)
         f = None if fext is None else np.ascontiguousarray(np.asarray(fext, dtype=np.float64).reshape(6))

@@ -52,6 +52,38 @@ extern "C" int emu_rne(rtbhip_dyn_t h, const double *q, const double *qd, const 
     return 0;
 }
 
+// the base wrench of rtbhip_rne_base_wrench: the run-time-n lane function with the wrench receiver, as k_rne_rt runs it
+struct EmuWrench {
+    static constexpr bool on = true;
+    double *row;
+    bool wanted() const { return row != nullptr; }
+    void operator()(int k, double v) const { row[k] = v; }
+};
+
+extern "C" int emu_rne_base_wrench(rtbhip_dyn_t h, const double *q, const double *qd, const double *qdd, int64_t N,
+                                   const double *grav3, const double *fext6, double *tau, double *wbase)
+{
+    const std::shared_ptr<Dyn> d_owner = dyn_from_handle(h);
+    Dyn *d = d_owner.get();
+    if (!d) return -1;
+    V3 g = v3(grav3[0], grav3[1], grav3[2]);
+    V3 f = fext6 ? v3(fext6[0], fext6[1], fext6[2]) : v3(0, 0, 0);
+    V3 nt = fext6 ? v3(fext6[3], fext6[4], fext6[5]) : v3(0, 0, 0);
+    const DevLink *links = d->links.data();
+    const int n = d->n;
+    for (int64_t s = 0; s < N; ++s) {
+        const double *a = q + s * n, *b = qd ? qd + s * n : nullptr, *c = qdd ? qdd + s * n : nullptr;
+        double *o = tau + s * n;
+        auto qi = [&](int j) { return a[j]; };
+        auto qdi = [&](int j) { return b ? b[j] : 0.0; };
+        auto qddi = [&](int j) { return c ? c[j] : 0.0; };
+        auto out = [&](int j, double v) { o[j] = v; };
+        if (d->mdh) rne_lane<0, true, true, false>(links, n, g, f, nt, qi, qdi, qddi, out, EmuWrench{wbase + s * 6});
+        else rne_lane<0, false, true, false>(links, n, g, f, nt, qi, qdi, qddi, out, EmuWrench{wbase + s * 6});
+    }
+    return 0;
+}
+
 extern "C" int emu_dyn(rtbhip_dyn_t h, int mode, const double *q, const double *qd, const double *tq, int64_t N,
                        const double *grav3, double *out)
 {

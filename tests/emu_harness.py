@@ -86,6 +86,7 @@ def lib():
         _lib.rtbhip_chain_set_q_width.argtypes = [_u64, _i32]
         _lib.emu_kin.argtypes = [_u64, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _i32]
         _lib.emu_rne.argtypes = [_u64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32]
+        _lib.emu_rne_base_wrench.argtypes = [_u64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]
         _lib.emu_kin_hess.argtypes = [_u64, _vp, _i64, _vp, _i32, _vp]
         _lib.emu_kin_hess_tile.argtypes = [_u64, _vp, _i64, _vp, _i32, _i32, _vp]
         _lib.emu_diff.argtypes = [_u64, _i32, _i32, _vp, _vp, _i64, _vp, _i32, _vp]
@@ -182,6 +183,23 @@ def rne(L24, mdh, q, qd, qdd, grav_c, fext=None, force_generic=False):
     rc = lib().emu_rne(h.value, _p(q), _p(qd), _p(qdd), q.shape[0], _p(g), _p(f), _p(tau), int(force_generic))
     assert rc == 0
     return tau
+
+
+def rne_base_wrench(L24, mdh, q, qd, qdd, grav_c, fext=None):
+    """(tau, wbase) as rtbhip_rne_base_wrench's kernel (the run-time-n lane function with the wrench receiver) computes them."""
+    L = np.ascontiguousarray(L24, dtype=np.float64).reshape(-1, 24)
+    n = L.shape[0]
+    h = _u64(0)
+    rc = lib().rtbhip_dyn_create(_p(L), n, int(mdh), C.byref(h))
+    assert rc == 0, lib().rtbhip_last_error()
+    q, qd, qdd = (None if x is None else np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1, n)) for x in (q, qd, qdd))
+    tau = np.full(q.shape, np.nan)
+    wb = np.full((q.shape[0], 6), np.nan)
+    g = np.ascontiguousarray(grav_c, dtype=np.float64)
+    f = None if fext is None else np.ascontiguousarray(fext, dtype=np.float64)
+    rc = lib().emu_rne_base_wrench(h.value, _p(q), _p(qd), _p(qdd), q.shape[0], _p(g), _p(f), _p(tau), _p(wb))
+    assert rc == 0
+    return tau, wb
 
 
 def hess_reg(ets, q, tool=None, frame=0, rounds=0):
