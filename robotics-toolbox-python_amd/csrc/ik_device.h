@@ -606,7 +606,10 @@ RTB_HD void ik_emit(const IkLane<NJ> &st, QA qa, const PD &p, QL qlim, int64_t t
 // waves: longest wave 219 -> 194 iterations, lane utilisation 0.72 -> 0.78 against a ring of 32).  The struct is sized so
 // that 8 waves per CU still fit the 160 KB of LDS for chains of up to 8 joints (20288 B with QR = 8): 32-bit target
 // indices, 16-bit b / res, 8-bit list, and only as many q rows as the kernel's joint count class needs.
-constexpr int kIkRing = 64;                 // outstanding (unaccounted) searches per slot
+#ifndef RTB_IK_RING
+#define RTB_IK_RING 64
+#endif
+constexpr int kIkRing = RTB_IK_RING;        // outstanding (unaccounted) searches per slot (a power of two)
 template <int QR>
 struct IkWaveSharedT {
     uint32_t vix[64];                       // work-item index = output row (the target itself without a work list; < 2^32)
