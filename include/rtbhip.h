@@ -282,6 +282,16 @@ int rtbhip_tree_upload(rtbhip_tree_t tree, int32_t device); /* as rtbhip_chain_u
 int rtbhip_tree_rne(rtbhip_tree_t tree, const double *q, const double *qd, const double *qdd, int64_t N,
                     const double *gravity3, double *tau, int32_t mem, void *stream);
 
+/* The Dynamics-mixin terms of an ETS robot -- Dynamics.inertia / coriolis / accel (robot/Dynamics.py:704-763, 765-861, 424-509), which the
+ * reference builds from n, n + n(n-1)/2 and n + 1 calls of Robot.rne per configuration -- one fused kernel each, every pass of a
+ * configuration in one lane:  M (N,n,n), row i = rne(q, 0, e_i, gravity 0);  C (N,n,n);  qdd (N,n) = M^-1 (torque - rne(q, qd, 0)) with
+ * gravity3 as rtbhip_tree_rne takes it.  gravload / itorque are rtbhip_tree_rne with NULL qd / qdd.  Robots of up to 12 joints
+ * (RTBHIP_ELIMIT beyond). */
+int rtbhip_tree_inertia(rtbhip_tree_t tree, const double *q, int64_t N, double *M, int32_t mem, void *stream);
+int rtbhip_tree_coriolis(rtbhip_tree_t tree, const double *q, const double *qd, int64_t N, double *C, int32_t mem, void *stream);
+int rtbhip_tree_accel(rtbhip_tree_t tree, const double *q, const double *qd, const double *torque, int64_t N,
+                      const double *gravity3, double *qdd, int32_t mem, void *stream);
+
 /* Mixed fleet (BASELINE config 5): n_chains independent chains, each with its own batch; one
  * launch walks all of them (block -> chain map).  q[c] is (N[c], q_width_c), T[c] (N[c],4,4),
  * J[c] (N[c],6,n_c).  The pointer tables themselves are HOST arrays. */

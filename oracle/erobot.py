@@ -148,3 +148,53 @@ def erobot_rne(links, q, qd, qdd, gravity=(0, 0, -9.81)):
                 gidx = [i for i, g in enumerate(link_groups) if pidx in g][0]
                 f[gidx] = f[gidx] + Ad(Xup[j]).T @ f[j]                      # SE3 * SpatialForce = Ad(T)^T f
     return Q
+
+
+# ---- the Dynamics-mixin terms of an ETS robot: restatement of robot/Dynamics.py over erobot_rne (TEST INFRASTRUCTURE, as the rest of
+# this file).  Pinned in tests/test_erobot_dynamics.py on the reference's OWN DynamicsMixin methods, executed unmodified
+# (oracle/ref_classes.load_dh) on a stand-in robot whose `rne` is erobot_rne: the loops below and the reference's loops must agree bit
+# for bit, since they call the same function with the same arguments in the same order.
+def erobot_inertia(links, q, gravity=(0, 0, -9.81)):
+    """Dynamics.inertia (robot/Dynamics.py:744-763): row i of M = rne(q, 0, e_i) without gravity."""
+    q = np.atleast_2d(np.asarray(q, dtype=np.float64))
+    n = q.shape[1]
+    out = np.zeros((q.shape[0], n, n))
+    for k, qk in enumerate(q):
+        out[k] = erobot_rne(links, np.tile(qk, (n, 1)), np.zeros((n, n)), np.eye(n), (0, 0, 0))
+    return out
+
+
+def erobot_coriolis(links, q, qd):
+    """Dynamics.coriolis (robot/Dynamics.py:811-861), statement for statement."""
+    q, qd = np.atleast_2d(np.asarray(q, dtype=np.float64)), np.atleast_2d(np.asarray(qd, dtype=np.float64))
+    n = q.shape[1]
+    Cm, Csq = np.zeros((q.shape[0], n, n)), np.zeros((q.shape[0], n, n))
+    z = np.zeros(n)
+    for k, qk in enumerate(q):
+        for i in range(n):
+            QD = np.zeros(n)
+            QD[i] = 1
+            Csq[k, :, i] = Csq[k, :, i] + erobot_rne(links, qk, QD, z, (0, 0, 0))[0]
+    for k, (qk, qdk) in enumerate(zip(q, qd)):
+        for i in range(n):
+            for j in range(i + 1, n):
+                QD = np.zeros(n)
+                QD[i] = 1
+                QD[j] = 1
+                tau = erobot_rne(links, qk, QD, z, (0, 0, 0))[0]
+                Cm[k, :, j] = Cm[k, :, j] + (tau - Csq[k, :, j] - Csq[k, :, i]) * qdk[i] / 2
+                Cm[k, :, i] = Cm[k, :, i] + (tau - Csq[k, :, j] - Csq[k, :, i]) * qdk[j] / 2
+        Cm[k] = Cm[k] + Csq[k] @ np.diag(qdk)
+    return Cm
+
+
+def erobot_accel(links, q, qd, torque, gravity=(0, 0, -9.81)):
+    """Dynamics.accel (robot/Dynamics.py:483-505): solve(M, torque - rne(q, qd, 0))."""
+    q, qd, torque = (np.atleast_2d(np.asarray(x, dtype=np.float64)) for x in (q, qd, torque))
+    n = q.shape[1]
+    out = np.zeros((q.shape[0], n))
+    for k, (qk, qdk, tk) in enumerate(zip(q, qd, torque)):
+        M = erobot_rne(links, np.tile(qk, (n, 1)), np.zeros((n, n)), np.eye(n), (0, 0, 0))
+        tau = erobot_rne(links, qk, qdk, np.zeros(n), gravity)[0]
+        out[k] = np.linalg.solve(M, tk - tau)
+    return out

@@ -1043,6 +1043,54 @@ int rtbhip_accel(rtbhip_dyn_t dyn, const double *q, const double *qd, const doub
     return dyn_entry("accel", dyn, 2, q, qd, torque, N, grav3, qdd, mem, stream);
 }
 
+/* the same terms for an ETS robot (link tree): Dynamics.inertia / coriolis / accel over Robot.rne */
+static int tree_dyn_entry(const char *fn, rtbhip_tree_t tree, int mode, const double *q, const double *qd, const double *tq,
+                          int64_t N, const double *grav3, double *out, int32_t mem, void *stream)
+{
+    const std::shared_ptr<Tree> t_owner = tree_from_handle(tree);
+    Tree *t = t_owner.get();
+    RTB_TRACE((std::string("rtbhip_") + fn).c_str());
+    if (!t) { set_error(std::string(fn) + ": unknown tree handle"); return RTBHIP_EINVAL; }
+    DeviceScope dscope;
+    RTB_TRY(check_batch(fn, q, N, mem, &dscope));
+    if (N > 0 && !out) { set_error(std::string(fn) + ": NULL output"); return RTBHIP_EINVAL; }
+    if (N > 0 && mode >= 1 && !qd) { set_error(std::string(fn) + ": NULL qd"); return RTBHIP_EINVAL; }
+    if (N > 0 && mode == 2 && (!tq || !grav3)) { set_error(std::string(fn) + ": NULL torque/gravity"); return RTBHIP_EINVAL; }
+    if (N == 0) return RTBHIP_OK;
+    const DevGroup *groups = nullptr;
+    RTB_TRY(tree_device_groups(t, &groups));
+    if (mem == RTBHIP_MEM_DEVICE)
+        return launch_tree_dyn(t, groups, mode, q, qd, tq, N, grav3, out, (hipStream_t)stream);
+    Staging st;
+    const size_t n = (size_t)t->n, bytes = (size_t)N * n * 8, obytes = mode == 2 ? bytes : bytes * n;
+    void *dq, *dqd = nullptr, *dtq = nullptr, *dout;
+    RTB_TRY(st.in(q, bytes, &dq));
+    if (mode >= 1) RTB_TRY(st.in(qd, bytes, &dqd));
+    if (mode == 2) RTB_TRY(st.in(tq, bytes, &dtq));
+    RTB_TRY(st.out(obytes, &dout));
+    RTB_TRY(launch_tree_dyn(t, groups, mode, (const double *)dq, (const double *)dqd, (const double *)dtq, N, grav3,
+                            (double *)dout, nullptr));
+    RTB_HIP(hipDeviceSynchronize());
+    RTB_TRY(fetch(out, dout, obytes));
+    return RTBHIP_OK;
+}
+
+int rtbhip_tree_inertia(rtbhip_tree_t tree, const double *q, int64_t N, double *M, int32_t mem, void *stream)
+{
+    return tree_dyn_entry("tree_inertia", tree, 0, q, nullptr, nullptr, N, nullptr, M, mem, stream);
+}
+
+int rtbhip_tree_coriolis(rtbhip_tree_t tree, const double *q, const double *qd, int64_t N, double *Cm, int32_t mem, void *stream)
+{
+    return tree_dyn_entry("tree_coriolis", tree, 1, q, qd, nullptr, N, nullptr, Cm, mem, stream);
+}
+
+int rtbhip_tree_accel(rtbhip_tree_t tree, const double *q, const double *qd, const double *torque, int64_t N,
+                      const double *gravity3, double *qdd, int32_t mem, void *stream)
+{
+    return tree_dyn_entry("tree_accel", tree, 2, q, qd, torque, N, gravity3, qdd, mem, stream);
+}
+
 int rtbhip_fleet_fkine_jacob(const rtbhip_chain_t *chains, int32_t n_chains, const double *const *q,
                              const int64_t *N, int32_t frame, double *const *T, double *const *J,
                              int32_t mem, void *stream)

@@ -106,8 +106,9 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, cons
         // the reference's order of operations ~1e-15 of max|C| (tests: oracle.coriolis_dh statement for statement, emu and
         // GPU, velocities from 1e-9 to 1e9).  Its rounding error scales with (max|qd|)^2 max|h| / s, the reference's with the
         // largest single term |h_rjk qd_j|: for a row whose nonzero velocities span more than 2^16 the two can differ by that
-        // ratio, so such rows -- any one of them sends its whole wave there; with normally distributed velocities that is ~1 % of
-        // the waves (a threshold of 2^12 sent 17 % of them) -- take the reference's own scheme below instead.
+        // ratio, so such rows take the reference's own scheme below instead -- each row on its own (a wave that holds such a row, ~1 % of
+        // the waves with normally distributed velocities, runs both bodies under the execution mask), so that a row's result never depends
+        // on which other rows share its tile.
         // qd in registers: the kernel may keep the input row in the C tile itself, which the first pass starts to overwrite
         double qdv[NJ], vmax = 0.0;
 #pragma unroll
@@ -120,11 +121,12 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, cons
         if (!(vmax > 0.0) || !(vmax < 1.7e308)) ex = 0;
         ex = ex > 400 ? 400 : (ex < -400 ? -400 : ex);
         const double sc = ldexp(1.0, ex);
-        const double inv4s = 0.25 / sc;
+        // (a row at rest is exactly zero, as in the reference -- not the rounding difference of the two probes)
+        const double inv4s = vmax > 0.0 || vmax != vmax ? 0.25 / sc : 0.0;
         bool wide = false;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) wide = wide || (qdv[j] != 0.0 && fabs(qdv[j]) * 65536.0 < vmax);
-        if (!wave_any(wide)) {
+        auto polar = [&]() {
 #pragma unroll 1
         for (int k = 0; k < NJ; ++k) {
             dyn_opaque<NJ>(st, ct);
@@ -134,7 +136,8 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, cons
             rne_core<NJ, MDH, false, ALLREV, true>(links, NJ, st, ct, zero, zero, zero, qin, [&](int j) { return j == k ? qdv[j] - sc : qdv[j]; },
                                      [&](int) { return 0.0; }, [&](int r, double v) { mA[r * NJ + k] = (mA[r * NJ + k] - v) * inv4s; });
         }
-        } else {
+        };
+        auto reference_scheme = [&]() {
         // Dynamics.py:828-856 regrouped so that ONE n x n tile per lane suffices (the reference keeps Csq and C):
         //   C[:,k] = sum_{j != k} (T_jk - Csq_k - Csq_j) qd_j / 2 + Csq_k qd_k
         //          = 1/2 sum_{j != k} T_jk qd_j + Csq_k (2 qd_k - S / 2) - U / 2,   S = sum_j qd_j,  U = sum_j Csq_j qd_j
@@ -168,7 +171,12 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, cons
                                          });
             }
         }
-        }
+        };
+        // the common case (no such row in the wave) stays one straight wave-uniform body; only a wave that holds a wide row pays for the
+        // per-lane choice (measured: the per-lane branch around the common case alone cost 7 % of the kernel)
+        if (!wave_any(wide)) polar();
+        else if (!wide) polar();
+        else reference_scheme();
     }
 }
 

@@ -20,7 +20,7 @@
 // transform but not the motion subspace (robot/ET.py:592-608 ignores `flip`); no friction, no motor
 // inertia; gravity enters as the base acceleration -g (:1804-1807).
 #pragma once
-#include "rne_device.h"
+#include "dyn_device.h"
 
 namespace rtbhip {
 
@@ -61,15 +61,10 @@ template <class G> RTB_HD V3 inertia_rot(const G &g, V3 w)   // I_bar w
 
 // One sample.  groups: wave-uniform table; qin/qdin/qddin(column) -> double; tau(column, value);
 // slot(index) -> double& into this lane's kTreeSlotDoubles * nslots scratch (LDS on the GPU).
-template <int NG, class GroupsP, class InQ, class InQd, class InQdd, class Out, class Slot>
-RTB_HD void tree_rne_lane(GroupsP groups, int nslots, V3 gravity, InQ qin, InQd qdin, InQdd qddin, Out tau, Slot slot)
+// joint angles -> sin/cos up front (branch-free reduction; one wave-wide library fallback)
+template <int NG, class GroupsP, class InQ>
+RTB_HD void tree_trig(GroupsP groups, InQ qin, double (&sn)[NG], double (&cs)[NG])
 {
-    double sn[NG], cs[NG];
-    V3 Fl[NG], Fa[NG];
-    for (int k = 0; k < nslots; ++k)
-        for (int e = 12; e < 18; ++e) slot(k * kTreeSlotDoubles + e) = 0.0;
-
-    // ---- joint angles -> sin/cos up front (branch-free reduction; one wave-wide library fallback)
     {
         bool big = false;
 #pragma unroll
@@ -88,6 +83,16 @@ RTB_HD void tree_rne_lane(GroupsP groups, int nslots, V3 gravity, InQ qin, InQd 
         }
         sched_fence();
     }
+}
+
+// The two recursions with the sines and cosines supplied (the dynamics terms run several passes at one configuration).
+template <int NG, class GroupsP, class InQ, class InQd, class InQdd, class Out, class Slot>
+RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], const double (&cs)[NG], V3 gravity, InQ qin, InQd qdin, InQdd qddin,
+                          Out tau, Slot slot)
+{
+    V3 Fl[NG], Fa[NG];
+    for (int k = 0; k < nslots; ++k)
+        for (int e = 12; e < 18; ++e) slot(k * kTreeSlotDoubles + e) = 0.0;
 
     // ---- forward recursion (Robot.py:1822-1872)
     V3 vl = v3(0, 0, 0), va = v3(0, 0, 0), al = v3(0, 0, 0), aa = v3(0, 0, 0);   // state of the previous group
@@ -173,6 +178,140 @@ RTB_HD void tree_rne_lane(GroupsP groups, int nslots, V3 gravity, InQ qin, InQd 
             }
         }
         sched_fence();
+    }
+}
+
+template <int NG, class GroupsP, class InQ, class InQd, class InQdd, class Out, class Slot>
+RTB_HD void tree_rne_lane(GroupsP groups, int nslots, V3 gravity, InQ qin, InQd qdin, InQdd qddin, Out tau, Slot slot)
+{
+    double sn[NG], cs[NG];
+    tree_trig<NG>(groups, qin, sn, cs);
+    tree_rne_core<NG>(groups, nslots, sn, cs, gravity, qin, qdin, qddin, tau, slot);
+}
+
+// ---- the Dynamics-mixin terms of an ETS robot (robot/Dynamics.py:704-861, 424-509 on Robot.rne): every Newton-Euler pass the
+// reference makes for ONE configuration, in one lane, as dyn_device.h does for DH chains.
+//   mine : this lane's inputs [q (n) | qd (n) | torque (n)] (what the mode needs)      mA : n x n tile, row-major
+//   inertia   mA[i][:] = rne(q, 0, e_i, gravity 0)                    (the unsymmetrised rows the reference returns, :752-758)
+//   coriolis  mA = C(q, qd): the polar form / the reference's own 28-pass scheme, chosen per row exactly as dyn_device.h does
+//   accel     mA[0..n) = qdd = M^-1 (torque - rne(q, qd, 0))          (:492-505; M's lower triangle, LDL^T)
+template <int NG>
+RTB_HD void tree_opaque(double (&sn)[NG], double (&cs)[NG])
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int j = 0; j < NG; ++j) asm volatile("" : "+v"(sn[j]), "+v"(cs[j]));     // keeps each pass self-contained (dyn_device.h: dyn_opaque)
+#endif
+}
+
+// a[j] = v / a[j] += v for a wave-uniform run-time j (the tau column of a group) without indexing the register array
+template <int NG>
+RTB_HD void tree_put(double (&a)[NG], int j, double v)
+{
+#pragma unroll
+    for (int k = 0; k < NG; ++k) a[k] = (j == k) ? v : a[k];
+}
+template <int NG>
+RTB_HD void tree_add(double (&a)[NG], int j, double v)
+{
+#pragma unroll
+    for (int k = 0; k < NG; ++k) a[k] += (j == k) ? v : 0.0;
+}
+
+template <int NG, int MODE, class GroupsP, class Slot>
+RTB_HD void tree_dyn_lane(GroupsP groups, int nslots, const double *mine, double *mA, V3 grav, Slot slot)
+{
+    const V3 zero = v3(0, 0, 0);
+    auto qin = [&](int j) { return mine[j]; };
+    auto none = [&](int) { return 0.0; };
+    double sn[NG], cs[NG];
+    tree_trig<NG>(groups, qin, sn, cs);
+    if (MODE == kDynInertia) {
+#pragma unroll 1
+        for (int i = 0; i < NG; ++i) {
+            tree_opaque<NG>(sn, cs);
+            tree_rne_core<NG>(groups, nslots, sn, cs, zero, qin, none, [&](int j) { return j == i ? 1.0 : 0.0; },
+                              [&](int j, double v) { mA[i * NG + j] = v; }, slot);
+        }
+    }
+    if (MODE == kDynAccel) {
+        double b[NG];
+        tree_opaque<NG>(sn, cs);
+        tree_rne_core<NG>(groups, nslots, sn, cs, grav, qin, [&](int j) { return mine[NG + j]; }, none,
+                          [&](int j, double v) { tree_put<NG>(b, j, mine[2 * NG + j] - v); }, slot);
+#pragma unroll 1
+        for (int i = 0; i < NG; ++i) {
+            tree_opaque<NG>(sn, cs);
+            tree_rne_core<NG>(groups, nslots, sn, cs, zero, qin, none, [&](int j) { return j == i ? 1.0 : 0.0; },
+                              [&](int j, double v) { if (j <= i) mA[i * (i + 1) / 2 + j] = v; }, slot);
+        }
+        double x[NG], M[NG][NG];
+#pragma unroll
+        for (int r = 0; r < NG; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) M[r][c] = mA[r * (r + 1) / 2 + c];
+        ldl_solve<NG>(M, b, x);
+#pragma unroll
+        for (int j = 0; j < NG; ++j) mA[j] = x[j];
+    }
+    if (MODE == kDynCoriolis) {
+        // dyn_device.h, the same two schemes and the same per-row choice between them
+        double qdv[NG], vmax = 0.0;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) { qdv[j] = mine[NG + j]; vmax = fmax(vmax, fabs(qdv[j])); }
+        int ex = 0;
+        const double mant = frexp(vmax, &ex);
+        if (mant == 0.5) ex -= 1;
+        if (!(vmax > 0.0) || !(vmax < 1.7e308)) ex = 0;
+        ex = ex > 400 ? 400 : (ex < -400 ? -400 : ex);
+        const double sc = ldexp(1.0, ex);
+        const double inv4s = vmax > 0.0 || vmax != vmax ? 0.25 / sc : 0.0;
+        bool wide = false;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) wide = wide || (qdv[j] != 0.0 && fabs(qdv[j]) * 65536.0 < vmax);
+        auto polar = [&]() {
+#pragma unroll 1
+            for (int k = 0; k < NG; ++k) {
+                tree_opaque<NG>(sn, cs);
+                tree_rne_core<NG>(groups, nslots, sn, cs, zero, qin, [&](int j) { return j == k ? qdv[j] + sc : qdv[j]; }, none,
+                                  [&](int r, double v) { mA[r * NG + k] = v; }, slot);
+                tree_opaque<NG>(sn, cs);
+                tree_rne_core<NG>(groups, nslots, sn, cs, zero, qin, [&](int j) { return j == k ? qdv[j] - sc : qdv[j]; }, none,
+                                  [&](int r, double v) { mA[r * NG + k] = (mA[r * NG + k] - v) * inv4s; }, slot);
+            }
+        };
+        auto reference_scheme = [&]() {
+            double S = 0.0, U[NG];
+#pragma unroll
+            for (int j = 0; j < NG; ++j) { S += qdv[j]; U[j] = 0.0; }
+#pragma unroll 1
+            for (int i = 0; i < NG; ++i) {
+                const double qdi = dyn_pick<NG>(qdv, i), wi = 2.0 * qdi - 0.5 * S;
+                tree_opaque<NG>(sn, cs);
+                tree_rne_core<NG>(groups, nslots, sn, cs, zero, qin, [&](int j) { return j == i ? 1.0 : 0.0; }, none,
+                                  [&](int r, double v) { mA[r * NG + i] = v * wi; tree_add<NG>(U, r, v * qdi); }, slot);
+            }
+#pragma unroll
+            for (int r = 0; r < NG; ++r)
+#pragma unroll
+                for (int c = 0; c < NG; ++c) mA[r * NG + c] -= 0.5 * U[r];
+#pragma unroll 1
+            for (int i = 0; i < NG; ++i) {
+#pragma unroll 1
+                for (int j = i + 1; j < NG; ++j) {
+                    const double hi = 0.5 * dyn_pick<NG>(qdv, i), hj = 0.5 * dyn_pick<NG>(qdv, j);
+                    tree_opaque<NG>(sn, cs);
+                    tree_rne_core<NG>(groups, nslots, sn, cs, zero, qin, [&](int k) { return (k == i || k == j) ? 1.0 : 0.0; }, none,
+                                      [&](int r, double tq) {
+                                          mA[r * NG + j] += tq * hi;
+                                          mA[r * NG + i] += tq * hj;
+                                      }, slot);
+                }
+            }
+        };
+        if (!wave_any(wide)) polar();
+        else if (!wide) polar();
+        else reference_scheme();
     }
 }
 

@@ -118,4 +118,109 @@ int launch_tree_rne(const Tree *t, const DevGroup *groups, const double *q, cons
     return RTBHIP_OK;
 }
 
+// ---- Dynamics-mixin terms of an ETS robot: inertia / coriolis / accel, every pass of a configuration in one lane (tree_device.h:
+// tree_dyn_lane).  LDS per lane: the inputs the mode reads ([q] | [q, qd] | [q, qd, torque]) and an n x n tile, plus the tree's slots;
+// inputs arrive and results leave through the same coalesced tile copies as k_tree_rne.  Robots of up to 12 joints.
+constexpr int kTreeDynMax = 12;
+
+template <int NG, int MODE>
+__global__ __launch_bounds__(kWave, 1) void k_tree_dyn(TreeParams tp, const DevGroup *groups_g, const double *__restrict__ q,
+                                                       const double *__restrict__ qd, const double *__restrict__ tq,
+                                                       double *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    ConstGroups groups = (ConstGroups)groups_g;
+    const int lane = threadIdx.x;
+    constexpr int K = MODE == kDynInertia ? 1 : (MODE == kDynCoriolis ? 2 : 3);
+    constexpr int W = MODE == kDynAccel ? NG * (NG + 1) / 2 + NG : NG * NG;      // accel: packed lower triangle (>= n doubles: qdd leaves from its head)
+    constexpr int in_stride = (K * NG) | 1, w_stride = W | 1;
+    double *A = lds + kWave * in_stride;
+    double *slots = A + kWave * w_stride;
+    const int64_t cfg0 = (int64_t)blockIdx.x * kWave;
+    const int64_t left = tp.N - cfg0;
+    const int ncfg = left < kWave ? (int)left : kWave;
+    const int count = ncfg * NG;
+    {
+        const double *src[3] = {q + cfg0 * NG, qd ? qd + cfg0 * NG : nullptr, tq ? tq + cfg0 * NG : nullptr};
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double r[NG];
+#pragma unroll
+            for (int i = 0; i < NG; ++i) { const int f = lane + kWave * i; r[i] = (f < count && src[k]) ? src[k][f] : 0.0; }
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                const int f = lane + kWave * i;
+                const int row = f / NG, c = f - row * NG;
+                lds[row * in_stride + k * NG + c] = r[i];
+            }
+        }
+    }
+    __syncthreads();
+    if (lane < ncfg)
+        tree_dyn_lane<NG, MODE>(groups, tp.nslots, lds + lane * in_stride, A + lane * w_stride, v3(tp.grav[0], tp.grav[1], tp.grav[2]),
+                                [&](int i) -> double & { return slots[i * kWave + lane]; });
+    __syncthreads();
+    if (MODE == kDynAccel) flush_run(A, w_stride, NG, ncfg, out + cfg0 * NG, lane);
+    else flush_run(A, w_stride, NG * NG, ncfg, out + cfg0 * (NG * NG), lane);
+}
+
+template <int NG, int MODE>
+static hipError_t launch_tree_dyn_one(dim3 grid, hipStream_t s, int nslots, const TreeParams &tp, const DevGroup *g, const double *q,
+                                      const double *qd, const double *tq, double *out, size_t *lds_out)
+{
+    constexpr int K = MODE == kDynInertia ? 1 : (MODE == kDynCoriolis ? 2 : 3);
+    constexpr int W = MODE == kDynAccel ? NG * (NG + 1) / 2 + NG : NG * NG;
+    const size_t lds = (size_t)kWave * (((K * NG) | 1) + (W | 1) + kTreeSlotDoubles * nslots) * sizeof(double);
+    *lds_out = lds;
+    if (lds > 160 * 1024) return hipSuccess;          // reported by the caller
+    auto k = k_tree_dyn<NG, MODE>;
+    if (lds > 48 * 1024) { hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL(k, grid, dim3(kWave), lds, s, tp, g, q, qd, tq, out);
+    return hipSuccess;
+}
+
+template <int NG>
+static hipError_t launch_tree_dyn_ng(int mode, dim3 grid, hipStream_t s, int nslots, const TreeParams &tp, const DevGroup *g, const double *q,
+                                     const double *qd, const double *tq, double *out, size_t *lds)
+{
+    if (mode == kDynInertia) return launch_tree_dyn_one<NG, kDynInertia>(grid, s, nslots, tp, g, q, qd, tq, out, lds);
+    if (mode == kDynCoriolis) return launch_tree_dyn_one<NG, kDynCoriolis>(grid, s, nslots, tp, g, q, qd, tq, out, lds);
+    return launch_tree_dyn_one<NG, kDynAccel>(grid, s, nslots, tp, g, q, qd, tq, out, lds);
+}
+
+int launch_tree_dyn(const Tree *t, const DevGroup *groups, int mode, const double *q, const double *qd, const double *tq, int64_t N,
+                    const double *grav3, double *out, hipStream_t s)
+{
+    if (N == 0) return RTBHIP_OK;
+    if (t->n > kTreeDynMax) { set_error("tree inertia/coriolis/accel: this build handles robots of up to 12 joints"); return RTBHIP_ELIMIT; }
+    const int64_t tiles = (N + kWave - 1) / kWave;
+    if (tiles > 0x7fffffff) { set_error("tree inertia/coriolis/accel: batch too large for one launch"); return RTBHIP_ELIMIT; }
+    TreeParams tp;
+    tp.n = t->n; tp.nslots = t->nslots; tp.N = N;
+    for (int i = 0; i < 3; i++) tp.grav[i] = grav3 ? grav3[i] : 0.0;
+    dim3 grid((unsigned)tiles);
+    size_t lds = 0;
+    hipError_t e = hipSuccess;
+    switch (t->n) {
+    case 1: e = launch_tree_dyn_ng<1>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
+    case 2: e = launch_tree_dyn_ng<2>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
+    case 3: e = launch_tree_dyn_ng<3>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
+    case 4: e = launch_tree_dyn_ng<4>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
+    case 5: e = launch_tree_dyn_ng<5>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
+    case 6: e = launch_tree_dyn_ng<6>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
+    case 7: e = launch_tree_dyn_ng<7>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
+    case 8: e = launch_tree_dyn_ng<8>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
+    case 9: e = launch_tree_dyn_ng<9>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
+    case 10: e = launch_tree_dyn_ng<10>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
+    case 11: e = launch_tree_dyn_ng<11>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
+    default: e = launch_tree_dyn_ng<12>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
+    }
+    if (lds > 160 * 1024) { set_error("tree inertia/coriolis/accel: the robot needs more LDS than a CU has"); return RTBHIP_ELIMIT; }
+    note_launch((int)grid.x, kWave, (int)lds);
+    if (e != hipSuccess) return hip_fail(e, "k_tree_dyn launch");
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "k_tree_dyn launch");
+    return RTBHIP_OK;
+}
+
 }  // namespace rtbhip

@@ -82,6 +82,9 @@ SIGNATURES = {
     "rtbhip_tree_create": (C.c_int, [C.POINTER(rtbhip_tree_group), _i32, C.POINTER(_u64)]),
     "rtbhip_tree_destroy": (C.c_int, [_u64]),
     "rtbhip_tree_rne": (C.c_int, [_u64, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp]),
+    "rtbhip_tree_inertia": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _vp]),
+    "rtbhip_tree_coriolis": (C.c_int, [_u64, _vp, _vp, _i64, _vp, _i32, _vp]),
+    "rtbhip_tree_accel": (C.c_int, [_u64, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp]),
     "rtbhip_inertia": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _vp]),
     "rtbhip_coriolis": (C.c_int, [_u64, _vp, _vp, _i64, _vp, _i32, _vp]),
     "rtbhip_accel": (C.c_int, [_u64, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp]),

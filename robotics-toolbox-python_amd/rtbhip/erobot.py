@@ -327,3 +327,57 @@ class ERobot(RobotKinematics):
             ptr, stream, mem = host_ptr, None, MEM_HOST
         check(lib().rtbhip_tree_rne(self._handle(), ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2]), N, host_ptr(g), ptr(tau), mem, stream))
         return tau[0] if single else tau
+
+    # ---- the Dynamics-mixin terms (reference robot/Dynamics.py, which Robot inherits through BaseRobot): one fused kernel each
+    def _dyn_args(self, arrays):
+        """(arrays as (N,n), N, single, torch?, ptr, stream, mem, empty(shape))"""
+        n = self.n
+        tm = is_torch(arrays[0]) and arrays[0].is_cuda
+        if tm:
+            single = arrays[0].dim() == 1
+            arrs = [x.reshape(-1, n).contiguous() for x in arrays]
+        else:
+            single = as_numeric(arrays[0]).ndim == 1
+            arrs = [np.ascontiguousarray(as_numeric(x).reshape(-1, n)) for x in arrays]
+        N = arrs[0].shape[0]
+        if any(tuple(x.shape) != (N, n) for x in arrs):
+            raise ValueError("arguments must all be (%d,) or (N,%d)" % (n, n))
+        if tm:
+            import torch
+            _lib.note_device(arrs[0])
+            dev = arrs[0].device
+            return (arrs, N, single or N == 1, lambda x: C.c_void_p(x.data_ptr()), _lib.current_stream_ptr(), MEM_DEVICE,
+                    lambda shape: torch.empty(shape, dtype=torch.float64, device=dev))
+        return arrs, N, single or N == 1, host_ptr, None, MEM_HOST, _lib.host_empty
+
+    def gravload(self, q=None, gravity=None):
+        """tau_g(q) (reference Dynamics.gravload robot/Dynamics.py:863-922): rne(q, 0, 0)."""
+        return self.rne(q, None, None, gravity=gravity)
+
+    def itorque(self, q, qdd):
+        """M(q) qdd (reference Dynamics.itorque robot/Dynamics.py:1407-1465): rne(q, 0, qdd) without gravity."""
+        return self.rne(q, None, qdd, gravity=[0, 0, 0])
+
+    def inertia(self, q):
+        """Joint-space inertia matrix: (n,n) or (N,n,n) (reference Dynamics.inertia robot/Dynamics.py:704-763: n Robot.rne calls per
+        configuration, row i = rne(q, 0, e_i) without gravity; here all passes of a configuration in one lane, csrc/tree_device.h)."""
+        arrs, N, single, ptr, stream, mem, empty = self._dyn_args([q])
+        M = empty((N, self.n, self.n))
+        check(lib().rtbhip_tree_inertia(self._handle(), ptr(arrs[0]), N, ptr(M), mem, stream))
+        return M[0] if single else M
+
+    def coriolis(self, q, qd):
+        """Coriolis / centripetal matrix C(q, qd): (n,n) or (N,n,n) (reference Dynamics.coriolis robot/Dynamics.py:765-861:
+        n + n(n-1)/2 Robot.rne calls per configuration; here 2 n passes, the scheme of csrc/dyn_device.h)."""
+        arrs, N, single, ptr, stream, mem, empty = self._dyn_args([q, qd])
+        Cm = empty((N, self.n, self.n))
+        check(lib().rtbhip_tree_coriolis(self._handle(), ptr(arrs[0]), ptr(arrs[1]), N, ptr(Cm), mem, stream))
+        return Cm[0] if single else Cm
+
+    def accel(self, q, qd, torque, gravity=None):
+        """Forward dynamics qdd = M(q)^-1 (torque - rne(q, qd, 0)): (n,) or (N,n) (reference Dynamics.accel robot/Dynamics.py:424-509)."""
+        arrs, N, single, ptr, stream, mem, empty = self._dyn_args([q, qd, torque])
+        g = np.ascontiguousarray(self.gravity if gravity is None else np.asarray(gravity, dtype=np.float64).reshape(3))
+        qdd = empty((N, self.n))
+        check(lib().rtbhip_tree_accel(self._handle(), ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2]), N, host_ptr(g), ptr(qdd), mem, stream))
+        return qdd[0] if single else qdd

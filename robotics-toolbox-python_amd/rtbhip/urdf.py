@@ -276,16 +276,32 @@ class URDFRobot:
 
     def fkine_all(self, q, exclude=()):
         """Pose of every link frame (reference Robot.fkine_all robot/Robot.py:638-698): see ERobot.fkine_all."""
+        return self._tree(exclude).fkine_all(q)
+
+    def _tree(self, exclude=()):
         key = ("erobot", tuple(exclude))
         if key not in self._cache:
             self._cache[key] = self.erobot(exclude)
-        return self._cache[key].fkine_all(q)
+        return self._cache[key]
 
     def rne(self, q, qd=None, qdd=None, gravity=None, exclude=()):
-        key = ("erobot", tuple(exclude))
-        if key not in self._cache:
-            self._cache[key] = self.erobot(exclude)
-        return self._cache[key].rne(q, qd, qdd, gravity=gravity)
+        return self._tree(exclude).rne(q, qd, qdd, gravity=gravity)
+
+    # the Dynamics-mixin terms (reference robot/Dynamics.py over Robot.rne): see ERobot
+    def inertia(self, q, exclude=()):
+        return self._tree(exclude).inertia(q)
+
+    def coriolis(self, q, qd, exclude=()):
+        return self._tree(exclude).coriolis(q, qd)
+
+    def gravload(self, q, gravity=None, exclude=()):
+        return self._tree(exclude).gravload(q, gravity=gravity)
+
+    def itorque(self, q, qdd, exclude=()):
+        return self._tree(exclude).itorque(q, qdd)
+
+    def accel(self, q, qd, torque, gravity=None, exclude=()):
+        return self._tree(exclude).accel(q, qd, torque, gravity=gravity)
 
 
 def loadstr(urdf_string, **kw):

@@ -138,6 +138,47 @@ static void tree_run(const Tree *t, const double *q, const double *qd, const dou
                           [&](int i) -> double & { return slots[i]; });
     }
 }
+// Dynamics-mixin terms of an ETS robot: tree_device.h's tree_dyn_lane on the CPU (mode 0 inertia, 1 coriolis, 2 accel)
+template <int NG, int MODE>
+static void tree_dyn_run(const Tree *t, const double *q, const double *qd, const double *tq, int64_t N, V3 g, double *out)
+{
+    std::vector<double> slots((size_t)kTreeSlotDoubles * std::max(1, t->nslots));
+    constexpr int W = MODE == kDynAccel ? NG : NG * NG;
+    for (int64_t s = 0; s < N; ++s) {
+        double mine[3 * NG], A[NG * NG + NG];
+        for (int j = 0; j < NG; ++j) { mine[j] = q[s * NG + j]; mine[NG + j] = qd ? qd[s * NG + j] : 0.0; mine[2 * NG + j] = tq ? tq[s * NG + j] : 0.0; }
+        tree_dyn_lane<NG, MODE>(t->groups.data(), t->nslots, mine, A, g, [&](int i) -> double & { return slots[i]; });
+        for (int k = 0; k < W; ++k) out[s * W + k] = A[k];
+    }
+}
+template <int NG>
+static void tree_dyn_mode(int mode, const Tree *t, const double *q, const double *qd, const double *tq, int64_t N, V3 g, double *out)
+{
+    if (mode == 0) tree_dyn_run<NG, kDynInertia>(t, q, qd, tq, N, g, out);
+    else if (mode == 1) tree_dyn_run<NG, kDynCoriolis>(t, q, qd, tq, N, g, out);
+    else tree_dyn_run<NG, kDynAccel>(t, q, qd, tq, N, g, out);
+}
+extern "C" int emu_tree_dyn(const rtbhip_tree_group *groups, int ng, int mode, const double *q, const double *qd, const double *tq,
+                            int64_t N, const double *grav3, double *out)
+{
+    Tree t;
+    if (compile_tree(groups, ng, &t) != RTBHIP_OK) return -1;
+    V3 g = grav3 ? v3(grav3[0], grav3[1], grav3[2]) : v3(0, 0, 0);
+    switch (t.n) {
+    case 1: tree_dyn_mode<1>(mode, &t, q, qd, tq, N, g, out); break;
+    case 2: tree_dyn_mode<2>(mode, &t, q, qd, tq, N, g, out); break;
+    case 3: tree_dyn_mode<3>(mode, &t, q, qd, tq, N, g, out); break;
+    case 4: tree_dyn_mode<4>(mode, &t, q, qd, tq, N, g, out); break;
+    case 5: tree_dyn_mode<5>(mode, &t, q, qd, tq, N, g, out); break;
+    case 6: tree_dyn_mode<6>(mode, &t, q, qd, tq, N, g, out); break;
+    case 7: tree_dyn_mode<7>(mode, &t, q, qd, tq, N, g, out); break;
+    case 8: tree_dyn_mode<8>(mode, &t, q, qd, tq, N, g, out); break;
+    case 9: tree_dyn_mode<9>(mode, &t, q, qd, tq, N, g, out); break;
+    default: return -2;       // (10..12 joints are built for the device only: the host build of every size is slow)
+    }
+    return 0;
+}
+
 extern "C" int emu_tree_rne(const rtbhip_tree_group *groups, int ng, const double *q, const double *qd, const double *qdd,
                             int64_t N, const double *grav3, double *tau)
 {

@@ -294,6 +294,28 @@ def tree_rne(recs, q, qd, qdd, gravity):
     return tau
 
 
+def tree_dyn(recs, mode, q, qd=None, torque=None, gravity=None):
+    """mode 0 inertia (N,n,n), 1 coriolis (N,n,n), 2 accel (N,n) of an ETS robot: tree_device.h's tree_dyn_lane on the CPU."""
+    from rtbhip._lib import rtbhip_tree_group
+    ng = len(recs)
+    arr = (rtbhip_tree_group * ng)()
+    for k, r in enumerate(recs):
+        arr[k].parent, arr[k].kind, arr[k].flip, arr[k].jindex = r["parent"], r["kind"], r["flip"], r["jindex"]
+        arr[k].T[:] = list(np.ascontiguousarray(r["T"]).reshape(16))
+        arr[k].m = r["m"]
+        arr[k].h[:] = list(r["h"])
+        arr[k].I[:] = list(r["I"])
+    q, qd, torque = (None if x is None else np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1, ng)) for x in (q, qd, torque))
+    N = q.shape[0]
+    out = np.full((N, ng) if mode == 2 else (N, ng, ng), np.nan)
+    g = None if gravity is None else np.ascontiguousarray(gravity, dtype=np.float64)
+    f = lib().emu_tree_dyn
+    f.argtypes = [C.POINTER(rtbhip_tree_group), _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp]
+    rc = f(arr, ng, mode, _p(q), _p(qd), _p(torque), N, _p(g), _p(out))
+    assert rc == 0, rc
+    return out
+
+
 def dyn(L24, mdh, mode, q, qd=None, torque=None, grav_c=None):
     """mode 0 inertia (N,n,n), 1 coriolis (N,n,n), 2 accel (N,n): dyn_device.h's per-lane body on the CPU."""
     L = np.ascontiguousarray(L24, dtype=np.float64).reshape(-1, 24)
