@@ -64,7 +64,8 @@ def ik_roofline(lm_iterations_per_s):
 # upper bound of the arithmetic actually done (address, select and LDS-move instructions are in the count), i.e. the fraction is the share of
 # the chip's VALU issue slots the kernel fills.
 VALU_PER_UNIT = {"gravload": 833, "inertia": 3433, "coriolis": 10708, "accel": 3377, "tree_ur5": 1930, "jacob0_dot": 1692,
-                 "manipulability": 1512, "jacobm": 2732}
+                 "manipulability": 1512, "jacobm": 2732,
+                 "tree_inertia_ur5": 10078, "tree_coriolis_ur5": 26443, "tree_accel_ur5": 11667}      # profiles/r03_o_sq_tree_dyn.txt
 
 
 def valu_roofline(key, units_per_s, kernel, hbm_bytes_per_unit):
@@ -309,6 +310,19 @@ def main():
         print(json.dumps({"metric": "triples/sec (URDF UR5 Robot.rne, %d link groups)" % er.n, "value": N / (avg * 1e-3), "unit": "triples/s",
                           "n": N, "kernel_avg_ms": avg, "kernel_min_ms": best,
                           "roofline": valu_roofline("tree_ur5", N / (avg * 1e-3), "k_tree_rne<6>", byts)}), flush=True)
+        # the Dynamics-mixin terms of the same URDF arm (Dynamics.inertia / coriolis / accel over Robot.rne): k_tree_dyn<6, mode>
+        tq = qdd
+        for name, fn, byts, key in (("inertia", lambda: er.inertia(q), 8 * er.n + 8 * er.n * er.n, "tree_inertia_ur5"),
+                                    ("coriolis", lambda: er.coriolis(q, qd), 16 * er.n + 8 * er.n * er.n, "tree_coriolis_ur5"),
+                                    ("accel", lambda: er.accel(q, qd, tq), 32 * er.n, "tree_accel_ur5")):
+            avg, best = ev_time(fn, max(3, args.steps // 2), 2)
+            line = {"metric": "configurations/sec (URDF UR5 %s, Dynamics mixin over Robot.rne)" % name, "value": N / (avg * 1e-3),
+                    "unit": "configurations/s", "n": N, "kernel_avg_ms": avg, "kernel_min_ms": best}
+            if key in VALU_PER_UNIT:
+                line["roofline"] = valu_roofline(key, N / (avg * 1e-3), "k_tree_dyn<6,%s>" % name, byts)
+            else:
+                line["hbm_GBs"] = byts * N / (avg * 1e-3) / 1e9
+            print(json.dumps(line), flush=True)
 
     if "ik" in what:
         N = args.n_ik
