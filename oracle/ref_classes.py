@@ -60,12 +60,45 @@ def dh_available():
     return available() and all(os.path.exists(os.path.join(REF_PKG, f)) or os.path.exists(_pyc(f)) for f in DH_FILES)
 
 
+# the reference's own unit-test files that tests/test_reference_suite.py runs against the GPU backend
+REF_TESTS = "/root/reference/tests"
+TEST_FILES = ["test_ET.py", "test_ETS.py", "test_jacob.py", "test_IK.py"]
+
+
+def _test_pyc(name):
+    return os.path.join(HERE, "_ref", "pytests", name + "c")
+
+
+def tests_available():
+    return all(os.path.exists(os.path.join(REF_TESTS, f)) or os.path.exists(_test_pyc(f)) for f in TEST_FILES)
+
+
+def load_test_module(name):
+    """One of the reference's test files (tests/<name>.py) as a module object: executed from where it lies, or -- on the GPU box -- from
+    its byte-compiled copy under oracle/_ref/pytests (make -f oracle/Makefile refpy).  The caller installs the module shims first."""
+    fname = name + ".py"
+    src = os.path.join(REF_TESTS, fname)
+    modname = "reference_tests_" + name
+    if os.path.exists(src):
+        spec = importlib.util.spec_from_file_location(modname, src)
+    elif os.path.exists(_test_pyc(fname)):
+        spec = importlib.util.spec_from_loader(modname, importlib.machinery.SourcelessFileLoader(modname, _test_pyc(fname)))
+    else:
+        raise ImportError("neither %s nor its byte-compiled copy exists" % src)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def compile_pyc():
     """The `refpy` recipe of oracle/Makefile: byte-compile the reference files from where they lie into oracle/_ref/pyref."""
     import py_compile
     os.makedirs(PYC_DIR, exist_ok=True)
     for f in FILES + DH_FILES:
         py_compile.compile(os.path.join(REF_PKG, f), cfile=_pyc(f), dfile="roboticstoolbox/" + f, doraise=True)
+    os.makedirs(os.path.dirname(_test_pyc("x")), exist_ok=True)
+    for f in TEST_FILES:
+        py_compile.compile(os.path.join(REF_TESTS, f), cfile=_test_pyc(f), dfile="tests/" + f, doraise=True)
 
 
 def _exec(modname, rel):

@@ -171,6 +171,44 @@ def islistof(value, what, n=None):
     return all(what(x) for x in value)
 
 
+def tr2x(T, representation="rpy/xyz"):
+    """spatialmath.base.tr2x: [t, Gamma] -- the restatement the oracle already holds (oracle/oracle.py: tr2x)."""
+    from . import oracle as _o
+    return _o.tr2x(np.asarray(T, dtype=np.float64), representation)
+
+
+def numjac(f, x, dx=1e-8, SO=0, SE=0):
+    """spatialmath.base.numjac: forward-difference Jacobian of f at x.  f returns a vector, or -- SE=3 -- a 4x4 pose, in which case a
+    column is [dt / dx ; vex(dR R^T) / dx] (the spatial velocity per unit joint rate), or -- SO=3 -- a rotation matrix."""
+    x = np.asarray(x, dtype=np.float64)
+    f0 = np.asarray(f(x))
+    cols = []
+    for i in range(len(x)):
+        xi = x.copy()
+        xi[i] += dx
+        fi = np.asarray(f(xi))
+        if SE == 3 or SO == 3:
+            R0, Ri = f0[:3, :3], fi[:3, :3]
+            S = ((Ri - R0) / dx) @ R0.T
+            w = 0.5 * np.array([S[2, 1] - S[1, 2], S[0, 2] - S[2, 0], S[1, 0] - S[0, 1]])
+            cols.append(np.r_[(fi[:3, 3] - f0[:3, 3]) / dx, w] if SE == 3 else w)
+        else:
+            cols.append((fi - f0) / dx)
+    return np.array(cols).T
+
+
+def numhess(J, x, dx=1e-8):
+    """spatialmath.base.numhess: H[i] = (J(x + dx e_i) - J(x)) / dx."""
+    x = np.asarray(x, dtype=np.float64)
+    J0 = np.asarray(J(x))
+    out = []
+    for i in range(len(x)):
+        xi = x.copy()
+        xi[i] += dx
+        out.append((np.asarray(J(xi)) - J0) / dx)
+    return np.array(out)
+
+
 def rot2jac(R, representation=None):
     """spatialmath.base.rot2jac: blkdiag(R, R) (robot/Dynamics.py, the operational-space terms)."""
     J = np.zeros((6, 6))
@@ -190,8 +228,10 @@ class SE3:
     """spatialmath.SE3 as far as robot/ET.py, robot/ETS.py and robot/IK.py use it: construction from a 4x4 / a stack (with
     check=False), Empty() / append() (ETS.fkine, robot/ETS.py:1006-1017), isinstance, len, iteration, `.A`, `.inv()`, `.t`, `.R`, `*`."""
 
-    def __init__(self, arg=None, check=True):
-        if arg is None:
+    def __init__(self, arg=None, y=None, z=None, check=True):
+        if y is not None and z is not None:                   # SE3(x, y, z): a pure translation
+            self._data = [transl(float(arg), float(y), float(z))]
+        elif arg is None:
             self._data = [np.eye(4)]
         elif isinstance(arg, SE3):
             self._data = [a.copy() for a in arg._data]
@@ -259,6 +299,15 @@ class SE3:
     def Rz(cls, theta, unit="rad"): return cls(trotz(theta, unit), check=False)
 
     @classmethod
+    def RPY(cls, roll, pitch=None, yaw=None, order="zyx", unit="rad"):
+        """spatialmath SE3.RPY, zyx order: R = Rz(yaw) Ry(pitch) Rx(roll)."""
+        if pitch is None:
+            roll, pitch, yaw = roll
+        if order != "zyx":
+            raise NotImplementedError("spatialmath stand-in: SE3.RPY order %r is not restated" % order)
+        return cls(trotz(yaw, unit) @ troty(pitch, unit) @ trotx(roll, unit), check=False)
+
+    @classmethod
     def Trans(cls, x, y=None, z=None):
         v = np.asarray(x, dtype=np.float64).reshape(-1) if y is None else np.array([x, y, z], dtype=np.float64)
         T = np.eye(4)
@@ -291,9 +340,9 @@ def modules():
     """(spatialmath, spatialmath.base) module objects to be placed in sys.modules while the reference files are loaded."""
     sm = types.ModuleType("spatialmath")
     smb = types.ModuleType("spatialmath.base")
-    for f in (trotx, troty, trotz, issymbol, getvector, getmatrix, verifymatrix, t2r, tr2jac, simplify, isvector, ismatrix, getunit, rot2jac, transl, islistof):
+    for f in (trotx, troty, trotz, issymbol, getvector, getmatrix, verifymatrix, t2r, tr2jac, simplify, isvector, ismatrix, getunit, rot2jac, transl, islistof, tr2x, numjac, numhess):
         setattr(smb, f.__name__, f)
-    for name in ("tr2rpy", "tr2eul", "trlog", "trot2", "transl2", "tr2xyt", "tr2jac2", "rotvelxform", "r2x", "rotvelxform_inv_dot", "numhess"):
+    for name in ("tr2rpy", "tr2eul", "trlog", "trot2", "transl2", "tr2xyt", "tr2jac2", "rotvelxform", "r2x", "rotvelxform_inv_dot"):
         setattr(smb, name, _not_offered(name))
     argcheck = types.ModuleType("spatialmath.base.argcheck")
     for f in (getvector, getmatrix, verifymatrix, isscalar, isvector, ismatrix, getunit):

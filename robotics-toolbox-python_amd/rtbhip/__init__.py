@@ -15,6 +15,7 @@ CPU fallback: every call raises RtbHipError when librtbhip.so or a GPU is missin
 """
 from ._lib import RtbHipError, lib, device_count, tune, shard_range, last_launch, ik_target_base, trim  # noqa: F401
 from .et import ET, ETS, IKSolution, angle_axis, p_servo, hessian_from_jacobian  # noqa: F401
+from .ik import IKSolver, IK_NR, IK_GN, IK_LM, IK_QP  # noqa: F401
 from .dh import DHLink, DHRobot, RevoluteDH, PrismaticDH, RevoluteMDH, PrismaticMDH  # noqa: F401
 from .erobot import Link, ERobot  # noqa: F401
 from .poe import PoELink, PoERevolute, PoEPrismatic, PoERobot  # noqa: F401
@@ -24,6 +25,6 @@ from . import urdf  # noqa: F401
 from .fleet import fleet_fkine_jacob  # noqa: F401
 from .shard import ShardedBatch  # noqa: F401
 
-__all__ = ["ET", "ETS", "IKSolution", "angle_axis", "p_servo", "hessian_from_jacobian", "DHLink", "DHRobot", "RevoluteDH", "PrismaticDH", "RevoluteMDH",
+__all__ = ["ET", "ETS", "IKSolution", "IKSolver", "IK_NR", "IK_GN", "IK_LM", "IK_QP", "angle_axis", "p_servo", "hessian_from_jacobian", "DHLink", "DHRobot", "RevoluteDH", "PrismaticDH", "RevoluteMDH",
            "PrismaticMDH", "Link", "ERobot", "PoELink", "PoERevolute", "PoEPrismatic", "PoERobot", "RobotKinematics", "models", "urdf", "fleet_fkine_jacob", "ShardedBatch", "RtbHipError", "lib",
            "device_count", "tune", "shard_range", "last_launch", "ik_target_base", "trim"]

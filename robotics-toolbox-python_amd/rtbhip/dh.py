@@ -180,7 +180,7 @@ class DHRobot(RobotKinematics):
         robot/DHLink.py:633-673), base and tool included; the ETS lowering evaluated on the GPU is the same product (tests pin
         the two against each other).  The reference's signature is fkine(q, **kwargs) with the keywords unused."""
         self._refuse("fkine", **kwargs)
-        return self.ets().eval(q)
+        return self.ets().fkine(q)
 
     def fkine_all(self, q, old=None):
         """Poses of frames {0} (the base) to {n}: (n+1,4,4) or (N,n+1,4,4).  reference robot/DHRobot.py:1018-1064:

@@ -105,6 +105,32 @@ def p_servo(wTe, wTep, gain=1.0, threshold=0.1, method="angle-axis"):
     return v, (bool(arrived) if e.ndim == 1 else arrived)
 
 
+class SE3Array(np.ndarray):
+    """What `fkine` returns for host input: the (4,4) / (N,4,4) array itself, answering to the few attributes callers of the reference
+    use on the spatialmath.SE3 it returns there -- `.A` (the plain ndarray), `.t`, `.R`, `.inv()`, and a length / iteration over poses
+    for a stack.  Arithmetic stays NumPy's (no operator is redefined): compose poses with `@`."""
+
+    @property
+    def A(self): return np.asarray(self)
+    @property
+    def t(self): return np.asarray(self)[..., :3, 3]
+    @property
+    def R(self): return np.asarray(self)[..., :3, :3]
+
+    def inv(self):
+        a = np.asarray(self)
+        out = np.zeros_like(a)
+        Rt = np.swapaxes(a[..., :3, :3], -1, -2)
+        out[..., :3, :3] = Rt
+        out[..., :3, 3] = -np.einsum("...ij,...j->...i", Rt, a[..., :3, 3])
+        out[..., 3, 3] = 1.0
+        return out.view(SE3Array)
+
+
+def _poses(T):
+    return T.view(SE3Array) if isinstance(T, np.ndarray) else T
+
+
 class ET:
     """One elementary transform (reference robot/ET.py BaseET/ET)."""
 
@@ -114,10 +140,12 @@ class ET:
             if isinstance(eta, str) or not np.isscalar(eta) or isinstance(eta, complex):
                 raise TypeError("Symbolic value")  # symbolic chains stay on the reference's Python path
             eta = float(eta)
-            if unit == "deg" and axis[0] == "R":
+            if unit.lower().startswith("deg") and axis[0] == "R":          # robot/ET.py:59 (any spelling that starts with "deg")
                 eta = eta * math.pi / 180.0
         self.eta = eta
         self.isflip = bool(flip)
+        self.fknm = object()          # identity token: shared by copy(), fresh on deepcopy() -- what the reference's C handle is to its tests
+        self._jindex = None
         self.jindex = jindex
         self.qlim = None if qlim is None else np.asarray(qlim, dtype=np.float64).reshape(2)
         if axis == "SE3":
@@ -153,9 +181,59 @@ class ET:
     def isrotation(self): return self.axis[0] == "R"
     @property
     def istranslation(self): return self.axis[0] == "t"
+    @property
+    def iselementary(self):
+        """False for a general constant (ET.SE3), True for the six axis transforms (reference robot/ET.py:353-368)."""
+        return self.axis[0] != "S"
+
+    @property
+    def jindex(self): return self._jindex
+
+    @jindex.setter
+    def jindex(self, j):
+        if j is not None and (not isinstance(j, (int, np.integer)) or isinstance(j, bool) or j < 0):
+            raise ValueError("jindex is %r, must be an int >= 0" % (j,))          # robot/ET.py:496-501
+        self._jindex = None if j is None else int(j)
+
+    def A(self, q=0.0):
+        """The 4x4 of this transform at joint value q (reference ET.A robot/ET.py:560-583 -> fknm.ET_T core/fknm.cpp:1241-1281):
+        a constant returns a copy of its matrix; a joint is evaluated on the device as a one-element chain, `flip` included."""
+        if not self.isjoint:
+            return self.T.copy()
+        if isinstance(q, (list, tuple, np.ndarray)):
+            q = np.asarray(q, dtype=np.float64).reshape(-1)[0]
+        if not isinstance(q, (int, float, np.integer, np.floating)):
+            raise TypeError("Symbolic value")
+        one = ETS(ET(self.axis, flip=self.isflip, qlim=self.qlim))
+        return one.eval(np.array([float(q)]))
 
     def __mul__(self, other): return ETS(self) * other
     def __add__(self, other): return ETS(self) * other
+    def __eq__(self, other): return isinstance(other, ET) and repr(self) == repr(other)      # robot/ET.py:241-242
+    __hash__ = None
+
+    def __str__(self):
+        """The reference's short form (robot/ET.py:160-198): `Rx(88.41°)`, `tx(1.543)`, `tz(q3)`, `Rx(q)`; a general constant as its
+        translation and roll-pitch-yaw angles."""
+        if self.isjoint:
+            arg = "q" if self.jindex is None else "q%d" % self.jindex
+        elif self.axis == "SE3":
+            T = self.T
+            # roll-pitch-yaw, zyx order (spatialmath tr2rpy default), in degrees
+            if abs(abs(T[2, 0]) - 1.0) < 1e-12:
+                r, pch, y = 0.0, -math.asin(max(-1.0, min(1.0, T[2, 0]))), math.atan2(-T[0, 1], T[1, 1]) if T[2, 0] < 0 else -math.atan2(-T[0, 1], T[1, 1])
+            else:
+                r, pch, y = math.atan2(T[2, 1], T[2, 2]), -math.asin(T[2, 0]), math.atan2(T[1, 0], T[0, 0])
+            rpy = np.array([r, pch, y]) * 180.0 / math.pi
+            t = T[:3, 3]
+            ts = "%.4g, %.4g, %.4g" % tuple(t)
+            rs = "%.4g°, %.4g°, %.4g°" % tuple(rpy)
+            arg = (ts + "; " + rs) if (t.any() and rpy.any()) else (ts if t.any() else (rs if rpy.any() else ""))
+        elif self.isrotation:
+            arg = "%.4g°" % (self.eta * 180.0 / math.pi)
+        else:
+            arg = "%.4g" % self.eta
+        return "%s(%s)" % (self.axis, arg)
 
     def inv(self):
         """Inverse of this ET (reference robot/ET.py:413-445): a joint keeps its axis and toggles `flip`, a constant is
@@ -167,6 +245,15 @@ class ET:
         return ET(self.axis, -self.eta)
 
     def __repr__(self):
+        """`ET.Rx(eta=1.543, jindex=5, flip=True, qlim=array([-1.,  1.]))` (reference robot/ET.py:200-217)."""
+        parts = ["" if self.eta is None else "eta=%s" % self.eta,
+                 "T=%r" % self.T if self.axis == "SE3" else "",
+                 "" if self.jindex is None else "jindex=%d" % self.jindex,
+                 "" if not self.isflip else "flip=True",
+                 "" if self.qlim is None else "qlim=%r" % self.qlim]
+        return "ET.%s(%s)" % (self.axis, ", ".join(x for x in parts if x))
+
+    def _short(self):
         if self.axis == "SE3":
             return "SE3(...)"
         arg = "q%s" % ("" if self.jindex is None else self.jindex) if self.isjoint else "%.4g" % self.eta
@@ -187,6 +274,19 @@ class IKSolution:
     def __iter__(self):
         return iter((self.q, self.success, self.iterations, self.searches, self.residual, self.reason))
 
+    def __str__(self):
+        """The reference's one-line form (robot/IK.py:60-100): analytic solutions (no iterations, no searches) print without the counters."""
+        if self.q is not None:
+            q_str = np.array2string(np.asarray(self.q), separator=", ", formatter={"float": lambda x: "{:.4g}".format(0 if abs(x) < 1e-6 else x)})
+        else:
+            q_str = None
+        if self.iterations == 0 and self.searches == 0:
+            return "IKSolution: q=%s, success=True" % q_str if self.success else "IKSolution: q=%s, success=False, reason=%s" % (q_str, self.reason)
+        if self.success:
+            return "IKSolution: q=%s, success=True, iterations=%d, searches=%d, residual=%.3g" % (q_str, self.iterations, self.searches, self.residual)
+        return "IKSolution: q=%s, success=False, reason=%s, iterations=%d, searches=%d, residual=%.3g" % (
+            q_str, self.reason, self.iterations, self.searches, np.round(self.residual, 4))
+
 
 class ETS:
     """A sequence of elementary transforms bound to a device chain handle (reference robot/ETS.py)."""
@@ -198,10 +298,14 @@ class ETS:
             ets = [arg]
         elif isinstance(arg, ETS):
             ets = list(arg._ets)
-        else:
+        elif isinstance(arg, (list, tuple)):
             ets = []
             for a in arg:
+                if not isinstance(a, (ET, ETS)):
+                    raise TypeError("bad arg")                # robot/ETS.py:785-797
                 ets.extend(a._ets if isinstance(a, ETS) else [a])
+        else:
+            raise TypeError("Invalid arg")
         self._ets = ets
         self._handle_ = None
         self._qlim = None
@@ -235,8 +339,125 @@ class ETS:
 
     def __len__(self): return len(self._ets)
     def __iter__(self): return iter(self._ets)
-    def __getitem__(self, i): return self._ets[i]
-    def __repr__(self): return " * ".join(repr(e) for e in self._ets) or "ETS()"
+
+    def __getitem__(self, i):
+        """An ET for an index, an ETS for a slice (reference robot/ETS.py: UserList semantics)."""
+        return ETS(self._ets[i]) if isinstance(i, slice) else self._ets[i]
+
+    def __eq__(self, other):
+        return isinstance(other, ETS) and len(self) == len(other) and all(a == b for a, b in zip(self._ets, other._ets))
+    __hash__ = None
+
+    # ---- list-like editing (the reference's ETS is a UserList, robot/ETS.py:28-60, 430-503); any edit drops the device table
+    @property
+    def data(self): return self._ets
+
+    def _edited(self):
+        self._drop_handle()
+        self._qlim = None
+        self._q_width = None
+
+    @staticmethod
+    def _items(arg):
+        if isinstance(arg, ET):
+            return [arg]
+        if isinstance(arg, ETS):
+            return list(arg._ets)
+        raise TypeError("can only add / insert an ET or an ETS")
+
+    def copy(self):
+        out = ETS(list(self._ets))
+        out._qlim = None if self._qlim is None else self._qlim.copy()
+        return out
+
+    def append(self, et):
+        self._ets.extend(self._items(et)); self._edited()
+
+    def extend(self, ets):
+        for e in ets:
+            self._ets.extend(self._items(e))
+        self._edited()
+
+    def insert(self, arg, i=-1):
+        """Insert an ET or an ETS; the inserted value ends up at position i, the default is the end (reference robot/ETS.py:433-470)."""
+        items = self._items(arg)
+        if i == -1:
+            i = len(self._ets)
+        for k, e in enumerate(items):
+            self._ets.insert(i + k, e)
+        self._edited()
+
+    def pop(self, i=-1):
+        """Remove and return element i (reference robot/ETS.py:472-503)."""
+        item = self._ets.pop(i)
+        self._edited()
+        return item
+
+    def remove(self, et):
+        self._ets.remove(et); self._edited()
+
+    def clear(self):
+        self._ets.clear(); self._edited()
+
+    def reverse(self):
+        self._ets.reverse(); self._edited()
+
+    def index(self, et, *a): return self._ets.index(et, *a)
+    def count(self, et): return self._ets.count(et)
+
+    def joint_idx(self):
+        """Positions of the joints within the sequence (reference robot/ETS.py:207-227)."""
+        return np.array([i for i, e in enumerate(self._ets) if e.isjoint], dtype=np.int64)
+
+    def jindex_set(self):
+        """The set of joint indices (reference robot/ETS.py:249-267)."""
+        return set(int(j) for j in self.jindices)
+
+    @property
+    def structure(self):
+        """'R' / 'P' per joint (reference robot/ETS.py:366-388)."""
+        return "".join("R" if self._ets[i].isrotation else "P" for i in self.joint_idx())
+
+    def compile(self):
+        """Constants between joints folded into one SE3 each, identities dropped (reference robot/ETS.py:857-906).  (The device chain
+        table is compiled this way whether or not this is called: csrc/chain.cpp.)"""
+        out, const = [], None
+        for e in self._ets:
+            if e.isjoint:
+                if const is not None and not np.array_equal(const, np.eye(4)):
+                    out.append(ET.SE3(const))
+                const = None
+                out.append(e)
+            else:
+                const = e.T.copy() if const is None else const @ e.T
+        if const is not None and not np.array_equal(const, np.eye(4)):
+            out.append(ET.SE3(const))
+        return ETS(out)
+
+    def random_q(self, i=1):
+        """Uniform samples within the joint limits: (n,) for i = 1, else (i, n) (reference robot/ETS.py:680-724; the reference draws from
+        Python's `random.uniform`, here numpy's global generator)."""
+        ql = self.qlim
+        q = np.random.uniform(ql[0], ql[1], (int(i), self.n))
+        return q[0] if i == 1 else q
+    def __repr__(self): return " * ".join(e._short() for e in self._ets) or "ETS()"
+
+    def __str__(self, q=None):
+        """The reference's one-line form (robot/ETS.py:71-190): `Rx(88.41°) ⊕ Rx(q0) ⊕ tx(1)`; `q` is the format of a joint variable
+        ("q{0}" numbered from 0, "θ{1}" numbered from 1; default "q{0}", or plain "q" for a single joint); an empty sequence is `SE3()`."""
+        if not self._ets:
+            return "SE3()"
+        if q is None:
+            q = "q{0}" if self.n > 1 else "q"
+        jidx = iter(self._assigned_jindices())
+        out = []
+        for e in self._ets:
+            if e.isjoint:
+                j = next(jidx)
+                out.append("%s(%s%s)" % (e.axis, "-" if e.isflip else "", q.format(j, j + 1)))
+            else:
+                out.append(str(e))
+        return " \u2295 ".join(out)
 
     def __del__(self):
         h = getattr(self, "_handle_", None)
@@ -267,9 +488,7 @@ class ETS:
     @property
     def jindices(self): return np.array(self._assigned_jindices(), dtype=int)
 
-    @property
-    def qlim(self):
-        """(2, n) joint limits, defaults as reference robot/ET.py:109-115."""
+    def _limits(self, strict):
         if self._qlim is not None:
             return self._qlim
         lo, hi = [], []
@@ -278,9 +497,17 @@ class ETS:
                 lo.append(e.qlim[0]); hi.append(e.qlim[1])
             elif e.isrotation:
                 lo.append(-math.pi); hi.append(math.pi)
+            elif strict:
+                raise ValueError("undefined prismatic joint limit")       # robot/ETS.py:335-337
             else:
                 lo.append(0.0); hi.append(1.0)
         return np.array([lo, hi], dtype=np.float64)
+
+    @property
+    def qlim(self):
+        """(2, n) joint limits as the reference's ETS.qlim (robot/ETS.py:300-345): an unset revolute limit reads as [-pi, pi], an unset
+        prismatic one raises.  (The device table, like the reference's C structs -- robot/ET.py:109-115 -- holds [0, 1] there.)"""
+        return self._limits(True)
 
     @qlim.setter
     def qlim(self, v):
@@ -317,7 +544,7 @@ class ETS:
                 flat = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
                 for k in range(16):
                     arr[i].T[k] = flat[k]
-            ql = np.ascontiguousarray(self.qlim.reshape(-1)) if self.n else None
+            ql = np.ascontiguousarray(self._limits(False).reshape(-1)) if self.n else None
             h = C.c_uint64(0)
             check(lib().rtbhip_chain_create(arr, len(rows), host_ptr(ql), C.byref(h)))
             self._handle_ = h.value
@@ -428,10 +655,9 @@ class ETS:
         return out[0] if single else out
 
     def fkine(self, q, base=None, tool=None, include_base=True):
-        """reference ETS.fkine (robot/ETS.py:1006-1019) wraps eval() in spatialmath.SE3; spatialmath
-        is not a dependency here, so the SE(3) matrices are returned as an ndarray -- wrap with
-        ``SE3(list(T), check=False)`` where spatialmath is available."""
-        return self.eval(q, base=base, tool=tool, include_base=include_base)
+        """reference ETS.fkine (robot/ETS.py:1006-1019) wraps eval() in spatialmath.SE3; spatialmath is not a dependency here: host
+        input returns the array as an SE3Array (an ndarray that also answers `.A`, `.t`, `.R`, `.inv()`), device input a tensor."""
+        return _poses(self.eval(q, base=base, tool=tool, include_base=include_base))
 
     def _jac(self, q, tool, frame):
         q2, single, tm = self._shape_q(q)
@@ -607,6 +833,29 @@ class ETS:
                 raise ValueError("Tep must be a 4x4 SE3 matrix")
             Tq = np.ascontiguousarray(a.reshape(-1, 4, 4))
         N = Tq.shape[0]
+        if flavour == 1 and single and q0 is not None and not is_torch(q0):
+            rows = as_numeric(q0, "q0")
+            if rows.ndim == 2 and rows.shape[0] > 1 and rows.shape[1] == n:
+                # IKSolver.solve (robot/IK.py:226-240): for ONE pose a (k, n) q0 holds the start vectors of the first k searches; the
+                # searches after them start from random vectors.  One search at a time from the supplied rows, then the rest in one call.
+                slimit = int(slimit)
+                iters, used = 0, 0
+                out = None
+                for row in rows[:slimit]:
+                    out = self._ik(Tep, row, ilimit, 1, tol, mask, joint_limits, k, method, flavour, seed, nullspace, qp)
+                    used += 1
+                    iters += int(out[3][0])
+                    if int(out[2][0]):
+                        break
+                if not int(out[2][0]) and used < slimit:
+                    out = self._ik(Tep, None, ilimit, slimit - used, tol, mask, joint_limits, k, method, flavour, seed, nullspace, qp)
+                    used += int(out[4][0])
+                    iters += int(out[3][0])
+                _, qo, ok, it, se, E = out
+                it = it.copy() if isinstance(it, np.ndarray) else it.clone()
+                se = se.copy() if isinstance(se, np.ndarray) else se.clone()
+                it[0], se[0] = iters, used
+                return True, qo, ok, it, se, E
         q0p = None
         if q0 is not None:
             if tm:

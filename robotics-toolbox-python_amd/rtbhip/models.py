@@ -154,5 +154,19 @@ class DH:
             self.qn = np.array([0, pi / 4, pi, 0, pi / 4, 0])
 
 
+class Puma560ETS(ERobot):
+    """Unimation Puma560 as an ETS, 13 ETs / 6 joints (reference models/ETS/Puma560.py:38-68: zero angles = the vertical pose)."""
+
+    def __init__(self):
+        l1, l2, l3, l4, l5, l6 = 0.672, -0.2337, 0.4318, 0.0203, 0.0837, 0.4318
+        ets = (ET.tz(l1) * ET.Rz() * ET.ty(l2) * ET.Ry() * ET.tz(l3) * ET.tx(l4) * ET.ty(l5) * ET.Ry() * ET.tz(l6) * ET.Rz() * ET.Ry() * ET.Rz()
+               * ET.tx(0.2))
+        super().__init__(ets, name="Puma560", manufacturer="Unimation")
+        self.qr = np.array([0, -math.pi / 2, math.pi / 2, 0, 0, 0])
+        self.qz = np.zeros(6)
+
+
 class ETSModels:
+    """what the reference reaches as `rtb.models.ETS.<name>`"""
     Panda = Panda
+    Puma560 = Puma560ETS

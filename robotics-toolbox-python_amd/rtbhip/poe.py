@@ -168,7 +168,7 @@ class _PoEChain(ETS):
 
     def _handle(self):
         if self._handle_ is None:
-            ql = np.ascontiguousarray(self.qlim.reshape(-1)) if self.n else None
+            ql = np.ascontiguousarray(self._limits(False).reshape(-1)) if self.n else None
             h = C.c_uint64(0)
             check(lib().rtbhip_chain_create_poe(host_ptr(self._twists), int(self._twists.shape[0]), host_ptr(self._T0), host_ptr(ql), C.byref(h)))
             self._handle_ = h.value

@@ -194,9 +194,12 @@ class URDFRobot:
 
     def ets(self, end=None, start=None, compact=True):
         """ETS from the root (or `start`) to `end`.  compact=True numbers the joints 0..n-1 along the
-        path (q is (N, n)); compact=False keeps the robot-wide jindex (q is (N, robot.n))."""
+        path (q is (N, n)); compact=False keeps the robot-wide jindex (q is (N, robot.n)).
+        With no `end` the chain runs to the model's end effector AND carries the gripper's tool transform as its last element, as
+        the reference's BaseRobot.ets does for a robot with one gripper (robot/BaseRobot.py:1610-1616, 1469-1473)."""
+        with_tool = end is None and self.tool is not None
         end = self.ee if end is None else (end if isinstance(end, str) else end.name)
-        key = (end, start, compact)
+        key = (end, start, compact, with_tool)
         if key in self._cache:
             return self._cache[key]
         links = self.path(end)
@@ -215,30 +218,55 @@ class URDFRobot:
                 if var is not None:
                     ets.append(var)
                     k += 1
+        if with_tool:
+            ets.append(ET.SE3(self.tool))
         e = ETS(ets)
         if not compact:
             e.q_width = self.n          # every branch reads the same (N, robot.n) array
         self._cache[key] = e
         return e
 
+    def _tool_for(self, end, tool):
+        """the tool a pass-through hands its chain: an explicit one, else the model's -- unless ets(None) already carries it"""
+        if tool is not None:
+            return tool
+        return None if end is None else self.tool
+
     def qlim(self, end=None):
         return self.ets(end).qlim
 
     # ------------------------------------------------------------ kinematics pass-throughs
     def fkine(self, q, end=None, tool=None):
-        return self.ets(end).eval(q, tool=self.tool if tool is None else tool)
+        return self.ets(end).fkine(q, tool=self._tool_for(end, tool))
 
     def jacob0(self, q, end=None, tool=None):
-        return self.ets(end).jacob0(q, tool=self.tool if tool is None else tool)
+        return self.ets(end).jacob0(q, tool=self._tool_for(end, tool))
 
     def jacobe(self, q, end=None, tool=None):
-        return self.ets(end).jacobe(q, tool=self.tool if tool is None else tool)
+        return self.ets(end).jacobe(q, tool=self._tool_for(end, tool))
 
     def fkine_jacob0(self, q, end=None, tool=None):
-        return self.ets(end).fkine_jacob0(q, tool=self.tool if tool is None else tool)
+        return self.ets(end).fkine_jacob0(q, tool=self._tool_for(end, tool))
 
     def ik_LM(self, Tep, end=None, **kw):
         return self.ets(end).ik_LM(Tep, **kw)
+
+    # the other solvers and differential-kinematics methods of RobotKinematicsMixin (robot/RobotKinematics.py): self.ets(end).<name>(...)
+    def ik_GN(self, Tep, end=None, **kw): return self.ets(end).ik_GN(Tep, **kw)
+    def ik_NR(self, Tep, end=None, **kw): return self.ets(end).ik_NR(Tep, **kw)
+    def ikine_LM(self, Tep, end=None, **kw): return self.ets(end).ikine_LM(Tep, **kw)
+    def ikine_NR(self, Tep, end=None, **kw): return self.ets(end).ikine_NR(Tep, **kw)
+    def ikine_GN(self, Tep, end=None, **kw): return self.ets(end).ikine_GN(Tep, **kw)
+    def ikine_QP(self, Tep, end=None, **kw): return self.ets(end).ikine_QP(Tep, **kw)
+    def hessian0(self, q=None, end=None, J0=None, tool=None): return self.ets(end).hessian0(q, J0=J0, tool=self._tool_for(end, tool))
+    def hessiane(self, q=None, end=None, Je=None, tool=None): return self.ets(end).hessiane(q, Je=Je, tool=self._tool_for(end, tool))
+    def manipulability(self, q=None, end=None, **kw):
+        e = self.ets(end)
+        return e.manipulability(np.zeros(e.n) if q is None else q, **kw)      # q=None: the robot's stored configuration, zeros (BaseRobot.q)
+    def jacobm(self, q, end=None, **kw): return self.ets(end).jacobm(q, **kw)
+    def jacob0_dot(self, q, qd, end=None, **kw): return self.ets(end).jacob0_dot(q, qd, **kw)
+    def jacob0_analytical(self, q, end=None, **kw): return self.ets(end).jacob0_analytical(q, **kw)
+    def partial_fkine0(self, q, n=3, end=None): return self.ets(end).partial_fkine0(q, n)
 
     # ------------------------------------------------------------ dynamics (SURVEY 8f-1)
     def erobot(self, exclude=()):
@@ -318,6 +346,18 @@ _MODEL_EE = {
 }
 
 
+# named joint configurations of the reference's model classes (models/URDF/Panda.py:54-55, UR5.py:48-68, Puma560.py:57-91): vectors over the
+# joints of the arm (the path to the model's end effector), set as attributes by load()
+_pi = np.pi
+_MODEL_Q = {
+    "Panda": dict(qr=[0, -0.3, 0, -2.2, 0, 2.0, _pi / 4], qz=[0.0] * 7),
+    "UR5": dict(qr=[_pi, 0, 0, 0, _pi / 2, 0], qz=[0.0] * 6, q1=[0, -_pi / 2, _pi / 2, 0, _pi / 2, 0]),
+    "Puma560": dict(qr=[0, _pi / 2, -_pi / 2, 0, 0, 0], qz=[0.0] * 6, ru=[-0.0, 0.7854, 3.1416, -0.0, 0.7854, 0.0],
+                    rd=[-0.0, -0.8335, 0.0940, -3.1416, 0.8312, 3.1416], lu=[2.6486, -3.9270, 0.0940, 2.5326, 0.9743, 0.3734],
+                    ld=[2.6486, -2.3081, 3.1416, 0.6743, 0.8604, 2.6611], qs=[0, 0, -_pi / 2, 0, 0, 0], qn=[0, _pi / 4, _pi, 0, _pi / 4, 0]),
+}
+
+
 def load(name, **kw):
     """One of the pre-expanded robot descriptions in rtbhip/data/urdf (see available())."""
     path = os.path.join(DATA_DIR, name + ".urdf")
@@ -325,7 +365,10 @@ def load(name, **kw):
         raise ValueError("unknown robot %r; available: %s" % (name, ", ".join(available())))
     if name in _MODEL_EE and "ee" not in kw:
         kw["ee"], kw["tool"] = _MODEL_EE[name][0], np.array(_MODEL_EE[name][1], dtype=np.float64)
-    return URDFRobot(open(path).read(), name=name, **kw)
+    robot = URDFRobot(open(path).read(), name=name, **kw)
+    for key, v in _MODEL_Q.get(name, {}).items():
+        setattr(robot, key, np.array(v, dtype=np.float64))
+    return robot
 
 
 # the 16 arms of BASELINE config 5 ("mixed fleet", 4..10 joints on the path to the deepest leaf)

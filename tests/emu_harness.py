@@ -120,7 +120,7 @@ def chain_handle(ets):
     """ets: an rtbhip.ETS (its optable() is handed to the emu library's own chain compiler)."""
     from rtbhip._lib import rtbhip_et
     if hasattr(ets, "_twists"):                       # a PoE chain: the emu library's own copy of compile_poe (csrc/chain.cpp)
-        ql = np.ascontiguousarray(ets.qlim.reshape(-1)) if ets.n else None
+        ql = np.ascontiguousarray(ets._limits(False).reshape(-1)) if ets.n else None
         tw, T0 = np.ascontiguousarray(ets._twists), np.ascontiguousarray(ets._T0)
         h = _u64(0)
         fn = lib().rtbhip_chain_create_poe
@@ -135,7 +135,7 @@ def chain_handle(ets):
         flat = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
         for k in range(16):
             arr[i].T[k] = flat[k]
-    ql = np.ascontiguousarray(ets.qlim.reshape(-1)) if ets.n else None
+    ql = np.ascontiguousarray(ets._limits(False).reshape(-1)) if ets.n else None
     h = _u64(0)
     rc = lib().rtbhip_chain_create(arr, len(rows), _p(ql), C.byref(h))
     assert rc == 0, lib().rtbhip_last_error()

@@ -122,7 +122,7 @@ def chain_from_ets(ets):
             spec.append(np.array(T, dtype=np.float64))
         else:
             spec.append((("Rx", "Ry", "Rz", "tx", "ty", "tz")[kind], None, bool(flip)))
-    return chains.Chain(spec, qlim=ets.qlim)
+    return chains.Chain(spec, qlim=ets._limits(False))
 
 
 def urdf_fk_numpy(urdf_path, end, q):

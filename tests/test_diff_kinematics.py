@@ -42,11 +42,11 @@ def test_manipulability_goldens_reference_models():
     import emu_harness as emu
     p = urdf.load("Panda")
     qr = np.array([0, -0.3, 0, -2.2, 0, 2.0, np.pi / 4])
-    nt.assert_almost_equal(emu.diff(p.ets(), 1, qr, axes=63 | (2 << 8), tool=p.tool)[0], 0.11222, decimal=4)      # test_cond
-    nt.assert_almost_equal(emu.diff(p.ets(), 1, qr, axes=63 | (1 << 8), tool=p.tool)[0], 0.209013, decimal=4)     # test_minsingular
+    nt.assert_almost_equal(emu.diff(p.ets(), 1, qr, axes=63 | (2 << 8))[0], 0.11222, decimal=4)      # test_cond
+    nt.assert_almost_equal(emu.diff(p.ets(), 1, qr, axes=63 | (1 << 8))[0], 0.209013, decimal=4)     # test_minsingular
     for axes, mask, want in (("all", 63, 0.0837), ("trans", 7, 0.1438), ("rot", 56, 2.7455)):
-        nt.assert_almost_equal(emu.diff(p.ets(), 1, qr, axes=mask, tool=p.tool)[0], want, decimal=4)
-        nt.assert_almost_equal(oracle.manipulability(chain_from_ets(p.ets()), qr, axes, tool=p.tool)[0], want, decimal=4)
+        nt.assert_almost_equal(emu.diff(p.ets(), 1, qr, axes=mask)[0], want, decimal=4)
+        nt.assert_almost_equal(oracle.manipulability(chain_from_ets(p.ets()), qr, axes)[0], want, decimal=4)
     pu = urdf.load("Puma560")
     qn = np.array([0, np.pi / 4, np.pi, 0, np.pi / 4, 0])
     for mask, want in ((63, 0.0805), (7, 0.1354), (56, 2.44949)):
@@ -168,18 +168,18 @@ def test_gpu_goldens_shapes_errors():
         nt.assert_array_almost_equal(jm, LIT["K_panda_jacobm"])
     p = urdf.load("Panda")
     qr = np.array([0, -0.3, 0, -2.2, 0, 2.0, np.pi / 4])
-    nt.assert_almost_equal(p.ets().manipulability(qr, tool=p.tool), 0.0837, decimal=4)
-    nt.assert_almost_equal(p.ets().manipulability(qr, axes="trans", tool=p.tool), 0.1438, decimal=4)
-    nt.assert_almost_equal(p.ets().manipulability(qr, axes="rot", tool=p.tool), 2.7455, decimal=4)
-    m2 = p.ets().manipulability(np.c_[qr, qr].T, tool=p.tool)
+    nt.assert_almost_equal(p.ets().manipulability(qr), 0.0837, decimal=4)
+    nt.assert_almost_equal(p.ets().manipulability(qr, axes="trans"), 0.1438, decimal=4)
+    nt.assert_almost_equal(p.ets().manipulability(qr, axes="rot"), 2.7455, decimal=4)
+    m2 = p.ets().manipulability(np.c_[qr, qr].T)
     assert m2.shape == (2,)
     with pytest.raises(ValueError):
         panda.manipulability(qr, axes="abcdef")
     with pytest.raises(ValueError):
         panda.manipulability(qr, method="nonsense")
     # reference tests/test_ETS.py:4339-4353 (URDF Panda at qr)
-    nt.assert_almost_equal(p.ets().manipulability(qr, method="invcondition", tool=p.tool), 0.11222, decimal=4)
-    nt.assert_almost_equal(p.ets().manipulability(qr, method="minsingular", tool=p.tool), 0.209013, decimal=4)
+    nt.assert_almost_equal(p.ets().manipulability(qr, method="invcondition"), 0.11222, decimal=4)
+    nt.assert_almost_equal(p.ets().manipulability(qr, method="minsingular"), 0.209013, decimal=4)
     seventeen = rtbhip.DHRobot([rtbhip.RevoluteDH(a=0.1) for _ in range(17)]).ets()
     with pytest.raises(rtbhip.RtbHipError):
         seventeen.manipulability(np.zeros(17))

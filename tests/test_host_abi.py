@@ -90,7 +90,9 @@ def test_chain_create_rejects_bad_input():
 
 def test_default_and_explicit_qlim():
     e = rtbhip.ET.Rz() * rtbhip.ET.tx() * rtbhip.ET.Ry(qlim=[-1, 2])
-    np.testing.assert_allclose(e.qlim, [[-np.pi, 0, -1], [np.pi, 1, 2]])   # reference robot/ET.py:109-115
+    np.testing.assert_allclose(e._limits(False), [[-np.pi, 0, -1], [np.pi, 1, 2]])   # the device table's defaults, reference robot/ET.py:109-115
+    with pytest.raises(ValueError):
+        e.qlim                                                                          # the Python property: robot/ETS.py:335-337
     e.qlim = [[-1, 0, -1], [1, 0.5, 1]]
     assert e.qlim.shape == (2, 3)
 

@@ -1,0 +1,143 @@
+"""The reference's OWN unit-test files -- tests/test_ET.py, test_ETS.py, test_jacob.py, test_IK.py of robotics-toolbox-python --
+executed UNMODIFIED against this backend on the GPU.
+
+`import roboticstoolbox as rtb` in those files resolves to a module object whose `ET`, `ETS`, `IK_LM` ..., `models.*` are rtbhip's
+classes; `spatialmath` resolves to the stand-in of oracle/sm_standin.py (SE3 wrappers, trotx ..., numjac / tr2x for the numerical
+Jacobian checks).  Where /root/reference exists the test files run from where they lie; on the GPU box their byte-compiled copies
+(oracle/_ref/pytests, `make -f oracle/Makefile refpy`) run.  Nothing of the reference's implementation is involved: every number the
+tests check comes from librtbhip.so.
+
+EXPECTED below is the ledger of the tests that do not pass, each with its reason -- features SURVEY section 8 leaves out (2-D classes,
+symbolic arithmetic, plotting) or spots where the reference's own test leans on undefined behaviour.  A test that is not in the ledger
+must pass; a test in the ledger that starts passing fails this file too (so the ledger stays honest)."""
+import sys
+import types
+import unittest
+
+import numpy as np
+import pytest
+
+import rtbhip
+from rtbhip import urdf
+from oracle import ref_classes, sm_standin
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not ref_classes.tests_available(), reason="needs the reference's test files (oracle/_ref/pytests)")]
+
+SYM = "symbolic (sympy) joint values / parameters: the reference's pure-Python fall-back, out of scope (SURVEY 8b keeps it on the reference)"
+EXPECTED = {
+    "test_ET": {
+        "test_et2_T": "ET2 / ETS2, the 2-D classes: not on the path (SURVEY 8a lists the 3-D chain only)",
+        "test_str": SYM, "test_T": SYM,
+        "test_axis_error": "BaseET's axis_func constructor protocol is an implementation detail of the reference's class split",
+    },
+    "test_ETS": {
+        "test_fkine_sym": SYM, "test_jacob0_sym": SYM, "test_jacobe_sym": SYM, "test_hessian_sym": SYM, "test_str_sym": SYM,
+        "test_plot": "plotting: out of scope", "test_teach": "plotting: out of scope",
+        "test_jacob0": "the reference's test hands a ONE-element q to a six-joint chain (reads past the end of q in the C extension)",
+        "test_jacobe": "the reference's test hands a ONE-element q to a six-joint chain (reads past the end of q in the C extension)",
+        "test_insert": "the reference's test evaluates a 7-joint chain with a 6-element q (it reads past the end of q: undefined "
+                       "behaviour in the C extension); this backend validates the length and raises",
+    },
+    "test_jacob": {},
+    "test_IK": {},
+}
+
+
+# tests whose outcome depends on the restart draws (the reference's RNG is not this backend's): accepted either way, with the reason
+DRAW_DEPENDENT = {
+    "test_IK": {
+        "test_IK_GN3": "the target is a wrist singularity of the UR5 (q4 = 0) and the Python solver returns q AFTER one more pseudo-inverse step "
+                       "once E < tol (robot/IK.py:319-327): near the singular branch that last step moves q by ~1e-2, so the test's "
+                       "E(FK(q)) < 1e-5 holds or not depending on which restart converged (measured here: solver residual 4e-8, E(FK(q)) 8.6e-3)",
+    },
+}
+
+
+def install_shims():
+    """sys.modules entries the reference's test files import; returns the names to restore."""
+    sm, smb = sm_standin.modules()
+    rtb = types.ModuleType("roboticstoolbox")
+    rtb.__path__ = []
+    for nm in dir(rtbhip):
+        if not nm.startswith("_"):
+            setattr(rtb, nm, getattr(rtbhip, nm))
+    rtb.Robot = rtbhip.models.ERobot
+    # rtb.models.<name>() are the URDF models in the reference, rtb.models.ETS.<name>() / rtb.models.DH.<name>() the ETS / DH ones
+    rtb.models = types.SimpleNamespace(Panda=lambda: urdf.load("Panda"), UR5=lambda: urdf.load("UR5"), Puma560=lambda: urdf.load("Puma560"),
+                                       ETS=rtbhip.models.ETSModels, DH=rtbhip.models.DH)
+    robot = types.ModuleType("roboticstoolbox.robot")
+    robot.__path__ = []
+    etm = types.ModuleType("roboticstoolbox.robot.ET")
+    etm.BaseET, etm.ET = rtbhip.ET, rtbhip.ET
+    tests = types.ModuleType("tests")
+    tests.__path__ = []
+    marks = types.ModuleType("tests.marks")
+    marks.skip_no_qp = pytest.mark.skipif(False, reason="")            # IK_QP runs on the device: no qpsolvers needed
+    new = {"spatialmath": sm, "spatialmath.base": smb, "spatialmath.base.argcheck": smb.argcheck, "spatialmath.base.symbolic": smb.symbolic,
+           "roboticstoolbox": rtb, "roboticstoolbox.robot": robot, "roboticstoolbox.robot.ET": etm, "tests": tests, "tests.marks": marks}
+    saved = {k: sys.modules.get(k) for k in new}
+    sys.modules.update(new)
+    return saved
+
+
+def restore(saved):
+    for k, v in saved.items():
+        if v is None:
+            sys.modules.pop(k, None)
+        else:
+            sys.modules[k] = v
+
+
+def run_module(mod):
+    """{test name: None | 'ExcType: message'} for every test of the module: unittest.TestCase classes through unittest, pytest-style
+    classes (tests/test_jacob.py: a plain class with an autouse fixture `setUp`) by calling the fixture's function and then each test."""
+    out = {}
+    for cname, cls in vars(mod).items():
+        if not isinstance(cls, type) or cls.__module__ != mod.__name__:
+            continue
+        if issubclass(cls, unittest.TestCase):
+            suite = unittest.defaultTestLoader.loadTestsFromTestCase(cls)
+            for t in suite:
+                out[t._testMethodName] = None
+            res = unittest.TestResult()
+            suite.run(res)
+            for t, tb in res.failures + res.errors:
+                out[t._testMethodName] = tb.strip().split("\n")[-1][:300]
+            for t, why in res.skipped:
+                out[t._testMethodName] = "skipped: " + why
+        elif cname.startswith("Test"):
+            names = [n for n in dir(cls) if n.startswith("test")]
+            for n in names:
+                obj = cls()
+                try:
+                    fx = getattr(cls, "setUp", None)
+                    if fx is not None:
+                        fn = fx._get_wrapped_function() if hasattr(fx, "_get_wrapped_function") else getattr(fx, "__wrapped__", fx)
+                        fn = getattr(getattr(fn, "__pytest_wrapped__", None), "obj", fn)
+                        r = fn(obj)
+                        if hasattr(r, "__next__"):
+                            next(r, None)
+                    getattr(obj, n)()
+                    out[n] = None
+                except Exception as e:              # noqa: BLE001 -- the ledger wants every outcome
+                    out[n] = "%s: %s" % (type(e).__name__, str(e).split("\n")[0][:300])
+    return out
+
+
+@pytest.mark.parametrize("name", ["test_ET", "test_ETS", "test_jacob", "test_IK"])
+def test_reference_test_file(name):
+    np.random.seed(0)
+    saved = install_shims()
+    try:
+        mod = ref_classes.load_test_module(name)
+        results = run_module(mod)
+    finally:
+        restore(saved)
+    assert len(results) >= {"test_ET": 31, "test_ETS": 43, "test_jacob": 12, "test_IK": 36}[name], sorted(results)
+    failed = {k: v for k, v in results.items() if v is not None}
+    either = DRAW_DEPENDENT.get(name, {})
+    unexpected = {k: v for k, v in failed.items() if k not in EXPECTED[name] and k not in either}
+    now_passing = [k for k in EXPECTED[name] if results.get(k, "") is None]
+    print("%s: %d tests, %d pass, %d in the ledger" % (name, len(results), len(results) - len(failed), len(EXPECTED[name])))
+    assert not unexpected, "reference tests that should pass and do not: %r" % unexpected
+    assert not now_passing, "ledger entries that pass now (remove them): %r" % now_passing

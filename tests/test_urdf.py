@@ -39,7 +39,7 @@ def test_G12_readme_panda_fkine_qr():
     import emu_harness as emu
     p = urdf.load("Panda")
     qr = np.array([0, -0.3, 0, -2.2, 0, 2.0, np.pi / 4])
-    T, _, _ = emu.kin(p.ets(), qr, tool=p.tool, want=("T",))
+    T, _, _ = emu.kin(p.ets(), qr, want=("T",))            # ets() carries the gripper tool (BaseRobot.ets, robot/BaseRobot.py:1610-1616)
     want = np.array([[0.995, 0, 0.09983, 0.484], [0, -1, 0, 0], [0.09983, 0, -0.995, 0.4126], [0, 0, 0, 1]])
     nt.assert_allclose(T[0], want, atol=6e-4)
 
@@ -55,8 +55,9 @@ def test_lowering_equals_independent_urdf_fk_and_oracle(name):
     q = _rand_q(rng, e, 6)
     T, J, _ = emu.kin(e, q, want=("T", "J"), reg=e.n <= 8)
     path = os.path.join(urdf.DATA_DIR, name + ".urdf")
+    tool = np.eye(4) if r.tool is None else r.tool          # ets() ends with the model's gripper tool (Panda), the XML walk does not
     for i in range(len(q)):
-        nt.assert_allclose(T[i], urdf_fk_numpy(path, r.ee, q[i]), atol=1e-12)
+        nt.assert_allclose(T[i], urdf_fk_numpy(path, r.ee, q[i]) @ tool, atol=1e-12)
     oc = chain_from_ets(e)
     nt.assert_allclose(T, oracle.fkine(oc, q), atol=TOL)
     nt.assert_allclose(J, oracle.jacob0(oc, q), atol=TOL)
