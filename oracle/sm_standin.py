@@ -209,6 +209,19 @@ def numhess(J, x, dx=1e-8):
     return np.array(out)
 
 
+def trnorm(T):
+    """spatialmath.base.trnorm: the rotation part made orthonormal again -- n = o x a, o = a x n, columns normalised."""
+    T = np.asarray(T, dtype=np.float64)
+    o, a = T[:3, 1], T[:3, 2]
+    n = np.cross(o, a)
+    o = np.cross(a, n)
+    R = np.stack([n / np.linalg.norm(n), o / np.linalg.norm(o), a / np.linalg.norm(a)], axis=1)
+    out = np.eye(4)
+    out[:3, :3] = R
+    out[:3, 3] = T[:3, 3]
+    return out
+
+
 def rot2jac(R, representation=None):
     """spatialmath.base.rot2jac: blkdiag(R, R) (robot/Dynamics.py, the operational-space terms)."""
     J = np.zeros((6, 6))
@@ -340,7 +353,7 @@ def modules():
     """(spatialmath, spatialmath.base) module objects to be placed in sys.modules while the reference files are loaded."""
     sm = types.ModuleType("spatialmath")
     smb = types.ModuleType("spatialmath.base")
-    for f in (trotx, troty, trotz, issymbol, getvector, getmatrix, verifymatrix, t2r, tr2jac, simplify, isvector, ismatrix, getunit, rot2jac, transl, islistof, tr2x, numjac, numhess):
+    for f in (trotx, troty, trotz, issymbol, getvector, getmatrix, verifymatrix, t2r, tr2jac, simplify, isvector, ismatrix, getunit, rot2jac, transl, islistof, tr2x, numjac, numhess, trnorm):
         setattr(smb, f.__name__, f)
     for name in ("tr2rpy", "tr2eul", "trlog", "trot2", "transl2", "tr2xyt", "tr2jac2", "rotvelxform", "r2x", "rotvelxform_inv_dot"):
         setattr(smb, name, _not_offered(name))

@@ -17,6 +17,7 @@ from ._lib import RtbHipError, lib, device_count, tune, shard_range, last_launch
 from .et import ET, ETS, IKSolution, angle_axis, p_servo, hessian_from_jacobian  # noqa: F401
 from .ik import IKSolver, IK_NR, IK_GN, IK_LM, IK_QP  # noqa: F401
 from .dh import DHLink, DHRobot, RevoluteDH, PrismaticDH, RevoluteMDH, PrismaticMDH  # noqa: F401
+SerialLink = DHRobot          # the reference keeps the old name as an alias (robot/DHRobot.py:2505-2520)
 from .erobot import Link, ERobot  # noqa: F401
 from .poe import PoELink, PoERevolute, PoEPrismatic, PoERobot  # noqa: F401
 from .kinematics import RobotKinematics  # noqa: F401

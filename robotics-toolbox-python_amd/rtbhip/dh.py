@@ -11,7 +11,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import check, lib, as_numeric, host_ptr, is_torch, MEM_HOST, MEM_DEVICE
-from .et import ET, ETS
+from .et import ET, ETS, _poses
 from .kinematics import RobotKinematics
 
 
@@ -25,7 +25,11 @@ class DHLink:
         self.r = np.zeros(3) if r is None else np.asarray(r, dtype=np.float64).reshape(3)
         self.I = self._inertia(I)
         self.Jm, self.G, self.B = float(Jm), float(G), float(B)
-        self.Tc = np.zeros(2) if Tc is None else np.asarray(Tc, dtype=np.float64).reshape(2)
+        if Tc is None:
+            self.Tc = np.zeros(2)
+        else:
+            Tc = np.asarray(Tc, dtype=np.float64).reshape(-1)
+            self.Tc = np.array([Tc[0], -Tc[0]]) if Tc.size == 1 else Tc.reshape(2)      # a scalar is symmetric friction (robot/Link.py:830-846)
 
     @staticmethod
     def _inertia(I):
@@ -51,6 +55,38 @@ class DHLink:
     def isrevolute(self): return self.sigma == 0
     @property
     def isprismatic(self): return self.sigma == 1
+
+    def copy(self):
+        import copy as _copy
+        return _copy.deepcopy(self)
+
+    def islimit(self, q):
+        """q outside [qlim0, qlim1]; no limits set -> False (reference robot/Link.py:1300-1330)."""
+        return False if self.qlim is None else bool(q < self.qlim[0] or q > self.qlim[1])
+
+    def friction(self, qd, coulomb=True):
+        """Joint friction torque at joint velocity qd, referred to the link side: -|G| (B |G| qd + Tc+/-) (reference robot/Link.py:1395-1448)."""
+        tau = self.B * abs(self.G) * qd
+        if coulomb:
+            tau += self.Tc[0] if qd > 0 else (self.Tc[1] if qd < 0 else 0.0)
+        return -abs(self.G) * tau
+
+    def nofriction(self, coulomb=True, viscous=False):
+        """A copy with the Coulomb (and, if asked, viscous) friction removed (reference robot/Link.py:1350-1393)."""
+        l = self.copy()
+        if viscous:
+            l.B = 0.0
+        if coulomb:
+            l.Tc = np.zeros(2)
+        return l
+
+    def __add__(self, other):
+        """link + link / link + robot -> DHRobot (reference robot/DHLink.py:227-255)."""
+        if isinstance(other, DHLink):
+            return DHRobot([self, other])
+        if isinstance(other, DHRobot):
+            return DHRobot([self] + list(other.links))
+        raise TypeError("Cannot add a DHLink with %s" % type(other).__name__)
 
     def ets(self):
         """DH -> elementary transforms, same sequence as reference robot/DHLink.py:173-225."""
@@ -114,7 +150,15 @@ def _mat4(T):
 
 class DHRobot(RobotKinematics):
     def __init__(self, links, name="", manufacturer="", base=None, tool=None, gravity=None, **kw):
-        self.links = list(links)
+        flat = []
+        for l in links:                                       # links, or whole robots whose links are spliced in (robot/DHRobot.py:90-112)
+            if isinstance(l, DHLink):
+                flat.append(l)
+            elif isinstance(l, DHRobot):
+                flat.extend(l.links)
+            else:
+                raise TypeError("Input can be only DHLink or DHRobot")
+        self.links = flat
         if not self.links:
             raise ValueError("no links")
         if len({l.mdh for l in self.links}) != 1:
@@ -125,6 +169,114 @@ class DHRobot(RobotKinematics):
         self.gravity = np.array([0.0, 0.0, -9.81]) if gravity is None else np.asarray(gravity, dtype=np.float64).reshape(3)
         self._ets = None
         self._dyn = None
+        self.q = np.zeros(len(self.links))                    # the stored configuration (BaseRobot.q): what islimit() etc. default to
+        self._control_mode = "v"
+
+    @property
+    def control_mode(self): return self._control_mode
+
+    @control_mode.setter
+    def control_mode(self, cn):
+        if cn not in ("p", "v", "a"):
+            raise ValueError("Control type must be one of 'p', 'v', or 'a'")          # robot/BaseRobot.py:1330-1338
+        self._control_mode = cn
+
+    def __add__(self, other):
+        """robot + robot / robot + link -> a longer DHRobot (reference robot/DHRobot.py:299-327)."""
+        if isinstance(other, DHRobot):
+            return DHRobot(self.links + other.links, name=self.name + other.name, gravity=self.gravity)
+        if isinstance(other, DHLink):
+            return DHRobot(self.links + [other], name=self.name, manufacturer=self.manufacturer, gravity=self.gravity)
+        raise TypeError("can only add DHRobot or DHLink to DHRobot")
+
+    # per-link parameter vectors (reference robot/DHRobot.py:345-470)
+    def _vec(self, name): return [getattr(l, name) for l in self.links]              # lists, as the reference returns them
+    @property
+    def d(self): return self._vec("d")
+    @property
+    def a(self): return self._vec("a")
+    @property
+    def alpha(self): return self._vec("alpha")
+    @property
+    def theta(self): return self._vec("theta")
+    @property
+    def offset(self): return self._vec("offset")
+    @property
+    def r(self):
+        """centres of mass, one column per link; a vector for a one-link robot (robot/DHRobot.py:438-460)"""
+        R = np.array([l.r for l in self.links]).T
+        return R.reshape(-1) if R.shape[1] == 1 else R
+
+    def isrevolute(self, j): return bool(self.links[j].isrevolute)
+    def isprismatic(self, j): return bool(self.links[j].isprismatic)
+    @property
+    def revolutejoints(self): return [bool(l.isrevolute) for l in self.links]
+    @property
+    def prismaticjoints(self): return [bool(l.isprismatic) for l in self.links]
+
+    def todegrees(self, q=None):
+        """revolute joint values in degrees, prismatic ones untouched (reference robot/DHRobot.py:540-568)"""
+        q = np.array(self.q if q is None else q, dtype=np.float64)
+        k = np.array(self.revolutejoints)
+        q[..., k] *= 180.0 / np.pi
+        return q
+
+    def toradians(self, q):
+        q = np.array(q, dtype=np.float64)
+        k = np.array(self.revolutejoints)
+        q[..., k] *= np.pi / 180.0
+        return q
+
+    def islimit(self, q=None):
+        """per joint: outside its limits? (reference robot/DHRobot.py:714-743)"""
+        q = self.q if q is None else np.asarray(q, dtype=np.float64).reshape(-1)
+        return [l.islimit(qk) for l, qk in zip(self.links, q)]
+
+    def isspherical(self):
+        """last three joints form a spherical wrist (reference robot/DHRobot.py:745-778)"""
+        if self.n < 3:
+            return False
+        L = self.links[self.n - 3:]
+        al = (-np.pi / 2, np.pi / 2)
+        return bool(L[0].a == 0 and L[1].a == 0 and L[1].d == 0
+                    and ((L[0].alpha == al[0] and L[1].alpha == al[1]) or (L[0].alpha == al[1] and L[1].alpha == al[0]))
+                    and L[0].sigma == 0 and L[1].sigma == 0 and L[2].sigma == 0)
+
+    def A(self, j, q=None):
+        """Product of the link transforms j0 .. j1 (j an index: 0 .. j), without base and tool (reference robot/DHRobot.py:660-712);
+        evaluated on the device as the sub-chain of those links."""
+        j0, jn = (0, int(j)) if np.isscalar(j) else (int(j[0]), int(j[1]))
+        jn += 1
+        if jn > self.n:
+            raise ValueError("The joints value out of range")
+        q = np.asarray(self.q if q is None else q, dtype=np.float64).reshape(-1)
+        cache = self.__dict__.setdefault("_sub_ets", {})
+        if (j0, jn) not in cache:
+            e = ETS()
+            for l in self.links[j0:jn]:
+                e = e * l.ets()
+            cache[(j0, jn)] = e
+        return cache[(j0, jn)].fkine(q[j0:jn])
+
+    def payload(self, m, p=None):
+        """A point-mass payload at p in the last link's frame: it REPLACES that link's mass and centre of mass
+        (reference robot/Dynamics.py:614-651)."""
+        last = self.links[-1]
+        last.m = float(m)
+        last.r = np.zeros(3) if p is None else np.asarray(p, dtype=np.float64).reshape(3)
+        if self._dyn is not None:
+            lib().rtbhip_dyn_destroy(self._dyn)
+        self._dyn = None                                      # the device table is rebuilt from the links
+
+    def friction(self, qd):
+        """joint friction torques at the velocities qd (reference robot/Dynamics.py:511-560)"""
+        qd = np.asarray(qd, dtype=np.float64).reshape(-1)
+        return np.array([l.friction(v) for l, v in zip(self.links, qd)])
+
+    def nofriction(self, coulomb=True, viscous=False):
+        """A copy of the robot without Coulomb (and, if asked, viscous) friction (reference robot/Dynamics.py:562-612)"""
+        return DHRobot([l.nofriction(coulomb, viscous) for l in self.links], name=self.name, manufacturer=self.manufacturer, base=self.base,
+                       tool=self.tool, gravity=self.gravity)
 
     def __len__(self): return len(self.links)
     def __iter__(self): return iter(self.links)
@@ -180,6 +332,10 @@ class DHRobot(RobotKinematics):
         robot/DHLink.py:633-673), base and tool included; the ETS lowering evaluated on the GPU is the same product (tests pin
         the two against each other).  The reference's signature is fkine(q, **kwargs) with the keywords unused."""
         self._refuse("fkine", **kwargs)
+        if isinstance(q, (list, tuple, np.ndarray)):
+            a = np.asarray(q)
+            if a.ndim == 1 and a.size > self.n and a.size % self.n == 0:
+                q = a.reshape(-1, self.n)                     # a flat run of configurations (getmatrix(q, (None, n)), robot/DHRobot.py:960)
         return self.ets().fkine(q)
 
     def fkine_all(self, q, old=None):
@@ -191,7 +347,7 @@ class DHRobot(RobotKinematics):
         for l in self.links:
             k += len(l.ets())
             marks.append(k)
-        return e.link_frames(q, marks)
+        return _poses(e.link_frames(q, marks))
 
     @staticmethod
     def _half(J, half):
