@@ -59,7 +59,8 @@ class ERobot(RobotKinematics):
     into one link per joint ("a link frame after every joint", named link0, link1, ...; :116-131).  Kinematics: the
     RobotKinematics surface over ets(start, end); dynamics: rne."""
 
-    def __init__(self, links, name="", gravity=(0, 0, -9.81), base=None, tool=None, manufacturer="", **kw):
+    def __init__(self, links, name="", gravity=(0, 0, -9.81), base=None, tool=None, manufacturer="", comment="", keywords=(), **kw):
+        self.comment, self.keywords = comment, tuple(keywords)
         if kw:
             raise TypeError("unexpected keyword argument(s): %s" % ", ".join(sorted(kw)))
         if isinstance(links, ET):

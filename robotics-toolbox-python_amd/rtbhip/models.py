@@ -61,6 +61,17 @@ class ERobot(RobotKinematics):
             made[(a, b)] = ETS([e for seg in segs[a:b + 1] for e in seg])
         return made[(a, b)]
 
+    def fkine_all(self, q):
+        """Poses of the base and of every link frame: (K+1,4,4) or (N,K+1,4,4) (reference Robot.fkine_all robot/Robot.py:638-698), one
+        chain walk per configuration."""
+        from .et import _poses
+        k = 0
+        marks = [0]
+        for seg in self._links():
+            k += len(seg)
+            marks.append(k)
+        return _poses(self._ets.link_frames(q, marks, base=self.base))
+
     # fkine, jacob0, jacobe, hessian0/e, jacob0_dot, manipulability, jacobm, jacob0_analytical, partial_fkine0, ik_* and ikine_*
     # come from RobotKinematics: each is self.ets(start, end).<method>(...) with the robot's base / tool, as in the reference.
 

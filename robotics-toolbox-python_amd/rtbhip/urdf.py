@@ -261,9 +261,16 @@ class URDFRobot:
     def hessian0(self, q=None, end=None, J0=None, tool=None): return self.ets(end).hessian0(q, J0=J0, tool=self._tool_for(end, tool))
     def hessiane(self, q=None, end=None, Je=None, tool=None): return self.ets(end).hessiane(q, Je=Je, tool=self._tool_for(end, tool))
     def manipulability(self, q=None, end=None, **kw):
-        e = self.ets(end)
+        e = self.ets(end)                                     # Robot.manipulability: self.ets(end, start), gripper tool included (robot/Robot.py:825)
         return e.manipulability(np.zeros(e.n) if q is None else q, **kw)      # q=None: the robot's stored configuration, zeros (BaseRobot.q)
-    def jacobm(self, q, end=None, **kw): return self.ets(end).jacobm(q, **kw)
+
+    # Robot.jacobm resolves `end` to a LINK first (robot/Robot.py:1182, _get_limit_links robot/BaseRobot.py:1478-1540) and drops the gripper
+    # tool it returns, so its Jacobian is that of the end LINK's frame -- unlike robot.manipulability(q) and robot.ets().jacobm(q), whose
+    # chain carries the tool.  (Only the translational measure can tell the two apart.)  Reproduced.
+
+    def jacobm(self, q=None, end=None, **kw):
+        e = self.ets(self.ee if end is None else end)
+        return e.jacobm(np.zeros(e.n) if q is None else q, **kw)
     def jacob0_dot(self, q, qd, end=None, **kw): return self.ets(end).jacob0_dot(q, qd, **kw)
     def jacob0_analytical(self, q, end=None, **kw): return self.ets(end).jacob0_analytical(q, **kw)
     def partial_fkine0(self, q, n=3, end=None): return self.ets(end).partial_fkine0(q, n)

@@ -76,7 +76,7 @@ def install_shims():
     for nm in dir(rtbhip):
         if not nm.startswith("_"):
             setattr(rtb, nm, getattr(rtbhip, nm))
-    rtb.Robot = rtbhip.models.ERobot
+    rtb.Robot = rtbhip.ERobot                  # Robot(ets) / Robot(links): robot/Robot.py:60-160
     rtb.ERobot = rtbhip.ERobot
     # rtb.models.<name>() are the URDF models in the reference, rtb.models.ETS.<name>() / rtb.models.DH.<name>() the ETS / DH ones
     rtb.models = types.SimpleNamespace(Panda=lambda: urdf.load("Panda"), UR5=lambda: urdf.load("UR5"), Puma560=lambda: urdf.load("Puma560"),
@@ -99,12 +99,14 @@ def install_shims():
         return H
     tools.hessian_numerical = hessian_numerical
     rtb.tools = tools
+    sg = ref_classes._Placeholders("spatialgeometry")                # shapes for collision / display: import targets only
     tests = types.ModuleType("tests")
     tests.__path__ = []
     marks = types.ModuleType("tests.marks")
     marks.skip_no_qp = pytest.mark.skipif(False, reason="")            # IK_QP runs on the device: no qpsolvers needed
+    marks.skip_no_pybullet = unittest.skip("pybullet (collision checking) is not part of this backend")
     new = {"spatialmath": sm, "spatialmath.base": smb, "spatialmath.base.argcheck": smb.argcheck, "spatialmath.base.symbolic": smb.symbolic,
-           "roboticstoolbox": rtb, "roboticstoolbox.tools": tools, "roboticstoolbox.robot": robot, "roboticstoolbox.robot.ET": etm, "tests": tests, "tests.marks": marks}
+           "roboticstoolbox": rtb, "spatialgeometry": sg, "roboticstoolbox.tools": tools, "roboticstoolbox.robot": robot, "roboticstoolbox.robot.ET": etm, "tests": tests, "tests.marks": marks}
     saved = {k: sys.modules.get(k) for k in new}
     sys.modules.update(new)
     return saved
