@@ -21,6 +21,7 @@ class ERobot(RobotKinematics):
         self.name, self.manufacturer = name, manufacturer
         self.base = None if base is None else np.asarray(base, dtype=np.float64)
         self.tool = None if tool is None else np.asarray(tool, dtype=np.float64)
+        self.q = np.zeros(self._ets.n)                         # the stored configuration (BaseRobot.q)
 
     @property
     def n(self): return self._ets.n

@@ -42,6 +42,29 @@ EXPECTED = {
     "test_jacob": {},
     "test_IK": {},
     "test_PoERobot": {},
+    "test_ERobot": {
+        **{t: "uses models.ETS.Planar2, a 2-D (ETS2) robot: the 2-D classes are not on the path" for t in (
+            "test_base", "test_jacobe", "test_plot", "test_plot_with_fellipse", "test_plot_with_vellipse", "test_teach")},
+        "test_collided": "pybullet collision checking: skipped by its own mark", "test_dist": "pybullet collision checking: skipped by its own mark",
+        "test_dict": "scene-graph dictionaries for the Swift visualiser (grippers, geometry): out of scope",
+        "test_fkdict": "scene-graph dictionaries for the Swift visualiser: out of scope",
+        "test_jacobm": SYM, "test_symdyn": SYM,
+    },
+    "test_Robot": {
+        "test_URDF": "URDF file reader as a class method (ERobot.URDF / xacro processing at run time): this backend ships pre-expanded descriptions",
+        "test_URDF2": "URDF file reader as a class method",
+        "test_asada": "Asada's measure needs the Cartesian inertia matrix: operational-space dynamics are not on the path",
+        "test_collided2": "pybullet collision checking: skipped by its own mark",
+        "test_link_collision_damper": "pybullet collision checking: skipped by its own mark",
+        "test_copy_init": "Robot(robot) copy-construction from a URDF model object",
+        **{t: "graphviz dot-file export: presentation, out of scope" for t in ("test_dotfile", "test_dotfile2", "test_dotfile3", "test_dotfile4", "test_showgraph")},
+        "test_erobot2": "ETS2 / ERobot2: the 2-D classes",
+        "test_fk_dict": "scene-graph dictionaries for the Swift visualiser", "test_to_dict": "scene-graph dictionaries for the Swift visualiser",
+        "test_fkine_all2": "models.YuMi as a Robot object with two grippers (this backend serves YuMi through rtbhip.urdf.load)",
+        "test_jtraj": "jtraj (trajectory generation): not on the path", "test_jtraj2": "jtraj (trajectory generation): not on the path",
+        "test_qlim_setters": "per-link qlim setters of a URDF Robot's Link objects",
+        "test_velocity_damper": "joint_velocity_damper (a controller helper): not on the path",
+    },
     "test_DHRobot": {
         **{t: "plotting / teach panels: out of scope" for t in (
             "test_plot", "test_plot_traj", "test_plot_fellipse", "test_plot_vellipse", "test_plot_with_fellipse", "test_plot_with_vellipse",
@@ -156,7 +179,7 @@ def run_module(mod):
     return out
 
 
-@pytest.mark.parametrize("name", ["test_ET", "test_ETS", "test_jacob", "test_IK", "test_PoERobot", "test_DHRobot"])
+@pytest.mark.parametrize("name", ["test_ET", "test_ETS", "test_jacob", "test_IK", "test_PoERobot", "test_DHRobot", "test_ERobot", "test_Robot"])
 def test_reference_test_file(name):
     np.random.seed(0)
     saved = install_shims()
@@ -165,7 +188,7 @@ def test_reference_test_file(name):
         results = run_module(mod)
     finally:
         restore(saved)
-    assert len(results) >= {"test_ET": 31, "test_ETS": 43, "test_jacob": 12, "test_IK": 36, "test_PoERobot": 1, "test_DHRobot": 71}[name], sorted(results)
+    assert len(results) >= {"test_ET": 31, "test_ETS": 43, "test_jacob": 12, "test_IK": 36, "test_PoERobot": 1, "test_DHRobot": 71, "test_ERobot": 15, "test_Robot": 35}[name], sorted(results)
     failed = {k: v for k, v in results.items() if v is not None}
     either = DRAW_DEPENDENT.get(name, {})
     unexpected = {k: v for k, v in failed.items() if k not in EXPECTED[name] and k not in either}
