@@ -32,6 +32,7 @@ struct IkDev {   // wave-uniform solver parameters (kernarg)
     int32_t ilimit, slimit, reject_jl, method, flavour, has_q0;
     int32_t fresh_cap, pool_chunk;   // scheduler: fresh targets a wave may start per pass / reserves per refill
     int32_t pass_mask, spec_policy;  // scheduler: the pass runs on iterations with (tick & pass_mask) == 0; 0 round-robin / 1 failure-weighted speculation
+    int32_t unit_we, pad_we;         // every we[k] == 1 (the default mask): W J and W e need no products -- the same bits, 48 multiplies fewer per iteration
     double tol, lambda;
     double we[6];
     uint64_t seed;
@@ -105,7 +106,7 @@ RTB_HD void ik_angle_axis(const Pose &P, TD Td, double (&e)[6])
 
 // ---------------------------------------------------------------- one LM step
 // dq = (J^T W J + wn I)^-1 J^T W e, J in registers (slot r*NJ + j), W = diag(we).
-template <int NJ, class W>
+template <int NJ, bool UNITW = false, class W>
 RTB_HD void ik_lm_step(const double (&jac)[6 * NJ], const double (&e)[6], W we /* we[k], k < 6 */, double wn,
                        double (&dq)[NJ])
 {
@@ -113,7 +114,7 @@ RTB_HD void ik_lm_step(const double (&jac)[6 * NJ], const double (&e)[6], W we /
     double g[NJ];
     double we_e[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) we_e[k] = we[k] * e[k];
+    for (int k = 0; k < 6; ++k) we_e[k] = UNITW ? e[k] : we[k] * e[k];       // (x * 1.0 == x exactly: the unit-weight form returns the same bits)
     // row r of W J once (6 products), then each of its normal-equation entries is 6 fused multiply-adds on it:
     // the same products in the same order as (J[k][r] * we[k]) * J[k][c], formed 7 times instead of 28
 #pragma unroll
@@ -122,7 +123,7 @@ RTB_HD void ik_lm_step(const double (&jac)[6 * NJ], const double (&e)[6], W we /
         double s = 0.0;
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            wjr[k] = jac[k * NJ + r] * we[k];
+            wjr[k] = UNITW ? jac[k * NJ + r] : jac[k * NJ + r] * we[k];
             s += jac[k * NJ + r] * we_e[k];
         }
         g[r] = s;
@@ -487,7 +488,8 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, Q
         if (!qp_done) ik_pinv_step<NJ>(jac, e, rows, d2, &p.we[0], p.method == 3, dq);
     } else {
         const double wn = (p.method == 1) ? p.lambda : (p.method == 2) ? E + p.lambda : p.lambda * E;   // ik.cpp:169,183,205
-        ik_lm_step<NJ>(jac, e, &p.we[0], wn, dq);
+        if (p.unit_we) ik_lm_step<NJ, true>(jac, e, &p.we[0], wn, dq);          // wave-uniform
+        else ik_lm_step<NJ, false>(jac, e, &p.we[0], wn, dq);
     }
     if constexpr (NULLSP) {
         if (!qp_done) {                // (the bounded QP returns the whole step)

@@ -438,6 +438,7 @@ int g_ik_phased = 0;      // 0 never (default: the CPU replay and the GPU both s
 int g_ik_spec_policy = 0;
 int g_ik_fresh_pct = 50;  // share of a wave's even part of the batch it may start per scheduling pass, in percent: the rest is
                           // drawn as lanes fall idle, so quick waves take more (1e5 Panda targets: 1.60 ms at 100, 1.49-1.52 at 35-80)
+int g_ik_unit_we = 1;          // rtbhip_tune("ik_unit_we", 0): the weighted LM step even for a mask of ones (A/B)
 int g_ik_waves_per_cu = 8;
 int g_ik_pass_mask = 3;   // measured on MI355X, 1e6 Panda targets: 8.20 (0) / 7.75 (1) / 7.66 (3) / 8.08 ms (7)
 std::mutex g_ctr_mu;
@@ -448,6 +449,7 @@ constexpr int kCtrRing = 256;
 
 void ik_tune(const char *key, int value)
 {
+    if (std::string(key) == "ik_unit_we") g_ik_unit_we = value != 0;
     if (std::string(key) == "ik_waves_per_cu") g_ik_waves_per_cu = value < 1 ? 1 : value;
     if (std::string(key) == "ik_flat") g_ik_flat = value < 0 ? 0 : (value > 2 ? 2 : value);
     if (std::string(key) == "ik_flat_l0") g_ik_flat_l0 = value < 1 ? 1 : value;
@@ -530,6 +532,8 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
     p.ilimit = ip.ilimit; p.slimit = ip.slimit; p.reject_jl = ip.reject_jl; p.method = ip.method;
     p.flavour = ip.flavour; p.has_q0 = q0 != nullptr; p.tol = ip.tol; p.lambda = ip.lambda;
     for (int k = 0; k < 6; ++k) p.we[k] = ip.we[k];
+    p.unit_we = g_ik_unit_we; p.pad_we = 0;
+    for (int k = 0; k < 6; ++k) p.unit_we = p.unit_we && p.we[k] == 1.0;
     p.seed = ip.seed; p.target0 = ip.target0;
     p.N = N;
     p.kq = ip.kq; p.km = ip.km; p.ps = ip.ps; p.ks = ip.ks;

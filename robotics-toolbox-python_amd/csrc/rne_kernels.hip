@@ -152,6 +152,20 @@ __global__ __launch_bounds__(kW, RTB_RNE_WAVES) void k_rne(RneParams rp, const D
     rne_tile<NJ, MDH, ALLREV>(rp, (ConstLinks)links_g, NJ, rne_stride(NJ), blockIdx.x, q, qd, qdd, tau, lds, threadIdx.x);
 }
 
+// The same tile function, WPB waves per workgroup, every wave on a tile of its own (rtbhip_tune("rne_wpb", 2 | 4)): a quarter of the
+// workgroup launches for the same waves.  The two barriers of rne_tile then couple the workgroup's waves (they load, compute and store in
+// step); tiles past the end are empty (count <= 0: nothing loaded, nothing stored).
+template <int NJ, bool MDH, bool ALLREV, int WPB>
+__global__ __launch_bounds__(kW * WPB, RTB_RNE_WAVES) void k_rne_wpb(RneParams rp, const DevLink *links_g, const double *__restrict__ q,
+                                                                     const double *__restrict__ qd, const double *__restrict__ qdd,
+                                                                     double *__restrict__ tau)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int wave = threadIdx.x / kW, lane = threadIdx.x % kW;
+    const int stride = rne_stride(NJ);
+    rne_tile<NJ, MDH, ALLREV>(rp, (ConstLinks)links_g, NJ, stride, (int64_t)blockIdx.x * WPB + wave, q, qd, qdd, tau, lds + wave * kW * stride, lane);
+}
+
 // Persistent form of k_rne (rtbhip_tune("rne_persist", 1)): the grid is sized to the chip (three waves per SIMD) and every wave walks
 // tiles blockIdx.x, + gridDim.x, ... .  The loop the comment above warns about, made safe the way k_ik does it: the link-table pointer is
 // laundered once per trip, so the scalar loads stay inside the trip (the scalar cache serves them) instead of being hoisted into SGPRs that
@@ -198,10 +212,11 @@ __global__ __launch_bounds__(kW) void k_rne_rt(RneParams rp, const DevLink *link
     }
 }
 
-namespace { int g_rne_tiles_per_wave = 1; int g_rne_persist = 0; }
+namespace { int g_rne_tiles_per_wave = 1; int g_rne_persist = 0; int g_rne_wpb = 1; }
 void rne_tune(const char *key, int value)
 {
     if (std::string(key) == "rne_persist") g_rne_persist = value < 0 ? 0 : (value > 4 ? 4 : value);      // waves per SIMD of the persistent grid, 0 = one tile per workgroup
+    if (std::string(key) == "rne_wpb") g_rne_wpb = (value == 2 || value == 4) ? value : 1;
     if (std::string(key) == "rne_tiles_per_wave") g_rne_tiles_per_wave = value < 1 ? 1 : value;
 }
 
@@ -220,6 +235,14 @@ static void launch_nj(bool mdh, bool allrev, dim3 grid, size_t lds, hipStream_t 
             const dim3 pg((unsigned)(cus * 4 * g_rne_persist));          // g_rne_persist waves per SIMD
             if (mdh) hipLaunchKernelGGL((k_rne_persist<NJ, true, true>), pg, dim3(kW), lds, s, rp, links, q, qd, qdd, tau);
             else hipLaunchKernelGGL((k_rne_persist<NJ, false, true>), pg, dim3(kW), lds, s, rp, links, q, qd, qdd, tau);
+            return;
+        }
+    }
+    if constexpr (NJ == 7) {                              // A/B knob, the benchmark's instantiation only
+        if (g_rne_wpb > 1 && mdh && allrev) {
+            const dim3 g2((grid.x + g_rne_wpb - 1) / g_rne_wpb);
+            if (g_rne_wpb == 2) hipLaunchKernelGGL((k_rne_wpb<NJ, true, true, 2>), g2, dim3(kW * 2), lds * 2, s, rp, links, q, qd, qdd, tau);
+            else hipLaunchKernelGGL((k_rne_wpb<NJ, true, true, 4>), g2, dim3(kW * 4), lds * 4, s, rp, links, q, qd, qdd, tau);
             return;
         }
     }

@@ -40,6 +40,8 @@ extern "C" int emu_ik(rtbhip_chain_t h, const double *Tep, int64_t N, const doub
     p.kq = g_emu_ns[0]; p.km = g_emu_ns[1]; p.ps = g_emu_ns[2]; for (int j = 0; j < 16; ++j) p.pi[j] = g_emu_pi[j]; p.ks = g_emu_ks; p.target0 = g_emu_target0;
     p.flat_chunks = 0; p.flat_l0 = 0; p.flat_len = 0; p.flat_n = 0; p.flat_done = nullptr; p.stats = nullptr;
     for (int k = 0; k < 6; ++k) p.we[k] = we6 ? we6[k] : 1.0;
+    p.unit_we = 1; p.pad_we = 0;
+    for (int k = 0; k < 6; ++k) p.unit_we = p.unit_we && p.we[k] == 1.0;
     switch (c->n) {
     case 1: emu_ik_run<1>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;
     case 2: emu_ik_run<2>(c, p, Tep, q0, q_out, success, iters, searches, residual); break;

@@ -14,6 +14,8 @@ extern "C" int emu_ik_wave(rtbhip_chain_t h, int waves, double *stats, const dou
     p.kq = g_emu_ns[0]; p.km = g_emu_ns[1]; p.ps = g_emu_ns[2]; for (int j = 0; j < 16; ++j) p.pi[j] = g_emu_pi[j]; p.ks = g_emu_ks; p.target0 = g_emu_target0;
     p.flat_chunks = 0; p.flat_l0 = 0; p.flat_len = 0; p.flat_n = 0; p.flat_done = nullptr; p.stats = nullptr;
     for (int k = 0; k < 6; ++k) p.we[k] = we6 ? we6[k] : 1.0;
+    p.unit_we = 1; p.pad_we = 0;
+    for (int k = 0; k < 6; ++k) p.unit_we = p.unit_we && p.we[k] == 1.0;
     if (const char *pm = getenv("EMU_IK_PASS_MASK")) p.pass_mask = atoi(pm);
     { const int64_t g = waves; const int64_t cap = (N + g - 1) / g; p.fresh_cap = cap > 64 ? 64 : (int)cap;
       const int64_t lanes = g * kWave; p.pool_chunk = N >= 8 * lanes ? 64 : (N >= 3 * lanes ? 16 : 0); }
