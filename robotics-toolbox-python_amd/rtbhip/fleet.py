@@ -8,12 +8,15 @@ from . import _lib
 from ._lib import check, lib, as_numeric, is_torch, MEM_HOST, MEM_DEVICE
 
 
-def fleet_fkine_jacob(chains, qs, frame=0):
+def fleet_fkine_jacob(chains, qs, frame=0, out=None):
     """chains: list of ETS; qs: list of (N_c, n_c) arrays (all NumPy or all CUDA float64 tensors).
-    Returns (list of T (N_c,4,4), list of J (N_c,6,n_c))."""
+    Returns (list of T (N_c,4,4), list of J (N_c,6,n_c)).  `out` = (Ts, Js) of an earlier call: the results are written into those
+    buffers (a serving loop then allocates nothing per step)."""
     if len(chains) != len(qs):
         raise ValueError("one q batch per chain")
     k = len(chains)
+    if out is not None and (len(out) != 2 or len(out[0]) != k or len(out[1]) != k):
+        raise ValueError("out must be (Ts, Js) with one buffer per chain")
     tm = k > 0 and is_torch(qs[0]) and qs[0].is_cuda
     handles = (C.c_uint64 * max(1, k))()
     qp = (C.c_void_p * max(1, k))()
@@ -27,13 +30,25 @@ def fleet_fkine_jacob(chains, qs, frame=0):
             import torch
             q2 = q.reshape(-1, ch.q_width).contiguous()
             _lib.note_device(q2)
-            T = torch.empty((q2.shape[0], 4, 4), dtype=torch.float64, device=q2.device)
-            J = torch.empty((q2.shape[0], 6, ch.n), dtype=torch.float64, device=q2.device)
+            if out is None:
+                T = torch.empty((q2.shape[0], 4, 4), dtype=torch.float64, device=q2.device)
+                J = torch.empty((q2.shape[0], 6, ch.n), dtype=torch.float64, device=q2.device)
+            else:
+                T, J = out[0][i], out[1][i]
+                if (tuple(T.shape) != (q2.shape[0], 4, 4) or tuple(J.shape) != (q2.shape[0], 6, ch.n) or not T.is_contiguous()
+                        or not J.is_contiguous() or T.dtype != torch.float64 or J.dtype != torch.float64 or T.device != q2.device):
+                    raise ValueError("out buffers of chain %d do not match its batch" % i)
             qp[i], Tp[i], Jp[i] = q2.data_ptr(), T.data_ptr(), J.data_ptr()
         else:
             q2 = np.ascontiguousarray(as_numeric(q).reshape(-1, ch.q_width))
-            T = _lib.host_empty((q2.shape[0], 4, 4))
-            J = _lib.host_empty((q2.shape[0], 6, ch.n))
+            if out is None:
+                T = _lib.host_empty((q2.shape[0], 4, 4))
+                J = _lib.host_empty((q2.shape[0], 6, ch.n))
+            else:
+                T, J = out[0][i], out[1][i]
+                if (not isinstance(T, np.ndarray) or T.shape != (q2.shape[0], 4, 4) or J.shape != (q2.shape[0], 6, ch.n)
+                        or not T.flags.c_contiguous or not J.flags.c_contiguous or T.dtype != np.float64 or J.dtype != np.float64):
+                    raise ValueError("out buffers of chain %d do not match its batch" % i)
             qp[i], Tp[i], Jp[i] = q2.ctypes.data, T.ctypes.data, J.ctypes.data
         Ns[i] = q2.shape[0]
         keep.append(q2)

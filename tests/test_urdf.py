@@ -113,6 +113,26 @@ def test_gpu_fleet16_urdf_arms_one_launch_vs_oracle():
         Tb, Jb = c.fkine_jacob0(q)                       # the per-chain kernels agree with the fleet kernel
         nt.assert_allclose(T, np.reshape(Tb, T.shape), atol=1e-13)
         nt.assert_allclose(J, np.reshape(Jb, J.shape), atol=1e-13)
+    # out=: a second call writes into the buffers of the first (host arrays and device tensors)
+    want = [T.copy() for T in Ts], [J.copy() for J in Js]
+    for T, J in zip(Ts, Js):
+        T[...] = 0; J[...] = 0
+    T2, J2 = rtbhip.fleet_fkine_jacob(chs, qs, out=(Ts, Js))
+    assert all(a is b for a, b in zip(T2, Ts)) and all(a is b for a, b in zip(J2, Js))
+    for a, b in zip(Ts + Js, want[0] + want[1]):
+        nt.assert_array_equal(a, b)
+    import torch
+    qd = [torch.from_numpy(q).cuda() for q in qs]
+    Td, Jd = rtbhip.fleet_fkine_jacob(chs, qd)
+    ptrs = [t.data_ptr() for t in Td + Jd]
+    for t in Td + Jd:
+        t.zero_()
+    Td2, Jd2 = rtbhip.fleet_fkine_jacob(chs, qd, out=(Td, Jd))
+    assert [t.data_ptr() for t in Td2 + Jd2] == ptrs
+    for a, b in zip(Td + Jd, want[0] + want[1]):
+        nt.assert_array_equal(a.cpu().numpy(), b)
+    with pytest.raises(ValueError):
+        rtbhip.fleet_fkine_jacob(chs, qd, out=(Td[:-1], Jd))
 
 
 @pytest.mark.gpu
