@@ -192,7 +192,9 @@ RTB_HD void tree_rne_lane(GroupsP groups, int nslots, V3 gravity, InQ qin, InQd 
 // ---- the Dynamics-mixin terms of an ETS robot (robot/Dynamics.py:704-861, 424-509 on Robot.rne): every Newton-Euler pass the
 // reference makes for ONE configuration, in one lane, as dyn_device.h does for DH chains.
 //   mine : this lane's inputs [q (n) | qd (n) | torque (n)] (what the mode needs)      mA : n x n tile, row-major
-//   inertia   mA[i][:] = rne(q, 0, e_i, gravity 0)                    (the unsymmetrised rows the reference returns, :752-758)
+//   inertia   pass i = rne(q, 0, e_i, gravity 0) gives row i of M (:752-758); kept: its entries j >= i, in the packed lower triangle
+//             mA[j (j + 1) / 2 + i] -- the kernel's flush mirrors them (M is symmetric; the mirrored half differs from the reference's
+//             separately rounded entries by rounding only), 21 instead of 36 doubles of LDS per lane for n = 6
 //   coriolis  mA = C(q, qd): the polar form / the reference's own 28-pass scheme, chosen per row exactly as dyn_device.h does
 //   accel     mA[0..n) = qdd = M^-1 (torque - rne(q, qd, 0))          (:492-505; M's lower triangle, LDL^T)
 template <int NG>
@@ -231,7 +233,7 @@ RTB_HD void tree_dyn_lane(GroupsP groups, int nslots, const double *mine, double
         for (int i = 0; i < NG; ++i) {
             tree_opaque<NG>(sn, cs);
             tree_rne_core<NG>(groups, nslots, sn, cs, zero, qin, none, [&](int j) { return j == i ? 1.0 : 0.0; },
-                              [&](int j, double v) { mA[i * NG + j] = v; }, slot);
+                              [&](int j, double v) { if (j >= i) mA[j * (j + 1) / 2 + i] = v; }, slot);
         }
     }
     if (MODE == kDynAccel) {

@@ -123,6 +123,29 @@ int launch_tree_rne(const Tree *t, const DevGroup *groups, const double *q, cons
 // inputs arrive and results leave through the same coalesced tile copies as k_tree_rne.  Robots of up to 12 joints.
 constexpr int kTreeDynMax = 12;
 
+// packed lower triangles (row r, column c <= r at r (r + 1) / 2 + c) of ncfg lanes -> the full symmetric (n, n) matrices, one contiguous run
+template <int NG>
+__device__ __forceinline__ void tree_flush_symmetric(const double *rows, int stride, int ncfg, double *__restrict__ dst, int lane)
+{
+    constexpr int W = NG * NG;
+    const int total = ncfg * W;
+    auto at = [&](int f) {
+        const int cfg = f / W, rem = f - cfg * W, r = rem / NG, c = rem - r * NG;
+        const int hi = r > c ? r : c, lo = r > c ? c : r;
+        return rows[cfg * stride + hi * (hi + 1) / 2 + lo];
+    };
+    for (int f = 2 * lane; f < total; f += 2 * kWave) {
+        const double a = at(f);
+        if (f + 1 < total) {
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            v2d w = {a, at(f + 1)};
+            __builtin_nontemporal_store(w, reinterpret_cast<v2d *>(dst + f));
+        } else {
+            __builtin_nontemporal_store(a, dst + f);
+        }
+    }
+}
+
 template <int NG, int MODE>
 __global__ __launch_bounds__(kWave, 1) void k_tree_dyn(TreeParams tp, const DevGroup *groups_g, const double *__restrict__ q,
                                                        const double *__restrict__ qd, const double *__restrict__ tq,
@@ -132,7 +155,8 @@ __global__ __launch_bounds__(kWave, 1) void k_tree_dyn(TreeParams tp, const DevG
     ConstGroups groups = (ConstGroups)groups_g;
     const int lane = threadIdx.x;
     constexpr int K = MODE == kDynInertia ? 1 : (MODE == kDynCoriolis ? 2 : 3);
-    constexpr int W = MODE == kDynAccel ? NG * (NG + 1) / 2 + NG : NG * NG;      // accel: packed lower triangle (>= n doubles: qdd leaves from its head)
+    // accel and inertia: packed lower triangle (accel: >= n doubles, qdd leaves from its head); coriolis: the full n x n tile
+    constexpr int W = MODE == kDynCoriolis ? NG * NG : NG * (NG + 1) / 2 + (MODE == kDynAccel ? NG : 0);
     constexpr int in_stride = (K * NG) | 1, w_stride = W | 1;
     double *A = lds + kWave * in_stride;
     double *slots = A + kWave * w_stride;
@@ -161,6 +185,7 @@ __global__ __launch_bounds__(kWave, 1) void k_tree_dyn(TreeParams tp, const DevG
                                 [&](int i) -> double & { return slots[i * kWave + lane]; });
     __syncthreads();
     if (MODE == kDynAccel) flush_run(A, w_stride, NG, ncfg, out + cfg0 * NG, lane);
+    else if (MODE == kDynInertia) tree_flush_symmetric<NG>(A, w_stride, ncfg, out + cfg0 * (NG * NG), lane);
     else flush_run(A, w_stride, NG * NG, ncfg, out + cfg0 * (NG * NG), lane);
 }
 
@@ -169,7 +194,7 @@ static hipError_t launch_tree_dyn_one(dim3 grid, hipStream_t s, int nslots, cons
                                       const double *qd, const double *tq, double *out, size_t *lds_out)
 {
     constexpr int K = MODE == kDynInertia ? 1 : (MODE == kDynCoriolis ? 2 : 3);
-    constexpr int W = MODE == kDynAccel ? NG * (NG + 1) / 2 + NG : NG * NG;
+    constexpr int W = MODE == kDynCoriolis ? NG * NG : NG * (NG + 1) / 2 + (MODE == kDynAccel ? NG : 0);
     const size_t lds = (size_t)kWave * (((K * NG) | 1) + (W | 1) + kTreeSlotDoubles * nslots) * sizeof(double);
     *lds_out = lds;
     if (lds > 160 * 1024) return hipSuccess;          // reported by the caller
