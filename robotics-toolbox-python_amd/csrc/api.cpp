@@ -1170,6 +1170,14 @@ int rtbhip_last_launch(int32_t *grid, int32_t *block, int32_t *lds_bytes)
     return RTBHIP_OK;
 }
 
+int rtbhip_stream_probe(const double *src, int64_t read_doubles, double *dst, int64_t write_doubles, void *stream)
+{
+    if ((read_doubles > 0 && !src) || (write_doubles > 0 && !dst) || read_doubles < 0 || write_doubles < 0) { set_error("stream_probe: bad argument"); return RTBHIP_EINVAL; }
+    DeviceScope dscope;
+    RTB_TRY(check_batch("stream_probe", dst ? dst : src, 1, RTBHIP_MEM_DEVICE, &dscope));
+    return launch_stream_probe(src, read_doubles, dst, write_doubles, (hipStream_t)stream);
+}
+
 int rtbhip_tune(const char *key, int32_t value)
 {
     if (!key) { set_error("tune: NULL key"); return RTBHIP_EINVAL; }

@@ -60,4 +60,25 @@ int launch_frames(const Chain *c, const DevChain &dc, const FrameTable &ft, cons
     return RTBHIP_OK;
 }
 
+// ---- measurement aid (bench.py): a plain streaming kernel with a given read / write mix -- what this GPU delivers, on this box, today, for the
+// headline kernel's traffic pattern (56 MB read, 464 MB written per launch), to put next to the 8 TB/s of the data sheet.  16-byte coalesced
+// loads, 16-byte non-temporal stores, 2048 workgroups of 256 threads grid-striding.
+__global__ __launch_bounds__(256) void k_stream_probe(const double *__restrict__ src, int64_t nr2, double *__restrict__ dst, int64_t nw2)
+{
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+    v2d acc = {0.0, 0.0};
+    for (int64_t i = tid; i < nr2; i += nth) acc += reinterpret_cast<const v2d *>(src)[i];
+    const v2d w = {(double)tid, acc.x + acc.y == -1.2345e300 ? 1.0 : 0.0};      // the sum stays live, the stored values do not depend on it in practice
+    for (int64_t i = tid; i < nw2; i += nth) __builtin_nontemporal_store(w, reinterpret_cast<v2d *>(dst) + i);
+}
+
+int launch_stream_probe(const double *src, int64_t read_doubles, double *dst, int64_t write_doubles, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_stream_probe, dim3(2048), dim3(256), 0, s, src, read_doubles / 2, dst, write_doubles / 2);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "k_stream_probe launch");
+    return RTBHIP_OK;
+}
+
 }  // namespace rtbhip

@@ -87,6 +87,7 @@ std::shared_ptr<Tree> tree_from_handle(rtbhip_tree_t h);
 int tree_device_groups(Tree *t, const DevGroup **out);
 int launch_tree_rne(const Tree *t, const DevGroup *groups, const double *q, const double *qd, const double *qdd, int64_t N,
                     const double *grav3, double *tau, hipStream_t s);
+int launch_stream_probe(const double *src, int64_t read_doubles, double *dst, int64_t write_doubles, hipStream_t s);
 int launch_tree_dyn(const Tree *t, const DevGroup *groups, int mode /* 0 inertia, 1 coriolis, 2 accel */, const double *q, const double *qd,
                     const double *tq, int64_t N, const double *grav3, double *out, hipStream_t s);
 

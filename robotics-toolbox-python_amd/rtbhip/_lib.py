@@ -95,6 +95,7 @@ SIGNATURES = {
     "rtbhip_shard_range": (C.c_int, [_i64, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
     "rtbhip_last_launch": (C.c_int, [_ip, _ip, _ip]),
     "rtbhip_tune": (C.c_int, [C.c_char_p, _i32]),
+    "rtbhip_stream_probe": (C.c_int, [_vp, _i64, _vp, _i64, _vp]),
 }
 
 _lib = None
