@@ -192,8 +192,11 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         pms = e0.elapsed_time(e1) / 20
-        probe = {"kernel": "k_stream_probe: 16-byte coalesced loads of 56 B and non-temporal stores of 464 B per configuration, nothing else",
-                 "ms": pms, "GBs": BYTES_PER_CONFIG * N / (pms * 1e-3) / 1e9}
+        moved = ((N * 7) // 512 + (N * 58) // 512) * 4096           # whole 4 KiB pages (the kernel leaves the tails alone)
+        probe = {"kernel": "k_stream_probe: single-wave workgroups, one aligned 4 KiB page of 16-byte non-temporal stores each (the best pattern of "
+                           "profiles/r01_k_write_probe.txt = the rate of hipMemsetAsync), every 8th also loads a page; 56 B read + 464 B written per "
+                           "configuration, no arithmetic",
+                 "ms": pms, "GBs": moved / (pms * 1e-3) / 1e9}
         del dst
     # the one exchange of the path, outside the timed region: T|J rows of every rank to every rank
     gather_ms = rk.gather_ms(torch.cat([T.reshape(N, 16), J.reshape(N, 42)], dim=1)) if rk.dist is not None else None

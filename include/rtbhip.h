@@ -333,7 +333,7 @@ int rtbhip_last_launch(int32_t *grid, int32_t *block, int32_t *lds_bytes);
  *         "partial3" 1 | 0 (order-3 partial_fkine0 on workgroups that own whole configurations / on the general kernel),
  *         "host_chunk_kb" (host-pointer pipeline). */
 /* Measurement aid, no reference counterpart: one launch of a plain streaming kernel that reads `read_doubles` doubles from `src` and writes
- * `write_doubles` doubles to `dst` (device pointers, even counts) -- the memory rate this GPU delivers for a given read / write mix, which
+ * `write_doubles` doubles to `dst` (device pointers, 4 KiB-aligned; whole 4 KiB pages are moved, the tails are left alone) -- the memory rate this GPU delivers for a given read / write mix, which
  * bench.py reports next to the headline kernel's rate. */
 int rtbhip_stream_probe(const double *src, int64_t read_doubles, double *dst, int64_t write_doubles, void *stream);
 

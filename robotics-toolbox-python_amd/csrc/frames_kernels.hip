@@ -61,21 +61,37 @@ int launch_frames(const Chain *c, const DevChain &dc, const FrameTable &ft, cons
 }
 
 // ---- measurement aid (bench.py): a plain streaming kernel with a given read / write mix -- what this GPU delivers, on this box, today, for the
-// headline kernel's traffic pattern (56 MB read, 464 MB written per launch), to put next to the 8 TB/s of the data sheet.  16-byte coalesced
-// loads, 16-byte non-temporal stores, 2048 workgroups of 256 threads grid-striding.
-__global__ __launch_bounds__(256) void k_stream_probe(const double *__restrict__ src, int64_t nr2, double *__restrict__ dst, int64_t nw2)
+// headline kernel's traffic (56 MB read, 464 MB written per launch), to put next to the 8 TB/s of the data sheet.  The pattern is the best
+// one of the round-1 write probe (scripts/write_probe.hip, profiles/r01_k_write_probe.txt: the rate of hipMemsetAsync): single-wave workgroups,
+// each storing exactly one aligned 4 KiB page with 16-byte non-temporal stores; every `rstep`-th workgroup also loads one 4 KiB page of `src`.
+__global__ __launch_bounds__(64) void k_stream_probe(const double *__restrict__ src, int64_t rpages, int rstep, double *__restrict__ dst, int64_t wpages)
 {
     typedef double v2d __attribute__((ext_vector_type(2)));
-    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+    const int64_t b = blockIdx.x;
+    const int lane = threadIdx.x;
     v2d acc = {0.0, 0.0};
-    for (int64_t i = tid; i < nr2; i += nth) acc += reinterpret_cast<const v2d *>(src)[i];
-    const v2d w = {(double)tid, acc.x + acc.y == -1.2345e300 ? 1.0 : 0.0};      // the sum stays live, the stored values do not depend on it in practice
-    for (int64_t i = tid; i < nw2; i += nth) __builtin_nontemporal_store(w, reinterpret_cast<v2d *>(dst) + i);
+    if (b % rstep == 0 && b / rstep < rpages) {
+        const v2d *p = reinterpret_cast<const v2d *>(src) + (b / rstep) * 256;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc += p[k * 64 + lane];
+    }
+    if (b < wpages) {
+        const v2d w = {(double)b, acc.x + acc.y == -1.2345e300 ? 1.0 : 0.0};      // the loaded values stay live; in practice they do not change what is stored
+        v2d *o = reinterpret_cast<v2d *>(dst) + b * 256;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(w, o + k * 64 + lane);
+    }
 }
 
 int launch_stream_probe(const double *src, int64_t read_doubles, double *dst, int64_t write_doubles, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_stream_probe, dim3(2048), dim3(256), 0, s, src, read_doubles / 2, dst, write_doubles / 2);
+    const int64_t rpages = read_doubles / 512, wpages = write_doubles / 512;      // whole 4 KiB pages only (the tails are not touched)
+    const int64_t grid = wpages > 0 ? wpages : rpages;
+    if (grid <= 0) return RTBHIP_OK;
+    if (grid > 0x7fffffff) { set_error("stream_probe: too large for one launch"); return RTBHIP_ELIMIT; }
+    int rstep = rpages > 0 && wpages > 0 ? (int)(wpages / rpages) : 1;
+    if (rstep < 1) rstep = 1;
+    hipLaunchKernelGGL(k_stream_probe, dim3((unsigned)grid), dim3(64), 0, s, src, rpages, rstep, dst, wpages);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "k_stream_probe launch");
     return RTBHIP_OK;
