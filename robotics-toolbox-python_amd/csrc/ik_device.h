@@ -22,6 +22,10 @@
 #include "ldl.h"
 #include "diff_device.h"
 
+#ifndef RTB_IK_UNITW
+#define RTB_IK_UNITW 0          // 1: a second, multiplication-free copy of the LM step for a mask of ones.  Measured (round 3, visit y, four builds on
+#endif                          // one box): the copy costs 30 VGPRs (223 -> 256 + scratch) and 4-8 % of every IK line; the 48 products it saves do not pay
+
 namespace rtbhip {
 
 constexpr double kIkPi = 3.14159265358979323846264338327950288;   // linalg.h:19
@@ -488,7 +492,7 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, Q
         if (!qp_done) ik_pinv_step<NJ>(jac, e, rows, d2, &p.we[0], p.method == 3, dq);
     } else {
         const double wn = (p.method == 1) ? p.lambda : (p.method == 2) ? E + p.lambda : p.lambda * E;   // ik.cpp:169,183,205
-        if (p.unit_we) ik_lm_step<NJ, true>(jac, e, &p.we[0], wn, dq);          // wave-uniform
+        if (RTB_IK_UNITW && p.unit_we) ik_lm_step<NJ, true>(jac, e, &p.we[0], wn, dq);          // wave-uniform
         else ik_lm_step<NJ, false>(jac, e, &p.we[0], wn, dq);
     }
     if constexpr (NULLSP) {

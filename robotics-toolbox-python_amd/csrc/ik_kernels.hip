@@ -58,7 +58,10 @@ constexpr int kIkNullMax = 12;   // null-space step variants: 6..8 joints in reg
 #ifndef RTB_IK_SHARE
 #define RTB_IK_SHARE 1          // 0: build without the cross-wave sharing code (A/B of what its presence costs the plain schedule)
 #endif
-template <int NJ, int STEP>
+// AUX: bit 0 = the flat schedule, bit 1 = the per-wave diagnostic counters (RTBHIP_IK_STATS).  Compile-time, because carrying either through the
+// persistent loop as run-time switches cost the plain schedule 6-9 % (20 VGPRs; round 3, visit x: the round-2 build against this one on one box).
+constexpr int kIkAuxFlat = 1, kIkAuxStats = 2;
+template <int NJ, int STEP, int AUX = 0>
 __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull) ? RTB_IK_WAVES : 1)) void k_ik(IkDev p, DevChain dc, const double *qlim_g, const double *__restrict__ Tep,
                                                 const double *__restrict__ q0, unsigned long long *counter,
                                                 double *__restrict__ q_out, int32_t *__restrict__ success,
@@ -80,7 +83,8 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
     bool drained = false;            // wave-uniform: the device-wide counter has passed N
     unsigned long long pool_next = 0, pool_end = 0;   // wave-uniform: targets reserved by this wave and not started yet
     unsigned long long pool_live = 0;                 // flat schedule, wave-uniform: bit k = item pool_next + k was drawn, is still worth starting and has not been started
-    const bool flat = p.flat_chunks > 0;              // wave-uniform
+    constexpr bool flat = (AUX & kIkAuxFlat) != 0;    // the launcher picks this instantiation exactly when p.flat_chunks > 0
+    constexpr bool kStats = (AUX & kIkAuxStats) != 0;
     bool evidence = false;                            // flat schedule, wave-uniform: one of this wave's own chunk-0 items has FAILED -- first chunks do fail in this batch
     bool c0_out = false;                              // flat schedule, wave-uniform: the device-wide counter has passed the chunk-0 numbers
     unsigned long long st_iters = 0, st_passes = 0, st_lane = 0, st_items = 0;   // diagnostics (p.stats), wave-uniform
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
         // hundred mostly scalar / LDS instructions, is amortised over more useful iterations
         if (first || ((tick++ & ka->p.pass_mask) == 0 && __any(st.fin != 0))) {
             first = false;
-            ++st_passes;
+            if constexpr (kStats) ++st_passes;
             const RTB_CONST IkDev &p = ka->p;      // shadows the by-value arguments for the whole pass
             const RTB_CONST double *qlim = (const RTB_CONST double *)ka->qlim;
             const double *Tep = ka->Tep, *q0 = ka->q0;
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                         ik_start_target<NJ>(st, sh, lane, p, qlim, myslot, v, w, Tep, q0);
                         sh.chunk[myslot] = (uint8_t)chunk;
                     }
-                    st_items += (unsigned long long)nvalid;
+                    if constexpr (kStats) st_items += (unsigned long long)nvalid;
                     busy |= __ballot(((freeslots >> lane) & 1ull) && ik_rank(freeslots, lane) < nvalid);
                     __syncthreads();
                     idle = __ballot(st.status == kIkIdle);
@@ -365,11 +369,11 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
             const RTB_CONST double *ql = (const RTB_CONST double *)ka->qlim;
             asm volatile("" : "+s"(cvi.seg), "+s"(cvi.jmeta), "+s"(ql));
             const int myslot = st.slot;
-            if (ka->p.stats) { ++st_iters; st_lane += (unsigned long long)__popcll(__ballot(st.status == kIkRun && !st.fin)); }
+            if constexpr (kStats) { ++st_iters; st_lane += (unsigned long long)__popcll(__ballot(st.status == kIkRun && !st.fin)); }
             ik_iter<NJ, STEP>(st, ka->p, cvi, ql, [&](int k) { return sh.Td[k][myslot]; }, ik_lds_q(sh, lane));
         }
     }
-    if (ka->p.stats && lane == 0) {
+    if (kStats && ka->p.stats && lane == 0) {
         unsigned long long *o = ka->p.stats + 4ull * blockIdx.x;
         o[0] = st_iters; o[1] = st_passes; o[2] = st_lane; o[3] = st_items;
     }
@@ -512,9 +516,20 @@ static void launch_nj(dim3 grid, hipStream_t s, const IkDev &p, const DevChain &
         if (v == 2) { hipLaunchKernelGGL((k_ik<NJ, 2>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share); return; }
         if (v == 3) { hipLaunchKernelGGL((k_ik<NJ, 3>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share); return; }
     }
-    if (v & kIkStepPinv) hipLaunchKernelGGL((k_ik<NJ, 1>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share);
-    else hipLaunchKernelGGL((k_ik<NJ, 0>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share);
+    if (v & kIkStepPinv) { hipLaunchKernelGGL((k_ik<NJ, 1>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share); return; }
+    const bool flat = p.flat_chunks > 0, stats = p.stats != nullptr;       // launch_ik offers these only where they are instantiated (ik_aux_served)
+    if constexpr (NJ <= kRegMaxJoints) {
+        if (flat && !stats) { hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxFlat>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share); return; }
+    }
+    if constexpr (NJ == 7) {                              // the counters: the benchmark's arm only
+        if (stats && flat) { hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxFlat | kIkAuxStats>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share); return; }
+        if (stats) { hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxStats>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share); return; }
+    }
+    hipLaunchKernelGGL((k_ik<NJ, 0>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share);
 }
+
+// where the flat schedule / the counters exist as instantiations: plain LM-family steps (STEP 0), chains of up to 8 joints / the 7-joint arm
+static bool ik_aux_served(const IkDev &p, int n, bool stats) { return ik_step_variant(p, n) == 0 && (stats ? n == 7 : n <= kRegMaxJoints); }
 
 #define RTB_TRY_IK(expr) do { int _rc = (expr); if (_rc != RTBHIP_OK) return _rc; } while (0)
 int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const double *Tep, int64_t N, const double *q0,
@@ -585,7 +600,7 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
         // scheduling passes, lane-iterations spent on a running search, items started).  Synchronises the stream: not for timed runs.
         static const char *stats_path = std::getenv("RTBHIP_IK_STATS");
         unsigned long long *dstats = nullptr;
-        if (stats_path && *stats_path) {
+        if (stats_path && *stats_path && ik_aux_served(p2, n, true)) {
             RTB_HIP(hipMallocAsync((void **)&dstats, (size_t)g * 4 * sizeof(unsigned long long), s));
             RTB_HIP(hipMemsetAsync(dstats, 0, (size_t)g * 4 * sizeof(unsigned long long), s));
             p2.stats = dstats;
@@ -634,7 +649,7 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
     // batch is resident at once: the regime in which a wave is stuck with the targets it drew) / always (tests).
     {
         const IkFlatPlan fp = ik_flat_plan(p, g_ik_flat_l0, g_ik_flat_len);
-        const bool flat_fits = fp.chunks > 1 && fp.chunks < 250 && (long long)N * fp.chunks < (1ll << 32) - 4096;
+        const bool flat_fits = fp.chunks > 1 && fp.chunks < 250 && (long long)N * fp.chunks < (1ll << 32) - 4096 && ik_aux_served(p, n, false);
         // automatic: the batch is resident at once (a wave cannot trade targets) AND large enough that waves hold several targets each -- below
         // that a wave's 64 lanes already serve its one or two targets' searches in parallel and the temporaries would only add latency
         // ... AND converged searches can still be rejected (joint limits): that is what makes first chunks fail (Panda defaults: a search succeeds
