@@ -51,7 +51,7 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, cons
         // passes for M.  This pass comes FIRST so that the kernel may keep q, qd and torque in the M tile itself until here (the
         // passes below overwrite them): 22.5 -> 14.8 KB of LDS per wave for n = 7, 7 -> 10 waves per CU
         dyn_opaque<NJ>(st, ct);
-        rne_core<NJ, MDH, true, ALLREV, true>(links, NJ, st, ct, grav, zero, zero, qin, [&](int j) { return mine[NJ + j]; },
+        rne_core<NJ, MDH, true, ALLREV, true, false, false>(links, NJ, st, ct, grav, zero, zero, qin, [&](int j) { return mine[NJ + j]; },
                                 [&](int) { return 0.0; }, [&](int j, double v) { b[j] = mine[2 * NJ + j] - v; });
 #if defined(__HIP_DEVICE_COMPILE__)
         // the pass must be over -- its link state dead -- before the passes below start (scheduled together they spill)
@@ -68,13 +68,13 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, cons
             if constexpr (ALLREV) {
                 // column i of M from the acceleration-only pass (rne_device.h): torques of joints j >= i = entries (j, i) of the
                 // packed lower triangle -- what accel's LDL^T solve reads, and what the inertia kernel's flush mirrors into (n, n)
-                rne_core<NJ, MDH, false, true, true, true>(links, NJ, st, ct, zero, zero, zero, qin, [&](int) { return 0.0; },
+                rne_core<NJ, MDH, false, true, true, true, false>(links, NJ, st, ct, zero, zero, zero, qin, [&](int) { return 0.0; },
                                         [&](int j) { return j == i ? 1.0 : 0.0; },
                                         [&](int j, double v) { mA[j * (j + 1) / 2 + i] = v; }, i);
             } else {
                 // inertia: the full row as computed (the reference returns the unsymmetrised matrix); accel: only the lower
                 // triangle the LDL^T solve reads, packed -- 28 instead of 49 doubles of LDS per lane for n = 7
-                rne_core<NJ, MDH, true, ALLREV, true>(links, NJ, st, ct, zero, zero, zero, qin, [&](int) { return 0.0; },
+                rne_core<NJ, MDH, true, ALLREV, true, false, false>(links, NJ, st, ct, zero, zero, zero, qin, [&](int) { return 0.0; },
                                         [&](int j) { return j == i ? 1.0 : 0.0; },
                                         [&](int j, double v) {
                                             if (MODE == kDynAccel) { if (j <= i) mA[i * (i + 1) / 2 + j] = v; }
@@ -130,10 +130,10 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, cons
 #pragma unroll 1
         for (int k = 0; k < NJ; ++k) {
             dyn_opaque<NJ>(st, ct);
-            rne_core<NJ, MDH, false, ALLREV, true>(links, NJ, st, ct, zero, zero, zero, qin, [&](int j) { return j == k ? qdv[j] + sc : qdv[j]; },
+            rne_core<NJ, MDH, false, ALLREV, true, false, false>(links, NJ, st, ct, zero, zero, zero, qin, [&](int j) { return j == k ? qdv[j] + sc : qdv[j]; },
                                      [&](int) { return 0.0; }, [&](int r, double v) { mA[r * NJ + k] = v; });
             dyn_opaque<NJ>(st, ct);
-            rne_core<NJ, MDH, false, ALLREV, true>(links, NJ, st, ct, zero, zero, zero, qin, [&](int j) { return j == k ? qdv[j] - sc : qdv[j]; },
+            rne_core<NJ, MDH, false, ALLREV, true, false, false>(links, NJ, st, ct, zero, zero, zero, qin, [&](int j) { return j == k ? qdv[j] - sc : qdv[j]; },
                                      [&](int) { return 0.0; }, [&](int r, double v) { mA[r * NJ + k] = (mA[r * NJ + k] - v) * inv4s; });
         }
         };
@@ -150,7 +150,7 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, cons
         for (int i = 0; i < NJ; ++i) {
             const double qdi = dyn_pick<NJ>(qdv, i), wi = 2.0 * qdi - 0.5 * S;
             dyn_opaque<NJ>(st, ct);
-            rne_core<NJ, MDH, false, ALLREV, true>(links, NJ, st, ct, zero, zero, zero, qin, [&](int j) { return j == i ? 1.0 : 0.0; },
+            rne_core<NJ, MDH, false, ALLREV, true, false, false>(links, NJ, st, ct, zero, zero, zero, qin, [&](int j) { return j == i ? 1.0 : 0.0; },
                                      [&](int) { return 0.0; }, [&](int r, double v) { mA[r * NJ + i] = v * wi; U[r] += v * qdi; });
         }
 #pragma unroll
@@ -163,7 +163,7 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, cons
             for (int j = i + 1; j < NJ; ++j) {
                 const double hi = 0.5 * dyn_pick<NJ>(qdv, i), hj = 0.5 * dyn_pick<NJ>(qdv, j);
                 dyn_opaque<NJ>(st, ct);
-                rne_core<NJ, MDH, false, ALLREV, true>(links, NJ, st, ct, zero, zero, zero, qin,
+                rne_core<NJ, MDH, false, ALLREV, true, false, false>(links, NJ, st, ct, zero, zero, zero, qin,
                                          [&](int k) { return (k == i || k == j) ? 1.0 : 0.0; }, [&](int) { return 0.0; },
                                          [&](int r, double tau) {
                                              mA[r * NJ + j] += tau * hi;
@@ -172,8 +172,9 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, cons
             }
         }
         };
-        // the common case (no such row in the wave) stays one straight wave-uniform body; only a wave that holds a wide row pays for the
-        // per-lane choice (measured: the per-lane branch around the common case alone cost 7 % of the kernel)
+        // the common case (no such row in the wave) is one straight wave-uniform body; only a wave that holds a wide row runs the per-lane choice.
+        // Price of the per-row choice against round 2's per-wave one, same box (visit z): 0.56 -> 0.60 ms per 1e6 (the form that runs the polar
+        // body for every lane and lets wide rows redo their tile measured the same)
         if (!wave_any(wide)) polar();
         else if (!wide) polar();
         else reference_scheme();

@@ -211,8 +211,10 @@ struct NoWrench {
     RTB_HD void operator()(int, double) const {}
 };
 
-template <int NJ, bool MDH, bool FRICTION, bool ALLREV, bool HAVE_TRIG, bool ACC = false, class LinksP, class InQ, class InQd, class InQdd, class Out,
-          class WOut = NoWrench>
+// PSZ: honour the p* = 0 link flag (kLinkPsZero).  The single-pass kernels do (k_rne: -1.4 %); the multi-pass dynamics kernels do not -- there the
+// extra wave-uniform branches in every inlined pass cost 6-16 % (round 3, visit z: the round-2 tree beside this one on one box).
+template <int NJ, bool MDH, bool FRICTION, bool ALLREV, bool HAVE_TRIG, bool ACC = false, bool PSZ = true, class LinksP, class InQ, class InQd, class InQdd,
+          class Out, class WOut = NoWrench>
 RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_MAX_JOINTS], double (&ct)[NJ > 0 ? NJ : RTBHIP_MAX_JOINTS],
                      V3 grav, V3 ftip, V3 ntip, InQ qin, InQd qdin, InQdd qddin, Out tau, int first = 0, WOut wout = WOut())
 {
@@ -260,7 +262,7 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
         if constexpr (ACC) {
             if (j >= first) {          // wave-uniform
                 V3 wdn, an;
-                const bool ps0 = (flg[j] & kLinkPsZero) != 0;      // wave-uniform: p* = 0, the cross products with it are exact zeros
+                const bool ps0 = PSZ && (flg[j] & kLinkPsZero) != 0;      // wave-uniform: p* = 0, the cross products with it are exact zeros
                 if (MDH) {             // w = 0:  wd' = R^T wd + z qdd,  a' = R^T (a + wd x p*)
                     wdn = addz(rot_inv<MDH>(R, wd), qddj);
                     an = rot_inv<MDH>(R, ps0 ? a : cross_add(wd, ps, a));
@@ -292,7 +294,7 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
                     const V3 u = rot_inv_add<MDH>(R, wd, v3(t1.y * qdj, -(t1.x * qdj), 0.0));
                     wdn = ALLREV ? addz(u, qddj) : u + qddv;
                     // (p* = 0 -- a link whose origin coincides with its predecessor's: wave-uniform -- leaves a' = R^T a)
-                    an = rot_inv<MDH>(R, (flg[j] & kLinkPsZero) ? a : cross_add(wd, ps, cross_add(w, cross(w, ps), a)));
+                    an = rot_inv<MDH>(R, (PSZ && (flg[j] & kLinkPsZero)) ? a : cross_add(wd, ps, cross_add(w, cross(w, ps), a)));
                 }
             } else {
                 if (j == 0) {
@@ -314,7 +316,7 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
                 wdn = rot_inv<MDH>(R, t3);
                 {
                     const V3 ra = rot_inv<MDH>(R, (j == 0) ? grav : a);
-                    an = (flg[j] & kLinkPsZero) ? ra : cross_add(wdn, ps, cross_add(wn, cross(wn, ps), ra));
+                    an = (PSZ && (flg[j] & kLinkPsZero)) ? ra : cross_add(wdn, ps, cross_add(wn, cross(wn, ps), ra));
                 }
             } else {
                 wn = (j == 0) ? v3(0, 0, 0) : rot_inv<MDH>(R, w);
@@ -379,7 +381,7 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
             const V3 base = rzero ? Nn[j] : cross_add(rc, F[j], Nn[j]);
             // (psn = p* of link j + 1: zero for a kLinkPsZero link, wave-uniform)
             if (last) nj = nn + base;
-            else if (flg[j + 1 < n ? j + 1 : j] & kLinkPsZero) nj = rot_fwd_add<MDH>(Rn, nn, base);
+            else if (PSZ && (flg[j + 1 < n ? j + 1 : j] & kLinkPsZero)) nj = rot_fwd_add<MDH>(Rn, nn, base);
             else nj = cross_add(psn, fn, rot_fwd_add<MDH>(Rn, nn, base));
         } else {
             fj = last ? F[j] + f : rot_fwd_add<MDH>(Rn, f, F[j]);
@@ -420,7 +422,7 @@ RTB_HD void rne_lane(LinksP links, int n_rt, V3 grav, V3 ftip, V3 ntip, InQ qin,
     constexpr int CAP = NJ > 0 ? NJ : RTBHIP_MAX_JOINTS;
     double st[CAP], ct[CAP];
     if constexpr (NJ > 0) rne_trig<NJ, ALLREV>(links, qin, st, ct);
-    if constexpr (ATREST) rne_core<NJ, MDH, false, true, true, true>(links, n_rt, st, ct, grav, ftip, ntip, qin, qdin, qddin, tau, 0);
+    if constexpr (ATREST) rne_core<NJ, MDH, false, true, true, true, false>(links, n_rt, st, ct, grav, ftip, ntip, qin, qdin, qddin, tau, 0);   // (PSZ off: +7 % on gravload with it, visit z)
     else rne_core<NJ, MDH, FRICTION, ALLREV, (NJ > 0)>(links, n_rt, st, ct, grav, ftip, ntip, qin, qdin, qddin, tau, 0, wout);
 }
 

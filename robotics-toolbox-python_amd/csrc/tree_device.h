@@ -311,9 +311,10 @@ RTB_HD void tree_dyn_lane(GroupsP groups, int nslots, const double *mine, double
                 }
             }
         };
-        if (!wave_any(wide)) polar();
-        else if (!wide) polar();
-        else reference_scheme();
+        polar();                                   // every lane; wide rows redo their tile below (dyn_device.h)
+        if (wave_any(wide)) {
+            if (wide) reference_scheme();
+        }
     }
 }
 
