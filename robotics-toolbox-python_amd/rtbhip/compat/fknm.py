@@ -127,7 +127,10 @@ def _ets(obj):
 
 
 def _q_rows(e, q):
-    """(rows (N, q_width), single): 1-D, (1,n) and (n,1) are one configuration (core/fknm.cpp:964-988)."""
+    """(rows (N, q_width), single): 1-D, (1,n) and (n,1) are one configuration (core/fknm.cpp:964-988).
+    One deliberate difference: for a ONE-joint chain the reference's rule makes every (N,1) array "a single q vector" (it then evaluates
+    the first element only, :973-979); here (N,1) with N > 1 on a one-joint chain is the trajectory of N configurations it looks like
+    ((1,1) is still one configuration).  Documented because the module otherwise follows the reference's shape rules to the letter."""
     a = _numeric(q)
     e.handle()
     if a.ndim == 0:
