@@ -295,3 +295,27 @@ def test_gpu_dynamics_limits_and_errors():
         nt.assert_allclose(rob.coriolis(q, qd)[:k], oracle.coriolis_dh(L, 0, q[:k], qd[:k]), rtol=1e-10, atol=1e-11)
         a = rob.accel(q, qd, tq)
         nt.assert_allclose(rob.rne(q, qd, a), tq, rtol=1e-8, atol=1e-8 * np.abs(tq).max())
+
+
+@pytest.mark.gpu
+def test_gpu_coriolis_row_does_not_depend_on_its_tile_mates():
+    """The round-2 advisor's finding, fixed in round 3: the choice between the polar form and the reference's 28-pass scheme is made per ROW, so a
+    row's C(q, qd) is bit-identical whether it is evaluated alone, among ordinary rows, or next to a row whose velocities span nine orders of
+    magnitude (which used to send its whole 64-row tile to the other scheme).  DH kernel and tree kernel."""
+    from rtbhip import urdf
+    rng = np.random.default_rng(123)
+    for rob in (rtbhip.models.DH.Panda(), urdf.load("UR5")):
+        n = rob.n
+        q = rng.uniform(-1.5, 1.5, (64, n))
+        qd = rng.normal(size=(64, n))
+        alone = np.stack([rob.coriolis(q[i], qd[i]) for i in range(64)])
+        together = rob.coriolis(q, qd)
+        qd_wide = qd.copy()
+        qd_wide[17] = qd[17] * np.logspace(-6, 3, n)            # one wide row in the tile
+        with_wide = rob.coriolis(q, qd_wide)
+        keep = np.arange(64) != 17
+        nt.assert_array_equal(together, alone)
+        nt.assert_array_equal(with_wide[keep], alone[keep])
+        nt.assert_array_equal(with_wide[17], rob.coriolis(q[17], qd_wide[17]))
+        # and under a batch split (ShardedBatch row blocks): the same bits
+        nt.assert_array_equal(np.concatenate([rob.coriolis(q[:23], qd_wide[:23]), rob.coriolis(q[23:], qd_wide[23:])]), with_wide)
