@@ -331,6 +331,8 @@ int rtbhip_last_launch(int32_t *grid, int32_t *block, int32_t *lds_bytes);
  *   "ik_fresh_pct" p, "ik_pass_mask" m, "ik_waves_per_cu" w, "ik_spec_policy" 0 | 1     pacing of the per-wave scheduler
  * Others: "coalesced", "reg", "tiles_per_wave", "hess_mode" (fkine / Jacobian / Hessian store paths), "rne_tiles_per_wave",
  *         "partial3" 1 | 0 (order-3 partial_fkine0 on workgroups that own whole configurations / on the general kernel),
+ *         "partial3_fused" 1 | 0 (that kernel forms the Hessians from the Jacobians it stages / reads a Hessian tensor written by a launch of its own),
+ *         "rne_persist", "rne_wpb", "ik_unit_we" (A/B forms that measured slower and are off),
  *         "host_chunk_kb" (host-pointer pipeline). */
 /* Measurement aid, no reference counterpart: one launch of a plain streaming kernel that reads `read_doubles` doubles from `src` and writes
  * `write_doubles` doubles to `dst` (device pointers, 4 KiB-aligned; whole 4 KiB pages are moved, the tails are left alone) -- the memory rate this GPU delivers for a given read / write mix, which

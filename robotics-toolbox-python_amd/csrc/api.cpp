@@ -720,7 +720,9 @@ int rtbhip_partial_fkine0(rtbhip_chain_t chain, const double *q, int64_t N, cons
     RTB_TRY(pool_keep_cached());
     double *lower[kPartialMaxOrder] = {nullptr};
     int rc = RTBHIP_OK;
+    const bool skip_h = order == 3 && partial3_needs_no_hessian(n);       // k_partial3 forms the Hessians from the Jacobians it stages
     for (int a = 1; a < order && rc == RTBHIP_OK; ++a) {
+        if (a == 2 && skip_h) continue;
         void *p = nullptr;
         hipError_t e = hipMallocAsync(&p, (size_t)N * (size_t)partial_size(n, a) * 8, s);
         if (e != hipSuccess) rc = hip_fail(e, "hipMallocAsync (partial_fkine0 temporaries)");
@@ -728,7 +730,7 @@ int rtbhip_partial_fkine0(rtbhip_chain_t chain, const double *q, int64_t N, cons
     }
     // the two specialised launches (register-resident Jacobian, staged Hessian) beat the combined generic tile
     if (rc == RTBHIP_OK) rc = launch_kin(c, ops, (const double *)dq, N, base, tool, 0, nullptr, lower[0], nullptr, s);
-    if (rc == RTBHIP_OK) rc = launch_kin(c, ops, (const double *)dq, N, base, tool, 0, nullptr, nullptr, lower[1], s);
+    if (rc == RTBHIP_OK && !skip_h) rc = launch_kin(c, ops, (const double *)dq, N, base, tool, 0, nullptr, nullptr, lower[1], s);
     for (int a = 3; a <= order && rc == RTBHIP_OK; ++a)
         rc = launch_partial(n, a, lower, N, a == order ? (double *)dout : lower[a - 1], s);
     for (int a = 1; a < order; ++a)

@@ -125,7 +125,24 @@ __global__ __launch_bounds__(kPartialBlock) void k_partial3(int n, int G, int64_
     const int64_t cfg0 = (int64_t)blockIdx.x * G;
     const int g = (int)(N - cfg0 < G ? N - cfg0 : G);
     double *tile = lds, *stage = lds + ((G * 6 * (int)cols + 1) & ~1);          // [g output runs][g Jacobians][g Hessians]
-    {
+    if (H == nullptr) {
+        // no Hessian tensor supplied (rtbhip_partial_fkine0 at order 3): stage the Jacobians and form the Hessians from them right here --
+        // H[j, row, i] = hessian_entry (kin_device.h: the expression the Hessian kernel evaluates, so the same bits) -- instead of having a
+        // launch write 2352 B per configuration that this one reads back: the call's second launch and 470 MB of traffic per 1e5 Panda
+        // configurations go away
+        const double *Js = J + cfg0 * szj;
+        const int tj = g * szj;
+        for (int i = tid; i < tj; i += kPartialBlock) stage[i] = Js[i];
+        __syncthreads();
+        const int th = g * szh;
+        for (int i = tid; i < th; i += kPartialBlock) {
+            const int c = i / szh, w = i - c * szh;
+            const int j = w / szj, w2 = w - j * szj;
+            const int row = w2 / n, col = w2 - row * n;
+            stage[tj + i] = hessian_entry(stage + c * szj, n, j, row, col);
+        }
+        __syncthreads();
+    } else {
         const double *Js = J + cfg0 * szj, *Hs = H + cfg0 * szh;
         const int tj = g * szj, tot = g * (szj + szh);
         for (int i0 = 0; i0 < tot; i0 += 4 * kPartialBlock) {                   // four loads in flight per lane and round
@@ -171,7 +188,20 @@ __global__ __launch_bounds__(kPartialBlock) void k_partial3(int n, int G, int64_
 }
 
 static int g_partial3 = 1;        // rtbhip_tune("partial3", 0): the general kernel at order 3 too (A/B)
-void partial_tune(const char *key, int value) { if (std::string(key) == "partial3") g_partial3 = value != 0; }
+static int g_partial3_fused = 1;  // rtbhip_tune("partial3_fused", 0): feed k_partial3 a Hessian tensor from its own launch, as before (A/B)
+void partial_tune(const char *key, int value)
+{
+    if (std::string(key) == "partial3") g_partial3 = value != 0;
+    if (std::string(key) == "partial3_fused") g_partial3_fused = value != 0;
+}
+
+// order 3 of an n-joint chain goes to k_partial3, which needs no Hessian tensor (it forms the Hessians from the Jacobians it stages)
+bool partial3_needs_no_hessian(int n)
+{
+    int G = 0, U = 0;
+    partial3_geometry(n, kPartialBlock, &G, &U);
+    return g_partial3 && g_partial3_fused && G > 0 && (int64_t)6 * n * n * n * G < (1 << 24);
+}
 
 // lower[a-1] = order-a tensor (device), a = 1 .. order-1; out = order-`order` tensor
 int launch_partial(int n, int order, const double *const *lower, int64_t N, double *out, hipStream_t s)

@@ -157,6 +157,7 @@ struct FrameTable;
 int compile_frames(const Chain *c, const int32_t *marks, int nmarks, FrameTable *ft);
 int launch_frames(const Chain *c, const DevChain &dc, const FrameTable &ft, const double *q, int64_t N, double *out, hipStream_t s);
 int launch_partial(int n, int order, const double *const *lower, int64_t N, double *out, hipStream_t s);
+bool partial3_needs_no_hessian(int n);   // order 3: k_partial3 forms the Hessians itself, lower[1] may be NULL
 
 struct FleetEntry {   // device-visible descriptor of one chain of a fleet launch
     DevChain dc;
