@@ -13,7 +13,7 @@ for ln in sys.stdin:
     if not ln.startswith('{'): continue
     d=json.loads(ln); print('$l', d['metric'][:52].ljust(52), 'step %.4f' % d.get('ms_per_step', 0), 'kernel avg %.4f min %.4f' % (d.get('kernel_avg_ms', 0), d.get('kernel_min_ms', 0)))"
 }
-if [ -d $R/r2cmp ]; then
+if [ -d $R/r2cmp ] && [ -z "$SKIP_R2" ]; then
 {
 for rep in 1 2; do
   run $R/r2cmp "r2 " --what rne --no-cpu --steps 30

@@ -19,12 +19,33 @@ _vp, _u64, _i64, _i32 = C.c_void_p, C.c_uint64, C.c_int64, C.c_int32
 _lib = None
 
 
+def _deps():
+    emu_dir = os.path.join(ROOT, "tests", "emu")
+    return sorted(set([os.path.join(ROOT, s) for s in SRCS] + [os.path.join(PKG, "csrc", f) for f in os.listdir(os.path.join(PKG, "csrc"))]
+                      + [os.path.join(emu_dir, f) for f in os.listdir(emu_dir) if f.endswith((".h", ".cpp"))] + [os.path.join(ROOT, "include", "rtbhip.h")]))
+
+
+def _digest():
+    import sys
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    return g.source_digest(_deps())
+
+
 def _stale():
+    """By CONTENT (a sha256 of every source kept next to the library), not by file times: those do not survive the trip to the GPU box in a
+    useful order, and a rebuild there costs minutes of the GPU lease."""
     if not os.path.exists(EMU_SO):
         return True
+    stamp = EMU_SO + ".stamp"
+    if os.path.exists(stamp):
+        return open(stamp).read().strip() != _digest()
     t = os.path.getmtime(EMU_SO)
-    deps = [os.path.join(ROOT, s) for s in SRCS] + [os.path.join(PKG, "csrc", f) for f in os.listdir(os.path.join(PKG, "csrc"))]
-    return any(os.path.getmtime(d) > t for d in deps)
+    if any(os.path.getmtime(d) > t for d in _deps()):
+        return True
+    open(stamp, "w").write(_digest())                  # a library from before the stamps existed, newer than its sources: adopt it
+    return False
 
 
 def _deps_newer(obj, dep_file):
@@ -70,6 +91,7 @@ def build():
     if missing:                                  # a prebuilt library travelled without its objects: compile them
         g.build_lib(force=True)
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + prod + ["-o", EMU_SO])
+    open(EMU_SO + ".stamp", "w").write(_digest())
 
 
 def lib():
