@@ -1,6 +1,7 @@
 """-m "not gpu": runs the kernels' own per-lane phase functions on the CPU (tests/emu) and checks
 them against the oracle and the golden fixtures: same LDS layout, same flush arithmetic, same
 recursions as the gfx950 kernels -- only the lanes are a for-loop."""
+import os
 import numpy as np
 import numpy.testing as nt
 import pytest
@@ -708,3 +709,21 @@ def test_xcd_tile_mapping_is_a_bijection_with_contiguous_eighths():
         for x in range(min(8, g)):
             mine = tiles[x::8]
             assert np.all(np.diff(mine) == 1), (g, x)
+
+
+def test_ik_schedule_study_tool_runs_and_its_floor_is_a_floor():
+    """tests/tools/ik_schedule_study.py (the CPU study behind profiles/r03_ab_ik_schedule_floor.txt) at a small size: the idealised pool can
+    never finish before the useful work alone would, never runs less than the useful work, and the replay's useful work is the
+    sequential specification's."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ik_schedule_study", os.path.join(os.path.dirname(__file__), "tools", "ik_schedule_study.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    N, lanes = 3000, 64 * 60
+    ets, Tep = tool.targets(N)
+    it = emu.ik(ets, Tep, seed=2)[2]
+    tau, useful, discarded = tool.floor(N, lanes, 4)
+    assert tau * lanes >= useful + discarded >= useful > 0
+    assert abs(useful - int(it.sum())) <= 0.02 * it.sum()          # (the model rounds a target's search length)
+    assert tool.replay(N, 60) == int(it.sum())
+    assert "EMU_IK_FLAT" not in os.environ and "EMU_IK_PASS_MASK" not in os.environ

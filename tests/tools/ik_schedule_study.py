@@ -54,9 +54,13 @@ def replay(N, waves):
               % (name, st[0], st[1] / waves, st[3] / waves, slots, 100.0 * useful / slots, 100.0 * (st[2] - useful) / slots, 100.0 * (slots - st[2]) / slots,
                  time.time() - t0))
     print("useful lane-iterations %d = %.1f iterations of %d lanes" % (useful, useful / (64.0 * waves), 64 * waves))
+    for k in ("EMU_IK_FLAT", "EMU_IK_FLAT_L0", "EMU_IK_FLAT_LEN", "EMU_IK_PASS_MASK"):
+        os.environ.pop(k, None)
+    return useful
 
 
 def floor(N, lanes, period):
+    """Returns (iterations to the last result, useful lane-iterations, discarded lane-iterations)."""
     ets, Tep = targets(N)
     q, ok, it, se, E = emu.ik(ets, Tep, seed=2)          # the sequential specification: searches and iterations each target needs
     need = np.where(ok == 1, se, 100).astype(np.int64)
@@ -104,6 +108,7 @@ def floor(N, lanes, period):
         tau += period
     print("idealised pool of %d lanes, a pass every %d iterations: %d iterations to the last result; useful %.3e + discarded %.3e lane-iterations;"
           " useful alone = %.1f iterations" % (lanes, period, tau, useful, discarded, it.sum() / lanes))
+    return tau, useful, discarded
 
 
 if __name__ == "__main__":
