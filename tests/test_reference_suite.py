@@ -179,8 +179,17 @@ def run_module(mod):
     return out
 
 
-@pytest.mark.parametrize("name", ["test_ET", "test_ETS", "test_jacob", "test_IK", "test_PoERobot", "test_DHRobot", "test_ERobot", "test_Robot"])
+FILES = ["test_ET", "test_ETS", "test_jacob", "test_IK", "test_PoERobot", "test_DHRobot", "test_ERobot", "test_Robot"]
+
+
+@pytest.mark.parametrize("name", FILES)
 def test_reference_test_file(name):
+    check_file(name)
+
+
+def check_file(name):
+    """One reference test file against whatever rtbhip._lib.lib() hands out: the GPU library here, the CPU replay of the kernel bodies in
+    tests/test_reference_suite_cpu.py -- the same ledger either way."""
     np.random.seed(0)
     saved = install_shims()
     try:
