@@ -136,6 +136,15 @@ int rtbhip_hessian_from_jacobian(const double *J, int64_t N, int32_t n, double *
  * 16-byte aligned. */
 int rtbhip_angle_axis(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, double *e, int32_t mem, void *stream);
 
+/* The error vector of rtb.p_servo (tools/p_servo.py:46-117), batched, same buffers as rtbhip_angle_axis:
+ *   method 0 "angle-axis": rtbhip_angle_axis (error in the base frame, p_servo.py:98-99);
+ *   method 1 "rpy" -- the reference's DEFAULT (p_servo.py:88-97): eTep = inv(wTe) wTep, e = [eTep.t ; tr2rpy(eTep, order "zyx")]
+ *     = (x, y, z, roll, pitch, yaw) seen from the end-effector frame.  tr2rpy belongs to spatialmath-python (>= 1.1.16,
+ *     pyproject.toml:22, not vendored); its algorithm is restated in csrc/servo_device.h, singular branch included.
+ * The gain and the `arrived` test (p_servo.py:101-108) are one multiply and one sum over e: the caller's. */
+int rtbhip_p_servo_error(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, int32_t method, double *e, int32_t mem,
+                         void *stream);
+
 /* Differential-kinematics consumers computed from the Jacobian while it is still in registers (SURVEY 8f-4;
  * compile-time joint counts up to 16 -- 1..8 at two waves per SIMD, 9..16 at one, the longest with some scratch):
  *   rtbhip_jacob_dot       Robot.jacob0_dot (robot/Robot.py:964-1098, representation=None): Jd (N,6,n) = H(q) . qd,

@@ -62,7 +62,8 @@ def dh_available():
 
 # the reference's own unit-test files that tests/test_reference_suite.py runs against the GPU backend
 REF_TESTS = "/root/reference/tests"
-TEST_FILES = ["test_ET.py", "test_ETS.py", "test_jacob.py", "test_IK.py", "test_DHRobot.py", "test_PoERobot.py", "test_ERobot.py", "test_Robot.py"]
+TEST_FILES = ["test_ET.py", "test_ETS.py", "test_jacob.py", "test_IK.py", "test_DHRobot.py", "test_PoERobot.py", "test_ERobot.py", "test_Robot.py",
+              "test_tools.py", "test_Link.py", "test_ELink.py"]
 
 
 def _test_pyc(name):

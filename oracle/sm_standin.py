@@ -177,6 +177,16 @@ def tr2x(T, representation="rpy/xyz"):
     return _o.tr2x(np.asarray(T, dtype=np.float64), representation)
 
 
+def tr2rpy(T, unit="rad", order="zyx", check=False):
+    """spatialmath.base.tr2rpy for the order tools/p_servo.py:97 asks for ("zyx", the default): the restatement the oracle already
+    holds for SE3.rpy() (oracle/poe.py: tr2rpy_zyx, singular branch included)."""
+    if order not in ("zyx", "vehicle"):
+        raise NotImplementedError("spatialmath stand-in: tr2rpy order %r is not restated" % (order,))
+    from . import poe as _p
+    rpy = _p.tr2rpy_zyx(np.asarray(T, dtype=np.float64)[:3, :3])
+    return np.degrees(rpy) if unit == "deg" else rpy
+
+
 def numjac(f, x, dx=1e-8, SO=0, SE=0):
     """spatialmath.base.numjac: forward-difference Jacobian of f at x.  f returns a vector, or -- SE=3 -- a 4x4 pose, in which case a
     column is [dt / dx ; vex(dR R^T) / dx] (the spatial velocity per unit joint rate), or -- SO=3 -- a rotation matrix."""
@@ -353,9 +363,9 @@ def modules():
     """(spatialmath, spatialmath.base) module objects to be placed in sys.modules while the reference files are loaded."""
     sm = types.ModuleType("spatialmath")
     smb = types.ModuleType("spatialmath.base")
-    for f in (trotx, troty, trotz, issymbol, getvector, getmatrix, verifymatrix, t2r, tr2jac, simplify, isvector, ismatrix, getunit, rot2jac, transl, islistof, tr2x, numjac, numhess, trnorm):
+    for f in (trotx, troty, trotz, issymbol, getvector, getmatrix, verifymatrix, t2r, tr2jac, simplify, isvector, ismatrix, getunit, rot2jac, transl, islistof, tr2x, tr2rpy, numjac, numhess, trnorm):
         setattr(smb, f.__name__, f)
-    for name in ("tr2rpy", "tr2eul", "trlog", "trot2", "transl2", "tr2xyt", "tr2jac2", "rotvelxform", "r2x", "rotvelxform_inv_dot"):
+    for name in ("tr2eul", "trlog", "trot2", "transl2", "tr2xyt", "tr2jac2", "rotvelxform", "r2x", "rotvelxform_inv_dot"):
         setattr(smb, name, _not_offered(name))
     argcheck = types.ModuleType("spatialmath.base.argcheck")
     for f in (getvector, getmatrix, verifymatrix, isscalar, isvector, ismatrix, getunit):

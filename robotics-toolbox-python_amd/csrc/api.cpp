@@ -566,9 +566,24 @@ int rtbhip_hessian_from_jacobian(const double *J, int64_t N, int32_t n, double *
 }
 
 /* fknm.Angle_Axis (core/fknm.cpp:112-162 -> _angle_axis core/ik.cpp:241-286), batched with broadcasting */
+static int pose_error_entry(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, int method, double *e, int32_t mem, void *stream);
+
 int rtbhip_angle_axis(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, double *e, int32_t mem, void *stream)
 {
     RTB_TRACE("rtbhip_angle_axis");
+    return pose_error_entry(Te, nTe, Tep, nTep, 0, e, mem, stream);
+}
+
+/* the error vector of tools/p_servo.py:46-117: method 0 "angle-axis" (= rtbhip_angle_axis), 1 "rpy" (the reference's default) */
+int rtbhip_p_servo_error(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, int32_t method, double *e, int32_t mem, void *stream)
+{
+    RTB_TRACE("rtbhip_p_servo_error");
+    if (method != 0 && method != 1) { set_error("p_servo_error: method must be 0 angle-axis or 1 rpy"); return RTBHIP_EINVAL; }
+    return pose_error_entry(Te, nTe, Tep, nTep, method, e, mem, stream);
+}
+
+static int pose_error_entry(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, int method, double *e, int32_t mem, void *stream)
+{
     if (mem != RTBHIP_MEM_HOST && mem != RTBHIP_MEM_DEVICE) { set_error("angle_axis: bad mem kind"); return RTBHIP_EINVAL; }
     if (nTe < 0 || nTep < 0) { set_error("angle_axis: negative count"); return RTBHIP_EINVAL; }
     if (nTe == 0 || nTep == 0) return RTBHIP_OK;
@@ -579,14 +594,14 @@ int rtbhip_angle_axis(const double *Te, int64_t nTe, const double *Tep, int64_t 
         if (((uintptr_t)Te | (uintptr_t)Tep | (uintptr_t)e) & 15) { set_error("angle_axis: device buffers must be 16-byte aligned"); return RTBHIP_EINVAL; }
         DeviceScope dscope;
         RTB_TRY(dscope.enter_for("angle_axis", e));
-        return launch_angle_axis(Te, nTe, Tep, nTep, N, e, (hipStream_t)stream);
+        return launch_angle_axis(Te, nTe, Tep, nTep, N, e, (hipStream_t)stream, method);
     }
     Staging st;
     void *dA, *dB, *dE;
     RTB_TRY(st.in(Te, (size_t)nTe * 128, &dA));
     RTB_TRY(st.in(Tep, (size_t)nTep * 128, &dB));
     RTB_TRY(st.out((size_t)N * 48, &dE));
-    RTB_TRY(launch_angle_axis((const double *)dA, nTe, (const double *)dB, nTep, N, (double *)dE, nullptr));
+    RTB_TRY(launch_angle_axis((const double *)dA, nTe, (const double *)dB, nTep, N, (double *)dE, nullptr, method));
     RTB_HIP(hipDeviceSynchronize());
     RTB_TRY(fetch(e, dE, (size_t)N * 48));
     return RTBHIP_OK;

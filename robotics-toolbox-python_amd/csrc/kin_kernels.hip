@@ -314,6 +314,8 @@ int launch_hess_from_jac(int n, const double *J, int64_t N, double *H, hipStream
 // e[i] = angle_axis(Te[i or 0], Tep[i or 0]) (core/fknm.cpp:112-162 -> core/ik.cpp:241-286).  256 B in, 48 B out per
 // pair; both tiles through LDS as contiguous runs; a broadcast operand (count 1) is read by every lane from the same
 // 128 bytes.  LDS: 64 x 17 doubles per operand, the first re-used for the 64 x 7 staging of e.
+// RPY = true: the same staging around servo_rpy_lane (p_servo's method "rpy", servo_device.h).
+template <bool RPY>
 __global__ __launch_bounds__(kWave) void k_angle_axis(const double *__restrict__ Te, int te_each, const double *__restrict__ Tep, int tep_each,
                                                      int64_t N, double *__restrict__ e)
 {
@@ -331,18 +333,23 @@ __global__ __launch_bounds__(kWave) void k_angle_axis(const double *__restrict__
 #pragma unroll
     for (int k = 0; k < 12; ++k) { te16[k] = a[la * kAaStride + k]; tep16[k] = b[lb * kAaStride + k]; }
     __syncthreads();
-    aa_lane(te16, tep16, a + lane * 7);
+    if constexpr (RPY) servo_rpy_lane(te16, tep16, a + lane * 7);
+    else aa_lane(te16, tep16, a + lane * 7);
     __syncthreads();
     kin_flush(a, 7, 6, ncfg, e + cfg0 * 6, lane);
 }
 
-int launch_angle_axis(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, int64_t N, double *e, hipStream_t s)
+int launch_angle_axis(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, int64_t N, double *e, hipStream_t s, int method)
 {
     if (N == 0) return RTBHIP_OK;
     const int64_t tiles = (N + kWave - 1) / kWave;
     if (tiles > 0x7fffffff) { set_error("angle_axis: batch too large for one launch"); return RTBHIP_ELIMIT; }
-    hipLaunchKernelGGL(k_angle_axis, dim3((unsigned)tiles), dim3(kWave), 0, s, Te, nTe == N ? 1 : 0, Tep,
-                       nTep == N ? 1 : 0, N, e);
+    if (method == 1)
+        hipLaunchKernelGGL(k_angle_axis<true>, dim3((unsigned)tiles), dim3(kWave), 0, s, Te, nTe == N ? 1 : 0, Tep,
+                           nTep == N ? 1 : 0, N, e);
+    else
+        hipLaunchKernelGGL(k_angle_axis<false>, dim3((unsigned)tiles), dim3(kWave), 0, s, Te, nTe == N ? 1 : 0, Tep,
+                           nTep == N ? 1 : 0, N, e);
     note_launch((int)tiles, kWave, (int)(2 * kWave * kAaStride * sizeof(double)));
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return hip_fail(err, "k_angle_axis launch");

@@ -151,7 +151,7 @@ int launch_kin_diff(const Chain *c, const DevChain &dc, int mode, int axes, cons
                     const Affine &tool, int frame, double *out, hipStream_t s);
 
 int launch_hess_from_jac(int n, const double *J, int64_t N, double *H, hipStream_t s);
-int launch_angle_axis(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, int64_t N, double *e, hipStream_t s);
+int launch_angle_axis(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, int64_t N, double *e, hipStream_t s, int method = 0);
 
 struct FrameTable;
 int compile_frames(const Chain *c, const int32_t *marks, int nmarks, FrameTable *ft);

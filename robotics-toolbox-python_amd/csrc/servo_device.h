@@ -39,6 +39,42 @@ RTB_HD void aa_lane(const double *te16, const double *tep16, double *erow)
     for (int k = 0; k < 6; ++k) erow[k] = e[k];
 }
 
+// phase B of p_servo's DEFAULT method "rpy" (tools/p_servo.py:88-97): e = [t ; rpy] of eTep = inv(wTe) wTep -- the error seen from
+// the end-effector frame -- with rpy = spatialmath.base.tr2rpy(eTep, order "zyx", check=False) = (roll, pitch, yaw),
+// R = Rz(yaw) Ry(pitch) Rx(roll).  tr2rpy is third-party (spatialmath-python, absent from the reference tree); its published
+// algorithm is restated here branch for branch: |R20| = 1 within 10 eps is the singular case (roll = 0, yaw from R01, R02);
+// otherwise roll = atan2(R21, R22), yaw = atan2(R10, R00) and the pitch from R20 over the LARGEST of |R00|, |R10|, |R21|, |R22|
+// (the first one on a tie, as numpy.argmax).  The reference inverts wTe with a general 4x4 LU; for a rigid transform that is
+// [R^T, -R^T t] up to rounding, which is what is formed here.
+RTB_HD void servo_rpy_lane(const double *te, const double *tep, double *erow)
+{
+    double R[3][3], d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d[k] = tep[4 * k + 3] - te[4 * k + 3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) R[i][j] = te[i] * tep[j] + te[4 + i] * tep[4 + j] + te[8 + i] * tep[8 + j];
+        erow[i] = te[i] * d[0] + te[4 + i] * d[1] + te[8 + i] * d[2];
+    }
+    double roll, pitch, yaw;
+    if (fabs(fabs(R[2][0]) - 1.0) < 10.0 * 2.220446049250313e-16) {
+        roll = 0.0;
+        yaw = R[2][0] < 0.0 ? -atan2(R[0][1], R[0][2]) : atan2(-R[0][1], -R[0][2]);
+        const double c = R[2][0] < -1.0 ? -1.0 : (R[2][0] > 1.0 ? 1.0 : R[2][0]);
+        pitch = -asin(c);
+    } else {
+        roll = atan2(R[2][1], R[2][2]);
+        yaw = atan2(R[1][0], R[0][0]);
+        const double m0 = fabs(R[0][0]), m1 = fabs(R[1][0]), m2 = fabs(R[2][1]), m3 = fabs(R[2][2]);
+        if (m0 >= m1 && m0 >= m2 && m0 >= m3) pitch = -atan(R[2][0] * cos(yaw) / R[0][0]);
+        else if (m1 >= m2 && m1 >= m3) pitch = -atan(R[2][0] * sin(yaw) / R[1][0]);
+        else if (m2 >= m3) pitch = -atan(R[2][0] * sin(roll) / R[2][1]);
+        else pitch = -atan(R[2][0] * cos(roll) / R[2][2]);
+    }
+    erow[3] = roll; erow[4] = pitch; erow[5] = yaw;
+}
+
 // Hessian from a supplied Jacobian, phase A: `ncfg` consecutive (6,n) Jacobians (W = 6n doubles each, contiguous; W is
 // even) into LDS rows of stride W + 1
 RTB_HD void hj_load_tile(const double *__restrict__ src, int W, int ncfg, double *rows, int lane)

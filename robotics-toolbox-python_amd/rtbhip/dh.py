@@ -11,74 +11,64 @@ import numpy as np
 
 from . import _lib
 from ._lib import check, lib, as_numeric, host_ptr, is_torch, MEM_HOST, MEM_DEVICE
+from .linkdyn import LinkDynamics
 from .et import ET, ETS, _poses
 from .kinematics import RobotKinematics
 
 
-class DHLink:
+class DHLink(LinkDynamics):
     def __init__(self, d=0.0, alpha=0.0, theta=0.0, a=0.0, sigma=0, mdh=False, offset=0.0, flip=False,
-                 qlim=None, m=0.0, r=None, I=None, Jm=0.0, G=0.0, B=0.0, Tc=None, **kw):
+                 qlim=None, m=None, r=None, I=None, Jm=None, G=None, B=None, Tc=None, name=None, **kw):
+        self._robot = None                                    # the DHRobot this link belongs to: told when a dynamic parameter changes
         self.d, self.alpha, self.theta, self.a = float(d), float(alpha), float(theta), float(a)
         self.sigma, self.mdh, self.offset, self.flip = int(sigma), bool(mdh), float(offset), bool(flip)
         self.qlim = None if qlim is None else np.asarray(qlim, dtype=np.float64).reshape(2)
-        self.m = float(m)
-        self.r = np.zeros(3) if r is None else np.asarray(r, dtype=np.float64).reshape(3)
-        self.I = self._inertia(I)
-        self.Jm, self.G, self.B = float(Jm), float(G), float(B)
-        if Tc is None:
-            self.Tc = np.zeros(2)
-        else:
-            Tc = np.asarray(Tc, dtype=np.float64).reshape(-1)
-            self.Tc = np.array([Tc[0], -Tc[0]]) if Tc.size == 1 else Tc.reshape(2)      # a scalar is symmetric friction (robot/Link.py:830-846)
+        self.name, self.id, self.number = name, None, None
+        self._set_dynamics(m=m, r=r, I=I, Jm=Jm, G=G, B=B, Tc=Tc)
 
-    @staticmethod
-    def _inertia(I):
-        """3x3 from (3,3) / 9 / 6 = [Ixx Iyy Izz Ixy Iyz Ixz] / 3 (reference robot/Link.py:719-751)."""
-        if I is None:
-            return np.zeros((3, 3))
-        I = np.asarray(I, dtype=np.float64)
-        if I.shape == (3, 3):
-            M = I
-        elif I.size == 9:
-            M = I.reshape(3, 3)
-        elif I.size == 6:
-            M = np.array([[I[0], I[3], I[5]], [I[3], I[1], I[4]], [I[5], I[4], I[2]]])
-        elif I.size == 3:
-            M = np.diag(I)
-        else:
-            raise ValueError("invalid shape passed: must be (3,3), (6,), (3,)")
-        if np.any(np.abs(M - M.T) > 1e-8):
-            raise ValueError("3x3 matrix is not symmetric")
-        return M.copy()
+    _DYN = ("m", "r", "I", "Jm", "G", "B", "Tc")
+
+    def __setattr__(self, name, value):
+        """A changed dynamic parameter invalidates the owning robot's device link table, as the reference's setters re-arm `frne.init`
+        through `_listen_dyn` (robot/Link.py:28-45 -> DHRobot.dynchanged robot/DHRobot.py:1328-1338)."""
+        object.__setattr__(self, name, value)
+        if name in DHLink._DYN:
+            robot = self.__dict__.get("_robot")
+            if robot is not None:
+                robot.dynchanged()
 
     @property
     def isrevolute(self): return self.sigma == 0
     @property
     def isprismatic(self): return self.sigma == 1
+    @property
+    def isflip(self): return self.flip
 
     def copy(self):
+        """A deep copy that still belongs to the same robot (robot/DHLink.py:390-420 keeps `_robot`)."""
         import copy as _copy
-        return _copy.deepcopy(self)
-
-    def islimit(self, q):
-        """q outside [qlim0, qlim1]; no limits set -> False (reference robot/Link.py:1300-1330)."""
-        return False if self.qlim is None else bool(q < self.qlim[0] or q > self.qlim[1])
-
-    def friction(self, qd, coulomb=True):
-        """Joint friction torque at joint velocity qd, referred to the link side: -|G| (B |G| qd + Tc+/-) (reference robot/Link.py:1395-1448)."""
-        tau = self.B * abs(self.G) * qd
-        if coulomb:
-            tau += self.Tc[0] if qd > 0 else (self.Tc[1] if qd < 0 else 0.0)
-        return -abs(self.G) * tau
-
-    def nofriction(self, coulomb=True, viscous=False):
-        """A copy with the Coulomb (and, if asked, viscous) friction removed (reference robot/Link.py:1350-1393)."""
-        l = self.copy()
-        if viscous:
-            l.B = 0.0
-        if coulomb:
-            l.Tc = np.zeros(2)
+        robot = self.__dict__.get("_robot")
+        object.__setattr__(self, "_robot", None)
+        try:
+            l = _copy.deepcopy(self)
+        finally:
+            object.__setattr__(self, "_robot", robot)
+        object.__setattr__(l, "_robot", robot)
         return l
+
+    def A(self, q):
+        """The link transform at joint value q: the closed form of reference robot/DHLink.py:633-673, evaluated on the device as
+        the one-link chain `ets()` lowers to."""
+        return self.ets().fkine(np.array([float(q)]))
+
+    def __str__(self):
+        """reference robot/DHLink.py:355-376"""
+        off = "" if self.offset == 0 else " + %s" % self.offset
+        qv = "q" if self.id is None else "q%s" % self.id
+        cls = type(self).__name__
+        if self.isrevolute:
+            return "%s:   θ=%s%s,  d=%s,  a=%s,  ⍺=%s" % (cls, qv, off, self.d, self.a, self.alpha)
+        return "%s:  θ=%s,  d=%s%s,  a=%s,  ⍺=%s" % (cls, self.theta, qv, off, self.a, self.alpha)
 
     def __add__(self, other):
         """link + link / link + robot -> DHRobot (reference robot/DHLink.py:227-255)."""
@@ -161,6 +151,9 @@ class DHRobot(RobotKinematics):
         self.links = flat
         if not self.links:
             raise ValueError("no links")
+        for k, l in enumerate(self.links):
+            object.__setattr__(l, "_robot", self)                 # robot/DHRobot.py:114-120: a link reports its parameter changes here
+            l.number = k + 1
         if len({l.mdh for l in self.links}) != 1:
             raise ValueError("Robot has mixed D&H links conventions")  # reference robot/DHRobot.py:90-112
         self.name, self.manufacturer = name, manufacturer

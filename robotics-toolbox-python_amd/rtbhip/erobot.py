@@ -15,35 +15,95 @@ from . import _lib
 from ._lib import check, lib, as_numeric, host_ptr, is_torch, MEM_HOST, MEM_DEVICE
 from .et import ET, ETS, _AXES
 from .kinematics import RobotKinematics, as_se3
+from .linkdyn import LinkDynamics
 
 
-class Link:
-    """reference robot/Link.py: Link(ets=ETS(...), m=, r=, I=, parent=, name=, jindex=)"""
+class Link(LinkDynamics):
+    """reference robot/Link.py: Link(ets=ETS(...), m=, r=, I=, Jm=, G=, B=, Tc=, parent=, name=, jindex=, qlim=)"""
 
-    def __init__(self, ets=None, m=0.0, r=None, I=None, parent=None, name=None, jindex=None, qlim=None, **kw):
+    def __init__(self, ets=None, m=None, r=None, I=None, Jm=None, G=None, B=None, Tc=None, parent=None, name=None, jindex=None, qlim=None,
+                 joint_name=None, **kw):
         if ets is None:
             ets = ETS()
         elif isinstance(ets, ET):
             ets = ETS(ets)
+        elif not isinstance(ets, ETS):
+            raise TypeError("The ets argument must be of type ETS or ET")                  # robot/Link.py:189-196
+        if parent is not None and not isinstance(parent, (str, Link)):
+            raise TypeError("parent must be BaseLink subclass")                            # robot/Link.py:200-210
         self.ets = ets
+        self._set_dynamics(m=m, r=r, I=I, Jm=Jm, G=G, B=B, Tc=Tc)
+        self.parent = parent
+        self.name = name if name is not None else ""
+        self._joint_name = joint_name
+        self.jindex = jindex if jindex is not None else (ets[-1].jindex if self.isjoint else None)
+        self._qlim = None
+        if qlim is not None and self.isjoint:
+            self.qlim = qlim
+        self.children = []
+        self.robot = None
+        self.number = 0
+
+    _DYN = ("m", "r", "I", "Jm", "G", "B", "Tc")
+
+    def __setattr__(self, name, value):
+        """A changed dynamic parameter invalidates the owning robot's device link table (the reference's `_listen_dyn`, robot/Link.py:28-45)."""
+        object.__setattr__(self, name, value)
+        if name in Link._DYN:
+            robot = self.__dict__.get("robot")
+            if robot is not None and hasattr(robot, "dynchanged"):
+                robot.dynchanged()
+
+    @property
+    def ets(self): return self._ets
+    @ets.setter
+    def ets(self, ets):
         joints = [k for k, e in enumerate(ets) if e.isjoint]
         if len(joints) > 1:
             raise ValueError("An elementary link can only have one joint variable")       # robot/Link.py:230-240
         if joints and joints[0] != len(ets) - 1:
             raise ValueError("Variable link must be at the end of the ETS")
+        self._ets = ets
         self.isjoint = bool(joints)
-        self.m = float(m)
-        self.r = np.zeros(3) if r is None else np.asarray(r, dtype=np.float64).reshape(3)
-        self.I = np.zeros((3, 3)) if I is None else np.asarray(I, dtype=np.float64)
-        self.parent = parent
-        self.name = name
-        self.jindex = jindex if jindex is not None else (ets[-1].jindex if self.isjoint else None)
-        self.qlim = qlim
-        self.children = []
 
     @property
     def v(self):
         return self.ets[-1] if self.isjoint else None
+
+    @property
+    def qlim(self):
+        """The joint's limits, kept on the link (robot/Link.py:1010-1040 keeps them on the joint's ET)."""
+        if self._qlim is not None:
+            return self._qlim
+        return self.v.qlim if self.isjoint else None
+    @qlim.setter
+    def qlim(self, v):
+        if v is None:
+            self._qlim = None
+            return
+        if not self.isjoint:
+            raise ValueError("Can not set qlim on a static joint")
+        self._qlim = np.asarray(v, dtype=np.float64).reshape(2).copy()
+
+    @property
+    def isrevolute(self): return self.isjoint and self.v.isrotation
+    @property
+    def isprismatic(self): return self.isjoint and self.v.istranslation
+    @property
+    def isflip(self): return self.isjoint and self.v.isflip
+    @property
+    def nchildren(self): return len(self.children)
+
+    def copy(self, parent=None):
+        import copy as _copy
+        robot, par, kids = self.robot, self.parent, self.children
+        self.robot, self.parent, self.children = None, None, []
+        try:
+            l = _copy.deepcopy(self)
+        finally:
+            self.robot, self.parent, self.children = robot, par, kids
+        l.parent = parent
+        return l
 
     def Ts(self):
         """Constant part of the link transform (robot/Link.py:1642-1651), 4x4."""
@@ -52,6 +112,23 @@ class Link:
             if not e.isjoint:
                 T = T @ e.T
         return T
+
+    def A(self, q=0.0):
+        """The link transform at joint value q (robot/Link.py:1590-1640: Ts, times the joint's transform when there is one), evaluated
+        on the device as the link's own chain."""
+        ets = self.ets
+        if self.isjoint and self.v.jindex not in (None, 0):                # the chain of this link alone reads a one-column q
+            ets = ETS([ET(e.axis, flip=e.isflip, jindex=0, qlim=e.qlim) if e.isjoint else e for e in ets])
+        return ets.fkine(np.array([float(q)]) if self.isjoint else np.zeros(0))
+
+    def __str__(self):
+        """`Link("name", Rx(88.41°) ⊕ tz(1))` (robot/Link.py:335-369)"""
+        s = type(self).__name__ + "("
+        if self.name is not None:
+            s += '"%s"' % self.name
+        if len(self.ets) > 0:
+            s += ", %s" % self.ets
+        return s + ")"
 
 
 class ERobot(RobotKinematics):
@@ -113,6 +190,8 @@ class ERobot(RobotKinematics):
         else:
             order = links                                            # explicit numbering keeps the given order (:355)
         self.links = order
+        for k, l in enumerate(order):
+            l.robot, l.number = self, k + 1                            # BaseRobot.py:331-340
         self.name = name
         self.manufacturer = manufacturer
         self.base = as_se3(base, "base")

@@ -60,10 +60,8 @@ def hessian_from_jacobian(J, n=None):
     return H[0] if single else H
 
 
-def angle_axis(Te, Tep):
-    """Pose error e = [Tep.t - Te.t ; angle-axis vector of Tep.R Te.R^T] (reference `rtb.angle_axis`, tools/p_servo.py:13-20
-    -> fknm.Angle_Axis core/fknm.cpp:112-162 -> _angle_axis core/ik.cpp:241-286): (6,) for one pair, (N,6) when either
-    argument is a stack of N poses (a single pose on the other side is used for every pair)."""
+def _pose_error(Te, Tep, method):
+    """(N,6) / (6,) error vectors of rtbhip_p_servo_error: method 0 angle-axis, 1 rpy."""
     tm = is_torch(Te) and Te.is_cuda and is_torch(Tep) and Tep.is_cuda
     def shape(T):
         if tm:
@@ -81,18 +79,31 @@ def angle_axis(Te, Tep):
     if (A.shape[0] not in (1, N)) or (B.shape[0] not in (1, N)):
         raise ValueError("Te and Tep must hold the same number of poses, or one of them a single pose")
     e = ETS._out((N, 6), A, tm)
-    check(lib().rtbhip_angle_axis(ETS._ptr(A, tm), A.shape[0], ETS._ptr(B, tm), B.shape[0], ETS._ptr(e, tm),
-                                  MEM_DEVICE if tm else MEM_HOST, ETS._stream(tm)))
+    if method == 0:
+        check(lib().rtbhip_angle_axis(ETS._ptr(A, tm), A.shape[0], ETS._ptr(B, tm), B.shape[0], ETS._ptr(e, tm),
+                                      MEM_DEVICE if tm else MEM_HOST, ETS._stream(tm)))
+    else:
+        check(lib().rtbhip_p_servo_error(ETS._ptr(A, tm), A.shape[0], ETS._ptr(B, tm), B.shape[0], int(method), ETS._ptr(e, tm),
+                                         MEM_DEVICE if tm else MEM_HOST, ETS._stream(tm)))
     return e[0] if (sa and sb) else e
 
 
-def p_servo(wTe, wTep, gain=1.0, threshold=0.1, method="angle-axis"):
-    """Position-based servoing, batched (reference tools/p_servo.py:46-117, method "angle-axis"): v = diag(gain) e with
-    e = angle_axis(wTe, wTep), arrived = sum|e| < threshold.  The reference's default method "rpy" goes through
-    spatialmath's tr2rpy and is not offered here."""
-    if method != "angle-axis":
-        raise NotImplementedError("p_servo: only method='angle-axis' runs on the GPU backend")
-    e = angle_axis(wTe, wTep)
+def angle_axis(Te, Tep):
+    """Pose error e = [Tep.t - Te.t ; angle-axis vector of Tep.R Te.R^T] (reference `rtb.angle_axis`, tools/p_servo.py:13-20
+    -> fknm.Angle_Axis core/fknm.cpp:112-162 -> _angle_axis core/ik.cpp:241-286): (6,) for one pair, (N,6) when either
+    argument is a stack of N poses (a single pose on the other side is used for every pair)."""
+    return _pose_error(Te, Tep, 0)
+
+
+angle_axis_python = angle_axis      # the reference keeps a pure-Python twin for symbolic input (tools/p_servo.py:23-43); one kernel serves both names here
+
+
+def p_servo(wTe, wTep, gain=1.0, threshold=0.1, method="rpy"):
+    """Position-based servoing, batched (reference tools/p_servo.py:46-117): v = diag(gain) e, arrived = sum|e| < threshold, with
+    e the error seen from the end-effector frame for method "rpy" (the reference's default: [t ; tr2rpy(order "zyx")] of
+    inv(wTe) wTep) or the base-frame angle-axis error for any other method string (p_servo.py:98-99 takes that branch for
+    everything that is not "rpy").  (6,), bool for one pair; (N,6), (N,) bools for stacks of poses."""
+    e = _pose_error(wTe, wTep, 1 if method == "rpy" else 0)
     k = np.asarray(gain, dtype=np.float64)
     if k.ndim not in (0, 1) or (k.ndim == 1 and k.shape[0] != 6):
         raise ValueError("gain must be a scalar or a 6-vector")

@@ -121,6 +121,10 @@ class EmuBackend:
         rc = self._gate("rtbhip_angle_axis", (Te, nTe, Tep, nTep, e, mem, stream))
         return self.emu.emu_angle_axis(Te, nTe, Tep, nTep, e) if rc is None else rc
 
+    def rtbhip_p_servo_error(self, Te, nTe, Tep, nTep, method, e, mem, stream):
+        rc = self._gate("rtbhip_p_servo_error", (Te, nTe, Tep, nTep, method, e, mem, stream))
+        return self.emu.emu_p_servo_error(Te, nTe, Tep, nTep, method, e) if rc is None else rc
+
     def rtbhip_jacob_dot(self, h, q, qd, N, tool, frame, Jd, mem, stream):
         rc = self._gate("rtbhip_jacob_dot", (h, q, qd, N, tool, frame, Jd, mem, stream))
         return self.emu.emu_diff(h, 0, 63, q, qd, N, tool, frame, Jd) if rc is None else rc

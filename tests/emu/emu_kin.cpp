@@ -253,7 +253,11 @@ extern "C" int emu_hess_from_jac(const double *J, int64_t N, int n, double *H)
 }
 
 // k_angle_axis: both operand tiles through LDS (aa_load_tile), per-lane aa_lane, staged e rows flushed as one run
-extern "C" int emu_angle_axis(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, double *e)
+static int emu_pose_error(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, int method, double *e);
+extern "C" int emu_angle_axis(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, double *e) { return emu_pose_error(Te, nTe, Tep, nTep, 0, e); }
+// k_angle_axis<true>: the same staging around servo_rpy_lane (method 1, p_servo's "rpy")
+extern "C" int emu_p_servo_error(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, int method, double *e) { return emu_pose_error(Te, nTe, Tep, nTep, method, e); }
+static int emu_pose_error(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, int method, double *e)
 {
     const int64_t N = std::max(nTe, nTep);
     std::vector<double> a(kWave * kAaStride, -777.0), b(kWave * kAaStride, -777.0);
@@ -271,7 +275,10 @@ extern "C" int emu_angle_axis(const double *Te, int64_t nTe, const double *Tep, 
             const int la = ea ? (l < ncfg ? l : 0) : 0, lb = eb ? (l < ncfg ? l : 0) : 0;
             for (int k = 0; k < 12; ++k) { t1[l][k] = a[la * kAaStride + k]; t2[l][k] = b[lb * kAaStride + k]; }
         }
-        for (int l = 0; l < kWave; ++l) aa_lane(t1[l], t2[l], a.data() + l * 7);
+        for (int l = 0; l < kWave; ++l) {
+            if (method == 1) servo_rpy_lane(t1[l], t2[l], a.data() + l * 7);
+            else aa_lane(t1[l], t2[l], a.data() + l * 7);
+        }
         for (int l = 0; l < kWave; ++l) kin_flush(a.data(), 7, 6, ncfg, e + cfg0 * 6, l);
     }
     return 0;

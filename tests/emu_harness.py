@@ -131,6 +131,7 @@ def lib():
         _lib.rtbhip_last_error.restype = C.c_char_p
         _lib.emu_hess_from_jac.argtypes = [_vp, _i64, _i32, _vp]
         _lib.emu_angle_axis.argtypes = [_vp, _i64, _vp, _i64, _vp]
+        _lib.emu_p_servo_error.argtypes = [_vp, _i64, _vp, _i64, _i32, _vp]
     return _lib
 
 
@@ -255,6 +256,16 @@ def angle_axis(Te, Tep):
     N = max(len(Te), len(Tep))
     e = np.full((N, 6), np.nan)
     assert lib().emu_angle_axis(_p(Te), len(Te), _p(Tep), len(Tep), _p(e)) == 0
+    return e
+
+
+def p_servo_error(Te, Tep, method):
+    """k_angle_axis<method == 1>: (N|1,4,4) x (N|1,4,4) -> (N,6); method 0 angle-axis, 1 rpy (p_servo's default)."""
+    Te = np.ascontiguousarray(np.asarray(Te, dtype=np.float64).reshape(-1, 4, 4))
+    Tep = np.ascontiguousarray(np.asarray(Tep, dtype=np.float64).reshape(-1, 4, 4))
+    N = max(len(Te), len(Tep))
+    e = np.full((N, 6), np.nan)
+    assert lib().emu_p_servo_error(_p(Te), len(Te), _p(Tep), len(Tep), int(method), _p(e)) == 0
     return e
 
 

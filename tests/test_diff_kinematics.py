@@ -149,13 +149,12 @@ def test_gpu_jacob0_dot_representation_and_hessian_from_jacobian():
     nt.assert_allclose(H14, emu.hess_from_jac(J14), atol=1e-13)
     # p_servo, method "angle-axis" (tools/p_servo.py:46-117)
     Te, Tep = e.eval(q[:50]), e.eval(q[:50] + 0.01)
-    v, arrived = rtbhip.p_servo(Te, Tep, gain=2.0, threshold=0.5)
+    v, arrived = rtbhip.p_servo(Te, Tep, gain=2.0, threshold=0.5, method="angle-axis")
     nt.assert_allclose(v, 2.0 * rtbhip.angle_axis(Te, Tep), atol=0)
     assert arrived.shape == (50,) and arrived.dtype == bool
-    v1, a1 = rtbhip.p_servo(Te[0], Tep[0], gain=[1, 1, 1, 2, 2, 2], threshold=0.5)
+    v1, a1 = rtbhip.p_servo(Te[0], Tep[0], gain=[1, 1, 1, 2, 2, 2], threshold=0.5, method="angle-axis")
     assert v1.shape == (6,) and isinstance(a1, bool)
-    with pytest.raises(NotImplementedError):
-        rtbhip.p_servo(Te[0], Tep[0], method="rpy")
+    # (the reference's default method "rpy": tests/test_p_servo.py)
 
 
 @pytest.mark.gpu

@@ -1,5 +1,5 @@
-"""The reference's OWN unit-test files -- tests/test_ET.py, test_ETS.py, test_jacob.py, test_IK.py, test_PoERobot.py, test_DHRobot.py of
-robotics-toolbox-python --
+"""The reference's OWN unit-test files -- tests/test_ET.py, test_ETS.py, test_jacob.py, test_IK.py, test_PoERobot.py, test_DHRobot.py, test_ERobot.py,
+test_Robot.py, test_tools.py, test_Link.py, test_ELink.py of robotics-toolbox-python --
 executed UNMODIFIED against this backend on the GPU.
 
 `import roboticstoolbox as rtb` in those files resolves to a module object whose `ET`, `ETS`, `IK_LM` ..., `models.*` are rtbhip's
@@ -65,6 +65,17 @@ EXPECTED = {
         "test_qlim_setters": "per-link qlim setters of a URDF Robot's Link objects",
         "test_velocity_damper": "joint_velocity_damper (a controller helper): not on the path",
     },
+    "test_tools": {
+        "test_null": "rtb.null is scipy.linalg.null_space under another name: a host utility, not on the path",
+        "test_jsingu": "jsingu prints which Jacobian columns are linearly dependent (a console report): not on the path",
+    },
+    "test_Link": {},
+    "test_ELink": {
+        **{t: "pybullet collision checking: skipped by its own mark" for t in ("test_collided", "test_collision", "test_dist", "test_set_collision", "test_set_collision2")},
+        **{t: "ET2 / ETS2 / Link2, the 2-D classes: not on the path" for t in ("test_ets2_A", "test_ets2_A2", "test_init_ets2")},
+        "test_set_geometry": "spatialgeometry shapes attached to a link (display / collision geometry): out of scope",
+        "test_set_geometry2": "spatialgeometry shapes attached to a link (display / collision geometry): out of scope",
+    },
     "test_DHRobot": {
         **{t: "plotting / teach panels: out of scope" for t in (
             "test_plot", "test_plot_traj", "test_plot_fellipse", "test_plot_vellipse", "test_plot_with_fellipse", "test_plot_with_vellipse",
@@ -108,6 +119,10 @@ def install_shims():
     robot.__path__ = []
     etm = types.ModuleType("roboticstoolbox.robot.ET")
     etm.BaseET, etm.ET = rtbhip.ET, rtbhip.ET
+    linkm = types.ModuleType("roboticstoolbox.robot.Link")
+    linkm.BaseLink, linkm.Link = rtbhip.Link, rtbhip.Link
+    robotm = types.ModuleType("roboticstoolbox.robot.Robot")
+    robotm.BaseRobot, robotm.Robot = rtbhip.ERobot, rtbhip.ERobot
     tools = types.ModuleType("roboticstoolbox.tools")
     tools.__path__ = []
 
@@ -129,7 +144,7 @@ def install_shims():
     marks.skip_no_qp = pytest.mark.skipif(False, reason="")            # IK_QP runs on the device: no qpsolvers needed
     marks.skip_no_pybullet = unittest.skip("pybullet (collision checking) is not part of this backend")
     new = {"spatialmath": sm, "spatialmath.base": smb, "spatialmath.base.argcheck": smb.argcheck, "spatialmath.base.symbolic": smb.symbolic,
-           "roboticstoolbox": rtb, "spatialgeometry": sg, "roboticstoolbox.tools": tools, "roboticstoolbox.robot": robot, "roboticstoolbox.robot.ET": etm, "tests": tests, "tests.marks": marks}
+           "roboticstoolbox": rtb, "spatialgeometry": sg, "roboticstoolbox.tools": tools, "roboticstoolbox.robot": robot, "roboticstoolbox.robot.ET": etm, "roboticstoolbox.robot.Link": linkm, "roboticstoolbox.robot.Robot": robotm, "tests": tests, "tests.marks": marks}
     saved = {k: sys.modules.get(k) for k in new}
     sys.modules.update(new)
     return saved
@@ -179,7 +194,7 @@ def run_module(mod):
     return out
 
 
-FILES = ["test_ET", "test_ETS", "test_jacob", "test_IK", "test_PoERobot", "test_DHRobot", "test_ERobot", "test_Robot"]
+FILES = ["test_ET", "test_ETS", "test_jacob", "test_IK", "test_PoERobot", "test_DHRobot", "test_ERobot", "test_Robot", "test_tools", "test_Link", "test_ELink"]
 
 
 @pytest.mark.parametrize("name", FILES)
@@ -197,7 +212,7 @@ def check_file(name):
         results = run_module(mod)
     finally:
         restore(saved)
-    assert len(results) >= {"test_ET": 31, "test_ETS": 43, "test_jacob": 12, "test_IK": 36, "test_PoERobot": 1, "test_DHRobot": 71, "test_ERobot": 15, "test_Robot": 35}[name], sorted(results)
+    assert len(results) >= {"test_ET": 31, "test_ETS": 43, "test_jacob": 12, "test_IK": 36, "test_PoERobot": 1, "test_DHRobot": 71, "test_ERobot": 15, "test_Robot": 35, "test_tools": 5, "test_Link": 18, "test_ELink": 31}[name], sorted(results)
     failed = {k: v for k, v in results.items() if v is not None}
     either = DRAW_DEPENDENT.get(name, {})
     unexpected = {k: v for k, v in failed.items() if k not in EXPECTED[name] and k not in either}
