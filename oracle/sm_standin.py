@@ -281,6 +281,7 @@ class SE3:
     def append(self, other):
         self._data.extend(other._data)
 
+    def copy(self): return SE3(self)                          # robot/DHRobot.py:1058 (fkine_all starts from a copy of the base)
     def __len__(self): return len(self._data)
     def __iter__(self): return (SE3(a, check=False) for a in self._data)
     def __getitem__(self, i): return SE3(self._data[i], check=False)

@@ -58,7 +58,10 @@ class DHLink(LinkDynamics):
 
     def A(self, q):
         """The link transform at joint value q: the closed form of reference robot/DHLink.py:633-673, evaluated on the device as
-        the one-link chain `ets()` lowers to."""
+        the one-link chain `ets()` lowers to.  A `flip`ped joint is flipped here for every link, as it is in
+        `ets()` and therefore in the Jacobians of both libraries; the reference's closed form asks the LAST element of the link's ETS
+        (robot/DHLink.py:636-639), which for a standard-DH link with a trailing tz(d) / tx(a) / Rx(alpha) is a constant, and so leaves
+        the flip out of `A` and `DHRobot.fkine` (a product of `A`s) while its `jacob0` keeps it.  That inconsistency is not reproduced."""
         return self.ets().fkine(np.array([float(q)]))
 
     def __str__(self):
@@ -535,7 +538,10 @@ class DHRobot(RobotKinematics):
 
     def accel(self, q, qd, torque, gravity=None):
         """Forward dynamics qdd = M^-1 (torque - rne(q, qd, 0)): (n,) or (N,n)
-        (reference Dynamics.accel robot/Dynamics.py:424-509)."""
+        (reference Dynamics.accel robot/Dynamics.py:424-509).  The solve is an LDL^T of the lower triangle of M as the recursion produces
+        it.  One case where that matters: for a modified-DH chain whose FIRST joint is prismatic the reference's recursion (core/ne.c) yields a
+        non-symmetric M (the first joint's force misses the link masses; `inertia` returns it as the reference does), and the reference's
+        accel solves with that full matrix -- the two answers differ there and neither is physical (tests/test_dropin_differential_cpu.py)."""
         arrs, N, single, tm, ptr, stream, mem, dev = self._dyn_args([q, qd, torque])
         gc = self._gravity_c(gravity)
         qdd = self._empty((N, self.n), tm, dev)
