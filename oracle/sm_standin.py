@@ -281,6 +281,15 @@ class SE3:
     def append(self, other):
         self._data.extend(other._data)
 
+    @classmethod
+    def Alloc(cls, n):                                        # robot/Robot.py:669 (fkine_all fills a preallocated stack)
+        x = cls()
+        x._data = [np.eye(4) for _ in range(n)]
+        return x
+
+    def __setitem__(self, i, v):
+        self._data[i] = (v.A if isinstance(v, SE3) else np.asarray(v, dtype=np.float64)).copy()
+
     def copy(self): return SE3(self)                          # robot/DHRobot.py:1058 (fkine_all starts from a copy of the base)
     def __len__(self): return len(self._data)
     def __iter__(self): return (SE3(a, check=False) for a in self._data)

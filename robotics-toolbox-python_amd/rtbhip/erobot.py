@@ -190,8 +190,8 @@ class ERobot(RobotKinematics):
         else:
             order = links                                            # explicit numbering keeps the given order (:355)
         self.links = order
-        for k, l in enumerate(order):
-            l.robot, l.number = self, k + 1                            # BaseRobot.py:331-340
+        for k, l in enumerate(links):
+            l.robot, l.number = self, k + 1                            # BaseRobot.py:234-236: numbered in the order GIVEN, before the sort
         self.name = name
         self.manufacturer = manufacturer
         self.base = as_se3(base, "base")
@@ -273,7 +273,9 @@ class ERobot(RobotKinematics):
         return lim
 
     def fkine_all(self, q, base=None):
-        """Pose of every link frame: T[0] = base, T[k+1] = link k of self.links; (nlinks+1,4,4) or (N,nlinks+1,4,4)
+        """Pose of every link frame: T[0] = base, T[link.number] = that link -- `number` is the link's position in the list the robot
+        was built from, plus one (robot/Robot.py:679 indexes by it; for a serial chain that is its place in self.links);
+        (nlinks+1,4,4) or (N,nlinks+1,4,4)
         (reference Robot.fkine_all robot/Robot.py:638-698, a Python recursion over the link tree).  One chain walk per
         leaf of the tree: the frames of all the links on its path come out of the same launch."""
         index = {id(l): k for k, l in enumerate(self.links)}
@@ -303,9 +305,9 @@ class ERobot(RobotKinematics):
             import torch
             T0 = torch.eye(4, dtype=first.dtype, device=first.device) if base is None else torch.as_tensor(np.asarray(base, dtype=np.float64)).to(first.device)
             T0 = T0.expand(first.shape)
-            return torch.stack([T0] + [done[id(l)] for l in self.links], dim=-3)
+            return torch.stack([T0] + [done[id(l)] for l in sorted(self.links, key=lambda l: l.number)], dim=-3)
         T0 = np.broadcast_to(np.eye(4) if base is None else np.asarray(base, dtype=np.float64), first.shape)
-        return np.stack([T0] + [done[id(l)] for l in self.links], axis=-3)
+        return np.stack([T0] + [done[id(l)] for l in sorted(self.links, key=lambda l: l.number)], axis=-3)
 
     # ------------------------------------------------------------ dynamics
     def link_groups(self):

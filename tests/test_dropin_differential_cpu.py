@@ -291,3 +291,81 @@ def test_flipped_dh_joints_where_the_reference_is_not_self_consistent():
         nt.assert_allclose(A(mine.fkine(q)), A(ref.fkine(q)), atol=1e-12)         # (modified DH: the reference's fkine does honour the flip)
         z = np.zeros(3)
         nt.assert_allclose(mine.rne(q, z, z), ref.rne(q, z, z), atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------ ETS robots (link trees)
+def random_tree(rng, nlinks):
+    """[(name, parent name or None, ets spec)]: a tree of links, each a few constants and (mostly) one joint at the end; branching and
+    static links included."""
+    out = []
+    for k in range(nlinks):
+        parent = None if k == 0 else "L%d" % int(rng.integers(max(0, k - 3), k))
+        spec = []
+        for _ in range(int(rng.integers(0, 3))):
+            a = ["Rx", "Ry", "Rz", "tx", "ty", "tz"][int(rng.integers(6))]
+            spec.append((a, float(rng.uniform(-1.2, 1.2) if a[0] == "R" else rng.uniform(-0.3, 0.3))))
+        if k == 0 or rng.random() < 0.8:
+            spec.append((["Rx", "Ry", "Rz", "tx", "ty", "tz"][int(rng.integers(6))], None, bool(rng.random() < 0.25)))
+        out.append(("L%d" % k, parent, spec))
+    return out
+
+
+def build_tree(ET, ETS, Link, Robot, tree):
+    links = {}
+    for name, parent, spec in tree:
+        ets = ETS([getattr(ET, it[0])(it[1]) if it[1] is not None else getattr(ET, it[0])(flip=it[2]) for it in spec])
+        links[name] = Link(ets, name=name, parent=None if parent is None else links[parent])
+    return Robot(list(links.values()), name="tree"), links
+
+
+@pytest.mark.skipif(not ref_classes.dh_available(), reason="needs the reference's byte-compiled Link / Robot classes")
+def test_link_trees_agree_paths_and_kinematics():
+    import rtbhip
+    from test_reference_dh_classes import ref_dh
+    ns = ref_dh()
+    rLink, rRobot = ns.mods["Link"].Link, ns.mods["Robot"].Robot
+    rng = np.random.default_rng(33)
+    paths = 0
+    with cpu_backend.installed():
+        for k in range(25):
+            tree = random_tree(rng, 3 + k % 7)
+            ref, rl = build_tree(ns.ET, ns.ETS, rLink, rRobot, tree)
+            mine, ml = build_tree(rtbhip.ET, rtbhip.ETS, rtbhip.Link, rtbhip.ERobot, tree)
+            assert mine.n == ref.n and [l.name for l in mine.links] == [l.name for l in ref.links]
+            assert [l.jindex for l in mine.links] == [l.jindex for l in ref.links]
+            assert [bool(l.isjoint) for l in mine.links] == [bool(l.isjoint) for l in ref.links]
+            if ref.n == 0:
+                continue
+            q = rng.uniform(-1.5, 1.5, ref.n)
+            names = [t[0] for t in tree]
+            for end in names:
+                e_r = ref.ets(end=rl[end])
+                e_m = mine.ets(end=ml[end])
+                assert str(e_m) == str(e_r), (end, str(e_m), str(e_r))
+                if e_r.n == 0:
+                    continue
+                for form in (rl[end], end):                                   # a Link object or its name
+                    fm = ml[end] if form is rl[end] else end
+                    nt.assert_allclose(A(mine.fkine(q, end=fm)), A(ref.fkine(q, end=form)), atol=1e-12)
+                r, m = ref.jacob0(q, end=rl[end]), mine.jacob0(q, end=ml[end])
+                assert np.shape(m) == np.shape(r)
+                nt.assert_allclose(m, r, atol=1e-12)
+                nt.assert_allclose(mine.jacobe(q, end=ml[end]), ref.jacobe(q, end=rl[end]), atol=1e-12)
+                nt.assert_allclose(mine.hessian0(q, end=ml[end]), ref.hessian0(q, end=rl[end]), atol=1e-12)
+                paths += 1
+            # a path between two arbitrary links: up towards the common ancestor, then down (BaseRobot.py:1426-1467)
+            for _ in range(4):
+                a, b = names[int(rng.integers(len(names)))], names[int(rng.integers(len(names)))]
+                try:
+                    e_r = ref.ets(start=rl[a], end=rl[b])
+                except Exception as ex:
+                    with pytest.raises(type(ex)):
+                        mine.ets(start=ml[a], end=ml[b])
+                    continue
+                e_m = mine.ets(start=ml[a], end=ml[b])
+                assert str(e_m) == str(e_r), (a, b, str(e_m), str(e_r))
+                if e_r.n:
+                    nt.assert_allclose(A(mine.fkine(q, start=ml[a], end=ml[b])), A(ref.fkine(q, start=rl[a], end=rl[b])), atol=1e-12)
+                    nt.assert_allclose(mine.jacob0(q, start=ml[a], end=ml[b]), ref.jacob0(q, start=rl[a], end=rl[b]), atol=1e-12)
+            nt.assert_allclose(A(mine.fkine_all(q)), A(ref.fkine_all(q)), atol=1e-12)
+    assert paths >= 60
