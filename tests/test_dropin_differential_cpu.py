@@ -17,8 +17,9 @@ pytestmark = pytest.mark.skipif(not (ref_classes.available() and ref_harness.ava
                                 reason="needs oracle/_ref (the reference's compiled extension and byte-compiled classes)")
 
 
-def build(ET, ETS, spec, SE3=None):
-    """The chain of `spec` with the given constructors; joints numbered in order of appearance (as both libraries do for an ETS)."""
+def build(ET, ETS, spec, SE3=None, limits=False):
+    """The chain of `spec` with the given constructors; joints numbered in order of appearance (as both libraries do for an ETS);
+    limits: prismatic joints get [-1.5, 1.5] (the Python solvers refuse a chain with an unlimited prismatic joint)."""
     out = []
     for item in spec:
         if isinstance(item, np.ndarray):
@@ -27,19 +28,24 @@ def build(ET, ETS, spec, SE3=None):
         axis, eta = item[0], item[1]
         flip = bool(item[2]) if len(item) > 2 else False
         ctor = getattr(ET, axis)
-        out.append(ctor(eta) if eta is not None else ctor(flip=flip))
+        if eta is not None:
+            out.append(ctor(eta))
+        elif limits and axis[0] == "t":
+            out.append(ctor(flip=flip, qlim=[-1.5, 1.5]))
+        else:
+            out.append(ctor(flip=flip))
     return ETS(out)
 
 
-def both(seed, count, nmax=8):
+def both(seed, count, nmax=8, limits=False):
     import rtbhip
     ns = ref_classes.load_reference()
     rng = np.random.default_rng(seed)
     for k in range(count):
         n = 1 + k % nmax
         spec = random_spec(rng, n)
-        ref = build(ns.ET, ns.ETS, spec, SE3=ns.SE3)
-        mine = build(rtbhip.ET, rtbhip.ETS, spec)
+        ref = build(ns.ET, ns.ETS, spec, SE3=ns.SE3, limits=limits)
+        mine = build(rtbhip.ET, rtbhip.ETS, spec, limits=limits)
         yield n, spec, ref, mine, rng
 
 
@@ -369,3 +375,62 @@ def test_link_trees_agree_paths_and_kinematics():
                     nt.assert_allclose(mine.jacob0(q, start=ml[a], end=ml[b]), ref.jacob0(q, start=rl[a], end=rl[b]), atol=1e-12)
             nt.assert_allclose(A(mine.fkine_all(q)), A(ref.fkine_all(q)), atol=1e-12)
     assert paths >= 60
+
+
+def test_python_solvers_agree_for_a_supplied_start():
+    """ETS.ikine_LM / ikine_GN / ikine_NR (the Python solvers of robot/IK.py behind them) from a supplied start that converges in the first
+    search, on random chains: the IKSolution fields, value for value (success, iterations, searches, residual, q)."""
+    with cpu_backend.installed():
+        done = 0
+        for n, spec, ref, mine, rng in both(17, 56, limits=True):
+            if n < 6:
+                continue
+            qs = rng.uniform(-1.0, 1.0, n)
+            Tep = ref.eval(qs)
+            q0 = qs + rng.uniform(-0.05, 0.05, n)
+            sv = np.linalg.svd(ref.jacob0(qs), compute_uv=False)
+            if sv[5] < 1e-3 * sv[0]:
+                continue                                                  # (rank-deficient chains: see the C-solver test above)
+            for name, kw in (("ikine_LM", {"method": "chan", "k": 1.0}), ("ikine_LM", {"method": "wampler", "k": 0.01}),
+                             ("ikine_LM", {"method": "sugihara", "k": 0.01}), ("ikine_GN", {"pinv": True}), ("ikine_NR", {"pinv": True})):
+                r = getattr(ref, name)(Tep, q0=q0, ilimit=30, slimit=1, tol=1e-6, joint_limits=False, **kw)
+                m = getattr(mine, name)(Tep, q0=q0, ilimit=30, slimit=1, tol=1e-6, joint_limits=False, **kw)
+                assert (bool(m.success), int(m.iterations), int(m.searches)) == (bool(r.success), int(r.iterations), int(r.searches)), (name, kw, r, m)
+                if r.success:
+                    nt.assert_allclose(m.q, r.q, atol=1e-6)
+                    assert abs(m.residual - r.residual) <= 1e-9 + 1e-3 * r.residual
+                    assert m.reason == r.reason
+                done += 1
+        assert done >= 40
+
+
+def test_differential_kinematics_consumers_agree():
+    """ETS.manipulability (three methods x three axis selections), ETS.jacobm, ETS.partial_fkine0 (orders 2..4) on random chains.
+    The manipulability measures come from the eigenvalues of a Gram matrix on the device (csrc/diff_device.h) where the reference takes an SVD
+    of J itself: at a (numerically) singular configuration the device value carries an absolute error of ~1e-8 sigma_max (the square root
+    of the rounding noise of the Gram matrix) where the reference returns ~1e-17 -- the tolerance below says so; an all-zero selected block
+    (a chain of prismatic joints asked for axes="rot") gives 0/0 = nan for "invcondition" where the reference's 1 / cond returns 0."""
+    with cpu_backend.installed():
+        for n, spec, ref, mine, rng in both(41, 40):
+            q = rng.uniform(-2, 2, n)
+            smax = np.linalg.svd(ref.jacob0(q), compute_uv=False)[0]
+            for method in ("yoshikawa", "minsingular", "invcondition"):
+                for axes in ("all", "trans", "rot"):
+                    r = ref.manipulability(q, method=method, axes=axes)
+                    m = mine.manipulability(q, method=method, axes=axes)
+                    if np.isnan(m):
+                        sel = slice(0, 3) if axes == "trans" else slice(3, 6)
+                        assert method == "invcondition" and axes != "all" and np.abs(ref.jacob0(q)[sel]).max() == 0.0 and r == 0.0
+                        continue
+                    scale = max(1.0, smax) ** (min(n, 6 if axes == "all" else 3) if method == "yoshikawa" else 1)
+                    assert abs(m - r) <= 1e-7 * scale + 1e-9 * abs(r), (n, method, axes, r, m)
+            if n >= 2 and np.linalg.svd(ref.jacob0(q), compute_uv=False)[min(n, 6) - 1] > 1e-3 * smax and n >= 6:
+                nt.assert_allclose(np.ravel(mine.jacobm(q)), np.ravel(ref.jacobm(q)), rtol=1e-6, atol=1e-9)
+            for order in (2, 3, 4):
+                r, m = ref.partial_fkine0(q, n=order), mine.partial_fkine0(q, n=order)
+                assert np.shape(m) == np.shape(r)
+                nt.assert_allclose(m, r, atol=1e-10)
+            with pytest.raises(ValueError):
+                mine.manipulability(q, method="nonsense")
+            with pytest.raises(ValueError):
+                ref.manipulability(q, method="nonsense")
