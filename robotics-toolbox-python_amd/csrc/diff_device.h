@@ -111,7 +111,8 @@ RTB_HD double manipulability_singular(const double (&jac)[6 * NJ], int axes, int
         for (int i = 0; i < NJ; ++i) { lo = G[i][i] < lo ? G[i][i] : lo; hi = G[i][i] > hi ? G[i][i] : hi; }
     }
     lo = lo < 0.0 ? 0.0 : lo;
-    return mode == 1 ? sqrt(lo) : sqrt(lo / hi);
+    // (an all-zero selected block -- prismatic joints asked for their rotational part -- has cond = inf: 1 / cond = 0, ETS.py:1789-1791)
+    return mode == 1 ? sqrt(lo) : (hi > 0.0 ? sqrt(lo / hi) : 0.0);
 }
 
 // Analytical Jacobian (ETS.jacob0_analytical robot/ETS.py:1562-1626): Ja = blkdiag(I, A^-1) J0 with A the map from the
