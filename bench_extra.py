@@ -79,7 +79,7 @@ def valu_roofline(key, units_per_s, kernel, hbm_bytes_per_unit):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--what", default="rne,ik,fleet,dyn,tree,kin,poe,graph")
+    ap.add_argument("--what", default="rne,ik,fleet,dyn,tree,kin,poe,graph,servo")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
@@ -512,6 +512,22 @@ def main():
                               "wide_q_vs_path_q_max_abs_diff": err17,
                               "roofline": {"bound": "hbm", "achieved": byts17 / (avg17 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                            "frac": byts17 / (avg17 * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": byts17}}), flush=True)
+    if "servo" in what and world == 1:
+        # tools/p_servo.py's error vector over N pose pairs, both methods (k_angle_axis<RPY>): 2 x 128 B in + 48 B out per pair, HBM-bound
+        N = args.n_dyn
+        Te = rtbhip.models.Panda().ets().eval(torch.from_numpy(np.random.default_rng(21).uniform(-np.pi, np.pi, (N, 7))).cuda())
+        Tep = rtbhip.models.Panda().ets().eval(torch.from_numpy(np.random.default_rng(22).uniform(-np.pi, np.pi, (N, 7))).cuda())
+        for method in ("rpy", "angle-axis"):
+            hold = {}
+            def servo_step():
+                hold["o"] = rtbhip.p_servo(Te, Tep, method=method)
+            avg, best = ev_time(servo_step, args.steps, 3)
+            byts = 2 * 128 + 48
+            print(json.dumps({"metric": "pose pairs/sec (p_servo error, method %r; the gain and the arrived test are torch elementwise ops inside the timed call)" % method,
+                              "value": N / (avg * 1e-3), "unit": "pairs/s", "n": N, "kernel_avg_ms": avg, "kernel_min_ms": best,
+                              "roofline": {"bound": "hbm", "achieved": byts * N / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": byts * N / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": byts * N,
+                                           "kernel": "k_angle_axis<%s> (+ two torch elementwise kernels of the wrapper)" % ("true" if method == "rpy" else "false")}}), flush=True)
     rk.finish()
 
 
