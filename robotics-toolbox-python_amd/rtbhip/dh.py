@@ -334,9 +334,10 @@ class DHRobot(RobotKinematics):
                 q = a.reshape(-1, self.n)                     # a flat run of configurations (getmatrix(q, (None, n)), robot/DHRobot.py:960)
         return self.ets().fkine(q)
 
-    def fkine_all(self, q, old=None):
+    def fkine_all(self, q=None, old=True):
         """Poses of frames {0} (the base) to {n}: (n+1,4,4) or (N,n+1,4,4).  reference robot/DHRobot.py:1018-1064:
-        Tj = base; Tj *= L.A(q_j) for every link -- the tool is not applied."""
+        Tj = base; Tj *= L.A(q_j) for every link -- the tool is not applied; q defaults to the stored configuration."""
+        q = self.q if q is None else q
         e = self.ets()
         k = 1 if (self.base is not None and not np.array_equal(self.base, np.eye(4))) else 0
         marks = [k]
@@ -344,6 +345,12 @@ class DHRobot(RobotKinematics):
             k += len(l.ets())
             marks.append(k)
         return _poses(e.link_frames(q, marks))
+
+    def ikine_LM(self, Tep, q0=None, ilimit=30, slimit=100, tol=1e-6, joint_limits=False, mask=None, seed=None, **batch):
+        """The reference's DHRobot overrides RobotKinematics.ikine_LM with this narrower signature -- no start / end, and joint limits
+        NOT enforced unless asked (robot/DHRobot.py:2454-2474; `ETS.ikine_LM` and `Robot.ikine_LM` default to True): same positional order,
+        same defaults.  Further keywords go to ETS.ikine_LM, which checks them."""
+        return self.ets().ikine_LM(Tep, q0=q0, ilimit=ilimit, slimit=slimit, tol=tol, joint_limits=joint_limits, mask=mask, seed=seed, **batch)
 
     @staticmethod
     def _half(J, half):
@@ -409,7 +416,7 @@ class DHRobot(RobotKinematics):
             L[i, 19:24] = [l.Jm, l.G, l.B, l.Tc[0], l.Tc[1]]
         return np.ascontiguousarray(L)
 
-    def dynchanged(self):
+    def dynchanged(self, what=None):
         self.delete_rne()
 
     def delete_rne(self):

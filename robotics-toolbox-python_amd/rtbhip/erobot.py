@@ -21,8 +21,10 @@ from .linkdyn import LinkDynamics
 class Link(LinkDynamics):
     """reference robot/Link.py: Link(ets=ETS(...), m=, r=, I=, Jm=, G=, B=, Tc=, parent=, name=, jindex=, qlim=)"""
 
-    def __init__(self, ets=None, m=None, r=None, I=None, Jm=None, G=None, B=None, Tc=None, parent=None, name=None, jindex=None, qlim=None,
-                 joint_name=None, **kw):
+    def __init__(self, ets=None, jindex=None, name=None, parent=None, joint_name=None, m=None, r=None, I=None, Jm=None, B=None, Tc=None, G=None,
+                 qlim=None, **kw):
+        # (positional order of the reference: Link(ets, jindex, **kwargs) over BaseLink(ets, name, parent, joint_name, m, r, I, Jm, B, Tc, G,
+        # qlim, ...), robot/Link.py:1556-1580, :70-110)
         if ets is None:
             ets = ETS()
         elif isinstance(ets, ET):
@@ -136,10 +138,18 @@ class ERobot(RobotKinematics):
     into one link per joint ("a link frame after every joint", named link0, link1, ...; :116-131).  Kinematics: the
     RobotKinematics surface over ets(start, end); dynamics: rne."""
 
-    def __init__(self, links, name="", gravity=(0, 0, -9.81), base=None, tool=None, manufacturer="", comment="", keywords=(), **kw):
+    def __init__(self, links, gripper_links=None, name="", manufacturer="", comment="", base=None, tool=None, gravity=(0, 0, -9.81), keywords=(),
+                 symbolic=False, configs=None, check_jindex=True, urdf_string=None, urdf_filepath=None, **kw):
+        # (the reference's positional order, robot/BaseRobot.py:95-112 / robot/Robot.py:60-80)
         self.comment, self.keywords = comment, tuple(keywords)
         if kw:
             raise TypeError("unexpected keyword argument(s): %s" % ", ".join(sorted(kw)))
+        if gripper_links is not None:
+            raise TypeError("unexpected keyword argument(s): gripper_links")      # grippers are outside this backend (SURVEY section 8)
+        if symbolic:
+            raise TypeError("Symbolic value")                                      # symbolic robots stay on the reference's Python path
+        self.urdf_string, self.urdf_filepath = urdf_string, urdf_filepath
+        self.configs = dict(configs) if configs else {}
         if isinstance(links, ET):
             links = ETS(links)
         if isinstance(links, ETS):
@@ -369,7 +379,7 @@ class ERobot(RobotKinematics):
         check(lib().rtbhip_tree_upload(self._handle(), -1 if device is None else int(getattr(device, "index", device) or 0)))
         return self
 
-    def dynchanged(self):
+    def dynchanged(self, what=None):
         if self._tree is not None and _lib._lib is not None:
             _lib._lib.rtbhip_tree_destroy(self._tree)
         self._tree = None

@@ -88,11 +88,11 @@ def _pose_error(Te, Tep, method):
     return e[0] if (sa and sb) else e
 
 
-def angle_axis(Te, Tep):
-    """Pose error e = [Tep.t - Te.t ; angle-axis vector of Tep.R Te.R^T] (reference `rtb.angle_axis`, tools/p_servo.py:13-20
+def angle_axis(T, Td):
+    """Pose error e = [Td.t - T.t ; angle-axis vector of Td.R T.R^T] (reference `rtb.angle_axis(T, Td)`, tools/p_servo.py:13-20
     -> fknm.Angle_Axis core/fknm.cpp:112-162 -> _angle_axis core/ik.cpp:241-286): (6,) for one pair, (N,6) when either
     argument is a stack of N poses (a single pose on the other side is used for every pair)."""
-    return _pose_error(Te, Tep, 0)
+    return _pose_error(T, Td, 0)
 
 
 angle_axis_python = angle_axis      # the reference keeps a pure-Python twin for symbolic input (tools/p_servo.py:23-43); one kernel serves both names here
