@@ -192,13 +192,15 @@ class URDFRobot:
         best = max(self.leaves, key=lambda l: self.njoints(l))
         return best.name
 
-    def ets(self, end=None, start=None, compact=True):
-        """ETS from the root (or `start`) to `end`.  compact=True numbers the joints 0..n-1 along the
+    def ets(self, start=None, end=None, compact=True):
+        """ETS from the root (or `start`) to `end` -- `ets(start, end)`, the reference's order (BaseRobot.ets robot/BaseRobot.py:1555);
+        links as names or link objects.  compact=True numbers the joints 0..n-1 along the
         path (q is (N, n)); compact=False keeps the robot-wide jindex (q is (N, robot.n)).
         With no `end` the chain runs to the model's end effector AND carries the gripper's tool transform as its last element, as
         the reference's BaseRobot.ets does for a robot with one gripper (robot/BaseRobot.py:1610-1616, 1469-1473)."""
         with_tool = end is None and self.tool is not None
         end = self.ee if end is None else (end if isinstance(end, str) else end.name)
+        start = start if (start is None or isinstance(start, str)) else start.name
         key = (end, start, compact, with_tool)
         if key in self._cache:
             return self._cache[key]
@@ -233,47 +235,52 @@ class URDFRobot:
         return None if end is None else self.tool
 
     def qlim(self, end=None):
-        return self.ets(end).qlim
+        return self.ets(end=end).qlim
 
     # ------------------------------------------------------------ kinematics pass-throughs
-    def fkine(self, q, end=None, tool=None):
-        return self.ets(end).fkine(q, tool=self._tool_for(end, tool))
+    def fkine(self, q, end=None, start=None, tool=None):
+        return self.ets(start, end).fkine(q, tool=self._tool_for(end, tool))
 
-    def jacob0(self, q, end=None, tool=None):
-        return self.ets(end).jacob0(q, tool=self._tool_for(end, tool))
+    def jacob0(self, q, end=None, start=None, tool=None):
+        return self.ets(start, end).jacob0(q, tool=self._tool_for(end, tool))
 
-    def jacobe(self, q, end=None, tool=None):
-        return self.ets(end).jacobe(q, tool=self._tool_for(end, tool))
+    def jacobe(self, q, end=None, start=None, tool=None):
+        return self.ets(start, end).jacobe(q, tool=self._tool_for(end, tool))
 
-    def fkine_jacob0(self, q, end=None, tool=None):
-        return self.ets(end).fkine_jacob0(q, tool=self._tool_for(end, tool))
+    def fkine_jacob0(self, q, end=None, start=None, tool=None):
+        return self.ets(start, end).fkine_jacob0(q, tool=self._tool_for(end, tool))
 
-    def ik_LM(self, Tep, end=None, **kw):
-        return self.ets(end).ik_LM(Tep, **kw)
+    def ik_LM(self, Tep, end=None, start=None, **kw):
+        return self.ets(start, end).ik_LM(Tep, **kw)
 
     # the other solvers and differential-kinematics methods of RobotKinematicsMixin (robot/RobotKinematics.py): self.ets(end).<name>(...)
-    def ik_GN(self, Tep, end=None, **kw): return self.ets(end).ik_GN(Tep, **kw)
-    def ik_NR(self, Tep, end=None, **kw): return self.ets(end).ik_NR(Tep, **kw)
-    def ikine_LM(self, Tep, end=None, **kw): return self.ets(end).ikine_LM(Tep, **kw)
-    def ikine_NR(self, Tep, end=None, **kw): return self.ets(end).ikine_NR(Tep, **kw)
-    def ikine_GN(self, Tep, end=None, **kw): return self.ets(end).ikine_GN(Tep, **kw)
-    def ikine_QP(self, Tep, end=None, **kw): return self.ets(end).ikine_QP(Tep, **kw)
-    def hessian0(self, q=None, end=None, J0=None, tool=None): return self.ets(end).hessian0(q, J0=J0, tool=self._tool_for(end, tool))
-    def hessiane(self, q=None, end=None, Je=None, tool=None): return self.ets(end).hessiane(q, Je=Je, tool=self._tool_for(end, tool))
-    def manipulability(self, q=None, end=None, **kw):
-        e = self.ets(end)                                     # Robot.manipulability: self.ets(end, start), gripper tool included (robot/Robot.py:825)
+    def ik_GN(self, Tep, end=None, start=None, **kw): return self.ets(start, end).ik_GN(Tep, **kw)
+    def ik_NR(self, Tep, end=None, start=None, **kw): return self.ets(start, end).ik_NR(Tep, **kw)
+    def ikine_LM(self, Tep, end=None, start=None, **kw): return self.ets(start, end).ikine_LM(Tep, **kw)
+    def ikine_NR(self, Tep, end=None, start=None, **kw): return self.ets(start, end).ikine_NR(Tep, **kw)
+    def ikine_GN(self, Tep, end=None, start=None, **kw): return self.ets(start, end).ikine_GN(Tep, **kw)
+    def ikine_QP(self, Tep, end=None, start=None, **kw): return self.ets(start, end).ikine_QP(Tep, **kw)
+    def hessian0(self, q=None, end=None, start=None, J0=None, tool=None): return self.ets(start, end).hessian0(q, J0=J0, tool=self._tool_for(end, tool))
+    def hessiane(self, q=None, end=None, start=None, Je=None, tool=None): return self.ets(start, end).hessiane(q, Je=Je, tool=self._tool_for(end, tool))
+    def manipulability(self, q=None, J=None, end=None, start=None, **kw):
+        if J is not None:
+            raise NotImplementedError("manipulability(J=...) is not offered: pass q (the Jacobian never leaves the registers)")
+        e = self.ets(start, end)                                     # Robot.manipulability: self.ets(end, start), gripper tool included (robot/Robot.py:825)
         return e.manipulability(np.zeros(e.n) if q is None else q, **kw)      # q=None: the robot's stored configuration, zeros (BaseRobot.q)
 
     # Robot.jacobm resolves `end` to a LINK first (robot/Robot.py:1182, _get_limit_links robot/BaseRobot.py:1478-1540) and drops the gripper
     # tool it returns, so its Jacobian is that of the end LINK's frame -- unlike robot.manipulability(q) and robot.ets().jacobm(q), whose
     # chain carries the tool.  (Only the translational measure can tell the two apart.)  Reproduced.
 
-    def jacobm(self, q=None, end=None, **kw):
-        e = self.ets(self.ee if end is None else end)
+    def jacobm(self, q=None, J=None, H=None, end=None, start=None, **kw):
+        e = self.ets(start, self.ee if end is None else end)
+        if J is not None or H is not None:
+            raise NotImplementedError("jacobm(J=..., H=...) is not offered: pass q")
         return e.jacobm(np.zeros(e.n) if q is None else q, **kw)
-    def jacob0_dot(self, q, qd, end=None, **kw): return self.ets(end).jacob0_dot(q, qd, **kw)
-    def jacob0_analytical(self, q, end=None, **kw): return self.ets(end).jacob0_analytical(q, **kw)
-    def partial_fkine0(self, q, n=3, end=None): return self.ets(end).partial_fkine0(q, n)
+    def jacob0_dot(self, q, qd, J0=None, representation=None, end=None): return self.ets(end=end).jacob0_dot(q, qd, J0=J0, representation=representation)
+    def jacob0_analytical(self, q, representation="rpy/xyz", end=None, start=None, tool=None):
+        return self.ets(start, end).jacob0_analytical(q, representation=representation, tool=self._tool_for(end, tool))
+    def partial_fkine0(self, q, n=3, end=None, start=None): return self.ets(start, end).partial_fkine0(q, n)
 
     # ------------------------------------------------------------ dynamics
     def erobot(self, exclude=()):

@@ -77,16 +77,16 @@ def test_skew_axis_quirk_and_robotwide_jindex_and_errors():
         <axis xyz="1 0 0"/><limit lower="0" upper="0.5"/></joint>
       <joint name="j3" type="continuous"><parent link="a"/><child link="d"/><axis xyz="0 0.6 0.8"/></joint></robot>"""
     r = urdf.loadstr(xml)
-    e = r.ets("c")
+    e = r.ets(end="c")
     assert [x.axis for x in e.joints()] == ["Ry", "tx"] and e.joints()[0].isflip and not e.joints()[1].isflip
     nt.assert_allclose(e.qlim, [[-1, 0], [2, 0.5]])
     # skew axis: the reference folds angvec2r(|v|, v/|v|) into the constant and turns about z (urdf.py:1710-1722)
-    e3 = r.ets("d")
+    e3 = r.ets(end="d")
     assert e3.joints()[0].axis == "Rz"
     nt.assert_allclose(e3[0].T[:3, :3], urdf.angvec_matrix(1.0, np.array([0, 0.6, 0.8])), atol=1e-15)
     nt.assert_allclose(e3.qlim, [[-np.pi], [np.pi]])
     # robot-wide numbering keeps URDF joint order; compact numbering is per path
-    assert list(r.ets("d", compact=False).jindices) == [2] and list(r.ets("d").jindices) == [0]
+    assert list(r.ets(end="d", compact=False).jindices) == [2] and list(r.ets(end="d").jindices) == [0]
     with pytest.raises(ValueError):
         urdf.loadstr(xml.replace('name="d"/>', 'name="c"/>', 1))
     with pytest.raises(ValueError):
