@@ -27,15 +27,18 @@ class DHLink(LinkDynamics):
         self._set_dynamics(m=m, r=r, I=I, Jm=Jm, G=G, B=B, Tc=Tc)
 
     _DYN = ("m", "r", "I", "Jm", "G", "B", "Tc")
+    _KIN = ("d", "a", "alpha", "theta", "offset", "flip", "sigma", "mdh", "qlim")
 
     def __setattr__(self, name, value):
         """A changed dynamic parameter invalidates the owning robot's device link table, as the reference's setters re-arm `frne.init`
         through `_listen_dyn` (robot/Link.py:28-45 -> DHRobot.dynchanged robot/DHRobot.py:1328-1338)."""
         object.__setattr__(self, name, value)
-        if name in DHLink._DYN:
+        if name in DHLink._DYN or name in DHLink._KIN:
             robot = self.__dict__.get("_robot")
             if robot is not None:
-                robot.dynchanged()
+                robot.dynchanged()                     # the link record holds alpha, a, theta, d, sigma, offset too (robot/DHRobot.py:1342-1358)
+                if name in DHLink._KIN:
+                    robot._kinchanged()                # and the kept chains (with their device tables) are rebuilt from the new geometry
 
     @property
     def isrevolute(self): return self.sigma == 0
@@ -160,13 +163,41 @@ class DHRobot(RobotKinematics):
         if len({l.mdh for l in self.links}) != 1:
             raise ValueError("Robot has mixed D&H links conventions")  # reference robot/DHRobot.py:90-112
         self.name, self.manufacturer = name, manufacturer
-        self.base = _mat4(base)
-        self.tool = _mat4(tool)
+        self._ets = None
+        self.base = base
+        self.tool = tool
         self.gravity = np.array([0.0, 0.0, -9.81]) if gravity is None else np.asarray(gravity, dtype=np.float64).reshape(3)
         self._ets = None
         self._dyn = None
         self.q = np.zeros(len(self.links))                    # the stored configuration (BaseRobot.q): what islimit() etc. default to
         self._control_mode = "v"
+
+    # base and tool live inside ets() (robot/DHRobot.py:878-918 rebuilds that chain on every call; here it is built once and kept with its
+    # device table): assigning either one afterwards drops the kept chains, so the next call sees the new transform as the reference's does
+    def _kinchanged(self):
+        self._ets = None
+        self.__dict__.pop("_sub_ets", None)
+        self._paths_changed()
+
+    @property
+    def base(self): return self._base
+    @base.setter
+    def base(self, T):
+        self._base = _mat4(T)
+        self._kinchanged()
+
+    @property
+    def gravity(self): return self._gravity
+    @gravity.setter
+    def gravity(self, g):
+        self._gravity = np.asarray(g, dtype=np.float64).reshape(3).copy()          # robot/BaseRobot.py:903-906
+
+    @property
+    def tool(self): return self._tool_T
+    @tool.setter
+    def tool(self, T):
+        self._tool_T = _mat4(T)
+        self._kinchanged()
 
     @property
     def control_mode(self): return self._control_mode

@@ -216,6 +216,12 @@ class ERobot(RobotKinematics):
     def __len__(self): return len(self.links)
     def __getitem__(self, i): return self.links[i]
 
+    @property
+    def gravity(self): return self._gravity
+    @gravity.setter
+    def gravity(self, g):
+        self._gravity = np.asarray(g, dtype=np.float64).reshape(3).copy()          # robot/BaseRobot.py:903-906
+
     # ------------------------------------------------------------ kinematics over a path
     def _getlink(self, link, default):
         if link is None:

@@ -162,9 +162,29 @@ class URDFRobot:
             if j.actuated and j.variable() is not None:
                 self.jindex[j.name] = len(self.jindex)
         self.n = len(self.jindex)
-        self.tool = None if tool is None else np.asarray(tool, dtype=np.float64)
-        self._ee = ee
         self._cache = {}
+        self.tool = tool
+        self.base = None
+        self._ee = ee
+
+    # the gripper tool sits inside ets(None) (see ets); the base is applied by fkine alone, as in the reference (RobotKinematics.fkine hands it
+    # to ETS.fkine, the Jacobians are in the robot's base frame).  Assigning either drops the kept chains.
+    @property
+    def tool(self): return self._tool_T
+    @tool.setter
+    def tool(self, T):
+        if T is not None and hasattr(T, "A") and not isinstance(T, np.ndarray):
+            T = T.A
+        self._tool_T = None if T is None else np.asarray(T, dtype=np.float64).reshape(4, 4).copy()
+        self._cache.clear()
+
+    @property
+    def base(self): return self._base
+    @base.setter
+    def base(self, T):
+        if T is not None and hasattr(T, "A") and not isinstance(T, np.ndarray):
+            T = T.A
+        self._base = None if T is None else np.asarray(T, dtype=np.float64).reshape(4, 4).copy()
 
     # ------------------------------------------------------------ structure
     def path(self, end):
@@ -238,8 +258,8 @@ class URDFRobot:
         return self.ets(end=end).qlim
 
     # ------------------------------------------------------------ kinematics pass-throughs
-    def fkine(self, q, end=None, start=None, tool=None):
-        return self.ets(start, end).fkine(q, tool=self._tool_for(end, tool))
+    def fkine(self, q, end=None, start=None, tool=None, include_base=True):
+        return self.ets(start, end).fkine(q, base=self.base, tool=self._tool_for(end, tool), include_base=include_base)
 
     def jacob0(self, q, end=None, start=None, tool=None):
         return self.ets(start, end).jacob0(q, tool=self._tool_for(end, tool))

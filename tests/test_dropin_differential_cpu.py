@@ -255,9 +255,26 @@ def test_dh_robots_agree_kinematics_and_dynamics_in_every_call_form():
                 lower = np.tril(Mr) + np.tril(Mr, -1).T
                 nt.assert_allclose(m, np.linalg.solve(lower, qdd - ref.rne(q, qd, np.zeros(n))), rtol=1e-9 * cond, atol=1e-9 * cond)
                 lopsided += 1
+            # base / tool assigned AFTER the first calls are honoured (the reference rebuilds ets() per call; here the kept chain is dropped)
+            Bm = chains.elementary("tx", 0.4) @ chains.elementary("Rz", 0.7)
+            Tm = chains.elementary("tz", 0.1) @ chains.elementary("Rx", -0.3)
+            mine.base, ref.base = Bm, ref.base.__class__(Bm)
+            mine.tool, ref.tool = Tm, ref.tool.__class__(Tm)
+            nt.assert_allclose(A(mine.fkine(q)), A(ref.fkine(q)), atol=1e-12)
+            nt.assert_allclose(mine.jacob0(q), ref.jacob0(q), atol=1e-12)
+            nt.assert_allclose(mine.rne(q, qd, qdd), ref.rne(q, qd, qdd), rtol=1e-9, atol=1e-10)      # gravity seen from the new base
+            mine.base = ref.base = None
+            mine.tool = ref.tool = None
+            nt.assert_allclose(A(mine.fkine(q)), A(ref.fkine(q)), atol=1e-12)
             # a changed link parameter reaches the device table, as in the reference (Link setters -> dynchanged)
             mine.links[0].m = ref.links[0].m = 9.5
             mine.links[-1].Tc = ref.links[-1].Tc = [0.3, -0.2]
+            nt.assert_allclose(mine.rne(q, qd, qdd), ref.rne(q, qd, qdd), rtol=1e-9, atol=1e-10)
+            # ... and so does a changed KINEMATIC parameter (fkine and rne of the reference follow it; its jacob0 goes through the ets() built
+            # at construction and does not -- not compared), and a gravity vector assigned as a list
+            mine.links[-1].a = ref.links[-1].a = 0.77
+            mine.gravity = ref.gravity = [0.5, 0.0, -3.0]
+            nt.assert_allclose(A(mine.fkine(q)), A(ref.fkine(q)), atol=1e-12)
             nt.assert_allclose(mine.rne(q, qd, qdd), ref.rne(q, qd, qdd), rtol=1e-9, atol=1e-10)
         assert be.calls.get("rtbhip_rne", 0) > 100 and be.calls.get("rtbhip_coriolis", 0) > 20
     assert symmetric >= 20 and lopsided >= 1
