@@ -183,7 +183,7 @@ class DHRobot(RobotKinematics):
     def base(self): return self._base
     @base.setter
     def base(self, T):
-        self._base = _mat4(T)
+        self._base = _poses(_mat4(T))              # answers to .A / .t / .R like the SE3 the reference hands back
         self._kinchanged()
 
     @property
@@ -196,7 +196,7 @@ class DHRobot(RobotKinematics):
     def tool(self): return self._tool_T
     @tool.setter
     def tool(self, T):
-        self._tool_T = _mat4(T)
+        self._tool_T = _poses(_mat4(T))
         self._kinchanged()
 
     @property

@@ -25,7 +25,7 @@ import xml.etree.ElementTree as XT
 
 import numpy as np
 
-from .et import ET, ETS
+from .et import ET, ETS, _poses
 
 DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "urdf")
 
@@ -175,7 +175,7 @@ class URDFRobot:
     def tool(self, T):
         if T is not None and hasattr(T, "A") and not isinstance(T, np.ndarray):
             T = T.A
-        self._tool_T = None if T is None else np.asarray(T, dtype=np.float64).reshape(4, 4).copy()
+        self._tool_T = None if T is None else _poses(np.asarray(T, dtype=np.float64).reshape(4, 4).copy())
         self._cache.clear()
 
     @property
@@ -184,7 +184,7 @@ class URDFRobot:
     def base(self, T):
         if T is not None and hasattr(T, "A") and not isinstance(T, np.ndarray):
             T = T.A
-        self._base = None if T is None else np.asarray(T, dtype=np.float64).reshape(4, 4).copy()
+        self._base = None if T is None else _poses(np.asarray(T, dtype=np.float64).reshape(4, 4).copy())
 
     # ------------------------------------------------------------ structure
     def path(self, end):
