@@ -448,3 +448,44 @@ def test_differential_kinematics_consumers_agree():
                 mine.manipulability(q, method="nonsense")
             with pytest.raises(ValueError):
                 ref.manipulability(q, method="nonsense")
+
+
+def test_reference_classes_on_the_shim_modules_random_chains():
+    """The reference's OWN ET / ETS classes bound to `rtbhip.compat.fknm` (the plug-in module with the extension's function table, here over the
+    CPU replay) against the same classes on the reference's compiled extension: random chains, the calls of tests/test_reference_classes.py's GPU
+    half -- this is the drop-in boundary itself (SURVEY section 8 row b) with nothing of rtbhip's Python mirror in between."""
+    import rtbhip.compat
+    with cpu_backend.installed() as be:
+        before = sum(be.calls.values())
+        on_ext = ref_classes.load_reference()
+        on_shim = ref_classes.load(rtbhip.compat.fknm, "shim-cpu-replay")
+        rng = np.random.default_rng(77)
+        for k in range(30):
+            n = 1 + k % 8
+            spec = random_spec(rng, n)
+            a = build(on_ext.ET, on_ext.ETS, spec, SE3=on_ext.SE3)
+            b = build(on_shim.ET, on_shim.ETS, spec, SE3=on_shim.SE3)
+            assert type(b).__module__ == "roboticstoolbox.robot.ETS" and b is not a
+            q = rng.uniform(-2.5, 2.5, n)
+            tool = chains.elementary("ty", 0.1) @ chains.elementary("Rz", 0.4)
+            for qq in (q, list(q), q.reshape(1, n)):
+                nt.assert_allclose(b.eval(qq), a.eval(qq), atol=1e-12)
+                nt.assert_allclose(b.eval(qq, tool=tool), a.eval(qq, tool=tool), atol=1e-12)
+                nt.assert_allclose(b.jacob0(qq), a.jacob0(qq), atol=1e-12)
+                nt.assert_allclose(b.jacobe(qq, tool=tool), a.jacobe(qq, tool=tool), atol=1e-12)
+                nt.assert_allclose(b.hessian0(qq), a.hessian0(qq), atol=1e-12)
+                nt.assert_allclose(b.hessiane(qq), a.hessiane(qq), atol=1e-12)
+            assert b.eval(q).flags["F_CONTIGUOUS"] == a.eval(q).flags["F_CONTIGUOUS"]            # (4,4) comes back in Fortran order (fknm.cpp:993)
+            assert b.jacob0(q).flags["F_CONTIGUOUS"] == a.jacob0(q).flags["F_CONTIGUOUS"]
+            if n > 1:
+                Q = rng.uniform(-2.5, 2.5, (6, n))
+                nt.assert_allclose(b.eval(Q), a.eval(Q), atol=1e-12)
+            if n >= 6:
+                sv = np.linalg.svd(a.jacob0(q), compute_uv=False)
+                if sv[5] > 1e-3 * sv[0]:
+                    q0 = q + 0.03
+                    ra = a.ik_LM(a.eval(q), q0=q0, slimit=1, joint_limits=False)
+                    rb = b.ik_LM(b.eval(q), q0=q0, slimit=1, joint_limits=False)
+                    assert (ra[1], ra[2], ra[3]) == (rb[1], rb[2], rb[3])
+                    nt.assert_allclose(rb[0], ra[0], atol=1e-6)
+        assert sum(be.calls.values()) - before > 500
