@@ -489,3 +489,33 @@ def test_reference_classes_on_the_shim_modules_random_chains():
                     assert (ra[1], ra[2], ra[3]) == (rb[1], rb[2], rb[3])
                     nt.assert_allclose(rb[0], ra[0], atol=1e-6)
         assert sum(be.calls.values()) - before > 500
+
+
+@pytest.mark.skipif(not ref_classes.dh_available(), reason="needs the reference's byte-compiled DH classes")
+def test_reference_dh_classes_on_the_shim_modules_random_robots():
+    """The reference's OWN DHRobot / DHLink / Dynamics classes bound to `rtbhip.compat.fknm` + `rtbhip.compat.frne` (CPU replay) against the same
+    classes on the reference's compiled extensions: random robots (revolute / prismatic, both conventions, full inertial and friction parameters)."""
+    import rtbhip.compat
+    from test_reference_dh_classes import ref_dh
+    with cpu_backend.installed() as be:
+        on_ext = ref_dh()
+        on_shim = ref_classes.load_dh(rtbhip.compat.fknm, rtbhip.compat.frne, "shim-dh-cpu-replay")
+        rng = np.random.default_rng(91)
+        for k in range(20):
+            n, mdh = 2 + k % 7, bool(k % 2)
+            links = random_dh(rng, n, mdh)
+            a, b = build_dh(on_ext, links, mdh), build_dh(on_shim, links, mdh)
+            q, qd, qdd = rng.uniform(-1.5, 1.5, (3, n))
+            Q, QD, QDD = rng.uniform(-1.5, 1.5, (3, 4, n))
+            nt.assert_allclose(A(b.fkine(q)), A(a.fkine(q)), atol=1e-12)
+            nt.assert_allclose(b.jacob0(q), a.jacob0(q), atol=1e-12)
+            for args, kw in (((q, qd, qdd), {}), ((Q, QD, QDD), {}), ((q, qd, qdd), {"gravity": [0, 0, 0]}), ((q, qd, qdd), {"fext": [1, 2, 3, 0.1, 0.2, 0.3]})):
+                nt.assert_allclose(b.rne(*args, **kw), a.rne(*args, **kw), rtol=1e-9, atol=1e-10)
+            scale = 1.0 + np.abs(a.inertia(q)).max()
+            nt.assert_allclose(b.inertia(q), a.inertia(q), rtol=1e-8, atol=1e-9 * scale)
+            nt.assert_allclose(b.coriolis(q, qd), a.coriolis(q, qd), rtol=1e-8, atol=1e-9 * scale)
+            nt.assert_allclose(b.gravload(q), a.gravload(q), rtol=1e-9, atol=1e-10)
+            nt.assert_allclose(b.itorque(q, qdd), a.itorque(q, qdd), rtol=1e-8, atol=1e-9 * scale)
+            M = a.inertia(q)
+            nt.assert_allclose(b.accel(q, qd, qdd), a.accel(q, qd, qdd), rtol=1e-9 * np.linalg.cond(M), atol=1e-9 * np.linalg.cond(M))
+        assert be.calls.get("rtbhip_rne", 0) > 500                    # the reference's Dynamics mixin calls rne n or n^2 times per term
