@@ -346,8 +346,8 @@ class URDFRobot:
             self._cache[key] = self.erobot(exclude)
         return self._cache[key]
 
-    def rne(self, q, qd=None, qdd=None, gravity=None, exclude=()):
-        return self._tree(exclude).rne(q, qd, qdd, gravity=gravity)
+    def rne(self, q, qd=None, qdd=None, symbolic=False, gravity=None, exclude=()):
+        return self._tree(exclude).rne(q, qd, qdd, symbolic=symbolic, gravity=gravity)           # (Robot.rne's order, robot/Robot.py:1704)
 
     # the Dynamics-mixin terms (reference robot/Dynamics.py over Robot.rne): see ERobot
     def inertia(self, q, exclude=()):
@@ -356,8 +356,9 @@ class URDFRobot:
     def coriolis(self, q, qd, exclude=()):
         return self._tree(exclude).coriolis(q, qd)
 
-    def gravload(self, q, gravity=None, exclude=()):
-        return self._tree(exclude).gravload(q, gravity=gravity)
+    def gravload(self, q=None, gravity=None, exclude=()):
+        t = self._tree(exclude)
+        return t.gravload(np.zeros(t.n) if q is None else q, gravity=gravity)      # q=None: the stored configuration, zeros (BaseRobot.q)
 
     def itorque(self, q, qdd, exclude=()):
         return self._tree(exclude).itorque(q, qdd)
