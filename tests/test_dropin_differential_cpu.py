@@ -519,3 +519,31 @@ def test_reference_dh_classes_on_the_shim_modules_random_robots():
             M = a.inertia(q)
             nt.assert_allclose(b.accel(q, qd, qdd), a.accel(q, qd, qdd), rtol=1e-9 * np.linalg.cond(M), atol=1e-9 * np.linalg.cond(M))
         assert be.calls.get("rtbhip_rne", 0) > 500                    # the reference's Dynamics mixin calls rne n or n^2 times per term
+
+
+def test_solver_classes_agree_with_masks_limits_and_failures():
+    """IK_LM / IK_GN / IK_NR objects (robot/IK.py:IKSolver.solve) from a supplied start: weights (`mask`), joint-limit checking, a tight tolerance,
+    an iteration limit too small to converge -- success, iterations, searches, q and the `reason` string, on random chains."""
+    import rtbhip
+    ns = ref_classes.load_reference()
+    done = 0
+    with cpu_backend.installed():
+        for n, spec, ref, mine, rng in both(23, 40, limits=True):
+            if n < 6:
+                continue
+            qs = rng.uniform(-1.0, 1.0, n)
+            Tep, q0 = ref.eval(qs), qs + rng.uniform(-0.05, 0.05, n)
+            sv = np.linalg.svd(ref.jacob0(qs), compute_uv=False)
+            if sv[5] < 1e-3 * sv[0]:
+                continue
+            for cls, kw in (("IK_LM", dict(method="chan", k=1.0)), ("IK_LM", dict(method="sugihara", k=0.001, mask=[1, 1, 1, 0.5, 0.5, 0.5])),
+                            ("IK_LM", dict(method="wampler", k=0.01, mask=[1, 1, 1, 0, 0, 0])), ("IK_GN", dict(pinv=True)),
+                            ("IK_NR", dict(pinv=True, mask=[1, 1, 1, 1, 1, 0])), ("IK_LM", dict(joint_limits=True)),
+                            ("IK_LM", dict(tol=1e-10, ilimit=50)), ("IK_LM", dict(ilimit=2))):
+                r = getattr(ns.IK, cls)(slimit=1, **kw).solve(ref, Tep, q0)
+                m = getattr(rtbhip, cls)(slimit=1, **kw).solve(mine, Tep, q0)
+                assert (bool(m.success), int(m.iterations), int(m.searches), m.reason) == (bool(r.success), int(r.iterations), int(r.searches), r.reason), (cls, kw, r, m)
+                if r.success:
+                    nt.assert_allclose(m.q, r.q, atol=1e-6)
+                done += 1
+    assert done >= 60
