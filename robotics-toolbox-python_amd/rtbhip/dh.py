@@ -455,6 +455,14 @@ class DHRobot(RobotKinematics):
             _lib._lib.rtbhip_dyn_destroy(self._dyn)
         self._dyn = None
 
+    def __getstate__(self):
+        """copy.copy / copy.deepcopy / pickle: the device link table and the kept chains belong to THIS robot; a copy builds its own."""
+        state = dict(self.__dict__)
+        state["_dyn"], state["_ets"] = None, None
+        state.pop("_sub_ets", None)
+        state.pop("_path_cache", None)
+        return state
+
     def __del__(self):
         try:
             self.delete_rne()

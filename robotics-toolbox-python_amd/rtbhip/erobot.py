@@ -390,6 +390,14 @@ class ERobot(RobotKinematics):
             _lib._lib.rtbhip_tree_destroy(self._tree)
         self._tree = None
 
+    def __getstate__(self):
+        """copy.copy / copy.deepcopy / pickle: the device link-group table and the kept path chains belong to THIS robot; a copy builds its own."""
+        state = dict(self.__dict__)
+        state["_tree"] = None
+        state.pop("_ets_made", None)
+        state.pop("_path_cache", None)
+        return state
+
     def __del__(self):
         try:
             self.dynchanged()

@@ -470,6 +470,12 @@ class ETS:
                 out.append(str(e))
         return " \u2295 ".join(out)
 
+    def __getstate__(self):
+        """copy.copy / copy.deepcopy / pickle: the device chain handle belongs to THIS object (its __del__ destroys it); a copy makes its own."""
+        state = dict(self.__dict__)
+        state["_handle_"] = None
+        return state
+
     def __del__(self):
         h = getattr(self, "_handle_", None)
         if h is not None and _lib._lib is not None:

@@ -547,3 +547,51 @@ def test_solver_classes_agree_with_masks_limits_and_failures():
                     nt.assert_allclose(m.q, r.q, atol=1e-6)
                 done += 1
     assert done >= 60
+
+
+def test_copies_do_not_share_device_tables():
+    """copy.deepcopy / copy.copy of an ETS, a DHRobot, an ERobot: the copy builds its own device table -- the original keeps working after
+    the copy is collected (a shared handle was destroyed with the copy: found at the end of round 3), and an edit of the copy does not
+    reach the original."""
+    import copy
+    import gc
+    import rtbhip
+    with cpu_backend.installed():
+        p = rtbhip.models.DH.Puma560()
+        q = np.array([0.1, 0.7, 2.8, 0.2, 0.6, 0.3])
+        z = np.zeros(6)
+        t0, T0 = p.rne(q, z, z).copy(), np.asarray(p.fkine(q)).copy()
+        for make in (copy.deepcopy, copy.copy):
+            p2 = make(p)
+            nt.assert_array_equal(p2.rne(q, z, z), t0)
+            nt.assert_array_equal(np.asarray(p2.fkine(q)), T0)
+            del p2
+            gc.collect()
+            nt.assert_array_equal(p.rne(q, z, z), t0)
+            nt.assert_array_equal(np.asarray(p.fkine(q)), T0)
+        p3 = copy.deepcopy(p)
+        p3.links[1].m = 40.0
+        p3.base = chains.elementary("tx", 1.0)
+        assert np.abs(p3.rne(q, z, z) - t0).max() > 1.0 and abs(np.asarray(p3.fkine(q))[0, 3] - T0[0, 3] - 1.0) < 1e-12
+        nt.assert_array_equal(p.rne(q, z, z), t0)
+        nt.assert_array_equal(np.asarray(p.fkine(q)), T0)
+        e = rtbhip.models.Panda().ets()
+        q7 = np.linspace(-0.5, 0.5, 7)
+        E0 = e.eval(q7).copy()
+        for make in (copy.deepcopy, copy.copy):
+            e2 = make(e)
+            nt.assert_array_equal(e2.eval(q7), E0)
+            del e2
+            gc.collect()
+            nt.assert_array_equal(e.eval(q7), E0)
+        er = rtbhip.ERobot(e)
+        for l in er.links:
+            l.m = 1.0
+        g0 = er.gravload(q7).copy()
+        er2 = copy.deepcopy(er)
+        nt.assert_array_equal(er2.gravload(q7), g0)
+        er2.links[3].m = 9.0
+        assert np.abs(er2.gravload(q7) - g0).max() > 0.1
+        del er2
+        gc.collect()
+        nt.assert_array_equal(er.gravload(q7), g0)
