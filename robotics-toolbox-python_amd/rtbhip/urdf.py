@@ -254,21 +254,31 @@ class URDFRobot:
             return tool
         return None if end is None else self.tool
 
+    def _chain(self, q, start, end):
+        """The chain a pass-through evaluates: joints numbered along the path (q has the path's columns) -- or, when q carries one column per
+        joint of the WHOLE robot (`np.zeros(robot.n)`, as callers of the reference write: its chains address q by the robot-wide jindex),
+        the same path with the robot-wide numbers."""
+        e = self.ets(start, end)
+        width = None if q is None else (q.shape[-1] if hasattr(q, "shape") and len(q.shape) else len(q))
+        if width is not None and width == self.n and width != e.q_width:
+            return self.ets(start, end, compact=False)
+        return e
+
     def qlim(self, end=None):
         return self.ets(end=end).qlim
 
     # ------------------------------------------------------------ kinematics pass-throughs
     def fkine(self, q, end=None, start=None, tool=None, include_base=True):
-        return self.ets(start, end).fkine(q, base=self.base, tool=self._tool_for(end, tool), include_base=include_base)
+        return self._chain(q, start, end).fkine(q, base=self.base, tool=self._tool_for(end, tool), include_base=include_base)
 
     def jacob0(self, q, end=None, start=None, tool=None):
-        return self.ets(start, end).jacob0(q, tool=self._tool_for(end, tool))
+        return self._chain(q, start, end).jacob0(q, tool=self._tool_for(end, tool))
 
     def jacobe(self, q, end=None, start=None, tool=None):
-        return self.ets(start, end).jacobe(q, tool=self._tool_for(end, tool))
+        return self._chain(q, start, end).jacobe(q, tool=self._tool_for(end, tool))
 
     def fkine_jacob0(self, q, end=None, start=None, tool=None):
-        return self.ets(start, end).fkine_jacob0(q, tool=self._tool_for(end, tool))
+        return self._chain(q, start, end).fkine_jacob0(q, tool=self._tool_for(end, tool))
 
     def ik_LM(self, Tep, end=None, start=None, **kw):
         return self.ets(start, end).ik_LM(Tep, **kw)
@@ -280,8 +290,8 @@ class URDFRobot:
     def ikine_NR(self, Tep, end=None, start=None, **kw): return self.ets(start, end).ikine_NR(Tep, **kw)
     def ikine_GN(self, Tep, end=None, start=None, **kw): return self.ets(start, end).ikine_GN(Tep, **kw)
     def ikine_QP(self, Tep, end=None, start=None, **kw): return self.ets(start, end).ikine_QP(Tep, **kw)
-    def hessian0(self, q=None, end=None, start=None, J0=None, tool=None): return self.ets(start, end).hessian0(q, J0=J0, tool=self._tool_for(end, tool))
-    def hessiane(self, q=None, end=None, start=None, Je=None, tool=None): return self.ets(start, end).hessiane(q, Je=Je, tool=self._tool_for(end, tool))
+    def hessian0(self, q=None, end=None, start=None, J0=None, tool=None): return self._chain(q, start, end).hessian0(q, J0=J0, tool=self._tool_for(end, tool))
+    def hessiane(self, q=None, end=None, start=None, Je=None, tool=None): return self._chain(q, start, end).hessiane(q, Je=Je, tool=self._tool_for(end, tool))
     def manipulability(self, q=None, J=None, end=None, start=None, **kw):
         if J is not None:
             raise NotImplementedError("manipulability(J=...) is not offered: pass q (the Jacobian never leaves the registers)")
