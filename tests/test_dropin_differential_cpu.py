@@ -595,3 +595,22 @@ def test_copies_do_not_share_device_tables():
         del er2
         gc.collect()
         nt.assert_array_equal(er.gravload(q7), g0)
+
+
+def test_robots_and_chains_survive_pickling():
+    """One process per GPU: a robot handed to a worker through pickle (multiprocessing, torch.distributed object collectives) arrives without the
+    sender's native handles and builds its own tables on first use -- same numbers, and the sender's object is untouched."""
+    import pickle
+    import rtbhip
+    from rtbhip import urdf
+    with cpu_backend.installed():
+        q7 = np.linspace(-0.5, 0.5, 7)
+        poe = rtbhip.PoERobot([rtbhip.PoERevolute([0, 0, 1], [0, 0, 0]), rtbhip.PoEPrismatic([0, 1, 0])], np.eye(4))
+        for obj, call in ((rtbhip.models.Panda().ets(), lambda o: o.eval(q7)), (rtbhip.models.DH.Puma560(), lambda o: o.rne(q7[:6], q7[:6], q7[:6])),
+                          (rtbhip.models.Panda(), lambda o: np.asarray(o.fkine(q7))), (urdf.load("Panda"), lambda o: np.asarray(o.fkine(q7))),
+                          (rtbhip.ERobot(rtbhip.models.Panda().ets()), lambda o: o.jacob0(q7)), (poe, lambda o: np.asarray(o.fkine(q7[:2])))):
+            before = call(obj).copy()
+            twin = pickle.loads(pickle.dumps(obj))
+            nt.assert_array_equal(call(twin), before)
+            del twin
+            nt.assert_array_equal(call(obj), before)
