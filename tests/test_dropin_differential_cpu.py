@@ -614,3 +614,44 @@ def test_robots_and_chains_survive_pickling():
             nt.assert_array_equal(call(twin), before)
             del twin
             nt.assert_array_equal(call(obj), before)
+
+
+@pytest.mark.skipif(not ref_classes.dh_available(), reason="needs the reference's byte-compiled DH classes")
+def test_dh_robots_agree_on_the_rest_of_the_surface():
+    """What test_dh_robots_agree_kinematics_and_dynamics_in_every_call_form leaves out: jacob0 / jacobe(half=), jacob0(T=), hessian0 (from q and from a
+    supplied Jacobian), jacob0_dot, manipulability per axes, jacobm, islimit, isspherical, friction / nofriction, todegrees / toradians, A(j, q) and
+    A([j0, j1], q), payload, and the vector accessors -- value for value, and the same exception type for a bad `half`."""
+    def same(r, m, tol=1e-9):
+        r, m = np.asarray(A(r), dtype=float), np.asarray(A(m), dtype=float)
+        assert np.shape(r) == np.shape(m)
+        nt.assert_allclose(m, r, atol=tol, rtol=1e-7)
+    with cpu_backend.installed():
+        for n, mdh, ref, mine, rng in dh_both(55, 21):
+            q, qd = rng.uniform(-1.5, 1.5, (2, n))
+            for half in (None, "trans", "rot"):
+                same(ref.jacob0(q, half=half), mine.jacob0(q, half=half))
+                same(ref.jacobe(q, half=half), mine.jacobe(q, half=half))
+            for robot in (ref, mine):
+                with pytest.raises(ValueError):
+                    robot.jacob0(q, half="x")
+            T = ref.fkine(q)
+            same(ref.jacob0(q, T=T), mine.jacob0(q, T=A(T)))
+            same(ref.hessian0(q), mine.hessian0(q))
+            same(ref.hessian0(J0=ref.jacob0(q)), mine.hessian0(J0=mine.jacob0(q)))
+            same(ref.jacob0_dot(q, qd), mine.jacob0_dot(q, qd), 1e-8)
+            for axes in ("all", "trans", "rot"):
+                same(ref.manipulability(q, axes=axes), mine.manipulability(q, axes=axes), 1e-7)
+            if n >= 6:
+                same(ref.jacobm(q), mine.jacobm(q), 1e-6)
+            same(ref.islimit(q), mine.islimit(q))
+            assert bool(ref.isspherical()) == bool(mine.isspherical())
+            same(ref.friction(qd), mine.friction(qd))
+            same(ref.todegrees(q), mine.todegrees(q))
+            same(ref.toradians(q), mine.toradians(q))
+            same(ref.A(n - 1, q), mine.A(n - 1, q))
+            same(ref.A([1, n - 1], q), mine.A([1, n - 1], q))
+            same(ref.nofriction().rne(q, qd, qd), mine.nofriction().rne(q, qd, qd))
+            ref.payload(2.0, [0.1, 0, 0.2]); mine.payload(2.0, [0.1, 0, 0.2])
+            same(ref.gravload(q), mine.gravload(q))
+            for attr in ("d", "a", "alpha", "theta", "offset", "r", "revolutejoints", "prismaticjoints", "mdh", "n"):
+                same(getattr(ref, attr), getattr(mine, attr))
