@@ -333,8 +333,12 @@ class ETS:
     __add__ = __mul__
 
     def inv(self):
-        """Inverse ETS: the inverses of the elements in reverse order (reference robot/ETS.py:545-580)."""
-        return ETS([e.inv() for e in reversed(self._ets)])
+        """Inverse ETS: the inverses of the elements in reverse order (reference robot/ETS.py:545-580).  Every joint KEEPS its joint number --
+        `ets.inv().eval(q)` is the inverse of `ets.eval(q)` for the same q -- so joints numbered automatically (in order of appearance) carry that
+        number explicitly in the inverse, where they appear in the opposite order."""
+        idx = iter(self._assigned_jindices())
+        numbered = [ET(e.axis, flip=e.isflip, jindex=next(idx), qlim=e.qlim) if e.isjoint else e for e in self._ets]
+        return ETS([e.inv() for e in reversed(numbered)])
 
     def split(self):
         """Link segments: every piece but possibly the last ends with a joint (reference robot/ETS.py:511-543)."""
