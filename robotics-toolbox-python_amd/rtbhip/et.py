@@ -502,6 +502,8 @@ class ETS:
         js = self.joints()
         if all(e.jindex is None for e in js):
             return list(range(len(js)))
+        if js[-1].jindex is None and all(e.jindex == k for k, e in enumerate(js[:-1])):
+            return list(range(len(js)))                       # numbered 0 .. n-2 in order, the last one open: it is n-1 (robot/ETS.py:820-828)
         if any(e.jindex is None for e in js):
             raise ValueError("either all or none of the joints must have a jindex")
         return [int(e.jindex) for e in js]

@@ -663,3 +663,24 @@ def test_dh_robots_agree_on_the_rest_of_the_surface():
             same(ref.gravload(q), mine.gravload(q))
             for attr in ("d", "a", "alpha", "theta", "offset", "r", "revolutejoints", "prismaticjoints", "mdh", "n"):
                 same(getattr(ref, attr), getattr(mine, attr))
+
+
+def test_joint_numbering_rules_agree():
+    """Automatic numbering, explicit numbering, "numbered in order with the last one open" (robot/ETS.py:820-828: it becomes n-1), and the
+    refusal of any other mixture -- the same on both sides, strings and values."""
+    import rtbhip
+    ns = ref_classes.load_reference()
+    out = {}
+    with cpu_backend.installed():
+        for name, lib in (("ref", ns), ("mine", rtbhip)):
+            E = lib.ET
+            a = E.Rz(jindex=0) * E.tx(0.3) * E.Ry(jindex=1) * E.tz(0.2) * E.Rx()
+            b = E.Rz(jindex=2) * E.tx(0.3) * E.Ry(jindex=0) * E.tz(0.2) * E.Rx(jindex=1)
+            with pytest.raises(ValueError):
+                (E.Rz(jindex=1) * E.Rz()).eval([0.1, 0.2])
+            out[name] = (str(a), list(map(int, a.jindices)), a.eval([0.1, 0.2, 0.3]), str(b), list(map(int, b.jindices)), b.eval([0.1, 0.2, 0.3]))
+    for r, m in zip(out["ref"], out["mine"]):
+        if isinstance(r, np.ndarray):
+            nt.assert_allclose(m, r, atol=1e-12)
+        else:
+            assert m == r
