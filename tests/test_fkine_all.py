@@ -54,8 +54,8 @@ def test_emu_frames_every_mark_of_the_mixed_chain():
 
 
 @pytest.mark.gpu
-def test_gpu_fkine_all():
-    import torch
+def test_gpu_fkine_all_dh_robots():
+    """Host buffers only (the CPU replay of the suite runs this too)."""
     panda = rtbhip.models.DH.Panda()
     q1 = np.arange(1, 8, dtype=float)
     F = panda.fkine_all(q1)                                                           # reference tests/test_DHRobot.py:638-710
@@ -73,21 +73,6 @@ def test_gpu_fkine_all():
         nt.assert_allclose(F[:200], oracle.link_frames(ch, q[:200], _dh_marks(robot)), atol=1e-10)
         last = F[:, -1] if robot.tool is None else F[:, -1] @ robot.tool
         nt.assert_allclose(last, robot.fkine(q), atol=1e-12)
-        Ft = robot.fkine_all(torch.from_numpy(q).cuda())
-        nt.assert_array_equal(Ft.cpu().numpy(), F)
-    # branched URDF robot: every link frame equals fkine of the path to that link
-    for name in ("YuMi", "UR5", "Fetch"):
-        u = urdf.load(name)
-        er = u.erobot()
-        q = rng.uniform(-1, 1, (50, er.n))
-        F = er.fkine_all(q)
-        assert F.shape == (50, len(er.links) + 1, 4, 4)
-        nt.assert_allclose(F[:, 0], np.broadcast_to(np.eye(4), (50, 4, 4)), atol=0)
-        for k, l in enumerate(er.links):
-            e = er.ets(end=l)
-            want = e.eval(q[:, :e.q_width]) if e.n else np.broadcast_to(e.eval(np.zeros(0)), (50, 4, 4))
-            nt.assert_allclose(F[:, k + 1], want, atol=1e-12)
-        nt.assert_array_equal(u.fkine_all(q), F)
     # marks: errors and the empty cases
     e = panda.ets()
     with pytest.raises(rtbhip.RtbHipError):
@@ -95,3 +80,41 @@ def test_gpu_fkine_all():
     with pytest.raises(rtbhip.RtbHipError):
         e.link_frames(q1, [len(e) + 1])
     assert e.link_frames(np.zeros((0, 7)), [0, 1]).shape == (0, 2, 4, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["YuMi", "UR5", "Fetch", "Panda"])
+def test_gpu_fkine_all_urdf_trees_index_by_link_number(name):
+    """Branched URDF robots: slot 0 is the base, slot `link.number` is that link's frame -- the reference's contract
+    (robot/Robot.py:679 writes Tall[link.number]); `er.links` is in sorted order, `number` is the place in the list the robot was built from, so
+    the two differ for every branched robot.  Each frame equals fkine of the path to that link.  Host buffers only."""
+    rng = np.random.default_rng(5)
+    u = urdf.load(name)
+    er = u.erobot()
+    q = rng.uniform(-1, 1, (50, er.n))
+    F = er.fkine_all(q)
+    assert F.shape == (50, len(er.links) + 1, 4, 4)
+    nt.assert_allclose(F[:, 0], np.broadcast_to(np.eye(4), (50, 4, 4)), atol=0)
+    assert sorted(l.number for l in er.links) == list(range(1, len(er.links) + 1))
+    for l in er.links:
+        e = er.ets(end=l)
+        want = e.eval(q[:, :e.q_width]) if e.n else np.broadcast_to(e.eval(np.zeros(0)), (50, 4, 4))
+        nt.assert_allclose(F[:, l.number], want, atol=1e-12)
+    nt.assert_array_equal(u.fkine_all(q), F)
+    one = er.fkine_all(q[3])
+    nt.assert_array_equal(one, F[3])
+
+
+@pytest.mark.gpu
+def test_gpu_fkine_all_device_tensors():
+    """The same calls on device tensors give the host-buffer results bit for bit (needs a device)."""
+    import torch
+    rng = np.random.default_rng(6)
+    for robot in (rtbhip.models.DH.Panda(), rtbhip.models.DH.Puma560()):
+        q = rng.uniform(-3, 3, (1000, robot.n))
+        Ft = robot.fkine_all(torch.from_numpy(q).cuda())
+        nt.assert_array_equal(Ft.cpu().numpy(), robot.fkine_all(q))
+    er = urdf.load("YuMi").erobot()
+    q = rng.uniform(-1, 1, (50, er.n))
+    Ft = er.fkine_all(torch.from_numpy(q).cuda())
+    nt.assert_array_equal(Ft.cpu().numpy(), er.fkine_all(q))
