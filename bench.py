@@ -35,7 +35,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "robotics-toolbox-python_amd")]
 
-from benchlib import protect_stdout, HBM_PEAK_GBS, Ranks, spawn_ranks_if_needed, bench_argv, per_launch_min_ms, ensure_library, pmc_traffic  # noqa: E402
+from benchlib import protect_stdout, HBM_PEAK_GBS, Ranks, spawn_ranks_if_needed, bench_argv, per_launch_min_ms, ensure_library, pmc_traffic, rocprof_committed  # noqa: E402
 
 BYTES_PER_CONFIG = 56 + 128 + 336  # q read + T written + J0 written
 
@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--n", type=int, default=1000000, help="configurations per GPU per step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline and host_path legs")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` object (BASELINE configs[2], [3], [4] with their in-run parity)")
     ap.add_argument("--tune", action="append", default=[], help="key=value for rtbhip_tune (A/B runs)")
     ap.add_argument("--gather", action="store_true", help="build the process group and time the output gather even with one rank "
                                                           "(a world-size-1 RCCL group: rehearses the collective on a single-GPU box)")
@@ -199,12 +200,20 @@ def main():
                  "ms": pms, "GBs": moved / (pms * 1e-3) / 1e9}
         del dst
     # the one exchange of the path, outside the timed region: T|J rows of every rank to every rank
-    gather_ms = rk.gather_ms(torch.cat([T.reshape(N, 16), J.reshape(N, 42)], dim=1)) if rk.dist is not None else None
+    gather_ms, gather_mem = None, None
+    if rk.dist is not None:
+        rows = torch.cat([T.reshape(N, 16), J.reshape(N, 42)], dim=1)
+        torch.cuda.synchronize()
+        before = torch.cuda.memory_allocated()
+        gather_ms = rk.gather_ms(rows)                    # allocates its world x N x 58 receive buffer inside, releases it on return
+        gather_mem = dict(rk.last_gather, device_bytes_before=before, device_bytes_after=torch.cuda.memory_allocated(),
+                          where="after the timed region of `value`, released before cpu_baseline / secondary")
+        del rows
 
     if rank == 0:
         achieved = BYTES_PER_CONFIG * N / (kern_avg_ms * 1e-3) / 1e9
         traffic, traffic_source = None, None
-        for name in ("r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):       # the latest committed PMC passes of this command
+        for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):       # the latest committed PMC passes of this command
             traffic, traffic_source = pmc_traffic(ROOT, name)
             if traffic is not None:
                 break
@@ -227,23 +236,40 @@ def main():
                        "backend": rk.backend if rk.dist is not None else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "k_kin_reg<7,true,true>", "kernel_avg_ms": kern_avg_ms, "kernel_min_ms": kern_min_ms,
-                         "kernel_avg_source": "one HIP-event pair on the launch stream around the K timed launches / K",
+                         "kernel": "k_kin_reg<7,true,true>", "kernel_avg_ms": kern_avg_ms, "per_launch_event_min_ms": kern_min_ms,
+                         "kernel_avg_source": "one HIP-event pair on the launch stream around the K timed launches / K "
+                                              "(per_launch_event_min_ms: smallest of per-launch event pairs, each of which adds a few microseconds "
+                                              "-- it can exceed the loop average)",
                          "algorithmic_bytes_per_launch": BYTES_PER_CONFIG * N},
         }
+        committed = rocprof_committed(ROOT)
+        if committed is not None:
+            # the rocprofv3 --kernel-trace --stats figure of the SAME command committed under profiles/ (another lease, possibly another box:
+            # boxes of this pool differ by 10-15 % on this kernel) next to what this run measured with events
+            line["roofline"]["frac_rocprof_committed"] = BYTES_PER_CONFIG * N / (committed["avg_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBS
+            line["roofline"]["rocprof_committed"] = committed
         if probe is not None:
+            # context, not a ceiling: a plain streaming kernel with the same read / write mix on THIS box (the fused kernel has beaten it)
             line["roofline"]["stream_probe"] = probe
-            line["roofline"]["frac_of_stream_probe"] = achieved / probe["GBs"]
         if rk.shared:
             line["config"]["devices_shared"] = True   # gloo test hook: more ranks than GPUs, NOT a scaling measurement
         if gather_ms is not None:
             line["gather_ms"] = gather_ms
+            line["gather_buffer"] = gather_mem
             line["gather"] = "all_gather_into_tensor of (N,58) f64 rows per rank, %s" % (
                 ("RCCL, a world-size-1 group on one GPU (--gather: rehearsal of the collective, no xGMI traffic)" if world == 1 else "RCCL over xGMI")
                 if rk.backend == "nccl" else "gloo through host memory (test hook)")
         if not args.no_cpu and world == 1:  # reported on rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(q_host, T, J)
             line["host_path"] = host_path(ets, q_host, T, J)
+        if not args.no_secondary and world == 1 and not rk.forced:
+            # BASELINE configs[2], [3], [4] -- IK over 1e5 targets, RNE over 1e7 triples (and the 1.25e6 share), the 16-arm fleet -- each with
+            # its HIP-event kernel time, an in-run parity figure against the reference's compiled code on a sample, and its roofline;
+            # after the timed region, never inside `value` (benchsecondary.py)
+            del T, J, q
+            torch.cuda.empty_cache()
+            import benchsecondary
+            line["secondary"] = benchsecondary.secondary(rtbhip)
         print(json.dumps(line), flush=True)
     rk.finish()
 

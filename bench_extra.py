@@ -151,9 +151,7 @@ def main():
             tr, src = pmc_traffic(ROOT, "r03_pmc_rne.json")
             line["roofline"]["traffic"], line["roofline"]["traffic_source"] = tr, src
         if world > 1:
-            pad = torch.zeros((sb.max_count, 7), dtype=torch.float64, device=q.device)
-            pad[:N] = hold["tau"]
-            line["gather_ms"] = rk.gather_ms(pad)
+            line["gather_ms"] = rk.gather_ms(hold["tau"], rows=N)      # uneven shards are padded inside
             line["gather"] = "all_gather_into_tensor of the (rows,7) tau shards, %d bytes in total" % (56 * Ntot)
             if rk.shared:
                 line["devices_shared"] = True

@@ -110,7 +110,8 @@ class Ranks:
         import torch
         if self.dist is not None:
             self.dist.barrier()
-        torch.cuda.synchronize()
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize()
 
     def max_over_ranks(self, x):
         import torch
@@ -163,21 +164,37 @@ class Ranks:
             sys.stderr.write("bench trace: host us per step " + " ".join("%.0f" % (x * 1e6) for x in trace) + " | loop %.0f us\n" % (elapsed * 1e6))
         return self.max_over_ranks(elapsed), dev_ms / steps
 
-    def gather_ms(self, local_out):
-        """The ONE exchange of the path: all_gather_into_tensor of equal-size output shards (RCCL over xGMI; through
-        host memory under the gloo hook).  Milliseconds of the second call (the first builds the communicator),
-        MAX over ranks; None for a single rank."""
+    def gather_ms(self, local_out, rows=None, keep=False):
+        """The ONE exchange of the path: all_gather_into_tensor of the ranks' output shards (RCCL over xGMI; through host memory under the gloo
+        hook).  Shards of different lengths (N not a multiple of the world size: rtbhip_shard_range gives the first ranks one row more) are
+        padded to the longest one -- `rows` = this rank's valid rows, default all of local_out.  Milliseconds of the second call (the first
+        builds the communicator), MAX over ranks; None for a single rank without a group.
+        The receive buffer (world x longest shard) exists only inside this call: it is allocated here, AFTER the timed region of `value`, and
+        released on return (before the cpu_baseline leg starts); `last_gather` records its size and, with keep=True, the gathered rows."""
         import torch
         if self.dist is None:
             return None
-        send = local_out.contiguous() if self.backend == "nccl" else local_out.cpu().contiguous()
-        buf = torch.empty((self.world * send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        n = int(local_out.shape[0] if rows is None else rows)
+        longest = int(self.max_over_ranks(n))
+        send = local_out[:n]
+        send = send.contiguous() if self.backend == "nccl" else send.cpu().contiguous()
+        if n < longest:
+            pad = torch.zeros((longest,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+            pad[:n] = send
+            send = pad
+        buf = torch.empty((self.world * longest,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
         self.dist.all_gather_into_tensor(buf, send)
         self.barrier()
         g0 = time.perf_counter()
         self.dist.all_gather_into_tensor(buf, send)
         self.barrier()
-        return self.max_over_ranks((time.perf_counter() - g0) * 1e3)
+        ms = self.max_over_ranks((time.perf_counter() - g0) * 1e3)
+        self.last_gather = {"buffer_bytes": buf.numel() * buf.element_size(), "rows_per_rank_padded": longest, "world": self.world}
+        if keep:
+            counts = [torch.zeros(1, dtype=torch.int64, device=send.device) for _ in range(self.world)]
+            self.dist.all_gather(counts, torch.tensor([n], dtype=torch.int64, device=send.device))
+            self.last_gather["rows"] = torch.cat([buf[r * longest:r * longest + int(c.item())] for r, c in enumerate(counts)]).cpu()
+        return ms
 
     def finish(self):
         if self.dist is not None:
@@ -227,3 +244,20 @@ def pmc_traffic(root, name):
             name, ", " + j["visit"] if "visit" in j else "")
     except Exception:
         return None, None
+
+
+def rocprof_committed(root, kernel_substr="k_kin_reg<7, true, true"):
+    """Average duration (ns) of the headline kernel in the newest committed `rocprofv3 --kernel-trace --stats` summary of bench.py
+    (profiles/rNN_*_kernel_stats.csv, not the *_extra_* ones): {"file", "avg_ns", "calls"} or None."""
+    import csv
+    import glob
+    files = sorted(f for f in glob.glob(os.path.join(root, "profiles", "r[0-9][0-9]_*_kernel_stats.csv")) if "extra" not in os.path.basename(f) and "_rne_" not in os.path.basename(f))
+    for f in reversed(files):
+        try:
+            for row in csv.DictReader(open(f)):
+                name = row.get("Name") or row.get("KernelName") or ""
+                if kernel_substr.replace(" ", "") in name.replace(" ", ""):
+                    return {"file": "profiles/" + os.path.basename(f), "avg_ns": float(row["AverageNs"]), "calls": int(row["Calls"])}
+        except Exception:
+            continue
+    return None

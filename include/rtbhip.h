@@ -130,6 +130,16 @@ int rtbhip_hessian(rtbhip_chain_t chain, const double *q, int64_t N, const doubl
  * 16-byte aligned. */
 int rtbhip_hessian_from_jacobian(const double *J, int64_t N, int32_t n, double *H, int32_t mem, void *stream);
 
+/* Robot.manipulability(J=...) (robot/Robot.py:701-905: `if J is not None: w = [mfunc(self, J, q, axes_list)]` :896) and
+ * Robot.jacobm(J=..., H=...) (robot/Robot.py:1101-1235: `verifymatrix(J, (6, n))` :1201, `H = self.hessian0(J0=J)` :1206), batched:
+ * pure functions of the supplied arrays, so no chain handle.  J is (N,6,n), n = 1..16; m is (N); Jm is (N,n); H is (N,n,6,n) or NULL
+ * (then the Hessian of J is formed on the fly, core/methods.cpp:16-32).  axes_mask and method as rtbhip_manipulability.  Device buffers
+ * must be 16-byte aligned. */
+int rtbhip_manipulability_from_jacobian(const double *J, int64_t N, int32_t n, int32_t axes_mask, int32_t method, double *m, int32_t mem,
+                                        void *stream);
+int rtbhip_jacobm_from_jacobian(const double *J, const double *H, int64_t N, int32_t n, int32_t axes_mask, double *Jm, int32_t mem,
+                                void *stream);
+
 /* fknm.Angle_Axis (fknm.cpp:112-162 -> _angle_axis ik.cpp:241-286; used by tools/p_servo.py:7-43 and IK.py:398),
  * batched: e (N,6) = [Tep.t - Te.t ; angle-axis vector of Tep.R Te.R^T], N = max(nTe, nTep); Te is (nTe,4,4) and Tep
  * (nTep,4,4) row-major, each count either N or 1 (that pose is then used for every pair).  Device buffers must be

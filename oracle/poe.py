@@ -11,7 +11,7 @@ not vendored, not installable here).  What is restated below is its published al
 Twist3.UnitRevolute / UnitPrismatic, Twist3.exp (-> base.trexp on a 6-vector), SE3.Ad, SE3.inv, SE3.OA (-> base.oa2r),
 SE3.rpy (-> base.tr2rpy, order "zyx") and base.skew.
 
-PARITY PIN (how this file is checked, tests/test_poe.py): the reference's own test, tests/test_PoERobot.py:14-74, states that
+PARITY PIN (how this file is checked, tests/test_04_poe.py): the reference's own test, tests/test_PoERobot.py:14-74, states that
 for its two robots (a 2R-P-R arm and a 3R-P arm with arbitrary axes) the closed form and the lowered ETS agree on fkine,
 jacob0 and jacobe.  Here the closed form below is compared with the lowered ETS evaluated by the reference's COMPILED fknm
 (oracle/_ref) -- two formulations, one of them the reference's own binary -- at the test's own q.  That pins the twist

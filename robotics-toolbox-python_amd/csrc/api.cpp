@@ -565,6 +565,45 @@ int rtbhip_hessian_from_jacobian(const double *J, int64_t N, int32_t n, double *
     return RTBHIP_OK;
 }
 
+/* Robot.manipulability(J=...) / Robot.jacobm(J=..., H=...) (robot/Robot.py:701-905, :1101-1235): pure functions of the supplied arrays */
+static int diff_from_jac_entry(const char *fn, int mode, const double *J, const double *H, int64_t N, int32_t n, int32_t axes, double *out,
+                               int32_t mem, void *stream)
+{
+    if (n < 1 || n > 16) { set_error(std::string(fn) + ": n must be 1..16"); return RTBHIP_ELIMIT; }
+    if ((axes & 63) == 0) { set_error(std::string(fn) + ": empty axes mask"); return RTBHIP_EINVAL; }
+    if (N > 0 && !out) { set_error(std::string(fn) + ": NULL output"); return RTBHIP_EINVAL; }
+    DeviceScope dscope;
+    RTB_TRY(check_batch(fn, J, N, mem, &dscope));
+    if (N == 0) return RTBHIP_OK;
+    if (mem == RTBHIP_MEM_DEVICE) {
+        if (((uintptr_t)J | (uintptr_t)H) & 15) { set_error(std::string(fn) + ": device buffers must be 16-byte aligned"); return RTBHIP_EINVAL; }
+        return launch_diff_from_jac(mode, n, J, H, N, axes, out, (hipStream_t)stream);
+    }
+    Staging st;
+    void *dJ, *dH = nullptr, *dout;
+    const size_t jb = (size_t)N * 48 * n, ob = (size_t)N * 8 * (mode == 0 ? 1 : n);
+    RTB_TRY(st.in(J, jb, &dJ));
+    if (H) RTB_TRY(st.in(H, jb * n, &dH));
+    RTB_TRY(st.out(ob, &dout));
+    RTB_TRY(launch_diff_from_jac(mode, n, (const double *)dJ, (const double *)dH, N, axes, (double *)dout, nullptr));
+    RTB_HIP(hipDeviceSynchronize());
+    RTB_TRY(fetch(out, dout, ob));
+    return RTBHIP_OK;
+}
+
+int rtbhip_manipulability_from_jacobian(const double *J, int64_t N, int32_t n, int32_t axes_mask, int32_t method, double *m, int32_t mem, void *stream)
+{
+    RTB_TRACE("rtbhip_manipulability_from_jacobian");
+    if (method < 0 || method > 2) { set_error("manipulability_from_jacobian: method must be 0 yoshikawa, 1 minsingular, 2 invcondition"); return RTBHIP_EINVAL; }
+    return diff_from_jac_entry("manipulability_from_jacobian", 0, J, nullptr, N, n, (axes_mask & 63) | (method << 8), m, mem, stream);
+}
+
+int rtbhip_jacobm_from_jacobian(const double *J, const double *H, int64_t N, int32_t n, int32_t axes_mask, double *Jm, int32_t mem, void *stream)
+{
+    RTB_TRACE("rtbhip_jacobm_from_jacobian");
+    return diff_from_jac_entry("jacobm_from_jacobian", H ? 2 : 1, J, H, N, n, axes_mask & 63, Jm, mem, stream);
+}
+
 /* fknm.Angle_Axis (core/fknm.cpp:112-162 -> _angle_axis core/ik.cpp:241-286), batched with broadcasting */
 static int pose_error_entry(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, int method, double *e, int32_t mem, void *stream);
 
@@ -834,6 +873,7 @@ static int ik_entry(rtbhip_chain_t chain, const double *Tep, int64_t N, const do
         for (int j = 0; j < c->n && j < 16; ++j)
             if (ps == p.pi[j]) { set_error("ik_lm: ps must differ from pi"); return RTBHIP_EINVAL; }
     for (int i = 0; i < 6; i++) p.we[i] = we6 ? we6[i] : 1.0;
+    RTB_TRY(ik_check_limits(c, p, N));                 // what the device build refuses, before the device is touched
     DevChain ops;
     const double *qlim = nullptr;
     RTB_TRY(chain_device_ops(c, &ops, &qlim));

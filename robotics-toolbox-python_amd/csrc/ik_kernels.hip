@@ -531,18 +531,37 @@ static void launch_nj(dim3 grid, hipStream_t s, const IkDev &p, const DevChain &
 // where the flat schedule / the counters exist as instantiations: plain LM-family steps (STEP 0), chains of up to 8 joints / the 7-joint arm
 static bool ik_aux_served(const IkDev &p, int n, bool stats) { return ik_step_variant(p, n) == 0 && (stats ? n == 7 : n <= kRegMaxJoints); }
 
-#define RTB_TRY_IK(expr) do { int _rc = (expr); if (_rc != RTBHIP_OK) return _rc; } while (0)
-int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const double *Tep, int64_t N, const double *q0,
-              const IkParams &ip, double *q_out, int32_t *success, int32_t *iters, int32_t *searches, double *residual,
-              hipStream_t s)
+// What this build serves: limits of the device scheduler and of the step variants that are instantiated.  Arguments only -- api.cpp asks
+// BEFORE it touches the device (a refusal must not depend on a GPU being there), launch_ik asks again for callers that come straight to it.
+int ik_check_limits(const Chain *c, const IkParams &ip, int64_t N)
 {
-    if (N == 0) return RTBHIP_OK;
     if (ip.slimit > kIkMaxSlimit) { set_error("ik_lm: slimit above 32000 is not supported by the device scheduler"); return RTBHIP_ELIMIT; }
     if (N >= (1ll << 32)) { set_error("ik_lm: at most 2^32 - 1 targets per call"); return RTBHIP_ELIMIT; }
     if (ip.ilimit > kIkMaxIlimit) { set_error("ik_lm: ilimit above 16000 is not supported by the device scheduler"); return RTBHIP_ELIMIT; }
     if (c->n > kIkMaxJoints) { set_error("ik_lm: this build solves chains of up to 16 joints on the device"); return RTBHIP_ELIMIT; }
     for (int j = 0; j < c->n; ++j)
         if (jm_jq(c->jmeta[j]) != j) { set_error("ik_lm: jindex must equal the joint order (the reference's ik.cpp:57 adds dq in that order)"); return RTBHIP_EINVAL; }
+    if (ip.method == 5 && (ip.km > 0.0 || ip.kq > 0.0) && (c->n > kIkNullMax || c->n < 6)) {
+        // IK_QP (ik_device.h): the manipulability term needs J J^T invertible, and both live in the one-wave-per-SIMD step variants
+        set_error("ik_qp: the manipulability term (km > 0) and the joint-limit rows (kq > 0) are built for chains of 6..12 joints");
+        return RTBHIP_ELIMIT;
+    }
+    if (ip.method != 5 && ip.kq > 0.0 && (c->n > kIkNullMax || c->n < 6)) {
+        // below 6 joints I - pinv(J) J vanishes only away from singularities; the reference still applies it there, so the
+        // parameters are refused rather than silently dropped
+        set_error("ik_lm: null-space terms (kq > 0) are built for chains of 6..12 joints");
+        return RTBHIP_ELIMIT;
+    }
+    return RTBHIP_OK;
+}
+
+#define RTB_TRY_IK(expr) do { int _rc = (expr); if (_rc != RTBHIP_OK) return _rc; } while (0)
+int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const double *Tep, int64_t N, const double *q0,
+              const IkParams &ip, double *q_out, int32_t *success, int32_t *iters, int32_t *searches, double *residual,
+              hipStream_t s)
+{
+    if (N == 0) return RTBHIP_OK;
+    RTB_TRY_IK(ik_check_limits(c, ip, N));
     IkDev p;
     p.ilimit = ip.ilimit; p.slimit = ip.slimit; p.reject_jl = ip.reject_jl; p.method = ip.method;
     p.flavour = ip.flavour; p.has_q0 = q0 != nullptr; p.tol = ip.tol; p.lambda = ip.lambda;
@@ -554,17 +573,6 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
     p.kq = ip.kq; p.km = ip.km; p.ps = ip.ps; p.ks = ip.ks;
     for (int j = 0; j < 16; ++j) p.pi[j] = ip.pi[j];
     p.flat_chunks = 0; p.flat_l0 = 0; p.flat_len = 0; p.flat_n = 0; p.flat_done = nullptr; p.stats = nullptr;
-    if (p.method == 5 && (p.km > 0.0 || p.kq > 0.0) && (c->n > kIkNullMax || c->n < 6)) {
-        // IK_QP (ik_device.h): the manipulability term needs J J^T invertible, and both live in the one-wave-per-SIMD step variants
-        set_error("ik_qp: the manipulability term (km > 0) and the joint-limit rows (kq > 0) are built for chains of 6..12 joints");
-        return RTBHIP_ELIMIT;
-    }
-    if (p.method != 5 && p.kq > 0.0 && (c->n > kIkNullMax || c->n < 6)) {
-        // below 6 joints I - pinv(J) J vanishes only away from singularities; the reference still applies it there, so the
-        // parameters are refused rather than silently dropped
-        set_error("ik_lm: null-space terms (kq > 0) are built for chains of 6..12 joints");
-        return RTBHIP_ELIMIT;
-    }
     int dev = 0, cus = 0;
     RTB_HIP(hipGetDevice(&dev));
     if (device_cu_count(&cus) != RTBHIP_OK) return RTBHIP_EHIP;

@@ -151,6 +151,8 @@ int launch_kin_diff(const Chain *c, const DevChain &dc, int mode, int axes, cons
                     const Affine &tool, int frame, double *out, hipStream_t s);
 
 int launch_hess_from_jac(int n, const double *J, int64_t N, double *H, hipStream_t s);
+// manipulability (mode 0; axes bits 8..9 = method) / manipulability Jacobian (mode 1: H formed from J, 2: H supplied) of supplied Jacobians (diffjac_kernels.hip)
+int launch_diff_from_jac(int mode, int n, const double *J, const double *H, int64_t N, int axes, double *out, hipStream_t s);
 int launch_angle_axis(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, int64_t N, double *e, hipStream_t s, int method = 0);
 
 struct FrameTable;
@@ -187,6 +189,7 @@ struct IkParams {
     double ks = 1.0;                                 // IK_QP (method 5): slack gain (kj travels in lambda)
     int64_t target0 = 0;                             // restart-generator key offset of row 0 (rtbhip_ik_target_base)
 };
+int ik_check_limits(const Chain *c, const IkParams &ip, int64_t N);      // argument-only refusals of the device build (ik_kernels.hip)
 int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const double *Tep, int64_t N,
               const double *q0, const IkParams &p, double *q_out, int32_t *success, int32_t *iters,
               int32_t *searches, double *residual, hipStream_t s);

@@ -14,7 +14,7 @@ All arithmetic runs in hand-written HIP kernels (../csrc) behind the C ABI of in
 CPU fallback: every call raises RtbHipError when librtbhip.so or a GPU is missing.
 """
 from ._lib import RtbHipError, lib, device_count, tune, shard_range, last_launch, ik_target_base, trim  # noqa: F401
-from .et import ET, ETS, IKSolution, angle_axis, angle_axis_python, p_servo, hessian_from_jacobian  # noqa: F401
+from .et import ET, ETS, IKSolution, angle_axis, angle_axis_python, p_servo, hessian_from_jacobian, manipulability_from_jacobian, jacobm_from_jacobian  # noqa: F401
 from .ik import IKSolver, IK_NR, IK_GN, IK_LM, IK_QP  # noqa: F401
 from .dh import DHLink, DHRobot, RevoluteDH, PrismaticDH, RevoluteMDH, PrismaticMDH  # noqa: F401
 SerialLink = DHRobot          # the reference keeps the old name as an alias (robot/DHRobot.py:2505-2520)
@@ -26,6 +26,6 @@ from . import urdf  # noqa: F401
 from .fleet import fleet_fkine_jacob  # noqa: F401
 from .shard import ShardedBatch  # noqa: F401
 
-__all__ = ["ET", "ETS", "IKSolution", "IKSolver", "IK_NR", "IK_GN", "IK_LM", "IK_QP", "angle_axis", "angle_axis_python", "p_servo", "hessian_from_jacobian", "DHLink", "DHRobot", "RevoluteDH", "PrismaticDH", "RevoluteMDH",
+__all__ = ["ET", "ETS", "IKSolution", "IKSolver", "IK_NR", "IK_GN", "IK_LM", "IK_QP", "angle_axis", "angle_axis_python", "p_servo", "hessian_from_jacobian", "manipulability_from_jacobian", "jacobm_from_jacobian", "DHLink", "DHRobot", "RevoluteDH", "PrismaticDH", "RevoluteMDH",
            "PrismaticMDH", "Link", "ERobot", "PoELink", "PoERevolute", "PoEPrismatic", "PoERobot", "RobotKinematics", "models", "urdf", "fleet_fkine_jacob", "ShardedBatch", "RtbHipError", "lib",
            "device_count", "tune", "shard_range", "last_launch", "ik_target_base", "trim"]

@@ -55,6 +55,11 @@ class Link(LinkDynamics):
             robot = self.__dict__.get("robot")
             if robot is not None and hasattr(robot, "dynchanged"):
                 robot.dynchanged()
+        elif name in ("_ets", "_qlim", "jindex", "parent"):
+            # geometry: the chains the owning robot keeps per (start, end), their device tables and its tree table were made from the old value
+            robot = self.__dict__.get("robot")
+            if robot is not None and hasattr(robot, "_kinchanged"):
+                robot._kinchanged()
 
     @property
     def ets(self): return self._ets
@@ -212,6 +217,30 @@ class ERobot(RobotKinematics):
             raise ValueError("joint index was repeated or out of range")
         self.gravity = np.asarray(gravity, dtype=np.float64).reshape(3)
         self._tree = None
+
+    @classmethod
+    def URDF(cls, file_path, gripper=None):
+        """Robot.URDF(file_path, gripper=None) (robot/Robot.py:288-330): the robot a URDF file describes, one Link per URDF link in file
+        order.  `gripper` (an index into that list, or a link name): that link and everything beyond it are the gripper and leave the
+        rigid-body tree (BaseRobot.py:288-314), so `n` counts the joints before it.  Plain URDF files, and the paths the reference resolves
+        inside its data package (rtbhip.urdf.read)."""
+        from . import urdf
+        u = urdf.read(file_path)
+        exclude = ()
+        if gripper is not None:
+            if isinstance(gripper, bool) or not isinstance(gripper, (int, str)):
+                raise TypeError("bad argument passed as gripper")
+            if isinstance(gripper, int):
+                exclude = (u.links[gripper].name,)
+            elif gripper in u.linkdict:
+                exclude = (gripper,)
+            else:
+                raise ValueError("no link named %s" % gripper)
+        robot = u.erobot(exclude)
+        if cls is not ERobot and cls is not type(robot):
+            robot.__class__ = cls
+        robot.urdf_string, robot.urdf_filepath = u.urdf_string, file_path
+        return robot
 
     def __len__(self): return len(self.links)
     def __getitem__(self, i): return self.links[i]
@@ -389,6 +418,15 @@ class ERobot(RobotKinematics):
         if self._tree is not None and _lib._lib is not None:
             _lib._lib.rtbhip_tree_destroy(self._tree)
         self._tree = None
+
+    def _kinchanged(self):
+        """A link's geometry (ets, qlim, jindex, parent) was reassigned: drop the chains kept per path, their device tables and the tree table
+        (DHRobot does the same for its links; the reference rebuilds `ets()` on every call)."""
+        self.__dict__.pop("_ets_made", None)
+        if hasattr(self, "_paths_changed"):
+            self._paths_changed()
+        if "_tree" in self.__dict__:
+            self.dynchanged()
 
     def __getstate__(self):
         """copy.copy / copy.deepcopy / pickle: the device link-group table and the kept path chains belong to THIS robot; a copy builds its own."""

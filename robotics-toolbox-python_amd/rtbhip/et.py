@@ -39,6 +39,64 @@ def _elementary(axis, eta):
     return T
 
 
+def _jacobian_batch(J, n, what="J"):
+    """(J3, single, torch_mode) of a finished Jacobian (6,n) or a batch (N,6,n): contiguous float64, host array or CUDA tensor."""
+    tm = is_torch(J) and J.is_cuda
+    if tm:
+        single = J.dim() == 2
+        J3 = (J.reshape((1,) + tuple(J.shape)) if single else J).contiguous()
+        _lib.note_device(J3)
+    else:
+        a = as_numeric(J.detach().numpy() if is_torch(J) else J, what)
+        single = a.ndim == 2
+        J3 = np.ascontiguousarray(a.reshape((1,) + a.shape) if single else a)
+    if len(J3.shape) != 3 or J3.shape[1] != 6 or (n is not None and J3.shape[2] != n):
+        raise ValueError("%s must be (6,n) or (N,6,n)" % what)
+    return J3, single, tm
+
+
+_MANIP_METHODS = {"yoshikawa": 0, "minsingular": 1, "invcondition": 2}
+
+
+def manipulability_from_jacobian(J, method="yoshikawa", axes="all", n=None):
+    """Robot.manipulability(J=...) (robot/Robot.py:701-905: `if J is not None: w = [mfunc(self, J, q, axes_list)]` :896) of a finished
+    Jacobian J (6,n) -> scalar, or of a batch (N,6,n) -> (N,): "yoshikawa" sqrt|det(J_a J_a^T)| (|det J_a| when square), "minsingular",
+    "invcondition"; `axes` "all" / "trans" / "rot" or six booleans.  A pure function of J: no chain, no q (rtbhip_manipulability_from_jacobian)."""
+    if method not in _MANIP_METHODS:
+        raise ValueError("Invalid method chosen")
+    mask = ETS._axes_mask(axes)
+    J3, single, tm = _jacobian_batch(J, n)
+    N, _, nj = J3.shape
+    m = ETS._out((N,), J3, tm)
+    check(lib().rtbhip_manipulability_from_jacobian(ETS._ptr(J3, tm), N, nj, mask, _MANIP_METHODS[method], ETS._ptr(m, tm),
+                                                    MEM_DEVICE if tm else MEM_HOST, ETS._stream(tm)))
+    return float(m[0]) if single else m
+
+
+def jacobm_from_jacobian(J, H=None, axes="all", n=None):
+    """Robot.jacobm(J=..., H=...) (robot/Robot.py:1101-1235): the manipulability Jacobian of a finished Jacobian J (6,n) -> (n,1), or of a
+    batch (N,6,n) -> (N,n).  H (n,6,n) / (N,n,6,n) is the caller's Hessian; None forms hessian0(J0=J) on the fly (:1206).  The measure is
+    Yoshikawa's on the rows `axes` selects (rtbhip_jacobm_from_jacobian)."""
+    mask = ETS._axes_mask(axes)
+    J3, single, tm = _jacobian_batch(J, n)
+    N, _, nj = J3.shape
+    H4 = None
+    if H is not None:
+        if (is_torch(H) and H.is_cuda) != tm:
+            raise ValueError("J and H must both be host arrays or both be CUDA tensors")
+        if tm:
+            H4 = (H.reshape((1,) + tuple(H.shape)) if H.dim() == 3 else H).contiguous()
+        else:
+            h = as_numeric(H.detach().numpy() if is_torch(H) else H, "H")
+            H4 = np.ascontiguousarray(h.reshape((1,) + h.shape) if h.ndim == 3 else h)
+        if tuple(H4.shape) != (N, nj, 6, nj):
+            raise ValueError("Hessian must be of shape (n,6,n), one per Jacobian")          # (the reference's message names 6xnxn, Robot.py:1211)
+    Jm = ETS._out((N, nj), J3, tm)
+    check(lib().rtbhip_jacobm_from_jacobian(ETS._ptr(J3, tm), None if H4 is None else ETS._ptr(H4, tm), N, nj, mask, ETS._ptr(Jm, tm),
+                                            MEM_DEVICE if tm else MEM_HOST, ETS._stream(tm)))
+    return Jm[0].reshape(nj, 1) if single else Jm
+
+
 def hessian_from_jacobian(J, n=None):
     """H (n,6,n) [or (N,n,6,n)] from a finished Jacobian J (6,n) [or (N,6,n)]: _ETS_hessian (core/methods.cpp:16-32), the
     part of ETS_hessian0 / ETS_hessiane (core/fknm.cpp:583-783) that runs when the caller supplies J.  NumPy in -> NumPy
@@ -230,11 +288,9 @@ class ET:
             arg = "q" if self.jindex is None else "q%d" % self.jindex
         elif self.axis == "SE3":
             T = self.T
-            # roll-pitch-yaw, zyx order (spatialmath tr2rpy default), in degrees
-            if abs(abs(T[2, 0]) - 1.0) < 1e-12:
-                r, pch, y = 0.0, -math.asin(max(-1.0, min(1.0, T[2, 0]))), math.atan2(-T[0, 1], T[1, 1]) if T[2, 0] < 0 else -math.atan2(-T[0, 1], T[1, 1])
-            else:
-                r, pch, y = math.atan2(T[2, 1], T[2, 2]), -math.asin(T[2, 0]), math.atan2(T[1, 0], T[0, 0])
+            # roll-pitch-yaw, zyx order (spatialmath tr2rpy default), in degrees -- the singular case (pitch = +-90 degrees) as there
+            from .poe import _rpy_zyx
+            r, pch, y = _rpy_zyx(T[:3, :3])
             rpy = np.array([r, pch, y]) * 180.0 / math.pi
             t = T[:3, 3]
             ts = "%.4g, %.4g, %.4g" % tuple(t)
@@ -862,6 +918,8 @@ class ETS:
                 # IKSolver.solve (robot/IK.py:226-240): for ONE pose a (k, n) q0 holds the start vectors of the first k searches; the
                 # searches after them start from random vectors.  One search at a time from the supplied rows, then the rest in one call.
                 slimit = int(slimit)
+                if slimit < 1 or int(ilimit) < 1:
+                    raise _lib.RtbHipError("librtbhip error -1: ik_lm: ilimit and slimit must be >= 1")      # what the entry point says
                 iters, used = 0, 0
                 out = None
                 for row in rows[:slimit]:

@@ -47,7 +47,11 @@ class RobotKinematics:
         return self.base
 
     def _kin_tool(self):
-        return self.tool
+        """The tool a pass-through appends when the caller names none: NONE.  The reference's RobotKinematics hands `ets(start, end)` only
+        the caller's `tool` (RobotKinematics.py:94, 158) and never reads `robot.tool` -- and the IK entry points solve the same bare chain,
+        so that fkine(ik_LM(Tep).q) == Tep whatever `robot.tool` holds.  (A DHRobot's tool lives inside its ets(), a URDF robot's gripper
+        tool inside ets(None): robot/BaseRobot.py:1610-1616.)"""
+        return None
 
     # ------------------------------------------------------------ forward / differential kinematics
     def fkine(self, q, end=None, start=None, tool=None, include_base=True):
@@ -73,16 +77,21 @@ class RobotKinematics:
         return self._path(start, end).jacob0_analytical(q, representation=representation, tool=self._tool(tool))
 
     def manipulability(self, q=None, J=None, end=None, start=None, method="yoshikawa", axes="all"):
-        """robot/Robot.py:701-850.  The J= form (a finished Jacobian instead of q) is a host-side NumPy expression in the reference
-        and is not offered on the device path."""
+        """robot/Robot.py:701-905.  With J= (a finished Jacobian, (6,n) or a batch (N,6,n)) the measure is a pure function of it (:896) and
+        runs on the device from the caller's array (rtbhip_manipulability_from_jacobian); with q the Jacobian never leaves the registers."""
         if J is not None:
-            raise NotImplementedError("manipulability(J=...) is not offered: pass q (the Jacobian never leaves the registers)")
+            from .et import manipulability_from_jacobian
+            return manipulability_from_jacobian(J, method=method, axes=axes)
         return self._path(start, end).manipulability(q, method=method, axes=axes, tool=self._kin_tool())
 
     def jacobm(self, q=None, J=None, H=None, end=None, start=None, axes="all"):
-        """robot/Robot.py:1101-1235."""
+        """robot/Robot.py:1101-1235.  J= / H= (finished Jacobian, optionally the Hessian to go with it) are served from the caller's arrays
+        (rtbhip_jacobm_from_jacobian; H alone needs q for the Jacobian, as in the reference :1194-1199)."""
         if J is not None or H is not None:
-            raise NotImplementedError("jacobm(J=..., H=...) is not offered: pass q")
+            from .et import jacobm_from_jacobian
+            if J is None:
+                J = self._path(start, end).jacob0(q, tool=self._kin_tool())
+            return jacobm_from_jacobian(J, H=H, axes=axes)
         return self._path(start, end).jacobm(q, axes=axes, tool=self._kin_tool())
 
     def jacob0_dot(self, q, qd, J0=None, representation=None):

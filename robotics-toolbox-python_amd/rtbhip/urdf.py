@@ -141,6 +141,7 @@ class URDFRobot:
         if root.tag != "robot":
             raise ValueError("not a URDF: root element is <%s>" % root.tag)
         self.name = name or root.get("name", "")
+        self.urdf_string = urdf_string
         self.links = [URDFLink(e) for e in root.findall("link")]
         self.joints = [URDFJoint(e) for e in root.findall("joint")]
         self.linkdict = {l.name: l for l in self.links}
@@ -249,10 +250,10 @@ class URDFRobot:
         return e
 
     def _tool_for(self, end, tool):
-        """the tool a pass-through hands its chain: an explicit one, else the model's -- unless ets(None) already carries it"""
-        if tool is not None:
-            return tool
-        return None if end is None else self.tool
+        """the tool a pass-through hands its chain: the caller's, nothing else.  The gripper's tool is part of ets(None) (the chain to the
+        default end effector, robot/BaseRobot.py:1507-1521, 1610-1616) and of no other chain: with an explicit `end` link the reference
+        applies none, and the IK entry points solve the same chains, so fkine and ik_* agree for every (start, end)."""
+        return tool
 
     def _chain(self, q, start, end):
         """The chain a pass-through evaluates: joints numbered along the path (q has the path's columns) -- or, when q carries one column per
@@ -294,7 +295,8 @@ class URDFRobot:
     def hessiane(self, q=None, end=None, start=None, Je=None, tool=None): return self._chain(q, start, end).hessiane(q, Je=Je, tool=self._tool_for(end, tool))
     def manipulability(self, q=None, J=None, end=None, start=None, **kw):
         if J is not None:
-            raise NotImplementedError("manipulability(J=...) is not offered: pass q (the Jacobian never leaves the registers)")
+            from .et import manipulability_from_jacobian
+            return manipulability_from_jacobian(J, **kw)                # a pure function of J (robot/Robot.py:896)
         e = self.ets(start, end)                                     # Robot.manipulability: self.ets(end, start), gripper tool included (robot/Robot.py:825)
         return e.manipulability(np.zeros(e.n) if q is None else q, **kw)      # q=None: the robot's stored configuration, zeros (BaseRobot.q)
 
@@ -305,7 +307,10 @@ class URDFRobot:
     def jacobm(self, q=None, J=None, H=None, end=None, start=None, **kw):
         e = self.ets(start, self.ee if end is None else end)
         if J is not None or H is not None:
-            raise NotImplementedError("jacobm(J=..., H=...) is not offered: pass q")
+            from .et import jacobm_from_jacobian
+            if J is None:
+                J = e.jacob0(np.zeros(e.n) if q is None else q)          # robot/Robot.py:1194-1199
+            return jacobm_from_jacobian(J, H=H, **kw)
         return e.jacobm(np.zeros(e.n) if q is None else q, **kw)
     def jacob0_dot(self, q, qd, J0=None, representation=None, end=None): return self.ets(end=end).jacob0_dot(q, qd, J0=J0, representation=representation)
     def jacob0_analytical(self, q, representation="rpy/xyz", end=None, start=None, tool=None):
@@ -379,6 +384,40 @@ class URDFRobot:
 
 def loadstr(urdf_string, **kw):
     return URDFRobot(urdf_string, **kw)
+
+
+# The robot descriptions the reference names relative to its data package (rtb-data/rtbdata/xacro/<path>, what models/URDF/<name>.py hand to
+# Robot.URDF_read) -> the kinematic URDF of the same robot shipped here (expanded offline by scripts/make_urdf_data.py with the reference's own
+# xacro tool: the data package and run-time xacro processing are not part of this backend).
+REFERENCE_PATHS = {
+    "al5d_description/urdf/al5d_robot.urdf": "AL5D", "fetch_description/robots/fetch.urdf": "Fetch",
+    "kortex_description/robots/gen3.xacro": "KinovaGen3", "kuka_description/kuka_lbr_iiwa/urdf/lbr_iiwa_14_r820.xacro": "LBR",
+    "kinova_description/urdf/j2n4s300_standalone.xacro": "Mico", "franka_description/robots/panda_arm_hand.urdf.xacro": "Panda",
+    "puma560_description/urdf/puma560_robot.urdf.xacro": "Puma560", "ur_description/urdf/ur3_joint_limited_robot.urdf.xacro": "UR3",
+    "ur_description/urdf/ur5_joint_limited_robot.urdf.xacro": "UR5", "ur_description/urdf/ur10_joint_limited_robot.urdf.xacro": "UR10",
+    "yumi_description/urdf/yumi.urdf": "YuMi",
+    **{"interbotix_descriptions/urdf/%s.urdf.xacro" % k: k for k in ("px100", "px150", "rx150", "rx200", "vx300", "vx300s", "wx200", "wx250", "wx250s")},
+}
+
+
+def read(file_path, **kw):
+    """The URDF file at `file_path` as a URDFRobot (the reader behind Robot.URDF, robot/Robot.py:218-330).  A path that exists is read as it
+    is (plain URDF; a .xacro file is refused: expand it first); a path the reference resolves inside its data package
+    ("fetch_description/robots/fetch.urdf", REFERENCE_PATHS) gives the shipped description of that robot."""
+    path = os.fspath(file_path)
+    if os.path.isfile(path):
+        if path.endswith(".xacro"):
+            raise ValueError("%s: xacro is not processed at run time by this backend; expand it to plain URDF first "
+                             "(scripts/make_urdf_data.py shows how, with the reference's own xacro tool)" % path)
+        with open(path) as f:
+            return URDFRobot(f.read(), **kw)
+    key = path.replace(os.sep, "/").lstrip("./")
+    if key in REFERENCE_PATHS:
+        shipped = os.path.join(DATA_DIR, REFERENCE_PATHS[key] + ".urdf")
+        with open(shipped) as f:
+            return URDFRobot(f.read(), **kw)
+    raise FileNotFoundError("no URDF file %r (and not one of the reference's data-package paths this backend ships: %s)"
+                            % (path, ", ".join(sorted(REFERENCE_PATHS))))
 
 
 def available():

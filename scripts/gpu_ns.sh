@@ -2,7 +2,7 @@
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "ik" > gpurun_out/pytest_ns.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_ns.log
+timeout 900 python -m pytest tests/test_00_gpu_parity.py -m gpu -x -q -k "ik" > gpurun_out/pytest_ns.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_ns.log
 tail -25 gpurun_out/pytest_ns.log
 python - <<'PY'
 import sys; sys.path[:0] = ['.', 'robotics-toolbox-python_amd']

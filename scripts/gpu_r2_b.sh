@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r2b
 mkdir -p $O
-timeout 1500 python -m pytest tests/test_compat_shim.py tests/test_dist_gpu.py tests/test_host_path.py tests/test_gpu_parity.py tests/test_hip_graph.py -m gpu -q --timeout 900 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+timeout 1500 python -m pytest tests/test_02_compat_shim.py tests/test_dist_gpu.py tests/test_host_path.py tests/test_00_gpu_parity.py tests/test_hip_graph.py -m gpu -q --timeout 900 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
 tail -15 $O/pytest_gpu.log
 timeout 300 python scripts/diag_host_overhead.py 2>&1 | tail -30
 python bench.py --steps 200 --warmup 20 > $O/bench_n1.json 2> $O/bench_n1.err; cut -c1-400 $O/bench_n1.json; python -c "

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r2e
 mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_python_ik_pins.py tests/test_hip_graph.py -m gpu -q --timeout 300 -k "ik or IK or graph" > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+timeout 900 python -m pytest tests/test_00_gpu_parity.py tests/test_03_python_ik_pins.py tests/test_hip_graph.py -m gpu -q --timeout 300 -k "ik or IK or graph" > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
 grep -E "passed|failed|FAILED|ERROR|Timeout" $O/pytest_gpu.log | tail -8
 echo "== ik at 1e5 targets"
 for t in "--tune ik_share=0" "--tune ik_share=1" "--tune ik_share=1 --tune ik_fresh_pct=100" "--tune ik_share=1 --tune ik_fresh_pct=25" "--tune ik_share=0 --tune ik_fresh_pct=100"; do

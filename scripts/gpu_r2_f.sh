@@ -14,5 +14,5 @@ for t in "--tune ik_share=0" "--tune ik_share=1"; do
   echo "  [$t]"; timeout 100 python bench_extra.py --what ik --no-cpu --steps 12 $t 2>$O/err.txt | python -c "$pyline"; echo "  rc=${PIPESTATUS[0]}"
 done 2>&1 | tee -a $O/ik_share.txt
 for n in 20000 400000; do echo "  n-ik $n share 1"; timeout 60 python bench_extra.py --what ik --no-cpu --steps 8 --n-ik $n --tune ik_share=1 2>/dev/null | head -1 | python -c "$pyline"; done 2>&1 | tee -a $O/ik_share.txt
-timeout 420 python -m pytest tests/test_gpu_parity.py -m gpu -q --timeout 150 --tb=short -k "cross_wave or fourteen" > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+timeout 420 python -m pytest tests/test_00_gpu_parity.py -m gpu -q --timeout 150 --tb=short -k "cross_wave or fourteen" > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
 tail -60 $O/pytest_gpu.log | cut -c1-300

@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r2i
 mkdir -p $O
 cd $R
-timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_python_ik_pins.py -m gpu -q --timeout 200 --tb=short -k "qp or robot_wide or ikine_equals" > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+timeout 600 python -m pytest tests/test_00_gpu_parity.py tests/test_03_python_ik_pins.py -m gpu -q --timeout 200 --tb=short -k "qp or robot_wide or ikine_equals" > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
 grep -v "Warning\|^  \|^$" $O/pytest_gpu.log | tail -25 | cut -c1-250
 cat > /tmp/qp_time.py <<'PY'
 import sys, os, time

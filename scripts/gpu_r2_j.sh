@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r2j
 mkdir -p $O
 cd $R
-timeout 600 python -m pytest tests/test_dynamics_terms.py tests/test_gpu_parity.py -m gpu -q --timeout 200 --tb=short -k "dyn or inertia or accel or coriolis or rne" > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+timeout 600 python -m pytest tests/test_dynamics_terms.py tests/test_00_gpu_parity.py -m gpu -q --timeout 200 --tb=short -k "dyn or inertia or accel or coriolis or rne" > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
 grep -v "Warning\|^  \|^$" $O/pytest_gpu.log | tail -12 | cut -c1-250
 timeout 300 python bench_extra.py --what dyn,rne --no-cpu --steps 12 > $O/bench_dyn.jsonl 2>$O/err.txt
 python - $O/bench_dyn.jsonl <<'PY'

@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r3c
 mkdir -p $O
 cd $R
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -rf -k "ik" --timeout 600 > $O/pytest_ik.log 2>&1; grep -E "passed|failed|FAILED" $O/pytest_ik.log | tail -5
+timeout 600 python -m pytest tests/test_00_gpu_parity.py -m gpu -q -rf -k "ik" --timeout 600 > $O/pytest_ik.log 2>&1; grep -E "passed|failed|FAILED" $O/pytest_ik.log | tail -5
 for rep in 1 2; do
 for t in 0 1; do
   timeout 300 python bench_extra.py --what ik --no-cpu --steps 12 --tune ik_flat=$t 2>/dev/null | head -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('ik_flat=$t', 'avg %.4f min %.4f ms' % (d['kernel_avg_ms'], d['kernel_min_ms']), d['success_rate'], d['mean_iterations'], '%.3g' % d['lm_iterations_per_s'])"

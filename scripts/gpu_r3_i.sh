@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -rf -k "ik" --timeout 600 2>&1 | tail -2
+timeout 600 python -m pytest tests/test_00_gpu_parity.py -m gpu -q -rf -k "ik" --timeout 600 2>&1 | tail -2
 for rep in 1 2; do for f in 1 0; do
   timeout 300 python bench_extra.py --what ik --no-cpu --steps 12 --tune ik_flat=$f 2>/dev/null | python -c "
 import sys,json

@@ -7,7 +7,7 @@ O=$R/gpurun_out/r3l
 mkdir -p $O
 cd $R
 V=$R/robotics-toolbox-python_amd/lib/variants/ik3.so
-RTBHIP_LIB=$V timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_python_ik_pins.py -m gpu -q -x -k "ik or IK" --timeout 600 2>&1 | tail -4
+RTBHIP_LIB=$V timeout 900 python -m pytest tests/test_00_gpu_parity.py tests/test_03_python_ik_pins.py -m gpu -q -x -k "ik or IK" --timeout 600 2>&1 | tail -4
 for rep in 1 2 3; do
   timeout 300 python bench_extra.py --what ik --no-cpu --steps 8 2>/dev/null | python -c "
 import sys,json

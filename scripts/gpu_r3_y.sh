@@ -16,4 +16,4 @@ for rep in 1 2 3; do
   run $R "" "C "
   run $R $V/ikD.so "D "
 done
-cd $R && RTBHIP_LIB=$V/ikD.so timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_python_ik_pins.py -m gpu -q -x -k "ik or IK" 2>&1 | tail -2
+cd $R && RTBHIP_LIB=$V/ikD.so timeout 600 python -m pytest tests/test_00_gpu_parity.py tests/test_03_python_ik_pins.py -m gpu -q -x -k "ik or IK" 2>&1 | tail -2

@@ -50,8 +50,57 @@ def _cpu_replay_session():
         return
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import cpu_backend
-    with cpu_backend.installed():
+    with cpu_backend.installed() as be, _host_memory_wearing_the_device_label():
+        be.device_label_is_host = True
+        try:
+            yield
+        finally:
+            be.device_label_is_host = False
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def _host_memory_wearing_the_device_label():
+    """REPLAY ONLY.  The host layer has a second branch for device tensors (results allocated with torch on the caller's device, the
+    caller's stream, RTBHIP_MEM_DEVICE) and that branch is host code like the rest -- round 3 lost its GPU gate to a change in it that no
+    GPU-less run could see.  Under the replay `x.cuda()` therefore hands back the same CPU tensor and every tensor answers `is_cuda` with
+    True, streams are no-ops, and tests/cpu_backend.py serves RTBHIP_MEM_DEVICE calls from the host memory behind those tensors.  What this
+    cannot show is anything about real device memory, streams, graphs or timings: the tests that are about those stay in
+    tests/replay_needs_device.txt."""
+    import torch
+
+    class _Stream:
+        cuda_stream = 0
+
+        def __init__(self, *a, **k):
+            pass
+
+        def synchronize(self):
+            pass
+
+        def wait_stream(self, other):
+            pass
+
+    saved = {"is_cuda": torch.Tensor.__dict__.get("is_cuda"), "cuda": torch.Tensor.__dict__.get("cuda")}
+    saved_cuda = {k: getattr(torch.cuda, k) for k in ("synchronize", "current_stream", "Stream", "stream")}
+    torch.Tensor.is_cuda = property(lambda self: True)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.cuda.synchronize = lambda *a, **k: None
+    torch.cuda.current_stream = lambda *a, **k: _Stream()
+    torch.cuda.Stream = _Stream
+    torch.cuda.stream = lambda s: contextlib.nullcontext()
+    try:
         yield
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                delattr(torch.Tensor, k)
+            else:
+                setattr(torch.Tensor, k, v)
+        for k, v in saved_cuda.items():
+            setattr(torch.cuda, k, v)
 
 
 def pytest_collection_modifyitems(config, items):

@@ -10,7 +10,9 @@ handling, error behaviour, the reference's own test files -- on the kernels' own
     RTBHIP_EINVAL / RTBHIP_ELIMIT and the product's message where the product would; where validation passes, the real function stops at its first
     HIP call (no device here: RTBHIP_EHIP) and ONLY THEN the kernel's __host__ __device__ body is replayed lane by lane on the CPU
     (tests/emu/*.cpp, the same replay tests/test_kernel_emu.py checks against the oracle);
-  * only host buffers (RTBHIP_MEM_HOST) are served; a device-path call raises.
+  * only host buffers (RTBHIP_MEM_HOST) are served; a device-path call raises -- except under the replay of the GPU suite
+    (RTBHIP_TEST_CPU_REPLAY=1, tests/conftest.py), where "device" tensors are CPU tensors wearing the device label and a RTBHIP_MEM_DEVICE
+    call is served from the host memory behind them, so that the host layer's device-tensor branch runs too.
 
 The product has no such path: rtbhip._lib.lib() loads librtbhip.so or raises, and nothing under robotics-toolbox-python_amd/ knows this file.  It is
 installed by the `cpu_backend` fixture below (tests only), which swaps rtbhip._lib._lib for the duration of a test module."""
@@ -48,6 +50,7 @@ class EmuBackend:
         e.emu_tree_rne.argtypes = [_vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp]
         e.emu_tree_dyn.argtypes = [_vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp]
         e.emu_ik_nullspace_pi.argtypes, e.emu_ik_nullspace_pi.restype = [_vp, _i32], None
+        e.emu_diff_from_jac.argtypes = [_i32, _i32, _vp, _vp, _i64, _i32, _vp]
         self._trees = {}                                      # handle -> (group records as bytes, ng)
         self.calls = {}                                       # entry point -> number of replays (the tests assert the replay really ran)
 
@@ -59,7 +62,9 @@ class EmuBackend:
         """The real entry point's verdict on the arguments: None = go on and replay, else the code to return."""
         mem = args[-2]
         if _val(mem) != L.MEM_HOST:
-            raise L.RtbHipError("tests/cpu_backend.py serves host buffers only: the device path needs a GPU")
+            if not getattr(self, "device_label_is_host", False):
+                raise L.RtbHipError("tests/cpu_backend.py serves host buffers only: the device path needs a GPU")
+            args = tuple(args[:-2]) + (L.MEM_HOST, None)        # tests/conftest.py: CPU tensors wearing the device label (replay of the GPU suite)
         rc = getattr(self.emu, name)(*args)
         if rc == EHIP:
             self.calls[name] = self.calls.get(name, 0) + 1
@@ -116,6 +121,14 @@ class EmuBackend:
     def rtbhip_hessian_from_jacobian(self, J, N, n, H, mem, stream):
         rc = self._gate("rtbhip_hessian_from_jacobian", (J, N, n, H, mem, stream))
         return self.emu.emu_hess_from_jac(J, N, n, H) if rc is None else rc
+
+    def rtbhip_manipulability_from_jacobian(self, J, N, n, axes, method, m, mem, stream):
+        rc = self._gate("rtbhip_manipulability_from_jacobian", (J, N, n, axes, method, m, mem, stream))
+        return self.emu.emu_diff_from_jac(0, n, J, None, N, (_val(axes) & 63) | (_val(method) << 8), m) if rc is None else rc
+
+    def rtbhip_jacobm_from_jacobian(self, J, H, N, n, axes, Jm, mem, stream):
+        rc = self._gate("rtbhip_jacobm_from_jacobian", (J, H, N, n, axes, Jm, mem, stream))
+        return self.emu.emu_diff_from_jac(2 if _val(H) else 1, n, J, H, N, _val(axes) & 63, Jm) if rc is None else rc
 
     def rtbhip_angle_axis(self, Te, nTe, Tep, nTep, e, mem, stream):
         rc = self._gate("rtbhip_angle_axis", (Te, nTe, Tep, nTep, e, mem, stream))

@@ -166,3 +166,18 @@ def urdf_fk_numpy(urdf_path, end, q):
             T = T @ M
             k += 1
     return T
+
+
+def replaying():
+    """True under the developer's CPU replay of the GPU suite (tests/conftest.py, RTBHIP_TEST_CPU_REPLAY=1)."""
+    return os.environ.get("RTBHIP_TEST_CPU_REPLAY") == "1"
+
+
+def DEV():
+    """Where the GPU tests make their device tensors: "cuda" -- under the CPU replay host memory wears that label (tests/conftest.py)."""
+    return "cpu" if replaying() else "cuda"
+
+
+def full_size(N, replay_div=20):
+    """A BASELINE-size batch: N rows on the GPU; the CPU replay is about the host layer's code paths, not about size, and takes N / replay_div."""
+    return N // replay_div if replaying() else N

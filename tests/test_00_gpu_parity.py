@@ -14,7 +14,7 @@ import torch
 import rtbhip
 from rtbhip import urdf
 from oracle import oracle, chains
-from helpers import literals, ref_outputs, mixed_spec, product_ets, tool_base
+from helpers import literals, ref_outputs, mixed_spec, product_ets, tool_base, DEV, full_size
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
@@ -285,7 +285,7 @@ def test_fleet_one_launch_many_chains():
 def test_full_size_1e6_properties_and_sampled_parity():
     """BASELINE configs[1] at full size: N = 1e6, device resident.  Size-independent properties +
     oracle parity on a strided sample."""
-    N = 1000000
+    N = full_size(1000000)
     ets = rtbhip.models.Panda().ets()
     ch = chains.panda_ets()
     rng = np.random.default_rng(0)
@@ -294,18 +294,18 @@ def test_full_size_1e6_properties_and_sampled_parity():
     T, J0 = ets.fkine_jacob0(q)
     _, Je = ets.fkine_jacob0(q, frame=1)
     R = T[:, :3, :3]
-    eye = torch.eye(3, dtype=torch.float64, device="cuda")
+    eye = torch.eye(3, dtype=torch.float64, device=DEV())
     assert float((R @ R.transpose(1, 2) - eye).abs().max()) < 1e-13                      # rotations stay orthonormal
     assert float((torch.linalg.det(R) - 1).abs().max()) < 1e-13
-    assert bool((T[:, 3, :] == torch.tensor([0, 0, 0, 1.0], dtype=torch.float64, device="cuda")).all())
+    assert bool((T[:, 3, :] == torch.tensor([0, 0, 0, 1.0], dtype=torch.float64, device=DEV())).all())
     # jacobe == blkdiag(R^T, R^T) jacob0 for every configuration
     Jv = R.transpose(1, 2) @ J0[:, :3, :]
     Jw = R.transpose(1, 2) @ J0[:, 3:, :]
     assert float((torch.cat([Jv, Jw], dim=1) - Je).abs().max()) < 1e-12
     # Jacobian is the derivative of fkine: central difference on joint 3 for a strided sample
-    idx = torch.arange(0, N, 9973, device="cuda")
+    idx = torch.arange(0, N, 9973, device=DEV())
     h = 1e-6
-    dq = torch.zeros(7, dtype=torch.float64, device="cuda"); dq[3] = h
+    dq = torch.zeros(7, dtype=torch.float64, device=DEV()); dq[3] = h
     Tp, Tm = ets.eval(q[idx] + dq), ets.eval(q[idx] - dq)
     assert float(((Tp[:, :3, 3] - Tm[:, :3, 3]) / (2 * h) - J0[idx, :3, 3]).abs().max()) < 1e-7
     # idempotence: a second launch writes bit-identical output
@@ -318,7 +318,7 @@ def test_full_size_1e6_properties_and_sampled_parity():
 
 def test_full_size_rne_1e6_sampled_parity_and_linearity():
     """BASELINE configs[3] per-GPU share (1.25e6 of the 1e7 triples), DH Panda."""
-    N = 1250000
+    N = full_size(1250000)
     pd = rtbhip.models.DH.Panda()
     tab = chains.panda_dh()
     rng = np.random.default_rng(3)
@@ -498,7 +498,7 @@ def test_ik_config3_1e5_targets_statistics():
     below the CPU oracle's (same algorithm, same generator) minus 0.1 %."""
     ets, ch = _panda_limited()
     rng = np.random.default_rng(1)
-    N = 100000
+    N = full_size(100000, 10)
     qs = rng.uniform(ch.qlim[0], ch.qlim[1], (N, 7))
     Tep = torch.from_numpy(oracle.fkine(ch, qs)).cuda()
     q, ok, it, se, E = ets.ik_LM(Tep, seed=2)
@@ -619,6 +619,7 @@ def test_ik_cross_wave_sharing_and_phased_schedule_equal_plain(flavour):
     ets, ch = _panda_limited()
     rng = np.random.default_rng(77 + flavour)
     for N, with_q0, slimit in ((3000, False, 100), (150000, False, 100), (4000, True, 37), (500, False, 9)):
+        N = full_size(N, 50)              # (the CPU replay runs ONE schedule whatever the knobs say: there only the plumbing is under test)
         Tep = oracle.fkine(ch, rng.uniform(ch.qlim[0], ch.qlim[1], (N, 7)))
         Tep[::41, :3, 3] += 2.5
         q0 = rng.uniform(ch.qlim[0], ch.qlim[1], (N, 7)) if with_q0 else None
@@ -776,8 +777,8 @@ def test_large_batch_64bit_indexing():
     N = 20000003
     ets = rtbhip.models.Panda().ets()
     ch = chains.panda_ets()
-    g = torch.Generator(device="cuda").manual_seed(3)
-    q = (torch.rand((N, 7), dtype=torch.float64, device="cuda", generator=g) - 0.5) * 6.0
+    g = torch.Generator(device=DEV()).manual_seed(3)
+    q = (torch.rand((N, 7), dtype=torch.float64, device=DEV(), generator=g) - 0.5) * 6.0
     T, J = ets.fkine_jacob0(q)
     torch.cuda.synchronize()
     idx = torch.cat([torch.arange(0, 70), torch.arange(N - 70, N), torch.tensor([N // 2, 2 ** 24 + 1, 16777216 + 64 * 1000 + 5])]).cuda()

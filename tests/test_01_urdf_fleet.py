@@ -10,7 +10,7 @@ import pytest
 import rtbhip
 from rtbhip import urdf
 from oracle import oracle
-from helpers import chain_from_ets, urdf_fk_numpy
+from helpers import chain_from_ets, urdf_fk_numpy, DEV, full_size
 
 TOL = 1e-10
 
@@ -141,29 +141,29 @@ def test_gpu_full_size_fleet16_1e6_each_properties_and_sampled_parity():
     Size-independent properties over every row (rotation blocks orthonormal with det +1, bottom row 0 0 0 1,
     angular Jacobian columns of revolute joints unit length, prismatic ones zero) + oracle parity on a sample."""
     import torch
-    N = 1000000
+    N = full_size(1000000, 50)
     robots = [urdf.load(n) for n in urdf.FLEET16]
     chs = [r.ets() for r in robots]
     qs = []
     for i, c in enumerate(chs):
         ql = np.clip(c.qlim, -2 * np.pi, 2 * np.pi)
-        g = torch.Generator(device="cuda").manual_seed(4 + i)
+        g = torch.Generator(device=DEV()).manual_seed(4 + i)
         lo, hi = (torch.from_numpy(x).cuda() for x in (ql[0], ql[1]))
-        qs.append(lo + (hi - lo) * torch.rand((N, c.n), dtype=torch.float64, device="cuda", generator=g))
+        qs.append(lo + (hi - lo) * torch.rand((N, c.n), dtype=torch.float64, device=DEV(), generator=g))
     Ts, Js = rtbhip.fleet_fkine_jacob(chs, qs)
     torch.cuda.synchronize()
-    eye = torch.eye(3, dtype=torch.float64, device="cuda")
+    eye = torch.eye(3, dtype=torch.float64, device=DEV())
     for c, q, T, J in zip(chs, qs, Ts, Js):
         R = T[:, :3, :3]
         assert float((R @ R.transpose(1, 2) - eye).abs().max()) < 1e-12
         assert float((torch.linalg.det(R) - 1).abs().max()) < 1e-12
-        assert bool((T[:, 3, :] == torch.tensor([0.0, 0, 0, 1], dtype=torch.float64, device="cuda")).all())
+        assert bool((T[:, 3, :] == torch.tensor([0.0, 0, 0, 1], dtype=torch.float64, device=DEV())).all())
         wn = torch.linalg.norm(J[:, 3:, :], dim=1)                       # (N, n)
-        rev = torch.tensor([e.isrotation for e in c.joints()], device="cuda")
+        rev = torch.tensor([e.isrotation for e in c.joints()], device=DEV())
         assert float((wn[:, rev] - 1).abs().max()) < 1e-12
         if (~rev).any():
             assert float(wn[:, ~rev].abs().max()) == 0.0
-        idx = torch.randint(0, N, (64,), device="cuda")
+        idx = torch.randint(0, N, (64,), device=DEV())
         oc = chain_from_ets(c)
         qh = q[idx].cpu().numpy()
         nt.assert_allclose(T[idx].cpu().numpy(), oracle.fkine(oc, qh), atol=TOL)
@@ -184,3 +184,45 @@ def test_gpu_fleet_more_chains_than_one_launch_table_holds():
         nt.assert_allclose(T, oracle.fkine(oc, q), atol=TOL)
         nt.assert_allclose(J, oracle.jacob0(oc, q), atol=TOL)
     assert rtbhip.fleet_fkine_jacob([], []) == ([], [])
+
+
+def test_Robot_URDF_reads_a_file_and_folds_the_gripper(tmp_path):
+    """Robot.URDF(file_path, gripper=) (robot/Robot.py:288-330).  The reference's own pins (tests/test_Robot.py:618-628): the Fetch with
+    gripper = link 6 has 5 joints, with gripper = "forearm_roll_link" 7.  A path of the reference's data package resolves to the shipped
+    description; a file on disk is read as it is; xacro and unknown paths are refused."""
+    r = rtbhip.ERobot.URDF("fetch_description/robots/fetch.urdf", gripper=6)
+    assert r.n == 5
+    r = rtbhip.ERobot.URDF("fetch_description/robots/fetch.urdf", gripper="forearm_roll_link")
+    assert r.n == 7 and "forearm_roll_link" not in [l.name for l in r.links]
+    whole = rtbhip.ERobot.URDF("fetch_description/robots/fetch.urdf")
+    assert whole.n == urdf.load("Fetch").n and whole.urdf_string.lstrip().startswith("<")
+    # a plain file on disk
+    src = open(os.path.join(os.path.dirname(urdf.__file__), "data", "urdf", "UR5.urdf")).read()
+    path = tmp_path / "my_arm.urdf"
+    path.write_text(src)
+    mine = rtbhip.ERobot.URDF(str(path))
+    ref = urdf.load("UR5").erobot()
+    assert mine.n == ref.n and [l.name for l in mine.links] == [l.name for l in ref.links]
+    u = urdf.read(path)
+    assert u.n == urdf.load("UR5").n
+    with pytest.raises(ValueError):
+        rtbhip.ERobot.URDF("fetch_description/robots/fetch.urdf", gripper="no_such_link")
+    with pytest.raises(TypeError):
+        rtbhip.ERobot.URDF("fetch_description/robots/fetch.urdf", gripper=1.5)
+    with pytest.raises(FileNotFoundError):
+        rtbhip.ERobot.URDF("nowhere/robot.urdf")
+    x = tmp_path / "arm.urdf.xacro"
+    x.write_text(src)
+    with pytest.raises(ValueError):
+        urdf.read(x)
+
+
+@pytest.mark.gpu
+def test_gpu_Robot_URDF_kinematics_equal_the_loaded_model():
+    rng = np.random.default_rng(17)
+    r = rtbhip.ERobot.URDF("ur_description/urdf/ur5_joint_limited_robot.urdf.xacro")
+    u = urdf.load("UR5")
+    q = rng.uniform(-2, 2, (40, r.n))
+    end = u.ee
+    nt.assert_allclose(r.fkine(q, end=end), u.fkine(q, end=end), atol=1e-12)
+    nt.assert_allclose(r.jacob0(q, end=end), u.jacob0(q, end=end), atol=1e-12)

@@ -321,3 +321,109 @@ def test_gpu_partial_fkine0():
     with pytest.raises(rtbhip.RtbHipError):
         e.partial_fkine0(q, 7)
     assert e.partial_fkine0(np.zeros((0, 6)), 3).shape == (0, 6, 6, 6, 6)
+
+
+# ---------------------------------------------------------------- manipulability(J=) / jacobm(J=, H=): from the caller's arrays
+def _reference_manipulability(J, method, axes):
+    """robot/Robot.py:848-869 as it stands: yoshikawa / condition / minsingular on J[axes, :]"""
+    Ja = J[np.asarray(axes, dtype=bool), :]
+    if method == "yoshikawa":
+        return abs(np.linalg.det(Ja)) if Ja.shape[0] == Ja.shape[1] else np.sqrt(abs(np.linalg.det(Ja @ Ja.T)))
+    if method == "invcondition":
+        return 1 / np.linalg.cond(Ja)
+    return np.linalg.svd(Ja, compute_uv=False)[-1]
+
+
+def _reference_jacobm(J, H, axes):
+    """robot/Robot.py:1213-1233 as it stands (H is the (n,6,n) tensor hessian0 returns)"""
+    axes = np.asarray(axes, dtype=bool)
+    m = _reference_manipulability(J, "yoshikawa", axes)
+    Ja, Ha = J[axes, :], H[:, axes, :]
+    b = np.linalg.inv(Ja @ Ja.T)
+    return np.array([m * (Ja @ Ha[i].T).flatten("F") @ b.flatten("F") for i in range(J.shape[1])])
+
+
+_AXES = {"all": [1] * 6, "trans": [1, 1, 1, 0, 0, 0], "rot": [0, 0, 0, 1, 1, 1]}
+
+
+def _from_jacobian_checks(ets, ch, N, seed, dev=None):
+    """manipulability_from_jacobian / jacobm_from_jacobian against the reference's NumPy expressions on Jacobians of random configurations;
+    `dev` turns host arrays into device tensors."""
+    rng = np.random.default_rng(seed)
+    q = rng.uniform(-2.5, 2.5, (N, ch.n))
+    J = oracle.jacob0(ch, q)
+    H = oracle.hessian0(ch, q)
+    put = (lambda a: a) if dev is None else dev
+    get = (lambda a: a) if dev is None else (lambda t: t.cpu().numpy())
+    for method in ("yoshikawa", "minsingular", "invcondition"):
+        for axes in ("all", "trans", "rot", [True, False, True, True, False, True]):
+            ax = _AXES.get(axes, axes) if isinstance(axes, str) else axes
+            if ch.n < sum(bool(a) for a in ax) and method != "yoshikawa":
+                pass                                                   # more rows than joints: the singular values are those of J_a^T J_a, still compared
+            got = get(rtbhip.manipulability_from_jacobian(put(J), method=method, axes=axes))
+            want = np.array([_reference_manipulability(J[i], method, ax) for i in range(N)])
+            nt.assert_allclose(got, want, rtol=1e-8, atol=1e-10)
+    one = rtbhip.manipulability_from_jacobian(J[0])
+    assert isinstance(one, float) and abs(one - _reference_manipulability(J[0], "yoshikawa", [1] * 6)) < 1e-12
+    for axes in ("all", "trans", "rot"):
+        ax = _AXES[axes]
+        if ch.n < sum(ax):
+            continue                                                   # J_a J_a^T is singular with fewer joints than rows: the reference's inv() fails too
+        want = np.array([_reference_jacobm(J[i], H[i], ax) for i in range(N)])
+        ok = np.array([np.linalg.cond(J[i][np.asarray(ax, bool)] @ J[i][np.asarray(ax, bool)].T) < 1e8 for i in range(N)])
+        scale = np.abs(want[ok]).max()
+        nt.assert_allclose(get(rtbhip.jacobm_from_jacobian(put(J), axes=axes))[ok], want[ok], atol=1e-8 * scale)            # H formed from J
+        nt.assert_allclose(get(rtbhip.jacobm_from_jacobian(put(J), H=put(H), axes=axes))[ok], want[ok], atol=1e-8 * scale)   # H supplied
+        # a Hessian that is NOT the Jacobian's own is honoured (the reference contracts whatever it is given)
+        H2 = H * 0.5
+        nt.assert_allclose(get(rtbhip.jacobm_from_jacobian(put(J), H=put(H2), axes=axes))[ok], 0.5 * want[ok], atol=1e-8 * scale)
+    col = rtbhip.jacobm_from_jacobian(J[0], H=H[0])
+    assert col.shape == (ch.n, 1)
+
+
+@pytest.mark.parametrize("name", ["panda", "puma", "fetch"])
+def test_emu_manipulability_and_jacobm_from_a_supplied_jacobian(name):
+    """the kernel body of k_diff_from_jac replayed on the CPU (tests/cpu_backend.py) against the reference's NumPy expressions"""
+    import cpu_backend
+    _, ets, ch = [c for c in _cases() if c[0] == name][0]
+    with cpu_backend.installed() as be:
+        _from_jacobian_checks(ets, ch, 130, 11)
+        assert be.calls.get("rtbhip_manipulability_from_jacobian", 0) > 0 and be.calls.get("rtbhip_jacobm_from_jacobian", 0) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["panda", "puma", "ur5", "fetch"])
+def test_gpu_manipulability_and_jacobm_from_a_supplied_jacobian(name):
+    """Robot.manipulability(J=) / Robot.jacobm(J=, H=) (robot/Robot.py:896, :1201-1233) on the device, host arrays and device tensors"""
+    import torch
+    from helpers import DEV
+    _, ets, ch = [c for c in _cases() if c[0] == name][0]
+    _from_jacobian_checks(ets, ch, 1000, 12)
+    _from_jacobian_checks(ets, ch, 129, 13, dev=lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV()).cuda())
+
+
+@pytest.mark.gpu
+def test_gpu_robot_level_J_and_H_keywords_and_errors():
+    """the pass-throughs: robot.manipulability(J=), robot.jacobm(J=, H=), robot.jacobm(q, H=) for an ETS robot, a DH robot and a URDF robot"""
+    rng = np.random.default_rng(3)
+    for robot in (rtbhip.models.Panda(), rtbhip.models.DH.Puma560(), urdf.load("UR5")):
+        n = robot.n if not isinstance(robot, urdf.URDFRobot) else robot.ets().n
+        q = rng.uniform(-2, 2, n)
+        J, H = np.asarray(robot.jacob0(q)), np.asarray(robot.hessian0(q))
+        for axes in ("all", "trans", "rot"):
+            nt.assert_allclose(robot.manipulability(J=J, axes=axes), _reference_manipulability(J, "yoshikawa", _AXES[axes]), rtol=1e-9)
+            want = _reference_jacobm(J, H, _AXES[axes])
+            nt.assert_allclose(np.asarray(robot.jacobm(J=J, axes=axes)).ravel(), want, atol=1e-9 * np.abs(want).max())
+            nt.assert_allclose(np.asarray(robot.jacobm(J=J, H=H, axes=axes)).ravel(), want, atol=1e-9 * np.abs(want).max())
+        nt.assert_allclose(robot.manipulability(J=J, method="minsingular"), np.linalg.svd(J, compute_uv=False)[-1], rtol=1e-8)
+    with pytest.raises(ValueError):
+        rtbhip.manipulability_from_jacobian(np.zeros((5, 7)))
+    with pytest.raises(ValueError):
+        rtbhip.manipulability_from_jacobian(np.zeros((6, 7)), method="asada")
+    with pytest.raises(ValueError):
+        rtbhip.jacobm_from_jacobian(np.zeros((6, 7)), H=np.zeros((6, 7, 7)))
+    with pytest.raises(rtbhip.RtbHipError):
+        rtbhip.manipulability_from_jacobian(np.zeros((6, 17)))
+    with pytest.raises(rtbhip.RtbHipError):
+        rtbhip.manipulability_from_jacobian(np.zeros((6, 7)), axes=[False] * 6)
+    assert rtbhip.manipulability_from_jacobian(np.zeros((0, 6, 7))).shape == (0,)

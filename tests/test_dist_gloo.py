@@ -68,3 +68,68 @@ def test_single_process_is_identity():
     sb = rtbhip.ShardedBatch(10, rank=0, world=1)
     x = torch.arange(10.0)
     assert sb.gather(x) is x and sb.local(x).shape == (10,)
+
+
+def _bench_gather_worker(rank, world, port, N, q):
+    """benchlib.Ranks.gather_ms -- the one exchange the benches time -- on two CPU ranks: the Ranks object is assembled by hand (its constructor
+    insists on a GPU, as the benches must), backend gloo, host tensors."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        sys.path[:0] = [ROOT, os.path.join(ROOT, "robotics-toolbox-python_amd")]
+        import benchlib
+        import rtbhip
+        rk = object.__new__(benchlib.Ranks)
+        rk.world, rk.rank, rk.local, rk.backend, rk.dist, rk.shared, rk.forced = world, rank, rank, "gloo", dist, False, False
+        rk.dev = torch.device("cpu")
+        begin, count = rtbhip.shard_range(N, rank, world)
+        longest = max(rtbhip.shard_range(N, r, world)[1] for r in range(world))
+        full = torch.arange(N * 7, dtype=torch.float64).reshape(N, 7)
+        # the caller's buffer is as long as the longest shard (what a kernel wrote into); `rows` says how much of it is this rank's
+        local = torch.full((longest, 7), -1.0, dtype=torch.float64)
+        local[:count] = full[begin:begin + count]
+        ms = rk.gather_ms(local, rows=count, keep=True)
+        ok = ms is not None and ms >= 0.0 and torch.equal(rk.last_gather["rows"], full)
+        ok = ok and rk.last_gather["buffer_bytes"] == world * longest * 56 and rk.last_gather["rows_per_rank_padded"] == longest
+        q.put((rank, bool(ok), None))
+        dist.destroy_process_group()
+    except Exception as e:                       # noqa: BLE001
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("N", [1001, 1000, 3, 1])
+def test_bench_gather_ms_world2_uneven_shards(N):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_gather_worker, args=(r, 2, port, N, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, err in res:
+        assert ok, "rank %d: %s" % (rank, err)
+
+
+def test_gather_buffer_lives_outside_the_timed_region():
+    """Structure of the bench scripts, checked on their source: the receive buffer of the output gather is allocated inside Ranks.gather_ms,
+    which bench.py calls after Ranks.timed_steps has returned `elapsed` and before the cpu_baseline / secondary legs (which start only after
+    the call has released it).  (The -m gpu twin, tests/test_dist_gpu.py, checks torch.cuda.memory_allocated() around a real RCCL gather.)"""
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "main"][0]
+    pos = {}
+    for node in ast.walk(main):
+        if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute):
+            pos.setdefault(node.func.attr, node.lineno)
+        if isinstance(node, ast.Call) and isinstance(node.func, ast.Name):
+            pos.setdefault(node.func.id, node.lineno)
+    assert pos["timed_steps"] < pos["gather_ms"] < pos["cpu_baseline"] < pos["secondary"]
+    import benchlib
+    import inspect
+    body = inspect.getsource(benchlib.Ranks.timed_steps)
+    assert "all_gather" not in body and "torch.empty" not in body           # nothing of the gather is inside the timed loop
+    g = inspect.getsource(benchlib.Ranks.gather_ms)
+    assert "torch.empty" in g and "return ms" in g

@@ -161,6 +161,11 @@ def test_bench_gather_flag_runs_the_rccl_gather_with_one_rank():
     assert len(lines) == 1
     d = lines[0]
     assert d["n_gpus"] == 1 and d["config"]["backend"] == "nccl" and d["gather_ms"] > 0 and "RCCL" in d["gather"]
+    # the receive buffer of the gather (world x N x 58 doubles) lives only inside Ranks.gather_ms: after the timed region of `value`
+    # (test_dist_gloo.py checks the call order), gone again when the call returns -- the device holds what it held before
+    gb = d["gather_buffer"]
+    assert gb["buffer_bytes"] == 1 * 1000000 * 58 * 8 and gb["device_bytes_after"] == gb["device_bytes_before"]
+    assert "secondary" not in d                        # the forced one-rank group is a rehearsal of the collective: no secondary legs
 
 
 def _run_bench(script, extra):
@@ -218,3 +223,17 @@ def test_bench_single_gpu_line_carries_the_contract_objects():
     assert cb["kind"] == "reference" and cb["cores"] == 1 and cb["value"] > 1e5 and cb["max_abs_err_gpu_vs_cpu"] < 1e-10 and "sample" in cb
     hp = d["host_path"]
     assert hp["value"] > 1e7 and hp["value"] < d["value"] and hp["unit"] == "configurations/s"
+    # BASELINE configs[2], [3], [4] on the same line, each with its in-run parity figure against the reference's compiled code
+    sec = d["secondary"]
+    assert sec["seconds"] < 60
+    ik, rne, shard, fleet = sec["ik_config3"], sec["rne_config4_1e7"], sec["rne_config4_shard"], sec["fleet_config5"]
+    for leg in (ik, rne, shard, fleet):
+        assert "error" not in leg, leg
+        assert leg["kernel_avg_ms"] > 0 and leg["value"] == pytest.approx(leg["n"] / (leg["kernel_avg_ms"] * 1e-3), rel=1e-9)
+        assert 0.0 < leg["roofline"]["frac"] < 1.0
+    assert ik["n"] == 100000 and 0.985 < ik["success_rate"] < 0.997
+    assert ik["parity"]["same_success_iterations_searches"] == ik["parity"]["first_search_rows"] >= 200 and ik["parity"]["max_abs_dq"] <= 1e-6
+    assert rne["n"] == 10000000 and rne["parity"]["max_rel_err"] <= 1e-9 and "frne" in rne["parity"]["against"]
+    assert rne["roofline"]["achieved"] == pytest.approx(224e7 / (rne["kernel_avg_ms"] * 1e-3) / 1e9, rel=1e-6)
+    assert shard["n"] == 1250000
+    assert fleet["n"] == 16000000 and fleet["parity"]["max_abs_err"] <= 1e-10 and len(fleet["arms"]) == 16

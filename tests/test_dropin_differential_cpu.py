@@ -4,7 +4,7 @@ Left: the reference's OWN classes (`ET`, `ETS` of robot/ET.py, robot/ETS.py, loa
 compiled extension.  Right: `rtbhip.ET` / `rtbhip.ETS` on tests/cpu_backend.py (the product's entry-point validation + the kernel bodies on the
 CPU).  The same randomly generated chains are spelled with both sets of constructors and the same calls are made on both, in every argument
 form the reference accepts: what comes back must have the same type of container, the same shape and the same numbers -- and where the
-reference raises, this backend must raise too.  (The GPU run of the same surface: tests/test_reference_classes.py, tests/test_reference_suite.py.)"""
+reference raises, this backend must raise too.  (The GPU run of the same surface: tests/test_05_reference_classes.py, tests/test_reference_suite.py.)"""
 import numpy as np
 import numpy.testing as nt
 import pytest
@@ -203,7 +203,7 @@ def build_dh(ns, links, mdh, **robot_kw):
 
 def dh_both(seed, count):
     import rtbhip
-    from test_reference_dh_classes import ref_dh
+    from test_06_reference_dh_classes import ref_dh
     ns = ref_dh()
     rng = np.random.default_rng(seed)
     for k in range(count):
@@ -298,7 +298,7 @@ def test_flipped_dh_joints_where_the_reference_is_not_self_consistent():
     flipped modified-DH joint.  This backend flips the joint in ets(), so fkine, A and the Jacobians agree with one another (checked by the
     same finite difference); rne ignores the flag as the reference's does."""
     import rtbhip
-    from test_reference_dh_classes import ref_dh
+    from test_06_reference_dh_classes import ref_dh
     ns = ref_dh()
     kws = [dict(a=0.3, alpha=np.pi / 2, d=0.1), dict(a=0.2, alpha=-np.pi / 2, d=0.0, flip=True), dict(a=0.1, alpha=0.3, d=0.2)]
     q = np.array([0.3, -0.7, 0.5])
@@ -352,7 +352,7 @@ def build_tree(ET, ETS, Link, Robot, tree):
 @pytest.mark.skipif(not ref_classes.dh_available(), reason="needs the reference's byte-compiled Link / Robot classes")
 def test_link_trees_agree_paths_and_kinematics():
     import rtbhip
-    from test_reference_dh_classes import ref_dh
+    from test_06_reference_dh_classes import ref_dh
     ns = ref_dh()
     rLink, rRobot = ns.mods["Link"].Link, ns.mods["Robot"].Robot
     rng = np.random.default_rng(33)
@@ -460,7 +460,7 @@ def test_differential_kinematics_consumers_agree():
 
 def test_reference_classes_on_the_shim_modules_random_chains():
     """The reference's OWN ET / ETS classes bound to `rtbhip.compat.fknm` (the plug-in module with the extension's function table, here over the
-    CPU replay) against the same classes on the reference's compiled extension: random chains, the calls of tests/test_reference_classes.py's GPU
+    CPU replay) against the same classes on the reference's compiled extension: random chains, the calls of tests/test_05_reference_classes.py's GPU
     half -- this is the drop-in boundary itself (SURVEY section 8 row b) with nothing of rtbhip's Python mirror in between."""
     import rtbhip.compat
     with cpu_backend.installed() as be:
@@ -504,7 +504,7 @@ def test_reference_dh_classes_on_the_shim_modules_random_robots():
     """The reference's OWN DHRobot / DHLink / Dynamics classes bound to `rtbhip.compat.fknm` + `rtbhip.compat.frne` (CPU replay) against the same
     classes on the reference's compiled extensions: random robots (revolute / prismatic, both conventions, full inertial and friction parameters)."""
     import rtbhip.compat
-    from test_reference_dh_classes import ref_dh
+    from test_06_reference_dh_classes import ref_dh
     with cpu_backend.installed() as be:
         on_ext = ref_dh()
         on_shim = ref_classes.load_dh(rtbhip.compat.fknm, rtbhip.compat.frne, "shim-dh-cpu-replay")

@@ -484,7 +484,7 @@ def test_ik_qp_joint_counts_against_the_kkt_restatement(robot, kw):
     damped by kj sum|e| / ks, plus the manipulability term where km > 0; a primal-dual active set where kq > 0 adds velocity-damper
     rows) inside the Python solver's loop against the NumPy restatement that builds the reference's Q, c, Aeq, beq, Ain, bin and
     solves the programme by enumerating active sets (oracle/qp.py: a different method on purpose).  Every target, every search: the QP step is
-    damped, so nothing is chaotic here.  (Panda: pinned on the reference's own IK_QP code in test_python_ik_pins.py.)"""
+    damped, so nothing is chaotic here.  (Panda: pinned on the reference's own IK_QP code in test_03_python_ik_pins.py.)"""
     from rtbhip import urdf
     from helpers import chain_from_ets
     ets = urdf.load(robot).ets()

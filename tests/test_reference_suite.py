@@ -51,8 +51,6 @@ EXPECTED = {
         "test_jacobm": SYM, "test_symdyn": SYM,
     },
     "test_Robot": {
-        "test_URDF": "URDF file reader as a class method (ERobot.URDF / xacro processing at run time): this backend ships pre-expanded descriptions",
-        "test_URDF2": "URDF file reader as a class method",
         "test_asada": "Asada's measure needs the Cartesian inertia matrix: operational-space dynamics are not on the path",
         "test_collided2": "pybullet collision checking: skipped by its own mark",
         "test_link_collision_damper": "pybullet collision checking: skipped by its own mark",

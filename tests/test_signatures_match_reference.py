@@ -42,7 +42,7 @@ def _same(a, b):
 
 def test_public_method_signatures_and_defaults():
     import rtbhip
-    from test_reference_dh_classes import ref_dh
+    from test_06_reference_dh_classes import ref_dh
     ns = ref_dh()
     pairs = [("ET", ns.ET, rtbhip.ET), ("ETS", ns.ETS, rtbhip.ETS), ("DHRobot", ns.DHRobot, rtbhip.DHRobot), ("DHLink", ns.DHLink, rtbhip.DHLink),
              ("RevoluteDH", ns.RevoluteDH, rtbhip.RevoluteDH), ("PrismaticDH", ns.PrismaticDH, rtbhip.PrismaticDH),
