@@ -22,19 +22,25 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "robotics-toolbox-python_amd")]
 
-from benchlib import protect_stdout, HBM_PEAK_GBS, FP64_VALU_PEAK_TFLOPS, Ranks, spawn_ranks_if_needed, bench_argv, ensure_library, pmc_traffic  # noqa: E402
+from benchlib import protect_stdout, HBM_PEAK_GBS, FP64_VALU_PEAK_TFLOPS, Ranks, spawn_ranks_if_needed, bench_argv, ensure_library, pmc_traffic, sustained_counts  # noqa: E402
 
 
 def ev_time(fn, steps, warmup):
+    """(average, minimum) device-side duration of `fn` in the STEADY STATE: >= 30 ms of warm-up launches, then per-launch HIP-event pairs over
+    >= 30 ms of launches (at most 200), no synchronise in between (benchlib.sustained_counts says why: boost clock after an idle gap, then a
+    throttling transient, profiles/r04_rne_1e7.txt)."""
     import torch
     for _ in range(warmup):
         fn()
-    torch.cuda.synchronize()
+    warm, reps = sustained_counts(fn)
+    steps = max(steps, min(reps, 200))
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     import gc
     gc.collect()                      # no collector pause (40-60 ms here) between a launch and its closing event
     was = gc.isenabled()
     gc.disable()
+    for _ in range(warm):
+        fn()
     for a, b in ev:
         a.record(); fn(); b.record()
     torch.cuda.synchronize()
@@ -59,22 +65,38 @@ def ik_roofline(lm_iterations_per_s):
             "flops_per_iteration": IK_FLOPS_PER_ITERATION, "kernel": "k_ik<7,0>"}
 
 
-# VALU instructions per lane (= per configuration / triple) of the fp64-issue-bound secondary kernels, measured with SQ_INSTS_VALU / SQ_WAVES
-# (profiles/r03_a_sq_summary.txt).  Their roof is the fp64 vector rate, not HBM: each instruction is priced as one fp64 FMA (2 flop) -- an
-# upper bound of the arithmetic actually done (address, select and LDS-move instructions are in the count), i.e. the fraction is the share of
-# the chip's VALU issue slots the kernel fills.
+# ALGORITHMIC fp64 operations per unit of the issue-bound secondary kernels (fused multiply-add = 2), derived in DESIGN.md section 5 from the
+# recursion's own budget -- NOT from what the kernel happens to execute:
+#   one Newton-Euler link-pass = 135 fp64 operations-as-instructions (forward R^T w 8, w' 1, wd' 11, vd' 29, vd_c 21, F 3, N 24;
+#   backward R f 8, f 3, N + r_c x F 6, n 17, projection 4), priced as 270 flop; a pass over the 7-link arm = 1890 flop.
+#     gravload    1 pass                                                    1 890
+#     inertia     n passes (Dynamics.inertia: rne with qdd = e_i, qd = 0)   13 230
+#     coriolis    2 passes per column (polar form; the reference runs 28)   26 460
+#     accel       1 + n passes + LDL^T solve (n^3/3 + 2 n^2 = 212)           15 332
+#     tree_*      the same counts on the 6 link groups of the UR5:  rne 1 620, inertia 9 720, coriolis 19 440, accel 11 484
+#   FK + Jacobian walk of the 7-joint chain = 600 flop, then
+#     jacob0_dot      + sum over joint pairs (j <= i: two cross products and six FMAs = 30; j > i: 15): 28 x 30 + 21 x 15 = 1 155   -> 1 755
+#     manipulability  + J J^T (21 entries x 7 FMAs = 294) + 6x6 LU determinant (144) + sqrt                                      -> 1 050
+#     jacobm          + J J^T 294 + LDL^T 100 + 7 back-substitutions (504) + 49 Hessian-block contractions x 30 (1 470) + m        -> 3 000
+ALGO_FLOPS_PER_UNIT = {"gravload": 1890, "inertia": 13230, "coriolis": 26460, "accel": 15332, "tree_ur5": 1620, "jacob0_dot": 1755,
+                       "manipulability": 1050, "jacobm": 3000, "tree_inertia_ur5": 9720, "tree_coriolis_ur5": 19440, "tree_accel_ur5": 11484}
+# VALU instructions per lane actually EXECUTED (SQ_INSTS_VALU / SQ_WAVES, profiles/r03_a_sq_summary.txt, r03_o_sq_tree_dyn.txt): reported beside
+# the roofline as `valu_issue_util` (share of the chip's fp64 issue slots the kernel fills) -- a diagnostic, not a roofline: a kernel that
+# executed more instructions for the same answer would score higher on it.
 VALU_PER_UNIT = {"gravload": 833, "inertia": 3433, "coriolis": 10708, "accel": 3377, "tree_ur5": 1930, "jacob0_dot": 1692,
                  "manipulability": 1512, "jacobm": 2732,
-                 "tree_inertia_ur5": 10078, "tree_coriolis_ur5": 26443, "tree_accel_ur5": 11667}      # profiles/r03_o_sq_tree_dyn.txt
+                 "tree_inertia_ur5": 10078, "tree_coriolis_ur5": 26443, "tree_accel_ur5": 11667}
 
 
 def valu_roofline(key, units_per_s, kernel, hbm_bytes_per_unit):
+    flops = ALGO_FLOPS_PER_UNIT[key]
+    tf = flops * units_per_s / 1e12
     instr = VALU_PER_UNIT[key]
-    tf = 2.0 * instr * units_per_s / 1e12
     return {"bound": "fp64-valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
-            "valu_instructions_per_unit": instr, "counted_as": "one fp64 FMA (2 flop) per VALU instruction: issue-slot utilisation, an upper bound of the flops",
-            "source": "profiles/r03_a_sq_summary.txt (SQ_INSTS_VALU / SQ_WAVES)", "kernel": kernel,
-            "hbm_GBs": hbm_bytes_per_unit * units_per_s / 1e9}
+            "algorithmic_flops_per_unit": flops, "flops_source": "DESIGN.md section 5 (link-passes x 270 flop; FK + Jacobian 600 flop + the consumer's own products)",
+            "kernel": kernel, "hbm_GBs": hbm_bytes_per_unit * units_per_s / 1e9,
+            "valu_issue_util": 2.0 * instr * units_per_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
+            "valu_instructions_per_unit_measured": instr}
 
 
 def main():
@@ -136,13 +158,16 @@ def main():
                 raise RuntimeError(lib.rtbhip_last_error().decode())
         def rne_wrapper_step():
             hold["tau_w"] = rob.rne(q, qd, qdd)
-        elapsed, avg = rk.timed_steps(rne_step, args.steps, args.warmup)
+        # sustained: the warm-up outlasts the power controller's transient (profiles/r04_rne_1e7.txt); every rank runs the same counts
+        w_s, k_s = sustained_counts(rne_step)
+        K, W = max(args.steps, int(rk.max_over_ranks(k_s))), max(args.warmup, int(rk.max_over_ranks(w_s)))
+        elapsed, avg = rk.timed_steps(rne_step, K, W)
         _, best = ev_time(rne_step, min(args.steps, 10), 0)
         wavg, _ = ev_time(rne_wrapper_step, min(args.steps, 10), 3)
         hold.pop("tau_w", None)
-        step_ms = elapsed / args.steps * 1e3
+        step_ms = elapsed / K * 1e3
         line = {"metric": "triples/sec (DH Panda rne)", "value": Ntot / (step_ms * 1e-3), "unit": "triples/s", "n": Ntot,
-                "n_gpus": world, "scaling": "strong", "ms_per_step": step_ms, "rows_rank0": N,
+                "n_gpus": world, "scaling": "strong", "ms_per_step": step_ms, "rows_rank0": N, "steps": K, "warmup": W,
                 "kernel_avg_ms": avg, "kernel_min_ms": best, "python_wrapper_ms": wavg,
                 "roofline": {"bound": "hbm", "achieved": 224.0 * N / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": 224.0 * N / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": 224 * N,
@@ -357,8 +382,9 @@ def main():
             def run_local():
                 with sb.ik_rows():
                     res["out"] = ets.ik_LM(Tl, seed=2)
-            K = max(3, args.steps // 4)
-            elapsed, dev_ms = rk.timed_steps(run_local, K, 1)
+            w_s, k_s = sustained_counts(run_local)
+            K, W = max(3, args.steps // 4, int(rk.max_over_ranks(k_s))), max(1, int(rk.max_over_ranks(w_s)))
+            elapsed, dev_ms = rk.timed_steps(run_local, K, W)
             _, ok, it, _, _ = res["out"]
             solved, iters = rk.sum_over_ranks(float(ok.sum())), rk.sum_over_ranks(float(it.sum()))
             step_s = elapsed / K

@@ -261,3 +261,39 @@ def rocprof_committed(root, kernel_substr="k_kin_reg<7, true, true"):
         except Exception:
             continue
     return None
+
+
+def sustained_counts(step, warm_ms=30.0, timed_ms=30.0, least=5):
+    """(warm-up launches, timed launches) so that `step` runs for >= warm_ms before anything is timed and the timed loop lasts >= timed_ms.
+    Why: the dense-fp64 kernels (k_rne, k_ik, the dynamics terms) draw > 1 kW; the first ~2 ms after an idle gap run at the boost clock
+    (2.06 GHz), then the power controller overshoots down to ~1.3 GHz and settles near 1.9 GHz over the next ~10 ms
+    (profiles/r04_rne_1e7.txt, GRBM_GUI_ACTIVE per launch).  A 10-20-launch measurement after a synchronise reads the transient, a 5-launch
+    one the boost; the sustained rate needs a warm-up longer than the transient."""
+    import torch
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    step()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(3):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    est = max(e0.elapsed_time(e1) / 3, 1e-3)
+    return max(least, int(warm_ms / est) + 1), max(least, int(timed_ms / est) + 1)
+
+
+def sustained_ms(step, warm_ms=30.0, timed_ms=30.0):
+    """Average device-side duration of `step` in the steady state: warm-up launches and timed launches back to back (no synchronise in
+    between -- an idle gap would hand the boost clock back), ONE HIP-event pair on the launch stream around the timed ones.  Returns
+    (average ms, timed launches, warm-up launches)."""
+    import torch
+    warm, reps = sustained_counts(step, warm_ms, timed_ms)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(warm):
+        step()
+    e0.record()
+    for _ in range(reps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps, reps, warm
