@@ -434,14 +434,19 @@ __global__ __launch_bounds__(256) void k_ik_merge_flat(int64_t N, int n, int chu
 
 namespace {
 int g_ik_flat = 1;        // flat schedule (ik_device.h): 0 never, 1 automatic (the batch is resident at once), 2 always (tests)
-int g_ik_flat_l0 = 4;     // searches in a target's first chunk ...
-int g_ik_flat_len = 8;    // ... and in every later one (measured on the MI355X, 1e5 Panda targets: 4 / 8 1.39 ms, 4 / 16 1.45, 8 / 16 1.42, 12 / 24 1.51; plain 1.55)
+int g_ik_flat_l0 = 0;     // searches in a target's first chunk: 0 = automatic -- 8 while the batch is at most 1.5 items per lane of the grid, else 4 ...
+int g_ik_flat_len = 8;    // ... and in every later one.  Round 4, SUSTAINED timing (scripts/ik_ab.py, profiles/r04_ik_ab.txt; round 3 had tuned these on
+                          // 3-launch bursts, i.e. on the boost clock): 1e5 Panda targets, fresh share 100 %: 8/8 1.103 ms, 8/12 1.105, 10/10 1.105, 6/8 1.114,
+                          // 4/8 1.138, 5/6 1.145; plain 1.36.  From ~2.5 items per lane up a short first chunk wins again (3e5 targets: 4/8 3.18, 8/8 3.29 ms)
 int g_ik_donate_after = 3;   // sharing: failed searches of a target before its range may be cut (rtbhip_tune "ik_donate_after")
 int g_ik_share = 0;       // cross-wave sharing of search ranges: 0 never, 1 automatic (batch resident at once), 2 always (tests)
 int g_ik_phased = 0;      // 0 never (default: the CPU replay and the GPU both say it loses), 1 automatic, 2 always (tests)
 int g_ik_spec_policy = 0;
-int g_ik_fresh_pct = 50;  // share of a wave's even part of the batch it may start per scheduling pass, in percent: the rest is
-                          // drawn as lanes fall idle, so quick waves take more (1e5 Panda targets: 1.60 ms at 100, 1.49-1.52 at 35-80)
+int g_ik_fresh_pct = 100; // share of a wave's even part of the batch it may start per scheduling pass, in percent: what is left is drawn as lanes
+                          // fall idle, so quick waves take more.  Sustained, flat 4/8, 1e5 Panda targets: 25 % 1.35 ms, 50 % 1.194 (the round-3
+                          // default, chosen on burst timings of the plain schedule), 75 % 1.166, 90-100 % 1.138, 110 % 1.17 (with 8/8: 1.103 at
+                          // 90-100 %, 1.138 at 110 %); 2e4 targets 0.795 -> 0.63, notebook setting 0.43 -> 0.38; no effect from ~2.6e5 targets up
+                          // (the per-pass cap is 64 either way)
 int g_ik_unit_we = 1;          // rtbhip_tune("ik_unit_we", 0): the weighted LM step even for a mask of ones (A/B)
 int g_ik_waves_per_cu = 8;
 int g_ik_pass_mask = 3;   // measured on MI355X, 1e6 Panda targets: 8.20 (0) / 7.75 (1) / 7.66 (3) / 8.08 ms (7)
@@ -456,7 +461,7 @@ void ik_tune(const char *key, int value)
     if (std::string(key) == "ik_unit_we") g_ik_unit_we = value != 0;
     if (std::string(key) == "ik_waves_per_cu") g_ik_waves_per_cu = value < 1 ? 1 : value;
     if (std::string(key) == "ik_flat") g_ik_flat = value < 0 ? 0 : (value > 2 ? 2 : value);
-    if (std::string(key) == "ik_flat_l0") g_ik_flat_l0 = value < 1 ? 1 : value;
+    if (std::string(key) == "ik_flat_l0") g_ik_flat_l0 = value < 0 ? 0 : value;      // 0 = automatic
     if (std::string(key) == "ik_flat_len") g_ik_flat_len = value < 1 ? 1 : value;
     if (std::string(key) == "ik_pass_mask") g_ik_pass_mask = value < 0 ? 0 : value;
     if (std::string(key) == "ik_share") g_ik_share = value < 0 ? 0 : (value > 2 ? 2 : value);
@@ -656,7 +661,8 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
     // temporaries, a merge kernel folds each target's rows in chunk order.  rtbhip_tune("ik_flat", 0 / 1 / 2) = never / automatic (the
     // batch is resident at once: the regime in which a wave is stuck with the targets it drew) / always (tests).
     {
-        const IkFlatPlan fp = ik_flat_plan(p, g_ik_flat_l0, g_ik_flat_len);
+        const int l0_auto = 2 * N <= 3 * gmax * kWave ? 8 : 4;
+        const IkFlatPlan fp = ik_flat_plan(p, g_ik_flat_l0 > 0 ? g_ik_flat_l0 : l0_auto, g_ik_flat_len);
         const bool flat_fits = fp.chunks > 1 && fp.chunks < 250 && (long long)N * fp.chunks < (1ll << 32) - 4096 && ik_aux_served(p, n, false);
         // automatic: the batch is resident at once (a wave cannot trade targets) AND large enough that waves hold several targets each -- below
         // that a wave's 64 lanes already serve its one or two targets' searches in parallel and the temporaries would only add latency

@@ -630,12 +630,12 @@ def test_ik_cross_wave_sharing_and_phased_schedule_equal_plain(flavour):
         try:
             rtbhip.tune("ik_share", 0); rtbhip.tune("ik_phased", 0); rtbhip.tune("ik_flat", 0)
             base = [x.cpu().numpy() for x in run()]
-            for l0, length in ((4, 8), (1, 3), (7, 40)):              # the flat schedule, three cuts of the search range
+            for l0, length in ((4, 8), (8, 8), (1, 3), (7, 40)):      # the flat schedule, four cuts of the search range
                 rtbhip.tune("ik_flat", 2); rtbhip.tune("ik_flat_l0", l0); rtbhip.tune("ik_flat_len", length)
                 flat = [x.cpu().numpy() for x in run()]
                 for a, b in zip(base, flat):
                     nt.assert_array_equal(a, b)
-            rtbhip.tune("ik_flat", 0); rtbhip.tune("ik_flat_l0", 4); rtbhip.tune("ik_flat_len", 8)
+            rtbhip.tune("ik_flat", 0); rtbhip.tune("ik_flat_l0", 0); rtbhip.tune("ik_flat_len", 8)
             rtbhip.tune("ik_share", 2)
             shared = [x.cpu().numpy() for x in run()]
             rtbhip.tune("ik_donate_after", 0)                     # ranges cut as soon as a wave waits, not after three failures
@@ -645,7 +645,7 @@ def test_ik_cross_wave_sharing_and_phased_schedule_equal_plain(flavour):
             phased = [x.cpu().numpy() for x in run()]
         finally:
             rtbhip.tune("ik_share", 0); rtbhip.tune("ik_phased", 0); rtbhip.tune("ik_donate_after", 3)
-            rtbhip.tune("ik_flat", 1); rtbhip.tune("ik_flat_l0", 4); rtbhip.tune("ik_flat_len", 8)
+            rtbhip.tune("ik_flat", 1); rtbhip.tune("ik_flat_l0", 0); rtbhip.tune("ik_flat_len", 8)          # the defaults (l0 0 = automatic)
         for a, b, b0, c in zip(base, shared, shared0, phased):
             nt.assert_array_equal(a, b)
             nt.assert_array_equal(a, b0)
