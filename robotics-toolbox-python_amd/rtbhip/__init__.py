@@ -6,7 +6,7 @@ Only the hot path named in BASELINE.json / SURVEY.md section 8 is here:
   DHLink / DHRobot    fkine, jacob0/e, rne, gravload, itorque, inertia, coriolis, accel (+ the ETS pass-throughs)
   Link / ERobot       ETS robots (link trees): rne, and the RobotKinematics surface over ets(start, end)
   PoERevolute / PoEPrismatic / PoERobot   product-of-exponentials robots: twists lowered to the same chain form
-  urdf                plain-URDF loader + the reference's URDF -> ETS lowering, 20 pre-expanded robot descriptions
+  urdf / xacro        URDF loader + the reference's URDF -> ETS lowering; xacro expander (stdlib only); 20 pre-expanded robot descriptions
   angle_axis / p_servo / hessian_from_jacobian    the exports of the extension module that take finished matrices
   compat.fknm / compat.frne   plug-in modules with the reference extension modules' own function tables
   fleet_fkine_jacob   many different chains in one call;  ShardedBatch / shard_range  one row block per GPU rank
@@ -23,9 +23,10 @@ from .poe import PoELink, PoERevolute, PoEPrismatic, PoERobot  # noqa: F401
 from .kinematics import RobotKinematics  # noqa: F401
 from . import models  # noqa: F401
 from . import urdf  # noqa: F401
+from . import xacro  # noqa: F401
 from .fleet import fleet_fkine_jacob  # noqa: F401
 from .shard import ShardedBatch  # noqa: F401
 
 __all__ = ["ET", "ETS", "IKSolution", "IKSolver", "IK_NR", "IK_GN", "IK_LM", "IK_QP", "angle_axis", "angle_axis_python", "p_servo", "hessian_from_jacobian", "manipulability_from_jacobian", "jacobm_from_jacobian", "DHLink", "DHRobot", "RevoluteDH", "PrismaticDH", "RevoluteMDH",
-           "PrismaticMDH", "Link", "ERobot", "PoELink", "PoERevolute", "PoEPrismatic", "PoERobot", "RobotKinematics", "models", "urdf", "fleet_fkine_jacob", "ShardedBatch", "RtbHipError", "lib",
+           "PrismaticMDH", "Link", "ERobot", "PoELink", "PoERevolute", "PoEPrismatic", "PoERobot", "RobotKinematics", "models", "urdf", "xacro", "fleet_fkine_jacob", "ShardedBatch", "RtbHipError", "lib",
            "device_count", "tune", "shard_range", "last_launch", "ik_target_base", "trim"]

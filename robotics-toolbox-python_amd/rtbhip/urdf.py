@@ -388,7 +388,8 @@ def loadstr(urdf_string, **kw):
 
 # The robot descriptions the reference names relative to its data package (rtb-data/rtbdata/xacro/<path>, what models/URDF/<name>.py hand to
 # Robot.URDF_read) -> the kinematic URDF of the same robot shipped here (expanded offline by scripts/make_urdf_data.py with the reference's own
-# xacro tool: the data package and run-time xacro processing are not part of this backend).
+# xacro tool): the data package itself is not part of this backend, so these names work without it.  A file that IS on disk is read at run
+# time, xacro included (rtbhip.xacro).
 REFERENCE_PATHS = {
     "al5d_description/urdf/al5d_robot.urdf": "AL5D", "fetch_description/robots/fetch.urdf": "Fetch",
     "kortex_description/robots/gen3.xacro": "KinovaGen3", "kuka_description/kuka_lbr_iiwa/urdf/lbr_iiwa_14_r820.xacro": "LBR",
@@ -400,15 +401,16 @@ REFERENCE_PATHS = {
 }
 
 
-def read(file_path, **kw):
-    """The URDF file at `file_path` as a URDFRobot (the reader behind Robot.URDF, robot/Robot.py:218-330).  A path that exists is read as it
-    is (plain URDF; a .xacro file is refused: expand it first); a path the reference resolves inside its data package
-    ("fetch_description/robots/fetch.urdf", REFERENCE_PATHS) gives the shipped description of that robot."""
+def read(file_path, mappings=None, packages=None, **kw):
+    """The robot description at `file_path` as a URDFRobot (the reader behind Robot.URDF, robot/Robot.py:218-330).  A path that exists is read:
+    plain URDF as it is, a `.xacro` file through rtbhip.xacro (`mappings`: values for its xacro:arg's, `packages`: where `$(find pkg)` looks;
+    robot/Robot.py:262-275 does the same with the reference's bundled tool).  A path the reference resolves inside its data package
+    ("fetch_description/robots/fetch.urdf", REFERENCE_PATHS) that is not on disk gives the shipped description of that robot."""
     path = os.fspath(file_path)
     if os.path.isfile(path):
         if path.endswith(".xacro"):
-            raise ValueError("%s: xacro is not processed at run time by this backend; expand it to plain URDF first "
-                             "(scripts/make_urdf_data.py shows how, with the reference's own xacro tool)" % path)
+            from . import xacro
+            return URDFRobot(xacro.process(path, mappings=mappings, packages=packages), **kw)
         with open(path) as f:
             return URDFRobot(f.read(), **kw)
     key = path.replace(os.sep, "/").lstrip("./")

@@ -28,6 +28,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 REF_TESTS = "/root/reference/tests"
+REF_ROOT = "/root/reference"
 
 
 def literal(fname, func, var, nth=0):
@@ -161,7 +162,23 @@ def python_ik():
     print("wrote ref_python_ik.npz with", len(out), "arrays,", os.path.getsize(path), "bytes")
 
 
+def xacro_golden():
+    """tests/golden/xacro/demo_arm.expected.urdf: the synthetic description of tests/golden/xacro (written for this repository) expanded by the
+    REFERENCE's own xacro tool (tools/xacro/__init__.py, stdlib only) -- what rtbhip.xacro must reproduce element for element."""
+    from pathlib import PurePosixPath
+    sys.path.append(os.path.join(REF_ROOT, "src", "roboticstoolbox", "tools"))      # appended: the folder also holds a types.py
+    import xacro
+    src = PurePosixPath(os.path.join(HERE, "xacro", "demo_description", "urdf", "demo_arm.urdf.xacro"))
+    out = xacro.main(src, None)
+    dst = os.path.join(HERE, "xacro", "demo_arm.expected.urdf")
+    open(dst, "w").write(out)
+    print("wrote", dst, len(out), "bytes")
+
+
 def main():
+    if sys.argv[1:] == ["xacro"]:
+        xacro_golden()
+        return
     if sys.argv[1:] == ["python_ik"]:
         return python_ik()
     lit = {}
