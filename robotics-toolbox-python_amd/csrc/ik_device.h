@@ -22,6 +22,19 @@
 #include "ldl.h"
 #include "diff_device.h"
 
+// Two compile-time A/B switches, measured against each other on one box in the steady state (round 4 visit h, scripts/gpu_r4_h.sh: four builds,
+// three interleaved rounds; (success, iterations, searches) of all 1e5 / 1e6 targets identical in every build):
+//                              config 3 (1e5)          notebook setting       1e6 targets
+//   neither                    1.105 1.098 1.102 ms    0.380 0.381 0.382      6.13 6.10 6.17
+//   RTB_IK_FAST_RCP only       1.082 1.085 1.082       0.375 0.374 0.375      6.02 6.00 6.08       <- shipped (-1.7 %)
+//   RTB_IK_FMOD_FMA only       1.120 1.117 1.112       0.382 0.382 0.381      6.25 6.09 6.20       (+1.3 %: fewer instructions per wrap, but the
+//   both                       1.102 1.099 1.099       0.376 0.374 0.375      6.12 6.22 6.19        extra branch lengthens the scheduling pass)
+#ifndef RTB_IK_FAST_RCP
+#define RTB_IK_FAST_RCP 1       // the LM step's seven pivot reciprocals through rcp_pivot (ldl.h): ~60 VALU instructions of 1633 per iteration
+#endif
+#ifndef RTB_IK_FMOD_FMA
+#define RTB_IK_FMOD_FMA 0       // 1: the end-of-search wrap through an exact FMA remainder instead of the library fmod (ik_fmod_2pi, below)
+#endif
 #ifndef RTB_IK_UNITW
 #define RTB_IK_UNITW 0          // 1: a second, multiplication-free copy of the LM step for a mask of ones.  Measured (round 3, visit y, four builds on
 #endif                          // one box): the copy costs 30 VGPRs (223 -> 256 + scratch) and 4-8 % of every IK line; the 48 products it saves do not pay
@@ -140,7 +153,7 @@ RTB_HD void ik_lm_step(const double (&jac)[6 * NJ], const double (&e)[6], W we /
         }
     }
     sched_fence();   // J is dead from here on: do not let the factorisation overlap the products above
-    ldl_solve<NJ>(A, g, dq);
+    ldl_solve<NJ, RTB_IK_FAST_RCP != 0>(A, g, dq);
 }
 
 // ---------------------------------------------------------------- Gauss-Newton / Newton-Raphson steps
@@ -416,10 +429,28 @@ RTB_HD void ik_search_begin(IkLane<NJ> &st, QA qa, const PD &p, QL qlim, int64_t
     st.status = kIkRun;
 }
 
-RTB_HD double ik_wrap_c(double q) { return fmod(q + kIkPi, kIkPi2) - kIkPi; }        // ik.cpp:51
-RTB_HD double ik_wrap_py(double q)                                                      // IK.py:331
+// fmod(x, 2 pi) for the wrap at the end of a search, EXACT like the library's: with c = fl(2 pi) and n = the integer nearest to x / c, the
+// remainder r = x - n c is a multiple of 2^-50 of magnitude < 4 and therefore a double, so ONE fused multiply-add returns it without error
+// (an n that lands on the wrong side of a tie still gives |r| <= c / 2); fmod's result -- the remainder with the sign of x -- is r or r +- c,
+// again exact because fmod's own result is representable.  ~10 instructions against the library routine's ~35 (a bit-serial reduction loop);
+// seven of them per scheduling pass.  Beyond |x| = 2^40 (a diverged search) or for a non-finite x the library routine decides.
+RTB_HD double ik_fmod_2pi(double x)
 {
-    double r = fmod(q + kIkPi, 2 * kIkPi);
+#if RTB_IK_FMOD_FMA
+    if (fabs(x) < 1099511627776.0) {
+        const double n = rint(x * 0.15915494309189535);        // fl(1 / (2 pi))
+        double r = fma(-n, kIkPi2, x);
+        if (x >= 0.0) { if (r < 0.0) r += kIkPi2; }
+        else if (r > 0.0) r -= kIkPi2;
+        return r;
+    }
+#endif
+    return fmod(x, kIkPi2);
+}
+RTB_HD double ik_wrap_c(double q) { return ik_fmod_2pi(q + kIkPi) - kIkPi; }        // ik.cpp:51
+RTB_HD double ik_wrap_py(double q)                                                      // IK.py:331 (2 * fl(pi) == fl(2 pi): the same modulus)
+{
+    double r = ik_fmod_2pi(q + kIkPi);
     if (r < 0) r += 2 * kIkPi;
     return r - kIkPi;
 }
@@ -617,7 +648,7 @@ RTB_HD void ik_emit(const IkLane<NJ> &st, QA qa, const PD &p, QL qlim, int64_t t
 #endif
 constexpr int kIkRing = RTB_IK_RING;        // outstanding (unaccounted) searches per slot (a power of two)
 template <int QR>
-struct IkWaveSharedT {
+struct alignas(16) IkWaveSharedT {
     uint32_t vix[64];                       // work-item index = output row (the target itself without a work list; < 2^32)
     uint32_t tgt[64];                       // target index of the slot's item (E of an item's last search lives in residual[row])
     int16_t b[64];                          // lowest search index not yet accounted (slimit <= 32000)
@@ -735,6 +766,14 @@ RTB_HD void ik_finalize(IkLane<NJ> &st, SH &sh, int lane, const PD &p, QL qlim, 
     }
 }
 
+// a slot's ring of search records back to "nothing finished": 16-byte stores (the row is 2 * kIkRing bytes, 16-byte aligned inside the wave's
+// LDS block) instead of kIkRing 2-byte ones -- the loop runs for the whole wave whenever one lane starts a work item
+RTB_HD void ik_clear_ring(uint16_t (&row)[kIkRing])
+{
+    static_assert((kIkRing * sizeof(uint16_t)) % 16 == 0, "ring row must be a whole number of 16-byte pieces");
+    __builtin_memset(__builtin_assume_aligned(&row[0], 16), 0, sizeof(row));
+}
+
 // phase D1 helper: initialise slot `slot` for target tgt and start its first search in this lane
 template <int NJ, class SH, class PD, class QL>
 RTB_HD void ik_start_target(IkLane<NJ> &st, SH &sh, int lane, const PD &p, QL qlim, int slot, int64_t v, IkWork w,
@@ -745,7 +784,7 @@ RTB_HD void ik_start_target(IkLane<NJ> &st, SH &sh, int lane, const PD &p, QL ql
     sh.vix[slot] = (uint32_t)v; sh.tgt[slot] = (uint32_t)tgt; sh.b[slot] = (int16_t)s0; sh.next[slot] = s0 + 1; sh.best[slot] = kIkNoBest; sh.it[slot] = 0;
     sh.slast[slot] = w.s1;
     sh.res[slot] = 0;
-    for (int k = 0; k < kIkRing; ++k) sh.rec[slot][k] = 0;
+    ik_clear_ring(sh.rec[slot]);
     st.slot = slot;
     ik_load_target([&](int k, double v) { sh.Td[k][slot] = v; }, Tep + 16 * tgt);   // once per target, not per search
     ik_search_begin<NJ>(st, ik_lds_q(sh, lane), p, qlim, tgt, s0, p.has_q0 ? q0 + (int64_t)NJ * tgt : nullptr);

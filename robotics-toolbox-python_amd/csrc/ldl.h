@@ -8,8 +8,25 @@
 
 namespace rtbhip {
 
+// 1 / d for a pivot of an SPD factorisation: the hardware estimate (v_rcp_f64) and two Newton steps -- 5 instructions, within an ulp or two of
+// the quotient -- instead of the correctly rounded division's ~14 (v_div_scale x2, v_rcp, the refinement chain, v_div_fmas, v_div_fixup).  The
+// pivots of J^T W J + wn I are ordinary numbers (no denormals, no overflow to guard), and a pivot's reciprocal feeds products that are rounded
+// again anyway.  d = 0 / inf / NaN still yield a non-finite result.  On the host (tests/emu) it is the plain quotient.
+RTB_HD double rcp_pivot(double d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rcp(d);
+    y = fma(fma(-d, y, 1.0), y, y);
+    y = fma(fma(-d, y, 1.0), y, y);
+    return y;
+#else
+    return 1.0 / d;
+#endif
+}
+
 // A: lower triangle read; on return holds L (unit diagonal implied) with 1/d_j in dinv and d_j in dval.
-template <int N>
+// FAST: the pivots' reciprocals through rcp_pivot (the LM step of k_ik, where the solve is a fifth of every iteration).
+template <int N, bool FAST = false>
 RTB_HD void ldl_factor(double (&A)[N][N], double (&dval)[N], double (&dinv)[N])
 {
 #pragma unroll
@@ -18,7 +35,7 @@ RTB_HD void ldl_factor(double (&A)[N][N], double (&dval)[N], double (&dinv)[N])
 #pragma unroll
         for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k] * dval[k];
         dval[j] = d;
-        dinv[j] = 1.0 / d;
+        dinv[j] = FAST ? rcp_pivot(d) : 1.0 / d;
 #pragma unroll
         for (int i = j + 1; i < N; ++i) {
             double v = A[i][j];
@@ -52,11 +69,11 @@ RTB_HD void ldl_backsolve(const double (&A)[N][N], const double (&dinv)[N], doub
 }
 
 // A: lower triangle read (destroyed: holds L afterwards); g: right-hand side (destroyed); x: solution.
-template <int N>
+template <int N, bool FAST = false>
 RTB_HD void ldl_solve(double (&A)[N][N], double (&g)[N], double (&x)[N])
 {
     double dval[N], dinv[N];
-    ldl_factor<N>(A, dval, dinv);
+    ldl_factor<N, FAST>(A, dval, dinv);
     ldl_backsolve<N>(A, dinv, g, x);
 }
 
