@@ -462,7 +462,10 @@ RTB_HD double ik_wrap_py(double q)                                              
 // STEP bit 1: the Python solvers' null-space motion is added to the step.  Compile-time choices so that no kernel
 // carries another's step in its register budget.
 constexpr int kIkStepPinv = 1, kIkStepNull = 2;
-template <int NJ, int STEP, class PD, class CV, class QL, class TD, class QA>
+// UNITW (compile-time, LM steps only): the mask is all ones -- W J, W e and e^T W e need no products.  The same bits (x * 1.0 == x), 54
+// multiplies fewer per iteration; as a run-time switch inside one kernel it cost 30 VGPRs (round 3), as a kernel instantiation it costs nothing.
+// PLAIN (compile-time): an all-revolute chain without flipped joints -- reg_core<..., PLAIN> (kin_reg.h).
+template <int NJ, int STEP, bool UNITW = false, bool PLAIN = false, class PD, class CV, class QL, class TD, class QA>
 RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, QA qa)
 {
     constexpr bool PINV = (STEP & kIkStepPinv) != 0, NULLSP = (STEP & kIkStepNull) != 0 && NJ >= 6;
@@ -477,13 +480,13 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, Q
             q_finite = q_finite && __builtin_isfinite(qv[j]);
         }
         // the chain's last constant C_n (no tool in IK) is segment NJ of the table: {r[9], t[3]} contiguous
-        reg_core<NJ, true>(cv, &cv.seg[NJ].r[0], 0, qv, P, jac);   // ik.cpp:44,56 / IK.py:994,1009
+        reg_core<NJ, true, PLAIN>(cv, &cv.seg[NJ].r[0], 0, qv, P, jac);   // ik.cpp:44,56 / IK.py:994,1009
     }
     sched_fence();
     ik_angle_axis(P, td, e);
     double E = 0.0;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) E += e[k] * p.we[k] * e[k];
+    for (int k = 0; k < 6; ++k) E += (UNITW && !PINV) ? e[k] * e[k] : e[k] * p.we[k] * e[k];
     E *= 0.5;                                                   // ik.cpp:46
     double qn[NULLSP ? NJ : 1];
     if constexpr (NULLSP) {
@@ -523,7 +526,8 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, Q
         if (!qp_done) ik_pinv_step<NJ>(jac, e, rows, d2, &p.we[0], p.method == 3, dq);
     } else {
         const double wn = (p.method == 1) ? p.lambda : (p.method == 2) ? E + p.lambda : p.lambda * E;   // ik.cpp:169,183,205
-        if (RTB_IK_UNITW && p.unit_we) ik_lm_step<NJ, true>(jac, e, &p.we[0], wn, dq);          // wave-uniform
+        if constexpr (UNITW) ik_lm_step<NJ, true>(jac, e, &p.we[0], wn, dq);
+        else if (RTB_IK_UNITW && p.unit_we) ik_lm_step<NJ, true>(jac, e, &p.we[0], wn, dq);          // wave-uniform
         else ik_lm_step<NJ, false>(jac, e, &p.we[0], wn, dq);
     }
     if constexpr (NULLSP) {

@@ -60,7 +60,8 @@ constexpr int kIkNullMax = 12;   // null-space step variants: 6..8 joints in reg
 #endif
 // AUX: bit 0 = the flat schedule, bit 1 = the per-wave diagnostic counters (RTBHIP_IK_STATS).  Compile-time, because carrying either through the
 // persistent loop as run-time switches cost the plain schedule 6-9 % (20 VGPRs; round 3, visit x: the round-2 build against this one on one box).
-constexpr int kIkAuxFlat = 1, kIkAuxStats = 2;
+constexpr int kIkAuxFlat = 1, kIkAuxStats = 2, kIkAuxUnitW = 4;      // bit 2: every mask weight is 1 (the default), LM steps: ik_iter<..., UNITW>
+constexpr int kIkAuxPlain = 8;                                         // bit 3: all-revolute chain, no flipped joint: ik_iter<..., PLAIN>
 template <int NJ, int STEP, int AUX = 0>
 __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull) ? RTB_IK_WAVES : 1)) void k_ik(IkDev p, DevChain dc, const double *qlim_g, const double *__restrict__ Tep,
                                                 const double *__restrict__ q0, unsigned long long *counter,
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
             asm volatile("" : "+s"(cvi.seg), "+s"(cvi.jmeta), "+s"(ql));
             const int myslot = st.slot;
             if constexpr (kStats) { ++st_iters; st_lane += (unsigned long long)__popcll(__ballot(st.status == kIkRun && !st.fin)); }
-            ik_iter<NJ, STEP>(st, ka->p, cvi, ql, [&](int k) { return sh.Td[k][myslot]; }, ik_lds_q(sh, lane));
+            ik_iter<NJ, STEP, (AUX & kIkAuxUnitW) != 0 && STEP == 0, (AUX & kIkAuxPlain) != 0>(st, ka->p, cvi, ql, [&](int k) { return sh.Td[k][myslot]; }, ik_lds_q(sh, lane));
         }
     }
     if (kStats && ka->p.stats && lane == 0) {
@@ -448,6 +449,7 @@ int g_ik_fresh_pct = 100; // share of a wave's even part of the batch it may sta
                           // 90-100 %, 1.138 at 110 %); 2e4 targets 0.795 -> 0.63, notebook setting 0.43 -> 0.38; no effect from ~2.6e5 targets up
                           // (the per-pass cap is 64 either way)
 int g_ik_unit_we = 1;          // rtbhip_tune("ik_unit_we", 0): the weighted LM step even for a mask of ones (A/B)
+int g_ik_plain = 1;            // rtbhip_tune("ik_plain", 0): the general FK + Jacobian walk even for an all-revolute chain without flips (A/B)
 int g_ik_waves_per_cu = 8;
 int g_ik_pass_mask = 3;   // measured on MI355X, 1e6 Panda targets: 8.20 (0) / 7.75 (1) / 7.66 (3) / 8.08 ms (7)
 std::mutex g_ctr_mu;
@@ -459,6 +461,7 @@ constexpr int kCtrRing = 256;
 void ik_tune(const char *key, int value)
 {
     if (std::string(key) == "ik_unit_we") g_ik_unit_we = value != 0;
+    if (std::string(key) == "ik_plain") g_ik_plain = value != 0;
     if (std::string(key) == "ik_waves_per_cu") g_ik_waves_per_cu = value < 1 ? 1 : value;
     if (std::string(key) == "ik_flat") g_ik_flat = value < 0 ? 0 : (value > 2 ? 2 : value);
     if (std::string(key) == "ik_flat_l0") g_ik_flat_l0 = value < 0 ? 0 : value;      // 0 = automatic
@@ -524,6 +527,17 @@ static void launch_nj(dim3 grid, hipStream_t s, const IkDev &p, const DevChain &
     if (v & kIkStepPinv) { hipLaunchKernelGGL((k_ik<NJ, 1>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share); return; }
     const bool flat = p.flat_chunks > 0, stats = p.stats != nullptr;       // launch_ik offers these only where they are instantiated (ik_aux_served)
     if constexpr (NJ <= kRegMaxJoints) {
+        // the default mask (all ones) has its own instantiations for the arms the register-resident kernel serves: no products with the weights
+        if (p.unit_we && !stats) {
+            if (p.pad_we /* plain chain */ && g_ik_plain) {
+                if (flat) hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxFlat | kIkAuxUnitW | kIkAuxPlain>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share);
+                else hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxUnitW | kIkAuxPlain>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share);
+                return;
+            }
+            if (flat) hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxFlat | kIkAuxUnitW>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share);
+            else hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxUnitW>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share);
+            return;
+        }
         if (flat && !stats) { hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxFlat>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share); return; }
     }
     if constexpr (NJ == 7) {                              // the counters: the benchmark's arm only
@@ -571,8 +585,9 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
     p.ilimit = ip.ilimit; p.slimit = ip.slimit; p.reject_jl = ip.reject_jl; p.method = ip.method;
     p.flavour = ip.flavour; p.has_q0 = q0 != nullptr; p.tol = ip.tol; p.lambda = ip.lambda;
     for (int k = 0; k < 6; ++k) p.we[k] = ip.we[k];
-    p.unit_we = g_ik_unit_we; p.pad_we = 0;
+    p.unit_we = g_ik_unit_we; p.pad_we = 1;
     for (int k = 0; k < 6; ++k) p.unit_we = p.unit_we && p.we[k] == 1.0;
+    for (int j = 0; j < c->n; ++j) p.pad_we = p.pad_we && !jm_prismatic(c->jmeta[j]) && !jm_flip(c->jmeta[j]);   // (launcher only) an all-revolute chain, no flips
     p.seed = ip.seed; p.target0 = ip.target0;
     p.N = N;
     p.kq = ip.kq; p.km = ip.km; p.ps = ip.ps; p.ks = ip.ks;

@@ -36,7 +36,9 @@ RTB_HD int reg_lds_doubles(int n)
 // Per-lane core: joint values qv[] (chain order, as the caller holds them) -> P = C_0 Z_0 ... tail and
 // the finished Jacobian in registers.  jac slot r*NJ + j : rows 0..2 = p_j, rows 3..5 = z_j until
 // the closing loop finishes them.  Used by the tile kernel (reg_compute) and by the IK loop.
-template <int NJ, bool WANT_J, class CV, class TL>
+// PLAIN (compile-time): every joint is revolute and none is flipped (the caller checked the chain's descriptors): no descriptor is read, no
+// wave-uniform branch splits the walk -- one straight-line block from the first sine to the last Jacobian column.
+template <int NJ, bool WANT_J, bool PLAIN = false, class CV, class TL>
 RTB_HD void reg_core(const CV &cv, TL tail /* tail[k], k = 0..11 */, int frame, const double (&qv)[NJ], Pose &P,
                      double (&jac)[6 * NJ])
 {
@@ -50,8 +52,8 @@ RTB_HD void reg_core(const CV &cv, TL tail /* tail[k], k = 0..11 */, int frame, 
     bool big = false;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {   // methods.cpp:363-366 for flip
-        jmv[j] = cv.jmeta[j];
-        d[j] = qv[j] * (jm_flip(jmv[j]) ? -1.0 : 1.0);
+        jmv[j] = PLAIN ? 0 : cv.jmeta[j];
+        d[j] = PLAIN ? qv[j] : qv[j] * (jm_flip(jmv[j]) ? -1.0 : 1.0);
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {   // NJ independent evaluations, one basic block

@@ -25,10 +25,35 @@ RTB_HD double rcp_pivot(double d)
 }
 
 // A: lower triangle read; on return holds L (unit diagonal implied) with 1/d_j in dinv and d_j in dval.
-// FAST: the pivots' reciprocals through rcp_pivot (the LM step of k_ik, where the solve is a fifth of every iteration).
+// FAST (the LM step of k_ik, where the solve is a fifth of every iteration): the pivots' reciprocals through rcp_pivot, and the products
+// L_jk d_k of the textbook recurrence  d_j = a_jj - sum_k L_jk^2 d_k,  L_ij d_j = a_ij - sum_k L_ik L_jk d_k  are not re-formed term by term:
+// u_jk = L_jk d_k is the value the recurrence holds BEFORE it divides by the pivot, so it is kept (in the unused upper triangle, A[k][j]) and
+// every term is one fused multiply-add on it -- 56 multiplies fewer for N = 7, and each u_jk exact where L_jk d_k was a rounded product.
+#ifndef RTB_LDL_KEEP_U
+#define RTB_LDL_KEEP_U 1
+#endif
 template <int N, bool FAST = false>
 RTB_HD void ldl_factor(double (&A)[N][N], double (&dval)[N], double (&dinv)[N])
 {
+    if constexpr (FAST && RTB_LDL_KEEP_U) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            double d = A[j][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) d -= A[j][k] * A[k][j];
+            dval[j] = d;
+            dinv[j] = rcp_pivot(d);
+#pragma unroll
+            for (int i = j + 1; i < N; ++i) {
+                double v = A[i][j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) v -= A[i][k] * A[k][j];
+                A[j][i] = v;                      // u_ij = L_ij d_j
+                A[i][j] = v * dinv[j];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         double d = A[j][j];

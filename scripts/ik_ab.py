@@ -15,7 +15,7 @@ from benchlib import sustained_ms
 
 # "shipped" = the ROUND-3 defaults (flat 4/8, fresh share 50 %): the baseline of these sweeps.  Round 4 ships fresh 100 %, first chunk automatic (8 / 4).
 DEFAULTS = {"ik_flat": 1, "ik_flat_l0": 4, "ik_flat_len": 8, "ik_waves_per_cu": 8, "ik_pass_mask": 3, "ik_fresh_pct": 50, "ik_spec_policy": 0, "ik_share": 0}
-ROUND4 = {"ik_flat_l0": 0, "ik_fresh_pct": 100}
+ROUND4 = {"ik_flat_l0": 0, "ik_fresh_pct": 100, "ik_unit_we": 1, "ik_plain": 1}
 VARIANTS = [("shipped", {}), ("plain", {"ik_flat": 0}), ("flat 4/16", {"ik_flat_len": 16}), ("flat 8/16", {"ik_flat_l0": 8, "ik_flat_len": 16}),
             ("flat 2/8", {"ik_flat_l0": 2}), ("flat 4/4", {"ik_flat_len": 4}), ("flat 6/8", {"ik_flat_l0": 6}), ("flat 3/6", {"ik_flat_l0": 3, "ik_flat_len": 6}),
             ("flat 4/8, 4 waves/CU", {"ik_waves_per_cu": 4}), ("flat 4/8, 6 waves/CU", {"ik_waves_per_cu": 6}), ("plain, 4 waves/CU", {"ik_flat": 0, "ik_waves_per_cu": 4}),
@@ -35,6 +35,10 @@ if os.environ.get("IK_AB_SET") == "5":
                 ("fresh 100, flat 8/12", {"ik_fresh_pct": 100, "ik_flat_l0": 8, "ik_flat_len": 12}), ("fresh 100, flat 10/8", {"ik_fresh_pct": 100, "ik_flat_l0": 10})]
 if os.environ.get("IK_AB_SET") == "6":          # what round 4 ships against what round 3 shipped
     VARIANTS = [("round-3 knobs", {}), ("round-4 knobs (fresh 100 %, first chunk automatic)", dict(ROUND4))]
+if os.environ.get("IK_AB_SET") == "7":          # unit-weight kernel instantiations against the weighted ones (same library)
+    DEFAULTS = dict(DEFAULTS, **ROUND4)
+    VARIANTS = [("weighted kernel (ik_unit_we = 0)", {"ik_unit_we": 0}), ("unit-weight kernel, general walk", {"ik_unit_we": 1, "ik_plain": 0}),
+                ("unit-weight kernel, plain-revolute walk", {"ik_unit_we": 1, "ik_plain": 1})]
 if os.environ.get("IK_AB_SET") == "3":          # other batch sizes / settings: does the candidate hold?
     VARIANTS = [("shipped", {}), ("fresh 100", {"ik_fresh_pct": 100}), ("fresh 100, flat 6/8", {"ik_fresh_pct": 100, "ik_flat_l0": 6}), ("fresh 140, flat 6/8", {"ik_fresh_pct": 140, "ik_flat_l0": 6})]
 
