@@ -79,24 +79,41 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
     for (int j = 0; j < NJ; ++j) sh.q[j][lane] = 0.0;
 #pragma unroll
     for (int k = 0; k < 12; ++k) sh.Td[k][lane] = (k == 0 || k == 4 || k == 8) ? 1.0 : 0.0;   // slot `lane`
-    unsigned long long busy = 0;     // wave-uniform: slots holding an unresolved target
-    bool exhausted = false;          // wave-uniform: the global supply of fresh targets has run out
-    bool drained = false;            // wave-uniform: the device-wide counter has passed N
-    unsigned long long pool_next = 0, pool_end = 0;   // wave-uniform: targets reserved by this wave and not started yet
-    unsigned long long pool_live = 0;                 // flat schedule, wave-uniform: bit k = item pool_next + k was drawn, is still worth starting and has not been started
+    // The scheduler's wave-uniform state -- which slots are busy, the wave's pool of reserved work, what it knows about the counter -- changes
+    // only inside a scheduling pass (every 4th iteration) but, as loop-carried scalars, was alive across the LM iteration as well, whose FK walk
+    // needs the whole scalar register file for the chain constants: the compiler parked ~70 SGPRs in VGPR lanes before the walk and fetched
+    // them back after it, every iteration (212 v_writelane / v_readlane of the 1486 VALU instructions of an iteration; round 4).  It lives in
+    // LDS now: a pass loads it, works on locals, decides whether the wave leaves, and stores it back; between passes nothing of it is live.
+    __shared__ struct {
+        unsigned long long busy;         // slots holding an unresolved target
+        unsigned long long pool_next, pool_end;   // targets reserved by this wave and not started yet
+        unsigned long long pool_live;    // flat schedule: bit k = item pool_next + k was drawn, is still worth starting and has not been started
+        unsigned long long pend_item;    // sharing: a range handed to this wave (ticket pend_tick of its queue), started at the next pass
+        unsigned long long NN;           // number of work items of this launch
+        unsigned pend_tick;
+        unsigned flags;                  // kWsExhausted | kWsDrained | kWsEvidence | kWsC0Out
+    } ws;
+    constexpr unsigned kWsExhausted = 1u;   // the global supply of fresh targets has run out
+    constexpr unsigned kWsDrained = 2u;     // the device-wide counter has passed N
+    constexpr unsigned kWsEvidence = 4u;    // flat schedule: one of this wave's own chunk-0 items has FAILED -- first chunks do fail in this batch
+    constexpr unsigned kWsC0Out = 8u;       // flat schedule: the device-wide counter has passed the chunk-0 numbers
+    auto ws_get64 = [](const unsigned long long &w) -> unsigned long long {      // a uniform LDS word into scalar registers
+        const unsigned long long v = w;
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    };
+    auto ws_get32 = [](const unsigned &w) -> unsigned { return (unsigned)__builtin_amdgcn_readfirstlane((int)w); };
     constexpr bool flat = (AUX & kIkAuxFlat) != 0;    // the launcher picks this instantiation exactly when p.flat_chunks > 0
     constexpr bool kStats = (AUX & kIkAuxStats) != 0;
-    bool evidence = false;                            // flat schedule, wave-uniform: one of this wave's own chunk-0 items has FAILED -- first chunks do fail in this batch
-    bool c0_out = false;                              // flat schedule, wave-uniform: the device-wide counter has passed the chunk-0 numbers
+    ws.busy = 0; ws.pool_next = 0; ws.pool_end = 0; ws.pool_live = 0; ws.pend_item = kIkNoItem; ws.pend_tick = 0; ws.flags = 0;
+    ws.NN = count_g ? (unsigned long long)*count_g : (unsigned long long)p.N;
+    __syncthreads();
     unsigned long long st_iters = 0, st_passes = 0, st_lane = 0, st_items = 0;   // diagnostics (p.stats), wave-uniform
     bool first = true;
     unsigned tick = 0;
+    int leave = 0;                    // set by a pass: 1 the wave is done, 2 out of work with sharing on (take a ticket and wait)
     const long long patience = ik_patience(p, s_last);    // watchdog budget (ik_device.h), the pass latency included
     long long quiet = 0;
-    const unsigned long long NN = count_g ? (unsigned long long)*count_g : (unsigned long long)p.N;   // wave-uniform
     const bool sharing = RTB_IK_SHARE && share_g.tc != nullptr;   // wave-uniform
-    unsigned long long pend_item = kIkNoItem;   // sharing, wave-uniform: a range handed to this wave (ticket pend_tick of its queue), started at the next pass
-    unsigned pend_tick = 0;
     for (;;) {
         asm volatile("" : "+s"(ka));
         // the scheduling pass runs when some search has ended -- at most every (pass_mask + 1)-th iteration: a
@@ -105,6 +122,12 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
         if (first || ((tick++ & ka->p.pass_mask) == 0 && __any(st.fin != 0))) {
             first = false;
             if constexpr (kStats) ++st_passes;
+            unsigned long long busy = ws_get64(ws.busy), pool_next = ws_get64(ws.pool_next), pool_end = ws_get64(ws.pool_end), pool_live = ws_get64(ws.pool_live);
+            unsigned long long pend_item = ws_get64(ws.pend_item);
+            const unsigned long long NN = ws_get64(ws.NN);
+            const unsigned pend_tick = ws_get32(ws.pend_tick);
+            const unsigned wsf = ws_get32(ws.flags);
+            bool exhausted = (wsf & kWsExhausted) != 0, drained = (wsf & kWsDrained) != 0, evidence = (wsf & kWsEvidence) != 0, c0_out = (wsf & kWsC0Out) != 0;
             const RTB_CONST IkDev &p = ka->p;      // shadows the by-value arguments for the whole pass
             const RTB_CONST double *qlim = (const RTB_CONST double *)ka->qlim;
             const double *Tep = ka->Tep, *q0 = ka->q0;
@@ -291,12 +314,20 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
                     }
                 }
             }
+        
+            // flat schedule: a wave without evidence leaves once the chunk-0 numbers are out.  Every later chunk that is NEEDED belongs to a target whose
+            // first chunk failed, and the wave that saw that failure has evidence and stays until the counter is drained -- it draws what is left
+            leave = 0;
+            if (flat && busy == 0 && !evidence && pool_live == 0 && c0_out) leave = 1;
+            else if (busy == 0 && exhausted && pend_item == kIkNoItem) leave = sharing ? 2 : 1;
+            __syncthreads();                  // every lane has read the state this pass started from
+            ws.busy = busy; ws.pool_next = pool_next; ws.pool_end = pool_end; ws.pool_live = pool_live; ws.pend_item = pend_item;
+            ws.flags = (exhausted ? kWsExhausted : 0u) | (drained ? kWsDrained : 0u) | (evidence ? kWsEvidence : 0u) | (c0_out ? kWsC0Out : 0u);
+            __syncthreads();
         }
-        // flat schedule: a wave without evidence leaves once the chunk-0 numbers are out.  Every later chunk that is NEEDED belongs to a target whose
-        // first chunk failed, and the wave that saw that failure has evidence and stays until the counter is drained -- it draws what is left
-        if (flat && busy == 0 && !evidence && pool_live == 0 && c0_out) break;
-        if (busy == 0 && exhausted && pend_item == kIkNoItem) {
-            if (!sharing) break;
+        if (leave == 1) break;
+        if (leave == 2) {
+            leave = 0;
             // sharing: out of work -- take a ticket, then wait on this ticket's own word for a range or for the EXIT mark
             const IkShareCtl shc = share_of(ka);
             const int g = (int)(blockIdx.x % kIkQueues);
@@ -337,7 +368,8 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
             lo = __shfl(lo, 0); hi = __shfl(hi, 0);
             const unsigned long long x = ((unsigned long long)hi << 32) | lo;
             if (x == kIkNoItem || x == kIkExitItem) break;
-            pend_item = x; pend_tick = t;
+            ws.pend_item = x; ws.pend_tick = t;
+            __syncthreads();
             first = true;                             // run a scheduling pass now: it starts the range
             continue;
         }
@@ -348,6 +380,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
             const double nan = __longlong_as_double(0x7ff8000000000000ll);
             double *q_out = ka->q_out, *residual = ka->residual;
             int32_t *success = ka->success, *iters = ka->iters, *searches = ka->searches;
+            const unsigned long long busy = ws.busy, pool_next = ws.pool_next, pool_end = ws.pool_end;
             if ((busy >> lane) & 1ull) {
                 const int64_t t = sh.vix[lane];
                 for (int j = 0; j < NJ; ++j) q_out[t * NJ + j] = nan;

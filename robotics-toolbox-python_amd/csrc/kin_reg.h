@@ -74,7 +74,11 @@ RTB_HD void reg_core(const CV &cv, TL tail /* tail[k], k = 0..11 */, int frame, 
         // revolute: rotate by (c, s); prismatic: slide d -- a wave-uniform branch on the joint descriptor (s_cbranch)
         if (jm_prismatic(jmv[j])) pose_tz(P, d[j]);
         else pose_rotz(P, c[j], s[j]);
+#if defined(RTB_PLAIN_FENCE_EVERY)
+        if (!PLAIN || (j % RTB_PLAIN_FENCE_EVERY) == RTB_PLAIN_FENCE_EVERY - 1) sched_fence();      // A/B: fewer fences in the straight-line walk
+#else
         sched_fence();
+#endif
     }
     pose_mul_general(P, [&](int k) { return tail[k]; });
     sched_fence();
