@@ -22,7 +22,9 @@ namespace rtbhip {
 struct ConstChainIk {
     const RTB_CONST DevSeg *seg;
     const RTB_CONST int32_t *jmeta;
+    const RTB_CONST double *trig;       // kIkSincosTable, laundered with the other two once per iteration (trig.h: sincos_reduced_tab)
 };
+__constant__ double kIkSincosTable[kSincosTableLen] = RTB_SINCOS_TABLE_INIT;
 
 // The kernel's argument block, member for member.  Inside the persistent loop everything is read through a pointer to
 // the kernarg segment that is laundered once per iteration: as plain by-value arguments the eleven pointers and the
@@ -401,7 +403,8 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
             cvi.seg = (const RTB_CONST DevSeg *)ka->dc.seg;
             cvi.jmeta = (const RTB_CONST int32_t *)ka->dc.jmeta;
             const RTB_CONST double *ql = (const RTB_CONST double *)ka->qlim;
-            asm volatile("" : "+s"(cvi.seg), "+s"(cvi.jmeta), "+s"(ql));
+            cvi.trig = (const RTB_CONST double *)kIkSincosTable;
+            asm volatile("" : "+s"(cvi.seg), "+s"(cvi.jmeta), "+s"(ql), "+s"(cvi.trig));
             const int myslot = st.slot;
             if constexpr (kStats) { ++st_iters; st_lane += (unsigned long long)__popcll(__ballot(st.status == kIkRun && !st.fin)); }
             ik_iter<NJ, STEP, (AUX & kIkAuxUnitW) != 0 && STEP == 0, (AUX & kIkAuxPlain) != 0>(st, ka->p, cvi, ql, [&](int k) { return sh.Td[k][myslot]; }, ik_lds_q(sh, lane));

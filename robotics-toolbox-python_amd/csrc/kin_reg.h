@@ -36,6 +36,10 @@ RTB_HD int reg_lds_doubles(int n)
 // Per-lane core: joint values qv[] (chain order, as the caller holds them) -> P = C_0 Z_0 ... tail and
 // the finished Jacobian in registers.  jac slot r*NJ + j : rows 0..2 = p_j, rows 3..5 = z_j until
 // the closing loop finishes them.  Used by the tile kernel (reg_compute) and by the IK loop.
+// a chain view may carry a pointer to the sincos constants (k_ik: see sincos_reduced_tab in trig.h); the others use the literals
+template <class CV, class = void> struct cv_has_trig { static constexpr bool value = false; };
+template <class CV> struct cv_has_trig<CV, decltype((void)(((const CV *)nullptr)->trig))> { static constexpr bool value = true; };
+
 // PLAIN (compile-time): every joint is revolute and none is flipped (the caller checked the chain's descriptors): no descriptor is read, no
 // wave-uniform branch splits the walk -- one straight-line block from the first sine to the last Jacobian column.
 template <int NJ, bool WANT_J, bool PLAIN = false, class CV, class TL>
@@ -57,7 +61,8 @@ RTB_HD void reg_core(const CV &cv, TL tail /* tail[k], k = 0..11 */, int frame, 
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {   // NJ independent evaluations, one basic block
-        sincos_reduced(d[j], s[j], c[j]);
+        if constexpr (cv_has_trig<CV>::value) sincos_reduced_tab(d[j], s[j], c[j], cv.trig);
+        else sincos_reduced(d[j], s[j], c[j]);
         big = big || !(fabs(d[j]) < kTrigFastLimit);
     }
     if (wave_any(big)) {             // |q| >= 2^20, NaN, inf: library path for the whole wave

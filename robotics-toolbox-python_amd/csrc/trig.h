@@ -50,6 +50,44 @@ RTB_HD void sincos_reduced(double x, double &s, double &c)
     c = ((q + 1) & 2) ? -b : b;
 }
 
+// The same evaluation with its 16 constants read from a TABLE (kSincosTable's layout) instead of written as literals.  Why: inside a persistent
+// loop (k_ik) the compiler materialises the literals once, in ~30 SGPRs, outside the loop -- and, when the loop body needs the scalar file for
+// something else (the chain constants of the FK walk), parks them in VGPR lanes and fetches every one back with a v_readlane per iteration
+// (64 of them, round 4).  Read through a laundered constant-address-space pointer they arrive by s_load where they are used and are gone again.
+// Same operations in the same order as sincos_reduced: the same bits.
+constexpr int kSincosTableLen = 16;
+#define RTB_SINCOS_TABLE_INIT { 0x1.45f306dc9c883p-1, 0x1.921fb54442d18p+0, 0x1.1a62633145c07p-54, -0x1.f1976b7ed8fbcp-110, \
+    1.58969099521155010221e-10, -2.50507602534068634195e-08, 2.75573137070700676789e-06, -1.98412698298579493134e-04, \
+    8.33333333332248946124e-03, -1.66666666666666324348e-01, \
+    -1.13596475577881948265e-11, 2.08757232129817482790e-09, -2.75573143513906633035e-07, 2.48015872894767294178e-05, \
+    -1.38888888888741095749e-03, 4.16666666666666019037e-02 }
+template <class TAB>
+RTB_HD void sincos_reduced_tab(double x, double &s, double &c, TAB t)
+{
+    const double k = rint(x * t[0]);
+    double r = fma(-k, t[1], x);
+    r = fma(-k, t[2], r);
+    r = fma(-k, t[3], r);
+    const double z = r * r;
+    double ps = fma(z, t[4], t[5]);
+    ps = fma(z, ps, t[6]);
+    ps = fma(z, ps, t[7]);
+    ps = fma(z, ps, t[8]);
+    ps = fma(z, ps, t[9]);
+    const double sr = fma(r * z, ps, r);
+    double pc = fma(z, t[10], t[11]);
+    pc = fma(z, pc, t[12]);
+    pc = fma(z, pc, t[13]);
+    pc = fma(z, pc, t[14]);
+    pc = fma(z, pc, t[15]);
+    const double cr = fma(z * z, pc, fma(z, -0.5, 1.0));
+    const int q = (int)k & 3;
+    const double a = (q & 1) ? cr : sr;
+    const double b = (q & 1) ? sr : cr;
+    s = (q & 2) ? -a : a;
+    c = ((q + 1) & 2) ? -b : b;
+}
+
 // Keeps the machine scheduler from hoisting every segment's scalar loads to the top of the
 // straight-line walk (which overflows the 102 SGPRs and turns each constant operand into a pair of
 // v_readlane from a spill VGPR): loads of segment j+1 may overlap segment j, not run further ahead.

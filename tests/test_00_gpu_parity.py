@@ -653,6 +653,39 @@ def test_ik_cross_wave_sharing_and_phased_schedule_equal_plain(flavour):
         assert 0 < base[1].sum() < N
 
 
+def test_ik_kernel_specialisations_agree():
+    """The default mask (all ones) and an all-revolute chain without flips run their own kernel instantiations (no products with the weights;
+    a straight-line FK walk): same decisions, iterations and searches as the general kernels, q within the solver's own tolerance (a redundant
+    arm's solution moves by ~1e-7 along its null space under last-bit differences of the normal equations).  A weighted mask and a chain with a
+    prismatic joint must not be affected by the switches at all."""
+    ets, ch = _panda_limited()
+    rng = np.random.default_rng(91)
+    N = full_size(20000, 20)
+    Tep = oracle.fkine(ch, rng.uniform(ch.qlim[0], ch.qlim[1], (N, 7)))
+    outs = {}
+    try:
+        for u, pl in ((0, 0), (1, 0), (1, 1)):
+            rtbhip.tune("ik_unit_we", u); rtbhip.tune("ik_plain", pl)
+            outs[(u, pl)] = ets.ik_LM(Tep, seed=4)
+            outs[(u, pl, "mask")] = ets.ik_LM(Tep[:2000], seed=4, mask=[1, 1, 1, 0.5, 0.5, 0])
+    finally:
+        rtbhip.tune("ik_unit_we", 1); rtbhip.tune("ik_plain", 1)
+    base = outs[(0, 0)]
+    for key in ((1, 0), (1, 1)):
+        o = outs[key]
+        for k in (1, 2, 3):
+            nt.assert_array_equal(o[k], base[k])
+        ok = base[1] == 1
+        # q: the two kernels stop at the same iteration with E equal to ~1e-12, but a redundant arm's iterate may sit ~1e-6 apart along the
+        # null space (one target in 20000 does); what they must agree on is the pose they reach
+        assert np.abs(o[0][ok] - base[0][ok]).max() < 1e-5 and np.abs(o[4][ok] - base[4][ok]).max() < 1e-9
+        worst = np.argsort(np.abs(o[0] - base[0]).max(axis=1) * ok)[-50:]
+        assert np.abs(oracle.fkine(ch, o[0][worst]) - oracle.fkine(ch, base[0][worst])).max() < 1e-6
+        for a, b in zip(outs[key + ("mask",)], outs[(0, 0, "mask")]):
+            nt.assert_array_equal(a, b)                      # a weighted mask never takes the unit-weight kernels
+    assert 0.9 < base[1].mean() < 1.0
+
+
 def test_ik_qp_error_paths_and_batch_vs_oracle():
     """ETS.ikine_QP (IK_QP, robot/IK.py:1222-1520): the manipulability term / the joint-limit rows on a 5-joint arm and ps == pi
     are refused loudly; a UR5 batch on device tensors equals the restatement (the reference's matrices + an exact enumerating QP

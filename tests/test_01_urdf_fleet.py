@@ -189,7 +189,7 @@ def test_gpu_fleet_more_chains_than_one_launch_table_holds():
 def test_Robot_URDF_reads_a_file_and_folds_the_gripper(tmp_path):
     """Robot.URDF(file_path, gripper=) (robot/Robot.py:288-330).  The reference's own pins (tests/test_Robot.py:618-628): the Fetch with
     gripper = link 6 has 5 joints, with gripper = "forearm_roll_link" 7.  A path of the reference's data package resolves to the shipped
-    description; a file on disk is read as it is; xacro and unknown paths are refused."""
+    description; a file on disk is read as it is (xacro through rtbhip.xacro); unknown paths are refused."""
     r = rtbhip.ERobot.URDF("fetch_description/robots/fetch.urdf", gripper=6)
     assert r.n == 5
     r = rtbhip.ERobot.URDF("fetch_description/robots/fetch.urdf", gripper="forearm_roll_link")
@@ -211,10 +211,9 @@ def test_Robot_URDF_reads_a_file_and_folds_the_gripper(tmp_path):
         rtbhip.ERobot.URDF("fetch_description/robots/fetch.urdf", gripper=1.5)
     with pytest.raises(FileNotFoundError):
         rtbhip.ERobot.URDF("nowhere/robot.urdf")
-    x = tmp_path / "arm.urdf.xacro"
+    x = tmp_path / "arm.urdf.xacro"                      # an xacro file goes through rtbhip.xacro (tests/test_xacro.py); plain URDF is valid xacro
     x.write_text(src)
-    with pytest.raises(ValueError):
-        urdf.read(x)
+    assert urdf.read(x).n == u.n
 
 
 @pytest.mark.gpu
