@@ -36,6 +36,9 @@ RTB_HD int reg_lds_doubles(int n)
 // Per-lane core: joint values qv[] (chain order, as the caller holds them) -> P = C_0 Z_0 ... tail and
 // the finished Jacobian in registers.  jac slot r*NJ + j : rows 0..2 = p_j, rows 3..5 = z_j until
 // the closing loop finishes them.  Used by the tile kernel (reg_compute) and by the IK loop.
+#ifndef RTB_PIN_SEG_LOADS
+#define RTB_PIN_SEG_LOADS 1
+#endif
 // a chain view may carry a pointer to the sincos constants (k_ik: see sincos_reduced_tab in trig.h); the others use the literals
 template <class CV, class = void> struct cv_has_trig { static constexpr bool value = false; };
 template <class CV> struct cv_has_trig<CV, decltype((void)(((const CV *)nullptr)->trig))> { static constexpr bool value = true; };
@@ -71,7 +74,17 @@ RTB_HD void reg_core(const CV &cv, TL tail /* tail[k], k = 0..11 */, int frame, 
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__) && RTB_PIN_SEG_LOADS
+        // Inside k_ik's persistent loop (the chain views that carry `trig`): tie segment j's table pointer to a value of step j - 1, so that its
+        // scalar loads cannot be issued before the walk gets there.  Without this the loads of the later segments were issued early and their
+        // results parked in VGPR lanes (v_writelane) until needed (v_readlane): 475 -> 251 such instructions in the kernel, 253 -> 244 VGPRs,
+        // -2.4 % (config 3) ... -3.6 % (notebook setting) on one box (round 4 visit l).  RTB_PIN_SEG_LOADS = 2 pins the general (branchy) walk too.
+        CV cvj = cv;
+        if ((PLAIN || RTB_PIN_SEG_LOADS > 1) && cv_has_trig<CV>::value && j > 0) asm volatile("" : "+s"(cvj.seg), "+v"(P.tx));
+        if (j == 0) pose_from_seg(P, cvj, 0); else pose_mul_seg(P, cvj, j);
+#else
         if (j == 0) pose_from_seg(P, cv, 0); else pose_mul_seg(P, cv, j);
+#endif
         if (WANT_J) {
             jac[j] = P.tx; jac[NJ + j] = P.ty; jac[2 * NJ + j] = P.tz;
             jac[3 * NJ + j] = P.r02; jac[4 * NJ + j] = P.r12; jac[5 * NJ + j] = P.r22;
