@@ -123,6 +123,41 @@ RTB_HD void ik_angle_axis(const Pose &P, TD Td, double (&e)[6])
 
 // ---------------------------------------------------------------- one LM step
 // dq = (J^T W J + wn I)^-1 J^T W e, J in registers (slot r*NJ + j), W = diag(we).
+// The same step through the 6 x 6 system (unit weights, more joints than task dimensions):  (J^T J + wn 1)^-1 J^T e  =  J^T (J J^T + wn 1)^-1 e
+// for wn > 0 (push-through identity).  For the 7-joint arm: 21 entries of 7 products instead of 28 of 6, a 6 x 6 factorisation instead of a
+// 7 x 7 one -- 66 instructions fewer.  wn == 0 (a caller's k = 0) keeps the n x n form: there the reference inverts a singular matrix and the
+// two forms would disagree about the garbage.  MEASURED SLOWER and therefore off (round 4 visit o, one box, three interleaved rounds, sustained:
+// config 3 0.961 -> 1.004 ms, 1e6 targets 5.22 -> 5.52 ms): fewer instructions, but J must stay alive through the 6 x 6 solve for the final
+// J^T y, and the solve is one long dependent chain where the n x n form's right-hand side is formed alongside the matrix.  Kept as an A/B switch.
+#ifndef RTB_IK_DUAL
+#define RTB_IK_DUAL 0
+#endif
+template <int NJ>
+RTB_HD void ik_lm_step_dual(const double (&jac)[6 * NJ], const double (&e)[6], double wn, double (&dq)[NJ])
+{
+    double B[6][6], y[6], g[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        g[r] = e[r];
+#pragma unroll
+        for (int c = 0; c <= r; ++c) {
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < NJ; ++k) a += jac[r * NJ + k] * jac[c * NJ + k];
+            B[r][c] = (r == c) ? a + wn : a;
+        }
+    }
+    ldl_solve<6, RTB_IK_FAST_RCP != 0>(B, g, y);
+    sched_fence();
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) {
+        double a = 0.0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) a += jac[r * NJ + k] * y[r];
+        dq[k] = a;
+    }
+}
+
 template <int NJ, bool UNITW = false, class W>
 RTB_HD void ik_lm_step(const double (&jac)[6 * NJ], const double (&e)[6], W we /* we[k], k < 6 */, double wn,
                        double (&dq)[NJ])
@@ -526,7 +561,10 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, Q
         if (!qp_done) ik_pinv_step<NJ>(jac, e, rows, d2, &p.we[0], p.method == 3, dq);
     } else {
         const double wn = (p.method == 1) ? p.lambda : (p.method == 2) ? E + p.lambda : p.lambda * E;   // ik.cpp:169,183,205
-        if constexpr (UNITW) ik_lm_step<NJ, true>(jac, e, &p.we[0], wn, dq);
+        if constexpr (UNITW && RTB_IK_DUAL && NJ >= 7) {
+            if (p.lambda > 0.0 || p.method == 2) ik_lm_step_dual<NJ>(jac, e, wn, dq);      // wave-uniform; (sugihara: wn = E + lambda > 0 off the solution)
+            else ik_lm_step<NJ, true>(jac, e, &p.we[0], wn, dq);
+        } else if constexpr (UNITW) ik_lm_step<NJ, true>(jac, e, &p.we[0], wn, dq);
         else if (RTB_IK_UNITW && p.unit_we) ik_lm_step<NJ, true>(jac, e, &p.we[0], wn, dq);          // wave-uniform
         else ik_lm_step<NJ, false>(jac, e, &p.we[0], wn, dq);
     }

@@ -64,6 +64,14 @@ RTB_HD void pose_rotz(Pose &P, double c, double s)
 RTB_HD void pose_tx(Pose &P, double d) { P.tx += d * P.r00; P.ty += d * P.r10; P.tz += d * P.r20; }
 RTB_HD void pose_ty(Pose &P, double d) { P.tx += d * P.r01; P.ty += d * P.r11; P.tz += d * P.r21; }
 RTB_HD void pose_tz(Pose &P, double d) { P.tx += d * P.r02; P.ty += d * P.r12; P.tz += d * P.r22; }
+// P.t += R (x, y, z) as three fused chains seeded with the old translation (one instruction less per component than sum-then-add; used by
+// k_ik's plain walk, A/B switch RTB_POSE_T3_FMA)
+RTB_HD void pose_t3_fma(Pose &P, double x, double y, double z)
+{
+    P.tx = fma(z, P.r02, fma(y, P.r01, fma(x, P.r00, P.tx)));
+    P.ty = fma(z, P.r12, fma(y, P.r11, fma(x, P.r10, P.ty)));
+    P.tz = fma(z, P.r22, fma(y, P.r21, fma(x, P.r20, P.tz)));
+}
 RTB_HD void pose_t3(Pose &P, double x, double y, double z)
 {
     P.tx += x * P.r00 + y * P.r01 + z * P.r02;
@@ -71,10 +79,11 @@ RTB_HD void pose_t3(Pose &P, double x, double y, double z)
     P.tz += x * P.r20 + y * P.r21 + z * P.r22;
 }
 // P <- P * A for a general constant affine a = {R row-major (9), t (3)}
-template <class F>
+template <bool T3FMA = false, class F>
 RTB_HD void pose_mul_general(Pose &P, F a)
 {
-    pose_t3(P, a(9), a(10), a(11));
+    if (T3FMA) pose_t3_fma(P, a(9), a(10), a(11));
+    else pose_t3(P, a(9), a(10), a(11));
     double x, y, z;
     x = P.r00; y = P.r01; z = P.r02;
     P.r00 = x * a(0) + y * a(3) + z * a(6); P.r01 = x * a(1) + y * a(4) + z * a(7); P.r02 = x * a(2) + y * a(5) + z * a(8);
@@ -103,10 +112,10 @@ RTB_HD void pose_premul(Pose &P, const double *a /* row-major 3x4 */)
 }
 
 // P <- P * C for a constant segment read through a wave-uniform table
-template <class CV>
+template <bool T3FMA = false, class CV>
 RTB_HD void pose_mul_seg(Pose &P, const CV &cv, int j)
 {
-    pose_mul_general(P, [&](int k) { return k < 9 ? cv.seg[j].r[k] : cv.seg[j].t[k - 9]; });
+    pose_mul_general<T3FMA>(P, [&](int k) { return k < 9 ? cv.seg[j].r[k] : cv.seg[j].t[k - 9]; });
 }
 template <class CV>
 RTB_HD void pose_from_seg(Pose &P, const CV &cv, int j)

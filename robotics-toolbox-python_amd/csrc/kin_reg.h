@@ -36,6 +36,9 @@ RTB_HD int reg_lds_doubles(int n)
 // Per-lane core: joint values qv[] (chain order, as the caller holds them) -> P = C_0 Z_0 ... tail and
 // the finished Jacobian in registers.  jac slot r*NJ + j : rows 0..2 = p_j, rows 3..5 = z_j until
 // the closing loop finishes them.  Used by the tile kernel (reg_compute) and by the IK loop.
+#ifndef RTB_POSE_T3_FMA
+#define RTB_POSE_T3_FMA 1
+#endif
 #ifndef RTB_PIN_SEG_LOADS
 #define RTB_PIN_SEG_LOADS 1
 #endif
@@ -81,7 +84,7 @@ RTB_HD void reg_core(const CV &cv, TL tail /* tail[k], k = 0..11 */, int frame, 
         // -2.4 % (config 3) ... -3.6 % (notebook setting) on one box (round 4 visit l).  RTB_PIN_SEG_LOADS = 2 pins the general (branchy) walk too.
         CV cvj = cv;
         if ((PLAIN || RTB_PIN_SEG_LOADS > 1) && cv_has_trig<CV>::value && j > 0) asm volatile("" : "+s"(cvj.seg), "+v"(P.tx));
-        if (j == 0) pose_from_seg(P, cvj, 0); else pose_mul_seg(P, cvj, j);
+        if (j == 0) pose_from_seg(P, cvj, 0); else pose_mul_seg<(PLAIN && RTB_POSE_T3_FMA && cv_has_trig<CV>::value)>(P, cvj, j);
 #else
         if (j == 0) pose_from_seg(P, cv, 0); else pose_mul_seg(P, cv, j);
 #endif
@@ -98,7 +101,7 @@ RTB_HD void reg_core(const CV &cv, TL tail /* tail[k], k = 0..11 */, int frame, 
         sched_fence();
 #endif
     }
-    pose_mul_general(P, [&](int k) { return tail[k]; });
+    pose_mul_general<(PLAIN && RTB_POSE_T3_FMA && cv_has_trig<CV>::value)>(P, [&](int k) { return tail[k]; });
     sched_fence();
     if (WANT_J) {
         // Jv = z x (p_e - p), Jw = z (revolute) ; Jv = z, Jw = 0 (prismatic); flip negates
