@@ -35,7 +35,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "robotics-toolbox-python_amd")]
 
-from benchlib import protect_stdout, HBM_PEAK_GBS, Ranks, spawn_ranks_if_needed, bench_argv, per_launch_min_ms, ensure_library, pmc_traffic, rocprof_committed  # noqa: E402
+from benchlib import protect_stdout, HBM_PEAK_GBS, Ranks, spawn_ranks_if_needed, bench_argv, per_launch_min_ms, ensure_library, pmc_traffic, rocprof_committed, rocprof_committed_all  # noqa: E402
 
 BYTES_PER_CONFIG = 56 + 128 + 336  # q read + T written + J0 written
 
@@ -248,6 +248,8 @@ def main():
             # boxes of this pool differ by 10-15 % on this kernel) next to what this run measured with events
             line["roofline"]["frac_rocprof_committed"] = BYTES_PER_CONFIG * N / (committed["avg_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBS
             line["roofline"]["rocprof_committed"] = committed
+            line["roofline"]["rocprof_committed_leases"] = [dict(x, frac=BYTES_PER_CONFIG * N / (x["avg_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBS)
+                                                            for x in rocprof_committed_all(ROOT)]      # the spread between leases (boxes)
         if probe is not None:
             # context, not a ceiling: a plain streaming kernel with the same read / write mix on THIS box (the fused kernel has beaten it)
             line["roofline"]["stream_probe"] = probe

@@ -246,6 +246,31 @@ def pmc_traffic(root, name):
         return None, None
 
 
+def rocprof_committed_all(root, kernel_substr="k_kin_reg<7, true, true"):
+    """Every committed rocprofv3 summary of bench.py of the LATEST round, oldest first: [{"file", "avg_ns", "calls"}].  Each is another lease,
+    often another box: their spread is the box-to-box spread of the headline kernel."""
+    import csv
+    import glob
+    import re
+    files = sorted(f for f in glob.glob(os.path.join(root, "profiles", "r[0-9][0-9]_*_kernel_stats.csv"))
+                   if "extra" not in os.path.basename(f) and "_rne" not in os.path.basename(f))
+    if not files:
+        return []
+    latest = max(re.match(r"r(\d\d)_", os.path.basename(f)).group(1) for f in files)
+    out = []
+    for f in files:
+        if not os.path.basename(f).startswith("r" + latest + "_"):
+            continue
+        try:
+            for row in csv.DictReader(open(f)):
+                name = row.get("Name") or row.get("KernelName") or ""
+                if kernel_substr.replace(" ", "") in name.replace(" ", ""):
+                    out.append({"file": "profiles/" + os.path.basename(f), "avg_ns": float(row["AverageNs"]), "calls": int(row["Calls"])})
+        except Exception:
+            continue
+    return out
+
+
 def rocprof_committed(root, kernel_substr="k_kin_reg<7, true, true"):
     """Average duration (ns) of the headline kernel in the newest committed `rocprofv3 --kernel-trace --stats` summary of bench.py
     (profiles/rNN_*_kernel_stats.csv, not the *_extra_* ones): {"file", "avg_ns", "calls"} or None."""
