@@ -63,6 +63,9 @@ constexpr int kIkNullMax = 12;   // null-space step variants: 6..8 joints in reg
 // AUX: bit 0 = the flat schedule, bit 1 = the per-wave diagnostic counters (RTBHIP_IK_STATS).  Compile-time, because carrying either through the
 // persistent loop as run-time switches cost the plain schedule 6-9 % (20 VGPRs; round 3, visit x: the round-2 build against this one on one box).
 constexpr int kIkAuxFlat = 1, kIkAuxStats = 2, kIkAuxUnitW = 4;      // bit 2: every mask weight is 1 (the default), LM steps: ik_iter<..., UNITW>
+#ifndef RTB_IK_MASK_IDLE
+#define RTB_IK_MASK_IDLE 0
+#endif
 constexpr int kIkAuxPlain = 8;                                         // bit 3: all-revolute chain, no flipped joint: ik_iter<..., PLAIN>
 template <int NJ, int STEP, int AUX = 0>
 __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull) ? RTB_IK_WAVES : 1)) void k_ik(IkDev p, DevChain dc, const double *qlim_g, const double *__restrict__ Tep,
@@ -407,6 +410,12 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
             asm volatile("" : "+s"(cvi.seg), "+s"(cvi.jmeta), "+s"(ql), "+s"(cvi.trig));
             const int myslot = st.slot;
             if constexpr (kStats) { ++st_iters; st_lane += (unsigned long long)__popcll(__ballot(st.status == kIkRun && !st.fin)); }
+#if RTB_IK_MASK_IDLE
+            // lanes without a running search sit the iteration out with their EXEC bit cleared: the instruction stream is the same, but a
+            // third of the lane slots (idle and parked lanes, r04_g_ik_occupancy.txt) no longer toggle operands -- on a power-limited part
+            // that is clock (A/B: round 4 visit q)
+            if (st.status == kIkRun && !st.fin)
+#endif
             ik_iter<NJ, STEP, (AUX & kIkAuxUnitW) != 0 && STEP == 0, (AUX & kIkAuxPlain) != 0>(st, ka->p, cvi, ql, [&](int k) { return sh.Td[k][myslot]; }, ik_lds_q(sh, lane));
         }
     }
