@@ -66,20 +66,24 @@ def ik_roofline(lm_iterations_per_s):
 
 
 # ALGORITHMIC fp64 operations per unit of the issue-bound secondary kernels (fused multiply-add = 2), derived in DESIGN.md section 5 from the
-# recursion's own budget -- NOT from what the kernel happens to execute:
-#   one Newton-Euler link-pass = 135 fp64 operations-as-instructions (forward R^T w 8, w' 1, wd' 11, vd' 29, vd_c 21, F 3, N 24;
-#   backward R f 8, f 3, N + r_c x F 6, n 17, projection 4), priced as 270 flop; a pass over the 7-link arm = 1890 flop.
-#     gravload    1 pass                                                    1 890
-#     inertia     n passes (Dynamics.inertia: rne with qdd = e_i, qd = 0)   13 230
-#     coriolis    2 passes per column (polar form; the reference runs 28)   26 460
-#     accel       1 + n passes + LDL^T solve (n^3/3 + 2 n^2 = 212)           15 332
-#     tree_*      the same counts on the 6 link groups of the UR5:  rne 1 620, inertia 9 720, coriolis 19 440, accel 11 484
+# recursion's own budget -- the best formulation known here (the one the kernels implement), NOT what a kernel happens to execute:
+#   full Newton-Euler link-pass   135 fp64 operations-as-instructions = 270 flop
+#   acceleration-only link-pass   (all angular velocities zero: no w x (w x r) terms)  forward R^T wd 8, + z qdd 1, wd x p* 6, + vd 3, R^T(..) 8,
+#                                 vd_c 6, F 3, N = I wd 9; backward R f 8, f 3, N + r_c x F 6, n 17, projection 4 = 82 = 164 flop
+#   sincos                        30 operations = 60 flop per joint (Cody-Waite reduction + two degree-5 polynomials + quadrant selects)
+#     gravload    7 acceleration-only link-passes at rest (gravity as the base's acceleration) + 7 sincos       1 148 +   420 =  1 568
+#     inertia     column i = one acceleration-only pass over links i..n, mirrored: n (n + 1) / 2 = 28 link-passes                4 592 +   420 =  5 012
+#     coriolis    2 full passes per column (polar form of the quadratic velocity torque; the reference runs 28)                 26 460 +   420 = 26 880
+#     accel       1 full pass + the inertia columns + LDL^T solve (n^3 / 3 + 2 n^2 = 212)                         1 890 + 4 592 + 212 + 420 =  7 114
+#     tree_*      the same link-pass budgets on the 6 link groups of the UR5 (the spatial-vector recursion of Robot.rne is priced at the DH
+#                 budget: a lower bound of its arithmetic): rne 1 620 + 360 = 1 980, inertia 21 x 164 + 360 = 3 804, coriolis 12 x 6 x 270 + 360 = 19 800,
+#                 accel 1 620 + 3 444 + 144 + 360 = 5 568
 #   FK + Jacobian walk of the 7-joint chain = 600 flop, then
 #     jacob0_dot      + sum over joint pairs (j <= i: two cross products and six FMAs = 30; j > i: 15): 28 x 30 + 21 x 15 = 1 155   -> 1 755
 #     manipulability  + J J^T (21 entries x 7 FMAs = 294) + 6x6 LU determinant (144) + sqrt                                      -> 1 050
 #     jacobm          + J J^T 294 + LDL^T 100 + 7 back-substitutions (504) + 49 Hessian-block contractions x 30 (1 470) + m        -> 3 000
-ALGO_FLOPS_PER_UNIT = {"gravload": 1890, "inertia": 13230, "coriolis": 26460, "accel": 15332, "tree_ur5": 1620, "jacob0_dot": 1755,
-                       "manipulability": 1050, "jacobm": 3000, "tree_inertia_ur5": 9720, "tree_coriolis_ur5": 19440, "tree_accel_ur5": 11484}
+ALGO_FLOPS_PER_UNIT = {"gravload": 1568, "inertia": 5012, "coriolis": 26880, "accel": 7114, "tree_ur5": 1980, "jacob0_dot": 1755,
+                       "manipulability": 1050, "jacobm": 3000, "tree_inertia_ur5": 3804, "tree_coriolis_ur5": 19800, "tree_accel_ur5": 5568}
 # VALU instructions per lane actually EXECUTED (SQ_INSTS_VALU / SQ_WAVES, profiles/r03_a_sq_summary.txt, r03_o_sq_tree_dyn.txt): reported beside
 # the roofline as `valu_issue_util` (share of the chip's fp64 issue slots the kernel fills) -- a diagnostic, not a roofline: a kernel that
 # executed more instructions for the same answer would score higher on it.
@@ -93,7 +97,7 @@ def valu_roofline(key, units_per_s, kernel, hbm_bytes_per_unit):
     tf = flops * units_per_s / 1e12
     instr = VALU_PER_UNIT[key]
     return {"bound": "fp64-valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
-            "algorithmic_flops_per_unit": flops, "flops_source": "DESIGN.md section 5 (link-passes x 270 flop; FK + Jacobian 600 flop + the consumer's own products)",
+            "algorithmic_flops_per_unit": flops, "flops_source": "DESIGN.md section 5 (full / acceleration-only link-passes at 270 / 164 flop, 60 flop per sincos; FK + Jacobian 600 flop + the consumer's own products)",
             "kernel": kernel, "hbm_GBs": hbm_bytes_per_unit * units_per_s / 1e9,
             "valu_issue_util": 2.0 * instr * units_per_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
             "valu_instructions_per_unit_measured": instr}
