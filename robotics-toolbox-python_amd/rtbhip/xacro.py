@@ -211,6 +211,9 @@ class _Context:
     def expr(self, code, scope):
         if "load_yaml" in code:
             raise XacroError("load_yaml is not supported by rtbhip.xacro")
+        if "__" in code:
+            # expressions are evaluated with the builtins withheld; dunder attributes (`().__class__.__base__ ...`) are the way back to them
+            raise XacroError("double underscores are not allowed in ${%s}" % code)
         args = self.args
 
         class _Args(dict):                     # `arg('name')` inside expressions

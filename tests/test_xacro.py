@@ -119,7 +119,9 @@ def test_language_details(tmp_path):
     ('<a v="$(arg nothing)"/>', "undefined substitution argument"),
     ('<xacro:element xacro:name="x"/>', "not supported"),
     ('<a v="${load_yaml(1)}"/>', "load_yaml"),
-    ('<a v="${__import__(\'os\')}"/>', "__import__"),
+    ('<a v="${__import__(\'os\')}"/>', "double underscores"),
+    ('<a v="${().__class__.__base__.__subclasses__()}"/>', "double underscores"),
+    ('<a v="${open(\'/etc/passwd\').read()}"/>', "open"),
 ])
 def test_refusals(tmp_path, body, fragment):
     with pytest.raises(xacro.XacroError) as e:
