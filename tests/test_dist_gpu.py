@@ -196,6 +196,22 @@ def test_bench_extra_gpus_2_shards_config4_config3_and_config5():
     assert fleet["n_gpus"] == 2 and fleet["scaling"] == "strong" and len(fleet["arms"]) == 16
 
 
+def test_bench_gpus_8_on_a_smaller_box_fails_with_one_clear_line():
+    """`python bench.py --gpus 8` where fewer than 8 GPUs exist: every rank refuses with the same one-line reason (no silent sharing, no hang):
+    the RCCL path wants one device per rank."""
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("this box has 8 GPUs: the run would simply work")
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RTBHIP_BENCH_BACKEND", "RTBHIP_BENCH_FORCE_GROUP"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--no-cpu"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]             # no JSON line: nothing was measured
+    assert "8 ranks but %d GPUs" % torch.cuda.device_count() in r.stderr
+
+
 def test_bench_single_gpu_line_carries_the_contract_objects():
     """`python bench.py` as the driver runs it (N = 1, default workload): ONE JSON line with the contract's keys, the roofline
     object priced on 520 B per configuration, the reference-built CPU baseline, and the host-pointer rate as its own object."""
