@@ -118,7 +118,7 @@ def ik_config3(rtbhip, N=100000, sample=2000):
             rq, rok, rit, rse = np.asarray(o[0]), int(o[1]), int(o[2]), int(o[3])
         else:
             from oracle import oracle
-            o = oracle.ik_lm(ch, Th[i], restarts=np.array([q0[i]]), slimit=1)
+            o = oracle.ik_lm(ch, Th[i], q0=q0[i], restarts=np.zeros((2, 7)), slimit=1)
             rq, rok, rit, rse = np.asarray(o[0]), int(o[1]), int(o[2]), int(o[3])
         if rok and rse == 1:
             first += 1

@@ -660,14 +660,14 @@ def test_ik_kernel_specialisations_agree():
     prismatic joint must not be affected by the switches at all."""
     ets, ch = _panda_limited()
     rng = np.random.default_rng(91)
-    N = full_size(20000, 20)
+    N = full_size(20000, 100)             # (under the CPU replay all switches run the one replay: only the plumbing is under test there)
     Tep = oracle.fkine(ch, rng.uniform(ch.qlim[0], ch.qlim[1], (N, 7)))
     outs = {}
     try:
         for u, pl in ((0, 0), (1, 0), (1, 1)):
             rtbhip.tune("ik_unit_we", u); rtbhip.tune("ik_plain", pl)
             outs[(u, pl)] = ets.ik_LM(Tep, seed=4)
-            outs[(u, pl, "mask")] = ets.ik_LM(Tep[:2000], seed=4, mask=[1, 1, 1, 0.5, 0.5, 0])
+            outs[(u, pl, "mask")] = ets.ik_LM(Tep[:min(2000, N)], seed=4, mask=[1, 1, 1, 0.5, 0.5, 0])
     finally:
         rtbhip.tune("ik_unit_we", 1); rtbhip.tune("ik_plain", 1)
     base = outs[(0, 0)]
@@ -684,6 +684,46 @@ def test_ik_kernel_specialisations_agree():
         for a, b in zip(outs[key + ("mask",)], outs[(0, 0, "mask")]):
             nt.assert_array_equal(a, b)                      # a weighted mask never takes the unit-weight kernels
     assert 0.9 < base[1].mean() < 1.0
+
+
+@pytest.mark.parametrize("shape", ["six revolute", "seven with a flipped joint", "six with a prismatic joint", "eight revolute", "five revolute"])
+def test_ik_kernel_variants_on_other_chain_shapes_equal_the_oracle(shape):
+    """Which k_ik instantiation serves a call depends on the chain (all-revolute without flips: the straight-line walk; anything else: the
+    general one) and on the mask (all ones: no products with the weights).  Random chains of each kind, with the default mask and with a
+    weighted one, from a supplied start (no generator involved): (success, iterations, searches) equal the C restatement of the reference's
+    loop wherever it converges in its first search, q within 1e-6."""
+    rng = np.random.default_rng({"six revolute": 1, "seven with a flipped joint": 2, "six with a prismatic joint": 3, "eight revolute": 4, "five revolute": 5}[shape])
+    n = {"six revolute": 6, "seven with a flipped joint": 7, "six with a prismatic joint": 6, "eight revolute": 8, "five revolute": 5}[shape]
+    axes = ["Rz", "Ry", "Rx"]
+    spec = []
+    for j in range(n):
+        ax = axes[int(rng.integers(0, 3))]
+        flip = shape == "seven with a flipped joint" and j == 3
+        if shape == "six with a prismatic joint" and j == 2:
+            ax = "tz"
+        spec.append((ax, None, flip))
+        spec.append((["tx", "ty", "tz"][int(rng.integers(0, 3))], float(rng.uniform(0.1, 0.4))))
+        if j % 2 == 0:
+            spec.append((["Rx", "Ry"][int(rng.integers(0, 2))], float(rng.uniform(-1.5, 1.5))))
+    lo = np.array([-0.3 if s[0].startswith("t") else -2.6 for s in spec if s[1] is None])
+    qlim = np.array([lo, -lo * np.where(lo > -1, 2.0, 1.0)])
+    ets = product_ets(spec, qlim=qlim)
+    ch = chains.Chain(spec, qlim=qlim)
+    N = 300
+    qs = rng.uniform(qlim[0] * 0.9, qlim[1] * 0.9, (N, n))
+    Tep = oracle.fkine(ch, qs)
+    q0 = np.clip(qs + 0.2 * rng.normal(size=qs.shape), qlim[0], qlim[1])
+    masks = [None, [1, 1, 1, 0.5, 0.5, 0.25]] if n >= 6 else [[1, 1, 1, 0, 0, 1], [1, 0.5, 1, 0, 0, 1]]
+    for mask in masks:
+        q, ok, it, se, E = ets.ik_LM(Tep, q0=q0, mask=mask, slimit=3, seed=7)
+        checked = 0
+        for i in range(N):
+            o = oracle.ik_lm(ch, Tep[i], q0=q0[i], restarts=np.zeros((2, n)), slimit=1, we=None if mask is None else np.array(mask, dtype=float))
+            if o[1] and o[3] == 1:
+                checked += 1
+                assert (o[1], o[2], o[3]) == (ok[i], it[i], se[i]), (shape, mask, i)
+                nt.assert_allclose(q[i], o[0], atol=1e-6)
+        assert checked >= N // 3, (shape, mask, checked)
 
 
 def test_ik_qp_error_paths_and_batch_vs_oracle():
