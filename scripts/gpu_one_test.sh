@@ -1,1 +1,3 @@
-cd $GRAFT_REPO_ROOT; timeout 600 python -m pytest tests/test_00_gpu_parity.py -m gpu -q -x -k "specialisations" 2>&1 | grep -vE "^\s*$" | tail -40
+#!/bin/bash
+# run a subset of the GPU suite: bash scripts/gpu_one_test.sh <pytest args>
+cd $GRAFT_REPO_ROOT; timeout 900 python -m pytest -m gpu -q -rf "$@" 2>&1 | grep -vE "^\s*$" | tail -40

@@ -113,6 +113,22 @@ def test_bench_gather_ms_world2_uneven_shards(N):
         assert ok, "rank %d: %s" % (rank, err)
 
 
+def test_bench_gather_ms_world8_uneven_shards():
+    """the shape of the run the driver does on an 8-GPU node: eight ranks, N not a multiple of eight"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_gather_worker, args=(r, 8, port, 1003, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r for r, _, _ in res) == list(range(8))
+    for rank, ok, err in res:
+        assert ok, "rank %d: %s" % (rank, err)
+
+
 def test_gather_buffer_lives_outside_the_timed_region():
     """Structure of the bench scripts, checked on their source: the receive buffer of the output gather is allocated inside Ranks.gather_ms,
     which bench.py calls after Ranks.timed_steps has returned `elapsed` and before the cpu_baseline / secondary legs (which start only after

@@ -196,6 +196,29 @@ def test_bench_extra_gpus_2_shards_config4_config3_and_config5():
     assert fleet["n_gpus"] == 2 and fleet["scaling"] == "strong" and len(fleet["arms"]) == 16
 
 
+def test_bench_eight_ranks_sharing_the_gpu():
+    """The driver's 8-GPU run in miniature: `bench.py --gpus 8` and the sharded legs of `bench_extra.py --gpus 8` with eight ranks SHARING this
+    box's GPU (the gloo test hook: `devices_shared` is printed, this is no scaling figure).  What it checks is the eight-rank arithmetic:
+    row blocks of a batch that eight does not divide, the gather of eight uneven shards, max-over-ranks timing, one JSON line from rank 0."""
+    def run(script, extra):
+        env = dict(os.environ, RTBHIP_BENCH_BACKEND="gloo")
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, script), "--gpus", "8"] + extra, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    lines = run("bench.py", ["--steps", "4", "--warmup", "1", "--n", "100003", "--no-cpu"])
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["devices_shared"] is True and d["gather_ms"] > 0
+    assert d["gather_buffer"]["world"] == 8 and d["gather_buffer"]["buffer_bytes"] == 8 * 100003 * 58 * 8
+    assert d["value"] == pytest.approx(8 * 100003 * 4 / (d["ms_per_step"] * 4e-3), rel=1e-9) and "secondary" not in d
+    rne, ik, fleet = run("bench_extra.py", ["--what", "rne,ik,fleet", "--steps", "3", "--n-rne", "400003", "--n-ik", "40003", "--n-fleet", "20003", "--no-cpu"])
+    assert rne["n_gpus"] == 8 and rne["n"] == 400003 and rne["rows_rank0"] == 50001 and rne["gather_ms"] > 0
+    assert ik["n_gpus"] == 8 and ik["n"] == 40003 and ik["rows_rank0"] == 5001 and 0.97 < ik["success_rate"] <= 1.0
+    assert fleet["n_gpus"] == 8 and len(fleet["arms"]) == 16
+
+
 def test_bench_gpus_8_on_a_smaller_box_fails_with_one_clear_line():
     """`python bench.py --gpus 8` where fewer than 8 GPUs exist: every rank refuses with the same one-line reason (no silent sharing, no hang):
     the RCCL path wants one device per rank."""
