@@ -73,23 +73,29 @@ def ik_roofline(lm_iterations_per_s):
 #   sincos                        30 operations = 60 flop per joint (Cody-Waite reduction + two degree-5 polynomials + quadrant selects)
 #     gravload    7 acceleration-only link-passes at rest (gravity as the base's acceleration) + 7 sincos       1 148 +   420 =  1 568
 #     inertia     column i = one acceleration-only pass over links i..n, mirrored: n (n + 1) / 2 = 28 link-passes                4 592 +   420 =  5 012
-#     coriolis    2 full passes per column (polar form of the quadratic velocity torque; the reference runs 28)                 26 460 +   420 = 26 880
+#   two-field link-pass           (Dynamics.coriolis, column k = B(qd, e_k): both velocity fields through one recursion, every product of two
+#                                 velocities taken both ways round -- csrc/dyn_device.h rne_bilinear_core)  forward R^T w_u 8, R^T w_w 8, w' 2,
+#                                 wd' 12, a' 38 (wd x p*, two w x (w x p*), R^T), v_c 30, F 3, N 39 (three I w, two crosses); backward 38 = 178 = 356 flop
+#   prefix link-step              (links before the column's own: only w_u advances, 9, and the force is handed down, 22) = 31 = 62 flop
+#     coriolis    column k = one two-field pass over links k..n after the prefix: 28 two-field link-passes + 21 prefix steps      9 968 + 1 302 + 420 = 11 690
+#                 (rounds 1-3 ran 2 full passes per column -- the polar form, priced 26 880; the reference runs 28 full passes)
 #     accel       1 full pass + the inertia columns + LDL^T solve (n^3 / 3 + 2 n^2 = 212)                         1 890 + 4 592 + 212 + 420 =  7 114
 #     tree_*      the same link-pass budgets on the 6 link groups of the UR5 (the spatial-vector recursion of Robot.rne is priced at the DH
-#                 budget: a lower bound of its arithmetic): rne 1 620 + 360 = 1 980, inertia 21 x 164 + 360 = 3 804, coriolis 12 x 6 x 270 + 360 = 19 800,
+#                 budget: a lower bound of its arithmetic): rne 1 620 + 360 = 1 980, inertia 21 x 164 + 360 = 3 804, coriolis 21 x 356 + 15 x 62 + 360 = 8 766,
 #                 accel 1 620 + 3 444 + 144 + 360 = 5 568
 #   FK + Jacobian walk of the 7-joint chain = 600 flop, then
 #     jacob0_dot      + sum over joint pairs (j <= i: two cross products and six FMAs = 30; j > i: 15): 28 x 30 + 21 x 15 = 1 155   -> 1 755
 #     manipulability  + J J^T (21 entries x 7 FMAs = 294) + 6x6 LU determinant (144) + sqrt                                      -> 1 050
 #     jacobm          + J J^T 294 + LDL^T 100 + 7 back-substitutions (504) + 49 Hessian-block contractions x 30 (1 470) + m        -> 3 000
-ALGO_FLOPS_PER_UNIT = {"gravload": 1568, "inertia": 5012, "coriolis": 26880, "accel": 7114, "tree_ur5": 1980, "jacob0_dot": 1755,
-                       "manipulability": 1050, "jacobm": 3000, "tree_inertia_ur5": 3804, "tree_coriolis_ur5": 19800, "tree_accel_ur5": 5568}
-# VALU instructions per lane actually EXECUTED (SQ_INSTS_VALU / SQ_WAVES, profiles/r03_a_sq_summary.txt, r03_o_sq_tree_dyn.txt): reported beside
+ALGO_FLOPS_PER_UNIT = {"gravload": 1568, "inertia": 5012, "coriolis": 11690, "accel": 7114, "tree_ur5": 1980, "jacob0_dot": 1755,
+                       "manipulability": 1050, "jacobm": 3000, "tree_inertia_ur5": 3804, "tree_coriolis_ur5": 8766, "tree_accel_ur5": 5568}
+# VALU instructions per lane actually EXECUTED (SQ_INSTS_VALU / SQ_WAVES, profiles/r03_a_sq_summary.txt; coriolis and the tree dynamics kernels as
+# rebuilt in round 4: profiles/r04_u_sq_tree_dyn.txt, r04_v_sq_dyn.txt): reported beside
 # the roofline as `valu_issue_util` (share of the chip's fp64 issue slots the kernel fills) -- a diagnostic, not a roofline: a kernel that
 # executed more instructions for the same answer would score higher on it.
-VALU_PER_UNIT = {"gravload": 833, "inertia": 3433, "coriolis": 10708, "accel": 3377, "tree_ur5": 1930, "jacob0_dot": 1692,
+VALU_PER_UNIT = {"gravload": 833, "inertia": 3433, "coriolis": 5954, "accel": 3377, "tree_ur5": 1929, "jacob0_dot": 1692,
                  "manipulability": 1512, "jacobm": 2732,
-                 "tree_inertia_ur5": 10078, "tree_coriolis_ur5": 26443, "tree_accel_ur5": 11667}
+                 "tree_inertia_ur5": 4345, "tree_coriolis_ur5": 10864, "tree_accel_ur5": 7216}
 
 
 def valu_roofline(key, units_per_s, kernel, hbm_bytes_per_unit):
@@ -97,7 +103,7 @@ def valu_roofline(key, units_per_s, kernel, hbm_bytes_per_unit):
     tf = flops * units_per_s / 1e12
     instr = VALU_PER_UNIT[key]
     return {"bound": "fp64-valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
-            "algorithmic_flops_per_unit": flops, "flops_source": "DESIGN.md section 5 (full / acceleration-only link-passes at 270 / 164 flop, 60 flop per sincos; FK + Jacobian 600 flop + the consumer's own products)",
+            "algorithmic_flops_per_unit": flops, "flops_source": "DESIGN.md section 5 (full / acceleration-only / two-field link-passes at 270 / 164 / 356 flop, 60 flop per sincos; FK + Jacobian 600 flop + the consumer's own products)",
             "kernel": kernel, "hbm_GBs": hbm_bytes_per_unit * units_per_s / 1e9,
             "valu_issue_util": 2.0 * instr * units_per_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
             "valu_instructions_per_unit_measured": instr}
@@ -210,7 +216,7 @@ def main():
         tq = torch.from_numpy(rng.normal(size=(N, 7)) * 5).cuda()
         for name, fn, passes, byts in (("gravload", lambda: rob.gravload(q), 1, 56 + 56),
                                        ("inertia", lambda: rob.inertia(q), 7, 56 + 392),
-                                       ("coriolis", lambda: rob.coriolis(q, qd), 14, 112 + 392),
+                                       ("coriolis", lambda: rob.coriolis(q, qd), 7, 112 + 392),
                                        ("accel", lambda: rob.accel(q, qd, tq), 8, 168 + 56)):
             avg, best = ev_time(fn, max(3, args.steps // 2), 2)
             line = {"metric": "configurations/sec (DH Panda %s)" % name, "value": N / (avg * 1e-3), "unit": "configurations/s",
@@ -218,7 +224,7 @@ def main():
                     "rne_passes_per_s": passes * N / (avg * 1e-3),
                     "pass_kind": {"gravload": "one pass at qd = 0: acceleration-only forward recursion, gravity as the base's acceleration (k_rne_atrest)",
                                   "inertia": "acceleration-only passes from link i on, mirrored (csrc/rne_device.h ACC)",
-                                  "coriolis": "2 velocity passes per column, qd +- s e_k (polar form of the quadratic velocity torque; the reference runs 28 passes, and so do the waves that hold a row whose velocities span more than 2^16)",
+                                  "coriolis": "one two-field pass per column: C[:, k] = B(qd, e_k), the bilinear form of the velocity torque evaluated directly from link k on (csrc/dyn_device.h rne_bilinear_core; the reference runs 28 full passes, rounds 1-3 ran 14)",
                                   "accel": "1 full pass + 7 acceleration-only passes + LDL^T solve"}[name],
                     "roofline": valu_roofline(name, N / (avg * 1e-3), {"gravload": "k_rne_atrest<7,MDH>", "inertia": "k_dyn<7,MDH,inertia>",
                                                                         "coriolis": "k_dyn<7,MDH,coriolis>", "accel": "k_dyn<7,MDH,accel>"}[name], byts)}

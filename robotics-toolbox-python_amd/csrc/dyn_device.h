@@ -35,6 +35,133 @@ RTB_HD double dyn_pick(const double (&a)[NJ], int i)
     return r;
 }
 
+#ifndef RTB_DYN_BILINEAR
+#define RTB_DYN_BILINEAR 1      // 0: Dynamics.coriolis by the polar form over full passes (two per column) -- the first implementation, A/B
+#endif
+// ---- one column of C(q, qd), evaluated directly.  A Newton-Euler pass with gravity, friction and acceleration removed (what
+// Dynamics.coriolis runs, robot/Dynamics.py:811-861) is a quadratic form tau(v) = B(v, v) of the joint velocities, and the matrix the reference
+// assembles from its n + n (n - 1) / 2 unit-velocity passes is  C[:, k] = B(qd, e_k) = sum_j qd_j B(e_j, e_k).  B(u, w) comes out of ONE
+// recursion that carries both velocity fields -- the angular velocities under u = qd and under w = e_k -- and in which every product of two
+// velocities of ne.c:133-348, x(v) y(v), is replaced by x(u) y(w) + x(w) y(u) (that is 2 B; the caller halves): the terms are
+//      wd :  (R^T w) x z qd                       a :  w x (w x p*)   [+ 2 w x z qd for a prismatic joint]
+//      F  :  m ( .. + w x (w x r) )               N :  w x (I w)
+// Against the polar form  (tau(qd + s e_k) - tau(qd - s e_k)) / 4s  this is one pass of ~1.4x the arithmetic instead of two, it is exact for
+// any spread of velocities (no probe scale to choose, no cancellation: the rows whose velocities span many orders of magnitude need no other
+// scheme), and the links before `first` -- at rest under w when first <= k, so their wd, a, F, N vanish -- only advance w(u).
+template <int NJ, bool MDH, bool ALLREV, class LinksP, class InQ, class InQd, class Out>
+RTB_HD void rne_bilinear_core(LinksP links, double (&st)[NJ], double (&ct)[NJ], InQ qin, InQd qdin, int k, Out tau, int first)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(first), "+s"(k));       // (rne_core ACC: keeps the caller's column loop one loop)
+#else
+    asm volatile("" : "+r"(first), "+r"(k));
+#endif
+    const V3 o = v3(0, 0, 0);
+    V3 F[NJ], Nn[NJ];
+    int flg[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) flg[j] = links[j].flags;
+    V3 wu = o, ww = o, wd = o, a = o;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const auto &li = links[j];
+        const LinkFwd l = link_fwd<ALLREV>(li);
+        const bool pris = ALLREV ? false : (l.sigma != 0);
+        const double qdu = qdin(j), qdw = j == k ? 1.0 : 0.0;
+        const double d = pris ? qin(j) + l.offset : l.d;
+        const Rot R = {st[j], ct[j], l.sa, l.ca};
+        const V3 ps = link_offset<MDH>(l, d);
+        if (j < first) {               // wave-uniform: nothing moves under w yet
+            if (MDH) wu = (j == 0) ? v3(0, 0, qdu) : (pris ? rot_inv<MDH>(R, wu) : addz(rot_inv<MDH>(R, wu), qdu));
+            else wu = pris ? ((j == 0) ? o : rot_inv<MDH>(R, wu)) : rot_inv<MDH>(R, (j == 0) ? v3(0, 0, qdu) : addz(wu, qdu));
+            F[j] = o; Nn[j] = o;
+            sched_fence();
+            continue;
+        }
+        V3 nu, nw, wdn, an;
+        if (MDH) {
+            if (j == 0) {
+                nu = v3(0, 0, qdu); nw = v3(0, 0, qdw); wdn = o; an = o;
+            } else {
+                const V3 tu = rot_inv<MDH>(R, wu), tw = rot_inv<MDH>(R, ww);
+                const V3 lin = rot_inv<MDH>(R, cross_add(wd, ps, cross_add(wu, cross(ww, ps), cross_add(ww, cross(wu, ps), a))));
+                if (!pris) {
+                    nu = addz(tu, qdu); nw = addz(tw, qdw);
+                    wdn = rot_inv_add<MDH>(R, wd, crossz(tu, qdw) + crossz(tw, qdu));
+                    an = lin;
+                } else {
+                    nu = tu; nw = tw;
+                    wdn = rot_inv<MDH>(R, wd);
+                    an = lin + 2.0 * (crossz(tu, qdw) + crossz(tw, qdu));
+                }
+            }
+        } else {
+            if (!pris) {
+                nu = rot_inv<MDH>(R, (j == 0) ? v3(0, 0, qdu) : addz(wu, qdu));
+                nw = rot_inv<MDH>(R, (j == 0) ? v3(0, 0, qdw) : addz(ww, qdw));
+                wdn = (j == 0) ? o : rot_inv<MDH>(R, wd + (crossz(wu, qdw) + crossz(ww, qdu)));
+                an = cross_add(wdn, ps, cross_add(nu, cross(nw, ps), cross_add(nw, cross(nu, ps), (j == 0) ? o : rot_inv<MDH>(R, a))));
+            } else {
+                nu = (j == 0) ? o : rot_inv<MDH>(R, wu);
+                nw = (j == 0) ? o : rot_inv<MDH>(R, ww);
+                wdn = (j == 0) ? o : rot_inv<MDH>(R, wd);
+                an = (j == 0) ? o : rot_inv<MDH>(R, a);
+                an = an + cross(wdn, ps);
+                an = an + 2.0 * (cross(nu, rot_inv<MDH>(R, v3(0, 0, qdw))) + cross(nw, rot_inv<MDH>(R, v3(0, 0, qdu))));
+                an = cross_add(nu, cross(nw, ps), cross_add(nw, cross(nu, ps), an));
+            }
+        }
+        wu = nu; ww = nw; wd = wdn; a = an;
+        V3 ac = a;
+        if (!(flg[j] & kLinkRZero)) {
+            const V3 rc = v3(li.rx, li.ry, li.rz);
+            ac = cross_add(wd, rc, cross_add(wu, cross(ww, rc), cross_add(ww, cross(wu, rc), a)));
+        }
+        F[j] = l.m * ac;
+        if (flg[j] & kLinkIDiag) {
+            const V3 iu = v3(li.I[0] * wu.x, li.I[4] * wu.y, li.I[8] * wu.z), iw = v3(li.I[0] * ww.x, li.I[4] * ww.y, li.I[8] * ww.z);
+            Nn[j] = cross_add(wu, iw, cross_add(ww, iu, v3(li.I[0] * wd.x, li.I[4] * wd.y, li.I[8] * wd.z)));
+        } else {
+            Nn[j] = cross_add(wu, inertia_times(li, ww), cross_add(ww, inertia_times(li, wu), inertia_times(li, wd)));
+        }
+        sched_fence();
+    }
+    // ---- backward recursion + joint projection: rne_core's (ne.c:354-492) without friction, motor inertia (qdd = 0) and tip wrench
+    V3 f = o, nn = o;
+    Rot Rn = {0, 1, 0, 1};
+    V3 psn = o;
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+        const int j = NJ - 1 - jj;
+        const auto &li = links[j];
+        const LinkBwd l = link_bwd<ALLREV, false>(li);
+        const bool last = (jj == 0);
+        const bool pris = ALLREV ? false : (l.sigma != 0);
+        const bool rzero = (flg[j] & kLinkRZero) != 0;
+        const V3 rc = rzero ? o : v3(li.rx, li.ry, li.rz);
+        const double d = pris ? qin(j) + l.offset : l.d;
+        const Rot R = {st[j], ct[j], l.sa, l.ca};
+        const V3 ps = link_offset<MDH>(l, d);
+        V3 fj, nj;
+        if (MDH) {
+            const V3 fn = last ? f : rot_fwd<MDH>(Rn, f);
+            fj = fn + F[j];
+            const V3 base = rzero ? Nn[j] : cross_add(rc, F[j], Nn[j]);
+            if (last) nj = nn + base;
+            else nj = cross_add(psn, fn, rot_fwd_add<MDH>(Rn, nn, base));
+        } else {
+            fj = last ? F[j] + f : rot_fwd_add<MDH>(Rn, f, F[j]);
+            const V3 base = cross_add(ps + rc, F[j], Nn[j]);
+            if (!last) nj = rot_fwd_add<MDH>(Rn, cross_add(rot_inv<MDH>(Rn, ps), f, nn), base);
+            else nj = cross_add(ps, f, nn + base);
+        }
+        const V3 prj = pris ? fj : nj;
+        tau(j, MDH ? prj.z : fmad(l.sa, prj.y, l.ca * prj.z));
+        f = fj; nn = nj; Rn = R; psn = ps;
+        sched_fence();
+    }
+}
+
 template <int NJ, bool MDH, int MODE, bool ALLREV, class LinksP>
 RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, const double *qrow = nullptr)
 {
@@ -95,6 +222,8 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, cons
         for (int j = 0; j < NJ; ++j) mA[j] = x[j];        // the tile's first n slots become the output row
     }
     if (MODE == kDynCoriolis) {
+        // What ships is rne_bilinear_core above (RTB_DYN_BILINEAR = 1): one two-field pass per column.  The rest of this comment describes the
+        // first implementation, kept under RTB_DYN_BILINEAR = 0 as the A/B baseline (scripts/build_variant.sh dyn_kernels dyn_polar ...):
         // Dynamics.coriolis (robot/Dynamics.py:811-861) builds C from n passes at QD = e_i (Csq) and n (n - 1) / 2 passes at
         // QD = e_i + e_j (gravity, friction and acceleration removed).  Such a pass is a homogeneous quadratic form of qd,
         //      tau_r(v) = sum_ab h_rab v_a v_b   (h symmetric in a, b),
@@ -113,6 +242,16 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, cons
         double qdv[NJ], vmax = 0.0;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) { qdv[j] = mine[NJ + j]; vmax = fmax(vmax, fabs(qdv[j])); }
+#if RTB_DYN_BILINEAR
+        // (what ships: the two-field pass above, one per column; the polar form below is kept as the A/B baseline)
+        (void)vmax;
+#pragma unroll 1
+        for (int k = 0; k < NJ; ++k) {
+            dyn_opaque<NJ>(st, ct);
+            rne_bilinear_core<NJ, MDH, ALLREV>(links, st, ct, qin, [&](int j) { return qdv[j]; }, k,
+                                               [&](int r, double v) { mA[r * NJ + k] = 0.5 * v; }, k);
+        }
+#else
         // s = 2^ceil(log2(vmax)) through the exponent field (exact); 1 for qd = 0 and for non-finite rows (which come out NaN as
         // they should); the exponent is kept where s^2 neither overflows nor underflows
         int ex = 0;
@@ -178,6 +317,7 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, cons
         if (!wave_any(wide)) polar();
         else if (!wide) polar();
         else reference_scheme();
+#endif
     }
 }
 

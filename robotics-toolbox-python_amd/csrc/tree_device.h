@@ -38,6 +38,7 @@ struct alignas(16) DevGroup {   // wave-uniform, read through the scalar cache
 static_assert(sizeof(DevGroup) == 208, "DevGroup layout");
 
 constexpr int kTreeSlotDoubles = 18;   // v (6), a (6), force accumulator (6)
+constexpr int kTreeBilinearSlotDoubles = 24;   // tree_bilinear_core: v of both velocity fields (12), a (6), force accumulator (6)
 
 RTB_HD V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
 
@@ -86,9 +87,26 @@ RTB_HD void tree_trig(GroupsP groups, InQ qin, double (&sn)[NG], double (&cs)[NG
 }
 
 // The two recursions with the sines and cosines supplied (the dynamics terms run several passes at one configuration).
-template <int NG, class GroupsP, class InQ, class InQd, class InQdd, class Out, class Slot>
+#ifndef RTB_TREE_ACC_ONLY
+#define RTB_TREE_ACC_ONLY 1      // 0: the unit-acceleration passes run the full recursion (A/B switch, scripts/build_variant.sh)
+#endif
+// VEL = false (compile-time): every joint velocity is zero -- the unit-acceleration passes that build the columns of M(q) (Dynamics.inertia,
+// the inertia half of Dynamics.accel).  All velocities stay exactly zero through the recursion, so everything that multiplies them is left
+// out: the two motion transforms of (v, w), the v x vJ terms, I v and the v x* (I v) forces -- about 90 of the ~210 operations a group's forward
+// step costs.  The terms left out are exact zeros in the full recursion (x * 0 + y == y), so the torques are the same numbers.
+// first (VEL = false and gravity = 0 only; wave-uniform): the groups before position `first` are at rest AND their torques are not wanted --
+// the column pass for joint i of a robot whose groups are numbered in joint order starts at group i: every group before it has zero
+// acceleration (it is no descendant of i), so its forward step is skipped (its saved state is written as zeros for the branches that hang
+// off it) and so is its backward step (M's entries above the diagonal come from the mirror).  dyn_device.h does the same for DH chains.
+#ifndef RTB_TREE_BILINEAR
+#define RTB_TREE_BILINEAR 1      // 0: Dynamics.coriolis by the polar form over full passes (two per column), the first implementation
+#endif
+#ifndef RTB_TREE_SKIP_PREFIX
+#define RTB_TREE_SKIP_PREFIX 1
+#endif
+template <int NG, bool VEL = true, class GroupsP, class InQ, class InQd, class InQdd, class Out, class Slot>
 RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], const double (&cs)[NG], V3 gravity, InQ qin, InQd qdin, InQdd qddin,
-                          Out tau, Slot slot)
+                          Out tau, Slot slot, int first = 0)
 {
     V3 Fl[NG], Fa[NG];
     for (int k = 0; k < nslots; ++k)
@@ -99,9 +117,18 @@ RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], co
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
         const auto &g = groups[j];
+        if (!VEL && j < first) {
+            al = v3(0, 0, 0); aa = v3(0, 0, 0);
+            if (g.save_slot >= 0) {
+                const int b = g.save_slot * kTreeSlotDoubles;
+                for (int e = 6; e < 12; ++e) slot(b + e) = 0.0;
+            }
+            Fl[j] = v3(0, 0, 0); Fa[j] = v3(0, 0, 0);
+            continue;
+        }
         const bool pris = jm_prismatic(g.jmeta) != 0;
         const int col = jm_jq(g.jmeta);
-        const double qdj = qdin(col), qddj = qddin(col);
+        const double qdj = VEL ? qdin(col) : 0.0, qddj = qddin(col);
         const double d = pris ? qin(col) * (jm_flip(g.jmeta) ? -1.0 : 1.0) : 0.0;
         V3 pvl, pva, pal, paa;     // parent state
         if (g.parent < 0) {
@@ -109,7 +136,8 @@ RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], co
             pal = v3(-gravity.x, -gravity.y, -gravity.z); paa = v3(0, 0, 0);     // a_grav = -SpatialAcceleration(gravity)
         } else if (g.parent_slot >= 0) {
             const int b = g.parent_slot * kTreeSlotDoubles;
-            pvl = v3(slot(b + 0), slot(b + 1), slot(b + 2)); pva = v3(slot(b + 3), slot(b + 4), slot(b + 5));
+            if (VEL) { pvl = v3(slot(b + 0), slot(b + 1), slot(b + 2)); pva = v3(slot(b + 3), slot(b + 4), slot(b + 5)); }
+            else { pvl = v3(0, 0, 0); pva = v3(0, 0, 0); }
             pal = v3(slot(b + 6), slot(b + 7), slot(b + 8)); paa = v3(slot(b + 9), slot(b + 10), slot(b + 11));
         } else {
             pvl = vl; pva = va; pal = al; paa = aa;
@@ -118,33 +146,44 @@ RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], co
         const V3 p = v3(g.C.t[0] + g.C.r[2] * d, g.C.t[1] + g.C.r[5] * d, g.C.t[2] + g.C.r[8] * d);
         const double s = sn[j], c = cs[j];
         // X_up on motion vectors: w' = R^T w ; v' = R^T (v + w x p)
-        va = rz_t(s, c, seg_rt(g, pva));
-        vl = rz_t(s, c, seg_rt(g, pvl + cross(pva, p)));
+        if (VEL) {
+            va = rz_t(s, c, seg_rt(g, pva));
+            vl = rz_t(s, c, seg_rt(g, pvl + cross(pva, p)));
+        }
         aa = rz_t(s, c, seg_rt(g, paa));
         al = rz_t(s, c, seg_rt(g, pal + cross(paa, p)));
         // joint velocity vJ = s_j qd (the motion subspace ignores `flip`, ET.py:592-608), then
         // a += s_j qdd + v x vJ with the spatial motion cross product (Robot.py:1866-1870)
         if (pris) {
-            vl.z += qdj;
-            al = al + cross(va, v3(0, 0, qdj));
+            if (VEL) {
+                vl.z += qdj;
+                al = al + cross(va, v3(0, 0, qdj));
+            }
             al.z += qddj;
         } else {
-            va.z += qdj;
-            al = al + cross(vl, v3(0, 0, qdj));
-            aa = aa + cross(va, v3(0, 0, qdj));
+            if (VEL) {
+                va.z += qdj;
+                al = al + cross(vl, v3(0, 0, qdj));
+                aa = aa + cross(va, v3(0, 0, qdj));
+            }
             aa.z += qddj;
         }
         if (g.save_slot >= 0) {
             const int b = g.save_slot * kTreeSlotDoubles;
-            slot(b + 0) = vl.x; slot(b + 1) = vl.y; slot(b + 2) = vl.z; slot(b + 3) = va.x; slot(b + 4) = va.y; slot(b + 5) = va.z;
+            if (VEL) { slot(b + 0) = vl.x; slot(b + 1) = vl.y; slot(b + 2) = vl.z; slot(b + 3) = va.x; slot(b + 4) = va.y; slot(b + 5) = va.z; }
             slot(b + 6) = al.x; slot(b + 7) = al.y; slot(b + 8) = al.z; slot(b + 9) = aa.x; slot(b + 10) = aa.y; slot(b + 11) = aa.z;
         }
         // f = I a + v x* (I v) with I = [[M 1, -h x], [h x, I_bar]]  (Robot.py:1872)
         const V3 h = v3(g.h[0], g.h[1], g.h[2]);
-        const V3 Ivl = g.M * vl + cross(va, h), Iva = cross(h, vl) + inertia_rot(g, va);
         const V3 Ial = g.M * al + cross(aa, h), Iaa = cross(h, al) + inertia_rot(g, aa);
-        Fl[j] = Ial + cross(va, Ivl);
-        Fa[j] = (Iaa + cross(va, Iva)) + cross(vl, Ivl);
+        if (VEL) {
+            const V3 Ivl = g.M * vl + cross(va, h), Iva = cross(h, vl) + inertia_rot(g, va);
+            Fl[j] = Ial + cross(va, Ivl);
+            Fa[j] = (Iaa + cross(va, Iva)) + cross(vl, Ivl);
+        } else {
+            Fl[j] = Ial;
+            Fa[j] = Iaa;
+        }
         sched_fence();
     }
 
@@ -153,6 +192,7 @@ RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], co
 #pragma unroll
     for (int jj = 0; jj < NG; ++jj) {
         const int j = NG - 1 - jj;
+        if (!VEL && j < first) continue;
         const auto &g = groups[j];
         const bool pris = jm_prismatic(g.jmeta) != 0;
         V3 fl = Fl[j] + cl, fa = Fa[j] + ca;
@@ -181,6 +221,121 @@ RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], co
     }
 }
 
+// ---- one column of C(q, qd), evaluated directly.  The velocity torque of Robot.rne (gravity 0, qdd = 0) is a quadratic form tau(v) = B(v, v)
+// of the joint velocities, and what Dynamics.coriolis assembles from its n + n (n - 1) / 2 unit-velocity passes (robot/Dynamics.py:811-861)
+// is column k = B(qd, e_k): sum_i qd_i B(e_i, e_k).  B is evaluated here by carrying BOTH velocity fields through one recursion -- u = qd
+// and w = e_k -- and replacing every product of two velocities x(v) y(v) of Robot.py:1866-1872 by x(u) y(w) + x(w) y(u) (= 2 B; the caller
+// halves).  Against the two full passes per column of the polar form tau(qd + s e_k) - tau(qd - s e_k) this is one pass of ~1.1x the
+// arithmetic, exact for any spread of velocities (no scale s to choose, no cancellation), and the groups before `first` (w = 0 there: their
+// accelerations and forces vanish) only advance u.  `first` as in tree_rne_core; slots of kTreeBilinearSlotDoubles.
+template <int NG, class GroupsP, class InQ, class InQd, class Out, class Slot>
+RTB_HD void tree_bilinear_core(GroupsP groups, int nslots, const double (&sn)[NG], const double (&cs)[NG], InQ qin, InQd qdin, int k, Out tau,
+                               Slot slot, int first)
+{
+    constexpr int SD = kTreeBilinearSlotDoubles;
+    V3 Fl[NG], Fa[NG];
+    for (int i = 0; i < nslots; ++i)
+        for (int e = 18; e < 24; ++e) slot(i * SD + e) = 0.0;
+    const V3 o = v3(0, 0, 0);
+    V3 ul = o, ua = o, wl = o, wa = o, al = o, aa = o;       // previous group: velocity under u, under w, the bilinear acceleration
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const auto &g = groups[j];
+        const bool pris = jm_prismatic(g.jmeta) != 0;
+        const int col = jm_jq(g.jmeta);
+        const double qdu = qdin(col), qdw = col == k ? 1.0 : 0.0;
+        const double d = pris ? qin(col) * (jm_flip(g.jmeta) ? -1.0 : 1.0) : 0.0;
+        const bool rest = j < first;                           // wave-uniform: w, a and f are zero up to here
+        V3 pul, pua, pwl, pwa, pal, paa;
+        if (g.parent < 0) {
+            pul = o; pua = o; pwl = o; pwa = o; pal = o; paa = o;
+        } else if (g.parent_slot >= 0) {
+            const int b = g.parent_slot * SD;
+            pul = v3(slot(b + 0), slot(b + 1), slot(b + 2)); pua = v3(slot(b + 3), slot(b + 4), slot(b + 5));
+            if (rest) { pwl = o; pwa = o; pal = o; paa = o; }
+            else {
+                pwl = v3(slot(b + 6), slot(b + 7), slot(b + 8)); pwa = v3(slot(b + 9), slot(b + 10), slot(b + 11));
+                pal = v3(slot(b + 12), slot(b + 13), slot(b + 14)); paa = v3(slot(b + 15), slot(b + 16), slot(b + 17));
+            }
+        } else {
+            pul = ul; pua = ua; pwl = wl; pwa = wa; pal = al; paa = aa;
+        }
+        const V3 p = v3(g.C.t[0] + g.C.r[2] * d, g.C.t[1] + g.C.r[5] * d, g.C.t[2] + g.C.r[8] * d);
+        const double s = sn[j], c = cs[j];
+        ua = rz_t(s, c, seg_rt(g, pua));
+        ul = rz_t(s, c, seg_rt(g, pul + cross(pua, p)));
+        if (rest) {
+            if (pris) ul.z += qdu; else ua.z += qdu;
+            wl = o; wa = o; al = o; aa = o;
+            if (g.save_slot >= 0) {
+                const int b = g.save_slot * SD;
+                slot(b + 0) = ul.x; slot(b + 1) = ul.y; slot(b + 2) = ul.z; slot(b + 3) = ua.x; slot(b + 4) = ua.y; slot(b + 5) = ua.z;
+                for (int e = 6; e < 18; ++e) slot(b + e) = 0.0;
+            }
+            Fl[j] = o; Fa[j] = o;
+            sched_fence();
+            continue;
+        }
+        wa = rz_t(s, c, seg_rt(g, pwa));
+        wl = rz_t(s, c, seg_rt(g, pwl + cross(pwa, p)));
+        aa = rz_t(s, c, seg_rt(g, paa));
+        al = rz_t(s, c, seg_rt(g, pal + cross(paa, p)));
+        // a += v x vJ (Robot.py:1866-1870), both ways round; cross(v, (0, 0, t)) = (v.y t, -v.x t, 0)
+        if (pris) {
+            ul.z += qdu; wl.z += qdw;
+            al = al + (cross(ua, v3(0, 0, qdw)) + cross(wa, v3(0, 0, qdu)));
+        } else {
+            ua.z += qdu; wa.z += qdw;
+            al = al + (cross(ul, v3(0, 0, qdw)) + cross(wl, v3(0, 0, qdu)));
+            aa = aa + (cross(ua, v3(0, 0, qdw)) + cross(wa, v3(0, 0, qdu)));
+        }
+        if (g.save_slot >= 0) {
+            const int b = g.save_slot * SD;
+            slot(b + 0) = ul.x; slot(b + 1) = ul.y; slot(b + 2) = ul.z; slot(b + 3) = ua.x; slot(b + 4) = ua.y; slot(b + 5) = ua.z;
+            slot(b + 6) = wl.x; slot(b + 7) = wl.y; slot(b + 8) = wl.z; slot(b + 9) = wa.x; slot(b + 10) = wa.y; slot(b + 11) = wa.z;
+            slot(b + 12) = al.x; slot(b + 13) = al.y; slot(b + 14) = al.z; slot(b + 15) = aa.x; slot(b + 16) = aa.y; slot(b + 17) = aa.z;
+        }
+        // f = I a + v x* (I v) (Robot.py:1872) -> I a + u x* (I w) + w x* (I u);  v x* (fl, fa) = (va x fl, va x fa + vl x fl)
+        const V3 h = v3(g.h[0], g.h[1], g.h[2]);
+        const V3 Iul = g.M * ul + cross(ua, h), Iua = cross(h, ul) + inertia_rot(g, ua);
+        const V3 Iwl = g.M * wl + cross(wa, h), Iwa = cross(h, wl) + inertia_rot(g, wa);
+        const V3 Ial = g.M * al + cross(aa, h), Iaa = cross(h, al) + inertia_rot(g, aa);
+        Fl[j] = Ial + (cross(ua, Iwl) + cross(wa, Iul));
+        Fa[j] = (Iaa + (cross(ua, Iwa) + cross(wa, Iua))) + (cross(ul, Iwl) + cross(wl, Iul));
+        sched_fence();
+    }
+    // ---- backward recursion: tree_rne_core's, on the wider slots
+    V3 cl = o, ca = o;
+#pragma unroll
+    for (int jj = 0; jj < NG; ++jj) {
+        const int j = NG - 1 - jj;
+        const auto &g = groups[j];
+        const bool pris = jm_prismatic(g.jmeta) != 0;
+        V3 fl = Fl[j] + cl, fa = Fa[j] + ca;
+        if (g.save_slot >= 0) {
+            const int b = g.save_slot * SD + 18;
+            fl = fl + v3(slot(b + 0), slot(b + 1), slot(b + 2));
+            fa = fa + v3(slot(b + 3), slot(b + 4), slot(b + 5));
+        }
+        tau(g.out_col, pris ? fl.z : fa.z);
+        cl = o; ca = o;
+        if (g.parent >= 0) {
+            const double d = pris ? qin(jm_jq(g.jmeta)) * (jm_flip(g.jmeta) ? -1.0 : 1.0) : 0.0;
+            const V3 p = v3(g.C.t[0] + g.C.r[2] * d, g.C.t[1] + g.C.r[5] * d, g.C.t[2] + g.C.r[8] * d);
+            const V3 tl = seg_r(g, rz(sn[j], cs[j], fl));
+            const V3 ta = seg_r(g, rz(sn[j], cs[j], fa)) + cross(p, tl);
+            if (g.parent_slot >= 0) {
+                const int b = g.parent_slot * SD + 18;
+                slot(b + 0) += tl.x; slot(b + 1) += tl.y; slot(b + 2) += tl.z;
+                slot(b + 3) += ta.x; slot(b + 4) += ta.y; slot(b + 5) += ta.z;
+            } else {
+                cl = tl; ca = ta;
+            }
+        }
+        sched_fence();
+    }
+}
+
 template <int NG, class GroupsP, class InQ, class InQd, class InQdd, class Out, class Slot>
 RTB_HD void tree_rne_lane(GroupsP groups, int nslots, V3 gravity, InQ qin, InQd qdin, InQdd qddin, Out tau, Slot slot)
 {
@@ -195,7 +350,8 @@ RTB_HD void tree_rne_lane(GroupsP groups, int nslots, V3 gravity, InQ qin, InQd 
 //   inertia   pass i = rne(q, 0, e_i, gravity 0) gives row i of M (:752-758); kept: its entries j >= i, in the packed lower triangle
 //             mA[j (j + 1) / 2 + i] -- the kernel's flush mirrors them (M is symmetric; the mirrored half differs from the reference's
 //             separately rounded entries by rounding only), 21 instead of 36 doubles of LDS per lane for n = 6
-//   coriolis  mA = C(q, qd): the polar form / the reference's own 28-pass scheme, chosen per row exactly as dyn_device.h does
+//   coriolis  mA = C(q, qd): column k = B(qd, e_k) from one two-field pass (tree_bilinear_core); RTB_TREE_BILINEAR = 0: the polar form /
+//             the reference's own scheme of rounds 1-3
 //   accel     mA[0..n) = qdd = M^-1 (torque - rne(q, qd, 0))          (:492-505; M's lower triangle, LDL^T)
 template <int NG>
 RTB_HD void tree_opaque(double (&sn)[NG], double (&cs)[NG])
@@ -228,12 +384,15 @@ RTB_HD void tree_dyn_lane(GroupsP groups, int nslots, const double *mine, double
     auto none = [&](int) { return 0.0; };
     double sn[NG], cs[NG];
     tree_trig<NG>(groups, qin, sn, cs);
+    bool in_joint_order = RTB_TREE_SKIP_PREFIX && RTB_TREE_ACC_ONLY;      // group j moves joint j: a column pass can start at its own group
+#pragma unroll
+    for (int j = 0; j < NG; ++j) in_joint_order = in_joint_order && jm_jq(groups[j].jmeta) == j;
     if (MODE == kDynInertia) {
 #pragma unroll 1
         for (int i = 0; i < NG; ++i) {
             tree_opaque<NG>(sn, cs);
-            tree_rne_core<NG>(groups, nslots, sn, cs, zero, qin, none, [&](int j) { return j == i ? 1.0 : 0.0; },
-                              [&](int j, double v) { if (j >= i) mA[j * (j + 1) / 2 + i] = v; }, slot);
+            tree_rne_core<NG, !RTB_TREE_ACC_ONLY>(groups, nslots, sn, cs, zero, qin, none, [&](int j) { return j == i ? 1.0 : 0.0; },
+                                     [&](int j, double v) { if (j >= i) mA[j * (j + 1) / 2 + i] = v; }, slot, in_joint_order ? i : 0);
         }
     }
     if (MODE == kDynAccel) {
@@ -244,8 +403,8 @@ RTB_HD void tree_dyn_lane(GroupsP groups, int nslots, const double *mine, double
 #pragma unroll 1
         for (int i = 0; i < NG; ++i) {
             tree_opaque<NG>(sn, cs);
-            tree_rne_core<NG>(groups, nslots, sn, cs, zero, qin, none, [&](int j) { return j == i ? 1.0 : 0.0; },
-                              [&](int j, double v) { if (j <= i) mA[i * (i + 1) / 2 + j] = v; }, slot);
+            tree_rne_core<NG, !RTB_TREE_ACC_ONLY>(groups, nslots, sn, cs, zero, qin, none, [&](int j) { return j == i ? 1.0 : 0.0; },
+                                     [&](int j, double v) { if (j >= i) mA[j * (j + 1) / 2 + i] = v; }, slot, in_joint_order ? i : 0);
         }
         double x[NG], M[NG][NG];
 #pragma unroll
@@ -257,6 +416,18 @@ RTB_HD void tree_dyn_lane(GroupsP groups, int nslots, const double *mine, double
         for (int j = 0; j < NG; ++j) mA[j] = x[j];
     }
     if (MODE == kDynCoriolis) {
+#if RTB_TREE_BILINEAR
+        // column k = B(qd, e_k), one two-field pass each (tree_bilinear_core)
+        bool ordered = true;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) ordered = ordered && jm_jq(groups[j].jmeta) == j;
+#pragma unroll 1
+        for (int k = 0; k < NG; ++k) {
+            tree_opaque<NG>(sn, cs);
+            tree_bilinear_core<NG>(groups, nslots, sn, cs, qin, [&](int j) { return mine[NG + j]; }, k,
+                                   [&](int r, double v) { mA[r * NG + k] = 0.5 * v; }, slot, ordered ? k : 0);
+        }
+#else
         // dyn_device.h, the same two schemes and the same per-row choice between them
         double qdv[NG], vmax = 0.0;
 #pragma unroll
@@ -315,6 +486,7 @@ RTB_HD void tree_dyn_lane(GroupsP groups, int nslots, const double *mine, double
         if (wave_any(wide)) {
             if (wide) reference_scheme();
         }
+#endif
     }
 }
 

@@ -195,7 +195,7 @@ static hipError_t launch_tree_dyn_one(dim3 grid, hipStream_t s, int nslots, cons
 {
     constexpr int K = MODE == kDynInertia ? 1 : (MODE == kDynCoriolis ? 2 : 3);
     constexpr int W = MODE == kDynCoriolis ? NG * NG : NG * (NG + 1) / 2 + (MODE == kDynAccel ? NG : 0);
-    const size_t lds = (size_t)kWave * (((K * NG) | 1) + (W | 1) + kTreeSlotDoubles * nslots) * sizeof(double);
+    const size_t lds = (size_t)kWave * (((K * NG) | 1) + (W | 1) + (MODE == kDynCoriolis ? kTreeBilinearSlotDoubles : kTreeSlotDoubles) * nslots) * sizeof(double);
     *lds_out = lds;
     if (lds > 160 * 1024) return hipSuccess;          // reported by the caller
     auto k = k_tree_dyn<NG, MODE>;

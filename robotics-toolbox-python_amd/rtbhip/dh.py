@@ -576,7 +576,7 @@ class DHRobot(RobotKinematics):
     def coriolis(self, q, qd):
         """Coriolis/centripetal matrix C(q, qd): (n,n) or (N,n,n)
         (reference Dynamics.coriolis robot/Dynamics.py:765-861: n + n(n-1)/2 frictionless rne calls; here the same matrix from
-        2 n passes, csrc/dyn_device.h)."""
+        n two-field passes -- column k is the bilinear form B(qd, e_k) of the velocity torque, csrc/dyn_device.h)."""
         arrs, N, single, tm, ptr, stream, mem, dev = self._dyn_args([q, qd])
         Cm = self._empty((N, self.n, self.n), tm, dev)
         check(lib().rtbhip_coriolis(self._dyn_handle(), ptr(arrs[0]), ptr(arrs[1]), N, ptr(Cm), mem, stream))

@@ -512,7 +512,7 @@ class ERobot(RobotKinematics):
 
     def coriolis(self, q, qd):
         """Coriolis / centripetal matrix C(q, qd): (n,n) or (N,n,n) (reference Dynamics.coriolis robot/Dynamics.py:765-861:
-        n + n(n-1)/2 Robot.rne calls per configuration; here 2 n passes, the scheme of csrc/dyn_device.h)."""
+        n + n(n-1)/2 Robot.rne calls per configuration; here n two-field passes, column k = B(qd, e_k): csrc/tree_device.h tree_bilinear_core)."""
         arrs, N, single, ptr, stream, mem, empty = self._dyn_args([q, qd])
         Cm = empty((N, self.n, self.n))
         check(lib().rtbhip_tree_coriolis(self._handle(), ptr(arrs[0]), ptr(arrs[1]), N, ptr(Cm), mem, stream))

@@ -1,6 +1,11 @@
 #!/bin/bash
-# build_variant.sh NAME -DFOO=1 ... : builds robotics-toolbox-python_amd/lib/variants/NAME.so with extra defines (A/B runs via RTBHIP_LIB)
+# build_variant.sh SRC NAME -DFOO=1 ... : robotics-toolbox-python_amd/lib/variants/NAME.so = the product's objects (build/obj, from build_lib) with
+# csrc/SRC.hip recompiled under the extra defines -- an A/B library for RTBHIP_LIB without a full rebuild (build_ik_variant.sh for any kernel file).
+set -e
 R=$(cd $(dirname $0)/.. && pwd)
-name=$1; shift
-mkdir -p $R/robotics-toolbox-python_amd/lib/variants
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -w -I$R/include "$@" $R/robotics-toolbox-python_amd/csrc/*.cpp $R/robotics-toolbox-python_amd/csrc/*.hip -o $R/robotics-toolbox-python_amd/lib/variants/$name.so
+src=$1; name=$2; shift 2
+mkdir -p $R/robotics-toolbox-python_amd/lib/variants $R/build/variant
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -I$R/include "$@" -c $R/robotics-toolbox-python_amd/csrc/$src.hip -o $R/build/variant/${src}_$name.o
+objs=$(ls $R/build/obj/*.o | grep -v $src.hip.o)
+hipcc --offload-arch=gfx950 -shared -fPIC $objs $R/build/variant/${src}_$name.o -o $R/robotics-toolbox-python_amd/lib/variants/$name.so
+ls -la $R/robotics-toolbox-python_amd/lib/variants/$name.so

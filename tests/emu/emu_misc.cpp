@@ -142,7 +142,7 @@ static void tree_run(const Tree *t, const double *q, const double *qd, const dou
 template <int NG, int MODE>
 static void tree_dyn_run(const Tree *t, const double *q, const double *qd, const double *tq, int64_t N, V3 g, double *out)
 {
-    std::vector<double> slots((size_t)kTreeSlotDoubles * std::max(1, t->nslots));
+    std::vector<double> slots((size_t)kTreeBilinearSlotDoubles * std::max(1, t->nslots));
     constexpr int W = MODE == kDynAccel ? NG : NG * NG;
     for (int64_t s = 0; s < N; ++s) {
         double mine[3 * NG], A[NG * NG + NG];

@@ -128,15 +128,15 @@ def test_gpu_rne_at_rest_variant(robot):
 
 
 def _coriolis_scale_cases(n, rng):
-    """qd rows of very different scales (and mixed within a row, zero, one nonzero entry): the two-passes-per-column coriolis of
-    dyn_device.h probes with a power of two next above max|qd|, so its accuracy must not depend on the scale; a row whose nonzero
-    velocities span more than 2^16 (row 6: nine orders of magnitude) takes the reference's own 28-pass scheme instead (in the
-    one-tile regrouping of round 1, whose sums S and U carry the large entries: 1e-12 of max|C| there, 1e-13 elsewhere)."""
+    """qd rows of very different scales (and mixed within a row, zero, one nonzero entry).  dyn_device.h evaluates column k as the bilinear form
+    B(qd, e_k) in one two-field pass -- linear in qd, so its accuracy cannot depend on the scale or on the spread within a row.  (Rounds 1-3
+    probed with qd +- s e_k and sent rows spanning more than 2^16 to the reference's own 28-pass scheme; the tolerances below are from then:
+    for row 6 -- nine orders of magnitude -- 1e-12 of max|C| is the rounding of the REFERENCE's combination, which the oracle restates.)"""
     base = rng.normal(size=(8, n))
     rows = [base[0] * 1e-9, base[1] * 1e-3, base[2], base[3] * 1e3, base[4] * 1e9, np.zeros(n), base[6] * np.logspace(-6, 3, n)]
     one = np.zeros(n); one[n // 2] = -3.7
     rows.append(one)
-    rows.append(base[7] * np.logspace(-1.5, 1.5, n))           # spread below 2^16: still the two-pass scheme
+    rows.append(base[7] * np.logspace(-1.5, 1.5, n))           # a moderate spread
     return np.array(rows)
 
 
@@ -299,7 +299,8 @@ def test_gpu_dynamics_limits_and_errors():
 
 @pytest.mark.gpu
 def test_gpu_coriolis_row_does_not_depend_on_its_tile_mates():
-    """The round-2 advisor's finding, fixed in round 3: the choice between the polar form and the reference's 28-pass scheme is made per ROW, so a
+    """The round-2 advisor's finding (a row's result depended on its tile mates: one scheme per WAVE, chosen by the widest row).  Round 3 made
+    the choice per row; round 4's two-field pass has no choice to make at all.  The property stays pinned: a
     row's C(q, qd) is bit-identical whether it is evaluated alone, among ordinary rows, or next to a row whose velocities span nine orders of
     magnitude (which used to send its whole 64-row tile to the other scheme).  DH kernel and tree kernel."""
     from rtbhip import urdf
