@@ -88,25 +88,28 @@ def ik_roofline(lm_iterations_per_s):
 #     manipulability  + J J^T (21 entries x 7 FMAs = 294) + 6x6 LU determinant (144) + sqrt                                      -> 1 050
 #     jacobm          + J J^T 294 + LDL^T 100 + 7 back-substitutions (504) + 49 Hessian-block contractions x 30 (1 470) + m        -> 3 000
 ALGO_FLOPS_PER_UNIT = {"gravload": 1568, "inertia": 5012, "coriolis": 11690, "accel": 7114, "tree_ur5": 1980, "jacob0_dot": 1755,
-                       "manipulability": 1050, "jacobm": 3000, "tree_inertia_ur5": 3804, "tree_coriolis_ur5": 8766, "tree_accel_ur5": 5568}
+                       "manipulability": 1050, "jacobm": 3000, "tree_inertia_ur5": 3804, "tree_coriolis_ur5": 8766, "tree_accel_ur5": 5568,
+                       "tree_gravload_ur5": 1344}        # 6 acceleration-only link-passes + 6 sincos
 # VALU instructions per lane actually EXECUTED (SQ_INSTS_VALU / SQ_WAVES, profiles/r03_a_sq_summary.txt; coriolis and the tree dynamics kernels as
 # rebuilt in round 4: profiles/r04_u_sq_tree_dyn.txt, r04_v_sq_dyn.txt): reported beside
 # the roofline as `valu_issue_util` (share of the chip's fp64 issue slots the kernel fills) -- a diagnostic, not a roofline: a kernel that
 # executed more instructions for the same answer would score higher on it.
 VALU_PER_UNIT = {"gravload": 833, "inertia": 3433, "coriolis": 5954, "accel": 3377, "tree_ur5": 1929, "jacob0_dot": 1692,
                  "manipulability": 1512, "jacobm": 2732,
-                 "tree_inertia_ur5": 4345, "tree_coriolis_ur5": 10864, "tree_accel_ur5": 7216}
+                 "tree_inertia_ur5": 4345, "tree_coriolis_ur5": 10864, "tree_accel_ur5": 7216, "tree_gravload_ur5": 1275}
 
 
 def valu_roofline(key, units_per_s, kernel, hbm_bytes_per_unit):
     flops = ALGO_FLOPS_PER_UNIT[key]
     tf = flops * units_per_s / 1e12
-    instr = VALU_PER_UNIT[key]
-    return {"bound": "fp64-valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
-            "algorithmic_flops_per_unit": flops, "flops_source": "DESIGN.md section 5 (full / acceleration-only / two-field link-passes at 270 / 164 / 356 flop, 60 flop per sincos; FK + Jacobian 600 flop + the consumer's own products)",
-            "kernel": kernel, "hbm_GBs": hbm_bytes_per_unit * units_per_s / 1e9,
-            "valu_issue_util": 2.0 * instr * units_per_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
-            "valu_instructions_per_unit_measured": instr}
+    out = {"bound": "fp64-valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
+           "algorithmic_flops_per_unit": flops, "flops_source": "DESIGN.md section 5 (full / acceleration-only / two-field link-passes at 270 / 164 / 356 flop, 60 flop per sincos; FK + Jacobian 600 flop + the consumer's own products)",
+           "kernel": kernel, "hbm_GBs": hbm_bytes_per_unit * units_per_s / 1e9}
+    instr = VALU_PER_UNIT.get(key)
+    if instr is not None:
+        out["valu_issue_util"] = 2.0 * instr * units_per_s / 1e12 / FP64_VALU_PEAK_TFLOPS
+        out["valu_instructions_per_unit_measured"] = instr
+    return out
 
 
 def main():
@@ -361,6 +364,11 @@ def main():
         print(json.dumps({"metric": "triples/sec (URDF UR5 Robot.rne, %d link groups)" % er.n, "value": N / (avg * 1e-3), "unit": "triples/s",
                           "n": N, "kernel_avg_ms": avg, "kernel_min_ms": best,
                           "roofline": valu_roofline("tree_ur5", N / (avg * 1e-3), "k_tree_rne<6>", byts)}), flush=True)
+        # Dynamics.gravload of the same arm: rtbhip_tree_rne with qd = NULL -> the at-rest instantiation (no velocity half, no qd row)
+        avg, best = ev_time(lambda: er.gravload(q), args.steps, 3)
+        print(json.dumps({"metric": "configurations/sec (URDF UR5 gravload, %d link groups)" % er.n, "value": N / (avg * 1e-3), "unit": "configurations/s",
+                          "n": N, "kernel_avg_ms": avg, "kernel_min_ms": best,
+                          "roofline": valu_roofline("tree_gravload_ur5", N / (avg * 1e-3), "k_tree_rne<6, at rest>", 16 * er.n)}), flush=True)
         # the Dynamics-mixin terms of the same URDF arm (Dynamics.inertia / coriolis / accel over Robot.rne): k_tree_dyn<6, mode>
         tq = qdd
         for name, fn, byts, key in (("inertia", lambda: er.inertia(q), 8 * er.n + 8 * er.n * er.n, "tree_inertia_ur5"),

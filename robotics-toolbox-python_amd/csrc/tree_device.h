@@ -336,12 +336,14 @@ RTB_HD void tree_bilinear_core(GroupsP groups, int nslots, const double (&sn)[NG
     }
 }
 
-template <int NG, class GroupsP, class InQ, class InQd, class InQdd, class Out, class Slot>
+// ATREST: the caller has no joint velocities (rtbhip_tree_rne with qd = NULL: Dynamics.gravload, Dynamics.itorque) -- the recursion
+// without its velocity half (tree_rne_core VEL = false), gravity still the base's acceleration.
+template <int NG, bool ATREST = false, class GroupsP, class InQ, class InQd, class InQdd, class Out, class Slot>
 RTB_HD void tree_rne_lane(GroupsP groups, int nslots, V3 gravity, InQ qin, InQd qdin, InQdd qddin, Out tau, Slot slot)
 {
     double sn[NG], cs[NG];
     tree_trig<NG>(groups, qin, sn, cs);
-    tree_rne_core<NG>(groups, nslots, sn, cs, gravity, qin, qdin, qddin, tau, slot);
+    tree_rne_core<NG, !ATREST>(groups, nslots, sn, cs, gravity, qin, qdin, qddin, tau, slot);
 }
 
 // ---- the Dynamics-mixin terms of an ETS robot (robot/Dynamics.py:704-861, 424-509 on Robot.rne): every Newton-Euler pass the

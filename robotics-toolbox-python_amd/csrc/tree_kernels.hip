@@ -20,7 +20,10 @@ struct TreeParams {
 
 constexpr int kTreeMaxGroups = 24;   // 17..24 link groups: the per-group state spills to scratch; served, not fast
 
-template <int NG>
+// ATREST (qd == NULL, robots of up to kTreeAtRestMax groups): the velocity half of the recursion is not compiled in and the qd row is neither
+// read nor staged.
+constexpr int kTreeAtRestMax = 12;
+template <int NG, bool ATREST>
 __global__ __launch_bounds__(kWave, (NG <= 8 ? 2 : 1)) void k_tree_rne(TreeParams tp, const DevGroup *groups_g, const double *__restrict__ q,
                                                       const double *__restrict__ qd, const double *__restrict__ qdd,
                                                       double *__restrict__ tau)
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(kWave, (NG <= 8 ? 2 : 1)) void k_tree_rne(TreeParam
             const int f = lane + kWave * k;
             const bool in = f < count;
             r0[k] = in ? g0[f] : 0.0;
-            r1[k] = (in && qd) ? g1[f] : 0.0;
+            r1[k] = (!ATREST && in && qd) ? g1[f] : 0.0;
             r2[k] = (in && qdd) ? g2[f] : 0.0;
         }
 #pragma unroll
@@ -50,14 +53,15 @@ __global__ __launch_bounds__(kWave, (NG <= 8 ? 2 : 1)) void k_tree_rne(TreeParam
             const int f = lane + kWave * k;
             const int r = f / NG, c = f - r * NG;
             double *dst = lds + r * stride + c;
-            dst[0] = r0[k]; dst[NG] = r1[k]; dst[2 * NG] = r2[k];
+            dst[0] = r0[k]; dst[2 * NG] = r2[k];
+            if (!ATREST) dst[NG] = r1[k];
         }
     }
     __syncthreads();
     double *mine = lds + lane * stride;
     if (lane < ncfg)
-        tree_rne_lane<NG>(groups, tp.nslots, v3(tp.grav[0], tp.grav[1], tp.grav[2]), [&](int c) { return mine[c]; },
-                          [&](int c) { return mine[NG + c]; }, [&](int c) { return mine[2 * NG + c]; },
+        tree_rne_lane<NG, ATREST>(groups, tp.nslots, v3(tp.grav[0], tp.grav[1], tp.grav[2]), [&](int c) { return mine[c]; },
+                          [&](int c) { return ATREST ? 0.0 : mine[NG + c]; }, [&](int c) { return mine[2 * NG + c]; },
                           [&](int c, double v) { mine[3 * NG + c] = v; },
                           [&](int i) -> double & { return slots[i * kWave + lane]; });
     __syncthreads();
@@ -68,7 +72,15 @@ template <int NG>
 static void launch_ng(dim3 grid, size_t lds, hipStream_t s, const TreeParams &tp, const DevGroup *g, const double *q,
                       const double *qd, const double *qdd, double *tau)
 {
-    auto k = k_tree_rne<NG>;
+    if constexpr (NG <= kTreeAtRestMax) {
+        if (!qd) {
+            auto k = k_tree_rne<NG, true>;
+            if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k, grid, dim3(kWave), lds, s, tp, g, q, qd, qdd, tau);
+            return;
+        }
+    }
+    auto k = k_tree_rne<NG, false>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, grid, dim3(kWave), lds, s, tp, g, q, qd, qdd, tau);
 }

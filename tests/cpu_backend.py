@@ -241,8 +241,8 @@ class EmuBackend:
         if rc is not None:
             return rc
         rec, ng = self._tree(h)
-        zeros = np.zeros(max(1, _val(N)) * ng)                # NULL qd / qdd = zeros (gravload, itorque): the replay driver wants arrays
-        qd = qd if _val(qd) else zeros.ctypes.data_as(_vp)
+        zeros = np.zeros(max(1, _val(N)) * ng)                # NULL qdd = zeros (gravload): the replay driver wants an array
+        qd = qd if _val(qd) else None                         # NULL qd stays NULL: the at-rest instantiation, as the product dispatches
         qdd = qdd if _val(qdd) else zeros.ctypes.data_as(_vp)
         self.emu.emu_tree_rne.argtypes = [_vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp]      # (tests/emu_harness.py re-types it per call)
         return self.emu.emu_tree_rne(rec, ng, q, qd, qdd, N, g, tau)

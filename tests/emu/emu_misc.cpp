@@ -131,11 +131,17 @@ static void tree_run(const Tree *t, const double *q, const double *qd, const dou
 {
     std::vector<double> slots((size_t)kTreeSlotDoubles * std::max(1, t->nslots));
     for (int64_t s = 0; s < N; ++s) {
-        const double *a = q + s * NG, *b = qd + s * NG, *c = qdd + s * NG;
+        const double *a = q + s * NG, *b = qd ? qd + s * NG : nullptr, *c = qdd + s * NG;
         double *o = tau + s * NG;
-        tree_rne_lane<NG>(t->groups.data(), t->nslots, g, [&](int k) { return a[k]; }, [&](int k) { return b[k]; },
-                          [&](int k) { return c[k]; }, [&](int k, double v) { o[k] = v; },
-                          [&](int i) -> double & { return slots[i]; });
+        // qd == NULL on a robot of up to 12 groups: the at-rest instantiation, as launch_tree_rne dispatches (tree_kernels.hip kTreeAtRestMax)
+        if (!b && NG <= 12)
+            tree_rne_lane<NG, true>(t->groups.data(), t->nslots, g, [&](int k) { return a[k]; }, [&](int) { return 0.0; },
+                                    [&](int k) { return c[k]; }, [&](int k, double v) { o[k] = v; },
+                                    [&](int i) -> double & { return slots[i]; });
+        else
+            tree_rne_lane<NG>(t->groups.data(), t->nslots, g, [&](int k) { return a[k]; }, [&](int k) { return b ? b[k] : 0.0; },
+                              [&](int k) { return c[k]; }, [&](int k, double v) { o[k] = v; },
+                              [&](int i) -> double & { return slots[i]; });
     }
 }
 // Dynamics-mixin terms of an ETS robot: tree_device.h's tree_dyn_lane on the CPU (mode 0 inertia, 1 coriolis, 2 accel)
