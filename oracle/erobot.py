@@ -91,10 +91,12 @@ def erobot_rne(links, q, qd, qdd, gravity=(0, 0, -9.81)):
     names = [l["name"] for l in links]
     parts = [_link_parts(l) for l in links]
     isjoint = [p[1] is not None for p in parts]
-    # jindex in link order (auto numbering by the depth-first order the caller supplies)
+    # jindex in link order (auto numbering by the depth-first order the caller supplies) -- or the links' own "jindex" entries when the robot was
+    # numbered by hand (BaseRobot.py: "all links must have a jindex, or none have a jindex"); q, qd, qdd are read by jindex (Robot.py:1830-1853),
+    # the torques are returned in GROUP order (Q[k, j], :1880)
     jindex, k = [], 0
-    for j in isjoint:
-        jindex.append(k if j else None)
+    for l, j in zip(links, isjoint):
+        jindex.append((l.get("jindex", k) if j else None))
         k += 1 if j else 0
     n = k
     q = np.asarray(q, dtype=np.float64).reshape(-1, n)

@@ -349,7 +349,7 @@ RTB_HD void tree_rne_lane(GroupsP groups, int nslots, V3 gravity, InQ qin, InQd 
 // ---- the Dynamics-mixin terms of an ETS robot (robot/Dynamics.py:704-861, 424-509 on Robot.rne): every Newton-Euler pass the
 // reference makes for ONE configuration, in one lane, as dyn_device.h does for DH chains.
 //   mine : this lane's inputs [q (n) | qd (n) | torque (n)] (what the mode needs)      mA : n x n tile, row-major
-//   inertia   pass i = rne(q, 0, e_i, gravity 0) gives row i of M (:752-758); kept: its entries j >= i, in the packed lower triangle
+//   inertia   pass i = rne(q, 0, e_c, gravity 0) for the column c that group i moves (:752-758); kept: its entries j >= i, in the packed lower triangle
 //             mA[j (j + 1) / 2 + i] -- the kernel's flush mirrors them (M is symmetric; the mirrored half differs from the reference's
 //             separately rounded entries by rounding only), 21 instead of 36 doubles of LDS per lane for n = 6
 //   coriolis  mA = C(q, qd): column k = B(qd, e_k) from one two-field pass (tree_bilinear_core); RTB_TREE_BILINEAR = 0: the polar form /
@@ -378,6 +378,25 @@ RTB_HD void tree_add(double (&a)[NG], int j, double v)
     for (int k = 0; k < NG; ++k) a[k] += (j == k) ? v : 0.0;
 }
 
+// group j moves q column j for every j: the robot is numbered in group order (wave-uniform)
+template <int NG, class GroupsP>
+RTB_HD bool tree_in_group_order(GroupsP groups)
+{
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < NG; ++j) ok = ok && jm_jq(groups[j].jmeta) == j;
+    return ok;
+}
+// the position of the group that moves q column r (the row of Mp that is row r of the reference's inertia matrix)
+template <int NG, class GroupsP>
+RTB_HD int tree_row_position(GroupsP groups, int r)
+{
+    int a = 0;
+#pragma unroll
+    for (int j = 0; j < NG; ++j) a = jm_jq(groups[j].jmeta) == r ? j : a;
+    return a;
+}
+
 template <int NG, int MODE, class GroupsP, class Slot>
 RTB_HD void tree_dyn_lane(GroupsP groups, int nslots, const double *mine, double *mA, V3 grav, Slot slot)
 {
@@ -386,15 +405,20 @@ RTB_HD void tree_dyn_lane(GroupsP groups, int nslots, const double *mine, double
     auto none = [&](int) { return 0.0; };
     double sn[NG], cs[NG];
     tree_trig<NG>(groups, qin, sn, cs);
-    bool in_joint_order = RTB_TREE_SKIP_PREFIX && RTB_TREE_ACC_ONLY;      // group j moves joint j: a column pass can start at its own group
-#pragma unroll
-    for (int j = 0; j < NG; ++j) in_joint_order = in_joint_order && jm_jq(groups[j].jmeta) == j;
+    // The unit-acceleration passes run in GROUP order: pass i accelerates the joint of the group at position i (q column jq_i), so that
+    // Mp[j][i] = torque of group j is the symmetric joint-space inertia in group order -- only the entries j >= i are computed (the groups before i are
+    // no descendants of i: at rest), packed lower triangle.  The reference's matrix is M[c, :] = rne(q, 0, e_c) with c a q COLUMN and the torques
+    // in group order (Robot.py:1875-1893): row jq_i of the reference's M is row i of Mp.  For a robot numbered in group order (every URDF robot,
+    // every robot whose jindex was assigned automatically) the two coincide; otherwise the inertia kernel's flush permutes the rows and accel
+    // permutes its right-hand side (below) -- tree_row_position().
+    constexpr bool skip = RTB_TREE_SKIP_PREFIX && RTB_TREE_ACC_ONLY;
     if (MODE == kDynInertia) {
 #pragma unroll 1
         for (int i = 0; i < NG; ++i) {
             tree_opaque<NG>(sn, cs);
-            tree_rne_core<NG, !RTB_TREE_ACC_ONLY>(groups, nslots, sn, cs, zero, qin, none, [&](int j) { return j == i ? 1.0 : 0.0; },
-                                     [&](int j, double v) { if (j >= i) mA[j * (j + 1) / 2 + i] = v; }, slot, in_joint_order ? i : 0);
+            const int ci = jm_jq(groups[i].jmeta);
+            tree_rne_core<NG, !RTB_TREE_ACC_ONLY>(groups, nslots, sn, cs, zero, qin, none, [&](int c) { return c == ci ? 1.0 : 0.0; },
+                                     [&](int j, double v) { if (j >= i) mA[j * (j + 1) / 2 + i] = v; }, slot, skip ? i : 0);
         }
     }
     if (MODE == kDynAccel) {
@@ -402,11 +426,21 @@ RTB_HD void tree_dyn_lane(GroupsP groups, int nslots, const double *mine, double
         tree_opaque<NG>(sn, cs);
         tree_rne_core<NG>(groups, nslots, sn, cs, grav, qin, [&](int j) { return mine[NG + j]; }, none,
                           [&](int j, double v) { tree_put<NG>(b, j, mine[2 * NG + j] - v); }, slot);
+        // the reference solves M qdd = torque - tau_0 with ITS M (rows by q column): row i of Mp stands in row jq_i, so the right-hand side of
+        // the group-ordered system is entry jq_i of (torque - tau_0)
+        if (!tree_in_group_order<NG>(groups)) {         // wave-uniform
+            double b2[NG];
+#pragma unroll
+            for (int a = 0; a < NG; ++a) b2[a] = dyn_pick<NG>(b, jm_jq(groups[a].jmeta));
+#pragma unroll
+            for (int a = 0; a < NG; ++a) b[a] = b2[a];
+        }
 #pragma unroll 1
         for (int i = 0; i < NG; ++i) {
             tree_opaque<NG>(sn, cs);
-            tree_rne_core<NG, !RTB_TREE_ACC_ONLY>(groups, nslots, sn, cs, zero, qin, none, [&](int j) { return j == i ? 1.0 : 0.0; },
-                                     [&](int j, double v) { if (j >= i) mA[j * (j + 1) / 2 + i] = v; }, slot, in_joint_order ? i : 0);
+            const int ci = jm_jq(groups[i].jmeta);
+            tree_rne_core<NG, !RTB_TREE_ACC_ONLY>(groups, nslots, sn, cs, zero, qin, none, [&](int c) { return c == ci ? 1.0 : 0.0; },
+                                     [&](int j, double v) { if (j >= i) mA[j * (j + 1) / 2 + i] = v; }, slot, skip ? i : 0);
         }
         double x[NG], M[NG][NG];
 #pragma unroll

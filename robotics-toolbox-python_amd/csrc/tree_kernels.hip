@@ -136,13 +136,16 @@ int launch_tree_rne(const Tree *t, const DevGroup *groups, const double *q, cons
 constexpr int kTreeDynMax = 12;
 
 // packed lower triangles (row r, column c <= r at r (r + 1) / 2 + c) of ncfg lanes -> the full symmetric (n, n) matrices, one contiguous run
+// (row r of the reference's matrix is row tree_row_position(r) of the group-ordered one: tree_device.h; the identity for robots numbered in group order)
 template <int NG>
-__device__ __forceinline__ void tree_flush_symmetric(const double *rows, int stride, int ncfg, double *__restrict__ dst, int lane)
+__device__ __forceinline__ void tree_flush_symmetric(ConstGroups groups, const double *rows, int stride, int ncfg, double *__restrict__ dst, int lane)
 {
     constexpr int W = NG * NG;
     const int total = ncfg * W;
+    const bool ordered = tree_in_group_order<NG>(groups);
     auto at = [&](int f) {
-        const int cfg = f / W, rem = f - cfg * W, r = rem / NG, c = rem - r * NG;
+        const int cfg = f / W, rem = f - cfg * W, r0 = rem / NG, c = rem - r0 * NG;
+        const int r = ordered ? r0 : tree_row_position<NG>(groups, r0);
         const int hi = r > c ? r : c, lo = r > c ? c : r;
         return rows[cfg * stride + hi * (hi + 1) / 2 + lo];
     };
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(kWave, 1) void k_tree_dyn(TreeParams tp, const DevG
                                 [&](int i) -> double & { return slots[i * kWave + lane]; });
     __syncthreads();
     if (MODE == kDynAccel) flush_run(A, w_stride, NG, ncfg, out + cfg0 * NG, lane);
-    else if (MODE == kDynInertia) tree_flush_symmetric<NG>(A, w_stride, ncfg, out + cfg0 * (NG * NG), lane);
+    else if (MODE == kDynInertia) tree_flush_symmetric<NG>(groups, A, w_stride, ncfg, out + cfg0 * (NG * NG), lane);
     else flush_run(A, w_stride, NG * NG, ncfg, out + cfg0 * (NG * NG), lane);
 }
 

@@ -154,9 +154,11 @@ static void tree_dyn_run(const Tree *t, const double *q, const double *qd, const
         double mine[3 * NG], A[NG * NG + NG];
         for (int j = 0; j < NG; ++j) { mine[j] = q[s * NG + j]; mine[NG + j] = qd ? qd[s * NG + j] : 0.0; mine[2 * NG + j] = tq ? tq[s * NG + j] : 0.0; }
         tree_dyn_lane<NG, MODE>(t->groups.data(), t->nslots, mine, A, g, [&](int i) -> double & { return slots[i]; });
-        if (MODE == kDynInertia) {                  // the kernel's flush: packed lower triangle -> the full symmetric matrix
-            for (int r = 0; r < NG; ++r)
-                for (int c = 0; c < NG; ++c) out[s * W + r * NG + c] = A[(r > c ? r : c) * ((r > c ? r : c) + 1) / 2 + (r > c ? c : r)];
+        if (MODE == kDynInertia) {                  // the kernel's flush: packed lower triangle -> the full symmetric matrix, rows where the reference has them
+            for (int r0 = 0; r0 < NG; ++r0) {
+                const int r = tree_row_position<NG>(t->groups.data(), r0);
+                for (int c = 0; c < NG; ++c) out[s * W + r0 * NG + c] = A[(r > c ? r : c) * ((r > c ? r : c) + 1) / 2 + (r > c ? c : r)];
+            }
             continue;
         }
         for (int k = 0; k < W; ++k) out[s * W + k] = A[k];

@@ -85,6 +85,71 @@ def test_emu_coriolis_scale_cases_and_rest():
     assert not got[-1].any()
 
 
+def renumbered_case(seed, n_links):
+    """serial_case with the joints numbered by hand in a shuffled order: q / qd / qdd / torque are read by jindex, torques come back in group
+    order (Robot.py:1830-1893) -- so the reference's `inertia` is the symmetric group-ordered matrix with its ROWS permuted, and `accel` solves
+    with that matrix.  (Every URDF robot and every automatically numbered robot is in group order; this is the hand-numbered rest.)"""
+    rng = np.random.default_rng(seed)
+    while True:
+        prod, orc = random_tree(rng, n_links=n_links)
+        n = sum(1 for l in prod if l.isjoint)
+        if 3 <= n <= 9:
+            break
+    perm = rng.permutation(n)
+    while np.array_equal(perm, np.arange(n)):
+        perm = rng.permutation(n)
+    by_name, k = {}, 0
+    for l in dfs(orc):
+        if any(not isinstance(it, np.ndarray) and (len(it) == 1 or it[1] is None) for it in l["ets"]):
+            by_name[l["name"]] = int(perm[k]); k += 1
+    for l in orc:
+        if l["name"] in by_name:
+            l["jindex"] = by_name[l["name"]]
+    prod2 = []
+    for l in prod:
+        parent = None if l.parent is None else [p for p in prod2 if p.name == l.parent.name][0]
+        prod2.append(rtbhip.Link(l.ets, jindex=by_name.get(l.name), m=l.m, r=l.r, parent=parent, name=l.name))
+    return ERobot(prod2), orc, rng              # (hand-numbered links keep the order they were given in: BaseRobot.py:353-370 `orlinks = links`)
+
+
+@pytest.mark.parametrize("seed,n_links", [(11, 6), (12, 8), (13, 5)])
+def test_emu_hand_numbered_joints(seed, n_links):
+    import emu_harness as emu
+    rob, links, rng = renumbered_case(seed, n_links)
+    n = rob.n
+    recs = rob.group_table()
+    assert [r["jindex"] for r in recs] != list(range(n))
+    q, qd, tq = rng.uniform(-2, 2, (4, n)), rng.normal(size=(4, n)), rng.normal(size=(4, n))
+    g = np.array([0.5, -0.3, -9.81])
+    nt.assert_allclose(emu.tree_rne(recs, q, qd, tq, g), oer.erobot_rne(links, q, qd, tq, g), rtol=1e-10, atol=1e-10)
+    M = oer.erobot_inertia(links, q)
+    nt.assert_allclose(emu.tree_dyn(recs, 0, q), M, rtol=0, atol=1e-12 * max(1.0, np.abs(M).max()))
+    Cw = oer.erobot_coriolis(links, q, qd)
+    nt.assert_allclose(emu.tree_dyn(recs, 1, q, qd), Cw, rtol=0, atol=1e-12 * max(1.0, np.abs(Cw).max()))
+    if np.linalg.cond(M).max() < 1e8:
+        want = oer.erobot_accel(links, q, qd, tq, g)
+        nt.assert_allclose(emu.tree_dyn(recs, 2, q, qd, tq, g), want, rtol=1e-8, atol=1e-8 * max(1.0, np.abs(want).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n_links", [(11, 6), (12, 8), (13, 5)])
+def test_gpu_hand_numbered_joints(seed, n_links):
+    rob, links, rng = renumbered_case(seed, n_links)
+    n = rob.n
+    q, qd, tq = rng.uniform(-2, 2, (70, n)), rng.normal(size=(70, n)), rng.normal(size=(70, n))
+    g = np.array([0.5, -0.3, -9.81])
+    rob.gravity = g
+    k = slice(0, 4)
+    M = oer.erobot_inertia(links, q[k])
+    nt.assert_allclose(rob.inertia(q)[k], M, rtol=0, atol=1e-12 * max(1.0, np.abs(M).max()))
+    Cw = oer.erobot_coriolis(links, q[k], qd[k])
+    nt.assert_allclose(rob.coriolis(q, qd)[k], Cw, rtol=0, atol=1e-12 * max(1.0, np.abs(Cw).max()))
+    nt.assert_allclose(rob.rne(q, qd, tq)[k], oer.erobot_rne(links, q[k], qd[k], tq[k], g), rtol=1e-10, atol=1e-10)
+    if np.linalg.cond(M).max() < 1e8:
+        want = oer.erobot_accel(links, q[k], qd[k], tq[k], g)
+        nt.assert_allclose(rob.accel(q, qd, tq)[k], want, rtol=1e-8, atol=1e-8 * max(1.0, np.abs(want).max()))
+
+
 def urdf_pairs():
     out = []
     for name in ("UR5", "Panda"):
