@@ -9,6 +9,9 @@
 namespace rtbhip {
 
 enum { kDynInertia = 0, kDynCoriolis = 1, kDynAccel = 2 };
+// accel keeps M as a packed lower triangle -- except for modified-DH chains with prismatic joints, whose reference matrix can be unsymmetric
+// (a prismatic first joint: dyn_lane below): those keep the full n x n tile
+template <bool MDH, bool ALLREV> constexpr bool kDynFullTile = MDH && !ALLREV;
 
 // mine : this lane's inputs  [q (n) | qd (n) | torque (n)]   (what the mode needs)
 // mA   : n x n work/output tile (row-major): M for inertia / accel (accel leaves qdd in mA[0..n-1]), C for coriolis
@@ -204,7 +207,7 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, cons
                 rne_core<NJ, MDH, true, ALLREV, true, false, false>(links, NJ, st, ct, zero, zero, zero, qin, [&](int) { return 0.0; },
                                         [&](int j) { return j == i ? 1.0 : 0.0; },
                                         [&](int j, double v) {
-                                            if (MODE == kDynAccel) { if (j <= i) mA[i * (i + 1) / 2 + j] = v; }
+                                            if (MODE == kDynAccel && !kDynFullTile<MDH, ALLREV>) { if (j <= i) mA[i * (i + 1) / 2 + j] = v; }
                                             else mA[i * NJ + j] = v;
                                         });
             }
@@ -213,11 +216,25 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, cons
     if (MODE == kDynAccel) {
         // M qdd = torque - tau_0
         double x[NJ], M[NJ][NJ];
+        bool general = false;
+        if constexpr (kDynFullTile<MDH, ALLREV>) general = links[0].sigma != 0;        // wave-uniform
+        if (general) {
+            // the one chain shape whose reference matrix is not symmetric: modified DH with a prismatic FIRST joint (core/ne.c:187-196 gives link 1
+            // the joint rate and acceleration as ANGULAR velocity and acceleration).  The reference solves with the matrix as its passes return
+            // it (numpy.linalg.solve, robot/Dynamics.py:505): so does this, in memory, with the right-hand side in the torque row it came from
+            double *rhs = const_cast<double *>(mine) + 2 * NJ;
 #pragma unroll
-        for (int r = 0; r < NJ; ++r)
+            for (int j = 0; j < NJ; ++j) rhs[j] = b[j];
+            lu_solve_mem<NJ>(mA, rhs);
 #pragma unroll
-            for (int c = 0; c <= r; ++c) M[r][c] = mA[r * (r + 1) / 2 + c];
-        ldl_solve<NJ>(M, b, x);
+            for (int j = 0; j < NJ; ++j) x[j] = rhs[j];
+        } else {
+#pragma unroll
+            for (int r = 0; r < NJ; ++r)
+#pragma unroll
+                for (int c = 0; c <= r; ++c) M[r][c] = kDynFullTile<MDH, ALLREV> ? mA[r * NJ + c] : mA[r * (r + 1) / 2 + c];
+            ldl_solve<NJ>(M, b, x);
+        }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) mA[j] = x[j];        // the tile's first n slots become the output row
     }

@@ -48,7 +48,7 @@ __device__ __forceinline__ void dyn_load(double *lds, int stride, const double *
 }
 
 // LDS per wave (doubles): inputs 64 x (K*NJ | 1), then the n x n work / output tiles
-template <int NJ, int MODE, bool ALLREV = false>
+template <int NJ, int MODE, bool ALLREV = false, bool MDH = false>
 struct DynLayout {
     // inertia of an all-revolute chain reads q only for the sines / cosines, before the first pass writes its row: the
     // input row then lives in the output tile itself (28.7 -> 25.1 KB per wave for n = 7: 5 -> 6 waves per CU)
@@ -64,7 +64,7 @@ struct DynLayout {
     // accel: packed lower triangle of M; inertia of an all-revolute chain too (its columns come from the mirrored
     // acceleration-only passes of rne_device.h, so the tile holds 28 instead of 49 doubles per lane for n = 7 -- 6 -> 10 waves per
     // CU -- and the flush expands it to the full matrix)
-    static constexpr bool packed = MODE == kDynAccel || (MODE == kDynInertia && ALLREV);
+    static constexpr bool packed = (MODE == kDynAccel && !kDynFullTile<MDH, ALLREV>) || (MODE == kDynInertia && ALLREV);
     static constexpr int W = packed ? (NJ * (NJ + 1) / 2 > NJ ? NJ * (NJ + 1) / 2 : NJ) : NJ * NJ;
     static constexpr int w_stride = W | 1;
     static constexpr int tiles = 1;                                // coriolis too: Csq is folded into C as it is produced (dyn_device.h)
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kDW, (NJ <= 8 ? 2 : 1)) void k_dyn(DynParams dp, co
                                                 double *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    typedef DynLayout<NJ, MODE, ALLREV> L;
+    typedef DynLayout<NJ, MODE, ALLREV, MDH> L;
     ConstLinksD links = (ConstLinksD)links_g;
     const int lane = threadIdx.x;
     const int64_t cfg0 = (int64_t)blockIdx.x * kDW;
@@ -165,7 +165,8 @@ template <int NJ, int MODE>
 static hipError_t launch_mode(bool mdh, bool allrev, dim3 grid, hipStream_t s, const DynParams &dp, const DevLink *links, const double *q,
                               const double *qd, const double *tq, double *out, size_t *lds_out)
 {
-    const size_t lds = (size_t)(allrev ? DynLayout<NJ, MODE, true>::doubles : DynLayout<NJ, MODE, false>::doubles) * sizeof(double);
+    const size_t lds = (size_t)(allrev ? DynLayout<NJ, MODE, true>::doubles
+                                       : (mdh ? DynLayout<NJ, MODE, false, true>::doubles : DynLayout<NJ, MODE, false, false>::doubles)) * sizeof(double);
     *lds_out = lds;
     if (mdh) return allrev ? launch_one<NJ, MODE, true, true>(grid, s, lds, dp, links, q, qd, tq, out)
                            : launch_one<NJ, MODE, true, false>(grid, s, lds, dp, links, q, qd, tq, out);

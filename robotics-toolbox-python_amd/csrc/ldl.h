@@ -173,4 +173,42 @@ RTB_HD void jacobi_eigenvalues(double (&a)[N][N])
     }
 }
 
+// A x = b for a general N x N matrix in MEMORY (row-major, destroyed; b becomes x): Gaussian elimination with partial pivoting, run-time indices,
+// no unrolling -- what numpy.linalg.solve (LAPACK gesv) does, for the one case in which the matrix of Dynamics.accel is not symmetric (dyn_device.h:
+// a modified-DH chain whose first joint is prismatic).  Not a fast path.
+template <int N>
+RTB_HD void lu_solve_mem(double *A, double *b)
+{
+#pragma unroll 1
+    for (int c = 0; c < N; ++c) {
+        int p = c;
+        double best = fabs(A[c * N + c]);
+#pragma unroll 1
+        for (int r = c + 1; r < N; ++r) {
+            const double v = fabs(A[r * N + c]);
+            if (v > best) { best = v; p = r; }
+        }
+        if (p != c) {
+#pragma unroll 1
+            for (int k = 0; k < N; ++k) { const double t = A[c * N + k]; A[c * N + k] = A[p * N + k]; A[p * N + k] = t; }
+            const double t = b[c]; b[c] = b[p]; b[p] = t;
+        }
+        const double piv = A[c * N + c];
+#pragma unroll 1
+        for (int r = c + 1; r < N; ++r) {
+            const double f = A[r * N + c] / piv;
+#pragma unroll 1
+            for (int k = c + 1; k < N; ++k) A[r * N + k] -= f * A[c * N + k];
+            b[r] -= f * b[c];
+        }
+    }
+#pragma unroll 1
+    for (int r = N - 1; r >= 0; --r) {
+        double acc = b[r];
+#pragma unroll 1
+        for (int k = r + 1; k < N; ++k) acc -= A[r * N + k] * b[k];
+        b[r] = acc / A[r * N + r];
+    }
+}
+
 }  // namespace rtbhip

@@ -187,7 +187,10 @@ extern "C" int emu_tree_dyn(const rtbhip_tree_group *groups, int ng, int mode, c
     case 7: tree_dyn_mode<7>(mode, &t, q, qd, tq, N, g, out); break;
     case 8: tree_dyn_mode<8>(mode, &t, q, qd, tq, N, g, out); break;
     case 9: tree_dyn_mode<9>(mode, &t, q, qd, tq, N, g, out); break;
-    default: return -2;       // (10..12 joints are built for the device only: the host build of every size is slow)
+    case 10: tree_dyn_mode<10>(mode, &t, q, qd, tq, N, g, out); break;
+    case 11: tree_dyn_mode<11>(mode, &t, q, qd, tq, N, g, out); break;
+    case 12: tree_dyn_mode<12>(mode, &t, q, qd, tq, N, g, out); break;
+    default: return -2;
     }
     return 0;
 }

@@ -257,11 +257,11 @@ def test_dh_robots_agree_kinematics_and_dynamics_in_every_call_form():
                 # The reference's own recursion (core/ne.c) returns a NON-symmetric "inertia matrix" for a modified-DH chain whose FIRST joint
                 # is prismatic (M[0,0] holds the motor term only: the link masses are missing from the first joint's force) -- found by this
                 # test, reproduced to the bit by rtbhip's rne and inertia (asserted above).  Its accel solves with that full matrix
-                # (Dynamics.py:505); the kernel's LDL^T reads the lower triangle of the same numbers.  Neither answer means anything;
-                # the deviation is confined to this case:
+                # (Dynamics.py:505).  Rounds 1-3 solved with the lower triangle there (LDL^T) and recorded the deviation; since round 4 the
+                # kernel keeps the full matrix for modified-DH chains with prismatic joints and solves it as it stands (csrc/ldl.h
+                # lu_solve_mem): the reference's answer, confined to this case:
                 assert mdh and ref.links[0].isprismatic
-                lower = np.tril(Mr) + np.tril(Mr, -1).T
-                nt.assert_allclose(m, np.linalg.solve(lower, qdd - ref.rne(q, qd, np.zeros(n))), rtol=1e-9 * cond, atol=1e-9 * cond)
+                nt.assert_allclose(m, r, rtol=1e-9 * cond, atol=1e-9 * cond)
                 lopsided += 1
             # base / tool assigned AFTER the first calls are honoured (the reference rebuilds ets() per call; here the kept chain is dropped)
             Bm = chains.elementary("tx", 0.4) @ chains.elementary("Rz", 0.7)

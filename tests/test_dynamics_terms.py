@@ -233,6 +233,62 @@ def test_emu_eleven_to_sixteen_joints(n):
     nt.assert_allclose(emu.dyn(L, 0, 2, q, qd, tq, grav_c=gc), ref, rtol=1e-8, atol=1e-8 * np.abs(ref).max())
 
 
+def _mdh_arm_with_a_prismatic_first_joint(n=5):
+    rng = np.random.default_rng(5)
+    links = []
+    for k in range(n):
+        kw = dict(a=0.05 + 0.02 * k, alpha=[0.0, np.pi / 2, -np.pi / 2, 0.3][k % 4], m=1.0 + 0.1 * k, r=list(rng.uniform(-0.05, 0.05, 3)),
+                  I=np.diag(rng.uniform(0.01, 0.1, 3)), Jm=1e-4 * k, G=1.0 + k)
+        links.append(rtbhip.PrismaticMDH(theta=0.3, qlim=[0.0, 0.4], **kw) if k in (0, 3) else rtbhip.RevoluteMDH(d=0.1, **kw))
+    return rtbhip.DHRobot(links, name="mdh-p")
+
+
+def test_reference_inertia_of_an_mdh_chain_with_a_prismatic_first_joint_is_not_symmetric():
+    """core/ne.c:187-196 gives link 1 of such a chain the joint rate and acceleration as ANGULAR quantities: the matrix Dynamics.inertia returns
+    (and Dynamics.accel solves with, numpy.linalg.solve) is not symmetric.  Pinned on the compiled frne; the oracle restates it; the kernel
+    body keeps the full matrix for modified-DH chains with prismatic joints and solves it as it stands (ldl.h lu_solve_mem)."""
+    import emu_harness as emu
+    from oracle import ref_harness
+    rob = _mdh_arm_with_a_prismatic_first_joint()
+    L, n = rob.L24(), rob.n
+    rng = np.random.default_rng(1)
+    q, qd, tq = rng.uniform(-1, 1, (3, n)), rng.normal(size=(3, n)), rng.normal(size=(3, n))
+    q[:, 0] = rng.uniform(0, 0.4, 3); q[:, 3] = rng.uniform(0, 0.4, 3)
+    Mo = oracle.inertia_dh(L, 1, q)
+    assert np.abs(Mo - np.swapaxes(Mo, 1, 2)).max() > 1e-3 * np.abs(Mo).max()
+    if ref_harness.available():
+        ref = ref_harness.RefRNE(L, 1)
+        M = np.array(ref.rne(np.tile(q[0], (n, 1)), np.zeros((n, n)), np.eye(n), gravity=[0, 0, 0]))
+        nt.assert_allclose(Mo[0], M, rtol=0, atol=1e-13 * np.abs(M).max())
+    gc = -np.array([0.0, 0.0, -9.81])
+    nt.assert_allclose(emu.dyn(L, 1, 0, q), Mo, rtol=1e-11, atol=1e-12)
+    ref = oracle.accel_dh(L, 1, q, qd, tq, gc)
+    nt.assert_allclose(emu.dyn(L, 1, 2, q, qd, tq, grav_c=gc), ref, rtol=1e-9, atol=1e-9 * np.abs(ref).max())
+    # the same chain with a revolute first joint: symmetric, the LDL^T path over the full tile
+    rob2 = rtbhip.DHRobot([rtbhip.RevoluteMDH(d=0.1, a=0.05, alpha=0.0, m=1.0, r=[0.01, 0.02, 0.03], I=np.diag([0.02, 0.03, 0.04]))] + list(rob.links[1:]))
+    L2 = rob2.L24()
+    M2 = oracle.inertia_dh(L2, 1, q)
+    assert np.abs(M2 - np.swapaxes(M2, 1, 2)).max() < 1e-13 * np.abs(M2).max()
+    ref2 = oracle.accel_dh(L2, 1, q, qd, tq, gc)
+    nt.assert_allclose(emu.dyn(L2, 1, 2, q, qd, tq, grav_c=gc), ref2, rtol=1e-9, atol=1e-9 * np.abs(ref2).max())
+
+
+@pytest.mark.gpu
+def test_gpu_accel_of_an_mdh_chain_with_a_prismatic_first_joint():
+    rob = _mdh_arm_with_a_prismatic_first_joint()
+    L, n = rob.L24(), rob.n
+    rng = np.random.default_rng(2)
+    q, qd, tq = rng.uniform(-1, 1, (70, n)), rng.normal(size=(70, n)), rng.normal(size=(70, n))
+    q[:, 0] = rng.uniform(0, 0.4, 70); q[:, 3] = rng.uniform(0, 0.4, 70)
+    k = slice(62, 68)
+    nt.assert_allclose(rob.inertia(q)[k], oracle.inertia_dh(L, 1, q[k]), rtol=1e-11, atol=1e-12)
+    ref = oracle.accel_dh(L, 1, q[k], qd[k], tq[k], rob._gravity_c(None))
+    a = rob.accel(q, qd, tq)
+    nt.assert_allclose(a[k], ref, rtol=1e-9, atol=1e-9 * np.abs(ref).max())
+    # (no forward-then-inverse identity here: the passes return the ROWS of the matrix, superposition would need its transpose, and the
+    # reference solves with the matrix as returned -- for this one chain shape rne(q, qd, accel(q, qd, tau)) != tau in the reference as well)
+
+
 def _ten_joint_arm():
     """A 10-joint DH arm with a prismatic joint, centre-of-mass offsets, full and diagonal inertia tensors, motor inertia
     and friction: the 9- and 10-joint instantiations (one wave per SIMD)."""

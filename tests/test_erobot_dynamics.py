@@ -150,6 +150,53 @@ def test_gpu_hand_numbered_joints(seed, n_links):
         nt.assert_allclose(rob.accel(q, qd, tq)[k], want, rtol=1e-8, atol=1e-8 * max(1.0, np.abs(want).max()))
 
 
+def big_case(seed, n):
+    """a random branched robot with exactly n joints (10..12: the largest instantiations of the tree dynamics kernels)"""
+    rng = np.random.default_rng(seed)
+    while True:
+        prod, orc = random_tree(rng, n_links=n + int(rng.integers(0, 5)))
+        rob = ERobot(prod)
+        if rob.n == n:
+            return rob, dfs(orc), rng
+
+
+@pytest.mark.parametrize("n", [10, 11, 12])
+def test_emu_ten_to_twelve_joints(n):
+    import emu_harness as emu
+    rob, links, rng = big_case(40 + n, n)
+    recs = rob.group_table()
+    q, qd, tq = rng.uniform(-2, 2, (2, n)), rng.normal(size=(2, n)), rng.normal(size=(2, n))
+    g = np.array([0.5, -0.3, -9.81])
+    M = oer.erobot_inertia(links, q)
+    nt.assert_allclose(emu.tree_dyn(recs, 0, q), M, rtol=0, atol=1e-12 * max(1.0, np.abs(M).max()))
+    Cw = oer.erobot_coriolis(links, q, qd)
+    nt.assert_allclose(emu.tree_dyn(recs, 1, q, qd), Cw, rtol=0, atol=1e-12 * max(1.0, np.abs(Cw).max()))
+    if np.linalg.cond(M).max() < 1e8:
+        want = oer.erobot_accel(links, q, qd, tq, g)
+        nt.assert_allclose(emu.tree_dyn(recs, 2, q, qd, tq, g), want, rtol=1e-8, atol=1e-8 * max(1.0, np.abs(want).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [10, 11, 12])
+def test_gpu_ten_to_twelve_joints(n):
+    rob, links, rng = big_case(40 + n, n)
+    q, qd, tq = rng.uniform(-2, 2, (70, n)), rng.normal(size=(70, n)), rng.normal(size=(70, n))
+    g = np.array([0.5, -0.3, -9.81])
+    rob.gravity = g
+    k = slice(0, 2)
+    M, Cm = rob.inertia(q), rob.coriolis(q, qd)
+    Mo = oer.erobot_inertia(links, q[k])
+    nt.assert_allclose(M[k], Mo, rtol=0, atol=1e-12 * max(1.0, np.abs(Mo).max()))
+    Co = oer.erobot_coriolis(links, q[k], qd[k])
+    nt.assert_allclose(Cm[k], Co, rtol=0, atol=1e-12 * max(1.0, np.abs(Co).max()))
+    tau = rob.rne(q, qd, tq)                                  # all 70 rows: rne(q, qd, qdd) = M qdd + C qd + g
+    nt.assert_allclose(np.einsum("nij,nj->ni", M, tq) + np.einsum("nij,nj->ni", Cm, qd) + rob.gravload(q), tau,
+                       rtol=0, atol=1e-10 * max(1.0, np.abs(tau).max()))
+    if np.linalg.cond(M).max() < 1e8:
+        qdd = rob.accel(q, qd, tq)
+        nt.assert_allclose(rob.rne(q, qd, qdd), tq, rtol=0, atol=1e-8 * max(1.0, np.abs(tq).max()))
+
+
 def urdf_pairs():
     out = []
     for name in ("UR5", "Panda"):
