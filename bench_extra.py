@@ -100,11 +100,20 @@ VALU_PER_UNIT = {"gravload": 833, "inertia": 3433, "coriolis": 5954, "accel": 33
 
 
 def valu_roofline(key, units_per_s, kernel, hbm_bytes_per_unit):
+    """The roof that BINDS the kernel: algorithmic bytes / 8 TB/s against algorithmic flops / 78.6 TFLOP/s per unit, whichever takes longer (the other
+    fraction is carried beside it).  jacob0_dot (448 B against 1 755 flop per configuration) is HBM-bound by that rule; rounds 1-3 priced it as fp64."""
     flops = ALGO_FLOPS_PER_UNIT[key]
     tf = flops * units_per_s / 1e12
-    out = {"bound": "fp64-valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
-           "algorithmic_flops_per_unit": flops, "flops_source": "DESIGN.md section 5 (full / acceleration-only / two-field link-passes at 270 / 164 / 356 flop, 60 flop per sincos; FK + Jacobian 600 flop + the consumer's own products)",
-           "kernel": kernel, "hbm_GBs": hbm_bytes_per_unit * units_per_s / 1e9}
+    gbs = hbm_bytes_per_unit * units_per_s / 1e9
+    src = "DESIGN.md section 5 (full / acceleration-only / two-field link-passes at 270 / 164 / 356 flop, 60 flop per sincos; FK + Jacobian 600 flop + the consumer's own products)"
+    if hbm_bytes_per_unit / (HBM_PEAK_GBS * 1e9) >= flops / (FP64_VALU_PEAK_TFLOPS * 1e12):
+        out = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+               "algorithmic_bytes_per_unit": hbm_bytes_per_unit, "algorithmic_flops_per_unit": flops, "flops_source": src,
+               "kernel": kernel, "hbm_GBs": gbs, "fp64_valu_frac": tf / FP64_VALU_PEAK_TFLOPS}
+    else:
+        out = {"bound": "fp64-valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
+               "algorithmic_flops_per_unit": flops, "flops_source": src,
+               "kernel": kernel, "hbm_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
     instr = VALU_PER_UNIT.get(key)
     if instr is not None:
         out["valu_issue_util"] = 2.0 * instr * units_per_s / 1e12 / FP64_VALU_PEAK_TFLOPS

@@ -190,6 +190,10 @@ extern "C" int emu_tree_dyn(const rtbhip_tree_group *groups, int ng, int mode, c
     case 10: tree_dyn_mode<10>(mode, &t, q, qd, tq, N, g, out); break;
     case 11: tree_dyn_mode<11>(mode, &t, q, qd, tq, N, g, out); break;
     case 12: tree_dyn_mode<12>(mode, &t, q, qd, tq, N, g, out); break;
+    case 13: tree_dyn_mode<13>(mode, &t, q, qd, tq, N, g, out); break;
+    case 14: tree_dyn_mode<14>(mode, &t, q, qd, tq, N, g, out); break;
+    case 15: tree_dyn_mode<15>(mode, &t, q, qd, tq, N, g, out); break;
+    case 16: tree_dyn_mode<16>(mode, &t, q, qd, tq, N, g, out); break;
     default: return -2;
     }
     return 0;
