@@ -14,6 +14,7 @@ typedef const __attribute__((address_space(4))) DevGroup *ConstGroups;
 
 struct TreeParams {
     int32_t n, nslots;
+    int32_t tile, pad_;           // k_tree_dyn: configurations per single-wave workgroup (64; 32 when a 64-lane tile would not fit a CU's LDS)
     int64_t N;
     double grav[3];
 };
@@ -93,7 +94,7 @@ int launch_tree_rne(const Tree *t, const DevGroup *groups, const double *q, cons
     const int64_t tiles = (N + kWave - 1) / kWave;
     if (tiles > 0x7fffffff) { set_error("tree_rne: batch too large for one launch"); return RTBHIP_ELIMIT; }
     TreeParams tp;
-    tp.n = t->n; tp.nslots = t->nslots; tp.N = N;
+    tp.n = t->n; tp.nslots = t->nslots; tp.N = N; tp.tile = kWave; tp.pad_ = 0;
     for (int i = 0; i < 3; i++) tp.grav[i] = grav3[i];
     const size_t lds = (size_t)kWave * (((4 * t->n) | 1) + kTreeSlotDoubles * t->nslots) * sizeof(double);
     if (lds > 160 * 1024) { set_error("tree_rne: tree needs more LDS than a CU has"); return RTBHIP_ELIMIT; }
@@ -174,11 +175,12 @@ __global__ __launch_bounds__(kWave, 1) void k_tree_dyn(TreeParams tp, const DevG
     // accel and inertia: packed lower triangle (accel: >= n doubles, qdd leaves from its head); coriolis: the full n x n tile
     constexpr int W = MODE == kDynCoriolis ? NG * NG : NG * (NG + 1) / 2 + (MODE == kDynAccel ? NG : 0);
     constexpr int in_stride = (K * NG) | 1, w_stride = W | 1;
-    double *A = lds + kWave * in_stride;
-    double *slots = A + kWave * w_stride;
-    const int64_t cfg0 = (int64_t)blockIdx.x * kWave;
+    const int T = tp.tile;
+    double *A = lds + T * in_stride;
+    double *slots = A + T * w_stride;
+    const int64_t cfg0 = (int64_t)blockIdx.x * T;
     const int64_t left = tp.N - cfg0;
-    const int ncfg = left < kWave ? (int)left : kWave;
+    const int ncfg = left < T ? (int)left : T;
     const int count = ncfg * NG;
     {
         const double *src[3] = {q + cfg0 * NG, qd ? qd + cfg0 * NG : nullptr, tq ? tq + cfg0 * NG : nullptr};
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(kWave, 1) void k_tree_dyn(TreeParams tp, const DevG
     __syncthreads();
     if (lane < ncfg)
         tree_dyn_lane<NG, MODE>(groups, tp.nslots, lds + lane * in_stride, A + lane * w_stride, v3(tp.grav[0], tp.grav[1], tp.grav[2]),
-                                [&](int i) -> double & { return slots[i * kWave + lane]; });
+                                [&](int i) -> double & { return slots[i * T + lane]; });
     __syncthreads();
     if (MODE == kDynAccel) flush_run(A, w_stride, NG, ncfg, out + cfg0 * NG, lane);
     else if (MODE == kDynInertia) tree_flush_symmetric<NG>(groups, A, w_stride, ncfg, out + cfg0 * (NG * NG), lane);
@@ -211,12 +213,22 @@ static hipError_t launch_tree_dyn_one(dim3 grid, hipStream_t s, int nslots, cons
 {
     constexpr int K = MODE == kDynInertia ? 1 : (MODE == kDynCoriolis ? 2 : 3);
     constexpr int W = MODE == kDynCoriolis ? NG * NG : NG * (NG + 1) / 2 + (MODE == kDynAccel ? NG : 0);
-    const size_t lds = (size_t)kWave * (((K * NG) | 1) + (W | 1) + (MODE == kDynCoriolis ? kTreeBilinearSlotDoubles : kTreeSlotDoubles) * nslots) * sizeof(double);
+    const size_t per_lane = (size_t)(((K * NG) | 1) + (W | 1) + (MODE == kDynCoriolis ? kTreeBilinearSlotDoubles : kTreeSlotDoubles) * nslots) * sizeof(double);
+    // 64 configurations per wave; a robot whose tile would not fit a CU's 160 KB (15-16 joints with several branch points: the n x n tile
+    // of coriolis plus 24 doubles per branch slot) runs 32 per wave, the upper half of the lanes idle: served, not fast
+    TreeParams tq_ = tp;
+    tq_.tile = kWave;
+    if (per_lane * kWave > 160 * 1024) tq_.tile = kWave / 2;
+    const size_t lds = per_lane * tq_.tile;
     *lds_out = lds;
     if (lds > 160 * 1024) return hipSuccess;          // reported by the caller
+    const int64_t tiles = (tp.N + tq_.tile - 1) / tq_.tile;
+    if (tiles > 0x7fffffff) { *lds_out = 0; return hipErrorInvalidValue; }
+    grid = dim3((unsigned)tiles);
     auto k = k_tree_dyn<NG, MODE>;
     if (lds > 48 * 1024) { hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
-    hipLaunchKernelGGL(k, grid, dim3(kWave), lds, s, tp, g, q, qd, tq, out);
+    hipLaunchKernelGGL(k, grid, dim3(kWave), lds, s, tq_, g, q, qd, tq, out);
+    note_launch((int)grid.x, kWave, (int)lds);
     return hipSuccess;
 }
 
@@ -237,7 +249,7 @@ int launch_tree_dyn(const Tree *t, const DevGroup *groups, int mode, const doubl
     const int64_t tiles = (N + kWave - 1) / kWave;
     if (tiles > 0x7fffffff) { set_error("tree inertia/coriolis/accel: batch too large for one launch"); return RTBHIP_ELIMIT; }
     TreeParams tp;
-    tp.n = t->n; tp.nslots = t->nslots; tp.N = N;
+    tp.n = t->n; tp.nslots = t->nslots; tp.N = N; tp.tile = kWave; tp.pad_ = 0;
     for (int i = 0; i < 3; i++) tp.grav[i] = grav3 ? grav3[i] : 0.0;
     dim3 grid((unsigned)tiles);
     size_t lds = 0;
@@ -261,7 +273,6 @@ int launch_tree_dyn(const Tree *t, const DevGroup *groups, int mode, const doubl
     default: e = launch_tree_dyn_ng<16>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
     }
     if (lds > 160 * 1024) { set_error("tree inertia/coriolis/accel: the robot needs more LDS than a CU has"); return RTBHIP_ELIMIT; }
-    note_launch((int)grid.x, kWave, (int)lds);
     if (e != hipSuccess) return hip_fail(e, "k_tree_dyn launch");
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "k_tree_dyn launch");
