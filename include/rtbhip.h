@@ -304,7 +304,7 @@ int rtbhip_tree_rne(rtbhip_tree_t tree, const double *q, const double *qd, const
 /* The Dynamics-mixin terms of an ETS robot -- Dynamics.inertia / coriolis / accel (robot/Dynamics.py:704-763, 765-861, 424-509), which the
  * reference builds from n, n + n(n-1)/2 and n + 1 calls of Robot.rne per configuration -- one fused kernel each, every pass of a
  * configuration in one lane:  M (N,n,n), row i = rne(q, 0, e_i, gravity 0);  C (N,n,n);  qdd (N,n) = M^-1 (torque - rne(q, qd, 0)) with
- * gravity3 as rtbhip_tree_rne takes it.  gravload / itorque are rtbhip_tree_rne with NULL qd / qdd.  Robots of up to 16 joints
+ * gravity3 as rtbhip_tree_rne takes it.  gravload / itorque are rtbhip_tree_rne with NULL qd / qdd.  Robots of up to 20 joints
  * (RTBHIP_ELIMIT beyond). */
 int rtbhip_tree_inertia(rtbhip_tree_t tree, const double *q, int64_t N, double *M, int32_t mem, void *stream);
 int rtbhip_tree_coriolis(rtbhip_tree_t tree, const double *q, const double *qd, int64_t N, double *C, int32_t mem, void *stream);

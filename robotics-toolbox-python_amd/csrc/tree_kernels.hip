@@ -133,9 +133,9 @@ int launch_tree_rne(const Tree *t, const DevGroup *groups, const double *q, cons
 
 // ---- Dynamics-mixin terms of an ETS robot: inertia / coriolis / accel, every pass of a configuration in one lane (tree_device.h:
 // tree_dyn_lane).  LDS per lane: the inputs the mode reads ([q] | [q, qd] | [q, qd, torque]) and an n x n tile, plus the tree's slots;
-// inputs arrive and results leave through the same coalesced tile copies as k_tree_rne.  Robots of up to 16 joints (13..16 -- YuMi's two arms --
-// hold a 100+ KB tile per wave and spill part of the per-group state: served, not fast), as the DH kernels of dyn_kernels.hip.
-constexpr int kTreeDynMax = 16;
+// inputs arrive and results leave through the same coalesced tile copies as k_tree_rne.  Robots of up to 20 joints (13..20 -- YuMi's two arms, 14,
+// with its grippers 18 -- hold a 100+ KB tile per wave, the largest ones for 32 configurations only, and spill part of their state: served, not fast).
+constexpr int kTreeDynMax = 20;
 
 // packed lower triangles (row r, column c <= r at r (r + 1) / 2 + c) of ncfg lanes -> the full symmetric (n, n) matrices, one contiguous run
 // (row r of the reference's matrix is row tree_row_position(r) of the group-ordered one: tree_device.h; the identity for robots numbered in group order)
@@ -245,7 +245,7 @@ int launch_tree_dyn(const Tree *t, const DevGroup *groups, int mode, const doubl
                     const double *grav3, double *out, hipStream_t s)
 {
     if (N == 0) return RTBHIP_OK;
-    if (t->n > kTreeDynMax) { set_error("tree inertia/coriolis/accel: this build handles robots of up to 16 joints"); return RTBHIP_ELIMIT; }
+    if (t->n > kTreeDynMax) { set_error("tree inertia/coriolis/accel: this build handles robots of up to 20 joints"); return RTBHIP_ELIMIT; }
     const int64_t tiles = (N + kWave - 1) / kWave;
     if (tiles > 0x7fffffff) { set_error("tree inertia/coriolis/accel: batch too large for one launch"); return RTBHIP_ELIMIT; }
     TreeParams tp;
@@ -270,7 +270,11 @@ int launch_tree_dyn(const Tree *t, const DevGroup *groups, int mode, const doubl
     case 13: e = launch_tree_dyn_ng<13>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
     case 14: e = launch_tree_dyn_ng<14>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
     case 15: e = launch_tree_dyn_ng<15>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
-    default: e = launch_tree_dyn_ng<16>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
+    case 16: e = launch_tree_dyn_ng<16>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
+    case 17: e = launch_tree_dyn_ng<17>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
+    case 18: e = launch_tree_dyn_ng<18>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
+    case 19: e = launch_tree_dyn_ng<19>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
+    default: e = launch_tree_dyn_ng<20>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
     }
     if (lds > 160 * 1024) { set_error("tree inertia/coriolis/accel: the robot needs more LDS than a CU has"); return RTBHIP_ELIMIT; }
     if (e != hipSuccess) return hip_fail(e, "k_tree_dyn launch");

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""scripts/gpu_fuzz_dyn.py -- the dynamics kernels of every size on the device against the oracle, on random robots: link trees of 1..16 joints
+"""scripts/gpu_fuzz_dyn.py -- the dynamics kernels of every size on the device against the oracle, on random robots: link trees of 1..20 joints
 (numbered automatically and by hand) through k_tree_rne / k_tree_dyn, DH and modified-DH chains of 1..16 joints with prismatic joints through k_rne /
 k_dyn.  Two rows each (the oracle is Python).  One JSON line per family with the worst relative deviation; exit code 1 on a miss."""
 import json, os, sys, time
@@ -26,10 +26,10 @@ count = {"tree": 0, "tree_hand_numbered": 0, "dh": 0}
 seen = set()
 for seed in range(400):
     rng = np.random.default_rng(1000 + seed)
-    prod, orc = random_tree(rng, n_links=int(rng.integers(1, 22)))
+    prod, orc = random_tree(rng, n_links=int(rng.integers(1, 27)))
     rob = ERobot(prod)
     n = rob.n
-    if not 1 <= n <= 16 or (n, "t") in seen and count["tree"] >= 36:
+    if not 1 <= n <= 20 or (n, "t") in seen and count["tree"] >= 44:
         continue
     seen.add((n, "t")); count["tree"] += 1
     links = dfs(orc)

@@ -144,33 +144,7 @@ static void tree_run(const Tree *t, const double *q, const double *qd, const dou
                               [&](int i) -> double & { return slots[i]; });
     }
 }
-// Dynamics-mixin terms of an ETS robot: tree_device.h's tree_dyn_lane on the CPU (mode 0 inertia, 1 coriolis, 2 accel)
-template <int NG, int MODE>
-static void tree_dyn_run(const Tree *t, const double *q, const double *qd, const double *tq, int64_t N, V3 g, double *out)
-{
-    std::vector<double> slots((size_t)kTreeBilinearSlotDoubles * std::max(1, t->nslots));
-    constexpr int W = MODE == kDynAccel ? NG : NG * NG;
-    for (int64_t s = 0; s < N; ++s) {
-        double mine[3 * NG], A[NG * NG + NG];
-        for (int j = 0; j < NG; ++j) { mine[j] = q[s * NG + j]; mine[NG + j] = qd ? qd[s * NG + j] : 0.0; mine[2 * NG + j] = tq ? tq[s * NG + j] : 0.0; }
-        tree_dyn_lane<NG, MODE>(t->groups.data(), t->nslots, mine, A, g, [&](int i) -> double & { return slots[i]; });
-        if (MODE == kDynInertia) {                  // the kernel's flush: packed lower triangle -> the full symmetric matrix, rows where the reference has them
-            for (int r0 = 0; r0 < NG; ++r0) {
-                const int r = tree_row_position<NG>(t->groups.data(), r0);
-                for (int c = 0; c < NG; ++c) out[s * W + r0 * NG + c] = A[(r > c ? r : c) * ((r > c ? r : c) + 1) / 2 + (r > c ? c : r)];
-            }
-            continue;
-        }
-        for (int k = 0; k < W; ++k) out[s * W + k] = A[k];
-    }
-}
-template <int NG>
-static void tree_dyn_mode(int mode, const Tree *t, const double *q, const double *qd, const double *tq, int64_t N, V3 g, double *out)
-{
-    if (mode == 0) tree_dyn_run<NG, kDynInertia>(t, q, qd, tq, N, g, out);
-    else if (mode == 1) tree_dyn_run<NG, kDynCoriolis>(t, q, qd, tq, N, g, out);
-    else tree_dyn_run<NG, kDynAccel>(t, q, qd, tq, N, g, out);
-}
+#include "emu_tree.h"
 extern "C" int emu_tree_dyn(const rtbhip_tree_group *groups, int ng, int mode, const double *q, const double *qd, const double *tq,
                             int64_t N, const double *grav3, double *out)
 {
@@ -190,11 +164,7 @@ extern "C" int emu_tree_dyn(const rtbhip_tree_group *groups, int ng, int mode, c
     case 10: tree_dyn_mode<10>(mode, &t, q, qd, tq, N, g, out); break;
     case 11: tree_dyn_mode<11>(mode, &t, q, qd, tq, N, g, out); break;
     case 12: tree_dyn_mode<12>(mode, &t, q, qd, tq, N, g, out); break;
-    case 13: tree_dyn_mode<13>(mode, &t, q, qd, tq, N, g, out); break;
-    case 14: tree_dyn_mode<14>(mode, &t, q, qd, tq, N, g, out); break;
-    case 15: tree_dyn_mode<15>(mode, &t, q, qd, tq, N, g, out); break;
-    case 16: tree_dyn_mode<16>(mode, &t, q, qd, tq, N, g, out); break;
-    default: return -2;
+    default: return emu_tree_dyn_big(&t, mode, q, qd, tq, N, g, out);
     }
     return 0;
 }

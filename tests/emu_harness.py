@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "robotics-toolbox-python_amd")
 EMU_SO = os.path.join(ROOT, "tests", "emu", "libemu.so")
 SRCS = ["tests/emu/" + f for f in ("emu_kin.cpp", "emu_ik_seq.cpp", "emu_ik_wave_a.cpp", "emu_ik_wave_b.cpp", "emu_ik_wave_c.cpp", "emu_rne.cpp", "emu_dyn_a.cpp", "emu_dyn_b.cpp", "emu_dyn_c.cpp", "emu_dyn_d.cpp", "emu_dyn_e.cpp", "emu_dyn_f.cpp",
-                                   "emu_misc.cpp", "emu_diffjac.cpp")] + ["robotics-toolbox-python_amd/csrc/" + f for f in
+                                   "emu_misc.cpp", "emu_tree_big.cpp", "emu_diffjac.cpp")] + ["robotics-toolbox-python_amd/csrc/" + f for f in
                                 ("api.cpp", "chain.cpp", "tree.cpp", "hostpipe.cpp", "kin_kernels.hip", "rne_kernels.hip", "ik_kernels.hip", "dyn_kernels.hip",
                                  "tree_kernels.hip", "partial_kernels.hip", "frames_kernels.hip", "diffjac_kernels.hip")]
 _vp, _u64, _i64, _i32 = C.c_void_p, C.c_uint64, C.c_int64, C.c_int32
@@ -80,7 +80,7 @@ def build():
         if _deps_newer(obj, dep):
             # the 13..16-joint dynamics bodies are the long poles of this build: -O1 for them (the replay's arithmetic is the same:
             # no fast-math either way, contraction is decided per statement by the front end)
-            fl = [f if f != "-O2" else "-O1" for f in flags] if os.path.basename(src) in ("emu_dyn_d.cpp", "emu_dyn_e.cpp", "emu_dyn_f.cpp") else flags
+            fl = [f if f != "-O2" else "-O1" for f in flags] if os.path.basename(src) in ("emu_dyn_d.cpp", "emu_dyn_e.cpp", "emu_dyn_f.cpp", "emu_tree_big.cpp") else flags
             subprocess.check_call([hipcc] + fl + ["-MD", "-MF", dep, "-c", src, "-o", obj])
         return obj
 

@@ -151,7 +151,7 @@ def test_gpu_hand_numbered_joints(seed, n_links):
 
 
 def big_case(seed, n):
-    """a random branched robot with exactly n joints (10..16: the largest instantiations of the tree dynamics kernels)"""
+    """a random branched robot with exactly n joints (10..20: the largest instantiations of the tree dynamics kernels)"""
     rng = np.random.default_rng(seed)
     while True:
         prod, orc = random_tree(rng, n_links=n + int(rng.integers(0, 5)))
@@ -160,8 +160,8 @@ def big_case(seed, n):
             return rob, dfs(orc), rng
 
 
-@pytest.mark.parametrize("n", [10, 11, 12, 13, 14, 16])
-def test_emu_ten_to_twelve_joints(n):
+@pytest.mark.parametrize("n", [10, 11, 12, 13, 14, 16, 18, 20])
+def test_emu_ten_to_twenty_joints(n):
     import emu_harness as emu
     rob, links, rng = big_case(40 + n, n)
     recs = rob.group_table()
@@ -177,8 +177,8 @@ def test_emu_ten_to_twelve_joints(n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [10, 11, 12, 13, 15, 16])
-def test_gpu_ten_to_twelve_joints(n):
+@pytest.mark.parametrize("n", [10, 11, 12, 13, 15, 16, 17, 19, 20])
+def test_gpu_ten_to_twenty_joints(n):
     rob, links, rng = big_case(40 + n, n)
     q, qd, tq = rng.uniform(-2, 2, (70, n)), rng.normal(size=(70, n)), rng.normal(size=(70, n))
     g = np.array([0.5, -0.3, -9.81])
@@ -276,20 +276,22 @@ def test_gpu_urdf_arms_and_the_dh_cross_pin():
 
 
 @pytest.mark.gpu
-def test_gpu_yumi_both_arms_and_the_limit_beyond_sixteen_joints():
-    """YuMi without its grippers (14 joints, two 7-joint arms off one body: the widest robot of the fleet) through the 14-joint instantiations:
-    the terms are consistent with the robot's own rne on every row; with the grippers it has 18 joints and is refused loudly (no fallback)."""
+def test_gpu_yumi_whole_and_without_grippers_and_the_limit_beyond_twenty_joints():
+    """YuMi -- two 7-joint arms off one body, 14 joints without its grippers, 18 with them: the widest robot of the fleet -- through the 14- and
+    18-joint instantiations: the terms are consistent with the robot's own rne on every row; a robot of more than 20 joints is refused
+    loudly (no fallback)."""
     rob = urdf.load("YuMi")
     arms = ("gripper_r_base", "gripper_l_base")
-    n = rob.erobot(arms).n
-    assert n == 14 and rob.n == 18
+    assert rob.erobot(arms).n == 14 and rob.n == 18
     rng = np.random.default_rng(14)
-    q, qd, tq = rng.uniform(-1.5, 1.5, (70, n)), rng.normal(size=(70, n)), rng.normal(size=(70, n))
-    M, Cm, tau = rob.inertia(q, exclude=arms), rob.coriolis(q, qd, exclude=arms), rob.rne(q, qd, tq, exclude=arms)
-    nt.assert_allclose(M, np.swapaxes(M, 1, 2), rtol=0, atol=1e-11 * np.abs(M).max())
-    nt.assert_allclose(np.einsum("nij,nj->ni", M, tq) + np.einsum("nij,nj->ni", Cm, qd) + rob.gravload(q, exclude=arms), tau,
-                       rtol=0, atol=1e-10 * np.abs(tau).max())
-    if np.linalg.cond(M).max() < 1e8:
-        nt.assert_allclose(rob.rne(q, qd, rob.accel(q, qd, tq, exclude=arms), exclude=arms), tq, rtol=0, atol=1e-7 * np.abs(tq).max())
+    for exclude, n in ((arms, 14), ((), 18)):
+        q, qd, tq = rng.uniform(-1.5, 1.5, (70, n)), rng.normal(size=(70, n)), rng.normal(size=(70, n))
+        M, Cm, tau = rob.inertia(q, exclude=exclude), rob.coriolis(q, qd, exclude=exclude), rob.rne(q, qd, tq, exclude=exclude)
+        nt.assert_allclose(M, np.swapaxes(M, 1, 2), rtol=0, atol=1e-11 * np.abs(M).max())
+        nt.assert_allclose(np.einsum("nij,nj->ni", M, tq) + np.einsum("nij,nj->ni", Cm, qd) + rob.gravload(q, exclude=exclude), tau,
+                           rtol=0, atol=1e-10 * np.abs(tau).max())
+        if np.linalg.cond(M).max() < 1e8:
+            nt.assert_allclose(rob.rne(q, qd, rob.accel(q, qd, tq, exclude=exclude), exclude=exclude), tq, rtol=0, atol=1e-7 * np.abs(tq).max())
+    big, _, _ = big_case(3, 21)
     with pytest.raises(rtbhip.RtbHipError):
-        rob.inertia(np.zeros(rob.n))
+        big.inertia(np.zeros(big.n))
