@@ -591,10 +591,10 @@ class ETS:
     @qlim.setter
     def qlim(self, v):
         v = np.asarray(v, dtype=np.float64)
-        if v.shape == (self.n, 2):
-            v = v.T
+        if v.shape == (2,) and self.n == 1:                 # robot/ETS.py:346-351: (2,) for a single joint, else (2, n) and nothing else
+            v = v.reshape(2, 1)
         if v.shape != (2, self.n):
-            raise ValueError("qlim must be (2, n)")
+            raise ValueError("new_qlim must be of shape (2, n)")
         self._qlim = np.ascontiguousarray(v)
         self._drop_handle()
 

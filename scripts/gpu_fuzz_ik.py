@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""scripts/gpu_fuzz_ik.py -- every size of the IK kernels on the device against the C restatement of the reference's loop (oracle.ik_lm), on random
+chains of 1..16 joints: all-revolute (the straight-line walk) and with prismatic / flipped joints (the general walk), unit and weighted masks, the
+three LM damping rules.  From a supplied start, first search only (no restart generator involved): (success, iterations, searches) must be equal
+wherever the restatement converges in its first search, q within 1e-6.  One JSON line per joint count; exit code 1 on a miss."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "robotics-toolbox-python_amd"), os.path.join(ROOT, "tests")]
+import numpy as np
+import rtbhip
+from oracle import oracle, chains
+from helpers import product_ets
+
+N = int(os.environ.get("FUZZ_IK_ROWS", 120))
+miss, t0 = [], time.time()
+for n in range(1, 17):
+    line = {"joints": n, "checked": 0, "cases": 0, "worst_dq": 0.0}
+    for kind in ("revolute", "general"):
+        rng = np.random.default_rng(7000 + 16 * n + (kind == "general"))
+        spec = []
+        for j in range(n):
+            ax = ["Rz", "Ry", "Rx"][int(rng.integers(0, 3))]
+            flip = False
+            if kind == "general":
+                if j % 4 == 1: ax = ["tx", "ty", "tz"][int(rng.integers(0, 3))]
+                flip = j % 3 == 2
+            spec.append((ax, None, flip))
+            spec.append((["tx", "ty", "tz"][int(rng.integers(0, 3))], float(rng.uniform(0.1, 0.4))))
+            if j % 2 == 0:
+                spec.append((["Rx", "Ry"][int(rng.integers(0, 2))], float(rng.uniform(-1.5, 1.5))))
+        lo = np.array([-0.3 if s[0].startswith("t") else -2.6 for s in spec if s[1] is None])
+        qlim = np.array([lo, -lo * np.where(lo > -1, 2.0, 1.0)])
+        ets = product_ets(spec, qlim=qlim)
+        ch = chains.Chain(spec, qlim=qlim)
+        qs = rng.uniform(qlim[0] * 0.9, qlim[1] * 0.9, (N, n))
+        Tep = oracle.fkine(ch, qs)
+        q0 = np.clip(qs + 0.15 * rng.normal(size=qs.shape), qlim[0], qlim[1])
+        # a mask the chain can satisfy: fewer than six joints cannot reach an arbitrary pose -- but Tep IS reachable (it came from qs), so any mask works
+        for mask in (None, [1, 1, 1, 0.5, 0.5, 0.25]):
+            for method in ("chan", "wampler", "sugihara"):
+                k = {"chan": 1.0, "wampler": 1e-4, "sugihara": 1e-3}[method]
+                q, ok, it, se, E = ets.ik_LM(Tep, q0=q0, mask=mask, slimit=3, seed=7, method=method, k=k)
+                line["cases"] += 1
+                for i in range(N):
+                    o = oracle.ik_lm(ch, Tep[i], q0=q0[i], restarts=np.zeros((2, n)), slimit=1, we=None if mask is None else np.array(mask, dtype=float),
+                                     method=method, k=k)
+                    if o[1] and o[3] == 1:
+                        line["checked"] += 1
+                        dq = float(np.abs(q[i] - o[0]).max())
+                        line["worst_dq"] = max(line["worst_dq"], dq)
+                        if (o[1], o[2], o[3]) != (ok[i], it[i], se[i]) or dq > 1e-6:
+                            miss.append([n, kind, str(mask), method, i, [int(o[1]), int(o[2]), int(o[3])], [int(ok[i]), int(it[i]), int(se[i])], dq])
+    print(json.dumps(line), flush=True)
+print(json.dumps({"misses": miss[:40], "n_misses": len(miss), "seconds": round(time.time() - t0, 1)}))
+sys.exit(1 if miss else 0)

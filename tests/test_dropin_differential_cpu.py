@@ -684,3 +684,29 @@ def test_joint_numbering_rules_agree():
             nt.assert_allclose(m, r, atol=1e-12)
         else:
             assert m == r
+
+
+def test_ets_qlim_setter_takes_two_rows_and_nothing_else():
+    """robot/ETS.py:346-358: qlim is (2, n) -- row 0 the lower limits -- or (2,) for a single joint.  (rtbhip used to accept (n, 2) as well and
+    transposed it: for a TWO-joint chain that turned the reference's own (2, 2) form into [lo0 == hi0, lo1 == hi1], and every IK solution of a
+    two-joint arm was rejected by the limit check -- found by scripts/gpu_fuzz_ik.py in round 4.)"""
+    import rtbhip
+    ns = ref_classes.load_reference()
+    with cpu_backend.installed():
+        for lib in (ns, rtbhip):
+            E = lib.ET
+            two = E.Rz() * E.tx(0.3) * E.Ry() * E.tx(0.3)
+            two.qlim = np.array([[-1.0, -2.0], [1.5, 2.5]])
+            nt.assert_array_equal(np.asarray(two.qlim), [[-1.0, -2.0], [1.5, 2.5]])
+            one = E.Rz() * E.tx(0.3)
+            one.qlim = np.array([-0.5, 0.75])
+            nt.assert_array_equal(np.asarray(one.qlim), [[-0.5], [0.75]])
+            three = E.Rz() * E.tx(0.3) * E.Ry() * E.tx(0.3) * E.Rx()
+            with pytest.raises(ValueError):
+                three.qlim = np.zeros((3, 2))
+            # and the solver honours them: a two-joint arm, target inside the limits, from a nearby start
+            two.qlim = np.array([[-2.6, -2.6], [2.6, 2.6]])
+            T = two.eval([0.5, -0.7])
+            sol = two.ik_LM(T, q0=np.array([0.6, -0.6]), mask=[1, 1, 1, 0, 0, 0], slimit=1)
+            assert sol[1] == 1 and sol[3] == 1
+            nt.assert_allclose(two.eval(sol[0])[:3, 3], np.asarray(T)[:3, 3], atol=1e-4)          # (tol = 1e-6 on E = e.e / 2)
