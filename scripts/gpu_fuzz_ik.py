@@ -50,6 +50,16 @@ for n in range(1, 17):
                         line["worst_dq"] = max(line["worst_dq"], dq)
                         if (o[1], o[2], o[3]) != (ok[i], it[i], se[i]) or dq > 1e-6:
                             miss.append([n, kind, str(mask), method, i, [int(o[1]), int(o[2]), int(o[3])], [int(ok[i]), int(it[i]), int(se[i])], dq])
+        # the Python solver's flavour (ikine_LM: E tested after the step, % wrap -- robot/IK.py), one pose per call
+        for i in range(min(N, 12)):
+            sol = ets.ikine_LM(Tep[i], q0=q0[i], slimit=1)
+            o = oracle.ikine_lm(ch, Tep[i], q0[i][None, :], slimit=1)
+            if o[1]:
+                line["checked"] += 1
+                dq = float(np.abs(np.asarray(sol.q) - o[0]).max())
+                line["worst_dq"] = max(line["worst_dq"], dq)
+                if (bool(o[1]), o[2], o[3]) != (bool(sol.success), sol.iterations, sol.searches) or dq > 1e-6:
+                    miss.append([n, kind, "ikine_LM", "chan", i, [int(o[1]), int(o[2]), int(o[3])], [int(sol.success), int(sol.iterations), int(sol.searches)], dq])
     print(json.dumps(line), flush=True)
 print(json.dumps({"misses": miss[:40], "n_misses": len(miss), "seconds": round(time.time() - t0, 1)}))
 sys.exit(1 if miss else 0)
