@@ -313,6 +313,10 @@ static int kin_entry(const char *fn, rtbhip_chain_t h, const double *q, int64_t 
     if (frame != 0 && frame != 1) { set_error(std::string(fn) + ": frame must be 0 (jacob0) or 1 (jacobe)"); return RTBHIP_EINVAL; }
     if (N > 0 && !T && !J && !H) { set_error(std::string(fn) + ": no output buffer"); return RTBHIP_EINVAL; }
     if (N == 0) return RTBHIP_OK;
+    if (c->n == 0) {                  // a chain of constants: J is (N, 6, 0) and H (N, 0, 6, 0) -- nothing to write (the reference returns empty arrays)
+        J = nullptr; H = nullptr;
+        if (!T) return RTBHIP_OK;
+    }
     DevChain ops;
     RTB_TRY(chain_device_ops(c, &ops, nullptr));
     Affine base = affine_from16(base16), tool = affine_from16(tool16);

@@ -303,6 +303,8 @@ class ERobot(RobotKinematics):
         for l in reversed(down):
             out += self._link_ets(l)
         made[(id(a), id(b))] = ETS(out)
+        if made[(id(a), id(b))].n and self.n <= 256:
+            made[(id(a), id(b))].q_width = self.n            # every path reads the robot's q rows as they are (no column copy per call)
         return made[(id(a), id(b))]
 
     @property

@@ -667,6 +667,8 @@ class ETS:
                 raise TypeError("device q must be float64")
             single = q.dim() == 1 or (q.dim() == 2 and self._one_config(tuple(q.shape), qw))
             q2 = q.reshape(1, -1) if single else q
+            if q2.shape[1] > qw:
+                q2 = q2[:, :qw]                      # a wider row (the whole robot's q): the joints are read by number, the rest is not looked at
             q2 = q2.contiguous()
             if q2.shape[1] != qw:
                 raise ValueError("q has %d columns, chain needs %d" % (q2.shape[1], qw))
@@ -679,6 +681,10 @@ class ETS:
             raise ValueError("q must be 1-D or 2-D")
         single = a.ndim == 1 or self._one_config(a.shape, qw)
         a = a.reshape(1, -1) if single else a
+        if a.shape[1] > qw:
+            # the reference's C entry points take the row length from the array and read q[jindex] (core/fknm.cpp:964-988, methods.cpp:338): a row
+            # wider than the chain needs -- the whole robot's q handed to robot.ets(end=...) -- is read by joint number, the rest is not looked at
+            a = a[:, :qw]
         if a.shape[1] != qw:
             raise ValueError("q has %d columns, chain needs %d" % (a.shape[1], qw))
         return np.ascontiguousarray(a), single, False

@@ -7,6 +7,7 @@ extern "C" int emu_kin(rtbhip_chain_t h, const double *q, int64_t N, const doubl
     const std::shared_ptr<Chain> c_owner = chain_from_handle(h);
     Chain *c = c_owner.get();
     if (!c) return -1;
+    if (c->n == 0) { J = nullptr; H = nullptr; if (!T) return 0; }      // as kin_entry (api.cpp): empty Jacobian / Hessian of a chain of constants
     KinParams kp;
     kp.n = c->n; kp.qw = c->q_width; kp.stride = kin_stride(c->n);
     kp.frame = frame; kp.N = N; kp.pad = 0;

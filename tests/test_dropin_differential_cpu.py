@@ -136,9 +136,17 @@ def test_both_refuse_the_same_inputs():
                 for call in (lambda o: o.eval(sym), lambda o: o.jacob0(sym), lambda o: o.hessian0(sym)):
                     with pytest.raises(Exception):                        # the extension's TypeError("Symbolic value") starts the Python fall-back,
                         call(obj)                                         # which then fails on these objects in both libraries
-            for bad in (np.zeros(n + 1), np.zeros((3, n + 2))):           # a q that does not fit the chain
-                with pytest.raises(Exception):
-                    mine.eval(bad)
+            # a q row WIDER than the chain needs is read by joint number in both libraries (the C entry points take the row length from the
+            # array: core/fknm.cpp:964-988 -- it is how robot.ets(end=...) is handed the whole robot's q); a narrower one the reference
+            # reads out of bounds -- rtbhip refuses it
+            wide1, wide2 = rng.uniform(-1, 1, n + 1), rng.uniform(-1, 1, (3, n + 2))
+            nt.assert_allclose(A(mine.eval(wide1)), A(ref.eval(wide1)), atol=1e-12)
+            nt.assert_allclose(A(mine.eval(wide2)), A(ref.eval(wide2)), atol=1e-12)
+            nt.assert_allclose(mine.jacob0(wide1), ref.jacob0(wide1), atol=1e-12)
+            if n > 2:                                                     # (a (k, 1) array is ONE configuration of k values: fknm.cpp:976-981)
+                for bad in (np.zeros(n - 1), np.zeros((4, n - 1))):
+                    with pytest.raises(Exception):
+                        mine.eval(bad)
 
 
 def test_c_solver_tuples_agree_for_a_supplied_start():
@@ -710,3 +718,65 @@ def test_ets_qlim_setter_takes_two_rows_and_nothing_else():
             sol = two.ik_LM(T, q0=np.array([0.6, -0.6]), mask=[1, 1, 1, 0, 0, 0], slimit=1)
             assert sol[1] == 1 and sol[3] == 1
             nt.assert_allclose(two.eval(sol[0])[:3, 3], np.asarray(T)[:3, 3], atol=1e-4)          # (tol = 1e-6 on E = e.e / 2)
+
+
+def test_robot_paths_take_the_whole_robots_q_and_a_chain_of_constants_has_empty_derivatives():
+    """robot.ets(end=link) keeps the robot-wide joint numbers and is handed the ROBOT's q (reference Robot.jacob0(q, end=) =
+    self.ets(end=).jacob0(q), robot/Robot.py:1974-1981): every link of random branched robots -- numbered automatically and by hand -- against the
+    product of the links' own transforms, the Jacobian's translational rows against central differences of it.  A path without a joint (the base
+    link's constants) has a (6, 0) Jacobian and an empty Hessian.  Found by a fuzz run in round 4: the paths refused the robot's q, and the
+    joint-less Jacobian divided by its zero row width."""
+    import rtbhip
+    from rtbhip import ERobot
+    from oracle import chains
+    from test_erobot_rne import random_tree
+    from test_erobot_dynamics import renumbered_case
+
+    def link_T(l, q, jidx):
+        T = np.eye(4)
+        for it in l["ets"]:
+            if isinstance(it, np.ndarray):
+                T = T @ it
+            elif len(it) > 1 and it[1] is not None:
+                T = T @ chains.elementary(it[0], it[1])
+            else:
+                T = T @ chains.elementary(it[0], -q[jidx] if (len(it) > 2 and it[2]) else q[jidx])
+        return T
+
+    with cpu_backend.installed():
+        e = rtbhip.ET.tx(0.3) * rtbhip.ET.Rz(0.2)
+        assert e.jacob0(np.zeros((5, 0))).shape == (5, 6, 0) and e.hessian0(np.zeros((5, 0))).shape == (5, 0, 6, 0)
+        nt.assert_allclose(e.eval(np.zeros((2, 3)))[1], chains.elementary("tx", 0.3) @ chains.elementary("Rz", 0.2), atol=1e-15)
+        links_checked = 0
+        for seed in range(12):
+            rng = np.random.default_rng(500 + seed)
+            if seed % 2 == 0:
+                prod, orc = random_tree(rng, n_links=int(rng.integers(3, 10)))
+                rob = ERobot(prod)
+            else:
+                rob, orc, rng = renumbered_case(500 + seed, 4 + seed % 6)
+            n = rob.n
+            if n == 0:
+                continue
+            byname = {l["name"]: l for l in orc}
+            jix = {l.name: l.jindex for l in rob.links}
+
+            def world(name, qrow):
+                l = byname[name]
+                T = link_T(l, qrow, jix[name])
+                return (world(l["parent"], qrow) if l["parent"] is not None else np.eye(4)) @ T
+
+            q = rng.uniform(-2, 2, (4, n))
+            for l in rob.links:
+                path = rob.ets(end=l)
+                want = np.array([world(l.name, row) for row in q])
+                nt.assert_allclose(path.eval(q), want, atol=1e-12)
+                J = path.jacob0(q)
+                cols = [int(c) for c in path.jindices]
+                assert J.shape == (4, 6, len(cols))
+                for c, jq in enumerate(cols):
+                    qp, qm = q[0].copy(), q[0].copy()
+                    qp[jq] += 1e-6; qm[jq] -= 1e-6
+                    nt.assert_allclose(J[0, :3, c], (world(l.name, qp)[:3, 3] - world(l.name, qm)[:3, 3]) / 2e-6, atol=1e-7)
+                links_checked += 1
+        assert links_checked > 40
