@@ -52,6 +52,6 @@ find $O -name "*kernel_trace.csv" -size +8M -delete
 find $O -name "*counter_collection.csv" -size +8M -delete
 # every size of every kernel family on the device against the oracle, random robots (scripts/gpu_fuzz_*.py)
 cd $R
-for f in dyn ik kin rne paths; do
+for f in dyn ik kin rne paths fleet; do
   timeout 900 python scripts/gpu_fuzz_$f.py > $O/fuzz_$f.jsonl 2> $O/fuzz_$f.err; echo "fuzz $f rc=$?" >> $O/fuzz_$f.jsonl; tail -2 $O/fuzz_$f.jsonl | cut -c1-300
 done
