@@ -60,6 +60,27 @@ for n in range(1, 17):
                 line["worst_dq"] = max(line["worst_dq"], dq)
                 if (bool(o[1]), o[2], o[3]) != (bool(sol.success), sol.iterations, sol.searches) or dq > 1e-6:
                     miss.append([n, kind, "ikine_LM", "chan", i, [int(o[1]), int(o[2]), int(o[3])], [int(sol.success), int(sol.iterations), int(sol.searches)], dq])
+        # ikine_NR / ikine_GN (q += pinv(J) e) and ikine_QP (default gains) on chains of 6+ joints whose Jacobian is regular along the way: at a
+        # rank-deficient J the reference's SVD has a rank threshold the kernel's LDL^T has not -- not compared there
+        if n >= 6:
+            for i in range(min(N, 8)):
+                sv = np.linalg.svd(oracle.jacob0(ch, q0[i])[0], compute_uv=False)
+                sv2 = np.linalg.svd(oracle.jacob0(ch, qs[i])[0], compute_uv=False)
+                if min(sv[5], sv2[5]) < 1e-3 * sv[0]:
+                    continue
+                for name, step, kw in (("ikine_NR", "nr", {"pinv": True}), ("ikine_GN", "gn", {"pinv": True}), ("ikine_QP", "qp", {}),
+                                       ("ikine_LM", "lm", {"kq": 0.05, "km": 0.02, "ps": 0.1, "pi": 0.3}), ("ikine_NR", "nr", {"pinv": True, "kq": 0.05, "km": 0.02, "ps": 0.1})):
+                    if (step == "qp" or "kq" in kw) and not 6 <= n <= 12:
+                        continue
+                    sol = getattr(ets, name)(Tep[i], q0=q0[i], slimit=1, **kw)
+                    okw = {k_: v for k_, v in kw.items() if k_ in ("kq", "km", "ps", "pi")}
+                    o = oracle.ikine_py(ch, Tep[i], q0[i][None, :], step=step, slimit=1, **okw)
+                    if o[1]:
+                        line["checked"] += 1
+                        dq = float(np.abs(np.asarray(sol.q) - o[0]).max())
+                        line["worst_dq"] = max(line["worst_dq"], dq)
+                        if (bool(o[1]), o[2], o[3]) != (bool(sol.success), sol.iterations, sol.searches) or dq > 1e-6:
+                            miss.append([n, kind, name, "", i, [int(o[1]), int(o[2]), int(o[3])], [int(sol.success), int(sol.iterations), int(sol.searches)], dq])
     print(json.dumps(line), flush=True)
 print(json.dumps({"misses": miss[:40], "n_misses": len(miss), "seconds": round(time.time() - t0, 1)}))
 sys.exit(1 if miss else 0)
