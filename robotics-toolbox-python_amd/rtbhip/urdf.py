@@ -67,6 +67,10 @@ class URDFJoint:
         self.rpy = _floats(None if o is None else o.get("rpy"), 3, [0, 0, 0])
         a = el.find("axis")
         self.axis = _floats(None if a is None else a.get("xyz"), 3, [1, 0, 0])   # URDF default axis
+        norm = float(np.linalg.norm(self.axis))
+        if norm != 0:
+            self.axis = self.axis / norm          # the reference normalises when it parses (tools/urdf/urdf.py:1357-1369): its "normalising rotation" of
+                                                  # a skew axis (constant() below) is therefore always by |v/|v|| = 1 radian, whatever the length written
         lim = el.find("limit")
         self.lower = self.upper = None
         if lim is not None and self.type in ("revolute", "prismatic"):
