@@ -88,7 +88,7 @@ class URDFJoint:
         """4x4 constant part, incl. the reference's normalising rotation for a skew axis."""
         T = np.eye(4)
         R = rpy_matrix(self.rpy)
-        if self.actuated and np.count_nonzero(self.axis) >= 2:
+        if np.count_nonzero(self.axis) >= 2:       # (whatever the joint's type: the reference tests the axis before it looks at the type, :1706)
             n = float(np.linalg.norm(self.axis))
             R = R @ angvec_matrix(n, self.axis / n)                  # urdf.py:1713-1718
         T[:3, :3] = R
@@ -161,11 +161,19 @@ class URDFRobot:
         if len(roots) != 1:
             raise ValueError("URDF must have exactly one root link, found %d" % len(roots))
         self.base_link = roots[0]
-        # robot-wide joint numbering: actuated joints in URDF joint order
+        # robot-wide joint numbering: the reference's -- depth first from the base link, children in the order their joints appear in the file
+        # (BaseRobot._sort_links robot/BaseRobot.py:336-350 on the link list urdf.py:1694-1700 builds) -- so that every method of this object, the
+        # ERobot made from it (erobot(): the dynamics) and a reference Robot read the same column for the same joint.  (Until round 4 this was
+        # the joints' FILE order: the same thing for a serial arm, not for a branched robot whose file lists one branch's tail after another
+        # branch -- YuMi's grippers.)
         self.jindex = {}
-        for j in self.joints:
-            if j.actuated and j.variable() is not None:
+        stack = [self.base_link]
+        while stack:
+            l = stack.pop()
+            j = l.joint
+            if j is not None and j.actuated and j.variable() is not None:
                 self.jindex[j.name] = len(self.jindex)
+            stack.extend(reversed(l.children))
         self.n = len(self.jindex)
         self._cache = {}
         self.tool = tool

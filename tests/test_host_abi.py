@@ -66,7 +66,9 @@ def test_q_width_of_a_branch_can_be_the_robots():
     y = urdf.load("YuMi")
     r, l = y.ets(end="gripper_r_finger_r", compact=False), y.ets(end="gripper_l_finger_l", compact=False)
     assert r.q_width == l.q_width == y.n == 18 and _info(r)[2] == 18
-    assert sorted(set(r.jindices) | set(l.jindices)) == list(range(14)) + [14, 17]       # 7 + 7 arm joints and a finger each
+    # depth first from the body, as the reference numbers (BaseRobot._sort_links): the right arm 0..6 and its two fingers 7, 8, the left arm 9..15 and
+    # its fingers 16, 17 -- a finger each here
+    assert sorted(r.jindices) == list(range(8)) and sorted(l.jindices) == list(range(9, 16)) + [17]
 
 
 def test_chain_create_rejects_bad_input():

@@ -59,3 +59,33 @@ def test_skew_and_scaled_axes_are_lowered_as_the_reference_lowers_them():
     a = urdf.loadstr(joint_xml("revolute", [0, 0, 0], [0, 0, 0], [1, 1, 0])).joints[0].constant()
     b = urdf.loadstr(joint_xml("revolute", [0, 0, 0], [0, 0, 0], [5, 5, 0])).joints[0].constant()
     nt.assert_allclose(a, b, atol=1e-15)
+
+
+def test_a_fixed_joint_with_a_skew_axis_tag_gets_the_rotation_too():
+    """the reference tests the axis before it looks at the joint's type (:1706 against :1724-1755): a fixed joint that carries a skew <axis> tag has the
+    normalising rotation in its constant transform."""
+    xyz, rpy, axis = [0.1, -0.2, 0.3], [0.4, -0.5, 0.6], [1.0, 2.0, 0.0]
+    j = urdf.loadstr(joint_xml("fixed", xyz, rpy, axis).replace('<limit lower="-2" upper="2" effort="1" velocity="1"/>', "")).joints[0]
+    nt.assert_allclose(j.constant(), reference_constant(xyz, rpy, axis)[0], atol=1e-14)
+    assert j.variable() is None
+
+
+def test_joint_numbers_of_a_branched_robot_are_the_references_depth_first_ones():
+    """A file that lists one branch's tail after the other branch (YuMi's grippers): the robot-wide joint numbers are the reference's -- depth first
+    from the base link (BaseRobot._sort_links) -- in URDFRobot.jindex, in ets(compact=False) and in the ERobot made from it (the dynamics), so
+    that fkine and rne of one object read the same column for the same joint.  Until round 4 URDFRobot numbered in FILE order."""
+    def joint(name, parent, child, axis):
+        return ('<joint name="%s" type="revolute"><parent link="%s"/><child link="%s"/><origin xyz="0.1 0 0"/><axis xyz="%s"/>'
+                '<limit lower="-2" upper="2" effort="1" velocity="1"/></joint>' % (name, parent, child, axis))
+    links = "".join('<link name="%s"/>' % n for n in ("base", "a1", "a2", "b1", "b2", "a3"))
+    xml = '<robot name="y">' + links + joint("ja1", "base", "a1", "0 0 1") + joint("ja2", "a1", "a2", "0 1 0") + joint("jb1", "base", "b1", "0 0 1") \
+        + joint("jb2", "b1", "b2", "0 1 0") + joint("ja3", "a2", "a3", "1 0 0") + "</robot>"            # ja3 (branch a's tail) comes last in the file
+    r = urdf.loadstr(xml)
+    assert r.jindex == {"ja1": 0, "ja2": 1, "ja3": 2, "jb1": 3, "jb2": 4}
+    er = r.erobot()
+    assert {l.name: l.jindex for l in er.links if l.isjoint} == {"a1": 0, "a2": 1, "a3": 2, "b1": 3, "b2": 4}
+    assert list(r.ets(end="a3", compact=False).jindices) == [0, 1, 2] and list(r.ets(end="b2", compact=False).jindices) == [3, 4]
+    yumi = urdf.load("YuMi")
+    assert {l.joint.name: l.jindex for l in []} == {}                                      # (erobot links carry the link name; compare through it)
+    by_link = {l.name: l.jindex for l in yumi.erobot().links if l.isjoint}
+    assert {j.child: yumi.jindex[j.name] for j in yumi.joints if j.name in yumi.jindex} == by_link
