@@ -309,15 +309,34 @@ class ERobot(RobotKinematics):
 
     @property
     def qlim(self):
-        """(2, n) joint limits in joint-number order (reference BaseRobot.qlim robot/BaseRobot.py:783-850)."""
+        """(2, n) joint limits, one column per joint link IN LINK ORDER (reference BaseRobot.qlim robot/BaseRobot.py:979-1038 fills column j for the
+        j-th joint link it meets -- the joint numbers for every automatically numbered robot, not for one numbered by hand); an unset or NaN
+        revolute limit reads as [-pi, pi], an unset prismatic one raises."""
         lim = np.zeros((2, self.n))
+        j = 0
         for l in self.links:
-            if l.isjoint:
-                ql = l.qlim if l.qlim is not None else l.v.qlim
-                if ql is None:
-                    ql = (-np.pi, np.pi) if l.v.isrotation else (0.0, 1.0)
-                lim[:, l.jindex] = np.asarray(ql, dtype=np.float64).reshape(2)
+            if not l.isjoint:
+                continue
+            ql = l.qlim
+            if l.isrevolute:
+                if ql is None or np.any(np.isnan(np.asarray(ql, dtype=np.float64))):
+                    ql = (-np.pi, np.pi)
+            elif ql is None:
+                raise ValueError("Undefined prismatic joint limit")
+            lim[:, j] = np.asarray(ql, dtype=np.float64).reshape(2)
+            j += 1
         return lim
+
+    @qlim.setter
+    def qlim(self, new_qlim):
+        new_qlim = np.array(new_qlim)
+        if new_qlim.shape != (2, self.n):
+            raise ValueError("new_qlim must be of shape (2, n)")
+        j = 0
+        for l in self.links:                       # robot/BaseRobot.py:1041-1051: column j to the j-th joint link
+            if l.isjoint:
+                l.qlim = new_qlim[:, j]
+                j += 1
 
     def fkine_all(self, q, base=None):
         """Pose of every link frame: T[0] = base, T[link.number] = that link -- `number` is the link's position in the list the robot

@@ -780,3 +780,59 @@ def test_robot_paths_take_the_whole_robots_q_and_a_chain_of_constants_has_empty_
                     nt.assert_allclose(J[0, :3, c], (world(l.name, qp)[:3, 3] - world(l.name, qm)[:3, 3]) / 2e-6, atol=1e-7)
                 links_checked += 1
         assert links_checked > 40
+
+
+@pytest.mark.skipif(not ref_classes.dh_available(), reason="needs the reference's byte-compiled Link / Robot classes")
+def test_hand_numbered_link_trees_agree_paths_and_kinematics():
+    """The same with the joints numbered BY HAND in a shuffled order (`Link(..., jindex=k)` on every joint link: BaseRobot.py:353-370 keeps the links
+    in the order given and their numbers): link order, numbers, every path's ETS string, fkine / jacob0 / jacobe / hessian0 on the robot's q,
+    fkine_all, qlim -- the reference's own Link / Robot classes against rtbhip's."""
+    import rtbhip
+    from test_06_reference_dh_classes import ref_dh
+    ns = ref_dh()
+    rLink, rRobot = ns.mods["Link"].Link, ns.mods["Robot"].Robot
+    rng = np.random.default_rng(77)
+
+    def build(ET, ETS, Link, Robot, tree, numbers):
+        links = {}
+        for name, parent, spec in tree:
+            ets = ETS([getattr(ET, it[0])(it[1]) if it[1] is not None else getattr(ET, it[0])(flip=it[2]) for it in spec])
+            kw = {"jindex": numbers[name]} if name in numbers else {}
+            links[name] = Link(ets, name=name, parent=None if parent is None else links[parent], **kw)
+        return Robot(list(links.values()), name="tree"), links
+
+    paths = 0
+    with cpu_backend.installed():
+        for k in range(20):
+            tree = random_tree(rng, 3 + k % 7)
+            joint_links = [name for name, _, spec in tree if spec and spec[-1][1] is None]
+            if len(joint_links) < 2:
+                continue
+            numbers = dict(zip(joint_links, [int(x) for x in rng.permutation(len(joint_links))]))
+            ref, rl = build(ns.ET, ns.ETS, rLink, rRobot, tree, numbers)
+            mine, ml = build(rtbhip.ET, rtbhip.ETS, rtbhip.Link, rtbhip.ERobot, tree, numbers)
+            assert mine.n == ref.n and [l.name for l in mine.links] == [l.name for l in ref.links]
+            assert [l.jindex for l in mine.links] == [l.jindex for l in ref.links]
+            try:
+                want = ref.qlim
+            except ValueError as ex:                        # a prismatic joint without limits: "Undefined prismatic joint limit"
+                with pytest.raises(ValueError, match=str(ex)):
+                    mine.qlim
+                lim = np.tile(np.array([[-1.0], [2.0]]), (1, ref.n)) * rng.uniform(0.5, 1.5, (1, ref.n))
+                ref.qlim = lim; mine.qlim = lim             # ... set through the robot: column j to the j-th joint LINK (BaseRobot.py:1041-1051)
+                want = ref.qlim
+            nt.assert_array_equal(mine.qlim, want)
+            assert [None if l.qlim is None else list(l.qlim) for l in mine.links] == [None if l.qlim is None else list(l.qlim) for l in ref.links]
+            q = rng.uniform(-1.5, 1.5, ref.n)
+            for name, _, _ in tree:
+                e_r, e_m = ref.ets(end=rl[name]), mine.ets(end=ml[name])
+                assert str(e_m) == str(e_r), (name, str(e_m), str(e_r))
+                if e_r.n == 0:
+                    continue
+                nt.assert_allclose(A(mine.fkine(q, end=ml[name])), A(ref.fkine(q, end=rl[name])), atol=1e-12)
+                nt.assert_allclose(mine.jacob0(q, end=ml[name]), ref.jacob0(q, end=rl[name]), atol=1e-12)
+                nt.assert_allclose(mine.jacobe(q, end=ml[name]), ref.jacobe(q, end=rl[name]), atol=1e-12)
+                nt.assert_allclose(mine.hessian0(q, end=ml[name]), ref.hessian0(q, end=rl[name]), atol=1e-12)
+                paths += 1
+            nt.assert_allclose(A(mine.fkine_all(q)), A(ref.fkine_all(q)), atol=1e-12)
+    assert paths >= 40
