@@ -17,6 +17,20 @@
 
 namespace rtbhip {
 
+// The pose tile (128 B per configuration) leaves with ORDINARY stores and before the Jacobian rounds; the Jacobian (48 n B) keeps its non-temporal
+// ones.  With both arrays written non-temporally the kernel's time depended on WHERE the allocator had put T and J relative to one another:
+// 78 us or 90 us per 1e6 Panda configurations, fixed for a given pair of buffers, ~2 in 3 pairs slow (round 4: scripts/headline_placement_probe.py,
+// hbm_region_probe.py -- every buffer alone streams at the same rate, one T is fast with every J, most T only with a few).  Two non-temporal
+// write streams of different pitch meet in the memory system in a way that depends on their addresses; letting the small stream go through
+// the L2 removes the dependence: 78.0-78.1 us on every pair (scripts/headline_remap_probe.py, six pairs x six libraries in one process;
+// ordinary stores for BOTH arrays: 96-101 us).  RTB_T_NT = 1 / RTB_T_FIRST = 0: the form of rounds 1-3, kept as the A/B baseline.
+#ifndef RTB_T_FIRST
+#define RTB_T_FIRST 1
+#endif
+#ifndef RTB_T_NT
+#define RTB_T_NT 0
+#endif
+
 // The chain tables through the constant address space: uniform loads become s_load (SGPR operands).
 #define RTB_CONST __attribute__((address_space(4)))
 struct ConstChain {
@@ -68,7 +82,7 @@ __global__ __launch_bounds__(kWave) void k_kin(KinParams kp, DevChain dc,
             kin_stage_T(kp, lane, rows, P);
             if (COALESCED) {
                 __syncthreads();
-                kin_flush(rows, kp.stride, 16, ncfg, T + cfg0 * 16, lane);
+                kin_flush<RTB_T_NT != 0>(rows, kp.stride, 16, ncfg, T + cfg0 * 16, lane);
             } else {
                 kin_store_own(rows, kp.stride, 16, live, T + cfg * 16, lane);
             }
@@ -94,6 +108,14 @@ __device__ __forceinline__ void reg_tile(const KinParams &kp, const ConstChain &
     Pose P;
     double jac[6 * NJ];
     reg_compute<NJ, WANT_J>(kp, cv, q, cfg0 + lane, P, jac);
+#if RTB_T_FIRST
+    if (WANT_T) {
+        reg_stage_T(kp, P, buf, lane);
+        __syncthreads();
+        kin_flush<RTB_T_NT != 0>(buf, 17, 16, ncfg, T + cfg0 * 16, lane);
+        __syncthreads();
+    }
+#endif
     if (WANT_J) {
 #pragma unroll
         for (int r = 0; r < kWave / kJRound; ++r) {
@@ -105,11 +127,13 @@ __device__ __forceinline__ void reg_tile(const KinParams &kp, const ConstChain &
             __syncthreads();
         }
     }
+#if !RTB_T_FIRST
     if (WANT_T) {
         reg_stage_T(kp, P, buf, lane);
         __syncthreads();
-        kin_flush(buf, 17, 16, ncfg, T + cfg0 * 16, lane);
+        kin_flush<RTB_T_NT != 0>(buf, 17, 16, ncfg, T + cfg0 * 16, lane);
     }
+#endif
 }
 
 // ONE tile per single-wave workgroup, no grid-stride loop: with a loop LICM hoists every segment's
@@ -670,7 +694,7 @@ __global__ __launch_bounds__(kWave, (CLS == 0 ? RTB_REG_WAVES : 2)) void k_fleet
     __syncthreads();
     kin_stage_T(kp, lane, rows, P);
     __syncthreads();
-    kin_flush(rows, kp.stride, 16, ncfg, fe.T + cfg0 * 16, lane);
+    kin_flush<RTB_T_NT != 0>(rows, kp.stride, 16, ncfg, fe.T + cfg0 * 16, lane);
 }
 
 // Dynamic LDS and the register budget are per-launch quantities, so a mixed fleet is walked as (at most)

@@ -84,6 +84,7 @@ RTB_HD void kin_stage_T(const KinParams &kp, int lane, double *rows, Pose P)
 // phases C / E: the wave writes `ncfg` staged rows of W doubles (W even) as one contiguous run.
 // Lane l writes the 16-byte pieces l, l+64, l+128, ... of the run; (cfg, e) tracks which staged
 // row / element piece f falls in without a division per piece.
+template <bool NT = true>
 RTB_HD void kin_flush(const double *rows, int stride, int W, int ncfg, double *__restrict__ dst,
                       int lane)
 {
@@ -97,9 +98,13 @@ RTB_HD void kin_flush(const double *rows, int stride, int W, int ncfg, double *_
         v.x = src[0];
         v.y = src[1];
 #if RTB_NT_STORE && defined(__HIP_DEVICE_COMPILE__)
-        typedef double v2d __attribute__((ext_vector_type(2)));
-        v2d w = {v.x, v.y};
-        __builtin_nontemporal_store(w, reinterpret_cast<v2d *>(dst + f));   // global_store_dwordx4 ... nt
+        if (NT) {
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            v2d w = {v.x, v.y};
+            __builtin_nontemporal_store(w, reinterpret_cast<v2d *>(dst + f));   // global_store_dwordx4 ... nt
+        } else {
+            *reinterpret_cast<double2 *>(dst + f) = v;
+        }
 #else
         *reinterpret_cast<double2 *>(dst + f) = v;
 #endif
