@@ -17,19 +17,23 @@
 
 namespace rtbhip {
 
-// The pose tile (128 B per configuration) leaves with ORDINARY stores and before the Jacobian rounds; the Jacobian (48 n B) keeps its non-temporal
-// ones.  With both arrays written non-temporally the kernel's time depended on WHERE the allocator had put T and J relative to one another:
-// 78 us or 90 us per 1e6 Panda configurations, fixed for a given pair of buffers, ~2 in 3 pairs slow (round 4: scripts/headline_placement_probe.py,
-// hbm_region_probe.py -- every buffer alone streams at the same rate, one T is fast with every J, most T only with a few).  Two non-temporal
-// write streams of different pitch meet in the memory system in a way that depends on their addresses; letting the small stream go through
-// the L2 removes the dependence: 78.0-78.1 us on every pair (scripts/headline_remap_probe.py, six pairs x six libraries in one process;
-// ordinary stores for BOTH arrays: 96-101 us).  RTB_T_NT = 1 / RTB_T_FIRST = 0: the form of rounds 1-3, kept as the A/B baseline.
+// Store policy of the fused fkine + Jacobian kernels.  Both output arrays are streaming writes; written non-temporally, the pair's speed depends on
+// WHERE the allocator put T and J relative to one another -- 78 or 90 us per 1e6 Panda configurations, fixed for a given pair of buffers, about
+// two pairs in three slow (round 4: profiles/r04_headline_stores.txt).  When the pose array (128 B per configuration) is small enough to stay in
+// the part's 256 MB memory-side cache, writing IT with ordinary stores (and first) removes the dependence: a loop that writes the same output
+// arrays every step -- bench.py, a control loop with preallocated outputs -- then runs at 78 us on every pair, because the pose array is
+// absorbed by that cache and rewritten in place (with three or more output sets used in rotation both forms take 90 us).  Beyond that size
+// ordinary stores lose (2e6 configurations: 188-200 us against 148-171), so the launcher turns them on (KinParams.pad bit 0) only for a
+// pose array of at most kPoseCacheBytes; everything else -- fkine alone, the fleet, long batches -- streams non-temporally as before.
+// RTB_T_PLAIN_MAX_BYTES = 0 restores the form of rounds 1-3 (A/B).
 #ifndef RTB_T_FIRST
 #define RTB_T_FIRST 1
 #endif
-#ifndef RTB_T_NT
-#define RTB_T_NT 0
+#ifndef RTB_T_PLAIN_MAX_BYTES
+#define RTB_T_PLAIN_MAX_BYTES (136ll << 20)
 #endif
+constexpr long long kPoseCacheBytes = RTB_T_PLAIN_MAX_BYTES;
+constexpr int kKinPosePlain = 1;      // KinParams.pad bit 0
 
 // The chain tables through the constant address space: uniform loads become s_load (SGPR operands).
 #define RTB_CONST __attribute__((address_space(4)))
@@ -82,7 +86,8 @@ __global__ __launch_bounds__(kWave) void k_kin(KinParams kp, DevChain dc,
             kin_stage_T(kp, lane, rows, P);
             if (COALESCED) {
                 __syncthreads();
-                kin_flush<RTB_T_NT != 0>(rows, kp.stride, 16, ncfg, T + cfg0 * 16, lane);
+                if (kp.pad & kKinPosePlain) kin_flush<false>(rows, kp.stride, 16, ncfg, T + cfg0 * 16, lane);      // wave-uniform
+                else kin_flush<true>(rows, kp.stride, 16, ncfg, T + cfg0 * 16, lane);
             } else {
                 kin_store_own(rows, kp.stride, 16, live, T + cfg * 16, lane);
             }
@@ -112,7 +117,8 @@ __device__ __forceinline__ void reg_tile(const KinParams &kp, const ConstChain &
     if (WANT_T) {
         reg_stage_T(kp, P, buf, lane);
         __syncthreads();
-        kin_flush<RTB_T_NT != 0>(buf, 17, 16, ncfg, T + cfg0 * 16, lane);
+        if (kp.pad & kKinPosePlain) kin_flush<false>(buf, 17, 16, ncfg, T + cfg0 * 16, lane);      // wave-uniform
+        else kin_flush<true>(buf, 17, 16, ncfg, T + cfg0 * 16, lane);
         __syncthreads();
     }
 #endif
@@ -131,7 +137,8 @@ __device__ __forceinline__ void reg_tile(const KinParams &kp, const ConstChain &
     if (WANT_T) {
         reg_stage_T(kp, P, buf, lane);
         __syncthreads();
-        kin_flush<RTB_T_NT != 0>(buf, 17, 16, ncfg, T + cfg0 * 16, lane);
+        if (kp.pad & kKinPosePlain) kin_flush<false>(buf, 17, 16, ncfg, T + cfg0 * 16, lane);
+        else kin_flush<true>(buf, 17, 16, ncfg, T + cfg0 * 16, lane);
     }
 #endif
 }
@@ -568,7 +575,7 @@ int launch_kin(const Chain *c, const DevChain &ops, const double *q, int64_t N, 
     kp.stride = kin_stride(c->n);
     kp.frame = frame;
     kp.has_base = base.used;
-    kp.pad = 0;
+    kp.pad = (T && J && !H && (long long)N * 128 <= kPoseCacheBytes) ? kKinPosePlain : 0;      // (see the store policy at the top of this file)
     kp.N = N;
     for (int i = 0; i < 12; i++) kp.base[i] = base.v[i];
     chain_tail(c, tool, kp.tail);
@@ -694,7 +701,7 @@ __global__ __launch_bounds__(kWave, (CLS == 0 ? RTB_REG_WAVES : 2)) void k_fleet
     __syncthreads();
     kin_stage_T(kp, lane, rows, P);
     __syncthreads();
-    kin_flush<RTB_T_NT != 0>(rows, kp.stride, 16, ncfg, fe.T + cfg0 * 16, lane);
+    kin_flush(rows, kp.stride, 16, ncfg, fe.T + cfg0 * 16, lane);
 }
 
 // Dynamic LDS and the register budget are per-launch quantities, so a mixed fleet is walked as (at most)
