@@ -173,7 +173,7 @@ def main():
     elapsed, kern_avg_ms = rk.timed_steps(step, args.steps, args.warmup)
     kern_min_ms = per_launch_min_ms(step, min(args.steps, 50))
     rotating = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_secondary:      # (--no-secondary: the profiling runs, whose kernel averages are of the timed loop alone)
         # The timed loop above rewrites ONE pair of output arrays, as a control loop with preallocated outputs does: the pose array (128 MB at
         # N = 1e6) then stays in the part's 256 MB memory-side cache between steps (csrc/kin_kernels.hip: store policy).  Beside it, the same
         # kernel on THREE output pairs used in rotation -- every launch writes arrays the previous two did not touch: the rate at which the
