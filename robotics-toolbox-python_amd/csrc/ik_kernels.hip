@@ -481,7 +481,9 @@ __global__ __launch_bounds__(256) void k_ik_merge_flat(int64_t N, int n, int chu
 namespace {
 int g_ik_flat = 1;        // flat schedule (ik_device.h): 0 never, 1 automatic (the batch is resident at once), 2 always (tests)
 int g_ik_flat_l0 = 0;     // searches in a target's first chunk: 0 = automatic -- 8 while the batch is at most 1.5 items per lane of the grid, else 4 ...
-int g_ik_flat_len = 8;    // ... and in every later one.  Round 4, SUSTAINED timing (scripts/ik_ab.py, profiles/r04_ik_ab.txt; round 3 had tuned these on
+int g_ik_flat_len = 0;    // ... and in every later one: 0 = automatic -- 12 from 0.75 items per lane up, else 8 (re-measured on the final iteration,
+                          // sustained, three rounds, outputs bit-equal: 1e5 targets 0.9517 -> 0.9396 ms, 3e5 2.971 -> 2.889, 1e6 and the notebook
+                          // setting unchanged; 2e4 targets 0.535 with 8 against 0.558 with 12: profiles/r04_ik_ab.txt).  The earlier sweep:  Round 4, SUSTAINED timing (scripts/ik_ab.py, profiles/r04_ik_ab.txt; round 3 had tuned these on
                           // 3-launch bursts, i.e. on the boost clock): 1e5 Panda targets, fresh share 100 %: 8/8 1.103 ms, 8/12 1.105, 10/10 1.105, 6/8 1.114,
                           // 4/8 1.138, 5/6 1.145; plain 1.36.  From ~2.5 items per lane up a short first chunk wins again (3e5 targets: 4/8 3.18, 8/8 3.29 ms)
 int g_ik_donate_after = 3;   // sharing: failed searches of a target before its range may be cut (rtbhip_tune "ik_donate_after")
@@ -510,7 +512,7 @@ void ik_tune(const char *key, int value)
     if (std::string(key) == "ik_waves_per_cu") g_ik_waves_per_cu = value < 1 ? 1 : value;
     if (std::string(key) == "ik_flat") g_ik_flat = value < 0 ? 0 : (value > 2 ? 2 : value);
     if (std::string(key) == "ik_flat_l0") g_ik_flat_l0 = value < 0 ? 0 : value;      // 0 = automatic
-    if (std::string(key) == "ik_flat_len") g_ik_flat_len = value < 1 ? 1 : value;
+    if (std::string(key) == "ik_flat_len") g_ik_flat_len = value < 0 ? 0 : value;      // 0 = automatic
     if (std::string(key) == "ik_pass_mask") g_ik_pass_mask = value < 0 ? 0 : value;
     if (std::string(key) == "ik_share") g_ik_share = value < 0 ? 0 : (value > 2 ? 2 : value);
     if (std::string(key) == "ik_phased") g_ik_phased = value < 0 ? 0 : (value > 2 ? 2 : value);
@@ -722,7 +724,8 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
     // batch is resident at once: the regime in which a wave is stuck with the targets it drew) / always (tests).
     {
         const int l0_auto = 2 * N <= 3 * gmax * kWave ? 8 : 4;
-        const IkFlatPlan fp = ik_flat_plan(p, g_ik_flat_l0 > 0 ? g_ik_flat_l0 : l0_auto, g_ik_flat_len);
+        const int len_auto = 4 * (long long)N >= 3ll * gmax * kWave ? 12 : 8;
+        const IkFlatPlan fp = ik_flat_plan(p, g_ik_flat_l0 > 0 ? g_ik_flat_l0 : l0_auto, g_ik_flat_len > 0 ? g_ik_flat_len : len_auto);
         const bool flat_fits = fp.chunks > 1 && fp.chunks < 250 && (long long)N * fp.chunks < (1ll << 32) - 4096 && ik_aux_served(p, n, false);
         // automatic: the batch is resident at once (a wave cannot trade targets) AND large enough that waves hold several targets each -- below
         // that a wave's 64 lanes already serve its one or two targets' searches in parallel and the temporaries would only add latency

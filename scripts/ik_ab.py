@@ -15,7 +15,7 @@ from benchlib import sustained_ms
 
 # "shipped" = the ROUND-3 defaults (flat 4/8, fresh share 50 %): the baseline of these sweeps.  Round 4 ships fresh 100 %, first chunk automatic (8 / 4).
 DEFAULTS = {"ik_flat": 1, "ik_flat_l0": 4, "ik_flat_len": 8, "ik_waves_per_cu": 8, "ik_pass_mask": 3, "ik_fresh_pct": 50, "ik_spec_policy": 0, "ik_share": 0}
-ROUND4 = {"ik_flat_l0": 0, "ik_fresh_pct": 100, "ik_unit_we": 1, "ik_plain": 1}
+ROUND4 = {"ik_flat_l0": 0, "ik_flat_len": 0, "ik_fresh_pct": 100, "ik_unit_we": 1, "ik_plain": 1}
 VARIANTS = [("shipped", {}), ("plain", {"ik_flat": 0}), ("flat 4/16", {"ik_flat_len": 16}), ("flat 8/16", {"ik_flat_l0": 8, "ik_flat_len": 16}),
             ("flat 2/8", {"ik_flat_l0": 2}), ("flat 4/4", {"ik_flat_len": 4}), ("flat 6/8", {"ik_flat_l0": 6}), ("flat 3/6", {"ik_flat_l0": 3, "ik_flat_len": 6}),
             ("flat 4/8, 4 waves/CU", {"ik_waves_per_cu": 4}), ("flat 4/8, 6 waves/CU", {"ik_waves_per_cu": 6}), ("plain, 4 waves/CU", {"ik_flat": 0, "ik_waves_per_cu": 4}),
@@ -39,6 +39,10 @@ if os.environ.get("IK_AB_SET") == "7":          # unit-weight kernel instantiati
     DEFAULTS = dict(DEFAULTS, **ROUND4)
     VARIANTS = [("weighted kernel (ik_unit_we = 0)", {"ik_unit_we": 0}), ("unit-weight kernel, general walk", {"ik_unit_we": 1, "ik_plain": 0}),
                 ("unit-weight kernel, plain-revolute walk", {"ik_unit_we": 1, "ik_plain": 1})]
+if os.environ.get("IK_AB_SET") == "8":          # later-chunk length re-measured on the final iteration (round 4, after the kernel work)
+    DEFAULTS = dict(DEFAULTS, **ROUND4)
+    VARIANTS = [("flat auto/auto (shipped)", {}), ("flat auto/8", {"ik_flat_len": 8}), ("flat auto/10", {"ik_flat_len": 10}), ("flat auto/12", {"ik_flat_len": 12}), ("flat auto/16", {"ik_flat_len": 16}),
+                ("flat 10/10", {"ik_flat_l0": 10, "ik_flat_len": 10}), ("flat 8/12, fresh 90", {"ik_flat_l0": 8, "ik_flat_len": 12, "ik_fresh_pct": 90})]
 if os.environ.get("IK_AB_SET") == "3":          # other batch sizes / settings: does the candidate hold?
     VARIANTS = [("shipped", {}), ("fresh 100", {"ik_fresh_pct": 100}), ("fresh 100, flat 6/8", {"ik_fresh_pct": 100, "ik_flat_l0": 6}), ("fresh 140, flat 6/8", {"ik_fresh_pct": 140, "ik_flat_l0": 6})]
 

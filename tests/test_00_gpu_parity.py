@@ -635,7 +635,7 @@ def test_ik_cross_wave_sharing_and_phased_schedule_equal_plain(flavour):
                 flat = [x.cpu().numpy() for x in run()]
                 for a, b in zip(base, flat):
                     nt.assert_array_equal(a, b)
-            rtbhip.tune("ik_flat", 0); rtbhip.tune("ik_flat_l0", 0); rtbhip.tune("ik_flat_len", 8)
+            rtbhip.tune("ik_flat", 0); rtbhip.tune("ik_flat_l0", 0); rtbhip.tune("ik_flat_len", 0)
             rtbhip.tune("ik_share", 2)
             shared = [x.cpu().numpy() for x in run()]
             rtbhip.tune("ik_donate_after", 0)                     # ranges cut as soon as a wave waits, not after three failures
