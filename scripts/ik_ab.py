@@ -43,6 +43,11 @@ if os.environ.get("IK_AB_SET") == "8":          # later-chunk length re-measured
     DEFAULTS = dict(DEFAULTS, **ROUND4)
     VARIANTS = [("flat auto/auto (shipped)", {}), ("flat auto/8", {"ik_flat_len": 8}), ("flat auto/10", {"ik_flat_len": 10}), ("flat auto/12", {"ik_flat_len": 12}), ("flat auto/16", {"ik_flat_len": 16}),
                 ("flat 10/10", {"ik_flat_l0": 10, "ik_flat_len": 10}), ("flat 8/12, fresh 90", {"ik_flat_l0": 8, "ik_flat_len": 12, "ik_fresh_pct": 90})]
+if os.environ.get("IK_AB_SET") == "9":          # the other scheduler knobs once more, on the final kernel and the automatic chunk lengths
+    DEFAULTS = dict(DEFAULTS, **ROUND4)
+    VARIANTS = [("shipped", {}), ("pass every 2", {"ik_pass_mask": 1}), ("pass every 8", {"ik_pass_mask": 7}), ("fresh 90", {"ik_fresh_pct": 90}),
+                ("fresh 110", {"ik_fresh_pct": 110}), ("6 waves/CU", {"ik_waves_per_cu": 6}), ("10 waves/CU", {"ik_waves_per_cu": 10}),
+                ("first chunk 10", {"ik_flat_l0": 10}), ("first chunk 6", {"ik_flat_l0": 6})]
 if os.environ.get("IK_AB_SET") == "3":          # other batch sizes / settings: does the candidate hold?
     VARIANTS = [("shipped", {}), ("fresh 100", {"ik_fresh_pct": 100}), ("fresh 100, flat 6/8", {"ik_fresh_pct": 100, "ik_flat_l0": 6}), ("fresh 140, flat 6/8", {"ik_fresh_pct": 140, "ik_flat_l0": 6})]
 
