@@ -19,6 +19,9 @@ def declared():
 
 
 def build():
+    import shutil
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler on this box")
     import __graft_entry__ as g
     g.build_lib()
     os.makedirs(OUT, exist_ok=True)
