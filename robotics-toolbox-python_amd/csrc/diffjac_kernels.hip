@@ -28,9 +28,11 @@ __global__ __launch_bounds__(kWave, 1) void k_diff_from_jac(const double *__rest
     __syncthreads();
     double jac[W];
     const double *mine = buf + lane * (W + 1);
-    // a lane beyond the batch works on the identity-like Jacobian of a unit diagonal: finite arithmetic, nothing stored
+    // a lane beyond the batch works on a full-row-rank filler (row r has a one in column r mod NJ and, for NJ < 6, J J^T is made
+    // non-singular by the axes the measure keeps only when NJ >= their count -- so its results may still be inf / NaN for NJ < 6): nothing is
+    // stored for it, the arithmetic only has to stay in lock-step with the wave
 #pragma unroll
-    for (int k = 0; k < W; ++k) jac[k] = lane < ncfg ? mine[k] : ((k / NJ) == (k % NJ) ? 1.0 : 0.0);
+    for (int k = 0; k < W; ++k) jac[k] = lane < ncfg ? mine[k] : ((k / NJ) % NJ == (k % NJ) ? 1.0 : 0.0);
     __syncthreads();
     if (MODE == kFromJacManip) {
         const int method = (axes >> 8) & 3;

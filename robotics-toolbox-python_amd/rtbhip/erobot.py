@@ -268,7 +268,7 @@ class ERobot(RobotKinematics):
 
     def _link_ets(self, l):
         """A link's ETS with the robot-wide joint number on its joint."""
-        return [ET(e.axis, flip=e.isflip, jindex=l.jindex, qlim=e.qlim) if e.isjoint else e for e in l.ets]
+        return [ET(e.axis, flip=e.isflip, jindex=l.jindex, qlim=l.qlim) if e.isjoint else e for e in l.ets]     # l.qlim: the link-level limit first (robot/Link.py:1010-1040 writes through to the joint ET)
 
     def ets(self, start=None, end=None):
         """ETS of the path from link `start` (default: the base link) to link `end` (default: the last link), links given as

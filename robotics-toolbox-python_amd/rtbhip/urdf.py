@@ -156,13 +156,16 @@ class URDFRobot:
         for j in self.joints:
             child, parent = self.linkdict[j.child], self.linkdict[j.parent]
             child.parent, child.joint = parent, j
-            parent.children.append(child)
+        for l in self.links:                 # siblings in LINK file order (BaseRobot._sort_links robot/BaseRobot.py:264-267 walks the link list)
+            if l.parent is not None:
+                l.parent.children.append(l)
         roots = [l for l in self.links if l.parent is None]
         if len(roots) != 1:
             raise ValueError("URDF must have exactly one root link, found %d" % len(roots))
         self.base_link = roots[0]
-        # robot-wide joint numbering: the reference's -- depth first from the base link, children in the order their joints appear in the file
-        # (BaseRobot._sort_links robot/BaseRobot.py:336-350 on the link list urdf.py:1694-1700 builds) -- so that every method of this object, the
+        # robot-wide joint numbering: the reference's -- depth first from the base link, children in the order their LINKS appear in the file
+        # (BaseRobot._sort_links robot/BaseRobot.py:264-267, 336-350 on the link list urdf.py:1666-1676 builds in link order; the joints' order
+        # does not enter) -- so that every method of this object, the
         # ERobot made from it (erobot(): the dynamics) and a reference Robot read the same column for the same joint.  (Until round 4 this was
         # the joints' FILE order: the same thing for a serial arm, not for a branched robot whose file lists one branch's tail after another
         # branch -- YuMi's grippers.)

@@ -211,9 +211,21 @@ class _Context:
     def expr(self, code, scope):
         if "load_yaml" in code:
             raise XacroError("load_yaml is not supported by rtbhip.xacro")
-        if "__" in code:
-            # expressions are evaluated with the builtins withheld; dunder attributes (`().__class__.__base__ ...`) are the way back to them
+        # expressions are evaluated with the builtins withheld; dunder attributes (`().__class__.__base__ ...`) are the way back to them.  Python
+        # NFKC-normalises identifiers (fullwidth U+FF3F underscores resolve to `_`), so the check runs on the normalised text AND on the parsed
+        # tree: no attribute or name may start with an underscore.  (A .xacro file is still a program: its expressions are executed.)
+        import ast
+        import unicodedata
+        if "__" in unicodedata.normalize("NFKC", code):
             raise XacroError("double underscores are not allowed in ${%s}" % code)
+        try:
+            tree = ast.parse(code.strip(), mode="eval")
+        except SyntaxError as e:
+            raise XacroError("cannot evaluate ${%s}: SyntaxError: %s" % (code, e))
+        for node in ast.walk(tree):
+            ident = node.attr if isinstance(node, ast.Attribute) else node.id if isinstance(node, ast.Name) else None
+            if ident is not None and unicodedata.normalize("NFKC", ident).startswith("_"):
+                raise XacroError("names starting with an underscore are not allowed in ${%s}" % code)
         args = self.args
 
         class _Args(dict):                     # `arg('name')` inside expressions

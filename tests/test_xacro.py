@@ -121,6 +121,8 @@ def test_language_details(tmp_path):
     ('<a v="${load_yaml(1)}"/>', "load_yaml"),
     ('<a v="${__import__(\'os\')}"/>', "double underscores"),
     ('<a v="${().__class__.__base__.__subclasses__()}"/>', "double underscores"),
+    ('<a v="${().\uff3f\uff3fclass\uff3f\uff3f}"/>', "double underscores"),          # fullwidth low lines: Python NFKC-normalises identifiers
+    ('<a v="${()._x}"/>', "starting with an underscore"),
     ('<a v="${open(\'/etc/passwd\').read()}"/>', "open"),
 ])
 def test_refusals(tmp_path, body, fragment):
