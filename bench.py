@@ -38,6 +38,9 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "robotics-toolbox-python_amd")]
 from benchlib import protect_stdout, HBM_PEAK_GBS, Ranks, spawn_ranks_if_needed, bench_argv, per_launch_min_ms, ensure_library, pmc_traffic, rocprof_committed, rocprof_committed_all  # noqa: E402
 
 BYTES_PER_CONFIG = 56 + 128 + 336  # q read + T written + J0 written
+KERNEL = {"packed": "k_kin_reg<7,true,true,true> (rtbhip_fkine_jacob_packed: [T | J0] rows of one (N,58) array)",
+          "two": "k_kin_reg<7,true,true,false> (rtbhip_fkine_jacob: T (N,4,4) and J0 (N,6,7))"}
+KERNEL_SUBSTR = {"packed": "k_kin_reg<7, true, true, true>", "two": "k_kin_reg<7, true, true, false>"}
 
 
 def cpu_baseline_all_cores(sample, timeout_s=90.0):
@@ -131,6 +134,10 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline and host_path legs")
     ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` object (BASELINE configs[2], [3], [4] with their in-run parity)")
     ap.add_argument("--tune", action="append", default=[], help="key=value for rtbhip_tune (A/B runs)")
+    ap.add_argument("--layout", choices=("packed", "two"), default="packed",
+                    help="output layout of the timed step: 'packed' = rtbhip_fkine_jacob_packed, one (N,58) array of [T | J0] rows (a single write "
+                         "stream; the T||J gather message of SURVEY 8e); 'two' = rtbhip_fkine_jacob, T (N,4,4) and J0 (N,6,7) as two arrays.  Same "
+                         "arithmetic, same 520 algorithmic bytes per configuration, bit-identical values (the other layout is timed beside it)")
     ap.add_argument("--gather", action="store_true", help="build the process group and time the output gather even with one rank "
                                                           "(a world-size-1 RCCL group: rehearses the collective on a single-GPU box)")
     argv = bench_argv()
@@ -157,47 +164,75 @@ def main():
     rng = np.random.default_rng(rank)  # seed 0 on rank 0 = BASELINE config 2
     q_host = rng.uniform(-np.pi, np.pi, (N, 7))
     q = torch.from_numpy(q_host).to(dev)
-    T = torch.empty((N, 4, 4), dtype=torch.float64, device=dev)
-    J = torch.empty((N, 6, 7), dtype=torch.float64, device=dev)
+    packed = args.layout == "packed"
     lib = rtbhip.lib()
     import ctypes as C
     h = ets._handle()
-    qp, Tp, Jp = C.c_void_p(q.data_ptr()), C.c_void_p(T.data_ptr()), C.c_void_p(J.data_ptr())
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    qp = C.c_void_p(q.data_ptr())
 
-    def step():
-        rc = lib.rtbhip_fkine_jacob(h, qp, N, None, None, 0, Tp, Jp, 1, stream)
-        if rc != 0:
-            raise RuntimeError(lib.rtbhip_last_error().decode())
+    def make_outputs(layout):
+        """(buffers, step function over them): 'packed' one (N,58) array, 'two' the (N,4,4) + (N,6,7) pair"""
+        if layout == "packed":
+            TJ = torch.empty((N, 58), dtype=torch.float64, device=dev)
+            tjp = C.c_void_p(TJ.data_ptr())
 
-    elapsed, kern_avg_ms = rk.timed_steps(step, args.steps, args.warmup)
-    kern_min_ms = per_launch_min_ms(step, min(args.steps, 50))
-    rotating = None
-    if rank == 0 and world == 1 and not args.no_secondary:      # (--no-secondary: the profiling runs, whose kernel averages are of the timed loop alone)
-        # The timed loop above rewrites ONE pair of output arrays, as a control loop with preallocated outputs does: the pose array (128 MB at
-        # N = 1e6) then stays in the part's 256 MB memory-side cache between steps (csrc/kin_kernels.hip: store policy).  Beside it, the same
-        # kernel on THREE output pairs used in rotation -- every launch writes arrays the previous two did not touch: the rate at which the
-        # results stream into memory that has to take them (profiles/r04_headline_stores.txt).  Reported, never `value`.
-        extra = [(torch.empty((N, 4, 4), dtype=torch.float64, device=dev), torch.empty((N, 6, 7), dtype=torch.float64, device=dev)) for _ in range(2)]
-        ptrs = [(Tp, Jp)] + [(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr())) for a, b in extra]
-        state = {"k": 0}
+            def go():
+                rc = lib.rtbhip_fkine_jacob_packed(h, qp, N, None, None, 0, tjp, 1, stream)
+                if rc != 0:
+                    raise RuntimeError(lib.rtbhip_last_error().decode())
+            return (TJ,), go
+        T_ = torch.empty((N, 4, 4), dtype=torch.float64, device=dev)
+        J_ = torch.empty((N, 6, 7), dtype=torch.float64, device=dev)
+        tp, jp = C.c_void_p(T_.data_ptr()), C.c_void_p(J_.data_ptr())
 
-        def rotating_step():
-            tp, jp = ptrs[state["k"] % 3]
-            state["k"] += 1
+        def go():
             rc = lib.rtbhip_fkine_jacob(h, qp, N, None, None, 0, tp, jp, 1, stream)
             if rc != 0:
                 raise RuntimeError(lib.rtbhip_last_error().decode())
+        return (T_, J_), go
+
+    outs, step = make_outputs(args.layout)
+    if packed:
+        TJ = outs[0]
+        T, J = TJ[:, :16].unflatten(1, (4, 4)), TJ[:, 16:].unflatten(1, (6, 7))        # strided views of the rows
+    else:
+        T, J = outs
+        TJ = None
+
+    elapsed, kern_avg_ms = rk.timed_steps(step, args.steps, args.warmup)
+    kern_min_ms = per_launch_min_ms(step, min(args.steps, 50))
+    rotating, layouts = None, None
+    if rank == 0 and world == 1 and not args.no_secondary:      # (--no-secondary: the profiling runs, whose kernel averages are of the timed loop alone)
+        # The timed loop above rewrites ONE output buffer set, as a control loop with preallocated outputs does.  Beside it, for BOTH layouts:
+        # the sustained rate on one buffer set, and on THREE sets used in rotation -- every launch writes memory the previous two did not touch,
+        # the rate at which results stream into memory that has to take them.  The two-array form's rate depends on where the allocator put
+        # its two arrays relative to one another (10-14 %, profiles/r04_headline_stores.txt) and, on one set, on the pose array fitting the
+        # memory-side cache; the packed form is a single stream and has neither dependence.  Reported, never `value`.
         from benchlib import sustained_ms
-        rotating_step()
-        rms, _, _ = sustained_ms(rotating_step)
-        step()
-        sms, _, _ = sustained_ms(step)
-        rotating = {"output_pairs": 3, "kernel_avg_ms": rms, "frac": BYTES_PER_CONFIG * N / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "one_pair_sustained_ms": sms, "one_pair_sustained_frac": BYTES_PER_CONFIG * N / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "what": "sustained timing (>= 30 ms of back-to-back launches after >= 30 ms of warm-up); with one output pair the pose array is "
-                            "rewritten in the memory-side cache, with three pairs in rotation every launch streams to memory"}
-        del extra, ptrs
+        layouts = {}
+        for name in ("packed", "two"):
+            sets = [(outs, step)] if name == args.layout else [make_outputs(name)]
+            sets += [make_outputs(name) for _ in range(2)]
+            state = {"k": 0}
+
+            def rot():
+                sets[state["k"] % 3][1]()
+                state["k"] += 1
+            rot()
+            rms, _, _ = sustained_ms(rot)
+            sets[0][1]()
+            sms, _, _ = sustained_ms(sets[0][1])
+            frac = lambda ms: BYTES_PER_CONFIG * N / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            layouts[name] = {"one_set_sustained_ms": sms, "one_set_sustained_frac": frac(sms), "rotating3_ms": rms, "rotating3_frac": frac(rms)}
+            del sets
+        layouts["what"] = ("sustained timing (>= 30 ms of back-to-back launches after >= 30 ms of warm-up) of rtbhip_fkine_jacob_packed ('packed': one "
+                           "(N,58) array) and rtbhip_fkine_jacob ('two': T and J0 arrays) on one output set and on three sets in rotation; same values bit for bit")
+        cur = layouts[args.layout]
+        rotating = {"output_pairs": 3, "kernel_avg_ms": cur["rotating3_ms"], "frac": cur["rotating3_frac"],
+                    "one_pair_sustained_ms": cur["one_set_sustained_ms"], "one_pair_sustained_frac": cur["one_set_sustained_frac"],
+                    "what": "the timed layout (%s) under sustained timing: three output sets in rotation / one set" % args.layout}
+        torch.cuda.empty_cache()
     probe = None
     if rank == 0 and world == 1:
         # what the memory system of THIS box delivers for the same traffic (56 B read + 464 B written per configuration) through a plain
@@ -225,16 +260,24 @@ def main():
                            "configuration, no arithmetic",
                  "ms": pms, "GBs": moved / (pms * 1e-3) / 1e9}
         del dst
-    # the one exchange of the path, outside the timed region: T|J rows of every rank to every rank
+    # every rank's device identity and its own step / kernel times (the line answers "did N ranks drive N GPUs?" by itself)
+    per_rank = rk.identities(ms_per_step_own=rk.last_own_elapsed / args.steps * 1e3, kernel_avg_ms=kern_avg_ms) if rk.dist is not None else None
+    # the one exchange of the path, outside the timed region: the ranks' T||J rows to rank 0 (and, beside it, to every rank).  With the packed
+    # layout the rows ARE the kernel's output; with two arrays one more packed launch makes them (no torch.cat copy either way).
     gather_ms, gather_mem = None, None
     if rk.dist is not None:
-        rows = torch.cat([T.reshape(N, 16), J.reshape(N, 42)], dim=1)
+        if packed:
+            rows = TJ
+        else:
+            (rows,), go = make_outputs("packed")
+            go()
         torch.cuda.synchronize()
         before = torch.cuda.memory_allocated()
-        gather_ms = rk.gather_ms(rows)                    # allocates its world x N x 58 receive buffer inside, releases it on return
+        gather_ms = rk.gather_ms(rows)                    # allocates its N_total x 58 receive buffers inside, releases them on return
         gather_mem = dict(rk.last_gather, device_bytes_before=before, device_bytes_after=torch.cuda.memory_allocated(),
                           where="after the timed region of `value`, released before cpu_baseline / secondary")
-        del rows
+        if not packed:
+            del rows
 
     if rank == 0:
         achieved = BYTES_PER_CONFIG * N / (kern_avg_ms * 1e-3) / 1e9
@@ -262,32 +305,39 @@ def main():
                        "backend": rk.backend if rk.dist is not None else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "k_kin_reg<7,true,true>", "kernel_avg_ms": kern_avg_ms, "per_launch_event_min_ms": kern_min_ms,
+                         "kernel": KERNEL[args.layout], "layout": args.layout, "kernel_avg_ms": kern_avg_ms, "per_launch_event_min_ms": kern_min_ms,
                          "kernel_avg_source": "one HIP-event pair on the launch stream around the K timed launches / K "
                                               "(per_launch_event_min_ms: smallest of per-launch event pairs, each of which adds a few microseconds "
                                               "-- it can exceed the loop average)",
                          "algorithmic_bytes_per_launch": BYTES_PER_CONFIG * N},
         }
-        committed = rocprof_committed(ROOT)
+        committed = rocprof_committed(ROOT, KERNEL_SUBSTR[args.layout])
         if committed is not None:
             # the rocprofv3 --kernel-trace --stats figure of the SAME command committed under profiles/ (another lease, possibly another box:
             # boxes of this pool differ by 10-15 % on this kernel) next to what this run measured with events
             line["roofline"]["frac_rocprof_committed"] = BYTES_PER_CONFIG * N / (committed["avg_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBS
             line["roofline"]["rocprof_committed"] = committed
             line["roofline"]["rocprof_committed_leases"] = [dict(x, frac=BYTES_PER_CONFIG * N / (x["avg_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBS)
-                                                            for x in rocprof_committed_all(ROOT)]      # the spread between leases (boxes)
+                                                            for x in rocprof_committed_all(ROOT, KERNEL_SUBSTR[args.layout])]      # the spread between leases (boxes)
         if rotating is not None:
             line["roofline"]["rotating_outputs"] = rotating
+            line["roofline"]["layouts"] = layouts
         if probe is not None:
             # context, not a ceiling: a plain streaming kernel with the same read / write mix on THIS box (the fused kernel has beaten it)
             line["roofline"]["stream_probe"] = probe
         if rk.shared:
             line["config"]["devices_shared"] = True   # gloo test hook: more ranks than GPUs, NOT a scaling measurement
+        if per_rank is not None:
+            line["ranks"] = per_rank
+            line["world"] = {"launcher": world, "process_group": rk.dist.get_world_size(), "backend": rk.backend,
+                             "rccl_world": (gather_mem or {}).get("rccl_world"), "distinct_devices": len({r["uuid"] + r["pci_bus_id"] for r in per_rank})}
         if gather_ms is not None:
-            line["gather_ms"] = gather_ms
+            line["gather_ms"] = gather_ms                       # gather-to-root (rank 0), the default form of the exchange
+            line["all_gather_ms"] = gather_mem.get("all_gather_ms")
             line["gather_buffer"] = gather_mem
-            line["gather"] = "all_gather_into_tensor of (N,58) f64 rows per rank, %s" % (
-                ("RCCL, a world-size-1 group on one GPU (--gather: rehearsal of the collective, no xGMI traffic)" if world == 1 else "RCCL over xGMI")
+            line["gather"] = "gather of the ranks' (N,58) f64 T||J rows to rank 0 (gather_ms) and to every rank (all_gather_ms), %s" % (
+                ("RCCL through rtbhip_shard_gather, a world-size-1 communicator on one GPU (--gather: rehearsal of the collective, no xGMI traffic)" if world == 1
+                 else "RCCL over xGMI through rtbhip_shard_gather")
                 if rk.backend == "nccl" else "gloo through host memory (test hook)")
         if not args.no_cpu and world == 1:  # reported on rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(q_host, T, J)

@@ -198,8 +198,9 @@ def main():
             tr, src = pmc_traffic(ROOT, "r03_pmc_rne.json")
             line["roofline"]["traffic"], line["roofline"]["traffic_source"] = tr, src
         if world > 1:
-            line["gather_ms"] = rk.gather_ms(hold["tau"], rows=N)      # uneven shards are padded inside
-            line["gather"] = "all_gather_into_tensor of the (rows,7) tau shards, %d bytes in total" % (56 * Ntot)
+            line["gather_ms"] = rk.gather_ms(hold["tau"], rows=N)      # to rank 0; ragged shards go straight into place (RCCL) / padded (gloo hook)
+            line["all_gather_ms"] = rk.last_gather.get("all_gather_ms")
+            line["gather"] = "gather of the (rows,7) tau shards to rank 0 (gather_ms) and to every rank (all_gather_ms), %d bytes in total; %s" % (56 * Ntot, rk.last_gather.get("via"))
             if rk.shared:
                 line["devices_shared"] = True
         if rank != 0:

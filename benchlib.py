@@ -162,39 +162,122 @@ class Ranks:
         dev_ms = e0.elapsed_time(e1)
         if trace is not None and self.rank == 0:      # where does the host spend the loop?  (diagnosis only)
             sys.stderr.write("bench trace: host us per step " + " ".join("%.0f" % (x * 1e6) for x in trace) + " | loop %.0f us\n" % (elapsed * 1e6))
+        self.last_own_elapsed = elapsed                 # this rank's own host clock over the K steps (the contract's figure is the MAX over ranks)
         return self.max_over_ranks(elapsed), dev_ms / steps
 
+    def comm(self):
+        """This run's RCCL communicator BEHIND THE C ABI (rtbhip_shard_comm_create; csrc/shard.cpp): the process group only ships the 128-byte
+        id.  None under the gloo test hook (ranks share devices there; RCCL refuses two ranks on one GPU)."""
+        if self.dist is None or self.backend != "nccl":
+            return None
+        if getattr(self, "_comm", None) is None:
+            import rtbhip
+            self._comm = rtbhip.Communicator.from_process_group()
+        return self._comm
+
     def gather_ms(self, local_out, rows=None, keep=False):
-        """The ONE exchange of the path: all_gather_into_tensor of the ranks' output shards (RCCL over xGMI; through host memory under the gloo
-        hook).  Shards of different lengths (N not a multiple of the world size: rtbhip_shard_range gives the first ranks one row more) are
-        padded to the longest one -- `rows` = this rank's valid rows, default all of local_out.  Milliseconds of the second call (the first
-        builds the communicator), MAX over ranks; None for a single rank without a group.
-        The receive buffer (world x longest shard) exists only inside this call: it is allocated here, AFTER the timed region of `value`, and
-        released on return (before the cpu_baseline leg starts); `last_gather` records its size and, with keep=True, the gathered rows."""
+        """The ONE exchange of the path, in both forms: the gather of the ranks' output shards TO RANK 0 (the default form: every shard crosses
+        one xGMI link once, only the root holds all rows) and the all-gather (every rank receives every shard: world x the traffic and the
+        receive memory).  Under RCCL both are ONE call of rtbhip_shard_gather through the C ABI (ncclGather / ncclAllGather; ragged shards as
+        one group of sends / receives straight into place, no padding); under the gloo test hook they are torch.distributed's gather /
+        all_gather_into_tensor of shards padded to the longest one.  `rows` = this rank's valid rows, default all of local_out.
+        Returns the milliseconds of the second gather-to-root (the first call builds the communicator), MAX over ranks; None for a single rank
+        without a group.  `last_gather` holds both times, how they were made, and the receive buffer's size.
+        The receive buffers exist only inside this call: allocated here, AFTER the timed region of `value`, released on return (before the
+        cpu_baseline leg starts); with keep=True `last_gather["rows"]` keeps the gathered rows (a host copy)."""
         import torch
         if self.dist is None:
             return None
         n = int(local_out.shape[0] if rows is None else rows)
+        total = int(round(self.sum_over_ranks(n)))
         longest = int(self.max_over_ranks(n))
+        tail = tuple(local_out.shape[1:])
+        comm = self.comm()
+        import rtbhip
+        fits = n == rtbhip.shard_range(total, self.rank, self.world)[1]
+        if comm is not None and self.min_over_ranks(1.0 if fits else 0.0) > 0:
+            send = local_out[:n].contiguous()
+            out_root = torch.empty((total,) + tail, dtype=send.dtype, device=send.device) if self.rank == 0 else None
+
+            def timed(root, out):
+                comm.gather(send, total, root=root, out=out)
+                self.barrier()
+                g0 = time.perf_counter()
+                comm.gather(send, total, root=root, out=out)
+                self.barrier()
+                return self.max_over_ranks((time.perf_counter() - g0) * 1e3)
+            ms = timed(0, out_root)
+            kept = out_root.cpu() if (keep and self.rank == 0) else None
+            row_elems = 1
+            for d in tail:
+                row_elems *= int(d)
+            nbytes_root = total * row_elems * send.element_size()
+            out_root = None
+            out_all = torch.empty((total,) + tail, dtype=send.dtype, device=send.device)
+            ms_all = timed(-1, out_all)
+            if keep and kept is None:
+                kept = out_all.cpu()
+            w, r, ver = comm.info()
+            self.last_gather = {"buffer_bytes": nbytes_root, "world": self.world, "rows_per_rank_padded": longest, "padded": False,
+                                "root_gather_ms": ms, "all_gather_ms": ms_all, "all_gather_buffer_bytes_per_rank": nbytes_root,
+                                "via": "rtbhip_shard_gather (C ABI, csrc/shard.cpp) -> RCCL %s" % ("ncclGather / ncclAllGather" if total % self.world == 0 else "grouped ncclSend / ncclRecv (ragged shards)"),
+                                "rccl_world": w, "rccl_rank0": r if self.rank == 0 else None, "rccl_version": ver}
+            if keep:
+                self.last_gather["rows"] = kept
+            return ms
+        # gloo test hook (or shards that are not rtbhip_shard_range's): torch.distributed, shards padded to the longest
         send = local_out[:n]
         send = send.contiguous() if self.backend == "nccl" else send.cpu().contiguous()
         if n < longest:
             pad = torch.zeros((longest,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
             pad[:n] = send
             send = pad
+        lst = [torch.empty_like(send) for _ in range(self.world)] if self.rank == 0 else None
+        self.dist.gather(send, lst, dst=0)
+        self.barrier()
+        g0 = time.perf_counter()
+        self.dist.gather(send, lst, dst=0)
+        self.barrier()
+        ms = self.max_over_ranks((time.perf_counter() - g0) * 1e3)
+        lst = None
         buf = torch.empty((self.world * longest,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
         self.dist.all_gather_into_tensor(buf, send)
         self.barrier()
         g0 = time.perf_counter()
         self.dist.all_gather_into_tensor(buf, send)
         self.barrier()
-        ms = self.max_over_ranks((time.perf_counter() - g0) * 1e3)
-        self.last_gather = {"buffer_bytes": buf.numel() * buf.element_size(), "rows_per_rank_padded": longest, "world": self.world}
+        ms_all = self.max_over_ranks((time.perf_counter() - g0) * 1e3)
+        self.last_gather = {"buffer_bytes": buf.numel() * buf.element_size(), "rows_per_rank_padded": longest, "world": self.world, "padded": True,
+                            "root_gather_ms": ms, "all_gather_ms": ms_all,
+                            "via": "torch.distributed %s: gather(dst=0) / all_gather_into_tensor of padded shards" % self.backend}
         if keep:
             counts = [torch.zeros(1, dtype=torch.int64, device=send.device) for _ in range(self.world)]
             self.dist.all_gather(counts, torch.tensor([n], dtype=torch.int64, device=send.device))
             self.last_gather["rows"] = torch.cat([buf[r * longest:r * longest + int(c.item())] for r, c in enumerate(counts)]).cpu()
         return ms
+
+    def min_over_ranks(self, x):
+        import torch
+        if self.dist is None:
+            return float(x)
+        t = torch.tensor([float(x)], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return float(t.item())
+
+    def identities(self, **mine):
+        """Every rank's {"rank", "device", "pci_bus_id", "uuid", **mine} on every rank (all_gather_object), rank order: the run's own answer to
+        "did each rank drive its own GPU?".  Under RCCL two ranks on one physical device are an error (SystemExit on every rank, one line);
+        the gloo test hook shares devices on purpose (`shared`)."""
+        import rtbhip
+        me = dict(rtbhip._lib.device_identity(self.dev.index if self.dev.index is not None else 0), rank=self.rank, **mine)
+        if self.dist is None:
+            return [me]
+        box = [None] * self.world
+        self.dist.all_gather_object(box, me)
+        ids = [b["uuid"] + "/" + b["pci_bus_id"] for b in box]
+        if self.backend == "nccl" and len(set(ids)) != len(ids):
+            raise SystemExit("bench: two ranks report the same GPU (%s): one process per device is the contract" % ", ".join(ids))
+        return box
 
     def finish(self):
         if self.dist is not None:

@@ -215,47 +215,94 @@ def rne_config4(rtbhip, N=10000000, shard=1250000, sample=20000):
 
 
 def fleet_config5(rtbhip, N=1000000, sample=4000):
-    """BASELINE configs[4]: the 16 supplied URDF arms (4..10 joints on the path to the end effector), N configurations each, q ~ U(qlim)
-    (device generator, seed 4 + i), ONE variable-length-chain call for all of them.  Parity: the first `sample` rows of every arm through
-    the reference's compiled ETS_fkine / ETS_jacob0 on the same op-table."""
+    """BASELINE configs[4] in full: the 16 supplied URDF arms, N configurations each, q ~ U(qlim) (device generator, seed 4 + i), ONE
+    variable-length-chain call for all of them -- with YuMi as what it is, ONE 14-DOF dual-arm robot: its two arms (7 joints + a finger each)
+    are two chains that read the SAME (N, 18) robot-wide q array (the reference evaluates a branch on the robot's q: Robot.jacob0(q, end=...),
+    robot/Robot.py:1974-1981), so the call walks 17 chains of 16 robots and the robots span 4..14 DOF.  Timed in the packed layout
+    (rtbhip_fleet_fkine_jacob_packed: one [T | J] array per chain) and in the two-array layout; the 16-chain form of rounds 1-4 (YuMi as one
+    8-joint branch) is kept beside it.  Parity: the first `sample` rows of EVERY chain through the reference's compiled ETS_fkine / ETS_jacob0."""
     import numpy as np
     import torch
     from rtbhip import urdf
     robots = [urdf.load(nm) for nm in urdf.FLEET16]
-    chs = [r.ets() for r in robots]
-    qs = []
-    for i, c in enumerate(chs):
+    chs16 = [r.ets() for r in robots]
+    qs16 = []
+    for i, c in enumerate(chs16):
         ql = torch.from_numpy(np.clip(c.qlim, -2 * np.pi, 2 * np.pi)).cuda()
         g = torch.Generator(device="cuda").manual_seed(4 + i)
-        qs.append(ql[0] + (ql[1] - ql[0]) * torch.rand((N, c.n), dtype=torch.float64, device="cuda", generator=g))
+        qs16.append(ql[0] + (ql[1] - ql[0]) * torch.rand((N, c.n), dtype=torch.float64, device="cuda", generator=g))
+    yumi = robots[-1]
+    ends = ("gripper_r_finger_r", "gripper_l_finger_l")
+    arms = [yumi.ets(end=e, compact=False) for e in ends]                    # robot-wide joint numbers: both read the (N, 18) array
+    lo, hi = np.full(yumi.n, -1.0), np.full(yumi.n, 1.0)
+    for a in arms:
+        ql = np.clip(a.qlim, -2 * np.pi, 2 * np.pi)
+        lo[a.jindices], hi[a.jindices] = ql[0], ql[1]
+    g = torch.Generator(device="cuda").manual_seed(4 + 15)
+    lo_d, hi_d = torch.from_numpy(lo).cuda(), torch.from_numpy(hi).cuda()
+    qy = lo_d + (hi_d - lo_d) * torch.rand((N, yumi.n), dtype=torch.float64, device="cuda", generator=g)
+    chs17, qs17 = chs16[:-1] + arms, qs16[:-1] + [qy, qy]
     torch.cuda.empty_cache()
-    hold = {"out": rtbhip.fleet_fkine_jacob(chs, qs)}            # the result buffers, allocated once: the timed launches write into them
 
-    def step():
-        rtbhip.fleet_fkine_jacob(chs, qs, out=hold["out"])
-    step()
-    ms, reps, warm = sustained_ms(step)
-    byts = sum(N * (8 * c.n + 128 + 48 * c.n) for c in chs)
-    Ts, Js = hold["out"]
+    def measure(chs, qs):
+        """sustained ms of the call in both layouts on preallocated outputs; returns (ms_packed, ms_two, packed rows)"""
+        hold = {"two": rtbhip.fleet_fkine_jacob(chs, qs)}
+
+        def two():
+            rtbhip.fleet_fkine_jacob(chs, qs, out=hold["two"])
+        two()
+        ms_two, reps2, warm2 = sustained_ms(two)
+        del hold["two"]
+        torch.cuda.empty_cache()
+        hold["packed"] = rtbhip.fleet_fkine_jacob_packed(chs, qs)
+
+        def pk():
+            rtbhip.fleet_fkine_jacob_packed(chs, qs, out=hold["packed"])
+        pk()
+        ms_p, reps, warm = sustained_ms(pk)
+        return ms_p, ms_two, hold["packed"], reps, warm
+    ms16, ms16_two, rows16, _, _ = measure(chs16, qs16)
+    del rows16
+    torch.cuda.empty_cache()
+    ms, ms_two, rows, reps, warm = measure(chs17, qs17)
+    byts16 = sum(N * (8 * c.n + 128 + 48 * c.n) for c in chs16)
+    byts = sum(N * (8 * c.n + 128 + 48 * c.n) for c in chs16[:-1]) + N * (8 * yumi.n + sum(128 + 48 * a.n for a in arms))     # YuMi's q row is read once per arm chain but is ONE array: priced once
     err, cpu_s, kind = 0.0, 0.0, None
+    per_chain = {}
     n = min(sample, N)
-    for c, qd_, T, J in zip(chs, qs, Ts, Js):
+    names = list(urdf.FLEET16[:-1]) + ["YuMi:" + e for e in ends]
+    for nm, c, qd_, TJ in zip(names, chs17, qs17, rows):
         kind, _, fk, jc = _kin_checker(_oracle_chain(c))
         qh = qd_[:n].cpu().numpy()
+        if c.q_width != c.n:
+            qh = np.ascontiguousarray(qh[:, np.asarray(c.jindices)])         # the checker's chain numbers the path's joints 0..n-1 in order of appearance
         t0 = time.perf_counter()
         Tc, Jc = fk(qh), jc(qh)
         cpu_s += time.perf_counter() - t0
-        err = max(err, float(np.abs(T[:n].cpu().numpy() - Tc).max()), float(np.abs(J[:n].cpu().numpy() - Jc).max()))
+        got = TJ[:n].cpu().numpy()
+        e = max(float(np.abs(got[:, :16].reshape(n, 4, 4) - Tc).max()), float(np.abs(got[:, 16:].reshape(n, 6, c.n) - Jc).max()))
+        per_chain[nm] = e
+        err = max(err, e)
     if not err <= 1e-10:
-        raise SystemExit("bench: secondary fleet parity failed: max abs err %g" % err)
-    out = {"workload": "BASELINE configs[4]: %d URDF arms x %d configurations, q ~ U(qlim) (device generator seed 4+i), fkine + jacob0 of every arm, one call" % (len(chs), N),
-           "value": N * len(chs) / (ms * 1e-3), "unit": "configurations/s", "n": N * len(chs), "kernel_avg_ms": ms, "launches_timed": reps, "launches_warmup": warm,
-           "arms": {nm: int(c.n) for nm, c in zip(urdf.FLEET16, chs)},
+        raise SystemExit("bench: secondary fleet parity failed: max abs err %g (%r)" % (err, per_chain))
+    dof = {nm: int(c.n) for nm, c in zip(urdf.FLEET16[:-1], chs16[:-1])}
+    dof["YuMi"] = 14
+    out = {"workload": "BASELINE configs[4]: 16 URDF arms x %d configurations (4..14 DOF; YuMi as ONE 14-DOF dual-arm robot: two 8-joint chains -- 7 arm joints + a finger "
+                       "each -- reading its %d-column q), q ~ U(qlim) (device generator seed 4+i), fkine + jacob0 of every chain, ONE call (17 chains), packed [T | J] rows" % (N, yumi.n),
+           "value": N * 16 / (ms * 1e-3), "unit": "robot configurations/s", "n": N * 16, "chains": 17, "chain_evaluations_per_s": N * 17 / (ms * 1e-3),
+           "kernel_avg_ms": ms, "layout": "packed", "two_array_layout_ms": ms_two, "launches_timed": reps, "launches_warmup": warm,
+           "arms": dof, "chain_joints": {nm: int(c.n) for nm, c in zip(names, chs17)},
            "parity": {"against": "ETS_fkine + per-row ETS_jacob0 of the reference's compiled fknm (oracle/_ref)" if kind == "reference" else "oracle/liboracle.so",
-                      "sample": "the first %d configurations of each of the %d arms" % (n, len(chs)), "max_abs_err": err, "tolerance": 1e-10,
-                      "cpu_seconds": cpu_s, "cpu_configurations_per_s": n * len(chs) / cpu_s},
-           "roofline": _hbm(byts, ms, "k_fleet<0> + k_fleet<1> (one call, two launches: chains of up to 8 joints / beyond)")}
-    del hold, Ts, Js, qs
+                      "sample": "the first %d configurations of each of the 17 chains (YuMi's two arms on the columns of its robot-wide q)" % n,
+                      "max_abs_err": err, "max_abs_err_yumi_arms": max(per_chain[k] for k in per_chain if k.startswith("YuMi:")), "tolerance": 1e-10,
+                      "cpu_seconds": cpu_s, "cpu_configurations_per_s": n * 17 / cpu_s},
+           "roofline": _hbm(byts, ms, "k_fleet<0,packed> + k_fleet<1,packed> (one call, two launches: chains of up to 8 joints / beyond)"),
+           "sixteen_chain_form": {"what": "rounds 1-4's form: YuMi as one 8-joint branch with path-local q (16 chains, 4..10 joints)", "n": N * 16,
+                                  "kernel_avg_ms": ms16, "two_array_layout_ms": ms16_two, "value": N * 16 / (ms16 * 1e-3),
+                                  "roofline": _hbm(byts16, ms16, "k_fleet<0,packed> + k_fleet<1,packed>"),
+                                  "roofline_two_arrays": _hbm(byts16, ms16_two, "k_fleet<0> + k_fleet<1>")}}
+    out["roofline"]["two_array_layout_frac"] = byts / (ms_two * 1e-3) / 1e9 / HBM_PEAK_GBS
+    del rows, qs16, qs17, qy
     torch.cuda.empty_cache()
     return out
 

@@ -120,6 +120,14 @@ int rtbhip_fkine_jacob(rtbhip_chain_t chain, const double *q, int64_t N, const d
                        const double *tool16, int32_t frame, double *T, double *J, int32_t mem,
                        void *stream);
 
+/* The same fused op with ONE output array: TJ is (N, 16 + 6n) C-order, row i = [T[i] (4x4 row-major, 16 doubles) | J[i] ((6,n) C-order)].
+ * It is what ETS_fkine (fknm.cpp:923-1064) + ETS_jacob0 / ETS_jacobe (fknm.cpp:785-921) return for row i, laid side by side: the
+ * 464-byte T||J message of the multi-GPU gather (rtbhip_shard_gather below), and a single write stream for the device
+ * (the two-array form writes two, whose relative placement costs up to 14 %: profiles/r04_headline_stores.txt).  Values are bit for bit
+ * those of rtbhip_fkine_jacob. */
+int rtbhip_fkine_jacob_packed(rtbhip_chain_t chain, const double *q, int64_t N, const double *base16,
+                              const double *tool16, int32_t frame, double *TJ, int32_t mem, void *stream);
+
 /* ETS_hessian0 / ETS_hessiane (fknm.cpp:583-783 -> methods.cpp:16-32), batched: H is (N,n,6,n). */
 int rtbhip_hessian(rtbhip_chain_t chain, const double *q, int64_t N, const double *tool16,
                    int32_t frame, double *H, int32_t mem, void *stream);
@@ -318,6 +326,11 @@ int rtbhip_fleet_fkine_jacob(const rtbhip_chain_t *chains, int32_t n_chains,
                              const double *const *q, const int64_t *N, int32_t frame,
                              double *const *T, double *const *J, int32_t mem, void *stream);
 
+/* ... with packed rows: TJ[c] is (N[c], 16 + 6 n_c), row = [T | J] as rtbhip_fkine_jacob_packed. */
+int rtbhip_fleet_fkine_jacob_packed(const rtbhip_chain_t *chains, int32_t n_chains,
+                                    const double *const *q, const int64_t *N, int32_t frame,
+                                    double *const *TJ, int32_t mem, void *stream);
+
 /* Pinned host memory for the RTBHIP_MEM_HOST boundary.  Host arrays are streamed through the device in row chunks that
  * alternate between two persistent slots (stream + device buffer + pinned staging each), so H2D / kernel of one chunk overlap
  * the D2H of the previous one and nothing is allocated per call.  Pageable arrays are copied through the pinned staging by a few
@@ -336,6 +349,46 @@ int rtbhip_trim(uint64_t keep_device_bytes, uint64_t keep_pinned_bytes);
  * `world` (the first N % world ranks get one extra row).  Pure host arithmetic. */
 int rtbhip_shard_range(int64_t N, int32_t rank, int32_t world, int64_t *begin, int64_t *count);
 
+/* ---- The ONE exchange of the path: the gather of the ranks' output shards, on RCCL over xGMI. -------------------------------
+ * The reference has no counterpart (it is single-threaded: the batch loop of ETS_fkine fknm.cpp:1038-1052, the Python row loops around
+ * ETS_jacob0 / frne / IK_LM_c); this is the multi-GPU half of the replacement boundary.  The data path has NO collective -- rows are
+ * independent, every rank evaluates rtbhip_shard_range(N, rank, world) and leaves its rows in HBM; a consumer that wants them in one place
+ * calls rtbhip_shard_gather once.  librccl.so is dlopen'ed on first use (RTBHIP_RCCL_LIB overrides the name); nothing here needs PyTorch.
+ *
+ * Communicators.  One process per GPU (the usual form): rank 0 calls rtbhip_shard_comm_id, ships the 128 bytes to the other ranks by any
+ * means, every rank then calls rtbhip_shard_comm_create on its current device.  One process driving several GPUs: rtbhip_shard_comm_create_all
+ * (ndev communicators, devices[i] or 0..ndev-1), and the per-device rtbhip_shard_gather calls of one exchange go between rtbhip_shard_group(1)
+ * and rtbhip_shard_group(0) (ncclGroupStart / ncclGroupEnd).  comm = NULL is allowed for world = 1 (no RCCL is loaded: a device copy). */
+typedef void *rtbhip_comm_t;
+int rtbhip_shard_comm_id(void *id128);
+int rtbhip_shard_comm_create(const void *id128, int32_t world, int32_t rank, rtbhip_comm_t *comm);
+int rtbhip_shard_comm_create_all(int32_t ndev, const int32_t *devices, rtbhip_comm_t *comms);
+int rtbhip_shard_comm_destroy(rtbhip_comm_t comm);
+/* world size and rank the communicator itself reports, and the RCCL version (any out pointer may be NULL; comm may be NULL for the version) */
+int rtbhip_shard_comm_info(rtbhip_comm_t comm, int32_t *world, int32_t *rank, int32_t *rccl_version);
+int rtbhip_shard_group(int32_t begin);
+/* Gather: this rank holds `rows` = its rtbhip_shard_range count of the N global rows, each row_bytes long (56 for tau of the Panda, 464 for
+ * a T||J row of rtbhip_fkine_jacob_packed, ...), in DEVICE memory at `local`.  root >= 0: rank `root` receives all N rows in `out` (global
+ * row order; `out` may be NULL elsewhere) -- each shard crosses one xGMI link once.  root = -1: every rank receives them (all-gather: world
+ * times the traffic and receive memory).  Equal shards are one ncclGather / ncclAllGather; ragged ones one group of ncclSend / ncclRecv
+ * straight into place (no padding).  Enqueued on `stream` (a stream of the communicator's device); returns without waiting. */
+int rtbhip_shard_gather(rtbhip_comm_t comm, const void *local, int64_t rows, int64_t row_bytes, int64_t N, int32_t world, int32_t rank,
+                        int32_t root, void *out, void *stream);
+
+/* Device memory, copies and streams for a host WITHOUT a HIP binding of its own (C, Go over cgo, Java over JNI ...): enough to keep inputs and
+ * results resident (RTBHIP_MEM_DEVICE) and to drive one stream per GPU.  A consumer that already holds device pointers never needs them.
+ * rtbhip_device_copy kind: 1 host -> device, 2 device -> host, 3 device -> device; stream = NULL waits for the copy, else it is enqueued. */
+int rtbhip_device_alloc(int32_t device, uint64_t bytes, void **ptr);
+int rtbhip_device_free(void *ptr);
+int rtbhip_device_copy(void *dst, const void *src, uint64_t bytes, int32_t kind, void *stream);
+int rtbhip_stream_create(int32_t device, void **stream);
+int rtbhip_stream_destroy(void *stream);
+int rtbhip_stream_sync(void *stream);
+
+/* Which physical GPU is HIP device `device` of this process: its PCI bus id ("0000:05:00.0", a 32-byte buffer) and 16-byte UUID (either may be
+ * NULL).  A multi-rank run prints these per rank, so that "did every rank get its own GPU?" is answered by the output itself. */
+int rtbhip_device_identity(int32_t device, char *pci_bus_id32, unsigned char *uuid16);
+
 /* Launch-geometry report for the last kernel a call on this thread enqueued (diagnostics). */
 int rtbhip_last_launch(int32_t *grid, int32_t *block, int32_t *lds_bytes);
 
@@ -352,7 +405,7 @@ int rtbhip_last_launch(int32_t *grid, int32_t *block, int32_t *lds_bytes);
  *         "partial3" 1 | 0 (order-3 partial_fkine0 on workgroups that own whole configurations / on the general kernel),
  *         "partial3_fused" 1 | 0 (that kernel forms the Hessians from the Jacobians it stages / reads a Hessian tensor written by a launch of its own),
  *         "rne_persist", "rne_wpb", "ik_unit_we" (A/B forms that measured slower and are off),
- *         "host_chunk_kb" (host-pointer pipeline). */
+ *         "host_chunk_kb" (host-pointer pipeline), "shard_p2p" 1 | 0 (rtbhip_shard_gather: the grouped send / receive form for equal shards too). */
 /* Measurement aid, no reference counterpart: one launch of a plain streaming kernel that reads `read_doubles` doubles from `src` and writes
  * `write_doubles` doubles to `dst` (device pointers, 4 KiB-aligned; whole 4 KiB pages are moved, the tails are left alone) -- the memory rate this GPU delivers for a given read / write mix, which
  * bench.py reports next to the headline kernel's rate. */

@@ -334,6 +334,43 @@ static int kin_entry(const char *fn, rtbhip_chain_t h, const double *q, int64_t 
     });
 }
 
+// rtbhip_fkine_jacob_packed: as kin_entry for (T, J), but one (N, 16 + 6n) output array
+static int kin_packed_entry(rtbhip_chain_t h, const double *q, int64_t N, const double *base16, const double *tool16, int frame, double *TJ,
+                            int mem, void *stream)
+{
+    const char *fn = "fkine_jacob_packed";
+    const std::shared_ptr<Chain> c_owner = chain_from_handle(h);
+    Chain *c = c_owner.get();
+    RTB_TRACE("rtbhip_fkine_jacob_packed");
+    if (!c) { set_error(std::string(fn) + ": unknown chain handle"); return RTBHIP_EINVAL; }
+    DeviceScope dscope;
+    RTB_TRY(check_batch(fn, q, N, mem, &dscope));
+    if (frame != 0 && frame != 1) { set_error(std::string(fn) + ": frame must be 0 (jacob0) or 1 (jacobe)"); return RTBHIP_EINVAL; }
+    if (N > 0 && !TJ) { set_error(std::string(fn) + ": no output buffer"); return RTBHIP_EINVAL; }
+    if (N == 0) return RTBHIP_OK;
+    DevChain ops;
+    RTB_TRY(chain_device_ops(c, &ops, nullptr));
+    Affine base = affine_from16(base16), tool = affine_from16(tool16);
+    const size_t n = (size_t)c->n, qw = (size_t)c->q_width;
+    if (c->n == 0) {                  // a chain of constants: the row is the pose alone, (N, 16) -- the plain fkine kernel writes exactly that
+        if (mem == RTBHIP_MEM_DEVICE) return launch_kin(c, ops, q, N, base, tool, frame, TJ, nullptr, nullptr, (hipStream_t)stream);
+        HostIO io0;
+        io0.add_in(q, qw * 8);
+        io0.add_out(TJ, 128);
+        return host_pipeline(io0, N, [&](const void *const *din, void *const *dout, int64_t, int64_t rows, hipStream_t s) {
+            return launch_kin(c, ops, (const double *)din[0], rows, base, tool, frame, (double *)dout[0], nullptr, nullptr, s);
+        });
+    }
+    if (mem == RTBHIP_MEM_DEVICE)
+        return launch_kin_packed(c, ops, q, N, base, tool, frame, TJ, (hipStream_t)stream);
+    HostIO io;
+    io.add_in(q, qw * 8);
+    io.add_out(TJ, 128 + 48 * n);
+    return host_pipeline(io, N, [&](const void *const *din, void *const *dout, int64_t, int64_t rows, hipStream_t s) {
+        return launch_kin_packed(c, ops, (const double *)din[0], rows, base, tool, frame, (double *)dout[0], s);
+    });
+}
+
 void kin_tune(const char *key, int value);
 void rne_tune(const char *key, int value);
 void ik_tune(const char *key, int value);
@@ -341,6 +378,7 @@ void partial_tune(const char *key, int value);
 void ik_release_device_state();
 int ik_prepare_device();
 void hostpipe_tune(const char *key, int value);
+void shard_tune(const char *key, int value);
 
 }  // namespace rtbhip
 
@@ -536,6 +574,12 @@ int rtbhip_fkine_jacob(rtbhip_chain_t chain, const double *q, int64_t N, const d
 {
     if (N > 0 && (!T || !J)) { set_error("fkine_jacob: NULL T or J"); return RTBHIP_EINVAL; }
     return kin_entry("fkine_jacob", chain, q, N, base16, tool16, frame, T, J, nullptr, mem, stream);
+}
+
+int rtbhip_fkine_jacob_packed(rtbhip_chain_t chain, const double *q, int64_t N, const double *base16,
+                              const double *tool16, int32_t frame, double *TJ, int32_t mem, void *stream)
+{
+    return kin_packed_entry(chain, q, N, base16, tool16, frame, TJ, mem, stream);
 }
 
 int rtbhip_hessian(rtbhip_chain_t chain, const double *q, int64_t N, const double *tool16,
@@ -1152,12 +1196,13 @@ int rtbhip_tree_accel(rtbhip_tree_t tree, const double *q, const double *qd, con
     return tree_dyn_entry("tree_accel", tree, 2, q, qd, torque, N, gravity3, qdd, mem, stream);
 }
 
-int rtbhip_fleet_fkine_jacob(const rtbhip_chain_t *chains, int32_t n_chains, const double *const *q,
-                             const int64_t *N, int32_t frame, double *const *T, double *const *J,
-                             int32_t mem, void *stream)
+static int fleet_entry(const rtbhip_chain_t *chains, int32_t n_chains, const double *const *q,
+                       const int64_t *N, int32_t frame, double *const *T, double *const *J,
+                       int32_t mem, void *stream, bool packed)
 {
-    if (n_chains < 0 || (n_chains > 0 && (!chains || !q || !N || !T || !J))) { set_error("fleet: bad argument"); return RTBHIP_EINVAL; }
-    RTB_TRACE("rtbhip_fleet_fkine_jacob");
+    // packed: T[c] is the (N[c], 16 + 6 n_c) array of [T | J] rows, J is not used
+    if (n_chains < 0 || (n_chains > 0 && (!chains || !q || !N || !T || (!packed && !J)))) { set_error("fleet: bad argument"); return RTBHIP_EINVAL; }
+    RTB_TRACE(packed ? "rtbhip_fleet_fkine_jacob_packed" : "rtbhip_fleet_fkine_jacob");
     if (frame != 0 && frame != 1) { set_error("fleet: frame must be 0 or 1"); return RTBHIP_EINVAL; }
     if (mem != RTBHIP_MEM_HOST && mem != RTBHIP_MEM_DEVICE) { set_error("fleet: bad mem kind"); return RTBHIP_EINVAL; }
     std::vector<FleetEntry> entries;
@@ -1174,36 +1219,49 @@ int rtbhip_fleet_fkine_jacob(const rtbhip_chain_t *chains, int32_t n_chains, con
         if (!c) { set_error("fleet: unknown chain handle"); return RTBHIP_EINVAL; }
         if (N[i] < 0) { set_error("fleet: negative N"); return RTBHIP_EINVAL; }
         if (N[i] == 0) continue;
-        if (!q[i] || !T[i] || !J[i]) { set_error("fleet: NULL buffer"); return RTBHIP_EINVAL; }
+        if (!q[i] || !T[i] || (!packed && !J[i])) { set_error("fleet: NULL buffer"); return RTBHIP_EINVAL; }
         FleetEntry e;
         RTB_TRY(chain_device_ops(c, &e.dc, nullptr));
         e.n = c->n; e.q_width = c->q_width; e.N = N[i]; e.tile0 = tile0;
         e.stride = 0; e.pad = 0;
         if (mem == RTBHIP_MEM_DEVICE) {
-            e.q = q[i]; e.T = T[i]; e.J = J[i];
+            e.q = q[i]; e.T = T[i]; e.J = packed ? nullptr : J[i];
         } else {
             void *dq;
             RTB_TRY(st.in(q[i], (size_t)N[i] * c->q_width * 8, &dq));
-            RTB_TRY(st.out((size_t)N[i] * 128, &dT[i]));
-            RTB_TRY(st.out((size_t)N[i] * 48 * c->n, &dJ[i]));
+            RTB_TRY(st.out((size_t)N[i] * (packed ? 128 + 48 * c->n : 128), &dT[i]));
+            if (!packed) RTB_TRY(st.out((size_t)N[i] * 48 * c->n, &dJ[i]));
             e.q = (const double *)dq; e.T = (double *)dT[i]; e.J = (double *)dJ[i];
         }
         tile0 += (N[i] + 63) / 64;
         entries.push_back(e);
     }
     if (entries.empty()) return RTBHIP_OK;
-    RTB_TRY(launch_fleet(entries, frame, mem == RTBHIP_MEM_DEVICE ? (hipStream_t)stream : nullptr));
+    RTB_TRY(launch_fleet(entries, frame, mem == RTBHIP_MEM_DEVICE ? (hipStream_t)stream : nullptr, packed));
     if (mem == RTBHIP_MEM_HOST) {
         RTB_HIP(hipDeviceSynchronize());
         for (int i = 0; i < n_chains; i++) {
             if (N[i] == 0) continue;
             const std::shared_ptr<Chain> c_owner = chain_from_handle(chains[i]);
             Chain *c = c_owner.get();
-            RTB_TRY(fetch(T[i], dT[i], (size_t)N[i] * 128));
-            RTB_TRY(fetch(J[i], dJ[i], (size_t)N[i] * 48 * c->n));
+            RTB_TRY(fetch(T[i], dT[i], (size_t)N[i] * (packed ? 128 + 48 * c->n : 128)));
+            if (!packed) RTB_TRY(fetch(J[i], dJ[i], (size_t)N[i] * 48 * c->n));
         }
     }
     return RTBHIP_OK;
+}
+
+int rtbhip_fleet_fkine_jacob(const rtbhip_chain_t *chains, int32_t n_chains, const double *const *q,
+                             const int64_t *N, int32_t frame, double *const *T, double *const *J,
+                             int32_t mem, void *stream)
+{
+    return fleet_entry(chains, n_chains, q, N, frame, T, J, mem, stream, false);
+}
+
+int rtbhip_fleet_fkine_jacob_packed(const rtbhip_chain_t *chains, int32_t n_chains, const double *const *q,
+                                    const int64_t *N, int32_t frame, double *const *TJ, int32_t mem, void *stream)
+{
+    return fleet_entry(chains, n_chains, q, N, frame, TJ, nullptr, mem, stream, true);
 }
 
 int rtbhip_host_alloc(uint64_t bytes, void **ptr)
@@ -1248,6 +1306,7 @@ int rtbhip_tune(const char *key, int32_t value)
     partial_tune(key, value);
     if (std::string(key) == "rne_pszero") g_rne_pszero = value != 0;
     hostpipe_tune(key, value);
+    shard_tune(key, value);
     return RTBHIP_OK;
 }
 

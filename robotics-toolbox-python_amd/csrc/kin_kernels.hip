@@ -34,6 +34,7 @@ namespace rtbhip {
 #endif
 constexpr long long kPoseCacheBytes = RTB_T_PLAIN_MAX_BYTES;
 constexpr int kKinPosePlain = 1;      // KinParams.pad bit 0
+constexpr int kKinPacked = 2;         // KinParams.pad bit 1: T is the packed (N, 16 + 6n) array [T | J], J is not written separately (run-time-n tile)
 
 // The chain tables through the constant address space: uniform loads become s_load (SGPR operands).
 #define RTB_CONST __attribute__((address_space(4)))
@@ -73,6 +74,15 @@ __global__ __launch_bounds__(kWave) void k_kin(KinParams kp, DevChain dc,
         Pose P;
         kin_walk<(WANT_J || WANT_H)>(kp, ops, lane, qs, rows, P);
         if (WANT_H) kin_hessian(kp, lane, rows, live, H + cfg * (int64_t)(kp.n * W));
+        if (WANT_T && WANT_J && !WANT_H && COALESCED && (kp.pad & kKinPacked)) {      // wave-uniform: one contiguous run of [T | J] rows
+            double *rowsT = qs + kWave * kp.qw;
+            if (kp.has_base) pose_premul(P, kp.base);
+            pose_store16(P, [&](int k, double v) { rowsT[lane * 17 + k] = v; });
+            __syncthreads();
+            kin_flush_packed(rowsT, rows, kp.stride, W, ncfg, T + cfg0 * (16 + W), lane);
+            __syncthreads();
+            continue;
+        }
         if (WANT_J) {
             if (COALESCED) {
                 __syncthreads();
@@ -101,7 +111,7 @@ __global__ __launch_bounds__(kWave) void k_kin(KinParams kp, DevChain dc,
 #define RTB_REG_WAVES 3   // waves per SIMD the register allocator must leave room for (<= 168 VGPRs)
 #endif
 // One register-resident tile (64 configurations) of a chain with NJ joints; shared by k_kin_reg and k_fleet.
-template <int NJ, bool WANT_T, bool WANT_J>
+template <int NJ, bool WANT_T, bool WANT_J, bool PACKED = false>
 __device__ __forceinline__ void reg_tile(const KinParams &kp, const ConstChain &cv, const double *__restrict__ q,
                                          double *__restrict__ T, double *__restrict__ J, double *buf, int lane,
                                          int64_t tile)
@@ -113,6 +123,21 @@ __device__ __forceinline__ void reg_tile(const KinParams &kp, const ConstChain &
     Pose P;
     double jac[6 * NJ];
     reg_compute<NJ, WANT_J>(kp, cv, q, cfg0 + lane, P, jac);
+    if constexpr (PACKED) {
+        // T is the packed (N, 16 + W) array: rounds of kPRound lanes stage [T | J] and the wave writes the round's rows as one contiguous run
+        static_assert(!PACKED || (WANT_T && WANT_J), "packed rows carry both");
+        double *bufT = buf, *bufJ = buf + kPRound * 17;
+#pragma unroll
+        for (int r = 0; r < kWave / kPRound; ++r) {
+            if (lane / kPRound == r) reg_stage_packed<NJ>(kp, P, jac, bufT, bufJ, lane % kPRound);
+            __syncthreads();
+            int rows = ncfg - r * kPRound;
+            rows = rows < 0 ? 0 : (rows > kPRound ? kPRound : rows);
+            kin_flush_packed(bufT, bufJ, W + 1, W, rows, T + (cfg0 + r * kPRound) * (16 + W), lane);
+            __syncthreads();
+        }
+        return;
+    }
 #if RTB_T_FIRST
     if (WANT_T) {
         reg_stage_T(kp, P, buf, lane);
@@ -146,12 +171,12 @@ __device__ __forceinline__ void reg_tile(const KinParams &kp, const ConstChain &
 // ONE tile per single-wave workgroup, no grid-stride loop: with a loop LICM hoists every segment's
 // (loop-invariant) scalar loads into the preheader, where they overflow the SGPR file and come back
 // as v_readlane pairs on each use.  The dispatcher balances the tiles instead.
-template <int NJ, bool WANT_T, bool WANT_J>
+template <int NJ, bool WANT_T, bool WANT_J, bool PACKED = false>
 __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints ? RTB_REG_WAVES : 2)) void k_kin_reg(KinParams kp, DevChain dc, const double *__restrict__ q,
                                                   double *__restrict__ T, double *__restrict__ J)
 {
     extern __shared__ __attribute__((aligned(16))) double buf[];
-    reg_tile<NJ, WANT_T, WANT_J>(kp, const_view(dc), q, T, J, buf, threadIdx.x, xcd_tile());
+    reg_tile<NJ, WANT_T, WANT_J, PACKED>(kp, const_view(dc), q, T, J, buf, threadIdx.x, xcd_tile());
 }
 
 static int g_hess_mode = 0;   // A/B knob (rtbhip_tune "hess_mode")
@@ -565,6 +590,53 @@ static hipError_t launch_reg(dim3 grid, size_t lds, hipStream_t s, const KinPara
     return hipGetLastError();
 }
 
+template <int NJ>
+static hipError_t launch_reg_packed(dim3 grid, size_t lds, hipStream_t s, const KinParams &kp, const DevChain &dc, const double *q, double *TJ)
+{
+    hipLaunchKernelGGL((k_kin_reg<NJ, true, true, true>), grid, dim3(kWave), lds, s, kp, dc, q, TJ, (double *)nullptr);
+    return hipGetLastError();
+}
+
+// rtbhip_fkine_jacob_packed: rows [T (16, base applied) | J (6n)] of ONE (N, 16 + 6n) array -- a single write stream (SURVEY 8e's T||J message)
+int launch_kin_packed(const Chain *c, const DevChain &ops, const double *q, int64_t N, const Affine &base,
+                      const Affine &tool, int frame, double *TJ, hipStream_t s)
+{
+    if (N == 0) return RTBHIP_OK;
+    KinParams kp;
+    kp.n = c->n; kp.qw = c->q_width; kp.stride = kin_stride(c->n); kp.frame = frame; kp.has_base = base.used;
+    kp.pad = kKinPacked; kp.N = N;
+    for (int i = 0; i < 12; i++) kp.base[i] = base.v[i];
+    chain_tail(c, tool, kp.tail);
+    const int64_t tiles = (N + kWave - 1) / kWave;
+    if (tiles > 0x7fffffff) { set_error("fkine_jacob_packed: batch too large for one launch"); return RTBHIP_ELIMIT; }
+    dim3 grid((unsigned)tiles);
+    if (g_use_reg && c->n >= 1 && c->n <= kKinRegMax) {
+        const size_t rl = (size_t)reg_lds_doubles_packed(c->n) * sizeof(double);
+        hipError_t e = hipSuccess;
+        switch (c->n) {
+        case 1: e = launch_reg_packed<1>(grid, rl, s, kp, ops, q, TJ); break;
+        case 2: e = launch_reg_packed<2>(grid, rl, s, kp, ops, q, TJ); break;
+        case 3: e = launch_reg_packed<3>(grid, rl, s, kp, ops, q, TJ); break;
+        case 4: e = launch_reg_packed<4>(grid, rl, s, kp, ops, q, TJ); break;
+        case 5: e = launch_reg_packed<5>(grid, rl, s, kp, ops, q, TJ); break;
+        case 6: e = launch_reg_packed<6>(grid, rl, s, kp, ops, q, TJ); break;
+        case 7: e = launch_reg_packed<7>(grid, rl, s, kp, ops, q, TJ); break;
+        case 8: e = launch_reg_packed<8>(grid, rl, s, kp, ops, q, TJ); break;
+        case 9: e = launch_reg_packed<9>(grid, rl, s, kp, ops, q, TJ); break;
+        default: e = launch_reg_packed<10>(grid, rl, s, kp, ops, q, TJ); break;
+        }
+        note_launch((int)grid.x, kWave, (int)rl);
+        if (e != hipSuccess) return hip_fail(e, "k_kin_reg (packed) launch");
+        return RTBHIP_OK;
+    }
+    const size_t lds = kin_lds_bytes(c->n, c->q_width) + (size_t)kWave * 17 * sizeof(double);
+    if (lds > 160 * 1024) { set_error("chain too large for the per-wave LDS staging"); return RTBHIP_ELIMIT; }
+    hipError_t e = launch_variant<true, true, false>(true, grid, lds, s, kp, ops, q, TJ, TJ, nullptr);
+    note_launch((int)grid.x, kWave, (int)lds);
+    if (e != hipSuccess) return hip_fail(e, "k_kin (packed) launch");
+    return RTBHIP_OK;
+}
+
 int launch_kin(const Chain *c, const DevChain &ops, const double *q, int64_t N, const Affine &base,
                const Affine &tool, int frame, double *T, double *J, double *H, hipStream_t s)
 {
@@ -654,7 +726,7 @@ struct FleetArgs {
 // dynamic LDS are per-kernel / per-launch quantities: CLS 0 chains of 1..8 joints (register-resident tile, 3
 // waves per SIMD), CLS 1 chains of 9..10 joints (register-resident, 2 waves per SIMD), CLS 2 longer chains
 // (LDS tile).  Inside a class the joint count of a tile is wave-uniform: a switch picks the tile body.
-template <int CLS>
+template <int CLS, bool PACKED = false>
 __global__ __launch_bounds__(kWave, (CLS == 0 ? RTB_REG_WAVES : 2)) void k_fleet(FleetArgs fa)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -666,25 +738,25 @@ __global__ __launch_bounds__(kWave, (CLS == 0 ? RTB_REG_WAVES : 2)) void k_fleet
     const FleetEntry &fe = fa.e[ci];
     KinParams kp;
     kp.n = fe.n; kp.qw = fe.q_width; kp.stride = fe.stride;
-    kp.frame = fa.frame; kp.has_base = 0; kp.pad = 0; kp.N = fe.N;
+    kp.frame = fa.frame; kp.has_base = 0; kp.pad = PACKED ? kKinPacked : 0; kp.N = fe.N;
     const ConstChain ops = const_view(fe.dc);
     for (int k = 0; k < 9; ++k) kp.tail[k] = ops.seg[fe.n].r[k];
     for (int k = 0; k < 3; ++k) kp.tail[9 + k] = ops.seg[fe.n].t[k];
     const int64_t tile = gt - fe.tile0;
     if (CLS == 0) {
         switch (fe.n) {
-        case 1: reg_tile<1, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
-        case 2: reg_tile<2, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
-        case 3: reg_tile<3, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
-        case 4: reg_tile<4, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
-        case 5: reg_tile<5, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
-        case 6: reg_tile<6, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
-        case 7: reg_tile<7, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
-        default: reg_tile<8, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
+        case 1: reg_tile<1, true, true, PACKED>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
+        case 2: reg_tile<2, true, true, PACKED>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
+        case 3: reg_tile<3, true, true, PACKED>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
+        case 4: reg_tile<4, true, true, PACKED>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
+        case 5: reg_tile<5, true, true, PACKED>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
+        case 6: reg_tile<6, true, true, PACKED>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
+        case 7: reg_tile<7, true, true, PACKED>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
+        default: reg_tile<8, true, true, PACKED>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
         }
     } else if (CLS == 1) {
-        if (fe.n == 9) reg_tile<9, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile);
-        else reg_tile<10, true, true>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile);
+        if (fe.n == 9) reg_tile<9, true, true, PACKED>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile);
+        else reg_tile<10, true, true, PACKED>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile);
         return;
     }
     double *rows = lds;
@@ -696,6 +768,13 @@ __global__ __launch_bounds__(kWave, (CLS == 0 ? RTB_REG_WAVES : 2)) void k_fleet
     kin_load_q(kp, fe.q, cfg, lane, qs);
     Pose P;
     kin_walk<true>(kp, ops, lane, qs, rows, P);
+    if (PACKED) {
+        double *rowsT = qs + kWave * kp.qw;
+        pose_store16(P, [&](int k, double v) { rowsT[lane * 17 + k] = v; });
+        __syncthreads();
+        kin_flush_packed(rowsT, rows, kp.stride, W, ncfg, fe.T + cfg0 * (16 + W), lane);
+        return;
+    }
     __syncthreads();
     kin_flush(rows, kp.stride, W, ncfg, fe.J + cfg0 * W, lane);
     __syncthreads();
@@ -708,17 +787,30 @@ __global__ __launch_bounds__(kWave, (CLS == 0 ? RTB_REG_WAVES : 2)) void k_fleet
 // three launches, one per class -- a single launch capped every workgroup at 4 per CU (2.32 vs 1.57 ms for the
 // 16-arm fleet of BASELINE config 5).
 static int fleet_class_of(int n) { return n <= kRegMaxJoints ? 0 : (n <= kKinRegMax ? 1 : 2); }
-static int launch_fleet_class(int cls, const std::vector<FleetEntry> &entries, int frame, hipStream_t s);
-int launch_fleet(const std::vector<FleetEntry> &all, int frame, hipStream_t s)
+static int launch_fleet_class(int cls, const std::vector<FleetEntry> &entries, int frame, hipStream_t s, bool packed);
+int launch_fleet(const std::vector<FleetEntry> &all, int frame, hipStream_t s, bool packed)
 {
     std::vector<FleetEntry> by[3];
     for (const FleetEntry &e : all) by[fleet_class_of(e.n)].push_back(e);
     for (int c = 0; c < 3; ++c)
-        if (!by[c].empty()) { int rc = launch_fleet_class(c, by[c], frame, s); if (rc != RTBHIP_OK) return rc; }
+        if (!by[c].empty()) { int rc = launch_fleet_class(c, by[c], frame, s, packed); if (rc != RTBHIP_OK) return rc; }
     return RTBHIP_OK;
 }
 
-static int launch_fleet_class(int cls, const std::vector<FleetEntry> &entries, int frame, hipStream_t s)
+template <bool PACKED>
+static void fleet_go(int cls, unsigned g, size_t lds, hipStream_t s, const FleetArgs &fa)
+{
+    if (cls == 0) hipLaunchKernelGGL((k_fleet<0, PACKED>), dim3(g), dim3(kWave), lds, s, fa);
+    else if (cls == 1) hipLaunchKernelGGL((k_fleet<1, PACKED>), dim3(g), dim3(kWave), lds, s, fa);
+    else hipLaunchKernelGGL((k_fleet<2, PACKED>), dim3(g), dim3(kWave), lds, s, fa);
+}
+template <bool PACKED>
+static const void *fleet_fn(int cls)
+{
+    return cls == 0 ? (const void *)k_fleet<0, PACKED> : (cls == 1 ? (const void *)k_fleet<1, PACKED> : (const void *)k_fleet<2, PACKED>);
+}
+
+static int launch_fleet_class(int cls, const std::vector<FleetEntry> &entries, int frame, hipStream_t s, bool packed)
 {
     for (size_t first = 0; first < entries.size(); first += kFleetMax) {
         FleetArgs fa;
@@ -732,12 +824,12 @@ static int launch_fleet_class(int cls, const std::vector<FleetEntry> &entries, i
             fa.e[i].stride = kin_stride(fa.e[i].n);
             fa.e[i].tile0 = tiles;
             tiles += (fa.e[i].N + kWave - 1) / kWave;
-            lds = std::max(lds, cls < 2 ? (size_t)reg_lds_doubles(fa.e[i].n) * sizeof(double)
-                                        : kin_lds_bytes(fa.e[i].n, fa.e[i].q_width));
+            lds = std::max(lds, cls < 2 ? (size_t)(packed ? reg_lds_doubles_packed(fa.e[i].n) : reg_lds_doubles(fa.e[i].n)) * sizeof(double)
+                                        : kin_lds_bytes(fa.e[i].n, fa.e[i].q_width) + (packed ? (size_t)kWave * 17 * sizeof(double) : 0));
         }
         fa.tiles = tiles;
         if (lds > 160 * 1024) { set_error("fleet: chain too large for LDS staging"); return RTBHIP_ELIMIT; }
-        const void *kfn = cls == 0 ? (const void *)k_fleet<0> : (cls == 1 ? (const void *)k_fleet<1> : (const void *)k_fleet<2>);
+        const void *kfn = packed ? fleet_fn<true>(cls) : fleet_fn<false>(cls);
         if (lds > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return hip_fail(e, "k_fleet attr");
@@ -745,9 +837,7 @@ static int launch_fleet_class(int cls, const std::vector<FleetEntry> &entries, i
         for (int64_t t0 = 0; t0 < tiles; t0 += 0x7fffffff) {
             const int64_t g = std::min<int64_t>(0x7fffffff, tiles - t0);
             fa.tile_base = t0;
-            if (cls == 0) hipLaunchKernelGGL(k_fleet<0>, dim3((unsigned)g), dim3(kWave), lds, s, fa);
-            else if (cls == 1) hipLaunchKernelGGL(k_fleet<1>, dim3((unsigned)g), dim3(kWave), lds, s, fa);
-            else hipLaunchKernelGGL(k_fleet<2>, dim3((unsigned)g), dim3(kWave), lds, s, fa);
+            if (packed) fleet_go<true>(cls, (unsigned)g, lds, s, fa); else fleet_go<false>(cls, (unsigned)g, lds, s, fa);
             note_launch((int)g, kWave, (int)lds);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return hip_fail(e, "k_fleet launch");

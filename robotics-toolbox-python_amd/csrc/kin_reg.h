@@ -33,6 +33,13 @@ RTB_HD int reg_lds_doubles(int n)
     return a > b ? a : b;
 }
 
+// packed (T | J) rows: lanes staged per round -- each round holds kPRound x (17 + 6n + 1) doubles of LDS (n = 7, 16 lanes: 7.7 KB per wave)
+#ifndef RTB_PROUND
+#define RTB_PROUND 16
+#endif
+constexpr int kPRound = RTB_PROUND;
+RTB_HD int reg_lds_doubles_packed(int n) { return kPRound * (17 + 6 * n + 1); }
+
 // Per-lane core: joint values qv[] (chain order, as the caller holds them) -> P = C_0 Z_0 ... tail and
 // the finished Jacobian in registers.  jac slot r*NJ + j : rows 0..2 = p_j, rows 3..5 = z_j until
 // the closing loop finishes them.  Used by the tile kernel (reg_compute) and by the IK loop.
@@ -155,6 +162,18 @@ RTB_HD void reg_stage_J(const double (&jac)[6 * NJ], double *buf, int slot_lane)
     double *mine = buf + slot_lane * (6 * NJ + 1);
 #pragma unroll
     for (int k = 0; k < 6 * NJ; ++k) mine[k] = jac[k];
+}
+
+// packed rows: the lane's 4x4 (base applied) into the T area, its J into the J area of the same round (kin_flush_packed)
+template <int NJ>
+RTB_HD void reg_stage_packed(const KinParams &kp, Pose P, const double (&jac)[6 * NJ], double *bufT, double *bufJ, int slot_lane)
+{
+    if (kp.has_base) pose_premul(P, kp.base);
+    double *mt = bufT + slot_lane * 17;
+    pose_store16(P, [&](int k, double v) { mt[k] = v; });
+    double *mj = bufJ + slot_lane * (6 * NJ + 1);
+#pragma unroll
+    for (int k = 0; k < 6 * NJ; ++k) mj[k] = jac[k];
 }
 
 RTB_HD void reg_stage_T(const KinParams &kp, Pose P, double *buf, int lane)

@@ -114,6 +114,39 @@ RTB_HD void kin_flush(const double *rows, int stride, int W, int ncfg, double *_
     }
 }
 
+// PACKED output (SURVEY 8e's gather message: one (N, 16 + 6n) array, row = [T row-major 4x4 | J (6,n) C-order]): the wave writes `ncfg` staged
+// rows of 16 + W doubles as ONE contiguous run -- a single write stream per launch, where the two-array form has two.  T and J are staged in
+// separate LDS areas (rowsT: 17-double rows; rowsJ: `strideJ`-double rows); 16 and W are even, so a 16-byte piece never straddles the two.
+template <bool NT = true>
+RTB_HD void kin_flush_packed(const double *rowsT, const double *rowsJ, int strideJ, int W, int ncfg, double *__restrict__ dst, int lane)
+{
+    const int PW = 16 + W;
+    const int total = ncfg * PW;
+    int f = 2 * lane;
+    int cfg = f / PW, e = f - cfg * PW;
+    const int da = 128 / PW, db = 128 - da * PW;
+    for (; f < total; f += 128) {
+        const double *src = e < 16 ? rowsT + cfg * 17 + e : rowsJ + cfg * strideJ + (e - 16);
+        double2 v;
+        v.x = src[0];
+        v.y = src[1];
+#if RTB_NT_STORE && defined(__HIP_DEVICE_COMPILE__)
+        if (NT) {
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            v2d w = {v.x, v.y};
+            __builtin_nontemporal_store(w, reinterpret_cast<v2d *>(dst + f));
+        } else {
+            *reinterpret_cast<double2 *>(dst + f) = v;
+        }
+#else
+        *reinterpret_cast<double2 *>(dst + f) = v;
+#endif
+        e += db;
+        cfg += da;
+        if (e >= PW) { e -= PW; cfg += 1; }
+    }
+}
+
 #if defined(__HIPCC__)
 // contiguous run of ncfg rows of W doubles (row stride `stride` in LDS) -> global, 16 bytes per lane per
 // piece; W may be odd (a piece may then straddle two rows, and the run may end on a single double)

@@ -147,6 +147,9 @@ struct Affine { double v[12]; int used; };  // row-major 3x4, host-side small pa
 int launch_kin(const Chain *c, const DevChain &dc, const double *q, int64_t N, const Affine &base,
                const Affine &tool, int frame, double *T, double *J, double *H, hipStream_t s);
 
+int launch_kin_packed(const Chain *c, const DevChain &dc, const double *q, int64_t N, const Affine &base,
+                      const Affine &tool, int frame, double *TJ, hipStream_t s);
+
 int launch_kin_diff(const Chain *c, const DevChain &dc, int mode, int axes, const double *q, const double *qd, int64_t N,
                     const Affine &tool, int frame, double *out, hipStream_t s);
 
@@ -170,7 +173,7 @@ struct FleetEntry {   // device-visible descriptor of one chain of a fleet launc
     int64_t tile0;    // first global tile index of this chain
     int32_t n, q_width, stride, pad;
 };
-int launch_fleet(const std::vector<FleetEntry> &entries, int frame, hipStream_t s);
+int launch_fleet(const std::vector<FleetEntry> &entries, int frame, hipStream_t s, bool packed = false);   // packed: e.T is the (N, 16 + 6n) array, e.J unused
 
 int launch_rne(const Dyn *d, const DevLink *links, const double *q, const double *qd,
                const double *qdd, int64_t N, const double *grav3, const double *fext6, double *tau,

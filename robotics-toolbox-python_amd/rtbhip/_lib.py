@@ -57,6 +57,7 @@ SIGNATURES = {
     "rtbhip_fkine": (C.c_int, [_u64, _vp, _i64, _vp, _vp, _vp, _i32, _vp]),
     "rtbhip_jacob": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _vp, _i32, _vp]),
     "rtbhip_fkine_jacob": (C.c_int, [_u64, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
+    "rtbhip_fkine_jacob_packed": (C.c_int, [_u64, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _vp]),
     "rtbhip_hessian": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _vp, _i32, _vp]),
     "rtbhip_hessian_from_jacobian": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp]),
     "rtbhip_manipulability_from_jacobian": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp]),
@@ -93,9 +94,24 @@ SIGNATURES = {
     "rtbhip_accel": (C.c_int, [_u64, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp]),
     "rtbhip_fleet_fkine_jacob": (C.c_int, [C.POINTER(_u64), _i32, C.POINTER(_vp), C.POINTER(_i64), _i32,
                                            C.POINTER(_vp), C.POINTER(_vp), _i32, _vp]),
+    "rtbhip_fleet_fkine_jacob_packed": (C.c_int, [C.POINTER(_u64), _i32, C.POINTER(_vp), C.POINTER(_i64), _i32, C.POINTER(_vp), _i32, _vp]),
     "rtbhip_host_alloc": (C.c_int, [_u64, C.POINTER(_vp)]),
     "rtbhip_host_free": (C.c_int, [_vp]),
     "rtbhip_shard_range": (C.c_int, [_i64, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
+    "rtbhip_device_identity": (C.c_int, [_i32, _vp, _vp]),
+    "rtbhip_device_alloc": (C.c_int, [_i32, _u64, C.POINTER(_vp)]),
+    "rtbhip_device_free": (C.c_int, [_vp]),
+    "rtbhip_device_copy": (C.c_int, [_vp, _vp, _u64, _i32, _vp]),
+    "rtbhip_stream_create": (C.c_int, [_i32, C.POINTER(_vp)]),
+    "rtbhip_stream_destroy": (C.c_int, [_vp]),
+    "rtbhip_stream_sync": (C.c_int, [_vp]),
+    "rtbhip_shard_comm_id": (C.c_int, [_vp]),
+    "rtbhip_shard_comm_create": (C.c_int, [_vp, _i32, _i32, C.POINTER(_vp)]),
+    "rtbhip_shard_comm_create_all": (C.c_int, [_i32, _vp, C.POINTER(_vp)]),
+    "rtbhip_shard_comm_destroy": (C.c_int, [_vp]),
+    "rtbhip_shard_comm_info": (C.c_int, [_vp, _ip, _ip, _ip]),
+    "rtbhip_shard_group": (C.c_int, [_i32]),
+    "rtbhip_shard_gather": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
     "rtbhip_last_launch": (C.c_int, [_ip, _ip, _ip]),
     "rtbhip_tune": (C.c_int, [C.c_char_p, _i32]),
     "rtbhip_stream_probe": (C.c_int, [_vp, _i64, _vp, _i64, _vp]),
@@ -169,6 +185,16 @@ def last_launch():
     g, b, l = _i32(0), _i32(0), _i32(0)
     lib().rtbhip_last_launch(C.byref(g), C.byref(b), C.byref(l))
     return g.value, b.value, l.value
+
+
+def device_identity(device=None):
+    """{"device", "pci_bus_id", "uuid"} of HIP device `device` (default: torch's current one) -- rtbhip_device_identity."""
+    if device is None:
+        import torch
+        device = torch.cuda.current_device()
+    bus, uu = C.create_string_buffer(32), (C.c_ubyte * 16)()
+    check(lib().rtbhip_device_identity(int(device), bus, uu))
+    return {"device": int(device), "pci_bus_id": bus.value.decode(), "uuid": bytes(uu).hex()}
 
 
 def shard_range(N, rank, world):

@@ -762,11 +762,29 @@ class ETS:
         """End-effector-frame Jacobian (reference robot/ETS.py:1274-1330, core/fknm.cpp:852-921)."""
         return self._jac(q, tool, 1)
 
-    def fkine_jacob0(self, q, base=None, tool=None, frame=0):
+    def fkine_jacob0(self, q, base=None, tool=None, frame=0, packed=False, out=None):
         """Fused fkine + Jacobian in one chain walk (the headline op; no reference equivalent --
-        a reference user calls eval() then jacob0() per row)."""
+        a reference user calls eval() then jacob0() per row).
+        packed=True: ONE (N, 16 + 6n) array whose row i is [T[i] (16, row-major 4x4) | J[i] ((6,n) C-order)] -- the device writes a single
+        stream and the row is the T||J message of the multi-GPU gather (rtbhip_fkine_jacob_packed); the returned (T, J) are strided views
+        of it and `.packed` / the third item gives the array itself: `T, J, TJ = ets.fkine_jacob0(q, packed=True)`.  `out` = a TJ array of an
+        earlier call to write into."""
         q2, single, tm = self._shape_q(q)
         N = q2.shape[0]
+        if packed:
+            w = 16 + 6 * self.n
+            TJ = self._out((N, w), q2, tm) if out is None else out
+            if tuple(TJ.shape) != (N, w) or not (TJ.is_contiguous() if tm else TJ.flags.c_contiguous):
+                raise ValueError("out must be a contiguous (N, 16 + 6n) float64 array")
+            b, t = small(base, 16), small(tool, 16)
+            check(lib().rtbhip_fkine_jacob_packed(self._handle(), self._ptr(q2, tm), N, host_ptr(b), host_ptr(t), frame,
+                                                  self._ptr(TJ, tm), MEM_DEVICE if tm else MEM_HOST, self._stream(tm)))
+            if tm:
+                T, J = TJ[:, :16].unflatten(1, (4, 4)), TJ[:, 16:].unflatten(1, (6, self.n))       # strided views, no copy
+            else:
+                T = np.lib.stride_tricks.as_strided(TJ, (N, 4, 4), (8 * w, 32, 8))
+                J = np.lib.stride_tricks.as_strided(TJ[:, 16:], (N, 6, self.n), (8 * w, 8 * self.n, 8))
+            return (T[0], J[0], TJ[0]) if single else (T, J, TJ)
         T = self._out((N, 4, 4), q2, tm)
         J = self._out((N, 6, self.n), q2, tm)
         b, t = small(base, 16), small(tool, 16)

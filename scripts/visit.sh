@@ -1,0 +1,67 @@
+#!/bin/bash
+# scripts/visit.sh -- ONE parametrised GPU visit (replaces the ~150 one-off scripts/gpu_r*_*.sh of rounds 1-4).
+#   gpurun --timeout T -- 'VISIT=r5a STAGES="tests smoke bench prof pmc extra fuzz layout" bash scripts/visit.sh'
+# Stages (any subset, run in this order; results under gpurun_out/$VISIT):
+#   tests   the whole `pytest -m gpu` suite WITHOUT -x (TESTS="path::id ..." narrows it)       -> pytest_gpu.log
+#   smoke   __graft_entry__.smoke()
+#   bench   python bench.py $BENCH_ARGS (default --steps 50 --warmup 5)                         -> bench_n1.json
+#   prof    rocprofv3 --kernel-trace --stats of bench.py (and of the rne leg at 1e7)            -> prof/, prof_rne1e7/
+#   pmc     FETCH_SIZE / WRITE_SIZE passes (separate runs) of bench.py and of the rne leg       -> pmc_*/
+#   extra   python bench_extra.py $EXTRA_ARGS                                                   -> bench_extra.jsonl
+#   fuzz    scripts/gpu_fuzz_*.py (random robots through every kernel size against the oracle)  -> fuzz_*.jsonl
+#   layout  scripts/layout_probe.py --fleet (packed vs two-array outputs over fresh allocations; VARIANTS="a.so b.so" adds A/B libraries)
+#   ikab    scripts/ik_ab.py over VARIANTS (A/B libraries of the IK kernel, interleaved, sustained)
+#   cmd     eval "$CMD" (anything else; output -> cmd.log)
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
+O=$R/gpurun_out/${VISIT:-visit}
+mkdir -p $O
+cd $R
+has() { [[ " $STAGES " == *" $1 "* ]]; }
+if has tests; then
+  timeout ${TESTS_TIMEOUT:-1500} python -m pytest ${TESTS:-tests} -m gpu -q -rf --timeout 900 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+  grep -E "passed|failed|FAILED|ERROR|rc=" $O/pytest_gpu.log | tail -15
+fi
+if has smoke; then timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1; fi
+if has bench; then
+  timeout 600 python bench.py ${BENCH_ARGS:---steps 50 --warmup 5} > $O/bench_n1.json 2> $O/bench_n1.err; cut -c1-300 $O/bench_n1.json; tail -3 $O/bench_n1.err
+  python scripts/bench_digest.py $O/bench_n1.json
+fi
+if has layout; then
+  timeout 400 python scripts/layout_probe.py --fleet --tag product > $O/layout_probe.jsonl 2> $O/layout_probe.err; tail -2 $O/layout_probe.err
+  for v in $VARIANTS; do
+    RTBHIP_LIB=$R/robotics-toolbox-python_amd/lib/variants/$v timeout 300 python scripts/layout_probe.py --tag $v >> $O/layout_probe.jsonl 2>> $O/layout_probe.err
+  done
+  grep -v summary $O/layout_probe.jsonl | cut -c1-330
+fi
+if has prof; then
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python $R/bench.py --steps 40 --warmup 3 --no-cpu --no-secondary > $O/prof.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_rne1e7 -o rne -- python $R/bench_extra.py --what rne --no-cpu --steps 40 --n-rne 10000000 > $O/prof_rne1e7.log 2>&1
+  cd $R
+  find $O/prof $O/prof_rne1e7 -name "*kernel_stats*.csv" | while read f; do echo $f; cut -c1-170 "$f" | head -6; done
+fi
+if has pmc; then
+  cd /tmp
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o pmc -- python $R/bench.py --steps 5 --warmup 2 --no-cpu --no-secondary > $O/pmc_$c.log 2>&1 || echo "pmc $c failed"
+    timeout 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_rne_$c -o pmc -- python $R/bench_extra.py --what rne --no-cpu --steps 5 > $O/pmc_rne_$c.log 2>&1 || echo "pmc rne $c failed"
+  done
+  cd $R
+  python scripts/pmc_digest.py $O
+fi
+if has extra; then
+  timeout 900 python bench_extra.py $EXTRA_ARGS > $O/bench_extra.jsonl 2> $O/bench_extra.err; cut -c1-200 $O/bench_extra.jsonl; tail -2 $O/bench_extra.err
+fi
+if has ikab; then
+  timeout ${IKAB_TIMEOUT:-900} python scripts/ik_ab.py $IKAB_ARGS > $O/ik_ab.jsonl 2> $O/ik_ab.err; cut -c1-260 $O/ik_ab.jsonl | tail -60; tail -3 $O/ik_ab.err
+fi
+if has fuzz; then
+  for f in ${FUZZ:-dyn ik kin rne paths fleet}; do
+    timeout 900 python scripts/gpu_fuzz_$f.py > $O/fuzz_$f.jsonl 2> $O/fuzz_$f.err; echo "fuzz $f rc=$?" >> $O/fuzz_$f.jsonl; tail -2 $O/fuzz_$f.jsonl | cut -c1-300
+  done
+fi
+if has cmd; then eval "$CMD" > $O/cmd.log 2>&1; tail -${CMD_TAIL:-40} $O/cmd.log; fi
+find $O -name "*kernel_trace.csv" -size +8M -delete
+find $O -name "*counter_collection.csv" -size +8M -delete
+exit 0

@@ -114,6 +114,10 @@ class EmuBackend:
         rc = self._gate("rtbhip_fkine_jacob", (h, q, N, base, tool, frame, T, J, mem, stream))
         return self.emu.emu_kin(h, q, N, base, tool, frame, T, J, None, 1) if rc is None else rc
 
+    def rtbhip_fkine_jacob_packed(self, h, q, N, base, tool, frame, TJ, mem, stream):
+        rc = self._gate("rtbhip_fkine_jacob_packed", (h, q, N, base, tool, frame, TJ, mem, stream))
+        return self.emu.emu_kin_packed(h, q, N, base, tool, frame, TJ, 1) if rc is None else rc
+
     def rtbhip_hessian(self, h, q, N, tool, frame, H, mem, stream):
         rc = self._gate("rtbhip_hessian", (h, q, N, tool, frame, H, mem, stream))
         return self.emu.emu_kin(h, q, N, None, tool, frame, None, None, H, 1) if rc is None else rc
@@ -174,6 +178,16 @@ class EmuBackend:
             Ti = T[i] if T else None
             Ji = J[i] if J else None
             r = self.emu.emu_kin(chains[i], q[i], N[i], None, None, frame, Ti, Ji, None, 1)
+            if r:
+                return r
+        return 0
+
+    def rtbhip_fleet_fkine_jacob_packed(self, chains, nc, q, N, frame, TJ, mem, stream):
+        rc = self._gate("rtbhip_fleet_fkine_jacob_packed", (chains, nc, q, N, frame, TJ, mem, stream))
+        if rc is not None:
+            return rc
+        for i in range(_val(nc)):                              # k_fleet<CLS, true>: the register tile to 10 joints, the run-time-n tile beyond
+            r = self.emu.emu_kin_packed(chains[i], q[i], N[i], None, None, frame, TJ[i], 1)
             if r:
                 return r
         return 0

@@ -103,6 +103,79 @@ extern "C" int emu_kin_reg(rtbhip_chain_t h, const double *q, int64_t N, const d
     return 0;
 }
 
+// packed rows (rtbhip_fkine_jacob_packed): the register tile's rounds of kPRound lanes / the run-time-n tile's single run, as k_kin_reg<.., true>
+// and k_kin's packed branch execute them
+template <int NJ>
+static void emu_reg_packed_run(const KinParams &kp, const DevChain &cv, const double *q, int64_t N, double *TJ)
+{
+    std::vector<double> buf(reg_lds_doubles_packed(NJ), -777.0);
+    constexpr int W = 6 * NJ;
+    double *bufT = buf.data(), *bufJ = buf.data() + kPRound * 17;
+    const int64_t tiles = (N + kWave - 1) / kWave;
+    for (int64_t tile = 0; tile < tiles; ++tile) {
+        const int64_t cfg0 = tile * kWave;
+        const int ncfg = (int)std::min<int64_t>(kWave, N - cfg0);
+        Pose P[kWave];
+        double jac[kWave][6 * NJ];
+        for (int l = 0; l < kWave; ++l) reg_compute<NJ, true>(kp, cv, q, cfg0 + l, P[l], jac[l]);
+        for (int r = 0; r < kWave / kPRound; ++r) {
+            for (int l = 0; l < kWave; ++l)
+                if (l / kPRound == r) reg_stage_packed<NJ>(kp, P[l], jac[l], bufT, bufJ, l % kPRound);
+            int rows = std::max(0, std::min(kPRound, ncfg - r * kPRound));
+            for (int l = 0; l < kWave; ++l) kin_flush_packed(bufT, bufJ, W + 1, W, rows, TJ + (cfg0 + r * kPRound) * (16 + W), l);
+        }
+    }
+}
+
+extern "C" int emu_kin_packed(rtbhip_chain_t h, const double *q, int64_t N, const double *base16, const double *tool16,
+                              int frame, double *TJ, int reg)
+{
+    const std::shared_ptr<Chain> c_owner = chain_from_handle(h);
+    Chain *c = c_owner.get();
+    if (!c) return -1;
+    KinParams kp;
+    kp.n = c->n; kp.qw = c->q_width; kp.stride = kin_stride(c->n);
+    kp.frame = frame; kp.N = N; kp.pad = 2;
+    Affine b = aff16(base16), t = aff16(tool16);
+    kp.has_base = b.used;
+    for (int i = 0; i < 12; i++) kp.base[i] = b.v[i];
+    chain_tail(c, t, kp.tail);
+    const DevChain cv = chain_host_view(c);
+    if (c->n == 0) return emu_kin(h, q, N, base16, tool16, frame, TJ, nullptr, nullptr, 1);      // as kin_packed_entry (api.cpp)
+    if (reg && c->n <= kKinRegMax) {
+        switch (c->n) {
+        case 1: emu_reg_packed_run<1>(kp, cv, q, N, TJ); break;
+        case 2: emu_reg_packed_run<2>(kp, cv, q, N, TJ); break;
+        case 3: emu_reg_packed_run<3>(kp, cv, q, N, TJ); break;
+        case 4: emu_reg_packed_run<4>(kp, cv, q, N, TJ); break;
+        case 5: emu_reg_packed_run<5>(kp, cv, q, N, TJ); break;
+        case 6: emu_reg_packed_run<6>(kp, cv, q, N, TJ); break;
+        case 7: emu_reg_packed_run<7>(kp, cv, q, N, TJ); break;
+        case 8: emu_reg_packed_run<8>(kp, cv, q, N, TJ); break;
+        case 9: emu_reg_packed_run<9>(kp, cv, q, N, TJ); break;
+        default: emu_reg_packed_run<10>(kp, cv, q, N, TJ); break;
+        }
+        return 0;
+    }
+    std::vector<double> lds(kin_lds_bytes(kp.n, kp.qw) / sizeof(double) + kWave * 17, -777.0);
+    double *rows = lds.data(), *qs = lds.data() + kWave * kp.stride, *rowsT = qs + kWave * kp.qw;
+    const int W = 6 * kp.n;
+    const int64_t tiles = (N + kWave - 1) / kWave;
+    for (int64_t tile = 0; tile < tiles; ++tile) {
+        const int64_t cfg0 = tile * kWave;
+        const int ncfg = (int)std::min<int64_t>(kWave, N - cfg0);
+        for (int l = 0; l < kWave; ++l) kin_load_q(kp, q, cfg0 + l, l, qs);
+        for (int l = 0; l < kWave; ++l) {
+            Pose P;
+            kin_walk<true>(kp, cv, l, qs, rows, P);
+            if (kp.has_base) pose_premul(P, kp.base);
+            pose_store16(P, [&](int k, double v) { rowsT[l * 17 + k] = v; });
+        }
+        for (int l = 0; l < kWave; ++l) kin_flush_packed(rowsT, rows, kp.stride, W, ncfg, TJ + cfg0 * (16 + W), l);
+    }
+    return 0;
+}
+
 template <int NJ>
 static void emu_hess_run(const KinParams &kp, const DevChain &cv, const double *q, int64_t N, double *H)
 {

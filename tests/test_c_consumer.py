@@ -53,3 +53,26 @@ def test_gpu_c_program_computes_what_the_oracle_computes():
     T, J = oracle.fkine(ch, q), oracle.jacob0(ch, q)
     want = float((T.reshape(N, 16) * (1 + np.arange(16))).sum() + (J.reshape(N, 42) * (1 + np.arange(42))).sum())
     assert abs(float(out[7]) - want) < 1e-7 * max(1.0, abs(want))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p2p", [0, 1])
+def test_gpu_c_program_shards_and_gathers_over_rccl(p2p):
+    """`consumer shard N`: one C process, one RCCL communicator + stream per visible GPU (world 1 on a single-GPU box), packed T||J rows computed
+    per rank, ONE rtbhip_shard_gather to rank 0 and one to every rank -- no PyTorch anywhere in the process.  p2p = 1 forces the grouped
+    send / receive form ragged shards take."""
+    from oracle import oracle, chains
+    exe, _ = build()
+    N = 1003
+    r = subprocess.run([exe, "shard", str(N)] + (["p2p"] if p2p else []), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = [l for l in r.stdout.splitlines() if l.startswith("world ")][-1].split()
+    d = dict(zip(out[0::2], out[1::2]))
+    import torch
+    assert int(d["world"]) == torch.cuda.device_count() == int(d["comm_world"]) and int(d["comm_rank"]) == int(d["world"]) - 1
+    assert int(d["rccl"]) > 20000 and int(d["rows"]) == N and d["allgather_equal"] == "1" and int(d["p2p"]) == p2p
+    ch = chains.Chain(chains.PANDA_ETS)
+    q = 0.1 * (np.arange(7) + 1)[None, :] + 1e-3 * np.arange(N)[:, None]
+    T, J = oracle.fkine(ch, q), oracle.jacob0(ch, q)
+    want = float((T.reshape(N, 16) * (1 + np.arange(16))).sum() + (J.reshape(N, 42) * (1 + np.arange(42))).sum())
+    assert abs(float(d["checksum"]) - want) < 1e-7 * max(1.0, abs(want))

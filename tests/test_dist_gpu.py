@@ -166,6 +166,11 @@ def test_bench_gather_flag_runs_the_rccl_gather_with_one_rank():
     gb = d["gather_buffer"]
     assert gb["buffer_bytes"] == 1 * 1000000 * 58 * 8 and gb["device_bytes_after"] == gb["device_bytes_before"]
     assert "secondary" not in d                        # the forced one-rank group is a rehearsal of the collective: no secondary legs
+    # both forms of the exchange, through the C ABI (rtbhip_shard_gather -> RCCL), and the line's own account of who ran where
+    assert d["all_gather_ms"] > 0 and "rtbhip_shard_gather" in gb["via"] and gb["rccl_world"] == 1 and gb["padded"] is False
+    assert d["world"] == {"launcher": 1, "process_group": 1, "backend": "nccl", "rccl_world": 1, "distinct_devices": 1}
+    (r0,) = d["ranks"]
+    assert r0["rank"] == 0 and len(r0["uuid"]) == 32 and ":" in r0["pci_bus_id"] and r0["kernel_avg_ms"] > 0 and r0["ms_per_step_own"] > 0
 
 
 def _run_bench(script, extra):
@@ -212,6 +217,10 @@ def test_bench_eight_ranks_sharing_the_gpu():
     d = lines[0]
     assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["devices_shared"] is True and d["gather_ms"] > 0
     assert d["gather_buffer"]["world"] == 8 and d["gather_buffer"]["buffer_bytes"] == 8 * 100003 * 58 * 8
+    # the self-verifying part of the line: eight ranks, each with its device identity and its own times; one physical GPU here (and said so)
+    assert d["world"]["launcher"] == 8 and d["world"]["process_group"] == 8 and d["world"]["backend"] == "gloo" and d["world"]["distinct_devices"] == 1
+    assert [r["rank"] for r in d["ranks"]] == list(range(8)) and d["all_gather_ms"] > 0
+    assert all(len(r["uuid"]) == 32 and r["kernel_avg_ms"] > 0 and r["ms_per_step_own"] > 0 for r in d["ranks"])
     assert d["value"] == pytest.approx(8 * 100003 * 4 / (d["ms_per_step"] * 4e-3), rel=1e-9) and "secondary" not in d
     rne, ik, fleet = run("bench_extra.py", ["--what", "rne,ik,fleet", "--steps", "3", "--n-rne", "400003", "--n-ik", "40003", "--n-fleet", "20003", "--no-cpu"])
     assert rne["n_gpus"] == 8 and rne["n"] == 400003 and rne["rows_rank0"] == 50001 and rne["gather_ms"] > 0
@@ -276,3 +285,7 @@ def test_bench_single_gpu_line_carries_the_contract_objects():
     assert rne["roofline"]["achieved"] == pytest.approx(224e7 / (rne["kernel_avg_ms"] * 1e-3) / 1e9, rel=1e-6)
     assert shard["n"] == 1250000
     assert fleet["n"] == 16000000 and fleet["parity"]["max_abs_err"] <= 1e-10 and len(fleet["arms"]) == 16
+    # the FULL config 5: 17 chains of 16 robots, YuMi as the 14-DOF dual-arm robot on its 18-column q; 4..14 DOF; the 16-chain form beside it
+    assert fleet["chains"] == 17 and fleet["arms"]["YuMi"] == 14 and min(fleet["arms"].values()) == 4 and max(fleet["arms"].values()) == 14
+    assert fleet["parity"]["max_abs_err_yumi_arms"] <= 1e-10 and fleet["layout"] == "packed" and fleet["two_array_layout_ms"] > 0
+    assert fleet["sixteen_chain_form"]["kernel_avg_ms"] > 0 and 0.0 < fleet["sixteen_chain_form"]["roofline"]["frac"] < 1.0
