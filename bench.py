@@ -134,7 +134,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline and host_path legs")
     ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` object (BASELINE configs[2], [3], [4] with their in-run parity)")
     ap.add_argument("--tune", action="append", default=[], help="key=value for rtbhip_tune (A/B runs)")
-    ap.add_argument("--layout", choices=("packed", "two"), default="packed",
+    ap.add_argument("--layout", choices=("packed", "two"), default="two",
                     help="output layout of the timed step: 'packed' = rtbhip_fkine_jacob_packed, one (N,58) array of [T | J0] rows (a single write "
                          "stream; the T||J gather message of SURVEY 8e); 'two' = rtbhip_fkine_jacob, T (N,4,4) and J0 (N,6,7) as two arrays.  Same "
                          "arithmetic, same 520 algorithmic bytes per configuration, bit-identical values (the other layout is timed beside it)")

@@ -34,6 +34,9 @@ namespace rtbhip {
 #endif
 constexpr long long kPoseCacheBytes = RTB_T_PLAIN_MAX_BYTES;
 constexpr int kKinPosePlain = 1;      // KinParams.pad bit 0
+#ifndef RTB_PACKED_XCD
+#define RTB_PACKED_XCD 1
+#endif
 constexpr int kKinPacked = 2;         // KinParams.pad bit 1: T is the packed (N, 16 + 6n) array [T | J], J is not written separately (run-time-n tile)
 
 // The chain tables through the constant address space: uniform loads become s_load (SGPR operands).
@@ -176,7 +179,8 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints ? RTB_REG_WAVES : 2)) v
                                                   double *__restrict__ T, double *__restrict__ J)
 {
     extern __shared__ __attribute__((aligned(16))) double buf[];
-    reg_tile<NJ, WANT_T, WANT_J, PACKED>(kp, const_view(dc), q, T, J, buf, threadIdx.x, xcd_tile());
+    // (the packed form writes ~30 KB runs per wave: like the Hessian tile it may prefer the identity mapping -- RTB_PACKED_XCD, A/B'd in profiles/r05_*)
+    reg_tile<NJ, WANT_T, WANT_J, PACKED>(kp, const_view(dc), q, T, J, buf, threadIdx.x, (PACKED && !RTB_PACKED_XCD) ? blockIdx.x : xcd_tile());
 }
 
 static int g_hess_mode = 0;   // A/B knob (rtbhip_tune "hess_mode")
