@@ -545,7 +545,7 @@ int rtbhip_chain_set_q_width(rtbhip_chain_t chain, int32_t q_width)
     Chain *c = c_owner.get();
     if (!c) { set_error("chain_set_q_width: unknown handle"); return RTBHIP_EINVAL; }
     int need = 0;
-    for (int32_t jm : c->jmeta) need = std::max(need, jm_jq(jm) + 1);
+    for (int j = 0; j < c->n; ++j) need = std::max(need, jm_jq(c->jmeta[j]) + 1);
     if (q_width < need || q_width > 256) {
         set_error("chain_set_q_width: width " + std::to_string(q_width) + " outside [" + std::to_string(need) + ", 256] for this chain");
         return RTBHIP_EINVAL;

@@ -74,6 +74,25 @@ DevSeg perm_transpose_seg(const int perm[3])
     return O;
 }
 
+// structure class + translation mask of a folded constant (rtbhip_internal.h: kSeg*), from its EXACT zeros and ones
+int seg_class_bits(const DevSeg &a)
+{
+    const double *r = a.r;
+    auto is = [&](int k, double v) { return r[k] == v; };
+    int cls = kSegGeneral;
+    if (is(0, 1) && is(1, 0) && is(2, 0) && is(3, 0) && is(4, 1) && is(5, 0) && is(6, 0) && is(7, 0) && is(8, 1)) cls = kSegIdentity;
+    else if (is(0, 1) && is(1, 0) && is(2, 0) && is(3, 0) && is(6, 0))                 // row 0 and column 0 of an x rotation
+        cls = (is(5, -1) && is(7, 1)) ? kSegRxP : (is(5, 1) && is(7, -1)) ? kSegRxN : kSegRx;
+    else if (is(4, 1) && is(1, 0) && is(7, 0) && is(3, 0) && is(5, 0))                 // y
+        cls = (is(2, -1) && is(6, 1)) ? kSegRyP : (is(2, 1) && is(6, -1)) ? kSegRyN : kSegRy;
+    else if (is(8, 1) && is(2, 0) && is(5, 0) && is(6, 0) && is(7, 0))                 // z
+        cls = (is(1, -1) && is(3, 1)) ? kSegRzP : (is(1, 1) && is(3, -1)) ? kSegRzN : kSegRz;
+    else if (is(3, 1) && is(7, 1) && is(2, 1) && is(0, 0) && is(1, 0) && is(4, 0) && is(5, 0) && is(6, 0) && is(8, 0)) cls = kSegPermA;   // new columns = old (1, 2, 0)
+    else if (is(6, 1) && is(1, 1) && is(5, 1) && is(0, 0) && is(2, 0) && is(3, 0) && is(4, 0) && is(7, 0) && is(8, 0)) cls = kSegPermB;   // new columns = old (2, 0, 1)
+    const int tm = (a.t[0] != 0.0 ? 1 : 0) | (a.t[1] != 0.0 ? 2 : 0) | (a.t[2] != 0.0 ? 4 : 0);
+    return (cls << 20) | (tm << 24);
+}
+
 }  // namespace
 
 int compile_chain(const rtbhip_et *ets, int m, const double *qlim, Chain *out)
@@ -127,6 +146,8 @@ int compile_chain(const rtbhip_et *ets, int m, const double *qlim, Chain *out)
         hi.push_back(prismatic ? 1.0 : M_PI);
     }
     out->seg.push_back(cur);  // C_n (identity when the chain ends with a z joint)
+    for (int j = 0; j < n; j++) out->jmeta[j] |= seg_class_bits(out->seg[j]);
+    out->jmeta.push_back(seg_class_bits(out->seg[n]));      // descriptor n: the tail's class alone
     out->n = n;
     out->q_width = qw;
     out->qlim.resize(2 * (size_t)n);

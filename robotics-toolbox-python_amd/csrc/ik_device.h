@@ -500,7 +500,8 @@ constexpr int kIkStepPinv = 1, kIkStepNull = 2;
 // UNITW (compile-time, LM steps only): the mask is all ones -- W J, W e and e^T W e need no products.  The same bits (x * 1.0 == x), 54
 // multiplies fewer per iteration; as a run-time switch inside one kernel it cost 30 VGPRs (round 3), as a kernel instantiation it costs nothing.
 // PLAIN (compile-time): an all-revolute chain without flipped joints -- reg_core<..., PLAIN> (kin_reg.h).
-template <int NJ, int STEP, bool UNITW = false, bool PLAIN = false, class PD, class CV, class QL, class TD, class QA>
+// SIG (compile-time, with PLAIN): the chain's structure signature (kin_reg.h: SegSig) -- every constant segment multiplied in the form of its class.
+template <int NJ, int STEP, bool UNITW = false, bool PLAIN = false, SegSig SIG = 0, class PD, class CV, class QL, class TD, class QA>
 RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, QA qa)
 {
     constexpr bool PINV = (STEP & kIkStepPinv) != 0, NULLSP = (STEP & kIkStepNull) != 0 && NJ >= 6;
@@ -515,7 +516,7 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, Q
             q_finite = q_finite && __builtin_isfinite(qv[j]);
         }
         // the chain's last constant C_n (no tool in IK) is segment NJ of the table: {r[9], t[3]} contiguous
-        reg_core<NJ, true, PLAIN>(cv, &cv.seg[NJ].r[0], 0, qv, P, jac);   // ik.cpp:44,56 / IK.py:994,1009
+        reg_core<NJ, true, PLAIN, SIG>(cv, &cv.seg[NJ].r[0], 0, qv, P, jac);   // ik.cpp:44,56 / IK.py:994,1009
     }
     sched_fence();
     ik_angle_axis(P, td, e);

@@ -67,7 +67,14 @@ constexpr int kIkAuxFlat = 1, kIkAuxStats = 2, kIkAuxUnitW = 4;      // bit 2: e
 #define RTB_IK_MASK_IDLE 0
 #endif
 constexpr int kIkAuxPlain = 8;                                         // bit 3: all-revolute chain, no flipped joint: ik_iter<..., PLAIN>
-template <int NJ, int STEP, int AUX = 0>
+// Structure signatures this build has straight-line instantiations for (kin_reg.h: SegSig; the chain compiler's classes, rtbhip_internal.h).  A
+// signature is a property of the robot's constants; the launcher compares a chain's own with this list and falls back to the general kernels.
+//   Franka Panda as the reference models it (models/ETS/Panda.py:32-54), BASELINE config 3's arm: C_0 = tz, C_1 .. C_6 quarter turns about x with
+//   translations on some axes, the flange Rz(-pi/4) tz(0.103) as the tail.
+constexpr SegSig kIkSigPandaETS = kSegSigPresent | seg_sig_of(0, kSegIdentity, 4) | seg_sig_of(1, kSegRxN, 0) | seg_sig_of(2, kSegRxP, 6) | seg_sig_of(3, kSegRxP, 1) |
+                                  seg_sig_of(4, kSegRxN, 7) | seg_sig_of(5, kSegRxP, 0) | seg_sig_of(6, kSegRxP, 7) | seg_sig_of(7, kSegRz, 4);
+static int g_ik_sig = 1;          // rtbhip_tune("ik_sig", 0): never take a signature's instantiation (A/B, tests)
+template <int NJ, int STEP, int AUX = 0, SegSig SIG = 0>
 __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull) ? RTB_IK_WAVES : 1)) void k_ik(IkDev p, DevChain dc, const double *qlim_g, const double *__restrict__ Tep,
                                                 const double *__restrict__ q0, unsigned long long *counter,
                                                 double *__restrict__ q_out, int32_t *__restrict__ success,
@@ -416,7 +423,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
             // that is clock (A/B: round 4 visit q)
             if (st.status == kIkRun && !st.fin)
 #endif
-            ik_iter<NJ, STEP, (AUX & kIkAuxUnitW) != 0 && STEP == 0, (AUX & kIkAuxPlain) != 0>(st, ka->p, cvi, ql, [&](int k) { return sh.Td[k][myslot]; }, ik_lds_q(sh, lane));
+            ik_iter<NJ, STEP, (AUX & kIkAuxUnitW) != 0 && STEP == 0, (AUX & kIkAuxPlain) != 0, SIG>(st, ka->p, cvi, ql, [&](int k) { return sh.Td[k][myslot]; }, ik_lds_q(sh, lane));
         }
     }
     if (kStats && ka->p.stats && lane == 0) {
@@ -517,6 +524,7 @@ void ik_tune(const char *key, int value)
     if (std::string(key) == "ik_share") g_ik_share = value < 0 ? 0 : (value > 2 ? 2 : value);
     if (std::string(key) == "ik_phased") g_ik_phased = value < 0 ? 0 : (value > 2 ? 2 : value);
     if (std::string(key) == "ik_fresh_pct") g_ik_fresh_pct = value < 1 ? 1 : value;
+    if (std::string(key) == "ik_sig") g_ik_sig = value != 0;
     if (std::string(key) == "ik_spec_policy") g_ik_spec_policy = value != 0;
     if (std::string(key) == "ik_donate_after") g_ik_donate_after = value < 0 ? 0 : value;
 }
@@ -564,7 +572,7 @@ void ik_restart_host(const Chain *c, uint64_t seed, int64_t target, int draw, do
 template <int NJ>
 static void launch_nj(dim3 grid, hipStream_t s, const IkDev &p, const DevChain &dc, const double *qlim, const double *Tep,
                       const double *q0, unsigned long long *ctr, double *q_out, int32_t *success, int32_t *iters,
-                      int32_t *searches, double *residual, const IkWork *work, const unsigned *count, const IkShareCtl &share)
+                      int32_t *searches, double *residual, const IkWork *work, const unsigned *count, const IkShareCtl &share, SegSig chain_sig)
 {
     const int v = ik_step_variant(p, NJ);
     if constexpr (NJ >= 6 && NJ <= kIkNullMax) {        // the null-space variants exist for 6..12 joints (launch_ik checks)
@@ -577,6 +585,13 @@ static void launch_nj(dim3 grid, hipStream_t s, const IkDev &p, const DevChain &
         // the default mask (all ones) has its own instantiations for the arms the register-resident kernel serves: no products with the weights
         if (p.unit_we && !stats) {
             if (p.pad_we /* plain chain */ && g_ik_plain) {
+                if constexpr (NJ == 7) {
+                    if (g_ik_sig && chain_sig == kIkSigPandaETS) {       // a known robot: the walk specialised to its constants' structure
+                        if (flat) hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxFlat | kIkAuxUnitW | kIkAuxPlain, kIkSigPandaETS>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share);
+                        else hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxUnitW | kIkAuxPlain, kIkSigPandaETS>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share);
+                        return;
+                    }
+                }
                 if (flat) hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxFlat | kIkAuxUnitW | kIkAuxPlain>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share);
                 else hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxUnitW | kIkAuxPlain>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share);
                 return;
@@ -650,6 +665,7 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
     const bool one_wave = c->n > kRegMaxJoints || (ik_step_variant(p, c->n) & kIkStepNull);   // 9..12 joints, null-space: one wave per SIMD
     const int64_t gmax = (int64_t)cus * (one_wave ? 4 : g_ik_waves_per_cu);
     const int n = c->n;
+    const SegSig chain_sig = chain_signature(c->jmeta.data(), n);
     // one launch of the scheduler kernel over `items` work items (the targets themselves when work == NULL)
     auto run = [&](const IkDev &pp, int64_t items, const IkWork *work, const unsigned *count, double *qo, int32_t *ok, int32_t *it,
                    int32_t *se, double *E, IkShareCtl share = IkShareCtl(), int64_t first_items = -1) -> int {
@@ -682,22 +698,22 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
         }
         dim3 grid((unsigned)g);
         switch (n) {
-        case 1: launch_nj<1>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
-        case 2: launch_nj<2>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
-        case 3: launch_nj<3>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
-        case 4: launch_nj<4>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
-        case 5: launch_nj<5>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
-        case 6: launch_nj<6>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
-        case 7: launch_nj<7>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
-        case 8: launch_nj<8>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
-        case 9: launch_nj<9>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
-        case 10: launch_nj<10>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
-        case 11: launch_nj<11>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
-        case 12: launch_nj<12>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
-        case 13: launch_nj<13>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
-        case 14: launch_nj<14>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
-        case 15: launch_nj<15>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
-        default: launch_nj<16>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share); break;
+        case 1: launch_nj<1>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 2: launch_nj<2>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 3: launch_nj<3>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 4: launch_nj<4>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 5: launch_nj<5>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 6: launch_nj<6>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 7: launch_nj<7>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 8: launch_nj<8>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 9: launch_nj<9>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 10: launch_nj<10>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 11: launch_nj<11>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 12: launch_nj<12>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 13: launch_nj<13>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 14: launch_nj<14>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 15: launch_nj<15>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        default: launch_nj<16>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
         }
         note_launch((int)grid.x, kWave, 0);
         hipError_t e = hipGetLastError();

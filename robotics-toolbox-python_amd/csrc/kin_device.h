@@ -117,6 +117,115 @@ RTB_HD void pose_mul_seg(Pose &P, const CV &cv, int j)
 {
     pose_mul_general<T3FMA>(P, [&](int k) { return k < 9 ? cv.seg[j].r[k] : cv.seg[j].t[k - 9]; });
 }
+// ---------------------------------------------------------------- P <- P * C_j by the segment's STRUCTURE CLASS
+// (rtbhip_internal.h: kSeg*; decided on the host from the EXACT zeros and ones of the folded constant -- cos(pi/2) = 6.1e-17 stays what it is).
+// Every form below is written operation for operation as what the GENERAL product (pose_mul_general with the fused translation chains)
+// computes once its products with exact zeros are dropped and its products with exact +-1 are taken as the operand itself: the compiler
+// contracts  x a0 + y a3 + z a6  to  fma(z, a6, fma(x, a0, y a3))  -- y a3 is rounded on its own -- so for finite poses the structured product
+// returns THE SAME BITS as the general one (tests/test_segment_classes.py on the host replay; on the device: the IK outputs of the
+// specialised and the general kernel, profiles/r05_ik_*).  Costs (general: 27 + 9):
+//   translation   P.t += R C.t: one fused column per NON-ZERO component, in the order of pose_t3_fma                     3 each
+//   identity      nothing                                                                                                 0
+//   Rx / Ry / Rz  rotation about one axis, the two other columns mix                                                      12
+//   ..P / ..N     the quarter turns (off-diagonal +-1; the diagonal keeps its cos(pi/2))                                  9
+//   permA / permB the cyclic column permutations of the axis conjugation: register moves                                 0
+RTB_HD double mul_then_add(double x, double y, double z)      // round(x y) + z: two roundings, never contracted into one
+{
+#pragma clang fp contract(off)
+    const double t = x * y;
+    return t + z;
+}
+// The forms are PLAIN expressions whose operand order makes the compiler's contraction land where the general product's lands (an a*b + c*d is
+// fused as fma(a, b, round(c d)): the first product takes the fused slot); on a host without fused instructions both sides round every
+// product -- equal there too.  Where the general product leaves TWO roundings (a product with +-1 feeding an addition) mul_then_add keeps them.
+// rotation about x or y:  general  u' = fma(v, c, round(u a)),  v' = fma(v, d, round(u b));   SUB 1: (b, c) = (-1, +1);  SUB 2: (b, c) = (+1, -1)
+template <int SUB>
+RTB_HD void pose_mix_xy(double &u, double &v, double a, double b, double c, double d)
+{
+    const double x = u, y = v;
+    if (SUB == 0) { u = y * c + x * a; v = y * d + x * b; }
+    else if (SUB == 1) { u = mul_then_add(x, a, y); v = y * d - x; }
+    else { u = mul_then_add(x, a, -y); v = y * d + x; }
+}
+// rotation about z (columns 0 and 1):  general  u' = fma(u, a, round(v c)),  v' = fma(u, b, round(v d))
+template <int SUB>
+RTB_HD void pose_mix_z(double &u, double &v, double a, double b, double c, double d)
+{
+    const double x = u, y = v;
+    if (SUB == 0) { u = x * a + y * c; v = x * b + y * d; }
+    else if (SUB == 1) { u = x * a + y; v = mul_then_add(y, d, -x); }
+    else { u = x * a - y; v = mul_then_add(y, d, x); }
+}
+template <int TM, class CV>
+RTB_HD void pose_seg_translate(Pose &P, const CV &cv, int j)
+{
+    if (TM & 1) { const double x = cv.seg[j].t[0]; P.tx = fma(x, P.r00, P.tx); P.ty = fma(x, P.r10, P.ty); P.tz = fma(x, P.r20, P.tz); }
+    if (TM & 2) { const double y = cv.seg[j].t[1]; P.tx = fma(y, P.r01, P.tx); P.ty = fma(y, P.r11, P.ty); P.tz = fma(y, P.r21, P.tz); }
+    if (TM & 4) { const double z = cv.seg[j].t[2]; P.tx = fma(z, P.r02, P.tx); P.ty = fma(z, P.r12, P.ty); P.tz = fma(z, P.r22, P.tz); }
+}
+template <int CLS, class CV>
+RTB_HD void pose_seg_rotate(Pose &P, const CV &cv, int j)
+{
+    const auto &r = cv.seg[j].r;
+    if (CLS == kSegRxP || CLS == kSegRxN || CLS == kSegRx) {         // columns (1, 2): a = r[4], b = r[5], c = r[7], d = r[8]
+        constexpr int S = CLS == kSegRxP ? 1 : CLS == kSegRxN ? 2 : 0;
+        const double a = r[4], b = S ? 0.0 : r[5], c = S ? 0.0 : r[7], d = r[8];
+        pose_mix_xy<S>(P.r01, P.r02, a, b, c, d); pose_mix_xy<S>(P.r11, P.r12, a, b, c, d); pose_mix_xy<S>(P.r21, P.r22, a, b, c, d);
+    } else if (CLS == kSegRyP || CLS == kSegRyN || CLS == kSegRy) {  // columns (0, 2): a = r[0], b = r[2], c = r[6], d = r[8]
+        constexpr int S = CLS == kSegRyP ? 1 : CLS == kSegRyN ? 2 : 0;
+        const double a = r[0], b = S ? 0.0 : r[2], c = S ? 0.0 : r[6], d = r[8];
+        pose_mix_xy<S>(P.r00, P.r02, a, b, c, d); pose_mix_xy<S>(P.r10, P.r12, a, b, c, d); pose_mix_xy<S>(P.r20, P.r22, a, b, c, d);
+    } else if (CLS == kSegRzP || CLS == kSegRzN || CLS == kSegRz) {  // columns (0, 1): a = r[0], b = r[1], c = r[3], d = r[4]
+        constexpr int S = CLS == kSegRzP ? 1 : CLS == kSegRzN ? 2 : 0;
+        const double a = r[0], b = S ? 0.0 : r[1], c = S ? 0.0 : r[3], d = r[4];
+        pose_mix_z<S>(P.r00, P.r01, a, b, c, d); pose_mix_z<S>(P.r10, P.r11, a, b, c, d); pose_mix_z<S>(P.r20, P.r21, a, b, c, d);
+    } else if (CLS == kSegPermA) {                                    // new columns = old (1, 2, 0)
+        double x;
+        x = P.r00; P.r00 = P.r01; P.r01 = P.r02; P.r02 = x;
+        x = P.r10; P.r10 = P.r11; P.r11 = P.r12; P.r12 = x;
+        x = P.r20; P.r20 = P.r21; P.r21 = P.r22; P.r22 = x;
+    } else if (CLS == kSegPermB) {                                    // new columns = old (2, 0, 1)
+        double x;
+        x = P.r02; P.r02 = P.r01; P.r01 = P.r00; P.r00 = x;
+        x = P.r12; P.r12 = P.r11; P.r11 = P.r10; P.r10 = x;
+        x = P.r22; P.r22 = P.r21; P.r21 = P.r20; P.r20 = x;
+    }
+}
+// compile-time class and translation mask: straight-line code (k_ik's instantiations for known robots: ik_kernels.hip, kIkSig*)
+template <int CLS, int TM, class CV>
+RTB_HD void pose_mul_seg_sig(Pose &P, const CV &cv, int j)
+{
+    if (CLS == kSegGeneral) { pose_mul_seg<true>(P, cv, j); return; }
+    pose_seg_translate<TM>(P, cv, j);
+    pose_seg_rotate<CLS>(P, cv, j);
+}
+// run-time class (a wave-uniform switch on the descriptor): measured SLOWER than the general product inside k_ik (round 5 visit c: config 3
+// 0.986 against 0.939 ms -- the ~45 scalar branches per iteration cost more than the ~170 vector operations they save); kept for the host
+// replay's tests and as an A/B switch (RTB_SEG_CLASSES = 1)
+template <class CV>
+RTB_HD void pose_mul_seg_cls(Pose &P, const CV &cv, int j, int jm)
+{
+    const int cls = jm_cls(jm), tm = jm_tmask(jm);
+    if (cls == kSegGeneral) { pose_mul_seg<true>(P, cv, j); return; }
+    if (tm & 1) pose_seg_translate<1>(P, cv, j);
+    if (tm & 2) pose_seg_translate<2>(P, cv, j);
+    if (tm & 4) pose_seg_translate<4>(P, cv, j);
+    switch (cls) {                                        // wave-uniform
+    case kSegIdentity: break;
+    case kSegRxP: pose_seg_rotate<kSegRxP>(P, cv, j); break;
+    case kSegRxN: pose_seg_rotate<kSegRxN>(P, cv, j); break;
+    case kSegRx: pose_seg_rotate<kSegRx>(P, cv, j); break;
+    case kSegRyP: pose_seg_rotate<kSegRyP>(P, cv, j); break;
+    case kSegRyN: pose_seg_rotate<kSegRyN>(P, cv, j); break;
+    case kSegRy: pose_seg_rotate<kSegRy>(P, cv, j); break;
+    case kSegRzP: pose_seg_rotate<kSegRzP>(P, cv, j); break;
+    case kSegRzN: pose_seg_rotate<kSegRzN>(P, cv, j); break;
+    case kSegRz: pose_seg_rotate<kSegRz>(P, cv, j); break;
+    case kSegPermA: pose_seg_rotate<kSegPermA>(P, cv, j); break;
+    default: pose_seg_rotate<kSegPermB>(P, cv, j); break;
+    }
+}
+
 template <class CV>
 RTB_HD void pose_from_seg(Pose &P, const CV &cv, int j)
 {

@@ -46,6 +46,26 @@ RTB_HD int reg_lds_doubles_packed(int n) { return kPRound * (17 + 6 * n + 1); }
 #ifndef RTB_POSE_T3_FMA
 #define RTB_POSE_T3_FMA 1
 #endif
+#ifndef RTB_SEG_CLASSES
+#define RTB_SEG_CLASSES 0      // 1: k_ik multiplies by a constant segment through a RUN-TIME switch on its structure class (kin_device.h: pose_mul_seg_cls).
+#endif                         //    Measured slower than the general product (round 5 visit c); what ships is the COMPILE-TIME form below.
+// A chain's STRUCTURE SIGNATURE: 7 bits per constant segment C_0 .. C_n (class | translation mask << 4, rtbhip_internal.h: kSeg*), bit 63 = "present".
+// reg_core<..., SIG != 0> multiplies by every segment through pose_mul_seg_sig<class, mask>: straight-line code, no descriptor is read.  A
+// kernel instantiated for a signature serves exactly the chains whose table has it (ik_kernels.hip: the launcher compares).
+typedef unsigned long long SegSig;
+constexpr SegSig kSegSigPresent = 1ull << 63;
+constexpr int seg_sig_cls(SegSig s, int j) { return (int)((s >> (7 * j)) & 15u); }
+constexpr int seg_sig_tm(SegSig s, int j) { return (int)((s >> (7 * j + 4)) & 7u); }
+constexpr SegSig seg_sig_of(int j, int cls, int tm) { return (SegSig)((cls & 15) | ((tm & 7) << 4)) << (7 * j); }
+inline SegSig chain_signature(const int32_t *jmeta, int n)      // host: from the descriptors chain.cpp wrote (n joints + the tail's word)
+{
+    if (n > 8) return 0;
+    SegSig s = kSegSigPresent;
+    for (int j = 0; j <= n; ++j) s |= seg_sig_of(j, jm_cls(jmeta[j]), jm_tmask(jmeta[j]));
+    return s;
+}
+template <SegSig SIG, int J, class CV>
+RTB_HD void pose_mul_seg_by_sig(Pose &P, const CV &cv) { pose_mul_seg_sig<seg_sig_cls(SIG, J), seg_sig_tm(SIG, J)>(P, cv, J); }
 #ifndef RTB_PIN_SEG_LOADS
 #define RTB_PIN_SEG_LOADS 1
 #endif
@@ -53,37 +73,12 @@ RTB_HD int reg_lds_doubles_packed(int n) { return kPRound * (17 + 6 * n + 1); }
 template <class CV, class = void> struct cv_has_trig { static constexpr bool value = false; };
 template <class CV> struct cv_has_trig<CV, decltype((void)(((const CV *)nullptr)->trig))> { static constexpr bool value = true; };
 
-// PLAIN (compile-time): every joint is revolute and none is flipped (the caller checked the chain's descriptors): no descriptor is read, no
-// wave-uniform branch splits the walk -- one straight-line block from the first sine to the last Jacobian column.
-template <int NJ, bool WANT_J, bool PLAIN = false, class CV, class TL>
-RTB_HD void reg_core(const CV &cv, TL tail /* tail[k], k = 0..11 */, int frame, const double (&qv)[NJ], Pose &P,
-                     double (&jac)[6 * NJ])
+// joint J of the walk (compile-time index: a signature picks the segment's form by it)
+template <int NJ, bool WANT_J, bool PLAIN, SegSig SIG, int J, class CV>
+RTB_HD void reg_walk_step(const CV &cv, Pose &P, double (&jac)[6 * NJ], const int (&jmv)[NJ], const double (&c)[NJ], const double (&s)[NJ], const double (&d)[NJ])
 {
-    double c[NJ], s[NJ], d[NJ];
-    // Wave-uniform per-joint blend weights instead of per-lane selects: rv = 1 for a revolute joint,
-    // pv = 1 for a prismatic one, sg = -1 where the joint is flipped.  They are re-derived from the
-    // one-dword joint descriptor at every use (a few SALU ops) rather than kept as 3*NJ SGPR doubles
-    // across the whole walk: inside the persistent IK loop those 42 SGPRs were what overflowed the
-    // scalar register file.
-    int jmv[NJ];
-    bool big = false;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {   // methods.cpp:363-366 for flip
-        jmv[j] = PLAIN ? 0 : cv.jmeta[j];
-        d[j] = PLAIN ? qv[j] : qv[j] * (jm_flip(jmv[j]) ? -1.0 : 1.0);
-    }
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {   // NJ independent evaluations, one basic block
-        if constexpr (cv_has_trig<CV>::value) sincos_reduced_tab(d[j], s[j], c[j], cv.trig);
-        else sincos_reduced(d[j], s[j], c[j]);
-        big = big || !(fabs(d[j]) < kTrigFastLimit);
-    }
-    if (wave_any(big)) {             // |q| >= 2^20, NaN, inf: library path for the whole wave
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) sincos(d[j], &s[j], &c[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
+    constexpr int j = J;
+    {
 #if defined(__HIP_DEVICE_COMPILE__) && RTB_PIN_SEG_LOADS
         // Inside k_ik's persistent loop (the chain views that carry `trig`): tie segment j's table pointer to a value of step j - 1, so that its
         // scalar loads cannot be issued before the walk gets there.  Without this the loads of the later segments were issued early and their
@@ -91,9 +86,15 @@ RTB_HD void reg_core(const CV &cv, TL tail /* tail[k], k = 0..11 */, int frame, 
         // -2.4 % (config 3) ... -3.6 % (notebook setting) on one box (round 4 visit l).  RTB_PIN_SEG_LOADS = 2 pins the general (branchy) walk too.
         CV cvj = cv;
         if ((PLAIN || RTB_PIN_SEG_LOADS > 1) && cv_has_trig<CV>::value && j > 0) asm volatile("" : "+s"(cvj.seg), "+v"(P.tx));
-        if (j == 0) pose_from_seg(P, cvj, 0); else pose_mul_seg<(PLAIN && RTB_POSE_T3_FMA && cv_has_trig<CV>::value)>(P, cvj, j);
+        if (j == 0) pose_from_seg(P, cvj, 0);
+        else if constexpr (SIG != 0) pose_mul_seg_by_sig<SIG, J>(P, cvj);                                              // k_ik for a known robot: compile-time class
+        else if constexpr (RTB_SEG_CLASSES && cv_has_trig<CV>::value) pose_mul_seg_cls(P, cvj, j, cvj.jmeta[j]);      // k_ik: by structure class (run-time switch, A/B)
+        else pose_mul_seg<(PLAIN && RTB_POSE_T3_FMA && cv_has_trig<CV>::value)>(P, cvj, j);
 #else
-        if (j == 0) pose_from_seg(P, cv, 0); else pose_mul_seg(P, cv, j);
+        if (j == 0) pose_from_seg(P, cv, 0);
+        else if constexpr (SIG != 0) pose_mul_seg_by_sig<SIG, J>(P, cv);
+        else if constexpr (RTB_SEG_CLASSES && cv_has_trig<CV>::value) pose_mul_seg_cls(P, cv, j, cv.jmeta[j]);          // (the host replay of k_ik: the same arithmetic)
+        else pose_mul_seg(P, cv, j);
 #endif
         if (WANT_J) {
             jac[j] = P.tx; jac[NJ + j] = P.ty; jac[2 * NJ + j] = P.tz;
@@ -108,8 +109,19 @@ RTB_HD void reg_core(const CV &cv, TL tail /* tail[k], k = 0..11 */, int frame, 
         sched_fence();
 #endif
     }
-    pose_mul_general<(PLAIN && RTB_POSE_T3_FMA && cv_has_trig<CV>::value)>(P, [&](int k) { return tail[k]; });
-    sched_fence();
+}
+template <int NJ, bool WANT_J, bool PLAIN, SegSig SIG, int J = 0, class CV>
+RTB_HD void reg_walk_steps(const CV &cv, Pose &P, double (&jac)[6 * NJ], const int (&jmv)[NJ], const double (&c)[NJ], const double (&s)[NJ], const double (&d)[NJ])
+{
+    if constexpr (J < NJ) {
+        reg_walk_step<NJ, WANT_J, PLAIN, SIG, J>(cv, P, jac, jmv, c, s, d);
+        reg_walk_steps<NJ, WANT_J, PLAIN, SIG, J + 1>(cv, P, jac, jmv, c, s, d);
+    }
+}
+
+template <int NJ, bool WANT_J>
+RTB_HD void reg_close_jacobian(const Pose &P, int frame, const int (&jmv)[NJ], double (&jac)[6 * NJ])
+{
     if (WANT_J) {
         // Jv = z x (p_e - p), Jw = z (revolute) ; Jv = z, Jw = 0 (prismatic); flip negates
         // (methods.cpp:142-195); frame 1 rotates both halves by Re^T.
@@ -140,6 +152,45 @@ RTB_HD void reg_core(const CV &cv, TL tail /* tail[k], k = 0..11 */, int frame, 
             jac[3 * NJ + j] = wx; jac[4 * NJ + j] = wy; jac[5 * NJ + j] = wz;
         }
     }
+}
+
+// PLAIN (compile-time): every joint is revolute and none is flipped (the caller checked the chain's descriptors): no descriptor is read, no
+// wave-uniform branch splits the walk -- one straight-line block from the first sine to the last Jacobian column.
+template <int NJ, bool WANT_J, bool PLAIN = false, SegSig SIG = 0, class CV, class TL>
+RTB_HD void reg_core(const CV &cv, TL tail /* tail[k], k = 0..11 */, int frame, const double (&qv)[NJ], Pose &P,
+                     double (&jac)[6 * NJ])
+{
+    static_assert(SIG == 0 || (PLAIN && NJ <= 8), "a structure signature goes with the straight-line walk");
+    double c[NJ], s[NJ], d[NJ];
+    // Wave-uniform per-joint blend weights instead of per-lane selects: rv = 1 for a revolute joint,
+    // pv = 1 for a prismatic one, sg = -1 where the joint is flipped.  They are re-derived from the
+    // one-dword joint descriptor at every use (a few SALU ops) rather than kept as 3*NJ SGPR doubles
+    // across the whole walk: inside the persistent IK loop those 42 SGPRs were what overflowed the
+    // scalar register file.
+    int jmv[NJ];
+    bool big = false;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {   // methods.cpp:363-366 for flip
+        jmv[j] = PLAIN ? 0 : cv.jmeta[j];
+        d[j] = PLAIN ? qv[j] : qv[j] * (jm_flip(jmv[j]) ? -1.0 : 1.0);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {   // NJ independent evaluations, one basic block
+        if constexpr (cv_has_trig<CV>::value) sincos_reduced_tab(d[j], s[j], c[j], cv.trig);
+        else sincos_reduced(d[j], s[j], c[j]);
+        big = big || !(fabs(d[j]) < kTrigFastLimit);
+    }
+    if (wave_any(big)) {             // |q| >= 2^20, NaN, inf: library path for the whole wave
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) sincos(d[j], &s[j], &c[j]);
+    }
+    reg_walk_steps<NJ, WANT_J, PLAIN, SIG>(cv, P, jac, jmv, c, s, d);
+    // k_ik's chain views: the tail IS segment NJ of the table (no tool in IK), descriptor NJ carries its class
+    if constexpr (SIG != 0) pose_mul_seg_by_sig<SIG, NJ>(P, cv);
+    else if constexpr (RTB_SEG_CLASSES && cv_has_trig<CV>::value) pose_mul_seg_cls(P, cv, NJ, cv.jmeta[NJ]);
+    else pose_mul_general<(PLAIN && RTB_POSE_T3_FMA && cv_has_trig<CV>::value)>(P, [&](int k) { return tail[k]; });
+    sched_fence();
+    reg_close_jacobian<NJ, WANT_J>(P, frame, jmv, jac);
 }
 
 // whole per-lane compute of one tile: q row in memory -> (P, J)

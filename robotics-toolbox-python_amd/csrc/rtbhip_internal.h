@@ -33,18 +33,31 @@ static_assert(sizeof(DevSeg) == 96, "DevSeg layout");
 __host__ __device__ inline int jm_prismatic(int jm) { return jm & 1; }
 __host__ __device__ inline int jm_jq(int jm) { return (jm >> 8) & 0xff; }
 __host__ __device__ inline int jm_flip(int jm) { return (jm >> 16) & 1; }
+// bits 20..23: STRUCTURE CLASS of the constant segment C_j that precedes joint j, bits 24..26: which components of its translation are non-zero
+// (descriptor n -- one past the joints -- carries the class of the tail C_n alone).  Robot constants are mostly not general affines: a pure
+// translation (URDF origins with rpy = 0), a quarter turn about one axis times a translation (DH alpha = +-pi/2; models/ETS/Panda.py:32-54:
+// six of the Panda's seven inner constants), a rotation about one axis (the Panda's Rz(-pi/4) flange).  The class is decided from the EXACT
+// zeros and ones of the folded matrix (chain.cpp: seg_class) -- cos(pi/2) = 6.1e-17 stays what it is, nothing is snapped -- and lets the
+// kernels that opt in (k_ik) replace the 27 + 9 fused multiply-adds of a general P * C by 0 / 6 / 12 + 3 per non-zero translation component.
+constexpr int kSegGeneral = 0, kSegIdentity = 1,
+              kSegRxP = 2, kSegRxN = 3, kSegRx = 4,      // R = [1 0 0; 0 a b; 0 c d]: P (b, c) = (-1, +1), N (b, c) = (+1, -1), else any a b c d
+              kSegRyP = 5, kSegRyN = 6, kSegRy = 7,      // R = [a 0 b; 0 1 0; c 0 d]
+              kSegRzP = 8, kSegRzN = 9, kSegRz = 10,     // R = [a b 0; c d 0; 0 0 1]
+              kSegPermA = 11, kSegPermB = 12;            // the cyclic column permutations of the axis conjugation (chain.cpp: axis_perm): new columns (1,2,0) / (2,0,1)
+__host__ __device__ inline int jm_cls(int jm) { return (jm >> 20) & 15; }
+__host__ __device__ inline int jm_tmask(int jm) { return (jm >> 24) & 7; }
 
 // What a kernel receives: two wave-uniform tables in one device allocation.
 struct DevChain {
     const DevSeg *seg;     // n + 1 constants C_0 .. C_n
-    const int32_t *jmeta;  // n joint descriptors
+    const int32_t *jmeta;  // n joint descriptors (+ one more word: the structure class of the tail C_n)
 };
 
 // Host-side chain object behind an rtbhip_chain_t handle.
 struct Chain {
     std::vector<rtbhip_et> ets;   // as given (for chain_info / debugging)
     std::vector<DevSeg> seg;      // n + 1
-    std::vector<int32_t> jmeta;   // n
+    std::vector<int32_t> jmeta;   // n + 1: joint descriptors, then the tail's class word
     std::vector<double> qlim;     // 2*n (lows, highs)
     int n = 0, q_width = 0;
     std::map<int, void *> dev_ops;     // per-device upload: [seg | jmeta]

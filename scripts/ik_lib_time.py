@@ -10,7 +10,11 @@ ets = rtbhip.models.Panda().ets(); ets.qlim = rtbhip.models.PANDA_QLIM
 rng = np.random.default_rng(1)
 T5 = ets.eval(torch.from_numpy(rng.uniform(ets.qlim[0], ets.qlim[1], (100000, 7))).cuda())
 T6 = ets.eval(torch.from_numpy(rng.uniform(ets.qlim[0], ets.qlim[1], (1000000, 7))).cuda())
-out = {"lib": os.environ.get("RTBHIP_LIB", "product")}
+tunes = os.environ.get("RTBHIP_TUNE", "")          # "key=value,key=value": rtbhip_tune settings of this run (an A/B inside one library)
+for kv in filter(None, tunes.split(",")):
+    k, v = kv.split("=")
+    rtbhip.tune(k, int(v))
+out = {"lib": (os.environ.get("RTBHIP_LIB") or "product") + ((" " + tunes) if tunes else "")}
 for name, T, kw in (("config3", T5, {}), ("notebook", T5, {"k": 0.1, "joint_limits": False}), ("1e6", T6, {})):
     res = {}
     def run():
@@ -19,5 +23,6 @@ for name, T, kw in (("config3", T5, {}), ("notebook", T5, {"k": 0.1, "joint_limi
     ms, reps, warm = sustained_ms(run)
     q, ok, it, se, E = res["o"]
     h = hashlib.sha256(b"".join(x.cpu().numpy().tobytes() for x in (ok, it, se))).hexdigest()[:12]
-    out[name] = {"ms": round(ms, 4), "ok": float(ok.float().mean()), "its": int(it.sum()), "counts_sha": h, "q_sum": float(torch.nan_to_num(q).sum())}
+    hq = hashlib.sha256(q.cpu().numpy().tobytes() + E.cpu().numpy().tobytes()).hexdigest()[:12]          # every bit of q and E
+    out[name] = {"ms": round(ms, 4), "ok": float(ok.float().mean()), "its": int(it.sum()), "counts_sha": h, "bits_sha": hq, "q_sum": float(torch.nan_to_num(q).sum())}
 print(json.dumps(out), flush=True)

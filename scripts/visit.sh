@@ -11,6 +11,7 @@
 #   fuzz    scripts/gpu_fuzz_*.py (random robots through every kernel size against the oracle)  -> fuzz_*.jsonl
 #   layout  scripts/layout_probe.py --fleet (packed vs two-array outputs over fresh allocations; VARIANTS="a.so b.so" adds A/B libraries)
 #   ikab    scripts/ik_ab.py over VARIANTS (A/B libraries of the IK kernel, interleaved, sustained)
+#   libab   scripts/ik_lib_time.py for the product library and every VARIANTS library, LIBAB_ROUNDS interleaved rounds         -> ik_lib_ab.jsonl
 #   cmd     eval "$CMD" (anything else; output -> cmd.log)
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
@@ -55,6 +56,18 @@ if has extra; then
 fi
 if has ikab; then
   timeout ${IKAB_TIMEOUT:-900} python scripts/ik_ab.py $IKAB_ARGS > $O/ik_ab.jsonl 2> $O/ik_ab.err; cut -c1-260 $O/ik_ab.jsonl | tail -60; tail -3 $O/ik_ab.err
+fi
+if has libab; then
+  # A/B LIBRARIES of k_ik (robotics-toolbox-python_amd/lib/variants/*.so from scripts/build_ik_variant.sh), one process per library and round, interleaved
+  : > $O/ik_lib_ab.jsonl
+  for r in $(seq 1 ${LIBAB_ROUNDS:-3}); do
+    for v in product $VARIANTS; do
+      L=""; T=""                                    # an entry with '=' is an rtbhip_tune setting of the product library, else a variant library
+      if [[ $v == *=* ]]; then T=$v; elif [ $v != product ]; then L=$R/robotics-toolbox-python_amd/lib/variants/$v; fi
+      RTBHIP_LIB=$L RTBHIP_TUNE=$T timeout 200 python scripts/ik_lib_time.py >> $O/ik_lib_ab.jsonl 2>> $O/ik_lib_ab.err
+    done
+  done
+  python scripts/ik_lib_digest.py $O/ik_lib_ab.jsonl
 fi
 if has fuzz; then
   for f in ${FUZZ:-dyn ik kin rne paths fleet}; do

@@ -21,6 +21,20 @@
 
 using namespace rtbhip;
 
+// the chain view k_ik walks (ik_kernels.hip: ConstChainIk): segments, descriptors and the sincos constant table -- with `trig` present the
+// replay takes the kernel's own template paths (table-driven sincos, the constant segments multiplied by structure class)
+struct EmuChainIk {
+    const DevSeg *seg;
+    const int32_t *jmeta;
+    const double *trig;
+};
+static inline EmuChainIk emu_chain_ik(const Chain *c)
+{
+    static const double tab[kSincosTableLen] = RTB_SINCOS_TABLE_INIT;
+    const DevChain v = chain_host_view(c);
+    return EmuChainIk{v.seg, v.jmeta, tab};
+}
+
 static inline Affine aff16(const double *m)
 {
     Affine a;

@@ -5,7 +5,7 @@ template <int NJ>
 static void emu_ik_run(const Chain *c, const IkDev &p, const double *Tep, const double *q0, double *q_out, int32_t *success,
                        int32_t *iters, int32_t *searches, double *residual)
 {
-    const DevChain cv = chain_host_view(c);
+    const EmuChainIk cv = emu_chain_ik(c);
     const double *qlim = c->qlim.data();
     for (int64_t t = 0; t < p.N; ++t)   // the specification: searches one after another
         ik_solve_sequential<NJ>(p, cv, qlim, t, Tep, q0, q_out, success, iters, searches, residual);

@@ -27,7 +27,7 @@ static int emu_ik_wave_run(const Chain *c, const IkDev &p, int waves, const doub
                            int32_t *success, int32_t *iters, int32_t *searches, double *residual, double *stats,
                            const IkWork *work = nullptr, const IkShareCtl *share = nullptr)
 {
-    const DevChain cv = chain_host_view(c);
+    const EmuChainIk cv = emu_chain_ik(c);
     const double *qlim = c->qlim.data();
     const int s_last = ik_s_last(p);
     unsigned long long counter = 0;

@@ -204,3 +204,66 @@ extern "C" int emu_tree_rne(const rtbhip_tree_group *groups, int ng, const doubl
     }
     return 0;
 }
+
+// pose_mul_seg_cls (kin_device.h) against the general product on segment j of a chain: P_in (12: R row-major, t) -> out_cls, out_gen; returns the
+// descriptor's class bits (class | tmask << 4), -1 for a bad handle / index
+extern "C" int emu_pose_mul_seg(rtbhip_chain_t h, int j, const double *Pin, double *out_cls, double *out_gen)
+{
+    const std::shared_ptr<Chain> c_owner = chain_from_handle(h);
+    Chain *c = c_owner.get();
+    if (!c || j < 0 || j > c->n) return -1;
+    const EmuChainIk cv = emu_chain_ik(c);
+    auto load = [&](Pose &P) { P.r00 = Pin[0]; P.r01 = Pin[1]; P.r02 = Pin[2]; P.r10 = Pin[3]; P.r11 = Pin[4]; P.r12 = Pin[5]; P.r20 = Pin[6]; P.r21 = Pin[7]; P.r22 = Pin[8];
+                               P.tx = Pin[9]; P.ty = Pin[10]; P.tz = Pin[11]; };
+    auto store = [&](const Pose &P, double *o) { o[0] = P.r00; o[1] = P.r01; o[2] = P.r02; o[3] = P.r10; o[4] = P.r11; o[5] = P.r12; o[6] = P.r20; o[7] = P.r21; o[8] = P.r22;
+                                                 o[9] = P.tx; o[10] = P.ty; o[11] = P.tz; };
+    Pose A, B;
+    load(A); load(B);
+    const int jm = cv.jmeta[j];
+    pose_mul_seg_cls(A, cv, j, jm);
+    pose_mul_seg<true>(B, cv, j);
+    store(A, out_cls); store(B, out_gen);
+    return jm_cls(jm) | (jm_tmask(jm) << 4);
+}
+
+// the COMPILE-TIME form (pose_mul_seg_sig<class, mask>, what k_ik's signature instantiations execute) on the same segment: every (class, mask) pair
+// is instantiated here and picked by the descriptor's bits
+template <int CLS, int TM>
+static void emu_sig_one(Pose &P, const EmuChainIk &cv, int j) { pose_mul_seg_sig<CLS, TM>(P, cv, j); }
+template <int CLS>
+static void emu_sig_tm(Pose &P, const EmuChainIk &cv, int j, int tm)
+{
+    switch (tm) {
+    case 0: emu_sig_one<CLS, 0>(P, cv, j); break; case 1: emu_sig_one<CLS, 1>(P, cv, j); break; case 2: emu_sig_one<CLS, 2>(P, cv, j); break;
+    case 3: emu_sig_one<CLS, 3>(P, cv, j); break; case 4: emu_sig_one<CLS, 4>(P, cv, j); break; case 5: emu_sig_one<CLS, 5>(P, cv, j); break;
+    case 6: emu_sig_one<CLS, 6>(P, cv, j); break; default: emu_sig_one<CLS, 7>(P, cv, j); break;
+    }
+}
+extern "C" int emu_pose_mul_seg_sig(rtbhip_chain_t h, int j, const double *Pin, double *out_sig)
+{
+    const std::shared_ptr<Chain> c_owner = chain_from_handle(h);
+    Chain *c = c_owner.get();
+    if (!c || j < 0 || j > c->n) return -1;
+    const EmuChainIk cv = emu_chain_ik(c);
+    Pose P;
+    P.r00 = Pin[0]; P.r01 = Pin[1]; P.r02 = Pin[2]; P.r10 = Pin[3]; P.r11 = Pin[4]; P.r12 = Pin[5]; P.r20 = Pin[6]; P.r21 = Pin[7]; P.r22 = Pin[8];
+    P.tx = Pin[9]; P.ty = Pin[10]; P.tz = Pin[11];
+    const int jm = cv.jmeta[j], tm = jm_tmask(jm);
+    switch (jm_cls(jm)) {
+    case 0: emu_sig_tm<0>(P, cv, j, tm); break; case 1: emu_sig_tm<1>(P, cv, j, tm); break; case 2: emu_sig_tm<2>(P, cv, j, tm); break;
+    case 3: emu_sig_tm<3>(P, cv, j, tm); break; case 4: emu_sig_tm<4>(P, cv, j, tm); break; case 5: emu_sig_tm<5>(P, cv, j, tm); break;
+    case 6: emu_sig_tm<6>(P, cv, j, tm); break; case 7: emu_sig_tm<7>(P, cv, j, tm); break; case 8: emu_sig_tm<8>(P, cv, j, tm); break;
+    case 9: emu_sig_tm<9>(P, cv, j, tm); break; case 10: emu_sig_tm<10>(P, cv, j, tm); break; case 11: emu_sig_tm<11>(P, cv, j, tm); break;
+    default: emu_sig_tm<12>(P, cv, j, tm); break;
+    }
+    out_sig[0] = P.r00; out_sig[1] = P.r01; out_sig[2] = P.r02; out_sig[3] = P.r10; out_sig[4] = P.r11; out_sig[5] = P.r12; out_sig[6] = P.r20; out_sig[7] = P.r21; out_sig[8] = P.r22;
+    out_sig[9] = P.tx; out_sig[10] = P.ty; out_sig[11] = P.tz;
+    return 0;
+}
+// the structure signature of a chain (kin_reg.h: chain_signature), for the test that pins the Panda's
+extern "C" unsigned long long emu_chain_signature(rtbhip_chain_t h)
+{
+    const std::shared_ptr<Chain> c_owner = chain_from_handle(h);
+    Chain *c = c_owner.get();
+    return c ? chain_signature(c->jmeta.data(), c->n) : 0ull;
+}

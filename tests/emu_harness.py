@@ -108,6 +108,9 @@ def lib():
         _lib.rtbhip_chain_set_q_width.argtypes = [_u64, _i32]
         _lib.emu_kin.argtypes = [_u64, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _i32]
         _lib.emu_kin_packed.argtypes = [_u64, _vp, _i64, _vp, _vp, _i32, _vp, _i32]
+        _lib.emu_pose_mul_seg.argtypes = [_u64, _i32, _vp, _vp, _vp]
+        _lib.emu_pose_mul_seg_sig.argtypes = [_u64, _i32, _vp, _vp]
+        _lib.emu_chain_signature.argtypes, _lib.emu_chain_signature.restype = [_u64], C.c_uint64
         _lib.emu_rne.argtypes = [_u64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32]
         _lib.emu_rne_base_wrench.argtypes = [_u64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]
         _lib.emu_kin_hess.argtypes = [_u64, _vp, _i64, _vp, _i32, _vp]
