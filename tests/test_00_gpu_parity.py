@@ -686,6 +686,34 @@ def test_ik_kernel_specialisations_agree():
     assert 0.9 < base[1].mean() < 1.0
 
 
+def test_ik_structure_signature_kernel_returns_the_general_kernel_s_bits():
+    """The Panda's chain has a structure signature k_ik is instantiated for (six quarter turns about x, translations on some axes, the flange
+    rotation: csrc/ik_kernels.hip kIkSigPandaETS; its constant segments are then multiplied in the form of their class, csrc/kin_device.h).
+    Every structured product is the general product with its exact zeros dropped, operation for operation: q, E, success, iterations and
+    searches must be BIT-IDENTICAL to the general kernel's (rtbhip_tune "ik_sig" = 0), in both solver flavours and with a weighted mask (which
+    never takes the specialised kernel).  A chain with another signature is not affected by the switch."""
+    ets, ch = _panda_limited()
+    rng = np.random.default_rng(92)
+    N = full_size(20000, 100)
+    Tep = oracle.fkine(ch, rng.uniform(ch.qlim[0], ch.qlim[1], (N, 7)))
+    other = rtbhip.ETS(list(rtbhip.models.Panda().ets())[:-1] + [rtbhip.ET.Rx(0.2)])          # the flange replaced: another signature
+    other.qlim = ets.qlim
+    outs = {}
+    try:
+        for sig in (1, 0):
+            rtbhip.tune("ik_sig", sig)
+            outs[sig] = [ets.ik_LM(Tep, seed=5), ets.ikine_LM(Tep[:min(N, 3000)], seed=5), ets.ik_LM(Tep[:min(N, 2000)], seed=5, mask=[1, 1, 1, 0.5, 0.5, 0]),
+                         other.ik_LM(Tep[:min(N, 2000)], seed=5)]
+    finally:
+        rtbhip.tune("ik_sig", 1)
+    for a, b in zip(outs[1], outs[0]):
+        a = a if isinstance(a, tuple) else (a.q, a.success, a.iterations, a.searches, a.residual)
+        b = b if isinstance(b, tuple) else (b.q, b.success, b.iterations, b.searches, b.residual)
+        for x, y in zip(a, b):
+            nt.assert_array_equal(np.asarray(x), np.asarray(y))
+    assert 0.9 < np.asarray(outs[1][0][1]).mean() <= 1.0          # (under the CPU replay the sample is 200 targets: all may succeed)
+
+
 @pytest.mark.parametrize("shape", ["six revolute", "seven with a flipped joint", "six with a prismatic joint", "eight revolute", "five revolute"])
 def test_ik_kernel_variants_on_other_chain_shapes_equal_the_oracle(shape):
     """Which k_ik instantiation serves a call depends on the chain (all-revolute without flips: the straight-line walk; anything else: the
