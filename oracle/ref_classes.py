@@ -31,6 +31,7 @@ REF_PKG = "/root/reference/src/roboticstoolbox"
 PYC_DIR = os.path.join(HERE, "_ref", "pyref")
 FILES = ["tools/types.py", "tools/p_servo.py", "robot/IK.py", "robot/ET.py", "robot/ETS.py"]
 # the DH side (load_dh): the classes a `DHRobot` is made of and the two DH models the benchmark configurations name
+URDF_FILES = ["tools/urdf/utils.py", "tools/urdf/urdf.py"]
 DH_FILES = ["robot/Link.py", "robot/Gripper.py", "robot/RobotProto.py", "robot/DHLink.py", "robot/Dynamics.py", "robot/RobotKinematics.py",
             "robot/BaseRobot.py", "robot/Robot.py", "robot/DHRobot.py", "models/DH/Puma560.py", "models/DH/Panda.py"]
 _LOADED = {}
@@ -57,7 +58,7 @@ def available():
 
 
 def dh_available():
-    return available() and all(os.path.exists(os.path.join(REF_PKG, f)) or os.path.exists(_pyc(f)) for f in DH_FILES)
+    return available() and all(os.path.exists(os.path.join(REF_PKG, f)) or os.path.exists(_pyc(f)) for f in DH_FILES + URDF_FILES)
 
 
 # the reference's own unit-test files that tests/test_reference_suite.py runs against the GPU backend
@@ -95,7 +96,7 @@ def compile_pyc():
     """The `refpy` recipe of oracle/Makefile: byte-compile the reference files from where they lie into oracle/_ref/pyref."""
     import py_compile
     os.makedirs(PYC_DIR, exist_ok=True)
-    for f in FILES + DH_FILES:
+    for f in FILES + DH_FILES + URDF_FILES:
         py_compile.compile(os.path.join(REF_PKG, f), cfile=_pyc(f), dfile="roboticstoolbox/" + f, doraise=True)
     os.makedirs(os.path.dirname(_test_pyc("x")), exist_ok=True)
     for f in TEST_FILES:
@@ -148,7 +149,8 @@ _PLACEHOLDERS = ("spatialgeometry", "ansitable", "roboticstoolbox.backends", "ro
 _NAMES = ("spatialmath", "spatialmath.base", "spatialmath.base.argcheck", "spatialmath.base.symbolic", "qpsolvers", "roboticstoolbox",
           "roboticstoolbox.fknm", "roboticstoolbox.frne", "roboticstoolbox.tools",
           "roboticstoolbox.tools.types", "roboticstoolbox.tools.p_servo", "roboticstoolbox.robot", "roboticstoolbox.robot.IK",
-          "roboticstoolbox.robot.ET", "roboticstoolbox.robot.ETS", "roboticstoolbox.models", "roboticstoolbox.models.DH") + _PLACEHOLDERS + tuple(
+          "roboticstoolbox.robot.ET", "roboticstoolbox.robot.ETS", "roboticstoolbox.models", "roboticstoolbox.models.DH",
+          "roboticstoolbox.tools.urdf", "roboticstoolbox.tools.urdf.utils", "roboticstoolbox.tools.urdf.urdf") + _PLACEHOLDERS + tuple(
               "roboticstoolbox." + f[:-3].replace("/", ".") for f in DH_FILES)
 
 
@@ -246,6 +248,17 @@ def _load_dh(ns, rtb, tools, robot, frne):
     dh.Puma560 = _exec("roboticstoolbox.models.DH.Puma560", "models/DH/Puma560.py").Puma560
     dh.Panda = _exec("roboticstoolbox.models.DH.Panda", "models/DH/Panda.py").Panda
     ns.frne, ns.DHRobot, ns.Puma560, ns.PandaDH, ns.mods = frne, rtb.DHRobot, dh.Puma560, dh.Panda, mods
+    # the URDF reader, unmodified: tools/urdf/urdf.py lowers a URDF file to the list of Links (URDF.__init__ :1662-1786: one Link per <link> in
+    # file order, ets = SE3(origin) RPY [* joint ET], qlim, inertial parameters) that Robot.URDF hands to Robot.__init__ (whose _sort_links numbers
+    # the joints).  Its geometry objects (spatialgeometry shapes) are placeholders; meshes are never opened.
+    urdf_pkg = types.ModuleType("roboticstoolbox.tools.urdf")
+    urdf_pkg.__path__ = []
+    sys.modules["roboticstoolbox.tools.urdf"] = urdf_pkg
+    tools.urdf = urdf_pkg
+    urdf_pkg.utils = _exec("roboticstoolbox.tools.urdf.utils", "tools/urdf/utils.py")
+    urdf_pkg.urdf = _exec("roboticstoolbox.tools.urdf.urdf", "tools/urdf/urdf.py")
+    ns.URDF = urdf_pkg.urdf.URDF
+    ns.Robot = rtb.Robot
     for nm in ("DHLink", "RevoluteDH", "PrismaticDH", "RevoluteMDH", "PrismaticMDH"):
         setattr(ns, nm, getattr(rtb, nm))
 

@@ -187,6 +187,28 @@ def tr2rpy(T, unit="rad", order="zyx", check=False):
     return np.degrees(rpy) if unit == "deg" else rpy
 
 
+def unitvec_norm(v, tol=20):
+    """spatialmath.base.unitvec_norm (spatialmath-python >= 1.1, base/vectors.py): (v / |v|, |v|), or (None, None) for a vector shorter than
+    tol * eps.  tools/urdf/urdf.py:1713."""
+    v = getvector(v)
+    nm = float(np.linalg.norm(v))
+    if abs(nm) > tol * np.finfo(np.float64).eps:
+        return v / nm, nm
+    return None, None
+
+
+def angvec2r(theta, v, unit="rad", tol=20):
+    """spatialmath.base.angvec2r (base/transforms3d.py): Rodrigues' formula  R = I + sin(theta) S + (1 - cos(theta)) S^2,  S = skew(v / |v|);
+    the identity for a vector shorter than tol * eps.  tools/urdf/urdf.py:1714."""
+    v = getvector(v, 3)
+    if np.linalg.norm(v) < tol * np.finfo(np.float64).eps:
+        return np.eye(3)
+    th = math.radians(theta) if unit == "deg" else float(theta)
+    x, y, z = v / np.linalg.norm(v)
+    S = np.array([[0.0, -z, y], [z, 0.0, -x], [-y, x, 0.0]])
+    return np.eye(3) + math.sin(th) * S + (1.0 - math.cos(th)) * (S @ S)
+
+
 def numjac(f, x, dx=1e-8, SO=0, SE=0):
     """spatialmath.base.numjac: forward-difference Jacobian of f at x.  f returns a vector, or -- SE=3 -- a 4x4 pose, in which case a
     column is [dt / dx ; vex(dR R^T) / dx] (the spatial velocity per unit joint rate), or -- SO=3 -- a rotation matrix."""
@@ -262,7 +284,9 @@ class SE3:
             A = np.asarray(arg)
             if A.dtype != object:
                 A = A.astype(np.float64)
-            if A.ndim == 2:
+            if A.ndim == 1 and A.size == 3:                  # SE3(t): a pure translation (tools/urdf/utils.py:30, urdf.py:1708)
+                self._data = [transl(float(A[0]), float(A[1]), float(A[2]))]
+            elif A.ndim == 2:
                 self._data = [A]
             elif A.ndim == 3:
                 self._data = list(A)
@@ -316,6 +340,11 @@ class SE3:
     def __mul__(self, other):
         if isinstance(other, SE3):
             return SE3(self.A @ other.A, check=False)
+        if isinstance(other, np.ndarray) and other.ndim == 2 and other.shape[0] == 3 and len(self._data) == 1:
+            # spatialmath BasePoseMatrix.__mul__: a pose times a (3, N) array transforms its COLUMNS as points, h2e(A @ e2h(P)).  This is what
+            # tools/urdf/urdf.py:1716 `SE3.RPY(joint.rpy) * R` (R a 3x3 ndarray) evaluates to: RPY's rotation times R (its translation is zero)
+            A = self._data[0]
+            return A[:3, :3] @ other + A[:3, 3:4]
         return NotImplemented
 
     def __imul__(self, other):
@@ -373,7 +402,8 @@ def modules():
     """(spatialmath, spatialmath.base) module objects to be placed in sys.modules while the reference files are loaded."""
     sm = types.ModuleType("spatialmath")
     smb = types.ModuleType("spatialmath.base")
-    for f in (trotx, troty, trotz, issymbol, getvector, getmatrix, verifymatrix, t2r, tr2jac, simplify, isvector, ismatrix, getunit, rot2jac, transl, islistof, tr2x, tr2rpy, numjac, numhess, trnorm):
+    for f in (trotx, troty, trotz, issymbol, getvector, getmatrix, verifymatrix, t2r, tr2jac, simplify, isvector, ismatrix, getunit, rot2jac, transl, islistof, tr2x, tr2rpy, numjac, numhess, trnorm,
+              unitvec_norm, angvec2r):
         setattr(smb, f.__name__, f)
     for name in ("tr2eul", "trlog", "trot2", "transl2", "tr2xyt", "tr2jac2", "rotvelxform", "r2x", "rotvelxform_inv_dot"):
         setattr(smb, name, _not_offered(name))

@@ -71,11 +71,17 @@ class URDFJoint:
         if norm != 0:
             self.axis = self.axis / norm          # the reference normalises when it parses (tools/urdf/urdf.py:1357-1369): its "normalising rotation" of
                                                   # a skew axis (constant() below) is therefore always by |v/|v|| = 1 radian, whatever the length written
+        # limits as the reference's reader takes them (tools/urdf/urdf.py:1391-1402, 1762-1768): a revolute or prismatic joint MUST carry a
+        # <limit> (ValueError otherwise); whatever joint has one -- a `continuous` joint too: the Mico's and the Gen3's are limited to +-2 pi this
+        # way -- gets qlim = [lower, upper].  An attribute that is missing leaves a None in the reference's array (robot.qlim then reads a
+        # revolute joint as [-pi, pi] and a prismatic one as NaN): here such a half-written limit is simply no limit.
         lim = el.find("limit")
         self.lower = self.upper = None
-        if lim is not None and self.type in ("revolute", "prismatic"):
-            self.lower = float(lim.get("lower", 0.0))
-            self.upper = float(lim.get("upper", 0.0))
+        if lim is None and self.type in ("revolute", "prismatic"):
+            raise ValueError("Require joint limit for prismatic and revolute joints")
+        if lim is not None and lim.get("lower") is not None and lim.get("upper") is not None:
+            self.lower = float(lim.get("lower"))
+            self.upper = float(lim.get("upper"))
         d = el.find("dynamics")
         self.friction = None if d is None or d.get("friction") is None else float(d.get("friction"))
         self.damping = None if d is None or d.get("damping") is None else float(d.get("damping"))
