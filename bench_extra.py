@@ -575,7 +575,7 @@ def main():
                 hold["o"] = rtbhip.p_servo(Te, Tep, method=method)
             avg, best = ev_time(servo_step, args.steps, 3)
             byts = 2 * 128 + 48
-            print(json.dumps({"metric": "pose pairs/sec (p_servo error, method %r; the gain and the arrived test are torch elementwise ops inside the timed call)" % method,
+            print(json.dumps({"metric": "pose pairs/sec (p_servo, method %r: error vector, gain and arrived flag in one launch, rtbhip_p_servo)" % method,
                               "value": N / (avg * 1e-3), "unit": "pairs/s", "n": N, "kernel_avg_ms": avg, "kernel_min_ms": best,
                               "roofline": {"bound": "hbm", "achieved": byts * N / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                            "frac": byts * N / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": byts * N,

@@ -162,6 +162,10 @@ int rtbhip_angle_axis(const double *Te, int64_t nTe, const double *Tep, int64_t 
  * The gain and the `arrived` test (p_servo.py:101-108) are one multiply and one sum over e: the caller's. */
 int rtbhip_p_servo_error(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, int32_t method, double *e, int32_t mem,
                          void *stream);
+/* tools/p_servo.py:46-117 in ONE launch: v (N,6) = diag(gain6) e with e as rtbhip_p_servo_error (method 0 angle-axis, 1 "rpy"), and
+ * arrived (N bytes, 0 / 1) = sum|e| < threshold (:113; on e, before the gain).  gain6 is a HOST array of six gains (a scalar gain: six copies). */
+int rtbhip_p_servo(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, int32_t method, const double *gain6, double threshold, double *v,
+                   uint8_t *arrived, int32_t mem, void *stream);
 
 /* Differential-kinematics consumers computed from the Jacobian while it is still in registers (SURVEY 8f-4;
  * compile-time joint counts up to 16 -- 1..8 at two waves per SIMD, 9..16 at one, the longest with some scratch):

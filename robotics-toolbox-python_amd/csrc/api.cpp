@@ -669,6 +669,37 @@ int rtbhip_p_servo_error(const double *Te, int64_t nTe, const double *Tep, int64
     return pose_error_entry(Te, nTe, Tep, nTep, method, e, mem, stream);
 }
 
+/* tools/p_servo.py:46-117 whole: v = diag(gain) e and arrived = sum|e| < threshold in the launch that forms e */
+int rtbhip_p_servo(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, int32_t method, const double *gain6, double threshold, double *v,
+                   uint8_t *arrived, int32_t mem, void *stream)
+{
+    RTB_TRACE("rtbhip_p_servo");
+    if (method != 0 && method != 1) { set_error("p_servo: method must be 0 angle-axis or 1 rpy"); return RTBHIP_EINVAL; }
+    if (mem != RTBHIP_MEM_HOST && mem != RTBHIP_MEM_DEVICE) { set_error("p_servo: bad mem kind"); return RTBHIP_EINVAL; }
+    if (nTe < 0 || nTep < 0) { set_error("p_servo: negative count"); return RTBHIP_EINVAL; }
+    if (!gain6) { set_error("p_servo: NULL gain"); return RTBHIP_EINVAL; }
+    if (nTe == 0 || nTep == 0) return RTBHIP_OK;
+    const int64_t N = nTe > nTep ? nTe : nTep;
+    if ((nTe != N && nTe != 1) || (nTep != N && nTep != 1)) { set_error("p_servo: the pose counts must be equal, or one of them 1"); return RTBHIP_EINVAL; }
+    if (!Te || !Tep || !v || !arrived) { set_error("p_servo: NULL buffer"); return RTBHIP_EINVAL; }
+    if (mem == RTBHIP_MEM_DEVICE) {
+        if (((uintptr_t)Te | (uintptr_t)Tep | (uintptr_t)v) & 15) { set_error("p_servo: device buffers must be 16-byte aligned"); return RTBHIP_EINVAL; }
+        DeviceScope dscope;
+        RTB_TRY(dscope.enter_for("p_servo", v));
+        return launch_p_servo(Te, nTe, Tep, nTep, N, method, gain6, threshold, v, arrived, (hipStream_t)stream);
+    }
+    Staging st;
+    void *dA, *dB, *dV, *dF;
+    RTB_TRY(st.in(Te, (size_t)nTe * 128, &dA));
+    RTB_TRY(st.in(Tep, (size_t)nTep * 128, &dB));
+    RTB_TRY(st.out((size_t)N * 48, &dV));
+    RTB_TRY(st.out((size_t)N, &dF));
+    RTB_TRY(launch_p_servo((const double *)dA, nTe, (const double *)dB, nTep, N, method, gain6, threshold, (double *)dV, (unsigned char *)dF, nullptr));
+    RTB_HIP(hipDeviceSynchronize());
+    RTB_TRY(fetch(v, dV, (size_t)N * 48));
+    return fetch(arrived, dF, (size_t)N);
+}
+
 static int pose_error_entry(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, int method, double *e, int32_t mem, void *stream)
 {
     if (mem != RTBHIP_MEM_HOST && mem != RTBHIP_MEM_DEVICE) { set_error("angle_axis: bad mem kind"); return RTBHIP_EINVAL; }

@@ -375,9 +375,12 @@ int launch_hess_from_jac(int n, const double *J, int64_t N, double *H, hipStream
 // pair; both tiles through LDS as contiguous runs; a broadcast operand (count 1) is read by every lane from the same
 // 128 bytes.  LDS: 64 x 17 doubles per operand, the first re-used for the 64 x 7 staging of e.
 // RPY = true: the same staging around servo_rpy_lane (p_servo's method "rpy", servo_device.h).
-template <bool RPY>
+// SERVO (compile-time): the whole of tools/p_servo.py:46-117 in this launch -- after the error vector, arrived = sum|e| < threshold (one byte per
+// pair, read before the gain touches e) and v = gain * e leaves in its place.  Before round 5 the wrapper ran two more elementwise kernels for that.
+struct ServoTail { double gain[6]; double threshold; unsigned char *arrived; };
+template <bool RPY, bool SERVO = false>
 __global__ __launch_bounds__(kWave) void k_angle_axis(const double *__restrict__ Te, int te_each, const double *__restrict__ Tep, int tep_each,
-                                                     int64_t N, double *__restrict__ e)
+                                                     int64_t N, double *__restrict__ e, ServoTail tail = ServoTail())
 {
     __shared__ __attribute__((aligned(16))) double a[kWave * kAaStride];
     __shared__ __attribute__((aligned(16))) double b[kWave * kAaStride];
@@ -395,8 +398,34 @@ __global__ __launch_bounds__(kWave) void k_angle_axis(const double *__restrict__
     __syncthreads();
     if constexpr (RPY) servo_rpy_lane(te16, tep16, a + lane * 7);
     else aa_lane(te16, tep16, a + lane * 7);
+    if constexpr (SERVO) {
+        double *mine = a + lane * 7;
+        double sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sum += fabs(mine[k]);                    // p_servo.py:113 `np.sum(np.abs(e)) < threshold`, on e itself
+#pragma unroll
+        for (int k = 0; k < 6; ++k) mine[k] = tail.gain[k] * mine[k];        // :108-111 v = k @ e (k = gain * eye(6) or diag(gain))
+        if (lane < ncfg) tail.arrived[cfg0 + lane] = sum < tail.threshold ? 1 : 0;
+    }
     __syncthreads();
     kin_flush(a, 7, 6, ncfg, e + cfg0 * 6, lane);
+}
+
+int launch_p_servo(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, int64_t N, int method, const double *gain6, double threshold, double *v,
+                   unsigned char *arrived, hipStream_t s)
+{
+    if (N == 0) return RTBHIP_OK;
+    const int64_t tiles = (N + kWave - 1) / kWave;
+    if (tiles > 0x7fffffff) { set_error("p_servo: batch too large for one launch"); return RTBHIP_ELIMIT; }
+    ServoTail t;
+    for (int k = 0; k < 6; ++k) t.gain[k] = gain6[k];
+    t.threshold = threshold; t.arrived = arrived;
+    if (method == 1) hipLaunchKernelGGL((k_angle_axis<true, true>), dim3((unsigned)tiles), dim3(kWave), 0, s, Te, nTe == N ? 1 : 0, Tep, nTep == N ? 1 : 0, N, v, t);
+    else hipLaunchKernelGGL((k_angle_axis<false, true>), dim3((unsigned)tiles), dim3(kWave), 0, s, Te, nTe == N ? 1 : 0, Tep, nTep == N ? 1 : 0, N, v, t);
+    note_launch((int)tiles, kWave, (int)(2 * kWave * kAaStride * sizeof(double)));
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return hip_fail(err, "k_angle_axis (servo) launch");
+    return RTBHIP_OK;
 }
 
 int launch_angle_axis(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, int64_t N, double *e, hipStream_t s, int method)
@@ -405,11 +434,11 @@ int launch_angle_axis(const double *Te, int64_t nTe, const double *Tep, int64_t 
     const int64_t tiles = (N + kWave - 1) / kWave;
     if (tiles > 0x7fffffff) { set_error("angle_axis: batch too large for one launch"); return RTBHIP_ELIMIT; }
     if (method == 1)
-        hipLaunchKernelGGL(k_angle_axis<true>, dim3((unsigned)tiles), dim3(kWave), 0, s, Te, nTe == N ? 1 : 0, Tep,
-                           nTep == N ? 1 : 0, N, e);
+        hipLaunchKernelGGL((k_angle_axis<true, false>), dim3((unsigned)tiles), dim3(kWave), 0, s, Te, nTe == N ? 1 : 0, Tep,
+                           nTep == N ? 1 : 0, N, e, ServoTail());
     else
-        hipLaunchKernelGGL(k_angle_axis<false>, dim3((unsigned)tiles), dim3(kWave), 0, s, Te, nTe == N ? 1 : 0, Tep,
-                           nTep == N ? 1 : 0, N, e);
+        hipLaunchKernelGGL((k_angle_axis<false, false>), dim3((unsigned)tiles), dim3(kWave), 0, s, Te, nTe == N ? 1 : 0, Tep,
+                           nTep == N ? 1 : 0, N, e, ServoTail());
     note_launch((int)tiles, kWave, (int)(2 * kWave * kAaStride * sizeof(double)));
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return hip_fail(err, "k_angle_axis launch");
@@ -679,7 +708,8 @@ int launch_kin(const Chain *c, const DevChain &ops, const double *q, int64_t N, 
     }
     if (g_use_reg && !H && c->n >= 1 && c->n <= kKinRegMax && tiles <= 0x7fffffff) {
         grid = dim3((unsigned)tiles);
-        const size_t rl = (size_t)reg_lds_doubles(c->n) * sizeof(double);
+        // fkine alone stages only the 64 x 17 pose tile (8.7 KB): with the Jacobian's 32 x (6n + 1) rounds left out of the request more waves fit a CU
+        const size_t rl = (size_t)(J ? reg_lds_doubles(c->n) : kWave * 17) * sizeof(double);
         hipError_t e = hipSuccess;
         switch (c->n) {
         case 1: e = launch_reg<1>(grid, rl, s, kp, ops, q, T, J); break;

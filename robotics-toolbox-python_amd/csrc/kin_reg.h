@@ -85,7 +85,9 @@ RTB_HD void reg_walk_step(const CV &cv, Pose &P, double (&jac)[6 * NJ], const in
         // results parked in VGPR lanes (v_writelane) until needed (v_readlane): 475 -> 251 such instructions in the kernel, 253 -> 244 VGPRs,
         // -2.4 % (config 3) ... -3.6 % (notebook setting) on one box (round 4 visit l).  RTB_PIN_SEG_LOADS = 2 pins the general (branchy) walk too.
         CV cvj = cv;
-        if ((PLAIN || RTB_PIN_SEG_LOADS > 1) && cv_has_trig<CV>::value && j > 0) asm volatile("" : "+s"(cvj.seg), "+v"(P.tx));
+        // (a signature kernel reads two or three scalars per segment instead of twelve: there the pin and every second fence only cost -- round 5
+        // visit f, three interleaved rounds: config 3 0.844 -> 0.833 ms without them, outputs bit-identical)
+        if ((PLAIN || RTB_PIN_SEG_LOADS > 1) && SIG == 0 && cv_has_trig<CV>::value && j > 0) asm volatile("" : "+s"(cvj.seg), "+v"(P.tx));
         if (j == 0) pose_from_seg(P, cvj, 0);
         else if constexpr (SIG != 0) pose_mul_seg_by_sig<SIG, J>(P, cvj);                                              // k_ik for a known robot: compile-time class
         else if constexpr (RTB_SEG_CLASSES && cv_has_trig<CV>::value) pose_mul_seg_cls(P, cvj, j, cvj.jmeta[j]);      // k_ik: by structure class (run-time switch, A/B)
@@ -106,7 +108,7 @@ RTB_HD void reg_walk_step(const CV &cv, Pose &P, double (&jac)[6 * NJ], const in
 #if defined(RTB_PLAIN_FENCE_EVERY)
         if (!PLAIN || (j % RTB_PLAIN_FENCE_EVERY) == RTB_PLAIN_FENCE_EVERY - 1) sched_fence();      // A/B: fewer fences in the straight-line walk
 #else
-        sched_fence();
+        if (SIG == 0 || (j & 1) == 1) sched_fence();
 #endif
     }
 }

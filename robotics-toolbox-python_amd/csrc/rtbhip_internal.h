@@ -169,6 +169,8 @@ int launch_kin_diff(const Chain *c, const DevChain &dc, int mode, int axes, cons
 int launch_hess_from_jac(int n, const double *J, int64_t N, double *H, hipStream_t s);
 // manipulability (mode 0; axes bits 8..9 = method) / manipulability Jacobian (mode 1: H formed from J, 2: H supplied) of supplied Jacobians (diffjac_kernels.hip)
 int launch_diff_from_jac(int mode, int n, const double *J, const double *H, int64_t N, int axes, double *out, hipStream_t s);
+int launch_p_servo(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, int64_t N, int method, const double *gain6, double threshold, double *v,
+                   unsigned char *arrived, hipStream_t s);
 int launch_angle_axis(const double *Te, int64_t nTe, const double *Tep, int64_t nTep, int64_t N, double *e, hipStream_t s, int method = 0);
 
 struct FrameTable;

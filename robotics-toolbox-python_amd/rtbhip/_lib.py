@@ -64,6 +64,7 @@ SIGNATURES = {
     "rtbhip_jacobm_from_jacobian": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp]),
     "rtbhip_angle_axis": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _vp]),
     "rtbhip_p_servo_error": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _i32, _vp]),
+    "rtbhip_p_servo": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, C.c_double, _vp, _vp, _i32, _vp]),
     "rtbhip_ik_lm": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _i32, C.c_double, _i32, _vp, C.c_double,
                                _i32, _i32, _u64, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "rtbhip_ik_lm_nullspace": (C.c_int, [_u64, _vp, _i64, _vp, _i32, _i32, C.c_double, _i32, _vp, C.c_double, _i32, _i32, _u64,

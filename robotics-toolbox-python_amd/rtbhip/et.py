@@ -161,17 +161,39 @@ def p_servo(wTe, wTep, gain=1.0, threshold=0.1, method="rpy"):
     e the error seen from the end-effector frame for method "rpy" (the reference's default: [t ; tr2rpy(order "zyx")] of
     inv(wTe) wTep) or the base-frame angle-axis error for any other method string (p_servo.py:98-99 takes that branch for
     everything that is not "rpy").  (6,), bool for one pair; (N,6), (N,) bools for stacks of poses."""
-    e = _pose_error(wTe, wTep, 1 if method == "rpy" else 0)
     k = np.asarray(gain, dtype=np.float64)
     if k.ndim not in (0, 1) or (k.ndim == 1 and k.shape[0] != 6):
         raise ValueError("gain must be a scalar or a 6-vector")
-    if is_torch(e):
+    k6 = np.ascontiguousarray(np.broadcast_to(k, (6,)), dtype=np.float64)
+    # one launch (rtbhip_p_servo): the error vector, the gain and the arrival test -- shapes and broadcasting as _pose_error
+    tm = is_torch(wTe) and wTe.is_cuda and is_torch(wTep) and wTep.is_cuda
+    def shape(T):
+        if tm:
+            _lib.note_device(T)
+            return T.reshape(-1, 4, 4).contiguous(), T.dim() == 2
+        if hasattr(T, "A") and not isinstance(T, np.ndarray) and not is_torch(T):
+            T = T.A
+        a = as_numeric(T.detach().cpu().numpy() if is_torch(T) else T, "T")
+        if a.shape[-2:] != (4, 4):
+            raise ValueError("poses must be 4x4")
+        return np.ascontiguousarray(a.reshape(-1, 4, 4)), a.ndim == 2
+    A, sa = shape(wTe)
+    B, sb = shape(wTep)
+    N = max(A.shape[0], B.shape[0])
+    if (A.shape[0] not in (1, N)) or (B.shape[0] not in (1, N)):
+        raise ValueError("Te and Tep must hold the same number of poses, or one of them a single pose")
+    v = ETS._out((N, 6), A, tm)
+    if tm:
         import torch
-        kt = torch.as_tensor(k, dtype=e.dtype, device=e.device)
-        return e * kt, e.abs().sum(dim=-1) < threshold
-    v = e * k
-    arrived = np.abs(e).sum(axis=-1) < threshold
-    return v, (bool(arrived) if e.ndim == 1 else arrived)
+        flag = torch.empty((N,), dtype=torch.uint8, device=A.device)
+    else:
+        flag = np.empty((N,), dtype=np.uint8)
+    check(lib().rtbhip_p_servo(ETS._ptr(A, tm), A.shape[0], ETS._ptr(B, tm), B.shape[0], 1 if method == "rpy" else 0, host_ptr(k6), float(threshold),
+                               ETS._ptr(v, tm), ETS._ptr(flag, tm), MEM_DEVICE if tm else MEM_HOST, ETS._stream(tm)))
+    arrived = flag.view(torch.bool) if tm else flag.astype(bool)
+    if sa and sb:
+        return v[0], bool(arrived[0])
+    return v, arrived
 
 
 class SE3Array(np.ndarray):

@@ -2,8 +2,10 @@
 (robot/IK.py:579-763, 1020-1220, 766-1017, 1222-1520) with the constructor arguments of `IKSolver.__init__` (:149-172) and
 `solve(ets, Tep, q0)` (:174-290).  In the reference `solve` runs the Python search loop around the class's `step`; here the whole
 loop -- restarts, steps, limit checks, for every target of a batch -- is one kernel (csrc/ik_kernels.hip), reached through the
-`ETS.ikine_*` method of the same flavour.  `error` (:369-401) is the batched angle-axis kernel.  `step` is not exposed: it only
-exists fused into the device loop."""
+`ETS.ikine_*` method of the same flavour.  `error` (:369-401) is the batched angle-axis kernel.  `step(ets, Tep, q)` (:994-1017 and its
+siblings) is ONE iteration of the same device code -- a call of the search kernel with ilimit = slimit = 1 and a tolerance nothing meets -- for
+one configuration or a batch.  A subclass that OVERRIDES `step` gets what the reference gives it: `solve` then runs the reference's Python
+loop (:297-367: searches, steps, wrap, joint-limit check) around the user's step on the host."""
 import numpy as np
 
 from ._lib import as_numeric, is_torch
@@ -33,8 +35,10 @@ class IKSolver:
 
     def solve(self, ets, Tep, q0=None):
         """IKSolution for one pose, or for every pose of a (N,4,4) stack / SE3 sequence (robot/IK.py:174-290)."""
+        if type(self).step is not getattr(_builtin_step_owner(type(self)), "step", None):
+            return self._solve_with_user_step(ets, Tep, q0)          # a user's own step: the reference's loop around it, on the host
         if self._flavour is None:
-            raise NotImplementedError("IKSolver is abstract: use IK_NR, IK_GN, IK_LM or IK_QP")
+            raise NotImplementedError("IKSolver is abstract: use IK_NR, IK_GN, IK_LM or IK_QP, or subclass it with a step()")
         fn = getattr(ets, self._flavour)
         return fn(Tep, q0=q0, ilimit=self.ilimit, slimit=self.slimit, tol=self.tol, mask=np.diag(self.We).copy(),
                   joint_limits=self.joint_limits, seed=self.seed, **self._extra())
@@ -49,7 +53,87 @@ class IKSolver:
         return e, (float(E) if np.ndim(E) == 0 else E)
 
     def step(self, ets, Tep, q):
-        raise NotImplementedError("the step of %s exists only fused into the device search loop (csrc/ik_device.h)" % type(self).__name__)
+        """One iteration of this solver from `q` towards `Tep`: (E, q_new) with E the error BEFORE the step, as the reference's `step`
+        (robot/IK.py:994-1017 IK_LM, :732-763 IK_NR, :1190-1220 IK_GN, :1411-1520 IK_QP).  One configuration ((n,) q, (4,4) Tep: a float and an
+        (n,) array; an ndarray q is also updated in place, as there) or a batch ((N,n), (N,4,4) or one pose for all).  Served by the device
+        search kernel asked for exactly one step: ilimit = slimit = 1, tol = 0 (no E is below it, so nothing is wrapped or limit-checked)."""
+        if self._flavour is None:
+            raise NotImplementedError("IKSolver is abstract: its subclasses supply step()")
+        Tep = Tep.A if hasattr(Tep, "A") and not isinstance(Tep, np.ndarray) and not is_torch(Tep) else Tep
+        qa = q.detach().cpu().numpy() if is_torch(q) else as_numeric(q, "q")
+        single = qa.ndim == 1
+        q2 = np.ascontiguousarray(qa.reshape(1, -1) if single else qa, dtype=np.float64)
+        T2 = np.asarray(Tep.detach().cpu().numpy() if is_torch(Tep) else Tep, dtype=np.float64)
+        if T2.ndim == 2:
+            T2 = np.broadcast_to(T2, (q2.shape[0], 4, 4))
+        sol = getattr(ets, self._flavour)(np.ascontiguousarray(T2), q0=q2, ilimit=1, slimit=1, tol=0.0, mask=np.diag(self.We).copy(), joint_limits=False,
+                                          seed=self.seed, **self._extra())
+        qn = np.asarray(sol.q, dtype=np.float64).reshape(q2.shape)
+        E = np.asarray(sol.each["residual"] if sol.each else [sol.residual], dtype=np.float64).reshape(-1)
+        if single:
+            if isinstance(q, np.ndarray) and q.dtype == np.float64:
+                q[...] = qn[0]                                   # the reference's `q[ets.jindices] += ...`
+            return float(E[0]), qn[0]
+        return E, qn
+
+    def _check_jl(self, ets, q):
+        """robot/IK.py:403-430: every joint inside its limits"""
+        ql = np.asarray(ets.qlim, dtype=np.float64)
+        return bool(np.all(q >= ql[0]) and np.all(q <= ql[1]))
+
+    def _random_q(self, ets, rng, k):
+        ql = np.asarray(ets.qlim, dtype=np.float64)
+        return rng.uniform(ql[0], ql[1], (k, ets.n))                 # robot/IK.py:432-470
+
+    def _solve_with_user_step(self, ets, Tep, q0):
+        """The reference's loop (robot/IK.py:174-367) around a subclass's own `step(ets, Tep, q) -> (E, q)`: start vectors (the caller's rows
+        first, then uniform draws inside the limits, :222-240), up to slimit searches of up to ilimit steps, a success wrapped into [-pi, pi)
+        and checked against the joint limits, numpy.linalg.LinAlgError abandoning a search.  Host-side: it is the user's Python that runs."""
+        Tep = Tep.A if hasattr(Tep, "A") and not isinstance(Tep, np.ndarray) and not is_torch(Tep) else np.asarray(Tep, dtype=np.float64)
+        rng = np.random.default_rng(self.seed)
+        if q0 is None:
+            starts = self._random_q(ets, rng, self.slimit)
+        else:
+            q0 = np.atleast_2d(np.asarray(q0, dtype=np.float64))
+            starts = np.vstack([q0, self._random_q(ets, rng, max(self.slimit - q0.shape[0], 0))]) if q0.shape[0] < self.slimit else q0
+
+        def one(T):
+            total_i, found_with_limits, linalg_error, E, q = 0, False, 0, 0.0, starts[0]
+            for search in range(self.slimit):
+                q = starts[search].copy()
+                i = 0
+                while i < self.ilimit:
+                    i += 1
+                    try:
+                        E, q = self.step(ets, T, q)
+                        q = np.asarray(q, dtype=np.float64)
+                    except np.linalg.LinAlgError:
+                        linalg_error += 1
+                        break
+                    if E < self.tol:
+                        q = (q + np.pi) % (2 * np.pi) - np.pi
+                        if not self._check_jl(ets, q) and self.joint_limits:
+                            found_with_limits = True
+                            break
+                        return IKSolution(q=q, success=True, iterations=total_i + i, searches=search + 1, residual=E, reason="Success")
+                total_i += i
+            reason = "iteration and search limit reached"
+            if linalg_error:
+                reason += ", %d numpy.LinAlgError encountered" % linalg_error
+            if found_with_limits:
+                reason += ", solution found but violates joint limits"
+            return IKSolution(q=q, success=False, iterations=total_i, searches=self.slimit, residual=E, reason=reason)
+        if Tep.ndim == 3:
+            return [one(T) for T in Tep]
+        return one(Tep)
+
+
+def _builtin_step_owner(cls):
+    """the nearest class of this module in cls's ancestry: its `step` is the built-in one (a subclass that defines its own differs from it)"""
+    for c in cls.__mro__:
+        if c.__module__ == __name__:
+            return c
+    return IKSolver
 
 
 class _NullSpace(IKSolver):

@@ -142,6 +142,22 @@ class EmuBackend:
         rc = self._gate("rtbhip_p_servo_error", (Te, nTe, Tep, nTep, method, e, mem, stream))
         return self.emu.emu_p_servo_error(Te, nTe, Tep, nTep, method, e) if rc is None else rc
 
+    def rtbhip_p_servo(self, Te, nTe, Tep, nTep, method, gain6, threshold, v, arrived, mem, stream):
+        rc = self._gate("rtbhip_p_servo", (Te, nTe, Tep, nTep, method, gain6, threshold, v, arrived, mem, stream))
+        if rc is not None:
+            return rc
+        # the kernel's tail on the replayed error vectors (k_angle_axis<.., SERVO>): arrived from e, then the gain
+        n = max(_val(nTe), _val(nTep))
+        r = self.emu.emu_p_servo_error(Te, nTe, Tep, nTep, method, v)
+        if r:
+            return r
+        e = np.ctypeslib.as_array(C.cast(v, C.POINTER(C.c_double)), shape=(n, 6))
+        f = np.ctypeslib.as_array(C.cast(arrived, C.POINTER(C.c_uint8)), shape=(n,))
+        g = np.ctypeslib.as_array(C.cast(gain6, C.POINTER(C.c_double)), shape=(6,))
+        f[:] = np.abs(e).sum(axis=1) < float(_val(threshold))
+        e *= g
+        return 0
+
     def rtbhip_jacob_dot(self, h, q, qd, N, tool, frame, Jd, mem, stream):
         rc = self._gate("rtbhip_jacob_dot", (h, q, qd, N, tool, frame, Jd, mem, stream))
         return self.emu.emu_diff(h, 0, 63, q, qd, N, tool, frame, Jd) if rc is None else rc
