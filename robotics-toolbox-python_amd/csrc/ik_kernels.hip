@@ -73,6 +73,12 @@ constexpr int kIkAuxPlain = 8;                                         // bit 3:
 //   translations on some axes, the flange Rz(-pi/4) tz(0.103) as the tail.
 constexpr SegSig kIkSigPandaETS = kSegSigPresent | seg_sig_of(0, kSegIdentity, 4) | seg_sig_of(1, kSegRxN, 0) | seg_sig_of(2, kSegRxP, 6) | seg_sig_of(3, kSegRxP, 1) |
                                   seg_sig_of(4, kSegRxN, 7) | seg_sig_of(5, kSegRxP, 0) | seg_sig_of(6, kSegRxP, 7) | seg_sig_of(7, kSegRz, 4);
+//   The same arm read from its URDF (rtb-data franka_description, to the default end effector): the constants' tiny cos(pi/2) terms fall on other entries.
+constexpr SegSig kIkSigPandaURDF = kSegSigPresent | seg_sig_of(0, kSegIdentity, 4) | seg_sig_of(1, kSegRxN, 0) | seg_sig_of(2, kSegRxP, 2) | seg_sig_of(3, kSegRxP, 1) |
+                                   seg_sig_of(4, kSegRxN, 3) | seg_sig_of(5, kSegRxP, 0) | seg_sig_of(6, kSegRxP, 1) | seg_sig_of(7, kSegRz, 4);
+//   Universal Robots UR3 / UR5 / UR10 from their URDFs (ur_description, to tool0): six joints, one signature for the three sizes.
+constexpr SegSig kIkSigUR = kSegSigPresent | seg_sig_of(0, kSegIdentity, 4) | seg_sig_of(1, kSegGeneral, 2) | seg_sig_of(2, kSegIdentity, 5) | seg_sig_of(3, kSegRzP, 1) |
+                            seg_sig_of(4, kSegPermA, 4) | seg_sig_of(5, kSegPermB, 4) | seg_sig_of(6, kSegGeneral, 4);
 static int g_ik_sig = 1;          // rtbhip_tune("ik_sig", 0): never take a signature's instantiation (A/B, tests)
 template <int NJ, int STEP, int AUX = 0, SegSig SIG = 0>
 __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull) ? RTB_IK_WAVES : 1)) void k_ik(IkDev p, DevChain dc, const double *qlim_g, const double *__restrict__ Tep,
@@ -585,13 +591,23 @@ static void launch_nj(dim3 grid, hipStream_t s, const IkDev &p, const DevChain &
         // the default mask (all ones) has its own instantiations for the arms the register-resident kernel serves: no products with the weights
         if (p.unit_we && !stats) {
             if (p.pad_we /* plain chain */ && g_ik_plain) {
+                // a known robot: the walk specialised to its constants' structure
+#define RTB_IK_SIG_LAUNCH(SIG)                                                                                                                          \
+    if (g_ik_sig && chain_sig == SIG) {                                                                                                                 \
+        if (flat) hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxFlat | kIkAuxUnitW | kIkAuxPlain, SIG>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr,   \
+                                     q_out, success, iters, searches, residual, work, count, share);                                                   \
+        else hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxUnitW | kIkAuxPlain, SIG>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success,     \
+                                iters, searches, residual, work, count, share);                                                                        \
+        return;                                                                                                                                         \
+    }
                 if constexpr (NJ == 7) {
-                    if (g_ik_sig && chain_sig == kIkSigPandaETS) {       // a known robot: the walk specialised to its constants' structure
-                        if (flat) hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxFlat | kIkAuxUnitW | kIkAuxPlain, kIkSigPandaETS>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share);
-                        else hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxUnitW | kIkAuxPlain, kIkSigPandaETS>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share);
-                        return;
-                    }
+                    RTB_IK_SIG_LAUNCH(kIkSigPandaETS)
+                    RTB_IK_SIG_LAUNCH(kIkSigPandaURDF)
                 }
+                if constexpr (NJ == 6) {
+                    RTB_IK_SIG_LAUNCH(kIkSigUR)
+                }
+#undef RTB_IK_SIG_LAUNCH
                 if (flat) hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxFlat | kIkAuxUnitW | kIkAuxPlain>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share);
                 else hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxUnitW | kIkAuxPlain>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share);
                 return;

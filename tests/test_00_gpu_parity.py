@@ -712,6 +712,21 @@ def test_ik_structure_signature_kernel_returns_the_general_kernel_s_bits():
         for x, y in zip(a, b):
             nt.assert_array_equal(np.asarray(x), np.asarray(y))
     assert 0.9 < np.asarray(outs[1][0][1]).mean() <= 1.0          # (under the CPU replay the sample is 200 targets: all may succeed)
+    # the other robots with an instantiation: the Panda read from its URDF, a UR5 (six joints)
+    for robot, end in (("Panda", None), ("UR5", "tool0")):
+        e = urdf.load(robot).ets(end=end)
+        lim = np.clip(e.qlim, -2.8, 2.8)
+        T = np.asarray(e.eval(np.random.default_rng(93).uniform(lim[0], lim[1], (min(N, 4000), e.n))))
+        res = {}
+        try:
+            for sig in (1, 0):
+                rtbhip.tune("ik_sig", sig)
+                res[sig] = e.ik_LM(T, seed=6)
+        finally:
+            rtbhip.tune("ik_sig", 1)
+        for x, y in zip(res[1], res[0]):
+            nt.assert_array_equal(np.asarray(x), np.asarray(y))
+        assert np.asarray(res[1][1]).mean() > 0.8
 
 
 @pytest.mark.parametrize("shape", ["six revolute", "seven with a flipped joint", "six with a prismatic joint", "eight revolute", "five revolute"])

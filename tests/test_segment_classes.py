@@ -115,3 +115,29 @@ def test_random_robots_fkine_through_the_ik_walk_equals_the_oracle():
                     assert (o[1], o[2], o[3]) == (ok[i], it[i], se[i]), (trial, i)
                     np.testing.assert_allclose(q[i], o[0], atol=1e-6)
             assert checked >= 10, (trial, checked)
+
+
+def test_signatures_k_ik_is_instantiated_for_are_those_robots_signatures():
+    """csrc/ik_kernels.hip: kIkSigPandaETS (also the DH Panda lowered to an ETS), kIkSigPandaURDF, kIkSigUR -- read from the source, compared with what
+    the chain compiler computes for the robots they are named after (a constant that drifts from its robot would silently fall back to the general kernel)"""
+    import os, re
+    import cpu_backend
+    from rtbhip import urdf
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "robotics-toolbox-python_amd", "csrc", "ik_kernels.hip")).read()
+    cls = {"kSeg" + n[0].upper() + n[1:]: i for i, n in enumerate(NAMES)}
+    cls.update({"kSegPermA": 11, "kSegPermB": 12})
+
+    def constant(name):
+        body = re.search(r"constexpr SegSig %s = (.*?);" % name, src, re.S).group(1)
+        sig = 1 << 63
+        for j, c, tm in re.findall(r"seg_sig_of\((\d+), (kSeg\w+), (\d+)\)", body):
+            sig |= (cls[c] | (int(tm) << 4)) << (7 * int(j))
+        return sig
+    with cpu_backend.installed():
+        lib = emu_harness.lib()
+        robots = {"kIkSigPandaETS": [rtbhip.models.Panda().ets(), rtbhip.models.DH.Panda().ets()],
+                  "kIkSigPandaURDF": [urdf.load("Panda").ets()],
+                  "kIkSigUR": [urdf.load(n).ets(end="tool0") for n in ("UR3", "UR5", "UR10")]}
+        for name, chains_ in robots.items():
+            for e in chains_:
+                assert lib.emu_chain_signature(C.c_uint64(e._handle())) == constant(name), name
