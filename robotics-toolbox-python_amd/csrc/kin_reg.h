@@ -66,6 +66,9 @@ inline SegSig chain_signature(const int32_t *jmeta, int n)      // host: from th
 }
 template <SegSig SIG, int J, class CV>
 RTB_HD void pose_mul_seg_by_sig(Pose &P, const CV &cv) { pose_mul_seg_sig<seg_sig_cls(SIG, J), seg_sig_tm(SIG, J)>(P, cv, J); }
+#ifndef RTB_SIG_KEEP_PINS
+#define RTB_SIG_KEEP_PINS 0    // 1: signature kernels keep the load pins and every fence of the general plain walk (A/B)
+#endif
 #ifndef RTB_PIN_SEG_LOADS
 #define RTB_PIN_SEG_LOADS 1
 #endif
@@ -87,7 +90,7 @@ RTB_HD void reg_walk_step(const CV &cv, Pose &P, double (&jac)[6 * NJ], const in
         CV cvj = cv;
         // (a signature kernel reads two or three scalars per segment instead of twelve: there the pin and every second fence only cost -- round 5
         // visit f, three interleaved rounds: config 3 0.844 -> 0.833 ms without them, outputs bit-identical)
-        if ((PLAIN || RTB_PIN_SEG_LOADS > 1) && SIG == 0 && cv_has_trig<CV>::value && j > 0) asm volatile("" : "+s"(cvj.seg), "+v"(P.tx));
+        if ((PLAIN || RTB_PIN_SEG_LOADS > 1) && (SIG == 0 || RTB_SIG_KEEP_PINS) && cv_has_trig<CV>::value && j > 0) asm volatile("" : "+s"(cvj.seg), "+v"(P.tx));
         if (j == 0) pose_from_seg(P, cvj, 0);
         else if constexpr (SIG != 0) pose_mul_seg_by_sig<SIG, J>(P, cvj);                                              // k_ik for a known robot: compile-time class
         else if constexpr (RTB_SEG_CLASSES && cv_has_trig<CV>::value) pose_mul_seg_cls(P, cvj, j, cvj.jmeta[j]);      // k_ik: by structure class (run-time switch, A/B)
@@ -108,7 +111,7 @@ RTB_HD void reg_walk_step(const CV &cv, Pose &P, double (&jac)[6 * NJ], const in
 #if defined(RTB_PLAIN_FENCE_EVERY)
         if (!PLAIN || (j % RTB_PLAIN_FENCE_EVERY) == RTB_PLAIN_FENCE_EVERY - 1) sched_fence();      // A/B: fewer fences in the straight-line walk
 #else
-        if (SIG == 0 || (j & 1) == 1) sched_fence();
+        if (SIG == 0 || RTB_SIG_KEEP_PINS || (j & 1) == 1) sched_fence();
 #endif
     }
 }

@@ -267,3 +267,17 @@ extern "C" unsigned long long emu_chain_signature(rtbhip_chain_t h)
     Chain *c = c_owner.get();
     return c ? chain_signature(c->jmeta.data(), c->n) : 0ull;
 }
+
+// the folded constant segments of a chain (n + 1 rows of 12 doubles: R row-major, t) and their descriptor words -- for probes and tests
+extern "C" int emu_chain_segments(rtbhip_chain_t h, double *seg12, int32_t *jmeta)
+{
+    const std::shared_ptr<Chain> c_owner = chain_from_handle(h);
+    Chain *c = c_owner.get();
+    if (!c) return -1;
+    for (int j = 0; j <= c->n; ++j) {
+        for (int k = 0; k < 9; ++k) seg12[12 * j + k] = c->seg[j].r[k];
+        for (int k = 0; k < 3; ++k) seg12[12 * j + 9 + k] = c->seg[j].t[k];
+        jmeta[j] = c->jmeta[j];
+    }
+    return c->n;
+}
