@@ -195,7 +195,7 @@ def main():
                              "frac": 224.0 * N / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": 224 * N,
                              "kernel": "k_rne<7,MDH,all-revolute> on rank 0's rows"}}
         if N == 1250000:        # the committed PMC passes are of this shard size
-            tr, src = pmc_traffic(ROOT, "r03_pmc_rne.json")
+            tr, src = pmc_traffic(ROOT, "r05_pmc_rne.json")
             line["roofline"]["traffic"], line["roofline"]["traffic_source"] = tr, src
         if world > 1:
             line["gather_ms"] = rk.gather_ms(hold["tau"], rows=N)      # to rank 0; ragged shards go straight into place (RCCL) / padded (gloo hook)

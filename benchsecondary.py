@@ -218,9 +218,9 @@ def fleet_config5(rtbhip, N=1000000, sample=4000):
     """BASELINE configs[4] in full: the 16 supplied URDF arms, N configurations each, q ~ U(qlim) (device generator, seed 4 + i), ONE
     variable-length-chain call for all of them -- with YuMi as what it is, ONE 14-DOF dual-arm robot: its two arms (7 joints + a finger each)
     are two chains that read the SAME (N, 18) robot-wide q array (the reference evaluates a branch on the robot's q: Robot.jacob0(q, end=...),
-    robot/Robot.py:1974-1981), so the call walks 17 chains of 16 robots and the robots span 4..14 DOF.  Timed in the packed layout
-    (rtbhip_fleet_fkine_jacob_packed: one [T | J] array per chain) and in the two-array layout; the 16-chain form of rounds 1-4 (YuMi as one
-    8-joint branch) is kept beside it.  Parity: the first `sample` rows of EVERY chain through the reference's compiled ETS_fkine / ETS_jacob0."""
+    robot/Robot.py:1974-1981), so the call walks 17 chains of 16 robots and the robots span 4..14 DOF.  Timed in the two-array layout (the faster
+    one: profiles/r05_layout.txt) and in the packed layout (rtbhip_fleet_fkine_jacob_packed: one [T | J] array per chain; its rows must equal the
+    two-array form's bit for bit); the 16-chain form of rounds 1-4 (YuMi as one 8-joint branch) is kept beside it.  Parity: the first `sample` rows of EVERY chain through the reference's compiled ETS_fkine / ETS_jacob0."""
     import numpy as np
     import torch
     from rtbhip import urdf
@@ -244,27 +244,35 @@ def fleet_config5(rtbhip, N=1000000, sample=4000):
     chs17, qs17 = chs16[:-1] + arms, qs16[:-1] + [qy, qy]
     torch.cuda.empty_cache()
 
-    def measure(chs, qs):
-        """sustained ms of the call in both layouts on preallocated outputs; returns (ms_packed, ms_two, packed rows)"""
-        hold = {"two": rtbhip.fleet_fkine_jacob(chs, qs)}
-
-        def two():
-            rtbhip.fleet_fkine_jacob(chs, qs, out=hold["two"])
-        two()
-        ms_two, reps2, warm2 = sustained_ms(two)
-        del hold["two"]
-        torch.cuda.empty_cache()
-        hold["packed"] = rtbhip.fleet_fkine_jacob_packed(chs, qs)
+    def measure(chs, qs, keep=False):
+        """sustained ms of the call in both layouts on preallocated outputs; returns (ms_two, ms_packed, the two-array outputs' first `sample` rows
+        re-packed as [T | J] on the host when keep, timed-launch counts)"""
+        hold = {"packed": rtbhip.fleet_fkine_jacob_packed(chs, qs)}
 
         def pk():
             rtbhip.fleet_fkine_jacob_packed(chs, qs, out=hold["packed"])
         pk()
-        ms_p, reps, warm = sustained_ms(pk)
-        return ms_p, ms_two, hold["packed"], reps, warm
-    ms16, ms16_two, rows16, _, _ = measure(chs16, qs16)
-    del rows16
+        ms_p, _, _ = sustained_ms(pk)
+        head_p = [x[:min(sample, N)].cpu().numpy() for x in hold["packed"]] if keep else None
+        del hold["packed"]
+        torch.cuda.empty_cache()
+        hold["two"] = rtbhip.fleet_fkine_jacob(chs, qs)
+
+        def two():
+            rtbhip.fleet_fkine_jacob(chs, qs, out=hold["two"])
+        two()
+        ms_two, reps, warm = sustained_ms(two)
+        head = None
+        if keep:
+            n_ = min(sample, N)
+            head = [np.concatenate([T[:n_].reshape(n_, 16).cpu().numpy(), J[:n_].reshape(n_, -1).cpu().numpy()], axis=1) for T, J in zip(*hold["two"])]
+            for a, b in zip(head, head_p):
+                if not np.array_equal(a, b):
+                    raise SystemExit("bench: the packed fleet rows differ from the two-array form")
+        return ms_two, ms_p, head, reps, warm
+    ms16, ms16_packed, _, _, _ = measure(chs16, qs16)
     torch.cuda.empty_cache()
-    ms, ms_two, rows, reps, warm = measure(chs17, qs17)
+    ms, ms_packed, rows, reps, warm = measure(chs17, qs17, keep=True)
     byts16 = sum(N * (8 * c.n + 128 + 48 * c.n) for c in chs16)
     byts = sum(N * (8 * c.n + 128 + 48 * c.n) for c in chs16[:-1]) + N * (8 * yumi.n + sum(128 + 48 * a.n for a in arms))     # YuMi's q row is read once per arm chain but is ONE array: priced once
     err, cpu_s, kind = 0.0, 0.0, None
@@ -279,7 +287,7 @@ def fleet_config5(rtbhip, N=1000000, sample=4000):
         t0 = time.perf_counter()
         Tc, Jc = fk(qh), jc(qh)
         cpu_s += time.perf_counter() - t0
-        got = TJ[:n].cpu().numpy()
+        got = TJ[:n]
         e = max(float(np.abs(got[:, :16].reshape(n, 4, 4) - Tc).max()), float(np.abs(got[:, 16:].reshape(n, 6, c.n) - Jc).max()))
         per_chain[nm] = e
         err = max(err, e)
@@ -288,20 +296,21 @@ def fleet_config5(rtbhip, N=1000000, sample=4000):
     dof = {nm: int(c.n) for nm, c in zip(urdf.FLEET16[:-1], chs16[:-1])}
     dof["YuMi"] = 14
     out = {"workload": "BASELINE configs[4]: 16 URDF arms x %d configurations (4..14 DOF; YuMi as ONE 14-DOF dual-arm robot: two 8-joint chains -- 7 arm joints + a finger "
-                       "each -- reading its %d-column q), q ~ U(qlim) (device generator seed 4+i), fkine + jacob0 of every chain, ONE call (17 chains), packed [T | J] rows" % (N, yumi.n),
+                       "each -- reading its %d-column q), q ~ U(qlim) (device generator seed 4+i), fkine + jacob0 of every chain, ONE call (17 chains)" % (N, yumi.n),
            "value": N * 16 / (ms * 1e-3), "unit": "robot configurations/s", "n": N * 16, "chains": 17, "chain_evaluations_per_s": N * 17 / (ms * 1e-3),
-           "kernel_avg_ms": ms, "layout": "packed", "two_array_layout_ms": ms_two, "launches_timed": reps, "launches_warmup": warm,
+           "kernel_avg_ms": ms, "layout": "two arrays per chain (T, J0)", "packed_layout_ms": ms_packed, "packed_rows_equal_two_arrays": True,
+           "launches_timed": reps, "launches_warmup": warm,
            "arms": dof, "chain_joints": {nm: int(c.n) for nm, c in zip(names, chs17)},
            "parity": {"against": "ETS_fkine + per-row ETS_jacob0 of the reference's compiled fknm (oracle/_ref)" if kind == "reference" else "oracle/liboracle.so",
                       "sample": "the first %d configurations of each of the 17 chains (YuMi's two arms on the columns of its robot-wide q)" % n,
                       "max_abs_err": err, "max_abs_err_yumi_arms": max(per_chain[k] for k in per_chain if k.startswith("YuMi:")), "tolerance": 1e-10,
                       "cpu_seconds": cpu_s, "cpu_configurations_per_s": n * 17 / cpu_s},
-           "roofline": _hbm(byts, ms, "k_fleet<0,packed> + k_fleet<1,packed> (one call, two launches: chains of up to 8 joints / beyond)"),
+           "roofline": _hbm(byts, ms, "k_fleet<0> + k_fleet<1> (one call, two launches: chains of up to 8 joints / beyond)"),
            "sixteen_chain_form": {"what": "rounds 1-4's form: YuMi as one 8-joint branch with path-local q (16 chains, 4..10 joints)", "n": N * 16,
-                                  "kernel_avg_ms": ms16, "two_array_layout_ms": ms16_two, "value": N * 16 / (ms16 * 1e-3),
-                                  "roofline": _hbm(byts16, ms16, "k_fleet<0,packed> + k_fleet<1,packed>"),
-                                  "roofline_two_arrays": _hbm(byts16, ms16_two, "k_fleet<0> + k_fleet<1>")}}
-    out["roofline"]["two_array_layout_frac"] = byts / (ms_two * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                  "kernel_avg_ms": ms16, "packed_layout_ms": ms16_packed, "value": N * 16 / (ms16 * 1e-3),
+                                  "roofline": _hbm(byts16, ms16, "k_fleet<0> + k_fleet<1>"),
+                                  "roofline_packed": _hbm(byts16, ms16_packed, "k_fleet<0,packed> + k_fleet<1,packed>")}}
+    out["roofline"]["packed_layout_frac"] = byts / (ms_packed * 1e-3) / 1e9 / HBM_PEAK_GBS
     del rows, qs16, qs17, qy
     torch.cuda.empty_cache()
     return out

@@ -11,7 +11,7 @@ try:
             print("  layout", k, {a: round(b, 4) for a, b in v.items()})
     for k, v in d.get("secondary", {}).items():
         if isinstance(v, dict):
-            print(k, {a: (round(b, 5) if isinstance(b, float) else b) for a, b in v.items() if a in ("value", "kernel_avg_ms", "two_array_layout_ms", "seconds", "error", "success_rate")},
+            print(k, {a: (round(b, 5) if isinstance(b, float) else b) for a, b in v.items() if a in ("value", "kernel_avg_ms", "packed_layout_ms", "seconds", "error", "success_rate")},
                   "frac=%.3f" % v["roofline"]["frac"] if "roofline" in v else "", v.get("parity") if not isinstance(v.get("parity"), str) else "")
         else:
             print(k, v)

@@ -287,5 +287,5 @@ def test_bench_single_gpu_line_carries_the_contract_objects():
     assert fleet["n"] == 16000000 and fleet["parity"]["max_abs_err"] <= 1e-10 and len(fleet["arms"]) == 16
     # the FULL config 5: 17 chains of 16 robots, YuMi as the 14-DOF dual-arm robot on its 18-column q; 4..14 DOF; the 16-chain form beside it
     assert fleet["chains"] == 17 and fleet["arms"]["YuMi"] == 14 and min(fleet["arms"].values()) == 4 and max(fleet["arms"].values()) == 14
-    assert fleet["parity"]["max_abs_err_yumi_arms"] <= 1e-10 and fleet["layout"] == "packed" and fleet["two_array_layout_ms"] > 0
+    assert fleet["parity"]["max_abs_err_yumi_arms"] <= 1e-10 and fleet["packed_layout_ms"] > 0 and fleet["packed_rows_equal_two_arrays"] is True
     assert fleet["sixteen_chain_form"]["kernel_avg_ms"] > 0 and 0.0 < fleet["sixteen_chain_form"]["roofline"]["frac"] < 1.0
