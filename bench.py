@@ -260,26 +260,8 @@ def main():
                            "configuration, no arithmetic",
                  "ms": pms, "GBs": moved / (pms * 1e-3) / 1e9}
         del dst
-    # every rank's device identity and its own step / kernel times (the line answers "did N ranks drive N GPUs?" by itself)
-    per_rank = rk.identities(ms_per_step_own=rk.last_own_elapsed / args.steps * 1e3, kernel_avg_ms=kern_avg_ms) if rk.dist is not None else None
-    # the one exchange of the path, outside the timed region: the ranks' T||J rows to rank 0 (and, beside it, to every rank).  With the packed
-    # layout the rows ARE the kernel's output; with two arrays one more packed launch makes them (no torch.cat copy either way).
-    gather_ms, gather_mem = None, None
-    if rk.dist is not None:
-        if packed:
-            rows = TJ
-        else:
-            (rows,), go = make_outputs("packed")
-            go()
-        torch.cuda.synchronize()
-        before = torch.cuda.memory_allocated()
-        gather_ms = rk.gather_ms(rows)                    # allocates its N_total x 58 receive buffers inside, releases them on return
-        gather_mem = dict(rk.last_gather, device_bytes_before=before, device_bytes_after=torch.cuda.memory_allocated(),
-                          where="after the timed region of `value`, released before cpu_baseline / secondary")
-        if not packed:
-            del rows
-
-    if rank == 0:
+    line = None
+    if rank == 0:                                   # the line is complete BEFORE the exchange below is tried (see the watchdog)
         achieved = BYTES_PER_CONFIG * N / (kern_avg_ms * 1e-3) / 1e9
         traffic, traffic_source = None, None
         for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):       # the latest committed PMC passes of this command
@@ -327,6 +309,46 @@ def main():
             line["roofline"]["stream_probe"] = probe
         if rk.shared:
             line["config"]["devices_shared"] = True   # gloo test hook: more ranks than GPUs, NOT a scaling measurement
+    # every rank's device identity and its own step / kernel times (the line answers "did N ranks drive N GPUs?" by itself)
+    # Watchdog: the exchange below is the one part of a multi-rank run that no single-GPU box can rehearse at N > 1 (RCCL over xGMI).  If it has
+    # not come back after RTBHIP_BENCH_GATHER_TIMEOUT seconds (default 180) rank 0 prints the line it already holds -- `value`, the roofline --
+    # with the reason in place of the gather figures, and every rank leaves: a stuck collective must not cost the run its measurement.
+    watchdog = None
+    if rk.dist is not None and world > 1:
+        import threading
+
+        def give_up():
+            if rank == 0:
+                line["gather"] = "NOT MEASURED: the rank identities / output gather did not complete within %s s (watchdog)" % os.environ.get("RTBHIP_BENCH_GATHER_TIMEOUT", "180")
+                print(json.dumps(line), flush=True)
+            sys.stdout.flush()
+            os._exit(0)
+        watchdog = threading.Timer(float(os.environ.get("RTBHIP_BENCH_GATHER_TIMEOUT", "180")), give_up)
+        watchdog.daemon = True
+        watchdog.start()
+    if os.environ.get("RTBHIP_BENCH_TEST_STALL") and world > 1:       # TEST HOOK (tests/test_dist_gpu.py; never set by the driver): the exchange hangs
+        time.sleep(float(os.environ["RTBHIP_BENCH_TEST_STALL"]))
+    per_rank = rk.identities(ms_per_step_own=rk.last_own_elapsed / args.steps * 1e3, kernel_avg_ms=kern_avg_ms) if rk.dist is not None else None
+    # the one exchange of the path, outside the timed region: the ranks' T||J rows to rank 0 (and, beside it, to every rank).  With the packed
+    # layout the rows ARE the kernel's output; with two arrays one more packed launch makes them (no torch.cat copy either way).
+    gather_ms, gather_mem = None, None
+    if rk.dist is not None:
+        if packed:
+            rows = TJ
+        else:
+            (rows,), go = make_outputs("packed")
+            go()
+        torch.cuda.synchronize()
+        before = torch.cuda.memory_allocated()
+        gather_ms = rk.gather_ms(rows)                    # allocates its N_total x 58 receive buffers inside, releases them on return
+        gather_mem = dict(rk.last_gather, device_bytes_before=before, device_bytes_after=torch.cuda.memory_allocated(),
+                          where="after the timed region of `value`, released before cpu_baseline / secondary")
+        if not packed:
+            del rows
+    if watchdog is not None:
+        watchdog.cancel()
+
+    if rank == 0:
         if per_rank is not None:
             line["ranks"] = per_rank
             line["world"] = {"launcher": world, "process_group": rk.dist.get_world_size(), "backend": rk.backend,

@@ -8,6 +8,7 @@ import json
 import os
 import socket
 import subprocess
+import time
 import sys
 
 import numpy as np
@@ -226,6 +227,25 @@ def test_bench_eight_ranks_sharing_the_gpu():
     assert rne["n_gpus"] == 8 and rne["n"] == 400003 and rne["rows_rank0"] == 50001 and rne["gather_ms"] > 0
     assert ik["n_gpus"] == 8 and ik["n"] == 40003 and ik["rows_rank0"] == 5001 and 0.97 < ik["success_rate"] <= 1.0
     assert fleet["n_gpus"] == 8 and len(fleet["arms"]) == 16
+
+
+def test_bench_watchdog_keeps_the_measurement_when_the_exchange_hangs():
+    """The output gather is the one part of `bench.py --gpus N` a single-GPU box cannot rehearse at N > 1 over RCCL.  If it never comes back, rank 0
+    prints the line it already holds -- value, roofline -- with the reason in place of the gather figures, and all ranks leave (exit 0).
+    Here: two ranks on the gloo hook, the exchange stalled by the test hook for longer than a 2 s watchdog."""
+    env = dict(os.environ, RTBHIP_BENCH_BACKEND="gloo", RTBHIP_BENCH_TEST_STALL="30", RTBHIP_BENCH_GATHER_TIMEOUT="2")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--n", "100000", "--no-cpu"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert time.time() - t0 < 120
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["value"] > 0 and 0 < d["roofline"]["frac"] < 1 and "gather_ms" not in d
+    assert d["gather"].startswith("NOT MEASURED") and "watchdog" in d["gather"]
 
 
 def test_bench_gpus_8_on_a_smaller_box_fails_with_one_clear_line():
