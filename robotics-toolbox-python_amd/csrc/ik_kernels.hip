@@ -57,6 +57,9 @@ constexpr int kIkNullMax = 12;   // null-space step variants: 6..8 joints in reg
 #ifndef RTB_IK_WAVES
 #define RTB_IK_WAVES 2
 #endif
+#ifndef RTB_IK_PASS_LOW
+#define RTB_IK_PASS_LOW -1      // >= 0: a wave with at most this many running lanes passes at every iteration in which a search has ended (A/B, round 5)
+#endif
 #ifndef RTB_IK_SHARE
 #define RTB_IK_SHARE 1          // 0: build without the cross-wave sharing code (A/B of what its presence costs the plain schedule)
 #endif
@@ -137,7 +140,14 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
         // the scheduling pass runs when some search has ended -- at most every (pass_mask + 1)-th iteration: a
         // finished lane then idles for up to pass_mask iterations (of ~31 per search) and the pass, several
         // hundred mostly scalar / LDS instructions, is amortised over more useful iterations
+#if RTB_IK_PASS_LOW >= 0
+        // ... and at ANY iteration once at most RTB_IK_PASS_LOW lanes of the wave still run a search: the pass then costs less than the lanes it refills
+        // (0: only when nothing runs at all -- the iterations a wave would otherwise burn waiting for its pass slot)
+        const bool pass_slot = (tick++ & ka->p.pass_mask) == 0 || __popcll(__ballot(st.status == kIkRun && !st.fin)) <= RTB_IK_PASS_LOW;
+        if (first || (pass_slot && __any(st.fin != 0))) {
+#else
         if (first || ((tick++ & ka->p.pass_mask) == 0 && __any(st.fin != 0))) {
+#endif
             first = false;
             if constexpr (kStats) ++st_passes;
             unsigned long long busy = ws_get64(ws.busy), pool_next = ws_get64(ws.pool_next), pool_end = ws_get64(ws.pool_end), pool_live = ws_get64(ws.pool_live);

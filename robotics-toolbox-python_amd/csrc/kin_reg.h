@@ -88,8 +88,8 @@ RTB_HD void reg_walk_step(const CV &cv, Pose &P, double (&jac)[6 * NJ], const in
         // results parked in VGPR lanes (v_writelane) until needed (v_readlane): 475 -> 251 such instructions in the kernel, 253 -> 244 VGPRs,
         // -2.4 % (config 3) ... -3.6 % (notebook setting) on one box (round 4 visit l).  RTB_PIN_SEG_LOADS = 2 pins the general (branchy) walk too.
         CV cvj = cv;
-        // (a signature kernel reads two or three scalars per segment instead of twelve: there the pin and every second fence only cost -- round 5
-        // visit f, three interleaved rounds: config 3 0.844 -> 0.833 ms without them, outputs bit-identical)
+        // (a signature kernel reads two or three scalars per segment instead of twelve: there the pin and the fences only cost -- round 5
+        // visits f, k, three interleaved rounds each: config 3 0.844 -> 0.833 -> 0.830 ms without them, outputs bit-identical)
         if ((PLAIN || RTB_PIN_SEG_LOADS > 1) && (SIG == 0 || RTB_SIG_KEEP_PINS) && cv_has_trig<CV>::value && j > 0) asm volatile("" : "+s"(cvj.seg), "+v"(P.tx));
         if (j == 0) pose_from_seg(P, cvj, 0);
         else if constexpr (SIG != 0) pose_mul_seg_by_sig<SIG, J>(P, cvj);                                              // k_ik for a known robot: compile-time class
@@ -111,7 +111,7 @@ RTB_HD void reg_walk_step(const CV &cv, Pose &P, double (&jac)[6 * NJ], const in
 #if defined(RTB_PLAIN_FENCE_EVERY)
         if (!PLAIN || (j % RTB_PLAIN_FENCE_EVERY) == RTB_PLAIN_FENCE_EVERY - 1) sched_fence();      // A/B: fewer fences in the straight-line walk
 #else
-        if (SIG == 0 || RTB_SIG_KEEP_PINS || (j & 1) == 1) sched_fence();
+        if (SIG == 0 || RTB_SIG_KEEP_PINS) sched_fence();          // (signature kernels: no fence -- visit k: 0.8337 -> 0.8302 ms, every second one 0.8337)
 #endif
     }
 }
