@@ -101,6 +101,34 @@ class EmuBackend:
             self.emu.emu_ik_target_base(_val(base))
         return rc
 
+    # ------------------------------------------------------------------ the sharded path's one exchange (csrc/shard.cpp) -- REPLAY ONLY, a world of one:
+    # the real entry points' argument checks first; the communicator is a token, the "gather" the copy a single rank's exchange is
+    def rtbhip_shard_comm_id(self, buf):
+        C.memset(buf, 0x5a, 128)
+        return 0
+
+    def rtbhip_shard_comm_create(self, id128, world, rank, out):
+        if _val(world) != 1 or _val(rank) != 0:
+            raise L.RtbHipError("tests/cpu_backend.py replays a world of one rank only")
+        out._obj.value = 0x1234
+        return 0
+
+    def rtbhip_shard_comm_destroy(self, comm):
+        return 0
+
+    def rtbhip_shard_comm_info(self, comm, w, r, v):
+        for ref, val in ((w, 1), (r, 0), (v, 22000)):
+            if ref:
+                ref._obj.value = val
+        return 0
+
+    def rtbhip_shard_gather(self, comm, local, rows, row_bytes, N, world, rank, root, out, stream):
+        rc = self.emu.rtbhip_shard_gather(None, local, rows, row_bytes, N, world, rank, root, out, stream)      # the real checks (comm = NULL: allowed for one rank)
+        if rc == EHIP:                                                                                        # ... which then stop at the device copy
+            C.memmove(out, local, _val(N) * _val(row_bytes))
+            return 0
+        return rc
+
     # ------------------------------------------------------------------ kinematics
     def rtbhip_fkine(self, h, q, N, base, tool, T, mem, stream):
         rc = self._gate("rtbhip_fkine", (h, q, N, base, tool, T, mem, stream))
