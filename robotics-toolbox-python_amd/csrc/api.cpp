@@ -379,6 +379,7 @@ void ik_release_device_state();
 int ik_prepare_device();
 void hostpipe_tune(const char *key, int value);
 void shard_tune(const char *key, int value);
+void tree_tune(const char *key, int value);
 
 }  // namespace rtbhip
 
@@ -1338,6 +1339,7 @@ int rtbhip_tune(const char *key, int32_t value)
     if (std::string(key) == "rne_pszero") g_rne_pszero = value != 0;
     hostpipe_tune(key, value);
     shard_tune(key, value);
+    tree_tune(key, value);
     return RTBHIP_OK;
 }
 

@@ -74,6 +74,8 @@ DevSeg perm_transpose_seg(const int perm[3])
     return O;
 }
 
+}  // namespace
+
 // structure class + translation mask of a folded constant (rtbhip_internal.h: kSeg*), from its EXACT zeros and ones
 int seg_class_bits(const DevSeg &a)
 {
@@ -92,8 +94,6 @@ int seg_class_bits(const DevSeg &a)
     const int tm = (a.t[0] != 0.0 ? 1 : 0) | (a.t[1] != 0.0 ? 2 : 0) | (a.t[2] != 0.0 ? 4 : 0);
     return (cls << 20) | (tm << 24);
 }
-
-}  // namespace
 
 int compile_chain(const rtbhip_et *ets, int m, const double *qlim, Chain *out)
 {

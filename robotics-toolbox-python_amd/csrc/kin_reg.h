@@ -52,11 +52,7 @@ RTB_HD int reg_lds_doubles_packed(int n) { return kPRound * (17 + 6 * n + 1); }
 // A chain's STRUCTURE SIGNATURE: 7 bits per constant segment C_0 .. C_n (class | translation mask << 4, rtbhip_internal.h: kSeg*), bit 63 = "present".
 // reg_core<..., SIG != 0> multiplies by every segment through pose_mul_seg_sig<class, mask>: straight-line code, no descriptor is read.  A
 // kernel instantiated for a signature serves exactly the chains whose table has it (ik_kernels.hip: the launcher compares).
-typedef unsigned long long SegSig;
-constexpr SegSig kSegSigPresent = 1ull << 63;
-constexpr int seg_sig_cls(SegSig s, int j) { return (int)((s >> (7 * j)) & 15u); }
-constexpr int seg_sig_tm(SegSig s, int j) { return (int)((s >> (7 * j + 4)) & 7u); }
-constexpr SegSig seg_sig_of(int j, int cls, int tm) { return (SegSig)((cls & 15) | ((tm & 7) << 4)) << (7 * j); }
+// (SegSig and its accessors: rtbhip_internal.h)
 inline SegSig chain_signature(const int32_t *jmeta, int n)      // host: from the descriptors chain.cpp wrote (n joints + the tail's word)
 {
     if (n > 8) return 0;

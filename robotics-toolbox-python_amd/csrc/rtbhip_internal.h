@@ -46,6 +46,13 @@ constexpr int kSegGeneral = 0, kSegIdentity = 1,
               kSegPermA = 11, kSegPermB = 12;            // the cyclic column permutations of the axis conjugation (chain.cpp: axis_perm): new columns (1,2,0) / (2,0,1)
 __host__ __device__ inline int jm_cls(int jm) { return (jm >> 20) & 15; }
 __host__ __device__ inline int jm_tmask(int jm) { return (jm >> 24) & 7; }
+// STRUCTURE SIGNATURE of a chain (kin_reg.h) or a dynamics tree (tree_device.h): 7 bits per constant (class | translation mask << 4), bit 63 = present
+typedef unsigned long long SegSig;
+constexpr SegSig kSegSigPresent = 1ull << 63;
+__host__ __device__ constexpr int seg_sig_cls(SegSig s, int j) { return (int)((s >> (7 * j)) & 15u); }
+__host__ __device__ constexpr int seg_sig_tm(SegSig s, int j) { return (int)((s >> (7 * j + 4)) & 7u); }
+constexpr SegSig seg_sig_of(int j, int cls, int tm) { return (SegSig)((cls & 15) | ((tm & 7) << 4)) << (7 * j); }
+int seg_class_bits(const DevSeg &a);      // chain.cpp: (class << 20) | (translation mask << 24) of a folded constant
 
 // What a kernel receives: two wave-uniform tables in one device allocation.
 struct DevChain {
@@ -91,11 +98,13 @@ struct DevGroup;
 struct Tree {
     std::vector<DevGroup> groups;
     int n = 0, nslots = 0;
+    SegSig sig = 0;                    // structure signature of the group constants (tree_device.h), 0 beyond 8 groups
     std::map<int, DevGroup *> dev_groups;
     std::mutex mu;
     ~Tree();
 };
 int compile_tree(const rtbhip_tree_group *groups, int ng, Tree *out);
+SegSig tree_signature(const DevGroup *groups, int ng);
 std::shared_ptr<Tree> tree_from_handle(rtbhip_tree_t h);
 int tree_device_groups(Tree *t, const DevGroup **out);
 int launch_tree_rne(const Tree *t, const DevGroup *groups, const double *q, const double *qd, const double *qdd, int64_t N,

@@ -12,6 +12,22 @@ namespace {
 void perm_of_axis(int a, int perm[3]) { perm[2] = a; perm[0] = (a + 1) % 3; perm[1] = (a + 2) % 3; }   // M e_z = e_a
 }  // namespace
 
+// structure signature of a compiled tree (tree_device.h): class and translation mask of every group constant from its EXACT zeros and ones
+// (chain.cpp: seg_class_bits), plus kTreeSigPlain for a serial chain of revolute joints numbered in group order
+SegSig tree_signature(const DevGroup *g, int ng)
+{
+    if (ng < 1 || ng > kTreeSigMaxGroups) return 0;
+    SegSig s = kSegSigPresent;
+    bool plain = true;
+    for (int j = 0; j < ng; j++) {
+        const int bits = seg_class_bits(g[j].C);
+        s |= seg_sig_of(j, jm_cls(bits), jm_tmask(bits));
+        plain = plain && g[j].parent == j - 1 && g[j].save_slot < 0 && g[j].parent_slot < 0 && !jm_prismatic(g[j].jmeta) && jm_jq(g[j].jmeta) == j &&
+                g[j].out_col == j;
+    }
+    return plain ? (s | kTreeSigPlain) : s;
+}
+
 int compile_tree(const rtbhip_tree_group *in, int ng, Tree *out)
 {
     if (ng < 1 || in == nullptr) { set_error("tree_create: need at least one group"); return RTBHIP_EINVAL; }
@@ -70,6 +86,7 @@ int compile_tree(const rtbhip_tree_group *in, int ng, Tree *out)
     }
     out->n = ng;
     out->nslots = nslots;
+    out->sig = tree_signature(out->groups.data(), ng);
     return RTBHIP_OK;
 }
 

@@ -54,6 +54,90 @@ template <class G> RTB_HD V3 seg_r(const G &g, V3 v)    // R_C v
 }
 RTB_HD V3 rz_t(double s, double c, V3 v) { return v3(c * v.x + s * v.y, c * v.y - s * v.x, v.z); }   // Rz(theta)^T v
 RTB_HD V3 rz(double s, double c, V3 v) { return v3(c * v.x - s * v.y, s * v.x + c * v.y, v.z); }     // Rz(theta) v
+
+// ---- STRUCTURE SIGNATURES (rtbhip_internal.h: SegSig, kSeg*).  73 % of the group constants of the URDF robots are not general rotations
+// (identity 21 %, the cyclic permutations of the axis conjugation 23 %, quarter turns 18 %, one-axis rotations 11 %), and most of their
+// translations have one or two non-zero components.  A core instantiated for a signature (SIG != 0) multiplies by every group constant in the
+// form of its class and drops the cross-product terms of the zero translation components; the class is read from SIG at the unrolled
+// group index -- a compile-time constant in every copy of the loop body, so the `if` chains below fold away (a run-time switch costs more
+// than it saves: profiles/r05_ik_structured_constants.txt).  The forms are the general products with the exact zeros dropped and the exact
+// +-1 taken as the operand; single-term cross products are fused (fma) where the general form rounds the product first: results agree with
+// the general kernel to rounding (tests: 1e-12 relative), not bit for bit.
+// kTreeSigPlain: additionally a serial chain of revolute joints (parent of group j is group j - 1, no branch slots, no prismatic joint) --
+// the parent selection, slot traffic and prismatic branches are not compiled in: one straight-line basic block per group.
+constexpr SegSig kTreeSigPlain = 1ull << 56;
+constexpr int kTreeSigMaxGroups = 8;
+// The signatures with instantiations in this build (tree_kernels.hip; tree.cpp: tree_signature computes a robot's).  UR3 / UR5 / UR10 read
+// from their URDF: base translation; the shoulder's rpy = (0, pi/2, 0) with the file's 12-digit pi (general); a pure translation; a quarter
+// turn about z; the two cyclic permutations of the axis conjugation -- five of six constants structured, one or two translation components.
+constexpr SegSig kTreeSigUR = kSegSigPresent | kTreeSigPlain | seg_sig_of(0, kSegIdentity, 4) | seg_sig_of(1, kSegGeneral, 2) | seg_sig_of(2, kSegIdentity, 5) |
+                              seg_sig_of(3, kSegRzP, 1) | seg_sig_of(4, kSegPermA, 4) | seg_sig_of(5, kSegPermB, 4);
+// The Interbotix arms with eight link groups (px150, rx150, rx200, vx300, wx200, wx250: one signature): a branched tree -- two prismatic
+// gripper fingers hang off the wrist -- so not plain: the bookkeeping stays, seven of the eight constants are multiplied in the form of their class.
+constexpr SegSig kTreeSigIbx8 = kSegSigPresent | seg_sig_of(0, kSegIdentity, 4) | seg_sig_of(1, kSegPermB, 4) | seg_sig_of(2, kSegRy, 3) | seg_sig_of(3, kSegIdentity, 2) |
+                                seg_sig_of(4, kSegGeneral, 2) | seg_sig_of(5, kSegIdentity, 4) | seg_sig_of(6, kSegPermA, 4) | seg_sig_of(7, kSegIdentity, 0);
+static_assert(kTreeSigIbx8 == 0x80032e0a042de641ull && kTreeSigUR == 0x81000264b3145041ull, "signatures as tree.cpp computes them for the URDF files");
+
+template <class G> RTB_HD V3 seg_rt_c(int cls, const G &g, V3 v)   // R_C^T v for a constant of class cls
+{
+    const auto &r = g.C.r;
+    if (cls == kSegIdentity) return v;
+    if (cls == kSegPermA) return v3(v.y, v.z, v.x);
+    if (cls == kSegPermB) return v3(v.z, v.x, v.y);
+    if (cls == kSegRx) return v3(v.x, r[4] * v.y + r[7] * v.z, r[5] * v.y + r[8] * v.z);
+    if (cls == kSegRxP) return v3(v.x, r[4] * v.y + v.z, r[8] * v.z - v.y);
+    if (cls == kSegRxN) return v3(v.x, r[4] * v.y - v.z, r[8] * v.z + v.y);
+    if (cls == kSegRy) return v3(r[0] * v.x + r[6] * v.z, v.y, r[2] * v.x + r[8] * v.z);
+    if (cls == kSegRyP) return v3(r[0] * v.x + v.z, v.y, r[8] * v.z - v.x);
+    if (cls == kSegRyN) return v3(r[0] * v.x - v.z, v.y, r[8] * v.z + v.x);
+    if (cls == kSegRz) return v3(r[0] * v.x + r[3] * v.y, r[1] * v.x + r[4] * v.y, v.z);
+    if (cls == kSegRzP) return v3(r[0] * v.x + v.y, r[4] * v.y - v.x, v.z);
+    if (cls == kSegRzN) return v3(r[0] * v.x - v.y, r[4] * v.y + v.x, v.z);
+    return seg_rt(g, v);
+}
+template <class G> RTB_HD V3 seg_r_c(int cls, const G &g, V3 v)    // R_C v
+{
+    const auto &r = g.C.r;
+    if (cls == kSegIdentity) return v;
+    if (cls == kSegPermA) return v3(v.z, v.x, v.y);
+    if (cls == kSegPermB) return v3(v.y, v.z, v.x);
+    if (cls == kSegRx) return v3(v.x, r[4] * v.y + r[5] * v.z, r[7] * v.y + r[8] * v.z);
+    if (cls == kSegRxP) return v3(v.x, r[4] * v.y - v.z, r[8] * v.z + v.y);
+    if (cls == kSegRxN) return v3(v.x, r[4] * v.y + v.z, r[8] * v.z - v.y);
+    if (cls == kSegRy) return v3(r[0] * v.x + r[2] * v.z, v.y, r[6] * v.x + r[8] * v.z);
+    if (cls == kSegRyP) return v3(r[0] * v.x - v.z, v.y, r[8] * v.z + v.x);
+    if (cls == kSegRyN) return v3(r[0] * v.x + v.z, v.y, r[8] * v.z - v.x);
+    if (cls == kSegRz) return v3(r[0] * v.x + r[1] * v.y, r[3] * v.x + r[4] * v.y, v.z);
+    if (cls == kSegRzP) return v3(r[0] * v.x - v.y, r[4] * v.y + v.x, v.z);
+    if (cls == kSegRzN) return v3(r[0] * v.x + v.y, r[4] * v.y - v.x, v.z);
+    return seg_r(g, v);
+}
+// b + (u1 v1 - u2 v2) with the products of an absent (exactly zero) translation component dropped
+RTB_HD double tree_acc2(bool has1, bool has2, double b, double u1, double v1, double u2, double v2)
+{
+    if (has1 && has2) return b + (u1 * v1 - u2 * v2);
+    if (has1) return b + u1 * v1;
+    if (has2) return b - u2 * v2;
+    return b;
+}
+RTB_HD V3 add_cross_ap(int tm, V3 b, V3 a, V3 p)      // b + a x p;  tm: which components of p are not exact zeros (7: no knowledge)
+{
+    const bool X = tm & 1, Y = tm & 2, Z = tm & 4;
+    return v3(tree_acc2(Z, Y, b.x, a.y, p.z, a.z, p.y), tree_acc2(X, Z, b.y, a.z, p.x, a.x, p.z), tree_acc2(Y, X, b.z, a.x, p.y, a.y, p.x));
+}
+RTB_HD V3 add_cross_pa(int tm, V3 b, V3 p, V3 a)      // b + p x a
+{
+    const bool X = tm & 1, Y = tm & 2, Z = tm & 4;
+    return v3(tree_acc2(Y, Z, b.x, p.y, a.z, p.z, a.y), tree_acc2(Z, X, b.y, p.z, a.x, p.x, a.z), tree_acc2(X, Y, b.z, p.x, a.y, p.y, a.x));
+}
+template <bool PLAIN, class G> RTB_HD V3 tree_origin(const G &g, double d)      // p = t_C (+ R_C z d for a prismatic joint; a plain chain has none)
+{
+    if (PLAIN) return v3(g.C.t[0], g.C.t[1], g.C.t[2]);
+    return v3(g.C.t[0] + g.C.r[2] * d, g.C.t[1] + g.C.r[5] * d, g.C.t[2] + g.C.r[8] * d);
+}
+// what a core knows about group j at compile time (SIG = 0: nothing)
+template <SegSig SIG> RTB_HD constexpr int tree_cls(int j) { return SIG ? seg_sig_cls(SIG, j) : kSegGeneral; }
+template <SegSig SIG> RTB_HD constexpr int tree_tm(int j) { return (SIG & kTreeSigPlain) ? seg_sig_tm(SIG, j) : 7; }     // a prismatic joint adds R z d to p: plain chains only
 template <class G> RTB_HD V3 inertia_rot(const G &g, V3 w)   // I_bar w
 {
     return v3(g.I[0] * w.x + g.I[3] * w.y + g.I[4] * w.z, g.I[3] * w.x + g.I[1] * w.y + g.I[5] * w.z,
@@ -63,15 +147,17 @@ template <class G> RTB_HD V3 inertia_rot(const G &g, V3 w)   // I_bar w
 // One sample.  groups: wave-uniform table; qin/qdin/qddin(column) -> double; tau(column, value);
 // slot(index) -> double& into this lane's kTreeSlotDoubles * nslots scratch (LDS on the GPU).
 // joint angles -> sin/cos up front (branch-free reduction; one wave-wide library fallback)
-template <int NG, class GroupsP, class InQ>
+template <int NG, SegSig SIG = 0, class GroupsP, class InQ>
 RTB_HD void tree_trig(GroupsP groups, InQ qin, double (&sn)[NG], double (&cs)[NG])
 {
     {
         bool big = false;
+        constexpr bool kPlain = (SIG & kTreeSigPlain) != 0;        // revolute joints, group j on q column j
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
             const auto &g = groups[j];
-            const double th = jm_prismatic(g.jmeta) ? 0.0 : qin(jm_jq(g.jmeta)) * (jm_flip(g.jmeta) ? -1.0 : 1.0);
+            const double th = kPlain ? qin(j) * (jm_flip(g.jmeta) ? -1.0 : 1.0)
+                                     : (jm_prismatic(g.jmeta) ? 0.0 : qin(jm_jq(g.jmeta)) * (jm_flip(g.jmeta) ? -1.0 : 1.0));
             sn[j] = th;
             big = big || !(fabs(th) < kTrigFastLimit);
         }
@@ -104,38 +190,45 @@ RTB_HD void tree_trig(GroupsP groups, InQ qin, double (&sn)[NG], double (&cs)[NG
 #ifndef RTB_TREE_SKIP_PREFIX
 #define RTB_TREE_SKIP_PREFIX 1
 #endif
-template <int NG, bool VEL = true, class GroupsP, class InQ, class InQd, class InQdd, class Out, class Slot>
+template <int NG, bool VEL = true, SegSig SIG = 0, class GroupsP, class InQ, class InQd, class InQdd, class Out, class Slot>
 RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], const double (&cs)[NG], V3 gravity, InQ qin, InQd qdin, InQdd qddin,
                           Out tau, Slot slot, int first = 0)
 {
     V3 Fl[NG], Fa[NG];
-    for (int k = 0; k < nslots; ++k)
-        for (int e = 12; e < 18; ++e) slot(k * kTreeSlotDoubles + e) = 0.0;
+    constexpr bool kPlain = (SIG & kTreeSigPlain) != 0;
+    if (!kPlain)
+        for (int k = 0; k < nslots; ++k)
+            for (int e = 12; e < 18; ++e) slot(k * kTreeSlotDoubles + e) = 0.0;
 
     // ---- forward recursion (Robot.py:1822-1872)
     V3 vl = v3(0, 0, 0), va = v3(0, 0, 0), al = v3(0, 0, 0), aa = v3(0, 0, 0);   // state of the previous group
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
         const auto &g = groups[j];
+        const int cls = tree_cls<SIG>(j), tm = tree_tm<SIG>(j);          // constants of the unrolled copy (SIG = 0: general, 7)
+        // (read where they are used: loading the three words up front costs the general kernels some 70 registers)
+        auto parent_of = [&]() { return kPlain ? j - 1 : g.parent; };
+        auto parent_slot_of = [&]() { return kPlain ? -1 : g.parent_slot; };
+        auto save_slot_of = [&]() { return kPlain ? -1 : g.save_slot; };
         if (!VEL && j < first) {
             al = v3(0, 0, 0); aa = v3(0, 0, 0);
-            if (g.save_slot >= 0) {
-                const int b = g.save_slot * kTreeSlotDoubles;
+            if (save_slot_of() >= 0) {
+                const int b = save_slot_of() * kTreeSlotDoubles;
                 for (int e = 6; e < 12; ++e) slot(b + e) = 0.0;
             }
             Fl[j] = v3(0, 0, 0); Fa[j] = v3(0, 0, 0);
             continue;
         }
-        const bool pris = jm_prismatic(g.jmeta) != 0;
-        const int col = jm_jq(g.jmeta);
+        const bool pris = !kPlain && jm_prismatic(g.jmeta) != 0;
+        const int col = kPlain ? j : jm_jq(g.jmeta);
         const double qdj = VEL ? qdin(col) : 0.0, qddj = qddin(col);
         const double d = pris ? qin(col) * (jm_flip(g.jmeta) ? -1.0 : 1.0) : 0.0;
         V3 pvl, pva, pal, paa;     // parent state
-        if (g.parent < 0) {
+        if (parent_of() < 0) {
             pvl = v3(0, 0, 0); pva = v3(0, 0, 0);
             pal = v3(-gravity.x, -gravity.y, -gravity.z); paa = v3(0, 0, 0);     // a_grav = -SpatialAcceleration(gravity)
-        } else if (g.parent_slot >= 0) {
-            const int b = g.parent_slot * kTreeSlotDoubles;
+        } else if (parent_slot_of() >= 0) {
+            const int b = parent_slot_of() * kTreeSlotDoubles;
             if (VEL) { pvl = v3(slot(b + 0), slot(b + 1), slot(b + 2)); pva = v3(slot(b + 3), slot(b + 4), slot(b + 5)); }
             else { pvl = v3(0, 0, 0); pva = v3(0, 0, 0); }
             pal = v3(slot(b + 6), slot(b + 7), slot(b + 8)); paa = v3(slot(b + 9), slot(b + 10), slot(b + 11));
@@ -143,15 +236,15 @@ RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], co
             pvl = vl; pva = va; pal = al; paa = aa;
         }
         // frame j in the parent frame: R = R_C Rz(theta), p = t_C (+ R_C z d for a prismatic joint)
-        const V3 p = v3(g.C.t[0] + g.C.r[2] * d, g.C.t[1] + g.C.r[5] * d, g.C.t[2] + g.C.r[8] * d);
+        const V3 p = tree_origin<kPlain>(g, d);
         const double s = sn[j], c = cs[j];
         // X_up on motion vectors: w' = R^T w ; v' = R^T (v + w x p)
         if (VEL) {
-            va = rz_t(s, c, seg_rt(g, pva));
-            vl = rz_t(s, c, seg_rt(g, pvl + cross(pva, p)));
+            va = rz_t(s, c, seg_rt_c(cls, g, pva));
+            vl = rz_t(s, c, seg_rt_c(cls, g, add_cross_ap(tm, pvl, pva, p)));
         }
-        aa = rz_t(s, c, seg_rt(g, paa));
-        al = rz_t(s, c, seg_rt(g, pal + cross(paa, p)));
+        aa = rz_t(s, c, seg_rt_c(cls, g, paa));
+        al = rz_t(s, c, seg_rt_c(cls, g, add_cross_ap(tm, pal, paa, p)));
         // joint velocity vJ = s_j qd (the motion subspace ignores `flip`, ET.py:592-608), then
         // a += s_j qdd + v x vJ with the spatial motion cross product (Robot.py:1866-1870)
         if (pris) {
@@ -168,8 +261,8 @@ RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], co
             }
             aa.z += qddj;
         }
-        if (g.save_slot >= 0) {
-            const int b = g.save_slot * kTreeSlotDoubles;
+        if (save_slot_of() >= 0) {
+            const int b = save_slot_of() * kTreeSlotDoubles;
             if (VEL) { slot(b + 0) = vl.x; slot(b + 1) = vl.y; slot(b + 2) = vl.z; slot(b + 3) = va.x; slot(b + 4) = va.y; slot(b + 5) = va.z; }
             slot(b + 6) = al.x; slot(b + 7) = al.y; slot(b + 8) = al.z; slot(b + 9) = aa.x; slot(b + 10) = aa.y; slot(b + 11) = aa.z;
         }
@@ -194,23 +287,28 @@ RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], co
         const int j = NG - 1 - jj;
         if (!VEL && j < first) continue;
         const auto &g = groups[j];
-        const bool pris = jm_prismatic(g.jmeta) != 0;
+        const int cls = tree_cls<SIG>(j), tm = tree_tm<SIG>(j);
+        // (read where they are used: loading the three words up front costs the general kernels some 70 registers)
+        auto parent_of = [&]() { return kPlain ? j - 1 : g.parent; };
+        auto parent_slot_of = [&]() { return kPlain ? -1 : g.parent_slot; };
+        auto save_slot_of = [&]() { return kPlain ? -1 : g.save_slot; };
+        const bool pris = !kPlain && jm_prismatic(g.jmeta) != 0;
         V3 fl = Fl[j] + cl, fa = Fa[j] + ca;
-        if (g.save_slot >= 0) {
-            const int b = g.save_slot * kTreeSlotDoubles + 12;
+        if (save_slot_of() >= 0) {
+            const int b = save_slot_of() * kTreeSlotDoubles + 12;
             fl = fl + v3(slot(b + 0), slot(b + 1), slot(b + 2));
             fa = fa + v3(slot(b + 3), slot(b + 4), slot(b + 5));
         }
-        tau(g.out_col, pris ? fl.z : fa.z);                    // Q[k, j] = sum(f[j] * s[j])
+        tau(kPlain ? j : g.out_col, pris ? fl.z : fa.z);                    // Q[k, j] = sum(f[j] * s[j])
         cl = v3(0, 0, 0); ca = v3(0, 0, 0);
-        if (g.parent >= 0) {
+        if (parent_of() >= 0) {
             // f_parent += X_up^T f: lin' = R lin ; ang' = R ang + p x (R lin)
             const double d = pris ? qin(jm_jq(g.jmeta)) * (jm_flip(g.jmeta) ? -1.0 : 1.0) : 0.0;
-            const V3 p = v3(g.C.t[0] + g.C.r[2] * d, g.C.t[1] + g.C.r[5] * d, g.C.t[2] + g.C.r[8] * d);
-            const V3 tl = seg_r(g, rz(sn[j], cs[j], fl));
-            const V3 ta = seg_r(g, rz(sn[j], cs[j], fa)) + cross(p, tl);
-            if (g.parent_slot >= 0) {
-                const int b = g.parent_slot * kTreeSlotDoubles + 12;
+            const V3 p = tree_origin<kPlain>(g, d);
+            const V3 tl = seg_r_c(cls, g, rz(sn[j], cs[j], fl));
+            const V3 ta = add_cross_pa(tm, seg_r_c(cls, g, rz(sn[j], cs[j], fa)), p, tl);
+            if (parent_slot_of() >= 0) {
+                const int b = parent_slot_of() * kTreeSlotDoubles + 12;
                 slot(b + 0) += tl.x; slot(b + 1) += tl.y; slot(b + 2) += tl.z;
                 slot(b + 3) += ta.x; slot(b + 4) += ta.y; slot(b + 5) += ta.z;
             } else {
@@ -228,29 +326,36 @@ RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], co
 // halves).  Against the two full passes per column of the polar form tau(qd + s e_k) - tau(qd - s e_k) this is one pass of ~1.1x the
 // arithmetic, exact for any spread of velocities (no scale s to choose, no cancellation), and the groups before `first` (w = 0 there: their
 // accelerations and forces vanish) only advance u.  `first` as in tree_rne_core; slots of kTreeBilinearSlotDoubles.
-template <int NG, class GroupsP, class InQ, class InQd, class Out, class Slot>
+template <int NG, SegSig SIG = 0, class GroupsP, class InQ, class InQd, class Out, class Slot>
 RTB_HD void tree_bilinear_core(GroupsP groups, int nslots, const double (&sn)[NG], const double (&cs)[NG], InQ qin, InQd qdin, int k, Out tau,
                                Slot slot, int first)
 {
     constexpr int SD = kTreeBilinearSlotDoubles;
     V3 Fl[NG], Fa[NG];
-    for (int i = 0; i < nslots; ++i)
-        for (int e = 18; e < 24; ++e) slot(i * SD + e) = 0.0;
+    constexpr bool kPlain = (SIG & kTreeSigPlain) != 0;
+    if (!kPlain)
+        for (int i = 0; i < nslots; ++i)
+            for (int e = 18; e < 24; ++e) slot(i * SD + e) = 0.0;
     const V3 o = v3(0, 0, 0);
     V3 ul = o, ua = o, wl = o, wa = o, al = o, aa = o;       // previous group: velocity under u, under w, the bilinear acceleration
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
         const auto &g = groups[j];
-        const bool pris = jm_prismatic(g.jmeta) != 0;
-        const int col = jm_jq(g.jmeta);
+        const int cls = tree_cls<SIG>(j), tm = tree_tm<SIG>(j);
+        // (read where they are used: loading the three words up front costs the general kernels some 70 registers)
+        auto parent_of = [&]() { return kPlain ? j - 1 : g.parent; };
+        auto parent_slot_of = [&]() { return kPlain ? -1 : g.parent_slot; };
+        auto save_slot_of = [&]() { return kPlain ? -1 : g.save_slot; };
+        const bool pris = !kPlain && jm_prismatic(g.jmeta) != 0;
+        const int col = kPlain ? j : jm_jq(g.jmeta);
         const double qdu = qdin(col), qdw = col == k ? 1.0 : 0.0;
         const double d = pris ? qin(col) * (jm_flip(g.jmeta) ? -1.0 : 1.0) : 0.0;
         const bool rest = j < first;                           // wave-uniform: w, a and f are zero up to here
         V3 pul, pua, pwl, pwa, pal, paa;
-        if (g.parent < 0) {
+        if (parent_of() < 0) {
             pul = o; pua = o; pwl = o; pwa = o; pal = o; paa = o;
-        } else if (g.parent_slot >= 0) {
-            const int b = g.parent_slot * SD;
+        } else if (parent_slot_of() >= 0) {
+            const int b = parent_slot_of() * SD;
             pul = v3(slot(b + 0), slot(b + 1), slot(b + 2)); pua = v3(slot(b + 3), slot(b + 4), slot(b + 5));
             if (rest) { pwl = o; pwa = o; pal = o; paa = o; }
             else {
@@ -260,15 +365,15 @@ RTB_HD void tree_bilinear_core(GroupsP groups, int nslots, const double (&sn)[NG
         } else {
             pul = ul; pua = ua; pwl = wl; pwa = wa; pal = al; paa = aa;
         }
-        const V3 p = v3(g.C.t[0] + g.C.r[2] * d, g.C.t[1] + g.C.r[5] * d, g.C.t[2] + g.C.r[8] * d);
+        const V3 p = tree_origin<kPlain>(g, d);
         const double s = sn[j], c = cs[j];
-        ua = rz_t(s, c, seg_rt(g, pua));
-        ul = rz_t(s, c, seg_rt(g, pul + cross(pua, p)));
+        ua = rz_t(s, c, seg_rt_c(cls, g, pua));
+        ul = rz_t(s, c, seg_rt_c(cls, g, add_cross_ap(tm, pul, pua, p)));
         if (rest) {
             if (pris) ul.z += qdu; else ua.z += qdu;
             wl = o; wa = o; al = o; aa = o;
-            if (g.save_slot >= 0) {
-                const int b = g.save_slot * SD;
+            if (save_slot_of() >= 0) {
+                const int b = save_slot_of() * SD;
                 slot(b + 0) = ul.x; slot(b + 1) = ul.y; slot(b + 2) = ul.z; slot(b + 3) = ua.x; slot(b + 4) = ua.y; slot(b + 5) = ua.z;
                 for (int e = 6; e < 18; ++e) slot(b + e) = 0.0;
             }
@@ -276,10 +381,10 @@ RTB_HD void tree_bilinear_core(GroupsP groups, int nslots, const double (&sn)[NG
             sched_fence();
             continue;
         }
-        wa = rz_t(s, c, seg_rt(g, pwa));
-        wl = rz_t(s, c, seg_rt(g, pwl + cross(pwa, p)));
-        aa = rz_t(s, c, seg_rt(g, paa));
-        al = rz_t(s, c, seg_rt(g, pal + cross(paa, p)));
+        wa = rz_t(s, c, seg_rt_c(cls, g, pwa));
+        wl = rz_t(s, c, seg_rt_c(cls, g, add_cross_ap(tm, pwl, pwa, p)));
+        aa = rz_t(s, c, seg_rt_c(cls, g, paa));
+        al = rz_t(s, c, seg_rt_c(cls, g, add_cross_ap(tm, pal, paa, p)));
         // a += v x vJ (Robot.py:1866-1870), both ways round; cross(v, (0, 0, t)) = (v.y t, -v.x t, 0)
         if (pris) {
             ul.z += qdu; wl.z += qdw;
@@ -289,8 +394,8 @@ RTB_HD void tree_bilinear_core(GroupsP groups, int nslots, const double (&sn)[NG
             al = al + (cross(ul, v3(0, 0, qdw)) + cross(wl, v3(0, 0, qdu)));
             aa = aa + (cross(ua, v3(0, 0, qdw)) + cross(wa, v3(0, 0, qdu)));
         }
-        if (g.save_slot >= 0) {
-            const int b = g.save_slot * SD;
+        if (save_slot_of() >= 0) {
+            const int b = save_slot_of() * SD;
             slot(b + 0) = ul.x; slot(b + 1) = ul.y; slot(b + 2) = ul.z; slot(b + 3) = ua.x; slot(b + 4) = ua.y; slot(b + 5) = ua.z;
             slot(b + 6) = wl.x; slot(b + 7) = wl.y; slot(b + 8) = wl.z; slot(b + 9) = wa.x; slot(b + 10) = wa.y; slot(b + 11) = wa.z;
             slot(b + 12) = al.x; slot(b + 13) = al.y; slot(b + 14) = al.z; slot(b + 15) = aa.x; slot(b + 16) = aa.y; slot(b + 17) = aa.z;
@@ -310,22 +415,27 @@ RTB_HD void tree_bilinear_core(GroupsP groups, int nslots, const double (&sn)[NG
     for (int jj = 0; jj < NG; ++jj) {
         const int j = NG - 1 - jj;
         const auto &g = groups[j];
-        const bool pris = jm_prismatic(g.jmeta) != 0;
+        const int cls = tree_cls<SIG>(j), tm = tree_tm<SIG>(j);
+        // (read where they are used: loading the three words up front costs the general kernels some 70 registers)
+        auto parent_of = [&]() { return kPlain ? j - 1 : g.parent; };
+        auto parent_slot_of = [&]() { return kPlain ? -1 : g.parent_slot; };
+        auto save_slot_of = [&]() { return kPlain ? -1 : g.save_slot; };
+        const bool pris = !kPlain && jm_prismatic(g.jmeta) != 0;
         V3 fl = Fl[j] + cl, fa = Fa[j] + ca;
-        if (g.save_slot >= 0) {
-            const int b = g.save_slot * SD + 18;
+        if (save_slot_of() >= 0) {
+            const int b = save_slot_of() * SD + 18;
             fl = fl + v3(slot(b + 0), slot(b + 1), slot(b + 2));
             fa = fa + v3(slot(b + 3), slot(b + 4), slot(b + 5));
         }
-        tau(g.out_col, pris ? fl.z : fa.z);
+        tau(kPlain ? j : g.out_col, pris ? fl.z : fa.z);
         cl = o; ca = o;
-        if (g.parent >= 0) {
+        if (parent_of() >= 0) {
             const double d = pris ? qin(jm_jq(g.jmeta)) * (jm_flip(g.jmeta) ? -1.0 : 1.0) : 0.0;
-            const V3 p = v3(g.C.t[0] + g.C.r[2] * d, g.C.t[1] + g.C.r[5] * d, g.C.t[2] + g.C.r[8] * d);
-            const V3 tl = seg_r(g, rz(sn[j], cs[j], fl));
-            const V3 ta = seg_r(g, rz(sn[j], cs[j], fa)) + cross(p, tl);
-            if (g.parent_slot >= 0) {
-                const int b = g.parent_slot * SD + 18;
+            const V3 p = tree_origin<kPlain>(g, d);
+            const V3 tl = seg_r_c(cls, g, rz(sn[j], cs[j], fl));
+            const V3 ta = add_cross_pa(tm, seg_r_c(cls, g, rz(sn[j], cs[j], fa)), p, tl);
+            if (parent_slot_of() >= 0) {
+                const int b = parent_slot_of() * SD + 18;
                 slot(b + 0) += tl.x; slot(b + 1) += tl.y; slot(b + 2) += tl.z;
                 slot(b + 3) += ta.x; slot(b + 4) += ta.y; slot(b + 5) += ta.z;
             } else {
@@ -338,12 +448,12 @@ RTB_HD void tree_bilinear_core(GroupsP groups, int nslots, const double (&sn)[NG
 
 // ATREST: the caller has no joint velocities (rtbhip_tree_rne with qd = NULL: Dynamics.gravload, Dynamics.itorque) -- the recursion
 // without its velocity half (tree_rne_core VEL = false), gravity still the base's acceleration.
-template <int NG, bool ATREST = false, class GroupsP, class InQ, class InQd, class InQdd, class Out, class Slot>
+template <int NG, bool ATREST = false, SegSig SIG = 0, class GroupsP, class InQ, class InQd, class InQdd, class Out, class Slot>
 RTB_HD void tree_rne_lane(GroupsP groups, int nslots, V3 gravity, InQ qin, InQd qdin, InQdd qddin, Out tau, Slot slot)
 {
     double sn[NG], cs[NG];
-    tree_trig<NG>(groups, qin, sn, cs);
-    tree_rne_core<NG, !ATREST>(groups, nslots, sn, cs, gravity, qin, qdin, qddin, tau, slot);
+    tree_trig<NG, SIG>(groups, qin, sn, cs);
+    tree_rne_core<NG, !ATREST, SIG>(groups, nslots, sn, cs, gravity, qin, qdin, qddin, tau, slot);
 }
 
 // ---- the Dynamics-mixin terms of an ETS robot (robot/Dynamics.py:704-861, 424-509 on Robot.rne): every Newton-Euler pass the
@@ -397,14 +507,15 @@ RTB_HD int tree_row_position(GroupsP groups, int r)
     return a;
 }
 
-template <int NG, int MODE, class GroupsP, class Slot>
+template <int NG, int MODE, SegSig SIG = 0, class GroupsP, class Slot>
 RTB_HD void tree_dyn_lane(GroupsP groups, int nslots, const double *mine, double *mA, V3 grav, Slot slot)
 {
     const V3 zero = v3(0, 0, 0);
     auto qin = [&](int j) { return mine[j]; };
     auto none = [&](int) { return 0.0; };
     double sn[NG], cs[NG];
-    tree_trig<NG>(groups, qin, sn, cs);
+    tree_trig<NG, SIG>(groups, qin, sn, cs);
+    constexpr bool kPlain = (SIG & kTreeSigPlain) != 0;          // group j moves q column j: nothing to permute
     // The unit-acceleration passes run in GROUP order: pass i accelerates the joint of the group at position i (q column jq_i), so that
     // Mp[j][i] = torque of group j is the symmetric joint-space inertia in group order -- only the entries j >= i are computed (the groups before i are
     // no descendants of i: at rest), packed lower triangle.  The reference's matrix is M[c, :] = rne(q, 0, e_c) with c a q COLUMN and the torques
@@ -416,19 +527,19 @@ RTB_HD void tree_dyn_lane(GroupsP groups, int nslots, const double *mine, double
 #pragma unroll 1
         for (int i = 0; i < NG; ++i) {
             tree_opaque<NG>(sn, cs);
-            const int ci = jm_jq(groups[i].jmeta);
-            tree_rne_core<NG, !RTB_TREE_ACC_ONLY>(groups, nslots, sn, cs, zero, qin, none, [&](int c) { return c == ci ? 1.0 : 0.0; },
+            const int ci = kPlain ? i : jm_jq(groups[i].jmeta);
+            tree_rne_core<NG, !RTB_TREE_ACC_ONLY, SIG>(groups, nslots, sn, cs, zero, qin, none, [&](int c) { return c == ci ? 1.0 : 0.0; },
                                      [&](int j, double v) { if (j >= i) mA[j * (j + 1) / 2 + i] = v; }, slot, skip ? i : 0);
         }
     }
     if (MODE == kDynAccel) {
         double b[NG];
         tree_opaque<NG>(sn, cs);
-        tree_rne_core<NG>(groups, nslots, sn, cs, grav, qin, [&](int j) { return mine[NG + j]; }, none,
+        tree_rne_core<NG, true, SIG>(groups, nslots, sn, cs, grav, qin, [&](int j) { return mine[NG + j]; }, none,
                           [&](int j, double v) { tree_put<NG>(b, j, mine[2 * NG + j] - v); }, slot);
         // the reference solves M qdd = torque - tau_0 with ITS M (rows by q column): row i of Mp stands in row jq_i, so the right-hand side of
         // the group-ordered system is entry jq_i of (torque - tau_0)
-        if (!tree_in_group_order<NG>(groups)) {         // wave-uniform
+        if (!kPlain && !tree_in_group_order<NG>(groups)) {         // wave-uniform
             double b2[NG];
 #pragma unroll
             for (int a = 0; a < NG; ++a) b2[a] = dyn_pick<NG>(b, jm_jq(groups[a].jmeta));
@@ -438,8 +549,8 @@ RTB_HD void tree_dyn_lane(GroupsP groups, int nslots, const double *mine, double
 #pragma unroll 1
         for (int i = 0; i < NG; ++i) {
             tree_opaque<NG>(sn, cs);
-            const int ci = jm_jq(groups[i].jmeta);
-            tree_rne_core<NG, !RTB_TREE_ACC_ONLY>(groups, nslots, sn, cs, zero, qin, none, [&](int c) { return c == ci ? 1.0 : 0.0; },
+            const int ci = kPlain ? i : jm_jq(groups[i].jmeta);
+            tree_rne_core<NG, !RTB_TREE_ACC_ONLY, SIG>(groups, nslots, sn, cs, zero, qin, none, [&](int c) { return c == ci ? 1.0 : 0.0; },
                                      [&](int j, double v) { if (j >= i) mA[j * (j + 1) / 2 + i] = v; }, slot, skip ? i : 0);
         }
         double x[NG], M[NG][NG];
@@ -456,11 +567,11 @@ RTB_HD void tree_dyn_lane(GroupsP groups, int nslots, const double *mine, double
         // column k = B(qd, e_k), one two-field pass each (tree_bilinear_core)
         bool ordered = true;
 #pragma unroll
-        for (int j = 0; j < NG; ++j) ordered = ordered && jm_jq(groups[j].jmeta) == j;
+        for (int j = 0; j < NG; ++j) ordered = ordered && (kPlain || jm_jq(groups[j].jmeta) == j);
 #pragma unroll 1
         for (int k = 0; k < NG; ++k) {
             tree_opaque<NG>(sn, cs);
-            tree_bilinear_core<NG>(groups, nslots, sn, cs, qin, [&](int j) { return mine[NG + j]; }, k,
+            tree_bilinear_core<NG, SIG>(groups, nslots, sn, cs, qin, [&](int j) { return mine[NG + j]; }, k,
                                    [&](int r, double v) { mA[r * NG + k] = 0.5 * v; }, slot, ordered ? k : 0);
         }
 #else

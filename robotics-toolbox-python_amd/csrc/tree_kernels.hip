@@ -7,6 +7,7 @@
 // Bytes: 3*8n in + 8n out per sample; ~0.25 kflop per group: fp64-issue bound like k_rne.
 #include "tree_device.h"
 #include "kin_tile.h"
+#include <string>
 
 namespace rtbhip {
 
@@ -24,7 +25,12 @@ constexpr int kTreeMaxGroups = 24;   // 17..24 link groups: the per-group state 
 // ATREST (qd == NULL, robots of up to kTreeAtRestMax groups): the velocity half of the recursion is not compiled in and the qd row is neither
 // read nor staged.
 constexpr int kTreeAtRestMax = 12;
-template <int NG, bool ATREST>
+// kTreeSigUR, kTreeSigIbx8 (tree_device.h): the signatures this build has instantiations for; every other robot takes the general kernels
+static int g_tree_sig = 1;          // rtbhip_tune("tree_sig", 0): every robot does (A/B, tests)
+void tree_tune(const char *key, int value) { if (std::string(key) == "tree_sig") g_tree_sig = value != 0; }
+int tree_sig_enabled() { return g_tree_sig; }
+
+template <int NG, bool ATREST, SegSig SIG = 0>
 __global__ __launch_bounds__(kWave, (NG <= 8 ? 2 : 1)) void k_tree_rne(TreeParams tp, const DevGroup *groups_g, const double *__restrict__ q,
                                                       const double *__restrict__ qd, const double *__restrict__ qdd,
                                                       double *__restrict__ tau)
@@ -61,7 +67,7 @@ __global__ __launch_bounds__(kWave, (NG <= 8 ? 2 : 1)) void k_tree_rne(TreeParam
     __syncthreads();
     double *mine = lds + lane * stride;
     if (lane < ncfg)
-        tree_rne_lane<NG, ATREST>(groups, tp.nslots, v3(tp.grav[0], tp.grav[1], tp.grav[2]), [&](int c) { return mine[c]; },
+        tree_rne_lane<NG, ATREST, SIG>(groups, tp.nslots, v3(tp.grav[0], tp.grav[1], tp.grav[2]), [&](int c) { return mine[c]; },
                           [&](int c) { return ATREST ? 0.0 : mine[NG + c]; }, [&](int c) { return mine[2 * NG + c]; },
                           [&](int c, double v) { mine[3 * NG + c] = v; },
                           [&](int i) -> double & { return slots[i * kWave + lane]; });
@@ -69,19 +75,19 @@ __global__ __launch_bounds__(kWave, (NG <= 8 ? 2 : 1)) void k_tree_rne(TreeParam
     flush_run(lds + 3 * NG, stride, NG, ncfg, tau + cfg0 * NG, lane);
 }
 
-template <int NG>
+template <int NG, SegSig SIG = 0>
 static void launch_ng(dim3 grid, size_t lds, hipStream_t s, const TreeParams &tp, const DevGroup *g, const double *q,
                       const double *qd, const double *qdd, double *tau)
 {
     if constexpr (NG <= kTreeAtRestMax) {
         if (!qd) {
-            auto k = k_tree_rne<NG, true>;
+            auto k = k_tree_rne<NG, true, SIG>;
             if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(k, grid, dim3(kWave), lds, s, tp, g, q, qd, qdd, tau);
             return;
         }
     }
-    auto k = k_tree_rne<NG, false>;
+    auto k = k_tree_rne<NG, false, SIG>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, grid, dim3(kWave), lds, s, tp, g, q, qd, qdd, tau);
 }
@@ -99,6 +105,15 @@ int launch_tree_rne(const Tree *t, const DevGroup *groups, const double *q, cons
     const size_t lds = (size_t)kWave * (((4 * t->n) | 1) + kTreeSlotDoubles * t->nslots) * sizeof(double);
     if (lds > 160 * 1024) { set_error("tree_rne: tree needs more LDS than a CU has"); return RTBHIP_ELIMIT; }
     dim3 grid((unsigned)tiles);
+    const SegSig sig = g_tree_sig ? t->sig : 0;
+    if (sig == kTreeSigUR) {
+        launch_ng<6, kTreeSigUR>(grid, lds, s, tp, groups, q, qd, qdd, tau);
+    } else if (sig == kTreeSigIbx8) {
+        launch_ng<8, kTreeSigIbx8>(grid, lds, s, tp, groups, q, qd, qdd, tau);
+    } else
+#ifdef RTB_TREE_DEV_NG      // development builds (seconds instead of minutes): only this size is instantiated
+    launch_ng<RTB_TREE_DEV_NG>(grid, lds, s, tp, groups, q, qd, qdd, tau);
+#else
     switch (t->n) {
     case 1: launch_ng<1>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
     case 2: launch_ng<2>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
@@ -125,6 +140,7 @@ int launch_tree_rne(const Tree *t, const DevGroup *groups, const double *q, cons
     case 23: launch_ng<23>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
     default: launch_ng<24>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
     }
+#endif
     note_launch((int)grid.x, kWave, (int)lds);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "k_tree_rne launch");
@@ -163,8 +179,11 @@ __device__ __forceinline__ void tree_flush_symmetric(ConstGroups groups, const d
     }
 }
 
-template <int NG, int MODE>
-__global__ __launch_bounds__(kWave, 1) void k_tree_dyn(TreeParams tp, const DevGroup *groups_g, const double *__restrict__ q,
+// Robots of up to 7 joints keep two waves per SIMD (the second launch bound: at most 256 registers a lane): their tiles leave room for five or
+// more waves on a CU, and an allocation just above 256 -- the general accel kernel for six joints took 288 in one build of round 5, when the
+// recursion read a group's bookkeeping words before it needed them -- halves what the registers admit.  From 8 joints on the tile admits four.
+template <int NG, int MODE, SegSig SIG = 0>
+__global__ __launch_bounds__(kWave, (NG <= 7 ? 2 : 1)) void k_tree_dyn(TreeParams tp, const DevGroup *groups_g, const double *__restrict__ q,
                                                        const double *__restrict__ qd, const double *__restrict__ tq,
                                                        double *__restrict__ out)
 {
@@ -199,7 +218,7 @@ __global__ __launch_bounds__(kWave, 1) void k_tree_dyn(TreeParams tp, const DevG
     }
     __syncthreads();
     if (lane < ncfg)
-        tree_dyn_lane<NG, MODE>(groups, tp.nslots, lds + lane * in_stride, A + lane * w_stride, v3(tp.grav[0], tp.grav[1], tp.grav[2]),
+        tree_dyn_lane<NG, MODE, SIG>(groups, tp.nslots, lds + lane * in_stride, A + lane * w_stride, v3(tp.grav[0], tp.grav[1], tp.grav[2]),
                                 [&](int i) -> double & { return slots[i * T + lane]; });
     __syncthreads();
     if (MODE == kDynAccel) flush_run(A, w_stride, NG, ncfg, out + cfg0 * NG, lane);
@@ -207,7 +226,7 @@ __global__ __launch_bounds__(kWave, 1) void k_tree_dyn(TreeParams tp, const DevG
     else flush_run(A, w_stride, NG * NG, ncfg, out + cfg0 * (NG * NG), lane);
 }
 
-template <int NG, int MODE>
+template <int NG, int MODE, SegSig SIG = 0>
 static hipError_t launch_tree_dyn_one(dim3 grid, hipStream_t s, int nslots, const TreeParams &tp, const DevGroup *g, const double *q,
                                       const double *qd, const double *tq, double *out, size_t *lds_out)
 {
@@ -225,20 +244,20 @@ static hipError_t launch_tree_dyn_one(dim3 grid, hipStream_t s, int nslots, cons
     const int64_t tiles = (tp.N + tq_.tile - 1) / tq_.tile;
     if (tiles > 0x7fffffff) { *lds_out = 0; return hipErrorInvalidValue; }
     grid = dim3((unsigned)tiles);
-    auto k = k_tree_dyn<NG, MODE>;
+    auto k = k_tree_dyn<NG, MODE, SIG>;
     if (lds > 48 * 1024) { hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(k, grid, dim3(kWave), lds, s, tq_, g, q, qd, tq, out);
     note_launch((int)grid.x, kWave, (int)lds);
     return hipSuccess;
 }
 
-template <int NG>
+template <int NG, SegSig SIG = 0>
 static hipError_t launch_tree_dyn_ng(int mode, dim3 grid, hipStream_t s, int nslots, const TreeParams &tp, const DevGroup *g, const double *q,
                                      const double *qd, const double *tq, double *out, size_t *lds)
 {
-    if (mode == kDynInertia) return launch_tree_dyn_one<NG, kDynInertia>(grid, s, nslots, tp, g, q, qd, tq, out, lds);
-    if (mode == kDynCoriolis) return launch_tree_dyn_one<NG, kDynCoriolis>(grid, s, nslots, tp, g, q, qd, tq, out, lds);
-    return launch_tree_dyn_one<NG, kDynAccel>(grid, s, nslots, tp, g, q, qd, tq, out, lds);
+    if (mode == kDynInertia) return launch_tree_dyn_one<NG, kDynInertia, SIG>(grid, s, nslots, tp, g, q, qd, tq, out, lds);
+    if (mode == kDynCoriolis) return launch_tree_dyn_one<NG, kDynCoriolis, SIG>(grid, s, nslots, tp, g, q, qd, tq, out, lds);
+    return launch_tree_dyn_one<NG, kDynAccel, SIG>(grid, s, nslots, tp, g, q, qd, tq, out, lds);
 }
 
 int launch_tree_dyn(const Tree *t, const DevGroup *groups, int mode, const double *q, const double *qd, const double *tq, int64_t N,
@@ -254,6 +273,15 @@ int launch_tree_dyn(const Tree *t, const DevGroup *groups, int mode, const doubl
     dim3 grid((unsigned)tiles);
     size_t lds = 0;
     hipError_t e = hipSuccess;
+    const SegSig sig = g_tree_sig ? t->sig : 0;
+    if (sig == kTreeSigUR) {
+        e = launch_tree_dyn_ng<6, kTreeSigUR>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds);
+    } else if (sig == kTreeSigIbx8) {
+        e = launch_tree_dyn_ng<8, kTreeSigIbx8>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds);
+    } else
+#ifdef RTB_TREE_DEV_NG
+    e = launch_tree_dyn_ng<RTB_TREE_DEV_NG>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds);
+#else
     switch (t->n) {
     case 1: e = launch_tree_dyn_ng<1>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
     case 2: e = launch_tree_dyn_ng<2>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
@@ -276,6 +304,7 @@ int launch_tree_dyn(const Tree *t, const DevGroup *groups, int mode, const doubl
     case 19: e = launch_tree_dyn_ng<19>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
     default: e = launch_tree_dyn_ng<20>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
     }
+#endif
     if (lds > 160 * 1024) { set_error("tree inertia/coriolis/accel: the robot needs more LDS than a CU has"); return RTBHIP_ELIMIT; }
     if (e != hipSuccess) return hip_fail(e, "k_tree_dyn launch");
     e = hipGetLastError();

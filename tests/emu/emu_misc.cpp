@@ -126,7 +126,8 @@ extern "C" int emu_partial(rtbhip_chain_t h, const double *q, int64_t N, const d
 }
 
 // ETS-robot inverse dynamics: tree.cpp's compiled table + tree_device.h's per-lane recursion on the CPU
-template <int NG>
+namespace rtbhip { int tree_sig_enabled(); }      // tree_kernels.hip: rtbhip_tune("tree_sig")
+template <int NG, SegSig SIG = 0>
 static void tree_run(const Tree *t, const double *q, const double *qd, const double *qdd, int64_t N, V3 g, double *tau)
 {
     std::vector<double> slots((size_t)kTreeSlotDoubles * std::max(1, t->nslots));
@@ -135,22 +136,33 @@ static void tree_run(const Tree *t, const double *q, const double *qd, const dou
         double *o = tau + s * NG;
         // qd == NULL on a robot of up to 12 groups: the at-rest instantiation, as launch_tree_rne dispatches (tree_kernels.hip kTreeAtRestMax)
         if (!b && NG <= 12)
-            tree_rne_lane<NG, true>(t->groups.data(), t->nslots, g, [&](int k) { return a[k]; }, [&](int) { return 0.0; },
+            tree_rne_lane<NG, true, SIG>(t->groups.data(), t->nslots, g, [&](int k) { return a[k]; }, [&](int) { return 0.0; },
                                     [&](int k) { return c[k]; }, [&](int k, double v) { o[k] = v; },
                                     [&](int i) -> double & { return slots[i]; });
         else
-            tree_rne_lane<NG>(t->groups.data(), t->nslots, g, [&](int k) { return a[k]; }, [&](int k) { return b ? b[k] : 0.0; },
+            tree_rne_lane<NG, false, SIG>(t->groups.data(), t->nslots, g, [&](int k) { return a[k]; }, [&](int k) { return b ? b[k] : 0.0; },
                               [&](int k) { return c[k]; }, [&](int k, double v) { o[k] = v; },
                               [&](int i) -> double & { return slots[i]; });
     }
 }
 #include "emu_tree.h"
+// the structure signature tree.cpp computes for a robot (tree_device.h), for the test that pins the UR family's
+extern "C" unsigned long long emu_tree_signature(const rtbhip_tree_group *groups, int ng)
+{
+    Tree t;
+    if (compile_tree(groups, ng, &t) != RTBHIP_OK) return 0ull;
+    return t.sig;
+}
+extern "C" unsigned long long emu_tree_signature_ur() { return kTreeSigUR; }
+extern "C" unsigned long long emu_tree_signature_ibx8() { return kTreeSigIbx8; }
 extern "C" int emu_tree_dyn(const rtbhip_tree_group *groups, int ng, int mode, const double *q, const double *qd, const double *tq,
                             int64_t N, const double *grav3, double *out)
 {
     Tree t;
     if (compile_tree(groups, ng, &t) != RTBHIP_OK) return -1;
     V3 g = grav3 ? v3(grav3[0], grav3[1], grav3[2]) : v3(0, 0, 0);
+    if (rtbhip::tree_sig_enabled() && t.sig == kTreeSigUR) { tree_dyn_mode<6, kTreeSigUR>(mode, &t, q, qd, tq, N, g, out); return 0; }      // as launch_tree_dyn dispatches
+    if (rtbhip::tree_sig_enabled() && t.sig == kTreeSigIbx8) { tree_dyn_mode<8, kTreeSigIbx8>(mode, &t, q, qd, tq, N, g, out); return 0; }
     switch (t.n) {
     case 1: tree_dyn_mode<1>(mode, &t, q, qd, tq, N, g, out); break;
     case 2: tree_dyn_mode<2>(mode, &t, q, qd, tq, N, g, out); break;
@@ -175,6 +187,8 @@ extern "C" int emu_tree_rne(const rtbhip_tree_group *groups, int ng, const doubl
     Tree t;
     if (compile_tree(groups, ng, &t) != RTBHIP_OK) return -1;
     V3 g = v3(grav3[0], grav3[1], grav3[2]);
+    if (rtbhip::tree_sig_enabled() && t.sig == kTreeSigUR) { tree_run<6, kTreeSigUR>(&t, q, qd, qdd, N, g, tau); return 0; }      // as launch_tree_rne dispatches
+    if (rtbhip::tree_sig_enabled() && t.sig == kTreeSigIbx8) { tree_run<8, kTreeSigIbx8>(&t, q, qd, qdd, N, g, tau); return 0; }
     switch (ng) {
     case 1: tree_run<1>(&t, q, qd, qdd, N, g, tau); break;
     case 2: tree_run<2>(&t, q, qd, qdd, N, g, tau); break;

@@ -1,0 +1,136 @@
+"""Structure signatures of dynamics trees (csrc/tree_device.h: kTreeSigUR; tree.cpp: tree_signature; tree_kernels.hip's dispatch).
+
+The group constants of a URDF robot are mostly not general rotations; for the signature this build has instantiations for -- the UR family's --
+`k_tree_rne` / `k_tree_dyn` multiply by every constant in the form of its class, drop the cross-product terms of the zero translation
+components and compile the tree bookkeeping (parents, branch slots, prismatic joints) away.  The forms are the general recursion's with exact
+zeros dropped: the specialised kernels must agree with the general ones (rtbhip_tune "tree_sig" = 0) to rounding, and with the oracle
+(oracle/erobot.py, pinned on the reference's own mixin: test_erobot_dynamics.py) exactly as the general ones do.
+
+`-m "not gpu"`: the kernel bodies on the CPU replay (tests/emu mirrors the launcher's dispatch); `-m gpu`: the kernels themselves."""
+import ctypes as C
+
+import numpy as np
+import numpy.testing as nt
+import pytest
+
+import rtbhip
+from rtbhip import urdf
+from oracle import erobot as oer
+
+UR = ("UR3", "UR5", "UR10")
+
+
+IBX8 = ("px150", "rx150", "rx200", "vx300", "wx200", "wx250")
+
+
+def _signature(rob, which="ur"):
+    import emu_harness as emu
+    from rtbhip._lib import rtbhip_tree_group
+    recs = rob.erobot(()).group_table()
+    arr = (rtbhip_tree_group * len(recs))()
+    for k, r in enumerate(recs):
+        arr[k].parent, arr[k].kind, arr[k].flip, arr[k].jindex = r["parent"], r["kind"], r["flip"], r["jindex"]
+        arr[k].T[:] = list(np.ascontiguousarray(r["T"]).reshape(16))
+        arr[k].m = r["m"]
+        arr[k].h[:] = list(r["h"])
+        arr[k].I[:] = list(r["I"])
+    f = emu.lib().emu_tree_signature
+    f.argtypes, f.restype = [C.POINTER(rtbhip_tree_group), C.c_int32], C.c_uint64
+    g = getattr(emu.lib(), "emu_tree_signature_" + which)
+    g.restype = C.c_uint64
+    return f(arr, len(recs)), g()
+
+
+def _fields(sig, n):
+    return [((sig >> (7 * j)) & 15, (sig >> (7 * j + 4)) & 7) for j in range(n)]
+
+
+@pytest.mark.parametrize("name", UR)
+def test_ur_family_has_the_instantiated_signature(name):
+    sig, want = _signature(urdf.load(name))
+    assert sig == want, (_fields(sig, 6), _fields(want, 6), hex(sig >> 56))
+    assert sig >> 63 == 1 and (sig >> 56) & 1 == 1                    # present, plain serial chain of revolute joints
+
+
+@pytest.mark.parametrize("name", IBX8)
+def test_interbotix_arms_of_eight_groups_share_one_signature(name):
+    sig, want = _signature(urdf.load(name), "ibx8")
+    assert sig == want, (_fields(sig, 8), _fields(want, 8))
+    assert (sig >> 56) & 1 == 0                                        # a branched tree with prismatic fingers: not plain
+
+
+def test_other_robots_do_not():
+    for name in ("Panda", "Puma560"):
+        sig, want = _signature(urdf.load(name))
+        assert sig != want
+    sig, _ = _signature(urdf.load("YuMi"))                            # more groups than a signature describes
+    assert sig == 0
+
+
+def _terms(rob, q, qd, tq, g):
+    return {"rne": np.asarray(rob.rne(q, qd, tq, gravity=g)), "gravload": np.asarray(rob.gravload(q, gravity=g)),
+            "itorque": np.asarray(rob.itorque(q, tq)), "inertia": np.asarray(rob.inertia(q)), "coriolis": np.asarray(rob.coriolis(q, qd)),
+            "accel": np.asarray(rob.accel(q, qd, tq, gravity=g))}
+
+
+def _both(rob, q, qd, tq, g):
+    out = {}
+    try:
+        for s in (1, 0):
+            rtbhip.tune("tree_sig", s)
+            out[s] = _terms(rob, q, qd, tq, g)
+    finally:
+        rtbhip.tune("tree_sig", 1)
+    return out
+
+
+def _check(name, N, seed):
+    rob = urdf.load(name)
+    rng = np.random.default_rng(seed)
+    n = rob.n
+    q, qd, tq = rng.uniform(-3, 3, (N, n)), rng.normal(size=(N, n)), rng.normal(size=(N, n))
+    g = np.array([0.4, -0.3, -9.81])
+    out = _both(rob, q, qd, tq, g)
+    regular = np.linalg.cond(out[0]["inertia"]) < 1e8       # (the UR3's point-mass inertia matrix is singular: the reference's quirk, Robot.py:1793-1800)
+    for k in out[1]:
+        a, b = out[1][k], out[0][k]
+        if k == "accel":
+            a, b = a[regular], b[regular]
+        assert np.isfinite(b).all() and b.size or k == "accel"
+        tol = (1e-9 if k == "accel" else 1e-12) * max(1.0, np.abs(b).max() if b.size else 1.0)
+        nt.assert_allclose(a, b, rtol=0, atol=tol, err_msg=k)
+    return rob, q, qd, tq, g, out[1]
+
+
+@pytest.mark.parametrize("name", UR + ("wx250", "px150"))
+def test_signature_kernels_equal_the_general_kernels_on_the_cpu_replay(name):
+    import cpu_backend
+    with cpu_backend.installed():
+        rob, q, qd, tq, g, got = _check(name, 40, 11)
+    er = rob.erobot(())
+    links = [dict(name=l.name, parent=None if l.parent is None else l.parent.name, m=l.m, r=l.r,
+                  ets=[(e.axis, None, e.isflip) if e.isjoint else np.array(e.T) for e in l.ets]) for l in er.links]
+    k = slice(0, 6)
+    M = oer.erobot_inertia(links, q[k])
+    terms = [("rne", oer.erobot_rne(links, q[k], qd[k], tq[k], g)), ("inertia", M), ("coriolis", oer.erobot_coriolis(links, q[k], qd[k]))]
+    if np.linalg.cond(M).max() < 1e8:
+        terms.append(("accel", oer.erobot_accel(links, q[k], qd[k], tq[k], g)))
+    for term, want in terms:
+        nt.assert_allclose(got[term][k], want, rtol=0, atol=(1e-8 if term == "accel" else 1e-11) * max(1.0, np.abs(want).max()), err_msg=term)
+
+
+def test_switch_leaves_a_robot_with_another_signature_alone():
+    import cpu_backend
+    with cpu_backend.installed():
+        rob = urdf.load("Puma560")
+        rng = np.random.default_rng(3)
+        q, qd, tq = rng.uniform(-3, 3, (10, rob.n)), rng.normal(size=(10, rob.n)), rng.normal(size=(10, rob.n))
+        out = _both(rob, q, qd, tq, np.array([0, 0, -9.81]))
+    for k in out[1]:
+        nt.assert_array_equal(out[1][k], out[0][k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", UR + ("wx250", "rx150"))
+def test_gpu_signature_kernels_equal_the_general_kernels(name):
+    _check(name, 5000, 12)
