@@ -66,6 +66,12 @@ RTB_HD V3 rz(double s, double c, V3 v) { return v3(c * v.x - s * v.y, s * v.x + 
 // kTreeSigPlain: additionally a serial chain of revolute joints (parent of group j is group j - 1, no branch slots, no prismatic joint) --
 // the parent selection, slot traffic and prismatic branches are not compiled in: one straight-line basic block per group.
 constexpr SegSig kTreeSigPlain = 1ull << 56;
+// kTreeSigAnyConstants (with kTreeSigPlain): nothing is assumed about the group constants -- every one is multiplied as a general rotation, every
+// translation component may be non-zero.  The instantiation for "a serial chain of NG revolute joints", whatever the robot: most of what a
+// signature buys is the straight-line code (UR5: classes + masks + plain 1.65-2.3x; the branched Interbotix arms, classes alone, 1.08-1.14x).
+constexpr SegSig kTreeSigAnyConstants = 1ull << 57;
+constexpr SegSig kTreeSigPlainChain = kSegSigPresent | kTreeSigPlain | kTreeSigAnyConstants;
+constexpr int kTreePlainChainMax = 8;          // sizes with a plain-chain instantiation (tree_kernels.hip)
 constexpr int kTreeSigMaxGroups = 8;
 // The signatures with instantiations in this build (tree_kernels.hip; tree.cpp: tree_signature computes a robot's).  UR3 / UR5 / UR10 read
 // from their URDF: base translation; the shoulder's rpy = (0, pi/2, 0) with the file's 12-digit pi (general); a pure translation; a quarter
@@ -136,8 +142,11 @@ template <bool PLAIN, class G> RTB_HD V3 tree_origin(const G &g, double d)      
     return v3(g.C.t[0] + g.C.r[2] * d, g.C.t[1] + g.C.r[5] * d, g.C.t[2] + g.C.r[8] * d);
 }
 // what a core knows about group j at compile time (SIG = 0: nothing)
-template <SegSig SIG> RTB_HD constexpr int tree_cls(int j) { return SIG ? seg_sig_cls(SIG, j) : kSegGeneral; }
-template <SegSig SIG> RTB_HD constexpr int tree_tm(int j) { return (SIG & kTreeSigPlain) ? seg_sig_tm(SIG, j) : 7; }     // a prismatic joint adds R z d to p: plain chains only
+template <SegSig SIG> RTB_HD constexpr int tree_cls(int j) { return (SIG && !(SIG & kTreeSigAnyConstants)) ? seg_sig_cls(SIG, j) : kSegGeneral; }
+template <SegSig SIG> RTB_HD constexpr int tree_tm(int j)      // a prismatic joint adds R z d to p: masks for plain chains only
+{
+    return ((SIG & kTreeSigPlain) && !(SIG & kTreeSigAnyConstants)) ? seg_sig_tm(SIG, j) : 7;
+}
 template <class G> RTB_HD V3 inertia_rot(const G &g, V3 w)   // I_bar w
 {
     return v3(g.I[0] * w.x + g.I[3] * w.y + g.I[4] * w.z, g.I[3] * w.x + g.I[1] * w.y + g.I[5] * w.z,

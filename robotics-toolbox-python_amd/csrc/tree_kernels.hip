@@ -77,8 +77,11 @@ __global__ __launch_bounds__(kWave, (NG <= 8 ? 2 : 1)) void k_tree_rne(TreeParam
 
 template <int NG, SegSig SIG = 0>
 static void launch_ng(dim3 grid, size_t lds, hipStream_t s, const TreeParams &tp, const DevGroup *g, const double *q,
-                      const double *qd, const double *qdd, double *tau)
+                      const double *qd, const double *qdd, double *tau, bool plain = false)
 {
+    if constexpr (SIG == 0 && NG <= kTreePlainChainMax) {
+        if (plain) { launch_ng<NG, kTreeSigPlainChain>(grid, lds, s, tp, g, q, qd, qdd, tau); return; }      // a serial chain of revolute joints: straight-line code
+    }
     if constexpr (NG <= kTreeAtRestMax) {
         if (!qd) {
             auto k = k_tree_rne<NG, true, SIG>;
@@ -106,39 +109,40 @@ int launch_tree_rne(const Tree *t, const DevGroup *groups, const double *q, cons
     if (lds > 160 * 1024) { set_error("tree_rne: tree needs more LDS than a CU has"); return RTBHIP_ELIMIT; }
     dim3 grid((unsigned)tiles);
     const SegSig sig = g_tree_sig ? t->sig : 0;
+    const bool plain = (sig & kTreeSigPlain) != 0;
     if (sig == kTreeSigUR) {
         launch_ng<6, kTreeSigUR>(grid, lds, s, tp, groups, q, qd, qdd, tau);
     } else if (sig == kTreeSigIbx8) {
         launch_ng<8, kTreeSigIbx8>(grid, lds, s, tp, groups, q, qd, qdd, tau);
     } else
 #ifdef RTB_TREE_DEV_NG      // development builds (seconds instead of minutes): only this size is instantiated
-    launch_ng<RTB_TREE_DEV_NG>(grid, lds, s, tp, groups, q, qd, qdd, tau);
+    launch_ng<RTB_TREE_DEV_NG>(grid, lds, s, tp, groups, q, qd, qdd, tau, plain);
 #else
     switch (t->n) {
-    case 1: launch_ng<1>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
-    case 2: launch_ng<2>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
-    case 3: launch_ng<3>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
-    case 4: launch_ng<4>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
-    case 5: launch_ng<5>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
-    case 6: launch_ng<6>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
-    case 7: launch_ng<7>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
-    case 8: launch_ng<8>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
-    case 9: launch_ng<9>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
-    case 10: launch_ng<10>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
-    case 11: launch_ng<11>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
-    case 12: launch_ng<12>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
-    case 13: launch_ng<13>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
-    case 14: launch_ng<14>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
-    case 15: launch_ng<15>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
-    case 16: launch_ng<16>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
-    case 17: launch_ng<17>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
-    case 18: launch_ng<18>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
-    case 19: launch_ng<19>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
-    case 20: launch_ng<20>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
-    case 21: launch_ng<21>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
-    case 22: launch_ng<22>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
-    case 23: launch_ng<23>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
-    default: launch_ng<24>(grid, lds, s, tp, groups, q, qd, qdd, tau); break;
+    case 1: launch_ng<1>(grid, lds, s, tp, groups, q, qd, qdd, tau, plain); break;
+    case 2: launch_ng<2>(grid, lds, s, tp, groups, q, qd, qdd, tau, plain); break;
+    case 3: launch_ng<3>(grid, lds, s, tp, groups, q, qd, qdd, tau, plain); break;
+    case 4: launch_ng<4>(grid, lds, s, tp, groups, q, qd, qdd, tau, plain); break;
+    case 5: launch_ng<5>(grid, lds, s, tp, groups, q, qd, qdd, tau, plain); break;
+    case 6: launch_ng<6>(grid, lds, s, tp, groups, q, qd, qdd, tau, plain); break;
+    case 7: launch_ng<7>(grid, lds, s, tp, groups, q, qd, qdd, tau, plain); break;
+    case 8: launch_ng<8>(grid, lds, s, tp, groups, q, qd, qdd, tau, plain); break;
+    case 9: launch_ng<9>(grid, lds, s, tp, groups, q, qd, qdd, tau, plain); break;
+    case 10: launch_ng<10>(grid, lds, s, tp, groups, q, qd, qdd, tau, plain); break;
+    case 11: launch_ng<11>(grid, lds, s, tp, groups, q, qd, qdd, tau, plain); break;
+    case 12: launch_ng<12>(grid, lds, s, tp, groups, q, qd, qdd, tau, plain); break;
+    case 13: launch_ng<13>(grid, lds, s, tp, groups, q, qd, qdd, tau, plain); break;
+    case 14: launch_ng<14>(grid, lds, s, tp, groups, q, qd, qdd, tau, plain); break;
+    case 15: launch_ng<15>(grid, lds, s, tp, groups, q, qd, qdd, tau, plain); break;
+    case 16: launch_ng<16>(grid, lds, s, tp, groups, q, qd, qdd, tau, plain); break;
+    case 17: launch_ng<17>(grid, lds, s, tp, groups, q, qd, qdd, tau, plain); break;
+    case 18: launch_ng<18>(grid, lds, s, tp, groups, q, qd, qdd, tau, plain); break;
+    case 19: launch_ng<19>(grid, lds, s, tp, groups, q, qd, qdd, tau, plain); break;
+    case 20: launch_ng<20>(grid, lds, s, tp, groups, q, qd, qdd, tau, plain); break;
+    case 21: launch_ng<21>(grid, lds, s, tp, groups, q, qd, qdd, tau, plain); break;
+    case 22: launch_ng<22>(grid, lds, s, tp, groups, q, qd, qdd, tau, plain); break;
+    case 23: launch_ng<23>(grid, lds, s, tp, groups, q, qd, qdd, tau, plain); break;
+    default: launch_ng<24>(grid, lds, s, tp, groups, q, qd, qdd, tau, plain); break;
     }
 #endif
     note_launch((int)grid.x, kWave, (int)lds);
@@ -253,8 +257,11 @@ static hipError_t launch_tree_dyn_one(dim3 grid, hipStream_t s, int nslots, cons
 
 template <int NG, SegSig SIG = 0>
 static hipError_t launch_tree_dyn_ng(int mode, dim3 grid, hipStream_t s, int nslots, const TreeParams &tp, const DevGroup *g, const double *q,
-                                     const double *qd, const double *tq, double *out, size_t *lds)
+                                     const double *qd, const double *tq, double *out, size_t *lds, bool plain = false)
 {
+    if constexpr (SIG == 0 && NG <= kTreePlainChainMax) {
+        if (plain) return launch_tree_dyn_ng<NG, kTreeSigPlainChain>(mode, grid, s, nslots, tp, g, q, qd, tq, out, lds);
+    }
     if (mode == kDynInertia) return launch_tree_dyn_one<NG, kDynInertia, SIG>(grid, s, nslots, tp, g, q, qd, tq, out, lds);
     if (mode == kDynCoriolis) return launch_tree_dyn_one<NG, kDynCoriolis, SIG>(grid, s, nslots, tp, g, q, qd, tq, out, lds);
     return launch_tree_dyn_one<NG, kDynAccel, SIG>(grid, s, nslots, tp, g, q, qd, tq, out, lds);
@@ -274,35 +281,36 @@ int launch_tree_dyn(const Tree *t, const DevGroup *groups, int mode, const doubl
     size_t lds = 0;
     hipError_t e = hipSuccess;
     const SegSig sig = g_tree_sig ? t->sig : 0;
+    const bool plain = (sig & kTreeSigPlain) != 0;
     if (sig == kTreeSigUR) {
         e = launch_tree_dyn_ng<6, kTreeSigUR>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds);
     } else if (sig == kTreeSigIbx8) {
         e = launch_tree_dyn_ng<8, kTreeSigIbx8>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds);
     } else
 #ifdef RTB_TREE_DEV_NG
-    e = launch_tree_dyn_ng<RTB_TREE_DEV_NG>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds);
+    e = launch_tree_dyn_ng<RTB_TREE_DEV_NG>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds, plain);
 #else
     switch (t->n) {
-    case 1: e = launch_tree_dyn_ng<1>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
-    case 2: e = launch_tree_dyn_ng<2>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
-    case 3: e = launch_tree_dyn_ng<3>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
-    case 4: e = launch_tree_dyn_ng<4>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
-    case 5: e = launch_tree_dyn_ng<5>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
-    case 6: e = launch_tree_dyn_ng<6>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
-    case 7: e = launch_tree_dyn_ng<7>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
-    case 8: e = launch_tree_dyn_ng<8>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
-    case 9: e = launch_tree_dyn_ng<9>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
-    case 10: e = launch_tree_dyn_ng<10>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
-    case 11: e = launch_tree_dyn_ng<11>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
-    case 12: e = launch_tree_dyn_ng<12>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
-    case 13: e = launch_tree_dyn_ng<13>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
-    case 14: e = launch_tree_dyn_ng<14>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
-    case 15: e = launch_tree_dyn_ng<15>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
-    case 16: e = launch_tree_dyn_ng<16>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
-    case 17: e = launch_tree_dyn_ng<17>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
-    case 18: e = launch_tree_dyn_ng<18>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
-    case 19: e = launch_tree_dyn_ng<19>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
-    default: e = launch_tree_dyn_ng<20>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds); break;
+    case 1: e = launch_tree_dyn_ng<1>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds, plain); break;
+    case 2: e = launch_tree_dyn_ng<2>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds, plain); break;
+    case 3: e = launch_tree_dyn_ng<3>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds, plain); break;
+    case 4: e = launch_tree_dyn_ng<4>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds, plain); break;
+    case 5: e = launch_tree_dyn_ng<5>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds, plain); break;
+    case 6: e = launch_tree_dyn_ng<6>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds, plain); break;
+    case 7: e = launch_tree_dyn_ng<7>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds, plain); break;
+    case 8: e = launch_tree_dyn_ng<8>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds, plain); break;
+    case 9: e = launch_tree_dyn_ng<9>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds, plain); break;
+    case 10: e = launch_tree_dyn_ng<10>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds, plain); break;
+    case 11: e = launch_tree_dyn_ng<11>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds, plain); break;
+    case 12: e = launch_tree_dyn_ng<12>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds, plain); break;
+    case 13: e = launch_tree_dyn_ng<13>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds, plain); break;
+    case 14: e = launch_tree_dyn_ng<14>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds, plain); break;
+    case 15: e = launch_tree_dyn_ng<15>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds, plain); break;
+    case 16: e = launch_tree_dyn_ng<16>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds, plain); break;
+    case 17: e = launch_tree_dyn_ng<17>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds, plain); break;
+    case 18: e = launch_tree_dyn_ng<18>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds, plain); break;
+    case 19: e = launch_tree_dyn_ng<19>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds, plain); break;
+    default: e = launch_tree_dyn_ng<20>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds, plain); break;
     }
 #endif
     if (lds > 160 * 1024) { set_error("tree inertia/coriolis/accel: the robot needs more LDS than a CU has"); return RTBHIP_ELIMIT; }

@@ -163,6 +163,19 @@ extern "C" int emu_tree_dyn(const rtbhip_tree_group *groups, int ng, int mode, c
     V3 g = grav3 ? v3(grav3[0], grav3[1], grav3[2]) : v3(0, 0, 0);
     if (rtbhip::tree_sig_enabled() && t.sig == kTreeSigUR) { tree_dyn_mode<6, kTreeSigUR>(mode, &t, q, qd, tq, N, g, out); return 0; }      // as launch_tree_dyn dispatches
     if (rtbhip::tree_sig_enabled() && t.sig == kTreeSigIbx8) { tree_dyn_mode<8, kTreeSigIbx8>(mode, &t, q, qd, tq, N, g, out); return 0; }
+    if (rtbhip::tree_sig_enabled() && (t.sig & kTreeSigPlain)) {          // any other serial chain of up to 8 revolute joints: the plain-chain instantiation
+        switch (t.n) {
+        case 1: tree_dyn_mode<1, kTreeSigPlainChain>(mode, &t, q, qd, tq, N, g, out); return 0;
+        case 2: tree_dyn_mode<2, kTreeSigPlainChain>(mode, &t, q, qd, tq, N, g, out); return 0;
+        case 3: tree_dyn_mode<3, kTreeSigPlainChain>(mode, &t, q, qd, tq, N, g, out); return 0;
+        case 4: tree_dyn_mode<4, kTreeSigPlainChain>(mode, &t, q, qd, tq, N, g, out); return 0;
+        case 5: tree_dyn_mode<5, kTreeSigPlainChain>(mode, &t, q, qd, tq, N, g, out); return 0;
+        case 6: tree_dyn_mode<6, kTreeSigPlainChain>(mode, &t, q, qd, tq, N, g, out); return 0;
+        case 7: tree_dyn_mode<7, kTreeSigPlainChain>(mode, &t, q, qd, tq, N, g, out); return 0;
+        case 8: tree_dyn_mode<8, kTreeSigPlainChain>(mode, &t, q, qd, tq, N, g, out); return 0;
+        default: break;
+        }
+    }
     switch (t.n) {
     case 1: tree_dyn_mode<1>(mode, &t, q, qd, tq, N, g, out); break;
     case 2: tree_dyn_mode<2>(mode, &t, q, qd, tq, N, g, out); break;
@@ -189,6 +202,19 @@ extern "C" int emu_tree_rne(const rtbhip_tree_group *groups, int ng, const doubl
     V3 g = v3(grav3[0], grav3[1], grav3[2]);
     if (rtbhip::tree_sig_enabled() && t.sig == kTreeSigUR) { tree_run<6, kTreeSigUR>(&t, q, qd, qdd, N, g, tau); return 0; }      // as launch_tree_rne dispatches
     if (rtbhip::tree_sig_enabled() && t.sig == kTreeSigIbx8) { tree_run<8, kTreeSigIbx8>(&t, q, qd, qdd, N, g, tau); return 0; }
+    if (rtbhip::tree_sig_enabled() && (t.sig & kTreeSigPlain)) {
+        switch (t.n) {
+        case 1: tree_run<1, kTreeSigPlainChain>(&t, q, qd, qdd, N, g, tau); return 0;
+        case 2: tree_run<2, kTreeSigPlainChain>(&t, q, qd, qdd, N, g, tau); return 0;
+        case 3: tree_run<3, kTreeSigPlainChain>(&t, q, qd, qdd, N, g, tau); return 0;
+        case 4: tree_run<4, kTreeSigPlainChain>(&t, q, qd, qdd, N, g, tau); return 0;
+        case 5: tree_run<5, kTreeSigPlainChain>(&t, q, qd, qdd, N, g, tau); return 0;
+        case 6: tree_run<6, kTreeSigPlainChain>(&t, q, qd, qdd, N, g, tau); return 0;
+        case 7: tree_run<7, kTreeSigPlainChain>(&t, q, qd, qdd, N, g, tau); return 0;
+        case 8: tree_run<8, kTreeSigPlainChain>(&t, q, qd, qdd, N, g, tau); return 0;
+        default: break;
+        }
+    }
     switch (ng) {
     case 1: tree_run<1>(&t, q, qd, qdd, N, g, tau); break;
     case 2: tree_run<2>(&t, q, qd, qdd, N, g, tau); break;

@@ -24,9 +24,12 @@ IBX8 = ("px150", "rx150", "rx200", "vx300", "wx200", "wx250")
 
 
 def _signature(rob, which="ur"):
+    return _signature_of_table(rob.erobot(()).group_table(), which)
+
+
+def _signature_of_table(recs, which="ur"):
     import emu_harness as emu
     from rtbhip._lib import rtbhip_tree_group
-    recs = rob.erobot(()).group_table()
     arr = (rtbhip_tree_group * len(recs))()
     for k, r in enumerate(recs):
         arr[k].parent, arr[k].kind, arr[k].flip, arr[k].jindex = r["parent"], r["kind"], r["flip"], r["jindex"]
@@ -119,15 +122,56 @@ def test_signature_kernels_equal_the_general_kernels_on_the_cpu_replay(name):
         nt.assert_allclose(got[term][k], want, rtol=0, atol=(1e-8 if term == "accel" else 1e-11) * max(1.0, np.abs(want).max()), err_msg=term)
 
 
-def test_switch_leaves_a_robot_with_another_signature_alone():
+def test_switch_leaves_a_branched_robot_with_another_signature_alone():
     import cpu_backend
     with cpu_backend.installed():
-        rob = urdf.load("Puma560")
+        rob = urdf.load("px100")                                       # seven groups, branched (gripper fingers), no instantiation
+        sig, _ = _signature(rob)
+        assert sig >> 63 == 1 and (sig >> 56) & 1 == 0
         rng = np.random.default_rng(3)
         q, qd, tq = rng.uniform(-3, 3, (10, rob.n)), rng.normal(size=(10, rob.n)), rng.normal(size=(10, rob.n))
         out = _both(rob, q, qd, tq, np.array([0, 0, -9.81]))
     for k in out[1]:
         nt.assert_array_equal(out[1][k], out[0][k])
+
+
+def _random_serial_arm(n, seed):
+    """a serial chain of n revolute joints about random axes with random constants and point masses (rtbhip.ERobot of ETS links)"""
+    from rtbhip import ET, ETS, Link, ERobot
+    rng = np.random.default_rng(seed)
+    links, parent = [], None
+    for j in range(n):
+        const = ET.SE3(_random_se3(rng))
+        joint = [ET.Rx, ET.Ry, ET.Rz][int(rng.integers(3))](flip=bool(rng.integers(2)))
+        l = Link(ETS([const, joint]), name="l%d" % j, parent=parent, m=float(rng.uniform(0.5, 3)), r=rng.normal(size=3) * 0.1)
+        links.append(l)
+        parent = l
+    return ERobot(links)
+
+
+def _random_se3(rng):
+    from scipy.spatial.transform import Rotation
+    T = np.eye(4)
+    T[:3, :3] = Rotation.from_rotvec(rng.normal(size=3)).as_matrix()
+    T[:3, 3] = rng.normal(size=3) * 0.3
+    return T
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 7, 8, 9])
+def test_plain_chain_instantiation_serves_any_serial_revolute_arm(n):
+    """kTreeSigPlainChain (tree_device.h): a serial chain of up to eight revolute joints numbered in order takes the straight-line kernels whatever its
+    constants are -- same arithmetic as the general kernels, the bookkeeping compiled away: results agree to rounding; nine joints: general."""
+    import cpu_backend
+    rob = _random_serial_arm(n, 40 + n)
+    sig, _ = _signature_of_table(rob.group_table())
+    assert ((sig >> 56) & 1 == 1) == (n <= 8)
+    rng = np.random.default_rng(n)
+    q, qd, tq = rng.uniform(-3, 3, (12, n)), rng.normal(size=(12, n)), rng.normal(size=(12, n))
+    with cpu_backend.installed():
+        out = _both(rob, q, qd, tq, np.array([0.2, 0.1, -9.81]))
+    for k in out[1]:
+        b = out[0][k]
+        nt.assert_allclose(out[1][k], b, rtol=0, atol=(1e-9 if k == "accel" else 1e-12) * max(1.0, np.abs(b).max()), err_msg=k)
 
 
 @pytest.mark.gpu
