@@ -51,9 +51,19 @@ RTB_HD double dyn_pick(const double (&a)[NJ], int i)
 // Against the polar form  (tau(qd + s e_k) - tau(qd - s e_k)) / 4s  this is one pass of ~1.4x the arithmetic instead of two, it is exact for
 // any spread of velocities (no probe scale to choose, no cancellation: the rows whose velocities span many orders of magnitude need no other
 // scheme), and the links before `first` -- at rest under w when first <= k, so their wd, a, F, N vanish -- only advance w(u).
-template <int NJ, bool MDH, bool ALLREV, class LinksP, class InQ, class InQd, class Out>
+// acc + wd x p* + wu x (ww x p*) + ww x (wu x p*), p*'s zero components dropped (rne_device.h: offset_accel; pm = 7: the general chain)
+RTB_HD V3 offset_accel2(int pm, V3 wu, V3 ww, V3 wd, V3 ps, V3 acc)
+{
+    if (pm == 7) return cross_add(wd, ps, cross_add(wu, cross(ww, ps), cross_add(ww, cross(wu, ps), acc)));
+    int cu, cw;
+    const V3 xu = cross_bm(pm, wu, ps, cu), xw = cross_bm(pm, ww, ps, cw);
+    return cross_add_bm(pm, wd, ps, cross_add_bm(cw, wu, xw, cross_add_bm(cu, ww, xu, acc)));
+}
+// SIG: the chain's structure signature (rne_device.h: RneSig) -- flags, alpha classes and p* masks at compile time
+template <int NJ, bool MDH, bool ALLREV, RneSig SIG = 0, class LinksP, class InQ, class InQd, class Out>
 RTB_HD void rne_bilinear_core(LinksP links, double (&st)[NJ], double (&ct)[NJ], InQ qin, InQd qdin, int k, Out tau, int first)
 {
+    static_assert(SIG == 0 || (ALLREV && NJ <= kRneSigMaxLinks), "a structure signature describes an all-revolute chain");
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+s"(first), "+s"(k));       // (rne_core ACC: keeps the caller's column loop one loop)
 #else
@@ -63,7 +73,7 @@ RTB_HD void rne_bilinear_core(LinksP links, double (&st)[NJ], double (&ct)[NJ], 
     V3 F[NJ], Nn[NJ];
     int flg[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) flg[j] = links[j].flags;
+    for (int j = 0; j < NJ; ++j) flg[j] = SIG ? rsig_flags(SIG, j) : links[j].flags;
     V3 wu = o, ww = o, wd = o, a = o;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -72,7 +82,9 @@ RTB_HD void rne_bilinear_core(LinksP links, double (&st)[NJ], double (&ct)[NJ], 
         const bool pris = ALLREV ? false : (l.sigma != 0);
         const double qdu = qdin(j), qdw = j == k ? 1.0 : 0.0;
         const double d = pris ? qin(j) + l.offset : l.d;
-        const Rot R = {st[j], ct[j], l.sa, l.ca};
+        const int acls = SIG ? rsig_alpha(SIG, j) : 0, pm = SIG ? rsig_pmask(SIG, j) : 7;
+        const bool ps0 = SIG != 0 && (flg[j] & kLinkPsZero) != 0;          // compile-time only: a run-time branch on it costs more than it saves here
+        const Rot R = {st[j], ct[j], l.sa, l.ca, acls};
         const V3 ps = link_offset<MDH>(l, d);
         if (j < first) {               // wave-uniform: nothing moves under w yet
             if (MDH) wu = (j == 0) ? v3(0, 0, qdu) : (pris ? rot_inv<MDH>(R, wu) : addz(rot_inv<MDH>(R, wu), qdu));
@@ -87,7 +99,7 @@ RTB_HD void rne_bilinear_core(LinksP links, double (&st)[NJ], double (&ct)[NJ], 
                 nu = v3(0, 0, qdu); nw = v3(0, 0, qdw); wdn = o; an = o;
             } else {
                 const V3 tu = rot_inv<MDH>(R, wu), tw = rot_inv<MDH>(R, ww);
-                const V3 lin = rot_inv<MDH>(R, cross_add(wd, ps, cross_add(wu, cross(ww, ps), cross_add(ww, cross(wu, ps), a))));
+                const V3 lin = rot_inv<MDH>(R, ps0 ? a : offset_accel2(pm, wu, ww, wd, ps, a));
                 if (!pris) {
                     nu = addz(tu, qdu); nw = addz(tw, qdw);
                     wdn = rot_inv_add<MDH>(R, wd, crossz(tu, qdw) + crossz(tw, qdu));
@@ -103,7 +115,10 @@ RTB_HD void rne_bilinear_core(LinksP links, double (&st)[NJ], double (&ct)[NJ], 
                 nu = rot_inv<MDH>(R, (j == 0) ? v3(0, 0, qdu) : addz(wu, qdu));
                 nw = rot_inv<MDH>(R, (j == 0) ? v3(0, 0, qdw) : addz(ww, qdw));
                 wdn = (j == 0) ? o : rot_inv<MDH>(R, wd + (crossz(wu, qdw) + crossz(ww, qdu)));
-                an = cross_add(wdn, ps, cross_add(nu, cross(nw, ps), cross_add(nw, cross(nu, ps), (j == 0) ? o : rot_inv<MDH>(R, a))));
+                {
+                    const V3 ra = (j == 0) ? o : rot_inv<MDH>(R, a);
+                    an = ps0 ? ra : offset_accel2(pm, nu, nw, wdn, ps, ra);
+                }
             } else {
                 nu = (j == 0) ? o : rot_inv<MDH>(R, wu);
                 nw = (j == 0) ? o : rot_inv<MDH>(R, ww);
@@ -131,8 +146,9 @@ RTB_HD void rne_bilinear_core(LinksP links, double (&st)[NJ], double (&ct)[NJ], 
     }
     // ---- backward recursion + joint projection: rne_core's (ne.c:354-492) without friction, motor inertia (qdd = 0) and tip wrench
     V3 f = o, nn = o;
-    Rot Rn = {0, 1, 0, 1};
+    Rot Rn = {0, 1, 0, 1, 0};
     V3 psn = o;
+    int pmn = 7;
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj) {
         const int j = NJ - 1 - jj;
@@ -143,7 +159,8 @@ RTB_HD void rne_bilinear_core(LinksP links, double (&st)[NJ], double (&ct)[NJ], 
         const bool rzero = (flg[j] & kLinkRZero) != 0;
         const V3 rc = rzero ? o : v3(li.rx, li.ry, li.rz);
         const double d = pris ? qin(j) + l.offset : l.d;
-        const Rot R = {st[j], ct[j], l.sa, l.ca};
+        const int acls = SIG ? rsig_alpha(SIG, j) : 0, pm = SIG ? rsig_pmask(SIG, j) : 7;
+        const Rot R = {st[j], ct[j], l.sa, l.ca, acls};
         const V3 ps = link_offset<MDH>(l, d);
         V3 fj, nj;
         if (MDH) {
@@ -151,7 +168,7 @@ RTB_HD void rne_bilinear_core(LinksP links, double (&st)[NJ], double (&ct)[NJ], 
             fj = fn + F[j];
             const V3 base = rzero ? Nn[j] : cross_add(rc, F[j], Nn[j]);
             if (last) nj = nn + base;
-            else nj = cross_add(psn, fn, rot_fwd_add<MDH>(Rn, nn, base));
+            else nj = cross_add_am(pmn, psn, fn, rot_fwd_add<MDH>(Rn, nn, base));
         } else {
             fj = last ? F[j] + f : rot_fwd_add<MDH>(Rn, f, F[j]);
             const V3 base = cross_add(ps + rc, F[j], Nn[j]);
@@ -160,12 +177,12 @@ RTB_HD void rne_bilinear_core(LinksP links, double (&st)[NJ], double (&ct)[NJ], 
         }
         const V3 prj = pris ? fj : nj;
         tau(j, MDH ? prj.z : fmad(l.sa, prj.y, l.ca * prj.z));
-        f = fj; nn = nj; Rn = R; psn = ps;
+        f = fj; nn = nj; Rn = R; psn = ps; pmn = pm;
         sched_fence();
     }
 }
 
-template <int NJ, bool MDH, int MODE, bool ALLREV, class LinksP>
+template <int NJ, bool MDH, int MODE, bool ALLREV, RneSig SIG = 0, class LinksP>
 RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, const double *qrow = nullptr)
 {
     const V3 zero = v3(0, 0, 0);
@@ -181,7 +198,7 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, cons
         // passes for M.  This pass comes FIRST so that the kernel may keep q, qd and torque in the M tile itself until here (the
         // passes below overwrite them): 22.5 -> 14.8 KB of LDS per wave for n = 7, 7 -> 10 waves per CU
         dyn_opaque<NJ>(st, ct);
-        rne_core<NJ, MDH, true, ALLREV, true, false, false>(links, NJ, st, ct, grav, zero, zero, qin, [&](int j) { return mine[NJ + j]; },
+        rne_core<NJ, MDH, true, ALLREV, true, false, false, SIG>(links, NJ, st, ct, grav, zero, zero, qin, [&](int j) { return mine[NJ + j]; },
                                 [&](int) { return 0.0; }, [&](int j, double v) { b[j] = mine[2 * NJ + j] - v; });
 #if defined(__HIP_DEVICE_COMPILE__)
         // the pass must be over -- its link state dead -- before the passes below start (scheduled together they spill)
@@ -198,7 +215,7 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, cons
             if constexpr (ALLREV) {
                 // column i of M from the acceleration-only pass (rne_device.h): torques of joints j >= i = entries (j, i) of the
                 // packed lower triangle -- what accel's LDL^T solve reads, and what the inertia kernel's flush mirrors into (n, n)
-                rne_core<NJ, MDH, false, true, true, true, false>(links, NJ, st, ct, zero, zero, zero, qin, [&](int) { return 0.0; },
+                rne_core<NJ, MDH, false, true, true, true, false, SIG>(links, NJ, st, ct, zero, zero, zero, qin, [&](int) { return 0.0; },
                                         [&](int j) { return j == i ? 1.0 : 0.0; },
                                         [&](int j, double v) { mA[j * (j + 1) / 2 + i] = v; }, i);
             } else {
@@ -265,7 +282,7 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, cons
 #pragma unroll 1
         for (int k = 0; k < NJ; ++k) {
             dyn_opaque<NJ>(st, ct);
-            rne_bilinear_core<NJ, MDH, ALLREV>(links, st, ct, qin, [&](int j) { return qdv[j]; }, k,
+            rne_bilinear_core<NJ, MDH, ALLREV, SIG>(links, st, ct, qin, [&](int j) { return qdv[j]; }, k,
                                                [&](int r, double v) { mA[r * NJ + k] = 0.5 * v; }, k);
         }
 #else

@@ -95,7 +95,7 @@ __device__ __forceinline__ void flush_symmetric(const double *rows, int stride, 
     }
 }
 
-template <int NJ, bool MDH, int MODE, bool ALLREV>
+template <int NJ, bool MDH, int MODE, bool ALLREV, RneSig SIG = 0>
 __global__ __launch_bounds__(kDW, (NJ <= 8 ? 2 : 1)) void k_dyn(DynParams dp, const DevLink *links_g, const double *__restrict__ q,
                                                 const double *__restrict__ qd, const double *__restrict__ tq,
                                                 double *__restrict__ out)
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kDW, (NJ <= 8 ? 2 : 1)) void k_dyn(DynParams dp, co
     if (lane < ncfg) {
         // alias_q: the row holds qd only, at the offset dyn_lane expects it (mine[n + j])
         const double *mine = in + lane * in_stride - ((L::alias_q && !L::alias_all) ? NJ : 0);
-        dyn_lane<NJ, MDH, MODE, ALLREV>(links, mine, A + lane * L::w_stride, v3(dp.grav[0], dp.grav[1], dp.grav[2]),
+        dyn_lane<NJ, MDH, MODE, ALLREV, SIG>(links, mine, A + lane * L::w_stride, v3(dp.grav[0], dp.grav[1], dp.grav[2]),
                                         (L::alias_q && !L::alias_all) ? A + lane * L::w_stride : nullptr);
     }
     __syncthreads();
@@ -151,23 +151,27 @@ __global__ __launch_bounds__(kDW, (NJ <= 8 ? 2 : 1)) void k_dyn(DynParams dp, co
     else flush_run(A, L::w_stride, L::W, ncfg, out + cfg0 * L::W, lane);
 }
 
-template <int NJ, int MODE, bool MDH, bool ALLREV>
+template <int NJ, int MODE, bool MDH, bool ALLREV, RneSig SIG = 0>
 static hipError_t launch_one(dim3 grid, hipStream_t s, size_t lds, const DynParams &dp, const DevLink *links, const double *q,
                              const double *qd, const double *tq, double *out)
 {
-    auto k = k_dyn<NJ, MDH, MODE, ALLREV>;
+    auto k = k_dyn<NJ, MDH, MODE, ALLREV, SIG>;
     if (lds > 48 * 1024) { hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(k, grid, dim3(kDW), lds, s, dp, links, q, qd, tq, out);
     return hipGetLastError();
 }
 
+int rne_sig_enabled();      // rne_kernels.hip: rtbhip_tune("rne_sig")
 template <int NJ, int MODE>
 static hipError_t launch_mode(bool mdh, bool allrev, dim3 grid, hipStream_t s, const DynParams &dp, const DevLink *links, const double *q,
-                              const double *qd, const double *tq, double *out, size_t *lds_out)
+                              const double *qd, const double *tq, double *out, size_t *lds_out, RneSig sig)
 {
     const size_t lds = (size_t)(allrev ? DynLayout<NJ, MODE, true>::doubles
                                        : (mdh ? DynLayout<NJ, MODE, false, true>::doubles : DynLayout<NJ, MODE, false, false>::doubles)) * sizeof(double);
     *lds_out = lds;
+    // a robot whose link table has a structure signature this build is instantiated for (rne_device.h: kRneSig*)
+    if constexpr (NJ == 7) { if (sig == kRneSigPanda && mdh && allrev) return launch_one<7, MODE, true, true, kRneSigPanda>(grid, s, lds, dp, links, q, qd, tq, out); }
+    if constexpr (NJ == 6) { if (sig == kRneSigPuma560 && !mdh && allrev) return launch_one<6, MODE, false, true, kRneSigPuma560>(grid, s, lds, dp, links, q, qd, tq, out); }
     if (mdh) return allrev ? launch_one<NJ, MODE, true, true>(grid, s, lds, dp, links, q, qd, tq, out)
                            : launch_one<NJ, MODE, true, false>(grid, s, lds, dp, links, q, qd, tq, out);
     return allrev ? launch_one<NJ, MODE, false, true>(grid, s, lds, dp, links, q, qd, tq, out)
@@ -176,11 +180,11 @@ static hipError_t launch_mode(bool mdh, bool allrev, dim3 grid, hipStream_t s, c
 
 template <int NJ>
 static hipError_t launch_nj(int mode, bool mdh, bool allrev, dim3 grid, hipStream_t s, const DynParams &dp, const DevLink *links,
-                            const double *q, const double *qd, const double *tq, double *out, size_t *lds)
+                            const double *q, const double *qd, const double *tq, double *out, size_t *lds, RneSig sig = 0)
 {
-    if (mode == kDynInertia) return launch_mode<NJ, kDynInertia>(mdh, allrev, grid, s, dp, links, q, qd, tq, out, lds);
-    if (mode == kDynCoriolis) return launch_mode<NJ, kDynCoriolis>(mdh, allrev, grid, s, dp, links, q, qd, tq, out, lds);
-    return launch_mode<NJ, kDynAccel>(mdh, allrev, grid, s, dp, links, q, qd, tq, out, lds);
+    if (mode == kDynInertia) return launch_mode<NJ, kDynInertia>(mdh, allrev, grid, s, dp, links, q, qd, tq, out, lds, sig);
+    if (mode == kDynCoriolis) return launch_mode<NJ, kDynCoriolis>(mdh, allrev, grid, s, dp, links, q, qd, tq, out, lds, sig);
+    return launch_mode<NJ, kDynAccel>(mdh, allrev, grid, s, dp, links, q, qd, tq, out, lds, sig);
 }
 
 int launch_dyn(const Dyn *d, const DevLink *links, int mode, const double *q, const double *qd, const double *tq,
@@ -199,14 +203,15 @@ int launch_dyn(const Dyn *d, const DevLink *links, int mode, const double *q, co
     for (const DevLink &l : d->links) allrev = allrev && l.sigma == 0;
     hipError_t e = hipSuccess;
     size_t lds = 0;
+    const RneSig sig = (rne_sig_enabled() && allrev) ? rne_signature(d->links.data(), d->n) : 0;
     switch (d->n) {
     case 1: e = launch_nj<1>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
     case 2: e = launch_nj<2>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
     case 3: e = launch_nj<3>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
     case 4: e = launch_nj<4>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
     case 5: e = launch_nj<5>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
-    case 6: e = launch_nj<6>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
-    case 7: e = launch_nj<7>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    case 6: e = launch_nj<6>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds, sig); break;
+    case 7: e = launch_nj<7>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds, sig); break;
     case 8: e = launch_nj<8>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
     case 9: e = launch_nj<9>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;   // 9, 10: one wave per SIMD
     case 10: e = launch_nj<10>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;

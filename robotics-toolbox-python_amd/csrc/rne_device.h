@@ -31,10 +31,35 @@ RTB_HD double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 // R = Rz(theta) Rx(alpha), modified DH is R = Rx(alpha) Rz(theta), so R v and R^T v are two planar
 // rotations applied in turn straight from (sin theta, cos theta) [per lane] and (sin alpha, cos
 // alpha) [wave-uniform] -- 12 flops instead of 15 and no 9-register matrix to keep live.
-struct Rot { double s, c, sa, ca; };
+// acls: the STRUCTURE CLASS of alpha when the kernel knows it at compile time (RneSig below; 0 = nothing known): 1 alpha = 0 (sa = 0, ca = 1
+// exactly: the x rotation is the identity), 2 / 3 sa = +1 / -1 exactly (alpha = +-pi/2; ca keeps its libm value, 6.1e-17).  The class forms are
+// the general ones with the products by an exact 0 dropped and the products by an exact +-1 taken as the operand.
+struct Rot { double s, c, sa, ca; int acls; };
+// rotation about x by alpha of the pair (y, z):  fwd (ca y - sa z, sa y + ca z);  inv (ca y + sa z, ca z - sa y)
+RTB_HD void alpha_fwd(const Rot &r, double y, double z, double &oy, double &oz)
+{
+    if (r.acls == 1) { oy = y; oz = z; }
+    else if (r.acls == 2) { oy = __builtin_fma(r.ca, y, -z); oz = __builtin_fma(r.ca, z, y); }
+    else if (r.acls == 3) { oy = __builtin_fma(r.ca, y, z); oz = __builtin_fma(r.ca, z, -y); }
+    else { oy = r.ca * y - r.sa * z; oz = r.sa * y + r.ca * z; }
+}
+RTB_HD void alpha_inv(const Rot &r, double y, double z, double &oy, double &oz)
+{
+    if (r.acls == 1) { oy = y; oz = z; }
+    else if (r.acls == 2) { oy = __builtin_fma(r.ca, y, z); oz = __builtin_fma(r.ca, z, -y); }
+    else if (r.acls == 3) { oy = __builtin_fma(r.ca, y, -z); oz = __builtin_fma(r.ca, z, y); }
+    else { oy = r.ca * y + r.sa * z; oz = r.ca * z - r.sa * y; }
+}
 template <bool MDH>
 RTB_HD V3 rot_fwd(const Rot &r, V3 v)   // R v
 {
+    if (r.acls != 0) {
+        double oy, oz;
+        if (!MDH) { alpha_fwd(r, v.y, v.z, oy, oz); return v3(r.c * v.x - r.s * oy, r.s * v.x + r.c * oy, oz); }
+        const double ux = r.c * v.x - r.s * v.y, uy = r.s * v.x + r.c * v.y;
+        alpha_fwd(r, uy, v.z, oy, oz);
+        return v3(ux, oy, oz);
+    }
     if (!MDH) {
         const double uy = r.ca * v.y - r.sa * v.z, uz = r.sa * v.y + r.ca * v.z;
         return v3(r.c * v.x - r.s * uy, r.s * v.x + r.c * uy, uz);
@@ -46,6 +71,12 @@ RTB_HD V3 rot_fwd(const Rot &r, V3 v)   // R v
 template <bool MDH>
 RTB_HD V3 rot_inv(const Rot &r, V3 v)   // R^T v
 {
+    if (r.acls != 0) {
+        double oy, oz;
+        if (!MDH) { const double ux = r.c * v.x + r.s * v.y, uy = r.c * v.y - r.s * v.x; alpha_inv(r, uy, v.z, oy, oz); return v3(ux, oy, oz); }
+        alpha_inv(r, v.y, v.z, oy, oz);
+        return v3(r.c * v.x + r.s * oy, r.c * oy - r.s * v.x, oz);
+    }
     if (!MDH) {
         const double ux = r.c * v.x + r.s * v.y, uy = r.c * v.y - r.s * v.x;
         return v3(ux, r.ca * uy + r.sa * v.z, r.ca * v.z - r.sa * uy);
@@ -142,9 +173,105 @@ RTB_HD V3 cross_add(V3 a, V3 b, V3 acc)          // acc + a x b
 {
     return v3(fmad(a.y, b.z, fmad(-a.z, b.y, acc.x)), fmad(a.z, b.x, fmad(-a.x, b.z, acc.y)), fmad(a.x, b.y, fmad(-a.y, b.x, acc.z)));
 }
+// ---- STRUCTURE SIGNATURE of a DH / modified-DH chain of revolute links (up to 8): what the kernel may know about the link table at compile
+// time.  7 bits per link: the shortcut flags the host sets from EXACT zeros (kLinkRZero | kLinkIDiag | kLinkPsZero), the class of alpha (Rot),
+// a == 0, d == 0; bit 63 present, bit 62 no link has friction (B = 0 and Tc = 0: the viscous and Coulomb terms are exact zeros), bit 61 no motor inertia.  rne_core
+// instantiated for a signature reads no flag word and takes no wave-uniform branch on one, rotates about x in the form of alpha's class and
+// drops the cross-product terms of the zero components of p* = (a, -+d sa, d ca).  A kernel instantiated for a signature serves exactly the
+// robots whose table has it (rne_kernels.hip compares); every other robot takes the general kernels.
+typedef unsigned long long RneSig;
+constexpr RneSig kRneSigPresent = 1ull << 63, kRneSigNoFriction = 1ull << 62, kRneSigNoMotor = 1ull << 61;      // NoMotor: every G^2 Jm is an exact zero
+constexpr int kRneSigMaxLinks = 8;
+RTB_HD constexpr int rsig_flags(RneSig s, int j) { return (int)((s >> (7 * j)) & 7u); }
+RTB_HD constexpr int rsig_alpha(RneSig s, int j) { return (int)((s >> (7 * j + 3)) & 3u); }
+RTB_HD constexpr int rsig_pmask(RneSig s, int j)      // which components of p* may be non-zero: x = a; y = -+d sa; z = d ca
+{
+    const bool a0 = (s >> (7 * j + 5)) & 1u, d0 = (s >> (7 * j + 6)) & 1u;
+    return (a0 ? 0 : 1) | ((d0 || rsig_alpha(s, j) == 1) ? 0 : 2) | (d0 ? 0 : 4);
+}
+constexpr RneSig rsig_of(int j, int flags, int acls, bool a0, bool d0)
+{
+    return (RneSig)((flags & 7) | ((acls & 3) << 3) | ((a0 ? 1 : 0) << 5) | ((d0 ? 1 : 0) << 6)) << (7 * j);
+}
+template <class LinkT>
+inline RneSig rne_signature(const LinkT *links, int n)       // host: from the table api.cpp compiled (flags from exact zeros, sa / ca from libm)
+{
+    if (n < 1 || n > kRneSigMaxLinks) return 0;
+    RneSig s = kRneSigPresent | kRneSigNoFriction | kRneSigNoMotor;
+    for (int j = 0; j < n; ++j) {
+        const LinkT &l = links[j];
+        if (l.sigma != 0) return 0;
+        const int acls = (l.sa == 0.0 && l.ca == 1.0) ? 1 : (l.sa == 1.0 ? 2 : (l.sa == -1.0 ? 3 : 0));
+        s |= rsig_of(j, l.flags, acls, l.a == 0.0, l.d == 0.0);
+        if (l.gb != 0.0 || l.Tc0 != 0.0 || l.Tc1 != 0.0) s &= ~kRneSigNoFriction;
+        if (l.gjm != 0.0) s &= ~kRneSigNoMotor;
+    }
+    return s;
+}
+// Signatures with instantiations in this build (rne_kernels.hip, dyn_kernels.hip): the two DH models the reference ships with dynamics.
+//   Panda (modified DH, models/DH/Panda.py:44-157): centres of mass at the link origins, alpha = 0 / -+pi/2, a or d zero on most links, links 2 and
+//   6 at their predecessor's origin, no friction, no motor inertia
+constexpr RneSig kRneSigPanda = kRneSigPresent | kRneSigNoFriction | kRneSigNoMotor | rsig_of(0, 1, 1, true, false) | rsig_of(1, 5, 3, true, true) |
+                                rsig_of(2, 1, 2, true, false) | rsig_of(3, 1, 2, false, true) | rsig_of(4, 1, 3, false, false) | rsig_of(5, 5, 2, true, true) |
+                                rsig_of(6, 1, 2, false, false);
+//   Puma560 (standard DH, models/DH/Puma560.py:91-177): diagonal inertias, alpha = 0 / +-pi/2, friction and motor inertia on every joint
+constexpr RneSig kRneSigPuma560 = kRneSigPresent | rsig_of(0, 3, 2, true, false) | rsig_of(1, 2, 1, false, true) | rsig_of(2, 2, 3, false, false) |
+                                  rsig_of(3, 2, 2, true, false) | rsig_of(4, 7, 3, true, true) | rsig_of(5, 6, 1, true, true);
+static_assert(kRneSigPanda == 0xe00047a99a2c7ea9ull && kRneSigPuma560 == 0x80000377f646a533ull, "signatures as rne_signature computes them for the shipped models");
+// acc + u1 v1 - u2 v2 with the products of an absent (exactly zero) component dropped
+RTB_HD double fm2(bool has1, bool has2, double u1, double v1, double u2, double v2, double acc)
+{
+    if (has1 && has2) return fmad(u1, v1, fmad(-u2, v2, acc));
+    if (has1) return fmad(u1, v1, acc);
+    if (has2) return fmad(-u2, v2, acc);
+    return acc;
+}
+RTB_HD V3 cross_add_bm(int bm, V3 a, V3 b, V3 acc)     // acc + a x b, b's components outside bm exact zeros (7: cross_add)
+{
+    const bool X = bm & 1, Y = bm & 2, Z = bm & 4;
+    return v3(fm2(Z, Y, a.y, b.z, a.z, b.y, acc.x), fm2(X, Z, a.z, b.x, a.x, b.z, acc.y), fm2(Y, X, a.x, b.y, a.y, b.x, acc.z));
+}
+RTB_HD V3 cross_add_am(int am, V3 a, V3 b, V3 acc)     // acc + a x b, a's components outside am exact zeros
+{
+    const bool X = am & 1, Y = am & 2, Z = am & 4;
+    return v3(fm2(Y, Z, a.y, b.z, a.z, b.y, acc.x), fm2(Z, X, a.z, b.x, a.x, b.z, acc.y), fm2(X, Y, a.x, b.y, a.y, b.x, acc.z));
+}
+RTB_HD double df2(bool has1, bool has2, double u1, double v1, double u2, double v2)      // u1 v1 - u2 v2
+{
+    if (has1 && has2) return u1 * v1 - u2 * v2;
+    if (has1) return u1 * v1;
+    if (has2) return -(u2 * v2);
+    return 0.0;
+}
+RTB_HD V3 cross_bm(int bm, V3 a, V3 b, int &cm)        // a x b as cross_add_bm; cm: which components of the product may be non-zero
+{
+    const bool X = bm & 1, Y = bm & 2, Z = bm & 4;
+    cm = ((Z || Y) ? 1 : 0) | ((X || Z) ? 2 : 0) | ((Y || X) ? 4 : 0);
+    return v3(df2(Z, Y, a.y, b.z, a.z, b.y), df2(X, Z, a.z, b.x, a.x, b.z), df2(Y, X, a.x, b.y, a.y, b.x));
+}
+// acc + w x (w x p*) + wd x p*: the centripetal and tangential terms of a link offset, p*'s zero components dropped (pm = 7: the general chain)
+RTB_HD V3 offset_accel(int pm, V3 w, V3 wd, V3 ps, V3 acc)
+{
+    if (pm == 7) return cross_add(wd, ps, cross_add(w, cross(w, ps), acc));
+    int cm;
+    const V3 c = cross_bm(pm, w, ps, cm);
+    return cross_add_bm(pm, wd, ps, cross_add_bm(cm, w, c, acc));
+}
+
 template <bool MDH>
 RTB_HD V3 rot_inv_add(const Rot &r, V3 v, V3 acc)   // acc + R^T v
 {
+    if (r.acls != 0) {          // (alpha classes: Rot)
+        if (!MDH) {
+            const double uy = fmad(r.c, v.y, -(r.s * v.x)), x = fmad(r.c, v.x, fmad(r.s, v.y, acc.x));
+            if (r.acls == 1) return v3(x, acc.y + uy, acc.z + v.z);
+            if (r.acls == 2) return v3(x, fmad(r.ca, uy, acc.y + v.z), fmad(r.ca, v.z, acc.z - uy));
+            return v3(x, fmad(r.ca, uy, acc.y - v.z), fmad(r.ca, v.z, acc.z + uy));
+        }
+        const double uy = r.acls == 1 ? v.y : (r.acls == 2 ? fmad(r.ca, v.y, v.z) : fmad(r.ca, v.y, -v.z));
+        const double z = r.acls == 1 ? acc.z + v.z : (r.acls == 2 ? fmad(r.ca, v.z, acc.z - v.y) : fmad(r.ca, v.z, acc.z + v.y));
+        return v3(fmad(r.c, v.x, fmad(r.s, uy, acc.x)), fmad(r.c, uy, fmad(-r.s, v.x, acc.y)), z);
+    }
     if (!MDH) {
         const double uy = fmad(r.c, v.y, -(r.s * v.x));
         return v3(fmad(r.c, v.x, fmad(r.s, v.y, acc.x)), fmad(r.ca, uy, fmad(r.sa, v.z, acc.y)), fmad(r.ca, v.z, fmad(-r.sa, uy, acc.z)));
@@ -156,6 +283,17 @@ RTB_HD V3 rot_inv_add(const Rot &r, V3 v, V3 acc)   // acc + R^T v
 template <bool MDH>
 RTB_HD V3 rot_fwd_add(const Rot &r, V3 v, V3 acc)   // acc + R v
 {
+    if (r.acls != 0) {
+        if (!MDH) {
+            const double uy = r.acls == 1 ? v.y : (r.acls == 2 ? fmad(r.ca, v.y, -v.z) : fmad(r.ca, v.y, v.z));
+            const double z = r.acls == 1 ? acc.z + v.z : (r.acls == 2 ? fmad(r.ca, v.z, acc.z + v.y) : fmad(r.ca, v.z, acc.z - v.y));
+            return v3(fmad(r.c, v.x, fmad(-r.s, uy, acc.x)), fmad(r.s, v.x, fmad(r.c, uy, acc.y)), z);
+        }
+        const double uy = fmad(r.s, v.x, r.c * v.y), x = fmad(r.c, v.x, fmad(-r.s, v.y, acc.x));
+        if (r.acls == 1) return v3(x, acc.y + uy, acc.z + v.z);
+        if (r.acls == 2) return v3(x, fmad(r.ca, uy, acc.y - v.z), fmad(r.ca, v.z, acc.z + uy));
+        return v3(x, fmad(r.ca, uy, acc.y + v.z), fmad(r.ca, v.z, acc.z - uy));
+    }
     if (!MDH) {
         const double uy = fmad(r.ca, v.y, -(r.sa * v.z));
         return v3(fmad(r.c, v.x, fmad(-r.s, uy, acc.x)), fmad(r.s, v.x, fmad(r.c, uy, acc.y)), fmad(r.sa, v.y, fmad(r.ca, v.z, acc.z)));
@@ -213,12 +351,15 @@ struct NoWrench {
 
 // PSZ: honour the p* = 0 link flag (kLinkPsZero).  The single-pass kernels do (k_rne: -1.4 %); the multi-pass dynamics kernels do not -- there the
 // extra wave-uniform branches in every inlined pass cost 6-16 % (round 3, visit z: the round-2 tree beside this one on one box).
-template <int NJ, bool MDH, bool FRICTION, bool ALLREV, bool HAVE_TRIG, bool ACC = false, bool PSZ = true, class LinksP, class InQ, class InQd, class InQdd,
+template <int NJ, bool MDH, bool FRICTION_ARG, bool ALLREV, bool HAVE_TRIG, bool ACC = false, bool PSZ_ARG = true, RneSig SIG = 0, class LinksP, class InQ, class InQd, class InQdd,
           class Out, class WOut = NoWrench>
 RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_MAX_JOINTS], double (&ct)[NJ > 0 ? NJ : RTBHIP_MAX_JOINTS],
                      V3 grav, V3 ftip, V3 ntip, InQ qin, InQd qdin, InQdd qddin, Out tau, int first = 0, WOut wout = WOut())
 {
     static_assert(!ACC || (ALLREV && NJ > 0 && HAVE_TRIG), "the acceleration-only pass is built for all-revolute chains with compile-time n");
+    static_assert(SIG == 0 || (ALLREV && NJ > 0 && NJ <= kRneSigMaxLinks && HAVE_TRIG), "a structure signature describes an all-revolute chain with compile-time n");
+    constexpr bool FRICTION = FRICTION_ARG && !(SIG & kRneSigNoFriction);
+    constexpr bool PSZ = PSZ_ARG || SIG != 0;            // compile-time flags cost nothing
     if constexpr (ACC) {
         // `first` is the caller's pass counter: keep the optimiser from splitting the caller's loop into one specialised copy of this
         // whole recursion per value of it (the host build of tests/emu did not finish in 45 minutes); on the device it stays scalar
@@ -233,7 +374,7 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
     V3 F[CAP], Nn[CAP];
     int flg[CAP];                  // all the links' shortcut flags in one batch of scalar loads, ahead of the branches on them
 #pragma unroll
-    for (int j = 0; j < n; ++j) flg[j] = links[j].flags;
+    for (int j = 0; j < n; ++j) flg[j] = SIG ? rsig_flags(SIG, j) : links[j].flags;
 
     // ---- forward recursion (ne.c:133-348)
     // (ACC: the gravity field enters as the base's linear acceleration -- the general formulas inject it at link 0 in exactly that
@@ -257,7 +398,8 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
             rtb_sincos(th, &st[j], &ct[j]);
         }
         const double d = pris ? (NJ == 0 ? qin(j) : cur.qj) + l.offset : l.d;
-        const Rot R = {st[j], ct[j], l.sa, l.ca};
+        const int acls = SIG ? rsig_alpha(SIG, j) : 0, pm = SIG ? rsig_pmask(SIG, j) : 7;      // constants of the unrolled copy
+        const Rot R = {st[j], ct[j], l.sa, l.ca, acls};
         const V3 ps = link_offset<MDH>(l, d);
         if constexpr (ACC) {
             if (j >= first) {          // wave-uniform
@@ -265,10 +407,10 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
                 const bool ps0 = PSZ && (flg[j] & kLinkPsZero) != 0;      // wave-uniform: p* = 0, the cross products with it are exact zeros
                 if (MDH) {             // w = 0:  wd' = R^T wd + z qdd,  a' = R^T (a + wd x p*)
                     wdn = addz(rot_inv<MDH>(R, wd), qddj);
-                    an = rot_inv<MDH>(R, ps0 ? a : cross_add(wd, ps, a));
+                    an = rot_inv<MDH>(R, ps0 ? a : cross_add_bm(pm, wd, ps, a));
                 } else {               //         wd' = R^T (wd + z qdd),  a' = wd' x p* + R^T a
                     wdn = rot_inv<MDH>(R, v3(wd.x, wd.y, wd.z + qddj));
-                    an = ps0 ? rot_inv<MDH>(R, a) : cross_add(wdn, ps, rot_inv<MDH>(R, a));
+                    an = ps0 ? rot_inv<MDH>(R, a) : cross_add_bm(pm, wdn, ps, rot_inv<MDH>(R, a));
                 }
                 wd = wdn; a = an;
                 V3 ac = a;
@@ -294,7 +436,7 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
                     const V3 u = rot_inv_add<MDH>(R, wd, v3(t1.y * qdj, -(t1.x * qdj), 0.0));
                     wdn = ALLREV ? addz(u, qddj) : u + qddv;
                     // (p* = 0 -- a link whose origin coincides with its predecessor's: wave-uniform -- leaves a' = R^T a)
-                    an = rot_inv<MDH>(R, (PSZ && (flg[j] & kLinkPsZero)) ? a : cross_add(wd, ps, cross_add(w, cross(w, ps), a)));
+                    an = rot_inv<MDH>(R, (PSZ && (flg[j] & kLinkPsZero)) ? a : offset_accel(pm, w, wd, ps, a));
                 }
             } else {
                 if (j == 0) {
@@ -316,7 +458,7 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
                 wdn = rot_inv<MDH>(R, t3);
                 {
                     const V3 ra = rot_inv<MDH>(R, (j == 0) ? grav : a);
-                    an = (PSZ && (flg[j] & kLinkPsZero)) ? ra : cross_add(wdn, ps, cross_add(wn, cross(wn, ps), ra));
+                    an = (PSZ && (flg[j] & kLinkPsZero)) ? ra : offset_accel(pm, wn, wdn, ps, ra);
                 }
             } else {
                 wn = (j == 0) ? v3(0, 0, 0) : rot_inv<MDH>(R, w);
@@ -355,8 +497,9 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
 
     // ---- backward recursion + joint projection (ne.c:354-492), fused
     V3 f = ftip, nn = ntip;   // f_{j+1}, n_{j+1}; the reference's "tip" values for the last link
-    Rot Rn = {0, 1, 0, 1};    // frame of link j+1
+    Rot Rn = {0, 1, 0, 1, 0};    // frame of link j+1
     V3 psn = v3(0, 0, 0);
+    int pmn = 7;
     BwdOps bc = bwd_ops<ALLREV, FRICTION>(links[n - 1], flg[n - 1], n - 1, qin, qdin, qddin);
 #pragma unroll
     for (int jj = 0; jj < n; ++jj) {
@@ -372,7 +515,8 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
         const bool rzero = (flg[j] & kLinkRZero) != 0;
         const V3 rc = v3(bc.rx, bc.ry, bc.rz);
         const double d = pris ? (NJ == 0 ? qin(j) : bc.qj) + l.offset : l.d;
-        const Rot R = {st[j], ct[j], l.sa, l.ca};
+        const int acls = SIG ? rsig_alpha(SIG, j) : 0, pm = SIG ? rsig_pmask(SIG, j) : 7;
+        const Rot R = {st[j], ct[j], l.sa, l.ca, acls};
         const V3 ps = link_offset<MDH>(l, d);
         V3 fj, nj;
         if (MDH) {
@@ -382,7 +526,7 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
             // (psn = p* of link j + 1: zero for a kLinkPsZero link, wave-uniform)
             if (last) nj = nn + base;
             else if (PSZ && (flg[j + 1 < n ? j + 1 : j] & kLinkPsZero)) nj = rot_fwd_add<MDH>(Rn, nn, base);
-            else nj = cross_add(psn, fn, rot_fwd_add<MDH>(Rn, nn, base));
+            else nj = cross_add_am(pmn, psn, fn, rot_fwd_add<MDH>(Rn, nn, base));
         } else {
             fj = last ? F[j] + f : rot_fwd_add<MDH>(Rn, f, F[j]);
             const V3 base = cross_add(ps + rc, F[j], Nn[j]);
@@ -393,13 +537,13 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
         const V3 prj = pris ? fj : nj;
         const double qdj = bc.qdj, qddj = bc.qddj;
         double t = MDH ? prj.z : fmad(l.sa, prj.y, l.ca * prj.z);
-        t = fmad(l.gjm, qddj, t);
+        if (!(SIG & kRneSigNoMotor)) t = fmad(l.gjm, qddj, t);
         if (FRICTION) {
             t = fmad(l.gb, qdj, t);
             t = fmad(l.ag, (qdj > 0 ? l.Tc0 : 0.0) + (qdj < 0 ? l.Tc1 : 0.0), t);
         }
         tau(j, t);
-        f = fj; nn = nj; Rn = R; psn = ps;
+        f = fj; nn = nj; Rn = R; psn = ps; pmn = pm;
         bc = bn;
         if (!PF && NJ > 0 && !RTB_RNE_NOFENCE) sched_fence();
     }
@@ -415,15 +559,15 @@ RTB_HD void rne_core(LinksP links, int n_rt, double (&st)[NJ > 0 ? NJ : RTBHIP_M
 // One sample, trig included (the single-pass kernels and the run-time-n path).
 // ATREST: the caller knows qd = 0 for every joint (rtbhip_rne with qd = NULL: Dynamics.gravload, Dynamics.itorque): the
 // acceleration-only recursion from link 0, whole backward pass (all-revolute chains with compile-time n)
-template <int NJ, bool MDH, bool FRICTION = true, bool ALLREV = false, bool ATREST = false, class LinksP, class InQ, class InQd, class InQdd, class Out,
+template <int NJ, bool MDH, bool FRICTION = true, bool ALLREV = false, bool ATREST = false, RneSig SIG = 0, class LinksP, class InQ, class InQd, class InQdd, class Out,
           class WOut = NoWrench>
 RTB_HD void rne_lane(LinksP links, int n_rt, V3 grav, V3 ftip, V3 ntip, InQ qin, InQd qdin, InQdd qddin, Out tau, WOut wout = WOut())
 {
     constexpr int CAP = NJ > 0 ? NJ : RTBHIP_MAX_JOINTS;
     double st[CAP], ct[CAP];
     if constexpr (NJ > 0) rne_trig<NJ, ALLREV>(links, qin, st, ct);
-    if constexpr (ATREST) rne_core<NJ, MDH, false, true, true, true, false>(links, n_rt, st, ct, grav, ftip, ntip, qin, qdin, qddin, tau, 0);   // (PSZ off: +7 % on gravload with it, visit z)
-    else rne_core<NJ, MDH, FRICTION, ALLREV, (NJ > 0)>(links, n_rt, st, ct, grav, ftip, ntip, qin, qdin, qddin, tau, 0, wout);
+    if constexpr (ATREST) rne_core<NJ, MDH, false, true, true, true, false, SIG>(links, n_rt, st, ct, grav, ftip, ntip, qin, qdin, qddin, tau, 0);   // (PSZ off: +7 % on gravload with it, visit z)
+    else rne_core<NJ, MDH, FRICTION, ALLREV, (NJ > 0), false, true, SIG>(links, n_rt, st, ct, grav, ftip, ntip, qin, qdin, qddin, tau, 0, wout);
 }
 
 }  // namespace rtbhip

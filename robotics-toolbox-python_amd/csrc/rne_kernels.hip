@@ -58,7 +58,7 @@ __device__ __forceinline__ void tile_copy(double *rows, int stride, int col_off,
 // recursion with the LDS row as the accessor target (q is read once, up front; qd/qdd are re-read
 // from LDS where they are used, so they occupy no registers across the recursions; tau overwrites the
 // q slots, which are dead by then), write the torques back coalesced.
-template <int NJ, bool MDH, bool ALLREV, bool ATREST = false>
+template <int NJ, bool MDH, bool ALLREV, bool ATREST = false, RneSig SIG = 0>
 __device__ __forceinline__ void rne_tile(const RneParams &rp, ConstLinks links, int n, int stride, int64_t tile,
                                          const double *__restrict__ q, const double *__restrict__ qd,
                                          const double *__restrict__ qdd, double *__restrict__ tau, double *lds, int lane)
@@ -108,14 +108,14 @@ __device__ __forceinline__ void rne_tile(const RneParams &rp, ConstLinks links, 
     __syncthreads();
     if (lane < ncfg) {
         if constexpr (ATREST)
-            rne_lane<NJ, MDH, false, true, true>(links, n, grav, ftip, ntip, [&](int j) { return mine[j]; }, [&](int) { return 0.0; },
+            rne_lane<NJ, MDH, false, true, true, SIG>(links, n, grav, ftip, ntip, [&](int j) { return mine[j]; }, [&](int) { return 0.0; },
                               [&](int j) { return mine[2 * n + j]; }, [&](int j, double v) { mine[j] = v; });
         else if constexpr (NJ == 0)
             rne_lane<NJ, MDH, true, ALLREV>(links, n, grav, ftip, ntip, [&](int j) { return mine[j]; }, [&](int j) { return mine[n + j]; },
                               [&](int j) { return mine[2 * n + j]; }, [&](int j, double v) { mine[j] = v; },
                               WrenchRow{rp.wbase ? rp.wbase + (cfg0 + lane) * 6 : nullptr});
         else
-            rne_lane<NJ, MDH, true, ALLREV>(links, n, grav, ftip, ntip, [&](int j) { return mine[j]; }, [&](int j) { return mine[n + j]; },
+            rne_lane<NJ, MDH, true, ALLREV, false, SIG>(links, n, grav, ftip, ntip, [&](int j) { return mine[j]; }, [&](int j) { return mine[n + j]; },
                               [&](int j) { return mine[2 * n + j]; }, [&](int j, double v) { mine[j] = v; });
     }
     __syncthreads();
@@ -143,13 +143,13 @@ __device__ __forceinline__ void rne_tile(const RneParams &rp, ConstLinks links, 
 // LICM hoists every link's scalar table loads into the preheader, where they overflow the SGPR file;
 // first MI355X measurement of the looped version: 256 VGPRs + 90 AGPRs + 112 spilled SGPRs, one
 // wave per SIMD, 0.31 ms per 1.25e6 Panda triples).
-template <int NJ, bool MDH, bool ALLREV>
-__global__ __launch_bounds__(kW, RTB_RNE_WAVES) void k_rne(RneParams rp, const DevLink *links_g, const double *__restrict__ q,
+template <int NJ, bool MDH, bool ALLREV, RneSig SIG = 0>
+__global__ __launch_bounds__(kW, (SIG ? 3 : RTB_RNE_WAVES)) void k_rne(RneParams rp, const DevLink *links_g, const double *__restrict__ q,
                                            const double *__restrict__ qd, const double *__restrict__ qdd,
                                            double *__restrict__ tau)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    rne_tile<NJ, MDH, ALLREV>(rp, (ConstLinks)links_g, NJ, rne_stride(NJ), blockIdx.x, q, qd, qdd, tau, lds, threadIdx.x);
+    rne_tile<NJ, MDH, ALLREV, false, SIG>(rp, (ConstLinks)links_g, NJ, rne_stride(NJ), blockIdx.x, q, qd, qdd, tau, lds, threadIdx.x);
 }
 
 // The same tile function, WPB waves per workgroup, every wave on a tile of its own (rtbhip_tune("rne_wpb", 2 | 4)): a quarter of the
@@ -188,12 +188,12 @@ __global__ __launch_bounds__(kW, RTB_RNE_WAVES) void k_rne_persist(RneParams rp,
 // qd = NULL on an all-revolute chain (Dynamics.gravload: qd = qdd = 0; Dynamics.itorque: qd = 0, no gravity): every link's
 // angular velocity is zero, so the forward recursion is the acceleration-only one of rne_device.h (ACC) from link 0 -- about
 // half its fp64 operations -- with gravity entering as the base's linear acceleration; the backward recursion is the usual one.
-template <int NJ, bool MDH>
+template <int NJ, bool MDH, RneSig SIG = 0>
 __global__ __launch_bounds__(kW, RTB_RNE_WAVES) void k_rne_atrest(RneParams rp, const DevLink *links_g, const double *__restrict__ q,
                                                   const double *__restrict__ qdd, double *__restrict__ tau)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    rne_tile<NJ, MDH, true, true>(rp, (ConstLinks)links_g, NJ, rne_stride(NJ), blockIdx.x, q, nullptr, qdd, tau, lds, threadIdx.x);
+    rne_tile<NJ, MDH, true, true, SIG>(rp, (ConstLinks)links_g, NJ, rne_stride(NJ), blockIdx.x, q, nullptr, qdd, tau, lds, threadIdx.x);
 }
 
 // run-time joint count (n > 8): grid-stride over tiles, per-link state in private memory
@@ -212,18 +212,35 @@ __global__ __launch_bounds__(kW) void k_rne_rt(RneParams rp, const DevLink *link
     }
 }
 
-namespace { int g_rne_tiles_per_wave = 1; int g_rne_persist = 0; int g_rne_wpb = 1; }
+namespace { int g_rne_tiles_per_wave = 1; int g_rne_persist = 0; int g_rne_wpb = 1; int g_rne_sig = 1; }
+int rne_sig_enabled() { return g_rne_sig; }
 void rne_tune(const char *key, int value)
 {
+    if (std::string(key) == "rne_sig") g_rne_sig = value != 0;          // 0: never take a structure signature's instantiation (A/B, tests)
     if (std::string(key) == "rne_persist") g_rne_persist = value < 0 ? 0 : (value > 4 ? 4 : value);      // waves per SIMD of the persistent grid, 0 = one tile per workgroup
     if (std::string(key) == "rne_wpb") g_rne_wpb = (value == 2 || value == 4) ? value : 1;
     if (std::string(key) == "rne_tiles_per_wave") g_rne_tiles_per_wave = value < 1 ? 1 : value;
 }
 
+// a robot whose link table has a structure signature this build is instantiated for (rne_device.h: kRneSig*): straight-line kernels
+template <int NJ, bool MDH, RneSig SIG>
+static void launch_sig(dim3 grid, size_t lds, hipStream_t s, const RneParams &rp, const DevLink *links, const double *q, const double *qd, const double *qdd,
+                       double *tau)
+{
+    if (!qd) hipLaunchKernelGGL((k_rne_atrest<NJ, MDH, SIG>), grid, dim3(kW), lds, s, rp, links, q, qdd, tau);
+    else hipLaunchKernelGGL((k_rne<NJ, MDH, true, SIG>), grid, dim3(kW), lds, s, rp, links, q, qd, qdd, tau);
+}
+
 template <int NJ>
 static void launch_nj(bool mdh, bool allrev, dim3 grid, size_t lds, hipStream_t s, const RneParams &rp, const DevLink *links,
-                      const double *q, const double *qd, const double *qdd, double *tau)
+                      const double *q, const double *qd, const double *qdd, double *tau, RneSig sig = 0)
 {
+    if constexpr (NJ == 7) {
+        if (sig == kRneSigPanda && mdh && !g_rne_persist && g_rne_wpb == 1) { launch_sig<7, true, kRneSigPanda>(grid, lds, s, rp, links, q, qd, qdd, tau); return; }
+    }
+    if constexpr (NJ == 6) {
+        if (sig == kRneSigPuma560 && !mdh && !g_rne_persist) { launch_sig<6, false, kRneSigPuma560>(grid, lds, s, rp, links, q, qd, qdd, tau); return; }
+    }
     if (allrev && !qd) {
         if (mdh) hipLaunchKernelGGL((k_rne_atrest<NJ, true>), grid, dim3(kW), lds, s, rp, links, q, qdd, tau);
         else hipLaunchKernelGGL((k_rne_atrest<NJ, false>), grid, dim3(kW), lds, s, rp, links, q, qdd, tau);
@@ -280,15 +297,16 @@ int launch_rne(const Dyn *d, const DevLink *links, const double *q, const double
     int64_t g = rt ? (tiles + g_rne_tiles_per_wave - 1) / g_rne_tiles_per_wave : tiles;
     if (g > 0x7fffffff) g = 0x7fffffff;
     dim3 grid((unsigned)g);
+    const RneSig sig = (g_rne_sig && !rt) ? rne_signature(d->links.data(), d->n) : 0;
     switch (rt ? 0 : d->n) {
-    case 1: launch_nj<1>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau); break;
-    case 2: launch_nj<2>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau); break;
-    case 3: launch_nj<3>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau); break;
-    case 4: launch_nj<4>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau); break;
-    case 5: launch_nj<5>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau); break;
-    case 6: launch_nj<6>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau); break;
-    case 7: launch_nj<7>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau); break;
-    case 8: launch_nj<8>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau); break;
+    case 1: launch_nj<1>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau, sig); break;
+    case 2: launch_nj<2>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau, sig); break;
+    case 3: launch_nj<3>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau, sig); break;
+    case 4: launch_nj<4>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau, sig); break;
+    case 5: launch_nj<5>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau, sig); break;
+    case 6: launch_nj<6>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau, sig); break;
+    case 7: launch_nj<7>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau, sig); break;
+    case 8: launch_nj<8>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau, sig); break;
     default: launch_rt(mdh, grid, lds, s, rp, links, q, qd, qdd, tau); break;
     }
     note_launch((int)grid.x, kW, (int)lds);

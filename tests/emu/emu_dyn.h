@@ -3,6 +3,7 @@
 #pragma once
 #include "emu_common.h"
 
+namespace rtbhip { int rne_sig_enabled(); }      // rne_kernels.hip: rtbhip_tune("rne_sig")
 // dynamics terms: the kernel's per-lane body (dyn_device.h) on host arrays laid out like the LDS tile rows
 template <int NJ, bool MDH, int MODE>
 static void dyn_run(const Dyn *d, const double *q, const double *qd, const double *tq, int64_t N, V3 g, double *out)
@@ -21,7 +22,13 @@ static void dyn_run(const Dyn *d, const double *q, const double *qd, const doubl
         const bool alias_all = (MODE == kDynAccel && allrev && 3 * NJ <= NJ * (NJ + 1) / 2) || (MODE == kDynCoriolis && allrev && NJ >= 2);
         if (alias_all) for (int k = 0; k < (MODE == kDynAccel ? 3 : 2) * NJ; ++k) A[k] = in[k];
         const double *mine = alias_all ? A.data() : in.data();
-        if (allrev) dyn_lane<NJ, MDH, MODE, true>(links, mine, A.data(), g);
+        // as launch_dyn dispatches: the instantiation of the robot's structure signature, where this build has one (rne_device.h: kRneSig*)
+        const RneSig sig = (rtbhip::rne_sig_enabled() && allrev) ? rne_signature(links, d->n) : 0;
+        bool done = false;
+        if constexpr (NJ == 7 && MDH) { if (sig == kRneSigPanda) { dyn_lane<7, true, MODE, true, kRneSigPanda>(links, mine, A.data(), g); done = true; } }
+        if constexpr (NJ == 6 && !MDH) { if (sig == kRneSigPuma560) { dyn_lane<6, false, MODE, true, kRneSigPuma560>(links, mine, A.data(), g); done = true; } }
+        if (done) {}
+        else if (allrev) dyn_lane<NJ, MDH, MODE, true>(links, mine, A.data(), g);
         else dyn_lane<NJ, MDH, MODE, false>(links, mine, A.data(), g);
         const int W = MODE == kDynAccel ? NJ : NJ * NJ;
         if (MODE == kDynInertia && allrev) {           // packed lower triangle -> (n, n), as the kernel's flush_symmetric

@@ -1,6 +1,24 @@
 // tests/emu/emu_rne.cpp -- TEST INFRASTRUCTURE: Newton-Euler kernel body (and the entry point of the dynamics terms) replayed on the CPU.
 #include "emu_dyn.h"
 
+namespace rtbhip { int rne_sig_enabled(); }      // rne_kernels.hip: rtbhip_tune("rne_sig")
+// SIG != 0: the instantiation launch_rne picks for a robot with that structure signature (rne_device.h: kRneSig*)
+template <int NJ, bool MDH, RneSig SIG>
+static void rne_run_sig(const Dyn *d, const double *q, const double *qd, const double *qdd, int64_t N, V3 g, V3 f, V3 nt, double *tau)
+{
+    const DevLink *links = d->links.data();
+    for (int64_t s = 0; s < N; ++s) {
+        const double *a = q + s * NJ, *b = qd ? qd + s * NJ : nullptr, *c = qdd ? qdd + s * NJ : nullptr;
+        double *o = tau + s * NJ;
+        auto qi = [&](int j) { return a[j]; };
+        auto qdi = [&](int j) { return b ? b[j] : 0.0; };
+        auto qddi = [&](int j) { return c ? c[j] : 0.0; };
+        auto out = [&](int j, double v) { o[j] = v; };
+        if (!qd) rne_lane<NJ, MDH, false, true, true, SIG>(links, NJ, g, f, nt, qi, qdi, qddi, out);
+        else rne_lane<NJ, MDH, true, true, false, SIG>(links, NJ, g, f, nt, qi, qdi, qddi, out);
+    }
+}
+
 template <int NJ>
 static void rne_run(const Dyn *d, const double *q, const double *qd, const double *qdd, int64_t N, V3 g, V3 f, V3 nt,
                     double *tau)
@@ -28,6 +46,13 @@ static void rne_run(const Dyn *d, const double *q, const double *qd, const doubl
     }
 }
 
+// the structure signature rne_kernels.hip computes for a robot (rne_device.h: rne_signature), for the tests that pin the shipped models'
+extern "C" unsigned long long emu_rne_signature(rtbhip_dyn_t h)
+{
+    const std::shared_ptr<Dyn> d_owner = dyn_from_handle(h);
+    return d_owner ? rne_signature(d_owner->links.data(), d_owner->n) : 0ull;
+}
+
 extern "C" int emu_rne(rtbhip_dyn_t h, const double *q, const double *qd, const double *qdd, int64_t N,
                        const double *grav3, const double *fext6, double *tau, int force_generic)
 {
@@ -38,6 +63,9 @@ extern "C" int emu_rne(rtbhip_dyn_t h, const double *q, const double *qd, const 
     V3 f = fext6 ? v3(fext6[0], fext6[1], fext6[2]) : v3(0, 0, 0);
     V3 nt = fext6 ? v3(fext6[3], fext6[4], fext6[5]) : v3(0, 0, 0);
     if (force_generic) { rne_run<0>(d, q, qd, qdd, N, g, f, nt, tau); return 0; }
+    const RneSig sig = rtbhip::rne_sig_enabled() ? rne_signature(d->links.data(), d->n) : 0;
+    if (sig == kRneSigPanda && d->mdh) { rne_run_sig<7, true, kRneSigPanda>(d, q, qd, qdd, N, g, f, nt, tau); return 0; }
+    if (sig == kRneSigPuma560 && !d->mdh) { rne_run_sig<6, false, kRneSigPuma560>(d, q, qd, qdd, N, g, f, nt, tau); return 0; }
     switch (d->n) {
     case 1: rne_run<1>(d, q, qd, qdd, N, g, f, nt, tau); break;
     case 2: rne_run<2>(d, q, qd, qdd, N, g, f, nt, tau); break;
