@@ -193,7 +193,7 @@ def main():
                 "kernel_avg_ms": avg, "kernel_min_ms": best, "python_wrapper_ms": wavg,
                 "roofline": {"bound": "hbm", "achieved": 224.0 * N / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": 224.0 * N / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": 224 * N,
-                             "kernel": "k_rne<7,MDH,all-revolute> on rank 0's rows"}}
+                             "kernel": "k_rne<7,MDH,all-revolute,kRneSigPanda> on rank 0's rows"}}
         if N == 1250000:        # the committed PMC passes are of this shard size
             tr, src = pmc_traffic(ROOT, "r05_pmc_rne.json")
             line["roofline"]["traffic"], line["roofline"]["traffic_source"] = tr, src
@@ -239,8 +239,8 @@ def main():
                                   "inertia": "acceleration-only passes from link i on, mirrored (csrc/rne_device.h ACC)",
                                   "coriolis": "one two-field pass per column: C[:, k] = B(qd, e_k), the bilinear form of the velocity torque evaluated directly from link k on (csrc/dyn_device.h rne_bilinear_core; the reference runs 28 full passes, rounds 1-3 ran 14)",
                                   "accel": "1 full pass + 7 acceleration-only passes + LDL^T solve"}[name],
-                    "roofline": valu_roofline(name, N / (avg * 1e-3), {"gravload": "k_rne_atrest<7,MDH>", "inertia": "k_dyn<7,MDH,inertia>",
-                                                                        "coriolis": "k_dyn<7,MDH,coriolis>", "accel": "k_dyn<7,MDH,accel>"}[name], byts)}
+                    "roofline": valu_roofline(name, N / (avg * 1e-3), {"gravload": "k_rne_atrest<7,MDH,kRneSigPanda>", "inertia": "k_dyn<7,MDH,inertia,kRneSigPanda>",
+                                                                        "coriolis": "k_dyn<7,MDH,coriolis,kRneSigPanda>", "accel": "k_dyn<7,MDH,accel,kRneSigPanda>"}[name], byts)}
             if not args.no_cpu and name == "inertia":
                 from oracle import ref_harness
                 if ref_harness.available():
@@ -373,12 +373,12 @@ def main():
         byts = 32 * er.n
         print(json.dumps({"metric": "triples/sec (URDF UR5 Robot.rne, %d link groups)" % er.n, "value": N / (avg * 1e-3), "unit": "triples/s",
                           "n": N, "kernel_avg_ms": avg, "kernel_min_ms": best,
-                          "roofline": valu_roofline("tree_ur5", N / (avg * 1e-3), "k_tree_rne<6>", byts)}), flush=True)
+                          "roofline": valu_roofline("tree_ur5", N / (avg * 1e-3), "k_tree_rne<6, kTreeSigUR>", byts)}), flush=True)
         # Dynamics.gravload of the same arm: rtbhip_tree_rne with qd = NULL -> the at-rest instantiation (no velocity half, no qd row)
         avg, best = ev_time(lambda: er.gravload(q), args.steps, 3)
         print(json.dumps({"metric": "configurations/sec (URDF UR5 gravload, %d link groups)" % er.n, "value": N / (avg * 1e-3), "unit": "configurations/s",
                           "n": N, "kernel_avg_ms": avg, "kernel_min_ms": best,
-                          "roofline": valu_roofline("tree_gravload_ur5", N / (avg * 1e-3), "k_tree_rne<6, at rest>", 16 * er.n)}), flush=True)
+                          "roofline": valu_roofline("tree_gravload_ur5", N / (avg * 1e-3), "k_tree_rne<6, at rest, kTreeSigUR>", 16 * er.n)}), flush=True)
         # the Dynamics-mixin terms of the same URDF arm (Dynamics.inertia / coriolis / accel over Robot.rne): k_tree_dyn<6, mode>
         tq = qdd
         for name, fn, byts, key in (("inertia", lambda: er.inertia(q), 8 * er.n + 8 * er.n * er.n, "tree_inertia_ur5"),
@@ -388,7 +388,7 @@ def main():
             line = {"metric": "configurations/sec (URDF UR5 %s, Dynamics mixin over Robot.rne)" % name, "value": N / (avg * 1e-3),
                     "unit": "configurations/s", "n": N, "kernel_avg_ms": avg, "kernel_min_ms": best}
             if key in VALU_PER_UNIT:
-                line["roofline"] = valu_roofline(key, N / (avg * 1e-3), "k_tree_dyn<6,%s>" % name, byts)
+                line["roofline"] = valu_roofline(key, N / (avg * 1e-3), "k_tree_dyn<6,%s,kTreeSigUR>" % name, byts)
             else:
                 line["hbm_GBs"] = byts * N / (avg * 1e-3) / 1e9
             print(json.dumps(line), flush=True)

@@ -203,12 +203,12 @@ def rne_config4(rtbhip, N=10000000, shard=1250000, sample=20000):
                                             "memory system, moves these: profiles/r04_rne_1e7.txt"},
             "parity": {"against": against, "sample": "%d rows, every %d-th of the batch" % (len(got), max(1, N // sample)),
                        "max_rel_err": rel, "tolerance": 1e-9, "cpu_seconds": cpu_s, "cpu_triples_per_s": len(got) / cpu_s},
-            "roofline": _hbm(RNE_BYTES_PER_TRIPLE * N, ms_full, "k_rne<7,MDH,all-revolute>")}
+            "roofline": _hbm(RNE_BYTES_PER_TRIPLE * N, ms_full, "k_rne<7,MDH,all-revolute,kRneSigPanda>")}
     part = {"workload": "BASELINE configs[3] per-GPU share: the first %d of the same triples (what one of 8 ranks owns)" % shard,
             "value": shard / (ms_shard * 1e-3), "unit": "triples/s", "n": shard, "kernel_avg_ms": ms_shard, "launches_timed": reps_s,
             "launches_warmup": warm_s, "burst_ms_after_idle": burst_shard,
             "parity": "rows of the same buffers and the same kernel as rne_config4_1e7 (its sample covers this range)",
-            "roofline": _hbm(RNE_BYTES_PER_TRIPLE * shard, ms_shard, "k_rne<7,MDH,all-revolute>")}
+            "roofline": _hbm(RNE_BYTES_PER_TRIPLE * shard, ms_shard, "k_rne<7,MDH,all-revolute,kRneSigPanda>")}
     del q, qd, qdd, tau
     torch.cuda.empty_cache()
     return full, part

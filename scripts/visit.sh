@@ -7,6 +7,7 @@
 #   bench   python bench.py $BENCH_ARGS (default --steps 50 --warmup 5)                         -> bench_n1.json
 #   prof    rocprofv3 --kernel-trace --stats of bench.py (and of the rne leg at 1e7)            -> prof/, prof_rne1e7/
 #   pmc     FETCH_SIZE / WRITE_SIZE passes (separate runs) of bench.py and of the rne leg       -> pmc_*/
+#   sq      SQ_INSTS_VALU / SQ_WAVES of bench_extra.py --what $SQ_WHAT (default rne,dyn,tree)        -> pmc_sq/, sq_digest.txt
 #   extra   python bench_extra.py $EXTRA_ARGS                                                   -> bench_extra.jsonl
 #   fuzz    scripts/gpu_fuzz_*.py (random robots through every kernel size against the oracle)  -> fuzz_*.jsonl
 #   layout  scripts/layout_probe.py --fleet (packed vs two-array outputs over fresh allocations; VARIANTS="a.so b.so" adds A/B libraries)
@@ -50,6 +51,13 @@ if has pmc; then
   done
   cd $R
   python scripts/pmc_digest.py $O
+fi
+if has sq; then
+  # VALU instructions per wave of the issue-bound kernels (bench_extra.py VALU_PER_UNIT): SQ_INSTS_VALU / SQ_WAVES, its own pass
+  cd /tmp
+  timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d $O/pmc_sq -o sq -- python $R/bench_extra.py --what ${SQ_WHAT:-rne,dyn,tree} --no-cpu --steps 3 > $O/pmc_sq.log 2>&1 || echo "sq pass failed"
+  cd $R
+  python scripts/pmc_digest.py $O | grep pmc_sq > $O/sq_digest.txt; cut -c1-200 $O/sq_digest.txt | head -60
 fi
 if has extra; then
   timeout 900 python bench_extra.py $EXTRA_ARGS > $O/bench_extra.jsonl 2> $O/bench_extra.err; cut -c1-200 $O/bench_extra.jsonl; tail -2 $O/bench_extra.err
