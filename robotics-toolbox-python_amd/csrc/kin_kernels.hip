@@ -776,7 +776,16 @@ __global__ __launch_bounds__(kWave, (CLS == 0 ? RTB_REG_WAVES : 2)) void k_fleet
     const ConstChain ops = const_view(fe.dc);
     for (int k = 0; k < 9; ++k) kp.tail[k] = ops.seg[fe.n].r[k];
     for (int k = 0; k < 3; ++k) kp.tail[9 + k] = ops.seg[fe.n].t[k];
-    const int64_t tile = gt - fe.tile0;
+    // The chain's tiles are dealt to the XCDs as a launch of its own would deal them (trig.h: xcd_tile_of -- XCD x walks the x-th contiguous
+    // eighth of THIS chain's tiles; the hardware's round-robin is by global workgroup id, a fixed rotation of the XCD labels per chain): 1 % on the
+    // 16-arm fleet (1.391 -> 1.378 ms, profiles/r05_s_fleet_xcd_ab.txt).  (Its chains launched one by one in a loop take 1.196 ms -- but only because
+    // each call then rewrites the SAME 128 MB pose array, which the memory-side cache absorbs (store policy above); a fleet step writes 2 GB of poses
+    // once: it streams, at 0.72-0.73 of the HBM roof against 0.745 for a plain fill of the same bytes: profiles/r05_r_fleet_probe.jsonl.)
+    const int64_t local = gt - fe.tile0, ctiles = (fe.N + kWave - 1) / kWave;
+#ifndef RTB_FLEET_XCD
+#define RTB_FLEET_XCD 1
+#endif
+    const int64_t tile = (RTB_FLEET_XCD && ctiles <= 0x7fffffff) ? (int64_t)xcd_tile_of((unsigned)ctiles, (unsigned)local) : local;
     if (CLS == 0) {
         switch (fe.n) {
         case 1: reg_tile<1, true, true, PACKED>(kp, ops, fe.q, fe.T, fe.J, lds, lane, tile); return;
