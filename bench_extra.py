@@ -87,16 +87,24 @@ def ik_roofline(lm_iterations_per_s):
 #     jacob0_dot      + sum over joint pairs (j <= i: two cross products and six FMAs = 30; j > i: 15): 28 x 30 + 21 x 15 = 1 155   -> 1 755
 #     manipulability  + J J^T (21 entries x 7 FMAs = 294) + 6x6 LU determinant (144) + sqrt                                      -> 1 050
 #     jacobm          + J J^T 294 + LDL^T 100 + 7 back-substitutions (504) + 49 Hessian-block contractions x 30 (1 470) + m        -> 3 000
-ALGO_FLOPS_PER_UNIT = {"gravload": 1568, "inertia": 5012, "coriolis": 11690, "accel": 7114, "tree_ur5": 1980, "jacob0_dot": 1755,
+#   ROUND 5 -- the DH Panda re-priced.  Its link table is structured (alpha = 0 / +-pi/2, centres of mass at the link origins, a or d zero on most links, no
+#   friction, no motor inertia) and the kernels now exploit that at compile time (rne_device.h: RneSig), so the budgets above -- those of a GENERAL link --
+#   are no longer the best formulation known for THIS robot: a fraction quoted against them would count work nobody has to do (accel: 0.95).  The
+#   structured link-passes, from the signature kernels' own SQ counts less trig and staging (profiles/r05_t_sq_digest.txt): full 92 operations = 184 flop
+#   (general 135), acceleration-only 66 = 132 flop (82), two-field passes 0.76 of the general ones:
+#     gravload 7 x 132 + 420 = 1 344; inertia 28 x 132 + 420 = 4 116; coriolis 0.76 x (9 968 + 1 302) + 420 = 8 985; accel 7 x 184 + 28 x 132 + 212 + 420 = 5 616
+#   (the UR5 tree stays priced at the general DH budget: its signature kernels still execute more than that, 166 operations per group-pass)
+ALGO_FLOPS_PER_UNIT = {"gravload": 1344, "inertia": 4116, "coriolis": 8985, "accel": 5616, "tree_ur5": 1980, "jacob0_dot": 1755,
                        "manipulability": 1050, "jacobm": 3000, "tree_inertia_ur5": 3804, "tree_coriolis_ur5": 8766, "tree_accel_ur5": 5568,
                        "tree_gravload_ur5": 1344}        # 6 acceleration-only link-passes + 6 sincos
-# VALU instructions per lane actually EXECUTED (SQ_INSTS_VALU / SQ_WAVES, profiles/r03_a_sq_summary.txt; coriolis and the tree dynamics kernels as
-# rebuilt in round 4: profiles/r04_u_sq_tree_dyn.txt, r04_v_sq_dyn.txt): reported beside
+# VALU instructions per lane actually EXECUTED (SQ_INSTS_VALU / SQ_WAVES; the dynamics kernels' structure-signature instantiations of round 5:
+# profiles/r05_t_sq_digest.txt -- the general kernels execute 833 / 3433 / 5954 / 3377 and 1929 / 4345 / 10864 / 7216 / 1275, profiles/r04_u_sq_tree_dyn.txt,
+# r04_v_sq_dyn.txt; the kinematics consumers: profiles/r03_a_sq_summary.txt): reported beside
 # the roofline as `valu_issue_util` (share of the chip's fp64 issue slots the kernel fills) -- a diagnostic, not a roofline: a kernel that
 # executed more instructions for the same answer would score higher on it.
-VALU_PER_UNIT = {"gravload": 833, "inertia": 3433, "coriolis": 5954, "accel": 3377, "tree_ur5": 1929, "jacob0_dot": 1692,
+VALU_PER_UNIT = {"gravload": 687, "inertia": 2930, "coriolis": 4542, "accel": 2797, "tree_ur5": 1192, "jacob0_dot": 1692,
                  "manipulability": 1512, "jacobm": 2732,
-                 "tree_inertia_ur5": 4345, "tree_coriolis_ur5": 10864, "tree_accel_ur5": 7216, "tree_gravload_ur5": 1275}
+                 "tree_inertia_ur5": 2578, "tree_coriolis_ur5": 6032, "tree_accel_ur5": 3323, "tree_gravload_ur5": 713}
 
 
 def valu_roofline(key, units_per_s, kernel, hbm_bytes_per_unit):
@@ -105,7 +113,8 @@ def valu_roofline(key, units_per_s, kernel, hbm_bytes_per_unit):
     flops = ALGO_FLOPS_PER_UNIT[key]
     tf = flops * units_per_s / 1e12
     gbs = hbm_bytes_per_unit * units_per_s / 1e9
-    src = "DESIGN.md section 5 (full / acceleration-only / two-field link-passes at 270 / 164 / 356 flop, 60 flop per sincos; FK + Jacobian 600 flop + the consumer's own products)"
+    src = ("DESIGN.md section 5 (general link: full / acceleration-only / two-field link-passes at 270 / 164 / 356 flop; the DH Panda's structured table: 184 / 132 / "
+           "0.76 x; 60 flop per sincos; FK + Jacobian 600 flop + the consumer's own products)")
     if hbm_bytes_per_unit / (HBM_PEAK_GBS * 1e9) >= flops / (FP64_VALU_PEAK_TFLOPS * 1e12):
         out = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                "algorithmic_bytes_per_unit": hbm_bytes_per_unit, "algorithmic_flops_per_unit": flops, "flops_source": src,
