@@ -236,11 +236,9 @@ class ERobot(RobotKinematics):
                 exclude = (gripper,)
             else:
                 raise ValueError("no link named %s" % gripper)
-        robot = u.erobot(exclude)
-        if cls is not ERobot and cls is not type(robot):
-            robot.__class__ = cls
-        robot.urdf_string, robot.urdf_filepath = u.urdf_string, file_path
-        return robot
+        # constructed THROUGH the caller's class, as the reference does (`return cls(links, name=..., urdf_string=..., urdf_filepath=...)`,
+        # robot/Robot.py:325-331): a subclass's __init__ runs.  (The gripper's links are already out of the list: this backend has no Gripper objects.)
+        return cls(u.erobot_links(exclude), name=u.name, urdf_string=u.urdf_string, urdf_filepath=file_path)
 
     def __len__(self): return len(self.links)
     def __getitem__(self, i): return self.links[i]

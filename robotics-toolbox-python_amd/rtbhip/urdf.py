@@ -344,7 +344,12 @@ class URDFRobot:
         one Link per URDF link with ets = [SE3(constant) * joint ET], m, r from <inertial>).  `exclude`
         names links whose whole subtree is left out -- the reference removes gripper links from
         robot.links (BaseRobot.py:277-289), so Robot.rne never sees them."""
-        from .erobot import Link, ERobot
+        from .erobot import ERobot
+        return ERobot(self.erobot_links(exclude), name=self.name)
+
+    def erobot_links(self, exclude=()):
+        """The Link list erobot() constructs its robot from (Robot.URDF hands it to the caller's own class: robot/Robot.py:325-331)."""
+        from .erobot import Link
         drop = set()
 
         def mark(l):
@@ -370,7 +375,7 @@ class URDFRobot:
         for l in self.links:
             if l.name in made and l.parent is not None:
                 made[l.name].parent = made[l.parent.name]
-        return ERobot(links, name=self.name)
+        return links
 
     def fkine_all(self, q, exclude=()):
         """Pose of every link frame (reference Robot.fkine_all robot/Robot.py:638-698): see ERobot.fkine_all."""

@@ -211,6 +211,13 @@ def test_Robot_URDF_reads_a_file_and_folds_the_gripper(tmp_path):
         rtbhip.ERobot.URDF("fetch_description/robots/fetch.urdf", gripper=1.5)
     with pytest.raises(FileNotFoundError):
         rtbhip.ERobot.URDF("nowhere/robot.urdf")
+    # a subclass is constructed through its own __init__ (robot/Robot.py:325-331: `return cls(links, name=..., urdf_string=..., urdf_filepath=...)`)
+    class MyArm(rtbhip.ERobot):
+        def __init__(self, links, **kw):
+            super().__init__(links, **kw)
+            self.qr = np.zeros(self.n)
+    arm = MyArm.URDF(str(path))
+    assert type(arm) is MyArm and arm.qr.shape == (ref.n,) and arm.urdf_filepath == str(path) and arm.name == mine.name
     x = tmp_path / "arm.urdf.xacro"                      # an xacro file goes through rtbhip.xacro (tests/test_xacro.py); plain URDF is valid xacro
     x.write_text(src)
     assert urdf.read(x).n == u.n
