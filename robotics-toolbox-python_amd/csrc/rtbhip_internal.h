@@ -48,6 +48,7 @@ __host__ __device__ inline int jm_cls(int jm) { return (jm >> 20) & 15; }
 __host__ __device__ inline int jm_tmask(int jm) { return (jm >> 24) & 7; }
 // STRUCTURE SIGNATURE of a chain (kin_reg.h) or a dynamics tree (tree_device.h): 7 bits per constant (class | translation mask << 4), bit 63 = present
 typedef unsigned long long SegSig;
+typedef unsigned __int128 TreeTopo;      // tree_device.h
 constexpr SegSig kSegSigPresent = 1ull << 63;
 __host__ __device__ constexpr int seg_sig_cls(SegSig s, int j) { return (int)((s >> (7 * j)) & 15u); }
 __host__ __device__ constexpr int seg_sig_tm(SegSig s, int j) { return (int)((s >> (7 * j + 4)) & 7u); }
@@ -99,12 +100,14 @@ struct Tree {
     std::vector<DevGroup> groups;
     int n = 0, nslots = 0;
     SegSig sig = 0;                    // structure signature of the group constants (tree_device.h), 0 beyond 8 groups
+    TreeTopo topo = 0;                 // the tree's bookkeeping as one word (tree_device.h: TreeTopo), 0 where it does not apply
     std::map<int, DevGroup *> dev_groups;
     std::mutex mu;
     ~Tree();
 };
 int compile_tree(const rtbhip_tree_group *groups, int ng, Tree *out);
 SegSig tree_signature(const DevGroup *groups, int ng);
+TreeTopo tree_topology(const DevGroup *groups, int ng, int nslots);
 std::shared_ptr<Tree> tree_from_handle(rtbhip_tree_t h);
 int tree_device_groups(Tree *t, const DevGroup **out);
 int launch_tree_rne(const Tree *t, const DevGroup *groups, const double *q, const double *qd, const double *qdd, int64_t N,

@@ -28,6 +28,18 @@ SegSig tree_signature(const DevGroup *g, int ng)
     return plain ? (s | kTreeSigPlain) : s;
 }
 
+// the bookkeeping of a compiled tree as one word (tree_device.h: TreeTopo): trees of up to 8 groups numbered in group order, at most 7 branch slots
+TreeTopo tree_topology(const DevGroup *g, int ng, int nslots)
+{
+    if (ng < 1 || ng > kTreeSigMaxGroups || nslots > 6) return 0;
+    TreeTopo t = kTreeTopoPresent;
+    for (int j = 0; j < ng; j++) {
+        if (jm_jq(g[j].jmeta) != j || g[j].out_col != j || g[j].parent < -1 || g[j].parent >= j) return 0;
+        t |= topo_of(j, g[j].parent, jm_prismatic(g[j].jmeta) != 0, g[j].parent_slot, g[j].save_slot);
+    }
+    return t;
+}
+
 int compile_tree(const rtbhip_tree_group *in, int ng, Tree *out)
 {
     if (ng < 1 || in == nullptr) { set_error("tree_create: need at least one group"); return RTBHIP_EINVAL; }
@@ -87,6 +99,7 @@ int compile_tree(const rtbhip_tree_group *in, int ng, Tree *out)
     out->n = ng;
     out->nslots = nslots;
     out->sig = tree_signature(out->groups.data(), ng);
+    out->topo = tree_topology(out->groups.data(), ng, nslots);
     return RTBHIP_OK;
 }
 

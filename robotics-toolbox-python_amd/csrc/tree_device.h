@@ -72,6 +72,19 @@ constexpr SegSig kTreeSigPlain = 1ull << 56;
 constexpr SegSig kTreeSigAnyConstants = 1ull << 57;
 constexpr SegSig kTreeSigPlainChain = kSegSigPresent | kTreeSigPlain | kTreeSigAnyConstants;
 constexpr int kTreePlainChainMax = 8;          // sizes with a plain-chain instantiation (tree_kernels.hip)
+// A BRANCHED tree's bookkeeping at compile time: TreeTopo, 12 bits per group -- parent + 1 (4 bits; 0 = the base), prismatic (1), parent slot + 1 (3),
+// save slot + 1 (3) -- bit 127 = present; for trees of up to 8 groups numbered in group order (group j moves q column j and owns torque column j).
+// With it the parent selection, the branch-slot addresses and the joint kind are constants of each unrolled group step, as kTreeSigPlain makes
+// them for a serial chain, and the translation masks of the signature apply to every non-prismatic group.
+constexpr TreeTopo kTreeTopoPresent = (TreeTopo)1 << 127;
+RTB_HD constexpr int topo_parent(TreeTopo t, int j) { return (int)((unsigned)(t >> (12 * j)) & 15u) - 1; }
+RTB_HD constexpr bool topo_pris(TreeTopo t, int j) { return ((unsigned)(t >> (12 * j + 4)) & 1u) != 0; }
+RTB_HD constexpr int topo_parent_slot(TreeTopo t, int j) { return (int)((unsigned)(t >> (12 * j + 5)) & 7u) - 1; }
+RTB_HD constexpr int topo_save_slot(TreeTopo t, int j) { return (int)((unsigned)(t >> (12 * j + 8)) & 7u) - 1; }
+constexpr TreeTopo topo_of(int j, int parent, bool pris, int parent_slot, int save_slot)
+{
+    return (TreeTopo)((unsigned)(parent + 1) | ((pris ? 1u : 0u) << 4) | ((unsigned)(parent_slot + 1) << 5) | ((unsigned)(save_slot + 1) << 8)) << (12 * j);
+}
 constexpr int kTreeSigMaxGroups = 8;
 // The signatures with instantiations in this build (tree_kernels.hip; tree.cpp: tree_signature computes a robot's).  UR3 / UR5 / UR10 read
 // from their URDF: base translation; the shoulder's rpy = (0, pi/2, 0) with the file's 12-digit pi (general); a pure translation; a quarter
@@ -79,10 +92,15 @@ constexpr int kTreeSigMaxGroups = 8;
 constexpr SegSig kTreeSigUR = kSegSigPresent | kTreeSigPlain | seg_sig_of(0, kSegIdentity, 4) | seg_sig_of(1, kSegGeneral, 2) | seg_sig_of(2, kSegIdentity, 5) |
                               seg_sig_of(3, kSegRzP, 1) | seg_sig_of(4, kSegPermA, 4) | seg_sig_of(5, kSegPermB, 4);
 // The Interbotix arms with eight link groups (px150, rx150, rx200, vx300, wx200, wx250: one signature): a branched tree -- two prismatic
-// gripper fingers hang off the wrist -- so not plain: the bookkeeping stays, seven of the eight constants are multiplied in the form of their class.
+// gripper fingers hang off the wrist -- so not plain; seven of the eight constants are multiplied in the form of their class.
 constexpr SegSig kTreeSigIbx8 = kSegSigPresent | seg_sig_of(0, kSegIdentity, 4) | seg_sig_of(1, kSegPermB, 4) | seg_sig_of(2, kSegRy, 3) | seg_sig_of(3, kSegIdentity, 2) |
                                 seg_sig_of(4, kSegGeneral, 2) | seg_sig_of(5, kSegIdentity, 4) | seg_sig_of(6, kSegPermA, 4) | seg_sig_of(7, kSegIdentity, 0);
 static_assert(kTreeSigIbx8 == 0x80032e0a042de641ull && kTreeSigUR == 0x81000264b3145041ull, "signatures as tree.cpp computes them for the URDF files");
+// ... and their bookkeeping (tree.cpp: tree_topology): the group table the reference's grouping gives them is a serial chain -- six revolute arm joints, then
+// the two prismatic fingers one after the other -- so with the joint kinds known the whole recursion is straight-line code
+constexpr TreeTopo kTreeTopoIbx8 = kTreeTopoPresent | topo_of(0, -1, false, -1, -1) | topo_of(1, 0, false, -1, -1) | topo_of(2, 1, false, -1, -1) | topo_of(3, 2, false, -1, -1) |
+                                   topo_of(4, 3, false, -1, -1) | topo_of(5, 4, false, -1, -1) | topo_of(6, 5, true, -1, -1) | topo_of(7, 6, true, -1, -1);
+static_assert((unsigned long long)(kTreeTopoIbx8 >> 64) == 0x8000000001701600ull && (unsigned long long)kTreeTopoIbx8 == 0x5004003002001000ull, "as tree_topology computes it");
 
 template <class G> RTB_HD V3 seg_rt_c(int cls, const G &g, V3 v)   // R_C^T v for a constant of class cls
 {
@@ -136,17 +154,22 @@ RTB_HD V3 add_cross_pa(int tm, V3 b, V3 p, V3 a)      // b + p x a
     const bool X = tm & 1, Y = tm & 2, Z = tm & 4;
     return v3(tree_acc2(Y, Z, b.x, p.y, a.z, p.z, a.y), tree_acc2(Z, X, b.y, p.z, a.x, p.x, a.z), tree_acc2(X, Y, b.z, p.x, a.y, p.y, a.x));
 }
-template <bool PLAIN, class G> RTB_HD V3 tree_origin(const G &g, double d)      // p = t_C (+ R_C z d for a prismatic joint; a plain chain has none)
+template <class G> RTB_HD V3 tree_origin(bool revolute, const G &g, double d)      // p = t_C (+ R_C z d for a prismatic joint)
 {
-    if (PLAIN) return v3(g.C.t[0], g.C.t[1], g.C.t[2]);
+    if (revolute) return v3(g.C.t[0], g.C.t[1], g.C.t[2]);
     return v3(g.C.t[0] + g.C.r[2] * d, g.C.t[1] + g.C.r[5] * d, g.C.t[2] + g.C.r[8] * d);
 }
 // what a core knows about group j at compile time (SIG = 0: nothing)
 template <SegSig SIG> RTB_HD constexpr int tree_cls(int j) { return (SIG && !(SIG & kTreeSigAnyConstants)) ? seg_sig_cls(SIG, j) : kSegGeneral; }
-template <SegSig SIG> RTB_HD constexpr int tree_tm(int j)      // a prismatic joint adds R z d to p: masks for plain chains only
+template <SegSig SIG> RTB_HD constexpr int tree_tm(int j, bool revolute)      // a prismatic joint adds R z d to p: masks only where the joint is known to be revolute
 {
-    return ((SIG & kTreeSigPlain) && !(SIG & kTreeSigAnyConstants)) ? seg_sig_tm(SIG, j) : 7;
+    return (SIG && !(SIG & kTreeSigAnyConstants) && revolute) ? seg_sig_tm(SIG, j) : 7;
 }
+// what a core knows about group j's place in the tree at compile time: from kTreeSigPlain (serial chain) or a TreeTopo
+template <SegSig SIG, TreeTopo TOPO> struct TreeKnown {
+    static constexpr bool plain = (SIG & kTreeSigPlain) != 0, any = plain || TOPO != 0;
+    RTB_HD static constexpr bool revolute(int j) { return plain || (TOPO != 0 && !topo_pris(TOPO, j)); }
+};
 template <class G> RTB_HD V3 inertia_rot(const G &g, V3 w)   // I_bar w
 {
     return v3(g.I[0] * w.x + g.I[3] * w.y + g.I[4] * w.z, g.I[3] * w.x + g.I[1] * w.y + g.I[5] * w.z,
@@ -156,16 +179,16 @@ template <class G> RTB_HD V3 inertia_rot(const G &g, V3 w)   // I_bar w
 // One sample.  groups: wave-uniform table; qin/qdin/qddin(column) -> double; tau(column, value);
 // slot(index) -> double& into this lane's kTreeSlotDoubles * nslots scratch (LDS on the GPU).
 // joint angles -> sin/cos up front (branch-free reduction; one wave-wide library fallback)
-template <int NG, SegSig SIG = 0, class GroupsP, class InQ>
+template <int NG, SegSig SIG = 0, TreeTopo TOPO = 0, class GroupsP, class InQ>
 RTB_HD void tree_trig(GroupsP groups, InQ qin, double (&sn)[NG], double (&cs)[NG])
 {
     {
         bool big = false;
-        constexpr bool kPlain = (SIG & kTreeSigPlain) != 0;        // revolute joints, group j on q column j
+        typedef TreeKnown<SIG, TOPO> K;                             // known: group j on q column j, the joint kinds
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
             const auto &g = groups[j];
-            const double th = kPlain ? qin(j) * (jm_flip(g.jmeta) ? -1.0 : 1.0)
+            const double th = K::any ? (K::revolute(j) ? qin(j) * (jm_flip(g.jmeta) ? -1.0 : 1.0) : 0.0)
                                      : (jm_prismatic(g.jmeta) ? 0.0 : qin(jm_jq(g.jmeta)) * (jm_flip(g.jmeta) ? -1.0 : 1.0));
             sn[j] = th;
             big = big || !(fabs(th) < kTrigFastLimit);
@@ -199,12 +222,13 @@ RTB_HD void tree_trig(GroupsP groups, InQ qin, double (&sn)[NG], double (&cs)[NG
 #ifndef RTB_TREE_SKIP_PREFIX
 #define RTB_TREE_SKIP_PREFIX 1
 #endif
-template <int NG, bool VEL = true, SegSig SIG = 0, class GroupsP, class InQ, class InQd, class InQdd, class Out, class Slot>
+template <int NG, bool VEL = true, SegSig SIG = 0, TreeTopo TOPO = 0, class GroupsP, class InQ, class InQd, class InQdd, class Out, class Slot>
 RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], const double (&cs)[NG], V3 gravity, InQ qin, InQd qdin, InQdd qddin,
                           Out tau, Slot slot, int first = 0)
 {
     V3 Fl[NG], Fa[NG];
-    constexpr bool kPlain = (SIG & kTreeSigPlain) != 0;
+    typedef TreeKnown<SIG, TOPO> K;
+    constexpr bool kPlain = K::plain;
     if (!kPlain)
         for (int k = 0; k < nslots; ++k)
             for (int e = 12; e < 18; ++e) slot(k * kTreeSlotDoubles + e) = 0.0;
@@ -214,11 +238,11 @@ RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], co
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
         const auto &g = groups[j];
-        const int cls = tree_cls<SIG>(j), tm = tree_tm<SIG>(j);          // constants of the unrolled copy (SIG = 0: general, 7)
+        const int cls = tree_cls<SIG>(j), tm = tree_tm<SIG>(j, K::revolute(j));          // constants of the unrolled copy (SIG = 0: general, 7)
         // (read where they are used: loading the three words up front costs the general kernels some 70 registers)
-        auto parent_of = [&]() { return kPlain ? j - 1 : g.parent; };
-        auto parent_slot_of = [&]() { return kPlain ? -1 : g.parent_slot; };
-        auto save_slot_of = [&]() { return kPlain ? -1 : g.save_slot; };
+        auto parent_of = [&]() { return kPlain ? j - 1 : (TOPO ? topo_parent(TOPO, j) : g.parent); };
+        auto parent_slot_of = [&]() { return kPlain ? -1 : (TOPO ? topo_parent_slot(TOPO, j) : g.parent_slot); };
+        auto save_slot_of = [&]() { return kPlain ? -1 : (TOPO ? topo_save_slot(TOPO, j) : g.save_slot); };
         if (!VEL && j < first) {
             al = v3(0, 0, 0); aa = v3(0, 0, 0);
             if (save_slot_of() >= 0) {
@@ -228,8 +252,8 @@ RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], co
             Fl[j] = v3(0, 0, 0); Fa[j] = v3(0, 0, 0);
             continue;
         }
-        const bool pris = !kPlain && jm_prismatic(g.jmeta) != 0;
-        const int col = kPlain ? j : jm_jq(g.jmeta);
+        const bool pris = TOPO ? topo_pris(TOPO, j) : (!kPlain && jm_prismatic(g.jmeta) != 0);
+        const int col = K::any ? j : jm_jq(g.jmeta);
         const double qdj = VEL ? qdin(col) : 0.0, qddj = qddin(col);
         const double d = pris ? qin(col) * (jm_flip(g.jmeta) ? -1.0 : 1.0) : 0.0;
         V3 pvl, pva, pal, paa;     // parent state
@@ -245,7 +269,7 @@ RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], co
             pvl = vl; pva = va; pal = al; paa = aa;
         }
         // frame j in the parent frame: R = R_C Rz(theta), p = t_C (+ R_C z d for a prismatic joint)
-        const V3 p = tree_origin<kPlain>(g, d);
+        const V3 p = tree_origin(K::revolute(j), g, d);
         const double s = sn[j], c = cs[j];
         // X_up on motion vectors: w' = R^T w ; v' = R^T (v + w x p)
         if (VEL) {
@@ -296,24 +320,24 @@ RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], co
         const int j = NG - 1 - jj;
         if (!VEL && j < first) continue;
         const auto &g = groups[j];
-        const int cls = tree_cls<SIG>(j), tm = tree_tm<SIG>(j);
+        const int cls = tree_cls<SIG>(j), tm = tree_tm<SIG>(j, K::revolute(j));
         // (read where they are used: loading the three words up front costs the general kernels some 70 registers)
-        auto parent_of = [&]() { return kPlain ? j - 1 : g.parent; };
-        auto parent_slot_of = [&]() { return kPlain ? -1 : g.parent_slot; };
-        auto save_slot_of = [&]() { return kPlain ? -1 : g.save_slot; };
-        const bool pris = !kPlain && jm_prismatic(g.jmeta) != 0;
+        auto parent_of = [&]() { return kPlain ? j - 1 : (TOPO ? topo_parent(TOPO, j) : g.parent); };
+        auto parent_slot_of = [&]() { return kPlain ? -1 : (TOPO ? topo_parent_slot(TOPO, j) : g.parent_slot); };
+        auto save_slot_of = [&]() { return kPlain ? -1 : (TOPO ? topo_save_slot(TOPO, j) : g.save_slot); };
+        const bool pris = TOPO ? topo_pris(TOPO, j) : (!kPlain && jm_prismatic(g.jmeta) != 0);
         V3 fl = Fl[j] + cl, fa = Fa[j] + ca;
         if (save_slot_of() >= 0) {
             const int b = save_slot_of() * kTreeSlotDoubles + 12;
             fl = fl + v3(slot(b + 0), slot(b + 1), slot(b + 2));
             fa = fa + v3(slot(b + 3), slot(b + 4), slot(b + 5));
         }
-        tau(kPlain ? j : g.out_col, pris ? fl.z : fa.z);                    // Q[k, j] = sum(f[j] * s[j])
+        tau(K::any ? j : g.out_col, pris ? fl.z : fa.z);                    // Q[k, j] = sum(f[j] * s[j])
         cl = v3(0, 0, 0); ca = v3(0, 0, 0);
         if (parent_of() >= 0) {
             // f_parent += X_up^T f: lin' = R lin ; ang' = R ang + p x (R lin)
-            const double d = pris ? qin(jm_jq(g.jmeta)) * (jm_flip(g.jmeta) ? -1.0 : 1.0) : 0.0;
-            const V3 p = tree_origin<kPlain>(g, d);
+            const double d = pris ? qin(K::any ? j : jm_jq(g.jmeta)) * (jm_flip(g.jmeta) ? -1.0 : 1.0) : 0.0;
+            const V3 p = tree_origin(K::revolute(j), g, d);
             const V3 tl = seg_r_c(cls, g, rz(sn[j], cs[j], fl));
             const V3 ta = add_cross_pa(tm, seg_r_c(cls, g, rz(sn[j], cs[j], fa)), p, tl);
             if (parent_slot_of() >= 0) {
@@ -335,13 +359,14 @@ RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], co
 // halves).  Against the two full passes per column of the polar form tau(qd + s e_k) - tau(qd - s e_k) this is one pass of ~1.1x the
 // arithmetic, exact for any spread of velocities (no scale s to choose, no cancellation), and the groups before `first` (w = 0 there: their
 // accelerations and forces vanish) only advance u.  `first` as in tree_rne_core; slots of kTreeBilinearSlotDoubles.
-template <int NG, SegSig SIG = 0, class GroupsP, class InQ, class InQd, class Out, class Slot>
+template <int NG, SegSig SIG = 0, TreeTopo TOPO = 0, class GroupsP, class InQ, class InQd, class Out, class Slot>
 RTB_HD void tree_bilinear_core(GroupsP groups, int nslots, const double (&sn)[NG], const double (&cs)[NG], InQ qin, InQd qdin, int k, Out tau,
                                Slot slot, int first)
 {
     constexpr int SD = kTreeBilinearSlotDoubles;
     V3 Fl[NG], Fa[NG];
-    constexpr bool kPlain = (SIG & kTreeSigPlain) != 0;
+    typedef TreeKnown<SIG, TOPO> K;
+    constexpr bool kPlain = K::plain;
     if (!kPlain)
         for (int i = 0; i < nslots; ++i)
             for (int e = 18; e < 24; ++e) slot(i * SD + e) = 0.0;
@@ -350,13 +375,13 @@ RTB_HD void tree_bilinear_core(GroupsP groups, int nslots, const double (&sn)[NG
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
         const auto &g = groups[j];
-        const int cls = tree_cls<SIG>(j), tm = tree_tm<SIG>(j);
+        const int cls = tree_cls<SIG>(j), tm = tree_tm<SIG>(j, K::revolute(j));
         // (read where they are used: loading the three words up front costs the general kernels some 70 registers)
-        auto parent_of = [&]() { return kPlain ? j - 1 : g.parent; };
-        auto parent_slot_of = [&]() { return kPlain ? -1 : g.parent_slot; };
-        auto save_slot_of = [&]() { return kPlain ? -1 : g.save_slot; };
-        const bool pris = !kPlain && jm_prismatic(g.jmeta) != 0;
-        const int col = kPlain ? j : jm_jq(g.jmeta);
+        auto parent_of = [&]() { return kPlain ? j - 1 : (TOPO ? topo_parent(TOPO, j) : g.parent); };
+        auto parent_slot_of = [&]() { return kPlain ? -1 : (TOPO ? topo_parent_slot(TOPO, j) : g.parent_slot); };
+        auto save_slot_of = [&]() { return kPlain ? -1 : (TOPO ? topo_save_slot(TOPO, j) : g.save_slot); };
+        const bool pris = TOPO ? topo_pris(TOPO, j) : (!kPlain && jm_prismatic(g.jmeta) != 0);
+        const int col = K::any ? j : jm_jq(g.jmeta);
         const double qdu = qdin(col), qdw = col == k ? 1.0 : 0.0;
         const double d = pris ? qin(col) * (jm_flip(g.jmeta) ? -1.0 : 1.0) : 0.0;
         const bool rest = j < first;                           // wave-uniform: w, a and f are zero up to here
@@ -374,7 +399,7 @@ RTB_HD void tree_bilinear_core(GroupsP groups, int nslots, const double (&sn)[NG
         } else {
             pul = ul; pua = ua; pwl = wl; pwa = wa; pal = al; paa = aa;
         }
-        const V3 p = tree_origin<kPlain>(g, d);
+        const V3 p = tree_origin(K::revolute(j), g, d);
         const double s = sn[j], c = cs[j];
         ua = rz_t(s, c, seg_rt_c(cls, g, pua));
         ul = rz_t(s, c, seg_rt_c(cls, g, add_cross_ap(tm, pul, pua, p)));
@@ -424,23 +449,23 @@ RTB_HD void tree_bilinear_core(GroupsP groups, int nslots, const double (&sn)[NG
     for (int jj = 0; jj < NG; ++jj) {
         const int j = NG - 1 - jj;
         const auto &g = groups[j];
-        const int cls = tree_cls<SIG>(j), tm = tree_tm<SIG>(j);
+        const int cls = tree_cls<SIG>(j), tm = tree_tm<SIG>(j, K::revolute(j));
         // (read where they are used: loading the three words up front costs the general kernels some 70 registers)
-        auto parent_of = [&]() { return kPlain ? j - 1 : g.parent; };
-        auto parent_slot_of = [&]() { return kPlain ? -1 : g.parent_slot; };
-        auto save_slot_of = [&]() { return kPlain ? -1 : g.save_slot; };
-        const bool pris = !kPlain && jm_prismatic(g.jmeta) != 0;
+        auto parent_of = [&]() { return kPlain ? j - 1 : (TOPO ? topo_parent(TOPO, j) : g.parent); };
+        auto parent_slot_of = [&]() { return kPlain ? -1 : (TOPO ? topo_parent_slot(TOPO, j) : g.parent_slot); };
+        auto save_slot_of = [&]() { return kPlain ? -1 : (TOPO ? topo_save_slot(TOPO, j) : g.save_slot); };
+        const bool pris = TOPO ? topo_pris(TOPO, j) : (!kPlain && jm_prismatic(g.jmeta) != 0);
         V3 fl = Fl[j] + cl, fa = Fa[j] + ca;
         if (save_slot_of() >= 0) {
             const int b = save_slot_of() * SD + 18;
             fl = fl + v3(slot(b + 0), slot(b + 1), slot(b + 2));
             fa = fa + v3(slot(b + 3), slot(b + 4), slot(b + 5));
         }
-        tau(kPlain ? j : g.out_col, pris ? fl.z : fa.z);
+        tau(K::any ? j : g.out_col, pris ? fl.z : fa.z);
         cl = o; ca = o;
         if (parent_of() >= 0) {
-            const double d = pris ? qin(jm_jq(g.jmeta)) * (jm_flip(g.jmeta) ? -1.0 : 1.0) : 0.0;
-            const V3 p = tree_origin<kPlain>(g, d);
+            const double d = pris ? qin(K::any ? j : jm_jq(g.jmeta)) * (jm_flip(g.jmeta) ? -1.0 : 1.0) : 0.0;
+            const V3 p = tree_origin(K::revolute(j), g, d);
             const V3 tl = seg_r_c(cls, g, rz(sn[j], cs[j], fl));
             const V3 ta = add_cross_pa(tm, seg_r_c(cls, g, rz(sn[j], cs[j], fa)), p, tl);
             if (parent_slot_of() >= 0) {
@@ -457,12 +482,12 @@ RTB_HD void tree_bilinear_core(GroupsP groups, int nslots, const double (&sn)[NG
 
 // ATREST: the caller has no joint velocities (rtbhip_tree_rne with qd = NULL: Dynamics.gravload, Dynamics.itorque) -- the recursion
 // without its velocity half (tree_rne_core VEL = false), gravity still the base's acceleration.
-template <int NG, bool ATREST = false, SegSig SIG = 0, class GroupsP, class InQ, class InQd, class InQdd, class Out, class Slot>
+template <int NG, bool ATREST = false, SegSig SIG = 0, TreeTopo TOPO = 0, class GroupsP, class InQ, class InQd, class InQdd, class Out, class Slot>
 RTB_HD void tree_rne_lane(GroupsP groups, int nslots, V3 gravity, InQ qin, InQd qdin, InQdd qddin, Out tau, Slot slot)
 {
     double sn[NG], cs[NG];
-    tree_trig<NG, SIG>(groups, qin, sn, cs);
-    tree_rne_core<NG, !ATREST, SIG>(groups, nslots, sn, cs, gravity, qin, qdin, qddin, tau, slot);
+    tree_trig<NG, SIG, TOPO>(groups, qin, sn, cs);
+    tree_rne_core<NG, !ATREST, SIG, TOPO>(groups, nslots, sn, cs, gravity, qin, qdin, qddin, tau, slot);
 }
 
 // ---- the Dynamics-mixin terms of an ETS robot (robot/Dynamics.py:704-861, 424-509 on Robot.rne): every Newton-Euler pass the
@@ -516,15 +541,15 @@ RTB_HD int tree_row_position(GroupsP groups, int r)
     return a;
 }
 
-template <int NG, int MODE, SegSig SIG = 0, class GroupsP, class Slot>
+template <int NG, int MODE, SegSig SIG = 0, TreeTopo TOPO = 0, class GroupsP, class Slot>
 RTB_HD void tree_dyn_lane(GroupsP groups, int nslots, const double *mine, double *mA, V3 grav, Slot slot)
 {
     const V3 zero = v3(0, 0, 0);
     auto qin = [&](int j) { return mine[j]; };
     auto none = [&](int) { return 0.0; };
     double sn[NG], cs[NG];
-    tree_trig<NG, SIG>(groups, qin, sn, cs);
-    constexpr bool kPlain = (SIG & kTreeSigPlain) != 0;          // group j moves q column j: nothing to permute
+    tree_trig<NG, SIG, TOPO>(groups, qin, sn, cs);
+    constexpr bool kPlain = TreeKnown<SIG, TOPO>::any;          // group j moves q column j: nothing to permute
     // The unit-acceleration passes run in GROUP order: pass i accelerates the joint of the group at position i (q column jq_i), so that
     // Mp[j][i] = torque of group j is the symmetric joint-space inertia in group order -- only the entries j >= i are computed (the groups before i are
     // no descendants of i: at rest), packed lower triangle.  The reference's matrix is M[c, :] = rne(q, 0, e_c) with c a q COLUMN and the torques
@@ -537,14 +562,14 @@ RTB_HD void tree_dyn_lane(GroupsP groups, int nslots, const double *mine, double
         for (int i = 0; i < NG; ++i) {
             tree_opaque<NG>(sn, cs);
             const int ci = kPlain ? i : jm_jq(groups[i].jmeta);
-            tree_rne_core<NG, !RTB_TREE_ACC_ONLY, SIG>(groups, nslots, sn, cs, zero, qin, none, [&](int c) { return c == ci ? 1.0 : 0.0; },
+            tree_rne_core<NG, !RTB_TREE_ACC_ONLY, SIG, TOPO>(groups, nslots, sn, cs, zero, qin, none, [&](int c) { return c == ci ? 1.0 : 0.0; },
                                      [&](int j, double v) { if (j >= i) mA[j * (j + 1) / 2 + i] = v; }, slot, skip ? i : 0);
         }
     }
     if (MODE == kDynAccel) {
         double b[NG];
         tree_opaque<NG>(sn, cs);
-        tree_rne_core<NG, true, SIG>(groups, nslots, sn, cs, grav, qin, [&](int j) { return mine[NG + j]; }, none,
+        tree_rne_core<NG, true, SIG, TOPO>(groups, nslots, sn, cs, grav, qin, [&](int j) { return mine[NG + j]; }, none,
                           [&](int j, double v) { tree_put<NG>(b, j, mine[2 * NG + j] - v); }, slot);
         // the reference solves M qdd = torque - tau_0 with ITS M (rows by q column): row i of Mp stands in row jq_i, so the right-hand side of
         // the group-ordered system is entry jq_i of (torque - tau_0)
@@ -559,7 +584,7 @@ RTB_HD void tree_dyn_lane(GroupsP groups, int nslots, const double *mine, double
         for (int i = 0; i < NG; ++i) {
             tree_opaque<NG>(sn, cs);
             const int ci = kPlain ? i : jm_jq(groups[i].jmeta);
-            tree_rne_core<NG, !RTB_TREE_ACC_ONLY, SIG>(groups, nslots, sn, cs, zero, qin, none, [&](int c) { return c == ci ? 1.0 : 0.0; },
+            tree_rne_core<NG, !RTB_TREE_ACC_ONLY, SIG, TOPO>(groups, nslots, sn, cs, zero, qin, none, [&](int c) { return c == ci ? 1.0 : 0.0; },
                                      [&](int j, double v) { if (j >= i) mA[j * (j + 1) / 2 + i] = v; }, slot, skip ? i : 0);
         }
         double x[NG], M[NG][NG];
@@ -580,7 +605,7 @@ RTB_HD void tree_dyn_lane(GroupsP groups, int nslots, const double *mine, double
 #pragma unroll 1
         for (int k = 0; k < NG; ++k) {
             tree_opaque<NG>(sn, cs);
-            tree_bilinear_core<NG, SIG>(groups, nslots, sn, cs, qin, [&](int j) { return mine[NG + j]; }, k,
+            tree_bilinear_core<NG, SIG, TOPO>(groups, nslots, sn, cs, qin, [&](int j) { return mine[NG + j]; }, k,
                                    [&](int r, double v) { mA[r * NG + k] = 0.5 * v; }, slot, ordered ? k : 0);
         }
 #else

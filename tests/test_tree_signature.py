@@ -59,7 +59,28 @@ def test_ur_family_has_the_instantiated_signature(name):
 def test_interbotix_arms_of_eight_groups_share_one_signature(name):
     sig, want = _signature(urdf.load(name), "ibx8")
     assert sig == want, (_fields(sig, 8), _fields(want, 8))
-    assert (sig >> 56) & 1 == 0                                        # a branched tree with prismatic fingers: not plain
+    assert (sig >> 56) & 1 == 0                                        # prismatic fingers: not a plain chain
+    # ... and one bookkeeping word (tree_device.h: TreeTopo): six revolute groups in series, then the two prismatic fingers
+    import emu_harness as emu
+    from rtbhip._lib import rtbhip_tree_group
+    recs = urdf.load(name).erobot(()).group_table()
+    arr = (rtbhip_tree_group * len(recs))()
+    for k, r in enumerate(recs):
+        arr[k].parent, arr[k].kind, arr[k].flip, arr[k].jindex = r["parent"], r["kind"], r["flip"], r["jindex"]
+        arr[k].T[:] = list(np.ascontiguousarray(r["T"]).reshape(16))
+        arr[k].m = r["m"]
+        arr[k].h[:] = list(r["h"])
+        arr[k].I[:] = list(r["I"])
+    f, g = emu.lib().emu_tree_topology, emu.lib().emu_tree_topology_ibx8
+    f.argtypes = [C.POINTER(rtbhip_tree_group), C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    g.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    hi, lo, whi, wlo = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+    assert f(arr, len(recs), C.byref(hi), C.byref(lo)) == 0
+    g(C.byref(whi), C.byref(wlo))
+    assert (hi.value, lo.value) == (whi.value, wlo.value)
+    t = (hi.value << 64) | lo.value
+    assert [((t >> (12 * j)) & 15) - 1 for j in range(8)] == [r["parent"] for r in recs] == list(range(-1, 7))
+    assert [(t >> (12 * j + 4)) & 1 for j in range(8)] == [0] * 6 + [1, 1]
 
 
 def test_other_robots_do_not():
