@@ -494,6 +494,14 @@ __global__ __launch_bounds__(256) void k_ik_merge_chain(int64_t N, int n, const 
     if (t < N) ik_merge_chain(n, t, link, vq, vok, vit, vse, vE, q_out, success, iters, searches, residual);
 }
 
+// what a flat-schedule call needs cleared before k_ik starts, in ONE launch: every target's "lowest chunk that has succeeded" word and the launch's
+// work counter (two hipMemsetAsync before: 5.0 + 4.5 us of a 0.83 ms call, profiles/r05_w_ik_call_timeline.txt)
+__global__ __launch_bounds__(256) void k_ik_flat_prep(int32_t *__restrict__ done, int64_t N, unsigned long long *ctr)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < N) done[i] = kIkFlatNone;
+    if (i == 0) *ctr = 0ull;
+}
 __global__ __launch_bounds__(256) void k_ik_merge_flat(int64_t N, int n, int chunks, const double *vq, const int32_t *vok, const int32_t *vit, const int32_t *vse,
                                                        const double *vE, double *q_out, int32_t *success, int32_t *iters, int32_t *searches, double *residual)
 {
@@ -693,6 +701,8 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
     const int n = c->n;
     const SegSig chain_sig = chain_signature(c->jmeta.data(), n);
     // one launch of the scheduler kernel over `items` work items (the targets themselves when work == NULL)
+    unsigned long long *ctr_ready = nullptr;      // a counter the caller of run() has already taken from the ring AND cleared on the stream (flat schedule)
+    auto take_counter = [&]() { return ring + (g_ctr_next.fetch_add(1) % kCtrRing); };
     auto run = [&](const IkDev &pp, int64_t items, const IkWork *work, const unsigned *count, double *qo, int32_t *ok, int32_t *it,
                    int32_t *se, double *E, IkShareCtl share = IkShareCtl(), int64_t first_items = -1) -> int {
         IkDev p2 = pp;
@@ -711,8 +721,9 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
         const int64_t lanes = g * kWave;
         p2.pool_chunk = count ? 0 : (items >= 8 * lanes ? 64 : (items >= 3 * lanes ? 16 : 0));
         p2.N = items;
-        unsigned long long *ctr = ring + (g_ctr_next.fetch_add(1) % kCtrRing);
-        RTB_HIP(hipMemsetAsync(ctr, 0, sizeof(unsigned long long), s));
+        unsigned long long *ctr = ctr_ready ? ctr_ready : take_counter();
+        if (!ctr_ready) RTB_HIP(hipMemsetAsync(ctr, 0, sizeof(unsigned long long), s));
+        ctr_ready = nullptr;
         // diagnostics: RTBHIP_IK_STATS=<file> appends one JSON line per scheduler launch with the per-wave counters (loop iterations,
         // scheduling passes, lane-iterations spent on a running search, items started).  Synchronises the stream: not for timed runs.
         static const char *stats_path = std::getenv("RTBHIP_IK_STATS");
@@ -789,8 +800,11 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
             }
             int rc = RTBHIP_OK;
             {
-                hipError_t e = hipMemsetAsync(blk + o_done, 0x7f, (size_t)N * sizeof(int32_t), s);      // kIkFlatNone
-                if (e != hipSuccess) rc = hip_fail(e, "hipMemsetAsync (ik flat schedule)");
+                unsigned long long *c0 = take_counter();
+                hipLaunchKernelGGL(k_ik_flat_prep, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, (int32_t *)(blk + o_done), (int64_t)N, c0);
+                hipError_t e = hipGetLastError();
+                if (e != hipSuccess) rc = hip_fail(e, "k_ik_flat_prep launch");
+                else ctr_ready = c0;
             }
             int32_t *vok = (int32_t *)(blk + o_vok), *vit = (int32_t *)(blk + o_vit), *vse = (int32_t *)(blk + o_vse);
             double *vq = (double *)(blk + o_vq), *vE = (double *)(blk + o_vE);
