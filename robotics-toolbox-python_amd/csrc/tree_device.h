@@ -101,6 +101,13 @@ static_assert(kTreeSigIbx8 == 0x80032e0a042de641ull && kTreeSigUR == 0x81000264b
 constexpr TreeTopo kTreeTopoIbx8 = kTreeTopoPresent | topo_of(0, -1, false, -1, -1) | topo_of(1, 0, false, -1, -1) | topo_of(2, 1, false, -1, -1) | topo_of(3, 2, false, -1, -1) |
                                    topo_of(4, 3, false, -1, -1) | topo_of(5, 4, false, -1, -1) | topo_of(6, 5, true, -1, -1) | topo_of(7, 6, true, -1, -1);
 static_assert((unsigned long long)(kTreeTopoIbx8 >> 64) == 0x8000000001701600ull && (unsigned long long)kTreeTopoIbx8 == 0x5004003002001000ull, "as tree_topology computes it");
+// px100, the 7-group member of that family (five revolute joints and the two fingers): scripts/print_signatures.py prints these words for any robot
+constexpr SegSig kTreeSigPx100 = kSegSigPresent | seg_sig_of(0, kSegIdentity, 4) | seg_sig_of(1, kSegPermB, 4) | seg_sig_of(2, kSegRy, 3) | seg_sig_of(3, kSegIdentity, 2) |
+                                 seg_sig_of(4, kSegGeneral, 2) | seg_sig_of(5, kSegPermA, 4) | seg_sig_of(6, kSegIdentity, 0);
+constexpr TreeTopo kTreeTopoPx100 = kTreeTopoPresent | topo_of(0, -1, false, -1, -1) | topo_of(1, 0, false, -1, -1) | topo_of(2, 1, false, -1, -1) | topo_of(3, 2, false, -1, -1) |
+                                    topo_of(4, 3, false, -1, -1) | topo_of(5, 4, true, -1, -1) | topo_of(6, 5, true, -1, -1);
+static_assert(kTreeSigPx100 == 0x8000065a042de641ull && (unsigned long long)(kTreeTopoPx100 >> 64) == 0x8000000000001601ull &&
+              (unsigned long long)kTreeTopoPx100 == 0x5004003002001000ull, "as tree.cpp computes them for the URDF file");
 
 template <class G> RTB_HD V3 seg_rt_c(int cls, const G &g, V3 v)   // R_C^T v for a constant of class cls
 {

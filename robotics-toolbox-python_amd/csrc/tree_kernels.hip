@@ -25,7 +25,7 @@ constexpr int kTreeMaxGroups = 24;   // 17..24 link groups: the per-group state 
 // ATREST (qd == NULL, robots of up to kTreeAtRestMax groups): the velocity half of the recursion is not compiled in and the qd row is neither
 // read nor staged.
 constexpr int kTreeAtRestMax = 12;
-// kTreeSigUR, kTreeSigIbx8 (tree_device.h): the signatures this build has instantiations for; every other robot takes the general kernels
+// kTreeSigUR, kTreeSigIbx8, kTreeSigPx100 (tree_device.h): the signatures this build has instantiations for; every other robot takes the general kernels
 static int g_tree_sig = 1;          // rtbhip_tune("tree_sig", 0): every robot does (A/B, tests)
 void tree_tune(const char *key, int value) { if (std::string(key) == "tree_sig") g_tree_sig = value != 0; }
 int tree_sig_enabled() { return g_tree_sig; }
@@ -115,6 +115,8 @@ int launch_tree_rne(const Tree *t, const DevGroup *groups, const double *q, cons
         launch_ng<6, kTreeSigUR>(grid, lds, s, tp, groups, q, qd, qdd, tau);
     } else if (sig == kTreeSigIbx8 && topo == kTreeTopoIbx8) {
         launch_ng<8, kTreeSigIbx8, kTreeTopoIbx8>(grid, lds, s, tp, groups, q, qd, qdd, tau);
+    } else if (sig == kTreeSigPx100 && topo == kTreeTopoPx100) {
+        launch_ng<7, kTreeSigPx100, kTreeTopoPx100>(grid, lds, s, tp, groups, q, qd, qdd, tau);
     } else
 #ifdef RTB_TREE_DEV_NG      // development builds (seconds instead of minutes): only this size is instantiated
     launch_ng<RTB_TREE_DEV_NG>(grid, lds, s, tp, groups, q, qd, qdd, tau, plain);
@@ -288,6 +290,8 @@ int launch_tree_dyn(const Tree *t, const DevGroup *groups, int mode, const doubl
         e = launch_tree_dyn_ng<6, kTreeSigUR>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds);
     } else if (sig == kTreeSigIbx8 && topo == kTreeTopoIbx8) {
         e = launch_tree_dyn_ng<8, kTreeSigIbx8, kTreeTopoIbx8>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds);
+    } else if (sig == kTreeSigPx100 && topo == kTreeTopoPx100) {
+        e = launch_tree_dyn_ng<7, kTreeSigPx100, kTreeTopoPx100>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds);
     } else
 #ifdef RTB_TREE_DEV_NG
     e = launch_tree_dyn_ng<RTB_TREE_DEV_NG>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds, plain);

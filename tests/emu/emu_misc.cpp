@@ -172,6 +172,7 @@ extern "C" int emu_tree_dyn(const rtbhip_tree_group *groups, int ng, int mode, c
     V3 g = grav3 ? v3(grav3[0], grav3[1], grav3[2]) : v3(0, 0, 0);
     if (rtbhip::tree_sig_enabled() && t.sig == kTreeSigUR) { tree_dyn_mode<6, kTreeSigUR>(mode, &t, q, qd, tq, N, g, out); return 0; }      // as launch_tree_dyn dispatches
     if (rtbhip::tree_sig_enabled() && t.sig == kTreeSigIbx8 && t.topo == kTreeTopoIbx8) { tree_dyn_mode<8, kTreeSigIbx8, kTreeTopoIbx8>(mode, &t, q, qd, tq, N, g, out); return 0; }
+    if (rtbhip::tree_sig_enabled() && t.sig == kTreeSigPx100 && t.topo == kTreeTopoPx100) { tree_dyn_mode<7, kTreeSigPx100, kTreeTopoPx100>(mode, &t, q, qd, tq, N, g, out); return 0; }
     if (rtbhip::tree_sig_enabled() && (t.sig & kTreeSigPlain)) {          // any other serial chain of up to 8 revolute joints: the plain-chain instantiation
         switch (t.n) {
         case 1: tree_dyn_mode<1, kTreeSigPlainChain>(mode, &t, q, qd, tq, N, g, out); return 0;
@@ -211,6 +212,7 @@ extern "C" int emu_tree_rne(const rtbhip_tree_group *groups, int ng, const doubl
     V3 g = v3(grav3[0], grav3[1], grav3[2]);
     if (rtbhip::tree_sig_enabled() && t.sig == kTreeSigUR) { tree_run<6, kTreeSigUR>(&t, q, qd, qdd, N, g, tau); return 0; }      // as launch_tree_rne dispatches
     if (rtbhip::tree_sig_enabled() && t.sig == kTreeSigIbx8 && t.topo == kTreeTopoIbx8) { tree_run<8, kTreeSigIbx8, kTreeTopoIbx8>(&t, q, qd, qdd, N, g, tau); return 0; }
+    if (rtbhip::tree_sig_enabled() && t.sig == kTreeSigPx100 && t.topo == kTreeTopoPx100) { tree_run<7, kTreeSigPx100, kTreeTopoPx100>(&t, q, qd, qdd, N, g, tau); return 0; }
     if (rtbhip::tree_sig_enabled() && (t.sig & kTreeSigPlain)) {
         switch (t.n) {
         case 1: tree_run<1, kTreeSigPlainChain>(&t, q, qd, qdd, N, g, tau); return 0;

@@ -126,7 +126,7 @@ def _check(name, N, seed):
     return rob, q, qd, tq, g, out[1]
 
 
-@pytest.mark.parametrize("name", UR + ("wx250", "px150"))
+@pytest.mark.parametrize("name", UR + ("wx250", "px150", "px100"))
 def test_signature_kernels_equal_the_general_kernels_on_the_cpu_replay(name):
     import cpu_backend
     with cpu_backend.installed():
@@ -146,14 +146,25 @@ def test_signature_kernels_equal_the_general_kernels_on_the_cpu_replay(name):
 def test_switch_leaves_a_branched_robot_with_another_signature_alone():
     import cpu_backend
     with cpu_backend.installed():
-        rob = urdf.load("px100")                                       # seven groups, branched (gripper fingers), no instantiation
-        sig, _ = _signature(rob)
+        rob = _branched_arm()                                          # five groups, a real branch point: no instantiation
+        sig, _ = _signature_of_table(rob.group_table())
         assert sig >> 63 == 1 and (sig >> 56) & 1 == 0
         rng = np.random.default_rng(3)
         q, qd, tq = rng.uniform(-3, 3, (10, rob.n)), rng.normal(size=(10, rob.n)), rng.normal(size=(10, rob.n))
         out = _both(rob, q, qd, tq, np.array([0, 0, -9.81]))
     for k in out[1]:
         nt.assert_array_equal(out[1][k], out[0][k])
+
+
+def _branched_arm():
+    from rtbhip import ET, ETS, Link, ERobot
+    rng = np.random.default_rng(77)
+    base = Link(ETS([ET.SE3(_random_se3(rng)), ET.Rz()]), name="b", m=1.0, r=[0.1, 0, 0])
+    a1 = Link(ETS([ET.SE3(_random_se3(rng)), ET.Ry()]), name="a1", parent=base, m=0.5, r=[0, 0.1, 0])
+    a2 = Link(ETS([ET.SE3(_random_se3(rng)), ET.Rx()]), name="a2", parent=a1, m=0.4, r=[0, 0, 0.1])
+    c1 = Link(ETS([ET.SE3(_random_se3(rng)), ET.Rz()]), name="c1", parent=base, m=0.7, r=[0.05, 0, 0.02])
+    c2 = Link(ETS([ET.SE3(_random_se3(rng)), ET.tz()]), name="c2", parent=c1, m=0.3, r=[0, 0.03, 0])
+    return ERobot([base, a1, a2, c1, c2])
 
 
 def _random_serial_arm(n, seed):
@@ -196,6 +207,6 @@ def test_plain_chain_instantiation_serves_any_serial_revolute_arm(n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", UR + ("wx250", "rx150"))
+@pytest.mark.parametrize("name", UR + ("wx250", "rx150", "px100"))
 def test_gpu_signature_kernels_equal_the_general_kernels(name):
     _check(name, 5000, 12)
