@@ -99,14 +99,14 @@ struct DevGroup;
 struct Tree {
     std::vector<DevGroup> groups;
     int n = 0, nslots = 0;
-    SegSig sig = 0;                    // structure signature of the group constants (tree_device.h), 0 beyond 8 groups
+    SegSig sig = 0, sig2 = 0;          // structure signature of the group constants (tree_device.h): groups 0 .. 7 and 8 .. 15; 0 beyond 16 groups
     TreeTopo topo = 0;                 // the tree's bookkeeping as one word (tree_device.h: TreeTopo), 0 where it does not apply
     std::map<int, DevGroup *> dev_groups;
     std::mutex mu;
     ~Tree();
 };
 int compile_tree(const rtbhip_tree_group *groups, int ng, Tree *out);
-SegSig tree_signature(const DevGroup *groups, int ng);
+SegSig tree_signature(const DevGroup *groups, int ng, SegSig *sig2 = nullptr);
 TreeTopo tree_topology(const DevGroup *groups, int ng, int nslots);
 std::shared_ptr<Tree> tree_from_handle(rtbhip_tree_t h);
 int tree_device_groups(Tree *t, const DevGroup **out);

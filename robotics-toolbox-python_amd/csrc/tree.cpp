@@ -14,13 +14,16 @@ void perm_of_axis(int a, int perm[3]) { perm[2] = a; perm[0] = (a + 1) % 3; perm
 
 // structure signature of a compiled tree (tree_device.h): class and translation mask of every group constant from its EXACT zeros and ones
 // (chain.cpp: seg_class_bits), plus kTreeSigPlain for a serial chain of revolute joints numbered in group order
-SegSig tree_signature(const DevGroup *g, int ng)
+// (trees of 9 .. 16 groups: the fields of groups 8 .. 15 go to a second word, *sig2; such a tree is never "plain")
+SegSig tree_signature(const DevGroup *g, int ng, SegSig *sig2)
 {
-    if (ng < 1 || ng > kTreeSigMaxGroups) return 0;
+    if (sig2) *sig2 = 0;
+    if (ng < 1 || ng > (sig2 ? kTreeSig2MaxGroups : kTreeSigMaxGroups)) return 0;
     SegSig s = kSegSigPresent;
-    bool plain = true;
+    bool plain = ng <= kTreeSigMaxGroups;
     for (int j = 0; j < ng; j++) {
         const int bits = seg_class_bits(g[j].C);
+        if (j >= kTreeSigMaxGroups) { *sig2 |= kSegSigPresent | seg_sig_of(j - kTreeSigMaxGroups, jm_cls(bits), jm_tmask(bits)); continue; }
         s |= seg_sig_of(j, jm_cls(bits), jm_tmask(bits));
         plain = plain && g[j].parent == j - 1 && g[j].save_slot < 0 && g[j].parent_slot < 0 && !jm_prismatic(g[j].jmeta) && jm_jq(g[j].jmeta) == j &&
                 g[j].out_col == j;
@@ -28,10 +31,10 @@ SegSig tree_signature(const DevGroup *g, int ng)
     return plain ? (s | kTreeSigPlain) : s;
 }
 
-// the bookkeeping of a compiled tree as one word (tree_device.h: TreeTopo): trees of up to 8 groups numbered in group order, at most 7 branch slots
+// the bookkeeping of a compiled tree as one word (tree_device.h: TreeTopo): trees of up to 10 groups numbered in group order, at most 6 branch slots
 TreeTopo tree_topology(const DevGroup *g, int ng, int nslots)
 {
-    if (ng < 1 || ng > kTreeSigMaxGroups || nslots > 6) return 0;
+    if (ng < 1 || ng > kTreeTopoMaxGroups || nslots > 6) return 0;
     TreeTopo t = kTreeTopoPresent;
     for (int j = 0; j < ng; j++) {
         if (jm_jq(g[j].jmeta) != j || g[j].out_col != j || g[j].parent < -1 || g[j].parent >= j) return 0;
@@ -98,7 +101,7 @@ int compile_tree(const rtbhip_tree_group *in, int ng, Tree *out)
     }
     out->n = ng;
     out->nslots = nslots;
-    out->sig = tree_signature(out->groups.data(), ng);
+    out->sig = tree_signature(out->groups.data(), ng, &out->sig2);
     out->topo = tree_topology(out->groups.data(), ng, nslots);
     return RTBHIP_OK;
 }

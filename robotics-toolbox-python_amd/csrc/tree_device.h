@@ -73,10 +73,11 @@ constexpr SegSig kTreeSigAnyConstants = 1ull << 57;
 constexpr SegSig kTreeSigPlainChain = kSegSigPresent | kTreeSigPlain | kTreeSigAnyConstants;
 constexpr int kTreePlainChainMax = 8;          // sizes with a plain-chain instantiation (tree_kernels.hip)
 // A BRANCHED tree's bookkeeping at compile time: TreeTopo, 12 bits per group -- parent + 1 (4 bits; 0 = the base), prismatic (1), parent slot + 1 (3),
-// save slot + 1 (3) -- bit 127 = present; for trees of up to 8 groups numbered in group order (group j moves q column j and owns torque column j).
+// save slot + 1 (3) -- bit 127 = present; for trees of up to 10 groups numbered in group order (group j moves q column j and owns torque column j).
 // With it the parent selection, the branch-slot addresses and the joint kind are constants of each unrolled group step, as kTreeSigPlain makes
 // them for a serial chain, and the translation masks of the signature apply to every non-prismatic group.
 constexpr TreeTopo kTreeTopoPresent = (TreeTopo)1 << 127;
+constexpr int kTreeTopoMaxGroups = 10, kTreeSig2MaxGroups = 16;
 RTB_HD constexpr int topo_parent(TreeTopo t, int j) { return (int)((unsigned)(t >> (12 * j)) & 15u) - 1; }
 RTB_HD constexpr bool topo_pris(TreeTopo t, int j) { return ((unsigned)(t >> (12 * j + 4)) & 1u) != 0; }
 RTB_HD constexpr int topo_parent_slot(TreeTopo t, int j) { return (int)((unsigned)(t >> (12 * j + 5)) & 7u) - 1; }
@@ -101,6 +102,17 @@ static_assert(kTreeSigIbx8 == 0x80032e0a042de641ull && kTreeSigUR == 0x81000264b
 constexpr TreeTopo kTreeTopoIbx8 = kTreeTopoPresent | topo_of(0, -1, false, -1, -1) | topo_of(1, 0, false, -1, -1) | topo_of(2, 1, false, -1, -1) | topo_of(3, 2, false, -1, -1) |
                                    topo_of(4, 3, false, -1, -1) | topo_of(5, 4, false, -1, -1) | topo_of(6, 5, true, -1, -1) | topo_of(7, 6, true, -1, -1);
 static_assert((unsigned long long)(kTreeTopoIbx8 >> 64) == 0x8000000001701600ull && (unsigned long long)kTreeTopoIbx8 == 0x5004003002001000ull, "as tree_topology computes it");
+// Longer trees (9 .. 10 groups: a second class word; scripts/print_signatures.py prints all three words with their fields):
+//   vx300s / wx250s   nine groups in series, seven revolute + the two prismatic fingers           classes I pB Ry pB pA G I pA | I
+//   Fetch             ten groups in series, the prismatic torso lift and its second slide first   classes I pA G I pB pB pA pB | pA pB
+//   Mico              ten groups, three two-joint fingers off the wrist (one branch slot)         classes Ry G Ry G G I G I | G I
+constexpr TreeTopo topo_words(unsigned long long hi, unsigned long long lo) { return ((TreeTopo)hi << 64) | lo; }
+constexpr SegSig kTreeSigIbx9 = 0x80970504b58de641ull, kTreeSig2Ibx9 = 0x8000000000000001ull;
+constexpr TreeTopo kTreeTopoIbx9 = topo_words(0x8000001801700600ull, 0x5004003002001000ull);
+constexpr SegSig kTreeSigFetch = 0x80592d65ca380581ull, kTreeSig2Fetch = 0x800000000000164bull;
+constexpr TreeTopo kTreeTopoFetch = topo_words(0x8000900800700600ull, 0x5004003012011000ull);
+constexpr SegSig kTreeSigMico = 0x8063c18f0c09f047ull, kTreeSig2Mico = 0x80000000000018f0ull;
+constexpr TreeTopo kTreeTopoMico = topo_words(0x8000902400702400ull, 0x5004103002001000ull);
 // px100, the 7-group member of that family (five revolute joints and the two fingers): scripts/print_signatures.py prints these words for any robot
 constexpr SegSig kTreeSigPx100 = kSegSigPresent | seg_sig_of(0, kSegIdentity, 4) | seg_sig_of(1, kSegPermB, 4) | seg_sig_of(2, kSegRy, 3) | seg_sig_of(3, kSegIdentity, 2) |
                                  seg_sig_of(4, kSegGeneral, 2) | seg_sig_of(5, kSegPermA, 4) | seg_sig_of(6, kSegIdentity, 0);
@@ -167,13 +179,17 @@ template <class G> RTB_HD V3 tree_origin(bool revolute, const G &g, double d)   
     return v3(g.C.t[0] + g.C.r[2] * d, g.C.t[1] + g.C.r[5] * d, g.C.t[2] + g.C.r[8] * d);
 }
 // what a core knows about group j at compile time (SIG = 0: nothing)
-template <SegSig SIG> RTB_HD constexpr int tree_cls(int j) { return (SIG && !(SIG & kTreeSigAnyConstants)) ? seg_sig_cls(SIG, j) : kSegGeneral; }
-template <SegSig SIG> RTB_HD constexpr int tree_tm(int j, bool revolute)      // a prismatic joint adds R z d to p: masks only where the joint is known to be revolute
+// (groups 8 .. 15 of a longer tree have their fields in a second word, SIG2, at positions 0 .. 7)
+template <SegSig SIG, SegSig SIG2 = 0> RTB_HD constexpr int tree_cls(int j)
 {
-    return (SIG && !(SIG & kTreeSigAnyConstants) && revolute) ? seg_sig_tm(SIG, j) : 7;
+    return (SIG && !(SIG & kTreeSigAnyConstants)) ? (j < kTreeSigMaxGroups ? seg_sig_cls(SIG, j) : seg_sig_cls(SIG2, j - kTreeSigMaxGroups)) : kSegGeneral;
+}
+template <SegSig SIG, SegSig SIG2 = 0> RTB_HD constexpr int tree_tm(int j, bool revolute)      // a prismatic joint adds R z d to p: masks only where the joint is known to be revolute
+{
+    return (SIG && !(SIG & kTreeSigAnyConstants) && revolute) ? (j < kTreeSigMaxGroups ? seg_sig_tm(SIG, j) : seg_sig_tm(SIG2, j - kTreeSigMaxGroups)) : 7;
 }
 // what a core knows about group j's place in the tree at compile time: from kTreeSigPlain (serial chain) or a TreeTopo
-template <SegSig SIG, TreeTopo TOPO> struct TreeKnown {
+template <SegSig SIG, TreeTopo TOPO, SegSig SIG2 = 0> struct TreeKnown {
     static constexpr bool plain = (SIG & kTreeSigPlain) != 0, any = plain || TOPO != 0;
     RTB_HD static constexpr bool revolute(int j) { return plain || (TOPO != 0 && !topo_pris(TOPO, j)); }
 };
@@ -186,12 +202,12 @@ template <class G> RTB_HD V3 inertia_rot(const G &g, V3 w)   // I_bar w
 // One sample.  groups: wave-uniform table; qin/qdin/qddin(column) -> double; tau(column, value);
 // slot(index) -> double& into this lane's kTreeSlotDoubles * nslots scratch (LDS on the GPU).
 // joint angles -> sin/cos up front (branch-free reduction; one wave-wide library fallback)
-template <int NG, SegSig SIG = 0, TreeTopo TOPO = 0, class GroupsP, class InQ>
+template <int NG, SegSig SIG = 0, TreeTopo TOPO = 0, SegSig SIG2 = 0, class GroupsP, class InQ>
 RTB_HD void tree_trig(GroupsP groups, InQ qin, double (&sn)[NG], double (&cs)[NG])
 {
     {
         bool big = false;
-        typedef TreeKnown<SIG, TOPO> K;                             // known: group j on q column j, the joint kinds
+        typedef TreeKnown<SIG, TOPO, SIG2> K;                             // known: group j on q column j, the joint kinds
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
             const auto &g = groups[j];
@@ -229,12 +245,12 @@ RTB_HD void tree_trig(GroupsP groups, InQ qin, double (&sn)[NG], double (&cs)[NG
 #ifndef RTB_TREE_SKIP_PREFIX
 #define RTB_TREE_SKIP_PREFIX 1
 #endif
-template <int NG, bool VEL = true, SegSig SIG = 0, TreeTopo TOPO = 0, class GroupsP, class InQ, class InQd, class InQdd, class Out, class Slot>
+template <int NG, bool VEL = true, SegSig SIG = 0, TreeTopo TOPO = 0, SegSig SIG2 = 0, class GroupsP, class InQ, class InQd, class InQdd, class Out, class Slot>
 RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], const double (&cs)[NG], V3 gravity, InQ qin, InQd qdin, InQdd qddin,
                           Out tau, Slot slot, int first = 0)
 {
     V3 Fl[NG], Fa[NG];
-    typedef TreeKnown<SIG, TOPO> K;
+    typedef TreeKnown<SIG, TOPO, SIG2> K;
     constexpr bool kPlain = K::plain;
     if (!kPlain)
         for (int k = 0; k < nslots; ++k)
@@ -245,7 +261,7 @@ RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], co
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
         const auto &g = groups[j];
-        const int cls = tree_cls<SIG>(j), tm = tree_tm<SIG>(j, K::revolute(j));          // constants of the unrolled copy (SIG = 0: general, 7)
+        const int cls = tree_cls<SIG, SIG2>(j), tm = tree_tm<SIG, SIG2>(j, K::revolute(j));          // constants of the unrolled copy (SIG = 0: general, 7)
         // (read where they are used: loading the three words up front costs the general kernels some 70 registers)
         auto parent_of = [&]() { return kPlain ? j - 1 : (TOPO ? topo_parent(TOPO, j) : g.parent); };
         auto parent_slot_of = [&]() { return kPlain ? -1 : (TOPO ? topo_parent_slot(TOPO, j) : g.parent_slot); };
@@ -327,7 +343,7 @@ RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], co
         const int j = NG - 1 - jj;
         if (!VEL && j < first) continue;
         const auto &g = groups[j];
-        const int cls = tree_cls<SIG>(j), tm = tree_tm<SIG>(j, K::revolute(j));
+        const int cls = tree_cls<SIG, SIG2>(j), tm = tree_tm<SIG, SIG2>(j, K::revolute(j));
         // (read where they are used: loading the three words up front costs the general kernels some 70 registers)
         auto parent_of = [&]() { return kPlain ? j - 1 : (TOPO ? topo_parent(TOPO, j) : g.parent); };
         auto parent_slot_of = [&]() { return kPlain ? -1 : (TOPO ? topo_parent_slot(TOPO, j) : g.parent_slot); };
@@ -366,13 +382,13 @@ RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], co
 // halves).  Against the two full passes per column of the polar form tau(qd + s e_k) - tau(qd - s e_k) this is one pass of ~1.1x the
 // arithmetic, exact for any spread of velocities (no scale s to choose, no cancellation), and the groups before `first` (w = 0 there: their
 // accelerations and forces vanish) only advance u.  `first` as in tree_rne_core; slots of kTreeBilinearSlotDoubles.
-template <int NG, SegSig SIG = 0, TreeTopo TOPO = 0, class GroupsP, class InQ, class InQd, class Out, class Slot>
+template <int NG, SegSig SIG = 0, TreeTopo TOPO = 0, SegSig SIG2 = 0, class GroupsP, class InQ, class InQd, class Out, class Slot>
 RTB_HD void tree_bilinear_core(GroupsP groups, int nslots, const double (&sn)[NG], const double (&cs)[NG], InQ qin, InQd qdin, int k, Out tau,
                                Slot slot, int first)
 {
     constexpr int SD = kTreeBilinearSlotDoubles;
     V3 Fl[NG], Fa[NG];
-    typedef TreeKnown<SIG, TOPO> K;
+    typedef TreeKnown<SIG, TOPO, SIG2> K;
     constexpr bool kPlain = K::plain;
     if (!kPlain)
         for (int i = 0; i < nslots; ++i)
@@ -382,7 +398,7 @@ RTB_HD void tree_bilinear_core(GroupsP groups, int nslots, const double (&sn)[NG
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
         const auto &g = groups[j];
-        const int cls = tree_cls<SIG>(j), tm = tree_tm<SIG>(j, K::revolute(j));
+        const int cls = tree_cls<SIG, SIG2>(j), tm = tree_tm<SIG, SIG2>(j, K::revolute(j));
         // (read where they are used: loading the three words up front costs the general kernels some 70 registers)
         auto parent_of = [&]() { return kPlain ? j - 1 : (TOPO ? topo_parent(TOPO, j) : g.parent); };
         auto parent_slot_of = [&]() { return kPlain ? -1 : (TOPO ? topo_parent_slot(TOPO, j) : g.parent_slot); };
@@ -456,7 +472,7 @@ RTB_HD void tree_bilinear_core(GroupsP groups, int nslots, const double (&sn)[NG
     for (int jj = 0; jj < NG; ++jj) {
         const int j = NG - 1 - jj;
         const auto &g = groups[j];
-        const int cls = tree_cls<SIG>(j), tm = tree_tm<SIG>(j, K::revolute(j));
+        const int cls = tree_cls<SIG, SIG2>(j), tm = tree_tm<SIG, SIG2>(j, K::revolute(j));
         // (read where they are used: loading the three words up front costs the general kernels some 70 registers)
         auto parent_of = [&]() { return kPlain ? j - 1 : (TOPO ? topo_parent(TOPO, j) : g.parent); };
         auto parent_slot_of = [&]() { return kPlain ? -1 : (TOPO ? topo_parent_slot(TOPO, j) : g.parent_slot); };
@@ -489,12 +505,12 @@ RTB_HD void tree_bilinear_core(GroupsP groups, int nslots, const double (&sn)[NG
 
 // ATREST: the caller has no joint velocities (rtbhip_tree_rne with qd = NULL: Dynamics.gravload, Dynamics.itorque) -- the recursion
 // without its velocity half (tree_rne_core VEL = false), gravity still the base's acceleration.
-template <int NG, bool ATREST = false, SegSig SIG = 0, TreeTopo TOPO = 0, class GroupsP, class InQ, class InQd, class InQdd, class Out, class Slot>
+template <int NG, bool ATREST = false, SegSig SIG = 0, TreeTopo TOPO = 0, SegSig SIG2 = 0, class GroupsP, class InQ, class InQd, class InQdd, class Out, class Slot>
 RTB_HD void tree_rne_lane(GroupsP groups, int nslots, V3 gravity, InQ qin, InQd qdin, InQdd qddin, Out tau, Slot slot)
 {
     double sn[NG], cs[NG];
-    tree_trig<NG, SIG, TOPO>(groups, qin, sn, cs);
-    tree_rne_core<NG, !ATREST, SIG, TOPO>(groups, nslots, sn, cs, gravity, qin, qdin, qddin, tau, slot);
+    tree_trig<NG, SIG, TOPO, SIG2>(groups, qin, sn, cs);
+    tree_rne_core<NG, !ATREST, SIG, TOPO, SIG2>(groups, nslots, sn, cs, gravity, qin, qdin, qddin, tau, slot);
 }
 
 // ---- the Dynamics-mixin terms of an ETS robot (robot/Dynamics.py:704-861, 424-509 on Robot.rne): every Newton-Euler pass the
@@ -548,15 +564,15 @@ RTB_HD int tree_row_position(GroupsP groups, int r)
     return a;
 }
 
-template <int NG, int MODE, SegSig SIG = 0, TreeTopo TOPO = 0, class GroupsP, class Slot>
+template <int NG, int MODE, SegSig SIG = 0, TreeTopo TOPO = 0, SegSig SIG2 = 0, class GroupsP, class Slot>
 RTB_HD void tree_dyn_lane(GroupsP groups, int nslots, const double *mine, double *mA, V3 grav, Slot slot)
 {
     const V3 zero = v3(0, 0, 0);
     auto qin = [&](int j) { return mine[j]; };
     auto none = [&](int) { return 0.0; };
     double sn[NG], cs[NG];
-    tree_trig<NG, SIG, TOPO>(groups, qin, sn, cs);
-    constexpr bool kPlain = TreeKnown<SIG, TOPO>::any;          // group j moves q column j: nothing to permute
+    tree_trig<NG, SIG, TOPO, SIG2>(groups, qin, sn, cs);
+    constexpr bool kPlain = TreeKnown<SIG, TOPO, SIG2>::any;          // group j moves q column j: nothing to permute
     // The unit-acceleration passes run in GROUP order: pass i accelerates the joint of the group at position i (q column jq_i), so that
     // Mp[j][i] = torque of group j is the symmetric joint-space inertia in group order -- only the entries j >= i are computed (the groups before i are
     // no descendants of i: at rest), packed lower triangle.  The reference's matrix is M[c, :] = rne(q, 0, e_c) with c a q COLUMN and the torques
@@ -569,14 +585,14 @@ RTB_HD void tree_dyn_lane(GroupsP groups, int nslots, const double *mine, double
         for (int i = 0; i < NG; ++i) {
             tree_opaque<NG>(sn, cs);
             const int ci = kPlain ? i : jm_jq(groups[i].jmeta);
-            tree_rne_core<NG, !RTB_TREE_ACC_ONLY, SIG, TOPO>(groups, nslots, sn, cs, zero, qin, none, [&](int c) { return c == ci ? 1.0 : 0.0; },
+            tree_rne_core<NG, !RTB_TREE_ACC_ONLY, SIG, TOPO, SIG2>(groups, nslots, sn, cs, zero, qin, none, [&](int c) { return c == ci ? 1.0 : 0.0; },
                                      [&](int j, double v) { if (j >= i) mA[j * (j + 1) / 2 + i] = v; }, slot, skip ? i : 0);
         }
     }
     if (MODE == kDynAccel) {
         double b[NG];
         tree_opaque<NG>(sn, cs);
-        tree_rne_core<NG, true, SIG, TOPO>(groups, nslots, sn, cs, grav, qin, [&](int j) { return mine[NG + j]; }, none,
+        tree_rne_core<NG, true, SIG, TOPO, SIG2>(groups, nslots, sn, cs, grav, qin, [&](int j) { return mine[NG + j]; }, none,
                           [&](int j, double v) { tree_put<NG>(b, j, mine[2 * NG + j] - v); }, slot);
         // the reference solves M qdd = torque - tau_0 with ITS M (rows by q column): row i of Mp stands in row jq_i, so the right-hand side of
         // the group-ordered system is entry jq_i of (torque - tau_0)
@@ -591,7 +607,7 @@ RTB_HD void tree_dyn_lane(GroupsP groups, int nslots, const double *mine, double
         for (int i = 0; i < NG; ++i) {
             tree_opaque<NG>(sn, cs);
             const int ci = kPlain ? i : jm_jq(groups[i].jmeta);
-            tree_rne_core<NG, !RTB_TREE_ACC_ONLY, SIG, TOPO>(groups, nslots, sn, cs, zero, qin, none, [&](int c) { return c == ci ? 1.0 : 0.0; },
+            tree_rne_core<NG, !RTB_TREE_ACC_ONLY, SIG, TOPO, SIG2>(groups, nslots, sn, cs, zero, qin, none, [&](int c) { return c == ci ? 1.0 : 0.0; },
                                      [&](int j, double v) { if (j >= i) mA[j * (j + 1) / 2 + i] = v; }, slot, skip ? i : 0);
         }
         double x[NG], M[NG][NG];
@@ -612,7 +628,7 @@ RTB_HD void tree_dyn_lane(GroupsP groups, int nslots, const double *mine, double
 #pragma unroll 1
         for (int k = 0; k < NG; ++k) {
             tree_opaque<NG>(sn, cs);
-            tree_bilinear_core<NG, SIG, TOPO>(groups, nslots, sn, cs, qin, [&](int j) { return mine[NG + j]; }, k,
+            tree_bilinear_core<NG, SIG, TOPO, SIG2>(groups, nslots, sn, cs, qin, [&](int j) { return mine[NG + j]; }, k,
                                    [&](int r, double v) { mA[r * NG + k] = 0.5 * v; }, slot, ordered ? k : 0);
         }
 #else

@@ -30,7 +30,7 @@ static int g_tree_sig = 1;          // rtbhip_tune("tree_sig", 0): every robot d
 void tree_tune(const char *key, int value) { if (std::string(key) == "tree_sig") g_tree_sig = value != 0; }
 int tree_sig_enabled() { return g_tree_sig; }
 
-template <int NG, bool ATREST, SegSig SIG = 0, TreeTopo TOPO = 0>
+template <int NG, bool ATREST, SegSig SIG = 0, TreeTopo TOPO = 0, SegSig SIG2 = 0>
 __global__ __launch_bounds__(kWave, (NG <= 8 ? 2 : 1)) void k_tree_rne(TreeParams tp, const DevGroup *groups_g, const double *__restrict__ q,
                                                       const double *__restrict__ qd, const double *__restrict__ qdd,
                                                       double *__restrict__ tau)
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kWave, (NG <= 8 ? 2 : 1)) void k_tree_rne(TreeParam
     __syncthreads();
     double *mine = lds + lane * stride;
     if (lane < ncfg)
-        tree_rne_lane<NG, ATREST, SIG, TOPO>(groups, tp.nslots, v3(tp.grav[0], tp.grav[1], tp.grav[2]), [&](int c) { return mine[c]; },
+        tree_rne_lane<NG, ATREST, SIG, TOPO, SIG2>(groups, tp.nslots, v3(tp.grav[0], tp.grav[1], tp.grav[2]), [&](int c) { return mine[c]; },
                           [&](int c) { return ATREST ? 0.0 : mine[NG + c]; }, [&](int c) { return mine[2 * NG + c]; },
                           [&](int c, double v) { mine[3 * NG + c] = v; },
                           [&](int i) -> double & { return slots[i * kWave + lane]; });
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kWave, (NG <= 8 ? 2 : 1)) void k_tree_rne(TreeParam
     flush_run(lds + 3 * NG, stride, NG, ncfg, tau + cfg0 * NG, lane);
 }
 
-template <int NG, SegSig SIG = 0, TreeTopo TOPO = 0>
+template <int NG, SegSig SIG = 0, TreeTopo TOPO = 0, SegSig SIG2 = 0>
 static void launch_ng(dim3 grid, size_t lds, hipStream_t s, const TreeParams &tp, const DevGroup *g, const double *q,
                       const double *qd, const double *qdd, double *tau, bool plain = false)
 {
@@ -84,13 +84,13 @@ static void launch_ng(dim3 grid, size_t lds, hipStream_t s, const TreeParams &tp
     }
     if constexpr (NG <= kTreeAtRestMax) {
         if (!qd) {
-            auto k = k_tree_rne<NG, true, SIG, TOPO>;
+            auto k = k_tree_rne<NG, true, SIG, TOPO, SIG2>;
             if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(k, grid, dim3(kWave), lds, s, tp, g, q, qd, qdd, tau);
             return;
         }
     }
-    auto k = k_tree_rne<NG, false, SIG, TOPO>;
+    auto k = k_tree_rne<NG, false, SIG, TOPO, SIG2>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, grid, dim3(kWave), lds, s, tp, g, q, qd, qdd, tau);
 }
@@ -111,12 +111,19 @@ int launch_tree_rne(const Tree *t, const DevGroup *groups, const double *q, cons
     const SegSig sig = g_tree_sig ? t->sig : 0;
     const bool plain = (sig & kTreeSigPlain) != 0;
     const TreeTopo topo = g_tree_sig ? t->topo : 0;
+    const SegSig sig2 = g_tree_sig ? t->sig2 : 0;
     if (sig == kTreeSigUR) {
         launch_ng<6, kTreeSigUR>(grid, lds, s, tp, groups, q, qd, qdd, tau);
     } else if (sig == kTreeSigIbx8 && topo == kTreeTopoIbx8) {
         launch_ng<8, kTreeSigIbx8, kTreeTopoIbx8>(grid, lds, s, tp, groups, q, qd, qdd, tau);
     } else if (sig == kTreeSigPx100 && topo == kTreeTopoPx100) {
         launch_ng<7, kTreeSigPx100, kTreeTopoPx100>(grid, lds, s, tp, groups, q, qd, qdd, tau);
+    } else if (sig == kTreeSigIbx9 && sig2 == kTreeSig2Ibx9 && topo == kTreeTopoIbx9) {
+        launch_ng<9, kTreeSigIbx9, kTreeTopoIbx9, kTreeSig2Ibx9>(grid, lds, s, tp, groups, q, qd, qdd, tau);
+    } else if (sig == kTreeSigFetch && sig2 == kTreeSig2Fetch && topo == kTreeTopoFetch) {
+        launch_ng<10, kTreeSigFetch, kTreeTopoFetch, kTreeSig2Fetch>(grid, lds, s, tp, groups, q, qd, qdd, tau);
+    } else if (sig == kTreeSigMico && sig2 == kTreeSig2Mico && topo == kTreeTopoMico) {
+        launch_ng<10, kTreeSigMico, kTreeTopoMico, kTreeSig2Mico>(grid, lds, s, tp, groups, q, qd, qdd, tau);
     } else
 #ifdef RTB_TREE_DEV_NG      // development builds (seconds instead of minutes): only this size is instantiated
     launch_ng<RTB_TREE_DEV_NG>(grid, lds, s, tp, groups, q, qd, qdd, tau, plain);
@@ -189,7 +196,7 @@ __device__ __forceinline__ void tree_flush_symmetric(ConstGroups groups, const d
 // Robots of up to 7 joints keep two waves per SIMD (the second launch bound: at most 256 registers a lane): their tiles leave room for five or
 // more waves on a CU, and an allocation just above 256 -- the general accel kernel for six joints took 288 in one build of round 5, when the
 // recursion read a group's bookkeeping words before it needed them -- halves what the registers admit.  From 8 joints on the tile admits four.
-template <int NG, int MODE, SegSig SIG = 0, TreeTopo TOPO = 0>
+template <int NG, int MODE, SegSig SIG = 0, TreeTopo TOPO = 0, SegSig SIG2 = 0>
 __global__ __launch_bounds__(kWave, (NG <= 7 ? 2 : 1)) void k_tree_dyn(TreeParams tp, const DevGroup *groups_g, const double *__restrict__ q,
                                                        const double *__restrict__ qd, const double *__restrict__ tq,
                                                        double *__restrict__ out)
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(kWave, (NG <= 7 ? 2 : 1)) void k_tree_dyn(TreeParam
     }
     __syncthreads();
     if (lane < ncfg)
-        tree_dyn_lane<NG, MODE, SIG, TOPO>(groups, tp.nslots, lds + lane * in_stride, A + lane * w_stride, v3(tp.grav[0], tp.grav[1], tp.grav[2]),
+        tree_dyn_lane<NG, MODE, SIG, TOPO, SIG2>(groups, tp.nslots, lds + lane * in_stride, A + lane * w_stride, v3(tp.grav[0], tp.grav[1], tp.grav[2]),
                                 [&](int i) -> double & { return slots[i * T + lane]; });
     __syncthreads();
     if (MODE == kDynAccel) flush_run(A, w_stride, NG, ncfg, out + cfg0 * NG, lane);
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(kWave, (NG <= 7 ? 2 : 1)) void k_tree_dyn(TreeParam
     else flush_run(A, w_stride, NG * NG, ncfg, out + cfg0 * (NG * NG), lane);
 }
 
-template <int NG, int MODE, SegSig SIG = 0, TreeTopo TOPO = 0>
+template <int NG, int MODE, SegSig SIG = 0, TreeTopo TOPO = 0, SegSig SIG2 = 0>
 static hipError_t launch_tree_dyn_one(dim3 grid, hipStream_t s, int nslots, const TreeParams &tp, const DevGroup *g, const double *q,
                                       const double *qd, const double *tq, double *out, size_t *lds_out)
 {
@@ -251,23 +258,23 @@ static hipError_t launch_tree_dyn_one(dim3 grid, hipStream_t s, int nslots, cons
     const int64_t tiles = (tp.N + tq_.tile - 1) / tq_.tile;
     if (tiles > 0x7fffffff) { *lds_out = 0; return hipErrorInvalidValue; }
     grid = dim3((unsigned)tiles);
-    auto k = k_tree_dyn<NG, MODE, SIG, TOPO>;
+    auto k = k_tree_dyn<NG, MODE, SIG, TOPO, SIG2>;
     if (lds > 48 * 1024) { hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(k, grid, dim3(kWave), lds, s, tq_, g, q, qd, tq, out);
     note_launch((int)grid.x, kWave, (int)lds);
     return hipSuccess;
 }
 
-template <int NG, SegSig SIG = 0, TreeTopo TOPO = 0>
+template <int NG, SegSig SIG = 0, TreeTopo TOPO = 0, SegSig SIG2 = 0>
 static hipError_t launch_tree_dyn_ng(int mode, dim3 grid, hipStream_t s, int nslots, const TreeParams &tp, const DevGroup *g, const double *q,
                                      const double *qd, const double *tq, double *out, size_t *lds, bool plain = false)
 {
     if constexpr (SIG == 0 && NG <= kTreePlainChainMax) {
         if (plain) return launch_tree_dyn_ng<NG, kTreeSigPlainChain>(mode, grid, s, nslots, tp, g, q, qd, tq, out, lds);
     }
-    if (mode == kDynInertia) return launch_tree_dyn_one<NG, kDynInertia, SIG, TOPO>(grid, s, nslots, tp, g, q, qd, tq, out, lds);
-    if (mode == kDynCoriolis) return launch_tree_dyn_one<NG, kDynCoriolis, SIG, TOPO>(grid, s, nslots, tp, g, q, qd, tq, out, lds);
-    return launch_tree_dyn_one<NG, kDynAccel, SIG, TOPO>(grid, s, nslots, tp, g, q, qd, tq, out, lds);
+    if (mode == kDynInertia) return launch_tree_dyn_one<NG, kDynInertia, SIG, TOPO, SIG2>(grid, s, nslots, tp, g, q, qd, tq, out, lds);
+    if (mode == kDynCoriolis) return launch_tree_dyn_one<NG, kDynCoriolis, SIG, TOPO, SIG2>(grid, s, nslots, tp, g, q, qd, tq, out, lds);
+    return launch_tree_dyn_one<NG, kDynAccel, SIG, TOPO, SIG2>(grid, s, nslots, tp, g, q, qd, tq, out, lds);
 }
 
 int launch_tree_dyn(const Tree *t, const DevGroup *groups, int mode, const double *q, const double *qd, const double *tq, int64_t N,
@@ -286,12 +293,19 @@ int launch_tree_dyn(const Tree *t, const DevGroup *groups, int mode, const doubl
     const SegSig sig = g_tree_sig ? t->sig : 0;
     const bool plain = (sig & kTreeSigPlain) != 0;
     const TreeTopo topo = g_tree_sig ? t->topo : 0;
+    const SegSig sig2 = g_tree_sig ? t->sig2 : 0;
     if (sig == kTreeSigUR) {
         e = launch_tree_dyn_ng<6, kTreeSigUR>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds);
     } else if (sig == kTreeSigIbx8 && topo == kTreeTopoIbx8) {
         e = launch_tree_dyn_ng<8, kTreeSigIbx8, kTreeTopoIbx8>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds);
     } else if (sig == kTreeSigPx100 && topo == kTreeTopoPx100) {
         e = launch_tree_dyn_ng<7, kTreeSigPx100, kTreeTopoPx100>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds);
+    } else if (sig == kTreeSigIbx9 && sig2 == kTreeSig2Ibx9 && topo == kTreeTopoIbx9) {
+        e = launch_tree_dyn_ng<9, kTreeSigIbx9, kTreeTopoIbx9, kTreeSig2Ibx9>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds);
+    } else if (sig == kTreeSigFetch && sig2 == kTreeSig2Fetch && topo == kTreeTopoFetch) {
+        e = launch_tree_dyn_ng<10, kTreeSigFetch, kTreeTopoFetch, kTreeSig2Fetch>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds);
+    } else if (sig == kTreeSigMico && sig2 == kTreeSig2Mico && topo == kTreeTopoMico) {
+        e = launch_tree_dyn_ng<10, kTreeSigMico, kTreeTopoMico, kTreeSig2Mico>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds);
     } else
 #ifdef RTB_TREE_DEV_NG
     e = launch_tree_dyn_ng<RTB_TREE_DEV_NG>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds, plain);

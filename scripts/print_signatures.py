@@ -25,6 +25,7 @@ import cpu_backend
 CLS = ["G", "I", "RxP", "RxN", "Rx", "RyP", "RyN", "Ry", "RzP", "RzN", "Rz", "pA", "pB"]
 L = emu.lib()
 L.emu_tree_signature.argtypes, L.emu_tree_signature.restype = [C.POINTER(rtbhip_tree_group), C.c_int32], C.c_uint64
+L.emu_tree_signature2.argtypes, L.emu_tree_signature2.restype = [C.POINTER(rtbhip_tree_group), C.c_int32], C.c_uint64
 L.emu_tree_topology.argtypes = [C.POINTER(rtbhip_tree_group), C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
 L.emu_rne_signature.argtypes, L.emu_rne_signature.restype = [C.c_uint64], C.c_uint64
 
@@ -45,12 +46,14 @@ for n in names:
     recs = urdf.load(n).erobot(()).group_table()
     ng = len(recs)
     arr = table(recs)
-    sig = L.emu_tree_signature(arr, ng)
+    sig, sig2 = L.emu_tree_signature(arr, ng), L.emu_tree_signature2(arr, ng)
     hi, lo = C.c_uint64(), C.c_uint64()
     L.emu_tree_topology(arr, ng, C.byref(hi), C.byref(lo))
     topo = (hi.value << 64) | lo.value
     print("%-11s groups %2d  mass %-5s  SegSig 0x%016x %s%s" % (n, ng, sum(r["m"] for r in recs) > 0, sig, "plain " if (sig >> 56) & 1 else "",
-          [(CLS[(sig >> (7 * j)) & 15], (sig >> (7 * j + 4)) & 7) for j in range(ng)] if sig else "(more than 8 groups)"))
+          [(CLS[(sig >> (7 * j)) & 15], (sig >> (7 * j + 4)) & 7) for j in range(min(ng, 8))] if sig else "(more than 16 groups)"))
+    if sig2:
+        print("%-11s second word 0x%016x %s" % ("", sig2, [(CLS[(sig2 >> (7 * j)) & 15], (sig2 >> (7 * j + 4)) & 7) for j in range(ng - 8)]))
     if topo:
         print("%-11s TreeTopo hi 0x%016x lo 0x%016x  (parent, prismatic, parent slot, save slot) %s" % ("", hi.value, lo.value,
               [(((topo >> (12 * j)) & 15) - 1, (topo >> (12 * j + 4)) & 1, ((topo >> (12 * j + 5)) & 7) - 1, ((topo >> (12 * j + 8)) & 7) - 1) for j in range(ng)]))

@@ -127,7 +127,7 @@ extern "C" int emu_partial(rtbhip_chain_t h, const double *q, int64_t N, const d
 
 // ETS-robot inverse dynamics: tree.cpp's compiled table + tree_device.h's per-lane recursion on the CPU
 namespace rtbhip { int tree_sig_enabled(); }      // tree_kernels.hip: rtbhip_tune("tree_sig")
-template <int NG, SegSig SIG = 0, TreeTopo TOPO = 0>
+template <int NG, SegSig SIG = 0, TreeTopo TOPO = 0, SegSig SIG2 = 0>
 static void tree_run(const Tree *t, const double *q, const double *qd, const double *qdd, int64_t N, V3 g, double *tau)
 {
     std::vector<double> slots((size_t)kTreeSlotDoubles * std::max(1, t->nslots));
@@ -136,11 +136,11 @@ static void tree_run(const Tree *t, const double *q, const double *qd, const dou
         double *o = tau + s * NG;
         // qd == NULL on a robot of up to 12 groups: the at-rest instantiation, as launch_tree_rne dispatches (tree_kernels.hip kTreeAtRestMax)
         if (!b && NG <= 12)
-            tree_rne_lane<NG, true, SIG, TOPO>(t->groups.data(), t->nslots, g, [&](int k) { return a[k]; }, [&](int) { return 0.0; },
+            tree_rne_lane<NG, true, SIG, TOPO, SIG2>(t->groups.data(), t->nslots, g, [&](int k) { return a[k]; }, [&](int) { return 0.0; },
                                     [&](int k) { return c[k]; }, [&](int k, double v) { o[k] = v; },
                                     [&](int i) -> double & { return slots[i]; });
         else
-            tree_rne_lane<NG, false, SIG, TOPO>(t->groups.data(), t->nslots, g, [&](int k) { return a[k]; }, [&](int k) { return b ? b[k] : 0.0; },
+            tree_rne_lane<NG, false, SIG, TOPO, SIG2>(t->groups.data(), t->nslots, g, [&](int k) { return a[k]; }, [&](int k) { return b ? b[k] : 0.0; },
                               [&](int k) { return c[k]; }, [&](int k, double v) { o[k] = v; },
                               [&](int i) -> double & { return slots[i]; });
     }
@@ -162,6 +162,12 @@ extern "C" int emu_tree_topology(const rtbhip_tree_group *groups, int ng, unsign
     return 0;
 }
 extern "C" void emu_tree_topology_ibx8(unsigned long long *hi, unsigned long long *lo) { *hi = (unsigned long long)(kTreeTopoIbx8 >> 64); *lo = (unsigned long long)kTreeTopoIbx8; }
+extern "C" unsigned long long emu_tree_signature2(const rtbhip_tree_group *groups, int ng)      // the second class word (groups 8 .. 15)
+{
+    Tree t;
+    if (compile_tree(groups, ng, &t) != RTBHIP_OK) return 0ull;
+    return t.sig2;
+}
 extern "C" unsigned long long emu_tree_signature_ur() { return kTreeSigUR; }
 extern "C" unsigned long long emu_tree_signature_ibx8() { return kTreeSigIbx8; }
 extern "C" int emu_tree_dyn(const rtbhip_tree_group *groups, int ng, int mode, const double *q, const double *qd, const double *tq,
@@ -173,6 +179,9 @@ extern "C" int emu_tree_dyn(const rtbhip_tree_group *groups, int ng, int mode, c
     if (rtbhip::tree_sig_enabled() && t.sig == kTreeSigUR) { tree_dyn_mode<6, kTreeSigUR>(mode, &t, q, qd, tq, N, g, out); return 0; }      // as launch_tree_dyn dispatches
     if (rtbhip::tree_sig_enabled() && t.sig == kTreeSigIbx8 && t.topo == kTreeTopoIbx8) { tree_dyn_mode<8, kTreeSigIbx8, kTreeTopoIbx8>(mode, &t, q, qd, tq, N, g, out); return 0; }
     if (rtbhip::tree_sig_enabled() && t.sig == kTreeSigPx100 && t.topo == kTreeTopoPx100) { tree_dyn_mode<7, kTreeSigPx100, kTreeTopoPx100>(mode, &t, q, qd, tq, N, g, out); return 0; }
+    if (rtbhip::tree_sig_enabled() && t.sig == kTreeSigIbx9 && t.sig2 == kTreeSig2Ibx9 && t.topo == kTreeTopoIbx9) { tree_dyn_mode<9, kTreeSigIbx9, kTreeTopoIbx9, kTreeSig2Ibx9>(mode, &t, q, qd, tq, N, g, out); return 0; }
+    if (rtbhip::tree_sig_enabled() && t.sig == kTreeSigFetch && t.sig2 == kTreeSig2Fetch && t.topo == kTreeTopoFetch) { tree_dyn_mode<10, kTreeSigFetch, kTreeTopoFetch, kTreeSig2Fetch>(mode, &t, q, qd, tq, N, g, out); return 0; }
+    if (rtbhip::tree_sig_enabled() && t.sig == kTreeSigMico && t.sig2 == kTreeSig2Mico && t.topo == kTreeTopoMico) { tree_dyn_mode<10, kTreeSigMico, kTreeTopoMico, kTreeSig2Mico>(mode, &t, q, qd, tq, N, g, out); return 0; }
     if (rtbhip::tree_sig_enabled() && (t.sig & kTreeSigPlain)) {          // any other serial chain of up to 8 revolute joints: the plain-chain instantiation
         switch (t.n) {
         case 1: tree_dyn_mode<1, kTreeSigPlainChain>(mode, &t, q, qd, tq, N, g, out); return 0;
@@ -213,6 +222,9 @@ extern "C" int emu_tree_rne(const rtbhip_tree_group *groups, int ng, const doubl
     if (rtbhip::tree_sig_enabled() && t.sig == kTreeSigUR) { tree_run<6, kTreeSigUR>(&t, q, qd, qdd, N, g, tau); return 0; }      // as launch_tree_rne dispatches
     if (rtbhip::tree_sig_enabled() && t.sig == kTreeSigIbx8 && t.topo == kTreeTopoIbx8) { tree_run<8, kTreeSigIbx8, kTreeTopoIbx8>(&t, q, qd, qdd, N, g, tau); return 0; }
     if (rtbhip::tree_sig_enabled() && t.sig == kTreeSigPx100 && t.topo == kTreeTopoPx100) { tree_run<7, kTreeSigPx100, kTreeTopoPx100>(&t, q, qd, qdd, N, g, tau); return 0; }
+    if (rtbhip::tree_sig_enabled() && t.sig == kTreeSigIbx9 && t.sig2 == kTreeSig2Ibx9 && t.topo == kTreeTopoIbx9) { tree_run<9, kTreeSigIbx9, kTreeTopoIbx9, kTreeSig2Ibx9>(&t, q, qd, qdd, N, g, tau); return 0; }
+    if (rtbhip::tree_sig_enabled() && t.sig == kTreeSigFetch && t.sig2 == kTreeSig2Fetch && t.topo == kTreeTopoFetch) { tree_run<10, kTreeSigFetch, kTreeTopoFetch, kTreeSig2Fetch>(&t, q, qd, qdd, N, g, tau); return 0; }
+    if (rtbhip::tree_sig_enabled() && t.sig == kTreeSigMico && t.sig2 == kTreeSig2Mico && t.topo == kTreeTopoMico) { tree_run<10, kTreeSigMico, kTreeTopoMico, kTreeSig2Mico>(&t, q, qd, qdd, N, g, tau); return 0; }
     if (rtbhip::tree_sig_enabled() && (t.sig & kTreeSigPlain)) {
         switch (t.n) {
         case 1: tree_run<1, kTreeSigPlainChain>(&t, q, qd, qdd, N, g, tau); return 0;

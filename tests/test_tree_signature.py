@@ -83,6 +83,29 @@ def test_interbotix_arms_of_eight_groups_share_one_signature(name):
     assert [(t >> (12 * j + 4)) & 1 for j in range(8)] == [0] * 6 + [1, 1]
 
 
+def test_longer_trees_carry_a_second_class_word_and_take_their_instantiation():
+    """9 .. 16 groups: the fields of groups 8 .. 15 sit in a second word; up to 10 groups the bookkeeping word exists too.  The replay library dispatches
+    exactly as the launcher (tests/emu/emu_misc.cpp): with the switch on these robots run the instantiated bodies (the equality test below covers them)."""
+    import emu_harness as emu
+    from rtbhip._lib import rtbhip_tree_group
+    f2 = emu.lib().emu_tree_signature2
+    f2.argtypes, f2.restype = [C.POINTER(rtbhip_tree_group), C.c_int32], C.c_uint64
+    want = {"vx300s": (0x80970504b58de641, 0x8000000000000001), "wx250s": (0x80970504b58de641, 0x8000000000000001),
+            "Fetch": (0x80592d65ca380581, 0x800000000000164b), "Mico": (0x8063c18f0c09f047, 0x80000000000018f0)}
+    for name, (w1, w2) in want.items():
+        recs = urdf.load(name).erobot(()).group_table()
+        arr = (rtbhip_tree_group * len(recs))()
+        for k, r in enumerate(recs):
+            arr[k].parent, arr[k].kind, arr[k].flip, arr[k].jindex = r["parent"], r["kind"], r["flip"], r["jindex"]
+            arr[k].T[:] = list(np.ascontiguousarray(r["T"]).reshape(16))
+            arr[k].m = r["m"]
+            arr[k].h[:] = list(r["h"])
+            arr[k].I[:] = list(r["I"])
+        sig, _ = _signature_of_table(recs)
+        assert (sig, f2(arr, len(recs))) == (w1, w2), name
+        assert (sig >> 56) & 1 == 0
+
+
 def test_other_robots_do_not():
     for name in ("Panda", "Puma560"):
         sig, want = _signature(urdf.load(name))
@@ -126,7 +149,10 @@ def _check(name, N, seed):
     return rob, q, qd, tq, g, out[1]
 
 
-@pytest.mark.parametrize("name", UR + ("wx250", "px150", "px100"))
+LONGER = ("vx300s", "wx250s", "Fetch", "Mico")          # 9 .. 10 groups: a second class word; the Mico with a real branch point (one slot)
+
+
+@pytest.mark.parametrize("name", UR + ("wx250", "px150", "px100") + LONGER)
 def test_signature_kernels_equal_the_general_kernels_on_the_cpu_replay(name):
     import cpu_backend
     with cpu_backend.installed():
@@ -207,6 +233,6 @@ def test_plain_chain_instantiation_serves_any_serial_revolute_arm(n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", UR + ("wx250", "rx150", "px100"))
+@pytest.mark.parametrize("name", UR + ("wx250", "rx150", "px100") + LONGER)
 def test_gpu_signature_kernels_equal_the_general_kernels(name):
     _check(name, 5000, 12)
