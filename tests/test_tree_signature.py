@@ -106,6 +106,18 @@ def test_longer_trees_carry_a_second_class_word_and_take_their_instantiation():
         assert (sig >> 56) & 1 == 0
 
 
+def test_print_signatures_script_reports_the_words_the_kernels_dispatch_on():
+    """scripts/print_signatures.py is the maintainer's side of `a robot = its constants + one dispatch line`: its output for an instantiated robot must
+    carry exactly the words tree_device.h holds."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "print_signatures.py"), "UR5", "wx250", "Mico"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    text = out.stdout
+    assert "0x81000264b3145041 plain" in text and "0x80032e0a042de641" in text and "hi 0x8000000001701600 lo 0x5004003002001000" in text
+    assert "second word 0x80000000000018f0" in text and "RneSig 0xe00047a99a2c7ea9" in text
+
+
 def test_other_robots_do_not():
     for name in ("Panda", "Puma560"):
         sig, want = _signature(urdf.load(name))
