@@ -7,7 +7,7 @@ replay library, tests/emu: no GPU needed), for the shipped URDF robots (default:
   DH     RneSig  (csrc/rne_device.h: rne_signature)               per link: shortcut flags, class of alpha, a == 0, d == 0; no-friction / no-motor bits
 
 Serving another robot with straight-line kernels = one constant in tree_device.h / rne_device.h (what this script prints), one dispatch line in
-tree_kernels.hip / rne_kernels.hip + dyn_kernels.hip, one in tests/emu (the CPU replay mirrors the launcher), and the robot's name in
+tree_kernels.hip + tree_dyn_kernels.hip / rne_kernels.hip + dyn_kernels.hip, one in tests/emu (the CPU replay mirrors the launcher), and the robot's name in
 tests/test_tree_signature.py / test_rne_signature.py."""
 import ctypes as C
 import os

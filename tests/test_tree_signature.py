@@ -1,4 +1,4 @@
-"""Structure signatures of dynamics trees (csrc/tree_device.h: kTreeSigUR; tree.cpp: tree_signature; tree_kernels.hip's dispatch).
+"""Structure signatures of dynamics trees (csrc/tree_device.h: kTreeSigUR; tree.cpp: tree_signature; the dispatch of tree_kernels.hip / tree_dyn_kernels.hip).
 
 The group constants of a URDF robot are mostly not general rotations; for the signature this build has instantiations for -- the UR family's --
 `k_tree_rne` / `k_tree_dyn` multiply by every constant in the form of its class, drop the cross-product terms of the zero translation
