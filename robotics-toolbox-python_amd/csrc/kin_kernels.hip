@@ -388,8 +388,14 @@ __global__ __launch_bounds__(kWave) void k_angle_axis(const double *__restrict__
     const int64_t cfg0 = (int64_t)xcd_tile() * kWave;
     const int64_t left = N - cfg0;
     const int ncfg = left < kWave ? (int)left : kWave;
-    if (te_each) aa_load_tile(Te + cfg0 * 16, ncfg, a, lane); else aa_load_tile(Te, 1, a, lane);
-    if (tep_each) aa_load_tile(Tep + cfg0 * 16, ncfg, b, lane); else aa_load_tile(Tep, 1, b, lane);
+    {
+        // both operand tiles' loads in flight together (16 x 16 B per lane), then the LDS writes (servo_device.h: aa_fetch_tile)
+        AaTile ta, tb;
+        aa_fetch_tile(te_each ? Te + cfg0 * 16 : Te, te_each ? ncfg : 1, lane, ta);
+        aa_fetch_tile(tep_each ? Tep + cfg0 * 16 : Tep, tep_each ? ncfg : 1, lane, tb);
+        aa_store_tile(ta, te_each ? ncfg : 1, a, lane);
+        aa_store_tile(tb, tep_each ? ncfg : 1, b, lane);
+    }
     __syncthreads();
     double te16[12], tep16[12];
     const int la = te_each ? (lane < ncfg ? lane : 0) : 0, lb = tep_each ? (lane < ncfg ? lane : 0) : 0;

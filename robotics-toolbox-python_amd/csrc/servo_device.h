@@ -24,6 +24,28 @@ RTB_HD void aa_load_tile(const double *__restrict__ src, int ncfg, double *rows,
         dst[0] = v.x; dst[1] = v.y;
     }
 }
+// The same copy in two steps, for the kernel: ALL of a tile's global loads first (eight 16-byte loads per lane, in flight together), the LDS
+// writes afterwards.  The loop above has a run-time trip count: the compiler keeps it rolled and every trip is load -> wait -> LDS store, eight
+// dependent HBM round trips per operand (what k_rne's first tile copy suffered from, rne_kernels.hip).
+struct AaTile { double2 v[8]; };
+__device__ __forceinline__ void aa_fetch_tile(const double *__restrict__ src, int ncfg, int lane, AaTile &t)
+{
+    const int total = ncfg * 16;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int f = 2 * lane + 2 * kWave * k;
+        t.v[k] = f < total ? *reinterpret_cast<const double2 *>(src + f) : double2{0.0, 0.0};
+    }
+}
+__device__ __forceinline__ void aa_store_tile(const AaTile &t, int ncfg, double *rows, int lane)
+{
+    const int total = ncfg * 16;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int f = 2 * lane + 2 * kWave * k;
+        if (f < total) { double *dst = rows + (f >> 4) * kAaStride + (f & 15); dst[0] = t.v[k].x; dst[1] = t.v[k].y; }
+    }
+}
 
 // phase B: this lane's error vector e = angle_axis(Te, Tep) into the staging rows (stride 7)
 RTB_HD void aa_lane(const double *te16, const double *tep16, double *erow)
@@ -77,10 +99,24 @@ RTB_HD void servo_rpy_lane(const double *te, const double *tep, double *erow)
 
 // Hessian from a supplied Jacobian, phase A: `ncfg` consecutive (6,n) Jacobians (W = 6n doubles each, contiguous; W is
 // even) into LDS rows of stride W + 1
+// (eight 16-byte loads per lane in flight per trip, then their LDS writes: a trip of the plain loop is load -> wait -> LDS store, one HBM round
+// trip per 16 bytes -- see aa_fetch_tile)
 RTB_HD void hj_load_tile(const double *__restrict__ src, int W, int ncfg, double *rows, int lane)
 {
     const int total = ncfg * W;
-    for (int f = 2 * lane; f < total; f += 2 * kWave) {
+    int f = 2 * lane;
+    for (; f + 7 * 2 * kWave < total; f += 8 * 2 * kWave) {
+        double2 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const double2 *>(src + f + k * 2 * kWave);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int g = f + k * 2 * kWave, r = g / W, e = g - r * W;
+            double *dst = rows + r * (W + 1) + e;
+            dst[0] = v[k].x; dst[1] = v[k].y;
+        }
+    }
+    for (; f < total; f += 2 * kWave) {
         const double2 v = *reinterpret_cast<const double2 *>(src + f);
         const int r = f / W, e = f - r * W;      // W even: a piece never straddles two rows
         double *dst = rows + r * (W + 1) + e;
