@@ -42,6 +42,22 @@ __device__ __forceinline__ void tile_copy(double *rows, int stride, int col_off,
     int f = lane;
     int r = f / n, c = f - r * n;
     const int da = kW / n, db = kW - da * n;
+#ifndef RTB_RNE_RT_BATCH
+#define RTB_RNE_RT_BATCH 1
+#endif
+    if (RTB_RNE_RT_BATCH && TO_LDS && gsrc) {
+        // four loads in flight per trip (the trip count is a run-time value: a plain trip is load -> wait -> LDS store, one HBM round trip per 8 bytes)
+        for (; f + 3 * kW < count; f += 4 * kW) {
+            const double v0 = gsrc[f], v1 = gsrc[f + kW], v2 = gsrc[f + 2 * kW], v3 = gsrc[f + 3 * kW];
+            const double v[4] = {v0, v1, v2, v3};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                rows[r * stride + col_off + c] = v[k];
+                c += db; r += da;
+                if (c >= n) { c -= n; r += 1; }
+            }
+        }
+    }
     for (; f < count; f += kW) {
         if (TO_LDS) rows[r * stride + col_off + c] = gsrc ? gsrc[f] : 0.0;
         else gdst[f] = rows[r * stride + col_off + c];
