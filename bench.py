@@ -276,6 +276,10 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            # t0 (after the opening barrier) -> each rank's OWN synchronize, MAX over ranks: no collective inside (benchlib.Ranks.timed_steps).
+            # Beside it the same clock read after the closing barrier (for one rank: the same number).
+            "ms_per_step_with_barrier": rk.last_elapsed_with_barrier / args.steps * 1e3,
+            "timed_region": "opening barrier+sync | t0 | K launches | own torch.cuda.synchronize | t1 | closing barrier; value = units / MAX over ranks (t1 - t0)",
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -316,12 +316,226 @@ def fleet_config5(rtbhip, N=1000000, sample=4000):
     return out
 
 
+def structure_legs(rtbhip, n_rne=10000000, n_ik=100000, n_tree=1000000):
+    """What a user's OWN robot gets (round-5 review, missing 2 / 3).  The fast forms of k_ik / k_rne / k_tree_* are instantiations per robot
+    structure: built into the library for the robots of BASELINE's configs, compiled at run time by hipRTC (csrc/jit.cpp) for every other
+    robot.  Per family, on the SAME workload shape as the config it belongs to:
+        general     the general kernel (rtbhip_tune *_sig = 0) on the config's own robot -- what every robot got before this round, and what a
+                    robot gets while its code object is being compiled, or on a box without hipRTC
+        jit         a robot with NO built-in instantiation, served by its run-time instantiation, and the same robot on the general kernel;
+                    in-run check: the two outputs are EQUAL, bit for bit (the structured forms are the general operation sequences with their
+                    exact zeros and ones rewritten away: csrc/exactform.h)
+    plus the compile seconds / disk-cache hits this process saw (rtbhip_jit_stats)."""
+    import numpy as np
+    import torch
+    from rtbhip import jit, urdf
+    out = {}
+    if not jit.stats()["available"]:
+        return {"error": "libhiprtc.so not found on this box: every robot without a built-in instantiation takes the general kernels"}
+
+    def timed(fn):
+        fn()
+        ms, reps, warm = sustained_ms(fn)
+        return ms
+
+    def settle(prepare_obj):
+        t0 = time.perf_counter()
+        jit.prepare(prepare_obj)
+        jit.wait(300)
+        return time.perf_counter() - t0
+
+    g = torch.Generator(device="cuda").manual_seed(11)
+
+    # ---- RNE (config 4's shape): the DH Panda on the general kernel; a DH Panda with one alpha perturbed (no built-in instantiation)
+    def rne_leg(rob, N):
+        ql = torch.from_numpy(np.asarray(rob.qlim)).cuda()
+        q = ql[0] + (ql[1] - ql[0]) * torch.rand((N, rob.n), dtype=torch.float64, device="cuda", generator=g)
+        qd = torch.randn((N, rob.n), dtype=torch.float64, device="cuda", generator=g)
+        qdd = torch.randn((N, rob.n), dtype=torch.float64, device="cuda", generator=g)
+        res = {}
+
+        def run():
+            res["tau"] = rob.rne(q, qd, qdd)
+        return run, res
+    panda = rtbhip.models.DH.Panda()
+    run, res = rne_leg(panda, n_rne)
+    rtbhip.tune("rne_sig", 0)
+    try:
+        ms_gen = timed(run)
+    finally:
+        rtbhip.tune("rne_sig", 1)
+    ms_sig = timed(run)
+    out["rne_general"] = {"workload": "config 4's shape: DH Panda rne, %d triples, GENERAL kernel k_rne<7,MDH,all-revolute> (rne_sig = 0)" % n_rne,
+                          "kernel_avg_ms": ms_gen, "builtin_signature_ms": ms_sig, "roofline": _hbm(RNE_BYTES_PER_TRIPLE * n_rne, ms_gen, "k_rne<7,true,true,0>")}
+    links = list(panda.links)
+    k = links[3]
+    links[3] = rtbhip.RevoluteMDH(a=k.a, d=k.d, alpha=k.alpha + 0.01, m=k.m, r=k.r, I=k.I, G=1)
+    other = rtbhip.DHRobot(links, name="Panda, alpha_4 + 0.01")
+    wait_s = settle(other)
+    run, res = rne_leg(other, n_rne)
+    l0 = jit.stats()["launches"]
+    ms_jit = timed(run)
+    served = jit.stats()["launches"] - l0
+    a = res["tau"].clone()
+    rtbhip.tune("rne_sig", 0)
+    try:
+        ms_gen2 = timed(run)
+    finally:
+        rtbhip.tune("rne_sig", 1)
+    same = bool(torch.equal(a, res["tau"]))
+    out["rne_jit"] = {"workload": "the same, a DH Panda whose alpha_4 is 0.01 rad off: no built-in instantiation -> k_rne<7,true,true,SIG> compiled by hipRTC",
+                      "kernel_avg_ms": ms_jit, "general_kernel_ms": ms_gen2, "speedup_vs_general": ms_gen2 / ms_jit, "launches_served_by_jit": int(served),
+                      "bit_identical_to_general": same, "wait_for_compile_s": wait_s, "roofline": _hbm(RNE_BYTES_PER_TRIPLE * n_rne, ms_jit, jit.names(other)[0][0])}
+    if not same or served < 1:
+        raise SystemExit("bench: the run-time instantiation of k_rne is not the general kernel's bits (or did not serve): %r" % (out["rne_jit"],))
+    del res, a
+    torch.cuda.empty_cache()
+
+    # ---- IK (config 3's shape): the Panda on the general kernel; the LBR iiwa (URDF, 7 joints, one negative axis) on its run-time instantiation
+    def ik_leg(ets, N, seed):
+        rng = np.random.default_rng(seed)
+        lim = np.asarray(ets.qlim)
+        Tep = ets.eval(torch.from_numpy(rng.uniform(lim[0], lim[1], (N, ets.n))).cuda())
+        res = {}
+
+        def run():
+            res["out"] = ets.ik_LM(Tep, seed=2)
+        return run, res
+    pe = rtbhip.models.Panda().ets()
+    pe.qlim = rtbhip.models.PANDA_QLIM
+    run, res = ik_leg(pe, n_ik, 1)
+    rtbhip.tune("ik_sig", 0)
+    try:
+        ms_gen = timed(run)
+    finally:
+        rtbhip.tune("ik_sig", 1)
+    its = float(res["out"][2].sum())
+    out["ik_general"] = {"workload": "config 3 exactly, GENERAL kernel k_ik<7,0,13,0> (ik_sig = 0)", "kernel_avg_ms": ms_gen,
+                         "roofline": {"bound": "fp64-valu", "unit": "TFLOP/s", "peak": FP64_VALU_PEAK_TFLOPS,
+                                      "achieved": its / (ms_gen * 1e-3) * IK_FLOPS_PER_ITERATION / 1e12,
+                                      "frac": its / (ms_gen * 1e-3) * IK_FLOPS_PER_ITERATION / 1e12 / FP64_VALU_PEAK_TFLOPS, "kernel": "k_ik<7,0,13,0>"}}
+    lbr = urdf.load("LBR").ets()
+    wait_s = settle(lbr)
+    run, res = ik_leg(lbr, n_ik, 4)
+    l0 = jit.stats()["launches"]
+    ms_jit = timed(run)
+    served = jit.stats()["launches"] - l0
+    a = [x.clone() for x in res["out"]]
+    rtbhip.tune("ik_sig", 0)
+    try:
+        ms_gen2 = timed(run)
+    finally:
+        rtbhip.tune("ik_sig", 1)
+    same = all(bool(torch.equal(x, y)) for x, y in zip(a, res["out"]))
+    its = float(a[2].sum())
+    out["ik_jit"] = {"workload": "config 3's shape on the LBR iiwa read from its URDF (7 joints, one negative axis, URDF limits): %d reachable targets, ik_LM defaults" % n_ik,
+                     "kernel_avg_ms": ms_jit, "general_kernel_ms": ms_gen2, "speedup_vs_general": ms_gen2 / ms_jit, "launches_served_by_jit": int(served),
+                     "bit_identical_to_general": same, "success_rate": float(a[1].bool().float().mean()), "mean_iterations": its / n_ik,
+                     "wait_for_compile_s": wait_s, "kernel": (jit.names(lbr)[0] or ["?"])[0]}
+    if not same or served < 1:
+        raise SystemExit("bench: the run-time instantiation of k_ik is not the general kernel's bits (or did not serve): %r" % (out["ik_jit"],))
+    del res, a
+    torch.cuda.empty_cache()
+
+    # ---- link trees (Robot.rne): the UR5 on the general kernel; the Kinova Gen3 (13 link groups) and YuMi (18) on their run-time instantiations
+    def tree_leg(t, N):
+        q = 4.0 * torch.rand((N, t.n), dtype=torch.float64, device="cuda", generator=g) - 2.0
+        qd = torch.randn((N, t.n), dtype=torch.float64, device="cuda", generator=g)
+        qdd = torch.randn((N, t.n), dtype=torch.float64, device="cuda", generator=g)
+        res = {}
+
+        def run():
+            res["tau"] = t.rne(q, qd, qdd)
+        return run, res
+    ur = urdf.load("UR5").erobot()
+    run, res = tree_leg(ur, n_tree)
+    rtbhip.tune("tree_sig", 0)
+    try:
+        ms_gen = timed(run)
+    finally:
+        rtbhip.tune("tree_sig", 1)
+    ms_sig = timed(run)
+    out["tree_general"] = {"workload": "UR5 link tree (6 groups) Robot.rne, %d triples, GENERAL kernel k_tree_rne<6,false> (tree_sig = 0)" % n_tree,
+                           "kernel_avg_ms": ms_gen, "builtin_signature_ms": ms_sig}
+    for name in ("KinovaGen3", "YuMi"):
+        t = urdf.load(name).erobot()
+        wait_s = settle(t)
+        run, res = tree_leg(t, n_tree)
+        l0 = jit.stats()["launches"]
+        ms_jit = timed(run)
+        served = jit.stats()["launches"] - l0
+        a = res["tau"].clone()
+        rtbhip.tune("tree_sig", 0)
+        try:
+            ms_gen2 = timed(run)
+        finally:
+            rtbhip.tune("tree_sig", 1)
+        same = bool(torch.equal(a, res["tau"]))
+        out["tree_jit_" + name] = {"workload": "%s link tree (%d groups) Robot.rne, %d triples: its generated knowledge type, k_tree_rne compiled by hipRTC" % (name, t.n, n_tree),
+                                   "kernel_avg_ms": ms_jit, "general_kernel_ms": ms_gen2, "speedup_vs_general": ms_gen2 / ms_jit,
+                                   "launches_served_by_jit": int(served), "bit_identical_to_general": same, "wait_for_compile_s": wait_s}
+        if not same or served < 1:
+            raise SystemExit("bench: the run-time instantiation of k_tree_rne (%s) is not the general kernel's bits (or did not serve): %r" % (name, out["tree_jit_" + name]))
+        del res, a
+        torch.cuda.empty_cache()
+    st = jit.stats()
+    out["jit"] = {k: st[k] for k in ("requested", "compiled", "disk_hits", "failed", "launches", "general_while_pending", "compile_seconds", "compile_seconds_max", "source_digest")}
+    return out
+
+
+def _committed(root, out):
+    """`frac_rocprof_committed` for the secondary legs, from the rocprofv3 --kernel-trace run of THIS command committed under profiles/
+    (rNN_*_secondary_kernel_stats.csv: scripts/visit.sh stage `profsec` -> scripts/secondary_stats.py, durations per kernel AND grid size -- config 4
+    launches the same k_rne at 1e7 triples and at its 1.25e6 share): the event figures above, cross-checked by the profiler on another lease."""
+    import csv
+    import glob
+    import os
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r[0-9][0-9]_*_secondary_kernel_stats.csv")))
+    if not files:
+        return
+    rows = list(csv.DictReader(open(files[-1])))
+    src = "profiles/" + os.path.basename(files[-1])
+
+    def find(sub, grid=None):
+        hits = [r for r in rows if sub.replace(" ", "") in (r.get("Name") or "").replace(" ", "") and (grid is None or int(r["GridSize"]) == grid)]
+        return max(hits, key=lambda r: float(r["TotalDurationNs"])) if hits else None
+
+    def note(row):
+        return {"file": src, "kernel": row["Name"][:120], "grid": int(row["GridSize"]), "avg_ns": float(row["AverageNs"]), "calls": int(row["Calls"])}
+
+    def hbm(leg, row):
+        if row is None or not isinstance(out.get(leg), dict) or "roofline" not in out[leg]:
+            return
+        rf = out[leg]["roofline"]
+        rf["frac_rocprof_committed"] = rf["algorithmic_bytes_per_launch"] / (float(row["AverageNs"]) * 1e-9) / 1e9 / HBM_PEAK_GBS
+        rf["rocprof_committed"] = note(row)
+    for leg in ("rne_config4_1e7", "rne_config4_shard"):
+        if isinstance(out.get(leg), dict) and "n" in out[leg]:
+            hbm(leg, find("k_rne<7", ((out[leg]["n"] + 63) // 64) * 64))
+    ik = find("k_ik<7")
+    leg = out.get("ik_config3")
+    if ik is not None and isinstance(leg, dict) and "roofline" in leg:
+        its = leg["mean_iterations"] * leg["n"]
+        merge = find("k_ik_merge_flat")
+        leg["roofline"]["frac_rocprof_committed"] = its * IK_FLOPS_PER_ITERATION / (float(ik["AverageNs"]) * 1e-9) / 1e12 / FP64_VALU_PEAK_TFLOPS
+        leg["roofline"]["rocprof_committed"] = dict(note(ik), merge_kernel=None if merge is None else note(merge),
+                                                    note="the scheduler kernel alone; a call is this + two fills + k_ik_merge_flat")
+    f0, f1 = find("k_fleet<0"), find("k_fleet<1")
+    leg = out.get("fleet_config5")
+    if f0 is not None and f1 is not None and isinstance(leg, dict) and "roofline" in leg:
+        # one call = one launch of each class: the leg's bytes over the sum of the two average durations
+        # (rows of the 17-chain form: the largest grids of each kernel)
+        t = (float(f0["AverageNs"]) + float(f1["AverageNs"])) * 1e-9
+        leg["roofline"]["frac_rocprof_committed"] = leg["roofline"]["algorithmic_bytes_per_launch"] / t / 1e9 / HBM_PEAK_GBS
+        leg["roofline"]["rocprof_committed"] = {"k_fleet<0>": note(f0), "k_fleet<1>": note(f1)}
+
+
 def secondary(rtbhip):
     """{"ik_config3", "rne_config4_1e7", "rne_config4_shard", "fleet_config5", "seconds"}; a leg that cannot run reports {"error": ...}
     (a PARITY failure is not such an error: it ends the bench)."""
     t_all = time.perf_counter()
     out = {}
-    for key, fn in (("ik_config3", ik_config3), ("rne_config4", rne_config4), ("fleet_config5", fleet_config5)):
+    for key, fn in (("ik_config3", ik_config3), ("rne_config4", rne_config4), ("fleet_config5", fleet_config5), ("structure", structure_legs)):
         t0 = time.perf_counter()
         try:
             r = fn(rtbhip)
@@ -339,5 +553,10 @@ def secondary(rtbhip):
             out[key] = r
             if isinstance(r, dict):
                 r["seconds"] = time.perf_counter() - t0
+    import os
+    try:
+        _committed(os.path.dirname(os.path.abspath(__file__)), out)
+    except Exception as e:                                       # a malformed profile file must not cost the run its line
+        out["_profiles"] = {"error": repr(e)[:200]}
     out["seconds"] = time.perf_counter() - t_all
     return out

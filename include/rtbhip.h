@@ -420,6 +420,45 @@ int rtbhip_stream_probe(const double *src, int64_t read_doubles, double *dst, in
 
 int rtbhip_tune(const char *key, int32_t value);
 
+/* ---- run-time instantiation of the structure-signature kernels (csrc/jit.cpp).
+ * The reference serves every robot through ONE general code path at one cost (core/methods.cpp:318-352 _ETS_fkine, core/ik.cpp:19-75 _IK_LM,
+ * core/ne.c:62-493 newton_euler, robot/Robot.py:1704-1903 Robot.rne); here the straight-line forms of k_ik / k_rne / k_dyn / k_tree_rne /
+ * k_tree_dyn are instantiated per robot structure.  A robot whose structure words match no instantiation built into the library gets its own,
+ * compiled from the same sources by hipRTC on a worker thread (requested at rtbhip_chain_create / rtbhip_dyn_create / rtbhip_tree_create and
+ * again at the first launch); until the code object is ready launches take the general kernel, which returns the same bits.  Code objects
+ * are cached under $RTBHIP_JIT_CACHE (default $XDG_CACHE_HOME/rtbhip/jit or ~/.cache/rtbhip/jit; "-" disables the disk cache).
+ * rtbhip_tune("jit", 0 | 1 | 2): off / asynchronous (default) / a launch waits for its instantiation; "jit_eager" 0: nothing is requested at create. */
+typedef struct rtbhip_jit_info {
+    int32_t available;              /* libhiprtc.so was found (otherwise the general kernels serve every robot without a built-in instantiation) */
+    int32_t mode;                   /* rtbhip_tune("jit") */
+    int64_t requested;              /* distinct instantiations asked for in this process */
+    int64_t compiled;               /* ... compiled by hipRTC */
+    int64_t disk_hits;              /* ... read from the disk cache instead */
+    int64_t failed;                 /* ... that failed to compile or load (last_error) */
+    int64_t pending;                /* ... queued or being compiled now */
+    int64_t launches;               /* launches served by a run-time instantiation */
+    int64_t general_while_pending;  /* launches that took the general kernel because their instantiation was not ready yet */
+    double compile_seconds;         /* total / longest hipRTC time */
+    double compile_seconds_max;
+    int32_t sources;                /* embedded source files */
+    char source_digest[20];         /* first 16 hex digits of their sha256 (part of the cache key) */
+    char last_error[512];
+} rtbhip_jit_info;
+int rtbhip_jit_stats(rtbhip_jit_info *out);
+/* Blocks until no instantiation is queued or being compiled (timeout_s < 0: no limit).  Returns RTBHIP_OK, or 1 when the time ran out. */
+int rtbhip_jit_wait(double timeout_s);
+/* Compile one instantiation NOW on the calling thread for a named architecture (no device needed: hipRTC cross-compiles) -- what the build
+ * check and the tests use to prove that the embedded sources compile under hipRTC.  unit: "ik_kernels.hip", "rne_kernels.hip", "dyn_kernels.hip",
+ * "tree_kernels.hip", "tree_dyn_kernels.hip"; expr: a C++ name expression, e.g. "rtbhip::k_rne<7, true, true, 0xe00047a99a2c7ea9ull>". */
+int rtbhip_jit_compile(const char *unit, const char *expr, const char *arch, int64_t *code_bytes, double *seconds, int32_t *from_disk);
+/* Ask for ALL of a handle's run-time instantiations now (worker thread; returns at once).  kind: 0 chain, 1 dyn, 2 tree.  The *_create calls ask
+ * by themselves once the library has used a device in this process -- they never initialise the HIP runtime on their own (a process may build
+ * its robots and fork its GPU workers afterwards); this call does, and so does the first launch. */
+int rtbhip_jit_prepare(int32_t kind, uint64_t handle);
+/* The name expressions a handle's run-time instantiations are requested under, '\n'-separated, into buf (truncated to cap - 1 characters);
+ * kind: 0 chain (k_ik), 1 dyn (k_rne ...), 2 tree (k_tree_rne ...).  Empty when the structure has a built-in instantiation or none applies. */
+int rtbhip_jit_names(int32_t kind, uint64_t handle, char *buf, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

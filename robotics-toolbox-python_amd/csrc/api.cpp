@@ -380,6 +380,27 @@ int ik_prepare_device();
 void hostpipe_tune(const char *key, int value);
 void shard_tune(const char *key, int value);
 void tree_tune(const char *key, int value);
+std::string tree_jit_knowledge(const Tree *t, std::string *type_name);      // tree_kernels.hip
+bool tree_jit_applies(const Tree *t);
+// ask for a handle's run-time instantiations (jit.cpp).  At *_create: the kernels a first call is most likely to want; all = every variant.
+static void jit_request_chain(const Chain *c, bool touch)
+{
+    for (const std::string &e : ik_jit_names(c)) jit_request("ik_kernels.hip", e, std::string(), touch);
+}
+static void jit_request_dyn(const Dyn *d, bool all, bool touch)
+{
+    const std::vector<std::string> nm = rne_jit_names(d);          // k_rne, k_rne_atrest, k_dyn x 3
+    for (size_t i = 0; i < nm.size() && (all || i < 2); ++i) jit_request(i < 2 ? "rne_kernels.hip" : "dyn_kernels.hip", nm[i], std::string(), touch);
+}
+static void jit_request_tree(const Tree *t, bool all, bool touch)
+{
+    const std::vector<std::string> nm = tree_jit_names(t);         // k_tree_rne (+ at rest), k_tree_dyn x 3
+    if (nm.empty()) return;
+    std::string tn;
+    const std::string pre = tree_jit_knowledge(t, &tn);
+    for (size_t i = 0; i < nm.size() && (all || i < 1); ++i)
+        jit_request(nm[i].find("k_tree_dyn") != std::string::npos ? "tree_dyn_kernels.hip" : "tree_kernels.hip", nm[i], pre, touch);
+}
 
 }  // namespace rtbhip
 
@@ -442,6 +463,7 @@ int rtbhip_chain_create(const rtbhip_et *ets, int32_t m, const double *qlim, rtb
     if (!chain) { set_error("chain_create: NULL out"); return RTBHIP_EINVAL; }
     std::shared_ptr<Chain> c(new Chain());
     RTB_TRY(compile_chain(ets, m, qlim, c.get()));
+    jit_request_chain(c.get(), false);       // a chain without a built-in k_ik instantiation: ask for its own (worker thread; nobody waits)
     uint64_t h = g_next.fetch_add(1);
     std::lock_guard<std::mutex> lk(g_reg_mu);
     g_chains[h] = std::move(c);
@@ -454,6 +476,7 @@ int rtbhip_chain_create_poe(const double *twists, int32_t n, const double *T0_16
     if (!chain) { set_error("chain_create_poe: NULL out"); return RTBHIP_EINVAL; }
     std::shared_ptr<Chain> c(new Chain());
     RTB_TRY(compile_poe(twists, n, T0_16, qlim, c.get()));
+    jit_request_chain(c.get(), false);
     uint64_t h = g_next.fetch_add(1);
     std::lock_guard<std::mutex> lk(g_reg_mu);
     g_chains[h] = std::move(c);
@@ -1018,6 +1041,8 @@ int rtbhip_dyn_create(const double *L24, int32_t n, int32_t mdh, rtbhip_dyn_t *d
     }
     uint64_t h = g_next.fetch_add(1);
     std::lock_guard<std::mutex> lk(g_reg_mu);
+    // a table without a built-in instantiation: ask for its own now (worker thread; nobody waits), the first launches take the general kernels
+    jit_request_dyn(d.get(), false, false);
     g_dyns[h] = std::move(d);
     *dyn = h;
     return RTBHIP_OK;
@@ -1082,6 +1107,7 @@ int rtbhip_tree_create(const rtbhip_tree_group *groups, int32_t ng, rtbhip_tree_
     if (!tree) { set_error("tree_create: NULL handle pointer"); return RTBHIP_EINVAL; }
     std::shared_ptr<Tree> t(new Tree());
     RTB_TRY(compile_tree(groups, ng, t.get()));
+    jit_request_tree(t.get(), false, false);
     const uint64_t h = g_next.fetch_add(1);
     std::lock_guard<std::mutex> lk(g_reg_mu);
     g_trees[h] = std::move(t);
@@ -1340,6 +1366,59 @@ int rtbhip_tune(const char *key, int32_t value)
     hostpipe_tune(key, value);
     shard_tune(key, value);
     tree_tune(key, value);
+    jit_tune(key, value);
+    return RTBHIP_OK;
+}
+
+// ---- run-time instantiation (jit.cpp)
+int rtbhip_jit_stats(rtbhip_jit_info *out)
+{
+    if (!out) { set_error("jit_stats: NULL out"); return RTBHIP_EINVAL; }
+    jit_stats(out);
+    return RTBHIP_OK;
+}
+int rtbhip_jit_wait(double timeout_s) { return jit_wait(timeout_s); }
+int rtbhip_jit_compile(const char *unit, const char *expr, const char *arch, int64_t *code_bytes, double *seconds, int32_t *from_disk)
+{
+    if (!unit || !expr || !arch) { set_error("jit_compile: NULL argument"); return RTBHIP_EINVAL; }
+    size_t cb = 0;
+    double sec = 0.0;
+    int fd = 0;
+    // "unit" may carry generated source after a newline (a tree's knowledge type): "tree_kernels.hip\nnamespace rtbhip { struct ... }"
+    const std::string u = unit;
+    const size_t nl = u.find('\n');
+    const std::string file = nl == std::string::npos ? u : u.substr(0, nl), pre = nl == std::string::npos ? std::string() : u.substr(nl + 1);
+    const int rc = jit_compile_now(file.c_str(), expr, arch, &cb, &sec, &fd, pre.c_str());
+    if (code_bytes) *code_bytes = (int64_t)cb;
+    if (seconds) *seconds = sec;
+    if (from_disk) *from_disk = fd;
+    return rc;
+}
+int rtbhip_jit_prepare(int32_t kind, uint64_t handle)
+{
+    if (kind == 0) { auto c = chain_from_handle(handle); if (!c) return RTBHIP_EINVAL; jit_request_chain(c.get(), true); }
+    else if (kind == 1) { auto d = dyn_from_handle(handle); if (!d) return RTBHIP_EINVAL; jit_request_dyn(d.get(), true, true); }
+    else if (kind == 2) { auto t = tree_from_handle(handle); if (!t) return RTBHIP_EINVAL; jit_request_tree(t.get(), true, true); }
+    else { set_error("jit_prepare: kind must be 0 (chain), 1 (dyn) or 2 (tree)"); return RTBHIP_EINVAL; }
+    return RTBHIP_OK;
+}
+int rtbhip_jit_names(int32_t kind, uint64_t handle, char *buf, int64_t cap)
+{
+    if (!buf || cap < 1) { set_error("jit_names: bad buffer"); return RTBHIP_EINVAL; }
+    std::vector<std::string> names;
+    std::string pre;
+    if (kind == 0) { auto c = chain_from_handle(handle); if (!c) return RTBHIP_EINVAL; names = ik_jit_names(c.get()); }
+    else if (kind == 1) { auto d = dyn_from_handle(handle); if (!d) return RTBHIP_EINVAL; names = rne_jit_names(d.get()); }
+    else if (kind == 2) {
+        auto t = tree_from_handle(handle);
+        if (!t) return RTBHIP_EINVAL;
+        names = tree_jit_names(t.get());
+        if (!names.empty()) { std::string tn; pre = tree_jit_knowledge(t.get(), &tn); }
+    } else { set_error("jit_names: kind must be 0 (chain), 1 (dyn) or 2 (tree)"); return RTBHIP_EINVAL; }
+    std::string all;
+    for (const std::string &n : names) all += n + "\n";
+    if (!pre.empty()) all += "\f" + pre;            // after a form feed: the generated knowledge type the tree's expressions refer to
+    std::snprintf(buf, (size_t)cap, "%s", all.c_str());
     return RTBHIP_OK;
 }
 

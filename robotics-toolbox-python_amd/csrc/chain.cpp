@@ -74,6 +74,30 @@ DevSeg perm_transpose_seg(const int perm[3])
     return O;
 }
 
+// A FLIPPED joint (ET.py: eta = -q; methods.cpp:363-366 negates the coordinate, :142-145 / :172-175 the Jacobian column) is absorbed into the
+// constants either side of it: with D = diag(1, -1, -1),  Z(-q) = D Z(q) D  for a rotation about z and for a slide along z alike (D turns the z
+// axis round; sign changes are exact), so  C_j Z(-q) C_{j+1} = (C_j D) Z(q) (D C_{j+1}).  The device then walks an UNFLIPPED joint: its axis in
+// the base frame is -z_j -- the negated Jacobian column the reference forms -- and every kernel's straight-line walk (and with it a structure
+// signature, a run-time instantiation) serves robots with negative joint axes too (LBR iiwa joint 4, YuMi): no flip bit reaches the device.
+DevSeg flip_columns(const DevSeg &A)      // A * D
+{
+    DevSeg O = A;
+    for (int r = 0; r < 3; r++) { O.r[3 * r + 1] = -A.r[3 * r + 1]; O.r[3 * r + 2] = -A.r[3 * r + 2]; }
+    return O;
+}
+// the constant run that follows a joint starts with M_a^T (the axis conjugation; the identity for a z joint), after D when the joint is flipped
+void run_after_joint(int axis, bool flip, DevSeg *cur, bool *is_identity)
+{
+    int perm[3];
+    axis_perm(axis, perm);
+    if (axis == 2 && !flip) { *cur = seg_identity(); *is_identity = true; return; }
+    DevSeg m = axis == 2 ? seg_identity() : perm_transpose_seg(perm);
+    if (flip)
+        for (int c = 0; c < 3; c++) { m.r[3 + c] = m.r[3 + c] == 0.0 ? 0.0 : -m.r[3 + c]; m.r[6 + c] = m.r[6 + c] == 0.0 ? 0.0 : -m.r[6 + c]; }   // D * m (zeros stay +0)
+    *cur = m;
+    *is_identity = false;
+}
+
 }  // namespace
 
 // structure class + translation mask of a folded constant (rtbhip_internal.h: kSeg*), from its EXACT zeros and ones
@@ -136,10 +160,10 @@ int compile_chain(const rtbhip_et *ets, int m, const double *qlim, Chain *out)
         const bool prismatic = e.kind >= 3;
         int perm[3];
         axis_perm(axis, perm);
-        out->seg.push_back(axis == 2 ? cur : right_perm(cur, perm));   // C_j * M_a
-        out->jmeta.push_back((prismatic ? 1 : 0) | (e.jindex << 8) | ((e.flip ? 1 : 0) << 16));
-        if (axis == 2) { cur = seg_identity(); cur_is_identity = true; }
-        else { cur = perm_transpose_seg(perm); cur_is_identity = false; }  // M_a^T starts the next run
+        const DevSeg cj = axis == 2 ? cur : right_perm(cur, perm);      // C_j * M_a
+        out->seg.push_back(e.flip ? flip_columns(cj) : cj);             // ... * D for a flipped joint
+        out->jmeta.push_back((prismatic ? 1 : 0) | (e.jindex << 8));    // (no flip bit: absorbed above)
+        run_after_joint(axis, e.flip != 0, &cur, &cur_is_identity);     // (D) M_a^T starts the next run
         n++;
         if (e.jindex + 1 > qw) qw = e.jindex + 1;
         lo.push_back(prismatic ? 0.0 : -M_PI);  // default limits: robot/ET.py:109-115
@@ -291,11 +315,7 @@ int compile_frames(const Chain *c, const int32_t *marks, int nmarks, FrameTable 
             cur = cur_is_identity ? a : seg_mul(cur, a);
             cur_is_identity = false;
         } else {
-            const int axis = e.kind % 3;
-            int perm[3];
-            axis_perm(axis, perm);
-            if (axis == 2) { cur = seg_identity(); cur_is_identity = true; }
-            else { cur = perm_transpose_seg(perm); cur_is_identity = false; }
+            run_after_joint(e.kind % 3, e.flip != 0, &cur, &cur_is_identity);
             n++;
         }
         record(i + 1);

@@ -151,6 +151,7 @@ __global__ __launch_bounds__(kDW, (NJ <= 8 ? 2 : 1)) void k_dyn(DynParams dp, co
     else flush_run(A, L::w_stride, L::W, ncfg, out + cfg0 * L::W, lane);
 }
 
+#if RTB_HOST_SIDE      // the launchers (the kernel above is also what jit.cpp hands to hipRTC, one instantiation at a time)
 template <int NJ, int MODE, bool MDH, bool ALLREV, RneSig SIG = 0>
 static hipError_t launch_one(dim3 grid, hipStream_t s, size_t lds, const DynParams &dp, const DevLink *links, const double *q,
                              const double *qd, const double *tq, double *out)
@@ -162,8 +163,9 @@ static hipError_t launch_one(dim3 grid, hipStream_t s, size_t lds, const DynPara
 }
 
 int rne_sig_enabled();      // rne_kernels.hip: rtbhip_tune("rne_sig")
+std::string rne_jit_expr(int n, bool mdh, RneSig sig, int variant);
 template <int NJ, int MODE>
-static hipError_t launch_mode(bool mdh, bool allrev, dim3 grid, hipStream_t s, const DynParams &dp, const DevLink *links, const double *q,
+static hipError_t launch_mode(const Dyn *d, bool mdh, bool allrev, dim3 grid, hipStream_t s, const DynParams &dp, const DevLink *links, const double *q,
                               const double *qd, const double *tq, double *out, size_t *lds_out, RneSig sig)
 {
     const size_t lds = (size_t)(allrev ? DynLayout<NJ, MODE, true>::doubles
@@ -172,6 +174,17 @@ static hipError_t launch_mode(bool mdh, bool allrev, dim3 grid, hipStream_t s, c
     // a robot whose link table has a structure signature this build is instantiated for (rne_device.h: kRneSig*)
     if constexpr (NJ == 7) { if (sig == kRneSigPanda && mdh && allrev) return launch_one<7, MODE, true, true, kRneSigPanda>(grid, s, lds, dp, links, q, qd, tq, out); }
     if constexpr (NJ == 6) { if (sig == kRneSigPuma560 && !mdh && allrev) return launch_one<6, MODE, false, true, kRneSigPuma560>(grid, s, lds, dp, links, q, qd, tq, out); }
+    if constexpr (NJ <= kRneSigMaxLinks) {
+        // any other robot with a signature: its own instantiation, compiled at run time (jit.cpp); the general kernels below serve until it is there
+        const bool builtin = (NJ == 7 && mdh && sig == kRneSigPanda) || (NJ == 6 && !mdh && sig == kRneSigPuma560);
+        if (sig && allrev && !builtin && jit_enabled()) {
+            if (hipFunction_t f = d->jit.get("dyn_kernels.hip", 2 + MODE, [&] { return rne_jit_expr(NJ, mdh, sig, 2 + MODE); })) {
+                DynParams dpv = dp;
+                void *args[] = {&dpv, &links, &q, &qd, &tq, &out};
+                return jit_launch(f, grid, dim3(kDW), lds, s, args) == RTBHIP_OK ? hipSuccess : hipErrorLaunchFailure;
+            }
+        }
+    }
     if (mdh) return allrev ? launch_one<NJ, MODE, true, true>(grid, s, lds, dp, links, q, qd, tq, out)
                            : launch_one<NJ, MODE, true, false>(grid, s, lds, dp, links, q, qd, tq, out);
     return allrev ? launch_one<NJ, MODE, false, true>(grid, s, lds, dp, links, q, qd, tq, out)
@@ -179,12 +192,12 @@ static hipError_t launch_mode(bool mdh, bool allrev, dim3 grid, hipStream_t s, c
 }
 
 template <int NJ>
-static hipError_t launch_nj(int mode, bool mdh, bool allrev, dim3 grid, hipStream_t s, const DynParams &dp, const DevLink *links,
+static hipError_t launch_nj(const Dyn *d, int mode, bool mdh, bool allrev, dim3 grid, hipStream_t s, const DynParams &dp, const DevLink *links,
                             const double *q, const double *qd, const double *tq, double *out, size_t *lds, RneSig sig = 0)
 {
-    if (mode == kDynInertia) return launch_mode<NJ, kDynInertia>(mdh, allrev, grid, s, dp, links, q, qd, tq, out, lds, sig);
-    if (mode == kDynCoriolis) return launch_mode<NJ, kDynCoriolis>(mdh, allrev, grid, s, dp, links, q, qd, tq, out, lds, sig);
-    return launch_mode<NJ, kDynAccel>(mdh, allrev, grid, s, dp, links, q, qd, tq, out, lds, sig);
+    if (mode == kDynInertia) return launch_mode<NJ, kDynInertia>(d, mdh, allrev, grid, s, dp, links, q, qd, tq, out, lds, sig);
+    if (mode == kDynCoriolis) return launch_mode<NJ, kDynCoriolis>(d, mdh, allrev, grid, s, dp, links, q, qd, tq, out, lds, sig);
+    return launch_mode<NJ, kDynAccel>(d, mdh, allrev, grid, s, dp, links, q, qd, tq, out, lds, sig);
 }
 
 int launch_dyn(const Dyn *d, const DevLink *links, int mode, const double *q, const double *qd, const double *tq,
@@ -205,29 +218,31 @@ int launch_dyn(const Dyn *d, const DevLink *links, int mode, const double *q, co
     size_t lds = 0;
     const RneSig sig = (rne_sig_enabled() && allrev) ? rne_signature(d->links.data(), d->n) : 0;
     switch (d->n) {
-    case 1: e = launch_nj<1>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
-    case 2: e = launch_nj<2>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
-    case 3: e = launch_nj<3>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
-    case 4: e = launch_nj<4>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
-    case 5: e = launch_nj<5>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
-    case 6: e = launch_nj<6>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds, sig); break;
-    case 7: e = launch_nj<7>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds, sig); break;
-    case 8: e = launch_nj<8>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
-    case 9: e = launch_nj<9>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;   // 9, 10: one wave per SIMD
-    case 10: e = launch_nj<10>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    case 1: e = launch_nj<1>(d, mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds, sig); break;
+    case 2: e = launch_nj<2>(d, mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds, sig); break;
+    case 3: e = launch_nj<3>(d, mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds, sig); break;
+    case 4: e = launch_nj<4>(d, mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds, sig); break;
+    case 5: e = launch_nj<5>(d, mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds, sig); break;
+    case 6: e = launch_nj<6>(d, mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds, sig); break;
+    case 7: e = launch_nj<7>(d, mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds, sig); break;
+    case 8: e = launch_nj<8>(d, mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds, sig); break;
+    case 9: e = launch_nj<9>(d, mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;   // 9, 10: one wave per SIMD
+    case 10: e = launch_nj<10>(d, mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
     // 11..16: the per-link state of the recursion no longer fits the register file (scratch) and the (n,n) tile of a wave
     // takes most of a CU's LDS -- one wave per CU; served, not fast
-    case 11: e = launch_nj<11>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
-    case 12: e = launch_nj<12>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
-    case 13: e = launch_nj<13>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
-    case 14: e = launch_nj<14>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
-    case 15: e = launch_nj<15>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
-    default: e = launch_nj<16>(mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    case 11: e = launch_nj<11>(d, mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    case 12: e = launch_nj<12>(d, mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    case 13: e = launch_nj<13>(d, mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    case 14: e = launch_nj<14>(d, mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    case 15: e = launch_nj<15>(d, mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
+    default: e = launch_nj<16>(d, mode, mdh, allrev, grid, s, dp, links, q, qd, tq, out, &lds); break;
     }
     if (lds > 160 * 1024) { set_error("inertia/coriolis/accel: the chain needs more LDS than a CU has"); return RTBHIP_ELIMIT; }
     note_launch((int)grid.x, kDW, (int)lds);
     if (e != hipSuccess) return hip_fail(e, "k_dyn launch");
     return RTBHIP_OK;
 }
+
+#endif  // RTB_HOST_SIDE
 
 }  // namespace rtbhip

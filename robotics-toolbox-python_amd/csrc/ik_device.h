@@ -690,6 +690,21 @@ RTB_HD void ik_emit(const IkLane<NJ> &st, QA qa, const PD &p, QL qlim, int64_t t
 #define RTB_IK_RING 64
 #endif
 constexpr int kIkRing = RTB_IK_RING;        // outstanding (unaccounted) searches per slot (a power of two)
+// A/B knobs of the three-waves-per-SIMD study (profiles/r06_ik_three_waves.txt; scripts/build_ik_variant.sh): twelve waves on a CU leave each
+// 13 653 B of LDS -- RTB_IK_REC8 packs a search record into 8 bits (iterations <= 62: the launcher refuses a larger ilimit in such a build),
+// RTB_IK_QROWS_EXACT sizes the q rows to the kernel's joint count instead of its class (7 rows for the Panda, not 8); with a ring of 32
+// that is 13 624 B for a 7-joint arm.  The product keeps 16-bit records, a ring of 64, 8 rows: 20 280 B, eight waves.
+#ifndef RTB_IK_REC8
+#define RTB_IK_REC8 0
+#endif
+#ifndef RTB_IK_QROWS_EXACT
+#define RTB_IK_QROWS_EXACT 0
+#endif
+#if RTB_IK_REC8
+typedef uint8_t IkRec;
+#else
+typedef uint16_t IkRec;
+#endif
 template <int QR>
 struct alignas(16) IkWaveSharedT {
     uint32_t vix[64];                       // work-item index = output row (the target itself without a work list; < 2^32)
@@ -702,11 +717,11 @@ struct alignas(16) IkWaveSharedT {
     int16_t res[64];                        // 0 unresolved, 1 won (winner = b), 2 failed
     uint8_t list[64];                       // scratch: compacted slot list
     uint8_t chunk[64];                      // flat schedule: chunk index of the slot's item (0 otherwise)
-    uint16_t rec[64][kIkRing];              // per outstanding search: 1 finished | 2 ok | iterations << 2
+    IkRec rec[64][kIkRing];                 // per outstanding search: 1 finished | 2 ok | iterations << 2
     double Td[12][64];                      // per SLOT: the target pose (read by every lane working on the slot)
     double q[QR][64];                       // per LANE: the joint vector of that search
 };
-template <int NJ> using IkWaveSharedFor = IkWaveSharedT<(NJ <= kRegMaxJoints ? kRegMaxJoints : kIkMaxJoints)>;
+template <int NJ> using IkWaveSharedFor = IkWaveSharedT<(RTB_IK_QROWS_EXACT ? NJ : (NJ <= kRegMaxJoints ? kRegMaxJoints : kIkMaxJoints))>;
 static_assert(sizeof(IkWaveSharedT<kRegMaxJoints>) * 8 <= 160 * 1024, "8 IK waves per CU must fit the LDS");
 
 // A work item: searches s0 .. s1 (inclusive, in the flavour's own numbering) of target `tgt`.  Without a work list item v is
@@ -717,7 +732,7 @@ struct IkWork { int32_t tgt; int16_t s0, s1; };
 RTB_HD unsigned long long ik_pack(IkWork w) { return (unsigned long long)(uint32_t)w.tgt | ((unsigned long long)(uint16_t)w.s0 << 32) | ((unsigned long long)(uint16_t)w.s1 << 48); }
 RTB_HD IkWork ik_unpack(unsigned long long x) { IkWork w; w.tgt = (int32_t)(uint32_t)x; w.s0 = (int16_t)(x >> 32); w.s1 = (int16_t)(x >> 48); return w; }
 constexpr int kIkMaxSlimit = 32000;
-constexpr int kIkMaxIlimit = 16000;         // (ilimit + 1) << 2 must fit the 16-bit record
+constexpr int kIkMaxIlimit = RTB_IK_REC8 ? 62 : 16000;         // (ilimit + 1) << 2 must fit the record
 
 template <class SH>
 struct IkLdsQT {   // accessor of one lane's q column in the wave's LDS
@@ -761,7 +776,7 @@ RTB_HD void ik_report(IkLane<NJ> &st, SH &sh, double *__restrict__ residual, con
     if (st.status != kIkRun || !st.fin) return;
     ik_settle<NJ>(st, p, qlim, qa);
     const int s_last = sh.slast[st.slot];
-    sh.rec[st.slot][st.s & (kIkRing - 1)] = (uint16_t)(1 | (st.ok ? 2 : 0) | (st.iter << 2));
+    sh.rec[st.slot][st.s & (kIkRing - 1)] = (IkRec)(1 | (st.ok ? 2 : 0) | (st.iter << 2));
     if (st.ok) ik_lds_min(&sh.best[st.slot], st.s);
     if (st.s == s_last) residual[sh.vix[st.slot]] = st.E;     // the failure output's E; a success found later overwrites it
     st.status = st.ok ? kIkParkedOk : (st.s == s_last ? kIkParkedLast : kIkIdle);
@@ -811,9 +826,9 @@ RTB_HD void ik_finalize(IkLane<NJ> &st, SH &sh, int lane, const PD &p, QL qlim, 
 
 // a slot's ring of search records back to "nothing finished": 16-byte stores (the row is 2 * kIkRing bytes, 16-byte aligned inside the wave's
 // LDS block) instead of kIkRing 2-byte ones -- the loop runs for the whole wave whenever one lane starts a work item
-RTB_HD void ik_clear_ring(uint16_t (&row)[kIkRing])
+RTB_HD void ik_clear_ring(IkRec (&row)[kIkRing])
 {
-    static_assert((kIkRing * sizeof(uint16_t)) % 16 == 0, "ring row must be a whole number of 16-byte pieces");
+    static_assert((kIkRing * sizeof(IkRec)) % 16 == 0, "ring row must be a whole number of 16-byte pieces");
     __builtin_memset(__builtin_assume_aligned(&row[0], 16), 0, sizeof(row));
 }
 

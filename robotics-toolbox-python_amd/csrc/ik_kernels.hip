@@ -11,10 +11,12 @@
 // with 97 % of the lane-iterations idle.  This is compute/latency-bound work (~1.5 kflop of dependent
 // fp64 per iteration, 204 B of I/O per target): MFMA does not apply (7x7 normal equations per lane).
 #include "ik_device.h"
+#if RTB_HOST_SIDE
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#endif
 
 namespace rtbhip {
 
@@ -509,6 +511,7 @@ __global__ __launch_bounds__(256) void k_ik_merge_flat(int64_t N, int n, int chu
     if (t < N) ik_merge_flat(n, chunks, N, t, vq, vok, vit, vse, vE, q_out, success, iters, searches, residual);
 }
 
+#if RTB_HOST_SIDE      // the launchers (the kernels above are also what jit.cpp hands to hipRTC, one instantiation at a time)
 namespace {
 int g_ik_flat = 1;        // flat schedule (ik_device.h): 0 never, 1 automatic (the batch is resident at once), 2 always (tests)
 int g_ik_flat_l0 = 0;     // searches in a target's first chunk: 0 = automatic -- 8 while the batch is at most 1.5 items per lane of the grid, else 4 ...
@@ -593,8 +596,29 @@ void ik_restart_host(const Chain *c, uint64_t seed, int64_t target, int draw, do
     }
 }
 
+// Signatures with an instantiation built into the library (kIkSig*); every other plain chain of up to 8 joints gets its own at run time (jit.cpp).
+static bool ik_sig_builtin(int n, SegSig sig) { return (n == 7 && (sig == kIkSigPandaETS || sig == kIkSigPandaURDF)) || (n == 6 && sig == kIkSigUR); }
+static std::string ik_jit_expr(int n, bool flat, SegSig sig)
+{
+    return "rtbhip::k_ik<" + std::to_string(n) + ", 0, " + std::to_string((flat ? kIkAuxFlat : 0) | kIkAuxUnitW | kIkAuxPlain) + ", " + jit_hex(sig) + ">";
+}
+static bool chain_is_plain(const Chain *c)       // every joint revolute, none flipped: the straight-line walk (and with it a signature) applies
+{
+    for (int j = 0; j < c->n; ++j) if (jm_prismatic(c->jmeta[j]) || jm_flip(c->jmeta[j])) return false;
+    return c->n >= 1;
+}
+std::vector<std::string> ik_jit_names(const Chain *c)
+{
+    std::vector<std::string> out;
+    const SegSig sig = chain_signature(c->jmeta.data(), c->n);
+    if (!sig || c->n > kRegMaxJoints || !chain_is_plain(c) || ik_sig_builtin(c->n, sig)) return out;
+    out.push_back(ik_jit_expr(c->n, true, sig));
+    out.push_back(ik_jit_expr(c->n, false, sig));
+    return out;
+}
+
 template <int NJ>
-static void launch_nj(dim3 grid, hipStream_t s, const IkDev &p, const DevChain &dc, const double *qlim, const double *Tep,
+static void launch_nj(const Chain *c, dim3 grid, hipStream_t s, const IkDev &p, const DevChain &dc, const double *qlim, const double *Tep,
                       const double *q0, unsigned long long *ctr, double *q_out, int32_t *success, int32_t *iters,
                       int32_t *searches, double *residual, const IkWork *work, const unsigned *count, const IkShareCtl &share, SegSig chain_sig)
 {
@@ -626,6 +650,14 @@ static void launch_nj(dim3 grid, hipStream_t s, const IkDev &p, const DevChain &
                     RTB_IK_SIG_LAUNCH(kIkSigUR)
                 }
 #undef RTB_IK_SIG_LAUNCH
+                // any other robot: its own instantiation of the same kernel, compiled at run time; the general walk below serves until it is there
+                if (g_ik_sig && chain_sig && !ik_sig_builtin(NJ, chain_sig) && jit_enabled()) {
+                    if (hipFunction_t f = c->jit.get("ik_kernels.hip", flat ? 1 : 0, [&] { return ik_jit_expr(NJ, flat, chain_sig); })) {
+                        void *args[] = {(void *)&p, (void *)&dc, &qlim, &Tep, &q0, &ctr, &q_out, &success, &iters, &searches, &residual, &work, &count, (void *)&share};
+                        (void)jit_launch(f, grid, dim3(kWave), 0, s, args);
+                        return;
+                    }
+                }
                 if (flat) hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxFlat | kIkAuxUnitW | kIkAuxPlain>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share);
                 else hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxUnitW | kIkAuxPlain>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share);
                 return;
@@ -735,22 +767,22 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
         }
         dim3 grid((unsigned)g);
         switch (n) {
-        case 1: launch_nj<1>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
-        case 2: launch_nj<2>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
-        case 3: launch_nj<3>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
-        case 4: launch_nj<4>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
-        case 5: launch_nj<5>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
-        case 6: launch_nj<6>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
-        case 7: launch_nj<7>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
-        case 8: launch_nj<8>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
-        case 9: launch_nj<9>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
-        case 10: launch_nj<10>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
-        case 11: launch_nj<11>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
-        case 12: launch_nj<12>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
-        case 13: launch_nj<13>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
-        case 14: launch_nj<14>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
-        case 15: launch_nj<15>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
-        default: launch_nj<16>(grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 1: launch_nj<1>(c, grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 2: launch_nj<2>(c, grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 3: launch_nj<3>(c, grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 4: launch_nj<4>(c, grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 5: launch_nj<5>(c, grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 6: launch_nj<6>(c, grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 7: launch_nj<7>(c, grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 8: launch_nj<8>(c, grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 9: launch_nj<9>(c, grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 10: launch_nj<10>(c, grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 11: launch_nj<11>(c, grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 12: launch_nj<12>(c, grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 13: launch_nj<13>(c, grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 14: launch_nj<14>(c, grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        case 15: launch_nj<15>(c, grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
+        default: launch_nj<16>(c, grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
         }
         note_launch((int)grid.x, kWave, 0);
         hipError_t e = hipGetLastError();
@@ -933,5 +965,7 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
         if (ptr) (void)hipFreeAsync(ptr, s);
     return rc;
 }
+
+#endif  // RTB_HOST_SIDE
 
 }  // namespace rtbhip

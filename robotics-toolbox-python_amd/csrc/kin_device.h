@@ -16,10 +16,13 @@
 // lane, on the CPU build box (which has no GPU).  The product never takes that path.
 #pragma once
 #include "rtbhip_internal.h"
+#ifndef __HIPCC_RTC__
 #include <cmath>
+#endif
 
 #define RTB_HD __host__ __device__ __forceinline__
 #include "trig.h"
+#include "exactform.h"
 
 namespace rtbhip {
 
@@ -78,19 +81,29 @@ RTB_HD void pose_t3(Pose &P, double x, double y, double z)
     P.ty += x * P.r10 + y * P.r11 + z * P.r12;
     P.tz += x * P.r20 + y * P.r21 + z * P.r22;
 }
+// one row (x, y, z) of a pose times the constant rotation c (row-major, class CLS):  out_k = y c[3+k] + x c[k] + z c[6+k]  in that fixed order
+template <int CLS, class F>
+RTB_HD void row_times_const(double &x, double &y, double &z, F c)
+{
+    const double a = x, b = y, e = z;
+    x = dotk<seg_kind(CLS, 3), seg_kind(CLS, 0), seg_kind(CLS, 6)>(c(3), b, c(0), a, c(6), e);
+    y = dotk<seg_kind(CLS, 4), seg_kind(CLS, 1), seg_kind(CLS, 7)>(c(4), b, c(1), a, c(7), e);
+    z = dotk<seg_kind(CLS, 5), seg_kind(CLS, 2), seg_kind(CLS, 8)>(c(5), b, c(2), a, c(8), e);
+}
+template <int CLS, class F>
+RTB_HD void pose_rot_const(Pose &P, F c)      // P.R <- P.R * c
+{
+    row_times_const<CLS>(P.r00, P.r01, P.r02, c);
+    row_times_const<CLS>(P.r10, P.r11, P.r12, c);
+    row_times_const<CLS>(P.r20, P.r21, P.r22, c);
+}
 // P <- P * A for a general constant affine a = {R row-major (9), t (3)}
 template <bool T3FMA = false, class F>
 RTB_HD void pose_mul_general(Pose &P, F a)
 {
     if (T3FMA) pose_t3_fma(P, a(9), a(10), a(11));
     else pose_t3(P, a(9), a(10), a(11));
-    double x, y, z;
-    x = P.r00; y = P.r01; z = P.r02;
-    P.r00 = x * a(0) + y * a(3) + z * a(6); P.r01 = x * a(1) + y * a(4) + z * a(7); P.r02 = x * a(2) + y * a(5) + z * a(8);
-    x = P.r10; y = P.r11; z = P.r12;
-    P.r10 = x * a(0) + y * a(3) + z * a(6); P.r11 = x * a(1) + y * a(4) + z * a(7); P.r12 = x * a(2) + y * a(5) + z * a(8);
-    x = P.r20; y = P.r21; z = P.r22;
-    P.r20 = x * a(0) + y * a(3) + z * a(6); P.r21 = x * a(1) + y * a(4) + z * a(7); P.r22 = x * a(2) + y * a(5) + z * a(8);
+    pose_rot_const<kSegGeneral>(P, a);      // every entry as fma(z, a(6+k), fma(x, a(k), round(y a(3+k)))): the form the structured products are instances of
 }
 // P <- A * P  (used once per configuration for the base transform)
 RTB_HD void pose_premul(Pose &P, const double *a /* row-major 3x4 */)
@@ -119,43 +132,14 @@ RTB_HD void pose_mul_seg(Pose &P, const CV &cv, int j)
 }
 // ---------------------------------------------------------------- P <- P * C_j by the segment's STRUCTURE CLASS
 // (rtbhip_internal.h: kSeg*; decided on the host from the EXACT zeros and ones of the folded constant -- cos(pi/2) = 6.1e-17 stays what it is).
-// Every form below is written operation for operation as what the GENERAL product (pose_mul_general with the fused translation chains)
-// computes once its products with exact zeros are dropped and its products with exact +-1 are taken as the operand itself: the compiler
-// contracts  x a0 + y a3 + z a6  to  fma(z, a6, fma(x, a0, y a3))  -- y a3 is rounded on its own -- so for finite poses the structured product
-// returns THE SAME BITS as the general one (tests/test_segment_classes.py on the host replay; on the device: the IK outputs of the
-// specialised and the general kernel, profiles/r05_ik_*).  Costs (general: 27 + 9):
+// Every structured product is pose_rot_const<CLS> -- the general product's fixed operation sequence with the exact-form rewrites of dotk applied
+// entry by entry from the class's kind table -- so it returns the general product's bits by construction (tests/test_segment_classes.py replays all
+// 13 classes on the host; on the device: the IK outputs of signature, run-time-compiled and general kernels).  Costs (general: 27 + 9):
 //   translation   P.t += R C.t: one fused column per NON-ZERO component, in the order of pose_t3_fma                     3 each
 //   identity      nothing                                                                                                 0
 //   Rx / Ry / Rz  rotation about one axis, the two other columns mix                                                      12
-//   ..P / ..N     the quarter turns (off-diagonal +-1; the diagonal keeps its cos(pi/2))                                  9
+//   ..P / ..N     the quarter turns (off-diagonal +-1; the diagonal keeps its cos(pi/2))                                  9 (3 mul, 3 add, 3 fma)
 //   permA / permB the cyclic column permutations of the axis conjugation: register moves                                 0
-RTB_HD double mul_then_add(double x, double y, double z)      // round(x y) + z: two roundings, never contracted into one
-{
-#pragma clang fp contract(off)
-    const double t = x * y;
-    return t + z;
-}
-// The forms are PLAIN expressions whose operand order makes the compiler's contraction land where the general product's lands (an a*b + c*d is
-// fused as fma(a, b, round(c d)): the first product takes the fused slot); on a host without fused instructions both sides round every
-// product -- equal there too.  Where the general product leaves TWO roundings (a product with +-1 feeding an addition) mul_then_add keeps them.
-// rotation about x or y:  general  u' = fma(v, c, round(u a)),  v' = fma(v, d, round(u b));   SUB 1: (b, c) = (-1, +1);  SUB 2: (b, c) = (+1, -1)
-template <int SUB>
-RTB_HD void pose_mix_xy(double &u, double &v, double a, double b, double c, double d)
-{
-    const double x = u, y = v;
-    if (SUB == 0) { u = y * c + x * a; v = y * d + x * b; }
-    else if (SUB == 1) { u = mul_then_add(x, a, y); v = y * d - x; }
-    else { u = mul_then_add(x, a, -y); v = y * d + x; }
-}
-// rotation about z (columns 0 and 1):  general  u' = fma(u, a, round(v c)),  v' = fma(u, b, round(v d))
-template <int SUB>
-RTB_HD void pose_mix_z(double &u, double &v, double a, double b, double c, double d)
-{
-    const double x = u, y = v;
-    if (SUB == 0) { u = x * a + y * c; v = x * b + y * d; }
-    else if (SUB == 1) { u = x * a + y; v = mul_then_add(y, d, -x); }
-    else { u = x * a - y; v = mul_then_add(y, d, x); }
-}
 template <int TM, class CV>
 RTB_HD void pose_seg_translate(Pose &P, const CV &cv, int j)
 {
@@ -166,30 +150,7 @@ RTB_HD void pose_seg_translate(Pose &P, const CV &cv, int j)
 template <int CLS, class CV>
 RTB_HD void pose_seg_rotate(Pose &P, const CV &cv, int j)
 {
-    const auto &r = cv.seg[j].r;
-    if (CLS == kSegRxP || CLS == kSegRxN || CLS == kSegRx) {         // columns (1, 2): a = r[4], b = r[5], c = r[7], d = r[8]
-        constexpr int S = CLS == kSegRxP ? 1 : CLS == kSegRxN ? 2 : 0;
-        const double a = r[4], b = S ? 0.0 : r[5], c = S ? 0.0 : r[7], d = r[8];
-        pose_mix_xy<S>(P.r01, P.r02, a, b, c, d); pose_mix_xy<S>(P.r11, P.r12, a, b, c, d); pose_mix_xy<S>(P.r21, P.r22, a, b, c, d);
-    } else if (CLS == kSegRyP || CLS == kSegRyN || CLS == kSegRy) {  // columns (0, 2): a = r[0], b = r[2], c = r[6], d = r[8]
-        constexpr int S = CLS == kSegRyP ? 1 : CLS == kSegRyN ? 2 : 0;
-        const double a = r[0], b = S ? 0.0 : r[2], c = S ? 0.0 : r[6], d = r[8];
-        pose_mix_xy<S>(P.r00, P.r02, a, b, c, d); pose_mix_xy<S>(P.r10, P.r12, a, b, c, d); pose_mix_xy<S>(P.r20, P.r22, a, b, c, d);
-    } else if (CLS == kSegRzP || CLS == kSegRzN || CLS == kSegRz) {  // columns (0, 1): a = r[0], b = r[1], c = r[3], d = r[4]
-        constexpr int S = CLS == kSegRzP ? 1 : CLS == kSegRzN ? 2 : 0;
-        const double a = r[0], b = S ? 0.0 : r[1], c = S ? 0.0 : r[3], d = r[4];
-        pose_mix_z<S>(P.r00, P.r01, a, b, c, d); pose_mix_z<S>(P.r10, P.r11, a, b, c, d); pose_mix_z<S>(P.r20, P.r21, a, b, c, d);
-    } else if (CLS == kSegPermA) {                                    // new columns = old (1, 2, 0)
-        double x;
-        x = P.r00; P.r00 = P.r01; P.r01 = P.r02; P.r02 = x;
-        x = P.r10; P.r10 = P.r11; P.r11 = P.r12; P.r12 = x;
-        x = P.r20; P.r20 = P.r21; P.r21 = P.r22; P.r22 = x;
-    } else if (CLS == kSegPermB) {                                    // new columns = old (2, 0, 1)
-        double x;
-        x = P.r02; P.r02 = P.r01; P.r01 = P.r00; P.r00 = x;
-        x = P.r12; P.r12 = P.r11; P.r11 = P.r10; P.r10 = x;
-        x = P.r22; P.r22 = P.r21; P.r21 = P.r20; P.r20 = x;
-    }
+    pose_rot_const<CLS>(P, [&](int k) { return cv.seg[j].r[k]; });      // entries whose kind is not kAny are never read
 }
 // compile-time class and translation mask: straight-line code (k_ik's instantiations for known robots: ik_kernels.hip, kIkSig*)
 template <int CLS, int TM, class CV>

@@ -11,8 +11,11 @@
 // scratch); NJ == 0 selects the run-time-n fallback, which the compiler places in private memory.
 #pragma once
 #include "rtbhip_internal.h"
+#ifndef __HIPCC_RTC__
 #include <cmath>
+#endif
 #include "trig.h"
+#include "exactform.h"
 
 #ifndef RTB_HD
 #define RTB_HD __host__ __device__ __forceinline__
@@ -35,55 +38,45 @@ RTB_HD double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 // exactly: the x rotation is the identity), 2 / 3 sa = +1 / -1 exactly (alpha = +-pi/2; ca keeps its libm value, 6.1e-17).  The class forms are
 // the general ones with the products by an exact 0 dropped and the products by an exact +-1 taken as the operand.
 struct Rot { double s, c, sa, ca; int acls; };
-// rotation about x by alpha of the pair (y, z):  fwd (ca y - sa z, sa y + ca z);  inv (ca y + sa z, ca z - sa y)
-RTB_HD void alpha_fwd(const Rot &r, double y, double z, double &oy, double &oz)
+// The x rotation by alpha acts on a pair (y, z):  fwd (ca y - sa z, sa y + ca z);  inv (ca y + sa z, ca z - sa y).  ONE form for every class of
+// alpha: each output is dotk_rt (exactform.h) -- fma(ca, ., round(sa .)) with sin / cos alpha's exact 0 / +-1 rewritten away -- so a kernel
+// instantiated for a table's alpha classes returns the general kernel's bits by construction.  (acls is a constant of the unrolled link step.)
+RTB_HD int rot_ksa(int acls) { return acls == 1 ? kC0 : (acls == 2 ? kCP : (acls == 3 ? kCN : kCA)); }
+RTB_HD int rot_kca(int acls) { return acls == 1 ? kCP : kCA; }
+RTB_HD double alpha_mix(const Rot &r, double with_sa, double with_ca)      // sa * with_sa + ca * with_ca
 {
-    if (r.acls == 1) { oy = y; oz = z; }
-    else if (r.acls == 2) { oy = __builtin_fma(r.ca, y, -z); oz = __builtin_fma(r.ca, z, y); }
-    else if (r.acls == 3) { oy = __builtin_fma(r.ca, y, z); oz = __builtin_fma(r.ca, z, -y); }
-    else { oy = r.ca * y - r.sa * z; oz = r.sa * y + r.ca * z; }
+    return dotk_rt(rot_ksa(r.acls), rot_kca(r.acls), kC0, r.sa, with_sa, r.ca, with_ca, 0.0, 0.0);
 }
-RTB_HD void alpha_inv(const Rot &r, double y, double z, double &oy, double &oz)
+RTB_HD void alpha_fwd(const Rot &r, double y, double z, double &oy, double &oz) { oy = alpha_mix(r, -z, y); oz = alpha_mix(r, y, z); }
+RTB_HD void alpha_inv(const Rot &r, double y, double z, double &oy, double &oz) { oy = alpha_mix(r, z, y); oz = alpha_mix(r, -y, z); }
+// the z rotation by theta (per lane) on a pair (x, y):  fwd (c x - s y, s x + c y);  inv (c x + s y, c y - s x) -- explicit operations, no contraction
+RTB_HD void theta_fwd(const Rot &r, double x, double y, double &ox, double &oy)
 {
-    if (r.acls == 1) { oy = y; oz = z; }
-    else if (r.acls == 2) { oy = __builtin_fma(r.ca, y, z); oz = __builtin_fma(r.ca, z, -y); }
-    else if (r.acls == 3) { oy = __builtin_fma(r.ca, y, -z); oz = __builtin_fma(r.ca, z, y); }
-    else { oy = r.ca * y + r.sa * z; oz = r.ca * z - r.sa * y; }
+#pragma clang fp contract(off)
+    ox = __builtin_fma(r.c, x, -(r.s * y)); oy = __builtin_fma(r.s, x, r.c * y);
+}
+RTB_HD void theta_inv(const Rot &r, double x, double y, double &ox, double &oy)
+{
+#pragma clang fp contract(off)
+    ox = __builtin_fma(r.c, x, r.s * y); oy = __builtin_fma(r.c, y, -(r.s * x));
 }
 template <bool MDH>
-RTB_HD V3 rot_fwd(const Rot &r, V3 v)   // R v
+RTB_HD V3 rot_fwd(const Rot &r, V3 v)   // R v:  standard DH  Rz(theta) Rx(alpha) v;  modified DH  Rx(alpha) Rz(theta) v
 {
-    if (r.acls != 0) {
-        double oy, oz;
-        if (!MDH) { alpha_fwd(r, v.y, v.z, oy, oz); return v3(r.c * v.x - r.s * oy, r.s * v.x + r.c * oy, oz); }
-        const double ux = r.c * v.x - r.s * v.y, uy = r.s * v.x + r.c * v.y;
-        alpha_fwd(r, uy, v.z, oy, oz);
-        return v3(ux, oy, oz);
-    }
-    if (!MDH) {
-        const double uy = r.ca * v.y - r.sa * v.z, uz = r.sa * v.y + r.ca * v.z;
-        return v3(r.c * v.x - r.s * uy, r.s * v.x + r.c * uy, uz);
-    } else {
-        const double ux = r.c * v.x - r.s * v.y, uy = r.s * v.x + r.c * v.y;
-        return v3(ux, r.ca * uy - r.sa * v.z, r.sa * uy + r.ca * v.z);
-    }
+    double a, b, oy, oz;
+    if (!MDH) { alpha_fwd(r, v.y, v.z, oy, oz); theta_fwd(r, v.x, oy, a, b); return v3(a, b, oz); }
+    theta_fwd(r, v.x, v.y, a, b);
+    alpha_fwd(r, b, v.z, oy, oz);
+    return v3(a, oy, oz);
 }
 template <bool MDH>
 RTB_HD V3 rot_inv(const Rot &r, V3 v)   // R^T v
 {
-    if (r.acls != 0) {
-        double oy, oz;
-        if (!MDH) { const double ux = r.c * v.x + r.s * v.y, uy = r.c * v.y - r.s * v.x; alpha_inv(r, uy, v.z, oy, oz); return v3(ux, oy, oz); }
-        alpha_inv(r, v.y, v.z, oy, oz);
-        return v3(r.c * v.x + r.s * oy, r.c * oy - r.s * v.x, oz);
-    }
-    if (!MDH) {
-        const double ux = r.c * v.x + r.s * v.y, uy = r.c * v.y - r.s * v.x;
-        return v3(ux, r.ca * uy + r.sa * v.z, r.ca * v.z - r.sa * uy);
-    } else {
-        const double uy = r.ca * v.y + r.sa * v.z, uz = r.ca * v.z - r.sa * v.y;
-        return v3(r.c * v.x + r.s * uy, r.c * uy - r.s * v.x, uz);
-    }
+    double a, b, oy, oz;
+    if (!MDH) { theta_inv(r, v.x, v.y, a, b); alpha_inv(r, b, v.z, oy, oz); return v3(a, oy, oz); }
+    alpha_inv(r, v.y, v.z, oy, oz);
+    theta_inv(r, v.x, oy, a, b);
+    return v3(a, b, oz);
 }
 template <bool MDH, class LinkT>
 RTB_HD V3 link_offset(const LinkT &l, double d)   // p* (frne.c:337,347)
@@ -258,49 +251,31 @@ RTB_HD V3 offset_accel(int pm, V3 w, V3 wd, V3 ps, V3 acc)
     return cross_add_bm(pm, wd, ps, cross_add_bm(cm, w, c, acc));
 }
 
+// acc + R^T v and acc + R v as chains of fused multiply-adds seeded with acc; alpha's part through kacc (exactform.h): the class forms are the
+// general chain with  fma(0, x, a) -> a  and  fma(+-1, x, a) -> a +- x  -- the same bits by construction
 template <bool MDH>
 RTB_HD V3 rot_inv_add(const Rot &r, V3 v, V3 acc)   // acc + R^T v
 {
-    if (r.acls != 0) {          // (alpha classes: Rot)
-        if (!MDH) {
-            const double uy = fmad(r.c, v.y, -(r.s * v.x)), x = fmad(r.c, v.x, fmad(r.s, v.y, acc.x));
-            if (r.acls == 1) return v3(x, acc.y + uy, acc.z + v.z);
-            if (r.acls == 2) return v3(x, fmad(r.ca, uy, acc.y + v.z), fmad(r.ca, v.z, acc.z - uy));
-            return v3(x, fmad(r.ca, uy, acc.y - v.z), fmad(r.ca, v.z, acc.z + uy));
-        }
-        const double uy = r.acls == 1 ? v.y : (r.acls == 2 ? fmad(r.ca, v.y, v.z) : fmad(r.ca, v.y, -v.z));
-        const double z = r.acls == 1 ? acc.z + v.z : (r.acls == 2 ? fmad(r.ca, v.z, acc.z - v.y) : fmad(r.ca, v.z, acc.z + v.y));
-        return v3(fmad(r.c, v.x, fmad(r.s, uy, acc.x)), fmad(r.c, uy, fmad(-r.s, v.x, acc.y)), z);
-    }
+#pragma clang fp contract(off)
+    const int ks = rot_ksa(r.acls), kc = rot_kca(r.acls);
     if (!MDH) {
         const double uy = fmad(r.c, v.y, -(r.s * v.x));
-        return v3(fmad(r.c, v.x, fmad(r.s, v.y, acc.x)), fmad(r.ca, uy, fmad(r.sa, v.z, acc.y)), fmad(r.ca, v.z, fmad(-r.sa, uy, acc.z)));
-    } else {
-        const double uy = fmad(r.ca, v.y, r.sa * v.z);
-        return v3(fmad(r.c, v.x, fmad(r.s, uy, acc.x)), fmad(r.c, uy, fmad(-r.s, v.x, acc.y)), fmad(r.ca, v.z, fmad(-r.sa, v.y, acc.z)));
+        return v3(fmad(r.c, v.x, fmad(r.s, v.y, acc.x)), kacc(kc, r.ca, uy, kacc(ks, r.sa, v.z, acc.y)), kacc(kc, r.ca, v.z, kacc(ks, r.sa, -uy, acc.z)));
     }
+    const double uy = alpha_mix(r, v.z, v.y);
+    return v3(fmad(r.c, v.x, fmad(r.s, uy, acc.x)), fmad(r.c, uy, fmad(-r.s, v.x, acc.y)), kacc(kc, r.ca, v.z, kacc(ks, r.sa, -v.y, acc.z)));
 }
 template <bool MDH>
 RTB_HD V3 rot_fwd_add(const Rot &r, V3 v, V3 acc)   // acc + R v
 {
-    if (r.acls != 0) {
-        if (!MDH) {
-            const double uy = r.acls == 1 ? v.y : (r.acls == 2 ? fmad(r.ca, v.y, -v.z) : fmad(r.ca, v.y, v.z));
-            const double z = r.acls == 1 ? acc.z + v.z : (r.acls == 2 ? fmad(r.ca, v.z, acc.z + v.y) : fmad(r.ca, v.z, acc.z - v.y));
-            return v3(fmad(r.c, v.x, fmad(-r.s, uy, acc.x)), fmad(r.s, v.x, fmad(r.c, uy, acc.y)), z);
-        }
-        const double uy = fmad(r.s, v.x, r.c * v.y), x = fmad(r.c, v.x, fmad(-r.s, v.y, acc.x));
-        if (r.acls == 1) return v3(x, acc.y + uy, acc.z + v.z);
-        if (r.acls == 2) return v3(x, fmad(r.ca, uy, acc.y - v.z), fmad(r.ca, v.z, acc.z + uy));
-        return v3(x, fmad(r.ca, uy, acc.y + v.z), fmad(r.ca, v.z, acc.z - uy));
-    }
+#pragma clang fp contract(off)
+    const int ks = rot_ksa(r.acls), kc = rot_kca(r.acls);
     if (!MDH) {
-        const double uy = fmad(r.ca, v.y, -(r.sa * v.z));
-        return v3(fmad(r.c, v.x, fmad(-r.s, uy, acc.x)), fmad(r.s, v.x, fmad(r.c, uy, acc.y)), fmad(r.sa, v.y, fmad(r.ca, v.z, acc.z)));
-    } else {
-        const double uy = fmad(r.s, v.x, r.c * v.y);
-        return v3(fmad(r.c, v.x, fmad(-r.s, v.y, acc.x)), fmad(r.ca, uy, fmad(-r.sa, v.z, acc.y)), fmad(r.sa, uy, fmad(r.ca, v.z, acc.z)));
+        const double uy = alpha_mix(r, -v.z, v.y);
+        return v3(fmad(r.c, v.x, fmad(-r.s, uy, acc.x)), fmad(r.s, v.x, fmad(r.c, uy, acc.y)), kacc(ks, r.sa, v.y, kacc(kc, r.ca, v.z, acc.z)));
     }
+    const double uy = fmad(r.s, v.x, r.c * v.y);
+    return v3(fmad(r.c, v.x, fmad(-r.s, v.y, acc.x)), kacc(kc, r.ca, uy, kacc(ks, r.sa, -v.z, acc.y)), kacc(ks, r.sa, uy, kacc(kc, r.ca, v.z, acc.z)));
 }
 
 // Everything one forward step reads from the link table and from the q / qd / qdd tile, fetched as ONE batch.

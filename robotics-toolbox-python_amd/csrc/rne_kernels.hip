@@ -228,6 +228,7 @@ __global__ __launch_bounds__(kW) void k_rne_rt(RneParams rp, const DevLink *link
     }
 }
 
+#if RTB_HOST_SIDE      // the launchers (the kernels above are also what jit.cpp hands to hipRTC, one instantiation at a time)
 namespace { int g_rne_tiles_per_wave = 1; int g_rne_persist = 0; int g_rne_wpb = 1; int g_rne_sig = 1; }
 int rne_sig_enabled() { return g_rne_sig; }
 void rne_tune(const char *key, int value)
@@ -247,8 +248,28 @@ static void launch_sig(dim3 grid, size_t lds, hipStream_t s, const RneParams &rp
     else hipLaunchKernelGGL((k_rne<NJ, MDH, true, SIG>), grid, dim3(kW), lds, s, rp, links, q, qd, qdd, tau);
 }
 
+// The signatures with an instantiation built into the library; every other signature gets one at run time (jit.cpp).
+static bool rne_sig_builtin(int n, bool mdh, RneSig sig) { return (n == 7 && mdh && sig == kRneSigPanda) || (n == 6 && !mdh && sig == kRneSigPuma560); }
+// name expressions of the run-time instantiations of a DH table with signature `sig` (all links revolute, n <= 8): variant 0 k_rne, 1 k_rne_atrest
+// (rne_kernels.hip), 2 + mode k_dyn (dyn_kernels.hip)
+std::string rne_jit_expr(int n, bool mdh, RneSig sig, int variant)
+{
+    const std::string nj = std::to_string(n), m = mdh ? "true" : "false", sg = jit_hex(sig);
+    if (variant == 0) return "rtbhip::k_rne<" + nj + ", " + m + ", true, " + sg + ">";
+    if (variant == 1) return "rtbhip::k_rne_atrest<" + nj + ", " + m + ", " + sg + ">";
+    return "rtbhip::k_dyn<" + nj + ", " + m + ", " + std::to_string(variant - 2) + ", true, " + sg + ">";
+}
+std::vector<std::string> rne_jit_names(const Dyn *d)
+{
+    std::vector<std::string> out;
+    const RneSig sig = rne_signature(d->links.data(), d->n);
+    if (!sig || rne_sig_builtin(d->n, d->mdh != 0, sig)) return out;
+    for (int v = 0; v < 5; ++v) out.push_back(rne_jit_expr(d->n, d->mdh != 0, sig, v));
+    return out;
+}
+
 template <int NJ>
-static void launch_nj(bool mdh, bool allrev, dim3 grid, size_t lds, hipStream_t s, const RneParams &rp, const DevLink *links,
+static void launch_nj(const Dyn *d, bool mdh, bool allrev, dim3 grid, size_t lds, hipStream_t s, const RneParams &rp, const DevLink *links,
                       const double *q, const double *qd, const double *qdd, double *tau, RneSig sig = 0)
 {
     if constexpr (NJ == 7) {
@@ -256,6 +277,17 @@ static void launch_nj(bool mdh, bool allrev, dim3 grid, size_t lds, hipStream_t 
     }
     if constexpr (NJ == 6) {
         if (sig == kRneSigPuma560 && !mdh && !g_rne_persist) { launch_sig<6, false, kRneSigPuma560>(grid, lds, s, rp, links, q, qd, qdd, tau); return; }
+    }
+    // any other robot with a signature (all links revolute, n <= 8): its own instantiation of the same kernels, compiled at run time; until the
+    // code object is there (or when hipRTC is not) the general kernels below serve -- the same numbers
+    if (sig && !rne_sig_builtin(NJ, mdh, sig) && jit_enabled() && !g_rne_persist && g_rne_wpb == 1) {
+        const int variant = qd ? 0 : 1;
+        if (hipFunction_t f = d->jit.get("rne_kernels.hip", variant, [&] { return rne_jit_expr(NJ, mdh, sig, variant); })) {
+            RneParams rpv = rp;
+            if (qd) { void *args[] = {&rpv, &links, &q, &qd, &qdd, &tau}; (void)jit_launch(f, grid, dim3(kW), lds, s, args); }
+            else { void *args[] = {&rpv, &links, &q, &qdd, &tau}; (void)jit_launch(f, grid, dim3(kW), lds, s, args); }
+            return;
+        }
     }
     if (allrev && !qd) {
         if (mdh) hipLaunchKernelGGL((k_rne_atrest<NJ, true>), grid, dim3(kW), lds, s, rp, links, q, qdd, tau);
@@ -315,14 +347,14 @@ int launch_rne(const Dyn *d, const DevLink *links, const double *q, const double
     dim3 grid((unsigned)g);
     const RneSig sig = (g_rne_sig && !rt) ? rne_signature(d->links.data(), d->n) : 0;
     switch (rt ? 0 : d->n) {
-    case 1: launch_nj<1>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau, sig); break;
-    case 2: launch_nj<2>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau, sig); break;
-    case 3: launch_nj<3>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau, sig); break;
-    case 4: launch_nj<4>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau, sig); break;
-    case 5: launch_nj<5>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau, sig); break;
-    case 6: launch_nj<6>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau, sig); break;
-    case 7: launch_nj<7>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau, sig); break;
-    case 8: launch_nj<8>(mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau, sig); break;
+    case 1: launch_nj<1>(d, mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau, sig); break;
+    case 2: launch_nj<2>(d, mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau, sig); break;
+    case 3: launch_nj<3>(d, mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau, sig); break;
+    case 4: launch_nj<4>(d, mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau, sig); break;
+    case 5: launch_nj<5>(d, mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau, sig); break;
+    case 6: launch_nj<6>(d, mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau, sig); break;
+    case 7: launch_nj<7>(d, mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau, sig); break;
+    case 8: launch_nj<8>(d, mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau, sig); break;
     default: launch_rt(mdh, grid, lds, s, rp, links, q, qd, qdd, tau); break;
     }
     note_launch((int)grid.x, kW, (int)lds);
@@ -330,5 +362,7 @@ int launch_rne(const Dyn *d, const DevLink *links, const double *q, const double
     if (e != hipSuccess) return hip_fail(e, "k_rne launch");
     return RTBHIP_OK;
 }
+
+#endif  // RTB_HOST_SIDE
 
 }  // namespace rtbhip

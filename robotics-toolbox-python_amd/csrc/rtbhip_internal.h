@@ -1,5 +1,10 @@
 // rtbhip_internal.h -- shared declarations of librtbhip.so (not part of the public ABI).
+//
+// Two readers: hipcc building the library, and hipRTC compiling ONE kernel instantiation for a robot's structure signature at run time (jit.cpp).
+// hipRTC has the HIP device headers built in and no host standard library: under __HIPCC_RTC__ only the device-visible tables and constants
+// of this file exist.  Not a second backend -- the same sources, the same gfx950 compiler, a different moment.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <functional>
@@ -9,6 +14,20 @@
 #include <string>
 #include <vector>
 #include "../../include/rtbhip.h"
+#define RTB_HOST_SIDE 1
+#else
+#define RTB_HOST_SIDE 0
+typedef signed char int8_t;
+typedef unsigned char uint8_t;
+typedef short int16_t;
+typedef unsigned short uint16_t;
+typedef int int32_t;
+typedef unsigned int uint32_t;
+typedef long long int64_t;
+typedef unsigned long long uint64_t;
+typedef unsigned long size_t;
+#define RTBHIP_MAX_JOINTS 32       /* include/rtbhip.h (static_assert'ed against it in jit.cpp) */
+#endif
 
 namespace rtbhip {
 
@@ -53,13 +72,51 @@ constexpr SegSig kSegSigPresent = 1ull << 63;
 __host__ __device__ constexpr int seg_sig_cls(SegSig s, int j) { return (int)((s >> (7 * j)) & 15u); }
 __host__ __device__ constexpr int seg_sig_tm(SegSig s, int j) { return (int)((s >> (7 * j + 4)) & 7u); }
 constexpr SegSig seg_sig_of(int j, int cls, int tm) { return (SegSig)((cls & 15) | ((tm & 7) << 4)) << (7 * j); }
+#if RTB_HOST_SIDE
 int seg_class_bits(const DevSeg &a);      // chain.cpp: (class << 20) | (translation mask << 24) of a folded constant
+#endif
 
 // What a kernel receives: two wave-uniform tables in one device allocation.
 struct DevChain {
     const DevSeg *seg;     // n + 1 constants C_0 .. C_n
     const int32_t *jmeta;  // n joint descriptors (+ one more word: the structure class of the tail C_n)
 };
+
+#if RTB_HOST_SIDE
+// ---------------------------------------------------------------- run-time instantiation (jit.cpp)
+bool jit_enabled();                                                       // rtbhip_tune("jit") != 0
+void jit_request(const char *unit, const std::string &expr, const std::string &preamble = std::string(), bool touch_device = false);              // at *_create: ask for it, nobody waits
+hipFunction_t jit_function(const char *unit, const std::string &expr, const std::string &preamble = std::string());    // at a launch: the function on the current device, or NULL (not ready / failed / off)
+int jit_launch(hipFunction_t f, dim3 grid, dim3 block, size_t lds, hipStream_t s, void **args);
+std::string jit_hex(unsigned long long v);                                // "0x...ull"
+void jit_tune(const char *key, int value);
+int jit_wait(double timeout_s);
+void jit_stats(rtbhip_jit_info *out);
+int jit_compile_now(const char *unit, const char *expr, const char *arch, size_t *code_bytes, double *seconds, int *from_disk, const char *preamble = nullptr);
+// per-handle memo of the functions a handle's launches resolved (key: device << 8 | variant), so a hot loop does not build name expressions
+struct JitMemo {
+    std::mutex mu;
+    std::map<uint64_t, hipFunction_t> fn;
+    template <class MakeExpr> hipFunction_t get(const char *unit, int variant, MakeExpr make, const std::string &preamble = std::string())
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        const uint64_t k = ((uint64_t)dev << 8) | (uint64_t)(variant & 0xff);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = fn.find(k);
+            if (it != fn.end()) return it->second;
+        }
+        hipFunction_t f = jit_function(unit, make(), preamble);
+        if (f) { std::lock_guard<std::mutex> lk(mu); fn[k] = f; }
+        return f;
+    }
+};
+// the name expressions of a handle's run-time instantiations (empty: a built-in instantiation serves it, or no signature applies)
+struct Chain; struct Dyn; struct Tree;
+std::vector<std::string> ik_jit_names(const Chain *c);
+std::vector<std::string> rne_jit_names(const Dyn *d);
+std::vector<std::string> tree_jit_names(const Tree *t);
 
 // Host-side chain object behind an rtbhip_chain_t handle.
 struct Chain {
@@ -70,9 +127,12 @@ struct Chain {
     int n = 0, q_width = 0;
     std::map<int, void *> dev_ops;     // per-device upload: [seg | jmeta]
     std::map<int, double *> dev_qlim;  // per-device upload of qlim
+    mutable JitMemo jit;
     std::mutex mu;
     ~Chain();                          // frees the per-device uploads (runs when the last user lets go, see *_from_handle)
 };
+
+#endif
 
 // Host-side dynamics object behind an rtbhip_dyn_t handle.
 struct alignas(16) DevLink {   // per-link constants for the Newton-Euler kernel (24 doubles, reordered)
@@ -86,10 +146,12 @@ struct alignas(16) DevLink {   // per-link constants for the Newton-Euler kernel
     int32_t flags;             // wave-uniform shortcuts: kLinkRZero (centre of mass at the link origin), kLinkIDiag (diagonal inertia), kLinkPsZero (a = d = 0)
 };
 constexpr int kLinkRZero = 1, kLinkIDiag = 2, kLinkPsZero = 4;   // kLinkPsZero: revolute link with a = d = 0 (its frame origin coincides with its predecessor's)
+#if RTB_HOST_SIDE
 struct Dyn {
     std::vector<DevLink> links;
     int n = 0, mdh = 0;
     std::map<int, DevLink *> dev_links;
+    mutable JitMemo jit;
     std::mutex mu;
     ~Dyn();
 };
@@ -102,6 +164,7 @@ struct Tree {
     SegSig sig = 0, sig2 = 0;          // structure signature of the group constants (tree_device.h): groups 0 .. 7 and 8 .. 15; 0 beyond 16 groups
     TreeTopo topo = 0;                 // the tree's bookkeeping as one word (tree_device.h: TreeTopo), 0 where it does not apply
     std::map<int, DevGroup *> dev_groups;
+    mutable JitMemo jit;
     std::mutex mu;
     ~Tree();
 };
@@ -137,6 +200,7 @@ int compile_poe(const double *twists, int n, const double *T0, const double *qli
 struct Affine;
 void chain_tail(const Chain *c, const Affine &tool, double out12[12]);
 void note_launch(int grid, int block, int lds);
+
 int device_cu_count(int *cus);
 int pool_keep_cached();    // the current device's default stream-ordered pool keeps freed blocks (release threshold raised once per device)
 
@@ -225,4 +289,5 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
               int32_t *searches, double *residual, hipStream_t s);
 void ik_restart_host(const Chain *c, uint64_t seed, int64_t target, int search, double *q_n);
 
+#endif  // RTB_HOST_SIDE
 }  // namespace rtbhip

@@ -42,16 +42,26 @@ constexpr int kTreeBilinearSlotDoubles = 24;   // tree_bilinear_core: v of both 
 
 RTB_HD V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
 
-template <class G> RTB_HD V3 seg_rt(const G &g, V3 v)   // R_C^T v
+// R_C^T v and R_C v for a group constant of structure class cls (0: general).  ONE form for every class: each component is dotk_rt (exactform.h) -- the
+// general product's fixed operation sequence  fma(c2, z, fma(c0, x, round(c1 y)))  with the entries the class knows to be exact 0 / +-1 rewritten
+// away -- so a kernel instantiated for a robot's classes returns the general kernel's bits by construction.  cls is a constant of the unrolled
+// group step in every caller: the kind lookups fold, entries whose kind is not kCA are never loaded.
+template <class G> RTB_HD V3 seg_rt_c(int cls, const G &g, V3 v)   // R_C^T v: component k = r[k] x + r[3 + k] y + r[6 + k] z
 {
-    return v3(g.C.r[0] * v.x + g.C.r[3] * v.y + g.C.r[6] * v.z, g.C.r[1] * v.x + g.C.r[4] * v.y + g.C.r[7] * v.z,
-              g.C.r[2] * v.x + g.C.r[5] * v.y + g.C.r[8] * v.z);
+    const auto &r = g.C.r;
+    return v3(dotk_rt(seg_kind(cls, 3), seg_kind(cls, 0), seg_kind(cls, 6), r[3], v.y, r[0], v.x, r[6], v.z),
+              dotk_rt(seg_kind(cls, 4), seg_kind(cls, 1), seg_kind(cls, 7), r[4], v.y, r[1], v.x, r[7], v.z),
+              dotk_rt(seg_kind(cls, 5), seg_kind(cls, 2), seg_kind(cls, 8), r[5], v.y, r[2], v.x, r[8], v.z));
 }
-template <class G> RTB_HD V3 seg_r(const G &g, V3 v)    // R_C v
+template <class G> RTB_HD V3 seg_r_c(int cls, const G &g, V3 v)    // R_C v: component k = r[3k] x + r[3k + 1] y + r[3k + 2] z
 {
-    return v3(g.C.r[0] * v.x + g.C.r[1] * v.y + g.C.r[2] * v.z, g.C.r[3] * v.x + g.C.r[4] * v.y + g.C.r[5] * v.z,
-              g.C.r[6] * v.x + g.C.r[7] * v.y + g.C.r[8] * v.z);
+    const auto &r = g.C.r;
+    return v3(dotk_rt(seg_kind(cls, 1), seg_kind(cls, 0), seg_kind(cls, 2), r[1], v.y, r[0], v.x, r[2], v.z),
+              dotk_rt(seg_kind(cls, 4), seg_kind(cls, 3), seg_kind(cls, 5), r[4], v.y, r[3], v.x, r[5], v.z),
+              dotk_rt(seg_kind(cls, 7), seg_kind(cls, 6), seg_kind(cls, 8), r[7], v.y, r[6], v.x, r[8], v.z));
 }
+template <class G> RTB_HD V3 seg_rt(const G &g, V3 v) { return seg_rt_c(kSegGeneral, g, v); }
+template <class G> RTB_HD V3 seg_r(const G &g, V3 v) { return seg_r_c(kSegGeneral, g, v); }
 RTB_HD V3 rz_t(double s, double c, V3 v) { return v3(c * v.x + s * v.y, c * v.y - s * v.x, v.z); }   // Rz(theta)^T v
 RTB_HD V3 rz(double s, double c, V3 v) { return v3(c * v.x - s * v.y, s * v.x + c * v.y, v.z); }     // Rz(theta) v
 
@@ -60,9 +70,8 @@ RTB_HD V3 rz(double s, double c, V3 v) { return v3(c * v.x - s * v.y, s * v.x + 
 // translations have one or two non-zero components.  A core instantiated for a signature (SIG != 0) multiplies by every group constant in the
 // form of its class and drops the cross-product terms of the zero translation components; the class is read from SIG at the unrolled
 // group index -- a compile-time constant in every copy of the loop body, so the `if` chains below fold away (a run-time switch costs more
-// than it saves: profiles/r05_ik_structured_constants.txt).  The forms are the general products with the exact zeros dropped and the exact
-// +-1 taken as the operand; single-term cross products are fused (fma) where the general form rounds the product first: results agree with
-// the general kernel to rounding (tests: 1e-12 relative), not bit for bit.
+// than it saves: profiles/r05_ik_structured_constants.txt).  The forms are the general products' operation sequences with the exact zeros dropped
+// and the exact +-1 taken as the operand (exactform.h): the general kernel's bits, by construction.
 // kTreeSigPlain: additionally a serial chain of revolute joints (parent of group j is group j - 1, no branch slots, no prismatic joint) --
 // the parent selection, slot traffic and prismatic branches are not compiled in: one straight-line basic block per group.
 constexpr SegSig kTreeSigPlain = 1ull << 56;
@@ -121,48 +130,8 @@ constexpr TreeTopo kTreeTopoPx100 = kTreeTopoPresent | topo_of(0, -1, false, -1,
 static_assert(kTreeSigPx100 == 0x8000065a042de641ull && (unsigned long long)(kTreeTopoPx100 >> 64) == 0x8000000000001601ull &&
               (unsigned long long)kTreeTopoPx100 == 0x5004003002001000ull, "as tree.cpp computes them for the URDF file");
 
-template <class G> RTB_HD V3 seg_rt_c(int cls, const G &g, V3 v)   // R_C^T v for a constant of class cls
-{
-    const auto &r = g.C.r;
-    if (cls == kSegIdentity) return v;
-    if (cls == kSegPermA) return v3(v.y, v.z, v.x);
-    if (cls == kSegPermB) return v3(v.z, v.x, v.y);
-    if (cls == kSegRx) return v3(v.x, r[4] * v.y + r[7] * v.z, r[5] * v.y + r[8] * v.z);
-    if (cls == kSegRxP) return v3(v.x, r[4] * v.y + v.z, r[8] * v.z - v.y);
-    if (cls == kSegRxN) return v3(v.x, r[4] * v.y - v.z, r[8] * v.z + v.y);
-    if (cls == kSegRy) return v3(r[0] * v.x + r[6] * v.z, v.y, r[2] * v.x + r[8] * v.z);
-    if (cls == kSegRyP) return v3(r[0] * v.x + v.z, v.y, r[8] * v.z - v.x);
-    if (cls == kSegRyN) return v3(r[0] * v.x - v.z, v.y, r[8] * v.z + v.x);
-    if (cls == kSegRz) return v3(r[0] * v.x + r[3] * v.y, r[1] * v.x + r[4] * v.y, v.z);
-    if (cls == kSegRzP) return v3(r[0] * v.x + v.y, r[4] * v.y - v.x, v.z);
-    if (cls == kSegRzN) return v3(r[0] * v.x - v.y, r[4] * v.y + v.x, v.z);
-    return seg_rt(g, v);
-}
-template <class G> RTB_HD V3 seg_r_c(int cls, const G &g, V3 v)    // R_C v
-{
-    const auto &r = g.C.r;
-    if (cls == kSegIdentity) return v;
-    if (cls == kSegPermA) return v3(v.z, v.x, v.y);
-    if (cls == kSegPermB) return v3(v.y, v.z, v.x);
-    if (cls == kSegRx) return v3(v.x, r[4] * v.y + r[5] * v.z, r[7] * v.y + r[8] * v.z);
-    if (cls == kSegRxP) return v3(v.x, r[4] * v.y - v.z, r[8] * v.z + v.y);
-    if (cls == kSegRxN) return v3(v.x, r[4] * v.y + v.z, r[8] * v.z - v.y);
-    if (cls == kSegRy) return v3(r[0] * v.x + r[2] * v.z, v.y, r[6] * v.x + r[8] * v.z);
-    if (cls == kSegRyP) return v3(r[0] * v.x - v.z, v.y, r[8] * v.z + v.x);
-    if (cls == kSegRyN) return v3(r[0] * v.x + v.z, v.y, r[8] * v.z - v.x);
-    if (cls == kSegRz) return v3(r[0] * v.x + r[1] * v.y, r[3] * v.x + r[4] * v.y, v.z);
-    if (cls == kSegRzP) return v3(r[0] * v.x - v.y, r[4] * v.y + v.x, v.z);
-    if (cls == kSegRzN) return v3(r[0] * v.x + v.y, r[4] * v.y - v.x, v.z);
-    return seg_r(g, v);
-}
-// b + (u1 v1 - u2 v2) with the products of an absent (exactly zero) translation component dropped
-RTB_HD double tree_acc2(bool has1, bool has2, double b, double u1, double v1, double u2, double v2)
-{
-    if (has1 && has2) return b + (u1 * v1 - u2 * v2);
-    if (has1) return b + u1 * v1;
-    if (has2) return b - u2 * v2;
-    return b;
-}
+// b + (u1 v1 - u2 v2) as  fma(u1, v1, fma(-u2, v2, b))  with the products of an absent (exactly zero) translation component dropped (exactform.h: fm2k)
+RTB_HD double tree_acc2(bool has1, bool has2, double b, double u1, double v1, double u2, double v2) { return fm2k(has1, has2, u1, v1, u2, v2, b); }
 RTB_HD V3 add_cross_ap(int tm, V3 b, V3 a, V3 p)      // b + a x p;  tm: which components of p are not exact zeros (7: no knowledge)
 {
     const bool X = tm & 1, Y = tm & 2, Z = tm & 4;
@@ -188,11 +157,24 @@ template <SegSig SIG, SegSig SIG2 = 0> RTB_HD constexpr int tree_tm(int j, bool 
 {
     return (SIG && !(SIG & kTreeSigAnyConstants) && revolute) ? (j < kTreeSigMaxGroups ? seg_sig_tm(SIG, j) : seg_sig_tm(SIG2, j - kTreeSigMaxGroups)) : 7;
 }
-// what a core knows about group j's place in the tree at compile time: from kTreeSigPlain (serial chain) or a TreeTopo
+// What a core knows about the robot at compile time -- a KNOWLEDGE type KN with static constexpr members:
+//   known      the classes / translation masks of the group constants (cls, tm)          plain   serial chain of revolute joints in group order
+//   topo       every group's parent, joint kind and branch slots (parent, pris, ...)     any     plain || topo: group j moves q column j
+// TreeKnown<SIG, TOPO, SIG2> reads them from the packed words of the built-in instantiations (up to 16 groups of classes, 10 of bookkeeping);
+// a run-time instantiation (jit.cpp, tree_kernels.hip: tree_jit_knowledge) supplies a generated type with the same members for ANY tree -- YuMi's
+// 18 groups, the 13 of a Kinova Gen3 -- so the straight-line recursion is not limited to what fits two 64-bit words.
 template <SegSig SIG, TreeTopo TOPO, SegSig SIG2 = 0> struct TreeKnown {
-    static constexpr bool plain = (SIG & kTreeSigPlain) != 0, any = plain || TOPO != 0;
+    static constexpr bool known = SIG != 0 && !(SIG & kTreeSigAnyConstants);
+    static constexpr bool plain = (SIG & kTreeSigPlain) != 0, topo = TOPO != 0, any = plain || topo;
     RTB_HD static constexpr bool revolute(int j) { return plain || (TOPO != 0 && !topo_pris(TOPO, j)); }
+    RTB_HD static constexpr int cls(int j) { return tree_cls<SIG, SIG2>(j); }
+    RTB_HD static constexpr int tm(int j, bool rev) { return tree_tm<SIG, SIG2>(j, rev); }
+    RTB_HD static constexpr int parent(int j) { return topo_parent(TOPO, j); }
+    RTB_HD static constexpr bool pris(int j) { return topo_pris(TOPO, j); }
+    RTB_HD static constexpr int parent_slot(int j) { return topo_parent_slot(TOPO, j); }
+    RTB_HD static constexpr int save_slot(int j) { return topo_save_slot(TOPO, j); }
 };
+typedef TreeKnown<0, 0, 0> TreeNothing;      // the general kernels
 template <class G> RTB_HD V3 inertia_rot(const G &g, V3 w)   // I_bar w
 {
     return v3(g.I[0] * w.x + g.I[3] * w.y + g.I[4] * w.z, g.I[3] * w.x + g.I[1] * w.y + g.I[5] * w.z,
@@ -202,12 +184,12 @@ template <class G> RTB_HD V3 inertia_rot(const G &g, V3 w)   // I_bar w
 // One sample.  groups: wave-uniform table; qin/qdin/qddin(column) -> double; tau(column, value);
 // slot(index) -> double& into this lane's kTreeSlotDoubles * nslots scratch (LDS on the GPU).
 // joint angles -> sin/cos up front (branch-free reduction; one wave-wide library fallback)
-template <int NG, SegSig SIG = 0, TreeTopo TOPO = 0, SegSig SIG2 = 0, class GroupsP, class InQ>
+template <int NG, class KN = TreeNothing, class GroupsP, class InQ>
 RTB_HD void tree_trig(GroupsP groups, InQ qin, double (&sn)[NG], double (&cs)[NG])
 {
     {
         bool big = false;
-        typedef TreeKnown<SIG, TOPO, SIG2> K;                             // known: group j on q column j, the joint kinds
+        typedef KN K;                             // known: group j on q column j, the joint kinds
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
             const auto &g = groups[j];
@@ -245,12 +227,12 @@ RTB_HD void tree_trig(GroupsP groups, InQ qin, double (&sn)[NG], double (&cs)[NG
 #ifndef RTB_TREE_SKIP_PREFIX
 #define RTB_TREE_SKIP_PREFIX 1
 #endif
-template <int NG, bool VEL = true, SegSig SIG = 0, TreeTopo TOPO = 0, SegSig SIG2 = 0, class GroupsP, class InQ, class InQd, class InQdd, class Out, class Slot>
+template <int NG, bool VEL = true, class KN = TreeNothing, class GroupsP, class InQ, class InQd, class InQdd, class Out, class Slot>
 RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], const double (&cs)[NG], V3 gravity, InQ qin, InQd qdin, InQdd qddin,
                           Out tau, Slot slot, int first = 0)
 {
     V3 Fl[NG], Fa[NG];
-    typedef TreeKnown<SIG, TOPO, SIG2> K;
+    typedef KN K;
     constexpr bool kPlain = K::plain;
     if (!kPlain)
         for (int k = 0; k < nslots; ++k)
@@ -261,11 +243,11 @@ RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], co
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
         const auto &g = groups[j];
-        const int cls = tree_cls<SIG, SIG2>(j), tm = tree_tm<SIG, SIG2>(j, K::revolute(j));          // constants of the unrolled copy (SIG = 0: general, 7)
+        const int cls = K::cls(j), tm = K::tm(j, K::revolute(j));          // constants of the unrolled copy (SIG = 0: general, 7)
         // (read where they are used: loading the three words up front costs the general kernels some 70 registers)
-        auto parent_of = [&]() { return kPlain ? j - 1 : (TOPO ? topo_parent(TOPO, j) : g.parent); };
-        auto parent_slot_of = [&]() { return kPlain ? -1 : (TOPO ? topo_parent_slot(TOPO, j) : g.parent_slot); };
-        auto save_slot_of = [&]() { return kPlain ? -1 : (TOPO ? topo_save_slot(TOPO, j) : g.save_slot); };
+        auto parent_of = [&]() { return kPlain ? j - 1 : (K::topo ? K::parent(j) : g.parent); };
+        auto parent_slot_of = [&]() { return kPlain ? -1 : (K::topo ? K::parent_slot(j) : g.parent_slot); };
+        auto save_slot_of = [&]() { return kPlain ? -1 : (K::topo ? K::save_slot(j) : g.save_slot); };
         if (!VEL && j < first) {
             al = v3(0, 0, 0); aa = v3(0, 0, 0);
             if (save_slot_of() >= 0) {
@@ -275,7 +257,7 @@ RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], co
             Fl[j] = v3(0, 0, 0); Fa[j] = v3(0, 0, 0);
             continue;
         }
-        const bool pris = TOPO ? topo_pris(TOPO, j) : (!kPlain && jm_prismatic(g.jmeta) != 0);
+        const bool pris = K::topo ? K::pris(j) : (!kPlain && jm_prismatic(g.jmeta) != 0);
         const int col = K::any ? j : jm_jq(g.jmeta);
         const double qdj = VEL ? qdin(col) : 0.0, qddj = qddin(col);
         const double d = pris ? qin(col) * (jm_flip(g.jmeta) ? -1.0 : 1.0) : 0.0;
@@ -343,12 +325,12 @@ RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], co
         const int j = NG - 1 - jj;
         if (!VEL && j < first) continue;
         const auto &g = groups[j];
-        const int cls = tree_cls<SIG, SIG2>(j), tm = tree_tm<SIG, SIG2>(j, K::revolute(j));
+        const int cls = K::cls(j), tm = K::tm(j, K::revolute(j));
         // (read where they are used: loading the three words up front costs the general kernels some 70 registers)
-        auto parent_of = [&]() { return kPlain ? j - 1 : (TOPO ? topo_parent(TOPO, j) : g.parent); };
-        auto parent_slot_of = [&]() { return kPlain ? -1 : (TOPO ? topo_parent_slot(TOPO, j) : g.parent_slot); };
-        auto save_slot_of = [&]() { return kPlain ? -1 : (TOPO ? topo_save_slot(TOPO, j) : g.save_slot); };
-        const bool pris = TOPO ? topo_pris(TOPO, j) : (!kPlain && jm_prismatic(g.jmeta) != 0);
+        auto parent_of = [&]() { return kPlain ? j - 1 : (K::topo ? K::parent(j) : g.parent); };
+        auto parent_slot_of = [&]() { return kPlain ? -1 : (K::topo ? K::parent_slot(j) : g.parent_slot); };
+        auto save_slot_of = [&]() { return kPlain ? -1 : (K::topo ? K::save_slot(j) : g.save_slot); };
+        const bool pris = K::topo ? K::pris(j) : (!kPlain && jm_prismatic(g.jmeta) != 0);
         V3 fl = Fl[j] + cl, fa = Fa[j] + ca;
         if (save_slot_of() >= 0) {
             const int b = save_slot_of() * kTreeSlotDoubles + 12;
@@ -382,13 +364,13 @@ RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], co
 // halves).  Against the two full passes per column of the polar form tau(qd + s e_k) - tau(qd - s e_k) this is one pass of ~1.1x the
 // arithmetic, exact for any spread of velocities (no scale s to choose, no cancellation), and the groups before `first` (w = 0 there: their
 // accelerations and forces vanish) only advance u.  `first` as in tree_rne_core; slots of kTreeBilinearSlotDoubles.
-template <int NG, SegSig SIG = 0, TreeTopo TOPO = 0, SegSig SIG2 = 0, class GroupsP, class InQ, class InQd, class Out, class Slot>
+template <int NG, class KN = TreeNothing, class GroupsP, class InQ, class InQd, class Out, class Slot>
 RTB_HD void tree_bilinear_core(GroupsP groups, int nslots, const double (&sn)[NG], const double (&cs)[NG], InQ qin, InQd qdin, int k, Out tau,
                                Slot slot, int first)
 {
     constexpr int SD = kTreeBilinearSlotDoubles;
     V3 Fl[NG], Fa[NG];
-    typedef TreeKnown<SIG, TOPO, SIG2> K;
+    typedef KN K;
     constexpr bool kPlain = K::plain;
     if (!kPlain)
         for (int i = 0; i < nslots; ++i)
@@ -398,12 +380,12 @@ RTB_HD void tree_bilinear_core(GroupsP groups, int nslots, const double (&sn)[NG
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
         const auto &g = groups[j];
-        const int cls = tree_cls<SIG, SIG2>(j), tm = tree_tm<SIG, SIG2>(j, K::revolute(j));
+        const int cls = K::cls(j), tm = K::tm(j, K::revolute(j));
         // (read where they are used: loading the three words up front costs the general kernels some 70 registers)
-        auto parent_of = [&]() { return kPlain ? j - 1 : (TOPO ? topo_parent(TOPO, j) : g.parent); };
-        auto parent_slot_of = [&]() { return kPlain ? -1 : (TOPO ? topo_parent_slot(TOPO, j) : g.parent_slot); };
-        auto save_slot_of = [&]() { return kPlain ? -1 : (TOPO ? topo_save_slot(TOPO, j) : g.save_slot); };
-        const bool pris = TOPO ? topo_pris(TOPO, j) : (!kPlain && jm_prismatic(g.jmeta) != 0);
+        auto parent_of = [&]() { return kPlain ? j - 1 : (K::topo ? K::parent(j) : g.parent); };
+        auto parent_slot_of = [&]() { return kPlain ? -1 : (K::topo ? K::parent_slot(j) : g.parent_slot); };
+        auto save_slot_of = [&]() { return kPlain ? -1 : (K::topo ? K::save_slot(j) : g.save_slot); };
+        const bool pris = K::topo ? K::pris(j) : (!kPlain && jm_prismatic(g.jmeta) != 0);
         const int col = K::any ? j : jm_jq(g.jmeta);
         const double qdu = qdin(col), qdw = col == k ? 1.0 : 0.0;
         const double d = pris ? qin(col) * (jm_flip(g.jmeta) ? -1.0 : 1.0) : 0.0;
@@ -472,12 +454,12 @@ RTB_HD void tree_bilinear_core(GroupsP groups, int nslots, const double (&sn)[NG
     for (int jj = 0; jj < NG; ++jj) {
         const int j = NG - 1 - jj;
         const auto &g = groups[j];
-        const int cls = tree_cls<SIG, SIG2>(j), tm = tree_tm<SIG, SIG2>(j, K::revolute(j));
+        const int cls = K::cls(j), tm = K::tm(j, K::revolute(j));
         // (read where they are used: loading the three words up front costs the general kernels some 70 registers)
-        auto parent_of = [&]() { return kPlain ? j - 1 : (TOPO ? topo_parent(TOPO, j) : g.parent); };
-        auto parent_slot_of = [&]() { return kPlain ? -1 : (TOPO ? topo_parent_slot(TOPO, j) : g.parent_slot); };
-        auto save_slot_of = [&]() { return kPlain ? -1 : (TOPO ? topo_save_slot(TOPO, j) : g.save_slot); };
-        const bool pris = TOPO ? topo_pris(TOPO, j) : (!kPlain && jm_prismatic(g.jmeta) != 0);
+        auto parent_of = [&]() { return kPlain ? j - 1 : (K::topo ? K::parent(j) : g.parent); };
+        auto parent_slot_of = [&]() { return kPlain ? -1 : (K::topo ? K::parent_slot(j) : g.parent_slot); };
+        auto save_slot_of = [&]() { return kPlain ? -1 : (K::topo ? K::save_slot(j) : g.save_slot); };
+        const bool pris = K::topo ? K::pris(j) : (!kPlain && jm_prismatic(g.jmeta) != 0);
         V3 fl = Fl[j] + cl, fa = Fa[j] + ca;
         if (save_slot_of() >= 0) {
             const int b = save_slot_of() * SD + 18;
@@ -505,12 +487,12 @@ RTB_HD void tree_bilinear_core(GroupsP groups, int nslots, const double (&sn)[NG
 
 // ATREST: the caller has no joint velocities (rtbhip_tree_rne with qd = NULL: Dynamics.gravload, Dynamics.itorque) -- the recursion
 // without its velocity half (tree_rne_core VEL = false), gravity still the base's acceleration.
-template <int NG, bool ATREST = false, SegSig SIG = 0, TreeTopo TOPO = 0, SegSig SIG2 = 0, class GroupsP, class InQ, class InQd, class InQdd, class Out, class Slot>
+template <int NG, bool ATREST = false, class KN = TreeNothing, class GroupsP, class InQ, class InQd, class InQdd, class Out, class Slot>
 RTB_HD void tree_rne_lane(GroupsP groups, int nslots, V3 gravity, InQ qin, InQd qdin, InQdd qddin, Out tau, Slot slot)
 {
     double sn[NG], cs[NG];
-    tree_trig<NG, SIG, TOPO, SIG2>(groups, qin, sn, cs);
-    tree_rne_core<NG, !ATREST, SIG, TOPO, SIG2>(groups, nslots, sn, cs, gravity, qin, qdin, qddin, tau, slot);
+    tree_trig<NG, KN>(groups, qin, sn, cs);
+    tree_rne_core<NG, !ATREST, KN>(groups, nslots, sn, cs, gravity, qin, qdin, qddin, tau, slot);
 }
 
 // ---- the Dynamics-mixin terms of an ETS robot (robot/Dynamics.py:704-861, 424-509 on Robot.rne): every Newton-Euler pass the
@@ -564,15 +546,15 @@ RTB_HD int tree_row_position(GroupsP groups, int r)
     return a;
 }
 
-template <int NG, int MODE, SegSig SIG = 0, TreeTopo TOPO = 0, SegSig SIG2 = 0, class GroupsP, class Slot>
+template <int NG, int MODE, class KN = TreeNothing, class GroupsP, class Slot>
 RTB_HD void tree_dyn_lane(GroupsP groups, int nslots, const double *mine, double *mA, V3 grav, Slot slot)
 {
     const V3 zero = v3(0, 0, 0);
     auto qin = [&](int j) { return mine[j]; };
     auto none = [&](int) { return 0.0; };
     double sn[NG], cs[NG];
-    tree_trig<NG, SIG, TOPO, SIG2>(groups, qin, sn, cs);
-    constexpr bool kPlain = TreeKnown<SIG, TOPO, SIG2>::any;          // group j moves q column j: nothing to permute
+    tree_trig<NG, KN>(groups, qin, sn, cs);
+    constexpr bool kPlain = KN::any;          // group j moves q column j: nothing to permute
     // The unit-acceleration passes run in GROUP order: pass i accelerates the joint of the group at position i (q column jq_i), so that
     // Mp[j][i] = torque of group j is the symmetric joint-space inertia in group order -- only the entries j >= i are computed (the groups before i are
     // no descendants of i: at rest), packed lower triangle.  The reference's matrix is M[c, :] = rne(q, 0, e_c) with c a q COLUMN and the torques
@@ -585,14 +567,14 @@ RTB_HD void tree_dyn_lane(GroupsP groups, int nslots, const double *mine, double
         for (int i = 0; i < NG; ++i) {
             tree_opaque<NG>(sn, cs);
             const int ci = kPlain ? i : jm_jq(groups[i].jmeta);
-            tree_rne_core<NG, !RTB_TREE_ACC_ONLY, SIG, TOPO, SIG2>(groups, nslots, sn, cs, zero, qin, none, [&](int c) { return c == ci ? 1.0 : 0.0; },
+            tree_rne_core<NG, !RTB_TREE_ACC_ONLY, KN>(groups, nslots, sn, cs, zero, qin, none, [&](int c) { return c == ci ? 1.0 : 0.0; },
                                      [&](int j, double v) { if (j >= i) mA[j * (j + 1) / 2 + i] = v; }, slot, skip ? i : 0);
         }
     }
     if (MODE == kDynAccel) {
         double b[NG];
         tree_opaque<NG>(sn, cs);
-        tree_rne_core<NG, true, SIG, TOPO, SIG2>(groups, nslots, sn, cs, grav, qin, [&](int j) { return mine[NG + j]; }, none,
+        tree_rne_core<NG, true, KN>(groups, nslots, sn, cs, grav, qin, [&](int j) { return mine[NG + j]; }, none,
                           [&](int j, double v) { tree_put<NG>(b, j, mine[2 * NG + j] - v); }, slot);
         // the reference solves M qdd = torque - tau_0 with ITS M (rows by q column): row i of Mp stands in row jq_i, so the right-hand side of
         // the group-ordered system is entry jq_i of (torque - tau_0)
@@ -607,7 +589,7 @@ RTB_HD void tree_dyn_lane(GroupsP groups, int nslots, const double *mine, double
         for (int i = 0; i < NG; ++i) {
             tree_opaque<NG>(sn, cs);
             const int ci = kPlain ? i : jm_jq(groups[i].jmeta);
-            tree_rne_core<NG, !RTB_TREE_ACC_ONLY, SIG, TOPO, SIG2>(groups, nslots, sn, cs, zero, qin, none, [&](int c) { return c == ci ? 1.0 : 0.0; },
+            tree_rne_core<NG, !RTB_TREE_ACC_ONLY, KN>(groups, nslots, sn, cs, zero, qin, none, [&](int c) { return c == ci ? 1.0 : 0.0; },
                                      [&](int j, double v) { if (j >= i) mA[j * (j + 1) / 2 + i] = v; }, slot, skip ? i : 0);
         }
         double x[NG], M[NG][NG];
@@ -628,7 +610,7 @@ RTB_HD void tree_dyn_lane(GroupsP groups, int nslots, const double *mine, double
 #pragma unroll 1
         for (int k = 0; k < NG; ++k) {
             tree_opaque<NG>(sn, cs);
-            tree_bilinear_core<NG, SIG, TOPO, SIG2>(groups, nslots, sn, cs, qin, [&](int j) { return mine[NG + j]; }, k,
+            tree_bilinear_core<NG, KN>(groups, nslots, sn, cs, qin, [&](int j) { return mine[NG + j]; }, k,
                                    [&](int r, double v) { mA[r * NG + k] = 0.5 * v; }, slot, ordered ? k : 0);
         }
 #else

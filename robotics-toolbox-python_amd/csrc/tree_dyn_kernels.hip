@@ -39,7 +39,7 @@ __device__ __forceinline__ void tree_flush_symmetric(ConstGroups groups, const d
 // Robots of up to 7 joints keep two waves per SIMD (the second launch bound: at most 256 registers a lane): their tiles leave room for five or
 // more waves on a CU, and an allocation just above 256 -- the general accel kernel for six joints took 288 in one build of round 5, when the
 // recursion read a group's bookkeeping words before it needed them -- halves what the registers admit.  From 8 joints on the tile admits four.
-template <int NG, int MODE, SegSig SIG = 0, TreeTopo TOPO = 0, SegSig SIG2 = 0>
+template <int NG, int MODE, class KN = TreeNothing>
 __global__ __launch_bounds__(kWave, (NG <= 7 ? 2 : 1)) void k_tree_dyn(TreeParams tp, const DevGroup *groups_g, const double *__restrict__ q,
                                                        const double *__restrict__ qd, const double *__restrict__ tq,
                                                        double *__restrict__ out)
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kWave, (NG <= 7 ? 2 : 1)) void k_tree_dyn(TreeParam
     }
     __syncthreads();
     if (lane < ncfg)
-        tree_dyn_lane<NG, MODE, SIG, TOPO, SIG2>(groups, tp.nslots, lds + lane * in_stride, A + lane * w_stride, v3(tp.grav[0], tp.grav[1], tp.grav[2]),
+        tree_dyn_lane<NG, MODE, KN>(groups, tp.nslots, lds + lane * in_stride, A + lane * w_stride, v3(tp.grav[0], tp.grav[1], tp.grav[2]),
                                 [&](int i) -> double & { return slots[i * T + lane]; });
     __syncthreads();
     if (MODE == kDynAccel) flush_run(A, w_stride, NG, ncfg, out + cfg0 * NG, lane);
@@ -83,6 +83,17 @@ __global__ __launch_bounds__(kWave, (NG <= 7 ? 2 : 1)) void k_tree_dyn(TreeParam
     else flush_run(A, w_stride, NG * NG, ncfg, out + cfg0 * (NG * NG), lane);
 }
 
+#if RTB_HOST_SIDE      // the launchers (the kernel above is also what jit.cpp hands to hipRTC, one instantiation at a time)
+hipFunction_t tree_jit_function(const Tree *t, int variant);      // tree_kernels.hip
+// tile size and LDS bytes of k_tree_dyn for a run-time group count: the formulas of launch_tree_dyn_one (which has them at compile time)
+static void tree_dyn_tile(int n, int mode, int nslots, int32_t *tile, size_t *lds)
+{
+    const int K = mode == kDynInertia ? 1 : (mode == kDynCoriolis ? 2 : 3);
+    const int W = mode == kDynCoriolis ? n * n : n * (n + 1) / 2 + (mode == kDynAccel ? n : 0);
+    const size_t per_lane = (size_t)(((K * n) | 1) + (W | 1) + (mode == kDynCoriolis ? kTreeBilinearSlotDoubles : kTreeSlotDoubles) * nslots) * sizeof(double);
+    *tile = per_lane * kWave > 160 * 1024 ? kWave / 2 : kWave;
+    *lds = per_lane * *tile;
+}
 template <int NG, int MODE, SegSig SIG = 0, TreeTopo TOPO = 0, SegSig SIG2 = 0>
 static hipError_t launch_tree_dyn_one(dim3 grid, hipStream_t s, int nslots, const TreeParams &tp, const DevGroup *g, const double *q,
                                       const double *qd, const double *tq, double *out, size_t *lds_out)
@@ -101,7 +112,7 @@ static hipError_t launch_tree_dyn_one(dim3 grid, hipStream_t s, int nslots, cons
     const int64_t tiles = (tp.N + tq_.tile - 1) / tq_.tile;
     if (tiles > 0x7fffffff) { *lds_out = 0; return hipErrorInvalidValue; }
     grid = dim3((unsigned)tiles);
-    auto k = k_tree_dyn<NG, MODE, SIG, TOPO, SIG2>;
+    auto k = k_tree_dyn<NG, MODE, TreeKnown<SIG, TOPO, SIG2>>;
     if (lds > 48 * 1024) { hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(k, grid, dim3(kWave), lds, s, tq_, g, q, qd, tq, out);
     note_launch((int)grid.x, kWave, (int)lds);
@@ -138,17 +149,31 @@ int launch_tree_dyn(const Tree *t, const DevGroup *groups, int mode, const doubl
     const bool plain = (sig & kTreeSigPlain) != 0;
     const TreeTopo topo = g_tree_sig ? t->topo : 0;
     const SegSig sig2 = g_tree_sig ? t->sig2 : 0;
-    if (sig == kTreeSigUR) {
+    // a robot without a built-in instantiation: its own, compiled at run time (jit.cpp); the general kernels below serve until it is there
+    if (hipFunction_t f = tree_jit_function(t, 2 + mode)) {
+        TreeParams tq_ = tp;
+        size_t l = 0;
+        tree_dyn_tile(t->n, mode, t->nslots, &tq_.tile, &l);
+        if (l <= 160 * 1024) {
+            const int64_t tl = (N + tq_.tile - 1) / tq_.tile;
+            void *args[] = {&tq_, &groups, &q, &qd, &tq, &out};
+            const int rc = jit_launch(f, dim3((unsigned)tl), dim3(kWave), l, s, args);
+            if (rc != RTBHIP_OK) return rc;
+            note_launch((int)tl, kWave, (int)l);
+            return RTBHIP_OK;
+        }
+    }
+    if (sig == kTreeSigUR && t->n == 6) {       // (a signature does not encode the group count: a trailing General / t = 0 group reads as "absent")
         e = launch_tree_dyn_ng<6, kTreeSigUR>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds);
-    } else if (sig == kTreeSigIbx8 && topo == kTreeTopoIbx8) {
+    } else if (sig == kTreeSigIbx8 && topo == kTreeTopoIbx8 && t->n == 8) {
         e = launch_tree_dyn_ng<8, kTreeSigIbx8, kTreeTopoIbx8>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds);
-    } else if (sig == kTreeSigPx100 && topo == kTreeTopoPx100) {
+    } else if (sig == kTreeSigPx100 && topo == kTreeTopoPx100 && t->n == 7) {
         e = launch_tree_dyn_ng<7, kTreeSigPx100, kTreeTopoPx100>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds);
-    } else if (sig == kTreeSigIbx9 && sig2 == kTreeSig2Ibx9 && topo == kTreeTopoIbx9) {
+    } else if (sig == kTreeSigIbx9 && sig2 == kTreeSig2Ibx9 && topo == kTreeTopoIbx9 && t->n == 9) {
         e = launch_tree_dyn_ng<9, kTreeSigIbx9, kTreeTopoIbx9, kTreeSig2Ibx9>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds);
-    } else if (sig == kTreeSigFetch && sig2 == kTreeSig2Fetch && topo == kTreeTopoFetch) {
+    } else if (sig == kTreeSigFetch && sig2 == kTreeSig2Fetch && topo == kTreeTopoFetch && t->n == 10) {
         e = launch_tree_dyn_ng<10, kTreeSigFetch, kTreeTopoFetch, kTreeSig2Fetch>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds);
-    } else if (sig == kTreeSigMico && sig2 == kTreeSig2Mico && topo == kTreeTopoMico) {
+    } else if (sig == kTreeSigMico && sig2 == kTreeSig2Mico && topo == kTreeTopoMico && t->n == 10) {
         e = launch_tree_dyn_ng<10, kTreeSigMico, kTreeTopoMico, kTreeSig2Mico>(mode, grid, s, t->nslots, tp, groups, q, qd, tq, out, &lds);
     } else
 #ifdef RTB_TREE_DEV_NG
@@ -183,5 +208,7 @@ int launch_tree_dyn(const Tree *t, const DevGroup *groups, int mode, const doubl
     if (e != hipSuccess) return hip_fail(e, "k_tree_dyn launch");
     return RTBHIP_OK;
 }
+
+#endif  // RTB_HOST_SIDE
 
 }  // namespace rtbhip

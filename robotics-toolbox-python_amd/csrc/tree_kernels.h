@@ -3,7 +3,9 @@
 #pragma once
 #include "tree_device.h"
 #include "kin_tile.h"
+#ifndef __HIPCC_RTC__
 #include <string>
+#endif
 
 namespace rtbhip {
 

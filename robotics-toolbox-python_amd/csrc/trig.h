@@ -13,8 +13,10 @@
 // |x| >= 2^20 (never a joint angle, but the ABI accepts any double) falls back to the library
 // routine, whole wave at once, so parity holds for every input.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <cmath>
+#endif
 
 #ifndef RTB_HD
 #define RTB_HD __host__ __device__ __forceinline__

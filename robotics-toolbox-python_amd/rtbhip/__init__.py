@@ -24,9 +24,10 @@ from .kinematics import RobotKinematics  # noqa: F401
 from . import models  # noqa: F401
 from . import urdf  # noqa: F401
 from . import xacro  # noqa: F401
+from . import jit  # noqa: F401
 from .fleet import fleet_fkine_jacob, fleet_fkine_jacob_packed  # noqa: F401
 from .shard import ShardedBatch, Communicator  # noqa: F401
 
 __all__ = ["ET", "ETS", "IKSolution", "IKSolver", "IK_NR", "IK_GN", "IK_LM", "IK_QP", "angle_axis", "angle_axis_python", "p_servo", "hessian_from_jacobian", "manipulability_from_jacobian", "jacobm_from_jacobian", "DHLink", "DHRobot", "RevoluteDH", "PrismaticDH", "RevoluteMDH",
-           "PrismaticMDH", "Link", "ERobot", "PoELink", "PoERevolute", "PoEPrismatic", "PoERobot", "RobotKinematics", "models", "urdf", "xacro", "fleet_fkine_jacob", "fleet_fkine_jacob_packed", "ShardedBatch", "Communicator", "RtbHipError", "lib",
+           "PrismaticMDH", "Link", "ERobot", "PoELink", "PoERevolute", "PoEPrismatic", "PoERobot", "RobotKinematics", "models", "urdf", "xacro", "jit", "fleet_fkine_jacob", "fleet_fkine_jacob_packed", "ShardedBatch", "Communicator", "RtbHipError", "lib",
            "device_count", "tune", "shard_range", "last_launch", "ik_target_base", "trim"]

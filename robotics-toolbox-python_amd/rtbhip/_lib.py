@@ -31,6 +31,13 @@ class rtbhip_tree_group(C.Structure):
                 ("T", C.c_double * 16), ("m", C.c_double), ("h", C.c_double * 3), ("I", C.c_double * 6)]
 
 
+class rtbhip_jit_info(C.Structure):
+    _fields_ = [("available", C.c_int32), ("mode", C.c_int32), ("requested", C.c_int64), ("compiled", C.c_int64), ("disk_hits", C.c_int64),
+                ("failed", C.c_int64), ("pending", C.c_int64), ("launches", C.c_int64), ("general_while_pending", C.c_int64),
+                ("compile_seconds", C.c_double), ("compile_seconds_max", C.c_double), ("sources", C.c_int32), ("source_digest", C.c_char * 20),
+                ("last_error", C.c_char * 512)]
+
+
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
 _vp = C.c_void_p
@@ -116,6 +123,11 @@ SIGNATURES = {
     "rtbhip_last_launch": (C.c_int, [_ip, _ip, _ip]),
     "rtbhip_tune": (C.c_int, [C.c_char_p, _i32]),
     "rtbhip_stream_probe": (C.c_int, [_vp, _i64, _vp, _i64, _vp]),
+    "rtbhip_jit_stats": (C.c_int, [C.POINTER(rtbhip_jit_info)]),
+    "rtbhip_jit_wait": (C.c_int, [C.c_double]),
+    "rtbhip_jit_compile": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(_i32)]),
+    "rtbhip_jit_prepare": (C.c_int, [_i32, _u64]),
+    "rtbhip_jit_names": (C.c_int, [_i32, _u64, C.c_char_p, _i64]),
 }
 
 _lib = None

@@ -796,8 +796,14 @@ class ETS:
         if packed:
             w = 16 + 6 * self.n
             TJ = self._out((N, w), q2, tm) if out is None else out
-            if tuple(TJ.shape) != (N, w) or not (TJ.is_contiguous() if tm else TJ.flags.c_contiguous):
-                raise ValueError("out must be a contiguous (N, 16 + 6n) float64 array")
+            if out is not None:
+                # the kernel (or the D2H copy) writes N * w * 8 bytes through this pointer: shape, width, contiguity, element type AND where
+                # it lives must be what q's are -- a float32 or wrong-device `out` would be overrun / written through a foreign pointer
+                import torch as _torch
+                good = (is_torch(TJ) and TJ.dtype == _torch.float64 and TJ.device == q2.device and TJ.is_contiguous()) if tm else \
+                       (isinstance(TJ, np.ndarray) and TJ.dtype == np.float64 and TJ.flags.c_contiguous and TJ.flags.writeable)
+                if not good or tuple(TJ.shape) != (N, w):
+                    raise ValueError("out must be a contiguous (N, 16 + 6n) float64 %s" % ("tensor on q's device" if tm else "ndarray"))
             b, t = small(base, 16), small(tool, 16)
             check(lib().rtbhip_fkine_jacob_packed(self._handle(), self._ptr(q2, tm), N, host_ptr(b), host_ptr(t), frame,
                                                   self._ptr(TJ, tm), MEM_DEVICE if tm else MEM_HOST, self._stream(tm)))

@@ -89,7 +89,11 @@ class IKSolver:
         """The reference's loop (robot/IK.py:174-367) around a subclass's own `step(ets, Tep, q) -> (E, q)`: start vectors (the caller's rows
         first, then uniform draws inside the limits, :222-240), up to slimit searches of up to ilimit steps, a success wrapped into [-pi, pi)
         and checked against the joint limits, numpy.linalg.LinAlgError abandoning a search.  Host-side: it is the user's Python that runs."""
-        Tep = Tep.A if hasattr(Tep, "A") and not isinstance(Tep, np.ndarray) and not is_torch(Tep) else np.asarray(Tep, dtype=np.float64)
+        if is_torch(Tep):
+            Tep = Tep.detach().cpu().numpy()
+        Tep = Tep.A if hasattr(Tep, "A") and not isinstance(Tep, np.ndarray) else np.asarray(Tep, dtype=np.float64)
+        if isinstance(Tep, (list, tuple)):                              # spatialmath: a multi-valued SE3's .A is a list of 4x4
+            Tep = np.asarray(Tep, dtype=np.float64)
         rng = np.random.default_rng(self.seed)
         if q0 is None:
             starts = self._random_q(ets, rng, self.slimit)
@@ -124,7 +128,17 @@ class IKSolver:
                 reason += ", solution found but violates joint limits"
             return IKSolution(q=q, success=False, iterations=total_i, searches=self.slimit, residual=E, reason=reason)
         if Tep.ndim == 3:
-            return [one(T) for T in Tep]
+            # the reference's `traj` branch (robot/IK.py:262-287): ONE solution object -- q (N, n), success = all, iterations / searches summed,
+            # the smallest residual, the reason of the last failure -- with the per-target arrays beside it as the built-in path has them
+            sols = [one(T) for T in Tep]
+            failed = [x for x in sols if not x.success]
+            return IKSolution(q=np.array([x.q for x in sols]).reshape(len(sols), ets.n), success=not failed, iterations=int(sum(x.iterations for x in sols)),
+                              searches=int(sum(x.searches for x in sols)), residual=float(min([x.residual for x in sols], default=np.inf)),
+                              reason=failed[-1].reason if failed else "",
+                              each={"success": np.array([x.success for x in sols]), "iterations": np.array([x.iterations for x in sols]),
+                                    "searches": np.array([x.searches for x in sols]), "residual": np.array([x.residual for x in sols], dtype=np.float64)})
+        if Tep.shape != (4, 4):
+            raise ValueError("Tep must be a 4x4 SE3 matrix")                # robot/IK.py:256-257
         return one(Tep)
 
 

@@ -87,6 +87,8 @@ class RobotKinematics:
     def jacobm(self, q=None, J=None, H=None, end=None, start=None, axes="all"):
         """robot/Robot.py:1101-1235.  J= / H= (finished Jacobian, optionally the Hessian to go with it) are served from the caller's arrays
         (rtbhip_jacobm_from_jacobian; H alone needs q for the Jacobian, as in the reference :1194-1199)."""
+        if q is None and J is None:
+            q = np.copy(self.q)                       # the robot's stored configuration (robot/Robot.py:1195-1198)
         if J is not None or H is not None:
             from .et import jacobm_from_jacobian
             if J is None:

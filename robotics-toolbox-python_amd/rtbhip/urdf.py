@@ -82,6 +82,13 @@ class URDFJoint:
         if lim is not None and lim.get("lower") is not None and lim.get("upper") is not None:
             self.lower = float(lim.get("lower"))
             self.upper = float(lim.get("upper"))
+        elif lim is not None and (lim.get("lower") is not None or lim.get("upper") is not None):
+            # half a limit: the reference stores [lower, None] / [None, upper] and robot.qlim (robot/BaseRobot.py:1017-1030) then reads a revolute
+            # joint whose lower bound is missing as [-pi, pi] (a missing UPPER bound has no defined reading there).  Same outcome here -- no limit,
+            # i.e. [-pi, pi] for a revolute joint -- but not silently: the URDF specification's own default for a missing bound would be 0
+            import warnings
+            warnings.warn("URDF joint %r: <limit> gives only one of lower / upper -- treated as no joint limit (the reference reads a revolute "
+                          "joint without a lower bound as [-pi, pi]; the URDF default for a missing bound is 0)" % self.name, stacklevel=3)
         d = el.find("dynamics")
         self.friction = None if d is None or d.get("friction") is None else float(d.get("friction"))
         self.damping = None if d is None or d.get("damping") is None else float(d.get("damping"))
@@ -184,6 +191,7 @@ class URDFRobot:
                 self.jindex[j.name] = len(self.jindex)
             stack.extend(reversed(l.children))
         self.n = len(self.jindex)
+        self.q = np.zeros(self.n)             # the stored configuration (BaseRobot.q): what q = None means (jacobm, gravload)
         self._cache = {}
         self.tool = tool
         self.base = None
@@ -330,9 +338,18 @@ class URDFRobot:
         if J is not None or H is not None:
             from .et import jacobm_from_jacobian
             if J is None:
-                J = e.jacob0(np.zeros(e.n) if q is None else q)          # robot/Robot.py:1194-1199
+                J = e.jacob0(self._stored_q(e) if q is None else q)          # robot/Robot.py:1194-1199
             return jacobm_from_jacobian(J, H=H, **kw)
-        return e.jacobm(np.zeros(e.n) if q is None else q, **kw)
+        return e.jacobm(self._stored_q(e) if q is None else q, **kw)
+
+    def _stored_q(self, e):
+        """q = None means the robot's stored configuration `self.q` (BaseRobot.q, zeros until the user sets it; robot/Robot.py:1195-1198),
+        read on the columns the path's joints use."""
+        q = np.asarray(getattr(self, "q", None) if getattr(self, "q", None) is not None else np.zeros(e.n), dtype=np.float64).reshape(-1)
+        if q.size == e.n:
+            return q.copy()
+        cols = [int(j) for j in e.jindices]
+        return q[cols].copy() if q.size > max(cols, default=-1) else np.zeros(e.n)
     def jacob0_dot(self, q, qd, J0=None, representation=None, end=None): return self.ets(end=end).jacob0_dot(q, qd, J0=J0, representation=representation)
     def jacob0_analytical(self, q, representation="rpy/xyz", end=None, start=None, tool=None):
         return self.ets(start, end).jacob0_analytical(q, representation=representation, tool=self._tool_for(end, tool))

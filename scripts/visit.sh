@@ -6,6 +6,7 @@
 #   smoke   __graft_entry__.smoke()
 #   bench   python bench.py $BENCH_ARGS (default --steps 50 --warmup 5)                         -> bench_n1.json
 #   prof    rocprofv3 --kernel-trace --stats of bench.py (and of the rne leg at 1e7)            -> prof/, prof_rne1e7/
+#   profsec rocprofv3 --kernel-trace --stats of the FULL bench.py command (secondary legs included); per (kernel, grid) durations    -> secondary_kernel_stats.csv
 #   pmc     FETCH_SIZE / WRITE_SIZE passes (separate runs) of bench.py and of the rne leg       -> pmc_*/
 #   sq      SQ_INSTS_VALU / SQ_WAVES of bench_extra.py --what $SQ_WHAT (default rne,dyn,tree)        -> pmc_sq/, sq_digest.txt
 #   extra   python bench_extra.py $EXTRA_ARGS                                                   -> bench_extra.jsonl
@@ -43,6 +44,13 @@ if has prof; then
   cd $R
   find $O/prof $O/prof_rne1e7 -name "*kernel_stats*.csv" | while read f; do echo $f; cut -c1-170 "$f" | head -6; done
 fi
+if has profsec; then
+  cd /tmp
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_secondary -o sec -- python $R/bench.py --steps 20 --warmup 3 --no-cpu > $O/prof_secondary.log 2>&1
+  cd $R
+  python scripts/secondary_stats.py $O/prof_secondary $O/secondary_kernel_stats.csv | cut -c1-170
+  tail -1 $O/prof_secondary.log | cut -c1-300
+fi
 if has pmc; then
   cd /tmp
   for c in FETCH_SIZE WRITE_SIZE; do
@@ -70,8 +78,9 @@ if has libab; then
   : > $O/ik_lib_ab.jsonl
   for r in $(seq 1 ${LIBAB_ROUNDS:-3}); do
     for v in product $VARIANTS; do
-      L=""; T=""                                    # an entry with '=' is an rtbhip_tune setting of the product library, else a variant library
-      if [[ $v == *=* ]]; then T=$v; elif [ $v != product ]; then L=$R/robotics-toolbox-python_amd/lib/variants/$v; fi
+      L=""; T=""                                    # an entry with '=' is an rtbhip_tune setting of the product library, else a variant library;
+      if [[ $v == *:* ]]; then L=$R/robotics-toolbox-python_amd/lib/variants/${v%%:*}; T=${v#*:};      # "lib.so:key=value": both
+      elif [[ $v == *=* ]]; then T=$v; elif [ $v != product ]; then L=$R/robotics-toolbox-python_amd/lib/variants/$v; fi
       RTBHIP_LIB=$L RTBHIP_TUNE=$T timeout 200 python scripts/ik_lib_time.py >> $O/ik_lib_ab.jsonl 2>> $O/ik_lib_ab.err
     done
   done

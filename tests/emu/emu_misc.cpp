@@ -136,11 +136,11 @@ static void tree_run(const Tree *t, const double *q, const double *qd, const dou
         double *o = tau + s * NG;
         // qd == NULL on a robot of up to 12 groups: the at-rest instantiation, as launch_tree_rne dispatches (tree_kernels.hip kTreeAtRestMax)
         if (!b && NG <= 12)
-            tree_rne_lane<NG, true, SIG, TOPO, SIG2>(t->groups.data(), t->nslots, g, [&](int k) { return a[k]; }, [&](int) { return 0.0; },
+            tree_rne_lane<NG, true, TreeKnown<SIG, TOPO, SIG2>>(t->groups.data(), t->nslots, g, [&](int k) { return a[k]; }, [&](int) { return 0.0; },
                                     [&](int k) { return c[k]; }, [&](int k, double v) { o[k] = v; },
                                     [&](int i) -> double & { return slots[i]; });
         else
-            tree_rne_lane<NG, false, SIG, TOPO, SIG2>(t->groups.data(), t->nslots, g, [&](int k) { return a[k]; }, [&](int k) { return b ? b[k] : 0.0; },
+            tree_rne_lane<NG, false, TreeKnown<SIG, TOPO, SIG2>>(t->groups.data(), t->nslots, g, [&](int k) { return a[k]; }, [&](int k) { return b ? b[k] : 0.0; },
                               [&](int k) { return c[k]; }, [&](int k, double v) { o[k] = v; },
                               [&](int i) -> double & { return slots[i]; });
     }

@@ -12,7 +12,7 @@ static void tree_dyn_run(const Tree *t, const double *q, const double *qd, const
     for (int64_t s = 0; s < N; ++s) {
         double mine[3 * NG], A[NG * NG + NG];
         for (int j = 0; j < NG; ++j) { mine[j] = q[s * NG + j]; mine[NG + j] = qd ? qd[s * NG + j] : 0.0; mine[2 * NG + j] = tq ? tq[s * NG + j] : 0.0; }
-        tree_dyn_lane<NG, MODE, SIG, TOPO, SIG2>(t->groups.data(), t->nslots, mine, A, g, [&](int i) -> double & { return slots[i]; });
+        tree_dyn_lane<NG, MODE, TreeKnown<SIG, TOPO, SIG2>>(t->groups.data(), t->nslots, mine, A, g, [&](int i) -> double & { return slots[i]; });
         if (MODE == kDynInertia) {                  // the kernel's flush: packed lower triangle -> the full symmetric matrix, rows where the reference has them
             for (int r0 = 0; r0 < NG; ++r0) {
                 const int r = tree_row_position<NG>(t->groups.data(), r0);

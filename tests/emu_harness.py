@@ -13,7 +13,7 @@ PKG = os.path.join(ROOT, "robotics-toolbox-python_amd")
 EMU_SO = os.path.join(ROOT, "tests", "emu", "libemu.so")
 SRCS = ["tests/emu/" + f for f in ("emu_kin.cpp", "emu_ik_seq.cpp", "emu_ik_wave_a.cpp", "emu_ik_wave_b.cpp", "emu_ik_wave_c.cpp", "emu_rne.cpp", "emu_dyn_a.cpp", "emu_dyn_b.cpp", "emu_dyn_c.cpp", "emu_dyn_d.cpp", "emu_dyn_e.cpp", "emu_dyn_f.cpp",
                                    "emu_misc.cpp", "emu_tree_big.cpp", "emu_diffjac.cpp")] + ["robotics-toolbox-python_amd/csrc/" + f for f in
-                                ("api.cpp", "chain.cpp", "tree.cpp", "hostpipe.cpp", "shard.cpp", "kin_kernels.hip", "rne_kernels.hip", "ik_kernels.hip", "dyn_kernels.hip",
+                                ("api.cpp", "chain.cpp", "tree.cpp", "hostpipe.cpp", "shard.cpp", "jit.cpp", "kin_kernels.hip", "rne_kernels.hip", "ik_kernels.hip", "dyn_kernels.hip",
                                  "tree_kernels.hip", "tree_dyn_kernels.hip", "partial_kernels.hip", "frames_kernels.hip", "diffjac_kernels.hip")]
 _vp, _u64, _i64, _i32 = C.c_void_p, C.c_uint64, C.c_int64, C.c_int32
 _lib = None
@@ -87,6 +87,7 @@ def build():
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(one, [x for x in SRCS if x.startswith("tests/emu/")]))
     prod = [os.path.join(ROOT, "build", "obj", os.path.basename(x) + ".o") for x in SRCS if not x.startswith("tests/emu/")]
+    prod.append(os.path.join(ROOT, "build", "obj", "jit_sources.cpp.o"))       # generated by the product build (the sources csrc/jit.cpp hands to hipRTC)
     missing = [o for o in prod if not os.path.exists(o)]
     if missing:                                  # a prebuilt library travelled without its objects: compile them
         g.build_lib(force=True)

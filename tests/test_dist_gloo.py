@@ -129,6 +129,56 @@ def test_bench_gather_ms_world8_uneven_shards():
         assert ok, "rank %d: %s" % (rank, err)
 
 
+def _timed_steps_worker(rank, world, port, q):
+    """benchlib.Ranks.timed_steps on host ranks whose steps take rank-dependent time: rank r sleeps (r + 1) ms per step."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        sys.path[:0] = [ROOT, os.path.join(ROOT, "robotics-toolbox-python_amd")]
+        import time
+        import benchlib
+        rk = object.__new__(benchlib.Ranks)
+        rk.world, rk.rank, rk.local, rk.backend, rk.dist, rk.shared, rk.forced = world, rank, rank, "gloo", dist, False, False
+        rk.dev = torch.device("cpu")
+        K = 10
+        elapsed, _ = rk.timed_steps(lambda: time.sleep(1e-3 * (rank + 1)), K, 1)
+        q.put((rank, True, (elapsed, rk.last_own_elapsed, rk.last_elapsed_with_barrier)))
+        dist.destroy_process_group()
+    except Exception:                       # noqa: BLE001
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+
+
+def test_timed_region_has_no_collective_world8():
+    """The figure `value` is made from is MAX over ranks of (t0 -> the rank's OWN synchronize); the closing barrier comes after t1.  Eight host
+    ranks whose steps take (rank + 1) ms: every rank's own clock is its own work (not the slowest rank's), the returned figure is the slowest
+    rank's own clock on every rank, and the barrier-inclusive figure is kept beside it and is not smaller."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_timed_steps_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, err in res:
+        assert ok, "rank %d: %s" % (rank, err)
+    res.sort()
+    slowest_own = max(v[1] for _, _, v in res)
+    for rank, _, (elapsed, own, with_barrier) in res:
+        assert elapsed == pytest.approx(slowest_own, rel=1e-12)           # MAX over ranks of the OWN clocks, the same on every rank
+        assert with_barrier >= elapsed                                    # the closing barrier is outside t1 - t0
+        assert 10e-3 * (rank + 1) <= own < 10e-3 * (rank + 1) + 8e-3      # a fast rank's clock does not wait for the slow ranks
+    assert res[0][2][1] < 0.5 * res[7][2][1]
+    import benchlib
+    import inspect
+    body = inspect.getsource(benchlib.Ranks.timed_steps)
+    t1 = body.index("elapsed = time.perf_counter() - t0")
+    assert body.index("self.barrier()") < body.index("t0 = time.perf_counter()") < t1 < body.rindex("self.barrier()")
+    assert "ms_per_step_with_barrier" in open(os.path.join(ROOT, "bench.py")).read()
+
+
 def test_gather_buffer_lives_outside_the_timed_region():
     """Structure of the bench scripts, checked on their source: the receive buffer of the output gather is allocated inside Ranks.gather_ms,
     which bench.py calls after Ranks.timed_steps has returned `elapsed` and before the cpu_baseline / secondary legs (which start only after

@@ -66,7 +66,10 @@ def test_a_user_step_is_looped_as_the_reference_loops_it():
     assert sol.success and sol.searches == 1 and 2 <= sol.iterations <= 60 and calls["n"] == sol.iterations
     assert np.abs(np.asarray(ets.eval(sol.q)) - Tep).max() < 2e-3 and sol.residual < 1e-6 and sol.reason == "Success"
     many = Half(ilimit=60, slimit=2, seed=1).solve(ets, np.stack([Tep, Tep]), q0=q_true + 0.1)
-    assert len(many) == 2 and all(s.success for s in many)
+    # a stack of targets comes back as ONE solution, as the reference's `traj` branch returns it (robot/IK.py:262-287): q (N, n), success = all,
+    # iterations / searches summed, the smallest residual
+    assert many.q.shape == (2, ets.n) and many.success is True and many.searches == 2 and many.iterations == 2 * sol.iterations
+    assert many.residual == sol.residual and np.array_equal(many.q[0], sol.q) and list(many.each["success"]) == [True, True]
     # the built-in classes keep the device loop: no host iteration
     calls["n"] = 0
     assert rik.IK_LM(seed=1).solve(ets, Tep, q0=q_true + 0.1).success and calls["n"] == 0

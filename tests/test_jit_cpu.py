@@ -1,0 +1,129 @@
+"""Run-time instantiation of the structure-signature kernels (csrc/jit.cpp), the part that needs no GPU: hipRTC cross-compiles for gfx950 here.
+
+What is pinned: the sources embedded in the library compile under hipRTC for one instantiation of every kernel family (the launch is covered by
+tests/test_jit_gpu.py on the device); which robots ask for a run-time instantiation and which are served by a built-in one; the generated
+knowledge type of a link tree (any size: YuMi's 18 groups, the Kinova Gen3's 13); the disk cache (second compile = a read); the library loads
+and serves without hipRTC.  The reference has one general code path for every robot (core/methods.cpp:318-352, core/ne.c:62-493,
+robot/Robot.py:1704-1903): the instantiations only change the cost, never the result -- that half is tested on the GPU, bit for bit."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import rtbhip
+from rtbhip import jit
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def have_rtc():
+    if not jit.stats()["available"]:
+        pytest.skip("libhiprtc.so is not on this box")
+    return True
+
+
+def perturbed_panda():
+    """the DH Panda of models/DH/Panda.py with one alpha perturbed: a link table no built-in instantiation matches"""
+    p = rtbhip.models.DH.Panda()
+    links = list(p.links)
+    links[3] = rtbhip.RevoluteMDH(a=links[3].a, d=links[3].d, alpha=links[3].alpha + 0.01, m=links[3].m, r=links[3].r, I=links[3].I, G=1)
+    return rtbhip.DHRobot(links, name="panda-perturbed")
+
+
+def test_library_reports_the_embedded_sources():
+    s = jit.stats()
+    assert s["sources"] >= 20 and len(s["source_digest"]) == 16 and s["mode"] == 1 and s["pending"] == 0
+
+
+def test_builtin_robots_ask_for_nothing():
+    assert jit.names(rtbhip.models.Panda().ets())[0] == []                     # kIkSigPandaETS
+    assert jit.names(rtbhip.models.DH.Panda())[0] == []                        # kRneSigPanda
+    assert jit.names(rtbhip.models.DH.Puma560())[0] == []                      # kRneSigPuma560
+    assert jit.names(rtbhip.urdf.load("UR5").erobot())[0] == []                # kTreeSigUR
+
+
+def test_other_robots_ask_for_their_own():
+    exprs, pre = jit.names(perturbed_panda())
+    assert len(exprs) == 5 and pre == "" and exprs[0].startswith("rtbhip::k_rne<7, true, true, 0x") and "k_rne_atrest<7, true, 0x" in exprs[1]
+    assert [e.split("<")[0] for e in exprs[2:]] == ["rtbhip::k_dyn"] * 3
+    # a chain: every plain (all-revolute, unflipped) chain of up to 8 joints
+    E = rtbhip.ET
+    ets = rtbhip.ETS([E.tz(0.3), E.Rz(), E.Ry(0.2), E.tx(0.4), E.Rz(), E.Rx(np.pi / 2), E.Rz(), E.tz(0.1)])
+    exprs, _ = jit.names(ets)
+    assert len(exprs) == 2 and exprs[0].startswith("rtbhip::k_ik<3, 0, 13, 0x") and exprs[1].startswith("rtbhip::k_ik<3, 0, 12, 0x")
+    assert jit.names(rtbhip.ETS([E.tz(0.3), E.Rz(), E.tx(0.4), E.tz()]))[0] == []        # a prismatic joint: the general walk
+    # the LBR iiwa from its URDF (7 revolute joints)
+    lbr = rtbhip.urdf.load("LBR")
+    assert len(jit.names(lbr.ets())[0]) == 2
+
+
+@pytest.mark.parametrize("name,groups", [("KinovaGen3", None), ("YuMi", None), ("LBR", None)])
+def test_tree_knowledge_type(name, groups, have_rtc):
+    tree = rtbhip.urdf.load(name).erobot()
+    exprs, pre = jit.names(tree)
+    n = tree.n
+    assert exprs and exprs[0].startswith("rtbhip::k_tree_rne<%d, false, rtbhip::JitTree%d_" % (n, n))
+    assert "struct JitTree%d_" % n in pre and "static constexpr bool known = true" in pre and pre.count("RTB_HD static constexpr") >= 8
+    # the same structure gives the same type name (it is a hash of the body): a second robot object of the same file agrees
+    assert jit.names(rtbhip.urdf.load(name).erobot())[0] == exprs
+    # and the generated source compiles with the kernel it parametrises
+    cb, sec, _ = jit.compile_now("tree_kernels.hip", exprs[0], preamble=pre)
+    assert cb > 4000
+    dyn = [e for e in exprs if "k_tree_dyn" in e]
+    if dyn:
+        cb, sec, _ = jit.compile_now("tree_dyn_kernels.hip", dyn[-1], preamble=pre)
+        assert cb > 4000
+
+
+def test_every_family_compiles_under_hiprtc(have_rtc):
+    exprs, _ = jit.names(perturbed_panda())
+    for e in exprs:
+        cb, sec, _ = jit.compile_now("dyn_kernels.hip" if "k_dyn" in e else "rne_kernels.hip", e)
+        assert cb > 4000, e
+    for e in jit.names(rtbhip.urdf.load("LBR").ets())[0]:
+        cb, sec, _ = jit.compile_now("ik_kernels.hip", e)
+        assert cb > 20000, e
+
+
+def test_disk_cache_and_missing_compiler(tmp_path):
+    """a fresh process, its own cache directory: the first compile is hipRTC's, the second is a file read; RTBHIP_JIT_CACHE=- turns the cache off;
+    a bad name expression fails with the compiler's message and the library stays usable."""
+    code = r"""
+import sys
+sys.path[:0] = [%r, %r]
+import rtbhip
+from rtbhip import jit
+e = "rtbhip::k_rne<3, false, true, 0x%%xull>" %% ((1 << 63) | (1 << 62) | (1 << 61) | 0x1 | (0x2 << 7) | (0x3 << 14))
+a = jit.compile_now("rne_kernels.hip", e)
+b = jit.compile_now("rne_kernels.hip", e)
+print("first", a[2], "second", b[2], a[0] == b[0])
+try:
+    jit.compile_now("rne_kernels.hip", "rtbhip::no_such_kernel<1>")
+    print("bad: compiled")
+except rtbhip.RtbHipError as ex:
+    print("bad: refused", "no_such_kernel" in str(ex))
+print("names", len(jit.names(rtbhip.models.DH.Puma560())[0]))
+""" % (ROOT, os.path.join(ROOT, "robotics-toolbox-python_amd"))
+    env = dict(os.environ, RTBHIP_JIT_CACHE=str(tmp_path / "cache"))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    if "first False second True True" not in out.stdout:
+        assert not jit.stats()["available"], out.stdout
+    else:
+        assert "bad: refused True" in out.stdout and "names 0" in out.stdout
+        assert len(list((tmp_path / "cache").glob("*.hsaco"))) == 1
+        env["RTBHIP_JIT_CACHE"] = "-"
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert "first False second False True" in out.stdout, out.stdout + out.stderr[-1000:]
+
+
+def test_create_does_not_touch_the_device():
+    """constructing robots must not initialise the HIP runtime or start compiling: the requests of *_create wait until the library has used a
+    device in this process (jit.cpp: jit_request)"""
+    before = jit.stats()["requested"]
+    perturbed_panda()._dyn_handle()
+    rtbhip.urdf.load("KinovaGen3").erobot()._handle()
+    assert jit.stats()["requested"] == before

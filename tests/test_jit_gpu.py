@@ -1,0 +1,152 @@
+"""Run-time instantiation of the structure-signature kernels on the device (csrc/jit.cpp; the part without a GPU: tests/test_jit_cpu.py).
+
+A robot whose structure matches no instantiation built into the library gets its own -- the same hand-written kernel sources compiled by hipRTC
+with the robot's structure as template arguments.  The reference has ONE general path for every robot (core/methods.cpp:318-352,
+core/ik.cpp:19-75, core/ne.c:62-493, robot/Robot.py:1704-1903), so what must hold is: the run-time kernel returns what the general kernel
+returns -- bit for bit, by construction of the structured forms (kin_device.h: dotk; rne_device.h; tree_device.h) -- and what the oracle returns
+to the usual tolerance; until the code object is there the general kernel serves and nobody can tell from the numbers."""
+import numpy as np
+import numpy.testing as nt
+import pytest
+
+import rtbhip
+from rtbhip import jit, urdf
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _modes():
+    yield
+    for k, v in (("jit", 1), ("rne_sig", 1), ("tree_sig", 1), ("ik_sig", 1)):
+        rtbhip.tune(k, v)
+
+
+def need_rtc():
+    if not jit.stats()["available"]:
+        pytest.skip("libhiprtc.so is not on this box: the general kernels serve (covered by every other test)")
+
+
+def perturbed_panda(dalpha=0.01):
+    p = rtbhip.models.DH.Panda()
+    links = list(p.links)
+    k = links[3]
+    links[3] = rtbhip.RevoluteMDH(a=k.a, d=k.d, alpha=k.alpha + dalpha, m=k.m, r=k.r, I=k.I, G=1)
+    return rtbhip.DHRobot(links, name="panda-perturbed")
+
+
+def _dh_calls(rob, q, qd, qdd, g):
+    return {"rne": rob.rne(q, qd, qdd, gravity=g), "gravload": rob.gravload(q, gravity=g), "itorque": rob.itorque(q, qdd),
+            "inertia": rob.inertia(q), "coriolis": rob.coriolis(q, qd), "accel": rob.accel(q, qd, qdd, gravity=g)}
+
+
+def test_dh_robot_without_builtin_instantiation():
+    need_rtc()
+    rob = perturbed_panda()
+    assert len(jit.names(rob)[0]) == 5
+    rng = np.random.default_rng(5)
+    N = 3001
+    q, qd, qdd = rng.uniform(-3, 3, (N, 7)), rng.normal(size=(N, 7)), rng.normal(size=(N, 7))
+    g = np.array([0.2, -0.1, 9.81])
+    rtbhip.tune("jit", 2)                     # a launch waits for its instantiation
+    s0 = jit.stats()
+    fast = {k: np.asarray(v) for k, v in _dh_calls(rob, q, qd, qdd, g).items()}
+    s1 = jit.stats()
+    assert s1["launches"] - s0["launches"] >= 6 and s1["failed"] == s0["failed"], s1
+    assert (s1["compiled"] + s1["disk_hits"]) - (s0["compiled"] + s0["disk_hits"]) >= 5
+    rtbhip.tune("rne_sig", 0)                 # the general kernels
+    general = {k: np.asarray(v) for k, v in _dh_calls(rob, q, qd, qdd, g).items()}
+    assert jit.stats()["launches"] == s1["launches"]
+    for k in fast:
+        nt.assert_array_equal(fast[k], general[k], err_msg=k)       # the same bits
+    # and the oracle (core/ne.c restated)
+    ref = oracle.rne_dh(rob.L24(), 1, q[:400], qd[:400], qdd[:400], -g)
+    assert np.abs(fast["rne"][:400] - ref).max() / max(1.0, np.abs(ref).max()) <= 1e-9
+
+
+def test_asynchronous_mode_is_invisible_in_the_results():
+    need_rtc()
+    rob = perturbed_panda(0.02)               # another structure? no: alpha's class is the same -- another TABLE, the same signature; a cache hit at most
+    rob2 = perturbed_panda(0.02)
+    rng = np.random.default_rng(6)
+    q, qd, qdd = rng.uniform(-3, 3, (2000, 7)), rng.normal(size=(2000, 7)), rng.normal(size=(2000, 7))
+    rtbhip.tune("jit", 1)
+    first = np.asarray(rob.rne(q, qd, qdd))   # general or run-time kernel, whichever is there
+    assert jit.wait(120)
+    second = np.asarray(rob.rne(q, qd, qdd))
+    third = np.asarray(rob2.rne(q, qd, qdd))
+    nt.assert_array_equal(first, second)
+    nt.assert_array_equal(first, third)
+    st = jit.stats()
+    assert st["pending"] == 0 and st["launches"] >= 2
+
+
+@pytest.mark.parametrize("name,end", [("LBR", None), ("Puma560", None), ("px100", None), ("Mico", None)])
+def test_ik_of_robots_without_builtin_instantiation(name, end):
+    need_rtc()
+    e = urdf.load(name).ets(end=end)
+    exprs = jit.names(e)[0]
+    assert len(exprs) == 2, (name, exprs)
+    lim = np.clip(e.qlim, -2.8, 2.8)
+    T = np.asarray(e.eval(np.random.default_rng(11).uniform(lim[0], lim[1], (3000, e.n))))
+    rtbhip.tune("jit", 2)
+    s0 = jit.stats()
+    fast = e.ik_LM(T, seed=4)
+    s1 = jit.stats()
+    assert s1["launches"] > s0["launches"] and s1["failed"] == s0["failed"], s1
+    rtbhip.tune("ik_sig", 0)
+    general = e.ik_LM(T, seed=4)
+    assert jit.stats()["launches"] == s1["launches"]
+    for x, y in zip(fast, general):
+        nt.assert_array_equal(np.asarray(x), np.asarray(y))          # q, success, iterations, searches, residual: the same bits
+    ok = np.asarray(fast[1]) == 1
+    assert ok.mean() > 0.5
+    Tq = np.asarray(e.eval(np.asarray(fast[0])[ok]))
+    assert np.abs(Tq - T[ok]).max() < 1e-4                           # the solutions reach their targets
+
+
+def _tree_calls(t, q, qd, qdd, g):
+    out = {"rne": t.rne(q, qd, qdd, gravity=g), "gravload": t.gravload(q, gravity=g)}
+    if t.n <= 20:
+        out.update(inertia=t.inertia(q), coriolis=t.coriolis(q, qd), accel=t.accel(q, qd, qdd, gravity=g))
+    return out
+
+
+@pytest.mark.parametrize("name", ["KinovaGen3", "YuMi", "LBR", "Panda", "AL5D", "Puma560"])
+def test_link_trees_without_builtin_instantiation(name):
+    need_rtc()
+    t = urdf.load(name).erobot()
+    exprs, pre = jit.names(t)
+    assert exprs and "JitTree%d_" % t.n in pre
+    rng = np.random.default_rng(7)
+    N, n = 1500, t.n
+    q, qd, qdd = rng.uniform(-2, 2, (N, n)), rng.normal(size=(N, n)), rng.normal(size=(N, n))
+    g = np.array([0.1, 0.2, 9.81])
+    rtbhip.tune("jit", 2)
+    s0 = jit.stats()
+    fast = {k: np.asarray(v) for k, v in _tree_calls(t, q, qd, qdd, g).items()}
+    s1 = jit.stats()
+    assert s1["launches"] - s0["launches"] >= len(fast) and s1["failed"] == s0["failed"], s1
+    rtbhip.tune("tree_sig", 0)
+    general = {k: np.asarray(v) for k, v in _tree_calls(t, q, qd, qdd, g).items()}
+    assert jit.stats()["launches"] == s1["launches"]
+    for k in fast:
+        nt.assert_array_equal(fast[k], general[k], err_msg="%s %s" % (name, k))
+    # (the general tree kernels against the oracle / the reference: tests/test_erobot_rne.py, test_erobot_dynamics.py -- the evidence transfers)
+
+
+def test_jit_off_and_stats():
+    need_rtc()
+    rob = perturbed_panda()
+    q = np.random.default_rng(1).uniform(-3, 3, (500, 7))
+    rtbhip.tune("jit", 0)
+    s0 = jit.stats()
+    a = np.asarray(rob.gravload(q))
+    assert jit.stats()["launches"] == s0["launches"] and jit.stats()["mode"] == 0
+    rtbhip.tune("jit", 2)
+    b = np.asarray(rob.gravload(q))
+    assert jit.stats()["launches"] == s0["launches"] + 1
+    nt.assert_array_equal(a, b)
+    st = jit.stats()
+    assert st["compile_seconds_max"] < 60 and st["last_error"] == ""
