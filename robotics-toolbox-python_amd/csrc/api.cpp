@@ -970,10 +970,10 @@ static int ik_entry(rtbhip_chain_t chain, const double *Tep, int64_t N, const do
     p.ilimit = ilimit; p.slimit = slimit; p.reject_jl = reject_jl ? 1 : 0; p.method = method;
     p.flavour = flavour; p.tol = tol; p.lambda = lambda; p.seed = seed;
     p.kq = kq; p.km = km; p.ps = ps; p.ks = ks; p.target0 = t_ik_target_base;
-    for (int j = 0; j < 16; ++j) p.pi[j] = pi ? pi[j < c->n ? j : (c->n > 0 ? c->n - 1 : 0)] : 0.3;      // NULL: the reference's default
+    for (int j = 0; j < RTBHIP_MAX_JOINTS; ++j) p.pi[j] = pi ? pi[j < c->n ? j : (c->n > 0 ? c->n - 1 : 0)] : 0.3;      // NULL: the reference's default
     if (kq > 0.0 && flavour != 1) { set_error("ik_lm: null-space terms belong to the Python solvers (flavour 1)"); return RTBHIP_EINVAL; }
     if (kq > 0.0)
-        for (int j = 0; j < c->n && j < 16; ++j)
+        for (int j = 0; j < c->n && j < RTBHIP_MAX_JOINTS; ++j)
             if (ps == p.pi[j]) { set_error("ik_lm: ps must differ from pi"); return RTBHIP_EINVAL; }
     for (int i = 0; i < 6; i++) p.we[i] = we6 ? we6[i] : 1.0;
     RTB_TRY(ik_check_limits(c, p, N));                 // what the device build refuses, before the device is touched

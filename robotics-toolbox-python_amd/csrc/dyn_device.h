@@ -7,6 +7,8 @@
 #include "ldl.h"
 
 namespace rtbhip {
+#pragma clang fp contract(off)      // every operation written out, as in rne_device.h (why: there)
+
 
 enum { kDynInertia = 0, kDynCoriolis = 1, kDynAccel = 2 };
 // accel keeps M as a packed lower triangle -- except for modified-DH chains with prismatic joints, whose reference matrix can be unsymmetric
@@ -355,4 +357,5 @@ RTB_HD void dyn_lane(LinksP links, const double *mine, double *mA, V3 grav, cons
     }
 }
 
+#pragma clang fp contract(fast)
 }  // namespace rtbhip

@@ -22,6 +22,7 @@ struct DynParams {
     int32_t n, mode;
     int64_t N;
     double grav[3];
+    int32_t tile, pad_;      // configurations per single-wave workgroup: 64, or fewer where the (n, n) tiles of 64 lanes exceed a CU's LDS (n > 16)
 };
 
 
@@ -104,11 +105,12 @@ __global__ __launch_bounds__(kDW, (NJ <= 8 ? 2 : 1)) void k_dyn(DynParams dp, co
     typedef DynLayout<NJ, MODE, ALLREV, MDH> L;
     ConstLinksD links = (ConstLinksD)links_g;
     const int lane = threadIdx.x;
-    const int64_t cfg0 = (int64_t)blockIdx.x * kDW;
+    const int T = dp.tile;
+    const int64_t cfg0 = (int64_t)blockIdx.x * T;
     const int64_t left = dp.N - cfg0;
-    const int ncfg = left < kDW ? (int)left : kDW;
+    const int ncfg = left < T ? (int)left : T;
     const int count = ncfg * NJ;
-    double *A = lds + (L::alias_in || L::alias_all ? 0 : kDW * L::in_stride);   // n x n tile: M (inertia, accel) or C (coriolis)
+    double *A = lds + (L::alias_in || L::alias_all ? 0 : T * L::in_stride);   // n x n tile: M (inertia, accel) or C (coriolis)
     double *in = (L::alias_in || L::alias_all) ? A : lds;
     constexpr int in_stride = (L::alias_in || L::alias_all) ? L::w_stride : L::in_stride;
     if (MODE == kDynInertia) { const double *const src[1] = {q}; dyn_load<NJ, 1>(in, in_stride, src, cfg0, count, lane); }
@@ -200,15 +202,54 @@ static hipError_t launch_nj(const Dyn *d, int mode, bool mdh, bool allrev, dim3 
     return launch_mode<NJ, kDynAccel>(d, mdh, allrev, grid, s, dp, links, q, qd, tq, out, lds, sig);
 }
 
+// Chains of 17 .. RTBHIP_MAX_JOINTS joints: no built-in instantiation -- the same k_dyn template instantiated at run time (jit.cpp; the caller waits:
+// seconds to a minute on first use, a file read afterwards), on tiles of fewer than 64 configurations where 64 (n, n) tiles do not fit a CU's
+// LDS.  Served, not fast; the reference's loops take any n (robot/Dynamics.py:704-861, 424-509).
+static int launch_dyn_runtime_size(const Dyn *d, const DevLink *links, int mode, const double *q, const double *qd, const double *tq, int64_t N,
+                                   const double *grav3, double *out, hipStream_t s)
+{
+    const int n = d->n;
+    const bool mdh = d->mdh != 0;
+    bool allrev = true;
+    for (const DevLink &l : d->links) allrev = allrev && l.sigma == 0;
+    // DynLayout's arithmetic for a run-time n (the kernel has it at compile time)
+    const int K = mode == kDynInertia ? 1 : (mode == kDynCoriolis ? 2 : 3);
+    const bool alias_in = mode == kDynInertia && allrev;
+    const bool alias_all = (mode == kDynAccel && allrev && 3 * n <= n * (n + 1) / 2) || (mode == kDynCoriolis && allrev && n >= 2);
+    const int in_stride = (((mode == kDynCoriolis || mode == kDynAccel) && allrev ? K - 1 : K) * n) | 1;
+    const bool full_tile = mdh && !allrev;                                                  // kDynFullTile<MDH, ALLREV> (dyn_device.h)
+    const bool packed = (mode == kDynAccel && !full_tile) || (mode == kDynInertia && allrev);
+    const int W = packed ? (n * (n + 1) / 2 > n ? n * (n + 1) / 2 : n) : n * n;
+    const size_t per_lane = (size_t)((alias_in || alias_all ? 0 : in_stride) + (W | 1)) * sizeof(double);
+    int tile = kDW;
+    while (tile > 8 && per_lane * tile > 160 * 1024) tile /= 2;
+    const size_t lds = per_lane * tile;
+    if (lds > 160 * 1024) { set_error("inertia/coriolis/accel: the chain needs more LDS than a CU has"); return RTBHIP_ELIMIT; }
+    const int64_t tiles = (N + tile - 1) / tile;
+    if (tiles > 0x7fffffff) { set_error("inertia/coriolis/accel: batch too large for one launch"); return RTBHIP_ELIMIT; }
+    DynParams dp;
+    dp.n = n; dp.mode = mode; dp.N = N; dp.tile = tile; dp.pad_ = 0;
+    for (int i = 0; i < 3; i++) dp.grav[i] = grav3 ? grav3[i] : 0.0;
+    hipFunction_t f = d->jit.get_wait("dyn_kernels.hip", 8 + mode, [&] {
+        return "rtbhip::k_dyn<" + std::to_string(n) + ", " + (mdh ? "true" : "false") + ", " + std::to_string(mode) + ", " + (allrev ? "true" : "false") + ", 0>"; });
+    if (!f) return RTBHIP_ELIMIT;
+    void *args[] = {(void *)&dp, (void *)&links, (void *)&q, (void *)&qd, (void *)&tq, (void *)&out};
+    const int rc = jit_launch(f, dim3((unsigned)tiles), dim3(kDW), lds, s, args);
+    if (rc != RTBHIP_OK) return rc;
+    note_launch((int)tiles, kDW, (int)lds);
+    return RTBHIP_OK;
+}
+
 int launch_dyn(const Dyn *d, const DevLink *links, int mode, const double *q, const double *qd, const double *tq,
                int64_t N, const double *grav3, double *out, hipStream_t s)
 {
     if (N == 0) return RTBHIP_OK;
-    if (d->n > kDynMaxJoints) { set_error("inertia/coriolis/accel: this build handles chains of up to 16 joints on the device"); return RTBHIP_ELIMIT; }
+    if (d->n > RTBHIP_MAX_JOINTS) { set_error("inertia/coriolis/accel: more than RTBHIP_MAX_JOINTS joints"); return RTBHIP_ELIMIT; }
+    if (d->n > kDynMaxJoints) return launch_dyn_runtime_size(d, links, mode, q, qd, tq, N, grav3, out, s);
     const int64_t tiles = (N + kDW - 1) / kDW;
     if (tiles > 0x7fffffff) { set_error("inertia/coriolis/accel: batch too large for one launch"); return RTBHIP_ELIMIT; }
     DynParams dp;
-    dp.n = d->n; dp.mode = mode; dp.N = N;
+    dp.n = d->n; dp.mode = mode; dp.N = N; dp.tile = kDW; dp.pad_ = 0;
     for (int i = 0; i < 3; i++) dp.grav[i] = grav3 ? grav3[i] : 0.0;
     dim3 grid((unsigned)tiles);
     const bool mdh = d->mdh != 0;

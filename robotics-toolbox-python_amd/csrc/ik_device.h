@@ -55,7 +55,7 @@ struct IkDev {   // wave-uniform solver parameters (kernarg)
     uint64_t seed;
     int64_t N;
     double kq, km, ps;               // null-space terms of the Python solvers (IK.py:507-576); kq <= 0: none
-    double pi[16];                   // ... the influence distance, one per joint (IK.py:507-540 and :1441-1442 accept a scalar or an array)
+    double pi[RTBHIP_MAX_JOINTS];    // ... the influence distance, one per joint (IK.py:507-540 and :1441-1442 accept a scalar or an array)
     double ks;                       // IK_QP (method 5): slack gain; its joint-velocity gain kj travels in `lambda`
     int64_t target0;                 // added to a target's row number where it keys the restart generator (rtbhip_ik_target_base):
                                      // a row block of a larger batch then draws what the whole batch would have drawn for those targets
@@ -721,7 +721,8 @@ struct alignas(16) IkWaveSharedT {
     double Td[12][64];                      // per SLOT: the target pose (read by every lane working on the slot)
     double q[QR][64];                       // per LANE: the joint vector of that search
 };
-template <int NJ> using IkWaveSharedFor = IkWaveSharedT<(RTB_IK_QROWS_EXACT ? NJ : (NJ <= kRegMaxJoints ? kRegMaxJoints : kIkMaxJoints))>;
+// q rows by joint-count class: 8 (the register-resident kernels), 16 (the other built-in sizes), RTBHIP_MAX_JOINTS (sizes instantiated at run time)
+template <int NJ> using IkWaveSharedFor = IkWaveSharedT<(RTB_IK_QROWS_EXACT ? NJ : (NJ <= kRegMaxJoints ? kRegMaxJoints : (NJ <= kIkMaxJoints ? kIkMaxJoints : RTBHIP_MAX_JOINTS)))>;
 static_assert(sizeof(IkWaveSharedT<kRegMaxJoints>) * 8 <= 160 * 1024, "8 IK waves per CU must fit the LDS");
 
 // A work item: searches s0 .. s1 (inclusive, in the flavour's own numbering) of target `tgt`.  Without a work list item v is

@@ -685,15 +685,16 @@ int ik_check_limits(const Chain *c, const IkParams &ip, int64_t N)
     if (ip.slimit > kIkMaxSlimit) { set_error("ik_lm: slimit above 32000 is not supported by the device scheduler"); return RTBHIP_ELIMIT; }
     if (N >= (1ll << 32)) { set_error("ik_lm: at most 2^32 - 1 targets per call"); return RTBHIP_ELIMIT; }
     if (ip.ilimit > kIkMaxIlimit) { set_error("ik_lm: ilimit above 16000 is not supported by the device scheduler"); return RTBHIP_ELIMIT; }
-    if (c->n > kIkMaxJoints) { set_error("ik_lm: this build solves chains of up to 16 joints on the device"); return RTBHIP_ELIMIT; }
+    // (chains of up to kIkMaxJoints joints have built-in kernels; longer ones -- up to RTBHIP_MAX_JOINTS -- get theirs at run time: launch_ik)
+    if (c->n > RTBHIP_MAX_JOINTS) { set_error("ik_lm: more than RTBHIP_MAX_JOINTS joints"); return RTBHIP_ELIMIT; }
     for (int j = 0; j < c->n; ++j)
         if (jm_jq(c->jmeta[j]) != j) { set_error("ik_lm: jindex must equal the joint order (the reference's ik.cpp:57 adds dq in that order)"); return RTBHIP_EINVAL; }
-    if (ip.method == 5 && (ip.km > 0.0 || ip.kq > 0.0) && (c->n > kIkNullMax || c->n < 6)) {
+    if (ip.method == 5 && (ip.km > 0.0 || ip.kq > 0.0) && c->n < 6) {
         // IK_QP (ik_device.h): the manipulability term needs J J^T invertible, and both live in the one-wave-per-SIMD step variants
         set_error("ik_qp: the manipulability term (km > 0) and the joint-limit rows (kq > 0) are built for chains of 6..12 joints");
         return RTBHIP_ELIMIT;
     }
-    if (ip.method != 5 && ip.kq > 0.0 && (c->n > kIkNullMax || c->n < 6)) {
+    if (ip.method != 5 && ip.kq > 0.0 && c->n < 6) {
         // below 6 joints I - pinv(J) J vanishes only away from singularities; the reference still applies it there, so the
         // parameters are refused rather than silently dropped
         set_error("ik_lm: null-space terms (kq > 0) are built for chains of 6..12 joints");
@@ -719,7 +720,7 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
     p.seed = ip.seed; p.target0 = ip.target0;
     p.N = N;
     p.kq = ip.kq; p.km = ip.km; p.ps = ip.ps; p.ks = ip.ks;
-    for (int j = 0; j < 16; ++j) p.pi[j] = ip.pi[j];
+    for (int j = 0; j < RTBHIP_MAX_JOINTS; ++j) p.pi[j] = ip.pi[j];
     p.flat_chunks = 0; p.flat_l0 = 0; p.flat_len = 0; p.flat_n = 0; p.flat_done = nullptr; p.stats = nullptr;
     int dev = 0, cus = 0;
     RTB_HIP(hipGetDevice(&dev));
@@ -766,6 +767,20 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
             p2.stats = dstats;
         }
         dim3 grid((unsigned)g);
+        // a SIZE without a built-in instantiation -- a chain of 17 .. RTBHIP_MAX_JOINTS joints, the null-space / IK_QP step variants beyond 12 --
+        // gets its kernel at run time: the same k_ik template, its joint count a template argument as ever, compiled by hipRTC on first use
+        // (seconds to a minute, then a file read: jit.cpp).  The reference loops over any n (robot/IK.py:542-576, core/ik.cpp:19-75).
+        const int variant = ik_step_variant(p2, n);
+        if (n > kIkMaxJoints || ((variant == 2 || variant == 3) && n > kIkNullMax)) {
+            const int V = (variant == 2 || variant == 3) ? variant : ((variant & kIkStepPinv) ? 1 : 0);
+            hipFunction_t f = c->jit.get_wait("ik_kernels.hip", 16 + V, [&] { return "rtbhip::k_ik<" + std::to_string(n) + ", " + std::to_string(V) + ", 0, 0>"; });
+            if (!f) return RTBHIP_ELIMIT;                       // (the reason is in rtbhip_last_error: no hipRTC on this box, or the compiler's message)
+            void *args[] = {(void *)&p2, (void *)&dc, (void *)&qlim, (void *)&Tep, (void *)&q0, (void *)&ctr, (void *)&qo, (void *)&ok, (void *)&it, (void *)&se,
+                            (void *)&E, (void *)&work, (void *)&count, (void *)&share};
+            RTB_TRY_IK(jit_launch(f, grid, dim3(kWave), 0, s, args));
+            note_launch((int)grid.x, kWave, 0);
+            return RTBHIP_OK;
+        }
         switch (n) {
         case 1: launch_nj<1>(c, grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;
         case 2: launch_nj<2>(c, grid, s, p2, dc, qlim, Tep, q0, ctr, qo, ok, it, se, E, work, count, share, chain_sig); break;

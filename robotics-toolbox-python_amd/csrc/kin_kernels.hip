@@ -12,6 +12,7 @@
 #include "kin_reg.h"
 #include "diff_device.h"
 #include "servo_device.h"
+#include "diff_kernel.h"
 #include <algorithm>
 #include <cstring>
 
@@ -38,20 +39,6 @@ constexpr int kKinPosePlain = 1;      // KinParams.pad bit 0
 #define RTB_PACKED_XCD 1
 #endif
 constexpr int kKinPacked = 2;         // KinParams.pad bit 1: T is the packed (N, 16 + 6n) array [T | J], J is not written separately (run-time-n tile)
-
-// The chain tables through the constant address space: uniform loads become s_load (SGPR operands).
-#define RTB_CONST __attribute__((address_space(4)))
-struct ConstChain {
-    const RTB_CONST DevSeg *seg;
-    const RTB_CONST int32_t *jmeta;
-};
-__device__ __forceinline__ ConstChain const_view(const DevChain &dc)
-{
-    ConstChain cv;
-    cv.seg = (const RTB_CONST DevSeg *)dc.seg;
-    cv.jmeta = (const RTB_CONST int32_t *)dc.jmeta;
-    return cv;
-}
 
 template <bool WANT_T, bool WANT_J, bool WANT_H, bool COALESCED>
 __global__ __launch_bounds__(kWave) void k_kin(KinParams kp, DevChain dc,
@@ -452,86 +439,6 @@ int launch_angle_axis(const double *Te, int64_t nTe, const double *Tep, int64_t 
 }
 
 // ---------------------------------------------------------------- differential-kinematics consumers (n <= 8)
-// jacob0_dot / manipulability / jacobm straight from the register-resident Jacobian: the (n,6,n) Hessian
-// the reference materialises for each of them (robot/Robot.py:1069, robot/ETS.py:1671) never exists.
-constexpr int kDiffMax = 16;   // jacob_dot / manipulability / jacobm / analytical Jacobian: compile-time joint counts up to here
-enum { kDiffJdot = 0, kDiffManip = 1, kDiffJacobm = 2, kDiffAnalytical = 3, kDiffAnalyticalDot = 4 };
-template <int NJ, int MODE>
-__global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && MODE != 4 ? 2 : 1)) void k_kin_diff(KinParams kp, DevChain dc, int axes, const double *__restrict__ q,
-                                                       const double *__restrict__ qd, double *__restrict__ out)
-{
-    extern __shared__ __attribute__((aligned(16))) double buf[];
-    const ConstChain cv = const_view(dc);
-    const int lane = threadIdx.x;
-    const int64_t cfg0 = (int64_t)xcd_tile() * kWave, cfg = cfg0 + lane;
-    const int64_t left = kp.N - cfg0;
-    const int ncfg = left < kWave ? (int)left : kWave;
-    Pose P;
-    double jac[6 * NJ];
-    if constexpr (MODE == kDiffAnalyticalDot) {
-        // Robot.jacob0_dot with an orientation `representation` (robot/Robot.py:1065-1098): the reference has no closed form
-        // ("not actually sure this can be written in closed form") and takes  H = numhess(jacob0_analytical, q)  -- spatialmath's
-        // FORWARD difference  H[i] = (Ja(q + dx e_i) - Ja(q)) / dx,  dx = 1e-8 -- then  Jd = tensordot(H, qd, (0, 0)).  Restated
-        // as it stands (a drop-in returns the reference's numbers, truncation error included): n + 1 chain walks per lane,
-        // everything in registers.
-        const bool live = cfg < kp.N;
-        double qv[NJ], v[NJ], jd[6 * NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int col = jm_jq(cv.jmeta[j]);
-            qv[j] = live ? q[cfg * kp.qw + col] : 0.0;
-            v[j] = live ? qd[cfg * kp.qw + col] : 0.0;
-        }
-        jacob_analytical_dot<NJ>(cv, kp.tail, qv, v, axes, jd);
-        constexpr int W = 6 * NJ;
-#pragma unroll
-        for (int r = 0; r < kWave / kJRound; ++r) {
-            if (lane / kJRound == r) reg_stage_J<NJ>(jd, buf, lane % kJRound);
-            __syncthreads();
-            int rows = ncfg - r * kJRound;
-            rows = rows < 0 ? 0 : (rows > kJRound ? kJRound : rows);
-            kin_flush(buf, W + 1, W, rows, out + (cfg0 + r * kJRound) * W, lane);
-            __syncthreads();
-        }
-        return;
-    }
-    reg_compute<NJ, true>(kp, cv, q, cfg, P, jac);
-    if (MODE == kDiffJdot || MODE == kDiffAnalytical) {
-        double jd[6 * NJ];
-        if (MODE == kDiffJdot) {
-            double v[NJ];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) v[j] = cfg < kp.N ? qd[cfg * kp.qw + jm_jq(cv.jmeta[j])] : 0.0;
-            jacob_dot<NJ>(jac, v, jd);
-        } else {
-            jacob_analytical<NJ>(P, jac, axes, jd);          // axes carries the representation code
-        }
-        constexpr int W = 6 * NJ;
-#pragma unroll
-        for (int r = 0; r < kWave / kJRound; ++r) {
-            if (lane / kJRound == r) reg_stage_J<NJ>(jd, buf, lane % kJRound);
-            __syncthreads();
-            int rows = ncfg - r * kJRound;
-            rows = rows < 0 ? 0 : (rows > kJRound ? kJRound : rows);
-            kin_flush(buf, W + 1, W, rows, out + (cfg0 + r * kJRound) * W, lane);
-            __syncthreads();
-        }
-    } else if (MODE == kDiffManip) {
-        // axes: bits 0..5 = Cartesian rows, bits 8..9 = method (0 yoshikawa, 1 minsingular, 2 invcondition)
-        const int method = (axes >> 8) & 3;
-        const double m = method == 0 ? manipulability_yoshikawa<NJ>(jac, axes & 63) : manipulability_singular<NJ>(jac, axes & 63, method);
-        if (cfg < kp.N) out[cfg] = m;                      // 8 bytes per lane, contiguous across the wave
-    } else {
-        double jm[NJ];
-        jacobm<NJ>(jac, axes, jm);
-        constexpr int S = NJ | 1;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) buf[lane * S + j] = jm[j];
-        __syncthreads();
-        flush_run(buf, S, NJ, ncfg, out + cfg0 * NJ, lane);
-    }
-}
-
 template <int NJ>
 static hipError_t launch_diff_nj(int mode, dim3 grid, size_t lds, hipStream_t s, const KinParams &kp, const DevChain &dc,
                                  int axes, const double *q, const double *qd, double *out)
@@ -548,7 +455,7 @@ int launch_kin_diff(const Chain *c, const DevChain &dc, int mode, int axes, cons
                     const Affine &tool, int frame, double *out, hipStream_t s)
 {
     if (N == 0) return RTBHIP_OK;
-    if (c->n < 1 || c->n > kDiffMax) { set_error("jacob_dot/manipulability/jacobm/jacob0_analytical: chains of 1..16 joints on the device"); return RTBHIP_ELIMIT; }
+    if (c->n < 1 || c->n > RTBHIP_MAX_JOINTS) { set_error("jacob_dot/manipulability/jacobm/jacob0_analytical: chains of 1..RTBHIP_MAX_JOINTS joints"); return RTBHIP_ELIMIT; }
     const int64_t tiles = (N + kWave - 1) / kWave;
     if (tiles > 0x7fffffff) { set_error("jacob_dot/manipulability/jacobm: batch too large for one launch"); return RTBHIP_ELIMIT; }
     KinParams kp;
@@ -558,6 +465,18 @@ int launch_kin_diff(const Chain *c, const DevChain &dc, int mode, int axes, cons
     const size_t lds = (size_t)reg_lds_doubles(c->n) * sizeof(double);
     dim3 grid((unsigned)tiles);
     hipError_t e = hipSuccess;
+    if (c->n > kDiffMax) {
+        // a joint count without a built-in instantiation: the same k_kin_diff template, instantiated at run time (jit.cpp; seconds to a minute on first
+        // use, then a file read).  The reference's loops take any n (robot/Robot.py:964-1235, robot/ETS.py:1687-1819).
+        const int m = mode == kDiffJdot ? kDiffJdot : (mode == kDiffManip ? kDiffManip : (mode == kDiffAnalytical ? kDiffAnalytical : (mode == kDiffAnalyticalDot ? kDiffAnalyticalDot : kDiffJacobm)));
+        hipFunction_t f = c->jit.get_wait("diff_kernel.h", 32 + m, [&] { return "rtbhip::k_kin_diff<" + std::to_string(c->n) + ", " + std::to_string(m) + ">"; });
+        if (!f) return RTBHIP_ELIMIT;                         // (rtbhip_last_error says why: no hipRTC on this box, or the compiler's message)
+        void *args[] = {(void *)&kp, (void *)&dc, (void *)&axes, (void *)&q, (void *)&qd, (void *)&out};
+        const int rc = jit_launch(f, grid, dim3(kWave), lds, s, args);
+        if (rc != RTBHIP_OK) return rc;
+        note_launch((int)grid.x, kWave, (int)lds);
+        return RTBHIP_OK;
+    }
     switch (c->n) {
     case 1: e = launch_diff_nj<1>(mode, grid, lds, s, kp, dc, axes, q, qd, out); break;
     case 2: e = launch_diff_nj<2>(mode, grid, lds, s, kp, dc, axes, q, qd, out); break;

@@ -9,6 +9,9 @@
 // 8-byte-per-lane loads into a lane-major LDS tile (odd row stride => conflict-free) and the torques
 // leave the same way.
 #include "rne_device.h"
+#if RTB_HOST_SIDE
+#include <cstdlib>
+#endif
 
 namespace rtbhip {
 
@@ -345,7 +348,11 @@ int launch_rne(const Dyn *d, const DevLink *links, const double *q, const double
     int64_t g = rt ? (tiles + g_rne_tiles_per_wave - 1) / g_rne_tiles_per_wave : tiles;
     if (g > 0x7fffffff) g = 0x7fffffff;
     dim3 grid((unsigned)g);
-    const RneSig sig = (g_rne_sig && !rt) ? rne_signature(d->links.data(), d->n) : 0;
+    RneSig sig = (g_rne_sig && !rt) ? rne_signature(d->links.data(), d->n) : 0;
+    // diagnostic (scripts/jit_diag.py): RTBHIP_RNE_SIG_AND=<hex> clears fields of the signature before the dispatch -- a kernel that KNOWS less about the
+    // table is still a correct kernel for it (a cleared flag is a shortcut not taken, a cleared alpha class the general rotation ...)
+    static const RneSig sig_and = std::getenv("RTBHIP_RNE_SIG_AND") ? std::strtoull(std::getenv("RTBHIP_RNE_SIG_AND"), nullptr, 16) : ~0ull;
+    if (sig) sig = (sig & sig_and) | kRneSigPresent;
     switch (rt ? 0 : d->n) {
     case 1: launch_nj<1>(d, mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau, sig); break;
     case 2: launch_nj<2>(d, mdh, allrev, grid, lds, s, rp, links, q, qd, qdd, tau, sig); break;

@@ -87,6 +87,7 @@ struct DevChain {
 bool jit_enabled();                                                       // rtbhip_tune("jit") != 0
 void jit_request(const char *unit, const std::string &expr, const std::string &preamble = std::string(), bool touch_device = false);              // at *_create: ask for it, nobody waits
 hipFunction_t jit_function(const char *unit, const std::string &expr, const std::string &preamble = std::string());    // at a launch: the function on the current device, or NULL (not ready / failed / off)
+hipFunction_t jit_function_wait(const char *unit, const std::string &expr, const std::string &preamble = std::string());   // sizes with no built-in kernel: waits; NULL = error set
 int jit_launch(hipFunction_t f, dim3 grid, dim3 block, size_t lds, hipStream_t s, void **args);
 std::string jit_hex(unsigned long long v);                                // "0x...ull"
 void jit_tune(const char *key, int value);
@@ -108,6 +109,20 @@ struct JitMemo {
             if (it != fn.end()) return it->second;
         }
         hipFunction_t f = jit_function(unit, make(), preamble);
+        if (f) { std::lock_guard<std::mutex> lk(mu); fn[k] = f; }
+        return f;
+    }
+    template <class MakeExpr> hipFunction_t get_wait(const char *unit, int variant, MakeExpr make, const std::string &preamble = std::string())
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        const uint64_t k = ((uint64_t)dev << 8) | (uint64_t)(variant & 0xff);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = fn.find(k);
+            if (it != fn.end()) return it->second;
+        }
+        hipFunction_t f = jit_function_wait(unit, make(), preamble);
         if (f) { std::lock_guard<std::mutex> lk(mu); fn[k] = f; }
         return f;
     }
@@ -279,7 +294,7 @@ struct IkParams {
     double we[6];
     uint64_t seed;
     double kq = 0.0, km = 0.0, ps = 0.1;             // null-space terms of the Python solvers; kq <= 0: none
-    double pi[16];                                   // ... influence distance per joint (filled by ik_entry)
+    double pi[RTBHIP_MAX_JOINTS];                    // ... influence distance per joint (filled by ik_entry)
     double ks = 1.0;                                 // IK_QP (method 5): slack gain (kj travels in lambda)
     int64_t target0 = 0;                             // restart-generator key offset of row 0 (rtbhip_ik_target_base)
 };

@@ -23,6 +23,7 @@
 #include "dyn_device.h"
 
 namespace rtbhip {
+#pragma clang fp contract(off)      // every operation written out, as in rne_device.h (why: there)
 
 struct alignas(16) DevGroup {   // wave-uniform, read through the scalar cache
     DevSeg C;                   // parent-group frame -> this group's joint frame before the joint motion
@@ -62,8 +63,9 @@ template <class G> RTB_HD V3 seg_r_c(int cls, const G &g, V3 v)    // R_C v: com
 }
 template <class G> RTB_HD V3 seg_rt(const G &g, V3 v) { return seg_rt_c(kSegGeneral, g, v); }
 template <class G> RTB_HD V3 seg_r(const G &g, V3 v) { return seg_r_c(kSegGeneral, g, v); }
-RTB_HD V3 rz_t(double s, double c, V3 v) { return v3(c * v.x + s * v.y, c * v.y - s * v.x, v.z); }   // Rz(theta)^T v
-RTB_HD V3 rz(double s, double c, V3 v) { return v3(c * v.x - s * v.y, s * v.x + c * v.y, v.z); }     // Rz(theta) v
+RTB_HD V3 rz_t(double s, double c, V3 v) { return v3(fmad(c, v.x, s * v.y), fmad(c, v.y, -(s * v.x)), v.z); }   // Rz(theta)^T v
+RTB_HD V3 rz(double s, double c, V3 v) { return v3(fmad(c, v.x, -(s * v.y)), fmad(s, v.x, c * v.y), v.z); }     // Rz(theta) v
+RTB_HD V3 crossz_add(V3 v, double t, V3 acc) { return v3(fmad(v.y, t, acc.x), fmad(-v.x, t, acc.y), acc.z); }   // acc + v x (0, 0, t)
 
 // ---- STRUCTURE SIGNATURES (rtbhip_internal.h: SegSig, kSeg*).  73 % of the group constants of the URDF robots are not general rotations
 // (identity 21 %, the cyclic permutations of the axis conjugation 23 %, quarter turns 18 %, one-axis rotations 11 %), and most of their
@@ -145,7 +147,7 @@ RTB_HD V3 add_cross_pa(int tm, V3 b, V3 p, V3 a)      // b + p x a
 template <class G> RTB_HD V3 tree_origin(bool revolute, const G &g, double d)      // p = t_C (+ R_C z d for a prismatic joint)
 {
     if (revolute) return v3(g.C.t[0], g.C.t[1], g.C.t[2]);
-    return v3(g.C.t[0] + g.C.r[2] * d, g.C.t[1] + g.C.r[5] * d, g.C.t[2] + g.C.r[8] * d);
+    return v3(fmad(g.C.r[2], d, g.C.t[0]), fmad(g.C.r[5], d, g.C.t[1]), fmad(g.C.r[8], d, g.C.t[2]));
 }
 // what a core knows about group j at compile time (SIG = 0: nothing)
 // (groups 8 .. 15 of a longer tree have their fields in a second word, SIG2, at positions 0 .. 7)
@@ -177,8 +179,8 @@ template <SegSig SIG, TreeTopo TOPO, SegSig SIG2 = 0> struct TreeKnown {
 typedef TreeKnown<0, 0, 0> TreeNothing;      // the general kernels
 template <class G> RTB_HD V3 inertia_rot(const G &g, V3 w)   // I_bar w
 {
-    return v3(g.I[0] * w.x + g.I[3] * w.y + g.I[4] * w.z, g.I[3] * w.x + g.I[1] * w.y + g.I[5] * w.z,
-              g.I[4] * w.x + g.I[5] * w.y + g.I[2] * w.z);
+    return v3(fmad(g.I[4], w.z, fmad(g.I[3], w.y, g.I[0] * w.x)), fmad(g.I[5], w.z, fmad(g.I[1], w.y, g.I[3] * w.x)),
+              fmad(g.I[2], w.z, fmad(g.I[5], w.y, g.I[4] * w.x)));
 }
 
 // One sample.  groups: wave-uniform table; qin/qdin/qddin(column) -> double; tau(column, value);
@@ -288,14 +290,14 @@ RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], co
         if (pris) {
             if (VEL) {
                 vl.z += qdj;
-                al = al + cross(va, v3(0, 0, qdj));
+                al = crossz_add(va, qdj, al);
             }
             al.z += qddj;
         } else {
             if (VEL) {
                 va.z += qdj;
-                al = al + cross(vl, v3(0, 0, qdj));
-                aa = aa + cross(va, v3(0, 0, qdj));
+                al = crossz_add(vl, qdj, al);
+                aa = crossz_add(va, qdj, aa);
             }
             aa.z += qddj;
         }
@@ -306,11 +308,11 @@ RTB_HD void tree_rne_core(GroupsP groups, int nslots, const double (&sn)[NG], co
         }
         // f = I a + v x* (I v) with I = [[M 1, -h x], [h x, I_bar]]  (Robot.py:1872)
         const V3 h = v3(g.h[0], g.h[1], g.h[2]);
-        const V3 Ial = g.M * al + cross(aa, h), Iaa = cross(h, al) + inertia_rot(g, aa);
+        const V3 Ial = cross_add(aa, h, g.M * al), Iaa = cross_add(h, al, inertia_rot(g, aa));
         if (VEL) {
-            const V3 Ivl = g.M * vl + cross(va, h), Iva = cross(h, vl) + inertia_rot(g, va);
-            Fl[j] = Ial + cross(va, Ivl);
-            Fa[j] = (Iaa + cross(va, Iva)) + cross(vl, Ivl);
+            const V3 Ivl = cross_add(va, h, g.M * vl), Iva = cross_add(h, vl, inertia_rot(g, va));
+            Fl[j] = cross_add(va, Ivl, Ial);
+            Fa[j] = cross_add(vl, Ivl, cross_add(va, Iva, Iaa));
         } else {
             Fl[j] = Ial;
             Fa[j] = Iaa;
@@ -427,11 +429,11 @@ RTB_HD void tree_bilinear_core(GroupsP groups, int nslots, const double (&sn)[NG
         // a += v x vJ (Robot.py:1866-1870), both ways round; cross(v, (0, 0, t)) = (v.y t, -v.x t, 0)
         if (pris) {
             ul.z += qdu; wl.z += qdw;
-            al = al + (cross(ua, v3(0, 0, qdw)) + cross(wa, v3(0, 0, qdu)));
+            al = crossz_add(wa, qdu, crossz_add(ua, qdw, al));
         } else {
             ua.z += qdu; wa.z += qdw;
-            al = al + (cross(ul, v3(0, 0, qdw)) + cross(wl, v3(0, 0, qdu)));
-            aa = aa + (cross(ua, v3(0, 0, qdw)) + cross(wa, v3(0, 0, qdu)));
+            al = crossz_add(wl, qdu, crossz_add(ul, qdw, al));
+            aa = crossz_add(wa, qdu, crossz_add(ua, qdw, aa));
         }
         if (save_slot_of() >= 0) {
             const int b = save_slot_of() * SD;
@@ -441,11 +443,11 @@ RTB_HD void tree_bilinear_core(GroupsP groups, int nslots, const double (&sn)[NG
         }
         // f = I a + v x* (I v) (Robot.py:1872) -> I a + u x* (I w) + w x* (I u);  v x* (fl, fa) = (va x fl, va x fa + vl x fl)
         const V3 h = v3(g.h[0], g.h[1], g.h[2]);
-        const V3 Iul = g.M * ul + cross(ua, h), Iua = cross(h, ul) + inertia_rot(g, ua);
-        const V3 Iwl = g.M * wl + cross(wa, h), Iwa = cross(h, wl) + inertia_rot(g, wa);
-        const V3 Ial = g.M * al + cross(aa, h), Iaa = cross(h, al) + inertia_rot(g, aa);
-        Fl[j] = Ial + (cross(ua, Iwl) + cross(wa, Iul));
-        Fa[j] = (Iaa + (cross(ua, Iwa) + cross(wa, Iua))) + (cross(ul, Iwl) + cross(wl, Iul));
+        const V3 Iul = cross_add(ua, h, g.M * ul), Iua = cross_add(h, ul, inertia_rot(g, ua));
+        const V3 Iwl = cross_add(wa, h, g.M * wl), Iwa = cross_add(h, wl, inertia_rot(g, wa));
+        const V3 Ial = cross_add(aa, h, g.M * al), Iaa = cross_add(h, al, inertia_rot(g, aa));
+        Fl[j] = cross_add(wa, Iul, cross_add(ua, Iwl, Ial));
+        Fa[j] = cross_add(wl, Iul, cross_add(ul, Iwl, cross_add(wa, Iua, cross_add(ua, Iwa, Iaa))));
         sched_fence();
     }
     // ---- backward recursion: tree_rne_core's, on the wider slots
@@ -676,4 +678,5 @@ RTB_HD void tree_dyn_lane(GroupsP groups, int nslots, const double *mine, double
     }
 }
 
+#pragma clang fp contract(fast)
 }  // namespace rtbhip

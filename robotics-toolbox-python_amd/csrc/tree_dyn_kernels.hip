@@ -91,8 +91,10 @@ static void tree_dyn_tile(int n, int mode, int nslots, int32_t *tile, size_t *ld
     const int K = mode == kDynInertia ? 1 : (mode == kDynCoriolis ? 2 : 3);
     const int W = mode == kDynCoriolis ? n * n : n * (n + 1) / 2 + (mode == kDynAccel ? n : 0);
     const size_t per_lane = (size_t)(((K * n) | 1) + (W | 1) + (mode == kDynCoriolis ? kTreeBilinearSlotDoubles : kTreeSlotDoubles) * nslots) * sizeof(double);
-    *tile = per_lane * kWave > 160 * 1024 ? kWave / 2 : kWave;
-    *lds = per_lane * *tile;
+    int tl = kWave;
+    while (tl > 8 && per_lane * tl > 160 * 1024) tl /= 2;          // 64 / 32 / 16 / 8 configurations per wave (the other lanes idle): served, not fast
+    *tile = tl;
+    *lds = per_lane * tl;
 }
 template <int NG, int MODE, SegSig SIG = 0, TreeTopo TOPO = 0, SegSig SIG2 = 0>
 static hipError_t launch_tree_dyn_one(dim3 grid, hipStream_t s, int nslots, const TreeParams &tp, const DevGroup *g, const double *q,
@@ -135,7 +137,7 @@ int launch_tree_dyn(const Tree *t, const DevGroup *groups, int mode, const doubl
                     const double *grav3, double *out, hipStream_t s)
 {
     if (N == 0) return RTBHIP_OK;
-    if (t->n > kTreeDynMax) { set_error("tree inertia/coriolis/accel: this build handles robots of up to 20 joints"); return RTBHIP_ELIMIT; }
+    if (t->n > RTBHIP_MAX_JOINTS) { set_error("tree inertia/coriolis/accel: more than RTBHIP_MAX_JOINTS joints"); return RTBHIP_ELIMIT; }
     const int64_t tiles = (N + kWave - 1) / kWave;
     if (tiles > 0x7fffffff) { set_error("tree inertia/coriolis/accel: batch too large for one launch"); return RTBHIP_ELIMIT; }
     TreeParams tp;
@@ -150,10 +152,17 @@ int launch_tree_dyn(const Tree *t, const DevGroup *groups, int mode, const doubl
     const TreeTopo topo = g_tree_sig ? t->topo : 0;
     const SegSig sig2 = g_tree_sig ? t->sig2 : 0;
     // a robot without a built-in instantiation: its own, compiled at run time (jit.cpp); the general kernels below serve until it is there
-    if (hipFunction_t f = tree_jit_function(t, 2 + mode)) {
+    hipFunction_t f = tree_jit_function(t, 2 + mode);
+    if (!f && t->n > kTreeDynMax) {
+        // beyond the built-in sizes (1 .. 20): the general kernel of this size, instantiated at run time; the caller waits (robot/Dynamics.py:704-861)
+        f = t->jit.get_wait("tree_dyn_kernels.hip", 10 + mode, [&] { return "rtbhip::k_tree_dyn<" + std::to_string(t->n) + ", " + std::to_string(mode) + ", rtbhip::TreeNothing>"; });
+        if (!f) return RTBHIP_ELIMIT;
+    }
+    if (f) {
         TreeParams tq_ = tp;
         size_t l = 0;
         tree_dyn_tile(t->n, mode, t->nslots, &tq_.tile, &l);
+        if (l > 160 * 1024 && t->n > kTreeDynMax) { set_error("tree inertia/coriolis/accel: the robot needs more LDS than a CU has"); return RTBHIP_ELIMIT; }
         if (l <= 160 * 1024) {
             const int64_t tl = (N + tq_.tile - 1) / tq_.tile;
             void *args[] = {&tq_, &groups, &q, &qd, &tq, &out};

@@ -128,12 +128,12 @@ std::string tree_jit_expr(const Tree *t, const std::string &type_name, int varia
 std::vector<std::string> tree_jit_names(const Tree *t)
 {
     std::vector<std::string> out;
-    if (!tree_jit_applies(t) || t->n > 24) return out;
+    if (!tree_jit_applies(t) || t->n > RTBHIP_MAX_JOINTS) return out;
     std::string type_name;
     (void)tree_jit_knowledge(t, &type_name);
     out.push_back(tree_jit_expr(t, type_name, 0));
     if (t->n <= 12) out.push_back(tree_jit_expr(t, type_name, 1));
-    if (t->n <= 20) for (int m = 0; m < 3; ++m) out.push_back(tree_jit_expr(t, type_name, 2 + m));
+    for (int m = 0; m < 3; ++m) out.push_back(tree_jit_expr(t, type_name, 2 + m));
     return out;
 }
 // the function of variant `variant` on the current device, or NULL (not compiled yet / no hipRTC / jit or signatures off / not applicable)
@@ -176,7 +176,7 @@ int launch_tree_rne(const Tree *t, const DevGroup *groups, const double *q, cons
                     const double *grav3, double *tau, hipStream_t s)
 {
     if (N == 0) return RTBHIP_OK;
-    if (t->n > kTreeMaxGroups) { set_error("tree_rne: this build handles up to 24 joints (link groups) on the device"); return RTBHIP_ELIMIT; }
+    if (t->n > RTBHIP_MAX_JOINTS) { set_error("tree_rne: more than RTBHIP_MAX_JOINTS joints (link groups)"); return RTBHIP_ELIMIT; }
     const int64_t tiles = (N + kWave - 1) / kWave;
     if (tiles > 0x7fffffff) { set_error("tree_rne: batch too large for one launch"); return RTBHIP_ELIMIT; }
     TreeParams tp;
@@ -190,7 +190,14 @@ int launch_tree_rne(const Tree *t, const DevGroup *groups, const double *q, cons
     const TreeTopo topo = g_tree_sig ? t->topo : 0;
     const SegSig sig2 = g_tree_sig ? t->sig2 : 0;
     // a robot without a built-in instantiation: its own, compiled at run time (jit.cpp); the general kernels below serve until it is there
-    if (hipFunction_t f = tree_jit_function(t, (!qd && t->n <= kTreeAtRestMax) ? 1 : 0)) {
+    hipFunction_t f = tree_jit_function(t, (!qd && t->n <= kTreeAtRestMax) ? 1 : 0);
+    if (!f && t->n > kTreeMaxGroups) {
+        // more groups than the built-in sizes (1 .. 24) and no knowledge-type instantiation to hand: the general kernel of this size, instantiated
+        // at run time; the caller waits (the reference's loops take any n: robot/Robot.py:1704-1903)
+        f = t->jit.get_wait("tree_kernels.hip", 8, [&] { return "rtbhip::k_tree_rne<" + std::to_string(t->n) + ", false, rtbhip::TreeNothing>"; });
+        if (!f) return RTBHIP_ELIMIT;
+    }
+    if (f) {
         TreeParams tpv = tp;
         void *args[] = {&tpv, &groups, &q, &qd, &qdd, &tau};
         const int rc = jit_launch(f, grid, dim3(kWave), lds, s, args);

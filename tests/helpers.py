@@ -181,3 +181,13 @@ def DEV():
 def full_size(N, replay_div=20):
     """A BASELINE-size batch: N rows on the GPU; the CPU replay is about the host layer's code paths, not about size, and takes N / replay_div."""
     return N // replay_div if replaying() else N
+
+
+def large_sizes_served():
+    """Joint counts beyond the built-in kernel sizes (IK / differential consumers / DH dynamics terms > 16 joints, tree dynamics > 20) are
+    instantiated at run time by hipRTC (csrc/jit.cpp) -- on a real device with libhiprtc.so.  The CPU replay keeps the built-in set, and so does a
+    box without hipRTC: there such a call is still refused loudly (RTBHIP_ELIMIT), never dropped."""
+    if replaying():
+        return False
+    from rtbhip import jit
+    return bool(jit.stats()["available"])

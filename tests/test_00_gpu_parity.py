@@ -471,8 +471,18 @@ def test_ikine_nullspace_terms():
     sh = ets.ikine_LM(T, q0=q0, seed=5, slimit=3, kq=0.1, km=0.1)
     nt.assert_array_equal(st.q, sh.q)
     long13 = rtbhip.DHRobot([rtbhip.RevoluteDH(a=0.1, d=0.05, alpha=[0.0, 1.5][k % 2]) for k in range(13)]).ets()
-    with pytest.raises(rtbhip.RtbHipError):
-        long13.ikine_LM(long13.eval(np.zeros(13)), kq=0.1)    # null-space variants exist for 6..12 joints
+    # null-space step variants are built in for 6..12 joints; beyond, the same template is instantiated at run time (csrc/jit.cpp) -- the
+    # reference's loop takes any n (robot/IK.py:542-576).  On the device: served, and the solution reaches its target.
+    from helpers import replaying
+    if not replaying():
+        from rtbhip import jit
+        q13 = np.full(13, 0.2)
+        if jit.stats()["available"]:
+            s13 = long13.ikine_LM(long13.eval(q13), q0=q13 + 0.02, kq=0.1, km=0.1, seed=1)
+            assert s13.success and np.abs(np.asarray(long13.eval(s13.q)) - np.asarray(long13.eval(q13))).max() < 1e-4
+        else:
+            with pytest.raises(rtbhip.RtbHipError):
+                long13.ikine_LM(long13.eval(q13), kq=0.1)
     five = urdf.load("px100").ets()
     assert five.n < 6
     with pytest.raises(rtbhip.RtbHipError):
@@ -549,8 +559,14 @@ def test_ik_ten_joint_chain_equals_oracle():
     good = ok == 1
     assert good.mean() > 0.8 and np.all(E[good] < 1e-6)
     seventeen = rtbhip.DHRobot([rtbhip.RevoluteDH(a=0.1) for _ in range(17)]).ets()
-    with pytest.raises(rtbhip.RtbHipError):
-        seventeen.ik_LM(np.eye(4))
+    from helpers import large_sizes_served
+    if large_sizes_served():                   # 17 joints: no built-in k_ik -- instantiated at run time (tests/test_large_chains_gpu.py checks it against the oracle)
+        q17 = np.linspace(0.1, 0.5, 17)
+        s17 = seventeen.ik_LM(seventeen.eval(q17), q0=q17 + 0.01)
+        assert s17[1] == 1
+    else:
+        with pytest.raises(rtbhip.RtbHipError):
+            seventeen.ik_LM(np.eye(4))
 
 
 def test_ik_fourteen_joint_chain_equals_oracle():
@@ -881,7 +897,7 @@ def test_ik_small_chains_and_errors():
     q, ok, it, se, E = arm.ik_LM(Tep, mask=[1, 1, 0, 0, 0, 1], joint_limits=False)
     assert ok.all()
     nt.assert_allclose(oracle.fkine(ch, q)[:, :2, 3], Tep[:, :2, 3], atol=2e-3)
-    big = rtbhip.ETS([ET.Rz() for _ in range(17)])             # 17 joints: beyond the 16 the device build solves
+    big = rtbhip.ETS([ET.Rz() for _ in range(33)])             # 33 joints: beyond RTBHIP_MAX_JOINTS, refused when the chain is made
     with pytest.raises(rtbhip.RtbHipError):
         big.ik_LM(np.eye(4))
     perm = ET.Rz(jindex=1) * ET.tx(1.0) * ET.Rz(jindex=0)
