@@ -18,27 +18,32 @@ namespace rtbhip {
 
 // H[j', :, i] as the reference fills it (methods.cpp:16-32): for j' <= i  (w_j' x v_i ; w_j' x w_i),
 // for j' > i  (w_i x v_j' ; 0).
+// Written with running sums instead of the pair loop the definition suggests (28 + 21 cross products for 7 joints):
+//   Jd_v[i] = sum_{j<=i} qd_j (w_j x v_i) + sum_{j>i} qd_j (w_i x v_j) = W_i x v_i + w_i x V_i,   Jd_w[i] = sum_{j<=i} qd_j (w_j x w_i) = W_i x w_i
+// with W_i = sum_{j<=i} qd_j w_j (a prefix sum) and V_i = sum_{j>i} qd_j v_j (a suffix sum): 6 n fused multiply-adds for the sums and three cross
+// products per joint -- O(n) where the pair loop is O(n^2); the same quantity to rounding (round 6: 1 692 -> ~560 executed instructions per configuration).
 template <int NJ>
 RTB_HD void jacob_dot(const double (&jac)[6 * NJ], const double (&qd)[NJ], double (&jd)[6 * NJ])
 {
+    double Vx[NJ], Vy[NJ], Vz[NJ];          // V_i, i = NJ - 1 .. 0
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+#pragma unroll
+    for (int i = NJ - 1; i >= 0; --i) {
+        Vx[i] = sx; Vy[i] = sy; Vz[i] = sz;
+        sx = fma(qd[i], jac[i], sx); sy = fma(qd[i], jac[NJ + i], sy); sz = fma(qd[i], jac[2 * NJ + i], sz);
+    }
+    double Wx = 0.0, Wy = 0.0, Wz = 0.0;
 #pragma unroll
     for (int i = 0; i < NJ; ++i) {
         const double vix = jac[i], viy = jac[NJ + i], viz = jac[2 * NJ + i];
         const double wix = jac[3 * NJ + i], wiy = jac[4 * NJ + i], wiz = jac[5 * NJ + i];
-        double ax = 0, ay = 0, az = 0, bx = 0, by = 0, bz = 0;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const double wjx = jac[3 * NJ + j], wjy = jac[4 * NJ + j], wjz = jac[5 * NJ + j];
-            if (j <= i) {
-                ax += qd[j] * (wjy * viz - wjz * viy); ay += qd[j] * (wjz * vix - wjx * viz); az += qd[j] * (wjx * viy - wjy * vix);
-                bx += qd[j] * (wjy * wiz - wjz * wiy); by += qd[j] * (wjz * wix - wjx * wiz); bz += qd[j] * (wjx * wiy - wjy * wix);
-            } else {
-                const double vjx = jac[j], vjy = jac[NJ + j], vjz = jac[2 * NJ + j];
-                ax += qd[j] * (wiy * vjz - wiz * vjy); ay += qd[j] * (wiz * vjx - wix * vjz); az += qd[j] * (wix * vjy - wiy * vjx);
-            }
-        }
-        jd[i] = ax; jd[NJ + i] = ay; jd[2 * NJ + i] = az;
-        jd[3 * NJ + i] = bx; jd[4 * NJ + i] = by; jd[5 * NJ + i] = bz;
+        Wx = fma(qd[i], wix, Wx); Wy = fma(qd[i], wiy, Wy); Wz = fma(qd[i], wiz, Wz);
+        jd[i] = (Wy * viz - Wz * viy) + (wiy * Vz[i] - wiz * Vy[i]);
+        jd[NJ + i] = (Wz * vix - Wx * viz) + (wiz * Vx[i] - wix * Vz[i]);
+        jd[2 * NJ + i] = (Wx * viy - Wy * vix) + (wix * Vy[i] - wiy * Vx[i]);
+        jd[3 * NJ + i] = Wy * wiz - Wz * wiy;
+        jd[4 * NJ + i] = Wz * wix - Wx * wiz;
+        jd[5 * NJ + i] = Wx * wiy - Wy * wix;
     }
 }
 
@@ -75,7 +80,10 @@ RTB_HD double manipulability_yoshikawa(const double (&jac)[6 * NJ], int axes)
     }
     double B[6][6];
     jjt_masked<NJ>(jac, axes, B);
-    return sqrt(fabs(det_lu<6>(B)));              // ETS.py:1786-1787
+    // ETS.py:1786-1787.  J_a J_a^T is symmetric positive semi-definite: its determinant is the product of the pivots of an LDL^T factorisation
+    // without pivoting (ldl.h: det_psd) -- ~90 instructions where the row-exchanging LU that numpy.linalg.det runs costs ~350 as straight-line
+    // selects.  The same number to rounding; an exactly singular matrix (the arm stretched out at q = 0) gives an exact 0 either way.
+    return sqrt(fabs(det_psd<6>(B)));
 }
 
 // Smallest singular value of J_a (mode 1, ETS.py:1793-1796 `minsingular`) or 1/cond_2(J_a) = s_min / s_max
@@ -220,39 +228,45 @@ RTB_HD void jacob_analytical_dot(const CV &cv, TL tail, const double (&qv)[NJ], 
     }
 }
 
-// jacobm given the LDL^T factorisation (B, dinv) of the masked J J^T
+// jacobm given the LDL^T factorisation (B, dinv; pivots dval) of the masked J J^T.
+//   m = sqrt|det(J_a J_a^T)| = sqrt|prod dval|  (Robot.py:1216-1222: the factorisation is there already -- rounds 1-5 formed J J^T a second time and ran
+//   the row-exchanging LU on it);
+//   Jm[i] = m sum_{b,k} H[i,b,k] G[b,k] with G = (J_a J_a^T)^-1 J_a and the Hessian blocks of methods.cpp:16-32.  With Ga_k / Gb_k the translational /
+//   rotational halves of column k of G and the triple product  (a x b) . c = a . (b x c):
+//       sum_{k>=i} (w_i x v_k) . Ga_k + (w_i x w_k) . Gb_k  =  w_i . S_i,   S_i = sum_{k>=i} (v_k x Ga_k + w_k x Gb_k)      (a suffix sum)
+//       sum_{k<i}  (w_k x v_i) . Ga_k                       =  v_i . P_i,   P_i = sum_{k<i} (Ga_k x w_k)                    (a prefix sum)
+//   -- three cross products per joint instead of one or two per joint PAIR (49 blocks for 7 joints): 2 732 -> ~1 500 executed instructions.
 template <int NJ>
-RTB_HD void jacobm_factored(const double (&jac)[6 * NJ], int axes, const double (&B)[6][6], const double (&dinv)[6], double (&jm)[NJ])
+RTB_HD void jacobm_factored(const double (&jac)[6 * NJ], int axes, const double (&B)[6][6], const double (&dval)[6], const double (&dinv)[6], double (&jm)[NJ])
 {
-    const double m = manipulability_yoshikawa<NJ>(jac, axes);     // Robot.py:1216-1222
-    // G = (J_a J_a^T)^-1 J_a, column by column (rows outside `axes` come out zero)
-    double G[6 * NJ];
+    double det = dval[0];
+#pragma unroll
+    for (int r = 1; r < 6; ++r) det *= dval[r];
+    // (a square J_a: |det J| itself, ETS.py:1782-1784 -- near a singularity it keeps the digits the square root of det(J J^T) loses)
+    const double m = (NJ == 6 && (axes & 63) == 63) ? manipulability_yoshikawa<NJ>(jac, axes) : sqrt(fabs(det));
+    double Px[NJ], Py[NJ], Pz[NJ];          // P_i
+    double cx[NJ], cy[NJ], cz[NJ];          // v_k x Ga_k + w_k x Gb_k
+    double px = 0.0, py = 0.0, pz = 0.0;
 #pragma unroll
     for (int k = 0; k < NJ; ++k) {
+        // column k of G = (J_a J_a^T)^-1 J_a (rows outside `axes` come out zero)
         double g[6], x[6];
 #pragma unroll
         for (int r = 0; r < 6; ++r) g[r] = ((axes >> r) & 1) ? jac[r * NJ + k] : 0.0;
         ldl_backsolve<6>(B, dinv, g, x);
-#pragma unroll
-        for (int r = 0; r < 6; ++r) G[r * NJ + k] = x[r];
+        const double vkx = jac[k], vky = jac[NJ + k], vkz = jac[2 * NJ + k];
+        const double wkx = jac[3 * NJ + k], wky = jac[4 * NJ + k], wkz = jac[5 * NJ + k];
+        cx[k] = (vky * x[2] - vkz * x[1]) + (wky * x[5] - wkz * x[4]);
+        cy[k] = (vkz * x[0] - vkx * x[2]) + (wkz * x[3] - wkx * x[5]);
+        cz[k] = (vkx * x[1] - vky * x[0]) + (wkx * x[4] - wky * x[3]);
+        Px[k] = px; Py[k] = py; Pz[k] = pz;
+        px += x[1] * wkz - x[2] * wky; py += x[2] * wkx - x[0] * wkz; pz += x[0] * wky - x[1] * wkx;      // Ga_k x w_k
     }
-    // Jm[i] = m sum_{b,k} H[i,b,k] G[b,k]
+    double sx = 0.0, sy = 0.0, sz = 0.0;
 #pragma unroll
-    for (int i = 0; i < NJ; ++i) {
-        const double vix = jac[i], viy = jac[NJ + i], viz = jac[2 * NJ + i];
-        const double wix = jac[3 * NJ + i], wiy = jac[4 * NJ + i], wiz = jac[5 * NJ + i];
-        double acc = 0.0;
-#pragma unroll
-        for (int k = 0; k < NJ; ++k) {
-            const double vkx = jac[k], vky = jac[NJ + k], vkz = jac[2 * NJ + k];
-            const double wkx = jac[3 * NJ + k], wky = jac[4 * NJ + k], wkz = jac[5 * NJ + k];
-            if (k >= i) {       // H[i,:3,k] = w_i x v_k ; H[i,3:,k] = w_i x w_k
-                acc += (wiy * vkz - wiz * vky) * G[k] + (wiz * vkx - wix * vkz) * G[NJ + k] + (wix * vky - wiy * vkx) * G[2 * NJ + k];
-                acc += (wiy * wkz - wiz * wky) * G[3 * NJ + k] + (wiz * wkx - wix * wkz) * G[4 * NJ + k] + (wix * wky - wiy * wkx) * G[5 * NJ + k];
-            } else {            // H[i,:3,k] = w_k x v_i ; H[i,3:,k] = 0
-                acc += (wky * viz - wkz * viy) * G[k] + (wkz * vix - wkx * viz) * G[NJ + k] + (wkx * viy - wky * vix) * G[2 * NJ + k];
-            }
-        }
+    for (int i = NJ - 1; i >= 0; --i) {
+        sx += cx[i]; sy += cy[i]; sz += cz[i];
+        const double acc = (jac[3 * NJ + i] * sx + jac[4 * NJ + i] * sy + jac[5 * NJ + i] * sz) + (jac[i] * Px[i] + jac[NJ + i] * Py[i] + jac[2 * NJ + i] * Pz[i]);
         jm[i] = m * acc;
     }
 }
@@ -263,7 +277,7 @@ RTB_HD void jacobm(const double (&jac)[6 * NJ], int axes, double (&jm)[NJ])
     double B[6][6], dval[6], dinv[6];
     jjt_masked<NJ>(jac, axes, B);
     ldl_factor<6>(B, dval, dinv);
-    jacobm_factored<NJ>(jac, axes, B, dinv, jm);
+    jacobm_factored<NJ>(jac, axes, B, dval, dinv, jm);
 }
 
 }  // namespace rtbhip

@@ -64,7 +64,7 @@ struct IkDev {   // wave-uniform solver parameters (kernarg)
     int32_t flat_chunks, flat_l0, flat_len;
     uint32_t flat_n;
     int32_t *flat_done;              // per target: index of the lowest chunk that has SUCCEEDED so far (kIkFlatNone: none yet); device memory
-    unsigned long long *stats;       // diagnostics (RTBHIP_IK_STATS): 4 words per wave -- loop iterations, scheduling passes, lane-iterations
+    unsigned long long *stats;       // diagnostics (RTBHIP_IK_STATS): 6 words per wave (ik_kernels.hip: kIkStatWords) -- loop iterations, scheduling passes, lane-iterations
                                      // spent on a running search, work items started; NULL in normal runs
 };
 
@@ -95,19 +95,22 @@ RTB_HD void ik_restart(uint64_t seed, int64_t target, int draw, QL qlim, double 
 template <class TD>
 RTB_HD void ik_angle_axis(const Pose &P, TD Td, double (&e)[6])
 {
+#pragma clang fp contract(off)
+    // (every sum of products written out -- kin_device.h, mix_pp: the pose comes out of a structure instantiation's walk or out of the general one,
+    // and what the compiler would make of `a b + c d + e f` depends on which)
     e[0] = Td(9) - P.tx; e[1] = Td(10) - P.ty; e[2] = Td(11) - P.tz;
     // R = Rd * Re^T ; only the entries the formula reads
-    const double r00 = Td(0) * P.r00 + Td(1) * P.r01 + Td(2) * P.r02;
-    const double r01 = Td(0) * P.r10 + Td(1) * P.r11 + Td(2) * P.r12;
-    const double r02 = Td(0) * P.r20 + Td(1) * P.r21 + Td(2) * P.r22;
-    const double r10 = Td(3) * P.r00 + Td(4) * P.r01 + Td(5) * P.r02;
-    const double r11 = Td(3) * P.r10 + Td(4) * P.r11 + Td(5) * P.r12;
-    const double r12 = Td(3) * P.r20 + Td(4) * P.r21 + Td(5) * P.r22;
-    const double r20 = Td(6) * P.r00 + Td(7) * P.r01 + Td(8) * P.r02;
-    const double r21 = Td(6) * P.r10 + Td(7) * P.r11 + Td(8) * P.r12;
-    const double r22 = Td(6) * P.r20 + Td(7) * P.r21 + Td(8) * P.r22;
+    const double r00 = dot3x(Td(0), P.r00, Td(1), P.r01, Td(2), P.r02);
+    const double r01 = dot3x(Td(0), P.r10, Td(1), P.r11, Td(2), P.r12);
+    const double r02 = dot3x(Td(0), P.r20, Td(1), P.r21, Td(2), P.r22);
+    const double r10 = dot3x(Td(3), P.r00, Td(4), P.r01, Td(5), P.r02);
+    const double r11 = dot3x(Td(3), P.r10, Td(4), P.r11, Td(5), P.r12);
+    const double r12 = dot3x(Td(3), P.r20, Td(4), P.r21, Td(5), P.r22);
+    const double r20 = dot3x(Td(6), P.r00, Td(7), P.r01, Td(8), P.r02);
+    const double r21 = dot3x(Td(6), P.r10, Td(7), P.r11, Td(8), P.r12);
+    const double r22 = dot3x(Td(6), P.r20, Td(7), P.r21, Td(8), P.r22);
     const double lx = r21 - r12, ly = r02 - r20, lz = r10 - r01;
-    const double nrm = sqrt(lx * lx + ly * ly + lz * lz);
+    const double nrm = sqrt(dot3x(lx, lx, ly, ly, lz, lz));
     const double tr = r00 + r11 + r22;
     if (nrm < 1e-6) {
         if (tr > 0) {
@@ -119,6 +122,17 @@ RTB_HD void ik_angle_axis(const Pose &P, TD Td, double (&e)[6])
         const double k = atan2(nrm, tr - 1) / nrm;
         e[3] = k * lx; e[4] = k * ly; e[5] = k * lz;
     }
+}
+
+// E = e^T W e / 2 (ik.cpp:46), one fixed chain of fused multiply-adds
+template <bool UNITW, class W>
+RTB_HD double ik_half_weighted_square(const double (&e)[6], W we)
+{
+#pragma clang fp contract(off)
+    double E = UNITW ? e[0] * e[0] : (e[0] * we[0]) * e[0];
+#pragma unroll
+    for (int k = 1; k < 6; ++k) E = UNITW ? __builtin_fma(e[k], e[k], E) : __builtin_fma(e[k] * we[k], e[k], E);
+    return E * 0.5;
 }
 
 // ---------------------------------------------------------------- one LM step
@@ -162,28 +176,28 @@ template <int NJ, bool UNITW = false, class W>
 RTB_HD void ik_lm_step(const double (&jac)[6 * NJ], const double (&e)[6], W we /* we[k], k < 6 */, double wn,
                        double (&dq)[NJ])
 {
+#pragma clang fp contract(off)
     double A[NJ][NJ];   // lower triangle used; after factorisation holds L (unit diagonal implied)
     double g[NJ];
     double we_e[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) we_e[k] = UNITW ? e[k] : we[k] * e[k];       // (x * 1.0 == x exactly: the unit-weight form returns the same bits)
-    // row r of W J once (6 products), then each of its normal-equation entries is 6 fused multiply-adds on it:
-    // the same products in the same order as (J[k][r] * we[k]) * J[k][c], formed 7 times instead of 28
+    // row r of W J once (6 products), then each of its normal-equation entries is one rounded product and 5 fused multiply-adds on it, k = 0 .. 5
+    // in that order (written out: nothing for the compiler to decide); formed 7 times instead of 28
 #pragma unroll
     for (int r = 0; r < NJ; ++r) {
         double wjr[6];
-        double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            wjr[k] = UNITW ? jac[k * NJ + r] : jac[k * NJ + r] * we[k];
-            s += jac[k * NJ + r] * we_e[k];
-        }
+        for (int k = 0; k < 6; ++k) wjr[k] = UNITW ? jac[k * NJ + r] : jac[k * NJ + r] * we[k];
+        double s = jac[r] * we_e[0];
+#pragma unroll
+        for (int k = 1; k < 6; ++k) s = __builtin_fma(jac[k * NJ + r], we_e[k], s);
         g[r] = s;
 #pragma unroll
         for (int c = 0; c <= r; ++c) {
-            double a = 0.0;
+            double a = wjr[0] * jac[c];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) a += wjr[k] * jac[k * NJ + c];
+            for (int k = 1; k < 6; ++k) a = __builtin_fma(wjr[k], jac[k * NJ + c], a);
             A[r][c] = (r == c) ? a + wn : a;
         }
     }
@@ -270,7 +284,7 @@ RTB_HD void ik_qnull(const double (&jac)[6 * NJ], const PD &p, QL qlim, QA qa, d
     ldl_factor<6>(B, dval, dinv);
     if (p.km > 0.0) {
         double jm[NJ];
-        jacobm_factored<NJ>(jac, 63, B, dinv, jm);
+        jacobm_factored<NJ>(jac, 63, B, dval, dinv, jm);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) grad[j] += (1.0 / p.km) * jm[j];
     }
@@ -520,10 +534,7 @@ RTB_HD void ik_iter(IkLane<NJ> &st, const PD &p, const CV &cv, QL qlim, TD td, Q
     }
     sched_fence();
     ik_angle_axis(P, td, e);
-    double E = 0.0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) E += (UNITW && !PINV) ? e[k] * e[k] : e[k] * p.we[k] * e[k];
-    E *= 0.5;                                                   // ik.cpp:46
+    double E = ik_half_weighted_square<(UNITW && !PINV)>(e, p.we);   // ik.cpp:46
     double qn[NULLSP ? NJ : 1];
     if constexpr (NULLSP) {
         if (PINV && p.method == 5) ik_qp_gain<NJ>(jac, p, qn);  // IK_QP's manipulability term (wave-uniform branch)

@@ -67,6 +67,7 @@ constexpr int kIkNullMax = 12;   // null-space step variants: 6..8 joints in reg
 #endif
 // AUX: bit 0 = the flat schedule, bit 1 = the per-wave diagnostic counters (RTBHIP_IK_STATS).  Compile-time, because carrying either through the
 // persistent loop as run-time switches cost the plain schedule 6-9 % (20 VGPRs; round 3, visit x: the round-2 build against this one on one box).
+constexpr int kIkStatWords = 6;  // per wave: loop iterations, scheduling passes, lane-iterations on a running search, items started, shader cycles, 100 MHz ticks
 constexpr int kIkAuxFlat = 1, kIkAuxStats = 2, kIkAuxUnitW = 4;      // bit 2: every mask weight is 1 (the default), LM steps: ik_iter<..., UNITW>
 #ifndef RTB_IK_MASK_IDLE
 #define RTB_IK_MASK_IDLE 0
@@ -131,6 +132,8 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
     ws.NN = count_g ? (unsigned long long)*count_g : (unsigned long long)p.N;
     __syncthreads();
     unsigned long long st_iters = 0, st_passes = 0, st_lane = 0, st_items = 0;   // diagnostics (p.stats), wave-uniform
+    unsigned long long st_t0 = 0, st_r0 = 0;                                     // ... the wave's life in shader cycles (s_memtime) and in 100 MHz ticks (s_memrealtime)
+    if constexpr (kStats) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
     bool first = true;
     unsigned tick = 0;
     int leave = 0;                    // set by a pass: 1 the wave is done, 2 out of work with sharing on (take a ticket and wait)
@@ -445,8 +448,9 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && !(STEP & kIkStepNull
         }
     }
     if (kStats && ka->p.stats && lane == 0) {
-        unsigned long long *o = ka->p.stats + 4ull * blockIdx.x;
+        unsigned long long *o = ka->p.stats + (unsigned long long)kIkStatWords * blockIdx.x;
         o[0] = st_iters; o[1] = st_passes; o[2] = st_lane; o[3] = st_items;
+        o[4] = __builtin_amdgcn_s_memtime() - st_t0; o[5] = __builtin_amdgcn_s_memrealtime() - st_r0;
     }
 }
 
@@ -759,11 +763,11 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
         ctr_ready = nullptr;
         // diagnostics: RTBHIP_IK_STATS=<file> appends one JSON line per scheduler launch with the per-wave counters (loop iterations,
         // scheduling passes, lane-iterations spent on a running search, items started).  Synchronises the stream: not for timed runs.
-        static const char *stats_path = std::getenv("RTBHIP_IK_STATS");
+        const char *stats_path = std::getenv("RTBHIP_IK_STATS");           // (read at every launch: a caller may switch it on for one call)
         unsigned long long *dstats = nullptr;
         if (stats_path && *stats_path && ik_aux_served(p2, n, true)) {
-            RTB_HIP(hipMallocAsync((void **)&dstats, (size_t)g * 4 * sizeof(unsigned long long), s));
-            RTB_HIP(hipMemsetAsync(dstats, 0, (size_t)g * 4 * sizeof(unsigned long long), s));
+            RTB_HIP(hipMallocAsync((void **)&dstats, (size_t)g * kIkStatWords * sizeof(unsigned long long), s));
+            RTB_HIP(hipMemsetAsync(dstats, 0, (size_t)g * kIkStatWords * sizeof(unsigned long long), s));
             p2.stats = dstats;
         }
         dim3 grid((unsigned)g);
@@ -803,7 +807,7 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "k_ik launch");
         if (dstats) {
-            std::vector<unsigned long long> hs((size_t)g * 4);
+            std::vector<unsigned long long> hs((size_t)g * kIkStatWords);
             RTB_HIP(hipMemcpyAsync(hs.data(), dstats, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
             RTB_HIP(hipStreamSynchronize(s));
             (void)hipFreeAsync(dstats, s);
@@ -811,7 +815,7 @@ int launch_ik(const Chain *c, const DevChain &dc, const double *qlim, const doub
                 std::fprintf(f, "{\"grid\": %lld, \"items\": %lld, \"flat_chunks\": %d, \"waves_per_cu\": %d, \"pass_mask\": %d, \"n\": %d, \"per_wave\": [",
                              (long long)g, (long long)items, (int)p2.flat_chunks, g_ik_waves_per_cu, g_ik_pass_mask, n);
                 for (int64_t w = 0; w < g; ++w)
-                    std::fprintf(f, "%s[%llu,%llu,%llu,%llu]", w ? "," : "", hs[4 * w], hs[4 * w + 1], hs[4 * w + 2], hs[4 * w + 3]);
+                    std::fprintf(f, "%s[%llu,%llu,%llu,%llu,%llu,%llu]", w ? "," : "", hs[6 * w], hs[6 * w + 1], hs[6 * w + 2], hs[6 * w + 3], hs[6 * w + 4], hs[6 * w + 5]);
                 std::fprintf(f, "]}\n");
                 std::fclose(f);
             }

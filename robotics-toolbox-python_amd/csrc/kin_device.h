@@ -42,44 +42,70 @@ RTB_HD void pose_identity(Pose &P)
 }
 
 // P <- P * Rot_axis(c, s): a rotation about a coordinate axis only mixes two columns.
+// Every sum of two products below is WRITTEN OUT as one rounded product and one fused multiply-add (fp contract(off): nothing is left to the
+// compiler).  Left to it, `a * c + b * s` becomes fma(a, c, round(b s)) or fma(b, s, round(a c)) depending on where a and b CAME FROM (LLVM orders
+// the operands of a commutative add by the depth of their expression trees before it fuses) -- measured in round 6: the same source line gave
+// different bits in a structure instantiation (a = a bare copy of an input) and in the general kernel (a = the end of a chain of three fused
+// multiply-adds), and k_ik's signature kernels drifted from the general one by 1e-10 in q.  scripts/contraction_probe.hip reproduces it.
+RTB_HD double mix_pp(double a, double c, double b, double s)      // a c + b s  :=  fma(a, c, round(b s))
+{
+#pragma clang fp contract(off)
+    return __builtin_fma(a, c, b * s);
+}
+RTB_HD double mix_pm(double b, double c, double a, double s)      // b c - a s  :=  fma(b, c, -round(a s))
+{
+#pragma clang fp contract(off)
+    return __builtin_fma(b, c, -(a * s));
+}
+RTB_HD double dot3x(double a0, double b0, double a1, double b1, double a2, double b2)      // a0 b0 + a1 b1 + a2 b2  :=  fma(a2, b2, fma(a1, b1, round(a0 b0)))
+{
+#pragma clang fp contract(off)
+    return __builtin_fma(a2, b2, __builtin_fma(a1, b1, a0 * b0));
+}
+RTB_HD double fmax_(double a, double b, double acc)               // fma(a, b, acc) as such: no `contract` flag, nothing fuses into or out of it
+{
+#pragma clang fp contract(off)
+    return __builtin_fma(a, b, acc);
+}
 RTB_HD void pose_rotx(Pose &P, double c, double s)
 {
     double a, b;
-    a = P.r01; b = P.r02; P.r01 = a * c + b * s; P.r02 = b * c - a * s;
-    a = P.r11; b = P.r12; P.r11 = a * c + b * s; P.r12 = b * c - a * s;
-    a = P.r21; b = P.r22; P.r21 = a * c + b * s; P.r22 = b * c - a * s;
+    a = P.r01; b = P.r02; P.r01 = mix_pp(a, c, b, s); P.r02 = mix_pm(b, c, a, s);
+    a = P.r11; b = P.r12; P.r11 = mix_pp(a, c, b, s); P.r12 = mix_pm(b, c, a, s);
+    a = P.r21; b = P.r22; P.r21 = mix_pp(a, c, b, s); P.r22 = mix_pm(b, c, a, s);
 }
 RTB_HD void pose_roty(Pose &P, double c, double s)
 {
     double a, b;
-    a = P.r00; b = P.r02; P.r00 = a * c - b * s; P.r02 = a * s + b * c;
-    a = P.r10; b = P.r12; P.r10 = a * c - b * s; P.r12 = a * s + b * c;
-    a = P.r20; b = P.r22; P.r20 = a * c - b * s; P.r22 = a * s + b * c;
+    a = P.r00; b = P.r02; P.r00 = mix_pm(a, c, b, s); P.r02 = mix_pp(a, s, b, c);
+    a = P.r10; b = P.r12; P.r10 = mix_pm(a, c, b, s); P.r12 = mix_pp(a, s, b, c);
+    a = P.r20; b = P.r22; P.r20 = mix_pm(a, c, b, s); P.r22 = mix_pp(a, s, b, c);
 }
 RTB_HD void pose_rotz(Pose &P, double c, double s)
 {
     double a, b;
-    a = P.r00; b = P.r01; P.r00 = a * c + b * s; P.r01 = b * c - a * s;
-    a = P.r10; b = P.r11; P.r10 = a * c + b * s; P.r11 = b * c - a * s;
-    a = P.r20; b = P.r21; P.r20 = a * c + b * s; P.r21 = b * c - a * s;
+    a = P.r00; b = P.r01; P.r00 = mix_pp(a, c, b, s); P.r01 = mix_pm(b, c, a, s);
+    a = P.r10; b = P.r11; P.r10 = mix_pp(a, c, b, s); P.r11 = mix_pm(b, c, a, s);
+    a = P.r20; b = P.r21; P.r20 = mix_pp(a, c, b, s); P.r21 = mix_pm(b, c, a, s);
 }
 // P <- P * Trans(axis, d): t += d * column
-RTB_HD void pose_tx(Pose &P, double d) { P.tx += d * P.r00; P.ty += d * P.r10; P.tz += d * P.r20; }
-RTB_HD void pose_ty(Pose &P, double d) { P.tx += d * P.r01; P.ty += d * P.r11; P.tz += d * P.r21; }
-RTB_HD void pose_tz(Pose &P, double d) { P.tx += d * P.r02; P.ty += d * P.r12; P.tz += d * P.r22; }
+RTB_HD void pose_tx(Pose &P, double d) { P.tx = fmax_(d, P.r00, P.tx); P.ty = fmax_(d, P.r10, P.ty); P.tz = fmax_(d, P.r20, P.tz); }
+RTB_HD void pose_ty(Pose &P, double d) { P.tx = fmax_(d, P.r01, P.tx); P.ty = fmax_(d, P.r11, P.ty); P.tz = fmax_(d, P.r21, P.tz); }
+RTB_HD void pose_tz(Pose &P, double d) { P.tx = fmax_(d, P.r02, P.tx); P.ty = fmax_(d, P.r12, P.ty); P.tz = fmax_(d, P.r22, P.tz); }
 // P.t += R (x, y, z) as three fused chains seeded with the old translation (one instruction less per component than sum-then-add; used by
 // k_ik's plain walk, A/B switch RTB_POSE_T3_FMA)
 RTB_HD void pose_t3_fma(Pose &P, double x, double y, double z)
 {
-    P.tx = fma(z, P.r02, fma(y, P.r01, fma(x, P.r00, P.tx)));
-    P.ty = fma(z, P.r12, fma(y, P.r11, fma(x, P.r10, P.ty)));
-    P.tz = fma(z, P.r22, fma(y, P.r21, fma(x, P.r20, P.tz)));
+    P.tx = fmax_(z, P.r02, fmax_(y, P.r01, fmax_(x, P.r00, P.tx)));
+    P.ty = fmax_(z, P.r12, fmax_(y, P.r11, fmax_(x, P.r10, P.ty)));
+    P.tz = fmax_(z, P.r22, fmax_(y, P.r21, fmax_(x, P.r20, P.tz)));
 }
 RTB_HD void pose_t3(Pose &P, double x, double y, double z)
 {
-    P.tx += x * P.r00 + y * P.r01 + z * P.r02;
-    P.ty += x * P.r10 + y * P.r11 + z * P.r12;
-    P.tz += x * P.r20 + y * P.r21 + z * P.r22;
+#pragma clang fp contract(off)
+    P.tx = P.tx + dot3x(x, P.r00, y, P.r01, z, P.r02);
+    P.ty = P.ty + dot3x(x, P.r10, y, P.r11, z, P.r12);
+    P.tz = P.tz + dot3x(x, P.r20, y, P.r21, z, P.r22);
 }
 // one row (x, y, z) of a pose times the constant rotation c (row-major, class CLS):  out_k = y c[3+k] + x c[k] + z c[6+k]  in that fixed order
 template <int CLS, class F>
@@ -143,9 +169,9 @@ RTB_HD void pose_mul_seg(Pose &P, const CV &cv, int j)
 template <int TM, class CV>
 RTB_HD void pose_seg_translate(Pose &P, const CV &cv, int j)
 {
-    if (TM & 1) { const double x = cv.seg[j].t[0]; P.tx = fma(x, P.r00, P.tx); P.ty = fma(x, P.r10, P.ty); P.tz = fma(x, P.r20, P.tz); }
-    if (TM & 2) { const double y = cv.seg[j].t[1]; P.tx = fma(y, P.r01, P.tx); P.ty = fma(y, P.r11, P.ty); P.tz = fma(y, P.r21, P.tz); }
-    if (TM & 4) { const double z = cv.seg[j].t[2]; P.tx = fma(z, P.r02, P.tx); P.ty = fma(z, P.r12, P.ty); P.tz = fma(z, P.r22, P.tz); }
+    if (TM & 1) { const double x = cv.seg[j].t[0]; P.tx = fmax_(x, P.r00, P.tx); P.ty = fmax_(x, P.r10, P.ty); P.tz = fmax_(x, P.r20, P.tz); }
+    if (TM & 2) { const double y = cv.seg[j].t[1]; P.tx = fmax_(y, P.r01, P.tx); P.ty = fmax_(y, P.r11, P.ty); P.tz = fmax_(y, P.r21, P.tz); }
+    if (TM & 4) { const double z = cv.seg[j].t[2]; P.tx = fmax_(z, P.r02, P.tx); P.ty = fmax_(z, P.r12, P.ty); P.tz = fmax_(z, P.r22, P.tz); }
 }
 template <int CLS, class CV>
 RTB_HD void pose_seg_rotate(Pose &P, const CV &cv, int j)
@@ -239,9 +265,9 @@ RTB_HD void jacobian_close(const CV &cv, int n, const Pose &P, int frame, Get ge
         double vx, vy, vz, wx, wy, wz;
         if (!jm_prismatic(jm)) {
             double dx = P.tx - get(j), dy = P.ty - get(n + j), dz = P.tz - get(2 * n + j);
-            vx = zy * dz - zz * dy;
-            vy = zz * dx - zx * dz;
-            vz = zx * dy - zy * dx;
+            vx = mix_pm(zy, dz, zz, dy);
+            vy = mix_pm(zz, dx, zx, dz);
+            vz = mix_pm(zx, dy, zy, dx);
             wx = zx; wy = zy; wz = zz;
         } else {
             vx = zx; vy = zy; vz = zz;
@@ -253,13 +279,13 @@ RTB_HD void jacobian_close(const CV &cv, int n, const Pose &P, int frame, Get ge
         }
         if (frame == 1) {
             double a = vx, b = vy, c = vz;
-            vx = P.r00 * a + P.r10 * b + P.r20 * c;
-            vy = P.r01 * a + P.r11 * b + P.r21 * c;
-            vz = P.r02 * a + P.r12 * b + P.r22 * c;
+            vx = dot3x(P.r00, a, P.r10, b, P.r20, c);
+            vy = dot3x(P.r01, a, P.r11, b, P.r21, c);
+            vz = dot3x(P.r02, a, P.r12, b, P.r22, c);
             a = wx; b = wy; c = wz;
-            wx = P.r00 * a + P.r10 * b + P.r20 * c;
-            wy = P.r01 * a + P.r11 * b + P.r21 * c;
-            wz = P.r02 * a + P.r12 * b + P.r22 * c;
+            wx = dot3x(P.r00, a, P.r10, b, P.r20, c);
+            wy = dot3x(P.r01, a, P.r11, b, P.r21, c);
+            wz = dot3x(P.r02, a, P.r12, b, P.r22, c);
         }
         put(j, vx); put(n + j, vy); put(2 * n + j, vz);
         put(3 * n + j, wx); put(4 * n + j, wy); put(5 * n + j, wz);

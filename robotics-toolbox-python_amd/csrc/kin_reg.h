@@ -124,6 +124,7 @@ template <int NJ, bool WANT_J>
 RTB_HD void reg_close_jacobian(const Pose &P, int frame, const int (&jmv)[NJ], double (&jac)[6 * NJ])
 {
     if (WANT_J) {
+#pragma clang fp contract(off)
         // Jv = z x (p_e - p), Jw = z (revolute) ; Jv = z, Jw = 0 (prismatic); flip negates
         // (methods.cpp:142-195); frame 1 rotates both halves by Re^T.
 #pragma unroll
@@ -136,18 +137,18 @@ RTB_HD void reg_close_jacobian(const Pose &P, int frame, const int (&jmv)[NJ], d
                 wx = 0.0; wy = 0.0; wz = 0.0;
             } else {
                 const double dx = P.tx - jac[j], dy = P.ty - jac[NJ + j], dz = P.tz - jac[2 * NJ + j];
-                vx = zy * dz - zz * dy; vy = zz * dx - zx * dz; vz = zx * dy - zy * dx;
+                vx = mix_pm(zy, dz, zz, dy); vy = mix_pm(zz, dx, zx, dz); vz = mix_pm(zx, dy, zy, dx);      // (written out: kin_device.h, mix_pp)
                 wx = zx; wy = zy; wz = zz;
             }
             if (frame == 1) {
                 double a = vx, b = vy, e = vz;
-                vx = P.r00 * a + P.r10 * b + P.r20 * e;
-                vy = P.r01 * a + P.r11 * b + P.r21 * e;
-                vz = P.r02 * a + P.r12 * b + P.r22 * e;
+                vx = dot3x(P.r00, a, P.r10, b, P.r20, e);
+                vy = dot3x(P.r01, a, P.r11, b, P.r21, e);
+                vz = dot3x(P.r02, a, P.r12, b, P.r22, e);
                 a = wx; b = wy; e = wz;
-                wx = P.r00 * a + P.r10 * b + P.r20 * e;
-                wy = P.r01 * a + P.r11 * b + P.r21 * e;
-                wz = P.r02 * a + P.r12 * b + P.r22 * e;
+                wx = dot3x(P.r00, a, P.r10, b, P.r20, e);
+                wy = dot3x(P.r01, a, P.r11, b, P.r21, e);
+                wz = dot3x(P.r02, a, P.r12, b, P.r22, e);
             }
             jac[j] = vx; jac[NJ + j] = vy; jac[2 * NJ + j] = vz;
             jac[3 * NJ + j] = wx; jac[4 * NJ + j] = wy; jac[5 * NJ + j] = wz;

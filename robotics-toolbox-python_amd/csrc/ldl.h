@@ -14,10 +14,11 @@ namespace rtbhip {
 // again anyway.  d = 0 / inf / NaN still yield a non-finite result.  On the host (tests/emu) it is the plain quotient.
 RTB_HD double rcp_pivot(double d)
 {
+#pragma clang fp contract(off)
 #if defined(__HIP_DEVICE_COMPILE__)
     double y = __builtin_amdgcn_rcp(d);
-    y = fma(fma(-d, y, 1.0), y, y);
-    y = fma(fma(-d, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
     return y;
 #else
     return 1.0 / d;
@@ -32,22 +33,25 @@ RTB_HD double rcp_pivot(double d)
 #ifndef RTB_LDL_KEEP_U
 #define RTB_LDL_KEEP_U 1
 #endif
+// (fp contract(off), every fused multiply-add written: the recurrences are single chains the compiler would fuse the same way, but "would" is not
+// a construction -- see kin_device.h, mix_pp)
 template <int N, bool FAST = false>
 RTB_HD void ldl_factor(double (&A)[N][N], double (&dval)[N], double (&dinv)[N])
 {
+#pragma clang fp contract(off)
     if constexpr (FAST && RTB_LDL_KEEP_U) {
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             double d = A[j][j];
 #pragma unroll
-            for (int k = 0; k < j; ++k) d -= A[j][k] * A[k][j];
+            for (int k = 0; k < j; ++k) d = __builtin_fma(-A[j][k], A[k][j], d);
             dval[j] = d;
             dinv[j] = rcp_pivot(d);
 #pragma unroll
             for (int i = j + 1; i < N; ++i) {
                 double v = A[i][j];
 #pragma unroll
-                for (int k = 0; k < j; ++k) v -= A[i][k] * A[k][j];
+                for (int k = 0; k < j; ++k) v = __builtin_fma(-A[i][k], A[k][j], v);
                 A[j][i] = v;                      // u_ij = L_ij d_j
                 A[i][j] = v * dinv[j];
             }
@@ -58,14 +62,14 @@ RTB_HD void ldl_factor(double (&A)[N][N], double (&dval)[N], double (&dinv)[N])
     for (int j = 0; j < N; ++j) {
         double d = A[j][j];
 #pragma unroll
-        for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k] * dval[k];
+        for (int k = 0; k < j; ++k) d = __builtin_fma(-(A[j][k] * A[j][k]), dval[k], d);
         dval[j] = d;
         dinv[j] = FAST ? rcp_pivot(d) : 1.0 / d;
 #pragma unroll
         for (int i = j + 1; i < N; ++i) {
             double v = A[i][j];
 #pragma unroll
-            for (int k = 0; k < j; ++k) v -= A[i][k] * A[j][k] * dval[k];
+            for (int k = 0; k < j; ++k) v = __builtin_fma(-(A[i][k] * A[j][k]), dval[k], v);
             A[i][j] = v * dinv[j];
         }
     }
@@ -75,11 +79,12 @@ RTB_HD void ldl_factor(double (&A)[N][N], double (&dval)[N], double (&dinv)[N])
 template <int N>
 RTB_HD void ldl_backsolve(const double (&A)[N][N], const double (&dinv)[N], double (&g)[N], double (&x)[N])
 {
+#pragma clang fp contract(off)
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         double v = g[i];
 #pragma unroll
-        for (int k = 0; k < i; ++k) v -= A[i][k] * g[k];
+        for (int k = 0; k < i; ++k) v = __builtin_fma(-A[i][k], g[k], v);
         g[i] = v;
     }
 #pragma unroll
@@ -88,7 +93,7 @@ RTB_HD void ldl_backsolve(const double (&A)[N][N], const double (&dinv)[N], doub
     for (int i = N - 1; i >= 0; --i) {
         double v = g[i];
 #pragma unroll
-        for (int k = i + 1; k < N; ++k) v -= A[k][i] * x[k];
+        for (int k = i + 1; k < N; ++k) v = __builtin_fma(-A[k][i], x[k], v);
         x[i] = v;
     }
 }
@@ -100,6 +105,36 @@ RTB_HD void ldl_solve(double (&A)[N][N], double (&g)[N], double (&x)[N])
     double dval[N], dinv[N];
     ldl_factor<N, FAST>(A, dval, dinv);
     ldl_backsolve<N>(A, dinv, g, x);
+}
+
+// Determinant of a symmetric positive SEMI-definite matrix (a Gram matrix J J^T): the product of the pivots of the LDL^T factorisation without
+// pivoting (the u-keeping recurrence of ldl_factor<N, true>).  A pivot that is exactly zero -- the matrix is singular, and in exact arithmetic the
+// column below it is zero too -- gets reciprocal 0 instead of infinity: the product, and with it the result, is an exact 0 rather than a NaN.
+// A is destroyed.
+template <int N>
+RTB_HD double det_psd(double (&A)[N][N])
+{
+#pragma clang fp contract(off)
+    double det = 1.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double d = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d = __builtin_fma(-A[j][k], A[k][j], d);
+        det *= d;
+        if (j + 1 < N) {
+            const double r = d != 0.0 ? rcp_pivot(d) : 0.0;
+#pragma unroll
+            for (int i = j + 1; i < N; ++i) {
+                double v = A[i][j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) v = __builtin_fma(-A[i][k], A[k][j], v);
+                A[j][i] = v;
+                A[i][j] = v * r;
+            }
+        }
+    }
+    return det;
 }
 
 // Determinant of a general N x N matrix by LU with partial pivoting (what numpy.linalg.det does through
