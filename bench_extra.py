@@ -84,9 +84,12 @@ def ik_roofline(lm_iterations_per_s):
 #                 budget: a lower bound of its arithmetic): rne 1 620 + 360 = 1 980, inertia 21 x 164 + 360 = 3 804, coriolis 21 x 356 + 15 x 62 + 360 = 8 766,
 #                 accel 1 620 + 3 444 + 144 + 360 = 5 568
 #   FK + Jacobian walk of the 7-joint chain = 600 flop, then
-#     jacob0_dot      + sum over joint pairs (j <= i: two cross products and six FMAs = 30; j > i: 15): 28 x 30 + 21 x 15 = 1 155   -> 1 755
-#     manipulability  + J J^T (21 entries x 7 FMAs = 294) + 6x6 LU determinant (144) + sqrt                                      -> 1 050
-#     jacobm          + J J^T 294 + LDL^T 100 + 7 back-substitutions (504) + 49 Hessian-block contractions x 30 (1 470) + m        -> 3 000
+#   (rounds 1-5 priced the pair loops the definitions suggest: jacob0_dot 1 755, manipulability 1 050 with a row-exchanging LU, jacobm 3 000 with 49
+#   Hessian-block contractions.  Round 6 found the O(n) running-sum forms -- csrc/diff_device.h -- and the budgets are those of the better formulation now;
+#   `frac_at_round5_pricing` on the line keeps the old yardstick beside the new one: a faster kernel must not look slower because its algorithm improved.)
+#     jacob0_dot      + prefix / suffix sums (6 FMAs per joint) + three cross products and three adds per joint (30): 7 x 42 = 294       ->   894
+#     manipulability  + J J^T (21 entries x 7 FMAs = 294) + LDL^T pivots of the 6 x 6 Gram matrix (116) + sqrt                          -> 1 010
+#     jacobm          + J J^T 294 + LDL^T 100 + 7 back-substitutions (462) + per joint three cross products, sums and two dot products (45 x 7) + m   -> 1 780
 #   ROUND 5 -- the DH Panda re-priced.  Its link table is structured (alpha = 0 / +-pi/2, centres of mass at the link origins, a or d zero on most links, no
 #   friction, no motor inertia) and the kernels now exploit that at compile time (rne_device.h: RneSig), so the budgets above -- those of a GENERAL link --
 #   are no longer the best formulation known for THIS robot: a fraction quoted against them would count work nobody has to do (accel: 0.95).  The
@@ -94,16 +97,18 @@ def ik_roofline(lm_iterations_per_s):
 #   (general 135), acceleration-only 66 = 132 flop (82), two-field passes 0.76 of the general ones:
 #     gravload 7 x 132 + 420 = 1 344; inertia 28 x 132 + 420 = 4 116; coriolis 0.76 x (9 968 + 1 302) + 420 = 8 985; accel 7 x 184 + 28 x 132 + 212 + 420 = 5 616
 #   (the UR5 tree stays priced at the general DH budget: its signature kernels still execute more than that, 166 operations per group-pass)
-ALGO_FLOPS_PER_UNIT = {"gravload": 1344, "inertia": 4116, "coriolis": 8985, "accel": 5616, "tree_ur5": 1980, "jacob0_dot": 1755,
-                       "manipulability": 1050, "jacobm": 3000, "tree_inertia_ur5": 3804, "tree_coriolis_ur5": 8766, "tree_accel_ur5": 5568,
+ROUND5_FLOPS_PER_UNIT = {"jacob0_dot": 1755, "manipulability": 1050, "jacobm": 3000}
+ALGO_FLOPS_PER_UNIT = {"gravload": 1344, "inertia": 4116, "coriolis": 8985, "accel": 5616, "tree_ur5": 1980, "jacob0_dot": 894,
+                       "manipulability": 1010, "jacobm": 1780, "tree_inertia_ur5": 3804, "tree_coriolis_ur5": 8766, "tree_accel_ur5": 5568,
                        "tree_gravload_ur5": 1344}        # 6 acceleration-only link-passes + 6 sincos
 # VALU instructions per lane actually EXECUTED (SQ_INSTS_VALU / SQ_WAVES; the dynamics kernels' structure-signature instantiations of round 5:
 # profiles/r05_t_sq_digest.txt -- the general kernels execute 833 / 3433 / 5954 / 3377 and 1929 / 4345 / 10864 / 7216 / 1275, profiles/r04_u_sq_tree_dyn.txt,
 # r04_v_sq_dyn.txt; the kinematics consumers: profiles/r03_a_sq_summary.txt): reported beside
 # the roofline as `valu_issue_util` (share of the chip's fp64 issue slots the kernel fills) -- a diagnostic, not a roofline: a kernel that
 # executed more instructions for the same answer would score higher on it.
-VALU_PER_UNIT = {"gravload": 687, "inertia": 2930, "coriolis": 4542, "accel": 2797, "tree_ur5": 1192, "jacob0_dot": 1692,
-                 "manipulability": 1512, "jacobm": 2732,
+# (jacob0_dot / manipulability / jacobm: round 6's running-sum forms, profiles/r06_i_sq_digest_kin.txt -- rounds 3-5: 1692 / 1512 / 2732)
+VALU_PER_UNIT = {"gravload": 687, "inertia": 2930, "coriolis": 4542, "accel": 2797, "tree_ur5": 1192, "jacob0_dot": 1361,
+                 "manipulability": 1182, "jacobm": 1897,
                  "tree_inertia_ur5": 2578, "tree_coriolis_ur5": 6032, "tree_accel_ur5": 3323, "tree_gravload_ur5": 713}
 
 
@@ -123,6 +128,8 @@ def valu_roofline(key, units_per_s, kernel, hbm_bytes_per_unit):
         out = {"bound": "fp64-valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
                "algorithmic_flops_per_unit": flops, "flops_source": src,
                "kernel": kernel, "hbm_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
+    if key in ROUND5_FLOPS_PER_UNIT:
+        out["frac_at_round5_pricing"] = ROUND5_FLOPS_PER_UNIT[key] * units_per_s / 1e12 / FP64_VALU_PEAK_TFLOPS
     instr = VALU_PER_UNIT.get(key)
     if instr is not None:
         out["valu_issue_util"] = 2.0 * instr * units_per_s / 1e12 / FP64_VALU_PEAK_TFLOPS

@@ -131,6 +131,57 @@ def ik_config3(rtbhip, N=100000, sample=2000):
                      "cpu_seconds": cpu_s}
     if first < n // 2 or same != first or not dq <= 1e-6:
         raise SystemExit("bench: secondary ik parity failed: %r" % (out["parity"],))
+    out["loss_factors"] = ik_loss_factors(run, its, ms)
+    return out
+
+
+def ik_loss_factors(run, its, ms):
+    """Where k_ik's distance from the fp64 roof goes (config 3), measured by this run where it can be:
+        lane_running   share of the lane slots of the kernel's LM iterations that held a running search (the rest: idle or parked lanes)
+        lane_useful    share that produced an iteration the reference's sequential loop REPORTS (running minus discarded speculation:
+                       searches started ahead of an earlier one that then succeeded)
+        clock_ghz      effective shader clock of the waves while they ran: s_memtime cycles / s_memrealtime 100 MHz ticks, summed over waves
+    from ONE extra launch of the same call with the kernel's diagnostic counters on (RTBHIP_IK_STATS: the counting instantiation of the SAME
+    signature kernel, csrc/ik_kernels.hip kIkAuxStats -- six words per wave), and, from the committed SQ-counter pass of this round
+    (profiles/r06_ik_sq.json: rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES over scripts/ik_loss_factors.py -- counters are their own run, never the timed one):
+        valu_per_iteration   VALU instructions a wave executes per LM iteration of its loop, scheduling passes amortised in
+        valu_issue_util      those instructions against the fp64 issue slots the kernel's duration offers (one wave64 instruction per SIMD per 4 cycles
+                             at clock_ghz): how full the pipes are -- a diagnostic, a kernel executing more instructions for the same answer scores higher
+    The product  lane_useful x (algorithmic FMAs / valu_per_iteration) x valu_issue_util x (clock_ghz / 2.4)  is the roofline fraction, up to the
+    share of the flop count that is not FMA."""
+    import json
+    import os
+    import tempfile
+    import numpy as np
+    import torch
+    import rtbhip
+    fd, path = tempfile.mkstemp(suffix=".jsonl")
+    os.close(fd)
+    os.environ["RTBHIP_IK_STATS"] = path
+    try:
+        run()
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["RTBHIP_IK_STATS"]
+    rows = [json.loads(l) for l in open(path) if l.strip()]
+    os.unlink(path)
+    if not rows:
+        return {"error": "no counters came back (RTBHIP_IK_STATS is served for the 7-joint arm only)"}
+    w = np.array([x for r in rows for x in r["per_wave"]], dtype=np.float64)
+    wave_iters, passes, running, cyc, ticks = w[:, 0].sum(), w[:, 1].sum(), w[:, 2].sum(), w[:, 4].sum(), w[:, 5].sum()
+    clock = 0.1 * cyc / ticks if ticks > 0 else None
+    out = {"wave_iterations": int(wave_iters), "scheduling_passes": int(passes), "waves": int(len(w)), "lane_running": running / (64.0 * wave_iters),
+           "lane_useful": its / (64.0 * wave_iters), "clock_ghz": clock,
+           "how": "one extra launch with the diagnostic counters of the same signature kernel (not timed); clock = s_memtime cycles / s_memrealtime ticks over the waves' lives"}
+    here = os.path.dirname(os.path.abspath(__file__))
+    sq = os.path.join(here, "profiles", "r06_ik_sq.json")
+    if os.path.exists(sq):
+        c = json.load(open(sq))
+        vpi = c["valu_per_wave_iteration"]
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        slots = ms * 1e-3 * (clock or 2.4) * 1e9 / 4.0 * cus * 4
+        out.update({"valu_per_iteration": vpi, "valu_issue_util": vpi * wave_iters / slots, "algorithmic_fma_per_iteration": IK_FLOPS_PER_ITERATION / 2.0,
+                    "valu_source": "committed constant: profiles/r06_ik_sq.json (SQ_INSTS_VALU / wave iterations of the counted launches, %s)" % c.get("visit", "")})
     return out
 
 
@@ -486,6 +537,12 @@ def structure_legs(rtbhip, n_rne=10000000, n_ik=100000, n_tree=1000000):
     return out
 
 
+# the instantiations that serve configs 3 and 4 (the structure legs launch the general kernels and run-time instantiations of the same templates on the
+# same grids: the committed profile is read for exactly these names) -- csrc/ik_kernels.hip kIkSigPandaETS, csrc/rne_device.h kRneSigPanda
+K_IK_PANDA = "k_ik<7, 0, 13, 9265531810339127745ull>"
+K_RNE_PANDA = "k_rne<7, true, true, 16140979858257510057ull>"
+
+
 def _committed(root, out):
     """`frac_rocprof_committed` for the secondary legs, from the rocprofv3 --kernel-trace run of THIS command committed under profiles/
     (rNN_*_secondary_kernel_stats.csv: scripts/visit.sh stage `profsec` -> scripts/secondary_stats.py, durations per kernel AND grid size -- config 4
@@ -514,8 +571,8 @@ def _committed(root, out):
         rf["rocprof_committed"] = note(row)
     for leg in ("rne_config4_1e7", "rne_config4_shard"):
         if isinstance(out.get(leg), dict) and "n" in out[leg]:
-            hbm(leg, find("k_rne<7", ((out[leg]["n"] + 63) // 64) * 64))
-    ik = find("k_ik<7")
+            hbm(leg, find(K_RNE_PANDA, ((out[leg]["n"] + 63) // 64) * 64))
+    ik = find(K_IK_PANDA)
     leg = out.get("ik_config3")
     if ik is not None and isinstance(leg, dict) and "roofline" in leg:
         its = leg["mean_iterations"] * leg["n"]

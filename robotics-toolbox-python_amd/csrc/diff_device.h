@@ -244,9 +244,8 @@ RTB_HD void jacobm_factored(const double (&jac)[6 * NJ], int axes, const double 
     for (int r = 1; r < 6; ++r) det *= dval[r];
     // (a square J_a: |det J| itself, ETS.py:1782-1784 -- near a singularity it keeps the digits the square root of det(J J^T) loses)
     const double m = (NJ == 6 && (axes & 63) == 63) ? manipulability_yoshikawa<NJ>(jac, axes) : sqrt(fabs(det));
-    double Px[NJ], Py[NJ], Pz[NJ];          // P_i
     double cx[NJ], cy[NJ], cz[NJ];          // v_k x Ga_k + w_k x Gb_k
-    double px = 0.0, py = 0.0, pz = 0.0;
+    double px = 0.0, py = 0.0, pz = 0.0;    // P_k, consumed as it grows (no array of prefixes is kept)
 #pragma unroll
     for (int k = 0; k < NJ; ++k) {
         // column k of G = (J_a J_a^T)^-1 J_a (rows outside `axes` come out zero)
@@ -259,15 +258,14 @@ RTB_HD void jacobm_factored(const double (&jac)[6 * NJ], int axes, const double 
         cx[k] = (vky * x[2] - vkz * x[1]) + (wky * x[5] - wkz * x[4]);
         cy[k] = (vkz * x[0] - vkx * x[2]) + (wkz * x[3] - wkx * x[5]);
         cz[k] = (vkx * x[1] - vky * x[0]) + (wkx * x[4] - wky * x[3]);
-        Px[k] = px; Py[k] = py; Pz[k] = pz;
-        px += x[1] * wkz - x[2] * wky; py += x[2] * wkx - x[0] * wkz; pz += x[0] * wky - x[1] * wkx;      // Ga_k x w_k
+        jm[k] = vkx * px + vky * py + vkz * pz;                                                             // v_k . P_k
+        px += x[1] * wkz - x[2] * wky; py += x[2] * wkx - x[0] * wkz; pz += x[0] * wky - x[1] * wkx;      // + Ga_k x w_k
     }
     double sx = 0.0, sy = 0.0, sz = 0.0;
 #pragma unroll
     for (int i = NJ - 1; i >= 0; --i) {
         sx += cx[i]; sy += cy[i]; sz += cz[i];
-        const double acc = (jac[3 * NJ + i] * sx + jac[4 * NJ + i] * sy + jac[5 * NJ + i] * sz) + (jac[i] * Px[i] + jac[NJ + i] * Py[i] + jac[2 * NJ + i] * Pz[i]);
-        jm[i] = m * acc;
+        jm[i] = m * ((jac[3 * NJ + i] * sx + jac[4 * NJ + i] * sy + jac[5 * NJ + i] * sz) + jm[i]);
     }
 }
 

@@ -26,8 +26,11 @@ __device__ __forceinline__ ConstChain const_view(const DevChain &dc)
 // the reference materialises for each of them (robot/Robot.py:1069, robot/ETS.py:1671) never exists.
 constexpr int kDiffMax = 16;   // jacob_dot / manipulability / jacobm / analytical Jacobian: compile-time joint counts up to here
 enum { kDiffJdot = 0, kDiffManip = 1, kDiffJacobm = 2, kDiffAnalytical = 3, kDiffAnalyticalDot = 4 };
+#ifndef RTB_DIFF_WAVES
+#define RTB_DIFF_WAVES 2        // waves per SIMD the register allocator must leave room for (chains of up to 8 joints; A/B knob)
+#endif
 template <int NJ, int MODE>
-__global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && MODE != 4 ? 2 : 1)) void k_kin_diff(KinParams kp, DevChain dc, int axes, const double *__restrict__ q,
+__global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && MODE != 4 ? RTB_DIFF_WAVES : 1)) void k_kin_diff(KinParams kp, DevChain dc, int axes, const double *__restrict__ q,
                                                        const double *__restrict__ qd, double *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) double buf[];

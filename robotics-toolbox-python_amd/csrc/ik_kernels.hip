@@ -673,6 +673,13 @@ static void launch_nj(const Chain *c, dim3 grid, hipStream_t s, const IkDev &p, 
         if (flat && !stats) { hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxFlat>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share); return; }
     }
     if constexpr (NJ == 7) {                              // the counters: the benchmark's arm only
+        // ... on the very instantiation that serves config 3 (the Panda's signature, unit mask): lane utilisation and the effective clock on the bench line
+        // (benchsecondary.py: ik_loss_factors) are then those of the kernel that is timed, not of the general one
+        if (stats && p.unit_we && p.pad_we && g_ik_plain && g_ik_sig && chain_sig == kIkSigPandaETS) {
+            if (flat) hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxFlat | kIkAuxStats | kIkAuxUnitW | kIkAuxPlain, kIkSigPandaETS>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share);
+            else hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxStats | kIkAuxUnitW | kIkAuxPlain, kIkSigPandaETS>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share);
+            return;
+        }
         if (stats && flat) { hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxFlat | kIkAuxStats>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share); return; }
         if (stats) { hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxStats>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share); return; }
     }

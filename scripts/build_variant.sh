@@ -5,7 +5,7 @@ set -e
 R=$(cd $(dirname $0)/.. && pwd)
 src=$1; name=$2; shift 2
 mkdir -p $R/robotics-toolbox-python_amd/lib/variants $R/build/variant
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -I$R/include "$@" -c $R/robotics-toolbox-python_amd/csrc/$src.hip -o $R/build/variant/${src}_$name.o
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -mllvm -pragma-unroll-threshold=1048576 -I$R/include "$@" -c $R/robotics-toolbox-python_amd/csrc/$src.hip -o $R/build/variant/${src}_$name.o
 objs=$(ls $R/build/obj/*.o | grep -v $src.hip.o)
 hipcc --offload-arch=gfx950 -shared -fPIC $objs $R/build/variant/${src}_$name.o -o $R/robotics-toolbox-python_amd/lib/variants/$name.so
 ls -la $R/robotics-toolbox-python_amd/lib/variants/$name.so

@@ -14,6 +14,8 @@
 #   layout  scripts/layout_probe.py --fleet (packed vs two-array outputs over fresh allocations; VARIANTS="a.so b.so" adds A/B libraries)
 #   ikab    scripts/ik_ab.py over VARIANTS (A/B libraries of the IK kernel, interleaved, sustained)
 #   libab   scripts/ik_lib_time.py for the product library and every VARIANTS library, LIBAB_ROUNDS interleaved rounds         -> ik_lib_ab.jsonl
+#   iksq    scripts/ik_loss_factors.py plainly and under an SQ_INSTS_VALU / SQ_WAVES pass                                      -> ik_loss_factors.json, ik_sq.json
+#   place   scripts/placement_pmc.py: allocator variants of one 464 MB non-temporal stream, TCC counter passes                  -> placement.jsonl, place_table*.txt
 #   cmd     eval "$CMD" (anything else; output -> cmd.log)
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
@@ -90,6 +92,38 @@ if has fuzz; then
   for f in ${FUZZ:-dyn ik kin rne paths fleet}; do
     timeout 900 python scripts/gpu_fuzz_$f.py > $O/fuzz_$f.jsonl 2> $O/fuzz_$f.err; echo "fuzz $f rc=$?" >> $O/fuzz_$f.jsonl; tail -2 $O/fuzz_$f.jsonl | cut -c1-300
   done
+fi
+if has iksq; then
+  # k_ik's executed VALU instructions per wave iteration: SQ_INSTS_VALU / SQ_WAVES of config 3's call (its own pass), divided by the wave iterations
+  # the same script reports from the kernel's diagnostic counters -> ik_sq.json (committed as profiles/r06_ik_sq.json: the bench line's constant)
+  timeout 300 python scripts/ik_loss_factors.py > $O/ik_loss_factors.json 2> $O/ik_loss_factors.err; cut -c1-600 $O/ik_loss_factors.json
+  cd /tmp
+  mkdir -p $O/pmc_iksq
+  timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d $O/pmc_iksq -o sq -- python $R/scripts/ik_loss_factors.py --launches 4 > $O/pmc_iksq/run.json 2> $O/pmc_iksq.log || echo "ik sq pass failed"
+  cd $R
+  python scripts/ik_loss_factors.py --digest $O/pmc_iksq $O/ik_sq.json | cut -c1-500
+fi
+if has place; then
+  # placement of ONE non-temporal 464 MB output stream (scripts/placement_pmc.py): allocator variants timed plainly, then counter passes on torch's arrays
+  : > $O/placement.jsonl
+  for al in ${PLACE_ALLOCS:-torch hip ext:0x3 ext:0x4 align:2 align:1024}; do
+    timeout 300 python scripts/placement_pmc.py --alloc $al >> $O/placement.jsonl 2>> $O/placement.err
+  done
+  grep summary $O/placement.jsonl | cut -c1-300
+  (rocprofv3 -L 2>/dev/null || rocprofv3 --list-avail 2>/dev/null) | grep -o "TCC_[A-Z0-9_a-z]*\|MALL[A-Z0-9_a-z]*" | sort -u > $O/tcc_counters.txt; wc -l $O/tcc_counters.txt
+  cd /tmp
+  i=0
+  while read -r set; do
+    [ -z "$set" ] && continue
+    i=$((i+1))
+    mkdir -p $O/pmc_place$i
+    timeout 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_place$i -o pl -- python $R/scripts/placement_pmc.py --launches 12 > $O/pmc_place$i/run.jsonl 2> $O/pmc_place$i.log || echo "place pass $i ($set) failed"
+    python $R/scripts/placement_pmc.py --digest $O/pmc_place$i $O/pmc_place$i/run.jsonl > $O/place_table$i.txt 2>> $O/placement.err; cat $O/place_table$i.txt | cut -c1-250
+  done <<< "${PLACE_SETS:-TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum
+TCC_TAG_STALL_sum TCC_BUSY_sum
+TCC_HIT_sum TCC_MISS_sum TCC_WRITEBACK_sum
+TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WRREQ_GMI_sum TCC_EA0_WRREQ_IO_sum}"
+  cd $R
 fi
 if has cmd; then eval "$CMD" > $O/cmd.log 2>&1; tail -${CMD_TAIL:-40} $O/cmd.log; fi
 find $O -name "*kernel_trace.csv" -size +8M -delete

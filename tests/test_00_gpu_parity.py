@@ -741,8 +741,10 @@ def test_ik_structure_signature_kernel_returns_the_general_kernel_s_bits():
         finally:
             rtbhip.tune("ik_sig", 1)
         # every structured segment form is the general product's operation sequence with its exact zeros and ones rewritten (kin_device.h: dotk,
-        # explicit fused multiply-adds under fp contract(off)): the SAME BITS by construction -- the Panda's and (round 5: 6e-9 apart, the compiler
-        # having fused across a pure-permutation constant) the UR's too
+        # explicit fused multiply-adds under fp contract(off)), and everything downstream of it in the iteration -- the joint rotations, the Jacobian's
+        # cross products, the pose error, the normal equations, the LDL^T solve -- is written out the same way (kin_device.h: mix_pp; what the compiler
+        # makes of `a c + b s` depends on where a and b came from, scripts/contraction_probe.hip): the SAME BITS by construction -- the Panda's and
+        # (round 5: 6e-9 apart) the UR's too
         for x, y in zip(res[1], res[0]):
             nt.assert_array_equal(np.asarray(x), np.asarray(y))
         assert np.asarray(res[1][1]).mean() > 0.8
