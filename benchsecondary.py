@@ -395,6 +395,28 @@ def structure_legs(rtbhip, n_rne=10000000, n_ik=100000, n_tree=1000000):
         jit.wait(300)
         return time.perf_counter() - t0
 
+    def runtime_instead_of_builtin(obj, run, res, ms_builtin):
+        """The SAME robot and workload served by the kernel hipRTC compiles for its structure instead of the instantiation built into the library
+        (rtbhip_tune("sig_builtin", 0)): what "compiled at run time" costs against "instantiated by hand" -- same sources, same words, another moment."""
+        def snap():
+            return [x.clone() for x in (res["out"] if "out" in res else [res["tau"]])]
+        run()
+        ref = snap()
+        rtbhip.tune("sig_builtin", 0)
+        try:
+            wait_s = settle(obj)
+            l0 = jit.stats()["launches"]
+            ms = timed(run)
+            served = jit.stats()["launches"] - l0
+            same = all(bool(torch.equal(a, b)) for a, b in zip(ref, snap()))
+        finally:
+            rtbhip.tune("sig_builtin", 1)
+        r = {"builtin_ms": ms_builtin, "runtime_ms": ms, "runtime_over_builtin": ms / ms_builtin, "launches_served_by_jit": int(served), "bit_identical": same,
+             "wait_for_compile_s": wait_s}
+        if not same or served < 1:
+            raise SystemExit("bench: a robot's run-time instantiation differs from its built-in one (or did not serve): %r" % (r,))
+        return r
+
     g = torch.Generator(device="cuda").manual_seed(11)
 
     # ---- RNE (config 4's shape): the DH Panda on the general kernel; a DH Panda with one alpha perturbed (no built-in instantiation)
@@ -418,6 +440,7 @@ def structure_legs(rtbhip, n_rne=10000000, n_ik=100000, n_tree=1000000):
     ms_sig = timed(run)
     out["rne_general"] = {"workload": "config 4's shape: DH Panda rne, %d triples, GENERAL kernel k_rne<7,MDH,all-revolute> (rne_sig = 0)" % n_rne,
                           "kernel_avg_ms": ms_gen, "builtin_signature_ms": ms_sig, "roofline": _hbm(RNE_BYTES_PER_TRIPLE * n_rne, ms_gen, "k_rne<7,true,true,0>")}
+    out["rne_general"]["runtime_vs_builtin"] = runtime_instead_of_builtin(panda, run, res, ms_sig)
     links = list(panda.links)
     k = links[3]
     links[3] = rtbhip.RevoluteMDH(a=k.a, d=k.d, alpha=k.alpha + 0.01, m=k.m, r=k.r, I=k.I, G=1)
@@ -465,6 +488,9 @@ def structure_legs(rtbhip, n_rne=10000000, n_ik=100000, n_tree=1000000):
                          "roofline": {"bound": "fp64-valu", "unit": "TFLOP/s", "peak": FP64_VALU_PEAK_TFLOPS,
                                       "achieved": its / (ms_gen * 1e-3) * IK_FLOPS_PER_ITERATION / 1e12,
                                       "frac": its / (ms_gen * 1e-3) * IK_FLOPS_PER_ITERATION / 1e12 / FP64_VALU_PEAK_TFLOPS, "kernel": "k_ik<7,0,13,0>"}}
+    ms_sig = timed(run)
+    out["ik_general"]["builtin_signature_ms"] = ms_sig
+    out["ik_general"]["runtime_vs_builtin"] = runtime_instead_of_builtin(pe, run, res, ms_sig)
     lbr = urdf.load("LBR").ets()
     wait_s = settle(lbr)
     run, res = ik_leg(lbr, n_ik, 4)
@@ -480,7 +506,7 @@ def structure_legs(rtbhip, n_rne=10000000, n_ik=100000, n_tree=1000000):
     counts_same = all(bool(torch.equal(a[k], res["out"][k])) for k in (1, 2, 3))
     okb = a[1].bool()
     dq = float((a[0][okb] - res["out"][0][okb]).abs().max()) if bool(okb.any()) else 0.0
-    same = counts_same and dq <= 1e-8            # (decisions and counts equal; q: the same bits for this robot today -- `max_abs_dq` says)
+    same = counts_same and dq == 0.0             # the same bits, q included (round 6: by construction, csrc/kin_device.h mix_pp)
     its = float(a[2].sum())
     out["ik_jit"] = {"workload": "config 3's shape on the LBR iiwa read from its URDF (7 joints, one negative axis, URDF limits): %d reachable targets, ik_LM defaults" % n_ik,
                      "kernel_avg_ms": ms_jit, "general_kernel_ms": ms_gen2, "speedup_vs_general": ms_gen2 / ms_jit, "launches_served_by_jit": int(served),
@@ -511,6 +537,7 @@ def structure_legs(rtbhip, n_rne=10000000, n_ik=100000, n_tree=1000000):
     ms_sig = timed(run)
     out["tree_general"] = {"workload": "UR5 link tree (6 groups) Robot.rne, %d triples, GENERAL kernel k_tree_rne<6,false> (tree_sig = 0)" % n_tree,
                            "kernel_avg_ms": ms_gen, "builtin_signature_ms": ms_sig}
+    out["tree_general"]["runtime_vs_builtin"] = runtime_instead_of_builtin(ur, run, res, ms_sig)
     for name in ("KinovaGen3", "YuMi"):
         t = urdf.load(name).erobot()
         wait_s = settle(t)

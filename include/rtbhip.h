@@ -405,9 +405,10 @@ int rtbhip_last_launch(int32_t *grid, int32_t *block, int32_t *lds_bytes);
  *   "ik_donate_after" k       ... ranges are cut only from targets with k failed searches (default 3)
  *   "ik_phased" 0 | 1 | 2     phased schedule (first searches, then compacted work lists): never (default) / automatic / always
  *   "ik_fresh_pct" p, "ik_pass_mask" m, "ik_waves_per_cu" w, "ik_spec_policy" 0 | 1     pacing of the per-wave scheduler
- *   "ik_sig" 1 | 0            a chain whose constants have a structure signature the build is instantiated for (the Panda's) takes that kernel / never does
- *   "rne_sig", "tree_sig" 1 | 0   the same switch for the dynamics kernels: a DH link table (Panda, Puma560) / a link tree (UR3 / 5 / 10, the 8-group Interbotix arms,
- *                             any serial arm of up to 8 revolute joints) with an instantiated structure signature takes the straight-line kernels / never does
+ *   "ik_sig" 1 | 0            a chain takes the kernel instantiated for its constants' structure (built in: Panda, UR; any other: compiled at run time, see
+ *                             rtbhip_jit_* below) / always the general kernel -- the same bits either way
+ *   "rne_sig", "tree_sig" 1 | 0   the same switch for the dynamics kernels: a DH link table (built in: Panda, Puma560) / a link tree (built in: UR3 / 5 / 10, the
+ *                             Interbotix arms, Fetch, Mico, any serial arm of up to 8 revolute joints); every other robot: its run-time instantiation
  * Others: "coalesced", "reg", "tiles_per_wave", "hess_mode" (fkine / Jacobian / Hessian store paths), "rne_tiles_per_wave",
  *         "partial3" 1 | 0 (order-3 partial_fkine0 on workgroups that own whole configurations / on the general kernel),
  *         "partial3_fused" 1 | 0 (that kernel forms the Hessians from the Jacobians it stages / reads a Hessian tensor written by a launch of its own),

@@ -174,11 +174,11 @@ static hipError_t launch_mode(const Dyn *d, bool mdh, bool allrev, dim3 grid, hi
                                        : (mdh ? DynLayout<NJ, MODE, false, true>::doubles : DynLayout<NJ, MODE, false, false>::doubles)) * sizeof(double);
     *lds_out = lds;
     // a robot whose link table has a structure signature this build is instantiated for (rne_device.h: kRneSig*)
-    if constexpr (NJ == 7) { if (sig == kRneSigPanda && mdh && allrev) return launch_one<7, MODE, true, true, kRneSigPanda>(grid, s, lds, dp, links, q, qd, tq, out); }
-    if constexpr (NJ == 6) { if (sig == kRneSigPuma560 && !mdh && allrev) return launch_one<6, MODE, false, true, kRneSigPuma560>(grid, s, lds, dp, links, q, qd, tq, out); }
+    if constexpr (NJ == 7) { if (sig == kRneSigPanda && mdh && allrev && jit_builtin_enabled()) return launch_one<7, MODE, true, true, kRneSigPanda>(grid, s, lds, dp, links, q, qd, tq, out); }
+    if constexpr (NJ == 6) { if (sig == kRneSigPuma560 && !mdh && allrev && jit_builtin_enabled()) return launch_one<6, MODE, false, true, kRneSigPuma560>(grid, s, lds, dp, links, q, qd, tq, out); }
     if constexpr (NJ <= kRneSigMaxLinks) {
         // any other robot with a signature: its own instantiation, compiled at run time (jit.cpp); the general kernels below serve until it is there
-        const bool builtin = (NJ == 7 && mdh && sig == kRneSigPanda) || (NJ == 6 && !mdh && sig == kRneSigPuma560);
+        const bool builtin = jit_builtin_enabled() && ((NJ == 7 && mdh && sig == kRneSigPanda) || (NJ == 6 && !mdh && sig == kRneSigPuma560));
         if (sig && allrev && !builtin && jit_enabled()) {
             if (hipFunction_t f = d->jit.get("dyn_kernels.hip", 2 + MODE, [&] { return rne_jit_expr(NJ, mdh, sig, 2 + MODE); })) {
                 DynParams dpv = dp;

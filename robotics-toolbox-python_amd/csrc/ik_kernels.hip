@@ -601,7 +601,7 @@ void ik_restart_host(const Chain *c, uint64_t seed, int64_t target, int draw, do
 }
 
 // Signatures with an instantiation built into the library (kIkSig*); every other plain chain of up to 8 joints gets its own at run time (jit.cpp).
-static bool ik_sig_builtin(int n, SegSig sig) { return (n == 7 && (sig == kIkSigPandaETS || sig == kIkSigPandaURDF)) || (n == 6 && sig == kIkSigUR); }
+static bool ik_sig_builtin(int n, SegSig sig) { return jit_builtin_enabled() && ((n == 7 && (sig == kIkSigPandaETS || sig == kIkSigPandaURDF)) || (n == 6 && sig == kIkSigUR)); }
 static std::string ik_jit_expr(int n, bool flat, SegSig sig)
 {
     return "rtbhip::k_ik<" + std::to_string(n) + ", 0, " + std::to_string((flat ? kIkAuxFlat : 0) | kIkAuxUnitW | kIkAuxPlain) + ", " + jit_hex(sig) + ">";
@@ -639,7 +639,7 @@ static void launch_nj(const Chain *c, dim3 grid, hipStream_t s, const IkDev &p, 
             if (p.pad_we /* plain chain */ && g_ik_plain) {
                 // a known robot: the walk specialised to its constants' structure
 #define RTB_IK_SIG_LAUNCH(SIG)                                                                                                                          \
-    if (g_ik_sig && chain_sig == SIG) {                                                                                                                 \
+    if (g_ik_sig && chain_sig == SIG && ik_sig_builtin(NJ, SIG)) {                                                                                      \
         if (flat) hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxFlat | kIkAuxUnitW | kIkAuxPlain, SIG>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr,   \
                                      q_out, success, iters, searches, residual, work, count, share);                                                   \
         else hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxUnitW | kIkAuxPlain, SIG>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success,     \
@@ -675,7 +675,7 @@ static void launch_nj(const Chain *c, dim3 grid, hipStream_t s, const IkDev &p, 
     if constexpr (NJ == 7) {                              // the counters: the benchmark's arm only
         // ... on the very instantiation that serves config 3 (the Panda's signature, unit mask): lane utilisation and the effective clock on the bench line
         // (benchsecondary.py: ik_loss_factors) are then those of the kernel that is timed, not of the general one
-        if (stats && p.unit_we && p.pad_we && g_ik_plain && g_ik_sig && chain_sig == kIkSigPandaETS) {
+        if (stats && p.unit_we && p.pad_we && g_ik_plain && g_ik_sig && chain_sig == kIkSigPandaETS && ik_sig_builtin(NJ, chain_sig)) {
             if (flat) hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxFlat | kIkAuxStats | kIkAuxUnitW | kIkAuxPlain, kIkSigPandaETS>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share);
             else hipLaunchKernelGGL((k_ik<NJ, 0, kIkAuxStats | kIkAuxUnitW | kIkAuxPlain, kIkSigPandaETS>), grid, dim3(kWave), 0, s, p, dc, qlim, Tep, q0, ctr, q_out, success, iters, searches, residual, work, count, share);
             return;

@@ -252,7 +252,7 @@ static void launch_sig(dim3 grid, size_t lds, hipStream_t s, const RneParams &rp
 }
 
 // The signatures with an instantiation built into the library; every other signature gets one at run time (jit.cpp).
-static bool rne_sig_builtin(int n, bool mdh, RneSig sig) { return (n == 7 && mdh && sig == kRneSigPanda) || (n == 6 && !mdh && sig == kRneSigPuma560); }
+static bool rne_sig_builtin(int n, bool mdh, RneSig sig) { return jit_builtin_enabled() && ((n == 7 && mdh && sig == kRneSigPanda) || (n == 6 && !mdh && sig == kRneSigPuma560)); }
 // name expressions of the run-time instantiations of a DH table with signature `sig` (all links revolute, n <= 8): variant 0 k_rne, 1 k_rne_atrest
 // (rne_kernels.hip), 2 + mode k_dyn (dyn_kernels.hip)
 std::string rne_jit_expr(int n, bool mdh, RneSig sig, int variant)
@@ -276,10 +276,10 @@ static void launch_nj(const Dyn *d, bool mdh, bool allrev, dim3 grid, size_t lds
                       const double *q, const double *qd, const double *qdd, double *tau, RneSig sig = 0)
 {
     if constexpr (NJ == 7) {
-        if (sig == kRneSigPanda && mdh && !g_rne_persist && g_rne_wpb == 1) { launch_sig<7, true, kRneSigPanda>(grid, lds, s, rp, links, q, qd, qdd, tau); return; }
+        if (sig == kRneSigPanda && mdh && !g_rne_persist && g_rne_wpb == 1 && jit_builtin_enabled()) { launch_sig<7, true, kRneSigPanda>(grid, lds, s, rp, links, q, qd, qdd, tau); return; }
     }
     if constexpr (NJ == 6) {
-        if (sig == kRneSigPuma560 && !mdh && !g_rne_persist) { launch_sig<6, false, kRneSigPuma560>(grid, lds, s, rp, links, q, qd, qdd, tau); return; }
+        if (sig == kRneSigPuma560 && !mdh && !g_rne_persist && jit_builtin_enabled()) { launch_sig<6, false, kRneSigPuma560>(grid, lds, s, rp, links, q, qd, qdd, tau); return; }
     }
     // any other robot with a signature (all links revolute, n <= 8): its own instantiation of the same kernels, compiled at run time; until the
     // code object is there (or when hipRTC is not) the general kernels below serve -- the same numbers

@@ -85,6 +85,7 @@ struct DevChain {
 #if RTB_HOST_SIDE
 // ---------------------------------------------------------------- run-time instantiation (jit.cpp)
 bool jit_enabled();                                                       // rtbhip_tune("jit") != 0
+bool jit_builtin_enabled();                                               // rtbhip_tune("sig_builtin") != 0: built-in structure instantiations are used
 void jit_request(const char *unit, const std::string &expr, const std::string &preamble = std::string(), bool touch_device = false);              // at *_create: ask for it, nobody waits
 hipFunction_t jit_function(const char *unit, const std::string &expr, const std::string &preamble = std::string());    // at a launch: the function on the current device, or NULL (not ready / failed / off)
 hipFunction_t jit_function_wait(const char *unit, const std::string &expr, const std::string &preamble = std::string());   // sizes with no built-in kernel: waits; NULL = error set

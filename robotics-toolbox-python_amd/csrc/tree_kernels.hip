@@ -73,6 +73,7 @@ static bool tree_builtin(const Tree *t)
 {
     const SegSig sig = t->sig, sig2 = t->sig2;
     const TreeTopo topo = t->topo;
+    if (!jit_builtin_enabled()) return false;       // (the dispatch below still finds the built-in kernel while the run-time one is being compiled: same bits)
     return (sig == kTreeSigUR && t->n == 6) || (sig == kTreeSigIbx8 && topo == kTreeTopoIbx8 && t->n == 8) || (sig == kTreeSigPx100 && topo == kTreeTopoPx100 && t->n == 7) ||
            (sig == kTreeSigIbx9 && sig2 == kTreeSig2Ibx9 && topo == kTreeTopoIbx9 && t->n == 9) || (sig == kTreeSigFetch && sig2 == kTreeSig2Fetch && topo == kTreeTopoFetch && t->n == 10) ||
            (sig == kTreeSigMico && sig2 == kTreeSig2Mico && topo == kTreeTopoMico && t->n == 10);

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _modes():
     yield
-    for k, v in (("jit", 1), ("rne_sig", 1), ("tree_sig", 1), ("ik_sig", 1)):
+    for k, v in (("jit", 1), ("rne_sig", 1), ("tree_sig", 1), ("ik_sig", 1), ("sig_builtin", 1)):
         rtbhip.tune(k, v)
 
 
@@ -157,3 +157,41 @@ def test_jit_off_and_stats():
     nt.assert_array_equal(a, b)
     st = jit.stats()
     assert st["compile_seconds_max"] < 60 and st["last_error"] == ""
+
+
+def test_robots_with_a_builtin_instantiation_served_by_their_runtime_one_instead():
+    """rtbhip_tune("sig_builtin", 0): the launchers pass over the instantiations built into the library, so the Panda (IK, DH dynamics) and the UR5
+    (link tree) take the run-time route like any other robot.  Same sources, same structure words, compiled at another moment: the outputs must be the
+    built-in kernels' bits (and a process that never compiles anything -- "jit" = 0 -- falls back to the general kernels, the same bits again)."""
+    need_rtc()
+    rng = np.random.default_rng(77)
+    ets = rtbhip.models.Panda().ets()
+    ets.qlim = rtbhip.models.PANDA_QLIM
+    Tep = np.asarray(ets.eval(rng.uniform(ets.qlim[0], ets.qlim[1], (1500, 7))))
+    dh = rtbhip.models.DH.Panda()
+    ur = urdf.load("UR5").erobot()
+    N = 1200
+    q7, qd7, qdd7 = rng.uniform(-2.5, 2.5, (N, 7)), rng.normal(size=(N, 7)), rng.normal(size=(N, 7))
+    q6, qd6, qdd6 = rng.uniform(-2.5, 2.5, (N, 6)), rng.normal(size=(N, 6)), rng.normal(size=(N, 6))
+
+    def everything():
+        out = [np.asarray(x) for x in ets.ik_LM(Tep, seed=9)]
+        out += [np.asarray(v) for v in _dh_calls(dh, q7, qd7, qdd7, np.array([0.0, 0.0, 9.81])).values()]
+        out += [np.asarray(ur.rne(q6, qd6, qdd6)), np.asarray(ur.inertia(q6)), np.asarray(ur.coriolis(q6, qd6)), np.asarray(ur.accel(q6, qd6, qdd6))]
+        return out
+    assert jit.names(ets)[0] == [] and jit.names(dh)[0] == [] and jit.names(ur)[0] == []       # built in: nothing to compile
+    builtin = everything()
+    rtbhip.tune("sig_builtin", 0)
+    assert len(jit.names(ets)[0]) == 2 and len(jit.names(dh)[0]) == 5 and len(jit.names(ur)[0]) >= 4
+    rtbhip.tune("jit", 2)                     # a launch waits for its instantiation
+    s0 = jit.stats()
+    runtime = everything()
+    s1 = jit.stats()
+    assert s1["launches"] - s0["launches"] >= 11 and s1["failed"] == s0["failed"], s1
+    for a, b in zip(runtime, builtin):
+        nt.assert_array_equal(a, b)
+    rtbhip.tune("jit", 0)                     # nothing is compiled or looked up: the general kernels
+    general = everything()
+    assert jit.stats()["launches"] == s1["launches"]
+    for a, b in zip(general, builtin):
+        nt.assert_array_equal(a, b)
