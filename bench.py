@@ -11,7 +11,7 @@ Extra objects on the line:
   roofline     achieved = 520 B/config x N / (average duration of the dominant kernel = the device-side duration
                of the K timed launches, ONE HIP-event pair on the launch stream around the timed loop, / K)
                against the 8 TB/s HBM3E peak; traffic = HBM bytes per launch from the committed rocprofv3 --pmc
-               passes of this command (profiles/r05_pmc.json; `traffic_source` says so -- it is not measured
+               passes of this command (profiles/r06_pmc.json; `traffic_source` says so -- it is not measured
                by this run), else null.
   host_path    (N=1 only, never `value`) the same 1e6 configurations handed over as NumPy arrays through the
                RTBHIP_MEM_HOST boundary: PCIe-inclusive configurations/s of the pinned, chunked, double-buffered
@@ -264,7 +264,7 @@ def main():
     if rank == 0:                                   # the line is complete BEFORE the exchange below is tried (see the watchdog)
         achieved = BYTES_PER_CONFIG * N / (kern_avg_ms * 1e-3) / 1e9
         traffic, traffic_source = None, None
-        for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):       # the latest committed PMC passes of this command
+        for name in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):       # the latest committed PMC passes of this command
             traffic, traffic_source = pmc_traffic(ROOT, name)
             if traffic is not None:
                 break

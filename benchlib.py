@@ -350,7 +350,7 @@ def rocprof_committed_all(root, kernel_substr="k_kin_reg<7, true, true"):
     import glob
     import re
     files = sorted(f for f in glob.glob(os.path.join(root, "profiles", "r[0-9][0-9]_*_kernel_stats.csv"))
-                   if "extra" not in os.path.basename(f) and "_rne" not in os.path.basename(f))
+                   if "extra" not in os.path.basename(f) and "_rne" not in os.path.basename(f) and "secondary" not in os.path.basename(f))
     if not files:
         return []
     latest = max(re.match(r"r(\d\d)_", os.path.basename(f)).group(1) for f in files)
@@ -373,7 +373,7 @@ def rocprof_committed(root, kernel_substr="k_kin_reg<7, true, true"):
     (profiles/rNN_*_kernel_stats.csv, not the *_extra_* ones): {"file", "avg_ns", "calls"} or None."""
     import csv
     import glob
-    files = sorted(f for f in glob.glob(os.path.join(root, "profiles", "r[0-9][0-9]_*_kernel_stats.csv")) if "extra" not in os.path.basename(f) and "_rne_" not in os.path.basename(f))
+    files = sorted(f for f in glob.glob(os.path.join(root, "profiles", "r[0-9][0-9]_*_kernel_stats.csv")) if "extra" not in os.path.basename(f) and "_rne_" not in os.path.basename(f) and "secondary" not in os.path.basename(f))
     for f in reversed(files):
         try:
             for row in csv.DictReader(open(f)):

@@ -411,8 +411,9 @@ def structure_legs(rtbhip, n_rne=10000000, n_ik=100000, n_tree=1000000):
             same = all(bool(torch.equal(a, b)) for a, b in zip(ref, snap()))
         finally:
             rtbhip.tune("sig_builtin", 1)
-        r = {"builtin_ms": ms_builtin, "runtime_ms": ms, "runtime_over_builtin": ms / ms_builtin, "launches_served_by_jit": int(served), "bit_identical": same,
-             "wait_for_compile_s": wait_s}
+        ms_again = timed(run)          # the built-in kernel once more, with the buffers where they are now (the comparison that counts: same placement, back to back)
+        r = {"builtin_ms": ms_again, "runtime_ms": ms, "runtime_over_builtin": ms / ms_again, "builtin_ms_before_the_snapshot": ms_builtin,
+             "launches_served_by_jit": int(served), "bit_identical": same, "wait_for_compile_s": wait_s}
         if not same or served < 1:
             raise SystemExit("bench: a robot's run-time instantiation differs from its built-in one (or did not serve): %r" % (r,))
         return r

@@ -89,7 +89,7 @@ if has libab; then
   python scripts/ik_lib_digest.py $O/ik_lib_ab.jsonl
 fi
 if has fuzz; then
-  for f in ${FUZZ:-dyn ik kin rne paths fleet}; do
+  for f in ${FUZZ:-dyn ik kin rne paths fleet jit}; do
     timeout 900 python scripts/gpu_fuzz_$f.py > $O/fuzz_$f.jsonl 2> $O/fuzz_$f.err; echo "fuzz $f rc=$?" >> $O/fuzz_$f.jsonl; tail -2 $O/fuzz_$f.jsonl | cut -c1-300
   done
 fi
