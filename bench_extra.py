@@ -106,10 +106,10 @@ ALGO_FLOPS_PER_UNIT = {"gravload": 1344, "inertia": 4116, "coriolis": 8985, "acc
 # r04_v_sq_dyn.txt; the kinematics consumers: profiles/r03_a_sq_summary.txt): reported beside
 # the roofline as `valu_issue_util` (share of the chip's fp64 issue slots the kernel fills) -- a diagnostic, not a roofline: a kernel that
 # executed more instructions for the same answer would score higher on it.
-# (jacob0_dot / manipulability / jacobm: round 6's running-sum forms, profiles/r06_i_sq_digest_kin.txt -- rounds 3-5: 1692 / 1512 / 2732)
-VALU_PER_UNIT = {"gravload": 687, "inertia": 2930, "coriolis": 4542, "accel": 2797, "tree_ur5": 1192, "jacob0_dot": 1361,
+# (jacob0_dot / manipulability / jacobm: round 6's running-sum forms, profiles/r06_z_sq_digest.txt -- rounds 3-5: 1692 / 1512 / 2732)
+VALU_PER_UNIT = {"gravload": 691, "inertia": 2958, "coriolis": 4682, "accel": 2839, "tree_ur5": 1055, "jacob0_dot": 1361,
                  "manipulability": 1182, "jacobm": 1897,
-                 "tree_inertia_ur5": 2578, "tree_coriolis_ur5": 6032, "tree_accel_ur5": 3323, "tree_gravload_ur5": 713}
+                 "tree_inertia_ur5": 2638, "tree_coriolis_ur5": 5231, "tree_accel_ur5": 3246, "tree_gravload_ur5": 706}      # profiles/r06_z_sq_digest.txt (round 5: r05_t_sq_digest.txt)
 
 
 def valu_roofline(key, units_per_s, kernel, hbm_bytes_per_unit):
