@@ -282,14 +282,27 @@ def main():
         for name, fn, byts in (("fkine", lambda: ets.eval(q), 56 + 128), ("jacob0", lambda: ets.jacob0(q), 56 + 336),
                                ("hessian0", lambda: ets.hessian0(q), 56 + 2352), ("jacob0_dot", lambda: ets.jacob0_dot(q, qd), 112 + 336),
                                ("manipulability", lambda: ets.manipulability(q), 56 + 8), ("jacobm", lambda: ets.jacobm(q), 56 + 56)):
+            extra = {}
+            if name in VALU_PER_UNIT:
+                # the general kernel first (what any robot gets until its own instantiation is compiled), then the robot's structure instantiation
+                # (k_kin_diff<7, MODE, SIG>, compiled at run time; "jit" = 2: the launch waits for it) on the same buffers: the same bits
+                rtbhip.tune("diff_sig", 0)
+                g_avg, g_best = ev_time(fn, args.steps, 2)
+                g_out = fn().clone()
+                rtbhip.tune("diff_sig", 1); rtbhip.tune("jit", 2)
+                fn(); torch.cuda.synchronize()
+                rtbhip.tune("jit", 1)
+                extra = {"general_kernel_avg_ms": g_avg, "general_kernel_min_ms": g_best}
             avg, best = ev_time(fn, args.steps, 2)
             if name in VALU_PER_UNIT:      # jacob0_dot / manipulability / jacobm: a few hundred bytes of I/O against 1.5-2.7 k instructions per configuration
-                rf = valu_roofline(name, N / (avg * 1e-3), "k_kin_diff<7,%s>" % name, byts)
+                extra["structure_vs_general_bit_equal"] = bool(torch.equal(fn(), g_out))
+                extra["structure_over_general"] = g_avg / avg
+                rf = valu_roofline(name, N / (avg * 1e-3), "k_kin_diff<7,%s,SIG> (run-time structure instantiation; general kernel: general_kernel_avg_ms)" % name, byts)
             else:
                 rf = {"bound": "hbm", "achieved": byts * N / (avg * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                       "frac": byts * N / (avg * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": byts * N}
             print(json.dumps({"metric": "configurations/sec (Panda %s)" % name, "value": N / (avg * 1e-3), "unit": "configurations/s", "n": N,
-                              "kernel_avg_ms": avg, "kernel_min_ms": best, "roofline": rf}), flush=True)
+                              "kernel_avg_ms": avg, "kernel_min_ms": best, "roofline": rf, **extra}), flush=True)
 
         # fkine_all: the 8 link frames of the DH Panda (1 KB per configuration out)
         arm = rtbhip.models.DH.Panda()

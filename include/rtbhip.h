@@ -268,9 +268,12 @@ int rtbhip_rne(rtbhip_dyn_t dyn, const double *q, const double *qd, const double
                const double *grav3, const double *fext6, double *tau, int32_t mem, void *stream);
 
 /* DHRobot.rne(..., base_wrench=True) -> rne_python (robot/DHRobot.py:1409-1412, 1765-1770), batched: the torques as rtbhip_rne and
- * wbase (N,6) = [R_1 f_1, R_1 n_1], the force and moment link 1 exerts on the base, rotated into frame 0 -- what the backward
- * recursion of rtbhip_rne holds when it ends.  (The reference allocates wbase as (N,n), so its own call only works for six-joint
- * robots; here wbase is (N,6) for any n.)  Served by the run-time-n kernel: correct for every chain, not the fast path. */
+ * wbase (N,6) = [R_1 f_1, R_1 n_1], the force and moment the base exerts on link 1, rotated into frame 0 -- what the backward
+ * recursion of rtbhip_rne holds when it ends; the moment refers to the origin of frame 0 (standard DH) / of frame 1 (modified DH).
+ * (The reference allocates wbase as (N,n), so its own call only works for six-joint robots; here wbase is (N,6) for any n.  Its
+ * rne_python contradicts its own frne for modified-DH chains, :1640 / :1711: there the definition is served, with frne's torques,
+ * and checked against momentum balance, tests/test_base_wrench_balance.py.)  Served by the run-time-n kernel: correct for every
+ * chain, not the fast path. */
 int rtbhip_rne_base_wrench(rtbhip_dyn_t dyn, const double *q, const double *qd, const double *qdd, int64_t N,
                            const double *grav3, const double *fext6, double *tau, double *wbase, int32_t mem, void *stream);
 

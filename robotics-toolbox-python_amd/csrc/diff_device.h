@@ -18,6 +18,22 @@ namespace rtbhip {
 
 // H[j', :, i] as the reference fills it (methods.cpp:16-32): for j' <= i  (w_j' x v_i ; w_j' x w_i),
 // for j' > i  (w_i x v_j' ; 0).
+// (a b - c d) + (e f - g h) as one fixed sequence:  fma(e, f, fma(-g, h, fma(a, b, -round(c d))))
+RTB_HD double cross_sum(double a, double b, double c, double d, double e, double f, double g, double h)
+{
+#pragma clang fp contract(off)
+    return __builtin_fma(e, f, __builtin_fma(-g, h, __builtin_fma(a, b, -(c * d))));
+}
+// sum_k a(k) b(k), k = 0 .. N - 1, as round(a0 b0) followed by N - 1 fused multiply-adds in index order
+template <int N, class A, class B>
+RTB_HD double chain_dot(A a, B b)
+{
+#pragma clang fp contract(off)
+    double s = a(0) * b(0);
+#pragma unroll
+    for (int k = 1; k < N; ++k) s = __builtin_fma(a(k), b(k), s);
+    return s;
+}
 // Written with running sums instead of the pair loop the definition suggests (28 + 21 cross products for 7 joints):
 //   Jd_v[i] = sum_{j<=i} qd_j (w_j x v_i) + sum_{j>i} qd_j (w_i x v_j) = W_i x v_i + w_i x V_i,   Jd_w[i] = sum_{j<=i} qd_j (w_j x w_i) = W_i x w_i
 // with W_i = sum_{j<=i} qd_j w_j (a prefix sum) and V_i = sum_{j>i} qd_j v_j (a suffix sum): 6 n fused multiply-adds for the sums and three cross
@@ -30,20 +46,21 @@ RTB_HD void jacob_dot(const double (&jac)[6 * NJ], const double (&qd)[NJ], doubl
 #pragma unroll
     for (int i = NJ - 1; i >= 0; --i) {
         Vx[i] = sx; Vy[i] = sy; Vz[i] = sz;
-        sx = fma(qd[i], jac[i], sx); sy = fma(qd[i], jac[NJ + i], sy); sz = fma(qd[i], jac[2 * NJ + i], sz);
+        sx = fmax_(qd[i], jac[i], sx); sy = fmax_(qd[i], jac[NJ + i], sy); sz = fmax_(qd[i], jac[2 * NJ + i], sz);
     }
     double Wx = 0.0, Wy = 0.0, Wz = 0.0;
 #pragma unroll
     for (int i = 0; i < NJ; ++i) {
         const double vix = jac[i], viy = jac[NJ + i], viz = jac[2 * NJ + i];
         const double wix = jac[3 * NJ + i], wiy = jac[4 * NJ + i], wiz = jac[5 * NJ + i];
-        Wx = fma(qd[i], wix, Wx); Wy = fma(qd[i], wiy, Wy); Wz = fma(qd[i], wiz, Wz);
-        jd[i] = (Wy * viz - Wz * viy) + (wiy * Vz[i] - wiz * Vy[i]);
-        jd[NJ + i] = (Wz * vix - Wx * viz) + (wiz * Vx[i] - wix * Vz[i]);
-        jd[2 * NJ + i] = (Wx * viy - Wy * vix) + (wix * Vy[i] - wiy * Vx[i]);
-        jd[3 * NJ + i] = Wy * wiz - Wz * wiy;
-        jd[4 * NJ + i] = Wz * wix - Wx * wiz;
-        jd[5 * NJ + i] = Wx * wiy - Wy * wix;
+        Wx = fmax_(qd[i], wix, Wx); Wy = fmax_(qd[i], wiy, Wy); Wz = fmax_(qd[i], wiz, Wz);
+        // (every sum of products written out -- kin_device.h, mix_pp: a structure instantiation of the walk must not change what the compiler fuses here)
+        jd[i] = cross_sum(Wy, viz, Wz, viy, wiy, Vz[i], wiz, Vy[i]);
+        jd[NJ + i] = cross_sum(Wz, vix, Wx, viz, wiz, Vx[i], wix, Vz[i]);
+        jd[2 * NJ + i] = cross_sum(Wx, viy, Wy, vix, wix, Vy[i], wiy, Vx[i]);
+        jd[3 * NJ + i] = mix_pm(Wy, wiz, Wz, wiy);
+        jd[4 * NJ + i] = mix_pm(Wz, wix, Wx, wiz);
+        jd[5 * NJ + i] = mix_pm(Wx, wiy, Wy, wix);
     }
 }
 
@@ -57,9 +74,7 @@ RTB_HD void jjt_masked(const double (&jac)[6 * NJ], int axes, double (&B)[6][6])
 #pragma unroll
         for (int c = 0; c <= r; ++c) {
             const bool uc = (axes >> c) & 1;
-            double s = 0.0;
-#pragma unroll
-            for (int k = 0; k < NJ; ++k) s += jac[r * NJ + k] * jac[c * NJ + k];
+            double s = chain_dot<NJ>([&](int k) { return jac[r * NJ + k]; }, [&](int k) { return jac[c * NJ + k]; });
             const double v = (ur && uc) ? s : (r == c ? 1.0 : 0.0);
             B[r][c] = v;
             B[c][r] = v;
@@ -109,9 +124,7 @@ RTB_HD double manipulability_singular(const double (&jac)[6 * NJ], int axes, int
         for (int i = 0; i < NJ; ++i)
 #pragma unroll
             for (int j = 0; j <= i; ++j) {
-                double s = 0.0;
-#pragma unroll
-                for (int r = 0; r < 6; ++r) s += ((axes >> r) & 1) ? jac[r * NJ + i] * jac[r * NJ + j] : 0.0;
+                const double s = chain_dot<6>([&](int r) { return ((axes >> r) & 1) ? jac[r * NJ + i] : 0.0; }, [&](int r) { return jac[r * NJ + j]; });
                 G[i][j] = s; G[j][i] = s;
             }
         jacobi_eigenvalues<NJ>(G);
@@ -136,6 +149,9 @@ RTB_HD double manipulability_singular(const double (&jac)[6 * NJ], int axes, int
 // A^-1 = I - [Gamma]x / 2 + (1/theta^2 - (1 + cos theta) / (2 theta sin theta)) [Gamma]x^2.
 RTB_HD void rotvel_inverse(const Pose &P, int rep, double (&Ai)[3][3])
 {
+    // (no contraction: every operation below is rounded on its own, in whichever instantiation of whichever compiler -- a structure instantiation compiled
+    //  at run time chose other multiply-add pairs of the rotation-vector branch to fuse than the built-in general kernel did: 1e-15 apart, 2.7 % of entries)
+#pragma clang fp contract(off)
     if (rep == 3) {
         const double lx = P.r21 - P.r12, ly = P.r02 - P.r20, lz = P.r10 - P.r01;      // 2 sin(theta) axis
         const double nrm = sqrt(lx * lx + ly * ly + lz * lz), tr = P.r00 + P.r11 + P.r22;
@@ -189,9 +205,9 @@ RTB_HD void jacob_analytical(const Pose &P, const double (&jac)[6 * NJ], int rep
     for (int i = 0; i < NJ; ++i) {
         ja[i] = jac[i]; ja[NJ + i] = jac[NJ + i]; ja[2 * NJ + i] = jac[2 * NJ + i];
         const double wx = jac[3 * NJ + i], wy = jac[4 * NJ + i], wz = jac[5 * NJ + i];
-        ja[3 * NJ + i] = Ai[0][0] * wx + Ai[0][1] * wy + Ai[0][2] * wz;
-        ja[4 * NJ + i] = Ai[1][0] * wx + Ai[1][1] * wy + Ai[1][2] * wz;
-        ja[5 * NJ + i] = Ai[2][0] * wx + Ai[2][1] * wy + Ai[2][2] * wz;
+        ja[3 * NJ + i] = dot3x(Ai[0][0], wx, Ai[0][1], wy, Ai[0][2], wz);
+        ja[4 * NJ + i] = dot3x(Ai[1][0], wx, Ai[1][1], wy, Ai[1][2], wz);
+        ja[5 * NJ + i] = dot3x(Ai[2][0], wx, Ai[2][1], wy, Ai[2][2], wz);
     }
 }
 
@@ -255,17 +271,17 @@ RTB_HD void jacobm_factored(const double (&jac)[6 * NJ], int axes, const double 
         ldl_backsolve<6>(B, dinv, g, x);
         const double vkx = jac[k], vky = jac[NJ + k], vkz = jac[2 * NJ + k];
         const double wkx = jac[3 * NJ + k], wky = jac[4 * NJ + k], wkz = jac[5 * NJ + k];
-        cx[k] = (vky * x[2] - vkz * x[1]) + (wky * x[5] - wkz * x[4]);
-        cy[k] = (vkz * x[0] - vkx * x[2]) + (wkz * x[3] - wkx * x[5]);
-        cz[k] = (vkx * x[1] - vky * x[0]) + (wkx * x[4] - wky * x[3]);
-        jm[k] = vkx * px + vky * py + vkz * pz;                                                             // v_k . P_k
-        px += x[1] * wkz - x[2] * wky; py += x[2] * wkx - x[0] * wkz; pz += x[0] * wky - x[1] * wkx;      // + Ga_k x w_k
+        cx[k] = cross_sum(vky, x[2], vkz, x[1], wky, x[5], wkz, x[4]);
+        cy[k] = cross_sum(vkz, x[0], vkx, x[2], wkz, x[3], wkx, x[5]);
+        cz[k] = cross_sum(vkx, x[1], vky, x[0], wkx, x[4], wky, x[3]);
+        jm[k] = dot3x(vkx, px, vky, py, vkz, pz);                                                           // v_k . P_k
+        px = fmax_(x[1], wkz, fmax_(-x[2], wky, px)); py = fmax_(x[2], wkx, fmax_(-x[0], wkz, py)); pz = fmax_(x[0], wky, fmax_(-x[1], wkx, pz));      // + Ga_k x w_k
     }
     double sx = 0.0, sy = 0.0, sz = 0.0;
 #pragma unroll
     for (int i = NJ - 1; i >= 0; --i) {
         sx += cx[i]; sy += cy[i]; sz += cz[i];
-        jm[i] = m * ((jac[3 * NJ + i] * sx + jac[4 * NJ + i] * sy + jac[5 * NJ + i] * sz) + jm[i]);
+        jm[i] = m * (dot3x(jac[3 * NJ + i], sx, jac[4 * NJ + i], sy, jac[5 * NJ + i], sz) + jm[i]);
     }
 }
 

@@ -22,19 +22,38 @@ __device__ __forceinline__ ConstChain const_view(const DevChain &dc)
     return cv;
 }
 
+// k_kin_diff's own view: the same two tables, plus the request for the fused-chain translation form (kin_reg.h: cv_t3fma) -- the form the structured
+// segment products are instances of, so that k_kin_diff<NJ, MODE, SIG> returns k_kin_diff<NJ, MODE, 0>'s bits
+struct ConstChainF : ConstChain { typedef void t3fma_tag; };
+__device__ __forceinline__ ConstChainF const_view_f(const DevChain &dc)
+{
+    ConstChainF cv;
+    cv.seg = (const RTB_CONST DevSeg *)dc.seg;
+    cv.jmeta = (const RTB_CONST int32_t *)dc.jmeta;
+    return cv;
+}
+
 // jacob0_dot / manipulability / jacobm straight from the register-resident Jacobian: the (n,6,n) Hessian
 // the reference materialises for each of them (robot/Robot.py:1069, robot/ETS.py:1671) never exists.
+// SIG (round 6): the chain's structure signature (kin_reg.h: SegSig; an all-revolute chain of up to 8 joints without flips, called without a tool) --
+// the walk multiplies by every constant in the form of its class, as k_ik's instantiations do; compiled at run time for the robot at hand (jit.cpp;
+// kin_kernels.hip: launch_kin_diff), the general kernel serving until the code object is there.  Same bits: the walk by construction (exactform.h),
+// the consumers because their sums of products are written out (diff_device.h).
 constexpr int kDiffMax = 16;   // jacob_dot / manipulability / jacobm / analytical Jacobian: compile-time joint counts up to here
 enum { kDiffJdot = 0, kDiffManip = 1, kDiffJacobm = 2, kDiffAnalytical = 3, kDiffAnalyticalDot = 4 };
 #ifndef RTB_DIFF_WAVES
 #define RTB_DIFF_WAVES 2        // waves per SIMD the register allocator must leave room for (chains of up to 8 joints; A/B knob)
 #endif
-template <int NJ, int MODE>
-__global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && MODE != 4 ? RTB_DIFF_WAVES : 1)) void k_kin_diff(KinParams kp, DevChain dc, int axes, const double *__restrict__ q,
+#ifndef RTB_DIFF_WAVES_MANIP
+#define RTB_DIFF_WAVES_MANIP 4  // manipulability fits 128 registers (hipcc: 123-125 without being asked; hipRTC took 157 -- three waves -- until told)
+#endif
+template <int NJ, int MODE, SegSig SIG = 0>
+__global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && MODE != 4 ? (MODE == kDiffManip ? RTB_DIFF_WAVES_MANIP : RTB_DIFF_WAVES) : 1)) void k_kin_diff(KinParams kp, DevChain dc, int axes, const double *__restrict__ q,
                                                        const double *__restrict__ qd, double *__restrict__ out)
 {
+    static_assert(SIG == 0 || (NJ <= kRegMaxJoints && MODE != kDiffAnalyticalDot), "structure instantiations: register-resident sizes, one walk");
     extern __shared__ __attribute__((aligned(16))) double buf[];
-    const ConstChain cv = const_view(dc);
+    const ConstChainF cv = const_view_f(dc);
     const int lane = threadIdx.x;
     const int64_t cfg0 = (int64_t)xcd_tile() * kWave, cfg = cfg0 + lane;
     const int64_t left = kp.N - cfg0;
@@ -68,7 +87,7 @@ __global__ __launch_bounds__(kWave, (NJ <= kRegMaxJoints && MODE != 4 ? RTB_DIFF
         }
         return;
     }
-    reg_compute<NJ, true>(kp, cv, q, cfg, P, jac);
+    reg_compute<NJ, true, SIG>(kp, cv, q, cfg, P, jac);
     if (MODE == kDiffJdot || MODE == kDiffAnalytical) {
         double jd[6 * NJ];
         if (MODE == kDiffJdot) {

@@ -439,6 +439,7 @@ int launch_angle_axis(const double *Te, int64_t nTe, const double *Tep, int64_t 
 }
 
 // ---------------------------------------------------------------- differential-kinematics consumers (n <= 8)
+static int g_diff_sig = 1;     // rtbhip_tune("diff_sig", 0): k_kin_diff never takes a robot's structure instantiation (A/B, tests)
 template <int NJ>
 static hipError_t launch_diff_nj(int mode, dim3 grid, size_t lds, hipStream_t s, const KinParams &kp, const DevChain &dc,
                                  int axes, const double *q, const double *qd, double *out)
@@ -465,6 +466,23 @@ int launch_kin_diff(const Chain *c, const DevChain &dc, int mode, int axes, cons
     const size_t lds = (size_t)reg_lds_doubles(c->n) * sizeof(double);
     dim3 grid((unsigned)tiles);
     hipError_t e = hipSuccess;
+    // a structure instantiation of the walk for THIS robot (diff_kernel.h: k_kin_diff<NJ, MODE, SIG>), compiled at run time on first use; the general
+    // kernel below serves until the code object is there and returns the same bits.  rtbhip_tune("diff_sig", 0): never.
+    if (g_diff_sig && c->n <= kRegMaxJoints && !tool.used && mode != kDiffAnalyticalDot && jit_enabled()) {
+        bool plain = true;
+        for (int j = 0; j < c->n; ++j) plain = plain && !jm_prismatic(c->jmeta[j]) && !jm_flip(c->jmeta[j]);
+        const SegSig sig = plain ? chain_signature(c->jmeta.data(), c->n) : 0;
+        if (sig) {
+            const int m = mode == kDiffJdot ? kDiffJdot : (mode == kDiffManip ? kDiffManip : (mode == kDiffAnalytical ? kDiffAnalytical : kDiffJacobm));
+            if (hipFunction_t f = c->jit.get("diff_kernel.h", 48 + m, [&] { return "rtbhip::k_kin_diff<" + std::to_string(c->n) + ", " + std::to_string(m) + ", " + jit_hex(sig) + ">"; })) {
+                void *args[] = {(void *)&kp, (void *)&dc, (void *)&axes, (void *)&q, (void *)&qd, (void *)&out};
+                const int rc = jit_launch(f, grid, dim3(kWave), lds, s, args);
+                if (rc != RTBHIP_OK) return rc;
+                note_launch((int)grid.x, kWave, (int)lds);
+                return RTBHIP_OK;
+            }
+        }
+    }
     if (c->n > kDiffMax) {
         // a joint count without a built-in instantiation: the same k_kin_diff template, instantiated at run time (jit.cpp; seconds to a minute on first
         // use, then a file read).  The reference's loops take any n (robot/Robot.py:964-1235, robot/ETS.py:1687-1819).
@@ -514,6 +532,7 @@ void kin_tune(const char *key, int value)
     if (k == "tiles_per_wave") g_tiles_per_wave = value < 1 ? 1 : value;
     if (k == "reg") g_use_reg = value;
     if (k == "hess_mode") g_hess_mode = value;
+    if (k == "diff_sig") g_diff_sig = value != 0;
 }
 
 template <bool WT, bool WJ, bool WH>

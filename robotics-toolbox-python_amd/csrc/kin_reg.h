@@ -71,6 +71,10 @@ RTB_HD void pose_mul_seg_by_sig(Pose &P, const CV &cv) { pose_mul_seg_sig<seg_si
 // a chain view may carry a pointer to the sincos constants (k_ik: see sincos_reduced_tab in trig.h); the others use the literals
 template <class CV, class = void> struct cv_has_trig { static constexpr bool value = false; };
 template <class CV> struct cv_has_trig<CV, decltype((void)(((const CV *)nullptr)->trig))> { static constexpr bool value = true; };
+// ... or ask for the fused-chain translation  t += R c  (pose_t3_fma: the form every structured segment product is an instance of) without carrying the
+// sincos table: k_kin_diff's views (diff_kernel.h), so that its structure instantiations return its general kernel's bits
+template <class CV, class = void> struct cv_t3fma { static constexpr bool value = false; };
+template <class CV> struct cv_t3fma<CV, typename CV::t3fma_tag> { static constexpr bool value = true; };
 
 // joint J of the walk (compile-time index: a signature picks the segment's form by it)
 template <int NJ, bool WANT_J, bool PLAIN, SegSig SIG, int J, class CV>
@@ -90,12 +94,12 @@ RTB_HD void reg_walk_step(const CV &cv, Pose &P, double (&jac)[6 * NJ], const in
         if (j == 0) pose_from_seg(P, cvj, 0);
         else if constexpr (SIG != 0) pose_mul_seg_by_sig<SIG, J>(P, cvj);                                              // k_ik for a known robot: compile-time class
         else if constexpr (RTB_SEG_CLASSES && cv_has_trig<CV>::value) pose_mul_seg_cls(P, cvj, j, cvj.jmeta[j]);      // k_ik: by structure class (run-time switch, A/B)
-        else pose_mul_seg<(PLAIN && RTB_POSE_T3_FMA && cv_has_trig<CV>::value)>(P, cvj, j);
+        else pose_mul_seg<((PLAIN && RTB_POSE_T3_FMA && cv_has_trig<CV>::value) || cv_t3fma<CV>::value)>(P, cvj, j);
 #else
         if (j == 0) pose_from_seg(P, cv, 0);
         else if constexpr (SIG != 0) pose_mul_seg_by_sig<SIG, J>(P, cv);
         else if constexpr (RTB_SEG_CLASSES && cv_has_trig<CV>::value) pose_mul_seg_cls(P, cv, j, cv.jmeta[j]);          // (the host replay of k_ik: the same arithmetic)
-        else pose_mul_seg(P, cv, j);
+        else pose_mul_seg<cv_t3fma<CV>::value>(P, cv, j);
 #endif
         if (WANT_J) {
             jac[j] = P.tx; jac[NJ + j] = P.ty; jac[2 * NJ + j] = P.tz;
@@ -190,13 +194,14 @@ RTB_HD void reg_core(const CV &cv, TL tail /* tail[k], k = 0..11 */, int frame, 
     // k_ik's chain views: the tail IS segment NJ of the table (no tool in IK), descriptor NJ carries its class
     if constexpr (SIG != 0) pose_mul_seg_by_sig<SIG, NJ>(P, cv);
     else if constexpr (RTB_SEG_CLASSES && cv_has_trig<CV>::value) pose_mul_seg_cls(P, cv, NJ, cv.jmeta[NJ]);
-    else pose_mul_general<(PLAIN && RTB_POSE_T3_FMA && cv_has_trig<CV>::value)>(P, [&](int k) { return tail[k]; });
+    else pose_mul_general<((PLAIN && RTB_POSE_T3_FMA && cv_has_trig<CV>::value) || cv_t3fma<CV>::value)>(P, [&](int k) { return tail[k]; });
     sched_fence();
     reg_close_jacobian<NJ, WANT_J>(P, frame, jmv, jac);
 }
 
 // whole per-lane compute of one tile: q row in memory -> (P, J)
-template <int NJ, bool WANT_J, class CV>
+// SIG != 0: the chain's structure signature (all joints revolute, none flipped, no tool: the tail is segment NJ of the table) -- the straight-line walk
+template <int NJ, bool WANT_J, SegSig SIG = 0, class CV>
 RTB_HD void reg_compute(const KinParams &kp, const CV &cv, const double *__restrict__ q, int64_t cfg,
                         Pose &P, double (&jac)[6 * NJ])
 {
@@ -205,7 +210,8 @@ RTB_HD void reg_compute(const KinParams &kp, const CV &cv, const double *__restr
     double qv[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) qv[j] = live ? qrow[jm_jq(cv.jmeta[j])] : 0.0;
-    reg_core<NJ, WANT_J>(cv, kp.tail, kp.frame, qv, P, jac);
+    if constexpr (SIG != 0) reg_core<NJ, WANT_J, true, SIG>(cv, &cv.seg[NJ].r[0], kp.frame, qv, P, jac);
+    else reg_core<NJ, WANT_J>(cv, kp.tail, kp.frame, qv, P, jac);
 }
 
 // staging: lane writes its finished J row / its 4x4 into the wave's LDS transposer

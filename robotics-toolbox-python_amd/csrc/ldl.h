@@ -177,6 +177,7 @@ RTB_HD double det_lu(double (&a)[N][N])
 template <int N>
 RTB_HD void jacobi_eigenvalues(double (&a)[N][N])
 {
+#pragma clang fp contract(off)
 #pragma unroll 1
     for (int sweep = 0; sweep < 7; ++sweep) {
 #pragma unroll
@@ -198,7 +199,7 @@ RTB_HD void jacobi_eigenvalues(double (&a)[N][N])
                 for (int k = 0; k < N; ++k) {
                     if (k != p && k != q) {
                         const double akp = a[k][p], akq = a[k][q];
-                        const double np_ = c * akp - s * akq, nq_ = s * akp + c * akq;
+                        const double np_ = __builtin_fma(c, akp, -(s * akq)), nq_ = __builtin_fma(s, akp, c * akq);      // (written out: kin_device.h, mix_pp)
                         a[k][p] = np_; a[p][k] = np_;
                         a[k][q] = nq_; a[q][k] = nq_;
                     }

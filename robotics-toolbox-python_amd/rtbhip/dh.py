@@ -527,19 +527,16 @@ class DHRobot(RobotKinematics):
         qd / qdd = None means zeros (no zero arrays are read by the kernel)."""
         if base_wrench:
             # robot/DHRobot.py:1409-1412 sends base_wrench=True to rne_python (:1458-1796), which returns (tau, wbase) with
-            # wbase = [R_1 f_1, R_1 n_1] (:1765-1770).  That second, pure-Python formulation agrees with the compiled frne for standard
-            # DH chains without a base transform -- the case served here, from the backward recursion the kernel already runs.  Its
-            # modified-DH branch does not (operator precedence at :1649 rotates only the first term of the linear acceleration; the
-            # torques it returns differ from DHRobot.rne's) and with a base it enters gravity with the opposite sign (:1597 against
-            # :1591); neither is reproduced.  The reference allocates wbase as (N, n) (:1557), so its call only succeeds for six-joint
-            # robots; here wbase is (N, 6) for any n.  A prismatic joint's extension is q + offset as in frne (rne_python drops the
-            # offset, :1612).
-            if self.mdh:
-                raise NotImplementedError("rne(base_wrench=True): the reference's rne_python disagrees with its own frne for modified-DH "
-                                          "chains (robot/DHRobot.py:1649); not offered")
-            if self.base is not None and not np.array_equal(self.base, np.eye(4)):
-                raise NotImplementedError("rne(base_wrench=True) with a base transform: the reference's rne_python enters gravity with the "
-                                          "opposite sign there (robot/DHRobot.py:1597); not offered")
+            # wbase = [R_1 f_1, R_1 n_1] (:1765-1770): the wrench the base exerts on link 1 as the backward recursion holds it when it ends,
+            # turned into the robot's frame 0.  That second, pure-Python formulation agrees with the compiled frne for standard DH chains
+            # without a base transform, and pins this path there (tests/test_06_reference_dh_classes.py).  For a modified-DH chain it does
+            # not (:1640 rotates only the first term of the linear acceleration, :1711 takes F_j's moment about p*; the torques it returns
+            # differ from DHRobot.rne's) and with a base it enters gravity with the opposite sign (:1597 against :1591).  Those two cases are
+            # served by the DEFINITION -- the same wrench from frne's own recursion, with frne's torques and rne's gravity (turned by the
+            # base, :1431-1433) -- and checked against momentum balance (tests/test_base_wrench_balance.py).  The moment refers to the origin
+            # of frame 0 (standard DH) / of frame 1 (modified DH), as n_1 does.  The reference allocates wbase as (N, n) (:1557), so its call
+            # only succeeds for six-joint robots; here wbase is (N, 6) for any n.  A prismatic joint's extension is q + offset as in frne
+            # (rne_python drops the offset, :1612).
             arrs, N, single, tm, ptr, stream, mem, dev = self._dyn_args([q, qd, qdd])
             gc = self._gravity_c(gravity)
             f = None if fext is None else np.ascontiguousarray(np.asarray(fext, dtype=np.float64).reshape(6))

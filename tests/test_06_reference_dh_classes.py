@@ -156,12 +156,16 @@ def test_base_wrench_on_the_device():
     assert tau_d.is_cuda and wb_d.shape == (1000, 6)
     tau_h, wb_h = mine.rne(qt.cpu().numpy(), qdt.cpu().numpy(), qddt.cpu().numpy(), base_wrench=True)
     nt.assert_array_equal(wb_d.cpu().numpy(), wb_h)
-    # what is refused, and why (robot/DHRobot.py:1649, :1597)
-    with pytest.raises(NotImplementedError):
-        rtbhip.models.DH.Panda().rne(np.zeros(7), np.zeros(7), np.zeros(7), base_wrench=True)
+    # modified DH and robots with a base: the reference's rne_python disagrees with its own frne there (robot/DHRobot.py:1640, :1711, :1597); served by
+    # the definition with frne's torques, against momentum balance in tests/test_base_wrench_balance.py
+    panda = rtbhip.models.DH.Panda()
+    q7p = rng.uniform(-1, 1, (4, 7))
+    tau_p, wb_p = panda.rne(q7p, q7p, q7p, base_wrench=True)
+    nt.assert_allclose(tau_p, panda.rne(q7p, q7p, q7p), rtol=1e-12, atol=1e-12)
+    assert wb_p.shape == (4, 6) and np.isfinite(wb_p).all()
     based = rtbhip.DHRobot(mine.links, base=np.array([[0, -1, 0, 0], [1, 0, 0, 0], [0, 0, 1, 0.2], [0, 0, 0, 1.0]]))
-    with pytest.raises(NotImplementedError):
-        based.rne(QN, QN, QN, base_wrench=True)
+    tau_b, wb_b = based.rne(QN, QN, QN, base_wrench=True)
+    nt.assert_allclose(tau_b, based.rne(QN, QN, QN), rtol=1e-12, atol=1e-12)
     # seven joints: served with a (N, 6) wrench (the reference's own call raises there: wbase is allocated (N, n))
     links7 = [rtbhip.RevoluteDH(d=0.1 * k, a=0.05 * k, alpha=(-1) ** k * np.pi / 2, m=1.0 + k, r=[0.01 * k, 0.02, 0.03]) for k in range(7)]
     arm7 = rtbhip.DHRobot(links7)

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _modes():
     yield
-    for k, v in (("jit", 1), ("rne_sig", 1), ("tree_sig", 1), ("ik_sig", 1), ("sig_builtin", 1)):
+    for k, v in (("jit", 1), ("rne_sig", 1), ("tree_sig", 1), ("ik_sig", 1), ("sig_builtin", 1), ("diff_sig", 1)):
         rtbhip.tune(k, v)
 
 
@@ -195,3 +195,44 @@ def test_robots_with_a_builtin_instantiation_served_by_their_runtime_one_instead
     assert jit.stats()["launches"] == s1["launches"]
     for a, b in zip(general, builtin):
         nt.assert_array_equal(a, b)
+
+
+def _diff_calls(e, q, qd):
+    out = {"jacob0_dot": e.jacob0_dot(q, qd), "jacobm": e.jacobm(q), "jacobm_trans": e.jacobm(q, axes="trans")}
+    for method in ("yoshikawa", "minsingular", "invcondition"):
+        for axes in ("all", "trans", "rot"):
+            out["manipulability_%s_%s" % (method, axes)] = e.manipulability(q, method=method, axes=axes)
+    for rep in ("rpy/xyz", "rpy/zyx", "eul", "exp"):
+        out["jacob0_analytical_" + rep] = e.jacob0_analytical(q, rep)
+    return {k: np.asarray(v) for k, v in out.items()}
+
+
+@pytest.mark.parametrize("name", ["Panda", "UR5", "LBR", "Puma560", "px100"])
+def test_differential_consumers_by_structure_instantiation(name):
+    """k_kin_diff<NJ, MODE, SIG> (csrc/diff_kernel.h): jacob0_dot / manipulability / jacobm / the analytical Jacobians with the walk of THIS robot
+    written out, compiled at run time.  The reference computes all of them through one general path (robot/Robot.py:964-1235,
+    robot/ETS.py:1687-1819): the instantiation must return the general kernel's bits, and the oracle's numbers."""
+    need_rtc()
+    e = urdf.load(name).ets()
+    rng = np.random.default_rng(21)
+    N = 2500
+    q, qd = rng.uniform(-3, 3, (N, e.n)), rng.normal(size=(N, e.n))
+    rtbhip.tune("jit", 2)
+    s0 = jit.stats()
+    fast = _diff_calls(e, q, qd)
+    s1 = jit.stats()
+    assert s1["launches"] - s0["launches"] >= len(fast) and s1["failed"] == s0["failed"], s1
+    rtbhip.tune("diff_sig", 0)
+    try:
+        general = _diff_calls(e, q, qd)
+    finally:
+        rtbhip.tune("diff_sig", 1)
+    assert jit.stats()["launches"] == s1["launches"]
+    for k in fast:
+        nt.assert_array_equal(fast[k], general[k], err_msg=k)
+    from helpers import chain_from_ets
+    ch = chain_from_ets(e)
+    nt.assert_allclose(fast["jacob0_dot"][:50].reshape(50, 6, e.n), oracle.jacob_dot(ch, q[:50], qd[:50]), atol=1e-10)
+    # (a 4-joint arm's six-axis measure is a rounding-level number: its translational one is compared instead)
+    axes = "all" if e.n >= 6 else "trans"
+    nt.assert_allclose(fast["manipulability_yoshikawa_" + axes][:50], oracle.manipulability(ch, q[:50], [1, 1, 1, 1, 1, 1] if e.n >= 6 else [1, 1, 1, 0, 0, 0]), rtol=1e-9, atol=1e-12)
