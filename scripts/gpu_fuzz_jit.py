@@ -6,7 +6,8 @@ product's operation sequence with exact zeros and ones rewritten away; kin_devic
 hand-written tests check that on the robots of the model library; this script checks it on robots nobody looked at: constants drawn from the classes the
 chain compiler distinguishes (identity, quarter turns, one-axis rotations, pure translations on some axes, general), all of them mixed.
     DH link tables    2..8 revolute joints, alpha in {0, +-pi/2, general}, a / d / centre of mass / friction / motor inertia zero or not     rne, gravload, inertia, coriolis, accel
-    ETS chains        3..8 revolute joints about x / y / z, constants = products of structured elementary transforms                          ik_LM (q, success, iterations, searches, residual)
+    ETS chains        3..8 revolute joints about x / y / z, constants = products of structured elementary transforms                          ik_LM (q, success, iterations, searches, residual);
+                      jacob0_dot, manipulability (3 methods), jacobm, analytical Jacobians (4 representations)
     link trees        3..12 groups, branching, prismatic joints, URDF-style origins (rpy multiples of pi/2 or general, xyz with zeros)      rne, inertia, coriolis, accel
 Every output of the run-time kernel (rtbhip_tune "jit" = 2: a launch waits for its instantiation) must EQUAL the general kernel's (*_sig = 0).
 One JSON line per family; exit code 1 on a differing bit, 0 otherwise (also 0, with a note, where libhiprtc.so is absent)."""
@@ -66,6 +67,7 @@ print(json.dumps(line), flush=True)
 
 # ---------------------------------------------------------------- ETS chains (IK)
 line = {"family": "ETS chains (k_ik)", "robots": 0, "arrays": 0, "served_by_jit": 0, "success_rate": []}
+diff_line = {"family": "ETS chains (k_kin_diff)", "robots": 0, "arrays": 0, "served_by_jit": 0}
 for n in range(3, 9):
     rng = np.random.default_rng(22000 + n)
     ets = ETS()
@@ -95,7 +97,19 @@ for n in range(3, 9):
     for name, a, b in zip(("q", "success", "iterations", "searches", "residual"), fast, gen):
         if not np.array_equal(a, b, equal_nan=True):
             miss.append(["ik", n, name, int((a != b).sum()), float(np.nanmax(np.abs(a.astype(float) - b.astype(float))))])
+    # the same chain through k_kin_diff<NJ, MODE, SIG> (csrc/diff_kernel.h): jacob0_dot, manipulability in its three methods, jacobm, the analytical Jacobians
+    qdv = rng.normal(size=qs.shape)
+    names = ("jacob0_dot", "manip_yoshikawa", "manip_minsingular", "manip_invcondition_trans", "jacobm", "jacobm_rot", "ja_rpy/xyz", "ja_rpy/zyx", "ja_eul", "ja_exp")
+    fast, gen, served = both("diff_sig", lambda: (ets.jacob0_dot(qs, qdv), ets.manipulability(qs), ets.manipulability(qs, method="minsingular"),
+                                                  ets.manipulability(qs, method="invcondition", axes="trans"), ets.jacobm(qs), ets.jacobm(qs, axes="rot"),
+                                                  ets.jacob0_analytical(qs, "rpy/xyz"), ets.jacob0_analytical(qs, "rpy/zyx"), ets.jacob0_analytical(qs, "eul"),
+                                                  ets.jacob0_analytical(qs, "exp")))
+    diff_line["robots"] += 1; diff_line["arrays"] += len(fast); diff_line["served_by_jit"] += served
+    for name, a, b in zip(names, fast, gen):
+        if not np.array_equal(a, b, equal_nan=True):
+            miss.append(["diff", n, name, int((a != b).sum()), float(np.nanmax(np.abs(a - b)))])
 print(json.dumps(line), flush=True)
+print(json.dumps(diff_line), flush=True)
 
 # ---------------------------------------------------------------- link trees
 line = {"family": "link trees (k_tree_rne, k_tree_dyn)", "robots": 0, "arrays": 0, "served_by_jit": 0}

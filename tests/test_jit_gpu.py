@@ -98,17 +98,16 @@ def test_ik_of_robots_without_builtin_instantiation(name, end):
     rtbhip.tune("ik_sig", 0)
     general = e.ik_LM(T, seed=4)
     assert jit.stats()["launches"] == s1["launches"]
-    # decisions and counts: equal.  q, residual: the same bits for LBR / px100 / Mico (and the built-in Panda, UR); the Puma560's come out <= 1e-10
-    # apart -- the IK iteration is NOT yet written contraction-free the way the dynamics recursions are (rne_device.h), so the compiler still
-    # fuses across the walk's boundary differently in the two instantiations; stated, and bounded here
+    # decisions, counts, q and the residual: the same bits, for every robot (the Puma560's q was <= 1e-10 apart until the IK iteration was written
+    # contraction-free like the dynamics recursions: ik_device.h, ldl.h)
     for k in (1, 2, 3):
         nt.assert_array_equal(np.asarray(fast[k]), np.asarray(general[k]))
     ok = np.asarray(fast[1]) == 1
     assert ok.mean() > 0.5
     assert np.abs(np.asarray(fast[0])[ok] - np.asarray(general[0])[ok]).max() < 1e-8
     assert np.abs(np.asarray(fast[4])[ok] - np.asarray(general[4])[ok]).max() < 1e-12
-    if name != "Puma560":
-        nt.assert_array_equal(np.asarray(fast[0]), np.asarray(general[0]))
+    nt.assert_array_equal(np.asarray(fast[0]), np.asarray(general[0]))
+    nt.assert_array_equal(np.asarray(fast[4]), np.asarray(general[4]))
     Tq = np.asarray(e.eval(np.asarray(fast[0])[ok]))
     assert np.abs(Tq - T[ok]).max() < 5e-3                           # E = e'e / 2 < 1e-6: the pose error is below 1.5e-3
 
