@@ -19,8 +19,6 @@ def test_dhrobot_refuses_what_the_reference_ignores():
             call()
     with pytest.raises(ValueError):
         puma._half(np.zeros((6, 6)), "both")                 # robot/DHRobot.py:1139 "bad half specified"
-    with pytest.raises(NotImplementedError):                  # modified DH: the reference's rne_python disagrees with its frne there
-        rtbhip.models.DH.Panda().rne(np.zeros(7), np.zeros(7), np.zeros(7), base_wrench=True)
     # None is what the reference's own pass-throughs hand over: accepted
     assert puma.ets(None, None) is puma.ets()
 
