@@ -127,3 +127,54 @@ def test_create_does_not_touch_the_device():
     perturbed_panda()._dyn_handle()
     rtbhip.urdf.load("KinovaGen3").erobot()._handle()
     assert jit.stats()["requested"] == before
+
+
+def test_ahead_of_time_cache(tmp_path):
+    """__graft_entry__.build_aot_cache compiles a manifest of instantiations into a directory of code objects; a process whose own cache is empty
+    finds them there (csrc/jit.cpp: aot_dir -- RTBHIP_JIT_AOT names the directory, by default `jitcache/` next to the library), "-" turns that off,
+    and a second build of an unchanged manifest does nothing."""
+    import json
+    import __graft_entry__ as g
+    if not jit.stats()["available"]:
+        pytest.skip("libhiprtc.so is not here: nothing is compiled ahead of time either")
+    e1 = "rtbhip::k_rne<2, false, true, 0x%xull>" % ((1 << 63) | (1 << 62) | (1 << 61) | 0x1 | (0x2 << 7))
+    e2 = "rtbhip::k_kin_diff<3, 1, 0>"
+    man = tmp_path / "manifest.jsonl"
+    man.write_text(json.dumps({"unit": "rne_kernels.hip", "expr": e1, "preamble": ""}) + "\n" + json.dumps({"unit": "diff_kernel.h", "expr": e2, "preamble": ""}) + "\n")
+    aot = tmp_path / "aot"
+    assert g.build_aot_cache(manifest=str(man), out_dir=str(aot)) == 2
+    assert len(list(aot.glob("*.hsaco"))) == 2
+    assert g.build_aot_cache(manifest=str(man), out_dir=str(aot)) == 0                   # up to date by content
+    code = r"""
+import sys
+sys.path[:0] = [%r, %r]
+from rtbhip import jit
+a = jit.compile_now("rne_kernels.hip", %r)
+b = jit.compile_now("diff_kernel.h", %r)
+print("from_disk", a[2], b[2])
+""" % (ROOT, os.path.join(ROOT, "robotics-toolbox-python_amd"), e1, e2)
+    env = dict(os.environ, RTBHIP_JIT_CACHE=str(tmp_path / "mine"), RTBHIP_JIT_AOT=str(aot))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert "from_disk True True" in out.stdout, out.stdout + out.stderr[-1000:]
+    assert not list((tmp_path / "mine").glob("*.hsaco"))                                 # nothing was compiled, nothing was written
+    env["RTBHIP_JIT_AOT"] = "-"
+    env["RTBHIP_JIT_CACHE"] = str(tmp_path / "mine2")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert "from_disk False False" in out.stdout, out.stdout + out.stderr[-1000:]
+
+
+def test_committed_manifest_is_well_formed():
+    """robotics-toolbox-python_amd/jit_aot_manifest.jsonl: one JSON object per line with the three keys, no repeats, units that exist."""
+    import json
+    path = os.path.join(ROOT, "robotics-toolbox-python_amd", "jit_aot_manifest.jsonl")
+    if not os.path.exists(path):
+        pytest.skip("no ahead-of-time list in this tree")
+    seen = set()
+    for line in open(path):
+        e = json.loads(line)
+        assert set(e) == {"unit", "expr", "preamble"} and e["expr"].startswith("rtbhip::k_")
+        assert os.path.exists(os.path.join(ROOT, "robotics-toolbox-python_amd", "csrc", e["unit"]))
+        key = (e["unit"], e["expr"], e["preamble"])
+        assert key not in seen
+        seen.add(key)
+    assert len(seen) >= 10

@@ -235,3 +235,34 @@ def test_differential_consumers_by_structure_instantiation(name):
     # (a 4-joint arm's six-axis measure is a rounding-level number: its translational one is compared instead)
     axes = "all" if e.n >= 6 else "trans"
     nt.assert_allclose(fast["manipulability_yoshikawa_" + axes][:50], oracle.manipulability(ch, q[:50], [1, 1, 1, 1, 1, 1] if e.n >= 6 else [1, 1, 1, 0, 0, 0]), rtol=1e-9, atol=1e-12)
+
+
+def test_manifest_of_requested_instantiations(tmp_path):
+    """RTBHIP_JIT_MANIFEST=<file>: every instantiation a process asks for is appended as one JSON line {"unit", "expr", "preamble"} -- how the
+    ahead-of-time list (jit_aot_manifest.jsonl, compiled by __graft_entry__.build_aot_cache) is gathered on the device."""
+    import json, os, subprocess, sys
+    need_rtc()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys
+sys.path[:0] = [%r, %r, %r]
+import numpy as np, rtbhip
+from rtbhip import jit, urdf
+from test_jit_gpu import perturbed_panda
+rtbhip.tune("jit", 2)
+rob = perturbed_panda(0.03)
+q = np.random.default_rng(0).uniform(-2, 2, (100, 7))
+rob.rne(q, q, q)
+t = urdf.load("KinovaGen3").erobot()
+q7 = np.zeros((10, t.n))
+t.rne(q7, q7, q7)
+print("launches", jit.stats()["launches"])
+""" % (root, os.path.join(root, "robotics-toolbox-python_amd"), os.path.join(root, "tests"))
+    man = tmp_path / "manifest.jsonl"
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RTBHIP_JIT_MANIFEST=str(man)), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and int(out.stdout.split("launches")[1]) >= 2, out.stdout + out.stderr[-1500:]
+    rows = [json.loads(l) for l in man.read_text().splitlines()]
+    assert all(set(r) == {"unit", "expr", "preamble"} for r in rows)
+    assert any(r["unit"] == "rne_kernels.hip" and r["expr"].startswith("rtbhip::k_rne<7, true") for r in rows)
+    tree = [r for r in rows if r["unit"] == "tree_kernels.hip"]
+    assert tree and "struct" in tree[0]["preamble"]                  # a tree's generated knowledge type travels as the preamble
