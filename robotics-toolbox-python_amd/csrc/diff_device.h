@@ -132,8 +132,10 @@ RTB_HD double manipulability_singular(const double (&jac)[6 * NJ], int axes, int
         for (int i = 0; i < NJ; ++i) { lo = G[i][i] < lo ? G[i][i] : lo; hi = G[i][i] > hi ? G[i][i] : hi; }
     }
     lo = lo < 0.0 ? 0.0 : lo;
-    // (an all-zero selected block -- prismatic joints asked for their rotational part -- has cond = inf: 1 / cond = 0, ETS.py:1789-1791)
-    return mode == 1 ? sqrt(lo) : (hi > 0.0 ? sqrt(lo / hi) : 0.0);
+    // (an all-zero selected block -- prismatic joints asked for their rotational part -- has cond = inf: 1 / cond = 0, ETS.py:1789-1791.  A block that
+    //  is zero but for rounding counts as zero: a tool translation exactly along the last joint's axis leaves 1e-17 in  z x (p_e - p)  where the
+    //  reference's column formula multiplies exact zeros -- largest singular value below 1e-14, profiles/r06_aj_fuzz_more.txt)
+    return mode == 1 ? sqrt(lo) : (hi > 1e-28 ? sqrt(lo / hi) : 0.0);
 }
 
 // Analytical Jacobian (ETS.jacob0_analytical robot/ETS.py:1562-1626): Ja = blkdiag(I, A^-1) J0 with A the map from the

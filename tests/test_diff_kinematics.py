@@ -431,3 +431,22 @@ def test_gpu_robot_level_J_and_H_keywords_and_errors():
     with pytest.raises(rtbhip.RtbHipError):
         rtbhip.manipulability_from_jacobian(np.zeros((6, 7)), axes=[False] * 6)
     assert rtbhip.manipulability_from_jacobian(np.zeros((0, 6, 7))).shape == (0,)
+
+
+def test_emu_inverse_condition_of_a_block_that_is_zero_but_for_rounding():
+    """A single Rx joint behind two general constants, with a tool whose translation lies exactly along the joint axis: the translational Jacobian is
+    a zero vector.  The reference's column formula multiplies exact zeros of the tool (cond = inf, 1 / cond = 0: ETS.py:1789-1791); the one-walk form
+    z x (p_e - p) leaves 1e-17 of rounding, whose "condition number" would be 1.  Found by scripts/fuzz_more.py (profiles/r06_aj_fuzz_more.txt)."""
+    import emu_harness as emu
+    A = chains.elementary("Rz", 0.7) @ chains.elementary("Ry", -0.4) @ chains.elementary("tx", 0.15) @ chains.elementary("tz", -0.1)
+    B = chains.elementary("Rx", 1.1) @ chains.elementary("Rz", -0.9) @ chains.elementary("ty", 0.09)
+    spec = [A, B, ("Rx", None, False)]
+    e, ch = product_ets(spec), chains.Chain(spec)
+    tool = chains.elementary("tx", 0.17) @ chains.elementary("Rx", 0.6)
+    q = np.random.default_rng(5).uniform(-2.5, 2.5, (12, 1))
+    ref = oracle.manipulability(ch, q, "trans", tool=tool, method="invcondition")
+    nt.assert_array_equal(ref, 0.0)
+    nt.assert_array_equal(emu.diff(e, 1, q, axes=7 | (2 << 8), tool=tool), 0.0)
+    nt.assert_array_equal(emu.diff(e, 1, q, axes=7 | (1 << 8), tool=tool) < 1e-15, True)          # the smallest singular value: rounding level
+    # and a block that is NOT zero keeps its value
+    nt.assert_allclose(emu.diff(e, 1, q, axes=56 | (2 << 8), tool=tool), 1.0, rtol=1e-12)
