@@ -51,7 +51,9 @@ for n in range(1, 17):
                 worst = max(worst, dev("manipulability %s %s" % (method, axes), n, ets.manipulability(q, method=method, axes=axes, tool=tool)[k], want, tol=1e-7))
         try:
             want = oracle.jacobm(ch, q[k], tool=tool)
-            if np.isfinite(want).all() and np.abs(want).max() < 1e6:
+            # (fewer than six joints: J J^T is singular, the measure is 0 and its gradient -- m times the inverse of a singular matrix -- is whatever
+            #  rounding makes of it in numpy and in the LDL^T alike: not compared, profiles/r06_aj_fuzz_more.txt)
+            if n >= 6 and np.isfinite(want).all() and np.abs(want).max() < 1e6:
                 worst = max(worst, dev("jacobm", n, ets.jacobm(q, tool=tool)[k], want, tol=1e-6))
         except Exception:
             pass
